@@ -1,0 +1,48 @@
+# Builds everything native in this repo for gfx950 (MI355X):
+#   hwang_amd/libhwang_amd.so   product: host C++ + HIP kernels, C ABI
+#   oracle/_build/*             CPU oracle (test infrastructure)
+#   oracle/_ref/*               reference sources compiled in place (only
+#                               where /root/reference exists)
+# hipcc cross-compiles without a GPU.  `make -j8` is fine on this box.
+HIPCC      ?= /opt/rocm/bin/hipcc
+ARCH       ?= gfx950
+CXXFLAGS   := -std=c++17 -O2 -fPIC -Wall -Wno-unused-function -pthread
+HIPFLAGS   := --offload-arch=$(ARCH) $(CXXFLAGS)
+CSRC       := hwang_amd/csrc
+BUILD      := build/obj
+
+CPP_SRCS   := $(wildcard $(CSRC)/*.cpp $(CSRC)/h264/*.cpp $(CSRC)/amd/*.cpp)
+HIP_SRCS   := $(wildcard $(CSRC)/amd/*.hip)
+OBJS       := $(patsubst %.cpp,$(BUILD)/%.o,$(CPP_SRCS)) \
+              $(patsubst %.hip,$(BUILD)/%.hip.o,$(HIP_SRCS))
+HDRS       := $(wildcard include/*.h $(CSRC)/*.h $(CSRC)/*/*.h)
+
+LIB        := hwang_amd/libhwang_amd.so
+
+.PHONY: all lib oracle ref corpus clean
+all: lib oracle corpus ref
+
+lib: $(LIB)
+
+$(BUILD)/%.o: %.cpp $(HDRS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(CXXFLAGS) -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $< -o $@
+
+$(BUILD)/%.hip.o: %.hip $(HDRS)
+	@mkdir -p $(dir $@)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -pthread
+
+oracle:
+	$(MAKE) -C oracle
+
+corpus:
+	$(MAKE) -C corpus
+
+ref:
+	$(MAKE) -C oracle ref
+
+clean:
+	rm -rf build $(LIB) oracle/_build oracle/_ref corpus/_build

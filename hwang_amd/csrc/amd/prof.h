@@ -1,0 +1,34 @@
+// Per-kernel HIP-event profiling used by bench.py's roofline block.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace hwang {
+namespace prof {
+
+enum KernelId {
+  K_RESIDUAL = 0,   // dequant + inverse transforms
+  K_INTER = 1,      // motion compensation + residual add
+  K_INTRA = 2,      // intra prediction wavefront + residual add
+  K_DEBLOCK = 3,    // in-loop deblocking wavefront
+  K_RGB = 4,        // I420 -> RGB24
+  K_COUNT = 5,
+};
+
+bool enabled();
+
+// RAII-free helpers: begin() records a start event on `stream`, end() the
+// stop event and files (kernel, algorithmic bytes); totals are resolved
+// lazily in read() once the events have completed.
+struct Span {
+  hipEvent_t start = nullptr;
+  hipEvent_t stop = nullptr;
+};
+Span begin(hipStream_t stream);
+void end(const Span& span, hipStream_t stream, KernelId kernel,
+         uint64_t algorithmic_bytes);
+
+}  // namespace prof
+}  // namespace hwang

@@ -1,0 +1,282 @@
+#include "decoder_automata.h"
+
+#include "sparse_hints.h"
+
+#include <chrono>
+
+namespace hwang {
+
+namespace {
+constexpr auto kPoll = std::chrono::microseconds(100);
+}
+
+DecoderAutomata::DecoderAutomata(VideoDecoderInterface* decoder)
+    : decoder_(decoder) {
+  feeder_thread_ = std::thread(&DecoderAutomata::feeder, this);
+}
+
+DecoderAutomata* DecoderAutomata::make_instance(DeviceHandle device_handle,
+                                                int32_t num_devices,
+                                                VideoDecoderType decoder_type) {
+  VideoDecoderInterface* decoder = VideoDecoderFactory::make_from_config(
+      device_handle, static_cast<uint32_t>(num_devices), decoder_type);
+  if (decoder == nullptr) return nullptr;
+  return new DecoderAutomata(decoder);
+}
+
+DecoderAutomata* DecoderAutomata::make_with_decoder(
+    VideoDecoderInterface* decoder) {
+  if (decoder == nullptr) return nullptr;
+  return new DecoderAutomata(decoder);
+}
+
+DecoderAutomata::~DecoderAutomata() {
+  {
+    std::unique_lock<std::mutex> lk(m_);
+    quit_ = true;
+  }
+  cv_.notify_all();
+  feeder_thread_.join();
+  if (dirty_) decoder_->flush();
+  while (decoder_->decoded_frames_buffered() > 0) {
+    if (!decoder_->discard_frame().ok) break;
+  }
+}
+
+DecoderAutomata::Stats DecoderAutomata::stats() {
+  std::unique_lock<std::mutex> lk(m_);
+  return stats_;
+}
+
+// Drops every frame the backend currently buffers.  Called with the lock
+// held; releases it around the backend calls.
+void DecoderAutomata::drain_locked(std::unique_lock<std::mutex>& lk) {
+  lk.unlock();
+  int64_t dropped = 0;
+  while (decoder_->decoded_frames_buffered() > 0) {
+    if (!decoder_->discard_frame().ok) break;
+    ++dropped;
+  }
+  lk.lock();
+  stats_.frames_discarded += dropped;
+}
+
+Result DecoderAutomata::initialize(const std::vector<EncodedData>& encoded_data,
+                                   const std::vector<uint8_t>& extradata) {
+  if (encoded_data.empty()) {
+    return Result(false, "DecoderAutomata::initialize: no encoded data");
+  }
+  for (const EncodedData& d : encoded_data) {
+    if (d.sample_offsets.size() != d.sample_sizes.size()) {
+      return Result(false,
+                    "DecoderAutomata::initialize: sample_offsets and "
+                    "sample_sizes differ in length");
+    }
+  }
+  std::unique_lock<std::mutex> lk(m_);
+  // get_frames() leaves the feeder parked; wait out a backend call that may
+  // still be in flight.
+  cv_.wait(lk, [&] { return !feeder_busy_; });
+
+  if (dirty_) {
+    lk.unlock();
+    Result r = decoder_->flush();
+    lk.lock();
+    if (!r.ok) return r;
+    dirty_ = false;
+  }
+  drain_locked(lk);
+
+  segments_ = encoded_data;
+  frame_size_ = static_cast<size_t>(encoded_data[0].width) *
+                encoded_data[0].height * 3;
+  seg_complete_.assign(segments_.size(), 0);
+  feed_seg_ = 0;
+  feed_sample_ = 0;
+  next_kf_idx_ = 0;
+  flushed_segs_ = 0;
+  ret_seg_ = 0;
+  ret_valid_ = 0;
+  ret_frame_ = segments_[0].keyframes.empty() ? segments_[0].start_keyframe
+                                              : segments_[0].keyframes[0];
+  failed_ = false;
+  failure_ = Result();
+
+  VideoDecoderInterface::FrameInfo info;
+  info.width = encoded_data[0].width;
+  info.height = encoded_data[0].height;
+  info.format = encoded_data[0].format;
+  lk.unlock();
+  return decoder_->configure(info, extradata);
+}
+
+Result DecoderAutomata::get_frames(uint8_t* buffer, int32_t num_frames) {
+  std::unique_lock<std::mutex> lk(m_);
+  if (segments_.empty()) {
+    return Result(false, "DecoderAutomata::get_frames before initialize");
+  }
+  active_ = true;
+  cv_.notify_all();
+
+  auto finish = [&](const Result& r) {
+    active_ = false;
+    cv_.notify_all();
+    cv_.wait(lk, [&] { return !feeder_busy_; });
+    return r;
+  };
+
+  int32_t got = 0;
+  while (got < num_frames) {
+    if (failed_) return finish(failure_);
+    if (ret_seg_ >= segments_.size()) {
+      return finish(Result(
+          false, "DecoderAutomata::get_frames: more frames requested than "
+                 "the initialized intervals hold"));
+    }
+    const EncodedData& seg = segments_[ret_seg_];
+
+    if (ret_valid_ >= seg.valid_frames.size()) {
+      // Interval finished on our side: let the feeder cut it short, wait for
+      // its end-of-interval flush, drop what that flush pushed out, then
+      // move both cursors to the next interval.
+      seg_complete_[ret_seg_] = 1;
+      cv_.notify_all();
+      while (flushed_segs_ <= static_cast<int64_t>(ret_seg_) && !failed_) {
+        drain_locked(lk);  // keep back-pressure from stalling the feeder
+        if (flushed_segs_ > static_cast<int64_t>(ret_seg_)) break;
+        cv_.wait_for(lk, kPoll);
+      }
+      if (failed_) return finish(failure_);
+      drain_locked(lk);
+      ++ret_seg_;
+      ret_valid_ = 0;
+      if (ret_seg_ < segments_.size()) {
+        const EncodedData& next = segments_[ret_seg_];
+        ret_frame_ = next.keyframes.empty() ? next.start_keyframe
+                                            : next.keyframes[0];
+      }
+      cv_.notify_all();
+      continue;
+    }
+
+    if (decoder_->decoded_frames_buffered() > 0) {
+      const bool wanted = ret_frame_ == seg.valid_frames[ret_valid_];
+      uint8_t* dst = buffer + static_cast<size_t>(got) * frame_size_;
+      lk.unlock();
+      Result r = wanted ? decoder_->get_frame(dst, frame_size_)
+                        : decoder_->discard_frame();
+      lk.lock();
+      if (!r.ok) return finish(r);
+      if (wanted) {
+        ++got;
+        ++ret_valid_;
+        ++stats_.frames_returned;
+      } else {
+        ++stats_.frames_discarded;
+      }
+      ++ret_frame_;
+      cv_.notify_all();
+    } else {
+      if (flushed_segs_ > static_cast<int64_t>(ret_seg_)) {
+        // Whole interval was fed and flushed, nothing is buffered, and a
+        // wanted frame is still outstanding: rows outside the interval,
+        // unsorted rows, or a backend that dropped a frame.
+        return finish(Result(
+            false, "DecoderAutomata::get_frames: interval exhausted before "
+                   "frame " + std::to_string(seg.valid_frames[ret_valid_]) +
+                   " was produced"));
+      }
+      cv_.wait_for(lk, kPoll);
+    }
+  }
+  Result done = finish(Result());
+  lk.unlock();
+  HWANG_RETURN_ON_ERROR(decoder_->wait_until_frames_copied());
+  return done;
+}
+
+void DecoderAutomata::feeder() {
+  std::unique_lock<std::mutex> lk(m_);
+  for (;;) {
+    // Work on interval k only once the retriever has moved on to k, so the
+    // frames of two intervals never mix in the backend's queue.
+    cv_.wait(lk, [&] {
+      return quit_ || (active_ && !failed_ && feed_seg_ < segments_.size() &&
+                       feed_seg_ <= ret_seg_);
+    });
+    if (quit_) return;
+
+    const EncodedData& seg = segments_[feed_seg_];
+    const size_t nsamples = seg.sample_offsets.size();
+    auto latch = [&](const Result& r) {
+      failed_ = true;
+      failure_ = r;
+    };
+
+    if (seg_complete_[feed_seg_] || feed_sample_ >= nsamples) {
+      feeder_busy_ = true;
+      lk.unlock();
+      Result r = decoder_->feed(nullptr, 0, false);
+      if (r.ok) r = decoder_->flush();
+      lk.lock();
+      feeder_busy_ = false;
+      dirty_ = false;
+      ++stats_.flushes;
+      if (!r.ok) latch(r);
+      ++feed_seg_;
+      feed_sample_ = 0;
+      next_kf_idx_ = 0;
+      ++flushed_segs_;
+      cv_.notify_all();
+      continue;
+    }
+
+    if (decoder_->decoded_frames_buffered() > MAX_BUFFERED_FRAMES) {
+      cv_.wait_for(lk, kPoll);
+      continue;
+    }
+
+    const uint64_t first_frame =
+        seg.keyframes.empty() ? seg.start_keyframe : seg.keyframes[0];
+    const uint64_t frame = first_frame + feed_sample_;
+    const uint64_t off = seg.sample_offsets[feed_sample_];
+    const uint64_t size = seg.sample_sizes[feed_sample_];
+    if (off > seg.encoded_video.size() ||
+        size > seg.encoded_video.size() - off) {
+      latch(Result(false, "DecoderAutomata: sample " + std::to_string(frame) +
+                              " lies outside encoded_video"));
+      cv_.notify_all();
+      continue;
+    }
+    bool keyframe = false;
+    if (next_kf_idx_ < seg.keyframes.size() &&
+        seg.keyframes[next_kf_idx_] == frame) {
+      keyframe = true;
+      ++next_kf_idx_;
+    }
+    const bool first_of_interval = feed_sample_ == 0;
+    const uint8_t* ptr = seg.encoded_video.data() + off;
+
+    feeder_busy_ = true;
+    lk.unlock();
+    if (first_of_interval) {
+      if (auto* hints = dynamic_cast<SparseDecodeHints*>(decoder_.get())) {
+        std::vector<uint64_t> ordinals;
+        ordinals.reserve(seg.valid_frames.size());
+        for (uint64_t f : seg.valid_frames)
+          if (f >= first_frame) ordinals.push_back(f - first_frame);
+        hints->set_wanted_frames(ordinals);
+      }
+    }
+    Result r = decoder_->feed(ptr, static_cast<size_t>(size), keyframe);
+    lk.lock();
+    feeder_busy_ = false;
+    dirty_ = true;
+    ++stats_.samples_fed;
+    ++feed_sample_;
+    if (!r.ok) latch(r);
+    cv_.notify_all();
+  }
+}
+
+}  // namespace hwang

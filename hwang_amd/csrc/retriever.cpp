@@ -1,0 +1,195 @@
+#include "retriever.h"
+
+#include <algorithm>
+#include <chrono>
+#include <thread>
+
+namespace hwang {
+
+ParallelRetriever* ParallelRetriever::make(DeviceHandle device,
+                                           VideoDecoderType type,
+                                           int32_t num_lanes) {
+  if (num_lanes <= 0) {
+    unsigned hw = std::thread::hardware_concurrency();
+    num_lanes = static_cast<int32_t>(std::min<unsigned>(hw ? hw : 4, 16));
+  }
+  std::unique_ptr<ParallelRetriever> r(new ParallelRetriever());
+  r->lanes_.resize(num_lanes);
+  for (Lane& lane : r->lanes_) {
+    lane.backend.reset(VideoDecoderFactory::make_from_config(device, 1, type));
+    if (!lane.backend) return nullptr;
+  }
+  return r.release();
+}
+
+ParallelRetriever::~ParallelRetriever() {}
+
+Result ParallelRetriever::run_item(Lane& lane, const WorkItem& item,
+                                   const VideoIndex& index, const uint8_t* file,
+                                   size_t file_size, uint8_t* out,
+                                   size_t frame_bytes, bool yuv) {
+  VideoDecoderInterface* dec = lane.backend.get();
+  auto* hints = dynamic_cast<SparseDecodeHints*>(dec);
+  auto* planar = dynamic_cast<PlanarOutput*>(dec);
+  if (yuv && !planar) {
+    return Result(false, "retrieve: backend has no planar (I420) output");
+  }
+  const std::vector<uint64_t>& valid = *item.valid;
+  if (hints) {
+    std::vector<uint64_t> ordinals(valid.size());
+    for (size_t i = 0; i < valid.size(); ++i) ordinals[i] = valid[i] - item.start;
+    hints->set_wanted_frames(ordinals);
+  }
+  const auto& offs = index.sample_offsets();
+  const auto& sizes = index.sample_sizes();
+  const auto& kfs = index.keyframe_indices();
+  size_t kf_cursor =
+      std::lower_bound(kfs.begin(), kfs.end(), item.start) - kfs.begin();
+
+  uint64_t next_out = item.start;  // display ordinal of the next output frame
+  size_t got = 0;
+  auto consume = [&]() -> Result {
+    while (got < valid.size() && dec->decoded_frames_buffered() > 0) {
+      if (next_out == valid[got]) {
+        uint8_t* dst = out + (item.out_slot + got) * frame_bytes;
+        HWANG_RETURN_ON_ERROR(yuv ? planar->get_frame_yuv(dst, frame_bytes)
+                                  : dec->get_frame(dst, frame_bytes));
+        ++got;
+        ++lane.frames_returned;
+      } else {
+        HWANG_RETURN_ON_ERROR(dec->discard_frame());
+      }
+      ++next_out;
+    }
+    return Result();
+  };
+
+  for (uint64_t s = item.start; s < item.end && got < valid.size(); ++s) {
+    if (offs[s] > file_size || sizes[s] > file_size - offs[s]) {
+      return Result(false, "retrieve: sample " + std::to_string(s) +
+                               " lies outside the file");
+    }
+    bool keyframe = false;
+    if (kf_cursor < kfs.size() && kfs[kf_cursor] == s) {
+      keyframe = true;
+      ++kf_cursor;
+    }
+    HWANG_RETURN_ON_ERROR(dec->feed(file + offs[s], sizes[s], keyframe));
+    ++lane.samples_fed;
+    HWANG_RETURN_ON_ERROR(consume());
+  }
+  // End of interval: empty packet + flush pushes out whatever the reorder
+  // buffer still holds (decoder_automata.cpp:383-389 protocol).
+  HWANG_RETURN_ON_ERROR(dec->feed(nullptr, 0, false));
+  HWANG_RETURN_ON_ERROR(dec->flush());
+  HWANG_RETURN_ON_ERROR(consume());
+  while (dec->decoded_frames_buffered() > 0) {
+    HWANG_RETURN_ON_ERROR(dec->discard_frame());
+  }
+  if (got != valid.size()) {
+    return Result(false, "retrieve: interval [" + std::to_string(item.start) +
+                             "," + std::to_string(item.end) + ") produced " +
+                             std::to_string(got) + " of " +
+                             std::to_string(valid.size()) + " wanted frames");
+  }
+  return Result();
+}
+
+Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
+                                   size_t file_size,
+                                   const std::vector<uint64_t>& rows,
+                                   uint8_t* out, size_t out_capacity, bool yuv) {
+  const auto t0 = std::chrono::steady_clock::now();
+  stats_ = Stats();
+  const size_t w = index.frame_width(), h = index.frame_height();
+  const size_t frame_bytes =
+      yuv ? w * h + 2 * ((w + 1) / 2) * ((h + 1) / 2) : w * h * 3;
+  if (out_capacity < frame_bytes * rows.size()) {
+    return Result(false, "retrieve: output buffer too small");
+  }
+  if (rows.empty()) return Result();
+  if (!std::is_sorted(rows.begin(), rows.end())) {
+    return Result(false, "retrieve: rows must be sorted ascending");
+  }
+  bool ok = true;
+  VideoIntervals plan = slice_into_video_intervals(index, rows, &ok);
+  if (!ok) return Result(false, "retrieve: row out of range");
+
+  std::vector<WorkItem> items;
+  size_t slot = 0;
+  const auto& sizes = index.sample_sizes();
+  for (size_t i = 0; i < plan.sample_index_intervals.size(); ++i) {
+    if (plan.valid_frames[i].empty()) continue;
+    WorkItem it;
+    it.start = std::get<0>(plan.sample_index_intervals[i]);
+    it.end = std::get<1>(plan.sample_index_intervals[i]);
+    it.valid = &plan.valid_frames[i];
+    it.out_slot = slot;
+    slot += it.valid->size();
+    // Host entropy time tracks bytes; only samples up to the last wanted
+    // frame (plus reorder slack) will be fed.
+    uint64_t last = std::min<uint64_t>(it.end, it.valid->back() + 4);
+    for (uint64_t s = it.start; s < last; ++s) it.cost += sizes[s];
+    items.push_back(it);
+  }
+  stats_.intervals = static_cast<int64_t>(items.size());
+  // Longest first, pulled from a shared cursor: greedy LPT balance.
+  std::vector<size_t> order(items.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    return items[a].cost > items[b].cost;
+  });
+
+  VideoDecoderInterface::FrameInfo info;
+  info.width = index.frame_width();
+  info.height = index.frame_height();
+  info.format = index.format();
+
+  std::atomic<size_t> cursor{0};
+  std::atomic<bool> abort{false};
+  const size_t nl = std::min(lanes_.size(), items.size());
+  std::vector<std::thread> threads;
+  for (size_t li = 0; li < nl; ++li) {
+    Lane& lane = lanes_[li];
+    lane.result = Result();
+    lane.samples_fed = 0;
+    lane.frames_returned = 0;
+    threads.emplace_back([&, li]() {
+      Lane& lane = lanes_[li];
+      if (auto* c = dynamic_cast<CountedBackend*>(lane.backend.get()))
+        c->reset_counters();
+      Result r = lane.backend->configure(info, index.metadata_bytes());
+      while (r.ok && !abort.load()) {
+        size_t k = cursor.fetch_add(1);
+        if (k >= order.size()) break;
+        r = run_item(lane, items[order[k]], index, file, file_size, out,
+                     frame_bytes, yuv);
+      }
+      if (r.ok) r = lane.backend->wait_until_frames_copied();
+      if (!r.ok) abort.store(true);
+      lane.result = r;
+    });
+  }
+  for (auto& t : threads) t.join();
+
+  Result result;
+  for (size_t li = 0; li < nl; ++li) {
+    Lane& lane = lanes_[li];
+    if (!lane.result.ok && result.ok) result = lane.result;
+    stats_.samples_fed += lane.samples_fed;
+    stats_.frames_returned += lane.frames_returned;
+    if (auto* c = dynamic_cast<CountedBackend*>(lane.backend.get())) {
+      BackendCounters bc = c->counters();
+      stats_.pictures_reconstructed += bc.pictures_reconstructed;
+      stats_.pictures_skipped += bc.pictures_skipped;
+      stats_.bytes_uploaded += bc.bytes_uploaded;
+      stats_.entropy_ns += bc.entropy_ns;
+    }
+  }
+  stats_.wall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(
+                       std::chrono::steady_clock::now() - t0)
+                       .count();
+  return result;
+}
+
+}  // namespace hwang

@@ -1,0 +1,35 @@
+#include "video_decoder_factory.h"
+
+#include "amd/amd_video_decoder.h"
+#include "stamp_video_decoder.h"
+
+namespace hwang {
+
+// Reference: video_decoder_factory.cpp:31-98.  Only the MI355X backend (and
+// the protocol test fixture) exist in this build.
+std::vector<VideoDecoderType> VideoDecoderFactory::get_supported_decoder_types() {
+  return {VideoDecoderType::AMD, VideoDecoderType::STAMP};
+}
+
+bool VideoDecoderFactory::has_decoder_type(VideoDecoderType type) {
+  for (VideoDecoderType t : get_supported_decoder_types())
+    if (t == type) return true;
+  return false;
+}
+
+VideoDecoderInterface* VideoDecoderFactory::make_from_config(
+    DeviceHandle device_handle, uint32_t num_devices, VideoDecoderType type) {
+  switch (type) {
+    case VideoDecoderType::AMD:
+      // The reconstruct kernels only exist for the GPU; a CPU handle is a
+      // configuration error, not a cue to fall back.
+      if (device_handle.type != DeviceType::GPU) return nullptr;
+      return make_amd_video_decoder(device_handle.id, num_devices);
+    case VideoDecoderType::STAMP:
+      return new StampVideoDecoder();
+    default:
+      return nullptr;
+  }
+}
+
+}  // namespace hwang

@@ -1,0 +1,160 @@
+"""hwang.Decoder (python/hwang/decoder.py:5-69) on the MI355X backend.
+
+`retrieve(rows)` keeps the reference's meaning -- the k-th returned array is
+frame rows[k] as H x W x 3 uint8 RGB -- but a GPU Decoder hands the whole
+request to the library's parallel retriever (all keyframe-anchored intervals
+in flight at once on separate HIP streams) instead of looping one
+DecoderAutomata over the intervals.  `retrieve_serial` is the literal
+reference loop, kept for parity tests of the automata path.
+"""
+import ctypes as C
+import mmap
+
+import numpy as np
+
+from . import _capi
+from ._capi import lib
+from .api import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData,
+                  VideoDecoderType, slice_into_video_intervals)
+
+
+class Decoder(object):
+    def __init__(self, f_or_path, video_index=None, device_type=DeviceType.GPU,
+                 device_id=0, decoder_type=None, num_lanes=0):
+        import hwang_amd
+        if video_index is None:
+            video_index = hwang_amd.index_video(f_or_path)
+        self.video_index = video_index
+        if isinstance(f_or_path, str):
+            f = open(f_or_path, 'rb')
+        else:
+            f = f_or_path
+        self.f = f
+
+        if decoder_type is None:
+            # The reference hard-wires GPU -> NVIDIA, CPU -> SOFTWARE
+            # (decoder.py:24-27).  Here GPU -> AMD; a CPU handle has no
+            # backend in this build and fails below.
+            decoder_type = (VideoDecoderType.AMD if device_type == DeviceType.GPU
+                            else VideoDecoderType.SOFTWARE)
+        self.device_type = device_type
+        self.device_id = device_id
+        self.decoder_type = decoder_type
+        self.num_lanes = num_lanes
+        self._automata = None
+        self._retriever = None
+        if not lib.hwang_decoder_type_supported(int(decoder_type)):
+            raise RuntimeError(
+                "hwang_amd.Decoder: decoder type %r is not built into "
+                "libhwang_amd.so (only AMD on a GPU device; there is no CPU "
+                "fallback)" % (decoder_type,))
+
+    # -- literal reference loop ----------------------------------------------
+    def _get_automata(self):
+        if self._automata is None:
+            handle = DeviceHandle(self.device_type, self.device_id)
+            self._automata = DecoderAutomata(handle, 1, self.decoder_type)
+        return self._automata
+
+    def retrieve_serial(self, rows):
+        video_intervals = slice_into_video_intervals(self.video_index, rows)
+        frames = []
+        sample_offsets = self.video_index.sample_offsets()
+        sample_sizes = self.video_index.sample_sizes()
+        sample_offsets.append(sample_offsets[-1] + sample_sizes[-1])
+        sample_sizes.append(0)
+        keyframes = self.video_index.keyframe_indices()
+        dec = self._get_automata()
+        for (start_index, end_index), valid_frames in video_intervals:
+            if not valid_frames:
+                continue
+            start_offset = sample_offsets[start_index]
+            end_offset = sample_offsets[end_index] + sample_sizes[end_index]
+            self.f.seek(start_offset, 0)
+            encoded_data = self.f.read(end_offset - start_offset)
+
+            data = EncodedData()
+            data.width = self.video_index.frame_width()
+            data.height = self.video_index.frame_height()
+            data.format = self.video_index.format()
+            data.start_keyframe = start_index
+            data.end_keyframe = end_index
+            data.sample_offsets = [o - start_offset
+                                   for o in sample_offsets[start_index:end_index]]
+            data.sample_sizes = sample_sizes[start_index:end_index]
+            data.valid_frames = valid_frames
+            data.keyframes = [k for k in keyframes
+                              if k >= start_index and k <= end_index]
+            data.encoded_video = encoded_data
+            dec.initialize([data], self.video_index.metadata_bytes())
+            frames += dec.get_frames(self.video_index, len(valid_frames))
+        return frames
+
+    # -- parallel path ---------------------------------------------------------
+    def _get_retriever(self):
+        if self._retriever is None:
+            h = lib.hwang_retriever_create(int(self.device_type), self.device_id,
+                                           int(self.decoder_type), self.num_lanes)
+            if not h:
+                raise RuntimeError(
+                    "hwang_amd.Decoder: cannot open backend %r on device %d" %
+                    (self.decoder_type, self.device_id))
+            self._retriever = h
+        return self._retriever
+
+    def _file_view(self):
+        try:
+            return mmap.mmap(self.f.fileno(), 0, access=mmap.ACCESS_READ)
+        except (AttributeError, OSError, ValueError):
+            self.f.seek(0, 0)
+            return self.f.read()
+
+    def retrieve_into(self, rows, out_ptr, out_capacity, yuv=False):
+        """Decode `rows` (sorted) into caller memory (host or HBM address)."""
+        r = self._get_retriever()
+        view = self._file_view()
+        n = len(view)
+        if isinstance(view, bytes):
+            src, keep = view, view
+        else:
+            keep = (C.c_char * n).from_buffer_copy(view) if False else None
+            arr = np.frombuffer(view, dtype=np.uint8)
+            src, keep = C.c_void_p(arr.ctypes.data), arr
+        rows_arr = _capi.u64_array(rows)
+        rc = lib.hwang_retriever_retrieve(r, self.video_index._h, src, n, rows_arr,
+                                          len(rows_arr), out_ptr, out_capacity,
+                                          1 if yuv else 0)
+        del keep
+        if rc:
+            raise RuntimeError(lib.hwang_retriever_last_error(r).decode())
+
+    def retrieve(self, rows):
+        rows = list(rows)
+        h, w = self.video_index.frame_height(), self.video_index.frame_width()
+        buf = np.empty((len(rows), h, w, 3), dtype=np.uint8)
+        if rows:
+            self.retrieve_into(rows, buf.ctypes.data, buf.nbytes)
+        return [buf[i] for i in range(len(rows))]
+
+    def retrieve_yuv(self, rows):
+        """Planar I420 frames (the normative decoder output), one 1-D array each."""
+        rows = list(rows)
+        h, w = self.video_index.frame_height(), self.video_index.frame_width()
+        fs = w * h + 2 * ((w + 1) // 2) * ((h + 1) // 2)
+        buf = np.empty((len(rows), fs), dtype=np.uint8)
+        if rows:
+            self.retrieve_into(rows, buf.ctypes.data, buf.nbytes, yuv=True)
+        return [buf[i] for i in range(len(rows))]
+
+    def stats(self):
+        s = (C.c_int64 * 8)()
+        lib.hwang_retriever_stats(self._get_retriever(), s)
+        keys = ("intervals", "samples_fed", "pictures_reconstructed",
+                "pictures_skipped", "frames_returned", "bytes_uploaded",
+                "entropy_ns", "wall_ns")
+        return dict(zip(keys, list(s)))
+
+    def __del__(self):
+        h, self._retriever = getattr(self, "_retriever", None), None
+        if h:
+            lib.hwang_retriever_destroy(h)

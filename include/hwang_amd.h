@@ -1,0 +1,230 @@
+/* hwang_amd.h -- C ABI of libhwang_amd.so, the MI355X-native sparse H.264
+ * decode path behind scanner-research/hwang's plugin boundary.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes, and is
+ * what a foreign-function binding for this path would bind.  Each group names
+ * the reference interface it replaces (paths relative to the reference
+ * tree).  Functions returning `int` return 0 on success and non-zero on
+ * failure; the failure text is available from the object's *_last_error /
+ * *_error_message accessor (never thrown, never aborted).
+ *
+ * Threading: a decoder handle follows the reference's two-thread contract
+ * (feed/flush on one thread, get/discard/buffered on another).  All other
+ * handles are single-threaded objects.
+ */
+#ifndef HWANG_AMD_H_
+#define HWANG_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* -- enums (hwang/common.h:20-23, hwang/video_decoder_factory.h:23-27) ---- */
+enum { HWANG_DEVICE_CPU = 0, HWANG_DEVICE_GPU = 1 };
+enum {
+  HWANG_DECODER_SOFTWARE = 0, /* FFmpeg backend: not built here            */
+  HWANG_DECODER_NVIDIA = 1,   /* NVDEC backend: not built here             */
+  HWANG_DECODER_INTEL = 2,    /* dead in the reference                     */
+  HWANG_DECODER_AMD = 3,      /* this library's MI355X backend             */
+  HWANG_DECODER_STAMP = 100   /* protocol test fixture, decodes nothing    */
+};
+
+const char* hwang_amd_version(void);
+
+/* -- VideoIndex (hwang/video_index.h:22-77) -------------------------------- */
+typedef struct hwang_video_index hwang_video_index;
+
+hwang_video_index* hwang_video_index_create(
+    uint32_t timescale, uint64_t duration, uint32_t width, uint32_t height,
+    const char* format, const uint64_t* sample_offsets,
+    const uint64_t* sample_sizes, size_t num_samples,
+    const uint64_t* keyframe_indices, size_t num_keyframes,
+    const uint8_t* metadata, size_t metadata_size);
+void hwang_video_index_destroy(hwang_video_index* index);
+/* VideoIndex::deserialize / serialize (video_index.cpp:24-60): proto3 wire
+ * format of hwang/hwang_descriptors.proto:5-15.  deserialize returns NULL on
+ * malformed input.  serialize: call with out == NULL to get the size. */
+hwang_video_index* hwang_video_index_deserialize(const uint8_t* data,
+                                                 size_t size);
+size_t hwang_video_index_serialize(const hwang_video_index* index,
+                                   uint8_t* out, size_t out_capacity);
+uint32_t hwang_video_index_timescale(const hwang_video_index* index);
+uint64_t hwang_video_index_duration(const hwang_video_index* index);
+double hwang_video_index_fps(const hwang_video_index* index);
+uint32_t hwang_video_index_frame_width(const hwang_video_index* index);
+uint32_t hwang_video_index_frame_height(const hwang_video_index* index);
+const char* hwang_video_index_format(const hwang_video_index* index);
+uint64_t hwang_video_index_frames(const hwang_video_index* index);
+const uint64_t* hwang_video_index_sample_offsets(const hwang_video_index* index);
+const uint64_t* hwang_video_index_sample_sizes(const hwang_video_index* index);
+size_t hwang_video_index_num_keyframes(const hwang_video_index* index);
+const uint64_t* hwang_video_index_keyframe_indices(const hwang_video_index* index);
+size_t hwang_video_index_metadata_size(const hwang_video_index* index);
+const uint8_t* hwang_video_index_metadata_bytes(const hwang_video_index* index);
+
+/* -- MP4IndexCreator (hwang/mp4_index_creator.h:23-45) --------------------- */
+typedef struct hwang_mp4_indexer hwang_mp4_indexer;
+
+hwang_mp4_indexer* hwang_mp4_indexer_create(uint64_t file_size);
+void hwang_mp4_indexer_destroy(hwang_mp4_indexer* indexer);
+/* MP4IndexCreator::feed: returns 1 while more data is wanted (then
+ * *next_offset / *next_size say what to read), 0 when done or failed. */
+int hwang_mp4_indexer_feed(hwang_mp4_indexer* indexer, const uint8_t* data,
+                           size_t size, uint64_t* next_offset,
+                           uint64_t* next_size);
+int hwang_mp4_indexer_is_done(hwang_mp4_indexer* indexer);
+int hwang_mp4_indexer_is_error(hwang_mp4_indexer* indexer);
+const char* hwang_mp4_indexer_error_message(hwang_mp4_indexer* indexer);
+/* Caller owns the returned index. */
+hwang_video_index* hwang_mp4_indexer_get_video_index(hwang_mp4_indexer* indexer);
+
+/* -- slice_into_video_intervals (hwang/video_index.h:79-85) ---------------- */
+typedef struct hwang_video_intervals hwang_video_intervals;
+
+/* Returns NULL when a row is >= frames() (the reference asserts). */
+hwang_video_intervals* hwang_slice_into_video_intervals(
+    const hwang_video_index* index, const uint64_t* rows, size_t num_rows);
+void hwang_video_intervals_destroy(hwang_video_intervals* intervals);
+size_t hwang_video_intervals_count(const hwang_video_intervals* intervals);
+void hwang_video_intervals_range(const hwang_video_intervals* intervals,
+                                 size_t i, uint64_t* start_sample,
+                                 uint64_t* end_sample);
+size_t hwang_video_intervals_num_valid(const hwang_video_intervals* intervals,
+                                       size_t i);
+const uint64_t* hwang_video_intervals_valid(const hwang_video_intervals* intervals,
+                                            size_t i);
+
+/* -- VideoDecoderInterface + VideoDecoderFactory ---------------------------
+ * One C entry point per virtual of hwang/video_decoder_interface.h:35-49;
+ * hwang_decoder_create is VideoDecoderFactory::make_from_config
+ * (hwang/video_decoder_factory.h:35-37). */
+typedef struct hwang_decoder hwang_decoder;
+
+int hwang_decoder_type_supported(int decoder_type);
+/* NULL when the type is unsupported or the device cannot be opened. */
+hwang_decoder* hwang_decoder_create(int device_type, int32_t device_id,
+                                    uint32_t num_devices, int decoder_type);
+void hwang_decoder_destroy(hwang_decoder* dec);
+int hwang_decoder_configure(hwang_decoder* dec, uint32_t width, uint32_t height,
+                            const char* format, const uint8_t* extradata,
+                            size_t extradata_size);
+int hwang_decoder_feed(hwang_decoder* dec, const uint8_t* encoded,
+                       size_t encoded_size, int keyframe);
+int hwang_decoder_flush(hwang_decoder* dec);
+int hwang_decoder_discard_frame(hwang_decoder* dec);
+/* `decoded` may be host or device (HBM) memory; RGB24, stride width*3. */
+int hwang_decoder_get_frame(hwang_decoder* dec, uint8_t* decoded,
+                            size_t decoded_size);
+int hwang_decoder_decoded_frames_buffered(hwang_decoder* dec);
+int hwang_decoder_wait_until_frames_copied(hwang_decoder* dec);
+const char* hwang_decoder_last_error(hwang_decoder* dec);
+/* Extensions (not in the reference interface):
+ *  - set_wanted: SparseDecodeHints; ordinals are 0-based output positions
+ *    from the interval start, ascending, valid until the next flush.
+ *  - get_frame_yuv: like get_frame but copies the cropped planar I420 frame
+ *    (Y w*h, then U, then V (w/2)*(h/2)); the normative decoder output used
+ *    by the bit-exact parity tests.
+ *  - set_output_yuv: 1 => get_frame is not expected and RGB conversion is
+ *    skipped for this handle. */
+int hwang_decoder_set_wanted(hwang_decoder* dec, const uint64_t* ordinals,
+                             size_t n);
+int hwang_decoder_get_frame_yuv(hwang_decoder* dec, uint8_t* decoded,
+                                size_t decoded_size);
+
+/* -- DecoderAutomata (hwang/decoder_automata.h:38-70) ---------------------- */
+typedef struct hwang_automata hwang_automata;
+
+/* DecoderAutomata::EncodedData (decoder_automata.h:43-66) as a plain struct;
+ * all pointers are borrowed for the duration of hwang_automata_initialize. */
+typedef struct hwang_encoded_data {
+  const uint8_t* encoded_video;
+  size_t encoded_video_size;
+  uint32_t width;
+  uint32_t height;
+  uint64_t start_keyframe;
+  uint64_t end_keyframe;
+  const char* format;
+  const uint64_t* sample_offsets;
+  const uint64_t* sample_sizes;
+  size_t num_samples;
+  const uint64_t* keyframes;
+  size_t num_keyframes;
+  const uint64_t* valid_frames;
+  size_t num_valid_frames;
+} hwang_encoded_data;
+
+/* DecoderAutomata::make_instance; NULL if the backend cannot be made. */
+hwang_automata* hwang_automata_create(int device_type, int32_t device_id,
+                                      int32_t num_devices, int decoder_type);
+void hwang_automata_destroy(hwang_automata* a);
+int hwang_automata_initialize(hwang_automata* a, const hwang_encoded_data* data,
+                              size_t num_data, const uint8_t* extradata,
+                              size_t extradata_size);
+/* Fills num_frames * width*height*3 bytes of packed RGB24. */
+int hwang_automata_get_frames(hwang_automata* a, uint8_t* buffer,
+                              int32_t num_frames);
+const char* hwang_automata_last_error(hwang_automata* a);
+/* stats[4] = samples_fed, frames_discarded, frames_returned, flushes */
+void hwang_automata_stats(hwang_automata* a, int64_t stats[4]);
+/* STAMP backend only: trace[8] = configures, feeds, keyframe_feeds,
+ * empty_feeds, flushes, gets, discards, hints.  Returns non-zero otherwise. */
+int hwang_automata_stamp_trace(hwang_automata* a, int32_t trace[8]);
+
+/* -- Parallel sparse retrieval (the perf path) ------------------------------
+ * What python/hwang/decoder.py:30-69 (Decoder.retrieve) does one interval at
+ * a time through one DecoderAutomata, done for all intervals at once: the
+ * plan's intervals are trimmed to their last wanted frame and fanned out
+ * over `num_lanes` independent backend instances (one host entropy thread +
+ * one HIP stream each) on one GPU.  No data-path collective. */
+typedef struct hwang_retriever hwang_retriever;
+
+hwang_retriever* hwang_retriever_create(int device_type, int32_t device_id,
+                                        int decoder_type, int32_t num_lanes);
+void hwang_retriever_destroy(hwang_retriever* r);
+/* `file` is the whole MP4 mapped or read into memory (borrowed for the
+ * call).  rows must be sorted ascending.  `out` receives num_rows frames in
+ * row order; out_is_yuv selects cropped I420 (w*h*3/2 per frame) instead of
+ * RGB24 (w*h*3).  `out` may be host or device memory. */
+int hwang_retriever_retrieve(hwang_retriever* r, const hwang_video_index* index,
+                             const uint8_t* file, size_t file_size,
+                             const uint64_t* rows, size_t num_rows,
+                             uint8_t* out, size_t out_capacity, int out_is_yuv);
+const char* hwang_retriever_last_error(hwang_retriever* r);
+/* stats of the last retrieve():
+ *  [0] intervals, [1] samples fed, [2] pictures reconstructed on the GPU,
+ *  [3] pictures skipped (unwanted non-reference), [4] frames returned,
+ *  [5] bytes uploaded (macroblock records + coefficients),
+ *  [6] host entropy-decode nanoseconds summed over lanes,
+ *  [7] wall nanoseconds */
+void hwang_retriever_stats(hwang_retriever* r, int64_t stats[8]);
+
+/* -- Kernel-level entry points (parity tests + per-kernel roofline) ---------
+ * Each runs one HIP kernel of the reconstruct pipeline on device buffers the
+ * caller provides (plain device pointers, e.g. torch tensor data_ptr()),
+ * on the given hipStream_t (NULL = default stream), asynchronously. */
+/* K5: cropped planar I420 -> packed RGB24 (replaces sws_scale in
+ * impls/software/software_video_decoder.cpp:281-339 and NV12_to_RGB in
+ * impls/nvidia/convert.cu:109-219). */
+int hwang_k_yuv420_to_rgb24(const uint8_t* y, const uint8_t* u,
+                            const uint8_t* v, int y_stride, int c_stride,
+                            int width, int height, uint8_t* rgb, void* stream);
+
+/* -- Profiling hooks ---------------------------------------------------------
+ * When enabled, every kernel launch of the backend is bracketed with HIP
+ * events on its own stream; hwang_prof_read drains the accumulated
+ * per-kernel totals.  kernel ids: see hwang_prof_kernel_name(). */
+void hwang_prof_enable(int on);
+int hwang_prof_num_kernels(void);
+const char* hwang_prof_kernel_name(int kernel_id);
+/* out[0]=launches, out[1]=total microseconds, out[2]=algorithmic bytes */
+int hwang_prof_read(int kernel_id, double out[3]);
+void hwang_prof_reset(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* HWANG_AMD_H_ */
