@@ -203,7 +203,7 @@ void hwang_retriever_stats(hwang_retriever* r, int64_t stats[8]);
 
 /* -- Kernel-level entry points (parity tests + per-kernel roofline) ---------
  * Each runs one HIP kernel of the reconstruct pipeline on device buffers the
- * caller provides (plain device pointers, e.g. torch tensor data_ptr()),
+ * caller provides (plain device pointers),
  * on the given hipStream_t (NULL = default stream), asynchronously. */
 /* K5: cropped planar I420 -> packed RGB24 (replaces sws_scale in
  * impls/software/software_video_decoder.cpp:281-339 and NV12_to_RGB in

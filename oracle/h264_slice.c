@@ -1,0 +1,1201 @@
+/* TEST INFRASTRUCTURE -- oracle: slice_data() / macroblock_layer() parsing
+ * with both entropy coders (9.2 CAVLC, 9.3 CABAC), intra mode and motion
+ * vector derivation (8.3.1.1, 8.4.1).  Restates FFmpeg's h264_cabac.c /
+ * h264_cavlc.c / h264_mvpred.h / h264_direct.c as used behind
+ * software_video_decoder.cpp:353-357 (avcodec_send_packet). */
+#include "h264_internal.h"
+
+#include <stdio.h>
+
+/* ======================================================================== */
+/* CABAC engine (9.3.1.2, 9.3.3.2)                                          */
+/* ======================================================================== */
+static void cabac_start(Cabac* c, Bits* b) {
+  c->bits = b;
+  c->range = 510;
+  c->offset = get_bits(b, 9);
+}
+
+static void cabac_init_contexts(Cabac* c, int slice_type, int idc, int qp) {
+  const int t = slice_type == 2 ? 0 : 1 + idc;
+  qp = iclip(0, 51, qp);
+  for (int i = 0; i < CABAC_CTX_COUNT; ++i) {
+    int m = cabac_init_mn[t][i][0], n = cabac_init_mn[t][i][1];
+    int pre = iclip(1, 126, ((m * qp) >> 4) + n);
+    if (pre <= 63)
+      c->state[i] = (uint8_t)((63 - pre) << 1);
+    else
+      c->state[i] = (uint8_t)(((pre - 64) << 1) | 1);
+  }
+}
+
+static int cabac_bin(Cabac* c, int ctx) {
+  int p = c->state[ctx] >> 1, mps = c->state[ctx] & 1;
+  unsigned lps = cabac_range_lps[p][(c->range >> 6) & 3];
+  int bin;
+  c->range -= lps;
+  if (c->offset >= c->range) {
+    bin = !mps;
+    c->offset -= c->range;
+    c->range = lps;
+    if (p == 0) mps = !mps;
+    p = cabac_trans_lps[p];
+  } else {
+    bin = mps;
+    if (p < 62) ++p;
+  }
+  c->state[ctx] = (uint8_t)((p << 1) | mps);
+  while (c->range < 256) {
+    c->range <<= 1;
+    c->offset = (c->offset << 1) | get_bit(c->bits);
+  }
+  return bin;
+}
+
+static int cabac_bypass(Cabac* c) {
+  c->offset = (c->offset << 1) | get_bit(c->bits);
+  if (c->offset >= c->range) {
+    c->offset -= c->range;
+    return 1;
+  }
+  return 0;
+}
+
+static int cabac_terminate(Cabac* c) {
+  c->range -= 2;
+  if (c->offset >= c->range) return 1;
+  while (c->range < 256) {
+    c->range <<= 1;
+    c->offset = (c->offset << 1) | get_bit(c->bits);
+  }
+  return 0;
+}
+
+/* ======================================================================== */
+/* neighbour helpers                                                        */
+/* ======================================================================== */
+static inline int mb_avail(const H264Oracle* d, int mbx, int mby) {
+  if (mbx < 0 || mby < 0 || mbx >= d->mbw || mby >= d->mbh) return 0;
+  return d->mb_slice[mby * d->mbw + mbx] == d->slice_index;
+}
+
+typedef struct {
+  int ref; /* -2 partition not available, -1 list not used / intra, >= 0 refIdx */
+  int mv[2];
+} NB;
+
+/* (rx, ry): 4x4-block coordinates relative to the current macroblock,
+ * -1..4.  cur_zz: luma4x4BlkIdx of the predicting partition's first block
+ * (blocks of the current MB later than that in decoding order are "not yet
+ * decoded", 6.4.11.7). */
+static NB fetch_nb(const H264Oracle* d, int list, int rx, int ry, int cur_zz) {
+  NB nb = {-2, {0, 0}};
+  if (rx > 3 && ry >= 0) return nb;
+  const int ox = rx < 0 ? -1 : (rx > 3 ? 1 : 0), oy = ry < 0 ? -1 : 0;
+  const int nx = d->mb.mbx + ox, ny = d->mb.mby + oy;
+  const int bx = rx & 3, by = ry & 3;
+  if (ox == 0 && oy == 0) {
+    if (raster_to_blk4[by * 4 + bx] >= cur_zz) return nb;
+  } else if (!mb_avail(d, nx, ny)) {
+    return nb;
+  }
+  const int addr = ny * d->mbw + nx;
+  const Picture* cur = d->cur;
+  nb.ref = -1;
+  if (cur->mb_intra[addr]) return nb;
+  int r = cur->ref_idx[list][addr * 4 + (by >> 1) * 2 + (bx >> 1)];
+  if (r < 0) return nb;
+  nb.ref = r;
+  nb.mv[0] = cur->mv[list][addr * 16 + by * 4 + bx][0];
+  nb.mv[1] = cur->mv[list][addr * 16 + by * 4 + bx][1];
+  return nb;
+}
+
+enum { PRED_MEDIAN = 0, PRED_16x8_TOP, PRED_16x8_BOTTOM, PRED_8x16_LEFT, PRED_8x16_RIGHT };
+
+/* 8.4.1.3 */
+static void pred_mv(const H264Oracle* d, int list, int bx, int by, int bw, int ref, int dir,
+                    int out[2]) {
+  const int zz = raster_to_blk4[by * 4 + bx];
+  NB A = fetch_nb(d, list, bx - 1, by, zz);
+  NB B = fetch_nb(d, list, bx, by - 1, zz);
+  NB C = fetch_nb(d, list, bx + bw, by - 1, zz);
+  if (C.ref == -2) C = fetch_nb(d, list, bx - 1, by - 1, zz);
+  const NB* pick = NULL;
+  if (dir == PRED_16x8_TOP && B.ref == ref) pick = &B;
+  if (dir == PRED_16x8_BOTTOM && A.ref == ref) pick = &A;
+  if (dir == PRED_8x16_LEFT && A.ref == ref) pick = &A;
+  if (dir == PRED_8x16_RIGHT && C.ref == ref) pick = &C;
+  if (!pick) {
+    int match = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+    if (match == 1) {
+      pick = A.ref == ref ? &A : (B.ref == ref ? &B : &C);
+    } else if (match == 0 && B.ref == -2 && C.ref == -2 && A.ref != -2) {
+      pick = &A;
+    }
+  }
+  if (pick) {
+    out[0] = pick->mv[0];
+    out[1] = pick->mv[1];
+  } else {
+    out[0] = median3(A.mv[0], B.mv[0], C.mv[0]);
+    out[1] = median3(A.mv[1], B.mv[1], C.mv[1]);
+  }
+}
+
+static void set_mv_block(H264Oracle* d, int list, int bx, int by, int bw, int bh, int mvx, int mvy) {
+  const int base = d->mb.addr * 16;
+  for (int y = by; y < by + bh; ++y)
+    for (int x = bx; x < bx + bw; ++x) {
+      d->cur->mv[list][base + y * 4 + x][0] = (int16_t)mvx;
+      d->cur->mv[list][base + y * 4 + x][1] = (int16_t)mvy;
+      d->mb.mv[list][y * 4 + x][0] = (int16_t)mvx;
+      d->mb.mv[list][y * 4 + x][1] = (int16_t)mvy;
+    }
+}
+
+static void set_mvd_block(H264Oracle* d, int list, int bx, int by, int bw, int bh, int dx, int dy) {
+  uint8_t ax = (uint8_t)imin(iabs(dx), 255), ay = (uint8_t)imin(iabs(dy), 255);
+  for (int y = by; y < by + bh; ++y)
+    for (int x = bx; x < bx + bw; ++x) {
+      d->mvd[d->mb.addr][list][y * 4 + x][0] = ax;
+      d->mvd[d->mb.addr][list][y * 4 + x][1] = ay;
+    }
+}
+
+static void set_ref8(H264Oracle* d, int list, int b8, int ref) {
+  Picture* cur = d->cur;
+  const int i = d->mb.addr * 4 + b8;
+  d->mb.ref[list][b8] = (int8_t)ref;
+  cur->ref_idx[list][i] = (int8_t)ref;
+  if (ref >= 0 && ref < d->sl.num_ref_idx[list] && d->sl.ref_list[list][ref]) {
+    const Picture* r = d->sl.ref_list[list][ref];
+    cur->ref_uid[list][i] = r->uid;
+    cur->ref_poc[list][i] = r->poc;
+    cur->ref_long[list][i] = r->ref == 2;
+  } else {
+    cur->ref_uid[list][i] = -1;
+    cur->ref_poc[list][i] = 0;
+    cur->ref_long[list][i] = 0;
+  }
+}
+
+/* ======================================================================== */
+/* direct prediction (8.4.1.2)                                              */
+/* ======================================================================== */
+/* Fills mv/ref of 8x8 block b8 (or all four when b8 < 0). */
+static int pred_direct(H264Oracle* d, int only_b8) {
+  Slice* sl = &d->sl;
+  MB* m = &d->mb;
+  const Picture* col = sl->ref_list[1][0];
+  if (!col) return h264i_fail(d, "direct prediction without RefPicList1[0]");
+  const int inf8 = d->asps->direct_8x8_inference;
+  const int addr = m->addr;
+
+  if (sl->direct_spatial) {
+    int ref[2], mvp[2][2] = {{0, 0}, {0, 0}};
+    for (int l = 0; l < 2; ++l) {
+      NB A = fetch_nb(d, l, -1, 0, 0);
+      NB B = fetch_nb(d, l, 0, -1, 0);
+      NB C = fetch_nb(d, l, 4, -1, 0);
+      if (C.ref == -2) C = fetch_nb(d, l, -1, -1, 0);
+      int r = -1;
+      if (A.ref >= 0) r = A.ref;
+      if (B.ref >= 0 && (r < 0 || B.ref < r)) r = B.ref;
+      if (C.ref >= 0 && (r < 0 || C.ref < r)) r = C.ref;
+      ref[l] = r;
+      if (r >= 0) pred_mv(d, l, 0, 0, 4, r, PRED_MEDIAN, mvp[l]);
+    }
+    if (ref[0] < 0 && ref[1] < 0) ref[0] = ref[1] = 0; /* directZeroPrediction */
+    const int col_short = col->ref == 1;
+    for (int b8 = 0; b8 < 4; ++b8) {
+      if (only_b8 >= 0 && b8 != only_b8) continue;
+      for (int l = 0; l < 2; ++l) set_ref8(d, l, b8, ref[l]);
+      for (int s = 0; s < 4; ++s) {
+        const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
+        /* co-located 4x4: the corner block under direct_8x8_inference */
+        const int cx = inf8 ? (b8 & 1) * 3 : bx, cy = inf8 ? (b8 >> 1) * 3 : by;
+        int col_zero = 0;
+        if (col_short && !col->mb_intra[addr]) {
+          const int c8 = addr * 4 + (cy >> 1) * 2 + (cx >> 1);
+          int cl = col->ref_idx[0][c8] >= 0 ? 0 : 1;
+          if (col->ref_idx[cl][c8] == 0) {
+            const int16_t* cm = col->mv[cl][addr * 16 + cy * 4 + cx];
+            col_zero = cm[0] >= -1 && cm[0] <= 1 && cm[1] >= -1 && cm[1] <= 1;
+          }
+        }
+        for (int l = 0; l < 2; ++l) {
+          int zero = ref[l] < 0 || (ref[l] == 0 && col_zero);
+          set_mv_block(d, l, bx, by, 1, 1, zero ? 0 : mvp[l][0], zero ? 0 : mvp[l][1]);
+        }
+      }
+    }
+    return 0;
+  }
+
+  /* temporal direct (8.4.1.2.3) */
+  for (int b8 = 0; b8 < 4; ++b8) {
+    if (only_b8 >= 0 && b8 != only_b8) continue;
+    for (int s = 0; s < 4; ++s) {
+      const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
+      const int cx = inf8 ? (b8 & 1) * 3 : bx, cy = inf8 ? (b8 >> 1) * 3 : by;
+      int ref0 = 0, mvc[2] = {0, 0};
+      if (!col->mb_intra[addr]) {
+        const int c8 = addr * 4 + (cy >> 1) * 2 + (cx >> 1);
+        int cl = col->ref_idx[0][c8] >= 0 ? 0 : 1;
+        if (col->ref_idx[cl][c8] >= 0) {
+          mvc[0] = col->mv[cl][addr * 16 + cy * 4 + cx][0];
+          mvc[1] = col->mv[cl][addr * 16 + cy * 4 + cx][1];
+          int uid = col->ref_uid[cl][c8];
+          ref0 = -1;
+          for (int i = 0; i < sl->num_ref_idx[0]; ++i)
+            if (sl->ref_list[0][i] && sl->ref_list[0][i]->uid == uid) {
+              ref0 = i;
+              break;
+            }
+          if (ref0 < 0) return h264i_fail(d, "temporal direct: co-located reference not in RefPicList0");
+        }
+      }
+      const Picture* p0 = sl->ref_list[0][ref0];
+      int mv0[2], mv1[2];
+      int td = iclip(-128, 127, col->poc - p0->poc);
+      if (p0->ref == 2 || td == 0) {
+        mv0[0] = mvc[0];
+        mv0[1] = mvc[1];
+        mv1[0] = mv1[1] = 0;
+      } else {
+        int tb = iclip(-128, 127, d->cur->poc - p0->poc);
+        int tx = (16384 + iabs(td / 2)) / td;
+        int dsf = iclip(-1024, 1023, (tb * tx + 32) >> 6);
+        mv0[0] = (dsf * mvc[0] + 128) >> 8;
+        mv0[1] = (dsf * mvc[1] + 128) >> 8;
+        mv1[0] = mv0[0] - mvc[0];
+        mv1[1] = mv0[1] - mvc[1];
+      }
+      if (s == 0 || !inf8) {
+        /* refs are per 8x8; without 8x8 inference every 4x4 of the 8x8 maps
+         * to the same picture in a frame-coded co-located MB partition */
+      }
+      if (s == 0) {
+        set_ref8(d, 0, b8, ref0);
+        set_ref8(d, 1, b8, 0);
+      }
+      set_mv_block(d, 0, bx, by, 1, 1, mv0[0], mv0[1]);
+      set_mv_block(d, 1, bx, by, 1, 1, mv1[0], mv1[1]);
+    }
+  }
+  return 0;
+}
+
+/* ======================================================================== */
+/* residual: CAVLC (9.2)                                                    */
+/* ======================================================================== */
+static int read_vlc(Bits* b, const uint8_t* len, const uint8_t* bits, int n) {
+  /* tables are small: linear search on (len, code) */
+  for (int i = 0; i < n; ++i) {
+    if (!len[i]) continue;
+    if (bits_left(b) >= len[i] && show_bits(b, len[i]) == bits[i]) {
+      b->pos += len[i];
+      return i;
+    }
+  }
+  b->overrun = 1;
+  return -1;
+}
+
+/* nC from the total_coeff of the left/top neighbours of block (rx, ry) in
+ * plane-local 4x4 units; plane: 0 luma (4x4 blocks per MB = 4), 1/2 chroma
+ * (2 per MB). */
+static int cavlc_nc(const H264Oracle* d, int plane, int rx, int ry) {
+  const int n = plane == 0 ? 4 : 2;
+  const int base = plane == 0 ? 0 : (plane == 1 ? 16 : 20);
+  int na = -1, nb = -1;
+  if (rx > 0) {
+    na = d->mb.nnz[base + ry * n + rx - 1];
+  } else if (mb_avail(d, d->mb.mbx - 1, d->mb.mby)) {
+    na = d->nnz[(d->mb.addr - 1) * 24 + base + ry * n + n - 1];
+  }
+  if (ry > 0) {
+    nb = d->mb.nnz[base + (ry - 1) * n + rx];
+  } else if (mb_avail(d, d->mb.mbx, d->mb.mby - 1)) {
+    nb = d->nnz[(d->mb.addr - d->mbw) * 24 + base + (n - 1) * n + rx];
+  }
+  if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
+  if (na >= 0) return na;
+  if (nb >= 0) return nb;
+  return 0;
+}
+
+/* Decodes one residual block into out[scan[start + k]].  Returns total_coeff
+ * or -1.  nc == -1 selects the chroma DC tables. */
+static int cavlc_block(H264Oracle* d, Bits* b, int nc, int max_coeff, const uint8_t* scan, int start,
+                       int16_t* out) {
+  int token;
+  if (nc == -1) {
+    token = read_vlc(b, chroma_dc_coeff_token_len, chroma_dc_coeff_token_bits, 20);
+  } else {
+    int t = nc < 2 ? 0 : (nc < 4 ? 1 : (nc < 8 ? 2 : 3));
+    token = read_vlc(b, coeff_token_len[t], coeff_token_bits[t], 68);
+  }
+  if (token < 0) return h264i_fail(d, "CAVLC: bad coeff_token");
+  const int total = token >> 2, t1 = token & 3;
+  if (total == 0) return 0;
+  if (total > max_coeff) return h264i_fail(d, "CAVLC: total_coeff exceeds block size");
+  int level[16];
+  for (int i = 0; i < t1; ++i) level[i] = get_bit(b) ? -1 : 1;
+  int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
+  for (int i = t1; i < total; ++i) {
+    int prefix = 0;
+    while (!get_bit(b)) {
+      if (++prefix > 31 || b->overrun) return h264i_fail(d, "CAVLC: bad level_prefix");
+    }
+    int code = imin(15, prefix) << suffix_len;
+    int size = suffix_len;
+    if (prefix == 14 && suffix_len == 0) size = 4;
+    if (prefix >= 15) size = prefix - 3;
+    if (size > 0) code += get_bits(b, size);
+    if (prefix >= 15 && suffix_len == 0) code += 15;
+    if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+    if (i == t1 && t1 < 3) code += 2;
+    level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+    if (suffix_len == 0) suffix_len = 1;
+    if (iabs(level[i]) > (3 << (suffix_len - 1)) && suffix_len < 6) ++suffix_len;
+  }
+  int zeros_left = 0;
+  if (total < max_coeff) {
+    int tz;
+    if (nc == -1)
+      tz = read_vlc(b, chroma_dc_total_zeros_len[total - 1], chroma_dc_total_zeros_bits[total - 1], 4);
+    else
+      tz = read_vlc(b, total_zeros_len[total - 1], total_zeros_bits[total - 1], total_zeros_count[total - 1]);
+    if (tz < 0) return h264i_fail(d, "CAVLC: bad total_zeros");
+    zeros_left = tz;
+  }
+  if (zeros_left + total > max_coeff) return h264i_fail(d, "CAVLC: total_zeros exceeds block size");
+  int pos = zeros_left + total - 1; /* scan index of the highest coefficient */
+  for (int i = 0; i < total; ++i) {
+    out[scan[start + pos]] = (int16_t)level[i];
+    if (i == total - 1) break;
+    int run = 0;
+    if (zeros_left > 0) {
+      int t = imin(zeros_left, 7) - 1;
+      run = read_vlc(b, run_before_len[t], run_before_bits[t], run_before_count[t]);
+      if (run < 0 || run > zeros_left) return h264i_fail(d, "CAVLC: bad run_before");
+      zeros_left -= run;
+    }
+    pos -= run + 1;
+  }
+  return total;
+}
+
+/* ======================================================================== */
+/* residual: CABAC (9.3.2.x / 9.3.3.1.3)                                    */
+/* ======================================================================== */
+static const int cbf_cat_offset[6] = {0, 4, 8, 12, 16, 0};
+static const int sig_cat_offset[6] = {0, 15, 29, 44, 47, 0};
+static const int abs_cat_offset[6] = {0, 10, 20, 30, 39, 0};
+
+/* cat: 0 I16 DC, 1 I16 AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC, 5 luma 8x8.
+ * cbf_inc < 0: no coded_block_flag (cat 5 in 4:2:0).  Returns nonzero count. */
+static int cabac_block(H264Oracle* d, int cat, int cbf_inc, int max_coeff, const uint8_t* scan,
+                       int start, int16_t* out) {
+  Cabac* c = &d->cabac;
+  if (cbf_inc >= 0) {
+    if (!cabac_bin(c, 85 + cbf_cat_offset[cat] + cbf_inc)) return 0;
+  }
+  const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
+  const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
+  const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
+  int idx[64], n = 0;
+  int i;
+  for (i = 0; i < max_coeff - 1; ++i) {
+    int sinc, linc;
+    if (cat == 5) {
+      sinc = sig_coeff_offset_8x8[i];
+      linc = last_coeff_offset_8x8[i];
+    } else if (cat == 3) {
+      sinc = linc = imin(i, 2);
+    } else {
+      sinc = linc = i;
+    }
+    if (cabac_bin(c, sig_base + sinc)) {
+      idx[n++] = i;
+      if (cabac_bin(c, last_base + linc)) break;
+    }
+  }
+  if (i == max_coeff - 1) idx[n++] = max_coeff - 1; /* inferred significant */
+  int gt1 = 0, eq1 = 0;
+  for (int k = n - 1; k >= 0; --k) {
+    int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
+    int val;
+    if (!cabac_bin(c, abs_base + inc0)) {
+      val = 1;
+      ++eq1;
+    } else {
+      int inc = 5 + imin(4 - (cat == 3 ? 1 : 0), gt1);
+      val = 2;
+      while (val < 15 && cabac_bin(c, abs_base + inc)) ++val;
+      if (val == 15) { /* prefix saturated: Exp-Golomb k=0 suffix */
+        int k0 = 0;
+        while (cabac_bypass(c)) {
+          val += 1 << k0;
+          if (++k0 > 24) return h264i_fail(d, "CABAC: coeff_abs_level overflow");
+        }
+        while (k0--) val += cabac_bypass(c) << k0;
+      }
+      ++gt1;
+    }
+    if (cabac_bypass(c)) val = -val;
+    out[scan[start + idx[k]]] = (int16_t)val;
+  }
+  return n;
+}
+
+/* coded_block_flag ctxIdxInc from the two neighbouring transform blocks.
+ * kind: 0 luma DC, 1 luma 4x4 block (rx, ry), 2 chroma DC plane p, 3 chroma
+ * AC block (rx, ry) of plane p. */
+static int cbf_neighbour(const H264Oracle* d, int kind, int p, int rx, int ry, int left) {
+  const MB* m = &d->mb;
+  const int cur_intra = m->kind != MB_INTER;
+  int nx = m->mbx, ny = m->mby, inside = 0;
+  if (kind == 1 || kind == 3) {
+    if (left) {
+      if (rx > 0) inside = 1; else nx--;
+    } else {
+      if (ry > 0) inside = 1; else ny--;
+    }
+  } else {
+    if (left) nx--; else ny--;
+  }
+  if (inside) {
+    if (kind == 1) return m->nnz[(left ? ry * 4 + rx - 1 : (ry - 1) * 4 + rx)] != 0;
+    const int base = 16 + 4 * p;
+    return m->nnz[base + (left ? ry * 2 + rx - 1 : (ry - 1) * 2 + rx)] != 0;
+  }
+  if (!mb_avail(d, nx, ny)) return cur_intra;
+  const int addr = ny * d->mbw + nx;
+  if (d->mb_kind[addr] == MB_IPCM) return 1;
+  switch (kind) {
+    case 0: return d->mb_kind[addr] == MB_I16x16 && (d->mb_cbf_dc[addr] & 1);
+    case 1: return d->nnz[addr * 24 + (left ? ry * 4 + 3 : 12 + rx)] != 0;
+    case 2: return (d->mb_cbf_dc[addr] >> (1 + p)) & 1;
+    default: return d->nnz[addr * 24 + 16 + 4 * p + (left ? ry * 2 + 1 : 2 + rx)] != 0;
+  }
+}
+static int cbf_inc(const H264Oracle* d, int kind, int p, int rx, int ry) {
+  return cbf_neighbour(d, kind, p, rx, ry, 1) + 2 * cbf_neighbour(d, kind, p, rx, ry, 0);
+}
+
+/* ======================================================================== */
+/* macroblock syntax helpers                                                */
+/* ======================================================================== */
+typedef struct {
+  H264Oracle* d;
+  Bits* b;
+  int cabac;
+} Rd;
+
+static int rd_intra_mb_type(Rd* r, int ctx_base, int intra_slice) {
+  Cabac* c = &r->d->cabac;
+  if (intra_slice) {
+    const H264Oracle* d = r->d;
+    int inc = 0;
+    if (mb_avail(d, d->mb.mbx - 1, d->mb.mby)) {
+      int k = d->mb_kind[d->mb.addr - 1];
+      inc += k != MB_I4x4 && k != MB_I8x8;
+    }
+    if (mb_avail(d, d->mb.mbx, d->mb.mby - 1)) {
+      int k = d->mb_kind[d->mb.addr - d->mbw];
+      inc += k != MB_I4x4 && k != MB_I8x8;
+    }
+    if (!cabac_bin(c, ctx_base + inc)) return 0;
+    ctx_base += 2;
+  } else {
+    if (!cabac_bin(c, ctx_base)) return 0;
+  }
+  if (cabac_terminate(c)) return 25;
+  int t = 1;
+  t += 12 * cabac_bin(c, ctx_base + 1);
+  if (cabac_bin(c, ctx_base + 2)) t += 4 + 4 * cabac_bin(c, ctx_base + 2 + intra_slice);
+  t += 2 * cabac_bin(c, ctx_base + 3 + intra_slice);
+  t += cabac_bin(c, ctx_base + 3 + 2 * intra_slice);
+  return t;
+}
+
+/* returns the slice-type specific mb_type number (before intra offset removal) */
+static int rd_mb_type(Rd* r) {
+  H264Oracle* d = r->d;
+  const int st = d->sl.type;
+  if (!r->cabac) return (int)get_ue(r->b);
+  Cabac* c = &d->cabac;
+  if (st == 2) return rd_intra_mb_type(r, 3, 1);
+  if (st == 0) {
+    if (!cabac_bin(c, 14)) {
+      if (!cabac_bin(c, 15)) return 3 * cabac_bin(c, 16);
+      return 2 - cabac_bin(c, 17);
+    }
+    return 5 + rd_intra_mb_type(r, 17, 0);
+  }
+  int inc = 0;
+  if (mb_avail(d, d->mb.mbx - 1, d->mb.mby) && !d->mb_direct[d->mb.addr - 1]) inc++;
+  if (mb_avail(d, d->mb.mbx, d->mb.mby - 1) && !d->mb_direct[d->mb.addr - d->mbw]) inc++;
+  if (!cabac_bin(c, 27 + inc)) return 0;
+  if (!cabac_bin(c, 27 + 3)) return 1 + cabac_bin(c, 27 + 5);
+  int bits = cabac_bin(c, 27 + 4) << 3;
+  bits |= cabac_bin(c, 27 + 5) << 2;
+  bits |= cabac_bin(c, 27 + 5) << 1;
+  bits |= cabac_bin(c, 27 + 5);
+  if (bits < 8) return bits + 3;
+  if (bits == 13) return 23 + rd_intra_mb_type(r, 32, 0);
+  if (bits == 14) return 11;
+  if (bits == 15) return 22;
+  bits = (bits << 1) | cabac_bin(c, 27 + 5);
+  return bits - 4;
+}
+
+static int rd_sub_mb_type(Rd* r) {
+  H264Oracle* d = r->d;
+  if (!r->cabac) return (int)get_ue(r->b);
+  Cabac* c = &d->cabac;
+  if (d->sl.type == 0) {
+    if (cabac_bin(c, 21)) return 0;
+    if (!cabac_bin(c, 22)) return 1;
+    return cabac_bin(c, 23) ? 2 : 3;
+  }
+  if (!cabac_bin(c, 36)) return 0;
+  if (!cabac_bin(c, 37)) return 1 + cabac_bin(c, 39);
+  int t = 3;
+  if (cabac_bin(c, 38)) {
+    if (cabac_bin(c, 39)) return 11 + cabac_bin(c, 39);
+    t += 4;
+  }
+  t += 2 * cabac_bin(c, 39);
+  t += cabac_bin(c, 39);
+  return t;
+}
+
+static int rd_ref_idx(Rd* r, int list, int b8) {
+  H264Oracle* d = r->d;
+  const int n = d->sl.num_ref_idx[list];
+  if (!r->cabac) return n > 1 ? get_te(r->b, n - 1) : 0;
+  if (n <= 1) return 0;
+  /* neighbours A (left) and B (top) of the 8x8 block at 4x4 position */
+  const int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2;
+  int inc = 0;
+  for (int k = 0; k < 2; ++k) {
+    int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
+    int nx = d->mb.mbx + (rx < 0 ? -1 : 0), ny = d->mb.mby + (ry < 0 ? -1 : 0);
+    int inside = rx >= 0 && ry >= 0;
+    if (!inside && !mb_avail(d, nx, ny)) continue;
+    int addr = ny * d->mbw + nx;
+    int q = ((ry & 3) >> 1) * 2 + ((rx & 3) >> 1);
+    if (d->cur->mb_intra[addr]) continue;
+    if (d->sl.type == 1 && d->direct8[addr * 4 + q]) continue;
+    if (d->cur->ref_idx[list][addr * 4 + q] > 0) inc += k == 0 ? 1 : 2;
+  }
+  Cabac* c = &d->cabac;
+  int ref = 0;
+  while (cabac_bin(c, 54 + inc)) {
+    ++ref;
+    inc = (inc >> 2) + 4;
+    if (ref >= 32) return -1;
+  }
+  return ref;
+}
+
+static int rd_mvd(Rd* r, int list, int bx, int by, int comp) {
+  H264Oracle* d = r->d;
+  if (!r->cabac) return get_se(r->b);
+  int sum = 0;
+  for (int k = 0; k < 2; ++k) {
+    int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
+    int nx = d->mb.mbx + (rx < 0 ? -1 : 0), ny = d->mb.mby + (ry < 0 ? -1 : 0);
+    int inside = rx >= 0 && ry >= 0;
+    if (!inside && !mb_avail(d, nx, ny)) continue;
+    sum += d->mvd[ny * d->mbw + nx][list][(ry & 3) * 4 + (rx & 3)][comp];
+  }
+  Cabac* c = &d->cabac;
+  const int base = comp == 0 ? 40 : 47;
+  int inc = sum < 3 ? 0 : (sum > 32 ? 2 : 1);
+  if (!cabac_bin(c, base + inc)) return 0;
+  int v = 1, ctx = base + 3;
+  while (v < 9 && cabac_bin(c, ctx)) {
+    if (v < 4) ++ctx;
+    ++v;
+  }
+  if (v >= 9) {
+    int k = 3;
+    while (cabac_bypass(c)) {
+      v += 1 << k;
+      if (++k > 24) return 0;
+    }
+    while (k--) v += cabac_bypass(c) << k;
+  }
+  return cabac_bypass(c) ? -v : v;
+}
+
+static int rd_cbp(Rd* r, int intra) {
+  H264Oracle* d = r->d;
+  MB* m = &d->mb;
+  if (!r->cabac) {
+    unsigned code = get_ue(r->b);
+    if (code > 47) return -1;
+    return intra ? cbp_intra_from_code[code] : cbp_inter_from_code[code];
+  }
+  Cabac* c = &d->cabac;
+  const int la = mb_avail(d, m->mbx - 1, m->mby), ta = mb_avail(d, m->mbx, m->mby - 1);
+  /* unavailable neighbours behave like "all luma bits set" */
+  const int cbp_a = la ? d->mb_cbp[m->addr - 1] : 0x0f;
+  const int cbp_b = ta ? d->mb_cbp[m->addr - d->mbw] : 0x0f;
+  int cbp = 0;
+  for (int b8 = 0; b8 < 4; ++b8) {
+    int bit_a = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
+    int bit_b = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
+    cbp |= cabac_bin(c, 73 + !bit_a + 2 * !bit_b) << b8;
+  }
+  const int ca = la ? d->mb_cbp[m->addr - 1] >> 4 : 0;
+  const int cb = ta ? d->mb_cbp[m->addr - d->mbw] >> 4 : 0;
+  if (cabac_bin(c, 77 + (ca != 0) + 2 * (cb != 0))) {
+    int v = 1 + cabac_bin(c, 77 + 4 + (ca == 2) + 2 * (cb == 2));
+    cbp |= v << 4;
+  }
+  return cbp;
+}
+
+static int rd_qp_delta(Rd* r) {
+  H264Oracle* d = r->d;
+  if (!r->cabac) return get_se(r->b);
+  Cabac* c = &d->cabac;
+  int ctx = d->last_qp_delta_nonzero ? 1 : 0;
+  int v = 0;
+  while (cabac_bin(c, 60 + ctx)) {
+    ctx = 2 + (ctx >> 1);
+    if (++v > 104) return 1000;
+  }
+  return (v & 1) ? (v + 1) >> 1 : -((v + 1) >> 1);
+}
+
+static int rd_chroma_pred_mode(Rd* r) {
+  H264Oracle* d = r->d;
+  const MB* m = &d->mb;
+  if (!r->cabac) return (int)get_ue(r->b);
+  Cabac* c = &d->cabac;
+  int inc = 0;
+  if (mb_avail(d, m->mbx - 1, m->mby) && d->mb_chroma_mode[m->addr - 1]) inc++;
+  if (mb_avail(d, m->mbx, m->mby - 1) && d->mb_chroma_mode[m->addr - d->mbw]) inc++;
+  if (!cabac_bin(c, 64 + inc)) return 0;
+  if (!cabac_bin(c, 64 + 3)) return 1;
+  return 2 + cabac_bin(c, 64 + 3);
+}
+
+static int rd_t8x8_flag(Rd* r) {
+  H264Oracle* d = r->d;
+  const MB* m = &d->mb;
+  if (!r->cabac) return get_bit(r->b);
+  int inc = 0;
+  if (mb_avail(d, m->mbx - 1, m->mby) && d->mb_t8x8[m->addr - 1]) inc++;
+  if (mb_avail(d, m->mbx, m->mby - 1) && d->mb_t8x8[m->addr - d->mbw]) inc++;
+  return cabac_bin(&d->cabac, 399 + inc);
+}
+
+/* prev_intra4x4_pred_mode_flag / rem_intra4x4_pred_mode; returns -1 for
+ * "use predicted", else rem 0..7 */
+static int rd_intra_pred_mode(Rd* r) {
+  if (!r->cabac) return get_bit(r->b) ? -1 : (int)get_bits(r->b, 3);
+  Cabac* c = &r->d->cabac;
+  if (cabac_bin(c, 68)) return -1;
+  int v = cabac_bin(c, 69);
+  v |= cabac_bin(c, 69) << 1;
+  v |= cabac_bin(c, 69) << 2;
+  return v;
+}
+
+/* predicted Intra4x4/8x8 mode for the block whose top-left 4x4 is (bx,by) */
+static int predicted_intra_mode(const H264Oracle* d, int bx, int by) {
+  const MB* m = &d->mb;
+  int mode[2];
+  for (int k = 0; k < 2; ++k) {
+    int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
+    if (rx >= 0 && ry >= 0) {
+      mode[k] = m->i4_mode[ry * 4 + rx];
+      continue;
+    }
+    int nx = m->mbx + (rx < 0 ? -1 : 0), ny = m->mby + (ry < 0 ? -1 : 0);
+    if (!mb_avail(d, nx, ny)) return 2;
+    int addr = ny * d->mbw + nx;
+    int kind = d->mb_kind[addr];
+    if (kind == MB_INTER && d->apps->constrained_intra_pred) return 2;
+    if (kind != MB_I4x4 && kind != MB_I8x8)
+      mode[k] = 2;
+    else
+      mode[k] = d->i4mode[addr * 16 + (ry & 3) * 4 + (rx & 3)];
+  }
+  return imin(mode[0], mode[1]);
+}
+
+/* ======================================================================== */
+/* residual()                                                               */
+/* ======================================================================== */
+static const uint8_t identity_scan_pos4[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+
+static int parse_residual(Rd* r) {
+  H264Oracle* d = r->d;
+  MB* m = &d->mb;
+  Bits* b = r->b;
+  const int i16 = m->kind == MB_I16x16;
+  (void)identity_scan_pos4;
+
+  if (i16) {
+    /* Intra16x16DCLevel: parsed in zig-zag over the 4x4 matrix of DCs whose
+     * (row, col) is the 4x4 block's (y, x) */
+    int n;
+    if (r->cabac)
+      n = cabac_block(d, 0, cbf_inc(d, 0, 0, 0, 0), 16, zigzag4x4, 0, m->luma_dc);
+    else
+      n = cavlc_block(d, b, cavlc_nc(d, 0, 0, 0), 16, zigzag4x4, 0, m->luma_dc);
+    if (n < 0) return -1;
+    if (n) m->cbf_dc |= 1;
+  }
+  for (int b8 = 0; b8 < 4; ++b8) {
+    if (!((m->cbp >> b8) & 1)) continue;
+    if (m->t8x8 && r->cabac) {
+      int n = cabac_block(d, 5, -1, 64, zigzag8x8, 0, m->luma8[b8]);
+      if (n < 0) return -1;
+      for (int s = 0; s < 4; ++s)
+        m->nnz[((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)] = (uint8_t)n;
+      continue;
+    }
+    for (int s = 0; s < 4; ++s) {
+      const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
+      const int ri = by * 4 + bx;
+      int n;
+      if (m->t8x8) {
+        /* CAVLC 8x8: four interleaved 4x4 passes, coefficient 4k+s */
+        int16_t tmp[16];
+        memset(tmp, 0, sizeof(tmp));
+        n = cavlc_block(d, b, cavlc_nc(d, 0, bx, by), 16, identity_scan_pos4, 0, tmp);
+        if (n < 0) return -1;
+        for (int k = 0; k < 16; ++k)
+          if (tmp[k]) m->luma8[b8][zigzag8x8[4 * k + s]] = tmp[k];
+      } else if (i16) {
+        n = r->cabac ? cabac_block(d, 1, cbf_inc(d, 1, 0, bx, by), 15, zigzag4x4, 1, m->luma[ri])
+                     : cavlc_block(d, b, cavlc_nc(d, 0, bx, by), 15, zigzag4x4, 1, m->luma[ri]);
+      } else {
+        n = r->cabac ? cabac_block(d, 2, cbf_inc(d, 1, 0, bx, by), 16, zigzag4x4, 0, m->luma[ri])
+                     : cavlc_block(d, b, cavlc_nc(d, 0, bx, by), 16, zigzag4x4, 0, m->luma[ri]);
+      }
+      if (n < 0) return -1;
+      m->nnz[ri] = (uint8_t)n;
+    }
+  }
+  const int cc = m->cbp >> 4;
+  if (cc) {
+    static const uint8_t dc_scan[4] = {0, 1, 2, 3};
+    for (int p = 0; p < 2; ++p) {
+      int n = r->cabac ? cabac_block(d, 3, cbf_inc(d, 2, p, 0, 0), 4, dc_scan, 0, m->chroma_dc[p])
+                       : cavlc_block(d, b, -1, 4, dc_scan, 0, m->chroma_dc[p]);
+      if (n < 0) return -1;
+      if (n) m->cbf_dc |= 2 << p;
+    }
+  }
+  if (cc == 2) {
+    for (int p = 0; p < 2; ++p)
+      for (int s = 0; s < 4; ++s) {
+        const int bx = s & 1, by = s >> 1;
+        int n = r->cabac
+                    ? cabac_block(d, 4, cbf_inc(d, 3, p, bx, by), 15, zigzag4x4, 1, m->chroma_ac[p][s])
+                    : cavlc_block(d, b, cavlc_nc(d, 1 + p, bx, by), 15, zigzag4x4, 1, m->chroma_ac[p][s]);
+        if (n < 0) return -1;
+        m->nnz[16 + 4 * p + s] = (uint8_t)n;
+      }
+  }
+  return b->overrun ? h264i_fail(d, "residual ran past the end of the slice") : 0;
+}
+
+/* ======================================================================== */
+/* inter prediction syntax                                                  */
+/* ======================================================================== */
+/* B macroblock partition table: shape 0=16x16 1=16x8 2=8x16; pred per part
+ * 0=L0 1=L1 2=Bi */
+static const uint8_t b_mb_info[23][3] = {
+    {0, 0, 0}, {0, 0, 0}, {0, 1, 1}, {0, 2, 2}, {1, 0, 0}, {2, 0, 0}, {1, 1, 1}, {2, 1, 1},
+    {1, 0, 1}, {2, 0, 1}, {1, 1, 0}, {2, 1, 0}, {1, 0, 2}, {2, 0, 2}, {1, 1, 2}, {2, 1, 2},
+    {1, 2, 0}, {2, 2, 0}, {1, 2, 1}, {2, 2, 1}, {1, 2, 2}, {2, 2, 2}, {3, 0, 0}};
+/* B sub-macroblock: shape 0=8x8 1=8x4 2=4x8 3=4x4; pred 0=L0 1=L1 2=Bi 3=direct */
+static const uint8_t b_sub_info[13][2] = {{0, 3}, {0, 0}, {0, 1}, {0, 2}, {1, 0}, {2, 0}, {1, 1},
+                                          {2, 1}, {1, 2}, {2, 2}, {3, 0}, {3, 1}, {3, 2}};
+
+static inline int uses_list(int pred, int list) { return pred == 2 || pred == list; }
+
+static int parse_inter(Rd* r, int mb_type) {
+  H264Oracle* d = r->d;
+  MB* m = &d->mb;
+  const int is_b = d->sl.type == 1;
+  int shape, pred[4], sub_shape[4] = {0, 0, 0, 0};
+  int nparts;
+
+  if (!is_b) {
+    shape = mb_type == 0 ? 0 : (mb_type == 1 ? 1 : (mb_type == 2 ? 2 : 3));
+    pred[0] = pred[1] = pred[2] = pred[3] = 0;
+  } else {
+    shape = b_mb_info[mb_type][0];
+    pred[0] = b_mb_info[mb_type][1];
+    pred[1] = b_mb_info[mb_type][2];
+  }
+  nparts = shape == 0 ? 1 : (shape == 3 ? 4 : 2);
+
+  if (shape == 3) {
+    for (int i = 0; i < 4; ++i) {
+      int t = rd_sub_mb_type(r);
+      if (t < 0 || t > (is_b ? 12 : 3)) return h264i_fail(d, "bad sub_mb_type");
+      m->sub_type[i] = t;
+      if (is_b) {
+        sub_shape[i] = b_sub_info[t][0];
+        pred[i] = b_sub_info[t][1];
+      } else {
+        sub_shape[i] = t;
+        pred[i] = 0;
+      }
+    }
+    if (is_b) {
+      for (int i = 0; i < 4; ++i)
+        if (pred[i] == 3) {
+          d->direct8[m->addr * 4 + i] = 1;
+          if (pred_direct(d, i) < 0) return -1;
+        }
+    }
+  }
+
+  /* ref_idx_l0 for every partition, then ref_idx_l1 */
+  for (int l = 0; l < (is_b ? 2 : 1); ++l) {
+    for (int i = 0; i < nparts; ++i) {
+      if (pred[i] == 3) continue;
+      int ref = -1;
+      if (uses_list(pred[i], l)) {
+        if (!is_b && mb_type == 4)
+          ref = 0; /* P_8x8ref0 */
+        else {
+          int b8 = shape == 0 ? 0 : (shape == 1 ? i * 2 : (shape == 2 ? i : i));
+          ref = rd_ref_idx(r, l, b8);
+          if (ref < 0 || ref >= d->sl.num_ref_idx[l]) return h264i_fail(d, "ref_idx out of range");
+        }
+      }
+      if (shape == 0) {
+        for (int q = 0; q < 4; ++q) set_ref8(d, l, q, ref);
+      } else if (shape == 1) {
+        set_ref8(d, l, i * 2, ref);
+        set_ref8(d, l, i * 2 + 1, ref);
+      } else if (shape == 2) {
+        set_ref8(d, l, i, ref);
+        set_ref8(d, l, i + 2, ref);
+      } else {
+        set_ref8(d, l, i, ref);
+      }
+    }
+  }
+  /* mvd_l0 for every (sub-)partition, then mvd_l1 */
+  for (int l = 0; l < (is_b ? 2 : 1); ++l) {
+    for (int i = 0; i < nparts; ++i) {
+      if (pred[i] == 3 || !uses_list(pred[i], l)) continue;
+      int px, py, pw, ph;
+      if (shape == 0) { px = 0; py = 0; pw = 4; ph = 4; }
+      else if (shape == 1) { px = 0; py = i * 2; pw = 4; ph = 2; }
+      else if (shape == 2) { px = i * 2; py = 0; pw = 2; ph = 4; }
+      else { px = (i & 1) * 2; py = (i >> 1) * 2; pw = 2; ph = 2; }
+      int ss = shape == 3 ? sub_shape[i] : 0;
+      int sw = (ss == 2 || ss == 3) ? pw / 2 : pw, sh = (ss == 1 || ss == 3) ? ph / 2 : ph;
+      if (shape != 3) { sw = pw; sh = ph; }
+      const int ref = m->ref[l][(py >> 1) * 2 + (px >> 1)];
+      for (int sy = 0; sy < ph; sy += sh)
+        for (int sx = 0; sx < pw; sx += sw) {
+          int bx = px + sx, by = py + sy;
+          int dir = PRED_MEDIAN;
+          if (shape == 1) dir = i == 0 ? PRED_16x8_TOP : PRED_16x8_BOTTOM;
+          if (shape == 2) dir = i == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT;
+          int mvp[2];
+          pred_mv(d, l, bx, by, sw, ref, dir, mvp);
+          int dx = rd_mvd(r, l, bx, by, 0);
+          int dy = rd_mvd(r, l, bx, by, 1);
+          set_mvd_block(d, l, bx, by, sw, sh, dx, dy);
+          set_mv_block(d, l, bx, by, sw, sh, mvp[0] + dx, mvp[1] + dy);
+        }
+    }
+  }
+  return 0;
+}
+
+/* ======================================================================== */
+/* macroblock_layer()                                                       */
+/* ======================================================================== */
+static void begin_mb(H264Oracle* d, int addr) {
+  MB* m = &d->mb;
+  memset(m, 0, sizeof(*m));
+  m->addr = addr;
+  m->mbx = addr % d->mbw;
+  m->mby = addr / d->mbw;
+  memset(m->ref, -1, sizeof(m->ref));
+  memset(m->i4_mode, 2, sizeof(m->i4_mode));
+  Picture* cur = d->cur;
+  for (int l = 0; l < 2; ++l) {
+    memset(cur->mv[l] + addr * 16, 0, 16 * sizeof(int16_t[2]));
+    for (int q = 0; q < 4; ++q) {
+      cur->ref_idx[l][addr * 4 + q] = -1;
+      cur->ref_uid[l][addr * 4 + q] = -1;
+    }
+  }
+  memset(d->mvd[addr], 0, sizeof(d->mvd[addr]));
+  memset(d->direct8 + addr * 4, 0, 4);
+  cur->mb_intra[addr] = 0;
+  d->mb_slice[addr] = (int16_t)d->slice_index;
+  d->mb_kind[addr] = MB_NONE;
+}
+
+static void commit_mb(H264Oracle* d) {
+  MB* m = &d->mb;
+  const int a = m->addr;
+  const PPS* pps = d->apps;
+  m->qpc[0] = chroma_qp_table[iclip(0, 51, m->qp + pps->chroma_qp_offset[0])];
+  m->qpc[1] = chroma_qp_table[iclip(0, 51, m->qp + pps->chroma_qp_offset[1])];
+  d->mb_kind[a] = (uint8_t)m->kind;
+  d->mb_skip[a] = (uint8_t)m->skip;
+  d->mb_direct[a] = (uint8_t)(m->skip || m->direct16) && d->sl.type == 1;
+  d->mb_t8x8[a] = (uint8_t)m->t8x8;
+  d->mb_cbp[a] = (uint8_t)(m->kind == MB_IPCM ? 0x2f : m->cbp);
+  d->mb_cbf_dc[a] = (uint8_t)m->cbf_dc;
+  d->mb_qp[a] = (int8_t)(m->kind == MB_IPCM ? 0 : m->qp);
+  d->mb_qpc[0][a] = (int8_t)(m->kind == MB_IPCM ? chroma_qp_table[iclip(0, 51, pps->chroma_qp_offset[0])] : m->qpc[0]);
+  d->mb_qpc[1][a] = (int8_t)(m->kind == MB_IPCM ? chroma_qp_table[iclip(0, 51, pps->chroma_qp_offset[1])] : m->qpc[1]);
+  d->mb_chroma_mode[a] = (uint8_t)((m->kind != MB_INTER && m->kind != MB_IPCM) ? m->chroma_mode : 0);
+  memcpy(d->i4mode + a * 16, m->i4_mode, 16);
+  memcpy(d->nnz + a * 24, m->nnz, 24);
+  d->mb_deblock[a].disable = (int8_t)d->sl.disable_deblock;
+  d->mb_deblock[a].alpha = (int8_t)d->sl.alpha_offset;
+  d->mb_deblock[a].beta = (int8_t)d->sl.beta_offset;
+  d->cur->mb_intra[a] = m->kind != MB_INTER;
+  d->counters[2]++;
+  if (m->kind != MB_INTER) d->counters[7]++;
+  if (m->skip) d->counters[8]++;
+  if (m->t8x8) d->counters[9]++;
+}
+
+static int decode_skip_mb(H264Oracle* d, int addr) {
+  begin_mb(d, addr);
+  MB* m = &d->mb;
+  m->kind = MB_INTER;
+  m->skip = 1;
+  m->qp = d->qp;
+  d->last_qp_delta_nonzero = 0;
+  if (d->sl.type == 0) {
+    for (int q = 0; q < 4; ++q) set_ref8(d, 0, q, 0);
+    NB A = fetch_nb(d, 0, -1, 0, 0), B = fetch_nb(d, 0, 0, -1, 0);
+    int mv[2] = {0, 0};
+    if (!(A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) ||
+          (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
+      pred_mv(d, 0, 0, 0, 4, 0, PRED_MEDIAN, mv);
+    set_mv_block(d, 0, 0, 0, 4, 4, mv[0], mv[1]);
+  } else {
+    m->direct16 = 1;
+    memset(d->direct8 + addr * 4, 1, 4);
+    if (pred_direct(d, -1) < 0) return -1;
+  }
+  commit_mb(d);
+  h264i_recon_mb(d);
+  return 0;
+}
+
+static int decode_mb(Rd* r, int addr) {
+  H264Oracle* d = r->d;
+  Bits* b = r->b;
+  const PPS* pps = d->apps;
+  begin_mb(d, addr);
+  MB* m = &d->mb;
+  const int st = d->sl.type;
+  int t = rd_mb_type(r);
+  int intra_t = -1;
+  if (st == 2) {
+    intra_t = t;
+  } else if (st == 0) {
+    if (t > 30 || t < 0) return h264i_fail(d, "bad mb_type (P)");
+    if (t >= 5) intra_t = t - 5;
+  } else {
+    if (t > 48 || t < 0) return h264i_fail(d, "bad mb_type (B)");
+    if (t >= 23) intra_t = t - 23;
+  }
+  if (intra_t > 25) return h264i_fail(d, "bad mb_type (I)");
+  m->mb_type_raw = t;
+  m->qp = d->qp;
+
+  if (intra_t == 25) { /* I_PCM */
+    m->kind = MB_IPCM;
+    /* CABAC: the terminating bin consumed the encoder's flush including its
+     * final '1'; what follows are the pcm_alignment_zero_bits */
+    while (b->pos & 7) get_bit(b);
+    for (int i = 0; i < 384; ++i) m->pcm[i] = (uint8_t)get_bits(b, 8);
+    if (b->overrun) return h264i_fail(d, "truncated I_PCM");
+    if (r->cabac) cabac_start(&d->cabac, b);
+    memset(m->nnz, 16, sizeof(m->nnz));
+    m->cbf_dc = 7;
+    d->last_qp_delta_nonzero = 0;
+    commit_mb(d);
+    h264i_recon_mb(d);
+    return 0;
+  }
+
+  if (intra_t >= 0) {
+    if (intra_t == 0) {
+      m->kind = MB_I4x4;
+      if (pps->transform_8x8_mode && rd_t8x8_flag(r)) {
+        m->kind = MB_I8x8;
+        m->t8x8 = 1;
+      }
+      if (m->kind == MB_I4x4) {
+        for (int k = 0; k < 16; ++k) {
+          const int bx = blk4_x[k], by = blk4_y[k];
+          int pm = predicted_intra_mode(d, bx, by);
+          int rem = rd_intra_pred_mode(r);
+          m->i4_mode[by * 4 + bx] = (int8_t)(rem < 0 ? pm : (rem < pm ? rem : rem + 1));
+        }
+      } else {
+        for (int k = 0; k < 4; ++k) {
+          const int bx = (k & 1) * 2, by = (k >> 1) * 2;
+          int pm = predicted_intra_mode(d, bx, by);
+          int rem = rd_intra_pred_mode(r);
+          int mode = rem < 0 ? pm : (rem < pm ? rem : rem + 1);
+          for (int s = 0; s < 4; ++s) m->i4_mode[(by + (s >> 1)) * 4 + bx + (s & 1)] = (int8_t)mode;
+        }
+      }
+    } else {
+      m->kind = MB_I16x16;
+      m->i16_mode = (intra_t - 1) & 3;
+      m->cbp = (((intra_t - 1) >> 2) % 3) << 4 | ((intra_t - 1) >= 12 ? 15 : 0);
+    }
+    m->chroma_mode = rd_chroma_pred_mode(r);
+    if (m->chroma_mode > 3 || m->chroma_mode < 0) return h264i_fail(d, "bad intra_chroma_pred_mode");
+    d->cur->mb_intra[addr] = 1;
+  } else {
+    m->kind = MB_INTER;
+    if (st == 1 && t == 0) {
+      m->direct16 = 1;
+      memset(d->direct8 + addr * 4, 1, 4);
+      if (pred_direct(d, -1) < 0) return -1;
+    } else {
+      if (parse_inter(r, t) < 0) return -1;
+    }
+  }
+
+  if (m->kind != MB_I16x16) {
+    int cbp = rd_cbp(r, m->kind != MB_INTER);
+    if (cbp < 0) return h264i_fail(d, "bad coded_block_pattern");
+    m->cbp = cbp;
+    if ((cbp & 15) && pps->transform_8x8_mode && m->kind == MB_INTER) {
+      int ok = 1;
+      if (st == 1 && t == 0) ok = d->asps->direct_8x8_inference;
+      if ((st == 0 && (t == 3 || t == 4)) || (st == 1 && t == 22)) {
+        for (int i = 0; i < 4; ++i) {
+          if (st == 1 && m->sub_type[i] == 0) {
+            if (!d->asps->direct_8x8_inference) ok = 0;
+          } else if (st == 1 ? b_sub_info[m->sub_type[i]][0] != 0 : m->sub_type[i] != 0) {
+            ok = 0;
+          }
+        }
+      }
+      if (ok) m->t8x8 = rd_t8x8_flag(r);
+    }
+  }
+  if (m->cbp || m->kind == MB_I16x16) {
+    int dq = rd_qp_delta(r);
+    if (dq < -26 || dq > 25) return h264i_fail(d, "mb_qp_delta out of range");
+    d->last_qp_delta_nonzero = dq != 0;
+    d->qp = (d->qp + dq + 52) % 52;
+    m->qp = d->qp;
+    if (parse_residual(r) < 0) return -1;
+  } else {
+    d->last_qp_delta_nonzero = 0;
+  }
+  commit_mb(d);
+  h264i_recon_mb(d);
+  return 0;
+}
+
+/* ======================================================================== */
+/* slice_data()                                                             */
+/* ======================================================================== */
+int h264i_decode_slice_data(H264Oracle* d, Bits* b) {
+  Slice* sl = &d->sl;
+  const PPS* pps = d->apps;
+  const int nmb = d->mbw * d->mbh;
+  Rd r = {d, b, pps->cabac};
+  int addr = sl->first_mb;
+  if (addr >= nmb) return h264i_fail(d, "first_mb_in_slice out of range");
+  d->qp = sl->qp;
+  d->last_qp_delta_nonzero = 0;
+  d->counters[0]++;
+
+  if (pps->cabac) {
+    while (b->pos & 7) {
+      if (!get_bit(b)) return h264i_fail(d, "cabac_alignment_one_bit is zero");
+    }
+    cabac_init_contexts(&d->cabac, sl->type, sl->cabac_init_idc, sl->qp);
+    cabac_start(&d->cabac, b);
+    for (;;) {
+      if (addr >= nmb) return h264i_fail(d, "slice runs past the end of the picture");
+      int skipped = 0;
+      if (sl->type != 2) {
+        d->mb.addr = addr;
+        d->mb.mbx = addr % d->mbw;
+        d->mb.mby = addr / d->mbw;
+        int inc = 0;
+        if (mb_avail(d, d->mb.mbx - 1, d->mb.mby) && !d->mb_skip[addr - 1]) inc++;
+        if (mb_avail(d, d->mb.mbx, d->mb.mby - 1) && !d->mb_skip[addr - d->mbw]) inc++;
+        skipped = cabac_bin(&d->cabac, (sl->type == 0 ? 11 : 24) + inc);
+      }
+      if (skipped) {
+        if (decode_skip_mb(d, addr) < 0) return -1;
+      } else {
+        if (decode_mb(&r, addr) < 0) return -1;
+      }
+      if (b->overrun) return h264i_fail(d, "slice data ran past the end of the NAL unit");
+      ++addr;
+      if (cabac_terminate(&d->cabac)) break;
+    }
+    /* desync check.  The arithmetic decoder runs 9 bits ahead of the
+     * encoder's committed output and the encoder never writes its first
+     * (dummy) bit, so after the terminating bin the LAST bit consumed is the
+     * rbsp_stop_one_bit the encoder's flush ends with; only alignment zeros
+     * (and cabac_zero_words) may follow. */
+    {
+      Bits t = *b;
+      int ok = t.pos > 0 && ((t.buf[(t.pos - 1) >> 3] >> (7 - ((t.pos - 1) & 7))) & 1);
+      while (ok && t.pos < t.size_bits)
+        if (get_bit(&t)) ok = 0;
+      if (ok && !b->overrun) d->counters[1]++;
+    }
+    return 0;
+  }
+
+  /* CAVLC */
+  for (;;) {
+    if (sl->type != 2) {
+      unsigned run = get_ue(b);
+      if (run > (unsigned)(nmb - addr)) return h264i_fail(d, "mb_skip_run out of range");
+      while (run--) {
+        if (decode_skip_mb(d, addr) < 0) return -1;
+        ++addr;
+      }
+      if (!h264i_more_rbsp_data(b)) break;
+    }
+    if (addr >= nmb) return h264i_fail(d, "slice runs past the end of the picture");
+    if (decode_mb(&r, addr) < 0) return -1;
+    if (b->overrun) return h264i_fail(d, "slice data ran past the end of the NAL unit");
+    ++addr;
+    if (!h264i_more_rbsp_data(b)) break;
+  }
+  {
+    Bits t = *b;
+    int ok = get_bit(&t) == 1;
+    while (ok && t.pos < t.size_bits)
+      if (get_bit(&t)) ok = 0;
+    if (ok && !t.overrun) d->counters[1]++;
+  }
+  return 0;
+}
