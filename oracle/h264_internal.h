@@ -178,6 +178,19 @@ typedef struct {
   uint8_t state[CABAC_CTX_COUNT]; /* (pStateIdx << 1) | valMPS */
 } Cabac;
 
+/* ---- bit writer + CABAC encoder (corpus generator only) ---------------------- */
+typedef struct {
+  uint8_t* buf;
+  size_t cap;
+  size_t pos; /* bits */
+} BitWriter;
+
+typedef struct {
+  BitWriter* w;
+  unsigned low, range;
+  int outstanding, first;
+} CabacEnc;
+
 /* ---- current macroblock ------------------------------------------------------ */
 enum { MB_NONE = 0, MB_I4x4, MB_I8x8, MB_I16x16, MB_IPCM, MB_INTER };
 
@@ -258,6 +271,7 @@ struct H264Oracle {
   /* per-MB reference picture identity for deblocking is in cur->ref_uid */
 
   Cabac cabac;
+  CabacEnc cenc;
   int last_qp_delta_nonzero;
   int qp; /* running QP_Y */
   MB mb;
@@ -277,9 +291,42 @@ void h264i_output_all(H264Oracle* d);
 
 /* h264_slice.c */
 int h264i_decode_slice_data(H264Oracle* d, Bits* b);
+/* encoder side of the same syntax engine (used by corpus/h264_encoder.c) */
+void bw_put(BitWriter* w, unsigned v, int n);
+void bw_ue(BitWriter* w, unsigned v);
+void bw_se(BitWriter* w, int v);
+typedef struct {
+  int is_skip; /* P_Skip / B_Skip */
+  MB mb;       /* target values: kind, mb_type_raw, modes, sub types, refs, mvs, cbp, t8x8, qp, levels */
+} MbPlan;
+void h264i_enc_begin_slice(H264Oracle* d, BitWriter* w);
+/* Codes macroblock `addr` as `plan` says, reconstructs it and updates all
+ * neighbour state exactly as the decoder would.  Returns 0 / -1. */
+int h264i_enc_mb(H264Oracle* d, BitWriter* w, int addr, const MbPlan* plan, int last_in_slice);
+void h264i_enc_end_slice(H264Oracle* d, BitWriter* w);
+/* Neighbour-state queries the mode decision needs (valid after
+ * h264i_begin_mb). */
+void h264i_begin_mb(H264Oracle* d, int addr);
+void h264i_pskip_mv(H264Oracle* d, int mv[2]);
+void h264i_pred_mv16(H264Oracle* d, int list, int ref, int mv[2]);
+int h264i_pred_direct_mb(H264Oracle* d);
 
 /* h264_recon.c */
 void h264i_recon_mb(H264Oracle* d);
+void h264i_inter_pred_mb(H264Oracle* d);
 void h264i_deblock_picture(H264Oracle* d);
+/* prediction primitives, also used by the corpus encoder's mode decision */
+void h264i_pred4x4(uint8_t* dst, int stride, int mode, int has_left, int has_top, int has_tl, int has_tr);
+void h264i_pred8x8l(uint8_t* dst, int stride, int mode, int has_left, int has_top, int has_tl, int has_tr);
+void h264i_pred16x16(uint8_t* dst, int stride, int mode, int has_left, int has_top);
+void h264i_pred_chroma8x8(uint8_t* dst, int stride, int mode, int has_left, int has_top);
+int h264i_intra_mb_ok(const H264Oracle* d, int mbx, int mby);
+int h264i_intra_blk_ok(const H264Oracle* d, int rx, int ry, int cur_zz);
+/* w x h block of plane `plane` predicted from `ref` at integer position
+ * (x, y) + motion vector (quarter-sample luma / eighth-sample chroma units) */
+void h264i_mc_block(const Picture* ref, int plane, int pic_w, int pic_h, int x, int y, int mvx,
+                    int mvy, int w, int h, uint8_t* dst, int dst_stride);
+int h264i_level_scale4(const uint8_t* weight, int qp, int pos);
+int h264i_level_scale8(const uint8_t* weight, int qp, int pos);
 
 #endif

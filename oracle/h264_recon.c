@@ -62,13 +62,13 @@ static void idct8x8(const int* in, int* out) {
   for (int k = 0; k < 64; ++k) out[k] = (out[k] + 32) >> 6;
 }
 
-static inline int level_scale4(const uint8_t* weight, int qp, int pos) {
+int h264i_level_scale4(const uint8_t* weight, int qp, int pos) {
   const int i = pos >> 2, j = pos & 3;
   const int cls = ((i & 1) == 0 && (j & 1) == 0) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2);
   return weight[pos] * norm_adjust4x4[qp % 6][cls];
 }
 
-static inline int level_scale8(const uint8_t* weight, int qp, int pos) {
+int h264i_level_scale8(const uint8_t* weight, int qp, int pos) {
   const int i = pos >> 3, j = pos & 7;
   int cls;
   if ((i & 3) == 0 && (j & 3) == 0) cls = 0;
@@ -87,7 +87,7 @@ static void scale4x4(const int16_t* lv, const uint8_t* weight, int qp, int dc_gi
       out[0] = dc;
       continue;
     }
-    int v = lv[k] * level_scale4(weight, qp, k);
+    int v = lv[k] * h264i_level_scale4(weight, qp, k);
     out[k] = qp >= 24 ? v << (qp / 6 - 4) : (v + (1 << (3 - qp / 6))) >> (4 - qp / 6);
   }
 }
@@ -101,7 +101,7 @@ static void add_residual(uint8_t* dst, int stride, const int* res, int n) {
 /* intra prediction                                                         */
 /* ======================================================================== */
 /* availability of the neighbouring macroblock for INTRA prediction */
-static int intra_mb_ok(const H264Oracle* d, int mbx, int mby) {
+int h264i_intra_mb_ok(const H264Oracle* d, int mbx, int mby) {
   if (mbx < 0 || mby < 0 || mbx >= d->mbw || mby >= d->mbh) return 0;
   const int a = mby * d->mbw + mbx;
   if (d->mb_slice[a] != d->slice_index) return 0;
@@ -111,14 +111,14 @@ static int intra_mb_ok(const H264Oracle* d, int mbx, int mby) {
 
 /* Is the 4x4 luma block at MB-relative (rx, ry) (may be -1 / 4) usable as an
  * intra neighbour of the block whose decode index is cur_zz? */
-static int intra_blk_ok(const H264Oracle* d, int rx, int ry, int cur_zz) {
+int h264i_intra_blk_ok(const H264Oracle* d, int rx, int ry, int cur_zz) {
   const MB* m = &d->mb;
   if (rx > 3 && ry >= 0) return 0;
   if (rx >= 0 && rx <= 3 && ry >= 0) return raster_to_blk4[ry * 4 + rx] < cur_zz;
-  return intra_mb_ok(d, m->mbx + (rx < 0 ? -1 : (rx > 3 ? 1 : 0)), m->mby + (ry < 0 ? -1 : 0));
+  return h264i_intra_mb_ok(d, m->mbx + (rx < 0 ? -1 : (rx > 3 ? 1 : 0)), m->mby + (ry < 0 ? -1 : 0));
 }
 
-static void pred4x4(uint8_t* dst, int stride, int mode, int has_left, int has_top, int has_tl, int has_tr) {
+void h264i_pred4x4(uint8_t* dst, int stride, int mode, int has_left, int has_top, int has_tl, int has_tr) {
   int t[8], l[4], tl = 128;
   for (int i = 0; i < 4; ++i) {
     l[i] = has_left ? dst[i * stride - 1] : 128;
@@ -186,7 +186,7 @@ static void pred4x4(uint8_t* dst, int stride, int mode, int has_left, int has_to
 #undef L
 }
 
-static void pred8x8l(uint8_t* dst, int stride, int mode, int has_left, int has_top, int has_tl, int has_tr) {
+void h264i_pred8x8l(uint8_t* dst, int stride, int mode, int has_left, int has_top, int has_tl, int has_tr) {
   int rt[16], rl[8], rtl = 128; /* raw */
   int t[16], l[8], tl = 128;    /* filtered */
   for (int i = 0; i < 8; ++i) {
@@ -280,7 +280,7 @@ static void pred8x8l(uint8_t* dst, int stride, int mode, int has_left, int has_t
   for (int y = 0; y < 8; ++y) memcpy(dst + y * stride, out + y * 8, 8);
 }
 
-static void pred16x16(uint8_t* dst, int stride, int mode, int has_left, int has_top) {
+void h264i_pred16x16(uint8_t* dst, int stride, int mode, int has_left, int has_top) {
   int t[16], l[16], tl = has_left && has_top ? dst[-stride - 1] : 128;
   for (int i = 0; i < 16; ++i) {
     t[i] = has_top ? dst[-stride + i] : 128;
@@ -313,7 +313,7 @@ static void pred16x16(uint8_t* dst, int stride, int mode, int has_left, int has_
     }
 }
 
-static void pred_chroma8x8(uint8_t* dst, int stride, int mode, int has_left, int has_top) {
+void h264i_pred_chroma8x8(uint8_t* dst, int stride, int mode, int has_left, int has_top) {
   int t[8], l[8], tl = has_left && has_top ? dst[-stride - 1] : 128;
   for (int i = 0; i < 8; ++i) {
     t[i] = has_top ? dst[-stride + i] : 128;
@@ -414,64 +414,159 @@ static int chroma_sample(const Picture* p, int plane, int w, int h, int x, int y
   return ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
 }
 
-static void inter_pred_mb(H264Oracle* d) {
+/* Block form of the two sample functions above: identical arithmetic,
+ * evaluated separably over a (w+5) x (h+5) window. */
+void h264i_mc_block(const Picture* ref, int plane, int pw, int ph, int x, int y, int mvx, int mvy,
+                    int w, int h, uint8_t* dst, int ds) {
+  if (plane != 0) {
+    const int fx = mvx & 7, fy = mvy & 7, ix = x + (mvx >> 3), iy = y + (mvy >> 3);
+    for (int j = 0; j < h; ++j)
+      for (int i = 0; i < w; ++i) dst[j * ds + i] = (uint8_t)chroma_sample(ref, plane, pw, ph, ix + i, iy + j, fx, fy);
+    return;
+  }
+  const int fx = mvx & 3, fy = mvy & 3, ix = x + (mvx >> 2), iy = y + (mvy >> 2);
+  int src[21][22]; /* rows -2..h+2, cols -2..w+3 */
+  for (int j = 0; j < h + 5; ++j) {
+    const int yy = iclip(0, ph - 1, iy - 2 + j);
+    const uint8_t* row = ref->plane[0] + yy * ref->stride[0];
+    for (int i = 0; i < w + 6; ++i) src[j][i] = row[iclip(0, pw - 1, ix - 2 + i)];
+  }
+#define G(i, j) src[(j) + 2][(i) + 2]
+  if (fx == 0 && fy == 0) {
+    for (int j = 0; j < h; ++j)
+      for (int i = 0; i < w; ++i) dst[j * ds + i] = (uint8_t)G(i, j);
+    return;
+  }
+  int B1[21][17]; /* horizontal 6-tap, rows -2..h+2, cols 0..w */
+  int H1[16][17]; /* vertical 6-tap, rows 0..h-1, cols 0..w */
+  const int need_b = fy == 0 || fx == 2 || (fx & 1 && fy & 1) || fy == 2;
+  const int need_h = fx == 0 || fy == 2 || (fx & 1 && fy & 1) || fx == 2;
+  if (need_b || fx == 2 || fy == 2)
+    for (int j = 0; j < h + 5; ++j)
+      for (int i = 0; i <= w; ++i)
+        B1[j][i] = tap6(src[j][i], src[j][i + 1], src[j][i + 2], src[j][i + 3], src[j][i + 4], src[j][i + 5]);
+  if (need_h)
+    for (int j = 0; j < h; ++j)
+      for (int i = 0; i <= w; ++i)
+        H1[j][i] = tap6(src[j][i + 2], src[j + 1][i + 2], src[j + 2][i + 2], src[j + 3][i + 2], src[j + 4][i + 2],
+                        src[j + 5][i + 2]);
+#define HB(i, j) clip8((B1[(j) + 2][i] + 16) >> 5)
+#define HH(i, j) clip8((H1[j][i] + 16) >> 5)
+#define JJ(i, j) \
+  clip8((tap6(B1[j][i], B1[(j) + 1][i], B1[(j) + 2][i], B1[(j) + 3][i], B1[(j) + 4][i], B1[(j) + 5][i]) + 512) >> 10)
+  for (int j = 0; j < h; ++j)
+    for (int i = 0; i < w; ++i) {
+      int v;
+      if (fy == 0) {
+        int b = HB(i, j);
+        v = fx == 2 ? b : (fx == 1 ? (G(i, j) + b + 1) >> 1 : (G(i + 1, j) + b + 1) >> 1);
+      } else if (fx == 0) {
+        int hh = HH(i, j);
+        v = fy == 2 ? hh : (fy == 1 ? (G(i, j) + hh + 1) >> 1 : (G(i, j + 1) + hh + 1) >> 1);
+      } else if (fx == 2 || fy == 2) {
+        int jj = JJ(i, j);
+        if (fx == 2 && fy == 2) v = jj;
+        else if (fx == 2) v = fy == 1 ? (HB(i, j) + jj + 1) >> 1 : (HB(i, j + 1) + jj + 1) >> 1;
+        else v = fx == 1 ? (HH(i, j) + jj + 1) >> 1 : (HH(i + 1, j) + jj + 1) >> 1;
+      } else {
+        int b = fy == 1 ? HB(i, j) : HB(i, j + 1);
+        int hh = fx == 1 ? HH(i, j) : HH(i + 1, j);
+        v = (b + hh + 1) >> 1;
+      }
+      dst[j * ds + i] = (uint8_t)v;
+    }
+#undef G
+#undef HB
+#undef HH
+#undef JJ
+}
+
+/* Inter prediction of the current macroblock from d->mb.{ref,mv} into the
+ * current picture.  Prediction is defined per sample, so blocks that share
+ * motion are predicted in one piece (16x16 / 8x8 / 4x4) purely for speed. */
+static void inter_pred_region(H264Oracle* d, int bx, int by, int n4) {
   const MB* m = &d->mb;
   const Slice* sl = &d->sl;
   Picture* cur = d->cur;
   const int W = d->mbw * 16, H = d->mbh * 16;
-  for (int blk = 0; blk < 16; ++blk) {
-    const int bx = blk & 3, by = blk >> 2, b8 = (by >> 1) * 2 + (bx >> 1);
-    const int r0 = m->ref[0][b8], r1 = m->ref[1][b8];
-    const Picture* p0 = r0 >= 0 ? sl->ref_list[0][r0] : NULL;
-    const Picture* p1 = r1 >= 0 ? sl->ref_list[1][r1] : NULL;
-    for (int plane = 0; plane < 3; ++plane) {
-      const int n = plane ? 2 : 4;
-      const int pw = plane ? W / 2 : W, ph = plane ? H / 2 : H;
-      const int x0 = (m->mbx * 16 + bx * 4) >> (plane ? 1 : 0), y0 = (m->mby * 16 + by * 4) >> (plane ? 1 : 0);
-      uint8_t* dst = cur->plane[plane] + y0 * cur->stride[plane] + x0;
-      for (int y = 0; y < n; ++y)
-        for (int x = 0; x < n; ++x) {
-          int s[2] = {0, 0};
-          for (int l = 0; l < 2; ++l) {
-            const Picture* p = l ? p1 : p0;
-            if (!p) continue;
-            const int mvx = m->mv[l][blk][0], mvy = m->mv[l][blk][1];
-            if (plane == 0)
-              s[l] = luma_sample(p, pw, ph, x0 + x + (mvx >> 2), y0 + y + (mvy >> 2), mvx & 3, mvy & 3);
-            else
-              s[l] = chroma_sample(p, plane, pw, ph, x0 + x + (mvx >> 3), y0 + y + (mvy >> 3), mvx & 7, mvy & 7);
+  const int blk = by * 4 + bx, b8 = (by >> 1) * 2 + (bx >> 1);
+  const int r0 = m->ref[0][b8], r1 = m->ref[1][b8];
+  const Picture* p0 = r0 >= 0 ? sl->ref_list[0][r0] : NULL;
+  const Picture* p1 = r1 >= 0 ? sl->ref_list[1][r1] : NULL;
+  for (int plane = 0; plane < 3; ++plane) {
+    const int n = plane ? n4 * 2 : n4 * 4;
+    const int pw = plane ? W / 2 : W, ph = plane ? H / 2 : H;
+    const int x0 = (m->mbx * 16 + bx * 4) >> (plane ? 1 : 0), y0 = (m->mby * 16 + by * 4) >> (plane ? 1 : 0);
+    uint8_t* dst = cur->plane[plane] + y0 * cur->stride[plane] + x0;
+    uint8_t pb[2][256];
+    for (int l = 0; l < 2; ++l) {
+      const Picture* p = l ? p1 : p0;
+      if (!p) continue;
+      h264i_mc_block(p, plane, pw, ph, x0, y0, m->mv[l][blk][0], m->mv[l][blk][1], n, n, pb[l], 16);
+    }
+    for (int y = 0; y < n; ++y)
+      for (int x = 0; x < n; ++x) {
+        int s[2] = {p0 ? pb[0][y * 16 + x] : 0, p1 ? pb[1][y * 16 + x] : 0};
+        int v;
+        if (sl->use_weight == 1) {
+          const int ld = plane ? sl->chroma_log2_denom : sl->luma_log2_denom;
+          int w0 = 0, w1 = 0, o0 = 0, o1 = 0;
+          if (p0) {
+            w0 = plane ? sl->chroma_weight[0][r0][plane - 1] : sl->luma_weight[0][r0];
+            o0 = plane ? sl->chroma_offset[0][r0][plane - 1] : sl->luma_offset[0][r0];
           }
-          int v;
-          if (sl->use_weight == 1) {
-            const int ld = plane ? sl->chroma_log2_denom : sl->luma_log2_denom;
-            int w0 = 0, w1 = 0, o0 = 0, o1 = 0;
-            if (p0) {
-              w0 = plane ? sl->chroma_weight[0][r0][plane - 1] : sl->luma_weight[0][r0];
-              o0 = plane ? sl->chroma_offset[0][r0][plane - 1] : sl->luma_offset[0][r0];
-            }
-            if (p1) {
-              w1 = plane ? sl->chroma_weight[1][r1][plane - 1] : sl->luma_weight[1][r1];
-              o1 = plane ? sl->chroma_offset[1][r1][plane - 1] : sl->luma_offset[1][r1];
-            }
-            if (p0 && p1)
-              v = ((s[0] * w0 + s[1] * w1 + (1 << ld)) >> (ld + 1)) + ((o0 + o1 + 1) >> 1);
-            else {
-              int sv = p0 ? s[0] : s[1], w = p0 ? w0 : w1, o = p0 ? o0 : o1;
-              v = ld >= 1 ? ((sv * w + (1 << (ld - 1))) >> ld) + o : sv * w + o;
-            }
-            v = clip8(v);
-          } else if (p0 && p1) {
-            if (sl->use_weight == 2) {
-              int w1 = sl->implicit_weight[r0][r1], w0 = 64 - w1;
-              v = clip8((s[0] * w0 + s[1] * w1 + 32) >> 6);
-            } else {
-              v = (s[0] + s[1] + 1) >> 1;
-            }
+          if (p1) {
+            w1 = plane ? sl->chroma_weight[1][r1][plane - 1] : sl->luma_weight[1][r1];
+            o1 = plane ? sl->chroma_offset[1][r1][plane - 1] : sl->luma_offset[1][r1];
+          }
+          if (p0 && p1)
+            v = ((s[0] * w0 + s[1] * w1 + (1 << ld)) >> (ld + 1)) + ((o0 + o1 + 1) >> 1);
+          else {
+            int sv = p0 ? s[0] : s[1], w = p0 ? w0 : w1, o = p0 ? o0 : o1;
+            v = ld >= 1 ? ((sv * w + (1 << (ld - 1))) >> ld) + o : sv * w + o;
+          }
+          v = clip8(v);
+        } else if (p0 && p1) {
+          if (sl->use_weight == 2) {
+            int w1 = sl->implicit_weight[r0][r1], w0 = 64 - w1;
+            v = clip8((s[0] * w0 + s[1] * w1 + 32) >> 6);
           } else {
-            v = p0 ? s[0] : s[1];
+            v = (s[0] + s[1] + 1) >> 1;
           }
-          dst[y * cur->stride[plane] + x] = (uint8_t)v;
+        } else {
+          v = p0 ? s[0] : s[1];
         }
+        dst[y * cur->stride[plane] + x] = (uint8_t)v;
+      }
+  }
+}
+
+static int same_motion(const MB* m, int a, int b) {
+  const int a8 = (a >> 3) * 2 + ((a & 3) >> 1), b8 = (b >> 3) * 2 + ((b & 3) >> 1);
+  for (int l = 0; l < 2; ++l) {
+    if (m->ref[l][a8] != m->ref[l][b8]) return 0;
+    if (m->ref[l][a8] >= 0 && (m->mv[l][a][0] != m->mv[l][b][0] || m->mv[l][a][1] != m->mv[l][b][1])) return 0;
+  }
+  return 1;
+}
+
+void h264i_inter_pred_mb(H264Oracle* d) {
+  const MB* m = &d->mb;
+  int uniform = 1;
+  for (int k = 1; k < 16 && uniform; ++k) uniform = same_motion(m, 0, k);
+  if (uniform) {
+    inter_pred_region(d, 0, 0, 4);
+    return;
+  }
+  for (int q = 0; q < 4; ++q) {
+    const int bx = (q & 1) * 2, by = (q >> 1) * 2, b = by * 4 + bx;
+    if (same_motion(m, b, b + 1) && same_motion(m, b, b + 4) && same_motion(m, b, b + 5)) {
+      inter_pred_region(d, bx, by, 2);
+    } else {
+      inter_pred_region(d, bx, by, 1);
+      inter_pred_region(d, bx + 1, by, 1);
+      inter_pred_region(d, bx, by + 1, 1);
+      inter_pred_region(d, bx + 1, by + 1, 1);
     }
   }
 }
@@ -503,7 +598,7 @@ static void recon_luma_residual_8x8(H264Oracle* d, int b8, const uint8_t* weight
   int sc[64], res[64];
   const int qp = m->qp;
   for (int k = 0; k < 64; ++k) {
-    int v = m->luma8[b8][k] * level_scale8(weight, qp, k);
+    int v = m->luma8[b8][k] * h264i_level_scale8(weight, qp, k);
     sc[k] = qp >= 36 ? v << (qp / 6 - 6) : (v + (1 << (5 - qp / 6))) >> (6 - qp / 6);
   }
   idct8x8(sc, res);
@@ -521,7 +616,7 @@ static void recon_chroma_residual(H264Oracle* d) {
     const int16_t* c = m->chroma_dc[p];
     int f[4] = {c[0] + c[1] + c[2] + c[3], c[0] - c[1] + c[2] - c[3], c[0] + c[1] - c[2] - c[3],
                 c[0] - c[1] - c[2] + c[3]};
-    const int ls = level_scale4(weight, qp, 0);
+    const int ls = h264i_level_scale4(weight, qp, 0);
     for (int s = 0; s < 4; ++s) {
       int dc = ((f[s] * ls) << (qp / 6)) >> 5;
       int sc[16], res[16];
@@ -552,7 +647,7 @@ void h264i_recon_mb(H264Oracle* d) {
   }
 
   if (m->kind == MB_INTER) {
-    inter_pred_mb(d);
+    h264i_inter_pred_mb(d);
     const uint8_t* w4 = pps->scaling4[3];
     if (m->t8x8) {
       for (int b8 = 0; b8 < 4; ++b8) recon_luma_residual_8x8(d, b8, pps->scaling8[1]);
@@ -563,9 +658,9 @@ void h264i_recon_mb(H264Oracle* d) {
     return;
   }
 
-  const int left_ok = intra_mb_ok(d, m->mbx - 1, m->mby), top_ok = intra_mb_ok(d, m->mbx, m->mby - 1);
+  const int left_ok = h264i_intra_mb_ok(d, m->mbx - 1, m->mby), top_ok = h264i_intra_mb_ok(d, m->mbx, m->mby - 1);
   if (m->kind == MB_I16x16) {
-    pred16x16(y0, sy, m->i16_mode, left_ok, top_ok);
+    h264i_pred16x16(y0, sy, m->i16_mode, left_ok, top_ok);
     /* DC: inverse 4x4 Hadamard, then scaling (8.5.10) */
     const uint8_t* w4 = pps->scaling4[0];
     int c[16], f[16], t[16];
@@ -584,7 +679,7 @@ void h264i_recon_mb(H264Oracle* d) {
       f[8 + j] = a - b - cc + dd;
       f[12 + j] = a - b + cc - dd;
     }
-    const int qp = m->qp, ls = level_scale4(w4, qp, 0);
+    const int qp = m->qp, ls = h264i_level_scale4(w4, qp, 0);
     for (int k = 0; k < 16; ++k) {
       int dc = qp >= 36 ? (f[k] * ls) << (qp / 6 - 6) : (f[k] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
       recon_luma_residual_4x4(d, k, 1, dc, w4); /* f is indexed [row=by][col=bx] = raster block */
@@ -594,9 +689,9 @@ void h264i_recon_mb(H264Oracle* d) {
     for (int k = 0; k < 16; ++k) {
       const int bx = blk4_x[k], by = blk4_y[k];
       uint8_t* dst = y0 + by * 4 * sy + bx * 4;
-      int hl = intra_blk_ok(d, bx - 1, by, k), ht = intra_blk_ok(d, bx, by - 1, k);
-      int htl = intra_blk_ok(d, bx - 1, by - 1, k), htr = intra_blk_ok(d, bx + 1, by - 1, k);
-      pred4x4(dst, sy, m->i4_mode[by * 4 + bx], hl, ht, htl, htr);
+      int hl = h264i_intra_blk_ok(d, bx - 1, by, k), ht = h264i_intra_blk_ok(d, bx, by - 1, k);
+      int htl = h264i_intra_blk_ok(d, bx - 1, by - 1, k), htr = h264i_intra_blk_ok(d, bx + 1, by - 1, k);
+      h264i_pred4x4(dst, sy, m->i4_mode[by * 4 + bx], hl, ht, htl, htr);
       recon_luma_residual_4x4(d, by * 4 + bx, 0, 0, w4);
     }
   } else { /* MB_I8x8 */
@@ -604,15 +699,15 @@ void h264i_recon_mb(H264Oracle* d) {
       const int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2;
       uint8_t* dst = y0 + by * 4 * sy + bx * 4;
       const int zz = b8 * 4;
-      int hl = intra_blk_ok(d, bx - 1, by, zz), ht = intra_blk_ok(d, bx, by - 1, zz);
-      int htl = intra_blk_ok(d, bx - 1, by - 1, zz), htr = intra_blk_ok(d, bx + 2, by - 1, zz);
-      pred8x8l(dst, sy, m->i4_mode[by * 4 + bx], hl, ht, htl, htr);
+      int hl = h264i_intra_blk_ok(d, bx - 1, by, zz), ht = h264i_intra_blk_ok(d, bx, by - 1, zz);
+      int htl = h264i_intra_blk_ok(d, bx - 1, by - 1, zz), htr = h264i_intra_blk_ok(d, bx + 2, by - 1, zz);
+      h264i_pred8x8l(dst, sy, m->i4_mode[by * 4 + bx], hl, ht, htl, htr);
       recon_luma_residual_8x8(d, b8, pps->scaling8[0]);
     }
   }
   for (int p = 0; p < 2; ++p) {
     uint8_t* c0 = cur->plane[1 + p] + m->mby * 8 * cur->stride[1 + p] + m->mbx * 8;
-    pred_chroma8x8(c0, cur->stride[1 + p], m->chroma_mode, left_ok, top_ok);
+    h264i_pred_chroma8x8(c0, cur->stride[1 + p], m->chroma_mode, left_ok, top_ok);
   }
   recon_chroma_residual(d);
 }

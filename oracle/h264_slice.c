@@ -72,6 +72,105 @@ static int cabac_terminate(Cabac* c) {
 }
 
 /* ======================================================================== */
+/* bit writer + CABAC encoder (9.3.4.2) -- corpus generation only           */
+/* ======================================================================== */
+void bw_put(BitWriter* w, unsigned v, int n) {
+  for (int i = n - 1; i >= 0; --i) {
+    if ((w->pos >> 3) >= w->cap) {
+      w->cap = w->cap ? w->cap * 2 : 1 << 16;
+      w->buf = (uint8_t*)realloc(w->buf, w->cap);
+    }
+    if ((w->pos & 7) == 0) w->buf[w->pos >> 3] = 0;
+    if ((v >> i) & 1) w->buf[w->pos >> 3] |= (uint8_t)(0x80 >> (w->pos & 7));
+    w->pos++;
+  }
+}
+void bw_ue(BitWriter* w, unsigned v) {
+  unsigned x = v + 1;
+  int len = 0;
+  while ((x >> len) > 1) ++len;
+  bw_put(w, 0, len);
+  bw_put(w, x, len + 1);
+}
+void bw_se(BitWriter* w, int v) { bw_ue(w, v > 0 ? 2u * v - 1 : 2u * (unsigned)(-v)); }
+
+static void cenc_start(CabacEnc* e, BitWriter* w) {
+  e->w = w;
+  e->low = 0;
+  e->range = 510;
+  e->outstanding = 0;
+  e->first = 1;
+}
+static void cenc_put(CabacEnc* e, int b) {
+  if (e->first)
+    e->first = 0;
+  else
+    bw_put(e->w, b, 1);
+  while (e->outstanding > 0) {
+    bw_put(e->w, !b, 1);
+    e->outstanding--;
+  }
+}
+static void cenc_renorm(CabacEnc* e) {
+  while (e->range < 256) {
+    if (e->low < 256) {
+      cenc_put(e, 0);
+    } else if (e->low >= 512) {
+      e->low -= 512;
+      cenc_put(e, 1);
+    } else {
+      e->low -= 256;
+      e->outstanding++;
+    }
+    e->range <<= 1;
+    e->low <<= 1;
+  }
+}
+static int cenc_bin(CabacEnc* e, uint8_t* state, int bin) {
+  int p = *state >> 1, mps = *state & 1;
+  unsigned lps = cabac_range_lps[p][(e->range >> 6) & 3];
+  e->range -= lps;
+  if (bin != mps) {
+    e->low += e->range;
+    e->range = lps;
+    if (p == 0) mps = !mps;
+    p = cabac_trans_lps[p];
+  } else if (p < 62) {
+    ++p;
+  }
+  *state = (uint8_t)((p << 1) | mps);
+  cenc_renorm(e);
+  return bin;
+}
+static int cenc_bypass(CabacEnc* e, int bin) {
+  e->low <<= 1;
+  if (bin) e->low += e->range;
+  if (e->low >= 1024) {
+    cenc_put(e, 1);
+    e->low -= 1024;
+  } else if (e->low < 512) {
+    cenc_put(e, 0);
+  } else {
+    e->low -= 512;
+    e->outstanding++;
+  }
+  return bin;
+}
+static int cenc_terminate(CabacEnc* e, int bin) {
+  e->range -= 2;
+  if (bin) {
+    e->low += e->range;
+    e->range = 2;
+    cenc_renorm(e);
+    cenc_put(e, (e->low >> 9) & 1);
+    bw_put(e->w, ((e->low >> 7) & 3) | 1, 2);
+  } else {
+    cenc_renorm(e);
+  }
+  return bin;
+}
+
+/* ======================================================================== */
 /* neighbour helpers                                                        */
 /* ======================================================================== */
 static inline int mb_avail(const H264Oracle* d, int mbx, int mby) {
@@ -288,6 +387,45 @@ static int pred_direct(H264Oracle* d, int only_b8) {
 }
 
 /* ======================================================================== */
+/* syntax element I/O: one code path for parsing (oracle decoder) and for    */
+/* writing (corpus encoder).  Every sx_* takes the value to write; when     */
+/* parsing the argument is ignored and the parsed value is returned.        */
+/* ======================================================================== */
+typedef struct {
+  H264Oracle* d;
+  Bits* b;        /* parse side */
+  int cabac;
+  int enc;        /* 1 = writing */
+  BitWriter* w;   /* write side */
+  const MbPlan* plan;
+} Rd;
+
+static inline int sx_bin(Rd* r, int ctx, int v) {
+  return r->enc ? cenc_bin(&r->d->cenc, &r->d->cabac.state[ctx], v) : cabac_bin(&r->d->cabac, ctx);
+}
+static inline int sx_bypass(Rd* r, int v) {
+  return r->enc ? cenc_bypass(&r->d->cenc, v) : cabac_bypass(&r->d->cabac);
+}
+static inline int sx_terminate(Rd* r, int v) {
+  return r->enc ? cenc_terminate(&r->d->cenc, v) : cabac_terminate(&r->d->cabac);
+}
+static inline unsigned sx_u(Rd* r, int n, unsigned v) {
+  if (!r->enc) return get_bits(r->b, n);
+  bw_put(r->w, v, n);
+  return v;
+}
+static inline unsigned sx_ue(Rd* r, unsigned v) {
+  if (!r->enc) return get_ue(r->b);
+  bw_ue(r->w, v);
+  return v;
+}
+static inline int sx_se(Rd* r, int v) {
+  if (!r->enc) return get_se(r->b);
+  bw_se(r->w, v);
+  return v;
+}
+
+/* ======================================================================== */
 /* residual: CAVLC (9.2)                                                    */
 /* ======================================================================== */
 static int read_vlc(Bits* b, const uint8_t* len, const uint8_t* bits, int n) {
@@ -302,10 +440,14 @@ static int read_vlc(Bits* b, const uint8_t* len, const uint8_t* bits, int n) {
   b->overrun = 1;
   return -1;
 }
+static int sx_vlc(Rd* r, const uint8_t* len, const uint8_t* bits, int n, int v) {
+  if (!r->enc) return read_vlc(r->b, len, bits, n);
+  bw_put(r->w, bits[v], len[v]);
+  return v;
+}
 
 /* nC from the total_coeff of the left/top neighbours of block (rx, ry) in
- * plane-local 4x4 units; plane: 0 luma (4x4 blocks per MB = 4), 1/2 chroma
- * (2 per MB). */
+ * plane-local 4x4 units; plane: 0 luma (4 blocks per MB row), 1/2 chroma. */
 static int cavlc_nc(const H264Oracle* d, int plane, int rx, int ry) {
   const int n = plane == 0 ? 4 : 2;
   const int base = plane == 0 ? 0 : (plane == 1 ? 16 : 20);
@@ -326,38 +468,97 @@ static int cavlc_nc(const H264Oracle* d, int plane, int rx, int ry) {
   return 0;
 }
 
-/* Decodes one residual block into out[scan[start + k]].  Returns total_coeff
- * or -1.  nc == -1 selects the chroma DC tables. */
-static int cavlc_block(H264Oracle* d, Bits* b, int nc, int max_coeff, const uint8_t* scan, int start,
-                       int16_t* out) {
-  int token;
+/* One residual block; coefficients live at io[scan[start + k]].  Parsing
+ * fills them, writing emits them.  Returns total_coeff or -1.  nc == -1
+ * selects the chroma DC tables. */
+static int cavlc_block(Rd* r, int nc, int max_coeff, const uint8_t* scan, int start, int16_t* io) {
+  H264Oracle* d = r->d;
+  Bits* b = r->b;
+  int level[16], run[16];
+  int total = 0, t1 = 0, zeros_total = 0;
+  if (r->enc) {
+    /* gather levels from the highest scan position down */
+    int last = -1;
+    for (int k = max_coeff - 1; k >= 0; --k) {
+      int v = io[scan[start + k]];
+      if (!v) continue;
+      if (last < 0) {
+        last = k;
+      } else {
+        run[total - 1] = last - k - 1;
+        last = k;
+      }
+      level[total++] = v;
+    }
+    if (total) {
+      run[total - 1] = last; /* zeros before the lowest coefficient */
+      zeros_total = 0;
+      for (int i = 0; i < total; ++i) zeros_total += run[i];
+      while (t1 < 3 && t1 < total && (level[t1] == 1 || level[t1] == -1)) ++t1;
+    }
+  }
+  int token = 4 * total + t1;
   if (nc == -1) {
-    token = read_vlc(b, chroma_dc_coeff_token_len, chroma_dc_coeff_token_bits, 20);
+    token = sx_vlc(r, chroma_dc_coeff_token_len, chroma_dc_coeff_token_bits, 20, token);
   } else {
     int t = nc < 2 ? 0 : (nc < 4 ? 1 : (nc < 8 ? 2 : 3));
-    token = read_vlc(b, coeff_token_len[t], coeff_token_bits[t], 68);
+    token = sx_vlc(r, coeff_token_len[t], coeff_token_bits[t], 68, token);
   }
   if (token < 0) return h264i_fail(d, "CAVLC: bad coeff_token");
-  const int total = token >> 2, t1 = token & 3;
+  total = token >> 2;
+  t1 = token & 3;
   if (total == 0) return 0;
   if (total > max_coeff) return h264i_fail(d, "CAVLC: total_coeff exceeds block size");
-  int level[16];
-  for (int i = 0; i < t1; ++i) level[i] = get_bit(b) ? -1 : 1;
+  for (int i = 0; i < t1; ++i) {
+    int neg = sx_u(r, 1, r->enc ? level[i] < 0 : 0);
+    level[i] = neg ? -1 : 1;
+  }
   int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
   for (int i = t1; i < total; ++i) {
-    int prefix = 0;
-    while (!get_bit(b)) {
-      if (++prefix > 31 || b->overrun) return h264i_fail(d, "CAVLC: bad level_prefix");
+    int prefix, code;
+    if (r->enc) {
+      /* invert 9.2.2.1: find (level_prefix, level_suffix) for this level */
+      code = level[i] > 0 ? 2 * level[i] - 2 : -2 * level[i] - 1;
+      if (i == t1 && t1 < 3) code -= 2;
+      int size;
+      if (suffix_len == 0) {
+        if (code < 14) { prefix = code; size = 0; }
+        else if (code < 30) { prefix = 14; size = 4; }
+        else { prefix = 15; size = 12; }
+      } else {
+        if ((code >> suffix_len) < 15) { prefix = code >> suffix_len; size = suffix_len; }
+        else { prefix = 15; size = 12; }
+      }
+      int base = imin(15, prefix) << suffix_len;
+      if (prefix >= 15 && suffix_len == 0) base += 15;
+      int suffix = code - base;
+      if (prefix == 15 && suffix >= (1 << 12)) {
+        /* escape beyond 12 bits: longer prefixes (level_prefix >= 16) */
+        prefix = 16;
+        for (;;) {
+          int b16 = (15 << suffix_len) + (suffix_len == 0 ? 15 : 0) + (1 << (prefix - 3)) - 4096;
+          if (code - b16 < (1 << (prefix - 3))) { suffix = code - b16; size = prefix - 3; break; }
+          ++prefix;
+        }
+      }
+      bw_put(r->w, 0, prefix);
+      bw_put(r->w, 1, 1);
+      if (size > 0) bw_put(r->w, suffix, size);
+    } else {
+      prefix = 0;
+      while (!get_bit(b)) {
+        if (++prefix > 31 || b->overrun) return h264i_fail(d, "CAVLC: bad level_prefix");
+      }
+      code = imin(15, prefix) << suffix_len;
+      int size = suffix_len;
+      if (prefix == 14 && suffix_len == 0) size = 4;
+      if (prefix >= 15) size = prefix - 3;
+      if (size > 0) code += get_bits(b, size);
+      if (prefix >= 15 && suffix_len == 0) code += 15;
+      if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+      if (i == t1 && t1 < 3) code += 2;
+      level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
     }
-    int code = imin(15, prefix) << suffix_len;
-    int size = suffix_len;
-    if (prefix == 14 && suffix_len == 0) size = 4;
-    if (prefix >= 15) size = prefix - 3;
-    if (size > 0) code += get_bits(b, size);
-    if (prefix >= 15 && suffix_len == 0) code += 15;
-    if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
-    if (i == t1 && t1 < 3) code += 2;
-    level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
     if (suffix_len == 0) suffix_len = 1;
     if (iabs(level[i]) > (3 << (suffix_len - 1)) && suffix_len < 6) ++suffix_len;
   }
@@ -365,25 +566,25 @@ static int cavlc_block(H264Oracle* d, Bits* b, int nc, int max_coeff, const uint
   if (total < max_coeff) {
     int tz;
     if (nc == -1)
-      tz = read_vlc(b, chroma_dc_total_zeros_len[total - 1], chroma_dc_total_zeros_bits[total - 1], 4);
+      tz = sx_vlc(r, chroma_dc_total_zeros_len[total - 1], chroma_dc_total_zeros_bits[total - 1], 4, zeros_total);
     else
-      tz = read_vlc(b, total_zeros_len[total - 1], total_zeros_bits[total - 1], total_zeros_count[total - 1]);
+      tz = sx_vlc(r, total_zeros_len[total - 1], total_zeros_bits[total - 1], total_zeros_count[total - 1], zeros_total);
     if (tz < 0) return h264i_fail(d, "CAVLC: bad total_zeros");
     zeros_left = tz;
   }
   if (zeros_left + total > max_coeff) return h264i_fail(d, "CAVLC: total_zeros exceeds block size");
   int pos = zeros_left + total - 1; /* scan index of the highest coefficient */
   for (int i = 0; i < total; ++i) {
-    out[scan[start + pos]] = (int16_t)level[i];
+    if (!r->enc) io[scan[start + pos]] = (int16_t)level[i];
     if (i == total - 1) break;
-    int run = 0;
+    int rb = 0;
     if (zeros_left > 0) {
       int t = imin(zeros_left, 7) - 1;
-      run = read_vlc(b, run_before_len[t], run_before_bits[t], run_before_count[t]);
-      if (run < 0 || run > zeros_left) return h264i_fail(d, "CAVLC: bad run_before");
-      zeros_left -= run;
+      rb = sx_vlc(r, run_before_len[t], run_before_bits[t], run_before_count[t], r->enc ? run[i] : 0);
+      if (rb < 0 || rb > zeros_left) return h264i_fail(d, "CAVLC: bad run_before");
+      zeros_left -= rb;
     }
-    pos -= run + 1;
+    pos -= rb + 1;
   }
   return total;
 }
@@ -397,11 +598,24 @@ static const int abs_cat_offset[6] = {0, 10, 20, 30, 39, 0};
 
 /* cat: 0 I16 DC, 1 I16 AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC, 5 luma 8x8.
  * cbf_inc < 0: no coded_block_flag (cat 5 in 4:2:0).  Returns nonzero count. */
-static int cabac_block(H264Oracle* d, int cat, int cbf_inc, int max_coeff, const uint8_t* scan,
-                       int start, int16_t* out) {
-  Cabac* c = &d->cabac;
+static int cabac_block(Rd* r, int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start,
+                       int16_t* io) {
+  H264Oracle* d = r->d;
+  int want[64];
+  int nz = 0, last_nz = -1;
+  if (r->enc) {
+    for (int k = 0; k < max_coeff; ++k) {
+      want[k] = io[scan[start + k]];
+      if (want[k]) {
+        ++nz;
+        last_nz = k;
+      }
+    }
+  }
   if (cbf_inc >= 0) {
-    if (!cabac_bin(c, 85 + cbf_cat_offset[cat] + cbf_inc)) return 0;
+    if (!sx_bin(r, 85 + cbf_cat_offset[cat] + cbf_inc, nz != 0)) return 0;
+  } else if (r->enc && !nz) {
+    return h264i_fail(d, "encoder: 8x8 block flagged in CBP has no coefficients");
   }
   const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
   const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
@@ -418,35 +632,37 @@ static int cabac_block(H264Oracle* d, int cat, int cbf_inc, int max_coeff, const
     } else {
       sinc = linc = i;
     }
-    if (cabac_bin(c, sig_base + sinc)) {
+    if (sx_bin(r, sig_base + sinc, r->enc ? want[i] != 0 : 0)) {
       idx[n++] = i;
-      if (cabac_bin(c, last_base + linc)) break;
+      if (sx_bin(r, last_base + linc, i == last_nz)) break;
     }
   }
   if (i == max_coeff - 1) idx[n++] = max_coeff - 1; /* inferred significant */
   int gt1 = 0, eq1 = 0;
   for (int k = n - 1; k >= 0; --k) {
+    const int target = r->enc ? iabs(want[idx[k]]) : 0;
     int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
     int val;
-    if (!cabac_bin(c, abs_base + inc0)) {
+    if (!sx_bin(r, abs_base + inc0, target > 1)) {
       val = 1;
       ++eq1;
     } else {
       int inc = 5 + imin(4 - (cat == 3 ? 1 : 0), gt1);
       val = 2;
-      while (val < 15 && cabac_bin(c, abs_base + inc)) ++val;
+      while (val < 15 && sx_bin(r, abs_base + inc, target > val)) ++val;
       if (val == 15) { /* prefix saturated: Exp-Golomb k=0 suffix */
-        int k0 = 0;
-        while (cabac_bypass(c)) {
+        int k0 = 0, rem = target - 15;
+        while (sx_bypass(r, rem >= (1 << k0))) {
           val += 1 << k0;
+          rem -= 1 << k0;
           if (++k0 > 24) return h264i_fail(d, "CABAC: coeff_abs_level overflow");
         }
-        while (k0--) val += cabac_bypass(c) << k0;
+        while (k0--) val += sx_bypass(r, (rem >> k0) & 1) << k0;
       }
       ++gt1;
     }
-    if (cabac_bypass(c)) val = -val;
-    out[scan[start + idx[k]]] = (int16_t)val;
+    if (sx_bypass(r, r->enc ? want[idx[k]] < 0 : 0)) val = -val;
+    if (!r->enc) io[scan[start + idx[k]]] = (int16_t)val;
   }
   return n;
 }
@@ -487,16 +703,12 @@ static int cbf_inc(const H264Oracle* d, int kind, int p, int rx, int ry) {
 }
 
 /* ======================================================================== */
-/* macroblock syntax helpers                                                */
+/* macroblock syntax elements                                               */
 /* ======================================================================== */
-typedef struct {
-  H264Oracle* d;
-  Bits* b;
-  int cabac;
-} Rd;
-
-static int rd_intra_mb_type(Rd* r, int ctx_base, int intra_slice) {
-  Cabac* c = &r->d->cabac;
+static int sx_intra_mb_type(Rd* r, int ctx_base, int intra_slice, int v) {
+  /* v: 0 I_NxN, 1..24 I_16x16 family, 25 I_PCM */
+  const int t = v - 1;
+  const int luma = v >= 13, chroma = (t >> 2) % 3, mode = t & 3;
   if (intra_slice) {
     const H264Oracle* d = r->d;
     int inc = 0;
@@ -508,78 +720,86 @@ static int rd_intra_mb_type(Rd* r, int ctx_base, int intra_slice) {
       int k = d->mb_kind[d->mb.addr - d->mbw];
       inc += k != MB_I4x4 && k != MB_I8x8;
     }
-    if (!cabac_bin(c, ctx_base + inc)) return 0;
+    if (!sx_bin(r, ctx_base + inc, v != 0)) return 0;
     ctx_base += 2;
   } else {
-    if (!cabac_bin(c, ctx_base)) return 0;
+    if (!sx_bin(r, ctx_base, v != 0)) return 0;
   }
-  if (cabac_terminate(c)) return 25;
-  int t = 1;
-  t += 12 * cabac_bin(c, ctx_base + 1);
-  if (cabac_bin(c, ctx_base + 2)) t += 4 + 4 * cabac_bin(c, ctx_base + 2 + intra_slice);
-  t += 2 * cabac_bin(c, ctx_base + 3 + intra_slice);
-  t += cabac_bin(c, ctx_base + 3 + 2 * intra_slice);
-  return t;
+  if (sx_terminate(r, v == 25)) return 25;
+  int out = 1;
+  out += 12 * sx_bin(r, ctx_base + 1, luma);
+  if (sx_bin(r, ctx_base + 2, chroma != 0)) out += 4 + 4 * sx_bin(r, ctx_base + 2 + intra_slice, chroma == 2);
+  out += 2 * sx_bin(r, ctx_base + 3 + intra_slice, mode >> 1);
+  out += sx_bin(r, ctx_base + 3 + 2 * intra_slice, mode & 1);
+  return out;
 }
 
-/* returns the slice-type specific mb_type number (before intra offset removal) */
-static int rd_mb_type(Rd* r) {
+/* slice-type specific mb_type number */
+static int sx_mb_type(Rd* r, int v) {
   H264Oracle* d = r->d;
   const int st = d->sl.type;
-  if (!r->cabac) return (int)get_ue(r->b);
-  Cabac* c = &d->cabac;
-  if (st == 2) return rd_intra_mb_type(r, 3, 1);
+  if (!r->cabac) return (int)sx_ue(r, v);
+  if (st == 2) return sx_intra_mb_type(r, 3, 1, v);
   if (st == 0) {
-    if (!cabac_bin(c, 14)) {
-      if (!cabac_bin(c, 15)) return 3 * cabac_bin(c, 16);
-      return 2 - cabac_bin(c, 17);
+    if (!sx_bin(r, 14, v >= 5)) {
+      if (!sx_bin(r, 15, v == 1 || v == 2)) return 3 * sx_bin(r, 16, v == 3);
+      return 2 - sx_bin(r, 17, v == 1);
     }
-    return 5 + rd_intra_mb_type(r, 17, 0);
+    return 5 + sx_intra_mb_type(r, 17, 0, v - 5);
   }
   int inc = 0;
   if (mb_avail(d, d->mb.mbx - 1, d->mb.mby) && !d->mb_direct[d->mb.addr - 1]) inc++;
   if (mb_avail(d, d->mb.mbx, d->mb.mby - 1) && !d->mb_direct[d->mb.addr - d->mbw]) inc++;
-  if (!cabac_bin(c, 27 + inc)) return 0;
-  if (!cabac_bin(c, 27 + 3)) return 1 + cabac_bin(c, 27 + 5);
-  int bits = cabac_bin(c, 27 + 4) << 3;
-  bits |= cabac_bin(c, 27 + 5) << 2;
-  bits |= cabac_bin(c, 27 + 5) << 1;
-  bits |= cabac_bin(c, 27 + 5);
+  if (!sx_bin(r, 27 + inc, v != 0)) return 0;
+  if (!sx_bin(r, 27 + 3, v > 2)) return 1 + sx_bin(r, 27 + 5, v == 2);
+  /* 4-bit code (5 for the 12..21 group) */
+  int code, extra = -1;
+  if (v >= 23) code = 13;
+  else if (v == 11) code = 14;
+  else if (v == 22) code = 15;
+  else if (v <= 10) code = v - 3;
+  else { code = (v + 4) >> 1; extra = (v + 4) & 1; }
+  int bits = sx_bin(r, 27 + 4, (code >> 3) & 1) << 3;
+  bits |= sx_bin(r, 27 + 5, (code >> 2) & 1) << 2;
+  bits |= sx_bin(r, 27 + 5, (code >> 1) & 1) << 1;
+  bits |= sx_bin(r, 27 + 5, code & 1);
   if (bits < 8) return bits + 3;
-  if (bits == 13) return 23 + rd_intra_mb_type(r, 32, 0);
+  if (bits == 13) return 23 + sx_intra_mb_type(r, 32, 0, v - 23);
   if (bits == 14) return 11;
   if (bits == 15) return 22;
-  bits = (bits << 1) | cabac_bin(c, 27 + 5);
+  bits = (bits << 1) | sx_bin(r, 27 + 5, extra);
   return bits - 4;
 }
 
-static int rd_sub_mb_type(Rd* r) {
+static int sx_sub_mb_type(Rd* r, int v) {
   H264Oracle* d = r->d;
-  if (!r->cabac) return (int)get_ue(r->b);
-  Cabac* c = &d->cabac;
+  if (!r->cabac) return (int)sx_ue(r, v);
   if (d->sl.type == 0) {
-    if (cabac_bin(c, 21)) return 0;
-    if (!cabac_bin(c, 22)) return 1;
-    return cabac_bin(c, 23) ? 2 : 3;
+    if (sx_bin(r, 21, v == 0)) return 0;
+    if (!sx_bin(r, 22, v != 1)) return 1;
+    return sx_bin(r, 23, v == 2) ? 2 : 3;
   }
-  if (!cabac_bin(c, 36)) return 0;
-  if (!cabac_bin(c, 37)) return 1 + cabac_bin(c, 39);
+  if (!sx_bin(r, 36, v != 0)) return 0;
+  if (!sx_bin(r, 37, v > 2)) return 1 + sx_bin(r, 39, v == 2);
   int t = 3;
-  if (cabac_bin(c, 38)) {
-    if (cabac_bin(c, 39)) return 11 + cabac_bin(c, 39);
+  if (sx_bin(r, 38, v >= 7)) {
+    if (sx_bin(r, 39, v >= 11)) return 11 + sx_bin(r, 39, v == 12);
     t += 4;
   }
-  t += 2 * cabac_bin(c, 39);
-  t += cabac_bin(c, 39);
+  const int rem = v - t; /* 0..3 */
+  t += 2 * sx_bin(r, 39, (rem >> 1) & 1);
+  t += sx_bin(r, 39, rem & 1);
   return t;
 }
 
-static int rd_ref_idx(Rd* r, int list, int b8) {
+static int sx_ref_idx(Rd* r, int list, int b8, int v) {
   H264Oracle* d = r->d;
   const int n = d->sl.num_ref_idx[list];
-  if (!r->cabac) return n > 1 ? get_te(r->b, n - 1) : 0;
   if (n <= 1) return 0;
-  /* neighbours A (left) and B (top) of the 8x8 block at 4x4 position */
+  if (!r->cabac) {
+    if (n == 2) return !sx_u(r, 1, !v);
+    return (int)sx_ue(r, v);
+  }
   const int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2;
   int inc = 0;
   for (int k = 0; k < 2; ++k) {
@@ -593,9 +813,8 @@ static int rd_ref_idx(Rd* r, int list, int b8) {
     if (d->sl.type == 1 && d->direct8[addr * 4 + q]) continue;
     if (d->cur->ref_idx[list][addr * 4 + q] > 0) inc += k == 0 ? 1 : 2;
   }
-  Cabac* c = &d->cabac;
   int ref = 0;
-  while (cabac_bin(c, 54 + inc)) {
+  while (sx_bin(r, 54 + inc, v > ref)) {
     ++ref;
     inc = (inc >> 2) + 4;
     if (ref >= 32) return -1;
@@ -603,9 +822,9 @@ static int rd_ref_idx(Rd* r, int list, int b8) {
   return ref;
 }
 
-static int rd_mvd(Rd* r, int list, int bx, int by, int comp) {
+static int sx_mvd(Rd* r, int list, int bx, int by, int comp, int v) {
   H264Oracle* d = r->d;
-  if (!r->cabac) return get_se(r->b);
+  if (!r->cabac) return sx_se(r, v);
   int sum = 0;
   for (int k = 0; k < 2; ++k) {
     int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
@@ -614,35 +833,40 @@ static int rd_mvd(Rd* r, int list, int bx, int by, int comp) {
     if (!inside && !mb_avail(d, nx, ny)) continue;
     sum += d->mvd[ny * d->mbw + nx][list][(ry & 3) * 4 + (rx & 3)][comp];
   }
-  Cabac* c = &d->cabac;
   const int base = comp == 0 ? 40 : 47;
+  const int a = iabs(v);
   int inc = sum < 3 ? 0 : (sum > 32 ? 2 : 1);
-  if (!cabac_bin(c, base + inc)) return 0;
-  int v = 1, ctx = base + 3;
-  while (v < 9 && cabac_bin(c, ctx)) {
-    if (v < 4) ++ctx;
-    ++v;
+  if (!sx_bin(r, base + inc, a != 0)) return 0;
+  int val = 1, ctx = base + 3;
+  while (val < 9 && sx_bin(r, ctx, a > val)) {
+    if (val < 4) ++ctx;
+    ++val;
   }
-  if (v >= 9) {
-    int k = 3;
-    while (cabac_bypass(c)) {
-      v += 1 << k;
+  if (val >= 9) {
+    int k = 3, rem = a - 9;
+    while (sx_bypass(r, rem >= (1 << k))) {
+      val += 1 << k;
+      rem -= 1 << k;
       if (++k > 24) return 0;
     }
-    while (k--) v += cabac_bypass(c) << k;
+    while (k--) val += sx_bypass(r, (rem >> k) & 1) << k;
   }
-  return cabac_bypass(c) ? -v : v;
+  return sx_bypass(r, v < 0) ? -val : val;
 }
 
-static int rd_cbp(Rd* r, int intra) {
+static int sx_cbp(Rd* r, int intra, int v) {
   H264Oracle* d = r->d;
   MB* m = &d->mb;
   if (!r->cabac) {
-    unsigned code = get_ue(r->b);
+    unsigned code = 0;
+    if (r->enc) {
+      const uint8_t* tab = intra ? cbp_intra_from_code : cbp_inter_from_code;
+      while (tab[code] != v) ++code;
+    }
+    code = sx_ue(r, code);
     if (code > 47) return -1;
     return intra ? cbp_intra_from_code[code] : cbp_inter_from_code[code];
   }
-  Cabac* c = &d->cabac;
   const int la = mb_avail(d, m->mbx - 1, m->mby), ta = mb_avail(d, m->mbx, m->mby - 1);
   /* unavailable neighbours behave like "all luma bits set" */
   const int cbp_a = la ? d->mb_cbp[m->addr - 1] : 0x0f;
@@ -651,63 +875,64 @@ static int rd_cbp(Rd* r, int intra) {
   for (int b8 = 0; b8 < 4; ++b8) {
     int bit_a = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
     int bit_b = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
-    cbp |= cabac_bin(c, 73 + !bit_a + 2 * !bit_b) << b8;
+    cbp |= sx_bin(r, 73 + !bit_a + 2 * !bit_b, (v >> b8) & 1) << b8;
   }
   const int ca = la ? d->mb_cbp[m->addr - 1] >> 4 : 0;
   const int cb = ta ? d->mb_cbp[m->addr - d->mbw] >> 4 : 0;
-  if (cabac_bin(c, 77 + (ca != 0) + 2 * (cb != 0))) {
-    int v = 1 + cabac_bin(c, 77 + 4 + (ca == 2) + 2 * (cb == 2));
-    cbp |= v << 4;
+  if (sx_bin(r, 77 + (ca != 0) + 2 * (cb != 0), (v >> 4) != 0)) {
+    int c2 = 1 + sx_bin(r, 77 + 4 + (ca == 2) + 2 * (cb == 2), (v >> 4) == 2);
+    cbp |= c2 << 4;
   }
   return cbp;
 }
 
-static int rd_qp_delta(Rd* r) {
+static int sx_qp_delta(Rd* r, int v) {
   H264Oracle* d = r->d;
-  if (!r->cabac) return get_se(r->b);
-  Cabac* c = &d->cabac;
+  if (!r->cabac) return sx_se(r, v);
   int ctx = d->last_qp_delta_nonzero ? 1 : 0;
-  int v = 0;
-  while (cabac_bin(c, 60 + ctx)) {
+  const int target = v > 0 ? 2 * v - 1 : -2 * v;
+  int n = 0;
+  while (sx_bin(r, 60 + ctx, target > n)) {
     ctx = 2 + (ctx >> 1);
-    if (++v > 104) return 1000;
+    if (++n > 104) return 1000;
   }
-  return (v & 1) ? (v + 1) >> 1 : -((v + 1) >> 1);
+  return (n & 1) ? (n + 1) >> 1 : -((n + 1) >> 1);
 }
 
-static int rd_chroma_pred_mode(Rd* r) {
+static int sx_chroma_pred_mode(Rd* r, int v) {
   H264Oracle* d = r->d;
   const MB* m = &d->mb;
-  if (!r->cabac) return (int)get_ue(r->b);
-  Cabac* c = &d->cabac;
+  if (!r->cabac) return (int)sx_ue(r, v);
   int inc = 0;
   if (mb_avail(d, m->mbx - 1, m->mby) && d->mb_chroma_mode[m->addr - 1]) inc++;
   if (mb_avail(d, m->mbx, m->mby - 1) && d->mb_chroma_mode[m->addr - d->mbw]) inc++;
-  if (!cabac_bin(c, 64 + inc)) return 0;
-  if (!cabac_bin(c, 64 + 3)) return 1;
-  return 2 + cabac_bin(c, 64 + 3);
+  if (!sx_bin(r, 64 + inc, v != 0)) return 0;
+  if (!sx_bin(r, 64 + 3, v != 1)) return 1;
+  return 2 + sx_bin(r, 64 + 3, v == 3);
 }
 
-static int rd_t8x8_flag(Rd* r) {
+static int sx_t8x8_flag(Rd* r, int v) {
   H264Oracle* d = r->d;
   const MB* m = &d->mb;
-  if (!r->cabac) return get_bit(r->b);
+  if (!r->cabac) return (int)sx_u(r, 1, v);
   int inc = 0;
   if (mb_avail(d, m->mbx - 1, m->mby) && d->mb_t8x8[m->addr - 1]) inc++;
   if (mb_avail(d, m->mbx, m->mby - 1) && d->mb_t8x8[m->addr - d->mbw]) inc++;
-  return cabac_bin(&d->cabac, 399 + inc);
+  return sx_bin(r, 399 + inc, v);
 }
 
-/* prev_intra4x4_pred_mode_flag / rem_intra4x4_pred_mode; returns -1 for
- * "use predicted", else rem 0..7 */
-static int rd_intra_pred_mode(Rd* r) {
-  if (!r->cabac) return get_bit(r->b) ? -1 : (int)get_bits(r->b, 3);
-  Cabac* c = &r->d->cabac;
-  if (cabac_bin(c, 68)) return -1;
-  int v = cabac_bin(c, 69);
-  v |= cabac_bin(c, 69) << 1;
-  v |= cabac_bin(c, 69) << 2;
-  return v;
+/* prev_intra4x4_pred_mode_flag / rem_intra4x4_pred_mode; -1 = "use
+ * predicted", else rem 0..7 */
+static int sx_intra_pred_mode(Rd* r, int v) {
+  if (!r->cabac) {
+    if (sx_u(r, 1, v < 0)) return -1;
+    return (int)sx_u(r, 3, v);
+  }
+  if (sx_bin(r, 68, v < 0)) return -1;
+  int out = sx_bin(r, 69, v & 1);
+  out |= sx_bin(r, 69, (v >> 1) & 1) << 1;
+  out |= sx_bin(r, 69, (v >> 2) & 1) << 2;
+  return out;
 }
 
 /* predicted Intra4x4/8x8 mode for the block whose top-left 4x4 is (bx,by) */
@@ -736,30 +961,25 @@ static int predicted_intra_mode(const H264Oracle* d, int bx, int by) {
 /* ======================================================================== */
 /* residual()                                                               */
 /* ======================================================================== */
-static const uint8_t identity_scan_pos4[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+static const uint8_t identity_scan16[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
 
-static int parse_residual(Rd* r) {
+static int code_residual(Rd* r) {
   H264Oracle* d = r->d;
   MB* m = &d->mb;
-  Bits* b = r->b;
   const int i16 = m->kind == MB_I16x16;
-  (void)identity_scan_pos4;
 
   if (i16) {
-    /* Intra16x16DCLevel: parsed in zig-zag over the 4x4 matrix of DCs whose
+    /* Intra16x16DCLevel: zig-zag over the 4x4 matrix of DCs whose
      * (row, col) is the 4x4 block's (y, x) */
-    int n;
-    if (r->cabac)
-      n = cabac_block(d, 0, cbf_inc(d, 0, 0, 0, 0), 16, zigzag4x4, 0, m->luma_dc);
-    else
-      n = cavlc_block(d, b, cavlc_nc(d, 0, 0, 0), 16, zigzag4x4, 0, m->luma_dc);
+    int n = r->cabac ? cabac_block(r, 0, cbf_inc(d, 0, 0, 0, 0), 16, zigzag4x4, 0, m->luma_dc)
+                     : cavlc_block(r, cavlc_nc(d, 0, 0, 0), 16, zigzag4x4, 0, m->luma_dc);
     if (n < 0) return -1;
     if (n) m->cbf_dc |= 1;
   }
   for (int b8 = 0; b8 < 4; ++b8) {
     if (!((m->cbp >> b8) & 1)) continue;
     if (m->t8x8 && r->cabac) {
-      int n = cabac_block(d, 5, -1, 64, zigzag8x8, 0, m->luma8[b8]);
+      int n = cabac_block(r, 5, -1, 64, zigzag8x8, 0, m->luma8[b8]);
       if (n < 0) return -1;
       for (int s = 0; s < 4; ++s)
         m->nnz[((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)] = (uint8_t)n;
@@ -772,17 +992,17 @@ static int parse_residual(Rd* r) {
       if (m->t8x8) {
         /* CAVLC 8x8: four interleaved 4x4 passes, coefficient 4k+s */
         int16_t tmp[16];
-        memset(tmp, 0, sizeof(tmp));
-        n = cavlc_block(d, b, cavlc_nc(d, 0, bx, by), 16, identity_scan_pos4, 0, tmp);
+        for (int k = 0; k < 16; ++k) tmp[k] = r->enc ? m->luma8[b8][zigzag8x8[4 * k + s]] : 0;
+        n = cavlc_block(r, cavlc_nc(d, 0, bx, by), 16, identity_scan16, 0, tmp);
         if (n < 0) return -1;
         for (int k = 0; k < 16; ++k)
           if (tmp[k]) m->luma8[b8][zigzag8x8[4 * k + s]] = tmp[k];
       } else if (i16) {
-        n = r->cabac ? cabac_block(d, 1, cbf_inc(d, 1, 0, bx, by), 15, zigzag4x4, 1, m->luma[ri])
-                     : cavlc_block(d, b, cavlc_nc(d, 0, bx, by), 15, zigzag4x4, 1, m->luma[ri]);
+        n = r->cabac ? cabac_block(r, 1, cbf_inc(d, 1, 0, bx, by), 15, zigzag4x4, 1, m->luma[ri])
+                     : cavlc_block(r, cavlc_nc(d, 0, bx, by), 15, zigzag4x4, 1, m->luma[ri]);
       } else {
-        n = r->cabac ? cabac_block(d, 2, cbf_inc(d, 1, 0, bx, by), 16, zigzag4x4, 0, m->luma[ri])
-                     : cavlc_block(d, b, cavlc_nc(d, 0, bx, by), 16, zigzag4x4, 0, m->luma[ri]);
+        n = r->cabac ? cabac_block(r, 2, cbf_inc(d, 1, 0, bx, by), 16, zigzag4x4, 0, m->luma[ri])
+                     : cavlc_block(r, cavlc_nc(d, 0, bx, by), 16, zigzag4x4, 0, m->luma[ri]);
       }
       if (n < 0) return -1;
       m->nnz[ri] = (uint8_t)n;
@@ -792,8 +1012,8 @@ static int parse_residual(Rd* r) {
   if (cc) {
     static const uint8_t dc_scan[4] = {0, 1, 2, 3};
     for (int p = 0; p < 2; ++p) {
-      int n = r->cabac ? cabac_block(d, 3, cbf_inc(d, 2, p, 0, 0), 4, dc_scan, 0, m->chroma_dc[p])
-                       : cavlc_block(d, b, -1, 4, dc_scan, 0, m->chroma_dc[p]);
+      int n = r->cabac ? cabac_block(r, 3, cbf_inc(d, 2, p, 0, 0), 4, dc_scan, 0, m->chroma_dc[p])
+                       : cavlc_block(r, -1, 4, dc_scan, 0, m->chroma_dc[p]);
       if (n < 0) return -1;
       if (n) m->cbf_dc |= 2 << p;
     }
@@ -803,20 +1023,21 @@ static int parse_residual(Rd* r) {
       for (int s = 0; s < 4; ++s) {
         const int bx = s & 1, by = s >> 1;
         int n = r->cabac
-                    ? cabac_block(d, 4, cbf_inc(d, 3, p, bx, by), 15, zigzag4x4, 1, m->chroma_ac[p][s])
-                    : cavlc_block(d, b, cavlc_nc(d, 1 + p, bx, by), 15, zigzag4x4, 1, m->chroma_ac[p][s]);
+                    ? cabac_block(r, 4, cbf_inc(d, 3, p, bx, by), 15, zigzag4x4, 1, m->chroma_ac[p][s])
+                    : cavlc_block(r, cavlc_nc(d, 1 + p, bx, by), 15, zigzag4x4, 1, m->chroma_ac[p][s]);
         if (n < 0) return -1;
         m->nnz[16 + 4 * p + s] = (uint8_t)n;
       }
   }
-  return b->overrun ? h264i_fail(d, "residual ran past the end of the slice") : 0;
+  if (!r->enc && r->b->overrun) return h264i_fail(d, "residual ran past the end of the slice");
+  return 0;
 }
 
 /* ======================================================================== */
 /* inter prediction syntax                                                  */
 /* ======================================================================== */
-/* B macroblock partition table: shape 0=16x16 1=16x8 2=8x16; pred per part
- * 0=L0 1=L1 2=Bi */
+/* B macroblock partition table: shape 0=16x16 1=16x8 2=8x16 3=8x8; pred per
+ * part 0=L0 1=L1 2=Bi */
 static const uint8_t b_mb_info[23][3] = {
     {0, 0, 0}, {0, 0, 0}, {0, 1, 1}, {0, 2, 2}, {1, 0, 0}, {2, 0, 0}, {1, 1, 1}, {2, 1, 1},
     {1, 0, 1}, {2, 0, 1}, {1, 1, 0}, {2, 1, 0}, {1, 0, 2}, {2, 0, 2}, {1, 1, 2}, {2, 1, 2},
@@ -827,9 +1048,10 @@ static const uint8_t b_sub_info[13][2] = {{0, 3}, {0, 0}, {0, 1}, {0, 2}, {1, 0}
 
 static inline int uses_list(int pred, int list) { return pred == 2 || pred == list; }
 
-static int parse_inter(Rd* r, int mb_type) {
+static int code_inter(Rd* r, int mb_type) {
   H264Oracle* d = r->d;
   MB* m = &d->mb;
+  const MB* P = r->enc ? &r->plan->mb : NULL;
   const int is_b = d->sl.type == 1;
   int shape, pred[4], sub_shape[4] = {0, 0, 0, 0};
   int nparts;
@@ -846,7 +1068,7 @@ static int parse_inter(Rd* r, int mb_type) {
 
   if (shape == 3) {
     for (int i = 0; i < 4; ++i) {
-      int t = rd_sub_mb_type(r);
+      int t = sx_sub_mb_type(r, P ? P->sub_type[i] : 0);
       if (t < 0 || t > (is_b ? 12 : 3)) return h264i_fail(d, "bad sub_mb_type");
       m->sub_type[i] = t;
       if (is_b) {
@@ -871,12 +1093,12 @@ static int parse_inter(Rd* r, int mb_type) {
     for (int i = 0; i < nparts; ++i) {
       if (pred[i] == 3) continue;
       int ref = -1;
+      const int b8 = shape == 0 ? 0 : (shape == 1 ? i * 2 : i);
       if (uses_list(pred[i], l)) {
-        if (!is_b && mb_type == 4)
+        if (!is_b && mb_type == 4) {
           ref = 0; /* P_8x8ref0 */
-        else {
-          int b8 = shape == 0 ? 0 : (shape == 1 ? i * 2 : (shape == 2 ? i : i));
-          ref = rd_ref_idx(r, l, b8);
+        } else {
+          ref = sx_ref_idx(r, l, b8, P ? P->ref[l][b8] : 0);
           if (ref < 0 || ref >= d->sl.num_ref_idx[l]) return h264i_fail(d, "ref_idx out of range");
         }
       }
@@ -902,9 +1124,12 @@ static int parse_inter(Rd* r, int mb_type) {
       else if (shape == 1) { px = 0; py = i * 2; pw = 4; ph = 2; }
       else if (shape == 2) { px = i * 2; py = 0; pw = 2; ph = 4; }
       else { px = (i & 1) * 2; py = (i >> 1) * 2; pw = 2; ph = 2; }
-      int ss = shape == 3 ? sub_shape[i] : 0;
-      int sw = (ss == 2 || ss == 3) ? pw / 2 : pw, sh = (ss == 1 || ss == 3) ? ph / 2 : ph;
-      if (shape != 3) { sw = pw; sh = ph; }
+      int sw = pw, sh = ph;
+      if (shape == 3) {
+        const int ss = sub_shape[i];
+        if (ss == 2 || ss == 3) sw = 1;
+        if (ss == 1 || ss == 3) sh = 1;
+      }
       const int ref = m->ref[l][(py >> 1) * 2 + (px >> 1)];
       for (int sy = 0; sy < ph; sy += sh)
         for (int sx = 0; sx < pw; sx += sw) {
@@ -914,8 +1139,10 @@ static int parse_inter(Rd* r, int mb_type) {
           if (shape == 2) dir = i == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT;
           int mvp[2];
           pred_mv(d, l, bx, by, sw, ref, dir, mvp);
-          int dx = rd_mvd(r, l, bx, by, 0);
-          int dy = rd_mvd(r, l, bx, by, 1);
+          int tx = P ? P->mv[l][by * 4 + bx][0] - mvp[0] : 0;
+          int ty = P ? P->mv[l][by * 4 + bx][1] - mvp[1] : 0;
+          int dx = sx_mvd(r, l, bx, by, 0, tx);
+          int dy = sx_mvd(r, l, bx, by, 1, ty);
           set_mvd_block(d, l, bx, by, sw, sh, dx, dy);
           set_mv_block(d, l, bx, by, sw, sh, mvp[0] + dx, mvp[1] + dy);
         }
@@ -927,7 +1154,7 @@ static int parse_inter(Rd* r, int mb_type) {
 /* ======================================================================== */
 /* macroblock_layer()                                                       */
 /* ======================================================================== */
-static void begin_mb(H264Oracle* d, int addr) {
+void h264i_begin_mb(H264Oracle* d, int addr) {
   MB* m = &d->mb;
   memset(m, 0, sizeof(*m));
   m->addr = addr;
@@ -948,6 +1175,7 @@ static void begin_mb(H264Oracle* d, int addr) {
   cur->mb_intra[addr] = 0;
   d->mb_slice[addr] = (int16_t)d->slice_index;
   d->mb_kind[addr] = MB_NONE;
+  m->qp = d->qp;
 }
 
 static void commit_mb(H264Oracle* d) {
@@ -958,7 +1186,7 @@ static void commit_mb(H264Oracle* d) {
   m->qpc[1] = chroma_qp_table[iclip(0, 51, m->qp + pps->chroma_qp_offset[1])];
   d->mb_kind[a] = (uint8_t)m->kind;
   d->mb_skip[a] = (uint8_t)m->skip;
-  d->mb_direct[a] = (uint8_t)(m->skip || m->direct16) && d->sl.type == 1;
+  d->mb_direct[a] = (uint8_t)((m->skip || m->direct16) && d->sl.type == 1);
   d->mb_t8x8[a] = (uint8_t)m->t8x8;
   d->mb_cbp[a] = (uint8_t)(m->kind == MB_IPCM ? 0x2f : m->cbp);
   d->mb_cbf_dc[a] = (uint8_t)m->cbf_dc;
@@ -978,20 +1206,30 @@ static void commit_mb(H264Oracle* d) {
   if (m->t8x8) d->counters[9]++;
 }
 
-static int decode_skip_mb(H264Oracle* d, int addr) {
-  begin_mb(d, addr);
+void h264i_pskip_mv(H264Oracle* d, int mv[2]) {
+  NB A = fetch_nb(d, 0, -1, 0, 0), B = fetch_nb(d, 0, 0, -1, 0);
+  mv[0] = mv[1] = 0;
+  if (!(A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) ||
+        (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
+    pred_mv(d, 0, 0, 0, 4, 0, PRED_MEDIAN, mv);
+}
+
+void h264i_pred_mv16(H264Oracle* d, int list, int ref, int mv[2]) {
+  pred_mv(d, list, 0, 0, 4, ref, PRED_MEDIAN, mv);
+}
+
+int h264i_pred_direct_mb(H264Oracle* d) { return pred_direct(d, -1); }
+
+static int code_skip_mb(H264Oracle* d, int addr) {
+  h264i_begin_mb(d, addr);
   MB* m = &d->mb;
   m->kind = MB_INTER;
   m->skip = 1;
-  m->qp = d->qp;
   d->last_qp_delta_nonzero = 0;
   if (d->sl.type == 0) {
     for (int q = 0; q < 4; ++q) set_ref8(d, 0, q, 0);
-    NB A = fetch_nb(d, 0, -1, 0, 0), B = fetch_nb(d, 0, 0, -1, 0);
-    int mv[2] = {0, 0};
-    if (!(A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) ||
-          (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
-      pred_mv(d, 0, 0, 0, 4, 0, PRED_MEDIAN, mv);
+    int mv[2];
+    h264i_pskip_mv(d, mv);
     set_mv_block(d, 0, 0, 0, 4, 4, mv[0], mv[1]);
   } else {
     m->direct16 = 1;
@@ -1003,14 +1241,14 @@ static int decode_skip_mb(H264Oracle* d, int addr) {
   return 0;
 }
 
-static int decode_mb(Rd* r, int addr) {
+static int code_mb(Rd* r, int addr) {
   H264Oracle* d = r->d;
-  Bits* b = r->b;
   const PPS* pps = d->apps;
-  begin_mb(d, addr);
+  const MB* P = r->enc ? &r->plan->mb : NULL;
+  h264i_begin_mb(d, addr);
   MB* m = &d->mb;
   const int st = d->sl.type;
-  int t = rd_mb_type(r);
+  int t = sx_mb_type(r, P ? P->mb_type_raw : 0);
   int intra_t = -1;
   if (st == 2) {
     intra_t = t;
@@ -1023,16 +1261,25 @@ static int decode_mb(Rd* r, int addr) {
   }
   if (intra_t > 25) return h264i_fail(d, "bad mb_type (I)");
   m->mb_type_raw = t;
-  m->qp = d->qp;
 
   if (intra_t == 25) { /* I_PCM */
     m->kind = MB_IPCM;
-    /* CABAC: the terminating bin consumed the encoder's flush including its
-     * final '1'; what follows are the pcm_alignment_zero_bits */
-    while (b->pos & 7) get_bit(b);
-    for (int i = 0; i < 384; ++i) m->pcm[i] = (uint8_t)get_bits(b, 8);
-    if (b->overrun) return h264i_fail(d, "truncated I_PCM");
-    if (r->cabac) cabac_start(&d->cabac, b);
+    if (r->enc) {
+      /* CABAC: the terminating bin flushed the arithmetic coder; its final
+       * '1' is followed by pcm_alignment_zero_bits */
+      while (r->w->pos & 7) bw_put(r->w, 0, 1);
+      for (int i = 0; i < 384; ++i) {
+        m->pcm[i] = P->pcm[i];
+        bw_put(r->w, m->pcm[i], 8);
+      }
+      if (r->cabac) cenc_start(&d->cenc, r->w);
+    } else {
+      Bits* b = r->b;
+      while (b->pos & 7) get_bit(b);
+      for (int i = 0; i < 384; ++i) m->pcm[i] = (uint8_t)get_bits(b, 8);
+      if (b->overrun) return h264i_fail(d, "truncated I_PCM");
+      if (r->cabac) cabac_start(&d->cabac, b);
+    }
     memset(m->nnz, 16, sizeof(m->nnz));
     m->cbf_dc = 7;
     d->last_qp_delta_nonzero = 0;
@@ -1044,23 +1291,24 @@ static int decode_mb(Rd* r, int addr) {
   if (intra_t >= 0) {
     if (intra_t == 0) {
       m->kind = MB_I4x4;
-      if (pps->transform_8x8_mode && rd_t8x8_flag(r)) {
+      if (pps->transform_8x8_mode && sx_t8x8_flag(r, P ? P->t8x8 : 0)) {
         m->kind = MB_I8x8;
         m->t8x8 = 1;
       }
-      if (m->kind == MB_I4x4) {
-        for (int k = 0; k < 16; ++k) {
-          const int bx = blk4_x[k], by = blk4_y[k];
-          int pm = predicted_intra_mode(d, bx, by);
-          int rem = rd_intra_pred_mode(r);
-          m->i4_mode[by * 4 + bx] = (int8_t)(rem < 0 ? pm : (rem < pm ? rem : rem + 1));
+      const int nblk = m->kind == MB_I4x4 ? 16 : 4;
+      for (int k = 0; k < nblk; ++k) {
+        const int bx = nblk == 16 ? blk4_x[k] : (k & 1) * 2, by = nblk == 16 ? blk4_y[k] : (k >> 1) * 2;
+        const int pm = predicted_intra_mode(d, bx, by);
+        int want = -1;
+        if (P) {
+          int target = P->i4_mode[by * 4 + bx];
+          want = target == pm ? -1 : (target < pm ? target : target - 1);
         }
-      } else {
-        for (int k = 0; k < 4; ++k) {
-          const int bx = (k & 1) * 2, by = (k >> 1) * 2;
-          int pm = predicted_intra_mode(d, bx, by);
-          int rem = rd_intra_pred_mode(r);
-          int mode = rem < 0 ? pm : (rem < pm ? rem : rem + 1);
+        int rem = sx_intra_pred_mode(r, want);
+        int mode = rem < 0 ? pm : (rem < pm ? rem : rem + 1);
+        if (nblk == 16) {
+          m->i4_mode[by * 4 + bx] = (int8_t)mode;
+        } else {
           for (int s = 0; s < 4; ++s) m->i4_mode[(by + (s >> 1)) * 4 + bx + (s & 1)] = (int8_t)mode;
         }
       }
@@ -1069,7 +1317,7 @@ static int decode_mb(Rd* r, int addr) {
       m->i16_mode = (intra_t - 1) & 3;
       m->cbp = (((intra_t - 1) >> 2) % 3) << 4 | ((intra_t - 1) >= 12 ? 15 : 0);
     }
-    m->chroma_mode = rd_chroma_pred_mode(r);
+    m->chroma_mode = sx_chroma_pred_mode(r, P ? P->chroma_mode : 0);
     if (m->chroma_mode > 3 || m->chroma_mode < 0) return h264i_fail(d, "bad intra_chroma_pred_mode");
     d->cur->mb_intra[addr] = 1;
   } else {
@@ -1079,12 +1327,12 @@ static int decode_mb(Rd* r, int addr) {
       memset(d->direct8 + addr * 4, 1, 4);
       if (pred_direct(d, -1) < 0) return -1;
     } else {
-      if (parse_inter(r, t) < 0) return -1;
+      if (code_inter(r, t) < 0) return -1;
     }
   }
 
   if (m->kind != MB_I16x16) {
-    int cbp = rd_cbp(r, m->kind != MB_INTER);
+    int cbp = sx_cbp(r, m->kind != MB_INTER, P ? P->cbp : 0);
     if (cbp < 0) return h264i_fail(d, "bad coded_block_pattern");
     m->cbp = cbp;
     if ((cbp & 15) && pps->transform_8x8_mode && m->kind == MB_INTER) {
@@ -1099,16 +1347,29 @@ static int decode_mb(Rd* r, int addr) {
           }
         }
       }
-      if (ok) m->t8x8 = rd_t8x8_flag(r);
+      if (ok) m->t8x8 = sx_t8x8_flag(r, P ? P->t8x8 : 0);
     }
   }
   if (m->cbp || m->kind == MB_I16x16) {
-    int dq = rd_qp_delta(r);
+    int want = 0;
+    if (P) {
+      want = P->qp - d->qp;
+      if (want > 25) want -= 52;
+      if (want < -26) want += 52;
+    }
+    int dq = sx_qp_delta(r, want);
     if (dq < -26 || dq > 25) return h264i_fail(d, "mb_qp_delta out of range");
     d->last_qp_delta_nonzero = dq != 0;
     d->qp = (d->qp + dq + 52) % 52;
     m->qp = d->qp;
-    if (parse_residual(r) < 0) return -1;
+    if (P) { /* the levels to write */
+      memcpy(m->luma_dc, P->luma_dc, sizeof(m->luma_dc));
+      memcpy(m->luma, P->luma, sizeof(m->luma));
+      memcpy(m->luma8, P->luma8, sizeof(m->luma8));
+      memcpy(m->chroma_dc, P->chroma_dc, sizeof(m->chroma_dc));
+      memcpy(m->chroma_ac, P->chroma_ac, sizeof(m->chroma_ac));
+    }
+    if (code_residual(r) < 0) return -1;
   } else {
     d->last_qp_delta_nonzero = 0;
   }
@@ -1118,13 +1379,23 @@ static int decode_mb(Rd* r, int addr) {
 }
 
 /* ======================================================================== */
-/* slice_data()                                                             */
+/* slice_data(): parse                                                      */
 /* ======================================================================== */
+static int skip_flag_ctx(H264Oracle* d, int addr) {
+  d->mb.addr = addr;
+  d->mb.mbx = addr % d->mbw;
+  d->mb.mby = addr / d->mbw;
+  int inc = 0;
+  if (mb_avail(d, d->mb.mbx - 1, d->mb.mby) && !d->mb_skip[addr - 1]) inc++;
+  if (mb_avail(d, d->mb.mbx, d->mb.mby - 1) && !d->mb_skip[addr - d->mbw]) inc++;
+  return (d->sl.type == 0 ? 11 : 24) + inc;
+}
+
 int h264i_decode_slice_data(H264Oracle* d, Bits* b) {
   Slice* sl = &d->sl;
   const PPS* pps = d->apps;
   const int nmb = d->mbw * d->mbh;
-  Rd r = {d, b, pps->cabac};
+  Rd r = {d, b, pps->cabac, 0, NULL, NULL};
   int addr = sl->first_mb;
   if (addr >= nmb) return h264i_fail(d, "first_mb_in_slice out of range");
   d->qp = sl->qp;
@@ -1140,19 +1411,11 @@ int h264i_decode_slice_data(H264Oracle* d, Bits* b) {
     for (;;) {
       if (addr >= nmb) return h264i_fail(d, "slice runs past the end of the picture");
       int skipped = 0;
-      if (sl->type != 2) {
-        d->mb.addr = addr;
-        d->mb.mbx = addr % d->mbw;
-        d->mb.mby = addr / d->mbw;
-        int inc = 0;
-        if (mb_avail(d, d->mb.mbx - 1, d->mb.mby) && !d->mb_skip[addr - 1]) inc++;
-        if (mb_avail(d, d->mb.mbx, d->mb.mby - 1) && !d->mb_skip[addr - d->mbw]) inc++;
-        skipped = cabac_bin(&d->cabac, (sl->type == 0 ? 11 : 24) + inc);
-      }
+      if (sl->type != 2) skipped = cabac_bin(&d->cabac, skip_flag_ctx(d, addr));
       if (skipped) {
-        if (decode_skip_mb(d, addr) < 0) return -1;
+        if (code_skip_mb(d, addr) < 0) return -1;
       } else {
-        if (decode_mb(&r, addr) < 0) return -1;
+        if (code_mb(&r, addr) < 0) return -1;
       }
       if (b->overrun) return h264i_fail(d, "slice data ran past the end of the NAL unit");
       ++addr;
@@ -1179,13 +1442,13 @@ int h264i_decode_slice_data(H264Oracle* d, Bits* b) {
       unsigned run = get_ue(b);
       if (run > (unsigned)(nmb - addr)) return h264i_fail(d, "mb_skip_run out of range");
       while (run--) {
-        if (decode_skip_mb(d, addr) < 0) return -1;
+        if (code_skip_mb(d, addr) < 0) return -1;
         ++addr;
       }
       if (!h264i_more_rbsp_data(b)) break;
     }
     if (addr >= nmb) return h264i_fail(d, "slice runs past the end of the picture");
-    if (decode_mb(&r, addr) < 0) return -1;
+    if (code_mb(&r, addr) < 0) return -1;
     if (b->overrun) return h264i_fail(d, "slice data ran past the end of the NAL unit");
     ++addr;
     if (!h264i_more_rbsp_data(b)) break;
@@ -1198,4 +1461,58 @@ int h264i_decode_slice_data(H264Oracle* d, Bits* b) {
     if (ok && !t.overrun) d->counters[1]++;
   }
   return 0;
+}
+
+/* ======================================================================== */
+/* slice_data(): write (corpus encoder)                                     */
+/* ======================================================================== */
+/* The caller has already parsed its own slice header through
+ * h264i_parse_slice_header (so reference lists, POC and the picture exist)
+ * and appended the same header bits to `w`. */
+void h264i_enc_begin_slice(H264Oracle* d, BitWriter* w) {
+  Slice* sl = &d->sl;
+  d->qp = sl->qp;
+  d->last_qp_delta_nonzero = 0;
+  d->counters[0]++;
+  d->cenc.outstanding = 0;
+  if (d->apps->cabac) {
+    while (w->pos & 7) bw_put(w, 1, 1); /* cabac_alignment_one_bit */
+    cabac_init_contexts(&d->cabac, sl->type, sl->cabac_init_idc, sl->qp);
+    cenc_start(&d->cenc, w);
+  }
+}
+
+int h264i_enc_mb(H264Oracle* d, BitWriter* w, int addr, const MbPlan* plan, int last_in_slice) {
+  const int cabac = d->apps->cabac;
+  Rd r = {d, NULL, cabac, 1, w, plan};
+  int rc;
+  if (cabac) {
+    if (d->sl.type != 2) cenc_bin(&d->cenc, &d->cabac.state[skip_flag_ctx(d, addr)], plan->is_skip);
+    rc = plan->is_skip ? code_skip_mb(d, addr) : code_mb(&r, addr);
+    if (rc < 0) return rc;
+    cenc_terminate(&d->cenc, last_in_slice);
+    return 0;
+  }
+  /* CAVLC: skip runs are written lazily in front of the next coded MB (or
+   * at the end of the slice); the count lives in cenc.outstanding, which is
+   * otherwise unused without CABAC. */
+  if (plan->is_skip) {
+    rc = code_skip_mb(d, addr);
+    d->cenc.outstanding++;
+    if (last_in_slice) {
+      bw_ue(w, d->cenc.outstanding);
+      d->cenc.outstanding = 0;
+    }
+    return rc;
+  }
+  if (d->sl.type != 2) {
+    bw_ue(w, d->cenc.outstanding);
+    d->cenc.outstanding = 0;
+  }
+  return code_mb(&r, addr);
+}
+
+void h264i_enc_end_slice(H264Oracle* d, BitWriter* w) {
+  if (!d->apps->cabac) bw_put(w, 1, 1); /* rbsp_stop_one_bit (CABAC: written by the flush) */
+  while (w->pos & 7) bw_put(w, 0, 1);
 }

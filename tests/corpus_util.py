@@ -1,0 +1,49 @@
+"""Helpers around the synthetic-corpus generator (corpus/h264_encoder.c)."""
+import os
+import subprocess
+
+import numpy as np
+
+from tests.util import ROOT
+
+ENCODER = os.path.join(ROOT, "corpus", "_build", "h264_encoder")
+
+
+def make_clip(path, width=320, height=240, yuv=True, **kw):
+    """Encodes a synthetic clip; returns the encoder's own reconstruction
+    (display order, cropped I420, one row per frame) when yuv=True."""
+    if not os.path.exists(ENCODER):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "corpus")])
+    args = [ENCODER, "--width", str(width), "--height", str(height), "--out", path]
+    ypath = path + ".yuv"
+    if yuv:
+        args += ["--yuv-out", ypath]
+    for k, v in kw.items():
+        args += ["--" + k.replace("_", "-"), str(v)]
+    r = subprocess.run(args, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("corpus encoder failed: " + r.stderr[-400:])
+    if not yuv:
+        return None
+    fs = width * height * 3 // 2
+    gold = np.fromfile(ypath, dtype=np.uint8).reshape(-1, fs)
+    os.unlink(ypath)
+    return gold
+
+
+# (name, kwargs): small clips that together touch every syntax path the
+# generator can emit
+MATRIX = [
+    ("ip_cabac_t8", dict(frames=10, gop=10, bframes=0, cabac=1, t8x8=1, refs=2)),
+    ("ibp_cabac", dict(frames=13, gop=13, bframes=2, cabac=1, t8x8=0, refs=2)),
+    ("ibp_cabac_t8", dict(frames=13, gop=13, bframes=2, cabac=1, t8x8=1, refs=2)),
+    ("ip_cavlc_baseline", dict(frames=8, gop=8, bframes=0, cabac=0, t8x8=0, refs=1)),
+    ("ibp_cavlc_t8", dict(frames=13, gop=7, bframes=2, cabac=0, t8x8=1, refs=3)),
+    ("slices3", dict(frames=10, gop=5, bframes=1, cabac=1, t8x8=1, refs=2, slices=3)),
+    ("temporal_implicit", dict(frames=10, gop=10, bframes=2, cabac=1, t8x8=1, temporal_direct=1, implicit_wp=1)),
+    ("deblock_idc2", dict(frames=7, gop=7, bframes=1, cabac=1, deblock=2, slices=2, alpha=2, beta=-1,
+                          chroma_qp_offset=-2)),
+    ("qp40", dict(frames=7, gop=7, bframes=2, qp=40)),
+    ("qp12", dict(frames=5, gop=5, bframes=2, qp=12)),
+    ("pcm", dict(frames=4, gop=4, bframes=1, pcm_period=37)),
+]
