@@ -1,0 +1,116 @@
+// The host -> GPU seam of the MI355X backend: what the host-side H.264
+// parser (entropy decode, motion-vector derivation, DPB) hands to the HIP
+// reconstruct kernels for one picture.  Everything serial and
+// context-dependent has been resolved on the host; what is left is
+// sample-parallel.
+//
+// Layout in HBM per picture (one "job", uploaded with one H2D copy per
+// array from a pinned staging slot):
+//   MbInfo   mb[num_mbs]        32 B each   macroblock header
+//   MbMotion motion[num_mbs]    144 B each  only for P/B pictures
+//   int16_t  coefs[...]         dense 16-coefficient groups, only for coded
+//                               transform blocks, addressed by
+//                               MbInfo::coef_offset + popcount(coded_mask)
+//   SliceParams slices[n]       weights / POCs / deblock offsets per slice
+// Surfaces (decoded pictures) are planar I420 of the CODED size, luma pitch a
+// multiple of 256 B so every macroblock row starts line-aligned.
+#pragma once
+
+#include <cstdint>
+
+namespace hwang {
+namespace amd {
+
+enum MbKind : uint8_t {
+  MBK_I4x4 = 0,
+  MBK_I8x8 = 1,
+  MBK_I16x16 = 2,
+  MBK_IPCM = 3,
+  MBK_INTER = 4,
+};
+
+// MbInfo::flags
+enum : uint8_t {
+  MBF_T8X8 = 1,        // transform_size_8x8_flag
+  MBF_INTRA = 2,
+  // intra-prediction availability of the neighbouring macroblocks (slice
+  // membership and constrained_intra_pred already applied)
+  MBF_AVAIL_A = 4,     // left
+  MBF_AVAIL_B = 8,     // top
+  MBF_AVAIL_C = 16,    // top-right
+  MBF_AVAIL_D = 32,    // top-left
+  // deblocking: which of this macroblock's outer edges are filtered
+  MBF_DB_LEFT = 64,
+  MBF_DB_TOP = 128,
+};
+
+// coded_mask bits: which 16-coefficient groups are present at coef_offset,
+// in this order.
+//   0..15  luma 4x4 block at raster position k (y*4+x); with MBF_T8X8 the
+//          8x8 block b8 sets bits 4*b8 .. 4*b8+3 and its 64 coefficients
+//          (raster 8x8) occupy those four groups
+//   16     Intra16x16 luma DC (16 values, raster = block position)
+//   17     chroma DC (Cb[4], Cr[4], 8 zeros)
+//   18..21 Cb AC blocks 0..3, 22..25 Cr AC blocks 0..3 (DC slot zero)
+// An I_PCM macroblock stores its 384 samples as 192 int16 (two bytes each,
+// little endian) and sets coded_mask = 0.
+constexpr int kMaskLumaDc = 16;
+constexpr int kMaskChromaDc = 17;
+constexpr int kMaskChromaAc = 18;
+
+struct MbInfo {
+  uint8_t kind;
+  uint8_t flags;
+  uint8_t qp;          // QP_Y (0 for I_PCM, as the deblocking filter wants)
+  uint8_t qpc[2];      // QP_C for Cb, Cr
+  uint8_t pred_modes;  // low nibble: Intra16x16 mode, high nibble: chroma mode
+  uint8_t slice;       // index into SliceParams
+  uint8_t deblock_internal;  // 1: internal edges filtered (idc != 1)
+  uint32_t coded_mask;
+  uint32_t coef_offset;      // in int16 units
+  uint8_t i4_modes[8];       // 16 x 4 bit, raster 4x4 order
+  uint16_t nz_mask;          // 4x4 luma blocks (raster) holding non-zero
+                             // coefficients, as the bS derivation sees them
+  uint8_t pad[6];
+};
+static_assert(sizeof(MbInfo) == 32, "MbInfo must stay 32 bytes");
+
+struct MbMotion {
+  int16_t mv[2][16][2];   // [list][raster 4x4][x, y] quarter samples
+  int8_t ref_slot[2][4];  // DPB surface per 8x8, -1 = list unused
+  int8_t ref_idx[2][4];   // index into the slice's list (for weights)
+};
+static_assert(sizeof(MbMotion) == 144, "MbMotion must stay 144 bytes");
+
+struct SliceParams {
+  int8_t alpha_offset, beta_offset;  // already multiplied by 2
+  uint8_t weight_mode;               // 0 default, 1 explicit, 2 implicit
+  uint8_t luma_log2_denom, chroma_log2_denom;
+  uint8_t pad[3];
+  int32_t cur_poc;
+  int16_t luma_weight[2][32], luma_offset[2][32];
+  int16_t chroma_weight[2][32][2], chroma_offset[2][32][2];
+  int32_t ref_poc[2][32];
+  uint8_t ref_long[2][32];
+};
+
+struct Surface {
+  uint8_t* y;
+  uint8_t* u;
+  uint8_t* v;
+};
+
+constexpr int kMaxSurfaces = 40;
+
+struct PictureParams {
+  int32_t mb_width, mb_height;
+  int32_t y_pitch, c_pitch;
+  int32_t cur_slot;
+  int32_t num_slices;
+  uint8_t scaling4[6][16];  // weightScale, raster order
+  uint8_t scaling8[2][64];
+  Surface surfaces[kMaxSurfaces];
+};
+
+}  // namespace amd
+}  // namespace hwang

@@ -1,0 +1,1033 @@
+// K1-K4: the sample-parallel half of H.264 decoding on CDNA4 (gfx950).
+//
+//   k_inter    K1+K2  every inter macroblock of a picture at once: dequant +
+//                     4x4 / 8x8 inverse transforms, quarter-sample luma and
+//                     eighth-sample chroma motion compensation (default,
+//                     explicit and implicit weighting), prediction + residual
+//   k_intra    K1+K3  intra macroblocks in dependency order: one workgroup
+//                     walks one macroblock row, rows hand their progress to
+//                     the row below through agent-scope release/acquire
+//   k_deblock  K4     in-loop deblocking filter, same row-wavefront scheme
+//
+// These replace what the reference gets from libavcodec's hl_decode_mb /
+// loop_filter behind avcodec_send_packet
+// (impls/software/software_video_decoder.cpp:353-357) and from NVDEC's
+// fixed-function pipeline (impls/nvidia/nvidia_video_decoder.cpp:335,489).
+// All arithmetic is 8-bit samples with <= 20-bit integer intermediates: these
+// are stencils on bytes, bound by memory latency/bandwidth -- no MFMA.
+//
+// Bit-exactness: every formula below is the oracle's (oracle/h264_recon.c),
+// i.e. ITU-T H.264 8.3 (intra), 8.4.2.2 (interpolation), 8.4.2.3 (weighting),
+// 8.5 (transforms), 8.7 (deblocking); tests/test_gpu_decode.py compares whole
+// pictures bit for bit.
+#include "frame_job.h"
+#include "prof.h"
+
+#include <hip/hip_runtime.h>
+
+namespace hwang {
+namespace amd {
+
+namespace {
+
+__constant__ uint8_t c_norm4[6][3] = {{10, 16, 13}, {11, 18, 14}, {13, 20, 16},
+                                      {14, 23, 18}, {16, 25, 20}, {18, 29, 23}};
+__constant__ uint8_t c_norm8[6][6] = {{20, 18, 32, 19, 25, 24}, {22, 19, 35, 21, 28, 26},
+                                      {26, 23, 42, 24, 33, 31}, {28, 25, 45, 26, 35, 33},
+                                      {32, 28, 51, 30, 40, 38}, {36, 32, 58, 34, 46, 43}};
+__constant__ uint8_t c_alpha[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,
+                                    0,  0,  0,  4,  4,  5,  6,  7,  8,  9,  10, 12, 13,
+                                    15, 17, 20, 22, 25, 28, 32, 36, 40, 45, 50, 56, 63,
+                                    71, 80, 90, 101, 113, 127, 144, 162, 182, 203, 226, 255, 255};
+__constant__ uint8_t c_beta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,
+                                   0,  0,  0,  2,  2,  2,  3,  3,  3,  3,  4,  4,  4,
+                                   6,  6,  7,  7,  8,  8,  9,  9,  10, 10, 11, 11, 12,
+                                   12, 13, 13, 14, 14, 15, 15, 16, 16, 17, 17, 18, 18};
+__constant__ uint8_t c_tc0[52][3] = {
+    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},
+    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 0},
+    {0, 0, 0},   {0, 0, 0},   {0, 0, 0},   {0, 0, 1},   {0, 0, 1},   {0, 0, 1},   {0, 0, 1},
+    {0, 1, 1},   {0, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 1},   {1, 1, 2},
+    {1, 1, 2},   {1, 1, 2},   {1, 1, 2},   {1, 2, 3},   {1, 2, 3},   {2, 2, 3},   {2, 2, 4},
+    {2, 3, 4},   {2, 3, 4},   {3, 3, 5},   {3, 4, 6},   {3, 4, 6},   {4, 5, 7},   {4, 5, 8},
+    {4, 6, 9},   {5, 7, 10},  {6, 8, 11},  {6, 8, 13},  {7, 10, 14}, {8, 11, 16}, {9, 12, 18},
+    {10, 13, 20}, {11, 15, 23}, {13, 17, 25}};
+// luma4x4BlkIdx (decode order) <-> raster position
+__constant__ uint8_t c_blk_x[16] = {0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3};
+__constant__ uint8_t c_blk_y[16] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3};
+__constant__ uint8_t c_raster_to_zz[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
+
+__device__ __forceinline__ int iclip(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+__device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+
+__device__ __forceinline__ int level_scale4(const uint8_t* weight, int qp, int pos) {
+  const int i = pos >> 2, j = pos & 3;
+  const int cls = ((i & 1) == 0 && (j & 1) == 0) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2);
+  return weight[pos] * c_norm4[qp % 6][cls];
+}
+__device__ __forceinline__ int level_scale8(const uint8_t* weight, int qp, int pos) {
+  const int i = pos >> 3, j = pos & 7;
+  int cls;
+  if ((i & 3) == 0 && (j & 3) == 0) cls = 0;
+  else if ((i & 1) && (j & 1)) cls = 1;
+  else if ((i & 3) == 2 && (j & 3) == 2) cls = 2;
+  else if (((i & 3) == 0 && (j & 1)) || ((i & 1) && (j & 3) == 0)) cls = 3;
+  else if (((i & 3) == 0 && (j & 3) == 2) || ((i & 3) == 2 && (j & 3) == 0)) cls = 4;
+  else cls = 5;
+  return weight[pos] * c_norm8[qp % 6][cls];
+}
+
+// coefficient group `g` of a macroblock, or nullptr when it was not coded
+__device__ __forceinline__ const int16_t* coef_group(const MbInfo& mb, const int16_t* coefs, int g) {
+  if (!((mb.coded_mask >> g) & 1)) return nullptr;
+  return coefs + mb.coef_offset + 16 * __popc(mb.coded_mask & ((1u << g) - 1));
+}
+
+// ---------------------------------------------------------------------------
+// Residual of one macroblock into LDS (256 threads cooperate).
+//   res_y[256]   luma residual, raster 16x16
+//   res_c[2][64] chroma residual, raster 8x8 per plane
+// `work` is 384 ints of scratch.
+// ---------------------------------------------------------------------------
+__device__ void mb_residual(const MbInfo& mb, const int16_t* coefs, const PictureParams& pp, int tid,
+                            int* work, int16_t* res_y, int16_t* res_c) {
+  const bool intra = mb.flags & MBF_INTRA;
+  const int qp = mb.qp;
+  int* dy = work;        // 256
+  int* dc = work + 256;  // 128
+  __shared__ int s_dc[16 + 8];
+
+  // ---- luma DC of Intra16x16: inverse Hadamard + scaling (8.5.10)
+  if (mb.kind == MBK_I16x16) {
+    const int16_t* g = coef_group(mb, coefs, kMaskLumaDc);
+    if (tid < 16) {
+      int f = 0;
+      if (g) {
+        const int i = tid >> 2, j = tid & 3;
+        // f = H c H with H = [[1,1,1,1],[1,1,-1,-1],[1,-1,-1,1],[1,-1,1,-1]]
+        const int hs[4][4] = {{1, 1, 1, 1}, {1, 1, -1, -1}, {1, -1, -1, 1}, {1, -1, 1, -1}};
+        for (int a = 0; a < 4; ++a)
+          for (int b = 0; b < 4; ++b) f += hs[i][a] * g[a * 4 + b] * hs[b][j];
+        const int ls = level_scale4(pp.scaling4[0], qp, 0);
+        f = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+      }
+      s_dc[tid] = f;
+    }
+  }
+  // ---- chroma DC: 2x2 Hadamard + scaling (8.5.11)
+  if (tid >= 16 && tid < 24) {
+    const int p = (tid - 16) >> 2, k = (tid - 16) & 3;
+    const int16_t* g = coef_group(mb, coefs, kMaskChromaDc);
+    int v = 0;
+    if (g) {
+      const int16_t* c = g + 4 * p;
+      const int f = k == 0 ? c[0] + c[1] + c[2] + c[3]
+                  : k == 1 ? c[0] - c[1] + c[2] - c[3]
+                  : k == 2 ? c[0] + c[1] - c[2] - c[3]
+                           : c[0] - c[1] - c[2] + c[3];
+      const int qpc = mb.qpc[p];
+      const int ls = level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, 0);
+      v = ((f * ls) << (qpc / 6)) >> 5;
+    }
+    s_dc[16 + (tid - 16)] = v;
+  }
+  __syncthreads();
+
+  // ---- scaling (8.5.12.1)
+  if (mb.flags & MBF_T8X8) {
+    const int b8 = tid >> 6, k = tid & 63;
+    const int16_t* g = coef_group(mb, coefs, 4 * b8);
+    int v = 0;
+    if (g) {
+      const int lv = g[k];  // the four groups of an 8x8 block are contiguous
+      if (lv) {
+        const int s = lv * level_scale8(pp.scaling8[intra ? 0 : 1], qp, k);
+        v = qp >= 36 ? s << (qp / 6 - 6) : (s + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+      }
+    }
+    dy[tid] = v;
+  } else {
+    const int blk = tid >> 4, k = tid & 15;
+    const int16_t* g = coef_group(mb, coefs, blk);
+    int v = 0;
+    if (g && g[k]) {
+      const int s = g[k] * level_scale4(pp.scaling4[intra ? 0 : 3], qp, k);
+      v = qp >= 24 ? s << (qp / 6 - 4) : (s + (1 << (3 - qp / 6))) >> (4 - qp / 6);
+    }
+    if (k == 0 && mb.kind == MBK_I16x16) v = s_dc[blk];
+    dy[tid] = v;
+  }
+  if (tid < 128) {
+    const int p = tid >> 6, blk = (tid >> 4) & 3, k = tid & 15;
+    const int16_t* g = coef_group(mb, coefs, kMaskChromaAc + 4 * p + blk);
+    int v = 0;
+    const int qpc = mb.qpc[p];
+    if (g && g[k]) {
+      const int s = g[k] * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, k);
+      v = qpc >= 24 ? s << (qpc / 6 - 4) : (s + (1 << (3 - qpc / 6))) >> (4 - qpc / 6);
+    }
+    if (k == 0) v = s_dc[16 + 4 * p + blk];
+    dc[tid] = v;
+  }
+  __syncthreads();
+
+  // ---- rows
+  if (mb.flags & MBF_T8X8) {
+    if (tid < 32) {
+      int* d = dy + (tid >> 3) * 64 + (tid & 7) * 8;
+      const int d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
+      const int e0 = d0 + d4, e1 = -d3 + d5 - d7 - (d7 >> 1), e2 = d0 - d4, e3 = d1 + d7 - d3 - (d3 >> 1);
+      const int e4 = (d2 >> 1) - d6, e5 = -d1 + d7 + d5 + (d5 >> 1), e6 = d2 + (d6 >> 1), e7 = d3 + d5 + d1 + (d1 >> 1);
+      const int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
+      const int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+      d[0] = f0 + f7; d[1] = f2 + f5; d[2] = f4 + f3; d[3] = f6 + f1;
+      d[4] = f6 - f1; d[5] = f4 - f3; d[6] = f2 - f5; d[7] = f0 - f7;
+    }
+  } else if (tid < 64) {
+    int* d = dy + (tid >> 2) * 16 + (tid & 3) * 4;
+    const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
+    d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
+  }
+  if (tid >= 64 && tid < 96) {
+    const int t = tid - 64;
+    int* d = dc + (t >> 2) * 16 + (t & 3) * 4;
+    const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
+    d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
+  }
+  __syncthreads();
+
+  // ---- columns, rounding, scatter to raster
+  if (mb.flags & MBF_T8X8) {
+    if (tid < 32) {
+      const int b8 = tid >> 3, c = tid & 7;
+      const int* d = dy + b8 * 64 + c;
+      const int d0 = d[0], d1 = d[8], d2 = d[16], d3 = d[24], d4 = d[32], d5 = d[40], d6 = d[48], d7 = d[56];
+      const int e0 = d0 + d4, e1 = -d3 + d5 - d7 - (d7 >> 1), e2 = d0 - d4, e3 = d1 + d7 - d3 - (d3 >> 1);
+      const int e4 = (d2 >> 1) - d6, e5 = -d1 + d7 + d5 + (d5 >> 1), e6 = d2 + (d6 >> 1), e7 = d3 + d5 + d1 + (d1 >> 1);
+      const int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
+      const int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+      const int o[8] = {f0 + f7, f2 + f5, f4 + f3, f6 + f1, f6 - f1, f4 - f3, f2 - f5, f0 - f7};
+      const int x = (b8 & 1) * 8 + c, y0 = (b8 >> 1) * 8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) res_y[(y0 + r) * 16 + x] = (int16_t)((o[r] + 32) >> 6);
+    }
+  } else if (tid < 64) {
+    const int blk = tid >> 2, c = tid & 3;
+    const int* d = dy + blk * 16 + c;
+    const int e0 = d[0] + d[8], e1 = d[0] - d[8], e2 = (d[4] >> 1) - d[12], e3 = d[4] + (d[12] >> 1);
+    const int x = (blk & 3) * 4 + c, y0 = (blk >> 2) * 4;
+    res_y[(y0 + 0) * 16 + x] = (int16_t)((e0 + e3 + 32) >> 6);
+    res_y[(y0 + 1) * 16 + x] = (int16_t)((e1 + e2 + 32) >> 6);
+    res_y[(y0 + 2) * 16 + x] = (int16_t)((e1 - e2 + 32) >> 6);
+    res_y[(y0 + 3) * 16 + x] = (int16_t)((e0 - e3 + 32) >> 6);
+  }
+  if (tid >= 64 && tid < 96) {
+    const int t = tid - 64, pb = t >> 2, c = t & 3;  // pb = plane*4 + blk
+    const int* d = dc + pb * 16 + c;
+    const int e0 = d[0] + d[8], e1 = d[0] - d[8], e2 = (d[4] >> 1) - d[12], e3 = d[4] + (d[12] >> 1);
+    const int p = pb >> 2, blk = pb & 3;
+    const int x = (blk & 1) * 4 + c, y0 = (blk >> 1) * 4;
+    int16_t* r = res_c + p * 64;
+    r[(y0 + 0) * 8 + x] = (int16_t)((e0 + e3 + 32) >> 6);
+    r[(y0 + 1) * 8 + x] = (int16_t)((e1 + e2 + 32) >> 6);
+    r[(y0 + 2) * 8 + x] = (int16_t)((e1 - e2 + 32) >> 6);
+    r[(y0 + 3) * 8 + x] = (int16_t)((e0 - e3 + 32) >> 6);
+  }
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// Motion compensation, one sample (8.4.2.2).  Reference coordinates are
+// clamped to the picture (unrestricted motion vectors).
+// ---------------------------------------------------------------------------
+struct RefPlane {
+  const uint8_t* p;
+  int pitch, w, h;
+};
+__device__ __forceinline__ int rpx(const RefPlane& r, int x, int y) {
+  x = iclip(0, r.w - 1, x);
+  y = iclip(0, r.h - 1, y);
+  return r.p[y * r.pitch + x];
+}
+__device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
+__device__ __forceinline__ int b1(const RefPlane& r, int x, int y) {
+  return tap6(rpx(r, x - 2, y), rpx(r, x - 1, y), rpx(r, x, y), rpx(r, x + 1, y), rpx(r, x + 2, y), rpx(r, x + 3, y));
+}
+__device__ __forceinline__ int h1(const RefPlane& r, int x, int y) {
+  return tap6(rpx(r, x, y - 2), rpx(r, x, y - 1), rpx(r, x, y), rpx(r, x, y + 1), rpx(r, x, y + 2), rpx(r, x, y + 3));
+}
+__device__ int luma_sample(const RefPlane& r, int x, int y, int fx, int fy) {
+  if ((fx | fy) == 0) return rpx(r, x, y);
+  if (fy == 0) {
+    const int b = clip8((b1(r, x, y) + 16) >> 5);
+    return fx == 2 ? b : (fx == 1 ? (rpx(r, x, y) + b + 1) >> 1 : (rpx(r, x + 1, y) + b + 1) >> 1);
+  }
+  if (fx == 0) {
+    const int h = clip8((h1(r, x, y) + 16) >> 5);
+    return fy == 2 ? h : (fy == 1 ? (rpx(r, x, y) + h + 1) >> 1 : (rpx(r, x, y + 1) + h + 1) >> 1);
+  }
+  if (fx == 2 || fy == 2) {
+    const int j1 = tap6(b1(r, x, y - 2), b1(r, x, y - 1), b1(r, x, y), b1(r, x, y + 1), b1(r, x, y + 2), b1(r, x, y + 3));
+    const int j = clip8((j1 + 512) >> 10);
+    if (fx == 2 && fy == 2) return j;
+    if (fx == 2) {
+      const int b = clip8((b1(r, x, fy == 1 ? y : y + 1) + 16) >> 5);
+      return (b + j + 1) >> 1;
+    }
+    const int h = clip8((h1(r, fx == 1 ? x : x + 1, y) + 16) >> 5);
+    return (h + j + 1) >> 1;
+  }
+  const int b = clip8((b1(r, x, fy == 1 ? y : y + 1) + 16) >> 5);
+  const int h = clip8((h1(r, fx == 1 ? x : x + 1, y) + 16) >> 5);
+  return (b + h + 1) >> 1;
+}
+__device__ __forceinline__ int chroma_sample(const RefPlane& r, int x, int y, int fx, int fy) {
+  const int A = rpx(r, x, y), B = rpx(r, x + 1, y), C = rpx(r, x, y + 1), D = rpx(r, x + 1, y + 1);
+  return ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
+}
+
+__device__ int implicit_w1(const SliceParams& sp, int r0, int r1) {
+  if (sp.ref_long[0][r0] || sp.ref_long[1][r1]) return 32;
+  const int tb = iclip(-128, 127, sp.cur_poc - sp.ref_poc[0][r0]);
+  const int td = iclip(-128, 127, sp.ref_poc[1][r1] - sp.ref_poc[0][r0]);
+  if (td == 0) return 32;
+  const int tx = (16384 + iabs(td / 2)) / td;
+  const int dsf = iclip(-1024, 1023, (tb * tx + 32) >> 6);
+  const int w = dsf >> 2;
+  return (w >= -64 && w <= 128) ? w : 32;
+}
+
+// weighted combination of up to two predictions (8.4.2.3); plane 0 luma, 1/2 chroma
+__device__ int combine_pred(const SliceParams& sp, int plane, bool use0, bool use1, int s0, int s1, int r0, int r1) {
+  if (sp.weight_mode == 1) {
+    const int ld = plane ? sp.chroma_log2_denom : sp.luma_log2_denom;
+    int w0 = 0, w1 = 0, o0 = 0, o1 = 0;
+    if (use0) {
+      w0 = plane ? sp.chroma_weight[0][r0][plane - 1] : sp.luma_weight[0][r0];
+      o0 = plane ? sp.chroma_offset[0][r0][plane - 1] : sp.luma_offset[0][r0];
+    }
+    if (use1) {
+      w1 = plane ? sp.chroma_weight[1][r1][plane - 1] : sp.luma_weight[1][r1];
+      o1 = plane ? sp.chroma_offset[1][r1][plane - 1] : sp.luma_offset[1][r1];
+    }
+    int v;
+    if (use0 && use1) {
+      v = ((s0 * w0 + s1 * w1 + (1 << ld)) >> (ld + 1)) + ((o0 + o1 + 1) >> 1);
+    } else {
+      const int sv = use0 ? s0 : s1, w = use0 ? w0 : w1, o = use0 ? o0 : o1;
+      v = ld >= 1 ? ((sv * w + (1 << (ld - 1))) >> ld) + o : sv * w + o;
+    }
+    return clip8(v);
+  }
+  if (use0 && use1) {
+    if (sp.weight_mode == 2) {
+      const int w1 = implicit_w1(sp, r0, r1), w0 = 64 - w1;
+      return clip8((s0 * w0 + s1 * w1 + 32) >> 6);
+    }
+    return (s0 + s1 + 1) >> 1;
+  }
+  return use0 ? s0 : s1;
+}
+
+}  // namespace
+
+// ===========================================================================
+// k_inter: one workgroup (256 threads) per macroblock; intra macroblocks exit.
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_inter(PictureParams pp, const MbInfo* __restrict__ mbs,
+                                               const MbMotion* __restrict__ motions,
+                                               const int16_t* __restrict__ coefs,
+                                               const SliceParams* __restrict__ slices) {
+  const int mbi = blockIdx.x;
+  const MbInfo mb = mbs[mbi];
+  if (mb.kind != MBK_INTER) return;
+  const int tid = threadIdx.x;
+  const int mbx = mbi % pp.mb_width, mby = mbi / pp.mb_width;
+  __shared__ int work[384];
+  __shared__ int16_t res_y[256];
+  __shared__ int16_t res_c[128];
+  __shared__ MbMotion mo;
+  // stage the motion record (144 B) through LDS
+  if (tid < 36) reinterpret_cast<uint32_t*>(&mo)[tid] = reinterpret_cast<const uint32_t*>(&motions[mbi])[tid];
+  mb_residual(mb, coefs, pp, tid, work, res_y, res_c);  // ends with a barrier
+
+  const SliceParams& sp = slices[mb.slice];
+  const Surface cur = pp.surfaces[pp.cur_slot];
+  const int W = pp.mb_width * 16, H = pp.mb_height * 16;
+  {  // luma: one sample per thread
+    const int x = tid & 15, y = tid >> 4;
+    const int blk = (y >> 2) * 4 + (x >> 2), b8 = (y >> 3) * 2 + (x >> 3);
+    const int r0 = mo.ref_idx[0][b8], r1 = mo.ref_idx[1][b8];
+    const int px = mbx * 16 + x, py = mby * 16 + y;
+    int s0 = 0, s1 = 0;
+    if (r0 >= 0) {
+      const RefPlane rp{pp.surfaces[mo.ref_slot[0][b8]].y, pp.y_pitch, W, H};
+      const int mvx = mo.mv[0][blk][0], mvy = mo.mv[0][blk][1];
+      s0 = luma_sample(rp, px + (mvx >> 2), py + (mvy >> 2), mvx & 3, mvy & 3);
+    }
+    if (r1 >= 0) {
+      const RefPlane rp{pp.surfaces[mo.ref_slot[1][b8]].y, pp.y_pitch, W, H};
+      const int mvx = mo.mv[1][blk][0], mvy = mo.mv[1][blk][1];
+      s1 = luma_sample(rp, px + (mvx >> 2), py + (mvy >> 2), mvx & 3, mvy & 3);
+    }
+    const int pred = combine_pred(sp, 0, r0 >= 0, r1 >= 0, s0, s1, r0, r1);
+    cur.y[py * pp.y_pitch + px] = (uint8_t)clip8(pred + res_y[tid]);
+  }
+  if (tid < 128) {  // chroma: 64 samples per plane
+    const int plane = tid >> 6, x = tid & 7, y = (tid >> 3) & 7;
+    const int blk = (y >> 1) * 4 + (x >> 1), b8 = (y >> 2) * 2 + (x >> 2);
+    const int r0 = mo.ref_idx[0][b8], r1 = mo.ref_idx[1][b8];
+    const int px = mbx * 8 + x, py = mby * 8 + y;
+    int s0 = 0, s1 = 0;
+    if (r0 >= 0) {
+      const Surface& s = pp.surfaces[mo.ref_slot[0][b8]];
+      const RefPlane rp{plane ? s.v : s.u, pp.c_pitch, W / 2, H / 2};
+      const int mvx = mo.mv[0][blk][0], mvy = mo.mv[0][blk][1];
+      s0 = chroma_sample(rp, px + (mvx >> 3), py + (mvy >> 3), mvx & 7, mvy & 7);
+    }
+    if (r1 >= 0) {
+      const Surface& s = pp.surfaces[mo.ref_slot[1][b8]];
+      const RefPlane rp{plane ? s.v : s.u, pp.c_pitch, W / 2, H / 2};
+      const int mvx = mo.mv[1][blk][0], mvy = mo.mv[1][blk][1];
+      s1 = chroma_sample(rp, px + (mvx >> 3), py + (mvy >> 3), mvx & 7, mvy & 7);
+    }
+    const int pred = combine_pred(sp, 1 + plane, r0 >= 0, r1 >= 0, s0, s1, r0, r1);
+    uint8_t* dst = plane ? cur.v : cur.u;
+    dst[py * pp.c_pitch + px] = (uint8_t)clip8(pred + res_c[plane * 64 + y * 8 + x]);
+  }
+}
+
+// ===========================================================================
+// Row-wavefront plumbing shared by k_intra and k_deblock.
+//   sync[0]            ticket counter: workgroups take rows in arrival order,
+//                      so a row only ever waits on rows taken earlier
+//   sync[1 + r]        number of macroblocks of row r that are complete
+// The producer publishes with an agent-scope release, the consumer polls
+// relaxed and acquires once (cdna guide, guideline 16).
+// ===========================================================================
+namespace {
+
+__device__ __forceinline__ void publish_progress(unsigned* slot, unsigned value, int tid) {
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// returns false on timeout (the caller records it and carries on; the host
+// reports the failure instead of hanging the queue)
+__device__ __forceinline__ bool wait_progress(unsigned* slot, unsigned need, int tid, unsigned* timeout_word) {
+  __shared__ int s_ok;
+  if (tid == 0) {
+    int ok = 1;
+    unsigned spins = 0;
+    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 26)) {
+        ok = 0;
+        __hip_atomic_store(timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_ok = ok;
+  }
+  __syncthreads();
+  return s_ok != 0;
+}
+
+// ---- intra prediction helpers working on an LDS tile -----------------------
+// tile: 17 rows x 28 columns (stride 28): row 0 / col 0 hold the neighbours
+// (tile[0][0] = top-left, tile[0][1..16] = top, tile[0][17..24] = top-right of
+// the MB, tile[1..16][0] = left), interior = current macroblock.
+constexpr int TS = 28;
+
+__device__ int pred4x4_sample(const uint8_t* t /* block origin in tile */, int mode, int x, int y, bool hl, bool ht,
+                              bool htl, bool htr) {
+  // neighbours of this 4x4 block
+  auto T = [&](int i) -> int {  // p[i, -1], i in -1..7
+    if (i < 0) return htl ? t[-TS - 1] : 128;
+    if (!ht) return 128;
+    if (i > 3 && !htr) return t[-TS + 3];
+    return t[-TS + i];
+  };
+  auto L = [&](int j) -> int {  // p[-1, j], j in -1..3
+    if (j < 0) return htl ? t[-TS - 1] : 128;
+    return hl ? t[j * TS - 1] : 128;
+  };
+  switch (mode) {
+    case 0: return T(x);
+    case 1: return L(y);
+    case 2:
+      if (ht && hl) return (T(0) + T(1) + T(2) + T(3) + L(0) + L(1) + L(2) + L(3) + 4) >> 3;
+      if (hl) return (L(0) + L(1) + L(2) + L(3) + 2) >> 2;
+      if (ht) return (T(0) + T(1) + T(2) + T(3) + 2) >> 2;
+      return 128;
+    case 3: return (x == 3 && y == 3) ? (T(6) + 3 * T(7) + 2) >> 2 : (T(x + y) + 2 * T(x + y + 1) + T(x + y + 2) + 2) >> 2;
+    case 4:
+      if (x > y) return (T(x - y - 2) + 2 * T(x - y - 1) + T(x - y) + 2) >> 2;
+      if (x < y) return (L(y - x - 2) + 2 * L(y - x - 1) + L(y - x) + 2) >> 2;
+      return (T(0) + 2 * T(-1) + L(0) + 2) >> 2;
+    case 5: {
+      const int z = 2 * x - y;
+      if (z >= 0 && !(z & 1)) return (T(x - (y >> 1) - 1) + T(x - (y >> 1)) + 1) >> 1;
+      if (z >= 0) return (T(x - (y >> 1) - 2) + 2 * T(x - (y >> 1) - 1) + T(x - (y >> 1)) + 2) >> 2;
+      if (z == -1) return (L(0) + 2 * T(-1) + T(0) + 2) >> 2;
+      return (L(y - 1) + 2 * L(y - 2) + L(y - 3) + 2) >> 2;
+    }
+    case 6: {
+      const int z = 2 * y - x;
+      if (z >= 0 && !(z & 1)) return (L(y - (x >> 1) - 1) + L(y - (x >> 1)) + 1) >> 1;
+      if (z >= 0) return (L(y - (x >> 1) - 2) + 2 * L(y - (x >> 1) - 1) + L(y - (x >> 1)) + 2) >> 2;
+      if (z == -1) return (L(0) + 2 * T(-1) + T(0) + 2) >> 2;
+      return (T(x - 1) + 2 * T(x - 2) + T(x - 3) + 2) >> 2;
+    }
+    case 7:
+      if (!(y & 1)) return (T(x + (y >> 1)) + T(x + (y >> 1) + 1) + 1) >> 1;
+      return (T(x + (y >> 1)) + 2 * T(x + (y >> 1) + 1) + T(x + (y >> 1) + 2) + 2) >> 2;
+    default: {
+      const int z = x + 2 * y;
+      if (z > 5) return L(3);
+      if (z == 5) return (L(2) + 3 * L(3) + 2) >> 2;
+      if (!(z & 1)) return (L(y + (x >> 1)) + L(y + (x >> 1) + 1) + 1) >> 1;
+      return (L(y + (x >> 1)) + 2 * L(y + (x >> 1) + 1) + L(y + (x >> 1) + 2) + 2) >> 2;
+    }
+  }
+}
+
+// Intra 8x8: `ft` = filtered top (16) , `fl` = filtered left (8), ftl corner;
+// prepared by the caller (8.3.2.2.1).
+__device__ int pred8x8_sample(const int* ft, const int* fl, int ftl, int mode, int x, int y, bool hl, bool ht) {
+  auto T = [&](int i) -> int { return i < 0 ? ftl : ft[i]; };
+  auto L = [&](int j) -> int { return j < 0 ? ftl : fl[j]; };
+  switch (mode) {
+    case 0: return T(x);
+    case 1: return L(y);
+    case 2: {
+      int st = 0, sl = 0;
+      for (int i = 0; i < 8; ++i) {
+        st += ft[i];
+        sl += fl[i];
+      }
+      if (ht && hl) return (st + sl + 8) >> 4;
+      if (hl) return (sl + 4) >> 3;
+      if (ht) return (st + 4) >> 3;
+      return 128;
+    }
+    case 3: return (x == 7 && y == 7) ? (T(14) + 3 * T(15) + 2) >> 2 : (T(x + y) + 2 * T(x + y + 1) + T(x + y + 2) + 2) >> 2;
+    case 4:
+      if (x > y) return (T(x - y - 2) + 2 * T(x - y - 1) + T(x - y) + 2) >> 2;
+      if (x < y) return (L(y - x - 2) + 2 * L(y - x - 1) + L(y - x) + 2) >> 2;
+      return (T(0) + 2 * ftl + L(0) + 2) >> 2;
+    case 5: {
+      const int z = 2 * x - y;
+      if (z >= 0 && !(z & 1)) return (T(x - (y >> 1) - 1) + T(x - (y >> 1)) + 1) >> 1;
+      if (z >= 0) return (T(x - (y >> 1) - 2) + 2 * T(x - (y >> 1) - 1) + T(x - (y >> 1)) + 2) >> 2;
+      if (z == -1) return (L(0) + 2 * ftl + T(0) + 2) >> 2;
+      return (L(y - 2 * x - 1) + 2 * L(y - 2 * x - 2) + L(y - 2 * x - 3) + 2) >> 2;
+    }
+    case 6: {
+      const int z = 2 * y - x;
+      if (z >= 0 && !(z & 1)) return (L(y - (x >> 1) - 1) + L(y - (x >> 1)) + 1) >> 1;
+      if (z >= 0) return (L(y - (x >> 1) - 2) + 2 * L(y - (x >> 1) - 1) + L(y - (x >> 1)) + 2) >> 2;
+      if (z == -1) return (L(0) + 2 * ftl + T(0) + 2) >> 2;
+      return (T(x - 2 * y - 1) + 2 * T(x - 2 * y - 2) + T(x - 2 * y - 3) + 2) >> 2;
+    }
+    case 7:
+      if (!(y & 1)) return (T(x + (y >> 1)) + T(x + (y >> 1) + 1) + 1) >> 1;
+      return (T(x + (y >> 1)) + 2 * T(x + (y >> 1) + 1) + T(x + (y >> 1) + 2) + 2) >> 2;
+    default: {
+      const int z = x + 2 * y;
+      if (z > 13) return L(7);
+      if (z == 13) return (L(6) + 3 * L(7) + 2) >> 2;
+      if (!(z & 1)) return (L(y + (x >> 1)) + L(y + (x >> 1) + 1) + 1) >> 1;
+      return (L(y + (x >> 1)) + 2 * L(y + (x >> 1) + 1) + L(y + (x >> 1) + 2) + 2) >> 2;
+    }
+  }
+}
+
+}  // namespace
+
+// ===========================================================================
+// k_intra: grid = mb_height workgroups of 256 threads.
+// ===========================================================================
+__global__ __launch_bounds__(256) void k_intra(PictureParams pp, const MbInfo* __restrict__ mbs,
+                                               const int16_t* __restrict__ coefs, unsigned* sync) {
+  const int tid = threadIdx.x;
+  __shared__ int s_row;
+  if (tid == 0) s_row = (int)atomicAdd(&sync[0], 1u);
+  __syncthreads();
+  const int mby = s_row;
+  if (mby >= pp.mb_height) return;
+  unsigned* progress = sync + 2;
+  unsigned* timeout_word = sync + 1;
+
+  __shared__ int work[384];
+  __shared__ int16_t res_y[256];
+  __shared__ int16_t res_c[128];
+  __shared__ uint8_t tile[17 * TS];
+  __shared__ uint8_t ctile[2][9 * 12];  // chroma: 9 rows x (1 + 8) cols, stride 12
+  __shared__ int f_top[16], f_left[8], f_tl;
+
+  const Surface cur = pp.surfaces[pp.cur_slot];
+  const int yp = pp.y_pitch, cp = pp.c_pitch;
+
+  for (int mbx = 0; mbx < pp.mb_width; ++mbx) {
+    const int mbi = mby * pp.mb_width + mbx;
+    const MbInfo mb = mbs[mbi];
+    if (!(mb.flags & MBF_INTRA)) {
+      // nothing to do here, but rows below still count macroblocks
+      if (tid == 0) __hip_atomic_store(&progress[mby], (unsigned)(mbx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    // the row above must be done up to the top-right neighbour
+    if (mby > 0 && (mb.flags & (MBF_AVAIL_B | MBF_AVAIL_C | MBF_AVAIL_D))) {
+      const unsigned need = (unsigned)min(mbx + 2, pp.mb_width);
+      wait_progress(&progress[mby - 1], need, tid, timeout_word);
+    }
+    uint8_t* dy = cur.y + (size_t)(mby * 16) * yp + mbx * 16;
+    uint8_t* du = cur.u + (size_t)(mby * 8) * cp + mbx * 8;
+    uint8_t* dv = cur.v + (size_t)(mby * 8) * cp + mbx * 8;
+
+    if (mb.kind == MBK_IPCM) {
+      const uint8_t* pcm = reinterpret_cast<const uint8_t*>(coefs + mb.coef_offset);
+      dy[(tid >> 4) * yp + (tid & 15)] = pcm[tid];
+      if (tid < 64) du[(tid >> 3) * cp + (tid & 7)] = pcm[256 + tid];
+      else if (tid < 128) dv[((tid - 64) >> 3) * cp + (tid & 7)] = pcm[320 + tid - 64];
+      publish_progress(&progress[mby], (unsigned)(mbx + 1), tid);
+      continue;
+    }
+
+    mb_residual(mb, coefs, pp, tid, work, res_y, res_c);
+
+    const bool hA = mb.flags & MBF_AVAIL_A, hB = mb.flags & MBF_AVAIL_B;
+    const bool hC = mb.flags & MBF_AVAIL_C, hD = mb.flags & MBF_AVAIL_D;
+    // neighbours into the tiles (the left column comes from global too: it
+    // was written by this workgroup one iteration ago, ordered by the
+    // barriers in between)
+    if (tid < 25) tile[tid] = (tid == 0) ? (hD ? dy[-yp - 1] : 128)
+                              : (tid <= 16) ? (hB ? dy[-yp + tid - 1] : 128)
+                                            : (hC ? dy[-yp + tid - 1] : 128);
+    if (tid >= 32 && tid < 48) tile[(tid - 31) * TS] = hA ? dy[(tid - 32) * yp - 1] : 128;
+    if (tid >= 64 && tid < 82) {
+      const int p = (tid - 64) / 9, i = (tid - 64) % 9;
+      const uint8_t* d = p ? dv : du;
+      ctile[p][i] = (i == 0) ? (hD ? d[-cp - 1] : 128) : (hB ? d[-cp + i - 1] : 128);
+    }
+    if (tid >= 96 && tid < 112) {
+      const int p = (tid - 96) >> 3, j = (tid - 96) & 7;
+      const uint8_t* d = p ? dv : du;
+      ctile[p][(j + 1) * 12] = hA ? d[j * cp - 1] : 128;
+    }
+    __syncthreads();
+
+    const int x = tid & 15, y = tid >> 4;
+    if (mb.kind == MBK_I16x16) {
+      const int mode = mb.pred_modes & 15;
+      int v;
+      if (mode == 0) v = tile[1 + x];
+      else if (mode == 1) v = tile[(1 + y) * TS];
+      else if (mode == 2) {
+        int st = 0, sl = 0;
+        for (int i = 0; i < 16; ++i) {
+          st += tile[1 + i];
+          sl += tile[(1 + i) * TS];
+        }
+        v = (hB && hA) ? (st + sl + 16) >> 5 : hA ? (sl + 8) >> 4 : hB ? (st + 8) >> 4 : 128;
+      } else {
+        int Hh = 0, Vv = 0;
+        for (int k = 0; k < 8; ++k) {
+          Hh += (k + 1) * (tile[1 + 8 + k] - tile[1 + 6 - k]);          // 6-k == -1 -> tile[0]
+          Vv += (k + 1) * (tile[(1 + 8 + k) * TS] - tile[(1 + 6 - k) * TS]);
+        }
+        const int a = 16 * (tile[16 * TS] + tile[16]);
+        const int b = (5 * Hh + 32) >> 6, c = (5 * Vv + 32) >> 6;
+        v = clip8((a + b * (x - 7) + c * (y - 7) + 16) >> 5);
+      }
+      dy[y * yp + x] = (uint8_t)clip8(v + res_y[tid]);
+    } else if (mb.kind == MBK_I4x4) {
+      for (int k = 0; k < 16; ++k) {  // decode order
+        const int bx = c_blk_x[k], by = c_blk_y[k];
+        if (tid < 16) {
+          const int px = tid & 3, py = tid >> 2;
+          // neighbour availability of this block
+          const bool hl = bx > 0 || hA, ht = by > 0 || hB;
+          const bool htl = (bx > 0 && by > 0) ? true : (bx > 0) ? hB : (by > 0) ? hA : hD;
+          bool htr;
+          if (by == 0) htr = bx < 3 ? hB : hC;
+          else if (bx == 3) htr = false;
+          else htr = c_raster_to_zz[(by - 1) * 4 + bx + 1] < k;
+          const int raster = by * 4 + bx;
+          const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
+          const uint8_t* t = tile + (1 + by * 4) * TS + 1 + bx * 4;
+          const int v = pred4x4_sample(t, mode, px, py, hl, ht, htl, htr);
+          const int out = clip8(v + res_y[(by * 4 + py) * 16 + bx * 4 + px]);
+          // all 16 samples are predicted before any is overwritten
+          __builtin_amdgcn_wave_barrier();
+          tile[(1 + by * 4 + py) * TS + 1 + bx * 4 + px] = (uint8_t)out;
+        }
+        __syncthreads();
+      }
+      dy[y * yp + x] = tile[(1 + y) * TS + 1 + x];
+    } else {  // MBK_I8x8
+      for (int b8 = 0; b8 < 4; ++b8) {
+        const int bx = (b8 & 1) * 8, by = (b8 >> 1) * 8;
+        const bool hl = bx > 0 || hA, ht = by > 0 || hB;
+        const bool htl = (bx > 0 && by > 0) ? true : (bx > 0) ? hB : (by > 0) ? hA : hD;
+        const bool htr = b8 == 0 ? hB : b8 == 1 ? hC : b8 == 2;
+        const uint8_t* t = tile + (1 + by) * TS + 1 + bx;
+        // reference sample filtering (8.3.2.2.1)
+        if (tid < 16) {
+          int v = 128;
+          if (ht) {
+            auto R = [&](int i) -> int { return (i > 7 && !htr) ? t[-TS + 7] : t[-TS + i]; };
+            if (tid == 0) v = htl ? (t[-TS - 1] + 2 * R(0) + R(1) + 2) >> 2 : (3 * R(0) + R(1) + 2) >> 2;
+            else if (tid == 15) v = (R(14) + 3 * R(15) + 2) >> 2;
+            else v = (R(tid - 1) + 2 * R(tid) + R(tid + 1) + 2) >> 2;
+          }
+          f_top[tid] = v;
+        } else if (tid < 24) {
+          const int j = tid - 16;
+          int v = 128;
+          if (hl) {
+            auto Lr = [&](int i) -> int { return t[i * TS - 1]; };
+            if (j == 0) v = htl ? (t[-TS - 1] + 2 * Lr(0) + Lr(1) + 2) >> 2 : (3 * Lr(0) + Lr(1) + 2) >> 2;
+            else if (j == 7) v = (Lr(6) + 3 * Lr(7) + 2) >> 2;
+            else v = (Lr(j - 1) + 2 * Lr(j) + Lr(j + 1) + 2) >> 2;
+          }
+          f_left[j] = v;
+        } else if (tid == 24) {
+          int v = 128;
+          if (htl) {
+            const int c = t[-TS - 1];
+            if (ht && hl) v = (t[-TS] + 2 * c + t[-1] + 2) >> 2;
+            else if (ht) v = (3 * c + t[-TS] + 2) >> 2;
+            else if (hl) v = (3 * c + t[-1] + 2) >> 2;
+            else v = c;
+          }
+          f_tl = v;
+        }
+        __syncthreads();
+        if (tid < 64) {
+          const int px = tid & 7, py = tid >> 3;
+          const int raster = (by >> 2) * 4 + (bx >> 2);
+          const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
+          const int v = pred8x8_sample(f_top, f_left, f_tl, mode, px, py, hl, ht);
+          tile[(1 + by + py) * TS + 1 + bx + px] = (uint8_t)clip8(v + res_y[(by + py) * 16 + bx + px]);
+        }
+        __syncthreads();
+      }
+      dy[y * yp + x] = tile[(1 + y) * TS + 1 + x];
+    }
+
+    // chroma 8x8, both planes: threads 0..127
+    if (tid < 128) {
+      const int p = tid >> 6, cx = tid & 7, cy = (tid >> 3) & 7;
+      const uint8_t* ct = ctile[p];
+      const int mode = mb.pred_modes >> 4;
+      int v;
+      if (mode == 0) {
+        const int bx = cx >> 2, by = cy >> 2;
+        int st = 0, sl = 0;
+        for (int i = 0; i < 4; ++i) {
+          st += ct[1 + 4 * bx + i];
+          sl += ct[(1 + 4 * by + i) * 12];
+        }
+        if (bx == by) v = (hB && hA) ? (st + sl + 4) >> 3 : hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
+        else if (bx == 1) v = hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
+        else v = hA ? (sl + 2) >> 2 : hB ? (st + 2) >> 2 : 128;
+      } else if (mode == 1) {
+        v = ct[(1 + cy) * 12];
+      } else if (mode == 2) {
+        v = ct[1 + cx];
+      } else {
+        int Hh = 0, Vv = 0;
+        for (int k = 0; k < 4; ++k) {
+          Hh += (k + 1) * (ct[1 + 4 + k] - ct[1 + 2 - k]);
+          Vv += (k + 1) * (ct[(1 + 4 + k) * 12] - ct[(1 + 2 - k) * 12]);
+        }
+        const int a = 16 * (ct[8 * 12] + ct[8]);
+        const int b = (34 * Hh + 32) >> 6, c = (34 * Vv + 32) >> 6;
+        v = clip8((a + b * (cx - 3) + c * (cy - 3) + 16) >> 5);
+      }
+      uint8_t* d = p ? dv : du;
+      d[cy * cp + cx] = (uint8_t)clip8(v + res_c[p * 64 + cy * 8 + cx]);
+    }
+    publish_progress(&progress[mby], (unsigned)(mbx + 1), tid);
+  }
+}
+
+// ===========================================================================
+// k_deblock: grid = mb_height workgroups of 64 threads (one wave).
+// ===========================================================================
+namespace {
+
+__device__ __forceinline__ void filter_sample(uint8_t* pix, int step, int bs, int alpha, int beta, int tc0, bool chroma) {
+  const int p0 = pix[-step], p1 = pix[-2 * step], q0 = pix[0], q1 = pix[step];
+  if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
+  if (bs < 4) {
+    int tc;
+    if (chroma) {
+      tc = tc0 + 1;
+    } else {
+      const int p2 = pix[-3 * step], q2 = pix[2 * step];
+      const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
+      tc = tc0 + (ap < beta) + (aq < beta);
+      if (ap < beta) pix[-2 * step] = (uint8_t)(p1 + iclip(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1));
+      if (aq < beta) pix[step] = (uint8_t)(q1 + iclip(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1));
+    }
+    const int delta = iclip(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+    pix[-step] = (uint8_t)clip8(p0 + delta);
+    pix[0] = (uint8_t)clip8(q0 - delta);
+    return;
+  }
+  if (chroma) {
+    pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+    pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+    return;
+  }
+  const int p2 = pix[-3 * step], q2 = pix[2 * step];
+  const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
+  const bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
+  if (ap < beta && strong) {
+    const int p3 = pix[-4 * step];
+    pix[-step] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+    pix[-2 * step] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
+    pix[-3 * step] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+  } else {
+    pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+  }
+  if (aq < beta && strong) {
+    const int q3 = pix[3 * step];
+    pix[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+    pix[step] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
+    pix[2 * step] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+  } else {
+    pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+  }
+}
+
+__device__ int boundary_strength(const MbInfo& pm, const MbInfo& qm, const MbMotion* pmo, const MbMotion* qmo,
+                                 int pblk, int qblk, bool mb_edge) {
+  if ((pm.flags | qm.flags) & MBF_INTRA) return mb_edge ? 4 : 3;
+  if (((pm.nz_mask >> pblk) & 1) || ((qm.nz_mask >> qblk) & 1)) return 2;
+  const int p8 = (pblk >> 3) * 2 + ((pblk & 3) >> 1), q8 = (qblk >> 3) * 2 + ((qblk & 3) >> 1);
+  const int pr0 = pmo->ref_slot[0][p8], pr1 = pmo->ref_slot[1][p8];
+  const int qr0 = qmo->ref_slot[0][q8], qr1 = qmo->ref_slot[1][q8];
+  const int16_t* pm0 = pmo->mv[0][pblk];
+  const int16_t* pm1 = pmo->mv[1][pblk];
+  const int16_t* qm0 = qmo->mv[0][qblk];
+  const int16_t* qm1 = qmo->mv[1][qblk];
+#define FAR(a, b) (iabs((a)[0] - (b)[0]) >= 4 || iabs((a)[1] - (b)[1]) >= 4)
+  if (!((pr0 == qr0 && pr1 == qr1) || (pr0 == qr1 && pr1 == qr0))) return 1;
+  if (pr0 == pr1) {
+    if (pr0 < 0) return 0;
+    const bool straight = FAR(pm0, qm0) || FAR(pm1, qm1);
+    const bool cross = FAR(pm0, qm1) || FAR(pm1, qm0);
+    return (straight && cross) ? 1 : 0;
+  }
+  if (pr0 == qr0) {
+    if (pr0 >= 0 && FAR(pm0, qm0)) return 1;
+    if (pr1 >= 0 && FAR(pm1, qm1)) return 1;
+    return 0;
+  }
+  if (pr0 >= 0 && FAR(pm0, qm1)) return 1;
+  if (pr1 >= 0 && FAR(pm1, qm0)) return 1;
+  return 0;
+#undef FAR
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_deblock(PictureParams pp, const MbInfo* __restrict__ mbs,
+                                                const MbMotion* __restrict__ motions,
+                                                const SliceParams* __restrict__ slices, unsigned* sync) {
+  const int tid = threadIdx.x;
+  __shared__ int s_row;
+  if (tid == 0) s_row = (int)atomicAdd(&sync[0], 1u);
+  __syncthreads();
+  const int mby = s_row;
+  if (mby >= pp.mb_height) return;
+  unsigned* progress = sync + 2;
+  unsigned* timeout_word = sync + 1;
+
+  // luma tile: rows -4..15, cols -4..15 -> 20 x 20 (stride 24); chroma tiles
+  // rows -2..7, cols -2..7 -> 10 x 10 (stride 12).  Between macroblocks the
+  // right-most columns slide to the left edge, so a row never re-reads what
+  // it just filtered.
+  constexpr int LS = 24, CS = 12;
+  __shared__ uint8_t lt[20 * LS];
+  __shared__ uint8_t ct[2][10 * CS];
+  __shared__ uint8_t bsv[16], bsh[16];
+  __shared__ MbMotion mo_cur, mo_left, mo_top;
+
+  const Surface cur = pp.surfaces[pp.cur_slot];
+  const int yp = pp.y_pitch, cp = pp.c_pitch;
+
+  for (int mbx = 0; mbx < pp.mb_width; ++mbx) {
+    const int mbi = mby * pp.mb_width + mbx;
+    const MbInfo mb = mbs[mbi];
+    const bool do_left = mb.flags & MBF_DB_LEFT, do_top = mb.flags & MBF_DB_TOP;
+    // This macroblock's top-edge filter rewrites the three bottom rows of the
+    // macroblock above; the macroblock to the right of that one must already
+    // have run its left-edge filter over them (it reads and rewrites their
+    // right-most columns).
+    if (mby > 0) {
+      const unsigned need = (unsigned)min(mbx + 2, pp.mb_width);
+      wait_progress(&progress[mby - 1], need, tid, timeout_word);
+    }
+    uint8_t* gy = cur.y + (size_t)(mby * 16) * yp + mbx * 16;
+    uint8_t* gu = cur.u + (size_t)(mby * 8) * cp + mbx * 8;
+    uint8_t* gv = cur.v + (size_t)(mby * 8) * cp + mbx * 8;
+
+    // ---- load: interior + top rows from global; left columns slide in LDS
+    for (int i = tid; i < 20 * 16; i += 64) {
+      const int r = i >> 4, c = i & 15;  // tile row r <-> picture row r-4
+      if (r >= 4 || mby > 0) lt[r * LS + 4 + c] = gy[(r - 4) * yp + c];
+    }
+    if (mbx == 0) {
+      // no left neighbour: nothing to slide in; keep the columns defined
+      for (int i = tid; i < 20 * 4; i += 64) lt[(i >> 2) * LS + (i & 3)] = 0;
+    }
+    for (int i = tid; i < 2 * 10 * 8; i += 64) {
+      const int p = i / 80, r = (i % 80) >> 3, c = i & 7;
+      const uint8_t* g = p ? gv : gu;
+      if (r >= 2 || mby > 0) ct[p][r * CS + 2 + c] = g[(r - 2) * cp + c];
+    }
+    if (mbx == 0)
+      for (int i = tid; i < 2 * 10 * 2; i += 64) ct[i / 20][((i % 20) >> 1) * CS + (i & 1)] = 0;
+    // motion records for the bS derivation
+    const bool need_mo = !(mb.flags & MBF_INTRA);
+    if (need_mo && tid < 36) reinterpret_cast<uint32_t*>(&mo_cur)[tid] = reinterpret_cast<const uint32_t*>(&motions[mbi])[tid];
+    if (need_mo && do_left && tid < 36) reinterpret_cast<uint32_t*>(&mo_left)[tid] = reinterpret_cast<const uint32_t*>(&motions[mbi - 1])[tid];
+    if (need_mo && do_top && tid < 36) reinterpret_cast<uint32_t*>(&mo_top)[tid] = reinterpret_cast<const uint32_t*>(&motions[mbi - pp.mb_width])[tid];
+    __syncthreads();
+
+    // ---- boundary strengths: 16 vertical-edge + 16 horizontal-edge segments
+    if (tid < 32) {
+      const int dir = tid >> 4, e = (tid >> 2) & 3, k = tid & 3;
+      int bs = 0;
+      const bool edge_on = e == 0 ? (dir == 0 ? do_left : do_top) : (mb.deblock_internal != 0);
+      if (edge_on) {
+        const int qblk = dir == 0 ? k * 4 + e : e * 4 + k;
+        if (e == 0) {
+          const MbInfo nb = mbs[dir == 0 ? mbi - 1 : mbi - pp.mb_width];
+          const int pblk = dir == 0 ? k * 4 + 3 : 12 + k;
+          bs = boundary_strength(nb, mb, dir == 0 ? &mo_left : &mo_top, &mo_cur, pblk, qblk, true);
+        } else {
+          const int pblk = dir == 0 ? k * 4 + e - 1 : (e - 1) * 4 + k;
+          bs = boundary_strength(mb, mb, &mo_cur, &mo_cur, pblk, qblk, false);
+        }
+      }
+      (dir == 0 ? bsv : bsh)[e * 4 + k] = (uint8_t)bs;
+    }
+    __syncthreads();
+
+    const SliceParams& sp = slices[mb.slice];
+    const int a_off = sp.alpha_offset, b_off = sp.beta_offset;
+    const MbInfo left = do_left ? mbs[mbi - 1] : mb;
+    const MbInfo top = do_top ? mbs[mbi - pp.mb_width] : mb;
+
+    // ---- vertical edges (filter across columns), then horizontal edges
+    for (int dir = 0; dir < 2; ++dir) {
+      const uint8_t* bsa = dir == 0 ? bsv : bsh;
+      const MbInfo& nb = dir == 0 ? left : top;
+      for (int e = 0; e < 4; ++e) {
+        const bool luma_edge = !((mb.flags & MBF_T8X8) && (e & 1));
+        if (tid < 16) {
+          if (luma_edge) {
+            const int bs = bsa[e * 4 + (tid >> 2)];
+            if (bs) {
+              const int qpav = ((e == 0 ? nb.qp : mb.qp) + mb.qp + 1) >> 1;
+              const int ia = iclip(0, 51, qpav + a_off), ib = iclip(0, 51, qpav + b_off);
+              uint8_t* pix = dir == 0 ? lt + (4 + tid) * LS + 4 + e * 4 : lt + (4 + e * 4) * LS + 4 + tid;
+              filter_sample(pix, dir == 0 ? 1 : LS, bs, c_alpha[ia], c_beta[ib], bs < 4 ? c_tc0[ia][bs - 1] : 0, false);
+            }
+          }
+        } else if (tid < 32 && !(e & 1)) {
+          const int p = (tid - 16) >> 3, i = (tid - 16) & 7;
+          const int bs = bsa[e * 4 + (i >> 1)];
+          if (bs) {
+            const int qpav = ((e == 0 ? nb.qpc[p] : mb.qpc[p]) + mb.qpc[p] + 1) >> 1;
+            const int ia = iclip(0, 51, qpav + a_off), ib = iclip(0, 51, qpav + b_off);
+            uint8_t* pix = dir == 0 ? ct[p] + (2 + i) * CS + 2 + e * 2 : ct[p] + (2 + e * 2) * CS + 2 + i;
+            filter_sample(pix, dir == 0 ? 1 : CS, bs, c_alpha[ia], c_beta[ib], bs < 4 ? c_tc0[ia][bs - 1] : 0, true);
+          }
+        }
+        __syncthreads();
+      }
+    }
+
+    // ---- store everything this macroblock may have changed: rows -3..15,
+    // cols -3..15 (luma); rows -1..7, cols -1..7 (chroma)
+    for (int i = tid; i < 19 * 19; i += 64) {
+      const int r = i / 19 + 1, c = i % 19 + 1;  // tile coordinates
+      if ((r >= 4 || mby > 0) && (c >= 4 || mbx > 0)) gy[(r - 4) * yp + (c - 4)] = lt[r * LS + c];
+    }
+    for (int i = tid; i < 2 * 81; i += 64) {
+      const int p = i / 81, r = (i % 81) / 9 + 1, c = (i % 81) % 9 + 1;
+      uint8_t* g = p ? gv : gu;
+      if ((r >= 2 || mby > 0) && (c >= 2 || mbx > 0)) g[(r - 2) * cp + (c - 2)] = ct[p][r * CS + c];
+    }
+    __syncthreads();
+    // ---- slide the last four (two) columns to the left edge for the next MB
+    if (mbx + 1 < pp.mb_width) {
+      uint8_t keep_l = 0, keep_c = 0;
+      const int r = tid >> 2, c = tid & 3;
+      uint8_t k2 = 0;
+      if (tid < 64) keep_l = lt[r * LS + 16 + c];                       // rows 0..15
+      if (tid < 16) k2 = lt[(16 + (tid >> 2)) * LS + 16 + (tid & 3)];    // rows 16..19
+      if (tid < 40) keep_c = ct[tid / 20][((tid % 20) >> 1) * CS + 8 + (tid & 1)];
+      __syncthreads();
+      if (tid < 64) lt[r * LS + c] = keep_l;
+      if (tid < 16) lt[(16 + (tid >> 2)) * LS + (tid & 3)] = k2;
+      if (tid < 40) ct[tid / 20][((tid % 20) >> 1) * CS + (tid & 1)] = keep_c;
+    }
+    publish_progress(&progress[mby], (unsigned)(mbx + 1), tid);
+  }
+}
+
+// ===========================================================================
+// launch helpers (host)
+// ===========================================================================
+hipError_t launch_inter(const PictureParams& pp, const MbInfo* mbs, const MbMotion* motions, const int16_t* coefs,
+                        const SliceParams* slices, hipStream_t stream) {
+  const int nmb = pp.mb_width * pp.mb_height;
+  prof::Span span;
+  const bool profiled = prof::enabled();
+  if (profiled) span = prof::begin(stream);
+  hipLaunchKernelGGL(k_inter, dim3(nmb), dim3(256), 0, stream, pp, mbs, motions, coefs, slices);
+  if (profiled) prof::end(span, stream, prof::K_INTER, (uint64_t)nmb * 384 * 2);
+  return hipGetLastError();
+}
+
+hipError_t launch_intra(const PictureParams& pp, const MbInfo* mbs, const int16_t* coefs, unsigned* sync,
+                        hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (2 + pp.mb_height), stream);
+  if (e != hipSuccess) return e;
+  prof::Span span;
+  const bool profiled = prof::enabled();
+  if (profiled) span = prof::begin(stream);
+  hipLaunchKernelGGL(k_intra, dim3(pp.mb_height), dim3(256), 0, stream, pp, mbs, coefs, sync);
+  if (profiled) prof::end(span, stream, prof::K_INTRA, (uint64_t)pp.mb_width * pp.mb_height * 384);
+  return hipGetLastError();
+}
+
+hipError_t launch_deblock(const PictureParams& pp, const MbInfo* mbs, const MbMotion* motions,
+                          const SliceParams* slices, unsigned* sync, hipStream_t stream) {
+  hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (2 + pp.mb_height), stream);
+  if (e != hipSuccess) return e;
+  prof::Span span;
+  const bool profiled = prof::enabled();
+  if (profiled) span = prof::begin(stream);
+  hipLaunchKernelGGL(k_deblock, dim3(pp.mb_height), dim3(64), 0, stream, pp, mbs, motions, slices, sync);
+  if (profiled) prof::end(span, stream, prof::K_DEBLOCK, (uint64_t)pp.mb_width * pp.mb_height * 384 * 2);
+  return hipGetLastError();
+}
+
+}  // namespace amd
+}  // namespace hwang

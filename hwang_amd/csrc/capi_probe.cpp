@@ -1,0 +1,111 @@
+// C ABI: host-only probe of the H.264 parser (no GPU needed).  Runs the
+// product's entropy decoder / DPB logic over a sequence of samples with a
+// sink that only provides host buffers, and reports counters plus an FNV-1a
+// digest of every record the GPU would have received.  Used by the CPU test
+// suite to pin the host half of the backend (desync check, output order,
+// sparse skipping) on machines without a GPU.
+#include "../../include/hwang_amd.h"
+
+#include "h264/h264_parser.h"
+
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+using namespace hwang;
+
+namespace {
+
+struct ProbeSink : public h264::PictureSink {
+  struct Slot {
+    bool busy = false;
+    std::vector<amd::MbMotion> motion;
+  };
+  std::vector<Slot> slots = std::vector<Slot>(amd::kMaxSurfaces);
+  std::vector<amd::MbInfo> mb;
+  std::vector<int16_t> coefs;
+  std::vector<amd::SliceParams> slices = std::vector<amd::SliceParams>(64);
+  int nmb = 0;
+  uint64_t digest = 1469598103934665603ull;
+  std::vector<int> outputs;  // slot per output (-1 skipped)
+  int64_t coef_total = 0, inter_pics = 0;
+
+  void mix(const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (size_t i = 0; i < n; ++i) digest = (digest ^ b[i]) * 1099511628211ull;
+  }
+  bool begin_picture(const h264::PicSetup& s, h264::PicBuffers* out, std::string* error) override {
+    nmb = s.mb_width * s.mb_height;
+    int slot = -1;
+    for (int i = 0; i < amd::kMaxSurfaces; ++i)
+      if (!slots[i].busy) {
+        slot = i;
+        break;
+      }
+    if (slot < 0) {
+      *error = "probe: out of surfaces";
+      return false;
+    }
+    slots[slot].busy = true;
+    slots[slot].motion.assign(nmb, amd::MbMotion());
+    mb.assign(nmb, amd::MbInfo());
+    coefs.assign(static_cast<size_t>(nmb) * 27 * 16, 0);
+    out->mb = mb.data();
+    out->motion = slots[slot].motion.data();
+    out->coefs = coefs.data();
+    out->coef_capacity = coefs.size();
+    out->slices = slices.data();
+    out->max_slices = static_cast<int>(slices.size());
+    out->slot = slot;
+    return true;
+  }
+  bool end_picture(const h264::PicDone& d, std::string*) override {
+    mix(mb.data(), mb.size() * sizeof(amd::MbInfo));
+    mix(coefs.data(), d.coef_count * 2);
+    if (d.has_inter) {
+      // ref_slot depends on this sink's slot numbering, which is stable
+      mix(slots[d.slot].motion.data(), slots[d.slot].motion.size() * sizeof(amd::MbMotion));
+      ++inter_pics;
+    }
+    coef_total += static_cast<int64_t>(d.coef_count);
+    return true;
+  }
+  void output_picture(int slot) override { outputs.push_back(slot); }
+  void release_surface(int slot) override {
+    if (slot >= 0) slots[slot].busy = false;
+  }
+};
+
+}  // namespace
+
+extern "C" int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
+                                const uint64_t* sample_offsets, const uint64_t* sample_sizes,
+                                size_t num_samples, const uint64_t* wanted, size_t num_wanted,
+                                int64_t out[8], char* error, size_t error_capacity) {
+  ProbeSink sink;
+  h264::Parser parser(&sink);
+  auto report = [&](const std::string& e) {
+    if (error && error_capacity) {
+      std::strncpy(error, e.c_str(), error_capacity - 1);
+      error[error_capacity - 1] = 0;
+    }
+    return 1;
+  };
+  if (!parser.configure(avcc, avcc_size)) return report(parser.error());
+  if (num_wanted) parser.set_wanted(std::vector<uint64_t>(wanted, wanted + num_wanted));
+  for (size_t i = 0; i < num_samples; ++i)
+    if (!parser.decode(data + sample_offsets[i], sample_sizes[i])) return report(parser.error());
+  if (!parser.flush()) return report(parser.error());
+  int64_t skipped_out = 0;
+  for (int s : sink.outputs) skipped_out += s < 0;
+  out[0] = parser.slices();
+  out[1] = parser.slices_clean_end();
+  out[2] = parser.pictures_decoded();
+  out[3] = parser.pictures_skipped();
+  out[4] = static_cast<int64_t>(sink.outputs.size());
+  out[5] = skipped_out;
+  out[6] = sink.coef_total;
+  out[7] = static_cast<int64_t>(sink.digest & 0x7fffffffffffffffull);
+  return 0;
+}

@@ -1,0 +1,2231 @@
+#include "h264_parser.h"
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace hwang {
+namespace h264 {
+
+#include "h264_tables.h"
+
+using amd::MbInfo;
+using amd::MbMotion;
+using amd::SliceParams;
+
+namespace {
+
+constexpr int kMaxSps = 32, kMaxPps = 256, kMaxDpb = amd::kMaxSurfaces, kMaxRefs = 32;
+
+inline int iclip(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
+inline int imin(int a, int b) { return a < b ? a : b; }
+inline int imax(int a, int b) { return a > b ? a : b; }
+inline int iabs(int a) { return a < 0 ? -a : a; }
+inline int median3(int a, int b, int c) {
+  return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b));
+}
+
+// ---------------------------------------------------------------------------
+// Bit reader over an RBSP: 64-bit window, refilled bytewise.
+// ---------------------------------------------------------------------------
+struct Bits {
+  const uint8_t* buf = nullptr;
+  int size_bits = 0;
+  int pos = 0;
+  bool overrun = false;
+
+  int left() const { return size_bits - pos; }
+  unsigned peek(int n) const {  // n <= 25
+    uint32_t v = 0;
+    const int byte = pos >> 3;
+    const int nbytes = (size_bits + 7) >> 3;
+    for (int i = 0; i < 4; ++i) v = (v << 8) | (byte + i < nbytes ? buf[byte + i] : 0);
+    return (v << (pos & 7)) >> (32 - n);
+  }
+  unsigned get(int n) {
+    if (n == 0) return 0;
+    if (n > 25) {
+      unsigned hi = get(n - 16);
+      return (hi << 16) | get(16);
+    }
+    if (pos + n > size_bits) {
+      overrun = true;
+      pos = size_bits;
+      return 0;
+    }
+    unsigned v = peek(n);
+    pos += n;
+    return v;
+  }
+  unsigned bit() { return get(1); }
+  unsigned ue() {
+    int zeros = 0;
+    while (!bit()) {
+      if (++zeros > 32 || overrun) return 0;
+    }
+    return zeros ? ((1u << zeros) - 1 + get(zeros)) : 0;
+  }
+  int se() {
+    unsigned k = ue();
+    return (k & 1) ? static_cast<int>((k + 1) >> 1) : -static_cast<int>(k >> 1);
+  }
+  bool more_rbsp_data() const {
+    int last = size_bits - 1;
+    while (last >= 0 && !((buf[last >> 3] >> (7 - (last & 7))) & 1)) --last;
+    return pos < last;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// CABAC decoding engine (9.3.3.2).  `value` carries the 9-bit offset plus
+// `extra` prefetched stream bits, so renormalisation is a counter decrement
+// and the stream is touched once per byte instead of once per bit.
+// ---------------------------------------------------------------------------
+struct Cabac {
+  const uint8_t* p = nullptr;
+  const uint8_t* end = nullptr;
+  const uint8_t* start = nullptr;
+  uint64_t value = 0;
+  int extra = 0;
+  uint32_t range = 0;
+  bool overrun = false;
+  uint8_t state[CABAC_CTX_COUNT];
+
+  void refill() {
+    while (extra < 24) {
+      uint32_t b = 0;
+      if (p < end) b = *p;
+      else if (p > end + 8) overrun = true;
+      ++p;
+      value = (value << 8) | b;
+      extra += 8;
+    }
+  }
+  void begin(const uint8_t* data, const uint8_t* data_end) {
+    start = p = data;
+    end = data_end;
+    value = 0;
+    extra = -9;  // the first nine bits become the offset
+    overrun = false;
+    range = 510;
+    refill();
+  }
+  // bits of the stream consumed so far
+  int bits_consumed() const { return static_cast<int>(p - start) * 8 - extra; }
+
+  void init_contexts(int slice_type, int idc, int qp) {
+    const int t = slice_type == 2 ? 0 : 1 + idc;
+    qp = iclip(0, 51, qp);
+    for (int i = 0; i < CABAC_CTX_COUNT; ++i) {
+      int m = cabac_init_mn[t][i][0], n = cabac_init_mn[t][i][1];
+      int pre = iclip(1, 126, ((m * qp) >> 4) + n);
+      state[i] = pre <= 63 ? static_cast<uint8_t>((63 - pre) << 1)
+                           : static_cast<uint8_t>(((pre - 64) << 1) | 1);
+    }
+  }
+  inline int bin(int ctx) {
+    int ps = state[ctx] >> 1, mps = state[ctx] & 1;
+    const uint32_t lps = cabac_range_lps[ps][(range >> 6) & 3];
+    range -= lps;
+    const uint64_t scaled = static_cast<uint64_t>(range) << extra;
+    int b;
+    if (value >= scaled) {
+      b = !mps;
+      value -= scaled;
+      range = lps;
+      if (ps == 0) mps = !mps;
+      ps = cabac_trans_lps[ps];
+    } else {
+      b = mps;
+      if (ps < 62) ++ps;
+    }
+    state[ctx] = static_cast<uint8_t>((ps << 1) | mps);
+    if (range < 256) {
+      const int shift = __builtin_clz(range) - 23;
+      range <<= shift;
+      extra -= shift;
+      if (extra < 8) refill();
+    }
+    return b;
+  }
+  inline int bypass() {
+    extra -= 1;
+    if (extra < 8) refill();
+    const uint64_t scaled = static_cast<uint64_t>(range) << extra;
+    if (value >= scaled) {
+      value -= scaled;
+      return 1;
+    }
+    return 0;
+  }
+  inline int terminate() {
+    range -= 2;
+    const uint64_t scaled = static_cast<uint64_t>(range) << extra;
+    if (value >= scaled) return 1;
+    if (range < 256) {
+      range <<= 1;
+      extra -= 1;
+      if (extra < 8) refill();
+    }
+    return 0;
+  }
+};
+
+// ---------------------------------------------------------------------------
+struct Sps {
+  bool valid = false;
+  int profile_idc = 0, level_idc = 0, constraint_flags = 0;
+  int log2_max_frame_num = 4, poc_type = 0, log2_max_poc_lsb = 4;
+  int delta_pic_order_always_zero = 0, offset_for_non_ref_pic = 0, offset_for_top_to_bottom = 0;
+  int num_ref_frames_in_poc_cycle = 0;
+  int offset_for_ref_frame[256];
+  int max_num_ref_frames = 0;
+  int mb_width = 0, mb_height = 0;
+  int direct_8x8_inference = 0;
+  int crop_left = 0, crop_right = 0, crop_top = 0, crop_bottom = 0;
+  int bitstream_restriction = 0, num_reorder_frames = -1;
+  int scaling_matrix_present = 0;
+  uint8_t scaling4[6][16];
+  uint8_t scaling8[2][64];
+};
+
+struct Pps {
+  bool valid = false;
+  int sps_id = 0, cabac = 0, bottom_field_pic_order_present = 0;
+  int num_ref_idx_default[2] = {1, 1};
+  int weighted_pred = 0, weighted_bipred_idc = 0;
+  int init_qp = 26;
+  int chroma_qp_offset[2] = {0, 0};
+  int deblocking_control_present = 0, constrained_intra_pred = 0, redundant_pic_cnt_present = 0;
+  int transform_8x8_mode = 0;
+  uint8_t scaling4[6][16];
+  uint8_t scaling8[2][64];
+};
+
+// A decoded (or skipped) picture in the DPB.
+struct Pic {
+  bool in_use = false;
+  int slot = -1;          // GPU surface; -1 for a skipped picture
+  int uid = 0;
+  int poc = 0;
+  int frame_num = 0, frame_num_wrap = 0, pic_num = 0;
+  int ref = 0;            // 0 unused, 1 short-term, 2 long-term
+  int long_term_idx = -1;
+  bool needed_for_output = false;
+  // motion kept for co-located lookups
+  MbMotion* motion = nullptr;         // owned by the sink (pinned, per surface)
+  std::vector<int32_t> ref_uid[2];    // per 8x8
+  std::vector<uint8_t> mb_intra;
+};
+
+struct SliceHdr {
+  int first_mb = 0, type = 2, pps_id = 0, frame_num = 0;
+  int poc_lsb = 0, delta_poc_bottom = 0, delta_poc[2] = {0, 0};
+  int direct_spatial = 0;
+  int num_ref_idx[2] = {0, 0};
+  int cabac_init_idc = 0, qp = 26;
+  int disable_deblock = 0, alpha_offset = 0, beta_offset = 0;
+  int luma_log2_denom = 0, chroma_log2_denom = 0;
+  int luma_weight[2][kMaxRefs], luma_offset[2][kMaxRefs];
+  int chroma_weight[2][kMaxRefs][2], chroma_offset[2][kMaxRefs][2];
+  int use_weight = 0;
+  int nal_ref_idc = 0;
+  bool is_idr = false;
+  int long_term_reference_flag = 0, adaptive_marking = 0;
+  int mmco_count = 0;
+  struct { int op, a, b; } mmco[66];
+  Pic* ref_list[2][kMaxRefs + 1];
+};
+
+enum { MB_NONE = 0, MB_I4x4, MB_I8x8, MB_I16x16, MB_IPCM, MB_INTER };
+
+struct NB {
+  int ref;  // -2 partition not available, -1 list unused / intra, >= 0 refIdx
+  int mv[2];
+};
+
+enum { PRED_MEDIAN = 0, PRED_16x8_TOP, PRED_16x8_BOTTOM, PRED_8x16_LEFT, PRED_8x16_RIGHT };
+
+const uint8_t b_mb_info[23][3] = {
+    {0, 0, 0}, {0, 0, 0}, {0, 1, 1}, {0, 2, 2}, {1, 0, 0}, {2, 0, 0}, {1, 1, 1}, {2, 1, 1},
+    {1, 0, 1}, {2, 0, 1}, {1, 1, 0}, {2, 1, 0}, {1, 0, 2}, {2, 0, 2}, {1, 1, 2}, {2, 1, 2},
+    {1, 2, 0}, {2, 2, 0}, {1, 2, 1}, {2, 2, 1}, {1, 2, 2}, {2, 2, 2}, {3, 0, 0}};
+const uint8_t b_sub_info[13][2] = {{0, 3}, {0, 0}, {0, 1}, {0, 2}, {1, 0}, {2, 0}, {1, 1},
+                                   {2, 1}, {1, 2}, {2, 2}, {3, 0}, {3, 1}, {3, 2}};
+inline bool uses_list(int pred, int list) { return pred == 2 || pred == list; }
+
+const int cbf_cat_offset[6] = {0, 4, 8, 12, 16, 0};
+const int sig_cat_offset[6] = {0, 15, 29, 44, 47, 0};
+const int abs_cat_offset[6] = {0, 10, 20, 30, 39, 0};
+const uint8_t identity_scan16[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+const uint8_t dc_scan4[4] = {0, 1, 2, 3};
+
+}  // namespace
+
+// ===========================================================================
+struct Parser::Impl {
+  Parser* owner;
+  PictureSink* sink;
+  std::string* err;
+
+  int nal_length_size = 4;
+  Sps sps[kMaxSps];
+  Pps pps[kMaxPps];
+  const Sps* asps = nullptr;
+  const Pps* apps = nullptr;
+  int mbw = 0, mbh = 0;
+
+  std::vector<uint8_t> rbsp;
+
+  Pic dpb[kMaxDpb + 8];
+  int next_uid = 0;
+  Pic* cur = nullptr;
+  bool pic_in_progress = false;
+  bool skipping_picture = false;  // remaining slices of a picture skipped on purpose
+  PicBuffers bufs;
+  size_t coef_used = 0;
+  int num_slices = 0;
+  bool has_inter = false, has_intra = false;
+  int slice_type_mask = 0;
+
+  int prev_poc_msb = 0, prev_poc_lsb = 0, prev_frame_num = 0, prev_frame_num_offset = 0;
+  bool prev_ref_has_mmco5 = false;
+  int max_long_term_frame_idx = -1;
+
+  // sparse decoding
+  std::vector<uint64_t> wanted;
+  uint64_t outputs_emitted = 0;  // since last flush/configure
+
+  SliceHdr sl;
+  int slice_index = 0;
+  // per-picture macroblock state (host only)
+  std::vector<int16_t> mb_slice;
+  std::vector<uint8_t> mb_kind, mb_skip, mb_direct, direct8, mb_t8x8, mb_cbp, mb_cbf_dc, mb_chroma_mode;
+  std::vector<int8_t> i4mode;
+  std::vector<uint8_t> nnz;  // mb*24
+  std::vector<uint8_t> mvd;  // mb*[2][16][2]
+  Bits bits;
+  Cabac cabac;
+  bool use_cabac = false;
+  int last_qp_delta_nonzero = 0;
+  int qp = 26;
+
+  // current macroblock
+  struct Mb {
+    int mbx, mby, addr, kind, skip, direct16, t8x8, i16_mode, chroma_mode, cbp, qp;
+    int sub_type[4];
+    int8_t i4_mode[16];
+    uint8_t nnz[24];
+    int cbf_dc;
+    uint32_t coded_mask;
+    int16_t* coef_base;  // this MB's groups in the coefficient buffer
+    int16_t scratch[26][16];  // levels before compaction, indexed by mask bit
+  } mb;
+
+  bool fail(const char* msg) {
+    if (err->empty()) *err = msg;
+    return false;
+  }
+
+  // ----------------------------------------------------------------- NAL
+  int unescape(const uint8_t* src, size_t n) {
+    rbsp.resize(n + 8);
+    size_t o = 0;
+    int zeros = 0;
+    for (size_t i = 0; i < n; ++i) {
+      uint8_t c = src[i];
+      if (zeros >= 2 && c == 3) {
+        zeros = 0;
+        continue;
+      }
+      rbsp[o++] = c;
+      zeros = c == 0 ? zeros + 1 : 0;
+    }
+    memset(rbsp.data() + o, 0, 8);
+    return static_cast<int>(o);
+  }
+
+  // -------------------------------------------------------- parameter sets
+  void scaling_list(Bits& b, uint8_t* out, int size, const uint8_t* fallback, const uint8_t* default_zz) {
+    const uint8_t* scan = size == 16 ? zigzag4x4 : zigzag8x8;
+    if (!b.bit()) {
+      memcpy(out, fallback, size);
+      return;
+    }
+    int last = 8, next = 8;
+    for (int j = 0; j < size; ++j) {
+      if (next != 0) {
+        int delta = b.se();
+        next = (last + delta + 256) & 255;
+        if (j == 0 && next == 0) {
+          for (int k = 0; k < size; ++k) out[scan[k]] = default_zz[k];
+          return;
+        }
+      }
+      last = next == 0 ? last : next;
+      out[scan[j]] = static_cast<uint8_t>(last);
+    }
+  }
+  void scaling_matrices(Bits& b, bool want8, uint8_t s4[6][16], uint8_t s8[2][64], const uint8_t fb4[6][16],
+                        const uint8_t fb8[2][64], bool sps_fallback) {
+    uint8_t d4i[16], d4p[16], d8i[64], d8p[64];
+    for (int k = 0; k < 16; ++k) {
+      d4i[zigzag4x4[k]] = default_4x4_intra[k];
+      d4p[zigzag4x4[k]] = default_4x4_inter[k];
+    }
+    for (int k = 0; k < 64; ++k) {
+      d8i[zigzag8x8[k]] = default_8x8_intra[k];
+      d8p[zigzag8x8[k]] = default_8x8_inter[k];
+    }
+    const uint8_t* f0 = sps_fallback ? fb4[0] : d4i;
+    const uint8_t* f3 = sps_fallback ? fb4[3] : d4p;
+    const uint8_t* f6 = sps_fallback ? fb8[0] : d8i;
+    const uint8_t* f7 = sps_fallback ? fb8[1] : d8p;
+    scaling_list(b, s4[0], 16, f0, default_4x4_intra);
+    scaling_list(b, s4[1], 16, s4[0], default_4x4_intra);
+    scaling_list(b, s4[2], 16, s4[1], default_4x4_intra);
+    scaling_list(b, s4[3], 16, f3, default_4x4_inter);
+    scaling_list(b, s4[4], 16, s4[3], default_4x4_inter);
+    scaling_list(b, s4[5], 16, s4[4], default_4x4_inter);
+    if (want8) {
+      scaling_list(b, s8[0], 64, f6, default_8x8_intra);
+      scaling_list(b, s8[1], 64, f7, default_8x8_inter);
+    } else {
+      memcpy(s8[0], f6, 64);
+      memcpy(s8[1], f7, 64);
+    }
+  }
+
+  int max_dpb_frames(const Sps& s) const {
+    static const int lv[][2] = {{10, 396},   {11, 900},   {12, 2376},  {13, 2376},   {20, 2376},  {21, 4752},
+                                {22, 8100},  {30, 8100},  {31, 18000}, {32, 20480},  {40, 32768}, {41, 32768},
+                                {42, 34816}, {50, 110400}, {51, 184320}, {52, 184320}};
+    int mbs = 184320;
+    for (auto& l : lv)
+      if (l[0] == s.level_idc) mbs = l[1];
+    if (s.level_idc == 11 && (s.constraint_flags & 0x10)) mbs = 396;
+    return iclip(1, 16, mbs / (s.mb_width * s.mb_height));
+  }
+
+  bool parse_sps(Bits& b) {
+    Sps s;
+    memset(s.scaling4, 16, sizeof(s.scaling4));
+    memset(s.scaling8, 16, sizeof(s.scaling8));
+    s.profile_idc = b.get(8);
+    s.constraint_flags = b.get(8);
+    s.level_idc = b.get(8);
+    unsigned id = b.ue();
+    if (id >= kMaxSps) return fail("sps_id out of range");
+    int p = s.profile_idc;
+    if (p == 100 || p == 110 || p == 122 || p == 244 || p == 44 || p == 83 || p == 86 || p == 118 || p == 128 ||
+        p == 138 || p == 139 || p == 134 || p == 135) {
+      int chroma_format_idc = b.ue();
+      if (chroma_format_idc == 3) b.bit();
+      int bdl = b.ue(), bdc = b.ue(), bypass = b.bit();
+      if (chroma_format_idc != 1 || bdl || bdc || bypass)
+        return fail("unsupported stream: only 8-bit 4:2:0 without transform bypass is decoded");
+      s.scaling_matrix_present = b.bit();
+      if (s.scaling_matrix_present) {
+        uint8_t flat4[6][16], flat8[2][64];
+        memset(flat4, 16, sizeof(flat4));
+        memset(flat8, 16, sizeof(flat8));
+        scaling_matrices(b, true, s.scaling4, s.scaling8, flat4, flat8, false);
+      }
+    }
+    s.log2_max_frame_num = b.ue() + 4;
+    s.poc_type = b.ue();
+    if (s.poc_type == 0) {
+      s.log2_max_poc_lsb = b.ue() + 4;
+    } else if (s.poc_type == 1) {
+      s.delta_pic_order_always_zero = b.bit();
+      s.offset_for_non_ref_pic = b.se();
+      s.offset_for_top_to_bottom = b.se();
+      s.num_ref_frames_in_poc_cycle = b.ue();
+      if (s.num_ref_frames_in_poc_cycle > 255) return fail("bad poc cycle");
+      for (int i = 0; i < s.num_ref_frames_in_poc_cycle; ++i) s.offset_for_ref_frame[i] = b.se();
+    } else if (s.poc_type != 2) {
+      return fail("bad pic_order_cnt_type");
+    }
+    s.max_num_ref_frames = b.ue();
+    b.bit();  // gaps_in_frame_num_value_allowed_flag
+    s.mb_width = b.ue() + 1;
+    s.mb_height = b.ue() + 1;
+    if (!b.bit()) return fail("unsupported stream: interlaced coding (frame_mbs_only_flag = 0)");
+    s.direct_8x8_inference = b.bit();
+    if (b.bit()) {
+      s.crop_left = 2 * b.ue();
+      s.crop_right = 2 * b.ue();
+      s.crop_top = 2 * b.ue();
+      s.crop_bottom = 2 * b.ue();
+    }
+    if (b.bit()) {  // VUI
+      if (b.bit() && b.get(8) == 255) b.get(32);
+      if (b.bit()) b.bit();
+      if (b.bit()) {
+        b.get(4);
+        if (b.bit()) b.get(24);
+      }
+      if (b.bit()) {
+        b.ue();
+        b.ue();
+      }
+      if (b.bit()) {
+        b.get(32);
+        b.get(32);
+        b.bit();
+      }
+      bool hrd = false;
+      for (int pass = 0; pass < 2; ++pass) {
+        if (!b.bit()) continue;
+        hrd = true;
+        int cpb = b.ue() + 1;
+        b.get(8);
+        for (int i = 0; i < cpb && !b.overrun; ++i) {
+          b.ue();
+          b.ue();
+          b.bit();
+        }
+        b.get(20);
+      }
+      if (hrd) b.bit();
+      b.bit();
+      s.bitstream_restriction = b.bit();
+      if (s.bitstream_restriction) {
+        b.bit();
+        b.ue();
+        b.ue();
+        b.ue();
+        b.ue();
+        s.num_reorder_frames = b.ue();
+        b.ue();
+      }
+    }
+    if (b.overrun) return fail("truncated SPS");
+    if (s.mb_width > 512 || s.mb_height > 512 || s.mb_width < 1 || s.mb_height < 1)
+      return fail("picture size out of range");
+    s.valid = true;
+    sps[id] = s;
+    return true;
+  }
+
+  bool parse_pps(Bits& b) {
+    Pps p;
+    unsigned id = b.ue();
+    if (id >= kMaxPps) return fail("pps_id out of range");
+    p.sps_id = b.ue();
+    if (p.sps_id >= kMaxSps || !sps[p.sps_id].valid) return fail("PPS refers to a missing SPS");
+    const Sps& s = sps[p.sps_id];
+    p.cabac = b.bit();
+    p.bottom_field_pic_order_present = b.bit();
+    if (b.ue() != 0) return fail("unsupported stream: slice groups (FMO)");
+    p.num_ref_idx_default[0] = b.ue() + 1;
+    p.num_ref_idx_default[1] = b.ue() + 1;
+    p.weighted_pred = b.bit();
+    p.weighted_bipred_idc = b.get(2);
+    p.init_qp = 26 + b.se();
+    b.se();
+    p.chroma_qp_offset[0] = b.se();
+    p.deblocking_control_present = b.bit();
+    p.constrained_intra_pred = b.bit();
+    p.redundant_pic_cnt_present = b.bit();
+    p.chroma_qp_offset[1] = p.chroma_qp_offset[0];
+    memcpy(p.scaling4, s.scaling4, sizeof(p.scaling4));
+    memcpy(p.scaling8, s.scaling8, sizeof(p.scaling8));
+    if (b.more_rbsp_data()) {
+      p.transform_8x8_mode = b.bit();
+      if (b.bit())
+        scaling_matrices(b, p.transform_8x8_mode, p.scaling4, p.scaling8, s.scaling4, s.scaling8,
+                         s.scaling_matrix_present);
+      p.chroma_qp_offset[1] = b.se();
+    }
+    if (b.overrun) return fail("truncated PPS");
+    p.valid = true;
+    pps[id] = p;
+    return true;
+  }
+
+  // ------------------------------------------------------------------ DPB
+  void release_unused() {
+    for (Pic& p : dpb) {
+      if (p.in_use && &p != cur && !p.ref && !p.needed_for_output) {
+        p.in_use = false;
+        if (p.slot >= 0) sink->release_surface(p.slot);
+        p.slot = -1;
+      }
+    }
+  }
+  Pic* grab_pic() {
+    for (Pic& p : dpb)
+      if (!p.in_use) {
+        p.in_use = true;
+        p.uid = ++next_uid;
+        p.ref = 0;
+        p.needed_for_output = false;
+        p.long_term_idx = -1;
+        p.slot = -1;
+        p.motion = nullptr;
+        return &p;
+      }
+    return nullptr;
+  }
+  void emit(Pic* p) {
+    sink->output_picture(p->slot);
+    if (p->slot < 0 && !wanted.empty() &&
+        std::binary_search(wanted.begin(), wanted.end(), outputs_emitted)) {
+      // A picture was skipped on the prediction that nobody wants its output
+      // position, and the prediction was wrong.  Never hand out garbage.
+      fail("sparse decode mispredicted the display position of a skipped picture");
+    }
+    ++outputs_emitted;
+    p->needed_for_output = false;
+  }
+  Pic* lowest_poc_pending(int* count) {
+    Pic* best = nullptr;
+    int n = 0;
+    for (Pic& p : dpb) {
+      if (!p.in_use || !p.needed_for_output || &p == cur) continue;
+      ++n;
+      if (!best || p.poc < best->poc) best = &p;
+    }
+    if (count) *count = n;
+    return best;
+  }
+  void output_all() {
+    while (Pic* p = lowest_poc_pending(nullptr)) emit(p);
+    release_unused();
+  }
+  int reorder_depth() const {
+    if (asps->poc_type == 2) return 0;
+    if (asps->bitstream_restriction && asps->num_reorder_frames >= 0) return asps->num_reorder_frames;
+    return const_cast<Impl*>(this)->max_dpb_frames(*asps);
+  }
+
+  // ------------------------------------------------------------------ POC
+  void compute_poc(Pic* c) {
+    const Sps& s = *asps;
+    const int max_frame_num = 1 << s.log2_max_frame_num;
+    int fno;
+    if (sl.is_idr) fno = 0;
+    else if (prev_frame_num > sl.frame_num) fno = prev_frame_num_offset + max_frame_num;
+    else fno = prev_frame_num_offset;
+    int top, bottom;
+    if (s.poc_type == 0) {
+      const int max_lsb = 1 << s.log2_max_poc_lsb;
+      if (sl.is_idr) prev_poc_msb = prev_poc_lsb = 0;
+      int msb;
+      if (sl.poc_lsb < prev_poc_lsb && prev_poc_lsb - sl.poc_lsb >= max_lsb / 2) msb = prev_poc_msb + max_lsb;
+      else if (sl.poc_lsb > prev_poc_lsb && sl.poc_lsb - prev_poc_lsb > max_lsb / 2) msb = prev_poc_msb - max_lsb;
+      else msb = prev_poc_msb;
+      top = msb + sl.poc_lsb;
+      bottom = top + sl.delta_poc_bottom;
+      if (sl.nal_ref_idc) {
+        prev_poc_msb = msb;
+        prev_poc_lsb = sl.poc_lsb;
+      }
+    } else if (s.poc_type == 1) {
+      int abs_frame_num = s.num_ref_frames_in_poc_cycle ? fno + sl.frame_num : 0;
+      if (!sl.nal_ref_idc && abs_frame_num > 0) abs_frame_num--;
+      int per_cycle = 0;
+      for (int i = 0; i < s.num_ref_frames_in_poc_cycle; ++i) per_cycle += s.offset_for_ref_frame[i];
+      int expected = 0;
+      if (abs_frame_num > 0) {
+        int cycle = (abs_frame_num - 1) / s.num_ref_frames_in_poc_cycle;
+        int in_cycle = (abs_frame_num - 1) % s.num_ref_frames_in_poc_cycle;
+        expected = cycle * per_cycle;
+        for (int i = 0; i <= in_cycle; ++i) expected += s.offset_for_ref_frame[i];
+      }
+      if (!sl.nal_ref_idc) expected += s.offset_for_non_ref_pic;
+      top = expected + sl.delta_poc[0];
+      bottom = top + s.offset_for_top_to_bottom + sl.delta_poc[1];
+    } else {
+      top = bottom = sl.is_idr ? 0 : 2 * (fno + sl.frame_num) - (sl.nal_ref_idc ? 0 : 1);
+    }
+    c->poc = imin(top, bottom);
+    prev_frame_num_offset = fno;
+    prev_frame_num = sl.frame_num;
+  }
+
+  // ----------------------------------------------------------- ref lists
+  void init_ref_lists() {
+    const int max_frame_num = 1 << asps->log2_max_frame_num;
+    std::vector<Pic*> st, lt;
+    for (Pic& p : dpb) {
+      if (!p.in_use || &p == cur) continue;
+      if (p.ref == 1) {
+        p.frame_num_wrap = p.frame_num > sl.frame_num ? p.frame_num - max_frame_num : p.frame_num;
+        p.pic_num = p.frame_num_wrap;
+        st.push_back(&p);
+      } else if (p.ref == 2) {
+        p.pic_num = p.long_term_idx;
+        lt.push_back(&p);
+      }
+    }
+    std::sort(lt.begin(), lt.end(), [](Pic* a, Pic* b) { return a->long_term_idx < b->long_term_idx; });
+    for (int l = 0; l < 2; ++l) memset(sl.ref_list[l], 0, sizeof(sl.ref_list[l]));
+    if (sl.type == 0) {
+      std::sort(st.begin(), st.end(), [](Pic* a, Pic* b) { return a->pic_num > b->pic_num; });
+      int n = 0;
+      for (Pic* p : st) if (n < kMaxRefs) sl.ref_list[0][n++] = p;
+      for (Pic* p : lt) if (n < kMaxRefs) sl.ref_list[0][n++] = p;
+    } else if (sl.type == 1) {
+      std::vector<Pic*> before, after;
+      for (Pic* p : st) (p->poc < cur->poc ? before : after).push_back(p);
+      std::sort(before.begin(), before.end(), [](Pic* a, Pic* b) { return a->poc > b->poc; });
+      std::sort(after.begin(), after.end(), [](Pic* a, Pic* b) { return a->poc < b->poc; });
+      int n0 = 0, n1 = 0;
+      for (Pic* p : before) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
+      for (Pic* p : after) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
+      for (Pic* p : lt) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
+      for (Pic* p : after) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
+      for (Pic* p : before) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
+      for (Pic* p : lt) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
+      if (n1 > 1 && n0 == n1 && !memcmp(sl.ref_list[0], sl.ref_list[1], n1 * sizeof(Pic*)))
+        std::swap(sl.ref_list[1][0], sl.ref_list[1][1]);
+    }
+  }
+
+  bool modify_ref_list(Bits& b, int list) {
+    const int max_pic_num = 1 << asps->log2_max_frame_num;
+    int pred = sl.frame_num, idx = 0;
+    const int n = sl.num_ref_idx[list];
+    Pic** L = sl.ref_list[list];
+    for (;;) {
+      unsigned op = b.ue();
+      if (op == 3) break;
+      if (op > 3 || b.overrun || idx >= n) return fail("bad ref_pic_list_modification");
+      Pic* pic = nullptr;
+      if (op < 2) {
+        int diff = b.ue() + 1;
+        if (op == 0) {
+          pred -= diff;
+          if (pred < 0) pred += max_pic_num;
+        } else {
+          pred += diff;
+          if (pred >= max_pic_num) pred -= max_pic_num;
+        }
+        int pic_num = pred > sl.frame_num ? pred - max_pic_num : pred;
+        for (Pic& p : dpb)
+          if (p.in_use && &p != cur && p.ref == 1 && p.pic_num == pic_num) pic = &p;
+      } else {
+        int lt_num = b.ue();
+        for (Pic& p : dpb)
+          if (p.in_use && &p != cur && p.ref == 2 && p.long_term_idx == lt_num) pic = &p;
+      }
+      if (!pic) return fail("ref_pic_list_modification names a missing picture");
+      for (int c = n; c > idx; --c) L[c] = L[c - 1];
+      L[idx++] = pic;
+      int w = idx;
+      for (int c = idx; c <= n; ++c)
+        if (L[c] != pic) L[w++] = L[c];
+    }
+    return true;
+  }
+
+  // --------------------------------------------------------- slice header
+  // returns 0 ok, 1 skip this NAL, -1 error
+  int parse_slice_header(Bits& b, int nal_ref_idc, int nal_type) {
+    sl = SliceHdr();
+    sl.nal_ref_idc = nal_ref_idc;
+    sl.is_idr = nal_type == 5;
+    sl.first_mb = b.ue();
+    unsigned st = b.ue();
+    if (st > 9) return fail("bad slice_type") ? 0 : -1;
+    st %= 5;
+    if (st > 2) return fail("unsupported stream: SP/SI slices") ? 0 : -1;
+    sl.type = st;
+    sl.pps_id = b.ue();
+    if (sl.pps_id >= kMaxPps || !pps[sl.pps_id].valid) return fail("slice refers to a missing PPS") ? 0 : -1;
+    const Pps* p = &pps[sl.pps_id];
+    const Sps* s = &sps[p->sps_id];
+    sl.frame_num = b.get(s->log2_max_frame_num);
+    if (sl.is_idr) b.ue();
+    if (s->poc_type == 0) {
+      sl.poc_lsb = b.get(s->log2_max_poc_lsb);
+      if (p->bottom_field_pic_order_present) sl.delta_poc_bottom = b.se();
+    } else if (s->poc_type == 1 && !s->delta_pic_order_always_zero) {
+      sl.delta_poc[0] = b.se();
+      if (p->bottom_field_pic_order_present) sl.delta_poc[1] = b.se();
+    }
+    if (p->redundant_pic_cnt_present && b.ue() != 0) return 1;
+    if (sl.type == 1) sl.direct_spatial = b.bit();
+    sl.num_ref_idx[0] = p->num_ref_idx_default[0];
+    sl.num_ref_idx[1] = p->num_ref_idx_default[1];
+    if (sl.type != 2) {
+      if (b.bit()) {
+        sl.num_ref_idx[0] = b.ue() + 1;
+        if (sl.type == 1) sl.num_ref_idx[1] = b.ue() + 1;
+      }
+      if (sl.num_ref_idx[0] > kMaxRefs || sl.num_ref_idx[1] > kMaxRefs)
+        return fail("num_ref_idx_active out of range") ? 0 : -1;
+    }
+    if (sl.type != 1) sl.num_ref_idx[1] = 0;
+    if (sl.type == 2) sl.num_ref_idx[0] = 0;
+
+    if (sl.first_mb != 0 && skipping_picture) return 1;
+    skipping_picture = false;
+    if (sl.first_mb == 0 || !pic_in_progress) {
+      if (pic_in_progress && !finish_picture()) return -1;
+      apps = p;
+      asps = s;
+      int r = start_picture();
+      if (r != 0) return r;
+    } else if (p->sps_id != apps->sps_id) {
+      return fail("SPS changed inside a picture") ? 0 : -1;
+    } else {
+      apps = p;
+    }
+
+    if (sl.type != 2) {
+      init_ref_lists();
+      if (b.bit() && !modify_ref_list(b, 0)) return -1;
+      if (sl.type == 1 && b.bit() && !modify_ref_list(b, 1)) return -1;
+      for (int l = 0; l < 2; ++l)
+        for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
+          if (!sl.ref_list[l][i]) return fail("reference list has a missing picture") ? 0 : -1;
+          if (sl.ref_list[l][i]->slot < 0)
+            return fail("a skipped picture is used as a reference") ? 0 : -1;
+        }
+    }
+    sl.use_weight = 0;
+    if ((p->weighted_pred && sl.type == 0) || (p->weighted_bipred_idc == 1 && sl.type == 1)) {
+      sl.use_weight = 1;
+      sl.luma_log2_denom = b.ue();
+      sl.chroma_log2_denom = b.ue();
+      if (sl.luma_log2_denom > 7 || sl.chroma_log2_denom > 7) return fail("bad weight denominator") ? 0 : -1;
+      for (int l = 0; l < (sl.type == 1 ? 2 : 1); ++l)
+        for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
+          sl.luma_weight[l][i] = 1 << sl.luma_log2_denom;
+          sl.luma_offset[l][i] = 0;
+          if (b.bit()) {
+            sl.luma_weight[l][i] = b.se();
+            sl.luma_offset[l][i] = b.se();
+          }
+          for (int c = 0; c < 2; ++c) {
+            sl.chroma_weight[l][i][c] = 1 << sl.chroma_log2_denom;
+            sl.chroma_offset[l][i][c] = 0;
+          }
+          if (b.bit())
+            for (int c = 0; c < 2; ++c) {
+              sl.chroma_weight[l][i][c] = b.se();
+              sl.chroma_offset[l][i][c] = b.se();
+            }
+        }
+    } else if (p->weighted_bipred_idc == 2 && sl.type == 1) {
+      sl.use_weight = 2;
+    }
+    if (nal_ref_idc) {
+      if (sl.is_idr) {
+        b.bit();
+        sl.long_term_reference_flag = b.bit();
+      } else {
+        sl.adaptive_marking = b.bit();
+        if (sl.adaptive_marking) {
+          for (;;) {
+            unsigned op = b.ue();
+            if (op == 0) break;
+            if (op > 6 || sl.mmco_count >= 64 || b.overrun) return fail("bad MMCO") ? 0 : -1;
+            int a = 0, c = 0;
+            if (op == 1 || op == 3) a = b.ue();
+            if (op == 2) a = b.ue();
+            if (op == 3 || op == 6) c = b.ue();
+            if (op == 4) a = b.ue();
+            sl.mmco[sl.mmco_count].op = op;
+            sl.mmco[sl.mmco_count].a = a;
+            sl.mmco[sl.mmco_count].b = c;
+            sl.mmco_count++;
+          }
+        }
+      }
+    }
+    if (p->cabac && sl.type != 2) {
+      sl.cabac_init_idc = b.ue();
+      if (sl.cabac_init_idc > 2) return fail("bad cabac_init_idc") ? 0 : -1;
+    }
+    sl.qp = p->init_qp + b.se();
+    if (sl.qp < 0 || sl.qp > 51) return fail("slice QP out of range") ? 0 : -1;
+    if (p->deblocking_control_present) {
+      sl.disable_deblock = b.ue();
+      if (sl.disable_deblock > 2) return fail("bad disable_deblocking_filter_idc") ? 0 : -1;
+      if (sl.disable_deblock != 1) {
+        sl.alpha_offset = b.se() * 2;
+        sl.beta_offset = b.se() * 2;
+      }
+    }
+    if (b.overrun) return fail("truncated slice header") ? 0 : -1;
+    if (num_slices >= bufs.max_slices) return fail("too many slices in one picture") ? 0 : -1;
+    slice_index = num_slices + 1;
+    fill_slice_params(&bufs.slices[num_slices]);
+    ++num_slices;
+    slice_type_mask |= sl.type == 0 ? 1 : (sl.type == 1 ? 2 : 4);
+    return 0;
+  }
+
+  void fill_slice_params(SliceParams* sp) {
+    memset(sp, 0, sizeof(*sp));
+    sp->alpha_offset = static_cast<int8_t>(sl.alpha_offset);
+    sp->beta_offset = static_cast<int8_t>(sl.beta_offset);
+    sp->weight_mode = static_cast<uint8_t>(sl.use_weight);
+    sp->luma_log2_denom = static_cast<uint8_t>(sl.luma_log2_denom);
+    sp->chroma_log2_denom = static_cast<uint8_t>(sl.chroma_log2_denom);
+    sp->cur_poc = cur->poc;
+    for (int l = 0; l < 2; ++l)
+      for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
+        sp->luma_weight[l][i] = static_cast<int16_t>(sl.luma_weight[l][i]);
+        sp->luma_offset[l][i] = static_cast<int16_t>(sl.luma_offset[l][i]);
+        for (int c = 0; c < 2; ++c) {
+          sp->chroma_weight[l][i][c] = static_cast<int16_t>(sl.chroma_weight[l][i][c]);
+          sp->chroma_offset[l][i][c] = static_cast<int16_t>(sl.chroma_offset[l][i][c]);
+        }
+        sp->ref_poc[l][i] = sl.ref_list[l][i]->poc;
+        sp->ref_long[l][i] = sl.ref_list[l][i]->ref == 2;
+      }
+  }
+
+  // returns 0 ok, 1 picture skipped on purpose, -1 error
+  int start_picture() {
+    mbw = asps->mb_width;
+    mbh = asps->mb_height;
+    const int nmb = mbw * mbh;
+    if (sl.is_idr) {
+      cur = nullptr;
+      output_all();
+      for (Pic& p : dpb) p.ref = 0;
+      release_unused();
+      prev_frame_num = prev_frame_num_offset = 0;
+      max_long_term_frame_idx = -1;
+    } else if (prev_ref_has_mmco5) {
+      prev_frame_num = prev_frame_num_offset = 0;
+    }
+    prev_ref_has_mmco5 = false;
+    release_unused();
+    Pic* c = grab_pic();
+    if (!c) return fail("decoded picture buffer exhausted") ? 0 : -1;
+    cur = c;
+    c->frame_num = sl.frame_num;
+    compute_poc(c);
+
+    // Sparse decode: an unwanted non-reference picture is not decoded.  Its
+    // display position is predicted as (already output) + (pending pictures
+    // that precede it); emit() verifies the prediction.
+    if (!wanted.empty() && !sl.nal_ref_idc) {
+      uint64_t pos = outputs_emitted;
+      for (Pic& p : dpb)
+        if (p.in_use && &p != c && p.needed_for_output && p.poc < c->poc) ++pos;
+      if (!std::binary_search(wanted.begin(), wanted.end(), pos)) {
+        c->slot = -1;
+        c->needed_for_output = true;
+        cur = nullptr;
+        pic_in_progress = false;
+        skipping_picture = true;
+        ++owner->pictures_skipped_;
+        bump();
+        return 1;
+      }
+    }
+
+    PicSetup setup{mbw, mbh, asps->crop_left, asps->crop_right, asps->crop_top, asps->crop_bottom};
+    bufs = PicBuffers();
+    if (!sink->begin_picture(setup, &bufs, err)) {
+      c->in_use = false;
+      cur = nullptr;
+      return -1;
+    }
+    c->slot = bufs.slot;
+    c->motion = bufs.motion;
+    for (int l = 0; l < 2; ++l) c->ref_uid[l].assign(nmb * 4, -1);
+    c->mb_intra.assign(nmb, 0);
+    mb_slice.assign(nmb, -1);
+    mb_kind.assign(nmb, 0);
+    mb_skip.assign(nmb, 0);
+    mb_direct.assign(nmb, 0);
+    direct8.assign(nmb * 4, 0);
+    mb_t8x8.assign(nmb, 0);
+    mb_cbp.assign(nmb, 0);
+    mb_cbf_dc.assign(nmb, 0);
+    mb_chroma_mode.assign(nmb, 0);
+    i4mode.assign(nmb * 16, 2);
+    nnz.assign(nmb * 24, 0);
+    mvd.assign(static_cast<size_t>(nmb) * 64, 0);
+    coef_used = 0;
+    num_slices = 0;
+    slice_index = 0;
+    has_inter = has_intra = false;
+    slice_type_mask = 0;
+    pic_in_progress = true;
+    return 0;
+  }
+
+  void unmark_long_idx(int idx, Pic* except) {
+    for (Pic& p : dpb)
+      if (p.in_use && &p != except && p.ref == 2 && p.long_term_idx == idx) p.ref = 0;
+  }
+
+  void mark_references(Pic* c) {
+    if (!sl.nal_ref_idc) return;
+    if (sl.is_idr) {
+      if (sl.long_term_reference_flag) {
+        c->ref = 2;
+        c->long_term_idx = 0;
+        max_long_term_frame_idx = 0;
+      } else {
+        c->ref = 1;
+        max_long_term_frame_idx = -1;
+      }
+      return;
+    }
+    bool cur_is_long = false;
+    if (sl.adaptive_marking) {
+      for (int k = 0; k < sl.mmco_count; ++k) {
+        const int op = sl.mmco[k].op, a = sl.mmco[k].a, bb = sl.mmco[k].b;
+        if (op == 1 || op == 3) {
+          const int pic_num = sl.frame_num - (a + 1);
+          for (Pic& p : dpb) {
+            if (!p.in_use || &p == c || p.ref != 1 || p.pic_num != pic_num) continue;
+            if (op == 1) {
+              p.ref = 0;
+            } else {
+              unmark_long_idx(bb, &p);
+              p.ref = 2;
+              p.long_term_idx = bb;
+            }
+          }
+        } else if (op == 2) {
+          for (Pic& p : dpb)
+            if (p.in_use && &p != c && p.ref == 2 && p.long_term_idx == a) p.ref = 0;
+        } else if (op == 4) {
+          max_long_term_frame_idx = a - 1;
+          for (Pic& p : dpb)
+            if (p.in_use && &p != c && p.ref == 2 && p.long_term_idx > a - 1) p.ref = 0;
+        } else if (op == 5) {
+          for (Pic& p : dpb)
+            if (&p != c) p.ref = 0;
+          max_long_term_frame_idx = -1;
+          prev_ref_has_mmco5 = true;
+          prev_poc_msb = prev_poc_lsb = 0;
+          c->frame_num = 0;
+        } else if (op == 6) {
+          unmark_long_idx(a, c);
+          c->ref = 2;
+          c->long_term_idx = a;
+          cur_is_long = true;
+        }
+      }
+    } else {
+      int n = 0;
+      Pic* oldest = nullptr;
+      for (Pic& p : dpb) {
+        if (!p.in_use || &p == c || !p.ref) continue;
+        ++n;
+        if (p.ref == 1 && (!oldest || p.frame_num_wrap < oldest->frame_num_wrap)) oldest = &p;
+      }
+      if (n >= imax(asps->max_num_ref_frames, 1) && oldest) oldest->ref = 0;
+    }
+    if (!cur_is_long) c->ref = 1;
+  }
+
+  void bump() {
+    const int depth = reorder_depth();
+    for (;;) {
+      int n = 0;
+      Pic* p = lowest_poc_pending(&n);
+      if (!p || n <= depth) break;
+      emit(p);
+    }
+    release_unused();
+  }
+
+  bool finish_picture() {
+    if (!pic_in_progress) return true;
+    pic_in_progress = false;
+    Pic* c = cur;
+    const int nmb = mbw * mbh;
+    for (int i = 0; i < nmb; ++i)
+      if (mb_slice[i] < 0) return fail("picture ended with undecoded macroblocks");
+
+    PicDone done;
+    memset(&done, 0, sizeof(done));
+    done.slot = c->slot;
+    done.num_slices = num_slices;
+    done.coef_count = coef_used;
+    done.has_inter = has_inter;
+    done.has_intra = has_intra;
+    done.slice_type_mask = slice_type_mask;
+    done.scaling4 = apps->scaling4;
+    done.scaling8 = apps->scaling8;
+    done.num_ref_slots = 0;
+    for (Pic& p : dpb)
+      if (p.in_use && &p != c && p.ref && p.slot >= 0 && done.num_ref_slots < 32)
+        done.ref_slots[done.num_ref_slots++] = p.slot;
+    if (!sink->end_picture(done, err)) return false;
+    ++owner->pictures_decoded_;
+
+    const int max_frame_num = 1 << asps->log2_max_frame_num;
+    for (Pic& p : dpb)
+      if (p.in_use && &p != c && p.ref == 1) {
+        p.frame_num_wrap = p.frame_num > sl.frame_num ? p.frame_num - max_frame_num : p.frame_num;
+        p.pic_num = p.frame_num_wrap;
+      }
+    mark_references(c);
+    c->needed_for_output = true;
+    if (prev_ref_has_mmco5) {
+      cur = nullptr;
+      c->needed_for_output = false;
+      output_all();
+      c->needed_for_output = true;
+      c->poc = 0;
+    }
+    cur = nullptr;
+    bump();
+    return err->empty();
+  }
+
+  // =================================================================== MBs
+  inline bool mb_avail(int mbx, int mby) const {
+    if (mbx < 0 || mby < 0 || mbx >= mbw || mby >= mbh) return false;
+    return mb_slice[mby * mbw + mbx] == slice_index;
+  }
+  inline bool intra_mb_ok(int mbx, int mby) const {
+    if (!mb_avail(mbx, mby)) return false;
+    return !(apps->constrained_intra_pred && mb_kind[mby * mbw + mbx] == MB_INTER);
+  }
+  uint8_t* mvd_at(int addr, int list, int blk) { return &mvd[(static_cast<size_t>(addr) * 2 + list) * 32 + blk * 2]; }
+
+  NB fetch_nb(int list, int rx, int ry, int cur_zz) const {
+    NB nb = {-2, {0, 0}};
+    if (rx > 3 && ry >= 0) return nb;
+    const int ox = rx < 0 ? -1 : (rx > 3 ? 1 : 0), oy = ry < 0 ? -1 : 0;
+    const int nx = mb.mbx + ox, ny = mb.mby + oy;
+    const int bx = rx & 3, by = ry & 3;
+    if (ox == 0 && oy == 0) {
+      if (raster_to_blk4[by * 4 + bx] >= cur_zz) return nb;
+    } else if (!mb_avail(nx, ny)) {
+      return nb;
+    }
+    const int addr = ny * mbw + nx;
+    nb.ref = -1;
+    if (cur->mb_intra[addr]) return nb;
+    const MbMotion& mo = cur->motion[addr];
+    int r = mo.ref_idx[list][(by >> 1) * 2 + (bx >> 1)];
+    if (r < 0) return nb;
+    nb.ref = r;
+    nb.mv[0] = mo.mv[list][by * 4 + bx][0];
+    nb.mv[1] = mo.mv[list][by * 4 + bx][1];
+    return nb;
+  }
+
+  void pred_mv(int list, int bx, int by, int bw, int ref, int dir, int out[2]) const {
+    const int zz = raster_to_blk4[by * 4 + bx];
+    NB A = fetch_nb(list, bx - 1, by, zz);
+    NB B = fetch_nb(list, bx, by - 1, zz);
+    NB C = fetch_nb(list, bx + bw, by - 1, zz);
+    if (C.ref == -2) C = fetch_nb(list, bx - 1, by - 1, zz);
+    const NB* pick = nullptr;
+    if (dir == PRED_16x8_TOP && B.ref == ref) pick = &B;
+    if (dir == PRED_16x8_BOTTOM && A.ref == ref) pick = &A;
+    if (dir == PRED_8x16_LEFT && A.ref == ref) pick = &A;
+    if (dir == PRED_8x16_RIGHT && C.ref == ref) pick = &C;
+    if (!pick) {
+      int match = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+      if (match == 1) pick = A.ref == ref ? &A : (B.ref == ref ? &B : &C);
+      else if (match == 0 && B.ref == -2 && C.ref == -2 && A.ref != -2) pick = &A;
+    }
+    if (pick) {
+      out[0] = pick->mv[0];
+      out[1] = pick->mv[1];
+    } else {
+      out[0] = median3(A.mv[0], B.mv[0], C.mv[0]);
+      out[1] = median3(A.mv[1], B.mv[1], C.mv[1]);
+    }
+  }
+
+  void set_mv_block(int list, int bx, int by, int bw, int bh, int mvx, int mvy) {
+    MbMotion& mo = cur->motion[mb.addr];
+    for (int y = by; y < by + bh; ++y)
+      for (int x = bx; x < bx + bw; ++x) {
+        mo.mv[list][y * 4 + x][0] = static_cast<int16_t>(mvx);
+        mo.mv[list][y * 4 + x][1] = static_cast<int16_t>(mvy);
+      }
+  }
+  void set_mvd_block(int list, int bx, int by, int bw, int bh, int dx, int dy) {
+    uint8_t ax = static_cast<uint8_t>(imin(iabs(dx), 255)), ay = static_cast<uint8_t>(imin(iabs(dy), 255));
+    for (int y = by; y < by + bh; ++y)
+      for (int x = bx; x < bx + bw; ++x) {
+        uint8_t* m = mvd_at(mb.addr, list, y * 4 + x);
+        m[0] = ax;
+        m[1] = ay;
+      }
+  }
+  void set_ref8(int list, int b8, int ref) {
+    MbMotion& mo = cur->motion[mb.addr];
+    mo.ref_idx[list][b8] = static_cast<int8_t>(ref);
+    if (ref >= 0 && ref < sl.num_ref_idx[list] && sl.ref_list[list][ref]) {
+      const Pic* r = sl.ref_list[list][ref];
+      mo.ref_slot[list][b8] = static_cast<int8_t>(r->slot);
+      cur->ref_uid[list][mb.addr * 4 + b8] = r->uid;
+    } else {
+      mo.ref_slot[list][b8] = -1;
+      cur->ref_uid[list][mb.addr * 4 + b8] = -1;
+    }
+  }
+
+  bool pred_direct(int only_b8) {
+    const Pic* col = sl.ref_list[1][0];
+    if (!col || !col->motion) return fail("direct prediction without RefPicList1[0]");
+    const int inf8 = asps->direct_8x8_inference;
+    const int addr = mb.addr;
+    const MbMotion& cm = col->motion[addr];
+    if (sl.direct_spatial) {
+      int ref[2], mvp[2][2] = {{0, 0}, {0, 0}};
+      for (int l = 0; l < 2; ++l) {
+        NB A = fetch_nb(l, -1, 0, 0), B = fetch_nb(l, 0, -1, 0), C = fetch_nb(l, 4, -1, 0);
+        if (C.ref == -2) C = fetch_nb(l, -1, -1, 0);
+        int r = -1;
+        if (A.ref >= 0) r = A.ref;
+        if (B.ref >= 0 && (r < 0 || B.ref < r)) r = B.ref;
+        if (C.ref >= 0 && (r < 0 || C.ref < r)) r = C.ref;
+        ref[l] = r;
+        if (r >= 0) pred_mv(l, 0, 0, 4, r, PRED_MEDIAN, mvp[l]);
+      }
+      if (ref[0] < 0 && ref[1] < 0) ref[0] = ref[1] = 0;
+      const bool col_short = col->ref == 1;
+      for (int b8 = 0; b8 < 4; ++b8) {
+        if (only_b8 >= 0 && b8 != only_b8) continue;
+        for (int l = 0; l < 2; ++l) set_ref8(l, b8, ref[l]);
+        for (int s = 0; s < 4; ++s) {
+          const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
+          const int cx = inf8 ? (b8 & 1) * 3 : bx, cy = inf8 ? (b8 >> 1) * 3 : by;
+          bool col_zero = false;
+          if (col_short && !col->mb_intra[addr]) {
+            const int c8 = (cy >> 1) * 2 + (cx >> 1);
+            const int cl = cm.ref_idx[0][c8] >= 0 ? 0 : 1;
+            if (cm.ref_idx[cl][c8] == 0) {
+              const int16_t* v = cm.mv[cl][cy * 4 + cx];
+              col_zero = v[0] >= -1 && v[0] <= 1 && v[1] >= -1 && v[1] <= 1;
+            }
+          }
+          for (int l = 0; l < 2; ++l) {
+            bool zero = ref[l] < 0 || (ref[l] == 0 && col_zero);
+            set_mv_block(l, bx, by, 1, 1, zero ? 0 : mvp[l][0], zero ? 0 : mvp[l][1]);
+          }
+        }
+      }
+      return true;
+    }
+    for (int b8 = 0; b8 < 4; ++b8) {
+      if (only_b8 >= 0 && b8 != only_b8) continue;
+      for (int s = 0; s < 4; ++s) {
+        const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
+        const int cx = inf8 ? (b8 & 1) * 3 : bx, cy = inf8 ? (b8 >> 1) * 3 : by;
+        int ref0 = 0, mvc[2] = {0, 0};
+        if (!col->mb_intra[addr]) {
+          const int c8 = (cy >> 1) * 2 + (cx >> 1);
+          const int cl = cm.ref_idx[0][c8] >= 0 ? 0 : 1;
+          if (cm.ref_idx[cl][c8] >= 0) {
+            mvc[0] = cm.mv[cl][cy * 4 + cx][0];
+            mvc[1] = cm.mv[cl][cy * 4 + cx][1];
+            const int uid = col->ref_uid[cl][addr * 4 + c8];
+            ref0 = -1;
+            for (int i = 0; i < sl.num_ref_idx[0]; ++i)
+              if (sl.ref_list[0][i] && sl.ref_list[0][i]->uid == uid) {
+                ref0 = i;
+                break;
+              }
+            if (ref0 < 0) return fail("temporal direct: co-located reference not in RefPicList0");
+          }
+        }
+        const Pic* p0 = sl.ref_list[0][ref0];
+        int mv0[2], mv1[2];
+        const int td = iclip(-128, 127, col->poc - p0->poc);
+        if (p0->ref == 2 || td == 0) {
+          mv0[0] = mvc[0];
+          mv0[1] = mvc[1];
+          mv1[0] = mv1[1] = 0;
+        } else {
+          const int tb = iclip(-128, 127, cur->poc - p0->poc);
+          const int tx = (16384 + iabs(td / 2)) / td;
+          const int dsf = iclip(-1024, 1023, (tb * tx + 32) >> 6);
+          mv0[0] = (dsf * mvc[0] + 128) >> 8;
+          mv0[1] = (dsf * mvc[1] + 128) >> 8;
+          mv1[0] = mv0[0] - mvc[0];
+          mv1[1] = mv0[1] - mvc[1];
+        }
+        if (s == 0) {
+          set_ref8(0, b8, ref0);
+          set_ref8(1, b8, 0);
+        }
+        set_mv_block(0, bx, by, 1, 1, mv0[0], mv0[1]);
+        set_mv_block(1, bx, by, 1, 1, mv1[0], mv1[1]);
+      }
+    }
+    return true;
+  }
+
+  // ------------------------------------------------------------- residual
+  int read_vlc(const uint8_t* len, const uint8_t* code, int n) {
+    const unsigned window = bits.peek(16);
+    for (int i = 0; i < n; ++i) {
+      if (!len[i]) continue;
+      if ((window >> (16 - len[i])) == code[i]) {
+        if (bits.left() < len[i]) break;
+        bits.pos += len[i];
+        return i;
+      }
+    }
+    bits.overrun = true;
+    return -1;
+  }
+  int cavlc_nc(int plane, int rx, int ry) const {
+    const int n = plane == 0 ? 4 : 2;
+    const int base = plane == 0 ? 0 : (plane == 1 ? 16 : 20);
+    int na = -1, nb = -1;
+    if (rx > 0) na = mb.nnz[base + ry * n + rx - 1];
+    else if (mb_avail(mb.mbx - 1, mb.mby)) na = nnz[(mb.addr - 1) * 24 + base + ry * n + n - 1];
+    if (ry > 0) nb = mb.nnz[base + (ry - 1) * n + rx];
+    else if (mb_avail(mb.mbx, mb.mby - 1)) nb = nnz[(mb.addr - mbw) * 24 + base + (n - 1) * n + rx];
+    if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
+    if (na >= 0) return na;
+    if (nb >= 0) return nb;
+    return 0;
+  }
+  int cavlc_block(int nc, int max_coeff, const uint8_t* scan, int start, int16_t* out) {
+    Bits& b = bits;
+    int token;
+    if (nc == -1) {
+      token = read_vlc(chroma_dc_coeff_token_len, chroma_dc_coeff_token_bits, 20);
+    } else {
+      const int t = nc < 2 ? 0 : (nc < 4 ? 1 : (nc < 8 ? 2 : 3));
+      token = read_vlc(coeff_token_len[t], coeff_token_bits[t], 68);
+    }
+    if (token < 0) return fail("CAVLC: bad coeff_token") ? 0 : -1;
+    const int total = token >> 2, t1 = token & 3;
+    if (total == 0) return 0;
+    if (total > max_coeff) return fail("CAVLC: total_coeff exceeds block size") ? 0 : -1;
+    int level[16];
+    for (int i = 0; i < t1; ++i) level[i] = b.bit() ? -1 : 1;
+    int suffix_len = (total > 10 && t1 < 3) ? 1 : 0;
+    for (int i = t1; i < total; ++i) {
+      int prefix = 0;
+      while (!b.bit()) {
+        if (++prefix > 31 || b.overrun) return fail("CAVLC: bad level_prefix") ? 0 : -1;
+      }
+      int code = imin(15, prefix) << suffix_len;
+      int size = suffix_len;
+      if (prefix == 14 && suffix_len == 0) size = 4;
+      if (prefix >= 15) size = prefix - 3;
+      if (size > 0) code += b.get(size);
+      if (prefix >= 15 && suffix_len == 0) code += 15;
+      if (prefix >= 16) code += (1 << (prefix - 3)) - 4096;
+      if (i == t1 && t1 < 3) code += 2;
+      level[i] = (code & 1) ? (-code - 1) >> 1 : (code + 2) >> 1;
+      if (suffix_len == 0) suffix_len = 1;
+      if (iabs(level[i]) > (3 << (suffix_len - 1)) && suffix_len < 6) ++suffix_len;
+    }
+    int zeros_left = 0;
+    if (total < max_coeff) {
+      int tz = nc == -1 ? read_vlc(chroma_dc_total_zeros_len[total - 1], chroma_dc_total_zeros_bits[total - 1], 4)
+                        : read_vlc(total_zeros_len[total - 1], total_zeros_bits[total - 1],
+                                   total_zeros_count[total - 1]);
+      if (tz < 0) return fail("CAVLC: bad total_zeros") ? 0 : -1;
+      zeros_left = tz;
+    }
+    if (zeros_left + total > max_coeff) return fail("CAVLC: total_zeros exceeds block size") ? 0 : -1;
+    int pos = zeros_left + total - 1;
+    for (int i = 0; i < total; ++i) {
+      out[scan[start + pos]] = static_cast<int16_t>(level[i]);
+      if (i == total - 1) break;
+      int run = 0;
+      if (zeros_left > 0) {
+        const int t = imin(zeros_left, 7) - 1;
+        run = read_vlc(run_before_len[t], run_before_bits[t], run_before_count[t]);
+        if (run < 0 || run > zeros_left) return fail("CAVLC: bad run_before") ? 0 : -1;
+        zeros_left -= run;
+      }
+      pos -= run + 1;
+    }
+    return total;
+  }
+
+  int cabac_block(int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start, int16_t* out) {
+    Cabac& c = cabac;
+    if (cbf_inc >= 0 && !c.bin(85 + cbf_cat_offset[cat] + cbf_inc)) return 0;
+    const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
+    const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
+    const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
+    int idx[64], n = 0, i;
+    for (i = 0; i < max_coeff - 1; ++i) {
+      int sinc, linc;
+      if (cat == 5) {
+        sinc = sig_coeff_offset_8x8[i];
+        linc = last_coeff_offset_8x8[i];
+      } else if (cat == 3) {
+        sinc = linc = imin(i, 2);
+      } else {
+        sinc = linc = i;
+      }
+      if (c.bin(sig_base + sinc)) {
+        idx[n++] = i;
+        if (c.bin(last_base + linc)) break;
+      }
+    }
+    if (i == max_coeff - 1) idx[n++] = max_coeff - 1;
+    int gt1 = 0, eq1 = 0;
+    for (int k = n - 1; k >= 0; --k) {
+      const int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
+      int val;
+      if (!c.bin(abs_base + inc0)) {
+        val = 1;
+        ++eq1;
+      } else {
+        const int inc = 5 + imin(4 - (cat == 3 ? 1 : 0), gt1);
+        val = 2;
+        while (val < 15 && c.bin(abs_base + inc)) ++val;
+        if (val == 15) {
+          int k0 = 0;
+          while (c.bypass()) {
+            val += 1 << k0;
+            if (++k0 > 24) return fail("CABAC: coeff_abs_level overflow") ? 0 : -1;
+          }
+          while (k0--) val += c.bypass() << k0;
+        }
+        ++gt1;
+      }
+      if (c.bypass()) val = -val;
+      out[scan[start + idx[k]]] = static_cast<int16_t>(val);
+    }
+    return n;
+  }
+
+  int cbf_neighbour(int kind, int p, int rx, int ry, bool left) const {
+    const bool cur_intra = mb.kind != MB_INTER;
+    int nx = mb.mbx, ny = mb.mby;
+    bool inside = false;
+    if (kind == 1 || kind == 3) {
+      if (left) {
+        if (rx > 0) inside = true; else nx--;
+      } else {
+        if (ry > 0) inside = true; else ny--;
+      }
+    } else {
+      if (left) nx--; else ny--;
+    }
+    if (inside) {
+      if (kind == 1) return mb.nnz[left ? ry * 4 + rx - 1 : (ry - 1) * 4 + rx] != 0;
+      return mb.nnz[16 + 4 * p + (left ? ry * 2 + rx - 1 : (ry - 1) * 2 + rx)] != 0;
+    }
+    if (!mb_avail(nx, ny)) return cur_intra;
+    const int addr = ny * mbw + nx;
+    if (mb_kind[addr] == MB_IPCM) return 1;
+    switch (kind) {
+      case 0: return mb_kind[addr] == MB_I16x16 && (mb_cbf_dc[addr] & 1);
+      case 1: return nnz[addr * 24 + (left ? ry * 4 + 3 : 12 + rx)] != 0;
+      case 2: return (mb_cbf_dc[addr] >> (1 + p)) & 1;
+      default: return nnz[addr * 24 + 16 + 4 * p + (left ? ry * 2 + 1 : 2 + rx)] != 0;
+    }
+  }
+  int cbf_inc(int kind, int p, int rx, int ry) const {
+    return cbf_neighbour(kind, p, rx, ry, true) + 2 * cbf_neighbour(kind, p, rx, ry, false);
+  }
+
+  // ---------------------------------------------------- syntax elements
+  int rd_intra_mb_type(int ctx_base, int intra_slice) {
+    Cabac& c = cabac;
+    if (intra_slice) {
+      int inc = 0;
+      if (mb_avail(mb.mbx - 1, mb.mby)) {
+        int k = mb_kind[mb.addr - 1];
+        inc += k != MB_I4x4 && k != MB_I8x8;
+      }
+      if (mb_avail(mb.mbx, mb.mby - 1)) {
+        int k = mb_kind[mb.addr - mbw];
+        inc += k != MB_I4x4 && k != MB_I8x8;
+      }
+      if (!c.bin(ctx_base + inc)) return 0;
+      ctx_base += 2;
+    } else if (!c.bin(ctx_base)) {
+      return 0;
+    }
+    if (c.terminate()) return 25;
+    int t = 1;
+    t += 12 * c.bin(ctx_base + 1);
+    if (c.bin(ctx_base + 2)) t += 4 + 4 * c.bin(ctx_base + 2 + intra_slice);
+    t += 2 * c.bin(ctx_base + 3 + intra_slice);
+    t += c.bin(ctx_base + 3 + 2 * intra_slice);
+    return t;
+  }
+  int rd_mb_type() {
+    const int st = sl.type;
+    if (!use_cabac) return static_cast<int>(bits.ue());
+    Cabac& c = cabac;
+    if (st == 2) return rd_intra_mb_type(3, 1);
+    if (st == 0) {
+      if (!c.bin(14)) {
+        if (!c.bin(15)) return 3 * c.bin(16);
+        return 2 - c.bin(17);
+      }
+      return 5 + rd_intra_mb_type(17, 0);
+    }
+    int inc = 0;
+    if (mb_avail(mb.mbx - 1, mb.mby) && !mb_direct[mb.addr - 1]) inc++;
+    if (mb_avail(mb.mbx, mb.mby - 1) && !mb_direct[mb.addr - mbw]) inc++;
+    if (!c.bin(27 + inc)) return 0;
+    if (!c.bin(27 + 3)) return 1 + c.bin(27 + 5);
+    int v = c.bin(27 + 4) << 3;
+    v |= c.bin(27 + 5) << 2;
+    v |= c.bin(27 + 5) << 1;
+    v |= c.bin(27 + 5);
+    if (v < 8) return v + 3;
+    if (v == 13) return 23 + rd_intra_mb_type(32, 0);
+    if (v == 14) return 11;
+    if (v == 15) return 22;
+    v = (v << 1) | c.bin(27 + 5);
+    return v - 4;
+  }
+  int rd_sub_mb_type() {
+    if (!use_cabac) return static_cast<int>(bits.ue());
+    Cabac& c = cabac;
+    if (sl.type == 0) {
+      if (c.bin(21)) return 0;
+      if (!c.bin(22)) return 1;
+      return c.bin(23) ? 2 : 3;
+    }
+    if (!c.bin(36)) return 0;
+    if (!c.bin(37)) return 1 + c.bin(39);
+    int t = 3;
+    if (c.bin(38)) {
+      if (c.bin(39)) return 11 + c.bin(39);
+      t += 4;
+    }
+    t += 2 * c.bin(39);
+    t += c.bin(39);
+    return t;
+  }
+  int rd_ref_idx(int list, int b8) {
+    const int n = sl.num_ref_idx[list];
+    if (n <= 1) return 0;
+    if (!use_cabac) return n == 2 ? !bits.bit() : static_cast<int>(bits.ue());
+    const int bx = (b8 & 1) * 2, by = (b8 >> 1) * 2;
+    int inc = 0;
+    for (int k = 0; k < 2; ++k) {
+      const int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
+      const int nx = mb.mbx + (rx < 0 ? -1 : 0), ny = mb.mby + (ry < 0 ? -1 : 0);
+      const bool inside = rx >= 0 && ry >= 0;
+      if (!inside && !mb_avail(nx, ny)) continue;
+      const int addr = ny * mbw + nx;
+      const int q = ((ry & 3) >> 1) * 2 + ((rx & 3) >> 1);
+      if (cur->mb_intra[addr]) continue;
+      if (sl.type == 1 && direct8[addr * 4 + q]) continue;
+      if (cur->motion[addr].ref_idx[list][q] > 0) inc += k == 0 ? 1 : 2;
+    }
+    int ref = 0;
+    while (cabac.bin(54 + inc)) {
+      ++ref;
+      inc = (inc >> 2) + 4;
+      if (ref >= 32) return -1;
+    }
+    return ref;
+  }
+  int rd_mvd(int list, int bx, int by, int comp) {
+    if (!use_cabac) return bits.se();
+    int sum = 0;
+    for (int k = 0; k < 2; ++k) {
+      const int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
+      const int nx = mb.mbx + (rx < 0 ? -1 : 0), ny = mb.mby + (ry < 0 ? -1 : 0);
+      const bool inside = rx >= 0 && ry >= 0;
+      if (!inside && !mb_avail(nx, ny)) continue;
+      sum += mvd_at(ny * mbw + nx, list, (ry & 3) * 4 + (rx & 3))[comp];
+    }
+    Cabac& c = cabac;
+    const int base = comp == 0 ? 40 : 47;
+    const int inc = sum < 3 ? 0 : (sum > 32 ? 2 : 1);
+    if (!c.bin(base + inc)) return 0;
+    int v = 1, ctx = base + 3;
+    while (v < 9 && c.bin(ctx)) {
+      if (v < 4) ++ctx;
+      ++v;
+    }
+    if (v >= 9) {
+      int k = 3;
+      while (c.bypass()) {
+        v += 1 << k;
+        if (++k > 24) return 0;
+      }
+      while (k--) v += c.bypass() << k;
+    }
+    return c.bypass() ? -v : v;
+  }
+  int rd_cbp(bool intra) {
+    if (!use_cabac) {
+      unsigned code = bits.ue();
+      if (code > 47) return -1;
+      return intra ? cbp_intra_from_code[code] : cbp_inter_from_code[code];
+    }
+    Cabac& c = cabac;
+    const bool la = mb_avail(mb.mbx - 1, mb.mby), ta = mb_avail(mb.mbx, mb.mby - 1);
+    const int cbp_a = la ? mb_cbp[mb.addr - 1] : 0x0f;
+    const int cbp_b = ta ? mb_cbp[mb.addr - mbw] : 0x0f;
+    int cbp = 0;
+    for (int b8 = 0; b8 < 4; ++b8) {
+      int bit_a = (b8 & 1) ? (cbp >> (b8 - 1)) & 1 : (cbp_a >> (b8 + 1)) & 1;
+      int bit_b = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
+      cbp |= c.bin(73 + !bit_a + 2 * !bit_b) << b8;
+    }
+    const int ca = la ? mb_cbp[mb.addr - 1] >> 4 : 0;
+    const int cb = ta ? mb_cbp[mb.addr - mbw] >> 4 : 0;
+    if (c.bin(77 + (ca != 0) + 2 * (cb != 0))) cbp |= (1 + c.bin(77 + 4 + (ca == 2) + 2 * (cb == 2))) << 4;
+    return cbp;
+  }
+  int rd_qp_delta() {
+    if (!use_cabac) return bits.se();
+    int ctx = last_qp_delta_nonzero ? 1 : 0, v = 0;
+    while (cabac.bin(60 + ctx)) {
+      ctx = 2 + (ctx >> 1);
+      if (++v > 104) return 1000;
+    }
+    return (v & 1) ? (v + 1) >> 1 : -((v + 1) >> 1);
+  }
+  int rd_chroma_pred_mode() {
+    if (!use_cabac) return static_cast<int>(bits.ue());
+    int inc = 0;
+    if (mb_avail(mb.mbx - 1, mb.mby) && mb_chroma_mode[mb.addr - 1]) inc++;
+    if (mb_avail(mb.mbx, mb.mby - 1) && mb_chroma_mode[mb.addr - mbw]) inc++;
+    if (!cabac.bin(64 + inc)) return 0;
+    if (!cabac.bin(64 + 3)) return 1;
+    return 2 + cabac.bin(64 + 3);
+  }
+  int rd_t8x8_flag() {
+    if (!use_cabac) return bits.bit();
+    int inc = 0;
+    if (mb_avail(mb.mbx - 1, mb.mby) && mb_t8x8[mb.addr - 1]) inc++;
+    if (mb_avail(mb.mbx, mb.mby - 1) && mb_t8x8[mb.addr - mbw]) inc++;
+    return cabac.bin(399 + inc);
+  }
+  int rd_intra_pred_mode() {
+    if (!use_cabac) return bits.bit() ? -1 : static_cast<int>(bits.get(3));
+    if (cabac.bin(68)) return -1;
+    int v = cabac.bin(69);
+    v |= cabac.bin(69) << 1;
+    v |= cabac.bin(69) << 2;
+    return v;
+  }
+  int predicted_intra_mode(int bx, int by) const {
+    int mode[2];
+    for (int k = 0; k < 2; ++k) {
+      const int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
+      if (rx >= 0 && ry >= 0) {
+        mode[k] = mb.i4_mode[ry * 4 + rx];
+        continue;
+      }
+      const int nx = mb.mbx + (rx < 0 ? -1 : 0), ny = mb.mby + (ry < 0 ? -1 : 0);
+      if (!mb_avail(nx, ny)) return 2;
+      const int addr = ny * mbw + nx;
+      const int kind = mb_kind[addr];
+      if (kind == MB_INTER && apps->constrained_intra_pred) return 2;
+      mode[k] = (kind != MB_I4x4 && kind != MB_I8x8) ? 2 : i4mode[addr * 16 + (ry & 3) * 4 + (rx & 3)];
+    }
+    return imin(mode[0], mode[1]);
+  }
+
+  // scratch group for mask bit `g` (zeroed on first use)
+  int16_t* group(int g) {
+    if (!(mb.coded_mask & (1u << g))) {
+      mb.coded_mask |= 1u << g;
+      memset(mb.scratch[g], 0, sizeof(mb.scratch[g]));
+    }
+    return mb.scratch[g];
+  }
+
+  bool parse_residual() {
+    const bool i16 = mb.kind == MB_I16x16;
+    if (i16) {
+      int16_t tmp[16] = {0};
+      int n = use_cabac ? cabac_block(0, cbf_inc(0, 0, 0, 0), 16, zigzag4x4, 0, tmp)
+                        : cavlc_block(cavlc_nc(0, 0, 0), 16, zigzag4x4, 0, tmp);
+      if (n < 0) return false;
+      if (n) {
+        mb.cbf_dc |= 1;
+        memcpy(group(amd::kMaskLumaDc), tmp, sizeof(tmp));
+      }
+    }
+    for (int b8 = 0; b8 < 4; ++b8) {
+      if (!((mb.cbp >> b8) & 1)) continue;
+      if (mb.t8x8) {
+        // 64 coefficients in raster 8x8 order spread over groups 4*b8..4*b8+3
+        int16_t blk[64];
+        memset(blk, 0, sizeof(blk));
+        int total = 0;
+        if (use_cabac) {
+          int n = cabac_block(5, -1, 64, zigzag8x8, 0, blk);
+          if (n < 0) return false;
+          total = n;
+          for (int s = 0; s < 4; ++s) mb.nnz[((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)] = static_cast<uint8_t>(n);
+        } else {
+          for (int s = 0; s < 4; ++s) {
+            const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
+            int16_t tmp[16] = {0};
+            int n = cavlc_block(cavlc_nc(0, bx, by), 16, identity_scan16, 0, tmp);
+            if (n < 0) return false;
+            for (int k = 0; k < 16; ++k)
+              if (tmp[k]) blk[zigzag8x8[4 * k + s]] = tmp[k];
+            mb.nnz[by * 4 + bx] = static_cast<uint8_t>(n);
+            total += n;
+          }
+        }
+        if (total) {
+          for (int g = 0; g < 4; ++g) memcpy(group(4 * b8 + g), blk + 16 * g, 32);
+        }
+        continue;
+      }
+      for (int s = 0; s < 4; ++s) {
+        const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
+        const int ri = by * 4 + bx;
+        int16_t tmp[16] = {0};
+        int n;
+        if (i16)
+          n = use_cabac ? cabac_block(1, cbf_inc(1, 0, bx, by), 15, zigzag4x4, 1, tmp)
+                        : cavlc_block(cavlc_nc(0, bx, by), 15, zigzag4x4, 1, tmp);
+        else
+          n = use_cabac ? cabac_block(2, cbf_inc(1, 0, bx, by), 16, zigzag4x4, 0, tmp)
+                        : cavlc_block(cavlc_nc(0, bx, by), 16, zigzag4x4, 0, tmp);
+        if (n < 0) return false;
+        mb.nnz[ri] = static_cast<uint8_t>(n);
+        if (n) memcpy(group(ri), tmp, sizeof(tmp));
+      }
+    }
+    const int cc = mb.cbp >> 4;
+    if (cc) {
+      for (int p = 0; p < 2; ++p) {
+        int16_t tmp[4] = {0, 0, 0, 0};
+        int n = use_cabac ? cabac_block(3, cbf_inc(2, p, 0, 0), 4, dc_scan4, 0, tmp)
+                          : cavlc_block(-1, 4, dc_scan4, 0, tmp);
+        if (n < 0) return false;
+        if (n) {
+          mb.cbf_dc |= 2 << p;
+          memcpy(group(amd::kMaskChromaDc) + 4 * p, tmp, sizeof(tmp));
+        }
+      }
+    }
+    if (cc == 2) {
+      for (int p = 0; p < 2; ++p)
+        for (int s = 0; s < 4; ++s) {
+          const int bx = s & 1, by = s >> 1;
+          int16_t tmp[16] = {0};
+          int n = use_cabac ? cabac_block(4, cbf_inc(3, p, bx, by), 15, zigzag4x4, 1, tmp)
+                            : cavlc_block(cavlc_nc(1 + p, bx, by), 15, zigzag4x4, 1, tmp);
+          if (n < 0) return false;
+          mb.nnz[16 + 4 * p + s] = static_cast<uint8_t>(n);
+          if (n) memcpy(group(amd::kMaskChromaAc + 4 * p + s), tmp, sizeof(tmp));
+        }
+    }
+    if (!use_cabac && bits.overrun) return fail("residual ran past the end of the slice");
+    return true;
+  }
+
+  bool parse_inter(int mb_type) {
+    const bool is_b = sl.type == 1;
+    int shape, pred[4], sub_shape[4] = {0, 0, 0, 0};
+    if (!is_b) {
+      shape = mb_type == 0 ? 0 : (mb_type == 1 ? 1 : (mb_type == 2 ? 2 : 3));
+      pred[0] = pred[1] = pred[2] = pred[3] = 0;
+    } else {
+      shape = b_mb_info[mb_type][0];
+      pred[0] = b_mb_info[mb_type][1];
+      pred[1] = b_mb_info[mb_type][2];
+    }
+    const int nparts = shape == 0 ? 1 : (shape == 3 ? 4 : 2);
+    if (shape == 3) {
+      for (int i = 0; i < 4; ++i) {
+        int t = rd_sub_mb_type();
+        if (t < 0 || t > (is_b ? 12 : 3)) return fail("bad sub_mb_type");
+        mb.sub_type[i] = t;
+        if (is_b) {
+          sub_shape[i] = b_sub_info[t][0];
+          pred[i] = b_sub_info[t][1];
+        } else {
+          sub_shape[i] = t;
+          pred[i] = 0;
+        }
+      }
+      if (is_b)
+        for (int i = 0; i < 4; ++i)
+          if (pred[i] == 3) {
+            direct8[mb.addr * 4 + i] = 1;
+            if (!pred_direct(i)) return false;
+          }
+    }
+    for (int l = 0; l < (is_b ? 2 : 1); ++l)
+      for (int i = 0; i < nparts; ++i) {
+        if (pred[i] == 3) continue;
+        int ref = -1;
+        const int b8 = shape == 0 ? 0 : (shape == 1 ? i * 2 : i);
+        if (uses_list(pred[i], l)) {
+          if (!is_b && mb_type == 4) {
+            ref = 0;
+          } else {
+            ref = rd_ref_idx(l, b8);
+            if (ref < 0 || ref >= sl.num_ref_idx[l]) return fail("ref_idx out of range");
+          }
+        }
+        if (shape == 0) {
+          for (int q = 0; q < 4; ++q) set_ref8(l, q, ref);
+        } else if (shape == 1) {
+          set_ref8(l, i * 2, ref);
+          set_ref8(l, i * 2 + 1, ref);
+        } else if (shape == 2) {
+          set_ref8(l, i, ref);
+          set_ref8(l, i + 2, ref);
+        } else {
+          set_ref8(l, i, ref);
+        }
+      }
+    const MbMotion& mo = cur->motion[mb.addr];
+    for (int l = 0; l < (is_b ? 2 : 1); ++l)
+      for (int i = 0; i < nparts; ++i) {
+        if (pred[i] == 3 || !uses_list(pred[i], l)) continue;
+        int px, py, pw, ph;
+        if (shape == 0) { px = 0; py = 0; pw = 4; ph = 4; }
+        else if (shape == 1) { px = 0; py = i * 2; pw = 4; ph = 2; }
+        else if (shape == 2) { px = i * 2; py = 0; pw = 2; ph = 4; }
+        else { px = (i & 1) * 2; py = (i >> 1) * 2; pw = 2; ph = 2; }
+        int sw = pw, sh = ph;
+        if (shape == 3) {
+          const int ss = sub_shape[i];
+          if (ss == 2 || ss == 3) sw = 1;
+          if (ss == 1 || ss == 3) sh = 1;
+        }
+        const int ref = mo.ref_idx[l][(py >> 1) * 2 + (px >> 1)];
+        for (int sy = 0; sy < ph; sy += sh)
+          for (int sx = 0; sx < pw; sx += sw) {
+            const int bx = px + sx, by = py + sy;
+            int dir = PRED_MEDIAN;
+            if (shape == 1) dir = i == 0 ? PRED_16x8_TOP : PRED_16x8_BOTTOM;
+            if (shape == 2) dir = i == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT;
+            int mvp[2];
+            pred_mv(l, bx, by, sw, ref, dir, mvp);
+            const int dx = rd_mvd(l, bx, by, 0);
+            const int dy = rd_mvd(l, bx, by, 1);
+            set_mvd_block(l, bx, by, sw, sh, dx, dy);
+            set_mv_block(l, bx, by, sw, sh, mvp[0] + dx, mvp[1] + dy);
+          }
+      }
+    return true;
+  }
+
+  void begin_mb(int addr) {
+    mb.addr = addr;
+    mb.mbx = addr % mbw;
+    mb.mby = addr / mbw;
+    mb.kind = MB_NONE;
+    mb.skip = mb.direct16 = mb.t8x8 = mb.i16_mode = mb.chroma_mode = mb.cbp = 0;
+    mb.qp = qp;
+    mb.cbf_dc = 0;
+    mb.coded_mask = 0;
+    memset(mb.sub_type, 0, sizeof(mb.sub_type));
+    memset(mb.i4_mode, 2, sizeof(mb.i4_mode));
+    memset(mb.nnz, 0, sizeof(mb.nnz));
+    MbMotion& mo = cur->motion[addr];
+    memset(mo.mv, 0, sizeof(mo.mv));
+    memset(mo.ref_slot, -1, sizeof(mo.ref_slot));
+    memset(mo.ref_idx, -1, sizeof(mo.ref_idx));
+    for (int l = 0; l < 2; ++l)
+      for (int q = 0; q < 4; ++q) cur->ref_uid[l][addr * 4 + q] = -1;
+    memset(mvd_at(addr, 0, 0), 0, 64);
+    memset(&direct8[addr * 4], 0, 4);
+    cur->mb_intra[addr] = 0;
+    mb_slice[addr] = static_cast<int16_t>(slice_index);
+    mb_kind[addr] = MB_NONE;
+  }
+
+  bool commit_mb(const uint8_t* pcm) {
+    const int a = mb.addr;
+    const Pps& p = *apps;
+    MbInfo& o = bufs.mb[a];
+    memset(&o, 0, sizeof(o));
+    mb_kind[a] = static_cast<uint8_t>(mb.kind);
+    mb_skip[a] = static_cast<uint8_t>(mb.skip);
+    mb_direct[a] = static_cast<uint8_t>((mb.skip || mb.direct16) && sl.type == 1);
+    mb_t8x8[a] = static_cast<uint8_t>(mb.t8x8);
+    mb_cbp[a] = static_cast<uint8_t>(mb.kind == MB_IPCM ? 0x2f : mb.cbp);
+    mb_cbf_dc[a] = static_cast<uint8_t>(mb.cbf_dc);
+    mb_chroma_mode[a] = static_cast<uint8_t>((mb.kind != MB_INTER && mb.kind != MB_IPCM) ? mb.chroma_mode : 0);
+    memcpy(&i4mode[a * 16], mb.i4_mode, 16);
+    memcpy(&nnz[a * 24], mb.nnz, 24);
+    const bool intra = mb.kind != MB_INTER;
+    cur->mb_intra[a] = intra;
+    if (intra) has_intra = true; else has_inter = true;
+
+    static const uint8_t kind_map[6] = {0, amd::MBK_I4x4, amd::MBK_I8x8, amd::MBK_I16x16, amd::MBK_IPCM, amd::MBK_INTER};
+    o.kind = kind_map[mb.kind];
+    uint8_t f = 0;
+    if (mb.t8x8) f |= amd::MBF_T8X8;
+    if (intra) f |= amd::MBF_INTRA;
+    if (intra_mb_ok(mb.mbx - 1, mb.mby)) f |= amd::MBF_AVAIL_A;
+    if (intra_mb_ok(mb.mbx, mb.mby - 1)) f |= amd::MBF_AVAIL_B;
+    if (intra_mb_ok(mb.mbx + 1, mb.mby - 1)) f |= amd::MBF_AVAIL_C;
+    if (intra_mb_ok(mb.mbx - 1, mb.mby - 1)) f |= amd::MBF_AVAIL_D;
+    if (sl.disable_deblock != 1) {
+      if (mb.mbx > 0 && !(sl.disable_deblock == 2 && mb_slice[a - 1] != mb_slice[a])) f |= amd::MBF_DB_LEFT;
+      if (mb.mby > 0 && !(sl.disable_deblock == 2 && mb_slice[a - mbw] != mb_slice[a])) f |= amd::MBF_DB_TOP;
+      o.deblock_internal = 1;
+    }
+    o.flags = f;
+    const int qy = mb.kind == MB_IPCM ? 0 : mb.qp;
+    o.qp = static_cast<uint8_t>(qy);
+    o.qpc[0] = chroma_qp_table[iclip(0, 51, qy + p.chroma_qp_offset[0])];
+    o.qpc[1] = chroma_qp_table[iclip(0, 51, qy + p.chroma_qp_offset[1])];
+    o.pred_modes = static_cast<uint8_t>((mb.i16_mode & 15) | (mb.chroma_mode << 4));
+    o.slice = static_cast<uint8_t>(slice_index - 1);
+    for (int k = 0; k < 8; ++k) o.i4_modes[k] = static_cast<uint8_t>((mb.i4_mode[2 * k] & 15) | (mb.i4_mode[2 * k + 1] << 4));
+    uint16_t nz = 0;
+    for (int k = 0; k < 16; ++k)
+      if (mb.nnz[k]) nz |= 1u << k;
+    if (mb.t8x8)  // the transform block is the 8x8: any coefficient marks all four
+      for (int b8 = 0; b8 < 4; ++b8) {
+        const int o4 = (b8 >> 1) * 8 + (b8 & 1) * 2;
+        const uint16_t m = (1u << o4) | (1u << (o4 + 1)) | (1u << (o4 + 4)) | (1u << (o4 + 5));
+        if (nz & m) nz |= m;
+      }
+    if (mb.kind == MB_IPCM) nz = 0xffff;
+    o.nz_mask = nz;
+
+    // coefficients: compact the groups that were touched
+    o.coef_offset = static_cast<uint32_t>(coef_used);
+    if (mb.kind == MB_IPCM) {
+      if (coef_used + 192 > bufs.coef_capacity) return fail("coefficient buffer overflow");
+      memcpy(bufs.coefs + coef_used, pcm, 384);
+      coef_used += 192;
+      o.coded_mask = 0;
+    } else {
+      const int groups = __builtin_popcount(mb.coded_mask);
+      if (coef_used + static_cast<size_t>(groups) * 16 > bufs.coef_capacity) return fail("coefficient buffer overflow");
+      int16_t* dst = bufs.coefs + coef_used;
+      for (uint32_t m = mb.coded_mask; m; m &= m - 1) {
+        memcpy(dst, mb.scratch[__builtin_ctz(m)], 32);
+        dst += 16;
+      }
+      coef_used += static_cast<size_t>(groups) * 16;
+      o.coded_mask = mb.coded_mask;
+    }
+    return true;
+  }
+
+  bool decode_skip_mb(int addr) {
+    begin_mb(addr);
+    mb.kind = MB_INTER;
+    mb.skip = 1;
+    last_qp_delta_nonzero = 0;
+    if (sl.type == 0) {
+      for (int q = 0; q < 4; ++q) set_ref8(0, q, 0);
+      NB A = fetch_nb(0, -1, 0, 0), B = fetch_nb(0, 0, -1, 0);
+      int mv[2] = {0, 0};
+      if (!(A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) ||
+            (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
+        pred_mv(0, 0, 0, 4, 0, PRED_MEDIAN, mv);
+      set_mv_block(0, 0, 0, 4, 4, mv[0], mv[1]);
+    } else {
+      mb.direct16 = 1;
+      memset(&direct8[addr * 4], 1, 4);
+      if (!pred_direct(-1)) return false;
+    }
+    return commit_mb(nullptr);
+  }
+
+  bool decode_mb(int addr) {
+    const Pps& p = *apps;
+    begin_mb(addr);
+    const int st = sl.type;
+    const int t = rd_mb_type();
+    int intra_t = -1;
+    if (st == 2) {
+      intra_t = t;
+    } else if (st == 0) {
+      if (t > 30 || t < 0) return fail("bad mb_type (P)");
+      if (t >= 5) intra_t = t - 5;
+    } else {
+      if (t > 48 || t < 0) return fail("bad mb_type (B)");
+      if (t >= 23) intra_t = t - 23;
+    }
+    if (intra_t > 25) return fail("bad mb_type (I)");
+
+    if (intra_t == 25) {
+      mb.kind = MB_IPCM;
+      uint8_t pcm[384];
+      if (use_cabac) {
+        // the terminating bin consumed the encoder's flush; align and read
+        int pos = cabac.bits_consumed();
+        pos = (pos + 7) & ~7;
+        const uint8_t* src = cabac.start + (pos >> 3);
+        if (src + 384 > cabac.end) return fail("truncated I_PCM");
+        memcpy(pcm, src, 384);
+        Cabac saved = cabac;
+        cabac.begin(src + 384, saved.end);
+        memcpy(cabac.state, saved.state, sizeof(cabac.state));
+        cabac.start = saved.start;  // keep positions relative to the slice data
+      } else {
+        while (bits.pos & 7) bits.bit();
+        for (int i = 0; i < 384; ++i) pcm[i] = static_cast<uint8_t>(bits.get(8));
+        if (bits.overrun) return fail("truncated I_PCM");
+      }
+      memset(mb.nnz, 16, sizeof(mb.nnz));
+      mb.cbf_dc = 7;
+      last_qp_delta_nonzero = 0;
+      return commit_mb(pcm);
+    }
+
+    if (intra_t >= 0) {
+      if (intra_t == 0) {
+        mb.kind = MB_I4x4;
+        if (p.transform_8x8_mode && rd_t8x8_flag()) {
+          mb.kind = MB_I8x8;
+          mb.t8x8 = 1;
+        }
+        const int nblk = mb.kind == MB_I4x4 ? 16 : 4;
+        for (int k = 0; k < nblk; ++k) {
+          const int bx = nblk == 16 ? blk4_x[k] : (k & 1) * 2, by = nblk == 16 ? blk4_y[k] : (k >> 1) * 2;
+          const int pm = predicted_intra_mode(bx, by);
+          const int rem = rd_intra_pred_mode();
+          const int mode = rem < 0 ? pm : (rem < pm ? rem : rem + 1);
+          if (nblk == 16) mb.i4_mode[by * 4 + bx] = static_cast<int8_t>(mode);
+          else
+            for (int s = 0; s < 4; ++s) mb.i4_mode[(by + (s >> 1)) * 4 + bx + (s & 1)] = static_cast<int8_t>(mode);
+        }
+      } else {
+        mb.kind = MB_I16x16;
+        mb.i16_mode = (intra_t - 1) & 3;
+        mb.cbp = (((intra_t - 1) >> 2) % 3) << 4 | ((intra_t - 1) >= 12 ? 15 : 0);
+      }
+      mb.chroma_mode = rd_chroma_pred_mode();
+      if (mb.chroma_mode > 3 || mb.chroma_mode < 0) return fail("bad intra_chroma_pred_mode");
+      cur->mb_intra[addr] = 1;
+    } else {
+      mb.kind = MB_INTER;
+      if (st == 1 && t == 0) {
+        mb.direct16 = 1;
+        memset(&direct8[addr * 4], 1, 4);
+        if (!pred_direct(-1)) return false;
+      } else if (!parse_inter(t)) {
+        return false;
+      }
+    }
+
+    if (mb.kind != MB_I16x16) {
+      int cbp = rd_cbp(mb.kind != MB_INTER);
+      if (cbp < 0) return fail("bad coded_block_pattern");
+      mb.cbp = cbp;
+      if ((cbp & 15) && p.transform_8x8_mode && mb.kind == MB_INTER) {
+        bool ok = true;
+        if (st == 1 && t == 0) ok = asps->direct_8x8_inference;
+        if ((st == 0 && (t == 3 || t == 4)) || (st == 1 && t == 22)) {
+          for (int i = 0; i < 4; ++i) {
+            if (st == 1 && mb.sub_type[i] == 0) {
+              if (!asps->direct_8x8_inference) ok = false;
+            } else if (st == 1 ? b_sub_info[mb.sub_type[i]][0] != 0 : mb.sub_type[i] != 0) {
+              ok = false;
+            }
+          }
+        }
+        if (ok) mb.t8x8 = rd_t8x8_flag();
+      }
+    }
+    if (mb.cbp || mb.kind == MB_I16x16) {
+      const int dq = rd_qp_delta();
+      if (dq < -26 || dq > 25) return fail("mb_qp_delta out of range");
+      last_qp_delta_nonzero = dq != 0;
+      qp = (qp + dq + 52) % 52;
+      mb.qp = qp;
+      if (!parse_residual()) return false;
+    } else {
+      last_qp_delta_nonzero = 0;
+    }
+    return commit_mb(nullptr);
+  }
+
+  bool decode_slice_data(Bits& b) {
+    const Pps& p = *apps;
+    const int nmb = mbw * mbh;
+    int addr = sl.first_mb;
+    if (addr >= nmb) return fail("first_mb_in_slice out of range");
+    qp = sl.qp;
+    last_qp_delta_nonzero = 0;
+    use_cabac = p.cabac;
+    if (use_cabac) {
+      while (b.pos & 7)
+        if (!b.bit()) return fail("cabac_alignment_one_bit is zero");
+      cabac.init_contexts(sl.type, sl.cabac_init_idc, sl.qp);
+      cabac.begin(b.buf + (b.pos >> 3), b.buf + ((b.size_bits + 7) >> 3));
+      for (;;) {
+        if (addr >= nmb) return fail("slice runs past the end of the picture");
+        bool skipped = false;
+        if (sl.type != 2) {
+          mb.addr = addr;
+          mb.mbx = addr % mbw;
+          mb.mby = addr / mbw;
+          int inc = 0;
+          if (mb_avail(mb.mbx - 1, mb.mby) && !mb_skip[addr - 1]) inc++;
+          if (mb_avail(mb.mbx, mb.mby - 1) && !mb_skip[addr - mbw]) inc++;
+          skipped = cabac.bin((sl.type == 0 ? 11 : 24) + inc);
+        }
+        if (!(skipped ? decode_skip_mb(addr) : decode_mb(addr))) return false;
+        if (cabac.overrun) return fail("slice data ran past the end of the NAL unit");
+        ++addr;
+        if (cabac.terminate()) break;
+      }
+      {  // desync check: last consumed bit is the stop bit, only zeros follow
+        const int pos = (b.pos & ~7) + cabac.bits_consumed();
+        bool ok = pos > 0 && pos <= b.size_bits && ((b.buf[(pos - 1) >> 3] >> (7 - ((pos - 1) & 7))) & 1);
+        for (int i = pos; ok && i < b.size_bits; ++i)
+          if ((b.buf[i >> 3] >> (7 - (i & 7))) & 1) ok = false;
+        ++owner->slices_;
+        if (ok) ++owner->slices_clean_end_;
+      }
+      return true;
+    }
+    bits = b;
+    for (;;) {
+      if (sl.type != 2) {
+        unsigned run = bits.ue();
+        if (run > static_cast<unsigned>(nmb - addr)) return fail("mb_skip_run out of range");
+        while (run--) {
+          if (!decode_skip_mb(addr)) return false;
+          ++addr;
+        }
+        if (!bits.more_rbsp_data()) break;
+      }
+      if (addr >= nmb) return fail("slice runs past the end of the picture");
+      if (!decode_mb(addr)) return false;
+      if (bits.overrun) return fail("slice data ran past the end of the NAL unit");
+      ++addr;
+      if (!bits.more_rbsp_data()) break;
+    }
+    {
+      Bits t = bits;
+      bool ok = t.bit() == 1;
+      while (ok && t.pos < t.size_bits)
+        if (t.bit()) ok = false;
+      ++owner->slices_;
+      if (ok && !t.overrun) ++owner->slices_clean_end_;
+    }
+    return true;
+  }
+
+  bool decode_nal(const uint8_t* nal, size_t n) {
+    if (n < 1) return true;
+    const int ref_idc = (nal[0] >> 5) & 3, type = nal[0] & 31;
+    if (type != 1 && type != 5 && type != 7 && type != 8) return true;
+    const int rn = unescape(nal + 1, n - 1);
+    Bits b;
+    b.buf = rbsp.data();
+    b.size_bits = rn * 8;
+    if (type == 7) return parse_sps(b);
+    if (type == 8) return parse_pps(b);
+    const int r = parse_slice_header(b, ref_idc, type);
+    if (r < 0 || !err->empty()) return false;
+    if (r > 0) return true;
+    return decode_slice_data(b);
+  }
+
+  void abort_picture() {
+    pic_in_progress = false;
+    if (cur) {
+      if (cur->slot >= 0) sink->release_surface(cur->slot);
+      cur->in_use = false;
+      cur->slot = -1;
+      cur = nullptr;
+    }
+  }
+};
+
+// ===========================================================================
+Parser::Parser(PictureSink* sink) : impl_(new Impl()) {
+  impl_->owner = this;
+  impl_->sink = sink;
+  impl_->err = &error_;
+}
+Parser::~Parser() { delete impl_; }
+
+int Parser::width() const {
+  const Sps* s = impl_->asps;
+  if (!s)
+    for (const Sps& c : impl_->sps)
+      if (c.valid) { s = &c; break; }
+  return s ? s->mb_width * 16 - s->crop_left - s->crop_right : 0;
+}
+int Parser::height() const {
+  const Sps* s = impl_->asps;
+  if (!s)
+    for (const Sps& c : impl_->sps)
+      if (c.valid) { s = &c; break; }
+  return s ? s->mb_height * 16 - s->crop_top - s->crop_bottom : 0;
+}
+
+bool Parser::configure(const uint8_t* avcc, size_t size) {
+  error_.clear();
+  Impl& d = *impl_;
+  if (size < 7 || avcc[0] != 1) return d.fail("extradata is not an avcC record");
+  d.nal_length_size = (avcc[4] & 3) + 1;
+  size_t pos = 5;
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pos >= size) return d.fail("truncated avcC");
+    int count = pass == 0 ? (avcc[pos] & 31) : avcc[pos];
+    pos++;
+    for (int i = 0; i < count; ++i) {
+      if (pos + 2 > size) return d.fail("truncated avcC");
+      size_t len = (avcc[pos] << 8) | avcc[pos + 1];
+      pos += 2;
+      if (pos + len > size) return d.fail("truncated avcC");
+      if (!d.decode_nal(avcc + pos, len)) return false;
+      pos += len;
+    }
+  }
+  return true;
+}
+
+bool Parser::decode(const uint8_t* sample, size_t size) {
+  error_.clear();
+  Impl& d = *impl_;
+  size_t pos = 0;
+  const int ls = d.nal_length_size;
+  while (pos + ls <= size) {
+    size_t len = 0;
+    for (int i = 0; i < ls; ++i) len = (len << 8) | sample[pos + i];
+    pos += ls;
+    if (len > size - pos) {
+      d.abort_picture();
+      return d.fail("NAL length exceeds sample");
+    }
+    if (!d.decode_nal(sample + pos, len)) {
+      d.abort_picture();
+      return false;
+    }
+    pos += len;
+  }
+  d.skipping_picture = false;
+  if (!d.finish_picture()) {
+    d.abort_picture();
+    return false;
+  }
+  return true;
+}
+
+bool Parser::flush() {
+  Impl& d = *impl_;
+  if (d.pic_in_progress && !d.finish_picture()) return false;
+  if (d.asps) {
+    d.cur = nullptr;
+    d.output_all();
+    for (Pic& p : d.dpb) p.ref = 0;
+    d.release_unused();
+  }
+  d.outputs_emitted = 0;
+  d.wanted.clear();
+  return error_.empty();
+}
+
+void Parser::set_wanted(const std::vector<uint64_t>& ordinals) {
+  impl_->wanted = ordinals;
+  std::sort(impl_->wanted.begin(), impl_->wanted.end());
+}
+
+}  // namespace h264
+}  // namespace hwang

@@ -1,0 +1,107 @@
+// Host side of the MI355X H.264 backend: everything that is serial per slice
+// or context dependent.  NAL / parameter-set / slice-header parsing, CAVLC and
+// CABAC entropy decoding, intra-mode and motion-vector derivation (including
+// spatial / temporal direct), reference lists, marking, POC and display-order
+// output.  It reconstructs no samples: per picture it fills the frame_job.h
+// records and hands them to a PictureSink, which runs the HIP kernels.
+//
+// This is what the reference obtains from libavcodec's h264 decoder up to,
+// but not including, hl_decode_mb (software_video_decoder.cpp:353-357 ->
+// avcodec_send_packet).  Supported: Baseline/Main/High 4:2:0 8-bit, frame
+// (progressive) coding, CAVLC + CABAC, I/P/B, multiple references and slices,
+// 8x8 transform, scaling matrices, explicit/implicit weighted prediction.
+// Rejected with an error (never silently mis-decoded): interlaced / MBAFF,
+// FMO/ASO, SP/SI, 4:2:2 / 4:4:4, > 8 bit.
+#pragma once
+
+#include "../amd/frame_job.h"
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace hwang {
+namespace h264 {
+
+struct PicBuffers {
+  amd::MbInfo* mb = nullptr;         // [mb_width * mb_height]
+  amd::MbMotion* motion = nullptr;   // [mb_width * mb_height], lives with the surface
+  int16_t* coefs = nullptr;
+  size_t coef_capacity = 0;          // in int16 units
+  amd::SliceParams* slices = nullptr;
+  int max_slices = 0;
+  int slot = -1;                     // surface the picture is reconstructed into
+};
+
+struct PicSetup {
+  int mb_width, mb_height;
+  int crop_left, crop_right, crop_top, crop_bottom;  // luma samples
+};
+
+struct PicDone {
+  int slot;
+  int num_slices;
+  size_t coef_count;     // int16 units used
+  bool has_inter;        // motion[] must be uploaded
+  bool has_intra;
+  int slice_type_mask;   // bit0 P, bit1 B, bit2 I
+  const uint8_t (*scaling4)[16];
+  const uint8_t (*scaling8)[64];
+  int ref_slots[32];     // surfaces read by this picture (for lifetime tracking)
+  int num_ref_slots;
+};
+
+class PictureSink {
+ public:
+  virtual ~PictureSink() {}
+  // A new picture starts; provide a free surface and record buffers.
+  virtual bool begin_picture(const PicSetup& setup, PicBuffers* out, std::string* error) = 0;
+  // All macroblocks of the picture are in the buffers: reconstruct it.
+  virtual bool end_picture(const PicDone& done, std::string* error) = 0;
+  // Display-order emission.  slot < 0: a picture that was skipped on purpose
+  // (unwanted non-reference picture); it still occupies one output position.
+  virtual void output_picture(int slot) = 0;
+  // The parser no longer needs the surface as a reference nor for output.
+  virtual void release_surface(int slot) = 0;
+};
+
+class Parser {
+ public:
+  explicit Parser(PictureSink* sink);
+  ~Parser();
+
+  // avcC payload.
+  bool configure(const uint8_t* avcc, size_t size);
+  // One MP4 sample = one access unit (AVCC framing).
+  bool decode(const uint8_t* sample, size_t size);
+  // End of interval: emit everything pending, drop all references.
+  bool flush();
+
+  // Sparse decoding: output positions, counted from the first
+  // picture after the last flush/configure, that will be fetched.  Unwanted
+  // non-reference pictures are not entropy decoded at all.  Empty = all.
+  void set_wanted(const std::vector<uint64_t>& ordinals);
+
+  const std::string& error() const { return error_; }
+  int width() const;    // cropped
+  int height() const;
+  int64_t pictures_decoded() const { return pictures_decoded_; }
+  int64_t pictures_skipped() const { return pictures_skipped_; }
+  // Slices parsed / slices whose data ended exactly on rbsp_trailing_bits
+  // (an entropy-decoder desync check that needs no second decoder).
+  int64_t slices() const { return slices_; }
+  int64_t slices_clean_end() const { return slices_clean_end_; }
+
+  struct Impl;
+
+ private:
+  Impl* impl_;
+  std::string error_;
+  int64_t pictures_decoded_ = 0;
+  int64_t pictures_skipped_ = 0;
+  int64_t slices_ = 0, slices_clean_end_ = 0;
+};
+
+}  // namespace h264
+}  // namespace hwang

@@ -212,6 +212,18 @@ int hwang_k_yuv420_to_rgb24(const uint8_t* y, const uint8_t* u,
                             const uint8_t* v, int y_stride, int c_stride,
                             int width, int height, uint8_t* rgb, void* stream);
 
+/* -- Host-only parser probe (CPU tests; no GPU) -----------------------------
+ * Runs the backend's host half (entropy decode, motion derivation, DPB,
+ * display-order output, sparse skipping) over samples laid out in `data`.
+ * out[0]=slices, [1]=slices that ended exactly on rbsp_trailing_bits,
+ * [2]=pictures parsed, [3]=pictures skipped (unwanted non-reference),
+ * [4]=frames output, [5]=of which skipped, [6]=int16 coefficients emitted,
+ * [7]=FNV-1a digest of every record the kernels would receive. */
+int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
+                     const uint64_t* sample_offsets, const uint64_t* sample_sizes,
+                     size_t num_samples, const uint64_t* wanted, size_t num_wanted,
+                     int64_t out[8], char* error, size_t error_capacity);
+
 /* -- Profiling hooks ---------------------------------------------------------
  * When enabled, every kernel launch of the backend is bracketed with HIP
  * events on its own stream; hwang_prof_read drains the accumulated

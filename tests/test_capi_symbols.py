@@ -36,7 +36,11 @@ def test_product_does_not_reference_oracle():
             for f in files:
                 if f.endswith((".py", ".h", ".cpp", ".hip", ".c")):
                     t = open(os.path.join(dirpath, f), errors="ignore").read()
-                    if re.search(r'(from|import)\s+oracle|#include\s+"[^"]*oracle|liboracle|h264o_', t):
+                    if f.endswith(".py"):
+                        hit = re.search(r'^\s*(from|import)\s+oracle\b|liboracle|oracle_py', t, flags=re.M)
+                    else:
+                        hit = re.search(r'#include\s+"[^"]*oracle|liboracle|h264o_|h264i_', t)
+                    if hit:
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
     mk = open(os.path.join(ROOT, "Makefile")).read()

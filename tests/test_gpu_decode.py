@@ -1,0 +1,107 @@
+"""-m gpu: whole-picture parity of the MI355X backend against the CPU oracle,
+through the C ABI (libhwang_amd.so: host entropy decode + HIP kernels).  The
+bar is bit-exact I420 planes (H.264 reconstruction is integer arithmetic) and
+bit-exact RGB against the oracle's statement of the colour conversion."""
+import numpy as np
+import pytest
+
+from tests.corpus_util import MATRIX, make_clip
+from tests.util import REALSHORT, have_file
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no fallback"
+    return torch
+
+
+def oracle_frames(oracle, hw, path):
+    idx = hw.index_video(path)
+    frames, counters = oracle.decode_file(path, idx)
+    return idx, frames
+
+
+@pytest.mark.parametrize("name,kw", MATRIX, ids=[m[0] for m in MATRIX])
+def test_all_frames_bit_exact(hw, oracle, gpu, tmp_path, name, kw):
+    w, h = (322, 242) if name == "qp40" else (320, 240)
+    path = str(tmp_path / (name + ".mp4"))
+    gold = make_clip(path, width=w, height=h, **kw)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=2)
+    got = dec.retrieve_yuv(list(range(idx.frames())))
+    assert len(got) == len(gold)
+    for i in range(len(gold)):
+        assert np.array_equal(got[i], gold[i]), "frame %d differs from the oracle/encoder reconstruction" % i
+
+
+@pytest.mark.skipif(not have_file(REALSHORT), reason="realshort.mp4 not in this image")
+def test_real_x264_stream_bit_exact(hw, oracle, gpu):
+    idx, ref = oracle_frames(oracle, hw, REALSHORT)
+    dec = hw.Decoder(REALSHORT, video_index=idx, num_lanes=1)
+    got = dec.retrieve_yuv(list(range(36)))
+    for i in range(36):
+        assert np.array_equal(got[i], ref[i][0]), "frame %d" % i
+
+
+def test_sparse_rows_and_rgb(hw, oracle, gpu, tmp_path):
+    """Decoder.retrieve(rows): k-th array == frame rows[k] of a sequential
+    decode (the reference's GatherFramesComparison invariant), RGB."""
+    path = str(tmp_path / "sparse.mp4")
+    gold = make_clip(path, frames=48, gop=12, bframes=2, slices=2)
+    idx = hw.index_video(path)
+    rows = [0, 1, 5, 11, 12, 13, 30, 35, 47]
+    dec = hw.Decoder(path, video_index=idx, num_lanes=3)
+    got = dec.retrieve(rows)
+    st = dec.stats()
+    assert st["frames_returned"] == len(rows)
+    assert st["pictures_skipped"] > 0, "unwanted non-reference pictures should not be reconstructed"
+    for k, r in enumerate(rows):
+        want = oracle.i420_to_rgb(gold[r], 320, 240)
+        assert got[k].shape == (240, 320, 3)
+        assert np.array_equal(got[k], want), "row %d" % r
+    # same through the reference-shaped serial path (DecoderAutomata)
+    serial = dec.retrieve_serial(rows)
+    for k, r in enumerate(rows):
+        assert np.array_equal(serial[k], got[k]), "serial row %d" % r
+
+
+def test_device_resident_output(hw, oracle, gpu, tmp_path):
+    torch = gpu
+    path = str(tmp_path / "dev.mp4")
+    gold = make_clip(path, frames=10, gop=10, bframes=1)
+    idx = hw.index_video(path)
+    rows = [2, 3, 9]
+    out = torch.zeros((len(rows), 240, 320, 3), dtype=torch.uint8, device="cuda")
+    dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+    dec.retrieve_into(rows, out.data_ptr(), out.numel())
+    torch.cuda.synchronize()
+    host = out.cpu().numpy()
+    for k, r in enumerate(rows):
+        assert np.array_equal(host[k], oracle.i420_to_rgb(gold[r], 320, 240))
+
+
+def test_1080p_cropping(hw, oracle, gpu, tmp_path):
+    path = str(tmp_path / "hd.mp4")
+    gold = make_clip(path, width=1920, height=1080, frames=5, gop=5, bframes=2, threads=4)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+    got = dec.retrieve_yuv([0, 2, 4])
+    for k, r in enumerate([0, 2, 4]):
+        assert np.array_equal(got[k], gold[r])
+
+
+def test_errors_are_loud(hw, gpu, tmp_path):
+    path = str(tmp_path / "e.mp4")
+    make_clip(path, frames=4, gop=4, bframes=0, yuv=False)
+    idx = hw.index_video(path)
+    data = bytearray(open(path, "rb").read())
+    off = idx.sample_offsets()[0]
+    data[off + 40:off + 400] = b"\xff" * 360   # corrupt the IDR's slice data
+    bad = str(tmp_path / "bad.mp4")
+    open(bad, "wb").write(data)
+    dec = hw.Decoder(bad, video_index=idx, num_lanes=1)
+    with pytest.raises(RuntimeError):
+        dec.retrieve_yuv([0, 1])
