@@ -740,9 +740,10 @@ static int decide_intra(Enc* e, MbPlan* plan, int qp, int slice_type) {
 /* evaluates the motion currently in d->mb (ref/mv): predicts, returns SAD */
 static int eval_inter(Enc* e) {
   H264Oracle* d = e->d;
+  d->pred_luma_only = 1;
   h264i_inter_pred_mb(d);
-  return sad_block(e, d->mb.mbx * 16, d->mb.mby * 16, 16) +
-         sad_region(e, 1, d->mb.mbx * 8, d->mb.mby * 8, 8, 8) + sad_region(e, 2, d->mb.mbx * 8, d->mb.mby * 8, 8, 8);
+  d->pred_luma_only = 0;
+  return sad_block(e, d->mb.mbx * 16, d->mb.mby * 16, 16);
 }
 
 static void set_all_motion(MB* m, int list, int ref, int mvx, int mvy) {
@@ -802,17 +803,30 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
 #define ADD(r, x, y) do { if (nc < 40 && mv_ok(e, (x), (y))) { cand[nc][0] = (r); cand[nc][1] = (x); cand[nc][2] = (y); ++nc; } } while (0)
   ADD(0, skip_mv[0], skip_mv[1]);
   ADD(0, 0, 0);
-  for (int r = 0; r < nref; ++r) {
+  {
     int mvp[2];
-    h264i_pred_mv16(d, 0, r, mvp);
-    ADD(r, mvp[0], mvp[1]);
+    h264i_pred_mv16(d, 0, 0, mvp);
+    ADD(0, mvp[0], mvp[1]);
+    const int dd0 = (d->cur->poc - d->sl.ref_list[0][0]->poc) / 2;
+    ADD(0, e->hints[0][0] * dd0, e->hints[0][1] * dd0); /* background */
+  }
+  const int n_first = nc;
+  for (int r = 0; r < nref; ++r) {
     const Picture* rp = d->sl.ref_list[0][r];
     const int dd = (d->cur->poc - rp->poc) / 2;
-    for (int h = 0; h < e->hint_n; ++h) ADD(r, e->hints[h][0] * dd, e->hints[h][1] * dd);
+    if (r > 0) {
+      int mvp[2];
+      h264i_pred_mv16(d, 0, r, mvp);
+      ADD(r, mvp[0], mvp[1]);
+    }
+    for (int h = r > 0 ? 0 : 1; h < e->hint_n; ++h) ADD(r, e->hints[h][0] * dd, e->hints[h][1] * dd);
   }
   (void)dist;
+  /* stage 1: the usual suspects; the long list only when none of them fits
+   * (film grain alone costs about 256 * 2.3 of SAD) */
   int best = 0, bc = 1 << 30;
   for (int i = 0; i < nc; ++i) {
+    if (i == n_first && bc < 256 * 3) break;
     set_all_motion(&d->mb, 0, cand[i][0], cand[i][1], cand[i][2]);
     int c = eval_inter(e) + (i == 0 ? 0 : 24);
     if (c < bc) {
@@ -821,11 +835,11 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
     }
   }
   int br = cand[best][0], bx = cand[best][1], by = cand[best][2];
-  /* quarter-sample refinement */
-  for (int it = 0; it < 2; ++it) {
-    static const int dx[8] = {1, -1, 0, 0, 1, 1, -1, -1}, dy[8] = {0, 0, 1, -1, 1, -1, 1, -1};
+  /* quarter-sample refinement when the match is still poor */
+  for (int it = 0; it < 2 && bc > 256 * 3; ++it) {
+    static const int dx[4] = {1, -1, 0, 0}, dy[4] = {0, 0, 1, -1};
     int improved = 0;
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 4; ++k) {
       if (!mv_ok(e, bx + dx[k], by + dy[k])) continue;
       set_all_motion(&d->mb, 0, br, bx + dx[k], by + dy[k]);
       int c = eval_inter(e) + 24;
@@ -841,7 +855,7 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
   }
 
   /* intra fallback for uncovered content */
-  if (bc > 256 * 14) {
+  if (bc > 256 * 10) {
     MbPlan ip;
     memset(&ip, 0, sizeof(ip));
     h264i_begin_mb(d, addr);
@@ -858,12 +872,14 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
   set_all_motion(&d->mb, 0, br, bx, by);
   /* partitioned motion: when the 16x16 match is poor, or on a hash-chosen
    * subset (syntax coverage), give every 8x8 its own best candidate */
-  if (bc > 256 * 6 || hv % 11 == 0) {
+  if (bc > 256 * 4 || hv % 11 == 0) {
     int pm[4][3], qb[4] = {1 << 30, 1 << 30, 1 << 30, 1 << 30};
     for (int i = 0; i < nc + 1; ++i) {
       int r = i < nc ? cand[i][0] : br, x = i < nc ? cand[i][1] : bx, y = i < nc ? cand[i][2] : by;
       set_all_motion(&d->mb, 0, r, x, y);
+      d->pred_luma_only = 1;
       h264i_inter_pred_mb(d);
+      d->pred_luma_only = 0;
       for (int q = 0; q < 4; ++q) {
         int c = sad_block(e, d->mb.mbx * 16 + (q & 1) * 8, d->mb.mby * 16 + (q >> 1) * 8, 8) + (i == nc ? -16 : 0);
         if (c < qb[q]) {
@@ -942,6 +958,7 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
   int bc = eval_inter(e);
   int bmv[2][2] = {{0, 0}, {0, 0}};
   for (int h = 0; h < e->hint_n + 1; ++h) {
+    if (h == 1 && bc < 256 * 3) break; /* direct or the background already fits */
     int hx = h < e->hint_n ? e->hints[h][0] : 0, hy = h < e->hint_n ? e->hints[h][1] : 0;
     int m0[2] = {hx * d0, hy * d0}, m1[2] = {hx * d1, hy * d1};
     for (int kind = 1; kind <= 3; ++kind) {
@@ -956,7 +973,7 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
       }
     }
   }
-  if (bc > 256 * 16) {
+  if (bc > 256 * 11) {
     MbPlan ip;
     memset(&ip, 0, sizeof(ip));
     h264i_begin_mb(d, addr);

@@ -19,6 +19,7 @@
 #include "../h264/h264_parser.h"
 #include "../sparse_hints.h"
 #include "frame_job.h"
+#include "gpu_executor.h"
 #include "hip_check.h"
 #include "prof.h"
 
@@ -35,15 +36,8 @@
 namespace hwang {
 
 namespace amd {
-hipError_t launch_inter(const PictureParams& pp, const MbInfo* mbs, const MbMotion* motions, const int16_t* coefs,
-                        const SliceParams* slices, hipStream_t stream);
-hipError_t launch_intra(const PictureParams& pp, const MbInfo* mbs, const int16_t* coefs, unsigned* sync,
-                        hipStream_t stream);
-hipError_t launch_deblock(const PictureParams& pp, const MbInfo* mbs, const MbMotion* motions,
-                          const SliceParams* slices, unsigned* sync, hipStream_t stream);
+size_t deblock_scratch_bytes(int num_mbs);
 }  // namespace amd
-hipError_t launch_yuv420_to_rgb24(const uint8_t* y, const uint8_t* u, const uint8_t* v, int y_stride, int c_stride,
-                                  int width, int height, uint8_t* rgb, hipStream_t stream);
 
 namespace {
 
@@ -69,10 +63,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       *error = "cannot select GPU " + std::to_string(device_);
       return false;
     }
-    if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) {
-      *error = "cannot create a HIP stream";
-      return false;
-    }
+    exec_ = amd::GpuExecutor::get(device_, error);
+    if (!exec_) return false;
+    lane_ = exec_->register_lane();
     return true;
   }
 
@@ -85,6 +78,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     HWANG_RETURN_ON_ERROR(drain_and_reset());
     info_ = metadata;
+    if (parser_) {
+      folded_decoded_ += parser_->pictures_decoded();
+      folded_skipped_ += parser_->pictures_skipped();
+    }
     parser_.reset(new h264::Parser(this));
     if (!parser_->configure(extradata.data(), extradata.size()))
       return Result(false, "AMDVideoDecoder::configure: " + parser_->error());
@@ -143,15 +140,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   Result wait_until_frames_copied() override {
     HWANG_HIP_RETURN(hipSetDevice(device_));
-    HWANG_HIP_RETURN(hipStreamSynchronize(stream_));
+    HWANG_RETURN_ON_ERROR(wait_seq(last_seq_));
     std::lock_guard<std::mutex> lk(out_mu_);
-    for (Bounce& b : bounce_) {
-      if (b.dst) {
-        std::memcpy(b.dst, b.host, b.size);
-        b.dst = nullptr;
-      }
-    }
-    return check_gpu_flags();
+    deliver_bounces_locked();
+    return Result();
   }
 
   // ------------------------------------------------------------ extensions
@@ -161,16 +153,14 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
   BackendCounters counters() override {
     BackendCounters c = counters_;
-    if (parser_) {
-      c.pictures_reconstructed = parser_->pictures_decoded() - decoded_base_;
-      c.pictures_skipped = parser_->pictures_skipped() - skipped_base_;
-    }
+    c.pictures_reconstructed = folded_decoded_ + (parser_ ? parser_->pictures_decoded() : 0) - decoded_base_;
+    c.pictures_skipped = folded_skipped_ + (parser_ ? parser_->pictures_skipped() : 0) - skipped_base_;
     return c;
   }
   void reset_counters() override {
     counters_ = BackendCounters();
-    decoded_base_ = parser_ ? parser_->pictures_decoded() : 0;
-    skipped_base_ = parser_ ? parser_->pictures_skipped() : 0;
+    decoded_base_ = folded_decoded_ + (parser_ ? parser_->pictures_decoded() : 0);
+    skipped_base_ = folded_skipped_ + (parser_ ? parser_->pictures_skipped() : 0);
   }
 
   // ------------------------------------------------------------ PictureSink
@@ -193,25 +183,15 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     if (!alloc_surface(slot, error)) return false;
     // the motion buffer of this surface may still be the source of an upload
-    if (surf_[slot].motion_busy) {
-      if (hipEventSynchronize(surf_[slot].motion_done) != hipSuccess) {
-        *error = "AMDVideoDecoder: waiting for a motion upload failed";
-        return false;
-      }
-      surf_[slot].motion_busy = false;
+    if (surf_[slot].motion_seq) {
+      if (!exec_->wait(lane_, surf_[slot].motion_seq, error)) return false;
+      surf_[slot].motion_seq = 0;
     }
     // a staging job
     Job& j = jobs_[job_cursor_];
-    if (j.in_flight) {
-      if (hipEventSynchronize(j.done) != hipSuccess) {
-        *error = "AMDVideoDecoder: waiting for a staging slot failed";
-        return false;
-      }
-      j.in_flight = false;
-      if (*j.timeout_host) {
-        *error = "AMDVideoDecoder: GPU row-wavefront timed out";
-        return false;
-      }
+    if (j.seq) {
+      if (!exec_->wait(lane_, j.seq, error)) return false;
+      j.seq = 0;
     }
     cur_job_ = job_cursor_;
     job_cursor_ = (job_cursor_ + 1) % kJobs;
@@ -225,33 +205,23 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     return true;
   }
 
-  bool end_picture(const h264::PicDone& d, std::string* error) override {
+  bool end_picture(const h264::PicDone& d, std::string* /*error*/) override {
     Job& j = jobs_[cur_job_];
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
-    auto fail = [&](const char* what, hipError_t e) {
-      *error = std::string("AMDVideoDecoder: ") + what + ": " + hipGetErrorString(e);
-      return false;
+    amd::PicSubmit sub;
+    std::memset(&sub.desc, 0, sizeof(sub.desc));
+    auto add_copy = [&](void* dst, const void* src, size_t bytes) {
+      sub.copies[sub.ncopies].dst = dst;
+      sub.copies[sub.ncopies].src = src;
+      sub.copies[sub.ncopies].bytes = bytes;
+      ++sub.ncopies;
+      counters_.bytes_uploaded += bytes;
     };
-    hipError_t e;
-    if ((e = hipMemcpyAsync(j.mb_dev, j.mb_host, nmb * sizeof(MbInfo), hipMemcpyHostToDevice, stream_)) != hipSuccess)
-      return fail("upload of macroblock records", e);
-    if (d.coef_count &&
-        (e = hipMemcpyAsync(j.coef_dev, j.coef_host, d.coef_count * 2, hipMemcpyHostToDevice, stream_)) != hipSuccess)
-      return fail("upload of coefficients", e);
-    if ((e = hipMemcpyAsync(j.slice_dev, j.slice_host, d.num_slices * sizeof(SliceParams), hipMemcpyHostToDevice,
-                            stream_)) != hipSuccess)
-      return fail("upload of slice parameters", e);
-    counters_.bytes_uploaded += nmb * sizeof(MbInfo) + d.coef_count * 2 + d.num_slices * sizeof(SliceParams);
-    if (d.has_inter) {
-      if ((e = hipMemcpyAsync(j.motion_dev, surf_[d.slot].motion_host, nmb * sizeof(MbMotion),
-                              hipMemcpyHostToDevice, stream_)) != hipSuccess)
-        return fail("upload of motion records", e);
-      (void)hipEventRecord(surf_[d.slot].motion_done, stream_);
-      surf_[d.slot].motion_busy = true;
-      counters_.bytes_uploaded += nmb * sizeof(MbMotion);
-    }
-    amd::PictureParams pp;
-    std::memset(&pp, 0, sizeof(pp));
+    add_copy(j.mb_dev, j.mb_host, nmb * sizeof(MbInfo));
+    if (d.coef_count) add_copy(j.coef_dev, j.coef_host, d.coef_count * 2);
+    add_copy(j.slice_dev, j.slice_host, d.num_slices * sizeof(SliceParams));
+    if (d.has_inter) add_copy(j.motion_dev, surf_[d.slot].motion_host, nmb * sizeof(MbMotion));
+    amd::PictureParams& pp = sub.desc.pp;
     pp.mb_width = mbw_;
     pp.mb_height = mbh_;
     pp.y_pitch = y_pitch_;
@@ -265,20 +235,21 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       pp.surfaces[i].u = surf_[i].dev ? surf_[i].dev + u_offset_ : nullptr;
       pp.surfaces[i].v = surf_[i].dev ? surf_[i].dev + v_offset_ : nullptr;
     }
-    if (d.has_inter &&
-        (e = amd::launch_inter(pp, j.mb_dev, j.motion_dev, j.coef_dev, j.slice_dev, stream_)) != hipSuccess)
-      return fail("k_inter launch", e);
-    if (d.has_intra && (e = amd::launch_intra(pp, j.mb_dev, j.coef_dev, j.sync_dev, stream_)) != hipSuccess)
-      return fail("k_intra launch", e);
-    if ((e = amd::launch_deblock(pp, j.mb_dev, j.motion_dev, j.slice_dev, j.sync_dev + sync_words_, stream_)) !=
-        hipSuccess)
-      return fail("k_deblock launch", e);
-    // bring the wavefront timeout words back with the job
-    (void)hipMemcpyAsync(j.timeout_host, j.sync_dev + 1, sizeof(unsigned), hipMemcpyDeviceToHost, stream_);
-    (void)hipMemcpyAsync(j.timeout_host + 1, j.sync_dev + sync_words_ + 1, sizeof(unsigned), hipMemcpyDeviceToHost,
-                         stream_);
-    (void)hipEventRecord(j.done, stream_);
-    j.in_flight = true;
+    sub.desc.mbs = j.mb_dev;
+    sub.desc.motions = j.motion_dev;
+    sub.desc.coefs = j.coef_dev;
+    sub.desc.slices = j.slice_dev;
+    sub.desc.db = j.db_dev;
+    sub.desc.do_inter = d.has_inter;
+    sub.desc.do_intra = d.has_intra;
+    sub.desc.do_deblock = d.any_deblock;
+    sub.num_mbs = static_cast<int>(nmb);
+    const uint64_t S = nmb * 384;  // coded I420 bytes
+    sub.bytes_inter = d.has_inter ? S * (1 + ((d.slice_type_mask & 2) ? 2 : 1)) : 0;
+    sub.bytes_intra = d.has_intra ? S : 0;
+    sub.bytes_deblock = d.any_deblock ? 2 * S : 0;
+    j.seq = last_seq_ = exec_->submit_picture(lane_, sub);
+    if (d.has_inter) surf_[d.slot].motion_seq = j.seq;
     return true;
   }
 
@@ -300,22 +271,19 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   struct SurfaceSlot {
     uint8_t* dev = nullptr;
     MbMotion* motion_host = nullptr;  // pinned; also the co-located source
-    hipEvent_t motion_done = nullptr;
-    bool motion_busy = false;
+    uint64_t motion_seq = 0;          // submission that still uploads from motion_host
     int held = 0;
   };
   struct Job {
     MbInfo* mb_host = nullptr;
     int16_t* coef_host = nullptr;
     SliceParams* slice_host = nullptr;
-    unsigned* timeout_host = nullptr;  // [2]
     MbInfo* mb_dev = nullptr;
     MbMotion* motion_dev = nullptr;
     int16_t* coef_dev = nullptr;
     SliceParams* slice_dev = nullptr;
-    unsigned* sync_dev = nullptr;  // two blocks of sync_words_
-    hipEvent_t done = nullptr;
-    bool in_flight = false;
+    void* db_dev = nullptr;  // k_bs -> k_deblock records
+    uint64_t seq = 0;  // submission that still reads the staging buffers
   };
   struct Bounce {
     uint8_t* host = nullptr;
@@ -329,17 +297,22 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (slot >= 0 && slot < amd::kMaxSurfaces) surf_[slot].held &= ~who;
   }
 
-  Result check_gpu_flags() {
-    for (Job& j : jobs_)
-      if (j.timeout_host && (j.timeout_host[0] || j.timeout_host[1])) {
-        j.timeout_host[0] = j.timeout_host[1] = 0;
-        return Result(false, "AMDVideoDecoder: GPU row-wavefront timed out");
-      }
+  Result wait_seq(uint64_t seq) {
+    if (!seq) return Result();
+    std::string error;
+    if (!exec_->wait(lane_, seq, &error)) return Result(false, "AMDVideoDecoder: " + error);
     return Result();
+  }
+  void deliver_bounces_locked() {
+    for (Bounce& b : bounce_)
+      if (b.dst) {
+        std::memcpy(b.dst, b.host, b.size);
+        b.dst = nullptr;
+      }
   }
 
   Result drain_and_reset() {
-    if (stream_) HWANG_HIP_RETURN(hipStreamSynchronize(stream_));
+    HWANG_RETURN_ON_ERROR(wait_seq(last_seq_));
     std::lock_guard<std::mutex> lk(out_mu_);
     outq_.clear();
     buffered_.store(0);
@@ -355,7 +328,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       return true;
     }
     // new geometry: everything in flight belongs to the old one
-    (void)hipStreamSynchronize(stream_);
+    (void)wait_seq(last_seq_);
     free_buffers();
     mbw_ = s.mb_width;
     mbh_ = s.mb_height;
@@ -369,23 +342,19 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
     // worst case: every one of 27 groups of every macroblock coded
     coef_capacity_ = nmb * 27 * 16;
-    sync_words_ = ((2 + mbh_ + 3) / 4) * 4;
     for (Job& j : jobs_) {
       if (hipHostMalloc(reinterpret_cast<void**>(&j.mb_host), nmb * sizeof(MbInfo), hipHostMallocDefault) != hipSuccess ||
           hipHostMalloc(reinterpret_cast<void**>(&j.coef_host), coef_capacity_ * 2, hipHostMallocDefault) != hipSuccess ||
           hipHostMalloc(reinterpret_cast<void**>(&j.slice_host), kMaxSlices * sizeof(SliceParams), hipHostMallocDefault) != hipSuccess ||
-          hipHostMalloc(reinterpret_cast<void**>(&j.timeout_host), 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.mb_dev), nmb * sizeof(MbInfo)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.motion_dev), nmb * sizeof(MbMotion)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.coef_dev), coef_capacity_ * 2) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.slice_dev), kMaxSlices * sizeof(SliceParams)) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.sync_dev), 2 * sync_words_ * sizeof(unsigned)) != hipSuccess ||
-          hipEventCreateWithFlags(&j.done, hipEventDisableTiming) != hipSuccess) {
+          hipMalloc(&j.db_dev, amd::deblock_scratch_bytes(static_cast<int>(nmb))) != hipSuccess) {
         *error = "AMDVideoDecoder: out of memory for staging buffers";
         return false;
       }
-      j.timeout_host[0] = j.timeout_host[1] = 0;
-      j.in_flight = false;
+      j.seq = 0;
     }
     job_cursor_ = 0;
     return true;
@@ -396,8 +365,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (s.dev) return true;
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
     if (hipMalloc(reinterpret_cast<void**>(&s.dev), surface_bytes_) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s.motion_host), nmb * sizeof(MbMotion), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&s.motion_done, hipEventDisableTiming) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void**>(&s.motion_host), nmb * sizeof(MbMotion), hipHostMallocDefault) != hipSuccess) {
       *error = "AMDVideoDecoder: out of memory for a decode surface";
       return false;
     }
@@ -409,19 +377,16 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       if (j.mb_host) (void)hipHostFree(j.mb_host);
       if (j.coef_host) (void)hipHostFree(j.coef_host);
       if (j.slice_host) (void)hipHostFree(j.slice_host);
-      if (j.timeout_host) (void)hipHostFree(j.timeout_host);
       if (j.mb_dev) (void)hipFree(j.mb_dev);
       if (j.motion_dev) (void)hipFree(j.motion_dev);
       if (j.coef_dev) (void)hipFree(j.coef_dev);
       if (j.slice_dev) (void)hipFree(j.slice_dev);
-      if (j.sync_dev) (void)hipFree(j.sync_dev);
-      if (j.done) (void)hipEventDestroy(j.done);
+      if (j.db_dev) (void)hipFree(j.db_dev);
       j = Job();
     }
     for (SurfaceSlot& s : surf_) {
       if (s.dev) (void)hipFree(s.dev);
       if (s.motion_host) (void)hipHostFree(s.motion_host);
-      if (s.motion_done) (void)hipEventDestroy(s.motion_done);
       s = SurfaceSlot();
     }
     for (Bounce& b : bounce_) {
@@ -434,11 +399,12 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   void teardown() {
     if (hipSetDevice(device_) != hipSuccess) return;
-    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (exec_) {
+      (void)wait_seq(last_seq_);
+      exec_->unregister_lane(lane_);
+    }
     parser_.reset();
     free_buffers();
-    if (stream_) (void)hipStreamDestroy(stream_);
-    stream_ = nullptr;
   }
 
   static bool is_device_pointer(const void* p) {
@@ -469,39 +435,31 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       buffered_.store(static_cast<int>(outq_.size()));
     }
     const SurfaceSlot& s = surf_[slot];
-    const uint8_t* y = s.dev + static_cast<size_t>(crop_top_) * y_pitch_ + crop_left_;
-    const uint8_t* u = s.dev + u_offset_ + static_cast<size_t>(crop_top_ / 2) * c_pitch_ + crop_left_ / 2;
-    const uint8_t* v = s.dev + v_offset_ + static_cast<size_t>(crop_top_ / 2) * c_pitch_ + crop_left_ / 2;
-    const bool to_device = is_device_pointer(dst);
+    amd::ConvSubmit sub;
+    std::memset(&sub.desc, 0, sizeof(sub.desc));
+    sub.desc.y = s.dev + static_cast<size_t>(crop_top_) * y_pitch_ + crop_left_;
+    sub.desc.u = s.dev + u_offset_ + static_cast<size_t>(crop_top_ / 2) * c_pitch_ + crop_left_ / 2;
+    sub.desc.v = s.dev + v_offset_ + static_cast<size_t>(crop_top_ / 2) * c_pitch_ + crop_left_ / 2;
+    sub.desc.y_pitch = y_pitch_;
+    sub.desc.c_pitch = c_pitch_;
+    sub.desc.width = static_cast<int>(w);
+    sub.desc.height = static_cast<int>(h);
+    sub.desc.yuv = yuv ? 1 : 0;
+    sub.bytes = need + (yuv ? need : w * h + 2 * cw * ch);
     Result r;
-    uint8_t* target = dst;
-    Bounce* bounce = nullptr;
-    if (!to_device || !yuv) {
-      // RGB to the device writes straight into dst; everything else goes
-      // through a bounce buffer (device for the kernel output, pinned host
-      // for the copy-out)
-      if (!(to_device && !yuv)) {
-        r = acquire_bounce(need, &bounce);
-        if (!r.ok) return finish_take(slot, r);
-        target = bounce->dev;
-      }
-    }
-    hipError_t e = hipSuccess;
-    if (yuv) {
-      uint8_t* t = to_device ? dst : target;
-      e = hipMemcpy2DAsync(t, w, y, y_pitch_, w, h, hipMemcpyDeviceToDevice, stream_);
-      if (e == hipSuccess) e = hipMemcpy2DAsync(t + w * h, cw, u, c_pitch_, cw, ch, hipMemcpyDeviceToDevice, stream_);
-      if (e == hipSuccess)
-        e = hipMemcpy2DAsync(t + w * h + cw * ch, cw, v, c_pitch_, cw, ch, hipMemcpyDeviceToDevice, stream_);
+    if (is_device_pointer(dst)) {
+      sub.desc.dst = dst;  // the kernel writes caller memory in HBM directly
     } else {
-      e = launch_yuv420_to_rgb24(y, u, v, y_pitch_, c_pitch_, static_cast<int>(w), static_cast<int>(h), target, stream_);
-    }
-    if (e == hipSuccess && !to_device) {
-      e = hipMemcpyAsync(bounce->host, bounce->dev, need, hipMemcpyDeviceToHost, stream_);
+      Bounce* bounce = nullptr;
+      r = acquire_bounce(need, &bounce);
+      if (!r.ok) return finish_take(slot, r);
+      sub.desc.dst = bounce->dev;
+      sub.d2h_dst = bounce->host;
+      sub.d2h_bytes = need;
       bounce->dst = dst;
       bounce->size = need;
     }
-    if (e != hipSuccess) r = Result(false, std::string("AMDVideoDecoder::get_frame: ") + hipGetErrorString(e));
+    last_seq_ = exec_->submit_convert(lane_, sub);
     return finish_take(slot, r);
   }
 
@@ -516,13 +474,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     Bounce& b = bounce_[bounce_cursor_];
     bounce_cursor_ = (bounce_cursor_ + 1) % kBounce;
     if (b.dst) {
-      // the ring wrapped: deliver the oldest pending frame now
-      HWANG_HIP_RETURN(hipStreamSynchronize(stream_));
-      for (Bounce& p : bounce_)
-        if (p.dst) {
-          std::memcpy(p.dst, p.host, p.size);
-          p.dst = nullptr;
-        }
+      // the ring wrapped: deliver what is pending now
+      HWANG_RETURN_ON_ERROR(wait_seq(last_seq_));
+      deliver_bounces_locked();
     }
     if (b.capacity < need) {
       if (b.host) (void)hipHostFree(b.host);
@@ -537,7 +491,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   const int device_;
-  hipStream_t stream_ = nullptr;
+  amd::GpuExecutor* exec_ = nullptr;
+  int lane_ = -1;
+  uint64_t last_seq_ = 0;
   FrameInfo info_{};
   std::unique_ptr<h264::Parser> parser_;
   std::string sink_error_;
@@ -545,7 +501,6 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   int mbw_ = 0, mbh_ = 0, y_pitch_ = 0, c_pitch_ = 0, crop_left_ = 0, crop_top_ = 0;
   size_t u_offset_ = 0, v_offset_ = 0, surface_bytes_ = 0, coef_capacity_ = 0;
-  int sync_words_ = 0;
   SurfaceSlot surf_[amd::kMaxSurfaces];
   Job jobs_[kJobs];
   int job_cursor_ = 0, cur_job_ = 0;
@@ -557,7 +512,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   std::atomic<int> buffered_{0};
 
   BackendCounters counters_;
-  int64_t decoded_base_ = 0, skipped_base_ = 0;
+  int64_t decoded_base_ = 0, skipped_base_ = 0, folded_decoded_ = 0, folded_skipped_ = 0;
 };
 
 }  // namespace

@@ -112,5 +112,30 @@ struct PictureParams {
   Surface surfaces[kMaxSurfaces];
 };
 
+// One picture's worth of work as the batched kernels see it.  The executor
+// uploads an array of these per batch; workgroup -> job is blockIdx.y (k_inter)
+// or blockIdx.x (row pipelines, k_bs uses blockIdx.y).
+struct JobDesc {
+  PictureParams pp;
+  const MbInfo* mbs;
+  const MbMotion* motions;
+  const int16_t* coefs;
+  const SliceParams* slices;
+  void* db;            // k_bs -> k_deblock records
+  int32_t do_inter, do_intra, do_deblock;
+  int32_t pad;
+};
+
+// One colour-conversion / plane-copy request.
+struct ConvertDesc {
+  const uint8_t* y;
+  const uint8_t* u;
+  const uint8_t* v;
+  uint8_t* dst;        // device memory: RGB24 (w*h*3) or I420 (w*h*3/2)
+  int32_t y_pitch, c_pitch, width, height;
+  int32_t yuv;         // 1: copy cropped planes instead of converting
+  int32_t pad[3];
+};
+
 }  // namespace amd
 }  // namespace hwang

@@ -1,0 +1,120 @@
+// Per-device batching executor.
+//
+// Sparse decoding is parallel across keyframe-anchored intervals ("lanes":
+// one host thread + one DPB each), not inside a picture, whose intra and
+// deblocking stages are raster-order pipelines that keep one CU busy.  To
+// fill 256 CUs the GPU therefore has to work on many lanes' pictures at the
+// same time.  Doing that with one HIP stream per lane runs into the
+// hardware-queue limit and into per-call runtime overhead, so lanes only
+// *describe* work here and a single submitter thread per GPU turns whatever
+// is pending into a few large launches:
+//
+//     H2D of the new pictures' records            (copy engine)
+//     k_inter    grid (max_mbs, pictures)         every inter MB of every picture
+//     k_intra    grid (pictures)                  one 16-wave row pipeline each
+//     k_bs       grid (max_mbs/8, pictures)
+//     k_deblock  grid (pictures)
+//     convert    grid (.., .., frames)            I420 -> RGB24 / plane copies
+//     D2H of frames that go to host memory
+//
+// A batch takes at most one picture per lane (a lane's pictures depend on
+// each other) plus the conversions queued behind it; batches execute in
+// order on one stream, which is all the ordering a lane needs.
+#pragma once
+
+#include "frame_job.h"
+
+#include <hip/hip_runtime.h>
+
+#include <condition_variable>
+#include <cstdint>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace hwang {
+namespace amd {
+
+struct PicSubmit {
+  JobDesc desc;  // device pointers
+  struct Copy {
+    void* dst;
+    const void* src;
+    size_t bytes;
+  } copies[4];
+  int ncopies = 0;
+  int num_mbs = 0;
+  uint64_t bytes_inter = 0, bytes_intra = 0, bytes_deblock = 0;  // algorithmic, for the roofline
+};
+
+struct ConvSubmit {
+  ConvertDesc desc;
+  void* d2h_dst = nullptr;  // pinned host target, or null when desc.dst is the final destination
+  size_t d2h_bytes = 0;
+  uint64_t bytes = 0;
+};
+
+class GpuExecutor {
+ public:
+  // One executor per device for the life of the process.
+  static GpuExecutor* get(int device, std::string* error);
+
+  int register_lane();
+  void unregister_lane(int lane);
+  // Both return the lane-local sequence number of the submission (1, 2, ...).
+  uint64_t submit_picture(int lane, const PicSubmit& job);
+  uint64_t submit_convert(int lane, const ConvSubmit& job);
+  // Blocks until the lane's submissions up to `seq` have finished on the GPU.
+  bool wait(int lane, uint64_t seq, std::string* error);
+
+  struct Stats {
+    uint64_t batches = 0, pictures = 0, conversions = 0;
+  };
+  Stats stats();
+
+ private:
+  explicit GpuExecutor(int device) : device_(device) {}
+  bool start(std::string* error);
+  void run();
+  void stop();
+  friend void shutdown_executors();
+
+  struct Item {
+    bool is_picture;
+    PicSubmit pic;
+    ConvSubmit conv;
+  };
+  struct Lane {
+    bool active = false;
+    std::deque<Item> fifo;
+    uint64_t submitted = 0, completed = 0;
+  };
+  struct Batch {
+    std::vector<std::pair<int, int>> lane_counts;  // (lane, items taken)
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+  };
+
+  static constexpr int kInflight = 3;
+  static constexpr int kMaxJobs = 512;
+
+  const int device_;
+  std::thread thread_;
+  std::mutex mu_;
+  std::condition_variable cv_work_, cv_done_;
+  bool stop_ = false;
+  std::string error_;
+  std::vector<Lane> lanes_;
+  hipStream_t stream_ = nullptr;
+  Batch batches_[kInflight];
+  JobDesc* job_table_host_[kInflight] = {nullptr, nullptr, nullptr};
+  JobDesc* job_table_dev_[kInflight] = {nullptr, nullptr, nullptr};
+  ConvertDesc* conv_table_host_[kInflight] = {nullptr, nullptr, nullptr};
+  ConvertDesc* conv_table_dev_[kInflight] = {nullptr, nullptr, nullptr};
+  Stats stats_;
+};
+
+}  // namespace amd
+}  // namespace hwang

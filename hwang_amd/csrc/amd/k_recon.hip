@@ -335,11 +335,15 @@ __device__ int combine_pred(const SliceParams& sp, int plane, bool use0, bool us
 // ===========================================================================
 // k_inter: one workgroup (256 threads) per macroblock; intra macroblocks exit.
 // ===========================================================================
-__global__ __launch_bounds__(256) void k_inter(PictureParams pp, const MbInfo* __restrict__ mbs,
-                                               const MbMotion* __restrict__ motions,
-                                               const int16_t* __restrict__ coefs,
-                                               const SliceParams* __restrict__ slices) {
+__global__ __launch_bounds__(256) void k_inter(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.y];
+  const PictureParams& pp = job.pp;
   const int mbi = blockIdx.x;
+  if (!job.do_inter || mbi >= pp.mb_width * pp.mb_height) return;
+  const MbInfo* __restrict__ mbs = job.mbs;
+  const MbMotion* __restrict__ motions = job.motions;
+  const int16_t* __restrict__ coefs = job.coefs;
+  const SliceParams* __restrict__ slices = job.slices;
   const MbInfo mb = mbs[mbi];
   if (mb.kind != MBK_INTER) return;
   const int tid = threadIdx.x;
@@ -399,45 +403,186 @@ __global__ __launch_bounds__(256) void k_inter(PictureParams pp, const MbInfo* _
 }
 
 // ===========================================================================
-// Row-wavefront plumbing shared by k_intra and k_deblock.
-//   sync[0]            ticket counter: workgroups take rows in arrival order,
-//                      so a row only ever waits on rows taken earlier
-//   sync[1 + r]        number of macroblocks of row r that are complete
-// The producer publishes with an agent-scope release, the consumer polls
-// relaxed and acquires once (cdna guide, guideline 16).
+// Row pipelines (k_intra, k_deblock).
+//
+// Intra prediction and the deblocking filter have true raster-order
+// dependencies: a macroblock needs its left, top-left, top and top-right
+// neighbours finished.  Rows can run concurrently as long as each stays two
+// macroblocks behind the row above.  Each picture is handled by ONE workgroup
+// of 16 waves; wave w walks rows w, w+16, w+32, ... one macroblock at a time
+// (64 lanes = one macroblock), and rows hand their progress to the row below
+// through counters in LDS.  Consequences:
+//   * no inter-workgroup protocol at all: visibility between waves of one
+//     workgroup needs only workgroup-scope fences (all waves share the CU's
+//     L1), never an agent-scope release/acquire or a cross-CU poll;
+//   * all 16 waves are resident by construction, so the waits cannot
+//     deadlock; a wave only ever waits on a row that started earlier;
+//   * one picture occupies one CU, so up to 256 pictures (lanes) reconstruct
+//     concurrently per GPU -- the parallelism of sparse decoding is across
+//     keyframe-anchored intervals, not inside one picture.
 // ===========================================================================
 namespace {
 
-__device__ __forceinline__ void publish_progress(unsigned* slot, unsigned value, int tid) {
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(slot, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+constexpr int kRowWaves = 16;
+constexpr int kMaxRows = 512;
+
+// everything one wave wrote to LDS is visible to its other lanes afterwards
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// returns false on timeout (the caller records it and carries on; the host
-// reports the failure instead of hanging the queue)
-__device__ __forceinline__ bool wait_progress(unsigned* slot, unsigned need, int tid, unsigned* timeout_word) {
-  __shared__ int s_ok;
-  if (tid == 0) {
-    int ok = 1;
-    unsigned spins = 0;
-    while (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 26)) {
-        ok = 0;
-        __hip_atomic_store(timeout_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+// progress[r + 1] = macroblocks of row r that are complete; progress[0] is
+// the (always complete) row above the picture
+__device__ __forceinline__ void row_wait(volatile int* progress, int row, int need) {
+  while (progress[row] < need) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void row_publish(volatile int* progress, int row, int done) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // global stores of this wave have landed
+  progress[row + 1] = done;
+}
+
+// ---------------------------------------------------------------------------
+// Residual of one macroblock, computed by ONE wave (64 lanes) into LDS.
+//   work[384] ints scratch, dcs[24] ints, res_y[256], res_c[128] int16
+// ---------------------------------------------------------------------------
+__device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const PictureParams& pp, int lane,
+                              int* work, int* dcs, int16_t* res_y, int16_t* res_c) {
+  const bool intra = mb.flags & MBF_INTRA;
+  const int qp = mb.qp;
+  int* dy = work;
+  int* dc = work + 256;
+  if (mb.kind == MBK_I16x16 && lane < 16) {
+    const int16_t* g = coef_group(mb, coefs, kMaskLumaDc);
+    int f = 0;
+    if (g) {
+      const int i = lane >> 2, j = lane & 3;
+      for (int a = 0; a < 4; ++a) {
+        const int sa = (i == 0 || (i == 1 && a < 2) || (i == 2 && (a == 0 || a == 3)) || (i == 3 && (a & 1) == 0)) ? 1 : -1;
+        for (int b = 0; b < 4; ++b) {
+          const int sb = (j == 0 || (j == 1 && b < 2) || (j == 2 && (b == 0 || b == 3)) || (j == 3 && (b & 1) == 0)) ? 1 : -1;
+          f += sa * sb * g[a * 4 + b];
+        }
       }
+      const int ls = level_scale4(pp.scaling4[0], qp, 0);
+      f = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_ok = ok;
+    dcs[lane] = f;
   }
-  __syncthreads();
-  return s_ok != 0;
+  if (lane >= 16 && lane < 24) {
+    const int p = (lane - 16) >> 2, k = (lane - 16) & 3;
+    const int16_t* g = coef_group(mb, coefs, kMaskChromaDc);
+    int v = 0;
+    if (g) {
+      const int16_t* c = g + 4 * p;
+      const int f = k == 0 ? c[0] + c[1] + c[2] + c[3]
+                  : k == 1 ? c[0] - c[1] + c[2] - c[3]
+                  : k == 2 ? c[0] + c[1] - c[2] - c[3]
+                           : c[0] - c[1] - c[2] + c[3];
+      const int qpc = mb.qpc[p];
+      const int ls = level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, 0);
+      v = ((f * ls) << (qpc / 6)) >> 5;
+    }
+    dcs[lane] = v;
+  }
+  wave_sync();
+  // scaling
+  for (int t = lane; t < 256; t += 64) {
+    int v = 0;
+    if (mb.flags & MBF_T8X8) {
+      const int b8 = t >> 6, k = t & 63;
+      const int16_t* g = coef_group(mb, coefs, 4 * b8);
+      if (g && g[k]) {
+        const int s = g[k] * level_scale8(pp.scaling8[intra ? 0 : 1], qp, k);
+        v = qp >= 36 ? s << (qp / 6 - 6) : (s + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+      }
+    } else {
+      const int blk = t >> 4, k = t & 15;
+      const int16_t* g = coef_group(mb, coefs, blk);
+      if (g && g[k]) {
+        const int s = g[k] * level_scale4(pp.scaling4[intra ? 0 : 3], qp, k);
+        v = qp >= 24 ? s << (qp / 6 - 4) : (s + (1 << (3 - qp / 6))) >> (4 - qp / 6);
+      }
+      if (k == 0 && mb.kind == MBK_I16x16) v = dcs[blk];
+    }
+    dy[t] = v;
+  }
+  for (int t = lane; t < 128; t += 64) {
+    const int p = t >> 6, blk = (t >> 4) & 3, k = t & 15;
+    const int16_t* g = coef_group(mb, coefs, kMaskChromaAc + 4 * p + blk);
+    int v = 0;
+    const int qpc = mb.qpc[p];
+    if (g && g[k]) {
+      const int s = g[k] * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, k);
+      v = qpc >= 24 ? s << (qpc / 6 - 4) : (s + (1 << (3 - qpc / 6))) >> (4 - qpc / 6);
+    }
+    if (k == 0) v = dcs[16 + 4 * p + blk];
+    dc[t] = v;
+  }
+  wave_sync();
+  // rows
+  if (mb.flags & MBF_T8X8) {
+    if (lane < 32) {
+      int* d = dy + (lane >> 3) * 64 + (lane & 7) * 8;
+      const int d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
+      const int e0 = d0 + d4, e1 = -d3 + d5 - d7 - (d7 >> 1), e2 = d0 - d4, e3 = d1 + d7 - d3 - (d3 >> 1);
+      const int e4 = (d2 >> 1) - d6, e5 = -d1 + d7 + d5 + (d5 >> 1), e6 = d2 + (d6 >> 1), e7 = d3 + d5 + d1 + (d1 >> 1);
+      const int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
+      const int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+      d[0] = f0 + f7; d[1] = f2 + f5; d[2] = f4 + f3; d[3] = f6 + f1;
+      d[4] = f6 - f1; d[5] = f4 - f3; d[6] = f2 - f5; d[7] = f0 - f7;
+    }
+  } else {
+    int* d = dy + (lane >> 2) * 16 + (lane & 3) * 4;
+    const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
+    d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
+  }
+  if (lane < 32) {
+    int* d = dc + (lane >> 2) * 16 + (lane & 3) * 4;
+    const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
+    d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
+  }
+  wave_sync();
+  // columns
+  if (mb.flags & MBF_T8X8) {
+    if (lane < 32) {
+      const int b8 = lane >> 3, c = lane & 7;
+      const int* d = dy + b8 * 64 + c;
+      const int d0 = d[0], d1 = d[8], d2 = d[16], d3 = d[24], d4 = d[32], d5 = d[40], d6 = d[48], d7 = d[56];
+      const int e0 = d0 + d4, e1 = -d3 + d5 - d7 - (d7 >> 1), e2 = d0 - d4, e3 = d1 + d7 - d3 - (d3 >> 1);
+      const int e4 = (d2 >> 1) - d6, e5 = -d1 + d7 + d5 + (d5 >> 1), e6 = d2 + (d6 >> 1), e7 = d3 + d5 + d1 + (d1 >> 1);
+      const int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
+      const int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
+      const int o[8] = {f0 + f7, f2 + f5, f4 + f3, f6 + f1, f6 - f1, f4 - f3, f2 - f5, f0 - f7};
+      const int x = (b8 & 1) * 8 + c, y0 = (b8 >> 1) * 8;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) res_y[(y0 + r) * 16 + x] = (int16_t)((o[r] + 32) >> 6);
+    }
+  } else {
+    const int blk = lane >> 2, c = lane & 3;
+    const int* d = dy + blk * 16 + c;
+    const int e0 = d[0] + d[8], e1 = d[0] - d[8], e2 = (d[4] >> 1) - d[12], e3 = d[4] + (d[12] >> 1);
+    const int x = (blk & 3) * 4 + c, y0 = (blk >> 2) * 4;
+    res_y[(y0 + 0) * 16 + x] = (int16_t)((e0 + e3 + 32) >> 6);
+    res_y[(y0 + 1) * 16 + x] = (int16_t)((e1 + e2 + 32) >> 6);
+    res_y[(y0 + 2) * 16 + x] = (int16_t)((e1 - e2 + 32) >> 6);
+    res_y[(y0 + 3) * 16 + x] = (int16_t)((e0 - e3 + 32) >> 6);
+  }
+  if (lane < 32) {
+    const int pb = lane >> 2, c = lane & 3;
+    const int* d = dc + pb * 16 + c;
+    const int e0 = d[0] + d[8], e1 = d[0] - d[8], e2 = (d[4] >> 1) - d[12], e3 = d[4] + (d[12] >> 1);
+    const int p = pb >> 2, blk = pb & 3;
+    const int x = (blk & 1) * 4 + c, y0 = (blk >> 1) * 4;
+    int16_t* r = res_c + p * 64;
+    r[(y0 + 0) * 8 + x] = (int16_t)((e0 + e3 + 32) >> 6);
+    r[(y0 + 1) * 8 + x] = (int16_t)((e1 + e2 + 32) >> 6);
+    r[(y0 + 2) * 8 + x] = (int16_t)((e1 - e2 + 32) >> 6);
+    r[(y0 + 3) * 8 + x] = (int16_t)((e0 - e3 + 32) >> 6);
+  }
+  wave_sync();
 }
 
 // ---- intra prediction helpers working on an LDS tile -----------------------
@@ -448,7 +593,6 @@ constexpr int TS = 28;
 
 __device__ int pred4x4_sample(const uint8_t* t /* block origin in tile */, int mode, int x, int y, bool hl, bool ht,
                               bool htl, bool htr) {
-  // neighbours of this 4x4 block
   auto T = [&](int i) -> int {  // p[i, -1], i in -1..7
     if (i < 0) return htl ? t[-TS - 1] : 128;
     if (!ht) return 128;
@@ -499,7 +643,7 @@ __device__ int pred4x4_sample(const uint8_t* t /* block origin in tile */, int m
   }
 }
 
-// Intra 8x8: `ft` = filtered top (16) , `fl` = filtered left (8), ftl corner;
+// Intra 8x8: `ft` = filtered top (16), `fl` = filtered left (8), ftl corner;
 // prepared by the caller (8.3.2.2.1).
 __device__ int pred8x8_sample(const int* ft, const int* fl, int ftl, int mode, int x, int y, bool hl, bool ht) {
   auto T = [&](int i) -> int { return i < 0 ? ftl : ft[i]; };
@@ -550,264 +694,294 @@ __device__ int pred8x8_sample(const int* ft, const int* fl, int ftl, int mode, i
   }
 }
 
+struct IntraWaveLds {
+  int work[384];
+  int dcs[24];
+  int16_t res_y[256];
+  int16_t res_c[128];
+  uint8_t tile[17 * TS];
+  uint8_t ctile[2][9 * 12];
+  int f_top[16], f_left[8], f_tl;
+};
+
 }  // namespace
 
 // ===========================================================================
-// k_intra: grid = mb_height workgroups of 256 threads.
+// k_intra: grid = 1 workgroup of 16 waves per picture.
 // ===========================================================================
-__global__ __launch_bounds__(256) void k_intra(PictureParams pp, const MbInfo* __restrict__ mbs,
-                                               const int16_t* __restrict__ coefs, unsigned* sync) {
-  const int tid = threadIdx.x;
-  __shared__ int s_row;
-  if (tid == 0) s_row = (int)atomicAdd(&sync[0], 1u);
+__global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.x];
+  if (!job.do_intra) return;
+  const PictureParams& pp = job.pp;
+  const MbInfo* __restrict__ mbs = job.mbs;
+  const int16_t* __restrict__ coefs = job.coefs;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ int s_progress[kMaxRows + 1];
+  __shared__ IntraWaveLds s_lds[kRowWaves];
+  volatile int* progress = s_progress;
+  for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
   __syncthreads();
-  const int mby = s_row;
-  if (mby >= pp.mb_height) return;
-  unsigned* progress = sync + 2;
-  unsigned* timeout_word = sync + 1;
-
-  __shared__ int work[384];
-  __shared__ int16_t res_y[256];
-  __shared__ int16_t res_c[128];
-  __shared__ uint8_t tile[17 * TS];
-  __shared__ uint8_t ctile[2][9 * 12];  // chroma: 9 rows x (1 + 8) cols, stride 12
-  __shared__ int f_top[16], f_left[8], f_tl;
-
+  IntraWaveLds& L = s_lds[wave];
+  uint8_t* tile = L.tile;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
 
-  for (int mbx = 0; mbx < pp.mb_width; ++mbx) {
-    const int mbi = mby * pp.mb_width + mbx;
-    const MbInfo mb = mbs[mbi];
-    if (!(mb.flags & MBF_INTRA)) {
-      // nothing to do here, but rows below still count macroblocks
-      if (tid == 0) __hip_atomic_store(&progress[mby], (unsigned)(mbx + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      continue;
-    }
-    // the row above must be done up to the top-right neighbour
-    if (mby > 0 && (mb.flags & (MBF_AVAIL_B | MBF_AVAIL_C | MBF_AVAIL_D))) {
-      const unsigned need = (unsigned)min(mbx + 2, pp.mb_width);
-      wait_progress(&progress[mby - 1], need, tid, timeout_word);
-    }
-    uint8_t* dy = cur.y + (size_t)(mby * 16) * yp + mbx * 16;
-    uint8_t* du = cur.u + (size_t)(mby * 8) * cp + mbx * 8;
-    uint8_t* dv = cur.v + (size_t)(mby * 8) * cp + mbx * 8;
-
-    if (mb.kind == MBK_IPCM) {
-      const uint8_t* pcm = reinterpret_cast<const uint8_t*>(coefs + mb.coef_offset);
-      dy[(tid >> 4) * yp + (tid & 15)] = pcm[tid];
-      if (tid < 64) du[(tid >> 3) * cp + (tid & 7)] = pcm[256 + tid];
-      else if (tid < 128) dv[((tid - 64) >> 3) * cp + (tid & 7)] = pcm[320 + tid - 64];
-      publish_progress(&progress[mby], (unsigned)(mbx + 1), tid);
-      continue;
-    }
-
-    mb_residual(mb, coefs, pp, tid, work, res_y, res_c);
-
-    const bool hA = mb.flags & MBF_AVAIL_A, hB = mb.flags & MBF_AVAIL_B;
-    const bool hC = mb.flags & MBF_AVAIL_C, hD = mb.flags & MBF_AVAIL_D;
-    // neighbours into the tiles (the left column comes from global too: it
-    // was written by this workgroup one iteration ago, ordered by the
-    // barriers in between)
-    if (tid < 25) tile[tid] = (tid == 0) ? (hD ? dy[-yp - 1] : 128)
-                              : (tid <= 16) ? (hB ? dy[-yp + tid - 1] : 128)
-                                            : (hC ? dy[-yp + tid - 1] : 128);
-    if (tid >= 32 && tid < 48) tile[(tid - 31) * TS] = hA ? dy[(tid - 32) * yp - 1] : 128;
-    if (tid >= 64 && tid < 82) {
-      const int p = (tid - 64) / 9, i = (tid - 64) % 9;
-      const uint8_t* d = p ? dv : du;
-      ctile[p][i] = (i == 0) ? (hD ? d[-cp - 1] : 128) : (hB ? d[-cp + i - 1] : 128);
-    }
-    if (tid >= 96 && tid < 112) {
-      const int p = (tid - 96) >> 3, j = (tid - 96) & 7;
-      const uint8_t* d = p ? dv : du;
-      ctile[p][(j + 1) * 12] = hA ? d[j * cp - 1] : 128;
-    }
-    __syncthreads();
-
-    const int x = tid & 15, y = tid >> 4;
-    if (mb.kind == MBK_I16x16) {
-      const int mode = mb.pred_modes & 15;
-      int v;
-      if (mode == 0) v = tile[1 + x];
-      else if (mode == 1) v = tile[(1 + y) * TS];
-      else if (mode == 2) {
-        int st = 0, sl = 0;
-        for (int i = 0; i < 16; ++i) {
-          st += tile[1 + i];
-          sl += tile[(1 + i) * TS];
+  for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
+    for (int mbx0 = 0; mbx0 < pp.mb_width; mbx0 += 64) {
+      // which of the next 64 macroblocks of this row are intra?
+      const int probe = mbx0 + lane;
+      const bool is_intra = probe < pp.mb_width && (mbs[mby * pp.mb_width + probe].flags & MBF_INTRA);
+      unsigned long long todo = __ballot(is_intra);
+      while (todo) {
+        const int mbx = mbx0 + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int mbi = mby * pp.mb_width + mbx;
+        const MbInfo mb = mbs[mbi];
+        uint8_t* dy = cur.y + (size_t)(mby * 16) * yp + mbx * 16;
+        uint8_t* du = cur.u + (size_t)(mby * 8) * cp + mbx * 8;
+        uint8_t* dv = cur.v + (size_t)(mby * 8) * cp + mbx * 8;
+        if (mb.kind == MBK_IPCM) {
+          const uint8_t* pcm = reinterpret_cast<const uint8_t*>(coefs + mb.coef_offset);
+          for (int t = lane; t < 256; t += 64) dy[(t >> 4) * yp + (t & 15)] = pcm[t];
+          du[(lane >> 3) * cp + (lane & 7)] = pcm[256 + lane];
+          dv[(lane >> 3) * cp + (lane & 7)] = pcm[320 + lane];
+          row_publish(progress, mby, mbx + 1);
+          continue;
         }
-        v = (hB && hA) ? (st + sl + 16) >> 5 : hA ? (sl + 8) >> 4 : hB ? (st + 8) >> 4 : 128;
-      } else {
-        int Hh = 0, Vv = 0;
-        for (int k = 0; k < 8; ++k) {
-          Hh += (k + 1) * (tile[1 + 8 + k] - tile[1 + 6 - k]);          // 6-k == -1 -> tile[0]
-          Vv += (k + 1) * (tile[(1 + 8 + k) * TS] - tile[(1 + 6 - k) * TS]);
+        wave_residual(mb, coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);
+        const bool hA = mb.flags & MBF_AVAIL_A, hB = mb.flags & MBF_AVAIL_B;
+        const bool hC = mb.flags & MBF_AVAIL_C, hD = mb.flags & MBF_AVAIL_D;
+        // the row above must be complete up to the top-right neighbour
+        if (hB || hC || hD) row_wait(progress, mby, min(mbx + 2, pp.mb_width));
+        // neighbours into the tiles
+        if (lane < 25)
+          tile[lane] = (lane == 0) ? (hD ? dy[-yp - 1] : 128) : (lane <= 16) ? (hB ? dy[-yp + lane - 1] : 128)
+                                                                             : (hC ? dy[-yp + lane - 1] : 128);
+        else if (lane >= 32 && lane < 48)
+          tile[(lane - 31) * TS] = hA ? dy[(lane - 32) * yp - 1] : 128;
+        if (lane < 18) {
+          const int p = lane / 9, i = lane % 9;
+          const uint8_t* d = p ? dv : du;
+          L.ctile[p][i] = (i == 0) ? (hD ? d[-cp - 1] : 128) : (hB ? d[-cp + i - 1] : 128);
+        } else if (lane >= 32 && lane < 48) {
+          const int p = (lane - 32) >> 3, j = (lane - 32) & 7;
+          const uint8_t* d = p ? dv : du;
+          L.ctile[p][(j + 1) * 12] = hA ? d[j * cp - 1] : 128;
         }
-        const int a = 16 * (tile[16 * TS] + tile[16]);
-        const int b = (5 * Hh + 32) >> 6, c = (5 * Vv + 32) >> 6;
-        v = clip8((a + b * (x - 7) + c * (y - 7) + 16) >> 5);
-      }
-      dy[y * yp + x] = (uint8_t)clip8(v + res_y[tid]);
-    } else if (mb.kind == MBK_I4x4) {
-      for (int k = 0; k < 16; ++k) {  // decode order
-        const int bx = c_blk_x[k], by = c_blk_y[k];
-        if (tid < 16) {
-          const int px = tid & 3, py = tid >> 2;
-          // neighbour availability of this block
-          const bool hl = bx > 0 || hA, ht = by > 0 || hB;
-          const bool htl = (bx > 0 && by > 0) ? true : (bx > 0) ? hB : (by > 0) ? hA : hD;
-          bool htr;
-          if (by == 0) htr = bx < 3 ? hB : hC;
-          else if (bx == 3) htr = false;
-          else htr = c_raster_to_zz[(by - 1) * 4 + bx + 1] < k;
-          const int raster = by * 4 + bx;
-          const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
-          const uint8_t* t = tile + (1 + by * 4) * TS + 1 + bx * 4;
-          const int v = pred4x4_sample(t, mode, px, py, hl, ht, htl, htr);
-          const int out = clip8(v + res_y[(by * 4 + py) * 16 + bx * 4 + px]);
-          // all 16 samples are predicted before any is overwritten
-          __builtin_amdgcn_wave_barrier();
-          tile[(1 + by * 4 + py) * TS + 1 + bx * 4 + px] = (uint8_t)out;
-        }
-        __syncthreads();
-      }
-      dy[y * yp + x] = tile[(1 + y) * TS + 1 + x];
-    } else {  // MBK_I8x8
-      for (int b8 = 0; b8 < 4; ++b8) {
-        const int bx = (b8 & 1) * 8, by = (b8 >> 1) * 8;
-        const bool hl = bx > 0 || hA, ht = by > 0 || hB;
-        const bool htl = (bx > 0 && by > 0) ? true : (bx > 0) ? hB : (by > 0) ? hA : hD;
-        const bool htr = b8 == 0 ? hB : b8 == 1 ? hC : b8 == 2;
-        const uint8_t* t = tile + (1 + by) * TS + 1 + bx;
-        // reference sample filtering (8.3.2.2.1)
-        if (tid < 16) {
-          int v = 128;
-          if (ht) {
-            auto R = [&](int i) -> int { return (i > 7 && !htr) ? t[-TS + 7] : t[-TS + i]; };
-            if (tid == 0) v = htl ? (t[-TS - 1] + 2 * R(0) + R(1) + 2) >> 2 : (3 * R(0) + R(1) + 2) >> 2;
-            else if (tid == 15) v = (R(14) + 3 * R(15) + 2) >> 2;
-            else v = (R(tid - 1) + 2 * R(tid) + R(tid + 1) + 2) >> 2;
+        wave_sync();
+
+        if (mb.kind == MBK_I16x16) {
+          const int mode = mb.pred_modes & 15;
+          int dcv = 128, a = 0, b = 0, c = 0;
+          if (mode == 2) {
+            int st = 0, sl = 0;
+            for (int i = 0; i < 16; ++i) {
+              st += tile[1 + i];
+              sl += tile[(1 + i) * TS];
+            }
+            dcv = (hB && hA) ? (st + sl + 16) >> 5 : hA ? (sl + 8) >> 4 : hB ? (st + 8) >> 4 : 128;
+          } else if (mode == 3) {
+            int Hh = 0, Vv = 0;
+            for (int k = 0; k < 8; ++k) {
+              Hh += (k + 1) * (tile[1 + 8 + k] - tile[1 + 6 - k]);
+              Vv += (k + 1) * (tile[(1 + 8 + k) * TS] - tile[(1 + 6 - k) * TS]);
+            }
+            a = 16 * (tile[16 * TS] + tile[16]);
+            b = (5 * Hh + 32) >> 6;
+            c = (5 * Vv + 32) >> 6;
           }
-          f_top[tid] = v;
-        } else if (tid < 24) {
-          const int j = tid - 16;
-          int v = 128;
-          if (hl) {
-            auto Lr = [&](int i) -> int { return t[i * TS - 1]; };
-            if (j == 0) v = htl ? (t[-TS - 1] + 2 * Lr(0) + Lr(1) + 2) >> 2 : (3 * Lr(0) + Lr(1) + 2) >> 2;
-            else if (j == 7) v = (Lr(6) + 3 * Lr(7) + 2) >> 2;
-            else v = (Lr(j - 1) + 2 * Lr(j) + Lr(j + 1) + 2) >> 2;
+          for (int t = lane; t < 256; t += 64) {
+            const int x = t & 15, y = t >> 4;
+            const int v = mode == 0 ? tile[1 + x] : mode == 1 ? tile[(1 + y) * TS] : mode == 2 ? dcv
+                                                  : clip8((a + b * (x - 7) + c * (y - 7) + 16) >> 5);
+            dy[y * yp + x] = (uint8_t)clip8(v + L.res_y[t]);
           }
-          f_left[j] = v;
-        } else if (tid == 24) {
-          int v = 128;
-          if (htl) {
-            const int c = t[-TS - 1];
-            if (ht && hl) v = (t[-TS] + 2 * c + t[-1] + 2) >> 2;
-            else if (ht) v = (3 * c + t[-TS] + 2) >> 2;
-            else if (hl) v = (3 * c + t[-1] + 2) >> 2;
-            else v = c;
+        } else if (mb.kind == MBK_I4x4) {
+          for (int k = 0; k < 16; ++k) {  // decode order
+            const int bx = c_blk_x[k], by = c_blk_y[k];
+            if (lane < 16) {
+              const int px = lane & 3, py = lane >> 2;
+              const bool hl = bx > 0 || hA, ht = by > 0 || hB;
+              const bool htl = (bx > 0 && by > 0) ? true : (bx > 0) ? hB : (by > 0) ? hA : hD;
+              bool htr;
+              if (by == 0) htr = bx < 3 ? hB : hC;
+              else if (bx == 3) htr = false;
+              else htr = c_raster_to_zz[(by - 1) * 4 + bx + 1] < k;
+              const int raster = by * 4 + bx;
+              const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
+              const uint8_t* t = tile + (1 + by * 4) * TS + 1 + bx * 4;
+              const int v = pred4x4_sample(t, mode, px, py, hl, ht, htl, htr);
+              const int out = clip8(v + L.res_y[(by * 4 + py) * 16 + bx * 4 + px]);
+              tile[(1 + by * 4 + py) * TS + 1 + bx * 4 + px] = (uint8_t)out;  // neighbours lie outside the block
+            }
+            wave_sync();
           }
-          f_tl = v;
+          for (int t = lane; t < 256; t += 64) dy[(t >> 4) * yp + (t & 15)] = tile[(1 + (t >> 4)) * TS + 1 + (t & 15)];
+        } else {  // MBK_I8x8
+          for (int b8 = 0; b8 < 4; ++b8) {
+            const int bx = (b8 & 1) * 8, by = (b8 >> 1) * 8;
+            const bool hl = bx > 0 || hA, ht = by > 0 || hB;
+            const bool htl = (bx > 0 && by > 0) ? true : (bx > 0) ? hB : (by > 0) ? hA : hD;
+            const bool htr = b8 == 0 ? hB : b8 == 1 ? hC : b8 == 2;
+            const uint8_t* t = tile + (1 + by) * TS + 1 + bx;
+            if (lane < 16) {
+              int v = 128;
+              if (ht) {
+                auto R = [&](int i) -> int { return (i > 7 && !htr) ? t[-TS + 7] : t[-TS + i]; };
+                if (lane == 0) v = htl ? (t[-TS - 1] + 2 * R(0) + R(1) + 2) >> 2 : (3 * R(0) + R(1) + 2) >> 2;
+                else if (lane == 15) v = (R(14) + 3 * R(15) + 2) >> 2;
+                else v = (R(lane - 1) + 2 * R(lane) + R(lane + 1) + 2) >> 2;
+              }
+              L.f_top[lane] = v;
+            } else if (lane < 24) {
+              const int j = lane - 16;
+              int v = 128;
+              if (hl) {
+                auto Lr = [&](int i) -> int { return t[i * TS - 1]; };
+                if (j == 0) v = htl ? (t[-TS - 1] + 2 * Lr(0) + Lr(1) + 2) >> 2 : (3 * Lr(0) + Lr(1) + 2) >> 2;
+                else if (j == 7) v = (Lr(6) + 3 * Lr(7) + 2) >> 2;
+                else v = (Lr(j - 1) + 2 * Lr(j) + Lr(j + 1) + 2) >> 2;
+              }
+              L.f_left[j] = v;
+            } else if (lane == 24) {
+              int v = 128;
+              if (htl) {
+                const int cc = t[-TS - 1];
+                if (ht && hl) v = (t[-TS] + 2 * cc + t[-1] + 2) >> 2;
+                else if (ht) v = (3 * cc + t[-TS] + 2) >> 2;
+                else if (hl) v = (3 * cc + t[-1] + 2) >> 2;
+                else v = cc;
+              }
+              L.f_tl = v;
+            }
+            wave_sync();
+            {
+              const int px = lane & 7, py = lane >> 3;
+              const int raster = (by >> 2) * 4 + (bx >> 2);
+              const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
+              const int v = pred8x8_sample(L.f_top, L.f_left, L.f_tl, mode, px, py, hl, ht);
+              tile[(1 + by + py) * TS + 1 + bx + px] = (uint8_t)clip8(v + L.res_y[(by + py) * 16 + bx + px]);
+            }
+            wave_sync();
+          }
+          for (int t = lane; t < 256; t += 64) dy[(t >> 4) * yp + (t & 15)] = tile[(1 + (t >> 4)) * TS + 1 + (t & 15)];
         }
-        __syncthreads();
-        if (tid < 64) {
-          const int px = tid & 7, py = tid >> 3;
-          const int raster = (by >> 2) * 4 + (bx >> 2);
-          const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
-          const int v = pred8x8_sample(f_top, f_left, f_tl, mode, px, py, hl, ht);
-          tile[(1 + by + py) * TS + 1 + bx + px] = (uint8_t)clip8(v + res_y[(by + py) * 16 + bx + px]);
-        }
-        __syncthreads();
-      }
-      dy[y * yp + x] = tile[(1 + y) * TS + 1 + x];
-    }
 
-    // chroma 8x8, both planes: threads 0..127
-    if (tid < 128) {
-      const int p = tid >> 6, cx = tid & 7, cy = (tid >> 3) & 7;
-      const uint8_t* ct = ctile[p];
-      const int mode = mb.pred_modes >> 4;
-      int v;
-      if (mode == 0) {
-        const int bx = cx >> 2, by = cy >> 2;
-        int st = 0, sl = 0;
-        for (int i = 0; i < 4; ++i) {
-          st += ct[1 + 4 * bx + i];
-          sl += ct[(1 + 4 * by + i) * 12];
+        // chroma 8x8, both planes: two samples per lane
+        for (int t = lane; t < 128; t += 64) {
+          const int p = t >> 6, cx = t & 7, cy = (t >> 3) & 7;
+          const uint8_t* ct = L.ctile[p];
+          const int mode = mb.pred_modes >> 4;
+          int v;
+          if (mode == 0) {
+            const int bx = cx >> 2, by = cy >> 2;
+            int st = 0, sl = 0;
+            for (int i = 0; i < 4; ++i) {
+              st += ct[1 + 4 * bx + i];
+              sl += ct[(1 + 4 * by + i) * 12];
+            }
+            if (bx == by) v = (hB && hA) ? (st + sl + 4) >> 3 : hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
+            else if (bx == 1) v = hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
+            else v = hA ? (sl + 2) >> 2 : hB ? (st + 2) >> 2 : 128;
+          } else if (mode == 1) {
+            v = ct[(1 + cy) * 12];
+          } else if (mode == 2) {
+            v = ct[1 + cx];
+          } else {
+            int Hh = 0, Vv = 0;
+            for (int k = 0; k < 4; ++k) {
+              Hh += (k + 1) * (ct[1 + 4 + k] - ct[1 + 2 - k]);
+              Vv += (k + 1) * (ct[(1 + 4 + k) * 12] - ct[(1 + 2 - k) * 12]);
+            }
+            const int a = 16 * (ct[8 * 12] + ct[8]);
+            const int b = (34 * Hh + 32) >> 6, c = (34 * Vv + 32) >> 6;
+            v = clip8((a + b * (cx - 3) + c * (cy - 3) + 16) >> 5);
+          }
+          uint8_t* d = p ? dv : du;
+          d[cy * cp + cx] = (uint8_t)clip8(v + L.res_c[p * 64 + cy * 8 + cx]);
         }
-        if (bx == by) v = (hB && hA) ? (st + sl + 4) >> 3 : hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
-        else if (bx == 1) v = hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
-        else v = hA ? (sl + 2) >> 2 : hB ? (st + 2) >> 2 : 128;
-      } else if (mode == 1) {
-        v = ct[(1 + cy) * 12];
-      } else if (mode == 2) {
-        v = ct[1 + cx];
-      } else {
-        int Hh = 0, Vv = 0;
-        for (int k = 0; k < 4; ++k) {
-          Hh += (k + 1) * (ct[1 + 4 + k] - ct[1 + 2 - k]);
-          Vv += (k + 1) * (ct[(1 + 4 + k) * 12] - ct[(1 + 2 - k) * 12]);
-        }
-        const int a = 16 * (ct[8 * 12] + ct[8]);
-        const int b = (34 * Hh + 32) >> 6, c = (34 * Vv + 32) >> 6;
-        v = clip8((a + b * (cx - 3) + c * (cy - 3) + 16) >> 5);
+        row_publish(progress, mby, mbx + 1);
       }
-      uint8_t* d = p ? dv : du;
-      d[cy * cp + cx] = (uint8_t)clip8(v + res_c[p * 64 + cy * 8 + cx]);
     }
-    publish_progress(&progress[mby], (unsigned)(mbx + 1), tid);
+    // inter macroblocks at the end of the row need no work: the row is done
+    row_publish(progress, mby, pp.mb_width);
   }
 }
 
 // ===========================================================================
-// k_deblock: grid = mb_height workgroups of 64 threads (one wave).
+// k_deblock: grid = 1 workgroup of 16 waves per picture.
 // ===========================================================================
 namespace {
 
-__device__ __forceinline__ void filter_sample(uint8_t* pix, int step, int bs, int alpha, int beta, int tc0, bool chroma) {
-  const int p0 = pix[-step], p1 = pix[-2 * step], q0 = pix[0], q1 = pix[step];
-  if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
+// One edge position.  v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (chroma uses p1..q1
+// only); filtered in place.  Returns false when nothing changed.
+__device__ __forceinline__ bool filter_line(int* v, int bs, int alpha, int beta, int tc0, bool chroma) {
+  const int p0 = v[3], p1 = v[2], q0 = v[4], q1 = v[5];
+  if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return false;
   if (bs < 4) {
     int tc;
     if (chroma) {
       tc = tc0 + 1;
     } else {
-      const int p2 = pix[-3 * step], q2 = pix[2 * step];
+      const int p2 = v[1], q2 = v[6];
       const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
       tc = tc0 + (ap < beta) + (aq < beta);
-      if (ap < beta) pix[-2 * step] = (uint8_t)(p1 + iclip(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1));
-      if (aq < beta) pix[step] = (uint8_t)(q1 + iclip(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1));
+      if (ap < beta) v[2] = p1 + iclip(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1);
+      if (aq < beta) v[5] = q1 + iclip(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1);
     }
     const int delta = iclip(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-    pix[-step] = (uint8_t)clip8(p0 + delta);
-    pix[0] = (uint8_t)clip8(q0 - delta);
-    return;
+    v[3] = clip8(p0 + delta);
+    v[4] = clip8(q0 - delta);
+    return true;
   }
   if (chroma) {
-    pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
-    pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
-    return;
+    v[3] = (2 * p1 + p0 + q1 + 2) >> 2;
+    v[4] = (2 * q1 + q0 + p1 + 2) >> 2;
+    return true;
   }
-  const int p2 = pix[-3 * step], q2 = pix[2 * step];
+  const int p2 = v[1], q2 = v[6], p3 = v[0], q3 = v[7];
   const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
   const bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
   if (ap < beta && strong) {
-    const int p3 = pix[-4 * step];
-    pix[-step] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
-    pix[-2 * step] = (uint8_t)((p2 + p1 + p0 + q0 + 2) >> 2);
-    pix[-3 * step] = (uint8_t)((2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+    v[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
+    v[2] = (p2 + p1 + p0 + q0 + 2) >> 2;
+    v[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
   } else {
-    pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
+    v[3] = (2 * p1 + p0 + q1 + 2) >> 2;
   }
   if (aq < beta && strong) {
-    const int q3 = pix[3 * step];
-    pix[0] = (uint8_t)((p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
-    pix[step] = (uint8_t)((p0 + q0 + q1 + q2 + 2) >> 2);
-    pix[2 * step] = (uint8_t)((2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3);
+    v[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
+    v[5] = (p0 + q0 + q1 + q2 + 2) >> 2;
+    v[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
   } else {
-    pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
+    v[4] = (2 * q1 + q0 + p1 + 2) >> 2;
+  }
+  return true;
+}
+
+// Filters the edge whose first q sample is at `q` in an LDS tile; `step` is
+// the distance between samples across the edge (1: vertical edge, row stride:
+// horizontal edge).  Vertical edges move the 8 samples as two dwords.
+__device__ __forceinline__ void filter_edge(uint8_t* q, int step, int bs, int alpha, int beta, int tc0, bool chroma) {
+  int v[8];
+  if (step == 1) {
+    const uint32_t lo = *reinterpret_cast<const uint32_t*>(q - 4), hi = *reinterpret_cast<const uint32_t*>(q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      v[i] = (lo >> (8 * i)) & 0xff;
+      v[4 + i] = (hi >> (8 * i)) & 0xff;
+    }
+    if (!filter_line(v, bs, alpha, beta, tc0, chroma)) return;
+    *reinterpret_cast<uint32_t*>(q - 4) = v[0] | (v[1] << 8) | (v[2] << 16) | ((uint32_t)v[3] << 24);
+    *reinterpret_cast<uint32_t*>(q) = v[4] | (v[5] << 8) | (v[6] << 16) | ((uint32_t)v[7] << 24);
+  } else {
+    const int lo = chroma ? 2 : 0, hi = chroma ? 6 : 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (i >= lo && i < hi) ? q[(i - 4) * step] : 0;
+    if (!filter_line(v, bs, alpha, beta, tc0, chroma)) return;
+#pragma unroll
+    for (int i = 1; i < 7; ++i)
+      if (i >= lo && i < hi) q[(i - 4) * step] = (uint8_t)v[i];
   }
 }
 
@@ -841,193 +1015,287 @@ __device__ int boundary_strength(const MbInfo& pm, const MbInfo& qm, const MbMot
 #undef FAR
 }
 
+// Per-macroblock deblocking record, produced by k_bs (fully parallel) so the
+// serial row pipeline touches no MbInfo / motion data: 32 boundary strengths
+// (16 vertical-edge segments, then 16 horizontal; 0 = edge not filtered) and
+// the table indices indexA / indexB per plane for the left edge, the top edge
+// and the internal edges.
+struct DbInfo {
+  uint8_t bs[32];
+  uint8_t alpha[3][3];   // [plane][0 left, 1 top, 2 internal]
+  uint8_t beta[3][3];
+  uint8_t tc0[3][3][3];  // [plane][class][bS - 1]
+  uint8_t t8x8;
+  uint8_t any;           // some bs != 0
+  uint8_t pad[17];
+};
+static_assert(sizeof(DbInfo) == 96, "DbInfo must stay 96 bytes");
+
+// luma tile: picture rows -4..15, cols -4..15 -> 20 x 20 bytes, stride 24;
+// chroma tiles: rows -2..7, cols -4..7 -> 10 x 12 bytes, stride 12.  Column 4
+// of either tile is the macroblock's first column, so every row is a whole
+// number of aligned dwords in LDS and in the picture.
+constexpr int LS = 24, CS = 12;
+struct DeblockWaveLds {
+  uint8_t lt[20 * LS];
+  uint8_t ct[2][10 * CS];
+  DbInfo db;
+};
+
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_deblock(PictureParams pp, const MbInfo* __restrict__ mbs,
-                                                const MbMotion* __restrict__ motions,
-                                                const SliceParams* __restrict__ slices, unsigned* sync) {
-  const int tid = threadIdx.x;
-  __shared__ int s_row;
-  if (tid == 0) s_row = (int)atomicAdd(&sync[0], 1u);
-  __syncthreads();
-  const int mby = s_row;
-  if (mby >= pp.mb_height) return;
-  unsigned* progress = sync + 2;
-  unsigned* timeout_word = sync + 1;
-
-  // luma tile: rows -4..15, cols -4..15 -> 20 x 20 (stride 24); chroma tiles
-  // rows -2..7, cols -2..7 -> 10 x 10 (stride 12).  Between macroblocks the
-  // right-most columns slide to the left edge, so a row never re-reads what
-  // it just filtered.
-  constexpr int LS = 24, CS = 12;
-  __shared__ uint8_t lt[20 * LS];
-  __shared__ uint8_t ct[2][10 * CS];
-  __shared__ uint8_t bsv[16], bsh[16];
-  __shared__ MbMotion mo_cur, mo_left, mo_top;
-
-  const Surface cur = pp.surfaces[pp.cur_slot];
-  const int yp = pp.y_pitch, cp = pp.c_pitch;
-
-  for (int mbx = 0; mbx < pp.mb_width; ++mbx) {
-    const int mbi = mby * pp.mb_width + mbx;
-    const MbInfo mb = mbs[mbi];
-    const bool do_left = mb.flags & MBF_DB_LEFT, do_top = mb.flags & MBF_DB_TOP;
-    // This macroblock's top-edge filter rewrites the three bottom rows of the
-    // macroblock above; the macroblock to the right of that one must already
-    // have run its left-edge filter over them (it reads and rewrites their
-    // right-most columns).
-    if (mby > 0) {
-      const unsigned need = (unsigned)min(mbx + 2, pp.mb_width);
-      wait_progress(&progress[mby - 1], need, tid, timeout_word);
+// k_bs: 32 lanes per macroblock, 8 macroblocks per 256-thread workgroup.
+__global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.y];
+  if (!job.do_deblock) return;
+  const PictureParams& pp = job.pp;
+  const MbInfo* __restrict__ mbs = job.mbs;
+  const MbMotion* __restrict__ motions = job.motions;
+  const SliceParams* __restrict__ slices = job.slices;
+  DbInfo* __restrict__ out = static_cast<DbInfo*>(job.db);
+  const int nmb = pp.mb_width * pp.mb_height;
+  const int mbi = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int t = threadIdx.x & 31;
+  if (mbi >= nmb) return;
+  const MbInfo mb = mbs[mbi];
+  const bool do_left = mb.flags & MBF_DB_LEFT, do_top = mb.flags & MBF_DB_TOP;
+  const int dir = t >> 4, e = (t >> 2) & 3, k = t & 3;
+  int bs = 0;
+  const bool edge_on = e == 0 ? (dir == 0 ? do_left : do_top) : (mb.deblock_internal != 0);
+  const bool skip_luma_only = (mb.flags & MBF_T8X8) && (e & 1);  // odd edges: neither luma nor chroma
+  if (edge_on && !skip_luma_only) {
+    const int qblk = dir == 0 ? k * 4 + e : e * 4 + k;
+    if (e == 0) {
+      const int nbi = dir == 0 ? mbi - 1 : mbi - pp.mb_width;
+      const MbInfo nb = mbs[nbi];
+      const int pblk = dir == 0 ? k * 4 + 3 : 12 + k;
+      if ((nb.flags | mb.flags) & MBF_INTRA) bs = 4;
+      else bs = boundary_strength(nb, mb, &motions[nbi], &motions[mbi], pblk, qblk, true);
+    } else {
+      const int pblk = dir == 0 ? k * 4 + e - 1 : (e - 1) * 4 + k;
+      if (mb.flags & MBF_INTRA) bs = 3;
+      else bs = boundary_strength(mb, mb, &motions[mbi], &motions[mbi], pblk, qblk, false);
     }
-    uint8_t* gy = cur.y + (size_t)(mby * 16) * yp + mbx * 16;
-    uint8_t* gu = cur.u + (size_t)(mby * 8) * cp + mbx * 8;
-    uint8_t* gv = cur.v + (size_t)(mby * 8) * cp + mbx * 8;
-
-    // ---- load: interior + top rows from global; left columns slide in LDS
-    for (int i = tid; i < 20 * 16; i += 64) {
-      const int r = i >> 4, c = i & 15;  // tile row r <-> picture row r-4
-      if (r >= 4 || mby > 0) lt[r * LS + 4 + c] = gy[(r - 4) * yp + c];
-    }
-    if (mbx == 0) {
-      // no left neighbour: nothing to slide in; keep the columns defined
-      for (int i = tid; i < 20 * 4; i += 64) lt[(i >> 2) * LS + (i & 3)] = 0;
-    }
-    for (int i = tid; i < 2 * 10 * 8; i += 64) {
-      const int p = i / 80, r = (i % 80) >> 3, c = i & 7;
-      const uint8_t* g = p ? gv : gu;
-      if (r >= 2 || mby > 0) ct[p][r * CS + 2 + c] = g[(r - 2) * cp + c];
-    }
-    if (mbx == 0)
-      for (int i = tid; i < 2 * 10 * 2; i += 64) ct[i / 20][((i % 20) >> 1) * CS + (i & 1)] = 0;
-    // motion records for the bS derivation
-    const bool need_mo = !(mb.flags & MBF_INTRA);
-    if (need_mo && tid < 36) reinterpret_cast<uint32_t*>(&mo_cur)[tid] = reinterpret_cast<const uint32_t*>(&motions[mbi])[tid];
-    if (need_mo && do_left && tid < 36) reinterpret_cast<uint32_t*>(&mo_left)[tid] = reinterpret_cast<const uint32_t*>(&motions[mbi - 1])[tid];
-    if (need_mo && do_top && tid < 36) reinterpret_cast<uint32_t*>(&mo_top)[tid] = reinterpret_cast<const uint32_t*>(&motions[mbi - pp.mb_width])[tid];
-    __syncthreads();
-
-    // ---- boundary strengths: 16 vertical-edge + 16 horizontal-edge segments
-    if (tid < 32) {
-      const int dir = tid >> 4, e = (tid >> 2) & 3, k = tid & 3;
-      int bs = 0;
-      const bool edge_on = e == 0 ? (dir == 0 ? do_left : do_top) : (mb.deblock_internal != 0);
-      if (edge_on) {
-        const int qblk = dir == 0 ? k * 4 + e : e * 4 + k;
-        if (e == 0) {
-          const MbInfo nb = mbs[dir == 0 ? mbi - 1 : mbi - pp.mb_width];
-          const int pblk = dir == 0 ? k * 4 + 3 : 12 + k;
-          bs = boundary_strength(nb, mb, dir == 0 ? &mo_left : &mo_top, &mo_cur, pblk, qblk, true);
-        } else {
-          const int pblk = dir == 0 ? k * 4 + e - 1 : (e - 1) * 4 + k;
-          bs = boundary_strength(mb, mb, &mo_cur, &mo_cur, pblk, qblk, false);
-        }
-      }
-      (dir == 0 ? bsv : bsh)[e * 4 + k] = (uint8_t)bs;
-    }
-    __syncthreads();
-
+  }
+  DbInfo* o = &out[mbi];
+  o->bs[t] = (uint8_t)bs;
+  const unsigned long long nz = __ballot(bs != 0);
+  if (t < 9) {
+    const int plane = t / 3, cls = t % 3;  // cls: 0 left, 1 top, 2 internal
     const SliceParams& sp = slices[mb.slice];
-    const int a_off = sp.alpha_offset, b_off = sp.beta_offset;
-    const MbInfo left = do_left ? mbs[mbi - 1] : mb;
-    const MbInfo top = do_top ? mbs[mbi - pp.mb_width] : mb;
-
-    // ---- vertical edges (filter across columns), then horizontal edges
-    for (int dir = 0; dir < 2; ++dir) {
-      const uint8_t* bsa = dir == 0 ? bsv : bsh;
-      const MbInfo& nb = dir == 0 ? left : top;
-      for (int e = 0; e < 4; ++e) {
-        const bool luma_edge = !((mb.flags & MBF_T8X8) && (e & 1));
-        if (tid < 16) {
-          if (luma_edge) {
-            const int bs = bsa[e * 4 + (tid >> 2)];
-            if (bs) {
-              const int qpav = ((e == 0 ? nb.qp : mb.qp) + mb.qp + 1) >> 1;
-              const int ia = iclip(0, 51, qpav + a_off), ib = iclip(0, 51, qpav + b_off);
-              uint8_t* pix = dir == 0 ? lt + (4 + tid) * LS + 4 + e * 4 : lt + (4 + e * 4) * LS + 4 + tid;
-              filter_sample(pix, dir == 0 ? 1 : LS, bs, c_alpha[ia], c_beta[ib], bs < 4 ? c_tc0[ia][bs - 1] : 0, false);
-            }
-          }
-        } else if (tid < 32 && !(e & 1)) {
-          const int p = (tid - 16) >> 3, i = (tid - 16) & 7;
-          const int bs = bsa[e * 4 + (i >> 1)];
-          if (bs) {
-            const int qpav = ((e == 0 ? nb.qpc[p] : mb.qpc[p]) + mb.qpc[p] + 1) >> 1;
-            const int ia = iclip(0, 51, qpav + a_off), ib = iclip(0, 51, qpav + b_off);
-            uint8_t* pix = dir == 0 ? ct[p] + (2 + i) * CS + 2 + e * 2 : ct[p] + (2 + e * 2) * CS + 2 + i;
-            filter_sample(pix, dir == 0 ? 1 : CS, bs, c_alpha[ia], c_beta[ib], bs < 4 ? c_tc0[ia][bs - 1] : 0, true);
-          }
-        }
-        __syncthreads();
-      }
+    int qn;
+    if (cls == 2 || (cls == 0 && !do_left) || (cls == 1 && !do_top)) {
+      qn = plane == 0 ? mb.qp : mb.qpc[plane - 1];
+    } else {
+      const MbInfo nb = mbs[cls == 0 ? mbi - 1 : mbi - pp.mb_width];
+      qn = plane == 0 ? nb.qp : nb.qpc[plane - 1];
     }
-
-    // ---- store everything this macroblock may have changed: rows -3..15,
-    // cols -3..15 (luma); rows -1..7, cols -1..7 (chroma)
-    for (int i = tid; i < 19 * 19; i += 64) {
-      const int r = i / 19 + 1, c = i % 19 + 1;  // tile coordinates
-      if ((r >= 4 || mby > 0) && (c >= 4 || mbx > 0)) gy[(r - 4) * yp + (c - 4)] = lt[r * LS + c];
-    }
-    for (int i = tid; i < 2 * 81; i += 64) {
-      const int p = i / 81, r = (i % 81) / 9 + 1, c = (i % 81) % 9 + 1;
-      uint8_t* g = p ? gv : gu;
-      if ((r >= 2 || mby > 0) && (c >= 2 || mbx > 0)) g[(r - 2) * cp + (c - 2)] = ct[p][r * CS + c];
-    }
-    __syncthreads();
-    // ---- slide the last four (two) columns to the left edge for the next MB
-    if (mbx + 1 < pp.mb_width) {
-      uint8_t keep_l = 0, keep_c = 0;
-      const int r = tid >> 2, c = tid & 3;
-      uint8_t k2 = 0;
-      if (tid < 64) keep_l = lt[r * LS + 16 + c];                       // rows 0..15
-      if (tid < 16) k2 = lt[(16 + (tid >> 2)) * LS + 16 + (tid & 3)];    // rows 16..19
-      if (tid < 40) keep_c = ct[tid / 20][((tid % 20) >> 1) * CS + 8 + (tid & 1)];
-      __syncthreads();
-      if (tid < 64) lt[r * LS + c] = keep_l;
-      if (tid < 16) lt[(16 + (tid >> 2)) * LS + (tid & 3)] = k2;
-      if (tid < 40) ct[tid / 20][((tid % 20) >> 1) * CS + (tid & 1)] = keep_c;
-    }
-    publish_progress(&progress[mby], (unsigned)(mbx + 1), tid);
+    const int qc = plane == 0 ? mb.qp : mb.qpc[plane - 1];
+    const int qpav = (qn + qc + 1) >> 1;
+    const int ia = iclip(0, 51, qpav + sp.alpha_offset), ib = iclip(0, 51, qpav + sp.beta_offset);
+    o->alpha[plane][cls] = c_alpha[ia];
+    o->beta[plane][cls] = c_beta[ib];
+    for (int b = 0; b < 3; ++b) o->tc0[plane][cls][b] = c_tc0[ia][b];
+  }
+  if (t == 0) {
+    o->t8x8 = (mb.flags & MBF_T8X8) ? 1 : 0;
+    // lanes of this macroblock are bits [32*(mb&1) ...) of the wave's ballot
+    const unsigned mine = (unsigned)(nz >> (32 * ((threadIdx.x >> 5) & 1)));
+    o->any = mine != 0;
   }
 }
 
 // ===========================================================================
-// launch helpers (host)
+// k_deblock: grid = 1 workgroup of 16 waves per picture; every wave walks its
+// rows one macroblock at a time.  Per macroblock the only dependent memory
+// traffic is the four rows above (after the row above has passed); the
+// macroblock's own samples and its DbInfo are prefetched one iteration ahead
+// and its stores are drained one iteration late.
 // ===========================================================================
-hipError_t launch_inter(const PictureParams& pp, const MbInfo* mbs, const MbMotion* motions, const int16_t* coefs,
-                        const SliceParams* slices, hipStream_t stream) {
-  const int nmb = pp.mb_width * pp.mb_height;
-  prof::Span span;
+__global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.x];
+  if (!job.do_deblock) return;
+  const PictureParams& pp = job.pp;
+  const DbInfo* __restrict__ dbs = static_cast<const DbInfo*>(job.db);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ int s_progress[kMaxRows + 1];
+  __shared__ DeblockWaveLds s_lds[kRowWaves];
+  volatile int* progress = s_progress;
+  for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
+  __syncthreads();
+  DeblockWaveLds& L = s_lds[wave];
+  uint8_t* lt = L.lt;
+  const Surface cur = pp.surfaces[pp.cur_slot];
+  const int yp = pp.y_pitch, cp = pp.c_pitch;
+  const int W = pp.mb_width;
+
+  // lane roles for the dword tile traffic
+  const int lr = lane >> 2, lc4 = lane & 3;                      // luma interior: row, dword
+  const int cpn = (lane >> 4) & 1, ccr = (lane >> 1) & 7, ccc = lane & 1;  // chroma interior (lanes 0..31)
+
+  for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
+    uint8_t* rowy = cur.y + (size_t)(mby * 16) * yp;
+    uint8_t* rowu = cur.u + (size_t)(mby * 8) * cp;
+    uint8_t* rowv = cur.v + (size_t)(mby * 8) * cp;
+    const DbInfo* rowdb = dbs + mby * W;
+    // prefetch macroblock 0
+    uint32_t n_luma = *reinterpret_cast<const uint32_t*>(rowy + lr * yp + lc4 * 4);
+    uint32_t n_chroma = 0, n_db = 0;
+    if (lane < 32) n_chroma = *reinterpret_cast<const uint32_t*>((cpn ? rowv : rowu) + ccr * cp + ccc * 4);
+    if (lane < 24) n_db = reinterpret_cast<const uint32_t*>(rowdb)[lane];
+
+    for (int mbx = 0; mbx < W; ++mbx) {
+      uint8_t* gy = rowy + mbx * 16;
+      uint8_t* gu = rowu + mbx * 8;
+      uint8_t* gv = rowv + mbx * 8;
+      // ---- land the prefetched interior + record, start the next prefetch
+      *reinterpret_cast<uint32_t*>(&L.lt[(4 + lr) * LS + 4 + lc4 * 4]) = n_luma;
+      if (lane < 32) *reinterpret_cast<uint32_t*>(&L.ct[cpn][(2 + ccr) * CS + 4 + ccc * 4]) = n_chroma;
+      if (lane < 24) reinterpret_cast<uint32_t*>(&L.db)[lane] = n_db;
+      if (mbx + 1 < W) {
+        n_luma = *reinterpret_cast<const uint32_t*>(gy + 16 + lr * yp + lc4 * 4);
+        if (lane < 32) n_chroma = *reinterpret_cast<const uint32_t*>((cpn ? gv : gu) + 8 + ccr * cp + ccc * 4);
+        if (lane < 24) n_db = reinterpret_cast<const uint32_t*>(rowdb + mbx + 1)[lane];
+      }
+      // ---- rows above: wait for the row above to be two macroblocks ahead
+      uint32_t top_word = 0;
+      if (mby > 0) {
+        row_wait(progress, mby, min(mbx + 2, W));
+        if (lane < 16) top_word = *reinterpret_cast<const uint32_t*>(gy + ((lane >> 2) - 4) * yp + (lane & 3) * 4);
+        else if (lane < 24) {
+          const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
+          top_word = *reinterpret_cast<const uint32_t*>((p ? gv : gu) + (cr - 2) * cp + cc * 4);
+        }
+      }
+      wave_sync();
+      const bool any = L.db.any != 0;
+      if (any) {
+        const int t8 = L.db.t8x8;
+        // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each
+        for (int e = 0; e < 4; ++e) {
+          if (lane < 16) {
+            const int bs = L.db.bs[e * 4 + (lane >> 2)];
+            if (bs && !(t8 && (e & 1))) {
+              const int cls = e == 0 ? 0 : 2;
+              filter_edge(lt + (4 + lane) * LS + 4 + e * 4, 1, bs, L.db.alpha[0][cls], L.db.beta[0][cls],
+                          bs < 4 ? L.db.tc0[0][cls][bs - 1] : 0, false);
+            }
+          } else if (lane < 32 && !(e & 1)) {
+            const int p = (lane - 16) >> 3, i = (lane - 16) & 7;
+            const int bs = L.db.bs[e * 4 + (i >> 1)];
+            if (bs) {
+              const int cls = e == 0 ? 0 : 2;
+              // chroma vertical edge: p1 p0 | q0 q1 -> bytes q-2 .. q+1
+              uint8_t* q = L.ct[p] + (2 + i) * CS + 4 + e * 2;
+              int v[8] = {0, 0, q[-2], q[-1], q[0], q[1], 0, 0};
+              if (filter_line(v, bs, L.db.alpha[1 + p][cls], L.db.beta[1 + p][cls],
+                              bs < 4 ? L.db.tc0[1 + p][cls][bs - 1] : 0, true)) {
+                q[-1] = (uint8_t)v[3];
+                q[0] = (uint8_t)v[4];
+              }
+            }
+          }
+          wave_sync();
+        }
+      }
+      // ---- the rows above arrive now (their latency hid behind the vertical edges)
+      if (mby > 0) {
+        if (lane < 16) *reinterpret_cast<uint32_t*>(&L.lt[(lane >> 2) * LS + 4 + (lane & 3) * 4]) = top_word;
+        else if (lane < 24) {
+          const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
+          *reinterpret_cast<uint32_t*>(&L.ct[p][cr * CS + 4 + cc * 4]) = top_word;
+        }
+        wave_sync();
+      }
+      if (any) {
+        const int t8 = L.db.t8x8;
+        // ---- horizontal edges: lanes 0..15 one luma column each, 16..31 chroma columns
+        for (int e = 0; e < 4; ++e) {
+          if (lane < 16) {
+            const int bs = L.db.bs[16 + e * 4 + (lane >> 2)];
+            if (bs && !(t8 && (e & 1))) {
+              const int cls = e == 0 ? 1 : 2;
+              filter_edge(lt + (4 + e * 4) * LS + 4 + lane, LS, bs, L.db.alpha[0][cls], L.db.beta[0][cls],
+                          bs < 4 ? L.db.tc0[0][cls][bs - 1] : 0, false);
+            }
+          } else if (lane < 32 && !(e & 1)) {
+            const int p = (lane - 16) >> 3, i = (lane - 16) & 7;
+            const int bs = L.db.bs[16 + e * 4 + (i >> 1)];
+            if (bs) {
+              const int cls = e == 0 ? 1 : 2;
+              filter_edge(L.ct[p] + (2 + e * 2) * CS + 4 + i, CS, bs, L.db.alpha[1 + p][cls], L.db.beta[1 + p][cls],
+                          bs < 4 ? L.db.tc0[1 + p][cls][bs - 1] : 0, true);
+            }
+          }
+          wave_sync();
+        }
+      }
+      // ---- the previous macroblock's stores have had a whole iteration to
+      // land: make sure, then tell the row below about it
+      if (mbx > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        progress[mby + 1] = mbx;  // macroblocks 0..mbx-1 are final in memory
+      }
+      // ---- store the tile: rows -4..15 x cols -4..15 luma (5 dwords a row),
+      // rows -2..7 x cols -4..7 chroma (3 dwords a row); parts outside the
+      // picture are skipped.  (With nothing filtered the samples are unchanged.)
+      if (any) {
+        for (int t = lane; t < 100; t += 64) {
+          const int r = t / 5, c4 = t % 5;
+          if ((r >= 4 || mby > 0) && (c4 >= 1 || mbx > 0))
+            *reinterpret_cast<uint32_t*>(gy + (r - 4) * yp + (c4 - 1) * 4) =
+                *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]);
+        }
+        if (lane < 60) {
+          const int p = lane / 30, t = lane % 30, r = t / 3, c4 = t % 3;
+          uint8_t* g = p ? gv : gu;
+          if ((r >= 2 || mby > 0) && (c4 >= 1 || mbx > 0))
+            *reinterpret_cast<uint32_t*>(g + (r - 2) * cp + (c4 - 1) * 4) =
+                *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]);
+        }
+      }
+      // ---- slide the last four columns to the left edge for the next macroblock
+      if (mbx + 1 < W) {
+        uint32_t keep = 0;
+        if (lane < 20) keep = *reinterpret_cast<const uint32_t*>(&L.lt[lane * LS + 16]);
+        else if (lane < 40) keep = *reinterpret_cast<const uint32_t*>(&L.ct[(lane - 20) / 10][((lane - 20) % 10) * CS + 8]);
+        wave_sync();
+        if (lane < 20) *reinterpret_cast<uint32_t*>(&L.lt[lane * LS]) = keep;
+        else if (lane < 40) *reinterpret_cast<uint32_t*>(&L.ct[(lane - 20) / 10][((lane - 20) % 10) * CS]) = keep;
+      }
+    }
+    row_publish(progress, mby, W);
+  }
+}
+
+// ===========================================================================
+// launch helpers (host).  `jobs` is a device array of `njobs` descriptors;
+// `max_mbs` the largest macroblock count among them.
+// ===========================================================================
+hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
+                        bool any_deblock, const uint64_t bytes[3], hipStream_t stream) {
   const bool profiled = prof::enabled();
-  if (profiled) span = prof::begin(stream);
-  hipLaunchKernelGGL(k_inter, dim3(nmb), dim3(256), 0, stream, pp, mbs, motions, coefs, slices);
-  if (profiled) prof::end(span, stream, prof::K_INTER, (uint64_t)nmb * 384 * 2);
+  prof::Span span;
+  if (any_inter) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_inter, dim3(max_mbs, njobs), dim3(256), 0, stream, jobs);
+    if (profiled) prof::end(span, stream, prof::K_INTER, bytes[0]);
+  }
+  if (any_intra) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_intra, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
+    if (profiled) prof::end(span, stream, prof::K_INTRA, bytes[1]);
+  }
+  if (any_deblock) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_bs, dim3((max_mbs + 7) / 8, njobs), dim3(256), 0, stream, jobs);
+    hipLaunchKernelGGL(k_deblock, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
+    if (profiled) prof::end(span, stream, prof::K_DEBLOCK, bytes[2]);
+  }
   return hipGetLastError();
 }
 
-hipError_t launch_intra(const PictureParams& pp, const MbInfo* mbs, const int16_t* coefs, unsigned* sync,
-                        hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (2 + pp.mb_height), stream);
-  if (e != hipSuccess) return e;
-  prof::Span span;
-  const bool profiled = prof::enabled();
-  if (profiled) span = prof::begin(stream);
-  hipLaunchKernelGGL(k_intra, dim3(pp.mb_height), dim3(256), 0, stream, pp, mbs, coefs, sync);
-  if (profiled) prof::end(span, stream, prof::K_INTRA, (uint64_t)pp.mb_width * pp.mb_height * 384);
-  return hipGetLastError();
-}
-
-hipError_t launch_deblock(const PictureParams& pp, const MbInfo* mbs, const MbMotion* motions,
-                          const SliceParams* slices, unsigned* sync, hipStream_t stream) {
-  hipError_t e = hipMemsetAsync(sync, 0, sizeof(unsigned) * (2 + pp.mb_height), stream);
-  if (e != hipSuccess) return e;
-  prof::Span span;
-  const bool profiled = prof::enabled();
-  if (profiled) span = prof::begin(stream);
-  hipLaunchKernelGGL(k_deblock, dim3(pp.mb_height), dim3(64), 0, stream, pp, mbs, motions, slices, sync);
-  if (profiled) prof::end(span, stream, prof::K_DEBLOCK, (uint64_t)pp.mb_width * pp.mb_height * 384 * 2);
-  return hipGetLastError();
-}
+size_t deblock_scratch_bytes(int num_mbs) { return (size_t)num_mbs * sizeof(DbInfo); }
 
 }  // namespace amd
 }  // namespace hwang

@@ -23,6 +23,7 @@
 // plane, and three 8-byte stores per output row, so a wave covers 512
 // contiguous luma bytes and 1536 contiguous output bytes per row.
 #include "../../../include/hwang_amd.h"
+#include "frame_job.h"
 #include "prof.h"
 
 #include <hip/hip_runtime.h>
@@ -117,9 +118,98 @@ __global__ __launch_bounds__(256) void yuv420_to_rgb24_any(
   }
 }
 
+// Batched form: blockIdx.z selects the request; handles conversion and the
+// plain cropped-plane copy (I420 output) with one launch per batch.
+__global__ __launch_bounds__(256) void convert_batch(const hwang::amd::ConvertDesc* __restrict__ reqs) {
+  const hwang::amd::ConvertDesc& q = reqs[blockIdx.z];
+  const int cy = blockIdx.y;
+  if (cy * 2 >= q.height) return;
+  const int cw = (q.width + 1) / 2, ch = (q.height + 1) / 2;
+  if (q.yuv) {
+    // two luma rows + one row of each chroma plane per blockIdx.y
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < q.width; x += gridDim.x * blockDim.x) {
+      for (int r = 0; r < 2; ++r)
+        if (cy * 2 + r < q.height) q.dst[(size_t)(cy * 2 + r) * q.width + x] = q.y[(size_t)(cy * 2 + r) * q.y_pitch + x];
+      if (x < cw) {
+        q.dst[(size_t)q.width * q.height + (size_t)cy * cw + x] = q.u[(size_t)cy * q.c_pitch + x];
+        q.dst[(size_t)q.width * q.height + (size_t)cw * ch + (size_t)cy * cw + x] = q.v[(size_t)cy * q.c_pitch + x];
+      }
+    }
+    return;
+  }
+  const bool aligned = (q.width % 8 == 0) && (reinterpret_cast<uintptr_t>(q.y) % 8 == 0) &&
+                       (reinterpret_cast<uintptr_t>(q.u) % 4 == 0) && (reinterpret_cast<uintptr_t>(q.v) % 4 == 0) &&
+                       (reinterpret_cast<uintptr_t>(q.dst) % 8 == 0) && (q.y_pitch % 8 == 0) && (q.c_pitch % 4 == 0);
+  if (aligned) {
+    const int groups = q.width >> 3;
+    for (int gx = blockIdx.x * blockDim.x + threadIdx.x; gx < groups; gx += gridDim.x * blockDim.x) {
+      const uint32_t u4 = *reinterpret_cast<const uint32_t*>(q.u + (size_t)cy * q.c_pitch + gx * 4);
+      const uint32_t v4 = *reinterpret_cast<const uint32_t*>(q.v + (size_t)cy * q.c_pitch + gx * 4);
+      ChromaTerm ct[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ct[i] = chroma_terms((u4 >> (8 * i)) & 0xff, (v4 >> (8 * i)) & 0xff);
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        const int y = cy * 2 + r;
+        if (y >= q.height) break;
+        const uint2 yy = *reinterpret_cast<const uint2*>(q.y + (size_t)y * q.y_pitch + gx * 8);
+        uint8_t px[24];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t word = i < 4 ? yy.x : yy.y;
+          const int l = luma_term((word >> (8 * (i & 3))) & 0xff);
+          const ChromaTerm& c = ct[i >> 1];
+          px[3 * i + 0] = (uint8_t)sat8(l + c.r);
+          px[3 * i + 1] = (uint8_t)sat8(l + c.g);
+          px[3 * i + 2] = (uint8_t)sat8(l + c.b);
+        }
+        uint2* dst = reinterpret_cast<uint2*>(q.dst + (size_t)y * q.width * 3 + gx * 24);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          uint2 o;
+          o.x = px[8 * k] | (px[8 * k + 1] << 8) | (px[8 * k + 2] << 16) | ((uint32_t)px[8 * k + 3] << 24);
+          o.y = px[8 * k + 4] | (px[8 * k + 5] << 8) | (px[8 * k + 6] << 16) | ((uint32_t)px[8 * k + 7] << 24);
+          dst[k] = o;
+        }
+      }
+    }
+    return;
+  }
+  for (int cx = blockIdx.x * blockDim.x + threadIdx.x; cx * 2 < q.width; cx += gridDim.x * blockDim.x) {
+    const ChromaTerm c = chroma_terms(q.u[(size_t)cy * q.c_pitch + cx], q.v[(size_t)cy * q.c_pitch + cx]);
+    for (int r = 0; r < 2; ++r) {
+      const int y = cy * 2 + r;
+      if (y >= q.height) break;
+      for (int k = 0; k < 2; ++k) {
+        const int x = cx * 2 + k;
+        if (x >= q.width) break;
+        const int l = luma_term(q.y[(size_t)y * q.y_pitch + x]);
+        uint8_t* o = q.dst + ((size_t)y * q.width + x) * 3;
+        o[0] = (uint8_t)sat8(l + c.r);
+        o[1] = (uint8_t)sat8(l + c.g);
+        o[2] = (uint8_t)sat8(l + c.b);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 namespace hwang {
+
+hipError_t launch_convert_batch(const amd::ConvertDesc* reqs_dev, int n, int max_width, int max_height,
+                                uint64_t bytes, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  prof::Span span;
+  const bool profiled = prof::enabled();
+  if (profiled) span = prof::begin(stream);
+  const int groups = (max_width + 7) / 8;
+  const int bx = groups >= 256 ? 256 : ((groups + 63) / 64) * 64;
+  dim3 grid((groups + bx - 1) / bx, (max_height + 1) / 2, n);
+  hipLaunchKernelGGL(convert_batch, grid, dim3(bx), 0, stream, reqs_dev);
+  if (profiled) prof::end(span, stream, prof::K_RGB, bytes);
+  return hipGetLastError();
+}
 
 hipError_t launch_yuv420_to_rgb24(const uint8_t* y, const uint8_t* u,
                                   const uint8_t* v, int y_stride, int c_stride,

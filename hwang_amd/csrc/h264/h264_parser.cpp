@@ -287,7 +287,7 @@ struct Parser::Impl {
   PicBuffers bufs;
   size_t coef_used = 0;
   int num_slices = 0;
-  bool has_inter = false, has_intra = false;
+  bool has_inter = false, has_intra = false, any_deblock = false;
   int slice_type_mask = 0;
 
   int prev_poc_msb = 0, prev_poc_lsb = 0, prev_frame_num = 0, prev_frame_num_offset = 0;
@@ -859,6 +859,7 @@ struct Parser::Impl {
     fill_slice_params(&bufs.slices[num_slices]);
     ++num_slices;
     slice_type_mask |= sl.type == 0 ? 1 : (sl.type == 1 ? 2 : 4);
+    if (sl.disable_deblock != 1) any_deblock = true;
     return 0;
   }
 
@@ -951,7 +952,7 @@ struct Parser::Impl {
     coef_used = 0;
     num_slices = 0;
     slice_index = 0;
-    has_inter = has_intra = false;
+    has_inter = has_intra = any_deblock = false;
     slice_type_mask = 0;
     pic_in_progress = true;
     return 0;
@@ -1051,6 +1052,7 @@ struct Parser::Impl {
     done.coef_count = coef_used;
     done.has_inter = has_inter;
     done.has_intra = has_intra;
+    done.any_deblock = any_deblock;
     done.slice_type_mask = slice_type_mask;
     done.scaling4 = apps->scaling4;
     done.scaling8 = apps->scaling8;

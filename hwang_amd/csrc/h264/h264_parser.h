@@ -45,6 +45,7 @@ struct PicDone {
   size_t coef_count;     // int16 units used
   bool has_inter;        // motion[] must be uploaded
   bool has_intra;
+  bool any_deblock;      // some slice has the in-loop filter enabled
   int slice_type_mask;   // bit0 P, bit1 B, bit2 I
   const uint8_t (*scaling4)[16];
   const uint8_t (*scaling8)[64];

@@ -115,23 +115,47 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
   VideoIntervals plan = slice_into_video_intervals(index, rows, &ok);
   if (!ok) return Result(false, "retrieve: row out of range");
 
+  // Work items.  The planner merges byte-adjacent GOPs into one interval
+  // (one seek for the reference's serial loop); every GOP still starts at a
+  // sync sample, so for parallel decoding each GOP that holds a wanted row is
+  // its own item, fed only up to its last wanted frame.
   std::vector<WorkItem> items;
+  std::vector<std::vector<uint64_t>> item_rows;
+  item_rows.reserve(rows.size());
   size_t slot = 0;
   const auto& sizes = index.sample_sizes();
+  const auto& kfs = index.keyframe_indices();
   for (size_t i = 0; i < plan.sample_index_intervals.size(); ++i) {
-    if (plan.valid_frames[i].empty()) continue;
-    WorkItem it;
-    it.start = std::get<0>(plan.sample_index_intervals[i]);
-    it.end = std::get<1>(plan.sample_index_intervals[i]);
-    it.valid = &plan.valid_frames[i];
-    it.out_slot = slot;
-    slot += it.valid->size();
-    // Host entropy time tracks bytes; only samples up to the last wanted
-    // frame (plus reorder slack) will be fed.
-    uint64_t last = std::min<uint64_t>(it.end, it.valid->back() + 4);
-    for (uint64_t s = it.start; s < last; ++s) it.cost += sizes[s];
-    items.push_back(it);
+    const std::vector<uint64_t>& valid = plan.valid_frames[i];
+    if (valid.empty()) continue;
+    const uint64_t istart = std::get<0>(plan.sample_index_intervals[i]);
+    const uint64_t iend = std::get<1>(plan.sample_index_intervals[i]);
+    size_t k = std::upper_bound(kfs.begin(), kfs.end(), istart) - kfs.begin();  // first keyframe after istart
+    uint64_t gop_start = istart;
+    size_t v = 0;
+    while (v < valid.size()) {
+      const uint64_t gop_end = (k < kfs.size() && kfs[k] < iend) ? kfs[k] : iend;
+      size_t v2 = v;
+      while (v2 < valid.size() && valid[v2] < gop_end) ++v2;
+      if (v2 > v) {
+        item_rows.emplace_back(valid.begin() + v, valid.begin() + v2);
+        WorkItem it;
+        it.start = gop_start;
+        it.end = gop_end;
+        it.valid = nullptr;  // fixed up below (item_rows may still grow)
+        it.out_slot = slot;
+        slot += v2 - v;
+        const uint64_t last = std::min<uint64_t>(it.end, item_rows.back().back() + 4);
+        for (uint64_t s2 = it.start; s2 < last; ++s2) it.cost += sizes[s2];
+        items.push_back(it);
+      }
+      v = v2;
+      gop_start = gop_end;
+      ++k;
+      if (gop_end >= iend) break;
+    }
   }
+  for (size_t i = 0; i < items.size(); ++i) items[i].valid = &item_rows[i];
   stats_.intervals = static_cast<int64_t>(items.size());
   // Longest first, pulled from a shared cursor: greedy LPT balance.
   std::vector<size_t> order(items.size());

@@ -277,6 +277,7 @@ struct H264Oracle {
   MB mb;
 
   int64_t counters[10];
+  int pred_luma_only; /* corpus encoder: motion search evaluates luma only */
 };
 
 /* h264_headers.c */

@@ -493,7 +493,7 @@ static void inter_pred_region(H264Oracle* d, int bx, int by, int n4) {
   const int r0 = m->ref[0][b8], r1 = m->ref[1][b8];
   const Picture* p0 = r0 >= 0 ? sl->ref_list[0][r0] : NULL;
   const Picture* p1 = r1 >= 0 ? sl->ref_list[1][r1] : NULL;
-  for (int plane = 0; plane < 3; ++plane) {
+  for (int plane = 0; plane < (d->pred_luma_only ? 1 : 3); ++plane) {
     const int n = plane ? n4 * 2 : n4 * 4;
     const int pw = plane ? W / 2 : W, ph = plane ? H / 2 : H;
     const int x0 = (m->mbx * 16 + bx * 4) >> (plane ? 1 : 0), y0 = (m->mby * 16 + by * 4) >> (plane ? 1 : 0);

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Development aid (GPU box): throughput of Decoder.retrieve on a synthetic
+1080p clip for several lane counts, plus per-kernel event timings."""
+import ctypes as C
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import hwang_amd as hw  # noqa: E402
+from hwang_amd._capi import lib  # noqa: E402
+
+W, H = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080))
+FRAMES = int(os.environ.get("FRAMES", 600))
+REPEAT = int(os.environ.get("REPEAT", 6))
+GOP = int(os.environ.get("GOP", 60))
+path = "/tmp/probe_%dx%d_%d_%d_%d.mp4" % (W, H, FRAMES, REPEAT, GOP)
+if not os.path.exists(path):
+    t = time.time()
+    subprocess.check_call([os.path.join(ROOT, "corpus/_build/h264_encoder"), "--width", str(W), "--height", str(H),
+                           "--frames", str(FRAMES), "--gop", str(GOP), "--bframes", "2", "--threads", "64",
+                           "--repeat", str(REPEAT), "--out", path])
+    print("corpus: %.1fs, %.1f MB" % (time.time() - t, os.path.getsize(path) / 1e6))
+idx = hw.index_video(path)
+n = idx.frames()
+rng = np.random.default_rng(20240601)
+rows = sorted(rng.choice(n, max(1, round(0.01 * n)), replace=False).tolist())
+print("frames", n, "rows", len(rows))
+import torch
+out = torch.empty((len(rows), H, W, 3), dtype=torch.uint8, device="cuda")
+for lanes in [int(x) for x in os.environ.get("LANES", "1,4,16,32,64").split(",")]:
+    dec = hw.Decoder(path, video_index=idx, num_lanes=lanes)
+    best = None
+    for it in range(3):
+        t = time.time()
+        dec.retrieve_into(rows, out.data_ptr(), out.numel())
+        dt = time.time() - t
+        best = dt if best is None else min(best, dt)
+    st = dec.stats()
+    print("lanes %3d: %.3fs  returned %.1f fps  reconstructed %.0f pics/s  fed %d skipped %d entropy %.2fs(sum) upload %.1f MB" % (
+        lanes, best, len(rows) / best, st["pictures_reconstructed"] / best, st["samples_fed"], st["pictures_skipped"],
+        st["entropy_ns"] / 1e9, st["bytes_uploaded"] / 1e6))
+    del dec
+# per-kernel timings with one lane (events serialise nothing else)
+lib.hwang_prof_enable(1)
+lib.hwang_prof_reset()
+dec = hw.Decoder(path, video_index=idx, num_lanes=int(os.environ.get("PROF_LANES", "8")))
+dec.retrieve_into(rows, out.data_ptr(), out.numel())
+lib.hwang_prof_enable(0)
+for k in range(lib.hwang_prof_num_kernels()):
+    o = (C.c_double * 3)()
+    lib.hwang_prof_read(k, o)
+    if o[0]:
+        print("%-16s launches %6d  avg %8.1f us  alg %.2f GB/s" % (lib.hwang_prof_kernel_name(k).decode(), o[0], o[1] / o[0], o[2] / (o[1] * 1e-6) / 1e9))
