@@ -103,9 +103,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     HWANG_HIP_RETURN(hipSetDevice(device_));
     const auto t0 = std::chrono::steady_clock::now();
     sink_error_.clear();
+    const int64_t stall0 = counters_.stall_ns;
     const bool ok = parser_->decode(encoded_buffer, encoded_size);
     counters_.entropy_ns +=
-        std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+        std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() -
+        (counters_.stall_ns - stall0);
     ++counters_.samples_fed;
     if (!ok) return Result(false, "AMDVideoDecoder::feed: " + parser_->error());
     return Result();
@@ -182,14 +184,24 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       return false;
     }
     if (!alloc_surface(slot, error)) return false;
+    const auto stall_t0 = std::chrono::steady_clock::now();
+    struct StallTimer {
+      BackendCounters& c;
+      std::chrono::steady_clock::time_point t0;
+      ~StallTimer() {
+        c.stall_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      }
+    };
     // the motion buffer of this surface may still be the source of an upload
     if (surf_[slot].motion_seq) {
+      StallTimer st{counters_, stall_t0};
       if (!exec_->wait(lane_, surf_[slot].motion_seq, error)) return false;
       surf_[slot].motion_seq = 0;
     }
     // a staging job
     Job& j = jobs_[job_cursor_];
     if (j.seq) {
+      StallTimer st{counters_, std::chrono::steady_clock::now()};
       if (!exec_->wait(lane_, j.seq, error)) return false;
       j.seq = 0;
     }
@@ -244,6 +256,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.do_intra = d.has_intra;
     sub.desc.do_deblock = d.any_deblock;
     sub.num_mbs = static_cast<int>(nmb);
+    sub.heavy = (d.has_intra && !d.has_inter) ? 1 : 0;
     const uint64_t S = nmb * 384;  // coded I420 bytes
     sub.bytes_inter = d.has_inter ? S * (1 + ((d.slice_type_mask & 2) ? 2 : 1)) : 0;
     sub.bytes_intra = d.has_intra ? S : 0;
@@ -354,6 +367,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         *error = "AMDVideoDecoder: out of memory for staging buffers";
         return false;
       }
+      if (!gpu_visible(j.mb_host) || !gpu_visible(j.coef_host) || !gpu_visible(j.slice_host)) {
+        *error = "AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device";
+        return false;
+      }
       j.seq = 0;
     }
     job_cursor_ = 0;
@@ -369,7 +386,17 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       *error = "AMDVideoDecoder: out of memory for a decode surface";
       return false;
     }
+    if (!gpu_visible(s.motion_host)) {
+      *error = "AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device";
+      return false;
+    }
     return true;
+  }
+
+  // k_upload reads the staging buffers through their host addresses.
+  static bool gpu_visible(void* host) {
+    void* dev = nullptr;
+    return hipHostGetDevicePointer(&dev, host, 0) == hipSuccess && dev == host;
   }
 
   void free_buffers() {

@@ -115,6 +115,15 @@ struct PictureParams {
 // One picture's worth of work as the batched kernels see it.  The executor
 // uploads an array of these per batch; workgroup -> job is blockIdx.y (k_inter)
 // or blockIdx.x (row pipelines, k_bs uses blockIdx.y).
+// One host -> HBM transfer of k_upload: `src` is pinned host memory mapped
+// into the GPU's address space, read over PCIe by the kernel itself.
+struct UploadDesc {
+  void* dst;
+  const void* src;
+  uint64_t bytes;
+};
+constexpr int kJobUploads = 4;
+
 struct JobDesc {
   PictureParams pp;
   const MbInfo* mbs;
@@ -123,7 +132,8 @@ struct JobDesc {
   const SliceParams* slices;
   void* db;            // k_bs -> k_deblock records
   int32_t do_inter, do_intra, do_deblock;
-  int32_t pad;
+  int32_t num_uploads;
+  UploadDesc uploads[kJobUploads];
 };
 
 // One colour-conversion / plane-copy request.

@@ -13,6 +13,7 @@ hipError_t launch_convert_batch(const amd::ConvertDesc* reqs_dev, int n, int max
 
 namespace amd {
 
+hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream);
 hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
                         bool any_deblock, const uint64_t bytes[3], hipStream_t stream);
 
@@ -50,16 +51,21 @@ bool GpuExecutor::start(std::string* error) {
     return false;
   };
   if (hipSetDevice(device_) != hipSuccess) return fail("cannot select the device");
-  if (hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking) != hipSuccess) return fail("cannot create a stream");
-  for (int i = 0; i < kInflight; ++i) {
-    if (hipHostMalloc(reinterpret_cast<void**>(&job_table_host_[i]), sizeof(JobDesc) * kMaxJobs, hipHostMallocDefault) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&job_table_dev_[i]), sizeof(JobDesc) * kMaxJobs) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&conv_table_host_[i]), sizeof(ConvertDesc) * kMaxJobs, hipHostMallocDefault) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&conv_table_dev_[i]), sizeof(ConvertDesc) * kMaxJobs) != hipSuccess ||
-        hipEventCreateWithFlags(&batches_[i].done, hipEventDisableTiming) != hipSuccess)
-      return fail("out of memory for job tables");
+  for (Engine& en : engines_) {
+    if (hipStreamCreateWithFlags(&en.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&en.copy_stream, hipStreamNonBlocking) != hipSuccess)
+      return fail("cannot create a stream");
+    for (int i = 0; i < kInflight; ++i) {
+      if (hipHostMalloc(reinterpret_cast<void**>(&en.job_table_host[i]), sizeof(JobDesc) * kMaxJobs, hipHostMallocDefault) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&en.job_table_dev[i]), sizeof(JobDesc) * kMaxJobs) != hipSuccess ||
+          hipHostMalloc(reinterpret_cast<void**>(&en.conv_table_host[i]), sizeof(ConvertDesc) * kMaxJobs, hipHostMallocDefault) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&en.conv_table_dev[i]), sizeof(ConvertDesc) * kMaxJobs) != hipSuccess ||
+          hipEventCreateWithFlags(&en.batches[i].done, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&en.copied[i], hipEventDisableTiming) != hipSuccess)
+        return fail("out of memory for job tables");
+    }
   }
-  thread_ = std::thread(&GpuExecutor::run, this);
+  for (int e = 0; e < kEngines; ++e) engines_[e].thread = std::thread(&GpuExecutor::run, this, e);
   return true;
 }
 
@@ -70,7 +76,8 @@ void GpuExecutor::stop() {
     stop_ = true;
   }
   cv_work_.notify_all();
-  if (thread_.joinable()) thread_.join();
+  for (Engine& en : engines_)
+    if (en.thread.joinable()) en.thread.join();
 }
 
 int GpuExecutor::register_lane() {
@@ -102,7 +109,7 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
   }
-  cv_work_.notify_one();
+  cv_work_.notify_all();
   return seq;
 }
 
@@ -116,7 +123,7 @@ uint64_t GpuExecutor::submit_convert(int lane, const ConvSubmit& job) {
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
   }
-  cv_work_.notify_one();
+  cv_work_.notify_all();
   return seq;
 }
 
@@ -139,8 +146,9 @@ GpuExecutor::Stats GpuExecutor::stats() {
   return stats_;
 }
 
-void GpuExecutor::run() {
+void GpuExecutor::run(int engine) {
   (void)hipSetDevice(device_);
+  Engine& en = engines_[engine];
   uint64_t batch_index = 0;
   auto retire = [&](Batch& b) {
     if (!b.in_flight) return;
@@ -151,6 +159,7 @@ void GpuExecutor::run() {
     b.lane_counts.clear();
     b.in_flight = false;
     cv_done_.notify_all();
+    cv_work_.notify_all();  // the other engine may now take over some of these lanes
   };
 
   std::vector<PicSubmit> pics;
@@ -158,19 +167,19 @@ void GpuExecutor::run() {
   const bool debug = getenv("HWANG_EXEC_DEBUG") != nullptr;
   auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   double t_retire = 0, t_idle = 0, t_launch = 0;
-  uint64_t hist[9] = {0};
+  uint64_t hist[9] = {0}, n_batches = 0, n_pics = 0, n_convs = 0;
   for (;;) {
     double t0 = now();
     const int slot = static_cast<int>(batch_index % kInflight);
-    Batch& batch = batches_[slot];
+    Batch& batch = en.batches[slot];
     retire(batch);  // the slot's previous occupant (kInflight batches ago)
     // Form the next batch late, not eagerly: while two batches are already
     // queued on the GPU, every lane keeps parsing, so by the time the older
     // one finishes most lanes have their next picture ready and the batch is
     // wide.  (Launching whatever is pending right away produced batches of
     // ~5 pictures that each held the GPU for a full pipeline latency.)
-    if (batches_[(slot + kInflight - 2) % kInflight].in_flight && batches_[(slot + kInflight - 1) % kInflight].in_flight)
-      retire(batches_[(slot + kInflight - 2) % kInflight]);
+    if (en.batches[(slot + kInflight - 2) % kInflight].in_flight && en.batches[(slot + kInflight - 1) % kInflight].in_flight)
+      retire(en.batches[(slot + kInflight - 2) % kInflight]);
     t_retire += now() - t0;
     t0 = now();
 
@@ -180,16 +189,16 @@ void GpuExecutor::run() {
       std::unique_lock<std::mutex> lk(mu_);
       auto have_work = [&] {
         for (const Lane& l : lanes_)
-          if (!l.fifo.empty()) return true;
+          if (eligible(l, engine)) return true;
         return false;
       };
       while (!stop_ && !have_work()) {
         // nothing to launch: finish what is in flight so waiters wake up
         bool any = false;
-        for (int i = 0; i < kInflight; ++i) any |= batches_[i].in_flight;
+        for (int i = 0; i < kInflight; ++i) any |= en.batches[i].in_flight;
         if (any) {
           lk.unlock();
-          for (int i = 1; i <= kInflight; ++i) retire(batches_[(slot + i) % kInflight]);
+          for (int i = 1; i <= kInflight; ++i) retire(en.batches[(slot + i) % kInflight]);
           lk.lock();
           continue;
         }
@@ -202,7 +211,7 @@ void GpuExecutor::run() {
         Lane& l = lanes_[li];
         int taken = 0;
         bool took_picture = false;
-        while (!l.fifo.empty()) {
+        while (eligible(l, engine)) {
           Item& it = l.fifo.front();
           if (it.is_picture) {
             if (took_picture || taken > 0 || pics.size() >= kMaxJobs) break;
@@ -213,6 +222,8 @@ void GpuExecutor::run() {
             convs.push_back(it.conv);
           }
           l.fifo.pop_front();
+          ++l.launched;
+          l.last_engine = engine;
           ++taken;
         }
         if (taken) batch.lane_counts.emplace_back(static_cast<int>(li), taken);
@@ -221,6 +232,9 @@ void GpuExecutor::run() {
       stats_.pictures += pics.size();
       stats_.conversions += convs.size();
     }
+    ++n_batches;
+    n_pics += pics.size();
+    n_convs += convs.size();
 
     t_idle += now() - t0;
     t0 = now();
@@ -236,9 +250,14 @@ void GpuExecutor::run() {
       uint64_t bytes[3] = {0, 0, 0};
       for (size_t i = 0; i < pics.size() && e == hipSuccess; ++i) {
         const PicSubmit& p = pics[i];
-        for (int c = 0; c < p.ncopies && e == hipSuccess; ++c)
-          e = hipMemcpyAsync(p.copies[c].dst, p.copies[c].src, p.copies[c].bytes, hipMemcpyHostToDevice, stream_);
-        job_table_host_[slot][i] = p.desc;
+        JobDesc& jd = en.job_table_host[slot][i];
+        jd = p.desc;
+        jd.num_uploads = p.ncopies;
+        for (int c = 0; c < p.ncopies; ++c) {
+          jd.uploads[c].dst = p.copies[c].dst;
+          jd.uploads[c].src = p.copies[c].src;
+          jd.uploads[c].bytes = p.copies[c].bytes;
+        }
         max_mbs = p.num_mbs > max_mbs ? p.num_mbs : max_mbs;
         any_inter |= p.desc.do_inter != 0;
         any_intra |= p.desc.do_intra != 0;
@@ -248,36 +267,40 @@ void GpuExecutor::run() {
         bytes[2] += p.bytes_deblock;
       }
       if (e == hipSuccess)
-        e = hipMemcpyAsync(job_table_dev_[slot], job_table_host_[slot], sizeof(JobDesc) * pics.size(),
-                           hipMemcpyHostToDevice, stream_);
+        e = hipMemcpyAsync(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(),
+                           hipMemcpyHostToDevice, en.copy_stream);
+      if (e == hipSuccess) e = launch_upload(en.job_table_dev[slot], static_cast<int>(pics.size()), en.copy_stream);
+      if (e == hipSuccess) e = hipEventRecord(en.copied[slot], en.copy_stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(en.stream, en.copied[slot], 0);
       if (e == hipSuccess)
-        e = launch_batch(job_table_dev_[slot], static_cast<int>(pics.size()), max_mbs, any_inter, any_intra,
-                         any_deblock, bytes, stream_);
+        e = launch_batch(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, any_inter, any_intra,
+                         any_deblock, bytes, en.stream);
     }
     if (!convs.empty() && e == hipSuccess) {
       int mw = 0, mh = 0;
       uint64_t bytes = 0;
       for (size_t i = 0; i < convs.size(); ++i) {
-        conv_table_host_[slot][i] = convs[i].desc;
+        en.conv_table_host[slot][i] = convs[i].desc;
         mw = convs[i].desc.width > mw ? convs[i].desc.width : mw;
         mh = convs[i].desc.height > mh ? convs[i].desc.height : mh;
         bytes += convs[i].bytes;
       }
-      e = hipMemcpyAsync(conv_table_dev_[slot], conv_table_host_[slot], sizeof(ConvertDesc) * convs.size(),
-                         hipMemcpyHostToDevice, stream_);
+      e = hipMemcpyAsync(en.conv_table_dev[slot], en.conv_table_host[slot], sizeof(ConvertDesc) * convs.size(),
+                         hipMemcpyHostToDevice, en.stream);
       if (e == hipSuccess)
-        e = launch_convert_batch(conv_table_dev_[slot], static_cast<int>(convs.size()), mw, mh, bytes, stream_);
+        e = launch_convert_batch(en.conv_table_dev[slot], static_cast<int>(convs.size()), mw, mh, bytes, en.stream);
       for (size_t i = 0; i < convs.size() && e == hipSuccess; ++i)
         if (convs[i].d2h_dst)
-          e = hipMemcpyAsync(convs[i].d2h_dst, convs[i].desc.dst, convs[i].d2h_bytes, hipMemcpyDeviceToHost, stream_);
+          e = hipMemcpyAsync(convs[i].d2h_dst, convs[i].desc.dst, convs[i].d2h_bytes, hipMemcpyDeviceToHost, en.stream);
     }
-    if (e == hipSuccess) e = hipEventRecord(batch.done, stream_);
+    if (e == hipSuccess) e = hipEventRecord(batch.done, en.stream);
     if (e != hipSuccess) {
       std::lock_guard<std::mutex> lk(mu_);
       if (error_.empty()) error_ = std::string("GpuExecutor: launch failed: ") + hipGetErrorString(e);
       for (auto& lc : batch.lane_counts) lanes_[lc.first].completed += lc.second;
       batch.lane_counts.clear();
       cv_done_.notify_all();
+      cv_work_.notify_all();
     } else {
       batch.in_flight = true;
     }
@@ -285,13 +308,13 @@ void GpuExecutor::run() {
     t_launch += now() - t0;
   }
   if (debug)
-    fprintf(stderr, "[executor] batches %llu pics %llu convs %llu | retire %.3fs idle %.3fs launch %.3fs | batch size hist 0:%llu 1:%llu 2:%llu <=4:%llu <=8:%llu <=16:%llu <=32:%llu <=64:%llu >64:%llu\n",
-            (unsigned long long)stats_.batches, (unsigned long long)stats_.pictures, (unsigned long long)stats_.conversions,
+    fprintf(stderr, "[executor %s] batches %llu pics %llu convs %llu | retire %.3fs idle %.3fs launch %.3fs | batch size hist 0:%llu 1:%llu 2:%llu <=4:%llu <=8:%llu <=16:%llu <=32:%llu <=64:%llu >64:%llu\n",
+            engine ? "heavy" : "light", (unsigned long long)n_batches, (unsigned long long)n_pics, (unsigned long long)n_convs,
             t_retire, t_idle, t_launch, (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2],
             (unsigned long long)hist[3], (unsigned long long)hist[4], (unsigned long long)hist[5], (unsigned long long)hist[6],
             (unsigned long long)hist[7], (unsigned long long)hist[8]);
-  for (int i = 0; i < kInflight; ++i) retire(batches_[i]);
-  (void)hipStreamSynchronize(stream_);
+  for (int i = 0; i < kInflight; ++i) retire(en.batches[i]);
+  (void)hipStreamSynchronize(en.stream);
 }
 
 }  // namespace amd

@@ -18,8 +18,20 @@
 //     D2H of frames that go to host memory
 //
 // A batch takes at most one picture per lane (a lane's pictures depend on
-// each other) plus the conversions queued behind it; batches execute in
-// order on one stream, which is all the ordering a lane needs.
+// each other) plus the conversions queued behind it.
+//
+// Two engines run side by side, each with its own submitter thread, compute
+// stream, copy stream and ring of in-flight batches:
+//   light  P/B pictures: k_inter dominates, the row pipelines mostly skip
+//   heavy  intra-only pictures: every macroblock goes through the 16-wave
+//          row pipeline, several milliseconds per picture
+// A kernel launch lasts as long as its slowest workgroup, so one I picture in
+// a batch of P pictures would hold the whole batch (and every lane in it) for
+// its own duration; with two engines the P/B batches keep their short period.
+// Ordering across engines: a lane's next item is only taken by an engine when
+// everything the lane launched before has either completed or was launched
+// on that same engine (stream order).  Uploads go through the engine's copy
+// stream so that batch N+1's records travel while batch N's kernels run.
 #pragma once
 
 #include "frame_job.h"
@@ -46,6 +58,7 @@ struct PicSubmit {
   } copies[4];
   int ncopies = 0;
   int num_mbs = 0;
+  int heavy = 0;  // engine: 1 for intra-only pictures
   uint64_t bytes_inter = 0, bytes_intra = 0, bytes_deblock = 0;  // algorithmic, for the roofline
 };
 
@@ -77,7 +90,7 @@ class GpuExecutor {
  private:
   explicit GpuExecutor(int device) : device_(device) {}
   bool start(std::string* error);
-  void run();
+  void run(int engine);
   void stop();
   friend void shutdown_executors();
 
@@ -89,7 +102,8 @@ class GpuExecutor {
   struct Lane {
     bool active = false;
     std::deque<Item> fifo;
-    uint64_t submitted = 0, completed = 0;
+    uint64_t submitted = 0, launched = 0, completed = 0;
+    int last_engine = 0;
   };
   struct Batch {
     std::vector<std::pair<int, int>> lane_counts;  // (lane, items taken)
@@ -99,20 +113,35 @@ class GpuExecutor {
 
   static constexpr int kInflight = 3;
   static constexpr int kMaxJobs = 512;
+  static constexpr int kEngines = 2;
+
+  struct Engine {
+    std::thread thread;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    Batch batches[kInflight];
+    hipEvent_t copied[kInflight] = {nullptr, nullptr, nullptr};
+    JobDesc* job_table_host[kInflight] = {nullptr, nullptr, nullptr};
+    JobDesc* job_table_dev[kInflight] = {nullptr, nullptr, nullptr};
+    ConvertDesc* conv_table_host[kInflight] = {nullptr, nullptr, nullptr};
+    ConvertDesc* conv_table_dev[kInflight] = {nullptr, nullptr, nullptr};
+  };
+
+  // May engine `e` take the head of this lane's queue?  (mu_ held)
+  bool eligible(const Lane& l, int e) const {
+    if (l.fifo.empty()) return false;
+    if (l.launched != l.completed && l.last_engine != e) return false;
+    const Item& it = l.fifo.front();
+    if (it.is_picture) return it.pic.heavy == e;
+    return l.launched == l.completed ? e == l.last_engine : true;
+  }
 
   const int device_;
-  std::thread thread_;
   std::mutex mu_;
   std::condition_variable cv_work_, cv_done_;
   bool stop_ = false;
   std::string error_;
   std::vector<Lane> lanes_;
-  hipStream_t stream_ = nullptr;
-  Batch batches_[kInflight];
-  JobDesc* job_table_host_[kInflight] = {nullptr, nullptr, nullptr};
-  JobDesc* job_table_dev_[kInflight] = {nullptr, nullptr, nullptr};
-  ConvertDesc* conv_table_host_[kInflight] = {nullptr, nullptr, nullptr};
-  ConvertDesc* conv_table_dev_[kInflight] = {nullptr, nullptr, nullptr};
+  Engine engines_[kEngines];
   Stats stats_;
 };
 

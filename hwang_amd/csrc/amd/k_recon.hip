@@ -60,6 +60,7 @@ __constant__ uint8_t c_raster_to_zz[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13,
 __device__ __forceinline__ int iclip(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
+__device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
 __device__ __forceinline__ int level_scale4(const uint8_t* weight, int qp, int pos) {
   const int i = pos >> 2, j = pos & 3;
@@ -1266,6 +1267,42 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
     }
     row_publish(progress, mby, W);
   }
+}
+
+// ===========================================================================
+// k_upload: the batch's host -> HBM transfers as ONE launch.
+//
+// Each picture brings up to four arrays (MbInfo, coefficients, SliceParams,
+// MbMotion) from its lane's pinned staging buffers.  As separate
+// hipMemcpyAsync calls they cost tens of microseconds each on the copy queue,
+// so the kernel pulls them over PCIe itself: grid.y = picture * 4 + array,
+// grid.x strides over 16-byte chunks, every wave has a full cache line in
+// flight per load.  The job table (which carries the UploadDesc) is the only
+// hipMemcpyAsync left per batch.
+// ===========================================================================
+constexpr int kUploadBlocks = 48;
+
+__global__ __launch_bounds__(256) void k_upload(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.y / kJobUploads];
+  const int a = blockIdx.y % kJobUploads;
+  if (a >= job.num_uploads) return;
+  const UploadDesc u = job.uploads[a];
+  const uint64_t n16 = u.bytes >> 4;
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  const v4u* __restrict__ src = static_cast<const v4u*>(u.src);
+  v4u* __restrict__ dst = static_cast<v4u*>(u.dst);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)kUploadBlocks * 256)
+    dst[i] = __builtin_nontemporal_load(&src[i]);
+  if (blockIdx.x == 0) {
+    const uint64_t tail = u.bytes & 15;
+    if (threadIdx.x < tail)
+      static_cast<uint8_t*>(u.dst)[(n16 << 4) + threadIdx.x] = static_cast<const uint8_t*>(u.src)[(n16 << 4) + threadIdx.x];
+  }
+}
+
+hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream) {
+  hipLaunchKernelGGL(k_upload, dim3(kUploadBlocks, njobs * kJobUploads), dim3(256), 0, stream, jobs);
+  return hipGetLastError();
 }
 
 // ===========================================================================

@@ -134,7 +134,7 @@ int hwang_retriever_retrieve(hwang_retriever* r, const hwang_video_index* index,
 const char* hwang_retriever_last_error(hwang_retriever* r) {
   return r->error.c_str();
 }
-void hwang_retriever_stats(hwang_retriever* r, int64_t stats[8]) {
+void hwang_retriever_stats(hwang_retriever* r, int64_t stats[10]) {
   ParallelRetriever::Stats s = r->r->stats();
   stats[0] = s.intervals;
   stats[1] = s.samples_fed;
@@ -144,6 +144,8 @@ void hwang_retriever_stats(hwang_retriever* r, int64_t stats[8]) {
   stats[5] = s.bytes_uploaded;
   stats[6] = s.entropy_ns;
   stats[7] = s.wall_ns;
+  stats[8] = s.stall_ns;
+  stats[9] = 0;
 }
 
 }  // extern "C"

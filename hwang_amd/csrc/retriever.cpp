@@ -208,6 +208,7 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
       stats_.pictures_skipped += bc.pictures_skipped;
       stats_.bytes_uploaded += bc.bytes_uploaded;
       stats_.entropy_ns += bc.entropy_ns;
+      stats_.stall_ns += bc.stall_ns;
     }
   }
   stats_.wall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(

@@ -36,6 +36,7 @@ class ParallelRetriever {
     int64_t frames_returned = 0;
     int64_t bytes_uploaded = 0;
     int64_t entropy_ns = 0;
+    int64_t stall_ns = 0;
     int64_t wall_ns = 0;
   };
 

@@ -42,7 +42,8 @@ struct BackendCounters {
   int64_t pictures_reconstructed = 0;
   int64_t pictures_skipped = 0;
   int64_t bytes_uploaded = 0;
-  int64_t entropy_ns = 0;
+  int64_t entropy_ns = 0;   // host parse time, GPU stalls excluded
+  int64_t stall_ns = 0;     // time the parser was blocked on the GPU (staging ring full)
 };
 class CountedBackend {
  public:

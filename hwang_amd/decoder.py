@@ -147,11 +147,11 @@ class Decoder(object):
         return [buf[i] for i in range(len(rows))]
 
     def stats(self):
-        s = (C.c_int64 * 8)()
+        s = (C.c_int64 * 10)()
         lib.hwang_retriever_stats(self._get_retriever(), s)
         keys = ("intervals", "samples_fed", "pictures_reconstructed",
                 "pictures_skipped", "frames_returned", "bytes_uploaded",
-                "entropy_ns", "wall_ns")
+                "entropy_ns", "wall_ns", "stall_ns", "reserved")
         return dict(zip(keys, list(s)))
 
     def __del__(self):

@@ -197,9 +197,10 @@ const char* hwang_retriever_last_error(hwang_retriever* r);
  *  [0] intervals, [1] samples fed, [2] pictures reconstructed on the GPU,
  *  [3] pictures skipped (unwanted non-reference), [4] frames returned,
  *  [5] bytes uploaded (macroblock records + coefficients),
- *  [6] host entropy-decode nanoseconds summed over lanes,
- *  [7] wall nanoseconds */
-void hwang_retriever_stats(hwang_retriever* r, int64_t stats[8]);
+ *  [6] host entropy-decode nanoseconds summed over lanes (GPU stalls excluded),
+ *  [7] wall nanoseconds, [8] nanoseconds lanes were blocked on the GPU (staging
+ *  ring full), summed over lanes, [9] reserved (0) */
+void hwang_retriever_stats(hwang_retriever* r, int64_t stats[10]);
 
 /* -- Kernel-level entry points (parity tests + per-kernel roofline) ---------
  * Each runs one HIP kernel of the reconstruct pipeline on device buffers the

@@ -41,9 +41,9 @@ for lanes in [int(x) for x in os.environ.get("LANES", "1,4,16,32,64").split(",")
         dt = time.time() - t
         best = dt if best is None else min(best, dt)
     st = dec.stats()
-    print("lanes %3d: %.3fs  returned %.1f fps  reconstructed %.0f pics/s  fed %d skipped %d entropy %.2fs(sum) upload %.1f MB" % (
+    print("lanes %3d: %.3fs  returned %.1f fps  reconstructed %.0f pics/s  fed %d skipped %d entropy %.2fs stall %.2fs (sum over lanes) upload %.1f MB" % (
         lanes, best, len(rows) / best, st["pictures_reconstructed"] / best, st["samples_fed"], st["pictures_skipped"],
-        st["entropy_ns"] / 1e9, st["bytes_uploaded"] / 1e6))
+        st["entropy_ns"] / 1e9, st["stall_ns"] / 1e9, st["bytes_uploaded"] / 1e6))
     del dec
 # per-kernel timings with one lane (events serialise nothing else)
 lib.hwang_prof_enable(1)
