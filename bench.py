@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Headline benchmark: sparse H.264 frame retrieval on MI355X.
+
+Workload (BASELINE.json configs[1], "C1"): one synthetic 1080p30 High-profile
+CABAC clip of 108 000 frames (1 h; GOP 60, 2 B-frames between references),
+rows = sorted(default_rng(20240601 + rank).choice(N, round(0.01 N))) -> 1080
+frames per rank, returned as RGB24 into a tensor that lives in HBM.  One
+"step" = one full retrieval of the rank's row set through the C ABI
+(hwang_retriever_retrieve); the encoded file is resident in host memory (it
+is what the host-side entropy decoder reads), every decoded frame and every
+intermediate picture stays in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by torch.distributed.run, one rank per GPU.  The path
+shards by keyframe-anchored interval with no data exchange, so ranks only
+meet in the timing barrier (weak scaling: every rank decodes its own 1 %
+sample of the clip).
+
+Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events
+on the executor's streams (hwang_prof_*) in an extra pass after the timed
+region; `cpu_baseline` times the CPU oracle (a port, test infrastructure) on
+a bounded sample of the same workload under the reference's semantics (every
+sample of every touched GOP is decoded, wanted frames converted to RGB).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT = 1920, 1080
+UNIQUE_FRAMES = 1200          # encoded once ...
+GOP, BFRAMES = 60, 2
+SEED = 20240601
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def corpus_path(total_frames):
+    return "/tmp/hwang_bench_c1_%dx%d_%d_gop%d_b%d.mp4" % (WIDTH, HEIGHT, total_frames, GOP, BFRAMES)
+
+
+def make_corpus(total_frames):
+    """1080p30 clip: UNIQUE_FRAMES frames encoded by the in-tree encoder and
+    repeated (each repeat is an independent run of closed GOPs)."""
+    path = corpus_path(total_frames)
+    if os.path.exists(path):
+        return path
+    enc = os.path.join(ROOT, "corpus", "_build", "h264_encoder")
+    if not os.path.exists(enc):
+        raise SystemExit("bench.py: corpus encoder missing; run __graft_entry__.build() first")
+    unique = min(UNIQUE_FRAMES, total_frames)
+    repeat = max(1, total_frames // unique)
+    tmp = path + ".tmp.%d" % os.getpid()
+    subprocess.check_call([enc, "--width", str(WIDTH), "--height", str(HEIGHT), "--frames", str(unique),
+                           "--gop", str(GOP), "--bframes", str(BFRAMES), "--fps", "30",
+                           "--threads", str(min(64, os.cpu_count() or 8)), "--repeat", str(repeat), "--out", tmp],
+                          stdout=subprocess.DEVNULL)
+    os.replace(tmp, path)
+    return path
+
+
+# --------------------------------------------------------------- CPU baseline
+def cpu_gop_worker(spec_path):
+    """Child process (`bench.py --cpu-worker spec.json`): decodes whole GOPs
+    with the oracle the way the reference's software backend does
+    (software_video_decoder.cpp:103-457 driven by DecoderAutomata: every sample
+    of the interval is fed, unwanted frames are discarded, wanted ones are
+    converted to RGB24)."""
+    from oracle import oracle_py  # cpu_baseline leg only
+    with open(spec_path) as f:
+        spec = json.load(f)
+    avcc = bytes.fromhex(spec["avcc"])
+    returned = fed = 0
+    t0 = time.time()
+    with open(spec["path"], "rb") as f:
+        for gop in spec["gops"]:
+            dec = oracle_py.OracleDecoder(avcc)
+            frames = []
+            for off, size in gop["samples"]:
+                f.seek(off)
+                frames += dec.decode(f.read(size))
+                fed += 1
+            frames += dec.flush()
+            for k in gop["wanted"]:
+                buf, w, h, _ = frames[k]
+                oracle_py.i420_to_rgb(buf, w, h)
+                returned += 1
+            dec.close()
+    print(json.dumps({"returned": returned, "fed": fed, "seconds": time.time() - t0}))
+
+
+def cpu_baseline(path, index, rows, workers):
+    import tempfile
+    offs, sizes = index.sample_offsets(), index.sample_sizes()
+    kfs = index.keyframe_indices() + [index.frames()]
+    # the first `workers` touched GOPs, one per worker process
+    gops, ki = [], 0
+    for r in rows:
+        while kfs[ki + 1] <= r:
+            ki += 1
+        if gops and gops[-1]["gop"] == ki:
+            gops[-1]["wanted"].append(r - kfs[ki])
+        elif len(gops) < workers:
+            gops.append({"gop": ki, "samples": [(offs[s], sizes[s]) for s in range(kfs[ki], kfs[ki + 1])],
+                         "wanted": [r - kfs[ki]]})
+        else:
+            break
+    avcc = bytes(index.metadata_bytes()).hex()
+    procs = []
+    t0 = time.time()
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, g in enumerate(gops):
+            spec = os.path.join(tmp, "w%d.json" % i)
+            with open(spec, "w") as f:
+                json.dump({"path": path, "avcc": avcc, "gops": [g]}, f)
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec],
+                                          stdout=subprocess.PIPE))
+        res = []
+        for p in procs:
+            out, _ = p.communicate()
+            if p.returncode:
+                raise SystemExit("bench.py: cpu_baseline worker failed")
+            res.append(json.loads(out.decode().strip().splitlines()[-1]))
+    wall = time.time() - t0
+    busy = max(r["seconds"] for r in res)  # slowest worker's decode time (interpreter start-up excluded)
+    returned = sum(r["returned"] for r in res)
+    fed = sum(r["fed"] for r in res)
+    return {
+        "value": round(returned / busy, 3),
+        "unit": "frames/s",
+        "cores": len(gops),
+        "kind": "port",
+        "sample": "%d touched GOPs of the same clip (%d samples fed, %d wanted frames returned as RGB24), one "
+                  "single-threaded oracle decoder per core, reference semantics (whole GOP decoded); %.1f s wall"
+                  % (len(gops), fed, returned, wall),
+        "fed_samples_per_s": round(fed / busy, 2),
+    }
+
+
+# ----------------------------------------------------------------------- main
+def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
+        return cpu_gop_worker(sys.argv[2])
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("HWANG_BENCH_FRAMES", 108000)),
+                    help="clip length; the headline configuration is 108000 (1 h of 1080p30)")
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("HWANG_BENCH_LANES", 0)))
+    ap.add_argument("--cpu-workers", type=int, default=int(os.environ.get("HWANG_BENCH_CPU_WORKERS", 16)))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import numpy as np
+    import hwang_amd as hw
+    from hwang_amd._capi import lib
+
+    # corpus + index (rank 0 generates; the others wait for the file)
+    path = corpus_path(args.frames)
+    if rank == 0:
+        make_corpus(args.frames)
+    else:
+        while not os.path.exists(path):
+            time.sleep(0.5)
+    index = hw.index_video(path)
+    n = index.frames()
+    rows = sorted(np.random.default_rng(SEED + rank).choice(n, max(1, round(0.01 * n)), replace=False).tolist())
+
+    # CPU baseline first (rank 0, N = 1 only): spawns processes, so it runs
+    # before this process touches the GPU.
+    cpu = None
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(path, index, rows, max(1, min(args.cpu_workers, os.cpu_count() or 1)))
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU visible (the decoder has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    lanes = args.lanes or max(8, min(128, (os.cpu_count() or 8) // max(1, world)))
+    dec = hw.Decoder(path, video_index=index, device_id=local_rank, num_lanes=lanes)
+    out = torch.empty((len(rows), HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda")
+
+    def step():
+        dec.retrieve_into(rows, out.data_ptr(), out.numel())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stats = dec.stats()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([len(rows), stats["pictures_reconstructed"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        total_rows, total_pics = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        total_rows, total_pics = len(rows), stats["pictures_reconstructed"]
+
+    # roofline pass: one more step with the per-kernel HIP-event spans enabled
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        lib.hwang_prof_reset()
+        lib.hwang_prof_enable(1)
+        step()
+        torch.cuda.synchronize()
+        lib.hwang_prof_enable(0)
+        best = None
+        for k in range(lib.hwang_prof_num_kernels()):
+            o = (C.c_double * 3)()
+            lib.hwang_prof_read(k, o)
+            if not o[0]:
+                continue
+            name = lib.hwang_prof_kernel_name(k).decode()
+            kernels[name] = {"launches": int(o[0]), "avg_us": round(o[1] / o[0], 1),
+                             "alg_GBps": round(o[2] / (o[1] * 1e-6) / 1e9, 1)}
+            if best is None or o[1] > best[1]:
+                best = (name, o[1], o[2], o[0])
+        if best:
+            achieved = best[2] / (best[1] * 1e-6) / 1e9
+            roofline = {"bound": "hbm", "kernel": best[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "launches": int(best[3]), "avg_launch_us": round(best[1] / best[3], 1)}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        value = total_rows * args.steps / elapsed
+        print(json.dumps({
+            "metric": "decoded frames/sec, 1080p H.264 1%-sparse sample, 1/2/4/8 MI355X vs FFmpeg CPU",
+            "value": round(value, 2),
+            "unit": "frames/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 2),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "C1: single 1080p30 High-profile CABAC mp4, %d frames, GOP %d, %d B-frames, "
+                                   "1%% uniform-random rows (%d per GPU) returned as RGB24 in HBM"
+                                   % (n, GOP, BFRAMES, len(rows)),
+                       "lanes_per_gpu": lanes, "sharding": "keyframe-anchored intervals, no collective"},
+            "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
+            "roofline": roofline,
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+        }))
+
+
+if __name__ == "__main__":
+    main()
