@@ -143,6 +143,18 @@ def cpu_baseline(path, index, rows, workers):
     }
 
 
+def effective_cpus():
+    """Hardware threads, capped by the cgroup CPU quota (cpu.max) if any."""
+    n = float(len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, float(quota) / float(period))
+    except (OSError, ValueError):
+        pass
+    return max(1, int(n + 0.5))
+
+
 # ----------------------------------------------------------------------- main
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
@@ -185,7 +197,7 @@ def main():
     # before this process touches the GPU.
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(path, index, rows, max(1, min(args.cpu_workers, os.cpu_count() or 1)))
+        cpu = cpu_baseline(path, index, rows, max(1, min(args.cpu_workers, effective_cpus())))
 
     import torch
     import torch.distributed as dist
@@ -194,7 +206,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    lanes = args.lanes or max(8, min(128, (os.cpu_count() or 8) // max(1, world)))
+    # 0 = one lane per CPU this process may use (the library reads the cgroup
+    # quota); with several ranks on one host the CPUs are shared
+    lanes = args.lanes or (0 if world == 1 else max(2, effective_cpus() // world))
     dec = hw.Decoder(path, video_index=index, device_id=local_rank, num_lanes=lanes)
     out = torch.empty((len(rows), HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda")
 
@@ -273,7 +287,7 @@ def main():
             "config": {"workload": "C1: single 1080p30 High-profile CABAC mp4, %d frames, GOP %d, %d B-frames, "
                                    "1%% uniform-random rows (%d per GPU) returned as RGB24 in HBM"
                                    % (n, GOP, BFRAMES, len(rows)),
-                       "lanes_per_gpu": lanes, "sharding": "keyframe-anchored intervals, no collective"},
+                       "lanes_per_gpu": lanes or effective_cpus(), "host_cpus": effective_cpus(), "sharding": "keyframe-anchored intervals, no collective"},
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
             "roofline": roofline,
             "kernels": kernels,

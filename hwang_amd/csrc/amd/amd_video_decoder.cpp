@@ -27,6 +27,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <memory>
@@ -168,15 +169,30 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   // ------------------------------------------------------------ PictureSink
   bool begin_picture(const h264::PicSetup& s, h264::PicBuffers* out, std::string* error) override {
     if (!ensure_geometry(s, error)) return false;
-    // a free surface
+    // A free surface.  Its pinned motion buffer is the parser's output for
+    // this picture, so it must not still be the source of an earlier picture's
+    // upload: prefer a free surface whose last upload has finished, then a new
+    // one (up to a soft limit), and only then wait for the oldest.  (Taking
+    // the lowest free index re-used the surface released most recently and
+    // made every picture wait for the one submitted just before it.)
     int slot = -1;
     {
+      const uint64_t done = exec_->completed(lane_);
       std::lock_guard<std::mutex> lk(out_mu_);
-      for (int i = 0; i < amd::kMaxSurfaces; ++i)
-        if (!surf_[i].held) {
+      int fresh = -1, oldest = -1, allocated = 0;
+      for (int i = 0; i < amd::kMaxSurfaces; ++i) {
+        if (surf_[i].dev) ++allocated;
+        if (surf_[i].held) continue;
+        if (!surf_[i].dev) {
+          if (fresh < 0) fresh = i;
+        } else if (surf_[i].motion_seq <= done) {
           slot = i;
           break;
+        } else if (oldest < 0 || surf_[i].motion_seq < surf_[oldest].motion_seq) {
+          oldest = i;
         }
+      }
+      if (slot < 0) slot = (fresh >= 0 && (allocated < kSoftSurfaces || oldest < 0)) ? fresh : oldest;
       if (slot >= 0) surf_[slot].held = kHeldByParser;
     }
     if (slot < 0) {
@@ -195,6 +211,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // the motion buffer of this surface may still be the source of an upload
     if (surf_[slot].motion_seq) {
       StallTimer st{counters_, stall_t0};
+      ++dbg_motion_waits_;
+      const auto t0 = std::chrono::steady_clock::now();
+      struct Acc { int64_t& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{dbg_motion_ns_, t0};
       if (!exec_->wait(lane_, surf_[slot].motion_seq, error)) return false;
       surf_[slot].motion_seq = 0;
     }
@@ -202,6 +221,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     Job& j = jobs_[job_cursor_];
     if (j.seq) {
       StallTimer st{counters_, std::chrono::steady_clock::now()};
+      ++dbg_job_waits_;
+      struct Acc { int64_t& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{dbg_job_ns_, std::chrono::steady_clock::now()};
       if (!exec_->wait(lane_, j.seq, error)) return false;
       j.seq = 0;
     }
@@ -280,6 +301,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
  private:
   enum { kHeldByParser = 1, kHeldByOutput = 2 };
+  static constexpr int kSoftSurfaces = 12;  // beyond this, wait for an upload rather than grow
 
   struct SurfaceSlot {
     uint8_t* dev = nullptr;
@@ -381,7 +403,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     SurfaceSlot& s = surf_[slot];
     if (s.dev) return true;
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
-    if (hipMalloc(reinterpret_cast<void**>(&s.dev), surface_bytes_) != hipSuccess ||
+    // + 64: k_inter fetches unaligned dwords and may read 3 bytes past a plane's last sample
+    if (hipMalloc(reinterpret_cast<void**>(&s.dev), surface_bytes_ + 64) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s.motion_host), nmb * sizeof(MbMotion), hipHostMallocDefault) != hipSuccess) {
       *error = "AMDVideoDecoder: out of memory for a decode surface";
       return false;
@@ -425,6 +448,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   void teardown() {
+    if (getenv("HWANG_EXEC_DEBUG") && (dbg_motion_waits_ || dbg_job_waits_))
+      fprintf(stderr, "[decoder lane %d] motion waits %lld (%.3f s)  job-ring waits %lld (%.3f s)\n", lane_,
+              (long long)dbg_motion_waits_, dbg_motion_ns_ / 1e9, (long long)dbg_job_waits_, dbg_job_ns_ / 1e9);
     if (hipSetDevice(device_) != hipSuccess) return;
     if (exec_) {
       (void)wait_seq(last_seq_);
@@ -528,6 +554,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   int mbw_ = 0, mbh_ = 0, y_pitch_ = 0, c_pitch_ = 0, crop_left_ = 0, crop_top_ = 0;
   size_t u_offset_ = 0, v_offset_ = 0, surface_bytes_ = 0, coef_capacity_ = 0;
+  int64_t dbg_motion_waits_ = 0, dbg_motion_ns_ = 0, dbg_job_waits_ = 0, dbg_job_ns_ = 0;
   SurfaceSlot surf_[amd::kMaxSurfaces];
   Job jobs_[kJobs];
   int job_cursor_ = 0, cur_job_ = 0;

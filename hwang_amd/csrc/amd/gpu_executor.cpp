@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <pthread.h>
 #include <map>
 #include <memory>
 
@@ -18,6 +19,15 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_in
                         bool any_deblock, const uint64_t bytes[3], hipStream_t stream);
 
 namespace {
+// The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
+// (default 4) and kernels of streams that share a queue serialise.  The
+// executor needs its engines to really run side by side, so ask for more
+// before the runtime initialises (no effect if the process already did, or if
+// the user set the variable).
+struct HwQueueEnv {
+  HwQueueEnv() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_hw_queue_env;
+
 std::mutex g_registry_mu;
 std::map<int, GpuExecutor*> g_registry;
 bool g_atexit_registered = false;
@@ -51,16 +61,42 @@ bool GpuExecutor::start(std::string* error) {
     return false;
   };
   if (hipSetDevice(device_) != hipSuccess) return fail("cannot select the device");
-  for (Engine& en : engines_) {
-    if (hipStreamCreateWithFlags(&en.stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&en.copy_stream, hipStreamNonBlocking) != hipSuccess)
-      return fail("cannot create a stream");
+  // CU partition.  An intra-only picture is ONE 16-wave workgroup whose
+  // speed is the latency of a dependent chain; sharing its CU with k_inter
+  // waves of the light engine more than doubles that latency (measured:
+  // 7 ms -> 17 ms per 1080p I picture), and every interval waits for its
+  // keyframe.  So every 8th CU (one per XCD position, 32 of 256) is reserved
+  // for the heavy engines and the light engine's streams get the rest.
+  // HWANG_CU_PARTITION=0 disables the masks.
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_) != hipSuccess) return fail("cannot query the device");
+  const int num_cus = prop.multiProcessorCount;
+  const char* part_env = getenv("HWANG_CU_PARTITION");
+  const int stride = part_env ? atoi(part_env) : 8;
+  std::vector<uint32_t> heavy_mask((num_cus + 31) / 32, 0u), light_mask((num_cus + 31) / 32, 0u);
+  for (int cu = 0; cu < num_cus; ++cu) {
+    const bool heavy = stride > 1 && (cu % stride) == stride - 1;
+    (heavy ? heavy_mask : light_mask)[cu / 32] |= 1u << (cu % 32);
+  }
+  auto make_stream = [&](hipStream_t* st, const std::vector<uint32_t>& mask) {
+    if (stride > 1 && hipExtStreamCreateWithCUMask(st, static_cast<uint32_t>(mask.size()), mask.data()) == hipSuccess)
+      return true;
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+  };
+  for (int ei = 0; ei < kEngines; ++ei) {
+    Engine& en = engines_[ei];
+    if (!make_stream(&en.stream, ei == 0 ? light_mask : heavy_mask)) return fail("cannot create a stream");
+    // only the light engine overlaps uploads with the previous batch's kernels
+    if (ei == 0) {
+      if (!make_stream(&en.copy_stream, light_mask)) return fail("cannot create a stream");
+    } else {
+      en.copy_stream = en.stream;
+    }
     for (int i = 0; i < kInflight; ++i) {
       if (hipHostMalloc(reinterpret_cast<void**>(&en.job_table_host[i]), sizeof(JobDesc) * kMaxJobs, hipHostMallocDefault) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&en.job_table_dev[i]), sizeof(JobDesc) * kMaxJobs) != hipSuccess ||
           hipHostMalloc(reinterpret_cast<void**>(&en.conv_table_host[i]), sizeof(ConvertDesc) * kMaxJobs, hipHostMallocDefault) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&en.conv_table_dev[i]), sizeof(ConvertDesc) * kMaxJobs) != hipSuccess ||
-          hipEventCreateWithFlags(&en.batches[i].done, hipEventDisableTiming) != hipSuccess ||
           hipEventCreateWithFlags(&en.copied[i], hipEventDisableTiming) != hipSuccess)
         return fail("out of memory for job tables");
     }
@@ -106,6 +142,7 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     Item it;
     it.is_picture = true;
     it.pic = job;
+    it.engine = job.heavy ? 1 + lane % kHeavyEngines : 0;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
   }
@@ -127,9 +164,16 @@ uint64_t GpuExecutor::submit_convert(int lane, const ConvSubmit& job) {
   return seq;
 }
 
+uint64_t GpuExecutor::completed(int lane) {
+  std::lock_guard<std::mutex> lk(mu_);
+  return lanes_[lane].completed;
+}
+
 bool GpuExecutor::wait(int lane, uint64_t seq, std::string* error) {
   std::unique_lock<std::mutex> lk(mu_);
+  ++lanes_[lane].waiters;
   cv_done_.wait(lk, [&] { return lanes_[lane].completed >= seq || !error_.empty() || stop_; });
+  --lanes_[lane].waiters;
   if (!error_.empty()) {
     if (error) *error = error_;
     return false;
@@ -146,45 +190,52 @@ GpuExecutor::Stats GpuExecutor::stats() {
   return stats_;
 }
 
+void GpuExecutor::on_batch_done(void* p) {
+  Batch* b = static_cast<Batch*>(p);
+  b->owner->complete(b, hipSuccess);
+}
+
+void GpuExecutor::complete(Batch* b, hipError_t status) {
+  std::lock_guard<std::mutex> lk(mu_);
+  if (status != hipSuccess && error_.empty())
+    error_ = std::string("GpuExecutor: launch failed: ") + hipGetErrorString(status);
+  for (auto& lc : b->lane_counts) lanes_[lc.first].completed += lc.second;
+  b->lane_counts.clear();
+  b->in_flight = false;
+  --engines_[b->engine].inflight;
+  cv_done_.notify_all();
+  cv_work_.notify_all();  // a batch slot is free; other engines may take over these lanes
+}
+
+// Engine thread: sleeps until one of its lanes has something eligible AND a
+// batch slot is free, forms the batch, launches it and appends a host
+// function to the stream that reports completion.  Nothing polls and nothing
+// blocks inside the HIP runtime, so the threads cost no CPU while the GPU
+// works (the host's CPUs belong to the entropy decoders).
 void GpuExecutor::run(int engine) {
+  {
+    char name[16];
+    snprintf(name, sizeof(name), engine ? "hw-heavy%d" : "hw-light", engine);
+    pthread_setname_np(pthread_self(), name);
+  }
   (void)hipSetDevice(device_);
   Engine& en = engines_[engine];
-  uint64_t batch_index = 0;
-  auto retire = [&](Batch& b) {
-    if (!b.in_flight) return;
-    hipError_t e = hipEventSynchronize(b.done);
-    std::lock_guard<std::mutex> lk(mu_);
-    if (e != hipSuccess && error_.empty()) error_ = std::string("GpuExecutor: batch failed: ") + hipGetErrorString(e);
-    for (auto& lc : b.lane_counts) lanes_[lc.first].completed += lc.second;
-    b.lane_counts.clear();
-    b.in_flight = false;
-    cv_done_.notify_all();
-    cv_work_.notify_all();  // the other engine may now take over some of these lanes
-  };
+  // Light batches are formed late, not eagerly: with one batch running and
+  // one queued behind it, every lane keeps parsing, so by the time the running
+  // one finishes most lanes have their next picture ready and the next batch
+  // is wide.  (Launching whatever is pending right away produced batches of
+  // ~5 pictures that each held the GPU for a full pipeline latency.)  Heavy
+  // batches are latency bound and launch as soon as there is work.
+  const int max_inflight = engine == 0 ? 2 : kInflight;
 
   std::vector<PicSubmit> pics;
   std::vector<ConvSubmit> convs;
   const bool debug = getenv("HWANG_EXEC_DEBUG") != nullptr;
-  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-  double t_retire = 0, t_idle = 0, t_launch = 0;
-  uint64_t hist[9] = {0}, n_batches = 0, n_pics = 0, n_convs = 0;
+  uint64_t hist[9] = {0}, n_batches = 0, n_pics = 0, n_convs = 0, lane_state[5] = {0, 0, 0, 0, 0};
   for (;;) {
-    double t0 = now();
-    const int slot = static_cast<int>(batch_index % kInflight);
-    Batch& batch = en.batches[slot];
-    retire(batch);  // the slot's previous occupant (kInflight batches ago)
-    // Form the next batch late, not eagerly: while two batches are already
-    // queued on the GPU, every lane keeps parsing, so by the time the older
-    // one finishes most lanes have their next picture ready and the batch is
-    // wide.  (Launching whatever is pending right away produced batches of
-    // ~5 pictures that each held the GPU for a full pipeline latency.)
-    if (en.batches[(slot + kInflight - 2) % kInflight].in_flight && en.batches[(slot + kInflight - 1) % kInflight].in_flight)
-      retire(en.batches[(slot + kInflight - 2) % kInflight]);
-    t_retire += now() - t0;
-    t0 = now();
-
     pics.clear();
     convs.clear();
+    int slot = -1;
     {
       std::unique_lock<std::mutex> lk(mu_);
       auto have_work = [&] {
@@ -192,23 +243,22 @@ void GpuExecutor::run(int engine) {
           if (eligible(l, engine)) return true;
         return false;
       };
-      while (!stop_ && !have_work()) {
-        // nothing to launch: finish what is in flight so waiters wake up
-        bool any = false;
-        for (int i = 0; i < kInflight; ++i) any |= en.batches[i].in_flight;
-        if (any) {
-          lk.unlock();
-          for (int i = 1; i <= kInflight; ++i) retire(en.batches[(slot + i) % kInflight]);
-          lk.lock();
-          continue;
-        }
-        cv_work_.wait(lk);
-      }
+      cv_work_.wait(lk, [&] { return stop_ || (en.inflight < max_inflight && have_work()); });
       if (stop_) break;
+      for (int i = 0; i < kInflight; ++i)
+        if (!en.batches[i].in_flight) slot = i;
+      Batch& batch = en.batches[slot];
       // per lane: one picture and the conversions queued behind it, or the
       // leading conversions when the head of the queue is a conversion
       for (size_t li = 0; li < lanes_.size(); ++li) {
         Lane& l = lanes_[li];
+        if (debug && l.active) {
+          const int cls = eligible(l, engine) ? 0
+                          : !l.fifo.empty() ? 1                       // queued for / held by another engine
+                          : l.launched != l.completed ? (l.waiters ? 2 : 3)  // in flight: thread blocked / parsing ahead
+                          : 4;                                        // nothing in flight: thread parsing or idle
+          ++lane_state[cls];
+        }
         int taken = 0;
         bool took_picture = false;
         while (eligible(l, engine)) {
@@ -228,16 +278,18 @@ void GpuExecutor::run(int engine) {
         }
         if (taken) batch.lane_counts.emplace_back(static_cast<int>(li), taken);
       }
+      batch.in_flight = true;
+      batch.owner = this;
+      batch.engine = engine;
+      ++en.inflight;
       ++stats_.batches;
       stats_.pictures += pics.size();
       stats_.conversions += convs.size();
     }
+    Batch& batch = en.batches[slot];
     ++n_batches;
     n_pics += pics.size();
     n_convs += convs.size();
-
-    t_idle += now() - t0;
-    t0 = now();
     {
       size_t n = pics.size();
       int b = n == 0 ? 0 : n <= 1 ? 1 : n <= 2 ? 2 : n <= 4 ? 3 : n <= 8 ? 4 : n <= 16 ? 5 : n <= 32 ? 6 : n <= 64 ? 7 : 8;
@@ -248,7 +300,7 @@ void GpuExecutor::run(int engine) {
       int max_mbs = 0;
       bool any_inter = false, any_intra = false, any_deblock = false;
       uint64_t bytes[3] = {0, 0, 0};
-      for (size_t i = 0; i < pics.size() && e == hipSuccess; ++i) {
+      for (size_t i = 0; i < pics.size(); ++i) {
         const PicSubmit& p = pics[i];
         JobDesc& jd = en.job_table_host[slot][i];
         jd = p.desc;
@@ -266,12 +318,13 @@ void GpuExecutor::run(int engine) {
         bytes[1] += p.bytes_intra;
         bytes[2] += p.bytes_deblock;
       }
-      if (e == hipSuccess)
-        e = hipMemcpyAsync(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(),
-                           hipMemcpyHostToDevice, en.copy_stream);
+      e = hipMemcpyAsync(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(),
+                         hipMemcpyHostToDevice, en.copy_stream);
       if (e == hipSuccess) e = launch_upload(en.job_table_dev[slot], static_cast<int>(pics.size()), en.copy_stream);
-      if (e == hipSuccess) e = hipEventRecord(en.copied[slot], en.copy_stream);
-      if (e == hipSuccess) e = hipStreamWaitEvent(en.stream, en.copied[slot], 0);
+      if (en.copy_stream != en.stream) {
+        if (e == hipSuccess) e = hipEventRecord(en.copied[slot], en.copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(en.stream, en.copied[slot], 0);
+      }
       if (e == hipSuccess)
         e = launch_batch(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, any_inter, any_intra,
                          any_deblock, bytes, en.stream);
@@ -293,28 +346,25 @@ void GpuExecutor::run(int engine) {
         if (convs[i].d2h_dst)
           e = hipMemcpyAsync(convs[i].d2h_dst, convs[i].desc.dst, convs[i].d2h_bytes, hipMemcpyDeviceToHost, en.stream);
     }
-    if (e == hipSuccess) e = hipEventRecord(batch.done, en.stream);
+    if (e == hipSuccess) e = hipLaunchHostFunc(en.stream, &GpuExecutor::on_batch_done, &batch);
     if (e != hipSuccess) {
-      std::lock_guard<std::mutex> lk(mu_);
-      if (error_.empty()) error_ = std::string("GpuExecutor: launch failed: ") + hipGetErrorString(e);
-      for (auto& lc : batch.lane_counts) lanes_[lc.first].completed += lc.second;
-      batch.lane_counts.clear();
-      cv_done_.notify_all();
-      cv_work_.notify_all();
-    } else {
-      batch.in_flight = true;
+      // whatever was enqueued must drain before the lanes may reuse their buffers
+      (void)hipStreamSynchronize(en.stream);
+      complete(&batch, e);
     }
-    ++batch_index;
-    t_launch += now() - t0;
   }
-  if (debug)
-    fprintf(stderr, "[executor %s] batches %llu pics %llu convs %llu | retire %.3fs idle %.3fs launch %.3fs | batch size hist 0:%llu 1:%llu 2:%llu <=4:%llu <=8:%llu <=16:%llu <=32:%llu <=64:%llu >64:%llu\n",
-            engine ? "heavy" : "light", (unsigned long long)n_batches, (unsigned long long)n_pics, (unsigned long long)n_convs,
-            t_retire, t_idle, t_launch, (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2],
+  if (debug) {
+    fprintf(stderr, "[executor %s%d] batches %llu pics %llu convs %llu | batch size hist 0:%llu 1:%llu 2:%llu <=4:%llu <=8:%llu <=16:%llu <=32:%llu <=64:%llu >64:%llu\n",
+            engine ? "heavy" : "light", engine, (unsigned long long)n_batches, (unsigned long long)n_pics, (unsigned long long)n_convs,
+            (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2],
             (unsigned long long)hist[3], (unsigned long long)hist[4], (unsigned long long)hist[5], (unsigned long long)hist[6],
             (unsigned long long)hist[7], (unsigned long long)hist[8]);
-  for (int i = 0; i < kInflight; ++i) retire(en.batches[i]);
-  (void)hipStreamSynchronize(en.stream);
+    if (n_batches)
+      fprintf(stderr, "[executor %s%d] lanes at batch formation (avg): taken %.1f, other-engine %.1f, in-flight+blocked %.1f, in-flight+parsing %.1f, idle/parsing %.1f\n",
+              engine ? "heavy" : "light", engine, lane_state[0] / (double)n_batches, lane_state[1] / (double)n_batches,
+              lane_state[2] / (double)n_batches, lane_state[3] / (double)n_batches, lane_state[4] / (double)n_batches);
+  }
+  (void)hipStreamSynchronize(en.stream);  // outstanding completions run before the thread goes away
 }
 
 }  // namespace amd

@@ -20,11 +20,17 @@
 // A batch takes at most one picture per lane (a lane's pictures depend on
 // each other) plus the conversions queued behind it.
 //
-// Two engines run side by side, each with its own submitter thread, compute
-// stream, copy stream and ring of in-flight batches:
-//   light  P/B pictures: k_inter dominates, the row pipelines mostly skip
-//   heavy  intra-only pictures: every macroblock goes through the 16-wave
-//          row pipeline, several milliseconds per picture
+// Several engines run side by side, each with its own submitter thread,
+// compute stream, copy stream and ring of in-flight batches:
+//   light      P/B pictures: k_inter dominates, the row pipelines mostly skip;
+//              batches are formed late so that they are wide
+//   heavy x H  intra-only pictures: every macroblock goes through the 16-wave
+//              row pipeline, several milliseconds per picture on ONE CU.  A
+//              heavy batch is latency bound and tiny (a handful of CUs), so
+//              there are H of them (lane % H picks one) launching eagerly and
+//              running concurrently; a lane waits for its keyframe before its
+//              first P picture can go anywhere, which makes this latency the
+//              critical path of every interval.
 // A kernel launch lasts as long as its slowest workgroup, so one I picture in
 // a batch of P pictures would hold the whole batch (and every lane in it) for
 // its own duration; with two engines the P/B batches keep their short period.
@@ -79,6 +85,8 @@ class GpuExecutor {
   // Both return the lane-local sequence number of the submission (1, 2, ...).
   uint64_t submit_picture(int lane, const PicSubmit& job);
   uint64_t submit_convert(int lane, const ConvSubmit& job);
+  // How many of the lane's submissions have finished (non-blocking).
+  uint64_t completed(int lane);
   // Blocks until the lane's submissions up to `seq` have finished on the GPU.
   bool wait(int lane, uint64_t seq, std::string* error);
 
@@ -92,10 +100,12 @@ class GpuExecutor {
   bool start(std::string* error);
   void run(int engine);
   void stop();
+
   friend void shutdown_executors();
 
   struct Item {
     bool is_picture;
+    int engine = 0;  // pictures: the engine that must run it
     PicSubmit pic;
     ConvSubmit conv;
   };
@@ -104,19 +114,28 @@ class GpuExecutor {
     std::deque<Item> fifo;
     uint64_t submitted = 0, launched = 0, completed = 0;
     int last_engine = 0;
+    int waiters = 0;  // threads blocked in wait() (diagnostics)
   };
   struct Batch {
     std::vector<std::pair<int, int>> lane_counts;  // (lane, items taken)
-    hipEvent_t done = nullptr;
     bool in_flight = false;
+    GpuExecutor* owner = nullptr;
+    int engine = 0;
   };
+
+  // Stream callback (hipLaunchHostFunc) at the end of a batch: credits the
+  // lanes and wakes waiters.  Runs on a HIP runtime thread; no HIP calls.
+  static void on_batch_done(void* batch);
+  void complete(Batch* b, hipError_t status);
 
   static constexpr int kInflight = 3;
   static constexpr int kMaxJobs = 512;
-  static constexpr int kEngines = 2;
+  static constexpr int kHeavyEngines = 3;
+  static constexpr int kEngines = 1 + kHeavyEngines;
 
   struct Engine {
     std::thread thread;
+    int inflight = 0;  // batches launched and not yet completed (mu_)
     hipStream_t stream = nullptr, copy_stream = nullptr;
     Batch batches[kInflight];
     hipEvent_t copied[kInflight] = {nullptr, nullptr, nullptr};
@@ -131,7 +150,7 @@ class GpuExecutor {
     if (l.fifo.empty()) return false;
     if (l.launched != l.completed && l.last_engine != e) return false;
     const Item& it = l.fifo.front();
-    if (it.is_picture) return it.pic.heavy == e;
+    if (it.is_picture) return it.engine == e;
     return l.launched == l.completed ? e == l.last_engine : true;
   }
 

@@ -85,208 +85,7 @@ __device__ __forceinline__ const int16_t* coef_group(const MbInfo& mb, const int
   return coefs + mb.coef_offset + 16 * __popc(mb.coded_mask & ((1u << g) - 1));
 }
 
-// ---------------------------------------------------------------------------
-// Residual of one macroblock into LDS (256 threads cooperate).
-//   res_y[256]   luma residual, raster 16x16
-//   res_c[2][64] chroma residual, raster 8x8 per plane
-// `work` is 384 ints of scratch.
-// ---------------------------------------------------------------------------
-__device__ void mb_residual(const MbInfo& mb, const int16_t* coefs, const PictureParams& pp, int tid,
-                            int* work, int16_t* res_y, int16_t* res_c) {
-  const bool intra = mb.flags & MBF_INTRA;
-  const int qp = mb.qp;
-  int* dy = work;        // 256
-  int* dc = work + 256;  // 128
-  __shared__ int s_dc[16 + 8];
-
-  // ---- luma DC of Intra16x16: inverse Hadamard + scaling (8.5.10)
-  if (mb.kind == MBK_I16x16) {
-    const int16_t* g = coef_group(mb, coefs, kMaskLumaDc);
-    if (tid < 16) {
-      int f = 0;
-      if (g) {
-        const int i = tid >> 2, j = tid & 3;
-        // f = H c H with H = [[1,1,1,1],[1,1,-1,-1],[1,-1,-1,1],[1,-1,1,-1]]
-        const int hs[4][4] = {{1, 1, 1, 1}, {1, 1, -1, -1}, {1, -1, -1, 1}, {1, -1, 1, -1}};
-        for (int a = 0; a < 4; ++a)
-          for (int b = 0; b < 4; ++b) f += hs[i][a] * g[a * 4 + b] * hs[b][j];
-        const int ls = level_scale4(pp.scaling4[0], qp, 0);
-        f = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
-      }
-      s_dc[tid] = f;
-    }
-  }
-  // ---- chroma DC: 2x2 Hadamard + scaling (8.5.11)
-  if (tid >= 16 && tid < 24) {
-    const int p = (tid - 16) >> 2, k = (tid - 16) & 3;
-    const int16_t* g = coef_group(mb, coefs, kMaskChromaDc);
-    int v = 0;
-    if (g) {
-      const int16_t* c = g + 4 * p;
-      const int f = k == 0 ? c[0] + c[1] + c[2] + c[3]
-                  : k == 1 ? c[0] - c[1] + c[2] - c[3]
-                  : k == 2 ? c[0] + c[1] - c[2] - c[3]
-                           : c[0] - c[1] - c[2] + c[3];
-      const int qpc = mb.qpc[p];
-      const int ls = level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, 0);
-      v = ((f * ls) << (qpc / 6)) >> 5;
-    }
-    s_dc[16 + (tid - 16)] = v;
-  }
-  __syncthreads();
-
-  // ---- scaling (8.5.12.1)
-  if (mb.flags & MBF_T8X8) {
-    const int b8 = tid >> 6, k = tid & 63;
-    const int16_t* g = coef_group(mb, coefs, 4 * b8);
-    int v = 0;
-    if (g) {
-      const int lv = g[k];  // the four groups of an 8x8 block are contiguous
-      if (lv) {
-        const int s = lv * level_scale8(pp.scaling8[intra ? 0 : 1], qp, k);
-        v = qp >= 36 ? s << (qp / 6 - 6) : (s + (1 << (5 - qp / 6))) >> (6 - qp / 6);
-      }
-    }
-    dy[tid] = v;
-  } else {
-    const int blk = tid >> 4, k = tid & 15;
-    const int16_t* g = coef_group(mb, coefs, blk);
-    int v = 0;
-    if (g && g[k]) {
-      const int s = g[k] * level_scale4(pp.scaling4[intra ? 0 : 3], qp, k);
-      v = qp >= 24 ? s << (qp / 6 - 4) : (s + (1 << (3 - qp / 6))) >> (4 - qp / 6);
-    }
-    if (k == 0 && mb.kind == MBK_I16x16) v = s_dc[blk];
-    dy[tid] = v;
-  }
-  if (tid < 128) {
-    const int p = tid >> 6, blk = (tid >> 4) & 3, k = tid & 15;
-    const int16_t* g = coef_group(mb, coefs, kMaskChromaAc + 4 * p + blk);
-    int v = 0;
-    const int qpc = mb.qpc[p];
-    if (g && g[k]) {
-      const int s = g[k] * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, k);
-      v = qpc >= 24 ? s << (qpc / 6 - 4) : (s + (1 << (3 - qpc / 6))) >> (4 - qpc / 6);
-    }
-    if (k == 0) v = s_dc[16 + 4 * p + blk];
-    dc[tid] = v;
-  }
-  __syncthreads();
-
-  // ---- rows
-  if (mb.flags & MBF_T8X8) {
-    if (tid < 32) {
-      int* d = dy + (tid >> 3) * 64 + (tid & 7) * 8;
-      const int d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
-      const int e0 = d0 + d4, e1 = -d3 + d5 - d7 - (d7 >> 1), e2 = d0 - d4, e3 = d1 + d7 - d3 - (d3 >> 1);
-      const int e4 = (d2 >> 1) - d6, e5 = -d1 + d7 + d5 + (d5 >> 1), e6 = d2 + (d6 >> 1), e7 = d3 + d5 + d1 + (d1 >> 1);
-      const int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
-      const int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
-      d[0] = f0 + f7; d[1] = f2 + f5; d[2] = f4 + f3; d[3] = f6 + f1;
-      d[4] = f6 - f1; d[5] = f4 - f3; d[6] = f2 - f5; d[7] = f0 - f7;
-    }
-  } else if (tid < 64) {
-    int* d = dy + (tid >> 2) * 16 + (tid & 3) * 4;
-    const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
-    d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
-  }
-  if (tid >= 64 && tid < 96) {
-    const int t = tid - 64;
-    int* d = dc + (t >> 2) * 16 + (t & 3) * 4;
-    const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
-    d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
-  }
-  __syncthreads();
-
-  // ---- columns, rounding, scatter to raster
-  if (mb.flags & MBF_T8X8) {
-    if (tid < 32) {
-      const int b8 = tid >> 3, c = tid & 7;
-      const int* d = dy + b8 * 64 + c;
-      const int d0 = d[0], d1 = d[8], d2 = d[16], d3 = d[24], d4 = d[32], d5 = d[40], d6 = d[48], d7 = d[56];
-      const int e0 = d0 + d4, e1 = -d3 + d5 - d7 - (d7 >> 1), e2 = d0 - d4, e3 = d1 + d7 - d3 - (d3 >> 1);
-      const int e4 = (d2 >> 1) - d6, e5 = -d1 + d7 + d5 + (d5 >> 1), e6 = d2 + (d6 >> 1), e7 = d3 + d5 + d1 + (d1 >> 1);
-      const int f0 = e0 + e6, f1 = e1 + (e7 >> 2), f2 = e2 + e4, f3 = e3 + (e5 >> 2);
-      const int f4 = e2 - e4, f5 = (e3 >> 2) - e5, f6 = e0 - e6, f7 = e7 - (e1 >> 2);
-      const int o[8] = {f0 + f7, f2 + f5, f4 + f3, f6 + f1, f6 - f1, f4 - f3, f2 - f5, f0 - f7};
-      const int x = (b8 & 1) * 8 + c, y0 = (b8 >> 1) * 8;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) res_y[(y0 + r) * 16 + x] = (int16_t)((o[r] + 32) >> 6);
-    }
-  } else if (tid < 64) {
-    const int blk = tid >> 2, c = tid & 3;
-    const int* d = dy + blk * 16 + c;
-    const int e0 = d[0] + d[8], e1 = d[0] - d[8], e2 = (d[4] >> 1) - d[12], e3 = d[4] + (d[12] >> 1);
-    const int x = (blk & 3) * 4 + c, y0 = (blk >> 2) * 4;
-    res_y[(y0 + 0) * 16 + x] = (int16_t)((e0 + e3 + 32) >> 6);
-    res_y[(y0 + 1) * 16 + x] = (int16_t)((e1 + e2 + 32) >> 6);
-    res_y[(y0 + 2) * 16 + x] = (int16_t)((e1 - e2 + 32) >> 6);
-    res_y[(y0 + 3) * 16 + x] = (int16_t)((e0 - e3 + 32) >> 6);
-  }
-  if (tid >= 64 && tid < 96) {
-    const int t = tid - 64, pb = t >> 2, c = t & 3;  // pb = plane*4 + blk
-    const int* d = dc + pb * 16 + c;
-    const int e0 = d[0] + d[8], e1 = d[0] - d[8], e2 = (d[4] >> 1) - d[12], e3 = d[4] + (d[12] >> 1);
-    const int p = pb >> 2, blk = pb & 3;
-    const int x = (blk & 1) * 4 + c, y0 = (blk >> 1) * 4;
-    int16_t* r = res_c + p * 64;
-    r[(y0 + 0) * 8 + x] = (int16_t)((e0 + e3 + 32) >> 6);
-    r[(y0 + 1) * 8 + x] = (int16_t)((e1 + e2 + 32) >> 6);
-    r[(y0 + 2) * 8 + x] = (int16_t)((e1 - e2 + 32) >> 6);
-    r[(y0 + 3) * 8 + x] = (int16_t)((e0 - e3 + 32) >> 6);
-  }
-  __syncthreads();
-}
-
-// ---------------------------------------------------------------------------
-// Motion compensation, one sample (8.4.2.2).  Reference coordinates are
-// clamped to the picture (unrestricted motion vectors).
-// ---------------------------------------------------------------------------
-struct RefPlane {
-  const uint8_t* p;
-  int pitch, w, h;
-};
-__device__ __forceinline__ int rpx(const RefPlane& r, int x, int y) {
-  x = iclip(0, r.w - 1, x);
-  y = iclip(0, r.h - 1, y);
-  return r.p[y * r.pitch + x];
-}
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
-__device__ __forceinline__ int b1(const RefPlane& r, int x, int y) {
-  return tap6(rpx(r, x - 2, y), rpx(r, x - 1, y), rpx(r, x, y), rpx(r, x + 1, y), rpx(r, x + 2, y), rpx(r, x + 3, y));
-}
-__device__ __forceinline__ int h1(const RefPlane& r, int x, int y) {
-  return tap6(rpx(r, x, y - 2), rpx(r, x, y - 1), rpx(r, x, y), rpx(r, x, y + 1), rpx(r, x, y + 2), rpx(r, x, y + 3));
-}
-__device__ int luma_sample(const RefPlane& r, int x, int y, int fx, int fy) {
-  if ((fx | fy) == 0) return rpx(r, x, y);
-  if (fy == 0) {
-    const int b = clip8((b1(r, x, y) + 16) >> 5);
-    return fx == 2 ? b : (fx == 1 ? (rpx(r, x, y) + b + 1) >> 1 : (rpx(r, x + 1, y) + b + 1) >> 1);
-  }
-  if (fx == 0) {
-    const int h = clip8((h1(r, x, y) + 16) >> 5);
-    return fy == 2 ? h : (fy == 1 ? (rpx(r, x, y) + h + 1) >> 1 : (rpx(r, x, y + 1) + h + 1) >> 1);
-  }
-  if (fx == 2 || fy == 2) {
-    const int j1 = tap6(b1(r, x, y - 2), b1(r, x, y - 1), b1(r, x, y), b1(r, x, y + 1), b1(r, x, y + 2), b1(r, x, y + 3));
-    const int j = clip8((j1 + 512) >> 10);
-    if (fx == 2 && fy == 2) return j;
-    if (fx == 2) {
-      const int b = clip8((b1(r, x, fy == 1 ? y : y + 1) + 16) >> 5);
-      return (b + j + 1) >> 1;
-    }
-    const int h = clip8((h1(r, fx == 1 ? x : x + 1, y) + 16) >> 5);
-    return (h + j + 1) >> 1;
-  }
-  const int b = clip8((b1(r, x, fy == 1 ? y : y + 1) + 16) >> 5);
-  const int h = clip8((h1(r, fx == 1 ? x : x + 1, y) + 16) >> 5);
-  return (b + h + 1) >> 1;
-}
-__device__ __forceinline__ int chroma_sample(const RefPlane& r, int x, int y, int fx, int fy) {
-  const int A = rpx(r, x, y), B = rpx(r, x + 1, y), C = rpx(r, x, y + 1), D = rpx(r, x + 1, y + 1);
-  return ((8 - fx) * (8 - fy) * A + fx * (8 - fy) * B + (8 - fx) * fy * C + fx * fy * D + 32) >> 6;
-}
 
 __device__ int implicit_w1(const SliceParams& sp, int r0, int r1) {
   if (sp.ref_long[0][r0] || sp.ref_long[1][r1]) return 32;
@@ -331,102 +130,6 @@ __device__ int combine_pred(const SliceParams& sp, int plane, bool use0, bool us
   return use0 ? s0 : s1;
 }
 
-}  // namespace
-
-// ===========================================================================
-// k_inter: one workgroup (256 threads) per macroblock; intra macroblocks exit.
-// ===========================================================================
-__global__ __launch_bounds__(256) void k_inter(const JobDesc* __restrict__ jobs) {
-  const JobDesc& job = jobs[blockIdx.y];
-  const PictureParams& pp = job.pp;
-  const int mbi = blockIdx.x;
-  if (!job.do_inter || mbi >= pp.mb_width * pp.mb_height) return;
-  const MbInfo* __restrict__ mbs = job.mbs;
-  const MbMotion* __restrict__ motions = job.motions;
-  const int16_t* __restrict__ coefs = job.coefs;
-  const SliceParams* __restrict__ slices = job.slices;
-  const MbInfo mb = mbs[mbi];
-  if (mb.kind != MBK_INTER) return;
-  const int tid = threadIdx.x;
-  const int mbx = mbi % pp.mb_width, mby = mbi / pp.mb_width;
-  __shared__ int work[384];
-  __shared__ int16_t res_y[256];
-  __shared__ int16_t res_c[128];
-  __shared__ MbMotion mo;
-  // stage the motion record (144 B) through LDS
-  if (tid < 36) reinterpret_cast<uint32_t*>(&mo)[tid] = reinterpret_cast<const uint32_t*>(&motions[mbi])[tid];
-  mb_residual(mb, coefs, pp, tid, work, res_y, res_c);  // ends with a barrier
-
-  const SliceParams& sp = slices[mb.slice];
-  const Surface cur = pp.surfaces[pp.cur_slot];
-  const int W = pp.mb_width * 16, H = pp.mb_height * 16;
-  {  // luma: one sample per thread
-    const int x = tid & 15, y = tid >> 4;
-    const int blk = (y >> 2) * 4 + (x >> 2), b8 = (y >> 3) * 2 + (x >> 3);
-    const int r0 = mo.ref_idx[0][b8], r1 = mo.ref_idx[1][b8];
-    const int px = mbx * 16 + x, py = mby * 16 + y;
-    int s0 = 0, s1 = 0;
-    if (r0 >= 0) {
-      const RefPlane rp{pp.surfaces[mo.ref_slot[0][b8]].y, pp.y_pitch, W, H};
-      const int mvx = mo.mv[0][blk][0], mvy = mo.mv[0][blk][1];
-      s0 = luma_sample(rp, px + (mvx >> 2), py + (mvy >> 2), mvx & 3, mvy & 3);
-    }
-    if (r1 >= 0) {
-      const RefPlane rp{pp.surfaces[mo.ref_slot[1][b8]].y, pp.y_pitch, W, H};
-      const int mvx = mo.mv[1][blk][0], mvy = mo.mv[1][blk][1];
-      s1 = luma_sample(rp, px + (mvx >> 2), py + (mvy >> 2), mvx & 3, mvy & 3);
-    }
-    const int pred = combine_pred(sp, 0, r0 >= 0, r1 >= 0, s0, s1, r0, r1);
-    cur.y[py * pp.y_pitch + px] = (uint8_t)clip8(pred + res_y[tid]);
-  }
-  if (tid < 128) {  // chroma: 64 samples per plane
-    const int plane = tid >> 6, x = tid & 7, y = (tid >> 3) & 7;
-    const int blk = (y >> 1) * 4 + (x >> 1), b8 = (y >> 2) * 2 + (x >> 2);
-    const int r0 = mo.ref_idx[0][b8], r1 = mo.ref_idx[1][b8];
-    const int px = mbx * 8 + x, py = mby * 8 + y;
-    int s0 = 0, s1 = 0;
-    if (r0 >= 0) {
-      const Surface& s = pp.surfaces[mo.ref_slot[0][b8]];
-      const RefPlane rp{plane ? s.v : s.u, pp.c_pitch, W / 2, H / 2};
-      const int mvx = mo.mv[0][blk][0], mvy = mo.mv[0][blk][1];
-      s0 = chroma_sample(rp, px + (mvx >> 3), py + (mvy >> 3), mvx & 7, mvy & 7);
-    }
-    if (r1 >= 0) {
-      const Surface& s = pp.surfaces[mo.ref_slot[1][b8]];
-      const RefPlane rp{plane ? s.v : s.u, pp.c_pitch, W / 2, H / 2};
-      const int mvx = mo.mv[1][blk][0], mvy = mo.mv[1][blk][1];
-      s1 = chroma_sample(rp, px + (mvx >> 3), py + (mvy >> 3), mvx & 7, mvy & 7);
-    }
-    const int pred = combine_pred(sp, 1 + plane, r0 >= 0, r1 >= 0, s0, s1, r0, r1);
-    uint8_t* dst = plane ? cur.v : cur.u;
-    dst[py * pp.c_pitch + px] = (uint8_t)clip8(pred + res_c[plane * 64 + y * 8 + x]);
-  }
-}
-
-// ===========================================================================
-// Row pipelines (k_intra, k_deblock).
-//
-// Intra prediction and the deblocking filter have true raster-order
-// dependencies: a macroblock needs its left, top-left, top and top-right
-// neighbours finished.  Rows can run concurrently as long as each stays two
-// macroblocks behind the row above.  Each picture is handled by ONE workgroup
-// of 16 waves; wave w walks rows w, w+16, w+32, ... one macroblock at a time
-// (64 lanes = one macroblock), and rows hand their progress to the row below
-// through counters in LDS.  Consequences:
-//   * no inter-workgroup protocol at all: visibility between waves of one
-//     workgroup needs only workgroup-scope fences (all waves share the CU's
-//     L1), never an agent-scope release/acquire or a cross-CU poll;
-//   * all 16 waves are resident by construction, so the waits cannot
-//     deadlock; a wave only ever waits on a row that started earlier;
-//   * one picture occupies one CU, so up to 256 pictures (lanes) reconstruct
-//     concurrently per GPU -- the parallelism of sparse decoding is across
-//     keyframe-anchored intervals, not inside one picture.
-// ===========================================================================
-namespace {
-
-constexpr int kRowWaves = 16;
-constexpr int kMaxRows = 512;
-
 // everything one wave wrote to LDS is visible to its other lanes afterwards
 __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -434,16 +137,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// progress[r + 1] = macroblocks of row r that are complete; progress[0] is
-// the (always complete) row above the picture
-__device__ __forceinline__ void row_wait(volatile int* progress, int row, int need) {
-  while (progress[row] < need) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-__device__ __forceinline__ void row_publish(volatile int* progress, int row, int done) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // global stores of this wave have landed
-  progress[row + 1] = done;
-}
 
 // ---------------------------------------------------------------------------
 // Residual of one macroblock, computed by ONE wave (64 lanes) into LDS.
@@ -584,6 +277,292 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
     r[(y0 + 3) * 8 + x] = (int16_t)((e0 - e3 + 32) >> 6);
   }
   wave_sync();
+}
+
+
+// ---------------------------------------------------------------------------
+// Motion compensation (8.4.2.2), register resident.
+//
+// A lane predicts 4 horizontally adjacent luma samples (one row of a 4x4
+// block, so one motion vector) and 2 chroma samples.  What the 6-tap filter
+// needs - bytes x-2 .. x+6 of rows y-2 .. y+3, or less when the vector is
+// integer in one direction - is fetched straight from the reference surface
+// as UNALIGNED dwords (gfx950 serves them from the vector L1, which neighbour
+// lanes' overlapping windows keep hot), at most 18 per lane and list, and
+// filtered in registers: no LDS staging, no barrier.  A window that leaves the
+// picture takes a byte-wise path with clamped coordinates (the padding of
+// unrestricted motion vectors); that is decided per lane.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+
+// 12 bytes (3 dwords) of row y starting at column xs, coordinates clamped
+__device__ __forceinline__ void row_clamped(const uint8_t* plane, int pitch, int W, int H, int xs, int y, int nd,
+                                            uint32_t* w) {
+  const uint8_t* row = plane + (size_t)iclip(0, H - 1, y) * pitch;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d >= nd) break;
+    uint32_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) v |= (uint32_t)row[iclip(0, W - 1, xs + 4 * d + b)] << (8 * b);
+    w[d] = v;
+  }
+}
+
+#define BYTE_OF(w, k) (((w)[(k) >> 2] >> (8 * ((k) & 3))) & 0xff)
+
+__device__ __forceinline__ int tap6_row(const uint32_t* w, int i) {  // bytes i .. i+5 of the row
+  return tap6(BYTE_OF(w, i), BYTE_OF(w, i + 1), BYTE_OF(w, i + 2), BYTE_OF(w, i + 3), BYTE_OF(w, i + 4), BYTE_OF(w, i + 5));
+}
+
+// plane: reference luma; (px, py): position of the lane's first sample; mv in quarter samples
+__device__ __forceinline__ void luma_pred4(const uint8_t* plane, int pitch, int W, int H, int px, int py, int mvx,
+                                           int mvy, int* out) {
+  const int fx = mvx & 3, fy = mvy & 3;
+  const int x = px + (mvx >> 2), y = py + (mvy >> 2);
+  const bool horiz = fx != 0, vert = fy != 0;
+  const int xs = horiz ? x - 2 : x;      // first byte that is used
+  const int nd = horiz ? 3 : 1;          // dwords per row (9 resp. 4 bytes used)
+  const int r0 = vert ? 0 : 2, r1 = vert ? 5 : 2;  // rows y-2+r
+  const bool inside = xs >= 0 && xs + (horiz ? 9 : 4) <= W && y - 2 + r0 >= 0 && y - 2 + r1 < H;
+  uint32_t w[6][3];
+  if (inside) {
+    const uint8_t* base = plane + (size_t)(y - 2) * pitch + xs;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      if (r < r0 || r > r1) continue;
+      w[r][0] = ld32u(base + r * pitch);
+      if (horiz) {
+        w[r][1] = ld32u(base + r * pitch + 4);
+        w[r][2] = ld32u(base + r * pitch + 8);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      if (r < r0 || r > r1) continue;
+      row_clamped(plane, pitch, W, H, xs, y - 2 + r, nd, w[r]);
+    }
+  }
+  if (!horiz && !vert) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = BYTE_OF(w[2], i);
+    return;
+  }
+  if (!vert) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = clip8((tap6_row(w[2], i) + 16) >> 5);
+      out[i] = fx == 2 ? b : ((fx == 1 ? BYTE_OF(w[2], i + 2) : BYTE_OF(w[2], i + 3)) + b + 1) >> 1;
+    }
+    return;
+  }
+  if (!horiz) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int h = clip8((tap6(BYTE_OF(w[0], i), BYTE_OF(w[1], i), BYTE_OF(w[2], i), BYTE_OF(w[3], i), BYTE_OF(w[4], i),
+                                BYTE_OF(w[5], i)) + 16) >> 5);
+      out[i] = fy == 2 ? h : ((fy == 1 ? BYTE_OF(w[2], i) : BYTE_OF(w[3], i)) + h + 1) >> 1;
+    }
+    return;
+  }
+  if (fx == 2 || fy == 2) {
+    int j1[4] = {0, 0, 0, 0}, bsel[4] = {0, 0, 0, 0};
+    const int brow = fy == 3 ? 3 : 2;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+      const int wt = (r == 0 || r == 5) ? 1 : ((r == 1 || r == 4) ? -5 : 20);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int bb = tap6_row(w[r], i);
+        j1[i] += wt * bb;
+        if (r == brow) bsel[i] = bb;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = clip8((j1[i] + 512) >> 10);
+      if (fx == 2 && fy == 2) {
+        out[i] = j;
+      } else if (fx == 2) {
+        out[i] = (clip8((bsel[i] + 16) >> 5) + j + 1) >> 1;
+      } else {
+        const int c = i + 2 + (fx == 3);  // column of the half sample h; resolved per lane below
+        const int h = fx == 3 ? tap6(BYTE_OF(w[0], i + 3), BYTE_OF(w[1], i + 3), BYTE_OF(w[2], i + 3), BYTE_OF(w[3], i + 3),
+                                     BYTE_OF(w[4], i + 3), BYTE_OF(w[5], i + 3))
+                              : tap6(BYTE_OF(w[0], i + 2), BYTE_OF(w[1], i + 2), BYTE_OF(w[2], i + 2), BYTE_OF(w[3], i + 2),
+                                     BYTE_OF(w[4], i + 2), BYTE_OF(w[5], i + 2));
+        (void)c;
+        out[i] = (clip8((h + 16) >> 5) + j + 1) >> 1;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int bb = fy == 3 ? tap6_row(w[3], i) : tap6_row(w[2], i);
+    const int h = fx == 3 ? tap6(BYTE_OF(w[0], i + 3), BYTE_OF(w[1], i + 3), BYTE_OF(w[2], i + 3), BYTE_OF(w[3], i + 3),
+                                 BYTE_OF(w[4], i + 3), BYTE_OF(w[5], i + 3))
+                          : tap6(BYTE_OF(w[0], i + 2), BYTE_OF(w[1], i + 2), BYTE_OF(w[2], i + 2), BYTE_OF(w[3], i + 2),
+                                 BYTE_OF(w[4], i + 2), BYTE_OF(w[5], i + 2));
+    out[i] = (clip8((bb + 16) >> 5) + clip8((h + 16) >> 5) + 1) >> 1;
+  }
+}
+
+// two horizontally adjacent chroma samples (8.4.2.2.2); mv in eighth samples
+__device__ __forceinline__ void chroma_pred2(const uint8_t* plane, int pitch, int W, int H, int px, int py, int mvx,
+                                             int mvy, int* out) {
+  const int fx = mvx & 7, fy = mvy & 7;
+  const int x = px + (mvx >> 3), y = py + (mvy >> 3);
+  uint32_t a, c;
+  if (x >= 0 && x + 3 <= W && y >= 0 && y + 1 < H) {
+    a = ld32u(plane + (size_t)y * pitch + x);
+    c = ld32u(plane + (size_t)(y + 1) * pitch + x);
+  } else {
+    uint32_t t[3];
+    row_clamped(plane, pitch, W, H, x, y, 1, t);
+    a = t[0];
+    row_clamped(plane, pitch, W, H, x, y + 1, 1, t);
+    c = t[0];
+  }
+  const int a0 = a & 0xff, a1 = (a >> 8) & 0xff, a2 = (a >> 16) & 0xff;
+  const int c0 = c & 0xff, c1 = (c >> 8) & 0xff, c2 = (c >> 16) & 0xff;
+  out[0] = ((8 - fx) * (8 - fy) * a0 + fx * (8 - fy) * a1 + (8 - fx) * fy * c0 + fx * fy * c1 + 32) >> 6;
+  out[1] = ((8 - fx) * (8 - fy) * a1 + fx * (8 - fy) * a2 + (8 - fx) * fy * c1 + fx * fy * c2 + 32) >> 6;
+}
+
+constexpr int kInterWaves = 4;
+struct InterWave {
+  int work[384];
+  int dcs[24];
+  int16_t res_y[256];
+  int16_t res_c[128];
+};
+
+}  // namespace
+
+// ===========================================================================
+// k_inter: one WAVE per inter macroblock, four macroblocks (64 luma bytes per
+// row) per workgroup, no workgroup barriers.  Per macroblock:
+//   residual (dequant + IDCT) into LDS unless nothing was coded,
+//   each lane predicts 4 luma + 2 chroma samples per list in registers,
+//   weighted combination, + residual, one dword / one halfword store.
+// Workgroups are numbered so that each XCD (blockIdx % 8) owns a contiguous
+// band of the picture: its L2 then sees whole cache lines of the output and
+// the overlapping reference windows of neighbouring macroblocks.
+// ===========================================================================
+__global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.y];
+  const PictureParams& pp = job.pp;
+  if (!job.do_inter) return;
+  const int nmb = pp.mb_width * pp.mb_height;
+  const int ngroups = (nmb + kInterWaves - 1) / kInterWaves;
+  const int band = (ngroups + 7) / 8;
+  const int group = (blockIdx.x % 8) * band + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= band || group >= ngroups) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int mbi = group * kInterWaves + wave;
+  if (mbi >= nmb) return;
+  const MbMotion* __restrict__ mo = job.motions + mbi;
+  // the lane's motion data: luma block (row y, 4x4 column lane&3), chroma block
+  const int y = lane >> 2, bcol = lane & 3;
+  const int blk = (y >> 2) * 4 + bcol, b8 = (y >> 3) * 2 + (bcol >> 1);
+  const int cplane = lane >> 5, ct = lane & 31, cy = ct >> 2, cbcol = ct & 3;
+  const int cblk = (cy >> 1) * 4 + cbcol, cb8 = (cy >> 2) * 2 + (cbcol >> 1);
+  const uint32_t mvw0 = reinterpret_cast<const uint32_t*>(mo->mv[0])[blk];
+  const uint32_t mvw1 = reinterpret_cast<const uint32_t*>(mo->mv[1])[blk];
+  const uint32_t cmvw0 = reinterpret_cast<const uint32_t*>(mo->mv[0])[cblk];
+  const uint32_t cmvw1 = reinterpret_cast<const uint32_t*>(mo->mv[1])[cblk];
+  const uint32_t slots0 = *reinterpret_cast<const uint32_t*>(mo->ref_slot[0]);
+  const uint32_t slots1 = *reinterpret_cast<const uint32_t*>(mo->ref_slot[1]);
+  const uint32_t idx0 = *reinterpret_cast<const uint32_t*>(mo->ref_idx[0]);
+  const uint32_t idx1 = *reinterpret_cast<const uint32_t*>(mo->ref_idx[1]);
+  const MbInfo mb = job.mbs[mbi];
+  if (mb.kind != MBK_INTER) return;
+  __shared__ InterWave lds[kInterWaves];
+  InterWave& L = lds[wave];
+  const int mbx = mbi % pp.mb_width, mby = mbi / pp.mb_width;
+  const bool has_res = mb.coded_mask != 0;
+  if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+
+  const SliceParams& sp = job.slices[mb.slice];
+  const Surface cur = pp.surfaces[pp.cur_slot];
+  const int W = pp.mb_width * 16, H = pp.mb_height * 16;
+  auto byte_of = [](uint32_t w, int k) { return (int)(int8_t)((w >> (8 * k)) & 0xff); };
+  {  // luma
+    const int r0 = byte_of(idx0, b8), r1 = byte_of(idx1, b8);
+    const int px = mbx * 16 + bcol * 4, py = mby * 16 + y;
+    int s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+    if (r0 >= 0)
+      luma_pred4(pp.surfaces[byte_of(slots0, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
+    if (r1 >= 0)
+      luma_pred4(pp.surfaces[byte_of(slots1, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pred = combine_pred(sp, 0, r0 >= 0, r1 >= 0, s0[i], s1[i], r0, r1);
+      const int v = has_res ? clip8(pred + L.res_y[y * 16 + bcol * 4 + i]) : pred;
+      packed |= (uint32_t)v << (8 * i);
+    }
+    *reinterpret_cast<uint32_t*>(cur.y + (size_t)py * pp.y_pitch + px) = packed;
+  }
+  {  // chroma: lanes 0..31 Cb, 32..63 Cr
+    const int r0 = byte_of(idx0, cb8), r1 = byte_of(idx1, cb8);
+    const int px = mbx * 8 + cbcol * 2, py = mby * 8 + cy;
+    int s0[2] = {0, 0}, s1[2] = {0, 0};
+    if (r0 >= 0) {
+      const Surface& sf = pp.surfaces[byte_of(slots0, cb8)];
+      chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
+    }
+    if (r1 >= 0) {
+      const Surface& sf = pp.surfaces[byte_of(slots1, cb8)];
+      chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
+    }
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int pred = combine_pred(sp, 1 + cplane, r0 >= 0, r1 >= 0, s0[i], s1[i], r0, r1);
+      const int v = has_res ? clip8(pred + L.res_c[cplane * 64 + cy * 8 + cbcol * 2 + i]) : pred;
+      packed |= (uint32_t)v << (8 * i);
+    }
+    uint8_t* dst = cplane ? cur.v : cur.u;
+    *reinterpret_cast<uint16_t*>(dst + (size_t)py * pp.c_pitch + px) = (uint16_t)packed;
+  }
+}
+
+// ===========================================================================
+// Row pipelines (k_intra, k_deblock).
+//
+// Intra prediction and the deblocking filter have true raster-order
+// dependencies: a macroblock needs its left, top-left, top and top-right
+// neighbours finished.  Rows can run concurrently as long as each stays two
+// macroblocks behind the row above.  Each picture is handled by ONE workgroup
+// of 16 waves; wave w walks rows w, w+16, w+32, ... one macroblock at a time
+// (64 lanes = one macroblock), and rows hand their progress to the row below
+// through counters in LDS.  Consequences:
+//   * no inter-workgroup protocol at all: visibility between waves of one
+//     workgroup needs only workgroup-scope fences (all waves share the CU's
+//     L1), never an agent-scope release/acquire or a cross-CU poll;
+//   * all 16 waves are resident by construction, so the waits cannot
+//     deadlock; a wave only ever waits on a row that started earlier;
+//   * one picture occupies one CU, so up to 256 pictures (lanes) reconstruct
+//     concurrently per GPU -- the parallelism of sparse decoding is across
+//     keyframe-anchored intervals, not inside one picture.
+// ===========================================================================
+namespace {
+
+constexpr int kRowWaves = 16;
+constexpr int kMaxRows = 512;
+
+// progress[r + 1] = macroblocks of row r that are complete; progress[0] is
+// the (always complete) row above the picture
+__device__ __forceinline__ void row_wait(volatile int* progress, int row, int need) {
+  while (progress[row] < need) __builtin_amdgcn_s_sleep(1);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void row_publish(volatile int* progress, int row, int done) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // global stores of this wave have landed
+  progress[row + 1] = done;
 }
 
 // ---- intra prediction helpers working on an LDS tile -----------------------
@@ -1315,7 +1294,8 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_in
   prof::Span span;
   if (any_inter) {
     if (profiled) span = prof::begin(stream);
-    hipLaunchKernelGGL(k_inter, dim3(max_mbs, njobs), dim3(256), 0, stream, jobs);
+    hipLaunchKernelGGL(k_inter, dim3(((max_mbs + kInterWaves - 1) / kInterWaves + 7) / 8 * 8, njobs), dim3(kInterWaves * 64), 0,
+                       stream, jobs);
     if (profiled) prof::end(span, stream, prof::K_INTER, bytes[0]);
   }
   if (any_intra) {

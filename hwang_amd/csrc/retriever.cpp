@@ -2,33 +2,62 @@
 
 #include <algorithm>
 #include <chrono>
+#include <pthread.h>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 
 namespace hwang {
 
+// CPUs this process may actually use: hardware threads, capped by a cgroup
+// CPU-bandwidth quota when there is one (cgroup v2 cpu.max, v1 cfs_quota).
+// Entropy decoding is what lanes spend CPU on; more lanes than CPUs only
+// makes the quota throttle the whole process in bursts.
+int32_t ParallelRetriever::effective_cpus() {
+  unsigned hw = std::thread::hardware_concurrency();
+  double cpus = hw ? hw : 4;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32];
+    long period = 0;
+    if (fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && quota[0] != 'm')
+      cpus = std::min(cpus, atof(quota) / period);
+    fclose(f);
+  } else {
+    long q = -1, per = 0;
+    if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+      if (fscanf(fq, "%ld", &q) != 1) q = -1;
+      fclose(fq);
+    }
+    if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+      if (fscanf(fp, "%ld", &per) != 1) per = 0;
+      fclose(fp);
+    }
+    if (q > 0 && per > 0) cpus = std::min(cpus, static_cast<double>(q) / per);
+  }
+  return std::max<int32_t>(1, static_cast<int32_t>(cpus + 0.5));
+}
+
 ParallelRetriever* ParallelRetriever::make(DeviceHandle device,
                                            VideoDecoderType type,
                                            int32_t num_lanes) {
-  if (num_lanes <= 0) {
-    unsigned hw = std::thread::hardware_concurrency();
-    num_lanes = static_cast<int32_t>(std::min<unsigned>(hw ? hw : 4, 16));
-  }
+  if (num_lanes <= 0) num_lanes = std::min<int32_t>(effective_cpus(), 128);
   std::unique_ptr<ParallelRetriever> r(new ParallelRetriever());
   r->lanes_.resize(num_lanes);
   for (Lane& lane : r->lanes_) {
-    lane.backend.reset(VideoDecoderFactory::make_from_config(device, 1, type));
-    if (!lane.backend) return nullptr;
+    for (auto& b : lane.backend) {
+      b.reset(VideoDecoderFactory::make_from_config(device, 1, type));
+      if (!b) return nullptr;
+    }
   }
   return r.release();
 }
 
 ParallelRetriever::~ParallelRetriever() {}
 
-Result ParallelRetriever::run_item(Lane& lane, const WorkItem& item,
+Result ParallelRetriever::run_item(Lane& lane, VideoDecoderInterface* dec, const WorkItem& item,
                                    const VideoIndex& index, const uint8_t* file,
                                    size_t file_size, uint8_t* out,
                                    size_t frame_bytes, bool yuv) {
-  VideoDecoderInterface* dec = lane.backend.get();
   auto* hints = dynamic_cast<SparseDecodeHints*>(dec);
   auto* planar = dynamic_cast<PlanarOutput*>(dec);
   if (yuv && !planar) {
@@ -157,12 +186,26 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
   }
   for (size_t i = 0; i < items.size(); ++i) items[i].valid = &item_rows[i];
   stats_.intervals = static_cast<int64_t>(items.size());
-  // Longest first, pulled from a shared cursor: greedy LPT balance.
+  // Order of the shared work queue.  Longest-first (LPT) balances the tail,
+  // but sorted items keep all lanes in lock-step: every lane reaches its next
+  // keyframe at the same moment, the GPU sees a burst of intra-only pictures
+  // followed by a burst of P pictures, and the two engines take turns instead
+  // of overlapping.  So only the shortest quarter stays sorted (at the end,
+  // where it evens out the finish); everything before it is shuffled with a
+  // fixed seed.
   std::vector<size_t> order(items.size());
   for (size_t i = 0; i < order.size(); ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
     return items[a].cost > items[b].cost;
   });
+  if (order.size() > 2 * lanes_.size()) {
+    uint64_t state = 0x9e3779b97f4a7c15ull;
+    const size_t head = order.size() - order.size() / 4;
+    for (size_t i = head - 1; i > 0; --i) {
+      state = state * 6364136223846793005ull + 1442695040888963407ull;
+      std::swap(order[i], order[(state >> 33) % (i + 1)]);
+    }
+  }
 
   VideoDecoderInterface::FrameInfo info;
   info.width = index.frame_width();
@@ -180,16 +223,22 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
     lane.frames_returned = 0;
     threads.emplace_back([&, li]() {
       Lane& lane = lanes_[li];
-      if (auto* c = dynamic_cast<CountedBackend*>(lane.backend.get()))
-        c->reset_counters();
-      Result r = lane.backend->configure(info, index.metadata_bytes());
+      pthread_setname_np(pthread_self(), "hw-lane");
+      Result r;
+      for (auto& b : lane.backend) {
+        if (auto* c = dynamic_cast<CountedBackend*>(b.get())) c->reset_counters();
+        if (r.ok) r = b->configure(info, index.metadata_bytes());
+      }
+      int turn = 0;
       while (r.ok && !abort.load()) {
         size_t k = cursor.fetch_add(1);
         if (k >= order.size()) break;
-        r = run_item(lane, items[order[k]], index, file, file_size, out,
+        r = run_item(lane, lane.backend[turn].get(), items[order[k]], index, file, file_size, out,
                      frame_bytes, yuv);
+        turn = (turn + 1) % kBackendsPerLane;
       }
-      if (r.ok) r = lane.backend->wait_until_frames_copied();
+      for (auto& b : lane.backend)
+        if (r.ok) r = b->wait_until_frames_copied();
       if (!r.ok) abort.store(true);
       lane.result = r;
     });
@@ -202,13 +251,15 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
     if (!lane.result.ok && result.ok) result = lane.result;
     stats_.samples_fed += lane.samples_fed;
     stats_.frames_returned += lane.frames_returned;
-    if (auto* c = dynamic_cast<CountedBackend*>(lane.backend.get())) {
-      BackendCounters bc = c->counters();
-      stats_.pictures_reconstructed += bc.pictures_reconstructed;
-      stats_.pictures_skipped += bc.pictures_skipped;
-      stats_.bytes_uploaded += bc.bytes_uploaded;
-      stats_.entropy_ns += bc.entropy_ns;
-      stats_.stall_ns += bc.stall_ns;
+    for (auto& b : lane.backend) {
+      if (auto* c = dynamic_cast<CountedBackend*>(b.get())) {
+        BackendCounters bc = c->counters();
+        stats_.pictures_reconstructed += bc.pictures_reconstructed;
+        stats_.pictures_skipped += bc.pictures_skipped;
+        stats_.bytes_uploaded += bc.bytes_uploaded;
+        stats_.entropy_ns += bc.entropy_ns;
+        stats_.stall_ns += bc.stall_ns;
+      }
     }
   }
   stats_.wall_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(

@@ -2,8 +2,11 @@
 // (Decoder.retrieve) in one native call, with the plan's keyframe-anchored
 // intervals fanned out over independent lanes.
 //
-// A lane = one host thread + one backend instance (for the AMD backend: one
-// HIP stream, one DPB, one pinned staging ring).  Intervals are independent
+// A lane = one host thread + two backend instances (for the AMD backend: a
+// DPB of surfaces in HBM and a pinned staging ring each) used alternately, so
+// that the thread is already parsing the next interval - whose keyframe takes
+// the long intra-only path on the GPU - while the previous interval's last
+// pictures are still being reconstructed.  Intervals are independent
 // (closed GOPs) so lanes never exchange data; each writes its
 // frames straight into the caller's output at the row's position.  Compared
 // with the reference's per-interval loop this
@@ -40,7 +43,8 @@ class ParallelRetriever {
     int64_t wall_ns = 0;
   };
 
-  // num_lanes <= 0 picks min(hardware threads, 16).
+  // num_lanes <= 0 picks one lane per CPU the process may use (effective_cpus).
+  static int32_t effective_cpus();
   static ParallelRetriever* make(DeviceHandle device, VideoDecoderType type,
                                  int32_t num_lanes);
   ~ParallelRetriever();
@@ -61,15 +65,16 @@ class ParallelRetriever {
     size_t out_slot = 0;                    // position of valid[0] in rows
     uint64_t cost = 0;
   };
+  static constexpr int kBackendsPerLane = 2;
   struct Lane {
-    std::unique_ptr<VideoDecoderInterface> backend;
+    std::unique_ptr<VideoDecoderInterface> backend[kBackendsPerLane];
     Result result;
     int64_t samples_fed = 0;
     int64_t frames_returned = 0;
   };
 
   ParallelRetriever() {}
-  Result run_item(Lane& lane, const WorkItem& item, const VideoIndex& index,
+  Result run_item(Lane& lane, VideoDecoderInterface* dec, const WorkItem& item, const VideoIndex& index,
                   const uint8_t* file, size_t file_size, uint8_t* out,
                   size_t frame_bytes, bool yuv);
 

@@ -58,3 +58,34 @@ if qkey:
         print("queue %s: kernels %d busy %.3f s span %.3f s (%.0f%%) median gap %.1f us, gaps>1ms: %d (sum %.3f s) kernels=%s" % (
             q, len(ev), busy / 1e9, span / 1e9, 100.0 * busy / max(span, 1), sorted(gaps)[len(gaps) // 2] / 1e3 if gaps else 0,
             sum(1 for g in gaps if g > 1e6), sum(g for g in gaps if g > 1e6) / 1e9, ",".join(names)))
+
+# ---- a slice of the timeline (all queues), steady state
+if len(sys.argv) > 2:
+    at = float(sys.argv[2])  # fraction of the window
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 80
+    ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r[qkey] if qkey else "?",
+                 r["Kernel_Name"].split("(")[0].split("::")[-1][:14],
+                 int(r.get("Grid_Size_X", 0)) // max(1, int(r.get("Workgroup_Size_X", 1))), int(r.get("Grid_Size_Y", 1)))
+                for r in rows)
+    start = t0 + int((t1 - t0) * at)
+    sel = [e for e in ev if e[0] >= start][:n]
+    print()
+    for s, e, q, name, gx, gy in sel:
+        print("t=%9.3f ms  q%s  %-14s grid %5d x %4d  dur %8.1f us" % ((s - start) / 1e6, q, name, gx, gy, (e - s) / 1e3))
+
+# ---- the largest idle gaps of the busiest queue, and what ran elsewhere meanwhile
+if qkey:
+    busiest = max(byq.items(), key=lambda kv: len(kv[1]))[0]
+    ev = sorted(byq[busiest])
+    gaps = sorted(((ev[i + 1][0] - ev[i][1], ev[i][1], ev[i + 1][0]) for i in range(len(ev) - 1)), reverse=True)[:12]
+    print()
+    print("largest gaps on queue", busiest)
+    for g, gs, ge in sorted(gaps, key=lambda x: x[1]):
+        other = defaultdict(int)
+        for q, evq in byq.items():
+            if q == busiest:
+                continue
+            for s, e, nme in evq:
+                if s < ge and e > gs:
+                    other[nme] += 1
+        print("  at %8.1f ms  gap %7.2f ms  other queues: %s" % ((gs - t0) / 1e6, g / 1e6, dict(other)))

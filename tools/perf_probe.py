@@ -29,6 +29,12 @@ idx = hw.index_video(path)
 n = idx.frames()
 rng = np.random.default_rng(20240601)
 rows = sorted(rng.choice(n, max(1, round(0.01 * n)), replace=False).tolist())
+if os.environ.get("ROWS_MODE") == "keyframes":   # intra-only path in isolation
+    kf = idx.keyframe_indices()
+    rows = sorted(rng.choice(kf, min(len(kf), len(rows)), replace=False).tolist())
+elif os.environ.get("ROWS_MODE") == "gopend":    # longest P chains
+    kf = idx.keyframe_indices()
+    rows = sorted(set(int(k) - 3 for k in rng.choice(kf[1:], min(len(kf) - 1, len(rows)), replace=False)))
 print("frames", n, "rows", len(rows))
 import torch
 out = torch.empty((len(rows), H, W, 3), dtype=torch.uint8, device="cuda")
@@ -41,6 +47,20 @@ for lanes in [int(x) for x in os.environ.get("LANES", "1,4,16,32,64").split(",")
         dt = time.time() - t
         best = dt if best is None else min(best, dt)
     st = dec.stats()
+    if os.environ.get("CPU_ACCOUNT"):
+        # CPU seconds per thread name since process start (lane threads are re-created per retrieve)
+        import collections, glob
+        acc = collections.Counter()
+        for f in glob.glob("/proc/self/task/*/stat"):
+            try:
+                txt = open(f).read()
+            except OSError:
+                continue
+            name = txt[txt.index("(") + 1:txt.rindex(")")]
+            fields = txt[txt.rindex(")") + 2:].split()
+            acc[name] += (int(fields[11]) + int(fields[12])) / os.sysconf("SC_CLK_TCK")
+        t = os.times()
+        print("   process cpu user %.1f s sys %.1f s; live threads by name: %s" % (t.user, t.system, dict(acc.most_common(8))))
     print("lanes %3d: %.3fs  returned %.1f fps  reconstructed %.0f pics/s  fed %d skipped %d entropy %.2fs stall %.2fs (sum over lanes) upload %.1f MB" % (
         lanes, best, len(rows) / best, st["pictures_reconstructed"] / best, st["samples_fed"], st["pictures_skipped"],
         st["entropy_ns"] / 1e9, st["stall_ns"] / 1e9, st["bytes_uploaded"] / 1e6))
