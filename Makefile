@@ -6,7 +6,7 @@
 # hipcc cross-compiles without a GPU.  `make -j8` is fine on this box.
 HIPCC      ?= /opt/rocm/bin/hipcc
 ARCH       ?= gfx950
-CXXFLAGS   := -std=c++17 -O2 -fPIC -Wall -Wno-unused-function -pthread
+CXXFLAGS   := -std=c++17 -O3 -march=x86-64-v3 -fPIC -Wall -Wno-unused-function -pthread
 HIPFLAGS   := --offload-arch=$(ARCH) $(CXXFLAGS)
 CSRC       := hwang_amd/csrc
 BUILD      := build/obj

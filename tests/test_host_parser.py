@@ -1,0 +1,95 @@
+"""Host half of the MI355X backend on CPU (hwang_h264_probe: entropy decode,
+MV derivation, DPB, output order, sparse skipping - no GPU involved).
+
+* every slice of every corpus configuration ends exactly on
+  rbsp_trailing_bits (a CABAC/CAVLC desync cannot hide), one output per sample;
+* slice / picture counts agree with the oracle decoding the same file;
+* the digest of all records the kernels would receive equals
+  tests/golden/parser_digest.json, frozen from a build whose GPU output was
+  bit-exact against the oracle (regenerate with
+  `python -m tests.test_host_parser` only after `pytest -m gpu` is green);
+* sparse hints skip exactly the unwanted non-reference pictures."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.corpus_util import MATRIX, make_clip
+from tests.util import REALSHORT, ROOT, have_file
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "parser_digest.json")
+
+
+def probe(hw, path, wanted=None):
+    from hwang_amd._capi import lib
+    idx = hw.index_video(path)
+    data = np.fromfile(path, dtype=np.uint8)
+    offs = np.ascontiguousarray(idx.sample_offsets_np().astype(np.uint64))
+    sizes = np.ascontiguousarray(idx.sample_sizes_np().astype(np.uint64))
+    avcc = bytes(idx.metadata_bytes())
+    out = (C.c_int64 * 8)()
+    err = C.create_string_buffer(256)
+    w = np.asarray(wanted if wanted is not None else [], dtype=np.uint64)
+    rc = lib.hwang_h264_probe(avcc, len(avcc), data.ctypes.data_as(C.POINTER(C.c_uint8)),
+                              offs.ctypes.data_as(C.POINTER(C.c_uint64)), sizes.ctypes.data_as(C.POINTER(C.c_uint64)),
+                              idx.frames(), w.ctypes.data_as(C.POINTER(C.c_uint64)) if len(w) else None, len(w), out,
+                              err, 256)
+    assert rc == 0, err.value
+    keys = ("slices", "clean_end", "pictures", "skipped", "outputs", "outputs_skipped", "coefficients", "digest")
+    return idx, dict(zip(keys, list(out)))
+
+
+def golden():
+    return json.load(open(GOLDEN)) if os.path.exists(GOLDEN) else {}
+
+
+@pytest.mark.parametrize("name,kw", MATRIX, ids=[m[0] for m in MATRIX])
+def test_corpus_clip(hw, oracle, tmp_path, name, kw):
+    path = str(tmp_path / (name + ".mp4"))
+    make_clip(path, yuv=False, **kw)
+    idx, r = probe(hw, path)
+    assert r["slices"] == r["clean_end"] > 0
+    assert r["pictures"] == r["outputs"] == idx.frames() and r["skipped"] == 0
+    _, c = oracle.decode_file(path, idx)
+    assert c["slices"] == r["slices"] and c["pictures"] == r["pictures"]
+    assert probe(hw, path)[1]["digest"] == r["digest"]  # deterministic
+    g = golden()
+    assert name in g, "no golden digest for %s (run python -m tests.test_host_parser)" % name
+    assert g[name] == {k: r[k] for k in ("slices", "coefficients", "digest")}
+
+
+def test_sparse_hint_skips_only_unwanted_non_reference(hw, tmp_path):
+    path = str(tmp_path / "ibp.mp4")
+    make_clip(path, yuv=False, frames=13, gop=13, bframes=2, cabac=1, t8x8=1, refs=2)
+    idx, full = probe(hw, path)
+    # display order I B B P B B P ...: wanting only P/I positions skips all 8 B pictures
+    idx, r = probe(hw, path, wanted=[0, 3, 6, 12])
+    assert r["outputs"] == idx.frames()
+    assert r["skipped"] == r["outputs_skipped"] == 8
+    assert r["pictures"] == full["pictures"] - 8 and r["slices"] == r["clean_end"]
+    # wanting a B picture decodes that one
+    _, r2 = probe(hw, path, wanted=[1, 12])
+    assert r2["skipped"] == 7
+
+
+@pytest.mark.skipif(not have_file(REALSHORT), reason="realshort.mp4 not in this image")
+def test_real_x264_stream(hw):
+    idx, r = probe(hw, REALSHORT)
+    assert r["slices"] == r["clean_end"] == r["pictures"] == idx.frames() == 36
+
+
+if __name__ == "__main__":  # regenerate the golden digests
+    import tempfile
+
+    import hwang_amd
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, kw in MATRIX:
+            p = os.path.join(tmp, name + ".mp4")
+            make_clip(p, yuv=False, **kw)
+            r = probe(hwang_amd, p)[1]
+            out[name] = {k: r[k] for k in ("slices", "coefficients", "digest")}
+    json.dump(out, open(GOLDEN, "w"), indent=1, sort_keys=True)
+    print("wrote", GOLDEN)

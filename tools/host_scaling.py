@@ -30,7 +30,7 @@ def work(tid, res):
     out = (C.c_int64 * 8)()
     err = C.create_string_buffer(256)
     # ONE probe call (one parser, one set of buffers) over GOPS consecutive GOPs
-    k = (tid * GOPS) % (len(kf) - 1 - GOPS)
+    k = (tid * GOPS) % max(1, len(kf) - GOPS)
     a, b = kf[k], kf[k + GOPS]
     o = np.ascontiguousarray(offs[a:b])
     s = np.ascontiguousarray(sizes[a:b])
