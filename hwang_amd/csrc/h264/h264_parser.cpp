@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <emmintrin.h>
 
 namespace hwang {
 namespace h264 {
@@ -83,6 +84,26 @@ struct Bits {
 // `extra` prefetched stream bits, so renormalisation is a counter decrement
 // and the stream is touched once per byte instead of once per bit.
 // ---------------------------------------------------------------------------
+// CABAC decoding engine (9.3.1.2, 9.3.3.2).  `value` holds the arithmetic
+// decoder's offset scaled by 2^extra: `extra` bits of the stream beyond the
+// nine the standard keeps are already shifted in, so renormalisation is a
+// shift of `range` plus bookkeeping and the bitstream is touched once per 32
+// bits.  Decisions are branch-free (the LPS/MPS outcome is data, not control
+// flow - about half of all bins sit in contexts near p = 0.5 and mispredict).
+struct CabacTables {
+  uint8_t next[128][2];   // [state = pStateIdx << 1 | valMPS][0 MPS taken, 1 LPS taken]
+  uint8_t lps[4][128];    // [qCodIRangeIdx][state]
+  CabacTables() {
+    for (int st = 0; st < 128; ++st) {
+      const int ps = st >> 1, mps = st & 1;
+      next[st][0] = static_cast<uint8_t>(((ps < 62 ? ps + 1 : ps) << 1) | mps);
+      next[st][1] = static_cast<uint8_t>((cabac_trans_lps[ps] << 1) | (ps == 0 ? !mps : mps));
+      for (int q = 0; q < 4; ++q) lps[q][st] = cabac_range_lps[ps][q];
+    }
+  }
+};
+static const CabacTables g_cabac_tables;
+
 struct Cabac {
   const uint8_t* p = nullptr;
   const uint8_t* end = nullptr;
@@ -93,7 +114,16 @@ struct Cabac {
   bool overrun = false;
   uint8_t state[CABAC_CTX_COUNT];
 
+  // called with extra < 8 (or -9 at the start): afterwards extra >= 24
   void refill() {
+    if (extra >= 0 && p + 4 <= end) {
+      const uint32_t w = (static_cast<uint32_t>(p[0]) << 24) | (static_cast<uint32_t>(p[1]) << 16) |
+                         (static_cast<uint32_t>(p[2]) << 8) | p[3];
+      p += 4;
+      value = (value << 32) | w;
+      extra += 32;
+      return;
+    }
     while (extra < 24) {
       uint32_t b = 0;
       if (p < end) b = *p;
@@ -126,39 +156,29 @@ struct Cabac {
     }
   }
   inline int bin(int ctx) {
-    int ps = state[ctx] >> 1, mps = state[ctx] & 1;
-    const uint32_t lps = cabac_range_lps[ps][(range >> 6) & 3];
-    range -= lps;
-    const uint64_t scaled = static_cast<uint64_t>(range) << extra;
-    int b;
-    if (value >= scaled) {
-      b = !mps;
-      value -= scaled;
-      range = lps;
-      if (ps == 0) mps = !mps;
-      ps = cabac_trans_lps[ps];
-    } else {
-      b = mps;
-      if (ps < 62) ++ps;
-    }
-    state[ctx] = static_cast<uint8_t>((ps << 1) | mps);
-    if (range < 256) {
-      const int shift = __builtin_clz(range) - 23;
-      range <<= shift;
-      extra -= shift;
-      if (extra < 8) refill();
-    }
-    return b;
+    const uint32_t st = state[ctx];
+    const uint32_t lps = g_cabac_tables.lps[(range >> 6) & 3][st];
+    uint32_t r = range - lps;
+    const uint64_t scaled = static_cast<uint64_t>(r) << extra;
+    // all ones when the LPS is decoded (value >= scaled)
+    const uint64_t lmask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
+    value -= scaled & lmask;
+    r += (lps - r) & static_cast<uint32_t>(lmask);
+    const uint32_t l = static_cast<uint32_t>(lmask) & 1;
+    state[ctx] = g_cabac_tables.next[st][l];
+    const int shift = __builtin_clz(r) - 23;  // 0 when r >= 256
+    range = r << shift;
+    extra -= shift;
+    if (__builtin_expect(extra < 8, 0)) refill();
+    return static_cast<int>((st & 1) ^ l);
   }
   inline int bypass() {
     extra -= 1;
-    if (extra < 8) refill();
+    if (__builtin_expect(extra < 8, 0)) refill();
     const uint64_t scaled = static_cast<uint64_t>(range) << extra;
-    if (value >= scaled) {
-      value -= scaled;
-      return 1;
-    }
-    return 0;
+    const uint64_t mask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
+    value -= scaled & mask;
+    return static_cast<int>(mask & 1);
   }
   inline int terminate() {
     range -= 2;
@@ -311,10 +331,15 @@ struct Parser::Impl {
   bool use_cabac = false;
   int last_qp_delta_nonzero = 0;
   int qp = 26;
+  int mbs_decoded = 0;  // of the picture in progress
 
   // current macroblock
   struct Mb {
     int mbx, mby, addr, kind, skip, direct16, t8x8, i16_mode, chroma_mode, cbp, qp;
+    // neighbour macroblocks in the same slice (and inside the picture), by
+    // offset: av[(oy + 1) * 3 + ox + 1] for ox in -1..1, oy in -1..0
+    bool av[6];
+    bool avA, avB;
     int sub_type[4];
     int8_t i4_mode[16];
     uint8_t nnz[24];
@@ -935,20 +960,27 @@ struct Parser::Impl {
     }
     c->slot = bufs.slot;
     c->motion = bufs.motion;
-    for (int l = 0; l < 2; ++l) c->ref_uid[l].assign(nmb * 4, -1);
-    c->mb_intra.assign(nmb, 0);
-    mb_slice.assign(nmb, -1);
-    mb_kind.assign(nmb, 0);
-    mb_skip.assign(nmb, 0);
-    mb_direct.assign(nmb, 0);
-    direct8.assign(nmb * 4, 0);
-    mb_t8x8.assign(nmb, 0);
-    mb_cbp.assign(nmb, 0);
-    mb_cbf_dc.assign(nmb, 0);
-    mb_chroma_mode.assign(nmb, 0);
-    i4mode.assign(nmb * 16, 2);
-    nnz.assign(nmb * 24, 0);
-    mvd.assign(static_cast<size_t>(nmb) * 64, 0);
+    // Per-macroblock state is (re)written by begin_mb / commit_mb before any
+    // later macroblock of this picture reads it (neighbours precede in raster
+    // order; FMO/ASO are rejected), so nothing is cleared per picture.
+    if (mb_slice.size() != static_cast<size_t>(nmb)) {
+      mb_slice.assign(nmb, -1);
+      mb_kind.assign(nmb, 0);
+      mb_skip.assign(nmb, 0);
+      mb_direct.assign(nmb, 0);
+      direct8.assign(nmb * 4, 0);
+      mb_t8x8.assign(nmb, 0);
+      mb_cbp.assign(nmb, 0);
+      mb_cbf_dc.assign(nmb, 0);
+      mb_chroma_mode.assign(nmb, 0);
+      i4mode.assign(nmb * 16, 2);
+      nnz.assign(nmb * 24, 0);
+      mvd.assign(static_cast<size_t>(nmb) * 64, 0);
+    }
+    for (int l = 0; l < 2; ++l)
+      if (c->ref_uid[l].size() != static_cast<size_t>(nmb) * 4) c->ref_uid[l].assign(nmb * 4, -1);
+    if (c->mb_intra.size() != static_cast<size_t>(nmb)) c->mb_intra.assign(nmb, 0);
+    mbs_decoded = 0;
     coef_used = 0;
     num_slices = 0;
     slice_index = 0;
@@ -1042,8 +1074,7 @@ struct Parser::Impl {
     pic_in_progress = false;
     Pic* c = cur;
     const int nmb = mbw * mbh;
-    for (int i = 0; i < nmb; ++i)
-      if (mb_slice[i] < 0) return fail("picture ended with undecoded macroblocks");
+    if (mbs_decoded != nmb) return fail("picture ended with undecoded macroblocks");
 
     PicDone done;
     memset(&done, 0, sizeof(done));
@@ -1084,12 +1115,31 @@ struct Parser::Impl {
   }
 
   // =================================================================== MBs
+  // Sets the current macroblock's position and which neighbours are available
+  // (6.4.9: inside the picture and in the same slice).  Everything else asks
+  // mb.av[] instead of re-deriving it per syntax element.
+  inline void set_position(int addr) {
+    mb.addr = addr;
+    mb.mbx = addr % mbw;
+    mb.mby = addr / mbw;
+    const bool left = mb.mbx > 0, top = mb.mby > 0, right = mb.mbx + 1 < mbw;
+    const int16_t si = static_cast<int16_t>(slice_index);
+    mb.av[0] = left && top && mb_slice[addr - mbw - 1] == si;   // D
+    mb.av[1] = top && mb_slice[addr - mbw] == si;               // B
+    mb.av[2] = right && top && mb_slice[addr - mbw + 1] == si;  // C
+    mb.av[3] = left && mb_slice[addr - 1] == si;                // A
+    mb.av[4] = true;                                            // the macroblock itself
+    mb.av[5] = false;                                           // right neighbour: never decoded yet
+    mb.avA = mb.av[3];
+    mb.avB = mb.av[1];
+  }
+  inline bool nb_avail(int ox, int oy) const { return mb.av[(oy + 1) * 3 + ox + 1]; }
   inline bool mb_avail(int mbx, int mby) const {
     if (mbx < 0 || mby < 0 || mbx >= mbw || mby >= mbh) return false;
     return mb_slice[mby * mbw + mbx] == slice_index;
   }
   inline bool intra_mb_ok(int mbx, int mby) const {
-    if (!mb_avail(mbx, mby)) return false;
+    if (!nb_avail(mbx - mb.mbx, mby - mb.mby)) return false;
     return !(apps->constrained_intra_pred && mb_kind[mby * mbw + mbx] == MB_INTER);
   }
   uint8_t* mvd_at(int addr, int list, int blk) { return &mvd[(static_cast<size_t>(addr) * 2 + list) * 32 + blk * 2]; }
@@ -1102,7 +1152,7 @@ struct Parser::Impl {
     const int bx = rx & 3, by = ry & 3;
     if (ox == 0 && oy == 0) {
       if (raster_to_blk4[by * 4 + bx] >= cur_zz) return nb;
-    } else if (!mb_avail(nx, ny)) {
+    } else if (!nb_avail(ox, oy)) {
       return nb;
     }
     const int addr = ny * mbw + nx;
@@ -1283,9 +1333,9 @@ struct Parser::Impl {
     const int base = plane == 0 ? 0 : (plane == 1 ? 16 : 20);
     int na = -1, nb = -1;
     if (rx > 0) na = mb.nnz[base + ry * n + rx - 1];
-    else if (mb_avail(mb.mbx - 1, mb.mby)) na = nnz[(mb.addr - 1) * 24 + base + ry * n + n - 1];
+    else if (mb.avA) na = nnz[(mb.addr - 1) * 24 + base + ry * n + n - 1];
     if (ry > 0) nb = mb.nnz[base + (ry - 1) * n + rx];
-    else if (mb_avail(mb.mbx, mb.mby - 1)) nb = nnz[(mb.addr - mbw) * 24 + base + (n - 1) * n + rx];
+    else if (mb.avB) nb = nnz[(mb.addr - mbw) * 24 + base + (n - 1) * n + rx];
     if (na >= 0 && nb >= 0) return (na + nb + 1) >> 1;
     if (na >= 0) return na;
     if (nb >= 0) return nb;
@@ -1416,7 +1466,7 @@ struct Parser::Impl {
       if (kind == 1) return mb.nnz[left ? ry * 4 + rx - 1 : (ry - 1) * 4 + rx] != 0;
       return mb.nnz[16 + 4 * p + (left ? ry * 2 + rx - 1 : (ry - 1) * 2 + rx)] != 0;
     }
-    if (!mb_avail(nx, ny)) return cur_intra;
+    if (!nb_avail(nx - mb.mbx, ny - mb.mby)) return cur_intra;
     const int addr = ny * mbw + nx;
     if (mb_kind[addr] == MB_IPCM) return 1;
     switch (kind) {
@@ -1435,11 +1485,11 @@ struct Parser::Impl {
     Cabac& c = cabac;
     if (intra_slice) {
       int inc = 0;
-      if (mb_avail(mb.mbx - 1, mb.mby)) {
+      if (mb.avA) {
         int k = mb_kind[mb.addr - 1];
         inc += k != MB_I4x4 && k != MB_I8x8;
       }
-      if (mb_avail(mb.mbx, mb.mby - 1)) {
+      if (mb.avB) {
         int k = mb_kind[mb.addr - mbw];
         inc += k != MB_I4x4 && k != MB_I8x8;
       }
@@ -1469,8 +1519,8 @@ struct Parser::Impl {
       return 5 + rd_intra_mb_type(17, 0);
     }
     int inc = 0;
-    if (mb_avail(mb.mbx - 1, mb.mby) && !mb_direct[mb.addr - 1]) inc++;
-    if (mb_avail(mb.mbx, mb.mby - 1) && !mb_direct[mb.addr - mbw]) inc++;
+    if (mb.avA && !mb_direct[mb.addr - 1]) inc++;
+    if (mb.avB && !mb_direct[mb.addr - mbw]) inc++;
     if (!c.bin(27 + inc)) return 0;
     if (!c.bin(27 + 3)) return 1 + c.bin(27 + 5);
     int v = c.bin(27 + 4) << 3;
@@ -1513,7 +1563,7 @@ struct Parser::Impl {
       const int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
       const int nx = mb.mbx + (rx < 0 ? -1 : 0), ny = mb.mby + (ry < 0 ? -1 : 0);
       const bool inside = rx >= 0 && ry >= 0;
-      if (!inside && !mb_avail(nx, ny)) continue;
+      if (!inside && !nb_avail(nx - mb.mbx, ny - mb.mby)) continue;
       const int addr = ny * mbw + nx;
       const int q = ((ry & 3) >> 1) * 2 + ((rx & 3) >> 1);
       if (cur->mb_intra[addr]) continue;
@@ -1535,7 +1585,7 @@ struct Parser::Impl {
       const int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
       const int nx = mb.mbx + (rx < 0 ? -1 : 0), ny = mb.mby + (ry < 0 ? -1 : 0);
       const bool inside = rx >= 0 && ry >= 0;
-      if (!inside && !mb_avail(nx, ny)) continue;
+      if (!inside && !nb_avail(nx - mb.mbx, ny - mb.mby)) continue;
       sum += mvd_at(ny * mbw + nx, list, (ry & 3) * 4 + (rx & 3))[comp];
     }
     Cabac& c = cabac;
@@ -1564,7 +1614,7 @@ struct Parser::Impl {
       return intra ? cbp_intra_from_code[code] : cbp_inter_from_code[code];
     }
     Cabac& c = cabac;
-    const bool la = mb_avail(mb.mbx - 1, mb.mby), ta = mb_avail(mb.mbx, mb.mby - 1);
+    const bool la = mb.avA, ta = mb.avB;
     const int cbp_a = la ? mb_cbp[mb.addr - 1] : 0x0f;
     const int cbp_b = ta ? mb_cbp[mb.addr - mbw] : 0x0f;
     int cbp = 0;
@@ -1590,8 +1640,8 @@ struct Parser::Impl {
   int rd_chroma_pred_mode() {
     if (!use_cabac) return static_cast<int>(bits.ue());
     int inc = 0;
-    if (mb_avail(mb.mbx - 1, mb.mby) && mb_chroma_mode[mb.addr - 1]) inc++;
-    if (mb_avail(mb.mbx, mb.mby - 1) && mb_chroma_mode[mb.addr - mbw]) inc++;
+    if (mb.avA && mb_chroma_mode[mb.addr - 1]) inc++;
+    if (mb.avB && mb_chroma_mode[mb.addr - mbw]) inc++;
     if (!cabac.bin(64 + inc)) return 0;
     if (!cabac.bin(64 + 3)) return 1;
     return 2 + cabac.bin(64 + 3);
@@ -1599,8 +1649,8 @@ struct Parser::Impl {
   int rd_t8x8_flag() {
     if (!use_cabac) return bits.bit();
     int inc = 0;
-    if (mb_avail(mb.mbx - 1, mb.mby) && mb_t8x8[mb.addr - 1]) inc++;
-    if (mb_avail(mb.mbx, mb.mby - 1) && mb_t8x8[mb.addr - mbw]) inc++;
+    if (mb.avA && mb_t8x8[mb.addr - 1]) inc++;
+    if (mb.avB && mb_t8x8[mb.addr - mbw]) inc++;
     return cabac.bin(399 + inc);
   }
   int rd_intra_pred_mode() {
@@ -1620,7 +1670,7 @@ struct Parser::Impl {
         continue;
       }
       const int nx = mb.mbx + (rx < 0 ? -1 : 0), ny = mb.mby + (ry < 0 ? -1 : 0);
-      if (!mb_avail(nx, ny)) return 2;
+      if (!nb_avail(nx - mb.mbx, ny - mb.mby)) return 2;
       const int addr = ny * mbw + nx;
       const int kind = mb_kind[addr];
       if (kind == MB_INTER && apps->constrained_intra_pred) return 2;
@@ -1815,9 +1865,7 @@ struct Parser::Impl {
   }
 
   void begin_mb(int addr) {
-    mb.addr = addr;
-    mb.mbx = addr % mbw;
-    mb.mby = addr / mbw;
+    set_position(addr);
     mb.kind = MB_NONE;
     mb.skip = mb.direct16 = mb.t8x8 = mb.i16_mode = mb.chroma_mode = mb.cbp = 0;
     mb.qp = qp;
@@ -1841,6 +1889,7 @@ struct Parser::Impl {
 
   bool commit_mb(const uint8_t* pcm) {
     const int a = mb.addr;
+    ++mbs_decoded;
     const Pps& p = *apps;
     MbInfo& o = bufs.mb[a];
     memset(&o, 0, sizeof(o));
@@ -1879,9 +1928,8 @@ struct Parser::Impl {
     o.pred_modes = static_cast<uint8_t>((mb.i16_mode & 15) | (mb.chroma_mode << 4));
     o.slice = static_cast<uint8_t>(slice_index - 1);
     for (int k = 0; k < 8; ++k) o.i4_modes[k] = static_cast<uint8_t>((mb.i4_mode[2 * k] & 15) | (mb.i4_mode[2 * k + 1] << 4));
-    uint16_t nz = 0;
-    for (int k = 0; k < 16; ++k)
-      if (mb.nnz[k]) nz |= 1u << k;
+    uint16_t nz = static_cast<uint16_t>(~_mm_movemask_epi8(
+        _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(mb.nnz)), _mm_setzero_si128())));
     if (mb.t8x8)  // the transform block is the 8x8: any coefficient marks all four
       for (int b8 = 0; b8 < 4; ++b8) {
         const int o4 = (b8 >> 1) * 8 + (b8 & 1) * 2;
@@ -2060,12 +2108,10 @@ struct Parser::Impl {
         if (addr >= nmb) return fail("slice runs past the end of the picture");
         bool skipped = false;
         if (sl.type != 2) {
-          mb.addr = addr;
-          mb.mbx = addr % mbw;
-          mb.mby = addr / mbw;
+          set_position(addr);
           int inc = 0;
-          if (mb_avail(mb.mbx - 1, mb.mby) && !mb_skip[addr - 1]) inc++;
-          if (mb_avail(mb.mbx, mb.mby - 1) && !mb_skip[addr - mbw]) inc++;
+          if (mb.avA && !mb_skip[addr - 1]) inc++;
+          if (mb.avB && !mb_skip[addr - mbw]) inc++;
           skipped = cabac.bin((sl.type == 0 ? 11 : 24) + inc);
         }
         if (!(skipped ? decode_skip_mb(addr) : decode_mb(addr))) return false;
