@@ -273,6 +273,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.coefs = j.coef_dev;
     sub.desc.slices = j.slice_dev;
     sub.desc.db = j.db_dev;
+    sub.desc.resid = j.resid_dev;
     sub.desc.do_inter = d.has_inter;
     sub.desc.do_intra = d.has_intra;
     sub.desc.do_deblock = d.any_deblock;
@@ -318,6 +319,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     int16_t* coef_dev = nullptr;
     SliceParams* slice_dev = nullptr;
     void* db_dev = nullptr;  // k_bs -> k_deblock records
+    int16_t* resid_dev = nullptr;  // k_residual -> k_intra
     uint64_t seq = 0;  // submission that still reads the staging buffers
   };
   struct Bounce {
@@ -385,7 +387,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
           hipMalloc(reinterpret_cast<void**>(&j.motion_dev), nmb * sizeof(MbMotion)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.coef_dev), coef_capacity_ * 2) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.slice_dev), kMaxSlices * sizeof(SliceParams)) != hipSuccess ||
-          hipMalloc(&j.db_dev, amd::deblock_scratch_bytes(static_cast<int>(nmb))) != hipSuccess) {
+          hipMalloc(&j.db_dev, amd::deblock_scratch_bytes(static_cast<int>(nmb))) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&j.resid_dev), nmb * 384 * sizeof(int16_t)) != hipSuccess) {
         *error = "AMDVideoDecoder: out of memory for staging buffers";
         return false;
       }
@@ -432,6 +435,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       if (j.coef_dev) (void)hipFree(j.coef_dev);
       if (j.slice_dev) (void)hipFree(j.slice_dev);
       if (j.db_dev) (void)hipFree(j.db_dev);
+      if (j.resid_dev) (void)hipFree(j.resid_dev);
       j = Job();
     }
     for (SurfaceSlot& s : surf_) {

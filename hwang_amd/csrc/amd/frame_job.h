@@ -131,6 +131,7 @@ struct JobDesc {
   const int16_t* coefs;
   const SliceParams* slices;
   void* db;            // k_bs -> k_deblock records
+  int16_t* resid;      // k_residual -> k_intra: 384 int16 per macroblock (256 luma raster, 64 Cb, 64 Cr)
   int32_t do_inter, do_intra, do_deblock;
   int32_t num_uploads;
   UploadDesc uploads[kJobUploads];

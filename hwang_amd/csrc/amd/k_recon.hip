@@ -675,8 +675,6 @@ __device__ int pred8x8_sample(const int* ft, const int* fl, int ftl, int mode, i
 }
 
 struct IntraWaveLds {
-  int work[384];
-  int dcs[24];
   int16_t res_y[256];
   int16_t res_c[128];
   uint8_t tile[17 * TS];
@@ -687,8 +685,57 @@ struct IntraWaveLds {
 }  // namespace
 
 // ===========================================================================
-// k_intra: grid = 1 workgroup of 16 waves per picture.
+// k_residual: dequantisation + inverse transforms of every intra macroblock,
+// fully parallel (one wave per macroblock, 4 per workgroup), written as int16
+// to the job's residual scratch.  It takes the coefficient loads, the scaling
+// and the IDCT out of k_intra's raster-order chain: there the residual of the
+// next macroblock is then a plain prefetch at an address that depends on
+// nothing.
 // ===========================================================================
+__global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.y];
+  const PictureParams& pp = job.pp;
+  if (!job.do_intra) return;
+  const int nmb = pp.mb_width * pp.mb_height;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int mbi = blockIdx.x * kInterWaves + wave;
+  if (mbi >= nmb) return;
+  const MbInfo mb = job.mbs[mbi];
+  if (!(mb.flags & MBF_INTRA) || mb.kind == MBK_IPCM) return;
+  __shared__ InterWave lds[kInterWaves];
+  InterWave& L = lds[wave];
+  uint32_t* out = reinterpret_cast<uint32_t*>(job.resid + (size_t)mbi * 384);
+  if (mb.coded_mask == 0) {
+    out[lane] = 0;
+    out[64 + lane] = 0;
+    out[128 + lane] = 0;
+    return;
+  }
+  wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+  const uint32_t* ry = reinterpret_cast<const uint32_t*>(L.res_y);
+  const uint32_t* rc = reinterpret_cast<const uint32_t*>(L.res_c);
+  out[lane] = ry[lane];
+  out[64 + lane] = ry[64 + lane];
+  out[128 + lane] = rc[lane];
+}
+
+// ===========================================================================
+// k_intra: grid = 1 workgroup of 16 waves per picture.
+//
+// Two neighbour paths, chosen per picture:
+//  * intra-only pictures no wider than kLineMbs macroblocks (every I picture
+//    up to 2K): a macroblock's neighbours never leave LDS.  The left column
+//    is the previous macroblock's tile, the row above comes from a line buffer
+//    the wave of that row fills (bottom luma row + both chroma rows, 32 B per
+//    macroblock).  Progress is published after an LDS-only wait, global stores
+//    drain in the background and nothing in this kernel reads them back, so the
+//    per-macroblock chain holds no global-memory round trip but the records.
+//  * pictures with inter macroblocks (k_inter wrote those to HBM) and wider
+//    pictures: neighbours are read from the surface; a release fence precedes
+//    the progress counter.
+// ===========================================================================
+constexpr int kLineMbs = 128;
+
 __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restrict__ jobs) {
   const JobDesc& job = jobs[blockIdx.x];
   if (!job.do_intra) return;
@@ -698,6 +745,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ int s_progress[kMaxRows + 1];
   __shared__ IntraWaveLds s_lds[kRowWaves];
+  __shared__ uint8_t s_line[kRowWaves][kLineMbs][32];
   volatile int* progress = s_progress;
   for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
   __syncthreads();
@@ -705,52 +753,100 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
   uint8_t* tile = L.tile;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
+  const bool lds_nb = !job.do_inter && pp.mb_width <= kLineMbs;  // wave uniform
+  uint8_t (*line_up)[32] = s_line[(wave + kRowWaves - 1) % kRowWaves];
+  uint8_t (*line_me)[32] = s_line[wave];
 
+  const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(job.resid);
   for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
+    int prev_mbx = -2;  // macroblock whose samples the tile still holds
     for (int mbx0 = 0; mbx0 < pp.mb_width; mbx0 += 64) {
       // which of the next 64 macroblocks of this row are intra?
       const int probe = mbx0 + lane;
       const bool is_intra = probe < pp.mb_width && (mbs[mby * pp.mb_width + probe].flags & MBF_INTRA);
       unsigned long long todo = __ballot(is_intra);
+      // residual of the first macroblock of the run; inside the loop the next one's is fetched a macroblock ahead
+      uint32_t r0 = 0, r1 = 0, r2 = 0;
+      if (todo) {
+        const uint32_t* rp = resid + (size_t)(mby * pp.mb_width + mbx0 + __builtin_ctzll(todo)) * 192;
+        r0 = rp[lane];
+        r1 = rp[64 + lane];
+        r2 = rp[128 + lane];
+      }
       while (todo) {
         const int mbx = mbx0 + __builtin_ctzll(todo);
         todo &= todo - 1;
         const int mbi = mby * pp.mb_width + mbx;
         const MbInfo mb = mbs[mbi];
+        // land this macroblock's residual in LDS, start the next one's loads
+        reinterpret_cast<uint32_t*>(L.res_y)[lane] = r0;
+        reinterpret_cast<uint32_t*>(L.res_y)[64 + lane] = r1;
+        reinterpret_cast<uint32_t*>(L.res_c)[lane] = r2;
+        if (todo) {
+          const uint32_t* rp = resid + (size_t)(mby * pp.mb_width + mbx0 + __builtin_ctzll(todo)) * 192;
+          r0 = rp[lane];
+          r1 = rp[64 + lane];
+          r2 = rp[128 + lane];
+        }
         uint8_t* dy = cur.y + (size_t)(mby * 16) * yp + mbx * 16;
         uint8_t* du = cur.u + (size_t)(mby * 8) * cp + mbx * 8;
         uint8_t* dv = cur.v + (size_t)(mby * 8) * cp + mbx * 8;
-        if (mb.kind == MBK_IPCM) {
-          const uint8_t* pcm = reinterpret_cast<const uint8_t*>(coefs + mb.coef_offset);
-          for (int t = lane; t < 256; t += 64) dy[(t >> 4) * yp + (t & 15)] = pcm[t];
-          du[(lane >> 3) * cp + (lane & 7)] = pcm[256 + lane];
-          dv[(lane >> 3) * cp + (lane & 7)] = pcm[320 + lane];
-          row_publish(progress, mby, mbx + 1);
-          continue;
-        }
-        wave_residual(mb, coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);
+        const bool pcm = mb.kind == MBK_IPCM;
         const bool hA = mb.flags & MBF_AVAIL_A, hB = mb.flags & MBF_AVAIL_B;
         const bool hC = mb.flags & MBF_AVAIL_C, hD = mb.flags & MBF_AVAIL_D;
         // the row above must be complete up to the top-right neighbour
-        if (hB || hC || hD) row_wait(progress, mby, min(mbx + 2, pp.mb_width));
-        // neighbours into the tiles
-        if (lane < 25)
-          tile[lane] = (lane == 0) ? (hD ? dy[-yp - 1] : 128) : (lane <= 16) ? (hB ? dy[-yp + lane - 1] : 128)
-                                                                             : (hC ? dy[-yp + lane - 1] : 128);
-        else if (lane >= 32 && lane < 48)
-          tile[(lane - 31) * TS] = hA ? dy[(lane - 32) * yp - 1] : 128;
-        if (lane < 18) {
-          const int p = lane / 9, i = lane % 9;
-          const uint8_t* d = p ? dv : du;
-          L.ctile[p][i] = (i == 0) ? (hD ? d[-cp - 1] : 128) : (hB ? d[-cp + i - 1] : 128);
-        } else if (lane >= 32 && lane < 48) {
-          const int p = (lane - 32) >> 3, j = (lane - 32) & 7;
-          const uint8_t* d = p ? dv : du;
-          L.ctile[p][(j + 1) * 12] = hA ? d[j * cp - 1] : 128;
+        if (hB || hC || hD) {
+          row_wait(progress, mby, min(mbx + 2, pp.mb_width));
+        }
+        // ---- neighbours into the tiles
+        if (lds_nb) {
+          // left column: the previous macroblock of this row is still in the tile
+          if (lane >= 32 && lane < 48) {
+            const int r = lane - 31;
+            tile[r * TS] = (hA && prev_mbx == mbx - 1) ? tile[r * TS + 16] : 128;
+          } else if (lane >= 48) {
+            const int p = (lane - 48) >> 3, j = (lane - 48) & 7;
+            L.ctile[p][(j + 1) * 12] = (hA && prev_mbx == mbx - 1) ? L.ctile[p][(j + 1) * 12 + 8] : 128;
+          }
+          if (lane < 25) {
+            int v = 128;
+            if (lane == 0) { if (hD) v = line_up[mbx - 1][15]; }
+            else if (lane <= 16) { if (hB) v = line_up[mbx][lane - 1]; }
+            else if (hC) v = line_up[mbx + 1][lane - 17];
+            tile[lane] = (uint8_t)v;
+          } else if (lane < 32) {
+            // nothing
+          }
+          if (lane < 18) {
+            const int p = lane / 9, i = lane % 9;
+            int v = 128;
+            if (i == 0) { if (hD) v = line_up[mbx - 1][16 + 8 * p + 7]; }
+            else if (hB) v = line_up[mbx][16 + 8 * p + i - 1];
+            L.ctile[p][i] = (uint8_t)v;
+          }
+        } else {
+          if (lane < 25)
+            tile[lane] = (lane == 0) ? (hD ? dy[-yp - 1] : 128) : (lane <= 16) ? (hB ? dy[-yp + lane - 1] : 128)
+                                                                               : (hC ? dy[-yp + lane - 1] : 128);
+          else if (lane >= 32 && lane < 48)
+            tile[(lane - 31) * TS] = hA ? dy[(lane - 32) * yp - 1] : 128;
+          if (lane < 18) {
+            const int p = lane / 9, i = lane % 9;
+            const uint8_t* d = p ? dv : du;
+            L.ctile[p][i] = (i == 0) ? (hD ? d[-cp - 1] : 128) : (hB ? d[-cp + i - 1] : 128);
+          } else if (lane >= 32 && lane < 48) {
+            const int p = (lane - 32) >> 3, j = (lane - 32) & 7;
+            const uint8_t* d = p ? dv : du;
+            L.ctile[p][(j + 1) * 12] = hA ? d[j * cp - 1] : 128;
+          }
         }
         wave_sync();
 
-        if (mb.kind == MBK_I16x16) {
+        if (pcm) {
+          const uint8_t* src = reinterpret_cast<const uint8_t*>(coefs + mb.coef_offset);
+          for (int t = lane; t < 256; t += 64) tile[(1 + (t >> 4)) * TS + 1 + (t & 15)] = src[t];
+          for (int t = lane; t < 128; t += 64) L.ctile[t >> 6][(1 + ((t >> 3) & 7)) * 12 + 1 + (t & 7)] = src[256 + t];
+        } else if (mb.kind == MBK_I16x16) {
           const int mode = mb.pred_modes & 15;
           int dcv = 128, a = 0, b = 0, c = 0;
           if (mode == 2) {
@@ -770,11 +866,19 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
             b = (5 * Hh + 32) >> 6;
             c = (5 * Vv + 32) >> 6;
           }
-          for (int t = lane; t < 256; t += 64) {
-            const int x = t & 15, y = t >> 4;
+          int outv[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int t = lane + it * 64, x = t & 15, y = t >> 4;
             const int v = mode == 0 ? tile[1 + x] : mode == 1 ? tile[(1 + y) * TS] : mode == 2 ? dcv
                                                   : clip8((a + b * (x - 7) + c * (y - 7) + 16) >> 5);
-            dy[y * yp + x] = (uint8_t)clip8(v + L.res_y[t]);
+            outv[it] = clip8(v + L.res_y[t]);
+          }
+          wave_sync();  // every lane has read its neighbours before the tile is overwritten
+#pragma unroll
+          for (int it = 0; it < 4; ++it) {
+            const int t = lane + it * 64;
+            tile[(1 + (t >> 4)) * TS + 1 + (t & 15)] = (uint8_t)outv[it];
           }
         } else if (mb.kind == MBK_I4x4) {
           for (int k = 0; k < 16; ++k) {  // decode order
@@ -796,7 +900,6 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
             }
             wave_sync();
           }
-          for (int t = lane; t < 256; t += 64) dy[(t >> 4) * yp + (t & 15)] = tile[(1 + (t >> 4)) * TS + 1 + (t & 15)];
         } else {  // MBK_I8x8
           for (int b8 = 0; b8 < 4; ++b8) {
             const int bx = (b8 & 1) * 8, by = (b8 >> 1) * 8;
@@ -844,47 +947,81 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
             }
             wave_sync();
           }
-          for (int t = lane; t < 256; t += 64) dy[(t >> 4) * yp + (t & 15)] = tile[(1 + (t >> 4)) * TS + 1 + (t & 15)];
         }
 
         // chroma 8x8, both planes: two samples per lane
-        for (int t = lane; t < 128; t += 64) {
-          const int p = t >> 6, cx = t & 7, cy = (t >> 3) & 7;
-          const uint8_t* ct = L.ctile[p];
-          const int mode = mb.pred_modes >> 4;
-          int v;
-          if (mode == 0) {
-            const int bx = cx >> 2, by = cy >> 2;
-            int st = 0, sl = 0;
-            for (int i = 0; i < 4; ++i) {
-              st += ct[1 + 4 * bx + i];
-              sl += ct[(1 + 4 * by + i) * 12];
+        if (!pcm) {
+          int outc[2];
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const int p = it, cx = lane & 7, cy = lane >> 3;
+            const uint8_t* ct = L.ctile[p];
+            const int mode = mb.pred_modes >> 4;
+            int v;
+            if (mode == 0) {
+              const int bx = cx >> 2, by = cy >> 2;
+              int st = 0, sl = 0;
+              for (int i = 0; i < 4; ++i) {
+                st += ct[1 + 4 * bx + i];
+                sl += ct[(1 + 4 * by + i) * 12];
+              }
+              if (bx == by) v = (hB && hA) ? (st + sl + 4) >> 3 : hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
+              else if (bx == 1) v = hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
+              else v = hA ? (sl + 2) >> 2 : hB ? (st + 2) >> 2 : 128;
+            } else if (mode == 1) {
+              v = ct[(1 + cy) * 12];
+            } else if (mode == 2) {
+              v = ct[1 + cx];
+            } else {
+              int Hh = 0, Vv = 0;
+              for (int k = 0; k < 4; ++k) {
+                Hh += (k + 1) * (ct[1 + 4 + k] - ct[1 + 2 - k]);
+                Vv += (k + 1) * (ct[(1 + 4 + k) * 12] - ct[(1 + 2 - k) * 12]);
+              }
+              const int a = 16 * (ct[8 * 12] + ct[8]);
+              const int b = (34 * Hh + 32) >> 6, c = (34 * Vv + 32) >> 6;
+              v = clip8((a + b * (cx - 3) + c * (cy - 3) + 16) >> 5);
             }
-            if (bx == by) v = (hB && hA) ? (st + sl + 4) >> 3 : hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
-            else if (bx == 1) v = hB ? (st + 2) >> 2 : hA ? (sl + 2) >> 2 : 128;
-            else v = hA ? (sl + 2) >> 2 : hB ? (st + 2) >> 2 : 128;
-          } else if (mode == 1) {
-            v = ct[(1 + cy) * 12];
-          } else if (mode == 2) {
-            v = ct[1 + cx];
-          } else {
-            int Hh = 0, Vv = 0;
-            for (int k = 0; k < 4; ++k) {
-              Hh += (k + 1) * (ct[1 + 4 + k] - ct[1 + 2 - k]);
-              Vv += (k + 1) * (ct[(1 + 4 + k) * 12] - ct[(1 + 2 - k) * 12]);
-            }
-            const int a = 16 * (ct[8 * 12] + ct[8]);
-            const int b = (34 * Hh + 32) >> 6, c = (34 * Vv + 32) >> 6;
-            v = clip8((a + b * (cx - 3) + c * (cy - 3) + 16) >> 5);
+            outc[it] = clip8(v + L.res_c[p * 64 + cy * 8 + cx]);
           }
-          uint8_t* d = p ? dv : du;
-          d[cy * cp + cx] = (uint8_t)clip8(v + L.res_c[p * 64 + cy * 8 + cx]);
+          wave_sync();
+          L.ctile[0][(1 + (lane >> 3)) * 12 + 1 + (lane & 7)] = (uint8_t)outc[0];
+          L.ctile[1][(1 + (lane >> 3)) * 12 + 1 + (lane & 7)] = (uint8_t)outc[1];
         }
-        row_publish(progress, mby, mbx + 1);
+        wave_sync();
+
+        // ---- tiles -> surface: one dword per lane (luma), 32 lanes x dword (chroma)
+        {
+          const int r = lane >> 2, c4 = (lane & 3) * 4;
+          const uint8_t* tp = tile + (1 + r) * TS + 1 + c4;
+          const uint32_t v = tp[0] | (tp[1] << 8) | (tp[2] << 16) | ((uint32_t)tp[3] << 24);
+          *reinterpret_cast<uint32_t*>(dy + (size_t)r * yp + c4) = v;
+          if (lane < 32) {
+            const int p = lane >> 4, rr = (lane >> 1) & 7, cc = (lane & 1) * 4;
+            const uint8_t* cpx = L.ctile[p] + (1 + rr) * 12 + 1 + cc;
+            const uint32_t w = cpx[0] | (cpx[1] << 8) | (cpx[2] << 16) | ((uint32_t)cpx[3] << 24);
+            *reinterpret_cast<uint32_t*>((p ? dv : du) + (size_t)rr * cp + cc) = w;
+          }
+        }
+        if (lds_nb) {
+          // bottom rows for the row below, then the counter: LDS only
+          if (lane < 16) line_me[mbx][lane] = tile[16 * TS + 1 + lane];
+          else if (lane < 32) line_me[mbx][lane] = L.ctile[(lane - 16) >> 3][8 * 12 + 1 + ((lane - 16) & 7)];
+          __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          progress[mby + 1] = mbx + 1;
+        } else {
+          row_publish(progress, mby, mbx + 1);
+        }
+        prev_mbx = mbx;
       }
     }
     // inter macroblocks at the end of the row need no work: the row is done
-    row_publish(progress, mby, pp.mb_width);
+    if (lds_nb) {
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      progress[mby + 1] = pp.mb_width;
+    } else {
+      row_publish(progress, mby, pp.mb_width);
+    }
   }
 }
 
@@ -1118,39 +1255,70 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
     uint8_t* rowu = cur.u + (size_t)(mby * 8) * cp;
     uint8_t* rowv = cur.v + (size_t)(mby * 8) * cp;
     const DbInfo* rowdb = dbs + mby * W;
-    // prefetch macroblock 0
-    uint32_t n_luma = *reinterpret_cast<const uint32_t*>(rowy + lr * yp + lc4 * 4);
-    uint32_t n_chroma = 0, n_db = 0;
-    if (lane < 32) n_chroma = *reinterpret_cast<const uint32_t*>((cpn ? rowv : rowu) + ccr * cp + ccc * 4);
-    if (lane < 24) n_db = reinterpret_cast<const uint32_t*>(rowdb)[lane];
+    int tile_mbx = -2;  // macroblock whose samples the tile holds (its last four columns slide left)
 
-    for (int mbx = 0; mbx < W; ++mbx) {
-      uint8_t* gy = rowy + mbx * 16;
-      uint8_t* gu = rowu + mbx * 8;
-      uint8_t* gv = rowv + mbx * 8;
-      // ---- land the prefetched interior + record, start the next prefetch
-      *reinterpret_cast<uint32_t*>(&L.lt[(4 + lr) * LS + 4 + lc4 * 4]) = n_luma;
-      if (lane < 32) *reinterpret_cast<uint32_t*>(&L.ct[cpn][(2 + ccr) * CS + 4 + ccc * 4]) = n_chroma;
-      if (lane < 24) reinterpret_cast<uint32_t*>(&L.db)[lane] = n_db;
-      if (mbx + 1 < W) {
-        n_luma = *reinterpret_cast<const uint32_t*>(gy + 16 + lr * yp + lc4 * 4);
-        if (lane < 32) n_chroma = *reinterpret_cast<const uint32_t*>((cpn ? gv : gu) + 8 + ccr * cp + ccc * 4);
-        if (lane < 24) n_db = reinterpret_cast<const uint32_t*>(rowdb + mbx + 1)[lane];
-      }
-      // ---- rows above: wait for the row above to be two macroblocks ahead
-      uint32_t top_word = 0;
-      if (mby > 0) {
-        row_wait(progress, mby, min(mbx + 2, W));
-        if (lane < 16) top_word = *reinterpret_cast<const uint32_t*>(gy + ((lane >> 2) - 4) * yp + (lane & 3) * 4);
-        else if (lane < 24) {
-          const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
-          top_word = *reinterpret_cast<const uint32_t*>((p ? gv : gu) + (cr - 2) * cp + cc * 4);
+    for (int mbx0 = 0; mbx0 < W; mbx0 += 64) {
+      // Macroblocks without a single edge to filter are skipped outright: they
+      // load nothing, store nothing; the counter simply jumps over them.
+      const int probe = mbx0 + lane;
+      unsigned long long todo = __ballot(probe < W && rowdb[probe].any != 0);
+      // prefetch of the first macroblock to filter
+      uint32_t n_luma = 0, n_chroma = 0, n_db = 0, n_left = 0;
+      auto prefetch = [&](int mbx) {
+        const uint8_t* gy = rowy + mbx * 16;
+        n_luma = *reinterpret_cast<const uint32_t*>(gy + lr * yp + lc4 * 4);
+        if (lane < 32) n_chroma = *reinterpret_cast<const uint32_t*>((cpn ? rowv : rowu) + mbx * 8 + ccr * cp + ccc * 4);
+        if (lane < 24) n_db = reinterpret_cast<const uint32_t*>(rowdb + mbx)[lane];
+        // the four columns to the left, in case the left neighbour was skipped:
+        // lanes 0..15 luma rows, 16..31 chroma rows of both planes
+        if (mbx > 0) {
+          if (lane < 16) n_left = *reinterpret_cast<const uint32_t*>(gy + lane * yp - 4);
+          else if (lane < 32) n_left = *reinterpret_cast<const uint32_t*>((((lane - 16) >> 3) ? rowv : rowu) + mbx * 8 +
+                                                                           ((lane - 16) & 7) * cp - 4);
         }
-      }
-      wave_sync();
-      const bool any = L.db.any != 0;
-      if (any) {
+      };
+      if (todo) prefetch(mbx0 + __builtin_ctzll(todo));
+
+      while (todo) {
+        const int mbx = mbx0 + __builtin_ctzll(todo);
+        todo &= todo - 1;
+        uint8_t* gy = rowy + mbx * 16;
+        uint8_t* gu = rowu + mbx * 8;
+        uint8_t* gv = rowv + mbx * 8;
+        // ---- everything before this macroblock is final once the previous
+        // filtered one's stores have landed (they had an iteration to do so)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        progress[mby + 1] = mbx;
+        // ---- left columns: slide from the tile, or take the prefetched ones
+        if (tile_mbx == mbx - 1) {
+          uint32_t keep = 0;
+          if (lane < 20) keep = *reinterpret_cast<const uint32_t*>(&L.lt[lane * LS + 16]);
+          else if (lane < 40) keep = *reinterpret_cast<const uint32_t*>(&L.ct[(lane - 20) / 10][((lane - 20) % 10) * CS + 8]);
+          wave_sync();
+          if (lane < 20) *reinterpret_cast<uint32_t*>(&L.lt[lane * LS]) = keep;
+          else if (lane < 40) *reinterpret_cast<uint32_t*>(&L.ct[(lane - 20) / 10][((lane - 20) % 10) * CS]) = keep;
+        } else if (mbx > 0) {
+          if (lane < 16) *reinterpret_cast<uint32_t*>(&L.lt[(4 + lane) * LS]) = n_left;
+          else if (lane < 32) *reinterpret_cast<uint32_t*>(&L.ct[(lane - 16) >> 3][(2 + ((lane - 16) & 7)) * CS]) = n_left;
+        }
+        // ---- land the prefetched interior + record, start the next prefetch
+        *reinterpret_cast<uint32_t*>(&L.lt[(4 + lr) * LS + 4 + lc4 * 4]) = n_luma;
+        if (lane < 32) *reinterpret_cast<uint32_t*>(&L.ct[cpn][(2 + ccr) * CS + 4 + ccc * 4]) = n_chroma;
+        if (lane < 24) reinterpret_cast<uint32_t*>(&L.db)[lane] = n_db;
+        if (todo) prefetch(mbx0 + __builtin_ctzll(todo));
+        wave_sync();
         const int t8 = L.db.t8x8;
+        const bool top_edge = mby > 0 && *reinterpret_cast<const uint32_t*>(&L.db.bs[16]) != 0;
+        // ---- rows above: wait for the row above to be two macroblocks ahead
+        uint32_t top_word = 0;
+        if (top_edge) {
+          row_wait(progress, mby, min(mbx + 2, W));
+          if (lane < 16) top_word = *reinterpret_cast<const uint32_t*>(gy + ((lane >> 2) - 4) * yp + (lane & 3) * 4);
+          else if (lane < 24) {
+            const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
+            top_word = *reinterpret_cast<const uint32_t*>((p ? gv : gu) + (cr - 2) * cp + cc * 4);
+          }
+        }
         // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each
         for (int e = 0; e < 4; ++e) {
           if (lane < 16) {
@@ -1177,20 +1345,17 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
           }
           wave_sync();
         }
-      }
-      // ---- the rows above arrive now (their latency hid behind the vertical edges)
-      if (mby > 0) {
-        if (lane < 16) *reinterpret_cast<uint32_t*>(&L.lt[(lane >> 2) * LS + 4 + (lane & 3) * 4]) = top_word;
-        else if (lane < 24) {
-          const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
-          *reinterpret_cast<uint32_t*>(&L.ct[p][cr * CS + 4 + cc * 4]) = top_word;
+        // ---- the rows above arrive now (their latency hid behind the vertical edges)
+        if (top_edge) {
+          if (lane < 16) *reinterpret_cast<uint32_t*>(&L.lt[(lane >> 2) * LS + 4 + (lane & 3) * 4]) = top_word;
+          else if (lane < 24) {
+            const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
+            *reinterpret_cast<uint32_t*>(&L.ct[p][cr * CS + 4 + cc * 4]) = top_word;
+          }
+          wave_sync();
         }
-        wave_sync();
-      }
-      if (any) {
-        const int t8 = L.db.t8x8;
         // ---- horizontal edges: lanes 0..15 one luma column each, 16..31 chroma columns
-        for (int e = 0; e < 4; ++e) {
+        for (int e = top_edge ? 0 : 1; e < 4; ++e) {
           if (lane < 16) {
             const int bs = L.db.bs[16 + e * 4 + (lane >> 2)];
             if (bs && !(t8 && (e & 1))) {
@@ -1209,39 +1374,24 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
           }
           wave_sync();
         }
-      }
-      // ---- the previous macroblock's stores have had a whole iteration to
-      // land: make sure, then tell the row below about it
-      if (mbx > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        progress[mby + 1] = mbx;  // macroblocks 0..mbx-1 are final in memory
-      }
-      // ---- store the tile: rows -4..15 x cols -4..15 luma (5 dwords a row),
-      // rows -2..7 x cols -4..7 chroma (3 dwords a row); parts outside the
-      // picture are skipped.  (With nothing filtered the samples are unchanged.)
-      if (any) {
+        // ---- store what the filters may have touched: rows 0..15 x cols -4..15
+        // and, with a top edge, rows -4..-1 x cols 0..15 (chroma: rows 0..7 x
+        // cols -4..7 and rows -2..-1 x cols 0..7).  The corner above-left belongs
+        // to other macroblocks' edges and is never written from here.
         for (int t = lane; t < 100; t += 64) {
           const int r = t / 5, c4 = t % 5;
-          if ((r >= 4 || mby > 0) && (c4 >= 1 || mbx > 0))
+          if (r >= 4 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1))
             *reinterpret_cast<uint32_t*>(gy + (r - 4) * yp + (c4 - 1) * 4) =
                 *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]);
         }
         if (lane < 60) {
           const int p = lane / 30, t = lane % 30, r = t / 3, c4 = t % 3;
           uint8_t* g = p ? gv : gu;
-          if ((r >= 2 || mby > 0) && (c4 >= 1 || mbx > 0))
+          if (r >= 2 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1))
             *reinterpret_cast<uint32_t*>(g + (r - 2) * cp + (c4 - 1) * 4) =
                 *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]);
         }
-      }
-      // ---- slide the last four columns to the left edge for the next macroblock
-      if (mbx + 1 < W) {
-        uint32_t keep = 0;
-        if (lane < 20) keep = *reinterpret_cast<const uint32_t*>(&L.lt[lane * LS + 16]);
-        else if (lane < 40) keep = *reinterpret_cast<const uint32_t*>(&L.ct[(lane - 20) / 10][((lane - 20) % 10) * CS + 8]);
-        wave_sync();
-        if (lane < 20) *reinterpret_cast<uint32_t*>(&L.lt[lane * LS]) = keep;
-        else if (lane < 40) *reinterpret_cast<uint32_t*>(&L.ct[(lane - 20) / 10][((lane - 20) % 10) * CS]) = keep;
+        tile_mbx = mbx;
       }
     }
     row_publish(progress, mby, W);
@@ -1300,6 +1450,8 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_in
   }
   if (any_intra) {
     if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_residual, dim3((max_mbs + kInterWaves - 1) / kInterWaves, njobs), dim3(kInterWaves * 64), 0, stream,
+                       jobs);
     hipLaunchKernelGGL(k_intra, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
     if (profiled) prof::end(span, stream, prof::K_INTRA, bytes[1]);
   }

@@ -340,6 +340,9 @@ struct Parser::Impl {
     // offset: av[(oy + 1) * 3 + ox + 1] for ox in -1..1, oy in -1..0
     bool av[6];
     bool avA, avB;
+    // motion record of each available, non-intra neighbour (same index as
+    // av[]; [4] = this macroblock), nullptr otherwise; filled by begin_mb
+    const MbMotion* nbmo[6];
     int sub_type[4];
     int8_t i4_mode[16];
     uint8_t nnz[24];
@@ -1147,18 +1150,16 @@ struct Parser::Impl {
   NB fetch_nb(int list, int rx, int ry, int cur_zz) const {
     NB nb = {-2, {0, 0}};
     if (rx > 3 && ry >= 0) return nb;
-    const int ox = rx < 0 ? -1 : (rx > 3 ? 1 : 0), oy = ry < 0 ? -1 : 0;
-    const int nx = mb.mbx + ox, ny = mb.mby + oy;
+    const int k = (ry < 0 ? 0 : 3) + (rx < 0 ? 0 : (rx > 3 ? 2 : 1));
     const int bx = rx & 3, by = ry & 3;
-    if (ox == 0 && oy == 0) {
+    if (k == 4) {
       if (raster_to_blk4[by * 4 + bx] >= cur_zz) return nb;
-    } else if (!nb_avail(ox, oy)) {
+    } else if (!mb.av[k]) {
       return nb;
     }
-    const int addr = ny * mbw + nx;
     nb.ref = -1;
-    if (cur->mb_intra[addr]) return nb;
-    const MbMotion& mo = cur->motion[addr];
+    if (!mb.nbmo[k]) return nb;  // intra neighbour
+    const MbMotion& mo = *mb.nbmo[k];
     int r = mo.ref_idx[list][(by >> 1) * 2 + (bx >> 1)];
     if (r < 0) return nb;
     nb.ref = r;
@@ -1194,11 +1195,10 @@ struct Parser::Impl {
 
   void set_mv_block(int list, int bx, int by, int bw, int bh, int mvx, int mvy) {
     MbMotion& mo = cur->motion[mb.addr];
+    const uint32_t packed = static_cast<uint16_t>(mvx) | (static_cast<uint32_t>(static_cast<uint16_t>(mvy)) << 16);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(mo.mv[list]);
     for (int y = by; y < by + bh; ++y)
-      for (int x = bx; x < bx + bw; ++x) {
-        mo.mv[list][y * 4 + x][0] = static_cast<int16_t>(mvx);
-        mo.mv[list][y * 4 + x][1] = static_cast<int16_t>(mvy);
-      }
+      for (int x = bx; x < bx + bw; ++x) dst[y * 4 + x] = packed;
   }
   void set_mvd_block(int list, int bx, int by, int bw, int bh, int dx, int dy) {
     uint8_t ax = static_cast<uint8_t>(imin(iabs(dx), 255)), ay = static_cast<uint8_t>(imin(iabs(dy), 255));
@@ -1866,6 +1866,15 @@ struct Parser::Impl {
 
   void begin_mb(int addr) {
     set_position(addr);
+    {
+      static const int off_x[4] = {-1, 0, 1, -1}, off_y[4] = {-1, -1, -1, 0};
+      for (int k = 0; k < 4; ++k) {
+        const int na = addr + off_y[k] * mbw + off_x[k];
+        mb.nbmo[k] = (mb.av[k] && !cur->mb_intra[na]) ? &cur->motion[na] : nullptr;
+      }
+      mb.nbmo[4] = &cur->motion[addr];
+      mb.nbmo[5] = nullptr;
+    }
     mb.kind = MB_NONE;
     mb.skip = mb.direct16 = mb.t8x8 = mb.i16_mode = mb.chroma_mode = mb.cbp = 0;
     mb.qp = qp;
