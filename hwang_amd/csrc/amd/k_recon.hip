@@ -62,6 +62,33 @@ __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 
 __device__ __forceinline__ int iabs(int v) { return v < 0 ? -v : v; }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 
+// Pointers that the kernels read out of the job table are "generic" to the
+// compiler, which then emits flat_load / flat_store.  Flat operations also
+// count on the LDS counter (lgkmcnt), so every wait for an LDS result would
+// wait for the global prefetches in flight as well - fatal for the row
+// pipelines, whose whole point is to keep loads and stores in flight across
+// LDS work.  All of these pointers are HBM (or pinned host memory mapped for
+// the GPU), so the accessors below go through address space 1 explicitly.
+#define HW_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ uint32_t gld32(const void* p) { return *(const HW_AS1 uint32_t*)p; }
+__device__ __forceinline__ uint16_t gld16(const void* p) { return *(const HW_AS1 uint16_t*)p; }
+__device__ __forceinline__ int gld16s(const void* p) { return *(const HW_AS1 int16_t*)p; }
+__device__ __forceinline__ uint8_t gld8(const void* p) { return *(const HW_AS1 uint8_t*)p; }
+__device__ __forceinline__ void gst32(void* p, uint32_t v) { *(HW_AS1 uint32_t*)p = v; }
+__device__ __forceinline__ void gst16(void* p, uint16_t v) { *(HW_AS1 uint16_t*)p = v; }
+__device__ __forceinline__ void gst8(void* p, uint8_t v) { *(HW_AS1 uint8_t*)p = v; }
+template <class T>
+__device__ __forceinline__ T gload(const T* p) {  // whole record, dword-wise
+  static_assert(sizeof(T) % 4 == 0, "dword-sized records only");
+  T out;
+  uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+  for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = gld32(reinterpret_cast<const uint32_t*>(p) + i);
+  return out;
+}
+template <class T>
+__device__ __forceinline__ T* gptr(T* p) { return p; }  // (documentation only: p is a global pointer)
+
 __device__ __forceinline__ int level_scale4(const uint8_t* weight, int qp, int pos) {
   const int i = pos >> 2, j = pos & 3;
   const int cls = ((i & 1) == 0 && (j & 1) == 0) ? 0 : (((i & 1) && (j & 1)) ? 1 : 2);
@@ -130,13 +157,16 @@ __device__ int combine_pred(const SliceParams& sp, int plane, bool use0, bool us
   return use0 ? s0 : s1;
 }
 
-// everything one wave wrote to LDS is visible to its other lanes afterwards
+// Everything one wave wrote to LDS is visible to its other lanes afterwards.
+// LDS instructions of a wave execute in issue order, so this only has to stop
+// the COMPILER from moving LDS accesses across it; a memory-model fence (even
+// at wavefront scope the backend pairs it with s_waitcnt vmcnt(0)) would drain
+// the global prefetches and stores that are deliberately left in flight.
 __device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __asm__ volatile("" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  __asm__ volatile("" ::: "memory");
 }
-
 
 // ---------------------------------------------------------------------------
 // Residual of one macroblock, computed by ONE wave (64 lanes) into LDS.
@@ -157,7 +187,7 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
         const int sa = (i == 0 || (i == 1 && a < 2) || (i == 2 && (a == 0 || a == 3)) || (i == 3 && (a & 1) == 0)) ? 1 : -1;
         for (int b = 0; b < 4; ++b) {
           const int sb = (j == 0 || (j == 1 && b < 2) || (j == 2 && (b == 0 || b == 3)) || (j == 3 && (b & 1) == 0)) ? 1 : -1;
-          f += sa * sb * g[a * 4 + b];
+          f += sa * sb * gld16s(g + a * 4 + b);
         }
       }
       const int ls = level_scale4(pp.scaling4[0], qp, 0);
@@ -171,10 +201,8 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
     int v = 0;
     if (g) {
       const int16_t* c = g + 4 * p;
-      const int f = k == 0 ? c[0] + c[1] + c[2] + c[3]
-                  : k == 1 ? c[0] - c[1] + c[2] - c[3]
-                  : k == 2 ? c[0] + c[1] - c[2] - c[3]
-                           : c[0] - c[1] - c[2] + c[3];
+      const int c0 = gld16s(c), c1 = gld16s(c + 1), c2 = gld16s(c + 2), c3 = gld16s(c + 3);
+      const int f = k == 0 ? c0 + c1 + c2 + c3 : k == 1 ? c0 - c1 + c2 - c3 : k == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3;
       const int qpc = mb.qpc[p];
       const int ls = level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, 0);
       v = ((f * ls) << (qpc / 6)) >> 5;
@@ -188,15 +216,17 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
     if (mb.flags & MBF_T8X8) {
       const int b8 = t >> 6, k = t & 63;
       const int16_t* g = coef_group(mb, coefs, 4 * b8);
-      if (g && g[k]) {
-        const int s = g[k] * level_scale8(pp.scaling8[intra ? 0 : 1], qp, k);
+      const int lv = g ? gld16s(g + k) : 0;
+      if (lv) {
+        const int s = lv * level_scale8(pp.scaling8[intra ? 0 : 1], qp, k);
         v = qp >= 36 ? s << (qp / 6 - 6) : (s + (1 << (5 - qp / 6))) >> (6 - qp / 6);
       }
     } else {
       const int blk = t >> 4, k = t & 15;
       const int16_t* g = coef_group(mb, coefs, blk);
-      if (g && g[k]) {
-        const int s = g[k] * level_scale4(pp.scaling4[intra ? 0 : 3], qp, k);
+      const int lv = g ? gld16s(g + k) : 0;
+      if (lv) {
+        const int s = lv * level_scale4(pp.scaling4[intra ? 0 : 3], qp, k);
         v = qp >= 24 ? s << (qp / 6 - 4) : (s + (1 << (3 - qp / 6))) >> (4 - qp / 6);
       }
       if (k == 0 && mb.kind == MBK_I16x16) v = dcs[blk];
@@ -208,8 +238,9 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
     const int16_t* g = coef_group(mb, coefs, kMaskChromaAc + 4 * p + blk);
     int v = 0;
     const int qpc = mb.qpc[p];
-    if (g && g[k]) {
-      const int s = g[k] * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, k);
+    const int lv = g ? gld16s(g + k) : 0;
+    if (lv) {
+      const int s = lv * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, k);
       v = qpc >= 24 ? s << (qpc / 6 - 4) : (s + (1 << (3 - qpc / 6))) >> (4 - qpc / 6);
     }
     if (k == 0) v = dcs[16 + 4 * p + blk];
@@ -293,7 +324,7 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
 // picture takes a byte-wise path with clamped coordinates (the padding of
 // unrestricted motion vectors); that is decided per lane.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { return *reinterpret_cast<const uint32_t*>(p); }
+__device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { return gld32(p); }
 
 // 12 bytes (3 dwords) of row y starting at column xs, coordinates clamped
 __device__ __forceinline__ void row_clamped(const uint8_t* plane, int pitch, int W, int H, int xs, int y, int nd,
@@ -304,7 +335,7 @@ __device__ __forceinline__ void row_clamped(const uint8_t* plane, int pitch, int
     if (d >= nd) break;
     uint32_t v = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) v |= (uint32_t)row[iclip(0, W - 1, xs + 4 * d + b)] << (8 * b);
+    for (int b = 0; b < 4; ++b) v |= (uint32_t)gld8(row + iclip(0, W - 1, xs + 4 * d + b)) << (8 * b);
     w[d] = v;
   }
 }
@@ -463,30 +494,33 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mbi = group * kInterWaves + wave;
   if (mbi >= nmb) return;
-  const MbMotion* __restrict__ mo = job.motions + mbi;
+  const MbMotion* __restrict__ mo = gptr(job.motions) + mbi;
   // the lane's motion data: luma block (row y, 4x4 column lane&3), chroma block
   const int y = lane >> 2, bcol = lane & 3;
   const int blk = (y >> 2) * 4 + bcol, b8 = (y >> 3) * 2 + (bcol >> 1);
   const int cplane = lane >> 5, ct = lane & 31, cy = ct >> 2, cbcol = ct & 3;
   const int cblk = (cy >> 1) * 4 + cbcol, cb8 = (cy >> 2) * 2 + (cbcol >> 1);
-  const uint32_t mvw0 = reinterpret_cast<const uint32_t*>(mo->mv[0])[blk];
-  const uint32_t mvw1 = reinterpret_cast<const uint32_t*>(mo->mv[1])[blk];
-  const uint32_t cmvw0 = reinterpret_cast<const uint32_t*>(mo->mv[0])[cblk];
-  const uint32_t cmvw1 = reinterpret_cast<const uint32_t*>(mo->mv[1])[cblk];
-  const uint32_t slots0 = *reinterpret_cast<const uint32_t*>(mo->ref_slot[0]);
-  const uint32_t slots1 = *reinterpret_cast<const uint32_t*>(mo->ref_slot[1]);
-  const uint32_t idx0 = *reinterpret_cast<const uint32_t*>(mo->ref_idx[0]);
-  const uint32_t idx1 = *reinterpret_cast<const uint32_t*>(mo->ref_idx[1]);
-  const MbInfo mb = job.mbs[mbi];
+  const uint32_t mvw0 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[0]) + blk);
+  const uint32_t mvw1 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[1]) + blk);
+  const uint32_t cmvw0 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[0]) + cblk);
+  const uint32_t cmvw1 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[1]) + cblk);
+  const uint32_t slots0 = gld32(mo->ref_slot[0]);
+  const uint32_t slots1 = gld32(mo->ref_slot[1]);
+  const uint32_t idx0 = gld32(mo->ref_idx[0]);
+  const uint32_t idx1 = gld32(mo->ref_idx[1]);
+  const MbInfo mb = gload(&job.mbs[mbi]);
   if (mb.kind != MBK_INTER) return;
   __shared__ InterWave lds[kInterWaves];
   InterWave& L = lds[wave];
   const int mbx = mbi % pp.mb_width, mby = mbi / pp.mb_width;
   const bool has_res = mb.coded_mask != 0;
-  if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+  if (has_res) wave_residual(mb, gptr(job.coefs), pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
 
-  const SliceParams& sp = job.slices[mb.slice];
-  const Surface cur = pp.surfaces[pp.cur_slot];
+  const SliceParams& sp = gptr(job.slices)[mb.slice];
+  Surface cur = pp.surfaces[pp.cur_slot];
+  cur.y = gptr(cur.y);
+  cur.u = gptr(cur.u);
+  cur.v = gptr(cur.v);
   const int W = pp.mb_width * 16, H = pp.mb_height * 16;
   auto byte_of = [](uint32_t w, int k) { return (int)(int8_t)((w >> (8 * k)) & 0xff); };
   {  // luma
@@ -494,9 +528,9 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     const int px = mbx * 16 + bcol * 4, py = mby * 16 + y;
     int s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     if (r0 >= 0)
-      luma_pred4(pp.surfaces[byte_of(slots0, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
+      luma_pred4(gptr(pp.surfaces[byte_of(slots0, b8)].y), pp.y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
     if (r1 >= 0)
-      luma_pred4(pp.surfaces[byte_of(slots1, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
+      luma_pred4(gptr(pp.surfaces[byte_of(slots1, b8)].y), pp.y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -504,7 +538,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
       const int v = has_res ? clip8(pred + L.res_y[y * 16 + bcol * 4 + i]) : pred;
       packed |= (uint32_t)v << (8 * i);
     }
-    *reinterpret_cast<uint32_t*>(cur.y + (size_t)py * pp.y_pitch + px) = packed;
+    gst32(cur.y + (size_t)py * pp.y_pitch + px, packed);
   }
   {  // chroma: lanes 0..31 Cb, 32..63 Cr
     const int r0 = byte_of(idx0, cb8), r1 = byte_of(idx1, cb8);
@@ -512,11 +546,11 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     int s0[2] = {0, 0}, s1[2] = {0, 0};
     if (r0 >= 0) {
       const Surface& sf = pp.surfaces[byte_of(slots0, cb8)];
-      chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
+      chroma_pred2(gptr(cplane ? sf.v : sf.u), pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
     }
     if (r1 >= 0) {
       const Surface& sf = pp.surfaces[byte_of(slots1, cb8)];
-      chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
+      chroma_pred2(gptr(cplane ? sf.v : sf.u), pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
     }
     uint32_t packed = 0;
 #pragma unroll
@@ -526,7 +560,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
       packed |= (uint32_t)v << (8 * i);
     }
     uint8_t* dst = cplane ? cur.v : cur.u;
-    *reinterpret_cast<uint16_t*>(dst + (size_t)py * pp.c_pitch + px) = (uint16_t)packed;
+    gst16(dst + (size_t)py * pp.c_pitch + px, (uint16_t)packed);
   }
 }
 
@@ -554,13 +588,22 @@ namespace {
 constexpr int kRowWaves = 16;
 constexpr int kMaxRows = 512;
 
+// The counters live in LDS and must be addressed as such: through a generic
+// volatile pointer they become flat_load ... sc0 sc1 followed by s_waitcnt
+// vmcnt(0), i.e. every poll would drain the wave's global traffic.
+typedef volatile __attribute__((address_space(3))) int lds_counter;
+
 // progress[r + 1] = macroblocks of row r that are complete; progress[0] is
 // the (always complete) row above the picture
-__device__ __forceinline__ void row_wait(volatile int* progress, int row, int need) {
+// The producer completed its global stores (s_waitcnt vmcnt(0)) before it
+// raised the counter, all waves of the workgroup share the CU's L1, and this
+// wave issues its dependent loads after the poll returns: no acquire fence
+// (which would also drain this wave's own outstanding stores and prefetches).
+__device__ __forceinline__ void row_wait(lds_counter* progress, int row, int need) {
   while (progress[row] < need) __builtin_amdgcn_s_sleep(1);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  __asm__ volatile("" ::: "memory");
 }
-__device__ __forceinline__ void row_publish(volatile int* progress, int row, int done) {
+__device__ __forceinline__ void row_publish(lds_counter* progress, int row, int done) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // global stores of this wave have landed
   progress[row + 1] = done;
 }
@@ -700,23 +743,23 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mbi = blockIdx.x * kInterWaves + wave;
   if (mbi >= nmb) return;
-  const MbInfo mb = job.mbs[mbi];
+  const MbInfo mb = gload(&job.mbs[mbi]);
   if (!(mb.flags & MBF_INTRA) || mb.kind == MBK_IPCM) return;
   __shared__ InterWave lds[kInterWaves];
   InterWave& L = lds[wave];
-  uint32_t* out = reinterpret_cast<uint32_t*>(job.resid + (size_t)mbi * 384);
+  uint32_t* out = reinterpret_cast<uint32_t*>(gptr(job.resid) + (size_t)mbi * 384);
   if (mb.coded_mask == 0) {
-    out[lane] = 0;
-    out[64 + lane] = 0;
-    out[128 + lane] = 0;
+    gst32(out + lane, 0);
+    gst32(out + 64 + lane, 0);
+    gst32(out + 128 + lane, 0);
     return;
   }
-  wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+  wave_residual(mb, gptr(job.coefs), pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
   const uint32_t* ry = reinterpret_cast<const uint32_t*>(L.res_y);
   const uint32_t* rc = reinterpret_cast<const uint32_t*>(L.res_c);
-  out[lane] = ry[lane];
-  out[64 + lane] = ry[64 + lane];
-  out[128 + lane] = rc[lane];
+  gst32(out + lane, ry[lane]);
+  gst32(out + 64 + lane, ry[64 + lane]);
+  gst32(out + 128 + lane, rc[lane]);
 }
 
 // ===========================================================================
@@ -740,53 +783,56 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
   const JobDesc& job = jobs[blockIdx.x];
   if (!job.do_intra) return;
   const PictureParams& pp = job.pp;
-  const MbInfo* __restrict__ mbs = job.mbs;
-  const int16_t* __restrict__ coefs = job.coefs;
+  const MbInfo* __restrict__ mbs = gptr(job.mbs);
+  const int16_t* __restrict__ coefs = gptr(job.coefs);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ int s_progress[kMaxRows + 1];
   __shared__ IntraWaveLds s_lds[kRowWaves];
   __shared__ uint8_t s_line[kRowWaves][kLineMbs][32];
-  volatile int* progress = s_progress;
+  lds_counter* progress = (lds_counter*)s_progress;
   for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
   __syncthreads();
   IntraWaveLds& L = s_lds[wave];
   uint8_t* tile = L.tile;
-  const Surface cur = pp.surfaces[pp.cur_slot];
+  Surface cur = pp.surfaces[pp.cur_slot];
+  cur.y = gptr(cur.y);
+  cur.u = gptr(cur.u);
+  cur.v = gptr(cur.v);
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const bool lds_nb = !job.do_inter && pp.mb_width <= kLineMbs;  // wave uniform
   uint8_t (*line_up)[32] = s_line[(wave + kRowWaves - 1) % kRowWaves];
   uint8_t (*line_me)[32] = s_line[wave];
 
-  const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(job.resid);
+  const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(gptr(job.resid));
   for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
     int prev_mbx = -2;  // macroblock whose samples the tile still holds
     for (int mbx0 = 0; mbx0 < pp.mb_width; mbx0 += 64) {
       // which of the next 64 macroblocks of this row are intra?
       const int probe = mbx0 + lane;
-      const bool is_intra = probe < pp.mb_width && (mbs[mby * pp.mb_width + probe].flags & MBF_INTRA);
+      const bool is_intra = probe < pp.mb_width && (gld8(&mbs[mby * pp.mb_width + probe].flags) & MBF_INTRA);
       unsigned long long todo = __ballot(is_intra);
       // residual of the first macroblock of the run; inside the loop the next one's is fetched a macroblock ahead
       uint32_t r0 = 0, r1 = 0, r2 = 0;
       if (todo) {
         const uint32_t* rp = resid + (size_t)(mby * pp.mb_width + mbx0 + __builtin_ctzll(todo)) * 192;
-        r0 = rp[lane];
-        r1 = rp[64 + lane];
-        r2 = rp[128 + lane];
+        r0 = gld32(rp + lane);
+        r1 = gld32(rp + 64 + lane);
+        r2 = gld32(rp + 128 + lane);
       }
       while (todo) {
         const int mbx = mbx0 + __builtin_ctzll(todo);
         todo &= todo - 1;
         const int mbi = mby * pp.mb_width + mbx;
-        const MbInfo mb = mbs[mbi];
+        const MbInfo mb = gload(&mbs[mbi]);
         // land this macroblock's residual in LDS, start the next one's loads
         reinterpret_cast<uint32_t*>(L.res_y)[lane] = r0;
         reinterpret_cast<uint32_t*>(L.res_y)[64 + lane] = r1;
         reinterpret_cast<uint32_t*>(L.res_c)[lane] = r2;
         if (todo) {
           const uint32_t* rp = resid + (size_t)(mby * pp.mb_width + mbx0 + __builtin_ctzll(todo)) * 192;
-          r0 = rp[lane];
-          r1 = rp[64 + lane];
-          r2 = rp[128 + lane];
+          r0 = gld32(rp + lane);
+          r1 = gld32(rp + 64 + lane);
+          r2 = gld32(rp + 128 + lane);
         }
         uint8_t* dy = cur.y + (size_t)(mby * 16) * yp + mbx * 16;
         uint8_t* du = cur.u + (size_t)(mby * 8) * cp + mbx * 8;
@@ -826,26 +872,26 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
           }
         } else {
           if (lane < 25)
-            tile[lane] = (lane == 0) ? (hD ? dy[-yp - 1] : 128) : (lane <= 16) ? (hB ? dy[-yp + lane - 1] : 128)
-                                                                               : (hC ? dy[-yp + lane - 1] : 128);
+            tile[lane] = (lane == 0) ? (hD ? gld8(dy - yp - 1) : 128) : (lane <= 16) ? (hB ? gld8(dy - yp + lane - 1) : 128)
+                                                                                     : (hC ? gld8(dy - yp + lane - 1) : 128);
           else if (lane >= 32 && lane < 48)
-            tile[(lane - 31) * TS] = hA ? dy[(lane - 32) * yp - 1] : 128;
+            tile[(lane - 31) * TS] = hA ? gld8(dy + (lane - 32) * yp - 1) : 128;
           if (lane < 18) {
             const int p = lane / 9, i = lane % 9;
             const uint8_t* d = p ? dv : du;
-            L.ctile[p][i] = (i == 0) ? (hD ? d[-cp - 1] : 128) : (hB ? d[-cp + i - 1] : 128);
+            L.ctile[p][i] = (i == 0) ? (hD ? gld8(d - cp - 1) : 128) : (hB ? gld8(d - cp + i - 1) : 128);
           } else if (lane >= 32 && lane < 48) {
             const int p = (lane - 32) >> 3, j = (lane - 32) & 7;
             const uint8_t* d = p ? dv : du;
-            L.ctile[p][(j + 1) * 12] = hA ? d[j * cp - 1] : 128;
+            L.ctile[p][(j + 1) * 12] = hA ? gld8(d + j * cp - 1) : 128;
           }
         }
         wave_sync();
 
         if (pcm) {
           const uint8_t* src = reinterpret_cast<const uint8_t*>(coefs + mb.coef_offset);
-          for (int t = lane; t < 256; t += 64) tile[(1 + (t >> 4)) * TS + 1 + (t & 15)] = src[t];
-          for (int t = lane; t < 128; t += 64) L.ctile[t >> 6][(1 + ((t >> 3) & 7)) * 12 + 1 + (t & 7)] = src[256 + t];
+          for (int t = lane; t < 256; t += 64) tile[(1 + (t >> 4)) * TS + 1 + (t & 15)] = gld8(src + t);
+          for (int t = lane; t < 128; t += 64) L.ctile[t >> 6][(1 + ((t >> 3) & 7)) * 12 + 1 + (t & 7)] = gld8(src + 256 + t);
         } else if (mb.kind == MBK_I16x16) {
           const int mode = mb.pred_modes & 15;
           int dcv = 128, a = 0, b = 0, c = 0;
@@ -995,12 +1041,12 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
           const int r = lane >> 2, c4 = (lane & 3) * 4;
           const uint8_t* tp = tile + (1 + r) * TS + 1 + c4;
           const uint32_t v = tp[0] | (tp[1] << 8) | (tp[2] << 16) | ((uint32_t)tp[3] << 24);
-          *reinterpret_cast<uint32_t*>(dy + (size_t)r * yp + c4) = v;
+          gst32(dy + (size_t)r * yp + c4, v);
           if (lane < 32) {
             const int p = lane >> 4, rr = (lane >> 1) & 7, cc = (lane & 1) * 4;
             const uint8_t* cpx = L.ctile[p] + (1 + rr) * 12 + 1 + cc;
             const uint32_t w = cpx[0] | (cpx[1] << 8) | (cpx[2] << 16) | ((uint32_t)cpx[3] << 24);
-            *reinterpret_cast<uint32_t*>((p ? dv : du) + (size_t)rr * cp + cc) = w;
+            gst32((p ? dv : du) + (size_t)rr * cp + cc, w);
           }
         }
         if (lds_nb) {
@@ -1138,13 +1184,15 @@ __device__ int boundary_strength(const MbInfo& pm, const MbInfo& qm, const MbMot
 // the table indices indexA / indexB per plane for the left edge, the top edge
 // and the internal edges.
 struct DbInfo {
-  uint8_t bs[32];
+  uint8_t bs[2][4][4];   // [0 vertical / 1 horizontal edges][position along the edge / 4][edge 0..3]:
+                         // the four strengths one filter lane needs are one dword
   uint8_t alpha[3][3];   // [plane][0 left, 1 top, 2 internal]
   uint8_t beta[3][3];
   uint8_t tc0[3][3][3];  // [plane][class][bS - 1]
   uint8_t t8x8;
   uint8_t any;           // some bs != 0
-  uint8_t pad[17];
+  uint8_t emask;         // bit e: vertical edge e has a non-zero bS, bit 4 + e: horizontal edge e
+  uint8_t pad[16];
 };
 static_assert(sizeof(DbInfo) == 96, "DbInfo must stay 96 bytes");
 
@@ -1166,10 +1214,10 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
   const JobDesc& job = jobs[blockIdx.y];
   if (!job.do_deblock) return;
   const PictureParams& pp = job.pp;
-  const MbInfo* __restrict__ mbs = job.mbs;
-  const MbMotion* __restrict__ motions = job.motions;
-  const SliceParams* __restrict__ slices = job.slices;
-  DbInfo* __restrict__ out = static_cast<DbInfo*>(job.db);
+  const MbInfo* __restrict__ mbs = gptr(job.mbs);
+  const MbMotion* __restrict__ motions = gptr(job.motions);
+  const SliceParams* __restrict__ slices = gptr(job.slices);
+  DbInfo* __restrict__ out = gptr(static_cast<DbInfo*>(job.db));
   const int nmb = pp.mb_width * pp.mb_height;
   const int mbi = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int t = threadIdx.x & 31;
@@ -1195,7 +1243,7 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
     }
   }
   DbInfo* o = &out[mbi];
-  o->bs[t] = (uint8_t)bs;
+  o->bs[dir][k][e] = (uint8_t)bs;
   const unsigned long long nz = __ballot(bs != 0);
   if (t < 9) {
     const int plane = t / 3, cls = t % 3;  // cls: 0 left, 1 top, 2 internal
@@ -1219,6 +1267,10 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
     // lanes of this macroblock are bits [32*(mb&1) ...) of the wave's ballot
     const unsigned mine = (unsigned)(nz >> (32 * ((threadIdx.x >> 5) & 1)));
     o->any = mine != 0;
+    unsigned em = 0;  // lane t = dir * 16 + e * 4 + k: one nibble per edge
+    for (int g = 0; g < 8; ++g)
+      if ((mine >> (4 * g)) & 0xf) em |= 1u << g;
+    o->emask = (uint8_t)em;
   }
 }
 
@@ -1233,16 +1285,19 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
   const JobDesc& job = jobs[blockIdx.x];
   if (!job.do_deblock) return;
   const PictureParams& pp = job.pp;
-  const DbInfo* __restrict__ dbs = static_cast<const DbInfo*>(job.db);
+  const DbInfo* __restrict__ dbs = gptr(static_cast<const DbInfo*>(job.db));
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ int s_progress[kMaxRows + 1];
   __shared__ DeblockWaveLds s_lds[kRowWaves];
-  volatile int* progress = s_progress;
+  lds_counter* progress = (lds_counter*)s_progress;
   for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
   __syncthreads();
   DeblockWaveLds& L = s_lds[wave];
   uint8_t* lt = L.lt;
-  const Surface cur = pp.surfaces[pp.cur_slot];
+  Surface cur = pp.surfaces[pp.cur_slot];
+  cur.y = gptr(cur.y);
+  cur.u = gptr(cur.u);
+  cur.v = gptr(cur.v);
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const int W = pp.mb_width;
 
@@ -1261,23 +1316,24 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
       // Macroblocks without a single edge to filter are skipped outright: they
       // load nothing, store nothing; the counter simply jumps over them.
       const int probe = mbx0 + lane;
-      unsigned long long todo = __ballot(probe < W && rowdb[probe].any != 0);
+      unsigned long long todo = __ballot(probe < W && gld8(&rowdb[probe].any) != 0);
       // prefetch of the first macroblock to filter
       uint32_t n_luma = 0, n_chroma = 0, n_db = 0, n_left = 0;
       auto prefetch = [&](int mbx) {
         const uint8_t* gy = rowy + mbx * 16;
-        n_luma = *reinterpret_cast<const uint32_t*>(gy + lr * yp + lc4 * 4);
-        if (lane < 32) n_chroma = *reinterpret_cast<const uint32_t*>((cpn ? rowv : rowu) + mbx * 8 + ccr * cp + ccc * 4);
-        if (lane < 24) n_db = reinterpret_cast<const uint32_t*>(rowdb + mbx)[lane];
+        n_luma = gld32(gy + lr * yp + lc4 * 4);
+        if (lane < 32) n_chroma = gld32((cpn ? rowv : rowu) + mbx * 8 + ccr * cp + ccc * 4);
+        if (lane < 24) n_db = gld32(reinterpret_cast<const uint32_t*>(rowdb + mbx) + lane);
         // the four columns to the left, in case the left neighbour was skipped:
         // lanes 0..15 luma rows, 16..31 chroma rows of both planes
         if (mbx > 0) {
-          if (lane < 16) n_left = *reinterpret_cast<const uint32_t*>(gy + lane * yp - 4);
-          else if (lane < 32) n_left = *reinterpret_cast<const uint32_t*>((((lane - 16) >> 3) ? rowv : rowu) + mbx * 8 +
-                                                                           ((lane - 16) & 7) * cp - 4);
+          if (lane < 16) n_left = gld32(gy + lane * yp - 4);
+          else if (lane < 32) n_left = gld32((((lane - 16) >> 3) ? rowv : rowu) + mbx * 8 + ((lane - 16) & 7) * cp - 4);
         }
       };
       if (todo) prefetch(mbx0 + __builtin_ctzll(todo));
+      // (complete before the loop, so that inside it the registers count as ready - see below)
+      asm volatile("" : "+v"(n_luma), "+v"(n_chroma), "+v"(n_db), "+v"(n_left));
 
       while (todo) {
         const int mbx = mbx0 + __builtin_ctzll(todo);
@@ -1285,10 +1341,6 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
         uint8_t* gy = rowy + mbx * 16;
         uint8_t* gu = rowu + mbx * 8;
         uint8_t* gv = rowv + mbx * 8;
-        // ---- everything before this macroblock is final once the previous
-        // filtered one's stores have landed (they had an iteration to do so)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        progress[mby + 1] = mbx;
         // ---- left columns: slide from the tile, or take the prefetched ones
         if (tile_mbx == mbx - 1) {
           uint32_t keep = 0;
@@ -1307,37 +1359,45 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
         if (lane < 24) reinterpret_cast<uint32_t*>(&L.db)[lane] = n_db;
         if (todo) prefetch(mbx0 + __builtin_ctzll(todo));
         wave_sync();
-        const int t8 = L.db.t8x8;
-        const bool top_edge = mby > 0 && *reinterpret_cast<const uint32_t*>(&L.db.bs[16]) != 0;
+        // ---- this lane's parameters for all eight edge steps, in registers
+        const int emask = L.db.emask;
+        const bool top_edge = mby > 0 && (emask & 0x10);
+        const int kk = lane < 16 ? (lane >> 2) : (((lane - 16) & 7) >> 1);
+        const int pl = lane < 16 ? 0 : (lane < 32 ? 1 + ((lane - 16) >> 3) : 0);
+        const uint32_t vbs = *reinterpret_cast<const uint32_t*>(L.db.bs[0][kk]);
+        const uint32_t hbs = *reinterpret_cast<const uint32_t*>(L.db.bs[1][kk]);
+        const uint32_t a3 = L.db.alpha[pl][0] | (L.db.alpha[pl][1] << 8) | (L.db.alpha[pl][2] << 16);
+        const uint32_t b3 = L.db.beta[pl][0] | (L.db.beta[pl][1] << 8) | (L.db.beta[pl][2] << 16);
+        uint32_t tcw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tcw[c] = L.db.tc0[pl][c][0] | (L.db.tc0[pl][c][1] << 8) | (L.db.tc0[pl][c][2] << 16);
         // ---- rows above: wait for the row above to be two macroblocks ahead
         uint32_t top_word = 0;
         if (top_edge) {
           row_wait(progress, mby, min(mbx + 2, W));
-          if (lane < 16) top_word = *reinterpret_cast<const uint32_t*>(gy + ((lane >> 2) - 4) * yp + (lane & 3) * 4);
+          if (lane < 16) top_word = gld32(gy + ((lane >> 2) - 4) * yp + (lane & 3) * 4);
           else if (lane < 24) {
             const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
-            top_word = *reinterpret_cast<const uint32_t*>((p ? gv : gu) + (cr - 2) * cp + cc * 4);
+            top_word = gld32((p ? gv : gu) + (cr - 2) * cp + cc * 4);
           }
         }
         // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each
+#pragma unroll
         for (int e = 0; e < 4; ++e) {
+          if (!((emask >> e) & 1)) continue;  // wave uniform: nothing on this edge
+          const int bs = (vbs >> (8 * e)) & 0xff;
+          const int cls = e == 0 ? 0 : 2;
+          const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
+          const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
           if (lane < 16) {
-            const int bs = L.db.bs[e * 4 + (lane >> 2)];
-            if (bs && !(t8 && (e & 1))) {
-              const int cls = e == 0 ? 0 : 2;
-              filter_edge(lt + (4 + lane) * LS + 4 + e * 4, 1, bs, L.db.alpha[0][cls], L.db.beta[0][cls],
-                          bs < 4 ? L.db.tc0[0][cls][bs - 1] : 0, false);
-            }
+            if (bs) filter_edge(lt + (4 + lane) * LS + 4 + e * 4, 1, bs, alpha, beta, tc0, false);
           } else if (lane < 32 && !(e & 1)) {
             const int p = (lane - 16) >> 3, i = (lane - 16) & 7;
-            const int bs = L.db.bs[e * 4 + (i >> 1)];
             if (bs) {
-              const int cls = e == 0 ? 0 : 2;
               // chroma vertical edge: p1 p0 | q0 q1 -> bytes q-2 .. q+1
               uint8_t* q = L.ct[p] + (2 + i) * CS + 4 + e * 2;
               int v[8] = {0, 0, q[-2], q[-1], q[0], q[1], 0, 0};
-              if (filter_line(v, bs, L.db.alpha[1 + p][cls], L.db.beta[1 + p][cls],
-                              bs < 4 ? L.db.tc0[1 + p][cls][bs - 1] : 0, true)) {
+              if (filter_line(v, bs, alpha, beta, tc0, true)) {
                 q[-1] = (uint8_t)v[3];
                 q[0] = (uint8_t)v[4];
               }
@@ -1355,25 +1415,30 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
           wave_sync();
         }
         // ---- horizontal edges: lanes 0..15 one luma column each, 16..31 chroma columns
-        for (int e = top_edge ? 0 : 1; e < 4; ++e) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (!((emask >> (4 + e)) & 1) || (e == 0 && !top_edge)) continue;
+          const int bs = (hbs >> (8 * e)) & 0xff;
+          const int cls = e == 0 ? 1 : 2;
+          const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
+          const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
           if (lane < 16) {
-            const int bs = L.db.bs[16 + e * 4 + (lane >> 2)];
-            if (bs && !(t8 && (e & 1))) {
-              const int cls = e == 0 ? 1 : 2;
-              filter_edge(lt + (4 + e * 4) * LS + 4 + lane, LS, bs, L.db.alpha[0][cls], L.db.beta[0][cls],
-                          bs < 4 ? L.db.tc0[0][cls][bs - 1] : 0, false);
-            }
+            if (bs) filter_edge(lt + (4 + e * 4) * LS + 4 + lane, LS, bs, alpha, beta, tc0, false);
           } else if (lane < 32 && !(e & 1)) {
             const int p = (lane - 16) >> 3, i = (lane - 16) & 7;
-            const int bs = L.db.bs[16 + e * 4 + (i >> 1)];
-            if (bs) {
-              const int cls = e == 0 ? 1 : 2;
-              filter_edge(L.ct[p] + (2 + e * 2) * CS + 4 + i, CS, bs, L.db.alpha[1 + p][cls], L.db.beta[1 + p][cls],
-                          bs < 4 ? L.db.tc0[1 + p][cls][bs - 1] : 0, true);
-            }
+            if (bs) filter_edge(L.ct[p] + (2 + e * 2) * CS + 4 + i, CS, bs, alpha, beta, tc0, true);
           }
           wave_sync();
         }
+        // ---- the previous filtered macroblock's stores have had this whole
+        // iteration to land: make sure, then everything before this macroblock
+        // is final (skipped ones included)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        progress[mby + 1] = mbx;
+        // The prefetched registers are complete too; saying so here keeps the
+        // compiler from waiting for them at the top of the next iteration, where
+        // its in-order counter would also cover the stores issued just below.
+        asm volatile("" : "+v"(n_luma), "+v"(n_chroma), "+v"(n_db), "+v"(n_left));
         // ---- store what the filters may have touched: rows 0..15 x cols -4..15
         // and, with a top edge, rows -4..-1 x cols 0..15 (chroma: rows 0..7 x
         // cols -4..7 and rows -2..-1 x cols 0..7).  The corner above-left belongs
@@ -1381,15 +1446,13 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
         for (int t = lane; t < 100; t += 64) {
           const int r = t / 5, c4 = t % 5;
           if (r >= 4 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1))
-            *reinterpret_cast<uint32_t*>(gy + (r - 4) * yp + (c4 - 1) * 4) =
-                *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]);
+            gst32(gy + (r - 4) * yp + (c4 - 1) * 4, *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]));
         }
         if (lane < 60) {
           const int p = lane / 30, t = lane % 30, r = t / 3, c4 = t % 3;
           uint8_t* g = p ? gv : gu;
           if (r >= 2 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1))
-            *reinterpret_cast<uint32_t*>(g + (r - 2) * cp + (c4 - 1) * 4) =
-                *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]);
+            gst32(g + (r - 2) * cp + (c4 - 1) * 4, *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]));
         }
         tile_mbx = mbx;
       }
@@ -1418,8 +1481,8 @@ __global__ __launch_bounds__(256) void k_upload(const JobDesc* __restrict__ jobs
   const UploadDesc u = job.uploads[a];
   const uint64_t n16 = u.bytes >> 4;
   typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-  const v4u* __restrict__ src = static_cast<const v4u*>(u.src);
-  v4u* __restrict__ dst = static_cast<v4u*>(u.dst);
+  const HW_AS1 v4u* __restrict__ src = (const HW_AS1 v4u*)u.src;
+  HW_AS1 v4u* __restrict__ dst = (HW_AS1 v4u*)u.dst;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)kUploadBlocks * 256)
     dst[i] = __builtin_nontemporal_load(&src[i]);
   if (blockIdx.x == 0) {
