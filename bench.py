@@ -143,6 +143,31 @@ def cpu_baseline(path, index, rows, workers):
     }
 
 
+# Kernels inside each HIP-event span, and the span's algorithmic bytes per
+# 1080p picture (S = 1.5 * 1920 * 1088).
+_S = 1920 * 1088 * 3 // 2
+SPAN_KERNELS = {"inter_pred": (["k_inter"], 2 * _S), "intra_pred": (["k_residual", "k_intra"], _S),
+                "deblock": (["k_bs", "k_deblock"], 2 * _S), "yuv420_to_rgb24": (["convert_batch"], 9 * WIDTH * HEIGHT // 2)}
+
+
+def pmc_traffic_per_launch(span, alg_bytes_per_launch):
+    """HBM bytes per launch of `span` from the committed rocprofv3 --pmc passes
+    (profiles/pmc_summary.json: FETCH_SIZE x 2 + WRITE_SIZE per picture, see
+    tools/pmc_summary.py), scaled to this run's pictures per launch.  None if
+    no PMC summary has been committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary.json")
+    if span not in SPAN_KERNELS or not os.path.exists(path):
+        return None
+    pmc = json.load(open(path))
+    kernels, alg_per_picture = SPAN_KERNELS[span]
+    per_picture = 0
+    for k in kernels:
+        if k not in pmc or pmc[k].get("fetch_bytes_per_picture") is None:
+            return None
+        per_picture += pmc[k]["fetch_bytes_per_picture"] + pmc[k]["write_bytes_per_picture"]
+    return round(per_picture * alg_bytes_per_launch / alg_per_picture)
+
+
 def effective_cpus():
     """Hardware threads, capped by the cgroup CPU quota (cpu.max) if any."""
     n = float(len(os.sched_getaffinity(0)))
@@ -206,9 +231,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    # 0 = one lane per CPU this process may use (the library reads the cgroup
-    # quota); with several ranks on one host the CPUs are shared
-    lanes = args.lanes or (0 if world == 1 else max(2, effective_cpus() // world))
+    # four lanes per usable CPU (a lane mostly waits for the GPU; the CPUs are
+    # the bottleneck); with several ranks on one host the CPUs are shared
+    lanes = args.lanes or max(2, min(128, 4 * effective_cpus() // world))
     dec = hw.Decoder(path, video_index=index, device_id=local_rank, num_lanes=lanes)
     out = torch.empty((len(rows), HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda")
 
@@ -263,7 +288,9 @@ def main():
         if best:
             achieved = best[2] / (best[1] * 1e-6) / 1e9
             roofline = {"bound": "hbm", "kernel": best[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": pmc_traffic_per_launch(best[0], best[2] / best[3]),
+                        "algorithmic_bytes_per_launch": round(best[2] / best[3]),
                         "launches": int(best[3]), "avg_launch_us": round(best[1] / best[3], 1)}
     if world > 1:
         dist.barrier()
@@ -287,7 +314,7 @@ def main():
             "config": {"workload": "C1: single 1080p30 High-profile CABAC mp4, %d frames, GOP %d, %d B-frames, "
                                    "1%% uniform-random rows (%d per GPU) returned as RGB24 in HBM"
                                    % (n, GOP, BFRAMES, len(rows)),
-                       "lanes_per_gpu": lanes or effective_cpus(), "host_cpus": effective_cpus(), "sharding": "keyframe-anchored intervals, no collective"},
+                       "lanes_per_gpu": lanes, "host_cpus": effective_cpus(), "sharding": "keyframe-anchored intervals, no collective"},
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
             "roofline": roofline,
             "kernels": kernels,

@@ -117,12 +117,20 @@ PROTOTYPES = {
     "hwang_prof_kernel_name": (C.c_char_p, [C.c_int]),
     "hwang_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "hwang_prof_reset": (None, []),
+    "hwang_shutdown": (None, []),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():
     _fn = getattr(lib, _name)  # AttributeError here == library out of date
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+# Stop the executor threads while the interpreter (and the HIP runtime, and any
+# profiler wrapped around it) is still fully alive.
+import atexit  # noqa: E402
+
+atexit.register(lib.hwang_shutdown)
 
 
 def u64_array(values):

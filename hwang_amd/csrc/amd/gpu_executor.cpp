@@ -114,6 +114,27 @@ void GpuExecutor::stop() {
   cv_work_.notify_all();
   for (Engine& en : engines_)
     if (en.thread.joinable()) en.thread.join();
+  // leave nothing of ours for the runtime's own teardown to trip over
+  (void)hipSetDevice(device_);
+  for (Engine& en : engines_) {
+    if (en.stream) (void)hipStreamSynchronize(en.stream);
+    if (en.copy_stream && en.copy_stream != en.stream) {
+      (void)hipStreamSynchronize(en.copy_stream);
+      (void)hipStreamDestroy(en.copy_stream);
+    }
+    if (en.stream) (void)hipStreamDestroy(en.stream);
+    en.stream = en.copy_stream = nullptr;
+    for (int i = 0; i < kInflight; ++i) {
+      if (en.copied[i]) (void)hipEventDestroy(en.copied[i]);
+      if (en.job_table_host[i]) (void)hipHostFree(en.job_table_host[i]);
+      if (en.job_table_dev[i]) (void)hipFree(en.job_table_dev[i]);
+      if (en.conv_table_host[i]) (void)hipHostFree(en.conv_table_host[i]);
+      if (en.conv_table_dev[i]) (void)hipFree(en.conv_table_dev[i]);
+      en.copied[i] = nullptr;
+      en.job_table_host[i] = en.job_table_dev[i] = nullptr;
+      en.conv_table_host[i] = en.conv_table_dev[i] = nullptr;
+    }
+  }
 }
 
 int GpuExecutor::register_lane() {
@@ -369,3 +390,5 @@ void GpuExecutor::run(int engine) {
 
 }  // namespace amd
 }  // namespace hwang
+
+extern "C" void hwang_shutdown(void) { hwang::amd::shutdown_executors(); }

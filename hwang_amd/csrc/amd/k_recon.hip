@@ -1242,20 +1242,23 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
       else bs = boundary_strength(mb, mb, &motions[mbi], &motions[mbi], pblk, qblk, false);
     }
   }
-  DbInfo* o = &out[mbi];
+  // The record is assembled in LDS and leaves as 24 dwords: single-byte global
+  // stores from 32 lanes cost ~14x the record's size in HBM write traffic
+  // (rocprofv3 WRITE_SIZE: 11.2 MB per 1080p picture for 0.78 MB of records).
+  __shared__ DbInfo s_db[8];
+  DbInfo* o = &s_db[threadIdx.x >> 5];
   o->bs[dir][k][e] = (uint8_t)bs;
   const unsigned long long nz = __ballot(bs != 0);
   if (t < 9) {
     const int plane = t / 3, cls = t % 3;  // cls: 0 left, 1 top, 2 internal
     const SliceParams& sp = slices[mb.slice];
-    int qn;
-    if (cls == 2 || (cls == 0 && !do_left) || (cls == 1 && !do_top)) {
-      qn = plane == 0 ? mb.qp : mb.qpc[plane - 1];
-    } else {
-      const MbInfo nb = mbs[cls == 0 ? mbi - 1 : mbi - pp.mb_width];
-      qn = plane == 0 ? nb.qp : nb.qpc[plane - 1];
+    // (no dynamic indexing into the header copies: that would put them in scratch memory)
+    const int qc = plane == 0 ? mb.qp : (plane == 1 ? mb.qpc[0] : mb.qpc[1]);
+    int qn = qc;
+    if (!(cls == 2 || (cls == 0 && !do_left) || (cls == 1 && !do_top))) {
+      const MbInfo nb = gload(&mbs[cls == 0 ? mbi - 1 : mbi - pp.mb_width]);
+      qn = plane == 0 ? nb.qp : (plane == 1 ? nb.qpc[0] : nb.qpc[1]);
     }
-    const int qc = plane == 0 ? mb.qp : mb.qpc[plane - 1];
     const int qpav = (qn + qc + 1) >> 1;
     const int ia = iclip(0, 51, qpav + sp.alpha_offset), ib = iclip(0, 51, qpav + sp.beta_offset);
     o->alpha[plane][cls] = c_alpha[ia];
@@ -1272,6 +1275,8 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
       if ((mine >> (4 * g)) & 0xf) em |= 1u << g;
     o->emask = (uint8_t)em;
   }
+  wave_sync();  // the 32 lanes of a macroblock are half a wave
+  if (t < 24) gst32(reinterpret_cast<uint32_t*>(&out[mbi]) + t, reinterpret_cast<const uint32_t*>(o)[t]);
 }
 
 // ===========================================================================

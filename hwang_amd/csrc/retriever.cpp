@@ -40,7 +40,10 @@ int32_t ParallelRetriever::effective_cpus() {
 ParallelRetriever* ParallelRetriever::make(DeviceHandle device,
                                            VideoDecoderType type,
                                            int32_t num_lanes) {
-  if (num_lanes <= 0) num_lanes = std::min<int32_t>(effective_cpus(), 128);
+  // A lane spends most of its time waiting for the GPU (a picture's latency
+  // through the batching pipeline is several times its parse time), so it takes
+  // about four lanes per CPU to keep the CPUs - the bottleneck - busy.
+  if (num_lanes <= 0) num_lanes = std::min<int32_t>(4 * effective_cpus(), 128);
   std::unique_ptr<ParallelRetriever> r(new ParallelRetriever());
   r->lanes_.resize(num_lanes);
   for (Lane& lane : r->lanes_) {

@@ -236,6 +236,15 @@ const char* hwang_prof_kernel_name(int kernel_id);
 int hwang_prof_read(int kernel_id, double out[3]);
 void hwang_prof_reset(void);
 
+/* -- Orderly shutdown ----------------------------------------------------------
+ * Stops the per-device executor threads after draining their streams.  The
+ * library also does this from atexit; call it earlier (the ctypes package does,
+ * from Python's atexit) when something else - a profiler, an embedding
+ * runtime - tears the HIP runtime down before C atexit handlers run.  All
+ * decoders and retrievers must have been destroyed or be idle; afterwards new
+ * ones cannot be created in this process. */
+void hwang_shutdown(void);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif
