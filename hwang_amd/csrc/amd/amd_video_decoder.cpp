@@ -455,6 +455,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (getenv("HWANG_EXEC_DEBUG") && (dbg_motion_waits_ || dbg_job_waits_))
       fprintf(stderr, "[decoder lane %d] motion waits %lld (%.3f s)  job-ring waits %lld (%.3f s)\n", lane_,
               (long long)dbg_motion_waits_, dbg_motion_ns_ / 1e9, (long long)dbg_job_waits_, dbg_job_ns_ / 1e9);
+    if (exec_ && exec_->stopped()) {
+      // Destroyed after hwang_shutdown() (interpreter exit destroys module-level
+      // objects after its atexit handlers): the streams are gone and the HIP
+      // runtime may be tearing down; leave the device memory to process exit.
+      parser_.reset();
+      return;
+    }
     if (hipSetDevice(device_) != hipSuccess) return;
     if (exec_) {
       (void)wait_seq(last_seq_);

@@ -111,19 +111,35 @@ void GpuExecutor::stop() {
     if (stop_) return;
     stop_ = true;
   }
+  const bool dbg = getenv("HWANG_EXEC_DEBUG") != nullptr;
+  if (dbg) fprintf(stderr, "[executor] stop: joining engine threads\n");
   cv_work_.notify_all();
   for (Engine& en : engines_)
     if (en.thread.joinable()) en.thread.join();
-  // leave nothing of ours for the runtime's own teardown to trip over
+  // With every decoder gone, leave nothing of ours for the runtime's own
+  // teardown to trip over (rocprofv3 crashed in __cxa_finalize otherwise).  If
+  // decoders are still alive (objects destroyed after the interpreter's atexit
+  // handlers), their buffers are still registered with the runtime and tearing
+  // the streams down under them blocks: leave everything to process exit.
+  bool lanes_alive = false;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (const Lane& l : lanes_) lanes_alive |= l.active;
+  }
+  if (dbg) fprintf(stderr, "[executor] stop: threads joined%s\n", lanes_alive ? " (decoders still alive: streams kept)" : ", releasing streams");
+  if (lanes_alive) return;
   (void)hipSetDevice(device_);
   for (Engine& en : engines_) {
+    if (dbg) fprintf(stderr, "[executor] stop: engine %d sync\n", (int)(&en - engines_));
     if (en.stream) (void)hipStreamSynchronize(en.stream);
+    if (dbg) fprintf(stderr, "[executor] stop: engine %d destroy\n", (int)(&en - engines_));
     if (en.copy_stream && en.copy_stream != en.stream) {
       (void)hipStreamSynchronize(en.copy_stream);
       (void)hipStreamDestroy(en.copy_stream);
     }
     if (en.stream) (void)hipStreamDestroy(en.stream);
     en.stream = en.copy_stream = nullptr;
+    if (dbg) fprintf(stderr, "[executor] stop: engine %d free\n", (int)(&en - engines_));
     for (int i = 0; i < kInflight; ++i) {
       if (en.copied[i]) (void)hipEventDestroy(en.copied[i]);
       if (en.job_table_host[i]) (void)hipHostFree(en.job_table_host[i]);
@@ -135,6 +151,7 @@ void GpuExecutor::stop() {
       en.conv_table_host[i] = en.conv_table_dev[i] = nullptr;
     }
   }
+  if (dbg) fprintf(stderr, "[executor] stop: done\n");
 }
 
 int GpuExecutor::register_lane() {
@@ -183,6 +200,11 @@ uint64_t GpuExecutor::submit_convert(int lane, const ConvSubmit& job) {
   }
   cv_work_.notify_all();
   return seq;
+}
+
+bool GpuExecutor::stopped() {
+  std::lock_guard<std::mutex> lk(mu_);
+  return stop_;
 }
 
 uint64_t GpuExecutor::completed(int lane) {

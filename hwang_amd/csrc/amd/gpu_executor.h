@@ -85,6 +85,9 @@ class GpuExecutor {
   // Both return the lane-local sequence number of the submission (1, 2, ...).
   uint64_t submit_picture(int lane, const PicSubmit& job);
   uint64_t submit_convert(int lane, const ConvSubmit& job);
+  // True once the executor has been shut down (process exit): decoders that are
+  // destroyed later must not touch the HIP runtime any more.
+  bool stopped();
   // How many of the lane's submissions have finished (non-blocking).
   uint64_t completed(int lane);
   // Blocks until the lane's submissions up to `seq` have finished on the GPU.

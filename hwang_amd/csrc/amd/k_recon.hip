@@ -53,8 +53,6 @@ __constant__ uint8_t c_tc0[52][3] = {
     {4, 6, 9},   {5, 7, 10},  {6, 8, 11},  {6, 8, 13},  {7, 10, 14}, {8, 11, 16}, {9, 12, 18},
     {10, 13, 20}, {11, 15, 23}, {13, 17, 25}};
 // luma4x4BlkIdx (decode order) <-> raster position
-__constant__ uint8_t c_blk_x[16] = {0, 1, 0, 1, 2, 3, 2, 3, 0, 1, 0, 1, 2, 3, 2, 3};
-__constant__ uint8_t c_blk_y[16] = {0, 0, 1, 1, 0, 0, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3};
 __constant__ uint8_t c_raster_to_zz[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 
 __device__ __forceinline__ int iclip(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -614,107 +612,44 @@ __device__ __forceinline__ void row_publish(lds_counter* progress, int row, int 
 // the MB, tile[1..16][0] = left), interior = current macroblock.
 constexpr int TS = 28;
 
-__device__ int pred4x4_sample(const uint8_t* t /* block origin in tile */, int mode, int x, int y, bool hl, bool ht,
-                              bool htl, bool htr) {
-  auto T = [&](int i) -> int {  // p[i, -1], i in -1..7
-    if (i < 0) return htl ? t[-TS - 1] : 128;
-    if (!ht) return 128;
-    if (i > 3 && !htr) return t[-TS + 3];
-    return t[-TS + i];
-  };
-  auto L = [&](int j) -> int {  // p[-1, j], j in -1..3
-    if (j < 0) return htl ? t[-TS - 1] : 128;
-    return hl ? t[j * TS - 1] : 128;
-  };
-  switch (mode) {
-    case 0: return T(x);
-    case 1: return L(y);
-    case 2:
-      if (ht && hl) return (T(0) + T(1) + T(2) + T(3) + L(0) + L(1) + L(2) + L(3) + 4) >> 3;
-      if (hl) return (L(0) + L(1) + L(2) + L(3) + 2) >> 2;
-      if (ht) return (T(0) + T(1) + T(2) + T(3) + 2) >> 2;
-      return 128;
-    case 3: return (x == 3 && y == 3) ? (T(6) + 3 * T(7) + 2) >> 2 : (T(x + y) + 2 * T(x + y + 1) + T(x + y + 2) + 2) >> 2;
-    case 4:
-      if (x > y) return (T(x - y - 2) + 2 * T(x - y - 1) + T(x - y) + 2) >> 2;
-      if (x < y) return (L(y - x - 2) + 2 * L(y - x - 1) + L(y - x) + 2) >> 2;
-      return (T(0) + 2 * T(-1) + L(0) + 2) >> 2;
-    case 5: {
-      const int z = 2 * x - y;
-      if (z >= 0 && !(z & 1)) return (T(x - (y >> 1) - 1) + T(x - (y >> 1)) + 1) >> 1;
-      if (z >= 0) return (T(x - (y >> 1) - 2) + 2 * T(x - (y >> 1) - 1) + T(x - (y >> 1)) + 2) >> 2;
-      if (z == -1) return (L(0) + 2 * T(-1) + T(0) + 2) >> 2;
-      return (L(y - 1) + 2 * L(y - 2) + L(y - 3) + 2) >> 2;
-    }
-    case 6: {
-      const int z = 2 * y - x;
-      if (z >= 0 && !(z & 1)) return (L(y - (x >> 1) - 1) + L(y - (x >> 1)) + 1) >> 1;
-      if (z >= 0) return (L(y - (x >> 1) - 2) + 2 * L(y - (x >> 1) - 1) + L(y - (x >> 1)) + 2) >> 2;
-      if (z == -1) return (L(0) + 2 * T(-1) + T(0) + 2) >> 2;
-      return (T(x - 1) + 2 * T(x - 2) + T(x - 3) + 2) >> 2;
-    }
-    case 7:
-      if (!(y & 1)) return (T(x + (y >> 1)) + T(x + (y >> 1) + 1) + 1) >> 1;
-      return (T(x + (y >> 1)) + 2 * T(x + (y >> 1) + 1) + T(x + (y >> 1) + 2) + 2) >> 2;
-    default: {
-      const int z = x + 2 * y;
-      if (z > 5) return L(3);
-      if (z == 5) return (L(2) + 3 * L(3) + 2) >> 2;
-      if (!(z & 1)) return (L(y + (x >> 1)) + L(y + (x >> 1) + 1) + 1) >> 1;
-      return (L(y + (x >> 1)) + 2 * L(y + (x >> 1) + 1) + L(y + (x >> 1) + 2) + 2) >> 2;
-    }
-  }
-}
+// Directional intra prediction as data (8.3.1.2.x, 8.3.2.2.x): every sample of
+// every mode is a 1-, 2- or 3-tap combination of entries of the block's edge
+// array E (left column bottom-up, corner, top row incl. top-right), so the
+// per-sample code has no branches: entry = i0 | i1 << 4 | i2 << 8 | taps << 12
+// (4x4, E[13]) resp. i0 | i1 << 5 | i2 << 10 | taps << 15 (8x8, E[25]).
+__constant__ uint16_t c_p4tab[9][16] = {
+    {0x1005, 0x1006, 0x1007, 0x1008, 0x1005, 0x1006, 0x1007, 0x1008, 0x1005, 0x1006, 0x1007, 0x1008, 0x1005, 0x1006, 0x1007, 0x1008},
+    {0x1003, 0x1003, 0x1003, 0x1003, 0x1002, 0x1002, 0x1002, 0x1002, 0x1001, 0x1001, 0x1001, 0x1001, 0x1000, 0x1000, 0x1000, 0x1000},
+    {0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000, 0x0000},
+    {0x3765, 0x3876, 0x3987, 0x3a98, 0x3876, 0x3987, 0x3a98, 0x3ba9, 0x3987, 0x3a98, 0x3ba9, 0x3cba, 0x3a98, 0x3ba9, 0x3cba, 0x3ccb},
+    {0x3345, 0x3654, 0x3765, 0x3876, 0x3234, 0x3345, 0x3654, 0x3765, 0x3123, 0x3234, 0x3345, 0x3654, 0x3012, 0x3123, 0x3234, 0x3345},
+    {0x2054, 0x2065, 0x2076, 0x2087, 0x3543, 0x3654, 0x3765, 0x3876, 0x3432, 0x2054, 0x2065, 0x2076, 0x3321, 0x3543, 0x3654, 0x3765},
+    {0x2034, 0x3543, 0x3456, 0x3567, 0x2023, 0x3234, 0x2034, 0x3543, 0x2012, 0x3123, 0x2023, 0x3234, 0x2001, 0x3012, 0x2012, 0x3123},
+    {0x2065, 0x2076, 0x2087, 0x2098, 0x3765, 0x3876, 0x3987, 0x3a98, 0x2076, 0x2087, 0x2098, 0x20a9, 0x3876, 0x3987, 0x3a98, 0x3ba9},
+    {0x2023, 0x3123, 0x2012, 0x3012, 0x2012, 0x3012, 0x2001, 0x3001, 0x2001, 0x3001, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000},
+};
+__constant__ uint32_t c_p8tab[9][64] = {
+    {0x08009, 0x0800a, 0x0800b, 0x0800c, 0x0800d, 0x0800e, 0x0800f, 0x08010, 0x08009, 0x0800a, 0x0800b, 0x0800c, 0x0800d, 0x0800e, 0x0800f, 0x08010, 0x08009, 0x0800a, 0x0800b, 0x0800c, 0x0800d, 0x0800e, 0x0800f, 0x08010, 0x08009, 0x0800a, 0x0800b, 0x0800c, 0x0800d, 0x0800e, 0x0800f, 0x08010, 0x08009, 0x0800a, 0x0800b, 0x0800c, 0x0800d, 0x0800e, 0x0800f, 0x08010, 0x08009, 0x0800a, 0x0800b, 0x0800c, 0x0800d, 0x0800e, 0x0800f, 0x08010, 0x08009, 0x0800a, 0x0800b, 0x0800c, 0x0800d, 0x0800e, 0x0800f, 0x08010, 0x08009, 0x0800a, 0x0800b, 0x0800c, 0x0800d, 0x0800e, 0x0800f, 0x08010},
+    {0x08007, 0x08007, 0x08007, 0x08007, 0x08007, 0x08007, 0x08007, 0x08007, 0x08006, 0x08006, 0x08006, 0x08006, 0x08006, 0x08006, 0x08006, 0x08006, 0x08005, 0x08005, 0x08005, 0x08005, 0x08005, 0x08005, 0x08005, 0x08005, 0x08004, 0x08004, 0x08004, 0x08004, 0x08004, 0x08004, 0x08004, 0x08004, 0x08003, 0x08003, 0x08003, 0x08003, 0x08003, 0x08003, 0x08003, 0x08003, 0x08002, 0x08002, 0x08002, 0x08002, 0x08002, 0x08002, 0x08002, 0x08002, 0x08001, 0x08001, 0x08001, 0x08001, 0x08001, 0x08001, 0x08001, 0x08001, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000},
+    {0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000, 0x00000},
+    {0x1ad49, 0x1b16a, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1b16a, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1ce51, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1ce51, 0x1d272, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1ce51, 0x1d272, 0x1d693, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1ce51, 0x1d272, 0x1d693, 0x1dab4, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1ce51, 0x1d272, 0x1d693, 0x1dab4, 0x1ded5, 0x1c60f, 0x1ca30, 0x1ce51, 0x1d272, 0x1d693, 0x1dab4, 0x1ded5, 0x1e2f6, 0x1ca30, 0x1ce51, 0x1d272, 0x1d693, 0x1dab4, 0x1ded5, 0x1e2f6, 0x1e317},
+    {0x19d09, 0x1a928, 0x1ad49, 0x1b16a, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x198e8, 0x19d09, 0x1a928, 0x1ad49, 0x1b16a, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x194c7, 0x198e8, 0x19d09, 0x1a928, 0x1ad49, 0x1b16a, 0x1b58b, 0x1b9ac, 0x190a6, 0x194c7, 0x198e8, 0x19d09, 0x1a928, 0x1ad49, 0x1b16a, 0x1b58b, 0x18c85, 0x190a6, 0x194c7, 0x198e8, 0x19d09, 0x1a928, 0x1ad49, 0x1b16a, 0x18864, 0x18c85, 0x190a6, 0x194c7, 0x198e8, 0x19d09, 0x1a928, 0x1ad49, 0x18443, 0x18864, 0x18c85, 0x190a6, 0x194c7, 0x198e8, 0x19d09, 0x1a928, 0x18022, 0x18443, 0x18864, 0x18c85, 0x190a6, 0x194c7, 0x198e8, 0x19d09},
+    {0x10128, 0x10149, 0x1016a, 0x1018b, 0x101ac, 0x101cd, 0x101ee, 0x1020f, 0x1a507, 0x1a928, 0x1ad49, 0x1b16a, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1a0e6, 0x10128, 0x10149, 0x1016a, 0x1018b, 0x101ac, 0x101cd, 0x101ee, 0x19cc5, 0x1a507, 0x1a928, 0x1ad49, 0x1b16a, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x198a4, 0x1a0e6, 0x10128, 0x10149, 0x1016a, 0x1018b, 0x101ac, 0x101cd, 0x19483, 0x19cc5, 0x1a507, 0x1a928, 0x1ad49, 0x1b16a, 0x1b58b, 0x1b9ac, 0x19062, 0x198a4, 0x1a0e6, 0x10128, 0x10149, 0x1016a, 0x1018b, 0x101ac, 0x18c41, 0x19483, 0x19cc5, 0x1a507, 0x1a928, 0x1ad49, 0x1b16a, 0x1b58b},
+    {0x100e8, 0x1a507, 0x1a12a, 0x1a54b, 0x1a96c, 0x1ad8d, 0x1b1ae, 0x1b5cf, 0x100c7, 0x198e8, 0x100e8, 0x1a507, 0x1a12a, 0x1a54b, 0x1a96c, 0x1ad8d, 0x100a6, 0x194c7, 0x100c7, 0x198e8, 0x100e8, 0x1a507, 0x1a12a, 0x1a54b, 0x10085, 0x190a6, 0x100a6, 0x194c7, 0x100c7, 0x198e8, 0x100e8, 0x1a507, 0x10064, 0x18c85, 0x10085, 0x190a6, 0x100a6, 0x194c7, 0x100c7, 0x198e8, 0x10043, 0x18864, 0x10064, 0x18c85, 0x10085, 0x190a6, 0x100a6, 0x194c7, 0x10022, 0x18443, 0x10043, 0x18864, 0x10064, 0x18c85, 0x10085, 0x190a6, 0x10001, 0x18022, 0x10022, 0x18443, 0x10043, 0x18864, 0x10064, 0x18c85},
+    {0x10149, 0x1016a, 0x1018b, 0x101ac, 0x101cd, 0x101ee, 0x1020f, 0x10230, 0x1ad49, 0x1b16a, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1016a, 0x1018b, 0x101ac, 0x101cd, 0x101ee, 0x1020f, 0x10230, 0x10251, 0x1b16a, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1ce51, 0x1018b, 0x101ac, 0x101cd, 0x101ee, 0x1020f, 0x10230, 0x10251, 0x10272, 0x1b58b, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1ce51, 0x1d272, 0x101ac, 0x101cd, 0x101ee, 0x1020f, 0x10230, 0x10251, 0x10272, 0x10293, 0x1b9ac, 0x1bdcd, 0x1c1ee, 0x1c60f, 0x1ca30, 0x1ce51, 0x1d272, 0x1d693},
+    {0x100c7, 0x194c7, 0x100a6, 0x190a6, 0x10085, 0x18c85, 0x10064, 0x18864, 0x100a6, 0x190a6, 0x10085, 0x18c85, 0x10064, 0x18864, 0x10043, 0x18443, 0x10085, 0x18c85, 0x10064, 0x18864, 0x10043, 0x18443, 0x10022, 0x18022, 0x10064, 0x18864, 0x10043, 0x18443, 0x10022, 0x18022, 0x10001, 0x18001, 0x10043, 0x18443, 0x10022, 0x18022, 0x10001, 0x18001, 0x08000, 0x08000, 0x10022, 0x18022, 0x10001, 0x18001, 0x08000, 0x08000, 0x08000, 0x08000, 0x10001, 0x18001, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000, 0x08000},
+};
+// Order in which the sixteen 4x4 blocks of an Intra4x4 macroblock are predicted:
+// a block needs its left, top-left, top and top-right neighbours, so the
+// blocks (x, y) with equal x + 2y are independent - 10 steps instead of 16,
+// two blocks (32 lanes) in the six middle ones.
+__constant__ int8_t c_i4_step_a[10] = {0, 1, 2, 3, 6, 7, 10, 11, 14, 15};
+__constant__ int8_t c_i4_step_b[10] = {-1, -1, 4, 5, 8, 9, 12, 13, -1, -1};
 
-// Intra 8x8: `ft` = filtered top (16), `fl` = filtered left (8), ftl corner;
-// prepared by the caller (8.3.2.2.1).
-__device__ int pred8x8_sample(const int* ft, const int* fl, int ftl, int mode, int x, int y, bool hl, bool ht) {
-  auto T = [&](int i) -> int { return i < 0 ? ftl : ft[i]; };
-  auto L = [&](int j) -> int { return j < 0 ? ftl : fl[j]; };
-  switch (mode) {
-    case 0: return T(x);
-    case 1: return L(y);
-    case 2: {
-      int st = 0, sl = 0;
-      for (int i = 0; i < 8; ++i) {
-        st += ft[i];
-        sl += fl[i];
-      }
-      if (ht && hl) return (st + sl + 8) >> 4;
-      if (hl) return (sl + 4) >> 3;
-      if (ht) return (st + 4) >> 3;
-      return 128;
-    }
-    case 3: return (x == 7 && y == 7) ? (T(14) + 3 * T(15) + 2) >> 2 : (T(x + y) + 2 * T(x + y + 1) + T(x + y + 2) + 2) >> 2;
-    case 4:
-      if (x > y) return (T(x - y - 2) + 2 * T(x - y - 1) + T(x - y) + 2) >> 2;
-      if (x < y) return (L(y - x - 2) + 2 * L(y - x - 1) + L(y - x) + 2) >> 2;
-      return (T(0) + 2 * ftl + L(0) + 2) >> 2;
-    case 5: {
-      const int z = 2 * x - y;
-      if (z >= 0 && !(z & 1)) return (T(x - (y >> 1) - 1) + T(x - (y >> 1)) + 1) >> 1;
-      if (z >= 0) return (T(x - (y >> 1) - 2) + 2 * T(x - (y >> 1) - 1) + T(x - (y >> 1)) + 2) >> 2;
-      if (z == -1) return (L(0) + 2 * ftl + T(0) + 2) >> 2;
-      return (L(y - 2 * x - 1) + 2 * L(y - 2 * x - 2) + L(y - 2 * x - 3) + 2) >> 2;
-    }
-    case 6: {
-      const int z = 2 * y - x;
-      if (z >= 0 && !(z & 1)) return (L(y - (x >> 1) - 1) + L(y - (x >> 1)) + 1) >> 1;
-      if (z >= 0) return (L(y - (x >> 1) - 2) + 2 * L(y - (x >> 1) - 1) + L(y - (x >> 1)) + 2) >> 2;
-      if (z == -1) return (L(0) + 2 * ftl + T(0) + 2) >> 2;
-      return (T(x - 2 * y - 1) + 2 * T(x - 2 * y - 2) + T(x - 2 * y - 3) + 2) >> 2;
-    }
-    case 7:
-      if (!(y & 1)) return (T(x + (y >> 1)) + T(x + (y >> 1) + 1) + 1) >> 1;
-      return (T(x + (y >> 1)) + 2 * T(x + (y >> 1) + 1) + T(x + (y >> 1) + 2) + 2) >> 2;
-    default: {
-      const int z = x + 2 * y;
-      if (z > 13) return L(7);
-      if (z == 13) return (L(6) + 3 * L(7) + 2) >> 2;
-      if (!(z & 1)) return (L(y + (x >> 1)) + L(y + (x >> 1) + 1) + 1) >> 1;
-      return (L(y + (x >> 1)) + 2 * L(y + (x >> 1) + 1) + L(y + (x >> 1) + 2) + 2) >> 2;
-    }
-  }
+__device__ __forceinline__ int tap_sample(const uint8_t* e, unsigned ent, int shift, int mask) {
+  const int a = e[ent & mask], b = e[(ent >> shift) & mask], c = e[(ent >> (2 * shift)) & mask];
+  const int taps = ent >> (3 * shift);
+  return taps == 1 ? a : taps == 2 ? (a + b + 1) >> 1 : (a + 2 * b + c + 2) >> 2;
 }
 
 struct IntraWaveLds {
@@ -722,7 +657,8 @@ struct IntraWaveLds {
   int16_t res_c[128];
   uint8_t tile[17 * TS];
   uint8_t ctile[2][9 * 12];
-  int f_top[16], f_left[8], f_tl;
+  uint8_t e4[2][16];  // Intra4x4 edge arrays of the (up to) two blocks of a step
+  uint8_t e8[32];     // Intra8x8 filtered edge array
 };
 
 }  // namespace
@@ -927,22 +863,39 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
             tile[(1 + (t >> 4)) * TS + 1 + (t & 15)] = (uint8_t)outv[it];
           }
         } else if (mb.kind == MBK_I4x4) {
-          for (int k = 0; k < 16; ++k) {  // decode order
-            const int bx = c_blk_x[k], by = c_blk_y[k];
-            if (lane < 16) {
-              const int px = lane & 3, py = lane >> 2;
-              const bool hl = bx > 0 || hA, ht = by > 0 || hB;
+          for (int st = 0; st < 10; ++st) {
+            const int half = lane >> 4;  // lanes 0..15 first block of the step, 16..31 second
+            const int raster = half == 0 ? c_i4_step_a[st] : half == 1 ? c_i4_step_b[st] : -1;
+            const int bx = raster & 3, by = raster >> 2;
+            const bool hl = bx > 0 || hA, ht = by > 0 || hB;
+            const uint8_t* t = tile + (1 + by * 4) * TS + 1 + bx * 4;
+            if (raster >= 0 && (lane & 15) < 13) {
+              const int i = lane & 15;
               const bool htl = (bx > 0 && by > 0) ? true : (bx > 0) ? hB : (by > 0) ? hA : hD;
               bool htr;
               if (by == 0) htr = bx < 3 ? hB : hC;
               else if (bx == 3) htr = false;
-              else htr = c_raster_to_zz[(by - 1) * 4 + bx + 1] < k;
-              const int raster = by * 4 + bx;
+              else htr = c_raster_to_zz[(by - 1) * 4 + bx + 1] < c_raster_to_zz[raster];
+              int v = 128;
+              if (i < 4) { if (hl) v = t[(3 - i) * TS - 1]; }
+              else if (i == 4) { if (htl) v = t[-TS - 1]; }
+              else if (ht) v = (i > 8 && !htr) ? t[-TS + 3] : t[-TS + i - 5];
+              L.e4[half][i] = (uint8_t)v;
+            }
+            wave_sync();
+            if (raster >= 0) {
+              const int px = lane & 3, py = (lane >> 2) & 3;
               const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
-              const uint8_t* t = tile + (1 + by * 4) * TS + 1 + bx * 4;
-              const int v = pred4x4_sample(t, mode, px, py, hl, ht, htl, htr);
+              const uint8_t* e = L.e4[half];
+              int v;
+              if (mode == 2) {
+                const int st4 = e[5] + e[6] + e[7] + e[8], sl4 = e[0] + e[1] + e[2] + e[3];
+                v = (ht && hl) ? (st4 + sl4 + 4) >> 3 : hl ? (sl4 + 2) >> 2 : ht ? (st4 + 2) >> 2 : 128;
+              } else {
+                v = tap_sample(e, c_p4tab[mode > 8 ? 8 : mode][py * 4 + px], 4, 15);
+              }
               const int out = clip8(v + L.res_y[(by * 4 + py) * 16 + bx * 4 + px]);
-              tile[(1 + by * 4 + py) * TS + 1 + bx * 4 + px] = (uint8_t)out;  // neighbours lie outside the block
+              tile[(1 + by * 4 + py) * TS + 1 + bx * 4 + px] = (uint8_t)out;
             }
             wave_sync();
           }
@@ -953,6 +906,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
             const bool htl = (bx > 0 && by > 0) ? true : (bx > 0) ? hB : (by > 0) ? hA : hD;
             const bool htr = b8 == 0 ? hB : b8 == 1 ? hC : b8 == 2;
             const uint8_t* t = tile + (1 + by) * TS + 1 + bx;
+            // reference sample filtering (8.3.2.2.1) into E: [0..7] left bottom-up, [8] corner, [9..24] top
             if (lane < 16) {
               int v = 128;
               if (ht) {
@@ -961,7 +915,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
                 else if (lane == 15) v = (R(14) + 3 * R(15) + 2) >> 2;
                 else v = (R(lane - 1) + 2 * R(lane) + R(lane + 1) + 2) >> 2;
               }
-              L.f_top[lane] = v;
+              L.e8[9 + lane] = (uint8_t)v;
             } else if (lane < 24) {
               const int j = lane - 16;
               int v = 128;
@@ -971,7 +925,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
                 else if (j == 7) v = (Lr(6) + 3 * Lr(7) + 2) >> 2;
                 else v = (Lr(j - 1) + 2 * Lr(j) + Lr(j + 1) + 2) >> 2;
               }
-              L.f_left[j] = v;
+              L.e8[7 - j] = (uint8_t)v;
             } else if (lane == 24) {
               int v = 128;
               if (htl) {
@@ -981,14 +935,26 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
                 else if (hl) v = (3 * cc + t[-1] + 2) >> 2;
                 else v = cc;
               }
-              L.f_tl = v;
+              L.e8[8] = (uint8_t)v;
             }
             wave_sync();
             {
               const int px = lane & 7, py = lane >> 3;
               const int raster = (by >> 2) * 4 + (bx >> 2);
               const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
-              const int v = pred8x8_sample(L.f_top, L.f_left, L.f_tl, mode, px, py, hl, ht);
+              const uint8_t* e = L.e8;
+              int v;
+              if (mode == 2) {
+                int st8 = 0, sl8 = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                  st8 += e[9 + i];
+                  sl8 += e[i];
+                }
+                v = (ht && hl) ? (st8 + sl8 + 8) >> 4 : hl ? (sl8 + 4) >> 3 : ht ? (st8 + 4) >> 3 : 128;
+              } else {
+                v = tap_sample(e, c_p8tab[mode > 8 ? 8 : mode][py * 8 + px], 5, 31);
+              }
               tile[(1 + by + py) * TS + 1 + bx + px] = (uint8_t)clip8(v + L.res_y[(by + py) * 16 + bx + px]);
             }
             wave_sync();

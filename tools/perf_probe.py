@@ -76,3 +76,4 @@ for k in range(lib.hwang_prof_num_kernels()):
     lib.hwang_prof_read(k, o)
     if o[0]:
         print("%-16s launches %6d  avg %8.1f us  alg %.2f GB/s" % (lib.hwang_prof_kernel_name(k).decode(), o[0], o[1] / o[0], o[2] / (o[1] * 1e-6) / 1e9))
+del dec  # before interpreter exit: module globals outlive the library's atexit shutdown
