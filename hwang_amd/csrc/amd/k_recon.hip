@@ -1360,19 +1360,12 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
           const int cls = e == 0 ? 0 : 2;
           const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
           const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
-          if (lane < 16) {
-            if (bs) filter_edge(lt + (4 + lane) * LS + 4 + e * 4, 1, bs, alpha, beta, tc0, false);
-          } else if (lane < 32 && !(e & 1)) {
+          // luma rows (lanes 0..15) and chroma rows (16..31, even edges only) share
+          // one instruction stream: the sample pointer and the plane are lane data
+          if (lane < 32 && bs && (lane < 16 || !(e & 1))) {
             const int p = (lane - 16) >> 3, i = (lane - 16) & 7;
-            if (bs) {
-              // chroma vertical edge: p1 p0 | q0 q1 -> bytes q-2 .. q+1
-              uint8_t* q = L.ct[p] + (2 + i) * CS + 4 + e * 2;
-              int v[8] = {0, 0, q[-2], q[-1], q[0], q[1], 0, 0};
-              if (filter_line(v, bs, alpha, beta, tc0, true)) {
-                q[-1] = (uint8_t)v[3];
-                q[0] = (uint8_t)v[4];
-              }
-            }
+            uint8_t* q = lane < 16 ? lt + (4 + lane) * LS + 4 + e * 4 : L.ct[p] + (2 + i) * CS + 4 + e * 2;
+            filter_edge(q, 1, bs, alpha, beta, tc0, lane >= 16);
           }
           wave_sync();
         }
@@ -1393,11 +1386,10 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
           const int cls = e == 0 ? 1 : 2;
           const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
           const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
-          if (lane < 16) {
-            if (bs) filter_edge(lt + (4 + e * 4) * LS + 4 + lane, LS, bs, alpha, beta, tc0, false);
-          } else if (lane < 32 && !(e & 1)) {
+          if (lane < 32 && bs && (lane < 16 || !(e & 1))) {
             const int p = (lane - 16) >> 3, i = (lane - 16) & 7;
-            if (bs) filter_edge(L.ct[p] + (2 + e * 2) * CS + 4 + i, CS, bs, alpha, beta, tc0, true);
+            uint8_t* q = lane < 16 ? lt + (4 + e * 4) * LS + 4 + lane : L.ct[p] + (2 + e * 2) * CS + 4 + i;
+            filter_edge(q, lane < 16 ? LS : CS, bs, alpha, beta, tc0, lane >= 16);
           }
           wave_sync();
         }
