@@ -113,7 +113,11 @@ void GpuExecutor::stop() {
   }
   const bool dbg = getenv("HWANG_EXEC_DEBUG") != nullptr;
   if (dbg) fprintf(stderr, "[executor] stop: joining engine threads\n");
-  cv_work_.notify_all();
+  for (auto& cv : cv_work_) cv.notify_all();
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (Lane& l : lanes_) l.cv.notify_all();
+  }
   for (Engine& en : engines_)
     if (en.thread.joinable()) en.thread.join();
   // With every decoder gone, leave nothing of ours for the runtime's own
@@ -158,8 +162,11 @@ int GpuExecutor::register_lane() {
   std::lock_guard<std::mutex> lk(mu_);
   for (size_t i = 0; i < lanes_.size(); ++i)
     if (!lanes_[i].active && lanes_[i].fifo.empty() && lanes_[i].completed == lanes_[i].submitted) {
-      lanes_[i] = Lane();
-      lanes_[i].active = true;
+      Lane& l = lanes_[i];
+      l.submitted = l.launched = l.completed = 0;
+      l.last_engine = 0;
+      l.waiters = 0;
+      l.active = true;
       return static_cast<int>(i);
     }
   lanes_.emplace_back();
@@ -169,12 +176,13 @@ int GpuExecutor::register_lane() {
 
 void GpuExecutor::unregister_lane(int lane) {
   std::unique_lock<std::mutex> lk(mu_);
-  cv_done_.wait(lk, [&] { return lanes_[lane].completed == lanes_[lane].submitted || !error_.empty() || stop_; });
+  lanes_[lane].cv.wait(lk, [&] { return lanes_[lane].completed == lanes_[lane].submitted || !error_.empty() || stop_; });
   lanes_[lane].active = false;
 }
 
 uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
   uint64_t seq;
+  int target = 0;
   {
     std::lock_guard<std::mutex> lk(mu_);
     Item it;
@@ -183,13 +191,15 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     it.engine = job.heavy ? 1 + lane % kHeavyEngines : 0;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
+    target = it.engine;
   }
-  cv_work_.notify_all();
+  cv_work_[target].notify_one();
   return seq;
 }
 
 uint64_t GpuExecutor::submit_convert(int lane, const ConvSubmit& job) {
   uint64_t seq;
+  int target = 0;
   {
     std::lock_guard<std::mutex> lk(mu_);
     Item it;
@@ -197,8 +207,9 @@ uint64_t GpuExecutor::submit_convert(int lane, const ConvSubmit& job) {
     it.conv = job;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
+    target = lanes_[lane].last_engine;  // conversions follow the lane's last picture
   }
-  cv_work_.notify_all();
+  cv_work_[target].notify_one();
   return seq;
 }
 
@@ -215,7 +226,7 @@ uint64_t GpuExecutor::completed(int lane) {
 bool GpuExecutor::wait(int lane, uint64_t seq, std::string* error) {
   std::unique_lock<std::mutex> lk(mu_);
   ++lanes_[lane].waiters;
-  cv_done_.wait(lk, [&] { return lanes_[lane].completed >= seq || !error_.empty() || stop_; });
+  lanes_[lane].cv.wait(lk, [&] { return lanes_[lane].completed >= seq || !error_.empty() || stop_; });
   --lanes_[lane].waiters;
   if (!error_.empty()) {
     if (error) *error = error_;
@@ -242,12 +253,19 @@ void GpuExecutor::complete(Batch* b, hipError_t status) {
   std::lock_guard<std::mutex> lk(mu_);
   if (status != hipSuccess && error_.empty())
     error_ = std::string("GpuExecutor: launch failed: ") + hipGetErrorString(status);
-  for (auto& lc : b->lane_counts) lanes_[lc.first].completed += lc.second;
+  const bool failed = !error_.empty();
+  for (auto& lc : b->lane_counts) {
+    Lane& l = lanes_[lc.first];
+    l.completed += lc.second;
+    if (l.waiters) l.cv.notify_all();
+  }
+  if (failed)
+    for (Lane& l : lanes_) l.cv.notify_all();  // everyone must see the error
   b->lane_counts.clear();
   b->in_flight = false;
   --engines_[b->engine].inflight;
-  cv_done_.notify_all();
-  cv_work_.notify_all();  // a batch slot is free; other engines may take over these lanes
+  // a batch slot is free here, and the other engines may now take over these lanes
+  for (auto& cv : cv_work_) cv.notify_one();
 }
 
 // Engine thread: sleeps until one of its lanes has something eligible AND a
@@ -286,7 +304,7 @@ void GpuExecutor::run(int engine) {
           if (eligible(l, engine)) return true;
         return false;
       };
-      cv_work_.wait(lk, [&] { return stop_ || (en.inflight < max_inflight && have_work()); });
+      cv_work_[engine].wait(lk, [&] { return stop_ || (en.inflight < max_inflight && have_work()); });
       if (stop_) break;
       for (int i = 0; i < kInflight; ++i)
         if (!en.batches[i].in_flight) slot = i;

@@ -117,7 +117,11 @@ class GpuExecutor {
     std::deque<Item> fifo;
     uint64_t submitted = 0, launched = 0, completed = 0;
     int last_engine = 0;
-    int waiters = 0;  // threads blocked in wait() (diagnostics)
+    int waiters = 0;  // threads blocked in wait()
+    // A completed batch wakes exactly the lanes it contained (one shared
+    // condition variable woke every blocked lane thread for every batch: 10 %
+    // of the process's CPU time went into futex traffic).
+    std::condition_variable cv;
   };
   struct Batch {
     std::vector<std::pair<int, int>> lane_counts;  // (lane, items taken)
@@ -159,10 +163,10 @@ class GpuExecutor {
 
   const int device_;
   std::mutex mu_;
-  std::condition_variable cv_work_, cv_done_;
+  std::condition_variable cv_work_[kEngines];  // one per engine thread
   bool stop_ = false;
   std::string error_;
-  std::vector<Lane> lanes_;
+  std::deque<Lane> lanes_;  // stable addresses: lanes hold a condition variable
   Engine engines_[kEngines];
   Stats stats_;
 };
