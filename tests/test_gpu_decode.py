@@ -93,6 +93,21 @@ def test_1080p_cropping(hw, oracle, gpu, tmp_path):
         assert np.array_equal(got[k], gold[r])
 
 
+def test_4k_wide_pictures(hw, oracle, gpu, tmp_path):
+    """BASELINE config C2 geometry (3840x2160 = 240 x 135 macroblocks): wider
+    than the intra kernel's LDS line buffer, so intra-only pictures take the
+    surface-neighbour path; 3840-byte pitches; I, P and B pictures."""
+    path = str(tmp_path / "uhd.mp4")
+    gold = make_clip(path, width=3840, height=2160, frames=4, gop=4, bframes=1, threads=4)
+    idx = hw.index_video(path)
+    frames, _ = oracle.decode_file(path, idx)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+    got = dec.retrieve_yuv([0, 1, 2, 3])
+    for r in range(4):
+        assert np.array_equal(frames[r][0], gold[r]), "oracle != encoder reconstruction at frame %d" % r
+        assert np.array_equal(got[r], gold[r]), "GPU != oracle at frame %d" % r
+
+
 def test_errors_are_loud(hw, gpu, tmp_path):
     path = str(tmp_path / "e.mp4")
     make_clip(path, frames=4, gop=4, bframes=0, yuv=False)
