@@ -37,7 +37,10 @@ elif os.environ.get("ROWS_MODE") == "gopend":    # longest P chains
     rows = sorted(set(int(k) - 3 for k in rng.choice(kf[1:], min(len(kf) - 1, len(rows)), replace=False)))
 print("frames", n, "rows", len(rows))
 import torch
-out = torch.empty((len(rows), H, W, 3), dtype=torch.uint8, device="cuda")
+if os.environ.get("HOST_OUT"):   # PCIe-inclusive variant: frames land in pinned host memory
+    out = torch.empty((len(rows), H, W, 3), dtype=torch.uint8).pin_memory()
+else:
+    out = torch.empty((len(rows), H, W, 3), dtype=torch.uint8, device="cuda")
 for lanes in [int(x) for x in os.environ.get("LANES", "1,4,16,32,64").split(",")]:
     dec = hw.Decoder(path, video_index=idx, num_lanes=lanes)
     best = None
