@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhwang_amd.so")
+LIB_PATH = os.environ.get("HWANG_AMD_LIB") or os.path.join(_HERE, "libhwang_amd.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

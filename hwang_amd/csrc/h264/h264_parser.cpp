@@ -1399,53 +1399,132 @@ struct Parser::Impl {
     return total;
   }
 
+  // Residual block (9.3.2.x via 7.3.5.3.3).  Most of a picture's bins are
+  // decoded here, so the arithmetic decoder's registers (offset, range, bit
+  // budget, read pointer) live in locals for the duration of the block: the
+  // context bytes are stored through a uint8_t pointer, which may alias any
+  // member of the Cabac object and would otherwise force a store and reload of
+  // the engine state around every single bin.
   int cabac_block(int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start, int16_t* out) {
     Cabac& c = cabac;
-    if (cbf_inc >= 0 && !c.bin(85 + cbf_cat_offset[cat] + cbf_inc)) return 0;
+    uint64_t value = c.value;
+    uint32_t range = c.range;
+    int extra = c.extra;
+    const uint8_t* p = c.p;
+    const uint8_t* const end = c.end;
+    uint8_t* const state = c.state;
+    bool overrun = false;
+    auto refill = [&]() {
+      if (extra >= 0 && p + 4 <= end) {
+        const uint32_t w = (static_cast<uint32_t>(p[0]) << 24) | (static_cast<uint32_t>(p[1]) << 16) |
+                           (static_cast<uint32_t>(p[2]) << 8) | p[3];
+        p += 4;
+        value = (value << 32) | w;
+        extra += 32;
+        return;
+      }
+      while (extra < 24) {
+        uint32_t b = 0;
+        if (p < end) b = *p;
+        else if (p > end + 8) overrun = true;
+        ++p;
+        value = (value << 8) | b;
+        extra += 8;
+      }
+    };
+    auto bin = [&](int ctx) -> int {
+      const uint32_t st = state[ctx];
+      const uint32_t lps = g_cabac_tables.lps[(range >> 6) & 3][st];
+      uint32_t r = range - lps;
+      const uint64_t scaled = static_cast<uint64_t>(r) << extra;
+      const uint64_t lmask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
+      value -= scaled & lmask;
+      r += (lps - r) & static_cast<uint32_t>(lmask);
+      const uint32_t l = static_cast<uint32_t>(lmask) & 1;
+      state[ctx] = g_cabac_tables.next[st][l];
+      const int shift = __builtin_clz(r) - 23;
+      range = r << shift;
+      extra -= shift;
+      if (__builtin_expect(extra < 8, 0)) refill();
+      return static_cast<int>((st & 1) ^ l);
+    };
+    auto bypass = [&]() -> int {
+      extra -= 1;
+      if (__builtin_expect(extra < 8, 0)) refill();
+      const uint64_t scaled = static_cast<uint64_t>(range) << extra;
+      const uint64_t mask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
+      value -= scaled & mask;
+      return static_cast<int>(mask & 1);
+    };
+    auto leave = [&]() {
+      c.value = value;
+      c.range = range;
+      c.extra = extra;
+      c.p = p;
+      if (overrun) c.overrun = true;
+    };
+
+    if (cbf_inc >= 0 && !bin(85 + cbf_cat_offset[cat] + cbf_inc)) {
+      leave();
+      return 0;
+    }
     const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
     const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
     const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
-    int idx[64], n = 0, i;
-    for (i = 0; i < max_coeff - 1; ++i) {
-      int sinc, linc;
-      if (cat == 5) {
-        sinc = sig_coeff_offset_8x8[i];
-        linc = last_coeff_offset_8x8[i];
-      } else if (cat == 3) {
-        sinc = linc = imin(i, 2);
-      } else {
-        sinc = linc = i;
+    uint8_t idx[64];
+    int n = 0, i;
+    const int lastpos = max_coeff - 1;
+    if (cat == 5) {
+      for (i = 0; i < lastpos; ++i)
+        if (bin(sig_base + sig_coeff_offset_8x8[i])) {
+          idx[n++] = static_cast<uint8_t>(i);
+          if (bin(last_base + last_coeff_offset_8x8[i])) break;
+        }
+    } else if (cat == 3) {
+      for (i = 0; i < lastpos; ++i) {
+        const int inc = imin(i, 2);
+        if (bin(sig_base + inc)) {
+          idx[n++] = static_cast<uint8_t>(i);
+          if (bin(last_base + inc)) break;
+        }
       }
-      if (c.bin(sig_base + sinc)) {
-        idx[n++] = i;
-        if (c.bin(last_base + linc)) break;
-      }
+    } else {
+      for (i = 0; i < lastpos; ++i)
+        if (bin(sig_base + i)) {
+          idx[n++] = static_cast<uint8_t>(i);
+          if (bin(last_base + i)) break;
+        }
     }
-    if (i == max_coeff - 1) idx[n++] = max_coeff - 1;
+    if (i == lastpos) idx[n++] = static_cast<uint8_t>(lastpos);
     int gt1 = 0, eq1 = 0;
+    const int gt_cap = 4 - (cat == 3 ? 1 : 0);
     for (int k = n - 1; k >= 0; --k) {
       const int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
       int val;
-      if (!c.bin(abs_base + inc0)) {
+      if (!bin(abs_base + inc0)) {
         val = 1;
         ++eq1;
       } else {
-        const int inc = 5 + imin(4 - (cat == 3 ? 1 : 0), gt1);
+        const int inc = 5 + imin(gt_cap, gt1);
         val = 2;
-        while (val < 15 && c.bin(abs_base + inc)) ++val;
+        while (val < 15 && bin(abs_base + inc)) ++val;
         if (val == 15) {
           int k0 = 0;
-          while (c.bypass()) {
+          while (bypass()) {
             val += 1 << k0;
-            if (++k0 > 24) return fail("CABAC: coeff_abs_level overflow") ? 0 : -1;
+            if (++k0 > 24) {
+              leave();
+              return fail("CABAC: coeff_abs_level overflow") ? 0 : -1;
+            }
           }
-          while (k0--) val += c.bypass() << k0;
+          while (k0--) val += bypass() << k0;
         }
         ++gt1;
       }
-      if (c.bypass()) val = -val;
+      if (bypass()) val = -val;
       out[scan[start + idx[k]]] = static_cast<int16_t>(val);
     }
+    leave();
     return n;
   }
 
