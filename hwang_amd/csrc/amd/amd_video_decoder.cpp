@@ -4,13 +4,16 @@
 // nvidia_video_decoder.cpp:227-470 (configure / feed -> parser callbacks ->
 // ring of decoded surfaces / get_frame -> colour kernel -> copy).  Here the
 // "parser" is this repo's host-side H.264 front end (h264/h264_parser) and
-// the "decoder" is the set of HIP kernels in k_recon.hip / k_rgb.hip, all on
-// one HIP stream per instance:
+// the "decoder" is the set of HIP kernels in k_recon.hip / k_rgb.hip.  An
+// instance owns surfaces and staging buffers but no stream: it describes its
+// work to the device's GpuExecutor, which batches the pictures of all
+// instances into a few wide launches (gpu_executor.h):
 //
-//   feed(sample)  host: entropy decode + motion derivation -> pinned staging
-//                 stream: H2D records -> k_inter -> k_intra -> k_deblock
-//   get_frame()   stream: k_rgb (surface -> caller memory if it is in HBM,
-//                 else -> pinned bounce buffer -> caller memory)
+//   feed(sample)  host: entropy decode + motion derivation -> pinned staging,
+//                 submit_picture: k_upload -> k_inter -> k_residual/k_intra
+//                 -> k_bs/k_deblock in the executor's next batch
+//   get_frame()   submit_convert: convert_batch (surface -> caller memory if it
+//                 is in HBM, else -> pinned bounce buffer -> caller memory)
 //
 // Nothing here waits for the GPU except when a staging slot or a surface has
 // to be reused, and wait_until_frames_copied().

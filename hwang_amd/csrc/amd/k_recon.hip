@@ -1,13 +1,17 @@
-// K1-K4: the sample-parallel half of H.264 decoding on CDNA4 (gfx950).
+// The sample-parallel half of H.264 decoding on CDNA4 (gfx950).  Every kernel
+// takes an array of JobDesc, one per picture of the batch.
 //
-//   k_inter    K1+K2  every inter macroblock of a picture at once: dequant +
-//                     4x4 / 8x8 inverse transforms, quarter-sample luma and
-//                     eighth-sample chroma motion compensation (default,
-//                     explicit and implicit weighting), prediction + residual
-//   k_intra    K1+K3  intra macroblocks in dependency order: one workgroup
-//                     walks one macroblock row, rows hand their progress to
-//                     the row below through agent-scope release/acquire
-//   k_deblock  K4     in-loop deblocking filter, same row-wavefront scheme
+//   k_upload    the batch's records pulled from pinned host memory (one launch)
+//   k_inter     every inter macroblock at once, one wave each: dequant + 4x4 /
+//               8x8 inverse transforms, quarter-sample luma and eighth-sample
+//               chroma motion compensation from unaligned dword fetches
+//               (default, explicit and implicit weighting), + residual
+//   k_residual  dequant + inverse transforms of the intra macroblocks -> int16
+//   k_intra     intra prediction in dependency order: ONE workgroup of 16 waves
+//               per picture, a wave per macroblock row, progress handed down
+//               through LDS counters (workgroup scope only)
+//   k_bs        boundary strengths, alpha / beta / tc0, edge masks per macroblock
+//   k_deblock   in-loop deblocking filter, same 16-wave row pipeline
 //
 // These replace what the reference gets from libavcodec's hl_decode_mb /
 // loop_filter behind avcodec_send_packet

@@ -2,8 +2,9 @@
 
 `retrieve(rows)` keeps the reference's meaning -- the k-th returned array is
 frame rows[k] as H x W x 3 uint8 RGB -- but a GPU Decoder hands the whole
-request to the library's parallel retriever (all keyframe-anchored intervals
-in flight at once on separate HIP streams) instead of looping one
+request to the library's parallel retriever (keyframe-anchored intervals
+fanned out over lanes whose pictures are batched into wide GPU launches)
+instead of looping one
 DecoderAutomata over the intervals.  `retrieve_serial` is the literal
 reference loop, kept for parity tests of the automata path.
 """
