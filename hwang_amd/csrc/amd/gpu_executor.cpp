@@ -3,6 +3,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <ctime>
 #include <pthread.h>
 #include <map>
 #include <memory>
@@ -15,6 +16,7 @@ hipError_t launch_convert_batch(const amd::ConvertDesc* reqs_dev, int n, int max
 namespace amd {
 
 hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream);
+hipError_t launch_done(uint32_t* flag, uint32_t ticket, hipStream_t stream);
 hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
                         bool any_deblock, const uint64_t bytes[3], hipStream_t stream);
 
@@ -101,7 +103,13 @@ bool GpuExecutor::start(std::string* error) {
         return fail("out of memory for job tables");
     }
   }
+  const char* mode = getenv("HWANG_COMPLETION");
+  use_hostfunc_ = mode && std::string(mode) == "hostfunc";
+  if (hipHostMalloc(reinterpret_cast<void**>(&done_flags_), sizeof(uint32_t) * kEngines * kInflight, hipHostMallocDefault) != hipSuccess)
+    return fail("out of memory for completion flags");
+  for (int i = 0; i < kEngines * kInflight; ++i) done_flags_[i] = 0;
   for (int e = 0; e < kEngines; ++e) engines_[e].thread = std::thread(&GpuExecutor::run, this, e);
+  if (!use_hostfunc_) poller_ = std::thread(&GpuExecutor::poll_loop, this);
   return true;
 }
 
@@ -120,6 +128,8 @@ void GpuExecutor::stop() {
   }
   for (Engine& en : engines_)
     if (en.thread.joinable()) en.thread.join();
+  cv_poll_.notify_all();
+  if (poller_.joinable()) poller_.join();
   // With every decoder gone, leave nothing of ours for the runtime's own
   // teardown to trip over (rocprofv3 crashed in __cxa_finalize otherwise).  If
   // decoders are still alive (objects destroyed after the interpreter's atexit
@@ -264,8 +274,34 @@ void GpuExecutor::complete(Batch* b, hipError_t status) {
   b->lane_counts.clear();
   b->in_flight = false;
   --engines_[b->engine].inflight;
+  --total_inflight_;
   // a batch slot is free here, and the other engines may now take over these lanes
   for (auto& cv : cv_work_) cv.notify_one();
+}
+
+void GpuExecutor::poll_loop() {
+  pthread_setname_np(pthread_self(), "hw-poller");
+  std::vector<Batch*> done;
+  std::unique_lock<std::mutex> lk(mu_);
+  for (;;) {
+    if (stop_ && total_inflight_ == 0) break;
+    if (total_inflight_ == 0) {
+      cv_poll_.wait(lk);
+      continue;
+    }
+    done.clear();
+    for (Engine& en : engines_)
+      for (Batch& b : en.batches)
+        if (b.in_flight && b.flag && __atomic_load_n(const_cast<uint32_t*>(b.flag), __ATOMIC_ACQUIRE) == b.ticket) done.push_back(&b);
+    lk.unlock();
+    if (done.empty()) {
+      struct timespec ts = {0, 40000};  // 40 us: far below a batch's duration
+      nanosleep(&ts, nullptr);
+    } else {
+      for (Batch* b : done) complete(b, hipSuccess);
+    }
+    lk.lock();
+  }
 }
 
 // Engine thread: sleeps until one of its lanes has something eligible AND a
@@ -342,7 +378,10 @@ void GpuExecutor::run(int engine) {
       batch.in_flight = true;
       batch.owner = this;
       batch.engine = engine;
+      batch.ticket = ++next_ticket_;
+      batch.flag = done_flags_ + engine * kInflight + slot;
       ++en.inflight;
+      ++total_inflight_;
       ++stats_.batches;
       stats_.pictures += pics.size();
       stats_.conversions += convs.size();
@@ -407,7 +446,14 @@ void GpuExecutor::run(int engine) {
         if (convs[i].d2h_dst)
           e = hipMemcpyAsync(convs[i].d2h_dst, convs[i].desc.dst, convs[i].d2h_bytes, hipMemcpyDeviceToHost, en.stream);
     }
-    if (e == hipSuccess) e = hipLaunchHostFunc(en.stream, &GpuExecutor::on_batch_done, &batch);
+    if (e == hipSuccess) {
+      if (use_hostfunc_) {
+        e = hipLaunchHostFunc(en.stream, &GpuExecutor::on_batch_done, &batch);
+      } else {
+        e = launch_done(const_cast<uint32_t*>(batch.flag), batch.ticket, en.stream);
+        cv_poll_.notify_one();
+      }
+    }
     if (e != hipSuccess) {
       // whatever was enqueued must drain before the lanes may reuse their buffers
       (void)hipStreamSynchronize(en.stream);

@@ -128,12 +128,19 @@ class GpuExecutor {
     bool in_flight = false;
     GpuExecutor* owner = nullptr;
     int engine = 0;
+    uint32_t ticket = 0;              // value k_done stores into *flag when the batch is through
+    volatile uint32_t* flag = nullptr;  // pinned host memory
   };
 
-  // Stream callback (hipLaunchHostFunc) at the end of a batch: credits the
-  // lanes and wakes waiters.  Runs on a HIP runtime thread; no HIP calls.
+  // End of a batch: credits the lanes and wakes waiters.  Detected by the
+  // poller thread, which watches the tickets that k_done stores into pinned
+  // host memory (default), or by a stream callback (hipLaunchHostFunc,
+  // HWANG_COMPLETION=hostfunc) on a HIP runtime thread.  The poller costs a
+  // fraction of one core; the runtime's callback machinery cost ~8 % of the
+  // process's CPU time, which the entropy decoders need.
   static void on_batch_done(void* batch);
   void complete(Batch* b, hipError_t status);
+  void poll_loop();
 
   static constexpr int kInflight = 3;
   static constexpr int kMaxJobs = 512;
@@ -168,6 +175,12 @@ class GpuExecutor {
   std::string error_;
   std::deque<Lane> lanes_;  // stable addresses: lanes hold a condition variable
   Engine engines_[kEngines];
+  std::thread poller_;
+  std::condition_variable cv_poll_;
+  uint32_t* done_flags_ = nullptr;  // pinned: [kEngines][kInflight]
+  uint32_t next_ticket_ = 0;
+  int total_inflight_ = 0;
+  bool use_hostfunc_ = false;
   Stats stats_;
 };
 

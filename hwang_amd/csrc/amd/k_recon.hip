@@ -1459,6 +1459,18 @@ __global__ __launch_bounds__(256) void k_upload(const JobDesc* __restrict__ jobs
   }
 }
 
+// End-of-batch marker: one lane stores the batch's ticket into pinned host
+// memory (system scope).  Stream order puts it behind everything the batch
+// enqueued, copies included; the executor's poller thread reads it.
+__global__ void k_done(uint32_t* flag, uint32_t ticket) {
+  __hip_atomic_store(flag, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+hipError_t launch_done(uint32_t* flag, uint32_t ticket, hipStream_t stream) {
+  hipLaunchKernelGGL(k_done, dim3(1), dim3(1), 0, stream, flag, ticket);
+  return hipGetLastError();
+}
+
 hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream) {
   hipLaunchKernelGGL(k_upload, dim3(kUploadBlocks, njobs * kJobUploads), dim3(256), 0, stream, jobs);
   return hipGetLastError();
