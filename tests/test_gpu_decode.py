@@ -93,6 +93,30 @@ def test_1080p_cropping(hw, oracle, gpu, tmp_path):
         assert np.array_equal(got[k], gold[r])
 
 
+def test_many_lanes_random_rows_1080p(hw, gpu, tmp_path):
+    """The concurrent machinery end to end: 8 lanes x 2 decoders, intra-only and
+    P/B engines side by side, LRU surfaces, per-GOP work items - random rows of a
+    4-GOP 1080p clip, I420 and RGB, twice (state carried across retrieves),
+    against the encoder's reconstruction (== oracle, tests/test_corpus_roundtrip)."""
+    from oracle import oracle_py
+    path = str(tmp_path / "hd4.mp4")
+    gold = make_clip(path, width=1920, height=1080, frames=96, gop=24, bframes=2, threads=4)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=8)
+    rng = np.random.default_rng(7)
+    for rep in range(2):
+        rows = sorted(rng.choice(96, 24, replace=False).tolist())
+        got = dec.retrieve_yuv(rows)
+        for k, r in enumerate(rows):
+            assert np.array_equal(got[k], gold[r]), "pass %d frame %d" % (rep, r)
+    rows = [0, 23, 24, 47, 95]
+    rgb = dec.retrieve(rows)
+    for k, r in enumerate(rows):
+        assert np.array_equal(rgb[k], oracle_py.i420_to_rgb(gold[r], 1920, 1080))
+    st = dec.stats()
+    assert st["pictures_skipped"] > 0 and st["frames_returned"] == len(rows)
+
+
 def test_4k_wide_pictures(hw, oracle, gpu, tmp_path):
     """BASELINE config C2 geometry (3840x2160 = 240 x 135 macroblocks): wider
     than the intra kernel's LDS line buffer, so intra-only pictures take the
