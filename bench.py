@@ -316,6 +316,7 @@ def main():
                                    % (n, GOP, BFRAMES, len(rows)),
                        "lanes_per_gpu": lanes, "host_cpus": effective_cpus(), "sharding": "keyframe-anchored intervals, no collective"},
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
+            "samples_fed_per_s_rank0": round(stats["samples_fed"] / (elapsed / args.steps), 1),
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,

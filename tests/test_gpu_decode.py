@@ -117,6 +117,26 @@ def test_many_lanes_random_rows_1080p(hw, gpu, tmp_path):
     assert st["pictures_skipped"] > 0 and st["frames_returned"] == len(rows)
 
 
+def test_sparse_equals_sequential_at_scale(hw, gpu, tmp_path):
+    """The reference's only results test (GatherFramesComparison,
+    decoder_automata_test.cpp:262-342) at 1080p over 10 GOPs: frames gathered
+    sparsely == the same frames out of a dense decode, whatever the path
+    (parallel retriever with sparse hints and B skipping, other lane count,
+    the reference-shaped serial DecoderAutomata loop)."""
+    import hashlib
+    path = str(tmp_path / "long.mp4")
+    make_clip(path, width=1920, height=1080, frames=300, gop=30, bframes=2, threads=16, yuv=False)
+    idx = hw.index_video(path)
+    rows = sorted(np.random.default_rng(3).choice(300, 24, replace=False).tolist())
+    md5 = lambda frames: [hashlib.md5(f.tobytes()).hexdigest() for f in frames]
+    sparse16 = md5(hw.Decoder(path, video_index=idx, num_lanes=16).retrieve(rows))
+    sparse3 = md5(hw.Decoder(path, video_index=idx, num_lanes=3).retrieve(rows))
+    serial = md5(hw.Decoder(path, video_index=idx, num_lanes=1).retrieve_serial(rows))
+    dense = hw.Decoder(path, video_index=idx, num_lanes=8).retrieve(list(range(300)))
+    dense = md5([dense[r] for r in rows])
+    assert sparse16 == dense and sparse3 == dense and serial == dense
+
+
 def test_4k_wide_pictures(hw, oracle, gpu, tmp_path):
     """BASELINE config C2 geometry (3840x2160 = 240 x 135 macroblocks): wider
     than the intra kernel's LDS line buffer, so intra-only pictures take the
