@@ -88,8 +88,6 @@ __device__ __forceinline__ T gload(const T* p) {  // whole record, dword-wise
   for (unsigned i = 0; i < sizeof(T) / 4; ++i) o[i] = gld32(reinterpret_cast<const uint32_t*>(p) + i);
   return out;
 }
-template <class T>
-__device__ __forceinline__ T* gptr(T* p) { return p; }  // (documentation only: p is a global pointer)
 
 __device__ __forceinline__ int level_scale4(const uint8_t* weight, int qp, int pos) {
   const int i = pos >> 2, j = pos & 3;
@@ -496,7 +494,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mbi = group * kInterWaves + wave;
   if (mbi >= nmb) return;
-  const MbMotion* __restrict__ mo = gptr(job.motions) + mbi;
+  const MbMotion* __restrict__ mo = job.motions + mbi;
   // the lane's motion data: luma block (row y, 4x4 column lane&3), chroma block
   const int y = lane >> 2, bcol = lane & 3;
   const int blk = (y >> 2) * 4 + bcol, b8 = (y >> 3) * 2 + (bcol >> 1);
@@ -516,13 +514,10 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
   InterWave& L = lds[wave];
   const int mbx = mbi % pp.mb_width, mby = mbi / pp.mb_width;
   const bool has_res = mb.coded_mask != 0;
-  if (has_res) wave_residual(mb, gptr(job.coefs), pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+  if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
 
-  const SliceParams& sp = gptr(job.slices)[mb.slice];
-  Surface cur = pp.surfaces[pp.cur_slot];
-  cur.y = gptr(cur.y);
-  cur.u = gptr(cur.u);
-  cur.v = gptr(cur.v);
+  const SliceParams& sp = job.slices[mb.slice];
+  const Surface cur = pp.surfaces[pp.cur_slot];
   const int W = pp.mb_width * 16, H = pp.mb_height * 16;
   auto byte_of = [](uint32_t w, int k) { return (int)(int8_t)((w >> (8 * k)) & 0xff); };
   {  // luma
@@ -530,9 +525,9 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     const int px = mbx * 16 + bcol * 4, py = mby * 16 + y;
     int s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     if (r0 >= 0)
-      luma_pred4(gptr(pp.surfaces[byte_of(slots0, b8)].y), pp.y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
+      luma_pred4(pp.surfaces[byte_of(slots0, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
     if (r1 >= 0)
-      luma_pred4(gptr(pp.surfaces[byte_of(slots1, b8)].y), pp.y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
+      luma_pred4(pp.surfaces[byte_of(slots1, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -548,11 +543,11 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     int s0[2] = {0, 0}, s1[2] = {0, 0};
     if (r0 >= 0) {
       const Surface& sf = pp.surfaces[byte_of(slots0, cb8)];
-      chroma_pred2(gptr(cplane ? sf.v : sf.u), pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
+      chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
     }
     if (r1 >= 0) {
       const Surface& sf = pp.surfaces[byte_of(slots1, cb8)];
-      chroma_pred2(gptr(cplane ? sf.v : sf.u), pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
+      chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
     }
     uint32_t packed = 0;
 #pragma unroll
@@ -687,14 +682,14 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __
   if (!(mb.flags & MBF_INTRA) || mb.kind == MBK_IPCM) return;
   __shared__ InterWave lds[kInterWaves];
   InterWave& L = lds[wave];
-  uint32_t* out = reinterpret_cast<uint32_t*>(gptr(job.resid) + (size_t)mbi * 384);
+  uint32_t* out = reinterpret_cast<uint32_t*>(job.resid + (size_t)mbi * 384);
   if (mb.coded_mask == 0) {
     gst32(out + lane, 0);
     gst32(out + 64 + lane, 0);
     gst32(out + 128 + lane, 0);
     return;
   }
-  wave_residual(mb, gptr(job.coefs), pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+  wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
   const uint32_t* ry = reinterpret_cast<const uint32_t*>(L.res_y);
   const uint32_t* rc = reinterpret_cast<const uint32_t*>(L.res_c);
   gst32(out + lane, ry[lane]);
@@ -723,8 +718,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
   const JobDesc& job = jobs[blockIdx.x];
   if (!job.do_intra) return;
   const PictureParams& pp = job.pp;
-  const MbInfo* __restrict__ mbs = gptr(job.mbs);
-  const int16_t* __restrict__ coefs = gptr(job.coefs);
+  const MbInfo* __restrict__ mbs = job.mbs;
+  const int16_t* __restrict__ coefs = job.coefs;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ int s_progress[kMaxRows + 1];
   __shared__ IntraWaveLds s_lds[kRowWaves];
@@ -734,16 +729,13 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
   __syncthreads();
   IntraWaveLds& L = s_lds[wave];
   uint8_t* tile = L.tile;
-  Surface cur = pp.surfaces[pp.cur_slot];
-  cur.y = gptr(cur.y);
-  cur.u = gptr(cur.u);
-  cur.v = gptr(cur.v);
+  const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const bool lds_nb = !job.do_inter && pp.mb_width <= kLineMbs;  // wave uniform
   uint8_t (*line_up)[32] = s_line[(wave + kRowWaves - 1) % kRowWaves];
   uint8_t (*line_me)[32] = s_line[wave];
 
-  const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(gptr(job.resid));
+  const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(job.resid);
   for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
     int prev_mbx = -2;  // macroblock whose samples the tile still holds
     for (int mbx0 = 0; mbx0 < pp.mb_width; mbx0 += 64) {
@@ -1184,10 +1176,10 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
   const JobDesc& job = jobs[blockIdx.y];
   if (!job.do_deblock) return;
   const PictureParams& pp = job.pp;
-  const MbInfo* __restrict__ mbs = gptr(job.mbs);
-  const MbMotion* __restrict__ motions = gptr(job.motions);
-  const SliceParams* __restrict__ slices = gptr(job.slices);
-  DbInfo* __restrict__ out = gptr(static_cast<DbInfo*>(job.db));
+  const MbInfo* __restrict__ mbs = job.mbs;
+  const MbMotion* __restrict__ motions = job.motions;
+  const SliceParams* __restrict__ slices = job.slices;
+  DbInfo* __restrict__ out = static_cast<DbInfo*>(job.db);
   const int nmb = pp.mb_width * pp.mb_height;
   const int mbi = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int t = threadIdx.x & 31;
@@ -1260,7 +1252,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
   const JobDesc& job = jobs[blockIdx.x];
   if (!job.do_deblock) return;
   const PictureParams& pp = job.pp;
-  const DbInfo* __restrict__ dbs = gptr(static_cast<const DbInfo*>(job.db));
+  const DbInfo* __restrict__ dbs = static_cast<const DbInfo*>(job.db);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   __shared__ int s_progress[kMaxRows + 1];
   __shared__ DeblockWaveLds s_lds[kRowWaves];
@@ -1269,10 +1261,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
   __syncthreads();
   DeblockWaveLds& L = s_lds[wave];
   uint8_t* lt = L.lt;
-  Surface cur = pp.surfaces[pp.cur_slot];
-  cur.y = gptr(cur.y);
-  cur.u = gptr(cur.u);
-  cur.v = gptr(cur.v);
+  const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const int W = pp.mb_width;
 
