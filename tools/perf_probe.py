@@ -32,6 +32,8 @@ rows = sorted(rng.choice(n, max(1, round(0.01 * n)), replace=False).tolist())
 if os.environ.get("ROWS_MODE") == "keyframes":   # intra-only path in isolation
     kf = idx.keyframe_indices()
     rows = sorted(rng.choice(kf, min(len(kf), len(rows)), replace=False).tolist())
+elif os.environ.get("ROWS_MODE") == "stride10":  # BASELINE config C2: every 10th frame, every GOP touched
+    rows = list(range(0, n, 10))
 elif os.environ.get("ROWS_MODE") == "gopend":    # longest P chains
     kf = idx.keyframe_indices()
     rows = sorted(set(int(k) - 3 for k in rng.choice(kf[1:], min(len(kf) - 1, len(rows)), replace=False)))
