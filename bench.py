@@ -231,9 +231,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    # 2.5 lanes per usable CPU (a lane waits for the GPU more than it parses;
+    # 4 lanes per usable CPU (a lane waits for the GPU far more than it parses;
     # the CPUs are the bottleneck); with several ranks on one host the CPUs are shared
-    lanes = args.lanes or max(2, min(128, (5 * effective_cpus() // 2) // world))
+    lanes = args.lanes or max(2, min(128, 4 * effective_cpus() // world))
     dec = hw.Decoder(path, video_index=index, device_id=local_rank, num_lanes=lanes)
     out = torch.empty((len(rows), HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda")
 

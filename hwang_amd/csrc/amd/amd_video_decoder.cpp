@@ -238,6 +238,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     out->slices = j.slice_host;
     out->max_slices = kMaxSlices;
     out->slot = slot;
+    // k_mv derives the P macroblocks' motion vectors (its LDS line buffer covers 128 macroblocks per row)
+    out->device_mv = mbw_ <= 128 && !getenv("HWANG_HOST_MV");
     return true;
   }
 
@@ -280,6 +282,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.do_inter = d.has_inter;
     sub.desc.do_intra = d.has_intra;
     sub.desc.do_deblock = d.any_deblock;
+    sub.desc.do_mv = d.mv_deferred;
     sub.num_mbs = static_cast<int>(nmb);
     sub.heavy = (d.has_intra && !d.has_inter) ? 1 : 0;
     const uint64_t S = nmb * 384;  // coded I420 bytes

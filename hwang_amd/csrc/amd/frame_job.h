@@ -71,7 +71,22 @@ struct MbInfo {
   uint8_t i4_modes[8];       // 16 x 4 bit, raster 4x4 order
   uint16_t nz_mask;          // 4x4 luma blocks (raster) holding non-zero
                              // coefficients, as the bS derivation sees them
-  uint8_t pad[6];
+  // Motion-vector derivation left to k_mv (P macroblocks): MbMotion::mv[0]
+  // then holds the DIFFERENCES as parsed, one per partition, replicated over
+  // the partition's 4x4 blocks.
+  uint8_t mv_flags;          // MVF_* below
+  uint8_t mv_shape;          // 0 16x16, 1 16x8, 2 8x16, 3 8x8
+  uint8_t mv_sub;            // 8x8 only: 2 bits per quadrant: 0 8x8, 1 8x4, 2 4x8, 3 4x4
+  uint8_t pad[3];
+};
+enum : uint8_t {
+  MVF_DEFERRED = 1,          // mv[0] holds differences; derive (8.4.1.3)
+  MVF_PSKIP = 2,             // P_Skip inference (8.4.1.1)
+  // neighbouring macroblocks usable for mv prediction (same slice, inside the picture)
+  MVF_AVAIL_A = 16,
+  MVF_AVAIL_B = 32,
+  MVF_AVAIL_C = 64,
+  MVF_AVAIL_D = 128,
 };
 static_assert(sizeof(MbInfo) == 32, "MbInfo must stay 32 bytes");
 
@@ -133,7 +148,9 @@ struct JobDesc {
   void* db;            // k_bs -> k_deblock records
   int16_t* resid;      // k_residual -> k_intra: 384 int16 per macroblock (256 luma raster, 64 Cb, 64 Cr)
   int32_t do_inter, do_intra, do_deblock;
+  int32_t do_mv;       // some macroblocks carry MVF_DEFERRED
   int32_t num_uploads;
+  int32_t pad;
   UploadDesc uploads[kJobUploads];
 };
 

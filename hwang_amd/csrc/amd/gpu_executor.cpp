@@ -18,7 +18,7 @@ namespace amd {
 hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream);
 hipError_t launch_done(uint32_t* flag, uint32_t ticket, hipStream_t stream);
 hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
-                        bool any_deblock, const uint64_t bytes[3], hipStream_t stream);
+                        bool any_deblock, bool any_mv, const uint64_t bytes[3], hipStream_t stream);
 
 namespace {
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
@@ -398,7 +398,7 @@ void GpuExecutor::run(int engine) {
     hipError_t e = hipSuccess;
     if (!pics.empty()) {
       int max_mbs = 0;
-      bool any_inter = false, any_intra = false, any_deblock = false;
+      bool any_inter = false, any_intra = false, any_deblock = false, any_mv = false;
       uint64_t bytes[3] = {0, 0, 0};
       for (size_t i = 0; i < pics.size(); ++i) {
         const PicSubmit& p = pics[i];
@@ -414,6 +414,7 @@ void GpuExecutor::run(int engine) {
         any_inter |= p.desc.do_inter != 0;
         any_intra |= p.desc.do_intra != 0;
         any_deblock |= p.desc.do_deblock != 0;
+        any_mv |= p.desc.do_mv != 0;
         bytes[0] += p.bytes_inter;
         bytes[1] += p.bytes_intra;
         bytes[2] += p.bytes_deblock;
@@ -427,7 +428,7 @@ void GpuExecutor::run(int engine) {
       }
       if (e == hipSuccess)
         e = launch_batch(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, any_inter, any_intra,
-                         any_deblock, bytes, en.stream);
+                         any_deblock, any_mv, bytes, en.stream);
     }
     if (!convs.empty() && e == hipSuccess) {
       int mw = 0, mh = 0;

@@ -584,6 +584,7 @@ namespace {
 
 constexpr int kRowWaves = 16;
 constexpr int kMaxRows = 512;
+constexpr int kLineMbs = 128;  // width (macroblocks) the LDS line buffers of k_mv / k_intra cover
 
 // The counters live in LDS and must be addressed as such: through a generic
 // volatile pointer they become flat_load ... sc0 sc1 followed by s_waitcnt
@@ -663,6 +664,259 @@ struct IntraWaveLds {
 }  // namespace
 
 // ===========================================================================
+// k_mv: motion vectors of the P macroblocks whose derivation the host left to
+// the GPU (MbInfo::mv_flags & MVF_DEFERRED): MbMotion::mv[0] arrives holding
+// the parsed differences and leaves holding the vectors (8.4.1.1 P_Skip
+// inference, 8.4.1.3 median / directional prediction).  Prediction looks at
+// the left, top, top-right and top-left neighbours, i.e. it is the same
+// raster-order chain as intra prediction: one workgroup of 16 waves per
+// picture, a wave per macroblock row, neighbours handed on through LDS (the
+// previous macroblock's right column, a line buffer with every macroblock's
+// bottom row).  The chain itself is scalar work: lane 0 walks the partitions,
+// the other lanes move data.  Pictures wider than kLineMbs macroblocks are
+// derived on the host instead (h264_parser: PicBuffers::device_mv).
+// ===========================================================================
+namespace {
+struct MvEdge {        // what a neighbour below / to the right needs of a macroblock
+  uint32_t mv[4];      // packed (x, y) of four 4x4 blocks
+  int8_t ref[2];       // reference index of the two 8x8 quadrants they lie in (-1: intra / unused)
+  int8_t pad[2];
+};
+struct MvNb {
+  int ref;             // -2 not available, -1 intra or list unused, >= 0 reference index
+  int x, y;
+};
+constexpr int kMvChunk = 4;  // macroblocks whose records travel together (prefetch distance)
+struct MvWaveLds {
+  uint32_t mv[kMvChunk][16];  // differences in, vectors out
+  uint32_t ref[kMvChunk];     // ref_idx[0][0..3]
+  uint32_t info[kMvChunk];    // nz_mask | mv_flags << 16 | mv_shape << 24
+  uint32_t kind[kMvChunk];    // kind | flags << 8 | ...
+  uint32_t sub[kMvChunk];
+  MvEdge left;                // right column (blocks 3, 7, 11, 15; quadrants 1, 3) of the previous macroblock
+};
+// decode-order index of the 4x4 block at raster position (x, y) of a macroblock
+__device__ __forceinline__ int zz_of(int x, int y) { return ((y >> 1) << 3) | ((x >> 1) << 2) | ((y & 1) << 1) | (x & 1); }
+__device__ __forceinline__ int med3(int a, int b, int c) {
+  return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b));
+}
+}  // namespace
+
+__global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.x];
+  if (!job.do_mv) return;
+  const PictureParams& pp = job.pp;
+  const MbInfo* __restrict__ mbs = job.mbs;
+  MbMotion* __restrict__ motions = const_cast<MbMotion*>(job.motions);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __shared__ int s_progress[kMaxRows + 1];
+  __shared__ MvWaveLds s_lds[kRowWaves];
+  __shared__ MvEdge s_line[kRowWaves][kLineMbs];
+  lds_counter* progress = (lds_counter*)s_progress;
+  for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
+  __syncthreads();
+  MvWaveLds& L = s_lds[wave];
+  const MvEdge* line_up = s_line[(wave + kRowWaves - 1) % kRowWaves];
+  MvEdge* line_me = s_line[wave];
+  const int W = pp.mb_width;
+
+  for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
+    // Records travel kMvChunk macroblocks at a time, one chunk ahead: a single
+    // macroblock of lead is less than the memory latency once the per-macroblock
+    // work is down to a fraction of a microsecond.  lane -> (macroblock lane >> 4,
+    // block lane & 15) for the vectors, lanes 0..3 one macroblock each for the rest.
+    uint32_t n_mv = 0, n_ref = 0, n_info = 0, n_kind = 0, n_sub = 0;
+    auto prefetch = [&](int mbx0) {
+      const int m = min(mbx0 + (lane >> 4), W - 1);
+      n_mv = gld32(reinterpret_cast<const uint32_t*>(motions[mby * W + m].mv[0]) + (lane & 15));
+      if (lane < kMvChunk) {
+        const int q = min(mbx0 + lane, W - 1);
+        const MbInfo* mi = &mbs[mby * W + q];
+        n_info = gld32(reinterpret_cast<const uint8_t*>(mi) + 24);
+        n_kind = gld32(mi);
+        n_sub = gld8(&mi->mv_sub);
+        n_ref = gld32(motions[mby * W + q].ref_idx[0]);
+      }
+    };
+    prefetch(0);
+    asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_info), "+v"(n_kind), "+v"(n_sub));
+    for (int mbx0 = 0; mbx0 < W; mbx0 += kMvChunk) {
+      L.mv[lane >> 4][lane & 15] = n_mv;
+      if (lane < kMvChunk) {
+        L.ref[lane] = n_ref;
+        L.info[lane] = n_info;
+        L.kind[lane] = n_kind;
+        L.sub[lane] = n_sub;
+      }
+      if (mbx0 + kMvChunk < W) prefetch(mbx0 + kMvChunk);
+      wave_sync();
+      for (int k = 0; k < kMvChunk && mbx0 + k < W; ++k) {
+        const int mbx = mbx0 + k;
+        const int mbi = mby * W + mbx;
+        const uint32_t info = L.info[k];
+        const int flags = (info >> 16) & 0xff, shape = (info >> 24) & 3, sub = L.sub[k];
+        const bool intra = (L.kind[k] >> 8) & MBF_INTRA;  // MbInfo::flags is byte 1
+        const bool deferred = flags & MVF_DEFERRED;
+        uint32_t* cmv = L.mv[k];
+        const uint32_t refw = intra ? 0xffffffffu : L.ref[k];
+        auto cref = [&](int b8) { return (int)(int8_t)((refw >> (8 * b8)) & 0xff); };
+        if (deferred && (flags & (MVF_AVAIL_B | MVF_AVAIL_C | MVF_AVAIL_D))) row_wait(progress, mby, min(mbx + 2, W));
+        auto unpack_x = [](uint32_t v) { return (int)(int16_t)(v & 0xffff); };
+        auto unpack_y = [](uint32_t v) { return (int)(int16_t)(v >> 16); };
+        const bool whole = deferred && ((flags & MVF_PSKIP) || shape == 0);
+        if (whole) {
+          // One prediction for the macroblock, from neighbours that all lie outside
+          // it: every lane does the same register arithmetic, nothing is serial.
+          auto outside = [&](bool avail, int ref, uint32_t v) -> MvNb {
+            MvNb nb = {-2, 0, 0};
+            if (!avail) return nb;
+            nb.ref = ref < 0 ? -1 : ref;
+            if (ref >= 0) {
+              nb.x = unpack_x(v);
+              nb.y = unpack_y(v);
+            }
+            return nb;
+          };
+          const MvNb A = outside(flags & MVF_AVAIL_A, L.left.ref[0], L.left.mv[0]);
+          const MvNb B = outside(flags & MVF_AVAIL_B, line_up[mbx].ref[0], line_up[mbx].mv[0]);
+          MvNb C = outside(flags & MVF_AVAIL_C, line_up[min(mbx + 1, W - 1)].ref[0], line_up[min(mbx + 1, W - 1)].mv[0]);
+          if (C.ref == -2) C = outside(flags & MVF_AVAIL_D, line_up[max(mbx - 1, 0)].ref[1], line_up[max(mbx - 1, 0)].mv[3]);
+          const int ref = (flags & MVF_PSKIP) ? 0 : cref(0);
+          int mx, my;
+          const int match = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+          if (match == 1) {
+            const MvNb& P = A.ref == ref ? A : (B.ref == ref ? B : C);
+            mx = P.x;
+            my = P.y;
+          } else if (match == 0 && B.ref == -2 && C.ref == -2 && A.ref != -2) {
+            mx = A.x;
+            my = A.y;
+          } else {
+            mx = med3(A.x, B.x, C.x);
+            my = med3(A.y, B.y, C.y);
+          }
+          if (flags & MVF_PSKIP) {
+            if (A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.x == 0 && A.y == 0) || (B.ref == 0 && B.x == 0 && B.y == 0)) mx = my = 0;
+          } else {
+            const uint32_t d = cmv[0];
+            mx += unpack_x(d);
+            my += unpack_y(d);
+          }
+          wave_sync();
+          if (lane < 16) cmv[lane] = (uint32_t)(uint16_t)mx | ((uint32_t)(uint16_t)my << 16);
+        } else if (deferred && lane == 0) {
+          auto fetch = [&](int rx, int ry, int cur_zz) -> MvNb {
+            MvNb nb = {-2, 0, 0};
+            if (rx > 3 && ry >= 0) return nb;
+            int ref;
+            uint32_t v;
+            if (rx >= 0 && rx <= 3 && ry >= 0) {
+              if (zz_of(rx, ry) >= cur_zz) return nb;
+              ref = cref((ry >> 1) * 2 + (rx >> 1));
+              v = cmv[ry * 4 + rx];
+            } else if (ry >= 0) {  // left neighbour
+              if (!(flags & MVF_AVAIL_A)) return nb;
+              ref = L.left.ref[ry >> 1];
+              v = L.left.mv[ry];
+            } else if (rx < 0) {   // top-left
+              if (!(flags & MVF_AVAIL_D)) return nb;
+              ref = line_up[mbx - 1].ref[1];
+              v = line_up[mbx - 1].mv[3];
+            } else if (rx <= 3) {  // top
+              if (!(flags & MVF_AVAIL_B)) return nb;
+              ref = line_up[mbx].ref[rx >> 1];
+              v = line_up[mbx].mv[rx];
+            } else {               // top-right
+              if (!(flags & MVF_AVAIL_C)) return nb;
+              ref = line_up[mbx + 1].ref[0];
+              v = line_up[mbx + 1].mv[0];
+            }
+            nb.ref = -1;
+            if (ref < 0) return nb;
+            nb.ref = ref;
+            nb.x = unpack_x(v);
+            nb.y = unpack_y(v);
+            return nb;
+          };
+          // dir: 0 median, 1 16x8 top, 2 16x8 bottom, 3 8x16 left, 4 8x16 right
+          auto predict = [&](int bx, int by, int bw, int ref, int dir, int& ox, int& oy) {
+            const int zz = zz_of(bx, by);
+            const MvNb A = fetch(bx - 1, by, zz);
+            const MvNb B = fetch(bx, by - 1, zz);
+            MvNb C = fetch(bx + bw, by - 1, zz);
+            if (C.ref == -2) C = fetch(bx - 1, by - 1, zz);
+            int pick = -1;  // 0 A, 1 B, 2 C
+            if (dir == 1 && B.ref == ref) pick = 1;
+            if (dir == 2 && A.ref == ref) pick = 0;
+            if (dir == 3 && A.ref == ref) pick = 0;
+            if (dir == 4 && C.ref == ref) pick = 2;
+            if (pick < 0) {
+              const int match = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+              if (match == 1) pick = A.ref == ref ? 0 : (B.ref == ref ? 1 : 2);
+              else if (match == 0 && B.ref == -2 && C.ref == -2 && A.ref != -2) pick = 0;
+            }
+            if (pick == 0) { ox = A.x; oy = A.y; }
+            else if (pick == 1) { ox = B.x; oy = B.y; }
+            else if (pick == 2) { ox = C.x; oy = C.y; }
+            else { ox = med3(A.x, B.x, C.x); oy = med3(A.y, B.y, C.y); }
+          };
+          auto fill = [&](int bx, int by, int bw, int bh, int mvx, int mvy) {
+            const uint32_t packed = (uint32_t)(uint16_t)mvx | ((uint32_t)(uint16_t)mvy << 16);
+            for (int yy = by; yy < by + bh; ++yy)
+              for (int xx = bx; xx < bx + bw; ++xx) cmv[yy * 4 + xx] = packed;
+          };
+          const int nparts = shape == 3 ? 4 : 2;  // 16x16 took the path above
+          for (int i = 0; i < nparts; ++i) {
+            int px, py, pw, ph;
+            if (shape == 1) { px = 0; py = i * 2; pw = 4; ph = 2; }
+            else if (shape == 2) { px = i * 2; py = 0; pw = 2; ph = 4; }
+            else { px = (i & 1) * 2; py = (i >> 1) * 2; pw = 2; ph = 2; }
+            int sw = pw, sh = ph;
+            if (shape == 3) {
+              const int ss = (sub >> (2 * i)) & 3;
+              if (ss == 2 || ss == 3) sw = 1;
+              if (ss == 1 || ss == 3) sh = 1;
+            }
+            const int ref = cref((py >> 1) * 2 + (px >> 1));
+            for (int sy = 0; sy < ph; sy += sh)
+              for (int sx = 0; sx < pw; sx += sw) {
+                const int bx = px + sx, by = py + sy;
+                int dir = 0;
+                if (shape == 1) dir = i == 0 ? 1 : 2;
+                if (shape == 2) dir = i == 0 ? 3 : 4;
+                int mx, my;
+                predict(bx, by, sw, ref, dir, mx, my);
+                const uint32_t d = cmv[by * 4 + bx];
+                fill(bx, by, sw, sh, mx + unpack_x(d), my + unpack_y(d));
+              }
+          }
+        }
+        wave_sync();
+        // The prefetched registers have arrived by now; saying so before the store
+        // below is issued keeps the next chunk from waiting on that store (in-order
+        // vmcnt, see k_deblock).
+        if (k == kMvChunk - 1 || mbx == W - 1)
+          asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_info), "+v"(n_kind), "+v"(n_sub));
+        // vectors out (deferred macroblocks only), edges on to the neighbours
+        if (deferred && lane < 16) gst32(reinterpret_cast<uint32_t*>(motions[mbi].mv[0]) + lane, cmv[lane]);
+        if (lane < 4) {
+          line_me[mbx].mv[lane] = cmv[12 + lane];
+          L.left.mv[lane] = cmv[lane * 4 + 3];
+        } else if (lane == 4) {
+          line_me[mbx].ref[0] = (int8_t)cref(2);
+          line_me[mbx].ref[1] = (int8_t)cref(3);
+          L.left.ref[0] = (int8_t)cref(1);
+          L.left.ref[1] = (int8_t)cref(3);
+        }
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        progress[mby + 1] = mbx + 1;
+      }
+      wave_sync();  // the chunk buffer is rewritten at the top of the next round
+    }
+  }
+}
+
+// ===========================================================================
 // k_residual: dequantisation + inverse transforms of every intra macroblock,
 // fully parallel (one wave per macroblock, 4 per workgroup), written as int16
 // to the job's residual scratch.  It takes the coefficient loads, the scaling
@@ -712,7 +966,6 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __
 //    pictures: neighbours are read from the surface; a release fence precedes
 //    the progress counter.
 // ===========================================================================
-constexpr int kLineMbs = 128;
 
 __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restrict__ jobs) {
   const JobDesc& job = jobs[blockIdx.x];
@@ -1470,11 +1723,12 @@ hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream) {
 // `max_mbs` the largest macroblock count among them.
 // ===========================================================================
 hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
-                        bool any_deblock, const uint64_t bytes[3], hipStream_t stream) {
+                        bool any_deblock, bool any_mv, const uint64_t bytes[3], hipStream_t stream) {
   const bool profiled = prof::enabled();
   prof::Span span;
   if (any_inter) {
     if (profiled) span = prof::begin(stream);
+    if (any_mv) hipLaunchKernelGGL(k_mv, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
     hipLaunchKernelGGL(k_inter, dim3(((max_mbs + kInterWaves - 1) / kInterWaves + 7) / 8 * 8, njobs), dim3(kInterWaves * 64), 0,
                        stream, jobs);
     if (profiled) prof::end(span, stream, prof::K_INTER, bytes[0]);

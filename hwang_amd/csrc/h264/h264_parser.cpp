@@ -238,6 +238,15 @@ struct Pic {
   MbMotion* motion = nullptr;         // owned by the sink (pinned, per surface)
   std::vector<int32_t> ref_uid[2];    // per 8x8
   std::vector<uint8_t> mb_intra;
+  // P macroblocks are parsed without deriving their motion vectors (motion[]
+  // holds the differences); mvrec keeps what the derivation needs per
+  // macroblock: MbInfo::mv_flags, mv_shape, mv_sub.  `derived` is the lazily
+  // computed final motion, only ever needed when a B picture uses this one as
+  // its co-located picture.
+  std::vector<uint8_t> mvrec;
+  bool mv_deferred = false;
+  std::vector<MbMotion> derived;
+  bool derived_valid = false;
 };
 
 struct SliceHdr {
@@ -340,6 +349,7 @@ struct Parser::Impl {
     // offset: av[(oy + 1) * 3 + ox + 1] for ox in -1..1, oy in -1..0
     bool av[6];
     bool avA, avB;
+    int mv_shape, mv_sub, mv_pskip, mv_defer;  // deferred motion-vector derivation (P macroblocks)
     // motion record of each available, non-intra neighbour (same index as
     // av[]; [4] = this macroblock), nullptr otherwise; filled by begin_mb
     const MbMotion* nbmo[6];
@@ -983,6 +993,9 @@ struct Parser::Impl {
     for (int l = 0; l < 2; ++l)
       if (c->ref_uid[l].size() != static_cast<size_t>(nmb) * 4) c->ref_uid[l].assign(nmb * 4, -1);
     if (c->mb_intra.size() != static_cast<size_t>(nmb)) c->mb_intra.assign(nmb, 0);
+    if (c->mvrec.size() != static_cast<size_t>(nmb) * 3) c->mvrec.assign(static_cast<size_t>(nmb) * 3, 0);
+    c->mv_deferred = false;
+    c->derived_valid = false;
     mbs_decoded = 0;
     coef_used = 0;
     num_slices = 0;
@@ -1079,8 +1092,13 @@ struct Parser::Impl {
     const int nmb = mbw * mbh;
     if (mbs_decoded != nmb) return fail("picture ended with undecoded macroblocks");
 
+    if (c->mv_deferred && !bufs.device_mv) {
+      derive_deferred(c, c->motion);  // in place: nothing has been submitted yet
+      c->mv_deferred = false;
+    }
     PicDone done;
     memset(&done, 0, sizeof(done));
+    done.mv_deferred = c->mv_deferred;
     done.slot = c->slot;
     done.num_slices = num_slices;
     done.coef_count = coef_used;
@@ -1222,12 +1240,135 @@ struct Parser::Impl {
     }
   }
 
+  // ------------------------------------------------------------------------
+  // Motion vectors of the deferred (P) macroblocks of a whole picture, from the
+  // records the parser left: differences in mv[0], reference indices, partition
+  // shapes and neighbour availability (8.4.1.1, 8.4.1.3).  `motion` is written
+  // in place; macroblocks are visited in raster order, so every neighbour a
+  // prediction looks at is final already.  The GPU does the same in k_mv; this
+  // host version serves sinks without it and co-located lookups of B pictures.
+  // ------------------------------------------------------------------------
+  void derive_deferred(const Pic* p, MbMotion* motion) const {
+    const int nmb = mbw * mbh;
+    for (int addr = 0; addr < nmb; ++addr) {
+      const uint8_t* rec = &p->mvrec[static_cast<size_t>(addr) * 3];
+      const int flags = rec[0];
+      if (!(flags & amd::MVF_DEFERRED)) continue;
+      MbMotion& mo = motion[addr];
+      // neighbour sample: ref -2 unavailable, -1 intra / list unused
+      auto fetch = [&](int rx, int ry, int cur_zz) -> NB {
+        NB nb = {-2, {0, 0}};
+        if (rx > 3 && ry >= 0) return nb;
+        const int ox = rx < 0 ? -1 : (rx > 3 ? 1 : 0), oy = ry < 0 ? -1 : 0;
+        const int bx = rx & 3, by = ry & 3;
+        const MbMotion* m;
+        if (ox == 0 && oy == 0) {
+          if (raster_to_blk4[by * 4 + bx] >= cur_zz) return nb;
+          m = &mo;
+        } else {
+          const int bit = oy == 0 ? amd::MVF_AVAIL_A : (ox < 0 ? amd::MVF_AVAIL_D : (ox == 0 ? amd::MVF_AVAIL_B : amd::MVF_AVAIL_C));
+          if (!(flags & bit)) return nb;
+          const int na = addr + oy * mbw + ox;
+          nb.ref = -1;
+          if (p->mb_intra[na]) return nb;
+          m = &motion[na];
+        }
+        nb.ref = -1;
+        const int r = m->ref_idx[0][(by >> 1) * 2 + (bx >> 1)];
+        if (r < 0) return nb;
+        nb.ref = r;
+        nb.mv[0] = m->mv[0][by * 4 + bx][0];
+        nb.mv[1] = m->mv[0][by * 4 + bx][1];
+        return nb;
+      };
+      auto predict = [&](int bx, int by, int bw, int ref, int dir, int out[2]) {
+        const int zz = raster_to_blk4[by * 4 + bx];
+        NB A = fetch(bx - 1, by, zz);
+        NB B = fetch(bx, by - 1, zz);
+        NB C = fetch(bx + bw, by - 1, zz);
+        if (C.ref == -2) C = fetch(bx - 1, by - 1, zz);
+        const NB* pick = nullptr;
+        if (dir == PRED_16x8_TOP && B.ref == ref) pick = &B;
+        if (dir == PRED_16x8_BOTTOM && A.ref == ref) pick = &A;
+        if (dir == PRED_8x16_LEFT && A.ref == ref) pick = &A;
+        if (dir == PRED_8x16_RIGHT && C.ref == ref) pick = &C;
+        if (!pick) {
+          const int match = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
+          if (match == 1) pick = A.ref == ref ? &A : (B.ref == ref ? &B : &C);
+          else if (match == 0 && B.ref == -2 && C.ref == -2 && A.ref != -2) pick = &A;
+        }
+        if (pick) {
+          out[0] = pick->mv[0];
+          out[1] = pick->mv[1];
+        } else {
+          out[0] = median3(A.mv[0], B.mv[0], C.mv[0]);
+          out[1] = median3(A.mv[1], B.mv[1], C.mv[1]);
+        }
+      };
+      auto fill = [&](int bx, int by, int bw, int bh, int mvx, int mvy) {
+        const uint32_t packed = static_cast<uint16_t>(mvx) | (static_cast<uint32_t>(static_cast<uint16_t>(mvy)) << 16);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(mo.mv[0]);
+        for (int y = by; y < by + bh; ++y)
+          for (int x = bx; x < bx + bw; ++x) dst[y * 4 + x] = packed;
+      };
+      if (flags & amd::MVF_PSKIP) {
+        const NB A = fetch(-1, 0, 0), B = fetch(0, -1, 0);
+        int mv[2] = {0, 0};
+        if (!(A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) ||
+              (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
+          predict(0, 0, 4, 0, PRED_MEDIAN, mv);
+        fill(0, 0, 4, 4, mv[0], mv[1]);
+        continue;
+      }
+      const int shape = rec[1], sub = rec[2];
+      const int nparts = shape == 0 ? 1 : (shape == 3 ? 4 : 2);
+      for (int i = 0; i < nparts; ++i) {
+        int px, py, pw, ph;
+        if (shape == 0) { px = 0; py = 0; pw = 4; ph = 4; }
+        else if (shape == 1) { px = 0; py = i * 2; pw = 4; ph = 2; }
+        else if (shape == 2) { px = i * 2; py = 0; pw = 2; ph = 4; }
+        else { px = (i & 1) * 2; py = (i >> 1) * 2; pw = 2; ph = 2; }
+        int sw = pw, sh = ph;
+        if (shape == 3) {
+          const int ss = (sub >> (2 * i)) & 3;
+          if (ss == 2 || ss == 3) sw = 1;
+          if (ss == 1 || ss == 3) sh = 1;
+        }
+        const int ref = mo.ref_idx[0][(py >> 1) * 2 + (px >> 1)];
+        for (int sy = 0; sy < ph; sy += sh)
+          for (int sx = 0; sx < pw; sx += sw) {
+            const int bx = px + sx, by = py + sy;
+            int dir = PRED_MEDIAN;
+            if (shape == 1) dir = i == 0 ? PRED_16x8_TOP : PRED_16x8_BOTTOM;
+            if (shape == 2) dir = i == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT;
+            int mvp[2];
+            predict(bx, by, sw, ref, dir, mvp);
+            const int dx = mo.mv[0][by * 4 + bx][0], dy = mo.mv[0][by * 4 + bx][1];
+            fill(bx, by, sw, sh, mvp[0] + dx, mvp[1] + dy);
+          }
+      }
+    }
+  }
+
+  // Final motion of a (possibly deferred) picture for co-located lookups.
+  const MbMotion* final_motion(const Pic* cp) {
+    Pic* p = const_cast<Pic*>(cp);
+    if (!p->mv_deferred) return p->motion;
+    if (!p->derived_valid) {
+      const size_t nmb = static_cast<size_t>(mbw) * mbh;
+      p->derived.assign(p->motion, p->motion + nmb);  // the surface's buffer may still be uploading: work on a copy
+      derive_deferred(p, p->derived.data());
+      p->derived_valid = true;
+    }
+    return p->derived.data();
+  }
+
   bool pred_direct(int only_b8) {
     const Pic* col = sl.ref_list[1][0];
     if (!col || !col->motion) return fail("direct prediction without RefPicList1[0]");
     const int inf8 = asps->direct_8x8_inference;
     const int addr = mb.addr;
-    const MbMotion& cm = col->motion[addr];
+    const MbMotion& cm = final_motion(col)[addr];
     if (sl.direct_spatial) {
       int ref[2], mvp[2][2] = {{0, 0}, {0, 0}};
       for (int l = 0; l < 2; ++l) {
@@ -1910,6 +2051,12 @@ struct Parser::Impl {
           set_ref8(l, i, ref);
         }
       }
+    const bool defer = !is_b;  // P: record the differences, the vectors are derived per picture later
+    if (defer) {
+      mb.mv_defer = 1;
+      mb.mv_shape = shape;
+      mb.mv_sub = sub_shape[0] | (sub_shape[1] << 2) | (sub_shape[2] << 4) | (sub_shape[3] << 6);
+    }
     const MbMotion& mo = cur->motion[mb.addr];
     for (int l = 0; l < (is_b ? 2 : 1); ++l)
       for (int i = 0; i < nparts; ++i) {
@@ -1932,8 +2079,8 @@ struct Parser::Impl {
             int dir = PRED_MEDIAN;
             if (shape == 1) dir = i == 0 ? PRED_16x8_TOP : PRED_16x8_BOTTOM;
             if (shape == 2) dir = i == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT;
-            int mvp[2];
-            pred_mv(l, bx, by, sw, ref, dir, mvp);
+            int mvp[2] = {0, 0};
+            if (!defer) pred_mv(l, bx, by, sw, ref, dir, mvp);
             const int dx = rd_mvd(l, bx, by, 0);
             const int dy = rd_mvd(l, bx, by, 1);
             set_mvd_block(l, bx, by, sw, sh, dx, dy);
@@ -1956,6 +2103,7 @@ struct Parser::Impl {
     }
     mb.kind = MB_NONE;
     mb.skip = mb.direct16 = mb.t8x8 = mb.i16_mode = mb.chroma_mode = mb.cbp = 0;
+    mb.mv_shape = mb.mv_sub = mb.mv_pskip = mb.mv_defer = 0;
     mb.qp = qp;
     mb.cbf_dc = 0;
     mb.coded_mask = 0;
@@ -2015,6 +2163,23 @@ struct Parser::Impl {
     o.qpc[1] = chroma_qp_table[iclip(0, 51, qy + p.chroma_qp_offset[1])];
     o.pred_modes = static_cast<uint8_t>((mb.i16_mode & 15) | (mb.chroma_mode << 4));
     o.slice = static_cast<uint8_t>(slice_index - 1);
+    {
+      uint8_t mf = 0;
+      if (mb.mv_defer) mf |= amd::MVF_DEFERRED;
+      if (mb.mv_pskip) mf |= amd::MVF_PSKIP;
+      if (mb.av[3]) mf |= amd::MVF_AVAIL_A;
+      if (mb.av[1]) mf |= amd::MVF_AVAIL_B;
+      if (mb.av[2]) mf |= amd::MVF_AVAIL_C;
+      if (mb.av[0]) mf |= amd::MVF_AVAIL_D;
+      o.mv_flags = mf;
+      o.mv_shape = static_cast<uint8_t>(mb.mv_shape);
+      o.mv_sub = static_cast<uint8_t>(mb.mv_sub);
+      uint8_t* rec = &cur->mvrec[static_cast<size_t>(a) * 3];
+      rec[0] = mf;
+      rec[1] = o.mv_shape;
+      rec[2] = o.mv_sub;
+      if (mb.mv_defer) cur->mv_deferred = true;
+    }
     for (int k = 0; k < 8; ++k) o.i4_modes[k] = static_cast<uint8_t>((mb.i4_mode[2 * k] & 15) | (mb.i4_mode[2 * k + 1] << 4));
     uint16_t nz = static_cast<uint16_t>(~_mm_movemask_epi8(
         _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(mb.nnz)), _mm_setzero_si128())));
@@ -2055,12 +2220,8 @@ struct Parser::Impl {
     last_qp_delta_nonzero = 0;
     if (sl.type == 0) {
       for (int q = 0; q < 4; ++q) set_ref8(0, q, 0);
-      NB A = fetch_nb(0, -1, 0, 0), B = fetch_nb(0, 0, -1, 0);
-      int mv[2] = {0, 0};
-      if (!(A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.mv[0] == 0 && A.mv[1] == 0) ||
-            (B.ref == 0 && B.mv[0] == 0 && B.mv[1] == 0)))
-        pred_mv(0, 0, 0, 4, 0, PRED_MEDIAN, mv);
-      set_mv_block(0, 0, 0, 4, 4, mv[0], mv[1]);
+      mb.mv_defer = 1;   // mv[0] stays zero (begin_mb); the inference (8.4.1.1) runs with the picture's derivation
+      mb.mv_pskip = 1;
     } else {
       mb.direct16 = 1;
       memset(&direct8[addr * 4], 1, 4);

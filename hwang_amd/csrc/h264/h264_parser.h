@@ -32,6 +32,9 @@ struct PicBuffers {
   amd::SliceParams* slices = nullptr;
   int max_slices = 0;
   int slot = -1;                     // surface the picture is reconstructed into
+  // The sink derives the motion vectors of P macroblocks itself (k_mv) from
+  // the differences; if false the parser does it before end_picture.
+  bool device_mv = false;
 };
 
 struct PicSetup {
@@ -46,6 +49,7 @@ struct PicDone {
   bool has_inter;        // motion[] must be uploaded
   bool has_intra;
   bool any_deblock;      // some slice has the in-loop filter enabled
+  bool mv_deferred;      // MbInfo::mv_flags & MVF_DEFERRED on some macroblocks: run k_mv first
   int slice_type_mask;   // bit0 P, bit1 B, bit2 I
   const uint8_t (*scaling4)[16];
   const uint8_t (*scaling8)[64];

@@ -43,8 +43,9 @@ ParallelRetriever* ParallelRetriever::make(DeviceHandle device,
   // A lane spends most of its time waiting for the GPU (a picture's latency
   // through the batching pipeline is several times its parse time), so it takes
   // several lanes per CPU to keep the CPUs - the bottleneck - busy; measured
-  // optimum on a 16-CPU quota: 40 lanes (32: CPUs idle, 64: oversubscribed).
-  if (num_lanes <= 0) num_lanes = std::min<int32_t>((5 * effective_cpus() + 1) / 2, 128);
+  // optimum on a 16-CPU quota: 64 lanes (with motion-vector derivation on the
+  // GPU a picture costs less CPU and more GPU latency than it used to).
+  if (num_lanes <= 0) num_lanes = std::min<int32_t>(4 * effective_cpus(), 128);
   std::unique_ptr<ParallelRetriever> r(new ParallelRetriever());
   r->lanes_.resize(num_lanes);
   for (Lane& lane : r->lanes_) {
