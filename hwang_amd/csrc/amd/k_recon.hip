@@ -740,6 +740,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict
     };
     prefetch(0);
     asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_info), "+v"(n_kind), "+v"(n_sub));
+    int left_ref0 = -1;         // left neighbour's top-right quadrant: reference index ...
+    uint32_t left_mv0 = 0;      // ... and the vector of its block 3 (registers; L.left is the LDS copy for the general path)
     for (int mbx0 = 0; mbx0 < W; mbx0 += kMvChunk) {
       L.mv[lane >> 4][lane & 15] = n_mv;
       if (lane < kMvChunk) {
@@ -748,63 +750,86 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict
         L.kind[lane] = n_kind;
         L.sub[lane] = n_sub;
       }
+      // the chunk's records stay in these registers (lane k holds macroblock k's
+      // words, lane 16 k its first vector difference): readlane hands them to
+      // the scalar unit without an LDS round trip
+      const uint32_t c_info = n_info, c_kind = n_kind, c_sub = n_sub, c_ref = n_ref, c_mv = n_mv;
       if (mbx0 + kMvChunk < W) prefetch(mbx0 + kMvChunk);
       wave_sync();
       for (int k = 0; k < kMvChunk && mbx0 + k < W; ++k) {
         const int mbx = mbx0 + k;
         const int mbi = mby * W + mbx;
-        const uint32_t info = L.info[k];
-        const int flags = (info >> 16) & 0xff, shape = (info >> 24) & 3, sub = L.sub[k];
-        const bool intra = (L.kind[k] >> 8) & MBF_INTRA;  // MbInfo::flags is byte 1
+        // Everything below is wave-uniform arithmetic: what is read from LDS goes
+        // through readfirstlane, so the compiler keeps it in SGPRs and the scalar
+        // unit does the work (one cycle an instruction instead of four, with 16
+        // waves sharing the CU's SIMDs).
+        const uint32_t info = __builtin_amdgcn_readlane(c_info, k);
+        const int flags = (info >> 16) & 0xff, shape = (info >> 24) & 3, sub = __builtin_amdgcn_readlane(c_sub, k);
+        const bool intra = (__builtin_amdgcn_readlane(c_kind, k) >> 8) & MBF_INTRA;  // MbInfo::flags is byte 1
         const bool deferred = flags & MVF_DEFERRED;
         uint32_t* cmv = L.mv[k];
-        const uint32_t refw = intra ? 0xffffffffu : L.ref[k];
+        const uint32_t refw = intra ? 0xffffffffu : __builtin_amdgcn_readlane(c_ref, k);
         auto cref = [&](int b8) { return (int)(int8_t)((refw >> (8 * b8)) & 0xff); };
         if (deferred && (flags & (MVF_AVAIL_B | MVF_AVAIL_C | MVF_AVAIL_D))) row_wait(progress, mby, min(mbx + 2, W));
         auto unpack_x = [](uint32_t v) { return (int)(int16_t)(v & 0xffff); };
         auto unpack_y = [](uint32_t v) { return (int)(int16_t)(v >> 16); };
         const bool whole = deferred && ((flags & MVF_PSKIP) || shape == 0);
+        uint32_t whole_mv = 0;  // the macroblock's single vector when `whole`
         if (whole) {
           // One prediction for the macroblock, from neighbours that all lie outside
-          // it: every lane does the same register arithmetic, nothing is serial.
-          auto outside = [&](bool avail, int ref, uint32_t v) -> MvNb {
-            MvNb nb = {-2, 0, 0};
-            if (!avail) return nb;
-            nb.ref = ref < 0 ? -1 : ref;
-            if (ref >= 0) {
-              nb.x = unpack_x(v);
-              nb.y = unpack_y(v);
-            }
-            return nb;
-          };
-          const MvNb A = outside(flags & MVF_AVAIL_A, L.left.ref[0], L.left.mv[0]);
-          const MvNb B = outside(flags & MVF_AVAIL_B, line_up[mbx].ref[0], line_up[mbx].mv[0]);
-          MvNb C = outside(flags & MVF_AVAIL_C, line_up[min(mbx + 1, W - 1)].ref[0], line_up[min(mbx + 1, W - 1)].mv[0]);
-          if (C.ref == -2) C = outside(flags & MVF_AVAIL_D, line_up[max(mbx - 1, 0)].ref[1], line_up[max(mbx - 1, 0)].mv[3]);
-          const int ref = (flags & MVF_PSKIP) ? 0 : cref(0);
-          int mx, my;
-          const int match = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
-          if (match == 1) {
-            const MvNb& P = A.ref == ref ? A : (B.ref == ref ? B : C);
-            mx = P.x;
-            my = P.y;
-          } else if (match == 0 && B.ref == -2 && C.ref == -2 && A.ref != -2) {
-            mx = A.x;
-            my = A.y;
-          } else {
-            mx = med3(A.x, B.x, C.x);
-            my = med3(A.y, B.y, C.y);
+          // it.  The six LDS reads go out together and unconditionally (a value
+          // behind a cleared availability bit is simply not used); the rest is
+          // scalar arithmetic, and the result never passes through LDS.
+          const MvEdge& eb = line_up[mbx];
+          const MvEdge& ec = line_up[min(mbx + 1, W - 1)];
+          const MvEdge& ed = line_up[max(mbx - 1, 0)];
+          const uint32_t vb = eb.mv[0], vc = ec.mv[0], vd = ed.mv[3];
+          const uint32_t wb = *reinterpret_cast<const uint32_t*>(eb.ref), wc = *reinterpret_cast<const uint32_t*>(ec.ref),
+                         wd = *reinterpret_cast<const uint32_t*>(ed.ref);
+          const uint32_t svb = __builtin_amdgcn_readfirstlane(vb), svc = __builtin_amdgcn_readfirstlane(vc),
+                         svd = __builtin_amdgcn_readfirstlane(vd);
+          const int qb = (int)(int8_t)(__builtin_amdgcn_readfirstlane(wb) & 0xff), qc = (int)(int8_t)(__builtin_amdgcn_readfirstlane(wc) & 0xff),
+                    qd = (int)(int8_t)((__builtin_amdgcn_readfirstlane(wd) >> 8) & 0xff);
+          int ra = -2, ax = 0, ay = 0, rb = -2, bx = 0, by = 0, rc = -2, cx = 0, cy = 0;
+          if (flags & MVF_AVAIL_A) {
+            ra = left_ref0 < 0 ? -1 : left_ref0;
+            if (left_ref0 >= 0) { ax = unpack_x(left_mv0); ay = unpack_y(left_mv0); }
           }
-          if (flags & MVF_PSKIP) {
-            if (A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.x == 0 && A.y == 0) || (B.ref == 0 && B.x == 0 && B.y == 0)) mx = my = 0;
+          if (flags & MVF_AVAIL_B) {
+            rb = qb < 0 ? -1 : qb;
+            if (qb >= 0) { bx = unpack_x(svb); by = unpack_y(svb); }
+          }
+          if (flags & MVF_AVAIL_C) {
+            rc = qc < 0 ? -1 : qc;
+            if (qc >= 0) { cx = unpack_x(svc); cy = unpack_y(svc); }
+          } else if (flags & MVF_AVAIL_D) {
+            rc = qd < 0 ? -1 : qd;
+            if (qd >= 0) { cx = unpack_x(svd); cy = unpack_y(svd); }
+          }
+          const bool skip = flags & MVF_PSKIP;
+          const int ref = skip ? 0 : cref(0);
+          int mx, my;
+          const int match = (ra == ref) + (rb == ref) + (rc == ref);
+          if (match == 1) {
+            mx = ra == ref ? ax : (rb == ref ? bx : cx);
+            my = ra == ref ? ay : (rb == ref ? by : cy);
+          } else if (match == 0 && rb == -2 && rc == -2 && ra != -2) {
+            mx = ax;
+            my = ay;
           } else {
-            const uint32_t d = cmv[0];
+            mx = med3(ax, bx, cx);
+            my = med3(ay, by, cy);
+          }
+          if (skip) {
+            if (ra == -2 || rb == -2 || (ra == 0 && ax == 0 && ay == 0) || (rb == 0 && bx == 0 && by == 0)) mx = my = 0;
+          } else {
+            const uint32_t d = __builtin_amdgcn_readlane(c_mv, k * 16);
             mx += unpack_x(d);
             my += unpack_y(d);
           }
-          wave_sync();
-          if (lane < 16) cmv[lane] = (uint32_t)(uint16_t)mx | ((uint32_t)(uint16_t)my << 16);
-        } else if (deferred && lane == 0) {
+          whole_mv = (uint32_t)(uint16_t)mx | ((uint32_t)(uint16_t)my << 16);
+        } else if (deferred) {
+          auto sref = [](const int8_t& r) { return (int)(int8_t)__builtin_amdgcn_readfirstlane((uint32_t)(uint8_t)r); };
           auto fetch = [&](int rx, int ry, int cur_zz) -> MvNb {
             MvNb nb = {-2, 0, 0};
             if (rx > 3 && ry >= 0) return nb;
@@ -813,23 +838,23 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict
             if (rx >= 0 && rx <= 3 && ry >= 0) {
               if (zz_of(rx, ry) >= cur_zz) return nb;
               ref = cref((ry >> 1) * 2 + (rx >> 1));
-              v = cmv[ry * 4 + rx];
+              v = __builtin_amdgcn_readfirstlane(cmv[ry * 4 + rx]);
             } else if (ry >= 0) {  // left neighbour
               if (!(flags & MVF_AVAIL_A)) return nb;
-              ref = L.left.ref[ry >> 1];
-              v = L.left.mv[ry];
+              ref = sref(L.left.ref[ry >> 1]);
+              v = __builtin_amdgcn_readfirstlane(L.left.mv[ry]);
             } else if (rx < 0) {   // top-left
               if (!(flags & MVF_AVAIL_D)) return nb;
-              ref = line_up[mbx - 1].ref[1];
-              v = line_up[mbx - 1].mv[3];
+              ref = sref(line_up[mbx - 1].ref[1]);
+              v = __builtin_amdgcn_readfirstlane(line_up[mbx - 1].mv[3]);
             } else if (rx <= 3) {  // top
               if (!(flags & MVF_AVAIL_B)) return nb;
-              ref = line_up[mbx].ref[rx >> 1];
-              v = line_up[mbx].mv[rx];
+              ref = sref(line_up[mbx].ref[rx >> 1]);
+              v = __builtin_amdgcn_readfirstlane(line_up[mbx].mv[rx]);
             } else {               // top-right
               if (!(flags & MVF_AVAIL_C)) return nb;
-              ref = line_up[mbx + 1].ref[0];
-              v = line_up[mbx + 1].mv[0];
+              ref = sref(line_up[mbx + 1].ref[0]);
+              v = __builtin_amdgcn_readfirstlane(line_up[mbx + 1].mv[0]);
             }
             nb.ref = -1;
             if (ref < 0) return nb;
@@ -886,7 +911,7 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict
                 if (shape == 2) dir = i == 0 ? 3 : 4;
                 int mx, my;
                 predict(bx, by, sw, ref, dir, mx, my);
-                const uint32_t d = cmv[by * 4 + bx];
+                const uint32_t d = __builtin_amdgcn_readfirstlane(cmv[by * 4 + bx]);
                 fill(bx, by, sw, sh, mx + unpack_x(d), my + unpack_y(d));
               }
           }
@@ -898,16 +923,18 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict
         if (k == kMvChunk - 1 || mbx == W - 1)
           asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_info), "+v"(n_kind), "+v"(n_sub));
         // vectors out (deferred macroblocks only), edges on to the neighbours
-        if (deferred && lane < 16) gst32(reinterpret_cast<uint32_t*>(motions[mbi].mv[0]) + lane, cmv[lane]);
+        if (deferred && lane < 16) gst32(reinterpret_cast<uint32_t*>(motions[mbi].mv[0]) + lane, whole ? whole_mv : cmv[lane]);
         if (lane < 4) {
-          line_me[mbx].mv[lane] = cmv[12 + lane];
-          L.left.mv[lane] = cmv[lane * 4 + 3];
+          line_me[mbx].mv[lane] = whole ? whole_mv : cmv[12 + lane];
+          L.left.mv[lane] = whole ? whole_mv : cmv[lane * 4 + 3];
         } else if (lane == 4) {
           line_me[mbx].ref[0] = (int8_t)cref(2);
           line_me[mbx].ref[1] = (int8_t)cref(3);
           L.left.ref[0] = (int8_t)cref(1);
           L.left.ref[1] = (int8_t)cref(3);
         }
+        left_ref0 = cref(1);
+        left_mv0 = whole ? whole_mv : __builtin_amdgcn_readfirstlane(cmv[3]);
         __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         progress[mby + 1] = mbx + 1;
       }
