@@ -146,7 +146,7 @@ def cpu_baseline(path, index, rows, workers):
 # Kernels inside each HIP-event span, and the span's algorithmic bytes per
 # 1080p picture (S = 1.5 * 1920 * 1088).
 _S = 1920 * 1088 * 3 // 2
-SPAN_KERNELS = {"inter_pred": (["k_inter"], 2 * _S), "intra_pred": (["k_residual", "k_intra"], _S),
+SPAN_KERNELS = {"mv_derivation": (["k_mv"], 8160 * 176), "inter_pred": (["k_inter"], 2 * _S), "intra_pred": (["k_residual", "k_intra"], _S),
                 "deblock": (["k_bs", "k_deblock"], 2 * _S), "yuv420_to_rgb24": (["convert_batch"], 9 * WIDTH * HEIGHT // 2)}
 
 

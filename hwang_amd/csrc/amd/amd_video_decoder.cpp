@@ -289,6 +289,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.bytes_inter = d.has_inter ? S * (1 + ((d.slice_type_mask & 2) ? 2 : 1)) : 0;
     sub.bytes_intra = d.has_intra ? S : 0;
     sub.bytes_deblock = d.any_deblock ? 2 * S : 0;
+    sub.bytes_mv = d.mv_deferred ? nmb * (sizeof(MbInfo) + 80 + 64) : 0;  // header + differences/refs in, vectors out
     j.seq = last_seq_ = exec_->submit_picture(lane_, sub);
     if (d.has_inter) surf_[d.slot].motion_seq = j.seq;
     return true;

@@ -18,7 +18,7 @@ namespace amd {
 hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream);
 hipError_t launch_done(uint32_t* flag, uint32_t ticket, hipStream_t stream);
 hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
-                        bool any_deblock, bool any_mv, const uint64_t bytes[3], hipStream_t stream);
+                        bool any_deblock, bool any_mv, const uint64_t bytes[4], hipStream_t stream);
 
 namespace {
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
@@ -399,7 +399,7 @@ void GpuExecutor::run(int engine) {
     if (!pics.empty()) {
       int max_mbs = 0;
       bool any_inter = false, any_intra = false, any_deblock = false, any_mv = false;
-      uint64_t bytes[3] = {0, 0, 0};
+      uint64_t bytes[4] = {0, 0, 0, 0};
       for (size_t i = 0; i < pics.size(); ++i) {
         const PicSubmit& p = pics[i];
         JobDesc& jd = en.job_table_host[slot][i];
@@ -418,6 +418,7 @@ void GpuExecutor::run(int engine) {
         bytes[0] += p.bytes_inter;
         bytes[1] += p.bytes_intra;
         bytes[2] += p.bytes_deblock;
+        bytes[3] += p.bytes_mv;
       }
       e = hipMemcpyAsync(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(),
                          hipMemcpyHostToDevice, en.copy_stream);

@@ -65,7 +65,7 @@ struct PicSubmit {
   int ncopies = 0;
   int num_mbs = 0;
   int heavy = 0;  // engine: 1 for intra-only pictures
-  uint64_t bytes_inter = 0, bytes_intra = 0, bytes_deblock = 0;  // algorithmic, for the roofline
+  uint64_t bytes_inter = 0, bytes_intra = 0, bytes_deblock = 0, bytes_mv = 0;  // algorithmic, for the roofline
 };
 
 struct ConvSubmit {

@@ -1750,12 +1750,16 @@ hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream) {
 // `max_mbs` the largest macroblock count among them.
 // ===========================================================================
 hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
-                        bool any_deblock, bool any_mv, const uint64_t bytes[3], hipStream_t stream) {
+                        bool any_deblock, bool any_mv, const uint64_t bytes[4], hipStream_t stream) {
   const bool profiled = prof::enabled();
   prof::Span span;
+  if (any_mv) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_mv, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
+    if (profiled) prof::end(span, stream, prof::K_MV, bytes[3]);
+  }
   if (any_inter) {
     if (profiled) span = prof::begin(stream);
-    if (any_mv) hipLaunchKernelGGL(k_mv, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
     hipLaunchKernelGGL(k_inter, dim3(((max_mbs + kInterWaves - 1) / kInterWaves + 7) / 8 * 8, njobs), dim3(kInterWaves * 64), 0,
                        stream, jobs);
     if (profiled) prof::end(span, stream, prof::K_INTER, bytes[0]);

@@ -14,7 +14,8 @@ enum KernelId {
   K_INTRA = 2,      // intra prediction wavefront + residual add
   K_DEBLOCK = 3,    // in-loop deblocking wavefront
   K_RGB = 4,        // I420 -> RGB24
-  K_COUNT = 5,
+  K_MV = 5,         // motion-vector derivation of P macroblocks
+  K_COUNT = 6,
 };
 
 bool enabled();

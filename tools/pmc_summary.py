@@ -26,7 +26,7 @@ def load(d, counter):
                 continue
             name = r["Kernel_Name"].split("(")[0].split("::")[-1]
             gx, gy, gz, wx = dims.get(r["Dispatch_Id"], (int(r["Grid_Size"]), 1, 1, max(1, int(r["Workgroup_Size"]))))
-            if name in ("k_intra", "k_deblock"):
+            if name in ("k_intra", "k_deblock", "k_mv"):
                 pics = gx // wx
             elif name == "convert_batch":
                 pics = gz
