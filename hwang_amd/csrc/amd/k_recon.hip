@@ -582,7 +582,10 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
 // ===========================================================================
 namespace {
 
-constexpr int kRowWaves = 16;
+#ifndef HW_ROW_WAVES
+#define HW_ROW_WAVES 16
+#endif
+constexpr int kRowWaves = HW_ROW_WAVES;
 constexpr int kMaxRows = 512;
 constexpr int kLineMbs = 128;  // width (macroblocks) the LDS line buffers of k_mv / k_intra cover
 
