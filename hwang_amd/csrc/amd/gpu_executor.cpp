@@ -17,7 +17,7 @@ namespace amd {
 
 hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream);
 hipError_t launch_done(uint32_t* flag, uint32_t ticket, hipStream_t stream);
-hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
+hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_inter, bool any_intra,
                         bool any_deblock, bool any_mv, const uint64_t bytes[4], hipStream_t stream);
 
 namespace {
@@ -397,7 +397,7 @@ void GpuExecutor::run(int engine) {
     }
     hipError_t e = hipSuccess;
     if (!pics.empty()) {
-      int max_mbs = 0;
+      int max_mbs = 0, max_rows = 0;
       bool any_inter = false, any_intra = false, any_deblock = false, any_mv = false;
       uint64_t bytes[4] = {0, 0, 0, 0};
       for (size_t i = 0; i < pics.size(); ++i) {
@@ -405,12 +405,14 @@ void GpuExecutor::run(int engine) {
         JobDesc& jd = en.job_table_host[slot][i];
         jd = p.desc;
         jd.num_uploads = p.ncopies;
+        jd.pad = 0;
         for (int c = 0; c < p.ncopies; ++c) {
           jd.uploads[c].dst = p.copies[c].dst;
           jd.uploads[c].src = p.copies[c].src;
           jd.uploads[c].bytes = p.copies[c].bytes;
         }
         max_mbs = p.num_mbs > max_mbs ? p.num_mbs : max_mbs;
+        max_rows = p.desc.pp.mb_height > max_rows ? p.desc.pp.mb_height : max_rows;
         any_inter |= p.desc.do_inter != 0;
         any_intra |= p.desc.do_intra != 0;
         any_deblock |= p.desc.do_deblock != 0;
@@ -428,7 +430,7 @@ void GpuExecutor::run(int engine) {
         if (e == hipSuccess) e = hipStreamWaitEvent(en.stream, en.copied[slot], 0);
       }
       if (e == hipSuccess)
-        e = launch_batch(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, any_inter, any_intra,
+        e = launch_batch(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, max_rows, any_inter, any_intra,
                          any_deblock, any_mv, bytes, en.stream);
     }
     if (!convs.empty() && e == hipSuccess) {

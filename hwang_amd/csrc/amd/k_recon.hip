@@ -690,6 +690,32 @@ struct MvNb {
   int x, y;
 };
 constexpr int kMvChunk = 4;  // macroblocks whose records travel together (prefetch distance)
+// A picture's rows are spread over workgroups ("bands") of kMvWaves rows, one
+// wave per row.  Inside a band rows hand on through LDS; the last row of a
+// band exports its line to MvCtl in global memory and the first row of the
+// next band imports it.  Measured on the skeleton
+// (tools/experiments/rowpipe_bands.hip): a picture takes ~mb_width + 2 *
+// mb_height steps instead of ~mb_width * mb_height / 16, and a step is as fast
+// as a lone wave's because at most one wave sits on each SIMD.
+//
+// Hand-off words carry their own validity: every 32-bit datum travels as a
+// 64-bit store {datum, JobDesc::mv_epoch}, which is single-copy atomic, so the
+// producer neither waits for its stores nor maintains a counter, and the
+// consumer needs one round trip, not two (the scheme of low-latency collective
+// protocols).  Nothing is cleared between pictures: a slot left over from an
+// earlier picture carries an earlier epoch.
+constexpr int kMvWaves = 4;
+struct MvCtl {
+  uint64_t line[1][kLineMbs][5];  // [band][mbx]: MvEdge as five tagged words (really [bands of the picture])
+};
+// Agent-scope accesses (sc1 on gfx950): they bypass the per-XCD L2, so it does
+// not matter which XCDs the bands of a picture land on.
+__device__ __forceinline__ uint64_t agent_ld64(const uint64_t* p) {
+  return __hip_atomic_load((const HW_AS1 uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_st64(uint64_t* p, uint64_t v) {
+  __hip_atomic_store((HW_AS1 uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 struct MvWaveLds {
   uint32_t mv[kMvChunk][16];  // differences in, vectors out
   uint32_t ref[kMvChunk];     // ref_idx[0][0..3]
@@ -705,25 +731,65 @@ __device__ __forceinline__ int med3(int a, int b, int c) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict__ jobs) {
-  const JobDesc& job = jobs[blockIdx.x];
+__global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs, int njobs) {
+  // Bands are handed out by ticket, band-major: whoever holds band b of a
+  // picture started after the holder of band b - 1, so a poll below never waits
+  // for a workgroup that is not running yet - whatever order the dispatcher
+  // uses.  The counter is jobs[0].pad, zeroed by the host with the table.
+  __shared__ unsigned s_ticket;
+  __shared__ int s_progress[kMvWaves + 1];
+  __shared__ MvWaveLds s_lds[kMvWaves];
+  __shared__ MvEdge s_line[kMvWaves + 1][kLineMbs];  // [kMvWaves]: the line imported from the band above
+  if (threadIdx.x == 0) s_ticket = atomicAdd(reinterpret_cast<unsigned*>(&jobs[0].pad), 1u);
+  if (threadIdx.x <= kMvWaves) s_progress[threadIdx.x] = 0;
+  __syncthreads();
+  const int band = static_cast<int>(s_ticket) / njobs;
+  const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
   if (!job.do_mv) return;
   const PictureParams& pp = job.pp;
   const MbInfo* __restrict__ mbs = job.mbs;
   MbMotion* __restrict__ motions = const_cast<MbMotion*>(job.motions);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __shared__ int s_progress[kMaxRows + 1];
-  __shared__ MvWaveLds s_lds[kRowWaves];
-  __shared__ MvEdge s_line[kRowWaves][kLineMbs];
+  const int mby = band * kMvWaves + wave;
+  if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
   lds_counter* progress = (lds_counter*)s_progress;
-  for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
-  __syncthreads();
   MvWaveLds& L = s_lds[wave];
-  const MvEdge* line_up = s_line[(wave + kRowWaves - 1) % kRowWaves];
+  const MvEdge* line_up = wave == 0 ? s_line[kMvWaves] : s_line[wave - 1];
   MvEdge* line_me = s_line[wave];
   const int W = pp.mb_width;
+  MvCtl* ctl = static_cast<MvCtl*>(job.mv_ctl);
+  const uint32_t epoch = static_cast<uint32_t>(job.mv_epoch);
+  const bool importing = wave == 0 && band > 0;
+  const bool exporting = wave == kMvWaves - 1 && mby + 1 < pp.mb_height;
+  int seen = 0;  // macroblocks of the row above whose edges are in s_line[kMvWaves]
+  // First row of a band: fetch the next eight entries of the band above (lane ->
+  // entry lane >> 3, word lane & 7), keep the complete ones in front of the first
+  // missing word - in LDS, where the code below finds them like any other row's
+  // - and repeat until `need` macroblocks are there.  Whatever else has arrived
+  // comes along, so a consumer that has fallen behind catches up in one round
+  // trip.  A poll that never succeeds (cannot happen by construction) ends in
+  // wrong vectors, not in a hung GPU.
+  auto import_until = [&](int need) {
+    if (seen >= need) return;
+    const uint64_t* src = &ctl->line[0][0][0] + static_cast<size_t>(band - 1) * kLineMbs * 5;
+    for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
+      const int e = seen + (lane >> 3), d = lane & 7;
+      const bool act = d < 5 && e < W;
+      uint64_t v = 0;
+      if (act) v = agent_ld64(src + e * 5 + d);
+      const uint64_t missing = __ballot(act && static_cast<uint32_t>(v >> 32) != epoch);
+      const int nvalid = min(missing ? __builtin_ctzll(missing) >> 3 : 8, W - seen);
+      if (act && (lane >> 3) < nvalid) reinterpret_cast<uint32_t*>(&s_line[kMvWaves][e])[d] = static_cast<uint32_t>(v);
+      seen += nvalid;
+      if (seen < need) __builtin_amdgcn_s_sleep(1);
+    }
+    if (seen < need) seen = need;
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_sync();
+  };
+  if (wave == 0 && band == 0 && lane == 0) s_progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
 
-  for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
+  {
     // Records travel kMvChunk macroblocks at a time, one chunk ahead: a single
     // macroblock of lead is less than the memory latency once the per-macroblock
     // work is down to a fraction of a microsecond.  lane -> (macroblock lane >> 4,
@@ -773,7 +839,10 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict
         uint32_t* cmv = L.mv[k];
         const uint32_t refw = intra ? 0xffffffffu : __builtin_amdgcn_readlane(c_ref, k);
         auto cref = [&](int b8) { return (int)(int8_t)((refw >> (8 * b8)) & 0xff); };
-        if (deferred && (flags & (MVF_AVAIL_B | MVF_AVAIL_C | MVF_AVAIL_D))) row_wait(progress, mby, min(mbx + 2, W));
+        if (deferred && (flags & (MVF_AVAIL_B | MVF_AVAIL_C | MVF_AVAIL_D))) {
+          if (importing) import_until(min(mbx + 2, W));
+          else row_wait(progress, wave, min(mbx + 2, W));
+        }
         auto unpack_x = [](uint32_t v) { return (int)(int16_t)(v & 0xffff); };
         auto unpack_y = [](uint32_t v) { return (int)(int16_t)(v >> 16); };
         const bool whole = deferred && ((flags & MVF_PSKIP) || shape == 0);
@@ -938,8 +1007,16 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_mv(const JobDesc* __restrict
         }
         left_ref0 = cref(1);
         left_mv0 = whole ? whole_mv : __builtin_amdgcn_readfirstlane(cmv[3]);
-        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        progress[mby + 1] = mbx + 1;
+        if (exporting) {
+          // the band below reads this row's edges from global memory
+          uint64_t* dst = &ctl->line[0][0][0] + (static_cast<size_t>(band) * kLineMbs + mbx) * 5;
+          const uint32_t refs = static_cast<uint32_t>(static_cast<uint8_t>(cref(2))) | (static_cast<uint32_t>(static_cast<uint8_t>(cref(3))) << 8);
+          if (lane < 5) agent_st64(dst + lane, (static_cast<uint64_t>(epoch) << 32) | (lane < 4 ? (whole ? whole_mv : cmv[12 + (lane & 3)]) : refs));
+          __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+          __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          progress[wave + 1] = mbx + 1;
+        }
       }
       wave_sync();  // the chunk buffer is rewritten at the top of the next round
     }
@@ -1752,13 +1829,14 @@ hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream) {
 // launch helpers (host).  `jobs` is a device array of `njobs` descriptors;
 // `max_mbs` the largest macroblock count among them.
 // ===========================================================================
-hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_inter, bool any_intra,
+hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_inter, bool any_intra,
                         bool any_deblock, bool any_mv, const uint64_t bytes[4], hipStream_t stream) {
   const bool profiled = prof::enabled();
   prof::Span span;
   if (any_mv) {
     if (profiled) span = prof::begin(stream);
-    hipLaunchKernelGGL(k_mv, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
+    hipLaunchKernelGGL(k_mv, dim3(njobs * ((max_rows + kMvWaves - 1) / kMvWaves)), dim3(kMvWaves * 64), 0, stream,
+                       const_cast<JobDesc*>(jobs), njobs);
     if (profiled) prof::end(span, stream, prof::K_MV, bytes[3]);
   }
   if (any_inter) {
@@ -1784,6 +1862,7 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, bool any_in
 }
 
 size_t deblock_scratch_bytes(int num_mbs) { return (size_t)num_mbs * sizeof(DbInfo); }
+size_t mv_ctl_bytes(int mb_height) { return (size_t)((mb_height + kMvWaves - 1) / kMvWaves) * kLineMbs * 5 * sizeof(uint64_t); }
 
 }  // namespace amd
 }  // namespace hwang
