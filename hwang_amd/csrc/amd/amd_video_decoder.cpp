@@ -41,7 +41,7 @@ namespace hwang {
 
 namespace amd {
 size_t deblock_scratch_bytes(int num_mbs);
-size_t mv_ctl_bytes(int mb_height);
+size_t band_ctl_bytes(int mb_height);
 }  // namespace amd
 
 namespace {
@@ -280,9 +280,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.slices = j.slice_dev;
     sub.desc.db = j.db_dev;
     sub.desc.resid = j.resid_dev;
-    sub.desc.mv_ctl = j.mv_ctl_dev;
-    if (++mv_epoch_ == 0) ++mv_epoch_;
-    sub.desc.mv_epoch = mv_epoch_;
+    sub.desc.band_ctl = j.band_ctl_dev;
+    if (++epoch_ == 0) ++epoch_;
+    sub.desc.epoch = epoch_;
     sub.desc.do_inter = d.has_inter;
     sub.desc.do_intra = d.has_intra;
     sub.desc.do_deblock = d.any_deblock;
@@ -331,7 +331,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     SliceParams* slice_dev = nullptr;
     void* db_dev = nullptr;  // k_bs -> k_deblock records
     int16_t* resid_dev = nullptr;  // k_residual -> k_intra
-    void* mv_ctl_dev = nullptr;    // k_mv: hand-off between a picture's workgroups
+    void* band_ctl_dev = nullptr;    // k_mv, k_deblock: hand-off between a picture's workgroups
     uint64_t seq = 0;  // submission that still reads the staging buffers
   };
   struct Bounce {
@@ -401,8 +401,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
           hipMalloc(reinterpret_cast<void**>(&j.slice_dev), kMaxSlices * sizeof(SliceParams)) != hipSuccess ||
           hipMalloc(&j.db_dev, amd::deblock_scratch_bytes(static_cast<int>(nmb))) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.resid_dev), nmb * 384 * sizeof(int16_t)) != hipSuccess ||
-          hipMalloc(&j.mv_ctl_dev, amd::mv_ctl_bytes(mbh_)) != hipSuccess ||
-          hipMemset(j.mv_ctl_dev, 0, amd::mv_ctl_bytes(mbh_)) != hipSuccess) {
+          hipMalloc(&j.band_ctl_dev, amd::band_ctl_bytes(mbh_)) != hipSuccess ||
+          hipMemset(j.band_ctl_dev, 0, amd::band_ctl_bytes(mbh_)) != hipSuccess) {
         *error = "AMDVideoDecoder: out of memory for staging buffers";
         return false;
       }
@@ -450,7 +450,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       if (j.slice_dev) (void)hipFree(j.slice_dev);
       if (j.db_dev) (void)hipFree(j.db_dev);
       if (j.resid_dev) (void)hipFree(j.resid_dev);
-      if (j.mv_ctl_dev) (void)hipFree(j.mv_ctl_dev);
+      if (j.band_ctl_dev) (void)hipFree(j.band_ctl_dev);
       j = Job();
     }
     for (SurfaceSlot& s : surf_) {
@@ -573,7 +573,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   amd::GpuExecutor* exec_ = nullptr;
   int lane_ = -1;
   uint64_t last_seq_ = 0;
-  uint32_t mv_epoch_ = 0;  // per submitted picture, see JobDesc::mv_epoch
+  uint32_t epoch_ = 0;  // per submitted picture, see JobDesc::epoch
   FrameInfo info_{};
   std::unique_ptr<h264::Parser> parser_;
   std::string sink_error_;

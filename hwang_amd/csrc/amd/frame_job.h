@@ -150,10 +150,10 @@ struct JobDesc {
   int32_t do_inter, do_intra, do_deblock;
   int32_t do_mv;       // some macroblocks carry MVF_DEFERRED
   int32_t num_uploads;
-  int32_t pad;         // jobs[0].pad: k_mv's band ticket counter (zeroed by the host with every table)
-  void* mv_ctl;        // k_mv: hand-off between the workgroups of one picture (amd::mv_ctl_bytes)
-  uint32_t mv_epoch;   // tags this picture's words in mv_ctl (nothing is cleared between pictures); never 0
-  int32_t pad2;
+  uint32_t ticket_mv;  // jobs[0] only: band ticket counters of k_mv / k_deblock (zeroed by the host with every table)
+  void* band_ctl;      // hand-off between the workgroups of one picture (amd::band_ctl_bytes)
+  uint32_t epoch;      // tags this picture's words in band_ctl (nothing is cleared between pictures); never 0
+  uint32_t ticket_db;
   UploadDesc uploads[kJobUploads];
 };
 

@@ -587,6 +587,16 @@ namespace {
 #endif
 constexpr int kRowWaves = HW_ROW_WAVES;
 constexpr int kMaxRows = 512;
+// Row pipelines whose pictures are spread over several workgroups ("bands" of
+// kBandWaves rows, one wave per row; k_mv explains why).  BandCtl is the
+// per-picture hand-off area in global memory (JobDesc::band_ctl); every word in
+// it is tagged with JobDesc::epoch, nothing is cleared between pictures.
+constexpr int kBandWaves = 4;
+constexpr int kMaxBands = kMaxRows / kBandWaves;
+struct BandCtl {
+  uint64_t db_prog[kMaxBands];   // k_deblock: epoch << 32 | macroblocks of the band's last row that are final
+  uint64_t mv_line[1][128][5];   // k_mv: [band][mbx] MvEdge as five tagged words (really [bands of the picture])
+};
 constexpr int kLineMbs = 128;  // width (macroblocks) the LDS line buffers of k_mv / k_intra cover
 
 // The counters live in LDS and must be addressed as such: through a generic
@@ -704,14 +714,17 @@ constexpr int kMvChunk = 4;  // macroblocks whose records travel together (prefe
 // consumer needs one round trip, not two (the scheme of low-latency collective
 // protocols).  Nothing is cleared between pictures: a slot left over from an
 // earlier picture carries an earlier epoch.
-constexpr int kMvWaves = 4;
-struct MvCtl {
-  uint64_t line[1][kLineMbs][5];  // [band][mbx]: MvEdge as five tagged words (really [bands of the picture])
-};
+constexpr int kMvWaves = kBandWaves;
 // Agent-scope accesses (sc1 on gfx950): they bypass the per-XCD L2, so it does
 // not matter which XCDs the bands of a picture land on.
 __device__ __forceinline__ uint64_t agent_ld64(const uint64_t* p) {
   return __hip_atomic_load((const HW_AS1 uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t agent_ld32(const void* p) {
+  return __hip_atomic_load((const HW_AS1 uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_st32(void* p, uint32_t v) {
+  __hip_atomic_store((HW_AS1 uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void agent_st64(uint64_t* p, uint64_t v) {
   __hip_atomic_store((HW_AS1 uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -735,12 +748,12 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
   // Bands are handed out by ticket, band-major: whoever holds band b of a
   // picture started after the holder of band b - 1, so a poll below never waits
   // for a workgroup that is not running yet - whatever order the dispatcher
-  // uses.  The counter is jobs[0].pad, zeroed by the host with the table.
+  // uses.  The counter is jobs[0].ticket_mv, zeroed by the host with the table.
   __shared__ unsigned s_ticket;
   __shared__ int s_progress[kMvWaves + 1];
   __shared__ MvWaveLds s_lds[kMvWaves];
   __shared__ MvEdge s_line[kMvWaves + 1][kLineMbs];  // [kMvWaves]: the line imported from the band above
-  if (threadIdx.x == 0) s_ticket = atomicAdd(reinterpret_cast<unsigned*>(&jobs[0].pad), 1u);
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_mv, 1u);
   if (threadIdx.x <= kMvWaves) s_progress[threadIdx.x] = 0;
   __syncthreads();
   const int band = static_cast<int>(s_ticket) / njobs;
@@ -757,8 +770,8 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
   const MvEdge* line_up = wave == 0 ? s_line[kMvWaves] : s_line[wave - 1];
   MvEdge* line_me = s_line[wave];
   const int W = pp.mb_width;
-  MvCtl* ctl = static_cast<MvCtl*>(job.mv_ctl);
-  const uint32_t epoch = static_cast<uint32_t>(job.mv_epoch);
+  BandCtl* ctl = static_cast<BandCtl*>(job.band_ctl);
+  const uint32_t epoch = job.epoch;
   const bool importing = wave == 0 && band > 0;
   const bool exporting = wave == kMvWaves - 1 && mby + 1 < pp.mb_height;
   int seen = 0;  // macroblocks of the row above whose edges are in s_line[kMvWaves]
@@ -771,7 +784,7 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
   // wrong vectors, not in a hung GPU.
   auto import_until = [&](int need) {
     if (seen >= need) return;
-    const uint64_t* src = &ctl->line[0][0][0] + static_cast<size_t>(band - 1) * kLineMbs * 5;
+    const uint64_t* src = &ctl->mv_line[0][0][0] + static_cast<size_t>(band - 1) * kLineMbs * 5;
     for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
       const int e = seen + (lane >> 3), d = lane & 7;
       const bool act = d < 5 && e < W;
@@ -1009,7 +1022,7 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
         left_mv0 = whole ? whole_mv : __builtin_amdgcn_readfirstlane(cmv[3]);
         if (exporting) {
           // the band below reads this row's edges from global memory
-          uint64_t* dst = &ctl->line[0][0][0] + (static_cast<size_t>(band) * kLineMbs + mbx) * 5;
+          uint64_t* dst = &ctl->mv_line[0][0][0] + (static_cast<size_t>(band) * kLineMbs + mbx) * 5;
           const uint32_t refs = static_cast<uint32_t>(static_cast<uint8_t>(cref(2))) | (static_cast<uint32_t>(static_cast<uint8_t>(cref(3))) << 8);
           if (lane < 5) agent_st64(dst + lane, (static_cast<uint64_t>(epoch) << 32) | (lane < 4 ? (whole ? whole_mv : cmv[12 + (lane & 3)]) : refs));
           __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1608,28 +1621,53 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
 // macroblock's own samples and its DbInfo are prefetched one iteration ahead
 // and its stores are drained one iteration late.
 // ===========================================================================
-__global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __restrict__ jobs) {
-  const JobDesc& job = jobs[blockIdx.x];
+__global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict__ jobs, int njobs) {
+  // One workgroup per band of kBandWaves rows, bands handed out by ticket (see
+  // k_mv).  Rows hand over through the picture itself: inside a band the waves
+  // share the CU's L1 and an LDS counter; across bands the last row of a band
+  // writes its bottom rows with agent-scope stores and publishes its counter in
+  // BandCtl::db_prog once they have landed, and the first row of the next band
+  // polls that counter and reads the rows above with agent-scope loads.
+  __shared__ unsigned s_ticket;
+  __shared__ int s_progress[kBandWaves + 1];
+  __shared__ DeblockWaveLds s_lds[kBandWaves];
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_db, 1u);
+  if (threadIdx.x <= kBandWaves) s_progress[threadIdx.x] = 0;
+  __syncthreads();
+  const int band = static_cast<int>(s_ticket) / njobs;
+  const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
   if (!job.do_deblock) return;
   const PictureParams& pp = job.pp;
   const DbInfo* __restrict__ dbs = static_cast<const DbInfo*>(job.db);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __shared__ int s_progress[kMaxRows + 1];
-  __shared__ DeblockWaveLds s_lds[kRowWaves];
+  const int mby = band * kBandWaves + wave;
+  if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
   lds_counter* progress = (lds_counter*)s_progress;
-  for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
-  __syncthreads();
   DeblockWaveLds& L = s_lds[wave];
   uint8_t* lt = L.lt;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const int W = pp.mb_width;
+  BandCtl* ctl = static_cast<BandCtl*>(job.band_ctl);
+  const uint64_t epoch = static_cast<uint64_t>(job.epoch) << 32;
+  const bool importing = wave == 0 && band > 0;
+  const bool exporting = wave == kBandWaves - 1 && mby + 1 < pp.mb_height;
+  if (wave == 0 && band == 0 && lane == 0) s_progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
+  int seen = 0;  // importing: macroblocks of the row above known to be final
+  auto import_wait = [&](int need) {
+    for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
+      const uint64_t v = agent_ld64(&ctl->db_prog[band - 1]);
+      if ((v & 0xffffffff00000000ull) == epoch) seen = static_cast<int>(static_cast<uint32_t>(v));
+      if (seen < need) __builtin_amdgcn_s_sleep(2);
+    }
+    __asm__ volatile("" ::: "memory");  // a poll that never succeeds (impossible by construction) ends in wrong samples, not in a hang
+  };
 
   // lane roles for the dword tile traffic
   const int lr = lane >> 2, lc4 = lane & 3;                      // luma interior: row, dword
   const int cpn = (lane >> 4) & 1, ccr = (lane >> 1) & 7, ccc = lane & 1;  // chroma interior (lanes 0..31)
 
-  for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
+  {
     uint8_t* rowy = cur.y + (size_t)(mby * 16) * yp;
     uint8_t* rowu = cur.u + (size_t)(mby * 8) * cp;
     uint8_t* rowv = cur.v + (size_t)(mby * 8) * cp;
@@ -1698,11 +1736,18 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
         // ---- rows above: wait for the row above to be two macroblocks ahead
         uint32_t top_word = 0;
         if (top_edge) {
-          row_wait(progress, mby, min(mbx + 2, W));
-          if (lane < 16) top_word = gld32(gy + ((lane >> 2) - 4) * yp + (lane & 3) * 4);
+          const uint8_t* src = nullptr;
+          if (lane < 16) src = gy + ((lane >> 2) - 4) * yp + (lane & 3) * 4;
           else if (lane < 24) {
             const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
-            top_word = gld32((p ? gv : gu) + (cr - 2) * cp + cc * 4);
+            src = (p ? gv : gu) + (cr - 2) * cp + cc * 4;
+          }
+          if (importing) {
+            import_wait(min(mbx + 2, W));
+            if (lane < 24) top_word = agent_ld32(src);
+          } else {
+            row_wait(progress, wave, min(mbx + 2, W));
+            if (lane < 24) top_word = gld32(src);
           }
         }
         // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each
@@ -1750,7 +1795,8 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
         // iteration to land: make sure, then everything before this macroblock
         // is final (skipped ones included)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        progress[mby + 1] = mbx;
+        if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch | static_cast<uint32_t>(mbx)); }
+        else progress[wave + 1] = mbx;
         // The prefetched registers are complete too; saying so here keeps the
         // compiler from waiting for them at the top of the next iteration, where
         // its in-order counter would also cover the stores issued just below.
@@ -1761,19 +1807,27 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_deblock(const JobDesc* __res
         // to other macroblocks' edges and is never written from here.
         for (int t = lane; t < 100; t += 64) {
           const int r = t / 5, c4 = t % 5;
-          if (r >= 4 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1))
-            gst32(gy + (r - 4) * yp + (c4 - 1) * 4, *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]));
+          if (r >= 4 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1)) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]);
+            if (exporting && r >= 16) agent_st32(gy + (r - 4) * yp + (c4 - 1) * 4, v);  // the band below reads these rows
+            else gst32(gy + (r - 4) * yp + (c4 - 1) * 4, v);
+          }
         }
         if (lane < 60) {
           const int p = lane / 30, t = lane % 30, r = t / 3, c4 = t % 3;
           uint8_t* g = p ? gv : gu;
-          if (r >= 2 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1))
-            gst32(g + (r - 2) * cp + (c4 - 1) * 4, *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]));
+          if (r >= 2 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1)) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]);
+            if (exporting && r >= 8) agent_st32(g + (r - 2) * cp + (c4 - 1) * 4, v);
+            else gst32(g + (r - 2) * cp + (c4 - 1) * 4, v);
+          }
         }
         tile_mbx = mbx;
       }
     }
-    row_publish(progress, mby, W);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have landed
+    if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch | static_cast<uint32_t>(W)); }
+    else progress[wave + 1] = W;
   }
 }
 
@@ -1855,14 +1909,17 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_row
   if (any_deblock) {
     if (profiled) span = prof::begin(stream);
     hipLaunchKernelGGL(k_bs, dim3((max_mbs + 7) / 8, njobs), dim3(256), 0, stream, jobs);
-    hipLaunchKernelGGL(k_deblock, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
+    hipLaunchKernelGGL(k_deblock, dim3(njobs * ((max_rows + kBandWaves - 1) / kBandWaves)), dim3(kBandWaves * 64), 0, stream,
+                       const_cast<JobDesc*>(jobs), njobs);
     if (profiled) prof::end(span, stream, prof::K_DEBLOCK, bytes[2]);
   }
   return hipGetLastError();
 }
 
 size_t deblock_scratch_bytes(int num_mbs) { return (size_t)num_mbs * sizeof(DbInfo); }
-size_t mv_ctl_bytes(int mb_height) { return (size_t)((mb_height + kMvWaves - 1) / kMvWaves) * kLineMbs * 5 * sizeof(uint64_t); }
+size_t band_ctl_bytes(int mb_height) {
+  return offsetof(BandCtl, mv_line) + (size_t)((mb_height + kBandWaves - 1) / kBandWaves) * kLineMbs * 5 * sizeof(uint64_t);
+}
 
 }  // namespace amd
 }  // namespace hwang
