@@ -150,10 +150,12 @@ struct JobDesc {
   int32_t do_inter, do_intra, do_deblock;
   int32_t do_mv;       // some macroblocks carry MVF_DEFERRED
   int32_t num_uploads;
-  uint32_t ticket_mv;  // jobs[0] only: band ticket counters of k_mv / k_deblock (zeroed by the host with every table)
+  uint32_t ticket_mv;  // jobs[0] only: band ticket counters of k_mv / k_deblock / k_intra (zeroed by the host with every table)
   void* band_ctl;      // hand-off between the workgroups of one picture (amd::band_ctl_bytes)
   uint32_t epoch;      // tags this picture's words in band_ctl (nothing is cleared between pictures); never 0
   uint32_t ticket_db;
+  uint32_t ticket_in;
+  uint32_t pad;
   UploadDesc uploads[kJobUploads];
 };
 

@@ -405,7 +405,7 @@ void GpuExecutor::run(int engine) {
         JobDesc& jd = en.job_table_host[slot][i];
         jd = p.desc;
         jd.num_uploads = p.ncopies;
-        jd.ticket_mv = jd.ticket_db = 0;
+        jd.ticket_mv = jd.ticket_db = jd.ticket_in = 0;
         for (int c = 0; c < p.ncopies; ++c) {
           jd.uploads[c].dst = p.copies[c].dst;
           jd.uploads[c].src = p.copies[c].src;

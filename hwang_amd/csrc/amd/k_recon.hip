@@ -562,30 +562,32 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
 }
 
 // ===========================================================================
-// Row pipelines (k_intra, k_deblock).
+// Row pipelines (k_mv, k_intra, k_deblock).
 //
-// Intra prediction and the deblocking filter have true raster-order
-// dependencies: a macroblock needs its left, top-left, top and top-right
-// neighbours finished.  Rows can run concurrently as long as each stays two
-// macroblocks behind the row above.  Each picture is handled by ONE workgroup
-// of 16 waves; wave w walks rows w, w+16, w+32, ... one macroblock at a time
-// (64 lanes = one macroblock), and rows hand their progress to the row below
-// through counters in LDS.  Consequences:
-//   * no inter-workgroup protocol at all: visibility between waves of one
-//     workgroup needs only workgroup-scope fences (all waves share the CU's
-//     L1), never an agent-scope release/acquire or a cross-CU poll;
-//   * all 16 waves are resident by construction, so the waits cannot
-//     deadlock; a wave only ever waits on a row that started earlier;
-//   * one picture occupies one CU, so up to 256 pictures (lanes) reconstruct
-//     concurrently per GPU -- the parallelism of sparse decoding is across
-//     keyframe-anchored intervals, not inside one picture.
+// Motion-vector prediction, intra prediction and the deblocking filter have
+// true raster-order dependencies: a macroblock needs its left, top-left, top
+// and top-right neighbours finished.  Rows can run concurrently as long as
+// each stays two macroblocks behind the row above, so a picture takes about
+// mb_width + 2 * mb_height steps if every row has a wave of its own.  A step
+// is bound by the dependent chain inside one macroblock (measured
+// 1.3 - 2.7 us for a lone wave), and several waves on one SIMD only stretch
+// it, so a picture is cut into bands of kBandWaves = 4 rows, one workgroup of
+// four waves (one per SIMD) per band:
+//   * inside a band rows hand over through LDS: counters (row_wait) and, where
+//     the neighbours are small, the data itself (line buffers);
+//   * between bands the hand-off goes through global memory with agent-scope
+//     (sc1) accesses, which bypass the per-XCD L2 - either words that carry
+//     their own validity tag (k_mv, k_intra's LDS-neighbour path) or the
+//     picture's own samples plus a counter raised once they have landed
+//     (k_deblock, k_intra's surface path);
+//   * bands are handed out by an atomic ticket, band-major over the pictures
+//     of a batch, so a workgroup only ever waits for one that started before
+//     it: no deadlock whatever the dispatch order, and every poll is bounded
+//     anyway (a logic error would show as wrong samples in the parity tests,
+//     not as a hung GPU).
 // ===========================================================================
 namespace {
 
-#ifndef HW_ROW_WAVES
-#define HW_ROW_WAVES 16
-#endif
-constexpr int kRowWaves = HW_ROW_WAVES;
 constexpr int kMaxRows = 512;
 // Row pipelines whose pictures are spread over several workgroups ("bands" of
 // kBandWaves rows, one wave per row; k_mv explains why).  BandCtl is the
@@ -595,8 +597,14 @@ constexpr int kBandWaves = 4;
 constexpr int kMaxBands = kMaxRows / kBandWaves;
 struct BandCtl {
   uint64_t db_prog[kMaxBands];   // k_deblock: epoch << 32 | macroblocks of the band's last row that are final
-  uint64_t mv_line[1][128][5];   // k_mv: [band][mbx] MvEdge as five tagged words (really [bands of the picture])
+  uint64_t in_prog[kMaxBands];   // k_intra (neighbours read from the surface): likewise
+  // tagged words {datum, epoch}; with B = bands of the picture:
+  //   [0, B * 128 * 5)               k_mv: [band][mbx] MvEdge as five words
+  //   [B * 128 * 5, B * 128 * 13)    k_intra (LDS neighbours): [band][mbx] bottom rows, 32 bytes as eight words
+  uint64_t lines[1];
 };
+constexpr int kMvLineWords = 5, kIntraLineWords = 8;
+__device__ __forceinline__ int bands_of(int mb_height) { return (mb_height + kBandWaves - 1) / kBandWaves; }
 constexpr int kLineMbs = 128;  // width (macroblocks) the LDS line buffers of k_mv / k_intra cover
 
 // The counters live in LDS and must be addressed as such: through a generic
@@ -613,10 +621,6 @@ typedef volatile __attribute__((address_space(3))) int lds_counter;
 __device__ __forceinline__ void row_wait(lds_counter* progress, int row, int need) {
   while (progress[row] < need) __builtin_amdgcn_s_sleep(1);
   __asm__ volatile("" ::: "memory");
-}
-__device__ __forceinline__ void row_publish(lds_counter* progress, int row, int done) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // global stores of this wave have landed
-  progress[row + 1] = done;
 }
 
 // ---- intra prediction helpers working on an LDS tile -----------------------
@@ -723,6 +727,9 @@ __device__ __forceinline__ uint64_t agent_ld64(const uint64_t* p) {
 __device__ __forceinline__ uint32_t agent_ld32(const void* p) {
   return __hip_atomic_load((const HW_AS1 uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ int agent_ld8(const void* p) {
+  return __hip_atomic_load((const HW_AS1 uint8_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ void agent_st32(void* p, uint32_t v) {
   __hip_atomic_store((HW_AS1 uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -784,7 +791,7 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
   // wrong vectors, not in a hung GPU.
   auto import_until = [&](int need) {
     if (seen >= need) return;
-    const uint64_t* src = &ctl->mv_line[0][0][0] + static_cast<size_t>(band - 1) * kLineMbs * 5;
+    const uint64_t* src = ctl->lines + static_cast<size_t>(band - 1) * kLineMbs * kMvLineWords;
     for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
       const int e = seen + (lane >> 3), d = lane & 7;
       const bool act = d < 5 && e < W;
@@ -1022,7 +1029,7 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
         left_mv0 = whole ? whole_mv : __builtin_amdgcn_readfirstlane(cmv[3]);
         if (exporting) {
           // the band below reads this row's edges from global memory
-          uint64_t* dst = &ctl->mv_line[0][0][0] + (static_cast<size_t>(band) * kLineMbs + mbx) * 5;
+          uint64_t* dst = ctl->lines + (static_cast<size_t>(band) * kLineMbs + mbx) * kMvLineWords;
           const uint32_t refs = static_cast<uint32_t>(static_cast<uint8_t>(cref(2))) | (static_cast<uint32_t>(static_cast<uint8_t>(cref(3))) << 8);
           if (lane < 5) agent_st64(dst + lane, (static_cast<uint64_t>(epoch) << 32) | (lane < 4 ? (whole ? whole_mv : cmv[12 + (lane & 3)]) : refs));
           __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1072,7 +1079,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __
 }
 
 // ===========================================================================
-// k_intra: grid = 1 workgroup of 16 waves per picture.
+// k_intra: one workgroup of kBandWaves waves (= rows) per band of a picture; k_mv explains the bands.
 //
 // Two neighbour paths, chosen per picture:
 //  * intra-only pictures no wider than kLineMbs macroblocks (every I picture
@@ -1087,29 +1094,78 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __
 //    the progress counter.
 // ===========================================================================
 
-__global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restrict__ jobs) {
-  const JobDesc& job = jobs[blockIdx.x];
+__global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__ jobs, int njobs) {
+  // one workgroup per band of kBandWaves rows, bands handed out by ticket (see k_mv)
+  __shared__ unsigned s_ticket;
+  __shared__ int s_progress[kBandWaves + 1];
+  __shared__ IntraWaveLds s_lds[kBandWaves];
+  __shared__ uint8_t s_line[kBandWaves + 1][kLineMbs][32];  // [kBandWaves]: the line imported from the band above
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_in, 1u);
+  if (threadIdx.x <= kBandWaves) s_progress[threadIdx.x] = 0;
+  __syncthreads();
+  const int band = static_cast<int>(s_ticket) / njobs;
+  const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
   if (!job.do_intra) return;
   const PictureParams& pp = job.pp;
   const MbInfo* __restrict__ mbs = job.mbs;
   const int16_t* __restrict__ coefs = job.coefs;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  __shared__ int s_progress[kMaxRows + 1];
-  __shared__ IntraWaveLds s_lds[kRowWaves];
-  __shared__ uint8_t s_line[kRowWaves][kLineMbs][32];
+  const int mby = band * kBandWaves + wave;
+  if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
   lds_counter* progress = (lds_counter*)s_progress;
-  for (int i = threadIdx.x; i <= pp.mb_height; i += blockDim.x) s_progress[i] = i == 0 ? (1 << 30) : 0;
-  __syncthreads();
   IntraWaveLds& L = s_lds[wave];
   uint8_t* tile = L.tile;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const bool lds_nb = !job.do_inter && pp.mb_width <= kLineMbs;  // wave uniform
-  uint8_t (*line_up)[32] = s_line[(wave + kRowWaves - 1) % kRowWaves];
+  uint8_t (*line_up)[32] = wave == 0 ? s_line[kBandWaves] : s_line[wave - 1];
   uint8_t (*line_me)[32] = s_line[wave];
+  BandCtl* ctl = static_cast<BandCtl*>(job.band_ctl);
+  const uint32_t epoch = job.epoch;
+  const bool importing = wave == 0 && band > 0;
+  const bool exporting = wave == kBandWaves - 1 && mby + 1 < pp.mb_height;
+  uint64_t* const xline = ctl->lines + static_cast<size_t>(bands_of(pp.mb_height)) * 128 * kMvLineWords;
+  if (wave == 0 && band == 0 && lane == 0) s_progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
+  int seen = 0;  // importing: macroblocks of the row above that are known final (and, with lds_nb, sit in s_line[kBandWaves])
+  // lds_nb pictures: fetch the next eight entries of the band above, keep the
+  // complete ones in front of the first missing word (k_mv has the same scheme)
+  auto import_line = [&](int need) {
+    if (seen >= need) return;
+    const uint64_t* src = xline + static_cast<size_t>(band - 1) * kLineMbs * kIntraLineWords;
+    for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
+      const int e = seen + (lane >> 3), d = lane & 7;
+      const bool act = e < pp.mb_width;
+      uint64_t v = 0;
+      if (act) v = agent_ld64(src + e * kIntraLineWords + d);
+      const uint64_t missing = __ballot(act && static_cast<uint32_t>(v >> 32) != epoch);
+      const int nvalid = min(missing ? __builtin_ctzll(missing) >> 3 : 8, pp.mb_width - seen);
+      if (act && (lane >> 3) < nvalid) reinterpret_cast<uint32_t*>(s_line[kBandWaves][e])[d] = static_cast<uint32_t>(v);
+      seen += nvalid;
+      if (seen < need) __builtin_amdgcn_s_sleep(1);
+    }
+    if (seen < need) seen = need;  // impossible by construction; wrong samples rather than a hung GPU
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_sync();
+  };
+  // other pictures: the band above publishes a counter once its bottom rows have landed
+  auto import_wait = [&](int need) {
+    for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
+      const uint64_t v = agent_ld64(&ctl->in_prog[band - 1]);
+      if (static_cast<uint32_t>(v >> 32) == epoch) seen = static_cast<int>(static_cast<uint32_t>(v));
+      if (seen < need) __builtin_amdgcn_s_sleep(2);
+    }
+    __asm__ volatile("" ::: "memory");
+  };
+  // a sample of the row above: through the agent-coherent path when another workgroup wrote it
+  auto up8 = [&](const uint8_t* q) -> int { return importing ? agent_ld8(q) : gld8(q); };
+  auto publish = [&](int done) {  // surface path: this wave's stores land first
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (exporting) { if (lane == 0) agent_st64(&ctl->in_prog[band], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(done)); }
+    else progress[wave + 1] = done;
+  };
 
   const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(job.resid);
-  for (int mby = wave; mby < pp.mb_height; mby += kRowWaves) {
+  {
     int prev_mbx = -2;  // macroblock whose samples the tile still holds
     for (int mbx0 = 0; mbx0 < pp.mb_width; mbx0 += 64) {
       // which of the next 64 macroblocks of this row are intra?
@@ -1147,7 +1203,10 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
         const bool hC = mb.flags & MBF_AVAIL_C, hD = mb.flags & MBF_AVAIL_D;
         // the row above must be complete up to the top-right neighbour
         if (hB || hC || hD) {
-          row_wait(progress, mby, min(mbx + 2, pp.mb_width));
+          const int need = min(mbx + 2, pp.mb_width);
+          if (!importing) row_wait(progress, wave, need);
+          else if (lds_nb) import_line(need);
+          else import_wait(need);
         }
         // ---- neighbours into the tiles
         if (lds_nb) {
@@ -1177,14 +1236,14 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
           }
         } else {
           if (lane < 25)
-            tile[lane] = (lane == 0) ? (hD ? gld8(dy - yp - 1) : 128) : (lane <= 16) ? (hB ? gld8(dy - yp + lane - 1) : 128)
-                                                                                     : (hC ? gld8(dy - yp + lane - 1) : 128);
+            tile[lane] = (lane == 0) ? (hD ? up8(dy - yp - 1) : 128) : (lane <= 16) ? (hB ? up8(dy - yp + lane - 1) : 128)
+                                                                                    : (hC ? up8(dy - yp + lane - 1) : 128);
           else if (lane >= 32 && lane < 48)
             tile[(lane - 31) * TS] = hA ? gld8(dy + (lane - 32) * yp - 1) : 128;
           if (lane < 18) {
             const int p = lane / 9, i = lane % 9;
             const uint8_t* d = p ? dv : du;
-            L.ctile[p][i] = (i == 0) ? (hD ? gld8(d - cp - 1) : 128) : (hB ? gld8(d - cp + i - 1) : 128);
+            L.ctile[p][i] = (i == 0) ? (hD ? up8(d - cp - 1) : 128) : (hB ? up8(d - cp + i - 1) : 128);
           } else if (lane >= 32 && lane < 48) {
             const int p = (lane - 32) >> 3, j = (lane - 32) & 7;
             const uint8_t* d = p ? dv : du;
@@ -1376,12 +1435,16 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
           const int r = lane >> 2, c4 = (lane & 3) * 4;
           const uint8_t* tp = tile + (1 + r) * TS + 1 + c4;
           const uint32_t v = tp[0] | (tp[1] << 8) | (tp[2] << 16) | ((uint32_t)tp[3] << 24);
-          gst32(dy + (size_t)r * yp + c4, v);
+          // (surface path: the band below reads the bottom rows from another workgroup)
+          const bool coherent = exporting && !lds_nb;
+          if (coherent && r == 15) agent_st32(dy + (size_t)r * yp + c4, v);
+          else gst32(dy + (size_t)r * yp + c4, v);
           if (lane < 32) {
             const int p = lane >> 4, rr = (lane >> 1) & 7, cc = (lane & 1) * 4;
             const uint8_t* cpx = L.ctile[p] + (1 + rr) * 12 + 1 + cc;
             const uint32_t w = cpx[0] | (cpx[1] << 8) | (cpx[2] << 16) | ((uint32_t)cpx[3] << 24);
-            gst32((p ? dv : du) + (size_t)rr * cp + cc, w);
+            if (coherent && rr == 7) agent_st32((p ? dv : du) + (size_t)rr * cp + cc, w);
+            else gst32((p ? dv : du) + (size_t)rr * cp + cc, w);
           }
         }
         if (lds_nb) {
@@ -1389,9 +1452,18 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
           if (lane < 16) line_me[mbx][lane] = tile[16 * TS + 1 + lane];
           else if (lane < 32) line_me[mbx][lane] = L.ctile[(lane - 16) >> 3][8 * 12 + 1 + ((lane - 16) & 7)];
           __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          progress[mby + 1] = mbx + 1;
+          if (exporting) {
+            // the same 32 bytes, as eight tagged words, for the band below
+            wave_sync();
+            if (lane < 8)
+              agent_st64(xline + (static_cast<size_t>(band) * kLineMbs + mbx) * kIntraLineWords + lane,
+                         (static_cast<uint64_t>(epoch) << 32) | reinterpret_cast<const uint32_t*>(line_me[mbx])[lane]);
+            __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          } else {
+            progress[wave + 1] = mbx + 1;
+          }
         } else {
-          row_publish(progress, mby, mbx + 1);
+          publish(mbx + 1);
         }
         prev_mbx = mbx;
       }
@@ -1399,15 +1471,15 @@ __global__ __launch_bounds__(kRowWaves * 64) void k_intra(const JobDesc* __restr
     // inter macroblocks at the end of the row need no work: the row is done
     if (lds_nb) {
       __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      progress[mby + 1] = pp.mb_width;
+      if (!exporting) progress[wave + 1] = pp.mb_width;  // (every macroblock of an lds_nb picture exported its own entry)
     } else {
-      row_publish(progress, mby, pp.mb_width);
+      publish(pp.mb_width);
     }
   }
 }
 
 // ===========================================================================
-// k_deblock: grid = 1 workgroup of 16 waves per picture.
+// k_deblock: one workgroup of kBandWaves waves (= rows) per band of a picture.
 // ===========================================================================
 namespace {
 
@@ -1903,7 +1975,8 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_row
     if (profiled) span = prof::begin(stream);
     hipLaunchKernelGGL(k_residual, dim3((max_mbs + kInterWaves - 1) / kInterWaves, njobs), dim3(kInterWaves * 64), 0, stream,
                        jobs);
-    hipLaunchKernelGGL(k_intra, dim3(njobs), dim3(kRowWaves * 64), 0, stream, jobs);
+    hipLaunchKernelGGL(k_intra, dim3(njobs * ((max_rows + kBandWaves - 1) / kBandWaves)), dim3(kBandWaves * 64), 0, stream,
+                       const_cast<JobDesc*>(jobs), njobs);
     if (profiled) prof::end(span, stream, prof::K_INTRA, bytes[1]);
   }
   if (any_deblock) {
@@ -1918,7 +1991,8 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_row
 
 size_t deblock_scratch_bytes(int num_mbs) { return (size_t)num_mbs * sizeof(DbInfo); }
 size_t band_ctl_bytes(int mb_height) {
-  return offsetof(BandCtl, mv_line) + (size_t)((mb_height + kBandWaves - 1) / kBandWaves) * kLineMbs * 5 * sizeof(uint64_t);
+  return offsetof(BandCtl, lines) +
+         (size_t)((mb_height + kBandWaves - 1) / kBandWaves) * 128 * (kMvLineWords + kIntraLineWords) * sizeof(uint64_t);
 }
 
 }  // namespace amd
