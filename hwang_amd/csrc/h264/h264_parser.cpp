@@ -92,13 +92,15 @@ struct Bits {
 // flow - about half of all bins sit in contexts near p = 0.5 and mispredict).
 struct CabacTables {
   uint8_t next[128][2];   // [state = pStateIdx << 1 | valMPS][0 MPS taken, 1 LPS taken]
-  uint8_t lps[4][128];    // [qCodIRangeIdx][state]
+  uint32_t lps4[128];     // [state]: rangeTabLPS for qCodIRangeIdx 0..3, one byte each - the load depends on the
+                          // context only, so it is off the range -> range chain that paces consecutive bins
   CabacTables() {
     for (int st = 0; st < 128; ++st) {
       const int ps = st >> 1, mps = st & 1;
       next[st][0] = static_cast<uint8_t>(((ps < 62 ? ps + 1 : ps) << 1) | mps);
       next[st][1] = static_cast<uint8_t>((cabac_trans_lps[ps] << 1) | (ps == 0 ? !mps : mps));
-      for (int q = 0; q < 4; ++q) lps[q][st] = cabac_range_lps[ps][q];
+      lps4[st] = 0;
+      for (int q = 0; q < 4; ++q) lps4[st] |= static_cast<uint32_t>(cabac_range_lps[ps][q]) << (8 * q);
     }
   }
 };
@@ -112,7 +114,9 @@ struct Cabac {
   int extra = 0;
   uint32_t range = 0;
   bool overrun = false;
-  uint8_t state[CABAC_CTX_COUNT];
+  // 16-bit on purpose: a byte store may alias anything, which would force the
+  // engine's registers (value, range, extra, p) through memory around every bin
+  uint16_t state[CABAC_CTX_COUNT];
 
   // called with extra < 8 (or -9 at the start): afterwards extra >= 24
   void refill() {
@@ -155,9 +159,9 @@ struct Cabac {
                            : static_cast<uint8_t>(((pre - 64) << 1) | 1);
     }
   }
-  inline int bin(int ctx) {
+  __attribute__((always_inline)) inline int bin(int ctx) {
     const uint32_t st = state[ctx];
-    const uint32_t lps = g_cabac_tables.lps[(range >> 6) & 3][st];
+    const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
     uint32_t r = range - lps;
     const uint64_t scaled = static_cast<uint64_t>(r) << extra;
     // all ones when the LPS is decoded (value >= scaled)
@@ -172,7 +176,7 @@ struct Cabac {
     if (__builtin_expect(extra < 8, 0)) refill();
     return static_cast<int>((st & 1) ^ l);
   }
-  inline int bypass() {
+  __attribute__((always_inline)) inline int bypass() {
     extra -= 1;
     if (__builtin_expect(extra < 8, 0)) refill();
     const uint64_t scaled = static_cast<uint64_t>(range) << extra;
@@ -1553,7 +1557,7 @@ struct Parser::Impl {
     int extra = c.extra;
     const uint8_t* p = c.p;
     const uint8_t* const end = c.end;
-    uint8_t* const state = c.state;
+    uint16_t* const state = c.state;
     bool overrun = false;
     auto refill = [&]() {
       if (extra >= 0 && p + 4 <= end) {
@@ -1575,7 +1579,7 @@ struct Parser::Impl {
     };
     auto bin = [&](int ctx) -> int {
       const uint32_t st = state[ctx];
-      const uint32_t lps = g_cabac_tables.lps[(range >> 6) & 3][st];
+      const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
       uint32_t r = range - lps;
       const uint64_t scaled = static_cast<uint64_t>(r) << extra;
       const uint64_t lmask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
