@@ -231,9 +231,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    # 4 lanes per usable CPU (a lane waits for the GPU far more than it parses;
-    # the CPUs are the bottleneck); with several ranks on one host the CPUs are shared
-    lanes = args.lanes or max(2, min(128, 4 * effective_cpus() // world))
+    # 3 lanes per usable CPU (a lane waits for the GPU about as long as it parses;
+    # the CPUs are the bottleneck: measured 32 / 40 / 48 / 64 lanes on 16 CPUs ->
+    # 660 / 676 / 698 / 651 frames/s); with several ranks on one host the CPUs are shared
+    lanes = args.lanes or max(2, min(128, 3 * effective_cpus() // world))
     dec = hw.Decoder(path, video_index=index, device_id=local_rank, num_lanes=lanes)
     out = torch.empty((len(rows), HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda")
 

@@ -43,7 +43,7 @@ class ParallelRetriever {
     int64_t wall_ns = 0;
   };
 
-  // num_lanes <= 0 picks 4 lanes per CPU the process may use (effective_cpus), at most 128.
+  // num_lanes <= 0 picks 3 lanes per CPU the process may use (effective_cpus), at most 128.
   static int32_t effective_cpus();
   static ParallelRetriever* make(DeviceHandle device, VideoDecoderType type,
                                  int32_t num_lanes);

@@ -4,13 +4,17 @@
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md (HBM):
 the counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests at 64
 bytes, so it is doubled; WRITE_SIZE is taken as is.  Pictures per dispatch are
-recovered from the grid (row pipelines: one workgroup per picture; k_inter /
-k_bs / k_residual: grid.y pictures; convert_batch: grid.z frames)."""
+recovered from the grid (row pipelines: BANDS workgroups per picture - 17 for
+the bench's 1080p clip, 4 macroblock rows each; k_inter / k_bs / k_residual:
+grid.y pictures; convert_batch: grid.z frames)."""
 import csv
 import glob
 import json
+import os
 import sys
 from collections import defaultdict
+
+BANDS = int(os.environ.get("BANDS", 17))
 
 
 def load(d, counter):
@@ -27,7 +31,7 @@ def load(d, counter):
             name = r["Kernel_Name"].split("(")[0].split("::")[-1]
             gx, gy, gz, wx = dims.get(r["Dispatch_Id"], (int(r["Grid_Size"]), 1, 1, max(1, int(r["Workgroup_Size"]))))
             if name in ("k_intra", "k_deblock", "k_mv"):
-                pics = gx // wx
+                pics = max(1, gx // wx // BANDS)
             elif name == "convert_batch":
                 pics = gz
             elif name == "k_upload":
