@@ -1173,27 +1173,32 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
       const bool is_intra = probe < pp.mb_width && (gld8(&mbs[mby * pp.mb_width + probe].flags) & MBF_INTRA);
       unsigned long long todo = __ballot(is_intra);
       // residual of the first macroblock of the run; inside the loop the next one's is fetched a macroblock ahead
+      // (and its record: a load at the top of the macroblock would sit on the chain)
       uint32_t r0 = 0, r1 = 0, r2 = 0;
+      MbInfo next_mb = {};
       if (todo) {
-        const uint32_t* rp = resid + (size_t)(mby * pp.mb_width + mbx0 + __builtin_ctzll(todo)) * 192;
+        const int first = mby * pp.mb_width + mbx0 + __builtin_ctzll(todo);
+        const uint32_t* rp = resid + (size_t)first * 192;
         r0 = gld32(rp + lane);
         r1 = gld32(rp + 64 + lane);
         r2 = gld32(rp + 128 + lane);
+        next_mb = gload(&mbs[first]);
       }
       while (todo) {
         const int mbx = mbx0 + __builtin_ctzll(todo);
         todo &= todo - 1;
-        const int mbi = mby * pp.mb_width + mbx;
-        const MbInfo mb = gload(&mbs[mbi]);
+        const MbInfo mb = next_mb;
         // land this macroblock's residual in LDS, start the next one's loads
         reinterpret_cast<uint32_t*>(L.res_y)[lane] = r0;
         reinterpret_cast<uint32_t*>(L.res_y)[64 + lane] = r1;
         reinterpret_cast<uint32_t*>(L.res_c)[lane] = r2;
         if (todo) {
-          const uint32_t* rp = resid + (size_t)(mby * pp.mb_width + mbx0 + __builtin_ctzll(todo)) * 192;
+          const int nxt = mby * pp.mb_width + mbx0 + __builtin_ctzll(todo);
+          const uint32_t* rp = resid + (size_t)nxt * 192;
           r0 = gld32(rp + lane);
           r1 = gld32(rp + 64 + lane);
           r2 = gld32(rp + 128 + lane);
+          next_mb = gload(&mbs[nxt]);
         }
         uint8_t* dy = cur.y + (size_t)(mby * 16) * yp + mbx * 16;
         uint8_t* du = cur.u + (size_t)(mby * 8) * cp + mbx * 8;

@@ -37,6 +37,34 @@ def test_all_frames_bit_exact(hw, oracle, gpu, tmp_path, name, kw):
         assert np.array_equal(got[i], gold[i]), "frame %d differs from the oracle/encoder reconstruction" % i
 
 
+# The row kernels cut a picture into bands of four macroblock rows, one
+# workgroup each: cover every remainder (1, 2, 3 rows in the last band, a single
+# band, a single row, a single column), pictures wider than the 128-macroblock
+# LDS line buffers (surface hand-off, host-side vectors) and slices that end
+# inside a band.
+BAND_SIZES = [
+    ("1x1mb", 16, 16, dict(frames=6, gop=6, bframes=1)),
+    ("1col_5rows", 16, 80, dict(frames=6, gop=6, bframes=1)),
+    ("3x5mb", 48, 80, dict(frames=7, gop=7, bframes=2)),
+    ("4x6mb", 64, 96, dict(frames=7, gop=7, bframes=2, slices=2)),
+    ("qcif_9rows", 176, 144, dict(frames=9, gop=9, bframes=2, slices=3)),
+    ("wide_129x3mb", 2064, 48, dict(frames=5, gop=5, bframes=1)),
+    ("wide_130x7mb_slices", 2080, 112, dict(frames=5, gop=5, bframes=0, slices=4)),
+]
+
+
+@pytest.mark.parametrize("name,w,h,kw", BAND_SIZES, ids=[b[0] for b in BAND_SIZES])
+def test_band_edge_sizes_bit_exact(hw, gpu, tmp_path, name, w, h, kw):
+    path = str(tmp_path / (name + ".mp4"))
+    gold = make_clip(path, width=w, height=h, **kw)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=2)
+    got = dec.retrieve_yuv(list(range(idx.frames())))
+    assert len(got) == len(gold)
+    for i in range(len(gold)):
+        assert np.array_equal(got[i], gold[i]), "%s: frame %d differs from the encoder's reconstruction" % (name, i)
+
+
 @pytest.mark.skipif(not have_file(REALSHORT), reason="realshort.mp4 not in this image")
 def test_real_x264_stream_bit_exact(hw, oracle, gpu):
     idx, ref = oracle_frames(oracle, hw, REALSHORT)
