@@ -63,11 +63,11 @@ bool GpuExecutor::start(std::string* error) {
     return false;
   };
   if (hipSetDevice(device_) != hipSuccess) return fail("cannot select the device");
-  // CU partition.  An intra-only picture is ONE 16-wave workgroup whose
-  // speed is the latency of a dependent chain; sharing its CU with k_inter
-  // waves of the light engine more than doubles that latency (measured:
-  // 7 ms -> 17 ms per 1080p I picture), and every interval waits for its
-  // keyframe.  So every 8th CU (one per XCD position, 32 of 256) is reserved
+  // CU partition.  An intra-only picture is a wavefront of row pipelines
+  // whose speed is the latency of a dependent chain; sharing its CUs with
+  // k_inter waves of the light engine more than doubles that latency (measured
+  // with the original one-workgroup kernels: 7 ms -> 17 ms per 1080p I
+  // picture), and every interval waits for its keyframe.  So every 8th CU (one per XCD position, 32 of 256) is reserved
   // for the heavy engines and the light engine's streams get the rest.
   // HWANG_CU_PARTITION=0 disables the masks.
   hipDeviceProp_t prop;

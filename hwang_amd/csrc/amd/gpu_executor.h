@@ -1,19 +1,20 @@
 // Per-device batching executor.
 //
 // Sparse decoding is parallel across keyframe-anchored intervals ("lanes":
-// one host thread + one DPB each), not inside a picture, whose intra and
-// deblocking stages are raster-order pipelines that keep one CU busy.  To
-// fill 256 CUs the GPU therefore has to work on many lanes' pictures at the
-// same time.  Doing that with one HIP stream per lane runs into the
+// one host thread + one DPB each) far more than inside a picture, whose
+// vector-prediction, intra and deblocking stages are raster-order pipelines
+// that keep a CU per four macroblock rows busy.  To fill 256 CUs the GPU
+// therefore has to work on many lanes' pictures at the same time.  Doing that with one HIP stream per lane runs into the
 // hardware-queue limit and into per-call runtime overhead, so lanes only
 // *describe* work here and a single submitter thread per GPU turns whatever
 // is pending into a few large launches:
 //
 //     H2D of the new pictures' records            (copy engine)
+//     k_mv       grid (pictures x bands)          row pipeline, 4 rows per workgroup
 //     k_inter    grid (max_mbs, pictures)         every inter MB of every picture
-//     k_intra    grid (pictures)                  one 16-wave row pipeline each
+//     k_intra    grid (pictures x bands)          row pipeline
 //     k_bs       grid (max_mbs/8, pictures)
-//     k_deblock  grid (pictures)
+//     k_deblock  grid (pictures x bands)          row pipeline
 //     convert    grid (.., .., frames)            I420 -> RGB24 / plane copies
 //     D2H of frames that go to host memory
 //
@@ -24,9 +25,9 @@
 // compute stream, copy stream and ring of in-flight batches:
 //   light      P/B pictures: k_inter dominates, the row pipelines mostly skip;
 //              batches are formed late so that they are wide
-//   heavy x H  intra-only pictures: every macroblock goes through the 16-wave
-//              row pipeline, several milliseconds per picture on ONE CU.  A
-//              heavy batch is latency bound and tiny (a handful of CUs), so
+//   heavy x H  intra-only pictures: every macroblock goes through the intra
+//              and deblocking row pipelines, ~2 ms per 1080p picture.  A
+//              heavy batch is latency bound and small (17 CUs a picture), so
 //              there are H of them (lane % H picks one) launching eagerly and
 //              running concurrently; a lane waits for its keyframe before its
 //              first P picture can go anywhere, which makes this latency the

@@ -6,12 +6,14 @@
 //               8x8 inverse transforms, quarter-sample luma and eighth-sample
 //               chroma motion compensation from unaligned dword fetches
 //               (default, explicit and implicit weighting), + residual
+//   k_mv        motion vectors of P macroblocks from the parsed differences
 //   k_residual  dequant + inverse transforms of the intra macroblocks -> int16
-//   k_intra     intra prediction in dependency order: ONE workgroup of 16 waves
-//               per picture, a wave per macroblock row, progress handed down
-//               through LDS counters (workgroup scope only)
+//   k_intra     intra prediction in dependency order: a wave per macroblock
+//               row, four rows (one workgroup) per band, progress handed down
+//               through LDS inside a band and through agent-scope words in
+//               global memory between bands
 //   k_bs        boundary strengths, alpha / beta / tc0, edge masks per macroblock
-//   k_deblock   in-loop deblocking filter, same 16-wave row pipeline
+//   k_deblock   in-loop deblocking filter, same banded row pipeline
 //
 // These replace what the reference gets from libavcodec's hl_decode_mb /
 // loop_filter behind avcodec_send_packet
@@ -686,10 +688,10 @@ struct IntraWaveLds {
 // the parsed differences and leaves holding the vectors (8.4.1.1 P_Skip
 // inference, 8.4.1.3 median / directional prediction).  Prediction looks at
 // the left, top, top-right and top-left neighbours, i.e. it is the same
-// raster-order chain as intra prediction: one workgroup of 16 waves per
-// picture, a wave per macroblock row, neighbours handed on through LDS (the
-// previous macroblock's right column, a line buffer with every macroblock's
-// bottom row).  The chain itself is scalar work: lane 0 walks the partitions,
+// raster-order chain as intra prediction: a wave per macroblock row, four
+// rows per workgroup, neighbours handed on through LDS (the previous
+// macroblock's right column, a line buffer with every macroblock's bottom
+// row) and, between workgroups, through tagged words in global memory.  The chain itself is scalar work: lane 0 walks the partitions,
 // the other lanes move data.  Pictures wider than kLineMbs macroblocks are
 // derived on the host instead (h264_parser: PicBuffers::device_mv).
 // ===========================================================================
@@ -1692,8 +1694,8 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
 }
 
 // ===========================================================================
-// k_deblock: grid = 1 workgroup of 16 waves per picture; every wave walks its
-// rows one macroblock at a time.  Per macroblock the only dependent memory
+// k_deblock: one workgroup of kBandWaves waves per band; every wave walks its
+// row one macroblock at a time.  Per macroblock the only dependent memory
 // traffic is the four rows above (after the row above has passed); the
 // macroblock's own samples and its DbInfo are prefetched one iteration ahead
 // and its stores are drained one iteration late.
