@@ -139,7 +139,7 @@ struct UploadDesc {
 };
 constexpr int kJobUploads = 4;
 
-struct JobDesc {
+struct alignas(16) JobDesc {
   PictureParams pp;
   const MbInfo* mbs;
   const MbMotion* motions;
@@ -169,6 +169,10 @@ struct ConvertDesc {
   int32_t yuv;         // 1: copy cropped planes instead of converting
   int32_t pad[3];
 };
+
+// tables of these travel to the device in 16-byte chunks (launch_table_copy)
+static_assert(sizeof(JobDesc) % 16 == 0, "JobDesc must be a multiple of 16 bytes");
+static_assert(sizeof(ConvertDesc) % 16 == 0, "ConvertDesc must be a multiple of 16 bytes");
 
 }  // namespace amd
 }  // namespace hwang

@@ -16,6 +16,7 @@ hipError_t launch_convert_batch(const amd::ConvertDesc* reqs_dev, int n, int max
 namespace amd {
 
 hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream);
+hipError_t launch_table_copy(void* dst, const void* src, size_t bytes, hipStream_t stream);
 hipError_t launch_done(uint32_t* flag, uint32_t ticket, hipStream_t stream);
 hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_inter, bool any_intra,
                         bool any_deblock, bool any_mv, const uint64_t bytes[4], hipStream_t stream);
@@ -88,8 +89,14 @@ bool GpuExecutor::start(std::string* error) {
   for (int ei = 0; ei < kEngines; ++ei) {
     Engine& en = engines_[ei];
     if (!make_stream(&en.stream, ei == 0 ? light_mask : heavy_mask)) return fail("cannot create a stream");
-    // only the light engine overlaps uploads with the previous batch's kernels
-    if (ei == 0) {
+    // Uploads go on the engine's compute stream.  A separate copy stream for the
+    // light engine (HWANG_COPY_STREAM=1) lets batch N+1's records travel while
+    // batch N's kernels run, but the hipEventRecord / hipStreamWaitEvent pair
+    // that orders the two streams keeps one of the runtime's threads spinning in
+    // ioctl() for as long as work is in flight - a whole CPU out of the 16 the
+    // entropy decoders are short of (measured: 750-770 -> 817 frames/s without).
+    const char* cs_env = getenv("HWANG_COPY_STREAM");
+    if (ei == 0 && cs_env && atoi(cs_env) != 0) {
       if (!make_stream(&en.copy_stream, light_mask)) return fail("cannot create a stream");
     } else {
       en.copy_stream = en.stream;
@@ -422,8 +429,7 @@ void GpuExecutor::run(int engine) {
         bytes[2] += p.bytes_deblock;
         bytes[3] += p.bytes_mv;
       }
-      e = hipMemcpyAsync(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(),
-                         hipMemcpyHostToDevice, en.copy_stream);
+      e = launch_table_copy(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(), en.copy_stream);
       if (e == hipSuccess) e = launch_upload(en.job_table_dev[slot], static_cast<int>(pics.size()), en.copy_stream);
       if (en.copy_stream != en.stream) {
         if (e == hipSuccess) e = hipEventRecord(en.copied[slot], en.copy_stream);
@@ -442,8 +448,7 @@ void GpuExecutor::run(int engine) {
         mh = convs[i].desc.height > mh ? convs[i].desc.height : mh;
         bytes += convs[i].bytes;
       }
-      e = hipMemcpyAsync(en.conv_table_dev[slot], en.conv_table_host[slot], sizeof(ConvertDesc) * convs.size(),
-                         hipMemcpyHostToDevice, en.stream);
+      e = launch_table_copy(en.conv_table_dev[slot], en.conv_table_host[slot], sizeof(ConvertDesc) * convs.size(), en.stream);
       if (e == hipSuccess)
         e = launch_convert_batch(en.conv_table_dev[slot], static_cast<int>(convs.size()), mw, mh, bytes, en.stream);
       for (size_t i = 0; i < convs.size() && e == hipSuccess; ++i)

@@ -22,7 +22,7 @@
 // each other) plus the conversions queued behind it.
 //
 // Several engines run side by side, each with its own submitter thread,
-// compute stream, copy stream and ring of in-flight batches:
+// compute stream and ring of in-flight batches:
 //   light      P/B pictures: k_inter dominates, the row pipelines mostly skip;
 //              batches are formed late so that they are wide
 //   heavy x H  intra-only pictures: every macroblock goes through the intra
@@ -37,8 +37,9 @@
 // its own duration; with two engines the P/B batches keep their short period.
 // Ordering across engines: a lane's next item is only taken by an engine when
 // everything the lane launched before has either completed or was launched
-// on that same engine (stream order).  Uploads go through the engine's copy
-// stream so that batch N+1's records travel while batch N's kernels run.
+// on that same engine (stream order).  Uploads (k_table, k_upload) are the first
+// kernels of a batch on the same stream; an optional copy stream is described
+// in GpuExecutor::start.
 #pragma once
 
 #include "frame_job.h"

@@ -1953,6 +1953,21 @@ hipError_t launch_done(uint32_t* flag, uint32_t ticket, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// A descriptor table from pinned host memory to its device copy (a multiple of
+// 16 bytes).  A kernel instead of hipMemcpyAsync: the copy needs no completion
+// bookkeeping on the host, and it is one call path less into the runtime.
+__global__ __launch_bounds__(256) void k_table(void* __restrict__ dst_, const void* __restrict__ src_, uint32_t n16) {
+  typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+  const HW_AS1 v4u* __restrict__ src = (const HW_AS1 v4u*)src_;
+  HW_AS1 v4u* __restrict__ dst = (HW_AS1 v4u*)dst_;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dst[i] = __builtin_nontemporal_load(&src[i]);
+}
+hipError_t launch_table_copy(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+  const uint32_t n16 = static_cast<uint32_t>((bytes + 15) >> 4);
+  hipLaunchKernelGGL(k_table, dim3((n16 + 255) / 256 < 16 ? (n16 + 255) / 256 : 16), dim3(256), 0, stream, dst, src, n16);
+  return hipGetLastError();
+}
+
 hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream) {
   hipLaunchKernelGGL(k_upload, dim3(kUploadBlocks, njobs * kJobUploads), dim3(256), 0, stream, jobs);
   return hipGetLastError();

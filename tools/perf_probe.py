@@ -47,7 +47,12 @@ for lanes in [int(x) for x in os.environ.get("LANES", "1,4,16,32,64").split(",")
     dec = hw.Decoder(path, video_index=idx, num_lanes=lanes)
     best = None
     cpu_best = 0.0
-    for it in range(3):
+    smp = None
+    if os.environ.get("SAMPLE"):   # process-wide PC sampling of the last iteration -> gpurun_out/samples_<lanes>.txt
+        smp = C.CDLL(os.path.join(ROOT, "tools/hostprof/libsampler.so"))
+    for it in range(12 if smp else 3):
+        if smp and it == 2:
+            smp.hw_sampler_start()
         t = time.time()
         c0 = os.times()
         dec.retrieve_into(rows, out.data_ptr(), out.numel())
@@ -55,6 +60,9 @@ for lanes in [int(x) for x in os.environ.get("LANES", "1,4,16,32,64").split(",")
         c1 = os.times()
         if best is None or dt < best:
             best, cpu_best = dt, (c1.user - c0.user) + (c1.system - c0.system)
+    if smp:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        smp.hw_sampler_dump(os.path.join(ROOT, "gpurun_out", "samples_%d.txt" % lanes).encode())
     st = dec.stats()
     if os.environ.get("CPU_ACCOUNT"):
         # CPU seconds per thread name since process start (lane threads are re-created per retrieve)
