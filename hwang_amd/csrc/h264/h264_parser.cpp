@@ -1802,34 +1802,60 @@ struct Parser::Impl {
     }
     return ref;
   }
-  int rd_mvd(int list, int bx, int by, int comp) {
-    if (!use_cabac) return bits.se();
-    int sum = 0;
-    for (int k = 0; k < 2; ++k) {
-      const int rx = k == 0 ? bx - 1 : bx, ry = k == 0 ? by : by - 1;
-      const int nx = mb.mbx + (rx < 0 ? -1 : 0), ny = mb.mby + (ry < 0 ? -1 : 0);
-      const bool inside = rx >= 0 && ry >= 0;
-      if (!inside && !nb_avail(nx - mb.mbx, ny - mb.mby)) continue;
-      sum += mvd_at(ny * mbw + nx, list, (ry & 3) * 4 + (rx & 3))[comp];
+  // mvd_l0/l1 of one partition, both components (7.3.5.1 order: x then y): the
+  // two neighbours are looked up once for both (9.3.3.1.1.7).
+  void rd_mvd_pair(int list, int bx, int by, int* dx, int* dy) {
+    if (!use_cabac) {
+      *dx = bits.se();
+      *dy = bits.se();
+      return;
+    }
+    int sum[2] = {0, 0};
+    if (bx > 0) {
+      const uint8_t* m = mvd_at(mb.addr, list, by * 4 + bx - 1);
+      sum[0] += m[0];
+      sum[1] += m[1];
+    } else if (mb.av[3]) {  // left macroblock
+      const uint8_t* m = mvd_at(mb.addr - 1, list, by * 4 + 3);
+      sum[0] += m[0];
+      sum[1] += m[1];
+    }
+    if (by > 0) {
+      const uint8_t* m = mvd_at(mb.addr, list, (by - 1) * 4 + bx);
+      sum[0] += m[0];
+      sum[1] += m[1];
+    } else if (mb.av[1]) {  // macroblock above
+      const uint8_t* m = mvd_at(mb.addr - mbw, list, 12 + bx);
+      sum[0] += m[0];
+      sum[1] += m[1];
     }
     Cabac& c = cabac;
-    const int base = comp == 0 ? 40 : 47;
-    const int inc = sum < 3 ? 0 : (sum > 32 ? 2 : 1);
-    if (!c.bin(base + inc)) return 0;
-    int v = 1, ctx = base + 3;
-    while (v < 9 && c.bin(ctx)) {
-      if (v < 4) ++ctx;
-      ++v;
-    }
-    if (v >= 9) {
-      int k = 3;
-      while (c.bypass()) {
-        v += 1 << k;
-        if (++k > 24) return 0;
+    int out[2];
+    for (int comp = 0; comp < 2; ++comp) {
+      const int base = comp == 0 ? 40 : 47;
+      const int inc = sum[comp] < 3 ? 0 : (sum[comp] > 32 ? 2 : 1);
+      int v = 0;
+      if (c.bin(base + inc)) {
+        v = 1;
+        int ctx = base + 3;
+        while (v < 9 && c.bin(ctx)) {
+          if (v < 4) ++ctx;
+          ++v;
+        }
+        if (v >= 9) {
+          int k = 3;
+          while (c.bypass()) {
+            v += 1 << k;
+            if (++k > 24) { v = 0; break; }
+          }
+          if (k <= 24) while (k--) v += c.bypass() << k;
+        }
+        if (v && c.bypass()) v = -v;
       }
-      while (k--) v += c.bypass() << k;
+      out[comp] = v;
     }
-    return c.bypass() ? -v : v;
+    *dx = out[0];
+    *dy = out[1];
   }
   int rd_cbp(bool intra) {
     if (!use_cabac) {
@@ -2085,8 +2111,8 @@ struct Parser::Impl {
             if (shape == 2) dir = i == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT;
             int mvp[2] = {0, 0};
             if (!defer) pred_mv(l, bx, by, sw, ref, dir, mvp);
-            const int dx = rd_mvd(l, bx, by, 0);
-            const int dy = rd_mvd(l, bx, by, 1);
+            int dx, dy;
+            rd_mvd_pair(l, bx, by, &dx, &dy);
             set_mvd_block(l, bx, by, sw, sh, dx, dy);
             set_mv_block(l, bx, by, sw, sh, mvp[0] + dx, mvp[1] + dy);
           }
