@@ -106,6 +106,33 @@ struct CabacTables {
 };
 static const CabacTables g_cabac_tables;
 
+// cold path of the arithmetic decoder: called with extra < 8 (or -9 at the
+// start of a slice), returns with extra >= 24
+__attribute__((noinline)) static uint64_t cabac_refill_slow(uint64_t value, int* extra_io, const uint8_t** p_io,
+                                                           const uint8_t* end, bool* overrun) {
+  int extra = *extra_io;
+  const uint8_t* p = *p_io;
+  if (extra >= 0 && p + 4 <= end) {
+    const uint32_t w = (static_cast<uint32_t>(p[0]) << 24) | (static_cast<uint32_t>(p[1]) << 16) |
+                       (static_cast<uint32_t>(p[2]) << 8) | p[3];
+    p += 4;
+    value = (value << 32) | w;
+    extra += 32;
+  } else {
+    while (extra < 24) {
+      uint32_t b = 0;
+      if (p < end) b = *p;
+      else if (p > end + 8) *overrun = true;
+      ++p;
+      value = (value << 8) | b;
+      extra += 8;
+    }
+  }
+  *extra_io = extra;
+  *p_io = p;
+  return value;
+}
+
 struct Cabac {
   const uint8_t* p = nullptr;
   const uint8_t* end = nullptr;
@@ -185,6 +212,77 @@ struct Cabac {
     return static_cast<int>(mask & 1);
   }
   inline int terminate() {
+    range -= 2;
+    const uint64_t scaled = static_cast<uint64_t>(range) << extra;
+    if (value >= scaled) return 1;
+    if (range < 256) {
+      range <<= 1;
+      extra -= 1;
+      if (extra < 8) refill();
+    }
+    return 0;
+  }
+};
+
+// The engine's registers as locals of one syntax-element reader (leaf functions
+// only: nothing else may touch the Cabac object while one of these is alive).
+// Through the object every bin loads and stores offset, range and bit budget;
+// as locals whose address never escapes they stay in registers for the run of
+// bins and are written back once, in the destructor.
+struct CabacLocal {
+  Cabac& c;
+  uint64_t value;
+  uint32_t range;
+  int extra;
+  const uint8_t* p;
+  const uint8_t* const end;
+  uint16_t* const state;
+  bool overrun = false;
+  __attribute__((always_inline)) explicit CabacLocal(Cabac& cc)
+      : c(cc), value(cc.value), range(cc.range), extra(cc.extra), p(cc.p), end(cc.end), state(cc.state) {}
+  __attribute__((always_inline)) ~CabacLocal() {
+    c.value = value;
+    c.range = range;
+    c.extra = extra;
+    c.p = p;
+    if (overrun) c.overrun = true;
+  }
+  CabacLocal(const CabacLocal&) = delete;
+  CabacLocal& operator=(const CabacLocal&) = delete;
+  __attribute__((always_inline)) void refill() {
+    int e = extra;
+    const uint8_t* q = p;
+    bool ov = false;
+    value = cabac_refill_slow(value, &e, &q, end, &ov);
+    extra = e;
+    p = q;
+    overrun |= ov;
+  }
+  __attribute__((always_inline)) int bin(int ctx) {
+    const uint32_t st = state[ctx];
+    const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
+    uint32_t r = range - lps;
+    const uint64_t scaled = static_cast<uint64_t>(r) << extra;
+    const uint64_t lmask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
+    value -= scaled & lmask;
+    r += (lps - r) & static_cast<uint32_t>(lmask);
+    const uint32_t l = static_cast<uint32_t>(lmask) & 1;
+    state[ctx] = g_cabac_tables.next[st][l];
+    const int shift = __builtin_clz(r) - 23;
+    range = r << shift;
+    extra -= shift;
+    if (__builtin_expect(extra < 8, 0)) refill();
+    return static_cast<int>((st & 1) ^ l);
+  }
+  __attribute__((always_inline)) int bypass() {
+    extra -= 1;
+    if (__builtin_expect(extra < 8, 0)) refill();
+    const uint64_t scaled = static_cast<uint64_t>(range) << extra;
+    const uint64_t mask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
+    value -= scaled & mask;
+    return static_cast<int>(mask & 1);
+  }
+  __attribute__((always_inline)) int terminate() {
     range -= 2;
     const uint64_t scaled = static_cast<uint64_t>(range) << extra;
     if (value >= scaled) return 1;
@@ -1559,25 +1657,20 @@ struct Parser::Impl {
     const uint8_t* const end = c.end;
     uint16_t* const state = c.state;
     bool overrun = false;
-    auto refill = [&]() {
-      if (extra >= 0 && p + 4 <= end) {
-        const uint32_t w = (static_cast<uint32_t>(p[0]) << 24) | (static_cast<uint32_t>(p[1]) << 16) |
-                           (static_cast<uint32_t>(p[2]) << 8) | p[3];
-        p += 4;
-        value = (value << 32) | w;
-        extra += 32;
-        return;
-      }
-      while (extra < 24) {
-        uint32_t b = 0;
-        if (p < end) b = *p;
-        else if (p > end + 8) overrun = true;
-        ++p;
-        value = (value << 8) | b;
-        extra += 8;
-      }
+    // The refill is the cold path and stays out of line; it works on copies, so
+    // that taking their addresses does not pin the hot variables (value, extra,
+    // p) to the stack - a by-reference capture in an un-inlined lambda did, and
+    // every bin then went through a store and a reload of the offset.
+    auto refill = [&]() __attribute__((always_inline)) {
+      int e = extra;
+      const uint8_t* q = p;
+      bool ov = false;
+      value = cabac_refill_slow(value, &e, &q, end, &ov);
+      extra = e;
+      p = q;
+      overrun |= ov;
     };
-    auto bin = [&](int ctx) -> int {
+    auto bin = [&](int ctx) __attribute__((always_inline)) -> int {
       const uint32_t st = state[ctx];
       const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
       uint32_t r = range - lps;
@@ -1593,7 +1686,7 @@ struct Parser::Impl {
       if (__builtin_expect(extra < 8, 0)) refill();
       return static_cast<int>((st & 1) ^ l);
     };
-    auto bypass = [&]() -> int {
+    auto bypass = [&]() __attribute__((always_inline)) -> int {
       extra -= 1;
       if (__builtin_expect(extra < 8, 0)) refill();
       const uint64_t scaled = static_cast<uint64_t>(range) << extra;
@@ -1706,7 +1799,7 @@ struct Parser::Impl {
 
   // ---------------------------------------------------- syntax elements
   int rd_intra_mb_type(int ctx_base, int intra_slice) {
-    Cabac& c = cabac;
+    CabacLocal c(cabac);
     if (intra_slice) {
       int inc = 0;
       if (mb.avA) {
@@ -1760,7 +1853,7 @@ struct Parser::Impl {
   }
   int rd_sub_mb_type() {
     if (!use_cabac) return static_cast<int>(bits.ue());
-    Cabac& c = cabac;
+    CabacLocal c(cabac);
     if (sl.type == 0) {
       if (c.bin(21)) return 0;
       if (!c.bin(22)) return 1;
@@ -1795,7 +1888,8 @@ struct Parser::Impl {
       if (cur->motion[addr].ref_idx[list][q] > 0) inc += k == 0 ? 1 : 2;
     }
     int ref = 0;
-    while (cabac.bin(54 + inc)) {
+    CabacLocal c(cabac);
+    while (c.bin(54 + inc)) {
       ++ref;
       inc = (inc >> 2) + 4;
       if (ref >= 32) return -1;
@@ -1829,7 +1923,7 @@ struct Parser::Impl {
       sum[0] += m[0];
       sum[1] += m[1];
     }
-    Cabac& c = cabac;
+    CabacLocal c(cabac);
     int out[2];
     for (int comp = 0; comp < 2; ++comp) {
       const int base = comp == 0 ? 40 : 47;
@@ -1863,7 +1957,7 @@ struct Parser::Impl {
       if (code > 47) return -1;
       return intra ? cbp_intra_from_code[code] : cbp_inter_from_code[code];
     }
-    Cabac& c = cabac;
+    CabacLocal c(cabac);
     const bool la = mb.avA, ta = mb.avB;
     const int cbp_a = la ? mb_cbp[mb.addr - 1] : 0x0f;
     const int cbp_b = ta ? mb_cbp[mb.addr - mbw] : 0x0f;
@@ -1881,7 +1975,8 @@ struct Parser::Impl {
   int rd_qp_delta() {
     if (!use_cabac) return bits.se();
     int ctx = last_qp_delta_nonzero ? 1 : 0, v = 0;
-    while (cabac.bin(60 + ctx)) {
+    CabacLocal c(cabac);
+    while (c.bin(60 + ctx)) {
       ctx = 2 + (ctx >> 1);
       if (++v > 104) return 1000;
     }
@@ -1892,9 +1987,10 @@ struct Parser::Impl {
     int inc = 0;
     if (mb.avA && mb_chroma_mode[mb.addr - 1]) inc++;
     if (mb.avB && mb_chroma_mode[mb.addr - mbw]) inc++;
-    if (!cabac.bin(64 + inc)) return 0;
-    if (!cabac.bin(64 + 3)) return 1;
-    return 2 + cabac.bin(64 + 3);
+    CabacLocal c(cabac);
+    if (!c.bin(64 + inc)) return 0;
+    if (!c.bin(64 + 3)) return 1;
+    return 2 + c.bin(64 + 3);
   }
   int rd_t8x8_flag() {
     if (!use_cabac) return bits.bit();
@@ -1905,10 +2001,11 @@ struct Parser::Impl {
   }
   int rd_intra_pred_mode() {
     if (!use_cabac) return bits.bit() ? -1 : static_cast<int>(bits.get(3));
-    if (cabac.bin(68)) return -1;
-    int v = cabac.bin(69);
-    v |= cabac.bin(69) << 1;
-    v |= cabac.bin(69) << 2;
+    CabacLocal c(cabac);
+    if (c.bin(68)) return -1;
+    int v = c.bin(69);
+    v |= c.bin(69) << 1;
+    v |= c.bin(69) << 2;
     return v;
   }
   int predicted_intra_mode(int bx, int by) const {
