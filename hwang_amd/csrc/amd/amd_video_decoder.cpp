@@ -239,8 +239,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     out->slices = j.slice_host;
     out->max_slices = kMaxSlices;
     out->slot = slot;
-    // k_mv derives the P macroblocks' motion vectors (its LDS line buffer covers 128 macroblocks per row)
-    out->device_mv = mbw_ <= 128 && !getenv("HWANG_HOST_MV");
+    // k_mv derives the P macroblocks' motion vectors (its LDS line buffer covers kLineMbs macroblocks per row)
+    out->device_mv = mbw_ <= amd::kLineMbs && !getenv("HWANG_HOST_MV");
     return true;
   }
 

@@ -139,6 +139,11 @@ struct UploadDesc {
 };
 constexpr int kJobUploads = 4;
 
+// Width (macroblocks) that the LDS line buffers of k_mv and of k_intra's
+// LDS-neighbour path cover: 4K (240) fits; wider pictures take the host path
+// for motion vectors and the surface path for intra neighbours.
+constexpr int kLineMbs = 256;
+
 struct alignas(16) JobDesc {
   PictureParams pp;
   const MbInfo* mbs;

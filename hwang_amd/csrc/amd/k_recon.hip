@@ -601,13 +601,12 @@ struct BandCtl {
   uint64_t db_prog[kMaxBands];   // k_deblock: epoch << 32 | macroblocks of the band's last row that are final
   uint64_t in_prog[kMaxBands];   // k_intra (neighbours read from the surface): likewise
   // tagged words {datum, epoch}; with B = bands of the picture:
-  //   [0, B * 128 * 5)               k_mv: [band][mbx] MvEdge as five words
-  //   [B * 128 * 5, B * 128 * 13)    k_intra (LDS neighbours): [band][mbx] bottom rows, 32 bytes as eight words
+  //   [0, B * kLineMbs * 5)                      k_mv: [band][mbx] MvEdge as five words
+  //   [B * kLineMbs * 5, B * kLineMbs * 13)      k_intra (LDS neighbours): [band][mbx] bottom rows, 32 bytes as eight words
   uint64_t lines[1];
 };
 constexpr int kMvLineWords = 5, kIntraLineWords = 8;
 __device__ __forceinline__ int bands_of(int mb_height) { return (mb_height + kBandWaves - 1) / kBandWaves; }
-constexpr int kLineMbs = 128;  // width (macroblocks) the LDS line buffers of k_mv / k_intra cover
 
 // The counters live in LDS and must be addressed as such: through a generic
 // volatile pointer they become flat_load ... sc0 sc1 followed by s_waitcnt
@@ -1126,7 +1125,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
   const uint32_t epoch = job.epoch;
   const bool importing = wave == 0 && band > 0;
   const bool exporting = wave == kBandWaves - 1 && mby + 1 < pp.mb_height;
-  uint64_t* const xline = ctl->lines + static_cast<size_t>(bands_of(pp.mb_height)) * 128 * kMvLineWords;
+  uint64_t* const xline = ctl->lines + static_cast<size_t>(bands_of(pp.mb_height)) * kLineMbs * kMvLineWords;
   if (wave == 0 && band == 0 && lane == 0) s_progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
   int seen = 0;  // importing: macroblocks of the row above that are known final (and, with lds_nb, sit in s_line[kBandWaves])
   // lds_nb pictures: fetch the next eight entries of the band above, keep the
@@ -2014,7 +2013,7 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_row
 size_t deblock_scratch_bytes(int num_mbs) { return (size_t)num_mbs * sizeof(DbInfo); }
 size_t band_ctl_bytes(int mb_height) {
   return offsetof(BandCtl, lines) +
-         (size_t)((mb_height + kBandWaves - 1) / kBandWaves) * 128 * (kMvLineWords + kIntraLineWords) * sizeof(uint64_t);
+         (size_t)((mb_height + kBandWaves - 1) / kBandWaves) * kLineMbs * (kMvLineWords + kIntraLineWords) * sizeof(uint64_t);
 }
 
 }  // namespace amd

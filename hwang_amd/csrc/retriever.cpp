@@ -44,8 +44,10 @@ ParallelRetriever* ParallelRetriever::make(DeviceHandle device,
   // through the batching pipeline is comparable to its parse time), so it takes
   // a few lanes per CPU to keep the CPUs - the bottleneck - busy; measured on a
   // 16-CPU quota: 32 / 40 / 48 / 64 lanes -> 660 / 676 / 698 / 651 frames/s.
-  if (num_lanes <= 0) num_lanes = std::min<int32_t>(3 * effective_cpus(), 128);
+  const bool auto_lanes = num_lanes <= 0;
+  if (auto_lanes) num_lanes = std::min<int32_t>(3 * effective_cpus(), 128);
   std::unique_ptr<ParallelRetriever> r(new ParallelRetriever());
+  r->auto_lanes_ = auto_lanes;
   r->lanes_.resize(num_lanes);
   for (Lane& lane : r->lanes_) {
     for (auto& b : lane.backend) {
@@ -218,7 +220,13 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
 
   std::atomic<size_t> cursor{0};
   std::atomic<bool> abort{false};
-  const size_t nl = std::min(lanes_.size(), items.size());
+  size_t nl = std::min(lanes_.size(), items.size());
+  // A lane's working set grows with the picture (records of a 4K picture:
+  // ~13 MB); beyond two lanes per CPU the parsers evict each other (measured
+  // at 3840x2160 on 16 CPUs: 16 / 24 / 32 / 48 lanes -> 485 / 528 / 562 / 477
+  // frames/s, 7.4 -> 8.3 ms of CPU per picture).
+  if (auto_lanes_ && static_cast<int64_t>(index.frame_width()) * index.frame_height() > 2 * 1920 * 1088)
+    nl = std::min<size_t>(nl, static_cast<size_t>(2 * effective_cpus()));
   std::vector<std::thread> threads;
   for (size_t li = 0; li < nl; ++li) {
     Lane& lane = lanes_[li];

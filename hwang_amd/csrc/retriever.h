@@ -79,6 +79,7 @@ class ParallelRetriever {
                   size_t frame_bytes, bool yuv);
 
   std::vector<Lane> lanes_;
+  bool auto_lanes_ = false;  // lane count chosen here, not by the caller: retrieve() may use fewer for large pictures
   Stats stats_;
 };
 

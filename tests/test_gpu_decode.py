@@ -39,7 +39,7 @@ def test_all_frames_bit_exact(hw, oracle, gpu, tmp_path, name, kw):
 
 # The row kernels cut a picture into bands of four macroblock rows, one
 # workgroup each: cover every remainder (1, 2, 3 rows in the last band, a single
-# band, a single row, a single column), pictures wider than the 128-macroblock
+# band, a single row, a single column), pictures wider than the 256-macroblock
 # LDS line buffers (surface hand-off, host-side vectors) and slices that end
 # inside a band.
 BAND_SIZES = [
@@ -50,6 +50,8 @@ BAND_SIZES = [
     ("qcif_9rows", 176, 144, dict(frames=9, gop=9, bframes=2, slices=3)),
     ("wide_129x3mb", 2064, 48, dict(frames=5, gop=5, bframes=1)),
     ("wide_130x7mb_slices", 2080, 112, dict(frames=5, gop=5, bframes=0, slices=4)),
+    ("wide_257x3mb", 4112, 48, dict(frames=5, gop=5, bframes=1)),
+    ("wide_258x6mb_slices", 4128, 96, dict(frames=4, gop=4, bframes=0, slices=3)),
 ]
 
 
