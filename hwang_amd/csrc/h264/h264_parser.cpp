@@ -1469,6 +1469,7 @@ struct Parser::Impl {
     const Pic* col = sl.ref_list[1][0];
     if (!col || !col->motion) return fail("direct prediction without RefPicList1[0]");
     const int inf8 = asps->direct_8x8_inference;
+    const int bsz = inf8 ? 2 : 1;  // 4x4 blocks per side that share one derivation
     const int addr = mb.addr;
     const MbMotion& cm = final_motion(col)[addr];
     if (sl.direct_spatial) {
@@ -1488,7 +1489,9 @@ struct Parser::Impl {
       for (int b8 = 0; b8 < 4; ++b8) {
         if (only_b8 >= 0 && b8 != only_b8) continue;
         for (int l = 0; l < 2; ++l) set_ref8(l, b8, ref[l]);
-        for (int s = 0; s < 4; ++s) {
+        // with direct_8x8_inference the four 4x4 blocks of a quadrant share the
+        // co-located corner block: one evaluation, one 2x2 fill
+        for (int s = 0; s < (inf8 ? 1 : 4); ++s) {
           const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
           const int cx = inf8 ? (b8 & 1) * 3 : bx, cy = inf8 ? (b8 >> 1) * 3 : by;
           bool col_zero = false;
@@ -1502,7 +1505,7 @@ struct Parser::Impl {
           }
           for (int l = 0; l < 2; ++l) {
             bool zero = ref[l] < 0 || (ref[l] == 0 && col_zero);
-            set_mv_block(l, bx, by, 1, 1, zero ? 0 : mvp[l][0], zero ? 0 : mvp[l][1]);
+            set_mv_block(l, bx, by, bsz, bsz, zero ? 0 : mvp[l][0], zero ? 0 : mvp[l][1]);
           }
         }
       }
@@ -1510,7 +1513,7 @@ struct Parser::Impl {
     }
     for (int b8 = 0; b8 < 4; ++b8) {
       if (only_b8 >= 0 && b8 != only_b8) continue;
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < (inf8 ? 1 : 4); ++s) {
         const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
         const int cx = inf8 ? (b8 & 1) * 3 : bx, cy = inf8 ? (b8 >> 1) * 3 : by;
         int ref0 = 0, mvc[2] = {0, 0};
@@ -1550,8 +1553,8 @@ struct Parser::Impl {
           set_ref8(0, b8, ref0);
           set_ref8(1, b8, 0);
         }
-        set_mv_block(0, bx, by, 1, 1, mv0[0], mv0[1]);
-        set_mv_block(1, bx, by, 1, 1, mv1[0], mv1[1]);
+        set_mv_block(0, bx, by, bsz, bsz, mv0[0], mv0[1]);
+        set_mv_block(1, bx, by, bsz, bsz, mv1[0], mv1[1]);
       }
     }
     return true;
