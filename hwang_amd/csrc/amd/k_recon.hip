@@ -1161,8 +1161,15 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
   auto up8 = [&](const uint8_t* q) -> int { return importing ? agent_ld8(q) : gld8(q); };
   auto publish = [&](int done) {  // surface path: this wave's stores land first
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (exporting) { if (lane == 0) agent_st64(&ctl->in_prog[band], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(done)); }
-    else progress[wave + 1] = done;
+    if (exporting) {
+      // the workgroup-scope fence above does not wait for outstanding stores
+      // (inside a workgroup the shared L1 orders them); another workgroup must
+      // not see the counter before the samples
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) agent_st64(&ctl->in_prog[band], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(done));
+    } else {
+      progress[wave + 1] = done;
+    }
   };
 
   const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(job.resid);
@@ -1903,9 +1910,15 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
         tile_mbx = mbx;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's stores have landed
-    if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch | static_cast<uint32_t>(W)); }
-    else progress[wave + 1] = W;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (exporting) {
+      // (the workgroup-scope fence does not wait for outstanding stores; the band below must not see the
+      // counter before the last macroblock's samples)
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) agent_st64(&ctl->db_prog[band], epoch | static_cast<uint32_t>(W));
+    } else {
+      progress[wave + 1] = W;
+    }
   }
 }
 
