@@ -167,6 +167,40 @@ def test_sparse_equals_sequential_at_scale(hw, gpu, tmp_path):
     assert sparse16 == dense and sparse3 == dense and serial == dense
 
 
+def test_wide_batches_are_deterministic(hw, gpu, tmp_path):
+    """The row kernels hand rows over between workgroups through global memory.
+    A hand-off that is merely *usually* in time passes every small parity case,
+    so: one sparse request decoded with a single lane (one picture per launch,
+    nothing concurrent) and then repeatedly with many lanes (wide batches, all
+    engines busy) must return identical frames every time.  (This is the test
+    that caught a counter published before the last macroblock's samples.)"""
+    torch = gpu
+    path = str(tmp_path / "soak.mp4")
+    make_clip(path, width=1920, height=1080, frames=300, gop=60, bframes=2, threads=16, repeat=12, yuv=False)
+    idx = hw.index_video(path)
+    n = idx.frames()
+    rows = sorted(np.random.default_rng(7).choice(n, 120, replace=False).tolist())
+    out = torch.empty((len(rows), 1080, 1920, 3), dtype=torch.uint8, device="cuda")
+
+    def sums():
+        return (out.to(torch.int64).sum(dim=(1, 2, 3)).cpu().numpy(),
+                (out[:, ::7, ::5, :].to(torch.int64) * 31).sum(dim=(1, 2, 3)).cpu().numpy())
+
+    dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+    dec.retrieve_into(rows, out.data_ptr(), out.numel())
+    ref = sums()
+    del dec
+    for lanes in (48, 24):
+        dec = hw.Decoder(path, video_index=idx, num_lanes=lanes)
+        for rnd in range(4):
+            out.zero_()
+            dec.retrieve_into(rows, out.data_ptr(), out.numel())
+            got = sums()
+            bad = np.nonzero((got[0] != ref[0]) | (got[1] != ref[1]))[0]
+            assert bad.size == 0, "lanes %d round %d: frames %s differ from the single-lane decode" % (lanes, rnd, bad[:8].tolist())
+        del dec
+
+
 def test_4k_wide_pictures(hw, oracle, gpu, tmp_path):
     """BASELINE config C2 geometry (3840x2160 = 240 x 135 macroblocks): wider
     than the intra kernel's LDS line buffer, so intra-only pictures take the
