@@ -19,11 +19,12 @@ import torch  # noqa: E402
 
 W, H = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080))
 FRAMES, REPEAT, ROUNDS = int(os.environ.get("FRAMES", 600)), int(os.environ.get("REPEAT", 20)), int(os.environ.get("ROUNDS", 12))
-path = "/tmp/soak_%dx%d_%d_%d.mp4" % (W, H, FRAMES, REPEAT)
+ENC_ARGS = os.environ.get("ENC_ARGS", "").split()   # extra corpus-encoder options, e.g. "--slices 3 --qp 40"
+path = "/tmp/soak_%dx%d_%d_%d_%s.mp4" % (W, H, FRAMES, REPEAT, "".join(ENC_ARGS).replace("-", ""))
 if not os.path.exists(path):
     subprocess.check_call([os.path.join(ROOT, "corpus/_build/h264_encoder"), "--width", str(W), "--height", str(H),
                            "--frames", str(FRAMES), "--gop", "60", "--bframes", "2", "--threads", "64",
-                           "--repeat", str(REPEAT), "--out", path], stdout=subprocess.DEVNULL)
+                           "--repeat", str(REPEAT), "--out", path] + ENC_ARGS, stdout=subprocess.DEVNULL)
 idx = hw.index_video(path)
 n = idx.frames()
 rng = np.random.default_rng(7)
