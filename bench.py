@@ -250,11 +250,16 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    c0 = os.times()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    c1 = os.times()
+    # host side of the story (the path is host bound): CPU seconds this
+    # rank's process used per wall second of the timed region, all threads
+    host_cpus_busy = ((c1.user - c0.user) + (c1.system - c0.system)) / elapsed
     stats = dec.stats()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -318,6 +323,7 @@ def main():
                        "lanes_per_gpu": lanes, "host_cpus": effective_cpus(), "sharding": "keyframe-anchored intervals, no collective"},
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
             "samples_fed_per_s_rank0": round(stats["samples_fed"] / (elapsed / args.steps), 1),
+            "host_cpus_busy_rank0": round(host_cpus_busy, 2),
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,
