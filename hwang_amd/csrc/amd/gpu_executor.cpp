@@ -110,6 +110,9 @@ bool GpuExecutor::start(std::string* error) {
         return fail("out of memory for job tables");
     }
   }
+  // experiment knobs: how many of the heavy engines take work, how many batches each keeps in flight
+  if (const char* e = getenv("HWANG_HEAVY_ENGINES")) heavy_engines_ = std::max(1, std::min(kHeavyEngines, atoi(e)));
+  if (const char* e = getenv("HWANG_HEAVY_INFLIGHT")) heavy_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
   const char* mode = getenv("HWANG_COMPLETION");
   use_hostfunc_ = mode && std::string(mode) == "hostfunc";
   if (hipHostMalloc(reinterpret_cast<void**>(&done_flags_), sizeof(uint32_t) * kEngines * kInflight, hipHostMallocDefault) != hipSuccess)
@@ -205,7 +208,7 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     Item it;
     it.is_picture = true;
     it.pic = job;
-    it.engine = job.heavy ? 1 + lane % kHeavyEngines : 0;
+    it.engine = job.heavy ? 1 + lane % heavy_engines_ : 0;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
     target = it.engine;
@@ -330,7 +333,7 @@ void GpuExecutor::run(int engine) {
   // is wide.  (Launching whatever is pending right away produced batches of
   // ~5 pictures that each held the GPU for a full pipeline latency.)  Heavy
   // batches are latency bound and launch as soon as there is work.
-  const int max_inflight = engine == 0 ? 2 : kInflight;
+  const int max_inflight = engine == 0 ? 2 : heavy_inflight_;
 
   std::vector<PicSubmit> pics;
   std::vector<ConvSubmit> convs;

@@ -25,13 +25,14 @@
 // compute stream and ring of in-flight batches:
 //   light      P/B pictures: k_inter dominates, the row pipelines mostly skip;
 //              batches are formed late so that they are wide
-//   heavy x H  intra-only pictures: every macroblock goes through the intra
+//   heavy      intra-only pictures: every macroblock goes through the intra
 //              and deblocking row pipelines, ~2 ms per 1080p picture.  A
-//              heavy batch is latency bound and small (17 CUs a picture), so
-//              there are H of them (lane % H picks one) launching eagerly and
-//              running concurrently; a lane waits for its keyframe before its
-//              first P picture can go anywhere, which makes this latency the
-//              critical path of every interval.
+//              heavy batch is latency bound and small (17 CUs a picture); it
+//              launches eagerly beside the light batches (up to kHeavyEngines
+//              such engines exist, lane % H picks one; one is the default);
+//              a lane waits for its keyframe before its first P picture can
+//              go anywhere, which makes this latency the critical path of
+//              every interval.
 // A kernel launch lasts as long as its slowest workgroup, so one I picture in
 // a batch of P pictures would hold the whole batch (and every lane in it) for
 // its own duration; with two engines the P/B batches keep their short period.
@@ -180,6 +181,13 @@ class GpuExecutor {
   std::thread poller_;
   std::condition_variable cv_poll_;
   uint32_t* done_flags_ = nullptr;  // pinned: [kEngines][kInflight]
+  // One heavy engine with two batches in flight: measured against three engines
+  // with three each, the C1 rate and the CPU time are the same, but the
+  // intra-only pictures travel in half as many, twice as wide launches that
+  // each finish sooner (k_residual + k_intra span 2.3 -> 1.6 ms; fewer streams
+  // compete).  HWANG_HEAVY_ENGINES / HWANG_HEAVY_INFLIGHT override.
+  int heavy_engines_ = 1;
+  int heavy_inflight_ = 2;
   uint32_t next_ticket_ = 0;
   int total_inflight_ = 0;
   bool use_hostfunc_ = false;
