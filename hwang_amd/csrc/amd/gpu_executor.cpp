@@ -113,6 +113,7 @@ bool GpuExecutor::start(std::string* error) {
   // experiment knobs: how many of the heavy engines take work, how many batches each keeps in flight
   if (const char* e = getenv("HWANG_HEAVY_ENGINES")) heavy_engines_ = std::max(1, std::min(kHeavyEngines, atoi(e)));
   if (const char* e = getenv("HWANG_HEAVY_INFLIGHT")) heavy_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
+  if (const char* e = getenv("HWANG_LIGHT_INFLIGHT")) light_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
   const char* mode = getenv("HWANG_COMPLETION");
   use_hostfunc_ = mode && std::string(mode) == "hostfunc";
   if (hipHostMalloc(reinterpret_cast<void**>(&done_flags_), sizeof(uint32_t) * kEngines * kInflight, hipHostMallocDefault) != hipSuccess)
@@ -327,13 +328,12 @@ void GpuExecutor::run(int engine) {
   }
   (void)hipSetDevice(device_);
   Engine& en = engines_[engine];
-  // Light batches are formed late, not eagerly: with one batch running and
-  // one queued behind it, every lane keeps parsing, so by the time the running
-  // one finishes most lanes have their next picture ready and the next batch
-  // is wide.  (Launching whatever is pending right away produced batches of
-  // ~5 pictures that each held the GPU for a full pipeline latency.)  Heavy
-  // batches are latency bound and launch as soon as there is work.
-  const int max_inflight = engine == 0 ? 2 : heavy_inflight_;
+  // Batches are formed late, not eagerly: while one batch runs, every lane
+  // keeps parsing, so by the time it finishes most lanes have their next
+  // picture ready and the next batch is wide.  (Launching whatever is pending
+  // right away produced batches of ~5 pictures that each held the GPU for a
+  // full pipeline latency.)  See gpu_executor.h for the measured settings.
+  const int max_inflight = engine == 0 ? light_inflight_ : heavy_inflight_;
 
   std::vector<PicSubmit> pics;
   std::vector<ConvSubmit> convs;
