@@ -376,6 +376,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       crop_top_ = s.crop_top;
       return true;
     }
+    if (s.mb_height > amd::kMaxMbRows || s.mb_width > amd::kMaxMbRows) {
+      *error = "AMDVideoDecoder: pictures beyond 8192 samples a side are not supported";
+      return false;
+    }
     // new geometry: everything in flight belongs to the old one
     (void)wait_seq(last_seq_);
     free_buffers();

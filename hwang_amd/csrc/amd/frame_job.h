@@ -143,6 +143,9 @@ constexpr int kJobUploads = 4;
 // LDS-neighbour path cover: 4K (240) fits; wider pictures take the host path
 // for motion vectors and the surface path for intra neighbours.
 constexpr int kLineMbs = 256;
+// Largest picture side in macroblocks (8192 samples): sizes the row pipelines'
+// band tables (k_recon.hip: kMaxRows) - the decoder refuses anything larger.
+constexpr int kMaxMbRows = 512;
 
 struct alignas(16) JobDesc {
   PictureParams pp;

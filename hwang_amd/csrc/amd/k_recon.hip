@@ -590,7 +590,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
 // ===========================================================================
 namespace {
 
-constexpr int kMaxRows = 512;
+constexpr int kMaxRows = kMaxMbRows;
 // Row pipelines whose pictures are spread over several workgroups ("bands" of
 // kBandWaves rows, one wave per row; k_mv explains why).  BandCtl is the
 // per-picture hand-off area in global memory (JobDesc::band_ctl); every word in
