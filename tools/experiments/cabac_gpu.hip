@@ -55,28 +55,26 @@ __global__ __launch_bounds__(256) void k_cabac(const uint32_t* __restrict__ stre
   for (int i = 0; i < nbins; ++i) {
     const uint32_t ctx = (hist * 0x9e3779b1u >> 24) & 255;  // depends on the previous bins, like ctxIdxInc does
     const uint32_t sl = ctx & 63;
-    uint32_t st;
-    switch (ctx >> 6) {
-      case 0: st = __builtin_amdgcn_readlane(s0, sl); break;
-      case 1: st = __builtin_amdgcn_readlane(s1, sl); break;
-      case 2: st = __builtin_amdgcn_readlane(s2, sl); break;
-      default: st = __builtin_amdgcn_readlane(s3, sl); break;
-    }
+    // branch-free selects: a scalar branch costs more than the three extra readlanes
+    const uint32_t hi = ctx >> 6;
+    const uint32_t c0 = __builtin_amdgcn_readlane(s0, sl), c1 = __builtin_amdgcn_readlane(s1, sl),
+                   c2 = __builtin_amdgcn_readlane(s2, sl), c3 = __builtin_amdgcn_readlane(s3, sl);
+    const uint32_t st = hi == 0 ? c0 : hi == 1 ? c1 : hi == 2 ? c2 : c3;
     const uint32_t tl = st & 63;
-    const uint32_t lw = st < 64 ? __builtin_amdgcn_readlane(l0, tl) : __builtin_amdgcn_readlane(l1, tl);
-    const uint32_t nw = st < 64 ? __builtin_amdgcn_readlane(n0, tl) : __builtin_amdgcn_readlane(n1, tl);
+    const uint32_t la = __builtin_amdgcn_readlane(l0, tl), lb = __builtin_amdgcn_readlane(l1, tl);
+    const uint32_t na = __builtin_amdgcn_readlane(n0, tl), nb = __builtin_amdgcn_readlane(n1, tl);
+    const uint32_t lw = st < 64 ? la : lb, nw = st < 64 ? na : nb;
     const uint32_t lps = (lw >> ((range >> 3) & 24)) & 0xff;
     uint32_t r = range - lps;
     const uint64_t scaled = (uint64_t)r << extra;
     const bool is_lps = value >= scaled;
-    if (is_lps) { value -= scaled; r = lps; }
+    value -= is_lps ? scaled : 0;
+    r = is_lps ? lps : r;
     const uint32_t ns = is_lps ? (nw >> 8) & 0xff : nw & 0xff;
-    switch (ctx >> 6) {
-      case 0: s0 = writelane(ns, sl, s0); break;
-      case 1: s1 = writelane(ns, sl, s1); break;
-      case 2: s2 = writelane(ns, sl, s2); break;
-      default: s3 = writelane(ns, sl, s3); break;
-    }
+    s0 = writelane(hi == 0 ? ns : c0, sl, s0);
+    s1 = writelane(hi == 1 ? ns : c1, sl, s1);
+    s2 = writelane(hi == 2 ? ns : c2, sl, s2);
+    s3 = writelane(hi == 3 ? ns : c3, sl, s3);
     const int shift = __builtin_clz(r) - 23;
     range = r << shift;
     extra -= shift;
