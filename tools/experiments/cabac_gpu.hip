@@ -90,6 +90,55 @@ __global__ __launch_bounds__(256) void k_cabac(const uint32_t* __restrict__ stre
   if (lane == 0) out[wave] = acc;
 }
 
+__global__ __launch_bounds__(256) void k_cabac1024(const uint32_t* __restrict__ stream, uint32_t stream_words, const Tables* __restrict__ tab,
+                                               int nbins, uint32_t* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  // tables and context states in registers: entry e of a 128-entry table is lane e & 63 of register e >> 6
+  uint32_t l0 = tab->lps4[lane], l1 = tab->lps4[64 + lane];
+  uint32_t n0 = tab->next[lane], n1 = tab->next[64 + lane];
+  uint32_t S[16];  // 1024 states: context c is lane c & 63 of S[c >> 6]; the index is wave-uniform
+#pragma unroll
+  for (int q = 0; q < 16; ++q) S[q] = (lane * (2 * q + 3) + q) & 127;
+  uint32_t pos = __builtin_amdgcn_readfirstlane((wave * 977u) % (stream_words - 8));
+  uint64_t value = ((uint64_t)__builtin_bswap32(stream[pos]) << 32) | __builtin_bswap32(stream[pos + 1]);
+  pos += 2;
+  int extra = 64 - 9;  // bits of the stream in `value` beyond the nine of the offset
+  uint32_t range = 510;
+  uint32_t hist = 1, acc = 0;
+  for (int i = 0; i < nbins; ++i) {
+    const uint32_t ctx = (hist * 0x9e3779b1u >> 22) & 1023;  // depends on the previous bins, like ctxIdxInc does
+    const uint32_t sl = ctx & 63;
+    const uint32_t hi = ctx >> 6;
+    uint32_t sreg = S[hi];   // dynamic register index (v_movrels / gpr index mode)
+    const uint32_t st = __builtin_amdgcn_readlane(sreg, sl);
+    const uint32_t tl = st & 63;
+    const uint32_t la = __builtin_amdgcn_readlane(l0, tl), lb = __builtin_amdgcn_readlane(l1, tl);
+    const uint32_t na = __builtin_amdgcn_readlane(n0, tl), nb = __builtin_amdgcn_readlane(n1, tl);
+    const uint32_t lw = st < 64 ? la : lb, nw = st < 64 ? na : nb;
+    const uint32_t lps = (lw >> ((range >> 3) & 24)) & 0xff;
+    uint32_t r = range - lps;
+    const uint64_t scaled = (uint64_t)r << extra;
+    const bool is_lps = value >= scaled;
+    value -= is_lps ? scaled : 0;
+    r = is_lps ? lps : r;
+    const uint32_t ns = is_lps ? (nw >> 8) & 0xff : nw & 0xff;
+    S[hi] = writelane(ns, sl, sreg);
+    const int shift = __builtin_clz(r) - 23;
+    range = r << shift;
+    extra -= shift;
+    if (extra < 24) {  // refill 32 bits
+      value = (value << 32) | __builtin_bswap32(stream[pos]);
+      pos = pos + 1 < stream_words ? pos + 1 : 0;
+      extra += 32;
+    }
+    const uint32_t bin = (st & 1) ^ (is_lps ? 1u : 0u);
+    hist = (hist << 1) | bin;
+    acc += bin;
+  }
+  if (lane == 0) out[wave] = acc;
+}
+
 int main(int argc, char** argv) {
   const int nbins = argc > 1 ? atoi(argv[1]) : 200000;
   Tables t;
@@ -110,17 +159,19 @@ int main(int argc, char** argv) {
   (void)hipMemcpy(d_stream, h.data(), words * 4, hipMemcpyHostToDevice);
   (void)hipMemcpy(d_tab, &t, sizeof(t), hipMemcpyHostToDevice);
   hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-  for (int waves : {1, 4, 256, 1024, 4096, 8192}) {
+  for (int variant = 0; variant < 2; ++variant)
+  for (int waves : {1, 1024, 4096}) {
+    auto kern = variant ? k_cabac1024 : k_cabac;
     const int blocks = (waves + 3) / 4, threads = waves < 4 ? waves * 64 : 256;
-    hipLaunchKernelGGL(k_cabac, dim3(blocks), dim3(threads), 0, 0, d_stream, words, d_tab, 1000, d_out);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_stream, words, d_tab, 1000, d_out);
     (void)hipDeviceSynchronize();
     (void)hipEventRecord(a);
-    hipLaunchKernelGGL(k_cabac, dim3(blocks), dim3(threads), 0, 0, d_stream, words, d_tab, nbins, d_out);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), 0, 0, d_stream, words, d_tab, nbins, d_out);
     (void)hipEventRecord(b); (void)hipEventSynchronize(b);
     float ms; (void)hipEventElapsedTime(&ms, a, b);
     std::vector<uint32_t> o(waves);
     (void)hipMemcpy(o.data(), d_out, waves * 4, hipMemcpyDeviceToHost);
-    printf("%5d waves: %8.2f ms for %d bins each -> %7.1f ns/bin per stream, %8.1f Mbin/s aggregate (ones: %.3f)\n", waves, ms, nbins,
+    printf("%s %5d waves: %8.2f ms for %d bins each -> %7.1f ns/bin per stream, %8.1f Mbin/s aggregate (ones: %.3f)\n", variant ? "1024 ctx" : " 256 ctx", waves, ms, nbins,
            ms * 1e6 / nbins, waves * (double)nbins / ms / 1e3, o[0] / (double)nbins);
   }
   return 0;
