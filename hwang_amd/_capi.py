@@ -58,6 +58,7 @@ PROTOTYPES = {
     "hwang_video_index_frame_height": (C.c_uint32, [vp]),
     "hwang_video_index_format": (C.c_char_p, [vp]),
     "hwang_video_index_frames": (C.c_uint64, [vp]),
+    "hwang_video_index_problem": (C.c_char_p, [vp]),
     "hwang_video_index_sample_offsets": (u64p, [vp]),
     "hwang_video_index_sample_sizes": (u64p, [vp]),
     "hwang_video_index_num_keyframes": (C.c_size_t, [vp]),

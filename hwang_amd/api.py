@@ -50,6 +50,14 @@ class VideoIndex(object):
         self._h = lib.hwang_video_index_create(
             timescale, duration, width, height, format.encode(), offs, sizes,
             len(offs), kfs, len(kfs), bytes(metadata), len(metadata))
+        if not self._h:
+            raise ValueError("VideoIndex: bad arguments")
+
+    def problem(self):
+        """'' when the index can be decoded from; otherwise what is wrong with it
+        (such an index can be held and serialized -- the reference's own wire
+        golden is one -- but the planner and the decoders refuse it)."""
+        return lib.hwang_video_index_problem(self._h).decode()
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

@@ -147,7 +147,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   Result wait_until_frames_copied() override {
     HWANG_HIP_RETURN(hipSetDevice(device_));
-    HWANG_RETURN_ON_ERROR(wait_seq(last_seq_));
+    HWANG_RETURN_ON_ERROR(wait_seq(last_seq_.load()));
     std::lock_guard<std::mutex> lk(out_mu_);
     deliver_bounces_locked();
     return Result();
@@ -294,7 +294,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.bytes_intra = d.has_intra ? S : 0;
     sub.bytes_deblock = d.any_deblock ? 2 * S : 0;
     sub.bytes_mv = d.mv_deferred ? nmb * (sizeof(MbInfo) + 80 + 64) : 0;  // header + differences/refs in, vectors out
-    j.seq = last_seq_ = exec_->submit_picture(lane_, sub);
+    j.seq = exec_->submit_picture(lane_, sub);
+    note_seq(j.seq);
     if (d.has_inter) surf_[d.slot].motion_seq = j.seq;
     return true;
   }
@@ -361,7 +362,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   Result drain_and_reset() {
-    HWANG_RETURN_ON_ERROR(wait_seq(last_seq_));
+    HWANG_RETURN_ON_ERROR(wait_seq(last_seq_.load()));
     std::lock_guard<std::mutex> lk(out_mu_);
     outq_.clear();
     buffered_.store(0);
@@ -371,7 +372,20 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   bool ensure_geometry(const h264::PicSetup& s, std::string* error) {
+    // The output size was fixed by configure() (get_frame's contract is w*h*3 of
+    // the container's size): an in-band SPS may not change what a frame is.
+    const int cw = s.mb_width * 16 - s.crop_left - s.crop_right, ch = s.mb_height * 16 - s.crop_top - s.crop_bottom;
+    if (cw != static_cast<int>(info_.width) || ch != static_cast<int>(info_.height)) {
+      *error = "AMDVideoDecoder: the stream switches to " + std::to_string(cw) + "x" + std::to_string(ch) +
+               " pictures after configure() announced " + std::to_string(info_.width) + "x" +
+               std::to_string(info_.height);
+      return false;
+    }
     if (s.mb_width == mbw_ && s.mb_height == mbh_) {
+      if ((s.crop_left != crop_left_ || s.crop_top != crop_top_) && frames_pending_output()) {
+        *error = "AMDVideoDecoder: the cropping offsets change while decoded frames are still queued";
+        return false;
+      }
       crop_left_ = s.crop_left;
       crop_top_ = s.crop_top;
       return true;
@@ -380,11 +394,26 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       *error = "AMDVideoDecoder: pictures beyond 8192 samples a side are not supported";
       return false;
     }
-    // new geometry: everything in flight belongs to the old one
-    (void)wait_seq(last_seq_);
-    free_buffers();
-    mbw_ = s.mb_width;
-    mbh_ = s.mb_height;
+    // New coded geometry: every surface and staging buffer is re-made.  Frames
+    // that were emitted but not fetched yet still name the old surfaces, so
+    // this is only legal when nothing is queued (configure() drains; a stream
+    // that changes its coded size at an IDR with output pending is refused).
+    if (frames_pending_output()) {
+      *error = "AMDVideoDecoder: the coded picture size changes while decoded frames are still queued";
+      return false;
+    }
+    (void)wait_seq(last_seq_.load());
+    free_buffers();  // also zeroes mbw_/mbh_: they are set again only when every allocation has succeeded
+    const int new_mbw = s.mb_width, new_mbh = s.mb_height;
+    struct Rollback {
+      AMDVideoDecoder* d;
+      bool armed = true;
+      ~Rollback() {
+        if (armed) d->free_buffers();
+      }
+    } rollback{this};
+    mbw_ = new_mbw;
+    mbh_ = new_mbh;
     crop_left_ = s.crop_left;
     crop_top_ = s.crop_top;
     y_pitch_ = ((mbw_ * 16 + 255) / 256) * 256;
@@ -417,7 +446,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       j.seq = 0;
     }
     job_cursor_ = 0;
+    rollback.armed = false;
     return true;
+  }
+
+  bool frames_pending_output() {
+    std::lock_guard<std::mutex> lk(out_mu_);
+    return !outq_.empty();
   }
 
   bool alloc_surface(int slot, std::string* error) {
@@ -483,7 +518,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     if (hipSetDevice(device_) != hipSuccess) return;
     if (exec_) {
-      (void)wait_seq(last_seq_);
+      (void)wait_seq(last_seq_.load());
       exec_->unregister_lane(lane_);
     }
     parser_.reset();
@@ -542,7 +577,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       bounce->dst = dst;
       bounce->size = need;
     }
-    last_seq_ = exec_->submit_convert(lane_, sub);
+    note_seq(exec_->submit_convert(lane_, sub));
     return finish_take(slot, r);
   }
 
@@ -558,7 +593,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     bounce_cursor_ = (bounce_cursor_ + 1) % kBounce;
     if (b.dst) {
       // the ring wrapped: deliver what is pending now
-      HWANG_RETURN_ON_ERROR(wait_seq(last_seq_));
+      HWANG_RETURN_ON_ERROR(wait_seq(last_seq_.load()));
       deliver_bounces_locked();
     }
     if (b.capacity < need) {
@@ -576,7 +611,17 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   const int device_;
   amd::GpuExecutor* exec_ = nullptr;
   int lane_ = -1;
-  uint64_t last_seq_ = 0;
+  // Highest sequence number this decoder has submitted.  Written by the feeder
+  // thread (end_picture) and by the caller thread (take_frame) under
+  // DecoderAutomata, so it only ever moves forward (note_seq): a stale store
+  // from one thread must not hide the other's later submission from
+  // wait_until_frames_copied() / acquire_bounce().
+  std::atomic<uint64_t> last_seq_{0};
+  void note_seq(uint64_t seq) {
+    uint64_t cur = last_seq_.load(std::memory_order_relaxed);
+    while (cur < seq && !last_seq_.compare_exchange_weak(cur, seq, std::memory_order_release)) {
+    }
+  }
   uint32_t epoch_ = 0;  // per submitted picture, see JobDesc::epoch
   FrameInfo info_{};
   std::unique_ptr<h264::Parser> parser_;

@@ -8,6 +8,7 @@
 #include "video_index.h"
 
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 
@@ -38,14 +39,22 @@ hwang_video_index* hwang_video_index_create(
     const uint64_t* sample_sizes, size_t num_samples,
     const uint64_t* keyframe_indices, size_t num_keyframes,
     const uint8_t* metadata, size_t metadata_size) {
+  if ((num_samples && (!sample_offsets || !sample_sizes)) || (num_keyframes && !keyframe_indices) ||
+      (metadata_size && !metadata))
+    return nullptr;
   auto* h = new (std::nothrow) hwang_video_index;
   if (!h) return nullptr;
-  h->v = VideoIndex(
-      timescale, duration, width, height, format ? format : "",
-      std::vector<uint64_t>(sample_offsets, sample_offsets + num_samples),
-      std::vector<uint64_t>(sample_sizes, sample_sizes + num_samples),
-      std::vector<uint64_t>(keyframe_indices, keyframe_indices + num_keyframes),
-      std::vector<uint8_t>(metadata, metadata + metadata_size));
+  try {  // nothing may unwind through the C ABI
+    h->v = VideoIndex(
+        timescale, duration, width, height, format ? format : "",
+        std::vector<uint64_t>(sample_offsets, sample_offsets + num_samples),
+        std::vector<uint64_t>(sample_sizes, sample_sizes + num_samples),
+        std::vector<uint64_t>(keyframe_indices, keyframe_indices + num_keyframes),
+        std::vector<uint8_t>(metadata, metadata + metadata_size));
+  } catch (...) {
+    delete h;
+    return nullptr;
+  }
   return h;
 }
 void hwang_video_index_destroy(hwang_video_index* index) { delete index; }
@@ -54,7 +63,12 @@ hwang_video_index* hwang_video_index_deserialize(const uint8_t* data,
                                                  size_t size) {
   auto* h = new (std::nothrow) hwang_video_index;
   if (!h) return nullptr;
-  if (!VideoIndex::deserialize(data, size, &h->v)) {
+  bool ok = false;
+  try {
+    ok = VideoIndex::deserialize(data, size, &h->v);
+  } catch (...) {
+  }
+  if (!ok) {
     delete h;
     return nullptr;
   }
@@ -74,6 +88,7 @@ uint32_t hwang_video_index_frame_width(const hwang_video_index* i) { return i->v
 uint32_t hwang_video_index_frame_height(const hwang_video_index* i) { return i->v.frame_height(); }
 const char* hwang_video_index_format(const hwang_video_index* i) { return i->v.format().c_str(); }
 uint64_t hwang_video_index_frames(const hwang_video_index* i) { return i->v.frames(); }
+const char* hwang_video_index_problem(const hwang_video_index* i) { return i->v.problem().c_str(); }
 const uint64_t* hwang_video_index_sample_offsets(const hwang_video_index* i) { return i->v.sample_offsets().data(); }
 const uint64_t* hwang_video_index_sample_sizes(const hwang_video_index* i) { return i->v.sample_sizes().data(); }
 size_t hwang_video_index_num_keyframes(const hwang_video_index* i) { return i->v.keyframe_indices().size(); }
@@ -90,7 +105,14 @@ int hwang_mp4_indexer_feed(hwang_mp4_indexer* indexer, const uint8_t* data,
                            size_t size, uint64_t* next_offset,
                            uint64_t* next_size) {
   uint64_t off = 0, sz = 0;
-  bool more = indexer->v.feed(data, size, off, sz);
+  bool more = false;
+  try {
+    more = indexer->v.feed(data, size, off, sz);
+  } catch (const std::exception& e) {  // e.g. bad_alloc on a table the bounds checks let through
+    indexer->v.abort(std::string("MP4IndexCreator: ") + e.what());
+  } catch (...) {
+    indexer->v.abort("MP4IndexCreator: unexpected exception");
+  }
   if (next_offset) *next_offset = off;
   if (next_size) *next_size = sz;
   return more ? 1 : 0;
@@ -100,20 +122,29 @@ int hwang_mp4_indexer_is_error(hwang_mp4_indexer* i) { return i->v.is_error(); }
 const char* hwang_mp4_indexer_error_message(hwang_mp4_indexer* i) { return i->v.error_message().c_str(); }
 hwang_video_index* hwang_mp4_indexer_get_video_index(hwang_mp4_indexer* i) {
   auto* h = new (std::nothrow) hwang_video_index;
-  if (h) h->v = i->v.get_video_index();
+  try {
+    if (h) h->v = i->v.get_video_index();
+  } catch (...) {
+    delete h;
+    return nullptr;
+  }
   return h;
 }
 
 // ---- planner --------------------------------------------------------------
 hwang_video_intervals* hwang_slice_into_video_intervals(
     const hwang_video_index* index, const uint64_t* rows, size_t num_rows) {
-  bool ok = true;
-  VideoIntervals plan = slice_into_video_intervals(
-      index->v, std::vector<uint64_t>(rows, rows + num_rows), &ok);
-  if (!ok) return nullptr;
-  auto* h = new (std::nothrow) hwang_video_intervals;
-  if (h) h->v = std::move(plan);
-  return h;
+  try {
+    bool ok = true;
+    VideoIntervals plan = slice_into_video_intervals(
+        index->v, std::vector<uint64_t>(rows, rows + num_rows), &ok);
+    if (!ok) return nullptr;
+    auto* h = new (std::nothrow) hwang_video_intervals;
+    if (h) h->v = std::move(plan);
+    return h;
+  } catch (...) {
+    return nullptr;
+  }
 }
 void hwang_video_intervals_destroy(hwang_video_intervals* p) { delete p; }
 size_t hwang_video_intervals_count(const hwang_video_intervals* p) { return p->v.sample_index_intervals.size(); }

@@ -47,7 +47,12 @@ struct Bits {
   }
   unsigned get(int n) {
     if (n == 0) return 0;
-    if (n > 25) {
+    if (n < 0 || n > 32) {  // never produced by a conforming stream; a crafted one must not move pos backwards
+      overrun = true;
+      pos = size_bits;
+      return 0;
+    }
+    if (n > 25) {  // one level only: n - 16 <= 16
       unsigned hi = get(n - 16);
       return (hi << 16) | get(16);
     }
@@ -64,7 +69,10 @@ struct Bits {
   unsigned ue() {
     int zeros = 0;
     while (!bit()) {
-      if (++zeros > 32 || overrun) return 0;
+      if (++zeros > 31 || overrun) {  // codeNum must fit 32 bits (9.1)
+        overrun = true;
+        return 0;
+      }
     }
     return zeros ? ((1u << zeros) - 1 + get(zeros)) : 0;
   }
@@ -574,10 +582,16 @@ struct Parser::Impl {
         scaling_matrices(b, true, s.scaling4, s.scaling8, flat4, flat8, false);
       }
     }
-    s.log2_max_frame_num = b.ue() + 4;
+    // 7.4.2.1.1 ranges; unchecked values used to drive Bits::get(n) with absurd n
+    // (stack overflow / backwards cursor on a crafted avcC).
+    unsigned l2fn = b.ue();
+    if (l2fn > 12) return fail("SPS: log2_max_frame_num_minus4 out of range");
+    s.log2_max_frame_num = static_cast<int>(l2fn) + 4;
     s.poc_type = b.ue();
     if (s.poc_type == 0) {
-      s.log2_max_poc_lsb = b.ue() + 4;
+      unsigned l2poc = b.ue();
+      if (l2poc > 12) return fail("SPS: log2_max_pic_order_cnt_lsb_minus4 out of range");
+      s.log2_max_poc_lsb = static_cast<int>(l2poc) + 4;
     } else if (s.poc_type == 1) {
       s.delta_pic_order_always_zero = b.bit();
       s.offset_for_non_ref_pic = b.se();
@@ -588,17 +602,25 @@ struct Parser::Impl {
     } else if (s.poc_type != 2) {
       return fail("bad pic_order_cnt_type");
     }
-    s.max_num_ref_frames = b.ue();
+    unsigned nref = b.ue();
+    if (nref > 16) return fail("SPS: max_num_ref_frames out of range");
+    s.max_num_ref_frames = static_cast<int>(nref);
     b.bit();  // gaps_in_frame_num_value_allowed_flag
-    s.mb_width = b.ue() + 1;
-    s.mb_height = b.ue() + 1;
+    unsigned mbw = b.ue(), mbh = b.ue();
+    if (mbw >= 512 || mbh >= 512) return fail("picture size out of range");
+    s.mb_width = static_cast<int>(mbw) + 1;
+    s.mb_height = static_cast<int>(mbh) + 1;
     if (!b.bit()) return fail("unsupported stream: interlaced coding (frame_mbs_only_flag = 0)");
     s.direct_8x8_inference = b.bit();
     if (b.bit()) {
-      s.crop_left = 2 * b.ue();
-      s.crop_right = 2 * b.ue();
-      s.crop_top = 2 * b.ue();
-      s.crop_bottom = 2 * b.ue();
+      // crop offsets are in chroma units (x2 for 4:2:0); the sum must leave at least one luma column/row (7.4.2.1.1)
+      uint64_t cl = b.ue(), cr = b.ue(), ct = b.ue(), cb = b.ue();
+      if (2 * (cl + cr) >= 16ull * s.mb_width || 2 * (ct + cb) >= 16ull * s.mb_height)
+        return fail("SPS: frame cropping exceeds the picture");
+      s.crop_left = static_cast<int>(2 * cl);
+      s.crop_right = static_cast<int>(2 * cr);
+      s.crop_top = static_cast<int>(2 * ct);
+      s.crop_bottom = static_cast<int>(2 * cb);
     }
     if (b.bit()) {  // VUI
       if (b.bit() && b.get(8) == 255) b.get(32);
@@ -660,13 +682,19 @@ struct Parser::Impl {
     p.cabac = b.bit();
     p.bottom_field_pic_order_present = b.bit();
     if (b.ue() != 0) return fail("unsupported stream: slice groups (FMO)");
-    p.num_ref_idx_default[0] = b.ue() + 1;
-    p.num_ref_idx_default[1] = b.ue() + 1;
+    unsigned nr0 = b.ue(), nr1 = b.ue();
+    if (nr0 > 31 || nr1 > 31) return fail("PPS: num_ref_idx_default_active out of range");
+    p.num_ref_idx_default[0] = static_cast<int>(nr0) + 1;
+    p.num_ref_idx_default[1] = static_cast<int>(nr1) + 1;
     p.weighted_pred = b.bit();
     p.weighted_bipred_idc = b.get(2);
-    p.init_qp = 26 + b.se();
+    if (p.weighted_bipred_idc > 2) return fail("PPS: weighted_bipred_idc out of range");
+    int iq = b.se();
+    if (iq < -26 || iq > 25) return fail("PPS: pic_init_qp out of range");
+    p.init_qp = 26 + iq;
     b.se();
     p.chroma_qp_offset[0] = b.se();
+    if (p.chroma_qp_offset[0] < -12 || p.chroma_qp_offset[0] > 12) return fail("PPS: chroma_qp_index_offset out of range");
     p.deblocking_control_present = b.bit();
     p.constrained_intra_pred = b.bit();
     p.redundant_pic_cnt_present = b.bit();
@@ -679,6 +707,8 @@ struct Parser::Impl {
         scaling_matrices(b, p.transform_8x8_mode, p.scaling4, p.scaling8, s.scaling4, s.scaling8,
                          s.scaling_matrix_present);
       p.chroma_qp_offset[1] = b.se();
+      if (p.chroma_qp_offset[1] < -12 || p.chroma_qp_offset[1] > 12)
+        return fail("PPS: second_chroma_qp_index_offset out of range");
     }
     if (b.overrun) return fail("truncated PPS");
     p.valid = true;
@@ -941,6 +971,9 @@ struct Parser::Impl {
           if (b.bit()) {
             sl.luma_weight[l][i] = b.se();
             sl.luma_offset[l][i] = b.se();
+            if (sl.luma_weight[l][i] < -128 || sl.luma_weight[l][i] > 127 || sl.luma_offset[l][i] < -128 ||
+                sl.luma_offset[l][i] > 127)
+              return fail("prediction weight out of range") ? 0 : -1;
           }
           for (int c = 0; c < 2; ++c) {
             sl.chroma_weight[l][i][c] = 1 << sl.chroma_log2_denom;
@@ -950,6 +983,9 @@ struct Parser::Impl {
             for (int c = 0; c < 2; ++c) {
               sl.chroma_weight[l][i][c] = b.se();
               sl.chroma_offset[l][i][c] = b.se();
+              if (sl.chroma_weight[l][i][c] < -128 || sl.chroma_weight[l][i][c] > 127 ||
+                  sl.chroma_offset[l][i][c] < -128 || sl.chroma_offset[l][i][c] > 127)
+                return fail("prediction weight out of range") ? 0 : -1;
             }
         }
     } else if (p->weighted_bipred_idc == 2 && sl.type == 1) {

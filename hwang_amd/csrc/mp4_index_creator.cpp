@@ -123,7 +123,8 @@ bool MP4IndexCreator::fail(const std::string& msg) {
 
 bool MP4IndexCreator::want_exact(uint64_t offset, uint64_t size,
                                  uint64_t& next_offset, uint64_t& next_size) {
-  if (offset + size > file_size_) return fail("EOF in middle of box");
+  // overflow-safe: a 64-bit box size close to 2^64 must not wrap past the test
+  if (offset > file_size_ || size > file_size_ - offset) return fail("EOF in middle of box");
   next_offset = offset;
   next_size = size;
   return true;
@@ -292,6 +293,9 @@ bool MP4IndexCreator::parse_stbl(const uint8_t* body, uint64_t body_size) {
     uint32_t fixed = c.u32();
     uint32_t count = c.u32();
     if (c.bad || (fixed == 0 && c.left() / 4 < count)) return fail("Bad 'stsz'");
+    // every sample occupies file bytes: a fixed-size table cannot describe more than the file holds
+    // (an unchecked count of 2^32-1 was a 32 GB allocation)
+    if (fixed != 0 && static_cast<uint64_t>(count) > file_size_ / fixed) return fail("Bad 'stsz'");
     sizes.resize(count, fixed);
     if (fixed == 0)
       for (uint32_t i = 0; i < count; ++i) sizes[i] = c.u32();
@@ -340,6 +344,8 @@ bool MP4IndexCreator::parse_stbl(const uint8_t* body, uint64_t body_size) {
       c.u32();  // sample_description_index
       if (run_first != 0) {
         if (first_chunk < run_first) return fail("Bad 'stsc'");
+        // a run of empty chunks places nothing: it would spin through up to 2^32 chunks
+        if (run_len == 0 && first_chunk > run_first && placed < n) return fail("Bad 'stsc'");
         for (uint32_t k = run_first; k < first_chunk && placed < n; ++k) {
           samples_in_chunk.push_back(run_len);
           placed += run_len;
@@ -395,7 +401,12 @@ bool MP4IndexCreator::parse_stbl(const uint8_t* body, uint64_t body_size) {
     read_full(c);
     uint32_t count = c.u32();
     if (c.bad || c.left() / 4 < count) return fail("Bad 'stss'");
-    for (uint32_t i = 0; i < count; ++i) keyframes.push_back(c.u32() - 1);
+    for (uint32_t i = 0; i < count; ++i) {
+      const uint32_t number = c.u32();  // 1-based, strictly increasing (ISO/IEC 14496-12 8.6.2)
+      if (number == 0 || number > n || (!keyframes.empty() && number - 1 <= keyframes.back()))
+        return fail("Bad 'stss'");
+      keyframes.push_back(number - 1);
+    }
   } else {
     for (size_t i = 0; i < n; ++i) keyframes.push_back(sample_offsets_.size() + i);
   }
@@ -492,6 +503,10 @@ bool MP4IndexCreator::parse_moof(const uint8_t* box, uint64_t box_size,
       Cursor r{trun.body(), trun.body() + trun.body_size()};
       FullHeader th = read_full(r);
       uint32_t count = r.u32();
+      if (r.bad || count > r.left()) {  // even flag-less runs are bounded by the file through the sizes below
+        ok = fail("Truncated 'trun'");
+        return false;
+      }
       uint64_t at = run_end;
       if (th.flags & 0x000001)
         at = base + static_cast<int64_t>(static_cast<int32_t>(r.u32()));

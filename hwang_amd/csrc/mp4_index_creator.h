@@ -36,6 +36,9 @@ class MP4IndexCreator {
   }
   bool is_error() { return error_; }
   const std::string& error_message() { return error_message_; }
+  // Latches an error from outside the parser (the C ABI uses it when an
+  // allocation inside feed() throws).
+  void abort(const std::string& msg) { fail(msg); }
 
  private:
   struct TrackDefaults {  // 'trex'

@@ -146,6 +146,7 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
   if (!std::is_sorted(rows.begin(), rows.end())) {
     return Result(false, "retrieve: rows must be sorted ascending");
   }
+  if (!index.consistent()) return Result(false, "retrieve: inconsistent index: " + index.problem());
   bool ok = true;
   VideoIntervals plan = slice_into_video_intervals(index, rows, &ok);
   if (!ok) return Result(false, "retrieve: row out of range");

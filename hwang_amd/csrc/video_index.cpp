@@ -1,5 +1,7 @@
 #include "video_index.h"
 
+#include <algorithm>
+
 #include <cstring>
 
 namespace hwang {
@@ -153,9 +155,33 @@ bool VideoIndex::deserialize(const uint8_t* data, size_t size,
       return false;
     }
   }
+  if (offs.size() != sizes.size()) return false;
   *out = VideoIndex(timescale, duration, width, height, format, offs, sizes,
                     kfs, meta);
   return true;
+}
+
+void VideoIndex::check() {
+  problem_.clear();
+  if (sample_offsets_.size() != sample_sizes_.size()) {
+    problem_ = "sample_offsets and sample_sizes differ in length";
+    num_frames_ = std::min(sample_offsets_.size(), sample_sizes_.size());
+    return;
+  }
+  if (num_frames_ && keyframe_indices_.empty()) {
+    problem_ = "index has samples but no keyframe";
+    return;
+  }
+  for (size_t i = 0; i < keyframe_indices_.size(); ++i) {
+    if (keyframe_indices_[i] >= num_frames_) {
+      problem_ = "keyframe index beyond the last sample";
+      return;
+    }
+    if (i && keyframe_indices_[i] <= keyframe_indices_[i - 1]) {
+      problem_ = "keyframe indices are not strictly increasing";
+      return;
+    }
+  }
 }
 
 VideoIndex VideoIndex::deserialize(const std::vector<uint8_t>& data) {
@@ -187,7 +213,7 @@ VideoIntervals slice_into_video_intervals(const VideoIndex& index,
     if (ok) *ok = false;
     return VideoIntervals();
   };
-  if (bounds.size() < 2) return fail();
+  if (bounds.size() < 2 || !index.consistent()) return fail();
 
   const auto& offs = index.sample_offsets();
   const auto& sizes = index.sample_sizes();
@@ -196,7 +222,7 @@ VideoIntervals slice_into_video_intervals(const VideoIndex& index,
   std::vector<uint64_t> wanted;
 
   for (uint64_t row : rows) {
-    if (row >= index.frames()) return fail();
+    if (row >= index.frames() || row < bounds[0]) return fail();
     if (row >= bounds[last]) {
       const uint64_t edge = bounds[last];
       const bool contiguous = offs[edge - 1] + sizes[edge - 1] == offs[edge];

@@ -33,7 +33,20 @@ class VideoIndex {
         sample_offsets_(sample_offsets),
         sample_sizes_(sample_sizes),
         keyframe_indices_(keyframe_indices),
-        metadata_bytes_(metadata) {}
+        metadata_bytes_(metadata) {
+    check();
+  }
+
+  // Invariants every consumer below relies on (the reference used .at() and
+  // assertions; here they are checked once): offsets and sizes have one entry
+  // per sample, keyframe indices are strictly increasing and < frames(), and
+  // an index with samples has at least one keyframe.  deserialize() and
+  // hwang_video_index_create() refuse unequal table lengths; an index whose
+  // keyframes are inconsistent can still be held and re-serialized (the
+  // reference's own wire golden is such an index), but the planner, the
+  // automata glue and ParallelRetriever refuse to decode from it.
+  bool consistent() const { return problem_.empty(); }
+  const std::string& problem() const { return problem_; }
 
   // Returns false (and leaves *out untouched) on malformed input instead of
   // the reference's silent partial parse.
@@ -70,6 +83,8 @@ class VideoIndex {
   std::vector<uint64_t> sample_sizes_;
   std::vector<uint64_t> keyframe_indices_;
   std::vector<uint8_t> metadata_bytes_;
+  std::string problem_;
+  void check();
 };
 
 struct VideoIntervals {

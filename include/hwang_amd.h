@@ -64,6 +64,11 @@ size_t hwang_video_index_num_keyframes(const hwang_video_index* index);
 const uint64_t* hwang_video_index_keyframe_indices(const hwang_video_index* index);
 size_t hwang_video_index_metadata_size(const hwang_video_index* index);
 const uint8_t* hwang_video_index_metadata_bytes(const hwang_video_index* index);
+/* "" when the index satisfies the invariants the planner and the decoders rely
+ * on (the reference used vector::at and assert, video_index.cpp:70-95):
+ * keyframes strictly increasing and < frames, at least one keyframe.  Otherwise
+ * a description; such an index can be held and serialized but not decoded from. */
+const char* hwang_video_index_problem(const hwang_video_index* index);
 
 /* -- MP4IndexCreator (hwang/mp4_index_creator.h:23-45) --------------------- */
 typedef struct hwang_mp4_indexer hwang_mp4_indexer;
