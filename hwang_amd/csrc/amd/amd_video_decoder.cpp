@@ -287,6 +287,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.do_intra = d.has_intra;
     sub.desc.do_deblock = d.any_deblock;
     sub.desc.do_mv = d.mv_deferred;
+    static const bool inject = getenv("HWANG_INJECT_FAULT") != nullptr;  // tests/test_gpu_decode.py: the fault path
+    sub.desc.inject_fault = inject ? 1 : 0;
     sub.num_mbs = static_cast<int>(nmb);
     sub.heavy = (d.has_intra && !d.has_inter) ? 1 : 0;
     const uint64_t S = nmb * 384;  // coded I420 bytes

@@ -163,8 +163,22 @@ struct alignas(16) JobDesc {
   uint32_t epoch;      // tags this picture's words in band_ctl (nothing is cleared between pictures); never 0
   uint32_t ticket_db;
   uint32_t ticket_in;
-  uint32_t pad;
+  uint32_t inject_fault;  // test hook (HWANG_INJECT_FAULT): k_deblock's exporting rows withhold their progress word
+  // Pinned host word of the batch this picture travels in.  A row kernel whose
+  // bounded poll of another band expires (a broken hand-off: impossible by
+  // construction, but round 1 shipped one) stores a FAULT_* code here; the
+  // executor reads it when the batch completes and fails every waiter instead
+  // of returning wrong samples.
+  uint32_t* fault;
+  uint64_t reserved;
   UploadDesc uploads[kJobUploads];
+};
+
+enum : uint32_t {
+  FAULT_MV_IMPORT = 1,       // k_mv: line of the band above never arrived
+  FAULT_INTRA_LINE = 2,      // k_intra (LDS neighbours): likewise
+  FAULT_INTRA_PROGRESS = 3,  // k_intra (surface neighbours): progress word of the band above
+  FAULT_DEBLOCK_PROGRESS = 4,
 };
 
 // One colour-conversion / plane-copy request.

@@ -118,7 +118,9 @@ bool GpuExecutor::start(std::string* error) {
   use_hostfunc_ = mode && std::string(mode) == "hostfunc";
   if (hipHostMalloc(reinterpret_cast<void**>(&done_flags_), sizeof(uint32_t) * kEngines * kInflight, hipHostMallocDefault) != hipSuccess)
     return fail("out of memory for completion flags");
-  for (int i = 0; i < kEngines * kInflight; ++i) done_flags_[i] = 0;
+  if (hipHostMalloc(reinterpret_cast<void**>(&fault_flags_), sizeof(uint32_t) * kEngines * kInflight, hipHostMallocDefault) != hipSuccess)
+    return fail("out of memory for completion flags");
+  for (int i = 0; i < kEngines * kInflight; ++i) done_flags_[i] = fault_flags_[i] = 0;
   for (int e = 0; e < kEngines; ++e) engines_[e].thread = std::thread(&GpuExecutor::run, this, e);
   if (!use_hostfunc_) poller_ = std::thread(&GpuExecutor::poll_loop, this);
   return true;
@@ -270,10 +272,29 @@ void GpuExecutor::on_batch_done(void* p) {
   b->owner->complete(b, hipSuccess);
 }
 
+const char* GpuExecutor::fault_name(uint32_t code) {
+  switch (code) {
+    case FAULT_MV_IMPORT: return "k_mv: the motion-vector line of the band above never arrived";
+    case FAULT_INTRA_LINE: return "k_intra: the neighbour line of the band above never arrived";
+    case FAULT_INTRA_PROGRESS: return "k_intra: the band above never reported progress";
+    case FAULT_DEBLOCK_PROGRESS: return "k_deblock: the band above never reported progress";
+    default: return "unknown fault code";
+  }
+}
+
 void GpuExecutor::complete(Batch* b, hipError_t status) {
   std::lock_guard<std::mutex> lk(mu_);
   if (status != hipSuccess && error_.empty())
     error_ = std::string("GpuExecutor: launch failed: ") + hipGetErrorString(status);
+  // A row kernel gave up waiting for another band: the pictures of this batch
+  // (and everything predicted from them) hold wrong samples.  Sticky, like a
+  // launch failure: every lane's wait() fails from here on.
+  if (b->fault) {
+    const uint32_t code = __atomic_load_n(const_cast<uint32_t*>(b->fault), __ATOMIC_ACQUIRE);
+    if (code && error_.empty())
+      error_ = std::string("GpuExecutor: row-pipeline hand-off timed out (") + fault_name(code) +
+               "); the batch's pictures are invalid";
+  }
   const bool failed = !error_.empty();
   for (auto& lc : b->lane_counts) {
     Lane& l = lanes_[lc.first];
@@ -390,6 +411,8 @@ void GpuExecutor::run(int engine) {
       batch.engine = engine;
       batch.ticket = ++next_ticket_;
       batch.flag = done_flags_ + engine * kInflight + slot;
+      batch.fault = fault_flags_ + engine * kInflight + slot;
+      *batch.fault = 0;
       ++en.inflight;
       ++total_inflight_;
       ++stats_.batches;
@@ -416,6 +439,7 @@ void GpuExecutor::run(int engine) {
         jd = p.desc;
         jd.num_uploads = p.ncopies;
         jd.ticket_mv = jd.ticket_db = jd.ticket_in = 0;
+        jd.fault = const_cast<uint32_t*>(batch.fault);
         for (int c = 0; c < p.ncopies; ++c) {
           jd.uploads[c].dst = p.copies[c].dst;
           jd.uploads[c].src = p.copies[c].src;

@@ -133,6 +133,7 @@ class GpuExecutor {
     int engine = 0;
     uint32_t ticket = 0;              // value k_done stores into *flag when the batch is through
     volatile uint32_t* flag = nullptr;  // pinned host memory
+    volatile uint32_t* fault = nullptr; // pinned host memory: FAULT_* code stored by a row kernel whose poll expired
   };
 
   // End of a batch: credits the lanes and wakes waiters.  Detected by the
@@ -143,6 +144,7 @@ class GpuExecutor {
   // process's CPU time, which the entropy decoders need.
   static void on_batch_done(void* batch);
   void complete(Batch* b, hipError_t status);
+  static const char* fault_name(uint32_t code);
   void poll_loop();
 
   static constexpr int kInflight = 3;
@@ -181,6 +183,7 @@ class GpuExecutor {
   std::thread poller_;
   std::condition_variable cv_poll_;
   uint32_t* done_flags_ = nullptr;  // pinned: [kEngines][kInflight]
+  uint32_t* fault_flags_ = nullptr; // pinned: [kEngines][kInflight]
   // How much runs at once (interleaved A/B runs on the C1 probe, 16 CPUs):
   //  * one heavy engine instead of three: same rate and CPU time, but the
   //    intra-only pictures travel in half as many, twice as wide launches that

@@ -608,6 +608,13 @@ struct BandCtl {
 constexpr int kMvLineWords = 5, kIntraLineWords = 8;
 __device__ __forceinline__ int bands_of(int mb_height) { return (mb_height + kBandWaves - 1) / kBandWaves; }
 
+// A bounded poll of another band expired.  The polls are bounded so that a
+// protocol error can never hang the GPU; this makes the same error loud on the
+// host (GpuExecutor::complete fails the batch) instead of silent wrong samples.
+__device__ __forceinline__ void report_fault(const JobDesc& job, uint32_t code) {
+  if (job.fault) __hip_atomic_store((HW_AS1 uint32_t*)job.fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The counters live in LDS and must be addressed as such: through a generic
 // volatile pointer they become flat_load ... sc0 sc1 followed by s_waitcnt
 // vmcnt(0), i.e. every poll would drain the wave's global traffic.
@@ -804,7 +811,10 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
       seen += nvalid;
       if (seen < need) __builtin_amdgcn_s_sleep(1);
     }
-    if (seen < need) seen = need;
+    if (seen < need) {
+      report_fault(job, FAULT_MV_IMPORT);
+      seen = need;
+    }
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wave_sync();
   };
@@ -1144,7 +1154,10 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
       seen += nvalid;
       if (seen < need) __builtin_amdgcn_s_sleep(1);
     }
-    if (seen < need) seen = need;  // impossible by construction; wrong samples rather than a hung GPU
+    if (seen < need) {  // impossible by construction; reported, not hung
+      report_fault(job, FAULT_INTRA_LINE);
+      seen = need;
+    }
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     wave_sync();
   };
@@ -1154,6 +1167,10 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
       const uint64_t v = agent_ld64(&ctl->in_prog[band - 1]);
       if (static_cast<uint32_t>(v >> 32) == epoch) seen = static_cast<int>(static_cast<uint32_t>(v));
       if (seen < need) __builtin_amdgcn_s_sleep(2);
+    }
+    if (seen < need) {
+      report_fault(job, FAULT_INTRA_PROGRESS);
+      seen = need;
     }
     __asm__ volatile("" ::: "memory");
   };
@@ -1739,13 +1756,19 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
   const bool exporting = wave == kBandWaves - 1 && mby + 1 < pp.mb_height;
   if (wave == 0 && band == 0 && lane == 0) s_progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
   int seen = 0;  // importing: macroblocks of the row above known to be final
+  // test hook: a band whose progress words carry a wrong tag looks exactly like a band that never reports
+  const uint64_t epoch_out = job.inject_fault ? epoch ^ (1ull << 63) : epoch;
   auto import_wait = [&](int need) {
     for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
       const uint64_t v = agent_ld64(&ctl->db_prog[band - 1]);
       if ((v & 0xffffffff00000000ull) == epoch) seen = static_cast<int>(static_cast<uint32_t>(v));
       if (seen < need) __builtin_amdgcn_s_sleep(2);
     }
-    __asm__ volatile("" ::: "memory");  // a poll that never succeeds (impossible by construction) ends in wrong samples, not in a hang
+    if (seen < need) {  // a poll that never succeeds (impossible by construction) is reported to the host, and does not hang
+      report_fault(job, FAULT_DEBLOCK_PROGRESS);
+      seen = need;
+    }
+    __asm__ volatile("" ::: "memory");
   };
 
   // lane roles for the dword tile traffic
@@ -1880,7 +1903,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
         // iteration to land: make sure, then everything before this macroblock
         // is final (skipped ones included)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch | static_cast<uint32_t>(mbx)); }
+        if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch_out | static_cast<uint32_t>(mbx)); }
         else progress[wave + 1] = mbx;
         // The prefetched registers are complete too; saying so here keeps the
         // compiler from waiting for them at the top of the next iteration, where
@@ -1915,7 +1938,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
       // (the workgroup-scope fence does not wait for outstanding stores; the band below must not see the
       // counter before the last macroblock's samples)
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) agent_st64(&ctl->db_prog[band], epoch | static_cast<uint32_t>(W));
+      if (lane == 0) agent_st64(&ctl->db_prog[band], epoch_out | static_cast<uint32_t>(W));
     } else {
       progress[wave + 1] = W;
     }

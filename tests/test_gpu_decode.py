@@ -228,3 +228,33 @@ def test_errors_are_loud(hw, gpu, tmp_path):
     dec = hw.Decoder(bad, video_index=idx, num_lanes=1)
     with pytest.raises(RuntimeError):
         dec.retrieve_yuv([0, 1])
+
+
+def test_expired_band_poll_fails_the_request(hw, gpu, tmp_path):
+    """A row kernel whose bounded poll of the band above expires must fail the
+    request, not hand back wrong samples.  HWANG_INJECT_FAULT
+    makes k_deblock's exporting rows tag their progress words with a wrong epoch,
+    which to the band below is a band that never reports.  The error is sticky
+    for the process's executor, hence the child process."""
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    path = str(tmp_path / "fault.mp4")
+    make_clip(path, width=320, height=240, frames=3, gop=3, bframes=0, yuv=False)   # 15 rows = 4 bands
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import hwang_amd as hw\n"
+        "dec = hw.Decoder(%r, num_lanes=1)\n"
+        "try:\n"
+        "    dec.retrieve_yuv([0, 1, 2])\n"
+        "except RuntimeError as e:\n"
+        "    print('RAISED', e)\n"
+        "else:\n"
+        "    print('NO ERROR')\n" % (ROOT, path))
+    import os
+    env = dict(os.environ, HWANG_INJECT_FAULT="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert "RAISED" in r.stdout and "hand-off timed out" in r.stdout and "k_deblock" in r.stdout, r.stdout + r.stderr
+    # and the same clip decodes fine without the hook
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "NO ERROR" in r.stdout, r.stdout + r.stderr
