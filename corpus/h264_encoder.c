@@ -27,6 +27,12 @@ typedef struct {
   int width, height, frames, gop, bframes, qp, cabac, t8x8, refs, slices, seed, threads, repeat;
   int chroma_qp_offset, deblock_idc, alpha_div2, beta_div2, implicit_wp, temporal_direct;
   int intra_only_pcm_period;
+  /* syntax real encoders use by default that the first corpus never emitted */
+  int explicit_wp;  /* PPS weighted_pred_flag = 1, weighted_bipred_idc = 1: pred_weight_table in every P/B slice */
+  int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
+  int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
+  int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int scaling;      /* bit 0: SPS scaling matrices, bit 1: PPS scaling matrices (fall-back rules A and B, default flag) */
   const char* out;
   const char* yuv_out;
   int fps;
@@ -297,7 +303,40 @@ static int level_for(const Cfg* c) {
   return 51;
 }
 
-static int profile_for(const Cfg* c) { return c->t8x8 ? 100 : ((c->cabac || c->bframes) ? 77 : 66); }
+static int profile_for(const Cfg* c) {
+  if (c->t8x8 || c->scaling) return 100;
+  return (c->cabac || c->bframes || c->explicit_wp) ? 77 : 66;
+}
+
+/* scaling_list() syntax (7.3.2.1.1.1).  kind 0: not present (fall-back rule),
+ * 1: all `size` entries explicit, 2: useDefaultScalingMatrixFlag (first
+ * nextScale = 0), 3: explicit up to a hash-chosen position where nextScale
+ * becomes 0 and the last value repeats.  Values 6..56, rising with frequency. */
+static void put_scaling_list(BitWriter* w, int size, int kind, uint32_t seed) {
+  if (kind == 0) {
+    bw_put(w, 0, 1);
+    return;
+  }
+  bw_put(w, 1, 1);
+  if (kind == 2) {
+    bw_se(w, -8);
+    return;
+  }
+  int last = 8;
+  const int stop = kind == 3 ? size / 2 + (int)(seed % 5) : size;
+  for (int j = 0; j < size; ++j) {
+    if (j == stop) {
+      int delta = -last;
+      if (delta < -128) delta += 256;
+      bw_se(w, delta);
+      break;
+    }
+    int v = 6 + j * (size == 16 ? 40 : 10) / 16 + (int)(hash3(seed, (uint32_t)j, (uint32_t)size) % 7);
+    int delta = v - last;
+    bw_se(w, delta);
+    last = v;
+  }
+}
 
 static void write_sps(Enc* e) {
   const Cfg* c = e->cfg;
@@ -312,7 +351,16 @@ static void write_sps(Enc* e) {
     bw_ue(&w, 0);
     bw_ue(&w, 0);
     bw_put(&w, 0, 1); /* qpprime_y_zero_transform_bypass */
-    bw_put(&w, 0, 1); /* seq_scaling_matrix_present */
+    if (c->scaling & 1) {
+      /* Y-intra explicit, Cb-intra falls back to it, Cr-intra explicit, Y-inter "use default",
+       * Cb-inter falls back to that, Cr-inter stops early; 8x8 intra explicit, 8x8 inter absent
+       * (fall-back rule A: the default list) */
+      static const int kinds[8] = {1, 0, 1, 2, 0, 3, 1, 0};
+      bw_put(&w, 1, 1);
+      for (int i = 0; i < 8; ++i) put_scaling_list(&w, i < 6 ? 16 : 64, kinds[i], (uint32_t)c->seed * 31 + i);
+    } else {
+      bw_put(&w, 0, 1); /* seq_scaling_matrix_present */
+    }
   }
   bw_ue(&w, 4);      /* log2_max_frame_num_minus4 -> 8 bits */
   bw_ue(&w, 0);      /* pic_order_cnt_type */
@@ -369,17 +417,24 @@ static void write_pps(Enc* e) {
   bw_ue(&w, 0); /* slice groups */
   bw_ue(&w, c->refs - 1);
   bw_ue(&w, 0);
-  bw_put(&w, 0, 1);                      /* weighted_pred */
-  bw_put(&w, c->implicit_wp ? 2 : 0, 2); /* weighted_bipred_idc */
+  bw_put(&w, c->explicit_wp ? 1 : 0, 1);                           /* weighted_pred */
+  bw_put(&w, c->explicit_wp ? 1 : (c->implicit_wp ? 2 : 0), 2);    /* weighted_bipred_idc */
   bw_se(&w, c->qp - 26);
   bw_se(&w, 0);
   bw_se(&w, c->chroma_qp_offset);
   bw_put(&w, 1, 1); /* deblocking_filter_control_present */
   bw_put(&w, 0, 1); /* constrained_intra_pred */
   bw_put(&w, 0, 1); /* redundant_pic_cnt_present */
-  if (c->t8x8) {
-    bw_put(&w, 1, 1);
-    bw_put(&w, 0, 1);
+  if (c->t8x8 || (c->scaling & 2)) {
+    bw_put(&w, c->t8x8 ? 1 : 0, 1);
+    if (c->scaling & 2) {
+      /* fall-back rule B: absent lists 0 / 3 / 6 / 7 take the SPS's, absent 1, 2, 4, 5 the previous list */
+      static const int kinds[8] = {0, 1, 0, 1, 2, 0, 0, 3};
+      bw_put(&w, 1, 1);
+      for (int i = 0; i < 6 + (c->t8x8 ? 2 : 0); ++i) put_scaling_list(&w, i < 6 ? 16 : 64, kinds[i], (uint32_t)c->seed * 57 + 100 + i);
+    } else {
+      bw_put(&w, 0, 1);
+    }
     bw_se(&w, c->chroma_qp_offset > 0 ? c->chroma_qp_offset - 1 : c->chroma_qp_offset);
   }
   bw_trailing(&w);
@@ -1058,30 +1113,286 @@ typedef struct {
   int display;   /* index inside GOP */
   int frame_num;
   int is_ref;
+  int ref_ordinal; /* k-th reference picture of the GOP (IDR = 0) */
+  int mmco5;       /* this picture carries memory_management_control_operation 5 */
+  int poc_base;    /* display index of the last MMCO-5 picture before this one (POC restarts there) */
 } PicPlan;
 
-static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int first_mb, int nrefs_l0) {
+/* dec_ref_pic_marking of one picture (identical in all its slices) */
+typedef struct {
+  int idr_long;    /* IDR: long_term_reference_flag */
+  int adaptive;
+  int n;
+  int op[12], a[12], b[12];
+} Marking;
+
+/* The reference pictures in the oracle's DPB as the slice header syntax names
+ * them: PicNum of the short-term ones (8.2.4.1, relative to the current
+ * frame_num), LongTermPicNum of the long-term ones. */
+typedef struct {
+  int n_st, st_pn[MAX_DPB];
+  int n_lt, lt_idx[MAX_DPB];
+  int max_lt;
+} DpbView;
+
+static void dpb_view(const H264Oracle* d, int cur_frame_num, DpbView* v) {
+  memset(v, 0, sizeof(*v));
+  const int max_fn = 1 << d->sps[0].log2_max_frame_num;
+  for (int i = 0; i < MAX_DPB; ++i) {
+    const Picture* p = &d->pool[i];
+    if (!p->in_pool_use || p == d->cur) continue;
+    if (p->ref == 1) v->st_pn[v->n_st++] = p->frame_num > cur_frame_num ? p->frame_num - max_fn : p->frame_num;
+    else if (p->ref == 2) v->lt_idx[v->n_lt++] = p->long_term_idx;
+  }
+  v->max_lt = d->max_long_term_frame_idx;
+}
+
+static int dpb_refs(const H264Oracle* d) {
+  int n = 0;
+  for (int i = 0; i < MAX_DPB; ++i) n += d->pool[i].in_pool_use && &d->pool[i] != d->cur && d->pool[i].ref != 0;
+  return n;
+}
+
+/* Adaptive marking script.  Keeps the standard's constraint that at most
+ * max_num_ref_frames pictures are marked after the current one is added, and
+ * walks through every operation over the reference pictures of a GOP. */
+static void plan_marking(const Enc* e, const PicPlan* pp, Marking* m) {
   const Cfg* c = e->cfg;
+  memset(m, 0, sizeof(*m));
+  if (!c->mmco || !pp->is_ref) return;
+  if (pp->type == 2) {
+    m->idr_long = (e->frame_abs / c->gop) & 1;
+    return;
+  }
+  DpbView v;
+  dpb_view(e->d, pp->frame_num, &v);
+  const int maxrefs = c->refs, cur = pp->frame_num;
+  const uint32_t h = hash3((uint32_t)c->seed + 21, (uint32_t)e->frame_abs, 7);
+#define OP(o, x, y) do { m->op[m->n] = (o); m->a[m->n] = (x); m->b[m->n] = (y); m->n++; } while (0)
+  int cur_long = 0, cur_idx = -1;
+  if (pp->mmco5) {
+    OP(5, 0, 0);
+    m->adaptive = 1;
+    return;
+  }
+  /* helpers on the simulated state */
+  int oldest, newest;
+#define FIND_ST() do { oldest = newest = -1; for (int i = 0; i < v.n_st; ++i) { if (oldest < 0 || v.st_pn[i] < v.st_pn[oldest]) oldest = i; if (newest < 0 || v.st_pn[i] > v.st_pn[newest]) newest = i; } } while (0)
+#define DROP_ST(i) do { v.st_pn[(i)] = v.st_pn[--v.n_st]; } while (0)
+#define DROP_LT_IDX(x) do { for (int q = 0; q < v.n_lt; ++q) if (v.lt_idx[q] == (x)) { v.lt_idx[q] = v.lt_idx[--v.n_lt]; --q; } } while (0)
+  switch (pp->ref_ordinal % 6) {
+    case 1: /* oldest short-term picture becomes long-term */
+      FIND_ST();
+      if (oldest >= 0) {
+        if (v.max_lt < 1) {
+          OP(4, 2, 0);
+          v.max_lt = 1;
+        }
+        int idx = 0;
+        for (int q = 0; q < v.n_lt; ++q) if (v.lt_idx[q] == 0) idx = 1;
+        OP(3, cur - v.st_pn[oldest] - 1, idx);
+        DROP_LT_IDX(idx);
+        DROP_ST(oldest);
+        v.lt_idx[v.n_lt++] = idx;
+      }
+      break;
+    case 2: { /* the current picture becomes long-term */
+      if (v.max_lt < 0) {
+        OP(4, 1, 0);
+        v.max_lt = 0;
+      }
+      const int idx = v.max_lt >= 1 ? (int)(h & 1) : 0;
+      OP(6, idx, 0);
+      DROP_LT_IDX(idx);
+      cur_long = 1;
+      cur_idx = idx;
+      v.lt_idx[v.n_lt++] = idx;
+      break;
+    }
+    case 3: /* sliding window */
+      break;
+    case 4: /* a long-term picture goes, else the newest short-term one */
+      FIND_ST();
+      if (v.n_lt) {
+        const int idx = v.lt_idx[0];
+        OP(2, idx, 0);
+        DROP_LT_IDX(idx);
+      } else if (newest >= 0 && v.n_st >= 2) {
+        OP(1, cur - v.st_pn[newest] - 1, 0);
+        DROP_ST(newest);
+      }
+      break;
+    case 5: /* the second newest short-term picture goes */
+      if (v.n_st >= 2) {
+        FIND_ST();
+        int second = -1;
+        for (int i = 0; i < v.n_st; ++i)
+          if (i != newest && (second < 0 || v.st_pn[i] > v.st_pn[second])) second = i;
+        OP(1, cur - v.st_pn[second] - 1, 0);
+        DROP_ST(second);
+      }
+      break;
+    default: { /* max long-term index shrinks */
+      const int keep = (int)(h & 1); /* MaxLongTermFrameIdx = keep - 1 */
+      if (v.n_lt || v.max_lt >= keep) {
+        OP(4, keep, 0);
+        for (int q = 0; q < v.n_lt; ++q)
+          if (v.lt_idx[q] > keep - 1) {
+            v.lt_idx[q] = v.lt_idx[--v.n_lt];
+            --q;
+          }
+        v.max_lt = keep - 1;
+      }
+      break;
+    }
+  }
+  if (m->n == 0) {
+    /* sliding window: legal when it can find a short-term picture to drop, or nothing has to go */
+    if (v.n_st + v.n_lt < maxrefs || v.n_st > 0) return;
+  }
+  /* make room for the current picture (adaptive mode has no sliding window) */
+  while (v.n_st + v.n_lt + (cur_long ? 0 : 1) > maxrefs || (cur_long && v.n_st + v.n_lt > maxrefs)) {
+    FIND_ST();
+    if (oldest >= 0) {
+      OP(1, cur - v.st_pn[oldest] - 1, 0);
+      DROP_ST(oldest);
+    } else {
+      int big = -1;
+      for (int q = 0; q < v.n_lt; ++q)
+        if (v.lt_idx[q] != cur_idx && (big < 0 || v.lt_idx[q] > v.lt_idx[big])) big = q;
+      if (big < 0) break; /* only the current picture is left */
+      OP(2, v.lt_idx[big], 0);
+      v.lt_idx[big] = v.lt_idx[--v.n_lt];
+    }
+  }
+  m->adaptive = m->n > 0;
+#undef OP
+#undef FIND_ST
+#undef DROP_ST
+#undef DROP_LT_IDX
+}
+
+/* ref_pic_list_modification (7.3.3.1) for list `list` with `nactive` entries:
+ * moves one or two hash-chosen reference pictures (short-term by PicNum
+ * difference, both signs; long-term by LongTermPicNum) to the front. */
+static void write_rplm(const Enc* e, BitWriter* w, const PicPlan* pp, int nactive, uint32_t h) {
+  DpbView v;
+  dpb_view(e->d, pp->frame_num, &v);
+  if (!e->cfg->rplm || v.n_st + v.n_lt < 2 || h % 3 == 0) {
+    bw_put(w, 0, 1);
+    return;
+  }
+  bw_put(w, 1, 1);
+  const int max_pn = 1 << e->d->sps[0].log2_max_frame_num;
+  int pred = pp->frame_num; /* picNumLXPred, kept in [0, MaxPicNum) like the decoder does */
+  const int nops = 1 + (int)((h >> 4) % (unsigned)imin(2, nactive));
+  int used_st[MAX_DPB] = {0}, used_lt[MAX_DPB] = {0};
+  for (int k = 0; k < nops; ++k) {
+    const uint32_t hk = hash32(h + 77u * (uint32_t)k);
+    int done = 0;
+    if (v.n_lt && ((hk & 3) == 0 || !v.n_st)) {
+      for (int t = 0; t < v.n_lt && !done; ++t) {
+        const int j = (int)((hk >> 3) + t) % v.n_lt;
+        if (used_lt[j]) continue;
+        used_lt[j] = 1;
+        bw_ue(w, 2);
+        bw_ue(w, v.lt_idx[j]);
+        done = 1;
+      }
+    }
+    for (int t = 0; t < v.n_st && !done; ++t) {
+      const int j = (int)((hk >> 3) + t) % v.n_st;
+      if (used_st[j]) continue;
+      const int target = v.st_pn[j] < 0 ? v.st_pn[j] + max_pn : v.st_pn[j];
+      if (target == pred) continue;
+      used_st[j] = 1;
+      if (target < pred) {
+        bw_ue(w, 0);
+        bw_ue(w, pred - target - 1);
+      } else {
+        bw_ue(w, 1);
+        bw_ue(w, target - pred - 1);
+      }
+      pred = target;
+      done = 1;
+    }
+  }
+  bw_ue(w, 3);
+}
+
+/* pred_weight_table (7.3.3.2): per reference a hash-chosen mix of flags,
+ * weights around 2^denom and small offsets; chroma uses its own denominator. */
+static void write_pwt(const Enc* e, BitWriter* w, const PicPlan* pp, int nl0, int nl1, uint32_t h) {
+  const int ld = e->cfg->wp_denom, cd = (ld + 6) & 7;
+  bw_ue(w, ld);
+  bw_ue(w, cd);
+  for (int l = 0; l < (pp->type == 1 ? 2 : 1); ++l)
+    for (int i = 0; i < (l ? nl1 : nl0); ++i) {
+      const uint32_t hi = hash3(h, (uint32_t)(l * 32 + i), 5);
+      /* B slices: w0 + w1 <= 128 (127 at denominator 7) */
+      const int cap_l = pp->type == 1 && ld >= 6 ? (ld == 7 ? 63 : 64) : 127;
+      const int cap_c = pp->type == 1 && cd >= 6 ? (cd == 7 ? 63 : 64) : 127;
+      const int lf = (hi & 3) != 0;
+      bw_put(w, lf, 1);
+      if (lf) {
+        int wv = (1 << ld) + (ld >= 3 ? (int)((hi >> 2) % 7) - 3 : (ld >= 1 ? (int)((hi >> 2) % 3) - 1 : 0));
+        bw_se(w, iclip(-128, cap_l, wv));
+        bw_se(w, (int)((hi >> 8) % 11) - 5);
+      }
+      const int cf = ((hi >> 12) & 3) != 0;
+      bw_put(w, cf, 1);
+      if (cf)
+        for (int pl = 0; pl < 2; ++pl) {
+          int wv = (1 << cd) + (cd >= 3 ? (int)((hi >> (14 + 3 * pl)) % 5) - 2 : (cd >= 1 ? (int)((hi >> (14 + 3 * pl)) % 3) - 1 : 0));
+          bw_se(w, iclip(-128, cap_c, wv));
+          bw_se(w, (int)((hi >> (20 + 4 * pl)) % 9) - 4);
+        }
+    }
+}
+
+static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int first_mb, int nrefs_l0, const Marking* mk) {
+  const Cfg* c = e->cfg;
+  const uint32_t hs = hash3((uint32_t)c->seed + 13, (uint32_t)e->frame_abs, (uint32_t)first_mb);
   bw_ue(w, first_mb);
   bw_ue(w, pp->type);
   bw_ue(w, 0);
   bw_put(w, pp->frame_num & 255, 8);
   if (pp->type == 2) bw_ue(w, (e->frame_abs / c->gop) & 1); /* idr_pic_id */
-  bw_put(w, (pp->display * 2) & 255, 8);
+  bw_put(w, ((pp->display - pp->poc_base) * 2) & 255, 8);
   if (pp->type == 1) bw_put(w, c->temporal_direct ? 0 : 1, 1);
   if (pp->type != 2) {
+    const int nl0 = pp->type == 1 ? 1 : nrefs_l0;
     bw_put(w, 1, 1); /* num_ref_idx_active_override */
-    bw_ue(w, (pp->type == 1 ? 1 : nrefs_l0) - 1);
+    bw_ue(w, nl0 - 1);
     if (pp->type == 1) bw_ue(w, 0);
-    bw_put(w, 0, 1); /* ref_pic_list_modification_flag_l0 */
-    if (pp->type == 1) bw_put(w, 0, 1);
+    /* temporal direct needs the co-located block's reference in list 0: leave B lists alone there */
+    const int mod_ok = pp->type == 0 || !c->temporal_direct;
+    if (mod_ok) write_rplm(e, w, pp, nl0, hs);
+    else bw_put(w, 0, 1); /* ref_pic_list_modification_flag_l0 */
+    if (pp->type == 1) {
+      if (mod_ok) write_rplm(e, w, pp, 1, hash32(hs + 3));
+      else bw_put(w, 0, 1);
+    }
+    if (c->explicit_wp) write_pwt(e, w, pp, nl0, 1, hash32(hs + 9));
   }
   if (pp->is_ref) {
     if (pp->type == 2) {
       bw_put(w, 0, 1);
-      bw_put(w, 0, 1);
+      bw_put(w, mk->idr_long, 1);
     } else {
-      bw_put(w, 0, 1); /* sliding window */
+      bw_put(w, mk->adaptive, 1);
+      if (mk->adaptive) {
+        for (int k = 0; k < mk->n; ++k) {
+          const int op = mk->op[k];
+          bw_ue(w, op);
+          if (op == 1 || op == 3) bw_ue(w, mk->a[k]);
+          if (op == 2) bw_ue(w, mk->a[k]);
+          if (op == 3) bw_ue(w, mk->b[k]);
+          if (op == 6) bw_ue(w, mk->a[k]);
+          if (op == 4) bw_ue(w, mk->a[k]);
+        }
+        bw_ue(w, 0);
+      }
     }
   }
   if (c->cabac && pp->type != 2) bw_ue(w, (e->frame_abs + first_mb) % 3);
@@ -1103,12 +1414,14 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
   const int nal_type = pp->type == 2 ? 5 : 1;
   const int ref_idc = pp->is_ref ? (pp->type == 2 ? 3 : 2) : 0;
   const int nslices = imin(c->slices, mbh);
+  Marking mk;
+  plan_marking(e, pp, &mk); /* from the DPB as it is before this picture; the same in every slice */
 
   for (int s = 0; s < nslices; ++s) {
     const int row0 = s * mbh / nslices, row1 = (s + 1) * mbh / nslices;
     BitWriter* w = &e->w;
     w->pos = 0;
-    write_slice_header(e, w, pp, row0 * mbw, nrefs_l0);
+    write_slice_header(e, w, pp, row0 * mbw, nrefs_l0, &mk);
     /* let the oracle parse the header it will later be given: builds the
      * reference lists, POC, starts the picture */
     {
@@ -1161,15 +1474,22 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
 
 /* GOP structure in coding order */
 static int plan_gop(const Cfg* c, int n, PicPlan* out) {
-  int k = 0, fn = 0;
-  out[k++] = (PicPlan){2, 0, 0, 1};
+  int k = 0, fn = 0, ordinal = 0, poc_base = 0;
+  out[k++] = (PicPlan){2, 0, 0, 1, 0, 0, 0};
   int prev_anchor = 0;
   while (prev_anchor < n - 1) {
     int anchor = imin(prev_anchor + c->bframes + 1, n - 1);
     /* closed GOP: the tail is coded as P pictures */
     fn = (fn + 1) & 255;
-    out[k++] = (PicPlan){0, anchor, fn, 1};
-    for (int b = prev_anchor + 1; b < anchor; ++b) out[k++] = (PicPlan){1, b, (fn + 1) & 255, 0};
+    ++ordinal;
+    /* MMCO 5 on every 5th reference picture (only without B pictures: it acts like an IDR for output order) */
+    const int mmco5 = c->mmco == 2 && c->bframes == 0 && ordinal % 5 == 4;
+    out[k++] = (PicPlan){0, anchor, fn, 1, ordinal, mmco5, poc_base};
+    for (int b = prev_anchor + 1; b < anchor; ++b) out[k++] = (PicPlan){1, b, (fn + 1) & 255, 0, ordinal, 0, poc_base};
+    if (mmco5) { /* the picture counts as frame_num 0 / POC 0 from here on (8.2.1) */
+      fn = 0;
+      poc_base = anchor;
+    }
     prev_anchor = anchor;
   }
   return k;
@@ -1197,15 +1517,15 @@ static int encode_gop(Enc* e, int gop_index, int nframes, GopOut* out, int want_
   e->sstride[1] = e->sstride[2] = W / 2;
   const size_t fsz = (size_t)c->width * c->height * 3 / 2;
   if (want_recon) out->recon = (uint8_t*)malloc(fsz * nframes);
-  int refs_available = 0, k = 0;
+  int k = 0;
   for (int i = 0; i <= n; ++i) {
     if (i < n) {
       e->frame_abs = gop_index * c->gop + plans[i].display;
       scene_render(&e->scene, e->frame_abs);
-      if (plans[i].type == 2) refs_available = 0;
+      /* what the DPB holds (marking operations make this more than a count of coded pictures) */
+      const int refs_available = plans[i].type == 2 ? 0 : dpb_refs(d);
       int nl0 = imax(1, imin(c->temporal_direct ? 1 : c->refs, refs_available));
       if (encode_picture(e, &plans[i], nl0, &out->samples[i]) < 0) return -1;
-      if (plans[i].is_ref) refs_available++;
     } else {
       h264o_flush(d);
     }
@@ -1472,6 +1792,13 @@ int main(int argc, char** argv) {
   c.implicit_wp = arg_int(argc, argv, "--implicit-wp", 0);
   c.temporal_direct = arg_int(argc, argv, "--temporal-direct", 0);
   c.intra_only_pcm_period = arg_int(argc, argv, "--pcm-period", 4099);
+  c.explicit_wp = arg_int(argc, argv, "--explicit-wp", 0);
+  c.wp_denom = arg_int(argc, argv, "--wp-denom", 5);
+  c.rplm = arg_int(argc, argv, "--rplm", 0);
+  c.mmco = arg_int(argc, argv, "--mmco", 0);
+  c.scaling = arg_int(argc, argv, "--scaling", 0);
+  if (c.wp_denom < 0 || c.wp_denom > 7) c.wp_denom = 5;
+  if (c.explicit_wp) c.implicit_wp = 0;
   c.out = arg_str(argc, argv, "--out", "out.mp4");
   c.yuv_out = arg_str(argc, argv, "--yuv-out", NULL);
   if (c.refs < 1) c.refs = 1;

@@ -25,6 +25,15 @@ i32p = C.POINTER(C.c_int32)
 vp = C.c_void_p
 
 
+class RetrieveRequestStruct(C.Structure):
+    """hwang_retrieve_request (one clip of hwang_retriever_retrieve_batch)."""
+    _fields_ = [
+        ("index", C.c_void_p), ("file", C.c_void_p), ("file_size", C.c_size_t),
+        ("rows", C.POINTER(C.c_uint64)), ("num_rows", C.c_size_t),
+        ("out", C.c_void_p), ("out_capacity", C.c_size_t),
+    ]
+
+
 class EncodedDataStruct(C.Structure):
     """hwang_encoded_data (DecoderAutomata::EncodedData, decoder_automata.h:43-66)."""
     _fields_ = [
@@ -104,6 +113,11 @@ PROTOTYPES = {
     "hwang_automata_stamp_trace": (C.c_int, [vp, i32p]),
     # parallel retriever
     "hwang_retriever_create": (vp, [C.c_int, C.c_int32, C.c_int, C.c_int32]),
+    "hwang_retriever_create_multi": (vp, [C.c_int, i32p, C.c_size_t, C.c_int, C.c_int32]),
+    "hwang_retriever_set_shard": (C.c_int, [vp, C.c_int32, C.c_int32]),
+    "hwang_retriever_num_lanes": (C.c_int32, [vp]),
+    "hwang_retriever_retrieve_batch": (C.c_int, [vp, C.POINTER(RetrieveRequestStruct), C.c_size_t, C.c_int]),
+    "hwang_retriever_device_stats": (None, [vp, C.c_int32, i64p]),
     "hwang_retriever_destroy": (None, [vp]),
     "hwang_retriever_retrieve": (C.c_int, [vp, vp, vp, C.c_size_t, u64p, C.c_size_t, vp, C.c_size_t, C.c_int]),
     "hwang_retriever_last_error": (C.c_char_p, [vp]),

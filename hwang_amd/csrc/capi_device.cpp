@@ -7,6 +7,7 @@
 #include "video_decoder_factory.h"
 #include "video_index.h"
 
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -120,14 +121,77 @@ hwang_retriever* hwang_retriever_create(int device_type, int32_t device_id,
   h->r.reset(r);
   return h;
 }
+hwang_retriever* hwang_retriever_create_multi(int device_type, const int32_t* device_ids,
+                                              size_t num_devices, int decoder_type,
+                                              int32_t num_lanes) {
+  if (!device_ids || !num_devices) return nullptr;
+  std::vector<DeviceHandle> devices;
+  for (size_t i = 0; i < num_devices; ++i)
+    devices.push_back(DeviceHandle{static_cast<DeviceType>(device_type), device_ids[i]});
+  ParallelRetriever* r = nullptr;
+  try {
+    r = ParallelRetriever::make(devices, static_cast<VideoDecoderType>(decoder_type), num_lanes);
+  } catch (...) {
+  }
+  if (!r) return nullptr;
+  auto* h = new (std::nothrow) hwang_retriever;
+  if (!h) {
+    delete r;
+    return nullptr;
+  }
+  h->r.reset(r);
+  return h;
+}
+int hwang_retriever_set_shard(hwang_retriever* r, int32_t rank, int32_t world) {
+  Result res = r->r->set_shard(rank, world);
+  if (!res.ok) r->error = res.message;
+  return res.ok ? 0 : 1;
+}
+int32_t hwang_retriever_num_lanes(hwang_retriever* r) { return r->r->num_lanes(); }
+int hwang_retriever_retrieve_batch(hwang_retriever* r, const hwang_retrieve_request* requests,
+                                   size_t num_requests, int out_is_yuv) {
+  Result res;
+  try {
+    std::vector<ParallelRetriever::Request> reqs(num_requests);
+    for (size_t i = 0; i < num_requests; ++i) {
+      if (!requests[i].index) {
+        r->error = "retrieve_batch: request without an index";
+        return 1;
+      }
+      reqs[i].index = &requests[i].index->v;
+      reqs[i].file = requests[i].file;
+      reqs[i].file_size = requests[i].file_size;
+      reqs[i].rows = requests[i].rows;
+      reqs[i].num_rows = requests[i].num_rows;
+      reqs[i].out = requests[i].out;
+      reqs[i].out_capacity = requests[i].out_capacity;
+    }
+    res = r->r->retrieve_batch(reqs, out_is_yuv != 0);
+  } catch (const std::exception& e) {
+    res = Result(false, std::string("retrieve_batch: ") + e.what());
+  }
+  if (!res.ok) r->error = res.message;
+  return res.ok ? 0 : 1;
+}
+void hwang_retriever_device_stats(hwang_retriever* r, int32_t device_slot, int64_t stats[4]) {
+  ParallelRetriever::DeviceStats s = r->r->device_stats(device_slot);
+  stats[0] = s.lanes;
+  stats[1] = s.items;
+  stats[2] = s.frames_returned;
+  stats[3] = s.samples_fed;
+}
 void hwang_retriever_destroy(hwang_retriever* r) { delete r; }
 int hwang_retriever_retrieve(hwang_retriever* r, const hwang_video_index* index,
                              const uint8_t* file, size_t file_size,
                              const uint64_t* rows, size_t num_rows,
                              uint8_t* out, size_t out_capacity, int out_is_yuv) {
-  Result res = r->r->retrieve(index->v, file, file_size,
-                              std::vector<uint64_t>(rows, rows + num_rows), out,
-                              out_capacity, out_is_yuv != 0);
+  Result res;
+  try {
+    res = r->r->retrieve(index->v, file, file_size, std::vector<uint64_t>(rows, rows + num_rows), out,
+                         out_capacity, out_is_yuv != 0);
+  } catch (const std::exception& e) {
+    res = Result(false, std::string("retrieve: ") + e.what());
+  }
   if (!res.ok) r->error = res.message;
   return res.ok ? 0 : 1;
 }

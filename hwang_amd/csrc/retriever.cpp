@@ -5,6 +5,7 @@
 #include <pthread.h>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <thread>
 
 namespace hwang {
@@ -37,25 +38,40 @@ int32_t ParallelRetriever::effective_cpus() {
   return std::max<int32_t>(1, static_cast<int32_t>(cpus + 0.5));
 }
 
-ParallelRetriever* ParallelRetriever::make(DeviceHandle device,
+ParallelRetriever* ParallelRetriever::make(const std::vector<DeviceHandle>& devices,
                                            VideoDecoderType type,
                                            int32_t num_lanes) {
+  if (devices.empty()) return nullptr;
   // A lane waits for the GPU about as long as it parses (a picture's latency
   // through the batching pipeline is comparable to its parse time), so it takes
   // a few lanes per CPU to keep the CPUs - the bottleneck - busy; measured on a
   // 16-CPU quota: 32 / 40 / 48 / 64 lanes -> 660 / 676 / 698 / 651 frames/s.
+  // The CPUs are the process's, however many GPUs it drives: more devices do
+  // not mean more lanes, only fewer lanes per device.
   const bool auto_lanes = num_lanes <= 0;
   if (auto_lanes) num_lanes = std::min<int32_t>(3 * effective_cpus(), 128);
+  num_lanes = std::max<int32_t>(num_lanes, auto_lanes ? static_cast<int32_t>(devices.size()) : 1);
   std::unique_ptr<ParallelRetriever> r(new ParallelRetriever());
   r->auto_lanes_ = auto_lanes;
+  r->devices_ = devices;
+  r->device_stats_.resize(devices.size());
   r->lanes_.resize(num_lanes);
-  for (Lane& lane : r->lanes_) {
+  for (int32_t li = 0; li < num_lanes; ++li) {
+    Lane& lane = r->lanes_[li];
+    lane.device_slot = li % static_cast<int32_t>(devices.size());
     for (auto& b : lane.backend) {
-      b.reset(VideoDecoderFactory::make_from_config(device, 1, type));
+      b.reset(VideoDecoderFactory::make_from_config(devices[lane.device_slot], static_cast<uint32_t>(devices.size()), type));
       if (!b) return nullptr;
     }
   }
   return r.release();
+}
+
+Result ParallelRetriever::set_shard(int32_t rank, int32_t world) {
+  if (world < 1 || rank < 0 || rank >= world) return Result(false, "set_shard: need 0 <= rank < world");
+  shard_rank_ = rank;
+  shard_world_ = world;
+  return Result();
 }
 
 ParallelRetriever::~ParallelRetriever() {}
@@ -134,65 +150,121 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
                                    size_t file_size,
                                    const std::vector<uint64_t>& rows,
                                    uint8_t* out, size_t out_capacity, bool yuv) {
+  Request rq;
+  rq.index = &index;
+  rq.file = file;
+  rq.file_size = file_size;
+  rq.rows = rows.data();
+  rq.num_rows = rows.size();
+  rq.out = out;
+  rq.out_capacity = out_capacity;
+  return retrieve_batch(std::vector<Request>{rq}, yuv);
+}
+
+namespace {
+size_t frame_bytes_of(const VideoIndex& index, bool yuv) {
+  const size_t w = index.frame_width(), h = index.frame_height();
+  return yuv ? w * h + 2 * ((w + 1) / 2) * ((h + 1) / 2) : w * h * 3;
+}
+// (width, height, format, avcC) as one comparable blob
+std::vector<uint8_t> config_key_of(const VideoIndex& index) {
+  std::vector<uint8_t> k;
+  const uint32_t wh[2] = {index.frame_width(), index.frame_height()};
+  k.insert(k.end(), reinterpret_cast<const uint8_t*>(wh), reinterpret_cast<const uint8_t*>(wh) + sizeof(wh));
+  k.insert(k.end(), index.format().begin(), index.format().end());
+  k.push_back(0);
+  k.insert(k.end(), index.metadata_bytes().begin(), index.metadata_bytes().end());
+  return k;
+}
+}  // namespace
+
+Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, bool yuv) {
   const auto t0 = std::chrono::steady_clock::now();
   stats_ = Stats();
-  const size_t w = index.frame_width(), h = index.frame_height();
-  const size_t frame_bytes =
-      yuv ? w * h + 2 * ((w + 1) / 2) * ((h + 1) / 2) : w * h * 3;
-  if (out_capacity < frame_bytes * rows.size()) {
-    return Result(false, "retrieve: output buffer too small");
-  }
-  if (rows.empty()) return Result();
-  if (!std::is_sorted(rows.begin(), rows.end())) {
-    return Result(false, "retrieve: rows must be sorted ascending");
-  }
-  if (!index.consistent()) return Result(false, "retrieve: inconsistent index: " + index.problem());
-  bool ok = true;
-  VideoIntervals plan = slice_into_video_intervals(index, rows, &ok);
-  if (!ok) return Result(false, "retrieve: row out of range");
+  for (DeviceStats& ds : device_stats_) ds = DeviceStats();
+  for (const Lane& lane : lanes_) ++device_stats_[lane.device_slot].lanes;
 
   // Work items.  The planner merges byte-adjacent GOPs into one interval
   // (one seek for the reference's serial loop); every GOP still starts at a
   // sync sample, so for parallel decoding each GOP that holds a wanted row is
   // its own item, fed only up to its last wanted frame.
   std::vector<WorkItem> items;
-  std::vector<std::vector<uint64_t>> item_rows;
-  item_rows.reserve(rows.size());
-  size_t slot = 0;
-  const auto& sizes = index.sample_sizes();
-  const auto& kfs = index.keyframe_indices();
-  for (size_t i = 0; i < plan.sample_index_intervals.size(); ++i) {
-    const std::vector<uint64_t>& valid = plan.valid_frames[i];
-    if (valid.empty()) continue;
-    const uint64_t istart = std::get<0>(plan.sample_index_intervals[i]);
-    const uint64_t iend = std::get<1>(plan.sample_index_intervals[i]);
-    size_t k = std::upper_bound(kfs.begin(), kfs.end(), istart) - kfs.begin();  // first keyframe after istart
-    uint64_t gop_start = istart;
-    size_t v = 0;
-    while (v < valid.size()) {
-      const uint64_t gop_end = (k < kfs.size() && kfs[k] < iend) ? kfs[k] : iend;
-      size_t v2 = v;
-      while (v2 < valid.size() && valid[v2] < gop_end) ++v2;
-      if (v2 > v) {
-        item_rows.emplace_back(valid.begin() + v, valid.begin() + v2);
-        WorkItem it;
-        it.start = gop_start;
-        it.end = gop_end;
-        it.valid = nullptr;  // fixed up below (item_rows may still grow)
-        it.out_slot = slot;
-        slot += v2 - v;
-        const uint64_t last = std::min<uint64_t>(it.end, item_rows.back().back() + 4);
-        for (uint64_t s2 = it.start; s2 < last; ++s2) it.cost += sizes[s2];
-        items.push_back(it);
+  std::deque<std::vector<uint64_t>> item_rows;  // stable addresses while it grows
+  std::vector<std::vector<uint8_t>> keys(requests.size());
+  std::vector<size_t> frame_bytes(requests.size());
+  int64_t largest_picture = 0;
+  for (size_t ri = 0; ri < requests.size(); ++ri) {
+    const Request& rq = requests[ri];
+    if (!rq.index || (rq.num_rows && (!rq.rows || !rq.out || !rq.file)))
+      return Result(false, "retrieve: request " + std::to_string(ri) + " has a null argument");
+    const VideoIndex& index = *rq.index;
+    frame_bytes[ri] = frame_bytes_of(index, yuv);
+    if (rq.out_capacity < frame_bytes[ri] * rq.num_rows) return Result(false, "retrieve: output buffer too small");
+    if (!rq.num_rows) continue;
+    if (!index.consistent()) return Result(false, "retrieve: inconsistent index: " + index.problem());
+    const std::vector<uint64_t> rows(rq.rows, rq.rows + rq.num_rows);
+    if (!std::is_sorted(rows.begin(), rows.end())) return Result(false, "retrieve: rows must be sorted ascending");
+    bool ok = true;
+    VideoIntervals plan = slice_into_video_intervals(index, rows, &ok);
+    if (!ok) return Result(false, "retrieve: row out of range");
+    keys[ri] = config_key_of(index);
+    largest_picture = std::max<int64_t>(largest_picture, static_cast<int64_t>(index.frame_width()) * index.frame_height());
+
+    size_t slot = 0;
+    const auto& sizes = index.sample_sizes();
+    const auto& kfs = index.keyframe_indices();
+    for (size_t i = 0; i < plan.sample_index_intervals.size(); ++i) {
+      const std::vector<uint64_t>& valid = plan.valid_frames[i];
+      if (valid.empty()) continue;
+      const uint64_t istart = std::get<0>(plan.sample_index_intervals[i]);
+      const uint64_t iend = std::get<1>(plan.sample_index_intervals[i]);
+      size_t k = std::upper_bound(kfs.begin(), kfs.end(), istart) - kfs.begin();  // first keyframe after istart
+      uint64_t gop_start = istart;
+      size_t v = 0;
+      while (v < valid.size()) {
+        const uint64_t gop_end = (k < kfs.size() && kfs[k] < iend) ? kfs[k] : iend;
+        size_t v2 = v;
+        while (v2 < valid.size() && valid[v2] < gop_end) ++v2;
+        if (v2 > v) {
+          item_rows.emplace_back(valid.begin() + v, valid.begin() + v2);
+          WorkItem it;
+          it.request = static_cast<uint32_t>(ri);
+          it.start = gop_start;
+          it.end = gop_end;
+          it.valid = &item_rows.back();
+          it.out_slot = slot;
+          slot += v2 - v;
+          const uint64_t last = std::min<uint64_t>(it.end, item_rows.back().back() + 4);
+          for (uint64_t s2 = it.start; s2 < last; ++s2) it.cost += sizes[s2];
+          items.push_back(it);
+        }
+        v = v2;
+        gop_start = gop_end;
+        ++k;
+        if (gop_end >= iend) break;
       }
-      v = v2;
-      gop_start = gop_end;
-      ++k;
-      if (gop_end >= iend) break;
     }
   }
-  for (size_t i = 0; i < items.size(); ++i) items[i].valid = &item_rows[i];
-  stats_.intervals = static_cast<int64_t>(items.size());
+
+  // Longest first.  The order is a pure function of the requests (ties broken
+  // by request and position), so every rank of a sharded job computes the same.
+  std::vector<size_t> order(items.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    return items[a].cost > items[b].cost;
+  });
+  if (shard_world_ > 1) {
+    // LPT split: each item, longest first, to the share with the least work so far.
+    std::vector<uint64_t> load(shard_world_, 0);
+    std::vector<size_t> mine;
+    for (size_t k : order) {
+      const int32_t to = static_cast<int32_t>(std::min_element(load.begin(), load.end()) - load.begin());
+      load[to] += items[k].cost + 1;
+      if (to == shard_rank_) mine.push_back(k);
+    }
+    order.swap(mine);
+  }
+  stats_.intervals = static_cast<int64_t>(order.size());
   // Order of the shared work queue.  Longest-first (LPT) balances the tail,
   // but sorted items keep all lanes in lock-step: every lane reaches its next
   // keyframe at the same moment, the GPU sees a burst of intra-only pictures
@@ -200,11 +272,6 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
   // of overlapping.  So only the shortest quarter stays sorted (at the end,
   // where it evens out the finish); everything before it is shuffled with a
   // fixed seed.
-  std::vector<size_t> order(items.size());
-  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) {
-    return items[a].cost > items[b].cost;
-  });
   if (order.size() > 2 * lanes_.size()) {
     uint64_t state = 0x9e3779b97f4a7c15ull;
     const size_t head = order.size() - order.size() / 4;
@@ -214,40 +281,51 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
     }
   }
 
-  VideoDecoderInterface::FrameInfo info;
-  info.width = index.frame_width();
-  info.height = index.frame_height();
-  info.format = index.format();
-
   std::atomic<size_t> cursor{0};
   std::atomic<bool> abort{false};
-  size_t nl = std::min(lanes_.size(), items.size());
+  size_t nl = std::min(lanes_.size(), order.size());
   // A lane's working set grows with the picture (records of a 4K picture:
   // ~13 MB); beyond two lanes per CPU the parsers evict each other (measured
   // at 3840x2160 on 16 CPUs: 16 / 24 / 32 / 48 lanes -> 485 / 528 / 562 / 477
   // frames/s, 7.4 -> 8.3 ms of CPU per picture).
-  if (auto_lanes_ && static_cast<int64_t>(index.frame_width()) * index.frame_height() > 2 * 1920 * 1088)
-    nl = std::min<size_t>(nl, static_cast<size_t>(2 * effective_cpus()));
+  if (auto_lanes_ && largest_picture > 2 * 1920 * 1088)
+    nl = std::min<size_t>(nl, std::max<size_t>(devices_.size(), static_cast<size_t>(2 * effective_cpus())));
+  // with fewer items than lanes, still spread them over every device
+  if (nl < lanes_.size() && devices_.size() > 1) nl = std::min(lanes_.size(), std::max(nl, std::min(order.size(), devices_.size())));
   std::vector<std::thread> threads;
   for (size_t li = 0; li < nl; ++li) {
     Lane& lane = lanes_[li];
     lane.result = Result();
     lane.samples_fed = 0;
     lane.frames_returned = 0;
+    lane.items = 0;
     threads.emplace_back([&, li]() {
       Lane& lane = lanes_[li];
       pthread_setname_np(pthread_self(), "hw-lane");
       Result r;
-      for (auto& b : lane.backend) {
+      for (auto& b : lane.backend)
         if (auto* c = dynamic_cast<CountedBackend*>(b.get())) c->reset_counters();
-        if (r.ok) r = b->configure(info, index.metadata_bytes());
-      }
+      // configure() once per call and clip, not once per interval (the reference re-opens its codec
+      // for every interval, decoder.py:65): a backend is re-configured only when the clip changes
+      for (auto& key : lane.config_key) key.clear();
       int turn = 0;
       while (r.ok && !abort.load()) {
         size_t k = cursor.fetch_add(1);
         if (k >= order.size()) break;
-        r = run_item(lane, lane.backend[turn].get(), items[order[k]], index, file, file_size, out,
-                     frame_bytes, yuv);
+        const WorkItem& item = items[order[k]];
+        const Request& rq = requests[item.request];
+        if (lane.config_key[turn] != keys[item.request]) {
+          VideoDecoderInterface::FrameInfo info;
+          info.width = rq.index->frame_width();
+          info.height = rq.index->frame_height();
+          info.format = rq.index->format();
+          r = lane.backend[turn]->configure(info, rq.index->metadata_bytes());
+          if (!r.ok) break;
+          lane.config_key[turn] = keys[item.request];
+        }
+        r = run_item(lane, lane.backend[turn].get(), item, *rq.index, rq.file, rq.file_size, rq.out,
+                     frame_bytes[item.request], yuv);
+        ++lane.items;
         turn = (turn + 1) % kBackendsPerLane;
       }
       for (auto& b : lane.backend)
@@ -264,6 +342,10 @@ Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
     if (!lane.result.ok && result.ok) result = lane.result;
     stats_.samples_fed += lane.samples_fed;
     stats_.frames_returned += lane.frames_returned;
+    DeviceStats& ds = device_stats_[lane.device_slot];
+    ds.items += lane.items;
+    ds.frames_returned += lane.frames_returned;
+    ds.samples_fed += lane.samples_fed;
     for (auto& b : lane.backend) {
       if (auto* c = dynamic_cast<CountedBackend*>(b.get())) {
         BackendCounters bc = c->counters();

@@ -183,11 +183,44 @@ int hwang_automata_stamp_trace(hwang_automata* a, int32_t trace[8]);
  * a time through one DecoderAutomata, done for all intervals at once: the
  * plan's intervals are trimmed to their last wanted frame and fanned out
  * over `num_lanes` independent backend instances (one host entropy thread +
- * one HIP stream each) on one GPU.  No data-path collective. */
+ * one DPB in HBM each) on one GPU or on several.  No data-path collective.
+ *
+ * Multi-GPU (BASELINE.json north_star: "segments fan out embarrassingly-parallel
+ * across the 8 GPUs of one node"): the GOP work items of a call
+ * share one queue; lane i decodes on device_ids[i % num_devices]; frames land at
+ * the row's position of the request's output.  One process per GPU instead:
+ * hwang_retriever_set_shard(rank, world) makes this process decode only its
+ * share of every call's items (a deterministic longest-first split every rank
+ * computes identically); rows of other shares are not written. */
 typedef struct hwang_retriever hwang_retriever;
 
 hwang_retriever* hwang_retriever_create(int device_type, int32_t device_id,
                                         int decoder_type, int32_t num_lanes);
+/* num_lanes <= 0: 3 lanes per CPU the process may use (cgroup quota honoured),
+ * however many devices; never fewer than one per device. */
+hwang_retriever* hwang_retriever_create_multi(int device_type, const int32_t* device_ids,
+                                              size_t num_devices, int decoder_type,
+                                              int32_t num_lanes);
+int hwang_retriever_set_shard(hwang_retriever* r, int32_t rank, int32_t world);
+int32_t hwang_retriever_num_lanes(hwang_retriever* r);
+/* One clip of a batched call (BASELINE config C3: 128 clips, 1 % of each). */
+typedef struct hwang_retrieve_request {
+  const hwang_video_index* index;
+  const uint8_t* file;      /* whole MP4 in host memory, borrowed for the call */
+  size_t file_size;
+  const uint64_t* rows;     /* sorted ascending */
+  size_t num_rows;
+  uint8_t* out;             /* num_rows frames: host memory or HBM of any device of this process */
+  size_t out_capacity;
+} hwang_retrieve_request;
+/* All requests' GOP items are pooled into one queue (python/hwang/decoder.py:30-69
+ * is one clip, one interval at a time).  Clips may differ in size and codec
+ * configuration; a lane re-configures its backend only when they do. */
+int hwang_retriever_retrieve_batch(hwang_retriever* r, const hwang_retrieve_request* requests,
+                                   size_t num_requests, int out_is_yuv);
+/* per device slot (position in device_ids) after a call:
+ * [0] lanes bound to it, [1] work items it decoded, [2] frames returned, [3] samples fed */
+void hwang_retriever_device_stats(hwang_retriever* r, int32_t device_slot, int64_t stats[4]);
 void hwang_retriever_destroy(hwang_retriever* r);
 /* `file` is the whole MP4 mapped or read into memory (borrowed for the
  * call).  rows must be sorted ascending.  `out` receives num_rows frames in
