@@ -9,7 +9,7 @@ import os
 from .api import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData,
                   MP4IndexCreator, VideoDecoderType, VideoIndex,
                   slice_into_video_intervals)
-from .decoder import Decoder
+from .decoder import BatchRetriever, Decoder
 
 
 def index_video(f_or_string):

@@ -527,13 +527,29 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     free_buffers();
   }
 
-  static bool is_device_pointer(const void* p) {
+  // Is `p` in HBM?  If it is another GPU's HBM (one process driving several
+  // devices: a request's output lives on one of them), the conversion kernel
+  // writes it over xGMI - point-to-point stores, no copy, no collective - for
+  // which peer access is switched on the first time the pair is seen.
+  bool is_device_pointer(const void* p, Result* peer_error) {
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
       (void)hipGetLastError();  // unregistered host memory reports an error
       return false;
     }
-    return attr.type == hipMemoryTypeDevice;
+    if (attr.type != hipMemoryTypeDevice) return false;
+    if (attr.device != device_ && attr.device != peer_enabled_) {
+      const hipError_t e = hipDeviceEnablePeerAccess(attr.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+        *peer_error = Result(false, "AMDVideoDecoder: output buffer lives on GPU " + std::to_string(attr.device) +
+                                        " and GPU " + std::to_string(device_) + " cannot reach it (" +
+                                        hipGetErrorString(e) + ")");
+        return true;
+      }
+      (void)hipGetLastError();
+      peer_enabled_ = attr.device;
+    }
+    return true;
   }
 
   Result take_frame(uint8_t* dst, size_t dst_size, bool yuv) {
@@ -567,7 +583,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.yuv = yuv ? 1 : 0;
     sub.bytes = need + (yuv ? need : w * h + 2 * cw * ch);
     Result r;
-    if (is_device_pointer(dst)) {
+    if (is_device_pointer(dst, &r)) {
+      if (!r.ok) return finish_take(slot, r);
       sub.desc.dst = dst;  // the kernel writes caller memory in HBM directly
     } else {
       Bounce* bounce = nullptr;
@@ -611,6 +628,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   const int device_;
+  int peer_enabled_ = -1;  // last peer device whose HBM was made reachable from device_
   amd::GpuExecutor* exec_ = nullptr;
   int lane_ = -1;
   // Highest sequence number this decoder has submitted.  Written by the feeder

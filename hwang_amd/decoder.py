@@ -19,9 +19,100 @@ from .api import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData,
                   VideoDecoderType, slice_into_video_intervals)
 
 
+def _host_view(f):
+    """The whole file as (ctypes source, length, keep-alive)."""
+    try:
+        view = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ)
+    except (AttributeError, OSError, ValueError):
+        f.seek(0, 0)
+        view = f.read()
+    if isinstance(view, bytes):
+        return view, len(view), view
+    arr = np.frombuffer(view, dtype=np.uint8)
+    return C.c_void_p(arr.ctypes.data), len(view), (arr, view)
+
+
+class BatchRetriever(object):
+    """Many clips, one call (BASELINE config C3: 128 clips, 1 % of each): the
+    GOP work items of all requests share one queue that the lanes of every
+    device pull from.  `device_ids` lists the GPUs of this process; with one
+    process per GPU pass one id and `shard=(rank, world)`."""
+
+    def __init__(self, device_ids=(0,), device_type=DeviceType.GPU, decoder_type=None, num_lanes=0, shard=None):
+        if decoder_type is None:
+            decoder_type = VideoDecoderType.AMD if device_type == DeviceType.GPU else VideoDecoderType.SOFTWARE
+        if not lib.hwang_decoder_type_supported(int(decoder_type)):
+            raise RuntimeError("hwang_amd.BatchRetriever: decoder type %r is not built into libhwang_amd.so "
+                               "(there is no CPU fallback)" % (decoder_type,))
+        ids = (C.c_int32 * len(device_ids))(*device_ids)
+        self._h = lib.hwang_retriever_create_multi(int(device_type), ids, len(device_ids), int(decoder_type), num_lanes)
+        if not self._h:
+            raise RuntimeError("hwang_amd.BatchRetriever: cannot open backend %r on devices %r" %
+                               (decoder_type, list(device_ids)))
+        self.num_devices = len(device_ids)
+        if shard is not None and lib.hwang_retriever_set_shard(self._h, int(shard[0]), int(shard[1])):
+            raise RuntimeError(lib.hwang_retriever_last_error(self._h).decode())
+
+    def num_lanes(self):
+        return lib.hwang_retriever_num_lanes(self._h)
+
+    def retrieve_into(self, requests, yuv=False):
+        """requests: [(video_index, file object or path, rows, out_ptr, out_capacity)]"""
+        arr = (_capi.RetrieveRequestStruct * len(requests))()
+        keep = []
+        for i, (index, f, rows, out_ptr, cap) in enumerate(requests):
+            if isinstance(f, str):
+                f = open(f, "rb")
+            src, n, k = _host_view(f)
+            rows_arr = _capi.u64_array(rows)
+            keep.append((f, k, rows_arr, src))
+            arr[i].index = index._h
+            arr[i].file = C.cast(src, C.c_void_p) if not isinstance(src, C.c_void_p) else src
+            arr[i].file_size = n
+            arr[i].rows = rows_arr
+            arr[i].num_rows = len(rows_arr)
+            arr[i].out = out_ptr
+            arr[i].out_capacity = cap
+        rc = lib.hwang_retriever_retrieve_batch(self._h, arr, len(requests), 1 if yuv else 0)
+        del keep
+        if rc:
+            raise RuntimeError(lib.hwang_retriever_last_error(self._h).decode())
+
+    def retrieve(self, requests):
+        """requests: [(video_index, file or path, rows)] -> per request a list of H x W x 3 arrays."""
+        bufs, full = [], []
+        for index, f, rows in requests:
+            rows = list(rows)
+            buf = np.zeros((len(rows), index.frame_height(), index.frame_width(), 3), dtype=np.uint8)
+            bufs.append(buf)
+            full.append((index, f, rows, buf.ctypes.data, buf.nbytes))
+        self.retrieve_into(full)
+        return [[b[i] for i in range(b.shape[0])] for b in bufs]
+
+    def stats(self):
+        s = (C.c_int64 * 10)()
+        lib.hwang_retriever_stats(self._h, s)
+        keys = ("intervals", "samples_fed", "pictures_reconstructed", "pictures_skipped", "frames_returned",
+                "bytes_uploaded", "entropy_ns", "wall_ns", "stall_ns", "reserved")
+        return dict(zip(keys, list(s)))
+
+    def device_stats(self):
+        out = []
+        for d in range(self.num_devices):
+            s = (C.c_int64 * 4)()
+            lib.hwang_retriever_device_stats(self._h, d, s)
+            out.append(dict(zip(("lanes", "items", "frames_returned", "samples_fed"), list(s))))
+        return out
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            lib.hwang_retriever_destroy(h)
+
+
 class Decoder(object):
     def __init__(self, f_or_path, video_index=None, device_type=DeviceType.GPU,
-                 device_id=0, decoder_type=None, num_lanes=0):
+                 device_id=0, decoder_type=None, num_lanes=0, device_ids=None, shard=None):
         import hwang_amd
         if video_index is None:
             video_index = hwang_amd.index_video(f_or_path)
@@ -40,6 +131,10 @@ class Decoder(object):
                             else VideoDecoderType.SOFTWARE)
         self.device_type = device_type
         self.device_id = device_id
+        # several GPUs of this process (one request's GOP items fan out over all of them), and / or this
+        # process's share of a job that runs one process per GPU
+        self.device_ids = list(device_ids) if device_ids is not None else [device_id]
+        self.shard = shard
         self.decoder_type = decoder_type
         self.num_lanes = num_lanes
         self._automata = None
@@ -94,12 +189,15 @@ class Decoder(object):
     # -- parallel path ---------------------------------------------------------
     def _get_retriever(self):
         if self._retriever is None:
-            h = lib.hwang_retriever_create(int(self.device_type), self.device_id,
-                                           int(self.decoder_type), self.num_lanes)
+            ids = (C.c_int32 * len(self.device_ids))(*self.device_ids)
+            h = lib.hwang_retriever_create_multi(int(self.device_type), ids, len(self.device_ids),
+                                                 int(self.decoder_type), self.num_lanes)
             if not h:
                 raise RuntimeError(
-                    "hwang_amd.Decoder: cannot open backend %r on device %d" %
-                    (self.decoder_type, self.device_id))
+                    "hwang_amd.Decoder: cannot open backend %r on devices %r" %
+                    (self.decoder_type, self.device_ids))
+            if self.shard is not None and lib.hwang_retriever_set_shard(h, int(self.shard[0]), int(self.shard[1])):
+                raise RuntimeError(lib.hwang_retriever_last_error(h).decode())
             self._retriever = h
         return self._retriever
 
@@ -161,6 +259,14 @@ class Decoder(object):
                 "pictures_skipped", "frames_returned", "bytes_uploaded",
                 "entropy_ns", "wall_ns", "stall_ns", "reserved")
         return dict(zip(keys, list(s)))
+
+    def device_stats(self):
+        out = []
+        for d in range(len(self.device_ids)):
+            s = (C.c_int64 * 4)()
+            lib.hwang_retriever_device_stats(self._get_retriever(), d, s)
+            out.append(dict(zip(("lanes", "items", "frames_returned", "samples_fed"), list(s))))
+        return out
 
     def __del__(self):
         h, self._retriever = getattr(self, "_retriever", None), None

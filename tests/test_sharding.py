@@ -1,5 +1,9 @@
-"""The N > 1 path of bench.py (one process per GPU, interval sharding, no
-collective on the data path) on CPU: two gloo ranks, STAMP backend."""
+"""The N > 1 paths on CPU with the STAMP backend:
+* bench.py's launch (one process per GPU): two gloo ranks decode their shares
+  of one batched call, no collective on the data path;
+* one process driving several devices: a request's GOP items land on
+  different devices and come back in request order;
+* retrieve_batch over clips of different sizes."""
 import os
 import socket
 import subprocess
@@ -50,3 +54,75 @@ def test_automatic_lane_count(hw):
         for r, f in zip(rows, frames):
             assert f.shape == (h, w, 3)
             assert struct.unpack("<I", f.tobytes()[:4])[0] == r
+
+
+def _stamp_clip(hw, n, gop, w, h, tag=0):
+    import struct
+
+    import numpy as np
+    samples = [struct.pack("<I", (tag << 24) | i) + b"s" * (5 + i % 7) for i in range(n)]
+    offs = np.cumsum([0] + [len(s) for s in samples[:-1]]).tolist()
+    index = hw.VideoIndex(timescale=30000, duration=n * 1001, width=w, height=h, format="avc1",
+                          sample_offsets=offs, sample_sizes=[len(s) for s in samples],
+                          keyframe_indices=list(range(0, n, gop)), metadata=bytes([tag]))
+    return index, b"".join(samples)
+
+
+def test_one_request_fans_out_over_devices(hw):
+    """one request's intervals must land on different
+    devices and come back in request order."""
+    import io
+    import struct
+
+    import numpy as np
+    index, blob = _stamp_clip(hw, 3000, 30, 4, 2)
+    rows = sorted(np.random.default_rng(5).choice(3000, 90, replace=False).tolist())
+    for devices, lanes in (([0, 1], 4), ([0, 1, 2, 3], 0), ([0, 1, 2], 3)):
+        dec = hw.Decoder(io.BytesIO(blob), video_index=index, device_type=hw.DeviceType.CPU,
+                         decoder_type=hw.VideoDecoderType.STAMP, num_lanes=lanes, device_ids=devices)
+        frames = dec.retrieve(rows)
+        assert [struct.unpack("<I", f.tobytes()[:4])[0] for f in frames] == rows
+        ds = dec.device_stats()
+        assert len(ds) == len(devices)
+        assert all(d["lanes"] >= 1 and d["items"] >= 1 and d["frames_returned"] >= 1 for d in ds), ds
+        assert sum(d["frames_returned"] for d in ds) == len(rows)
+        assert sum(d["items"] for d in ds) == dec.stats()["intervals"]
+
+
+def test_retrieve_batch_pools_clips(hw):
+    """BASELINE C3's shape: many clips, a few rows of each, one call.  Clips of
+    different sizes share lanes (a lane re-configures when the clip changes)."""
+    import io
+    import struct
+
+    import numpy as np
+    from hwang_amd.decoder import BatchRetriever
+    rng = np.random.default_rng(11)
+    clips = [_stamp_clip(hw, 600 + 30 * k, 30, 4 + 2 * (k % 3), 2 + (k % 2), tag=k + 1) for k in range(12)]
+    reqs, want = [], []
+    for k, (index, blob) in enumerate(clips):
+        rows = sorted(rng.choice(index.frames(), 6, replace=False).tolist()) if k != 5 else []   # one empty request
+        reqs.append((index, io.BytesIO(blob), rows))
+        want.append([((k + 1) << 24) | r for r in rows])
+    br = BatchRetriever(device_ids=[0, 1], device_type=hw.DeviceType.CPU, decoder_type=hw.VideoDecoderType.STAMP,
+                        num_lanes=5)
+    got = br.retrieve(reqs)
+    for k in range(len(clips)):
+        assert [struct.unpack("<I", f.tobytes()[:4])[0] for f in got[k]] == want[k], k
+        for f in got[k]:
+            assert f.shape == (clips[k][0].frame_height(), clips[k][0].frame_width(), 3)
+    ds = br.device_stats()
+    assert all(d["items"] > 0 for d in ds) and sum(d["frames_returned"] for d in ds) == sum(len(w) for w in want)
+    # shares of a sharded job are disjoint and complete
+    seen = [np.zeros(len(w), dtype=np.int32) for w in want]
+    for rank in range(3):
+        brs = BatchRetriever(device_ids=[0], device_type=hw.DeviceType.CPU, decoder_type=hw.VideoDecoderType.STAMP,
+                             num_lanes=2, shard=(rank, 3))
+        part = brs.retrieve(reqs)
+        for k in range(len(clips)):
+            for i, f in enumerate(part[k]):
+                v = struct.unpack("<I", f.tobytes()[:4])[0]
+                if v:   # zero-initialised output: rows of other shares stay untouched
+                    assert v == want[k][i]
+                    seen[k][i] += 1
+    assert all((s == 1).all() for s in seen)
