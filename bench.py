@@ -2,26 +2,35 @@
 """Headline benchmark: sparse H.264 frame retrieval on MI355X.
 
 Workload (BASELINE.json configs[1], "C1"): one synthetic 1080p30 High-profile
-CABAC clip of 108 000 frames (1 h; GOP 60, 2 B-frames between references),
-rows = sorted(default_rng(20240601 + rank).choice(N, round(0.01 N))) -> 1080
-frames per rank, returned as RGB24 into a tensor that lives in HBM.  One
-"step" = one full retrieval of the rank's row set through the C ABI
-(hwang_retriever_retrieve); the encoded file is resident in host memory (it
-is what the host-side entropy decoder reads), every decoded frame and every
-intermediate picture stays in HBM.
+CABAC clip of 108 000 frames (1 h; 1 200 unique frames x 90 repeats of closed
+GOPs; GOP 60, 2 B-frames between references).  A request = rows =
+sorted(default_rng(20240601 + k).choice(N, round(0.01 N))) -> 1080 frames,
+returned as RGB24 into a tensor that lives in HBM.  One "step" = one batched
+call through the C ABI (hwang_retriever_retrieve_batch) of `--gpus` such
+requests (k = 0 .. gpus-1; at N = 1 exactly C1): the GOP segments of all
+requests are pooled and fanned out over the GPUs, so per-GPU work is fixed as N
+grows ("weak").  The encoded file is resident in host memory (it is what the
+host-side entropy decoder reads); every decoded frame and every intermediate
+picture stays in HBM.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by torch.distributed.run, one rank per GPU.  The path
-shards by keyframe-anchored interval with no data exchange, so ranks only
-meet in the timing barrier (weak scaling: every rank decodes its own 1 %
-sample of the clip).
+N > 1 under torch.distributed.run (the driver's launch) = one rank per GPU:
+every rank plans the whole batch and decodes its share of the work items
+(hwang_retriever_set_shard: a deterministic longest-first split), writing the
+rows of its share into its own output; ranks only meet in the timing barrier
+and the MAX / SUM of times and counts - no collective on the data path.
+`python bench.py --gpus N` without a launcher drives all N devices from one
+process instead (shared work queue, lanes bound round-robin to the devices).
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events
 on the executor's streams (hwang_prof_*) in an extra pass after the timed
-region; `cpu_baseline` times the CPU oracle (a port, test infrastructure) on
-a bounded sample of the same workload under the reference's semantics (every
-sample of every touched GOP is decoded, wanted frames converted to RGB).
+region (`end_to_end_frac`: SURVEY 8(d)'s whole-pipeline accounting);
+`value_host_output` is the D2H-inclusive rate (frames into pinned host memory)
+from another extra pass; `cpu_baseline` times the CPU oracle (a port, test
+infrastructure) on a bounded sample of the same workload under the
+reference's semantics (every sample of every touched GOP is decoded, wanted
+frames converted to RGB), and carries the run-time FFmpeg probe's verdict.
 """
 import argparse
 import ctypes as C
@@ -95,51 +104,65 @@ def cpu_gop_worker(spec_path):
     print(json.dumps({"returned": returned, "fed": fed, "seconds": time.time() - t0}))
 
 
-def cpu_baseline(path, index, rows, workers):
+def cpu_baseline(path, index, rows, workers, max_gops=64, repeats=3):
+    """The oracle under the reference's semantics on the first `max_gops`
+    touched GOPs of the request, `workers` single-threaded decoders pulling GOPs
+    round-robin, median of `repeats` runs."""
     import tempfile
     offs, sizes = index.sample_offsets(), index.sample_sizes()
     kfs = index.keyframe_indices() + [index.frames()]
-    # the first `workers` touched GOPs, one per worker process
     gops, ki = [], 0
     for r in rows:
         while kfs[ki + 1] <= r:
             ki += 1
         if gops and gops[-1]["gop"] == ki:
             gops[-1]["wanted"].append(r - kfs[ki])
-        elif len(gops) < workers:
+        elif len(gops) < max_gops:
             gops.append({"gop": ki, "samples": [(offs[s], sizes[s]) for s in range(kfs[ki], kfs[ki + 1])],
                          "wanted": [r - kfs[ki]]})
         else:
             break
+    workers = max(1, min(workers, len(gops)))
     avcc = bytes(index.metadata_bytes()).hex()
-    procs = []
-    t0 = time.time()
+    runs = []
+    t_all = time.time()
     with tempfile.TemporaryDirectory() as tmp:
-        for i, g in enumerate(gops):
-            spec = os.path.join(tmp, "w%d.json" % i)
-            with open(spec, "w") as f:
-                json.dump({"path": path, "avcc": avcc, "gops": [g]}, f)
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec],
-                                          stdout=subprocess.PIPE))
-        res = []
-        for p in procs:
-            out, _ = p.communicate()
-            if p.returncode:
-                raise SystemExit("bench.py: cpu_baseline worker failed")
-            res.append(json.loads(out.decode().strip().splitlines()[-1]))
-    wall = time.time() - t0
-    busy = max(r["seconds"] for r in res)  # slowest worker's decode time (interpreter start-up excluded)
-    returned = sum(r["returned"] for r in res)
-    fed = sum(r["fed"] for r in res)
+        for i in range(workers):
+            with open(os.path.join(tmp, "w%d.json" % i), "w") as f:
+                json.dump({"path": path, "avcc": avcc, "gops": gops[i::workers]}, f)
+        for _ in range(repeats):
+            procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
+                                       os.path.join(tmp, "w%d.json" % i)], stdout=subprocess.PIPE)
+                     for i in range(workers)]
+            res = []
+            for p in procs:
+                out, _ = p.communicate()
+                if p.returncode:
+                    raise SystemExit("bench.py: cpu_baseline worker failed")
+                res.append(json.loads(out.decode().strip().splitlines()[-1]))
+            busy = max(r["seconds"] for r in res)  # slowest worker's decode time (interpreter start-up excluded)
+            runs.append((sum(r["returned"] for r in res) / busy, sum(r["fed"] for r in res) / busy,
+                         sum(r["returned"] for r in res), sum(r["fed"] for r in res)))
+    runs.sort()
+    med = runs[len(runs) // 2]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import ffmpeg_probe
+        probe = ffmpeg_probe.probe(deep=False)
+        probe = {"available": probe["available"], "summary": probe["summary"]}
+    except Exception as e:  # noqa: BLE001
+        probe = {"available": False, "summary": "probe failed: %r" % (e,)}
     return {
-        "value": round(returned / busy, 3),
+        "value": round(med[0], 3),
         "unit": "frames/s",
-        "cores": len(gops),
+        "cores": workers,
         "kind": "port",
-        "sample": "%d touched GOPs of the same clip (%d samples fed, %d wanted frames returned as RGB24), one "
-                  "single-threaded oracle decoder per core, reference semantics (whole GOP decoded); %.1f s wall"
-                  % (len(gops), fed, returned, wall),
-        "fed_samples_per_s": round(fed / busy, 2),
+        "sample": "%d touched GOPs of the same request (%d samples fed, %d wanted frames returned as RGB24), %d "
+                  "single-threaded oracle decoders, reference semantics (whole GOP decoded); median of %d runs, "
+                  "%.1f s wall in total" % (len(gops), med[3], med[2], workers, repeats, time.time() - t_all),
+        "fed_samples_per_s": round(med[1], 2),
+        "runs_frames_per_s": [round(r[0], 3) for r in runs],
+        "ffmpeg_probe": probe,
     }
 
 
@@ -193,19 +216,25 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("HWANG_BENCH_LANES", 0)))
     ap.add_argument("--cpu-workers", type=int, default=int(os.environ.get("HWANG_BENCH_CPU_WORKERS", 16)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-output", action="store_true", help="skip the extra D2H-inclusive pass (N = 1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    # Two ways to use N GPUs: torch.distributed.run with N ranks (the driver's launch; every rank decodes
+    # its share of the batch), or one process driving all N devices (`python bench.py --gpus N`).
+    in_process_devices = 1
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-        args.gpus = world
+            in_process_devices = args.gpus
+        else:
+            args.gpus = world
 
     import numpy as np
     import hwang_amd as hw
     from hwang_amd._capi import lib
+    from hwang_amd.decoder import BatchRetriever
 
     # corpus + index (rank 0 generates; the others wait for the file)
     path = corpus_path(args.frames)
@@ -216,18 +245,25 @@ def main():
             time.sleep(0.5)
     index = hw.index_video(path)
     n = index.frames()
-    rows = sorted(np.random.default_rng(SEED + rank).choice(n, max(1, round(0.01 * n)), replace=False).tolist())
+    # The job: ONE batched call of `gpus` requests over the clip, request k = the 1 % sample with seed
+    # SEED + k (N = 1: exactly configuration C1).  All requests' GOP segments are pooled and fanned out
+    # over the GPUs; per-GPU work is fixed as N grows ("weak").
+    nreq = args.gpus
+    row_sets = [sorted(np.random.default_rng(SEED + k).choice(n, max(1, round(0.01 * n)), replace=False).tolist())
+                for k in range(nreq)]
 
     # CPU baseline first (rank 0, N = 1 only): spawns processes, so it runs
     # before this process touches the GPU.
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(path, index, rows, max(1, min(args.cpu_workers, effective_cpus())))
+        cpu = cpu_baseline(path, index, row_sets[0], max(1, min(args.cpu_workers, effective_cpus())))
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible (the decoder has no CPU fallback)")
+    if in_process_devices > torch.cuda.device_count():
+        raise SystemExit("bench.py: --gpus %d but only %d visible" % (in_process_devices, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -235,14 +271,22 @@ def main():
     # the CPUs are the bottleneck: measured 32 / 40 / 48 / 64 lanes on 16 CPUs ->
     # 660 / 676 / 698 / 651 frames/s); with several ranks on one host the CPUs are shared
     lanes = args.lanes or max(2, min(128, 3 * effective_cpus() // world))
-    dec = hw.Decoder(path, video_index=index, device_id=local_rank, num_lanes=lanes)
-    out = torch.empty((len(rows), HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda")
+    devices = list(range(in_process_devices)) if in_process_devices > 1 else [local_rank]
+    br = BatchRetriever(device_ids=devices, num_lanes=lanes, shard=(rank, world) if world > 1 else None)
+    # request k's frames land in HBM (N ranks: each rank writes the rows of its share into its own copy of
+    # the batch's output; nothing is gathered - no data-path collective)
+    fobj = open(path, "rb")
+    outs = [torch.empty((len(r), HEIGHT, WIDTH, 3), dtype=torch.uint8,
+                        device="cuda:%d" % (devices[k % len(devices)] if in_process_devices > 1 else local_rank))
+            for k, r in enumerate(row_sets)]
+    requests = [(index, fobj, row_sets[k], outs[k].data_ptr(), outs[k].numel()) for k in range(nreq)]
 
     def step():
-        dec.retrieve_into(rows, out.data_ptr(), out.numel())
+        br.retrieve_into(requests)
 
     def fence():
-        torch.cuda.synchronize()
+        for d in devices:
+            torch.cuda.synchronize(d)
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
@@ -260,50 +304,83 @@ def main():
     # host side of the story (the path is host bound): CPU seconds this
     # rank's process used per wall second of the timed region, all threads
     host_cpus_busy = ((c1.user - c0.user) + (c1.system - c0.system)) / elapsed
-    stats = dec.stats()
+    stats = br.stats()
+    dev_stats = br.device_stats()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([len(rows), stats["pictures_reconstructed"]], dtype=torch.float64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        total_rows, total_pics = int(cnt[0].item()), int(cnt[1].item())
+        cnt = torch.tensor([stats["frames_returned"], stats["pictures_reconstructed"], stats["intervals"], host_cpus_busy],
+                           dtype=torch.float64, device="cuda")
+        gathered = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(gathered, cnt)
+        total_rows = int(sum(g[0].item() for g in gathered))
+        total_pics = int(sum(g[1].item() for g in gathered))
+        per_gpu = [{"frames_returned": int(g[0].item()), "pictures_reconstructed": int(g[1].item()),
+                    "items": int(g[2].item()), "host_cpus_busy": round(g[3].item(), 2)} for g in gathered]
     else:
-        total_rows, total_pics = len(rows), stats["pictures_reconstructed"]
+        total_rows, total_pics = stats["frames_returned"], stats["pictures_reconstructed"]
+        per_gpu = [dict(d, host_cpus_busy=round(host_cpus_busy, 2)) for d in dev_stats] if len(devices) > 1 else None
+    assert total_rows == sum(len(r) for r in row_sets), "every row of every request must have been returned"
 
     # roofline pass: one more step with the per-kernel HIP-event spans enabled
     roofline = None
     kernels = {}
+    value_host = None
     if rank == 0:
         lib.hwang_prof_reset()
         lib.hwang_prof_enable(1)
         step()
-        torch.cuda.synchronize()
+        for d in devices:
+            torch.cuda.synchronize(d)
         lib.hwang_prof_enable(0)
+        prof_stats = br.stats()
         best = None
+        alg = {}
         for k in range(lib.hwang_prof_num_kernels()):
             o = (C.c_double * 3)()
             lib.hwang_prof_read(k, o)
             if not o[0]:
                 continue
             name = lib.hwang_prof_kernel_name(k).decode()
+            alg[name] = o[2]
             kernels[name] = {"launches": int(o[0]), "avg_us": round(o[1] / o[0], 1),
                              "alg_GBps": round(o[2] / (o[1] * 1e-6) / 1e9, 1)}
             if best is None or o[1] > best[1]:
                 best = (name, o[1], o[2], o[0])
         if best:
             achieved = best[2] / (best[1] * 1e-6) / 1e9
+            # SURVEY 8(d) end-to-end accounting for this rank's step: S (1 + r) per reconstructed picture
+            # (= the inter span's algorithmic bytes, + S per intra-only picture, one per work item) + B_in
+            # (bytes actually uploaded) + 4.5 W H per returned frame, over wall time x 8 TB/s.
+            e2e_bytes = alg.get("inter_pred", 0.0) + _S * prof_stats["intervals"] + prof_stats["bytes_uploaded"] + \
+                4.5 * WIDTH * HEIGHT * prof_stats["frames_returned"]
             roofline = {"bound": "hbm", "kernel": best[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": pmc_traffic_per_launch(best[0], best[2] / best[3]),
                         "algorithmic_bytes_per_launch": round(best[2] / best[3]),
-                        "launches": int(best[3]), "avg_launch_us": round(best[1] / best[3], 1)}
+                        "launches": int(best[3]), "avg_launch_us": round(best[1] / best[3], 1),
+                        "end_to_end_frac": round(e2e_bytes / (prof_stats["wall_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9), 5),
+                        "end_to_end_bytes_per_step": round(e2e_bytes)}
+        # D2H-inclusive rate (SURVEY 8d timing rules): the same request into pinned host memory.  Reported
+        # beside `value`, never as `value`.
+        if args.gpus == 1 and not args.no_host_output:
+            host_out = torch.empty((len(row_sets[0]), HEIGHT, WIDTH, 3), dtype=torch.uint8).pin_memory()
+            hreq = [(index, fobj, row_sets[0], host_out.data_ptr(), host_out.numel())]
+            br.retrieve_into(hreq)
+            th = time.perf_counter()
+            for _ in range(2):
+                br.retrieve_into(hreq)
+            torch.cuda.synchronize()
+            value_host = round(2 * len(row_sets[0]) / (time.perf_counter() - th), 2)
+            del host_out
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
     if rank == 0:
         value = total_rows * args.steps / elapsed
+        unique = min(UNIQUE_FRAMES, n)
         print(json.dumps({
             "metric": "decoded frames/sec, 1080p H.264 1%-sparse sample, 1/2/4/8 MI355X vs FFmpeg CPU",
             "value": round(value, 2),
@@ -317,17 +394,28 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "C1: single 1080p30 High-profile CABAC mp4, %d frames, GOP %d, %d B-frames, "
-                                   "1%% uniform-random rows (%d per GPU) returned as RGB24 in HBM"
-                                   % (n, GOP, BFRAMES, len(rows)),
-                       "lanes_per_gpu": lanes, "host_cpus": effective_cpus(), "sharding": "keyframe-anchored intervals, no collective"},
+            "config": {"workload": "C1: single 1080p30 High-profile CABAC mp4, %d frames (%d unique x %d repeats of closed "
+                                   "GOPs), GOP %d, %d B-frames; one batched call of %d request(s), each a 1%% "
+                                   "uniform-random sample (%d rows, seeds %d..%d), GOP segments pooled and fanned "
+                                   "out over %d GPU(s); frames returned as RGB24 in HBM"
+                                   % (n, unique, max(1, n // unique), GOP, BFRAMES, nreq, len(row_sets[0]), SEED,
+                                      SEED + nreq - 1, args.gpus),
+                       "launch": "one process, %d devices" % len(devices) if in_process_devices > 1 else "%d rank(s), one GPU each" % world,
+                       "lanes_per_gpu": lanes // len(devices), "host_cpus": effective_cpus(),
+                       "sharding": "GOP work items, longest-first split, no collective on the data path"},
+            "value_host_output": value_host,
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
             "samples_fed_per_s_rank0": round(stats["samples_fed"] / (elapsed / args.steps), 1),
             "host_cpus_busy_rank0": round(host_cpus_busy, 2),
+            "host_cpu_ms_per_picture": round(1000.0 * host_cpus_busy * (elapsed / args.steps) /
+                                             max(1, stats["pictures_reconstructed"]), 3),
+            "upload_MB_per_picture": round(stats["bytes_uploaded"] / 1e6 / max(1, stats["pictures_reconstructed"]), 3),
+            "per_gpu": per_gpu,
             "roofline": roofline,
             "kernels": kernels,
             "cpu_baseline": cpu,
         }))
+    del br
 
 
 if __name__ == "__main__":

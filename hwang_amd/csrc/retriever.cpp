@@ -281,7 +281,6 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
     }
   }
 
-  std::atomic<size_t> cursor{0};
   std::atomic<bool> abort{false};
   size_t nl = std::min(lanes_.size(), order.size());
   // A lane's working set grows with the picture (records of a 4K picture:
@@ -292,6 +291,9 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
     nl = std::min<size_t>(nl, std::max<size_t>(devices_.size(), static_cast<size_t>(2 * effective_cpus())));
   // with fewer items than lanes, still spread them over every device
   if (nl < lanes_.size() && devices_.size() > 1) nl = std::min(lanes_.size(), std::max(nl, std::min(order.size(), devices_.size())));
+  // Lane li starts with item li (so every lane, hence every device, has work from the first moment
+  // whatever order the threads come up in); everything after that is pulled from the shared queue.
+  std::atomic<size_t> cursor{nl};
   std::vector<std::thread> threads;
   for (size_t li = 0; li < nl; ++li) {
     Lane& lane = lanes_[li];
@@ -309,8 +311,10 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
       // for every interval, decoder.py:65): a backend is re-configured only when the clip changes
       for (auto& key : lane.config_key) key.clear();
       int turn = 0;
+      bool first = true;
       while (r.ok && !abort.load()) {
-        size_t k = cursor.fetch_add(1);
+        size_t k = first ? li : cursor.fetch_add(1);
+        first = false;
         if (k >= order.size()) break;
         const WorkItem& item = items[order[k]];
         const Request& rq = requests[item.request];
