@@ -18,9 +18,17 @@ OBJS       := $(patsubst %.cpp,$(BUILD)/%.o,$(CPP_SRCS)) \
 HDRS       := $(wildcard include/*.h $(CSRC)/*.h $(CSRC)/*/*.h)
 
 LIB        := hwang_amd/libhwang_amd.so
+# pybind11 module hwang._python (the reference's Python boundary) over the same C++ classes
+PYMOD      := hwang/_python$(shell python3-config --extension-suffix)
+PYBIND_INC := $(shell python3 -m pybind11 --includes)
 
-.PHONY: all lib oracle ref corpus clean
-all: lib oracle corpus ref
+.PHONY: all lib oracle ref corpus clean pymod
+all: lib pymod oracle corpus ref
+
+pymod: $(PYMOD)
+
+$(PYMOD): $(CSRC)/pybind/hwang_python.cpp $(LIB) $(HDRS)
+	g++ -std=c++17 -O2 -fPIC -shared -fvisibility=hidden $(PYBIND_INC) $< -o $@ -Lhwang_amd -lhwang_amd -Wl,-rpath,'$$ORIGIN/../hwang_amd'
 
 lib: $(LIB)
 
@@ -45,4 +53,4 @@ ref:
 	$(MAKE) -C oracle ref
 
 clean:
-	rm -rf build $(LIB) oracle/_build oracle/_ref corpus/_build
+	rm -rf build $(LIB) $(PYMOD) oracle/_build oracle/_ref corpus/_build

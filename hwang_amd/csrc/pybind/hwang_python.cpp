@@ -1,0 +1,184 @@
+// pybind11 module `hwang._python`: the reference's Python boundary
+// (hwang/hwang_python.cpp:102-167) over THIS repo's C++ classes, so that code
+// written against scanner-research/hwang (python/hwang/decoder.py:24-28 picks a
+// backend through hwang._python.VideoDecoderType) can select the MI355X
+// backend: VideoDecoderType.AMD is the one addition to the surface.
+//
+// Same names, argument meaning and error behaviour as the reference module:
+//   VideoIndex (13 methods), MP4IndexCreator(file_size).feed(data, size) ->
+//   (more, next_offset, next_size), slice_into_video_intervals(index, rows) ->
+//   [((start, end), [frames])], DeviceType, DeviceHandle, VideoDecoderType,
+//   EncodedData (10 fields), DecoderAutomata(handle, num_devices, type)
+//   .initialize(list, extradata) / .get_frames(index, n) -> [ndarray(H, W, 3)].
+// Differences, all on the safe side: a failing backend raises RuntimeError
+// from the constructor instead of dereferencing null later; frames are views
+// into ONE buffer per call kept alive by a capsule (the reference mallocs and
+// copies each frame twice, hwang_python.cpp:75-94); get_frames releases the
+// GIL while the backend works.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include "../decoder_automata.h"
+#include "../mp4_index_creator.h"
+#include "../video_decoder_factory.h"
+#include "../video_index.h"
+
+#include <memory>
+#include <stdexcept>
+
+namespace py = pybind11;
+using namespace hwang;
+
+namespace {
+
+py::bytes index_serialize(const VideoIndex& index) {
+  std::vector<uint8_t> wire = index.serialize();
+  return py::bytes(reinterpret_cast<const char*>(wire.data()), wire.size());
+}
+
+VideoIndex index_deserialize(const std::string& data) {
+  VideoIndex out;
+  if (!VideoIndex::deserialize(reinterpret_cast<const uint8_t*>(data.data()), data.size(), &out))
+    throw std::runtime_error("VideoIndex.deserialize: malformed data");
+  return out;
+}
+
+py::bytes index_metadata(const VideoIndex& index) {
+  const std::vector<uint8_t>& m = index.metadata_bytes();
+  return py::bytes(reinterpret_cast<const char*>(m.data()), m.size());
+}
+
+std::tuple<bool, uint64_t, uint64_t> indexer_feed(MP4IndexCreator& indexer, const std::string& data, size_t size) {
+  py::gil_scoped_release release;
+  uint64_t next_offset = 0, next_size = 0;
+  const bool more = indexer.feed(reinterpret_cast<const uint8_t*>(data.data()), std::min(size, data.size()),
+                                 next_offset, next_size);
+  return std::make_tuple(more, next_offset, next_size);
+}
+
+std::vector<std::tuple<std::tuple<uint64_t, uint64_t>, std::vector<uint64_t>>> plan(const VideoIndex& index,
+                                                                                    const std::vector<uint64_t>& rows) {
+  bool ok = true;
+  VideoIntervals v = slice_into_video_intervals(index, rows, &ok);
+  if (!ok) throw std::runtime_error("slice_into_video_intervals: row out of range or inconsistent index");
+  std::vector<std::tuple<std::tuple<uint64_t, uint64_t>, std::vector<uint64_t>>> out;
+  for (size_t i = 0; i < v.sample_index_intervals.size(); ++i)
+    out.emplace_back(std::make_tuple(std::get<0>(v.sample_index_intervals[i]), std::get<1>(v.sample_index_intervals[i])),
+                     v.valid_frames[i]);
+  return out;
+}
+
+std::unique_ptr<DecoderAutomata> make_automata(DeviceHandle handle, int32_t num_devices, VideoDecoderType type) {
+  DecoderAutomata* a = DecoderAutomata::make_instance(handle, num_devices, type);
+  if (!a)
+    throw std::runtime_error(
+        "DecoderAutomata: this build has no backend for the requested decoder type on that device "
+        "(only VideoDecoderType.AMD on a GPU handle; there is no CPU fallback)");
+  return std::unique_ptr<DecoderAutomata>(a);
+}
+
+void automata_initialize(DecoderAutomata& dec, const std::vector<DecoderAutomata::EncodedData>& segments,
+                         const py::object& extradata) {
+  std::vector<uint8_t> extra;
+  if (py::isinstance<py::bytes>(extradata) || py::isinstance<py::bytearray>(extradata)) {
+    const std::string s = py::cast<std::string>(py::bytes(extradata));
+    extra.assign(s.begin(), s.end());
+  } else {
+    extra = py::cast<std::vector<uint8_t>>(extradata);
+  }
+  Result r;
+  {
+    py::gil_scoped_release release;
+    r = dec.initialize(segments, extra);
+  }
+  if (!r.ok) throw std::runtime_error(r.message);
+}
+
+std::vector<py::array_t<uint8_t>> automata_get_frames(DecoderAutomata& dec, const VideoIndex& index, uint32_t num_frames) {
+  const size_t h = index.frame_height(), w = index.frame_width(), frame_size = w * h * 3;
+  auto* storage = new std::vector<uint8_t>(frame_size * num_frames);
+  py::capsule owner(storage, [](void* p) { delete static_cast<std::vector<uint8_t>*>(p); });
+  Result r;
+  {
+    py::gil_scoped_release release;
+    r = dec.get_frames(storage->data(), static_cast<int32_t>(num_frames));
+  }
+  if (!r.ok) throw std::runtime_error(r.message);
+  std::vector<py::array_t<uint8_t>> frames;
+  for (uint32_t i = 0; i < num_frames; ++i)
+    frames.emplace_back(std::vector<py::ssize_t>{(py::ssize_t)h, (py::ssize_t)w, 3},
+                        std::vector<py::ssize_t>{(py::ssize_t)(w * 3), 3, 1}, storage->data() + i * frame_size, owner);
+  return frames;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_python, m) {
+  m.doc() = "hwang C++ library (MI355X backend build)";
+  m.attr("__name__") = "hwang._python";
+
+  py::class_<VideoIndex>(m, "VideoIndex")
+      .def_static("deserialize", &index_deserialize)
+      .def("serialize", &index_serialize)
+      .def("timescale", &VideoIndex::timescale)
+      .def("duration", &VideoIndex::duration)
+      .def("fps", &VideoIndex::fps)
+      .def("frame_width", &VideoIndex::frame_width)
+      .def("frame_height", &VideoIndex::frame_height)
+      .def("format", &VideoIndex::format)
+      .def("frames", &VideoIndex::frames)
+      .def("sample_offsets", &VideoIndex::sample_offsets)
+      .def("sample_sizes", &VideoIndex::sample_sizes)
+      .def("keyframe_indices", &VideoIndex::keyframe_indices)
+      .def("metadata_bytes", &index_metadata);
+
+  py::class_<MP4IndexCreator>(m, "MP4IndexCreator")
+      .def(py::init<uint64_t>())
+      .def("feed", &indexer_feed)
+      .def("is_done", &MP4IndexCreator::is_done)
+      .def("is_error", &MP4IndexCreator::is_error)
+      .def("error_message", &MP4IndexCreator::error_message)
+      .def("get_video_index", &MP4IndexCreator::get_video_index);
+
+  m.def("slice_into_video_intervals", &plan);
+
+  py::enum_<DeviceType>(m, "DeviceType", py::arithmetic()).value("CPU", DeviceType::CPU).value("GPU", DeviceType::GPU);
+
+  py::class_<DeviceHandle>(m, "DeviceHandle")
+      .def(py::init([]() { return DeviceHandle{DeviceType::CPU, 0}; }))
+      .def_readwrite("type", &DeviceHandle::type)
+      .def_readwrite("id", &DeviceHandle::id);
+
+  py::enum_<VideoDecoderType>(m, "VideoDecoderType", py::arithmetic())
+      .value("SOFTWARE", VideoDecoderType::SOFTWARE)
+      .value("NVIDIA", VideoDecoderType::NVIDIA)
+      .value("INTEL", VideoDecoderType::INTEL)
+      .value("AMD", VideoDecoderType::AMD)
+      .value("STAMP", VideoDecoderType::STAMP);
+
+  py::class_<DecoderAutomata::EncodedData>(m, "EncodedData")
+      .def(py::init<>())
+      .def_property(
+          "encoded_video",
+          [](const DecoderAutomata::EncodedData& d) {
+            return py::bytes(reinterpret_cast<const char*>(d.encoded_video.data()), d.encoded_video.size());
+          },
+          [](DecoderAutomata::EncodedData& d, const std::string& v) { d.encoded_video.assign(v.begin(), v.end()); })
+      .def_readwrite("width", &DecoderAutomata::EncodedData::width)
+      .def_readwrite("height", &DecoderAutomata::EncodedData::height)
+      .def_readwrite("format", &DecoderAutomata::EncodedData::format)
+      .def_readwrite("start_keyframe", &DecoderAutomata::EncodedData::start_keyframe)
+      .def_readwrite("end_keyframe", &DecoderAutomata::EncodedData::end_keyframe)
+      .def_readwrite("sample_offsets", &DecoderAutomata::EncodedData::sample_offsets)
+      .def_readwrite("sample_sizes", &DecoderAutomata::EncodedData::sample_sizes)
+      .def_readwrite("keyframes", &DecoderAutomata::EncodedData::keyframes)
+      .def_readwrite("valid_frames", &DecoderAutomata::EncodedData::valid_frames);
+
+  py::class_<DecoderAutomata>(m, "DecoderAutomata")
+      .def(py::init(&make_automata))
+      .def("initialize", &automata_initialize)
+      .def("get_frames", &automata_get_frames);
+
+  m.def("supported_decoder_types", []() { return VideoDecoderFactory::get_supported_decoder_types(); });
+}

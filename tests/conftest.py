@@ -19,7 +19,9 @@ def built():
     import __graft_entry__ as g
     lib = os.path.join(ROOT, "hwang_amd", "libhwang_amd.so")
     ora = os.path.join(ROOT, "oracle", "_build", "liboracle_h264.so")
-    if not (os.path.exists(lib) and os.path.exists(ora)):
+    import glob
+    pymod = glob.glob(os.path.join(ROOT, "hwang", "_python*.so"))
+    if not (os.path.exists(lib) and os.path.exists(ora) and pymod):
         g.build()
     return True
 
