@@ -366,10 +366,12 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   Result drain_and_reset() {
     HWANG_RETURN_ON_ERROR(wait_seq(last_seq_.load()));
     std::lock_guard<std::mutex> lk(out_mu_);
+    // frames the caller has already taken with get_frame() are his: their copy-outs
+    // complete (a re-configure between two clips of a batched call used to drop them)
+    deliver_bounces_locked();
     outq_.clear();
     buffered_.store(0);
     for (SurfaceSlot& s : surf_) s.held = 0;
-    for (Bounce& b : bounce_) b.dst = nullptr;
     return Result();
   }
 
