@@ -407,6 +407,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       return false;
     }
     (void)wait_seq(last_seq_.load());
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      deliver_bounces_locked();
+    }
     free_buffers();  // also zeroes mbw_/mbh_: they are set again only when every allocation has succeeded
     const int new_mbw = s.mb_width, new_mbh = s.mb_height;
     struct Rollback {

@@ -63,6 +63,7 @@ struct ProbeSink : public h264::PictureSink {
     out->slices = slices.data();
     out->max_slices = static_cast<int>(slices.size());
     out->slot = slot;
+    out->device_mv = fast;  // timing runs measure what the GPU path runs (P vectors left to k_mv); digests keep the host derivation
     return true;
   }
   bool end_picture(const h264::PicDone& d, std::string*) override {

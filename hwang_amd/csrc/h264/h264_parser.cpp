@@ -451,6 +451,14 @@ struct Parser::Impl {
   int last_qp_delta_nonzero = 0;
   int qp = 26;
   int mbs_decoded = 0;  // of the picture in progress
+  bool pos_valid = false;  // mb.mbx / mb.mby / mb.addr describe a macroblock of the picture in progress
+
+  // P_Skip is 40 % of the macroblocks of a typical P picture and carries no
+  // syntax at all: everything it leaves behind is known when the slice starts,
+  // except its position, its neighbours and the running QP.  These templates are
+  // what begin_mb + decode_skip_mb + commit_mb would have produced field by field.
+  MbMotion pskip_motion;
+  int32_t pskip_ref_uid = -1;
 
   // current macroblock
   struct Mb {
@@ -466,6 +474,7 @@ struct Parser::Impl {
     int sub_type[4];
     int8_t i4_mode[16];
     uint8_t nnz[24];
+    uint8_t nz_left[8], nz_top[8];  // fill_nz_cache(): 4 luma + 2 Cb + 2 Cr flags per edge
     int cbf_dc;
     uint32_t coded_mask;
     int16_t* coef_base;  // this MB's groups in the coefficient buffer
@@ -1278,9 +1287,17 @@ struct Parser::Impl {
   // (6.4.9: inside the picture and in the same slice).  Everything else asks
   // mb.av[] instead of re-deriving it per syntax element.
   inline void set_position(int addr) {
+    if (addr == mb.addr + 1 && pos_valid) {  // the next macroblock in raster order: no division
+      if (++mb.mbx == mbw) {
+        mb.mbx = 0;
+        ++mb.mby;
+      }
+    } else {
+      mb.mbx = addr % mbw;
+      mb.mby = addr / mbw;
+      pos_valid = true;
+    }
     mb.addr = addr;
-    mb.mbx = addr % mbw;
-    mb.mby = addr / mbw;
     const bool left = mb.mbx > 0, top = mb.mby > 0, right = mb.mbx + 1 < mbw;
     const int16_t si = static_cast<int16_t>(slice_index);
     mb.av[0] = left && top && mb_slice[addr - mbw - 1] == si;   // D
@@ -1745,6 +1762,8 @@ struct Parser::Impl {
       leave();
       return 0;
     }
+    // the caller hands over uninitialised storage: it is cleared only when the block is coded
+    memset(out, 0, cat == 5 ? 128 : (cat == 3 ? 8 : 32));
     const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
     const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
     const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
@@ -1833,7 +1852,42 @@ struct Parser::Impl {
     }
   }
   int cbf_inc(int kind, int p, int rx, int ry) const {
+    if (kind == 1) {  // luma 4x4 / Intra16x16 AC: left and top flags from the cache, the rest from mb.nnz
+      const int a = rx > 0 ? mb.nnz[ry * 4 + rx - 1] != 0 : mb.nz_left[ry];
+      const int b = ry > 0 ? mb.nnz[(ry - 1) * 4 + rx] != 0 : mb.nz_top[rx];
+      return a + 2 * b;
+    }
+    if (kind == 3) {  // chroma AC
+      const int a = rx > 0 ? mb.nnz[16 + 4 * p + ry * 2] != 0 : mb.nz_left[4 + 2 * p + ry];
+      const int b = ry > 0 ? mb.nnz[16 + 4 * p + rx] != 0 : mb.nz_top[4 + 2 * p + rx];
+      return a + 2 * b;
+    }
     return cbf_neighbour(kind, p, rx, ry, true) + 2 * cbf_neighbour(kind, p, rx, ry, false);
+  }
+  // coded_block_flag context inputs of the blocks along the left and top edge of the current
+  // macroblock (9.3.3.1.1.9): "unavailable" counts as coded for intra macroblocks, I_PCM
+  // neighbours as coded.  Filled once per macroblock that has a residual.
+  void fill_nz_cache() {
+    const uint8_t unavailable = mb.kind != MB_INTER;
+    const int a = mb.addr;
+    if (mb.av[3]) {
+      const uint8_t* n = &nnz[(a - 1) * 24];
+      const bool pcm = mb_kind[a - 1] == MB_IPCM;
+      for (int y = 0; y < 4; ++y) mb.nz_left[y] = pcm || n[y * 4 + 3] != 0;
+      for (int pl = 0; pl < 2; ++pl)
+        for (int y = 0; y < 2; ++y) mb.nz_left[4 + 2 * pl + y] = pcm || n[16 + 4 * pl + y * 2 + 1] != 0;
+    } else {
+      memset(mb.nz_left, unavailable, sizeof(mb.nz_left));
+    }
+    if (mb.av[1]) {
+      const uint8_t* n = &nnz[(a - mbw) * 24];
+      const bool pcm = mb_kind[a - mbw] == MB_IPCM;
+      for (int x = 0; x < 4; ++x) mb.nz_top[x] = pcm || n[12 + x] != 0;
+      for (int pl = 0; pl < 2; ++pl)
+        for (int x = 0; x < 2; ++x) mb.nz_top[4 + 2 * pl + x] = pcm || n[16 + 4 * pl + 2 + x] != 0;
+    } else {
+      memset(mb.nz_top, unavailable, sizeof(mb.nz_top));
+    }
   }
 
   // ---------------------------------------------------- syntax elements
@@ -2076,29 +2130,36 @@ struct Parser::Impl {
 
   bool parse_residual() {
     const bool i16 = mb.kind == MB_I16x16;
+    if (use_cabac) fill_nz_cache();
     if (i16) {
-      int16_t tmp[16] = {0};
-      int n = use_cabac ? cabac_block(0, cbf_inc(0, 0, 0, 0), 16, zigzag4x4, 0, tmp)
-                        : cavlc_block(cavlc_nc(0, 0, 0), 16, zigzag4x4, 0, tmp);
-      if (n < 0) return false;
-      if (n) {
-        mb.cbf_dc |= 1;
-        memcpy(group(amd::kMaskLumaDc), tmp, sizeof(tmp));
+      int n;
+      if (use_cabac) {
+        n = cabac_block(0, cbf_inc(0, 0, 0, 0), 16, zigzag4x4, 0, mb.scratch[amd::kMaskLumaDc]);
+        if (n > 0) mb.coded_mask |= 1u << amd::kMaskLumaDc;
+      } else {
+        int16_t tmp[16] = {0};
+        n = cavlc_block(cavlc_nc(0, 0, 0), 16, zigzag4x4, 0, tmp);
+        if (n > 0) memcpy(group(amd::kMaskLumaDc), tmp, sizeof(tmp));
       }
+      if (n < 0) return false;
+      if (n) mb.cbf_dc |= 1;
     }
     for (int b8 = 0; b8 < 4; ++b8) {
       if (!((mb.cbp >> b8) & 1)) continue;
       if (mb.t8x8) {
         // 64 coefficients in raster 8x8 order spread over groups 4*b8..4*b8+3
+        if (use_cabac) {
+          // groups 4*b8 .. 4*b8+3 are adjacent in the scratch area: the 64 levels land in place
+          int n = cabac_block(5, -1, 64, zigzag8x8, 0, mb.scratch[4 * b8]);
+          if (n < 0) return false;
+          for (int s = 0; s < 4; ++s) mb.nnz[((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)] = static_cast<uint8_t>(n);
+          if (n) mb.coded_mask |= 0xfu << (4 * b8);
+          continue;
+        }
         int16_t blk[64];
         memset(blk, 0, sizeof(blk));
         int total = 0;
-        if (use_cabac) {
-          int n = cabac_block(5, -1, 64, zigzag8x8, 0, blk);
-          if (n < 0) return false;
-          total = n;
-          for (int s = 0; s < 4; ++s) mb.nnz[((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)] = static_cast<uint8_t>(n);
-        } else {
+        {
           for (int s = 0; s < 4; ++s) {
             const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
             int16_t tmp[16] = {0};
@@ -2118,17 +2179,18 @@ struct Parser::Impl {
       for (int s = 0; s < 4; ++s) {
         const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
         const int ri = by * 4 + bx;
-        int16_t tmp[16] = {0};
         int n;
-        if (i16)
-          n = use_cabac ? cabac_block(1, cbf_inc(1, 0, bx, by), 15, zigzag4x4, 1, tmp)
-                        : cavlc_block(cavlc_nc(0, bx, by), 15, zigzag4x4, 1, tmp);
-        else
-          n = use_cabac ? cabac_block(2, cbf_inc(1, 0, bx, by), 16, zigzag4x4, 0, tmp)
-                        : cavlc_block(cavlc_nc(0, bx, by), 16, zigzag4x4, 0, tmp);
+        if (use_cabac) {
+          n = i16 ? cabac_block(1, cbf_inc(1, 0, bx, by), 15, zigzag4x4, 1, mb.scratch[ri])
+                  : cabac_block(2, cbf_inc(1, 0, bx, by), 16, zigzag4x4, 0, mb.scratch[ri]);
+          if (n > 0) mb.coded_mask |= 1u << ri;
+        } else {
+          int16_t tmp[16] = {0};
+          n = i16 ? cavlc_block(cavlc_nc(0, bx, by), 15, zigzag4x4, 1, tmp) : cavlc_block(cavlc_nc(0, bx, by), 16, zigzag4x4, 0, tmp);
+          if (n > 0) memcpy(group(ri), tmp, sizeof(tmp));
+        }
         if (n < 0) return false;
         mb.nnz[ri] = static_cast<uint8_t>(n);
-        if (n) memcpy(group(ri), tmp, sizeof(tmp));
       }
     }
     const int cc = mb.cbp >> 4;
@@ -2148,12 +2210,18 @@ struct Parser::Impl {
       for (int p = 0; p < 2; ++p)
         for (int s = 0; s < 4; ++s) {
           const int bx = s & 1, by = s >> 1;
-          int16_t tmp[16] = {0};
-          int n = use_cabac ? cabac_block(4, cbf_inc(3, p, bx, by), 15, zigzag4x4, 1, tmp)
-                            : cavlc_block(cavlc_nc(1 + p, bx, by), 15, zigzag4x4, 1, tmp);
+          const int g = amd::kMaskChromaAc + 4 * p + s;
+          int n;
+          if (use_cabac) {
+            n = cabac_block(4, cbf_inc(3, p, bx, by), 15, zigzag4x4, 1, mb.scratch[g]);
+            if (n > 0) mb.coded_mask |= 1u << g;
+          } else {
+            int16_t tmp[16] = {0};
+            n = cavlc_block(cavlc_nc(1 + p, bx, by), 15, zigzag4x4, 1, tmp);
+            if (n > 0) memcpy(group(g), tmp, sizeof(tmp));
+          }
           if (n < 0) return false;
           mb.nnz[16 + 4 * p + s] = static_cast<uint8_t>(n);
-          if (n) memcpy(group(amd::kMaskChromaAc + 4 * p + s), tmp, sizeof(tmp));
         }
     }
     if (!use_cabac && bits.overrun) return fail("residual ran past the end of the slice");
@@ -2256,8 +2324,8 @@ struct Parser::Impl {
     return true;
   }
 
+  // (the caller has called set_position(addr))
   void begin_mb(int addr) {
-    set_position(addr);
     {
       static const int off_x[4] = {-1, 0, 1, -1}, off_y[4] = {-1, -1, -1, 0};
       for (int k = 0; k < 4; ++k) {
@@ -2379,7 +2447,88 @@ struct Parser::Impl {
     return true;
   }
 
+  // What every P_Skip macroblock of this slice shares (reference 0 of list 0, zero differences).
+  void prepare_pskip() {
+    memset(&pskip_motion, 0, sizeof(pskip_motion));
+    memset(pskip_motion.ref_slot, -1, sizeof(pskip_motion.ref_slot));
+    memset(pskip_motion.ref_idx, -1, sizeof(pskip_motion.ref_idx));
+    pskip_ref_uid = -1;
+    if (sl.num_ref_idx[0] > 0 && sl.ref_list[0][0]) {
+      const Pic* r = sl.ref_list[0][0];
+      for (int q = 0; q < 4; ++q) {
+        pskip_motion.ref_idx[0][q] = 0;
+        pskip_motion.ref_slot[0][q] = static_cast<int8_t>(r->slot);
+      }
+      pskip_ref_uid = r->uid;
+    }
+  }
+
+  // P_Skip in one pass: exactly the stores begin_mb + decode_skip_mb + commit_mb make for it
+  // (tests/golden/parser_digest.json pins the records byte for byte).
+  bool decode_pskip(int addr) {
+    const Pps& p = *apps;
+    last_qp_delta_nonzero = 0;
+    // host-side context state the neighbours will ask for
+    mb_slice[addr] = static_cast<int16_t>(slice_index);
+    mb_kind[addr] = MB_INTER;
+    mb_skip[addr] = 1;
+    mb_direct[addr] = 0;
+    mb_t8x8[addr] = 0;
+    mb_cbp[addr] = 0;
+    mb_cbf_dc[addr] = 0;
+    mb_chroma_mode[addr] = 0;
+    memset(&i4mode[addr * 16], 2, 16);
+    memset(&nnz[addr * 24], 0, 24);
+    memset(mvd_at(addr, 0, 0), 0, 64);
+    memset(&direct8[addr * 4], 0, 4);
+    cur->mb_intra[addr] = 0;
+    cur->motion[addr] = pskip_motion;
+    for (int q = 0; q < 4; ++q) {
+      cur->ref_uid[0][addr * 4 + q] = pskip_ref_uid;
+      cur->ref_uid[1][addr * 4 + q] = -1;
+    }
+    has_inter = true;
+    ++mbs_decoded;
+    // the record
+    MbInfo o;
+    memset(&o, 0, sizeof(o));
+    o.kind = amd::MBK_INTER;
+    uint8_t f = 0;
+    if (!p.constrained_intra_pred) {
+      f |= (mb.av[3] ? amd::MBF_AVAIL_A : 0) | (mb.av[1] ? amd::MBF_AVAIL_B : 0) | (mb.av[2] ? amd::MBF_AVAIL_C : 0) |
+           (mb.av[0] ? amd::MBF_AVAIL_D : 0);
+    } else {
+      if (intra_mb_ok(mb.mbx - 1, mb.mby)) f |= amd::MBF_AVAIL_A;
+      if (intra_mb_ok(mb.mbx, mb.mby - 1)) f |= amd::MBF_AVAIL_B;
+      if (intra_mb_ok(mb.mbx + 1, mb.mby - 1)) f |= amd::MBF_AVAIL_C;
+      if (intra_mb_ok(mb.mbx - 1, mb.mby - 1)) f |= amd::MBF_AVAIL_D;
+    }
+    if (sl.disable_deblock != 1) {
+      if (mb.mbx > 0 && !(sl.disable_deblock == 2 && mb_slice[addr - 1] != mb_slice[addr])) f |= amd::MBF_DB_LEFT;
+      if (mb.mby > 0 && !(sl.disable_deblock == 2 && mb_slice[addr - mbw] != mb_slice[addr])) f |= amd::MBF_DB_TOP;
+      o.deblock_internal = 1;
+    }
+    o.flags = f;
+    o.qp = static_cast<uint8_t>(qp);
+    o.qpc[0] = chroma_qp_table[iclip(0, 51, qp + p.chroma_qp_offset[0])];
+    o.qpc[1] = chroma_qp_table[iclip(0, 51, qp + p.chroma_qp_offset[1])];
+    o.slice = static_cast<uint8_t>(slice_index - 1);
+    const uint8_t mf = static_cast<uint8_t>(amd::MVF_DEFERRED | amd::MVF_PSKIP | (mb.av[3] ? amd::MVF_AVAIL_A : 0) |
+                                            (mb.av[1] ? amd::MVF_AVAIL_B : 0) | (mb.av[2] ? amd::MVF_AVAIL_C : 0) |
+                                            (mb.av[0] ? amd::MVF_AVAIL_D : 0));
+    o.mv_flags = mf;
+    uint8_t* rec = &cur->mvrec[static_cast<size_t>(addr) * 3];
+    rec[0] = mf;
+    rec[1] = rec[2] = 0;
+    cur->mv_deferred = true;
+    memset(o.i4_modes, 0x22, sizeof(o.i4_modes));
+    o.coef_offset = static_cast<uint32_t>(coef_used);
+    bufs.mb[addr] = o;
+    return true;
+  }
+
   bool decode_skip_mb(int addr) {
+    if (sl.type == 0) return decode_pskip(addr);
     begin_mb(addr);
     mb.kind = MB_INTER;
     mb.skip = 1;
@@ -2511,6 +2660,8 @@ struct Parser::Impl {
     const int nmb = mbw * mbh;
     int addr = sl.first_mb;
     if (addr >= nmb) return fail("first_mb_in_slice out of range");
+    pos_valid = false;
+    if (sl.type == 0) prepare_pskip();
     qp = sl.qp;
     last_qp_delta_nonzero = 0;
     use_cabac = p.cabac;
@@ -2522,8 +2673,8 @@ struct Parser::Impl {
       for (;;) {
         if (addr >= nmb) return fail("slice runs past the end of the picture");
         bool skipped = false;
+        set_position(addr);
         if (sl.type != 2) {
-          set_position(addr);
           int inc = 0;
           if (mb.avA && !mb_skip[addr - 1]) inc++;
           if (mb.avB && !mb_skip[addr - mbw]) inc++;
@@ -2550,12 +2701,14 @@ struct Parser::Impl {
         unsigned run = bits.ue();
         if (run > static_cast<unsigned>(nmb - addr)) return fail("mb_skip_run out of range");
         while (run--) {
+          set_position(addr);
           if (!decode_skip_mb(addr)) return false;
           ++addr;
         }
         if (!bits.more_rbsp_data()) break;
       }
       if (addr >= nmb) return fail("slice runs past the end of the picture");
+      set_position(addr);
       if (!decode_mb(addr)) return false;
       if (bits.overrun) return fail("slice data ran past the end of the NAL unit");
       ++addr;
