@@ -33,6 +33,9 @@ typedef struct {
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
   int scaling;      /* bit 0: SPS scaling matrices, bit 1: PPS scaling matrices (fall-back rules A and B, default flag) */
+  /* container variants (hwang/mp4_index_creator.cpp:516-733 and the stz2 / co64 branches of the moov parser) */
+  int fragmented;   /* 1..3: mvex/trex + one moof+mdat per GOP, three different tfhd / trun flag combinations */
+  int co64, stz2;   /* 64-bit chunk offsets; compact sample sizes (16-bit fields) */
   const char* out;
   const char* yuv_out;
   int fps;
@@ -1652,10 +1655,12 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
     box_end(m, v);
     box_end(m, a);
 
+    if (c->fragmented) n = 0; /* the sample tables of a fragmented file are empty: everything comes from the moofs */
     a = box_begin(m, "stts");
-    b32(m, 0); b32(m, 1); b32(m, (uint32_t)n); b32(m, delta);
+    b32(m, 0); b32(m, n ? 1 : 0);
+    if (n) { b32(m, (uint32_t)n); b32(m, delta); }
     box_end(m, a);
-    if (has_b) {
+    if (has_b && n) {
       a = box_begin(m, "ctts");
       b32(m, 0); b32(m, (uint32_t)n);
       for (size_t i = 0; i < n; ++i) { b32(m, 1); b32(m, (uint32_t)(cts[i] * (int32_t)delta)); }
@@ -1668,18 +1673,29 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
     for (size_t i = 0; i < n; ++i) if (keys[i]) b32(m, (uint32_t)i + 1);
     box_end(m, a);
     a = box_begin(m, "stsc");
-    b32(m, 0); b32(m, 1); b32(m, 1); b32(m, (uint32_t)n); b32(m, 1);
+    b32(m, 0); b32(m, n ? 1 : 0);
+    if (n) { b32(m, 1); b32(m, (uint32_t)n); b32(m, 1); }
     box_end(m, a);
-    a = box_begin(m, "stsz");
-    b32(m, 0); b32(m, 0); b32(m, (uint32_t)n);
-    for (size_t i = 0; i < n; ++i) b32(m, sizes[i]);
+    int fits16 = c->stz2;
+    for (size_t i = 0; i < n; ++i) fits16 &= sizes[i] < 65536;
+    if (fits16 && n) {
+      a = box_begin(m, "stz2");
+      b32(m, 0); b32(m, 16); b32(m, (uint32_t)n); /* reserved(24) + field_size(8) */
+      for (size_t i = 0; i < n; ++i) b16(m, sizes[i]);
+    } else {
+      a = box_begin(m, "stsz");
+      b32(m, 0); b32(m, 0); b32(m, (uint32_t)n);
+      for (size_t i = 0; i < n; ++i) b32(m, sizes[i]);
+    }
     box_end(m, a);
-    if (mdat_payload_offset > 0xfffffff0ULL) {
+    if (mdat_payload_offset > 0xfffffff0ULL || c->co64) {
       a = box_begin(m, "co64");
-      b32(m, 0); b32(m, 1); b64(m, mdat_payload_offset);
+      b32(m, 0); b32(m, n ? 1 : 0);
+      if (n) b64(m, mdat_payload_offset);
     } else {
       a = box_begin(m, "stco");
-      b32(m, 0); b32(m, 1); b32(m, (uint32_t)mdat_payload_offset);
+      b32(m, 0); b32(m, n ? 1 : 0);
+      if (n) b32(m, (uint32_t)mdat_payload_offset);
     }
     box_end(m, a);
   }
@@ -1687,7 +1703,74 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
   box_end(m, minf);
   box_end(m, mdia);
   box_end(m, trak);
+  if (c->fragmented) {
+    size_t a = box_begin(m, "mvex");
+    size_t t = box_begin(m, "trex");
+    /* track 1, description 1, duration, default size 0, default flags: not a sync sample */
+    b32(m, 0); b32(m, 1); b32(m, 1); b32(m, 1000); b32(m, 0); b32(m, 0x00010000);
+    box_end(m, t);
+    box_end(m, a);
+  }
   box_end(m, moov);
+}
+
+/* One movie fragment: moof for the samples [first, first + count) followed by
+ * the mdat header.  `variant` picks the tfhd / trun flag combination; `at` is
+ * the file offset the moof will have.  Returns the bytes (moof + 8 of mdat). */
+static void build_moof(Buf* m, int variant, uint32_t seq, uint64_t at, const uint32_t* sizes, const uint8_t* keys,
+                       const int32_t* cts, size_t count) {
+  const size_t moof = box_begin(m, "moof");
+  size_t a = box_begin(m, "mfhd");
+  b32(m, 0); b32(m, seq);
+  box_end(m, a);
+  const size_t traf = box_begin(m, "traf");
+  /* two passes: the data offsets depend on the moof's own size */
+  const size_t tfhd_at = m->n;
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint64_t moof_size = pass ? m->n - moof : 0; /* pass 0 writes placeholders, sizes do not change */
+    m->n = tfhd_at;
+    const uint64_t payload = at + moof_size + 8; /* first byte after the mdat header */
+    a = box_begin(m, "tfhd");
+    if (variant == 1) { /* default-base-is-moof; flags and sizes from trun / trex */
+      b32(m, 0x020000); b32(m, 1);
+    } else if (variant == 2) { /* explicit base data offset + default sample flags (non-sync) */
+      b32(m, 0x000001 | 0x000020); b32(m, 1); b64(m, payload); b32(m, 0x00010000);
+    } else { /* nothing: base = this moof (first traf), trex defaults */
+      b32(m, 0); b32(m, 1);
+    }
+    box_end(m, a);
+    const size_t nruns = variant == 3 && count > 1 ? 2 : 1;
+    size_t done = 0;
+    for (size_t r = 0; r < nruns; ++r) {
+      const size_t cnt = nruns == 1 ? count : (r == 0 ? count / 2 : count - count / 2);
+      a = box_begin(m, "trun");
+      if (variant == 1) {
+        b32(m, 0x000001 | 0x000004 | 0x000200); b32(m, (uint32_t)cnt);
+        b32(m, (uint32_t)(moof_size + 8));       /* data offset, relative to the moof */
+        b32(m, keys[0] ? 0x02000000 : 0x00010000); /* first_sample_flags */
+        for (size_t i = 0; i < cnt; ++i) b32(m, sizes[i]);
+      } else if (variant == 2) {
+        b32(m, 0x000100 | 0x000200 | 0x000400 | 0x000800); b32(m, (uint32_t)cnt); /* no data offset: continues at the base */
+        for (size_t i = 0; i < cnt; ++i) {
+          b32(m, 1000); b32(m, sizes[i]); b32(m, keys[i] ? 0x02000000 : 0x00010000); b32(m, (uint32_t)(cts[i] * 1000));
+        }
+      } else {
+        /* first run: data offset + per-sample flags; second run: neither (follows the first) */
+        uint64_t off = moof_size + 8;
+        if (r == 0) { b32(m, 0x000001 | 0x000200 | 0x000400); b32(m, (uint32_t)cnt); b32(m, (uint32_t)off); }
+        else { b32(m, 0x000200 | 0x000400); b32(m, (uint32_t)cnt); }
+        for (size_t i = 0; i < cnt; ++i) { b32(m, sizes[done + i]); b32(m, keys[done + i] ? 0x02000000 : 0x00010000); }
+      }
+      box_end(m, a);
+      done += cnt;
+    }
+    box_end(m, traf);
+    box_end(m, moof);
+  }
+  uint64_t payload_bytes = 0;
+  for (size_t i = 0; i < count; ++i) payload_bytes += sizes[i];
+  b32(m, (uint32_t)(payload_bytes + 8));
+  bput(m, "mdat", 4);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1797,6 +1880,9 @@ int main(int argc, char** argv) {
   c.rplm = arg_int(argc, argv, "--rplm", 0);
   c.mmco = arg_int(argc, argv, "--mmco", 0);
   c.scaling = arg_int(argc, argv, "--scaling", 0);
+  c.fragmented = arg_int(argc, argv, "--fragmented", 0);
+  c.co64 = arg_int(argc, argv, "--co64", 0);
+  c.stz2 = arg_int(argc, argv, "--stz2", 0);
   if (c.wp_denom < 0 || c.wp_denom > 7) c.wp_denom = 5;
   if (c.explicit_wp) c.implicit_wp = 0;
   c.out = arg_str(argc, argv, "--out", "out.mp4");
@@ -1876,6 +1962,28 @@ int main(int argc, char** argv) {
   }
   fwrite(head.b, 1, head.n, f);
   fwrite(moov.b, 1, moov.n, f);
+  if (c.fragmented) {
+    /* one moof + mdat per GOP (DASH-style); sizes / keys / cts are indexed in decode order */
+    uint64_t at = head.n + moov.n;
+    size_t k0 = 0;
+    uint32_t seq = 1;
+    for (int rep = 0; rep < c.repeat; ++rep)
+      for (int g = 0; g < wk.ngops; ++g) {
+        const size_t cnt = (size_t)wk.gops[g].count;
+        Buf frag = {0};
+        build_moof(&frag, c.fragmented, seq++, at, sizes + k0, keys + k0, cts + k0, cnt);
+        fwrite(frag.b, 1, frag.n, f);
+        at += frag.n;
+        for (size_t i = 0; i < cnt; ++i) {
+          fwrite(wk.gops[g].samples[i].data, 1, wk.gops[g].samples[i].size, f);
+          at += wk.gops[g].samples[i].size;
+        }
+        free(frag.b);
+        k0 += cnt;
+      }
+    fclose(f);
+    goto wrote;
+  }
   if (big) {
     Buf h = {0};
     b32(&h, 1); bput(&h, "mdat", 4); b64(&h, payload + 16);
@@ -1889,6 +1997,7 @@ int main(int argc, char** argv) {
     for (int g = 0; g < wk.ngops; ++g)
       for (int i = 0; i < wk.gops[g].count; ++i) fwrite(wk.gops[g].samples[i].data, 1, wk.gops[g].samples[i].size, f);
   fclose(f);
+wrote:
 
   if (c.yuv_out) {
     FILE* y = fopen(c.yuv_out, "wb");

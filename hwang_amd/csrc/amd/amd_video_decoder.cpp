@@ -21,6 +21,7 @@
 
 #include "../h264/h264_parser.h"
 #include "../sparse_hints.h"
+#include "../util/queue.h"
 #include "frame_job.h"
 #include "gpu_executor.h"
 #include "hip_check.h"
@@ -127,11 +128,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   Result discard_frame() override {
+    int slot;
+    if (!outq_.try_pop(slot)) return Result();
+    buffered_.fetch_sub(1, std::memory_order_acq_rel);
     std::lock_guard<std::mutex> lk(out_mu_);
-    if (outq_.empty()) return Result();
-    const int slot = outq_.front();
-    outq_.pop_front();
-    buffered_.store(static_cast<int>(outq_.size()));
     if (slot >= 0) unref_surface_locked(slot, kHeldByOutput);
     return Result();
   }
@@ -303,10 +303,12 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   void output_picture(int slot) override {
-    std::lock_guard<std::mutex> lk(out_mu_);
-    if (slot >= 0) surf_[slot].held |= kHeldByOutput;
-    outq_.push_back(slot);
-    buffered_.store(static_cast<int>(outq_.size()), std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      if (slot >= 0) surf_[slot].held |= kHeldByOutput;
+    }
+    outq_.push(slot);  // display order; the consumer side is get_frame / discard_frame
+    buffered_.fetch_add(1, std::memory_order_acq_rel);
   }
 
   void release_surface(int slot) override {
@@ -458,10 +460,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     return true;
   }
 
-  bool frames_pending_output() {
-    std::lock_guard<std::mutex> lk(out_mu_);
-    return !outq_.empty();
-  }
+  bool frames_pending_output() { return outq_.size() != 0; }
 
   bool alloc_surface(int slot, std::string* error) {
     SurfaceSlot& s = surf_[slot];
@@ -564,18 +563,15 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const size_t cw = (w + 1) / 2, ch = (h + 1) / 2;
     const size_t need = yuv ? w * h + 2 * cw * ch : w * h * 3;
     int slot;
-    {
-      std::lock_guard<std::mutex> lk(out_mu_);
-      if (outq_.empty()) return Result();  // reference behaviour: nothing to do
-      if (dst_size < need) return Result(false, "AMDVideoDecoder::get_frame: buffer too small");
-      slot = outq_.front();
-      if (slot < 0)
-        return Result(false,
-                      "AMDVideoDecoder::get_frame: this output position was excluded by the sparse hint "
-                      "(set_wanted) and was not decoded");
-      outq_.pop_front();
-      buffered_.store(static_cast<int>(outq_.size()));
-    }
+    // (one consumer thread per instance - get_frame / discard_frame - so peek-then-pop is safe)
+    if (!outq_.try_peek(slot)) return Result();  // reference behaviour: nothing to do
+    if (dst_size < need) return Result(false, "AMDVideoDecoder::get_frame: buffer too small");
+    if (slot < 0)
+      return Result(false,
+                    "AMDVideoDecoder::get_frame: this output position was excluded by the sparse hint "
+                    "(set_wanted) and was not decoded");
+    outq_.try_pop(slot);
+    buffered_.fetch_sub(1, std::memory_order_acq_rel);
     const SurfaceSlot& s = surf_[slot];
     amd::ConvSubmit sub;
     std::memset(&sub.desc, 0, sizeof(sub.desc));
@@ -664,7 +660,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   int bounce_cursor_ = 0;
 
   std::mutex out_mu_;
-  std::deque<int> outq_;  // surface slot per frame in display order, -1 = skipped
+  Queue<int> outq_{4096};  // surface slot per frame in display order, -1 = skipped (hwang/util/queue.h's role)
   std::atomic<int> buffered_{0};
 
   BackendCounters counters_;

@@ -348,6 +348,8 @@ __device__ __forceinline__ int tap6_row(const uint32_t* w, int i) {  // bytes i 
   return tap6(BYTE_OF(w, i), BYTE_OF(w, i + 1), BYTE_OF(w, i + 2), BYTE_OF(w, i + 3), BYTE_OF(w, i + 4), BYTE_OF(w, i + 5));
 }
 
+__device__ __forceinline__ void luma_filter4(const uint32_t (*w)[3], int fx, int fy, int* out);
+
 // plane: reference luma; (px, py): position of the lane's first sample; mv in quarter samples
 __device__ __forceinline__ void luma_pred4(const uint8_t* plane, int pitch, int W, int H, int px, int py, int mvx,
                                            int mvy, int* out) {
@@ -377,6 +379,15 @@ __device__ __forceinline__ void luma_pred4(const uint8_t* plane, int pitch, int 
       row_clamped(plane, pitch, W, H, xs, y - 2 + r, nd, w[r]);
     }
   }
+  luma_filter4(w, fx, fy, out);
+}
+
+// The arithmetic of 8.4.2.2.1 on a lane's 6 x 12-byte neighbourhood.  w[r] is row
+// y - 2 + r; with a horizontal fraction byte 0 is column x - 2 (nine bytes used),
+// without one byte 0 is column x (four bytes used); without a vertical fraction
+// only w[2] is read.
+__device__ __forceinline__ void luma_filter4(const uint32_t (*w)[3], int fx, int fy, int* out) {
+  const bool horiz = fx != 0, vert = fy != 0;
   if (!horiz && !vert) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) out[i] = BYTE_OF(w[2], i);
@@ -442,6 +453,7 @@ __device__ __forceinline__ void luma_pred4(const uint8_t* plane, int pitch, int 
   }
 }
 
+__device__ __forceinline__ void chroma_filter2(uint32_t a, uint32_t c, int fx, int fy, int* out);
 // two horizontally adjacent chroma samples (8.4.2.2.2); mv in eighth samples
 __device__ __forceinline__ void chroma_pred2(const uint8_t* plane, int pitch, int W, int H, int px, int py, int mvx,
                                              int mvy, int* out) {
@@ -458,6 +470,10 @@ __device__ __forceinline__ void chroma_pred2(const uint8_t* plane, int pitch, in
     row_clamped(plane, pitch, W, H, x, y + 1, 1, t);
     c = t[0];
   }
+  chroma_filter2(a, c, fx, fy, out);
+}
+// a: three bytes of row y from column x, c: of row y + 1
+__device__ __forceinline__ void chroma_filter2(uint32_t a, uint32_t c, int fx, int fy, int* out) {
   const int a0 = a & 0xff, a1 = (a >> 8) & 0xff, a2 = (a >> 16) & 0xff;
   const int c0 = c & 0xff, c1 = (c >> 8) & 0xff, c2 = (c >> 16) & 0xff;
   out[0] = ((8 - fx) * (8 - fy) * a0 + fx * (8 - fy) * a1 + (8 - fx) * fy * c0 + fx * fy * c1 + 32) >> 6;
@@ -465,11 +481,17 @@ __device__ __forceinline__ void chroma_pred2(const uint8_t* plane, int pitch, in
 }
 
 constexpr int kInterWaves = 4;
+// Reference window of one macroblock and one list, staged in LDS with the
+// macroblock's (integer) displacement already applied: luma rows y0-2 .. y0+18,
+// 24 bytes from column x0-2 (21 used), chroma 9 rows of 12 bytes (9 used).
+constexpr int kWinLumaRows = 21, kWinLumaDw = 6, kWinChromaRows = 9, kWinChromaDw = 3;
+constexpr int kWinDwords = kWinLumaRows * kWinLumaDw + 2 * kWinChromaRows * kWinChromaDw;  // 180
 struct InterWave {
   int work[384];
   int dcs[24];
   int16_t res_y[256];
   int16_t res_c[128];
+  uint32_t win[2][kWinDwords];
 };
 
 }  // namespace
@@ -477,8 +499,18 @@ struct InterWave {
 // ===========================================================================
 // k_inter: one WAVE per inter macroblock, four macroblocks (64 luma bytes per
 // row) per workgroup, no workgroup barriers.  Per macroblock:
-//   residual (dequant + IDCT) into LDS unless nothing was coded,
-//   each lane predicts 4 luma + 2 chroma samples per list in registers,
+//   residual (dequant + IDCT) into LDS unless nothing was coded;
+//   prediction.  A macroblock whose sixteen blocks share one vector and one
+//   reference per list (P_Skip, 16x16, B direct with uniform motion: ~ 88 % of
+//   the inter macroblocks of the bench corpus) takes the WINDOW path: the wave
+//   fetches the (16 + 5)^2 luma and two (8 + 1)^2 chroma neighbourhoods of each
+//   list ONCE, cooperatively - 180 unaligned dword loads per list, all issued
+//   before anything waits: one memory round trip - into LDS, shifted so that
+//   every lane's bytes start dword-aligned, and the 6-tap / bilinear filters
+//   read LDS.  (Before: every lane fetched its own 6 x 12 bytes, 18 loads per
+//   lane and list, 1152 per wave: 6.4 x the load instructions and a second
+//   round trip for chroma.)  Other macroblocks (partitions with different
+//   vectors, windows that leave the picture) take the per-lane register path;
 //   weighted combination, + residual, one dword / one halfword store.
 // Workgroups are numbered so that each XCD (blockIdx % 8) owns a contiguous
 // band of the picture: its L2 then sees whole cache lines of the output and
@@ -516,20 +548,107 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
   InterWave& L = lds[wave];
   const int mbx = mbi % pp.mb_width, mby = mbi / pp.mb_width;
   const bool has_res = mb.coded_mask != 0;
+  const int W = pp.mb_width * 16, H = pp.mb_height * 16;
+  auto byte_of = [](uint32_t w, int k) { return (int)(int8_t)((w >> (8 * k)) & 0xff); };
+
+  // ---- window path: is the macroblock's motion uniform per list, and do its windows lie inside the picture?
+  // (wave-uniform decisions: every lane holds one of the sixteen vectors, all four reference bytes)
+  bool use_win[2];
+  int wmvx[2], wmvy[2];
+  const uint8_t* wsrc[2][3];
+  bool window = true;
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const uint32_t mvw = l ? mvw1 : mvw0, idx = l ? idx1 : idx0, slots = l ? slots1 : slots0;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(mvw);
+    const int r = byte_of(idx, 0);
+    use_win[l] = r >= 0;
+    const bool uniform = __all(mvw == first) && idx == (idx & 0xff) * 0x01010101u && slots == (slots & 0xff) * 0x01010101u;
+    wmvx[l] = (int16_t)(first & 0xffff);
+    wmvy[l] = (int16_t)(first >> 16);
+    const int x0 = mbx * 16 + (wmvx[l] >> 2) - 2, y0 = mby * 16 + (wmvy[l] >> 2) - 2;
+    const int cx0 = mbx * 8 + (wmvx[l] >> 3), cy0 = mby * 8 + (wmvy[l] >> 3);
+    const bool inside = x0 >= 0 && x0 + 21 <= W && y0 >= 0 && y0 + 21 <= H && cx0 >= 0 && cx0 + 9 <= W / 2 && cy0 >= 0 &&
+                        cy0 + 9 <= H / 2;
+    if (idx != 0xffffffffu) window = window && uniform && inside;  // a list nobody uses constrains nothing
+    else use_win[l] = false;
+    if (use_win[l]) {
+      const Surface& sf = pp.surfaces[byte_of(slots, 0)];
+      wsrc[l][0] = sf.y + (size_t)y0 * pp.y_pitch + x0;
+      wsrc[l][1] = sf.u + (size_t)cy0 * pp.c_pitch + cx0;
+      wsrc[l][2] = sf.v + (size_t)cy0 * pp.c_pitch + cx0;
+    }
+  }
+  window = window && (use_win[0] || use_win[1]);
+  // issue every reference load of the macroblock now; they land while the residual is computed
+  uint32_t wreg[2][3];
+  if (window) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      if (!use_win[l]) continue;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int t = lane + 64 * k;
+        uint32_t v = 0;
+        if (t < kWinLumaRows * kWinLumaDw) {
+          const int r = t / kWinLumaDw, d = t - r * kWinLumaDw;
+          v = ld32u(wsrc[l][0] + (size_t)r * pp.y_pitch + 4 * d);
+        } else if (t < kWinDwords) {
+          const int u = t - kWinLumaRows * kWinLumaDw, pl = u >= kWinChromaRows * kWinChromaDw;
+          const int q = u - pl * kWinChromaRows * kWinChromaDw, r = q / kWinChromaDw, d = q - r * kWinChromaDw;
+          v = ld32u(wsrc[l][1 + pl] + (size_t)r * pp.c_pitch + 4 * d);
+        }
+        wreg[l][k] = v;
+      }
+    }
+  }
   if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+  if (window) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      if (!use_win[l]) continue;
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (lane + 64 * k < kWinDwords) L.win[l][lane + 64 * k] = wreg[l][k];
+    }
+    wave_sync();
+  }
 
   const SliceParams& sp = job.slices[mb.slice];
   const Surface cur = pp.surfaces[pp.cur_slot];
-  const int W = pp.mb_width * 16, H = pp.mb_height * 16;
-  auto byte_of = [](uint32_t w, int k) { return (int)(int8_t)((w >> (8 * k)) & 0xff); };
   {  // luma
     const int r0 = byte_of(idx0, b8), r1 = byte_of(idx1, b8);
     const int px = mbx * 16 + bcol * 4, py = mby * 16 + y;
     int s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    if (r0 >= 0)
-      luma_pred4(pp.surfaces[byte_of(slots0, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
-    if (r1 >= 0)
-      luma_pred4(pp.surfaces[byte_of(slots1, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
+    if (window) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        if (!use_win[l]) continue;
+        const int fx = wmvx[l] & 3, fy = wmvy[l] & 3;
+        // rows y .. y+5 of the window are sample rows y-2 .. y+3; bytes from column 4*bcol (= x - 2)
+        uint32_t w[6][3];
+        const uint32_t* base = L.win[l] + y * kWinLumaDw + bcol;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          if ((fy == 0) && r != 2) continue;
+          const uint32_t d0 = base[r * kWinLumaDw], d1 = base[r * kWinLumaDw + 1], d2 = base[r * kWinLumaDw + 2];
+          if (fx != 0) {
+            w[r][0] = d0;
+            w[r][1] = d1;
+            w[r][2] = d2;
+          } else {  // no horizontal fraction: the filter expects column x at byte 0
+            w[r][0] = __builtin_amdgcn_alignbyte(d1, d0, 2);
+            w[r][1] = w[r][2] = 0;
+          }
+        }
+        luma_filter4(w, fx, fy, l ? s1 : s0);
+      }
+    } else {
+      if (r0 >= 0)
+        luma_pred4(pp.surfaces[byte_of(slots0, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
+      if (r1 >= 0)
+        luma_pred4(pp.surfaces[byte_of(slots1, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
+    }
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -543,13 +662,26 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     const int r0 = byte_of(idx0, cb8), r1 = byte_of(idx1, cb8);
     const int px = mbx * 8 + cbcol * 2, py = mby * 8 + cy;
     int s0[2] = {0, 0}, s1[2] = {0, 0};
-    if (r0 >= 0) {
-      const Surface& sf = pp.surfaces[byte_of(slots0, cb8)];
-      chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
-    }
-    if (r1 >= 0) {
-      const Surface& sf = pp.surfaces[byte_of(slots1, cb8)];
-      chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
+    if (window) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        if (!use_win[l]) continue;
+        // row cy of the chroma window, bytes from column 2*cbcol: dword cbcol >> 1, shifted by two bytes for odd cbcol
+        const uint32_t* rowp = L.win[l] + kWinLumaRows * kWinLumaDw + cplane * kWinChromaRows * kWinChromaDw + cy * kWinChromaDw + (cbcol >> 1);
+        const uint32_t a0 = rowp[0], a1 = rowp[1], c0 = rowp[kWinChromaDw], c1 = rowp[kWinChromaDw + 1];
+        const uint32_t a = (cbcol & 1) ? __builtin_amdgcn_alignbyte(a1, a0, 2) : a0;
+        const uint32_t c = (cbcol & 1) ? __builtin_amdgcn_alignbyte(c1, c0, 2) : c0;
+        chroma_filter2(a, c, wmvx[l] & 7, wmvy[l] & 7, l ? s1 : s0);
+      }
+    } else {
+      if (r0 >= 0) {
+        const Surface& sf = pp.surfaces[byte_of(slots0, cb8)];
+        chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
+      }
+      if (r1 >= 0) {
+        const Surface& sf = pp.surfaces[byte_of(slots1, cb8)];
+        chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
+      }
     }
     uint32_t packed = 0;
 #pragma unroll

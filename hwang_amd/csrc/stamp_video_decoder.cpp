@@ -23,7 +23,7 @@ Result StampVideoDecoder::feed(const uint8_t* encoded_buffer,
   if (keyframe) ++trace_.keyframe_feeds;
   uint32_t stamp = 0;
   std::memcpy(&stamp, encoded_buffer, encoded_size < 4 ? encoded_size : 4);
-  stamps_.push_back(stamp);
+  stamps_.push(stamp);
   return Result();
 }
 
@@ -35,30 +35,28 @@ Result StampVideoDecoder::flush() {
 
 Result StampVideoDecoder::discard_frame() {
   std::lock_guard<std::mutex> lk(m_);
-  if (!stamps_.empty()) {
-    stamps_.pop_front();
-    ++trace_.discards;
-  }
+  uint32_t stamp;
+  if (stamps_.try_pop(stamp)) ++trace_.discards;
   return Result();
 }
 
 Result StampVideoDecoder::get_frame(uint8_t* decoded_buffer,
                                     size_t decoded_size) {
   std::lock_guard<std::mutex> lk(m_);
-  if (stamps_.empty()) return Result();
+  uint32_t stamp;
+  if (!stamps_.try_peek(stamp)) return Result();
   const size_t need = static_cast<size_t>(info_.width) * info_.height * 3;
   if (decoded_size < need || need < 4) {
     return Result(false, "StampVideoDecoder::get_frame: buffer too small");
   }
   std::memset(decoded_buffer, 0, need);
-  std::memcpy(decoded_buffer, &stamps_.front(), 4);
-  stamps_.pop_front();
+  std::memcpy(decoded_buffer, &stamp, 4);
+  stamps_.try_pop(stamp);
   ++trace_.gets;
   return Result();
 }
 
 int StampVideoDecoder::decoded_frames_buffered() {
-  std::lock_guard<std::mutex> lk(m_);
   return static_cast<int>(stamps_.size());
 }
 

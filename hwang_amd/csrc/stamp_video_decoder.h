@@ -6,9 +6,9 @@
 #pragma once
 
 #include "sparse_hints.h"
+#include "util/queue.h"
 #include "video_decoder_interface.h"
 
-#include <deque>
 #include <mutex>
 
 namespace hwang {
@@ -36,7 +36,7 @@ class StampVideoDecoder : public VideoDecoderInterface, public SparseDecodeHints
  private:
   std::mutex m_;
   FrameInfo info_{};
-  std::deque<uint32_t> stamps_;
+  Queue<uint32_t> stamps_{1 << 20};  // one entry per fed sample, consumed by get_frame / discard_frame
   Trace trace_;
 };
 
