@@ -49,6 +49,7 @@ namespace {
 
 using amd::MbInfo;
 using amd::MbMotion;
+using amd::PMotion;
 using amd::SliceParams;
 
 constexpr int kJobs = 4;        // staging ring depth
@@ -234,6 +235,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     job_cursor_ = (job_cursor_ + 1) % kJobs;
     out->mb = j.mb_host;
     out->motion = surf_[slot].motion_host;
+    out->pmo = surf_[slot].pmo_host;
+    out->pmx = surf_[slot].pmx_host;
+    out->pmx_capacity = pmx_words_;
     out->coefs = j.coef_host;
     out->coef_capacity = coef_capacity_;
     out->slices = j.slice_host;
@@ -259,7 +263,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     add_copy(j.mb_dev, j.mb_host, nmb * sizeof(MbInfo));
     if (d.coef_count) add_copy(j.coef_dev, j.coef_host, d.coef_count * 2);
     add_copy(j.slice_dev, j.slice_host, d.num_slices * sizeof(SliceParams));
-    if (d.has_inter) add_copy(j.motion_dev, surf_[d.slot].motion_host, nmb * sizeof(MbMotion));
+    // motion: full 144-byte records only for macroblocks the host derived itself (B slices, pictures too wide
+    // for k_mv); everything k_mv derives travels as 12-byte records + the extra differences
+    if (d.has_inter && d.full_motion) add_copy(j.motion_dev, surf_[d.slot].motion_host, nmb * sizeof(MbMotion));
+    if (d.compact_motion && d.has_inter) {  // (an intra-only picture's records are read by nobody)
+      add_copy(j.pmo_dev, surf_[d.slot].pmo_host, nmb * sizeof(PMotion));
+      add_copy(j.pmx_dev, surf_[d.slot].pmx_host, d.pmx_count * sizeof(uint32_t));
+    }
     amd::PictureParams& pp = sub.desc.pp;
     pp.mb_width = mbw_;
     pp.mb_height = mbh_;
@@ -281,6 +291,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.db = j.db_dev;
     sub.desc.resid = j.resid_dev;
     sub.desc.band_ctl = j.band_ctl_dev;
+    sub.desc.pmo = j.pmo_dev;
+    sub.desc.pmx = j.pmx_dev;
     if (++epoch_ == 0) ++epoch_;
     sub.desc.epoch = epoch_;
     sub.desc.do_inter = d.has_inter;
@@ -298,7 +310,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.bytes_mv = d.mv_deferred ? nmb * (sizeof(MbInfo) + 80 + 64) : 0;  // header + differences/refs in, vectors out
     j.seq = exec_->submit_picture(lane_, sub);
     note_seq(j.seq);
-    if (d.has_inter) surf_[d.slot].motion_seq = j.seq;
+    if (d.has_inter || d.compact_motion) surf_[d.slot].motion_seq = j.seq;  // the surface's pinned buffers are upload sources
     return true;
   }
 
@@ -323,6 +335,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   struct SurfaceSlot {
     uint8_t* dev = nullptr;
     MbMotion* motion_host = nullptr;  // pinned; also the co-located source
+    PMotion* pmo_host = nullptr;      // pinned: compact motion records ...
+    uint32_t* pmx_host = nullptr;     // ... and their extra stream (row table + difference words)
     uint64_t motion_seq = 0;          // submission that still uploads from motion_host
     int held = 0;
   };
@@ -332,6 +346,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     SliceParams* slice_host = nullptr;
     MbInfo* mb_dev = nullptr;
     MbMotion* motion_dev = nullptr;
+    PMotion* pmo_dev = nullptr;
+    uint32_t* pmx_dev = nullptr;
     int16_t* coef_dev = nullptr;
     SliceParams* slice_dev = nullptr;
     void* db_dev = nullptr;  // k_bs -> k_deblock records
@@ -434,12 +450,15 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
     // worst case: every one of 27 groups of every macroblock coded
     coef_capacity_ = nmb * 27 * 16;
+    pmx_words_ = static_cast<size_t>(mbh_) + nmb * 15;  // row table + up to 15 further partitions per macroblock
     for (Job& j : jobs_) {
       if (hipHostMalloc(reinterpret_cast<void**>(&j.mb_host), nmb * sizeof(MbInfo), hipHostMallocDefault) != hipSuccess ||
           hipHostMalloc(reinterpret_cast<void**>(&j.coef_host), coef_capacity_ * 2, hipHostMallocDefault) != hipSuccess ||
           hipHostMalloc(reinterpret_cast<void**>(&j.slice_host), kMaxSlices * sizeof(SliceParams), hipHostMallocDefault) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.mb_dev), nmb * sizeof(MbInfo)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.motion_dev), nmb * sizeof(MbMotion)) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&j.pmo_dev), nmb * sizeof(PMotion)) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&j.pmx_dev), (pmx_words_ + 64) * sizeof(uint32_t)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.coef_dev), coef_capacity_ * 2) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.slice_dev), kMaxSlices * sizeof(SliceParams)) != hipSuccess ||
           hipMalloc(&j.db_dev, amd::deblock_scratch_bytes(static_cast<int>(nmb))) != hipSuccess ||
@@ -468,11 +487,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
     // + 64: k_inter fetches unaligned dwords and may read 3 bytes past a plane's last sample
     if (hipMalloc(reinterpret_cast<void**>(&s.dev), surface_bytes_ + 64) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s.motion_host), nmb * sizeof(MbMotion), hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void**>(&s.motion_host), nmb * sizeof(MbMotion), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s.pmo_host), nmb * sizeof(PMotion), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&s.pmx_host), pmx_words_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
       *error = "AMDVideoDecoder: out of memory for a decode surface";
       return false;
     }
-    if (!gpu_visible(s.motion_host)) {
+    if (!gpu_visible(s.motion_host) || !gpu_visible(s.pmo_host) || !gpu_visible(s.pmx_host)) {
       *error = "AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device";
       return false;
     }
@@ -492,6 +513,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       if (j.slice_host) (void)hipHostFree(j.slice_host);
       if (j.mb_dev) (void)hipFree(j.mb_dev);
       if (j.motion_dev) (void)hipFree(j.motion_dev);
+      if (j.pmo_dev) (void)hipFree(j.pmo_dev);
+      if (j.pmx_dev) (void)hipFree(j.pmx_dev);
       if (j.coef_dev) (void)hipFree(j.coef_dev);
       if (j.slice_dev) (void)hipFree(j.slice_dev);
       if (j.db_dev) (void)hipFree(j.db_dev);
@@ -502,6 +525,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     for (SurfaceSlot& s : surf_) {
       if (s.dev) (void)hipFree(s.dev);
       if (s.motion_host) (void)hipHostFree(s.motion_host);
+      if (s.pmo_host) (void)hipHostFree(s.pmo_host);
+      if (s.pmx_host) (void)hipHostFree(s.pmx_host);
       s = SurfaceSlot();
     }
     for (Bounce& b : bounce_) {
@@ -651,7 +676,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   std::vector<uint64_t> pending_wanted_;
 
   int mbw_ = 0, mbh_ = 0, y_pitch_ = 0, c_pitch_ = 0, crop_left_ = 0, crop_top_ = 0;
-  size_t u_offset_ = 0, v_offset_ = 0, surface_bytes_ = 0, coef_capacity_ = 0;
+  size_t u_offset_ = 0, v_offset_ = 0, surface_bytes_ = 0, coef_capacity_ = 0, pmx_words_ = 0;
   int64_t dbg_motion_waits_ = 0, dbg_motion_ns_ = 0, dbg_job_waits_ = 0, dbg_job_ns_ = 0;
   SurfaceSlot surf_[amd::kMaxSurfaces];
   Job jobs_[kJobs];

@@ -82,6 +82,7 @@ struct MbInfo {
 enum : uint8_t {
   MVF_DEFERRED = 1,          // mv[0] holds differences; derive (8.4.1.3)
   MVF_PSKIP = 2,             // P_Skip inference (8.4.1.1)
+  MVF_COMPACT = 4,           // the macroblock's motion travels as PMotion (+ extra differences), not as MbMotion
   // neighbouring macroblocks usable for mv prediction (same slice, inside the picture)
   MVF_AVAIL_A = 16,
   MVF_AVAIL_B = 32,
@@ -96,6 +97,21 @@ struct MbMotion {
   int8_t ref_idx[2][4];   // index into the slice's list (for weights)
 };
 static_assert(sizeof(MbMotion) == 144, "MbMotion must stay 144 bytes");
+
+// Compact motion of a macroblock in a P (or I) slice whose vectors k_mv derives:
+// what the entropy decoder knows, nothing replicated.  P_Skip and 16x16 - 88 %
+// of the inter macroblocks of the bench corpus - are complete with this record;
+// other shapes keep the differences of their 2nd .. 16th partition (decode
+// order) in the picture's extra stream, whose words the macroblocks of a row
+// consume back to back from row_start[mby] on.  k_mv expands every such
+// macroblock to its full MbMotion in HBM (k_inter and k_bs read that), so the
+// 144-byte records never cross PCIe: 12 B instead of 144 B per macroblock.
+struct PMotion {
+  int8_t ref_idx[4];   // list 0, per 8x8; -1 = intra macroblock
+  int8_t ref_slot[4];  // DPB surface of that reference
+  int16_t mvd0[2];     // difference of the first (or only) partition; 0 for P_Skip / intra
+};
+static_assert(sizeof(PMotion) == 12, "PMotion must stay 12 bytes");
 
 struct SliceParams {
   int8_t alpha_offset, beta_offset;  // already multiplied by 2
@@ -137,7 +153,7 @@ struct UploadDesc {
   const void* src;
   uint64_t bytes;
 };
-constexpr int kJobUploads = 4;
+constexpr int kJobUploads = 5;
 
 // Width (macroblocks) that the LDS line buffers of k_mv and of k_intra's
 // LDS-neighbour path cover: 4K (240) fits; wider pictures take the host path
@@ -170,6 +186,10 @@ struct alignas(16) JobDesc {
   // executor reads it when the batch completes and fails every waiter instead
   // of returning wrong samples.
   uint32_t* fault;
+  // compact motion (macroblocks flagged MVF_COMPACT): records, and the extra stream
+  // = row_start[mb_height] followed by the difference words
+  const PMotion* pmo;
+  const uint32_t* pmx;
   uint64_t reserved;
   UploadDesc uploads[kJobUploads];
 };

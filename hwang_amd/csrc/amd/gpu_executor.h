@@ -64,7 +64,7 @@ struct PicSubmit {
     void* dst;
     const void* src;
     size_t bytes;
-  } copies[4];
+  } copies[kJobUploads];
   int ncopies = 0;
   int num_mbs = 0;
   int heavy = 0;  // engine: 1 for intra-only pictures

@@ -877,7 +877,8 @@ __device__ __forceinline__ void agent_st64(uint64_t* p, uint64_t v) {
   __hip_atomic_store((HW_AS1 uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 struct MvWaveLds {
-  uint32_t mv[kMvChunk][16];  // differences in, vectors out
+  uint32_t mv[kMvChunk][16];  // the vectors of a partitioned macroblock while they are derived
+  uint32_t x[64];             // the chunk's window of the extra-difference stream
   uint32_t ref[kMvChunk];     // ref_idx[0][0..3]
   uint32_t info[kMvChunk];    // nz_mask | mv_flags << 16 | mv_shape << 24
   uint32_t kind[kMvChunk];    // kind | flags << 8 | ...
@@ -909,6 +910,8 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
   const PictureParams& pp = job.pp;
   const MbInfo* __restrict__ mbs = job.mbs;
   MbMotion* __restrict__ motions = const_cast<MbMotion*>(job.motions);
+  const PMotion* __restrict__ pmos = job.pmo;
+  const uint32_t* __restrict__ pmx = job.pmx;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mby = band * kMvWaves + wave;
   if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
@@ -957,25 +960,44 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
     // macroblock of lead is less than the memory latency once the per-macroblock
     // work is down to a fraction of a microsecond.  lane -> (macroblock lane >> 4,
     // block lane & 15) for the vectors, lanes 0..3 one macroblock each for the rest.
-    uint32_t n_mv = 0, n_ref = 0, n_info = 0, n_kind = 0, n_sub = 0;
-    auto prefetch = [&](int mbx0) {
-      const int m = min(mbx0 + (lane >> 4), W - 1);
-      n_mv = gld32(reinterpret_cast<const uint32_t*>(motions[mby * W + m].mv[0]) + (lane & 15));
+    // The macroblocks' motion arrives as PMotion (12 B: reference indices, their surfaces, the first
+    // difference) plus, for partitioned macroblocks, further differences in the row's extra stream; a
+    // 64-word window of that stream travels with every chunk.
+    uint32_t n_mv = 0, n_ref = 0, n_slot = 0, n_info = 0, n_kind = 0, n_sub = 0, n_x = 0;
+    uint32_t xptr = __builtin_amdgcn_readfirstlane(gld32(pmx + mby));  // this row's first extra word
+    auto prefetch = [&](int mbx0, uint32_t xat) {
       if (lane < kMvChunk) {
         const int q = min(mbx0 + lane, W - 1);
         const MbInfo* mi = &mbs[mby * W + q];
         n_info = gld32(reinterpret_cast<const uint8_t*>(mi) + 24);
         n_kind = gld32(mi);
         n_sub = gld8(&mi->mv_sub);
-        n_ref = gld32(motions[mby * W + q].ref_idx[0]);
+        const uint32_t* pm = reinterpret_cast<const uint32_t*>(pmos + mby * W + q);
+        n_ref = gld32(pm);
+        n_slot = gld32(pm + 1);
+        n_mv = gld32(pm + 2);
       }
+      n_x = gld32(pmx + xat + lane);
     };
-    prefetch(0);
-    asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_info), "+v"(n_kind), "+v"(n_sub));
+    // extra words a macroblock consumes: its partitions beyond the first (lanes 0..3 hold the chunk's records)
+    auto extras_of = [&](uint32_t info, uint32_t sub) -> uint32_t {
+      const uint32_t flags = (info >> 16) & 0xff, shape = (info >> 24) & 3;
+      if (!(flags & MVF_DEFERRED) || (flags & MVF_PSKIP) || shape == 0) return 0;
+      if (shape != 3) return 1;
+      uint32_t n = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t ss = (sub >> (2 * q)) & 3;
+        n += ss == 0 ? 1 : (ss == 3 ? 4 : 2);
+      }
+      return n - 1;
+    };
+    prefetch(0, xptr);
+    asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_slot), "+v"(n_info), "+v"(n_kind), "+v"(n_sub), "+v"(n_x));
     int left_ref0 = -1;         // left neighbour's top-right quadrant: reference index ...
     uint32_t left_mv0 = 0;      // ... and the vector of its block 3 (registers; L.left is the LDS copy for the general path)
     for (int mbx0 = 0; mbx0 < W; mbx0 += kMvChunk) {
-      L.mv[lane >> 4][lane & 15] = n_mv;
+      L.x[lane] = n_x;
       if (lane < kMvChunk) {
         L.ref[lane] = n_ref;
         L.info[lane] = n_info;
@@ -983,10 +1005,17 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
         L.sub[lane] = n_sub;
       }
       // the chunk's records stay in these registers (lane k holds macroblock k's
-      // words, lane 16 k its first vector difference): readlane hands them to
-      // the scalar unit without an LDS round trip
-      const uint32_t c_info = n_info, c_kind = n_kind, c_sub = n_sub, c_ref = n_ref, c_mv = n_mv;
-      if (mbx0 + kMvChunk < W) prefetch(mbx0 + kMvChunk);
+      // words): readlane hands them to the scalar unit without an LDS round trip
+      const uint32_t c_info = n_info, c_kind = n_kind, c_sub = n_sub, c_ref = n_ref, c_slot = n_slot, c_mv = n_mv;
+      // where the next chunk's extras start: behind this chunk's
+      uint32_t xo = 0;  // extras of this chunk consumed so far (index into L.x)
+      {
+        const uint32_t e = (lane < kMvChunk && mbx0 + lane < W) ? extras_of(c_info, c_sub) : 0;
+        const uint32_t total = __builtin_amdgcn_readlane(e, 0) + __builtin_amdgcn_readlane(e, 1) + __builtin_amdgcn_readlane(e, 2) +
+                               __builtin_amdgcn_readlane(e, 3);
+        xptr += total;
+      }
+      if (mbx0 + kMvChunk < W) prefetch(mbx0 + kMvChunk, xptr);
       wave_sync();
       for (int k = 0; k < kMvChunk && mbx0 + k < W; ++k) {
         const int mbx = mbx0 + k;
@@ -1058,7 +1087,7 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
           if (skip) {
             if (ra == -2 || rb == -2 || (ra == 0 && ax == 0 && ay == 0) || (rb == 0 && bx == 0 && by == 0)) mx = my = 0;
           } else {
-            const uint32_t d = __builtin_amdgcn_readlane(c_mv, k * 16);
+            const uint32_t d = __builtin_amdgcn_readlane(c_mv, k);  // PMotion::mvd0
             mx += unpack_x(d);
             my += unpack_y(d);
           }
@@ -1126,6 +1155,7 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
               for (int xx = bx; xx < bx + bw; ++xx) cmv[yy * 4 + xx] = packed;
           };
           const int nparts = shape == 3 ? 4 : 2;  // 16x16 took the path above
+          int part = 0;                           // partitions in decode order: the first difference is mvd0, the others follow in the stream
           for (int i = 0; i < nparts; ++i) {
             int px, py, pw, ph;
             if (shape == 1) { px = 0; py = i * 2; pw = 4; ph = 2; }
@@ -1146,19 +1176,29 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
                 if (shape == 2) dir = i == 0 ? 3 : 4;
                 int mx, my;
                 predict(bx, by, sw, ref, dir, mx, my);
-                const uint32_t d = __builtin_amdgcn_readfirstlane(cmv[by * 4 + bx]);
+                const uint32_t d = part == 0 ? __builtin_amdgcn_readlane(c_mv, k) : __builtin_amdgcn_readfirstlane(L.x[(xo + part - 1) & 63]);
+                ++part;
                 fill(bx, by, sw, sh, mx + unpack_x(d), my + unpack_y(d));
               }
           }
+          xo += part - 1;
         }
         wave_sync();
         // The prefetched registers have arrived by now; saying so before the store
         // below is issued keeps the next chunk from waiting on that store (in-order
         // vmcnt, see k_deblock).
         if (k == kMvChunk - 1 || mbx == W - 1)
-          asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_info), "+v"(n_kind), "+v"(n_sub));
-        // vectors out (deferred macroblocks only), edges on to the neighbours
-        if (deferred && lane < 16) gst32(reinterpret_cast<uint32_t*>(motions[mbi].mv[0]) + lane, whole ? whole_mv : cmv[lane]);
+          asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_slot), "+v"(n_info), "+v"(n_kind), "+v"(n_sub), "+v"(n_x));
+        // The macroblock's full MbMotion (36 dwords: vectors of list 0, list 1 unused, surfaces, indices) for
+        // k_inter and k_bs - written here for every compact macroblock, intra ones included (no reference).
+        if ((flags & MVF_COMPACT) && lane < 36) {
+          uint32_t v = 0;
+          if (lane < 16) v = deferred ? (whole ? whole_mv : cmv[lane]) : 0;
+          else if (lane == 32) v = intra ? 0xffffffffu : __builtin_amdgcn_readlane(c_slot, k);
+          else if (lane == 34) v = refw;
+          else if (lane == 33 || lane == 35) v = 0xffffffffu;
+          gst32(reinterpret_cast<uint32_t*>(&motions[mbi]) + lane, v);
+        }
         if (lane < 4) {
           line_me[mbx].mv[lane] = whole ? whole_mv : cmv[12 + lane];
           L.left.mv[lane] = whole ? whole_mv : cmv[lane * 4 + 3];

@@ -22,6 +22,8 @@ struct ProbeSink : public h264::PictureSink {
   struct Slot {
     bool busy = false;
     std::vector<amd::MbMotion> motion;
+    std::vector<amd::PMotion> pmo;
+    std::vector<uint32_t> pmx;
   };
   std::vector<Slot> slots = std::vector<Slot>(amd::kMaxSurfaces);
   std::vector<amd::MbInfo> mb;
@@ -64,6 +66,15 @@ struct ProbeSink : public h264::PictureSink {
     out->max_slices = static_cast<int>(slices.size());
     out->slot = slot;
     out->device_mv = fast;  // timing runs measure what the GPU path runs (P vectors left to k_mv); digests keep the host derivation
+    if (fast) {
+      if (slots[slot].pmo.size() != static_cast<size_t>(nmb)) {
+        slots[slot].pmo.resize(nmb);
+        slots[slot].pmx.resize(static_cast<size_t>(s.mb_height) + static_cast<size_t>(nmb) * 15);
+      }
+      out->pmo = slots[slot].pmo.data();
+      out->pmx = slots[slot].pmx.data();
+      out->pmx_capacity = slots[slot].pmx.size();
+    }
     return true;
   }
   bool end_picture(const h264::PicDone& d, std::string*) override {

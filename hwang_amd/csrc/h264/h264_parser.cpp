@@ -355,6 +355,9 @@ struct Pic {
   // its co-located picture.
   std::vector<uint8_t> mvrec;
   bool mv_deferred = false;
+  // compact hand-over (PicBuffers::pmo / pmx): kept for the lazy derivation
+  const amd::PMotion* pmo = nullptr;
+  const uint32_t* pmx = nullptr;
   std::vector<MbMotion> derived;
   bool derived_valid = false;
 };
@@ -459,6 +462,10 @@ struct Parser::Impl {
   // what begin_mb + decode_skip_mb + commit_mb would have produced field by field.
   MbMotion pskip_motion;
   int32_t pskip_ref_uid = -1;
+  // compact motion hand-over of the picture in progress (bufs.pmo / bufs.pmx)
+  bool compact = false;        // macroblocks of P / I slices are written as PMotion
+  bool any_compact = false, any_full_motion = false;
+  size_t pmx_used = 0;         // words, row table included
 
   // current macroblock
   struct Mb {
@@ -468,6 +475,7 @@ struct Parser::Impl {
     bool av[6];
     bool avA, avB;
     int mv_shape, mv_sub, mv_pskip, mv_defer;  // deferred motion-vector derivation (P macroblocks)
+    int pm_parts;  // compact hand-over: partitions whose difference has been written so far
     // motion record of each available, non-intra neighbour (same index as
     // av[]; [4] = this macroblock), nullptr otherwise; filled by begin_mb
     const MbMotion* nbmo[6];
@@ -1120,6 +1128,15 @@ struct Parser::Impl {
     }
     c->slot = bufs.slot;
     c->motion = bufs.motion;
+    c->pmo = bufs.pmo;
+    c->pmx = bufs.pmx;
+    if (bufs.pmx && bufs.pmx_capacity < static_cast<size_t>(mbh) + static_cast<size_t>(nmb) * 15) bufs.pmo = nullptr, bufs.pmx = nullptr;
+    // a sink that derives vectors itself takes them compactly; without the buffers for that the host derives
+    if (!bufs.pmo || !bufs.pmx) bufs.device_mv = false, bufs.pmo = nullptr, bufs.pmx = nullptr;
+    if (!bufs.device_mv) bufs.pmo = nullptr, bufs.pmx = nullptr;
+    compact = false;
+    any_compact = any_full_motion = false;
+    pmx_used = bufs.pmx ? static_cast<size_t>(mbh) : 0;
     // Per-macroblock state is (re)written by begin_mb / commit_mb before any
     // later macroblock of this picture reads it (neighbours precede in raster
     // order; FMO/ASO are rejected), so nothing is cleared per picture.
@@ -1246,6 +1263,9 @@ struct Parser::Impl {
     PicDone done;
     memset(&done, 0, sizeof(done));
     done.mv_deferred = c->mv_deferred;
+    done.compact_motion = any_compact;
+    done.full_motion = any_full_motion;
+    done.pmx_count = pmx_used;
     done.slot = c->slot;
     done.num_slices = num_slices;
     done.coef_count = coef_used;
@@ -1298,6 +1318,7 @@ struct Parser::Impl {
       pos_valid = true;
     }
     mb.addr = addr;
+    if (bufs.pmx && mb.mbx == 0) bufs.pmx[mb.mby] = static_cast<uint32_t>(pmx_used);  // this row's extras start here
     const bool left = mb.mbx > 0, top = mb.mby > 0, right = mb.mbx + 1 < mbw;
     const int16_t si = static_cast<int16_t>(slice_index);
     mb.av[0] = left && top && mb_slice[addr - mbw - 1] == si;   // D
@@ -1505,6 +1526,52 @@ struct Parser::Impl {
     }
   }
 
+  // Macroblocks that were handed over as PMotion + extra differences (MVF_COMPACT), put back into the
+  // MbMotion form derive_deferred works on: reference indices, and the differences replicated over each
+  // partition's blocks.  Same partition walk, same order as the stream was written in.
+  void expand_compact(const Pic* p, MbMotion* motion) const {
+    if (!p->pmo || !p->pmx) return;
+    size_t x = 0;
+    for (int addr = 0; addr < mbw * mbh; ++addr) {
+      if (addr % mbw == 0) x = p->pmx[addr / mbw];
+      const uint8_t* rec = &p->mvrec[static_cast<size_t>(addr) * 3];
+      if (!(rec[0] & amd::MVF_COMPACT)) continue;
+      MbMotion& mo = motion[addr];
+      const amd::PMotion& pm = p->pmo[addr];
+      memset(&mo, 0, sizeof(mo));
+      memcpy(mo.ref_idx[0], pm.ref_idx, 4);
+      memcpy(mo.ref_slot[0], pm.ref_slot, 4);
+      memset(mo.ref_idx[1], -1, 4);
+      memset(mo.ref_slot[1], -1, 4);
+      if (!(rec[0] & amd::MVF_DEFERRED) || (rec[0] & amd::MVF_PSKIP)) continue;
+      const int shape = rec[1], sub = rec[2];
+      const int nparts = shape == 0 ? 1 : (shape == 3 ? 4 : 2);
+      int part = 0;
+      for (int i = 0; i < nparts; ++i) {
+        int px, py, pw, ph;
+        if (shape == 0) { px = 0; py = 0; pw = 4; ph = 4; }
+        else if (shape == 1) { px = 0; py = i * 2; pw = 4; ph = 2; }
+        else if (shape == 2) { px = i * 2; py = 0; pw = 2; ph = 4; }
+        else { px = (i & 1) * 2; py = (i >> 1) * 2; pw = 2; ph = 2; }
+        int sw = pw, sh = ph;
+        if (shape == 3) {
+          const int ss = (sub >> (2 * i)) & 3;
+          if (ss == 2 || ss == 3) sw = 1;
+          if (ss == 1 || ss == 3) sh = 1;
+        }
+        for (int sy = 0; sy < ph; sy += sh)
+          for (int sx = 0; sx < pw; sx += sw) {
+            uint32_t word;
+            if (part++ == 0) word = static_cast<uint16_t>(pm.mvd0[0]) | (static_cast<uint32_t>(static_cast<uint16_t>(pm.mvd0[1])) << 16);
+            else word = p->pmx[x++];
+            uint32_t* dst = reinterpret_cast<uint32_t*>(mo.mv[0]);
+            for (int yy = py + sy; yy < py + sy + sh; ++yy)
+              for (int xx = px + sx; xx < px + sx + sw; ++xx) dst[yy * 4 + xx] = word;
+          }
+      }
+    }
+  }
+
   // Final motion of a (possibly deferred) picture for co-located lookups.
   const MbMotion* final_motion(const Pic* cp) {
     Pic* p = const_cast<Pic*>(cp);
@@ -1512,6 +1579,7 @@ struct Parser::Impl {
     if (!p->derived_valid) {
       const size_t nmb = static_cast<size_t>(mbw) * mbh;
       p->derived.assign(p->motion, p->motion + nmb);  // the surface's buffer may still be uploading: work on a copy
+      expand_compact(p, p->derived.data());
       derive_deferred(p, p->derived.data());
       p->derived_valid = true;
     }
@@ -2318,7 +2386,18 @@ struct Parser::Impl {
             int dx, dy;
             rd_mvd_pair(l, bx, by, &dx, &dy);
             set_mvd_block(l, bx, by, sw, sh, dx, dy);
-            set_mv_block(l, bx, by, sw, sh, mvp[0] + dx, mvp[1] + dy);
+            if (compact) {
+              // decode order = the order k_mv walks the partitions in
+              const uint32_t word = static_cast<uint16_t>(dx) | (static_cast<uint32_t>(static_cast<uint16_t>(dy)) << 16);
+              if (mb.pm_parts++ == 0) {
+                bufs.pmo[mb.addr].mvd0[0] = static_cast<int16_t>(dx);
+                bufs.pmo[mb.addr].mvd0[1] = static_cast<int16_t>(dy);
+              } else {
+                bufs.pmx[pmx_used++] = word;
+              }
+            } else {
+              set_mv_block(l, bx, by, sw, sh, mvp[0] + dx, mvp[1] + dy);
+            }
           }
       }
     return true;
@@ -2345,9 +2424,10 @@ struct Parser::Impl {
     memset(mb.i4_mode, 2, sizeof(mb.i4_mode));
     memset(mb.nnz, 0, sizeof(mb.nnz));
     MbMotion& mo = cur->motion[addr];
-    memset(mo.mv, 0, sizeof(mo.mv));
+    if (!compact) memset(mo.mv, 0, sizeof(mo.mv));  // compact slices never read or upload these vectors
     memset(mo.ref_slot, -1, sizeof(mo.ref_slot));
     memset(mo.ref_idx, -1, sizeof(mo.ref_idx));
+    mb.pm_parts = 0;
     for (int l = 0; l < 2; ++l)
       for (int q = 0; q < 4; ++q) cur->ref_uid[l][addr * 4 + q] = -1;
     memset(mvd_at(addr, 0, 0), 0, 64);
@@ -2399,6 +2479,18 @@ struct Parser::Impl {
     o.slice = static_cast<uint8_t>(slice_index - 1);
     {
       uint8_t mf = 0;
+      if (compact) {
+        // every macroblock of a compact slice has a PMotion record (intra: no reference)
+        mf |= amd::MVF_COMPACT;
+        amd::PMotion& pm = bufs.pmo[a];
+        const MbMotion& mo = cur->motion[a];
+        memcpy(pm.ref_idx, mo.ref_idx[0], 4);
+        memcpy(pm.ref_slot, mo.ref_slot[0], 4);
+        if (mb.pm_parts == 0) pm.mvd0[0] = pm.mvd0[1] = 0;
+        any_compact = true;
+      } else if (!intra) {
+        any_full_motion = true;
+      }
       if (mb.mv_defer) mf |= amd::MVF_DEFERRED;
       if (mb.mv_pskip) mf |= amd::MVF_PSKIP;
       if (mb.av[3]) mf |= amd::MVF_AVAIL_A;
@@ -2482,7 +2574,18 @@ struct Parser::Impl {
     memset(mvd_at(addr, 0, 0), 0, 64);
     memset(&direct8[addr * 4], 0, 4);
     cur->mb_intra[addr] = 0;
-    cur->motion[addr] = pskip_motion;
+    if (compact) {
+      // the 12-byte record is all the GPU needs; the host keeps the reference indices for its contexts
+      amd::PMotion& pm = bufs.pmo[addr];
+      memcpy(pm.ref_idx, pskip_motion.ref_idx[0], 4);
+      memcpy(pm.ref_slot, pskip_motion.ref_slot[0], 4);
+      pm.mvd0[0] = pm.mvd0[1] = 0;
+      memcpy(cur->motion[addr].ref_idx, pskip_motion.ref_idx, sizeof(pskip_motion.ref_idx));
+      any_compact = true;
+    } else {
+      cur->motion[addr] = pskip_motion;
+      any_full_motion = true;
+    }
     for (int q = 0; q < 4; ++q) {
       cur->ref_uid[0][addr * 4 + q] = pskip_ref_uid;
       cur->ref_uid[1][addr * 4 + q] = -1;
@@ -2513,7 +2616,7 @@ struct Parser::Impl {
     o.qpc[0] = chroma_qp_table[iclip(0, 51, qp + p.chroma_qp_offset[0])];
     o.qpc[1] = chroma_qp_table[iclip(0, 51, qp + p.chroma_qp_offset[1])];
     o.slice = static_cast<uint8_t>(slice_index - 1);
-    const uint8_t mf = static_cast<uint8_t>(amd::MVF_DEFERRED | amd::MVF_PSKIP | (mb.av[3] ? amd::MVF_AVAIL_A : 0) |
+    const uint8_t mf = static_cast<uint8_t>(amd::MVF_DEFERRED | amd::MVF_PSKIP | (compact ? amd::MVF_COMPACT : 0) | (mb.av[3] ? amd::MVF_AVAIL_A : 0) |
                                             (mb.av[1] ? amd::MVF_AVAIL_B : 0) | (mb.av[2] ? amd::MVF_AVAIL_C : 0) |
                                             (mb.av[0] ? amd::MVF_AVAIL_D : 0));
     o.mv_flags = mf;
@@ -2661,6 +2764,8 @@ struct Parser::Impl {
     int addr = sl.first_mb;
     if (addr >= nmb) return fail("first_mb_in_slice out of range");
     pos_valid = false;
+    // P and I slices hand their motion over compactly when the sink derives the vectors (k_mv)
+    compact = bufs.device_mv && bufs.pmo && bufs.pmx && sl.type != 1;
     if (sl.type == 0) prepare_pskip();
     qp = sl.qp;
     last_qp_delta_nonzero = 0;

@@ -35,6 +35,13 @@ struct PicBuffers {
   // The sink derives the motion vectors of P macroblocks itself (k_mv) from
   // the differences; if false the parser does it before end_picture.
   bool device_mv = false;
+  // With device_mv: macroblocks of P and I slices are handed over as PMotion
+  // records plus the extra stream (frame_job.h) instead of MbMotion.  Both live
+  // with the surface, like `motion` (a later B picture may need them for its
+  // co-located lookups).  pmx[0 .. mb_height) is the row table.
+  amd::PMotion* pmo = nullptr;       // [mb_width * mb_height]
+  uint32_t* pmx = nullptr;
+  size_t pmx_capacity = 0;           // in words, >= mb_height + 15 * macroblocks
 };
 
 struct PicSetup {
@@ -50,6 +57,9 @@ struct PicDone {
   bool has_intra;
   bool any_deblock;      // some slice has the in-loop filter enabled
   bool mv_deferred;      // MbInfo::mv_flags & MVF_DEFERRED on some macroblocks: run k_mv first
+  bool compact_motion;   // some macroblocks are MVF_COMPACT: pmo[] and pmx[0 .. pmx_count) must be uploaded
+  bool full_motion;      // some inter macroblocks are not: motion[] must be uploaded
+  size_t pmx_count;      // words of pmx in use (row table included)
   int slice_type_mask;   // bit0 P, bit1 B, bit2 I
   const uint8_t (*scaling4)[16];
   const uint8_t (*scaling8)[64];
