@@ -261,7 +261,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       counters_.bytes_uploaded += bytes;
     };
     add_copy(j.mb_dev, j.mb_host, nmb * sizeof(MbInfo));
-    if (d.coef_count) add_copy(j.coef_dev, j.coef_host, d.coef_count * 2);
+    if (d.coef_count) add_copy(j.coef_dev, j.coef_host, d.coef_count * sizeof(uint32_t));
     add_copy(j.slice_dev, j.slice_host, d.num_slices * sizeof(SliceParams));
     // motion: full 144-byte records only for macroblocks the host derived itself (B slices, pictures too wide
     // for k_mv); everything k_mv derives travels as 12-byte records + the extra differences
@@ -342,13 +342,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   };
   struct Job {
     MbInfo* mb_host = nullptr;
-    int16_t* coef_host = nullptr;
+    uint32_t* coef_host = nullptr;
     SliceParams* slice_host = nullptr;
     MbInfo* mb_dev = nullptr;
     MbMotion* motion_dev = nullptr;
     PMotion* pmo_dev = nullptr;
     uint32_t* pmx_dev = nullptr;
-    int16_t* coef_dev = nullptr;
+    uint32_t* coef_dev = nullptr;
     SliceParams* slice_dev = nullptr;
     void* db_dev = nullptr;  // k_bs -> k_deblock records
     int16_t* resid_dev = nullptr;  // k_residual -> k_intra
@@ -448,18 +448,18 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     v_offset_ = u_offset_ + static_cast<size_t>(c_pitch_) * mbh_ * 8;
     surface_bytes_ = v_offset_ + static_cast<size_t>(c_pitch_) * mbh_ * 8;
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
-    // worst case: every one of 27 groups of every macroblock coded
-    coef_capacity_ = nmb * 27 * 16;
+    // worst case per macroblock: kMaxSparseCoefs entries, or 26 dense groups (fewer words)
+    coef_capacity_ = nmb * amd::kMaxSparseCoefs;
     pmx_words_ = static_cast<size_t>(mbh_) + nmb * 15;  // row table + up to 15 further partitions per macroblock
     for (Job& j : jobs_) {
       if (hipHostMalloc(reinterpret_cast<void**>(&j.mb_host), nmb * sizeof(MbInfo), hipHostMallocDefault) != hipSuccess ||
-          hipHostMalloc(reinterpret_cast<void**>(&j.coef_host), coef_capacity_ * 2, hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc(reinterpret_cast<void**>(&j.coef_host), coef_capacity_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
           hipHostMalloc(reinterpret_cast<void**>(&j.slice_host), kMaxSlices * sizeof(SliceParams), hipHostMallocDefault) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.mb_dev), nmb * sizeof(MbInfo)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.motion_dev), nmb * sizeof(MbMotion)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.pmo_dev), nmb * sizeof(PMotion)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.pmx_dev), (pmx_words_ + 64) * sizeof(uint32_t)) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.coef_dev), coef_capacity_ * 2) != hipSuccess ||
+          hipMalloc(reinterpret_cast<void**>(&j.coef_dev), coef_capacity_ * sizeof(uint32_t)) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.slice_dev), kMaxSlices * sizeof(SliceParams)) != hipSuccess ||
           hipMalloc(&j.db_dev, amd::deblock_scratch_bytes(static_cast<int>(nmb))) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&j.resid_dev), nmb * 384 * sizeof(int16_t)) != hipSuccess ||

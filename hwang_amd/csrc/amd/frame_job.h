@@ -52,7 +52,7 @@ enum : uint8_t {
 //   16     Intra16x16 luma DC (16 values, raster = block position)
 //   17     chroma DC (Cb[4], Cr[4], 8 zeros)
 //   18..21 Cb AC blocks 0..3, 22..25 Cr AC blocks 0..3 (DC slot zero)
-// An I_PCM macroblock stores its 384 samples as 192 int16 (two bytes each,
+// An I_PCM macroblock stores its 384 samples as 96 words (four bytes each,
 // little endian) and sets coded_mask = 0.
 constexpr int kMaskLumaDc = 16;
 constexpr int kMaskChromaDc = 17;
@@ -67,7 +67,7 @@ struct MbInfo {
   uint8_t slice;       // index into SliceParams
   uint8_t deblock_internal;  // 1: internal edges filtered (idc != 1)
   uint32_t coded_mask;
-  uint32_t coef_offset;      // in int16 units
+  uint32_t coef_offset;      // in 32-bit words
   uint8_t i4_modes[8];       // 16 x 4 bit, raster 4x4 order
   uint16_t nz_mask;          // 4x4 luma blocks (raster) holding non-zero
                              // coefficients, as the bS derivation sees them
@@ -77,8 +77,16 @@ struct MbInfo {
   uint8_t mv_flags;          // MVF_* below
   uint8_t mv_shape;          // 0 16x16, 1 16x8, 2 8x16, 3 8x8
   uint8_t mv_sub;            // 8x8 only: 2 bits per quadrant: 0 8x8, 1 8x4, 2 4x8, 3 4x4
-  uint8_t pad[3];
+  // Coefficients at coef_offset: `ncoef` sparse entries, one word per NON-ZERO level:
+  //   (group * 16 + position) << 16 | level (int16)   - group / position as in coded_mask above
+  // (a coded 4x4 block of a P picture holds one or two non-zero levels on average: 4-8 bytes instead of
+  // the 32 of a dense group).  kDenseCoefs: more than kMaxSparseCoefs levels - the groups follow densely,
+  // 16 int16 per set bit of coded_mask in bit order, which bounds a macroblock at 864 bytes either way.
+  uint8_t pad;
+  uint16_t ncoef;
 };
+constexpr uint16_t kDenseCoefs = 0xffff;
+constexpr int kMaxSparseCoefs = 216;
 enum : uint8_t {
   MVF_DEFERRED = 1,          // mv[0] holds differences; derive (8.4.1.3)
   MVF_PSKIP = 2,             // P_Skip inference (8.4.1.1)
@@ -167,7 +175,7 @@ struct alignas(16) JobDesc {
   PictureParams pp;
   const MbInfo* mbs;
   const MbMotion* motions;
-  const int16_t* coefs;
+  const uint32_t* coefs;   // sparse level entries / dense groups / I_PCM samples, see MbInfo::ncoef
   const SliceParams* slices;
   void* db;            // k_bs -> k_deblock records
   int16_t* resid;      // k_residual -> k_intra: 384 int16 per macroblock (256 luma raster, 64 Cb, 64 Cr)

@@ -108,10 +108,31 @@ __device__ __forceinline__ int level_scale8(const uint8_t* weight, int qp, int p
   return weight[pos] * c_norm8[qp % 6][cls];
 }
 
-// coefficient group `g` of a macroblock, or nullptr when it was not coded
-__device__ __forceinline__ const int16_t* coef_group(const MbInfo& mb, const int16_t* coefs, int g) {
-  if (!((mb.coded_mask >> g) & 1)) return nullptr;
-  return coefs + mb.coef_offset + 16 * __popc(mb.coded_mask & ((1u << g) - 1));
+// Levels of one macroblock, staged by its wave: lv[group * 16 + position] for the 26 groups of
+// MbInfo::coded_mask, zero where nothing was coded.  The stream holds one word per non-zero level
+// (or, beyond kMaxSparseCoefs levels, the coded groups densely): a scatter of a handful of words
+// instead of 384 conditional loads.
+constexpr int kLevels = 26 * 16;
+__device__ __forceinline__ void wave_sync();
+__device__ __forceinline__ void stage_levels(const MbInfo& mb, const uint32_t* coefs, int lane, int16_t* lv) {
+  uint32_t* z = reinterpret_cast<uint32_t*>(lv);
+#pragma unroll
+  for (int t = lane; t < kLevels / 2; t += 64) z[t] = 0;
+  wave_sync();
+  const uint32_t* src = coefs + mb.coef_offset;
+  if (mb.ncoef != kDenseCoefs) {
+    for (int t = lane; t < mb.ncoef; t += 64) {
+      const uint32_t w = gld32(src + t);
+      lv[w >> 16] = (int16_t)(w & 0xffff);
+    }
+  } else {
+    for (int t = lane; t < kLevels; t += 64) {
+      const int g = t >> 4;
+      if ((mb.coded_mask >> g) & 1)
+        lv[t] = (int16_t)gld16s(reinterpret_cast<const int16_t*>(src) + 16 * __popc(mb.coded_mask & ((1u << g) - 1)) + (t & 15));
+    }
+  }
+  wave_sync();
 }
 
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
@@ -172,24 +193,25 @@ __device__ __forceinline__ void wave_sync() {
 
 // ---------------------------------------------------------------------------
 // Residual of one macroblock, computed by ONE wave (64 lanes) into LDS.
-//   work[384] ints scratch, dcs[24] ints, res_y[256], res_c[128] int16
+//   work[384] ints scratch, dcs[24] ints, res_y[256], res_c[128] int16, lv[kLevels] int16
 // ---------------------------------------------------------------------------
-__device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const PictureParams& pp, int lane,
-                              int* work, int* dcs, int16_t* res_y, int16_t* res_c) {
+__device__ void wave_residual(const MbInfo& mb, const uint32_t* coefs, const PictureParams& pp, int lane,
+                              int* work, int* dcs, int16_t* res_y, int16_t* res_c, int16_t* lv) {
   const bool intra = mb.flags & MBF_INTRA;
   const int qp = mb.qp;
   int* dy = work;
   int* dc = work + 256;
+  stage_levels(mb, coefs, lane, lv);
   if (mb.kind == MBK_I16x16 && lane < 16) {
-    const int16_t* g = coef_group(mb, coefs, kMaskLumaDc);
+    const int16_t* g = lv + 16 * kMaskLumaDc;
     int f = 0;
-    if (g) {
+    if ((mb.coded_mask >> kMaskLumaDc) & 1) {
       const int i = lane >> 2, j = lane & 3;
       for (int a = 0; a < 4; ++a) {
         const int sa = (i == 0 || (i == 1 && a < 2) || (i == 2 && (a == 0 || a == 3)) || (i == 3 && (a & 1) == 0)) ? 1 : -1;
         for (int b = 0; b < 4; ++b) {
           const int sb = (j == 0 || (j == 1 && b < 2) || (j == 2 && (b == 0 || b == 3)) || (j == 3 && (b & 1) == 0)) ? 1 : -1;
-          f += sa * sb * gld16s(g + a * 4 + b);
+          f += sa * sb * g[a * 4 + b];
         }
       }
       const int ls = level_scale4(pp.scaling4[0], qp, 0);
@@ -199,11 +221,10 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
   }
   if (lane >= 16 && lane < 24) {
     const int p = (lane - 16) >> 2, k = (lane - 16) & 3;
-    const int16_t* g = coef_group(mb, coefs, kMaskChromaDc);
     int v = 0;
-    if (g) {
-      const int16_t* c = g + 4 * p;
-      const int c0 = gld16s(c), c1 = gld16s(c + 1), c2 = gld16s(c + 2), c3 = gld16s(c + 3);
+    if ((mb.coded_mask >> kMaskChromaDc) & 1) {
+      const int16_t* c = lv + 16 * kMaskChromaDc + 4 * p;
+      const int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
       const int f = k == 0 ? c0 + c1 + c2 + c3 : k == 1 ? c0 - c1 + c2 - c3 : k == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3;
       const int qpc = mb.qpc[p];
       const int ls = level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, 0);
@@ -216,19 +237,17 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
   for (int t = lane; t < 256; t += 64) {
     int v = 0;
     if (mb.flags & MBF_T8X8) {
-      const int b8 = t >> 6, k = t & 63;
-      const int16_t* g = coef_group(mb, coefs, 4 * b8);
-      const int lv = g ? gld16s(g + k) : 0;
-      if (lv) {
-        const int s = lv * level_scale8(pp.scaling8[intra ? 0 : 1], qp, k);
+      const int k = t & 63;
+      const int level = lv[t];  // group 4 * b8, position k: the 64 levels of an 8x8 block are contiguous
+      if (level) {
+        const int s = level * level_scale8(pp.scaling8[intra ? 0 : 1], qp, k);
         v = qp >= 36 ? s << (qp / 6 - 6) : (s + (1 << (5 - qp / 6))) >> (6 - qp / 6);
       }
     } else {
       const int blk = t >> 4, k = t & 15;
-      const int16_t* g = coef_group(mb, coefs, blk);
-      const int lv = g ? gld16s(g + k) : 0;
-      if (lv) {
-        const int s = lv * level_scale4(pp.scaling4[intra ? 0 : 3], qp, k);
+      const int level = lv[t];
+      if (level) {
+        const int s = level * level_scale4(pp.scaling4[intra ? 0 : 3], qp, k);
         v = qp >= 24 ? s << (qp / 6 - 4) : (s + (1 << (3 - qp / 6))) >> (4 - qp / 6);
       }
       if (k == 0 && mb.kind == MBK_I16x16) v = dcs[blk];
@@ -237,12 +256,11 @@ __device__ void wave_residual(const MbInfo& mb, const int16_t* coefs, const Pict
   }
   for (int t = lane; t < 128; t += 64) {
     const int p = t >> 6, blk = (t >> 4) & 3, k = t & 15;
-    const int16_t* g = coef_group(mb, coefs, kMaskChromaAc + 4 * p + blk);
     int v = 0;
     const int qpc = mb.qpc[p];
-    const int lv = g ? gld16s(g + k) : 0;
-    if (lv) {
-      const int s = lv * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, k);
+    const int level = lv[16 * kMaskChromaAc + t];
+    if (level) {
+      const int s = level * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, k);
       v = qpc >= 24 ? s << (qpc / 6 - 4) : (s + (1 << (3 - qpc / 6))) >> (4 - qpc / 6);
     }
     if (k == 0) v = dcs[16 + 4 * p + blk];
@@ -491,6 +509,7 @@ struct InterWave {
   int dcs[24];
   int16_t res_y[256];
   int16_t res_c[128];
+  int16_t lv[kLevels];
   uint32_t win[2][kWinDwords];
 };
 
@@ -602,7 +621,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
       }
     }
   }
-  if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+  if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c, L.lv);  // ends with wave_sync
   if (window) {
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
@@ -1253,7 +1272,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __
     gst32(out + 128 + lane, 0);
     return;
   }
-  wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c);  // ends with wave_sync
+  wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c, L.lv);  // ends with wave_sync
   const uint32_t* ry = reinterpret_cast<const uint32_t*>(L.res_y);
   const uint32_t* rc = reinterpret_cast<const uint32_t*>(L.res_c);
   gst32(out + lane, ry[lane]);
@@ -1291,7 +1310,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
   if (!job.do_intra) return;
   const PictureParams& pp = job.pp;
   const MbInfo* __restrict__ mbs = job.mbs;
-  const int16_t* __restrict__ coefs = job.coefs;
+  const uint32_t* __restrict__ coefs = job.coefs;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mby = band * kBandWaves + wave;
   if (mby >= pp.mb_height) return;  // no workgroup barrier below this point

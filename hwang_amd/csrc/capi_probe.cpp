@@ -27,7 +27,7 @@ struct ProbeSink : public h264::PictureSink {
   };
   std::vector<Slot> slots = std::vector<Slot>(amd::kMaxSurfaces);
   std::vector<amd::MbInfo> mb;
-  std::vector<int16_t> coefs;
+  std::vector<uint32_t> coefs;
   std::vector<amd::SliceParams> slices = std::vector<amd::SliceParams>(64);
   int nmb = 0;
   uint64_t digest = 1469598103934665603ull;
@@ -56,7 +56,7 @@ struct ProbeSink : public h264::PictureSink {
     if (!fast || slots[slot].motion.size() != static_cast<size_t>(nmb)) {
       slots[slot].motion.assign(nmb, amd::MbMotion());
       mb.assign(nmb, amd::MbInfo());
-      coefs.assign(static_cast<size_t>(nmb) * 27 * 16, 0);
+      coefs.assign(static_cast<size_t>(nmb) * amd::kMaxSparseCoefs, 0);
     }
     out->mb = mb.data();
     out->motion = slots[slot].motion.data();
@@ -83,7 +83,7 @@ struct ProbeSink : public h264::PictureSink {
         m.mv_flags = m.mv_shape = m.mv_sub = 0;
         mix(&m, sizeof(m));
       }
-    mix(coefs.data(), d.coef_count * 2);
+    mix(coefs.data(), d.coef_count * sizeof(uint32_t));
     if (d.has_inter) {
       // ref_slot depends on this sink's slot numbering, which is stable
       mix(slots[d.slot].motion.data(), slots[d.slot].motion.size() * sizeof(amd::MbMotion));

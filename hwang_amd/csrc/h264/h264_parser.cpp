@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <emmintrin.h>
+#include <immintrin.h>
 
 namespace hwang {
 namespace h264 {
@@ -485,8 +486,10 @@ struct Parser::Impl {
     uint8_t nz_left[8], nz_top[8];  // fill_nz_cache(): 4 luma + 2 Cb + 2 Cr flags per edge
     int cbf_dc;
     uint32_t coded_mask;
-    int16_t* coef_base;  // this MB's groups in the coefficient buffer
-    int16_t scratch[26][16];  // levels before compaction, indexed by mask bit
+    // the macroblock's non-zero levels as they will be handed over (MbInfo::ncoef): (group * 16 + position) << 16 | level
+    uint32_t ent[26 * 16];
+    int nent;
+    int16_t scratch[26][16];  // dense groups: CAVLC staging, and the fallback form of macroblocks with very many levels
   } mb;
 
   bool fail(const char* msg) {
@@ -1772,7 +1775,8 @@ struct Parser::Impl {
   // context bytes are stored through a uint8_t pointer, which may alias any
   // member of the Cabac object and would otherwise force a store and reload of
   // the engine state around every single bin.
-  int cabac_block(int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start, int16_t* out) {
+  // Non-zero levels are appended to mb.ent with flat index `gbase` + raster position (gbase = group * 16).
+  int cabac_block(int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start, int gbase) {
     Cabac& c = cabac;
     uint64_t value = c.value;
     uint32_t range = c.range;
@@ -1830,8 +1834,6 @@ struct Parser::Impl {
       leave();
       return 0;
     }
-    // the caller hands over uninitialised storage: it is cleared only when the block is coded
-    memset(out, 0, cat == 5 ? 128 : (cat == 3 ? 8 : 32));
     const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
     const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
     const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
@@ -1862,6 +1864,7 @@ struct Parser::Impl {
     if (i == lastpos) idx[n++] = static_cast<uint8_t>(lastpos);
     int gt1 = 0, eq1 = 0;
     const int gt_cap = 4 - (cat == 3 ? 1 : 0);
+    uint32_t* const ent = mb.ent + mb.nent;  // n <= 64 entries; a macroblock never has more than 26 * 16
     for (int k = n - 1; k >= 0; --k) {
       const int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
       int val;
@@ -1886,8 +1889,9 @@ struct Parser::Impl {
         ++gt1;
       }
       if (bypass()) val = -val;
-      out[scan[start + idx[k]]] = static_cast<int16_t>(val);
+      ent[k] = (static_cast<uint32_t>(gbase + scan[start + idx[k]]) << 16) | static_cast<uint16_t>(val);
     }
+    mb.nent += n;
     leave();
     return n;
   }
@@ -2187,13 +2191,16 @@ struct Parser::Impl {
     return imin(mode[0], mode[1]);
   }
 
-  // scratch group for mask bit `g` (zeroed on first use)
-  int16_t* group(int g) {
-    if (!(mb.coded_mask & (1u << g))) {
-      mb.coded_mask |= 1u << g;
-      memset(mb.scratch[g], 0, sizeof(mb.scratch[g]));
-    }
-    return mb.scratch[g];
+  // CAVLC staging -> level entries of group `g` (positions offset .. offset + n - 1); marks the group coded.
+  // `always`: mark it even when all n levels are zero (the four groups of an 8x8 block are coded together).
+  void emit_levels(int g, int offset, const int16_t* lv, int n, bool always = false) {
+    bool any = always;
+    for (int k = 0; k < n; ++k)
+      if (lv[k]) {
+        mb.ent[mb.nent++] = (static_cast<uint32_t>(g * 16 + offset + k) << 16) | static_cast<uint16_t>(lv[k]);
+        any = true;
+      }
+    if (any) mb.coded_mask |= 1u << g;
   }
 
   bool parse_residual() {
@@ -2202,12 +2209,12 @@ struct Parser::Impl {
     if (i16) {
       int n;
       if (use_cabac) {
-        n = cabac_block(0, cbf_inc(0, 0, 0, 0), 16, zigzag4x4, 0, mb.scratch[amd::kMaskLumaDc]);
+        n = cabac_block(0, cbf_inc(0, 0, 0, 0), 16, zigzag4x4, 0, 16 * amd::kMaskLumaDc);
         if (n > 0) mb.coded_mask |= 1u << amd::kMaskLumaDc;
       } else {
         int16_t tmp[16] = {0};
         n = cavlc_block(cavlc_nc(0, 0, 0), 16, zigzag4x4, 0, tmp);
-        if (n > 0) memcpy(group(amd::kMaskLumaDc), tmp, sizeof(tmp));
+        if (n > 0) emit_levels(amd::kMaskLumaDc, 0, tmp, 16);
       }
       if (n < 0) return false;
       if (n) mb.cbf_dc |= 1;
@@ -2218,7 +2225,7 @@ struct Parser::Impl {
         // 64 coefficients in raster 8x8 order spread over groups 4*b8..4*b8+3
         if (use_cabac) {
           // groups 4*b8 .. 4*b8+3 are adjacent in the scratch area: the 64 levels land in place
-          int n = cabac_block(5, -1, 64, zigzag8x8, 0, mb.scratch[4 * b8]);
+          int n = cabac_block(5, -1, 64, zigzag8x8, 0, 16 * 4 * b8);
           if (n < 0) return false;
           for (int s = 0; s < 4; ++s) mb.nnz[((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)] = static_cast<uint8_t>(n);
           if (n) mb.coded_mask |= 0xfu << (4 * b8);
@@ -2240,7 +2247,7 @@ struct Parser::Impl {
           }
         }
         if (total) {
-          for (int g = 0; g < 4; ++g) memcpy(group(4 * b8 + g), blk + 16 * g, 32);
+          for (int g = 0; g < 4; ++g) emit_levels(4 * b8 + g, 0, blk + 16 * g, 16, true);
         }
         continue;
       }
@@ -2249,13 +2256,13 @@ struct Parser::Impl {
         const int ri = by * 4 + bx;
         int n;
         if (use_cabac) {
-          n = i16 ? cabac_block(1, cbf_inc(1, 0, bx, by), 15, zigzag4x4, 1, mb.scratch[ri])
-                  : cabac_block(2, cbf_inc(1, 0, bx, by), 16, zigzag4x4, 0, mb.scratch[ri]);
+          n = i16 ? cabac_block(1, cbf_inc(1, 0, bx, by), 15, zigzag4x4, 1, 16 * ri)
+                  : cabac_block(2, cbf_inc(1, 0, bx, by), 16, zigzag4x4, 0, 16 * ri);
           if (n > 0) mb.coded_mask |= 1u << ri;
         } else {
           int16_t tmp[16] = {0};
           n = i16 ? cavlc_block(cavlc_nc(0, bx, by), 15, zigzag4x4, 1, tmp) : cavlc_block(cavlc_nc(0, bx, by), 16, zigzag4x4, 0, tmp);
-          if (n > 0) memcpy(group(ri), tmp, sizeof(tmp));
+          if (n > 0) emit_levels(ri, 0, tmp, 16);
         }
         if (n < 0) return false;
         mb.nnz[ri] = static_cast<uint8_t>(n);
@@ -2264,14 +2271,17 @@ struct Parser::Impl {
     const int cc = mb.cbp >> 4;
     if (cc) {
       for (int p = 0; p < 2; ++p) {
-        int16_t tmp[4] = {0, 0, 0, 0};
-        int n = use_cabac ? cabac_block(3, cbf_inc(2, p, 0, 0), 4, dc_scan4, 0, tmp)
-                          : cavlc_block(-1, 4, dc_scan4, 0, tmp);
-        if (n < 0) return false;
-        if (n) {
-          mb.cbf_dc |= 2 << p;
-          memcpy(group(amd::kMaskChromaDc) + 4 * p, tmp, sizeof(tmp));
+        int n;
+        if (use_cabac) {
+          n = cabac_block(3, cbf_inc(2, p, 0, 0), 4, dc_scan4, 0, 16 * amd::kMaskChromaDc + 4 * p);
+          if (n > 0) mb.coded_mask |= 1u << amd::kMaskChromaDc;
+        } else {
+          int16_t tmp[4] = {0, 0, 0, 0};
+          n = cavlc_block(-1, 4, dc_scan4, 0, tmp);
+          if (n > 0) emit_levels(amd::kMaskChromaDc, 4 * p, tmp, 4);
         }
+        if (n < 0) return false;
+        if (n) mb.cbf_dc |= 2 << p;
       }
     }
     if (cc == 2) {
@@ -2281,12 +2291,12 @@ struct Parser::Impl {
           const int g = amd::kMaskChromaAc + 4 * p + s;
           int n;
           if (use_cabac) {
-            n = cabac_block(4, cbf_inc(3, p, bx, by), 15, zigzag4x4, 1, mb.scratch[g]);
+            n = cabac_block(4, cbf_inc(3, p, bx, by), 15, zigzag4x4, 1, 16 * g);
             if (n > 0) mb.coded_mask |= 1u << g;
           } else {
             int16_t tmp[16] = {0};
             n = cavlc_block(cavlc_nc(1 + p, bx, by), 15, zigzag4x4, 1, tmp);
-            if (n > 0) memcpy(group(g), tmp, sizeof(tmp));
+            if (n > 0) emit_levels(g, 0, tmp, 16);
           }
           if (n < 0) return false;
           mb.nnz[16 + 4 * p + s] = static_cast<uint8_t>(n);
@@ -2420,6 +2430,7 @@ struct Parser::Impl {
     mb.qp = qp;
     mb.cbf_dc = 0;
     mb.coded_mask = 0;
+    mb.nent = 0;
     memset(mb.sub_type, 0, sizeof(mb.sub_type));
     memset(mb.i4_mode, 2, sizeof(mb.i4_mode));
     memset(mb.nnz, 0, sizeof(mb.nnz));
@@ -2518,22 +2529,30 @@ struct Parser::Impl {
     if (mb.kind == MB_IPCM) nz = 0xffff;
     o.nz_mask = nz;
 
-    // coefficients: compact the groups that were touched
+    // coefficients: one word per non-zero level of the groups that were touched (MbInfo::ncoef)
     o.coef_offset = static_cast<uint32_t>(coef_used);
+    if (coef_used + amd::kMaxSparseCoefs > bufs.coef_capacity) return fail("coefficient buffer overflow");
     if (mb.kind == MB_IPCM) {
-      if (coef_used + 192 > bufs.coef_capacity) return fail("coefficient buffer overflow");
       memcpy(bufs.coefs + coef_used, pcm, 384);
-      coef_used += 192;
+      coef_used += 96;
       o.coded_mask = 0;
-    } else {
-      const int groups = __builtin_popcount(mb.coded_mask);
-      if (coef_used + static_cast<size_t>(groups) * 16 > bufs.coef_capacity) return fail("coefficient buffer overflow");
-      int16_t* dst = bufs.coefs + coef_used;
-      for (uint32_t m = mb.coded_mask; m; m &= m - 1) {
-        memcpy(dst, mb.scratch[__builtin_ctz(m)], 32);
-        dst += 16;
+    } else if (mb.coded_mask) {
+      uint32_t* dst = bufs.coefs + coef_used;
+      if (mb.nent <= amd::kMaxSparseCoefs) {
+        memcpy(dst, mb.ent, sizeof(uint32_t) * mb.nent);
+        o.ncoef = static_cast<uint16_t>(mb.nent);
+        coef_used += mb.nent;
+      } else {  // more levels than the sparse form is worth: dense groups in mask order (at most 26 x 8 words)
+        for (uint32_t m = mb.coded_mask; m; m &= m - 1) memset(mb.scratch[__builtin_ctz(m)], 0, 32);
+        for (int i = 0; i < mb.nent; ++i) (&mb.scratch[0][0])[mb.ent[i] >> 16] = static_cast<int16_t>(mb.ent[i] & 0xffff);
+        int16_t* d16 = reinterpret_cast<int16_t*>(dst);
+        for (uint32_t m = mb.coded_mask; m; m &= m - 1) {
+          memcpy(d16, mb.scratch[__builtin_ctz(m)], 32);
+          d16 += 16;
+        }
+        o.ncoef = amd::kDenseCoefs;
+        coef_used += static_cast<size_t>(__builtin_popcount(mb.coded_mask)) * 8;
       }
-      coef_used += static_cast<size_t>(groups) * 16;
       o.coded_mask = mb.coded_mask;
     }
     return true;

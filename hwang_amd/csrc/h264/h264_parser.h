@@ -27,8 +27,8 @@ namespace h264 {
 struct PicBuffers {
   amd::MbInfo* mb = nullptr;         // [mb_width * mb_height]
   amd::MbMotion* motion = nullptr;   // [mb_width * mb_height], lives with the surface
-  int16_t* coefs = nullptr;
-  size_t coef_capacity = 0;          // in int16 units
+  uint32_t* coefs = nullptr;         // MbInfo::coef_offset / ncoef
+  size_t coef_capacity = 0;          // in 32-bit words, >= 216 per macroblock
   amd::SliceParams* slices = nullptr;
   int max_slices = 0;
   int slot = -1;                     // surface the picture is reconstructed into
@@ -52,7 +52,7 @@ struct PicSetup {
 struct PicDone {
   int slot;
   int num_slices;
-  size_t coef_count;     // int16 units used
+  size_t coef_count;     // 32-bit words used
   bool has_inter;        // motion[] must be uploaded
   bool has_intra;
   bool any_deblock;      // some slice has the in-loop filter enabled
