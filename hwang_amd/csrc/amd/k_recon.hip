@@ -108,32 +108,8 @@ __device__ __forceinline__ int level_scale8(const uint8_t* weight, int qp, int p
   return weight[pos] * c_norm8[qp % 6][cls];
 }
 
-// Levels of one macroblock, staged by its wave: lv[group * 16 + position] for the 26 groups of
-// MbInfo::coded_mask, zero where nothing was coded.  The stream holds one word per non-zero level
-// (or, beyond kMaxSparseCoefs levels, the coded groups densely): a scatter of a handful of words
-// instead of 384 conditional loads.
 constexpr int kLevels = 26 * 16;
 __device__ __forceinline__ void wave_sync();
-__device__ __forceinline__ void stage_levels(const MbInfo& mb, const uint32_t* coefs, int lane, int16_t* lv) {
-  uint32_t* z = reinterpret_cast<uint32_t*>(lv);
-#pragma unroll
-  for (int t = lane; t < kLevels / 2; t += 64) z[t] = 0;
-  wave_sync();
-  const uint32_t* src = coefs + mb.coef_offset;
-  if (mb.ncoef != kDenseCoefs) {
-    for (int t = lane; t < mb.ncoef; t += 64) {
-      const uint32_t w = gld32(src + t);
-      lv[w >> 16] = (int16_t)(w & 0xffff);
-    }
-  } else {
-    for (int t = lane; t < kLevels; t += 64) {
-      const int g = t >> 4;
-      if ((mb.coded_mask >> g) & 1)
-        lv[t] = (int16_t)gld16s(reinterpret_cast<const int16_t*>(src) + 16 * __popc(mb.coded_mask & ((1u << g) - 1)) + (t & 15));
-    }
-  }
-  wave_sync();
-}
 
 __device__ __forceinline__ int tap6(int a, int b, int c, int d, int e, int f) { return a - 5 * b + 20 * c + 20 * d - 5 * e + f; }
 
@@ -194,77 +170,91 @@ __device__ __forceinline__ void wave_sync() {
 // ---------------------------------------------------------------------------
 // Residual of one macroblock, computed by ONE wave (64 lanes) into LDS.
 //   work[384] ints scratch, dcs[24] ints, res_y[256], res_c[128] int16, lv[kLevels] int16
+//
+// The coefficient stream holds one word per NON-ZERO level ((group * 16 +
+// position) << 16 | level, MbInfo::ncoef of them; a coded 4x4 block of a P
+// picture has one or two).  Each lane takes an entry, scales it (8.5.9, 8.5.12.1,
+// 8.5.13) and drops it at its place in the zeroed work arrays - no loop over the
+// 384 coefficient slots, no address arithmetic over the mask.  DC levels of
+// Intra16x16 luma and of chroma go through their Hadamard transforms first
+// (8.5.10, 8.5.11).  kDenseCoefs (more than kMaxSparseCoefs levels): the coded
+// groups follow densely and every slot is visited.
 // ---------------------------------------------------------------------------
 __device__ void wave_residual(const MbInfo& mb, const uint32_t* coefs, const PictureParams& pp, int lane,
                               int* work, int* dcs, int16_t* res_y, int16_t* res_c, int16_t* lv) {
   const bool intra = mb.flags & MBF_INTRA;
+  const bool t8 = mb.flags & MBF_T8X8;
+  const bool i16 = mb.kind == MBK_I16x16;
   const int qp = mb.qp;
   int* dy = work;
   int* dc = work + 256;
-  stage_levels(mb, coefs, lane, lv);
-  if (mb.kind == MBK_I16x16 && lane < 16) {
-    const int16_t* g = lv + 16 * kMaskLumaDc;
-    int f = 0;
-    if ((mb.coded_mask >> kMaskLumaDc) & 1) {
-      const int i = lane >> 2, j = lane & 3;
-      for (int a = 0; a < 4; ++a) {
-        const int sa = (i == 0 || (i == 1 && a < 2) || (i == 2 && (a == 0 || a == 3)) || (i == 3 && (a & 1) == 0)) ? 1 : -1;
-        for (int b = 0; b < 4; ++b) {
-          const int sb = (j == 0 || (j == 1 && b < 2) || (j == 2 && (b == 0 || b == 3)) || (j == 3 && (b & 1) == 0)) ? 1 : -1;
-          f += sa * sb * g[a * 4 + b];
-        }
+  // zero the work arrays and the two DC staging rows (lv[0..15] luma DC, lv[16..23] chroma DC)
+#pragma unroll
+  for (int t = lane; t < 384; t += 64) work[t] = 0;
+  if (lane < 12) reinterpret_cast<uint32_t*>(lv)[lane] = 0;
+  wave_sync();
+  // wave-uniform scaling parameters
+  const int qs = qp / 6, qr = qp - 6 * qs;
+  const int qcs0 = mb.qpc[0] / 6, qcr0 = mb.qpc[0] - 6 * qcs0, qcs1 = mb.qpc[1] / 6, qcr1 = mb.qpc[1] - 6 * qcs1;
+  auto place = [&](int idx, int level) {
+    const int g = idx >> 4, pos = idx & 15;
+    if (g < 16) {
+      if (t8) {
+        const int k = idx & 63;
+        const int sc = level * level_scale8(pp.scaling8[intra ? 0 : 1], qr, k);
+        dy[idx] = qs >= 6 ? sc << (qs - 6) : (sc + (1 << (5 - qs))) >> (6 - qs);
+      } else {
+        const int sc = level * level_scale4(pp.scaling4[intra ? 0 : 3], qr, pos);
+        dy[idx] = qs >= 4 ? sc << (qs - 4) : (sc + (1 << (3 - qs))) >> (4 - qs);
       }
-      const int ls = level_scale4(pp.scaling4[0], qp, 0);
-      f = qp >= 36 ? (f * ls) << (qp / 6 - 6) : (f * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+    } else if (g == kMaskLumaDc) {
+      lv[pos] = (int16_t)level;
+    } else if (g == kMaskChromaDc) {
+      lv[16 + pos] = (int16_t)level;
+    } else {
+      const int c = idx - 16 * kMaskChromaAc, p = c >> 6;  // c: plane * 64 + block * 16 + position
+      const int s6 = p ? qcs1 : qcs0, r6 = p ? qcr1 : qcr0;
+      const int sc = level * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], r6, pos);
+      dc[c] = s6 >= 4 ? sc << (s6 - 4) : (sc + (1 << (3 - s6))) >> (4 - s6);
     }
-    dcs[lane] = f;
-  }
-  if (lane >= 16 && lane < 24) {
-    const int p = (lane - 16) >> 2, k = (lane - 16) & 3;
-    int v = 0;
-    if ((mb.coded_mask >> kMaskChromaDc) & 1) {
-      const int16_t* c = lv + 16 * kMaskChromaDc + 4 * p;
-      const int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-      const int f = k == 0 ? c0 + c1 + c2 + c3 : k == 1 ? c0 - c1 + c2 - c3 : k == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3;
-      const int qpc = mb.qpc[p];
-      const int ls = level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, 0);
-      v = ((f * ls) << (qpc / 6)) >> 5;
+  };
+  const uint32_t* src = coefs + mb.coef_offset;
+  if (mb.ncoef != kDenseCoefs) {
+    for (int t = lane; t < mb.ncoef; t += 64) {
+      const uint32_t w = gld32(src + t);
+      place((int)(w >> 16), (int)(int16_t)(w & 0xffff));
     }
-    dcs[lane] = v;
+  } else {
+    for (int t = lane; t < kLevels; t += 64) {
+      const int g = t >> 4;
+      if ((mb.coded_mask >> g) & 1) {
+        const int level = gld16s(reinterpret_cast<const int16_t*>(src) + 16 * __popc(mb.coded_mask & ((1u << g) - 1)) + (t & 15));
+        if (level) place(t, level);
+      }
+    }
   }
   wave_sync();
-  // scaling
-  for (int t = lane; t < 256; t += 64) {
-    int v = 0;
-    if (mb.flags & MBF_T8X8) {
-      const int k = t & 63;
-      const int level = lv[t];  // group 4 * b8, position k: the 64 levels of an 8x8 block are contiguous
-      if (level) {
-        const int s = level * level_scale8(pp.scaling8[intra ? 0 : 1], qp, k);
-        v = qp >= 36 ? s << (qp / 6 - 6) : (s + (1 << (5 - qp / 6))) >> (6 - qp / 6);
+  if (i16 && lane < 16 && ((mb.coded_mask >> kMaskLumaDc) & 1)) {
+    const int i = lane >> 2, j = lane & 3;
+    int f = 0;
+    for (int a = 0; a < 4; ++a) {
+      const int sa = (i == 0 || (i == 1 && a < 2) || (i == 2 && (a == 0 || a == 3)) || (i == 3 && (a & 1) == 0)) ? 1 : -1;
+      for (int b = 0; b < 4; ++b) {
+        const int sb = (j == 0 || (j == 1 && b < 2) || (j == 2 && (b == 0 || b == 3)) || (j == 3 && (b & 1) == 0)) ? 1 : -1;
+        f += sa * sb * lv[a * 4 + b];
       }
-    } else {
-      const int blk = t >> 4, k = t & 15;
-      const int level = lv[t];
-      if (level) {
-        const int s = level * level_scale4(pp.scaling4[intra ? 0 : 3], qp, k);
-        v = qp >= 24 ? s << (qp / 6 - 4) : (s + (1 << (3 - qp / 6))) >> (4 - qp / 6);
-      }
-      if (k == 0 && mb.kind == MBK_I16x16) v = dcs[blk];
     }
-    dy[t] = v;
+    const int ls = level_scale4(pp.scaling4[0], qr, 0);
+    dy[lane * 16] = qs >= 6 ? (f * ls) << (qs - 6) : (f * ls + (1 << (5 - qs))) >> (6 - qs);
   }
-  for (int t = lane; t < 128; t += 64) {
-    const int p = t >> 6, blk = (t >> 4) & 3, k = t & 15;
-    int v = 0;
-    const int qpc = mb.qpc[p];
-    const int level = lv[16 * kMaskChromaAc + t];
-    if (level) {
-      const int s = level * level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], qpc, k);
-      v = qpc >= 24 ? s << (qpc / 6 - 4) : (s + (1 << (3 - qpc / 6))) >> (4 - qpc / 6);
-    }
-    if (k == 0) v = dcs[16 + 4 * p + blk];
-    dc[t] = v;
+  if (lane >= 16 && lane < 24 && ((mb.coded_mask >> kMaskChromaDc) & 1)) {
+    const int p = (lane - 16) >> 2, k = (lane - 16) & 3;
+    const int16_t* c = lv + 16 + 4 * p;
+    const int c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+    const int f = k == 0 ? c0 + c1 + c2 + c3 : k == 1 ? c0 - c1 + c2 - c3 : k == 2 ? c0 + c1 - c2 - c3 : c0 - c1 - c2 + c3;
+    const int s6 = p ? qcs1 : qcs0, r6 = p ? qcr1 : qcr0;
+    const int ls = level_scale4(pp.scaling4[(intra ? 0 : 3) + 1 + p], r6, 0);
+    dc[p * 64 + k * 16] = ((f * ls) << s6) >> 5;
   }
   wave_sync();
   // rows
