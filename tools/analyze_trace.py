@@ -24,7 +24,7 @@ for r in rows:
     wx = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)
     jobs = gy if ("k_inter" in name or "k_bs" in name or "k_upload" in name) else max(1, gx // max(wx, 1))
     if "k_upload" in name:
-        jobs //= 4
+        jobs //= 5
     b = 1
     while b < jobs:
         b *= 2
