@@ -262,22 +262,33 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU visible (the decoder has no CPU fallback)")
-    if in_process_devices > torch.cuda.device_count():
+    # development aid: HWANG_BENCH_DEVICE_IDS=0,0 runs the one-process / several-device-slots path on a single GPU
+    forced_ids = [int(x) for x in os.environ.get("HWANG_BENCH_DEVICE_IDS", "").split(",") if x.strip()]
+    if in_process_devices > 1 and not forced_ids and in_process_devices > torch.cuda.device_count():
         raise SystemExit("bench.py: --gpus %d but only %d visible" % (in_process_devices, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
+    # One rank per GPU.  If the launcher started more ranks than there are GPUs (a development box with one
+    # GPU: the only way to exercise this path there) the ranks share devices and meet over gloo instead of
+    # RCCL, which refuses two ranks on one device; the line then says so in config.launch.
+    oversubscribed = world > torch.cuda.device_count()
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    red_dev = "cpu" if oversubscribed else "cuda"
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if oversubscribed:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
     # 3 lanes per usable CPU (a lane waits for the GPU about as long as it parses;
     # the CPUs are the bottleneck: measured 32 / 40 / 48 / 64 lanes on 16 CPUs ->
     # 660 / 676 / 698 / 651 frames/s); with several ranks on one host the CPUs are shared
     lanes = args.lanes or max(2, min(128, 3 * effective_cpus() // world))
-    devices = list(range(in_process_devices)) if in_process_devices > 1 else [local_rank]
+    devices = (forced_ids or list(range(in_process_devices))) if in_process_devices > 1 else [device_index]
     br = BatchRetriever(device_ids=devices, num_lanes=lanes, shard=(rank, world) if world > 1 else None)
     # request k's frames land in HBM (N ranks: each rank writes the rows of its share into its own copy of
     # the batch's output; nothing is gathered - no data-path collective)
     fobj = open(path, "rb")
     outs = [torch.empty((len(r), HEIGHT, WIDTH, 3), dtype=torch.uint8,
-                        device="cuda:%d" % (devices[k % len(devices)] if in_process_devices > 1 else local_rank))
+                        device="cuda:%d" % (devices[k % len(devices)] if in_process_devices > 1 else device_index))
             for k, r in enumerate(row_sets)]
     requests = [(index, fobj, row_sets[k], outs[k].data_ptr(), outs[k].numel()) for k in range(nreq)]
 
@@ -307,11 +318,11 @@ def main():
     stats = br.stats()
     dev_stats = br.device_stats()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         cnt = torch.tensor([stats["frames_returned"], stats["pictures_reconstructed"], stats["intervals"], host_cpus_busy],
-                           dtype=torch.float64, device="cuda")
+                           dtype=torch.float64, device=red_dev)
         gathered = [torch.zeros_like(cnt) for _ in range(world)]
         dist.all_gather(gathered, cnt)
         total_rows = int(sum(g[0].item() for g in gathered))
@@ -400,7 +411,10 @@ def main():
                                    "out over %d GPU(s); frames returned as RGB24 in HBM"
                                    % (n, unique, max(1, n // unique), GOP, BFRAMES, nreq, len(row_sets[0]), SEED,
                                       SEED + nreq - 1, args.gpus),
-                       "launch": "one process, %d devices" % len(devices) if in_process_devices > 1 else "%d rank(s), one GPU each" % world,
+                       "launch": ("one process, %d devices" % len(devices) if in_process_devices > 1 else
+                                  "%d rank(s), one GPU each" % world if not oversubscribed else
+                                  "%d ranks sharing %d GPU(s) (development run: gloo, not a scaling number)"
+                                  % (world, torch.cuda.device_count())),
                        "lanes_per_gpu": lanes // len(devices), "host_cpus": effective_cpus(),
                        "sharding": "GOP work items, longest-first split, no collective on the data path"},
             "value_host_output": value_host,
