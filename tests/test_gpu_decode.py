@@ -258,3 +258,36 @@ def test_expired_band_poll_fails_the_request(hw, gpu, tmp_path):
     # and the same clip decodes fine without the hook
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "NO ERROR" in r.stdout, r.stdout + r.stderr
+
+
+def test_corrupt_streams_never_hang_the_gpu(hw, gpu, tmp_path):
+    """Bit flips in slice data reach the kernels as absurd vectors, levels and modes (or are refused by the
+    parser).  Either is fine; a hung or faulted GPU is not: every request returns, and the executor is still
+    healthy afterwards (the pristine clip decodes bit-exactly through the same process)."""
+    path = str(tmp_path / "fz.mp4")
+    gold = make_clip(path, width=176, height=144, frames=12, gop=6, bframes=2, refs=3, slices=2, seed=5)
+    idx = hw.index_video(path)
+    data0 = np.fromfile(path, dtype=np.uint8)
+    offs, sizes = idx.sample_offsets(), idx.sample_sizes()
+    rng = np.random.default_rng(11)
+    errors = decoded = 0
+    for trial in range(40):
+        data = data0.copy()
+        for _ in range(1 + trial % 5):
+            s = int(rng.integers(0, len(offs)))
+            pos = offs[s] + int(rng.integers(6, sizes[s]))
+            data[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = str(tmp_path / ("fz_%d.mp4" % trial))
+        data.tofile(bad)
+        dec = hw.Decoder(bad, video_index=idx, num_lanes=2)
+        try:
+            out = dec.retrieve_yuv(list(range(12)))
+            assert len(out) == 12
+            decoded += 1
+        except RuntimeError:
+            errors += 1
+        del dec
+    assert errors + decoded == 40
+    got = hw.Decoder(path, video_index=idx, num_lanes=2).retrieve_yuv(list(range(12)))
+    for i in range(12):
+        assert np.array_equal(got[i], gold[i])
