@@ -50,6 +50,8 @@ class BatchRetriever(object):
             raise RuntimeError("hwang_amd.BatchRetriever: cannot open backend %r on devices %r" %
                                (decoder_type, list(device_ids)))
         self.num_devices = len(device_ids)
+        self._views = {}   # file object -> its mapping: one mmap for the retriever's lifetime (a fresh one per
+                           # call would fault every touched page in again)
         if shard is not None and lib.hwang_retriever_set_shard(self._h, int(shard[0]), int(shard[1])):
             raise RuntimeError(lib.hwang_retriever_last_error(self._h).decode())
 
@@ -62,8 +64,11 @@ class BatchRetriever(object):
         keep = []
         for i, (index, f, rows, out_ptr, cap) in enumerate(requests):
             if isinstance(f, str):
-                f = open(f, "rb")
-            src, n, k = _host_view(f)
+                f = self._views.setdefault(("path", f), open(f, "rb"))
+            view = self._views.get(id(f))
+            if view is None:
+                view = self._views[id(f)] = (f,) + _host_view(f)
+            _, src, n, k = view
             rows_arr = _capi.u64_array(rows)
             keep.append((f, k, rows_arr, src))
             arr[i].index = index._h

@@ -18,11 +18,13 @@ W, H = int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080))
 FRAMES = int(os.environ.get("FRAMES", 600))
 REPEAT = int(os.environ.get("REPEAT", 6))
 GOP = int(os.environ.get("GOP", 60))
-path = "/tmp/probe_%dx%d_%d_%d_%d.mp4" % (W, H, FRAMES, REPEAT, GOP)
+QP = int(os.environ.get("QP", 26))
+FPS = int(os.environ.get("FPS", 30))
+path = "/tmp/probe_%dx%d_%d_%d_%d_qp%d.mp4" % (W, H, FRAMES, REPEAT, GOP, QP)
 if not os.path.exists(path):
     t = time.time()
     subprocess.check_call([os.path.join(ROOT, "corpus/_build/h264_encoder"), "--width", str(W), "--height", str(H),
-                           "--frames", str(FRAMES), "--gop", str(GOP), "--bframes", "2", "--threads", "64",
+                           "--frames", str(FRAMES), "--gop", str(GOP), "--bframes", "2", "--threads", "64", "--qp", str(QP), "--fps", str(FPS),
                            "--repeat", str(REPEAT), "--out", path])
     print("corpus: %.1fs, %.1f MB" % (time.time() - t, os.path.getsize(path) / 1e6))
 idx = hw.index_video(path)
@@ -34,6 +36,8 @@ if os.environ.get("ROWS_MODE") == "keyframes":   # intra-only path in isolation
     rows = sorted(rng.choice(kf, min(len(kf), len(rows)), replace=False).tolist())
 elif os.environ.get("ROWS_MODE") == "stride10":  # BASELINE config C2: every 10th frame, every GOP touched
     rows = list(range(0, n, 10))
+elif os.environ.get("ROWS_MODE") == "dense":      # BASELINE config C4: every frame
+    rows = list(range(n))
 elif os.environ.get("ROWS_MODE") == "gopend":    # longest P chains
     kf = idx.keyframe_indices()
     rows = sorted(set(int(k) - 3 for k in rng.choice(kf[1:], min(len(kf) - 1, len(rows)), replace=False)))
