@@ -257,8 +257,17 @@ __device__ void wave_residual(const MbInfo& mb, const uint32_t* coefs, const Pic
     dc[p * 64 + k * 16] = ((f * ls) << s6) >> 5;
   }
   wave_sync();
+  // Inverse transforms, per plane group only where something was coded (wave uniform): a P macroblock often
+  // carries luma or chroma levels only.
+  const bool has_luma = (mb.coded_mask & 0x1ffffu) != 0, has_chroma = (mb.coded_mask >> kMaskChromaDc) != 0;
+  if (!has_luma) {
+    reinterpret_cast<uint32_t*>(res_y)[lane] = 0;
+    reinterpret_cast<uint32_t*>(res_y)[64 + lane] = 0;
+  }
+  if (!has_chroma) reinterpret_cast<uint32_t*>(res_c)[lane] = 0;
   // rows
-  if (mb.flags & MBF_T8X8) {
+  if (!has_luma) {
+  } else if (mb.flags & MBF_T8X8) {
     if (lane < 32) {
       int* d = dy + (lane >> 3) * 64 + (lane & 7) * 8;
       const int d0 = d[0], d1 = d[1], d2 = d[2], d3 = d[3], d4 = d[4], d5 = d[5], d6 = d[6], d7 = d[7];
@@ -274,14 +283,15 @@ __device__ void wave_residual(const MbInfo& mb, const uint32_t* coefs, const Pic
     const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
     d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
   }
-  if (lane < 32) {
+  if (has_chroma && lane < 32) {
     int* d = dc + (lane >> 2) * 16 + (lane & 3) * 4;
     const int e0 = d[0] + d[2], e1 = d[0] - d[2], e2 = (d[1] >> 1) - d[3], e3 = d[1] + (d[3] >> 1);
     d[0] = e0 + e3; d[1] = e1 + e2; d[2] = e1 - e2; d[3] = e0 - e3;
   }
   wave_sync();
   // columns
-  if (mb.flags & MBF_T8X8) {
+  if (!has_luma) {
+  } else if (mb.flags & MBF_T8X8) {
     if (lane < 32) {
       const int b8 = lane >> 3, c = lane & 7;
       const int* d = dy + b8 * 64 + c;
@@ -305,7 +315,7 @@ __device__ void wave_residual(const MbInfo& mb, const uint32_t* coefs, const Pic
     res_y[(y0 + 2) * 16 + x] = (int16_t)((e1 - e2 + 32) >> 6);
     res_y[(y0 + 3) * 16 + x] = (int16_t)((e0 - e3 + 32) >> 6);
   }
-  if (lane < 32) {
+  if (has_chroma && lane < 32) {
     const int pb = lane >> 2, c = lane & 3;
     const int* d = dc + pb * 16 + c;
     const int e0 = d[0] + d[8], e1 = d[0] - d[8], e2 = (d[4] >> 1) - d[12], e3 = d[4] + (d[12] >> 1);
@@ -625,6 +635,8 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
 
   const SliceParams& sp = job.slices[mb.slice];
   const Surface cur = pp.surfaces[pp.cur_slot];
+  // the common P macroblock: default weights, list 0 only -> the prediction is the interpolated sample itself
+  const bool plain = idx1 == 0xffffffffu && gld8(&sp.weight_mode) == 0 && !((idx0 & 0x80808080u));
   {  // luma
     const int r0 = byte_of(idx0, b8), r1 = byte_of(idx1, b8);
     const int px = mbx * 16 + bcol * 4, py = mby * 16 + y;
@@ -661,7 +673,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int pred = combine_pred(sp, 0, r0 >= 0, r1 >= 0, s0[i], s1[i], r0, r1);
+      const int pred = plain ? s0[i] : combine_pred(sp, 0, r0 >= 0, r1 >= 0, s0[i], s1[i], r0, r1);
       const int v = has_res ? clip8(pred + L.res_y[y * 16 + bcol * 4 + i]) : pred;
       packed |= (uint32_t)v << (8 * i);
     }
@@ -695,7 +707,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int pred = combine_pred(sp, 1 + cplane, r0 >= 0, r1 >= 0, s0[i], s1[i], r0, r1);
+      const int pred = plain ? s0[i] : combine_pred(sp, 1 + cplane, r0 >= 0, r1 >= 0, s0[i], s1[i], r0, r1);
       const int v = has_res ? clip8(pred + L.res_c[cplane * 64 + cy * 8 + cbcol * 2 + i]) : pred;
       packed |= (uint32_t)v << (8 * i);
     }

@@ -86,6 +86,19 @@ for lanes in [int(x) for x in os.environ.get("LANES", "1,4,16,32,64").split(",")
         lanes, best, len(rows) / best, st["pictures_reconstructed"] / best, st["samples_fed"], st["pictures_skipped"],
         st["entropy_ns"] / 1e9, st["stall_ns"] / 1e9, cpu_best, st["bytes_uploaded"] / 1e6))
     del dec
+if os.environ.get("SERIAL"):
+    # the reference-shaped path: ONE DecoderAutomata, intervals one after the other (python/hwang/decoder.py:30-69)
+    k = int(os.environ["SERIAL"])
+    dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+    dec.retrieve_serial(rows[:4])
+    t = time.time()
+    c0 = os.times()
+    got = dec.retrieve_serial(rows[:k])
+    dt = time.time() - t
+    c1 = os.times()
+    print("serial (one DecoderAutomata, reference loop): %d rows in %.2fs = %.1f returned fps, process cpu %.2fs" % (
+        len(got), dt, len(got) / dt, (c1.user - c0.user) + (c1.system - c0.system)))
+    del dec
 # per-kernel timings with one lane (events serialise nothing else)
 lib.hwang_prof_enable(1)
 lib.hwang_prof_reset()
