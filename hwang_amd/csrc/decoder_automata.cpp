@@ -8,6 +8,16 @@ namespace hwang {
 
 namespace {
 constexpr auto kPoll = std::chrono::microseconds(100);
+// A short timed wait.  libstdc++'s wait_for goes through pthread_cond_clockwait, which GCC 11's
+// ThreadSanitizer does not intercept (it then sees the mutex "locked twice" and invents races on everything
+// the lock protects); under TSAN the wait is phrased against the system clock = pthread_cond_timedwait.
+inline void wait_poll(std::condition_variable& cv, std::unique_lock<std::mutex>& lk) {
+#if defined(__SANITIZE_THREAD__)
+  cv.wait_until(lk, std::chrono::system_clock::now() + kPoll);
+#else
+  cv.wait_for(lk, kPoll);
+#endif
+}
 }
 
 DecoderAutomata::DecoderAutomata(VideoDecoderInterface* decoder)
@@ -144,7 +154,7 @@ Result DecoderAutomata::get_frames(uint8_t* buffer, int32_t num_frames) {
       while (flushed_segs_ <= static_cast<int64_t>(ret_seg_) && !failed_) {
         drain_locked(lk);  // keep back-pressure from stalling the feeder
         if (flushed_segs_ > static_cast<int64_t>(ret_seg_)) break;
-        cv_.wait_for(lk, kPoll);
+        wait_poll(cv_, lk);
       }
       if (failed_) return finish(failure_);
       drain_locked(lk);
@@ -186,7 +196,7 @@ Result DecoderAutomata::get_frames(uint8_t* buffer, int32_t num_frames) {
                    "frame " + std::to_string(seg.valid_frames[ret_valid_]) +
                    " was produced"));
       }
-      cv_.wait_for(lk, kPoll);
+      wait_poll(cv_, lk);
     }
   }
   Result done = finish(Result());
@@ -232,7 +242,7 @@ void DecoderAutomata::feeder() {
     }
 
     if (decoder_->decoded_frames_buffered() > MAX_BUFFERED_FRAMES) {
-      cv_.wait_for(lk, kPoll);
+      wait_poll(cv_, lk);
       continue;
     }
 
