@@ -53,6 +53,7 @@ class EncodedDataStruct(C.Structure):
 # and exported by the library.
 PROTOTYPES = {
     "hwang_amd_version": (C.c_char_p, []),
+    "hwang_register_decoder_backend": (C.c_int, [C.c_int, vp]),
     # VideoIndex
     "hwang_video_index_create": (vp, [C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
                                       C.c_char_p, u64p, u64p, C.c_size_t, u64p,
@@ -110,7 +111,6 @@ PROTOTYPES = {
     "hwang_automata_get_frames": (C.c_int, [vp, vp, C.c_int32]),
     "hwang_automata_last_error": (C.c_char_p, [vp]),
     "hwang_automata_stats": (None, [vp, i64p]),
-    "hwang_automata_stamp_trace": (C.c_int, [vp, i32p]),
     # parallel retriever
     "hwang_retriever_create": (vp, [C.c_int, C.c_int32, C.c_int, C.c_int32]),
     "hwang_retriever_create_multi": (vp, [C.c_int, i32p, C.c_size_t, C.c_int, C.c_int32]),

@@ -3,7 +3,8 @@
 
 Same class / method / function names and argument meaning, so code written
 against `hwang` runs against `hwang_amd` unchanged; the one addition is
-`VideoDecoderType.AMD` (and the `STAMP` protocol fixture).
+`VideoDecoderType.AMD`; decoder types >= 100 are backends registered at run
+time through `hwang_register_decoder_backend` (the test suite's STAMP fixture).
 """
 import ctypes as C
 import enum
@@ -24,7 +25,6 @@ class VideoDecoderType(enum.IntEnum):
     NVIDIA = 1
     INTEL = 2
     AMD = 3
-    STAMP = 100
 
 
 class DeviceHandle(object):
@@ -259,11 +259,3 @@ class DecoderAutomata(object):
         lib.hwang_automata_stats(self._h, s)
         return dict(samples_fed=s[0], frames_discarded=s[1],
                     frames_returned=s[2], flushes=s[3])
-
-    def stamp_trace(self):
-        t = (C.c_int32 * 8)()
-        if lib.hwang_automata_stamp_trace(self._h, t):
-            raise RuntimeError("stamp_trace: backend is not the STAMP fixture")
-        keys = ("configures", "feeds", "keyframe_feeds", "empty_feeds",
-                "flushes", "gets", "discards", "hints")
-        return dict(zip(keys, list(t)))

@@ -4,7 +4,6 @@
 
 #include "decoder_automata.h"
 #include "mp4_index_creator.h"
-#include "stamp_video_decoder.h"
 #include "video_index.h"
 
 #include <cstring>
@@ -214,20 +213,6 @@ void hwang_automata_stats(hwang_automata* a, int64_t stats[4]) {
   stats[1] = s.frames_discarded;
   stats[2] = s.frames_returned;
   stats[3] = s.flushes;
-}
-int hwang_automata_stamp_trace(hwang_automata* a, int32_t trace[8]) {
-  auto* stamp = dynamic_cast<StampVideoDecoder*>(a->backend);
-  if (!stamp) return 1;
-  StampVideoDecoder::Trace t = stamp->trace();
-  trace[0] = t.configures;
-  trace[1] = t.feeds;
-  trace[2] = t.keyframe_feeds;
-  trace[3] = t.empty_feeds;
-  trace[4] = t.flushes;
-  trace[5] = t.gets;
-  trace[6] = t.discards;
-  trace[7] = t.hints;
-  return 0;
 }
 
 }  // extern "C"

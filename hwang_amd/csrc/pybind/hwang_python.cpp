@@ -154,8 +154,7 @@ PYBIND11_MODULE(_python, m) {
       .value("SOFTWARE", VideoDecoderType::SOFTWARE)
       .value("NVIDIA", VideoDecoderType::NVIDIA)
       .value("INTEL", VideoDecoderType::INTEL)
-      .value("AMD", VideoDecoderType::AMD)
-      .value("STAMP", VideoDecoderType::STAMP);
+      .value("AMD", VideoDecoderType::AMD);  // values >= 100: backends registered at run time (include/hwang_amd.h)
 
   py::class_<DecoderAutomata::EncodedData>(m, "EncodedData")
       .def(py::init<>())

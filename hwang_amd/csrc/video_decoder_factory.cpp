@@ -1,14 +1,15 @@
 #include "video_decoder_factory.h"
 
 #include "amd/amd_video_decoder.h"
-#include "stamp_video_decoder.h"
 
 namespace hwang {
 
-// Reference: video_decoder_factory.cpp:31-98.  Only the MI355X backend (and
-// the protocol test fixture) exist in this build.
+// Reference: video_decoder_factory.cpp:31-98.  Only the MI355X backend exists
+// in this build, plus whatever was registered at run time.
 std::vector<VideoDecoderType> VideoDecoderFactory::get_supported_decoder_types() {
-  return {VideoDecoderType::AMD, VideoDecoderType::STAMP};
+  std::vector<VideoDecoderType> types = {VideoDecoderType::AMD};
+  for (VideoDecoderType t : registered_types()) types.push_back(t);
+  return types;
 }
 
 bool VideoDecoderFactory::has_decoder_type(VideoDecoderType type) {
@@ -25,10 +26,8 @@ VideoDecoderInterface* VideoDecoderFactory::make_from_config(
       // configuration error, not a cue to fall back.
       if (device_handle.type != DeviceType::GPU) return nullptr;
       return make_amd_video_decoder(device_handle.id, num_devices);
-    case VideoDecoderType::STAMP:
-      return new StampVideoDecoder();
     default:
-      return nullptr;
+      return make_registered(device_handle, num_devices, type);
   }
 }
 

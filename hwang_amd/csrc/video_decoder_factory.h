@@ -11,6 +11,8 @@
 
 #include <vector>
 
+struct hwang_backend_vtable;
+
 namespace hwang {
 
 enum class VideoDecoderType {
@@ -18,10 +20,8 @@ enum class VideoDecoderType {
   NVIDIA = 1,
   INTEL = 2,
   AMD = 3,
-  // Test fixture only: decodes nothing, emits one frame per fed sample whose
-  // first four bytes are the sample's first four payload bytes.  Used to pin
-  // the DecoderAutomata protocol on machines without a GPU.
-  STAMP = 100,
+  // values >= 100 (HWANG_DECODER_FIRST_REGISTERED): backends registered at run
+  // time through hwang_register_decoder_backend (include/hwang_amd.h)
 };
 
 class VideoDecoderFactory {
@@ -33,6 +33,13 @@ class VideoDecoderFactory {
   static VideoDecoderInterface* make_from_config(DeviceHandle device_handle,
                                                  uint32_t num_devices,
                                                  VideoDecoderType type);
+
+  // Run-time registry behind the C plug-in boundary (registered_backend.cpp).
+  static bool register_backend(int decoder_type, const struct hwang_backend_vtable* vtable);
+  static std::vector<VideoDecoderType> registered_types();
+
+ private:
+  static VideoDecoderInterface* make_registered(DeviceHandle device_handle, uint32_t num_devices, VideoDecoderType type);
 };
 
 }  // namespace hwang

@@ -29,8 +29,34 @@ enum {
   HWANG_DECODER_NVIDIA = 1,   /* NVDEC backend: not built here             */
   HWANG_DECODER_INTEL = 2,    /* dead in the reference                     */
   HWANG_DECODER_AMD = 3,      /* this library's MI355X backend             */
-  HWANG_DECODER_STAMP = 100   /* protocol test fixture, decodes nothing    */
+  HWANG_DECODER_FIRST_REGISTERED = 100 /* >= this: backends plugged in at run time, below */
 };
+
+/* -- Backend plug-in boundary ------------------------------------------------
+ * The seven entry points of VideoDecoderInterface (hwang/video_decoder_interface.h:28-49)
+ * as a table of C functions, so that a backend living outside this library can be
+ * driven by its DecoderAutomata and ParallelRetriever: the mirror image of
+ * INTEGRATION.md, where hwang's factory gains a case for this library.  The
+ * reference's factory is fixed at compile time (video_decoder_factory.cpp:31-98).
+ * Every function returns 0 on success; last_error(self) describes the last failure;
+ * set_wanted (the sparse hint, hwang_decoder_set_wanted) may be NULL.  The test
+ * suite's STAMP fixture (tests/fixtures/stamp_backend.c) is such a backend. */
+typedef struct hwang_backend_vtable {
+  void* (*create)(int device_type, int32_t device_id, uint32_t num_devices); /* NULL: cannot open */
+  void (*destroy)(void* self);
+  int (*configure)(void* self, uint32_t width, uint32_t height, const char* format,
+                   const uint8_t* extradata, size_t extradata_size);
+  int (*feed)(void* self, const uint8_t* encoded, size_t encoded_size, int keyframe);
+  int (*flush)(void* self);
+  int (*discard_frame)(void* self);
+  int (*get_frame)(void* self, uint8_t* decoded, size_t decoded_size);
+  int (*decoded_frames_buffered)(void* self);
+  int (*wait_until_frames_copied)(void* self);
+  const char* (*last_error)(void* self);
+  void (*set_wanted)(void* self, const uint64_t* ordinals, size_t n);
+} hwang_backend_vtable;
+/* decoder_type >= HWANG_DECODER_FIRST_REGISTERED; the table is copied.  Non-zero: refused. */
+int hwang_register_decoder_backend(int decoder_type, const hwang_backend_vtable* vtable);
 
 const char* hwang_amd_version(void);
 
@@ -174,9 +200,6 @@ int hwang_automata_get_frames(hwang_automata* a, uint8_t* buffer,
 const char* hwang_automata_last_error(hwang_automata* a);
 /* stats[4] = samples_fed, frames_discarded, frames_returned, flushes */
 void hwang_automata_stats(hwang_automata* a, int64_t stats[4]);
-/* STAMP backend only: trace[8] = configures, feeds, keyframe_feeds,
- * empty_feeds, flushes, gets, discards, hints.  Returns non-zero otherwise. */
-int hwang_automata_stamp_trace(hwang_automata* a, int32_t trace[8]);
 
 /* -- Parallel sparse retrieval (the perf path) ------------------------------
  * What python/hwang/decoder.py:30-69 (Decoder.retrieve) does one interval at

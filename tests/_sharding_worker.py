@@ -22,6 +22,10 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import hwang_amd as hw  # noqa: E402
+from tests.conftest import STAMP, load_stamp_backend  # noqa: E402
+
+hw.stamp_fixture = load_stamp_backend()
+hw.STAMP = STAMP
 from hwang_amd.decoder import BatchRetriever  # noqa: E402
 
 SEED = 20240601
@@ -43,7 +47,7 @@ def main():
         buf = np.full((len(rows), h, w, 3), 255, dtype=np.uint8)   # 255: "not written by this rank"
         bufs.append((rows, buf))
         requests.append((index, io.BytesIO(blob), rows, buf.ctypes.data, buf.nbytes))
-    br = BatchRetriever(device_ids=[0], device_type=hw.DeviceType.CPU, decoder_type=hw.VideoDecoderType.STAMP,
+    br = BatchRetriever(device_ids=[0], device_type=hw.DeviceType.CPU, decoder_type=hw.STAMP,
                         num_lanes=3, shard=(rank, world))
     dist.barrier()
     t0 = time.perf_counter()

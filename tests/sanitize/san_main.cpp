@@ -7,7 +7,8 @@
 #include "h264/h264_parser.h"
 #include "mp4_index_creator.h"
 #include "retriever.h"
-#include "stamp_video_decoder.h"
+#include "../../include/hwang_amd.h"
+#include "video_decoder_factory.h"
 #include "video_index.h"
 
 #include <cstdio>
@@ -22,6 +23,8 @@ namespace hwang {
 VideoDecoderInterface* make_amd_video_decoder(int32_t, uint32_t) { return nullptr; }
 }
 using namespace hwang;
+extern "C" const hwang_backend_vtable hwang_stamp_vtable;  // tests/fixtures/stamp_backend.c
+static const VideoDecoderType STAMP = static_cast<VideoDecoderType>(100);
 
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); ++fails; } } while (0)
@@ -41,13 +44,14 @@ static VideoIndex stamp_index(int n, int gop, std::vector<uint8_t>* blob) {
 }
 
 static void threads_part() {
+  CHECK(VideoDecoderFactory::register_backend(100, &hwang_stamp_vtable));
   std::vector<uint8_t> blob;
   VideoIndex idx = stamp_index(1200, 30, &blob);
   std::vector<uint64_t> rows;
   for (uint64_t r = 3; r < 1200; r += 17) rows.push_back(r);
   // several devices, more lanes than CPUs, batch of two requests
   std::unique_ptr<ParallelRetriever> pr(ParallelRetriever::make(
-      {DeviceHandle{DeviceType::CPU, 0}, DeviceHandle{DeviceType::CPU, 1}, DeviceHandle{DeviceType::CPU, 2}}, VideoDecoderType::STAMP, 12));
+      {DeviceHandle{DeviceType::CPU, 0}, DeviceHandle{DeviceType::CPU, 1}, DeviceHandle{DeviceType::CPU, 2}}, STAMP, 12));
   CHECK(pr != nullptr);
   std::vector<uint8_t> out1(rows.size() * 24), out2(rows.size() * 24);
   for (int rep = 0; rep < 3; ++rep) {
@@ -70,7 +74,7 @@ static void threads_part() {
     }
   }
   // DecoderAutomata: feeder thread vs caller thread
-  std::unique_ptr<DecoderAutomata> da(DecoderAutomata::make_instance(DeviceHandle{DeviceType::CPU, 0}, 1, VideoDecoderType::STAMP));
+  std::unique_ptr<DecoderAutomata> da(DecoderAutomata::make_instance(DeviceHandle{DeviceType::CPU, 0}, 1, STAMP));
   CHECK(da != nullptr);
   for (int rep = 0; rep < 4; ++rep) {
     std::vector<DecoderAutomata::EncodedData> segs;

@@ -52,16 +52,30 @@ def stamps(frames):
     return [int.from_bytes(f.tobytes()[:4], "little") for f in frames]
 
 
+def stamp_trace(hw):
+    """Call counters of the STAMP fixture (process-wide; reset by fresh_automata)."""
+    import ctypes
+    t = (ctypes.c_int32 * 8)()
+    hw.stamp_fixture.hwang_stamp_trace(t)
+    keys = ("configures", "feeds", "keyframe_feeds", "empty_feeds", "flushes", "gets", "discards", "hints")
+    return dict(zip(keys, list(t)))
+
+
+def fresh_automata(hw):
+    hw.stamp_fixture.hwang_stamp_reset()
+    return hw.DecoderAutomata(hw.DeviceHandle(hw.DeviceType.CPU, 0), 1, hw.STAMP)
+
+
 def test_reference_protocol_example(hw):
     # SURVEY.md 3.2: 4 touched GOPs of 10, wanted {3,4,27,55,58,99}
     idx, blob = make_clip(hw, 100, 10)
     rows = [3, 4, 27, 55, 58, 99]
     plan = hw.slice_into_video_intervals(idx, rows)
-    a = hw.DecoderAutomata(hw.DeviceHandle(hw.DeviceType.CPU, 0), 1, hw.VideoDecoderType.STAMP)
+    a = fresh_automata(hw)
     a.initialize(encoded_data(hw, idx, blob, plan), b"")
     got = a.get_frames(idx, 4) + a.get_frames(idx, 2)
     assert stamps(got) == rows
-    t = a.stamp_trace()
+    t = stamp_trace(hw)
     assert t["configures"] == 1
     assert t["gets"] == 6
     assert t["keyframe_feeds"] == 4          # one IDR per touched interval
@@ -79,7 +93,7 @@ def test_sparse_equals_sequential(hw, seed):
     idx, blob = make_clip(hw, n, gop, gap=rnd.choice([0, 5]))
     rows = sorted(rnd.sample(range(n), rnd.randint(1, min(n, 25))))
     plan = hw.slice_into_video_intervals(idx, rows)
-    a = hw.DecoderAutomata(hw.DeviceHandle(hw.DeviceType.CPU, 0), 1, hw.VideoDecoderType.STAMP)
+    a = fresh_automata(hw)
     a.initialize(encoded_data(hw, idx, blob, plan), b"")
     got, left = [], len(rows)
     while left:
@@ -94,7 +108,7 @@ def test_reinitialize_and_per_interval_loop(hw):
     # the reference's Python loop re-initializes per interval (decoder.py:65)
     idx, blob = make_clip(hw, 60, 6)
     rows = [0, 5, 6, 30, 59]
-    a = hw.DecoderAutomata(hw.DeviceHandle(hw.DeviceType.CPU, 0), 1, hw.VideoDecoderType.STAMP)
+    a = fresh_automata(hw)
     got = []
     for seg in encoded_data(hw, idx, blob, hw.slice_into_video_intervals(idx, rows)):
         a.initialize([seg], b"")
@@ -104,7 +118,7 @@ def test_reinitialize_and_per_interval_loop(hw):
 
 def test_errors_are_results_not_aborts(hw):
     idx, blob = make_clip(hw, 20, 10)
-    a = hw.DecoderAutomata(hw.DeviceHandle(hw.DeviceType.CPU, 0), 1, hw.VideoDecoderType.STAMP)
+    a = fresh_automata(hw)
     with pytest.raises(RuntimeError):
         a.get_frames(idx, 1)              # before initialize
     segs = encoded_data(hw, idx, blob, hw.slice_into_video_intervals(idx, [3]))

@@ -205,7 +205,7 @@ def test_inconsistent_index_is_refused(hw):
     import io
     with pytest.raises(RuntimeError) as e:
         hw.Decoder(io.BytesIO(b"\0" * 64), video_index=idx, device_type=hw.DeviceType.CPU,
-                   decoder_type=hw.VideoDecoderType.STAMP, num_lanes=1).retrieve([0])
+                   decoder_type=hw.STAMP, num_lanes=1).retrieve([0])
     assert "keyframe" in str(e.value)
 
 

@@ -16,7 +16,7 @@ from tests.util import REALSHORT, have_file
 
 
 @pytest.fixture(scope="module")
-def ref_api(built):
+def ref_api(built, hw):   # `hw` registers the STAMP fixture with the library both modules share
     import hwang
     return hwang
 
@@ -82,7 +82,7 @@ def test_reference_retrieve_loop_with_the_stamp_backend(ref_api, tmp_path):
                                 sample_sizes=[len(s) for s in samples], keyframe_indices=list(range(0, n, gop)), metadata=b"")
     index = ref_api.VideoIndex.deserialize(seed.serialize())
     dec = ref_api.Decoder(path, video_index=index, device_type=ref_api.DeviceType.CPU,
-                          decoder_type=ref_api.VideoDecoderType.STAMP)
+                          decoder_type=ref_api.VideoDecoderType(100))
     rows = [0, 1, 29, 30, 95, 96, 200, 239]
     frames = dec.retrieve(rows)
     assert len(frames) == len(rows)

@@ -17,14 +17,19 @@ from tests.util import ROOT
 
 CSRC = os.path.join(ROOT, "hwang_amd", "csrc")
 SOURCES = [os.path.join(ROOT, "tests", "sanitize", "san_main.cpp")] + [os.path.join(CSRC, f) for f in (
-    "retriever.cpp", "decoder_automata.cpp", "stamp_video_decoder.cpp", "video_decoder_factory.cpp", "video_index.cpp",
+    "retriever.cpp", "decoder_automata.cpp", "registered_backend.cpp", "video_decoder_factory.cpp", "video_index.cpp",
     "mp4_index_creator.cpp", "h264/h264_parser.cpp", "h264/h264_cabac_init.cpp")]
 
 
 def build(tmp_path, name, flags):
     exe = str(tmp_path / name)
+    fixture_obj = str(tmp_path / (name + "_stamp.o"))   # the STAMP fixture is C: compile it as such, sanitized too
+    r = subprocess.run(["gcc", "-O1", "-g", "-pthread", "-fno-omit-frame-pointer"] + [f for f in flags if f.startswith("-fsan")] +
+                       ["-c", os.path.join(ROOT, "tests", "fixtures", "stamp_backend.c"), "-o", fixture_obj],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-march=x86-64-v3", "-pthread", "-fno-omit-frame-pointer", "-I", CSRC,
-           "-I", os.path.join(ROOT, "include")] + flags + SOURCES + ["-o", exe]
+           "-I", os.path.join(ROOT, "include")] + flags + SOURCES + [fixture_obj, "-o", exe]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     return exe

@@ -38,7 +38,7 @@ def _stamp_decoder(hw, n, gop, w, h, num_lanes):
                           sample_offsets=offs, sample_sizes=[len(s) for s in samples],
                           keyframe_indices=list(range(0, n, gop)), metadata=b"")
     return hw.Decoder(io.BytesIO(b"".join(samples)), video_index=index, device_type=hw.DeviceType.CPU,
-                      decoder_type=hw.VideoDecoderType.STAMP, num_lanes=num_lanes)
+                      decoder_type=hw.STAMP, num_lanes=num_lanes)
 
 
 def test_automatic_lane_count(hw):
@@ -79,7 +79,7 @@ def test_one_request_fans_out_over_devices(hw):
     rows = sorted(np.random.default_rng(5).choice(3000, 90, replace=False).tolist())
     for devices, lanes in (([0, 1], 4), ([0, 1, 2, 3], 0), ([0, 1, 2], 3)):
         dec = hw.Decoder(io.BytesIO(blob), video_index=index, device_type=hw.DeviceType.CPU,
-                         decoder_type=hw.VideoDecoderType.STAMP, num_lanes=lanes, device_ids=devices)
+                         decoder_type=hw.STAMP, num_lanes=lanes, device_ids=devices)
         frames = dec.retrieve(rows)
         assert [struct.unpack("<I", f.tobytes()[:4])[0] for f in frames] == rows
         ds = dec.device_stats()
@@ -104,7 +104,7 @@ def test_retrieve_batch_pools_clips(hw):
         rows = sorted(rng.choice(index.frames(), 6, replace=False).tolist()) if k != 5 else []   # one empty request
         reqs.append((index, io.BytesIO(blob), rows))
         want.append([((k + 1) << 24) | r for r in rows])
-    br = BatchRetriever(device_ids=[0, 1], device_type=hw.DeviceType.CPU, decoder_type=hw.VideoDecoderType.STAMP,
+    br = BatchRetriever(device_ids=[0, 1], device_type=hw.DeviceType.CPU, decoder_type=hw.STAMP,
                         num_lanes=5)
     got = br.retrieve(reqs)
     for k in range(len(clips)):
@@ -116,7 +116,7 @@ def test_retrieve_batch_pools_clips(hw):
     # shares of a sharded job are disjoint and complete
     seen = [np.zeros(len(w), dtype=np.int32) for w in want]
     for rank in range(3):
-        brs = BatchRetriever(device_ids=[0], device_type=hw.DeviceType.CPU, decoder_type=hw.VideoDecoderType.STAMP,
+        brs = BatchRetriever(device_ids=[0], device_type=hw.DeviceType.CPU, decoder_type=hw.STAMP,
                              num_lanes=2, shard=(rank, 3))
         part = brs.retrieve(reqs)
         for k in range(len(clips)):
