@@ -1755,7 +1755,11 @@ __device__ __forceinline__ bool filter_line(int* v, int bs, int alpha, int beta,
 // Filters the edge whose first q sample is at `q` in an LDS tile; `step` is
 // the distance between samples across the edge (1: vertical edge, row stride:
 // horizontal edge).  Vertical edges move the 8 samples as two dwords.
-__device__ __forceinline__ void filter_edge(uint8_t* q, int step, int bs, int alpha, int beta, int tc0, bool chroma) {
+// `paired`: another lane filters the edge eight luma (four chroma) samples further on in the same step.  Luma
+// words are disjoint then; the two chroma edges share the word between them, so chroma stores only the two
+// samples it may change.
+__device__ __forceinline__ void filter_edge(uint8_t* q, int step, int bs, int alpha, int beta, int tc0, bool chroma,
+                                            bool paired = false) {
   int v[8];
   if (step == 1) {
     const uint32_t lo = *reinterpret_cast<const uint32_t*>(q - 4), hi = *reinterpret_cast<const uint32_t*>(q);
@@ -1765,6 +1769,11 @@ __device__ __forceinline__ void filter_edge(uint8_t* q, int step, int bs, int al
       v[4 + i] = (hi >> (8 * i)) & 0xff;
     }
     if (!filter_line(v, bs, alpha, beta, tc0, chroma)) return;
+    if (paired && chroma) {
+      q[-1] = (uint8_t)v[3];
+      q[0] = (uint8_t)v[4];
+      return;
+    }
     *reinterpret_cast<uint32_t*>(q - 4) = v[0] | (v[1] << 8) | (v[2] << 16) | ((uint32_t)v[3] << 24);
     *reinterpret_cast<uint32_t*>(q) = v[4] | (v[5] << 8) | (v[6] << 16) | ((uint32_t)v[7] << 24);
   } else {
@@ -2025,8 +2034,10 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
         // ---- this lane's parameters for all eight edge steps, in registers
         const int emask = L.db.emask;
         const bool top_edge = mby > 0 && (emask & 0x10);
-        const int kk = lane < 16 ? (lane >> 2) : (((lane - 16) & 7) >> 1);
-        const int pl = lane < 16 ? 0 : (lane < 32 ? 1 + ((lane - 16) >> 3) : 0);
+        // lanes 32..63 mirror lanes 0..31 (they take the second edge of a pair, below)
+        const int l32 = lane & 31;
+        const int kk = l32 < 16 ? (l32 >> 2) : (((l32 - 16) & 7) >> 1);
+        const int pl = l32 < 16 ? 0 : 1 + ((l32 - 16) >> 3);
         const uint32_t vbs = *reinterpret_cast<const uint32_t*>(L.db.bs[0][kk]);
         const uint32_t hbs = *reinterpret_cast<const uint32_t*>(L.db.bs[1][kk]);
         const uint32_t a3 = L.db.alpha[pl][0] | (L.db.alpha[pl][1] << 8) | (L.db.alpha[pl][2] << 16);
@@ -2051,7 +2062,23 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
             if (lane < 24) top_word = gld32(src);
           }
         }
-        // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each
+        // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each.
+        // Edges 0 and 2 touch disjoint samples (x <= 3 and x >= 4), so when the odd edges are not filtered
+        // - every macroblock with the 8x8 transform, and many without - both run in ONE step, the second on
+        // lanes 32..63: half the dependent edge steps of the pass.
+        if (!(emask & 0xa) && (emask & 0x5)) {
+          const int e = (lane >> 5) * 2;
+          const int bs = (vbs >> (8 * e)) & 0xff;
+          const int cls = e == 0 ? 0 : 2;
+          const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
+          const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
+          if (((emask >> e) & 1) && bs) {
+            const int p = (l32 - 16) >> 3, i = (l32 - 16) & 7;
+            uint8_t* q = l32 < 16 ? lt + (4 + l32) * LS + 4 + e * 4 : L.ct[p] + (2 + i) * CS + 4 + e * 2;
+            filter_edge(q, 1, bs, alpha, beta, tc0, l32 >= 16, true);
+          }
+          wave_sync();
+        } else
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (!((emask >> e) & 1)) continue;  // wave uniform: nothing on this edge
@@ -2077,7 +2104,22 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
           }
           wave_sync();
         }
-        // ---- horizontal edges: lanes 0..15 one luma column each, 16..31 chroma columns
+        // ---- horizontal edges: lanes 0..15 one luma column each, 16..31 chroma columns; edges 0 and 2 paired
+        // like the vertical ones when edges 1 and 3 are not filtered
+        const int hm = ((emask >> 4) & 0xf) & (top_edge ? 0xf : 0xe);
+        if (!(hm & 0xa) && (hm & 0x5)) {
+          const int e = (lane >> 5) * 2;
+          const int bs = (hbs >> (8 * e)) & 0xff;
+          const int cls = e == 0 ? 1 : 2;
+          const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
+          const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
+          if (((hm >> e) & 1) && bs) {
+            const int p = (l32 - 16) >> 3, i = (l32 - 16) & 7;
+            uint8_t* q = l32 < 16 ? lt + (4 + e * 4) * LS + 4 + l32 : L.ct[p] + (2 + e * 2) * CS + 4 + i;
+            filter_edge(q, l32 < 16 ? LS : CS, bs, alpha, beta, tc0, l32 >= 16);
+          }
+          wave_sync();
+        } else
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (!((emask >> (4 + e)) & 1) || (e == 0 && !top_edge)) continue;
