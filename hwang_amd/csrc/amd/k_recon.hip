@@ -503,34 +503,48 @@ constexpr int kInterWaves = 4;
 // macroblock's (integer) displacement already applied: luma rows y0-2 .. y0+18,
 // 24 bytes from column x0-2 (21 used), chroma 9 rows of 12 bytes (9 used).
 constexpr int kWinLumaRows = 21, kWinLumaDw = 6, kWinChromaRows = 9, kWinChromaDw = 3;
-constexpr int kWinDwords = kWinLumaRows * kWinLumaDw + 2 * kWinChromaRows * kWinChromaDw;  // 180
+constexpr int kWinLumaWords = kWinLumaRows * kWinLumaDw;                                   // 126
+constexpr int kWinDwords = kWinLumaWords + 2 * kWinChromaRows * kWinChromaDw;              // 180
 struct InterWave {
   int work[384];
   int dcs[24];
   int16_t res_y[256];
   int16_t res_c[128];
   int16_t lv[kLevels];
-  uint32_t win[2][kWinDwords];
+  alignas(8) uint32_t win[2][kWinDwords];
 };
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2 gld64u(const uint8_t* p) { return *(const HW_AS1 u32x2*)p; }  // any byte alignment
+#define HW_FN __device__ __forceinline__
+#define HW_ALIGNBYTE(hi, lo, n) __builtin_amdgcn_alignbyte(hi, lo, n)
+#define HW_PERM(hi, lo, sel) __builtin_amdgcn_perm(hi, lo, sel)
+#define HW_SDOT4(a, b, acc) __builtin_amdgcn_sdot4(a, b, acc, false)
+#define HW_UDOT4(a, b, acc) __builtin_amdgcn_udot4(a, b, acc, false)
+#include "inter_filters.h"
 
 }  // namespace
 
 // ===========================================================================
 // k_inter: one WAVE per inter macroblock, four macroblocks (64 luma bytes per
-// row) per workgroup, no workgroup barriers.  Per macroblock:
+// row) per workgroup, no workgroup barriers.  Everything that is the same for
+// the 64 lanes - the macroblock's index and records, the decision below, the
+// fractions of its vector, the surface pointers - lives in SGPRs (the wave index
+// is made provably uniform), so the vector pipe only sees per-sample work.
 //   residual (dequant + IDCT) into LDS unless nothing was coded;
 //   prediction.  A macroblock whose sixteen blocks share one vector and one
 //   reference per list (P_Skip, 16x16, B direct with uniform motion: ~ 88 % of
 //   the inter macroblocks of the bench corpus) takes the WINDOW path: the wave
 //   fetches the (16 + 5)^2 luma and two (8 + 1)^2 chroma neighbourhoods of each
-//   list ONCE, cooperatively - 180 unaligned dword loads per list, all issued
-//   before anything waits: one memory round trip - into LDS, shifted so that
-//   every lane's bytes start dword-aligned, and the 6-tap / bilinear filters
-//   read LDS.  (Before: every lane fetched its own 6 x 12 bytes, 18 loads per
-//   lane and list, 1152 per wave: 6.4 x the load instructions and a second
-//   round trip for chroma.)  Other macroblocks (partitions with different
-//   vectors, windows that leave the picture) take the per-lane register path;
-//   weighted combination, + residual, one dword / one halfword store.
+//   list ONCE, cooperatively - 63 eight-byte + 54 four-byte unaligned loads,
+//   scalar base + 32-bit lane offset, all issued before anything waits: one
+//   memory round trip - into LDS, shifted so that every lane's bytes start
+//   dword-aligned.  The filters read LDS and work on packed data: horizontal
+//   six-tap sums by the 8-bit dot product, vertical ones on 16-bit pairs,
+//   quarter-sample averages and the default bi-prediction on four bytes at once
+//   (luma_win4 / chroma_win2 above).  Other macroblocks (partitions with
+//   different vectors, windows that leave the picture) take the per-lane
+//   register path.  Weighted combination, + residual, one dword / one halfword store.
 // Workgroups are numbered so that each XCD (blockIdx % 8) owns a contiguous
 // band of the picture: its L2 then sees whole cache lines of the output and
 // the overlapping reference windows of neighbouring macroblocks.
@@ -538,36 +552,42 @@ struct InterWave {
 __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __restrict__ jobs) {
   const JobDesc& job = jobs[blockIdx.y];
   const PictureParams& pp = job.pp;
-  if (!job.do_inter) return;
-  const int nmb = pp.mb_width * pp.mb_height;
+  // everything the wave needs from the descriptor, requested in one go
+  const int do_inter = job.do_inter;
+  const int mb_width = pp.mb_width, mb_height = pp.mb_height, y_pitch = pp.y_pitch, c_pitch = pp.c_pitch;
+  const MbInfo* const mbs = job.mbs;
+  const MbMotion* const motions = job.motions;
+  const SliceParams* const slices = job.slices;
+  const Surface cur = pp.surfaces[pp.cur_slot];
+  if (!do_inter) return;
+  const int nmb = mb_width * mb_height;
   const int ngroups = (nmb + kInterWaves - 1) / kInterWaves;
   const int band = (ngroups + 7) / 8;
   const int group = (blockIdx.x % 8) * band + blockIdx.x / 8;
   if (blockIdx.x / 8 >= band || group >= ngroups) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int mbi = group * kInterWaves + wave;
   if (mbi >= nmb) return;
-  const MbMotion* __restrict__ mo = job.motions + mbi;
-  // the lane's motion data: luma block (row y, 4x4 column lane&3), chroma block
+  const MbMotion* __restrict__ mo = motions + mbi;
+  // the lane's motion data: luma block (row y, 4x4 column lane&3)
   const int y = lane >> 2, bcol = lane & 3;
   const int blk = (y >> 2) * 4 + bcol, b8 = (y >> 3) * 2 + (bcol >> 1);
   const int cplane = lane >> 5, ct = lane & 31, cy = ct >> 2, cbcol = ct & 3;
-  const int cblk = (cy >> 1) * 4 + cbcol, cb8 = (cy >> 2) * 2 + (cbcol >> 1);
   const uint32_t mvw0 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[0]) + blk);
   const uint32_t mvw1 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[1]) + blk);
-  const uint32_t cmvw0 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[0]) + cblk);
-  const uint32_t cmvw1 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[1]) + cblk);
   const uint32_t slots0 = gld32(mo->ref_slot[0]);
   const uint32_t slots1 = gld32(mo->ref_slot[1]);
   const uint32_t idx0 = gld32(mo->ref_idx[0]);
   const uint32_t idx1 = gld32(mo->ref_idx[1]);
-  const MbInfo mb = gload(&job.mbs[mbi]);
+  const MbInfo mb = gload(&mbs[mbi]);
   if (mb.kind != MBK_INTER) return;
+  const SliceParams& sp = slices[mb.slice];
+  const int weight_mode = gld8(&sp.weight_mode);
   __shared__ InterWave lds[kInterWaves];
   InterWave& L = lds[wave];
-  const int mbx = mbi % pp.mb_width, mby = mbi / pp.mb_width;
+  const int mbx = mbi % mb_width, mby = mbi / mb_width;
   const bool has_res = mb.coded_mask != 0;
-  const int W = pp.mb_width * 16, H = pp.mb_height * 16;
+  const int W = mb_width * 16, H = mb_height * 16;
   auto byte_of = [](uint32_t w, int k) { return (int)(int8_t)((w >> (8 * k)) & 0xff); };
 
   // ---- window path: is the macroblock's motion uniform per list, and do its windows lie inside the picture?
@@ -593,83 +613,102 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     else use_win[l] = false;
     if (use_win[l]) {
       const Surface& sf = pp.surfaces[byte_of(slots, 0)];
-      wsrc[l][0] = sf.y + (size_t)y0 * pp.y_pitch + x0;
-      wsrc[l][1] = sf.u + (size_t)cy0 * pp.c_pitch + cx0;
-      wsrc[l][2] = sf.v + (size_t)cy0 * pp.c_pitch + cx0;
+      wsrc[l][0] = sf.y + (size_t)y0 * y_pitch + x0;
+      wsrc[l][1] = sf.u + (size_t)cy0 * c_pitch + cx0;
+      wsrc[l][2] = sf.v + (size_t)cy0 * c_pitch + cx0;
     }
   }
   window = window && (use_win[0] || use_win[1]);
-  // issue every reference load of the macroblock now; they land while the residual is computed
-  uint32_t wreg[2][3];
+  uint8_t* const out_y = cur.y + (size_t)(mby * 16) * y_pitch + mbx * 16;
+  uint8_t* const out_c = (cplane ? cur.v : cur.u) + (size_t)(mby * 8) * c_pitch + mbx * 8;
+  const uint32_t out_yoff = (uint32_t)(y * y_pitch + bcol * 4), out_coff = (uint32_t)(cy * c_pitch + cbcol * 2);
+
   if (window) {
+    // issue every reference load of the macroblock now; they land while the residual is computed
+    const int lr = (lane * 43) >> 7, lc = lane - 3 * lr;                       // luma: row 0..20, eight-byte column 0..2 (lane < 63)
+    const int cpl = lane >= 27, cq = lane - 27 * cpl, cr = (cq * 43) >> 7, cd = cq - 3 * cr;  // chroma: plane, row, dword (lane < 54)
+    const uint32_t loff = (uint32_t)(lr * y_pitch + 8 * lc), coff = (uint32_t)(cr * c_pitch + 4 * cd);
+    u32x2 wy[2] = {0, 0};
+    uint32_t wc[2] = {0, 0};
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       if (!use_win[l]) continue;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int t = lane + 64 * k;
-        uint32_t v = 0;
-        if (t < kWinLumaRows * kWinLumaDw) {
-          const int r = t / kWinLumaDw, d = t - r * kWinLumaDw;
-          v = ld32u(wsrc[l][0] + (size_t)r * pp.y_pitch + 4 * d);
-        } else if (t < kWinDwords) {
-          const int u = t - kWinLumaRows * kWinLumaDw, pl = u >= kWinChromaRows * kWinChromaDw;
-          const int q = u - pl * kWinChromaRows * kWinChromaDw, r = q / kWinChromaDw, d = q - r * kWinChromaDw;
-          v = ld32u(wsrc[l][1 + pl] + (size_t)r * pp.c_pitch + 4 * d);
-        }
-        wreg[l][k] = v;
-      }
+      if (lane < 63) wy[l] = gld64u(wsrc[l][0] + loff);
+      if (lane < 54) wc[l] = ld32u((cpl ? wsrc[l][2] : wsrc[l][1]) + coff);
     }
-  }
-  if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c, L.lv);  // ends with wave_sync
-  if (window) {
+    if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c, L.lv);  // ends with wave_sync
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       if (!use_win[l]) continue;
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-        if (lane + 64 * k < kWinDwords) L.win[l][lane + 64 * k] = wreg[l][k];
+      if (lane < 63) *reinterpret_cast<u32x2*>(&L.win[l][lr * kWinLumaDw + 2 * lc]) = wy[l];
+      if (lane < 54) L.win[l][kWinLumaWords + lane] = wc[l];
     }
     wave_sync();
+
+    const bool bi = use_win[0] && use_win[1];
+    const int r0 = byte_of(idx0, 0), r1 = byte_of(idx1, 0);
+    {  // luma
+      uint32_t p[2] = {0, 0};
+#pragma unroll
+      for (int l = 0; l < 2; ++l)
+        if (use_win[l]) p[l] = luma_win4(L.win[l] + y * kWinLumaDw + bcol, wmvx[l] & 3, wmvy[l] & 3);
+      uint32_t pred;
+      if (weight_mode == 0) {
+        pred = bi ? avg4(p[0], p[1]) : (use_win[0] ? p[0] : p[1]);
+      } else {
+        int v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          v[i] = combine_pred(sp, 0, use_win[0], use_win[1], (p[0] >> (8 * i)) & 0xff, (p[1] >> (8 * i)) & 0xff, r0, r1);
+        pred = pack4(v[0], v[1], v[2], v[3]);
+      }
+      if (has_res) {
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(L.res_y + y * 16 + bcol * 4);
+        pred = add_res4(pred, rp[0], rp[1]);
+      }
+      gst32(out_y + out_yoff, pred);
+    }
+    {  // chroma: lanes 0..31 Cb, 32..63 Cr
+      uint32_t p[2] = {0, 0};
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        if (!use_win[l]) continue;
+        const int fx = wmvx[l] & 7, fy = wmvy[l] & 7;
+        const uint32_t wts = (uint32_t)((8 - fx) * (8 - fy)) | ((uint32_t)(fx * (8 - fy)) << 8) | ((uint32_t)((8 - fx) * fy) << 16) |
+                             ((uint32_t)(fx * fy) << 24);
+        p[l] = chroma_win2(L.win[l] + kWinLumaWords + cplane * kWinChromaRows * kWinChromaDw + cy * kWinChromaDw + (cbcol >> 1),
+                           cbcol & 1, wts);
+      }
+      uint32_t pred;
+      if (weight_mode == 0) {
+        pred = bi ? avg4(p[0], p[1]) : (use_win[0] ? p[0] : p[1]);
+      } else {
+        int v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          v[i] = combine_pred(sp, 1 + cplane, use_win[0], use_win[1], (p[0] >> (8 * i)) & 0xff, (p[1] >> (8 * i)) & 0xff, r0, r1);
+        pred = (uint32_t)v[0] | ((uint32_t)v[1] << 8);
+      }
+      if (has_res) pred = add_res2(pred, *reinterpret_cast<const uint32_t*>(L.res_c + cplane * 64 + cy * 8 + cbcol * 2));
+      gst16(out_c + out_coff, (uint16_t)pred);
+    }
+    return;
   }
 
-  const SliceParams& sp = job.slices[mb.slice];
-  const Surface cur = pp.surfaces[pp.cur_slot];
-  // the common P macroblock: default weights, list 0 only -> the prediction is the interpolated sample itself
-  const bool plain = idx1 == 0xffffffffu && gld8(&sp.weight_mode) == 0 && !((idx0 & 0x80808080u));
+  // ---- per-lane register path: partitions with their own vectors, windows that leave the picture
+  const int cblk = (cy >> 1) * 4 + cbcol, cb8 = (cy >> 2) * 2 + (cbcol >> 1);
+  const uint32_t cmvw0 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[0]) + cblk);
+  const uint32_t cmvw1 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[1]) + cblk);
+  if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c, L.lv);  // ends with wave_sync
+  const bool plain = idx1 == 0xffffffffu && weight_mode == 0 && !((idx0 & 0x80808080u));
   {  // luma
     const int r0 = byte_of(idx0, b8), r1 = byte_of(idx1, b8);
     const int px = mbx * 16 + bcol * 4, py = mby * 16 + y;
     int s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-    if (window) {
-#pragma unroll
-      for (int l = 0; l < 2; ++l) {
-        if (!use_win[l]) continue;
-        const int fx = wmvx[l] & 3, fy = wmvy[l] & 3;
-        // rows y .. y+5 of the window are sample rows y-2 .. y+3; bytes from column 4*bcol (= x - 2)
-        uint32_t w[6][3];
-        const uint32_t* base = L.win[l] + y * kWinLumaDw + bcol;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          if ((fy == 0) && r != 2) continue;
-          const uint32_t d0 = base[r * kWinLumaDw], d1 = base[r * kWinLumaDw + 1], d2 = base[r * kWinLumaDw + 2];
-          if (fx != 0) {
-            w[r][0] = d0;
-            w[r][1] = d1;
-            w[r][2] = d2;
-          } else {  // no horizontal fraction: the filter expects column x at byte 0
-            w[r][0] = __builtin_amdgcn_alignbyte(d1, d0, 2);
-            w[r][1] = w[r][2] = 0;
-          }
-        }
-        luma_filter4(w, fx, fy, l ? s1 : s0);
-      }
-    } else {
-      if (r0 >= 0)
-        luma_pred4(pp.surfaces[byte_of(slots0, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
-      if (r1 >= 0)
-        luma_pred4(pp.surfaces[byte_of(slots1, b8)].y, pp.y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
-    }
+    if (r0 >= 0)
+      luma_pred4(pp.surfaces[byte_of(slots0, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
+    if (r1 >= 0)
+      luma_pred4(pp.surfaces[byte_of(slots1, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -677,32 +716,19 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
       const int v = has_res ? clip8(pred + L.res_y[y * 16 + bcol * 4 + i]) : pred;
       packed |= (uint32_t)v << (8 * i);
     }
-    gst32(cur.y + (size_t)py * pp.y_pitch + px, packed);
+    gst32(out_y + out_yoff, packed);
   }
   {  // chroma: lanes 0..31 Cb, 32..63 Cr
     const int r0 = byte_of(idx0, cb8), r1 = byte_of(idx1, cb8);
     const int px = mbx * 8 + cbcol * 2, py = mby * 8 + cy;
     int s0[2] = {0, 0}, s1[2] = {0, 0};
-    if (window) {
-#pragma unroll
-      for (int l = 0; l < 2; ++l) {
-        if (!use_win[l]) continue;
-        // row cy of the chroma window, bytes from column 2*cbcol: dword cbcol >> 1, shifted by two bytes for odd cbcol
-        const uint32_t* rowp = L.win[l] + kWinLumaRows * kWinLumaDw + cplane * kWinChromaRows * kWinChromaDw + cy * kWinChromaDw + (cbcol >> 1);
-        const uint32_t a0 = rowp[0], a1 = rowp[1], c0 = rowp[kWinChromaDw], c1 = rowp[kWinChromaDw + 1];
-        const uint32_t a = (cbcol & 1) ? __builtin_amdgcn_alignbyte(a1, a0, 2) : a0;
-        const uint32_t c = (cbcol & 1) ? __builtin_amdgcn_alignbyte(c1, c0, 2) : c0;
-        chroma_filter2(a, c, wmvx[l] & 7, wmvy[l] & 7, l ? s1 : s0);
-      }
-    } else {
-      if (r0 >= 0) {
-        const Surface& sf = pp.surfaces[byte_of(slots0, cb8)];
-        chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
-      }
-      if (r1 >= 0) {
-        const Surface& sf = pp.surfaces[byte_of(slots1, cb8)];
-        chroma_pred2(cplane ? sf.v : sf.u, pp.c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
-      }
+    if (r0 >= 0) {
+      const Surface& sf = pp.surfaces[byte_of(slots0, cb8)];
+      chroma_pred2(cplane ? sf.v : sf.u, c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
+    }
+    if (r1 >= 0) {
+      const Surface& sf = pp.surfaces[byte_of(slots1, cb8)];
+      chroma_pred2(cplane ? sf.v : sf.u, c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
     }
     uint32_t packed = 0;
 #pragma unroll
@@ -711,8 +737,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
       const int v = has_res ? clip8(pred + L.res_c[cplane * 64 + cy * 8 + cbcol * 2 + i]) : pred;
       packed |= (uint32_t)v << (8 * i);
     }
-    uint8_t* dst = cplane ? cur.v : cur.u;
-    gst16(dst + (size_t)py * pp.c_pitch + px, (uint16_t)packed);
+    gst16(out_c + out_coff, (uint16_t)packed);
   }
 }
 
@@ -1260,7 +1285,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __
   const PictureParams& pp = job.pp;
   if (!job.do_intra) return;
   const int nmb = pp.mb_width * pp.mb_height;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // provably uniform: SGPRs, scalar loads
   const int mbi = blockIdx.x * kInterWaves + wave;
   if (mbi >= nmb) return;
   const MbInfo mb = gload(&job.mbs[mbi]);
@@ -1313,7 +1338,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
   const PictureParams& pp = job.pp;
   const MbInfo* __restrict__ mbs = job.mbs;
   const uint32_t* __restrict__ coefs = job.coefs;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // provably uniform: SGPRs, scalar loads
   const int mby = band * kBandWaves + wave;
   if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
   lds_counter* progress = (lds_counter*)s_progress;
