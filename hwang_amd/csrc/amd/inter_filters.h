@@ -60,22 +60,22 @@ HW_FN uint32_t hhalf4(uint32_t a, uint32_t b, uint32_t c) {
   htap4(a, b, c, 16, t);
   return clip_pack4(t[0] >> 5, t[1] >> 5, t[2] >> 5, t[3] >> 5);
 }
-// vertical half samples h (8-242) of four columns: g[r] holds the four samples of row y-2+r
-HW_FN uint32_t vhalf4(const uint32_t* g) {
-  pk16 e[6], o[6];
-#pragma unroll
-  for (int r = 0; r < 6; ++r) {
-    e[r] = as_pk(g[r] & 0x00ff00ffu);
-    o[r] = as_pk((g[r] >> 8) & 0x00ff00ffu);
-  }
-  const pk16 te = (e[0] + e[5]) + (e[2] + e[3]) * (short)20 - (e[1] + e[4]) * (short)5 + (short)16;
-  const pk16 to = (o[0] + o[5]) + (o[2] + o[3]) * (short)20 - (o[1] + o[4]) * (short)5 + (short)16;
-  return as_u32(clamp255(te >> 5)) | (as_u32(clamp255(to >> 5)) << 8);
+// Vertical six-tap sums of four columns, accumulated row by row on 16-bit pairs (samples 0,2 in `e`, 1,3 in `o`), so
+// that only the running sums stay live.  g = the four samples of one row, wt = that row's tap (1, -5, 20, 20, -5, 1).
+struct VAcc {
+  pk16 e, o;
+};
+HW_FN void vacc_add(VAcc& a, uint32_t g, int wt) {
+  a.e += as_pk(g & 0x00ff00ffu) * (short)wt;
+  a.o += as_pk((g >> 8) & 0x00ff00ffu) * (short)wt;
 }
+// vertical half samples h (8-242): (sum + 16) >> 5, clipped, packed; the accumulator starts at 16
+HW_FN uint32_t vacc_half(const VAcc& a) { return as_u32(clamp255(a.e >> 5)) | (as_u32(clamp255(a.o >> 5)) << 8); }
+HW_FN int tap_of_row(int r) { return (r == 0 || r == 5) ? 1 : ((r == 1 || r == 4) ? -5 : 20); }
 
 // 8.4.2.2.1 for the lane's four luma samples from the window: row r of the lane
 // (sample row y-2+r) is base[r * kWinLumaDw + 0..2], byte 0 = column x-2.  fx, fy
-// are wave uniform: the branches are scalar.
+// are wave uniform: the branches are scalar.  Rows are consumed one at a time.
 HW_FN uint32_t luma_win4(const uint32_t* base, int fx, int fy) {
   if (fy == 0) {
     const uint32_t a = base[2 * kWinLumaDw], b = base[2 * kWinLumaDw + 1], c = base[2 * kWinLumaDw + 2];
@@ -84,44 +84,48 @@ HW_FN uint32_t luma_win4(const uint32_t* base, int fx, int fy) {
     const uint32_t h = hhalf4(a, b, c);
     return fx == 2 ? h : avg4(h, fx == 1 ? g : bytes_at(a, b, 3));
   }
-  if (fx == 0) {
-    uint32_t g[6];
+  const int col = fx == 3 ? 3 : 2;  // column of the vertical half sample
+  if (fx != 2) {                    // d, h, n (fx 0) / e, g, p, r (fx odd, fy odd) / i, k (fx odd, fy 2): a vertical half sample is needed
+    VAcc acc = {(pk16)(16), (pk16)(16)};
+    uint32_t gsel = 0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) g[r] = bytes_at(base[r * kWinLumaDw], base[r * kWinLumaDw + 1], 2);
-    const uint32_t v = vhalf4(g);
-    return fy == 2 ? v : avg4(v, fy == 1 ? g[2] : g[3]);
-  }
-  const int col = fx == 3 ? 3 : 2;  // column of the vertical half sample that is averaged in
-  if (fx != 2 && fy != 2) {         // e, g, p, r: nearest horizontal and vertical half samples
-    const uint32_t* row = base + (fy == 3 ? 3 : 2) * kWinLumaDw;
-    const uint32_t hb = hhalf4(row[0], row[1], row[2]);
-    uint32_t g[6];
+    for (int r = 0; r < 6; ++r) {
+      const uint32_t g = bytes_at(base[r * kWinLumaDw], base[r * kWinLumaDw + 1], col);
+      vacc_add(acc, g, tap_of_row(r));
+      if (r == 2 || r == 3) gsel = (r == 2) == (fy != 3) ? g : gsel;
+    }
+    const uint32_t v = vacc_half(acc);
+    if (fx == 0) return fy == 2 ? v : avg4(v, gsel);
+    if (fy != 2) {                  // e, g, p, r: nearest horizontal and vertical half samples
+      const uint32_t* row = base + (fy == 3 ? 3 : 2) * kWinLumaDw;
+      return avg4(hhalf4(row[0], row[1], row[2]), v);
+    }
+    // i, k: centre sample j averaged with h: fall through to j below, keeping v
+    int j1[4] = {512, 512, 512, 512};
 #pragma unroll
-    for (int r = 0; r < 6; ++r) g[r] = bytes_at(base[r * kWinLumaDw], base[r * kWinLumaDw + 1], col);
-    return avg4(hb, vhalf4(g));
+    for (int r = 0; r < 6; ++r) {
+      int t[4];
+      htap4(base[r * kWinLumaDw], base[r * kWinLumaDw + 1], base[r * kWinLumaDw + 2], 0, t);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) j1[i] += tap_of_row(r) * t[i];
+    }
+    return avg4(clip_pack4(j1[0] >> 10, j1[1] >> 10, j1[2] >> 10, j1[3] >> 10), v);
   }
-  // the centre sample j from the six rows' horizontal sums; alone, or averaged with b (fx == 2) or h (fy == 2)
-  int t[6][4];
-  uint32_t g[6];
+  // fx == 2: the centre sample j from the six rows' horizontal sums; alone (fy 2) or averaged with b (f, q)
+  int j1[4] = {512, 512, 512, 512}, bb[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int r = 0; r < 6; ++r) {
-    const uint32_t a = base[r * kWinLumaDw], b = base[r * kWinLumaDw + 1], c = base[r * kWinLumaDw + 2];
-    htap4(a, b, c, 0, t[r]);
-    g[r] = bytes_at(a, b, col);
-  }
-  int j[4];
+    int t[4];
+    htap4(base[r * kWinLumaDw], base[r * kWinLumaDw + 1], base[r * kWinLumaDw + 2], 0, t);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    j[i] = ((t[0][i] + t[5][i]) + 20 * (t[2][i] + t[3][i]) - 5 * (t[1][i] + t[4][i]) + 512) >> 10;
-  const uint32_t jp = clip_pack4(j[0], j[1], j[2], j[3]);
-  if (fx == 2 && fy == 2) return jp;
-  if (fx == 2) {
-    int bb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) bb[i] = ((fy == 3 ? t[3][i] : t[2][i]) + 16) >> 5;
-    return avg4(jp, clip_pack4(bb[0], bb[1], bb[2], bb[3]));
+    for (int i = 0; i < 4; ++i) {
+      j1[i] += tap_of_row(r) * t[i];
+      if (r == 2 || r == 3) bb[i] = (r == 2) == (fy != 3) ? t[i] : bb[i];
+    }
   }
-  return avg4(jp, vhalf4(g));
+  const uint32_t jp = clip_pack4(j1[0] >> 10, j1[1] >> 10, j1[2] >> 10, j1[3] >> 10);
+  if (fy == 2) return jp;
+  return avg4(jp, clip_pack4((bb[0] + 16) >> 5, (bb[1] + 16) >> 5, (bb[2] + 16) >> 5, (bb[3] + 16) >> 5));
 }
 
 // 8.4.2.2.2 for the lane's two chroma samples: rowp points at the dword of window row cy that holds column
