@@ -2080,10 +2080,10 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
             src = (p ? gv : gu) + (cr - 2) * cp + cc * 4;
           }
           if (importing) {
-            import_wait(min(mbx + 2, W));
+            import_wait(min(mbx + 1, W));
             if (lane < 24) top_word = agent_ld32(src);
           } else {
-            row_wait(progress, wave, min(mbx + 2, W));
+            row_wait(progress, wave, min(mbx + 1, W));
             if (lane < 24) top_word = gld32(src);
           }
         }
@@ -2119,6 +2119,25 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
             filter_edge(q, 1, bs, alpha, beta, tc0, lane >= 16);
           }
           wave_sync();
+        }
+        // ---- the left neighbour's last four columns are final now (only this macroblock's left edge touches them
+        // from this row): store them at once, so that by the time this macroblock's progress is published - after
+        // its horizontal edges, below - the left neighbour is final IN MEMORY and the row below may filter under it.
+        // (They used to go out with the whole tile at the end of the iteration and count one macroblock later: a
+        // row ran three macroblocks behind the row above instead of two.)
+        if ((emask & 1) && mbx > 0 && lane < 32) {
+          if (lane < 16) {
+            const int r = 4 + lane;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.lt[r * LS]);
+            if (exporting && r >= 16) agent_st32(gy + (r - 4) * yp - 4, v);
+            else gst32(gy + (r - 4) * yp - 4, v);
+          } else {
+            const int p = (lane - 16) >> 3, r = 2 + ((lane - 16) & 7);
+            uint8_t* g = p ? gv : gu;
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS]);
+            if (exporting && r >= 8) agent_st32(g + (r - 2) * cp - 4, v);
+            else gst32(g + (r - 2) * cp - 4, v);
+          }
         }
         // ---- the rows above arrive now (their latency hid behind the vertical edges)
         if (top_edge) {
@@ -2169,13 +2188,13 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
         // compiler from waiting for them at the top of the next iteration, where
         // its in-order counter would also cover the stores issued just below.
         asm volatile("" : "+v"(n_luma), "+v"(n_chroma), "+v"(n_db), "+v"(n_left));
-        // ---- store what the filters may have touched: rows 0..15 x cols -4..15
+        // ---- store what else the filters may have touched: rows 0..15 x cols 0..15
         // and, with a top edge, rows -4..-1 x cols 0..15 (chroma: rows 0..7 x
-        // cols -4..7 and rows -2..-1 x cols 0..7).  The corner above-left belongs
+        // cols 0..7 and rows -2..-1 x cols 0..7).  The corner above-left belongs
         // to other macroblocks' edges and is never written from here.
         for (int t = lane; t < 100; t += 64) {
           const int r = t / 5, c4 = t % 5;
-          if (r >= 4 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1)) {
+          if (c4 >= 1 && (r >= 4 || top_edge)) {
             const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]);
             if (exporting && r >= 16) agent_st32(gy + (r - 4) * yp + (c4 - 1) * 4, v);  // the band below reads these rows
             else gst32(gy + (r - 4) * yp + (c4 - 1) * 4, v);
@@ -2184,7 +2203,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
         if (lane < 60) {
           const int p = lane / 30, t = lane % 30, r = t / 3, c4 = t % 3;
           uint8_t* g = p ? gv : gu;
-          if (r >= 2 ? (c4 >= 1 || mbx > 0) : (top_edge && c4 >= 1)) {
+          if (c4 >= 1 && (r >= 2 || top_edge)) {
             const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]);
             if (exporting && r >= 8) agent_st32(g + (r - 2) * cp + (c4 - 1) * 4, v);
             else gst32(g + (r - 2) * cp + (c4 - 1) * 4, v);

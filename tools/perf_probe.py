@@ -102,8 +102,6 @@ if os.environ.get("SERIAL"):
 # per-kernel timings with one lane (events serialise nothing else)
 lib.hwang_prof_enable(1)
 lib.hwang_prof_reset()
-if hasattr(lib, "hwang_exp_prof"):
-    lib.hwang_exp_prof((C.c_ulonglong * 16)(), 1)
 dec = hw.Decoder(path, video_index=idx, num_lanes=int(os.environ.get("PROF_LANES", "8")))
 dec.retrieve_into(rows, out.data_ptr(), out.numel())
 lib.hwang_prof_enable(0)
@@ -112,9 +110,4 @@ for k in range(lib.hwang_prof_num_kernels()):
     lib.hwang_prof_read(k, o)
     if o[0]:
         print("%-16s launches %6d  avg %8.1f us  alg %.2f GB/s" % (lib.hwang_prof_kernel_name(k).decode(), o[0], o[1] / o[0], o[2] / (o[1] * 1e-6) / 1e9))
-if hasattr(lib, "hwang_exp_prof"):  # experiment builds only (tools/experiments/build_variant.sh ... -DEXP_PROF): stage timers of k_inter
-    o = (C.c_ulonglong * 16)()
-    lib.hwang_exp_prof(o, 0)
-    n = max(1, o[15])
-    print("k_inter stage cycles per wave (%d waves): %s  total %.0f" % (o[15], " ".join("%.0f" % (o[i] / n) for i in range(7)), sum(o[i] for i in range(7)) / n))
 del dec  # before interpreter exit: module globals outlive the library's atexit shutdown
