@@ -58,8 +58,6 @@ __constant__ uint8_t c_tc0[52][3] = {
     {2, 3, 4},   {2, 3, 4},   {3, 3, 5},   {3, 4, 6},   {3, 4, 6},   {4, 5, 7},   {4, 5, 8},
     {4, 6, 9},   {5, 7, 10},  {6, 8, 11},  {6, 8, 13},  {7, 10, 14}, {8, 11, 16}, {9, 12, 18},
     {10, 13, 20}, {11, 15, 23}, {13, 17, 25}};
-// luma4x4BlkIdx (decode order) <-> raster position
-__constant__ uint8_t c_raster_to_zz[16] = {0, 1, 4, 5, 2, 3, 6, 7, 8, 9, 12, 13, 10, 11, 14, 15};
 
 __device__ __forceinline__ int iclip(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
@@ -846,9 +844,9 @@ __constant__ uint32_t c_p8tab[9][64] = {
 // a block needs its left, top-left, top and top-right neighbours, so the
 // blocks (x, y) with equal x + 2y are independent - 10 steps instead of 16,
 // two blocks (32 lanes) in the six middle ones.
-__constant__ int8_t c_i4_step_a[10] = {0, 1, 2, 3, 6, 7, 10, 11, 14, 15};
-__constant__ int8_t c_i4_step_b[10] = {-1, -1, 4, 5, 8, 9, 12, 13, -1, -1};
 
+// luma4x4BlkIdx of a raster 4x4 block ({0,1,4,5,2,3,6,7,8,9,12,13,10,11,14,15} as nibbles)
+__device__ __forceinline__ int zz_of_raster(int r) { return (int)((0xFEBADC9876325410ull >> (4 * r)) & 15); }
 __device__ __forceinline__ int tap_sample(const uint8_t* e, unsigned ent, int shift, int mask) {
   const int a = e[ent & mask], b = e[(ent >> shift) & mask], c = e[(ent >> (2 * shift)) & mask];
   const int taps = ent >> (3 * shift);
@@ -1329,8 +1327,15 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
   __shared__ int s_progress[kBandWaves + 1];
   __shared__ IntraWaveLds s_lds[kBandWaves];
   __shared__ uint8_t s_line[kBandWaves + 1][kLineMbs][32];  // [kBandWaves]: the line imported from the band above
+  // The Intra4x4 / Intra8x8 tap tables, in LDS: every one of a macroblock's (up to sixteen) dependent prediction
+  // steps looks its samples' taps up by (mode, position) per lane - from constant memory that was a vector-memory
+  // round trip inside each step of the chain.
+  __shared__ uint16_t s_p4tab[9][16];
+  __shared__ uint32_t s_p8tab[9][64];
   if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_in, 1u);
   if (threadIdx.x <= kBandWaves) s_progress[threadIdx.x] = 0;
+  for (int t = threadIdx.x; t < 9 * 64; t += kBandWaves * 64) s_p8tab[0][t] = c_p8tab[0][t];
+  if (threadIdx.x < 9 * 16) s_p4tab[0][threadIdx.x] = c_p4tab[0][threadIdx.x];
   __syncthreads();
   const int band = static_cast<int>(s_ticket) / njobs;
   const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
@@ -1539,9 +1544,16 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
             tile[(1 + (t >> 4)) * TS + 1 + (t & 15)] = (uint8_t)outv[it];
           }
         } else if (mb.kind == MBK_I4x4) {
+          // the blocks' sixteen prediction modes as one word: nibble r = raster block r (a register shift instead of
+          // indexing the record per lane, which went through scratch memory)
+          const uint64_t modes4 = (uint64_t)mb.i4_modes[0] | ((uint64_t)mb.i4_modes[1] << 8) | ((uint64_t)mb.i4_modes[2] << 16) |
+                                  ((uint64_t)mb.i4_modes[3] << 24) | ((uint64_t)mb.i4_modes[4] << 32) | ((uint64_t)mb.i4_modes[5] << 40) |
+                                  ((uint64_t)mb.i4_modes[6] << 48) | ((uint64_t)mb.i4_modes[7] << 56);
           for (int st = 0; st < 10; ++st) {
             const int half = lane >> 4;  // lanes 0..15 first block of the step, 16..31 second
-            const int raster = half == 0 ? c_i4_step_a[st] : half == 1 ? c_i4_step_b[st] : -1;
+            // step -> raster block: first {0,1,2,3,6,7,10,11,14,15}, second {-,-,4,5,8,9,12,13,-,-} (nibbles of constants)
+            const int raster = half == 0 ? (int)((0xFEBA763210ull >> (4 * st)) & 15)
+                                         : (half == 1 && st >= 2 && st <= 7) ? (int)((0x00DC985400ull >> (4 * st)) & 15) : -1;
             const int bx = raster & 3, by = raster >> 2;
             const bool hl = bx > 0 || hA, ht = by > 0 || hB;
             const uint8_t* t = tile + (1 + by * 4) * TS + 1 + bx * 4;
@@ -1551,7 +1563,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
               bool htr;
               if (by == 0) htr = bx < 3 ? hB : hC;
               else if (bx == 3) htr = false;
-              else htr = c_raster_to_zz[(by - 1) * 4 + bx + 1] < c_raster_to_zz[raster];
+              else htr = zz_of_raster((by - 1) * 4 + bx + 1) < zz_of_raster(raster);
               int v = 128;
               if (i < 4) { if (hl) v = t[(3 - i) * TS - 1]; }
               else if (i == 4) { if (htl) v = t[-TS - 1]; }
@@ -1561,14 +1573,14 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
             wave_sync();
             if (raster >= 0) {
               const int px = lane & 3, py = (lane >> 2) & 3;
-              const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
+              const int mode = (int)((modes4 >> (4 * raster)) & 15);
               const uint8_t* e = L.e4[half];
               int v;
               if (mode == 2) {
                 const int st4 = e[5] + e[6] + e[7] + e[8], sl4 = e[0] + e[1] + e[2] + e[3];
                 v = (ht && hl) ? (st4 + sl4 + 4) >> 3 : hl ? (sl4 + 2) >> 2 : ht ? (st4 + 2) >> 2 : 128;
               } else {
-                v = tap_sample(e, c_p4tab[mode > 8 ? 8 : mode][py * 4 + px], 4, 15);
+                v = tap_sample(e, s_p4tab[mode > 8 ? 8 : mode][py * 4 + px], 4, 15);
               }
               const int out = clip8(v + L.res_y[(by * 4 + py) * 16 + bx * 4 + px]);
               tile[(1 + by * 4 + py) * TS + 1 + bx * 4 + px] = (uint8_t)out;
@@ -1617,7 +1629,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
             {
               const int px = lane & 7, py = lane >> 3;
               const int raster = (by >> 2) * 4 + (bx >> 2);
-              const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;
+              const int mode = (mb.i4_modes[raster >> 1] >> ((raster & 1) * 4)) & 15;  // raster: one of four constants
               const uint8_t* e = L.e8;
               int v;
               if (mode == 2) {
@@ -1629,7 +1641,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
                 }
                 v = (ht && hl) ? (st8 + sl8 + 8) >> 4 : hl ? (sl8 + 4) >> 3 : ht ? (st8 + 4) >> 3 : 128;
               } else {
-                v = tap_sample(e, c_p8tab[mode > 8 ? 8 : mode][py * 8 + px], 5, 31);
+                v = tap_sample(e, s_p8tab[mode > 8 ? 8 : mode][py * 8 + px], 5, 31);
               }
               tile[(1 + by + py) * TS + 1 + bx + px] = (uint8_t)clip8(v + L.res_y[(by + py) * 16 + bx + px]);
             }
