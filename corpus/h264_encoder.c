@@ -32,6 +32,7 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int rate_kbit;    /* > 0: rate control - kbit per P picture (I: x4, B: x0.5), QP steered per macroblock row */
   int scaling;      /* bit 0: SPS scaling matrices, bit 1: PPS scaling matrices (fall-back rules A and B, default flag) */
   /* container variants (hwang/mp4_index_creator.cpp:516-733 and the stz2 / co64 branches of the moov parser) */
   int fragmented;   /* 1..3: mvex/trex + one moof+mdat per GOP, three different tfhd / trun flag combinations */
@@ -264,6 +265,8 @@ typedef struct {
   uint8_t* pps_nal;
   int pps_len;
   int frame_abs;   /* absolute display index of the picture being coded */
+  int rc_qp;       /* rate control: the QP the next macroblock row starts from (reset at every I picture, so that
+                      GOPs stay independent of each other and of the number of encoder threads) */
   int hint_n;
   int hints[10][2]; /* candidate motion per frame of distance, quarter samples */
 } Enc;
@@ -1420,6 +1423,12 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
   Marking mk;
   plan_marking(e, pp, &mk); /* from the DPB as it is before this picture; the same in every slice */
 
+  /* Rate control (--rate-kbit): a bit budget per picture by type, spent evenly over the macroblock rows; after
+   * every row the QP moves one step towards the budget (within +-8 of --qp), so mb_qp_delta runs in long
+   * monotonic stretches and neighbouring macroblocks (and deblocked edges) see different QPs all the time. */
+  if (pp->type == 2 || e->rc_qp == 0) e->rc_qp = c->qp;
+  const double rc_budget = c->rate_kbit * 1000.0 * (pp->type == 2 ? 4.0 : pp->type == 0 ? 1.0 : 0.5);
+  size_t rc_bits_before = 0;
   for (int s = 0; s < nslices; ++s) {
     const int row0 = s * mbh / nslices, row1 = (s + 1) * mbh / nslices;
     BitWriter* w = &e->w;
@@ -1440,7 +1449,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
       MbPlan plan;
       memset(&plan, 0, sizeof(plan));
       h264i_begin_mb(d, addr);
-      int qp = c->qp;
+      int qp = c->rate_kbit > 0 ? e->rc_qp : c->qp;
       uint32_t hq = hash3((uint32_t)c->seed + 3, (uint32_t)e->frame_abs, (uint32_t)addr);
       if (hq % 9 == 0) qp = iclip(10, 48, qp + (int)((hq >> 4) % 5) - 2);
       if (pp->type == 2) decide_intra(e, &plan, qp, 2);
@@ -1450,8 +1459,14 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
         fprintf(stderr, "encoder: %s\n", d->error);
         return -1;
       }
+      if (c->rate_kbit > 0 && (addr + 1) % mbw == 0) {
+        const double spent = (double)(rc_bits_before + w->pos), due = rc_budget * ((addr + 1) / mbw) / mbh;
+        if (spent > due * 1.05) e->rc_qp = imin(imin(e->rc_qp + 1, c->qp + 8), 48);
+        else if (spent < due * 0.95) e->rc_qp = imax(imax(e->rc_qp - 1, c->qp - 8), 10);
+      }
     }
     h264i_enc_end_slice(d, w);
+    rc_bits_before += w->pos;
     const size_t rb = w->pos / 8;
     if (ssize + rb * 3 / 2 + 16 > scap) {
       scap = (ssize + rb * 3 / 2 + 16) * 2;
@@ -1883,6 +1898,7 @@ int main(int argc, char** argv) {
   c.fragmented = arg_int(argc, argv, "--fragmented", 0);
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
+  c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
   if (c.wp_denom < 0 || c.wp_denom > 7) c.wp_denom = 5;
   if (c.explicit_wp) c.implicit_wp = 0;
   c.out = arg_str(argc, argv, "--out", "out.mp4");

@@ -61,4 +61,9 @@ MATRIX = [
     ("scaling_both_4x4only", dict(frames=7, gop=7, bframes=1, scaling=3, t8x8=0, cabac=0)),
     ("everything", dict(frames=26, gop=13, bframes=2, refs=4, scaling=3, explicit_wp=1, wp_denom=4, rplm=1, mmco=1,
                         slices=3, deblock=2, alpha=-1, beta=1, chroma_qp_offset=3)),
+    # rate control: the QP walks per macroblock row towards a bit budget (long monotonic runs of mb_qp_delta, every
+    # deblocked edge between different QPs), starved and generous
+    ("rate_cabac_low", dict(frames=13, gop=13, bframes=2, cabac=1, t8x8=1, refs=2, rate_kbit=12)),
+    ("rate_cavlc_high", dict(frames=10, gop=10, bframes=1, cabac=0, t8x8=1, refs=2, slices=3, rate_kbit=90,
+                             chroma_qp_offset=-3)),
 ]
