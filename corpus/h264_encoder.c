@@ -32,6 +32,9 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int poc_type;     /* pic_order_cnt_type 0 / 1 (one-frame cycle, per-slice delta) / 2 (needs bframes 0) */
+  int constrained_intra; /* PPS constrained_intra_pred_flag */
+  int direct8x8;    /* SPS direct_8x8_inference_flag (default 1) */
   int rate_kbit;    /* > 0: rate control - kbit per P picture (I: x4, B: x0.5), QP steered per macroblock row */
   int scaling;      /* bit 0: SPS scaling matrices, bit 1: PPS scaling matrices (fall-back rules A and B, default flag) */
   /* container variants (hwang/mp4_index_creator.cpp:516-733 and the stz2 / co64 branches of the moov parser) */
@@ -265,6 +268,7 @@ typedef struct {
   uint8_t* pps_nal;
   int pps_len;
   int frame_abs;   /* absolute display index of the picture being coded */
+  int poc1_prev_fn, poc1_fn_offset; /* pic_order_cnt_type 1: FrameNumOffset bookkeeping (8.2.1.2) */
   int rc_qp;       /* rate control: the QP the next macroblock row starts from (reset at every I picture, so that
                       GOPs stay independent of each other and of the number of encoder threads) */
   int hint_n;
@@ -369,14 +373,22 @@ static void write_sps(Enc* e) {
     }
   }
   bw_ue(&w, 4);      /* log2_max_frame_num_minus4 -> 8 bits */
-  bw_ue(&w, 0);      /* pic_order_cnt_type */
-  bw_ue(&w, 4);      /* log2_max_pic_order_cnt_lsb_minus4 -> 8 bits */
+  bw_ue(&w, c->poc_type); /* pic_order_cnt_type */
+  if (c->poc_type == 0) {
+    bw_ue(&w, 4);      /* log2_max_pic_order_cnt_lsb_minus4 -> 8 bits */
+  } else if (c->poc_type == 1) {
+    bw_put(&w, 0, 1);  /* delta_pic_order_always_zero_flag: every slice carries delta_pic_order_cnt[0] */
+    bw_se(&w, -1);     /* offset_for_non_ref_pic */
+    bw_se(&w, 0);      /* offset_for_top_to_bottom_field */
+    bw_ue(&w, 1);      /* num_ref_frames_in_pic_order_cnt_cycle */
+    bw_se(&w, 2 * (c->bframes + 1)); /* offset_for_ref_frame[0] */
+  }
   bw_ue(&w, c->refs);
   bw_put(&w, 0, 1);  /* gaps */
   bw_ue(&w, (c->width + 15) / 16 - 1);
   bw_ue(&w, (c->height + 15) / 16 - 1);
   bw_put(&w, 1, 1);  /* frame_mbs_only */
-  bw_put(&w, 1, 1);  /* direct_8x8_inference */
+  bw_put(&w, c->direct8x8 ? 1 : 0, 1);  /* direct_8x8_inference */
   const int cr = (((c->width + 15) & ~15) - c->width) / 2, cb = (((c->height + 15) & ~15) - c->height) / 2;
   if (cr || cb) {
     bw_put(&w, 1, 1);
@@ -429,7 +441,7 @@ static void write_pps(Enc* e) {
   bw_se(&w, 0);
   bw_se(&w, c->chroma_qp_offset);
   bw_put(&w, 1, 1); /* deblocking_filter_control_present */
-  bw_put(&w, 0, 1); /* constrained_intra_pred */
+  bw_put(&w, c->constrained_intra ? 1 : 0, 1); /* constrained_intra_pred */
   bw_put(&w, 0, 1); /* redundant_pic_cnt_present */
   if (c->t8x8 || (c->scaling & 2)) {
     bw_put(&w, c->t8x8 ? 1 : 0, 1);
@@ -1364,7 +1376,22 @@ static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int firs
   bw_ue(w, 0);
   bw_put(w, pp->frame_num & 255, 8);
   if (pp->type == 2) bw_ue(w, (e->frame_abs / c->gop) & 1); /* idr_pic_id */
-  bw_put(w, ((pp->display - pp->poc_base) * 2) & 255, 8);
+  if (c->poc_type == 0) {
+    bw_put(w, ((pp->display - pp->poc_base) * 2) & 255, 8);
+  } else if (c->poc_type == 1) {
+    /* 8.2.1.2 with a one-frame cycle: expected = absFrameNum * offset_for_ref_frame[0] (+ offset_for_non_ref_pic);
+     * delta_pic_order_cnt[0] makes up the difference to 2 * display */
+    if (first_mb == 0) {
+      if (pp->type == 2) e->poc1_fn_offset = 0;
+      else if (e->poc1_prev_fn > (pp->frame_num & 255)) e->poc1_fn_offset += 256;
+      e->poc1_prev_fn = pp->frame_num & 255;
+    }
+    int abs_fn = pp->type == 2 ? 0 : e->poc1_fn_offset + (pp->frame_num & 255);
+    if (!pp->is_ref && abs_fn > 0) --abs_fn;
+    int expected = abs_fn > 0 ? abs_fn * 2 * (c->bframes + 1) : 0;
+    if (!pp->is_ref) expected += -1;
+    bw_se(w, (pp->display - pp->poc_base) * 2 - expected);
+  }
   if (pp->type == 1) bw_put(w, c->temporal_direct ? 0 : 1, 1);
   if (pp->type != 2) {
     const int nl0 = pp->type == 1 ? 1 : nrefs_l0;
@@ -1899,6 +1926,13 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.poc_type = arg_int(argc, argv, "--poc-type", 0);
+  c.constrained_intra = arg_int(argc, argv, "--constrained-intra", 0);
+  c.direct8x8 = arg_int(argc, argv, "--direct8x8", 1);
+  if (c.poc_type < 0 || c.poc_type > 2 || (c.poc_type == 2 && c.bframes) || (c.poc_type && c.mmco == 2)) {
+    fprintf(stderr, "encoder: --poc-type 2 needs --bframes 0; types 1 and 2 do not combine with --mmco 2\n");
+    return 2;
+  }
   if (c.wp_denom < 0 || c.wp_denom > 7) c.wp_denom = 5;
   if (c.explicit_wp) c.implicit_wp = 0;
   c.out = arg_str(argc, argv, "--out", "out.mp4");

@@ -66,4 +66,12 @@ MATRIX = [
     ("rate_cabac_low", dict(frames=13, gop=13, bframes=2, cabac=1, t8x8=1, refs=2, rate_kbit=12)),
     ("rate_cavlc_high", dict(frames=10, gop=10, bframes=1, cabac=0, t8x8=1, refs=2, slices=3, rate_kbit=90,
                              chroma_qp_offset=-3)),
+    # picture order count types 1 (frame_num cycle + per-slice delta, with and without B pictures) and 2, intra
+    # prediction that may not lean on inter neighbours, direct prediction at 4x4 granularity (spatial and temporal)
+    ("poc1_b", dict(frames=20, gop=10, bframes=2, refs=3, poc_type=1, slices=2)),
+    ("poc1_p_cavlc", dict(frames=12, gop=6, bframes=0, refs=2, poc_type=1, cabac=0)),
+    ("poc2_p", dict(frames=12, gop=6, bframes=0, refs=3, poc_type=2, mmco=1)),
+    ("constrained_intra", dict(frames=13, gop=13, bframes=2, refs=2, constrained_intra=1, pcm_period=53)),
+    ("direct4x4_spatial", dict(frames=13, gop=13, bframes=2, refs=2, direct8x8=0)),
+    ("direct4x4_temporal", dict(frames=13, gop=13, bframes=2, refs=2, direct8x8=0, temporal_direct=1, implicit_wp=1, cabac=0)),
 ]
