@@ -32,6 +32,8 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int bpyramid;     /* the middle B picture between two anchors is a reference (x264's b-pyramid): needs bframes >= 2, refs >= 4 */
+  int slice_qp_delta; /* PPS pic_init_qp = qp - this, every slice header adds it back */
   int poc_type;     /* pic_order_cnt_type 0 / 1 (one-frame cycle, per-slice delta) / 2 (needs bframes 0) */
   int constrained_intra; /* PPS constrained_intra_pred_flag */
   int direct8x8;    /* SPS direct_8x8_inference_flag (default 1) */
@@ -417,8 +419,8 @@ static void write_sps(Enc* e) {
   bw_ue(&w, 0);
   bw_ue(&w, 16);
   bw_ue(&w, 16);
-  bw_ue(&w, c->bframes ? 1 : 0);           /* num_reorder_frames */
-  bw_ue(&w, imax(c->refs, c->bframes ? 2 : 1)); /* max_dec_frame_buffering */
+  bw_ue(&w, c->bframes ? (c->bpyramid ? 2 : 1) : 0);           /* num_reorder_frames */
+  bw_ue(&w, imax(c->refs, c->bframes ? (c->bpyramid ? 3 : 2) : 1)); /* max_dec_frame_buffering */
   bw_trailing(&w);
   e->sps_nal = (uint8_t*)malloc(w.pos / 8 * 2 + 8);
   e->sps_len = (int)nal_escape(w.buf, w.pos / 8, 0x67, e->sps_nal);
@@ -437,7 +439,7 @@ static void write_pps(Enc* e) {
   bw_ue(&w, 0);
   bw_put(&w, c->explicit_wp ? 1 : 0, 1);                           /* weighted_pred */
   bw_put(&w, c->explicit_wp ? 1 : (c->implicit_wp ? 2 : 0), 2);    /* weighted_bipred_idc */
-  bw_se(&w, c->qp - 26);
+  bw_se(&w, c->qp - c->slice_qp_delta - 26);
   bw_se(&w, 0);
   bw_se(&w, c->chroma_qp_offset);
   bw_put(&w, 1, 1); /* deblocking_filter_control_present */
@@ -1394,7 +1396,9 @@ static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int firs
   }
   if (pp->type == 1) bw_put(w, c->temporal_direct ? 0 : 1, 1);
   if (pp->type != 2) {
-    const int nl0 = pp->type == 1 ? 1 : nrefs_l0;
+    /* B slices predict from one picture per list; with a reference B picture as the co-located one, temporal direct
+     * may map to any picture it references, so list 0 then carries everything the DPB holds */
+    const int nl0 = pp->type == 1 ? ((c->bpyramid && c->temporal_direct) ? imin(c->refs, dpb_refs(e->d)) : 1) : nrefs_l0;
     bw_put(w, 1, 1); /* num_ref_idx_active_override */
     bw_ue(w, nl0 - 1);
     if (pp->type == 1) bw_ue(w, 0);
@@ -1429,7 +1433,7 @@ static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int firs
     }
   }
   if (c->cabac && pp->type != 2) bw_ue(w, (e->frame_abs + first_mb) % 3);
-  bw_se(w, 0); /* slice_qp_delta */
+  bw_se(w, c->slice_qp_delta); /* slice_qp_delta */
   bw_ue(w, c->deblock_idc);
   if (c->deblock_idc != 1) {
     bw_se(w, c->alpha_div2);
@@ -1530,7 +1534,15 @@ static int plan_gop(const Cfg* c, int n, PicPlan* out) {
     /* MMCO 5 on every 5th reference picture (only without B pictures: it acts like an IDR for output order) */
     const int mmco5 = c->mmco == 2 && c->bframes == 0 && ordinal % 5 == 4;
     out[k++] = (PicPlan){0, anchor, fn, 1, ordinal, mmco5, poc_base};
-    for (int b = prev_anchor + 1; b < anchor; ++b) out[k++] = (PicPlan){1, b, (fn + 1) & 255, 0, ordinal, 0, poc_base};
+    int mid = -1;
+    if (c->bpyramid && anchor - prev_anchor >= 3) { /* the middle B picture is coded right after the anchor, as a reference */
+      mid = (prev_anchor + anchor) / 2;
+      fn = (fn + 1) & 255;
+      ++ordinal;
+      out[k++] = (PicPlan){1, mid, fn, 1, ordinal, 0, poc_base};
+    }
+    for (int b = prev_anchor + 1; b < anchor; ++b)
+      if (b != mid) out[k++] = (PicPlan){1, b, (fn + 1) & 255, 0, ordinal, 0, poc_base};
     if (mmco5) { /* the picture counts as frame_num 0 / POC 0 from here on (8.2.1) */
       fn = 0;
       poc_base = anchor;
@@ -1926,6 +1938,12 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.bpyramid = arg_int(argc, argv, "--bpyramid", 0);
+  c.slice_qp_delta = arg_int(argc, argv, "--slice-qp-delta", 0);
+  if (c.bpyramid && (c.bframes < 2 || c.refs < 4 || c.mmco)) {
+    fprintf(stderr, "encoder: --bpyramid needs --bframes >= 2 and --refs >= 4 (sliding window: two anchors + two middle pictures), and does not combine with --mmco\n");
+    return 2;
+  }
   c.poc_type = arg_int(argc, argv, "--poc-type", 0);
   c.constrained_intra = arg_int(argc, argv, "--constrained-intra", 0);
   c.direct8x8 = arg_int(argc, argv, "--direct8x8", 1);

@@ -74,4 +74,11 @@ MATRIX = [
     ("constrained_intra", dict(frames=13, gop=13, bframes=2, refs=2, constrained_intra=1, pcm_period=53)),
     ("direct4x4_spatial", dict(frames=13, gop=13, bframes=2, refs=2, direct8x8=0)),
     ("direct4x4_temporal", dict(frames=13, gop=13, bframes=2, refs=2, direct8x8=0, temporal_direct=1, implicit_wp=1, cabac=0)),
+    # B pictures as references (x264's default b-pyramid): reordering depth 2, a B picture as the co-located one of
+    # temporal direct, sparse retrieval that may skip only the non-reference ones; slice_qp_delta != 0
+    ("bpyramid3", dict(frames=26, gop=13, bframes=3, refs=4, bpyramid=1, slices=2)),
+    ("bpyramid2_temporal", dict(frames=17, gop=17, bframes=2, refs=4, bpyramid=1, temporal_direct=1, implicit_wp=1)),
+    ("bpyramid3_cavlc_wp", dict(frames=17, gop=17, bframes=3, refs=4, bpyramid=1, cabac=0, explicit_wp=1, wp_denom=5,
+                                slice_qp_delta=5)),
+    ("slice_qp_delta", dict(frames=9, gop=9, bframes=1, refs=2, slice_qp_delta=-7, slices=3)),
 ]

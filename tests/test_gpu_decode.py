@@ -98,6 +98,24 @@ def test_sparse_rows_and_rgb(hw, oracle, gpu, tmp_path):
         assert np.array_equal(serial[k], got[k]), "serial row %d" % r
 
 
+def test_sparse_rows_with_reference_b_pictures(hw, oracle, gpu, tmp_path):
+    """b-pyramid: the middle B picture of every group is a reference and must be reconstructed for its neighbours
+    even when it is not wanted itself; only the non-reference ones may be skipped."""
+    path = str(tmp_path / "pyr.mp4")
+    gold = make_clip(path, frames=52, gop=13, bframes=3, refs=4, bpyramid=1, temporal_direct=1, implicit_wp=1)
+    idx = hw.index_video(path)
+    rows = [1, 3, 6, 13, 17, 27, 31, 45, 51]   # mostly non-reference B positions, whose prediction needs the middle one
+    dec = hw.Decoder(path, video_index=idx, num_lanes=2)
+    got = dec.retrieve_yuv(rows)
+    assert dec.stats()["pictures_skipped"] > 0
+    for k, r in enumerate(rows):
+        assert np.array_equal(got[k], gold[r]), "row %d" % r
+    serial = dec.retrieve_serial(rows)
+    rgb = dec.retrieve(rows)
+    for k, r in enumerate(rows):
+        assert np.array_equal(serial[k], rgb[k]), "serial row %d" % r
+
+
 def test_device_resident_output(hw, oracle, gpu, tmp_path):
     torch = gpu
     path = str(tmp_path / "dev.mp4")

@@ -74,6 +74,16 @@ def test_sparse_hint_skips_only_unwanted_non_reference(hw, tmp_path):
     assert r2["skipped"] == 7
 
 
+def test_sparse_hint_keeps_reference_b_pictures(hw, tmp_path):
+    path = str(tmp_path / "pyr.mp4")
+    make_clip(path, yuv=False, frames=13, gop=13, bframes=3, refs=4, bpyramid=1)
+    idx, full = probe(hw, path)
+    # display order I b B b P b B b P b B b P: wanting the anchors only skips the six non-reference b pictures,
+    # never the three middle ones (references)
+    _, r = probe(hw, path, wanted=[0, 4, 8, 12])
+    assert r["skipped"] == 6 and r["pictures"] == full["pictures"] - 6 and r["slices"] == r["clean_end"]
+
+
 @pytest.mark.skipif(not have_file(REALSHORT), reason="realshort.mp4 not in this image")
 def test_real_x264_stream(hw):
     idx, r = probe(hw, REALSHORT)
