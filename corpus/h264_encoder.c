@@ -32,6 +32,7 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int fn_bits, poc_bits; /* log2_max_frame_num, log2_max_pic_order_cnt_lsb (default 8 / 8; 4 makes both wrap every few pictures) */
   int bpyramid;     /* the middle B picture between two anchors is a reference (x264's b-pyramid): needs bframes >= 2, refs >= 4 */
   int slice_qp_delta; /* PPS pic_init_qp = qp - this, every slice header adds it back */
   int poc_type;     /* pic_order_cnt_type 0 / 1 (one-frame cycle, per-slice delta) / 2 (needs bframes 0) */
@@ -374,10 +375,10 @@ static void write_sps(Enc* e) {
       bw_put(&w, 0, 1); /* seq_scaling_matrix_present */
     }
   }
-  bw_ue(&w, 4);      /* log2_max_frame_num_minus4 -> 8 bits */
+  bw_ue(&w, c->fn_bits - 4);      /* log2_max_frame_num_minus4 */
   bw_ue(&w, c->poc_type); /* pic_order_cnt_type */
   if (c->poc_type == 0) {
-    bw_ue(&w, 4);      /* log2_max_pic_order_cnt_lsb_minus4 -> 8 bits */
+    bw_ue(&w, c->poc_bits - 4);      /* log2_max_pic_order_cnt_lsb_minus4 */
   } else if (c->poc_type == 1) {
     bw_put(&w, 0, 1);  /* delta_pic_order_always_zero_flag: every slice carries delta_pic_order_cnt[0] */
     bw_se(&w, -1);     /* offset_for_non_ref_pic */
@@ -1376,19 +1377,20 @@ static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int firs
   bw_ue(w, first_mb);
   bw_ue(w, pp->type);
   bw_ue(w, 0);
-  bw_put(w, pp->frame_num & 255, 8);
+  const int fn_mask = (1 << c->fn_bits) - 1;
+  bw_put(w, pp->frame_num & fn_mask, c->fn_bits);
   if (pp->type == 2) bw_ue(w, (e->frame_abs / c->gop) & 1); /* idr_pic_id */
   if (c->poc_type == 0) {
-    bw_put(w, ((pp->display - pp->poc_base) * 2) & 255, 8);
+    bw_put(w, ((pp->display - pp->poc_base) * 2) & ((1 << c->poc_bits) - 1), c->poc_bits);
   } else if (c->poc_type == 1) {
     /* 8.2.1.2 with a one-frame cycle: expected = absFrameNum * offset_for_ref_frame[0] (+ offset_for_non_ref_pic);
      * delta_pic_order_cnt[0] makes up the difference to 2 * display */
     if (first_mb == 0) {
       if (pp->type == 2) e->poc1_fn_offset = 0;
-      else if (e->poc1_prev_fn > (pp->frame_num & 255)) e->poc1_fn_offset += 256;
-      e->poc1_prev_fn = pp->frame_num & 255;
+      else if (e->poc1_prev_fn > (pp->frame_num & fn_mask)) e->poc1_fn_offset += fn_mask + 1;
+      e->poc1_prev_fn = pp->frame_num & fn_mask;
     }
-    int abs_fn = pp->type == 2 ? 0 : e->poc1_fn_offset + (pp->frame_num & 255);
+    int abs_fn = pp->type == 2 ? 0 : e->poc1_fn_offset + (pp->frame_num & fn_mask);
     if (!pp->is_ref && abs_fn > 0) --abs_fn;
     int expected = abs_fn > 0 ? abs_fn * 2 * (c->bframes + 1) : 0;
     if (!pp->is_ref) expected += -1;
@@ -1523,13 +1525,14 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
 
 /* GOP structure in coding order */
 static int plan_gop(const Cfg* c, int n, PicPlan* out) {
+  const int fn_mask = (1 << c->fn_bits) - 1;
   int k = 0, fn = 0, ordinal = 0, poc_base = 0;
   out[k++] = (PicPlan){2, 0, 0, 1, 0, 0, 0};
   int prev_anchor = 0;
   while (prev_anchor < n - 1) {
     int anchor = imin(prev_anchor + c->bframes + 1, n - 1);
     /* closed GOP: the tail is coded as P pictures */
-    fn = (fn + 1) & 255;
+    fn = (fn + 1) & fn_mask;
     ++ordinal;
     /* MMCO 5 on every 5th reference picture (only without B pictures: it acts like an IDR for output order) */
     const int mmco5 = c->mmco == 2 && c->bframes == 0 && ordinal % 5 == 4;
@@ -1537,12 +1540,12 @@ static int plan_gop(const Cfg* c, int n, PicPlan* out) {
     int mid = -1;
     if (c->bpyramid && anchor - prev_anchor >= 3) { /* the middle B picture is coded right after the anchor, as a reference */
       mid = (prev_anchor + anchor) / 2;
-      fn = (fn + 1) & 255;
+      fn = (fn + 1) & fn_mask;
       ++ordinal;
       out[k++] = (PicPlan){1, mid, fn, 1, ordinal, 0, poc_base};
     }
     for (int b = prev_anchor + 1; b < anchor; ++b)
-      if (b != mid) out[k++] = (PicPlan){1, b, (fn + 1) & 255, 0, ordinal, 0, poc_base};
+      if (b != mid) out[k++] = (PicPlan){1, b, (fn + 1) & fn_mask, 0, ordinal, 0, poc_base};
     if (mmco5) { /* the picture counts as frame_num 0 / POC 0 from here on (8.2.1) */
       fn = 0;
       poc_base = anchor;
@@ -1938,6 +1941,13 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.fn_bits = arg_int(argc, argv, "--fn-bits", 8);
+  c.poc_bits = arg_int(argc, argv, "--poc-bits", 8);
+  if (c.fn_bits < 4 || c.fn_bits > 12 || c.poc_bits < 4 || c.poc_bits > 12 || (1 << c.fn_bits) <= c.refs ||
+      4 * (c.bframes + 1) >= (1 << c.poc_bits)) {
+    fprintf(stderr, "encoder: --fn-bits / --poc-bits 4..12; MaxFrameNum > refs; 4 * (bframes + 1) < MaxPicOrderCntLsb\n");
+    return 2;
+  }
   c.bpyramid = arg_int(argc, argv, "--bpyramid", 0);
   c.slice_qp_delta = arg_int(argc, argv, "--slice-qp-delta", 0);
   if (c.bpyramid && (c.bframes < 2 || c.refs < 4 || c.mmco)) {

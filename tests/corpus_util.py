@@ -81,4 +81,11 @@ MATRIX = [
     ("bpyramid3_cavlc_wp", dict(frames=17, gop=17, bframes=3, refs=4, bpyramid=1, cabac=0, explicit_wp=1, wp_denom=5,
                                 slice_qp_delta=5)),
     ("slice_qp_delta", dict(frames=9, gop=9, bframes=1, refs=2, slice_qp_delta=-7, slices=3)),
+    # frame_num and pic_order_cnt_lsb four or five bits wide: both wrap every few pictures (FrameNumWrap in list
+    # initialisation, sliding window and the marking operations; PicOrderCntMsb), GOPs longer than either period
+    ("wrap_b", dict(frames=60, gop=30, bframes=1, refs=3, fn_bits=4, poc_bits=4)),
+    ("wrap_mmco_rplm", dict(frames=60, gop=30, bframes=2, refs=4, fn_bits=4, poc_bits=5, mmco=1, rplm=1)),
+    ("wrap_mmco5_p", dict(frames=60, gop=30, bframes=0, refs=4, fn_bits=4, poc_bits=5, mmco=2, rplm=1, cabac=0)),
+    ("wrap_poc1", dict(frames=48, gop=24, bframes=2, refs=3, fn_bits=5, poc_type=1)),
+    ("wrap_pyramid", dict(frames=52, gop=26, bframes=3, refs=4, fn_bits=4, poc_bits=5, bpyramid=1, temporal_direct=1, implicit_wp=1)),
 ]
