@@ -32,6 +32,9 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int nal_length_size; /* avcC lengthSizeMinusOne + 1: 4 (default), 2 or 1 */
+  int extra_nals;      /* access unit delimiter in front of every picture, in-band SPS + PPS and an SEI at every IDR,
+                          filler data behind the slices: what muxers and other encoders put into samples */
   int fn_bits, poc_bits; /* log2_max_frame_num, log2_max_pic_order_cnt_lsb (default 8 / 8; 4 makes both wrap every few pictures) */
   int bpyramid;     /* the middle B picture between two anchors is a reference (x264's b-pyramid): needs bframes >= 2, refs >= 4 */
   int slice_qp_delta; /* PPS pic_init_qp = qp - this, every slice header adds it back */
@@ -470,7 +473,7 @@ static size_t make_avcc(const Enc* e, uint8_t* out) {
   out[o++] = e->sps_nal[1];
   out[o++] = e->sps_nal[2];
   out[o++] = e->sps_nal[3];
-  out[o++] = 0xff;
+  out[o++] = (uint8_t)(0xfc | (e->cfg->nal_length_size - 1));
   out[o++] = 0xe1;
   out[o++] = (uint8_t)(e->sps_len >> 8);
   out[o++] = (uint8_t)e->sps_len;
@@ -1462,6 +1465,20 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
   if (pp->type == 2 || e->rc_qp == 0) e->rc_qp = c->qp;
   const double rc_budget = c->rate_kbit * 1000.0 * (pp->type == 2 ? 4.0 : pp->type == 0 ? 1.0 : 0.5);
   size_t rc_bits_before = 0;
+  if (c->extra_nals) { /* AUD; at an IDR also the parameter sets in band and a user-data SEI */
+    const int ls = c->nal_length_size;
+    scap = 512 + (size_t)e->sps_len + e->pps_len;
+    sample = (uint8_t*)malloc(scap);
+    const uint8_t aud[2] = {0x09, (uint8_t)((pp->type == 2 ? 0 : pp->type == 0 ? 1 : 2) << 5 | 0x10)};
+    const uint8_t sei[22] = {0x06, 0x05, 0x12, 'h', 'w', 'a', 'n', 'g', '-', 'c', 'o', 'r', 'p', 'u', 's', '-', 's', 'e', 'i', 'x', 'y', 0x80};
+    const uint8_t* nal[4] = {aud, e->sps_nal, e->pps_nal, sei};
+    const size_t len[4] = {sizeof(aud), (size_t)e->sps_len, (size_t)e->pps_len, sizeof(sei)};
+    for (int q = 0; q < (pp->type == 2 ? 4 : 1); ++q) {
+      for (int k = 0; k < ls; ++k) sample[ssize + k] = (uint8_t)(len[q] >> (8 * (ls - 1 - k)));
+      memcpy(sample + ssize + ls, nal[q], len[q]);
+      ssize += ls + len[q];
+    }
+  }
   for (int s = 0; s < nslices; ++s) {
     const int row0 = s * mbh / nslices, row1 = (s + 1) * mbh / nslices;
     BitWriter* w = &e->w;
@@ -1505,12 +1522,20 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
       scap = (ssize + rb * 3 / 2 + 16) * 2;
       sample = (uint8_t*)realloc(sample, scap);
     }
-    size_t n = nal_escape(w->buf, rb, (ref_idc << 5) | nal_type, sample + ssize + 4);
-    sample[ssize] = (uint8_t)(n >> 24);
-    sample[ssize + 1] = (uint8_t)(n >> 16);
-    sample[ssize + 2] = (uint8_t)(n >> 8);
-    sample[ssize + 3] = (uint8_t)n;
-    ssize += 4 + n;
+    const int ls = c->nal_length_size;
+    size_t n = nal_escape(w->buf, rb, (ref_idc << 5) | nal_type, sample + ssize + ls);
+    if (ls < 4 && n >= ((size_t)1 << (8 * ls))) {
+      fprintf(stderr, "encoder: a %zu-byte NAL unit does not fit --nal-length-size %d\n", n, ls);
+      return -1;
+    }
+    for (int k = 0; k < ls; ++k) sample[ssize + k] = (uint8_t)(n >> (8 * (ls - 1 - k)));
+    ssize += ls + n;
+    if (c->extra_nals && s == nslices - 1) { /* filler data (nal_unit_type 12) behind the last slice */
+      const uint8_t filler[6] = {0x0c, 0xff, 0xff, 0xff, 0xff, 0x80};
+      for (int k = 0; k < ls; ++k) sample[ssize + k] = (uint8_t)(sizeof(filler) >> (8 * (ls - 1 - k)));
+      memcpy(sample + ssize + ls, filler, sizeof(filler));
+      ssize += ls + sizeof(filler);
+    }
   }
   if (h264i_finish_picture(d) < 0) {
     fprintf(stderr, "encoder: finish_picture: %s\n", d->error);
@@ -1941,6 +1966,12 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.nal_length_size = arg_int(argc, argv, "--nal-length-size", 4);
+  c.extra_nals = arg_int(argc, argv, "--extra-nals", 0);
+  if (c.nal_length_size != 1 && c.nal_length_size != 2 && c.nal_length_size != 4) {
+    fprintf(stderr, "encoder: --nal-length-size 1, 2 or 4\n");
+    return 2;
+  }
   c.fn_bits = arg_int(argc, argv, "--fn-bits", 8);
   c.poc_bits = arg_int(argc, argv, "--poc-bits", 8);
   if (c.fn_bits < 4 || c.fn_bits > 12 || c.poc_bits < 4 || c.poc_bits > 12 || (1 << c.fn_bits) <= c.refs ||

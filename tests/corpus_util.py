@@ -88,4 +88,8 @@ MATRIX = [
     ("wrap_mmco5_p", dict(frames=60, gop=30, bframes=0, refs=4, fn_bits=4, poc_bits=5, mmco=2, rplm=1, cabac=0)),
     ("wrap_poc1", dict(frames=48, gop=24, bframes=2, refs=3, fn_bits=5, poc_type=1)),
     ("wrap_pyramid", dict(frames=52, gop=26, bframes=3, refs=4, fn_bits=4, poc_bits=5, bpyramid=1, temporal_direct=1, implicit_wp=1)),
+    # what muxers and other encoders put into samples: access unit delimiters, parameter sets in band and an SEI at
+    # every IDR, filler data behind the slices; two-byte NAL lengths in avcC
+    ("extra_nals", dict(frames=24, gop=8, bframes=2, refs=2, slices=2, extra_nals=1)),
+    ("nal_len2_extra_cavlc", dict(frames=16, gop=8, bframes=1, refs=2, cabac=0, extra_nals=1, nal_length_size=2)),
 ]
