@@ -32,6 +32,8 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int multi_pps;       /* a second picture parameter set (id 1: other pic_init_qp, other chroma QP offsets) used by every
+                          other coded picture */
   int nal_length_size; /* avcC lengthSizeMinusOne + 1: 4 (default), 2 or 1 */
   int extra_nals;      /* access unit delimiter in front of every picture, in-band SPS + PPS and an SEI at every IDR,
                           filler data behind the slices: what muxers and other encoders put into samples */
@@ -273,6 +275,9 @@ typedef struct {
   int sps_len;
   uint8_t* pps_nal;
   int pps_len;
+  uint8_t* pps1_nal; /* --multi-pps */
+  int pps1_len;
+  int coded_index;   /* pictures coded so far in this GOP (chooses the PPS) */
   int frame_abs;   /* absolute display index of the picture being coded */
   int poc1_prev_fn, poc1_fn_offset; /* pic_order_cnt_type 1: FrameNumOffset bookkeeping (8.2.1.2) */
   int rc_qp;       /* rate control: the QP the next macroblock row starts from (reset at every I picture, so that
@@ -431,10 +436,13 @@ static void write_sps(Enc* e) {
   free(w.buf);
 }
 
-static void write_pps(Enc* e) {
+/* the second parameter set differs where a decoder must follow the change per picture */
+static int pps_init_qp(const Cfg* c, int id) { return c->qp - c->slice_qp_delta + (id ? 4 : 0); }
+static int pps_chroma_offset(const Cfg* c, int id) { return id ? iclip(-12, 12, c->chroma_qp_offset + 2) : c->chroma_qp_offset; }
+static void write_pps_id(Enc* e, int id) {
   const Cfg* c = e->cfg;
   BitWriter w = {0};
-  bw_ue(&w, 0);
+  bw_ue(&w, id);
   bw_ue(&w, 0);
   bw_put(&w, c->cabac, 1);
   bw_put(&w, 0, 1);
@@ -443,9 +451,9 @@ static void write_pps(Enc* e) {
   bw_ue(&w, 0);
   bw_put(&w, c->explicit_wp ? 1 : 0, 1);                           /* weighted_pred */
   bw_put(&w, c->explicit_wp ? 1 : (c->implicit_wp ? 2 : 0), 2);    /* weighted_bipred_idc */
-  bw_se(&w, c->qp - c->slice_qp_delta - 26);
+  bw_se(&w, pps_init_qp(c, id) - 26);
   bw_se(&w, 0);
-  bw_se(&w, c->chroma_qp_offset);
+  bw_se(&w, pps_chroma_offset(c, id));
   bw_put(&w, 1, 1); /* deblocking_filter_control_present */
   bw_put(&w, c->constrained_intra ? 1 : 0, 1); /* constrained_intra_pred */
   bw_put(&w, 0, 1); /* redundant_pic_cnt_present */
@@ -459,12 +467,19 @@ static void write_pps(Enc* e) {
     } else {
       bw_put(&w, 0, 1);
     }
-    bw_se(&w, c->chroma_qp_offset > 0 ? c->chroma_qp_offset - 1 : c->chroma_qp_offset);
+    const int co = pps_chroma_offset(c, id);
+    bw_se(&w, co > 0 ? co - 1 : co);
   }
   bw_trailing(&w);
-  e->pps_nal = (uint8_t*)malloc(w.pos / 8 * 2 + 8);
-  e->pps_len = (int)nal_escape(w.buf, w.pos / 8, 0x68, e->pps_nal);
+  uint8_t* nal = (uint8_t*)malloc(w.pos / 8 * 2 + 8);
+  const int len = (int)nal_escape(w.buf, w.pos / 8, 0x68, nal);
+  if (id) e->pps1_nal = nal, e->pps1_len = len;
+  else e->pps_nal = nal, e->pps_len = len;
   free(w.buf);
+}
+static void write_pps(Enc* e) {
+  write_pps_id(e, 0);
+  if (e->cfg->multi_pps) write_pps_id(e, 1);
 }
 
 static size_t make_avcc(const Enc* e, uint8_t* out) {
@@ -479,11 +494,17 @@ static size_t make_avcc(const Enc* e, uint8_t* out) {
   out[o++] = (uint8_t)e->sps_len;
   memcpy(out + o, e->sps_nal, e->sps_len);
   o += e->sps_len;
-  out[o++] = 1;
+  out[o++] = e->cfg->multi_pps ? 2 : 1;
   out[o++] = (uint8_t)(e->pps_len >> 8);
   out[o++] = (uint8_t)e->pps_len;
   memcpy(out + o, e->pps_nal, e->pps_len);
   o += e->pps_len;
+  if (e->cfg->multi_pps) {
+    out[o++] = (uint8_t)(e->pps1_len >> 8);
+    out[o++] = (uint8_t)e->pps1_len;
+    memcpy(out + o, e->pps1_nal, e->pps1_len);
+    o += e->pps1_len;
+  }
   return o;
 }
 
@@ -1377,9 +1398,10 @@ static void write_pwt(const Enc* e, BitWriter* w, const PicPlan* pp, int nl0, in
 static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int first_mb, int nrefs_l0, const Marking* mk) {
   const Cfg* c = e->cfg;
   const uint32_t hs = hash3((uint32_t)c->seed + 13, (uint32_t)e->frame_abs, (uint32_t)first_mb);
+  const int pps_id = c->multi_pps ? (e->coded_index & 1) : 0;
   bw_ue(w, first_mb);
   bw_ue(w, pp->type);
-  bw_ue(w, 0);
+  bw_ue(w, pps_id);
   const int fn_mask = (1 << c->fn_bits) - 1;
   bw_put(w, pp->frame_num & fn_mask, c->fn_bits);
   if (pp->type == 2) bw_ue(w, (e->frame_abs / c->gop) & 1); /* idr_pic_id */
@@ -1438,7 +1460,7 @@ static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int firs
     }
   }
   if (c->cabac && pp->type != 2) bw_ue(w, (e->frame_abs + first_mb) % 3);
-  bw_se(w, c->slice_qp_delta); /* slice_qp_delta */
+  bw_se(w, c->qp - pps_init_qp(c, pps_id)); /* slice_qp_delta: the slice starts at --qp whatever the parameter set says */
   bw_ue(w, c->deblock_idc);
   if (c->deblock_idc != 1) {
     bw_se(w, c->alpha_div2);
@@ -1467,13 +1489,13 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
   size_t rc_bits_before = 0;
   if (c->extra_nals) { /* AUD; at an IDR also the parameter sets in band and a user-data SEI */
     const int ls = c->nal_length_size;
-    scap = 512 + (size_t)e->sps_len + e->pps_len;
+    scap = 512 + (size_t)e->sps_len + e->pps_len + e->pps1_len;
     sample = (uint8_t*)malloc(scap);
     const uint8_t aud[2] = {0x09, (uint8_t)((pp->type == 2 ? 0 : pp->type == 0 ? 1 : 2) << 5 | 0x10)};
     const uint8_t sei[22] = {0x06, 0x05, 0x12, 'h', 'w', 'a', 'n', 'g', '-', 'c', 'o', 'r', 'p', 'u', 's', '-', 's', 'e', 'i', 'x', 'y', 0x80};
-    const uint8_t* nal[4] = {aud, e->sps_nal, e->pps_nal, sei};
-    const size_t len[4] = {sizeof(aud), (size_t)e->sps_len, (size_t)e->pps_len, sizeof(sei)};
-    for (int q = 0; q < (pp->type == 2 ? 4 : 1); ++q) {
+    const uint8_t* nal[5] = {aud, e->sps_nal, e->pps_nal, sei, e->pps1_nal};
+    const size_t len[5] = {sizeof(aud), (size_t)e->sps_len, (size_t)e->pps_len, sizeof(sei), (size_t)e->pps1_len};
+    for (int q = 0; q < (pp->type == 2 ? (c->multi_pps ? 5 : 4) : 1); ++q) {
       for (int k = 0; k < ls; ++k) sample[ssize + k] = (uint8_t)(len[q] >> (8 * (ls - 1 - k)));
       memcpy(sample + ssize + ls, nal[q], len[q]);
       ssize += ls + len[q];
@@ -1606,6 +1628,7 @@ static int encode_gop(Enc* e, int gop_index, int nframes, GopOut* out, int want_
   for (int i = 0; i <= n; ++i) {
     if (i < n) {
       e->frame_abs = gop_index * c->gop + plans[i].display;
+      e->coded_index = i;
       scene_render(&e->scene, e->frame_abs);
       /* what the DPB holds (marking operations make this more than a count of coded pictures) */
       const int refs_available = plans[i].type == 2 ? 0 : dpb_refs(d);
@@ -1872,6 +1895,7 @@ static void enc_free(Enc* e) {
   free(e->w.buf);
   free(e->sps_nal);
   free(e->pps_nal);
+  free(e->pps1_nal);
   h264o_close(e->d);
 }
 
@@ -1966,6 +1990,7 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.multi_pps = arg_int(argc, argv, "--multi-pps", 0);
   c.nal_length_size = arg_int(argc, argv, "--nal-length-size", 4);
   c.extra_nals = arg_int(argc, argv, "--extra-nals", 0);
   if (c.nal_length_size != 1 && c.nal_length_size != 2 && c.nal_length_size != 4) {

@@ -92,4 +92,8 @@ MATRIX = [
     # every IDR, filler data behind the slices; two-byte NAL lengths in avcC
     ("extra_nals", dict(frames=24, gop=8, bframes=2, refs=2, slices=2, extra_nals=1)),
     ("nal_len2_extra_cavlc", dict(frames=16, gop=8, bframes=1, refs=2, cabac=0, extra_nals=1, nal_length_size=2)),
+    # two picture parameter sets (other pic_init_qp, other chroma QP offsets), alternating picture by picture
+    ("multi_pps", dict(frames=17, gop=17, bframes=2, refs=2, multi_pps=1)),
+    ("multi_pps_cavlc_inband", dict(frames=16, gop=8, bframes=1, refs=2, cabac=0, multi_pps=1, extra_nals=1,
+                                    chroma_qp_offset=-3, slice_qp_delta=2, slices=2)),
 ]
