@@ -326,7 +326,7 @@ static int level_for(const Cfg* c) {
 
 static int profile_for(const Cfg* c) {
   if (c->t8x8 || c->scaling) return 100;
-  return (c->cabac || c->bframes || c->explicit_wp) ? 77 : 66;
+  return (c->cabac || c->multi_pps == 2 || c->bframes || c->explicit_wp) ? 77 : 66;
 }
 
 /* scaling_list() syntax (7.3.2.1.1.1).  kind 0: not present (fall-back rule),
@@ -438,13 +438,15 @@ static void write_sps(Enc* e) {
 
 /* the second parameter set differs where a decoder must follow the change per picture */
 static int pps_init_qp(const Cfg* c, int id) { return c->qp - c->slice_qp_delta + (id ? 4 : 0); }
+/* --multi-pps 2: the second set also switches the entropy coder, so CABAC and CAVLC pictures alternate in one stream */
+static int pps_cabac(const Cfg* c, int id) { return (id && c->multi_pps == 2) ? !c->cabac : c->cabac; }
 static int pps_chroma_offset(const Cfg* c, int id) { return id ? iclip(-12, 12, c->chroma_qp_offset + 2) : c->chroma_qp_offset; }
 static void write_pps_id(Enc* e, int id) {
   const Cfg* c = e->cfg;
   BitWriter w = {0};
   bw_ue(&w, id);
   bw_ue(&w, 0);
-  bw_put(&w, c->cabac, 1);
+  bw_put(&w, pps_cabac(c, id), 1);
   bw_put(&w, 0, 1);
   bw_ue(&w, 0); /* slice groups */
   bw_ue(&w, c->refs - 1);
@@ -1459,7 +1461,7 @@ static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int firs
       }
     }
   }
-  if (c->cabac && pp->type != 2) bw_ue(w, (e->frame_abs + first_mb) % 3);
+  if (pps_cabac(c, pps_id) && pp->type != 2) bw_ue(w, (e->frame_abs + first_mb) % 3);
   bw_se(w, c->qp - pps_init_qp(c, pps_id)); /* slice_qp_delta: the slice starts at --qp whatever the parameter set says */
   bw_ue(w, c->deblock_idc);
   if (c->deblock_idc != 1) {

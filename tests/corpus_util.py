@@ -96,4 +96,7 @@ MATRIX = [
     ("multi_pps", dict(frames=17, gop=17, bframes=2, refs=2, multi_pps=1)),
     ("multi_pps_cavlc_inband", dict(frames=16, gop=8, bframes=1, refs=2, cabac=0, multi_pps=1, extra_nals=1,
                                     chroma_qp_offset=-3, slice_qp_delta=2, slices=2)),
+    # ... and the second set switches the entropy coder: CABAC and CAVLC pictures alternate in one stream
+    ("mixed_entropy", dict(frames=26, gop=13, bframes=2, refs=3, multi_pps=2, slices=2)),
+    ("mixed_entropy_p", dict(frames=16, gop=8, bframes=0, refs=2, cabac=0, multi_pps=2, t8x8=1)),
 ]
