@@ -99,4 +99,9 @@ MATRIX = [
     # ... and the second set switches the entropy coder: CABAC and CAVLC pictures alternate in one stream
     ("mixed_entropy", dict(frames=26, gop=13, bframes=2, refs=3, multi_pps=2, slices=2)),
     ("mixed_entropy_p", dict(frames=16, gop=8, bframes=0, refs=2, cabac=0, multi_pps=2, t8x8=1)),
+    # long reference lists: up to sixteen frames in the DPB (ref_idx beyond the first few contexts / te() ranges,
+    # sixteen decode surfaces per lane)
+    ("refs16_b_rplm", dict(frames=40, gop=40, bframes=2, refs=16, rplm=1)),
+    ("refs12_mmco_cavlc", dict(frames=30, gop=30, bframes=1, refs=12, mmco=1, cabac=0)),
+    ("refs8_p", dict(frames=24, gop=24, bframes=0, refs=8, explicit_wp=1, wp_denom=3)),
 ]
