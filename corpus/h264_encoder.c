@@ -32,6 +32,7 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int crop_left, crop_top; /* frame_crop_left / top_offset (two-sample units), taken out of the right / bottom padding */
   int multi_pps;       /* a second picture parameter set (id 1: other pic_init_qp, other chroma QP offsets) used by every
                           other coded picture */
   int nal_length_size; /* avcC lengthSizeMinusOne + 1: 4 (default), 2 or 1 */
@@ -403,10 +404,10 @@ static void write_sps(Enc* e) {
   const int cr = (((c->width + 15) & ~15) - c->width) / 2, cb = (((c->height + 15) & ~15) - c->height) / 2;
   if (cr || cb) {
     bw_put(&w, 1, 1);
-    bw_ue(&w, 0);
-    bw_ue(&w, cr);
-    bw_ue(&w, 0);
-    bw_ue(&w, cb);
+    bw_ue(&w, imin(c->crop_left, cr));
+    bw_ue(&w, cr - imin(c->crop_left, cr));
+    bw_ue(&w, imin(c->crop_top, cb));
+    bw_ue(&w, cb - imin(c->crop_top, cb));
   } else {
     bw_put(&w, 0, 1);
   }
@@ -1992,6 +1993,8 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.crop_left = arg_int(argc, argv, "--crop-left", 0);
+  c.crop_top = arg_int(argc, argv, "--crop-top", 0);
   c.multi_pps = arg_int(argc, argv, "--multi-pps", 0);
   c.nal_length_size = arg_int(argc, argv, "--nal-length-size", 4);
   c.extra_nals = arg_int(argc, argv, "--extra-nals", 0);

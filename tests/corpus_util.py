@@ -104,4 +104,7 @@ MATRIX = [
     ("refs16_b_rplm", dict(frames=40, gop=40, bframes=2, refs=16, rplm=1)),
     ("refs12_mmco_cavlc", dict(frames=30, gop=30, bframes=1, refs=12, mmco=1, cabac=0)),
     ("refs8_p", dict(frames=24, gop=24, bframes=0, refs=8, explicit_wp=1, wp_denom=3)),
+    # a cropping rectangle that starts inside the coded picture (left / top offsets, not only right / bottom padding)
+    ("crop_left_top", dict(width=322, height=242, frames=9, gop=9, bframes=2, crop_left=3, crop_top=2)),
+    ("crop_left_top_odd", dict(width=306, height=226, frames=7, gop=7, bframes=1, crop_left=5, crop_top=7, cabac=0)),
 ]

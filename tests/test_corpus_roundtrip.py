@@ -10,7 +10,8 @@ from tests.corpus_util import MATRIX, make_clip
 
 @pytest.mark.parametrize("name,kw", MATRIX, ids=[m[0] for m in MATRIX])
 def test_roundtrip(hw, oracle, tmp_path, name, kw):
-    w, h = (322, 242) if name == "qp40" else (320, 240)
+    kw = dict(kw)
+    w, h = kw.pop("width", 322 if name == "qp40" else 320), kw.pop("height", 242 if name == "qp40" else 240)
     path = str(tmp_path / (name + ".mp4"))
     gold = make_clip(path, width=w, height=h, **kw)
     idx = hw.index_video(path)

@@ -26,7 +26,8 @@ def oracle_frames(oracle, hw, path):
 
 @pytest.mark.parametrize("name,kw", MATRIX, ids=[m[0] for m in MATRIX])
 def test_all_frames_bit_exact(hw, oracle, gpu, tmp_path, name, kw):
-    w, h = (322, 242) if name == "qp40" else (320, 240)
+    kw = dict(kw)
+    w, h = kw.pop("width", 322 if name == "qp40" else 320), kw.pop("height", 242 if name == "qp40" else 240)
     path = str(tmp_path / (name + ".mp4"))
     gold = make_clip(path, width=w, height=h, **kw)
     idx = hw.index_video(path)
@@ -139,6 +140,19 @@ def test_1080p_cropping(hw, oracle, gpu, tmp_path):
     got = dec.retrieve_yuv([0, 2, 4])
     for k, r in enumerate([0, 2, 4]):
         assert np.array_equal(got[k], gold[r])
+
+
+def test_left_top_cropping_rgb(hw, oracle, gpu, tmp_path):
+    """The cropping rectangle starts inside the coded picture: the conversion reads from the offset surface."""
+    path = str(tmp_path / "crop.mp4")
+    gold = make_clip(path, width=306, height=226, frames=7, gop=7, bframes=1, crop_left=5, crop_top=7)
+    idx = hw.index_video(path)
+    assert (idx.frame_width(), idx.frame_height()) == (306, 226)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+    got = dec.retrieve([0, 3, 6])
+    for k, r in enumerate([0, 3, 6]):
+        assert got[k].shape == (226, 306, 3)
+        assert np.array_equal(got[k], oracle.i420_to_rgb(gold[r], 306, 226)), "row %d" % r
 
 
 def test_many_lanes_random_rows_1080p(hw, gpu, tmp_path):
