@@ -107,4 +107,6 @@ MATRIX = [
     # a cropping rectangle that starts inside the coded picture (left / top offsets, not only right / bottom padding)
     ("crop_left_top", dict(width=322, height=242, frames=9, gop=9, bframes=2, crop_left=3, crop_top=2)),
     ("crop_left_top_odd", dict(width=306, height=226, frames=7, gop=7, bframes=1, crop_left=5, crop_top=7, cabac=0)),
+    # the loop filter switched off (disable_deblocking_filter_idc = 1): no k_bs / k_deblock work at all
+    ("deblock_off", dict(frames=10, gop=10, bframes=2, refs=2, deblock=1, slices=2)),
 ]
