@@ -32,6 +32,8 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int mixed_slices;    /* slices of other types inside a picture: I slices in P pictures, P and I slices in B pictures
+                          (needs --slices >= 2) */
   int crop_left, crop_top; /* frame_crop_left / top_offset (two-sample units), taken out of the right / bottom padding */
   int multi_pps;       /* a second picture parameter set (id 1: other pic_init_qp, other chroma QP offsets) used by every
                           other coded picture */
@@ -1398,12 +1400,16 @@ static void write_pwt(const Enc* e, BitWriter* w, const PicPlan* pp, int nl0, in
     }
 }
 
-static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int first_mb, int nrefs_l0, const Marking* mk) {
+/* st: this slice's type (the picture's, or a "lower" one with --mixed-slices); pp->type == 2 still means an IDR picture */
+static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int st, int first_mb, int nrefs_l0, const Marking* mk) {
   const Cfg* c = e->cfg;
+  PicPlan as_slice = *pp;
+  as_slice.type = st;
+  const PicPlan* sp = &as_slice;
   const uint32_t hs = hash3((uint32_t)c->seed + 13, (uint32_t)e->frame_abs, (uint32_t)first_mb);
   const int pps_id = c->multi_pps ? (e->coded_index & 1) : 0;
   bw_ue(w, first_mb);
-  bw_ue(w, pp->type);
+  bw_ue(w, st);
   bw_ue(w, pps_id);
   const int fn_mask = (1 << c->fn_bits) - 1;
   bw_put(w, pp->frame_num & fn_mask, c->fn_bits);
@@ -1424,23 +1430,23 @@ static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int firs
     if (!pp->is_ref) expected += -1;
     bw_se(w, (pp->display - pp->poc_base) * 2 - expected);
   }
-  if (pp->type == 1) bw_put(w, c->temporal_direct ? 0 : 1, 1);
-  if (pp->type != 2) {
+  if (st == 1) bw_put(w, c->temporal_direct ? 0 : 1, 1);
+  if (st != 2) {
     /* B slices predict from one picture per list; with a reference B picture as the co-located one, temporal direct
      * may map to any picture it references, so list 0 then carries everything the DPB holds */
-    const int nl0 = pp->type == 1 ? ((c->bpyramid && c->temporal_direct) ? imin(c->refs, dpb_refs(e->d)) : 1) : nrefs_l0;
+    const int nl0 = st == 1 ? ((c->bpyramid && c->temporal_direct) ? imin(c->refs, dpb_refs(e->d)) : 1) : nrefs_l0;
     bw_put(w, 1, 1); /* num_ref_idx_active_override */
     bw_ue(w, nl0 - 1);
-    if (pp->type == 1) bw_ue(w, 0);
+    if (st == 1) bw_ue(w, 0);
     /* temporal direct needs the co-located block's reference in list 0: leave B lists alone there */
-    const int mod_ok = pp->type == 0 || !c->temporal_direct;
-    if (mod_ok) write_rplm(e, w, pp, nl0, hs);
+    const int mod_ok = st == 0 || !c->temporal_direct;
+    if (mod_ok) write_rplm(e, w, sp, nl0, hs);
     else bw_put(w, 0, 1); /* ref_pic_list_modification_flag_l0 */
-    if (pp->type == 1) {
-      if (mod_ok) write_rplm(e, w, pp, 1, hash32(hs + 3));
+    if (st == 1) {
+      if (mod_ok) write_rplm(e, w, sp, 1, hash32(hs + 3));
       else bw_put(w, 0, 1);
     }
-    if (c->explicit_wp) write_pwt(e, w, pp, nl0, 1, hash32(hs + 9));
+    if (c->explicit_wp) write_pwt(e, w, sp, nl0, 1, hash32(hs + 9));
   }
   if (pp->is_ref) {
     if (pp->type == 2) {
@@ -1462,7 +1468,7 @@ static void write_slice_header(Enc* e, BitWriter* w, const PicPlan* pp, int firs
       }
     }
   }
-  if (pps_cabac(c, pps_id) && pp->type != 2) bw_ue(w, (e->frame_abs + first_mb) % 3);
+  if (pps_cabac(c, pps_id) && st != 2) bw_ue(w, (e->frame_abs + first_mb) % 3);
   bw_se(w, c->qp - pps_init_qp(c, pps_id)); /* slice_qp_delta: the slice starts at --qp whatever the parameter set says */
   bw_ue(w, c->deblock_idc);
   if (c->deblock_idc != 1) {
@@ -1494,7 +1500,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
     const int ls = c->nal_length_size;
     scap = 512 + (size_t)e->sps_len + e->pps_len + e->pps1_len;
     sample = (uint8_t*)malloc(scap);
-    const uint8_t aud[2] = {0x09, (uint8_t)((pp->type == 2 ? 0 : pp->type == 0 ? 1 : 2) << 5 | 0x10)};
+    const uint8_t aud[2] = {0x09, (uint8_t)((pp->type == 2 ? 0 : pp->type == 0 ? 1 : 2) << 5 | 0x10)}; /* (an upper bound with --mixed-slices) */
     const uint8_t sei[22] = {0x06, 0x05, 0x12, 'h', 'w', 'a', 'n', 'g', '-', 'c', 'o', 'r', 'p', 'u', 's', '-', 's', 'e', 'i', 'x', 'y', 0x80};
     const uint8_t* nal[5] = {aud, e->sps_nal, e->pps_nal, sei, e->pps1_nal};
     const size_t len[5] = {sizeof(aud), (size_t)e->sps_len, (size_t)e->pps_len, sizeof(sei), (size_t)e->pps1_len};
@@ -1508,7 +1514,11 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
     const int row0 = s * mbh / nslices, row1 = (s + 1) * mbh / nslices;
     BitWriter* w = &e->w;
     w->pos = 0;
-    write_slice_header(e, w, pp, row0 * mbw, nrefs_l0, &mk);
+    /* --mixed-slices: every second slice of a P picture is an I slice; in a B picture the slices cycle B, P, I */
+    int st = pp->type;
+    if (c->mixed_slices && pp->type == 0 && (s & 1)) st = 2;
+    if (c->mixed_slices && pp->type == 1) st = s % 3 == 0 ? 1 : s % 3 == 1 ? 0 : 2;
+    write_slice_header(e, w, pp, st, row0 * mbw, nrefs_l0, &mk);
     /* let the oracle parse the header it will later be given: builds the
      * reference lists, POC, starts the picture */
     {
@@ -1527,8 +1537,8 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
       int qp = c->rate_kbit > 0 ? e->rc_qp : c->qp;
       uint32_t hq = hash3((uint32_t)c->seed + 3, (uint32_t)e->frame_abs, (uint32_t)addr);
       if (hq % 9 == 0) qp = iclip(10, 48, qp + (int)((hq >> 4) % 5) - 2);
-      if (pp->type == 2) decide_intra(e, &plan, qp, 2);
-      else if (pp->type == 0) decide_p(e, &plan, qp, 1);
+      if (st == 2) decide_intra(e, &plan, qp, 2);
+      else if (st == 0) decide_p(e, &plan, qp, 1);
       else decide_b(e, &plan, qp);
       if (h264i_enc_mb(d, w, addr, &plan, addr == row1 * mbw - 1) < 0) {
         fprintf(stderr, "encoder: %s\n", d->error);
@@ -1993,6 +2003,7 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.mixed_slices = arg_int(argc, argv, "--mixed-slices", 0);
   c.crop_left = arg_int(argc, argv, "--crop-left", 0);
   c.crop_top = arg_int(argc, argv, "--crop-top", 0);
   c.multi_pps = arg_int(argc, argv, "--multi-pps", 0);

@@ -254,6 +254,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     amd::PicSubmit sub;
     std::memset(&sub.desc, 0, sizeof(sub.desc));
     auto add_copy = [&](void* dst, const void* src, size_t bytes) {
+      static_assert(amd::kJobUploads >= 6, "MbInfo, coefficients, SliceParams, MbMotion, PMotion, extras");
       sub.copies[sub.ncopies].dst = dst;
       sub.copies[sub.ncopies].src = src;
       sub.copies[sub.ncopies].bytes = bytes;

@@ -161,7 +161,9 @@ struct UploadDesc {
   const void* src;
   uint64_t bytes;
 };
-constexpr int kJobUploads = 5;
+// MbInfo, coefficients, SliceParams, then MbMotion (slices whose vectors the host derived) and / or PMotion + extra
+// differences (slices left to k_mv): a picture with B and P slices brings all six
+constexpr int kJobUploads = 6;
 
 // Width (macroblocks) that the LDS line buffers of k_mv and of k_intra's
 // LDS-neighbour path cover: 4K (240) fits; wider pictures take the host path

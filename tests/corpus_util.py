@@ -109,4 +109,10 @@ MATRIX = [
     ("crop_left_top_odd", dict(width=306, height=226, frames=7, gop=7, bframes=1, crop_left=5, crop_top=7, cabac=0)),
     # the loop filter switched off (disable_deblocking_filter_idc = 1): no k_bs / k_deblock work at all
     ("deblock_off", dict(frames=10, gop=10, bframes=2, refs=2, deblock=1, slices=2)),
+    # slices of different types inside one picture: I slices in P pictures, P and I slices in B pictures
+    ("mixed_slices_b", dict(frames=13, gop=13, bframes=2, refs=3, slices=3, mixed_slices=1)),
+    ("mixed_slices_p_cavlc_wp", dict(frames=12, gop=12, bframes=0, refs=2, slices=4, mixed_slices=1, cabac=0, explicit_wp=1,
+                                     wp_denom=4)),
+    ("mixed_slices_temporal", dict(frames=13, gop=13, bframes=2, refs=3, slices=3, mixed_slices=1, temporal_direct=1,
+                                   implicit_wp=1, deblock=2)),
 ]

@@ -35,7 +35,7 @@ def load(d, counter):
             elif name == "convert_batch":
                 pics = gz
             elif name == "k_upload":
-                pics = gy // 5   # kJobUploads arrays per picture
+                pics = gy // 6   # kJobUploads arrays per picture
             else:
                 pics = gy
             e = out[name]
