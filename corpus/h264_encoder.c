@@ -32,6 +32,7 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int slice_mbs;       /* > 0: a new slice every so many macroblocks - boundaries in the middle of rows (overrides --slices) */
   int mixed_slices;    /* slices of other types inside a picture: I slices in P pictures, P and I slices in B pictures
                           (needs --slices >= 2) */
   int crop_left, crop_top; /* frame_crop_left / top_offset (two-sample units), taken out of the right / bottom padding */
@@ -1486,7 +1487,8 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
   size_t ssize = 0, scap = 0;
   const int nal_type = pp->type == 2 ? 5 : 1;
   const int ref_idc = pp->is_ref ? (pp->type == 2 ? 3 : 2) : 0;
-  const int nslices = imin(c->slices, mbh);
+  const int nmb_pic = mbw * mbh;
+  const int nslices = c->slice_mbs > 0 ? (nmb_pic + c->slice_mbs - 1) / c->slice_mbs : imin(c->slices, mbh);
   Marking mk;
   plan_marking(e, pp, &mk); /* from the DPB as it is before this picture; the same in every slice */
 
@@ -1512,13 +1514,15 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
   }
   for (int s = 0; s < nslices; ++s) {
     const int row0 = s * mbh / nslices, row1 = (s + 1) * mbh / nslices;
+    const int mb0 = c->slice_mbs > 0 ? s * c->slice_mbs : row0 * mbw;
+    const int mb1 = c->slice_mbs > 0 ? imin((s + 1) * c->slice_mbs, nmb_pic) : row1 * mbw;
     BitWriter* w = &e->w;
     w->pos = 0;
     /* --mixed-slices: every second slice of a P picture is an I slice; in a B picture the slices cycle B, P, I */
     int st = pp->type;
     if (c->mixed_slices && pp->type == 0 && (s & 1)) st = 2;
     if (c->mixed_slices && pp->type == 1) st = s % 3 == 0 ? 1 : s % 3 == 1 ? 0 : 2;
-    write_slice_header(e, w, pp, st, row0 * mbw, nrefs_l0, &mk);
+    write_slice_header(e, w, pp, st, mb0, nrefs_l0, &mk);
     /* let the oracle parse the header it will later be given: builds the
      * reference lists, POC, starts the picture */
     {
@@ -1530,7 +1534,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
       }
     }
     h264i_enc_begin_slice(d, w);
-    for (int addr = row0 * mbw; addr < row1 * mbw; ++addr) {
+    for (int addr = mb0; addr < mb1; ++addr) {
       MbPlan plan;
       memset(&plan, 0, sizeof(plan));
       h264i_begin_mb(d, addr);
@@ -1540,7 +1544,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
       if (st == 2) decide_intra(e, &plan, qp, 2);
       else if (st == 0) decide_p(e, &plan, qp, 1);
       else decide_b(e, &plan, qp);
-      if (h264i_enc_mb(d, w, addr, &plan, addr == row1 * mbw - 1) < 0) {
+      if (h264i_enc_mb(d, w, addr, &plan, addr == mb1 - 1) < 0) {
         fprintf(stderr, "encoder: %s\n", d->error);
         return -1;
       }
@@ -2003,6 +2007,7 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.slice_mbs = arg_int(argc, argv, "--slice-mbs", 0);
   c.mixed_slices = arg_int(argc, argv, "--mixed-slices", 0);
   c.crop_left = arg_int(argc, argv, "--crop-left", 0);
   c.crop_top = arg_int(argc, argv, "--crop-top", 0);

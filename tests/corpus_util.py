@@ -115,4 +115,9 @@ MATRIX = [
                                      wp_denom=4)),
     ("mixed_slices_temporal", dict(frames=13, gop=13, bframes=2, refs=3, slices=3, mixed_slices=1, temporal_direct=1,
                                    implicit_wp=1, deblock=2)),
+    # slice boundaries in the middle of macroblock rows (a new slice every N macroblocks), many small slices
+    ("slice_mbs37", dict(frames=10, gop=10, bframes=2, refs=3, slice_mbs=37)),
+    ("slice_mbs7_cavlc_idc2", dict(frames=8, gop=8, bframes=1, refs=2, slice_mbs=7, cabac=0, deblock=2, alpha=1, beta=-2)),
+    ("slice_mbs53_mixed", dict(frames=10, gop=10, bframes=2, refs=3, slice_mbs=53, mixed_slices=1, temporal_direct=1,
+                               implicit_wp=1)),
 ]
