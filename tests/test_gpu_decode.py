@@ -155,6 +155,21 @@ def test_left_top_cropping_rgb(hw, oracle, gpu, tmp_path):
         assert np.array_equal(got[k], oracle.i420_to_rgb(gold[r], 306, 226)), "row %d" % r
 
 
+def test_1080p_everything_at_once(hw, oracle, gpu, tmp_path):
+    """Full-size pictures (17 bands per row kernel) with the syntax variety of the small corpus cases combined:
+    reference B pictures, slices of mixed types cut in the middle of rows, two parameter sets that switch the
+    entropy coder, rate control, explicit weights, list modification."""
+    path = str(tmp_path / "hd_all.mp4")
+    gold = make_clip(path, width=1920, height=1080, frames=18, gop=9, bframes=3, refs=4, bpyramid=1, mixed_slices=1,
+                     slice_mbs=1777, multi_pps=2, rate_kbit=900, explicit_wp=1, wp_denom=5, rplm=1, threads=4)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=2)
+    rows = list(range(idx.frames()))
+    got = dec.retrieve_yuv(rows)
+    for r in rows:
+        assert np.array_equal(got[r], gold[r]), "frame %d" % r
+
+
 def test_many_lanes_random_rows_1080p(hw, gpu, tmp_path):
     """The concurrent machinery end to end: 8 lanes x 2 decoders, intra-only and
     P/B engines side by side, LRU surfaces, per-GOP work items - random rows of a
