@@ -2,6 +2,8 @@
 through the C ABI (libhwang_amd.so: host entropy decode + HIP kernels).  The
 bar is bit-exact I420 planes (H.264 reconstruction is integer arithmetic) and
 bit-exact RGB against the oracle's statement of the colour conversion."""
+import os
+
 import numpy as np
 import pytest
 
@@ -307,18 +309,30 @@ def test_expired_band_poll_fails_the_request(hw, gpu, tmp_path):
     assert "NO ERROR" in r.stdout, r.stdout + r.stderr
 
 
-def test_corrupt_streams_never_hang_the_gpu(hw, gpu, tmp_path):
+FUZZ_TRIALS = int(os.environ.get("HWANG_FUZZ_TRIALS", "120"))
+FUZZ_CLIPS = [
+    ("plain", dict(frames=12, gop=6, bframes=2, refs=3, slices=2, seed=5)),
+    ("pyramid_mixed", dict(frames=13, gop=13, bframes=3, refs=4, bpyramid=1, mixed_slices=1, slice_mbs=23, multi_pps=2,
+                           temporal_direct=1, implicit_wp=1, seed=6)),
+    ("cavlc_wp_mmco", dict(frames=14, gop=7, bframes=1, refs=4, cabac=0, explicit_wp=1, wp_denom=5, mmco=1, rplm=1, scaling=3,
+                           extra_nals=1, seed=7)),
+]
+
+
+@pytest.mark.parametrize("name,kw", FUZZ_CLIPS, ids=[c[0] for c in FUZZ_CLIPS])
+def test_corrupt_streams_never_hang_the_gpu(hw, gpu, tmp_path, name, kw):
     """Bit flips in slice data reach the kernels as absurd vectors, levels and modes (or are refused by the
     parser).  Either is fine; a hung or faulted GPU is not: every request returns, and the executor is still
     healthy afterwards (the pristine clip decodes bit-exactly through the same process)."""
     path = str(tmp_path / "fz.mp4")
-    gold = make_clip(path, width=176, height=144, frames=12, gop=6, bframes=2, refs=3, slices=2, seed=5)
+    gold = make_clip(path, width=176, height=144, **kw)
     idx = hw.index_video(path)
+    nf = idx.frames()
     data0 = np.fromfile(path, dtype=np.uint8)
     offs, sizes = idx.sample_offsets(), idx.sample_sizes()
     rng = np.random.default_rng(11)
     errors = decoded = 0
-    for trial in range(40):
+    for trial in range(FUZZ_TRIALS):
         data = data0.copy()
         for _ in range(1 + trial % 5):
             s = int(rng.integers(0, len(offs)))
@@ -328,13 +342,13 @@ def test_corrupt_streams_never_hang_the_gpu(hw, gpu, tmp_path):
         data.tofile(bad)
         dec = hw.Decoder(bad, video_index=idx, num_lanes=2)
         try:
-            out = dec.retrieve_yuv(list(range(12)))
-            assert len(out) == 12
+            out = dec.retrieve_yuv(list(range(nf)))
+            assert len(out) == nf
             decoded += 1
         except RuntimeError:
             errors += 1
         del dec
-    assert errors + decoded == 40
-    got = hw.Decoder(path, video_index=idx, num_lanes=2).retrieve_yuv(list(range(12)))
-    for i in range(12):
+    assert errors + decoded == FUZZ_TRIALS
+    got = hw.Decoder(path, video_index=idx, num_lanes=2).retrieve_yuv(list(range(nf)))
+    for i in range(nf):
         assert np.array_equal(got[i], gold[i])
