@@ -48,7 +48,12 @@ def test_address_and_ub_sanitizer(built, tmp_path):
     for i, kw in enumerate([dict(frames=7, gop=7, bframes=2, cabac=1, t8x8=1, refs=2, width=96, height=64),
                             dict(frames=6, gop=3, bframes=1, cabac=0, t8x8=0, refs=2, width=64, height=48, slices=2),
                             dict(frames=8, gop=8, bframes=0, refs=3, mmco=1, rplm=1, explicit_wp=1, scaling=3, width=80,
-                                 height=64, fragmented=1)]):
+                                 height=64, fragmented=1),
+                            dict(frames=13, gop=13, bframes=3, refs=4, bpyramid=1, mixed_slices=1, slice_mbs=5, multi_pps=2,
+                                 temporal_direct=1, implicit_wp=1, fn_bits=4, poc_bits=5, extra_nals=1, nal_length_size=2,
+                                 width=96, height=80),
+                            dict(frames=12, gop=6, bframes=2, refs=3, poc_type=1, constrained_intra=1, direct8x8=0,
+                                 rate_kbit=3, crop_left=3, crop_top=2, width=90, height=70, cabac=0)]):
         p = str(tmp_path / ("c%d.mp4" % i))
         make_clip(p, yuv=False, **kw)
         clips.append(p)
