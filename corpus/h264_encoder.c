@@ -1037,6 +1037,10 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
   }
   copy_motion_from_state(d, p);
   p->mb_type_raw = shape == 0 ? 0 : (shape == 1 ? 1 : (shape == 2 ? 2 : 3));
+  /* P_8x8ref0 (CAVLC only, 7.4.5): four quadrants that all use reference 0 need no ref_idx at all - every other time */
+  if (shape == 3 && !d->apps->cabac && d->sl.num_ref_idx[0] > 1 && p->ref[0][0] == 0 && p->ref[0][1] == 0 && p->ref[0][2] == 0 &&
+      p->ref[0][3] == 0 && ((hv >> 7) & 1))
+    p->mb_type_raw = 4;
   h264i_inter_pred_mb(d);
   int sub8 = 1;
   if (shape == 3)
