@@ -1109,16 +1109,30 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
         else p->sub_type[q] = uses0 && uses1 ? 3 : (uses0 ? 1 : 2);
       }
       /* explicit 8x8 sub-blocks need one vector: take the direct one of
-       * their first 4x4 */
+       * their first 4x4; every third explicit quadrant is split further (8x4, 4x8, 4x4: sub_mb_type 4..12) with
+       * slightly different vectors per part, the same in both lists it uses */
       for (int q = 0; q < 4; ++q)
         if (p->sub_type[q]) {
           int k0 = ((q >> 1) * 2) * 4 + (q & 1) * 2;
+          const uint32_t hs = hash3((uint32_t)e->cfg->seed + 17, hv, (uint32_t)q);
+          const int split = hs % 3 == 0 ? 1 + (int)((hs >> 3) % 3) : 0; /* 0 8x8, 1 8x4, 2 4x8, 3 4x4 */
           for (int l = 0; l < 2; ++l)
             for (int s = 0; s < 4; ++s) {
               int k = ((q >> 1) * 2 + (s >> 1)) * 4 + (q & 1) * 2 + (s & 1);
-              d->mb.mv[l][k][0] = d->mb.mv[l][k0][0];
-              d->mb.mv[l][k][1] = d->mb.mv[l][k0][1];
+              int jx = 0, jy = 0;
+              /* the part a 4x4 block belongs to: 8x4 -> its row, 4x8 -> its column, 4x4 -> itself */
+              const int part = split == 1 ? (s >> 1) : split == 2 ? (s & 1) : split == 3 ? s : 0;
+              if (part) {
+                jx = (int)((hs >> (6 + 2 * part)) & 3) - 1;
+                jy = (int)((hs >> (14 + 2 * part)) & 3) - 1;
+              }
+              d->mb.mv[l][k][0] = (int16_t)(d->mb.mv[l][k0][0] + (s ? jx : 0));
+              d->mb.mv[l][k][1] = (int16_t)(d->mb.mv[l][k0][1] + (s ? jy : 0));
             }
+          if (split) { /* L0 / L1 / Bi 8x8 (1, 2, 3) -> 8x4 (4, 6, 8), 4x8 (5, 7, 9), 4x4 (10, 11, 12) */
+            const int t = p->sub_type[q];
+            p->sub_type[q] = split == 3 ? 9 + t : 2 + 2 * t + (split == 2 ? 1 : 0);
+          }
         }
       copy_motion_from_state(d, p);
     } else {
