@@ -32,6 +32,8 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int qp_swing;        /* every few macroblocks the QP jumps anywhere in 0..51: large mb_qp_delta values, incl. the ones that
+                          only fit the -26..25 range by wrapping around 52 */
   int slice_mbs;       /* > 0: a new slice every so many macroblocks - boundaries in the middle of rows (overrides --slices) */
   int mixed_slices;    /* slices of other types inside a picture: I slices in P pictures, P and I slices in B pictures
                           (needs --slices >= 2) */
@@ -1559,6 +1561,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
       int qp = c->rate_kbit > 0 ? e->rc_qp : c->qp;
       uint32_t hq = hash3((uint32_t)c->seed + 3, (uint32_t)e->frame_abs, (uint32_t)addr);
       if (hq % 9 == 0) qp = iclip(10, 48, qp + (int)((hq >> 4) % 5) - 2);
+      if (c->qp_swing && hq % 7 == 3) qp = (int)((hq >> 8) % 52);
       if (st == 2) decide_intra(e, &plan, qp, 2);
       else if (st == 0) decide_p(e, &plan, qp, 1);
       else decide_b(e, &plan, qp);
@@ -2025,6 +2028,7 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.qp_swing = arg_int(argc, argv, "--qp-swing", 0);
   c.slice_mbs = arg_int(argc, argv, "--slice-mbs", 0);
   c.mixed_slices = arg_int(argc, argv, "--mixed-slices", 0);
   c.crop_left = arg_int(argc, argv, "--crop-left", 0);

@@ -120,4 +120,8 @@ MATRIX = [
     ("slice_mbs7_cavlc_idc2", dict(frames=8, gop=8, bframes=1, refs=2, slice_mbs=7, cabac=0, deblock=2, alpha=1, beta=-2)),
     ("slice_mbs53_mixed", dict(frames=10, gop=10, bframes=2, refs=3, slice_mbs=53, mixed_slices=1, temporal_direct=1,
                                implicit_wp=1)),
+    # the QP jumping anywhere in 0..51 every few macroblocks: mb_qp_delta up to the wrap-around, QP 0 levels that need
+    # the escape codes, chroma QP table ends
+    ("qp_swing_cabac", dict(frames=10, gop=10, bframes=2, refs=2, qp_swing=1)),
+    ("qp_swing_cavlc", dict(frames=8, gop=8, bframes=1, refs=2, qp_swing=1, cabac=0, chroma_qp_offset=5, scaling=3)),
 ]
