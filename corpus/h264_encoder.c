@@ -32,6 +32,8 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  int wild_mv;         /* now and then a P macroblock takes a vector hundreds of samples long, mostly to somewhere outside the
+                          reference picture: long mvd codes, prediction from clamped coordinates only */
   int qp_swing;        /* every few macroblocks the QP jumps anywhere in 0..51: large mb_qp_delta values, incl. the ones that
                           only fit the -26..25 range by wrapping around 52 */
   int slice_mbs;       /* > 0: a new slice every so many macroblocks - boundaries in the middle of rows (overrides --slices) */
@@ -975,6 +977,12 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
     h264i_begin_mb(d, addr);
   }
 
+  if (e->cfg->wild_mv && hv % 17 == 5) {
+    br = (int)((hv >> 3) % (uint32_t)nref);
+    bx = (int)((hv >> 5) % 3999) - 1999;
+    by = (int)((hv >> 17) % 1999) - 999;
+    bc = 0; /* keep it one 16x16 partition */
+  }
   p->kind = MB_INTER;
   int shape = 0; /* 0 16x16, 1 16x8, 2 8x16, 3 8x8 */
   set_all_motion(&d->mb, 0, br, bx, by);
@@ -2028,6 +2036,7 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.wild_mv = arg_int(argc, argv, "--wild-mv", 0);
   c.qp_swing = arg_int(argc, argv, "--qp-swing", 0);
   c.slice_mbs = arg_int(argc, argv, "--slice-mbs", 0);
   c.mixed_slices = arg_int(argc, argv, "--mixed-slices", 0);

@@ -124,4 +124,7 @@ MATRIX = [
     # the escape codes, chroma QP table ends
     ("qp_swing_cabac", dict(frames=10, gop=10, bframes=2, refs=2, qp_swing=1)),
     ("qp_swing_cavlc", dict(frames=8, gop=8, bframes=1, refs=2, qp_swing=1, cabac=0, chroma_qp_offset=5, scaling=3)),
+    # vectors hundreds of samples long, mostly pointing outside the reference picture (edge clamping only; long mvd codes)
+    ("wild_mv_p", dict(frames=10, gop=10, bframes=0, refs=3, wild_mv=1)),
+    ("wild_mv_b_cavlc", dict(frames=10, gop=10, bframes=2, refs=2, wild_mv=1, cabac=0, explicit_wp=1, wp_denom=6)),
 ]
