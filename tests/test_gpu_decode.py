@@ -55,6 +55,14 @@ BAND_SIZES = [
     ("wide_130x7mb_slices", 2080, 112, dict(frames=5, gop=5, bframes=0, slices=4)),
     ("wide_257x3mb", 4112, 48, dict(frames=5, gop=5, bframes=1)),
     ("wide_258x6mb_slices", 4128, 96, dict(frames=4, gop=4, bframes=0, slices=3)),
+    # the same edges with the syntax variety added in round 2: mixed slice types cut mid-row, reference B pictures,
+    # two parameter sets, wild vectors, QP swings
+    ("wide_257x5mb_mixed", 4112, 80, dict(frames=7, gop=7, bframes=2, refs=4, bpyramid=0, mixed_slices=1, slice_mbs=301,
+                                            multi_pps=2, wild_mv=1, qp_swing=1)),
+    ("wide_131x9mb_pyramid", 2096, 144, dict(frames=9, gop=9, bframes=3, refs=4, bpyramid=1, slice_mbs=97, mixed_slices=1,
+                                              temporal_direct=1, implicit_wp=1, rate_kbit=60)),
+    ("7x7mb_everything", 112, 112, dict(frames=13, gop=13, bframes=3, refs=4, bpyramid=1, slice_mbs=5, mixed_slices=1,
+                                          multi_pps=2, wild_mv=1, qp_swing=1, fn_bits=4, poc_bits=5, extra_nals=1)),
 ]
 
 
