@@ -32,6 +32,12 @@ typedef struct {
   int wp_denom;     /* luma_log2_weight_denom (chroma uses a different one) */
   int rplm;         /* ref_pic_list_modification on a hash-chosen subset of slices */
   int mmco;         /* 1: adaptive marking script (ops 1,2,3,4,6, long-term IDR); 2: also op 5 (needs bframes 0) */
+  /* container variants (not fragmented): */
+  int moov_last;       /* ftyp, mdat, moov - the layout of files that were not "fast-started" */
+  int free_boxes;      /* a free box between ftyp and what follows, a uuid box at the end of the file */
+  int large_mdat;      /* mdat with a 64-bit size field whatever its size */
+  int audio_track;     /* a second track (handler 'soun', own sample tables, its samples behind the video's in mdat) in front
+                          of the video track */
   int wild_mv;         /* now and then a P macroblock takes a vector hundreds of samples long, mostly to somewhere outside the
                           reference picture: long mvd codes, prediction from clamped coordinates only */
   int qp_swing;        /* every few macroblocks the QP jumps anywhere in 0..51: large mb_qp_delta values, incl. the ones that
@@ -1759,6 +1765,60 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
     bzero_(m, 24); b32(m, 2);
     box_end(m, a);
   }
+  if (c->audio_track) { /* n four-byte "audio" samples in one chunk behind the video payload */
+    uint64_t vbytes = 0;
+    for (size_t i = 0; i < n; ++i) vbytes += sizes[i];
+    size_t t = box_begin(m, "trak");
+    size_t a = box_begin(m, "tkhd");
+    b32(m, 3); b32(m, 0); b32(m, 0); b32(m, 2); b32(m, 0); b32(m, (uint32_t)(n * delta));
+    bzero_(m, 8); b16(m, 0); b16(m, 1); b16(m, 0x0100); b16(m, 0);
+    const uint32_t amat[9] = {0x10000, 0, 0, 0, 0x10000, 0, 0, 0, 0x40000000};
+    for (int i = 0; i < 9; ++i) b32(m, amat[i]);
+    b32(m, 0); b32(m, 0);
+    box_end(m, a);
+    size_t md = box_begin(m, "mdia");
+    a = box_begin(m, "mdhd");
+    b32(m, 0); b32(m, 0); b32(m, 0); b32(m, 48000); b32(m, (uint32_t)(n * 1024)); b16(m, 0x55c4); b16(m, 0);
+    box_end(m, a);
+    a = box_begin(m, "hdlr");
+    b32(m, 0); b32(m, 0); bput(m, "soun", 4); bzero_(m, 12); bput(m, "SoundHandler", 13);
+    box_end(m, a);
+    size_t mi = box_begin(m, "minf");
+    a = box_begin(m, "smhd");
+    b32(m, 0); b32(m, 0);
+    box_end(m, a);
+    a = box_begin(m, "dinf");
+    size_t d2 = box_begin(m, "dref");
+    b32(m, 0); b32(m, 1);
+    size_t u = box_begin(m, "url ");
+    b32(m, 1);
+    box_end(m, u);
+    box_end(m, d2);
+    box_end(m, a);
+    size_t st = box_begin(m, "stbl");
+    a = box_begin(m, "stsd");
+    b32(m, 0); b32(m, 1);
+    size_t en = box_begin(m, "mp4a");
+    bzero_(m, 6); b16(m, 1); bzero_(m, 8); b16(m, 2); b16(m, 16); b32(m, 0); b32(m, 48000u << 16);
+    box_end(m, en);
+    box_end(m, a);
+    a = box_begin(m, "stts");
+    b32(m, 0); b32(m, 1); b32(m, (uint32_t)n); b32(m, 1024);
+    box_end(m, a);
+    a = box_begin(m, "stsc");
+    b32(m, 0); b32(m, 1); b32(m, 1); b32(m, (uint32_t)n); b32(m, 1);
+    box_end(m, a);
+    a = box_begin(m, "stsz");
+    b32(m, 0); b32(m, 4); b32(m, (uint32_t)n);
+    box_end(m, a);
+    a = box_begin(m, "stco");
+    b32(m, 0); b32(m, 1); b32(m, (uint32_t)(mdat_payload_offset + vbytes));
+    box_end(m, a);
+    box_end(m, st);
+    box_end(m, mi);
+    box_end(m, md);
+    box_end(m, t);
+  }
   size_t trak = box_begin(m, "trak");
   {
     size_t a = box_begin(m, "tkhd");
@@ -2036,6 +2096,10 @@ int main(int argc, char** argv) {
   c.co64 = arg_int(argc, argv, "--co64", 0);
   c.stz2 = arg_int(argc, argv, "--stz2", 0);
   c.rate_kbit = arg_int(argc, argv, "--rate-kbit", 0);
+  c.moov_last = arg_int(argc, argv, "--moov-last", 0);
+  c.free_boxes = arg_int(argc, argv, "--free-boxes", 0);
+  c.large_mdat = arg_int(argc, argv, "--large-mdat", 0);
+  c.audio_track = arg_int(argc, argv, "--audio-track", 0);
   c.wild_mv = arg_int(argc, argv, "--wild-mv", 0);
   c.qp_swing = arg_int(argc, argv, "--qp-swing", 0);
   c.slice_mbs = arg_int(argc, argv, "--slice-mbs", 0);
@@ -2135,10 +2199,17 @@ int main(int argc, char** argv) {
   }
   /* moov's size does not depend on the chunk offset's value, only on its
    * width: build once to learn the size, then for real */
-  const int big = payload + head.n + (size_t)n * 16 + 4096 > 0xfffffff0ULL;
+  if (c.free_boxes) {
+    size_t a = box_begin(&head, "free");
+    bzero_(&head, 24);
+    box_end(&head, a);
+  }
+  const uint64_t audio_bytes = c.audio_track ? (uint64_t)n * 4 : 0;
+  const int really_big = payload + audio_bytes + head.n + (size_t)n * 16 + 4096 > 0xfffffff0ULL;
+  const int big = c.large_mdat || really_big; /* a forced 64-bit mdat size does not make the chunk offsets 64-bit */
   Buf moov = {0};
-  build_moov(&moov, &c, avcc, avcc_len, sizes, keys, cts, n, big ? 0x100000000ULL : 0, c.bframes > 0);
-  const uint64_t off = head.n + moov.n + (big ? 16 : 8);
+  build_moov(&moov, &c, avcc, avcc_len, sizes, keys, cts, n, really_big ? 0x100000000ULL : 0, c.bframes > 0);
+  const uint64_t off = head.n + (c.moov_last ? 0 : moov.n) + (big ? 16 : 8);
   moov.n = 0;
   build_moov(&moov, &c, avcc, avcc_len, sizes, keys, cts, n, off, c.bframes > 0);
   FILE* f = fopen(c.out, "wb");
@@ -2147,7 +2218,7 @@ int main(int argc, char** argv) {
     return 1;
   }
   fwrite(head.b, 1, head.n, f);
-  fwrite(moov.b, 1, moov.n, f);
+  if (!c.moov_last || c.fragmented) fwrite(moov.b, 1, moov.n, f);
   if (c.fragmented) {
     /* one moof + mdat per GOP (DASH-style); sizes / keys / cts are indexed in decode order */
     uint64_t at = head.n + moov.n;
@@ -2172,16 +2243,27 @@ int main(int argc, char** argv) {
   }
   if (big) {
     Buf h = {0};
-    b32(&h, 1); bput(&h, "mdat", 4); b64(&h, payload + 16);
+    b32(&h, 1); bput(&h, "mdat", 4); b64(&h, payload + audio_bytes + 16);
     fwrite(h.b, 1, h.n, f);
   } else {
     Buf h = {0};
-    b32(&h, (uint32_t)(payload + 8)); bput(&h, "mdat", 4);
+    b32(&h, (uint32_t)(payload + audio_bytes + 8)); bput(&h, "mdat", 4);
     fwrite(h.b, 1, h.n, f);
   }
   for (int rep = 0; rep < c.repeat; ++rep)
     for (int g = 0; g < wk.ngops; ++g)
       for (int i = 0; i < wk.gops[g].count; ++i) fwrite(wk.gops[g].samples[i].data, 1, wk.gops[g].samples[i].size, f);
+  for (uint64_t i = 0; i < audio_bytes; ++i) fputc((int)(0xa0 + (i & 15)), f);
+  if (c.moov_last) fwrite(moov.b, 1, moov.n, f);
+  if (c.free_boxes) {
+    Buf u = {0};
+    size_t a = box_begin(&u, "uuid");
+    bput(&u, "hwang-corpus-box", 16);
+    b64(&u, 0x0123456789abcdefULL);
+    box_end(&u, a);
+    fwrite(u.b, 1, u.n, f);
+    free(u.b);
+  }
   fclose(f);
 wrote:
 

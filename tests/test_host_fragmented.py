@@ -115,3 +115,37 @@ def test_co64_and_stz2_match_the_reference(hw, oracle, tmp_path, kw):
     assert not ref["error"]
     assert ref["sample_offsets"] == idx.sample_offsets() and ref["sample_sizes"] == idx.sample_sizes()
     assert ref["keyframes"] == idx.keyframe_indices() and ref["trace"] == pull_trace(hw, path)
+
+
+LAYOUTS = [
+    ("moov_last", dict(moov_last=1)),
+    ("free_and_uuid_boxes", dict(free_boxes=1)),
+    ("mdat_64bit_size", dict(large_mdat=1)),
+    ("audio_track_first", dict(audio_track=1)),
+    ("all_of_them_co64", dict(moov_last=1, free_boxes=1, large_mdat=1, audio_track=1, co64=1)),
+    ("audio_track_stz2", dict(audio_track=1, stz2=1, free_boxes=1)),
+]
+
+
+@pytest.mark.parametrize("name,kw", LAYOUTS, ids=[l[0] for l in LAYOUTS])
+def test_file_layouts_match_the_reference(hw, oracle, tmp_path, name, kw):
+    """Files as muxers leave them when nobody "fast-starts" them (moov behind mdat), with padding and vendor boxes,
+    a 64-bit mdat size, a sound track in front of the video track: index, extradata and the pull protocol's
+    (offset, size) trace equal the reference indexer's, and frames decode from the index."""
+    path = str(tmp_path / "v.mp4")
+    gold = make_clip(path, frames=12, gop=6, bframes=1, **kw)
+    idx = hw.index_video(path)
+    assert idx.frames() == 12 and idx.keyframe_indices() == [0, 6]
+    assert (idx.frame_width(), idx.frame_height(), idx.format()) == (320, 240, "avc1")
+    frames, c = oracle.decode_file(path, idx)
+    assert c["slices_clean_end"] == c["slices"] and len(frames) == 12
+    assert np.array_equal(frames[11][0], gold[11]) and np.array_equal(frames[0][0], gold[0])
+    if not os.path.exists(REF_BIN):
+        pytest.skip("reference indexer not built here")
+    ref = json.loads(subprocess.check_output([REF_BIN, path]))
+    assert not ref["error"]
+    assert ref["sample_offsets"] == idx.sample_offsets() and ref["sample_sizes"] == idx.sample_sizes()
+    assert ref["keyframes"] == idx.keyframe_indices() and ref["metadata"] == idx.metadata_bytes().hex()
+    assert (ref["timescale"], ref["duration"], ref["width"], ref["height"], ref["format"]) == (
+        idx.timescale(), idx.duration(), idx.frame_width(), idx.frame_height(), idx.format())
+    assert ref["trace"] == pull_trace(hw, path)
