@@ -38,6 +38,8 @@ typedef struct {
   int large_mdat;      /* mdat with a 64-bit size field whatever its size */
   int audio_track;     /* a second track (handler 'soun', own sample tables, its samples behind the video's in mdat) in front
                           of the video track */
+  int chunk_samples;   /* > 0: chunks of this many samples (every third chunk one more), the sound track's chunks between
+                          them: several stsc runs, one chunk offset per chunk with gaps */
   int wild_mv;         /* now and then a P macroblock takes a vector hundreds of samples long, mostly to somewhere outside the
                           reference picture: long mvd codes, prediction from clamped coordinates only */
   int qp_swing;        /* every few macroblocks the QP jumps anywhere in 0..51: large mb_qp_delta values, incl. the ones that
@@ -1751,6 +1753,13 @@ static void bzero_(Buf* b, size_t n) {
   }
 }
 
+/* samples in chunk k of the video track (--chunk-samples; 0 = everything in one chunk) */
+static size_t chunk_len(const Cfg* c, size_t k, size_t first, size_t n) {
+  if (c->chunk_samples <= 0) return n;
+  const size_t want = (size_t)c->chunk_samples + (k % 3 == 2 ? 1 : 0);
+  return first + want > n ? n - first : want;
+}
+
 /* sizes[], keys[], cts_off[] per sample in decode order */
 static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_len, const uint32_t* sizes,
                        const uint8_t* keys, const int32_t* cts, size_t n, uint64_t mdat_payload_offset, int has_b) {
@@ -1805,15 +1814,46 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
     a = box_begin(m, "stts");
     b32(m, 0); b32(m, 1); b32(m, (uint32_t)n); b32(m, 1024);
     box_end(m, a);
-    a = box_begin(m, "stsc");
-    b32(m, 0); b32(m, 1); b32(m, 1); b32(m, (uint32_t)n); b32(m, 1);
-    box_end(m, a);
-    a = box_begin(m, "stsz");
-    b32(m, 0); b32(m, 4); b32(m, (uint32_t)n);
-    box_end(m, a);
-    a = box_begin(m, "stco");
-    b32(m, 0); b32(m, 1); b32(m, (uint32_t)(mdat_payload_offset + vbytes));
-    box_end(m, a);
+    if (c->chunk_samples > 0) { /* one sound chunk behind every video chunk, as many samples as that one has */
+      size_t nch = 0;
+      for (size_t f = 0, k = 0; f < n; f += chunk_len(c, k, f, n), ++k) ++nch;
+      a = box_begin(m, "stsc");
+      size_t cnt_at = m->n + 4;
+      b32(m, 0); b32(m, 0);
+      uint32_t runs = 0;
+      size_t prev = 0;
+      for (size_t f = 0, k = 0; f < n; ++k) {
+        const size_t len = chunk_len(c, k, f, n);
+        if (len != prev) { b32(m, (uint32_t)k + 1); b32(m, (uint32_t)len); b32(m, 1); ++runs; prev = len; }
+        f += len;
+      }
+      m->b[cnt_at] = (uint8_t)(runs >> 24); m->b[cnt_at + 1] = (uint8_t)(runs >> 16); m->b[cnt_at + 2] = (uint8_t)(runs >> 8); m->b[cnt_at + 3] = (uint8_t)runs;
+      box_end(m, a);
+      a = box_begin(m, "stsz");
+      b32(m, 0); b32(m, 4); b32(m, (uint32_t)n);
+      box_end(m, a);
+      a = box_begin(m, "stco");
+      b32(m, 0); b32(m, (uint32_t)nch);
+      uint64_t at = mdat_payload_offset;
+      for (size_t f = 0, k = 0; f < n; ++k) {
+        const size_t len = chunk_len(c, k, f, n);
+        for (size_t i = 0; i < len; ++i) at += sizes[f + i];
+        b32(m, (uint32_t)at);
+        at += 4 * len;
+        f += len;
+      }
+      box_end(m, a);
+    } else {
+      a = box_begin(m, "stsc");
+      b32(m, 0); b32(m, 1); b32(m, 1); b32(m, (uint32_t)n); b32(m, 1);
+      box_end(m, a);
+      a = box_begin(m, "stsz");
+      b32(m, 0); b32(m, 4); b32(m, (uint32_t)n);
+      box_end(m, a);
+      a = box_begin(m, "stco");
+      b32(m, 0); b32(m, 1); b32(m, (uint32_t)(mdat_payload_offset + vbytes));
+      box_end(m, a);
+    }
     box_end(m, st);
     box_end(m, mi);
     box_end(m, md);
@@ -1884,8 +1924,21 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
     for (size_t i = 0; i < n; ++i) if (keys[i]) b32(m, (uint32_t)i + 1);
     box_end(m, a);
     a = box_begin(m, "stsc");
-    b32(m, 0); b32(m, n ? 1 : 0);
-    if (n) { b32(m, 1); b32(m, (uint32_t)n); b32(m, 1); }
+    if (c->chunk_samples > 0 && n) {
+      size_t cnt_at = m->n + 4;
+      b32(m, 0); b32(m, 0);
+      uint32_t runs = 0;
+      size_t prev = 0;
+      for (size_t f = 0, k = 0; f < n; ++k) {
+        const size_t len = chunk_len(c, k, f, n);
+        if (len != prev) { b32(m, (uint32_t)k + 1); b32(m, (uint32_t)len); b32(m, 1); ++runs; prev = len; }
+        f += len;
+      }
+      m->b[cnt_at] = (uint8_t)(runs >> 24); m->b[cnt_at + 1] = (uint8_t)(runs >> 16); m->b[cnt_at + 2] = (uint8_t)(runs >> 8); m->b[cnt_at + 3] = (uint8_t)runs;
+    } else {
+      b32(m, 0); b32(m, n ? 1 : 0);
+      if (n) { b32(m, 1); b32(m, (uint32_t)n); b32(m, 1); }
+    }
     box_end(m, a);
     int fits16 = c->stz2;
     for (size_t i = 0; i < n; ++i) fits16 &= sizes[i] < 65536;
@@ -1899,16 +1952,26 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
       for (size_t i = 0; i < n; ++i) b32(m, sizes[i]);
     }
     box_end(m, a);
-    if (mdat_payload_offset > 0xfffffff0ULL || c->co64) {
-      a = box_begin(m, "co64");
-      b32(m, 0); b32(m, n ? 1 : 0);
-      if (n) b64(m, mdat_payload_offset);
-    } else {
-      a = box_begin(m, "stco");
-      b32(m, 0); b32(m, n ? 1 : 0);
-      if (n) b32(m, (uint32_t)mdat_payload_offset);
+    {
+      const int wide = mdat_payload_offset > 0xfffffff0ULL || c->co64;
+      size_t nch = n ? 1 : 0;
+      if (c->chunk_samples > 0 && n) {
+        nch = 0;
+        for (size_t f = 0, k = 0; f < n; f += chunk_len(c, k, f, n), ++k) ++nch;
+      }
+      a = box_begin(m, wide ? "co64" : "stco");
+      b32(m, 0); b32(m, (uint32_t)nch);
+      uint64_t at = mdat_payload_offset;
+      for (size_t f = 0, k = 0; f < n && k < nch; ++k) {
+        const size_t len = chunk_len(c, k, f, n);
+        if (wide) b64(m, at);
+        else b32(m, (uint32_t)at);
+        for (size_t i = 0; i < len; ++i) at += sizes[f + i];
+        if (c->audio_track && c->chunk_samples > 0) at += 4 * len; /* the sound chunk in between */
+        f += len;
+      }
+      box_end(m, a);
     }
-    box_end(m, a);
   }
   box_end(m, stbl);
   box_end(m, minf);
@@ -2100,6 +2163,7 @@ int main(int argc, char** argv) {
   c.free_boxes = arg_int(argc, argv, "--free-boxes", 0);
   c.large_mdat = arg_int(argc, argv, "--large-mdat", 0);
   c.audio_track = arg_int(argc, argv, "--audio-track", 0);
+  c.chunk_samples = arg_int(argc, argv, "--chunk-samples", 0);
   c.wild_mv = arg_int(argc, argv, "--wild-mv", 0);
   c.qp_swing = arg_int(argc, argv, "--qp-swing", 0);
   c.slice_mbs = arg_int(argc, argv, "--slice-mbs", 0);
@@ -2250,10 +2314,24 @@ int main(int argc, char** argv) {
     b32(&h, (uint32_t)(payload + audio_bytes + 8)); bput(&h, "mdat", 4);
     fwrite(h.b, 1, h.n, f);
   }
-  for (int rep = 0; rep < c.repeat; ++rep)
-    for (int g = 0; g < wk.ngops; ++g)
-      for (int i = 0; i < wk.gops[g].count; ++i) fwrite(wk.gops[g].samples[i].data, 1, wk.gops[g].samples[i].size, f);
-  for (uint64_t i = 0; i < audio_bytes; ++i) fputc((int)(0xa0 + (i & 15)), f);
+  {
+    size_t k = 0, in_chunk = 0, first = 0, s_index = 0;
+    size_t len = chunk_len(&c, 0, 0, n);
+    for (int rep = 0; rep < c.repeat; ++rep)
+      for (int g = 0; g < wk.ngops; ++g)
+        for (int i = 0; i < wk.gops[g].count; ++i, ++s_index) {
+          fwrite(wk.gops[g].samples[i].data, 1, wk.gops[g].samples[i].size, f);
+          if (++in_chunk == len && c.chunk_samples > 0) { /* chunk complete: its sound chunk follows */
+            if (c.audio_track)
+              for (size_t b = 0; b < 4 * len; ++b) fputc((int)(0xa0 + (b & 15)), f);
+            first += len;
+            len = chunk_len(&c, ++k, first, n);
+            in_chunk = 0;
+          }
+        }
+    if (c.audio_track && c.chunk_samples <= 0)
+      for (uint64_t i = 0; i < audio_bytes; ++i) fputc((int)(0xa0 + (i & 15)), f);
+  }
   if (c.moov_last) fwrite(moov.b, 1, moov.n, f);
   if (c.free_boxes) {
     Buf u = {0};

@@ -124,6 +124,10 @@ LAYOUTS = [
     ("audio_track_first", dict(audio_track=1)),
     ("all_of_them_co64", dict(moov_last=1, free_boxes=1, large_mdat=1, audio_track=1, co64=1)),
     ("audio_track_stz2", dict(audio_track=1, stz2=1, free_boxes=1)),
+    # chunks of 3-4 / 5-6 samples (several stsc runs), the sound track's chunks interleaved: one offset per chunk, with gaps
+    ("chunks4", dict(chunk_samples=4)),
+    ("chunks3_interleaved_audio", dict(chunk_samples=3, audio_track=1)),
+    ("chunks5_interleaved_moov_last_co64_stz2", dict(chunk_samples=5, audio_track=1, moov_last=1, co64=1, stz2=1)),
 ]
 
 
@@ -136,6 +140,9 @@ def test_file_layouts_match_the_reference(hw, oracle, tmp_path, name, kw):
     gold = make_clip(path, frames=12, gop=6, bframes=1, **kw)
     idx = hw.index_video(path)
     assert idx.frames() == 12 and idx.keyframe_indices() == [0, 6]
+    offs, sizes = idx.sample_offsets(), idx.sample_sizes()
+    if kw.get("audio_track") and kw.get("chunk_samples"):  # the sound chunks leave gaps between the video chunks
+        assert any(offs[i + 1] != offs[i] + sizes[i] for i in range(11))
     assert (idx.frame_width(), idx.frame_height(), idx.format()) == (320, 240, "avc1")
     frames, c = oracle.decode_file(path, idx)
     assert c["slices_clean_end"] == c["slices"] and len(frames) == 12
