@@ -38,6 +38,7 @@ typedef struct {
   int large_mdat;      /* mdat with a 64-bit size field whatever its size */
   int audio_track;     /* a second track (handler 'soun', own sample tables, its samples behind the video's in mdat) in front
                           of the video track */
+  int no_stss;         /* leave the sync sample box out when every sample is one (--gop 1) */
   int chunk_samples;   /* > 0: chunks of this many samples (every third chunk one more), the sound track's chunks between
                           them: several stsc runs, one chunk offset per chunk with gaps */
   int wild_mv;         /* now and then a P macroblock takes a vector hundreds of samples long, mostly to somewhere outside the
@@ -1917,12 +1918,14 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
       for (size_t i = 0; i < n; ++i) { b32(m, 1); b32(m, (uint32_t)(cts[i] * (int32_t)delta)); }
       box_end(m, a);
     }
-    a = box_begin(m, "stss");
     uint32_t nk = 0;
     for (size_t i = 0; i < n; ++i) nk += keys[i];
-    b32(m, 0); b32(m, nk);
-    for (size_t i = 0; i < n; ++i) if (keys[i]) b32(m, (uint32_t)i + 1);
-    box_end(m, a);
+    if (!(c->no_stss && nk == n)) { /* --no-stss: an all-intra track may leave the box out (every sample is a sync sample) */
+      a = box_begin(m, "stss");
+      b32(m, 0); b32(m, nk);
+      for (size_t i = 0; i < n; ++i) if (keys[i]) b32(m, (uint32_t)i + 1);
+      box_end(m, a);
+    }
     a = box_begin(m, "stsc");
     if (c->chunk_samples > 0 && n) {
       size_t cnt_at = m->n + 4;
@@ -2163,6 +2166,7 @@ int main(int argc, char** argv) {
   c.free_boxes = arg_int(argc, argv, "--free-boxes", 0);
   c.large_mdat = arg_int(argc, argv, "--large-mdat", 0);
   c.audio_track = arg_int(argc, argv, "--audio-track", 0);
+  c.no_stss = arg_int(argc, argv, "--no-stss", 0);
   c.chunk_samples = arg_int(argc, argv, "--chunk-samples", 0);
   c.wild_mv = arg_int(argc, argv, "--wild-mv", 0);
   c.qp_swing = arg_int(argc, argv, "--qp-swing", 0);

@@ -156,3 +156,21 @@ def test_file_layouts_match_the_reference(hw, oracle, tmp_path, name, kw):
     assert (ref["timescale"], ref["duration"], ref["width"], ref["height"], ref["format"]) == (
         idx.timescale(), idx.duration(), idx.frame_width(), idx.frame_height(), idx.format())
     assert ref["trace"] == pull_trace(hw, path)
+
+
+def test_all_intra_track_without_stss(hw, oracle, tmp_path):
+    """No sync sample box: every sample is a keyframe (mp4_index_creator.cpp:413-417) - and every frame its own interval."""
+    path = str(tmp_path / "intra.mp4")
+    gold = make_clip(path, frames=7, gop=1, bframes=0, no_stss=1, chunk_samples=3)
+    assert b"stss" not in open(path, "rb").read()
+    idx = hw.index_video(path)
+    assert idx.keyframe_indices() == list(range(7))
+    plan = hw.slice_into_video_intervals(idx, [2, 5])
+    assert [iv for iv, _ in plan] == [(2, 3), (5, 6)]
+    frames, _ = oracle.decode_file(path, idx)
+    assert np.array_equal(frames[6][0], gold[6])
+    if not os.path.exists(REF_BIN):
+        pytest.skip("reference indexer not built here")
+    ref = json.loads(subprocess.check_output([REF_BIN, path]))
+    assert not ref["error"] and ref["keyframes"] == idx.keyframe_indices()
+    assert ref["sample_offsets"] == idx.sample_offsets() and ref["trace"] == pull_trace(hw, path)
