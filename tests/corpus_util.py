@@ -127,4 +127,7 @@ MATRIX = [
     # vectors hundreds of samples long, mostly pointing outside the reference picture (edge clamping only; long mvd codes)
     ("wild_mv_p", dict(frames=10, gop=10, bframes=0, refs=3, wild_mv=1)),
     ("wild_mv_b_cavlc", dict(frames=10, gop=10, bframes=2, refs=2, wild_mv=1, cabac=0, explicit_wp=1, wp_denom=6)),
+    # every picture an IDR picture (consecutive IDRs, idr_pic_id alternating), without a sync sample box
+    ("all_intra", dict(frames=6, gop=1, bframes=0, no_stss=1, qp_swing=1)),
+    ("all_intra_cavlc", dict(frames=5, gop=1, bframes=0, cabac=0, t8x8=0, slices=2, scaling=1)),
 ]
