@@ -28,7 +28,7 @@ struct ProbeSink : public h264::PictureSink {
   std::vector<Slot> slots = std::vector<Slot>(amd::kMaxSurfaces);
   std::vector<amd::MbInfo> mb;
   std::vector<uint32_t> coefs;
-  std::vector<amd::SliceParams> slices = std::vector<amd::SliceParams>(64);
+  std::vector<amd::SliceParams> slices = std::vector<amd::SliceParams>(256);  // as the decoder: MbInfo::slice is one byte
   int nmb = 0;
   uint64_t digest = 1469598103934665603ull;
   std::vector<int> outputs;  // slot per output (-1 skipped)

@@ -152,6 +152,20 @@ def test_1080p_cropping(hw, oracle, gpu, tmp_path):
         assert np.array_equal(got[k], gold[r])
 
 
+def test_slice_count_limit(hw, gpu, tmp_path):
+    """255 slices per picture (one macroblock each) decode bit-exactly; 300 are refused by name, loudly."""
+    path = str(tmp_path / "s255.mp4")
+    gold = make_clip(path, width=240, height=272, frames=5, gop=5, bframes=1, refs=2, slice_mbs=1, deblock=2)
+    idx = hw.index_video(path)
+    got = hw.Decoder(path, video_index=idx, num_lanes=1).retrieve_yuv(list(range(5)))
+    for i in range(5):
+        assert np.array_equal(got[i], gold[i]), "frame %d" % i
+    many = str(tmp_path / "s300.mp4")
+    make_clip(many, yuv=False, frames=3, gop=3, bframes=0, slice_mbs=1)
+    with pytest.raises(RuntimeError, match="too many slices"):
+        hw.Decoder(many, video_index=hw.index_video(many), num_lanes=1).retrieve_yuv([0, 1, 2])
+
+
 def test_left_top_cropping_rgb(hw, oracle, gpu, tmp_path):
     """The cropping rectangle starts inside the coded picture: the conversion reads from the offset surface."""
     path = str(tmp_path / "crop.mp4")

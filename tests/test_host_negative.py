@@ -275,3 +275,18 @@ def test_malformed_tables_are_errors(hw, kw):
     assert c.is_error() or not c.is_done(), "accepted a malformed table: %r" % (kw,)
     if c.is_error():
         assert c.error_message()
+
+
+def test_limits_are_errors_not_overruns(hw, tmp_path):
+    """A picture cut into more slices than the per-picture slice table holds (256) is refused by name; 255 slices
+    decode (host side: every slice ends on its trailing bits)."""
+    from tests.corpus_util import make_clip
+    from tests.test_host_parser import probe
+    many = str(tmp_path / "many.mp4")
+    make_clip(many, yuv=False, frames=3, gop=3, bframes=0, slice_mbs=1)       # 300 slices per picture
+    with pytest.raises(AssertionError, match="too many slices in one picture"):
+        probe(hw, many)
+    ok = str(tmp_path / "ok.mp4")
+    make_clip(ok, yuv=False, width=240, height=272, frames=3, gop=3, bframes=1, slice_mbs=1)   # 15 x 17 = 255 slices
+    idx, r = probe(hw, ok)
+    assert r["slices"] == r["clean_end"] == 3 * 255 and r["pictures"] == 3
