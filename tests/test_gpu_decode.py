@@ -61,6 +61,10 @@ BAND_SIZES = [
                                             multi_pps=2, wild_mv=1, qp_swing=1)),
     ("wide_131x9mb_pyramid", 2096, 144, dict(frames=9, gop=9, bframes=3, refs=4, bpyramid=1, slice_mbs=97, mixed_slices=1,
                                               temporal_direct=1, implicit_wp=1, rate_kbit=60)),
+    # the largest sides the decoder takes: 512 macroblocks (8192 samples) wide or high
+    ("wide_512x1mb", 8192, 16, dict(frames=4, gop=4, bframes=1)),
+    ("tall_1x512mb", 16, 8192, dict(frames=4, gop=4, bframes=1, slices=5)),
+    ("wide_511x2mb", 8176, 32, dict(frames=4, gop=4, bframes=1, refs=2, mixed_slices=1, slice_mbs=200)),
     ("7x7mb_everything", 112, 112, dict(frames=13, gop=13, bframes=3, refs=4, bpyramid=1, slice_mbs=5, mixed_slices=1,
                                           multi_pps=2, wild_mv=1, qp_swing=1, fn_bits=4, poc_bits=5, extra_nals=1)),
 ]
