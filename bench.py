@@ -278,9 +278,10 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
-    # 1.75 lanes per usable CPU (the library's own default, retriever.cpp: enough to keep the CPUs - the
-    # bottleneck - busy while lanes wait for the GPU, no more); with several ranks on one host the CPUs are shared
-    lanes = args.lanes or max(2, min(128, 7 * effective_cpus() // (4 * world)))
+    # 3 lanes per usable CPU (a lane waits for the GPU about as long as it parses;
+    # the CPUs are the bottleneck: measured 32 / 40 / 48 / 64 lanes on 16 CPUs ->
+    # 660 / 676 / 698 / 651 frames/s); with several ranks on one host the CPUs are shared
+    lanes = args.lanes or max(2, min(128, 3 * effective_cpus() // world))
     devices = (forced_ids or list(range(in_process_devices))) if in_process_devices > 1 else [device_index]
     br = BatchRetriever(device_ids=devices, num_lanes=lanes, shard=(rank, world) if world > 1 else None)
     # request k's frames land in HBM (N ranks: each rank writes the rows of its share into its own copy of

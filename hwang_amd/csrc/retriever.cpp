@@ -42,17 +42,14 @@ ParallelRetriever* ParallelRetriever::make(const std::vector<DeviceHandle>& devi
                                            VideoDecoderType type,
                                            int32_t num_lanes) {
   if (devices.empty()) return nullptr;
-  // A lane waits for the GPU part of the time it could parse (a picture's latency
-  // through the batching pipeline against its parse time), so it takes more lanes
-  // than CPUs to keep the CPUs - the bottleneck - busy, and every lane beyond that
-  // only adds threads fighting over the quota.  Measured on a 16-CPU quota at the
-  // end of round 2 (tools/experiments/exp_lanes3.sh, four interleaved repeats):
-  // 24 / 28 / 48 lanes -> 829 / 832 / 812 frames/s, 1.90 / 1.89 / 1.94 ms of CPU per
-  // picture; 20 lanes already keep 15.8 CPUs busy.  (With round 1's slower kernels
-  // the optimum was 3 lanes per CPU.)  The CPUs are the process's, however many GPUs
-  // it drives: more devices do not mean more lanes, only fewer lanes per device.
+  // A lane waits for the GPU about as long as it parses (a picture's latency
+  // through the batching pipeline is comparable to its parse time), so it takes
+  // a few lanes per CPU to keep the CPUs - the bottleneck - busy; measured on a
+  // 16-CPU quota: 32 / 40 / 48 / 64 lanes -> 660 / 676 / 698 / 651 frames/s.
+  // The CPUs are the process's, however many GPUs it drives: more devices do
+  // not mean more lanes, only fewer lanes per device.
   const bool auto_lanes = num_lanes <= 0;
-  if (auto_lanes) num_lanes = std::min<int32_t>(7 * effective_cpus() / 4, 128);
+  if (auto_lanes) num_lanes = std::min<int32_t>(3 * effective_cpus(), 128);
   num_lanes = std::max<int32_t>(num_lanes, auto_lanes ? static_cast<int32_t>(devices.size()) : 1);
   std::unique_ptr<ParallelRetriever> r(new ParallelRetriever());
   r->auto_lanes_ = auto_lanes;

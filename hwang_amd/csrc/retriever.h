@@ -72,7 +72,7 @@ class ParallelRetriever {
     size_t out_capacity = 0;
   };
 
-  // num_lanes <= 0 picks 1.75 lanes per CPU the process may use (effective_cpus), at most 128
+  // num_lanes <= 0 picks 3 lanes per CPU the process may use (effective_cpus), at most 128
   // (never fewer than one per device).  Lane i decodes on devices[i % devices.size()].
   static int32_t effective_cpus();
   static ParallelRetriever* make(const std::vector<DeviceHandle>& devices, VideoDecoderType type,

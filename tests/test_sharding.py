@@ -42,7 +42,7 @@ def _stamp_decoder(hw, n, gop, w, h, num_lanes):
 
 
 def test_automatic_lane_count(hw):
-    """num_lanes=0 lets the retriever choose (1.75 lanes per usable CPU, 2 for
+    """num_lanes=0 lets the retriever choose (3 lanes per usable CPU, 2 for
     pictures beyond 2x1080p, never more than there are work items): the rows
     must come back in request order whatever it chose."""
     import struct
