@@ -589,11 +589,15 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
   const int W = mb_width * 16, H = mb_height * 16;
   auto byte_of = [](uint32_t w, int k) { return (int)(int8_t)((w >> (8 * k)) & 0xff); };
 
-  // ---- window path: is the macroblock's motion uniform per list, and do its windows lie inside the picture?
-  // (wave-uniform decisions: every lane holds one of the sixteen vectors, all four reference bytes)
-  bool use_win[2];
-  int wmvx[2], wmvy[2];
+  // ---- window path: is the macroblock's motion uniform per list?  (wave-uniform decisions: every lane holds one
+  // of the sixteen vectors, all four reference bytes.)  A window that lies inside the reference picture is fetched
+  // with wide loads; one that leaves it - every macroblock along the picture's border, vectors that point outside -
+  // with byte loads from clamped coordinates (8.4.2.2.1's edge extension) into the same registers, so both kinds
+  // continue on the same path.
+  bool use_win[2], win_inside[2];
+  int wmvx[2], wmvy[2], wx0[2], wy0[2];
   const uint8_t* wsrc[2][3];
+  const uint8_t* wplane[2][3];
   bool window = true;
 #pragma unroll
   for (int l = 0; l < 2; ++l) {
@@ -608,13 +612,19 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     const int cx0 = mbx * 8 + (wmvx[l] >> 3), cy0 = mby * 8 + (wmvy[l] >> 3);
     const bool inside = x0 >= 0 && x0 + 21 <= W && y0 >= 0 && y0 + 21 <= H && cx0 >= 0 && cx0 + 9 <= W / 2 && cy0 >= 0 &&
                         cy0 + 9 <= H / 2;
-    if (idx != 0xffffffffu) window = window && uniform && inside;  // a list nobody uses constrains nothing
+    if (idx != 0xffffffffu) window = window && uniform;  // a list nobody uses constrains nothing
     else use_win[l] = false;
+    win_inside[l] = inside;
+    wx0[l] = x0;
+    wy0[l] = y0;
     if (use_win[l]) {
       const Surface& sf = pp.surfaces[byte_of(slots, 0)];
-      wsrc[l][0] = sf.y + (size_t)y0 * y_pitch + x0;
-      wsrc[l][1] = sf.u + (size_t)cy0 * c_pitch + cx0;
-      wsrc[l][2] = sf.v + (size_t)cy0 * c_pitch + cx0;
+      wplane[l][0] = sf.y;
+      wplane[l][1] = sf.u;
+      wplane[l][2] = sf.v;
+      wsrc[l][0] = sf.y + (ptrdiff_t)y0 * y_pitch + x0;
+      wsrc[l][1] = sf.u + (ptrdiff_t)cy0 * c_pitch + cx0;
+      wsrc[l][2] = sf.v + (ptrdiff_t)cy0 * c_pitch + cx0;
     }
   }
   window = window && (use_win[0] || use_win[1]);
@@ -632,8 +642,30 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       if (!use_win[l]) continue;
-      if (lane < 63) wy[l] = gld64u(wsrc[l][0] + loff);
-      if (lane < 54) wc[l] = ld32u((cpl ? wsrc[l][2] : wsrc[l][1]) + coff);
+      if (win_inside[l]) {
+        if (lane < 63) wy[l] = gld64u(wsrc[l][0] + loff);
+        if (lane < 54) wc[l] = ld32u((cpl ? wsrc[l][2] : wsrc[l][1]) + coff);
+      } else {  // the same bytes, one at a time, from clamped coordinates
+        if (lane < 63) {
+          const uint8_t* row = wplane[l][0] + (size_t)iclip(0, H - 1, wy0[l] + lr) * y_pitch;
+          uint32_t lo = 0, hi = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            lo |= (uint32_t)gld8(row + iclip(0, W - 1, wx0[l] + 8 * lc + b)) << (8 * b);
+            hi |= (uint32_t)gld8(row + iclip(0, W - 1, wx0[l] + 8 * lc + 4 + b)) << (8 * b);
+          }
+          wy[l].x = lo;
+          wy[l].y = hi;
+        }
+        if (lane < 54) {
+          const int cx0 = mbx * 8 + (wmvx[l] >> 3), cy0 = mby * 8 + (wmvy[l] >> 3);
+          const uint8_t* row = (cpl ? wplane[l][2] : wplane[l][1]) + (size_t)iclip(0, H / 2 - 1, cy0 + cr) * c_pitch;
+          uint32_t v = 0;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) v |= (uint32_t)gld8(row + iclip(0, W / 2 - 1, cx0 + 4 * cd + b)) << (8 * b);
+          wc[l] = v;
+        }
+      }
     }
     if (has_res) wave_residual(mb, job.coefs, pp, lane, L.work, L.dcs, L.res_y, L.res_c, L.lv);  // ends with wave_sync
 #pragma unroll
