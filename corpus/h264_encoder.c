@@ -38,6 +38,8 @@ typedef struct {
   int large_mdat;      /* mdat with a 64-bit size field whatever its size */
   int audio_track;     /* a second track (handler 'soun', own sample tables, its samples behind the video's in mdat) in front
                           of the video track */
+  int random_intra;    /* intra modes (chroma, 16x16, 4x4, 8x8) and the intra family drawn by hash among the valid ones instead of
+                          by best match: every mode of every family with every availability pattern shows up */
   int no_stss;         /* leave the sync sample box out when every sample is one (--gop 1) */
   int chunk_samples;   /* > 0: chunks of this many samples (every third chunk one more), the sound track's chunks between
                           them: several stsc runs, one chunk offset per chunk with gaps */
@@ -732,9 +734,10 @@ static int decide_intra(Enc* e, MbPlan* plan, int qp, int slice_type) {
       h264i_pred_chroma8x8(cur->plane[1 + pl] + mby * 8 * cur->stride[1 + pl] + mbx * 8, cur->stride[1 + pl], mode, left, top);
       cost += sad_region(e, 1 + pl, mbx * 8, mby * 8, 8, 8);
     }
-    if (cost < best_cc) {
+    if (cost < best_cc || (e->cfg->random_intra && (hv >> 20) % 4 == (uint32_t)mode)) {
       best_cc = cost;
       best_c = mode;
+      if (e->cfg->random_intra && (hv >> 20) % 4 == (uint32_t)mode) break;
     }
   }
   p->chroma_mode = best_c;
@@ -745,14 +748,16 @@ static int decide_intra(Enc* e, MbPlan* plan, int qp, int slice_type) {
     if ((mode == 0 && !top) || (mode == 1 && !left) || (mode == 3 && !(left && top && tl))) continue;
     h264i_pred16x16(y0, sy, mode, left, top);
     int cost = sad_block(e, mbx * 16, mby * 16, 16);
-    if (cost < cost16) {
+    if (cost < cost16 || (e->cfg->random_intra && (hv >> 22) % 4 == (uint32_t)mode)) {
       cost16 = cost;
       best16 = mode;
+      if (e->cfg->random_intra && (hv >> 22) % 4 == (uint32_t)mode) break;
     }
   }
   /* pick the family: smooth MBs -> 16x16; detailed ones -> 4x4 or 8x8 */
   int family = 16;
   if (cost16 > 256 * 5 || (hv >> 8) % 5 == 0) family = (e->cfg->t8x8 && ((hv >> 12) & 1)) ? 8 : 4;
+  if (e->cfg->random_intra) family = (hv >> 24) % 3 == 0 ? 16 : ((e->cfg->t8x8 && ((hv >> 12) & 1)) ? 8 : 4);
 
   if (family == 16) {
     p->kind = MB_I16x16;
@@ -829,6 +834,7 @@ static int decide_intra(Enc* e, MbPlan* plan, int qp, int slice_type) {
         bc = cost;
         best = mode;
       }
+      if (e->cfg->random_intra) break; /* the first valid mode of the hash-rotated scan */
     }
     if (n == 4) {
       h264i_pred4x4(dst, sy, best, hl, ht, htl, htr);
@@ -2166,6 +2172,7 @@ int main(int argc, char** argv) {
   c.free_boxes = arg_int(argc, argv, "--free-boxes", 0);
   c.large_mdat = arg_int(argc, argv, "--large-mdat", 0);
   c.audio_track = arg_int(argc, argv, "--audio-track", 0);
+  c.random_intra = arg_int(argc, argv, "--random-intra", 0);
   c.no_stss = arg_int(argc, argv, "--no-stss", 0);
   c.chunk_samples = arg_int(argc, argv, "--chunk-samples", 0);
   c.wild_mv = arg_int(argc, argv, "--wild-mv", 0);

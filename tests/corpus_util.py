@@ -130,4 +130,9 @@ MATRIX = [
     # every picture an IDR picture (consecutive IDRs, idr_pic_id alternating), without a sync sample box
     ("all_intra", dict(frames=6, gop=1, bframes=0, no_stss=1, qp_swing=1)),
     ("all_intra_cavlc", dict(frames=5, gop=1, bframes=0, cabac=0, t8x8=0, slices=2, scaling=1)),
+    # intra families and modes drawn by hash among the valid ones (not by best match): every mode of every family,
+    # every availability pattern - also with slices and with constrained intra prediction taking neighbours away
+    ("random_intra", dict(frames=8, gop=2, bframes=0, random_intra=1, qp=22)),
+    ("random_intra_cavlc_slices", dict(frames=9, gop=3, bframes=1, random_intra=1, cabac=0, slice_mbs=31, constrained_intra=1)),
+    ("random_intra_t4_only", dict(frames=6, gop=3, bframes=0, random_intra=1, t8x8=0, slices=3, qp=34)),
 ]
