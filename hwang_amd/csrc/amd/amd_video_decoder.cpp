@@ -117,13 +117,16 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         (counters_.stall_ns - stall0);
     ++counters_.samples_fed;
     if (!ok) return Result(false, "AMDVideoDecoder::feed: " + parser_->error());
+    if (!sink_error_.empty()) return Result(false, "AMDVideoDecoder::feed: " + sink_error_);
     return Result();
   }
 
   Result flush() override {
     if (!parser_) return Result();
     HWANG_HIP_RETURN(hipSetDevice(device_));
+    sink_error_.clear();
     if (!parser_->flush()) return Result(false, "AMDVideoDecoder::flush: " + parser_->error());
+    if (!sink_error_.empty()) return Result(false, "AMDVideoDecoder::flush: " + sink_error_);
     pending_wanted_.clear();
     return Result();
   }
@@ -320,8 +323,18 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       std::lock_guard<std::mutex> lk(out_mu_);
       if (slot >= 0) surf_[slot].held |= kHeldByOutput;
     }
-    outq_.push(slot);  // display order; the consumer side is get_frame / discard_frame
+    // display order; the consumer side is get_frame / discard_frame.  Counted before it becomes poppable (a consumer
+    // that pops in between must not see the count at -1); never blocks: the thread that feeds may also be the only
+    // consumer (ParallelRetriever::run_item), so a full queue is an error of the caller's protocol, not a wait.
     buffered_.fetch_add(1, std::memory_order_acq_rel);
+    if (!outq_.try_push(slot)) {
+      buffered_.fetch_sub(1, std::memory_order_acq_rel);
+      if (slot >= 0) {
+        std::lock_guard<std::mutex> lk(out_mu_);
+        unref_surface_locked(slot, kHeldByOutput);
+      }
+      sink_error_ = "too many undelivered pictures (decoded frames are not being fetched or discarded)";
+    }
   }
 
   void release_surface(int slot) override {

@@ -966,6 +966,10 @@ struct Parser::Impl {
     } else {
       apps = p;
     }
+    // Slices arrive in macroblock order (FMO / ASO are rejected): a slice that starts anywhere but at the
+    // first macroblock not decoded yet is a duplicate, an overlap or a gap.  Refused up front - a slice that
+    // re-decodes macroblocks would append to the per-picture streams (coefficients, motion extras) twice.
+    if (sl.first_mb != mbs_decoded) return fail("slice does not start at the next undecoded macroblock") ? 0 : -1;
 
     if (sl.type != 2) {
       init_ref_lists();
@@ -2403,6 +2407,7 @@ struct Parser::Impl {
                 bufs.pmo[mb.addr].mvd0[0] = static_cast<int16_t>(dx);
                 bufs.pmo[mb.addr].mvd0[1] = static_cast<int16_t>(dy);
               } else {
+                if (pmx_used >= bufs.pmx_capacity) return fail("motion extras overflow");
                 bufs.pmx[pmx_used++] = word;
               }
             } else {

@@ -64,7 +64,11 @@ class BatchRetriever(object):
         keep = []
         for i, (index, f, rows, out_ptr, cap) in enumerate(requests):
             if isinstance(f, str):
-                f = self._views.setdefault(("path", f), open(f, "rb"))
+                key = ("path", f)
+                fobj = self._views.get(key)
+                if fobj is None:   # open only on a miss (setdefault(open(...)) opened - and leaked - a handle per call)
+                    fobj = self._views[key] = open(f, "rb")
+                f = fobj
             view = self._views.get(id(f))
             if view is None:
                 view = self._views[id(f)] = (f,) + _host_view(f)
@@ -109,10 +113,22 @@ class BatchRetriever(object):
             out.append(dict(zip(("lanes", "items", "frames_returned", "samples_fed"), list(s))))
         return out
 
-    def __del__(self):
+    def close(self):
+        """Destroys the native retriever and lets go of the files opened by path (mappings are dropped with
+        their last view)."""
         h, self._h = getattr(self, "_h", None), None
         if h:
             lib.hwang_retriever_destroy(h)
+        views, self._views = getattr(self, "_views", {}), {}
+        for key, v in views.items():
+            if isinstance(key, tuple) and key[:1] == ("path",):
+                try:
+                    v.close()
+                except (OSError, ValueError, BufferError):
+                    pass
+
+    def __del__(self):
+        self.close()
 
 
 class Decoder(object):

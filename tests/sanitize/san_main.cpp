@@ -185,6 +185,37 @@ static void memory_part(int argc, char** argv) {
         }
         parser.flush();
         if (trial == 0) CHECK(parser.slices() > 0 && parser.slices() == parser.slices_clean_end());
+        if (trial == 0) {
+          // the last slice NAL of every sample repeated many times (re-decoded macroblocks used to
+          // append to the motion-extras stream past its end).  Must be refused, must not write out of bounds.
+          NullSink sink2;
+          sink2.compact = compact != 0;
+          h264::Parser dup(&sink2);
+          if (!dup.configure(idx.metadata_bytes().data(), idx.metadata_bytes().size())) continue;
+          const int ls = (idx.metadata_bytes()[4] & 3) + 1;
+          bool refused = false, expect = false;  // expect: some repeated NAL was a slice that does not start a picture
+          for (uint64_t s = 0; s < idx.frames() && !refused; ++s) {
+            const uint64_t o = idx.sample_offsets()[s], n = idx.sample_sizes()[s];
+            if (o > data.size() || n > data.size() - o) break;
+            // find the last NAL of the sample
+            uint64_t pos = 0, last = 0, last_len = 0;
+            while (pos + ls <= n) {
+              uint64_t len = 0;
+              for (int i = 0; i < ls; ++i) len = (len << 8) | data[o + pos + i];
+              if (len > n - pos - ls) break;
+              last = pos;
+              last_len = ls + len;
+              pos += ls + len;
+            }
+            std::vector<uint8_t> sample(data.begin() + o, data.begin() + o + n);
+            const int type = last_len > static_cast<uint64_t>(ls) ? (data[o + last + ls] & 31) : 0;
+            if ((type == 1 || type == 5) && last_len > static_cast<uint64_t>(ls) + 1 && !(data[o + last + ls + 1] & 0x80)) expect = true;
+            if (type == 1 || type == 5)
+              for (int k = 0; k < 250; ++k) sample.insert(sample.end(), data.begin() + o + last, data.begin() + o + last + last_len);
+            if (!dup.decode(sample.data(), sample.size())) refused = true;
+          }
+          CHECK(refused || !expect);
+        }
       }
     }
   }

@@ -180,6 +180,42 @@ def test_bit_flips_never_crash(hw, tmp_path):
     assert errors > 0  # some flips must be detected; none may crash
 
 
+def test_duplicated_slice_nal_is_refused(hw, tmp_path):
+    """a sample whose last slice NAL is repeated re-decodes macroblocks of the picture in
+    progress; the per-picture streams (motion extras, coefficients) must not grow past their buffers.
+    Slices have to start at the next undecoded macroblock - anything else is an error."""
+    from hwang_amd._capi import lib
+    for kw in (dict(cabac=0, slices=3, qp=51), dict(cabac=1, slices=2, qp=30)):
+        path = str(tmp_path / "d.mp4")
+        make_clip(path, yuv=False, width=64, height=48, frames=6, gop=6, bframes=0, refs=2, **kw)
+        idx = hw.index_video(path)
+        raw = open(path, "rb").read()
+        offs, sizes = idx.sample_offsets(), idx.sample_sizes()
+        blob, noffs, nsizes = bytearray(), [], []
+        for o, n in zip(offs, sizes):
+            sample = raw[o:o + n]
+            pos, last = 0, None
+            while pos + 4 <= len(sample):
+                ln = struct.unpack(">I", sample[pos:pos + 4])[0]
+                last = (pos, 4 + ln)
+                pos += 4 + ln
+            assert sample[last[0] + 4] & 31 in (1, 5)
+            sample = sample + sample[last[0]:last[0] + last[1]] * 250
+            noffs.append(len(blob))
+            nsizes.append(len(sample))
+            blob += sample
+        data = np.frombuffer(bytes(blob), dtype=np.uint8)
+        o = np.ascontiguousarray(np.array(noffs, dtype=np.uint64))
+        z = np.ascontiguousarray(np.array(nsizes, dtype=np.uint64))
+        ex = bytes(idx.metadata_bytes())
+        out = (C.c_int64 * 8)()
+        err = C.create_string_buffer(256)
+        rc = lib.hwang_h264_probe(ex, len(ex), data.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                  o.ctypes.data_as(C.POINTER(C.c_uint64)), z.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                  len(noffs), None, 0, out, err, 256)
+        assert rc != 0 and b"next undecoded macroblock" in err.value, err.value
+
+
 # ------------------------------------------------------------------ indexes
 def test_inconsistent_index_is_refused(hw):
     good = dict(timescale=90000, duration=9000, width=64, height=48, format="avc1",

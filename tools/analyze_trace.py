@@ -4,6 +4,8 @@
 traced window per kernel."""
 import csv
 import glob
+import re
+import os
 import sys
 from collections import defaultdict
 
@@ -14,6 +16,9 @@ for p in paths:
         rows += list(csv.DictReader(f))
 if not rows:
     sys.exit("no kernel_trace.csv under " + sys.argv[1])
+# k_upload's grid.y is pictures * kJobUploads (hwang_amd/csrc/amd/frame_job.h): read the constant, do not repeat it
+_hdr = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hwang_amd", "csrc", "amd", "frame_job.h")).read()
+K_JOB_UPLOADS = int(re.search(r"constexpr int kJobUploads = (\d+);", _hdr).group(1))
 t0 = min(int(r["Start_Timestamp"]) for r in rows)
 t1 = max(int(r["End_Timestamp"]) for r in rows)
 print("kernels %d  window %.3f s" % (len(rows), (t1 - t0) / 1e9))
@@ -24,7 +29,7 @@ for r in rows:
     wx = int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1)
     jobs = gy if ("k_inter" in name or "k_bs" in name or "k_upload" in name) else max(1, gx // max(wx, 1))
     if "k_upload" in name:
-        jobs //= 5
+        jobs //= K_JOB_UPLOADS
     b = 1
     while b < jobs:
         b *= 2
