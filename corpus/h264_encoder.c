@@ -43,6 +43,9 @@ typedef struct {
   int no_stss;         /* leave the sync sample box out when every sample is one (--gop 1) */
   int chunk_samples;   /* > 0: chunks of this many samples (every third chunk one more), the sound track's chunks between
                           them: several stsc runs, one chunk offset per chunk with gaps */
+  int cover;           /* widens syntax coverage by hash (tests/coverage_model.py): intra macroblocks of every family in P and B slices,
+                        * Intra16x16 with chroma but without luma AC, B 16x8 / 8x16 whose halves use different lists, and - at
+                        * QP <= 3 - now and then a level so large that CAVLC needs level_prefix >= 16 */
   int wild_mv;         /* now and then a P macroblock takes a vector hundreds of samples long, mostly to somewhere outside the
                           reference picture: long mvd codes, prediction from clamped coordinates only */
   int qp_swing;        /* every few macroblocks the QP jumps anywhere in 0..51: large mb_qp_delta values, incl. the ones that
@@ -567,6 +570,17 @@ static int quant_luma4(Enc* e, MB* p, int blk, int qp, int intra, int skip_dc) {
     any |= q != 0;
   }
   if (skip_dc) p->luma[blk][0] = 0;
+  if (e->cfg->cover && qp <= 1 && !skip_dc && wt[0] == 16) {
+    /* a level beyond what level_prefix 15 can carry (|level| > 2528), alone in its block: scaled (x 10 or x 11 at
+     * QP 0 / 1, flat weights) it is 27000 / 29700 - inside the 16-bit range the standard bounds coefficients and
+     * transform intermediates to (8.5.12.1), and the block decodes to clipped samples */
+    const uint32_t hl = hash3((uint32_t)e->cfg->seed + 29, (uint32_t)e->frame_abs, (uint32_t)(d->mb.addr * 16 + blk));
+    if (hl % 5 == 0) {
+      memset(p->luma[blk], 0, sizeof(p->luma[blk]));
+      p->luma[blk][0] = (int16_t)((hl >> 8) & 1 ? -2700 : 2700);
+      any = 1;
+    }
+  }
   return any;
 }
 
@@ -781,6 +795,7 @@ static int decide_intra(Enc* e, MbPlan* plan, int qp, int slice_type) {
         any_ac |= q != 0;
       }
     }
+    if (e->cfg->cover && (hv >> 27) % 3 == 0) any_ac = 0; /* Intra16x16 types 1..12: DC (and chroma) only */
     if (!any_ac) memset(p->luma, 0, sizeof(p->luma));
     /* decoder: f = H L H; dcY = f * LS * 2^(qp/6-6)  =>  L = H f H / 16 */
     const double step = h264i_level_scale4(wt, qp, 0) * pow(2.0, qp / 6 - 6);
@@ -795,6 +810,7 @@ static int decide_intra(Enc* e, MbPlan* plan, int qp, int slice_type) {
       double o[4] = {a + b + c2 + dd, a + b - c2 - dd, a - b - c2 + dd, a - b + c2 - dd};
       for (int i = 0; i < 4; ++i) p->luma_dc[4 * i + j] = (int16_t)quant(o[i] / 16, 1.0, 1.0 / 3);
     }
+    if (e->cfg->cover && slice_type != 2 && (hv >> 29) % 3 == 0) memset(p->luma_dc, 0, sizeof(p->luma_dc)); /* coded_block_flag 0 for the DC block */
     for (int pl = 0; pl < 2; ++pl)
       h264i_pred_chroma8x8(cur->plane[1 + pl] + mby * 8 * cur->stride[1 + pl] + mbx * 8, cur->stride[1 + pl], best_c, left, top);
     int cc = quant_chroma(e, p, qp, 1);
@@ -1154,6 +1170,9 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
               d->mb.mv[l][k][0] = (int16_t)(d->mb.mv[l][k0][0] + (s ? jx : 0));
               d->mb.mv[l][k][1] = (int16_t)(d->mb.mv[l][k0][1] + (s ? jy : 0));
             }
+          if (e->cfg->cover && (hs >> 24) % 3 == 0) /* an explicit quadrant may name any reference: index 0 next to neighbours > 0 */
+            for (int l = 0; l < 2; ++l)
+              if (d->mb.ref[l][q] > 0) d->mb.ref[l][q] = 0;
           if (split) { /* L0 / L1 / Bi 8x8 (1, 2, 3) -> 8x4 (4, 6, 8), 4x8 (5, 7, 9), 4x4 (10, 11, 12) */
             const int t = p->sub_type[q];
             p->sub_type[q] = split == 3 ? 9 + t : 2 + 2 * t + (split == 2 ? 1 : 0);
@@ -1175,6 +1194,7 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
       int shape = 1 + (int)((hv >> 3) & 1); /* 1 16x8, 2 8x16 */
       int pa = best_kind - 1, pb = best_kind - 1; /* 0 L0 1 L1 2 Bi */
       if (best_kind == 3 && ((hv >> 5) & 1)) pb = (int)((hv >> 6) & 1);
+      if (e->cfg->cover && best_kind != 3 && ((hv >> 5) & 1)) pb = (pa + 1 + (int)((hv >> 6) & 1)) % 3; /* L0_L1, L1_L0, L0_Bi, L1_Bi */
       static const int tab[3][3] = {{4, 8, 12}, {10, 6, 14}, {16, 18, 20}}; /* [predA][predB] -> 16x8 type */
       p->mb_type_raw = tab[pa][pb] + (shape == 2 ? 1 : 0);
       for (int q = 0; q < 4; ++q) {
@@ -1586,6 +1606,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
       if (hq % 9 == 0) qp = iclip(10, 48, qp + (int)((hq >> 4) % 5) - 2);
       if (c->qp_swing && hq % 7 == 3) qp = (int)((hq >> 8) % 52);
       if (st == 2) decide_intra(e, &plan, qp, 2);
+      else if (c->cover && hq % 5 == 1) decide_intra(e, &plan, qp, st);
       else if (st == 0) decide_p(e, &plan, qp, 1);
       else decide_b(e, &plan, qp);
       if (h264i_enc_mb(d, w, addr, &plan, addr == mb1 - 1) < 0) {
@@ -2173,6 +2194,7 @@ int main(int argc, char** argv) {
   c.large_mdat = arg_int(argc, argv, "--large-mdat", 0);
   c.audio_track = arg_int(argc, argv, "--audio-track", 0);
   c.random_intra = arg_int(argc, argv, "--random-intra", 0);
+  c.cover = arg_int(argc, argv, "--cover", 0);
   c.no_stss = arg_int(argc, argv, "--no-stss", 0);
   c.chunk_samples = arg_int(argc, argv, "--chunk-samples", 0);
   c.wild_mv = arg_int(argc, argv, "--wild-mv", 0);

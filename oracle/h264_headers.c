@@ -944,6 +944,7 @@ void h264o_close(H264Oracle* d) {
   free(d->mb_deblock);
   free(d->mb_qpc[0]);
   free(d->mb_qpc[1]);
+  free(d->cov);
   free(d);
 }
 
@@ -1046,6 +1047,16 @@ int h264o_pop_frame(H264Oracle* d, uint8_t* dst, size_t capacity) {
 }
 
 void h264o_counters(H264Oracle* d, int64_t out[10]) { memcpy(out, d->counters, sizeof(d->counters)); }
+
+void h264o_coverage_enable(H264Oracle* d) {
+  if (!d->cov) d->cov = (int64_t*)calloc(H264O_COV_CELLS, sizeof(int64_t));
+}
+int h264o_coverage(H264Oracle* d, int64_t* out, int n) {
+  if (n > H264O_COV_CELLS) n = H264O_COV_CELLS;
+  if (d->cov) memcpy(out, d->cov, (size_t)n * sizeof(int64_t));
+  else memset(out, 0, (size_t)n * sizeof(int64_t));
+  return H264O_COV_CELLS;
+}
 
 void h264o_yuv420_to_rgb24(const uint8_t* i420, int width, int height, uint8_t* rgb) {
   const int cw = (width + 1) / 2, ch = (height + 1) / 2;

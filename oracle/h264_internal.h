@@ -277,8 +277,12 @@ struct H264Oracle {
   MB mb;
 
   int64_t counters[10];
+  int64_t* cov;        /* coverage histogram (h264_oracle.h), NULL = not collected */
+  int cov_ctx_table;   /* which H264O_COV_CTX table the current slice's bins count in */
   int pred_luma_only; /* corpus encoder: motion search evaluates luma only */
 };
+
+#define COV(d, cell) do { if ((d)->cov) (d)->cov[(cell)]++; } while (0)
 
 /* h264_headers.c */
 int h264i_fail(H264Oracle* d, const char* msg);

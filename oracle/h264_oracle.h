@@ -47,6 +47,62 @@ const char* h264o_error(H264Oracle* d);
  * [4]=I/[5]=P/[6]=B slices, [7]=intra MBs, [8]=skip MBs, [9]=8x8-transform MBs */
 void h264o_counters(H264Oracle* d, int64_t out[10]);
 
+/* Coverage histogram of the syntax and arithmetic cases a stream exercised
+ * (tests/test_corpus_coverage.py asserts that the corpus reaches every
+ * reachable cell).  Off until enabled; counts are per decoder instance.
+ * Section layout (cell index = section base + the index given):
+ *   H264O_COV_I4        mode(0..8) * 16 + (left | top << 1 | topleft << 2 | topright << 3)
+ *   H264O_COV_I8        same for Intra 8x8
+ *   H264O_COV_I16       mode(0..3) * 4 + (left | top << 1)
+ *   H264O_COV_IC        chroma mode(0..3) * 4 + (left | top << 1)
+ *   H264O_COV_LUMA_MC   (yFrac * 4 + xFrac) * 3 + block class (0: 16x16, 1: 8x8, 2: 4x4 regions of equal motion)
+ *   H264O_COV_CHROMA_MC yFrac(0..7) * 8 + xFrac
+ *   H264O_COV_WP        weight mode(0 default, 1 explicit, 2 implicit) * 3 + (0 list0 only, 1 list1 only, 2 both)
+ *   H264O_COV_BS        ((dir * 2 + macroblock_edge) * 3 + plane) * 5 + bS       (per 4-sample luma / 2-sample chroma run)
+ *   H264O_COV_FILT      0-3 luma bS<4: (ap<beta) * 2 + (aq<beta); 4-7 luma bS=4: strong_p * 2 + strong_q;
+ *                       8 chroma bS<4; 9 chroma bS=4; 10 luma / 11 chroma sample left alone by the alpha / beta tests
+ *   H264O_COV_MBTYPE_I  mb_type 0..25
+ *   H264O_COV_MBTYPE_P  mb_type 0..30, 31 = P_Skip
+ *   H264O_COV_MBTYPE_B  mb_type 0..48, 49 = B_Skip
+ *   H264O_COV_SUB_P     sub_mb_type 0..3        H264O_COV_SUB_B  sub_mb_type 0..12
+ *   H264O_COV_COEFF_TOKEN  table(0..3 by nC, 4 chroma DC) * 68 + total_coeff * 4 + trailing_ones
+ *   H264O_COV_TOTAL_ZEROS  (total_coeff - 1) * 16 + total_zeros;  _DC: (total_coeff - 1) * 4 + total_zeros
+ *   H264O_COV_RUN_BEFORE   (min(zeros_left, 7) - 1) * 15 + run_before
+ *   H264O_COV_ESCAPE    0 CAVLC level_prefix 14 (suffixLength 0), 1 level_prefix 15, 2 level_prefix >= 16,
+ *                       3 CABAC coeff_abs_level suffix (>= 15), 4 CABAC mvd suffix (>= 9)
+ *   H264O_COV_DEQUANT   0/1 4x4 qP < 24 / >= 24, 2/3 8x8 qP < 36 / >= 36, 4/5 Intra16x16 DC qP < 36 / >= 36, 6 chroma DC
+ *   H264O_COV_DIRECT    (temporal * 2 + sub_macroblock_only) * 2 + direct_8x8_inference
+ *   H264O_COV_CTX       ((table * 460) + ctxIdx) * 2 + bin value; table: 0 I, 1..3 P with cabac_init_idc 0..2,
+ *                       4..6 B with cabac_init_idc 0..2 */
+enum {
+  H264O_COV_I4 = 0,
+  H264O_COV_I8 = H264O_COV_I4 + 144,
+  H264O_COV_I16 = H264O_COV_I8 + 144,
+  H264O_COV_IC = H264O_COV_I16 + 16,
+  H264O_COV_LUMA_MC = H264O_COV_IC + 16,
+  H264O_COV_CHROMA_MC = H264O_COV_LUMA_MC + 48,
+  H264O_COV_WP = H264O_COV_CHROMA_MC + 64,
+  H264O_COV_BS = H264O_COV_WP + 9,
+  H264O_COV_FILT = H264O_COV_BS + 60,
+  H264O_COV_MBTYPE_I = H264O_COV_FILT + 12,
+  H264O_COV_MBTYPE_P = H264O_COV_MBTYPE_I + 26,
+  H264O_COV_MBTYPE_B = H264O_COV_MBTYPE_P + 32,
+  H264O_COV_SUB_P = H264O_COV_MBTYPE_B + 50,
+  H264O_COV_SUB_B = H264O_COV_SUB_P + 4,
+  H264O_COV_COEFF_TOKEN = H264O_COV_SUB_B + 13,
+  H264O_COV_TOTAL_ZEROS = H264O_COV_COEFF_TOKEN + 340,
+  H264O_COV_TOTAL_ZEROS_DC = H264O_COV_TOTAL_ZEROS + 240,
+  H264O_COV_RUN_BEFORE = H264O_COV_TOTAL_ZEROS_DC + 12,
+  H264O_COV_ESCAPE = H264O_COV_RUN_BEFORE + 105,
+  H264O_COV_DEQUANT = H264O_COV_ESCAPE + 5,
+  H264O_COV_DIRECT = H264O_COV_DEQUANT + 7,
+  H264O_COV_CTX = H264O_COV_DIRECT + 8,
+  H264O_COV_CELLS = H264O_COV_CTX + 7 * 460 * 2
+};
+void h264o_coverage_enable(H264Oracle* d);
+/* copies min(n, H264O_COV_CELLS) cells; returns H264O_COV_CELLS */
+int h264o_coverage(H264Oracle* d, int64_t* out, int n);
+
 /* I420 -> RGB24 exactly as hwang_amd/csrc/amd/k_rgb.hip documents it. */
 void h264o_yuv420_to_rgb24(const uint8_t* i420, int width, int height,
                            uint8_t* rgb);

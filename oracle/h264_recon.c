@@ -499,9 +499,12 @@ static void inter_pred_region(H264Oracle* d, int bx, int by, int n4) {
     const int x0 = (m->mbx * 16 + bx * 4) >> (plane ? 1 : 0), y0 = (m->mby * 16 + by * 4) >> (plane ? 1 : 0);
     uint8_t* dst = cur->plane[plane] + y0 * cur->stride[plane] + x0;
     uint8_t pb[2][256];
+    if (plane == 0) COV(d, H264O_COV_WP + sl->use_weight * 3 + (p0 && p1 ? 2 : (p0 ? 0 : 1)));
     for (int l = 0; l < 2; ++l) {
       const Picture* p = l ? p1 : p0;
       if (!p) continue;
+      if (plane == 0) COV(d, H264O_COV_LUMA_MC + ((m->mv[l][blk][1] & 3) * 4 + (m->mv[l][blk][0] & 3)) * 3 + (n4 == 4 ? 0 : (n4 == 2 ? 1 : 2)));
+      else if (plane == 1) COV(d, H264O_COV_CHROMA_MC + (m->mv[l][blk][1] & 7) * 8 + (m->mv[l][blk][0] & 7));
       h264i_mc_block(p, plane, pw, ph, x0, y0, m->mv[l][blk][0], m->mv[l][blk][1], n, n, pb[l], 16);
     }
     for (int y = 0; y < n; ++y)
@@ -583,6 +586,7 @@ static void recon_luma_residual_4x4(H264Oracle* d, int blk_raster, int dc_given,
   for (int k = 0; k < 16 && !any; ++k) any = m->luma[blk_raster][k] != 0;
   if (!any) return;
   int sc[16], res[16];
+  COV(d, H264O_COV_DEQUANT + (m->qp >= 24));
   scale4x4(m->luma[blk_raster], weight, m->qp, dc_given, dc, sc);
   idct4x4(sc, res);
   add_residual(dst, cur->stride[0], res, 4);
@@ -597,6 +601,7 @@ static void recon_luma_residual_8x8(H264Oracle* d, int b8, const uint8_t* weight
   if (!any) return;
   int sc[64], res[64];
   const int qp = m->qp;
+  COV(d, H264O_COV_DEQUANT + 2 + (qp >= 36));
   for (int k = 0; k < 64; ++k) {
     int v = m->luma8[b8][k] * h264i_level_scale8(weight, qp, k);
     sc[k] = qp >= 36 ? v << (qp / 6 - 6) : (v + (1 << (5 - qp / 6))) >> (6 - qp / 6);
@@ -617,6 +622,7 @@ static void recon_chroma_residual(H264Oracle* d) {
     int f[4] = {c[0] + c[1] + c[2] + c[3], c[0] - c[1] + c[2] - c[3], c[0] + c[1] - c[2] - c[3],
                 c[0] - c[1] - c[2] + c[3]};
     const int ls = h264i_level_scale4(weight, qp, 0);
+    if (f[0] | f[1] | f[2] | f[3]) COV(d, H264O_COV_DEQUANT + 6);
     for (int s = 0; s < 4; ++s) {
       int dc = ((f[s] * ls) << (qp / 6)) >> 5;
       int sc[16], res[16];
@@ -661,6 +667,7 @@ void h264i_recon_mb(H264Oracle* d) {
   const int left_ok = h264i_intra_mb_ok(d, m->mbx - 1, m->mby), top_ok = h264i_intra_mb_ok(d, m->mbx, m->mby - 1);
   if (m->kind == MB_I16x16) {
     h264i_pred16x16(y0, sy, m->i16_mode, left_ok, top_ok);
+    COV(d, H264O_COV_I16 + m->i16_mode * 4 + (left_ok | top_ok << 1));
     /* DC: inverse 4x4 Hadamard, then scaling (8.5.10) */
     const uint8_t* w4 = pps->scaling4[0];
     int c[16], f[16], t[16];
@@ -680,6 +687,7 @@ void h264i_recon_mb(H264Oracle* d) {
       f[12 + j] = a - b + cc - dd;
     }
     const int qp = m->qp, ls = h264i_level_scale4(w4, qp, 0);
+    if (m->cbf_dc & 1) COV(d, H264O_COV_DEQUANT + 4 + (qp >= 36));
     for (int k = 0; k < 16; ++k) {
       int dc = qp >= 36 ? (f[k] * ls) << (qp / 6 - 6) : (f[k] * ls + (1 << (5 - qp / 6))) >> (6 - qp / 6);
       recon_luma_residual_4x4(d, k, 1, dc, w4); /* f is indexed [row=by][col=bx] = raster block */
@@ -692,6 +700,7 @@ void h264i_recon_mb(H264Oracle* d) {
       int hl = h264i_intra_blk_ok(d, bx - 1, by, k), ht = h264i_intra_blk_ok(d, bx, by - 1, k);
       int htl = h264i_intra_blk_ok(d, bx - 1, by - 1, k), htr = h264i_intra_blk_ok(d, bx + 1, by - 1, k);
       h264i_pred4x4(dst, sy, m->i4_mode[by * 4 + bx], hl, ht, htl, htr);
+      COV(d, H264O_COV_I4 + m->i4_mode[by * 4 + bx] * 16 + (hl | ht << 1 | htl << 2 | htr << 3));
       recon_luma_residual_4x4(d, by * 4 + bx, 0, 0, w4);
     }
   } else { /* MB_I8x8 */
@@ -702,6 +711,7 @@ void h264i_recon_mb(H264Oracle* d) {
       int hl = h264i_intra_blk_ok(d, bx - 1, by, zz), ht = h264i_intra_blk_ok(d, bx, by - 1, zz);
       int htl = h264i_intra_blk_ok(d, bx - 1, by - 1, zz), htr = h264i_intra_blk_ok(d, bx + 2, by - 1, zz);
       h264i_pred8x8l(dst, sy, m->i4_mode[by * 4 + bx], hl, ht, htl, htr);
+      COV(d, H264O_COV_I8 + m->i4_mode[by * 4 + bx] * 16 + (hl | ht << 1 | htl << 2 | htr << 3));
       recon_luma_residual_8x8(d, b8, pps->scaling8[0]);
     }
   }
@@ -709,23 +719,30 @@ void h264i_recon_mb(H264Oracle* d) {
     uint8_t* c0 = cur->plane[1 + p] + m->mby * 8 * cur->stride[1 + p] + m->mbx * 8;
     h264i_pred_chroma8x8(c0, cur->stride[1 + p], m->chroma_mode, left_ok, top_ok);
   }
+  COV(d, H264O_COV_IC + m->chroma_mode * 4 + (left_ok | top_ok << 1));
   recon_chroma_residual(d);
 }
 
 /* ======================================================================== */
 /* deblocking filter (8.7)                                                  */
 /* ======================================================================== */
-static void filter_edge_sample(uint8_t* pix, int step, int bs, int alpha, int beta, int tc0, int chroma) {
+static void filter_edge_sample(uint8_t* pix, int step, int bs, int alpha, int beta, int tc0, int chroma, int64_t* cov) {
   /* pix points at q0; p_i = pix[-(i+1)*step], q_i = pix[i*step] */
+#define FCOV(i) do { if (cov) cov[H264O_COV_FILT + (i)]++; } while (0)
   int p0 = pix[-step], p1 = pix[-2 * step], q0 = pix[0], q1 = pix[step];
-  if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return;
+  if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) {
+    FCOV(10 + (chroma != 0));
+    return;
+  }
   if (bs < 4) {
     int tc;
     if (chroma) {
       tc = tc0 + 1;
+      FCOV(8);
     } else {
       int p2 = pix[-3 * step], q2 = pix[2 * step];
       int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
+      FCOV((ap < beta) * 2 + (aq < beta));
       tc = tc0 + (ap < beta) + (aq < beta);
       if (ap < beta) pix[-2 * step] = (uint8_t)(p1 + iclip(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1));
       if (aq < beta) pix[step] = (uint8_t)(q1 + iclip(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1));
@@ -736,6 +753,7 @@ static void filter_edge_sample(uint8_t* pix, int step, int bs, int alpha, int be
     return;
   }
   if (chroma) {
+    FCOV(9);
     pix[-step] = (uint8_t)((2 * p1 + p0 + q1 + 2) >> 2);
     pix[0] = (uint8_t)((2 * q1 + q0 + p1 + 2) >> 2);
     return;
@@ -743,6 +761,8 @@ static void filter_edge_sample(uint8_t* pix, int step, int bs, int alpha, int be
   int p2 = pix[-3 * step], q2 = pix[2 * step];
   int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
   int strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
+  FCOV(4 + (ap < beta && strong) * 2 + (aq < beta && strong));
+#undef FCOV
   if (ap < beta && strong) {
     int p3 = pix[-4 * step];
     pix[-step] = (uint8_t)((p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
@@ -841,6 +861,14 @@ void h264i_deblock_picture(H264Oracle* d) {
             int pblk = e == 0 ? (dir == 0 ? k * 4 + 3 : 12 + k) : (dir == 0 ? k * 4 + e - 1 : (e - 1) * 4 + k);
             bs[k] = boundary_strength(d, na, pblk, a, qblk, e == 0);
           }
+          if (d->cov)
+            for (int k = 0; k < 4; ++k) {
+              if (luma_edge) COV(d, H264O_COV_BS + ((dir * 2 + (e == 0)) * 3 + 0) * 5 + bs[k]);
+              if (!(e & 1)) {
+                COV(d, H264O_COV_BS + ((dir * 2 + (e == 0)) * 3 + 1) * 5 + bs[k]);
+                COV(d, H264O_COV_BS + ((dir * 2 + (e == 0)) * 3 + 2) * 5 + bs[k]);
+              }
+            }
           if (!(bs[0] | bs[1] | bs[2] | bs[3])) continue;
           /* luma */
           if (luma_edge) {
@@ -852,7 +880,7 @@ void h264i_deblock_picture(H264Oracle* d) {
               int s = bs[i >> 2];
               if (!s) continue;
               uint8_t* pix = dir == 0 ? base + i * cur->stride[0] + e * 4 : base + e * 4 * cur->stride[0] + i;
-              filter_edge_sample(pix, dir == 0 ? 1 : cur->stride[0], s, alpha, beta, s < 4 ? deblock_tc0[ia][s - 1] : 0, 0);
+              filter_edge_sample(pix, dir == 0 ? 1 : cur->stride[0], s, alpha, beta, s < 4 ? deblock_tc0[ia][s - 1] : 0, 0, d->cov);
             }
           }
           /* chroma: 8x8 planes have edges at 0 and 4, i.e. luma edges 0 and 2 */
@@ -867,7 +895,7 @@ void h264i_deblock_picture(H264Oracle* d) {
                 int s = bs[i >> 1];
                 if (!s) continue;
                 uint8_t* pix = dir == 0 ? base + i * cs + e * 2 : base + e * 2 * cs + i;
-                filter_edge_sample(pix, dir == 0 ? 1 : cs, s, alpha, beta, s < 4 ? deblock_tc0[ia][s - 1] : 0, 1);
+                filter_edge_sample(pix, dir == 0 ? 1 : cs, s, alpha, beta, s < 4 ? deblock_tc0[ia][s - 1] : 0, 1, d->cov);
               }
             }
           }

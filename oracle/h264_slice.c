@@ -290,6 +290,7 @@ static int pred_direct(H264Oracle* d, int only_b8) {
   if (!col) return h264i_fail(d, "direct prediction without RefPicList1[0]");
   const int inf8 = d->asps->direct_8x8_inference;
   const int addr = m->addr;
+  COV(d, H264O_COV_DIRECT + ((sl->direct_spatial ? 0 : 1) * 2 + (only_b8 >= 0)) * 2 + (inf8 != 0));
 
   if (sl->direct_spatial) {
     int ref[2], mvp[2][2] = {{0, 0}, {0, 0}};
@@ -401,7 +402,9 @@ typedef struct {
 } Rd;
 
 static inline int sx_bin(Rd* r, int ctx, int v) {
-  return r->enc ? cenc_bin(&r->d->cenc, &r->d->cabac.state[ctx], v) : cabac_bin(&r->d->cabac, ctx);
+  const int bin = r->enc ? cenc_bin(&r->d->cenc, &r->d->cabac.state[ctx], v) : cabac_bin(&r->d->cabac, ctx);
+  COV(r->d, H264O_COV_CTX + (r->d->cov_ctx_table * CABAC_CTX_COUNT + ctx) * 2 + (bin != 0));
+  return bin;
 }
 static inline int sx_bypass(Rd* r, int v) {
   return r->enc ? cenc_bypass(&r->d->cenc, v) : cabac_bypass(&r->d->cabac);
@@ -505,6 +508,7 @@ static int cavlc_block(Rd* r, int nc, int max_coeff, const uint8_t* scan, int st
     token = sx_vlc(r, coeff_token_len[t], coeff_token_bits[t], 68, token);
   }
   if (token < 0) return h264i_fail(d, "CAVLC: bad coeff_token");
+  COV(d, H264O_COV_COEFF_TOKEN + (nc == -1 ? 4 : (nc < 2 ? 0 : (nc < 4 ? 1 : (nc < 8 ? 2 : 3)))) * 68 + token);
   total = token >> 2;
   t1 = token & 3;
   if (total == 0) return 0;
@@ -541,6 +545,7 @@ static int cavlc_block(Rd* r, int nc, int max_coeff, const uint8_t* scan, int st
           ++prefix;
         }
       }
+      if (prefix >= 14 && !(prefix == 14 && suffix_len)) COV(d, H264O_COV_ESCAPE + (prefix == 14 ? 0 : (prefix == 15 ? 1 : 2)));
       bw_put(r->w, 0, prefix);
       bw_put(r->w, 1, 1);
       if (size > 0) bw_put(r->w, suffix, size);
@@ -549,6 +554,7 @@ static int cavlc_block(Rd* r, int nc, int max_coeff, const uint8_t* scan, int st
       while (!get_bit(b)) {
         if (++prefix > 31 || b->overrun) return h264i_fail(d, "CAVLC: bad level_prefix");
       }
+      if (prefix >= 14 && !(prefix == 14 && suffix_len)) COV(d, H264O_COV_ESCAPE + (prefix == 14 ? 0 : (prefix == 15 ? 1 : 2)));
       code = imin(15, prefix) << suffix_len;
       int size = suffix_len;
       if (prefix == 14 && suffix_len == 0) size = 4;
@@ -570,6 +576,8 @@ static int cavlc_block(Rd* r, int nc, int max_coeff, const uint8_t* scan, int st
     else
       tz = sx_vlc(r, total_zeros_len[total - 1], total_zeros_bits[total - 1], total_zeros_count[total - 1], zeros_total);
     if (tz < 0) return h264i_fail(d, "CAVLC: bad total_zeros");
+    if (nc == -1) COV(d, H264O_COV_TOTAL_ZEROS_DC + (total - 1) * 4 + tz);
+    else COV(d, H264O_COV_TOTAL_ZEROS + (total - 1) * 16 + tz);
     zeros_left = tz;
   }
   if (zeros_left + total > max_coeff) return h264i_fail(d, "CAVLC: total_zeros exceeds block size");
@@ -582,6 +590,7 @@ static int cavlc_block(Rd* r, int nc, int max_coeff, const uint8_t* scan, int st
       int t = imin(zeros_left, 7) - 1;
       rb = sx_vlc(r, run_before_len[t], run_before_bits[t], run_before_count[t], r->enc ? run[i] : 0);
       if (rb < 0 || rb > zeros_left) return h264i_fail(d, "CAVLC: bad run_before");
+      COV(d, H264O_COV_RUN_BEFORE + t * 15 + rb);
       zeros_left -= rb;
     }
     pos -= rb + 1;
@@ -651,6 +660,7 @@ static int cabac_block(Rd* r, int cat, int cbf_inc, int max_coeff, const uint8_t
       val = 2;
       while (val < 15 && sx_bin(r, abs_base + inc, target > val)) ++val;
       if (val == 15) { /* prefix saturated: Exp-Golomb k=0 suffix */
+        COV(d, H264O_COV_ESCAPE + 3);
         int k0 = 0, rem = target - 15;
         while (sx_bypass(r, rem >= (1 << k0))) {
           val += 1 << k0;
@@ -843,6 +853,7 @@ static int sx_mvd(Rd* r, int list, int bx, int by, int comp, int v) {
     ++val;
   }
   if (val >= 9) {
+    COV(d, H264O_COV_ESCAPE + 4);
     int k = 3, rem = a - 9;
     while (sx_bypass(r, rem >= (1 << k))) {
       val += 1 << k;
@@ -1071,6 +1082,7 @@ static int code_inter(Rd* r, int mb_type) {
       int t = sx_sub_mb_type(r, P ? P->sub_type[i] : 0);
       if (t < 0 || t > (is_b ? 12 : 3)) return h264i_fail(d, "bad sub_mb_type");
       m->sub_type[i] = t;
+      COV(d, (is_b ? H264O_COV_SUB_B : H264O_COV_SUB_P) + t);
       if (is_b) {
         sub_shape[i] = b_sub_info[t][0];
         pred[i] = b_sub_info[t][1];
@@ -1226,6 +1238,7 @@ static int code_skip_mb(H264Oracle* d, int addr) {
   m->kind = MB_INTER;
   m->skip = 1;
   d->last_qp_delta_nonzero = 0;
+  COV(d, d->sl.type == 0 ? H264O_COV_MBTYPE_P + 31 : H264O_COV_MBTYPE_B + 49);
   if (d->sl.type == 0) {
     for (int q = 0; q < 4; ++q) set_ref8(d, 0, q, 0);
     int mv[2];
@@ -1261,6 +1274,7 @@ static int code_mb(Rd* r, int addr) {
   }
   if (intra_t > 25) return h264i_fail(d, "bad mb_type (I)");
   m->mb_type_raw = t;
+  COV(d, (st == 2 ? H264O_COV_MBTYPE_I : (st == 0 ? H264O_COV_MBTYPE_P : H264O_COV_MBTYPE_B)) + t);
 
   if (intra_t == 25) { /* I_PCM */
     m->kind = MB_IPCM;
@@ -1407,11 +1421,16 @@ int h264i_decode_slice_data(H264Oracle* d, Bits* b) {
       if (!get_bit(b)) return h264i_fail(d, "cabac_alignment_one_bit is zero");
     }
     cabac_init_contexts(&d->cabac, sl->type, sl->cabac_init_idc, sl->qp);
+    d->cov_ctx_table = sl->type == 2 ? 0 : (sl->type == 0 ? 1 : 4) + sl->cabac_init_idc;
     cabac_start(&d->cabac, b);
     for (;;) {
       if (addr >= nmb) return h264i_fail(d, "slice runs past the end of the picture");
       int skipped = 0;
-      if (sl->type != 2) skipped = cabac_bin(&d->cabac, skip_flag_ctx(d, addr));
+      if (sl->type != 2) {
+        const int sctx = skip_flag_ctx(d, addr);
+        skipped = cabac_bin(&d->cabac, sctx);
+        COV(d, H264O_COV_CTX + (d->cov_ctx_table * CABAC_CTX_COUNT + sctx) * 2 + (skipped != 0));
+      }
       if (skipped) {
         if (code_skip_mb(d, addr) < 0) return -1;
       } else {
@@ -1478,6 +1497,7 @@ void h264i_enc_begin_slice(H264Oracle* d, BitWriter* w) {
   if (d->apps->cabac) {
     while (w->pos & 7) bw_put(w, 1, 1); /* cabac_alignment_one_bit */
     cabac_init_contexts(&d->cabac, sl->type, sl->cabac_init_idc, sl->qp);
+    d->cov_ctx_table = sl->type == 2 ? 0 : (sl->type == 0 ? 1 : 4) + sl->cabac_init_idc;
     cenc_start(&d->cenc, w);
   }
 }

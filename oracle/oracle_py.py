@@ -25,14 +25,30 @@ def load():
     lib.h264o_error.argtypes = [C.c_void_p]
     lib.h264o_error.restype = C.c_char_p
     lib.h264o_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.h264o_coverage_enable.argtypes = [C.c_void_p]
+    lib.h264o_coverage.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
     lib.h264o_yuv420_to_rgb24.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     return lib
 
 
+# coverage histogram sections: name -> (base, cells); the layout is documented in h264_oracle.h
+COV_SECTIONS = {}
+_off = 0
+for _name, _n in (("i4", 144), ("i8", 144), ("i16", 16), ("ic", 16), ("luma_mc", 48), ("chroma_mc", 64), ("wp", 9),
+                  ("bs", 60), ("filt", 12), ("mbtype_i", 26), ("mbtype_p", 32), ("mbtype_b", 50), ("sub_p", 4),
+                  ("sub_b", 13), ("coeff_token", 340), ("total_zeros", 240), ("total_zeros_dc", 12),
+                  ("run_before", 105), ("escape", 5), ("dequant", 7), ("direct", 8), ("ctx", 7 * 460 * 2)):
+    COV_SECTIONS[_name] = (_off, _n)
+    _off += _n
+COV_CELLS = _off
+
+
 class OracleDecoder(object):
-    def __init__(self, extradata):
+    def __init__(self, extradata, coverage=False):
         self.lib = load()
         self.h = self.lib.h264o_open()
+        if coverage:
+            self.lib.h264o_coverage_enable(self.h)
         extradata = bytes(extradata)
         if self.lib.h264o_configure(self.h, extradata, len(extradata)):
             raise RuntimeError("oracle configure: " + self.error())
@@ -82,6 +98,17 @@ class OracleDecoder(object):
         return dict(zip(keys, list(c)))
 
 
+def _coverage(self):
+    """The coverage histogram as an int64 array of COV_CELLS cells (see COV_SECTIONS)."""
+    out = np.zeros(COV_CELLS, dtype=np.int64)
+    n = self.lib.h264o_coverage(self.h, out.ctypes.data_as(C.POINTER(C.c_int64)), COV_CELLS)
+    assert n == COV_CELLS, "oracle_py.COV_SECTIONS is out of step with h264_oracle.h"
+    return out
+
+
+OracleDecoder.coverage = _coverage
+
+
 def i420_to_rgb(i420, w, h):
     lib = load()
     rgb = np.empty((h, w, 3), dtype=np.uint8)
@@ -90,16 +117,19 @@ def i420_to_rgb(i420, w, h):
     return rgb
 
 
-def decode_file(path, index, first=0, count=None):
+def decode_file(path, index, first=0, count=None, coverage=None):
     """Sequentially decodes samples [first, first+count) of an indexed MP4;
-    returns frames in display order."""
+    returns frames in display order.  `coverage`: an int64 array of COV_CELLS
+    cells that this decode's histogram is added to."""
     offs, sizes = index.sample_offsets(), index.sample_sizes()
     n = index.frames() if count is None else count
-    dec = OracleDecoder(index.metadata_bytes())
+    dec = OracleDecoder(index.metadata_bytes(), coverage=coverage is not None)
     frames = []
     with open(path, "rb") as f:
         for i in range(first, first + n):
             f.seek(offs[i])
             frames += dec.decode(f.read(sizes[i]))
     frames += dec.flush()
+    if coverage is not None:
+        coverage += dec.coverage()
     return frames, dec.counters()

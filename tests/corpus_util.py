@@ -135,4 +135,84 @@ MATRIX = [
     ("random_intra", dict(frames=8, gop=2, bframes=0, random_intra=1, qp=22)),
     ("random_intra_cavlc_slices", dict(frames=9, gop=3, bframes=1, random_intra=1, cabac=0, slice_mbs=31, constrained_intra=1)),
     ("random_intra_t4_only", dict(frames=6, gop=3, bframes=0, random_intra=1, t8x8=0, slices=3, qp=34)),
+    # round 3: --cover makes the encoder take by hash what its mode decision never picks (intra macroblocks of every family
+    # and type in P and B slices, Intra16x16 with chroma but no luma AC or without a DC block, B 16x8 / 8x16 halves from
+    # different lists, explicit quadrants with reference 0 beside neighbours above 0, levels that need level_prefix >= 16):
+    # with these eight the corpus reaches every cell of the coverage histogram that tests/coverage_model.py calls reachable
+    ("cover_cabac", dict(frames=26, gop=13, bframes=2, refs=3, cover=1, random_intra=1, constrained_intra=1, qp_swing=1, slices=2)),
+    ("cover_cavlc", dict(frames=26, gop=13, bframes=2, refs=3, cover=1, random_intra=1, constrained_intra=1, qp_swing=1, cabac=0,
+                         slice_mbs=41)),
+    ("cover_cabac_t4", dict(frames=20, gop=10, bframes=1, refs=2, cover=1, random_intra=1, t8x8=0, qp=20)),
+    ("cover_cabac_hiqp", dict(frames=39, gop=13, bframes=2, refs=3, cover=1, random_intra=1, constrained_intra=1, qp=45,
+                              pcm_period=211, slice_mbs=67)),
+    ("cover_cavlc_midqp", dict(frames=26, gop=13, bframes=2, refs=2, cover=1, random_intra=1, qp=16, cabac=0, seed=5)),
+    ("cover_cabac_pyramid", dict(frames=39, gop=13, bframes=3, refs=4, cover=1, random_intra=1, bpyramid=1, temporal_direct=1,
+                                 implicit_wp=1, qp=36, seed=9)),
+    ("cover_cabac_hiqp2", dict(frames=52, gop=13, bframes=2, refs=4, cover=1, random_intra=1, constrained_intra=1, qp=40, slices=3,
+                               seed=9, rplm=1)),
+    ("cover_cabac_pyramid2", dict(frames=39, gop=13, bframes=3, refs=4, cover=1, bpyramid=1, temporal_direct=1, implicit_wp=1, qp=30,
+                                  seed=4, slices=2)),
 ]
+
+
+# The row kernels cut a picture into bands of four macroblock rows, one
+# workgroup each: cover every remainder (1, 2, 3 rows in the last band, a single
+# band, a single row, a single column), pictures wider than the 256-macroblock
+# LDS line buffers (surface hand-off, host-side vectors) and slices that end
+# inside a band.
+BAND_SIZES = [
+    ("1x1mb", 16, 16, dict(frames=6, gop=6, bframes=1)),
+    ("1col_5rows", 16, 80, dict(frames=6, gop=6, bframes=1)),
+    ("3x5mb", 48, 80, dict(frames=7, gop=7, bframes=2)),
+    ("4x6mb", 64, 96, dict(frames=7, gop=7, bframes=2, slices=2)),
+    ("qcif_9rows", 176, 144, dict(frames=9, gop=9, bframes=2, slices=3)),
+    ("wide_129x3mb", 2064, 48, dict(frames=5, gop=5, bframes=1)),
+    ("wide_130x7mb_slices", 2080, 112, dict(frames=5, gop=5, bframes=0, slices=4)),
+    ("wide_257x3mb", 4112, 48, dict(frames=5, gop=5, bframes=1)),
+    ("wide_258x6mb_slices", 4128, 96, dict(frames=4, gop=4, bframes=0, slices=3)),
+    # the same edges with the syntax variety added in round 2: mixed slice types cut mid-row, reference B pictures,
+    # two parameter sets, wild vectors, QP swings
+    ("wide_257x5mb_mixed", 4112, 80, dict(frames=7, gop=7, bframes=2, refs=4, bpyramid=0, mixed_slices=1, slice_mbs=301,
+                                            multi_pps=2, wild_mv=1, qp_swing=1)),
+    ("wide_131x9mb_pyramid", 2096, 144, dict(frames=9, gop=9, bframes=3, refs=4, bpyramid=1, slice_mbs=97, mixed_slices=1,
+                                              temporal_direct=1, implicit_wp=1, rate_kbit=60)),
+    # the largest sides the decoder takes: 512 macroblocks (8192 samples) wide or high
+    ("wide_512x1mb", 8192, 16, dict(frames=4, gop=4, bframes=1)),
+    ("tall_1x512mb", 16, 8192, dict(frames=4, gop=4, bframes=1, slices=5)),
+    ("wide_511x2mb", 8176, 32, dict(frames=4, gop=4, bframes=1, refs=2, mixed_slices=1, slice_mbs=200)),
+    ("7x7mb_everything", 112, 112, dict(frames=13, gop=13, bframes=3, refs=4, bpyramid=1, slice_mbs=5, mixed_slices=1,
+                                          multi_pps=2, wild_mv=1, qp_swing=1, fn_bits=4, poc_bits=5, extra_nals=1)),
+]
+
+
+def all_cases():
+    """(name, width, height, encoder kwargs) of every MATRIX and BAND_SIZES case, as the parity tests encode them."""
+    for name, kw in MATRIX:
+        kw = dict(kw)
+        w, h = kw.pop("width", 322 if name == "qp40" else 320), kw.pop("height", 242 if name == "qp40" else 240)
+        yield name, w, h, kw
+    for name, w, h, kw in BAND_SIZES:
+        yield name, w, h, dict(kw)
+
+
+def plane_md5s(i420, w, h):
+    """MD5 of the Y, U and V plane of one cropped I420 frame (the form tests/golden/corpus_md5.json holds)."""
+    import hashlib
+    cw, ch = (w + 1) // 2, (h + 1) // 2
+    b = np.ascontiguousarray(i420).tobytes()
+    y, u, v = b[:w * h], b[w * h:w * h + cw * ch], b[w * h + cw * ch:w * h + 2 * cw * ch]
+    return [hashlib.md5(p).hexdigest() for p in (y, u, v)]
+
+
+_GOLDEN_MD5 = None
+
+
+def golden_md5(name):
+    """The committed per-frame plane digests of a corpus case (tests/golden/corpus_md5.json, written by
+    tests/golden/make_corpus_golden.py from the CPU oracle's output): {"mp4_md5", "frames": [[y, u, v], ...]}."""
+    global _GOLDEN_MD5
+    if _GOLDEN_MD5 is None:
+        import json
+        with open(os.path.join(ROOT, "tests", "golden", "corpus_md5.json")) as f:
+            _GOLDEN_MD5 = json.load(f)
+    return _GOLDEN_MD5["cases"][name]

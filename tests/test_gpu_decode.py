@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from tests.corpus_util import MATRIX, make_clip
+from tests.corpus_util import BAND_SIZES, MATRIX, golden_md5, make_clip, plane_md5s
 from tests.util import REALSHORT, have_file
 
 pytestmark = pytest.mark.gpu
@@ -38,36 +38,8 @@ def test_all_frames_bit_exact(hw, oracle, gpu, tmp_path, name, kw):
     assert len(got) == len(gold)
     for i in range(len(gold)):
         assert np.array_equal(got[i], gold[i]), "frame %d differs from the oracle/encoder reconstruction" % i
-
-
-# The row kernels cut a picture into bands of four macroblock rows, one
-# workgroup each: cover every remainder (1, 2, 3 rows in the last band, a single
-# band, a single row, a single column), pictures wider than the 256-macroblock
-# LDS line buffers (surface hand-off, host-side vectors) and slices that end
-# inside a band.
-BAND_SIZES = [
-    ("1x1mb", 16, 16, dict(frames=6, gop=6, bframes=1)),
-    ("1col_5rows", 16, 80, dict(frames=6, gop=6, bframes=1)),
-    ("3x5mb", 48, 80, dict(frames=7, gop=7, bframes=2)),
-    ("4x6mb", 64, 96, dict(frames=7, gop=7, bframes=2, slices=2)),
-    ("qcif_9rows", 176, 144, dict(frames=9, gop=9, bframes=2, slices=3)),
-    ("wide_129x3mb", 2064, 48, dict(frames=5, gop=5, bframes=1)),
-    ("wide_130x7mb_slices", 2080, 112, dict(frames=5, gop=5, bframes=0, slices=4)),
-    ("wide_257x3mb", 4112, 48, dict(frames=5, gop=5, bframes=1)),
-    ("wide_258x6mb_slices", 4128, 96, dict(frames=4, gop=4, bframes=0, slices=3)),
-    # the same edges with the syntax variety added in round 2: mixed slice types cut mid-row, reference B pictures,
-    # two parameter sets, wild vectors, QP swings
-    ("wide_257x5mb_mixed", 4112, 80, dict(frames=7, gop=7, bframes=2, refs=4, bpyramid=0, mixed_slices=1, slice_mbs=301,
-                                            multi_pps=2, wild_mv=1, qp_swing=1)),
-    ("wide_131x9mb_pyramid", 2096, 144, dict(frames=9, gop=9, bframes=3, refs=4, bpyramid=1, slice_mbs=97, mixed_slices=1,
-                                              temporal_direct=1, implicit_wp=1, rate_kbit=60)),
-    # the largest sides the decoder takes: 512 macroblocks (8192 samples) wide or high
-    ("wide_512x1mb", 8192, 16, dict(frames=4, gop=4, bframes=1)),
-    ("tall_1x512mb", 16, 8192, dict(frames=4, gop=4, bframes=1, slices=5)),
-    ("wide_511x2mb", 8176, 32, dict(frames=4, gop=4, bframes=1, refs=2, mixed_slices=1, slice_mbs=200)),
-    ("7x7mb_everything", 112, 112, dict(frames=13, gop=13, bframes=3, refs=4, bpyramid=1, slice_mbs=5, mixed_slices=1,
-                                          multi_pps=2, wild_mv=1, qp_swing=1, fn_bits=4, poc_bits=5, extra_nals=1)),
-]
+    # ... and from the digests committed in tests/golden/corpus_md5.json (frozen oracle output)
+    assert [plane_md5s(f, w, h) for f in got] == golden_md5(name)["frames"]
 
 
 @pytest.mark.parametrize("name,w,h,kw", BAND_SIZES, ids=[b[0] for b in BAND_SIZES])
@@ -80,6 +52,7 @@ def test_band_edge_sizes_bit_exact(hw, gpu, tmp_path, name, w, h, kw):
     assert len(got) == len(gold)
     for i in range(len(gold)):
         assert np.array_equal(got[i], gold[i]), "%s: frame %d differs from the encoder's reconstruction" % (name, i)
+    assert [plane_md5s(f, w, h) for f in got] == golden_md5(name)["frames"]
 
 
 @pytest.mark.skipif(not have_file(REALSHORT), reason="realshort.mp4 not in this image")
