@@ -87,6 +87,105 @@ def test_c3_batch_of_clips(hw, oracle, gpu, tmp_path):
     assert all(s == [1, 1, 1, 1] for s in seen), seen
 
 
+@pytest.fixture(scope="module")
+def c3_clips(tmp_path_factory):
+    """Sixteen 1080p30 clips (BASELINE C3's per-GPU share: 128 clips over 8 GPUs), different seeds and settings,
+    600 frames each (120 unique frames = two GOPs of 60, repeated: every repeat is an independent run of closed
+    GOPs), encoded concurrently.  The encoder's reconstruction is kept only for the rows that are asked for."""
+    import os
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from tests.corpus_util import ENCODER
+    tmp = tmp_path_factory.mktemp("c3")
+    W, H, N, UNIQUE = 1920, 1080, 600, 120
+    fs = W * H * 3 // 2
+    rng = np.random.default_rng(20240601)
+
+    def encode(k):
+        path = str(tmp / ("clip%02d.mp4" % k))
+        args = [ENCODER, "--width", str(W), "--height", str(H), "--frames", str(UNIQUE), "--repeat", str(N // UNIQUE),
+                "--gop", "60", "--bframes", "2", "--refs", str(2 + k % 3), "--seed", str(100 + k), "--threads", "2",
+                "--cabac", "0" if k % 5 == 4 else "1", "--slices", str(1 + k % 2), "--qp", str(24 + k % 7),
+                "--out", path, "--yuv-out", path + ".yuv"]
+        r = subprocess.run(args, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-400:]
+        return path
+
+    with ThreadPoolExecutor(max_workers=max(1, (os.cpu_count() or 2) // 2)) as pool:
+        paths = list(pool.map(encode, range(16)))
+    clips = []
+    for k, path in enumerate(paths):
+        rows = sorted(rng.choice(N, N // 100, replace=False).tolist())   # the 1 % sample
+        gold = {}
+        with open(path + ".yuv", "rb") as f:
+            for r in rows:
+                f.seek(r * fs)
+                gold[r] = np.frombuffer(f.read(fs), dtype=np.uint8)
+        os.unlink(path + ".yuv")
+        clips.append((path, rows, gold))
+    return clips, W, H, N
+
+
+def test_c3_sixteen_1080p_clips_one_batch(hw, oracle, gpu, c3_clips):
+    """BASELINE C3 at its per-GPU size: 16 x 1080p clips, a 1 % random sample of each, ONE retrieve_batch call whose
+    GOP work items share the lanes; every returned row against the oracle-equal reconstruction (I420, bit-exact)
+    and, as RGB, against the oracle's colour conversion of it."""
+    from hwang_amd.decoder import BatchRetriever
+    clips, W, H, N = c3_clips
+    idxs = [hw.index_video(c[0]) for c in clips]
+    for idx in idxs:
+        assert idx.frames() == N and (idx.frame_width(), idx.frame_height()) == (W, H)
+    br = BatchRetriever(device_ids=[0], num_lanes=24)
+    fs = W * H * 3 // 2
+    bufs = [np.zeros((len(c[1]), fs), dtype=np.uint8) for c in clips]
+    br.retrieve_into([(idxs[k], clips[k][0], clips[k][1], bufs[k].ctypes.data, bufs[k].nbytes) for k in range(16)], yuv=True)
+    st = br.stats()
+    assert st["frames_returned"] == sum(len(c[1]) for c in clips)
+    assert st["pictures_skipped"] > 0
+    for k, (path, rows, gold) in enumerate(clips):
+        for i, r in enumerate(rows):
+            assert np.array_equal(bufs[k][i], gold[r]), "clip %d row %d differs from the reconstruction" % (k, r)
+    rgb = br.retrieve([(idxs[k], clips[k][0], clips[k][1][:2]) for k in range(16)])
+    for k, (path, rows, gold) in enumerate(clips):
+        for i in range(2):
+            assert np.array_equal(rgb[k][i], oracle.i420_to_rgb(gold[rows[i]], W, H)), "clip %d row %d (RGB)" % (k, rows[i])
+
+
+def test_c3_128_requests_batch_equals_per_clip_and_shards(hw, gpu, c3_clips):
+    """C3's full request count on one GPU: 128 requests (the sixteen clips, eight different 1 % samples each) in one
+    batch == the same requests clip by clip, and three shards of the batch are disjoint and together complete."""
+    from hwang_amd.decoder import BatchRetriever
+    clips, W, H, N = c3_clips
+    idxs = [hw.index_video(c[0]) for c in clips]
+    rng = np.random.default_rng(7)
+    reqs = []
+    for j in range(128):
+        k = j % 16
+        reqs.append((k, sorted(rng.choice(N, N // 100, replace=False).tolist())))
+    fs = W * H * 3 // 2
+
+    def run(br, subset):
+        bufs = [np.zeros((len(reqs[j][1]), fs), dtype=np.uint8) for j in subset]
+        br.retrieve_into([(idxs[reqs[j][0]], clips[reqs[j][0]][0], reqs[j][1], b.ctypes.data, b.nbytes)
+                          for j, b in zip(subset, bufs)], yuv=True)
+        return [md5s(b) for b in bufs]
+
+    batch = run(BatchRetriever(device_ids=[0], num_lanes=32), list(range(128)))
+    single = BatchRetriever(device_ids=[0], num_lanes=8)
+    for j in range(0, 128, 9):   # every ninth request on its own
+        assert run(single, [j])[0] == batch[j], "request %d: batch != per-clip" % j
+    zero = hashlib.md5(bytes(fs)).hexdigest()
+    seen = [[0] * len(r[1]) for r in reqs]
+    for rank in range(3):
+        part = run(BatchRetriever(device_ids=[0], num_lanes=16, shard=(rank, 3)), list(range(128)))
+        for j in range(128):
+            for i, d in enumerate(part[j]):
+                if d != zero:
+                    assert d == batch[j][i]
+                    seen[j][i] += 1
+    assert all(all(c == 1 for c in s) for s in seen)
+
+
 def test_c4_4k_high_bitrate_dense(hw, oracle, gpu, tmp_path):
     path = str(tmp_path / "c4.mp4")
     gold = make_clip(path, width=3840, height=2160, frames=16, gop=8, bframes=2, qp=18, fps=60, threads=2)
