@@ -118,9 +118,10 @@ def c3_clips(tmp_path_factory):
         rows = sorted(rng.choice(N, N // 100, replace=False).tolist())   # the 1 % sample
         gold = {}
         with open(path + ".yuv", "rb") as f:
-            for r in rows:
-                f.seek(r * fs)
+            for r in rows:   # the reconstruction file holds the unique frames once: frame r shows unique frame r % UNIQUE
+                f.seek((r % UNIQUE) * fs)
                 gold[r] = np.frombuffer(f.read(fs), dtype=np.uint8)
+                assert gold[r].size == fs
         os.unlink(path + ".yuv")
         clips.append((path, rows, gold))
     return clips, W, H, N
