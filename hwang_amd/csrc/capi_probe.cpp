@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,44 +27,70 @@ struct ProbeSink : public h264::PictureSink {
     std::vector<uint32_t> pmx;
   };
   std::vector<Slot> slots = std::vector<Slot>(amd::kMaxSurfaces);
-  std::vector<amd::MbInfo> mb;
-  std::vector<uint32_t> coefs;
-  std::vector<amd::SliceParams> slices = std::vector<amd::SliceParams>(256);  // as the decoder: MbInfo::slice is one byte
+  // staging buffers of the pictures between begin_picture and end_picture: one set in serial mode, a ring with
+  // entropy workers (PicBuffers::cookie names the set)
+  struct Staging {
+    std::vector<amd::MbInfo> mb;
+    std::vector<uint32_t> coefs;
+    std::vector<amd::SliceParams> slices = std::vector<amd::SliceParams>(256);  // as the decoder: MbInfo::slice is one byte
+  };
+  std::vector<Staging> staging = std::vector<Staging>(1);
+  int staging_cursor = 0;
+  bool pipelined = false;   // surfaces are handed out round robin: the numbering must not depend on when workers let go
+  int slot_cursor = 0;
+  std::mutex mu;            // release_surface comes from any thread
   int nmb = 0;
   uint64_t digest = 1469598103934665603ull;
+  uint64_t digest_noslot = 1469598103934665603ull;  // the same records with MbMotion::ref_slot blanked
   std::vector<int> outputs;  // slot per output (-1 skipped)
   int64_t coef_total = 0, inter_pics = 0;
 
   bool fast = getenv("HWANG_PROBE_FAST") != nullptr;  // timing runs: no digest, no clearing
-  void mix(const void* p, size_t n) {
+  void mix(const void* p, size_t n, bool both = true) {
     if (fast) return;
     const uint8_t* b = static_cast<const uint8_t*>(p);
-    for (size_t i = 0; i < n; ++i) digest = (digest ^ b[i]) * 1099511628211ull;
+    if (both)
+      for (size_t i = 0; i < n; ++i) digest = (digest ^ b[i]) * 1099511628211ull;
+    for (size_t i = 0; i < n; ++i) digest_noslot = (digest_noslot ^ b[i]) * 1099511628211ull;
   }
   bool begin_picture(const h264::PicSetup& s, h264::PicBuffers* out, std::string* error) override {
     nmb = s.mb_width * s.mb_height;
     int slot = -1;
-    for (int i = 0; i < amd::kMaxSurfaces; ++i)
-      if (!slots[i].busy) {
-        slot = i;
-        break;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (pipelined) {
+        if (!slots[slot_cursor].busy) {
+          slot = slot_cursor;
+          slot_cursor = (slot_cursor + 1) % amd::kMaxSurfaces;
+        }
+      } else {
+        for (int i = 0; i < amd::kMaxSurfaces; ++i)
+          if (!slots[i].busy) {
+            slot = i;
+            break;
+          }
       }
+      if (slot >= 0) slots[slot].busy = true;
+    }
     if (slot < 0) {
       *error = "probe: out of surfaces";
+      out->no_surface = true;
       return false;
     }
-    slots[slot].busy = true;
+    Staging& st = staging[staging_cursor];
+    out->cookie = staging_cursor;
+    staging_cursor = (staging_cursor + 1) % static_cast<int>(staging.size());
     if (!fast || slots[slot].motion.size() != static_cast<size_t>(nmb)) {
       slots[slot].motion.assign(nmb, amd::MbMotion());
-      mb.assign(nmb, amd::MbInfo());
-      coefs.assign(static_cast<size_t>(nmb) * amd::kMaxSparseCoefs, 0);
+      st.mb.assign(nmb, amd::MbInfo());
+      st.coefs.assign(static_cast<size_t>(nmb) * amd::kMaxSparseCoefs, 0);
     }
-    out->mb = mb.data();
+    out->mb = st.mb.data();
     out->motion = slots[slot].motion.data();
-    out->coefs = coefs.data();
-    out->coef_capacity = coefs.size();
-    out->slices = slices.data();
-    out->max_slices = static_cast<int>(slices.size());
+    out->coefs = st.coefs.data();
+    out->coef_capacity = st.coefs.size();
+    out->slices = st.slices.data();
+    out->max_slices = static_cast<int>(st.slices.size());
     out->slot = slot;
     out->device_mv = fast;  // timing runs measure what the GPU path runs (P vectors left to k_mv); digests keep the host derivation
     if (fast) {
@@ -78,34 +105,49 @@ struct ProbeSink : public h264::PictureSink {
     return true;
   }
   bool end_picture(const h264::PicDone& d, std::string*) override {
+    Staging& st = staging[d.cookie];
     if (!fast)
-      for (amd::MbInfo m : mb) {  // the derivation hints are not part of what the golden digests froze
+      for (amd::MbInfo m : st.mb) {  // the derivation hints are not part of what the golden digests froze
         m.mv_flags = m.mv_shape = m.mv_sub = 0;
         mix(&m, sizeof(m));
       }
-    mix(coefs.data(), d.coef_count * sizeof(uint32_t));
-    if (d.has_inter) {
+    mix(st.coefs.data(), d.coef_count * sizeof(uint32_t));
+    if (d.has_inter && !fast) {
       // ref_slot depends on this sink's slot numbering, which is stable
-      mix(slots[d.slot].motion.data(), slots[d.slot].motion.size() * sizeof(amd::MbMotion));
-      ++inter_pics;
+      const std::vector<amd::MbMotion>& mo = slots[d.slot].motion;
+      const uint64_t keep = digest_noslot;
+      mix(mo.data(), mo.size() * sizeof(amd::MbMotion));
+      digest_noslot = keep;
+      for (amd::MbMotion m : mo) {
+        std::memset(m.ref_slot, 0, sizeof(m.ref_slot));
+        mix(&m, sizeof(m), false);
+      }
     }
+    if (d.has_inter) ++inter_pics;
     coef_total += static_cast<int64_t>(d.coef_count);
     return true;
   }
   void output_picture(int slot) override { outputs.push_back(slot); }
   void release_surface(int slot) override {
+    std::lock_guard<std::mutex> lk(mu);
     if (slot >= 0) slots[slot].busy = false;
   }
 };
 
 }  // namespace
 
-extern "C" int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
-                                const uint64_t* sample_offsets, const uint64_t* sample_sizes,
-                                size_t num_samples, const uint64_t* wanted, size_t num_wanted,
-                                int64_t out[8], char* error, size_t error_capacity) {
+static int run_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data, const uint64_t* sample_offsets,
+                     const uint64_t* sample_sizes, size_t num_samples, const uint64_t* wanted, size_t num_wanted,
+                     int workers, int64_t* out, int nout, char* error, size_t error_capacity) {
   ProbeSink sink;
-  h264::Parser parser(&sink);
+  std::unique_ptr<h264::WorkerPool> pool;
+  const int in_flight = workers > 0 ? 2 * workers : 0;
+  if (workers > 0) {
+    pool.reset(new h264::WorkerPool(workers));
+    sink.pipelined = true;
+    sink.staging.resize(in_flight + 2);
+  }
+  h264::Parser parser(&sink, pool.get(), in_flight);
   auto report = [&](const std::string& e) {
     if (error && error_capacity) {
       std::strncpy(error, e.c_str(), error_capacity - 1);
@@ -128,5 +170,22 @@ extern "C" int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uin
   out[5] = skipped_out;
   out[6] = sink.coef_total;
   out[7] = static_cast<int64_t>(sink.digest & 0x7fffffffffffffffull);
+  if (nout > 8) out[8] = static_cast<int64_t>(sink.digest_noslot & 0x7fffffffffffffffull);
   return 0;
+}
+
+extern "C" int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
+                                const uint64_t* sample_offsets, const uint64_t* sample_sizes,
+                                size_t num_samples, const uint64_t* wanted, size_t num_wanted,
+                                int64_t out[8], char* error, size_t error_capacity) {
+  return run_probe(avcc, avcc_size, data, sample_offsets, sample_sizes, num_samples, wanted, num_wanted, 0, out, 8,
+                   error, error_capacity);
+}
+
+extern "C" int hwang_h264_probe_workers(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
+                                        const uint64_t* sample_offsets, const uint64_t* sample_sizes,
+                                        size_t num_samples, const uint64_t* wanted, size_t num_wanted,
+                                        int workers, int64_t out[9], char* error, size_t error_capacity) {
+  return run_probe(avcc, avcc_size, data, sample_offsets, sample_sizes, num_samples, wanted, num_wanted, workers, out, 9,
+                   error, error_capacity);
 }

@@ -5,6 +5,12 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <emmintrin.h>
 #include <immintrin.h>
 
@@ -335,17 +341,17 @@ struct Pps {
   uint8_t scaling8[2][64];
 };
 
-// A decoded (or skipped) picture in the DPB.
-struct Pic {
-  bool in_use = false;
+// What the slice-data decoders share of a picture: its motion for co-located
+// lookups and the surface it is reconstructed into.  In the serial mode the
+// parser thread is the only user; with entropy workers (Parser's `pool`) a
+// picture's records are written by the worker that decodes it and read by the
+// workers of later B pictures (direct prediction), so the object is reference
+// counted - the DPB entry, the picture's own task and every task that has it in
+// a reference list hold it - and its surface goes back to the sink when the
+// last holder lets go.
+struct PicData {
   int slot = -1;          // GPU surface; -1 for a skipped picture
   int uid = 0;
-  int poc = 0;
-  int frame_num = 0, frame_num_wrap = 0, pic_num = 0;
-  int ref = 0;            // 0 unused, 1 short-term, 2 long-term
-  int long_term_idx = -1;
-  bool needed_for_output = false;
-  // motion kept for co-located lookups
   MbMotion* motion = nullptr;         // owned by the sink (pinned, per surface)
   std::vector<int32_t> ref_uid[2];    // per 8x8
   std::vector<uint8_t> mb_intra;
@@ -361,6 +367,36 @@ struct Pic {
   const uint32_t* pmx = nullptr;
   std::vector<MbMotion> derived;
   bool derived_valid = false;
+  // entropy workers: `parsed` is raised (under mu) when every macroblock record
+  // of the picture is final; `submitted` when the sink has taken the picture
+  // (end_picture) - its display-order output is held back until then
+  std::mutex mu;
+  std::condition_variable cv;
+  bool parsed = true;
+  bool submitted = true;   // (under the parser's pipe_mu)
+  bool dropped = false;    // never handed to the sink (it or an earlier picture failed): its output position is void
+};
+
+// A decoded (or skipped) picture in the DPB: the sequence-level bookkeeping,
+// touched by the parser thread only.
+struct Pic {
+  bool in_use = false;
+  int slot = -1;          // = d->slot
+  int uid = 0;
+  int poc = 0;
+  int frame_num = 0, frame_num_wrap = 0, pic_num = 0;
+  int ref = 0;            // 0 unused, 1 short-term, 2 long-term
+  int long_term_idx = -1;
+  bool needed_for_output = false;
+  std::shared_ptr<PicData> d;
+};
+
+// A reference-list entry as the slice-data decoder sees it: frozen when the
+// slice header is parsed (marking and POC of the DPB entry change later).
+struct RefSnap {
+  PicData* d = nullptr;
+  int slot = -1, uid = 0, poc = 0;
+  int marking = 0;        // 1 short-term, 2 long-term at the time of this slice
 };
 
 struct SliceHdr {
@@ -379,7 +415,9 @@ struct SliceHdr {
   int long_term_reference_flag = 0, adaptive_marking = 0;
   int mmco_count = 0;
   struct { int op, a, b; } mmco[66];
-  Pic* ref_list[2][kMaxRefs + 1];
+  Pic* ref_list[2][kMaxRefs + 1];   // parser thread only
+  RefSnap ref[2][kMaxRefs + 1];      // what the slice data is decoded against
+  int cur_poc = 0;
 };
 
 enum { MB_NONE = 0, MB_I4x4, MB_I8x8, MB_I16x16, MB_IPCM, MB_INTER };
@@ -405,41 +443,67 @@ const int abs_cat_offset[6] = {0, 10, 20, 30, 39, 0};
 const uint8_t identity_scan16[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
 const uint8_t dc_scan4[4] = {0, 1, 2, 3};
 
-}  // namespace
+
+// Recycles PicData objects (their vectors are sized per picture geometry) and
+// gives a picture's surface back to the sink when the last holder lets go.
+struct PicPool : std::enable_shared_from_this<PicPool> {
+  PictureSink* sink = nullptr;
+  std::mutex mu;
+  std::vector<PicData*> free_;
+  ~PicPool() {
+    for (PicData* p : free_) delete p;
+  }
+  std::shared_ptr<PicData> grab() {
+    PicData* p = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      if (!free_.empty()) {
+        p = free_.back();
+        free_.pop_back();
+      }
+    }
+    if (!p) p = new PicData();
+    p->slot = -1;
+    p->motion = nullptr;
+    p->pmo = nullptr;
+    p->pmx = nullptr;
+    p->mv_deferred = false;
+    p->derived_valid = false;
+    p->parsed = p->submitted = true;
+    p->dropped = false;
+    std::shared_ptr<PicPool> self = shared_from_this();
+    return std::shared_ptr<PicData>(p, [self](PicData* q) {
+      if (q->slot >= 0) self->sink->release_surface(q->slot);
+      q->slot = -1;
+      std::lock_guard<std::mutex> lk(self->mu);
+      self->free_.push_back(q);
+    });
+  }
+};
 
 // ===========================================================================
-struct Parser::Impl {
-  Parser* owner;
-  PictureSink* sink;
-  std::string* err;
+// Entropy decoding of one picture's slice data (7.3.4 slice_data() down to the
+// residual blocks): everything below the slice header.  Self-contained per
+// picture - what it knows of other pictures comes frozen in the SliceHdr
+// (reference snapshots) and through PicData of the co-located picture - so
+// several of these may work on consecutive pictures at the same time.  The
+// parser thread owns one (serial mode); every entropy worker has its own.
+// ===========================================================================
+struct SliceData {
+  std::string err;  // first error of the picture in hand
+  int64_t slices = 0, slices_clean_end = 0;
+  bool fail(const char* msg) {
+    if (err.empty()) err = msg;
+    return false;
+  }
 
-  int nal_length_size = 4;
-  Sps sps[kMaxSps];
-  Pps pps[kMaxPps];
   const Sps* asps = nullptr;
   const Pps* apps = nullptr;
   int mbw = 0, mbh = 0;
-
-  std::vector<uint8_t> rbsp;
-
-  Pic dpb[kMaxDpb + 8];
-  int next_uid = 0;
-  Pic* cur = nullptr;
-  bool pic_in_progress = false;
-  bool skipping_picture = false;  // remaining slices of a picture skipped on purpose
+  PicData* cur = nullptr;
   PicBuffers bufs;
   size_t coef_used = 0;
-  int num_slices = 0;
-  bool has_inter = false, has_intra = false, any_deblock = false;
-  int slice_type_mask = 0;
-
-  int prev_poc_msb = 0, prev_poc_lsb = 0, prev_frame_num = 0, prev_frame_num_offset = 0;
-  bool prev_ref_has_mmco5 = false;
-  int max_long_term_frame_idx = -1;
-
-  // sparse decoding
-  std::vector<uint64_t> wanted;
-  uint64_t outputs_emitted = 0;  // since last flush/configure
+  bool has_inter = false, has_intra = false;
 
   SliceHdr sl;
   int slice_index = 0;
@@ -492,651 +556,15 @@ struct Parser::Impl {
     int16_t scratch[26][16];  // dense groups: CAVLC staging, and the fallback form of macroblocks with very many levels
   } mb;
 
-  bool fail(const char* msg) {
-    if (err->empty()) *err = msg;
-    return false;
-  }
-
-  // ----------------------------------------------------------------- NAL
-  int unescape(const uint8_t* src, size_t n) {
-    rbsp.resize(n + 8);
-    size_t o = 0;
-    int zeros = 0;
-    for (size_t i = 0; i < n; ++i) {
-      uint8_t c = src[i];
-      if (zeros >= 2 && c == 3) {
-        zeros = 0;
-        continue;
-      }
-      rbsp[o++] = c;
-      zeros = c == 0 ? zeros + 1 : 0;
-    }
-    memset(rbsp.data() + o, 0, 8);
-    return static_cast<int>(o);
-  }
-
-  // -------------------------------------------------------- parameter sets
-  void scaling_list(Bits& b, uint8_t* out, int size, const uint8_t* fallback, const uint8_t* default_zz) {
-    const uint8_t* scan = size == 16 ? zigzag4x4 : zigzag8x8;
-    if (!b.bit()) {
-      memcpy(out, fallback, size);
-      return;
-    }
-    int last = 8, next = 8;
-    for (int j = 0; j < size; ++j) {
-      if (next != 0) {
-        int delta = b.se();
-        next = (last + delta + 256) & 255;
-        if (j == 0 && next == 0) {
-          for (int k = 0; k < size; ++k) out[scan[k]] = default_zz[k];
-          return;
-        }
-      }
-      last = next == 0 ? last : next;
-      out[scan[j]] = static_cast<uint8_t>(last);
-    }
-  }
-  void scaling_matrices(Bits& b, bool want8, uint8_t s4[6][16], uint8_t s8[2][64], const uint8_t fb4[6][16],
-                        const uint8_t fb8[2][64], bool sps_fallback) {
-    uint8_t d4i[16], d4p[16], d8i[64], d8p[64];
-    for (int k = 0; k < 16; ++k) {
-      d4i[zigzag4x4[k]] = default_4x4_intra[k];
-      d4p[zigzag4x4[k]] = default_4x4_inter[k];
-    }
-    for (int k = 0; k < 64; ++k) {
-      d8i[zigzag8x8[k]] = default_8x8_intra[k];
-      d8p[zigzag8x8[k]] = default_8x8_inter[k];
-    }
-    const uint8_t* f0 = sps_fallback ? fb4[0] : d4i;
-    const uint8_t* f3 = sps_fallback ? fb4[3] : d4p;
-    const uint8_t* f6 = sps_fallback ? fb8[0] : d8i;
-    const uint8_t* f7 = sps_fallback ? fb8[1] : d8p;
-    scaling_list(b, s4[0], 16, f0, default_4x4_intra);
-    scaling_list(b, s4[1], 16, s4[0], default_4x4_intra);
-    scaling_list(b, s4[2], 16, s4[1], default_4x4_intra);
-    scaling_list(b, s4[3], 16, f3, default_4x4_inter);
-    scaling_list(b, s4[4], 16, s4[3], default_4x4_inter);
-    scaling_list(b, s4[5], 16, s4[4], default_4x4_inter);
-    if (want8) {
-      scaling_list(b, s8[0], 64, f6, default_8x8_intra);
-      scaling_list(b, s8[1], 64, f7, default_8x8_inter);
-    } else {
-      memcpy(s8[0], f6, 64);
-      memcpy(s8[1], f7, 64);
-    }
-  }
-
-  int max_dpb_frames(const Sps& s) const {
-    static const int lv[][2] = {{10, 396},   {11, 900},   {12, 2376},  {13, 2376},   {20, 2376},  {21, 4752},
-                                {22, 8100},  {30, 8100},  {31, 18000}, {32, 20480},  {40, 32768}, {41, 32768},
-                                {42, 34816}, {50, 110400}, {51, 184320}, {52, 184320}};
-    int mbs = 184320;
-    for (auto& l : lv)
-      if (l[0] == s.level_idc) mbs = l[1];
-    if (s.level_idc == 11 && (s.constraint_flags & 0x10)) mbs = 396;
-    return iclip(1, 16, mbs / (s.mb_width * s.mb_height));
-  }
-
-  bool parse_sps(Bits& b) {
-    Sps s;
-    memset(s.scaling4, 16, sizeof(s.scaling4));
-    memset(s.scaling8, 16, sizeof(s.scaling8));
-    s.profile_idc = b.get(8);
-    s.constraint_flags = b.get(8);
-    s.level_idc = b.get(8);
-    unsigned id = b.ue();
-    if (id >= kMaxSps) return fail("sps_id out of range");
-    int p = s.profile_idc;
-    if (p == 100 || p == 110 || p == 122 || p == 244 || p == 44 || p == 83 || p == 86 || p == 118 || p == 128 ||
-        p == 138 || p == 139 || p == 134 || p == 135) {
-      int chroma_format_idc = b.ue();
-      if (chroma_format_idc == 3) b.bit();
-      int bdl = b.ue(), bdc = b.ue(), bypass = b.bit();
-      if (chroma_format_idc != 1 || bdl || bdc || bypass)
-        return fail("unsupported stream: only 8-bit 4:2:0 without transform bypass is decoded");
-      s.scaling_matrix_present = b.bit();
-      if (s.scaling_matrix_present) {
-        uint8_t flat4[6][16], flat8[2][64];
-        memset(flat4, 16, sizeof(flat4));
-        memset(flat8, 16, sizeof(flat8));
-        scaling_matrices(b, true, s.scaling4, s.scaling8, flat4, flat8, false);
-      }
-    }
-    // 7.4.2.1.1 ranges; unchecked values used to drive Bits::get(n) with absurd n
-    // (ADVICE r1: stack overflow / backwards cursor on a crafted avcC).
-    unsigned l2fn = b.ue();
-    if (l2fn > 12) return fail("SPS: log2_max_frame_num_minus4 out of range");
-    s.log2_max_frame_num = static_cast<int>(l2fn) + 4;
-    s.poc_type = b.ue();
-    if (s.poc_type == 0) {
-      unsigned l2poc = b.ue();
-      if (l2poc > 12) return fail("SPS: log2_max_pic_order_cnt_lsb_minus4 out of range");
-      s.log2_max_poc_lsb = static_cast<int>(l2poc) + 4;
-    } else if (s.poc_type == 1) {
-      s.delta_pic_order_always_zero = b.bit();
-      s.offset_for_non_ref_pic = b.se();
-      s.offset_for_top_to_bottom = b.se();
-      s.num_ref_frames_in_poc_cycle = b.ue();
-      if (s.num_ref_frames_in_poc_cycle > 255) return fail("bad poc cycle");
-      for (int i = 0; i < s.num_ref_frames_in_poc_cycle; ++i) s.offset_for_ref_frame[i] = b.se();
-    } else if (s.poc_type != 2) {
-      return fail("bad pic_order_cnt_type");
-    }
-    unsigned nref = b.ue();
-    if (nref > 16) return fail("SPS: max_num_ref_frames out of range");
-    s.max_num_ref_frames = static_cast<int>(nref);
-    b.bit();  // gaps_in_frame_num_value_allowed_flag
-    unsigned mbw = b.ue(), mbh = b.ue();
-    if (mbw >= 512 || mbh >= 512) return fail("picture size out of range");
-    s.mb_width = static_cast<int>(mbw) + 1;
-    s.mb_height = static_cast<int>(mbh) + 1;
-    if (!b.bit()) return fail("unsupported stream: interlaced coding (frame_mbs_only_flag = 0)");
-    s.direct_8x8_inference = b.bit();
-    if (b.bit()) {
-      // crop offsets are in chroma units (x2 for 4:2:0); the sum must leave at least one luma column/row (7.4.2.1.1)
-      uint64_t cl = b.ue(), cr = b.ue(), ct = b.ue(), cb = b.ue();
-      if (2 * (cl + cr) >= 16ull * s.mb_width || 2 * (ct + cb) >= 16ull * s.mb_height)
-        return fail("SPS: frame cropping exceeds the picture");
-      s.crop_left = static_cast<int>(2 * cl);
-      s.crop_right = static_cast<int>(2 * cr);
-      s.crop_top = static_cast<int>(2 * ct);
-      s.crop_bottom = static_cast<int>(2 * cb);
-    }
-    if (b.bit()) {  // VUI
-      if (b.bit() && b.get(8) == 255) b.get(32);
-      if (b.bit()) b.bit();
-      if (b.bit()) {
-        b.get(4);
-        if (b.bit()) b.get(24);
-      }
-      if (b.bit()) {
-        b.ue();
-        b.ue();
-      }
-      if (b.bit()) {
-        b.get(32);
-        b.get(32);
-        b.bit();
-      }
-      bool hrd = false;
-      for (int pass = 0; pass < 2; ++pass) {
-        if (!b.bit()) continue;
-        hrd = true;
-        int cpb = b.ue() + 1;
-        b.get(8);
-        for (int i = 0; i < cpb && !b.overrun; ++i) {
-          b.ue();
-          b.ue();
-          b.bit();
-        }
-        b.get(20);
-      }
-      if (hrd) b.bit();
-      b.bit();
-      s.bitstream_restriction = b.bit();
-      if (s.bitstream_restriction) {
-        b.bit();
-        b.ue();
-        b.ue();
-        b.ue();
-        b.ue();
-        s.num_reorder_frames = b.ue();
-        b.ue();
-      }
-    }
-    if (b.overrun) return fail("truncated SPS");
-    if (s.mb_width > 512 || s.mb_height > 512 || s.mb_width < 1 || s.mb_height < 1)
-      return fail("picture size out of range");
-    s.valid = true;
-    sps[id] = s;
-    return true;
-  }
-
-  bool parse_pps(Bits& b) {
-    Pps p;
-    unsigned id = b.ue();
-    if (id >= kMaxPps) return fail("pps_id out of range");
-    p.sps_id = b.ue();
-    if (p.sps_id >= kMaxSps || !sps[p.sps_id].valid) return fail("PPS refers to a missing SPS");
-    const Sps& s = sps[p.sps_id];
-    p.cabac = b.bit();
-    p.bottom_field_pic_order_present = b.bit();
-    if (b.ue() != 0) return fail("unsupported stream: slice groups (FMO)");
-    unsigned nr0 = b.ue(), nr1 = b.ue();
-    if (nr0 > 31 || nr1 > 31) return fail("PPS: num_ref_idx_default_active out of range");
-    p.num_ref_idx_default[0] = static_cast<int>(nr0) + 1;
-    p.num_ref_idx_default[1] = static_cast<int>(nr1) + 1;
-    p.weighted_pred = b.bit();
-    p.weighted_bipred_idc = b.get(2);
-    if (p.weighted_bipred_idc > 2) return fail("PPS: weighted_bipred_idc out of range");
-    int iq = b.se();
-    if (iq < -26 || iq > 25) return fail("PPS: pic_init_qp out of range");
-    p.init_qp = 26 + iq;
-    b.se();
-    p.chroma_qp_offset[0] = b.se();
-    if (p.chroma_qp_offset[0] < -12 || p.chroma_qp_offset[0] > 12) return fail("PPS: chroma_qp_index_offset out of range");
-    p.deblocking_control_present = b.bit();
-    p.constrained_intra_pred = b.bit();
-    p.redundant_pic_cnt_present = b.bit();
-    p.chroma_qp_offset[1] = p.chroma_qp_offset[0];
-    memcpy(p.scaling4, s.scaling4, sizeof(p.scaling4));
-    memcpy(p.scaling8, s.scaling8, sizeof(p.scaling8));
-    if (b.more_rbsp_data()) {
-      p.transform_8x8_mode = b.bit();
-      if (b.bit())
-        scaling_matrices(b, p.transform_8x8_mode, p.scaling4, p.scaling8, s.scaling4, s.scaling8,
-                         s.scaling_matrix_present);
-      p.chroma_qp_offset[1] = b.se();
-      if (p.chroma_qp_offset[1] < -12 || p.chroma_qp_offset[1] > 12)
-        return fail("PPS: second_chroma_qp_index_offset out of range");
-    }
-    if (b.overrun) return fail("truncated PPS");
-    p.valid = true;
-    pps[id] = p;
-    return true;
-  }
-
-  // ------------------------------------------------------------------ DPB
-  void release_unused() {
-    for (Pic& p : dpb) {
-      if (p.in_use && &p != cur && !p.ref && !p.needed_for_output) {
-        p.in_use = false;
-        if (p.slot >= 0) sink->release_surface(p.slot);
-        p.slot = -1;
-      }
-    }
-  }
-  Pic* grab_pic() {
-    for (Pic& p : dpb)
-      if (!p.in_use) {
-        p.in_use = true;
-        p.uid = ++next_uid;
-        p.ref = 0;
-        p.needed_for_output = false;
-        p.long_term_idx = -1;
-        p.slot = -1;
-        p.motion = nullptr;
-        return &p;
-      }
-    return nullptr;
-  }
-  void emit(Pic* p) {
-    sink->output_picture(p->slot);
-    if (p->slot < 0 && !wanted.empty() &&
-        std::binary_search(wanted.begin(), wanted.end(), outputs_emitted)) {
-      // A picture was skipped on the prediction that nobody wants its output
-      // position, and the prediction was wrong.  Never hand out garbage.
-      fail("sparse decode mispredicted the display position of a skipped picture");
-    }
-    ++outputs_emitted;
-    p->needed_for_output = false;
-  }
-  Pic* lowest_poc_pending(int* count) {
-    Pic* best = nullptr;
-    int n = 0;
-    for (Pic& p : dpb) {
-      if (!p.in_use || !p.needed_for_output || &p == cur) continue;
-      ++n;
-      if (!best || p.poc < best->poc) best = &p;
-    }
-    if (count) *count = n;
-    return best;
-  }
-  void output_all() {
-    while (Pic* p = lowest_poc_pending(nullptr)) emit(p);
-    release_unused();
-  }
-  int reorder_depth() const {
-    if (asps->poc_type == 2) return 0;
-    if (asps->bitstream_restriction && asps->num_reorder_frames >= 0) return asps->num_reorder_frames;
-    return const_cast<Impl*>(this)->max_dpb_frames(*asps);
-  }
-
-  // ------------------------------------------------------------------ POC
-  void compute_poc(Pic* c) {
-    const Sps& s = *asps;
-    const int max_frame_num = 1 << s.log2_max_frame_num;
-    int fno;
-    if (sl.is_idr) fno = 0;
-    else if (prev_frame_num > sl.frame_num) fno = prev_frame_num_offset + max_frame_num;
-    else fno = prev_frame_num_offset;
-    int top, bottom;
-    if (s.poc_type == 0) {
-      const int max_lsb = 1 << s.log2_max_poc_lsb;
-      if (sl.is_idr) prev_poc_msb = prev_poc_lsb = 0;
-      int msb;
-      if (sl.poc_lsb < prev_poc_lsb && prev_poc_lsb - sl.poc_lsb >= max_lsb / 2) msb = prev_poc_msb + max_lsb;
-      else if (sl.poc_lsb > prev_poc_lsb && sl.poc_lsb - prev_poc_lsb > max_lsb / 2) msb = prev_poc_msb - max_lsb;
-      else msb = prev_poc_msb;
-      top = msb + sl.poc_lsb;
-      bottom = top + sl.delta_poc_bottom;
-      if (sl.nal_ref_idc) {
-        prev_poc_msb = msb;
-        prev_poc_lsb = sl.poc_lsb;
-      }
-    } else if (s.poc_type == 1) {
-      int abs_frame_num = s.num_ref_frames_in_poc_cycle ? fno + sl.frame_num : 0;
-      if (!sl.nal_ref_idc && abs_frame_num > 0) abs_frame_num--;
-      int per_cycle = 0;
-      for (int i = 0; i < s.num_ref_frames_in_poc_cycle; ++i) per_cycle += s.offset_for_ref_frame[i];
-      int expected = 0;
-      if (abs_frame_num > 0) {
-        int cycle = (abs_frame_num - 1) / s.num_ref_frames_in_poc_cycle;
-        int in_cycle = (abs_frame_num - 1) % s.num_ref_frames_in_poc_cycle;
-        expected = cycle * per_cycle;
-        for (int i = 0; i <= in_cycle; ++i) expected += s.offset_for_ref_frame[i];
-      }
-      if (!sl.nal_ref_idc) expected += s.offset_for_non_ref_pic;
-      top = expected + sl.delta_poc[0];
-      bottom = top + s.offset_for_top_to_bottom + sl.delta_poc[1];
-    } else {
-      top = bottom = sl.is_idr ? 0 : 2 * (fno + sl.frame_num) - (sl.nal_ref_idc ? 0 : 1);
-    }
-    c->poc = imin(top, bottom);
-    prev_frame_num_offset = fno;
-    prev_frame_num = sl.frame_num;
-  }
-
-  // ----------------------------------------------------------- ref lists
-  void init_ref_lists() {
-    const int max_frame_num = 1 << asps->log2_max_frame_num;
-    std::vector<Pic*> st, lt;
-    for (Pic& p : dpb) {
-      if (!p.in_use || &p == cur) continue;
-      if (p.ref == 1) {
-        p.frame_num_wrap = p.frame_num > sl.frame_num ? p.frame_num - max_frame_num : p.frame_num;
-        p.pic_num = p.frame_num_wrap;
-        st.push_back(&p);
-      } else if (p.ref == 2) {
-        p.pic_num = p.long_term_idx;
-        lt.push_back(&p);
-      }
-    }
-    std::sort(lt.begin(), lt.end(), [](Pic* a, Pic* b) { return a->long_term_idx < b->long_term_idx; });
-    for (int l = 0; l < 2; ++l) memset(sl.ref_list[l], 0, sizeof(sl.ref_list[l]));
-    if (sl.type == 0) {
-      std::sort(st.begin(), st.end(), [](Pic* a, Pic* b) { return a->pic_num > b->pic_num; });
-      int n = 0;
-      for (Pic* p : st) if (n < kMaxRefs) sl.ref_list[0][n++] = p;
-      for (Pic* p : lt) if (n < kMaxRefs) sl.ref_list[0][n++] = p;
-    } else if (sl.type == 1) {
-      std::vector<Pic*> before, after;
-      for (Pic* p : st) (p->poc < cur->poc ? before : after).push_back(p);
-      std::sort(before.begin(), before.end(), [](Pic* a, Pic* b) { return a->poc > b->poc; });
-      std::sort(after.begin(), after.end(), [](Pic* a, Pic* b) { return a->poc < b->poc; });
-      int n0 = 0, n1 = 0;
-      for (Pic* p : before) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
-      for (Pic* p : after) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
-      for (Pic* p : lt) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
-      for (Pic* p : after) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
-      for (Pic* p : before) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
-      for (Pic* p : lt) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
-      if (n1 > 1 && n0 == n1 && !memcmp(sl.ref_list[0], sl.ref_list[1], n1 * sizeof(Pic*)))
-        std::swap(sl.ref_list[1][0], sl.ref_list[1][1]);
-    }
-  }
-
-  bool modify_ref_list(Bits& b, int list) {
-    const int max_pic_num = 1 << asps->log2_max_frame_num;
-    int pred = sl.frame_num, idx = 0;
-    const int n = sl.num_ref_idx[list];
-    Pic** L = sl.ref_list[list];
-    for (;;) {
-      unsigned op = b.ue();
-      if (op == 3) break;
-      if (op > 3 || b.overrun || idx >= n) return fail("bad ref_pic_list_modification");
-      Pic* pic = nullptr;
-      if (op < 2) {
-        int diff = b.ue() + 1;
-        if (op == 0) {
-          pred -= diff;
-          if (pred < 0) pred += max_pic_num;
-        } else {
-          pred += diff;
-          if (pred >= max_pic_num) pred -= max_pic_num;
-        }
-        int pic_num = pred > sl.frame_num ? pred - max_pic_num : pred;
-        for (Pic& p : dpb)
-          if (p.in_use && &p != cur && p.ref == 1 && p.pic_num == pic_num) pic = &p;
-      } else {
-        int lt_num = b.ue();
-        for (Pic& p : dpb)
-          if (p.in_use && &p != cur && p.ref == 2 && p.long_term_idx == lt_num) pic = &p;
-      }
-      if (!pic) return fail("ref_pic_list_modification names a missing picture");
-      for (int c = n; c > idx; --c) L[c] = L[c - 1];
-      L[idx++] = pic;
-      int w = idx;
-      for (int c = idx; c <= n; ++c)
-        if (L[c] != pic) L[w++] = L[c];
-    }
-    return true;
-  }
-
-  // --------------------------------------------------------- slice header
-  // returns 0 ok, 1 skip this NAL, -1 error
-  int parse_slice_header(Bits& b, int nal_ref_idc, int nal_type) {
-    sl = SliceHdr();
-    sl.nal_ref_idc = nal_ref_idc;
-    sl.is_idr = nal_type == 5;
-    sl.first_mb = b.ue();
-    unsigned st = b.ue();
-    if (st > 9) return fail("bad slice_type") ? 0 : -1;
-    st %= 5;
-    if (st > 2) return fail("unsupported stream: SP/SI slices") ? 0 : -1;
-    sl.type = st;
-    sl.pps_id = b.ue();
-    if (sl.pps_id >= kMaxPps || !pps[sl.pps_id].valid) return fail("slice refers to a missing PPS") ? 0 : -1;
-    const Pps* p = &pps[sl.pps_id];
-    const Sps* s = &sps[p->sps_id];
-    sl.frame_num = b.get(s->log2_max_frame_num);
-    if (sl.is_idr) b.ue();
-    if (s->poc_type == 0) {
-      sl.poc_lsb = b.get(s->log2_max_poc_lsb);
-      if (p->bottom_field_pic_order_present) sl.delta_poc_bottom = b.se();
-    } else if (s->poc_type == 1 && !s->delta_pic_order_always_zero) {
-      sl.delta_poc[0] = b.se();
-      if (p->bottom_field_pic_order_present) sl.delta_poc[1] = b.se();
-    }
-    if (p->redundant_pic_cnt_present && b.ue() != 0) return 1;
-    if (sl.type == 1) sl.direct_spatial = b.bit();
-    sl.num_ref_idx[0] = p->num_ref_idx_default[0];
-    sl.num_ref_idx[1] = p->num_ref_idx_default[1];
-    if (sl.type != 2) {
-      if (b.bit()) {
-        sl.num_ref_idx[0] = b.ue() + 1;
-        if (sl.type == 1) sl.num_ref_idx[1] = b.ue() + 1;
-      }
-      if (sl.num_ref_idx[0] > kMaxRefs || sl.num_ref_idx[1] > kMaxRefs)
-        return fail("num_ref_idx_active out of range") ? 0 : -1;
-    }
-    if (sl.type != 1) sl.num_ref_idx[1] = 0;
-    if (sl.type == 2) sl.num_ref_idx[0] = 0;
-
-    if (sl.first_mb != 0 && skipping_picture) return 1;
-    skipping_picture = false;
-    if (sl.first_mb == 0 || !pic_in_progress) {
-      if (pic_in_progress && !finish_picture()) return -1;
-      apps = p;
-      asps = s;
-      int r = start_picture();
-      if (r != 0) return r;
-    } else if (p->sps_id != apps->sps_id) {
-      return fail("SPS changed inside a picture") ? 0 : -1;
-    } else {
-      apps = p;
-    }
-    // Slices arrive in macroblock order (FMO / ASO are rejected): a slice that starts anywhere but at the
-    // first macroblock not decoded yet is a duplicate, an overlap or a gap.  Refused up front - a slice that
-    // re-decodes macroblocks would append to the per-picture streams (coefficients, motion extras) twice.
-    if (sl.first_mb != mbs_decoded) return fail("slice does not start at the next undecoded macroblock") ? 0 : -1;
-
-    if (sl.type != 2) {
-      init_ref_lists();
-      if (b.bit() && !modify_ref_list(b, 0)) return -1;
-      if (sl.type == 1 && b.bit() && !modify_ref_list(b, 1)) return -1;
-      for (int l = 0; l < 2; ++l)
-        for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
-          if (!sl.ref_list[l][i]) return fail("reference list has a missing picture") ? 0 : -1;
-          if (sl.ref_list[l][i]->slot < 0)
-            return fail("a skipped picture is used as a reference") ? 0 : -1;
-        }
-    }
-    sl.use_weight = 0;
-    if ((p->weighted_pred && sl.type == 0) || (p->weighted_bipred_idc == 1 && sl.type == 1)) {
-      sl.use_weight = 1;
-      sl.luma_log2_denom = b.ue();
-      sl.chroma_log2_denom = b.ue();
-      if (sl.luma_log2_denom > 7 || sl.chroma_log2_denom > 7) return fail("bad weight denominator") ? 0 : -1;
-      for (int l = 0; l < (sl.type == 1 ? 2 : 1); ++l)
-        for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
-          sl.luma_weight[l][i] = 1 << sl.luma_log2_denom;
-          sl.luma_offset[l][i] = 0;
-          if (b.bit()) {
-            sl.luma_weight[l][i] = b.se();
-            sl.luma_offset[l][i] = b.se();
-            if (sl.luma_weight[l][i] < -128 || sl.luma_weight[l][i] > 127 || sl.luma_offset[l][i] < -128 ||
-                sl.luma_offset[l][i] > 127)
-              return fail("prediction weight out of range") ? 0 : -1;
-          }
-          for (int c = 0; c < 2; ++c) {
-            sl.chroma_weight[l][i][c] = 1 << sl.chroma_log2_denom;
-            sl.chroma_offset[l][i][c] = 0;
-          }
-          if (b.bit())
-            for (int c = 0; c < 2; ++c) {
-              sl.chroma_weight[l][i][c] = b.se();
-              sl.chroma_offset[l][i][c] = b.se();
-              if (sl.chroma_weight[l][i][c] < -128 || sl.chroma_weight[l][i][c] > 127 ||
-                  sl.chroma_offset[l][i][c] < -128 || sl.chroma_offset[l][i][c] > 127)
-                return fail("prediction weight out of range") ? 0 : -1;
-            }
-        }
-    } else if (p->weighted_bipred_idc == 2 && sl.type == 1) {
-      sl.use_weight = 2;
-    }
-    if (nal_ref_idc) {
-      if (sl.is_idr) {
-        b.bit();
-        sl.long_term_reference_flag = b.bit();
-      } else {
-        sl.adaptive_marking = b.bit();
-        if (sl.adaptive_marking) {
-          for (;;) {
-            unsigned op = b.ue();
-            if (op == 0) break;
-            if (op > 6 || sl.mmco_count >= 64 || b.overrun) return fail("bad MMCO") ? 0 : -1;
-            int a = 0, c = 0;
-            if (op == 1 || op == 3) a = b.ue();
-            if (op == 2) a = b.ue();
-            if (op == 3 || op == 6) c = b.ue();
-            if (op == 4) a = b.ue();
-            sl.mmco[sl.mmco_count].op = op;
-            sl.mmco[sl.mmco_count].a = a;
-            sl.mmco[sl.mmco_count].b = c;
-            sl.mmco_count++;
-          }
-        }
-      }
-    }
-    if (p->cabac && sl.type != 2) {
-      sl.cabac_init_idc = b.ue();
-      if (sl.cabac_init_idc > 2) return fail("bad cabac_init_idc") ? 0 : -1;
-    }
-    sl.qp = p->init_qp + b.se();
-    if (sl.qp < 0 || sl.qp > 51) return fail("slice QP out of range") ? 0 : -1;
-    if (p->deblocking_control_present) {
-      sl.disable_deblock = b.ue();
-      if (sl.disable_deblock > 2) return fail("bad disable_deblocking_filter_idc") ? 0 : -1;
-      if (sl.disable_deblock != 1) {
-        sl.alpha_offset = b.se() * 2;
-        sl.beta_offset = b.se() * 2;
-      }
-    }
-    if (b.overrun) return fail("truncated slice header") ? 0 : -1;
-    if (num_slices >= bufs.max_slices) return fail("too many slices in one picture") ? 0 : -1;
-    slice_index = num_slices + 1;
-    fill_slice_params(&bufs.slices[num_slices]);
-    ++num_slices;
-    slice_type_mask |= sl.type == 0 ? 1 : (sl.type == 1 ? 2 : 4);
-    if (sl.disable_deblock != 1) any_deblock = true;
-    return 0;
-  }
-
-  void fill_slice_params(SliceParams* sp) {
-    memset(sp, 0, sizeof(*sp));
-    sp->alpha_offset = static_cast<int8_t>(sl.alpha_offset);
-    sp->beta_offset = static_cast<int8_t>(sl.beta_offset);
-    sp->weight_mode = static_cast<uint8_t>(sl.use_weight);
-    sp->luma_log2_denom = static_cast<uint8_t>(sl.luma_log2_denom);
-    sp->chroma_log2_denom = static_cast<uint8_t>(sl.chroma_log2_denom);
-    sp->cur_poc = cur->poc;
-    for (int l = 0; l < 2; ++l)
-      for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
-        sp->luma_weight[l][i] = static_cast<int16_t>(sl.luma_weight[l][i]);
-        sp->luma_offset[l][i] = static_cast<int16_t>(sl.luma_offset[l][i]);
-        for (int c = 0; c < 2; ++c) {
-          sp->chroma_weight[l][i][c] = static_cast<int16_t>(sl.chroma_weight[l][i][c]);
-          sp->chroma_offset[l][i][c] = static_cast<int16_t>(sl.chroma_offset[l][i][c]);
-        }
-        sp->ref_poc[l][i] = sl.ref_list[l][i]->poc;
-        sp->ref_long[l][i] = sl.ref_list[l][i]->ref == 2;
-      }
-  }
-
-  // returns 0 ok, 1 picture skipped on purpose, -1 error
-  int start_picture() {
-    mbw = asps->mb_width;
-    mbh = asps->mb_height;
+  // A new picture: `c` receives its motion, `b` its records.
+  void begin_picture(const Sps* sps, PicData* c, const PicBuffers& b) {
+    asps = sps;
+    mbw = sps->mb_width;
+    mbh = sps->mb_height;
     const int nmb = mbw * mbh;
-    if (sl.is_idr) {
-      cur = nullptr;
-      output_all();
-      for (Pic& p : dpb) p.ref = 0;
-      release_unused();
-      prev_frame_num = prev_frame_num_offset = 0;
-      max_long_term_frame_idx = -1;
-    } else if (prev_ref_has_mmco5) {
-      prev_frame_num = prev_frame_num_offset = 0;
-    }
-    prev_ref_has_mmco5 = false;
-    release_unused();
-    Pic* c = grab_pic();
-    if (!c) return fail("decoded picture buffer exhausted") ? 0 : -1;
     cur = c;
-    c->frame_num = sl.frame_num;
-    compute_poc(c);
-
-    // Sparse decode: an unwanted non-reference picture is not decoded.  Its
-    // display position is predicted as (already output) + (pending pictures
-    // that precede it); emit() verifies the prediction.
-    if (!wanted.empty() && !sl.nal_ref_idc) {
-      uint64_t pos = outputs_emitted;
-      for (Pic& p : dpb)
-        if (p.in_use && &p != c && p.needed_for_output && p.poc < c->poc) ++pos;
-      if (!std::binary_search(wanted.begin(), wanted.end(), pos)) {
-        c->slot = -1;
-        c->needed_for_output = true;
-        cur = nullptr;
-        pic_in_progress = false;
-        skipping_picture = true;
-        ++owner->pictures_skipped_;
-        bump();
-        return 1;
-      }
-    }
-
-    PicSetup setup{mbw, mbh, asps->crop_left, asps->crop_right, asps->crop_top, asps->crop_bottom};
-    bufs = PicBuffers();
-    if (!sink->begin_picture(setup, &bufs, err)) {
-      c->in_use = false;
-      cur = nullptr;
-      return -1;
-    }
-    c->slot = bufs.slot;
-    c->motion = bufs.motion;
-    c->pmo = bufs.pmo;
-    c->pmx = bufs.pmx;
+    bufs = b;
+    err.clear();
     if (bufs.pmx && bufs.pmx_capacity < static_cast<size_t>(mbh) + static_cast<size_t>(nmb) * 15) bufs.pmo = nullptr, bufs.pmx = nullptr;
     // a sink that derives vectors itself takes them compactly; without the buffers for that the host derives
     if (!bufs.pmo || !bufs.pmx) bufs.device_mv = false, bufs.pmo = nullptr, bufs.pmx = nullptr;
@@ -1169,144 +597,34 @@ struct Parser::Impl {
     c->derived_valid = false;
     mbs_decoded = 0;
     coef_used = 0;
-    num_slices = 0;
-    slice_index = 0;
-    has_inter = has_intra = any_deblock = false;
-    slice_type_mask = 0;
-    pic_in_progress = true;
-    return 0;
+    has_inter = has_intra = false;
+    pos_valid = false;
   }
 
-  void unmark_long_idx(int idx, Pic* except) {
-    for (Pic& p : dpb)
-      if (p.in_use && &p != except && p.ref == 2 && p.long_term_idx == idx) p.ref = 0;
+  // One slice: header `h` (with its reference snapshots), the picture parameter set it names, its 1-based
+  // position in the picture, and the bit reader standing at slice_data().
+  bool decode_slice(const SliceHdr& h, const Pps* pps, int index, Bits b) {
+    sl = h;
+    apps = pps;
+    slice_index = index;
+    return decode_slice_data(b) && err.empty();
   }
 
-  void mark_references(Pic* c) {
-    if (!sl.nal_ref_idc) return;
-    if (sl.is_idr) {
-      if (sl.long_term_reference_flag) {
-        c->ref = 2;
-        c->long_term_idx = 0;
-        max_long_term_frame_idx = 0;
-      } else {
-        c->ref = 1;
-        max_long_term_frame_idx = -1;
-      }
-      return;
+  // All slices are in: what the slice data contributes to PicDone.
+  bool finish_picture(PicDone* done) {
+    if (mbs_decoded != mbw * mbh) return fail("picture ended with undecoded macroblocks");
+    if (cur->mv_deferred && !bufs.device_mv) {
+      derive_deferred(cur, cur->motion);  // in place: nothing has been submitted yet
+      cur->mv_deferred = false;
     }
-    bool cur_is_long = false;
-    if (sl.adaptive_marking) {
-      for (int k = 0; k < sl.mmco_count; ++k) {
-        const int op = sl.mmco[k].op, a = sl.mmco[k].a, bb = sl.mmco[k].b;
-        if (op == 1 || op == 3) {
-          const int pic_num = sl.frame_num - (a + 1);
-          for (Pic& p : dpb) {
-            if (!p.in_use || &p == c || p.ref != 1 || p.pic_num != pic_num) continue;
-            if (op == 1) {
-              p.ref = 0;
-            } else {
-              unmark_long_idx(bb, &p);
-              p.ref = 2;
-              p.long_term_idx = bb;
-            }
-          }
-        } else if (op == 2) {
-          for (Pic& p : dpb)
-            if (p.in_use && &p != c && p.ref == 2 && p.long_term_idx == a) p.ref = 0;
-        } else if (op == 4) {
-          max_long_term_frame_idx = a - 1;
-          for (Pic& p : dpb)
-            if (p.in_use && &p != c && p.ref == 2 && p.long_term_idx > a - 1) p.ref = 0;
-        } else if (op == 5) {
-          for (Pic& p : dpb)
-            if (&p != c) p.ref = 0;
-          max_long_term_frame_idx = -1;
-          prev_ref_has_mmco5 = true;
-          prev_poc_msb = prev_poc_lsb = 0;
-          c->frame_num = 0;
-        } else if (op == 6) {
-          unmark_long_idx(a, c);
-          c->ref = 2;
-          c->long_term_idx = a;
-          cur_is_long = true;
-        }
-      }
-    } else {
-      int n = 0;
-      Pic* oldest = nullptr;
-      for (Pic& p : dpb) {
-        if (!p.in_use || &p == c || !p.ref) continue;
-        ++n;
-        if (p.ref == 1 && (!oldest || p.frame_num_wrap < oldest->frame_num_wrap)) oldest = &p;
-      }
-      if (n >= imax(asps->max_num_ref_frames, 1) && oldest) oldest->ref = 0;
-    }
-    if (!cur_is_long) c->ref = 1;
-  }
-
-  void bump() {
-    const int depth = reorder_depth();
-    for (;;) {
-      int n = 0;
-      Pic* p = lowest_poc_pending(&n);
-      if (!p || n <= depth) break;
-      emit(p);
-    }
-    release_unused();
-  }
-
-  bool finish_picture() {
-    if (!pic_in_progress) return true;
-    pic_in_progress = false;
-    Pic* c = cur;
-    const int nmb = mbw * mbh;
-    if (mbs_decoded != nmb) return fail("picture ended with undecoded macroblocks");
-
-    if (c->mv_deferred && !bufs.device_mv) {
-      derive_deferred(c, c->motion);  // in place: nothing has been submitted yet
-      c->mv_deferred = false;
-    }
-    PicDone done;
-    memset(&done, 0, sizeof(done));
-    done.mv_deferred = c->mv_deferred;
-    done.compact_motion = any_compact;
-    done.full_motion = any_full_motion;
-    done.pmx_count = pmx_used;
-    done.slot = c->slot;
-    done.num_slices = num_slices;
-    done.coef_count = coef_used;
-    done.has_inter = has_inter;
-    done.has_intra = has_intra;
-    done.any_deblock = any_deblock;
-    done.slice_type_mask = slice_type_mask;
-    done.scaling4 = apps->scaling4;
-    done.scaling8 = apps->scaling8;
-    done.num_ref_slots = 0;
-    for (Pic& p : dpb)
-      if (p.in_use && &p != c && p.ref && p.slot >= 0 && done.num_ref_slots < 32)
-        done.ref_slots[done.num_ref_slots++] = p.slot;
-    if (!sink->end_picture(done, err)) return false;
-    ++owner->pictures_decoded_;
-
-    const int max_frame_num = 1 << asps->log2_max_frame_num;
-    for (Pic& p : dpb)
-      if (p.in_use && &p != c && p.ref == 1) {
-        p.frame_num_wrap = p.frame_num > sl.frame_num ? p.frame_num - max_frame_num : p.frame_num;
-        p.pic_num = p.frame_num_wrap;
-      }
-    mark_references(c);
-    c->needed_for_output = true;
-    if (prev_ref_has_mmco5) {
-      cur = nullptr;
-      c->needed_for_output = false;
-      output_all();
-      c->needed_for_output = true;
-      c->poc = 0;
-    }
-    cur = nullptr;
-    bump();
-    return err->empty();
+    done->mv_deferred = cur->mv_deferred;
+    done->compact_motion = any_compact;
+    done->full_motion = any_full_motion;
+    done->pmx_count = pmx_used;
+    done->coef_count = coef_used;
+    done->has_inter = has_inter;
+    done->has_intra = has_intra;
+    return err.empty();
   }
 
   // =================================================================== MBs
@@ -1413,10 +731,10 @@ struct Parser::Impl {
   void set_ref8(int list, int b8, int ref) {
     MbMotion& mo = cur->motion[mb.addr];
     mo.ref_idx[list][b8] = static_cast<int8_t>(ref);
-    if (ref >= 0 && ref < sl.num_ref_idx[list] && sl.ref_list[list][ref]) {
-      const Pic* r = sl.ref_list[list][ref];
-      mo.ref_slot[list][b8] = static_cast<int8_t>(r->slot);
-      cur->ref_uid[list][mb.addr * 4 + b8] = r->uid;
+    if (ref >= 0 && ref < sl.num_ref_idx[list] && sl.ref[list][ref].d) {
+      const RefSnap& r = sl.ref[list][ref];
+      mo.ref_slot[list][b8] = static_cast<int8_t>(r.slot);
+      cur->ref_uid[list][mb.addr * 4 + b8] = r.uid;
     } else {
       mo.ref_slot[list][b8] = -1;
       cur->ref_uid[list][mb.addr * 4 + b8] = -1;
@@ -1431,7 +749,7 @@ struct Parser::Impl {
   // prediction looks at is final already.  The GPU does the same in k_mv; this
   // host version serves sinks without it and co-located lookups of B pictures.
   // ------------------------------------------------------------------------
-  void derive_deferred(const Pic* p, MbMotion* motion) const {
+  void derive_deferred(const PicData* p, MbMotion* motion) const {
     const int nmb = mbw * mbh;
     for (int addr = 0; addr < nmb; ++addr) {
       const uint8_t* rec = &p->mvrec[static_cast<size_t>(addr) * 3];
@@ -1536,7 +854,7 @@ struct Parser::Impl {
   // Macroblocks that were handed over as PMotion + extra differences (MVF_COMPACT), put back into the
   // MbMotion form derive_deferred works on: reference indices, and the differences replicated over each
   // partition's blocks.  Same partition walk, same order as the stream was written in.
-  void expand_compact(const Pic* p, MbMotion* motion) const {
+  void expand_compact(const PicData* p, MbMotion* motion) const {
     if (!p->pmo || !p->pmx) return;
     size_t x = 0;
     for (int addr = 0; addr < mbw * mbh; ++addr) {
@@ -1580,8 +898,13 @@ struct Parser::Impl {
   }
 
   // Final motion of a (possibly deferred) picture for co-located lookups.
-  const MbMotion* final_motion(const Pic* cp) {
-    Pic* p = const_cast<Pic*>(cp);
+  // With entropy workers the co-located picture may still be in another
+  // worker's hands: wait for its records (it precedes this picture in decoding
+  // order, so its task started earlier and does not depend on this one); the
+  // derivation runs once, under the picture's lock.
+  const MbMotion* final_motion(PicData* p) {
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv.wait(lk, [&] { return p->parsed; });
     if (!p->mv_deferred) return p->motion;
     if (!p->derived_valid) {
       const size_t nmb = static_cast<size_t>(mbw) * mbh;
@@ -1594,8 +917,9 @@ struct Parser::Impl {
   }
 
   bool pred_direct(int only_b8) {
-    const Pic* col = sl.ref_list[1][0];
+    PicData* col = sl.ref[1][0].d;
     if (!col || !col->motion) return fail("direct prediction without RefPicList1[0]");
+    const RefSnap& colref = sl.ref[1][0];
     const int inf8 = asps->direct_8x8_inference;
     const int bsz = inf8 ? 2 : 1;  // 4x4 blocks per side that share one derivation
     const int addr = mb.addr;
@@ -1613,7 +937,7 @@ struct Parser::Impl {
         if (r >= 0) pred_mv(l, 0, 0, 4, r, PRED_MEDIAN, mvp[l]);
       }
       if (ref[0] < 0 && ref[1] < 0) ref[0] = ref[1] = 0;
-      const bool col_short = col->ref == 1;
+      const bool col_short = colref.marking == 1;
       for (int b8 = 0; b8 < 4; ++b8) {
         if (only_b8 >= 0 && b8 != only_b8) continue;
         for (int l = 0; l < 2; ++l) set_ref8(l, b8, ref[l]);
@@ -1654,22 +978,22 @@ struct Parser::Impl {
             const int uid = col->ref_uid[cl][addr * 4 + c8];
             ref0 = -1;
             for (int i = 0; i < sl.num_ref_idx[0]; ++i)
-              if (sl.ref_list[0][i] && sl.ref_list[0][i]->uid == uid) {
+              if (sl.ref[0][i].d && sl.ref[0][i].uid == uid) {
                 ref0 = i;
                 break;
               }
             if (ref0 < 0) return fail("temporal direct: co-located reference not in RefPicList0");
           }
         }
-        const Pic* p0 = sl.ref_list[0][ref0];
+        const RefSnap& p0 = sl.ref[0][ref0];
         int mv0[2], mv1[2];
-        const int td = iclip(-128, 127, col->poc - p0->poc);
-        if (p0->ref == 2 || td == 0) {
+        const int td = iclip(-128, 127, colref.poc - p0.poc);
+        if (p0.marking == 2 || td == 0) {
           mv0[0] = mvc[0];
           mv0[1] = mvc[1];
           mv1[0] = mv1[1] = 0;
         } else {
-          const int tb = iclip(-128, 127, cur->poc - p0->poc);
+          const int tb = iclip(-128, 127, sl.cur_poc - p0.poc);
           const int tx = (16384 + iabs(td / 2)) / td;
           const int dsf = iclip(-1024, 1023, (tb * tx + 32) >> 6);
           mv0[0] = (dsf * mvc[0] + 128) >> 8;
@@ -2569,13 +1893,13 @@ struct Parser::Impl {
     memset(pskip_motion.ref_slot, -1, sizeof(pskip_motion.ref_slot));
     memset(pskip_motion.ref_idx, -1, sizeof(pskip_motion.ref_idx));
     pskip_ref_uid = -1;
-    if (sl.num_ref_idx[0] > 0 && sl.ref_list[0][0]) {
-      const Pic* r = sl.ref_list[0][0];
+    if (sl.num_ref_idx[0] > 0 && sl.ref[0][0].d) {
+      const RefSnap& r = sl.ref[0][0];
       for (int q = 0; q < 4; ++q) {
         pskip_motion.ref_idx[0][q] = 0;
-        pskip_motion.ref_slot[0][q] = static_cast<int8_t>(r->slot);
+        pskip_motion.ref_slot[0][q] = static_cast<int8_t>(r.slot);
       }
-      pskip_ref_uid = r->uid;
+      pskip_ref_uid = r.uid;
     }
   }
 
@@ -2787,6 +2111,10 @@ struct Parser::Impl {
     const int nmb = mbw * mbh;
     int addr = sl.first_mb;
     if (addr >= nmb) return fail("first_mb_in_slice out of range");
+    // Slices arrive in macroblock order (FMO / ASO are rejected): a slice that starts anywhere but at the
+    // first macroblock not decoded yet is a duplicate, an overlap or a gap.  A slice that re-decodes
+    // macroblocks would append to the per-picture streams (coefficients, motion extras) twice.
+    if (addr != mbs_decoded) return fail("slice does not start at the next undecoded macroblock");
     pos_valid = false;
     // P and I slices hand their motion over compactly when the sink derives the vectors (k_mv)
     compact = bufs.device_mv && bufs.pmo && bufs.pmx && sl.type != 1;
@@ -2819,8 +2147,8 @@ struct Parser::Impl {
         bool ok = pos > 0 && pos <= b.size_bits && ((b.buf[(pos - 1) >> 3] >> (7 - ((pos - 1) & 7))) & 1);
         for (int i = pos; ok && i < b.size_bits; ++i)
           if ((b.buf[i >> 3] >> (7 - (i & 7))) & 1) ok = false;
-        ++owner->slices_;
-        if (ok) ++owner->slices_clean_end_;
+        ++slices;
+        if (ok) ++slices_clean_end;
       }
       return true;
     }
@@ -2848,10 +2176,1091 @@ struct Parser::Impl {
       bool ok = t.bit() == 1;
       while (ok && t.pos < t.size_bits)
         if (t.bit()) ok = false;
-      ++owner->slices_;
-      if (ok && !t.overrun) ++owner->slices_clean_end_;
+      ++slices;
+      if (ok && !t.overrun) ++slices_clean_end;
     }
     return true;
+  }
+
+};
+
+// One picture on its way through the entropy workers.
+struct PicTask {
+  std::shared_ptr<PicData> cur;
+  std::vector<std::shared_ptr<PicData>> keep;  // every picture a slice of this one refers to
+  Sps sps;
+  PicBuffers bufs;
+  struct Slice {
+    SliceHdr hdr;
+    Pps pps;
+    std::vector<uint8_t> rbsp;
+    int pos = 0, size_bits = 0, index = 0;
+  };
+  std::deque<Slice> slices;
+  PicDone done;
+  Pps done_pps;  // done.scaling4 / scaling8 point here
+  bool finished = false;  // slice data decoded (or failed): ready to be handed to the sink, in decoding order
+  std::string err;
+  int64_t slices_n = 0, clean_n = 0;
+};
+
+}  // namespace
+
+// ===========================================================================
+struct WorkerPool::State {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> jobs;
+  bool stop = false;
+  std::vector<std::thread> threads;
+};
+
+WorkerPool::WorkerPool(int threads) : state_(new State()) {
+  State* s = state_;
+  for (int i = 0; i < threads; ++i)
+    s->threads.emplace_back([s] {
+      for (;;) {
+        std::function<void()> job;
+        {
+          std::unique_lock<std::mutex> lk(s->mu);
+          s->cv.wait(lk, [&] { return s->stop || !s->jobs.empty(); });
+          if (s->jobs.empty()) return;  // stop, and nothing left to run
+          job = std::move(s->jobs.front());
+          s->jobs.pop_front();
+        }
+        job();
+      }
+    });
+}
+
+WorkerPool::~WorkerPool() {
+  {
+    std::lock_guard<std::mutex> lk(state_->mu);
+    state_->stop = true;
+  }
+  state_->cv.notify_all();
+  for (std::thread& t : state_->threads) t.join();
+  delete state_;
+}
+
+int WorkerPool::size() const { return static_cast<int>(state_->threads.size()); }
+
+void WorkerPool::submit(std::function<void()> job) {
+  {
+    std::lock_guard<std::mutex> lk(state_->mu);
+    state_->jobs.push_back(std::move(job));
+  }
+  state_->cv.notify_one();
+}
+
+// ===========================================================================
+// The parser thread's side: NAL units, parameter sets, slice headers, the DPB
+// (reference lists, marking, POC, display order).  Slice data goes to `sd` at
+// once (serial mode) or, picture by picture, to the entropy workers.
+// ===========================================================================
+struct Parser::Impl {
+  Parser* owner;
+  PictureSink* sink;
+  std::string* err;
+
+  int nal_length_size = 4;
+  Sps sps[kMaxSps];
+  Pps pps[kMaxPps];
+  const Sps* asps = nullptr;
+  const Pps* apps = nullptr;
+  int mbw = 0, mbh = 0;
+
+  std::vector<uint8_t> rbsp;
+
+  Pic dpb[kMaxDpb + 8];
+  std::shared_ptr<PicPool> pool;
+  int next_uid = 0;
+  Pic* cur = nullptr;
+  bool pic_in_progress = false;
+  bool skipping_picture = false;  // remaining slices of a picture skipped on purpose
+  PicBuffers bufs;
+  int num_slices = 0;
+  bool any_deblock = false;
+  int slice_type_mask = 0;
+
+  int prev_poc_msb = 0, prev_poc_lsb = 0, prev_frame_num = 0, prev_frame_num_offset = 0;
+  bool prev_ref_has_mmco5 = false;
+  int max_long_term_frame_idx = -1;
+
+  // sparse decoding
+  std::vector<uint64_t> wanted;
+  uint64_t outputs_emitted = 0;  // since last flush/configure
+
+  SliceHdr sl;
+  int slice_index = 0;
+  SliceData sd;  // serial mode: slice data is decoded on the parser thread
+
+  bool fail(const char* msg) {
+    if (err->empty()) *err = msg;
+    return false;
+  }
+
+  // ------------------------------------------------------- entropy workers
+  // With a WorkerPool the parser thread runs ahead: per picture it parses the
+  // headers, settles the DPB (references, marking, output order need nothing
+  // from the slice data) and queues a PicTask; workers decode the slice data of
+  // up to `max_in_flight` consecutive pictures at once.  A picture waits for
+  // another only where a B slice's direct prediction reads the co-located
+  // picture's motion (SliceData::final_motion).  Finished pictures are handed
+  // to the sink strictly in decoding order - by whichever worker completes the
+  // oldest one - and a picture's display-order output is passed on only after
+  // that hand-over, so the sink sees the same call order as in serial mode:
+  // begin_picture (parser thread) ... end_picture, output_picture (a worker or
+  // the parser thread, never two at once).
+  WorkerPool* workers = nullptr;
+  int max_in_flight = 0;
+  std::mutex pipe_mu;
+  std::condition_variable pipe_cv;
+  std::deque<std::shared_ptr<PicTask>> inflight;  // decoding order
+  bool handing_over = false;  // a thread is inside the in-order hand-over loop
+  bool pipe_failed = false;
+  std::string pipe_error;
+  struct PendingOut {
+    int slot;
+    std::shared_ptr<PicData> d;  // null: a picture skipped on purpose
+  };
+  std::deque<PendingOut> pending_out;
+  std::shared_ptr<PicTask> building;
+
+  void release_outputs_locked() {
+    while (!pending_out.empty() && (!pending_out.front().d || pending_out.front().d->submitted)) {
+      const PendingOut& o = pending_out.front();
+      sink->output_picture(o.d && o.d->dropped ? -1 : o.slot);
+      pending_out.pop_front();
+    }
+  }
+  void pipe_output(int slot, const std::shared_ptr<PicData>& d) {
+    std::lock_guard<std::mutex> lk(pipe_mu);
+    pending_out.push_back(PendingOut{slot, d});
+    release_outputs_locked();
+  }
+  bool pipe_check_locked() {
+    if (pipe_failed) return fail(pipe_error.c_str());
+    return true;
+  }
+  bool pipe_wait_for_room() {
+    std::unique_lock<std::mutex> lk(pipe_mu);
+    pipe_cv.wait(lk, [&] { return pipe_failed || static_cast<int>(inflight.size()) < max_in_flight; });
+    return pipe_check_locked();
+  }
+  // waits until one picture fewer is in flight; false if none is
+  bool pipe_wait_one() {
+    std::unique_lock<std::mutex> lk(pipe_mu);
+    const size_t n = inflight.size();
+    if (n == 0) return false;
+    pipe_cv.wait(lk, [&] { return inflight.size() < n; });
+    return true;
+  }
+  bool pipe_drain() {
+    std::unique_lock<std::mutex> lk(pipe_mu);
+    pipe_cv.wait(lk, [&] { return inflight.empty(); });
+    return pipe_check_locked();
+  }
+  void pipe_begin_task(Pic* c) {
+    building = std::make_shared<PicTask>();
+    building->cur = c->d;
+    building->sps = *asps;
+    building->bufs = bufs;
+  }
+  void pipe_add_slice(const Bits& b) {
+    building->slices.emplace_back();
+    PicTask::Slice& s = building->slices.back();
+    s.hdr = sl;
+    s.pps = *apps;
+    const size_t nbytes = static_cast<size_t>((b.size_bits + 7) >> 3);
+    s.rbsp.assign(rbsp.begin(), rbsp.begin() + std::min(rbsp.size(), nbytes + 8));  // unescape() pads with 8 zero bytes
+    s.pos = b.pos;
+    s.size_bits = b.size_bits;
+    s.index = slice_index;
+    for (int l = 0; l < 2; ++l)
+      for (int i = 0; i < sl.num_ref_idx[l]; ++i)
+        if (sl.ref_list[l][i]) building->keep.push_back(sl.ref_list[l][i]->d);
+  }
+  void pipe_drop_task() { building.reset(); }
+  void pipe_submit_task(const PicDone& front_done) {
+    std::shared_ptr<PicTask> t = std::move(building);
+    building.reset();
+    t->done = front_done;
+    t->done_pps = *apps;
+    t->done.scaling4 = t->done_pps.scaling4;
+    t->done.scaling8 = t->done_pps.scaling8;
+    {
+      std::lock_guard<std::mutex> lk(pipe_mu);
+      inflight.push_back(t);
+    }
+    workers->submit([this, t] { run_task(t); });
+  }
+  // worker thread
+  void run_task(const std::shared_ptr<PicTask>& t) {
+    static thread_local std::unique_ptr<SliceData> tls;
+    if (!tls) tls.reset(new SliceData());
+    SliceData& w = *tls;
+    w.begin_picture(&t->sps, t->cur.get(), t->bufs);
+    bool ok = true;
+    for (PicTask::Slice& s : t->slices) {
+      Bits b;
+      b.buf = s.rbsp.data();
+      b.size_bits = s.size_bits;
+      b.pos = s.pos;
+      if (!w.decode_slice(s.hdr, &s.pps, s.index, b)) {
+        ok = false;
+        break;
+      }
+    }
+    if (ok) ok = w.finish_picture(&t->done);
+    if (!ok) t->err = w.err.empty() ? "slice data could not be decoded" : w.err;
+    t->slices_n = w.slices;
+    t->clean_n = w.slices_clean_end;
+    w.slices = w.slices_clean_end = 0;
+    {
+      // every record of the picture is final (or the picture failed): B pictures waiting for it go on
+      std::lock_guard<std::mutex> lk(t->cur->mu);
+      t->cur->parsed = true;
+    }
+    t->cur->cv.notify_all();
+    hand_over(t);
+  }
+  // Pictures go to the sink in decoding order: whoever finishes the oldest one
+  // in flight hands over it and every finished one behind it.
+  void hand_over(const std::shared_ptr<PicTask>& done_task) {
+    std::unique_lock<std::mutex> lk(pipe_mu);
+    done_task->finished = true;
+    if (handing_over) return;  // the thread in the loop below will get to it
+    handing_over = true;
+    while (!inflight.empty() && inflight.front()->finished) {
+      std::shared_ptr<PicTask> t = inflight.front();
+      if (!pipe_failed && !t->err.empty()) {
+        pipe_failed = true;
+        pipe_error = t->err;
+      }
+      const bool drop = pipe_failed;  // this picture or an earlier one failed: nothing after it is trustworthy
+      lk.unlock();
+      std::string sink_error;
+      bool sink_ok = true;
+      if (!drop) sink_ok = sink->end_picture(t->done, &sink_error);
+      lk.lock();
+      if (!sink_ok && !pipe_failed) {
+        pipe_failed = true;
+        pipe_error = sink_error.empty() ? "the sink refused a picture" : sink_error;
+      }
+      owner->slices_ += t->slices_n;
+      owner->slices_clean_end_ += t->clean_n;
+      t->cur->dropped = drop || !sink_ok;
+      t->cur->submitted = true;
+      inflight.pop_front();
+      release_outputs_locked();
+      // the task's references go here, outside the lock (the last holder of a picture returns its surface)
+      lk.unlock();
+      t.reset();
+      pipe_cv.notify_all();
+      lk.lock();
+    }
+    handing_over = false;
+  }
+
+  // ----------------------------------------------------------------- NAL
+  int unescape(const uint8_t* src, size_t n) {
+    rbsp.resize(n + 8);
+    size_t o = 0;
+    int zeros = 0;
+    for (size_t i = 0; i < n; ++i) {
+      uint8_t c = src[i];
+      if (zeros >= 2 && c == 3) {
+        zeros = 0;
+        continue;
+      }
+      rbsp[o++] = c;
+      zeros = c == 0 ? zeros + 1 : 0;
+    }
+    memset(rbsp.data() + o, 0, 8);
+    return static_cast<int>(o);
+  }
+
+  // -------------------------------------------------------- parameter sets
+  void scaling_list(Bits& b, uint8_t* out, int size, const uint8_t* fallback, const uint8_t* default_zz) {
+    const uint8_t* scan = size == 16 ? zigzag4x4 : zigzag8x8;
+    if (!b.bit()) {
+      memcpy(out, fallback, size);
+      return;
+    }
+    int last = 8, next = 8;
+    for (int j = 0; j < size; ++j) {
+      if (next != 0) {
+        int delta = b.se();
+        next = (last + delta + 256) & 255;
+        if (j == 0 && next == 0) {
+          for (int k = 0; k < size; ++k) out[scan[k]] = default_zz[k];
+          return;
+        }
+      }
+      last = next == 0 ? last : next;
+      out[scan[j]] = static_cast<uint8_t>(last);
+    }
+  }
+  void scaling_matrices(Bits& b, bool want8, uint8_t s4[6][16], uint8_t s8[2][64], const uint8_t fb4[6][16],
+                        const uint8_t fb8[2][64], bool sps_fallback) {
+    uint8_t d4i[16], d4p[16], d8i[64], d8p[64];
+    for (int k = 0; k < 16; ++k) {
+      d4i[zigzag4x4[k]] = default_4x4_intra[k];
+      d4p[zigzag4x4[k]] = default_4x4_inter[k];
+    }
+    for (int k = 0; k < 64; ++k) {
+      d8i[zigzag8x8[k]] = default_8x8_intra[k];
+      d8p[zigzag8x8[k]] = default_8x8_inter[k];
+    }
+    const uint8_t* f0 = sps_fallback ? fb4[0] : d4i;
+    const uint8_t* f3 = sps_fallback ? fb4[3] : d4p;
+    const uint8_t* f6 = sps_fallback ? fb8[0] : d8i;
+    const uint8_t* f7 = sps_fallback ? fb8[1] : d8p;
+    scaling_list(b, s4[0], 16, f0, default_4x4_intra);
+    scaling_list(b, s4[1], 16, s4[0], default_4x4_intra);
+    scaling_list(b, s4[2], 16, s4[1], default_4x4_intra);
+    scaling_list(b, s4[3], 16, f3, default_4x4_inter);
+    scaling_list(b, s4[4], 16, s4[3], default_4x4_inter);
+    scaling_list(b, s4[5], 16, s4[4], default_4x4_inter);
+    if (want8) {
+      scaling_list(b, s8[0], 64, f6, default_8x8_intra);
+      scaling_list(b, s8[1], 64, f7, default_8x8_inter);
+    } else {
+      memcpy(s8[0], f6, 64);
+      memcpy(s8[1], f7, 64);
+    }
+  }
+
+  int max_dpb_frames(const Sps& s) const {
+    static const int lv[][2] = {{10, 396},   {11, 900},   {12, 2376},  {13, 2376},   {20, 2376},  {21, 4752},
+                                {22, 8100},  {30, 8100},  {31, 18000}, {32, 20480},  {40, 32768}, {41, 32768},
+                                {42, 34816}, {50, 110400}, {51, 184320}, {52, 184320}};
+    int mbs = 184320;
+    for (auto& l : lv)
+      if (l[0] == s.level_idc) mbs = l[1];
+    if (s.level_idc == 11 && (s.constraint_flags & 0x10)) mbs = 396;
+    return iclip(1, 16, mbs / (s.mb_width * s.mb_height));
+  }
+
+  bool parse_sps(Bits& b) {
+    Sps s;
+    memset(s.scaling4, 16, sizeof(s.scaling4));
+    memset(s.scaling8, 16, sizeof(s.scaling8));
+    s.profile_idc = b.get(8);
+    s.constraint_flags = b.get(8);
+    s.level_idc = b.get(8);
+    unsigned id = b.ue();
+    if (id >= kMaxSps) return fail("sps_id out of range");
+    int p = s.profile_idc;
+    if (p == 100 || p == 110 || p == 122 || p == 244 || p == 44 || p == 83 || p == 86 || p == 118 || p == 128 ||
+        p == 138 || p == 139 || p == 134 || p == 135) {
+      int chroma_format_idc = b.ue();
+      if (chroma_format_idc == 3) b.bit();
+      int bdl = b.ue(), bdc = b.ue(), bypass = b.bit();
+      if (chroma_format_idc != 1 || bdl || bdc || bypass)
+        return fail("unsupported stream: only 8-bit 4:2:0 without transform bypass is decoded");
+      s.scaling_matrix_present = b.bit();
+      if (s.scaling_matrix_present) {
+        uint8_t flat4[6][16], flat8[2][64];
+        memset(flat4, 16, sizeof(flat4));
+        memset(flat8, 16, sizeof(flat8));
+        scaling_matrices(b, true, s.scaling4, s.scaling8, flat4, flat8, false);
+      }
+    }
+    // 7.4.2.1.1 ranges; unchecked values used to drive Bits::get(n) with absurd n
+    // (ADVICE r1: stack overflow / backwards cursor on a crafted avcC).
+    unsigned l2fn = b.ue();
+    if (l2fn > 12) return fail("SPS: log2_max_frame_num_minus4 out of range");
+    s.log2_max_frame_num = static_cast<int>(l2fn) + 4;
+    s.poc_type = b.ue();
+    if (s.poc_type == 0) {
+      unsigned l2poc = b.ue();
+      if (l2poc > 12) return fail("SPS: log2_max_pic_order_cnt_lsb_minus4 out of range");
+      s.log2_max_poc_lsb = static_cast<int>(l2poc) + 4;
+    } else if (s.poc_type == 1) {
+      s.delta_pic_order_always_zero = b.bit();
+      s.offset_for_non_ref_pic = b.se();
+      s.offset_for_top_to_bottom = b.se();
+      s.num_ref_frames_in_poc_cycle = b.ue();
+      if (s.num_ref_frames_in_poc_cycle > 255) return fail("bad poc cycle");
+      for (int i = 0; i < s.num_ref_frames_in_poc_cycle; ++i) s.offset_for_ref_frame[i] = b.se();
+    } else if (s.poc_type != 2) {
+      return fail("bad pic_order_cnt_type");
+    }
+    unsigned nref = b.ue();
+    if (nref > 16) return fail("SPS: max_num_ref_frames out of range");
+    s.max_num_ref_frames = static_cast<int>(nref);
+    b.bit();  // gaps_in_frame_num_value_allowed_flag
+    unsigned mbw = b.ue(), mbh = b.ue();
+    if (mbw >= 512 || mbh >= 512) return fail("picture size out of range");
+    s.mb_width = static_cast<int>(mbw) + 1;
+    s.mb_height = static_cast<int>(mbh) + 1;
+    if (!b.bit()) return fail("unsupported stream: interlaced coding (frame_mbs_only_flag = 0)");
+    s.direct_8x8_inference = b.bit();
+    if (b.bit()) {
+      // crop offsets are in chroma units (x2 for 4:2:0); the sum must leave at least one luma column/row (7.4.2.1.1)
+      uint64_t cl = b.ue(), cr = b.ue(), ct = b.ue(), cb = b.ue();
+      if (2 * (cl + cr) >= 16ull * s.mb_width || 2 * (ct + cb) >= 16ull * s.mb_height)
+        return fail("SPS: frame cropping exceeds the picture");
+      s.crop_left = static_cast<int>(2 * cl);
+      s.crop_right = static_cast<int>(2 * cr);
+      s.crop_top = static_cast<int>(2 * ct);
+      s.crop_bottom = static_cast<int>(2 * cb);
+    }
+    if (b.bit()) {  // VUI
+      if (b.bit() && b.get(8) == 255) b.get(32);
+      if (b.bit()) b.bit();
+      if (b.bit()) {
+        b.get(4);
+        if (b.bit()) b.get(24);
+      }
+      if (b.bit()) {
+        b.ue();
+        b.ue();
+      }
+      if (b.bit()) {
+        b.get(32);
+        b.get(32);
+        b.bit();
+      }
+      bool hrd = false;
+      for (int pass = 0; pass < 2; ++pass) {
+        if (!b.bit()) continue;
+        hrd = true;
+        int cpb = b.ue() + 1;
+        b.get(8);
+        for (int i = 0; i < cpb && !b.overrun; ++i) {
+          b.ue();
+          b.ue();
+          b.bit();
+        }
+        b.get(20);
+      }
+      if (hrd) b.bit();
+      b.bit();
+      s.bitstream_restriction = b.bit();
+      if (s.bitstream_restriction) {
+        b.bit();
+        b.ue();
+        b.ue();
+        b.ue();
+        b.ue();
+        s.num_reorder_frames = b.ue();
+        b.ue();
+      }
+    }
+    if (b.overrun) return fail("truncated SPS");
+    if (s.mb_width > 512 || s.mb_height > 512 || s.mb_width < 1 || s.mb_height < 1)
+      return fail("picture size out of range");
+    s.valid = true;
+    sps[id] = s;
+    return true;
+  }
+
+  bool parse_pps(Bits& b) {
+    Pps p;
+    unsigned id = b.ue();
+    if (id >= kMaxPps) return fail("pps_id out of range");
+    p.sps_id = b.ue();
+    if (p.sps_id >= kMaxSps || !sps[p.sps_id].valid) return fail("PPS refers to a missing SPS");
+    const Sps& s = sps[p.sps_id];
+    p.cabac = b.bit();
+    p.bottom_field_pic_order_present = b.bit();
+    if (b.ue() != 0) return fail("unsupported stream: slice groups (FMO)");
+    unsigned nr0 = b.ue(), nr1 = b.ue();
+    if (nr0 > 31 || nr1 > 31) return fail("PPS: num_ref_idx_default_active out of range");
+    p.num_ref_idx_default[0] = static_cast<int>(nr0) + 1;
+    p.num_ref_idx_default[1] = static_cast<int>(nr1) + 1;
+    p.weighted_pred = b.bit();
+    p.weighted_bipred_idc = b.get(2);
+    if (p.weighted_bipred_idc > 2) return fail("PPS: weighted_bipred_idc out of range");
+    int iq = b.se();
+    if (iq < -26 || iq > 25) return fail("PPS: pic_init_qp out of range");
+    p.init_qp = 26 + iq;
+    b.se();
+    p.chroma_qp_offset[0] = b.se();
+    if (p.chroma_qp_offset[0] < -12 || p.chroma_qp_offset[0] > 12) return fail("PPS: chroma_qp_index_offset out of range");
+    p.deblocking_control_present = b.bit();
+    p.constrained_intra_pred = b.bit();
+    p.redundant_pic_cnt_present = b.bit();
+    p.chroma_qp_offset[1] = p.chroma_qp_offset[0];
+    memcpy(p.scaling4, s.scaling4, sizeof(p.scaling4));
+    memcpy(p.scaling8, s.scaling8, sizeof(p.scaling8));
+    if (b.more_rbsp_data()) {
+      p.transform_8x8_mode = b.bit();
+      if (b.bit())
+        scaling_matrices(b, p.transform_8x8_mode, p.scaling4, p.scaling8, s.scaling4, s.scaling8,
+                         s.scaling_matrix_present);
+      p.chroma_qp_offset[1] = b.se();
+      if (p.chroma_qp_offset[1] < -12 || p.chroma_qp_offset[1] > 12)
+        return fail("PPS: second_chroma_qp_index_offset out of range");
+    }
+    if (b.overrun) return fail("truncated PPS");
+    p.valid = true;
+    pps[id] = p;
+    return true;
+  }
+
+  // ------------------------------------------------------------------ DPB
+  void release_unused() {
+    for (Pic& p : dpb) {
+      if (p.in_use && &p != cur && !p.ref && !p.needed_for_output) {
+        p.in_use = false;
+        p.slot = -1;
+        p.d.reset();  // the surface goes back to the sink with the last holder (PicPool::Recycler)
+      }
+    }
+  }
+  Pic* grab_pic() {
+    for (Pic& p : dpb)
+      if (!p.in_use) {
+        p.in_use = true;
+        p.uid = ++next_uid;
+        p.ref = 0;
+        p.needed_for_output = false;
+        p.long_term_idx = -1;
+        p.slot = -1;
+        p.d = pool->grab();
+        p.d->uid = p.uid;
+        return &p;
+      }
+    return nullptr;
+  }
+  void emit(Pic* p) {
+    if (workers) pipe_output(p->slot, p->slot >= 0 ? p->d : nullptr);
+    else sink->output_picture(p->slot);
+    if (p->slot < 0 && !wanted.empty() &&
+        std::binary_search(wanted.begin(), wanted.end(), outputs_emitted)) {
+      // A picture was skipped on the prediction that nobody wants its output
+      // position, and the prediction was wrong.  Never hand out garbage.
+      fail("sparse decode mispredicted the display position of a skipped picture");
+    }
+    ++outputs_emitted;
+    p->needed_for_output = false;
+  }
+  Pic* lowest_poc_pending(int* count) {
+    Pic* best = nullptr;
+    int n = 0;
+    for (Pic& p : dpb) {
+      if (!p.in_use || !p.needed_for_output || &p == cur) continue;
+      ++n;
+      if (!best || p.poc < best->poc) best = &p;
+    }
+    if (count) *count = n;
+    return best;
+  }
+  void output_all() {
+    while (Pic* p = lowest_poc_pending(nullptr)) emit(p);
+    release_unused();
+  }
+  int reorder_depth() const {
+    if (asps->poc_type == 2) return 0;
+    if (asps->bitstream_restriction && asps->num_reorder_frames >= 0) return asps->num_reorder_frames;
+    return const_cast<Impl*>(this)->max_dpb_frames(*asps);
+  }
+
+  // ------------------------------------------------------------------ POC
+  void compute_poc(Pic* c) {
+    const Sps& s = *asps;
+    const int max_frame_num = 1 << s.log2_max_frame_num;
+    int fno;
+    if (sl.is_idr) fno = 0;
+    else if (prev_frame_num > sl.frame_num) fno = prev_frame_num_offset + max_frame_num;
+    else fno = prev_frame_num_offset;
+    int top, bottom;
+    if (s.poc_type == 0) {
+      const int max_lsb = 1 << s.log2_max_poc_lsb;
+      if (sl.is_idr) prev_poc_msb = prev_poc_lsb = 0;
+      int msb;
+      if (sl.poc_lsb < prev_poc_lsb && prev_poc_lsb - sl.poc_lsb >= max_lsb / 2) msb = prev_poc_msb + max_lsb;
+      else if (sl.poc_lsb > prev_poc_lsb && sl.poc_lsb - prev_poc_lsb > max_lsb / 2) msb = prev_poc_msb - max_lsb;
+      else msb = prev_poc_msb;
+      top = msb + sl.poc_lsb;
+      bottom = top + sl.delta_poc_bottom;
+      if (sl.nal_ref_idc) {
+        prev_poc_msb = msb;
+        prev_poc_lsb = sl.poc_lsb;
+      }
+    } else if (s.poc_type == 1) {
+      int abs_frame_num = s.num_ref_frames_in_poc_cycle ? fno + sl.frame_num : 0;
+      if (!sl.nal_ref_idc && abs_frame_num > 0) abs_frame_num--;
+      int per_cycle = 0;
+      for (int i = 0; i < s.num_ref_frames_in_poc_cycle; ++i) per_cycle += s.offset_for_ref_frame[i];
+      int expected = 0;
+      if (abs_frame_num > 0) {
+        int cycle = (abs_frame_num - 1) / s.num_ref_frames_in_poc_cycle;
+        int in_cycle = (abs_frame_num - 1) % s.num_ref_frames_in_poc_cycle;
+        expected = cycle * per_cycle;
+        for (int i = 0; i <= in_cycle; ++i) expected += s.offset_for_ref_frame[i];
+      }
+      if (!sl.nal_ref_idc) expected += s.offset_for_non_ref_pic;
+      top = expected + sl.delta_poc[0];
+      bottom = top + s.offset_for_top_to_bottom + sl.delta_poc[1];
+    } else {
+      top = bottom = sl.is_idr ? 0 : 2 * (fno + sl.frame_num) - (sl.nal_ref_idc ? 0 : 1);
+    }
+    c->poc = imin(top, bottom);
+    prev_frame_num_offset = fno;
+    prev_frame_num = sl.frame_num;
+  }
+
+  // ----------------------------------------------------------- ref lists
+  void init_ref_lists() {
+    const int max_frame_num = 1 << asps->log2_max_frame_num;
+    std::vector<Pic*> st, lt;
+    for (Pic& p : dpb) {
+      if (!p.in_use || &p == cur) continue;
+      if (p.ref == 1) {
+        p.frame_num_wrap = p.frame_num > sl.frame_num ? p.frame_num - max_frame_num : p.frame_num;
+        p.pic_num = p.frame_num_wrap;
+        st.push_back(&p);
+      } else if (p.ref == 2) {
+        p.pic_num = p.long_term_idx;
+        lt.push_back(&p);
+      }
+    }
+    std::sort(lt.begin(), lt.end(), [](Pic* a, Pic* b) { return a->long_term_idx < b->long_term_idx; });
+    for (int l = 0; l < 2; ++l) memset(sl.ref_list[l], 0, sizeof(sl.ref_list[l]));
+    if (sl.type == 0) {
+      std::sort(st.begin(), st.end(), [](Pic* a, Pic* b) { return a->pic_num > b->pic_num; });
+      int n = 0;
+      for (Pic* p : st) if (n < kMaxRefs) sl.ref_list[0][n++] = p;
+      for (Pic* p : lt) if (n < kMaxRefs) sl.ref_list[0][n++] = p;
+    } else if (sl.type == 1) {
+      std::vector<Pic*> before, after;
+      for (Pic* p : st) (p->poc < cur->poc ? before : after).push_back(p);
+      std::sort(before.begin(), before.end(), [](Pic* a, Pic* b) { return a->poc > b->poc; });
+      std::sort(after.begin(), after.end(), [](Pic* a, Pic* b) { return a->poc < b->poc; });
+      int n0 = 0, n1 = 0;
+      for (Pic* p : before) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
+      for (Pic* p : after) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
+      for (Pic* p : lt) if (n0 < kMaxRefs) sl.ref_list[0][n0++] = p;
+      for (Pic* p : after) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
+      for (Pic* p : before) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
+      for (Pic* p : lt) if (n1 < kMaxRefs) sl.ref_list[1][n1++] = p;
+      if (n1 > 1 && n0 == n1 && !memcmp(sl.ref_list[0], sl.ref_list[1], n1 * sizeof(Pic*)))
+        std::swap(sl.ref_list[1][0], sl.ref_list[1][1]);
+    }
+  }
+
+  bool modify_ref_list(Bits& b, int list) {
+    const int max_pic_num = 1 << asps->log2_max_frame_num;
+    int pred = sl.frame_num, idx = 0;
+    const int n = sl.num_ref_idx[list];
+    Pic** L = sl.ref_list[list];
+    for (;;) {
+      unsigned op = b.ue();
+      if (op == 3) break;
+      if (op > 3 || b.overrun || idx >= n) return fail("bad ref_pic_list_modification");
+      Pic* pic = nullptr;
+      if (op < 2) {
+        int diff = b.ue() + 1;
+        if (op == 0) {
+          pred -= diff;
+          if (pred < 0) pred += max_pic_num;
+        } else {
+          pred += diff;
+          if (pred >= max_pic_num) pred -= max_pic_num;
+        }
+        int pic_num = pred > sl.frame_num ? pred - max_pic_num : pred;
+        for (Pic& p : dpb)
+          if (p.in_use && &p != cur && p.ref == 1 && p.pic_num == pic_num) pic = &p;
+      } else {
+        int lt_num = b.ue();
+        for (Pic& p : dpb)
+          if (p.in_use && &p != cur && p.ref == 2 && p.long_term_idx == lt_num) pic = &p;
+      }
+      if (!pic) return fail("ref_pic_list_modification names a missing picture");
+      for (int c = n; c > idx; --c) L[c] = L[c - 1];
+      L[idx++] = pic;
+      int w = idx;
+      for (int c = idx; c <= n; ++c)
+        if (L[c] != pic) L[w++] = L[c];
+    }
+    return true;
+  }
+
+  // --------------------------------------------------------- slice header
+  // returns 0 ok, 1 skip this NAL, -1 error
+  int parse_slice_header(Bits& b, int nal_ref_idc, int nal_type) {
+    sl = SliceHdr();
+    sl.nal_ref_idc = nal_ref_idc;
+    sl.is_idr = nal_type == 5;
+    sl.first_mb = b.ue();
+    unsigned st = b.ue();
+    if (st > 9) return fail("bad slice_type") ? 0 : -1;
+    st %= 5;
+    if (st > 2) return fail("unsupported stream: SP/SI slices") ? 0 : -1;
+    sl.type = st;
+    sl.pps_id = b.ue();
+    if (sl.pps_id >= kMaxPps || !pps[sl.pps_id].valid) return fail("slice refers to a missing PPS") ? 0 : -1;
+    const Pps* p = &pps[sl.pps_id];
+    const Sps* s = &sps[p->sps_id];
+    sl.frame_num = b.get(s->log2_max_frame_num);
+    if (sl.is_idr) b.ue();
+    if (s->poc_type == 0) {
+      sl.poc_lsb = b.get(s->log2_max_poc_lsb);
+      if (p->bottom_field_pic_order_present) sl.delta_poc_bottom = b.se();
+    } else if (s->poc_type == 1 && !s->delta_pic_order_always_zero) {
+      sl.delta_poc[0] = b.se();
+      if (p->bottom_field_pic_order_present) sl.delta_poc[1] = b.se();
+    }
+    if (p->redundant_pic_cnt_present && b.ue() != 0) return 1;
+    if (sl.type == 1) sl.direct_spatial = b.bit();
+    sl.num_ref_idx[0] = p->num_ref_idx_default[0];
+    sl.num_ref_idx[1] = p->num_ref_idx_default[1];
+    if (sl.type != 2) {
+      if (b.bit()) {
+        sl.num_ref_idx[0] = b.ue() + 1;
+        if (sl.type == 1) sl.num_ref_idx[1] = b.ue() + 1;
+      }
+      if (sl.num_ref_idx[0] > kMaxRefs || sl.num_ref_idx[1] > kMaxRefs)
+        return fail("num_ref_idx_active out of range") ? 0 : -1;
+    }
+    if (sl.type != 1) sl.num_ref_idx[1] = 0;
+    if (sl.type == 2) sl.num_ref_idx[0] = 0;
+
+    if (sl.first_mb != 0 && skipping_picture) return 1;
+    skipping_picture = false;
+    if (sl.first_mb == 0 || !pic_in_progress) {
+      if (pic_in_progress && !finish_picture()) return -1;
+      apps = p;
+      asps = s;
+      int r = start_picture();
+      if (r != 0) return r;
+    } else if (p->sps_id != apps->sps_id) {
+      return fail("SPS changed inside a picture") ? 0 : -1;
+    } else {
+      apps = p;
+    }
+    if (sl.type != 2) {
+      init_ref_lists();
+      if (b.bit() && !modify_ref_list(b, 0)) return -1;
+      if (sl.type == 1 && b.bit() && !modify_ref_list(b, 1)) return -1;
+      for (int l = 0; l < 2; ++l)
+        for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
+          if (!sl.ref_list[l][i]) return fail("reference list has a missing picture") ? 0 : -1;
+          if (sl.ref_list[l][i]->slot < 0)
+            return fail("a skipped picture is used as a reference") ? 0 : -1;
+          const Pic* rp = sl.ref_list[l][i];
+          RefSnap& rs = sl.ref[l][i];
+          rs.d = rp->d.get();
+          rs.slot = rp->slot;
+          rs.uid = rp->uid;
+          rs.poc = rp->poc;
+          rs.marking = rp->ref;
+        }
+    }
+    sl.cur_poc = cur->poc;
+    sl.use_weight = 0;
+    if ((p->weighted_pred && sl.type == 0) || (p->weighted_bipred_idc == 1 && sl.type == 1)) {
+      sl.use_weight = 1;
+      sl.luma_log2_denom = b.ue();
+      sl.chroma_log2_denom = b.ue();
+      if (sl.luma_log2_denom > 7 || sl.chroma_log2_denom > 7) return fail("bad weight denominator") ? 0 : -1;
+      for (int l = 0; l < (sl.type == 1 ? 2 : 1); ++l)
+        for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
+          sl.luma_weight[l][i] = 1 << sl.luma_log2_denom;
+          sl.luma_offset[l][i] = 0;
+          if (b.bit()) {
+            sl.luma_weight[l][i] = b.se();
+            sl.luma_offset[l][i] = b.se();
+            if (sl.luma_weight[l][i] < -128 || sl.luma_weight[l][i] > 127 || sl.luma_offset[l][i] < -128 ||
+                sl.luma_offset[l][i] > 127)
+              return fail("prediction weight out of range") ? 0 : -1;
+          }
+          for (int c = 0; c < 2; ++c) {
+            sl.chroma_weight[l][i][c] = 1 << sl.chroma_log2_denom;
+            sl.chroma_offset[l][i][c] = 0;
+          }
+          if (b.bit())
+            for (int c = 0; c < 2; ++c) {
+              sl.chroma_weight[l][i][c] = b.se();
+              sl.chroma_offset[l][i][c] = b.se();
+              if (sl.chroma_weight[l][i][c] < -128 || sl.chroma_weight[l][i][c] > 127 ||
+                  sl.chroma_offset[l][i][c] < -128 || sl.chroma_offset[l][i][c] > 127)
+                return fail("prediction weight out of range") ? 0 : -1;
+            }
+        }
+    } else if (p->weighted_bipred_idc == 2 && sl.type == 1) {
+      sl.use_weight = 2;
+    }
+    if (nal_ref_idc) {
+      if (sl.is_idr) {
+        b.bit();
+        sl.long_term_reference_flag = b.bit();
+      } else {
+        sl.adaptive_marking = b.bit();
+        if (sl.adaptive_marking) {
+          for (;;) {
+            unsigned op = b.ue();
+            if (op == 0) break;
+            if (op > 6 || sl.mmco_count >= 64 || b.overrun) return fail("bad MMCO") ? 0 : -1;
+            int a = 0, c = 0;
+            if (op == 1 || op == 3) a = b.ue();
+            if (op == 2) a = b.ue();
+            if (op == 3 || op == 6) c = b.ue();
+            if (op == 4) a = b.ue();
+            sl.mmco[sl.mmco_count].op = op;
+            sl.mmco[sl.mmco_count].a = a;
+            sl.mmco[sl.mmco_count].b = c;
+            sl.mmco_count++;
+          }
+        }
+      }
+    }
+    if (p->cabac && sl.type != 2) {
+      sl.cabac_init_idc = b.ue();
+      if (sl.cabac_init_idc > 2) return fail("bad cabac_init_idc") ? 0 : -1;
+    }
+    sl.qp = p->init_qp + b.se();
+    if (sl.qp < 0 || sl.qp > 51) return fail("slice QP out of range") ? 0 : -1;
+    if (p->deblocking_control_present) {
+      sl.disable_deblock = b.ue();
+      if (sl.disable_deblock > 2) return fail("bad disable_deblocking_filter_idc") ? 0 : -1;
+      if (sl.disable_deblock != 1) {
+        sl.alpha_offset = b.se() * 2;
+        sl.beta_offset = b.se() * 2;
+      }
+    }
+    if (b.overrun) return fail("truncated slice header") ? 0 : -1;
+    if (num_slices >= bufs.max_slices) return fail("too many slices in one picture") ? 0 : -1;
+    slice_index = num_slices + 1;
+    fill_slice_params(&bufs.slices[num_slices]);
+    ++num_slices;
+    slice_type_mask |= sl.type == 0 ? 1 : (sl.type == 1 ? 2 : 4);
+    if (sl.disable_deblock != 1) any_deblock = true;
+    return 0;
+  }
+
+  void fill_slice_params(SliceParams* sp) {
+    memset(sp, 0, sizeof(*sp));
+    sp->alpha_offset = static_cast<int8_t>(sl.alpha_offset);
+    sp->beta_offset = static_cast<int8_t>(sl.beta_offset);
+    sp->weight_mode = static_cast<uint8_t>(sl.use_weight);
+    sp->luma_log2_denom = static_cast<uint8_t>(sl.luma_log2_denom);
+    sp->chroma_log2_denom = static_cast<uint8_t>(sl.chroma_log2_denom);
+    sp->cur_poc = cur->poc;
+    for (int l = 0; l < 2; ++l)
+      for (int i = 0; i < sl.num_ref_idx[l]; ++i) {
+        sp->luma_weight[l][i] = static_cast<int16_t>(sl.luma_weight[l][i]);
+        sp->luma_offset[l][i] = static_cast<int16_t>(sl.luma_offset[l][i]);
+        for (int c = 0; c < 2; ++c) {
+          sp->chroma_weight[l][i][c] = static_cast<int16_t>(sl.chroma_weight[l][i][c]);
+          sp->chroma_offset[l][i][c] = static_cast<int16_t>(sl.chroma_offset[l][i][c]);
+        }
+        sp->ref_poc[l][i] = sl.ref_list[l][i]->poc;
+        sp->ref_long[l][i] = sl.ref_list[l][i]->ref == 2;
+      }
+  }
+
+  // returns 0 ok, 1 picture skipped on purpose, -1 error
+  int start_picture() {
+    if (workers && (mbw != asps->mb_width || mbh != asps->mb_height) && !pipe_drain()) return -1;  // the sink re-makes its buffers
+    mbw = asps->mb_width;
+    mbh = asps->mb_height;
+    if (sl.is_idr) {
+      cur = nullptr;
+      output_all();
+      for (Pic& p : dpb) p.ref = 0;
+      release_unused();
+      prev_frame_num = prev_frame_num_offset = 0;
+      max_long_term_frame_idx = -1;
+    } else if (prev_ref_has_mmco5) {
+      prev_frame_num = prev_frame_num_offset = 0;
+    }
+    prev_ref_has_mmco5 = false;
+    release_unused();
+    Pic* c = grab_pic();
+    if (!c) return fail("decoded picture buffer exhausted") ? 0 : -1;
+    cur = c;
+    c->frame_num = sl.frame_num;
+    compute_poc(c);
+
+    // Sparse decode: an unwanted non-reference picture is not decoded.  Its
+    // display position is predicted as (already output) + (pending pictures
+    // that precede it); emit() verifies the prediction.
+    if (!wanted.empty() && !sl.nal_ref_idc) {
+      uint64_t pos = outputs_emitted;
+      for (Pic& p : dpb)
+        if (p.in_use && &p != c && p.needed_for_output && p.poc < c->poc) ++pos;
+      if (!std::binary_search(wanted.begin(), wanted.end(), pos)) {
+        c->slot = -1;
+        c->needed_for_output = true;
+        cur = nullptr;
+        pic_in_progress = false;
+        skipping_picture = true;
+        ++owner->pictures_skipped_;
+        bump();
+        return 1;
+      }
+    }
+
+    PicSetup setup{mbw, mbh, asps->crop_left, asps->crop_right, asps->crop_top, asps->crop_bottom};
+    if (workers && !pipe_wait_for_room()) {
+      c->in_use = false;
+      c->d.reset();
+      cur = nullptr;
+      return -1;
+    }
+    bufs = PicBuffers();
+    for (;;) {
+      if (sink->begin_picture(setup, &bufs, err)) break;
+      // every surface held by pictures that are still with the workers: one of them finishing frees one
+      if (workers && bufs.no_surface && pipe_wait_one()) {
+        err->clear();
+        bufs = PicBuffers();
+        continue;
+      }
+      c->in_use = false;
+      c->d.reset();
+      cur = nullptr;
+      return -1;
+    }
+    c->slot = bufs.slot;
+    PicData& d = *c->d;
+    d.slot = bufs.slot;
+    d.motion = bufs.motion;
+    d.pmo = bufs.pmo;
+    d.pmx = bufs.pmx;
+    d.parsed = d.submitted = !workers;
+    num_slices = 0;
+    slice_index = 0;
+    any_deblock = false;
+    slice_type_mask = 0;
+    pic_in_progress = true;
+    if (workers) pipe_begin_task(c);
+    else sd.begin_picture(asps, c->d.get(), bufs);
+    return 0;
+  }
+
+  void unmark_long_idx(int idx, Pic* except) {
+    for (Pic& p : dpb)
+      if (p.in_use && &p != except && p.ref == 2 && p.long_term_idx == idx) p.ref = 0;
+  }
+
+  void mark_references(Pic* c) {
+    if (!sl.nal_ref_idc) return;
+    if (sl.is_idr) {
+      if (sl.long_term_reference_flag) {
+        c->ref = 2;
+        c->long_term_idx = 0;
+        max_long_term_frame_idx = 0;
+      } else {
+        c->ref = 1;
+        max_long_term_frame_idx = -1;
+      }
+      return;
+    }
+    bool cur_is_long = false;
+    if (sl.adaptive_marking) {
+      for (int k = 0; k < sl.mmco_count; ++k) {
+        const int op = sl.mmco[k].op, a = sl.mmco[k].a, bb = sl.mmco[k].b;
+        if (op == 1 || op == 3) {
+          const int pic_num = sl.frame_num - (a + 1);
+          for (Pic& p : dpb) {
+            if (!p.in_use || &p == c || p.ref != 1 || p.pic_num != pic_num) continue;
+            if (op == 1) {
+              p.ref = 0;
+            } else {
+              unmark_long_idx(bb, &p);
+              p.ref = 2;
+              p.long_term_idx = bb;
+            }
+          }
+        } else if (op == 2) {
+          for (Pic& p : dpb)
+            if (p.in_use && &p != c && p.ref == 2 && p.long_term_idx == a) p.ref = 0;
+        } else if (op == 4) {
+          max_long_term_frame_idx = a - 1;
+          for (Pic& p : dpb)
+            if (p.in_use && &p != c && p.ref == 2 && p.long_term_idx > a - 1) p.ref = 0;
+        } else if (op == 5) {
+          for (Pic& p : dpb)
+            if (&p != c) p.ref = 0;
+          max_long_term_frame_idx = -1;
+          prev_ref_has_mmco5 = true;
+          prev_poc_msb = prev_poc_lsb = 0;
+          c->frame_num = 0;
+        } else if (op == 6) {
+          unmark_long_idx(a, c);
+          c->ref = 2;
+          c->long_term_idx = a;
+          cur_is_long = true;
+        }
+      }
+    } else {
+      int n = 0;
+      Pic* oldest = nullptr;
+      for (Pic& p : dpb) {
+        if (!p.in_use || &p == c || !p.ref) continue;
+        ++n;
+        if (p.ref == 1 && (!oldest || p.frame_num_wrap < oldest->frame_num_wrap)) oldest = &p;
+      }
+      if (n >= imax(asps->max_num_ref_frames, 1) && oldest) oldest->ref = 0;
+    }
+    if (!cur_is_long) c->ref = 1;
+  }
+
+  void bump() {
+    const int depth = reorder_depth();
+    for (;;) {
+      int n = 0;
+      Pic* p = lowest_poc_pending(&n);
+      if (!p || n <= depth) break;
+      emit(p);
+    }
+    release_unused();
+  }
+
+  bool finish_picture() {
+    if (!pic_in_progress) return true;
+    pic_in_progress = false;
+    Pic* c = cur;
+    PicDone done;
+    memset(&done, 0, sizeof(done));
+    done.slot = c->slot;
+    done.cookie = bufs.cookie;
+    done.num_slices = num_slices;
+    done.any_deblock = any_deblock;
+    done.slice_type_mask = slice_type_mask;
+    done.scaling4 = apps->scaling4;
+    done.scaling8 = apps->scaling8;
+    done.num_ref_slots = 0;
+    for (Pic& p : dpb)
+      if (p.in_use && &p != c && p.ref && p.slot >= 0 && done.num_ref_slots < 32)
+        done.ref_slots[done.num_ref_slots++] = p.slot;
+    if (workers) {
+      pipe_submit_task(done);  // the slice data is decoded, and the picture handed to the sink, by the workers
+    } else {
+      const bool ok = sd.finish_picture(&done);
+      owner->slices_ += sd.slices;
+      owner->slices_clean_end_ += sd.slices_clean_end;
+      sd.slices = sd.slices_clean_end = 0;
+      if (!ok) return fail(sd.err.c_str());
+      if (!sink->end_picture(done, err)) return false;
+    }
+    ++owner->pictures_decoded_;
+
+    const int max_frame_num = 1 << asps->log2_max_frame_num;
+    for (Pic& p : dpb)
+      if (p.in_use && &p != c && p.ref == 1) {
+        p.frame_num_wrap = p.frame_num > sl.frame_num ? p.frame_num - max_frame_num : p.frame_num;
+        p.pic_num = p.frame_num_wrap;
+      }
+    mark_references(c);
+    c->needed_for_output = true;
+    if (prev_ref_has_mmco5) {
+      cur = nullptr;
+      c->needed_for_output = false;
+      output_all();
+      c->needed_for_output = true;
+      c->poc = 0;
+    }
+    cur = nullptr;
+    bump();
+    return err->empty();
   }
 
   bool decode_nal(const uint8_t* nal, size_t n) {
@@ -2867,27 +3276,48 @@ struct Parser::Impl {
     const int r = parse_slice_header(b, ref_idc, type);
     if (r < 0 || !err->empty()) return false;
     if (r > 0) return true;
-    return decode_slice_data(b);
+    if (workers) {
+      pipe_add_slice(b);
+      return true;
+    }
+    if (!sd.decode_slice(sl, apps, slice_index, b)) return fail(sd.err.c_str());
+    return true;
   }
 
   void abort_picture() {
     pic_in_progress = false;
+    if (workers) pipe_drop_task();
     if (cur) {
-      if (cur->slot >= 0) sink->release_surface(cur->slot);
       cur->in_use = false;
       cur->slot = -1;
+      cur->d.reset();
       cur = nullptr;
     }
   }
 };
 
 // ===========================================================================
-Parser::Parser(PictureSink* sink) : impl_(new Impl()) {
+Parser::Parser(PictureSink* sink, WorkerPool* workers, int max_in_flight) : impl_(new Impl()) {
   impl_->owner = this;
   impl_->sink = sink;
   impl_->err = &error_;
+  impl_->pool = std::make_shared<PicPool>();
+  impl_->pool->sink = sink;
+  if (workers && workers->size() > 0) {
+    impl_->workers = workers;
+    impl_->max_in_flight = max_in_flight > 0 ? max_in_flight : 2 * workers->size();
+  }
 }
-Parser::~Parser() { delete impl_; }
+Parser::~Parser() {
+  if (impl_->workers) {
+    impl_->pipe_drop_task();
+    std::string ignored;
+    impl_->err = &ignored;
+    (void)impl_->pipe_drain();  // no task may outlive the object it points into
+    impl_->err = &error_;
+  }
+  delete impl_;
+}
 
 int Parser::width() const {
   const Sps* s = impl_->asps;
@@ -2929,6 +3359,10 @@ bool Parser::configure(const uint8_t* avcc, size_t size) {
 bool Parser::decode(const uint8_t* sample, size_t size) {
   error_.clear();
   Impl& d = *impl_;
+  if (d.workers) {  // a picture that failed with the workers is reported at the next call
+    std::lock_guard<std::mutex> lk(d.pipe_mu);
+    if (!d.pipe_check_locked()) return false;
+  }
   size_t pos = 0;
   const int ls = d.nal_length_size;
   while (pos + ls <= size) {
@@ -2956,6 +3390,7 @@ bool Parser::decode(const uint8_t* sample, size_t size) {
 bool Parser::flush() {
   Impl& d = *impl_;
   if (d.pic_in_progress && !d.finish_picture()) return false;
+  if (d.workers && !d.pipe_drain()) return false;  // every picture handed over, every output passed on
   if (d.asps) {
     d.cur = nullptr;
     d.output_all();

@@ -18,6 +18,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -42,6 +43,12 @@ struct PicBuffers {
   amd::PMotion* pmo = nullptr;       // [mb_width * mb_height]
   uint32_t* pmx = nullptr;
   size_t pmx_capacity = 0;           // in words, >= mb_height + 15 * macroblocks
+  // Handed back in PicDone::cookie (with entropy workers several pictures are
+  // between begin_picture and end_picture at a time: which staging buffers).
+  int cookie = 0;
+  // begin_picture failed because every surface is taken: with pictures still
+  // at the workers the parser waits for one to finish and asks again.
+  bool no_surface = false;
 };
 
 struct PicSetup {
@@ -51,6 +58,7 @@ struct PicSetup {
 
 struct PicDone {
   int slot;
+  int cookie;            // PicBuffers::cookie of this picture's begin_picture
   int num_slices;
   size_t coef_count;     // 32-bit words used
   bool has_inter;        // motion[] must be uploaded
@@ -67,6 +75,12 @@ struct PicDone {
   int num_ref_slots;
 };
 
+// Threads: with a serial Parser every call comes from the thread that calls
+// Parser::decode / flush.  With entropy workers begin_picture still comes from
+// that thread, while end_picture and output_picture come from a worker or the
+// parser thread - one call at a time, end_picture in decoding order,
+// output_picture in display order and never before the picture's end_picture -
+// and release_surface from any thread at any time.
 class PictureSink {
  public:
   virtual ~PictureSink() {}
@@ -81,9 +95,33 @@ class PictureSink {
   virtual void release_surface(int slot) = 0;
 };
 
+// Threads that decode slice data for one or more Parsers (the reference's
+// software backend hands `num_devices` to libavcodec as its thread count,
+// software_video_decoder.cpp:148; this is that knob).  Jobs start in the order
+// they were submitted.
+class WorkerPool {
+ public:
+  explicit WorkerPool(int threads);
+  ~WorkerPool();
+  WorkerPool(const WorkerPool&) = delete;
+  WorkerPool& operator=(const WorkerPool&) = delete;
+  int size() const;
+  void submit(std::function<void()> job);
+
+ private:
+  struct State;
+  State* state_;
+};
+
 class Parser {
  public:
-  explicit Parser(PictureSink* sink);
+  // Serial: slice data is decoded inside decode().  With `workers` the calling
+  // thread only parses headers and runs the DPB; the slice data of up to
+  // `max_in_flight` (default: two per worker) consecutive pictures is decoded by
+  // the pool at the same time, pictures reach the sink in decoding order, and an
+  // error in a picture's slice data is reported by a later decode() / flush().
+  // The pool must outlive the Parser.
+  explicit Parser(PictureSink* sink, WorkerPool* workers = nullptr, int max_in_flight = 0);
   ~Parser();
 
   // avcC payload.

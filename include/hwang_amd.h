@@ -286,6 +286,15 @@ int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
                      size_t num_samples, const uint64_t* wanted, size_t num_wanted,
                      int64_t out[8], char* error, size_t error_capacity);
 
+/* The same with the slice data decoded by `workers` entropy threads (0: on the calling thread, as above; the
+ * backend's `num_devices` > 1, software_video_decoder.cpp:148's thread count).  out[0..7] as above except that
+ * surfaces are numbered round robin; out[8] = the digest with the surface numbers blanked, which is the same for
+ * every worker count including 0. */
+int hwang_h264_probe_workers(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
+                             const uint64_t* sample_offsets, const uint64_t* sample_sizes,
+                             size_t num_samples, const uint64_t* wanted, size_t num_wanted,
+                             int workers, int64_t out[9], char* error, size_t error_capacity);
+
 /* -- Profiling hooks ---------------------------------------------------------
  * When enabled, every kernel launch of the backend is bracketed with HIP
  * events on its own stream; hwang_prof_read drains the accumulated

@@ -41,6 +41,28 @@ def probe(hw, path, wanted=None):
     return idx, dict(zip(keys, list(out)))
 
 
+def probe_workers(hw, path, workers, wanted=None):
+    """The same through hwang_h264_probe_workers: slice data decoded by `workers` entropy threads (0: serial)."""
+    from hwang_amd._capi import lib
+    idx = hw.index_video(path)
+    data = np.fromfile(path, dtype=np.uint8)
+    offs = np.ascontiguousarray(idx.sample_offsets_np().astype(np.uint64))
+    sizes = np.ascontiguousarray(idx.sample_sizes_np().astype(np.uint64))
+    avcc = bytes(idx.metadata_bytes())
+    out = (C.c_int64 * 9)()
+    err = C.create_string_buffer(256)
+    w = np.asarray(wanted if wanted is not None else [], dtype=np.uint64)
+    rc = lib.hwang_h264_probe_workers(avcc, len(avcc), data.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                      offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      sizes.ctypes.data_as(C.POINTER(C.c_uint64)), idx.frames(),
+                                      w.ctypes.data_as(C.POINTER(C.c_uint64)) if len(w) else None, len(w), workers,
+                                      out, err, 256)
+    assert rc == 0, err.value
+    keys = ("slices", "clean_end", "pictures", "skipped", "outputs", "outputs_skipped", "coefficients", "digest",
+            "digest_noslot")
+    return dict(zip(keys, list(out)))
+
+
 def golden():
     return json.load(open(GOLDEN)) if os.path.exists(GOLDEN) else {}
 
@@ -58,6 +80,32 @@ def test_corpus_clip(hw, oracle, tmp_path, name, kw):
     g = golden()
     assert name in g, "no golden digest for %s (run python -m tests.test_host_parser)" % name
     assert g[name] == {k: r[k] for k in ("slices", "coefficients", "digest")}
+
+
+@pytest.mark.parametrize("name,kw", MATRIX, ids=[m[0] for m in MATRIX])
+def test_entropy_workers_produce_the_same_records(hw, tmp_path, name, kw):
+    """num_devices > 1 (the reference's decoder thread count, software_video_decoder.cpp:148): consecutive pictures'
+    slice data decoded by a pool of workers while the calling thread runs ahead through the headers.  Every record
+    the GPU would receive, in hand-over order, is the same as in the serial decode - for 1, 3 and 8 workers, with
+    and without a sparse hint - and the serial digest is the committed golden one."""
+    path = str(tmp_path / (name + ".mp4"))
+    make_clip(path, yuv=False, **kw)
+    serial = probe_workers(hw, path, 0)
+    assert serial["digest"] == golden()[name]["digest"]
+    n = serial["outputs"]
+    sparse = sorted(set([0, n // 3, n // 2, n - 1]))
+    serial_sparse = probe_workers(hw, path, 0, wanted=sparse)
+    ref = None
+    for workers in (1, 3, 8):
+        r = probe_workers(hw, path, workers)
+        for k in ("slices", "clean_end", "pictures", "skipped", "outputs", "outputs_skipped", "coefficients",
+                  "digest_noslot"):
+            assert r[k] == serial[k], (workers, k)
+        ref = ref or r["digest"]
+        assert r["digest"] == ref, workers   # surface numbering included: the same whatever the worker count
+        rs = probe_workers(hw, path, workers, wanted=sparse)
+        for k in ("slices", "pictures", "skipped", "outputs", "outputs_skipped", "coefficients", "digest_noslot"):
+            assert rs[k] == serial_sparse[k], (workers, k, "sparse")
 
 
 def test_sparse_hint_skips_only_unwanted_non_reference(hw, tmp_path):
