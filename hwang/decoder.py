@@ -1,8 +1,23 @@
 """hwang.Decoder with the reference's semantics (python/hwang/decoder.py:5-69):
-`retrieve(rows)` walks the seek plan one keyframe interval at a time through
-ONE DecoderAutomata -- initialize, then get_frames for the interval's wanted
-rows -- and returns H x W x 3 uint8 arrays, frame rows[k] at position k.
-This is the drop-in path; the batched multi-lane path is `hwang_amd.Decoder`."""
+`retrieve(rows)` walks the seek plan through ONE DecoderAutomata and returns
+H x W x 3 uint8 arrays, frame rows[k] at position k.  This is the drop-in path;
+the batched multi-lane path is `hwang_amd.Decoder`.
+
+Two things differ from the reference's 69 lines, both inside its C++ API:
+
+* `num_devices` is a constructor argument (the reference hard-wires 1,
+  decoder.py:28).  It reaches the backend through
+  VideoDecoderFactory::make_from_config exactly as in the reference
+  (video_decoder_factory.cpp:90-91), where the software backend reads it as its
+  decoder thread count (software_video_decoder.cpp:148); the AMD backend reads it
+  the same way: that many threads entropy decode consecutive pictures at once.
+* the intervals of the seek plan go to `DecoderAutomata.initialize` in groups
+  (a list of EncodedData per call - what the C++ API takes and the reference's own
+  tests pass, decoder_automata_test.cpp:82-155) instead of one per call
+  (decoder.py:65).  Every `get_frames` ends with wait_until_frames_copied(), i.e.
+  with the GPU drained: per interval that costs the full latency of the interval's
+  dependent pictures every time, per group it is paid once.  `interval_group_bytes`
+  bounds the encoded bytes held per group; 0 restores the reference's loop."""
 import hwang
 
 from ._python import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData, VideoDecoderType,
@@ -10,7 +25,8 @@ from ._python import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData, Vi
 
 
 class Decoder(object):
-    def __init__(self, f_or_path, video_index=None, device_type=DeviceType.CPU, device_id=0, decoder_type=None):
+    def __init__(self, f_or_path, video_index=None, device_type=DeviceType.CPU, device_id=0, decoder_type=None,
+                 num_devices=1, interval_group_bytes=64 << 20):
         self.video_index = video_index if video_index is not None else hwang.index_video(f_or_path)
         self.f = open(f_or_path, "rb") if isinstance(f_or_path, str) else f_or_path
         handle = DeviceHandle()
@@ -20,7 +36,22 @@ class Decoder(object):
             # reference: GPU -> NVIDIA, CPU -> SOFTWARE.  This build: GPU -> AMD; a CPU handle has no backend
             # and the constructor below raises.
             decoder_type = VideoDecoderType.AMD if device_type == DeviceType.GPU else VideoDecoderType.SOFTWARE
-        self._decoder = DecoderAutomata(handle, 1, decoder_type)
+        self._decoder = DecoderAutomata(handle, num_devices, decoder_type)
+        self._group_bytes = interval_group_bytes
+
+    def _segment(self, index, offsets, sizes, keyframes, end_of_file, first, last, wanted):
+        begin = offsets[first]
+        end = offsets[last] if last < len(offsets) else end_of_file
+        self.f.seek(begin)
+        segment = EncodedData()
+        segment.encoded_video = self.f.read(end - begin)
+        segment.width, segment.height, segment.format = index.frame_width(), index.frame_height(), index.format()
+        segment.start_keyframe, segment.end_keyframe = first, last
+        segment.sample_offsets = [o - begin for o in offsets[first:last]]
+        segment.sample_sizes = sizes[first:last]
+        segment.keyframes = [k for k in keyframes if first <= k <= last]
+        segment.valid_frames = wanted
+        return segment, end - begin
 
     def retrieve(self, rows):
         index = self.video_index
@@ -29,18 +60,22 @@ class Decoder(object):
         keyframes = index.keyframe_indices()
         end_of_file = offsets[-1] + sizes[-1]
         frames = []
+        group, group_frames, group_bytes = [], 0, 0
+
+        def run_group():
+            self._decoder.initialize(group, index.metadata_bytes())
+            return self._decoder.get_frames(index, group_frames)
+
         for (first, last), wanted in slice_into_video_intervals(index, rows):
-            begin = offsets[first]
-            end = offsets[last] if last < len(offsets) else end_of_file
-            self.f.seek(begin)
-            segment = EncodedData()
-            segment.encoded_video = self.f.read(end - begin)
-            segment.width, segment.height, segment.format = index.frame_width(), index.frame_height(), index.format()
-            segment.start_keyframe, segment.end_keyframe = first, last
-            segment.sample_offsets = [o - begin for o in offsets[first:last]]
-            segment.sample_sizes = sizes[first:last]
-            segment.keyframes = [k for k in keyframes if first <= k <= last]
-            segment.valid_frames = wanted
-            self._decoder.initialize([segment], index.metadata_bytes())
-            frames += self._decoder.get_frames(index, len(wanted))
+            segment, nbytes = self._segment(index, offsets, sizes, keyframes, end_of_file, first, last, wanted)
+            if not wanted:   # (the planner's answer to an empty row list: one interval without frames)
+                continue
+            group.append(segment)
+            group_frames += len(wanted)
+            group_bytes += nbytes
+            if group_bytes >= self._group_bytes:
+                frames += run_group()
+                group, group_frames, group_bytes = [], 0, 0
+        if group:
+            frames += run_group()
         return frames

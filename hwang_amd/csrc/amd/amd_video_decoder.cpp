@@ -52,7 +52,8 @@ using amd::MbMotion;
 using amd::PMotion;
 using amd::SliceParams;
 
-constexpr int kJobs = 4;        // staging ring depth
+constexpr int kJobs = 4;        // staging ring depth (serial entropy decoding; with workers: pictures in flight + 3)
+constexpr int kPipeLanes = 8;   // executor lanes a decoder with entropy workers rotates through, one per interval
 constexpr int kMaxSlices = 256;
 constexpr int kBounce = 4;      // pinned output bounce buffers
 
@@ -62,7 +63,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
                         public CountedBackend,
                         public h264::PictureSink {
  public:
-  explicit AMDVideoDecoder(int device_id) : device_(device_id) {}
+  // num_workers > 1: the reference's `num_devices` (the software backend's decoder thread count,
+  // software_video_decoder.cpp:148) - that many entropy workers decode consecutive pictures' slice data at once.
+  AMDVideoDecoder(int device_id, int num_workers) : device_(device_id), num_workers_(num_workers > 1 ? num_workers : 0) {}
   ~AMDVideoDecoder() override { teardown(); }
 
   bool open(std::string* error) {
@@ -72,7 +75,19 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     exec_ = amd::GpuExecutor::get(device_, error);
     if (!exec_) return false;
-    lane_ = exec_->register_lane();
+    // One executor lane orders a decoder's pictures.  With entropy workers the host runs far ahead of the GPU, whose
+    // row kernels need ~2 ms per dependent picture: successive intervals (independent by construction) go to
+    // different lanes so that their pictures share batches.
+    const int nlanes = num_workers_ ? kPipeLanes : 1;
+    for (int i = 0; i < nlanes; ++i) lanes_.push_back(exec_->register_lane());
+    last_seq_.reset(new std::atomic<uint64_t>[nlanes]);
+    for (int i = 0; i < nlanes; ++i) last_seq_[i].store(0);
+    if (num_workers_) {
+      // Slice data of at most this many pictures is being decoded at a time; each holds a staging set and a surface.
+      max_in_flight_ = std::min(2 * num_workers_, 16);
+      pool_.reset(new h264::WorkerPool(num_workers_));
+    }
+    jobs_.resize(num_workers_ ? max_in_flight_ + 3 : kJobs);
     return true;
   }
 
@@ -83,13 +98,14 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       return Result(false, "AMDVideoDecoder: unsupported format '" + metadata.format +
                                "' (H.264 in avc1/h264 sample entries only)");
     }
-    HWANG_RETURN_ON_ERROR(drain_and_reset());
-    info_ = metadata;
     if (parser_) {
       folded_decoded_ += parser_->pictures_decoded();
       folded_skipped_ += parser_->pictures_skipped();
+      parser_.reset();  // (with entropy workers: waits until every picture in flight has been handed over)
     }
-    parser_.reset(new h264::Parser(this));
+    HWANG_RETURN_ON_ERROR(drain_and_reset());
+    info_ = metadata;
+    parser_.reset(new h264::Parser(this, pool_.get(), max_in_flight_));
     if (!parser_->configure(extradata.data(), extradata.size()))
       return Result(false, "AMDVideoDecoder::configure: " + parser_->error());
     if (parser_->width() != static_cast<int>(metadata.width) ||
@@ -109,7 +125,6 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (!parser_) return Result(false, "AMDVideoDecoder::feed before configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
     const auto t0 = std::chrono::steady_clock::now();
-    sink_error_.clear();
     const int64_t stall0 = counters_.stall_ns;
     const bool ok = parser_->decode(encoded_buffer, encoded_size);
     counters_.entropy_ns +=
@@ -117,17 +132,16 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         (counters_.stall_ns - stall0);
     ++counters_.samples_fed;
     if (!ok) return Result(false, "AMDVideoDecoder::feed: " + parser_->error());
-    if (!sink_error_.empty()) return Result(false, "AMDVideoDecoder::feed: " + sink_error_);
-    return Result();
+    return take_sink_error("AMDVideoDecoder::feed: ");
   }
 
   Result flush() override {
     if (!parser_) return Result();
     HWANG_HIP_RETURN(hipSetDevice(device_));
-    sink_error_.clear();
     if (!parser_->flush()) return Result(false, "AMDVideoDecoder::flush: " + parser_->error());
-    if (!sink_error_.empty()) return Result(false, "AMDVideoDecoder::flush: " + sink_error_);
+    HWANG_RETURN_ON_ERROR(take_sink_error("AMDVideoDecoder::flush: "));
     pending_wanted_.clear();
+    cur_lane_ = (cur_lane_ + 1) % static_cast<int>(lanes_.size());  // the next interval is independent of this one
     return Result();
   }
 
@@ -151,7 +165,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   Result wait_until_frames_copied() override {
     HWANG_HIP_RETURN(hipSetDevice(device_));
-    HWANG_RETURN_ON_ERROR(wait_seq(last_seq_.load()));
+    HWANG_RETURN_ON_ERROR(wait_all());
     std::lock_guard<std::mutex> lk(out_mu_);
     deliver_bounces_locked();
     return Result();
@@ -164,12 +178,14 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
   BackendCounters counters() override {
     BackendCounters c = counters_;
+    c.bytes_uploaded = bytes_uploaded_.load();
     c.pictures_reconstructed = folded_decoded_ + (parser_ ? parser_->pictures_decoded() : 0) - decoded_base_;
     c.pictures_skipped = folded_skipped_ + (parser_ ? parser_->pictures_skipped() : 0) - skipped_base_;
     return c;
   }
   void reset_counters() override {
     counters_ = BackendCounters();
+    bytes_uploaded_.store(0);
     decoded_base_ = folded_decoded_ + (parser_ ? parser_->pictures_decoded() : 0);
     skipped_base_ = folded_skipped_ + (parser_ ? parser_->pictures_skipped() : 0);
   }
@@ -179,13 +195,18 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (!ensure_geometry(s, error)) return false;
     // A free surface.  Its pinned motion buffer is the parser's output for
     // this picture, so it must not still be the source of an earlier picture's
-    // upload: prefer a free surface whose last upload has finished, then a new
-    // one (up to a soft limit), and only then wait for the oldest.  (Taking
-    // the lowest free index re-used the surface released most recently and
-    // made every picture wait for the one submitted just before it.)
+    // upload, and - when intervals rotate through several lanes - nothing that
+    // another lane submitted earlier may still read or write it: prefer a free
+    // surface that is through with both, then a new one (up to a soft limit),
+    // and only then wait for the oldest.  (Taking the lowest free index re-used
+    // the surface released most recently and made every picture wait for the
+    // one submitted just before it.)
+    const int lane = lanes_[cur_lane_];
     int slot = -1;
     {
-      const uint64_t done = exec_->completed(lane_);
+      std::vector<uint64_t> done(lanes_.size());
+      for (size_t i = 0; i < lanes_.size(); ++i) done[i] = exec_->completed(lanes_[i]);
+      auto settled = [&](const Stamp& st) { return !st.seq || done[st.lane] >= st.seq; };
       std::lock_guard<std::mutex> lk(out_mu_);
       int fresh = -1, oldest = -1, allocated = 0;
       for (int i = 0; i < amd::kMaxSurfaces; ++i) {
@@ -193,22 +214,22 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         if (surf_[i].held) continue;
         if (!surf_[i].dev) {
           if (fresh < 0) fresh = i;
-        } else if (surf_[i].motion_seq <= done) {
+        } else if (settled(surf_[i].motion) && (settled(surf_[i].busy) || lanes_[surf_[i].busy.lane] == lane)) {
           slot = i;
           break;
-        } else if (oldest < 0 || surf_[i].motion_seq < surf_[oldest].motion_seq) {
+        } else if (oldest < 0 || surf_[i].order < surf_[oldest].order) {
           oldest = i;
         }
       }
-      if (slot < 0) slot = (fresh >= 0 && (allocated < kSoftSurfaces || oldest < 0)) ? fresh : oldest;
+      if (slot < 0) slot = (fresh >= 0 && (allocated < soft_surfaces() || oldest < 0)) ? fresh : oldest;
       if (slot >= 0) surf_[slot].held = kHeldByParser;
     }
     if (slot < 0) {
       *error = "AMDVideoDecoder: out of decode surfaces (output frames are not being consumed)";
+      out->no_surface = true;
       return false;
     }
     if (!alloc_surface(slot, error)) return false;
-    const auto stall_t0 = std::chrono::steady_clock::now();
     struct StallTimer {
       BackendCounters& c;
       std::chrono::steady_clock::time_point t0;
@@ -216,26 +237,39 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         c.stall_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
       }
     };
+    Stamp motion, busy;
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      motion = surf_[slot].motion;
+      busy = surf_[slot].busy;
+    }
     // the motion buffer of this surface may still be the source of an upload
-    if (surf_[slot].motion_seq) {
-      StallTimer st{counters_, stall_t0};
+    if (motion.seq) {
+      StallTimer st{counters_, std::chrono::steady_clock::now()};
       ++dbg_motion_waits_;
-      const auto t0 = std::chrono::steady_clock::now();
-      struct Acc { int64_t& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{dbg_motion_ns_, t0};
-      if (!exec_->wait(lane_, surf_[slot].motion_seq, error)) return false;
-      surf_[slot].motion_seq = 0;
+      if (!wait_stamp(motion, error)) return false;
+    }
+    // work of another lane that still touches the surface (this lane's own is ordered by the lane)
+    if (busy.seq && lanes_[busy.lane] != lane) {
+      StallTimer st{counters_, std::chrono::steady_clock::now()};
+      if (!wait_stamp(busy, error)) return false;
+    }
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      surf_[slot].motion = Stamp();
     }
     // a staging job
-    Job& j = jobs_[job_cursor_];
-    if (j.seq) {
+    const int ji = job_cursor_;
+    Job& j = jobs_[ji];
+    if (j.stamp.seq) {
       StallTimer st{counters_, std::chrono::steady_clock::now()};
       ++dbg_job_waits_;
-      struct Acc { int64_t& a; std::chrono::steady_clock::time_point t; ~Acc() { a += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t).count(); } } acc{dbg_job_ns_, std::chrono::steady_clock::now()};
-      if (!exec_->wait(lane_, j.seq, error)) return false;
-      j.seq = 0;
+      if (!wait_stamp(j.stamp, error)) return false;
+      j.stamp = Stamp();
     }
-    cur_job_ = job_cursor_;
-    job_cursor_ = (job_cursor_ + 1) % kJobs;
+    job_cursor_ = (job_cursor_ + 1) % static_cast<int>(jobs_.size());
+    j.lane = cur_lane_;
+    out->cookie = ji;
     out->mb = j.mb_host;
     out->motion = surf_[slot].motion_host;
     out->pmo = surf_[slot].pmo_host;
@@ -251,8 +285,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     return true;
   }
 
+  // (with entropy workers: called by a worker thread, one call at a time, in decoding order)
   bool end_picture(const h264::PicDone& d, std::string* /*error*/) override {
-    Job& j = jobs_[cur_job_];
+    Job& j = jobs_[d.cookie];
+    const int lane_index = j.lane;
+    const int lane = lanes_[lane_index];
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
     amd::PicSubmit sub;
     std::memset(&sub.desc, 0, sizeof(sub.desc));
@@ -262,7 +299,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       sub.copies[sub.ncopies].src = src;
       sub.copies[sub.ncopies].bytes = bytes;
       ++sub.ncopies;
-      counters_.bytes_uploaded += bytes;
+      bytes_uploaded_.fetch_add(static_cast<int64_t>(bytes), std::memory_order_relaxed);
     };
     add_copy(j.mb_dev, j.mb_host, nmb * sizeof(MbInfo));
     if (d.coef_count) add_copy(j.coef_dev, j.coef_host, d.coef_count * sizeof(uint32_t));
@@ -283,10 +320,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     pp.num_slices = d.num_slices;
     std::memcpy(pp.scaling4, d.scaling4, sizeof(pp.scaling4));
     std::memcpy(pp.scaling8, d.scaling8, sizeof(pp.scaling8));
-    for (int i = 0; i < amd::kMaxSurfaces; ++i) {
-      pp.surfaces[i].y = surf_[i].dev;
-      pp.surfaces[i].u = surf_[i].dev ? surf_[i].dev + u_offset_ : nullptr;
-      pp.surfaces[i].v = surf_[i].dev ? surf_[i].dev + v_offset_ : nullptr;
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);  // (begin_picture may be allocating a surface on the parser thread)
+      for (int i = 0; i < amd::kMaxSurfaces; ++i) {
+        pp.surfaces[i].y = surf_[i].dev;
+        pp.surfaces[i].u = surf_[i].dev ? surf_[i].dev + u_offset_ : nullptr;
+        pp.surfaces[i].v = surf_[i].dev ? surf_[i].dev + v_offset_ : nullptr;
+      }
     }
     sub.desc.mbs = j.mb_dev;
     sub.desc.motions = j.motion_dev;
@@ -312,9 +352,20 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.bytes_intra = d.has_intra ? S : 0;
     sub.bytes_deblock = d.any_deblock ? 2 * S : 0;
     sub.bytes_mv = d.mv_deferred ? nmb * (sizeof(MbInfo) + 80 + 64) : 0;  // header + differences/refs in, vectors out
-    j.seq = exec_->submit_picture(lane_, sub);
-    note_seq(j.seq);
-    if (d.has_inter || d.compact_motion) surf_[d.slot].motion_seq = j.seq;  // the surface's pinned buffers are upload sources
+    j.stamp = Stamp{lane_index, exec_->submit_picture(lane, sub)};
+    note_seq(j.stamp);
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      SurfaceSlot& cs = surf_[d.slot];
+      if (d.has_inter || d.compact_motion) cs.motion = j.stamp;  // the surface's pinned buffers are upload sources
+      cs.busy = j.stamp;   // written by this submission ...
+      cs.lane = lane_index;
+      cs.order = ++use_order_;
+      for (int i = 0; i < d.num_ref_slots; ++i) {  // ... which reads these
+        surf_[d.ref_slots[i]].busy = j.stamp;
+        surf_[d.ref_slots[i]].order = use_order_;
+      }
+    }
     return true;
   }
 
@@ -333,6 +384,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         std::lock_guard<std::mutex> lk(out_mu_);
         unref_surface_locked(slot, kHeldByOutput);
       }
+      std::lock_guard<std::mutex> lk(out_mu_);
       sink_error_ = "too many undelivered pictures (decoded frames are not being fetched or discarded)";
     }
   }
@@ -344,14 +396,27 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
  private:
   enum { kHeldByParser = 1, kHeldByOutput = 2 };
-  static constexpr int kSoftSurfaces = 12;  // beyond this, wait for an upload rather than grow
+  // beyond this many surfaces, wait for an upload rather than grow (with entropy workers: the pictures in flight and
+  // the intervals still on the GPU hold surfaces too)
+  int soft_surfaces() const { return num_workers_ ? amd::kMaxSurfaces : 12; }
+
+  // A submission: which of this decoder's lanes, and the lane-local sequence number.  seq 0 = none.
+  struct Stamp {
+    int lane = 0;
+    uint64_t seq = 0;
+  };
+  bool wait_stamp(const Stamp& st, std::string* error) { return !st.seq || exec_->wait(lanes_[st.lane], st.seq, error); }
 
   struct SurfaceSlot {
     uint8_t* dev = nullptr;
     MbMotion* motion_host = nullptr;  // pinned; also the co-located source
     PMotion* pmo_host = nullptr;      // pinned: compact motion records ...
     uint32_t* pmx_host = nullptr;     // ... and their extra stream (row table + difference words)
-    uint64_t motion_seq = 0;          // submission that still uploads from motion_host
+    Stamp motion;                     // submission that still uploads from motion_host
+    Stamp busy;                       // latest submission that writes or reads the surface (its picture, pictures
+                                      // predicted from it, conversions of it)
+    int lane = 0;                     // lane index of the picture that was reconstructed into it
+    uint64_t order = 0;               // when it was last used (for "the oldest")
     int held = 0;
   };
   struct Job {
@@ -367,7 +432,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     void* db_dev = nullptr;  // k_bs -> k_deblock records
     int16_t* resid_dev = nullptr;  // k_residual -> k_intra
     void* band_ctl_dev = nullptr;    // k_mv, k_deblock: hand-off between a picture's workgroups
-    uint64_t seq = 0;  // submission that still reads the staging buffers
+    Stamp stamp;       // submission that still reads the staging buffers
+    int lane = 0;      // lane index the picture in these buffers goes to (begin_picture -> end_picture)
   };
   struct Bounce {
     uint8_t* host = nullptr;
@@ -375,17 +441,30 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     size_t capacity = 0;
     uint8_t* dst = nullptr;  // pending copy-out target
     size_t size = 0;
+    Stamp stamp;             // the conversion that fills it
   };
 
   void unref_surface_locked(int slot, int who) {
     if (slot >= 0 && slot < amd::kMaxSurfaces) surf_[slot].held &= ~who;
   }
 
-  Result wait_seq(uint64_t seq) {
-    if (!seq) return Result();
+  Result wait_result(const Stamp& st) {
     std::string error;
-    if (!exec_->wait(lane_, seq, &error)) return Result(false, "AMDVideoDecoder: " + error);
+    if (!wait_stamp(st, &error)) return Result(false, "AMDVideoDecoder: " + error);
     return Result();
+  }
+  // everything this decoder has submitted, on every lane
+  Result wait_all() {
+    for (size_t i = 0; i < lanes_.size(); ++i)
+      HWANG_RETURN_ON_ERROR(wait_result(Stamp{static_cast<int>(i), last_seq_[i].load()}));
+    return Result();
+  }
+  Result take_sink_error(const char* where) {
+    std::lock_guard<std::mutex> lk(out_mu_);
+    if (sink_error_.empty()) return Result();
+    Result r(false, where + sink_error_);
+    sink_error_.clear();
+    return r;
   }
   void deliver_bounces_locked() {
     for (Bounce& b : bounce_)
@@ -396,7 +475,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   Result drain_and_reset() {
-    HWANG_RETURN_ON_ERROR(wait_seq(last_seq_.load()));
+    HWANG_RETURN_ON_ERROR(wait_all());
     std::lock_guard<std::mutex> lk(out_mu_);
     // frames the caller has already taken with get_frame() are his: their copy-outs
     // complete (a re-configure between two clips of a batched call used to drop them)
@@ -438,7 +517,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       *error = "AMDVideoDecoder: the coded picture size changes while decoded frames are still queued";
       return false;
     }
-    (void)wait_seq(last_seq_.load());
+    (void)wait_all();
     {
       std::lock_guard<std::mutex> lk(out_mu_);
       deliver_bounces_locked();
@@ -486,7 +565,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         *error = "AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device";
         return false;
       }
-      j.seq = 0;
+      j.stamp = Stamp();
     }
     job_cursor_ = 0;
     rollback.armed = false;
@@ -496,21 +575,30 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   bool frames_pending_output() { return outq_.size() != 0; }
 
   bool alloc_surface(int slot, std::string* error) {
-    SurfaceSlot& s = surf_[slot];
-    if (s.dev) return true;
+    if (surf_[slot].dev) return true;
+    SurfaceSlot s;
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
+    auto give_up = [&](const char* msg) {
+      if (s.dev) (void)hipFree(s.dev);
+      if (s.motion_host) (void)hipHostFree(s.motion_host);
+      if (s.pmo_host) (void)hipHostFree(s.pmo_host);
+      if (s.pmx_host) (void)hipHostFree(s.pmx_host);
+      std::lock_guard<std::mutex> lk(out_mu_);
+      surf_[slot].held = 0;
+      *error = msg;
+      return false;
+    };
     // + 64: k_inter fetches unaligned dwords and may read 3 bytes past a plane's last sample
     if (hipMalloc(reinterpret_cast<void**>(&s.dev), surface_bytes_ + 64) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s.motion_host), nmb * sizeof(MbMotion), hipHostMallocDefault) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void**>(&s.pmo_host), nmb * sizeof(PMotion), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s.pmx_host), pmx_words_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
-      *error = "AMDVideoDecoder: out of memory for a decode surface";
-      return false;
-    }
-    if (!gpu_visible(s.motion_host) || !gpu_visible(s.pmo_host) || !gpu_visible(s.pmx_host)) {
-      *error = "AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device";
-      return false;
-    }
+        hipHostMalloc(reinterpret_cast<void**>(&s.pmx_host), pmx_words_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+      return give_up("AMDVideoDecoder: out of memory for a decode surface");
+    if (!gpu_visible(s.motion_host) || !gpu_visible(s.pmo_host) || !gpu_visible(s.pmx_host))
+      return give_up("AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device");
+    std::lock_guard<std::mutex> lk(out_mu_);  // (a worker may be copying the surface table in end_picture)
+    s.held = surf_[slot].held;
+    surf_[slot] = s;
     return true;
   }
 
@@ -553,21 +641,23 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   void teardown() {
     if (getenv("HWANG_EXEC_DEBUG") && (dbg_motion_waits_ || dbg_job_waits_))
-      fprintf(stderr, "[decoder lane %d] motion waits %lld (%.3f s)  job-ring waits %lld (%.3f s)\n", lane_,
+      fprintf(stderr, "[decoder lane %d] motion waits %lld (%.3f s)  job-ring waits %lld (%.3f s)\n", lanes_.empty() ? -1 : lanes_[0],
               (long long)dbg_motion_waits_, dbg_motion_ns_ / 1e9, (long long)dbg_job_waits_, dbg_job_ns_ / 1e9);
     if (exec_ && exec_->stopped()) {
       // Destroyed after hwang_shutdown() (interpreter exit destroys module-level
       // objects after its atexit handlers): the streams are gone and the HIP
       // runtime may be tearing down; leave the device memory to process exit.
       parser_.reset();
+      pool_.reset();
       return;
     }
     if (hipSetDevice(device_) != hipSuccess) return;
+    parser_.reset();  // (entropy workers: every picture in flight is handed over first)
+    pool_.reset();
     if (exec_) {
-      (void)wait_seq(last_seq_.load());
-      exec_->unregister_lane(lane_);
+      (void)wait_all();
+      for (int lane : lanes_) exec_->unregister_lane(lane);
     }
-    parser_.reset();
     free_buffers();
   }
 
@@ -624,6 +714,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.yuv = yuv ? 1 : 0;
     sub.bytes = need + (yuv ? need : w * h + 2 * cw * ch);
     Result r;
+    Bounce* bounce_used = nullptr;
     if (is_device_pointer(dst, &r)) {
       if (!r.ok) return finish_take(slot, r);
       sub.desc.dst = dst;  // the kernel writes caller memory in HBM directly
@@ -631,13 +722,26 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       Bounce* bounce = nullptr;
       r = acquire_bounce(need, &bounce);
       if (!r.ok) return finish_take(slot, r);
+      bounce_used = bounce;
       sub.desc.dst = bounce->dev;
       sub.d2h_dst = bounce->host;
       sub.d2h_bytes = need;
       bounce->dst = dst;
       bounce->size = need;
     }
-    note_seq(exec_->submit_convert(lane_, sub));
+    {
+      // behind the picture it shows, on that picture's lane
+      int lane_index;
+      {
+        std::lock_guard<std::mutex> lk(out_mu_);
+        lane_index = surf_[slot].lane;
+      }
+      const Stamp st{lane_index, exec_->submit_convert(lanes_[lane_index], sub)};
+      note_seq(st);
+      std::lock_guard<std::mutex> lk(out_mu_);
+      surf_[slot].busy = st;
+      if (bounce_used) bounce_used->stamp = st;
+    }
     return finish_take(slot, r);
   }
 
@@ -652,9 +756,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     Bounce& b = bounce_[bounce_cursor_];
     bounce_cursor_ = (bounce_cursor_ + 1) % kBounce;
     if (b.dst) {
-      // the ring wrapped: deliver what is pending now
-      HWANG_RETURN_ON_ERROR(wait_seq(last_seq_.load()));
-      deliver_bounces_locked();
+      // the ring wrapped: this buffer's conversion has to land, then it (and whatever else has landed) is delivered
+      HWANG_RETURN_ON_ERROR(wait_result(b.stamp));
+      std::memcpy(b.dst, b.host, b.size);
+      b.dst = nullptr;
     }
     if (b.capacity < need) {
       if (b.host) (void)hipHostFree(b.host);
@@ -671,16 +776,23 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   const int device_;
   int peer_enabled_ = -1;  // last peer device whose HBM was made reachable from device_
   amd::GpuExecutor* exec_ = nullptr;
-  int lane_ = -1;
-  // Highest sequence number this decoder has submitted.  Written by the feeder
-  // thread (end_picture) and by the caller thread (take_frame) under
+  const int num_workers_;       // entropy workers (0: slice data is decoded inside feed())
+  int max_in_flight_ = 0;       // pictures whose slice data may be with the workers at a time
+  std::unique_ptr<h264::WorkerPool> pool_;
+  std::vector<int> lanes_;      // executor lanes; one without workers, kPipeLanes with
+  int cur_lane_ = 0;            // index into lanes_: where the current interval's pictures go
+  uint64_t use_order_ = 0;      // (out_mu_)
+  std::atomic<int64_t> bytes_uploaded_{0};
+  // Highest sequence number this decoder has submitted, per lane.  Written by the feeder
+  // thread or an entropy worker (end_picture) and by the caller thread (take_frame) under
   // DecoderAutomata, so it only ever moves forward (note_seq): a stale store
   // from one thread must not hide the other's later submission from
-  // wait_until_frames_copied() / acquire_bounce().
-  std::atomic<uint64_t> last_seq_{0};
-  void note_seq(uint64_t seq) {
-    uint64_t cur = last_seq_.load(std::memory_order_relaxed);
-    while (cur < seq && !last_seq_.compare_exchange_weak(cur, seq, std::memory_order_release)) {
+  // wait_until_frames_copied().
+  std::unique_ptr<std::atomic<uint64_t>[]> last_seq_;
+  void note_seq(const Stamp& st) {
+    std::atomic<uint64_t>& a = last_seq_[st.lane];
+    uint64_t cur = a.load(std::memory_order_relaxed);
+    while (cur < st.seq && !a.compare_exchange_weak(cur, st.seq, std::memory_order_release)) {
     }
   }
   uint32_t epoch_ = 0;  // per submitted picture, see JobDesc::epoch
@@ -693,8 +805,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   size_t u_offset_ = 0, v_offset_ = 0, surface_bytes_ = 0, coef_capacity_ = 0, pmx_words_ = 0;
   int64_t dbg_motion_waits_ = 0, dbg_motion_ns_ = 0, dbg_job_waits_ = 0, dbg_job_ns_ = 0;
   SurfaceSlot surf_[amd::kMaxSurfaces];
-  Job jobs_[kJobs];
-  int job_cursor_ = 0, cur_job_ = 0;
+  std::vector<Job> jobs_;
+  int job_cursor_ = 0;
   Bounce bounce_[kBounce];
   int bounce_cursor_ = 0;
 
@@ -708,10 +820,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
 }  // namespace
 
-VideoDecoderInterface* make_amd_video_decoder(int32_t device_id, uint32_t /*num_devices*/) {
+// `num_devices` as the reference's software backend reads it (video_decoder_factory.cpp:90-91 ->
+// software_video_decoder.cpp:148: libavcodec's thread_count): how many threads may entropy decode for this decoder.
+// 0 and 1: the calling thread alone.
+VideoDecoderInterface* make_amd_video_decoder(int32_t device_id, uint32_t num_devices) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return nullptr;
-  auto* d = new AMDVideoDecoder(device_id);
+  auto* d = new AMDVideoDecoder(device_id, static_cast<int>(std::min<uint32_t>(num_devices, 64)));
   std::string error;
   if (!d->open(&error)) {
     delete d;

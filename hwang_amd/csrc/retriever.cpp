@@ -60,7 +60,9 @@ ParallelRetriever* ParallelRetriever::make(const std::vector<DeviceHandle>& devi
     Lane& lane = r->lanes_[li];
     lane.device_slot = li % static_cast<int32_t>(devices.size());
     for (auto& b : lane.backend) {
-      b.reset(VideoDecoderFactory::make_from_config(devices[lane.device_slot], static_cast<uint32_t>(devices.size()), type));
+      // num_devices = 1: a lane decodes on its own thread (for the AMD backend the argument is the number of entropy
+      // workers of ONE decoder, as the reference's software backend reads it; the lanes are this path's parallelism)
+      b.reset(VideoDecoderFactory::make_from_config(devices[lane.device_slot], 1, type));
       if (!b) return nullptr;
     }
   }

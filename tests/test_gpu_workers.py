@@ -1,0 +1,169 @@
+"""-m gpu: `num_devices` > 1 on the drop-in path.  The reference hands num_devices to its backend
+(video_decoder_factory.cpp:90-91), whose software flavour uses it as libavcodec's thread count
+(software_video_decoder.cpp:148).  The AMD backend does the same: ONE decoder behind ONE DecoderAutomata entropy
+decodes consecutive pictures on that many threads, hands them to the GPU in decoding order and rotates the
+intervals through several executor lanes.  Output must not depend on it: every case against the oracle-equal
+reconstruction and against the single-threaded decoder, through `hwang.Decoder` (pybind11, the reference's Python
+surface) and through the C ABI."""
+import ctypes as C
+import hashlib
+import threading
+
+import numpy as np
+import pytest
+
+from tests.corpus_util import make_clip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no fallback"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def ref_api(built):
+    import hwang
+    return hwang
+
+
+def md5s(frames):
+    return [hashlib.md5(np.ascontiguousarray(f).tobytes()).hexdigest() for f in frames]
+
+
+CASES = [
+    ("ibp", dict(frames=72, gop=12, bframes=2, slices=2, refs=2)),
+    ("pyramid_temporal", dict(frames=68, gop=17, bframes=3, refs=4, bpyramid=1, temporal_direct=1, implicit_wp=1)),
+    ("p_only_cavlc_mmco", dict(frames=60, gop=15, bframes=0, refs=4, cabac=0, mmco=1, rplm=1)),
+    ("mixed_everything", dict(frames=52, gop=13, bframes=2, refs=3, slice_mbs=37, mixed_slices=1, multi_pps=2, qp_swing=1,
+                              wild_mv=1, extra_nals=1)),
+    ("all_intra", dict(frames=12, gop=1, bframes=0, no_stss=1)),
+]
+
+
+@pytest.mark.parametrize("name,kw", CASES, ids=[c[0] for c in CASES])
+def test_reference_api_with_entropy_workers(ref_api, oracle, gpu, tmp_path, name, kw):
+    path = str(tmp_path / (name + ".mp4"))
+    gold = make_clip(path, **kw)
+    n = len(gold)
+    rng = np.random.default_rng(5)
+    sparse = sorted(rng.choice(n, max(3, n // 8), replace=False).tolist())
+    for rows in (list(range(n)), sparse):
+        want = [oracle.i420_to_rgb(gold[r], 320, 240) for r in rows]
+        for workers in (1, 4, 16):
+            for group_bytes in (64 << 20, 0):   # the intervals in one initialize, and the reference's one-by-one loop
+                dec = ref_api.Decoder(path, device_type=ref_api.DeviceType.GPU, num_devices=workers,
+                                      interval_group_bytes=group_bytes)
+                got = dec.retrieve(rows)
+                assert len(got) == len(rows)
+                for k, r in enumerate(rows):
+                    assert np.array_equal(got[k], want[k]), "%s: row %d, %d workers, groups of %d bytes" % (name, r, workers,
+                                                                                                         group_bytes)
+                del dec
+
+
+def test_workers_at_1080p_many_intervals(ref_api, oracle, gpu, tmp_path):
+    """Bench-shaped: 1080p, GOP 60 with two non-reference B pictures between P pictures, a sparse sample over many
+    GOPs.  16 workers == 1 worker == the multi-lane retriever, frame for frame; more surfaces in use than one interval
+    needs (the intervals overlap on the GPU)."""
+    import hwang_amd
+    path = str(tmp_path / "hd.mp4")
+    make_clip(path, yuv=False, width=1920, height=1080, frames=120, repeat=6, gop=60, bframes=2, refs=2, threads=2)
+    idx = hwang_amd.index_video(path)
+    rows = sorted(np.random.default_rng(11).choice(idx.frames(), 40, replace=False).tolist())
+    lanes = md5s(hwang_amd.Decoder(path, video_index=idx, num_lanes=8).retrieve(rows))
+    one = md5s(ref_api.Decoder(path, device_type=ref_api.DeviceType.GPU, num_devices=1).retrieve(rows))
+    many = md5s(ref_api.Decoder(path, device_type=ref_api.DeviceType.GPU, num_devices=16).retrieve(rows))
+    assert one == lanes
+    assert many == lanes
+    # again on the same object (state carried across calls), other rows
+    dec = ref_api.Decoder(path, device_type=ref_api.DeviceType.GPU, num_devices=16)
+    for seed in (1, 2, 3):
+        rows = sorted(np.random.default_rng(seed).choice(idx.frames(), 25, replace=False).tolist())
+        assert md5s(dec.retrieve(rows)) == md5s(hwang_amd.Decoder(path, video_index=idx, num_lanes=4).retrieve(rows))
+
+
+def test_workers_report_a_corrupt_picture(ref_api, gpu, tmp_path):
+    """A picture whose slice data fails with the workers: the error surfaces from retrieve (latched at a later feed or
+    at the flush), nothing hangs, the decoder object can be used again."""
+    path = str(tmp_path / "bad.mp4")
+    make_clip(path, yuv=False, frames=36, gop=12, bframes=0, refs=2, cabac=0)
+    import hwang_amd
+    idx = hwang_amd.index_video(path)
+    raw = bytearray(open(path, "rb").read())
+    o, n = idx.sample_offsets()[17], idx.sample_sizes()[17]
+    for k in range(o + 12, o + n):   # garbage behind the slice header of one P picture
+        raw[k] = (raw[k] * 7 + 13) & 0xff
+    bad = str(tmp_path / "bad2.mp4")
+    open(bad, "wb").write(bytes(raw))
+    done = {}
+
+    def run():
+        dec = ref_api.Decoder(bad, device_type=ref_api.DeviceType.GPU, num_devices=8)
+        try:
+            dec.retrieve(list(range(12, 24)))
+            done["error"] = None
+        except RuntimeError as e:
+            done["error"] = str(e)
+        done["good"] = len(dec.retrieve([0, 5, 30]))   # intervals that do not touch the damaged picture
+
+    t = threading.Thread(target=run)
+    t.start()
+    t.join(120)
+    assert not t.is_alive(), "retrieve hung on a corrupt picture"
+    assert done["error"], "the damaged interval decoded without an error"
+    assert done["good"] == 3
+
+
+def test_c_abi_decoder_with_workers(hw, oracle, gpu, tmp_path):
+    """hwang_decoder_create(..., num_devices = 8, ...): the seam's own entry points, fed from one thread, fetched from
+    another with the automata's back-pressure."""
+    from hwang_amd._capi import lib
+    path = str(tmp_path / "seam.mp4")
+    gold = make_clip(path, frames=48, gop=12, bframes=2, refs=2)
+    idx = hw.index_video(path)
+    raw = open(path, "rb").read()
+    offs, sizes = idx.sample_offsets(), idx.sample_sizes()
+    kfs = set(idx.keyframe_indices())
+    dec = lib.hwang_decoder_create(1, 0, 8, 3)   # GPU 0, num_devices 8, HWANG_DECODER_AMD
+    assert dec
+    ex = bytes(idx.metadata_bytes())
+    assert lib.hwang_decoder_configure(dec, 320, 240, b"avc1", ex, len(ex)) == 0
+    fs = 320 * 240 * 3
+    out = np.zeros((48, fs), dtype=np.uint8)
+    fed = threading.Event()
+    errors = []
+
+    def feeder():
+        for first in range(0, 48, 12):
+            for s in range(first, first + 12):
+                while lib.hwang_decoder_decoded_frames_buffered(dec) > 8:
+                    pass
+                if lib.hwang_decoder_feed(dec, raw[offs[s]:offs[s] + sizes[s]], sizes[s], 1 if s in kfs else 0):
+                    errors.append(lib.hwang_decoder_last_error(dec))
+                    return
+            lib.hwang_decoder_feed(dec, None, 0, 0)
+            if lib.hwang_decoder_flush(dec):
+                errors.append(lib.hwang_decoder_last_error(dec))
+                return
+        fed.set()
+
+    t = threading.Thread(target=feeder)
+    t.start()
+    got = 0
+    import time
+    deadline = time.time() + 120
+    while got < 48 and time.time() < deadline and not errors:
+        if lib.hwang_decoder_decoded_frames_buffered(dec) > 0:
+            assert lib.hwang_decoder_get_frame(dec, out[got].ctypes.data_as(C.c_void_p), fs) == 0
+            got += 1
+    t.join(30)
+    assert not errors, errors
+    assert got == 48 and fed.is_set()
+    assert lib.hwang_decoder_wait_until_frames_copied(dec) == 0
+    for r in range(48):
+        assert np.array_equal(out[r].reshape(240, 320, 3), oracle.i420_to_rgb(gold[r], 320, 240)), "frame %d" % r
+    lib.hwang_decoder_destroy(dec)
