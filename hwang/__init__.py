@@ -9,7 +9,17 @@ runs unchanged; the GPU device type selects `VideoDecoderType.AMD`
 hwang_amd/csrc/pybind/hwang_python.cpp and links libhwang_amd.so; there is no
 fallback if it is missing.
 """
+import ctypes as _ctypes
 import os
+
+# libhwang_amd.so (and through it ROCm's HIP runtime) goes in with RTLD_GLOBAL before the extension that links it, as
+# hwang_amd/_capi.py does: a Python extension is loaded RTLD_LOCAL, and a HIP runtime loaded that way is not shared with
+# a PyTorch imported later in the same process - which then brings up its bundled copy, and whichever of the two
+# initialises second finds no device ("no ROCm-capable device is detected").
+_lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hwang_amd", "libhwang_amd.so")
+if not os.path.exists(_lib):
+    raise ImportError("hwang: %s is missing -- build it with `make lib pymod` at the repo root; there is no fallback" % _lib)
+_ctypes.CDLL(_lib, mode=_ctypes.RTLD_GLOBAL)
 
 from ._python import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData, MP4IndexCreator, VideoDecoderType,
                       VideoIndex, slice_into_video_intervals, supported_decoder_types)

@@ -374,19 +374,18 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       std::lock_guard<std::mutex> lk(out_mu_);
       if (slot >= 0) surf_[slot].held |= kHeldByOutput;
     }
-    // display order; the consumer side is get_frame / discard_frame.  Counted before it becomes poppable (a consumer
-    // that pops in between must not see the count at -1); never blocks: the thread that feeds may also be the only
-    // consumer (ParallelRetriever::run_item), so a full queue is an error of the caller's protocol, not a wait.
-    buffered_.fetch_add(1, std::memory_order_acq_rel);
+    // display order; the consumer side is get_frame / discard_frame.  Never blocks: the thread that feeds may also be
+    // the only consumer (ParallelRetriever::run_item), so a full queue is an error of the caller's protocol, not a
+    // wait.  Counted after it is in the queue: a consumer acts on the count (the automata polls it), so the count must
+    // never run ahead of what get_frame can find (a consumer that fetches between the two steps sees the count dip to
+    // -1 for a moment, which nobody acts on).
     if (!outq_.try_push(slot)) {
-      buffered_.fetch_sub(1, std::memory_order_acq_rel);
-      if (slot >= 0) {
-        std::lock_guard<std::mutex> lk(out_mu_);
-        unref_surface_locked(slot, kHeldByOutput);
-      }
       std::lock_guard<std::mutex> lk(out_mu_);
+      if (slot >= 0) unref_surface_locked(slot, kHeldByOutput);
       sink_error_ = "too many undelivered pictures (decoded frames are not being fetched or discarded)";
+      return;
     }
+    buffered_.fetch_add(1, std::memory_order_acq_rel);
   }
 
   void release_surface(int slot) override {
@@ -825,10 +824,16 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 // 0 and 1: the calling thread alone.
 VideoDecoderInterface* make_amd_video_decoder(int32_t device_id, uint32_t num_devices) {
   int count = 0;
-  if (hipGetDeviceCount(&count) != hipSuccess || device_id < 0 || device_id >= count) return nullptr;
+  const hipError_t ce = hipGetDeviceCount(&count);
+  if (ce != hipSuccess || device_id < 0 || device_id >= count) {
+    fprintf(stderr, "hwang_amd: no GPU %d (%d visible%s%s)\n", device_id, count, ce != hipSuccess ? ": " : "",
+            ce != hipSuccess ? hipGetErrorString(ce) : "");
+    return nullptr;
+  }
   auto* d = new AMDVideoDecoder(device_id, static_cast<int>(std::min<uint32_t>(num_devices, 64)));
   std::string error;
   if (!d->open(&error)) {
+    fprintf(stderr, "hwang_amd: cannot open the MI355X backend on GPU %d: %s\n", device_id, error.c_str());
     delete d;
     return nullptr;
   }

@@ -36,7 +36,7 @@ struct ProbeSink : public h264::PictureSink {
   };
   std::vector<Staging> staging = std::vector<Staging>(1);
   int staging_cursor = 0;
-  bool pipelined = false;   // surfaces are handed out round robin: the numbering must not depend on when workers let go
+  bool pipelined = false;   // surfaces are handed out round robin
   int slot_cursor = 0;
   std::mutex mu;            // release_surface comes from any thread
   int nmb = 0;
@@ -59,10 +59,13 @@ struct ProbeSink : public h264::PictureSink {
     {
       std::lock_guard<std::mutex> lk(mu);
       if (pipelined) {
-        if (!slots[slot_cursor].busy) {
-          slot = slot_cursor;
-          slot_cursor = (slot_cursor + 1) % amd::kMaxSurfaces;
+        // from where the last one was taken onwards: a surface a worker has only just let go of is not taken again at
+        // once (when a worker lets go depends on timing; which surfaces the DPB holds does not)
+        for (int k = 0; k < amd::kMaxSurfaces && slot < 0; ++k) {
+          const int i = (slot_cursor + k) % amd::kMaxSurfaces;
+          if (!slots[i].busy) slot = i;
         }
+        if (slot >= 0) slot_cursor = (slot + 1) % amd::kMaxSurfaces;
       } else {
         for (int i = 0; i < amd::kMaxSurfaces; ++i)
           if (!slots[i].busy) {

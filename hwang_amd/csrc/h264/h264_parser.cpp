@@ -2318,7 +2318,8 @@ struct Parser::Impl {
   std::condition_variable pipe_cv;
   std::deque<std::shared_ptr<PicTask>> inflight;  // decoding order
   bool handing_over = false;  // a thread is inside the in-order hand-over loop
-  bool pipe_failed = false;
+  bool pipe_failed = false;    // a picture failed with the workers: nothing decodes until the next flush()
+  bool pipe_reported = false;  // ... and decode() / flush() has told the caller
   std::string pipe_error;
   struct PendingOut {
     int slot;
@@ -2340,8 +2341,9 @@ struct Parser::Impl {
     release_outputs_locked();
   }
   bool pipe_check_locked() {
-    if (pipe_failed) return fail(pipe_error.c_str());
-    return true;
+    if (!pipe_failed) return true;
+    pipe_reported = true;
+    return fail(pipe_error.c_str());
   }
   bool pipe_wait_for_room() {
     std::unique_lock<std::mutex> lk(pipe_mu);
@@ -2356,9 +2358,12 @@ struct Parser::Impl {
     pipe_cv.wait(lk, [&] { return inflight.size() < n; });
     return true;
   }
+  // Nothing in flight and no worker inside hand_over any more (the destructor relies on the second part: a worker
+  // that has popped the last picture still takes pipe_mu once more).
+  bool pipe_idle_locked() const { return inflight.empty() && !handing_over; }
   bool pipe_drain() {
     std::unique_lock<std::mutex> lk(pipe_mu);
-    pipe_cv.wait(lk, [&] { return inflight.empty(); });
+    pipe_cv.wait(lk, [&] { return pipe_idle_locked(); });
     return pipe_check_locked();
   }
   void pipe_begin_task(Pic* c) {
@@ -2461,6 +2466,7 @@ struct Parser::Impl {
       lk.lock();
     }
     handing_over = false;
+    pipe_cv.notify_all();  // (under the lock: the parser may be waiting for this to tear the object down)
   }
 
   // ----------------------------------------------------------------- NAL
@@ -3388,9 +3394,18 @@ bool Parser::decode(const uint8_t* sample, size_t size) {
 }
 
 bool Parser::flush() {
+  error_.clear();  // a failed decode() has been reported by that call; flush() answers for itself
   Impl& d = *impl_;
-  if (d.pic_in_progress && !d.finish_picture()) return false;
-  if (d.workers && !d.pipe_drain()) return false;  // every picture handed over, every output passed on
+  if (d.pic_in_progress && !d.finish_picture()) d.abort_picture();
+  if (d.workers) {
+    // every picture handed over, every output passed on.  A failure the caller has not heard of yet is reported
+    // here, once; either way the interval ends and the parser is ready for the next one.
+    std::unique_lock<std::mutex> lk(d.pipe_mu);
+    d.pipe_cv.wait(lk, [&] { return d.pipe_idle_locked(); });
+    if (d.pipe_failed && !d.pipe_reported) d.fail(d.pipe_error.c_str());
+    d.pipe_failed = d.pipe_reported = false;
+    d.pipe_error.clear();
+  }
   if (d.asps) {
     d.cur = nullptr;
     d.output_all();

@@ -288,8 +288,9 @@ int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
 
 /* The same with the slice data decoded by `workers` entropy threads (0: on the calling thread, as above; the
  * backend's `num_devices` > 1, software_video_decoder.cpp:148's thread count).  out[0..7] as above except that
- * surfaces are numbered round robin; out[8] = the digest with the surface numbers blanked, which is the same for
- * every worker count including 0. */
+ * surfaces are numbered round robin (which surface a picture gets may then depend on when a worker let go of one, so
+ * out[7] is not comparable between runs); out[8] = the digest with the surface numbers blanked, which is the same
+ * for every worker count including 0. */
 int hwang_h264_probe_workers(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
                              const uint64_t* sample_offsets, const uint64_t* sample_sizes,
                              size_t num_samples, const uint64_t* wanted, size_t num_wanted,

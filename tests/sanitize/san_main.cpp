@@ -221,8 +221,43 @@ static void memory_part(int argc, char** argv) {
   }
 }
 
+// Entropy workers (num_devices > 1): the parser thread runs ahead through the headers while a pool decodes the slice
+// data of consecutive pictures, B pictures wait for their co-located picture's records, finished pictures are handed
+// to the sink in decoding order by whichever worker holds the oldest.  Same records as the serial decode.
+static void workers_part(int argc, char** argv) {
+  for (int a = 2; a < argc; ++a) {
+    std::vector<uint8_t> data = slurp(argv[a]);
+    CHECK(!data.empty());
+    MP4IndexCreator ic(data.size());
+    uint64_t off = 0, size = std::min<uint64_t>(1024, data.size());
+    for (int it = 0; it < 4096 && !ic.is_done(); ++it) {
+      uint64_t no = 0, ns = 0;
+      ic.feed(data.data() + off, size, no, ns);
+      off = no; size = ns;
+    }
+    CHECK(ic.is_done() && !ic.is_error());
+    VideoIndex idx = ic.get_video_index();
+    int64_t serial[9] = {0}, piped[9] = {0};
+    char err[256] = {0};
+    CHECK(hwang_h264_probe_workers(idx.metadata_bytes().data(), idx.metadata_bytes().size(), data.data(),
+                                   idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0, 0,
+                                   serial, err, sizeof(err)) == 0);
+    for (int workers : {1, 2, 5}) {
+      for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hwang_h264_probe_workers(idx.metadata_bytes().data(), idx.metadata_bytes().size(), data.data(),
+                                       idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0,
+                                       workers, piped, err, sizeof(err)) == 0);
+        for (int k : {0, 1, 2, 4, 6, 8}) CHECK(piped[k] == serial[k]);
+      }
+    }
+  }
+}
+
 int main(int argc, char** argv) {
-  if (argc >= 2 && !std::strcmp(argv[1], "threads")) threads_part();
+  if (argc >= 3 && !std::strcmp(argv[1], "threads")) {
+    threads_part();
+    workers_part(argc, argv);
+  } else if (argc >= 2 && !std::strcmp(argv[1], "threads")) threads_part();
   else if (argc >= 3 && !std::strcmp(argv[1], "memory")) memory_part(argc, argv);
   else return 2;
   std::printf("%s: %s\n", argv[1], fails ? "FAILED" : "ok");

@@ -95,14 +95,11 @@ def test_entropy_workers_produce_the_same_records(hw, tmp_path, name, kw):
     n = serial["outputs"]
     sparse = sorted(set([0, n // 3, n // 2, n - 1]))
     serial_sparse = probe_workers(hw, path, 0, wanted=sparse)
-    ref = None
     for workers in (1, 3, 8):
         r = probe_workers(hw, path, workers)
         for k in ("slices", "clean_end", "pictures", "skipped", "outputs", "outputs_skipped", "coefficients",
                   "digest_noslot"):
             assert r[k] == serial[k], (workers, k)
-        ref = ref or r["digest"]
-        assert r["digest"] == ref, workers   # surface numbering included: the same whatever the worker count
         rs = probe_workers(hw, path, workers, wanted=sparse)
         for k in ("slices", "pictures", "skipped", "outputs", "outputs_skipped", "coefficients", "digest_noslot"):
             assert rs[k] == serial_sparse[k], (workers, k, "sparse")

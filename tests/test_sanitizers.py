@@ -2,8 +2,10 @@
 pool; the kernels are covered by the parity tests).
 
 * ThreadSanitizer: ParallelRetriever over three STAMP devices and 12 lanes, a
-  two-request batch, and DecoderAutomata's feeder / caller threads through
-  Queue<T> (ADVICE r1 found a real race in this area);
+  two-request batch, DecoderAutomata's feeder / caller threads through
+  Queue<T> (ADVICE r1 found a real race in this area), and the H.264 parser with
+  1, 2 and 5 entropy workers (num_devices > 1) over clips with temporal direct
+  and reference B pictures, records equal to the serial decode;
 * AddressSanitizer + UBSan: MP4 indexer -> proto codec -> planner -> H.264
   parser (both hand-over forms: full and compact motion) over corpus clips
   and over 24 bit-flipped copies of each."""
@@ -18,7 +20,7 @@ from tests.util import ROOT
 CSRC = os.path.join(ROOT, "hwang_amd", "csrc")
 SOURCES = [os.path.join(ROOT, "tests", "sanitize", "san_main.cpp")] + [os.path.join(CSRC, f) for f in (
     "retriever.cpp", "decoder_automata.cpp", "registered_backend.cpp", "video_decoder_factory.cpp", "video_index.cpp",
-    "mp4_index_creator.cpp", "h264/h264_parser.cpp", "h264/h264_cabac_init.cpp")]
+    "mp4_index_creator.cpp", "h264/h264_parser.cpp", "h264/h264_cabac_init.cpp", "capi_probe.cpp")]
 
 
 def build(tmp_path, name, flags):
@@ -35,9 +37,16 @@ def build(tmp_path, name, flags):
     return exe
 
 
-def test_thread_sanitizer(tmp_path):
+def test_thread_sanitizer(built, tmp_path):
+    clips = []
+    for i, kw in enumerate([dict(frames=26, gop=13, bframes=2, refs=2, temporal_direct=1, implicit_wp=1, slices=2, width=96, height=64),
+                            dict(frames=34, gop=17, bframes=3, refs=4, bpyramid=1, mixed_slices=1, slice_mbs=7, multi_pps=2, cabac=0,
+                                 width=80, height=64)]):
+        p = str(tmp_path / ("t%d.mp4" % i))
+        make_clip(p, yuv=False, **kw)
+        clips.append(p)
     exe = build(tmp_path, "san_tsan", ["-fsanitize=thread"])
-    r = subprocess.run([exe, "threads"], capture_output=True, text=True, timeout=600,
+    r = subprocess.run([exe, "threads"] + clips, capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
     assert r.returncode == 0 and "threads: ok" in r.stdout and "WARNING: ThreadSanitizer" not in r.stderr, \
         (r.stdout + r.stderr)[-4000:]
