@@ -217,6 +217,10 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=int(os.environ.get("HWANG_BENCH_CPU_WORKERS", 16)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-output", action="store_true", help="skip the extra D2H-inclusive pass (N = 1)")
+    ap.add_argument("--no-reference-api", action="store_true",
+                    help="skip the extra pass through hwang.Decoder(...).retrieve(rows), the reference's own API (N = 1)")
+    ap.add_argument("--reference-api-threads", type=int, default=int(os.environ.get("HWANG_BENCH_REF_THREADS", 0)),
+                    help="num_devices handed to the reference API's DecoderAutomata (default: the usable CPUs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -338,6 +342,7 @@ def main():
     roofline = None
     kernels = {}
     value_host = None
+    reference_api = None
     if rank == 0:
         lib.hwang_prof_reset()
         lib.hwang_prof_enable(1)
@@ -385,6 +390,34 @@ def main():
             torch.cuda.synchronize()
             value_host = round(2 * len(row_sets[0]) / (time.perf_counter() - th), 2)
             del host_out
+        # The drop-in path itself: hwang.Decoder(path, device_type=GPU, num_devices=T).retrieve(rows) - the
+        # reference's Python API (python/hwang/decoder.py) over the pybind11 module, ONE DecoderAutomata driving ONE
+        # AMD backend whose T entropy workers decode consecutive pictures at once (num_devices as the reference's
+        # software backend reads it, software_video_decoder.cpp:148).  Frames come back as numpy arrays in host
+        # memory, as the reference returns them.  The request goes in four calls so that the 6.7 GB of returned
+        # arrays never exist at once.
+        if args.gpus == 1 and not args.no_reference_api:
+            import hwang
+            t_ref = args.reference_api_threads or effective_cpus()
+            ridx = hwang.VideoIndex.deserialize(index.serialize())
+            rdec = hwang.Decoder(path, video_index=ridx, device_type=hwang.DeviceType.GPU, num_devices=t_ref)
+            rows0 = row_sets[0]
+            rdec.retrieve(rows0[:8])   # first-use costs (surfaces, staging, worker threads) stay outside
+            parts = [rows0[i:i + (len(rows0) + 3) // 4] for i in range(0, len(rows0), (len(rows0) + 3) // 4)]
+            cr0, tr0, got = os.times(), time.perf_counter(), 0
+            for part in parts:
+                frames = rdec.retrieve(part)
+                got += len(frames)
+                assert frames[0].shape == (HEIGHT, WIDTH, 3)
+                del frames
+            tr1, cr1 = time.perf_counter(), os.times()
+            assert got == len(rows0)
+            reference_api = {"value": round(got / (tr1 - tr0), 2), "unit": "frames/s", "num_devices": t_ref,
+                             "host_cpus_busy": round(((cr1.user - cr0.user) + (cr1.system - cr0.system)) / (tr1 - tr0), 2),
+                             "api": "hwang.Decoder(path, device_type=GPU, num_devices=%d).retrieve(rows): pybind11 "
+                                    "hwang._python.DecoderAutomata -> VideoDecoderFactory -> AMD backend; numpy frames "
+                                    "in host memory" % t_ref}
+            del rdec
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -418,6 +451,7 @@ def main():
                        "lanes_per_gpu": lanes // len(devices), "host_cpus": effective_cpus(),
                        "sharding": "GOP work items, longest-first split, no collective on the data path"},
             "value_host_output": value_host,
+            "value_reference_api": reference_api,
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
             "samples_fed_per_s_rank0": round(stats["samples_fed"] / (elapsed / args.steps), 1),
             "host_cpus_busy_rank0": round(host_cpus_busy, 2),

@@ -31,6 +31,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <deque>
@@ -55,7 +56,8 @@ using amd::SliceParams;
 constexpr int kJobs = 4;        // staging ring depth (serial entropy decoding; with workers: pictures in flight + 3)
 constexpr int kPipeLanes = 8;   // executor lanes a decoder with entropy workers rotates through, one per interval
 constexpr int kMaxSlices = 256;
-constexpr int kBounce = 4;      // pinned output bounce buffers
+constexpr int kBounce = 4;      // pinned output bounce buffers (serial entropy decoding)
+constexpr int kPipeBounce = 24; // ... with entropy workers: frames are fetched before their pictures reach the GPU
 
 class AMDVideoDecoder : public VideoDecoderInterface,
                         public SparseDecodeHints,
@@ -84,10 +86,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     for (int i = 0; i < nlanes; ++i) last_seq_[i].store(0);
     if (num_workers_) {
       // Slice data of at most this many pictures is being decoded at a time; each holds a staging set and a surface.
-      max_in_flight_ = std::min(2 * num_workers_, 16);
+      max_in_flight_ = std::min(2 * num_workers_, 24);
       pool_.reset(new h264::WorkerPool(num_workers_));
     }
     jobs_.resize(num_workers_ ? max_in_flight_ + 3 : kJobs);
+    bounce_.resize(num_workers_ ? kPipeBounce : kBounce);
     return true;
   }
 
@@ -165,10 +168,16 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   Result wait_until_frames_copied() override {
     HWANG_HIP_RETURN(hipSetDevice(device_));
+    // entropy workers: frames may have been fetched before their pictures were decoded; those pictures first
+    std::string worker_error;
+    const bool workers_ok = !parser_ || parser_->wait_idle(&worker_error);
     HWANG_RETURN_ON_ERROR(wait_all());
-    std::lock_guard<std::mutex> lk(out_mu_);
-    deliver_bounces_locked();
-    return Result();
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      deliver_bounces_locked();
+    }
+    if (!workers_ok) return Result(false, "AMDVideoDecoder: " + worker_error);
+    return take_sink_error("AMDVideoDecoder: ");
   }
 
   // ------------------------------------------------------------ extensions
@@ -257,6 +266,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     {
       std::lock_guard<std::mutex> lk(out_mu_);
       surf_[slot].motion = Stamp();
+      surf_[slot].submitted = surf_[slot].abandoned = false;
     }
     // a staging job
     const int ji = job_cursor_;
@@ -366,7 +376,53 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         surf_[d.ref_slots[i]].order = use_order_;
       }
     }
+    // conversions that were asked for before the picture got here (entropy workers: output_picture precedes
+    // end_picture, and the caller fetches frames as soon as they are announced) go right behind it
+    for (;;) {
+      Deferred def;
+      {
+        std::lock_guard<std::mutex> lk(out_mu_);
+        SurfaceSlot& cs = surf_[d.slot];
+        if (cs.deferred.empty()) {
+          cs.submitted = true;
+          break;
+        }
+        def = cs.deferred.front();
+        cs.deferred.pop_front();
+      }
+      submit_conversion(d.slot, lane_index, def.sub, def.bounce);
+    }
+    out_cv_.notify_all();
     return true;
+  }
+
+  // (entropy workers) the picture will never arrive: what was asked of its frame cannot be served
+  void abandon_picture(const h264::PicDone& d) override {
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      SurfaceSlot& cs = surf_[d.slot];
+      cs.abandoned = true;
+      for (Deferred& def : cs.deferred) {
+        if (def.bounce >= 0) bounce_[def.bounce].dst = nullptr;
+        sink_error_ = "a frame that was fetched could not be decoded (its picture or an earlier one of the interval failed)";
+        unref_surface_locked(d.slot, kHeldByOutput);
+      }
+      cs.deferred.clear();
+    }
+    out_cv_.notify_all();
+  }
+
+  // Submits one conversion of `slot` on the lane its picture went to, and lets go of the frame.
+  void submit_conversion(int slot, int lane_index, const amd::ConvSubmit& sub, int bounce) {
+    const Stamp st{lane_index, exec_->submit_convert(lanes_[lane_index], sub)};
+    note_seq(st);
+    std::lock_guard<std::mutex> lk(out_mu_);
+    surf_[slot].busy = st;
+    if (bounce >= 0) {
+      bounce_[bounce].stamp = st;
+      bounce_[bounce].queued = true;
+    }
+    unref_surface_locked(slot, kHeldByOutput);
   }
 
   void output_picture(int slot) override {
@@ -406,6 +462,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   };
   bool wait_stamp(const Stamp& st, std::string* error) { return !st.seq || exec_->wait(lanes_[st.lane], st.seq, error); }
 
+  struct Deferred {
+    amd::ConvSubmit sub;
+    int bounce = -1;  // index into bounce_, -1: straight into caller memory in HBM
+  };
   struct SurfaceSlot {
     uint8_t* dev = nullptr;
     MbMotion* motion_host = nullptr;  // pinned; also the co-located source
@@ -417,6 +477,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     int lane = 0;                     // lane index of the picture that was reconstructed into it
     uint64_t order = 0;               // when it was last used (for "the oldest")
     int held = 0;
+    bool submitted = true;            // its picture has been handed to the executor (end_picture)
+    bool abandoned = false;           // ... or never will be
+    std::deque<Deferred> deferred;    // conversions waiting for that
   };
   struct Job {
     MbInfo* mb_host = nullptr;
@@ -441,6 +504,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     uint8_t* dst = nullptr;  // pending copy-out target
     size_t size = 0;
     Stamp stamp;             // the conversion that fills it
+    bool queued = false;     // ... has been submitted (entropy workers: it may wait for its picture)
   };
 
   void unref_surface_locked(int slot, int who) {
@@ -713,35 +777,46 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.yuv = yuv ? 1 : 0;
     sub.bytes = need + (yuv ? need : w * h + 2 * cw * ch);
     Result r;
-    Bounce* bounce_used = nullptr;
+    int bounce = -1;
     if (is_device_pointer(dst, &r)) {
       if (!r.ok) return finish_take(slot, r);
       sub.desc.dst = dst;  // the kernel writes caller memory in HBM directly
     } else {
-      Bounce* bounce = nullptr;
       r = acquire_bounce(need, &bounce);
       if (!r.ok) return finish_take(slot, r);
-      bounce_used = bounce;
-      sub.desc.dst = bounce->dev;
-      sub.d2h_dst = bounce->host;
+      Bounce& b = bounce_[bounce];
+      sub.desc.dst = b.dev;
+      sub.d2h_dst = b.host;
       sub.d2h_bytes = need;
-      bounce->dst = dst;
-      bounce->size = need;
-    }
-    {
-      // behind the picture it shows, on that picture's lane
-      int lane_index;
-      {
-        std::lock_guard<std::mutex> lk(out_mu_);
-        lane_index = surf_[slot].lane;
-      }
-      const Stamp st{lane_index, exec_->submit_convert(lanes_[lane_index], sub)};
-      note_seq(st);
       std::lock_guard<std::mutex> lk(out_mu_);
-      surf_[slot].busy = st;
-      if (bounce_used) bounce_used->stamp = st;
+      b.dst = dst;
+      b.size = need;
+      b.queued = false;
+      b.stamp = Stamp();
     }
-    return finish_take(slot, r);
+    // behind the picture it shows, on that picture's lane - which, with entropy workers, may not have been handed to
+    // the executor yet: then the conversion waits with the surface and end_picture submits it
+    int lane_index;
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      SurfaceSlot& cs = surf_[slot];
+      if (cs.abandoned) {
+        if (bounce >= 0) bounce_[bounce].dst = nullptr;
+        unref_surface_locked(slot, kHeldByOutput);
+        return Result(false, "AMDVideoDecoder::get_frame: this frame could not be decoded (its picture or an earlier one "
+                             "of the interval failed)");
+      }
+      if (!cs.submitted) {
+        Deferred def;
+        def.sub = sub;
+        def.bounce = bounce;
+        cs.deferred.push_back(def);
+        return Result();
+      }
+      lane_index = cs.lane;
+    }
+    submit_conversion(slot, lane_index, sub, bounce);
+    return Result();
   }
 
   Result finish_take(int slot, const Result& r) {
@@ -751,24 +826,36 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   // A bounce buffer whose previous copy-out has been delivered.
-  Result acquire_bounce(size_t need, Bounce** out) {
-    Bounce& b = bounce_[bounce_cursor_];
-    bounce_cursor_ = (bounce_cursor_ + 1) % kBounce;
-    if (b.dst) {
-      // the ring wrapped: this buffer's conversion has to land, then it (and whatever else has landed) is delivered
-      HWANG_RETURN_ON_ERROR(wait_result(b.stamp));
-      std::memcpy(b.dst, b.host, b.size);
-      b.dst = nullptr;
+  Result acquire_bounce(size_t need, int* out) {
+    const int bi = bounce_cursor_;
+    Bounce& b = bounce_[bi];
+    bounce_cursor_ = (bounce_cursor_ + 1) % static_cast<int>(bounce_.size());
+    {
+      // the ring wrapped: this buffer's conversion has to be submitted (it may wait for its picture), then to land,
+      // then the frame is delivered
+      std::unique_lock<std::mutex> lk(out_mu_);
+      if (b.dst) {
+        out_cv_.wait(lk, [&] { return b.queued || !b.dst; });
+        if (b.dst) {
+          const Stamp st = b.stamp;
+          lk.unlock();
+          HWANG_RETURN_ON_ERROR(wait_result(st));
+          lk.lock();
+          if (b.dst) std::memcpy(b.dst, b.host, b.size);
+          b.dst = nullptr;
+        }
+      }
     }
     if (b.capacity < need) {
       if (b.host) (void)hipHostFree(b.host);
       if (b.dev) (void)hipFree(b.dev);
       b.host = b.dev = nullptr;
+      b.capacity = 0;
       HWANG_HIP_RETURN(hipHostMalloc(reinterpret_cast<void**>(&b.host), need, hipHostMallocDefault));
       HWANG_HIP_RETURN(hipMalloc(reinterpret_cast<void**>(&b.dev), need));
       b.capacity = need;
     }
-    *out = &b;
+    *out = bi;
     return Result();
   }
 
@@ -806,10 +893,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   SurfaceSlot surf_[amd::kMaxSurfaces];
   std::vector<Job> jobs_;
   int job_cursor_ = 0;
-  Bounce bounce_[kBounce];
+  std::vector<Bounce> bounce_;
   int bounce_cursor_ = 0;
 
   std::mutex out_mu_;
+  std::condition_variable out_cv_;  // a deferred conversion was submitted or cancelled
   Queue<int> outq_{4096};  // surface slot per frame in display order, -1 = skipped (hwang/util/queue.h's role)
   std::atomic<int> buffered_{0};
 

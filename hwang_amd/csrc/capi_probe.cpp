@@ -163,6 +163,10 @@ static int run_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
   for (size_t i = 0; i < num_samples; ++i)
     if (!parser.decode(data + sample_offsets[i], sample_sizes[i])) return report(parser.error());
   if (!parser.flush()) return report(parser.error());
+  {
+    std::string worker_error;  // entropy workers: flush() does not wait for them
+    if (!parser.wait_idle(&worker_error)) return report(worker_error);
+  }
   int64_t skipped_out = 0;
   for (int s : sink.outputs) skipped_out += s < 0;
   out[0] = parser.slices();

@@ -368,13 +368,10 @@ struct PicData {
   std::vector<MbMotion> derived;
   bool derived_valid = false;
   // entropy workers: `parsed` is raised (under mu) when every macroblock record
-  // of the picture is final; `submitted` when the sink has taken the picture
-  // (end_picture) - its display-order output is held back until then
+  // of the picture is final
   std::mutex mu;
   std::condition_variable cv;
   bool parsed = true;
-  bool submitted = true;   // (under the parser's pipe_mu)
-  bool dropped = false;    // never handed to the sink (it or an earlier picture failed): its output position is void
 };
 
 // A decoded (or skipped) picture in the DPB: the sequence-level bookkeeping,
@@ -469,8 +466,7 @@ struct PicPool : std::enable_shared_from_this<PicPool> {
     p->pmx = nullptr;
     p->mv_deferred = false;
     p->derived_valid = false;
-    p->parsed = p->submitted = true;
-    p->dropped = false;
+    p->parsed = true;
     std::shared_ptr<PicPool> self = shared_from_this();
     return std::shared_ptr<PicData>(p, [self](PicData* q) {
       if (q->slot >= 0) self->sink->release_surface(q->slot);
@@ -2199,6 +2195,7 @@ struct PicTask {
   std::deque<Slice> slices;
   PicDone done;
   Pps done_pps;  // done.scaling4 / scaling8 point here
+  uint64_t epoch = 0;     // which interval (Parser::Impl::epoch)
   bool finished = false;  // slice data decoded (or failed): ready to be handed to the sink, in decoding order
   std::string err;
   int64_t slices_n = 0, clean_n = 0;
@@ -2290,6 +2287,7 @@ struct Parser::Impl {
   // sparse decoding
   std::vector<uint64_t> wanted;
   uint64_t outputs_emitted = 0;  // since last flush/configure
+  uint64_t pictures_started = 0; // since last flush/configure: the decoding-order ordinal of the next picture
 
   SliceHdr sl;
   int slice_index = 0;
@@ -2308,47 +2306,36 @@ struct Parser::Impl {
   // another only where a B slice's direct prediction reads the co-located
   // picture's motion (SliceData::final_motion).  Finished pictures are handed
   // to the sink strictly in decoding order - by whichever worker completes the
-  // oldest one - and a picture's display-order output is passed on only after
-  // that hand-over, so the sink sees the same call order as in serial mode:
-  // begin_picture (parser thread) ... end_picture, output_picture (a worker or
-  // the parser thread, never two at once).
+  // oldest one.  Display-order output does NOT wait for that: output_picture is
+  // called from the parser thread as soon as the DPB releases a picture, so the
+  // caller's protocol (DecoderAutomata: one interval after the other) advances
+  // at header speed and the pictures of several intervals are with the workers
+  // at a time; the sink defers what it is asked to do with a frame until the
+  // frame's end_picture has come (or abandon_picture, if it never will).
   WorkerPool* workers = nullptr;
   int max_in_flight = 0;
   std::mutex pipe_mu;
   std::condition_variable pipe_cv;
   std::deque<std::shared_ptr<PicTask>> inflight;  // decoding order
   bool handing_over = false;  // a thread is inside the in-order hand-over loop
-  bool pipe_failed = false;    // a picture failed with the workers: nothing decodes until the next flush()
-  bool pipe_reported = false;  // ... and decode() / flush() has told the caller
+  // A picture that fails with the workers takes the rest of its interval with it (what follows refers to it);
+  // the next interval starts afresh.  Intervals are told apart by `epoch` (raised by flush()).  The failure is
+  // reported once, by the next decode(), flush() or wait_idle().
+  uint64_t epoch = 1;
+  uint64_t failed_epoch = 0;
+  bool pipe_unreported = false;
   std::string pipe_error;
-  struct PendingOut {
-    int slot;
-    std::shared_ptr<PicData> d;  // null: a picture skipped on purpose
-  };
-  std::deque<PendingOut> pending_out;
   std::shared_ptr<PicTask> building;
 
-  void release_outputs_locked() {
-    while (!pending_out.empty() && (!pending_out.front().d || pending_out.front().d->submitted)) {
-      const PendingOut& o = pending_out.front();
-      sink->output_picture(o.d && o.d->dropped ? -1 : o.slot);
-      pending_out.pop_front();
-    }
-  }
-  void pipe_output(int slot, const std::shared_ptr<PicData>& d) {
-    std::lock_guard<std::mutex> lk(pipe_mu);
-    pending_out.push_back(PendingOut{slot, d});
-    release_outputs_locked();
-  }
   bool pipe_check_locked() {
-    if (!pipe_failed) return true;
-    pipe_reported = true;
+    if (!pipe_unreported) return true;
+    pipe_unreported = false;
     return fail(pipe_error.c_str());
   }
   bool pipe_wait_for_room() {
     std::unique_lock<std::mutex> lk(pipe_mu);
-    pipe_cv.wait(lk, [&] { return pipe_failed || static_cast<int>(inflight.size()) < max_in_flight; });
-    return pipe_check_locked();
+    pipe_cv.wait(lk, [&] { return static_cast<int>(inflight.size()) < max_in_flight; });
+    return true;
   }
   // waits until one picture fewer is in flight; false if none is
   bool pipe_wait_one() {
@@ -2371,6 +2358,7 @@ struct Parser::Impl {
     building->cur = c->d;
     building->sps = *asps;
     building->bufs = bufs;
+    building->epoch = epoch;
   }
   void pipe_add_slice(const Bits& b) {
     building->slices.emplace_back();
@@ -2439,26 +2427,26 @@ struct Parser::Impl {
     handing_over = true;
     while (!inflight.empty() && inflight.front()->finished) {
       std::shared_ptr<PicTask> t = inflight.front();
-      if (!pipe_failed && !t->err.empty()) {
-        pipe_failed = true;
+      if (!t->err.empty() && failed_epoch != t->epoch) {
+        failed_epoch = t->epoch;
         pipe_error = t->err;
+        pipe_unreported = true;
       }
-      const bool drop = pipe_failed;  // this picture or an earlier one failed: nothing after it is trustworthy
+      const bool drop = failed_epoch == t->epoch;  // this picture or an earlier one of its interval failed
       lk.unlock();
       std::string sink_error;
       bool sink_ok = true;
       if (!drop) sink_ok = sink->end_picture(t->done, &sink_error);
+      if (drop || !sink_ok) sink->abandon_picture(t->done);
       lk.lock();
-      if (!sink_ok && !pipe_failed) {
-        pipe_failed = true;
+      if (!sink_ok && failed_epoch != t->epoch) {
+        failed_epoch = t->epoch;
         pipe_error = sink_error.empty() ? "the sink refused a picture" : sink_error;
+        pipe_unreported = true;
       }
       owner->slices_ += t->slices_n;
       owner->slices_clean_end_ += t->clean_n;
-      t->cur->dropped = drop || !sink_ok;
-      t->cur->submitted = true;
       inflight.pop_front();
-      release_outputs_locked();
       // the task's references go here, outside the lock (the last holder of a picture returns its surface)
       lk.unlock();
       t.reset();
@@ -2734,8 +2722,7 @@ struct Parser::Impl {
     return nullptr;
   }
   void emit(Pic* p) {
-    if (workers) pipe_output(p->slot, p->slot >= 0 ? p->d : nullptr);
-    else sink->output_picture(p->slot);
+    sink->output_picture(p->slot);
     if (p->slot < 0 && !wanted.empty() &&
         std::binary_search(wanted.begin(), wanted.end(), outputs_emitted)) {
       // A picture was skipped on the prediction that nobody wants its output
@@ -3066,6 +3053,25 @@ struct Parser::Impl {
     if (workers && (mbw != asps->mb_width || mbh != asps->mb_height) && !pipe_drain()) return -1;  // the sink re-makes its buffers
     mbw = asps->mb_width;
     mbh = asps->mb_height;
+    // Sparse decode, the tail of an interval: a picture at decoding position d is displayed at d - reorder depth or
+    // later, so once d exceeds the last wanted position by more than the reorder depth neither it nor anything that
+    // follows can be wanted or be referred to by a wanted picture.  Whatever the DPB still holds goes out first (all
+    // wanted positions are among it or out already), then every further sample is one void output position and no
+    // work at all.  (The reference's DecoderAutomata feeds every sample of an interval, decoder_automata.cpp:287-331;
+    // this is where that stops costing anything.)
+    const uint64_t ordinal = pictures_started++;
+    if (!wanted.empty() && ordinal > wanted.back() + static_cast<uint64_t>(reorder_depth())) {
+      cur = nullptr;
+      output_all();
+      for (Pic& p : dpb) p.ref = 0;
+      release_unused();
+      sink->output_picture(-1);
+      ++outputs_emitted;
+      pic_in_progress = false;
+      skipping_picture = true;
+      ++owner->pictures_skipped_;
+      return 1;
+    }
     if (sl.is_idr) {
       cur = nullptr;
       output_all();
@@ -3130,7 +3136,7 @@ struct Parser::Impl {
     d.motion = bufs.motion;
     d.pmo = bufs.pmo;
     d.pmx = bufs.pmx;
-    d.parsed = d.submitted = !workers;
+    d.parsed = !workers;
     num_slices = 0;
     slice_index = 0;
     any_deblock = false;
@@ -3398,13 +3404,13 @@ bool Parser::flush() {
   Impl& d = *impl_;
   if (d.pic_in_progress && !d.finish_picture()) d.abort_picture();
   if (d.workers) {
-    // every picture handed over, every output passed on.  A failure the caller has not heard of yet is reported
-    // here, once; either way the interval ends and the parser is ready for the next one.
+    // Does not wait for the workers: the interval's pictures keep decoding while the caller moves on to the next
+    // interval (wait_idle() is the barrier).  A failure that is known by now and that the caller has not heard of is
+    // reported here, once; a picture of this interval that fails later is reported by the next decode(), flush() or
+    // wait_idle().  Pictures of the next interval do not depend on a failed one (it starts with an IDR picture).
     std::unique_lock<std::mutex> lk(d.pipe_mu);
-    d.pipe_cv.wait(lk, [&] { return d.pipe_idle_locked(); });
-    if (d.pipe_failed && !d.pipe_reported) d.fail(d.pipe_error.c_str());
-    d.pipe_failed = d.pipe_reported = false;
-    d.pipe_error.clear();
+    (void)d.pipe_check_locked();
+    ++d.epoch;
   }
   if (d.asps) {
     d.cur = nullptr;
@@ -3413,8 +3419,20 @@ bool Parser::flush() {
     d.release_unused();
   }
   d.outputs_emitted = 0;
+  d.pictures_started = 0;
   d.wanted.clear();
   return error_.empty();
+}
+
+bool Parser::wait_idle(std::string* error) {
+  Impl& d = *impl_;
+  if (!d.workers) return true;
+  std::unique_lock<std::mutex> lk(d.pipe_mu);
+  d.pipe_cv.wait(lk, [&] { return d.pipe_idle_locked(); });
+  const bool failed = d.pipe_unreported;
+  if (failed && error) *error = d.pipe_error;
+  d.pipe_unreported = false;
+  return !failed;
 }
 
 void Parser::set_wanted(const std::vector<uint64_t>& ordinals) {

@@ -76,11 +76,14 @@ struct PicDone {
 };
 
 // Threads: with a serial Parser every call comes from the thread that calls
-// Parser::decode / flush.  With entropy workers begin_picture still comes from
-// that thread, while end_picture and output_picture come from a worker or the
-// parser thread - one call at a time, end_picture in decoding order,
-// output_picture in display order and never before the picture's end_picture -
-// and release_surface from any thread at any time.
+// Parser::decode / flush, and a picture's output_picture follows its
+// end_picture.  With entropy workers begin_picture and output_picture (display
+// order) still come from that thread, but output_picture may come BEFORE the
+// picture's end_picture: the DPB releases a picture on the strength of its
+// headers while its slice data is still with a worker.  end_picture - or, for a
+// picture that failed or follows one that did, abandon_picture - comes from a
+// worker thread, one call at a time, in decoding order; release_surface from
+// any thread at any time.
 class PictureSink {
  public:
   virtual ~PictureSink() {}
@@ -93,6 +96,10 @@ class PictureSink {
   virtual void output_picture(int slot) = 0;
   // The parser no longer needs the surface as a reference nor for output.
   virtual void release_surface(int slot) = 0;
+  // Entropy workers only: the picture begun with done.slot / done.cookie will
+  // not get an end_picture (its slice data, or an earlier picture's, could not
+  // be decoded).  Whatever was asked of its output position cannot be served.
+  virtual void abandon_picture(const PicDone& /*done*/) {}
 };
 
 // Threads that decode slice data for one or more Parsers (the reference's
@@ -128,8 +135,14 @@ class Parser {
   bool configure(const uint8_t* avcc, size_t size);
   // One MP4 sample = one access unit (AVCC framing).
   bool decode(const uint8_t* sample, size_t size);
-  // End of interval: emit everything pending, drop all references.
+  // End of interval: emit everything pending, drop all references.  With
+  // entropy workers this does not wait for them.
   bool flush();
+  // Entropy workers: blocks until every picture handed to them has reached the
+  // sink (end_picture or abandon_picture); false + message if one failed and the
+  // caller has not been told yet.  May be called from another thread than
+  // decode() / flush() as long as those are not running.  Serial: true at once.
+  bool wait_idle(std::string* error);
 
   // Sparse decoding: output positions, counted from the first
   // picture after the last flush/configure, that will be fetched.  Unwanted

@@ -119,6 +119,26 @@ def test_sparse_hint_skips_only_unwanted_non_reference(hw, tmp_path):
     assert r2["skipped"] == 7
 
 
+def test_sparse_hint_ends_the_interval_early(hw, tmp_path):
+    """Nothing behind the last wanted position + the reorder depth is decoded: the reference's automata feeds every
+    sample of a touched interval (decoder_automata.cpp:287-331), and each of them still yields one output position."""
+    path = str(tmp_path / "tail.mp4")
+    make_clip(path, yuv=False, frames=40, gop=40, bframes=2, cabac=1, refs=2)   # I B B P B B P ...; num_reorder_frames 1
+    idx, full = probe(hw, path)
+    assert full["pictures"] == 40
+    # wanted: display position 4 (a B picture between P3 and P6).  Decoding order I0 P3 B1 B2 P6 B4 B5 P9 ...:
+    # I0, P3, P6 and B4 are needed; decoding positions 0 .. 4 + 1 are looked at, everything later is void.
+    _, r = probe(hw, path, wanted=[4])
+    assert r["outputs"] == 40 and r["slices"] == r["clean_end"]
+    assert r["pictures"] == 4 and r["skipped"] == 36
+    for workers in (1, 4):
+        rw = probe_workers(hw, path, workers, wanted=[4])
+        assert (rw["pictures"], rw["skipped"], rw["outputs"]) == (4, 36, 40)
+    # the first frame only: the IDR picture, and (reorder depth 1) the P picture behind it
+    _, r0 = probe(hw, path, wanted=[0])
+    assert r0["pictures"] == 2 and r0["outputs"] == 40
+
+
 def test_sparse_hint_keeps_reference_b_pictures(hw, tmp_path):
     path = str(tmp_path / "pyr.mp4")
     make_clip(path, yuv=False, frames=13, gop=13, bframes=3, refs=4, bpyramid=1)
