@@ -21,6 +21,7 @@
 
 #include "../h264/h264_parser.h"
 #include "../sparse_hints.h"
+#include "../util/numa.h"
 #include "../util/queue.h"
 #include "frame_job.h"
 #include "gpu_executor.h"
@@ -54,7 +55,8 @@ using amd::PMotion;
 using amd::SliceParams;
 
 constexpr int kJobs = 4;        // staging ring depth (serial entropy decoding; with workers: pictures in flight + 3)
-constexpr int kPipeLanes = 8;   // executor lanes a decoder with entropy workers rotates through, one per interval
+constexpr int kPipeLanes = 16;  // executor lanes a decoder with entropy workers rotates through, one per interval
+constexpr int kPipeDepth = 96;  // ... and how many pictures may be queued between its workers and the GPU
 constexpr int kMaxSlices = 256;
 constexpr int kBounce = 4;      // pinned output bounce buffers (serial entropy decoding)
 constexpr int kPipeBounce = 24; // ... with entropy workers: frames are fetched before their pictures reach the GPU
@@ -89,7 +91,12 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       max_in_flight_ = std::min(2 * num_workers_, 24);
       pool_.reset(new h264::WorkerPool(num_workers_));
     }
-    jobs_.resize(num_workers_ ? max_in_flight_ + 3 : kJobs);
+    // A staging set is tied up from begin_picture until the GPU is through with the picture.  The GPU needs ~2 ms per
+    // dependent picture and interval, the workers deliver a picture every ~0.15 ms: only with the pictures of many
+    // intervals queued do the lanes' batches fill (HWANG_PIPE_DEPTH overrides the queue depth).
+    int depth = kPipeDepth;
+    if (const char* e = getenv("HWANG_PIPE_DEPTH")) depth = std::max(4, std::min(atoi(e), 1024));
+    jobs_.resize(num_workers_ ? max_in_flight_ + depth : kJobs);
     bounce_.resize(num_workers_ ? kPipeBounce : kBounce);
     return true;
   }
@@ -255,29 +262,54 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // the motion buffer of this surface may still be the source of an upload
     if (motion.seq) {
       StallTimer st{counters_, std::chrono::steady_clock::now()};
-      ++dbg_motion_waits_;
+      const auto w0 = std::chrono::steady_clock::now();
       if (!wait_stamp(motion, error)) return false;
+      if (std::chrono::steady_clock::now() - w0 > std::chrono::microseconds(50)) ++dbg_motion_waits_;
     }
     // work of another lane that still touches the surface (this lane's own is ordered by the lane)
     if (busy.seq && lanes_[busy.lane] != lane) {
       StallTimer st{counters_, std::chrono::steady_clock::now()};
+      const auto w0 = std::chrono::steady_clock::now();
       if (!wait_stamp(busy, error)) return false;
+      if (std::chrono::steady_clock::now() - w0 > std::chrono::microseconds(50)) ++dbg_busy_waits_;
     }
     {
       std::lock_guard<std::mutex> lk(out_mu_);
       surf_[slot].motion = Stamp();
       surf_[slot].submitted = surf_[slot].abandoned = false;
     }
-    // a staging job
-    const int ji = job_cursor_;
+    // A staging set: any one the GPU is through with.  (Taking them round robin made the parser wait for the picture
+    // submitted jobs_.size() pictures ago in particular - with intervals spread over lanes that is a picture in the
+    // middle of some lane's chain, and the parser then advanced one picture per batch, in step with that one lane.)
+    int ji = -1;
+    {
+      std::vector<uint64_t> done(lanes_.size());
+      for (size_t i = 0; i < lanes_.size(); ++i) done[i] = exec_->completed(lanes_[i]);
+      int oldest = -1;
+      const int nj = static_cast<int>(jobs_.size());
+      for (int k = 0; k < nj && ji < 0; ++k) {
+        const int i = (job_cursor_ + k) % nj;
+        const Job& cand = jobs_[i];
+        if (cand.in_use.load(std::memory_order_acquire)) continue;
+        if (!cand.stamp.seq || done[cand.stamp.lane] >= cand.stamp.seq) ji = i;
+        else if (oldest < 0 || cand.order < jobs_[oldest].order) oldest = i;
+      }
+      if (ji < 0) ji = oldest;
+    }
+    if (ji < 0) {
+      *error = "AMDVideoDecoder: every staging set is taken by a picture that is still being parsed";
+      return false;
+    }
     Job& j = jobs_[ji];
     if (j.stamp.seq) {
       StallTimer st{counters_, std::chrono::steady_clock::now()};
-      ++dbg_job_waits_;
+      const auto w0 = std::chrono::steady_clock::now();
       if (!wait_stamp(j.stamp, error)) return false;
+      if (std::chrono::steady_clock::now() - w0 > std::chrono::microseconds(50)) ++dbg_job_waits_;
       j.stamp = Stamp();
     }
-    job_cursor_ = (job_cursor_ + 1) % static_cast<int>(jobs_.size());
+    j.in_use.store(true, std::memory_order_release);
+    job_cursor_ = (ji + 1) % static_cast<int>(jobs_.size());
     j.lane = cur_lane_;
     out->cookie = ji;
     out->mb = j.mb_host;
@@ -364,6 +396,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.bytes_mv = d.mv_deferred ? nmb * (sizeof(MbInfo) + 80 + 64) : 0;  // header + differences/refs in, vectors out
     j.stamp = Stamp{lane_index, exec_->submit_picture(lane, sub)};
     note_seq(j.stamp);
+
     {
       std::lock_guard<std::mutex> lk(out_mu_);
       SurfaceSlot& cs = surf_[d.slot];
@@ -371,6 +404,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       cs.busy = j.stamp;   // written by this submission ...
       cs.lane = lane_index;
       cs.order = ++use_order_;
+      j.order = use_order_;
       for (int i = 0; i < d.num_ref_slots; ++i) {  // ... which reads these
         surf_[d.ref_slots[i]].busy = j.stamp;
         surf_[d.ref_slots[i]].order = use_order_;
@@ -393,11 +427,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       submit_conversion(d.slot, lane_index, def.sub, def.bounce);
     }
     out_cv_.notify_all();
+    j.in_use.store(false, std::memory_order_release);
     return true;
   }
 
   // (entropy workers) the picture will never arrive: what was asked of its frame cannot be served
   void abandon_picture(const h264::PicDone& d) override {
+    if (d.cookie >= 0 && d.cookie < static_cast<int>(jobs_.size())) jobs_[d.cookie].in_use.store(false, std::memory_order_release);
     {
       std::lock_guard<std::mutex> lk(out_mu_);
       SurfaceSlot& cs = surf_[d.slot];
@@ -495,7 +531,18 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     int16_t* resid_dev = nullptr;  // k_residual -> k_intra
     void* band_ctl_dev = nullptr;    // k_mv, k_deblock: hand-off between a picture's workgroups
     Stamp stamp;       // submission that still reads the staging buffers
+    uint64_t order = 0;
     int lane = 0;      // lane index the picture in these buffers goes to (begin_picture -> end_picture)
+    std::atomic<bool> in_use{false};  // between begin_picture and end_picture / abandon_picture
+    Job() = default;
+    Job(const Job& o) { *this = o; }
+    Job& operator=(const Job& o) {
+      mb_host = o.mb_host; coef_host = o.coef_host; slice_host = o.slice_host; mb_dev = o.mb_dev; motion_dev = o.motion_dev;
+      pmo_dev = o.pmo_dev; pmx_dev = o.pmx_dev; coef_dev = o.coef_dev; slice_dev = o.slice_dev; db_dev = o.db_dev;
+      resid_dev = o.resid_dev; band_ctl_dev = o.band_ctl_dev; stamp = o.stamp; order = o.order; lane = o.lane;
+      in_use.store(o.in_use.load());
+      return *this;
+    }
   };
   struct Bounce {
     uint8_t* host = nullptr;
@@ -703,9 +750,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   void teardown() {
-    if (getenv("HWANG_EXEC_DEBUG") && (dbg_motion_waits_ || dbg_job_waits_))
-      fprintf(stderr, "[decoder lane %d] motion waits %lld (%.3f s)  job-ring waits %lld (%.3f s)\n", lanes_.empty() ? -1 : lanes_[0],
-              (long long)dbg_motion_waits_, dbg_motion_ns_ / 1e9, (long long)dbg_job_waits_, dbg_job_ns_ / 1e9);
+    if (getenv("HWANG_EXEC_DEBUG"))
+      fprintf(stderr, "[decoder lane %d] samples fed %lld in %.3f s of feed() (%.3f s of it stalled on the GPU: motion waits %lld, "
+                      "job-ring waits %lld, surface waits %lld), workers %d\n", lanes_.empty() ? -1 : lanes_[0],
+              (long long)counters_.samples_fed, (counters_.entropy_ns + counters_.stall_ns) / 1e9, counters_.stall_ns / 1e9,
+              (long long)dbg_motion_waits_, (long long)dbg_job_waits_, (long long)dbg_busy_waits_, num_workers_);
     if (exec_ && exec_->stopped()) {
       // Destroyed after hwang_shutdown() (interpreter exit destroys module-level
       // objects after its atexit handlers): the streams are gone and the HIP
@@ -889,7 +938,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   int mbw_ = 0, mbh_ = 0, y_pitch_ = 0, c_pitch_ = 0, crop_left_ = 0, crop_top_ = 0;
   size_t u_offset_ = 0, v_offset_ = 0, surface_bytes_ = 0, coef_capacity_ = 0, pmx_words_ = 0;
-  int64_t dbg_motion_waits_ = 0, dbg_motion_ns_ = 0, dbg_job_waits_ = 0, dbg_job_ns_ = 0;
+  int64_t dbg_motion_waits_ = 0, dbg_job_waits_ = 0, dbg_busy_waits_ = 0;
   SurfaceSlot surf_[amd::kMaxSurfaces];
   std::vector<Job> jobs_;
   int job_cursor_ = 0;
@@ -906,6 +955,15 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 };
 
 }  // namespace
+
+int amd_device_numa_node(int32_t device_id) {
+  char bus_id[64] = {0};
+  if (hipDeviceGetPCIBusId(bus_id, sizeof(bus_id), device_id) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return numa::node_of_pci_device(bus_id);
+}
 
 // `num_devices` as the reference's software backend reads it (video_decoder_factory.cpp:90-91 ->
 // software_video_decoder.cpp:148: libavcodec's thread_count): how many threads may entropy decode for this decoder.

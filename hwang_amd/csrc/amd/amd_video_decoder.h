@@ -12,4 +12,7 @@ namespace hwang {
 VideoDecoderInterface* make_amd_video_decoder(int32_t device_id,
                                               uint32_t num_devices);
 
+// NUMA node the GPU is attached to (from its PCI address), -1 if unknown.
+int amd_device_numa_node(int32_t device_id);
+
 }  // namespace hwang

@@ -139,7 +139,9 @@ struct Surface {
   uint8_t* v;
 };
 
-constexpr int kMaxSurfaces = 40;
+// (MbMotion::ref_slot is an int8: at most 127.  A serial decoder uses a dozen; one with entropy workers keeps the
+// pictures of many intervals in flight between the host and the GPU, each in a surface of its own.)
+constexpr int kMaxSurfaces = 120;
 
 struct PictureParams {
   int32_t mb_width, mb_height;

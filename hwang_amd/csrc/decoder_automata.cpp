@@ -89,10 +89,12 @@ Result DecoderAutomata::initialize(const std::vector<EncodedData>& encoded_data,
   cv_.wait(lk, [&] { return !feeder_busy_; });
 
   if (dirty_) {
+    // An interval that was cut off (an error, or fewer frames taken than planned) is closed here.  What flush() has
+    // to say about it - a backend reports a picture that failed late at the flush - concerns the request that is
+    // over; the one that starts now configures the backend afresh.
     lk.unlock();
-    Result r = decoder_->flush();
+    (void)decoder_->flush();
     lk.lock();
-    if (!r.ok) return r;
     dirty_ = false;
   }
   drain_locked(lk);
@@ -128,10 +130,18 @@ Result DecoderAutomata::get_frames(uint8_t* buffer, int32_t num_frames) {
   active_ = true;
   cv_.notify_all();
 
+  // Every way out parks the feeder first.  On an error the frames fetched so far may still be on their way into
+  // `buffer` (a device backend copies asynchronously): they land - or are given up - before the caller gets its
+  // buffer back, whatever wait_until_frames_copied() itself has to report.
   auto finish = [&](const Result& r) {
     active_ = false;
     cv_.notify_all();
     cv_.wait(lk, [&] { return !feeder_busy_; });
+    if (!r.ok) {
+      lk.unlock();
+      (void)decoder_->wait_until_frames_copied();
+      lk.lock();
+    }
     return r;
   };
 

@@ -25,7 +25,9 @@ using amd::SliceParams;
 
 namespace {
 
-constexpr int kMaxSps = 32, kMaxPps = 256, kMaxDpb = amd::kMaxSurfaces, kMaxRefs = 32;
+// kMaxDpb: entries of the parser's picture table - references (<= 16), pictures waiting for output (reorder depth
+// <= 16) and void positions of skipped pictures among them
+constexpr int kMaxSps = 32, kMaxPps = 256, kMaxDpb = 40, kMaxRefs = 32;
 
 inline int iclip(int lo, int hi, int v) { return v < lo ? lo : (v > hi ? hi : v); }
 inline int imin(int a, int b) { return a < b ? a : b; }
@@ -2458,20 +2460,40 @@ struct Parser::Impl {
   }
 
   // ----------------------------------------------------------------- NAL
-  int unescape(const uint8_t* src, size_t n) {
-    rbsp.resize(n + 8);
-    size_t o = 0;
+  // Emulation-prevention bytes out, in two steps where that saves work: a slice NAL is unescaped only as far as its
+  // header can reach before the header is parsed, and the rest only if the picture is decoded at all (with a sparse
+  // request two samples out of three are non-reference pictures nobody wants: 20-50 KB each that are never touched).
+  struct {
+    const uint8_t* src = nullptr;
+    size_t n = 0, i = 0, o = 0;
     int zeros = 0;
-    for (size_t i = 0; i < n; ++i) {
-      uint8_t c = src[i];
+  } ue;
+  void unescape_begin(const uint8_t* src, size_t n) {
+    rbsp.resize(n + 8);
+    ue.src = src;
+    ue.n = n;
+    ue.i = ue.o = 0;
+    ue.zeros = 0;
+  }
+  // consumes input up to `upto` bytes; returns the RBSP bytes produced so far (8 zero bytes follow them)
+  int unescape_upto(size_t upto) {
+    const size_t end = std::min(upto, ue.n);
+    size_t o = ue.o;
+    int zeros = ue.zeros;
+    uint8_t* out = rbsp.data();
+    for (size_t i = ue.i; i < end; ++i) {
+      const uint8_t c = ue.src[i];
       if (zeros >= 2 && c == 3) {
         zeros = 0;
         continue;
       }
-      rbsp[o++] = c;
+      out[o++] = c;
       zeros = c == 0 ? zeros + 1 : 0;
     }
-    memset(rbsp.data() + o, 0, 8);
+    ue.i = std::max(ue.i, end);
+    ue.o = o;
+    ue.zeros = zeros;
+    memset(out + o, 0, 8);
     return static_cast<int>(o);
   }
 
@@ -3279,7 +3301,12 @@ struct Parser::Impl {
     if (n < 1) return true;
     const int ref_idc = (nal[0] >> 5) & 3, type = nal[0] & 31;
     if (type != 1 && type != 5 && type != 7 && type != 8) return true;
-    const int rn = unescape(nal + 1, n - 1);
+    // The longest slice header: two reference list modifications of 33 entries, prediction weights of 2 x 32
+    // references, 66 marking operations - about 1.2 KB.
+    constexpr size_t kHeaderReach = 2048;
+    const bool slice = type == 1 || type == 5;
+    unescape_begin(nal + 1, n - 1);
+    int rn = unescape_upto(slice ? kHeaderReach : n - 1);
     Bits b;
     b.buf = rbsp.data();
     b.size_bits = rn * 8;
@@ -3288,6 +3315,10 @@ struct Parser::Impl {
     const int r = parse_slice_header(b, ref_idc, type);
     if (r < 0 || !err->empty()) return false;
     if (r > 0) return true;
+    if (ue.i < ue.n) {  // the slice data
+      rn = unescape_upto(ue.n);
+      b.size_bits = rn * 8;
+    }
     if (workers) {
       pipe_add_slice(b);
       return true;
@@ -3297,6 +3328,13 @@ struct Parser::Impl {
   }
 
   void abort_picture() {
+    if (pic_in_progress && cur && cur->slot >= 0) {  // begin_picture without an end_picture: the sink takes its buffers back
+      PicDone gone;
+      memset(&gone, 0, sizeof(gone));
+      gone.slot = cur->slot;
+      gone.cookie = bufs.cookie;
+      sink->abandon_picture(gone);
+    }
     pic_in_progress = false;
     if (workers) pipe_drop_task();
     if (cur) {

@@ -96,9 +96,10 @@ class PictureSink {
   virtual void output_picture(int slot) = 0;
   // The parser no longer needs the surface as a reference nor for output.
   virtual void release_surface(int slot) = 0;
-  // Entropy workers only: the picture begun with done.slot / done.cookie will
-  // not get an end_picture (its slice data, or an earlier picture's, could not
-  // be decoded).  Whatever was asked of its output position cannot be served.
+  // The picture begun with done.slot / done.cookie (nothing else of `done` is
+  // meaningful) will not get an end_picture: its slice data, or with entropy
+  // workers an earlier picture's, could not be decoded.  Whatever was asked of
+  // its output position cannot be served; its record buffers are free again.
   virtual void abandon_picture(const PicDone& /*done*/) {}
 };
 

@@ -1,5 +1,7 @@
 #include "retriever.h"
 
+#include "util/numa.h"
+
 #include <algorithm>
 #include <chrono>
 #include <pthread.h>
@@ -306,6 +308,10 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
     threads.emplace_back([&, li]() {
       Lane& lane = lanes_[li];
       pthread_setname_np(pthread_self(), "hw-lane");
+      // several GPUs on one host (one process driving them, or one rank per GPU): a lane's thread - and the pinned
+      // staging buffers it is the first to ask for - stay on the socket its GPU hangs off (HWANG_NUMA_AFFINITY=0/1)
+      if (numa::enabled(devices_.size() > 1 || shard_world_ > 1))
+        numa::bind_current_thread_to_node(VideoDecoderFactory::device_numa_node(devices_[lane.device_slot]));
       Result r;
       for (auto& b : lane.backend)
         if (auto* c = dynamic_cast<CountedBackend*>(b.get())) c->reset_counters();

@@ -31,4 +31,8 @@ VideoDecoderInterface* VideoDecoderFactory::make_from_config(
   }
 }
 
+int VideoDecoderFactory::device_numa_node(DeviceHandle device_handle) {
+  return device_handle.type == DeviceType::GPU ? amd_device_numa_node(device_handle.id) : -1;
+}
+
 }  // namespace hwang

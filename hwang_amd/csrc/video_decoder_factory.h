@@ -34,6 +34,9 @@ class VideoDecoderFactory {
                                                  uint32_t num_devices,
                                                  VideoDecoderType type);
 
+  // NUMA node a device's host-side work (lane threads, pinned staging) should run on; -1: no preference.
+  static int device_numa_node(DeviceHandle device_handle);
+
   // Run-time registry behind the C plug-in boundary (registered_backend.cpp).
   static bool register_backend(int decoder_type, const struct hwang_backend_vtable* vtable);
   static std::vector<VideoDecoderType> registered_types();

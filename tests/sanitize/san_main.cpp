@@ -21,6 +21,7 @@
 
 namespace hwang {
 VideoDecoderInterface* make_amd_video_decoder(int32_t, uint32_t) { return nullptr; }
+int amd_device_numa_node(int32_t) { return -1; }
 }
 using namespace hwang;
 extern "C" const hwang_backend_vtable hwang_stamp_vtable;  // tests/fixtures/stamp_backend.c
@@ -173,6 +174,16 @@ static void memory_part(int argc, char** argv) {
       for (uint64_t r = 0; r < idx.frames(); r += 3) rows.push_back(r);
       slice_into_video_intervals(idx, rows, &ok);
       if (!idx.consistent()) continue;
+      {
+        // the same (possibly corrupted) samples through the entropy workers: errors, never out-of-bounds accesses -
+        // pictures behind a failed one still decode against whatever the failed one left behind
+        int64_t out[9];
+        char err[256];
+        for (int workers : {2, 4})
+          (void)hwang_h264_probe_workers(idx.metadata_bytes().data(), idx.metadata_bytes().size(), data.data(),
+                                         idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0,
+                                         workers, out, err, sizeof(err));
+      }
       for (int compact = 0; compact < 2; ++compact) {
         NullSink sink;
         sink.compact = compact != 0;
