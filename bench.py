@@ -46,12 +46,48 @@ sys.path.insert(0, ROOT)
 WIDTH, HEIGHT = 1920, 1080
 UNIQUE_FRAMES = 1200          # encoded once ...
 GOP, BFRAMES = 60, 2
+QP, FPS = 26, 30
 SEED = 20240601
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+CONFIG = "C1"
+
+# BASELINE.json's other single-GPU configurations, selectable with --config for profiles/ (the default line, the one
+# the driver records, is always C1): per configuration the clip and which rows a request asks for.
+CONFIGS = {
+    "C1": dict(width=1920, height=1080, unique=1200, frames=108000, qp=26, fps=30, rows="1pct",
+               what="single 1080p30 High-profile CABAC mp4, 1 % uniform-random sample"),
+    "C2": dict(width=3840, height=2160, unique=240, frames=3600, qp=26, fps=30, rows="stride10",
+               what="single 4K30 High-profile CABAC mp4, every 10th frame"),
+    "C4": dict(width=3840, height=2160, unique=120, frames=1200, qp=18, fps=60, rows="dense",
+               what="one of the 4K60 CABAC high-bitrate (QP 18) streams, every frame"),
+}
+
+
+def select_config(name, frames=None):
+    global WIDTH, HEIGHT, UNIQUE_FRAMES, QP, FPS, CONFIG, _S, SPAN_KERNELS
+    c = CONFIGS[name]
+    CONFIG = name
+    WIDTH, HEIGHT, UNIQUE_FRAMES, QP, FPS = c["width"], c["height"], c["unique"], c["qp"], c["fps"]
+    mbs = ((WIDTH + 15) // 16) * ((HEIGHT + 15) // 16)
+    _S = mbs * 384
+    SPAN_KERNELS = {"mv_derivation": (["k_mv"], mbs * 176), "inter_pred": (["k_inter"], 2 * _S),
+                    "intra_pred": (["k_residual", "k_intra"], _S), "deblock": (["k_bs", "k_deblock"], 2 * _S),
+                    "yuv420_to_rgb24": (["convert_batch"], 9 * WIDTH * HEIGHT // 2)}
+    return frames if frames else c["frames"]
+
+
+def request_rows(np, n, k):
+    """Rows of request k over a clip of n frames, as the selected configuration samples them."""
+    mode = CONFIGS[CONFIG]["rows"]
+    if mode == "1pct":
+        return sorted(np.random.default_rng(SEED + k).choice(n, max(1, round(0.01 * n)), replace=False).tolist())
+    if mode == "stride10":
+        return list(range(k % 10, n, 10))
+    return list(range(n))
 
 
 def corpus_path(total_frames):
-    return "/tmp/hwang_bench_c1_%dx%d_%d_gop%d_b%d.mp4" % (WIDTH, HEIGHT, total_frames, GOP, BFRAMES)
+    return "/tmp/hwang_bench_%s_%dx%d_%d_gop%d_b%d_qp%d.mp4" % (CONFIG.lower(), WIDTH, HEIGHT, total_frames, GOP, BFRAMES, QP)
 
 
 def make_corpus(total_frames):
@@ -67,7 +103,7 @@ def make_corpus(total_frames):
     repeat = max(1, total_frames // unique)
     tmp = path + ".tmp.%d" % os.getpid()
     subprocess.check_call([enc, "--width", str(WIDTH), "--height", str(HEIGHT), "--frames", str(unique),
-                           "--gop", str(GOP), "--bframes", str(BFRAMES), "--fps", "30",
+                           "--gop", str(GOP), "--bframes", str(BFRAMES), "--fps", str(FPS), "--qp", str(QP),
                            "--threads", str(min(64, os.cpu_count() or 8)), "--repeat", str(repeat), "--out", tmp],
                           stdout=subprocess.DEVNULL)
     os.replace(tmp, path)
@@ -169,8 +205,8 @@ def cpu_baseline(path, index, rows, workers, max_gops=64, repeats=3):
 # Kernels inside each HIP-event span, and the span's algorithmic bytes per
 # 1080p picture (S = 1.5 * 1920 * 1088).
 _S = 1920 * 1088 * 3 // 2
-SPAN_KERNELS = {"mv_derivation": (["k_mv"], 8160 * 176), "inter_pred": (["k_inter"], 2 * _S), "intra_pred": (["k_residual", "k_intra"], _S),
-                "deblock": (["k_bs", "k_deblock"], 2 * _S), "yuv420_to_rgb24": (["convert_batch"], 9 * WIDTH * HEIGHT // 2)}
+SPAN_KERNELS = {}
+select_config("C1")
 
 
 def pmc_traffic_per_launch(span, alg_bytes_per_launch):
@@ -179,8 +215,8 @@ def pmc_traffic_per_launch(span, alg_bytes_per_launch):
     tools/pmc_summary.py), scaled to this run's pictures per launch.  None if
     no PMC summary has been committed."""
     path = os.path.join(ROOT, "profiles", "pmc_summary.json")
-    if span not in SPAN_KERNELS or not os.path.exists(path):
-        return None
+    if span not in SPAN_KERNELS or not os.path.exists(path) or CONFIG != "C1":
+        return None   # (the committed PMC passes are of the C1 run: bytes per 1080p picture)
     pmc = json.load(open(path))
     kernels, alg_per_picture = SPAN_KERNELS[span]
     per_picture = 0
@@ -211,8 +247,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=int(os.environ.get("HWANG_BENCH_FRAMES", 108000)),
-                    help="clip length; the headline configuration is 108000 (1 h of 1080p30)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C1",
+                    help="BASELINE.json configuration; C1 is the headline (and the default); C2 / C4 are for profiles/")
+    ap.add_argument("--frames", type=int, default=int(os.environ.get("HWANG_BENCH_FRAMES", 0)),
+                    help="clip length; default: the configuration's (C1: 108000 = 1 h of 1080p30)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("HWANG_BENCH_LANES", 0)))
     ap.add_argument("--cpu-workers", type=int, default=int(os.environ.get("HWANG_BENCH_CPU_WORKERS", 16)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -222,6 +260,7 @@ def main():
     ap.add_argument("--reference-api-threads", type=int, default=int(os.environ.get("HWANG_BENCH_REF_THREADS", 0)),
                     help="num_devices handed to the reference API's DecoderAutomata (default: the usable CPUs)")
     args = ap.parse_args()
+    args.frames = select_config(args.config, args.frames)
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -253,13 +292,12 @@ def main():
     # SEED + k (N = 1: exactly configuration C1).  All requests' GOP segments are pooled and fanned out
     # over the GPUs; per-GPU work is fixed as N grows ("weak").
     nreq = args.gpus
-    row_sets = [sorted(np.random.default_rng(SEED + k).choice(n, max(1, round(0.01 * n)), replace=False).tolist())
-                for k in range(nreq)]
+    row_sets = [request_rows(np, n, k) for k in range(nreq)]
 
     # CPU baseline first (rank 0, N = 1 only): spawns processes, so it runs
     # before this process touches the GPU.
     cpu = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline and args.config == "C1":
         cpu = cpu_baseline(path, index, row_sets[0], max(1, min(args.cpu_workers, effective_cpus())))
 
     import torch
@@ -337,6 +375,27 @@ def main():
         total_rows, total_pics = stats["frames_returned"], stats["pictures_reconstructed"]
         per_gpu = [dict(d, host_cpus_busy=round(host_cpus_busy, 2)) for d in dev_stats] if len(devices) > 1 else None
     assert total_rows == sum(len(r) for r in row_sets), "every row of every request must have been returned"
+    host_cpus_total = round(sum(g["host_cpus_busy"] for g in per_gpu), 2) if (per_gpu and world > 1) else round(host_cpus_busy, 2)
+
+    # Strong scaling beside the weak line (N > 1): ONE request - request 0, north_star's C1 - whose GOP work items
+    # all N devices share (one process per GPU: the deterministic split; one process: the common queue).
+    strong = None
+    if args.gpus > 1:
+        one = [requests[0]]
+        br.retrieve_into(one)
+        fence()
+        ts = time.perf_counter()
+        for _ in range(args.steps):
+            br.retrieve_into(one)
+        fence()
+        s_elapsed = time.perf_counter() - ts
+        if world > 1:
+            t = torch.tensor([s_elapsed], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            s_elapsed = float(t.item())
+        strong = {"scaling": "strong", "value": round(len(row_sets[0]) * args.steps / s_elapsed, 2), "unit": "frames/s",
+                  "ms_per_step": round(1000.0 * s_elapsed / args.steps, 2),
+                  "work": "ONE request of %d rows, its GOP work items divided over %d GPUs" % (len(row_sets[0]), args.gpus)}
 
     # roofline pass: one more step with the per-kernel HIP-event spans enabled
     roofline = None
@@ -380,7 +439,7 @@ def main():
                         "end_to_end_bytes_per_step": round(e2e_bytes)}
         # D2H-inclusive rate (SURVEY 8d timing rules): the same request into pinned host memory.  Reported
         # beside `value`, never as `value`.
-        if args.gpus == 1 and not args.no_host_output:
+        if args.gpus == 1 and not args.no_host_output and args.config == "C1":
             host_out = torch.empty((len(row_sets[0]), HEIGHT, WIDTH, 3), dtype=torch.uint8).pin_memory()
             hreq = [(index, fobj, row_sets[0], host_out.data_ptr(), host_out.numel())]
             br.retrieve_into(hreq)
@@ -396,7 +455,7 @@ def main():
         # software backend reads it, software_video_decoder.cpp:148).  Frames come back as numpy arrays in host
         # memory, as the reference returns them.  The request goes in four calls so that the 6.7 GB of returned
         # arrays never exist at once.
-        if args.gpus == 1 and not args.no_reference_api:
+        if args.gpus == 1 and not args.no_reference_api and args.config == "C1":
             import hwang
             t_ref = args.reference_api_threads or effective_cpus()
             ridx = hwang.VideoIndex.deserialize(index.serialize())
@@ -438,12 +497,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "C1: single 1080p30 High-profile CABAC mp4, %d frames (%d unique x %d repeats of closed "
-                                   "GOPs), GOP %d, %d B-frames; one batched call of %d request(s), each a 1%% "
-                                   "uniform-random sample (%d rows, seeds %d..%d), GOP segments pooled and fanned "
+            "config": {"workload": "%s: %s; %dx%d, %d frames (%d unique x %d repeats of closed GOPs), GOP %d, %d B-frames, QP %d; "
+                                   "one batched call of %d request(s) (%d rows each%s), GOP segments pooled and fanned "
                                    "out over %d GPU(s); frames returned as RGB24 in HBM"
-                                   % (n, unique, max(1, n // unique), GOP, BFRAMES, nreq, len(row_sets[0]), SEED,
-                                      SEED + nreq - 1, args.gpus),
+                                   % (CONFIG, CONFIGS[CONFIG]["what"], WIDTH, HEIGHT, n, unique, max(1, n // unique), GOP,
+                                      BFRAMES, QP, nreq, len(row_sets[0]),
+                                      ", seeds %d..%d" % (SEED, SEED + nreq - 1) if CONFIGS[CONFIG]["rows"] == "1pct" else "",
+                                      args.gpus),
                        "launch": ("one process, %d devices" % len(devices) if in_process_devices > 1 else
                                   "%d rank(s), one GPU each" % world if not oversubscribed else
                                   "%d ranks sharing %d GPU(s) (development run: gloo, not a scaling number)"
@@ -455,6 +515,8 @@ def main():
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
             "samples_fed_per_s_rank0": round(stats["samples_fed"] / (elapsed / args.steps), 1),
             "host_cpus_busy_rank0": round(host_cpus_busy, 2),
+            "host_cpus_total": host_cpus_total,
+            "strong_scaling": strong,
             "host_cpu_ms_per_picture": round(1000.0 * host_cpus_busy * (elapsed / args.steps) /
                                              max(1, stats["pictures_reconstructed"]), 3),
             "upload_MB_per_picture": round(stats["bytes_uploaded"] / 1e6 / max(1, stats["pictures_reconstructed"]), 3),

@@ -126,7 +126,7 @@ PROTOTYPES = {
     "hwang_k_yuv420_to_rgb24": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "hwang_h264_probe": (C.c_int, [vp, C.c_size_t, vp, u64p, u64p, C.c_size_t, u64p, C.c_size_t,
                                    i64p, C.c_char_p, C.c_size_t]),
-    "hwang_h264_probe_workers": (C.c_int, [vp, C.c_size_t, vp, u64p, u64p, C.c_size_t, u64p, C.c_size_t, C.c_int,
+    "hwang_h264_probe_workers": (C.c_int, [vp, C.c_size_t, vp, u64p, u64p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, C.c_int,
                                            i64p, C.c_char_p, C.c_size_t]),
     # profiling
     "hwang_prof_enable": (None, [C.c_int]),

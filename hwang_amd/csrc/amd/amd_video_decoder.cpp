@@ -126,14 +126,19 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     if (!pending_wanted_.empty()) {
       parser_->set_wanted(pending_wanted_);
+      if (!pending_keyframes_.empty()) parser_->set_keyframes(pending_keyframes_);
     }
     return Result();
   }
 
-  Result feed(const uint8_t* encoded_buffer, size_t encoded_size, bool /*keyframe*/) override {
+  Result feed(const uint8_t* encoded_buffer, size_t encoded_size, bool keyframe) override {
     if (encoded_size == 0) return Result();  // end-of-interval marker; flush() follows
     if (!parser_) return Result(false, "AMDVideoDecoder::feed before configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
+    // A sync sample starts a closed GOP: nothing behind it refers to anything before it, so its pictures may go to
+    // another executor lane and run beside the previous GOP's (an interval is often several byte-adjacent GOPs: on
+    // one lane that is a chain of 40-60 dependent pictures at ~2 ms each).
+    if (keyframe) cur_lane_ = (cur_lane_ + 1) % static_cast<int>(lanes_.size());
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t stall0 = counters_.stall_ns;
     const bool ok = parser_->decode(encoded_buffer, encoded_size);
@@ -151,7 +156,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (!parser_->flush()) return Result(false, "AMDVideoDecoder::flush: " + parser_->error());
     HWANG_RETURN_ON_ERROR(take_sink_error("AMDVideoDecoder::flush: "));
     pending_wanted_.clear();
-    cur_lane_ = (cur_lane_ + 1) % static_cast<int>(lanes_.size());  // the next interval is independent of this one
+    pending_keyframes_.clear();
     return Result();
   }
 
@@ -191,6 +196,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   void set_wanted_frames(const std::vector<uint64_t>& ordinals) override {
     pending_wanted_ = ordinals;
     if (parser_) parser_->set_wanted(ordinals);
+  }
+  void set_interval_keyframes(const std::vector<uint64_t>& ordinals) override {
+    pending_keyframes_ = ordinals;
+    if (parser_) parser_->set_keyframes(ordinals);
   }
   BackendCounters counters() override {
     BackendCounters c = counters_;
@@ -237,7 +246,27 @@ class AMDVideoDecoder : public VideoDecoderInterface,
           oldest = i;
         }
       }
-      if (slot < 0) slot = (fresh >= 0 && (allocated < soft_surfaces() || oldest < 0)) ? fresh : oldest;
+      if (slot < 0) {
+        slot = (fresh >= 0 && (allocated < soft_surfaces() || oldest < 0)) ? fresh : oldest;
+        if (slot >= 0 && slot == oldest) {  // (debug statistics: what the surfaces were doing when none was ready)
+          ++dbg_none_ready_;
+          for (size_t i = 0; i < lanes_.size(); ++i) {
+            const uint64_t pend = last_seq_[i].load() - done[i];
+            dbg_pending_total_ += pend;
+            if (pend) ++dbg_pending_lanes_;
+          }
+          for (int i = 0; i < amd::kMaxSurfaces; ++i) {
+            if (surf_[i].dev && !surf_[i].held) {
+              if (!settled(surf_[i].motion)) ++dbg_unsettled_motion_;
+              if (!settled(surf_[i].busy)) ++dbg_unsettled_busy_;
+            }
+            if (!surf_[i].dev) continue;
+            if (surf_[i].held & kHeldByParser) ++dbg_held_parser_;
+            else if (surf_[i].held & kHeldByOutput) ++dbg_held_output_;
+            else ++dbg_free_busy_;
+          }
+        }
+      }
       if (slot >= 0) surf_[slot].held = kHeldByParser;
     }
     if (slot < 0) {
@@ -755,6 +784,16 @@ class AMDVideoDecoder : public VideoDecoderInterface,
                       "job-ring waits %lld, surface waits %lld), workers %d\n", lanes_.empty() ? -1 : lanes_[0],
               (long long)counters_.samples_fed, (counters_.entropy_ns + counters_.stall_ns) / 1e9, counters_.stall_ns / 1e9,
               (long long)dbg_motion_waits_, (long long)dbg_job_waits_, (long long)dbg_busy_waits_, num_workers_);
+    if (getenv("HWANG_EXEC_DEBUG") && dbg_none_ready_)
+      fprintf(stderr, "[decoder lane %d] no surface ready %lld times; then on average %.1f held by the parser, %.1f by the "
+                      "output queue, %.1f free but still in use on the GPU\n", lanes_.empty() ? -1 : lanes_[0],
+              (long long)dbg_none_ready_, 1.0 * dbg_held_parser_ / dbg_none_ready_, 1.0 * dbg_held_output_ / dbg_none_ready_,
+              1.0 * dbg_free_busy_ / dbg_none_ready_);
+    if (getenv("HWANG_EXEC_DEBUG") && dbg_none_ready_)
+      fprintf(stderr, "[decoder lane %d] ... of the free ones %.1f with a pending upload, %.1f with pending GPU work; %.1f lanes "
+                      "with %.1f submissions pending in all\n", lanes_.empty() ? -1 : lanes_[0],
+              1.0 * dbg_unsettled_motion_ / dbg_none_ready_, 1.0 * dbg_unsettled_busy_ / dbg_none_ready_,
+              1.0 * dbg_pending_lanes_ / dbg_none_ready_, 1.0 * dbg_pending_total_ / dbg_none_ready_);
     if (exec_ && exec_->stopped()) {
       // Destroyed after hwang_shutdown() (interpreter exit destroys module-level
       // objects after its atexit handlers): the streams are gone and the HIP
@@ -934,11 +973,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   FrameInfo info_{};
   std::unique_ptr<h264::Parser> parser_;
   std::string sink_error_;
-  std::vector<uint64_t> pending_wanted_;
+  std::vector<uint64_t> pending_wanted_, pending_keyframes_;
 
   int mbw_ = 0, mbh_ = 0, y_pitch_ = 0, c_pitch_ = 0, crop_left_ = 0, crop_top_ = 0;
   size_t u_offset_ = 0, v_offset_ = 0, surface_bytes_ = 0, coef_capacity_ = 0, pmx_words_ = 0;
   int64_t dbg_motion_waits_ = 0, dbg_job_waits_ = 0, dbg_busy_waits_ = 0;
+  int64_t dbg_none_ready_ = 0, dbg_held_parser_ = 0, dbg_held_output_ = 0, dbg_free_busy_ = 0;
+  int64_t dbg_unsettled_motion_ = 0, dbg_unsettled_busy_ = 0, dbg_pending_lanes_ = 0, dbg_pending_total_ = 0;
   SurfaceSlot surf_[amd::kMaxSurfaces];
   std::vector<Job> jobs_;
   int job_cursor_ = 0;

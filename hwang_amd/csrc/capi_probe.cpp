@@ -141,7 +141,8 @@ struct ProbeSink : public h264::PictureSink {
 
 static int run_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data, const uint64_t* sample_offsets,
                      const uint64_t* sample_sizes, size_t num_samples, const uint64_t* wanted, size_t num_wanted,
-                     int workers, int64_t* out, int nout, char* error, size_t error_capacity) {
+                     const uint64_t* keyframes, size_t num_keyframes, int workers, int64_t* out, int nout, char* error,
+                     size_t error_capacity) {
   ProbeSink sink;
   std::unique_ptr<h264::WorkerPool> pool;
   const int in_flight = workers > 0 ? 2 * workers : 0;
@@ -160,6 +161,7 @@ static int run_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
   };
   if (!parser.configure(avcc, avcc_size)) return report(parser.error());
   if (num_wanted) parser.set_wanted(std::vector<uint64_t>(wanted, wanted + num_wanted));
+  if (num_keyframes) parser.set_keyframes(std::vector<uint64_t>(keyframes, keyframes + num_keyframes));
   for (size_t i = 0; i < num_samples; ++i)
     if (!parser.decode(data + sample_offsets[i], sample_sizes[i])) return report(parser.error());
   if (!parser.flush()) return report(parser.error());
@@ -185,14 +187,15 @@ extern "C" int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uin
                                 const uint64_t* sample_offsets, const uint64_t* sample_sizes,
                                 size_t num_samples, const uint64_t* wanted, size_t num_wanted,
                                 int64_t out[8], char* error, size_t error_capacity) {
-  return run_probe(avcc, avcc_size, data, sample_offsets, sample_sizes, num_samples, wanted, num_wanted, 0, out, 8,
-                   error, error_capacity);
+  return run_probe(avcc, avcc_size, data, sample_offsets, sample_sizes, num_samples, wanted, num_wanted, nullptr, 0, 0, out,
+                   8, error, error_capacity);
 }
 
 extern "C" int hwang_h264_probe_workers(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
                                         const uint64_t* sample_offsets, const uint64_t* sample_sizes,
                                         size_t num_samples, const uint64_t* wanted, size_t num_wanted,
-                                        int workers, int64_t out[9], char* error, size_t error_capacity) {
-  return run_probe(avcc, avcc_size, data, sample_offsets, sample_sizes, num_samples, wanted, num_wanted, workers, out, 9,
-                   error, error_capacity);
+                                        const uint64_t* keyframes, size_t num_keyframes, int workers, int64_t out[9],
+                                        char* error, size_t error_capacity) {
+  return run_probe(avcc, avcc_size, data, sample_offsets, sample_sizes, num_samples, wanted, num_wanted, keyframes,
+                   num_keyframes, workers, out, 9, error, error_capacity);
 }

@@ -286,6 +286,10 @@ void DecoderAutomata::feeder() {
         for (uint64_t f : seg.valid_frames)
           if (f >= first_frame) ordinals.push_back(f - first_frame);
         hints->set_wanted_frames(ordinals);
+        std::vector<uint64_t> syncs;  // seg.keyframes: the interval's sync samples, then its end
+        for (uint64_t k : seg.keyframes)
+          if (k >= first_frame && k < seg.end_keyframe) syncs.push_back(k - first_frame);
+        hints->set_interval_keyframes(syncs);
       }
     }
     Result r = decoder_->feed(ptr, static_cast<size_t>(size), keyframe);

@@ -2288,6 +2288,7 @@ struct Parser::Impl {
 
   // sparse decoding
   std::vector<uint64_t> wanted;
+  std::vector<uint64_t> keyframes;  // decoding-order ordinals of the interval's sync samples (optional)
   uint64_t outputs_emitted = 0;  // since last flush/configure
   uint64_t pictures_started = 0; // since last flush/configure: the decoding-order ordinal of the next picture
 
@@ -3082,7 +3083,22 @@ struct Parser::Impl {
     // work at all.  (The reference's DecoderAutomata feeds every sample of an interval, decoder_automata.cpp:287-331;
     // this is where that stops costing anything.)
     const uint64_t ordinal = pictures_started++;
-    if (!wanted.empty() && ordinal > wanted.back() + static_cast<uint64_t>(reorder_depth())) {
+    bool useless = false;
+    if (!wanted.empty()) {
+      // the same inside an interval of several GOPs when the caller has said where the sync samples are: what lies
+      // between a GOP's last wanted position (+ reorder depth) and the next sync sample serves nobody - the GOPs
+      // are closed, which is what starting an interval at a sync sample assumes in the first place
+      uint64_t g0 = 0, g1 = UINT64_MAX;
+      if (!keyframes.empty()) {
+        auto it = std::upper_bound(keyframes.begin(), keyframes.end(), ordinal);
+        if (it != keyframes.end()) g1 = *it;
+        if (it != keyframes.begin()) g0 = *(it - 1);
+      }
+      auto hi = std::lower_bound(wanted.begin(), wanted.end(), g1);
+      const bool any = hi != wanted.begin() && *(hi - 1) >= g0;
+      useless = !any || ordinal > *(hi - 1) + static_cast<uint64_t>(reorder_depth());
+    }
+    if (useless) {
       cur = nullptr;
       output_all();
       for (Pic& p : dpb) p.ref = 0;
@@ -3459,6 +3475,7 @@ bool Parser::flush() {
   d.outputs_emitted = 0;
   d.pictures_started = 0;
   d.wanted.clear();
+  d.keyframes.clear();
   return error_.empty();
 }
 
@@ -3471,6 +3488,11 @@ bool Parser::wait_idle(std::string* error) {
   if (failed && error) *error = d.pipe_error;
   d.pipe_unreported = false;
   return !failed;
+}
+
+void Parser::set_keyframes(const std::vector<uint64_t>& ordinals) {
+  impl_->keyframes = ordinals;
+  std::sort(impl_->keyframes.begin(), impl_->keyframes.end());
 }
 
 void Parser::set_wanted(const std::vector<uint64_t>& ordinals) {

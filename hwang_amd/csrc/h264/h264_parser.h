@@ -149,6 +149,9 @@ class Parser {
   // picture after the last flush/configure, that will be fetched.  Unwanted
   // non-reference pictures are not entropy decoded at all.  Empty = all.
   void set_wanted(const std::vector<uint64_t>& ordinals);
+  // With set_wanted: which samples of the interval (0-based, decoding order) are sync samples, i.e. start closed
+  // GOPs.  Lets an interval of several GOPs end each GOP behind its last wanted position instead of only the last.
+  void set_keyframes(const std::vector<uint64_t>& ordinals);
 
   const std::string& error() const { return error_; }
   int width() const;    // cropped

@@ -20,6 +20,11 @@ class SparseDecodeHints {
   // `ordinals` are 0-based output positions counted from the interval's
   // first sample, sorted ascending.  Valid until the next flush().
   virtual void set_wanted_frames(const std::vector<uint64_t>& ordinals) = 0;
+  // Optional companion: which samples of the interval (same numbering) are
+  // sync samples.  An interval may span several GOPs (the planner merges
+  // byte-adjacent ones); with this a backend can stop each GOP behind its last
+  // wanted frame instead of only the interval.  Valid until the next flush().
+  virtual void set_interval_keyframes(const std::vector<uint64_t>& /*ordinals*/) {}
 };
 
 }  // namespace hwang

@@ -290,10 +290,12 @@ int hwang_h264_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
  * backend's `num_devices` > 1, software_video_decoder.cpp:148's thread count).  out[0..7] as above except that
  * surfaces are numbered round robin (which surface a picture gets may then depend on when a worker let go of one, so
  * out[7] is not comparable between runs); out[8] = the digest with the surface numbers blanked, which is the same
- * for every worker count including 0. */
+ * for every worker count including 0.  `keyframes` (optional, with `wanted`): ordinals of the sync samples among the
+ * samples given - each GOP then ends behind its own last wanted position (SparseDecodeHints::set_interval_keyframes). */
 int hwang_h264_probe_workers(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
                              const uint64_t* sample_offsets, const uint64_t* sample_sizes,
                              size_t num_samples, const uint64_t* wanted, size_t num_wanted,
+                             const uint64_t* keyframes, size_t num_keyframes,
                              int workers, int64_t out[9], char* error, size_t error_capacity);
 
 /* -- Profiling hooks ---------------------------------------------------------

@@ -181,7 +181,7 @@ static void memory_part(int argc, char** argv) {
         char err[256];
         for (int workers : {2, 4})
           (void)hwang_h264_probe_workers(idx.metadata_bytes().data(), idx.metadata_bytes().size(), data.data(),
-                                         idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0,
+                                         idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0, nullptr, 0,
                                          workers, out, err, sizeof(err));
       }
       for (int compact = 0; compact < 2; ++compact) {
@@ -251,12 +251,12 @@ static void workers_part(int argc, char** argv) {
     int64_t serial[9] = {0}, piped[9] = {0};
     char err[256] = {0};
     CHECK(hwang_h264_probe_workers(idx.metadata_bytes().data(), idx.metadata_bytes().size(), data.data(),
-                                   idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0, 0,
+                                   idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0, nullptr, 0, 0,
                                    serial, err, sizeof(err)) == 0);
     for (int workers : {1, 2, 5}) {
       for (int rep = 0; rep < 3; ++rep) {
         CHECK(hwang_h264_probe_workers(idx.metadata_bytes().data(), idx.metadata_bytes().size(), data.data(),
-                                       idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0,
+                                       idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0, nullptr, 0,
                                        workers, piped, err, sizeof(err)) == 0);
         for (int k : {0, 1, 2, 4, 6, 8}) CHECK(piped[k] == serial[k]);
       }

@@ -41,7 +41,7 @@ def probe(hw, path, wanted=None):
     return idx, dict(zip(keys, list(out)))
 
 
-def probe_workers(hw, path, workers, wanted=None):
+def probe_workers(hw, path, workers, wanted=None, keyframes=None):
     """The same through hwang_h264_probe_workers: slice data decoded by `workers` entropy threads (0: serial)."""
     from hwang_amd._capi import lib
     idx = hw.index_video(path)
@@ -52,10 +52,12 @@ def probe_workers(hw, path, workers, wanted=None):
     out = (C.c_int64 * 9)()
     err = C.create_string_buffer(256)
     w = np.asarray(wanted if wanted is not None else [], dtype=np.uint64)
+    kf = np.asarray(keyframes if keyframes is not None else [], dtype=np.uint64)
     rc = lib.hwang_h264_probe_workers(avcc, len(avcc), data.ctypes.data_as(C.POINTER(C.c_uint8)),
                                       offs.ctypes.data_as(C.POINTER(C.c_uint64)),
                                       sizes.ctypes.data_as(C.POINTER(C.c_uint64)), idx.frames(),
-                                      w.ctypes.data_as(C.POINTER(C.c_uint64)) if len(w) else None, len(w), workers,
+                                      w.ctypes.data_as(C.POINTER(C.c_uint64)) if len(w) else None, len(w),
+                                      kf.ctypes.data_as(C.POINTER(C.c_uint64)) if len(kf) else None, len(kf), workers,
                                       out, err, 256)
     assert rc == 0, err.value
     keys = ("slices", "clean_end", "pictures", "skipped", "outputs", "outputs_skipped", "coefficients", "digest",
@@ -137,6 +139,18 @@ def test_sparse_hint_ends_the_interval_early(hw, tmp_path):
     # the first frame only: the IDR picture, and (reorder depth 1) the P picture behind it
     _, r0 = probe(hw, path, wanted=[0])
     assert r0["pictures"] == 2 and r0["outputs"] == 40
+    # an interval of three GOPs (the planner merges byte-adjacent GOPs): with the sync samples known every GOP ends
+    # behind its own last wanted position, and a GOP nobody wants anything of is not touched at all
+    path3 = str(tmp_path / "tail3.mp4")
+    make_clip(path3, yuv=False, frames=36, gop=12, bframes=2, cabac=1, refs=2)
+    for workers in (0, 3):
+        whole = probe_workers(hw, path3, workers, wanted=[4, 27])
+        cut = probe_workers(hw, path3, workers, wanted=[4, 27], keyframes=[0, 12, 24])
+        assert whole["outputs"] == cut["outputs"] == 36
+        # without: every reference picture up to decoding position 27 + 1, and B4
+        assert whole["pictures"] == 14
+        # with: I0 P3 P6 B4 | nothing of the second GOP | I24 P27 and (decoding position 28 = 27 + the reorder depth) P30
+        assert cut["pictures"] == 7
 
 
 def test_sparse_hint_keeps_reference_b_pictures(hw, tmp_path):
