@@ -26,7 +26,7 @@ from ._python import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData, Vi
 
 class Decoder(object):
     def __init__(self, f_or_path, video_index=None, device_type=DeviceType.CPU, device_id=0, decoder_type=None,
-                 num_devices=1, interval_group_bytes=64 << 20):
+                 num_devices=1, interval_group_bytes=256 << 20):
         self.video_index = video_index if video_index is not None else hwang.index_video(f_or_path)
         self.f = open(f_or_path, "rb") if isinstance(f_or_path, str) else f_or_path
         handle = DeviceHandle()

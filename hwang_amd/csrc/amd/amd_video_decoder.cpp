@@ -56,7 +56,7 @@ using amd::SliceParams;
 
 constexpr int kJobs = 4;        // staging ring depth (serial entropy decoding; with workers: pictures in flight + 3)
 constexpr int kPipeLanes = 16;  // executor lanes a decoder with entropy workers rotates through, one per interval
-constexpr int kPipeDepth = 96;  // ... and how many pictures may be queued between its workers and the GPU
+constexpr int kPipeDepth = 128;  // ... and how many pictures may be queued between its workers and the GPU
 constexpr int kMaxSlices = 256;
 constexpr int kBounce = 4;      // pinned output bounce buffers (serial entropy decoding)
 constexpr int kPipeBounce = 24; // ... with entropy workers: frames are fetched before their pictures reach the GPU
@@ -239,7 +239,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         if (surf_[i].held) continue;
         if (!surf_[i].dev) {
           if (fresh < 0) fresh = i;
-        } else if (settled(surf_[i].motion) && (settled(surf_[i].busy) || lanes_[surf_[i].busy.lane] == lane)) {
+        } else if (settled(surf_[i].motion[next_set(surf_[i])]) && (settled(surf_[i].busy) || lanes_[surf_[i].busy.lane] == lane)) {
           slot = i;
           break;
         } else if (oldest < 0 || surf_[i].order < surf_[oldest].order) {
@@ -257,7 +257,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
           }
           for (int i = 0; i < amd::kMaxSurfaces; ++i) {
             if (surf_[i].dev && !surf_[i].held) {
-              if (!settled(surf_[i].motion)) ++dbg_unsettled_motion_;
+              if (!settled(surf_[i].motion[next_set(surf_[i])])) ++dbg_unsettled_motion_;
               if (!settled(surf_[i].busy)) ++dbg_unsettled_busy_;
             }
             if (!surf_[i].dev) continue;
@@ -285,7 +285,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     Stamp motion, busy;
     {
       std::lock_guard<std::mutex> lk(out_mu_);
-      motion = surf_[slot].motion;
+      surf_[slot].flip = next_set(surf_[slot]);
+      motion = surf_[slot].motion[surf_[slot].flip];
       busy = surf_[slot].busy;
     }
     // the motion buffer of this surface may still be the source of an upload
@@ -304,7 +305,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     {
       std::lock_guard<std::mutex> lk(out_mu_);
-      surf_[slot].motion = Stamp();
+      surf_[slot].motion[surf_[slot].flip] = Stamp();
       surf_[slot].submitted = surf_[slot].abandoned = false;
     }
     // A staging set: any one the GPU is through with.  (Taking them round robin made the parser wait for the picture
@@ -342,9 +343,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     j.lane = cur_lane_;
     out->cookie = ji;
     out->mb = j.mb_host;
-    out->motion = surf_[slot].motion_host;
-    out->pmo = surf_[slot].pmo_host;
-    out->pmx = surf_[slot].pmx_host;
+    const int set = surf_[slot].flip;
+    j.motion_set = set;
+    out->motion = surf_[slot].motion_host[set];
+    out->pmo = surf_[slot].pmo_host[set];
+    out->pmx = surf_[slot].pmx_host[set];
     out->pmx_capacity = pmx_words_;
     out->coefs = j.coef_host;
     out->coef_capacity = coef_capacity_;
@@ -377,10 +380,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     add_copy(j.slice_dev, j.slice_host, d.num_slices * sizeof(SliceParams));
     // motion: full 144-byte records only for macroblocks the host derived itself (B slices, pictures too wide
     // for k_mv); everything k_mv derives travels as 12-byte records + the extra differences
-    if (d.has_inter && d.full_motion) add_copy(j.motion_dev, surf_[d.slot].motion_host, nmb * sizeof(MbMotion));
+    const int set = j.motion_set;
+    if (d.has_inter && d.full_motion) add_copy(j.motion_dev, surf_[d.slot].motion_host[set], nmb * sizeof(MbMotion));
     if (d.compact_motion && d.has_inter) {  // (an intra-only picture's records are read by nobody)
-      add_copy(j.pmo_dev, surf_[d.slot].pmo_host, nmb * sizeof(PMotion));
-      add_copy(j.pmx_dev, surf_[d.slot].pmx_host, d.pmx_count * sizeof(uint32_t));
+      add_copy(j.pmo_dev, surf_[d.slot].pmo_host[set], nmb * sizeof(PMotion));
+      add_copy(j.pmx_dev, surf_[d.slot].pmx_host[set], d.pmx_count * sizeof(uint32_t));
     }
     amd::PictureParams& pp = sub.desc.pp;
     pp.mb_width = mbw_;
@@ -429,7 +433,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     {
       std::lock_guard<std::mutex> lk(out_mu_);
       SurfaceSlot& cs = surf_[d.slot];
-      if (d.has_inter || d.compact_motion) cs.motion = j.stamp;  // the surface's pinned buffers are upload sources
+      if (d.has_inter || d.compact_motion) cs.motion[set] = j.stamp;  // the surface's pinned buffers are upload sources
       cs.busy = j.stamp;   // written by this submission ...
       cs.lane = lane_index;
       cs.order = ++use_order_;
@@ -533,10 +537,15 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   };
   struct SurfaceSlot {
     uint8_t* dev = nullptr;
-    MbMotion* motion_host = nullptr;  // pinned; also the co-located source
-    PMotion* pmo_host = nullptr;      // pinned: compact motion records ...
-    uint32_t* pmx_host = nullptr;     // ... and their extra stream (row table + difference words)
-    Stamp motion;                     // submission that still uploads from motion_host
+    // Motion records of the picture in the surface: written by the parser, uploaded from here, and read again by the
+    // parser for co-located lookups as long as the picture is a reference.  Two sets with entropy workers, used in
+    // turn: the set the last picture in this surface wrote may still be waiting for its upload when the surface is
+    // taken again within its GOP (same lane, no wait for the GPU otherwise); the one before that hardly ever is.
+    MbMotion* motion_host[2] = {nullptr, nullptr};  // pinned; also the co-located source
+    PMotion* pmo_host[2] = {nullptr, nullptr};      // pinned: compact motion records ...
+    uint32_t* pmx_host[2] = {nullptr, nullptr};     // ... and their extra stream (row table + difference words)
+    Stamp motion[2];                  // submission that still uploads from the set
+    int flip = 0;                     // set of the picture in the surface now
     Stamp busy;                       // latest submission that writes or reads the surface (its picture, pictures
                                       // predicted from it, conversions of it)
     int lane = 0;                     // lane index of the picture that was reconstructed into it
@@ -546,6 +555,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     bool abandoned = false;           // ... or never will be
     std::deque<Deferred> deferred;    // conversions waiting for that
   };
+  // which motion record set the next picture in the surface takes
+  int next_set(const SurfaceSlot& s) const { return num_workers_ ? s.flip ^ 1 : 0; }
   struct Job {
     MbInfo* mb_host = nullptr;
     uint32_t* coef_host = nullptr;
@@ -562,6 +573,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     Stamp stamp;       // submission that still reads the staging buffers
     uint64_t order = 0;
     int lane = 0;      // lane index the picture in these buffers goes to (begin_picture -> end_picture)
+    int motion_set = 0;  // which of the surface's motion record sets the picture uses
     std::atomic<bool> in_use{false};  // between begin_picture and end_picture / abandon_picture
     Job() = default;
     Job(const Job& o) { *this = o; }
@@ -569,6 +581,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       mb_host = o.mb_host; coef_host = o.coef_host; slice_host = o.slice_host; mb_dev = o.mb_dev; motion_dev = o.motion_dev;
       pmo_dev = o.pmo_dev; pmx_dev = o.pmx_dev; coef_dev = o.coef_dev; slice_dev = o.slice_dev; db_dev = o.db_dev;
       resid_dev = o.resid_dev; band_ctl_dev = o.band_ctl_dev; stamp = o.stamp; order = o.order; lane = o.lane;
+      motion_set = o.motion_set;
       in_use.store(o.in_use.load());
       return *this;
     }
@@ -719,22 +732,27 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
     auto give_up = [&](const char* msg) {
       if (s.dev) (void)hipFree(s.dev);
-      if (s.motion_host) (void)hipHostFree(s.motion_host);
-      if (s.pmo_host) (void)hipHostFree(s.pmo_host);
-      if (s.pmx_host) (void)hipHostFree(s.pmx_host);
+      for (int k = 0; k < 2; ++k) {
+        if (s.motion_host[k]) (void)hipHostFree(s.motion_host[k]);
+        if (s.pmo_host[k]) (void)hipHostFree(s.pmo_host[k]);
+        if (s.pmx_host[k]) (void)hipHostFree(s.pmx_host[k]);
+      }
       std::lock_guard<std::mutex> lk(out_mu_);
       surf_[slot].held = 0;
       *error = msg;
       return false;
     };
     // + 64: k_inter fetches unaligned dwords and may read 3 bytes past a plane's last sample
-    if (hipMalloc(reinterpret_cast<void**>(&s.dev), surface_bytes_ + 64) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s.motion_host), nmb * sizeof(MbMotion), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s.pmo_host), nmb * sizeof(PMotion), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void**>(&s.pmx_host), pmx_words_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+    if (hipMalloc(reinterpret_cast<void**>(&s.dev), surface_bytes_ + 64) != hipSuccess)
       return give_up("AMDVideoDecoder: out of memory for a decode surface");
-    if (!gpu_visible(s.motion_host) || !gpu_visible(s.pmo_host) || !gpu_visible(s.pmx_host))
-      return give_up("AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device");
+    for (int k = 0; k < (num_workers_ ? 2 : 1); ++k) {
+      if (hipHostMalloc(reinterpret_cast<void**>(&s.motion_host[k]), nmb * sizeof(MbMotion), hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc(reinterpret_cast<void**>(&s.pmo_host[k]), nmb * sizeof(PMotion), hipHostMallocDefault) != hipSuccess ||
+          hipHostMalloc(reinterpret_cast<void**>(&s.pmx_host[k]), pmx_words_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+        return give_up("AMDVideoDecoder: out of memory for a decode surface");
+      if (!gpu_visible(s.motion_host[k]) || !gpu_visible(s.pmo_host[k]) || !gpu_visible(s.pmx_host[k]))
+        return give_up("AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device");
+    }
     std::lock_guard<std::mutex> lk(out_mu_);  // (a worker may be copying the surface table in end_picture)
     s.held = surf_[slot].held;
     surf_[slot] = s;
@@ -765,9 +783,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     for (SurfaceSlot& s : surf_) {
       if (s.dev) (void)hipFree(s.dev);
-      if (s.motion_host) (void)hipHostFree(s.motion_host);
-      if (s.pmo_host) (void)hipHostFree(s.pmo_host);
-      if (s.pmx_host) (void)hipHostFree(s.pmx_host);
+      for (int k = 0; k < 2; ++k) {
+        if (s.motion_host[k]) (void)hipHostFree(s.motion_host[k]);
+        if (s.pmo_host[k]) (void)hipHostFree(s.pmo_host[k]);
+        if (s.pmx_host[k]) (void)hipHostFree(s.pmx_host[k]);
+      }
       s = SurfaceSlot();
     }
     for (Bounce& b : bounce_) {

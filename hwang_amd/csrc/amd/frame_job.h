@@ -141,7 +141,7 @@ struct Surface {
 
 // (MbMotion::ref_slot is an int8: at most 127.  A serial decoder uses a dozen; one with entropy workers keeps the
 // pictures of many intervals in flight between the host and the GPU, each in a surface of its own.)
-constexpr int kMaxSurfaces = 120;
+constexpr int kMaxSurfaces = 126;
 
 struct PictureParams {
   int32_t mb_width, mb_height;
