@@ -26,7 +26,7 @@ from ._python import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData, Vi
 
 class Decoder(object):
     def __init__(self, f_or_path, video_index=None, device_type=DeviceType.CPU, device_id=0, decoder_type=None,
-                 num_devices=1, interval_group_bytes=256 << 20):
+                 num_devices=1, interval_group_bytes=128 << 20):
         self.video_index = video_index if video_index is not None else hwang.index_video(f_or_path)
         self.f = open(f_or_path, "rb") if isinstance(f_or_path, str) else f_or_path
         handle = DeviceHandle()
@@ -53,29 +53,66 @@ class Decoder(object):
         segment.valid_frames = wanted
         return segment, end - begin
 
-    def retrieve(self, rows):
+    def _groups(self, rows):
+        """The seek plan as lists of EncodedData, each list up to interval_group_bytes of encoded video (one interval
+        per list with 0): [(segments, frames wanted of them)]."""
         index = self.video_index
         offsets = index.sample_offsets()
         sizes = index.sample_sizes()
         keyframes = index.keyframe_indices()
         end_of_file = offsets[-1] + sizes[-1]
-        frames = []
         group, group_frames, group_bytes = [], 0, 0
-
-        def run_group():
-            self._decoder.initialize(group, index.metadata_bytes())
-            return self._decoder.get_frames(index, group_frames)
-
         for (first, last), wanted in slice_into_video_intervals(index, rows):
-            segment, nbytes = self._segment(index, offsets, sizes, keyframes, end_of_file, first, last, wanted)
             if not wanted:   # (the planner's answer to an empty row list: one interval without frames)
                 continue
+            segment, nbytes = self._segment(index, offsets, sizes, keyframes, end_of_file, first, last, wanted)
             group.append(segment)
             group_frames += len(wanted)
             group_bytes += nbytes
             if group_bytes >= self._group_bytes:
-                frames += run_group()
+                yield group, group_frames
                 group, group_frames, group_bytes = [], 0, 0
         if group:
-            frames += run_group()
+            yield group, group_frames
+
+    def retrieve(self, rows):
+        # The next group is read and packed (file reads, EncodedData) by a helper thread while the current one decodes:
+        # the extension releases the GIL inside initialize / get_frames.
+        import queue
+        import threading
+        extradata = self.video_index.metadata_bytes()
+        ready = queue.Queue(maxsize=1)
+        stop = threading.Event()
+
+        def produce():
+            try:
+                for item in self._groups(rows):
+                    while not stop.is_set():
+                        try:
+                            ready.put(item, timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                    if stop.is_set():
+                        return
+                ready.put(None)
+            except BaseException as e:  # noqa: BLE001  (handed to the caller below)
+                ready.put(e)
+
+        producer = threading.Thread(target=produce, name="hwang-read", daemon=True)
+        producer.start()
+        frames = []
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                group, nframes = item
+                self._decoder.initialize(group, extradata)
+                frames += self._decoder.get_frames(self.video_index, nframes)
+        finally:
+            stop.set()
+            producer.join()
         return frames

@@ -56,7 +56,7 @@ using amd::SliceParams;
 
 constexpr int kJobs = 4;        // staging ring depth (serial entropy decoding; with workers: pictures in flight + 3)
 constexpr int kPipeLanes = 16;  // executor lanes a decoder with entropy workers rotates through, one per interval
-constexpr int kPipeDepth = 128;  // ... and how many pictures may be queued between its workers and the GPU
+constexpr int kPipeDepth = 160;  // ... and how many pictures may be queued between its workers and the GPU
 constexpr int kMaxSlices = 256;
 constexpr int kBounce = 4;      // pinned output bounce buffers (serial entropy decoding)
 constexpr int kPipeBounce = 24; // ... with entropy workers: frames are fetched before their pictures reach the GPU
@@ -83,12 +83,17 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // row kernels need ~2 ms per dependent picture: successive intervals (independent by construction) go to
     // different lanes so that their pictures share batches.
     const int nlanes = num_workers_ ? kPipeLanes : 1;
-    for (int i = 0; i < nlanes; ++i) lanes_.push_back(exec_->register_lane());
+    // (with workers: the lanes are dealt to the executor's light engines in turn, so that the batches of GOPs in
+    // flight overlap on the GPU instead of queueing behind each other)
+    for (int i = 0; i < nlanes; ++i) lanes_.push_back(exec_->register_lane(num_workers_ ? i : 0));
     last_seq_.reset(new std::atomic<uint64_t>[nlanes]);
     for (int i = 0; i < nlanes; ++i) last_seq_[i].store(0);
     if (num_workers_) {
-      // Slice data of at most this many pictures is being decoded at a time; each holds a staging set and a surface.
-      max_in_flight_ = std::min(2 * num_workers_, 24);
+      // At most this many pictures are between the parser thread and the hand-over to the GPU; each holds a staging
+      // set and a surface.  Pictures are handed over in decoding order, so everything behind a slow one (an IDR
+      // picture takes five to ten times as long as a P picture) waits with the workers' results in hand: the window
+      // has to span the GOPs that go by while one IDR picture is parsed, or the parser thread stalls on it.
+      max_in_flight_ = std::min(std::max(4 * num_workers_, 64), 128);
       pool_.reset(new h264::WorkerPool(num_workers_));
     }
     // A staging set is tied up from begin_picture until the GPU is through with the picture.  The GPU needs ~2 ms per
@@ -238,7 +243,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         if (surf_[i].dev) ++allocated;
         if (surf_[i].held) continue;
         if (!surf_[i].dev) {
-          if (fresh < 0) fresh = i;
+          // (a decoder with workers takes new surfaces from the top: its tests then cover surface numbers >= 128)
+          if (fresh < 0 || num_workers_) fresh = i;
         } else if (settled(surf_[i].motion[next_set(surf_[i])]) && (settled(surf_[i].busy) || lanes_[surf_[i].busy.lane] == lane)) {
           slot = i;
           break;

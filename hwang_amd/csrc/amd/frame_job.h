@@ -101,7 +101,7 @@ static_assert(sizeof(MbInfo) == 32, "MbInfo must stay 32 bytes");
 
 struct MbMotion {
   int16_t mv[2][16][2];   // [list][raster 4x4][x, y] quarter samples
-  int8_t ref_slot[2][4];  // DPB surface per 8x8, -1 = list unused
+  int8_t ref_slot[2][4];  // DPB surface per 8x8 as a byte (0 .. kMaxSurfaces - 1), -1 / 0xff = list unused
   int8_t ref_idx[2][4];   // index into the slice's list (for weights)
 };
 static_assert(sizeof(MbMotion) == 144, "MbMotion must stay 144 bytes");
@@ -139,9 +139,10 @@ struct Surface {
   uint8_t* v;
 };
 
-// (MbMotion::ref_slot is an int8: at most 127.  A serial decoder uses a dozen; one with entropy workers keeps the
-// pictures of many intervals in flight between the host and the GPU, each in a surface of its own.)
-constexpr int kMaxSurfaces = 126;
+// (MbMotion::ref_slot is a byte, 0xff = "list not used": surfaces 0 .. 254.  A serial decoder uses a dozen; one with
+// entropy workers keeps the pictures of many GOPs in flight between the host and the GPU, each in a surface of
+// its own - its parser thread is through with a GOP's headers before the first of its pictures has been decoded.)
+constexpr int kMaxSurfaces = 250;
 
 struct PictureParams {
   int32_t mb_width, mb_height;

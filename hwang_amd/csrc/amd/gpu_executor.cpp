@@ -88,7 +88,7 @@ bool GpuExecutor::start(std::string* error) {
   };
   for (int ei = 0; ei < kEngines; ++ei) {
     Engine& en = engines_[ei];
-    if (!make_stream(&en.stream, ei == 0 ? light_mask : heavy_mask)) return fail("cannot create a stream");
+    if (!make_stream(&en.stream, is_light(ei) ? light_mask : heavy_mask)) return fail("cannot create a stream");
     // Uploads go on the engine's compute stream.  A separate copy stream for the
     // light engine (HWANG_COPY_STREAM=1) lets batch N+1's records travel while
     // batch N's kernels run, but the hipEventRecord / hipStreamWaitEvent pair
@@ -181,19 +181,23 @@ void GpuExecutor::stop() {
   if (dbg) fprintf(stderr, "[executor] stop: done\n");
 }
 
-int GpuExecutor::register_lane() {
+int GpuExecutor::register_lane(int light_group) {
+  const int g = light_group % (1 + kExtraLightEngines);
+  const int light_engine = g == 0 ? 0 : kHeavyEngines + g;
   std::lock_guard<std::mutex> lk(mu_);
   for (size_t i = 0; i < lanes_.size(); ++i)
     if (!lanes_[i].active && lanes_[i].fifo.empty() && lanes_[i].completed == lanes_[i].submitted) {
       Lane& l = lanes_[i];
       l.submitted = l.launched = l.completed = 0;
-      l.last_engine = 0;
+      l.last_engine = light_engine;
+      l.light_engine = light_engine;
       l.waiters = 0;
       l.active = true;
       return static_cast<int>(i);
     }
   lanes_.emplace_back();
   lanes_.back().active = true;
+  lanes_.back().light_engine = lanes_.back().last_engine = light_engine;
   return static_cast<int>(lanes_.size() - 1);
 }
 
@@ -211,7 +215,7 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     Item it;
     it.is_picture = true;
     it.pic = job;
-    it.engine = job.heavy ? 1 + lane % heavy_engines_ : 0;
+    it.engine = job.heavy ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
     target = it.engine;
@@ -344,7 +348,7 @@ void GpuExecutor::poll_loop() {
 void GpuExecutor::run(int engine) {
   {
     char name[16];
-    snprintf(name, sizeof(name), engine ? "hw-heavy%d" : "hw-light", engine);
+    snprintf(name, sizeof(name), is_light(engine) ? "hw-light%d" : "hw-heavy%d", engine);
     pthread_setname_np(pthread_self(), name);
   }
   (void)hipSetDevice(device_);
@@ -354,7 +358,7 @@ void GpuExecutor::run(int engine) {
   // picture ready and the next batch is wide.  (Launching whatever is pending
   // right away produced batches of ~5 pictures that each held the GPU for a
   // full pipeline latency.)  See gpu_executor.h for the measured settings.
-  const int max_inflight = engine == 0 ? light_inflight_ : heavy_inflight_;
+  const int max_inflight = is_light(engine) ? light_inflight_ : heavy_inflight_;
 
   std::vector<PicSubmit> pics;
   std::vector<ConvSubmit> convs;
@@ -498,13 +502,13 @@ void GpuExecutor::run(int engine) {
   }
   if (debug) {
     fprintf(stderr, "[executor %s%d] batches %llu pics %llu convs %llu | batch size hist 0:%llu 1:%llu 2:%llu <=4:%llu <=8:%llu <=16:%llu <=32:%llu <=64:%llu >64:%llu\n",
-            engine ? "heavy" : "light", engine, (unsigned long long)n_batches, (unsigned long long)n_pics, (unsigned long long)n_convs,
+            is_light(engine) ? "light" : "heavy", engine, (unsigned long long)n_batches, (unsigned long long)n_pics, (unsigned long long)n_convs,
             (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2],
             (unsigned long long)hist[3], (unsigned long long)hist[4], (unsigned long long)hist[5], (unsigned long long)hist[6],
             (unsigned long long)hist[7], (unsigned long long)hist[8]);
     if (n_batches)
       fprintf(stderr, "[executor %s%d] lanes at batch formation (avg): taken %.1f, other-engine %.1f, in-flight+blocked %.1f, in-flight+parsing %.1f, idle/parsing %.1f\n",
-              engine ? "heavy" : "light", engine, lane_state[0] / (double)n_batches, lane_state[1] / (double)n_batches,
+              is_light(engine) ? "light" : "heavy", engine, lane_state[0] / (double)n_batches, lane_state[1] / (double)n_batches,
               lane_state[2] / (double)n_batches, lane_state[3] / (double)n_batches, lane_state[4] / (double)n_batches);
   }
   (void)hipStreamSynchronize(en.stream);  // outstanding completions run before the thread goes away

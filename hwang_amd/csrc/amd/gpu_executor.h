@@ -83,7 +83,8 @@ class GpuExecutor {
   // One executor per device for the life of the process.
   static GpuExecutor* get(int device, std::string* error);
 
-  int register_lane();
+  // light_group: which of the 1 + kExtraLightEngines light engines runs the lane's P / B pictures (taken modulo).
+  int register_lane(int light_group = 0);
   void unregister_lane(int lane);
   // Both return the lane-local sequence number of the submission (1, 2, ...).
   uint64_t submit_picture(int lane, const PicSubmit& job);
@@ -120,6 +121,7 @@ class GpuExecutor {
     std::deque<Item> fifo;
     uint64_t submitted = 0, launched = 0, completed = 0;
     int last_engine = 0;
+    int light_engine = 0;  // engine of the lane's P / B pictures
     int waiters = 0;  // threads blocked in wait()
     // A completed batch wakes exactly the lanes it contained (one shared
     // condition variable woke every blocked lane thread for every batch: 10 %
@@ -150,7 +152,14 @@ class GpuExecutor {
   static constexpr int kInflight = 3;
   static constexpr int kMaxJobs = 512;
   static constexpr int kHeavyEngines = 3;
-  static constexpr int kEngines = 1 + kHeavyEngines;
+  // Further light engines (streams of their own, on the light share of the CUs) for lanes that ask for one at
+  // registration.  A batch runs the row pipelines of its pictures one after the other (vectors, intra, deblocking:
+  // three latency-bound kernels) and occupies 17 CUs per picture while it does; a decoder with entropy workers has
+  // some eight lanes with work at a time, so one batch leaves most of the GPU idle for ~3 ms.  Spread over several
+  // engines its lanes' batches overlap.  The retriever's lanes all use engine 0 (48 lanes: one wide batch is best).
+  static constexpr int kExtraLightEngines = 3;
+  static constexpr int kEngines = 1 + kHeavyEngines + kExtraLightEngines;
+  static bool is_light(int engine) { return engine == 0 || engine > kHeavyEngines; }
 
   struct Engine {
     std::thread thread;

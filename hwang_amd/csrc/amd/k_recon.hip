@@ -588,6 +588,8 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
   const bool has_res = mb.coded_mask != 0;
   const int W = mb_width * 16, H = mb_height * 16;
   auto byte_of = [](uint32_t w, int k) { return (int)(int8_t)((w >> (8 * k)) & 0xff); };
+  // surface numbers are bytes 0 .. kMaxSurfaces - 1 (0xff: the list is not used - and then the byte is not looked at)
+  auto slot_of = [](uint32_t w, int k) { return (int)((w >> (8 * k)) & 0xff); };
 
   // ---- window path: is the macroblock's motion uniform per list?  (wave-uniform decisions: every lane holds one
   // of the sixteen vectors, all four reference bytes.)  A window that lies inside the reference picture is fetched
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     wx0[l] = x0;
     wy0[l] = y0;
     if (use_win[l]) {
-      const Surface& sf = pp.surfaces[byte_of(slots, 0)];
+      const Surface& sf = pp.surfaces[slot_of(slots, 0)];
       wplane[l][0] = sf.y;
       wplane[l][1] = sf.u;
       wplane[l][2] = sf.v;
@@ -737,9 +739,9 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     const int px = mbx * 16 + bcol * 4, py = mby * 16 + y;
     int s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     if (r0 >= 0)
-      luma_pred4(pp.surfaces[byte_of(slots0, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
+      luma_pred4(pp.surfaces[slot_of(slots0, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
     if (r1 >= 0)
-      luma_pred4(pp.surfaces[byte_of(slots1, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
+      luma_pred4(pp.surfaces[slot_of(slots1, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -754,11 +756,11 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     const int px = mbx * 8 + cbcol * 2, py = mby * 8 + cy;
     int s0[2] = {0, 0}, s1[2] = {0, 0};
     if (r0 >= 0) {
-      const Surface& sf = pp.surfaces[byte_of(slots0, cb8)];
+      const Surface& sf = pp.surfaces[slot_of(slots0, cb8)];
       chroma_pred2(cplane ? sf.v : sf.u, c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
     }
     if (r1 >= 0) {
-      const Surface& sf = pp.surfaces[byte_of(slots1, cb8)];
+      const Surface& sf = pp.surfaces[slot_of(slots1, cb8)];
       chroma_pred2(cplane ? sf.v : sf.u, c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
     }
     uint32_t packed = 0;
@@ -1871,18 +1873,18 @@ __device__ int boundary_strength(const MbInfo& pm, const MbInfo& qm, const MbMot
 #define FAR(a, b) (iabs((a)[0] - (b)[0]) >= 4 || iabs((a)[1] - (b)[1]) >= 4)
   if (!((pr0 == qr0 && pr1 == qr1) || (pr0 == qr1 && pr1 == qr0))) return 1;
   if (pr0 == pr1) {
-    if (pr0 < 0) return 0;
+    if (pr0 == -1) return 0;  // (-1 = no reference; other negative bytes are surfaces 128 .. 254)
     const bool straight = FAR(pm0, qm0) || FAR(pm1, qm1);
     const bool cross = FAR(pm0, qm1) || FAR(pm1, qm0);
     return (straight && cross) ? 1 : 0;
   }
   if (pr0 == qr0) {
-    if (pr0 >= 0 && FAR(pm0, qm0)) return 1;
-    if (pr1 >= 0 && FAR(pm1, qm1)) return 1;
+    if (pr0 != -1 && FAR(pm0, qm0)) return 1;
+    if (pr1 != -1 && FAR(pm1, qm1)) return 1;
     return 0;
   }
-  if (pr0 >= 0 && FAR(pm0, qm1)) return 1;
-  if (pr1 >= 0 && FAR(pm1, qm0)) return 1;
+  if (pr0 != -1 && FAR(pm0, qm1)) return 1;
+  if (pr1 != -1 && FAR(pm1, qm0)) return 1;
   return 0;
 #undef FAR
 }

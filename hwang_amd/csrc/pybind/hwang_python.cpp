@@ -17,6 +17,7 @@
 // GIL while the backend works.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
+#include <cstdlib>
 #include <pybind11/stl.h>
 
 #include "../decoder_automata.h"
@@ -97,18 +98,22 @@ void automata_initialize(DecoderAutomata& dec, const std::vector<DecoderAutomata
 
 std::vector<py::array_t<uint8_t>> automata_get_frames(DecoderAutomata& dec, const VideoIndex& index, uint32_t num_frames) {
   const size_t h = index.frame_height(), w = index.frame_width(), frame_size = w * h * 3;
-  auto* storage = new std::vector<uint8_t>(frame_size * num_frames);
-  py::capsule owner(storage, [](void* p) { delete static_cast<std::vector<uint8_t>*>(p); });
+  // One buffer for the frames of the call, NOT zero-filled: a std::vector would touch every page first (gigabytes
+  // for a few hundred 1080p frames, a second of memset before the first sample is fed); every byte handed out below is
+  // written by get_frames, and on failure nothing is handed out.
+  uint8_t* storage = static_cast<uint8_t*>(std::malloc(std::max<size_t>(1, frame_size * num_frames)));
+  if (!storage) throw std::bad_alloc();
+  py::capsule owner(storage, [](void* p) { std::free(p); });
   Result r;
   {
     py::gil_scoped_release release;
-    r = dec.get_frames(storage->data(), static_cast<int32_t>(num_frames));
+    r = dec.get_frames(storage, static_cast<int32_t>(num_frames));
   }
   if (!r.ok) throw std::runtime_error(r.message);
   std::vector<py::array_t<uint8_t>> frames;
   for (uint32_t i = 0; i < num_frames; ++i)
     frames.emplace_back(std::vector<py::ssize_t>{(py::ssize_t)h, (py::ssize_t)w, 3},
-                        std::vector<py::ssize_t>{(py::ssize_t)(w * 3), 3, 1}, storage->data() + i * frame_size, owner);
+                        std::vector<py::ssize_t>{(py::ssize_t)(w * 3), 3, 1}, storage + i * frame_size, owner);
   return frames;
 }
 

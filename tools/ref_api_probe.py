@@ -12,6 +12,8 @@ import numpy as np  # noqa: E402
 import bench  # noqa: E402
 import hwang  # noqa: E402
 import hwang_amd  # noqa: E402
+import ctypes as C  # noqa: E402
+from hwang_amd._capi import lib  # noqa: E402
 
 args = dict(a.split("=") for a in sys.argv[1:])
 frames = int(args.get("frames", 108000))
@@ -25,9 +27,38 @@ rows = sorted(np.random.default_rng(bench.SEED).choice(idx.frames(), max(1, roun
 for t in threads:
     dec = hwang.Decoder(path, video_index=ridx, device_type=hwang.DeviceType.GPU, num_devices=t, interval_group_bytes=group)
     dec.retrieve(rows[:4])
+    tm = {"initialize": 0.0, "get_frames": 0.0}
+    inner = dec._decoder
+
+    class Timed(object):   # where retrieve() spends its time: building / copying the intervals vs decoding
+        def initialize(self, *a):
+            t = time.perf_counter()
+            r = inner.initialize(*a)
+            tm["initialize"] += time.perf_counter() - t
+            return r
+
+        def get_frames(self, *a):
+            t = time.perf_counter()
+            r = inner.get_frames(*a)
+            tm["get_frames"] += time.perf_counter() - t
+            return r
+    dec._decoder = Timed()
+    prof = bool(int(args.get("prof", 0)))
+    if prof:
+        lib.hwang_prof_reset()
+        lib.hwang_prof_enable(1)
     c0, t0 = os.times(), time.perf_counter()
     out = dec.retrieve(rows)
     t1, c1 = time.perf_counter(), os.times()
-    print("num_devices %2d: %6.1f frames/s  (%d rows in %.2f s, %.2f CPUs busy)" %
-          (t, len(out) / (t1 - t0), len(out), t1 - t0, ((c1.user - c0.user) + (c1.system - c0.system)) / (t1 - t0)), flush=True)
+    if prof:
+        lib.hwang_prof_enable(0)
+        for k in range(lib.hwang_prof_num_kernels()):
+            o = (C.c_double * 3)()
+            lib.hwang_prof_read(k, o)
+            if o[0]:
+                print("   %-18s launches %5d  avg %8.1f us  total %6.3f s" % (lib.hwang_prof_kernel_name(k).decode(), o[0], o[1] / o[0], o[1] / 1e6))
+    print("num_devices %2d: %6.1f frames/s  (%d rows in %.2f s, %.2f CPUs busy; initialize %.2f s, get_frames %.2f s, "
+          "Python around them %.2f s)" %
+          (t, len(out) / (t1 - t0), len(out), t1 - t0, ((c1.user - c0.user) + (c1.system - c0.system)) / (t1 - t0),
+           tm["initialize"], tm["get_frames"], t1 - t0 - tm["initialize"] - tm["get_frames"]), flush=True)
     del out, dec
