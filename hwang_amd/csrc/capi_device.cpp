@@ -99,6 +99,12 @@ int hwang_decoder_set_wanted(hwang_decoder* dec, const uint64_t* ordinals,
   hints->set_wanted_frames(std::vector<uint64_t>(ordinals, ordinals + n));
   return 0;
 }
+int hwang_decoder_set_interval_keyframes(hwang_decoder* dec, const uint64_t* ordinals, size_t n) {
+  auto* hints = dynamic_cast<SparseDecodeHints*>(dec->d.get());
+  if (!hints) return dec->set(Result(false, "backend takes no sparse hints"));
+  hints->set_interval_keyframes(std::vector<uint64_t>(ordinals, ordinals + n));
+  return 0;
+}
 int hwang_decoder_get_frame_yuv(hwang_decoder* dec, uint8_t* decoded,
                                 size_t decoded_size) {
   auto* planar = dynamic_cast<PlanarOutput*>(dec->d.get());

@@ -135,7 +135,12 @@ const uint64_t* hwang_video_intervals_valid(const hwang_video_intervals* interva
 typedef struct hwang_decoder hwang_decoder;
 
 int hwang_decoder_type_supported(int decoder_type);
-/* NULL when the type is unsupported or the device cannot be opened. */
+/* NULL when the type is unsupported or the device cannot be opened.
+ * num_devices: what VideoDecoderFactory::make_from_config hands to the backend
+ * (video_decoder_factory.cpp:90-91).  The AMD backend reads it as the reference's
+ * software backend does (software_video_decoder.cpp:148, libavcodec's
+ * thread_count): with n > 1, n threads entropy decode consecutive pictures of
+ * this ONE decoder at the same time (0 and 1: the thread that calls feed()). */
 hwang_decoder* hwang_decoder_create(int device_type, int32_t device_id,
                                     uint32_t num_devices, int decoder_type);
 void hwang_decoder_destroy(hwang_decoder* dec);
@@ -155,6 +160,10 @@ const char* hwang_decoder_last_error(hwang_decoder* dec);
 /* Extensions (not in the reference interface):
  *  - set_wanted: SparseDecodeHints; ordinals are 0-based output positions
  *    from the interval start, ascending, valid until the next flush.
+ *  - set_interval_keyframes (with set_wanted): which samples of the interval, same
+ *    numbering, are sync samples (DecoderAutomata::EncodedData::keyframes minus
+ *    the interval's first frame).  The planner merges byte-adjacent GOPs into one
+ *    interval; with this every GOP of it ends behind its own last wanted frame.
  *  - get_frame_yuv: like get_frame but copies the cropped planar I420 frame
  *    (Y w*h, then U, then V (w/2)*(h/2)); the normative decoder output used
  *    by the bit-exact parity tests.
@@ -162,6 +171,8 @@ const char* hwang_decoder_last_error(hwang_decoder* dec);
  *    skipped for this handle. */
 int hwang_decoder_set_wanted(hwang_decoder* dec, const uint64_t* ordinals,
                              size_t n);
+int hwang_decoder_set_interval_keyframes(hwang_decoder* dec, const uint64_t* ordinals,
+                                         size_t n);
 int hwang_decoder_get_frame_yuv(hwang_decoder* dec, uint8_t* decoded,
                                 size_t decoded_size);
 
