@@ -88,8 +88,8 @@ def test_corpus_clip(hw, oracle, tmp_path, name, kw):
 def test_entropy_workers_produce_the_same_records(hw, tmp_path, name, kw):
     """num_devices > 1 (the reference's decoder thread count, software_video_decoder.cpp:148): consecutive pictures'
     slice data decoded by a pool of workers while the calling thread runs ahead through the headers.  Every record
-    the GPU would receive, in hand-over order, is the same as in the serial decode - for 1, 3 and 8 workers, with
-    and without a sparse hint - and the serial digest is the committed golden one."""
+    the GPU would receive, in hand-over order, is the same as in the serial decode - for 3 workers on every case, for 1
+    and 8 on every fourth, with and without a sparse hint - and the serial digest is the committed golden one."""
     path = str(tmp_path / (name + ".mp4"))
     make_clip(path, yuv=False, **kw)
     serial = probe_workers(hw, path, 0)
@@ -97,7 +97,9 @@ def test_entropy_workers_produce_the_same_records(hw, tmp_path, name, kw):
     n = serial["outputs"]
     sparse = sorted(set([0, n // 3, n // 2, n - 1]))
     serial_sparse = probe_workers(hw, path, 0, wanted=sparse)
-    for workers in (1, 3, 8):
+    # three workers for every case; one and eight as well for every fourth (the suite's time)
+    every = [m[0] for m in MATRIX].index(name) % 4 == 0
+    for workers in ((1, 3, 8) if every else (3,)):
         r = probe_workers(hw, path, workers)
         for k in ("slices", "clean_end", "pictures", "skipped", "outputs", "outputs_skipped", "coefficients",
                   "digest_noslot"):
