@@ -323,7 +323,10 @@ def main():
     # 3 lanes per usable CPU (a lane waits for the GPU about as long as it parses;
     # the CPUs are the bottleneck: measured 32 / 40 / 48 / 64 lanes on 16 CPUs ->
     # 660 / 676 / 698 / 651 frames/s); with several ranks on one host the CPUs are shared
-    lanes = args.lanes or max(2, min(128, 3 * effective_cpus() // world))
+    # (4K: two per CPU - a lane's working set grows with the picture and beyond that the parsers evict each other,
+    # retriever.cpp; measured 16 / 24 / 32 / 48 lanes -> 485 / 528 / 562 / 477 frames/s)
+    per_cpu = 3 if WIDTH * HEIGHT <= 2 * 1920 * 1088 else 2
+    lanes = args.lanes or max(2, min(128, per_cpu * effective_cpus() // world))
     devices = (forced_ids or list(range(in_process_devices))) if in_process_devices > 1 else [device_index]
     br = BatchRetriever(device_ids=devices, num_lanes=lanes, shard=(rank, world) if world > 1 else None)
     # request k's frames land in HBM (N ranks: each rank writes the rows of its share into its own copy of
