@@ -70,8 +70,11 @@ def select_config(name, frames=None):
     WIDTH, HEIGHT, UNIQUE_FRAMES, QP, FPS = c["width"], c["height"], c["unique"], c["qp"], c["fps"]
     mbs = ((WIDTH + 15) // 16) * ((HEIGHT + 15) // 16)
     _S = mbs * 384
+    # (the records-only kernels - k_mv, k_bs, k_residual - run as a stage of their own since round 3, so k_bs and
+    # k_residual are spans of their own and no longer inside the deblock / intra spans)
     SPAN_KERNELS = {"mv_derivation": (["k_mv"], mbs * 176), "inter_pred": (["k_inter"], 2 * _S),
-                    "intra_pred": (["k_residual", "k_intra"], _S), "deblock": (["k_bs", "k_deblock"], 2 * _S),
+                    "intra_pred": (["k_intra"], _S), "deblock": (["k_deblock"], 2 * _S),
+                    "boundary_strength": (["k_bs"], mbs * (176 + 96)), "residual_idct": (["k_residual"], mbs * 768),
                     "yuv420_to_rgb24": (["convert_batch"], 9 * WIDTH * HEIGHT // 2)}
     return frames if frames else c["frames"]
 

@@ -20,6 +20,10 @@ hipError_t launch_table_copy(void* dst, const void* src, size_t bytes, hipStream
 hipError_t launch_done(uint32_t* flag, uint32_t ticket, hipStream_t stream);
 hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_inter, bool any_intra,
                         bool any_deblock, bool any_mv, const uint64_t bytes[4], hipStream_t stream);
+hipError_t launch_pre(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_mv, bool any_bs, bool any_residual,
+                      const uint64_t bytes[3], hipStream_t stream);
+hipError_t launch_main(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_inter, bool any_intra,
+                       bool any_deblock, const uint64_t bytes[3], hipStream_t stream);
 
 namespace {
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
@@ -88,7 +92,7 @@ bool GpuExecutor::start(std::string* error) {
   };
   for (int ei = 0; ei < kEngines; ++ei) {
     Engine& en = engines_[ei];
-    if (!make_stream(&en.stream, is_light(ei) ? light_mask : heavy_mask)) return fail("cannot create a stream");
+    if (!make_stream(&en.stream, (is_light(ei) || ei == kPreEngine) ? light_mask : heavy_mask)) return fail("cannot create a stream");
     // Uploads go on the engine's compute stream.  A separate copy stream for the
     // light engine (HWANG_COPY_STREAM=1) lets batch N+1's records travel while
     // batch N's kernels run, but the hipEventRecord / hipStreamWaitEvent pair
@@ -114,6 +118,7 @@ bool GpuExecutor::start(std::string* error) {
   if (const char* e = getenv("HWANG_HEAVY_ENGINES")) heavy_engines_ = std::max(1, std::min(kHeavyEngines, atoi(e)));
   if (const char* e = getenv("HWANG_HEAVY_INFLIGHT")) heavy_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
   if (const char* e = getenv("HWANG_LIGHT_INFLIGHT")) light_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
+  if (const char* e = getenv("HWANG_PRESTAGE")) prestage_ = atoi(e) != 0;
   const char* mode = getenv("HWANG_COMPLETION");
   use_hostfunc_ = mode && std::string(mode) == "hostfunc";
   if (hipHostMalloc(reinterpret_cast<void**>(&done_flags_), sizeof(uint32_t) * kEngines * kInflight, hipHostMallocDefault) != hipSuccess)
@@ -216,9 +221,10 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     it.is_picture = true;
     it.pic = job;
     it.engine = job.heavy ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
+    it.pre = prestage_ ? 0 : 2;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
-    target = it.engine;
+    target = prestage_ ? kPreEngine : it.engine;
   }
   cv_work_[target].notify_one();
   return seq;
@@ -300,6 +306,8 @@ void GpuExecutor::complete(Batch* b, hipError_t status) {
                "); the batch's pictures are invalid";
   }
   const bool failed = !error_.empty();
+  for (Item* it : b->pre_items) it->pre = 2;  // (a batch of the records-only stage credits no lane: the pictures go on)
+  b->pre_items.clear();
   for (auto& lc : b->lane_counts) {
     Lane& l = lanes_[lc.first];
     l.completed += lc.second;
@@ -345,7 +353,99 @@ void GpuExecutor::poll_loop() {
 // function to the stream that reports completion.  Nothing polls and nothing
 // blocks inside the HIP runtime, so the threads cost no CPU while the GPU
 // works (the host's CPUs belong to the entropy decoders).
+// The records-only stage.  Eager, one batch in flight: while it runs, whatever the lanes submit accumulates into the
+// next one, so the launches are as wide as the submission rate makes them.
+void GpuExecutor::run_pre() {
+  pthread_setname_np(pthread_self(), "hw-pre");
+  (void)hipSetDevice(device_);
+  Engine& en = engines_[kPreEngine];
+  const bool debug = getenv("HWANG_EXEC_DEBUG") != nullptr;
+  uint64_t n_batches = 0, n_pics = 0;
+  std::vector<Item*> items;
+  for (;;) {
+    items.clear();
+    int slot = -1;
+    {
+      std::unique_lock<std::mutex> lk(mu_);
+      auto have_work = [&] {
+        for (const Lane& l : lanes_)
+          for (const Item& it : l.fifo)
+            if (it.is_picture && it.pre == 0) return true;
+        return false;
+      };
+      cv_work_[kPreEngine].wait(lk, [&] { return stop_ || (en.inflight < 1 && have_work()); });
+      if (stop_) break;
+      for (int i = 0; i < kInflight; ++i)
+        if (!en.batches[i].in_flight) slot = i;
+      Batch& batch = en.batches[slot];
+      for (Lane& l : lanes_)
+        for (Item& it : l.fifo)
+          if (it.is_picture && it.pre == 0 && items.size() < static_cast<size_t>(kMaxJobs)) {
+            it.pre = 1;
+            items.push_back(&it);
+          }
+      batch.pre_items = items;
+      batch.in_flight = true;
+      batch.owner = this;
+      batch.engine = kPreEngine;
+      batch.ticket = ++next_ticket_;
+      batch.flag = done_flags_ + kPreEngine * kInflight + slot;
+      batch.fault = fault_flags_ + kPreEngine * kInflight + slot;
+      *batch.fault = 0;
+      ++en.inflight;
+      ++total_inflight_;
+    }
+    Batch& batch = en.batches[slot];
+    ++n_batches;
+    n_pics += items.size();
+    int max_mbs = 0, max_rows = 0;
+    bool any_mv = false, any_bs = false, any_residual = false;
+    uint64_t bytes[3] = {0, 0, 0};
+    for (size_t i = 0; i < items.size(); ++i) {
+      const PicSubmit& p = items[i]->pic;  // (stable: the item cannot leave its queue before this stage is through)
+      JobDesc& jd = en.job_table_host[slot][i];
+      jd = p.desc;
+      jd.num_uploads = p.ncopies;
+      jd.ticket_mv = jd.ticket_db = jd.ticket_in = 0;
+      jd.fault = const_cast<uint32_t*>(batch.fault);
+      for (int c = 0; c < p.ncopies; ++c) {
+        jd.uploads[c].dst = p.copies[c].dst;
+        jd.uploads[c].src = p.copies[c].src;
+        jd.uploads[c].bytes = p.copies[c].bytes;
+      }
+      max_mbs = p.num_mbs > max_mbs ? p.num_mbs : max_mbs;
+      max_rows = p.desc.pp.mb_height > max_rows ? p.desc.pp.mb_height : max_rows;
+      any_mv |= p.desc.do_mv != 0;
+      any_bs |= p.desc.do_deblock != 0;
+      any_residual |= p.desc.do_intra != 0;
+      bytes[0] += p.bytes_mv;
+      bytes[1] += p.desc.do_deblock ? static_cast<uint64_t>(p.num_mbs) * (176 + 96) : 0;
+      bytes[2] += p.desc.do_intra ? static_cast<uint64_t>(p.num_mbs) * 768 : 0;
+    }
+    hipError_t e = launch_table_copy(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * items.size(), en.stream);
+    if (e == hipSuccess) e = launch_upload(en.job_table_dev[slot], static_cast<int>(items.size()), en.stream);
+    if (e == hipSuccess)
+      e = launch_pre(en.job_table_dev[slot], static_cast<int>(items.size()), max_mbs, max_rows, any_mv, any_bs, any_residual,
+                     bytes, en.stream);
+    if (e == hipSuccess) {
+      if (use_hostfunc_) {
+        e = hipLaunchHostFunc(en.stream, &GpuExecutor::on_batch_done, &batch);
+      } else {
+        e = launch_done(const_cast<uint32_t*>(batch.flag), batch.ticket, en.stream);
+        cv_poll_.notify_one();
+      }
+    }
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(en.stream);
+      complete(&batch, e);
+    }
+  }
+  if (debug) fprintf(stderr, "[executor pre] batches %llu pics %llu\n", (unsigned long long)n_batches, (unsigned long long)n_pics);
+  (void)hipStreamSynchronize(en.stream);
+}
+
 void GpuExecutor::run(int engine) {
+  if (engine == kPreEngine) return run_pre();
   {
     char name[16];
     snprintf(name, sizeof(name), is_light(engine) ? "hw-light%d" : "hw-heavy%d", engine);
@@ -441,7 +541,7 @@ void GpuExecutor::run(int engine) {
         const PicSubmit& p = pics[i];
         JobDesc& jd = en.job_table_host[slot][i];
         jd = p.desc;
-        jd.num_uploads = p.ncopies;
+        jd.num_uploads = prestage_ ? 0 : p.ncopies;
         jd.ticket_mv = jd.ticket_db = jd.ticket_in = 0;
         jd.fault = const_cast<uint32_t*>(batch.fault);
         for (int c = 0; c < p.ncopies; ++c) {
@@ -461,14 +561,22 @@ void GpuExecutor::run(int engine) {
         bytes[3] += p.bytes_mv;
       }
       e = launch_table_copy(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(), en.copy_stream);
-      if (e == hipSuccess) e = launch_upload(en.job_table_dev[slot], static_cast<int>(pics.size()), en.copy_stream);
-      if (en.copy_stream != en.stream) {
-        if (e == hipSuccess) e = hipEventRecord(en.copied[slot], en.copy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(en.stream, en.copied[slot], 0);
+      if (prestage_) {
+        // records uploaded, vectors / boundary strengths / intra residuals computed by the records-only stage
+        const uint64_t b3[3] = {bytes[0], bytes[1], bytes[2]};
+        if (e == hipSuccess)
+          e = launch_main(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, max_rows, any_inter, any_intra,
+                          any_deblock, b3, en.stream);
+      } else {
+        if (e == hipSuccess) e = launch_upload(en.job_table_dev[slot], static_cast<int>(pics.size()), en.copy_stream);
+        if (en.copy_stream != en.stream) {
+          if (e == hipSuccess) e = hipEventRecord(en.copied[slot], en.copy_stream);
+          if (e == hipSuccess) e = hipStreamWaitEvent(en.stream, en.copied[slot], 0);
+        }
+        if (e == hipSuccess)
+          e = launch_batch(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, max_rows, any_inter, any_intra,
+                           any_deblock, any_mv, bytes, en.stream);
       }
-      if (e == hipSuccess)
-        e = launch_batch(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, max_rows, any_inter, any_intra,
-                         any_deblock, any_mv, bytes, en.stream);
     }
     if (!convs.empty() && e == hipSuccess) {
       int mw = 0, mh = 0;

@@ -2413,6 +2413,63 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_row
   return hipGetLastError();
 }
 
+// The same work as launch_batch in two stages.  What a picture's kernels need splits cleanly:
+//   records only   k_mv (vectors from differences), k_bs (boundary strengths from records and vectors),
+//                  k_residual (dequantisation + inverse transforms of intra macroblocks)
+//   samples        k_inter -> k_intra -> k_deblock, each reading what the one before (and the reference pictures) wrote
+// Only the second chain ties a picture to the one before it.  launch_pre runs the first for any set of pictures whose
+// records have been uploaded - pictures of one lane included, far ahead of their turn; launch_main the second.
+// bytes: [0] k_mv, [1] k_bs, [2] k_residual (algorithmic, for the spans).
+hipError_t launch_pre(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_mv, bool any_bs, bool any_residual,
+                      const uint64_t bytes[3], hipStream_t stream) {
+  const bool profiled = prof::enabled();
+  prof::Span span;
+  if (any_mv) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_mv, dim3(njobs * ((max_rows + kMvWaves - 1) / kMvWaves)), dim3(kMvWaves * 64), 0, stream,
+                       const_cast<JobDesc*>(jobs), njobs);
+    if (profiled) prof::end(span, stream, prof::K_MV, bytes[0]);
+  }
+  if (any_bs) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_bs, dim3(((max_mbs + 7) / 8 + 7) / 8 * 8, njobs), dim3(256), 0, stream, jobs);
+    if (profiled) prof::end(span, stream, prof::K_BS, bytes[1]);
+  }
+  if (any_residual) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_residual, dim3((max_mbs + kInterWaves - 1) / kInterWaves, njobs), dim3(kInterWaves * 64), 0, stream,
+                       jobs);
+    if (profiled) prof::end(span, stream, prof::K_RESIDUAL, bytes[2]);
+  }
+  return hipGetLastError();
+}
+
+// bytes: [0] k_inter, [1] k_intra, [2] k_deblock
+hipError_t launch_main(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_inter, bool any_intra,
+                       bool any_deblock, const uint64_t bytes[3], hipStream_t stream) {
+  const bool profiled = prof::enabled();
+  prof::Span span;
+  if (any_inter) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_inter, dim3(((max_mbs + kInterWaves - 1) / kInterWaves + 7) / 8 * 8, njobs), dim3(kInterWaves * 64), 0,
+                       stream, jobs);
+    if (profiled) prof::end(span, stream, prof::K_INTER, bytes[0]);
+  }
+  if (any_intra) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_intra, dim3(njobs * ((max_rows + kBandWaves - 1) / kBandWaves)), dim3(kBandWaves * 64), 0, stream,
+                       const_cast<JobDesc*>(jobs), njobs);
+    if (profiled) prof::end(span, stream, prof::K_INTRA, bytes[1]);
+  }
+  if (any_deblock) {
+    if (profiled) span = prof::begin(stream);
+    hipLaunchKernelGGL(k_deblock, dim3(njobs * ((max_rows + kBandWaves - 1) / kBandWaves)), dim3(kBandWaves * 64), 0, stream,
+                       const_cast<JobDesc*>(jobs), njobs);
+    if (profiled) prof::end(span, stream, prof::K_DEBLOCK, bytes[2]);
+  }
+  return hipGetLastError();
+}
+
 size_t deblock_scratch_bytes(int num_mbs) { return (size_t)num_mbs * sizeof(DbInfo); }
 size_t band_ctl_bytes(int mb_height) {
   return offsetof(BandCtl, lines) +

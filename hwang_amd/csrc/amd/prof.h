@@ -15,7 +15,8 @@ enum KernelId {
   K_DEBLOCK = 3,    // in-loop deblocking wavefront
   K_RGB = 4,        // I420 -> RGB24
   K_MV = 5,         // motion-vector derivation of P macroblocks
-  K_COUNT = 6,
+  K_BS = 6,         // boundary strengths + filter parameters (k_bs), when it runs as a stage of its own
+  K_COUNT = 7,
 };
 
 bool enabled();
