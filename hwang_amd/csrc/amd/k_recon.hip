@@ -1455,6 +1455,12 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
       const int probe = mbx0 + lane;
       const bool is_intra = probe < pp.mb_width && (gld8(&mbs[mby * pp.mb_width + probe].flags) & MBF_INTRA);
       unsigned long long todo = __ballot(is_intra);
+      // Surface path (pictures with inter macroblocks): those are final since k_inter, so the row is complete up to its
+      // next intra macroblock the moment the previous one's samples have landed - say so at once, not only "up to the
+      // one just finished".  A row below then waits only where an intra macroblock really sits above an intra
+      // macroblock (in a P picture they are few and scattered: the wavefront used to crawl through every row at the
+      // pace of the rows above whether or not anything there concerned it).
+      if (!lds_nb) publish(todo ? mbx0 + __builtin_ctzll(todo) : min(mbx0 + 64, pp.mb_width));
       // residual of the first macroblock of the run; inside the loop the next one's is fetched a macroblock ahead
       // (and its record: a load at the top of the macroblock would sit on the chain)
       uint32_t r0 = 0, r1 = 0, r2 = 0;
@@ -1758,7 +1764,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
             progress[wave + 1] = mbx + 1;
           }
         } else {
-          publish(mbx + 1);
+          publish(todo ? mbx0 + __builtin_ctzll(todo) : min(mbx0 + 64, pp.mb_width));  // up to the next intra macroblock
         }
         prev_mbx = mbx;
       }
@@ -2065,6 +2071,22 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
       // load nothing, store nothing; the counter simply jumps over them.
       const int probe = mbx0 + lane;
       unsigned long long todo = __ballot(probe < W && gld8(&rowdb[probe].any) != 0);
+      // "Macroblocks < P of this row are final" - the value is normally raised one macroblock late, in the iteration of
+      // the next macroblock that has edges (its stores have had that long to land).  Where that next one is further
+      // away the rows below would wait for nothing: a macroblock without an edge of its own is final as soon as its
+      // neighbours' edges are - all but its last columns, which the next filtered macroblock's left edge may still
+      // touch.  So before a gap the counter is raised at once to (next macroblock with edges) - 1.
+      auto publish_db = [&](int v) {
+        if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch_out | static_cast<uint32_t>(v)); }
+        else progress[wave + 1] = v;
+      };
+      {
+        const int first = todo ? mbx0 + __builtin_ctzll(todo) : (mbx0 + 64 < W ? mbx0 + 64 : W + 1);
+        if (first - 1 > mbx0) {  // (what lies before this stretch is final: the previous one's last iteration saw to it)
+          if (mbx0 > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          publish_db(first - 1 < W ? first - 1 : W);
+        }
+      }
       // Interior samples arrive a GROUP of four macroblocks at a time: 64 bytes of every luma row (lane = row x
       // macroblock of the group, 16 bytes each) and 32 bytes of every chroma row (lane = plane x row x macroblock,
       // 8 bytes each): one 16-byte and one 8-byte load per lane every fourth macroblock instead of two dword loads
@@ -2298,6 +2320,15 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
           }
         }
         tile_mbx = mbx;
+        {
+          // a gap behind this macroblock: let its stores land now and raise the counter over the gap
+          const int next = todo ? mbx0 + __builtin_ctzll(todo) : (mbx0 + 64 < W ? mbx0 + 64 : W + 1);
+          if (next - 1 > mbx + 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            publish_db(next - 1 < W ? next - 1 : W);
+            asm volatile("" : "+v"(n_gluma), "+v"(n_gchroma), "+v"(n_db), "+v"(n_left));  // (they have landed too)
+          }
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
