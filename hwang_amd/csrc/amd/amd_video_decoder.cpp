@@ -38,6 +38,8 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace hwang {
@@ -56,10 +58,12 @@ using amd::SliceParams;
 
 constexpr int kJobs = 4;        // staging ring depth (serial entropy decoding; with workers: pictures in flight + 3)
 constexpr int kPipeLanes = 16;  // executor lanes a decoder with entropy workers rotates through, one per interval
+constexpr size_t kPipeStagingBytes = size_t(2) << 30;  // ... within this much pinned host memory
 constexpr int kPipeDepth = 160;  // ... and how many pictures may be queued between its workers and the GPU
 constexpr int kMaxSlices = 256;
 constexpr int kBounce = 4;      // pinned output bounce buffers (serial entropy decoding)
 constexpr int kPipeBounce = 24; // ... with entropy workers: frames are fetched before their pictures reach the GPU
+constexpr int kCopiers = 4;     // ... and this many threads copy them out of the bounce buffers (copier_loop)
 
 class AMDVideoDecoder : public VideoDecoderInterface,
                         public SparseDecodeHints,
@@ -101,8 +105,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // intervals queued do the lanes' batches fill (HWANG_PIPE_DEPTH overrides the queue depth).
     int depth = kPipeDepth;
     if (const char* e = getenv("HWANG_PIPE_DEPTH")) depth = std::max(4, std::min(atoi(e), 1024));
-    jobs_.resize(num_workers_ ? max_in_flight_ + depth : kJobs);
+    pipe_depth_ = depth;
+    jobs_.resize(kJobs);  // with workers: sized with the picture geometry (ensure_geometry)
     bounce_.resize(num_workers_ ? kPipeBounce : kBounce);
+    if (num_workers_)
+      for (int i = 0; i < kCopiers; ++i) copiers_.emplace_back([this] { copier_loop(); });
     return true;
   }
 
@@ -190,8 +197,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const bool workers_ok = !parser_ || parser_->wait_idle(&worker_error);
     HWANG_RETURN_ON_ERROR(wait_all());
     {
-      std::lock_guard<std::mutex> lk(out_mu_);
-      deliver_bounces_locked();
+      std::unique_lock<std::mutex> lk(out_mu_);
+      drain_bounces(lk);
+      if (!copy_error_.empty()) {
+        Result r(false, "AMDVideoDecoder: " + copy_error_);
+        copy_error_.clear();
+        return r;
+      }
     }
     if (!workers_ok) return Result(false, "AMDVideoDecoder: " + worker_error);
     return take_sink_error("AMDVideoDecoder: ");
@@ -233,9 +245,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // one submitted just before it.)
     const int lane = lanes_[cur_lane_];
     int slot = -1;
+    uint64_t done[kPipeLanes];  // how far each of this decoder's lanes has got (a moment ago: good enough to tell "free")
+    exec_->completed(lanes_.data(), static_cast<int>(lanes_.size()), done);
     {
-      std::vector<uint64_t> done(lanes_.size());
-      for (size_t i = 0; i < lanes_.size(); ++i) done[i] = exec_->completed(lanes_[i]);
       auto settled = [&](const Stamp& st) { return !st.seq || done[st.lane] >= st.seq; };
       std::lock_guard<std::mutex> lk(out_mu_);
       int fresh = -1, oldest = -1, allocated = 0;
@@ -319,8 +331,6 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // middle of some lane's chain, and the parser then advanced one picture per batch, in step with that one lane.)
     int ji = -1;
     {
-      std::vector<uint64_t> done(lanes_.size());
-      for (size_t i = 0; i < lanes_.size(); ++i) done[i] = exec_->completed(lanes_[i]);
       int oldest = -1;
       const int nj = static_cast<int>(jobs_.size());
       for (int k = 0; k < nj && ji < 0; ++k) {
@@ -361,7 +371,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     out->max_slices = kMaxSlices;
     out->slot = slot;
     // k_mv derives the P macroblocks' motion vectors (its LDS line buffer covers kLineMbs macroblocks per row)
-    out->device_mv = mbw_ <= amd::kLineMbs && !getenv("HWANG_HOST_MV");
+    out->device_mv = mbw_ <= amd::kLineMbs && !host_mv_;
     return true;
   }
 
@@ -433,6 +443,22 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.bytes_intra = d.has_intra ? S : 0;
     sub.bytes_deblock = d.any_deblock ? 2 * S : 0;
     sub.bytes_mv = d.mv_deferred ? nmb * (sizeof(MbInfo) + 80 + 64) : 0;  // header + differences/refs in, vectors out
+    if (lanes_.size() > 1) {
+      // The lanes rotate at sync samples and the executor orders work only within a lane.  A sync sample that is not
+      // an IDR picture (open GOP) may be followed by pictures that refer to the GOP before it - on another lane:
+      // whatever that lane still has to do with such a reference is waited for here.  (Closed GOPs: never.)
+      Stamp foreign[32];
+      int nforeign = 0;
+      {
+        std::lock_guard<std::mutex> lk(out_mu_);
+        for (int i = 0; i < d.num_ref_slots; ++i) {
+          const SurfaceSlot& r = surf_[d.ref_slots[i]];
+          if (r.dev && r.lane != lane_index && r.busy.seq && r.busy.lane != lane_index) foreign[nforeign++] = r.busy;
+        }
+      }
+      std::string ignored;
+      for (int i = 0; i < nforeign; ++i) (void)wait_stamp(foreign[i], &ignored);  // (a failed lane fails every later wait too)
+    }
     j.stamp = Stamp{lane_index, exec_->submit_picture(lane, sub)};
     note_seq(j.stamp);
 
@@ -496,6 +522,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (bounce >= 0) {
       bounce_[bounce].stamp = st;
       bounce_[bounce].queued = true;
+      out_cv_.notify_all();  // (a copier may take it from here)
     }
     unref_surface_locked(slot, kHeldByOutput);
   }
@@ -600,6 +627,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     size_t size = 0;
     Stamp stamp;             // the conversion that fills it
     bool queued = false;     // ... has been submitted (entropy workers: it may wait for its picture)
+    bool copying = false;    // a thread is waiting for that conversion / copying the frame out (out_mu_ released)
   };
 
   void unref_surface_locked(int slot, int who) {
@@ -624,20 +652,79 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sink_error_.clear();
     return r;
   }
-  void deliver_bounces_locked() {
-    for (Bounce& b : bounce_)
-      if (b.dst) {
-        std::memcpy(b.dst, b.host, b.size);
-        b.dst = nullptr;
+  // ---- copy-out of fetched frames: pinned bounce buffer -> the caller's (pageable) memory.
+  // That is a 6 MB memcpy per 1080p frame into pages the caller has typically never touched: ~2 ms.  Done by the one
+  // consumer thread between its get_frame calls (and, as it was, with out_mu_ held) it capped a decoder at ~500
+  // frames/s whatever the entropy workers and the GPU delivered.  The copies happen outside the lock now, and a
+  // decoder with entropy workers has kCopiers threads for them; the consumer thread copies only when it needs a
+  // buffer that nobody has started on.
+  // (out_mu_ held) a frame whose conversion has been submitted and that nobody is copying yet, oldest first
+  int claimable_bounce_locked() const {
+    const int n = static_cast<int>(bounce_.size());
+    for (int k = 0; k < n; ++k) {
+      const int i = (bounce_cursor_ + k) % n;
+      if (bounce_[i].dst && bounce_[i].queued && !bounce_[i].copying) return i;
+    }
+    return -1;
+  }
+  // Waits for bounce i's conversion and copies the frame out; out_mu_ is released meanwhile.
+  void copy_out(std::unique_lock<std::mutex>& lk, int i) {
+    Bounce& b = bounce_[i];
+    b.copying = true;
+    const Stamp st = b.stamp;
+    uint8_t* const dst = b.dst;
+    const size_t size = b.size;
+    lk.unlock();
+    std::string error;
+    const bool ok = wait_stamp(st, &error);
+    if (ok) std::memcpy(dst, b.host, size);
+    lk.lock();
+    if (!ok && copy_error_.empty()) copy_error_ = error;
+    b.dst = nullptr;
+    b.copying = false;
+    out_cv_.notify_all();
+  }
+  void copier_loop() {
+    std::unique_lock<std::mutex> lk(out_mu_);
+    for (;;) {
+      int i = -1;
+      out_cv_.wait(lk, [&] { return copiers_stop_ || (i = claimable_bounce_locked()) >= 0; });
+      if (copiers_stop_) return;
+      copy_out(lk, i);
+    }
+  }
+  void stop_copiers() {
+    {
+      std::lock_guard<std::mutex> lk(out_mu_);
+      copiers_stop_ = true;
+    }
+    out_cv_.notify_all();
+    for (std::thread& t : copiers_) t.join();
+    copiers_.clear();
+  }
+  // Every fetched frame whose conversion has been submitted reaches its destination (this thread helps).  A frame
+  // whose conversion never was submitted (its picture did not arrive) is given up.
+  void drain_bounces(std::unique_lock<std::mutex>& lk) {
+    for (;;) {
+      const int i = claimable_bounce_locked();
+      if (i >= 0) {
+        copy_out(lk, i);
+        continue;
       }
+      bool copying = false;
+      for (Bounce& b : bounce_) copying |= b.copying;
+      if (!copying) break;
+      out_cv_.wait(lk);
+    }
+    for (Bounce& b : bounce_) b.dst = nullptr;
   }
 
   Result drain_and_reset() {
     HWANG_RETURN_ON_ERROR(wait_all());
-    std::lock_guard<std::mutex> lk(out_mu_);
+    std::unique_lock<std::mutex> lk(out_mu_);
     // frames the caller has already taken with get_frame() are his: their copy-outs
     // complete (a re-configure between two clips of a batched call used to drop them)
-    deliver_bounces_locked();
+    drain_bounces(lk);
     outq_.clear();
     buffered_.store(0);
     for (SurfaceSlot& s : surf_) s.held = 0;
@@ -677,8 +764,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     (void)wait_all();
     {
-      std::lock_guard<std::mutex> lk(out_mu_);
-      deliver_bounces_locked();
+      std::unique_lock<std::mutex> lk(out_mu_);
+      drain_bounces(lk);
     }
     free_buffers();  // also zeroes mbw_/mbh_: they are set again only when every allocation has succeeded
     const int new_mbw = s.mb_width, new_mbh = s.mb_height;
@@ -702,6 +789,14 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // worst case per macroblock: kMaxSparseCoefs entries, or 26 dense groups (fewer words)
     coef_capacity_ = nmb * amd::kMaxSparseCoefs;
     pmx_words_ = static_cast<size_t>(mbh_) + nmb * 15;  // row table + up to 15 further partitions per macroblock
+    if (num_workers_) {
+      // Staging sets: the pictures in the workers' hands plus the queue towards the GPU - as deep as kPipeStagingBytes
+      // of pinned memory allow (1080p: 7.3 MB a set, the full depth; 4K: 29 MB a set, the queue shrinks to a few).
+      const size_t per_job = nmb * sizeof(MbInfo) + coef_capacity_ * sizeof(uint32_t) + kMaxSlices * sizeof(SliceParams);
+      const int affordable = static_cast<int>(std::min<size_t>(kPipeStagingBytes / per_job, 4096));
+      jobs_.clear();
+      jobs_.resize(std::max(max_in_flight_ + 8, std::min(max_in_flight_ + pipe_depth_, affordable)));
+    }
     for (Job& j : jobs_) {
       if (hipHostMalloc(reinterpret_cast<void**>(&j.mb_host), nmb * sizeof(MbInfo), hipHostMallocDefault) != hipSuccess ||
           hipHostMalloc(reinterpret_cast<void**>(&j.coef_host), coef_capacity_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
@@ -810,6 +905,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
                       "job-ring waits %lld, surface waits %lld), workers %d\n", lanes_.empty() ? -1 : lanes_[0],
               (long long)counters_.samples_fed, (counters_.entropy_ns + counters_.stall_ns) / 1e9, counters_.stall_ns / 1e9,
               (long long)dbg_motion_waits_, (long long)dbg_job_waits_, (long long)dbg_busy_waits_, num_workers_);
+    if (getenv("HWANG_EXEC_DEBUG") && num_workers_) {
+      int64_t ps[6];
+      h264::pipe_debug_stats(ps);
+      fprintf(stderr, "[decoder lane %d] process-wide: parser waited %.3f s for room in the window, %.3f s for a surface; workers "
+                      "%.3f s on slice data of %lld pictures, %.3f s in the hand-over\n", lanes_.empty() ? -1 : lanes_[0], ps[0] / 1e9,
+              ps[1] / 1e9, ps[2] / 1e9, (long long)ps[4], ps[3] / 1e9);
+    }
     if (getenv("HWANG_EXEC_DEBUG") && dbg_none_ready_)
       fprintf(stderr, "[decoder lane %d] no surface ready %lld times; then on average %.1f held by the parser, %.1f by the "
                       "output queue, %.1f free but still in use on the GPU\n", lanes_.empty() ? -1 : lanes_[0],
@@ -820,6 +922,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
                       "with %.1f submissions pending in all\n", lanes_.empty() ? -1 : lanes_[0],
               1.0 * dbg_unsettled_motion_ / dbg_none_ready_, 1.0 * dbg_unsettled_busy_ / dbg_none_ready_,
               1.0 * dbg_pending_lanes_ / dbg_none_ready_, 1.0 * dbg_pending_total_ / dbg_none_ready_);
+    stop_copiers();
     if (exec_ && exec_->stopped()) {
       // Destroyed after hwang_shutdown() (interpreter exit destroys module-level
       // objects after its atexit handlers): the streams are gone and the HIP
@@ -941,25 +1044,23 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   // A bounce buffer whose previous copy-out has been delivered.
   Result acquire_bounce(size_t need, int* out) {
+    std::unique_lock<std::mutex> lk(out_mu_);
     const int bi = bounce_cursor_;
     Bounce& b = bounce_[bi];
     bounce_cursor_ = (bounce_cursor_ + 1) % static_cast<int>(bounce_.size());
-    {
+    if (b.dst) {
       // the ring wrapped: this buffer's conversion has to be submitted (it may wait for its picture), then to land,
-      // then the frame is delivered
-      std::unique_lock<std::mutex> lk(out_mu_);
-      if (b.dst) {
-        out_cv_.wait(lk, [&] { return b.queued || !b.dst; });
-        if (b.dst) {
-          const Stamp st = b.stamp;
-          lk.unlock();
-          HWANG_RETURN_ON_ERROR(wait_result(st));
-          lk.lock();
-          if (b.dst) std::memcpy(b.dst, b.host, b.size);
-          b.dst = nullptr;
-        }
-      }
+      // then the frame is delivered - by a copier thread, or here when none has picked it up
+      out_cv_.wait(lk, [&] { return b.queued || !b.dst; });
+      if (b.dst && !b.copying) copy_out(lk, bi);
+      out_cv_.wait(lk, [&] { return !b.dst; });
     }
+    if (!copy_error_.empty()) {
+      Result r(false, "AMDVideoDecoder: " + copy_error_);
+      copy_error_.clear();
+      return r;
+    }
+    lk.unlock();
     if (b.capacity < need) {
       if (b.host) (void)hipHostFree(b.host);
       if (b.dev) (void)hipFree(b.dev);
@@ -978,7 +1079,12 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   amd::GpuExecutor* exec_ = nullptr;
   const int num_workers_;       // entropy workers (0: slice data is decoded inside feed())
   int max_in_flight_ = 0;       // pictures whose slice data may be with the workers at a time
+  const bool host_mv_ = getenv("HWANG_HOST_MV") != nullptr;  // experiment: P vectors derived on the host
+  int pipe_depth_ = 0;          // ... and how many more may be queued towards the GPU (fewer when the staging budget says so)
   std::unique_ptr<h264::WorkerPool> pool_;
+  std::vector<std::thread> copiers_;
+  bool copiers_stop_ = false;   // (out_mu_)
+  std::string copy_error_;      // (out_mu_) a conversion that failed under a copier; reported by the next get_frame
   std::vector<int> lanes_;      // executor lanes; one without workers, kPipeLanes with
   int cur_lane_ = 0;            // index into lanes_: where the current interval's pictures go
   uint64_t use_order_ = 0;      // (out_mu_)

@@ -118,6 +118,7 @@ bool GpuExecutor::start(std::string* error) {
   if (const char* e = getenv("HWANG_HEAVY_ENGINES")) heavy_engines_ = std::max(1, std::min(kHeavyEngines, atoi(e)));
   if (const char* e = getenv("HWANG_HEAVY_INFLIGHT")) heavy_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
   if (const char* e = getenv("HWANG_LIGHT_INFLIGHT")) light_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
+  if (const char* e = getenv("HWANG_LIGHT_ENGINES")) light_engines_ = std::max(1, std::min(1 + kExtraLightEngines, atoi(e)));
   if (const char* e = getenv("HWANG_PRESTAGE")) prestage_ = atoi(e) != 0;
   const char* mode = getenv("HWANG_COMPLETION");
   use_hostfunc_ = mode && std::string(mode) == "hostfunc";
@@ -187,7 +188,7 @@ void GpuExecutor::stop() {
 }
 
 int GpuExecutor::register_lane(int light_group) {
-  const int g = light_group % (1 + kExtraLightEngines);
+  const int g = light_group % light_engines_;
   const int light_engine = g == 0 ? 0 : kHeavyEngines + g;
   std::lock_guard<std::mutex> lk(mu_);
   for (size_t i = 0; i < lanes_.size(); ++i)
@@ -254,6 +255,11 @@ bool GpuExecutor::stopped() {
 uint64_t GpuExecutor::completed(int lane) {
   std::lock_guard<std::mutex> lk(mu_);
   return lanes_[lane].completed;
+}
+
+void GpuExecutor::completed(const int* lanes, int n, uint64_t* out) {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (int i = 0; i < n; ++i) out[i] = lanes_[lanes[i]].completed;
 }
 
 bool GpuExecutor::wait(int lane, uint64_t seq, std::string* error) {

@@ -94,6 +94,7 @@ class GpuExecutor {
   bool stopped();
   // How many of the lane's submissions have finished (non-blocking).
   uint64_t completed(int lane);
+  void completed(const int* lanes, int n, uint64_t* out);  // several lanes under one lock
   // Blocks until the lane's submissions up to `seq` have finished on the GPU.
   bool wait(int lane, uint64_t seq, std::string* error);
 
@@ -215,6 +216,7 @@ class GpuExecutor {
   int heavy_engines_ = 1;
   int heavy_inflight_ = 1;
   int light_inflight_ = 1;
+  int light_engines_ = 4;  // light engines that lanes are dealt to (HWANG_LIGHT_ENGINES, up to 1 + kExtraLightEngines)
   uint32_t next_ticket_ = 0;
   int total_inflight_ = 0;
   bool use_hostfunc_ = false;

@@ -5,6 +5,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -2183,6 +2185,29 @@ struct SliceData {
 };
 
 // One picture on its way through the entropy workers.
+// Emulation prevention bytes out of src[i0 .. n) (what lies before i0 has been dealt with), appended at out + o; returns
+// the new length.  A 0x03 is dropped when the two bytes before it - in the escaped stream - are zero; everything
+// between two 0x03 bytes moves with memcpy (they are ~256 bytes apart on average).
+size_t unescape_span(const uint8_t* src, size_t n, size_t i0, uint8_t* out, size_t o) {
+  size_t i = i0;
+  while (i < n) {
+    const uint8_t* p = static_cast<const uint8_t*>(memchr(src + i, 3, n - i));
+    const size_t j = p ? static_cast<size_t>(p - src) : n;
+    memcpy(out + o, src + i, j - i);
+    o += j - i;
+    if (!p) break;
+    if (!(j >= 2 && src[j - 1] == 0 && src[j - 2] == 0)) out[o++] = 3;
+    i = j + 1;
+  }
+  return o;
+}
+
+// Where the pipeline's threads spend their time (process-wide, nanoseconds; read by pipe_debug_stats()).
+std::atomic<int64_t> g_ns_room{0}, g_ns_surface{0}, g_ns_worker_busy{0}, g_ns_handover{0}, g_n_tasks{0};
+inline int64_t now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 struct PicTask {
   std::shared_ptr<PicData> cur;
   std::vector<std::shared_ptr<PicData>> keep;  // every picture a slice of this one refers to
@@ -2191,8 +2216,8 @@ struct PicTask {
   struct Slice {
     SliceHdr hdr;
     Pps pps;
-    std::vector<uint8_t> rbsp;
-    int pos = 0, size_bits = 0, index = 0;
+    std::vector<uint8_t> raw;  // the NAL unit's payload as it came (escaped): the worker removes the emulation prevention bytes
+    int pos = 0, index = 0;    // pos: first bit of the slice data in the RBSP
   };
   std::deque<Slice> slices;
   PicDone done;
@@ -2204,6 +2229,15 @@ struct PicTask {
 };
 
 }  // namespace
+
+void pipe_debug_stats(int64_t out[6]) {
+  out[0] = g_ns_room.load();
+  out[1] = g_ns_surface.load();
+  out[2] = g_ns_worker_busy.load();
+  out[3] = g_ns_handover.load();
+  out[4] = g_n_tasks.load();
+  out[5] = 0;
+}
 
 // ===========================================================================
 struct WorkerPool::State {
@@ -2337,7 +2371,10 @@ struct Parser::Impl {
   }
   bool pipe_wait_for_room() {
     std::unique_lock<std::mutex> lk(pipe_mu);
+    if (static_cast<int>(inflight.size()) < max_in_flight) return true;
+    const int64_t t0 = now_ns();
     pipe_cv.wait(lk, [&] { return static_cast<int>(inflight.size()) < max_in_flight; });
+    g_ns_room += now_ns() - t0;
     return true;
   }
   // waits until one picture fewer is in flight; false if none is
@@ -2345,7 +2382,9 @@ struct Parser::Impl {
     std::unique_lock<std::mutex> lk(pipe_mu);
     const size_t n = inflight.size();
     if (n == 0) return false;
+    const int64_t t0 = now_ns();
     pipe_cv.wait(lk, [&] { return inflight.size() < n; });
+    g_ns_surface += now_ns() - t0;
     return true;
   }
   // Nothing in flight and no worker inside hand_over any more (the destructor relies on the second part: a worker
@@ -2368,10 +2407,8 @@ struct Parser::Impl {
     PicTask::Slice& s = building->slices.back();
     s.hdr = sl;
     s.pps = *apps;
-    const size_t nbytes = static_cast<size_t>((b.size_bits + 7) >> 3);
-    s.rbsp.assign(rbsp.begin(), rbsp.begin() + std::min(rbsp.size(), nbytes + 8));  // unescape() pads with 8 zero bytes
+    s.raw.assign(ue.src, ue.src + ue.n);  // (the caller's sample need not outlive feed())
     s.pos = b.pos;
-    s.size_bits = b.size_bits;
     s.index = slice_index;
     for (int l = 0; l < 2; ++l)
       for (int i = 0; i < sl.num_ref_idx[l]; ++i)
@@ -2396,12 +2433,17 @@ struct Parser::Impl {
     static thread_local std::unique_ptr<SliceData> tls;
     if (!tls) tls.reset(new SliceData());
     SliceData& w = *tls;
+    const int64_t t_begin = now_ns();
     w.begin_picture(&t->sps, t->cur.get(), t->bufs);
     bool ok = true;
+    static thread_local std::vector<uint8_t> rbsp_tls;
     for (PicTask::Slice& s : t->slices) {
+      rbsp_tls.resize(s.raw.size() + 8);
+      const size_t rn = unescape_span(s.raw.data(), s.raw.size(), 0, rbsp_tls.data(), 0);
+      memset(rbsp_tls.data() + rn, 0, 8);
       Bits b;
-      b.buf = s.rbsp.data();
-      b.size_bits = s.size_bits;
+      b.buf = rbsp_tls.data();
+      b.size_bits = static_cast<int>(rn) * 8;
       b.pos = s.pos;
       if (!w.decode_slice(s.hdr, &s.pps, s.index, b)) {
         ok = false;
@@ -2419,7 +2461,11 @@ struct Parser::Impl {
       t->cur->parsed = true;
     }
     t->cur->cv.notify_all();
+    const int64_t t_parsed = now_ns();
+    g_ns_worker_busy += t_parsed - t_begin;
+    ++g_n_tasks;
     hand_over(t);
+    g_ns_handover += now_ns() - t_parsed;
   }
   // Pictures go to the sink in decoding order: whoever finishes the oldest one
   // in flight hands over it and every finished one behind it.
@@ -2496,6 +2542,15 @@ struct Parser::Impl {
     ue.zeros = zeros;
     memset(out + o, 0, 8);
     return static_cast<int>(o);
+  }
+
+  // the rest of the unit at once
+  int unescape_rest() {
+    uint8_t* out = rbsp.data();
+    ue.o = unescape_span(ue.src, ue.n, ue.i, out, ue.o);
+    ue.i = ue.n;
+    memset(out + ue.o, 0, 8);
+    return static_cast<int>(ue.o);
   }
 
   // -------------------------------------------------------- parameter sets
@@ -3331,13 +3386,13 @@ struct Parser::Impl {
     const int r = parse_slice_header(b, ref_idc, type);
     if (r < 0 || !err->empty()) return false;
     if (r > 0) return true;
-    if (ue.i < ue.n) {  // the slice data
-      rn = unescape_upto(ue.n);
-      b.size_bits = rn * 8;
-    }
-    if (workers) {
+    if (workers) {  // (a worker unescapes the whole unit; the header's bit position is the same there)
       pipe_add_slice(b);
       return true;
+    }
+    if (ue.i < ue.n) {  // the slice data
+      rn = unescape_rest();
+      b.size_bits = rn * 8;
     }
     if (!sd.decode_slice(sl, apps, slice_index, b)) return fail(sd.err.c_str());
     return true;

@@ -121,6 +121,10 @@ class WorkerPool {
   State* state_;
 };
 
+// Development aid (HWANG_EXEC_DEBUG): process-wide nanoseconds the parser threads waited for room in the window
+// [0] / for a surface [1], the workers spent on slice data [2] and inside the in-order hand-over [3]; [4] pictures.
+void pipe_debug_stats(int64_t out[6]);
+
 class Parser {
  public:
   // Serial: slice data is decoded inside decode().  With `workers` the calling

@@ -179,6 +179,12 @@ static void memory_part(int argc, char** argv) {
         // pictures behind a failed one still decode against whatever the failed one left behind
         int64_t out[9];
         char err[256];
+        // (the probe takes the samples on trust, like VideoDecoderInterface::feed: a corrupted sample table that
+        // points outside the file is the caller's to refuse - DecoderAutomata does - and is not fed here)
+        bool inside = true;
+        for (uint64_t f = 0; f < idx.frames(); ++f)
+          inside &= idx.sample_offsets()[f] <= data.size() && idx.sample_sizes()[f] <= data.size() - idx.sample_offsets()[f];
+        if (inside)
         for (int workers : {2, 4})
           (void)hwang_h264_probe_workers(idx.metadata_bytes().data(), idx.metadata_bytes().size(), data.data(),
                                          idx.sample_offsets().data(), idx.sample_sizes().data(), idx.frames(), nullptr, 0, nullptr, 0,
