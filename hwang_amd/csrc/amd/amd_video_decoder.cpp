@@ -292,7 +292,15 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       out->no_surface = true;
       return false;
     }
-    if (!alloc_surface(slot, error)) return false;
+    {
+      const bool fresh_surface = !surf_[slot].dev;
+      const auto a0 = std::chrono::steady_clock::now();
+      if (!alloc_surface(slot, error)) return false;
+      if (fresh_surface) {
+        dbg_alloc_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - a0).count();
+        ++dbg_allocs_;
+      }
+    }
     struct StallTimer {
       BackendCounters& c;
       std::chrono::steady_clock::time_point t0;
@@ -905,6 +913,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
                       "job-ring waits %lld, surface waits %lld), workers %d\n", lanes_.empty() ? -1 : lanes_[0],
               (long long)counters_.samples_fed, (counters_.entropy_ns + counters_.stall_ns) / 1e9, counters_.stall_ns / 1e9,
               (long long)dbg_motion_waits_, (long long)dbg_job_waits_, (long long)dbg_busy_waits_, num_workers_);
+    if (getenv("HWANG_EXEC_DEBUG"))
+      fprintf(stderr, "[decoder lane %d] %lld surfaces allocated in %.3f s; the consumer waited %.3f s for a bounce buffer\n",
+              lanes_.empty() ? -1 : lanes_[0], (long long)dbg_allocs_, dbg_alloc_ns_ / 1e9, dbg_bounce_wait_ns_ / 1e9);
     if (getenv("HWANG_EXEC_DEBUG") && num_workers_) {
       int64_t ps[6];
       h264::pipe_debug_stats(ps);
@@ -1051,9 +1062,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (b.dst) {
       // the ring wrapped: this buffer's conversion has to be submitted (it may wait for its picture), then to land,
       // then the frame is delivered - by a copier thread, or here when none has picked it up
+      const auto w0 = std::chrono::steady_clock::now();
       out_cv_.wait(lk, [&] { return b.queued || !b.dst; });
       if (b.dst && !b.copying) copy_out(lk, bi);
       out_cv_.wait(lk, [&] { return !b.dst; });
+      dbg_bounce_wait_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
     }
     if (!copy_error_.empty()) {
       Result r(false, "AMDVideoDecoder: " + copy_error_);
@@ -1079,6 +1092,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   amd::GpuExecutor* exec_ = nullptr;
   const int num_workers_;       // entropy workers (0: slice data is decoded inside feed())
   int max_in_flight_ = 0;       // pictures whose slice data may be with the workers at a time
+  int64_t dbg_alloc_ns_ = 0, dbg_allocs_ = 0, dbg_bounce_wait_ns_ = 0;  // HWANG_EXEC_DEBUG
   const bool host_mv_ = getenv("HWANG_HOST_MV") != nullptr;  // experiment: P vectors derived on the host
   int pipe_depth_ = 0;          // ... and how many more may be queued towards the GPU (fewer when the staging budget says so)
   std::unique_ptr<h264::WorkerPool> pool_;

@@ -17,8 +17,12 @@
 // GIL while the backend works.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
-#include <cstdlib>
 #include <pybind11/stl.h>
+
+#include <stdlib.h>
+#include <sys/mman.h>
+
+#include <cstdlib>
 
 #include "../decoder_automata.h"
 #include "../mp4_index_creator.h"
@@ -101,7 +105,19 @@ std::vector<py::array_t<uint8_t>> automata_get_frames(DecoderAutomata& dec, cons
   // One buffer for the frames of the call, NOT zero-filled: a std::vector would touch every page first (gigabytes
   // for a few hundred 1080p frames, a second of memset before the first sample is fed); every byte handed out below is
   // written by get_frames, and on failure nothing is handed out.
-  uint8_t* storage = static_cast<uint8_t*>(std::malloc(std::max<size_t>(1, frame_size * num_frames)));
+  // Large answers ask for transparent huge pages (where the kernel grants them on request): the frames land in pages
+  // nobody has touched, and a 2 MB fault per 2 MB beats 512 faults of 4 KB under the copier threads.
+  const size_t bytes = std::max<size_t>(1, frame_size * num_frames);
+  uint8_t* storage = nullptr;
+  constexpr size_t kHuge = size_t(2) << 20;
+  if (bytes >= 4 * kHuge) {
+    void* p = nullptr;
+    if (posix_memalign(&p, kHuge, bytes) == 0) {
+      storage = static_cast<uint8_t*>(p);
+      (void)madvise(p, bytes, MADV_HUGEPAGE);
+    }
+  }
+  if (!storage) storage = static_cast<uint8_t*>(std::malloc(bytes));
   if (!storage) throw std::bad_alloc();
   py::capsule owner(storage, [](void* p) { std::free(p); });
   Result r;

@@ -24,6 +24,21 @@ path = bench.make_corpus(frames)
 idx = hwang_amd.index_video(path)
 ridx = hwang.VideoIndex.deserialize(idx.serialize())
 rows = sorted(np.random.default_rng(bench.SEED).choice(idx.frames(), max(1, round(0.01 * idx.frames())), replace=False).tolist())[:nrows]
+# what else the bench process has going when it runs this path (value_reference_api): a torch HIP context (torch=1),
+# a BatchRetriever that has just served the request (retr=1)
+if int(args.get("torch", 0)) or int(args.get("retr", 0)):
+    import torch
+    torch.cuda.synchronize()
+if int(args.get("retr", 0)):
+    from hwang_amd import BatchRetriever
+    br = BatchRetriever(device_ids=[0], num_lanes=int(args.get("lanes", 48)))
+    fobj = open(path, "rb")
+    out_t = torch.empty((len(rows), bench.HEIGHT, bench.WIDTH, 3), dtype=torch.uint8, device="cuda:0")
+    for _ in range(2):
+        br.retrieve_into([(idx, fobj, rows, out_t.data_ptr(), out_t.numel())])
+    torch.cuda.synchronize()
+    if int(args.get("retr", 0)) == 2:   # ... and is gone again
+        del br
 for t in threads:
     dec = hwang.Decoder(path, video_index=ridx, device_type=hwang.DeviceType.GPU, num_devices=t, interval_group_bytes=group)
     dec.retrieve(rows[:4])
