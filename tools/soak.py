@@ -57,5 +57,23 @@ for lanes in (48, 64, 24):
             print("MISMATCH lanes %d round %d: frames %s" % (lanes, r, np.nonzero(s != ref_s)[0][:10].tolist()))
     print("lanes %d: %d rounds done" % (lanes, ROUNDS))
     del dec
+# the drop-in path: ONE DecoderAutomata, ONE backend with entropy workers (deferred conversions, copier threads, 16
+# executor lanes) - frames come back in host memory and must be the same bytes
+if int(os.environ.get("WORKERS", 1)):
+    import hwang
+    ridx = hwang.VideoIndex.deserialize(idx.serialize())
+    ref_host = out.cpu().numpy()   # the last round above was identical to the reference, or counted as bad
+    for workers in (16, 4):
+        rdec = hwang.Decoder(path, video_index=ridx, device_type=hwang.DeviceType.GPU, num_devices=workers,
+                             interval_group_bytes=int(os.environ.get("GROUP_MB", 16)) << 20)
+        for r in range(ROUNDS):
+            frames = rdec.retrieve(rows)
+            wrong = [i for i, f in enumerate(frames) if not np.array_equal(f, ref_host[i])]
+            if wrong:
+                bad += 1
+                print("MISMATCH workers %d round %d: frames %s" % (workers, r, wrong[:10]))
+            del frames
+        print("workers %d: %d rounds done" % (workers, ROUNDS))
+        del rdec
 print("soak: %s" % ("OK, every round identical" if bad == 0 else "%d rounds differ" % bad))
 sys.exit(1 if bad else 0)
