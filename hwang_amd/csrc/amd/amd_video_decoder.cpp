@@ -150,7 +150,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // A sync sample starts a closed GOP: nothing behind it refers to anything before it, so its pictures may go to
     // another executor lane and run beside the previous GOP's (an interval is often several byte-adjacent GOPs: on
     // one lane that is a chain of 40-60 dependent pictures at ~2 ms each).
-    if (keyframe) cur_lane_ = (cur_lane_ + 1) % static_cast<int>(lanes_.size());
+    if (keyframe || rotate_always_) cur_lane_ = (cur_lane_ + 1) % static_cast<int>(lanes_.size());
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t stall0 = counters_.stall_ns;
     const bool ok = parser_->decode(encoded_buffer, encoded_size);
@@ -1093,6 +1093,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   const int num_workers_;       // entropy workers (0: slice data is decoded inside feed())
   int max_in_flight_ = 0;       // pictures whose slice data may be with the workers at a time
   int64_t dbg_alloc_ns_ = 0, dbg_allocs_ = 0, dbg_bounce_wait_ns_ = 0;  // HWANG_EXEC_DEBUG
+  // test hook (tests/test_gpu_workers.py): the lanes rotate at EVERY sample, so every picture's references were
+  // written on another lane - what a stream with open GOPs does at its sync samples, all the time
+  const bool rotate_always_ = getenv("HWANG_TEST_ROTATE_LANES") != nullptr;
   const bool host_mv_ = getenv("HWANG_HOST_MV") != nullptr;  // experiment: P vectors derived on the host
   int pipe_depth_ = 0;          // ... and how many more may be queued towards the GPU (fewer when the staging budget says so)
   std::unique_ptr<h264::WorkerPool> pool_;

@@ -86,6 +86,27 @@ def test_workers_at_1080p_many_intervals(ref_api, oracle, gpu, tmp_path):
         assert md5s(dec.retrieve(rows)) == md5s(hwang_amd.Decoder(path, video_index=idx, num_lanes=4).retrieve(rows))
 
 
+def test_references_written_on_another_lane_are_waited_for(ref_api, oracle, gpu, tmp_path, monkeypatch):
+    """A decoder with workers moves to the next executor lane at every sync sample; the executor orders work only within
+    a lane.  With open GOPs a picture behind a sync sample may refer to the GOP before it - to a surface another lane
+    wrote.  The corpus encoder only writes closed GOPs, so the test hook rotates the lanes at EVERY sample: every P and
+    B picture then reads references that a different lane reconstructs, and must still come out bit-exact."""
+    monkeypatch.setenv("HWANG_TEST_ROTATE_LANES", "1")
+    for name, kw in (("ibp", dict(frames=72, gop=24, bframes=2, refs=3)),
+                     ("pyramid", dict(frames=68, gop=17, bframes=3, refs=4, bpyramid=1, temporal_direct=1)),
+                     ("p_long_refs", dict(frames=60, gop=30, bframes=0, refs=4, mmco=1, rplm=1))):
+        path = str(tmp_path / (name + "_rot.mp4"))
+        gold = make_clip(path, **kw)
+        rows = list(range(len(gold)))
+        want = [oracle.i420_to_rgb(gold[r], 320, 240) for r in rows]
+        for rounds in range(3):
+            dec = ref_api.Decoder(path, device_type=ref_api.DeviceType.GPU, num_devices=8)
+            got = dec.retrieve(rows)
+            for k, r in enumerate(rows):
+                assert np.array_equal(got[k], want[k]), "%s: row %d (round %d)" % (name, r, rounds)
+            del dec
+
+
 def test_workers_report_a_corrupt_picture(ref_api, gpu, tmp_path):
     """A picture whose slice data fails with the workers: the error surfaces from retrieve (latched at a later feed or
     at the flush), nothing hangs, the decoder object can be used again."""
