@@ -62,6 +62,9 @@ class Decoder(object):
         keyframes = index.keyframe_indices()
         end_of_file = offsets[-1] + sizes[-1]
         group, group_frames, group_bytes = [], 0, 0
+        # the first group is a quarter of the bound (decoding starts while the helper thread reads on), the ones behind
+        # it twice the bound (each group ends with the GPU drained: fewer of them, fewer bubbles)
+        limit = self._group_bytes // 4
         for (first, last), wanted in slice_into_video_intervals(index, rows):
             if not wanted:   # (the planner's answer to an empty row list: one interval without frames)
                 continue
@@ -69,9 +72,10 @@ class Decoder(object):
             group.append(segment)
             group_frames += len(wanted)
             group_bytes += nbytes
-            if group_bytes >= self._group_bytes:
+            if group_bytes >= limit:
                 yield group, group_frames
                 group, group_frames, group_bytes = [], 0, 0
+                limit = self._group_bytes * 2
         if group:
             yield group, group_frames
 
@@ -110,7 +114,7 @@ class Decoder(object):
                 if isinstance(item, BaseException):
                     raise item
                 group, nframes = item
-                self._decoder.initialize(group, extradata)
+                self._decoder.initialize(group, extradata, True)   # (consume: the group's EncodedData are ours to give)
                 frames += self._decoder.get_frames(self.video_index, nframes)
         finally:
             stop.set()

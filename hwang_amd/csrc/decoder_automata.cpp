@@ -73,6 +73,11 @@ void DecoderAutomata::drain_locked(std::unique_lock<std::mutex>& lk) {
 
 Result DecoderAutomata::initialize(const std::vector<EncodedData>& encoded_data,
                                    const std::vector<uint8_t>& extradata) {
+  return initialize(std::vector<EncodedData>(encoded_data), extradata);
+}
+
+Result DecoderAutomata::initialize(std::vector<EncodedData>&& encoded_data,
+                                   const std::vector<uint8_t>& extradata) {
   if (encoded_data.empty()) {
     return Result(false, "DecoderAutomata::initialize: no encoded data");
   }
@@ -99,9 +104,9 @@ Result DecoderAutomata::initialize(const std::vector<EncodedData>& encoded_data,
   }
   drain_locked(lk);
 
-  segments_ = encoded_data;
-  frame_size_ = static_cast<size_t>(encoded_data[0].width) *
-                encoded_data[0].height * 3;
+  segments_ = std::move(encoded_data);
+  frame_size_ = static_cast<size_t>(segments_[0].width) *
+                segments_[0].height * 3;
   seg_complete_.assign(segments_.size(), 0);
   feed_seg_ = 0;
   feed_sample_ = 0;
@@ -115,9 +120,9 @@ Result DecoderAutomata::initialize(const std::vector<EncodedData>& encoded_data,
   failure_ = Result();
 
   VideoDecoderInterface::FrameInfo info;
-  info.width = encoded_data[0].width;
-  info.height = encoded_data[0].height;
-  info.format = encoded_data[0].format;
+  info.width = segments_[0].width;
+  info.height = segments_[0].height;
+  info.format = segments_[0].format;
   lk.unlock();
   return decoder_->configure(info, extradata);
 }

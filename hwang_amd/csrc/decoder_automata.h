@@ -67,6 +67,9 @@ class DecoderAutomata {
 
   Result initialize(const std::vector<EncodedData>& encoded_data,
                     const std::vector<uint8_t>& extradata);
+  // The same, taking the intervals over instead of copying them (not in the reference).
+  Result initialize(std::vector<EncodedData>&& encoded_data,
+                    const std::vector<uint8_t>& extradata);
 
   Result get_frames(uint8_t* buffer, int32_t num_frames);
 

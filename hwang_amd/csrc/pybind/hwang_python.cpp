@@ -83,8 +83,22 @@ std::unique_ptr<DecoderAutomata> make_automata(DeviceHandle handle, int32_t num_
   return std::unique_ptr<DecoderAutomata>(a);
 }
 
-void automata_initialize(DecoderAutomata& dec, const std::vector<DecoderAutomata::EncodedData>& segments,
-                         const py::object& extradata) {
+void automata_initialize(DecoderAutomata& dec, const py::list& segment_list, const py::object& extradata, bool consume) {
+  // The Python objects keep their data (the reference's API leaves them with the caller); the one copy made here is
+  // handed on to the automata, which used to copy it once more.  consume=True (not in the reference; hwang.Decoder
+  // builds its EncodedData per call and drops them) hands the encoded bytes over instead: the objects are left
+  // without them.
+  std::vector<DecoderAutomata::EncodedData> segments;
+  segments.reserve(segment_list.size());
+  for (const py::handle& h : segment_list) {
+    DecoderAutomata::EncodedData& e = h.cast<DecoderAutomata::EncodedData&>();
+    if (consume) {
+      segments.push_back(std::move(e));
+      e = DecoderAutomata::EncodedData();
+    } else {
+      segments.push_back(e);
+    }
+  }
   std::vector<uint8_t> extra;
   if (py::isinstance<py::bytes>(extradata) || py::isinstance<py::bytearray>(extradata)) {
     const std::string s = py::cast<std::string>(py::bytes(extradata));
@@ -95,7 +109,7 @@ void automata_initialize(DecoderAutomata& dec, const std::vector<DecoderAutomata
   Result r;
   {
     py::gil_scoped_release release;
-    r = dec.initialize(segments, extra);
+    r = dec.initialize(std::move(segments), extra);
   }
   if (!r.ok) throw std::runtime_error(r.message);
 }
@@ -184,7 +198,12 @@ PYBIND11_MODULE(_python, m) {
           [](const DecoderAutomata::EncodedData& d) {
             return py::bytes(reinterpret_cast<const char*>(d.encoded_video.data()), d.encoded_video.size());
           },
-          [](DecoderAutomata::EncodedData& d, const std::string& v) { d.encoded_video.assign(v.begin(), v.end()); })
+          [](DecoderAutomata::EncodedData& d, const py::bytes& v) {  // straight from the bytes object: one copy, not two
+            char* p = nullptr;
+            py::ssize_t n = 0;
+            if (PyBytes_AsStringAndSize(v.ptr(), &p, &n) != 0) throw py::error_already_set();
+            d.encoded_video.assign(reinterpret_cast<const uint8_t*>(p), reinterpret_cast<const uint8_t*>(p) + n);
+          })
       .def_readwrite("width", &DecoderAutomata::EncodedData::width)
       .def_readwrite("height", &DecoderAutomata::EncodedData::height)
       .def_readwrite("format", &DecoderAutomata::EncodedData::format)
@@ -197,7 +216,7 @@ PYBIND11_MODULE(_python, m) {
 
   py::class_<DecoderAutomata>(m, "DecoderAutomata")
       .def(py::init(&make_automata))
-      .def("initialize", &automata_initialize)
+      .def("initialize", &automata_initialize, py::arg("encoded_data"), py::arg("extradata"), py::arg("consume") = false)
       .def("get_frames", &automata_get_frames);
 
   m.def("supported_decoder_types", []() { return VideoDecoderFactory::get_supported_decoder_types(); });
