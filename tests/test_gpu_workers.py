@@ -107,6 +107,34 @@ def test_references_written_on_another_lane_are_waited_for(ref_api, oracle, gpu,
             del dec
 
 
+def test_gpu_fault_with_workers_fails_the_call_and_returns(gpu, tmp_path):
+    """The executor's fault word (a row kernel whose bounded poll expired, HWANG_INJECT_FAULT) on the drop-in path: frames
+    have been fetched before their pictures ran, copier threads are waiting for conversions that will never be good -
+    retrieve() must raise what the executor says and return, not hang and not hand out frames.  (The error is sticky
+    for the process's executor, hence the child process.)"""
+    import os
+    import subprocess
+    import sys
+    from tests.util import ROOT
+    path = str(tmp_path / "fault_workers.mp4")
+    make_clip(path, width=320, height=240, frames=24, gop=6, bframes=2, yuv=False)
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import hwang\n"
+        "dec = hwang.Decoder(%r, device_type=hwang.DeviceType.GPU, num_devices=4)\n"
+        "try:\n"
+        "    frames = dec.retrieve(list(range(24)))\n"
+        "except RuntimeError as e:\n"
+        "    print('RAISED', e)\n"
+        "else:\n"
+        "    print('NO ERROR', len(frames))\n" % (ROOT, path))
+    env = dict(os.environ, HWANG_INJECT_FAULT="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert "RAISED" in r.stdout and "hand-off timed out" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "NO ERROR 24" in r.stdout, r.stdout + r.stderr
+
+
 def test_workers_report_a_corrupt_picture(ref_api, gpu, tmp_path):
     """A picture whose slice data fails with the workers: the error surfaces from retrieve (latched at a later feed or
     at the flush), nothing hangs, the decoder object can be used again."""
