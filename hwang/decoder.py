@@ -88,20 +88,25 @@ class Decoder(object):
         ready = queue.Queue(maxsize=1)
         stop = threading.Event()
 
+        def put(item):
+            # (every hand-over gives way to `stop`: the consumer may have left with an error while the queue is full -
+            # a plain put() of the end marker then blocked forever and retrieve() never returned from its join)
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def produce():
             try:
                 for item in self._groups(rows):
-                    while not stop.is_set():
-                        try:
-                            ready.put(item, timeout=0.1)
-                            break
-                        except queue.Full:
-                            pass
-                    if stop.is_set():
+                    if not put(item):
                         return
-                ready.put(None)
+                put(None)
             except BaseException as e:  # noqa: BLE001  (handed to the caller below)
-                ready.put(e)
+                put(e)
 
         producer = threading.Thread(target=produce, name="hwang-read", daemon=True)
         producer.start()

@@ -107,6 +107,67 @@ def test_references_written_on_another_lane_are_waited_for(ref_api, oracle, gpu,
             del dec
 
 
+FUZZ_TRIALS = int(__import__("os").environ.get("HWANG_FUZZ_TRIALS", "120")) // 2
+FUZZ_CLIPS = [
+    ("plain", dict(frames=24, gop=6, bframes=2, refs=3, slices=2, seed=5)),
+    ("pyramid_mixed", dict(frames=26, gop=13, bframes=3, refs=4, bpyramid=1, mixed_slices=1, slice_mbs=23, multi_pps=2,
+                           temporal_direct=1, implicit_wp=1, seed=6)),
+]
+
+
+@pytest.mark.parametrize("name,kw", FUZZ_CLIPS, ids=[c[0] for c in FUZZ_CLIPS])
+def test_corrupt_streams_through_workers_never_hang(ref_api, oracle, gpu, tmp_path, name, kw):
+    """Bit flips in slice data on the drop-in path with entropy workers: a picture that fails takes its interval with
+    it (frames already fetched are cancelled, copier threads let go), absurd vectors / levels reach the kernels.  Every
+    call returns - with frames or with an error - on ONE decoder object that lives through all of them, and the
+    pristine clip decodes bit-exactly on that same object afterwards."""
+    import hwang_amd
+    path = str(tmp_path / "fzw.mp4")
+    gold = make_clip(path, width=176, height=144, **kw)
+    idx = hwang_amd.index_video(path)
+    nf = idx.frames()
+    data0 = np.fromfile(path, dtype=np.uint8)
+    offs, sizes = idx.sample_offsets(), idx.sample_sizes()
+    rng = np.random.default_rng(13)
+    errors = decoded = 0
+    for trial in range(FUZZ_TRIALS):
+        data = data0.copy()
+        for _ in range(1 + trial % 5):
+            s = int(rng.integers(0, len(offs)))
+            pos = offs[s] + int(rng.integers(6, sizes[s]))
+            data[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = str(tmp_path / ("fzw_%d.mp4" % trial))
+        data.tofile(bad)
+        ridx = ref_api.VideoIndex.deserialize(idx.serialize())
+        dec = ref_api.Decoder(bad, video_index=ridx, device_type=ref_api.DeviceType.GPU, num_devices=4,
+                              interval_group_bytes=(64 << 20) if trial % 2 else 0)
+        trace = __import__("os").environ.get("HWANG_FUZZ_TRACE")
+        if trace:
+            print("trial %d: retrieve" % trial, flush=True)
+        try:
+            out = dec.retrieve(list(range(nf)))
+            assert len(out) == nf
+            decoded += 1
+        except RuntimeError as e:
+            errors += 1
+            if trace:
+                print("trial %d: raised %s; again" % (trial, str(e)[:80]), flush=True)
+            # the same object goes on: whatever the failed call left behind is cleared by the next initialize
+            try:
+                dec.retrieve([0, nf - 1])
+            except RuntimeError:
+                pass
+        if trace:
+            print("trial %d: del" % trial, flush=True)
+        del dec
+        __import__("os").unlink(bad)
+    assert errors + decoded == FUZZ_TRIALS
+    dec = ref_api.Decoder(path, device_type=ref_api.DeviceType.GPU, num_devices=4)
+    got = dec.retrieve(list(range(nf)))
+    for i in range(nf):
+        assert np.array_equal(got[i], oracle.i420_to_rgb(gold[i], 176, 144)), "frame %d after %d errors" % (i, errors)
+
+
 def test_gpu_fault_with_workers_fails_the_call_and_returns(gpu, tmp_path):
     """The executor's fault word (a row kernel whose bounded poll expired, HWANG_INJECT_FAULT) on the drop-in path: frames
     have been fetched before their pictures ran, copier threads are waiting for conversions that will never be good -

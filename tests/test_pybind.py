@@ -93,6 +93,44 @@ def test_reference_retrieve_loop_with_the_stamp_backend(ref_api, tmp_path):
     del dec
     assert struct.unpack("<I", frames[3].tobytes()[:4])[0] == 30
 
+    # An error in the middle of a request (here: at the last group of intervals but one, with the last one already waiting
+    # in the queue) must come out of retrieve() at once: the helper thread that reads ahead is told to stop even while it
+    # is waiting to hand over the end marker (it used to block there on a full queue, and retrieve() hung in its join -
+    # found by the GPU fuzz test).
+    import threading
+    import time
+    for group_bytes in (0, 64):
+        dec = ref_api.Decoder(path, video_index=index, device_type=ref_api.DeviceType.CPU,
+                              decoder_type=ref_api.VideoDecoderType(100), interval_group_bytes=group_bytes)
+        inner, calls = dec._decoder, [0]
+        ngroups = sum(1 for _ in dec._groups(rows))
+        assert ngroups >= 3
+
+        class FailsLater(object):
+            def initialize(self, *a):
+                return inner.initialize(*a)
+
+            def get_frames(self, *a):
+                calls[0] += 1
+                if calls[0] >= ngroups - 1:
+                    time.sleep(0.3)   # (the helper thread gets to the end of the plan meanwhile)
+                    raise RuntimeError("decoder says no")
+                return inner.get_frames(*a)
+        dec._decoder = FailsLater()
+        result = []
+
+        def run():
+            try:
+                dec.retrieve(rows)
+                result.append("returned")
+            except RuntimeError as e:
+                result.append(str(e))
+        t = threading.Thread(target=run, daemon=True)
+        t.start()
+        t.join(20)
+        assert not t.is_alive(), "retrieve() hangs after an error (interval_group_bytes=%d)" % group_bytes
+        assert result == ["decoder says no"]
+
 
 @pytest.mark.gpu
 def test_reference_decoder_selects_the_amd_backend(ref_api, oracle, tmp_path):
