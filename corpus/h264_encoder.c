@@ -48,6 +48,11 @@ typedef struct {
                         * QP <= 3 - now and then a level so large that CAVLC needs level_prefix >= 16 */
   int wild_mv;         /* now and then a P macroblock takes a vector hundreds of samples long, mostly to somewhere outside the
                           reference picture: long mvd codes, prediction from clamped coordinates only */
+  int global_mv;       /* every P picture is its reference shifted by ONE vector (all macroblocks 16x16 / P_Skip, reference 0,
+                          nothing coded): what such a picture must decode to follows from the previous picture and the
+                          vector alone - tests/test_inter_independent.py computes it without a decoder.  The vector runs
+                          through all sixteen quarter-sample positions, both parities of the chroma eighths, and far outside
+                          the picture (global_mv_of) */
   int qp_swing;        /* every few macroblocks the QP jumps anywhere in 0..51: large mb_qp_delta values, incl. the ones that
                           only fit the -26..25 range by wrapping around 52 */
   int slice_mbs;       /* > 0: a new slice every so many macroblocks - boundaries in the middle of rows (overrides --slices) */
@@ -929,6 +934,17 @@ static void copy_motion_from_state(const H264Oracle* d, MB* p) {
   memcpy(p->ref, d->mb.ref, sizeof(p->ref));
 }
 
+/* --global-mv: the one vector of P picture number k (quarter samples).  tests/test_inter_independent.py restates this
+ * function; keep the two in step. */
+static void global_mv_of(int k, int width, int height, int* mvx, int* mvy) {
+  const int fx = k & 3, fy = (k >> 2) & 3;                 /* all 16 fractional positions over 16 pictures */
+  int ix = ((k * 5) % 9) - 4, iy = ((k * 7) % 5) - 2;      /* whole samples, both parities (chroma eighths) */
+  if (k % 6 == 5) ix = (k % 12 == 5 ? -1 : 1) * (width / 2 + 3 * k);   /* well outside, left / right */
+  if (k % 7 == 6) iy = (k % 14 == 6 ? -1 : 1) * (height / 2 + 2 * k);  /* ... above / below */
+  *mvx = ix * 4 + fx;
+  *mvy = iy * 4 + fy;
+}
+
 /* P macroblock */
 static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 */) {
   H264Oracle* d = e->d;
@@ -938,6 +954,19 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
   const int nref = d->sl.num_ref_idx[0];
   int skip_mv[2];
   h264i_pskip_mv(d, skip_mv);
+
+  if (e->cfg->global_mv) {
+    int gx, gy;
+    global_mv_of(e->frame_abs, e->cfg->width, e->cfg->height, &gx, &gy);
+    p->kind = MB_INTER;
+    set_all_motion(&d->mb, 0, 0, gx, gy);
+    copy_motion_from_state(d, p);
+    p->mb_type_raw = 0;
+    h264i_inter_pred_mb(d);
+    p->qp = qp; /* (plan is zeroed: no coefficients, cbp 0) */
+    if (gx == skip_mv[0] && gy == skip_mv[1]) plan->is_skip = 1;
+    return;
+  }
 
   /* candidates: (ref, mvx, mvy) */
   int cand[40][3], nc = 0;
@@ -2198,6 +2227,7 @@ int main(int argc, char** argv) {
   c.no_stss = arg_int(argc, argv, "--no-stss", 0);
   c.chunk_samples = arg_int(argc, argv, "--chunk-samples", 0);
   c.wild_mv = arg_int(argc, argv, "--wild-mv", 0);
+  c.global_mv = arg_int(argc, argv, "--global-mv", 0);
   c.qp_swing = arg_int(argc, argv, "--qp-swing", 0);
   c.slice_mbs = arg_int(argc, argv, "--slice-mbs", 0);
   c.mixed_slices = arg_int(argc, argv, "--mixed-slices", 0);

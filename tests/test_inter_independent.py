@@ -1,0 +1,138 @@
+"""Inter prediction checked against a restatement that shares nothing with the oracle or the kernels.
+
+The corpus encoder's `--global-mv` mode writes P pictures in which every macroblock is one 16x16 partition (or P_Skip)
+with reference 0 and ONE vector per picture, and codes no residual; no edge gets a boundary strength, so the in-loop
+filter does nothing.  Such a picture must decode to the previous picture shifted by that vector: the sample
+interpolation of 8.4.2.2.1 (luma, all sixteen quarter-sample positions) and 8.4.2.2.2 (chroma, eighths), with the
+reference coordinates clamped to the picture (8.4.2.2).  Here that is computed for whole pictures with numpy, straight
+from the clauses' equations, and compared with
+
+  * the oracle's decode of the stream (CPU) - a third statement of the filters beside oracle/h264_recon.c and
+    tests/fixtures/inter_filters_host.cpp, written against the decoder's OUTPUT rather than its code, and
+  * the HIP path's decode (GPU): parser -> k_mv (the vectors travel as differences) -> k_inter, including vectors that
+    point far outside the picture.
+"""
+import numpy as np
+import pytest
+
+from tests.corpus_util import make_clip
+
+SIZES = [(64, 48), (176, 144)]
+FRAMES = 36
+
+
+def global_mv_of(k, width, height):
+    """corpus/h264_encoder.c: global_mv_of (quarter samples)."""
+    fx, fy = k & 3, (k >> 2) & 3
+    ix, iy = ((k * 5) % 9) - 4, ((k * 7) % 5) - 2
+    if k % 6 == 5:
+        ix = (-1 if k % 12 == 5 else 1) * (width // 2 + 3 * k)
+    if k % 7 == 6:
+        iy = (-1 if k % 14 == 6 else 1) * (height // 2 + 2 * k)
+    return ix * 4 + fx, iy * 4 + fy
+
+
+def clip8(a):
+    return np.clip(a, 0, 255)
+
+
+def shift_luma(ref, mvx, mvy):
+    """8.4.2.2.1 for a whole picture: predPartL[x, y] for every (x, y), one vector."""
+    h, w = ref.shape
+    ox, oy, fx, fy = mvx >> 2, mvy >> 2, mvx & 3, mvy & 3
+    m = max(abs(ox), abs(oy)) + 8
+    r = np.pad(ref.astype(np.int64), m, mode="edge")   # = Clip3 of the reference coordinates (8-230, 8-231)
+
+    def G(dx, dy):   # integer sample at (x + ox + dx, y + oy + dy)
+        return r[m + oy + dy:m + oy + dy + h, m + ox + dx:m + ox + dx + w]
+
+    def tap(f, dx, dy, horizontal):   # the six-tap filter (1, -5, 20, 20, -5, 1) over f along one axis
+        o = [(-2, 0), (-1, 0), (0, 0), (1, 0), (2, 0), (3, 0)] if horizontal else [(0, -2), (0, -1), (0, 0), (0, 1), (0, 2), (0, 3)]
+        c = (1, -5, 20, 20, -5, 1)
+        return sum(ck * f(dx + ax, dy + ay) for ck, (ax, ay) in zip(c, o))
+
+    def b1(dx, dy):   # intermediate of the half sample to the right of G(dx, dy) (8-241)
+        return tap(G, dx, dy, True)
+
+    def h1(dx, dy):   # ... below G(dx, dy) (8-242)
+        return tap(G, dx, dy, False)
+
+    def b(dx, dy):
+        return clip8((b1(dx, dy) + 16) >> 5)   # (8-243)
+
+    def hh(dx, dy):
+        return clip8((h1(dx, dy) + 16) >> 5)   # (8-244)
+
+    j = clip8((tap(b1, 0, 0, False) + 512) >> 10)   # (8-245, 8-246): six-tap over the intermediates, vertically
+    g00, bb, hv = G(0, 0), b(0, 0), hh(0, 0)
+    s, mm = b(0, 1), hh(1, 0)   # the half samples one row below / one column to the right
+    avg = lambda p, q: (p + q + 1) >> 1   # noqa: E731  (8-250 .. 8-261)
+    table = {
+        (0, 0): g00, (1, 0): avg(g00, bb), (2, 0): bb, (3, 0): avg(G(1, 0), bb),
+        (0, 1): avg(g00, hv), (1, 1): avg(bb, hv), (2, 1): avg(bb, j), (3, 1): avg(bb, mm),
+        (0, 2): hv, (1, 2): avg(hv, j), (2, 2): j, (3, 2): avg(j, mm),
+        (0, 3): avg(G(0, 1), hv), (1, 3): avg(hv, s), (2, 3): avg(j, s), (3, 3): avg(mm, s),
+    }
+    return table[(fx, fy)].astype(np.uint8)
+
+
+def shift_chroma(ref, mvx, mvy):
+    """8.4.2.2.2 for a whole 4:2:0 chroma plane: the luma vector read in eighths of a chroma sample."""
+    h, w = ref.shape
+    ox, oy, fx, fy = mvx >> 3, mvy >> 3, mvx & 7, mvy & 7
+    m = max(abs(ox), abs(oy)) + 2
+    r = np.pad(ref.astype(np.int64), m, mode="edge")
+
+    def C(dx, dy):
+        return r[m + oy + dy:m + oy + dy + h, m + ox + dx:m + ox + dx + w]
+    out = ((8 - fx) * (8 - fy) * C(0, 0) + fx * (8 - fy) * C(1, 0) + (8 - fx) * fy * C(0, 1) + fx * fy * C(1, 1) + 32) >> 6   # (8-270)
+    return out.astype(np.uint8)
+
+
+def planes(frame, w, h):
+    y = frame[:w * h].reshape(h, w)
+    u = frame[w * h:w * h + (w // 2) * (h // 2)].reshape(h // 2, w // 2)
+    v = frame[w * h + (w // 2) * (h // 2):].reshape(h // 2, w // 2)
+    return y, u, v
+
+
+def expected_from(prev, k, w, h):
+    mvx, mvy = global_mv_of(k, w, h)
+    y, u, v = planes(prev, w, h)
+    return np.concatenate([shift_luma(y, mvx, mvy).ravel(), shift_chroma(u, mvx, mvy).ravel(), shift_chroma(v, mvx, mvy).ravel()])
+
+
+def test_the_vectors_cover_what_they_should():
+    for w, h in SIZES:
+        mvs = [global_mv_of(k, w, h) for k in range(1, FRAMES)]
+        assert {(x & 3, y & 3) for x, y in mvs} == {(a, b) for a in range(4) for b in range(4)}
+        assert {x & 7 for x, _ in mvs} == set(range(8)) and {y & 7 for _, y in mvs} == set(range(8))
+        assert any(x >> 2 <= -w // 2 for x, _ in mvs) and any(x >> 2 >= w // 2 for x, _ in mvs)
+        assert any(y >> 2 <= -h // 2 for _, y in mvs) and any(y >> 2 >= h // 2 for _, y in mvs)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_decodes_shifted_pictures_as_the_clauses_say(hw, oracle, tmp_path, w, h, cabac):
+    path = str(tmp_path / "gmv.mp4")
+    gold = make_clip(path, width=w, height=h, frames=FRAMES, gop=FRAMES, bframes=0, refs=1, global_mv=1, cabac=cabac)
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
+    for k in range(1, FRAMES):
+        want = expected_from(frames[k - 1][0], k, w, h)
+        assert np.array_equal(frames[k][0], want), "picture %d, vector %s" % (k, global_mv_of(k, w, h))
+        assert np.array_equal(frames[k][0], gold[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", SIZES)
+def test_hip_path_decodes_shifted_pictures_as_the_clauses_say(hw, tmp_path, w, h):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "gmv.mp4")
+    make_clip(path, width=w, height=h, frames=FRAMES, gop=FRAMES, bframes=0, refs=1, global_mv=1, yuv=False)
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
+    for k in range(1, FRAMES):
+        want = expected_from(got[k - 1], k, w, h)
+        assert np.array_equal(got[k], want), "picture %d, vector %s" % (k, global_mv_of(k, w, h))
