@@ -1469,6 +1469,22 @@ static void write_pwt(const Enc* e, BitWriter* w, const PicPlan* pp, int nl0, in
   const int ld = e->cfg->wp_denom, cd = (ld + 6) & 7;
   bw_ue(w, ld);
   bw_ue(w, cd);
+  if (e->cfg->global_mv) {
+    /* weights and offsets that follow from the picture's number alone (tests/test_inter_independent.py restates them):
+     * one entry per reference of list 0, all the same */
+    const int k = e->frame_abs;
+    for (int i = 0; i < nl0; ++i) {
+      bw_put(w, 1, 1);
+      bw_se(w, iclip(-128, 127, (1 << ld) + (ld >= 3 ? (k * 3) % 7 - 3 : (ld >= 1 ? k % 3 - 1 : 0))));
+      bw_se(w, (k * 5) % 11 - 5);
+      bw_put(w, 1, 1);
+      for (int pl = 0; pl < 2; ++pl) {
+        bw_se(w, iclip(-128, 127, (1 << cd) + (cd >= 3 ? (k + pl) % 5 - 2 : (cd >= 1 ? (k + pl) % 3 - 1 : 0))));
+        bw_se(w, (k * 3 + pl * 2) % 9 - 4);
+      }
+    }
+    return;
+  }
   for (int l = 0; l < (pp->type == 1 ? 2 : 1); ++l)
     for (int i = 0; i < (l ? nl1 : nl0); ++i) {
       const uint32_t hi = hash3(h, (uint32_t)(l * 32 + i), 5);

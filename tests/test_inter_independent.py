@@ -4,7 +4,8 @@ The corpus encoder's `--global-mv` mode writes P pictures in which every macrobl
 with reference 0 and ONE vector per picture, and codes no residual; no edge gets a boundary strength, so the in-loop
 filter does nothing.  Such a picture must decode to the previous picture shifted by that vector: the sample
 interpolation of 8.4.2.2.1 (luma, all sixteen quarter-sample positions) and 8.4.2.2.2 (chroma, eighths), with the
-reference coordinates clamped to the picture (8.4.2.2).  Here that is computed for whole pictures with numpy, straight
+reference coordinates clamped to the picture (8.4.2.2), and - with explicit weights, which in this mode follow from the
+picture's number - the weighted sample prediction of 8.4.2.3.2 on top of it.  Here that is computed for whole pictures with numpy, straight
 from the clauses' equations, and compared with
 
   * the oracle's decode of the stream (CPU) - a third statement of the filters beside oracle/h264_recon.c and
@@ -96,10 +97,31 @@ def planes(frame, w, h):
     return y, u, v
 
 
-def expected_from(prev, k, w, h):
+def weights_of(k, ld):
+    """corpus/h264_encoder.c: write_pwt in --global-mv mode: (luma_log2_weight_denom, weight, offset) for Y, Cb, Cr."""
+    cd = (ld + 6) & 7
+    wy = (1 << ld) + ((k * 3) % 7 - 3 if ld >= 3 else (k % 3 - 1 if ld >= 1 else 0))
+    out = [(ld, min(127, wy), (k * 5) % 11 - 5)]   # (a coded weight is an se(v) in -128 .. 127)
+    for pl in range(2):
+        wc = (1 << cd) + ((k + pl) % 5 - 2 if cd >= 3 else ((k + pl) % 3 - 1 if cd >= 1 else 0))
+        out.append((cd, min(127, wc), (k * 3 + pl * 2) % 9 - 4))
+    return out
+
+
+def weighted(pred, log_wd, w, o):
+    """8.4.2.3.2, one list: (8-297)."""
+    p = pred.astype(np.int64)
+    v = ((p * w + (1 << (log_wd - 1))) >> log_wd) + o if log_wd >= 1 else p * w + o
+    return clip8(v).astype(np.uint8)
+
+
+def expected_from(prev, k, w, h, wp_denom=None):
     mvx, mvy = global_mv_of(k, w, h)
     y, u, v = planes(prev, w, h)
-    return np.concatenate([shift_luma(y, mvx, mvy).ravel(), shift_chroma(u, mvx, mvy).ravel(), shift_chroma(v, mvx, mvy).ravel()])
+    out = [shift_luma(y, mvx, mvy), shift_chroma(u, mvx, mvy), shift_chroma(v, mvx, mvy)]
+    if wp_denom is not None:
+        out = [weighted(p, *wt) for p, wt in zip(out, weights_of(k, wp_denom))]
+    return np.concatenate([p.ravel() for p in out])
 
 
 def test_the_vectors_cover_what_they_should():
@@ -111,28 +133,39 @@ def test_the_vectors_cover_what_they_should():
         assert any(y >> 2 <= -h // 2 for _, y in mvs) and any(y >> 2 >= h // 2 for _, y in mvs)
 
 
+WP_DENOMS = [None, 5, 0, 7, 2]   # None: default prediction; else explicit weights with this luma denominator
+                                 # (the chroma one is (d + 6) & 7: 3, 6, 5, 0 - denominators 0 and >= 1 take different rules)
+
+
+def clip_args(wp_denom):
+    return {} if wp_denom is None else dict(explicit_wp=1, wp_denom=wp_denom)
+
+
 @pytest.mark.parametrize("w,h", SIZES)
 @pytest.mark.parametrize("cabac", [1, 0])
-def test_oracle_decodes_shifted_pictures_as_the_clauses_say(hw, oracle, tmp_path, w, h, cabac):
+@pytest.mark.parametrize("wp_denom", WP_DENOMS)
+def test_oracle_decodes_shifted_pictures_as_the_clauses_say(hw, oracle, tmp_path, w, h, cabac, wp_denom):
     path = str(tmp_path / "gmv.mp4")
-    gold = make_clip(path, width=w, height=h, frames=FRAMES, gop=FRAMES, bframes=0, refs=1, global_mv=1, cabac=cabac)
+    gold = make_clip(path, width=w, height=h, frames=FRAMES, gop=FRAMES, bframes=0, refs=1, global_mv=1, cabac=cabac,
+                     **clip_args(wp_denom))
     frames, c = oracle.decode_file(path, hw.index_video(path))
     assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
     for k in range(1, FRAMES):
-        want = expected_from(frames[k - 1][0], k, w, h)
+        want = expected_from(frames[k - 1][0], k, w, h, wp_denom)
         assert np.array_equal(frames[k][0], want), "picture %d, vector %s" % (k, global_mv_of(k, w, h))
         assert np.array_equal(frames[k][0], gold[k])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("w,h", SIZES)
-def test_hip_path_decodes_shifted_pictures_as_the_clauses_say(hw, tmp_path, w, h):
+@pytest.mark.parametrize("wp_denom", WP_DENOMS)
+def test_hip_path_decodes_shifted_pictures_as_the_clauses_say(hw, tmp_path, w, h, wp_denom):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     path = str(tmp_path / "gmv.mp4")
-    make_clip(path, width=w, height=h, frames=FRAMES, gop=FRAMES, bframes=0, refs=1, global_mv=1, yuv=False)
+    make_clip(path, width=w, height=h, frames=FRAMES, gop=FRAMES, bframes=0, refs=1, global_mv=1, yuv=False, **clip_args(wp_denom))
     got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
     for k in range(1, FRAMES):
-        want = expected_from(got[k - 1], k, w, h)
+        want = expected_from(got[k - 1], k, w, h, wp_denom)
         assert np.array_equal(got[k], want), "picture %d, vector %s" % (k, global_mv_of(k, w, h))
