@@ -1131,6 +1131,23 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
   const Picture* r1 = d->sl.ref_list[1][0];
   const int d0 = (d->cur->poc - r0->poc) / 2, d1 = (d->cur->poc - r1->poc) / 2; /* d1 < 0 */
 
+  if (e->cfg->global_mv) {
+    /* every macroblock one 16x16 partition from list 0, list 1 or both (by the picture's number), one vector per list
+     * and picture, nothing coded */
+    const int k = e->frame_abs, kind = 1 + k % 3; /* 1 L0, 2 L1, 3 Bi */
+    int m0[2], m1[2];
+    global_mv_of(k, e->cfg->width, e->cfg->height, &m0[0], &m0[1]);
+    global_mv_of(k + 17, e->cfg->width, e->cfg->height, &m1[0], &m1[1]);
+    p->kind = MB_INTER;
+    set_all_motion(&d->mb, 0, kind != 2 ? 0 : -1, m0[0], m0[1]);
+    set_all_motion(&d->mb, 1, kind != 1 ? 0 : -1, m1[0], m1[1]);
+    p->mb_type_raw = kind;
+    copy_motion_from_state(d, p);
+    h264i_inter_pred_mb(d);
+    p->qp = qp;
+    return;
+  }
+
   /* direct first: it also tells whether B_Skip is possible */
   if (h264i_pred_direct_mb(d) < 0) return;
   MB direct = d->mb;
@@ -1470,17 +1487,21 @@ static void write_pwt(const Enc* e, BitWriter* w, const PicPlan* pp, int nl0, in
   bw_ue(w, ld);
   bw_ue(w, cd);
   if (e->cfg->global_mv) {
-    /* weights and offsets that follow from the picture's number alone (tests/test_inter_independent.py restates them):
-     * one entry per reference of list 0, all the same */
-    const int k = e->frame_abs;
-    for (int i = 0; i < nl0; ++i) {
-      bw_put(w, 1, 1);
-      bw_se(w, iclip(-128, 127, (1 << ld) + (ld >= 3 ? (k * 3) % 7 - 3 : (ld >= 1 ? k % 3 - 1 : 0))));
-      bw_se(w, (k * 5) % 11 - 5);
-      bw_put(w, 1, 1);
-      for (int pl = 0; pl < 2; ++pl) {
-        bw_se(w, iclip(-128, 127, (1 << cd) + (cd >= 3 ? (k + pl) % 5 - 2 : (cd >= 1 ? (k + pl) % 3 - 1 : 0))));
-        bw_se(w, (k * 3 + pl * 2) % 9 - 4);
+    /* weights and offsets that follow from the picture's number and the list alone (tests/test_inter_independent.py
+     * restates them): every entry of a list the same.  B slices: w0 + w1 <= 128 (127 at denominator 7), hence the caps */
+    for (int l = 0; l < (pp->type == 1 ? 2 : 1); ++l) {
+      const int k = e->frame_abs + 7 * l;
+      const int cap_l = pp->type == 1 && ld >= 6 ? (ld == 7 ? 63 : 64) : 127;
+      const int cap_c = pp->type == 1 && cd >= 6 ? (cd == 7 ? 63 : 64) : 127;
+      for (int i = 0; i < (l ? nl1 : nl0); ++i) {
+        bw_put(w, 1, 1);
+        bw_se(w, iclip(-128, cap_l, (1 << ld) + (ld >= 3 ? (k * 3) % 7 - 3 : (ld >= 1 ? k % 3 - 1 : 0))));
+        bw_se(w, (k * 5) % 11 - 5);
+        bw_put(w, 1, 1);
+        for (int pl = 0; pl < 2; ++pl) {
+          bw_se(w, iclip(-128, cap_c, (1 << cd) + (cd >= 3 ? (k + pl) % 5 - 2 : (cd >= 1 ? (k + pl) % 3 - 1 : 0))));
+          bw_se(w, (k * 3 + pl * 2) % 9 - 4);
+        }
       }
     }
     return;

@@ -12,6 +12,10 @@ from the clauses' equations, and compared with
     tests/fixtures/inter_filters_host.cpp, written against the decoder's OUTPUT rather than its code, and
   * the HIP path's decode (GPU): parser -> k_mv (the vectors travel as differences) -> k_inter, including vectors that
     point far outside the picture.
+
+With --bframes 2 the mode also writes B pictures predicted from list 0, list 1 or both (one vector per list and picture):
+8.4.2.3's default average, implicit weights (from the POC distances) and explicit weights of both lists are restated
+the same way.
 """
 import numpy as np
 import pytest
@@ -97,14 +101,17 @@ def planes(frame, w, h):
     return y, u, v
 
 
-def weights_of(k, ld):
-    """corpus/h264_encoder.c: write_pwt in --global-mv mode: (luma_log2_weight_denom, weight, offset) for Y, Cb, Cr."""
+def weights_of(k, ld, lst=0, b_slice=False):
+    """corpus/h264_encoder.c: write_pwt in --global-mv mode: (log2 denominator, weight, offset) for Y, Cb, Cr of the
+    entries of list `lst` in picture k."""
     cd = (ld + 6) & 7
-    wy = (1 << ld) + ((k * 3) % 7 - 3 if ld >= 3 else (k % 3 - 1 if ld >= 1 else 0))
-    out = [(ld, min(127, wy), (k * 5) % 11 - 5)]   # (a coded weight is an se(v) in -128 .. 127)
+    kk = k + 7 * lst
+    cap = lambda d: (63 if d == 7 else 64) if (b_slice and d >= 6) else 127   # noqa: E731  (B: w0 + w1 <= 128, 127 at denominator 7)
+    wy = (1 << ld) + ((kk * 3) % 7 - 3 if ld >= 3 else (kk % 3 - 1 if ld >= 1 else 0))
+    out = [(ld, min(cap(ld), wy), (kk * 5) % 11 - 5)]   # (a coded weight is an se(v) in -128 .. 127)
     for pl in range(2):
-        wc = (1 << cd) + ((k + pl) % 5 - 2 if cd >= 3 else ((k + pl) % 3 - 1 if cd >= 1 else 0))
-        out.append((cd, min(127, wc), (k * 3 + pl * 2) % 9 - 4))
+        wc = (1 << cd) + ((kk + pl) % 5 - 2 if cd >= 3 else ((kk + pl) % 3 - 1 if cd >= 1 else 0))
+        out.append((cd, min(cap(cd), wc), (kk * 3 + pl * 2) % 9 - 4))
     return out
 
 
@@ -115,12 +122,63 @@ def weighted(pred, log_wd, w, o):
     return clip8(v).astype(np.uint8)
 
 
+def weighted_bi(p0, p1, log_wd, w0, w1, o0, o1):
+    """8.4.2.3.2, both lists: (8-299)."""
+    v = ((p0.astype(np.int64) * w0 + p1.astype(np.int64) * w1 + (1 << log_wd)) >> (log_wd + 1)) + ((o0 + o1 + 1) >> 1)
+    return clip8(v).astype(np.uint8)
+
+
+def implicit_weights(poc_cur, poc0, poc1):
+    """8.4.2.3.1 (implicit mode, frames, short-term references): (w0, w1), logWD = 5, offsets 0."""
+    clip3 = lambda lo, hi, x: max(lo, min(hi, x))   # noqa: E731
+    tb, td = clip3(-128, 127, poc_cur - poc0), clip3(-128, 127, poc1 - poc0)
+    if td == 0:
+        return 32, 32
+    tx = int((16384 + abs(td // 2 if td > 0 else -((-td) // 2))) / td)   # (16384 + Abs(td / 2)) / td, "/" truncating
+    dsf = clip3(-1024, 1023, (tb * tx + 32) >> 6)
+    if (dsf >> 2) < -64 or (dsf >> 2) > 128:
+        return 32, 32
+    return 64 - (dsf >> 2), dsf >> 2
+
+
+def shifted(frame, mv, w, h):
+    y, u, v = planes(frame, w, h)
+    return [shift_luma(y, *mv), shift_chroma(u, *mv), shift_chroma(v, *mv)]
+
+
 def expected_from(prev, k, w, h, wp_denom=None):
-    mvx, mvy = global_mv_of(k, w, h)
-    y, u, v = planes(prev, w, h)
-    out = [shift_luma(y, mvx, mvy), shift_chroma(u, mvx, mvy), shift_chroma(v, mvx, mvy)]
+    """P picture k of a clip without B pictures."""
+    out = shifted(prev, global_mv_of(k, w, h), w, h)
     if wp_denom is not None:
         out = [weighted(p, *wt) for p, wt in zip(out, weights_of(k, wp_denom))]
+    return np.concatenate([p.ravel() for p in out])
+
+
+def expected_b(dec, d, w, h, mode):
+    """Picture d of an I B B P B B P ... clip (--bframes 2): anchors refer to the anchor before them, a B picture to the
+    anchors around it (list 0: the one before, list 1: the one after); POC = 2 * display position.
+    mode: None (default prediction), "implicit" (weighted_bipred_idc 2) or a luma denominator (explicit weights)."""
+    explicit = mode is not None and mode != "implicit"
+    if d % 3 == 0:   # P
+        out = shifted(dec[d - 3], global_mv_of(d, w, h), w, h)
+        if explicit:
+            out = [weighted(p, *wt) for p, wt in zip(out, weights_of(d, mode))]
+        return np.concatenate([p.ravel() for p in out])
+    a, kind = d - d % 3, 1 + d % 3   # 1 L0, 2 L1, 3 Bi (corpus/h264_encoder.c: decide_b in --global-mv mode)
+    p0 = shifted(dec[a], global_mv_of(d, w, h), w, h)
+    p1 = shifted(dec[a + 3], global_mv_of(d + 17, w, h), w, h)
+    if kind != 3:
+        out, lst = (p0, 0) if kind == 1 else (p1, 1)
+        if explicit:
+            out = [weighted(p, *wt) for p, wt in zip(out, weights_of(d, mode, lst, True))]
+    elif explicit:
+        w0s, w1s = weights_of(d, mode, 0, True), weights_of(d, mode, 1, True)
+        out = [weighted_bi(x, y, a0[0], a0[1], a1[1], a0[2], a1[2]) for x, y, a0, a1 in zip(p0, p1, w0s, w1s)]
+    elif mode == "implicit":
+        w0, w1 = implicit_weights(2 * d, 2 * a, 2 * (a + 3))
+        out = [weighted_bi(x, y, 5, w0, w1, 0, 0) for x, y in zip(p0, p1)]
+    else:
+        out = [((x.astype(np.int64) + y + 1) >> 1).astype(np.uint8) for x, y in zip(p0, p1)]   # (8-273)
     return np.concatenate([p.ravel() for p in out])
 
 
@@ -154,6 +212,49 @@ def test_oracle_decodes_shifted_pictures_as_the_clauses_say(hw, oracle, tmp_path
         want = expected_from(frames[k - 1][0], k, w, h, wp_denom)
         assert np.array_equal(frames[k][0], want), "picture %d, vector %s" % (k, global_mv_of(k, w, h))
         assert np.array_equal(frames[k][0], gold[k])
+
+
+B_FRAMES = 37   # I B B P ... P: the last picture is an anchor
+B_MODES = [None, "implicit", 5, 0, 7, 2]
+
+
+def b_clip_args(mode):
+    return {} if mode is None else (dict(implicit_wp=1) if mode == "implicit" else dict(explicit_wp=1, wp_denom=mode))
+
+
+def test_implicit_weights_follow_the_distances():
+    assert implicit_weights(2, 0, 6) == (43, 21) and implicit_weights(4, 0, 6) == (22, 42)
+    assert implicit_weights(6, 0, 12) == (32, 32)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("cabac", [1, 0])
+@pytest.mark.parametrize("mode", B_MODES)
+def test_oracle_decodes_bipredicted_pictures_as_the_clauses_say(hw, oracle, tmp_path, w, h, cabac, mode):
+    """B pictures from list 0, list 1 or both (8.4.2.3: default, implicit and explicit weighting)."""
+    path = str(tmp_path / "gmvb.mp4")
+    gold = make_clip(path, width=w, height=h, frames=B_FRAMES, gop=B_FRAMES, bframes=2, refs=1, global_mv=1, cabac=cabac,
+                     **b_clip_args(mode))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == B_FRAMES
+    dec = [f[0] for f in frames]
+    for d in range(1, B_FRAMES):
+        assert np.array_equal(dec[d], expected_b(dec, d, w, h, mode)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+        assert np.array_equal(dec[d], gold[d])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("mode", B_MODES)
+def test_hip_path_decodes_bipredicted_pictures_as_the_clauses_say(hw, tmp_path, w, h, mode):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "gmvb.mp4")
+    make_clip(path, width=w, height=h, frames=B_FRAMES, gop=B_FRAMES, bframes=2, refs=1, global_mv=1, yuv=False, **b_clip_args(mode))
+    dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(B_FRAMES)))
+    for d in range(1, B_FRAMES):
+        assert np.array_equal(dec[d], expected_b(dec, d, w, h, mode)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
 
 
 @pytest.mark.gpu
