@@ -958,6 +958,13 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
   if (e->cfg->global_mv) {
     int gx, gy;
     global_mv_of(e->frame_abs, e->cfg->width, e->cfg->height, &gx, &gy);
+    /* --global-mv 2: a checkerboard of two vectors - every macroblock edge inside the picture then separates different
+     * motion and gets boundary strength 1 (nothing is coded, all macroblocks keep the slice's QP): the in-loop filter
+     * runs on known edges with known parameters */
+    if (e->cfg->global_mv == 2 && ((d->mb.mbx + d->mb.mby) & 1)) {
+      gx += 9;
+      gy -= 6;
+    }
     p->kind = MB_INTER;
     set_all_motion(&d->mb, 0, 0, gx, gy);
     copy_motion_from_state(d, p);
