@@ -945,6 +945,14 @@ static void global_mv_of(int k, int width, int height, int* mvx, int* mvy) {
   *mvy = iy * 4 + fy;
 }
 
+/* --global-mv 3: what an I_PCM macroblock's sample at (x, y) of plane pl differs by from the prediction there
+ * (restated in tests/test_deblock_independent.py): mostly a few levels, now and then a step the filter must leave alone */
+static int global_pcm_delta(int k, int pl, int x, int y) {
+  int e = (x * 7 + y * 13 + k * 5 + pl * 3) % 13 - 6;
+  if (((x >> 2) + (y >> 2) + k) % 5 == 0) e += 24;
+  return e;
+}
+
 /* P macroblock */
 static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 */) {
   H264Oracle* d = e->d;
@@ -971,6 +979,27 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
     p->mb_type_raw = 0;
     h264i_inter_pred_mb(d);
     p->qp = qp; /* (plan is zeroed: no coefficients, cbp 0) */
+    /* --global-mv 3: a checkerboard of such macroblocks and I_PCM macroblocks whose samples are what the vector predicts
+     * there plus a small known pattern (global_pcm_delta): every macroblock edge inside the picture has an intra
+     * macroblock on one side - boundary strength 4 - with QP 0 on that side (8.7.2.2) and the slice's QP on the other */
+    if (e->cfg->global_mv == 3 && ((d->mb.mbx + d->mb.mby) & 1)) {
+      const Picture* cur = d->cur;
+      p->kind = MB_IPCM;
+      p->mb_type_raw = 5 + 25;
+      for (int y = 0; y < 16; ++y)
+        for (int x = 0; x < 16; ++x) {
+          const int X = d->mb.mbx * 16 + x, Y = d->mb.mby * 16 + y;
+          p->pcm[y * 16 + x] = (uint8_t)iclip(0, 255, cur->plane[0][Y * cur->stride[0] + X] + global_pcm_delta(e->frame_abs, 0, X, Y));
+        }
+      for (int pl = 0; pl < 2; ++pl)
+        for (int y = 0; y < 8; ++y)
+          for (int x = 0; x < 8; ++x) {
+            const int X = d->mb.mbx * 8 + x, Y = d->mb.mby * 8 + y;
+            p->pcm[256 + pl * 64 + y * 8 + x] =
+                (uint8_t)iclip(0, 255, cur->plane[1 + pl][Y * cur->stride[1 + pl] + X] + global_pcm_delta(e->frame_abs, 1 + pl, X, Y));
+          }
+      return;
+    }
     if (gx == skip_mv[0] && gy == skip_mv[1]) plan->is_skip = 1;
     return;
   }

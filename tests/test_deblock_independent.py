@@ -32,8 +32,35 @@ def clip3(lo, hi, x):
     return max(lo, min(hi, x))
 
 
+def filter_line_strong(px, chroma, alpha, beta):
+    """One line across an edge with bS = 4 (8.7.2.4): px = [p3 p2 p1 p0 q0 q1 q2 q3] (ints), filtered in place."""
+    p3, p2, p1, p0, q0, q1, q2, q3 = px
+    if not (abs(p0 - q0) < alpha and abs(p1 - p0) < beta and abs(q1 - q0) < beta):
+        return
+    if chroma:
+        px[3] = (2 * p1 + p0 + q1 + 2) >> 2
+        px[4] = (2 * q1 + q0 + p1 + 2) >> 2
+        return
+    small = abs(p0 - q0) < ((alpha >> 2) + 2)
+    if abs(p2 - p0) < beta and small:
+        px[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3
+        px[2] = (p2 + p1 + p0 + q0 + 2) >> 2
+        px[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3
+    else:
+        px[3] = (2 * p1 + p0 + q1 + 2) >> 2
+    if abs(q2 - q0) < beta and small:
+        px[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3
+        px[5] = (p0 + q0 + q1 + q2 + 2) >> 2
+        px[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3
+    else:
+        px[4] = (2 * q1 + q0 + p1 + 2) >> 2
+
+
 def filter_line(px, chroma, alpha, beta, tc0):
-    """One line of samples across an edge, bS = 1 (8.7.2.3): px = [p3 p2 p1 p0 q0 q1 q2 q3] (ints), filtered in place."""
+    """One line of samples across an edge, bS = 1 (8.7.2.3): px = [p3 p2 p1 p0 q0 q1 q2 q3] (ints), filtered in place.
+    tc0 None: bS = 4."""
+    if tc0 is None:
+        return filter_line_strong(px, chroma, alpha, beta)
     p2, p1, p0, q0, q1, q2 = px[1], px[2], px[3], px[4], px[5], px[6]
     if not (abs(p0 - q0) < alpha and abs(p1 - p0) < beta and abs(q1 - q0) < beta):
         return
@@ -150,6 +177,85 @@ def test_every_row_of_the_threshold_tables(hw, oracle, tmp_path):
         frames, _ = oracle.decode_file(path, hw.index_video(path))
         for k in range(1, 4):
             assert np.array_equal(frames[k][0], expected(frames[k - 1][0], k, W, H, qp, 0, 0, 0)), "QP %d, picture %d" % (qp, k)
+
+
+# ---- boundary strength 4: a checkerboard of inter and I_PCM macroblocks (--global-mv 3) ------------------------------
+def pcm_delta(k, pl, x, y):
+    """corpus/h264_encoder.c: global_pcm_delta."""
+    e = (x * 7 + y * 13 + k * 5 + pl * 3) % 13 - 6
+    return e + 24 if ((x >> 2) + (y >> 2) + k) % 5 == 0 else e
+
+
+def mosaic_pcm(prev, k, w, h):
+    """Before the filter: every macroblock is the previous picture shifted by the picture's vector; where x + y is odd it
+    is an I_PCM macroblock carrying those samples plus pcm_delta."""
+    mv = global_mv_of(k, w, h)
+    out = []
+    for pl, (plane, mb, shift) in enumerate(zip(planes(prev, w, h), (16, 8, 8), (shift_luma, shift_chroma, shift_chroma))):
+        pa = shift(plane, *mv).astype(np.int64)
+        ph, pw = plane.shape
+        ys, xs = np.arange(ph), np.arange(pw)
+        delta = np.array([[pcm_delta(k, pl, int(x), int(y)) for x in xs] for y in ys])
+        odd = (np.add.outer(ys // mb, xs // mb) & 1).astype(bool)
+        out.append(np.where(odd, np.clip(pa + delta, 0, 255), pa).astype(np.uint8))
+    return out
+
+
+def expected_pcm(prev, k, w, h, qp, alpha_div2, beta_div2, cqo):
+    """Every macroblock edge inside the picture lies between an I_PCM macroblock (qP = 0 for luma, QPc of 0 for chroma:
+    8.7.2.2) and an inter macroblock with the slice's QP: bS = 4, thresholds from the average of the two."""
+    y, u, v = mosaic_pcm(prev, k, w, h)
+    qpav = (qp + 0 + 1) >> 1
+    a, b, _ = thresholds(qpav, alpha_div2, beta_div2)
+    y = deblock_plane(y, 16, False, a, b, None)
+    out = [y.ravel()]
+    for plane, off in ((u, cqo), (v, cqo - 1 if cqo > 0 else cqo)):
+        qpav = (chroma_qp(qp, off) + chroma_qp(0, off) + 1) >> 1
+        a, b, _ = thresholds(qpav, alpha_div2, beta_div2)
+        out.append(deblock_plane(plane, 8, True, a, b, None).ravel())
+    return np.concatenate(out)
+
+
+# the inter side's QP is the slice's, the I_PCM side's is 0: the average reaches 26 at most; FilterOffsetA / B up to +12
+PCM_SETTINGS = [(51, 0, 0, 0), (51, 6, 6, 0), (44, 3, 6, 0), (38, 6, 2, 0), (51, 4, 5, 6), (46, 6, 6, -4), (33, 6, 6, 0)]
+
+
+def pcm_clip_args(qp, a, b, cqo):
+    return dict(clip_args(qp, a, b, cqo), global_mv=3)
+
+
+@pytest.mark.parametrize("qp,a,b,cqo", PCM_SETTINGS)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_filters_intra_edges_as_the_clauses_say(hw, oracle, tmp_path, qp, a, b, cqo, cabac):
+    path = str(tmp_path / "dbk4.mp4")
+    gold = make_clip(path, width=W, height=H, cabac=cabac, **pcm_clip_args(qp, a, b, cqo))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
+    touched = untouched = 0
+    for k in range(1, FRAMES):
+        want = expected_pcm(frames[k - 1][0], k, W, H, qp, a, b, cqo)
+        assert np.array_equal(frames[k][0], want), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+        before = mosaic_pcm(frames[k - 1][0], k, W, H)[0]
+        after = want[:W * H].reshape(H, W)
+        for x0 in range(16, W, 16):
+            moved = (before[:, x0 - 1] != after[:, x0 - 1]) | (before[:, x0] != after[:, x0])
+            touched += int(moved.sum())
+            untouched += int((~moved).sum())
+    assert touched > 0 and untouched > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp,a,b,cqo", PCM_SETTINGS)
+def test_hip_path_filters_intra_edges_as_the_clauses_say(hw, tmp_path, qp, a, b, cqo):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "dbk4.mp4")
+    make_clip(path, width=W, height=H, yuv=False, **pcm_clip_args(qp, a, b, cqo))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
+    for k in range(1, FRAMES):
+        assert np.array_equal(got[k], expected_pcm(got[k - 1], k, W, H, qp, a, b, cqo)), "picture %d" % k
 
 
 @pytest.mark.gpu
