@@ -945,6 +945,17 @@ static void global_mv_of(int k, int width, int height, int* mvx, int* mvy) {
   *mvy = iy * 4 + fy;
 }
 
+/* --global-mv 4: the level of coefficient `pos` (raster, 0..15) of 4x4 block `blk` of macroblock `addr` in picture k;
+ * comp 0 luma (blk raster 0..15), 1 / 2 chroma AC of Cb / Cr (blk 0..3, pos 0 unused), 3 / 4 chroma DC of Cb / Cr (pos =
+ * the block).  Restated in tests/test_residual_independent.py: sparse, small, now and then a large one. */
+static int global_level(int k, int addr, int comp, int blk, int pos) {
+  const int t = addr * 7 + blk * 5 + pos * 3 + k * 11 + comp * 13;
+  if (t % 5 != 0) return 0;
+  int v = (addr + blk * 3 + pos + comp) % 9 - 4;
+  if (t % 35 == 0) v *= 9;
+  return v;
+}
+
 /* --global-mv 3: what an I_PCM macroblock's sample at (x, y) of plane pl differs by from the prediction there
  * (restated in tests/test_deblock_independent.py): mostly a few levels, now and then a step the filter must leave alone */
 static int global_pcm_delta(int k, int pl, int x, int y) {
@@ -998,6 +1009,31 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
             p->pcm[256 + pl * 64 + y * 8 + x] =
                 (uint8_t)iclip(0, 255, cur->plane[1 + pl][Y * cur->stride[1 + pl] + X] + global_pcm_delta(e->frame_abs, 1 + pl, X, Y));
           }
+      return;
+    }
+    /* --global-mv 4: the prediction plus a residual whose levels follow from position and picture number alone
+     * (global_level): dequantisation and the 4x4 inverse transforms (luma, chroma AC, chroma DC) on known input.  The
+     * macroblock's QP is the slice's (no mb_qp_delta worth the name), the 8x8 transform stays off */
+    if (e->cfg->global_mv == 4) {
+      const int k = e->frame_abs;
+      int cbp = 0, chroma = 0;
+      for (int blk = 0; blk < 16; ++blk)
+        for (int pos = 0; pos < 16; ++pos) {
+          p->luma[blk][pos] = (int16_t)global_level(k, addr, 0, blk, pos);
+          if (p->luma[blk][pos]) cbp |= 1 << ((blk >> 3) * 2 + ((blk & 3) >> 1));
+        }
+      for (int pl = 0; pl < 2; ++pl) {
+        for (int blk = 0; blk < 4; ++blk) {
+          p->chroma_dc[pl][blk] = (int16_t)global_level(k, addr, 3 + pl, 0, blk);
+          if (p->chroma_dc[pl][blk] && chroma < 1) chroma = 1;
+          for (int pos = 1; pos < 16; ++pos) {
+            p->chroma_ac[pl][blk][pos] = (int16_t)global_level(k, addr, 1 + pl, blk, pos);
+            if (p->chroma_ac[pl][blk][pos]) chroma = 2;
+          }
+        }
+      }
+      p->cbp = cbp | chroma << 4;
+      p->qp = e->cfg->qp;
       return;
     }
     if (gx == skip_mv[0] && gy == skip_mv[1]) plan->is_skip = 1;

@@ -1,0 +1,142 @@
+"""Dequantisation and the 4x4 inverse transforms checked against a restatement that shares nothing with the oracle or the
+kernels - the normAdjust table and the chroma QP table included: they are typed a second time here.
+
+`--global-mv 4` (corpus/h264_encoder.c) writes P pictures whose macroblocks all predict with one vector from reference 0
+(tests/test_inter_independent.py) and carry a residual whose coefficient LEVELS follow from the macroblock's address, the
+block, the position and the picture's number (global_level) - sparse, small, now and then large - with the slice's QP in
+every macroblock, the 4x4 transform only and the in-loop filter switched off.  So a picture must decode to
+
+    Clip1(prediction + inverse transform(scaled levels))
+
+with 8.5.12 (luma 4x4 blocks), 8.5.11 (chroma DC 2x2 and chroma AC) and the flat scaling of 8.5.9 (LevelScale4x4 =
+16 * normAdjust4x4).  That is computed here with numpy for QPs on both sides of the scaling rule's case split (QP < 24 /
+>= 24, chroma QPs up to 39) and compared with the oracle's decode (CPU) and the HIP path's (GPU: parser -> k_residual ->
+k_inter's residual add)."""
+import numpy as np
+import pytest
+
+from tests.corpus_util import make_clip
+from tests.test_deblock_independent import chroma_qp
+from tests.test_inter_independent import global_mv_of, planes, shift_chroma, shift_luma
+
+W, H = 64, 48
+FRAMES = 8
+
+# 8.5.9, Table of normAdjust4x4(m, i, j): v[m] = (positions with i, j both even; both odd; the others)
+NORM_ADJUST = [(10, 16, 13), (11, 18, 14), (13, 20, 16), (14, 23, 18), (16, 25, 20), (18, 29, 23)]
+
+
+def level_scale(m):
+    ls = np.zeros((4, 4), dtype=np.int64)
+    for i in range(4):
+        for j in range(4):
+            cls = 0 if (i % 2 == 0 and j % 2 == 0) else (1 if (i % 2 == 1 and j % 2 == 1) else 2)
+            ls[i, j] = 16 * NORM_ADJUST[m][cls]   # flat weightScale = 16
+    return ls
+
+
+def global_level(k, addr, comp, blk, pos):
+    """corpus/h264_encoder.c: global_level."""
+    t = addr * 7 + blk * 5 + pos * 3 + k * 11 + comp * 13
+    if t % 5 != 0:
+        return 0
+    v = (addr + blk * 3 + pos + comp) % 9 - 4
+    return v * 9 if t % 35 == 0 else v
+
+
+def scale_ac(c, qp):
+    """8.5.12.1: d_ij for a 4x4 block of levels c (all positions; the caller overrides d_00 where a DC path owns it)."""
+    ls = level_scale(qp % 6)
+    if qp >= 24:
+        return (c * ls) << (qp // 6 - 4)
+    return (c * ls + (1 << (3 - qp // 6))) >> (4 - qp // 6)
+
+
+def inverse4x4(d):
+    """8.5.12.2: rows, then columns, then (x + 32) >> 6."""
+    def butterfly(v):   # v: four values along the transformed axis (arrays over the other axis)
+        e0, e1 = v[0] + v[2], v[0] - v[2]
+        e2, e3 = (v[1] >> 1) - v[3], v[1] + (v[3] >> 1)
+        return [e0 + e3, e1 + e2, e1 - e2, e0 - e3]
+    f = np.stack(butterfly([d[:, 0], d[:, 1], d[:, 2], d[:, 3]]), axis=1)        # each row
+    h = np.stack(butterfly([f[0, :], f[1, :], f[2, :], f[3, :]]), axis=0)        # each column
+    return (h + 32) >> 6
+
+
+def residual_luma(k, addr, qp):
+    r = np.zeros((16, 16), dtype=np.int64)
+    for blk in range(16):
+        c = np.array([[global_level(k, addr, 0, blk, i * 4 + j) for j in range(4)] for i in range(4)], dtype=np.int64)
+        by, bx = (blk // 4) * 4, (blk % 4) * 4
+        r[by:by + 4, bx:bx + 4] = inverse4x4(scale_ac(c, qp))
+    return r
+
+
+def residual_chroma(k, addr, pl, qpc):
+    """8.5.11: the four DC levels through the 2x2 transform and their own scaling, then each block's AC with that DC."""
+    c = np.array([[global_level(k, addr, 3 + pl, 0, 0), global_level(k, addr, 3 + pl, 0, 1)],
+                  [global_level(k, addr, 3 + pl, 0, 2), global_level(k, addr, 3 + pl, 0, 3)]], dtype=np.int64)
+    a = np.array([[1, 1], [1, -1]], dtype=np.int64)
+    f = a @ c @ a
+    dc = ((f * level_scale(qpc % 6)[0, 0]) << (qpc // 6)) >> 5
+    r = np.zeros((8, 8), dtype=np.int64)
+    for blk in range(4):
+        lv = np.array([[0 if (i == 0 and j == 0) else global_level(k, addr, 1 + pl, blk, i * 4 + j) for j in range(4)] for i in range(4)],
+                      dtype=np.int64)
+        d = scale_ac(lv, qpc)
+        d[0, 0] = dc[blk // 2, blk % 2]
+        by, bx = (blk // 2) * 4, (blk % 2) * 4
+        r[by:by + 4, bx:bx + 4] = inverse4x4(d)
+    return r
+
+
+def expected(prev, k, w, h, qp, cqo):
+    mv = global_mv_of(k, w, h)
+    y, u, v = planes(prev, w, h)
+    py, pu, pv = (shift_luma(y, *mv).astype(np.int64), shift_chroma(u, *mv).astype(np.int64), shift_chroma(v, *mv).astype(np.int64))
+    mbw = w // 16
+    qpcs = (chroma_qp(qp, cqo), chroma_qp(qp, cqo))   # (--t8x8 0: the PPS carries no second_chroma_qp_index_offset, Cr follows Cb)
+    for addr in range(mbw * (h // 16)):
+        mx, my = addr % mbw, addr // mbw
+        py[my * 16:my * 16 + 16, mx * 16:mx * 16 + 16] += residual_luma(k, addr, qp)
+        pu[my * 8:my * 8 + 8, mx * 8:mx * 8 + 8] += residual_chroma(k, addr, 0, qpcs[0])
+        pv[my * 8:my * 8 + 8, mx * 8:mx * 8 + 8] += residual_chroma(k, addr, 1, qpcs[1])
+    return np.concatenate([np.clip(p, 0, 255).astype(np.uint8).ravel() for p in (py, pu, pv)])
+
+
+# (QP, chroma_qp_index_offset): every QP % 6, both sides of QP 24, chroma QPs in the table's tail
+SETTINGS = [(12, 0), (19, 0), (23, 0), (24, 0), (26, 0), (27, 0), (28, 0), (29, 0), (31, 0), (36, 0), (45, 0), (51, 0), (30, 6), (40, -6), (17, 5)]
+
+
+def clip_args(qp, cqo):
+    return dict(frames=FRAMES, gop=FRAMES, bframes=0, refs=1, global_mv=4, qp=qp, chroma_qp_offset=cqo, deblock=1, t8x8=0)
+
+
+@pytest.mark.parametrize("qp,cqo", SETTINGS)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_adds_known_residuals_as_the_clauses_say(hw, oracle, tmp_path, qp, cqo, cabac):
+    path = str(tmp_path / "res.mp4")
+    gold = make_clip(path, width=W, height=H, cabac=cabac, **clip_args(qp, cqo))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
+    moved = 0
+    for k in range(1, FRAMES):
+        want = expected(frames[k - 1][0], k, W, H, qp, cqo)
+        assert np.array_equal(frames[k][0], want), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+        mv = global_mv_of(k, W, H)
+        moved += int((want[:W * H].reshape(H, W) != shift_luma(planes(frames[k - 1][0], W, H)[0], *mv)).sum())
+    assert moved > 0   # (the residual does something)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp,cqo", SETTINGS)
+def test_hip_path_adds_known_residuals_as_the_clauses_say(hw, tmp_path, qp, cqo):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "res.mp4")
+    make_clip(path, width=W, height=H, yuv=False, **clip_args(qp, cqo))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
+    for k in range(1, FRAMES):
+        assert np.array_equal(got[k], expected(got[k - 1], k, W, H, qp, cqo)), "picture %d" % k
