@@ -16,7 +16,7 @@ import numpy as np
 import pytest
 
 from tests.corpus_util import make_clip
-from tests.test_deblock_independent import chroma_qp
+from tests.test_deblock_independent import ALPHA, BETA, chroma_qp, clip3, filter_line
 from tests.test_inter_independent import global_mv_of, planes, shift_chroma, shift_luma
 
 W, H = 64, 48
@@ -38,6 +38,8 @@ def level_scale(m):
 def global_level(k, addr, comp, blk, pos):
     """corpus/h264_encoder.c: global_level."""
     t = addr * 7 + blk * 5 + pos * 3 + k * 11 + comp * 13
+    if comp <= 2 and (addr + blk + k) % 3 == 0:
+        return 0   # a third of the blocks carry nothing (their edges: bS 0)
     if t % 5 != 0:
         return 0
     v = (addr + blk * 3 + pos + comp) % 9 - 4
@@ -140,3 +142,118 @@ def test_hip_path_adds_known_residuals_as_the_clauses_say(hw, tmp_path, qp, cqo)
     got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
     for k in range(1, FRAMES):
         assert np.array_equal(got[k], expected(got[k - 1], k, W, H, qp, cqo)), "picture %d" % k
+
+
+# ---- the same pictures with the in-loop filter on: boundary strength 2 ---------------------------------------------------
+# A 4x4 luma block with a non-zero level gives every edge it touches bS = 2 (8.7.2.1); all vectors and references are the
+# same, so every other edge has bS = 0.  Chroma edges take the strengths of the luma edge they lie on.
+TC0_BS2 = [0] * 21 + [1] * 10 + [2, 2, 2, 2, 3, 3, 3, 4, 4, 5, 5, 6, 7, 8, 8, 10, 11, 12, 13, 15, 17]   # Table 8-17, bS = 2
+assert len(TC0_BS2) == 52
+
+
+def coded(k, addr, blk):
+    return any(global_level(k, addr, 0, blk, pos) for pos in range(16))
+
+
+def filter_picture_bs2(y, u, v, k, w, h, qp, qpcs, alpha_div2, beta_div2):
+    mbw, mbh = w // 16, h // 16
+    nz = np.zeros((mbh * 4, mbw * 4), dtype=bool)   # per 4x4 luma block of the picture
+    for addr in range(mbw * mbh):
+        mx, my = addr % mbw, addr // mbw
+        for blk in range(16):
+            nz[my * 4 + blk // 4, mx * 4 + blk % 4] = coded(k, addr, blk)
+
+    def thr(q):
+        ia, ib = clip3(0, 51, q + 2 * alpha_div2), clip3(0, 51, q + 2 * beta_div2)
+        return ALPHA[ia], BETA[ib], TC0_BS2[ia]
+    pl = [p.astype(np.int64) for p in (y, u, v)]
+    th = [thr(qp), thr(qpcs[0]), thr(qpcs[1])]
+    for my in range(mbh):
+        for mx in range(mbw):
+            for vertical in (True, False):   # the macroblock's vertical edges left to right, then its horizontal ones
+                for e in range(4):
+                    if e == 0 and (mx == 0 if vertical else my == 0):
+                        continue   # the picture's border
+                    for seg in range(4):   # four lines of luma each
+                        if vertical:
+                            by, bx = my * 4 + seg, mx * 4 + e
+                            strong = nz[by, bx] or nz[by, bx - 1]
+                        else:
+                            by, bx = my * 4 + e, mx * 4 + seg
+                            strong = nz[by, bx] or nz[by - 1, bx]
+                        if not strong:
+                            continue
+                        for p_i, (a, chroma) in enumerate(((pl[0], False), (pl[1], True), (pl[2], True))):
+                            if chroma and e % 2:
+                                continue   # chroma has edges where luma has its edges 0 and 2
+                            alpha, beta, tc0 = th[p_i]
+                            n, reach = (2, 2) if chroma else (4, 4)
+                            for i in range(n):
+                                if vertical:
+                                    x0 = (mx * 16 + e * 4) // (2 if chroma else 1)
+                                    yy = (my * 16 + seg * 4) // (2 if chroma else 1) + i
+                                    px = [0] * 8
+                                    px[4 - reach:4 + reach] = [int(t) for t in a[yy, x0 - reach:x0 + reach]]
+                                    filter_line(px, chroma, alpha, beta, tc0)
+                                    a[yy, x0 - reach:x0 + reach] = px[4 - reach:4 + reach]
+                                else:
+                                    y0 = (my * 16 + e * 4) // (2 if chroma else 1)
+                                    xx = (mx * 16 + seg * 4) // (2 if chroma else 1) + i
+                                    px = [0] * 8
+                                    px[4 - reach:4 + reach] = [int(t) for t in a[y0 - reach:y0 + reach, xx]]
+                                    filter_line(px, chroma, alpha, beta, tc0)
+                                    a[y0 - reach:y0 + reach, xx] = px[4 - reach:4 + reach]
+    return np.concatenate([np.clip(p, 0, 255).astype(np.uint8).ravel() for p in pl])
+
+
+def expected_filtered(prev, k, w, h, qp, cqo, alpha_div2, beta_div2):
+    unfiltered = expected(prev, k, w, h, qp, cqo)
+    y, u, v = planes(unfiltered, w, h)
+    return filter_picture_bs2(y, u, v, k, w, h, qp, (chroma_qp(qp, cqo), chroma_qp(qp, cqo)), alpha_div2, beta_div2)
+
+
+# (QP, chroma_qp_index_offset, FilterOffsetA / 2, FilterOffsetB / 2)
+BS2_SETTINGS = [(26, 0, 0, 0), (32, 0, 0, 0), (38, 0, 0, 0), (45, 0, 0, 0), (51, 0, 0, 0), (28, 0, 3, -2), (36, 4, -1, 2), (41, -3, 2, 2), (22, 0, 6, 6)]
+
+
+def bs2_clip_args(qp, cqo, a, b):
+    return dict(clip_args(qp, cqo), deblock=0, alpha=a, beta=b)
+
+
+@pytest.mark.parametrize("qp,cqo,a,b", BS2_SETTINGS)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_filters_coded_blocks_edges_as_the_clauses_say(hw, oracle, tmp_path, qp, cqo, a, b, cabac):
+    path = str(tmp_path / "res2.mp4")
+    gold = make_clip(path, width=W, height=H, cabac=cabac, **bs2_clip_args(qp, cqo, a, b))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
+    moved = 0
+    for k in range(1, FRAMES):
+        want = expected_filtered(frames[k - 1][0], k, W, H, qp, cqo, a, b)
+        assert np.array_equal(frames[k][0], want), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+        moved += int((want != expected(frames[k - 1][0], k, W, H, qp, cqo)).sum())
+    assert moved > 0   # (the filter does something)
+
+
+def test_every_row_of_the_bs2_column(hw, oracle, tmp_path):
+    """QP 17 .. 51 without offsets: indexA = QP for luma: every non-zero row of the bS = 2 column of Table 8-17."""
+    for qp in range(17, 52):
+        path = str(tmp_path / ("res2_qp%d.mp4" % qp))
+        make_clip(path, width=W, height=H, yuv=False, **dict(bs2_clip_args(qp, 0, 0, 0), frames=3, gop=3))
+        frames, _ = oracle.decode_file(path, hw.index_video(path))
+        for k in range(1, 3):
+            assert np.array_equal(frames[k][0], expected_filtered(frames[k - 1][0], k, W, H, qp, 0, 0, 0)), "QP %d, picture %d" % (qp, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp,cqo,a,b", BS2_SETTINGS)
+def test_hip_path_filters_coded_blocks_edges_as_the_clauses_say(hw, tmp_path, qp, cqo, a, b):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "res2.mp4")
+    make_clip(path, width=W, height=H, yuv=False, **bs2_clip_args(qp, cqo, a, b))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
+    for k in range(1, FRAMES):
+        assert np.array_equal(got[k], expected_filtered(got[k - 1], k, W, H, qp, cqo, a, b)), "picture %d" % k
