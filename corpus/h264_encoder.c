@@ -947,10 +947,11 @@ static void global_mv_of(int k, int width, int height, int* mvx, int* mvy) {
 
 /* --global-mv 4: the level of coefficient `pos` (raster, 0..15) of 4x4 block `blk` of macroblock `addr` in picture k;
  * comp 0 luma (blk raster 0..15), 1 / 2 chroma AC of Cb / Cr (blk 0..3, pos 0 unused), 3 / 4 chroma DC of Cb / Cr (pos =
- * the block).  Restated in tests/test_residual_independent.py: sparse, small, now and then a large one. */
+ * the block), 5 luma with the 8x8 transform (blk = the 8x8 block, pos raster 0..63).  Restated in
+ * tests/test_residual_independent.py: sparse, small, now and then a large one. */
 static int global_level(int k, int addr, int comp, int blk, int pos) {
   const int t = addr * 7 + blk * 5 + pos * 3 + k * 11 + comp * 13;
-  if (comp <= 2 && (addr + blk + k) % 3 == 0) return 0; /* a third of the blocks carry nothing (their edges: bS 0) */
+  if ((comp <= 2 || comp == 5) && (addr + blk + k) % 3 == 0) return 0; /* a third of the blocks carry nothing (their edges: bS 0) */
   if (t % 5 != 0) return 0;
   int v = (addr + blk * 3 + pos + comp) % 9 - 4;
   if (t % 35 == 0) v *= 9;
@@ -1018,6 +1019,14 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
     if (e->cfg->global_mv == 4) {
       const int k = e->frame_abs;
       int cbp = 0, chroma = 0;
+      if (e->cfg->t8x8) { /* (--t8x8 1: the luma levels are those of four 8x8 blocks, comp 5, raster positions 0..63) */
+        p->t8x8 = 1;
+        for (int b8 = 0; b8 < 4; ++b8)
+          for (int pos = 0; pos < 64; ++pos) {
+            p->luma8[b8][pos] = (int16_t)global_level(k, addr, 5, b8, pos);
+            if (p->luma8[b8][pos]) cbp |= 1 << b8;
+          }
+      } else
       for (int blk = 0; blk < 16; ++blk)
         for (int pos = 0; pos < 16; ++pos) {
           p->luma[blk][pos] = (int16_t)global_level(k, addr, 0, blk, pos);

@@ -4,7 +4,8 @@ kernels - the normAdjust table and the chroma QP table included: they are typed 
 `--global-mv 4` (corpus/h264_encoder.c) writes P pictures whose macroblocks all predict with one vector from reference 0
 (tests/test_inter_independent.py) and carry a residual whose coefficient LEVELS follow from the macroblock's address, the
 block, the position and the picture's number (global_level) - sparse, small, now and then large - with the slice's QP in
-every macroblock, the 4x4 transform only and the in-loop filter switched off.  So a picture must decode to
+every macroblock and the in-loop filter switched off (further down: switched on; `--t8x8 1`: the luma levels are those
+of 8x8 blocks, 8.5.13).  So a picture must decode to
 
     Clip1(prediction + inverse transform(scaled levels))
 
@@ -38,7 +39,7 @@ def level_scale(m):
 def global_level(k, addr, comp, blk, pos):
     """corpus/h264_encoder.c: global_level."""
     t = addr * 7 + blk * 5 + pos * 3 + k * 11 + comp * 13
-    if comp <= 2 and (addr + blk + k) % 3 == 0:
+    if (comp <= 2 or comp == 5) and (addr + blk + k) % 3 == 0:
         return 0   # a third of the blocks carry nothing (their edges: bS 0)
     if t % 5 != 0:
         return 0
@@ -74,6 +75,60 @@ def residual_luma(k, addr, qp):
     return r
 
 
+# 8.5.9, normAdjust8x8(m, i, j): six classes of positions
+NORM_ADJUST8 = [(20, 18, 32, 19, 25, 24), (22, 19, 35, 21, 28, 26), (26, 23, 42, 24, 33, 31), (28, 25, 45, 26, 35, 33),
+                (32, 28, 51, 30, 40, 38), (36, 32, 58, 34, 46, 43)]
+
+
+def level_scale8(m):
+    ls = np.zeros((8, 8), dtype=np.int64)
+    for i in range(8):
+        for j in range(8):
+            if i % 4 == 0 and j % 4 == 0:
+                cls = 0
+            elif i % 2 == 1 and j % 2 == 1:
+                cls = 1
+            elif i % 4 == 2 and j % 4 == 2:
+                cls = 2
+            elif (i % 4 == 0 and j % 2 == 1) or (i % 2 == 1 and j % 4 == 0):
+                cls = 3
+            elif (i % 4 == 0 and j % 4 == 2) or (i % 4 == 2 and j % 4 == 0):
+                cls = 4
+            else:
+                cls = 5
+            ls[i, j] = 16 * NORM_ADJUST8[m][cls]
+    return ls
+
+
+def inverse8x8(c, qp):
+    """8.5.13: scaling, the one-dimensional transform over every row, then over every column, (x + 32) >> 6."""
+    ls = level_scale8(qp % 6)
+    d = (c * ls) << (qp // 6 - 6) if qp >= 36 else (c * ls + (1 << (5 - qp // 6))) >> (6 - qp // 6)
+
+    def one_d(v):
+        a0, a4 = v[0] + v[4], v[0] - v[4]
+        a2, a6 = (v[2] >> 1) - v[6], v[2] + (v[6] >> 1)
+        a1 = -v[3] + v[5] - v[7] - (v[7] >> 1)
+        a3 = v[1] + v[7] - v[3] - (v[3] >> 1)
+        a5 = -v[1] + v[7] + v[5] + (v[5] >> 1)
+        a7 = v[3] + v[5] + v[1] + (v[1] >> 1)
+        b0, b2, b4, b6 = a0 + a6, a4 + a2, a4 - a2, a0 - a6
+        b1, b3, b5, b7 = a1 + (a7 >> 2), a3 + (a5 >> 2), (a3 >> 2) - a5, a7 - (a1 >> 2)
+        return [b0 + b7, b2 + b5, b4 + b3, b6 + b1, b6 - b1, b4 - b3, b2 - b5, b0 - b7]
+    f = np.stack(one_d([d[:, n] for n in range(8)]), axis=1)
+    g = np.stack(one_d([f[n, :] for n in range(8)]), axis=0)
+    return (g + 32) >> 6
+
+
+def residual_luma8(k, addr, qp):
+    r = np.zeros((16, 16), dtype=np.int64)
+    for b8 in range(4):
+        c = np.array([[global_level(k, addr, 5, b8, i * 8 + j) for j in range(8)] for i in range(8)], dtype=np.int64)
+        by, bx = (b8 // 2) * 8, (b8 % 2) * 8
+        r[by:by + 8, bx:bx + 8] = inverse8x8(c, qp)
+    return r
+
+
 def residual_chroma(k, addr, pl, qpc):
     """8.5.11: the four DC levels through the 2x2 transform and their own scaling, then each block's AC with that DC."""
     c = np.array([[global_level(k, addr, 3 + pl, 0, 0), global_level(k, addr, 3 + pl, 0, 1)],
@@ -92,15 +147,16 @@ def residual_chroma(k, addr, pl, qpc):
     return r
 
 
-def expected(prev, k, w, h, qp, cqo):
+def expected(prev, k, w, h, qp, cqo, t8x8=False):
     mv = global_mv_of(k, w, h)
     y, u, v = planes(prev, w, h)
     py, pu, pv = (shift_luma(y, *mv).astype(np.int64), shift_chroma(u, *mv).astype(np.int64), shift_chroma(v, *mv).astype(np.int64))
     mbw = w // 16
-    qpcs = (chroma_qp(qp, cqo), chroma_qp(qp, cqo))   # (--t8x8 0: the PPS carries no second_chroma_qp_index_offset, Cr follows Cb)
+    # Cr: without the PPS extension (--t8x8 0) it follows Cb; with it the corpus encoder writes one less when positive
+    qpcs = (chroma_qp(qp, cqo), chroma_qp(qp, cqo - 1 if (t8x8 and cqo > 0) else cqo))
     for addr in range(mbw * (h // 16)):
         mx, my = addr % mbw, addr // mbw
-        py[my * 16:my * 16 + 16, mx * 16:mx * 16 + 16] += residual_luma(k, addr, qp)
+        py[my * 16:my * 16 + 16, mx * 16:mx * 16 + 16] += residual_luma8(k, addr, qp) if t8x8 else residual_luma(k, addr, qp)
         pu[my * 8:my * 8 + 8, mx * 8:mx * 8 + 8] += residual_chroma(k, addr, 0, qpcs[0])
         pv[my * 8:my * 8 + 8, mx * 8:mx * 8 + 8] += residual_chroma(k, addr, 1, qpcs[1])
     return np.concatenate([np.clip(p, 0, 255).astype(np.uint8).ravel() for p in (py, pu, pv)])
@@ -129,6 +185,34 @@ def test_oracle_adds_known_residuals_as_the_clauses_say(hw, oracle, tmp_path, qp
         mv = global_mv_of(k, W, H)
         moved += int((want[:W * H].reshape(H, W) != shift_luma(planes(frames[k - 1][0], W, H)[0], *mv)).sum())
     assert moved > 0   # (the residual does something)
+
+
+T8_SETTINGS = [(12, 0), (19, 0), (26, 0), (27, 0), (28, 0), (29, 0), (35, 0), (36, 0), (37, 0), (44, 3), (51, 0)]   # both sides of QP 36
+
+
+@pytest.mark.parametrize("qp,cqo", T8_SETTINGS)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_adds_known_8x8_residuals_as_the_clauses_say(hw, oracle, tmp_path, qp, cqo, cabac):
+    path = str(tmp_path / "res8.mp4")
+    gold = make_clip(path, width=W, height=H, cabac=cabac, **dict(clip_args(qp, cqo), t8x8=1))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
+    for k in range(1, FRAMES):
+        assert np.array_equal(frames[k][0], expected(frames[k - 1][0], k, W, H, qp, cqo, True)), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp,cqo", T8_SETTINGS)
+def test_hip_path_adds_known_8x8_residuals_as_the_clauses_say(hw, tmp_path, qp, cqo):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "res8.mp4")
+    make_clip(path, width=W, height=H, yuv=False, **dict(clip_args(qp, cqo), t8x8=1))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
+    for k in range(1, FRAMES):
+        assert np.array_equal(got[k], expected(got[k - 1], k, W, H, qp, cqo, True)), "picture %d" % k
 
 
 @pytest.mark.gpu
