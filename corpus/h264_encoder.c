@@ -947,7 +947,8 @@ static void global_mv_of(int k, int width, int height, int* mvx, int* mvy) {
 
 /* --global-mv 4: the level of coefficient `pos` (raster, 0..15) of 4x4 block `blk` of macroblock `addr` in picture k;
  * comp 0 luma (blk raster 0..15), 1 / 2 chroma AC of Cb / Cr (blk 0..3, pos 0 unused), 3 / 4 chroma DC of Cb / Cr (pos =
- * the block), 5 luma with the 8x8 transform (blk = the 8x8 block, pos raster 0..63).  Restated in
+ * the block), 5 luma with the 8x8 transform (blk = the 8x8 block, pos raster 0..63), 6 the Intra16x16 luma DC levels
+ * (pos = the block's position in the macroblock, raster).  Restated in
  * tests/test_residual_independent.py: sparse, small, now and then a large one. */
 static int global_level(int k, int addr, int comp, int blk, int pos) {
   const int t = addr * 7 + blk * 5 + pos * 3 + k * 11 + comp * 13;
@@ -1016,7 +1017,39 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
     /* --global-mv 4: the prediction plus a residual whose levels follow from position and picture number alone
      * (global_level): dequantisation and the 4x4 inverse transforms (luma, chroma AC, chroma DC) on known input.  The
      * macroblock's QP is the slice's (no mb_qp_delta worth the name), the 8x8 transform stays off */
-    if (e->cfg->global_mv == 4) {
+    /* --global-mv 5: as 4, but every other macroblock of a checkerboard is an Intra16x16 macroblock with known levels
+     * (the luma DC levels of comp 6 and the AC levels of comp 0) whose prediction modes follow from address and picture
+     * number where the neighbours allow them: Intra16x16 and chroma prediction from neighbouring inter macroblocks, the
+     * luma DC path (8.5.10) */
+    if (e->cfg->global_mv == 5 && ((d->mb.mbx + d->mb.mby) & 1)) {
+      const int k = e->frame_abs, left = d->mb.mbx > 0, top = d->mb.mby > 0;
+      int mode = (addr + k) % 4, cmode = (addr * 3 + k) % 4, any_ac = 0, chroma = 0;
+      if ((mode == 0 && !top) || (mode == 1 && !left) || (mode == 3 && !(left && top))) mode = 2;
+      if ((cmode == 1 && !left) || (cmode == 2 && !top) || (cmode == 3 && !(left && top))) cmode = 0;
+      p->kind = MB_I16x16;
+      p->i16_mode = mode;
+      p->chroma_mode = cmode;
+      for (int pos = 0; pos < 16; ++pos) p->luma_dc[pos] = (int16_t)global_level(k, addr, 6, 0, pos);
+      for (int blk = 0; blk < 16; ++blk)
+        for (int pos = 1; pos < 16; ++pos) {
+          p->luma[blk][pos] = (int16_t)global_level(k, addr, 0, blk, pos);
+          if (p->luma[blk][pos]) any_ac = 1;
+        }
+      for (int pl = 0; pl < 2; ++pl)
+        for (int blk = 0; blk < 4; ++blk) {
+          p->chroma_dc[pl][blk] = (int16_t)global_level(k, addr, 3 + pl, 0, blk);
+          if (p->chroma_dc[pl][blk] && chroma < 1) chroma = 1;
+          for (int pos = 1; pos < 16; ++pos) {
+            p->chroma_ac[pl][blk][pos] = (int16_t)global_level(k, addr, 1 + pl, blk, pos);
+            if (p->chroma_ac[pl][blk][pos]) chroma = 2;
+          }
+        }
+      p->cbp = (any_ac ? 15 : 0) | chroma << 4;
+      p->mb_type_raw = 5 + 1 + mode + 4 * chroma + (any_ac ? 12 : 0);
+      p->qp = e->cfg->qp;
+      return;
+    }
+    if (e->cfg->global_mv == 4 || e->cfg->global_mv == 5) {
       const int k = e->frame_abs;
       int cbp = 0, chroma = 0;
       if (e->cfg->t8x8) { /* (--t8x8 1: the luma levels are those of four 8x8 blocks, comp 5, raster positions 0..63) */

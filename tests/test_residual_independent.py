@@ -341,3 +341,150 @@ def test_hip_path_filters_coded_blocks_edges_as_the_clauses_say(hw, tmp_path, qp
     got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
     for k in range(1, FRAMES):
         assert np.array_equal(got[k], expected_filtered(got[k - 1], k, W, H, qp, cqo, a, b)), "picture %d" % k
+
+
+# ---- Intra16x16 macroblocks with known levels among the inter ones (--global-mv 5) ----------------------------------------
+# Odd macroblocks of the checkerboard: Intra16x16 with prediction modes that follow from address and picture number, the
+# luma DC levels of comp 6 (8.5.10: 4x4 Hadamard + its own scaling), AC levels of comp 0, chroma as before.  Their
+# neighbours are inter macroblocks (and, diagonally, intra ones) of the same picture: the picture is rebuilt macroblock
+# by macroblock in decoding order.  Filter off.
+def pred16(img, x0, y0, mode):
+    """8.3.3: Intra16x16 prediction at (x0, y0) of the luma plane under reconstruction."""
+    top = img[y0 - 1, x0:x0 + 16] if y0 > 0 else None
+    left = img[y0:y0 + 16, x0 - 1] if x0 > 0 else None
+    if mode == 0:
+        return np.tile(top, (16, 1))
+    if mode == 1:
+        return np.tile(left.reshape(16, 1), (1, 16))
+    if mode == 2:
+        if top is not None and left is not None:
+            dc = (int(top.sum()) + int(left.sum()) + 16) >> 5
+        elif top is not None or left is not None:
+            dc = (int((top if top is not None else left).sum()) + 8) >> 4
+        else:
+            dc = 128
+        return np.full((16, 16), dc, dtype=np.int64)
+    p = lambda x, y: int(img[y0 + y, x0 + x])   # noqa: E731  (x or y may be -1)
+    hh = sum((i + 1) * (p(8 + i, -1) - p(6 - i, -1)) for i in range(8))
+    vv = sum((i + 1) * (p(-1, 8 + i) - p(-1, 6 - i)) for i in range(8))
+    a, b, c = 16 * (p(-1, 15) + p(15, -1)), (5 * hh + 32) >> 6, (5 * vv + 32) >> 6
+    return np.array([[clip3(0, 255, (a + b * (x - 7) + c * (y - 7) + 16) >> 5) for x in range(16)] for y in range(16)], dtype=np.int64)
+
+
+def pred_chroma(img, x0, y0, mode):
+    """8.3.4: chroma prediction (4:2:0) at (x0, y0) of a chroma plane under reconstruction."""
+    top = img[y0 - 1, x0:x0 + 8] if y0 > 0 else None
+    left = img[y0:y0 + 8, x0 - 1] if x0 > 0 else None
+    if mode == 2:
+        return np.tile(top, (8, 1))
+    if mode == 1:
+        return np.tile(left.reshape(8, 1), (1, 8))
+    if mode == 0:
+        out = np.zeros((8, 8), dtype=np.int64)
+        for by in range(2):
+            for bx in range(2):
+                t = int(top[bx * 4:bx * 4 + 4].sum()) if top is not None else None
+                lf = int(left[by * 4:by * 4 + 4].sum()) if left is not None else None
+                if (bx, by) in ((0, 0), (1, 1)):
+                    dc = (t + lf + 4) >> 3 if (t is not None and lf is not None) else ((t + 2) >> 2 if t is not None else ((lf + 2) >> 2 if lf is not None else 128))
+                elif (bx, by) == (1, 0):   # prefers the samples above
+                    dc = (t + 2) >> 2 if t is not None else ((lf + 2) >> 2 if lf is not None else 128)
+                else:                      # (0, 1): prefers the samples to the left
+                    dc = (lf + 2) >> 2 if lf is not None else ((t + 2) >> 2 if t is not None else 128)
+                out[by * 4:by * 4 + 4, bx * 4:bx * 4 + 4] = dc
+        return out
+    p = lambda x, y: int(img[y0 + y, x0 + x])   # noqa: E731
+    hh = sum((i + 1) * (p(4 + i, -1) - p(2 - i, -1)) for i in range(4))
+    vv = sum((i + 1) * (p(-1, 4 + i) - p(-1, 2 - i)) for i in range(4))
+    a, b, c = 16 * (p(-1, 7) + p(7, -1)), (34 * hh + 32) >> 6, (34 * vv + 32) >> 6
+    return np.array([[clip3(0, 255, (a + b * (x - 3) + c * (y - 3) + 16) >> 5) for x in range(8)] for y in range(8)], dtype=np.int64)
+
+
+def residual_luma16(k, addr, qp):
+    """8.5.10 + 8.5.12: the DC levels through the 4x4 Hadamard transform and their scaling, then every block's AC."""
+    c = np.array([[global_level(k, addr, 6, 0, i * 4 + j) for j in range(4)] for i in range(4)], dtype=np.int64)
+    hm = np.array([[1, 1, 1, 1], [1, 1, -1, -1], [1, -1, -1, 1], [1, -1, 1, -1]], dtype=np.int64)
+    f = hm @ c @ hm
+    ls = level_scale(qp % 6)[0, 0]
+    dc = (f * ls) << (qp // 6 - 6) if qp >= 36 else (f * ls + (1 << (5 - qp // 6))) >> (6 - qp // 6)
+    r = np.zeros((16, 16), dtype=np.int64)
+    for blk in range(16):
+        lv = np.array([[0 if (i == 0 and j == 0) else global_level(k, addr, 0, blk, i * 4 + j) for j in range(4)] for i in range(4)],
+                      dtype=np.int64)
+        d = scale_ac(lv, qp)
+        d[0, 0] = dc[blk // 4, blk % 4]
+        by, bx = (blk // 4) * 4, (blk % 4) * 4
+        r[by:by + 4, bx:bx + 4] = inverse4x4(d)
+    return r
+
+
+def expected_intra16(prev, k, w, h, qp):
+    mv = global_mv_of(k, w, h)
+    y, u, v = planes(prev, w, h)
+    sy, su, sv = shift_luma(y, *mv).astype(np.int64), shift_chroma(u, *mv).astype(np.int64), shift_chroma(v, *mv).astype(np.int64)
+    oy, ou, ov = np.zeros_like(sy), np.zeros_like(su), np.zeros_like(sv)
+    mbw, qpc = w // 16, chroma_qp(qp, 0)
+    for addr in range(mbw * (h // 16)):
+        mx, my = addr % mbw, addr // mbw
+        ly, lx, cy, cx = my * 16, mx * 16, my * 8, mx * 8
+        if (mx + my) & 1:
+            left, top = mx > 0, my > 0
+            mode, cmode = (addr + k) % 4, (addr * 3 + k) % 4
+            if (mode == 0 and not top) or (mode == 1 and not left) or (mode == 3 and not (left and top)):
+                mode = 2
+            if (cmode == 1 and not left) or (cmode == 2 and not top) or (cmode == 3 and not (left and top)):
+                cmode = 0
+            py = pred16(oy, lx, ly, mode) + residual_luma16(k, addr, qp)
+            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc)
+            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc)
+        else:
+            py = sy[ly:ly + 16, lx:lx + 16] + residual_luma(k, addr, qp)
+            pu = su[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 0, qpc)
+            pv = sv[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 1, qpc)
+        oy[ly:ly + 16, lx:lx + 16] = np.clip(py, 0, 255)
+        ou[cy:cy + 8, cx:cx + 8] = np.clip(pu, 0, 255)
+        ov[cy:cy + 8, cx:cx + 8] = np.clip(pv, 0, 255)
+    return np.concatenate([p.astype(np.uint8).ravel() for p in (oy, ou, ov)])
+
+
+I16_QPS = [5, 10, 14, 22, 26, 29, 33, 35, 36, 37, 42, 51]   # both sides of QP 36 (the DC scaling case split); below 12 its rounding term counts
+I16_SIZE = (112, 80)                                  # 7 x 5 macroblocks: every mode meets every kind of neighbourhood
+
+
+@pytest.mark.parametrize("qp", I16_QPS)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_rebuilds_known_intra16_macroblocks_as_the_clauses_say(hw, oracle, tmp_path, qp, cabac):
+    w, h = I16_SIZE
+    path = str(tmp_path / "i16.mp4")
+    gold = make_clip(path, width=w, height=h, cabac=cabac, **dict(clip_args(qp, 0), global_mv=5))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
+    for k in range(1, FRAMES):
+        assert np.array_equal(frames[k][0], expected_intra16(frames[k - 1][0], k, w, h, qp)), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+
+
+def test_every_intra16_and_chroma_mode_occurs():
+    w, h = I16_SIZE
+    mbw, seen16, seenc = w // 16, set(), set()
+    for k in range(1, FRAMES):
+        for addr in range(mbw * (h // 16)):
+            mx, my = addr % mbw, addr // mbw
+            if (mx + my) & 1 and mx > 0 and my > 0:
+                seen16.add((addr + k) % 4)
+                seenc.add((addr * 3 + k) % 4)
+    assert seen16 == {0, 1, 2, 3} and seenc == {0, 1, 2, 3}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp", I16_QPS)
+def test_hip_path_rebuilds_known_intra16_macroblocks_as_the_clauses_say(hw, tmp_path, qp):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = I16_SIZE
+    path = str(tmp_path / "i16.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(clip_args(qp, 0), global_mv=5))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
+    for k in range(1, FRAMES):
+        assert np.array_equal(got[k], expected_intra16(got[k - 1], k, w, h, qp)), "picture %d" % k
