@@ -488,3 +488,117 @@ def test_hip_path_rebuilds_known_intra16_macroblocks_as_the_clauses_say(hw, tmp_
     got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
     for k in range(1, FRAMES):
         assert np.array_equal(got[k], expected_intra16(got[k - 1], k, w, h, qp)), "picture %d" % k
+
+
+# ---- the same mixed pictures with the in-loop filter on: all boundary strengths in one picture ----------------------------
+# Macroblock edges next to an Intra16x16 macroblock: bS 4; that macroblock's inner edges: bS 3; an inter macroblock's
+# edges: 2 where a 4x4 block on either side carries a level, else 0.  Every macroblock has the slice's QP.
+TC0_BS3 = [0] * 17 + [1] * 10 + [2] * 4 + [3, 3, 3, 4, 4, 4, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 23, 25]   # Table 8-17, bS = 3
+assert len(TC0_BS3) == 52
+
+
+def filter_picture_mixed(y, u, v, k, w, h, qp, qpc, alpha_div2, beta_div2):
+    mbw, mbh = w // 16, h // 16
+    nz = np.zeros((mbh * 4, mbw * 4), dtype=bool)
+    intra = np.zeros((mbh, mbw), dtype=bool)
+    for addr in range(mbw * mbh):
+        mx, my = addr % mbw, addr // mbw
+        intra[my, mx] = (mx + my) & 1
+        for blk in range(16):
+            nz[my * 4 + blk // 4, mx * 4 + blk % 4] = coded(k, addr, blk)
+
+    def thr(q, bs):
+        ia, ib = clip3(0, 51, q + 2 * alpha_div2), clip3(0, 51, q + 2 * beta_div2)
+        return ALPHA[ia], BETA[ib], (None if bs == 4 else (TC0_BS2 if bs == 2 else TC0_BS3)[ia])
+    pl = [p.astype(np.int64) for p in (y, u, v)]
+    for my in range(mbh):
+        for mx in range(mbw):
+            for vertical in (True, False):
+                for e in range(4):
+                    if e == 0 and (mx == 0 if vertical else my == 0):
+                        continue
+                    for seg in range(4):
+                        if vertical:
+                            by, bx = my * 4 + seg, mx * 4 + e
+                            pby, pbx, pmy, pmx = by, bx - 1, my, (mx - 1 if e == 0 else mx)
+                        else:
+                            by, bx = my * 4 + e, mx * 4 + seg
+                            pby, pbx, pmy, pmx = by - 1, bx, (my - 1 if e == 0 else my), mx
+                        if intra[my, mx] or intra[pmy, pmx]:
+                            bs = 4 if e == 0 else 3
+                        else:
+                            bs = 2 if (nz[by, bx] or nz[pby, pbx]) else 0
+                        if bs == 0:
+                            continue
+                        for p_i, (a, chroma) in enumerate(((pl[0], False), (pl[1], True), (pl[2], True))):
+                            if chroma and e % 2:
+                                continue
+                            alpha, beta, tc0 = thr(qpc if chroma else qp, bs)
+                            n, reach = (2, 2) if chroma else (4, 4)
+                            for i in range(n):
+                                if vertical:
+                                    x0 = (mx * 16 + e * 4) // (2 if chroma else 1)
+                                    yy = (my * 16 + seg * 4) // (2 if chroma else 1) + i
+                                    px = [0] * 8
+                                    px[4 - reach:4 + reach] = [int(t) for t in a[yy, x0 - reach:x0 + reach]]
+                                    filter_line(px, chroma, alpha, beta, tc0)
+                                    a[yy, x0 - reach:x0 + reach] = px[4 - reach:4 + reach]
+                                else:
+                                    y0 = (my * 16 + e * 4) // (2 if chroma else 1)
+                                    xx = (mx * 16 + seg * 4) // (2 if chroma else 1) + i
+                                    px = [0] * 8
+                                    px[4 - reach:4 + reach] = [int(t) for t in a[y0 - reach:y0 + reach, xx]]
+                                    filter_line(px, chroma, alpha, beta, tc0)
+                                    a[y0 - reach:y0 + reach, xx] = px[4 - reach:4 + reach]
+    return np.concatenate([np.clip(p, 0, 255).astype(np.uint8).ravel() for p in pl])
+
+
+def expected_mixed_filtered(prev, k, w, h, qp, alpha_div2, beta_div2):
+    y, u, v = planes(expected_intra16(prev, k, w, h, qp), w, h)
+    return filter_picture_mixed(y, u, v, k, w, h, qp, chroma_qp(qp, 0), alpha_div2, beta_div2)
+
+
+# (QP, FilterOffsetA / 2, FilterOffsetB / 2)
+MIXED_SETTINGS = [(22, 0, 0), (28, 0, 0), (34, 0, 0), (40, 0, 0), (46, 0, 0), (51, 0, 0), (30, 3, -2), (37, -2, 3), (25, 6, 6)]
+
+
+def mixed_clip_args(qp, a, b):
+    return dict(clip_args(qp, 0), global_mv=5, deblock=0, alpha=a, beta=b)
+
+
+@pytest.mark.parametrize("qp,a,b", MIXED_SETTINGS)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_filters_mixed_pictures_as_the_clauses_say(hw, oracle, tmp_path, qp, a, b, cabac):
+    w, h = I16_SIZE
+    path = str(tmp_path / "mix.mp4")
+    gold = make_clip(path, width=w, height=h, cabac=cabac, **mixed_clip_args(qp, a, b))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
+    for k in range(1, FRAMES):
+        assert np.array_equal(frames[k][0], expected_mixed_filtered(frames[k - 1][0], k, w, h, qp, a, b)), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+
+
+def test_every_row_of_the_bs3_column(hw, oracle, tmp_path):
+    """QP 17 .. 51 without offsets: every non-zero row of the bS = 3 column of Table 8-17 (an Intra16x16 macroblock's inner edges)."""
+    w, h = I16_SIZE
+    for qp in range(17, 52):
+        path = str(tmp_path / ("mix_qp%d.mp4" % qp))
+        make_clip(path, width=w, height=h, yuv=False, **dict(mixed_clip_args(qp, 0, 0), frames=3, gop=3))
+        frames, _ = oracle.decode_file(path, hw.index_video(path))
+        for k in range(1, 3):
+            assert np.array_equal(frames[k][0], expected_mixed_filtered(frames[k - 1][0], k, w, h, qp, 0, 0)), "QP %d, picture %d" % (qp, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp,a,b", MIXED_SETTINGS)
+def test_hip_path_filters_mixed_pictures_as_the_clauses_say(hw, tmp_path, qp, a, b):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = I16_SIZE
+    path = str(tmp_path / "mix.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **mixed_clip_args(qp, a, b))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
+    for k in range(1, FRAMES):
+        assert np.array_equal(got[k], expected_mixed_filtered(got[k - 1], k, w, h, qp, a, b)), "picture %d" % k
