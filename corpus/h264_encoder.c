@@ -1049,7 +1049,37 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
       p->qp = e->cfg->qp;
       return;
     }
-    if (e->cfg->global_mv == 4 || e->cfg->global_mv == 5) {
+    /* --global-mv 6: as 5 with Intra4x4 macroblocks: each 4x4 block's prediction mode follows from address, block and
+     * picture number (inside the picture all nine are legal everywhere; a macroblock on the left or top border takes DC
+     * throughout), levels of comp 0 incl. position 0 */
+    if (e->cfg->global_mv == 6 && ((d->mb.mbx + d->mb.mby) & 1)) {
+      const int k = e->frame_abs, inside = d->mb.mbx > 0 && d->mb.mby > 0;
+      int cmode = (addr * 3 + k) % 4, cbp = 0, chroma = 0;
+      if ((cmode == 1 && d->mb.mbx == 0) || (cmode == 2 && d->mb.mby == 0) || (cmode == 3 && !inside)) cmode = 0;
+      p->kind = MB_I4x4;
+      p->mb_type_raw = 5;
+      p->chroma_mode = cmode;
+      for (int blk = 0; blk < 16; ++blk) {
+        p->i4_mode[blk] = (int8_t)(inside ? (addr * 5 + blk * 7 + k) % 9 : 2);
+        for (int pos = 0; pos < 16; ++pos) {
+          p->luma[blk][pos] = (int16_t)global_level(k, addr, 0, blk, pos);
+          if (p->luma[blk][pos]) cbp |= 1 << ((blk >> 3) * 2 + ((blk & 3) >> 1));
+        }
+      }
+      for (int pl = 0; pl < 2; ++pl)
+        for (int blk = 0; blk < 4; ++blk) {
+          p->chroma_dc[pl][blk] = (int16_t)global_level(k, addr, 3 + pl, 0, blk);
+          if (p->chroma_dc[pl][blk] && chroma < 1) chroma = 1;
+          for (int pos = 1; pos < 16; ++pos) {
+            p->chroma_ac[pl][blk][pos] = (int16_t)global_level(k, addr, 1 + pl, blk, pos);
+            if (p->chroma_ac[pl][blk][pos]) chroma = 2;
+          }
+        }
+      p->cbp = cbp | chroma << 4;
+      p->qp = e->cfg->qp;
+      return;
+    }
+    if (e->cfg->global_mv >= 4 && e->cfg->global_mv <= 6) {
       const int k = e->frame_abs;
       int cbp = 0, chroma = 0;
       if (e->cfg->t8x8) { /* (--t8x8 1: the luma levels are those of four 8x8 blocks, comp 5, raster positions 0..63) */

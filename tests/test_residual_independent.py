@@ -602,3 +602,157 @@ def test_hip_path_filters_mixed_pictures_as_the_clauses_say(hw, tmp_path, qp, a,
     got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
     for k in range(1, FRAMES):
         assert np.array_equal(got[k], expected_mixed_filtered(got[k - 1], k, w, h, qp, a, b)), "picture %d" % k
+
+
+# ---- Intra4x4 macroblocks with known modes and levels (--global-mv 6) -----------------------------------------------------
+def pred4(img, x0, y0, mode, top_right_ok, w):
+    """8.3.1.2: the nine Intra4x4 prediction modes for the block at (x0, y0) of the luma plane under reconstruction.
+    Inside the picture (x0, y0 > 0) left, top and top-left samples exist; the top-right ones (E..H) are replaced by D
+    when that block has not been decoded yet or lies outside the picture."""
+    p = {}
+    for i in range(4):
+        p[(i, -1)] = int(img[y0 - 1, x0 + i]) if y0 > 0 else None
+        p[(-1, i)] = int(img[y0 + i, x0 - 1]) if x0 > 0 else None
+    for i in range(4):
+        p[(4 + i, -1)] = (int(img[y0 - 1, x0 + 4 + i]) if top_right_ok else p[(3, -1)]) if y0 > 0 else None
+    p[(-1, -1)] = int(img[y0 - 1, x0 - 1]) if (x0 > 0 and y0 > 0) else None
+    out = np.zeros((4, 4), dtype=np.int64)
+    if mode == 2:
+        t = [p[(i, -1)] for i in range(4)] if y0 > 0 else None
+        lf = [p[(-1, i)] for i in range(4)] if x0 > 0 else None
+        if t and lf:
+            out[:] = (sum(t) + sum(lf) + 4) >> 3
+        elif t or lf:
+            out[:] = (sum(t or lf) + 2) >> 2
+        else:
+            out[:] = 128
+        return out
+    for y in range(4):
+        for x in range(4):
+            if mode == 0:
+                v = p[(x, -1)]
+            elif mode == 1:
+                v = p[(-1, y)]
+            elif mode == 3:   # diagonal down-left
+                v = (p[(6, -1)] + 3 * p[(7, -1)] + 2) >> 2 if (x == 3 and y == 3) else (p[(x + y, -1)] + 2 * p[(x + y + 1, -1)] + p[(x + y + 2, -1)] + 2) >> 2
+            elif mode == 4:   # diagonal down-right
+                if x > y:
+                    v = (p[(x - y - 2, -1)] + 2 * p[(x - y - 1, -1)] + p[(x - y, -1)] + 2) >> 2
+                elif x < y:
+                    v = (p[(-1, y - x - 2)] + 2 * p[(-1, y - x - 1)] + p[(-1, y - x)] + 2) >> 2
+                else:
+                    v = (p[(0, -1)] + 2 * p[(-1, -1)] + p[(-1, 0)] + 2) >> 2
+            elif mode == 5:   # vertical-right
+                z, s = 2 * x - y, x - (y >> 1)
+                if z >= 0 and z % 2 == 0:
+                    v = (p[(s - 1, -1)] + p[(s, -1)] + 1) >> 1
+                elif z >= 0:
+                    v = (p[(s - 2, -1)] + 2 * p[(s - 1, -1)] + p[(s, -1)] + 2) >> 2
+                elif z == -1:
+                    v = (p[(-1, 0)] + 2 * p[(-1, -1)] + p[(0, -1)] + 2) >> 2
+                else:
+                    v = (p[(-1, y - 1)] + 2 * p[(-1, y - 2)] + p[(-1, y - 3)] + 2) >> 2
+            elif mode == 6:   # horizontal-down
+                z, s = 2 * y - x, y - (x >> 1)
+                if z >= 0 and z % 2 == 0:
+                    v = (p[(-1, s - 1)] + p[(-1, s)] + 1) >> 1
+                elif z >= 0:
+                    v = (p[(-1, s - 2)] + 2 * p[(-1, s - 1)] + p[(-1, s)] + 2) >> 2
+                elif z == -1:
+                    v = (p[(-1, 0)] + 2 * p[(-1, -1)] + p[(0, -1)] + 2) >> 2
+                else:
+                    v = (p[(x - 1, -1)] + 2 * p[(x - 2, -1)] + p[(x - 3, -1)] + 2) >> 2
+            elif mode == 7:   # vertical-left
+                s = x + (y >> 1)
+                v = (p[(s, -1)] + p[(s + 1, -1)] + 1) >> 1 if y % 2 == 0 else (p[(s, -1)] + 2 * p[(s + 1, -1)] + p[(s + 2, -1)] + 2) >> 2
+            else:             # 8: horizontal-up
+                z, s = x + 2 * y, y + (x >> 1)
+                if z > 5:
+                    v = p[(-1, 3)]
+                elif z == 5:
+                    v = (p[(-1, 2)] + 3 * p[(-1, 3)] + 2) >> 2
+                elif z % 2 == 0:
+                    v = (p[(-1, s)] + p[(-1, s + 1)] + 1) >> 1
+                else:
+                    v = (p[(-1, s)] + 2 * p[(-1, s + 1)] + p[(-1, s + 2)] + 2) >> 2
+            out[y, x] = v
+    # (the named sample p[-1, -1] and the four-sample runs use x < 0 / y < 0 only where the mode allows it)
+    return out
+
+
+def expected_intra4(prev, k, w, h, qp):
+    mv = global_mv_of(k, w, h)
+    y, u, v = planes(prev, w, h)
+    sy, su, sv = shift_luma(y, *mv).astype(np.int64), shift_chroma(u, *mv).astype(np.int64), shift_chroma(v, *mv).astype(np.int64)
+    oy, ou, ov = np.zeros_like(sy), np.zeros_like(su), np.zeros_like(sv)
+    mbw, mbh, qpc = w // 16, h // 16, chroma_qp(qp, 0)
+    for addr in range(mbw * mbh):
+        mx, my = addr % mbw, addr // mbw
+        ly, lx, cy, cx = my * 16, mx * 16, my * 8, mx * 8
+        if (mx + my) & 1:
+            inside = mx > 0 and my > 0
+            cmode = (addr * 3 + k) % 4
+            if (cmode == 1 and mx == 0) or (cmode == 2 and my == 0) or (cmode == 3 and not inside):
+                cmode = 0
+            for idx in range(16):   # the 4x4 blocks in decoding order (6.4.3)
+                bx, by = (idx & 1) + ((idx >> 2) & 1) * 2, ((idx >> 1) & 1) + ((idx >> 3) & 1) * 2
+                blk = by * 4 + bx
+                mode = (addr * 5 + blk * 7 + k) % 9 if inside else 2
+                if by == 0:   # the block above-right lies in the macroblock above, or (bx = 3) in the one above-right
+                    tr_ok = my > 0 and (bx < 3 or mx + 1 < mbw)
+                else:         # inside this macroblock: decoded already only for these positions; bx = 3: to the right, never
+                    tr_ok = (bx, by) in ((0, 1), (0, 2), (0, 3), (2, 1), (2, 2), (2, 3), (1, 2))
+                c = np.array([[global_level(k, addr, 0, blk, i * 4 + j) for j in range(4)] for i in range(4)], dtype=np.int64)
+                x0, y0 = lx + bx * 4, ly + by * 4
+                oy[y0:y0 + 4, x0:x0 + 4] = np.clip(pred4(oy, x0, y0, mode, tr_ok, w) + inverse4x4(scale_ac(c, qp)), 0, 255)
+            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc)
+            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc)
+        else:
+            oy[ly:ly + 16, lx:lx + 16] = np.clip(sy[ly:ly + 16, lx:lx + 16] + residual_luma(k, addr, qp), 0, 255)
+            pu = su[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 0, qpc)
+            pv = sv[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 1, qpc)
+        ou[cy:cy + 8, cx:cx + 8] = np.clip(pu, 0, 255)
+        ov[cy:cy + 8, cx:cx + 8] = np.clip(pv, 0, 255)
+    return np.concatenate([p.astype(np.uint8).ravel() for p in (oy, ou, ov)])
+
+
+I4_QPS = [20, 28, 37, 46]
+
+
+@pytest.mark.parametrize("qp", I4_QPS)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_rebuilds_known_intra4_macroblocks_as_the_clauses_say(hw, oracle, tmp_path, qp, cabac):
+    w, h = I16_SIZE
+    path = str(tmp_path / "i4.mp4")
+    gold = make_clip(path, width=w, height=h, cabac=cabac, **dict(clip_args(qp, 0), global_mv=6, frames=12, gop=12))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == 12
+    for k in range(1, 12):
+        assert np.array_equal(frames[k][0], expected_intra4(frames[k - 1][0], k, w, h, qp)), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+
+
+def test_every_intra4_mode_occurs_at_every_block():
+    w, h = I16_SIZE
+    mbw, seen = w // 16, set()
+    for k in range(1, 12):
+        for addr in range(mbw * (h // 16)):
+            mx, my = addr % mbw, addr // mbw
+            if (mx + my) & 1 and mx > 0 and my > 0:
+                for blk in range(16):
+                    seen.add((blk, (addr * 5 + blk * 7 + k) % 9))
+    assert len(seen) == 16 * 9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp", I4_QPS)
+def test_hip_path_rebuilds_known_intra4_macroblocks_as_the_clauses_say(hw, tmp_path, qp):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = I16_SIZE
+    path = str(tmp_path / "i4.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(clip_args(qp, 0), global_mv=6, frames=12, gop=12))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(12)))
+    for k in range(1, 12):
+        assert np.array_equal(got[k], expected_intra4(got[k - 1], k, w, h, qp)), "picture %d" % k
