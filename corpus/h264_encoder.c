@@ -977,6 +977,30 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
   int skip_mv[2];
   h264i_pskip_mv(d, skip_mv);
 
+  if (e->cfg->global_mv == 7) {
+    /* --global-mv 7: the vector DIFFERENCES and reference indices follow from address and picture number; the vectors
+     * are whatever the prediction of 8.4.1.3 makes of them (every fourth macroblock is P_Skip: 8.4.1.1).  Nothing is
+     * coded, one 16x16 partition per macroblock: what the picture decodes to says whether the decoder predicts
+     * vectors as the clause does (tests/test_mvpred_independent.py restates it) */
+    const int k = e->frame_abs;
+    p->kind = MB_INTER;
+    p->mb_type_raw = 0;
+    if (addr % 4 == 3) {
+      set_all_motion(&d->mb, 0, 0, skip_mv[0], skip_mv[1]);
+      plan->is_skip = 1;
+    } else if (addr % 7 == 5) {
+      set_all_motion(&d->mb, 0, 0, 0, 0); /* (reference 0, vector 0: what the P_Skip rule looks for in a neighbour) */
+    } else {
+      const int r = (addr * 3 + k) % nref;
+      int mvp[2];
+      h264i_pred_mv16(d, 0, r, mvp);
+      set_all_motion(&d->mb, 0, r, mvp[0] + (addr * 5 + k * 3) % 13 - 6, mvp[1] + (addr * 7 + k) % 9 - 4);
+    }
+    copy_motion_from_state(d, p);
+    h264i_inter_pred_mb(d);
+    p->qp = qp;
+    return;
+  }
   if (e->cfg->global_mv) {
     int gx, gy;
     global_mv_of(e->frame_abs, e->cfg->width, e->cfg->height, &gx, &gy);
