@@ -11,7 +11,12 @@
  * decode follows ITU-T H.264 clauses 7.3/7.4, 8.2-8.7, 9.1-9.3 restated from
  * memory; H.264 decoding is normative/bit-exact, so any conforming decoder
  * (FFmpeg included) yields these samples if the restatement is right.  What
- * pins it is listed in h264_tables.h and DESIGN.md.
+ * pins it is listed in h264_tables.h and DESIGN.md; since round 3 the
+ * reconstruction arithmetic (interpolation, weighted prediction, in-loop
+ * filter, transforms, intra and motion-vector prediction) is also checked
+ * against numpy / Python restatements written from the clauses
+ * (tests/test_*_independent.py) - not the entropy tables, which nothing here
+ * can check.
  */
 #ifndef ORACLE_H264_ORACLE_H_
 #define ORACLE_H264_ORACLE_H_
