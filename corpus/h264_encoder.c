@@ -1103,7 +1103,37 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
       p->qp = e->cfg->qp;
       return;
     }
-    if (e->cfg->global_mv >= 4 && e->cfg->global_mv <= 6) {
+    /* --global-mv 8 (needs --t8x8 1): as 6 with Intra8x8 macroblocks - one mode per 8x8 block, the luma levels of comp 5 */
+    if (e->cfg->global_mv == 8 && ((d->mb.mbx + d->mb.mby) & 1)) {
+      const int k = e->frame_abs, inside = d->mb.mbx > 0 && d->mb.mby > 0;
+      int cmode = (addr * 3 + k) % 4, cbp = 0, chroma = 0;
+      if ((cmode == 1 && d->mb.mbx == 0) || (cmode == 2 && d->mb.mby == 0) || (cmode == 3 && !inside)) cmode = 0;
+      p->kind = MB_I8x8;
+      p->t8x8 = 1;
+      p->mb_type_raw = 5;
+      p->chroma_mode = cmode;
+      for (int b8 = 0; b8 < 4; ++b8) {
+        const int mode = inside ? (addr * 5 + b8 * 7 + k) % 9 : 2;
+        for (int s4 = 0; s4 < 4; ++s4) p->i4_mode[((b8 >> 1) * 2 + (s4 >> 1)) * 4 + (b8 & 1) * 2 + (s4 & 1)] = (int8_t)mode;
+        for (int pos = 0; pos < 64; ++pos) {
+          p->luma8[b8][pos] = (int16_t)global_level(k, addr, 5, b8, pos);
+          if (p->luma8[b8][pos]) cbp |= 1 << b8;
+        }
+      }
+      for (int pl = 0; pl < 2; ++pl)
+        for (int blk = 0; blk < 4; ++blk) {
+          p->chroma_dc[pl][blk] = (int16_t)global_level(k, addr, 3 + pl, 0, blk);
+          if (p->chroma_dc[pl][blk] && chroma < 1) chroma = 1;
+          for (int pos = 1; pos < 16; ++pos) {
+            p->chroma_ac[pl][blk][pos] = (int16_t)global_level(k, addr, 1 + pl, blk, pos);
+            if (p->chroma_ac[pl][blk][pos]) chroma = 2;
+          }
+        }
+      p->cbp = cbp | chroma << 4;
+      p->qp = e->cfg->qp;
+      return;
+    }
+    if (e->cfg->global_mv >= 4 && e->cfg->global_mv <= 8) {
       const int k = e->frame_abs;
       int cbp = 0, chroma = 0;
       if (e->cfg->t8x8) { /* (--t8x8 1: the luma levels are those of four 8x8 blocks, comp 5, raster positions 0..63) */

@@ -756,3 +756,158 @@ def test_hip_path_rebuilds_known_intra4_macroblocks_as_the_clauses_say(hw, tmp_p
     got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(12)))
     for k in range(1, 12):
         assert np.array_equal(got[k], expected_intra4(got[k - 1], k, w, h, qp)), "picture %d" % k
+
+
+# ---- Intra8x8 macroblocks with known modes and levels (--global-mv 8, --t8x8 1) -------------------------------------------
+def pred8(img, x0, y0, mode, top_right_ok):
+    """8.3.2.2: the reference samples of the 8x8 block at (x0, y0) are filtered first (8.3.2.2.1), then one of nine
+    modes.  Inside the picture left, top and top-left samples exist; the sixteen samples above are p[0..15, -1], of
+    which 8..15 repeat p[7, -1] when the block above-right is not there (yet)."""
+    top_ok, left_ok = y0 > 0, x0 > 0
+    tl_ok = top_ok and left_ok
+    t = [int(img[y0 - 1, x0 + i]) for i in range(8)] if top_ok else None
+    if top_ok:
+        t += [int(img[y0 - 1, x0 + 8 + i]) for i in range(8)] if top_right_ok else [t[7]] * 8
+    lf = [int(img[y0 + i, x0 - 1]) for i in range(8)] if left_ok else None
+    tl = int(img[y0 - 1, x0 - 1]) if tl_ok else None
+    ft = fl = ftl = None
+    if top_ok:
+        ft = [0] * 16
+        ft[0] = (tl + 2 * t[0] + t[1] + 2) >> 2 if tl_ok else (3 * t[0] + t[1] + 2) >> 2
+        for i in range(1, 15):
+            ft[i] = (t[i - 1] + 2 * t[i] + t[i + 1] + 2) >> 2
+        ft[15] = (t[14] + 3 * t[15] + 2) >> 2
+    if left_ok:
+        fl = [0] * 8
+        fl[0] = (tl + 2 * lf[0] + lf[1] + 2) >> 2 if tl_ok else (3 * lf[0] + lf[1] + 2) >> 2
+        for i in range(1, 7):
+            fl[i] = (lf[i - 1] + 2 * lf[i] + lf[i + 1] + 2) >> 2
+        fl[7] = (lf[6] + 3 * lf[7] + 2) >> 2
+    if tl_ok:
+        ftl = (t[0] + 2 * tl + lf[0] + 2) >> 2
+    elif top_ok and tl is not None:
+        ftl = (3 * tl + t[0] + 2) >> 2
+
+    def p(x, y):   # the filtered samples by the clause's coordinates
+        if x == -1 and y == -1:
+            return ftl
+        return ft[x] if y == -1 else fl[y]
+    out = np.zeros((8, 8), dtype=np.int64)
+    if mode == 2:
+        if top_ok and left_ok:
+            out[:] = (sum(ft[:8]) + sum(fl) + 8) >> 4
+        elif top_ok or left_ok:
+            out[:] = (sum(ft[:8] if top_ok else fl) + 4) >> 3
+        else:
+            out[:] = 128
+        return out
+    for y in range(8):
+        for x in range(8):
+            if mode == 0:
+                v = p(x, -1)
+            elif mode == 1:
+                v = p(-1, y)
+            elif mode == 3:
+                v = (p(14, -1) + 3 * p(15, -1) + 2) >> 2 if (x == 7 and y == 7) else (p(x + y, -1) + 2 * p(x + y + 1, -1) + p(x + y + 2, -1) + 2) >> 2
+            elif mode == 4:
+                if x > y:
+                    v = (p(x - y - 2, -1) + 2 * p(x - y - 1, -1) + p(x - y, -1) + 2) >> 2
+                elif x < y:
+                    v = (p(-1, y - x - 2) + 2 * p(-1, y - x - 1) + p(-1, y - x) + 2) >> 2
+                else:
+                    v = (p(0, -1) + 2 * p(-1, -1) + p(-1, 0) + 2) >> 2
+            elif mode == 5:
+                z, s = 2 * x - y, x - (y >> 1)
+                if z >= 0 and z % 2 == 0:
+                    v = (p(s - 1, -1) + p(s, -1) + 1) >> 1
+                elif z >= 0:
+                    v = (p(s - 2, -1) + 2 * p(s - 1, -1) + p(s, -1) + 2) >> 2
+                elif z == -1:
+                    v = (p(-1, 0) + 2 * p(-1, -1) + p(0, -1) + 2) >> 2
+                else:
+                    v = (p(-1, y - 2 * x - 1) + 2 * p(-1, y - 2 * x - 2) + p(-1, y - 2 * x - 3) + 2) >> 2
+            elif mode == 6:
+                z, s = 2 * y - x, y - (x >> 1)
+                if z >= 0 and z % 2 == 0:
+                    v = (p(-1, s - 1) + p(-1, s) + 1) >> 1
+                elif z >= 0:
+                    v = (p(-1, s - 2) + 2 * p(-1, s - 1) + p(-1, s) + 2) >> 2
+                elif z == -1:
+                    v = (p(-1, 0) + 2 * p(-1, -1) + p(0, -1) + 2) >> 2
+                else:
+                    v = (p(x - 2 * y - 1, -1) + 2 * p(x - 2 * y - 2, -1) + p(x - 2 * y - 3, -1) + 2) >> 2
+            elif mode == 7:
+                s = x + (y >> 1)
+                v = (p(s, -1) + p(s + 1, -1) + 1) >> 1 if y % 2 == 0 else (p(s, -1) + 2 * p(s + 1, -1) + p(s + 2, -1) + 2) >> 2
+            else:
+                z, s = x + 2 * y, y + (x >> 1)
+                if z > 13:
+                    v = p(-1, 7)
+                elif z == 13:
+                    v = (p(-1, 6) + 3 * p(-1, 7) + 2) >> 2
+                elif z % 2 == 0:
+                    v = (p(-1, s) + p(-1, s + 1) + 1) >> 1
+                else:
+                    v = (p(-1, s) + 2 * p(-1, s + 1) + p(-1, s + 2) + 2) >> 2
+            out[y, x] = v
+    return out
+
+
+def expected_intra8(prev, k, w, h, qp):
+    mv = global_mv_of(k, w, h)
+    y, u, v = planes(prev, w, h)
+    sy, su, sv = shift_luma(y, *mv).astype(np.int64), shift_chroma(u, *mv).astype(np.int64), shift_chroma(v, *mv).astype(np.int64)
+    oy, ou, ov = np.zeros_like(sy), np.zeros_like(su), np.zeros_like(sv)
+    mbw, mbh, qpc = w // 16, h // 16, chroma_qp(qp, 0)
+    for addr in range(mbw * mbh):
+        mx, my = addr % mbw, addr // mbw
+        ly, lx, cy, cx = my * 16, mx * 16, my * 8, mx * 8
+        if (mx + my) & 1:
+            inside = mx > 0 and my > 0
+            cmode = (addr * 3 + k) % 4
+            if (cmode == 1 and mx == 0) or (cmode == 2 and my == 0) or (cmode == 3 and not inside):
+                cmode = 0
+            for b8 in range(4):
+                bx, by = b8 & 1, b8 >> 1
+                mode = (addr * 5 + b8 * 7 + k) % 9 if inside else 2
+                # above-right: block 0 - the macroblock above; 1 - the macroblock above-right; 2 - block 1; 3 - never
+                tr_ok = (my > 0) if b8 == 0 else ((my > 0 and mx + 1 < mbw) if b8 == 1 else b8 == 2)
+                c = np.array([[global_level(k, addr, 5, b8, i * 8 + j) for j in range(8)] for i in range(8)], dtype=np.int64)
+                x0, y0 = lx + bx * 8, ly + by * 8
+                oy[y0:y0 + 8, x0:x0 + 8] = np.clip(pred8(oy, x0, y0, mode, tr_ok) + inverse8x8(c, qp), 0, 255)
+            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc)
+            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc)
+        else:
+            oy[ly:ly + 16, lx:lx + 16] = np.clip(sy[ly:ly + 16, lx:lx + 16] + residual_luma8(k, addr, qp), 0, 255)
+            pu = su[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 0, qpc)
+            pv = sv[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 1, qpc)
+        ou[cy:cy + 8, cx:cx + 8] = np.clip(pu, 0, 255)
+        ov[cy:cy + 8, cx:cx + 8] = np.clip(pv, 0, 255)
+    return np.concatenate([p.astype(np.uint8).ravel() for p in (oy, ou, ov)])
+
+
+@pytest.mark.parametrize("qp", I4_QPS)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_rebuilds_known_intra8_macroblocks_as_the_clauses_say(hw, oracle, tmp_path, qp, cabac):
+    w, h = I16_SIZE
+    path = str(tmp_path / "i8.mp4")
+    gold = make_clip(path, width=w, height=h, cabac=cabac, **dict(clip_args(qp, 0), global_mv=8, t8x8=1, frames=12, gop=12))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == 12
+    for k in range(1, 12):
+        assert np.array_equal(frames[k][0], expected_intra8(frames[k - 1][0], k, w, h, qp)), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp", I4_QPS)
+def test_hip_path_rebuilds_known_intra8_macroblocks_as_the_clauses_say(hw, tmp_path, qp):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = I16_SIZE
+    path = str(tmp_path / "i8.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(clip_args(qp, 0), global_mv=8, t8x8=1, frames=12, gop=12))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(12)))
+    for k in range(1, 12):
+        assert np.array_equal(got[k], expected_intra8(got[k - 1], k, w, h, qp)), "picture %d" % k
