@@ -399,7 +399,20 @@ static void write_sps(Enc* e) {
     bw_ue(&w, 0);
     bw_ue(&w, 0);
     bw_put(&w, 0, 1); /* qpprime_y_zero_transform_bypass */
-    if (c->scaling & 1) {
+    if (c->scaling & 4) {
+      /* all eight lists explicit, entry j (zig-zag order) of list i = 8 + (i * 7 + j * 3) % 25: a scaling matrix that
+       * tests/test_residual_independent.py can restate without the hash */
+      bw_put(&w, 1, 1);
+      for (int i = 0; i < 8; ++i) {
+        int last = 8;
+        bw_put(&w, 1, 1);
+        for (int j = 0; j < (i < 6 ? 16 : 64); ++j) {
+          const int v = 8 + (i * 7 + j * 3) % 25;
+          bw_se(&w, v - last);
+          last = v;
+        }
+      }
+    } else if (c->scaling & 1) {
       /* Y-intra explicit, Cb-intra falls back to it, Cr-intra explicit, Y-inter "use default",
        * Cb-inter falls back to that, Cr-inter stops early; 8x8 intra explicit, 8x8 inter absent
        * (fall-back rule A: the default list) */

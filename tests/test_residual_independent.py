@@ -27,12 +27,30 @@ FRAMES = 8
 NORM_ADJUST = [(10, 16, 13), (11, 18, 14), (13, 20, 16), (14, 23, 18), (16, 25, 20), (18, 29, 23)]
 
 
-def level_scale(m):
+# Scaling matrices (--scaling 4, corpus/h264_encoder.c: write_sps): entry j, in zig-zag order, of list i is
+# 8 + (i * 7 + j * 3) % 25.  Lists 0-2: Intra Y / Cb / Cr 4x4, 3-5: Inter Y / Cb / Cr 4x4, 6 / 7: Intra / Inter Y 8x8.
+ZIGZAG4 = [0, 1, 4, 8, 5, 2, 3, 6, 9, 12, 13, 10, 7, 11, 14, 15]   # raster position of zig-zag index (8.5.6, frames)
+ZIGZAG8 = [0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49,
+           56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63]
+SCALING = {"on": False}   # set by the tests that encode with --scaling 4
+
+
+def weight_scale(lst, n):
+    if not SCALING["on"]:
+        return np.full((n, n), 16, dtype=np.int64)   # Flat_4x4_16 / Flat_8x8_16
+    w = np.zeros(n * n, dtype=np.int64)
+    for j, raster in enumerate(ZIGZAG4 if n == 4 else ZIGZAG8):
+        w[raster] = 8 + (lst * 7 + j * 3) % 25
+    return w.reshape(n, n)
+
+
+def level_scale(m, lst=3):
     ls = np.zeros((4, 4), dtype=np.int64)
+    ws = weight_scale(lst, 4)
     for i in range(4):
         for j in range(4):
             cls = 0 if (i % 2 == 0 and j % 2 == 0) else (1 if (i % 2 == 1 and j % 2 == 1) else 2)
-            ls[i, j] = 16 * NORM_ADJUST[m][cls]   # flat weightScale = 16
+            ls[i, j] = ws[i, j] * NORM_ADJUST[m][cls]
     return ls
 
 
@@ -47,9 +65,9 @@ def global_level(k, addr, comp, blk, pos):
     return v * 9 if t % 35 == 0 else v
 
 
-def scale_ac(c, qp):
+def scale_ac(c, qp, lst=3):
     """8.5.12.1: d_ij for a 4x4 block of levels c (all positions; the caller overrides d_00 where a DC path owns it)."""
-    ls = level_scale(qp % 6)
+    ls = level_scale(qp % 6, lst)
     if qp >= 24:
         return (c * ls) << (qp // 6 - 4)
     return (c * ls + (1 << (3 - qp // 6))) >> (4 - qp // 6)
@@ -71,7 +89,7 @@ def residual_luma(k, addr, qp):
     for blk in range(16):
         c = np.array([[global_level(k, addr, 0, blk, i * 4 + j) for j in range(4)] for i in range(4)], dtype=np.int64)
         by, bx = (blk // 4) * 4, (blk % 4) * 4
-        r[by:by + 4, bx:bx + 4] = inverse4x4(scale_ac(c, qp))
+        r[by:by + 4, bx:bx + 4] = inverse4x4(scale_ac(c, qp, 3))   # (an inter macroblock: list 3)
     return r
 
 
@@ -80,8 +98,9 @@ NORM_ADJUST8 = [(20, 18, 32, 19, 25, 24), (22, 19, 35, 21, 28, 26), (26, 23, 42,
                 (32, 28, 51, 30, 40, 38), (36, 32, 58, 34, 46, 43)]
 
 
-def level_scale8(m):
+def level_scale8(m, lst=7):
     ls = np.zeros((8, 8), dtype=np.int64)
+    ws = weight_scale(lst, 8)
     for i in range(8):
         for j in range(8):
             if i % 4 == 0 and j % 4 == 0:
@@ -96,13 +115,13 @@ def level_scale8(m):
                 cls = 4
             else:
                 cls = 5
-            ls[i, j] = 16 * NORM_ADJUST8[m][cls]
+            ls[i, j] = ws[i, j] * NORM_ADJUST8[m][cls]
     return ls
 
 
-def inverse8x8(c, qp):
+def inverse8x8(c, qp, lst=7):
     """8.5.13: scaling, the one-dimensional transform over every row, then over every column, (x + 32) >> 6."""
-    ls = level_scale8(qp % 6)
+    ls = level_scale8(qp % 6, lst)
     d = (c * ls) << (qp // 6 - 6) if qp >= 36 else (c * ls + (1 << (5 - qp // 6))) >> (6 - qp // 6)
 
     def one_d(v):
@@ -129,18 +148,19 @@ def residual_luma8(k, addr, qp):
     return r
 
 
-def residual_chroma(k, addr, pl, qpc):
+def residual_chroma(k, addr, pl, qpc, intra=False):
     """8.5.11: the four DC levels through the 2x2 transform and their own scaling, then each block's AC with that DC."""
+    lst = (1 if intra else 4) + pl
     c = np.array([[global_level(k, addr, 3 + pl, 0, 0), global_level(k, addr, 3 + pl, 0, 1)],
                   [global_level(k, addr, 3 + pl, 0, 2), global_level(k, addr, 3 + pl, 0, 3)]], dtype=np.int64)
     a = np.array([[1, 1], [1, -1]], dtype=np.int64)
     f = a @ c @ a
-    dc = ((f * level_scale(qpc % 6)[0, 0]) << (qpc // 6)) >> 5
+    dc = ((f * level_scale(qpc % 6, lst)[0, 0]) << (qpc // 6)) >> 5
     r = np.zeros((8, 8), dtype=np.int64)
     for blk in range(4):
         lv = np.array([[0 if (i == 0 and j == 0) else global_level(k, addr, 1 + pl, blk, i * 4 + j) for j in range(4)] for i in range(4)],
                       dtype=np.int64)
-        d = scale_ac(lv, qpc)
+        d = scale_ac(lv, qpc, lst)
         d[0, 0] = dc[blk // 2, blk % 2]
         by, bx = (blk // 2) * 4, (blk % 2) * 4
         r[by:by + 4, bx:bx + 4] = inverse4x4(d)
@@ -405,13 +425,13 @@ def residual_luma16(k, addr, qp):
     c = np.array([[global_level(k, addr, 6, 0, i * 4 + j) for j in range(4)] for i in range(4)], dtype=np.int64)
     hm = np.array([[1, 1, 1, 1], [1, 1, -1, -1], [1, -1, -1, 1], [1, -1, 1, -1]], dtype=np.int64)
     f = hm @ c @ hm
-    ls = level_scale(qp % 6)[0, 0]
+    ls = level_scale(qp % 6, 0)[0, 0]   # (Intra Y: list 0)
     dc = (f * ls) << (qp // 6 - 6) if qp >= 36 else (f * ls + (1 << (5 - qp // 6))) >> (6 - qp // 6)
     r = np.zeros((16, 16), dtype=np.int64)
     for blk in range(16):
         lv = np.array([[0 if (i == 0 and j == 0) else global_level(k, addr, 0, blk, i * 4 + j) for j in range(4)] for i in range(4)],
                       dtype=np.int64)
-        d = scale_ac(lv, qp)
+        d = scale_ac(lv, qp, 0)
         d[0, 0] = dc[blk // 4, blk % 4]
         by, bx = (blk // 4) * 4, (blk % 4) * 4
         r[by:by + 4, bx:bx + 4] = inverse4x4(d)
@@ -435,8 +455,8 @@ def expected_intra16(prev, k, w, h, qp):
             if (cmode == 1 and not left) or (cmode == 2 and not top) or (cmode == 3 and not (left and top)):
                 cmode = 0
             py = pred16(oy, lx, ly, mode) + residual_luma16(k, addr, qp)
-            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc)
-            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc)
+            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc, True)
+            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc, True)
         else:
             py = sy[ly:ly + 16, lx:lx + 16] + residual_luma(k, addr, qp)
             pu = su[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 0, qpc)
@@ -704,9 +724,9 @@ def expected_intra4(prev, k, w, h, qp):
                     tr_ok = (bx, by) in ((0, 1), (0, 2), (0, 3), (2, 1), (2, 2), (2, 3), (1, 2))
                 c = np.array([[global_level(k, addr, 0, blk, i * 4 + j) for j in range(4)] for i in range(4)], dtype=np.int64)
                 x0, y0 = lx + bx * 4, ly + by * 4
-                oy[y0:y0 + 4, x0:x0 + 4] = np.clip(pred4(oy, x0, y0, mode, tr_ok, w) + inverse4x4(scale_ac(c, qp)), 0, 255)
-            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc)
-            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc)
+                oy[y0:y0 + 4, x0:x0 + 4] = np.clip(pred4(oy, x0, y0, mode, tr_ok, w) + inverse4x4(scale_ac(c, qp, 0)), 0, 255)
+            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc, True)
+            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc, True)
         else:
             oy[ly:ly + 16, lx:lx + 16] = np.clip(sy[ly:ly + 16, lx:lx + 16] + residual_luma(k, addr, qp), 0, 255)
             pu = su[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 0, qpc)
@@ -874,9 +894,9 @@ def expected_intra8(prev, k, w, h, qp):
                 tr_ok = (my > 0) if b8 == 0 else ((my > 0 and mx + 1 < mbw) if b8 == 1 else b8 == 2)
                 c = np.array([[global_level(k, addr, 5, b8, i * 8 + j) for j in range(8)] for i in range(8)], dtype=np.int64)
                 x0, y0 = lx + bx * 8, ly + by * 8
-                oy[y0:y0 + 8, x0:x0 + 8] = np.clip(pred8(oy, x0, y0, mode, tr_ok) + inverse8x8(c, qp), 0, 255)
-            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc)
-            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc)
+                oy[y0:y0 + 8, x0:x0 + 8] = np.clip(pred8(oy, x0, y0, mode, tr_ok) + inverse8x8(c, qp, 6), 0, 255)
+            pu = pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc, True)
+            pv = pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc, True)
         else:
             oy[ly:ly + 16, lx:lx + 16] = np.clip(sy[ly:ly + 16, lx:lx + 16] + residual_luma8(k, addr, qp), 0, 255)
             pu = su[cy:cy + 8, cx:cx + 8] + residual_chroma(k, addr, 0, qpc)
@@ -911,3 +931,51 @@ def test_hip_path_rebuilds_known_intra8_macroblocks_as_the_clauses_say(hw, tmp_p
     got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(12)))
     for k in range(1, 12):
         assert np.array_equal(got[k], expected_intra8(got[k - 1], k, w, h, qp)), "picture %d" % k
+
+
+# ---- the same with scaling matrices (--scaling 4: eight explicit lists in the SPS) -----------------------------------------
+# LevelScale = weightScale * normAdjust with the list that belongs to the block (8.5.9): Intra / Inter x Y / Cb / Cr for
+# 4x4, Intra / Inter Y for 8x8; the DC paths take entry (0, 0) of theirs.  With unequal weights the rounding terms of the
+# scaling rules count (with the flat 16 they never do for 4x4 blocks).
+@pytest.fixture
+def scaling_on():
+    SCALING["on"] = True
+    yield
+    SCALING["on"] = False
+
+
+SCALED = [("inter4", 4, 0, (64, 48), [10, 17, 23, 24, 31, 44]), ("inter8", 4, 1, (64, 48), [12, 29, 35, 36, 47]),
+          ("intra16", 5, 0, I16_SIZE, [8, 21, 35, 36, 45]), ("intra4", 6, 0, I16_SIZE, [15, 26, 40]), ("intra8", 8, 1, I16_SIZE, [16, 33, 41])]
+SCALED_CASES = [(name, mode, t8, size, qp) for name, mode, t8, size, qps in SCALED for qp in qps]
+
+
+def scaled_expected(name, prev, k, w, h, qp):
+    return {"inter4": lambda: expected(prev, k, w, h, qp, 0), "inter8": lambda: expected(prev, k, w, h, qp, 0, True),
+            "intra16": lambda: expected_intra16(prev, k, w, h, qp), "intra4": lambda: expected_intra4(prev, k, w, h, qp),
+            "intra8": lambda: expected_intra8(prev, k, w, h, qp)}[name]()
+
+
+@pytest.mark.parametrize("name,mode,t8,size,qp", SCALED_CASES, ids=["%s_qp%d" % (c[0], c[4]) for c in SCALED_CASES])
+def test_oracle_applies_scaling_matrices_as_the_clauses_say(hw, oracle, tmp_path, scaling_on, name, mode, t8, size, qp):
+    w, h = size
+    path = str(tmp_path / "sc.mp4")
+    gold = make_clip(path, width=w, height=h, **dict(clip_args(qp, 0), global_mv=mode, t8x8=t8, scaling=4, frames=6, gop=6))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == 6
+    for k in range(1, 6):
+        assert np.array_equal(frames[k][0], scaled_expected(name, frames[k - 1][0], k, w, h, qp)), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,mode,t8,size,qp", SCALED_CASES, ids=["%s_qp%d" % (c[0], c[4]) for c in SCALED_CASES])
+def test_hip_path_applies_scaling_matrices_as_the_clauses_say(hw, tmp_path, scaling_on, name, mode, t8, size, qp):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = size
+    path = str(tmp_path / "sc.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(clip_args(qp, 0), global_mv=mode, t8x8=t8, scaling=4, frames=6, gop=6))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(6)))
+    for k in range(1, 6):
+        assert np.array_equal(got[k], scaled_expected(name, got[k - 1], k, w, h, qp)), "picture %d" % k
