@@ -1343,6 +1343,18 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
   const Picture* r1 = d->sl.ref_list[1][0];
   const int d0 = (d->cur->poc - r0->poc) / 2, d1 = (d->cur->poc - r1->poc) / 2; /* d1 < 0 */
 
+  if (e->cfg->global_mv == 9) {
+    /* every macroblock B_Skip: the vectors are what direct prediction (temporal with --temporal-direct 1) derives from
+     * the co-located macroblocks of the anchor behind - which all carry that picture's one vector */
+    if (h264i_pred_direct_mb(d) < 0) return;
+    p->kind = MB_INTER;
+    p->mb_type_raw = 0;
+    copy_motion_from_state(d, p);
+    h264i_inter_pred_mb(d);
+    p->qp = qp;
+    plan->is_skip = 1;
+    return;
+  }
   if (e->cfg->global_mv) {
     /* every macroblock one 16x16 partition from list 0, list 1 or both (by the picture's number), one vector per list
      * and picture, nothing coded */

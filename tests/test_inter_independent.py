@@ -270,3 +270,64 @@ def test_hip_path_decodes_shifted_pictures_as_the_clauses_say(hw, tmp_path, w, h
     for k in range(1, FRAMES):
         want = expected_from(got[k - 1], k, w, h, wp_denom)
         assert np.array_equal(got[k], want), "picture %d, vector %s" % (k, global_mv_of(k, w, h))
+
+
+# ---- temporal direct prediction (8.4.1.2.3) --------------------------------------------------------------------------------
+# --global-mv 9 with --temporal-direct 1: the anchors are shifted copies of each other as before; every macroblock of a B
+# picture is B_Skip.  Its vectors come from the co-located macroblock of the anchor behind it (list 1, entry 0), which
+# carries that anchor's one vector mvCol and refers to the anchor in front (list 0, entry 0):
+#     mvL0 = (DistScaleFactor * mvCol + 128) >> 8,   mvL1 = mvL0 - mvCol
+def temporal_direct_vectors(d, w, h):
+    a = d - d % 3
+    mv_col = global_mv_of(a + 3, w, h)
+    tb, td = 2 * (d - a), 2 * 3               # POC distances: current - list 0 reference, list 1 reference - list 0 reference
+    tx = (16384 + abs(td // 2)) // td
+    dsf = max(-1024, min(1023, (tb * tx + 32) >> 6))
+    mv0 = tuple((dsf * c + 128) >> 8 for c in mv_col)
+    return mv0, tuple(m0 - c for m0, c in zip(mv0, mv_col))
+
+
+def expected_direct(dec, d, w, h, implicit):
+    if d % 3 == 0:
+        return np.concatenate([p.ravel() for p in shifted(dec[d - 3], global_mv_of(d, w, h), w, h)])
+    a = d - d % 3
+    mv0, mv1 = temporal_direct_vectors(d, w, h)
+    p0, p1 = shifted(dec[a], mv0, w, h), shifted(dec[a + 3], mv1, w, h)
+    if implicit:
+        w0, w1 = implicit_weights(2 * d, 2 * a, 2 * (a + 3))
+        out = [weighted_bi(x, y, 5, w0, w1, 0, 0) for x, y in zip(p0, p1)]
+    else:
+        out = [((x.astype(np.int64) + y + 1) >> 1).astype(np.uint8) for x, y in zip(p0, p1)]
+    return np.concatenate([p.ravel() for p in out])
+
+
+def direct_clip_args(implicit):
+    return dict(frames=B_FRAMES, gop=B_FRAMES, bframes=2, refs=1, global_mv=9, temporal_direct=1, implicit_wp=1 if implicit else 0)
+
+
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("cabac", [1, 0])
+@pytest.mark.parametrize("implicit", [False, True])
+def test_oracle_derives_temporal_direct_vectors_as_the_clause_says(hw, oracle, tmp_path, w, h, cabac, implicit):
+    path = str(tmp_path / "td.mp4")
+    gold = make_clip(path, width=w, height=h, cabac=cabac, **direct_clip_args(implicit))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == B_FRAMES
+    dec = [f[0] for f in frames]
+    for d in range(1, B_FRAMES):
+        assert np.array_equal(dec[d], expected_direct(dec, d, w, h, implicit)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+        assert np.array_equal(dec[d], gold[d])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", SIZES)
+@pytest.mark.parametrize("implicit", [False, True])
+def test_hip_path_derives_temporal_direct_vectors_as_the_clause_says(hw, tmp_path, w, h, implicit):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "td.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **direct_clip_args(implicit))
+    dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(B_FRAMES)))
+    for d in range(1, B_FRAMES):
+        assert np.array_equal(dec[d], expected_direct(dec, d, w, h, implicit)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
