@@ -1003,6 +1003,16 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
       plan->is_skip = 1;
     } else if (addr % 7 == 5) {
       set_all_motion(&d->mb, 0, 0, 0, 0); /* (reference 0, vector 0: what the P_Skip rule looks for in a neighbour) */
+    } else if ((addr + k) % 3 != 0) {
+      /* two partitions, 16x8 or 8x16: each its own reference and difference; the second one's prediction sees the first */
+      const int shape = (addr + k) % 3;
+      for (int part = 0; part < 2; ++part) {
+        const int r = (addr * 3 + k + part) % nref;
+        int mvp[2];
+        h264i_pred_mv_part(d, shape, part, r, mvp);
+        h264i_set_part(d, shape, part, r, mvp[0] + (addr * 5 + k * 3 + part * 4) % 13 - 6, mvp[1] + (addr * 7 + k + part * 2) % 9 - 4);
+      }
+      p->mb_type_raw = shape;
     } else {
       const int r = (addr * 3 + k) % nref;
       int mvp[2];

@@ -315,6 +315,8 @@ void h264i_begin_mb(H264Oracle* d, int addr);
 void h264i_pskip_mv(H264Oracle* d, int mv[2]);
 void h264i_pred_mv16(H264Oracle* d, int list, int ref, int mv[2]);
 int h264i_pred_direct_mb(H264Oracle* d);
+void h264i_pred_mv_part(H264Oracle* d, int shape, int part, int ref, int mv[2]);
+void h264i_set_part(H264Oracle* d, int shape, int part, int ref, int mvx, int mvy);
 
 /* h264_recon.c */
 void h264i_recon_mb(H264Oracle* d);

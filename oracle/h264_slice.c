@@ -1232,6 +1232,19 @@ void h264i_pred_mv16(H264Oracle* d, int list, int ref, int mv[2]) {
 
 int h264i_pred_direct_mb(H264Oracle* d) { return pred_direct(d, -1); }
 
+/* (corpus generator, --global-mv 7) the prediction for one partition of the current macroblock - shape 1: 16x8, 2: 8x16,
+ * part 0 / 1 - and a way to put a partition's reference and vector where the next partition's prediction looks for it */
+void h264i_pred_mv_part(H264Oracle* d, int shape, int part, int ref, int mv[2]) {
+  if (shape == 1) pred_mv(d, 0, 0, part * 2, 4, ref, part == 0 ? PRED_16x8_TOP : PRED_16x8_BOTTOM, mv);
+  else pred_mv(d, 0, part * 2, 0, 2, ref, part == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT, mv);
+}
+void h264i_set_part(H264Oracle* d, int shape, int part, int ref, int mvx, int mvy) {
+  for (int q = 0; q < 4; ++q)
+    if ((shape == 1 ? (q >> 1) : (q & 1)) == part) set_ref8(d, 0, q, ref);
+  if (shape == 1) set_mv_block(d, 0, 0, part * 2, 4, 2, mvx, mvy);
+  else set_mv_block(d, 0, part * 2, 0, 2, 4, mvx, mvy);
+}
+
 static int code_skip_mb(H264Oracle* d, int addr) {
   h264i_begin_mb(d, addr);
   MB* m = &d->mb;

@@ -1,14 +1,15 @@
 """Motion-vector prediction (8.4.1.3) and the P_Skip inference (8.4.1.1) checked against a restatement that shares nothing
 with the oracle or the kernels.
 
-`--global-mv 7` (corpus/h264_encoder.c) writes P pictures in which every macroblock is one 16x16 partition whose reference
-index and vector DIFFERENCE follow from its address and the picture's number; every fourth macroblock is P_Skip, some
+`--global-mv 7` (corpus/h264_encoder.c) writes P pictures in which every macroblock is one 16x16 partition, or two 16x8 or
+8x16 ones, whose reference indices and vector DIFFERENCES follow from its address and the picture's number; every fourth macroblock is P_Skip, some
 have reference 0 and vector 0 outright (the neighbour the P_Skip rule looks for).  Nothing
 else is coded and the in-loop filter is off.  The vectors themselves are then whatever the median prediction makes of the
 differences - in the encoder (which uses the oracle's function), in the oracle, and in the HIP path's k_mv, which gets
 the differences and derives the vectors on the GPU.  This test derives them a third time, in Python, from the clause:
 neighbours A (left), B (above), C (above-right, or D above-left where C does not exist), the rule that a single
-neighbour with the same reference index wins, the median otherwise, "only A available" and the P_Skip conditions - and
+neighbour with the same reference index wins, the median otherwise, "only A available", the neighbour a 16x8 / 8x16
+partition looks at first (and that its second partition sees the first), and the P_Skip conditions - and
 builds the picture from the two reference pictures with the interpolation of tests/test_inter_independent.py.  Compared
 with the oracle's decode (CPU) and the HIP path's (GPU)."""
 import numpy as np
@@ -25,17 +26,35 @@ def median(a, b, c):
     return a + b + c - min(a, b, c) - max(a, b, c)
 
 
-def predict(mvs, refs, mx, my, mbw, ref):
-    """8.4.1.3 for a 16x16 partition of the macroblock at (mx, my): mvs / refs hold what the macroblocks decoded so far
-    ended up with (refs: -1 = not decoded / outside)."""
-    def nb(x, y):
-        if x < 0 or y < 0 or x >= mbw or refs[y][x] < 0:
+class Motion(object):
+    """What the macroblocks decoded so far ended up with, per 4x4 block of the picture: reference index (-1: not decoded
+    yet) and vector."""
+    def __init__(self, mbw, mbh):
+        self.w4, self.h4 = mbw * 4, mbh * 4
+        self.ref = [[-1] * self.w4 for _ in range(self.h4)]
+        self.mv = [[(0, 0)] * self.w4 for _ in range(self.h4)]
+
+    def at(self, x, y):
+        if x < 0 or y < 0 or x >= self.w4 or y >= self.h4 or self.ref[y][x] < 0:
             return None
-        return refs[y][x], mvs[y][x]
-    a, b = nb(mx - 1, my), nb(mx, my - 1)
-    c = nb(mx + 1, my - 1)
+        return self.ref[y][x], self.mv[y][x]
+
+    def put(self, x0, y0, w, h, ref, mv):
+        for y in range(y0, y0 + h):
+            for x in range(x0, x0 + w):
+                self.ref[y][x], self.mv[y][x] = ref, mv
+
+
+def predict(m, x, y, bw, ref, direction=None):
+    """8.4.1.3 for the partition whose top-left 4x4 block is (x, y) (picture coordinates, 4x4 units) and which is bw
+    blocks wide.  direction: None, or the neighbour a 16x8 / 8x16 partition looks at first ("A", "B", "C")."""
+    a, b = m.at(x - 1, y), m.at(x, y - 1)
+    c = m.at(x + bw, y - 1)
     if c is None:
-        c = nb(mx - 1, my - 1)   # (8.4.1.3.2: C is replaced by D when C is not available)
+        c = m.at(x - 1, y - 1)   # (8.4.1.3.2: C is replaced by D when C is not available)
+    first = {"A": a, "B": b, "C": c}.get(direction)
+    if first is not None and first[0] == ref:
+        return first[1]          # (8.4.1.3: the directional rules of 16x8 and 8x16 partitions)
     if b is None and c is None and a is not None:
         return a[1]              # only A is available
     cand = [(n[0], n[1]) if n is not None else (-1, (0, 0)) for n in (a, b, c)]
@@ -45,43 +64,58 @@ def predict(mvs, refs, mx, my, mbw, ref):
     return (median(cand[0][1][0], cand[1][1][0], cand[2][1][0]), median(cand[0][1][1], cand[1][1][1], cand[2][1][1]))
 
 
-def skip_vector(mvs, refs, mx, my, mbw):
+def skip_vector(m, x, y):
     """8.4.1.1: zero when A or B does not exist, or is (reference 0, vector 0); the prediction for reference 0 otherwise."""
-    def nb(x, y):
-        if x < 0 or y < 0 or x >= mbw or refs[y][x] < 0:
-            return None
-        return refs[y][x], mvs[y][x]
-    a, b = nb(mx - 1, my), nb(mx, my - 1)
+    a, b = m.at(x - 1, y), m.at(x, y - 1)
     if a is None or b is None or a == (0, (0, 0)) or b == (0, (0, 0)):
         return (0, 0)
-    return predict(mvs, refs, mx, my, mbw, 0)
+    return predict(m, x, y, 4, 0)
 
 
 def expected(dec, k, w, h):
-    """Picture k from the decoded pictures before it: list 0 of a P picture = the previous pictures, nearest first."""
+    """Picture k from the decoded pictures before it: list 0 of a P picture = the previous pictures, nearest first.
+    Returns the picture, the Motion it implies and, per macroblock, what kind it was."""
     mbw, mbh = w // 16, h // 16
     nref = min(2, k)
-    mvs = [[(0, 0)] * mbw for _ in range(mbh)]
-    refs = [[-1] * mbw for _ in range(mbh)]
+    m = Motion(mbw, mbh)
+    kinds = []
     out = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
     cache = {}
-    for addr in range(mbw * mbh):
-        mx, my = addr % mbw, addr // mbw
-        if addr % 4 == 3:
-            r, mv = 0, skip_vector(mvs, refs, mx, my, mbw)
-        elif addr % 7 == 5:
-            r, mv = 0, (0, 0)   # (the encoder codes whatever difference that takes)
-        else:
-            r = (addr * 3 + k) % nref
-            px, py = predict(mvs, refs, mx, my, mbw, r)
-            mv = (px + (addr * 5 + k * 3) % 13 - 6, py + (addr * 7 + k) % 9 - 4)
-        mvs[my][mx], refs[my][mx] = mv, r
+
+    def paint(x4, y4, w4, h4, r, mv):   # a partition, in 4x4 units of the picture
+        m.put(x4, y4, w4, h4, r, mv)
         if (r, mv) not in cache:
             y, u, v = planes(dec[k - 1 - r], w, h)
             cache[(r, mv)] = (shift_luma(y, *mv), shift_chroma(u, *mv), shift_chroma(v, *mv))
-        for pl, mb in ((0, 16), (1, 8), (2, 8)):
-            out[pl][my * mb:(my + 1) * mb, mx * mb:(mx + 1) * mb] = cache[(r, mv)][pl][my * mb:(my + 1) * mb, mx * mb:(mx + 1) * mb]
-    return np.concatenate([p.ravel() for p in out]), mvs, refs
+        for pl, s in ((0, 4), (1, 2), (2, 2)):
+            out[pl][y4 * s:(y4 + h4) * s, x4 * s:(x4 + w4) * s] = cache[(r, mv)][pl][y4 * s:(y4 + h4) * s, x4 * s:(x4 + w4) * s]
+    for addr in range(mbw * mbh):
+        mx, my = addr % mbw, addr // mbw
+        x, y = mx * 4, my * 4
+        shape = (addr + k) % 3
+        if addr % 4 == 3:
+            kinds.append("skip")
+            paint(x, y, 4, 4, 0, skip_vector(m, x, y))
+        elif addr % 7 == 5:
+            kinds.append("zero")
+            paint(x, y, 4, 4, 0, (0, 0))   # (the encoder codes whatever difference that takes)
+        elif shape:
+            kinds.append("16x8" if shape == 1 else "8x16")
+            for part in range(2):
+                r = (addr * 3 + k + part) % nref
+                dx, dy = (addr * 5 + k * 3 + part * 4) % 13 - 6, (addr * 7 + k + part * 2) % 9 - 4
+                if shape == 1:
+                    px, py = predict(m, x, y + 2 * part, 4, r, "B" if part == 0 else "A")
+                    paint(x, y + 2 * part, 4, 2, r, (px + dx, py + dy))
+                else:
+                    px, py = predict(m, x + 2 * part, y, 2, r, "A" if part == 0 else "C")
+                    paint(x + 2 * part, y, 2, 4, r, (px + dx, py + dy))
+        else:
+            kinds.append("16x16")
+            r = (addr * 3 + k) % nref
+            px, py = predict(m, x, y, 4, r)
+            paint(x, y, 4, 4, r, (px + (addr * 5 + k * 3) % 13 - 6, py + (addr * 7 + k) % 9 - 4))
+    return np.concatenate([p.ravel() for p in out]), m, kinds
 
 
 def clip_args():
@@ -89,31 +123,24 @@ def clip_args():
 
 
 def test_the_prediction_rules_all_come_into_play():
-    """(over the pictures of the clip: the single-match rule, the median, C replaced by D, only A, both P_Skip outcomes)"""
+    """(over the pictures of the clip: every macroblock kind, both P_Skip outcomes, macroblocks at the right border - C
+    replaced by D - and in the top row - only A)"""
     mbw, mbh = W // 16, H // 16
-    single = med = c_from_d = only_a = skip_zero = skip_pred = 0
+    seen = {}
     dec = [np.zeros(W * H * 3 // 2, np.uint8)] * FRAMES
     for k in range(1, FRAMES):
-        _, mvs, refs = expected(dec, k, W, H)
-        for addr in range(mbw * mbh):
+        _, m, kinds = expected(dec, k, W, H)
+        for addr, kind in enumerate(kinds):
             mx, my = addr % mbw, addr // mbw
-            if my > 0 and mx + 1 >= mbw:
-                c_from_d += 1
+            if kind == "skip":
+                kind = "skip_zero" if m.mv[my * 4][mx * 4] == (0, 0) else "skip_predicted"
+            seen[kind] = seen.get(kind, 0) + 1
+            if my > 0 and mx + 1 == mbw:
+                seen["right border"] = seen.get("right border", 0) + 1
             if my == 0 and mx > 0:
-                only_a += 1
-            if addr % 4 == 3:
-                if mvs[my][mx] == (0, 0):
-                    skip_zero += 1
-                else:
-                    skip_pred += 1
-            elif my > 0 and mx > 0:
-                r = refs[my][mx]
-                nbs = [refs[my][mx - 1], refs[my - 1][mx], refs[my - 1][mx + 1] if mx + 1 < mbw else refs[my - 1][mx - 1]]
-                if sum(1 for n in nbs if n == r) == 1:
-                    single += 1
-                else:
-                    med += 1
-    assert min(single, med, c_from_d, only_a, skip_zero, skip_pred) > 5, (single, med, c_from_d, only_a, skip_zero, skip_pred)
+                seen["top row"] = seen.get("top row", 0) + 1
+    for kind in ("16x16", "16x8", "8x16", "zero", "skip_zero", "skip_predicted", "right border", "top row"):
+        assert seen.get(kind, 0) > 5, seen
 
 
 @pytest.mark.parametrize("cabac", [1, 0])
