@@ -733,6 +733,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // frames the caller has already taken with get_frame() are his: their copy-outs
     // complete (a re-configure between two clips of a batched call used to drop them)
     drain_bounces(lk);
+    // what the request that is over still had to say (a fetched frame whose picture was given up after the call had
+    // already returned with another error) does not belong to the one that starts now
+    sink_error_.clear();
+    copy_error_.clear();
     outq_.clear();
     buffered_.store(0);
     for (SurfaceSlot& s : surf_) s.held = 0;
