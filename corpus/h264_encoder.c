@@ -1353,6 +1353,19 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
   const Picture* r1 = d->sl.ref_list[1][0];
   const int d0 = (d->cur->poc - r0->poc) / 2, d1 = (d->cur->poc - r1->poc) / 2; /* d1 < 0 */
 
+  if (e->cfg->global_mv == 10 && ((d->mb.mbx + d->mb.mby) & 1)) {
+    /* --global-mv 10: a checkerboard of coded macroblocks (below: list 0, list 1 or both by address and picture number,
+     * one vector per list and picture) and B_Skip macroblocks whose references and vectors SPATIAL direct prediction
+     * derives from those neighbours (8.4.1.2.2) */
+    if (h264i_pred_direct_mb(d) < 0) return;
+    p->kind = MB_INTER;
+    p->mb_type_raw = 0;
+    copy_motion_from_state(d, p);
+    h264i_inter_pred_mb(d);
+    p->qp = qp;
+    plan->is_skip = 1;
+    return;
+  }
   if (e->cfg->global_mv == 9) {
     /* every macroblock B_Skip: the vectors are what direct prediction (temporal with --temporal-direct 1) derives from
      * the co-located macroblocks of the anchor behind - which all carry that picture's one vector */
@@ -1368,7 +1381,7 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
   if (e->cfg->global_mv) {
     /* every macroblock one 16x16 partition from list 0, list 1 or both (by the picture's number), one vector per list
      * and picture, nothing coded */
-    const int k = e->frame_abs, kind = 1 + k % 3; /* 1 L0, 2 L1, 3 Bi */
+    const int k = e->frame_abs, kind = 1 + (e->cfg->global_mv == 10 ? k + addr : k) % 3; /* 1 L0, 2 L1, 3 Bi */
     int m0[2], m1[2];
     global_mv_of(k, e->cfg->width, e->cfg->height, &m0[0], &m0[1]);
     global_mv_of(k + 17, e->cfg->width, e->cfg->height, &m1[0], &m1[1]);

@@ -16,7 +16,8 @@ import numpy as np
 import pytest
 
 from tests.corpus_util import make_clip
-from tests.test_inter_independent import planes, shift_chroma, shift_luma
+from tests.test_inter_independent import (B_FRAMES, global_mv_of, implicit_weights, planes, shift_chroma, shift_luma, shifted,
+                                          weighted_bi)
 
 W, H = 112, 80   # 7 x 5 macroblocks
 FRAMES = 14
@@ -33,16 +34,19 @@ class Motion(object):
         self.w4, self.h4 = mbw * 4, mbh * 4
         self.ref = [[-1] * self.w4 for _ in range(self.h4)]
         self.mv = [[(0, 0)] * self.w4 for _ in range(self.h4)]
+        self.decoded = [[False] * self.w4 for _ in range(self.h4)]
 
     def at(self, x, y):
-        if x < 0 or y < 0 or x >= self.w4 or y >= self.h4 or self.ref[y][x] < 0:
+        """None: no such block (outside the picture, or not decoded yet); else (reference index, vector) - the index is
+        -1 and the vector zero where the block does not use this list."""
+        if x < 0 or y < 0 or x >= self.w4 or y >= self.h4 or not self.decoded[y][x]:
             return None
         return self.ref[y][x], self.mv[y][x]
 
     def put(self, x0, y0, w, h, ref, mv):
         for y in range(y0, y0 + h):
             for x in range(x0, x0 + w):
-                self.ref[y][x], self.mv[y][x] = ref, mv
+                self.ref[y][x], self.mv[y][x], self.decoded[y][x] = ref, (mv if ref >= 0 else (0, 0)), True
 
 
 def predict(m, x, y, bw, ref, direction=None):
@@ -166,3 +170,99 @@ def test_hip_path_predicts_vectors_as_the_clause_says(hw, tmp_path, cabac):
     dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
     for k in range(1, FRAMES):
         assert np.array_equal(dec[k], expected(dec, k, W, H)[0]), "picture %d" % k
+
+
+# ---- spatial direct prediction (8.4.1.2.2) ---------------------------------------------------------------------------------
+# --global-mv 10: B pictures as a checkerboard of coded macroblocks (list 0, list 1 or both by address and picture number,
+# one vector per list and picture) and B_Skip macroblocks.  A B_Skip macroblock takes, per list, the smallest non-negative
+# reference index among its neighbours A, B, C (both negative: reference 0 in both lists and zero vectors), the median
+# prediction for it as its vector - or zero where the reference index is 0 and the co-located macroblock of the anchor
+# behind "does not move" (reference 0, both vector components within +-1).
+def min_positive(a, b):
+    return min(a, b) if (a >= 0 and b >= 0) else max(a, b)
+
+
+def expected_spatial(dec, d, w, h, implicit):
+    if d % 3 == 0:
+        return np.concatenate([p.ravel() for p in shifted(dec[d - 3], global_mv_of(d, w, h), w, h)])
+    mbw, mbh, a = w // 16, h // 16, d - d % 3
+    lists = [Motion(mbw, mbh), Motion(mbw, mbh)]
+    mv_col = global_mv_of(a + 3, w, h)            # every macroblock of the anchor behind: reference 0, this vector
+    col_zero = abs(mv_col[0]) <= 1 and abs(mv_col[1]) <= 1
+    gm = (global_mv_of(d, w, h), global_mv_of(d + 17, w, h))
+    refs = (dec[a], dec[a + 3])
+    out = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
+    cache = {}
+
+    def pred(lst, mv):
+        if (lst, mv) not in cache:
+            cache[(lst, mv)] = shifted(refs[lst], mv, w, h)
+        return cache[(lst, mv)]
+    w0, w1 = implicit_weights(2 * d, 2 * a, 2 * (a + 3)) if implicit else (32, 32)
+    for addr in range(mbw * mbh):
+        mx, my = addr % mbw, addr // mbw
+        x, y = mx * 4, my * 4
+        if (mx + my) & 1:
+            ref = []
+            for m in lists:
+                nb = [m.at(x - 1, y), m.at(x, y - 1), m.at(x + 4, y - 1)]
+                if nb[2] is None:
+                    nb[2] = m.at(x - 1, y - 1)
+                r = [n[0] if n is not None else -1 for n in nb]
+                ref.append(min_positive(r[0], min_positive(r[1], r[2])))
+            if ref[0] < 0 and ref[1] < 0:
+                use = [(0, (0, 0)), (0, (0, 0))]
+            else:
+                use = []
+                for lst, m in enumerate(lists):
+                    if ref[lst] < 0:
+                        use.append((-1, (0, 0)))
+                    elif ref[lst] == 0 and col_zero:
+                        use.append((0, (0, 0)))
+                    else:
+                        use.append((ref[lst], predict(m, x, y, 4, ref[lst])))
+        else:
+            kind = 1 + (d + addr) % 3   # 1 list 0, 2 list 1, 3 both (corpus/h264_encoder.c: decide_b)
+            use = [(0, gm[0]) if kind != 2 else (-1, (0, 0)), (0, gm[1]) if kind != 1 else (-1, (0, 0))]
+        for lst in range(2):
+            lists[lst].put(x, y, 4, 4, use[lst][0], use[lst][1])
+        for pl, s in ((0, 16), (1, 8), (2, 8)):
+            reg = (slice(my * s, (my + 1) * s), slice(mx * s, (mx + 1) * s))
+            if use[0][0] >= 0 and use[1][0] >= 0:
+                p0, p1 = pred(0, use[0][1])[pl][reg], pred(1, use[1][1])[pl][reg]
+                out[pl][reg] = weighted_bi(p0, p1, 5, w0, w1, 0, 0) if implicit else ((p0.astype(np.int64) + p1 + 1) >> 1).astype(np.uint8)
+            else:
+                lst = 0 if use[0][0] >= 0 else 1
+                out[pl][reg] = pred(lst, use[lst][1])[pl][reg]
+    return np.concatenate([p.ravel() for p in out])
+
+
+def spatial_clip_args(implicit):
+    # (filter off: neighbouring macroblocks differ in which lists they use, their edges would get bS 1)
+    return dict(frames=B_FRAMES, gop=B_FRAMES, bframes=2, refs=1, global_mv=10, implicit_wp=1 if implicit else 0, deblock=1)
+
+
+@pytest.mark.parametrize("cabac", [1, 0])
+@pytest.mark.parametrize("implicit", [False, True])
+def test_oracle_derives_spatial_direct_motion_as_the_clause_says(hw, oracle, tmp_path, cabac, implicit):
+    path = str(tmp_path / "sd.mp4")
+    gold = make_clip(path, width=W, height=H, cabac=cabac, **spatial_clip_args(implicit))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == B_FRAMES
+    dec = [f[0] for f in frames]
+    for d in range(1, B_FRAMES):
+        assert np.array_equal(dec[d], expected_spatial(dec, d, W, H, implicit)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+        assert np.array_equal(dec[d], gold[d])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("implicit", [False, True])
+def test_hip_path_derives_spatial_direct_motion_as_the_clause_says(hw, tmp_path, implicit):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "sd.mp4")
+    make_clip(path, width=W, height=H, yuv=False, **spatial_clip_args(implicit))
+    dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(B_FRAMES)))
+    for d in range(1, B_FRAMES):
+        assert np.array_equal(dec[d], expected_spatial(dec, d, W, H, implicit)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
