@@ -1034,6 +1034,12 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
       gx += 9;
       gy -= 6;
     }
+    /* --global-mv 10: every third anchor hardly moves - (1, -1) - so that for the B pictures in front of it the co-located
+     * macroblocks "do not move" (8.4.1.2.2: colZeroFlag) */
+    if (e->cfg->global_mv == 10 && e->frame_abs % 9 == 0) {
+      gx = 1;
+      gy = -1;
+    }
     p->kind = MB_INTER;
     set_all_motion(&d->mb, 0, 0, gx, gy);
     copy_motion_from_state(d, p);

@@ -182,12 +182,17 @@ def min_positive(a, b):
     return min(a, b) if (a >= 0 and b >= 0) else max(a, b)
 
 
+def anchor_mv(k, w, h):
+    """corpus/h264_encoder.c, --global-mv 10: every third anchor hardly moves."""
+    return (1, -1) if k % 9 == 0 else global_mv_of(k, w, h)
+
+
 def expected_spatial(dec, d, w, h, implicit):
     if d % 3 == 0:
-        return np.concatenate([p.ravel() for p in shifted(dec[d - 3], global_mv_of(d, w, h), w, h)])
+        return np.concatenate([p.ravel() for p in shifted(dec[d - 3], anchor_mv(d, w, h), w, h)])
     mbw, mbh, a = w // 16, h // 16, d - d % 3
     lists = [Motion(mbw, mbh), Motion(mbw, mbh)]
-    mv_col = global_mv_of(a + 3, w, h)            # every macroblock of the anchor behind: reference 0, this vector
+    mv_col = anchor_mv(a + 3, w, h)               # every macroblock of the anchor behind: reference 0, this vector
     col_zero = abs(mv_col[0]) <= 1 and abs(mv_col[1]) <= 1
     gm = (global_mv_of(d, w, h), global_mv_of(d + 17, w, h))
     refs = (dec[a], dec[a + 3])
