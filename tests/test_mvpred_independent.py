@@ -30,8 +30,9 @@ def median(a, b, c):
 class Motion(object):
     """What the macroblocks decoded so far ended up with, per 4x4 block of the picture: reference index (-1: not decoded
     yet) and vector."""
-    def __init__(self, mbw, mbh):
+    def __init__(self, mbw, mbh, slice_mbs=0):
         self.w4, self.h4 = mbw * 4, mbh * 4
+        self.mbw, self.slice_mbs, self.cur = mbw, slice_mbs, 0   # cur: address of the macroblock being decoded
         self.ref = [[-1] * self.w4 for _ in range(self.h4)]
         self.mv = [[(0, 0)] * self.w4 for _ in range(self.h4)]
         self.decoded = [[False] * self.w4 for _ in range(self.h4)]
@@ -41,6 +42,8 @@ class Motion(object):
         -1 and the vector zero where the block does not use this list."""
         if x < 0 or y < 0 or x >= self.w4 or y >= self.h4 or not self.decoded[y][x]:
             return None
+        if self.slice_mbs and ((y // 4) * self.mbw + x // 4) // self.slice_mbs != self.cur // self.slice_mbs:
+            return None   # (a macroblock of another slice is not available: 6.4.4)
         return self.ref[y][x], self.mv[y][x]
 
     def put(self, x0, y0, w, h, ref, mv):
@@ -76,12 +79,13 @@ def skip_vector(m, x, y):
     return predict(m, x, y, 4, 0)
 
 
-def expected(dec, k, w, h):
+def expected(dec, k, w, h, slice_mbs=0):
     """Picture k from the decoded pictures before it: list 0 of a P picture = the previous pictures, nearest first.
+    slice_mbs: a new slice every so many macroblocks (--slice-mbs).
     Returns the picture, the Motion it implies and, per macroblock, what kind it was."""
     mbw, mbh = w // 16, h // 16
     nref = min(2, k)
-    m = Motion(mbw, mbh)
+    m = Motion(mbw, mbh, slice_mbs)
     kinds = []
     out = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
     cache = {}
@@ -96,6 +100,7 @@ def expected(dec, k, w, h):
     for addr in range(mbw * mbh):
         mx, my = addr % mbw, addr // mbw
         x, y = mx * 4, my * 4
+        m.cur = addr
         shape = (addr + k) % 3
         if addr % 4 == 3:
             kinds.append("skip")
@@ -122,8 +127,11 @@ def expected(dec, k, w, h):
     return np.concatenate([p.ravel() for p in out]), m, kinds
 
 
-def clip_args():
-    return dict(frames=FRAMES, gop=FRAMES, bframes=0, refs=2, global_mv=7, deblock=1)
+def clip_args(slice_mbs=0):
+    return dict(frames=FRAMES, gop=FRAMES, bframes=0, refs=2, global_mv=7, deblock=1, slice_mbs=slice_mbs)
+
+
+SLICE_MBS = [0, 11, 5]   # one slice; slices that end in the middle of rows
 
 
 def test_the_prediction_rules_all_come_into_play():
@@ -148,28 +156,30 @@ def test_the_prediction_rules_all_come_into_play():
 
 
 @pytest.mark.parametrize("cabac", [1, 0])
-def test_oracle_predicts_vectors_as_the_clause_says(hw, oracle, tmp_path, cabac):
+@pytest.mark.parametrize("slice_mbs", SLICE_MBS)
+def test_oracle_predicts_vectors_as_the_clause_says(hw, oracle, tmp_path, cabac, slice_mbs):
     path = str(tmp_path / "mvp.mp4")
-    gold = make_clip(path, width=W, height=H, cabac=cabac, **clip_args())
+    gold = make_clip(path, width=W, height=H, cabac=cabac, **clip_args(slice_mbs))
     frames, c = oracle.decode_file(path, hw.index_video(path))
     assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == FRAMES
     dec = [f[0] for f in frames]
     for k in range(1, FRAMES):
-        assert np.array_equal(dec[k], expected(dec, k, W, H)[0]), "picture %d" % k
+        assert np.array_equal(dec[k], expected(dec, k, W, H, slice_mbs)[0]), "picture %d" % k
         assert np.array_equal(dec[k], gold[k])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cabac", [1, 0])
-def test_hip_path_predicts_vectors_as_the_clause_says(hw, tmp_path, cabac):
+@pytest.mark.parametrize("slice_mbs", SLICE_MBS)
+def test_hip_path_predicts_vectors_as_the_clause_says(hw, tmp_path, cabac, slice_mbs):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     path = str(tmp_path / "mvp.mp4")
-    make_clip(path, width=W, height=H, yuv=False, cabac=cabac, **clip_args())
+    make_clip(path, width=W, height=H, yuv=False, cabac=cabac, **clip_args(slice_mbs))
     dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
     for k in range(1, FRAMES):
-        assert np.array_equal(dec[k], expected(dec, k, W, H)[0]), "picture %d" % k
+        assert np.array_equal(dec[k], expected(dec, k, W, H, slice_mbs)[0]), "picture %d" % k
 
 
 # ---- spatial direct prediction (8.4.1.2.2) ---------------------------------------------------------------------------------
