@@ -78,22 +78,28 @@ def filter_line(px, chroma, alpha, beta, tc0):
     px[4] = clip3(0, 255, q0 - delta)
 
 
-def deblock_plane(img, mb, chroma, alpha, beta, tc0):
+def deblock_plane(img, mb, chroma, alpha, beta, tc0, slice_mbs=0):
     """All macroblock edges inside the plane, bS = 1, macroblock by macroblock in raster order: the left edge's lines,
-    then the top edge's.  `mb`: macroblock size in this plane (16 luma, 8 chroma)."""
+    then the top edge's.  `mb`: macroblock size in this plane (16 luma, 8 chroma).  slice_mbs > 0: a new slice every so
+    many macroblocks and disable_deblocking_filter_idc = 2 - an edge shared with another slice is left alone (8.7)."""
     a = img.astype(np.int64)
     h, w = a.shape
+    mbw = w // mb
     reach = 2 if chroma else 4   # samples of either side a line may look at (chroma lines are shorter: p1 .. q1)
+    same_slice = lambda p, q: not slice_mbs or p // slice_mbs == q // slice_mbs   # noqa: E731
     for my in range(h // mb):
         for mx in range(w // mb):
             x0, y0 = mx * mb, my * mb
-            if mx > 0:
+            addr = my * mbw + mx
+            if mx > 0 and not same_slice(addr, addr - 1):
+                pass
+            elif mx > 0:
                 for y in range(y0, y0 + mb):
                     px = [0] * 8
                     px[4 - reach:4 + reach] = [int(v) for v in a[y, x0 - reach:x0 + reach]]
                     filter_line(px, chroma, alpha, beta, tc0)
                     a[y, x0 - reach:x0 + reach] = px[4 - reach:4 + reach]
-            if my > 0:
+            if my > 0 and same_slice(addr, addr - mbw):
                 for x in range(x0, x0 + mb):
                     px = [0] * 8
                     px[4 - reach:4 + reach] = [int(v) for v in a[y0 - reach:y0 + reach, x]]
@@ -126,14 +132,14 @@ def mosaic(prev, k, w, h):
     return out
 
 
-def expected(prev, k, w, h, qp, alpha_div2, beta_div2, cqo):
+def expected(prev, k, w, h, qp, alpha_div2, beta_div2, cqo, slice_mbs=0):
     y, u, v = mosaic(prev, k, w, h)
-    y = deblock_plane(y, 16, False, *thresholds(qp, alpha_div2, beta_div2))
+    y = deblock_plane(y, 16, False, *thresholds(qp, alpha_div2, beta_div2), slice_mbs=slice_mbs)
     # chroma edges: the thresholds come from the chroma QP of the two macroblocks (here the same) in place of QP_Y;
     # Cb with chroma_qp_index_offset, Cr with second_chroma_qp_index_offset - which the corpus encoder's PPS sets one
     # lower than the first when that is positive (corpus/h264_encoder.c: write_pps; the clips here carry the extension)
-    u = deblock_plane(u, 8, True, *thresholds(chroma_qp(qp, cqo), alpha_div2, beta_div2))
-    v = deblock_plane(v, 8, True, *thresholds(chroma_qp(qp, cqo - 1 if cqo > 0 else cqo), alpha_div2, beta_div2))
+    u = deblock_plane(u, 8, True, *thresholds(chroma_qp(qp, cqo), alpha_div2, beta_div2), slice_mbs=slice_mbs)
+    v = deblock_plane(v, 8, True, *thresholds(chroma_qp(qp, cqo - 1 if cqo > 0 else cqo), alpha_div2, beta_div2), slice_mbs=slice_mbs)
     return np.concatenate([y.ravel(), u.ravel(), v.ravel()])
 
 
@@ -165,6 +171,37 @@ def test_oracle_filters_known_edges_as_the_clauses_say(hw, oracle, tmp_path, qp,
             untouched += int((~moved).sum())
     # (both outcomes of the alpha / beta tests must occur, or the comparison says little; QP 18: alpha' = 5, most lines fail)
     assert touched > 0 and untouched > 0
+
+
+@pytest.mark.parametrize("slice_mbs", [11, 17, 40])
+def test_oracle_leaves_slice_edges_alone_when_told_to(hw, oracle, tmp_path, slice_mbs):
+    """disable_deblocking_filter_idc = 2 with slices that end in the middle of rows: edges between macroblocks of different
+    slices are not filtered, all others are."""
+    qp, a, b, cqo = 36, 1, 0, 0
+    path = str(tmp_path / "dbk_sl.mp4")
+    make_clip(path, width=W, height=H, yuv=False, **dict(clip_args(qp, a, b, cqo), deblock=2, slice_mbs=slice_mbs))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > FRAMES
+    differs = 0
+    for k in range(1, FRAMES):
+        want = expected(frames[k - 1][0], k, W, H, qp, a, b, cqo, slice_mbs)
+        assert np.array_equal(frames[k][0], want), "picture %d" % k
+        differs += int((want != expected(frames[k - 1][0], k, W, H, qp, a, b, cqo)).sum())
+    assert differs > 0   # (leaving those edges alone shows)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slice_mbs", [11, 17, 40])
+def test_hip_path_leaves_slice_edges_alone_when_told_to(hw, tmp_path, slice_mbs):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    qp, a, b, cqo = 36, 1, 0, 0
+    path = str(tmp_path / "dbk_sl.mp4")
+    make_clip(path, width=W, height=H, yuv=False, **dict(clip_args(qp, a, b, cqo), deblock=2, slice_mbs=slice_mbs))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(FRAMES)))
+    for k in range(1, FRAMES):
+        assert np.array_equal(got[k], expected(got[k - 1], k, W, H, qp, a, b, cqo, slice_mbs)), "picture %d" % k
 
 
 def test_every_row_of_the_threshold_tables(hw, oracle, tmp_path):
