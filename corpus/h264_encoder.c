@@ -48,11 +48,18 @@ typedef struct {
                         * QP <= 3 - now and then a level so large that CAVLC needs level_prefix >= 16 */
   int wild_mv;         /* now and then a P macroblock takes a vector hundreds of samples long, mostly to somewhere outside the
                           reference picture: long mvd codes, prediction from clamped coordinates only */
-  int global_mv;       /* every P picture is its reference shifted by ONE vector (all macroblocks 16x16 / P_Skip, reference 0,
-                          nothing coded): what such a picture must decode to follows from the previous picture and the
-                          vector alone - tests/test_inter_independent.py computes it without a decoder.  The vector runs
-                          through all sixteen quarter-sample positions, both parities of the chroma eighths, and far outside
-                          the picture (global_mv_of) */
+  int global_mv;       /* known-answer pictures: what they decode to follows from the previous picture(s) and a few numbers
+                          that depend on address / position / picture number only, so tests/test_*_independent.py can
+                          compute it from the standard's clauses without a decoder.  1: every P (and, with --bframes, B)
+                          picture is its reference(s) shifted by one vector per list (all quarter-sample positions, far
+                          outside the picture; explicit / implicit weights), nothing coded; 2: a checkerboard of two vectors
+                          (every macroblock edge: bS 1); 3: ... of inter and I_PCM macroblocks (bS 4, qP 0); 4: known
+                          coefficient levels in every macroblock (4x4 or, with --t8x8 1, 8x8 transform; filter on: bS 2);
+                          5 / 6 / 8: ... with Intra16x16 / Intra4x4 / Intra8x8 macroblocks of known modes in between
+                          (filter on: every bS); 7: known vector differences and reference indices, 16x16 / 16x8 / 8x16 /
+                          P_Skip (vector prediction); 9: all-B_Skip pictures (temporal direct with --temporal-direct 1);
+                          10: coded and B_Skip macroblocks in a checkerboard (spatial direct).  --scaling 4 adds
+                          scaling matrices with known entries */
   int qp_swing;        /* every few macroblocks the QP jumps anywhere in 0..51: large mb_qp_delta values, incl. the ones that
                           only fit the -26..25 range by wrapping around 52 */
   int slice_mbs;       /* > 0: a new slice every so many macroblocks - boundaries in the middle of rows (overrides --slices) */
