@@ -1010,6 +1010,25 @@ static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 *
       plan->is_skip = 1;
     } else if (addr % 7 == 5) {
       set_all_motion(&d->mb, 0, 0, 0, 0); /* (reference 0, vector 0: what the P_Skip rule looks for in a neighbour) */
+    } else if ((addr * 3 + k) % 5 == 4) {
+      /* P_8x8: a reference per quadrant, sub-macroblock types 8x8 / 8x4 / 4x8 / 4x4 by address, quadrant and picture
+       * number, a difference per sub-macroblock partition; all four reference indices first (as the syntax has them:
+       * a later quadrant's index is known while its vectors are not), then the partitions in decoding order */
+      for (int q = 0; q < 4; ++q) h264i_set_ref8(d, q, (addr + q + k) % nref);
+      for (int q = 0; q < 4; ++q) {
+        const int st = (addr + q * 3 + k) % 4, r = (addr + q + k) % nref;
+        const int pw = (st == 0 || st == 1) ? 2 : 1, ph = (st == 0 || st == 2) ? 2 : 1; /* 0 8x8, 1 8x4, 2 4x8, 3 4x4 */
+        int n = 0;
+        p->sub_type[q] = st;
+        for (int sy = 0; sy < 2; sy += ph)
+          for (int sx = 0; sx < 2; sx += pw, ++n) {
+            const int bx = (q & 1) * 2 + sx, by = (q >> 1) * 2 + sy;
+            int mvp[2];
+            h264i_pred_mv_blk(d, bx, by, pw, r, mvp);
+            h264i_set_blk(d, bx, by, pw, ph, mvp[0] + (addr * 5 + k * 3 + q * 4 + n) % 13 - 6, mvp[1] + (addr * 7 + k + q * 2 + n * 3) % 9 - 4);
+          }
+      }
+      p->mb_type_raw = 3;
     } else if ((addr + k) % 3 != 0) {
       /* two partitions, 16x8 or 8x16: each its own reference and difference; the second one's prediction sees the first */
       const int shape = (addr + k) % 3;

@@ -2,7 +2,7 @@
 with the oracle or the kernels.
 
 `--global-mv 7` (corpus/h264_encoder.c) writes P pictures in which every macroblock is one 16x16 partition, or two 16x8 or
-8x16 ones, whose reference indices and vector DIFFERENCES follow from its address and the picture's number; every fourth macroblock is P_Skip, some
+8x16 ones, or four quadrants with sub-macroblock partitions down to 4x4, whose reference indices and vector DIFFERENCES follow from its address and the picture's number; every fourth macroblock is P_Skip, some
 have reference 0 and vector 0 outright (the neighbour the P_Skip rule looks for).  Nothing
 else is coded and the in-loop filter is off.  The vectors themselves are then whatever the median prediction makes of the
 differences - in the encoder (which uses the oracle's function), in the oracle, and in the HIP path's k_mv, which gets
@@ -108,6 +108,18 @@ def expected(dec, k, w, h, slice_mbs=0):
         elif addr % 7 == 5:
             kinds.append("zero")
             paint(x, y, 4, 4, 0, (0, 0))   # (the encoder codes whatever difference that takes)
+        elif (addr * 3 + k) % 5 == 4:
+            kinds.append("8x8")   # P_8x8: a reference per quadrant, sub-macroblock partitions in decoding order
+            for q in range(4):
+                st, r = (addr + q * 3 + k) % 4, (addr + q + k) % nref
+                pw, ph = (2 if st in (0, 1) else 1), (2 if st in (0, 2) else 1)   # 0 8x8, 1 8x4, 2 4x8, 3 4x4
+                n = 0
+                for sy in range(0, 2, ph):
+                    for sx in range(0, 2, pw):
+                        bx, by = x + (q & 1) * 2 + sx, y + (q >> 1) * 2 + sy
+                        px, py = predict(m, bx, by, pw, r)
+                        paint(bx, by, pw, ph, r, (px + (addr * 5 + k * 3 + q * 4 + n) % 13 - 6, py + (addr * 7 + k + q * 2 + n * 3) % 9 - 4))
+                        n += 1
         elif shape:
             kinds.append("16x8" if shape == 1 else "8x16")
             for part in range(2):
@@ -151,7 +163,7 @@ def test_the_prediction_rules_all_come_into_play():
                 seen["right border"] = seen.get("right border", 0) + 1
             if my == 0 and mx > 0:
                 seen["top row"] = seen.get("top row", 0) + 1
-    for kind in ("16x16", "16x8", "8x16", "zero", "skip_zero", "skip_predicted", "right border", "top row"):
+    for kind in ("16x16", "16x8", "8x16", "8x8", "zero", "skip_zero", "skip_predicted", "right border", "top row"):
         assert seen.get(kind, 0) > 5, seen
 
 
