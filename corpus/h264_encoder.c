@@ -1418,8 +1418,12 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
     global_mv_of(k, e->cfg->width, e->cfg->height, &m0[0], &m0[1]);
     global_mv_of(k + 17, e->cfg->width, e->cfg->height, &m1[0], &m1[1]);
     p->kind = MB_INTER;
-    set_all_motion(&d->mb, 0, kind != 2 ? 0 : -1, m0[0], m0[1]);
-    set_all_motion(&d->mb, 1, kind != 1 ? 0 : -1, m1[0], m1[1]);
+    /* (--global-mv 10 with several references: the coded macroblocks name different ones, so that the B_Skip
+     * macroblocks between them have something to choose from) */
+    const int r0 = e->cfg->global_mv == 10 ? (addr / 2 + k) % d->sl.num_ref_idx[0] : 0;
+    const int r1 = e->cfg->global_mv == 10 ? (addr / 2 + k + 1) % d->sl.num_ref_idx[1] : 0;
+    set_all_motion(&d->mb, 0, kind != 2 ? r0 : -1, m0[0], m0[1]);
+    set_all_motion(&d->mb, 1, kind != 1 ? r1 : -1, m1[0], m1[1]);
     p->mb_type_raw = kind;
     copy_motion_from_state(d, p);
     h264i_inter_pred_mb(d);

@@ -209,7 +209,9 @@ def anchor_mv(k, w, h):
     return (1, -1) if k % 9 == 0 else global_mv_of(k, w, h)
 
 
-def expected_spatial(dec, d, w, h, implicit):
+def expected_spatial(dec, d, w, h, implicit, nrefs=1):
+    """nrefs 2: the lists of a B picture between the anchors a and a + 3 are [a, a + 3] and [a + 3, a] (8.2.4.2.3), and
+    the coded macroblocks use index (addr / 2 + d) % 2 in list 0, the other one in list 1."""
     if d % 3 == 0:
         return np.concatenate([p.ravel() for p in shifted(dec[d - 3], anchor_mv(d, w, h), w, h)])
     mbw, mbh, a = w // 16, h // 16, d - d % 3
@@ -217,15 +219,15 @@ def expected_spatial(dec, d, w, h, implicit):
     mv_col = anchor_mv(a + 3, w, h)               # every macroblock of the anchor behind: reference 0, this vector
     col_zero = abs(mv_col[0]) <= 1 and abs(mv_col[1]) <= 1
     gm = (global_mv_of(d, w, h), global_mv_of(d + 17, w, h))
-    refs = (dec[a], dec[a + 3])
+    pics = ([a, a + 3], [a + 3, a])               # picture behind (list, reference index)
     out = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
     cache = {}
 
-    def pred(lst, mv):
-        if (lst, mv) not in cache:
-            cache[(lst, mv)] = shifted(refs[lst], mv, w, h)
-        return cache[(lst, mv)]
-    w0, w1 = implicit_weights(2 * d, 2 * a, 2 * (a + 3)) if implicit else (32, 32)
+    def pred(lst, use):
+        pic = pics[lst][use[0]]
+        if (pic, use[1]) not in cache:
+            cache[(pic, use[1])] = shifted(dec[pic], use[1], w, h)
+        return cache[(pic, use[1])]
     for addr in range(mbw * mbh):
         mx, my = addr % mbw, addr // mbw
         x, y = mx * 4, my * 4
@@ -250,46 +252,50 @@ def expected_spatial(dec, d, w, h, implicit):
                         use.append((ref[lst], predict(m, x, y, 4, ref[lst])))
         else:
             kind = 1 + (d + addr) % 3   # 1 list 0, 2 list 1, 3 both (corpus/h264_encoder.c: decide_b)
-            use = [(0, gm[0]) if kind != 2 else (-1, (0, 0)), (0, gm[1]) if kind != 1 else (-1, (0, 0))]
+            r0, r1 = (addr // 2 + d) % nrefs, (addr // 2 + d + 1) % nrefs
+            use = [(r0, gm[0]) if kind != 2 else (-1, (0, 0)), (r1, gm[1]) if kind != 1 else (-1, (0, 0))]
         for lst in range(2):
             lists[lst].put(x, y, 4, 4, use[lst][0], use[lst][1])
         for pl, s in ((0, 16), (1, 8), (2, 8)):
             reg = (slice(my * s, (my + 1) * s), slice(mx * s, (mx + 1) * s))
             if use[0][0] >= 0 and use[1][0] >= 0:
-                p0, p1 = pred(0, use[0][1])[pl][reg], pred(1, use[1][1])[pl][reg]
+                p0, p1 = pred(0, use[0])[pl][reg], pred(1, use[1])[pl][reg]
+                w0, w1 = implicit_weights(2 * d, 2 * pics[0][use[0][0]], 2 * pics[1][use[1][0]]) if implicit else (32, 32)
                 out[pl][reg] = weighted_bi(p0, p1, 5, w0, w1, 0, 0) if implicit else ((p0.astype(np.int64) + p1 + 1) >> 1).astype(np.uint8)
             else:
                 lst = 0 if use[0][0] >= 0 else 1
-                out[pl][reg] = pred(lst, use[lst][1])[pl][reg]
+                out[pl][reg] = pred(lst, use[lst])[pl][reg]
     return np.concatenate([p.ravel() for p in out])
 
 
-def spatial_clip_args(implicit):
+def spatial_clip_args(implicit, nrefs=1):
     # (filter off: neighbouring macroblocks differ in which lists they use, their edges would get bS 1)
-    return dict(frames=B_FRAMES, gop=B_FRAMES, bframes=2, refs=1, global_mv=10, implicit_wp=1 if implicit else 0, deblock=1)
+    return dict(frames=B_FRAMES, gop=B_FRAMES, bframes=2, refs=nrefs, global_mv=10, implicit_wp=1 if implicit else 0, deblock=1)
 
 
 @pytest.mark.parametrize("cabac", [1, 0])
 @pytest.mark.parametrize("implicit", [False, True])
-def test_oracle_derives_spatial_direct_motion_as_the_clause_says(hw, oracle, tmp_path, cabac, implicit):
+@pytest.mark.parametrize("nrefs", [1])   # (the corpus encoder keeps one active reference per list in B slices)
+def test_oracle_derives_spatial_direct_motion_as_the_clause_says(hw, oracle, tmp_path, cabac, implicit, nrefs):
     path = str(tmp_path / "sd.mp4")
-    gold = make_clip(path, width=W, height=H, cabac=cabac, **spatial_clip_args(implicit))
+    gold = make_clip(path, width=W, height=H, cabac=cabac, **spatial_clip_args(implicit, nrefs))
     frames, c = oracle.decode_file(path, hw.index_video(path))
     assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == B_FRAMES
     dec = [f[0] for f in frames]
     for d in range(1, B_FRAMES):
-        assert np.array_equal(dec[d], expected_spatial(dec, d, W, H, implicit)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+        assert np.array_equal(dec[d], expected_spatial(dec, d, W, H, implicit, nrefs)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
         assert np.array_equal(dec[d], gold[d])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("implicit", [False, True])
-def test_hip_path_derives_spatial_direct_motion_as_the_clause_says(hw, tmp_path, implicit):
+@pytest.mark.parametrize("nrefs", [1])
+def test_hip_path_derives_spatial_direct_motion_as_the_clause_says(hw, tmp_path, implicit, nrefs):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     path = str(tmp_path / "sd.mp4")
-    make_clip(path, width=W, height=H, yuv=False, **spatial_clip_args(implicit))
+    make_clip(path, width=W, height=H, yuv=False, **spatial_clip_args(implicit, nrefs))
     dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(B_FRAMES)))
     for d in range(1, B_FRAMES):
-        assert np.array_equal(dec[d], expected_spatial(dec, d, W, H, implicit)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+        assert np.array_equal(dec[d], expected_spatial(dec, d, W, H, implicit, nrefs)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
