@@ -209,7 +209,7 @@ def anchor_mv(k, w, h):
     return (1, -1) if k % 9 == 0 else global_mv_of(k, w, h)
 
 
-def expected_spatial(dec, d, w, h, implicit, nrefs=1):
+def expected_spatial(dec, d, w, h, implicit, nrefs=1, motion_out=None):
     """nrefs 2: the lists of a B picture between the anchors a and a + 3 are [a, a + 3] and [a + 3, a] (8.2.4.2.3), and
     the coded macroblocks use index (addr / 2 + d) % 2 in list 0, the other one in list 1."""
     if d % 3 == 0:
@@ -256,6 +256,8 @@ def expected_spatial(dec, d, w, h, implicit, nrefs=1):
             use = [(r0, gm[0]) if kind != 2 else (-1, (0, 0)), (r1, gm[1]) if kind != 1 else (-1, (0, 0))]
         for lst in range(2):
             lists[lst].put(x, y, 4, 4, use[lst][0], use[lst][1])
+        if motion_out is not None:   # which pictures the macroblock predicts from, with which vectors
+            motion_out.append(sorted((pics[lst][use[lst][0]], use[lst][1]) for lst in range(2) if use[lst][0] >= 0))
         for pl, s in ((0, 16), (1, 8), (2, 8)):
             reg = (slice(my * s, (my + 1) * s), slice(mx * s, (mx + 1) * s))
             if use[0][0] >= 0 and use[1][0] >= 0:
@@ -299,3 +301,73 @@ def test_hip_path_derives_spatial_direct_motion_as_the_clause_says(hw, tmp_path,
     dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(B_FRAMES)))
     for d in range(1, B_FRAMES):
         assert np.array_equal(dec[d], expected_spatial(dec, d, W, H, implicit, nrefs)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+
+
+# ---- boundary strength 1 between differently predicted macroblocks of a B picture (8.7.2.1) --------------------------------
+# The same pictures with the filter on.  Nothing is coded, so an edge between two macroblocks has bS 1 when they predict
+# from different reference PICTURES (whatever the lists and indices that name them) or from a different number of them, or
+# when a vector differs by four or more quarter samples from its counterpart for the same picture; otherwise 0.
+def expected_spatial_filtered(dec, d, w, h, qp, deblock):
+    from tests.test_deblock_independent import chroma_qp, filter_line, thresholds
+    motion = []
+    unfiltered = expected_spatial(dec, d, w, h, False, 1, motion)
+    if d % 3 == 0:
+        return unfiltered   # (anchors: one vector, no edge has a strength)
+    mbw, mbh = w // 16, h // 16
+
+    def strength(p, q):
+        if [m[0] for m in p] != [m[0] for m in q]:
+            return 1         # different pictures, or a different number of them
+        return 1 if any(abs(a - b) >= 4 for mp, mq in zip(p, q) for a, b in zip(mp[1], mq[1])) else 0
+    planes_ = [pl.astype(np.int64) for pl in planes(unfiltered, w, h)]
+    th = [thresholds(qp, 0, 0), thresholds(chroma_qp(qp, 0), 0, 0), thresholds(chroma_qp(qp, 0), 0, 0)]
+    for my in range(mbh):
+        for mx in range(mbw):
+            for vertical in (True, False):
+                if (mx == 0) if vertical else (my == 0):
+                    continue
+                other = motion[my * mbw + mx - 1] if vertical else motion[(my - 1) * mbw + mx]
+                if not strength(other, motion[my * mbw + mx]):
+                    continue
+                for a, (alpha, beta, tc0), mb, chroma in zip(planes_, th, (16, 8, 8), (False, True, True)):
+                    reach = 2 if chroma else 4
+                    for i in range(mb):
+                        px = [0] * 8
+                        if vertical:
+                            px[4 - reach:4 + reach] = [int(t) for t in a[my * mb + i, mx * mb - reach:mx * mb + reach]]
+                            filter_line(px, chroma, alpha, beta, tc0)
+                            a[my * mb + i, mx * mb - reach:mx * mb + reach] = px[4 - reach:4 + reach]
+                        else:
+                            px[4 - reach:4 + reach] = [int(t) for t in a[my * mb - reach:my * mb + reach, mx * mb + i]]
+                            filter_line(px, chroma, alpha, beta, tc0)
+                            a[my * mb - reach:my * mb + reach, mx * mb + i] = px[4 - reach:4 + reach]
+    return np.concatenate([np.clip(pl, 0, 255).astype(np.uint8).ravel() for pl in planes_])
+
+
+@pytest.mark.parametrize("cabac", [1, 0])
+@pytest.mark.parametrize("qp", [30, 40])
+def test_oracle_rates_b_picture_edges_as_the_clause_says(hw, oracle, tmp_path, cabac, qp):
+    path = str(tmp_path / "sdf.mp4")
+    gold = make_clip(path, width=W, height=H, cabac=cabac, qp=qp, **dict(spatial_clip_args(False), deblock=0))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == B_FRAMES
+    dec = [f[0] for f in frames]
+    moved = 0
+    for d in range(1, B_FRAMES):
+        want = expected_spatial_filtered(dec, d, W, H, qp, 0)
+        assert np.array_equal(dec[d], want), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+        moved += int((want != expected_spatial(dec, d, W, H, False)).sum())
+    assert moved > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp", [30, 40])
+def test_hip_path_rates_b_picture_edges_as_the_clause_says(hw, tmp_path, qp):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "sdf.mp4")
+    make_clip(path, width=W, height=H, yuv=False, qp=qp, **dict(spatial_clip_args(False), deblock=0))
+    dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(B_FRAMES)))
+    for d in range(1, B_FRAMES):
+        assert np.array_equal(dec[d], expected_spatial_filtered(dec, d, W, H, qp, 0)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
