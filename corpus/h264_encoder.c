@@ -987,6 +987,83 @@ static int global_pcm_delta(int k, int pl, int x, int y) {
   return e;
 }
 
+/* --global-mv 11 (with --gop 1): intra pictures whose content follows from position and picture number alone - a
+ * checkerboard of I_PCM macroblocks (global_pcm_sample) and Intra16x16 / Intra4x4 / Intra8x8 macroblocks with known
+ * modes and levels (as --global-mv 5 / 6 / 8).  tests/test_residual_independent.py rebuilds them from nothing. */
+static int global_pcm_sample(int k, int pl, int x, int y) {
+  return (x * 7 + y * 13 + k * 29 + pl * 31 + ((x >> 2) ^ (y >> 3)) * 5) & 0xff;
+}
+static void decide_known_intra(Enc* e, MbPlan* plan) {
+  H264Oracle* d = e->d;
+  MB* p = &plan->mb;
+  const int addr = d->mb.addr, k = e->frame_abs, mbx = d->mb.mbx, mby = d->mb.mby;
+  if ((mbx + mby) & 1) {
+    p->kind = MB_IPCM;
+    p->mb_type_raw = 25;
+    for (int y = 0; y < 16; ++y)
+      for (int x = 0; x < 16; ++x) p->pcm[y * 16 + x] = (uint8_t)global_pcm_sample(k, 0, mbx * 16 + x, mby * 16 + y);
+    for (int pl = 0; pl < 2; ++pl)
+      for (int y = 0; y < 8; ++y)
+        for (int x = 0; x < 8; ++x) p->pcm[256 + pl * 64 + y * 8 + x] = (uint8_t)global_pcm_sample(k, 1 + pl, mbx * 8 + x, mby * 8 + y);
+    return;
+  }
+  const int inside = mbx > 0 && mby > 0;
+  int family = (addr / 2 + k) % 3; /* 0 Intra16x16, 1 Intra4x4, 2 Intra8x8 (Intra4x4 without --t8x8) */
+  int cmode = (addr * 3 + k) % 4, chroma = 0;
+  if (family == 2 && !e->cfg->t8x8) family = 1;
+  if ((cmode == 1 && mbx == 0) || (cmode == 2 && mby == 0) || (cmode == 3 && !inside)) cmode = 0;
+  p->chroma_mode = cmode;
+  for (int pl = 0; pl < 2; ++pl)
+    for (int blk = 0; blk < 4; ++blk) {
+      p->chroma_dc[pl][blk] = (int16_t)global_level(k, addr, 3 + pl, 0, blk);
+      if (p->chroma_dc[pl][blk] && chroma < 1) chroma = 1;
+      for (int pos = 1; pos < 16; ++pos) {
+        p->chroma_ac[pl][blk][pos] = (int16_t)global_level(k, addr, 1 + pl, blk, pos);
+        if (p->chroma_ac[pl][blk][pos]) chroma = 2;
+      }
+    }
+  p->qp = e->cfg->qp;
+  if (family == 0) {
+    int mode = (addr + k) % 4, any_ac = 0;
+    if ((mode == 0 && mby == 0) || (mode == 1 && mbx == 0) || (mode == 3 && !inside)) mode = 2;
+    p->kind = MB_I16x16;
+    p->i16_mode = mode;
+    for (int pos = 0; pos < 16; ++pos) p->luma_dc[pos] = (int16_t)global_level(k, addr, 6, 0, pos);
+    for (int blk = 0; blk < 16; ++blk)
+      for (int pos = 1; pos < 16; ++pos) {
+        p->luma[blk][pos] = (int16_t)global_level(k, addr, 0, blk, pos);
+        if (p->luma[blk][pos]) any_ac = 1;
+      }
+    p->cbp = (any_ac ? 15 : 0) | chroma << 4;
+    p->mb_type_raw = 1 + mode + 4 * chroma + (any_ac ? 12 : 0);
+    return;
+  }
+  int cbp = 0;
+  p->mb_type_raw = 0;
+  if (family == 1) {
+    p->kind = MB_I4x4;
+    for (int blk = 0; blk < 16; ++blk) {
+      p->i4_mode[blk] = (int8_t)(inside ? (addr * 5 + blk * 7 + k) % 9 : 2);
+      for (int pos = 0; pos < 16; ++pos) {
+        p->luma[blk][pos] = (int16_t)global_level(k, addr, 0, blk, pos);
+        if (p->luma[blk][pos]) cbp |= 1 << ((blk >> 3) * 2 + ((blk & 3) >> 1));
+      }
+    }
+  } else {
+    p->kind = MB_I8x8;
+    p->t8x8 = 1;
+    for (int b8 = 0; b8 < 4; ++b8) {
+      const int mode = inside ? (addr * 5 + b8 * 7 + k) % 9 : 2;
+      for (int s4 = 0; s4 < 4; ++s4) p->i4_mode[((b8 >> 1) * 2 + (s4 >> 1)) * 4 + (b8 & 1) * 2 + (s4 & 1)] = (int8_t)mode;
+      for (int pos = 0; pos < 64; ++pos) {
+        p->luma8[b8][pos] = (int16_t)global_level(k, addr, 5, b8, pos);
+        if (p->luma8[b8][pos]) cbp |= 1 << b8;
+      }
+    }
+  }
+  p->cbp = cbp | chroma << 4;
+}
+
 /* P macroblock */
 static void decide_p(Enc* e, MbPlan* plan, int qp, int dist /* frames to ref 0 */) {
   H264Oracle* d = e->d;
@@ -1954,7 +2031,8 @@ static int encode_picture(Enc* e, const PicPlan* pp, int nrefs_l0, Sample* out) 
       uint32_t hq = hash3((uint32_t)c->seed + 3, (uint32_t)e->frame_abs, (uint32_t)addr);
       if (hq % 9 == 0) qp = iclip(10, 48, qp + (int)((hq >> 4) % 5) - 2);
       if (c->qp_swing && hq % 7 == 3) qp = (int)((hq >> 8) % 52);
-      if (st == 2) decide_intra(e, &plan, qp, 2);
+      if (st == 2 && c->global_mv == 11) decide_known_intra(e, &plan);
+      else if (st == 2) decide_intra(e, &plan, qp, 2);
       else if (c->cover && hq % 5 == 1) decide_intra(e, &plan, qp, st);
       else if (st == 0) decide_p(e, &plan, qp, 1);
       else decide_b(e, &plan, qp);

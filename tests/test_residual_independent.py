@@ -979,3 +979,175 @@ def test_hip_path_applies_scaling_matrices_as_the_clauses_say(hw, tmp_path, scal
     got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(6)))
     for k in range(1, 6):
         assert np.array_equal(got[k], scaled_expected(name, got[k - 1], k, w, h, qp)), "picture %d" % k
+
+
+# ---- intra pictures rebuilt from nothing (--global-mv 11, --gop 1) ----------------------------------------------------------
+# Every picture an IDR picture: a checkerboard of I_PCM macroblocks (their samples a function of position and picture
+# number) and Intra16x16 / Intra4x4 / Intra8x8 macroblocks with known modes and levels.  Nothing of it depends on a
+# previous picture or on the encoder's content: the whole picture follows from the clauses.  (On the GPU an intra-only
+# picture takes k_intra's other path - neighbours through the LDS line buffers - and the heavy engine.)
+def pcm_sample(k, pl, x, y):
+    """corpus/h264_encoder.c: global_pcm_sample."""
+    return (x * 7 + y * 13 + k * 29 + pl * 31 + ((x >> 2) ^ (y >> 3)) * 5) & 0xff
+
+
+def expected_intra_picture(k, w, h, qp, t8x8):
+    oy, ou, ov = np.zeros((h, w), np.int64), np.zeros((h // 2, w // 2), np.int64), np.zeros((h // 2, w // 2), np.int64)
+    mbw, mbh, qpc = w // 16, h // 16, chroma_qp(qp, 0)
+    for addr in range(mbw * mbh):
+        mx, my = addr % mbw, addr // mbw
+        ly, lx, cy, cx = my * 16, mx * 16, my * 8, mx * 8
+        if (mx + my) & 1:
+            oy[ly:ly + 16, lx:lx + 16] = [[pcm_sample(k, 0, lx + x, ly + y) for x in range(16)] for y in range(16)]
+            ou[cy:cy + 8, cx:cx + 8] = [[pcm_sample(k, 1, cx + x, cy + y) for x in range(8)] for y in range(8)]
+            ov[cy:cy + 8, cx:cx + 8] = [[pcm_sample(k, 2, cx + x, cy + y) for x in range(8)] for y in range(8)]
+            continue
+        inside = mx > 0 and my > 0
+        family = (addr // 2 + k) % 3   # 0 Intra16x16, 1 Intra4x4, 2 Intra8x8
+        if family == 2 and not t8x8:
+            family = 1
+        cmode = (addr * 3 + k) % 4
+        if (cmode == 1 and mx == 0) or (cmode == 2 and my == 0) or (cmode == 3 and not inside):
+            cmode = 0
+        if family == 0:
+            mode = (addr + k) % 4
+            if (mode == 0 and my == 0) or (mode == 1 and mx == 0) or (mode == 3 and not inside):
+                mode = 2
+            oy[ly:ly + 16, lx:lx + 16] = np.clip(pred16(oy, lx, ly, mode) + residual_luma16(k, addr, qp), 0, 255)
+        elif family == 1:
+            for idx in range(16):
+                bx, by = (idx & 1) + ((idx >> 2) & 1) * 2, ((idx >> 1) & 1) + ((idx >> 3) & 1) * 2
+                blk = by * 4 + bx
+                mode = (addr * 5 + blk * 7 + k) % 9 if inside else 2
+                tr_ok = (my > 0 and (bx < 3 or mx + 1 < mbw)) if by == 0 else (bx, by) in ((0, 1), (0, 2), (0, 3), (2, 1), (2, 2), (2, 3), (1, 2))
+                c = np.array([[global_level(k, addr, 0, blk, i * 4 + j) for j in range(4)] for i in range(4)], dtype=np.int64)
+                x0, y0 = lx + bx * 4, ly + by * 4
+                oy[y0:y0 + 4, x0:x0 + 4] = np.clip(pred4(oy, x0, y0, mode, tr_ok, w) + inverse4x4(scale_ac(c, qp, 0)), 0, 255)
+        else:
+            for b8 in range(4):
+                bx, by = b8 & 1, b8 >> 1
+                mode = (addr * 5 + b8 * 7 + k) % 9 if inside else 2
+                tr_ok = (my > 0) if b8 == 0 else ((my > 0 and mx + 1 < mbw) if b8 == 1 else b8 == 2)
+                c = np.array([[global_level(k, addr, 5, b8, i * 8 + j) for j in range(8)] for i in range(8)], dtype=np.int64)
+                x0, y0 = lx + bx * 8, ly + by * 8
+                oy[y0:y0 + 8, x0:x0 + 8] = np.clip(pred8(oy, x0, y0, mode, tr_ok) + inverse8x8(c, qp, 6), 0, 255)
+        ou[cy:cy + 8, cx:cx + 8] = np.clip(pred_chroma(ou, cx, cy, cmode) + residual_chroma(k, addr, 0, qpc, True), 0, 255)
+        ov[cy:cy + 8, cx:cx + 8] = np.clip(pred_chroma(ov, cx, cy, cmode) + residual_chroma(k, addr, 1, qpc, True), 0, 255)
+    return np.concatenate([p.astype(np.uint8).ravel() for p in (oy, ou, ov)])
+
+
+INTRA_PICTURES = [(24, 1), (31, 1), (38, 1), (45, 1), (27, 0), (40, 0)]   # (QP, --t8x8)
+
+
+def intra_picture_args(qp, t8):
+    return dict(frames=7, gop=1, bframes=0, refs=1, global_mv=11, qp=qp, t8x8=t8, deblock=1)
+
+
+@pytest.mark.parametrize("qp,t8", INTRA_PICTURES)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_rebuilds_intra_pictures_from_nothing(hw, oracle, tmp_path, qp, t8, cabac):
+    w, h = I16_SIZE
+    path = str(tmp_path / "ip.mp4")
+    gold = make_clip(path, width=w, height=h, cabac=cabac, **intra_picture_args(qp, t8))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == 7
+    for k in range(7):
+        assert np.array_equal(frames[k][0], expected_intra_picture(k, w, h, qp, t8)), "picture %d" % k
+        assert np.array_equal(frames[k][0], gold[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp,t8", INTRA_PICTURES)
+def test_hip_path_rebuilds_intra_pictures_from_nothing(hw, tmp_path, qp, t8):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = I16_SIZE
+    path = str(tmp_path / "ip.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **intra_picture_args(qp, t8))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(7)))
+    for k in range(7):
+        assert np.array_equal(got[k], expected_intra_picture(k, w, h, qp, t8)), "picture %d" % k
+
+
+def filter_intra_picture(pic, k, w, h, qp, t8x8, alpha_div2, beta_div2):
+    """The in-loop filter on such a picture: every macroblock is intra - macroblock edges bS 4, inner edges bS 3; an
+    Intra8x8 macroblock has no luma edges 1 and 3 (transform_size_8x8_flag); qP is 0 for an I_PCM macroblock, and the
+    thresholds of an edge come from the average of the two sides (8.7.2.2), for chroma from the chroma QPs."""
+    mbw, mbh = w // 16, h // 16
+
+    def mb_kind(addr):
+        mx, my = addr % mbw, addr // mbw
+        if (mx + my) & 1:
+            return "pcm"
+        family = (addr // 2 + k) % 3
+        return "i8" if (family == 2 and t8x8) else "i"
+    qpy = lambda addr: 0 if mb_kind(addr) == "pcm" else qp   # noqa: E731
+    pl = [p.astype(np.int64) for p in planes(pic, w, h)]
+    for my in range(mbh):
+        for mx in range(mbw):
+            addr = my * mbw + mx
+            for vertical in (True, False):
+                for e in range(4):
+                    if e == 0 and (mx == 0 if vertical else my == 0):
+                        continue
+                    other = addr if e else (addr - 1 if vertical else addr - mbw)
+                    bs = 3 if e else 4
+                    for p_i, (a, chroma) in enumerate(((pl[0], False), (pl[1], True), (pl[2], True))):
+                        if chroma and e % 2:
+                            continue
+                        if not chroma and e % 2 and mb_kind(addr) == "i8":
+                            continue
+                        qa, qb = (qpy(addr), qpy(other)) if not chroma else (chroma_qp(qpy(addr), 0), chroma_qp(qpy(other), 0))
+                        qav = (qa + qb + 1) >> 1
+                        ia, ib = clip3(0, 51, qav + 2 * alpha_div2), clip3(0, 51, qav + 2 * beta_div2)
+                        alpha, beta, tc0 = ALPHA[ia], BETA[ib], (None if bs == 4 else TC0_BS3[ia])
+                        n, reach, s = (8, 2, 2) if chroma else (16, 4, 1)
+                        for i in range(n):
+                            px = [0] * 8
+                            if vertical:
+                                x0, yy = (mx * 16 + e * 4) // s, (my * 16) // s + i
+                                px[4 - reach:4 + reach] = [int(t) for t in a[yy, x0 - reach:x0 + reach]]
+                                filter_line(px, chroma, alpha, beta, tc0)
+                                a[yy, x0 - reach:x0 + reach] = px[4 - reach:4 + reach]
+                            else:
+                                y0, xx = (my * 16 + e * 4) // s, (mx * 16) // s + i
+                                px[4 - reach:4 + reach] = [int(t) for t in a[y0 - reach:y0 + reach, xx]]
+                                filter_line(px, chroma, alpha, beta, tc0)
+                                a[y0 - reach:y0 + reach, xx] = px[4 - reach:4 + reach]
+    return np.concatenate([np.clip(p, 0, 255).astype(np.uint8).ravel() for p in pl])
+
+
+FILTERED_INTRA = [(28, 1, 0, 0), (36, 1, 0, 0), (44, 1, 2, -1), (51, 1, 0, 0), (33, 0, -2, 3), (47, 0, 6, 6)]   # (QP, --t8x8, offsets / 2)
+
+
+@pytest.mark.parametrize("qp,t8,a,b", FILTERED_INTRA)
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_filters_intra_pictures_as_the_clauses_say(hw, oracle, tmp_path, qp, t8, a, b, cabac):
+    w, h = I16_SIZE
+    path = str(tmp_path / "ipf.mp4")
+    make_clip(path, width=w, height=h, cabac=cabac, yuv=False, **dict(intra_picture_args(qp, t8), deblock=0, alpha=a, beta=b))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == 7
+    moved = 0
+    for k in range(7):
+        plain = expected_intra_picture(k, w, h, qp, t8)
+        want = filter_intra_picture(plain, k, w, h, qp, t8, a, b)
+        assert np.array_equal(frames[k][0], want), "picture %d" % k
+        moved += int((want != plain).sum())
+    assert moved > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("qp,t8,a,b", FILTERED_INTRA)
+def test_hip_path_filters_intra_pictures_as_the_clauses_say(hw, tmp_path, qp, t8, a, b):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = I16_SIZE
+    path = str(tmp_path / "ipf.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(intra_picture_args(qp, t8), deblock=0, alpha=a, beta=b))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(7)))
+    for k in range(7):
+        want = filter_intra_picture(expected_intra_picture(k, w, h, qp, t8), k, w, h, qp, t8, a, b)
+        assert np.array_equal(got[k], want), "picture %d" % k
