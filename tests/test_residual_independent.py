@@ -1151,3 +1151,30 @@ def test_hip_path_filters_intra_pictures_as_the_clauses_say(hw, tmp_path, qp, t8
     for k in range(7):
         want = filter_intra_picture(expected_intra_picture(k, w, h, qp, t8), k, w, h, qp, t8, a, b)
         assert np.array_equal(got[k], want), "picture %d" % k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(640, 368), (1920, 1088)])
+def test_hip_path_filters_a_larger_intra_picture_as_the_clauses_say(hw, tmp_path, w, h):
+    """40 x 23 and 120 x 68 macroblocks: six and seventeen bands of the row pipelines (k_intra, k_deblock) and their
+    hand-offs, against pictures in which no sample comes from a decoder."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    qp, t8, a, b = 37, 1, 1, 0
+    path = str(tmp_path / "ipl.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(intra_picture_args(qp, t8), frames=2, deblock=0, alpha=a, beta=b))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv([0, 1])
+    for k in range(2):
+        want = filter_intra_picture(expected_intra_picture(k, w, h, qp, t8), k, w, h, qp, t8, a, b)
+        assert np.array_equal(got[k], want), "picture %d" % k
+
+
+def test_oracle_filters_a_larger_intra_picture_as_the_clauses_say(hw, oracle, tmp_path):
+    w, h, qp, t8, a, b = 640, 368, 37, 1, 1, 0
+    path = str(tmp_path / "ipl.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(intra_picture_args(qp, t8), frames=2, deblock=0, alpha=a, beta=b))
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0
+    for k in range(2):
+        assert np.array_equal(frames[k][0], filter_intra_picture(expected_intra_picture(k, w, h, qp, t8), k, w, h, qp, t8, a, b)), "picture %d" % k
