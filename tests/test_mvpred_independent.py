@@ -371,3 +371,17 @@ def test_hip_path_rates_b_picture_edges_as_the_clause_says(hw, tmp_path, qp):
     dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(B_FRAMES)))
     for d in range(1, B_FRAMES):
         assert np.array_equal(dec[d], expected_spatial_filtered(dec, d, W, H, qp, 0)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+
+
+@pytest.mark.gpu
+def test_hip_path_predicts_vectors_in_a_larger_picture_as_the_clause_says(hw, tmp_path):
+    """640 x 368 = 40 x 23 macroblocks: k_mv's row pipeline over six bands (line buffers handed from band to band)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h = 640, 368
+    path = str(tmp_path / "mvpl.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(clip_args(37), frames=3, gop=3))
+    dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(3)))
+    for k in range(1, 3):   # (a minute of Python: a whole-picture interpolation per distinct vector)
+        assert np.array_equal(dec[k], expected(dec, k, w, h, 37)[0]), "picture %d" % k

@@ -1178,3 +1178,18 @@ def test_oracle_filters_a_larger_intra_picture_as_the_clauses_say(hw, oracle, tm
     assert c["slices_clean_end"] == c["slices"] > 0
     for k in range(2):
         assert np.array_equal(frames[k][0], filter_intra_picture(expected_intra_picture(k, w, h, qp, t8), k, w, h, qp, t8, a, b)), "picture %d" % k
+
+
+@pytest.mark.gpu
+def test_hip_path_filters_a_larger_mixed_picture_as_the_clauses_say(hw, tmp_path):
+    """640 x 368: the mixed pictures (known Intra16x16 macroblocks among coded inter ones, every boundary strength) over
+    six bands of k_mv / k_intra / k_deblock."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    w, h, qp = 640, 368, 34
+    path = str(tmp_path / "mixl.mp4")
+    make_clip(path, width=w, height=h, yuv=False, **dict(mixed_clip_args(qp, 0, 0), frames=4, gop=4))
+    got = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(4)))
+    for k in range(1, 4):
+        assert np.array_equal(got[k], expected_mixed_filtered(got[k - 1], k, w, h, qp, 0, 0)), "picture %d" % k
