@@ -1462,6 +1462,30 @@ static void decide_b(Enc* e, MbPlan* plan, int qp) {
   const Picture* r1 = d->sl.ref_list[1][0];
   const int d0 = (d->cur->poc - r0->poc) / 2, d1 = (d->cur->poc - r1->poc) / 2; /* d1 < 0 */
 
+  if (e->cfg->global_mv == 12) {
+    /* --global-mv 12: B macroblocks of one 16x16 or two 16x8 / 8x16 partitions; which lists a partition uses (0, 1 or
+     * both) and the vector DIFFERENCE per list follow from address, partition and picture number - the vectors are what
+     * the prediction of 8.4.1.3 makes of them, list by list (a list a neighbour does not use counts as reference -1) */
+    const int k = e->frame_abs, shape = (addr + k) % 3; /* 0 16x16, 1 16x8, 2 8x16 */
+    int use[2];
+    for (int part = 0; part < (shape ? 2 : 1); ++part) {
+      use[part] = (addr * 2 + k + part) % 3; /* 0 list 0, 1 list 1, 2 both */
+      for (int l = 0; l < 2; ++l) {
+        const int on = use[part] == 2 || use[part] == l;
+        int mvp[2] = {0, 0};
+        if (on) h264i_pred_mv_part_l(d, l, shape, part, 0, mvp);
+        h264i_set_part_l(d, l, shape, part, on ? 0 : -1, mvp[0] + (addr * 5 + k * 3 + part * 4 + l * 2) % 13 - 6,
+                         mvp[1] + (addr * 7 + k + part * 2 + l * 5) % 9 - 4);
+      }
+    }
+    static const int tab[3][3] = {{4, 8, 12}, {10, 6, 14}, {16, 18, 20}}; /* [first partition][second] -> the 16x8 type */
+    p->kind = MB_INTER;
+    p->mb_type_raw = shape == 0 ? 1 + use[0] : tab[use[0]][use[1]] + (shape == 2 ? 1 : 0);
+    copy_motion_from_state(d, p);
+    h264i_inter_pred_mb(d);
+    p->qp = qp;
+    return;
+  }
   if (e->cfg->global_mv == 10 && ((d->mb.mbx + d->mb.mby) & 1)) {
     /* --global-mv 10: a checkerboard of coded macroblocks (below: list 0, list 1 or both by address and picture number,
      * one vector per list and picture) and B_Skip macroblocks whose references and vectors SPATIAL direct prediction

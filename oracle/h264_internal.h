@@ -317,6 +317,8 @@ void h264i_pred_mv16(H264Oracle* d, int list, int ref, int mv[2]);
 int h264i_pred_direct_mb(H264Oracle* d);
 void h264i_pred_mv_part(H264Oracle* d, int shape, int part, int ref, int mv[2]);
 void h264i_set_part(H264Oracle* d, int shape, int part, int ref, int mvx, int mvy);
+void h264i_pred_mv_part_l(H264Oracle* d, int list, int shape, int part, int ref, int mv[2]);
+void h264i_set_part_l(H264Oracle* d, int list, int shape, int part, int ref, int mvx, int mvy);
 void h264i_pred_mv_blk(H264Oracle* d, int bx, int by, int bw, int ref, int mv[2]);
 void h264i_set_blk(H264Oracle* d, int bx, int by, int bw, int bh, int mvx, int mvy);
 void h264i_set_ref8(H264Oracle* d, int b8, int ref);

@@ -1238,6 +1238,19 @@ void h264i_pred_mv_part(H264Oracle* d, int shape, int part, int ref, int mv[2]) 
   if (shape == 1) pred_mv(d, 0, 0, part * 2, 4, ref, part == 0 ? PRED_16x8_TOP : PRED_16x8_BOTTOM, mv);
   else pred_mv(d, 0, part * 2, 0, 2, ref, part == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT, mv);
 }
+/* ... per list, for the partitions of a B macroblock (shape 0: 16x16) */
+void h264i_pred_mv_part_l(H264Oracle* d, int list, int shape, int part, int ref, int mv[2]) {
+  if (shape == 0) pred_mv(d, list, 0, 0, 4, ref, PRED_MEDIAN, mv);
+  else if (shape == 1) pred_mv(d, list, 0, part * 2, 4, ref, part == 0 ? PRED_16x8_TOP : PRED_16x8_BOTTOM, mv);
+  else pred_mv(d, list, part * 2, 0, 2, ref, part == 0 ? PRED_8x16_LEFT : PRED_8x16_RIGHT, mv);
+}
+void h264i_set_part_l(H264Oracle* d, int list, int shape, int part, int ref, int mvx, int mvy) {
+  for (int q = 0; q < 4; ++q)
+    if (shape == 0 || (shape == 1 ? (q >> 1) : (q & 1)) == part) set_ref8(d, list, q, ref);
+  if (shape == 0) set_mv_block(d, list, 0, 0, 4, 4, ref >= 0 ? mvx : 0, ref >= 0 ? mvy : 0);
+  else if (shape == 1) set_mv_block(d, list, 0, part * 2, 4, 2, ref >= 0 ? mvx : 0, ref >= 0 ? mvy : 0);
+  else set_mv_block(d, list, part * 2, 0, 2, 4, ref >= 0 ? mvx : 0, ref >= 0 ? mvy : 0);
+}
 /* ... and the same for one sub-macroblock partition (bx, by, bw, bh in 4x4 blocks inside the macroblock) */
 void h264i_pred_mv_blk(H264Oracle* d, int bx, int by, int bw, int ref, int mv[2]) { pred_mv(d, 0, bx, by, bw, ref, PRED_MEDIAN, mv); }
 void h264i_set_blk(H264Oracle* d, int bx, int by, int bw, int bh, int mvx, int mvy) { set_mv_block(d, 0, bx, by, bw, bh, mvx, mvy); }

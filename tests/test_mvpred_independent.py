@@ -385,3 +385,79 @@ def test_hip_path_predicts_vectors_in_a_larger_picture_as_the_clause_says(hw, tm
     dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(3)))
     for k in range(1, 3):   # (a minute of Python: a whole-picture interpolation per distinct vector)
         assert np.array_equal(dec[k], expected(dec, k, w, h, 37)[0]), "picture %d" % k
+
+
+# ---- vector prediction in B pictures, list by list (--global-mv 12) --------------------------------------------------------
+# B macroblocks of one 16x16 or two 16x8 / 8x16 partitions; which lists a partition uses and the vector difference per list
+# follow from address, partition and picture number.  Each list is predicted on its own: a neighbour that does not use
+# the list counts as reference -1 with a zero vector.  (On this path the HOST derives the vectors: B pictures do not go
+# through k_mv.)
+def expected_b_partitions(dec, d, w, h):
+    if d % 3 == 0:
+        return np.concatenate([p.ravel() for p in shifted(dec[d - 3], global_mv_of(d, w, h), w, h)])
+    mbw, mbh, a = w // 16, h // 16, d - d % 3
+    lists = [Motion(mbw, mbh), Motion(mbw, mbh)]
+    refs = (dec[a], dec[a + 3])
+    out = [np.zeros((h, w), np.uint8), np.zeros((h // 2, w // 2), np.uint8), np.zeros((h // 2, w // 2), np.uint8)]
+    cache = {}
+
+    def pred(lst, mv):
+        if (lst, mv) not in cache:
+            cache[(lst, mv)] = shifted(refs[lst], mv, w, h)
+        return cache[(lst, mv)]
+    for addr in range(mbw * mbh):
+        mx, my = addr % mbw, addr // mbw
+        x, y = mx * 4, my * 4
+        shape = (addr + d) % 3   # 0 16x16, 1 16x8, 2 8x16
+        for part in range(2 if shape else 1):
+            use = (addr * 2 + d + part) % 3   # 0 list 0, 1 list 1, 2 both
+            if shape == 0:
+                rect, first = (x, y, 4, 4), None
+            elif shape == 1:
+                rect, first = (x, y + 2 * part, 4, 2), ("B" if part == 0 else "A")
+            else:
+                rect, first = (x + 2 * part, y, 2, 4), ("A" if part == 0 else "C")
+            mv = [None, None]
+            for lst in range(2):
+                if use == 2 or use == lst:
+                    px, py = predict(lists[lst], rect[0], rect[1], rect[2], 0, first)
+                    mv[lst] = (px + (addr * 5 + d * 3 + part * 4 + lst * 2) % 13 - 6, py + (addr * 7 + d + part * 2 + lst * 5) % 9 - 4)
+                    lists[lst].put(rect[0], rect[1], rect[2], rect[3], 0, mv[lst])
+                else:
+                    lists[lst].put(rect[0], rect[1], rect[2], rect[3], -1, (0, 0))
+            for pl, s in ((0, 4), (1, 2), (2, 2)):
+                reg = (slice(rect[1] * s, (rect[1] + rect[3]) * s), slice(rect[0] * s, (rect[0] + rect[2]) * s))
+                if mv[0] is not None and mv[1] is not None:
+                    out[pl][reg] = ((pred(0, mv[0])[pl][reg].astype(np.int64) + pred(1, mv[1])[pl][reg] + 1) >> 1).astype(np.uint8)
+                else:
+                    lst = 0 if mv[0] is not None else 1
+                    out[pl][reg] = pred(lst, mv[lst])[pl][reg]
+    return np.concatenate([p.ravel() for p in out])
+
+
+def b_partition_args():
+    return dict(frames=19, gop=19, bframes=2, refs=1, global_mv=12, deblock=1)
+
+
+@pytest.mark.parametrize("cabac", [1, 0])
+def test_oracle_predicts_b_partition_vectors_as_the_clause_says(hw, oracle, tmp_path, cabac):
+    path = str(tmp_path / "bp.mp4")
+    gold = make_clip(path, width=W, height=H, cabac=cabac, **b_partition_args())
+    frames, c = oracle.decode_file(path, hw.index_video(path))
+    assert c["slices_clean_end"] == c["slices"] > 0 and len(frames) == 19
+    dec = [f[0] for f in frames]
+    for d in range(1, 19):
+        assert np.array_equal(dec[d], expected_b_partitions(dec, d, W, H)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
+        assert np.array_equal(dec[d], gold[d])
+
+
+@pytest.mark.gpu
+def test_hip_path_predicts_b_partition_vectors_as_the_clause_says(hw, tmp_path):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = str(tmp_path / "bp.mp4")
+    make_clip(path, width=W, height=H, yuv=False, **b_partition_args())
+    dec = hw.Decoder(path, num_lanes=1).retrieve_yuv(list(range(19)))
+    for d in range(1, 19):
+        assert np.array_equal(dec[d], expected_b_partitions(dec, d, W, H)), "picture %d (%s)" % (d, "P" if d % 3 == 0 else "B")
