@@ -58,8 +58,10 @@ typedef struct {
                           5 / 6 / 8: ... with Intra16x16 / Intra4x4 / Intra8x8 macroblocks of known modes in between
                           (filter on: every bS); 7: known vector differences and reference indices, 16x16 / 16x8 / 8x16 /
                           P_Skip (vector prediction); 9: all-B_Skip pictures (temporal direct with --temporal-direct 1);
-                          10: coded and B_Skip macroblocks in a checkerboard (spatial direct).  --scaling 4 adds
-                          scaling matrices with known entries */
+                          10: coded and B_Skip macroblocks in a checkerboard (spatial direct); 11 (with --gop 1): intra
+                          pictures of I_PCM and known intra macroblocks, nothing taken from a previous picture; 12: B
+                          macroblocks with 16x16 / 16x8 / 8x16 partitions from list 0, 1 or both and known differences
+                          per list.  --scaling 4 adds scaling matrices with known entries */
   int qp_swing;        /* every few macroblocks the QP jumps anywhere in 0..51: large mb_qp_delta values, incl. the ones that
                           only fit the -26..25 range by wrapping around 52 */
   int slice_mbs;       /* > 0: a new slice every so many macroblocks - boundaries in the middle of rows (overrides --slices) */
