@@ -1,8 +1,8 @@
 """hwang_amd -- MI355X-native sparse H.264 frame retrieval behind
 scanner-research/hwang's API.
 
-Mirrors python/hwang/__init__.py:1-26 (index_video) and re-exports the
-`_python` surface plus Decoder.
+The ctypes twin of the `hwang` package (which sits on the pybind11 module): `index_video`, the `_python` surface
+re-hosted on the C ABI (api.py), and a Decoder whose retrieve() is ONE native call (decoder.py).
 """
 import os
 
@@ -12,26 +12,18 @@ from .api import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData,
 from .decoder import BatchRetriever, Decoder
 
 
-def index_video(f_or_string):
-    """Build a VideoIndex by driving MP4IndexCreator's pull protocol
-    (python/hwang/__init__.py:5-26)."""
-    def w(f):
-        f.seek(0, os.SEEK_END)
-        size = f.tell()
-        f.seek(0, 0)
-        indexer = MP4IndexCreator(size)
-        offset = 0
-        size_to_read = 1024
-        while not indexer.is_done():
-            f.seek(offset, 0)
-            data = f.read(size_to_read)
-            ret, offset, new_size = indexer.feed(data, size_to_read)
-            size_to_read = new_size
-        if indexer.is_error():
-            raise Exception(indexer.error_message())
-        return indexer.get_video_index()
-
-    if isinstance(f_or_string, str):
-        with open(f_or_string, 'rb') as f:
-            return w(f)
-    return w(f_or_string)
+def index_video(source):
+    """VideoIndex of an MP4 given as a path or a seekable binary file (the job of python/hwang/__init__.py:5-26):
+    MP4IndexCreator pulls - it is handed the first KiB and then names the byte range it wants next, until it has
+    seen `ftyp` + `moov` (+ every `moof`)."""
+    if isinstance(source, str):
+        with open(source, "rb") as f:
+            return index_video(f)
+    indexer = MP4IndexCreator(source.seek(0, os.SEEK_END))
+    offset, want = 0, 1024
+    while not indexer.is_done():
+        source.seek(offset)
+        _more, offset, want = indexer.feed(source.read(want), want)
+    if indexer.is_error():
+        raise Exception(indexer.error_message())
+    return indexer.get_video_index()

@@ -195,10 +195,17 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // entropy workers: frames may have been fetched before their pictures were decoded; those pictures first
     std::string worker_error;
     const bool workers_ok = !parser_ || parser_->wait_idle(&worker_error);
-    HWANG_RETURN_ON_ERROR(wait_all());
+    // Whatever wait_all() reports, no copier may still be writing into the caller's buffer when this returns: the
+    // caller frees it on an error (DecoderAutomata::get_frames -> the pybind wrapper).  A copier whose conversion had
+    // succeeded can be in the middle of its memcpy when a later batch trips the executor's sticky error.
+    const Result waited = wait_all();
     {
       std::unique_lock<std::mutex> lk(out_mu_);
       drain_bounces(lk);
+      if (!waited.ok) {
+        copy_error_.clear();
+        return waited;
+      }
       if (!copy_error_.empty()) {
         Result r(false, "AMDVideoDecoder: " + copy_error_);
         copy_error_.clear();
@@ -243,7 +250,6 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // and only then wait for the oldest.  (Taking the lowest free index re-used
     // the surface released most recently and made every picture wait for the
     // one submitted just before it.)
-    const int lane = lanes_[cur_lane_];
     int slot = -1;
     uint64_t done[kPipeLanes];  // how far each of this decoder's lanes has got (a moment ago: good enough to tell "free")
     exec_->completed(lanes_.data(), static_cast<int>(lanes_.size()), done);
@@ -257,7 +263,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         if (!surf_[i].dev) {
           // (a decoder with workers takes new surfaces from the top: its tests then cover surface numbers >= 128)
           if (fresh < 0 || num_workers_) fresh = i;
-        } else if (settled(surf_[i].motion[next_set(surf_[i])]) && (settled(surf_[i].busy) || lanes_[surf_[i].busy.lane] == lane)) {
+        } else if (settled(surf_[i].motion[next_set(surf_[i])]) && busy_elsewhere(surf_[i], cur_lane_, done) < 0) {
           slot = i;
           break;
         } else if (oldest < 0 || surf_[i].order < surf_[oldest].order) {
@@ -276,7 +282,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
           for (int i = 0; i < amd::kMaxSurfaces; ++i) {
             if (surf_[i].dev && !surf_[i].held) {
               if (!settled(surf_[i].motion[next_set(surf_[i])])) ++dbg_unsettled_motion_;
-              if (!settled(surf_[i].busy)) ++dbg_unsettled_busy_;
+              if (busy_elsewhere(surf_[i], -1, done) >= 0) ++dbg_unsettled_busy_;
             }
             if (!surf_[i].dev) continue;
             if (surf_[i].held & kHeldByParser) ++dbg_held_parser_;
@@ -308,12 +314,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         c.stall_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
       }
     };
-    Stamp motion, busy;
+    Stamp motion;
+    uint64_t busy[kPipeLanes];
     {
       std::lock_guard<std::mutex> lk(out_mu_);
       surf_[slot].flip = next_set(surf_[slot]);
       motion = surf_[slot].motion[surf_[slot].flip];
-      busy = surf_[slot].busy;
+      std::memcpy(busy, surf_[slot].busy_seq, sizeof(busy));
     }
     // the motion buffer of this surface may still be the source of an upload
     if (motion.seq) {
@@ -322,11 +329,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       if (!wait_stamp(motion, error)) return false;
       if (std::chrono::steady_clock::now() - w0 > std::chrono::microseconds(50)) ++dbg_motion_waits_;
     }
-    // work of another lane that still touches the surface (this lane's own is ordered by the lane)
-    if (busy.seq && lanes_[busy.lane] != lane) {
+    // work of other lanes that still touches the surface (this lane's own is ordered by the lane): every one of them -
+    // a reader on one lane and a conversion on another may both be pending
+    for (int li = 0; li < static_cast<int>(lanes_.size()); ++li) {
+      if (li == cur_lane_ || !busy[li] || done[li] >= busy[li]) continue;
       StallTimer st{counters_, std::chrono::steady_clock::now()};
       const auto w0 = std::chrono::steady_clock::now();
-      if (!wait_stamp(busy, error)) return false;
+      if (!wait_stamp(Stamp{li, busy[li]}, error)) return false;
       if (std::chrono::steady_clock::now() - w0 > std::chrono::microseconds(50)) ++dbg_busy_waits_;
     }
     {
@@ -455,17 +464,24 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       // The lanes rotate at sync samples and the executor orders work only within a lane.  A sync sample that is not
       // an IDR picture (open GOP) may be followed by pictures that refer to the GOP before it - on another lane:
       // whatever that lane still has to do with such a reference is waited for here.  (Closed GOPs: never.)
-      Stamp foreign[32];
-      int nforeign = 0;
+      uint64_t foreign[kPipeLanes] = {0};  // per lane: the latest submission that touches one of the references
+      bool any_foreign = false;
       {
         std::lock_guard<std::mutex> lk(out_mu_);
         for (int i = 0; i < d.num_ref_slots; ++i) {
           const SurfaceSlot& r = surf_[d.ref_slots[i]];
-          if (r.dev && r.lane != lane_index && r.busy.seq && r.busy.lane != lane_index) foreign[nforeign++] = r.busy;
+          if (!r.dev || r.lane == lane_index) continue;
+          for (int li = 0; li < static_cast<int>(lanes_.size()); ++li)
+            if (li != lane_index && r.busy_seq[li] > foreign[li]) {
+              foreign[li] = r.busy_seq[li];
+              any_foreign = true;
+            }
         }
       }
       std::string ignored;
-      for (int i = 0; i < nforeign; ++i) (void)wait_stamp(foreign[i], &ignored);  // (a failed lane fails every later wait too)
+      if (any_foreign)
+        for (int li = 0; li < static_cast<int>(lanes_.size()); ++li)
+          if (foreign[li]) (void)wait_stamp(Stamp{li, foreign[li]}, &ignored);  // (a failed lane fails every later wait too)
     }
     j.stamp = Stamp{lane_index, exec_->submit_picture(lane, sub)};
     note_seq(j.stamp);
@@ -474,12 +490,12 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       std::lock_guard<std::mutex> lk(out_mu_);
       SurfaceSlot& cs = surf_[d.slot];
       if (d.has_inter || d.compact_motion) cs.motion[set] = j.stamp;  // the surface's pinned buffers are upload sources
-      cs.busy = j.stamp;   // written by this submission ...
+      mark_busy(cs, j.stamp);   // written by this submission ...
       cs.lane = lane_index;
       cs.order = ++use_order_;
       j.order = use_order_;
       for (int i = 0; i < d.num_ref_slots; ++i) {  // ... which reads these
-        surf_[d.ref_slots[i]].busy = j.stamp;
+        mark_busy(surf_[d.ref_slots[i]], j.stamp);
         surf_[d.ref_slots[i]].order = use_order_;
       }
     }
@@ -526,7 +542,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const Stamp st{lane_index, exec_->submit_convert(lanes_[lane_index], sub)};
     note_seq(st);
     std::lock_guard<std::mutex> lk(out_mu_);
-    surf_[slot].busy = st;
+    mark_busy(surf_[slot], st);
     if (bounce >= 0) {
       bounce_[bounce].stamp = st;
       bounce_[bounce].queued = true;
@@ -587,8 +603,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     uint32_t* pmx_host[2] = {nullptr, nullptr};     // ... and their extra stream (row table + difference words)
     Stamp motion[2];                  // submission that still uploads from the set
     int flip = 0;                     // set of the picture in the surface now
-    Stamp busy;                       // latest submission that writes or reads the surface (its picture, pictures
-                                      // predicted from it, conversions of it)
+    uint64_t busy_seq[kPipeLanes] = {0};  // per lane of this decoder: the latest submission that writes or reads the
+                                      // surface (its picture, pictures predicted from it, conversions of it); one
+                                      // stamp for all lanes lost the reader on lane B when a conversion on lane A
+                                      // followed it (open GOPs, HWANG_TEST_ROTATE_LANES)
     int lane = 0;                     // lane index of the picture that was reconstructed into it
     uint64_t order = 0;               // when it was last used (for "the oldest")
     int held = 0;
@@ -637,6 +655,17 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     bool queued = false;     // ... has been submitted (entropy workers: it may wait for its picture)
     bool copying = false;    // a thread is waiting for that conversion / copying the frame out (out_mu_ released)
   };
+
+  static void mark_busy(SurfaceSlot& s, const Stamp& st) {
+    if (st.seq > s.busy_seq[st.lane]) s.busy_seq[st.lane] = st.seq;
+  }
+  // A lane other than `own_lane` (-1: any lane) that still has work pending on the surface, given how far each lane
+  // had got (`done`); -1 if none.
+  int busy_elsewhere(const SurfaceSlot& s, int own_lane, const uint64_t* done) const {
+    for (int li = 0; li < static_cast<int>(lanes_.size()); ++li)
+      if (li != own_lane && s.busy_seq[li] && done[li] < s.busy_seq[li]) return li;
+    return -1;
+  }
 
   void unref_surface_locked(int slot, int who) {
     if (slot >= 0 && slot < amd::kMaxSurfaces) surf_[slot].held &= ~who;
@@ -728,11 +757,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   Result drain_and_reset() {
-    HWANG_RETURN_ON_ERROR(wait_all());
+    const Result waited = wait_all();
     std::unique_lock<std::mutex> lk(out_mu_);
     // frames the caller has already taken with get_frame() are his: their copy-outs
-    // complete (a re-configure between two clips of a batched call used to drop them)
+    // complete (a re-configure between two clips of a batched call used to drop them) - also when the executor
+    // has failed: a copier that is in the middle of a frame finishes before anything is reset or reported
     drain_bounces(lk);
+    if (!waited.ok) return waited;
     // what the request that is over still had to say (a fetched frame whose picture was given up after the call had
     // already returned with another error) does not belong to the one that starts now
     sink_error_.clear();

@@ -1,6 +1,7 @@
 #include "decoder_automata.h"
 
 #include "sparse_hints.h"
+#include "util/avc_sample.h"
 
 #include <chrono>
 
@@ -119,6 +120,7 @@ Result DecoderAutomata::initialize(std::vector<EncodedData>&& encoded_data,
   failed_ = false;
   failure_ = Result();
 
+  nal_length_size_ = avc::nal_length_size(extradata);
   VideoDecoderInterface::FrameInfo info;
   info.width = segments_[0].width;
   info.height = segments_[0].height;
@@ -291,9 +293,20 @@ void DecoderAutomata::feeder() {
         for (uint64_t f : seg.valid_frames)
           if (f >= first_frame) ordinals.push_back(f - first_frame);
         hints->set_wanted_frames(ordinals);
-        std::vector<uint64_t> syncs;  // seg.keyframes: the interval's sync samples, then its end
-        for (uint64_t k : seg.keyframes)
-          if (k >= first_frame && k < seg.end_keyframe) syncs.push_back(k - first_frame);
+        // seg.keyframes: the interval's sync samples, then its end.  Only those that are IDR pictures bound a closed
+        // GOP: behind a recovery-point I picture (open GOP) leading pictures still refer to what came before, so the
+        // backend may not cut the decoding short in front of one (the reference decodes an interval continuously).
+        std::vector<uint64_t> syncs;
+        for (uint64_t k : seg.keyframes) {
+          if (k < first_frame || k >= seg.end_keyframe) continue;
+          const size_t si = static_cast<size_t>(k - first_frame);
+          if (si >= nsamples) continue;
+          const uint64_t so = seg.sample_offsets[si], ss = seg.sample_sizes[si];
+          if (so > seg.encoded_video.size() || ss > seg.encoded_video.size() - so) continue;
+          if (si == 0 || nal_length_size_ == 0 ||  // (no avcC - another codec, a test backend: trust the table)
+              avc::sample_is_idr(seg.encoded_video.data() + so, static_cast<size_t>(ss), nal_length_size_))
+            syncs.push_back(k - first_frame);
+        }
         hints->set_interval_keyframes(syncs);
       }
     }

@@ -101,6 +101,7 @@ class DecoderAutomata {
   bool dirty_ = false;         // something was fed since the last flush
   std::vector<EncodedData> segments_;
   size_t frame_size_ = 0;
+  int nal_length_size_ = 0;    // from the avcC handed to initialize(): to tell IDR sync samples from recovery points
 
   // feeder cursor
   size_t feed_seg_ = 0;

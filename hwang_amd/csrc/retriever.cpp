@@ -1,5 +1,6 @@
 #include "retriever.h"
 
+#include "util/avc_sample.h"
 #include "util/numa.h"
 
 #include <algorithm>
@@ -216,7 +217,16 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
 
     size_t slot = 0;
     const auto& sizes = index.sample_sizes();
+    const auto& offsets = index.sample_offsets();
     const auto& kfs = index.keyframe_indices();
+    // A GOP is an item of its own only if it is closed, i.e. if the sync sample behind it is an IDR picture; a
+    // recovery-point I picture (open GOP) stays in the item of the GOP before it.
+    const int length_size = avc::nal_length_size(index.metadata_bytes());
+    auto starts_closed_gop = [&](uint64_t sample) {
+      if (length_size == 0) return true;  // no avcC (another codec, a test backend): the sync table is all there is
+      return offsets[sample] <= rq.file_size && sizes[sample] <= rq.file_size - offsets[sample] &&
+             avc::sample_is_idr(rq.file + offsets[sample], static_cast<size_t>(sizes[sample]), length_size);
+    };
     for (size_t i = 0; i < plan.sample_index_intervals.size(); ++i) {
       const std::vector<uint64_t>& valid = plan.valid_frames[i];
       if (valid.empty()) continue;
@@ -226,6 +236,7 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
       uint64_t gop_start = istart;
       size_t v = 0;
       while (v < valid.size()) {
+        while (k < kfs.size() && kfs[k] < iend && !starts_closed_gop(kfs[k])) ++k;
         const uint64_t gop_end = (k < kfs.size() && kfs[k] < iend) ? kfs[k] : iend;
         size_t v2 = v;
         while (v2 < valid.size() && valid[v2] < gop_end) ++v2;

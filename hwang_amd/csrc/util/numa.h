@@ -28,7 +28,35 @@ inline int node_of_pci_device(const char* bus_id) {
   return node;
 }
 
-// CPUs of a node ("0-15,128-143") into `set`; false if the node has no list.
+// A sysfs cpulist ("0-15,128-143\n") into `set`; returns how many CPUs it names.  Parsed in place with strtol: lane
+// threads of several devices call this at the same time, so nothing with hidden state (strtok, which this used to
+// be written with, keeps its cursor in a process-wide static: concurrent callers walked each other's buffers).
+inline int parse_cpulist(const char* text, cpu_set_t* set) {
+  CPU_ZERO(set);
+  int n = 0;
+  for (const char* p = text; *p;) {
+    char* end = nullptr;
+    const long lo = strtol(p, &end, 10);
+    if (end == p) {  // a separator
+      ++p;
+      continue;
+    }
+    long hi = lo;
+    p = end;
+    if (*p == '-') {
+      hi = strtol(p + 1, &end, 10);
+      if (end == p + 1) hi = lo;
+      p = end;
+    }
+    for (long c = lo < 0 ? 0 : lo; c <= hi && c < CPU_SETSIZE; ++c) {
+      if (!CPU_ISSET(static_cast<int>(c), set)) ++n;
+      CPU_SET(static_cast<int>(c), set);
+    }
+  }
+  return n;
+}
+
+// CPUs of a node into `set`; false if the node has no list.
 inline bool cpus_of_node(int node, cpu_set_t* set) {
   char path[96];
   snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
@@ -38,22 +66,7 @@ inline bool cpus_of_node(int node, cpu_set_t* set) {
   const bool got = fgets(buf, sizeof(buf), f) != nullptr;
   fclose(f);
   if (!got) return false;
-  CPU_ZERO(set);
-  int n = 0;
-  for (char* tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
-    int lo = 0, hi = 0;
-    if (sscanf(tok, "%d-%d", &lo, &hi) == 2) {
-    } else if (sscanf(tok, "%d", &lo) == 1) {
-      hi = lo;
-    } else {
-      continue;
-    }
-    for (int c = lo; c <= hi && c < CPU_SETSIZE; ++c) {
-      CPU_SET(c, set);
-      ++n;
-    }
-  }
-  return n > 0;
+  return parse_cpulist(buf, set) > 0;
 }
 
 // Restricts the calling thread to the CPUs of `node` that it is allowed to use anyway.  Returns the number of CPUs

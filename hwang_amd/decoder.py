@@ -5,8 +5,9 @@ frame rows[k] as H x W x 3 uint8 RGB -- but a GPU Decoder hands the whole
 request to the library's parallel retriever (keyframe-anchored intervals
 fanned out over lanes whose pictures are batched into wide GPU launches)
 instead of looping one
-DecoderAutomata over the intervals.  `retrieve_serial` is the literal
-reference loop, kept for parity tests of the automata path.
+DecoderAutomata over the intervals.  `retrieve_serial` walks the intervals
+through one automata the way the reference does, for parity tests of that
+path.
 """
 import ctypes as C
 import mmap
@@ -166,46 +167,46 @@ class Decoder(object):
                 "libhwang_amd.so (only AMD on a GPU device; there is no CPU "
                 "fallback)" % (decoder_type,))
 
-    # -- literal reference loop ----------------------------------------------
+    # -- one DecoderAutomata, one interval at a time ---------------------------
     def _get_automata(self):
         if self._automata is None:
-            handle = DeviceHandle(self.device_type, self.device_id)
-            self._automata = DecoderAutomata(handle, 1, self.decoder_type)
+            self._automata = DecoderAutomata(DeviceHandle(self.device_type, self.device_id), 1, self.decoder_type)
         return self._automata
 
-    def retrieve_serial(self, rows):
-        video_intervals = slice_into_video_intervals(self.video_index, rows)
-        frames = []
-        sample_offsets = self.video_index.sample_offsets()
-        sample_sizes = self.video_index.sample_sizes()
-        sample_offsets.append(sample_offsets[-1] + sample_sizes[-1])
-        sample_sizes.append(0)
-        keyframes = self.video_index.keyframe_indices()
-        dec = self._get_automata()
-        for (start_index, end_index), valid_frames in video_intervals:
-            if not valid_frames:
-                continue
-            start_offset = sample_offsets[start_index]
-            end_offset = sample_offsets[end_index] + sample_sizes[end_index]
-            self.f.seek(start_offset, 0)
-            encoded_data = self.f.read(end_offset - start_offset)
+    def _interval(self, bounds, first, last, wanted):
+        """EncodedData of the planner interval [first, last): its bytes, its samples relative to them, the sync
+        samples inside it (the interval's end included, as the planner counts) and the frames wanted of it."""
+        begin, end = int(bounds[first]), int(bounds[last])
+        self.f.seek(begin)
+        piece = EncodedData()
+        piece.encoded_video = self.f.read(end - begin)
+        piece.width, piece.height = self.video_index.frame_width(), self.video_index.frame_height()
+        piece.format = self.video_index.format()
+        piece.start_keyframe, piece.end_keyframe = first, last
+        piece.sample_offsets = [int(o) - begin for o in bounds[first:last]]
+        piece.sample_sizes = self._sizes[first:last]
+        piece.keyframes = [k for k in self._keyframes if first <= k <= last]
+        piece.valid_frames = wanted
+        return piece
 
-            data = EncodedData()
-            data.width = self.video_index.frame_width()
-            data.height = self.video_index.frame_height()
-            data.format = self.video_index.format()
-            data.start_keyframe = start_index
-            data.end_keyframe = end_index
-            data.sample_offsets = [o - start_offset
-                                   for o in sample_offsets[start_index:end_index]]
-            data.sample_sizes = sample_sizes[start_index:end_index]
-            data.valid_frames = valid_frames
-            data.keyframes = [k for k in keyframes
-                              if k >= start_index and k <= end_index]
-            data.encoded_video = encoded_data
-            dec.initialize([data], self.video_index.metadata_bytes())
-            frames += dec.get_frames(self.video_index, len(valid_frames))
-        return frames
+    def retrieve_serial(self, rows):
+        """The shape of the reference's Decoder.retrieve (python/hwang/decoder.py:30-69) on the ctypes surface: the
+        seek plan's intervals go through ONE automata one after the other, each with an initialize() and a
+        get_frames() of its own.  Kept for the parity tests of the automata path; `retrieve` is the product."""
+        index = self.video_index
+        offsets = index.sample_offsets()
+        self._sizes = index.sample_sizes()
+        self._keyframes = index.keyframe_indices()
+        bounds = list(offsets) + [offsets[-1] + self._sizes[-1]]   # bounds[k]: where sample k starts / the file's samples end
+        extradata = index.metadata_bytes()
+        automata = self._get_automata()
+        out = []
+        for (first, last), wanted in slice_into_video_intervals(index, rows):
+            if not wanted:   # (the planner answers an empty request with one interval that wants nothing)
+                continue
+            automata.initialize([self._interval(bounds, first, last, wanted)], extradata)
+            out.extend(automata.get_frames(index, len(wanted)))
+        return out
 
     # -- parallel path ---------------------------------------------------------
     def _get_retriever(self):

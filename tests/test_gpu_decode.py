@@ -104,6 +104,34 @@ def test_sparse_rows_with_reference_b_pictures(hw, oracle, gpu, tmp_path):
         assert np.array_equal(serial[k], rgb[k]), "serial row %d" % r
 
 
+def test_sync_samples_that_are_not_idr_pictures_do_not_end_a_gop(hw, oracle, gpu, tmp_path):
+    """A sync-sample table may list random-access points that are not IDR pictures (x264's open-GOP mode lists
+    recovery-point I pictures in `stss`).  What lies behind such a sample may refer across it, so neither the per-GOP
+    cut behind the last wanted frame (automata path) nor the per-GOP work items (retriever path) may treat it as the
+    start of something self-contained.  Here the table of a closed-GOP clip is given extra entries in the
+    middle of its GOPs - P / B pictures, which certainly refer backwards: a planner interval that starts at a real
+    IDR picture and runs across such an entry must still decode every wanted frame exactly."""
+    path = str(tmp_path / "fakesync.mp4")
+    gold = make_clip(path, frames=48, gop=24, bframes=2, refs=2)
+    idx = hw.index_video(path)
+    assert idx.keyframe_indices() == [0, 24]
+    lying = hw.VideoIndex(timescale=idx.timescale(), duration=idx.duration(), width=idx.frame_width(),
+                          height=idx.frame_height(), format=idx.format(), sample_offsets=idx.sample_offsets(),
+                          sample_sizes=idx.sample_sizes(), keyframe_indices=[0, 12, 24, 37], metadata=idx.metadata_bytes())
+    rows = [5, 20, 30, 44]   # 20 and 44 lie behind a fake sync sample; their intervals start at 0 and 24
+    plan = hw.slice_into_video_intervals(lying, rows)
+    assert [tuple(iv) for iv, _ in plan] == [(0, 48)]   # (byte-adjacent GOPs: one interval with four "sync samples")
+    dec = hw.Decoder(path, video_index=lying, num_lanes=2)
+    got = dec.retrieve_yuv(rows)
+    for k, r in enumerate(rows):
+        assert np.array_equal(got[k], gold[r]), "retriever path, row %d" % r
+    rgb = dec.retrieve(rows)
+    serial = dec.retrieve_serial(rows)
+    for k, r in enumerate(rows):
+        assert np.array_equal(serial[k], rgb[k]), "automata path, row %d" % r
+        assert np.array_equal(rgb[k], oracle.i420_to_rgb(gold[r], 320, 240)), "row %d" % r
+
+
 def test_device_resident_output(hw, oracle, gpu, tmp_path):
     torch = gpu
     path = str(tmp_path / "dev.mp4")
