@@ -5,13 +5,14 @@ Workload (BASELINE.json configs[1], "C1"): one synthetic 1080p30 High-profile
 CABAC clip of 108 000 frames (1 h; 1 200 unique frames x 90 repeats of closed
 GOPs; GOP 60, 2 B-frames between references).  A request = rows =
 sorted(default_rng(20240601 + k).choice(N, round(0.01 N))) -> 1080 frames,
-returned as RGB24 into a tensor that lives in HBM.  One "step" = one batched
-call through the C ABI (hwang_retriever_retrieve_batch) of `--gpus` such
-requests (k = 0 .. gpus-1; at N = 1 exactly C1): the GOP segments of all
-requests are pooled and fanned out over the GPUs, so per-GPU work is fixed as N
-grows ("weak").  The encoded file is resident in host memory (it is what the
-host-side entropy decoder reads); every decoded frame and every intermediate
-picture stays in HBM.
+returned as RGB24 in HOST memory (SURVEY 8(d)'s timing rules: D2H included - what a
+caller of the reference gets).  One "step" = one batched call through the C ABI
+(hwang_retriever_retrieve_batch) of `--gpus` such requests (k = 0 .. gpus-1; at
+N = 1 exactly C1): the GOP segments of all requests are pooled and fanned out
+over the GPUs, so per-GPU work is fixed as N grows ("weak").  The encoded file is
+resident in host memory (it is what the host-side entropy decoder reads); every
+intermediate picture stays in HBM.  `value_hbm_resident` is the same request
+with the frames left in HBM (rounds 1-3 printed that as `value`).
 
     python bench.py --gpus N --steps K --warmup W
 
@@ -26,8 +27,12 @@ process instead (shared work queue, lanes bound round-robin to the devices).
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events
 on the executor's streams (hwang_prof_*) in an extra pass after the timed
 region (`end_to_end_frac`: SURVEY 8(d)'s whole-pipeline accounting);
-`value_host_output` is the D2H-inclusive rate (frames into pinned host memory)
-from another extra pass; `cpu_baseline` times the CPU oracle (a port, test
+`value_reference_api*` are the same request through the reference's Python API
+(one DecoderAutomata): with the reference's own unmodified caller loop
+(num_devices = 1, one interval per initialize: python/hwang/decoder.py:28,60-67)
+and with this build's grouped caller; `parity_check` compares MD5s of rows the
+TIMED configuration returned with the CPU oracle's decode of the same file;
+`cpu_baseline` times the CPU oracle (a port, test
 infrastructure) on a bounded sample of the same workload under the
 reference's semantics (every sample of every touched GOP is decoded, wanted
 frames converted to RGB), and carries the run-time FFmpeg probe's verdict.
@@ -90,7 +95,8 @@ def request_rows(np, n, k):
 
 
 def corpus_path(total_frames):
-    return "/tmp/hwang_bench_%s_%dx%d_%d_gop%d_b%d_qp%d.mp4" % (CONFIG.lower(), WIDTH, HEIGHT, total_frames, GOP, BFRAMES, QP)
+    tag = "" if UNIQUE_FRAMES == CONFIGS[CONFIG]["unique"] else "_u%d" % UNIQUE_FRAMES
+    return "/tmp/hwang_bench_%s_%dx%d_%d_gop%d_b%d_qp%d%s.mp4" % (CONFIG.lower(), WIDTH, HEIGHT, total_frames, GOP, BFRAMES, QP, tag)
 
 
 def make_corpus(total_frames):
@@ -120,11 +126,13 @@ def cpu_gop_worker(spec_path):
     (software_video_decoder.cpp:103-457 driven by DecoderAutomata: every sample
     of the interval is fed, unwanted frames are discarded, wanted ones are
     converted to RGB24)."""
+    import hashlib
     from oracle import oracle_py  # cpu_baseline leg only
     with open(spec_path) as f:
         spec = json.load(f)
     avcc = bytes.fromhex(spec["avcc"])
     returned = fed = 0
+    md5s = {}
     t0 = time.time()
     with open(spec["path"], "rb") as f:
         for gop in spec["gops"]:
@@ -135,12 +143,14 @@ def cpu_gop_worker(spec_path):
                 frames += dec.decode(f.read(size))
                 fed += 1
             frames += dec.flush()
-            for k in gop["wanted"]:
+            for k, row in zip(gop["wanted"], gop["rows"]):
                 buf, w, h, _ = frames[k]
-                oracle_py.i420_to_rgb(buf, w, h)
+                rgb = oracle_py.i420_to_rgb(buf, w, h)
                 returned += 1
+                if spec.get("md5"):   # (the untimed extra run that feeds bench.py's parity_check)
+                    md5s[str(row)] = hashlib.md5(rgb.tobytes()).hexdigest()
             dec.close()
-    print(json.dumps({"returned": returned, "fed": fed, "seconds": time.time() - t0}))
+    print(json.dumps({"returned": returned, "fed": fed, "seconds": time.time() - t0, "md5": md5s}))
 
 
 def cpu_baseline(path, index, rows, workers, max_gops=64, repeats=3):
@@ -156,9 +166,10 @@ def cpu_baseline(path, index, rows, workers, max_gops=64, repeats=3):
             ki += 1
         if gops and gops[-1]["gop"] == ki:
             gops[-1]["wanted"].append(r - kfs[ki])
+            gops[-1]["rows"].append(r)
         elif len(gops) < max_gops:
             gops.append({"gop": ki, "samples": [(offs[s], sizes[s]) for s in range(kfs[ki], kfs[ki + 1])],
-                         "wanted": [r - kfs[ki]]})
+                         "wanted": [r - kfs[ki]], "rows": [r]})
         else:
             break
     workers = max(1, min(workers, len(gops)))
@@ -169,7 +180,14 @@ def cpu_baseline(path, index, rows, workers, max_gops=64, repeats=3):
         for i in range(workers):
             with open(os.path.join(tmp, "w%d.json" % i), "w") as f:
                 json.dump({"path": path, "avcc": avcc, "gops": gops[i::workers]}, f)
-        for _ in range(repeats):
+        row_md5 = {}
+        for rep_i in range(repeats + 1):
+            # one more, untimed, run that also hashes what it returns: the oracle's answer for these rows
+            hashing = rep_i == repeats
+            if hashing:
+                for i in range(workers):
+                    with open(os.path.join(tmp, "w%d.json" % i), "w") as f:
+                        json.dump({"path": path, "avcc": avcc, "gops": gops[i::workers][:2], "md5": True}, f)
             procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker",
                                        os.path.join(tmp, "w%d.json" % i)], stdout=subprocess.PIPE)
                      for i in range(workers)]
@@ -179,6 +197,10 @@ def cpu_baseline(path, index, rows, workers, max_gops=64, repeats=3):
                 if p.returncode:
                     raise SystemExit("bench.py: cpu_baseline worker failed")
                 res.append(json.loads(out.decode().strip().splitlines()[-1]))
+            if hashing:
+                for r in res:
+                    row_md5.update(r["md5"])
+                break
             busy = max(r["seconds"] for r in res)  # slowest worker's decode time (interpreter start-up excluded)
             runs.append((sum(r["returned"] for r in res) / busy, sum(r["fed"] for r in res) / busy,
                          sum(r["returned"] for r in res), sum(r["fed"] for r in res)))
@@ -202,6 +224,7 @@ def cpu_baseline(path, index, rows, workers, max_gops=64, repeats=3):
         "fed_samples_per_s": round(med[1], 2),
         "runs_frames_per_s": [round(r[0], 3) for r in runs],
         "ffmpeg_probe": probe,
+        "_row_md5": row_md5,   # (popped by main(): the parity check's expected values, not part of the printed block)
     }
 
 
@@ -257,13 +280,20 @@ def main():
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("HWANG_BENCH_LANES", 0)))
     ap.add_argument("--cpu-workers", type=int, default=int(os.environ.get("HWANG_BENCH_CPU_WORKERS", 16)))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-output", action="store_true", help="skip the extra D2H-inclusive pass (N = 1)")
+    ap.add_argument("--no-hbm-output", action="store_true", help="skip the extra pass that leaves the frames in HBM (N = 1)")
+    ap.add_argument("--hbm-output", action="store_true",
+                    help="time the frames-stay-in-HBM variant as `value` (what rounds 1-3 printed); the line says so")
     ap.add_argument("--no-reference-api", action="store_true",
                     help="skip the extra pass through hwang.Decoder(...).retrieve(rows), the reference's own API (N = 1)")
     ap.add_argument("--reference-api-threads", type=int, default=int(os.environ.get("HWANG_BENCH_REF_THREADS", 0)),
                     help="num_devices handed to the reference API's DecoderAutomata (default: the usable CPUs)")
+    ap.add_argument("--unique", type=int, default=0,
+                    help="unique frames encoded before the clip repeats (default: the configuration's; C1: 1200 x 90)")
     args = ap.parse_args()
     args.frames = select_config(args.config, args.frames)
+    if args.unique:
+        global UNIQUE_FRAMES
+        UNIQUE_FRAMES = args.unique
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -332,12 +362,18 @@ def main():
     lanes = args.lanes or max(2, min(128, per_cpu * effective_cpus() // world))
     devices = (forced_ids or list(range(in_process_devices))) if in_process_devices > 1 else [device_index]
     br = BatchRetriever(device_ids=devices, num_lanes=lanes, shard=(rank, world) if world > 1 else None)
-    # request k's frames land in HBM (N ranks: each rank writes the rows of its share into its own copy of
-    # the batch's output; nothing is gathered - no data-path collective)
+    # request k's frames land in HOST memory (D2H is part of the job; N ranks: each rank writes the rows
+    # of its share into its own copy of the batch's output - pageable memory, so only the pages of its share ever
+    # exist; nothing is gathered - no data-path collective).  --hbm-output: a (rows, H, W, 3) tensor in HBM instead.
     fobj = open(path, "rb")
-    outs = [torch.empty((len(r), HEIGHT, WIDTH, 3), dtype=torch.uint8,
-                        device="cuda:%d" % (devices[k % len(devices)] if in_process_devices > 1 else device_index))
-            for k, r in enumerate(row_sets)]
+
+    def make_outs(in_hbm):
+        if in_hbm:
+            return [torch.empty((len(r), HEIGHT, WIDTH, 3), dtype=torch.uint8,
+                                device="cuda:%d" % (devices[k % len(devices)] if in_process_devices > 1 else device_index))
+                    for k, r in enumerate(row_sets)]
+        return [torch.empty((len(r), HEIGHT, WIDTH, 3), dtype=torch.uint8) for r in row_sets]
+    outs = make_outs(args.hbm_output)
     requests = [(index, fobj, row_sets[k], outs[k].data_ptr(), outs[k].numel()) for k in range(nreq)]
 
     def step():
@@ -403,11 +439,27 @@ def main():
                   "ms_per_step": round(1000.0 * s_elapsed / args.steps, 2),
                   "work": "ONE request of %d rows, its GOP work items divided over %d GPUs" % (len(row_sets[0]), args.gpus)}
 
+    # What the timed configuration returned, checked against the CPU oracle's decode of the same file (untimed): MD5 of
+    # the rows of request 0 that the cpu_baseline workers hashed.
+    parity = None
+    if rank == 0 and cpu and cpu.get("_row_md5"):
+        import hashlib
+        want = cpu.pop("_row_md5")
+        pos = {r: k for k, r in enumerate(row_sets[0])}
+        host0 = outs[0].cpu() if args.hbm_output else outs[0]
+        bad = [int(r) for r, h in want.items() if hashlib.md5(host0[pos[int(r)]].numpy().tobytes()).hexdigest() != h]
+        parity = {"rows_checked": len(want), "mismatches": len(bad), "mismatched_rows": bad[:8],
+                  "against": "oracle/ (CPU restatement) decoding the same file: MD5 of the RGB24 frame per row"}
+        del host0
+    if cpu:
+        cpu.pop("_row_md5", None)
+
     # roofline pass: one more step with the per-kernel HIP-event spans enabled
     roofline = None
     kernels = {}
-    value_host = None
+    value_other = None
     reference_api = None
+    reference_api_unmodified = None
     if rank == 0:
         lib.hwang_prof_reset()
         lib.hwang_prof_enable(1)
@@ -443,60 +495,72 @@ def main():
                         "launches": int(best[3]), "avg_launch_us": round(best[1] / best[3], 1),
                         "end_to_end_frac": round(e2e_bytes / (prof_stats["wall_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9), 5),
                         "end_to_end_bytes_per_step": round(e2e_bytes)}
-        # D2H-inclusive rate (SURVEY 8d timing rules): the same request into pinned host memory.  Reported
-        # beside `value`, never as `value`.
-        if args.gpus == 1 and not args.no_host_output and args.config == "C1":
-            host_out = torch.empty((len(row_sets[0]), HEIGHT, WIDTH, 3), dtype=torch.uint8).pin_memory()
-            hreq = [(index, fobj, row_sets[0], host_out.data_ptr(), host_out.numel())]
-            br.retrieve_into(hreq)
+        # The other output placement (N = 1): frames left in HBM when `value` is the host-memory rate, and vice versa.
+        if args.gpus == 1 and not args.no_hbm_output and args.config == "C1":
+            other = (torch.empty((len(row_sets[0]), HEIGHT, WIDTH, 3), dtype=torch.uint8) if args.hbm_output else
+                     torch.empty((len(row_sets[0]), HEIGHT, WIDTH, 3), dtype=torch.uint8, device="cuda:%d" % device_index))
+            oreq = [(index, fobj, row_sets[0], other.data_ptr(), other.numel())]
+            br.retrieve_into(oreq)
+            torch.cuda.synchronize()
             th = time.perf_counter()
             for _ in range(2):
-                br.retrieve_into(hreq)
+                br.retrieve_into(oreq)
             torch.cuda.synchronize()
-            value_host = round(2 * len(row_sets[0]) / (time.perf_counter() - th), 2)
-            del host_out
-        # The drop-in path itself: hwang.Decoder(path, device_type=GPU, num_devices=T).retrieve(rows) - the
-        # reference's Python API (python/hwang/decoder.py) over the pybind11 module, ONE DecoderAutomata driving ONE
-        # AMD backend whose T entropy workers decode consecutive pictures at once (num_devices as the reference's
-        # software backend reads it, software_video_decoder.cpp:148).  Frames come back as numpy arrays in host
-        # memory, as the reference returns them.  The request goes in four calls so that the 6.7 GB of returned
-        # arrays never exist at once.
+            value_other = round(2 * len(row_sets[0]) / (time.perf_counter() - th), 2)
+            del other
+        # The drop-in path itself: the reference's Python API (python/hwang/decoder.py) over the pybind11 module - ONE
+        # DecoderAutomata driving ONE AMD backend; frames come back as numpy arrays in host memory, as the reference
+        # returns them.  Two callers:
+        #  * `value_reference_api_unmodified`: the reference's own loop, unchanged - DecoderAutomata(handle, 1, type)
+        #    (decoder.py:28) and per planner interval one initialize([interval]) + one get_frames (decoder.py:60-67);
+        #    hwang.Decoder(..., num_devices=1, interval_group_bytes=0) is that loop.  Also with num_devices = the usable
+        #    CPUs (a one-character change in decoder.py:28).
+        #  * `value_reference_api`: this build's caller - num_devices = the usable CPUs, the seek plan's intervals
+        #    handed to initialize() in groups (the C++ API takes a list), the next group read ahead.
         if args.gpus == 1 and not args.no_reference_api and args.config == "C1":
             import hwang
             t_ref = args.reference_api_threads or effective_cpus()
             ridx = hwang.VideoIndex.deserialize(index.serialize())
-            rdec = hwang.Decoder(path, video_index=ridx, device_type=hwang.DeviceType.GPU, num_devices=t_ref)
             rows0 = row_sets[0]
-            rdec.retrieve(rows0[:40])   # first-use costs (surfaces, staging, worker threads) stay outside
-            # ONE retrieve(rows) call as the reference's API is used - its answer is a list of 1 080 arrays, 6.7 GB of
-            # host memory; on a machine that cannot spare that, four calls of a quarter each
             try:
                 avail = [int(l.split()[1]) for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0] * 1024
             except (OSError, IndexError, ValueError):
                 avail = 0
+            # ONE retrieve(rows) call as the reference's API is used - its answer is a list of 1 080 arrays, 6.7 GB of
+            # host memory; on a machine that cannot spare that, four calls of a quarter each
             nparts = 1 if avail > 4 * len(rows0) * HEIGHT * WIDTH * 3 else 4
             step_rows = (len(rows0) + nparts - 1) // nparts
             parts = [rows0[i:i + step_rows] for i in range(0, len(rows0), step_rows)]
-            # timed: the retrieve() calls themselves; letting go of a call's answer (munmap of up to 6.7 GB of touched
-            # pages: ~0.6 s) is the caller's business and happens between them
-            got, t_api, cpu_api = 0, 0.0, 0.0
-            for part in parts:
-                cr0, tr0 = os.times(), time.perf_counter()
-                frames = rdec.retrieve(part)
-                tr1, cr1 = time.perf_counter(), os.times()
-                t_api += tr1 - tr0
-                cpu_api += (cr1.user - cr0.user) + (cr1.system - cr0.system)
-                got += len(frames)
-                assert frames[0].shape == (HEIGHT, WIDTH, 3)
-                del frames
-            assert got == len(rows0)
-            reference_api = {"value": round(got / t_api, 2), "unit": "frames/s", "num_devices": t_ref,
-                             "host_cpus_busy": round(cpu_api / t_api, 2),
-                             "calls": len(parts),
-                             "api": "hwang.Decoder(path, device_type=GPU, num_devices=%d).retrieve(rows): pybind11 "
-                                    "hwang._python.DecoderAutomata -> VideoDecoderFactory -> AMD backend; numpy frames "
-                                    "in host memory" % t_ref}
-            del rdec
+
+            def run_api(num_devices, group_bytes, what):
+                rdec = hwang.Decoder(path, video_index=ridx, device_type=hwang.DeviceType.GPU, num_devices=num_devices,
+                                     interval_group_bytes=group_bytes)
+                rdec.retrieve(rows0[:40])   # first-use costs (surfaces, staging, worker threads) stay outside
+                # timed: the retrieve() calls themselves; letting go of a call's answer (munmap of up to 6.7 GB of
+                # touched pages: ~0.6 s) is the caller's business and happens between them
+                got, t_api, cpu_api = 0, 0.0, 0.0
+                for part in parts:
+                    cr0, tr0 = os.times(), time.perf_counter()
+                    frames = rdec.retrieve(part)
+                    tr1, cr1 = time.perf_counter(), os.times()
+                    t_api += tr1 - tr0
+                    cpu_api += (cr1.user - cr0.user) + (cr1.system - cr0.system)
+                    got += len(frames)
+                    assert frames[0].shape == (HEIGHT, WIDTH, 3)
+                    del frames
+                assert got == len(rows0)
+                del rdec
+                return {"value": round(got / t_api, 2), "unit": "frames/s", "num_devices": num_devices,
+                        "host_cpus_busy": round(cpu_api / t_api, 2), "calls": len(parts), "api": what}
+            reference_api_unmodified = {
+                "num_devices_1": run_api(1, 0, "hwang.Decoder(path, device_type=GPU).retrieve(rows) exactly as python/hwang/"
+                                               "decoder.py:28,60-67 drive it: DecoderAutomata(handle, 1, AMD), one initialize + "
+                                               "get_frames per planner interval (the backend picks its entropy workers itself)"),
+                "num_devices_cpus": run_api(t_ref, 0, "the same per-interval loop with num_devices = %d" % t_ref)}
+            reference_api = run_api(t_ref, 128 << 20,
+                                    "hwang.Decoder(path, device_type=GPU, num_devices=%d).retrieve(rows): pybind11 "
+                                    "hwang._python.DecoderAutomata -> VideoDecoderFactory -> AMD backend; intervals in 128 MB "
+                                    "groups per initialize(); numpy frames in host memory" % t_ref)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -519,19 +583,22 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %s; %dx%d, %d frames (%d unique x %d repeats of closed GOPs), GOP %d, %d B-frames, QP %d; "
                                    "one batched call of %d request(s) (%d rows each%s), GOP segments pooled and fanned "
-                                   "out over %d GPU(s); frames returned as RGB24 in HBM"
+                                   "out over %d GPU(s); frames returned as RGB24 in %s"
                                    % (CONFIG, CONFIGS[CONFIG]["what"], WIDTH, HEIGHT, n, unique, max(1, n // unique), GOP,
                                       BFRAMES, QP, nreq, len(row_sets[0]),
                                       ", seeds %d..%d" % (SEED, SEED + nreq - 1) if CONFIGS[CONFIG]["rows"] == "1pct" else "",
-                                      args.gpus),
+                                      args.gpus, "HBM (--hbm-output)" if args.hbm_output else "host memory (D2H inside the timed region)"),
                        "launch": ("one process, %d devices" % len(devices) if in_process_devices > 1 else
                                   "%d rank(s), one GPU each" % world if not oversubscribed else
                                   "%d ranks sharing %d GPU(s) (development run: gloo, not a scaling number)"
                                   % (world, torch.cuda.device_count())),
                        "lanes_per_gpu": lanes // len(devices), "host_cpus": effective_cpus(),
                        "sharding": "GOP work items, longest-first split, no collective on the data path"},
-            "value_host_output": value_host,
+            "value_host_output": round(value, 2) if not args.hbm_output else value_other,
+            "value_hbm_resident": value_other if not args.hbm_output else round(value, 2),
+            "value_reference_api_unmodified": reference_api_unmodified,
             "value_reference_api": reference_api,
+            "parity_check": parity,
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
             "samples_fed_per_s_rank0": round(stats["samples_fed"] / (elapsed / args.steps), 1),
             "host_cpus_busy_rank0": round(host_cpus_busy, 2),

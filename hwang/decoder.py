@@ -17,7 +17,12 @@ Two things differ from the reference's 69 lines, both inside its C++ API:
   (decoder.py:65).  Every `get_frames` ends with wait_until_frames_copied(), i.e.
   with the GPU drained: per interval that costs the full latency of the interval's
   dependent pictures every time, per group it is paid once.  `interval_group_bytes`
-  bounds the encoded bytes held per group; 0 restores the reference's loop."""
+  sizes the groups: the first is cut at a quarter of it (decoding starts early), the
+  following ones at twice it, and an interval is never split, so a group holds up to
+  2 x interval_group_bytes + one interval of encoded bytes.  Three groups exist at a
+  time (one decoding, one queued, one being read): about 6 x interval_group_bytes
+  (768 MB at the 128 MB default) of encoded video is resident beside the answer.
+  0 restores the reference's loop (one interval per initialize)."""
 import hwang
 
 from ._python import (DecoderAutomata, DeviceHandle, DeviceType, EncodedData, VideoDecoderType,
@@ -80,11 +85,19 @@ class Decoder(object):
             yield group, group_frames
 
     def retrieve(self, rows):
+        extradata = self.video_index.metadata_bytes()
+        if not self._group_bytes:
+            # the reference's loop as it stands (decoder.py:39-67): read an interval, initialize, fetch its frames -
+            # one after the other on this thread
+            frames = []
+            for group, nframes in self._groups(rows):
+                self._decoder.initialize(group, extradata, True)
+                frames += self._decoder.get_frames(self.video_index, nframes)
+            return frames
         # The next group is read and packed (file reads, EncodedData) by a helper thread while the current one decodes:
         # the extension releases the GIL inside initialize / get_frames.
         import queue
         import threading
-        extradata = self.video_index.metadata_bytes()
         ready = queue.Queue(maxsize=1)
         stop = threading.Event()
 

@@ -21,6 +21,7 @@
 
 #include "../h264/h264_parser.h"
 #include "../sparse_hints.h"
+#include "../util/cpus.h"
 #include "../util/numa.h"
 #include "../util/queue.h"
 #include "frame_job.h"
@@ -73,7 +74,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
  public:
   // num_workers > 1: the reference's `num_devices` (the software backend's decoder thread count,
   // software_video_decoder.cpp:148) - that many entropy workers decode consecutive pictures' slice data at once.
-  AMDVideoDecoder(int device_id, int num_workers) : device_(device_id), num_workers_(num_workers > 1 ? num_workers : 0) {}
+  // pool_member: one of many decoders that a caller drives from threads of its own (ParallelRetriever's lanes):
+  // no workers, and its pictures are meant for the executor's wide batches rather than for the shortest way through.
+  AMDVideoDecoder(int device_id, int num_workers, bool pool_member, bool auto_workers)
+      : device_(device_id), num_workers_(num_workers > 1 ? num_workers : 0), pool_member_(pool_member), auto_workers_(auto_workers) {}
   ~AMDVideoDecoder() override { teardown(); }
 
   bool open(std::string* error) {
@@ -97,13 +101,15 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       // set and a surface.  Pictures are handed over in decoding order, so everything behind a slow one (an IDR
       // picture takes five to ten times as long as a P picture) waits with the workers' results in hand: the window
       // has to span the GOPs that go by while one IDR picture is parsed, or the parser thread stalls on it.
-      max_in_flight_ = std::min(std::max(4 * num_workers_, 64), 128);
+      // (a decoder that chose its workers itself - num_devices = 1, the reference's own caller - serves one interval
+      // at a time: a window of two pictures per worker is all it can fill, and it should not pin 1.6 GB for it)
+      max_in_flight_ = auto_workers_ ? 2 * num_workers_ : std::min(std::max(4 * num_workers_, 64), 128);
       pool_.reset(new h264::WorkerPool(num_workers_));
     }
     // A staging set is tied up from begin_picture until the GPU is through with the picture.  The GPU needs ~2 ms per
     // dependent picture and interval, the workers deliver a picture every ~0.15 ms: only with the pictures of many
     // intervals queued do the lanes' batches fill (HWANG_PIPE_DEPTH overrides the queue depth).
-    int depth = kPipeDepth;
+    int depth = auto_workers_ ? 32 : kPipeDepth;
     if (const char* e = getenv("HWANG_PIPE_DEPTH")) depth = std::max(4, std::min(atoi(e), 1024));
     pipe_depth_ = depth;
     jobs_.resize(kJobs);  // with workers: sized with the picture geometry (ensure_geometry)
@@ -455,6 +461,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.inject_fault = inject ? 1 : 0;
     sub.num_mbs = static_cast<int>(nmb);
     sub.heavy = (d.has_intra && !d.has_inter) ? 1 : 0;
+    sub.num_intra_mbs = d.num_intra_mbs;
     const uint64_t S = nmb * 384;  // coded I420 bytes
     sub.bytes_inter = d.has_inter ? S * (1 + ((d.slice_type_mask & 2) ? 2 : 1)) : 0;
     sub.bytes_intra = d.has_intra ? S : 0;
@@ -1126,6 +1133,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   int peer_enabled_ = -1;  // last peer device whose HBM was made reachable from device_
   amd::GpuExecutor* exec_ = nullptr;
   const int num_workers_;       // entropy workers (0: slice data is decoded inside feed())
+  const bool pool_member_;      // created with num_devices = 0: a lane of a caller that brings the parallelism
+  const bool auto_workers_;     // created with num_devices = 1: the worker count is this backend's own choice
   int max_in_flight_ = 0;       // pictures whose slice data may be with the workers at a time
   int64_t dbg_alloc_ns_ = 0, dbg_allocs_ = 0, dbg_bounce_wait_ns_ = 0;  // HWANG_EXEC_DEBUG
   // test hook (tests/test_gpu_workers.py): the lanes rotate at EVERY sample, so every picture's references were
@@ -1190,9 +1199,13 @@ int amd_device_numa_node(int32_t device_id) {
   return numa::node_of_pci_device(bus_id);
 }
 
-// `num_devices` as the reference's software backend reads it (video_decoder_factory.cpp:90-91 ->
-// software_video_decoder.cpp:148: libavcodec's thread_count): how many threads may entropy decode for this decoder.
-// 0 and 1: the calling thread alone.
+// `num_devices` (video_decoder_factory.cpp:90-91 hands it to the backend; the reference's software backend reads it as
+// libavcodec's thread_count, software_video_decoder.cpp:148, its NVIDIA backend ignores it):
+//   n > 1  n threads entropy decode consecutive pictures of this ONE decoder at the same time;
+//   1      what the reference's own Python passes (python/hwang/decoder.py:28), i.e. "one decoder, nothing said about
+//          threads": the backend picks the worker count itself - the usable CPUs, at most 16; HWANG_ENTROPY_WORKERS
+//          overrides (0 or 1: the thread that calls feed() decodes alone, as in rounds 1-3);
+//   0      the caller is the parallelism (ParallelRetriever: one decoder per lane thread): no workers.
 VideoDecoderInterface* make_amd_video_decoder(int32_t device_id, uint32_t num_devices) {
   int count = 0;
   const hipError_t ce = hipGetDeviceCount(&count);
@@ -1201,7 +1214,13 @@ VideoDecoderInterface* make_amd_video_decoder(int32_t device_id, uint32_t num_de
             ce != hipSuccess ? hipGetErrorString(ce) : "");
     return nullptr;
   }
-  auto* d = new AMDVideoDecoder(device_id, static_cast<int>(std::min<uint32_t>(num_devices, 64)));
+  int workers = static_cast<int>(std::min<uint32_t>(num_devices, 64));
+  const bool auto_workers = num_devices == 1;
+  if (auto_workers) {
+    const char* e = getenv("HWANG_ENTROPY_WORKERS");
+    workers = e && *e ? std::max(0, std::min(atoi(e), 64)) : std::max(2, std::min<int>(usable_cpus(), 16));
+  }
+  auto* d = new AMDVideoDecoder(device_id, workers, num_devices == 0, auto_workers && workers > 1);
   std::string error;
   if (!d->open(&error)) {
     fprintf(stderr, "hwang_amd: cannot open the MI355X backend on GPU %d: %s\n", device_id, error.c_str());

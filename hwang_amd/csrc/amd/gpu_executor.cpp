@@ -426,7 +426,7 @@ void GpuExecutor::run_pre() {
       any_residual |= p.desc.do_intra != 0;
       bytes[0] += p.bytes_mv;
       bytes[1] += p.desc.do_deblock ? static_cast<uint64_t>(p.num_mbs) * (176 + 96) : 0;
-      bytes[2] += p.desc.do_intra ? static_cast<uint64_t>(p.num_mbs) * 768 : 0;
+      bytes[2] += p.desc.do_intra ? static_cast<uint64_t>(p.num_intra_mbs) * 768 : 0;  // (inter macroblocks return at once)
     }
     hipError_t e = launch_table_copy(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * items.size(), en.stream);
     if (e == hipSuccess) e = launch_upload(en.job_table_dev[slot], static_cast<int>(items.size()), en.stream);

@@ -68,6 +68,7 @@ struct PicSubmit {
   int ncopies = 0;
   int num_mbs = 0;
   int heavy = 0;  // engine: 1 for intra-only pictures
+  int num_intra_mbs = 0;
   uint64_t bytes_inter = 0, bytes_intra = 0, bytes_deblock = 0, bytes_mv = 0;  // algorithmic, for the roofline
 };
 

@@ -504,6 +504,7 @@ struct SliceData {
   PicBuffers bufs;
   size_t coef_used = 0;
   bool has_inter = false, has_intra = false;
+  int intra_mbs = 0;  // of this picture (the residual kernel's share of the work)
 
   SliceHdr sl;
   int slice_index = 0;
@@ -598,6 +599,7 @@ struct SliceData {
     mbs_decoded = 0;
     coef_used = 0;
     has_inter = has_intra = false;
+    intra_mbs = 0;
     pos_valid = false;
   }
 
@@ -624,6 +626,7 @@ struct SliceData {
     done->coef_count = coef_used;
     done->has_inter = has_inter;
     done->has_intra = has_intra;
+    done->num_intra_mbs = intra_mbs;
     return err.empty();
   }
 
@@ -1794,7 +1797,7 @@ struct SliceData {
     memcpy(&nnz[a * 24], mb.nnz, 24);
     const bool intra = mb.kind != MB_INTER;
     cur->mb_intra[a] = intra;
-    if (intra) has_intra = true; else has_inter = true;
+    if (intra) { has_intra = true; ++intra_mbs; } else has_inter = true;
 
     static const uint8_t kind_map[6] = {0, amd::MBK_I4x4, amd::MBK_I8x8, amd::MBK_I16x16, amd::MBK_IPCM, amd::MBK_INTER};
     o.kind = kind_map[mb.kind];

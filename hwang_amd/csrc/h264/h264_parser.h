@@ -63,6 +63,7 @@ struct PicDone {
   size_t coef_count;     // 32-bit words used
   bool has_inter;        // motion[] must be uploaded
   bool has_intra;
+  int num_intra_mbs;     // macroblocks that go through k_residual / k_intra
   bool any_deblock;      // some slice has the in-loop filter enabled
   bool mv_deferred;      // MbInfo::mv_flags & MVF_DEFERRED on some macroblocks: run k_mv first
   bool compact_motion;   // some macroblocks are MVF_COMPACT: pmo[] and pmx[0 .. pmx_count) must be uploaded

@@ -1,6 +1,7 @@
 #include "retriever.h"
 
 #include "util/avc_sample.h"
+#include "util/cpus.h"
 #include "util/numa.h"
 
 #include <algorithm>
@@ -13,33 +14,7 @@
 
 namespace hwang {
 
-// CPUs this process may actually use: hardware threads, capped by a cgroup
-// CPU-bandwidth quota when there is one (cgroup v2 cpu.max, v1 cfs_quota).
-// Entropy decoding is what lanes spend CPU on; more lanes than CPUs only
-// makes the quota throttle the whole process in bursts.
-int32_t ParallelRetriever::effective_cpus() {
-  unsigned hw = std::thread::hardware_concurrency();
-  double cpus = hw ? hw : 4;
-  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
-    char quota[32];
-    long period = 0;
-    if (fscanf(f, "%31s %ld", quota, &period) == 2 && period > 0 && quota[0] != 'm')
-      cpus = std::min(cpus, atof(quota) / period);
-    fclose(f);
-  } else {
-    long q = -1, per = 0;
-    if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
-      if (fscanf(fq, "%ld", &q) != 1) q = -1;
-      fclose(fq);
-    }
-    if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
-      if (fscanf(fp, "%ld", &per) != 1) per = 0;
-      fclose(fp);
-    }
-    if (q > 0 && per > 0) cpus = std::min(cpus, static_cast<double>(q) / per);
-  }
-  return std::max<int32_t>(1, static_cast<int32_t>(cpus + 0.5));
-}
+int32_t ParallelRetriever::effective_cpus() { return usable_cpus(); }
 
 ParallelRetriever* ParallelRetriever::make(const std::vector<DeviceHandle>& devices,
                                            VideoDecoderType type,
@@ -63,9 +38,10 @@ ParallelRetriever* ParallelRetriever::make(const std::vector<DeviceHandle>& devi
     Lane& lane = r->lanes_[li];
     lane.device_slot = li % static_cast<int32_t>(devices.size());
     for (auto& b : lane.backend) {
-      // num_devices = 1: a lane decodes on its own thread (for the AMD backend the argument is the number of entropy
-      // workers of ONE decoder, as the reference's software backend reads it; the lanes are this path's parallelism)
-      b.reset(VideoDecoderFactory::make_from_config(devices[lane.device_slot], 1, type));
+      // num_devices = 0: "the caller is the parallelism" - a lane decodes on its own thread and its pictures travel in
+      // the executor's wide batches.  (1 is what the reference's Python passes for ONE decoder that has the machine to
+      // itself, decoder.py:28: there the AMD backend brings its own entropy workers; n > 1: that many.)
+      b.reset(VideoDecoderFactory::make_from_config(devices[lane.device_slot], 0, type));
       if (!b) return nullptr;
     }
   }

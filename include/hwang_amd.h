@@ -140,7 +140,11 @@ int hwang_decoder_type_supported(int decoder_type);
  * (video_decoder_factory.cpp:90-91).  The AMD backend reads it as the reference's
  * software backend does (software_video_decoder.cpp:148, libavcodec's
  * thread_count): with n > 1, n threads entropy decode consecutive pictures of
- * this ONE decoder at the same time (0 and 1: the thread that calls feed()). */
+ * this ONE decoder at the same time.  1 - what the reference's Python passes
+ * (python/hwang/decoder.py:28) - leaves the count to the backend (the usable CPUs,
+ * at most 16; HWANG_ENTROPY_WORKERS overrides, 0 = the thread that calls feed()).
+ * 0: the caller brings the parallelism (one decoder per thread of its own, as
+ * hwang_retriever_* does): no workers, pictures batched for throughput. */
 hwang_decoder* hwang_decoder_create(int device_type, int32_t device_id,
                                     uint32_t num_devices, int decoder_type);
 void hwang_decoder_destroy(hwang_decoder* dec);
