@@ -93,7 +93,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const int nlanes = num_workers_ ? kPipeLanes : 1;
     // (with workers: the lanes are dealt to the executor's light engines in turn, so that the batches of GOPs in
     // flight overlap on the GPU instead of queueing behind each other)
-    for (int i = 0; i < nlanes; ++i) lanes_.push_back(exec_->register_lane(num_workers_ ? i : 0));
+    // (a decoder that is not one of a pool's lanes is served one interval at a time: its pictures travel as chains)
+    for (int i = 0; i < nlanes; ++i) lanes_.push_back(exec_->register_lane(num_workers_ ? i : 0, !pool_member_));
     last_seq_.reset(new std::atomic<uint64_t>[nlanes]);
     for (int i = 0; i < nlanes; ++i) last_seq_[i].store(0);
     if (num_workers_) {
@@ -112,7 +113,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     int depth = auto_workers_ ? 32 : kPipeDepth;
     if (const char* e = getenv("HWANG_PIPE_DEPTH")) depth = std::max(4, std::min(atoi(e), 1024));
     pipe_depth_ = depth;
-    jobs_.resize(kJobs);  // with workers: sized with the picture geometry (ensure_geometry)
+    // (with workers: sized with the picture geometry, ensure_geometry; a serial decoder outside a pool may have a
+    // chain's worth of pictures on the GPU at a time)
+    jobs_.resize(pool_member_ ? kJobs : 3 * kJobs);
     bounce_.resize(num_workers_ ? kPipeBounce : kBounce);
     if (num_workers_)
       for (int i = 0; i < kCopiers; ++i) copiers_.emplace_back([this] { copier_loop(); });
@@ -462,6 +465,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.num_mbs = static_cast<int>(nmb);
     sub.heavy = (d.has_intra && !d.has_inter) ? 1 : 0;
     sub.num_intra_mbs = d.num_intra_mbs;
+    sub.num_ref_slots = 0;
+    for (int i = 0; i < d.num_ref_slots && i < 32; ++i) sub.ref_slots[sub.num_ref_slots++] = static_cast<int16_t>(d.ref_slots[i]);
     const uint64_t S = nmb * 384;  // coded I420 bytes
     sub.bytes_inter = d.has_inter ? S * (1 + ((d.slice_type_mask & 2) ? 2 : 1)) : 0;
     sub.bytes_intra = d.has_intra ? S : 0;
@@ -586,7 +591,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   enum { kHeldByParser = 1, kHeldByOutput = 2 };
   // beyond this many surfaces, wait for an upload rather than grow (with entropy workers: the pictures in flight and
   // the intervals still on the GPU hold surfaces too)
-  int soft_surfaces() const { return num_workers_ ? amd::kMaxSurfaces : 12; }
+  int soft_surfaces() const { return num_workers_ ? amd::kMaxSurfaces : (pool_member_ ? 12 : 24); }
 
   // A submission: which of this decoder's lanes, and the lane-local sequence number.  seq 0 = none.
   struct Stamp {

@@ -205,14 +205,36 @@ struct alignas(16) JobDesc {
   const uint32_t* pmx;
   uint64_t reserved;
   UploadDesc uploads[kJobUploads];
+  // Chain launches (k_chain): the job - index into the launch's table - that reconstructs surface s in this same
+  // launch, -1 if the surface was final before the launch.  A picture that predicts from such a surface follows the
+  // progress its producer publishes (BandCtl::fin) instead of waiting for a kernel boundary.
+  int16_t slot_job[256];
 };
+static_assert(kMaxSurfaces <= 256, "JobDesc::slot_job");
 
 enum : uint32_t {
   FAULT_MV_IMPORT = 1,       // k_mv: line of the band above never arrived
   FAULT_INTRA_LINE = 2,      // k_intra (LDS neighbours): likewise
   FAULT_INTRA_PROGRESS = 3,  // k_intra (surface neighbours): progress word of the band above
   FAULT_DEBLOCK_PROGRESS = 4,
+  FAULT_CHAIN_REFERENCE = 5,  // k_chain: a reference picture of the same launch never got as far as a macroblock needs
+  FAULT_CHAIN_INTER = 6,      // k_chain: a row's inter macroblocks never all arrived
+  FAULT_CHAIN_INTRA = 7,      // k_chain: a row's intra prediction never finished
 };
+
+// A chain launch (k_chain): every stage of every picture of the batch as ONE launch of persistent workgroups that take
+// units from two lists by ticket - row units (a band of a picture's intra prediction or of its deblocking) and inter
+// units (a run of macroblocks) - both lists in an order in which a unit only ever depends on units before it (in
+// either list: gpu_executor.cpp builds them position by position of the lanes' chains).
+struct ChainArgs {
+  const JobDesc* jobs;
+  const uint32_t* row_units;    // job << 8 | stage << 7 | band     (stage 0 intra, 1 deblock)
+  const uint32_t* inter_units;  // job << 20 | run                  (macroblocks run * kChainRun ...)
+  uint32_t* tickets;            // [0] rows, [1] inter; zeroed with the table
+  uint32_t num_row_units, num_inter_units;
+  uint64_t bytes;               // algorithmic, for the span
+};
+constexpr int kChainRun = 8;    // macroblocks per inter unit
 
 // One colour-conversion / plane-copy request.
 struct ConvertDesc {

@@ -1,5 +1,6 @@
 #include "gpu_executor.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,7 @@ hipError_t launch_pre(const JobDesc* jobs, int njobs, int max_mbs, int max_rows,
                       const uint64_t bytes[3], hipStream_t stream);
 hipError_t launch_main(const JobDesc* jobs, int njobs, int max_mbs, int max_rows, bool any_inter, bool any_intra,
                        bool any_deblock, const uint64_t bytes[3], hipStream_t stream);
+hipError_t launch_chain(const ChainArgs& args, int workgroups, hipStream_t stream);
 
 namespace {
 // The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues
@@ -110,6 +112,8 @@ bool GpuExecutor::start(std::string* error) {
           hipMalloc(reinterpret_cast<void**>(&en.job_table_dev[i]), sizeof(JobDesc) * kMaxJobs) != hipSuccess ||
           hipHostMalloc(reinterpret_cast<void**>(&en.conv_table_host[i]), sizeof(ConvertDesc) * kMaxJobs, hipHostMallocDefault) != hipSuccess ||
           hipMalloc(reinterpret_cast<void**>(&en.conv_table_dev[i]), sizeof(ConvertDesc) * kMaxJobs) != hipSuccess ||
+          (is_light(ei) && (hipHostMalloc(reinterpret_cast<void**>(&en.unit_table_host[i]), sizeof(uint32_t) * kUnitWords, hipHostMallocDefault) != hipSuccess ||
+                            hipMalloc(reinterpret_cast<void**>(&en.unit_table_dev[i]), sizeof(uint32_t) * kUnitWords) != hipSuccess)) ||
           hipEventCreateWithFlags(&en.copied[i], hipEventDisableTiming) != hipSuccess)
         return fail("out of memory for job tables");
     }
@@ -179,6 +183,9 @@ void GpuExecutor::stop() {
       if (en.job_table_dev[i]) (void)hipFree(en.job_table_dev[i]);
       if (en.conv_table_host[i]) (void)hipHostFree(en.conv_table_host[i]);
       if (en.conv_table_dev[i]) (void)hipFree(en.conv_table_dev[i]);
+      if (en.unit_table_host[i]) (void)hipHostFree(en.unit_table_host[i]);
+      if (en.unit_table_dev[i]) (void)hipFree(en.unit_table_dev[i]);
+      en.unit_table_host[i] = en.unit_table_dev[i] = nullptr;
       en.copied[i] = nullptr;
       en.job_table_host[i] = en.job_table_dev[i] = nullptr;
       en.conv_table_host[i] = en.conv_table_dev[i] = nullptr;
@@ -187,7 +194,8 @@ void GpuExecutor::stop() {
   if (dbg) fprintf(stderr, "[executor] stop: done\n");
 }
 
-int GpuExecutor::register_lane(int light_group) {
+int GpuExecutor::register_lane(int light_group, bool chain) {
+  if (const char* e = getenv("HWANG_CHAIN")) chain = atoi(e) != 0;  // 1: every lane (the test suite runs the corpus through it), 0: none
   const int g = light_group % light_engines_;
   const int light_engine = g == 0 ? 0 : kHeavyEngines + g;
   std::lock_guard<std::mutex> lk(mu_);
@@ -197,6 +205,7 @@ int GpuExecutor::register_lane(int light_group) {
       l.submitted = l.launched = l.completed = 0;
       l.last_engine = light_engine;
       l.light_engine = light_engine;
+      l.chain = chain;
       l.waiters = 0;
       l.active = true;
       return static_cast<int>(i);
@@ -204,6 +213,7 @@ int GpuExecutor::register_lane(int light_group) {
   lanes_.emplace_back();
   lanes_.back().active = true;
   lanes_.back().light_engine = lanes_.back().last_engine = light_engine;
+  lanes_.back().chain = chain;
   return static_cast<int>(lanes_.size() - 1);
 }
 
@@ -221,7 +231,9 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     Item it;
     it.is_picture = true;
     it.pic = job;
-    it.engine = job.heavy ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
+    // (a chain lane's intra-only pictures stay with its other pictures: the P picture behind a keyframe follows it
+    // row by row inside one launch instead of waiting for another engine's batch to complete)
+    it.engine = (job.heavy && !lanes_[lane].chain) ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
     it.pre = prestage_ ? 0 : 2;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
@@ -468,11 +480,23 @@ void GpuExecutor::run(int engine) {
 
   std::vector<PicSubmit> pics;
   std::vector<ConvSubmit> convs;
+  std::vector<int> pic_lane, pic_pos, used_slots;  // per picture of the batch: its lane, its place in the lane's chain
+  // words a picture adds to a chain launch's unit table
+  auto chain_units = [](const PicSubmit& p) {
+    const size_t bands = static_cast<size_t>((p.desc.pp.mb_height + 3) / 4);
+    return (p.desc.do_inter ? static_cast<size_t>((p.num_mbs + kChainRun - 1) / kChainRun) : 0) + (p.desc.do_intra ? bands : 0) +
+           (p.desc.do_deblock ? bands : 0);
+  };
+  uint64_t n_chain_batches = 0, n_chain_pics = 0, max_chain = 0;
   const bool debug = getenv("HWANG_EXEC_DEBUG") != nullptr;
   uint64_t hist[9] = {0}, n_batches = 0, n_pics = 0, n_convs = 0, lane_state[5] = {0, 0, 0, 0, 0};
   for (;;) {
     pics.clear();
     convs.clear();
+    pic_lane.clear();
+    pic_pos.clear();
+    bool any_chain = false;
+    size_t chain_words = 0;
     int slot = -1;
     {
       std::unique_lock<std::mutex> lk(mu_);
@@ -497,14 +521,39 @@ void GpuExecutor::run(int engine) {
                           : 4;                                        // nothing in flight: thread parsing or idle
           ++lane_state[cls];
         }
-        int taken = 0;
-        bool took_picture = false;
+        int taken = 0, pictures = 0;
+        used_slots.clear();
         while (eligible(l, engine)) {
           Item& it = l.fifo.front();
           if (it.is_picture) {
-            if (took_picture || taken > 0 || pics.size() >= kMaxJobs) break;
+            if (pics.size() >= kMaxJobs) break;
+            if (!l.chain) {
+              if (taken > 0) break;  // one picture per lane and batch, then the conversions behind it
+            } else {
+              // A chain: the lane's next pictures as long as nothing but pictures has been taken, each predicted from
+              // the ones before inside the launch.  It ends in front of a picture that would overwrite a surface an
+              // earlier one of the chain writes or reads (in a chain "earlier in the lane" no longer means "finished"),
+              // behind a picture without deblocking (what follows it has no row progress to go by), and where the
+              // unit table is full.
+              if (taken > pictures) break;
+              const PicSubmit& p = it.pic;
+              if (pictures > 0) {
+                if (!pics.back().desc.do_deblock) break;
+                bool clash = false;
+                for (int sl : used_slots) clash |= sl == p.desc.pp.cur_slot;
+                if (clash) break;
+              }
+              const size_t units = chain_units(p);
+              if (chain_words + units > kUnitWords - 8) break;
+              chain_words += units;
+              used_slots.push_back(p.desc.pp.cur_slot);
+              for (int i = 0; i < p.num_ref_slots; ++i) used_slots.push_back(p.ref_slots[i]);
+              any_chain = true;
+            }
             pics.push_back(it.pic);
-            took_picture = true;
+            pic_lane.push_back(static_cast<int>(li));
+            pic_pos.push_back(pictures);
+            ++pictures;
           } else {
             if (convs.size() >= kMaxJobs) break;
             convs.push_back(it.conv);
@@ -566,6 +615,61 @@ void GpuExecutor::run(int engine) {
         bytes[2] += p.bytes_deblock;
         bytes[3] += p.bytes_mv;
       }
+      if (any_chain) {
+        // ---- chain launch: which job of the table writes which surface, and the two unit lists in dependency order
+        // (position by position of the lanes' chains; a picture's inter runs / intra bands / deblocking bands in turn)
+        int max_pos = 0;
+        for (size_t i = 0; i < pics.size(); ++i) {
+          JobDesc& jd = en.job_table_host[slot][i];
+          for (int k = 0; k < 256; ++k) jd.slot_job[k] = -1;
+          for (size_t j = 0; j < i; ++j)
+            if (pic_lane[j] == pic_lane[i]) jd.slot_job[pics[j].desc.pp.cur_slot] = static_cast<int16_t>(j);
+          max_pos = pic_pos[i] > max_pos ? pic_pos[i] : max_pos;
+        }
+        uint32_t* table = en.unit_table_host[slot];
+        table[0] = table[1] = table[2] = table[3] = 0;  // the tickets
+        uint32_t* rows = table + 4;
+        uint32_t nrows = 0, ninter = 0;
+        for (int pos = 0; pos <= max_pos; ++pos) {
+          for (int stage = 0; stage < 2; ++stage)
+            for (size_t i = 0; i < pics.size(); ++i) {
+              if (pic_pos[i] != pos || !(stage ? pics[i].desc.do_deblock : pics[i].desc.do_intra)) continue;
+              const int bands = (pics[i].desc.pp.mb_height + 3) / 4;
+              for (int b = 0; b < bands; ++b) rows[nrows++] = static_cast<uint32_t>(i) << 8 | static_cast<uint32_t>(stage) << 7 | static_cast<uint32_t>(b);
+            }
+        }
+        uint32_t* inter = rows + nrows;
+        for (int pos = 0; pos <= max_pos; ++pos)
+          for (size_t i = 0; i < pics.size(); ++i) {
+            if (pic_pos[i] != pos || !pics[i].desc.do_inter) continue;
+            const int runs = (pics[i].num_mbs + kChainRun - 1) / kChainRun;
+            for (int r = 0; r < runs; ++r) inter[ninter++] = static_cast<uint32_t>(i) << 20 | static_cast<uint32_t>(r);
+          }
+        ChainArgs args;
+        args.jobs = en.job_table_dev[slot];
+        args.tickets = en.unit_table_dev[slot];
+        args.row_units = en.unit_table_dev[slot] + 4;
+        args.inter_units = en.unit_table_dev[slot] + 4 + nrows;
+        args.num_row_units = nrows;
+        args.num_inter_units = ninter;
+        args.bytes = bytes[0] + bytes[1] + bytes[2];
+        e = launch_table_copy(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(), en.stream);
+        if (e == hipSuccess)
+          e = launch_table_copy(en.unit_table_dev[slot], en.unit_table_host[slot], sizeof(uint32_t) * (4 + nrows + ninter), en.stream);
+        if (!prestage_) {
+          const uint64_t b3[3] = {bytes[3], 0, 0};
+          if (e == hipSuccess) e = launch_upload(en.job_table_dev[slot], static_cast<int>(pics.size()), en.stream);
+          if (e == hipSuccess)
+            e = launch_pre(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, max_rows, any_mv, any_deblock, any_intra, b3,
+                           en.stream);
+        }
+        // a workgroup is four row waves + four inter waves; more of them than the device holds at once only queue
+        const uint32_t want = std::max<uint32_t>(nrows, (ninter + 3) / 4);
+        if (e == hipSuccess) e = launch_chain(args, static_cast<int>(std::min<uint32_t>(std::max<uint32_t>(want, 1u), 256u)), en.stream);
+        ++n_chain_batches;
+        n_chain_pics += pics.size();
+        max_chain = std::max<uint64_t>(max_chain, static_cast<uint64_t>(max_pos + 1));
+      } else {
       e = launch_table_copy(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * pics.size(), en.copy_stream);
       if (prestage_) {
         // records uploaded, vectors / boundary strengths / intra residuals computed by the records-only stage
@@ -582,6 +686,7 @@ void GpuExecutor::run(int engine) {
         if (e == hipSuccess)
           e = launch_batch(en.job_table_dev[slot], static_cast<int>(pics.size()), max_mbs, max_rows, any_inter, any_intra,
                            any_deblock, any_mv, bytes, en.stream);
+      }
       }
     }
     if (!convs.empty() && e == hipSuccess) {
@@ -620,6 +725,9 @@ void GpuExecutor::run(int engine) {
             (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2],
             (unsigned long long)hist[3], (unsigned long long)hist[4], (unsigned long long)hist[5], (unsigned long long)hist[6],
             (unsigned long long)hist[7], (unsigned long long)hist[8]);
+    if (n_chain_batches)
+      fprintf(stderr, "[executor %s%d] chain launches %llu with %llu pictures, longest chain %llu\n", is_light(engine) ? "light" : "heavy", engine,
+              (unsigned long long)n_chain_batches, (unsigned long long)n_chain_pics, (unsigned long long)max_chain);
     if (n_batches)
       fprintf(stderr, "[executor %s%d] lanes at batch formation (avg): taken %.1f, other-engine %.1f, in-flight+blocked %.1f, in-flight+parsing %.1f, idle/parsing %.1f\n",
               is_light(engine) ? "light" : "heavy", engine, lane_state[0] / (double)n_batches, lane_state[1] / (double)n_batches,

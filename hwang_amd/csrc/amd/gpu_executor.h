@@ -69,6 +69,9 @@ struct PicSubmit {
   int num_mbs = 0;
   int heavy = 0;  // engine: 1 for intra-only pictures
   int num_intra_mbs = 0;
+  // surfaces the picture predicts from (chain launches: a later picture of the same launch may not reuse them)
+  int16_t ref_slots[32];
+  int num_ref_slots = 0;
   uint64_t bytes_inter = 0, bytes_intra = 0, bytes_deblock = 0, bytes_mv = 0;  // algorithmic, for the roofline
 };
 
@@ -85,7 +88,12 @@ class GpuExecutor {
   static GpuExecutor* get(int device, std::string* error);
 
   // light_group: which of the 1 + kExtraLightEngines light engines runs the lane's P / B pictures (taken modulo).
-  int register_lane(int light_group = 0);
+  // chain: the lane's pictures - each predicted from the one before - travel SEVERAL to a batch and run as one chain
+  // launch (k_chain: picture n + 1 trails picture n by a few macroblock rows), intra-only pictures included.  For a
+  // decoder that is served one interval at a time (the reference's DecoderAutomata): latency is all it has.  Lanes
+  // of a caller that keeps dozens of decoders busy (ParallelRetriever) leave it off: one picture per lane and batch,
+  // in launches as wide as the lanes make them.
+  int register_lane(int light_group = 0, bool chain = false);
   void unregister_lane(int lane);
   // Both return the lane-local sequence number of the submission (1, 2, ...).
   uint64_t submit_picture(int lane, const PicSubmit& job);
@@ -126,6 +134,7 @@ class GpuExecutor {
     uint64_t submitted = 0, launched = 0, completed = 0;
     int last_engine = 0;
     int light_engine = 0;  // engine of the lane's P / B pictures
+    bool chain = false;    // see register_lane
     int waiters = 0;  // threads blocked in wait()
     // A completed batch wakes exactly the lanes it contained (one shared
     // condition variable woke every blocked lane thread for every batch: 10 %
@@ -182,7 +191,11 @@ class GpuExecutor {
     JobDesc* job_table_dev[kInflight] = {nullptr, nullptr, nullptr};
     ConvertDesc* conv_table_host[kInflight] = {nullptr, nullptr, nullptr};
     ConvertDesc* conv_table_dev[kInflight] = {nullptr, nullptr, nullptr};
+    // chain launches: [0 .. 3] the two ticket counters (zero), then the row units, then the inter units (ChainArgs)
+    uint32_t* unit_table_host[kInflight] = {nullptr, nullptr, nullptr};
+    uint32_t* unit_table_dev[kInflight] = {nullptr, nullptr, nullptr};
   };
+  static constexpr size_t kUnitWords = size_t(1) << 18;  // per table: 1 MB, ~250 1080p pictures' worth of units
 
   // May engine `e` take the head of this lane's queue?  (mu_ held)
   bool eligible(const Lane& l, int e) const {

@@ -106,6 +106,34 @@ __device__ __forceinline__ int level_scale8(const uint8_t* weight, int qp, int p
   return weight[pos] * c_norm8[qp % 6][cls];
 }
 
+// Agent-scope accesses (sc1 on gfx950): they bypass the per-XCD L2 (and the CU's L1), so it does not matter which
+// XCDs - or which workgroups of a launch - the two ends of a hand-off land on.
+__device__ __forceinline__ uint64_t agent_ld64(const uint64_t* p) {
+  return __hip_atomic_load((const HW_AS1 uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t agent_ld32(const void* p) {
+  return __hip_atomic_load((const HW_AS1 uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int agent_ld8(const void* p) {
+  return __hip_atomic_load((const HW_AS1 uint8_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_st32(void* p, uint32_t v) {
+  __hip_atomic_store((HW_AS1 uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_st16(void* p, uint16_t v) {
+  __hip_atomic_store((HW_AS1 uint16_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void agent_st64(uint64_t* p, uint64_t v) {
+  __hip_atomic_store((HW_AS1 uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Sample accessors of the reconstruction stages.  FRESH = the samples are produced / consumed by other workgroups of
+// the SAME launch (chain launches, k_chain below: no kernel boundary makes them visible), so every access is
+// agent-scope; otherwise the plain cached forms.
+template <bool FRESH> __device__ __forceinline__ uint32_t sld32(const void* p) { return FRESH ? agent_ld32(p) : gld32(p); }
+template <bool FRESH> __device__ __forceinline__ int sld8(const void* p) { return FRESH ? agent_ld8(p) : (int)gld8(p); }
+template <bool FRESH> __device__ __forceinline__ void sst32(void* p, uint32_t v) { if (FRESH) agent_st32(p, v); else gst32(p, v); }
+template <bool FRESH> __device__ __forceinline__ void sst16(void* p, uint16_t v) { if (FRESH) agent_st16(p, v); else gst16(p, v); }
+
 constexpr int kLevels = 26 * 16;
 __device__ __forceinline__ void wave_sync();
 
@@ -345,6 +373,7 @@ __device__ void wave_residual(const MbInfo& mb, const uint32_t* coefs, const Pic
 __device__ __forceinline__ uint32_t ld32u(const uint8_t* p) { return gld32(p); }
 
 // 12 bytes (3 dwords) of row y starting at column xs, coordinates clamped
+template <bool FRESH>
 __device__ __forceinline__ void row_clamped(const uint8_t* plane, int pitch, int W, int H, int xs, int y, int nd,
                                             uint32_t* w) {
   const uint8_t* row = plane + (size_t)iclip(0, H - 1, y) * pitch;
@@ -353,7 +382,7 @@ __device__ __forceinline__ void row_clamped(const uint8_t* plane, int pitch, int
     if (d >= nd) break;
     uint32_t v = 0;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) v |= (uint32_t)gld8(row + iclip(0, W - 1, xs + 4 * d + b)) << (8 * b);
+    for (int b = 0; b < 4; ++b) v |= (uint32_t)sld8<FRESH>(row + iclip(0, W - 1, xs + 4 * d + b)) << (8 * b);
     w[d] = v;
   }
 }
@@ -367,6 +396,7 @@ __device__ __forceinline__ int tap6_row(const uint32_t* w, int i) {  // bytes i 
 __device__ __forceinline__ void luma_filter4(const uint32_t (*w)[3], int fx, int fy, int* out);
 
 // plane: reference luma; (px, py): position of the lane's first sample; mv in quarter samples
+template <bool FRESH>
 __device__ __forceinline__ void luma_pred4(const uint8_t* plane, int pitch, int W, int H, int px, int py, int mvx,
                                            int mvy, int* out) {
   const int fx = mvx & 3, fy = mvy & 3;
@@ -382,17 +412,17 @@ __device__ __forceinline__ void luma_pred4(const uint8_t* plane, int pitch, int 
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       if (r < r0 || r > r1) continue;
-      w[r][0] = ld32u(base + r * pitch);
+      w[r][0] = sld32<FRESH>(base + r * pitch);
       if (horiz) {
-        w[r][1] = ld32u(base + r * pitch + 4);
-        w[r][2] = ld32u(base + r * pitch + 8);
+        w[r][1] = sld32<FRESH>(base + r * pitch + 4);
+        w[r][2] = sld32<FRESH>(base + r * pitch + 8);
       }
     }
   } else {
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
       if (r < r0 || r > r1) continue;
-      row_clamped(plane, pitch, W, H, xs, y - 2 + r, nd, w[r]);
+      row_clamped<FRESH>(plane, pitch, W, H, xs, y - 2 + r, nd, w[r]);
     }
   }
   luma_filter4(w, fx, fy, out);
@@ -471,19 +501,20 @@ __device__ __forceinline__ void luma_filter4(const uint32_t (*w)[3], int fx, int
 
 __device__ __forceinline__ void chroma_filter2(uint32_t a, uint32_t c, int fx, int fy, int* out);
 // two horizontally adjacent chroma samples (8.4.2.2.2); mv in eighth samples
+template <bool FRESH>
 __device__ __forceinline__ void chroma_pred2(const uint8_t* plane, int pitch, int W, int H, int px, int py, int mvx,
                                              int mvy, int* out) {
   const int fx = mvx & 7, fy = mvy & 7;
   const int x = px + (mvx >> 3), y = py + (mvy >> 3);
   uint32_t a, c;
   if (x >= 0 && x + 3 <= W && y >= 0 && y + 1 < H) {
-    a = ld32u(plane + (size_t)y * pitch + x);
-    c = ld32u(plane + (size_t)(y + 1) * pitch + x);
+    a = sld32<FRESH>(plane + (size_t)y * pitch + x);
+    c = sld32<FRESH>(plane + (size_t)(y + 1) * pitch + x);
   } else {
     uint32_t t[3];
-    row_clamped(plane, pitch, W, H, x, y, 1, t);
+    row_clamped<FRESH>(plane, pitch, W, H, x, y, 1, t);
     a = t[0];
-    row_clamped(plane, pitch, W, H, x, y + 1, 1, t);
+    row_clamped<FRESH>(plane, pitch, W, H, x, y + 1, 1, t);
     c = t[0];
   }
   chroma_filter2(a, c, fx, fy, out);
@@ -494,6 +525,36 @@ __device__ __forceinline__ void chroma_filter2(uint32_t a, uint32_t c, int fx, i
   const int c0 = c & 0xff, c1 = (c >> 8) & 0xff, c2 = (c >> 16) & 0xff;
   out[0] = ((8 - fx) * (8 - fy) * a0 + fx * (8 - fy) * a1 + (8 - fx) * fy * c0 + fx * fy * c1 + 32) >> 6;
   out[1] = ((8 - fx) * (8 - fy) * a1 + fx * (8 - fy) * a2 + (8 - fx) * fy * c1 + fx * fy * c2 + 32) >> 6;
+}
+
+constexpr int kMaxRows = kMaxMbRows;
+// Row pipelines whose pictures are spread over several workgroups ("bands" of
+// kBandWaves rows, one wave per row; k_mv explains why).  BandCtl is the
+// per-picture hand-off area in global memory (JobDesc::band_ctl); every word in
+// it is tagged with JobDesc::epoch, nothing is cleared between pictures.
+constexpr int kBandWaves = 4;
+constexpr int kMaxBands = kMaxRows / kBandWaves;
+struct BandCtl {
+  uint64_t db_prog[kMaxBands];   // k_deblock: epoch << 32 | macroblocks of the band's last row that are final
+  uint64_t in_prog[kMaxBands];   // k_intra (neighbours read from the surface): likewise
+  // Chain launches (k_chain): progress of the picture's stages per macroblock ROW, for the other stages of the same
+  // picture and for the pictures that predict from it inside the same launch.
+  uint64_t fin[kMaxRows];        // deblocking: epoch << 32 | macroblocks of row r that row r's own filtering has left final
+  uint64_t intra_fin[kMaxRows];  // intra prediction: epoch << 32 | 1 once row r is through
+  uint32_t inter_done[kMaxRows]; // motion compensation: inter macroblocks of row r stored (zeroed by k_upload)
+  // tagged words {datum, epoch}; with B = bands of the picture:
+  //   [0, B * kLineMbs * 5)                      k_mv: [band][mbx] MvEdge as five words
+  //   [B * kLineMbs * 5, B * kLineMbs * 13)      k_intra (LDS neighbours): [band][mbx] bottom rows, 32 bytes as eight words
+  uint64_t lines[1];
+};
+constexpr int kMvLineWords = 5, kIntraLineWords = 8;
+__device__ __forceinline__ int bands_of(int mb_height) { return (mb_height + kBandWaves - 1) / kBandWaves; }
+
+// A bounded poll of another band expired.  The polls are bounded so that a
+// protocol error can never hang the GPU; this makes the same error loud on the
+// host (GpuExecutor::complete fails the batch) instead of silent wrong samples.
+__device__ __forceinline__ void report_fault(const JobDesc& job, uint32_t code) {
+  if (job.fault) __hip_atomic_store((HW_AS1 uint32_t*)job.fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 constexpr int kInterWaves = 4;
@@ -548,25 +609,69 @@ __device__ __forceinline__ u32x2 gld64u(const uint8_t* p) { return *(const HW_AS
 // band of the picture: its L2 then sees whole cache lines of the output and
 // the overlapping reference windows of neighbouring macroblocks.
 // ===========================================================================
-__global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __restrict__ jobs) {
-  const JobDesc& job = jobs[blockIdx.y];
+namespace {
+// agent-scope forms of the window loads (any byte alignment, like gld64u / ld32u)
+HW_FN u32x2 agent_ld64u(const uint8_t* p) {
+  const uint64_t v = __hip_atomic_load((const HW_AS1 uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  u32x2 r;
+  r.x = (uint32_t)v;
+  r.y = (uint32_t)(v >> 32);
+  return r;
+}
+
+// Chain launches: a macroblock that predicts from a picture of the same launch waits until that picture's
+// deblocking has left final everything the prediction reads: luma rows up to `bottom`, columns up to `right`
+// (samples; chroma lies inside the same macroblocks).  Row R of the reference is final once the deblocking of row
+// R + 1 has passed the columns in question (its top edges still change row R's last lines); BandCtl::fin[r] counts
+// the macroblocks of row r that row r's own filtering - stores landed - is through with, and a row never runs ahead
+// of the row above, so one word says it all.  The poll is bounded like every other one.
+HW_FN void chain_wait_reference(const JobDesc& ref, const JobDesc& job, int bottom, int right) {
+  const int mbh = ref.pp.mb_height, mbw = ref.pp.mb_width;
+  const int row = imin(iclip(0, mbh - 1, bottom >> 4) + 1, mbh - 1);
+  const uint32_t need = (uint32_t)imin(iclip(0, mbw - 1, right >> 4) + 1, mbw);
+  const uint64_t* word = &static_cast<const BandCtl*>(ref.band_ctl)->fin[row];
+  const uint32_t epoch = ref.epoch;
+  for (int tries = 0; tries < (1 << 21); ++tries) {
+    const uint64_t v = agent_ld64(word);
+    if (static_cast<uint32_t>(v >> 32) == epoch && static_cast<uint32_t>(v) >= need) return;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  report_fault(job, FAULT_CHAIN_REFERENCE);
+}
+}  // namespace
+
+// One inter macroblock by one wave.  CHAIN: as a unit of k_chain - references of the same launch are waited for and
+// read with agent-scope loads, the macroblock's samples are stored agent-scope, and its row's counter is raised when
+// they have landed.
+struct InterPicture {  // what a wave needs from the descriptor, requested in one go
+  int mb_width, mb_height, y_pitch, c_pitch;
+  const MbInfo* mbs;
+  const MbMotion* motions;
+  const SliceParams* slices;
+  Surface cur;
+};
+__device__ __forceinline__ InterPicture inter_picture(const JobDesc& job) {
   const PictureParams& pp = job.pp;
-  // everything the wave needs from the descriptor, requested in one go
-  const int do_inter = job.do_inter;
-  const int mb_width = pp.mb_width, mb_height = pp.mb_height, y_pitch = pp.y_pitch, c_pitch = pp.c_pitch;
-  const MbInfo* const mbs = job.mbs;
-  const MbMotion* const motions = job.motions;
-  const SliceParams* const slices = job.slices;
-  const Surface cur = pp.surfaces[pp.cur_slot];
-  if (!do_inter) return;
-  const int nmb = mb_width * mb_height;
-  const int ngroups = (nmb + kInterWaves - 1) / kInterWaves;
-  const int band = (ngroups + 7) / 8;
-  const int group = (blockIdx.x % 8) * band + blockIdx.x / 8;
-  if (blockIdx.x / 8 >= band || group >= ngroups) return;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int mbi = group * kInterWaves + wave;
-  if (mbi >= nmb) return;
+  InterPicture ip;
+  ip.mb_width = pp.mb_width;
+  ip.mb_height = pp.mb_height;
+  ip.y_pitch = pp.y_pitch;
+  ip.c_pitch = pp.c_pitch;
+  ip.mbs = job.mbs;
+  ip.motions = job.motions;
+  ip.slices = job.slices;
+  ip.cur = pp.surfaces[pp.cur_slot];
+  return ip;
+}
+template <bool CHAIN>
+__device__ __forceinline__ void inter_mb(const JobDesc* __restrict__ jobs, const JobDesc& job, const InterPicture& ip, const int mbi,
+                                         const int lane, InterWave& L) {
+  const PictureParams& pp = job.pp;
+  const int mb_width = ip.mb_width, mb_height = ip.mb_height, y_pitch = ip.y_pitch, c_pitch = ip.c_pitch;
+  const MbInfo* const mbs = ip.mbs;
+  const MbMotion* const motions = ip.motions;
+  const SliceParams* const slices = ip.slices;
+  const Surface cur = ip.cur;
   const MbMotion* __restrict__ mo = motions + mbi;
   // the lane's motion data: luma block (row y, 4x4 column lane&3)
   const int y = lane >> 2, bcol = lane & 3;
@@ -582,8 +687,6 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
   if (mb.kind != MBK_INTER) return;
   const SliceParams& sp = slices[mb.slice];
   const int weight_mode = gld8(&sp.weight_mode);
-  __shared__ InterWave lds[kInterWaves];
-  InterWave& L = lds[wave];
   const int mbx = mbi % mb_width, mby = mbi / mb_width;
   const bool has_res = mb.coded_mask != 0;
   const int W = mb_width * 16, H = mb_height * 16;
@@ -630,6 +733,53 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     }
   }
   window = window && (use_win[0] || use_win[1]);
+  // chain: references that this launch reconstructs (wave-uniform: the record's words are the same in every lane)
+  bool fresh[2] = {false, false};
+  if constexpr (CHAIN) {
+    if (window) {
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        if (!use_win[l]) continue;
+        const int rj = job.slot_job[__builtin_amdgcn_readfirstlane(slot_of(l ? slots1 : slots0, 0))];
+        if (rj >= 0) {
+          fresh[l] = true;
+          chain_wait_reference(jobs[rj], job, wy0[l] + 20, wx0[l] + 20);
+        }
+      }
+    } else {
+      // partitions with vectors of their own: how far down / right any lane reads (six-tap margins included), then
+      // every reference of the record that this launch reconstructs has to have got that far
+      int bottom = 0, right = 0;
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const uint32_t mvw = l ? mvw1 : mvw0;
+        if (byte_of(l ? idx1 : idx0, b8) < 0) continue;
+        bottom = max(bottom, mby * 16 + y + ((int)(int16_t)(mvw >> 16) >> 2) + 3);
+        right = max(right, mbx * 16 + bcol * 4 + 3 + ((int)(int16_t)(mvw & 0xffff) >> 2) + 3);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        bottom = max(bottom, __shfl_xor(bottom, o));
+        right = max(right, __shfl_xor(right, o));
+      }
+      bottom = __builtin_amdgcn_readfirstlane(bottom);
+      right = __builtin_amdgcn_readfirstlane(right);
+#pragma unroll
+      for (int l = 0; l < 2; ++l) {
+        const uint32_t idx = __builtin_amdgcn_readfirstlane(l ? idx1 : idx0), slots = __builtin_amdgcn_readfirstlane(l ? slots1 : slots0);
+        int seen = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (byte_of(idx, k) < 0) continue;
+          const int sl = slot_of(slots, k);
+          if (sl == seen) continue;
+          seen = sl;
+          const int rj = job.slot_job[sl];
+          if (rj >= 0) chain_wait_reference(jobs[rj], job, bottom, right);
+        }
+      }
+    }
+  }
   uint8_t* const out_y = cur.y + (size_t)(mby * 16) * y_pitch + mbx * 16;
   uint8_t* const out_c = (cplane ? cur.v : cur.u) + (size_t)(mby * 8) * c_pitch + mbx * 8;
   const uint32_t out_yoff = (uint32_t)(y * y_pitch + bcol * 4), out_coff = (uint32_t)(cy * c_pitch + cbcol * 2);
@@ -644,7 +794,32 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       if (!use_win[l]) continue;
-      if (win_inside[l]) {
+      if (CHAIN && fresh[l]) {  // (the picture is being written by this launch: nothing of it may come from a cache)
+        if (win_inside[l]) {
+          if (lane < 63) wy[l] = agent_ld64u(wsrc[l][0] + loff);
+          if (lane < 54) wc[l] = agent_ld32((cpl ? wsrc[l][2] : wsrc[l][1]) + coff);
+        } else {
+          if (lane < 63) {
+            const uint8_t* row = wplane[l][0] + (size_t)iclip(0, H - 1, wy0[l] + lr) * y_pitch;
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+              lo |= (uint32_t)agent_ld8(row + iclip(0, W - 1, wx0[l] + 8 * lc + b)) << (8 * b);
+              hi |= (uint32_t)agent_ld8(row + iclip(0, W - 1, wx0[l] + 8 * lc + 4 + b)) << (8 * b);
+            }
+            wy[l].x = lo;
+            wy[l].y = hi;
+          }
+          if (lane < 54) {
+            const int cx0 = mbx * 8 + (wmvx[l] >> 3), cy0 = mby * 8 + (wmvy[l] >> 3);
+            const uint8_t* row = (cpl ? wplane[l][2] : wplane[l][1]) + (size_t)iclip(0, H / 2 - 1, cy0 + cr) * c_pitch;
+            uint32_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v |= (uint32_t)agent_ld8(row + iclip(0, W / 2 - 1, cx0 + 4 * cd + b)) << (8 * b);
+            wc[l] = v;
+          }
+        }
+      } else if (win_inside[l]) {
         if (lane < 63) wy[l] = gld64u(wsrc[l][0] + loff);
         if (lane < 54) wc[l] = ld32u((cpl ? wsrc[l][2] : wsrc[l][1]) + coff);
       } else {  // the same bytes, one at a time, from clamped coordinates
@@ -699,7 +874,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
         const uint32_t* rp = reinterpret_cast<const uint32_t*>(L.res_y + y * 16 + bcol * 4);
         pred = add_res4(pred, rp[0], rp[1]);
       }
-      gst32(out_y + out_yoff, pred);
+      sst32<CHAIN>(out_y + out_yoff, pred);
     }
     {  // chroma: lanes 0..31 Cb, 32..63 Cr
       uint32_t p[2] = {0, 0};
@@ -723,11 +898,10 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
         pred = (uint32_t)v[0] | ((uint32_t)v[1] << 8);
       }
       if (has_res) pred = add_res2(pred, *reinterpret_cast<const uint32_t*>(L.res_c + cplane * 64 + cy * 8 + cbcol * 2));
-      gst16(out_c + out_coff, (uint16_t)pred);
+      sst16<CHAIN>(out_c + out_coff, (uint16_t)pred);
     }
-    return;
-  }
-
+    if constexpr (!CHAIN) return;
+  } else {
   // ---- per-lane register path: partitions with their own vectors, windows that leave the picture
   const int cblk = (cy >> 1) * 4 + cbcol, cb8 = (cy >> 2) * 2 + (cbcol >> 1);
   const uint32_t cmvw0 = gld32(reinterpret_cast<const uint32_t*>(mo->mv[0]) + cblk);
@@ -739,9 +913,9 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     const int px = mbx * 16 + bcol * 4, py = mby * 16 + y;
     int s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
     if (r0 >= 0)
-      luma_pred4(pp.surfaces[slot_of(slots0, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
+      luma_pred4<CHAIN>(pp.surfaces[slot_of(slots0, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw0 & 0xffff), (int16_t)(mvw0 >> 16), s0);
     if (r1 >= 0)
-      luma_pred4(pp.surfaces[slot_of(slots1, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
+      luma_pred4<CHAIN>(pp.surfaces[slot_of(slots1, b8)].y, y_pitch, W, H, px, py, (int16_t)(mvw1 & 0xffff), (int16_t)(mvw1 >> 16), s1);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -749,7 +923,7 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
       const int v = has_res ? clip8(pred + L.res_y[y * 16 + bcol * 4 + i]) : pred;
       packed |= (uint32_t)v << (8 * i);
     }
-    gst32(out_y + out_yoff, packed);
+    sst32<CHAIN>(out_y + out_yoff, packed);
   }
   {  // chroma: lanes 0..31 Cb, 32..63 Cr
     const int r0 = byte_of(idx0, cb8), r1 = byte_of(idx1, cb8);
@@ -757,11 +931,11 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
     int s0[2] = {0, 0}, s1[2] = {0, 0};
     if (r0 >= 0) {
       const Surface& sf = pp.surfaces[slot_of(slots0, cb8)];
-      chroma_pred2(cplane ? sf.v : sf.u, c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
+      chroma_pred2<CHAIN>(cplane ? sf.v : sf.u, c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw0 & 0xffff), (int16_t)(cmvw0 >> 16), s0);
     }
     if (r1 >= 0) {
       const Surface& sf = pp.surfaces[slot_of(slots1, cb8)];
-      chroma_pred2(cplane ? sf.v : sf.u, c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
+      chroma_pred2<CHAIN>(cplane ? sf.v : sf.u, c_pitch, W / 2, H / 2, px, py, (int16_t)(cmvw1 & 0xffff), (int16_t)(cmvw1 >> 16), s1);
     }
     uint32_t packed = 0;
 #pragma unroll
@@ -770,8 +944,33 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
       const int v = has_res ? clip8(pred + L.res_c[cplane * 64 + cy * 8 + cbcol * 2 + i]) : pred;
       packed |= (uint32_t)v << (8 * i);
     }
-    gst16(out_c + out_coff, (uint16_t)packed);
+    sst16<CHAIN>(out_c + out_coff, (uint16_t)packed);
   }
+  }
+  if constexpr (CHAIN) {
+    // the macroblock's samples have landed (they were stored write-through): one more inter macroblock of its row
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+      __hip_atomic_fetch_add((HW_AS1 uint32_t*)&static_cast<BandCtl*>(job.band_ctl)->inter_done[mby], 1u, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(kInterWaves * 64, 7) void k_inter(const JobDesc* __restrict__ jobs) {
+  const JobDesc& job = jobs[blockIdx.y];
+  const int do_inter = job.do_inter;
+  const InterPicture ip = inter_picture(job);
+  if (!do_inter) return;
+  const int nmb = ip.mb_width * ip.mb_height;
+  const int ngroups = (nmb + kInterWaves - 1) / kInterWaves;
+  const int band = (ngroups + 7) / 8;
+  const int group = (blockIdx.x % 8) * band + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= band || group >= ngroups) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int mbi = group * kInterWaves + wave;
+  if (mbi >= nmb) return;
+  __shared__ InterWave lds[kInterWaves];
+  inter_mb<false>(jobs, job, ip, mbi, lane, lds[wave]);
 }
 
 // ===========================================================================
@@ -800,31 +999,6 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_inter(const JobDesc* __res
 //     not as a hung GPU).
 // ===========================================================================
 namespace {
-
-constexpr int kMaxRows = kMaxMbRows;
-// Row pipelines whose pictures are spread over several workgroups ("bands" of
-// kBandWaves rows, one wave per row; k_mv explains why).  BandCtl is the
-// per-picture hand-off area in global memory (JobDesc::band_ctl); every word in
-// it is tagged with JobDesc::epoch, nothing is cleared between pictures.
-constexpr int kBandWaves = 4;
-constexpr int kMaxBands = kMaxRows / kBandWaves;
-struct BandCtl {
-  uint64_t db_prog[kMaxBands];   // k_deblock: epoch << 32 | macroblocks of the band's last row that are final
-  uint64_t in_prog[kMaxBands];   // k_intra (neighbours read from the surface): likewise
-  // tagged words {datum, epoch}; with B = bands of the picture:
-  //   [0, B * kLineMbs * 5)                      k_mv: [band][mbx] MvEdge as five words
-  //   [B * kLineMbs * 5, B * kLineMbs * 13)      k_intra (LDS neighbours): [band][mbx] bottom rows, 32 bytes as eight words
-  uint64_t lines[1];
-};
-constexpr int kMvLineWords = 5, kIntraLineWords = 8;
-__device__ __forceinline__ int bands_of(int mb_height) { return (mb_height + kBandWaves - 1) / kBandWaves; }
-
-// A bounded poll of another band expired.  The polls are bounded so that a
-// protocol error can never hang the GPU; this makes the same error loud on the
-// host (GpuExecutor::complete fails the batch) instead of silent wrong samples.
-__device__ __forceinline__ void report_fault(const JobDesc& job, uint32_t code) {
-  if (job.fault) __hip_atomic_store((HW_AS1 uint32_t*)job.fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 // The counters live in LDS and must be addressed as such: through a generic
 // volatile pointer they become flat_load ... sc0 sc1 followed by s_waitcnt
@@ -938,23 +1112,6 @@ constexpr int kMvChunk = 4;  // macroblocks whose records travel together (prefe
 // protocols).  Nothing is cleared between pictures: a slot left over from an
 // earlier picture carries an earlier epoch.
 constexpr int kMvWaves = kBandWaves;
-// Agent-scope accesses (sc1 on gfx950): they bypass the per-XCD L2, so it does
-// not matter which XCDs the bands of a picture land on.
-__device__ __forceinline__ uint64_t agent_ld64(const uint64_t* p) {
-  return __hip_atomic_load((const HW_AS1 uint64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t agent_ld32(const void* p) {
-  return __hip_atomic_load((const HW_AS1 uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int agent_ld8(const void* p) {
-  return __hip_atomic_load((const HW_AS1 uint8_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void agent_st32(void* p, uint32_t v) {
-  __hip_atomic_store((HW_AS1 uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void agent_st64(uint64_t* p, uint64_t v) {
-  __hip_atomic_store((HW_AS1 uint64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 struct MvWaveLds {
   uint32_t mv[kMvChunk][16];  // the vectors of a partitioned macroblock while they are derived
   uint32_t x[64];             // the chunk's window of the extra-difference stream
@@ -1356,45 +1513,50 @@ __global__ __launch_bounds__(kInterWaves * 64) void k_residual(const JobDesc* __
 //    the progress counter.
 // ===========================================================================
 
-__global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__ jobs, int njobs) {
-  // one workgroup per band of kBandWaves rows, bands handed out by ticket (see k_mv)
-  __shared__ unsigned s_ticket;
-  __shared__ int s_progress[kBandWaves + 1];
-  __shared__ IntraWaveLds s_lds[kBandWaves];
-  __shared__ uint8_t s_line[kBandWaves + 1][kLineMbs][32];  // [kBandWaves]: the line imported from the band above
-  // The Intra4x4 / Intra8x8 tap tables, in LDS: every one of a macroblock's (up to sixteen) dependent prediction
-  // steps looks its samples' taps up by (mode, position) per lane - from constant memory that was a vector-memory
-  // round trip inside each step of the chain.
-  __shared__ uint16_t s_p4tab[9][16];
-  __shared__ uint32_t s_p8tab[9][64];
-  if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_in, 1u);
-  if (threadIdx.x <= kBandWaves) s_progress[threadIdx.x] = 0;
-  for (int t = threadIdx.x; t < 9 * 64; t += kBandWaves * 64) s_p8tab[0][t] = c_p8tab[0][t];
-  if (threadIdx.x < 9 * 16) s_p4tab[0][threadIdx.x] = c_p4tab[0][threadIdx.x];
-  __syncthreads();
-  const int band = static_cast<int>(s_ticket) / njobs;
-  const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
-  if (!job.do_intra) return;
+namespace {
+// LDS of one band's four waves (k_intra: the workgroup; k_chain: its row waves)
+struct IntraGroupLds {
+  int progress[kBandWaves + 1];
+  IntraWaveLds w[kBandWaves];
+  uint8_t line[kBandWaves + 1][kLineMbs][32];  // [kBandWaves]: the line imported from the band above
+};
+// The Intra4x4 / Intra8x8 tap tables, in LDS: every one of a macroblock's (up to sixteen) dependent prediction
+// steps looks its samples' taps up by (mode, position) per lane - from constant memory that was a vector-memory
+// round trip inside each step of the chain.
+struct IntraTables {
+  uint16_t p4[9][16];
+  uint32_t p8[9][64];
+};
+__device__ __forceinline__ void load_intra_tables(IntraTables& T, int tid, int nthreads) {
+  for (int t = tid; t < 9 * 64; t += nthreads) T.p8[0][t] = c_p8tab[0][t];
+  for (int t = tid; t < 9 * 16; t += nthreads) T.p4[0][t] = c_p4tab[0][t];
+}
+}  // namespace
+
+// One band (kBandWaves rows, a wave each) of one picture's intra prediction.  G.progress[1 ..] must be zero on entry.
+// CHAIN: as a unit of k_chain - see there.
+template <bool CHAIN>
+__device__ __forceinline__ void intra_band(const JobDesc& job, const int band, const int wave, const int lane, IntraGroupLds& G,
+                                           const IntraTables& T) {
   const PictureParams& pp = job.pp;
   const MbInfo* __restrict__ mbs = job.mbs;
   const uint32_t* __restrict__ coefs = job.coefs;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // provably uniform: SGPRs, scalar loads
   const int mby = band * kBandWaves + wave;
   if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
-  lds_counter* progress = (lds_counter*)s_progress;
-  IntraWaveLds& L = s_lds[wave];
+  lds_counter* progress = (lds_counter*)G.progress;
+  IntraWaveLds& L = G.w[wave];
   uint8_t* tile = L.tile;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const bool lds_nb = !job.do_inter && pp.mb_width <= kLineMbs;  // wave uniform
-  uint8_t (*line_up)[32] = wave == 0 ? s_line[kBandWaves] : s_line[wave - 1];
-  uint8_t (*line_me)[32] = s_line[wave];
+  uint8_t (*line_up)[32] = wave == 0 ? G.line[kBandWaves] : G.line[wave - 1];
+  uint8_t (*line_me)[32] = G.line[wave];
   BandCtl* ctl = static_cast<BandCtl*>(job.band_ctl);
   const uint32_t epoch = job.epoch;
   const bool importing = wave == 0 && band > 0;
   const bool exporting = wave == kBandWaves - 1 && mby + 1 < pp.mb_height;
   uint64_t* const xline = ctl->lines + static_cast<size_t>(bands_of(pp.mb_height)) * kLineMbs * kMvLineWords;
-  if (wave == 0 && band == 0 && lane == 0) s_progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
+  if (wave == 0 && band == 0 && lane == 0) G.progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
   int seen = 0;  // importing: macroblocks of the row above that are known final (and, with lds_nb, sit in s_line[kBandWaves])
   // lds_nb pictures: fetch the next eight entries of the band above, keep the
   // complete ones in front of the first missing word (k_mv has the same scheme)
@@ -1408,7 +1570,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
       if (act) v = agent_ld64(src + e * kIntraLineWords + d);
       const uint64_t missing = __ballot(act && static_cast<uint32_t>(v >> 32) != epoch);
       const int nvalid = min(missing ? __builtin_ctzll(missing) >> 3 : 8, pp.mb_width - seen);
-      if (act && (lane >> 3) < nvalid) reinterpret_cast<uint32_t*>(s_line[kBandWaves][e])[d] = static_cast<uint32_t>(v);
+      if (act && (lane >> 3) < nvalid) reinterpret_cast<uint32_t*>(G.line[kBandWaves][e])[d] = static_cast<uint32_t>(v);
       seen += nvalid;
       if (seen < need) __builtin_amdgcn_s_sleep(1);
     }
@@ -1433,9 +1595,11 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
     __asm__ volatile("" ::: "memory");
   };
   // a sample of the row above: through the agent-coherent path when another workgroup wrote it
-  auto up8 = [&](const uint8_t* q) -> int { return importing ? agent_ld8(q) : gld8(q); };
+  auto up8 = [&](const uint8_t* q) -> int { return (CHAIN || importing) ? agent_ld8(q) : gld8(q); };
   auto publish = [&](int done) {  // surface path: this wave's stores land first
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // (chain: the samples went out write-through and the row below reads them past its L1 - they have to have landed)
+    if constexpr (CHAIN) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (exporting) {
       // the workgroup-scope fence above does not wait for outstanding stores
       // (inside a workgroup the shared L1 orders them); another workgroup must
@@ -1447,6 +1611,26 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
     }
   };
 
+  if constexpr (CHAIN) {
+    // the row's neighbours among the inter macroblocks - its own row and the row above, top-right included - are
+    // written by this same launch: every inter macroblock of the two rows has to have landed
+    if (job.do_inter) {
+      for (int r = mby > 0 ? mby - 1 : 0; r <= mby; ++r) {
+        uint32_t n = 0;
+        for (int x0 = 0; x0 < pp.mb_width; x0 += 64) {
+          const int probe = x0 + lane;
+          n += __popcll(__ballot(probe < pp.mb_width && !(gld8(&mbs[r * pp.mb_width + probe].flags) & MBF_INTRA)));
+        }
+        const uint32_t* word = &ctl->inter_done[r];
+        bool ok = false;
+        for (int tries = 0; tries < (1 << 21) && !ok; ++tries) {
+          ok = agent_ld32(word) >= n;
+          if (!ok) __builtin_amdgcn_s_sleep(2);
+        }
+        if (!ok) report_fault(job, FAULT_CHAIN_INTER);
+      }
+    }
+  }
   const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(job.resid);
   {
     int prev_mbx = -2;  // macroblock whose samples the tile still holds
@@ -1533,7 +1717,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
             tile[lane] = (lane == 0) ? (hD ? up8(dy - yp - 1) : 128) : (lane <= 16) ? (hB ? up8(dy - yp + lane - 1) : 128)
                                                                                     : (hC ? up8(dy - yp + lane - 1) : 128);
           else if (lane >= 32 && lane < 48)
-            tile[(lane - 31) * TS] = hA ? gld8(dy + (lane - 32) * yp - 1) : 128;
+            tile[(lane - 31) * TS] = hA ? sld8<CHAIN>(dy + (lane - 32) * yp - 1) : 128;
           if (lane < 18) {
             const int p = lane / 9, i = lane % 9;
             const uint8_t* d = p ? dv : du;
@@ -1541,7 +1725,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
           } else if (lane >= 32 && lane < 48) {
             const int p = (lane - 32) >> 3, j = (lane - 32) & 7;
             const uint8_t* d = p ? dv : du;
-            L.ctile[p][(j + 1) * 12] = hA ? gld8(d + j * cp - 1) : 128;
+            L.ctile[p][(j + 1) * 12] = hA ? sld8<CHAIN>(d + j * cp - 1) : 128;
           }
         }
         wave_sync();
@@ -1621,7 +1805,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
                 const int st4 = e[5] + e[6] + e[7] + e[8], sl4 = e[0] + e[1] + e[2] + e[3];
                 v = (ht && hl) ? (st4 + sl4 + 4) >> 3 : hl ? (sl4 + 2) >> 2 : ht ? (st4 + 2) >> 2 : 128;
               } else {
-                v = tap_sample(e, s_p4tab[mode > 8 ? 8 : mode][py * 4 + px], 4, 15);
+                v = tap_sample(e, T.p4[mode > 8 ? 8 : mode][py * 4 + px], 4, 15);
               }
               const int out = clip8(v + L.res_y[(by * 4 + py) * 16 + bx * 4 + px]);
               tile[(1 + by * 4 + py) * TS + 1 + bx * 4 + px] = (uint8_t)out;
@@ -1682,7 +1866,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
                 }
                 v = (ht && hl) ? (st8 + sl8 + 8) >> 4 : hl ? (sl8 + 4) >> 3 : ht ? (st8 + 4) >> 3 : 128;
               } else {
-                v = tap_sample(e, s_p8tab[mode > 8 ? 8 : mode][py * 8 + px], 5, 31);
+                v = tap_sample(e, T.p8[mode > 8 ? 8 : mode][py * 8 + px], 5, 31);
               }
               tile[(1 + by + py) * TS + 1 + bx + px] = (uint8_t)clip8(v + L.res_y[(by + py) * 16 + bx + px]);
             }
@@ -1738,13 +1922,13 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
           const uint32_t v = tp[0] | (tp[1] << 8) | (tp[2] << 16) | ((uint32_t)tp[3] << 24);
           // (surface path: the band below reads the bottom rows from another workgroup)
           const bool coherent = exporting && !lds_nb;
-          if (coherent && r == 15) agent_st32(dy + (size_t)r * yp + c4, v);
+          if (CHAIN || (coherent && r == 15)) agent_st32(dy + (size_t)r * yp + c4, v);
           else gst32(dy + (size_t)r * yp + c4, v);
           if (lane < 32) {
             const int p = lane >> 4, rr = (lane >> 1) & 7, cc = (lane & 1) * 4;
             const uint8_t* cpx = L.ctile[p] + (1 + rr) * 12 + 1 + cc;
             const uint32_t w = cpx[0] | (cpx[1] << 8) | (cpx[2] << 16) | ((uint32_t)cpx[3] << 24);
-            if (coherent && rr == 7) agent_st32((p ? dv : du) + (size_t)rr * cp + cc, w);
+            if (CHAIN || (coherent && rr == 7)) agent_st32((p ? dv : du) + (size_t)rr * cp + cc, w);
             else gst32((p ? dv : du) + (size_t)rr * cp + cc, w);
           }
         }
@@ -1776,7 +1960,30 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
     } else {
       publish(pp.mb_width);
     }
+    if constexpr (CHAIN) {
+      // the deblocking of this launch starts on a row once the row BELOW it is through here (intra prediction reads
+      // unfiltered neighbours): the row's samples have landed, say so
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) agent_st64(&ctl->intra_fin[mby], (static_cast<uint64_t>(epoch) << 32) | 1u);
+    }
   }
+}
+
+
+__global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__ jobs, int njobs) {
+  // one workgroup per band of kBandWaves rows, bands handed out by ticket (see k_mv)
+  __shared__ unsigned s_ticket;
+  __shared__ IntraGroupLds s_group;
+  __shared__ IntraTables s_tables;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_in, 1u);
+  if (threadIdx.x <= kBandWaves) s_group.progress[threadIdx.x] = 0;
+  load_intra_tables(s_tables, threadIdx.x, kBandWaves * 64);
+  __syncthreads();
+  const int band = static_cast<int>(s_ticket) / njobs;
+  const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
+  if (!job.do_intra) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;  // provably uniform: SGPRs, scalar loads
+  intra_band<false>(job, band, wave, lane, s_group, s_tables);
 }
 
 // ===========================================================================
@@ -2016,29 +2223,23 @@ __global__ __launch_bounds__(256) void k_bs(const JobDesc* __restrict__ jobs) {
 // macroblock's own samples and its DbInfo are prefetched one iteration ahead
 // and its stores are drained one iteration late.
 // ===========================================================================
-__global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict__ jobs, int njobs) {
-  // One workgroup per band of kBandWaves rows, bands handed out by ticket (see
-  // k_mv).  Rows hand over through the picture itself: inside a band the waves
-  // share the CU's L1 and an LDS counter; across bands the last row of a band
-  // writes its bottom rows with agent-scope stores and publishes its counter in
-  // BandCtl::db_prog once they have landed, and the first row of the next band
-  // polls that counter and reads the rows above with agent-scope loads.
-  __shared__ unsigned s_ticket;
-  __shared__ int s_progress[kBandWaves + 1];
-  __shared__ DeblockWaveLds s_lds[kBandWaves];
-  if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_db, 1u);
-  if (threadIdx.x <= kBandWaves) s_progress[threadIdx.x] = 0;
-  __syncthreads();
-  const int band = static_cast<int>(s_ticket) / njobs;
-  const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
-  if (!job.do_deblock) return;
+namespace {
+struct DeblockGroupLds {
+  int progress[kBandWaves + 1];
+  DeblockWaveLds w[kBandWaves];
+};
+}  // namespace
+
+// One band (kBandWaves rows, a wave each) of one picture's deblocking.  G.progress[1 ..] must be zero on entry.
+// CHAIN: as a unit of k_chain - see there.
+template <bool CHAIN>
+__device__ __forceinline__ void deblock_band(const JobDesc& job, const int band, const int wave, const int lane, DeblockGroupLds& G) {
   const PictureParams& pp = job.pp;
   const DbInfo* __restrict__ dbs = static_cast<const DbInfo*>(job.db);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int mby = band * kBandWaves + wave;
   if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
-  lds_counter* progress = (lds_counter*)s_progress;
-  DeblockWaveLds& L = s_lds[wave];
+  lds_counter* progress = (lds_counter*)G.progress;
+  DeblockWaveLds& L = G.w[wave];
   uint8_t* lt = L.lt;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
@@ -2047,7 +2248,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
   const uint64_t epoch = static_cast<uint64_t>(job.epoch) << 32;
   const bool importing = wave == 0 && band > 0;
   const bool exporting = wave == kBandWaves - 1 && mby + 1 < pp.mb_height;
-  if (wave == 0 && band == 0 && lane == 0) s_progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
+  if (wave == 0 && band == 0 && lane == 0) G.progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
   int seen = 0;  // importing: macroblocks of the row above known to be final
   // test hook: a band whose progress words carry a wrong tag looks exactly like a band that never reports
   const uint64_t epoch_out = job.inject_fault ? epoch ^ (1ull << 63) : epoch;
@@ -2064,6 +2265,35 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
     __asm__ volatile("" ::: "memory");
   };
 
+  if constexpr (CHAIN) {
+    // The row's samples come from this same launch.  With intra macroblocks in the picture: intra prediction reads
+    // UNFILTERED neighbours, so the row below has to be through with it before this row is touched (which also says
+    // that this row's and the next row's inter macroblocks have landed: intra_band waited for them).  Without: every
+    // macroblock of the row is an inter macroblock.
+    bool ok = false;
+    if (job.do_intra) {
+      const uint64_t* word = &ctl->intra_fin[imin(mby + 1, pp.mb_height - 1)];
+      for (int tries = 0; tries < (1 << 21) && !ok; ++tries) {
+        ok = agent_ld64(word) == (epoch | 1u);
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok) report_fault(job, FAULT_CHAIN_INTRA);
+    } else if (job.do_inter) {
+      const uint32_t* word = &ctl->inter_done[mby];
+      for (int tries = 0; tries < (1 << 21) && !ok; ++tries) {
+        ok = agent_ld32(word) >= static_cast<uint32_t>(W);
+        if (!ok) __builtin_amdgcn_s_sleep(2);
+      }
+      if (!ok) report_fault(job, FAULT_CHAIN_INTER);
+    }
+  }
+  // (chain: what the rows of this launch read of each other's progress per ROW, and what the pictures predicted from
+  // this one follow)
+  auto publish_fin = [&](int v) {
+    if constexpr (CHAIN) {
+      if (lane == 0) agent_st64(&ctl->fin[mby], epoch | static_cast<uint32_t>(v));
+    }
+  };
   {
     uint8_t* rowy = cur.y + (size_t)(mby * 16) * yp;
     uint8_t* rowu = cur.u + (size_t)(mby * 8) * cp;
@@ -2084,6 +2314,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
       auto publish_db = [&](int v) {
         if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch_out | static_cast<uint32_t>(v)); }
         else progress[wave + 1] = v;
+        publish_fin(v);
       };
       {
         const int first = todo ? mbx0 + __builtin_ctzll(todo) : (mbx0 + 64 < W ? mbx0 + 64 : W + 1);
@@ -2103,8 +2334,20 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
       int gcur = -1, gnext = -1;
       auto prefetch_group = [&](int g) {
         const int mb = min(4 * g + (lane & 3), W - 1);
-        n_gluma = *(const HW_AS1 u32x4*)(rowy + mb * 16 + (lane >> 2) * yp);
-        n_gchroma = *(const HW_AS1 u32x2*)(((lane >> 5) ? rowv : rowu) + mb * 8 + ((lane >> 2) & 7) * cp);
+        if constexpr (CHAIN) {  // (written by this launch: past the caches)
+          const uint64_t* ly = reinterpret_cast<const uint64_t*>(rowy + mb * 16 + (lane >> 2) * yp);
+          const uint64_t l0 = agent_ld64(ly), l1 = agent_ld64(ly + 1);
+          const uint64_t c0 = agent_ld64(reinterpret_cast<const uint64_t*>(((lane >> 5) ? rowv : rowu) + mb * 8 + ((lane >> 2) & 7) * cp));
+          n_gluma.x = (uint32_t)l0;
+          n_gluma.y = (uint32_t)(l0 >> 32);
+          n_gluma.z = (uint32_t)l1;
+          n_gluma.w = (uint32_t)(l1 >> 32);
+          n_gchroma.x = (uint32_t)c0;
+          n_gchroma.y = (uint32_t)(c0 >> 32);
+        } else {
+          n_gluma = *(const HW_AS1 u32x4*)(rowy + mb * 16 + (lane >> 2) * yp);
+          n_gchroma = *(const HW_AS1 u32x2*)(((lane >> 5) ? rowv : rowu) + mb * 8 + ((lane >> 2) & 7) * cp);
+        }
         gnext = g;
       };
       // first group beyond macroblock `mbx` (of this 64-macroblock stretch) that has anything to filter, or -1
@@ -2121,8 +2364,8 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
         // the four columns to the left when the left neighbour was skipped (otherwise they slide over inside the
         // tile): lanes 0..15 luma rows, 16..31 chroma rows of both planes
         if (mbx > 0 && !left_in_tile) {
-          if (lane < 16) n_left = gld32(gy + lane * yp - 4);
-          else if (lane < 32) n_left = gld32((((lane - 16) >> 3) ? rowv : rowu) + mbx * 8 + ((lane - 16) & 7) * cp - 4);
+          if (lane < 16) n_left = sld32<CHAIN>(gy + lane * yp - 4);
+          else if (lane < 32) n_left = sld32<CHAIN>((((lane - 16) >> 3) ? rowv : rowu) + mbx * 8 + ((lane - 16) & 7) * cp - 4);
         }
       };
       if (todo) {
@@ -2217,7 +2460,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
             if (lane < 24) top_word = agent_ld32(src);
           } else {
             row_wait(progress, wave, min(mbx + 1, W));
-            if (lane < 24) top_word = gld32(src);
+            if (lane < 24) top_word = sld32<CHAIN>(src);
           }
         }
         // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each.
@@ -2263,7 +2506,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
             const int r = 4 + lane;
             const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.lt[r * LS]);
             if (v != *reinterpret_cast<const uint32_t*>(&L.lt0[r * LS])) {
-              if (exporting && r >= 16) agent_st32(gy + (r - 4) * yp - 4, v);
+              if (CHAIN || (exporting && r >= 16)) agent_st32(gy + (r - 4) * yp - 4, v);
               else gst32(gy + (r - 4) * yp - 4, v);
             }
           } else {
@@ -2271,7 +2514,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
             uint8_t* g = p ? gv : gu;
             const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS]);
             if (v != *reinterpret_cast<const uint32_t*>(&L.ct0[p][r * CS])) {
-              if (exporting && r >= 8) agent_st32(g + (r - 2) * cp - 4, v);
+              if (CHAIN || (exporting && r >= 8)) agent_st32(g + (r - 2) * cp - 4, v);
               else gst32(g + (r - 2) * cp - 4, v);
             }
           }
@@ -2324,6 +2567,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch_out | static_cast<uint32_t>(mbx)); }
         else progress[wave + 1] = mbx;
+        publish_fin(mbx);
         // The prefetched registers are complete too; saying so here keeps the
         // compiler from waiting for them at the top of the next iteration, where
         // its in-order counter would also cover the stores issued just below.
@@ -2337,7 +2581,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
           if (c4 >= 1 && (r >= 4 || top_edge)) {
             const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]);
             if (v != *reinterpret_cast<const uint32_t*>(&L.lt0[r * LS + c4 * 4])) {
-              if (exporting && r >= 16) agent_st32(gy + (r - 4) * yp + (c4 - 1) * 4, v);  // the band below reads these rows
+              if (CHAIN || (exporting && r >= 16)) agent_st32(gy + (r - 4) * yp + (c4 - 1) * 4, v);  // the band below reads these rows
               else gst32(gy + (r - 4) * yp + (c4 - 1) * 4, v);
             }
           }
@@ -2348,7 +2592,7 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
           if (c4 >= 1 && (r >= 2 || top_edge)) {
             const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]);
             if (v != *reinterpret_cast<const uint32_t*>(&L.ct0[p][r * CS + c4 * 4])) {
-              if (exporting && r >= 8) agent_st32(g + (r - 2) * cp + (c4 - 1) * 4, v);
+              if (CHAIN || (exporting && r >= 8)) agent_st32(g + (r - 2) * cp + (c4 - 1) * 4, v);
               else gst32(g + (r - 2) * cp + (c4 - 1) * 4, v);
             }
           }
@@ -2372,9 +2616,31 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) agent_st64(&ctl->db_prog[band], epoch_out | static_cast<uint32_t>(W));
     } else {
+      if constexpr (CHAIN) __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
       progress[wave + 1] = W;
     }
+    publish_fin(W);
   }
+}
+
+
+__global__ __launch_bounds__(kBandWaves * 64) void k_deblock(JobDesc* __restrict__ jobs, int njobs) {
+  // One workgroup per band of kBandWaves rows, bands handed out by ticket (see
+  // k_mv).  Rows hand over through the picture itself: inside a band the waves
+  // share the CU's L1 and an LDS counter; across bands the last row of a band
+  // writes its bottom rows with agent-scope stores and publishes its counter in
+  // BandCtl::db_prog once they have landed, and the first row of the next band
+  // polls that counter and reads the rows above with agent-scope loads.
+  __shared__ unsigned s_ticket;
+  __shared__ DeblockGroupLds s_group;
+  if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_db, 1u);
+  if (threadIdx.x <= kBandWaves) s_group.progress[threadIdx.x] = 0;
+  __syncthreads();
+  const int band = static_cast<int>(s_ticket) / njobs;
+  const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
+  if (!job.do_deblock) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  deblock_band<false>(job, band, wave, lane, s_group);
 }
 
 // ===========================================================================
@@ -2401,6 +2667,11 @@ __global__ __launch_bounds__(256) void k_upload(const JobDesc* __restrict__ jobs
   HW_AS1 v4u* __restrict__ dst = (HW_AS1 v4u*)u.dst;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)kUploadBlocks * 256)
     dst[i] = __builtin_nontemporal_load(&src[i]);
+  if (blockIdx.x == 1 && a == 0 && job.band_ctl) {
+    // (chain launches: the rows' inter-macroblock counters start from zero with every picture)
+    uint32_t* done = static_cast<BandCtl*>(job.band_ctl)->inter_done;
+    for (int r = threadIdx.x; r < job.pp.mb_height; r += 256) gst32(done + r, 0u);
+  }
   if (blockIdx.x == 0) {
     const uint64_t tail = u.bytes & 15;
     if (threadIdx.x < tail)
@@ -2437,6 +2708,122 @@ hipError_t launch_table_copy(void* dst, const void* src, size_t bytes, hipStream
 
 hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream) {
   hipLaunchKernelGGL(k_upload, dim3(kUploadBlocks, njobs * kJobUploads), dim3(256), 0, stream, jobs);
+  return hipGetLastError();
+}
+
+// ===========================================================================
+// k_chain: the sample stages of a batch - k_inter, k_intra, k_deblock - as ONE launch in which dependent pictures
+// overlap.  The three kernels above are separated by kernel boundaries, so a lane's pictures (each predicted from the
+// one before) cost the full latency of three wavefronts EACH: ~0.9 ms per 1080p P picture, and the reference's own
+// caller (one DecoderAutomata, one interval at a time: python/hwang/decoder.py:60-67) sits through a GOP's worth of
+// them per returned frame.  Here a picture's stages and the pictures of a chain follow each other row by row:
+//   inter macroblock of picture n + 1   waits for picture n's deblocking to have left final what its vectors reach
+//                                       (BandCtl::fin, per macroblock row; chain_wait_reference)
+//   intra row of picture n              waits for the inter macroblocks of its row and the row above (inter_done)
+//   deblocking row r of picture n       waits for intra row r + 1 (unfiltered neighbours!) or, in a picture without
+//                                       intra macroblocks, for the row's inter macroblocks
+// so picture n + 1 trails picture n by a few macroblock rows instead of by a picture.
+//
+// No kernel boundary orders anything here, so (1) every sample these stages hand to each other is stored and loaded
+// agent-scope (CHAIN = true instantiations: write-through stores, loads past L1 / L2, every counter raised behind
+// s_waitcnt vmcnt(0)); references that were final before the launch are read the cached way.  (2) Nothing may wait for
+// work that is not running.  HIP promises no dispatch order, so work is handed out by ticket from two lists the host
+// builds in dependency order (position by position of the lanes' chains; within a picture: inter runs top to bottom,
+// then intra bands, then deblocking bands).  A workgroup is four ROW waves (one band at a time, as k_intra / k_deblock)
+// plus four INTER waves (each takes runs of kChainRun macroblocks on its own).  The smallest unfinished row unit and
+// the smallest unfinished inter unit are always held by resident waves; a row unit depends on row units before it and
+// on inter units of its own picture, an inter unit on row units of EARLIER pictures: of the two smallest, one can
+// always run - whatever the residency, with no assumption about other launches on the device.  Polls are bounded
+// anyway and report to the batch's fault word.
+// ===========================================================================
+namespace {
+constexpr int kChainInterWaves = 4;
+struct ChainLds {
+  union {
+    IntraGroupLds intra;
+    DeblockGroupLds deblock;
+  } rows;
+  IntraTables tables;
+  InterWave inter[kChainInterWaves];
+  // hand-over of a row unit to the band's four waves: wave 0 takes the ticket
+  int generation;   // units handed out so far
+  int arrived;      // row waves that are through with their part of the current unit
+  uint32_t unit;
+};
+}  // namespace
+
+__global__ __launch_bounds__((kBandWaves + kChainInterWaves) * 64) void k_chain(const ChainArgs args) {
+  __shared__ ChainLds S;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  load_intra_tables(S.tables, threadIdx.x, (kBandWaves + kChainInterWaves) * 64);
+  if (threadIdx.x == 0) {
+    S.generation = 0;
+    S.arrived = kBandWaves;  // "everybody is through with unit 0 - 1"
+  }
+  __syncthreads();  // (the only workgroup barrier: the two halves go their own ways from here)
+  const JobDesc* __restrict__ jobs = args.jobs;
+
+  if (wave >= kBandWaves) {
+    // ---- inter waves
+    InterWave& L = S.inter[wave - kBandWaves];
+    for (;;) {
+      uint32_t t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add((HW_AS1 uint32_t*)(args.tickets + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t >= args.num_inter_units) break;
+      const uint32_t u = __builtin_amdgcn_readfirstlane(gld32(args.inter_units + t));
+      const JobDesc& job = jobs[u >> 20];
+      const InterPicture ip = inter_picture(job);
+      const int nmb = ip.mb_width * ip.mb_height;
+      const int first = static_cast<int>(u & 0xfffffu) * kChainRun;
+      for (int k = 0; k < kChainRun && first + k < nmb; ++k) {
+        inter_mb<true>(jobs, job, ip, first + k, lane, L);
+        wave_sync();  // (the next macroblock reuses the wave's LDS)
+      }
+    }
+    return;
+  }
+
+  // ---- row waves
+  lds_counter* generation = (lds_counter*)&S.generation;
+  lds_counter* arrived = (lds_counter*)&S.arrived;
+  for (int gen = 0;; ++gen) {
+    if (wave == 0) {
+      // everybody is through with the previous unit: take the next one, reset the band's counters, announce it
+      while (*arrived < kBandWaves * (gen + 1)) __builtin_amdgcn_s_sleep(1);
+      __asm__ volatile("" ::: "memory");
+      uint32_t t = 0;
+      if (lane == 0) t = __hip_atomic_fetch_add((HW_AS1 uint32_t*)args.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t = __builtin_amdgcn_readfirstlane(t);
+      const uint32_t u = t < args.num_row_units ? __builtin_amdgcn_readfirstlane(gld32(args.row_units + t)) : 0xffffffffu;
+      if (lane == 0) {
+        S.unit = u;
+        for (int i = 0; i <= kBandWaves; ++i) S.rows.intra.progress[i] = 0;  // (the same words in both members)
+      }
+      __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) *generation = gen + 1;
+    } else {
+      while (*generation < gen + 1) __builtin_amdgcn_s_sleep(1);
+      __asm__ volatile("" ::: "memory");
+    }
+    const uint32_t u = __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) uint32_t*)&S.unit);
+    if (u == 0xffffffffu) break;
+    const JobDesc& job = jobs[u >> 8];
+    const int band = static_cast<int>(u & 0x7f);
+    if (u & 0x80) deblock_band<true>(job, band, wave, lane, S.rows.deblock);
+    else intra_band<true>(job, band, wave, lane, S.rows.intra, S.tables);
+    // through with this unit's LDS
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)&S.arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+
+hipError_t launch_chain(const ChainArgs& args, int workgroups, hipStream_t stream) {
+  const bool profiled = prof::enabled();
+  prof::Span span;
+  if (profiled) span = prof::begin(stream);
+  hipLaunchKernelGGL(k_chain, dim3(workgroups), dim3((kBandWaves + kChainInterWaves) * 64), 0, stream, args);
+  if (profiled) prof::end(span, stream, prof::K_CHAIN, args.bytes);
   return hipGetLastError();
 }
 

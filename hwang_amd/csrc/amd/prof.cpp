@@ -25,7 +25,7 @@ struct Total {
 Total g_totals[K_COUNT];
 
 const char* kNames[K_COUNT] = {"residual_idct", "inter_pred", "intra_pred",
-                               "deblock", "yuv420_to_rgb24", "mv_derivation", "boundary_strength"};
+                               "deblock", "yuv420_to_rgb24", "mv_derivation", "boundary_strength", "chain"};
 
 hipEvent_t take_event() {
   if (!g_free_events.empty()) {

@@ -16,7 +16,8 @@ enum KernelId {
   K_RGB = 4,        // I420 -> RGB24
   K_MV = 5,         // motion-vector derivation of P macroblocks
   K_BS = 6,         // boundary strengths + filter parameters (k_bs), when it runs as a stage of its own
-  K_COUNT = 7,
+  K_CHAIN = 7,      // k_chain: inter + intra + deblocking of a batch's pictures as one launch of overlapping stages
+  K_COUNT = 8,
 };
 
 bool enabled();
