@@ -229,12 +229,13 @@ enum : uint32_t {
 struct ChainArgs {
   const JobDesc* jobs;
   const uint32_t* row_units;    // job << 8 | stage << 7 | band     (stage 0 intra, 1 deblock)
-  const uint32_t* inter_units;  // job << 20 | run                  (macroblocks run * kChainRun ...)
+  const uint32_t* inter_units;  // job << 20 | run                  (run = row * ceil(mb_width / kChainRun) + j: macroblocks 8 j .. of the row)
   uint32_t* tickets;            // [0] rows, [1] inter; zeroed with the table
   uint32_t num_row_units, num_inter_units;
   uint64_t bytes;               // algorithmic, for the span
 };
-constexpr int kChainRun = 8;    // macroblocks per inter unit
+constexpr int kChainRun = 8;    // macroblocks per inter unit (64 runs cover the widest row: BandCtl::inter_mask)
+static_assert(kMaxMbRows <= 64 * kChainRun, "BandCtl::inter_mask is one 64-bit word per row");
 
 // One colour-conversion / plane-copy request.
 struct ConvertDesc {

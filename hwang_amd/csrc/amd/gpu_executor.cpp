@@ -306,6 +306,9 @@ const char* GpuExecutor::fault_name(uint32_t code) {
     case FAULT_INTRA_LINE: return "k_intra: the neighbour line of the band above never arrived";
     case FAULT_INTRA_PROGRESS: return "k_intra: the band above never reported progress";
     case FAULT_DEBLOCK_PROGRESS: return "k_deblock: the band above never reported progress";
+    case FAULT_CHAIN_REFERENCE: return "k_chain: a reference picture of the same launch never got as far as a macroblock reads";
+    case FAULT_CHAIN_INTER: return "k_chain: inter macroblocks that a row waits for never landed";
+    case FAULT_CHAIN_INTRA: return "k_chain: the intra stage of a row never got as far as the deblocking needs";
     default: return "unknown fault code";
   }
 }
@@ -484,8 +487,8 @@ void GpuExecutor::run(int engine) {
   // words a picture adds to a chain launch's unit table
   auto chain_units = [](const PicSubmit& p) {
     const size_t bands = static_cast<size_t>((p.desc.pp.mb_height + 3) / 4);
-    return (p.desc.do_inter ? static_cast<size_t>((p.num_mbs + kChainRun - 1) / kChainRun) : 0) + (p.desc.do_intra ? bands : 0) +
-           (p.desc.do_deblock ? bands : 0);
+    const size_t runs = static_cast<size_t>(p.desc.pp.mb_height) * ((p.desc.pp.mb_width + kChainRun - 1) / kChainRun);
+    return (p.desc.do_inter ? runs : 0) + (p.desc.do_intra ? bands : 0) + (p.desc.do_deblock ? bands : 0);
   };
   uint64_t n_chain_batches = 0, n_chain_pics = 0, max_chain = 0;
   const bool debug = getenv("HWANG_EXEC_DEBUG") != nullptr;
@@ -642,7 +645,7 @@ void GpuExecutor::run(int engine) {
         for (int pos = 0; pos <= max_pos; ++pos)
           for (size_t i = 0; i < pics.size(); ++i) {
             if (pic_pos[i] != pos || !pics[i].desc.do_inter) continue;
-            const int runs = (pics[i].num_mbs + kChainRun - 1) / kChainRun;
+            const int runs = pics[i].desc.pp.mb_height * ((pics[i].desc.pp.mb_width + kChainRun - 1) / kChainRun);  // per row
             for (int r = 0; r < runs; ++r) inter[ninter++] = static_cast<uint32_t>(i) << 20 | static_cast<uint32_t>(r);
           }
         ChainArgs args;

@@ -540,8 +540,10 @@ struct BandCtl {
   // Chain launches (k_chain): progress of the picture's stages per macroblock ROW, for the other stages of the same
   // picture and for the pictures that predict from it inside the same launch.
   uint64_t fin[kMaxRows];        // deblocking: epoch << 32 | macroblocks of row r that row r's own filtering has left final
-  uint64_t intra_fin[kMaxRows];  // intra prediction: epoch << 32 | 1 once row r is through
-  uint32_t inter_done[kMaxRows]; // motion compensation: inter macroblocks of row r stored (zeroed by k_upload)
+  uint64_t intra_prog[kMaxRows]; // intra prediction: epoch << 32 | macroblocks of row r in front of which every intra
+                                 // macroblock has landed (inter macroblocks are not its business)
+  uint64_t inter_mask[kMaxRows]; // motion compensation: bit j = macroblocks 8 j .. 8 j + 7 of row r (a run, kChainRun:
+                                 // one inter unit) have landed; zeroed by k_upload
   // tagged words {datum, epoch}; with B = bands of the picture:
   //   [0, B * kLineMbs * 5)                      k_mv: [band][mbx] MvEdge as five words
   //   [B * kLineMbs * 5, B * kLineMbs * 13)      k_intra (LDS neighbours): [band][mbx] bottom rows, 32 bytes as eight words
@@ -553,8 +555,24 @@ __device__ __forceinline__ int bands_of(int mb_height) { return (mb_height + kBa
 // A bounded poll of another band expired.  The polls are bounded so that a
 // protocol error can never hang the GPU; this makes the same error loud on the
 // host (GpuExecutor::complete fails the batch) instead of silent wrong samples.
+// (A fault is sticky on the host - the executor fails every request from then on - so it may be sticky here as well:
+// once one poll of a chain launch has expired, the others give up at their next look instead of each sitting out its
+// own bound; a launch with a broken hand-off then ends in a fraction of a second, not in minutes.)
+__device__ uint32_t g_fault_seen = 0;
 __device__ __forceinline__ void report_fault(const JobDesc& job, uint32_t code) {
   if (job.fault) __hip_atomic_store((HW_AS1 uint32_t*)job.fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store((HW_AS1 uint32_t*)&g_fault_seen, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Development aid: what every wave of a chain launch is doing (hwang_debug_chain_state reads it while the launch is
+// still running): code << 24 | a << 12 | b per workgroup and wave.
+__device__ uint32_t g_chain_dbg[256 * 8];
+__device__ __forceinline__ void chain_dbg(uint32_t code, int a, int b) {
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 256)
+    __hip_atomic_store((HW_AS1 uint32_t*)&g_chain_dbg[blockIdx.x * 8 + (threadIdx.x >> 6)], code << 24 | (static_cast<uint32_t>(a) & 0xfff) << 12 | (static_cast<uint32_t>(b) & 0xfff),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool fault_seen() {
+  return __hip_atomic_load((const HW_AS1 uint32_t*)&g_fault_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
 
 constexpr int kInterWaves = 4;
@@ -620,29 +638,67 @@ HW_FN u32x2 agent_ld64u(const uint8_t* p) {
 }
 
 // Chain launches: a macroblock that predicts from a picture of the same launch waits until that picture's
-// deblocking has left final everything the prediction reads: luma rows up to `bottom`, columns up to `right`
-// (samples; chroma lies inside the same macroblocks).  Row R of the reference is final once the deblocking of row
-// R + 1 has passed the columns in question (its top edges still change row R's last lines); BandCtl::fin[r] counts
-// the macroblocks of row r that row r's own filtering - stores landed - is through with, and a row never runs ahead
-// of the row above, so one word says it all.  The poll is bounded like every other one.
-HW_FN void chain_wait_reference(const JobDesc& ref, const JobDesc& job, int bottom, int right) {
+// deblocking has left final everything the prediction reads: luma rows `top` .. `bottom`, columns up to `right`
+// (samples; chroma lies inside the same macroblocks).  BandCtl::fin[r] counts the macroblocks of row r that row r's
+// own filtering - stores landed - is through with.  A macroblock of row r is final once rows r AND r + 1 are through
+// with its column (the top edges of row r + 1 still change row r's last lines), and a row only stays behind the row
+// above where it has top edges to filter - so every row the window touches, and the one below, is asked.  The polls
+// are bounded like every other one.
+HW_FN void chain_wait_reference(const JobDesc& ref, const JobDesc& job, int top, int bottom, int right) {
   const int mbh = ref.pp.mb_height, mbw = ref.pp.mb_width;
-  const int row = imin(iclip(0, mbh - 1, bottom >> 4) + 1, mbh - 1);
+  const int first = iclip(0, mbh - 1, top >> 4), last = imin(iclip(0, mbh - 1, bottom >> 4) + 1, mbh - 1);
   const uint32_t need = (uint32_t)imin(iclip(0, mbw - 1, right >> 4) + 1, mbw);
-  const uint64_t* word = &static_cast<const BandCtl*>(ref.band_ctl)->fin[row];
+  const uint64_t* words = static_cast<const BandCtl*>(ref.band_ctl)->fin;
   const uint32_t epoch = ref.epoch;
-  for (int tries = 0; tries < (1 << 21); ++tries) {
-    const uint64_t v = agent_ld64(word);
-    if (static_cast<uint32_t>(v >> 32) == epoch && static_cast<uint32_t>(v) >= need) return;
-    __builtin_amdgcn_s_sleep(2);
+  for (int row = last; row >= first; --row) {  // (bottom-up: the lowest row is normally the last to get there)
+    bool ok = false;
+    chain_dbg(3, row, need);
+    for (int tries = 0; tries < (1 << 17) && !ok; ++tries) {
+      const uint64_t v = agent_ld64(words + row);
+      ok = static_cast<uint32_t>(v >> 32) == epoch && static_cast<uint32_t>(v) >= need;
+      if (!ok) {
+        if ((tries & 255) == 255 && fault_seen()) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+    }
+    if (!ok) {
+      report_fault(job, FAULT_CHAIN_REFERENCE);
+      return;
+    }
   }
-  report_fault(job, FAULT_CHAIN_REFERENCE);
+}
+// A stage's bounded poll of another stage's per-row word; what was seen last is kept, so a stage that trails the
+// other closely asks once per stretch the other has advanced, not once per macroblock.
+constexpr int kChainTries = 1 << 17;  // ~0.1 - 0.2 s of polling: far beyond any wait that can succeed
+HW_FN bool chain_need_inter(const BandCtl* ctl, int row, int upto_mb, uint64_t& seen) {
+  const uint64_t want = (2ull << (upto_mb >> 3)) - 1;  // every run up to the one that holds macroblock upto_mb (run 63: all ones)
+  if ((seen & want) == want) return true;
+  chain_dbg(1, row, upto_mb);
+  for (int tries = 0; tries < kChainTries; ++tries) {
+    seen = agent_ld64(&ctl->inter_mask[row]);
+    if ((seen & want) == want) return true;
+    if ((tries & 255) == 255 && fault_seen()) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
+}
+HW_FN bool chain_need_intra(const BandCtl* ctl, uint32_t epoch, int row, uint32_t count, uint32_t& seen) {
+  if (seen >= count) return true;
+  chain_dbg(2, row, count);
+  for (int tries = 0; tries < kChainTries; ++tries) {
+    const uint64_t v = agent_ld64(&ctl->intra_prog[row]);
+    if (static_cast<uint32_t>(v >> 32) == epoch) seen = static_cast<uint32_t>(v);
+    if (seen >= count) return true;
+    if ((tries & 255) == 255 && fault_seen()) return false;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return false;
 }
 }  // namespace
 
-// One inter macroblock by one wave.  CHAIN: as a unit of k_chain - references of the same launch are waited for and
-// read with agent-scope loads, the macroblock's samples are stored agent-scope, and its row's counter is raised when
-// they have landed.
+// One inter macroblock by one wave.  CHAIN: as part of a unit of k_chain - references of the same launch are waited for
+// and read with agent-scope loads, the macroblock's samples are stored agent-scope (k_chain raises the run's bit when
+// the run's last store has landed).
 struct InterPicture {  // what a wave needs from the descriptor, requested in one go
   int mb_width, mb_height, y_pitch, c_pitch;
   const MbInfo* mbs;
@@ -743,25 +799,29 @@ __device__ __forceinline__ void inter_mb(const JobDesc* __restrict__ jobs, const
         const int rj = job.slot_job[__builtin_amdgcn_readfirstlane(slot_of(l ? slots1 : slots0, 0))];
         if (rj >= 0) {
           fresh[l] = true;
-          chain_wait_reference(jobs[rj], job, wy0[l] + 20, wx0[l] + 20);
+          chain_wait_reference(jobs[rj], job, wy0[l], wy0[l] + 20, wx0[l] + 20);
         }
       }
     } else {
       // partitions with vectors of their own: how far down / right any lane reads (six-tap margins included), then
       // every reference of the record that this launch reconstructs has to have got that far
-      int bottom = 0, right = 0;
+      int top = 1 << 20, bottom = 0, right = 0;
 #pragma unroll
       for (int l = 0; l < 2; ++l) {
         const uint32_t mvw = l ? mvw1 : mvw0;
         if (byte_of(l ? idx1 : idx0, b8) < 0) continue;
-        bottom = max(bottom, mby * 16 + y + ((int)(int16_t)(mvw >> 16) >> 2) + 3);
+        const int yy = mby * 16 + y + ((int)(int16_t)(mvw >> 16) >> 2);
+        top = min(top, yy - 2);
+        bottom = max(bottom, yy + 3);
         right = max(right, mbx * 16 + bcol * 4 + 3 + ((int)(int16_t)(mvw & 0xffff) >> 2) + 3);
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
+        top = min(top, __shfl_xor(top, o));
         bottom = max(bottom, __shfl_xor(bottom, o));
         right = max(right, __shfl_xor(right, o));
       }
+      top = __builtin_amdgcn_readfirstlane(top);
       bottom = __builtin_amdgcn_readfirstlane(bottom);
       right = __builtin_amdgcn_readfirstlane(right);
 #pragma unroll
@@ -775,7 +835,7 @@ __device__ __forceinline__ void inter_mb(const JobDesc* __restrict__ jobs, const
           if (sl == seen) continue;
           seen = sl;
           const int rj = job.slot_job[sl];
-          if (rj >= 0) chain_wait_reference(jobs[rj], job, bottom, right);
+          if (rj >= 0) chain_wait_reference(jobs[rj], job, top, bottom, right);
         }
       }
     }
@@ -946,13 +1006,6 @@ __device__ __forceinline__ void inter_mb(const JobDesc* __restrict__ jobs, const
     }
     sst16<CHAIN>(out_c + out_coff, (uint16_t)packed);
   }
-  }
-  if constexpr (CHAIN) {
-    // the macroblock's samples have landed (they were stored write-through): one more inter macroblock of its row
-    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
-      __hip_atomic_fetch_add((HW_AS1 uint32_t*)&static_cast<BandCtl*>(job.band_ctl)->inter_done[mby], 1u, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1609,28 +1662,13 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
     } else {
       progress[wave + 1] = done;
     }
+    // (chain: the deblocking of this launch follows this row's and the next row's intra stage macroblock by macroblock)
+    if constexpr (CHAIN) {
+      if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(done));
+    }
   };
 
-  if constexpr (CHAIN) {
-    // the row's neighbours among the inter macroblocks - its own row and the row above, top-right included - are
-    // written by this same launch: every inter macroblock of the two rows has to have landed
-    if (job.do_inter) {
-      for (int r = mby > 0 ? mby - 1 : 0; r <= mby; ++r) {
-        uint32_t n = 0;
-        for (int x0 = 0; x0 < pp.mb_width; x0 += 64) {
-          const int probe = x0 + lane;
-          n += __popcll(__ballot(probe < pp.mb_width && !(gld8(&mbs[r * pp.mb_width + probe].flags) & MBF_INTRA)));
-        }
-        const uint32_t* word = &ctl->inter_done[r];
-        bool ok = false;
-        for (int tries = 0; tries < (1 << 21) && !ok; ++tries) {
-          ok = agent_ld32(word) >= n;
-          if (!ok) __builtin_amdgcn_s_sleep(2);
-        }
-        if (!ok) report_fault(job, FAULT_CHAIN_INTER);
-      }
-    }
-  }
+  uint64_t seen_inter_up = 0, seen_inter_me = 0;  // chain: the inter runs of the row above / this row known to have landed
   const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(job.resid);
   {
     int prev_mbx = -2;  // macroblock whose samples the tile still holds
@@ -1679,6 +1717,16 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
         const bool pcm = mb.kind == MBK_IPCM;
         const bool hA = mb.flags & MBF_AVAIL_A, hB = mb.flags & MBF_AVAIL_B;
         const bool hC = mb.flags & MBF_AVAIL_C, hD = mb.flags & MBF_AVAIL_D;
+        if constexpr (CHAIN) {
+          // the neighbours among the INTER macroblocks come from this same launch: the runs of the row above up to the
+          // top-right neighbour's, and of this row up to the left neighbour's, have to have landed
+          if (job.do_inter) {
+            bool ok = true;
+            if ((hB || hC || hD) && mby > 0) ok = chain_need_inter(ctl, mby - 1, min(mbx + 1, pp.mb_width - 1), seen_inter_up);
+            if (ok && hA && mbx > 0) ok = chain_need_inter(ctl, mby, mbx - 1, seen_inter_me);
+            if (!ok) report_fault(job, FAULT_CHAIN_INTER);
+          }
+        }
         // the row above must be complete up to the top-right neighbour
         if (hB || hC || hD) {
           const int need = min(mbx + 2, pp.mb_width);
@@ -1915,6 +1963,14 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
         }
         wave_sync();
 
+        if constexpr (CHAIN) {
+          if (lds_nb) {
+            // (the LDS hand-over to the row below needs no stores to have landed; the deblocking of this launch does:
+            // what is in flight here is the PREVIOUS macroblock's samples - say that everything before this one is there)
+            __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(mbx));
+          }
+        }
         // ---- tiles -> surface: one dword per lane (luma), 32 lanes x dword (chroma)
         {
           const int r = lane >> 2, c4 = (lane & 3) * 4;
@@ -1961,10 +2017,9 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
       publish(pp.mb_width);
     }
     if constexpr (CHAIN) {
-      // the deblocking of this launch starts on a row once the row BELOW it is through here (intra prediction reads
-      // unfiltered neighbours): the row's samples have landed, say so
+      // the row is through: its samples have landed
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) agent_st64(&ctl->intra_fin[mby], (static_cast<uint64_t>(epoch) << 32) | 1u);
+      if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(pp.mb_width));
     }
   }
 }
@@ -2265,28 +2320,30 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
     __asm__ volatile("" ::: "memory");
   };
 
-  if constexpr (CHAIN) {
-    // The row's samples come from this same launch.  With intra macroblocks in the picture: intra prediction reads
-    // UNFILTERED neighbours, so the row below has to be through with it before this row is touched (which also says
-    // that this row's and the next row's inter macroblocks have landed: intra_band waited for them).  Without: every
-    // macroblock of the row is an inter macroblock.
-    bool ok = false;
-    if (job.do_intra) {
-      const uint64_t* word = &ctl->intra_fin[imin(mby + 1, pp.mb_height - 1)];
-      for (int tries = 0; tries < (1 << 21) && !ok; ++tries) {
-        ok = agent_ld64(word) == (epoch | 1u);
-        if (!ok) __builtin_amdgcn_s_sleep(2);
-      }
-      if (!ok) report_fault(job, FAULT_CHAIN_INTRA);
-    } else if (job.do_inter) {
-      const uint32_t* word = &ctl->inter_done[mby];
-      for (int tries = 0; tries < (1 << 21) && !ok; ++tries) {
-        ok = agent_ld32(word) >= static_cast<uint32_t>(W);
-        if (!ok) __builtin_amdgcn_s_sleep(2);
-      }
+  // Chain: the row's samples come from this same launch, so before anything of macroblocks <= m of the row is read:
+  //  * the inter runs of the row up to m's have landed;
+  //  * the row's intra stage is past m (its intra macroblocks in front of m + 1 have landed) - and so is the intra stage
+  //    of the row BELOW, by one macroblock more: intra prediction reads UNFILTERED neighbours, top-right included, so
+  //    this row may not be touched where the row below still has to predict from it.
+  uint64_t seen_inter = 0;
+  uint32_t seen_intra_me = 0, seen_intra_below = 0;
+  const bool chain_inter = CHAIN && job.do_inter, chain_intra = CHAIN && job.do_intra;
+  auto chain_need = [&](int m) {
+    if constexpr (CHAIN) {
+      if (m < 0) return;
+      m = min(m, W - 1);
+      bool ok = true;
+      if (chain_inter) ok = chain_need_inter(ctl, mby, m, seen_inter);
       if (!ok) report_fault(job, FAULT_CHAIN_INTER);
+      if (chain_intra) {
+        // (m + 2 in both rows: the intra macroblock to the right of m predicts from m's column too - top-left in the
+        // row below, and in THIS row from the row above, whose last lines this row's top edges change)
+        ok = chain_need_intra(ctl, job.epoch, mby, static_cast<uint32_t>(min(m + 2, W)), seen_intra_me);
+        if (ok && mby + 1 < pp.mb_height) ok = chain_need_intra(ctl, job.epoch, mby + 1, static_cast<uint32_t>(min(m + 2, W)), seen_intra_below);
+        if (!ok) report_fault(job, FAULT_CHAIN_INTRA);
+      }
     }
-  }
+  };
   // (chain: what the rows of this launch read of each other's progress per ROW, and what the pictures predicted from
   // this one follow)
   auto publish_fin = [&](int v) {
@@ -2312,6 +2369,9 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
       // neighbours' edges are - all but its last columns, which the next filtered macroblock's left edge may still
       // touch.  So before a gap the counter is raised at once to (next macroblock with edges) - 1.
       auto publish_db = [&](int v) {
+        // (chain: "macroblocks < v are final" is also what the row below and the pictures predicted from this one go
+        // by for macroblocks this row never touches - a stretch without edges is final once its SAMPLES have landed)
+        if (v > 0) chain_need(v - 1);
         if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch_out | static_cast<uint32_t>(v)); }
         else progress[wave + 1] = v;
         publish_fin(v);
@@ -2333,6 +2393,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
       u32x2 g_chroma = 0, n_gchroma = 0;
       int gcur = -1, gnext = -1;
       auto prefetch_group = [&](int g) {
+        chain_need(4 * g + 3);
         const int mb = min(4 * g + (lane & 3), W - 1);
         if constexpr (CHAIN) {  // (written by this launch: past the caches)
           const uint64_t* ly = reinterpret_cast<const uint64_t*>(rowy + mb * 16 + (lane >> 2) * yp);
@@ -2359,6 +2420,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
       // per macroblock: its deblocking record and, in case the left neighbour was skipped, that one's last columns
       uint32_t n_db = 0, n_left = 0;
       auto prefetch = [&](int mbx, bool left_in_tile) {
+        chain_need(mbx);
         const uint8_t* gy = rowy + mbx * 16;
         if (lane < 24) n_db = gld32(reinterpret_cast<const uint32_t*>(rowdb + mbx) + lane);
         // the four columns to the left when the left neighbour was skipped (otherwise they slide over inside the
@@ -2609,6 +2671,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
         }
       }
     }
+    chain_need(W - 1);  // (a row that ends in a stretch without edges: see publish_db)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (exporting) {
       // (the workgroup-scope fence does not wait for outstanding stores; the band below must not see the
@@ -2668,9 +2731,12 @@ __global__ __launch_bounds__(256) void k_upload(const JobDesc* __restrict__ jobs
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)kUploadBlocks * 256)
     dst[i] = __builtin_nontemporal_load(&src[i]);
   if (blockIdx.x == 1 && a == 0 && job.band_ctl) {
-    // (chain launches: the rows' inter-macroblock counters start from zero with every picture)
-    uint32_t* done = static_cast<BandCtl*>(job.band_ctl)->inter_done;
-    for (int r = threadIdx.x; r < job.pp.mb_height; r += 256) gst32(done + r, 0u);
+    // (chain launches: the rows' inter-run masks start from zero with every picture)
+    uint64_t* mask = static_cast<BandCtl*>(job.band_ctl)->inter_mask;
+    for (int r = threadIdx.x; r < job.pp.mb_height; r += 256) {
+      gst32(reinterpret_cast<uint32_t*>(mask + r), 0u);
+      gst32(reinterpret_cast<uint32_t*>(mask + r) + 1, 0u);
+    }
   }
   if (blockIdx.x == 0) {
     const uint64_t tail = u.bytes & 15;
@@ -2719,10 +2785,12 @@ hipError_t launch_upload(const JobDesc* jobs, int njobs, hipStream_t stream) {
 // them per returned frame.  Here a picture's stages and the pictures of a chain follow each other row by row:
 //   inter macroblock of picture n + 1   waits for picture n's deblocking to have left final what its vectors reach
 //                                       (BandCtl::fin, per macroblock row; chain_wait_reference)
-//   intra row of picture n              waits for the inter macroblocks of its row and the row above (inter_done)
-//   deblocking row r of picture n       waits for intra row r + 1 (unfiltered neighbours!) or, in a picture without
-//                                       intra macroblocks, for the row's inter macroblocks
-// so picture n + 1 trails picture n by a few macroblock rows instead of by a picture.
+//   intra macroblock of picture n       waits for the inter runs that hold its neighbours (BandCtl::inter_mask: a bit
+//                                       per run of kChainRun macroblocks of a row)
+//   deblocking of picture n, row r      reads macroblocks <= m once the row's inter runs up to m's have landed and the
+//                                       intra stage of rows r and r + 1 is past m (BandCtl::intra_prog; the row below
+//                                       because intra prediction reads UNFILTERED neighbours)
+// so picture n + 1 trails picture n by a few macroblocks and rows instead of by a picture.
 //
 // No kernel boundary orders anything here, so (1) every sample these stages hand to each other is stored and loaded
 // agent-scope (CHAIN = true instantiations: write-through stores, loads past L1 / L2, every counter raised behind
@@ -2770,16 +2838,27 @@ __global__ __launch_bounds__((kBandWaves + kChainInterWaves) * 64) void k_chain(
       uint32_t t = 0;
       if (lane == 0) t = __hip_atomic_fetch_add((HW_AS1 uint32_t*)(args.tickets + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       t = __builtin_amdgcn_readfirstlane(t);
-      if (t >= args.num_inter_units) break;
+      if (t >= args.num_inter_units) {
+        chain_dbg(8, 0, 0);
+        break;
+      }
       const uint32_t u = __builtin_amdgcn_readfirstlane(gld32(args.inter_units + t));
       const JobDesc& job = jobs[u >> 20];
       const InterPicture ip = inter_picture(job);
-      const int nmb = ip.mb_width * ip.mb_height;
-      const int first = static_cast<int>(u & 0xfffffu) * kChainRun;
-      for (int k = 0; k < kChainRun && first + k < nmb; ++k) {
-        inter_mb<true>(jobs, job, ip, first + k, lane, L);
+      chain_dbg(4, u >> 20, u & 0xfff);
+      // runs are per row: run = row * runs_per_row + j, macroblocks 8 j .. 8 j + 7 of the row
+      const int runs_per_row = (ip.mb_width + kChainRun - 1) / kChainRun;
+      const int run = static_cast<int>(u & 0xfffffu), row = run / runs_per_row, j = run - row * runs_per_row;
+      const int x0 = j * kChainRun, x1 = min(x0 + kChainRun, ip.mb_width);
+      for (int x = x0; x < x1; ++x) {
+        inter_mb<true>(jobs, job, ip, row * ip.mb_width + x, lane, L);
         wave_sync();  // (the next macroblock reuses the wave's LDS)
       }
+      // the run's samples have landed (they were stored write-through): say so
+      __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0)
+        __hip_atomic_fetch_or((HW_AS1 uint64_t*)&static_cast<BandCtl*>(job.band_ctl)->inter_mask[row], 1ull << j, __ATOMIC_RELAXED,
+                              __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
@@ -2808,16 +2887,26 @@ __global__ __launch_bounds__((kBandWaves + kChainInterWaves) * 64) void k_chain(
     }
     const uint32_t u = __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) uint32_t*)&S.unit);
     if (u == 0xffffffffu) break;
+    chain_dbg(5 + ((u >> 7) & 1), u >> 8, u & 0x7f);
     const JobDesc& job = jobs[u >> 8];
     const int band = static_cast<int>(u & 0x7f);
     if (u & 0x80) deblock_band<true>(job, band, wave, lane, S.rows.deblock);
     else intra_band<true>(job, band, wave, lane, S.rows.intra, S.tables);
     // through with this unit's LDS
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    chain_dbg(7, u >> 8, u & 0xff);
     if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)&S.arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
+  chain_dbg(9, 0, 0);
 }
 
+}  // namespace amd
+}  // namespace hwang
+extern "C" int hwang_debug_chain_state(uint32_t* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(hwang::amd::g_chain_dbg), sizeof(uint32_t) * (n < 2048 ? n : 2048), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+namespace hwang {
+namespace amd {
 hipError_t launch_chain(const ChainArgs& args, int workgroups, hipStream_t stream) {
   const bool profiled = prof::enabled();
   prof::Span span;
