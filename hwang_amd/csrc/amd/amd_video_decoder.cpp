@@ -24,6 +24,7 @@
 #include "../util/cpus.h"
 #include "../util/numa.h"
 #include "../util/queue.h"
+#include "../util/trace.h"
 #include "frame_job.h"
 #include "gpu_executor.h"
 #include "hip_check.h"
@@ -124,6 +125,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
 
   // ------------------------------------------------------ VideoDecoderInterface
   Result configure(const FrameInfo& metadata, const std::vector<uint8_t>& extradata) override {
+    trace::event("configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
     if (metadata.format != "h264" && metadata.format != "avc1") {
       return Result(false, "AMDVideoDecoder: unsupported format '" + metadata.format +
@@ -160,6 +162,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // another executor lane and run beside the previous GOP's (an interval is often several byte-adjacent GOPs: on
     // one lane that is a chain of 40-60 dependent pictures at ~2 ms each).
     if (keyframe || rotate_always_) cur_lane_ = (cur_lane_ + 1) % static_cast<int>(lanes_.size());
+    if (keyframe) trace::event("feed sync sample", static_cast<long>(encoded_size));
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t stall0 = counters_.stall_ns;
     const bool ok = parser_->decode(encoded_buffer, encoded_size);
@@ -200,6 +203,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   int decoded_frames_buffered() override { return buffered_.load(std::memory_order_acquire); }
 
   Result wait_until_frames_copied() override {
+    trace::event("wait_until_frames_copied");
+    struct Done {
+      ~Done() { trace::event("frames copied"); }
+    } done;
     HWANG_HIP_RETURN(hipSetDevice(device_));
     // entropy workers: frames may have been fetched before their pictures were decoded; those pictures first
     std::string worker_error;
@@ -495,6 +502,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         for (int li = 0; li < static_cast<int>(lanes_.size()); ++li)
           if (foreign[li]) (void)wait_stamp(Stamp{li, foreign[li]}, &ignored);  // (a failed lane fails every later wait too)
     }
+    trace::event(sub.heavy ? "end_picture (intra-only)" : "end_picture", d.slot, static_cast<long>(d.coef_count));
     j.stamp = Stamp{lane_index, exec_->submit_picture(lane, sub)};
     note_seq(j.stamp);
 
@@ -726,7 +734,9 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     lk.unlock();
     std::string error;
     const bool ok = wait_stamp(st, &error);
+    trace::event("copy-out starts", static_cast<long>(size));
     if (ok) std::memcpy(dst, b.host, size);
+    trace::event("copy-out done");
     lk.lock();
     if (!ok && copy_error_.empty()) copy_error_ = error;
     b.dst = nullptr;
@@ -1039,6 +1049,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
                     "(set_wanted) and was not decoded");
     outq_.try_pop(slot);
     buffered_.fetch_sub(1, std::memory_order_acq_rel);
+    trace::event("get_frame", slot);
     const SurfaceSlot& s = surf_[slot];
     amd::ConvSubmit sub;
     std::memset(&sub.desc, 0, sizeof(sub.desc));

@@ -2,6 +2,7 @@
 
 #include "sparse_hints.h"
 #include "util/avc_sample.h"
+#include "util/trace.h"
 
 #include <chrono>
 
@@ -89,6 +90,7 @@ Result DecoderAutomata::initialize(std::vector<EncodedData>&& encoded_data,
                     "sample_sizes differ in length");
     }
   }
+  trace::event("initialize", static_cast<long>(encoded_data.size()));
   std::unique_lock<std::mutex> lk(m_);
   // get_frames() leaves the feeder parked; wait out a backend call that may
   // still be in flight.
@@ -130,6 +132,7 @@ Result DecoderAutomata::initialize(std::vector<EncodedData>&& encoded_data,
 }
 
 Result DecoderAutomata::get_frames(uint8_t* buffer, int32_t num_frames) {
+  trace::event("get_frames", num_frames);
   std::unique_lock<std::mutex> lk(m_);
   if (segments_.empty()) {
     return Result(false, "DecoderAutomata::get_frames before initialize");
@@ -219,6 +222,7 @@ Result DecoderAutomata::get_frames(uint8_t* buffer, int32_t num_frames) {
   Result done = finish(Result());
   lk.unlock();
   HWANG_RETURN_ON_ERROR(decoder_->wait_until_frames_copied());
+  trace::event("get_frames returns");
   return done;
 }
 
