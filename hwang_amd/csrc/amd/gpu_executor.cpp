@@ -126,6 +126,7 @@ bool GpuExecutor::start(std::string* error) {
   if (const char* e = getenv("HWANG_LIGHT_INFLIGHT")) light_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
   if (const char* e = getenv("HWANG_LIGHT_ENGINES")) light_engines_ = std::max(1, std::min(1 + kExtraLightEngines, atoi(e)));
   if (const char* e = getenv("HWANG_PRESTAGE")) prestage_ = atoi(e) != 0;
+  if (const char* e = getenv("HWANG_CHAIN_MAX_LANES")) chain_max_lanes_ = std::max(1, atoi(e));
   const char* mode = getenv("HWANG_COMPLETION");
   use_hostfunc_ = mode && std::string(mode) == "hostfunc";
   if (hipHostMalloc(reinterpret_cast<void**>(&done_flags_), sizeof(uint32_t) * kEngines * kInflight, hipHostMallocDefault) != hipSuccess)
@@ -233,9 +234,18 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     Item it;
     it.is_picture = true;
     it.pic = job;
-    // (a chain lane's intra-only pictures stay with its other pictures: the P picture behind a keyframe follows it
-    // row by row inside one launch instead of waiting for another engine's batch to complete)
-    it.engine = (job.heavy && !lanes_[lane].chain) ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
+    // A chain lane's intra-only pictures stay with its other pictures (the P picture behind a keyframe then follows it
+    // row by row inside one launch instead of waiting for another engine's batch to complete) - as long as the
+    // executor is not busy with many lanes: then batches are wide, chains are off (run()), and a keyframe inside a
+    // batch of P pictures would hold every lane of that batch for its own duration, which is what the heavy engines
+    // are there to avoid.
+    bool with_its_chain = false;
+    if (job.heavy && lanes_[lane].chain) {
+      int busy = 0;
+      for (const Lane& l : lanes_) busy += l.active && (!l.fifo.empty() || l.launched != l.completed);
+      with_its_chain = busy <= chain_max_lanes_;
+    }
+    it.engine = (job.heavy && !with_its_chain) ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
     it.pre = prestage_ ? 0 : 2;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
@@ -385,6 +395,7 @@ void GpuExecutor::run_pre() {
   Engine& en = engines_[kPreEngine];
   const bool debug = getenv("HWANG_EXEC_DEBUG") != nullptr;
   uint64_t n_batches = 0, n_pics = 0;
+  bool last_was_keyframes_only = false;
   std::vector<Item*> items;
   for (;;) {
     items.clear();
@@ -405,9 +416,13 @@ void GpuExecutor::run_pre() {
       // Intra-only pictures first, in a batch of their own: their records-only stage is an upload and k_residual
       // (tens of microseconds), and every picture of their GOP waits for them - behind a P picture's k_mv (0.7 ms)
       // a keyframe reached its sample stage 0.7 ms late, once per interval of the reference's caller.
+      // (never twice in a row: with many GOPs in flight there is always another keyframe, and the P pictures must
+      // not wait for ever)
       bool keyframes_waiting = false;
-      for (const Lane& l : lanes_)
-        for (const Item& it : l.fifo) keyframes_waiting |= it.is_picture && it.pre == 0 && it.pic.heavy;
+      if (!last_was_keyframes_only)
+        for (const Lane& l : lanes_)
+          for (const Item& it : l.fifo) keyframes_waiting |= it.is_picture && it.pre == 0 && it.pic.heavy;
+      last_was_keyframes_only = keyframes_waiting;
       for (Lane& l : lanes_)
         for (Item& it : l.fifo)
           if (it.is_picture && it.pre == 0 && items.size() < static_cast<size_t>(kMaxJobs) && (!keyframes_waiting || it.pic.heavy)) {
@@ -523,6 +538,17 @@ void GpuExecutor::run(int engine) {
       for (int i = 0; i < kInflight; ++i)
         if (!en.batches[i].in_flight) slot = i;
       Batch& batch = en.batches[slot];
+      // Chains are for a decoder that has ONE thing going - an interval of the reference's caller: a keyframe and the
+      // pictures behind it, nothing else on the device, latency is all there is.  With several lanes busy the GPU is
+      // fed by width instead (one picture per lane and batch through the wide kernels, whose throughput per picture is
+      // several times k_chain's: 8 160 inter waves at a time against 900 - and a chain launch's persistent workgroups
+      // hold the light CUs for milliseconds, in the way of the other engines' launches), and a decoder whose caller
+      // hands it many intervals at once (hwang.Decoder's grouped caller, 16 lanes over four engines) is host-bound
+      // either way - measured: 680 frames/s through the wide kernels, 500 with chain launches wherever an engine had
+      // two lanes or fewer ready.  So: the whole executor's busy lanes, not this engine's.
+      int busy_lanes = 0;
+      for (const Lane& l : lanes_) busy_lanes += l.active && (!l.fifo.empty() || l.launched != l.completed);
+      const bool chains_allowed = is_light(engine) && busy_lanes <= chain_max_lanes_;  // (a chain lane's keyframe may have been routed to a heavy engine)
       // per lane: one picture and the conversions queued behind it, or the
       // leading conversions when the head of the queue is a conversion
       for (size_t li = 0; li < lanes_.size(); ++li) {
@@ -540,7 +566,7 @@ void GpuExecutor::run(int engine) {
           Item& it = l.fifo.front();
           if (it.is_picture) {
             if (pics.size() >= kMaxJobs) break;
-            if (!l.chain) {
+            if (!l.chain || !chains_allowed) {
               if (taken > 0) break;  // one picture per lane and batch, then the conversions behind it
             } else {
               // A chain: the lane's next pictures as long as nothing but pictures has been taken, each predicted from

@@ -235,6 +235,7 @@ class GpuExecutor {
   int total_inflight_ = 0;
   bool use_hostfunc_ = false;
   bool prestage_ = true;
+  int chain_max_lanes_ = 2;  // chain launches only while at most this many lanes of the executor have work (HWANG_CHAIN_MAX_LANES)
   Stats stats_;
 };
 
