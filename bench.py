@@ -460,7 +460,10 @@ def main():
     value_other = None
     reference_api = None
     reference_api_unmodified = None
+    replay = None
     if rank == 0:
+        if len(devices) == 1:
+            lib.hwang_replay_keep(devices[0], 4 * lanes + 64)   # the executor remembers this step's last pictures (replay, below)
         lib.hwang_prof_reset()
         lib.hwang_prof_enable(1)
         step()
@@ -495,6 +498,39 @@ def main():
                         "launches": int(best[3]), "avg_launch_us": round(best[1] / best[3], 1),
                         "end_to_end_frac": round(e2e_bytes / (prof_stats["wall_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9), 5),
                         "end_to_end_bytes_per_step": round(e2e_bytes)}
+        # The GPU with the host out of the way (N = 1): the last pictures of that step - their records and surfaces are
+        # still in HBM, the lanes idle - launched again through the same kernels at widths the host's entropy decoders
+        # never produce (`roofline` above is what the host-bound run shows; this is what the kernels can do).
+        if len(devices) == 1 and world == 1:
+            replay = {"what": "the sample-stage kernels (k_inter, k_intra, k_deblock) and the records-only ones relaunched for the "
+                              "last pictures of a step straight from HBM, back to back, `width` pictures per launch", "runs": []}
+            for w in (48, 1 << 20):
+                o = (C.c_double * 4)()
+                err = C.create_string_buffer(256)
+                if lib.hwang_replay_run(devices[0], w, 3, 0, o, err, 256):
+                    replay["runs"].append({"error": err.value.decode()})
+                    break
+                lib.hwang_prof_reset()
+                lib.hwang_prof_enable(1)
+                rc = lib.hwang_replay_run(devices[0], w, 30, 0, o, err, 256)
+                lib.hwang_prof_enable(0)
+                if rc:
+                    replay["runs"].append({"error": err.value.decode()})
+                    break
+                sp = {}
+                for k in range(lib.hwang_prof_num_kernels()):
+                    q = (C.c_double * 3)()
+                    lib.hwang_prof_read(k, q)
+                    if q[0]:
+                        sp[lib.hwang_prof_kernel_name(k).decode()] = {"avg_us": round(q[1] / q[0], 1), "alg_GBps": round(q[2] / (q[1] * 1e-6) / 1e9, 1),
+                                                                      "hbm_frac": round(q[2] / (q[1] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
+                stage_us = sum(sp[n]["avg_us"] for n in ("inter_pred", "intra_pred", "deblock") if n in sp)
+                replay["runs"].append({"width": int(o[1]), "pictures_available": int(o[0]), "launches": int(o[2]),
+                                       "pictures_per_s_all_kernels_one_stream": round(o[1] * o[2] / o[3], 1),
+                                       "pictures_per_s_sample_stage": round(o[1] / (stage_us * 1e-6), 1) if stage_us else None,
+                                       "kernels": sp})
+            lib.hwang_replay_keep(devices[0], 0)
+            lib.hwang_prof_reset()
         # The other output placement (N = 1): frames left in HBM when `value` is the host-memory rate, and vice versa.
         if args.gpus == 1 and not args.no_hbm_output and args.config == "C1":
             other = (torch.empty((len(row_sets[0]), HEIGHT, WIDTH, 3), dtype=torch.uint8) if args.hbm_output else
@@ -610,6 +646,7 @@ def main():
             "per_gpu": per_gpu,
             "roofline": roofline,
             "kernels": kernels,
+            "replay": replay,
             "cpu_baseline": cpu,
         }))
     del br

@@ -136,6 +136,8 @@ PROTOTYPES = {
     "hwang_prof_read": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
     "hwang_prof_reset": (None, []),
     "hwang_shutdown": (None, []),
+    "hwang_replay_keep": (C.c_int, [C.c_int, C.c_int]),
+    "hwang_replay_run": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_char_p, C.c_size_t]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

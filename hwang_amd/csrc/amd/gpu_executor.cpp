@@ -250,6 +250,10 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
     target = prestage_ ? kPreEngine : it.engine;
+    if (keep_recent_ > 0) {
+      recent_.push_back(job);
+      while (static_cast<int>(recent_.size()) > keep_recent_) recent_.pop_front();
+    }
   }
   cv_work_[target].notify_one();
   return seq;
@@ -299,6 +303,132 @@ bool GpuExecutor::wait(int lane, uint64_t seq, std::string* error) {
     if (error) *error = "GpuExecutor: shut down";
     return false;
   }
+  return true;
+}
+
+void GpuExecutor::keep_recent(int pictures) {
+  std::lock_guard<std::mutex> lk(mu_);
+  keep_recent_ = pictures > 0 ? pictures : 0;
+  while (static_cast<int>(recent_.size()) > keep_recent_) recent_.pop_front();
+}
+
+bool GpuExecutor::replay(int width, int launches, bool chain, ReplayResult* out, std::string* error) {
+  // The pictures whose records and surfaces are still what they were: per staging set (desc.mbs) the LAST picture
+  // that used it; inter pictures only (a keyframe's cost is the heavy engine's, measured by the bench's spans).
+  std::vector<PicSubmit> pics;
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (const Lane& l : lanes_)
+      if (!l.fifo.empty() || l.launched != l.completed) {
+        *error = "GpuExecutor::replay: the executor is busy";
+        return false;
+      }
+    for (auto it = recent_.rbegin(); it != recent_.rend(); ++it) {
+      if (!it->desc.do_inter) continue;
+      bool dup = false;
+      for (const PicSubmit& p : pics) dup |= p.desc.mbs == it->desc.mbs || p.desc.pp.surfaces[p.desc.pp.cur_slot].y == it->desc.pp.surfaces[it->desc.pp.cur_slot].y;
+      if (!dup) pics.push_back(*it);
+    }
+  }
+  out->pictures_available = static_cast<int>(pics.size());
+  if (pics.empty()) {
+    *error = "GpuExecutor::replay: no pictures kept (keep_recent before the decode)";
+    return false;
+  }
+  width = std::max(1, std::min<int>({width, static_cast<int>(pics.size()), kMaxJobs}));
+  if (hipSetDevice(device_) != hipSuccess) {
+    *error = "GpuExecutor::replay: cannot select the device";
+    return false;
+  }
+  Engine& en = engines_[0];
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    *error = "GpuExecutor::replay: no events";
+    return false;
+  }
+  static uint32_t replay_epoch = 0x40000000u;
+  hipError_t e = hipEventRecord(e0, en.stream);
+  for (int it = 0; it < launches && e == hipSuccess; ++it) {
+    int max_mbs = 0, max_rows = 0;
+    bool any_inter = false, any_intra = false, any_deblock = false, any_mv = false;
+    uint64_t bytes[4] = {0, 0, 0, 0}, pre_bytes[3] = {0, 0, 0};
+    for (int i = 0; i < width; ++i) {
+      const PicSubmit& p = pics[(static_cast<size_t>(it) * width + i) % pics.size()];
+      JobDesc& jd = en.job_table_host[0][i];
+      jd = p.desc;
+      jd.num_uploads = 0;  // the records are where the decode left them
+      jd.ticket_mv = jd.ticket_db = jd.ticket_in = 0;
+      jd.fault = nullptr;
+      jd.epoch = ++replay_epoch ? replay_epoch : ++replay_epoch;
+      for (int k = 0; k < 256; ++k) jd.slot_job[k] = -1;
+      max_mbs = std::max(max_mbs, p.num_mbs);
+      max_rows = std::max(max_rows, p.desc.pp.mb_height);
+      any_inter |= p.desc.do_inter != 0;
+      any_intra |= p.desc.do_intra != 0;
+      any_deblock |= p.desc.do_deblock != 0;
+      any_mv |= p.desc.do_mv != 0;
+      bytes[0] += p.bytes_inter;
+      bytes[1] += p.bytes_intra;
+      bytes[2] += p.bytes_deblock;
+      pre_bytes[0] += p.bytes_mv;
+      pre_bytes[1] += p.desc.do_deblock ? static_cast<uint64_t>(p.num_mbs) * (176 + 96) : 0;
+      pre_bytes[2] += p.desc.do_intra ? static_cast<uint64_t>(p.num_intra_mbs) * 768 : 0;
+    }
+    // (the same picture twice in a launch would share its hand-off words: width <= pictures available sees to it)
+    e = launch_table_copy(en.job_table_dev[0], en.job_table_host[0], sizeof(JobDesc) * width, en.stream);
+    // the host table is rewritten for the next launch: the copy has to have happened (costs a round trip per launch,
+    // outside the kernels' spans; the wall time below includes it and says so)
+    if (e == hipSuccess) e = hipStreamSynchronize(en.stream);
+    if (e == hipSuccess) e = launch_pre(en.job_table_dev[0], width, max_mbs, max_rows, any_mv, any_deblock, any_intra, pre_bytes, en.stream);
+    if (e != hipSuccess) break;
+    if (chain) {
+      uint32_t* table = en.unit_table_host[0];
+      table[0] = table[1] = table[2] = table[3] = 0;
+      uint32_t* rows = table + 4;
+      uint32_t nrows = 0, ninter = 0;
+      for (int stage = 0; stage < 2; ++stage)
+        for (int i = 0; i < width; ++i) {
+          const JobDesc& jd = en.job_table_host[0][i];
+          if (!(stage ? jd.do_deblock : jd.do_intra)) continue;
+          for (int b = 0; b < (jd.pp.mb_height + 3) / 4; ++b) rows[nrows++] = static_cast<uint32_t>(i) << 8 | static_cast<uint32_t>(stage) << 7 | static_cast<uint32_t>(b);
+        }
+      uint32_t* inter = rows + nrows;
+      for (int i = 0; i < width; ++i) {
+        const JobDesc& jd = en.job_table_host[0][i];
+        const int runs = jd.pp.mb_height * ((jd.pp.mb_width + kChainRun - 1) / kChainRun);
+        for (int r = 0; r < runs && 4 + nrows + ninter < kUnitWords; ++r) inter[ninter++] = static_cast<uint32_t>(i) << 20 | static_cast<uint32_t>(r);
+      }
+      ChainArgs args;
+      args.jobs = en.job_table_dev[0];
+      args.tickets = en.unit_table_dev[0];
+      args.row_units = en.unit_table_dev[0] + 4;
+      args.inter_units = en.unit_table_dev[0] + 4 + nrows;
+      args.num_row_units = nrows;
+      args.num_inter_units = ninter;
+      args.bytes = bytes[0] + bytes[1] + bytes[2];
+      // (chain replays need the run masks zeroed, which is k_upload's job in a decode)
+      e = launch_upload(en.job_table_dev[0], width, en.stream);
+      if (e == hipSuccess) e = launch_table_copy(en.unit_table_dev[0], en.unit_table_host[0], sizeof(uint32_t) * (4 + nrows + ninter), en.stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(en.stream);
+      if (e == hipSuccess) e = launch_chain(args, static_cast<int>(std::min<uint32_t>(std::max<uint32_t>(std::max<uint32_t>(nrows, (ninter + 3) / 4), 1u), 256u)), en.stream);
+    } else {
+      const uint64_t b3[3] = {bytes[0], bytes[1], bytes[2]};
+      e = launch_main(en.job_table_dev[0], width, max_mbs, max_rows, any_inter, any_intra, any_deblock, b3, en.stream);
+    }
+  }
+  if (e == hipSuccess) e = hipEventRecord(e1, en.stream);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0.f;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (e != hipSuccess) {
+    *error = std::string("GpuExecutor::replay: ") + hipGetErrorString(e);
+    return false;
+  }
+  out->width = width;
+  out->launches = launches;
+  out->seconds = ms / 1000.0;
   return true;
 }
 
@@ -780,3 +910,26 @@ void GpuExecutor::run(int engine) {
 }  // namespace hwang
 
 extern "C" void hwang_shutdown(void) { hwang::amd::shutdown_executors(); }
+
+// Replay hooks (include/hwang_amd.h): see GpuExecutor::keep_recent / replay.
+extern "C" int hwang_replay_keep(int device, int pictures) {
+  std::string error;
+  hwang::amd::GpuExecutor* ex = hwang::amd::GpuExecutor::get(device, &error);
+  if (!ex) return 1;
+  ex->keep_recent(pictures);
+  return 0;
+}
+extern "C" int hwang_replay_run(int device, int width, int launches, int chain, double out[4], char* error, size_t error_capacity) {
+  std::string err;
+  hwang::amd::GpuExecutor* ex = hwang::amd::GpuExecutor::get(device, &err);
+  hwang::amd::GpuExecutor::ReplayResult r;
+  if (!ex || !ex->replay(width, launches, chain != 0, &r, &err)) {
+    if (error && error_capacity) snprintf(error, error_capacity, "%s", err.c_str());
+    return 1;
+  }
+  out[0] = r.pictures_available;
+  out[1] = r.width;
+  out[2] = r.launches;
+  out[3] = r.seconds;
+  return 0;
+}

@@ -112,6 +112,24 @@ class GpuExecutor {
   };
   Stats stats();
 
+  // ---- Replay: the GPU with the host out of the way (bench.py's `replay` block, profiles/rNN_replay.json).
+  // keep_recent(n) makes the executor remember the last n pictures submitted (their descriptors: the records and
+  // surfaces they name stay where they are as long as their decoders live and sit idle).  replay() then launches the
+  // sample-stage kernels - and the records-only ones - for `width` of those pictures per launch, `launches` times, back
+  // to back on one stream, every launch with fresh epochs: what the kernels deliver at a launch width the host's
+  // entropy decoders never produce.  The pictures are decoded in place again and again, so what ends up in the surfaces
+  // is whatever the last launch left (pictures that predict from each other are in the same launch): a measurement,
+  // not a decode - call it when nothing else is submitted and before the decoders are used again for real only after
+  // they have been re-configured (a new interval starts from a keyframe anyway).
+  void keep_recent(int pictures);
+  struct ReplayResult {
+    int pictures_available = 0;  // distinct pictures the executor still holds descriptors for (P / B pictures)
+    int width = 0;               // pictures per launch actually used
+    int launches = 0;
+    double seconds = 0;          // wall time of the launches (HIP events)
+  };
+  bool replay(int width, int launches, bool chain, ReplayResult* out, std::string* error);
+
  private:
   explicit GpuExecutor(int device) : device_(device) {}
   bool start(std::string* error);
@@ -235,6 +253,8 @@ class GpuExecutor {
   int total_inflight_ = 0;
   bool use_hostfunc_ = false;
   bool prestage_ = true;
+  int keep_recent_ = 0;                 // (mu_)
+  std::deque<PicSubmit> recent_;        // (mu_) the last keep_recent_ pictures submitted
   int chain_max_lanes_ = 2;  // chain launches only while at most this many lanes of the executor have work (HWANG_CHAIN_MAX_LANES)
   Stats stats_;
 };

@@ -2722,6 +2722,15 @@ constexpr int kUploadBlocks = 48;
 __global__ __launch_bounds__(256) void k_upload(const JobDesc* __restrict__ jobs) {
   const JobDesc& job = jobs[blockIdx.y / kJobUploads];
   const int a = blockIdx.y % kJobUploads;
+  if (blockIdx.x == 1 && a == 0 && job.band_ctl) {
+    // (chain launches: the rows' inter-run masks start from zero with every picture - also for a picture that brings
+    // nothing to upload: GpuExecutor::replay)
+    uint64_t* mask = static_cast<BandCtl*>(job.band_ctl)->inter_mask;
+    for (int r = threadIdx.x; r < job.pp.mb_height; r += 256) {
+      gst32(reinterpret_cast<uint32_t*>(mask + r), 0u);
+      gst32(reinterpret_cast<uint32_t*>(mask + r) + 1, 0u);
+    }
+  }
   if (a >= job.num_uploads) return;
   const UploadDesc u = job.uploads[a];
   const uint64_t n16 = u.bytes >> 4;
@@ -2730,14 +2739,6 @@ __global__ __launch_bounds__(256) void k_upload(const JobDesc* __restrict__ jobs
   HW_AS1 v4u* __restrict__ dst = (HW_AS1 v4u*)u.dst;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)kUploadBlocks * 256)
     dst[i] = __builtin_nontemporal_load(&src[i]);
-  if (blockIdx.x == 1 && a == 0 && job.band_ctl) {
-    // (chain launches: the rows' inter-run masks start from zero with every picture)
-    uint64_t* mask = static_cast<BandCtl*>(job.band_ctl)->inter_mask;
-    for (int r = threadIdx.x; r < job.pp.mb_height; r += 256) {
-      gst32(reinterpret_cast<uint32_t*>(mask + r), 0u);
-      gst32(reinterpret_cast<uint32_t*>(mask + r) + 1, 0u);
-    }
-  }
   if (blockIdx.x == 0) {
     const uint64_t tail = u.bytes & 15;
     if (threadIdx.x < tail)

@@ -324,6 +324,18 @@ const char* hwang_prof_kernel_name(int kernel_id);
 int hwang_prof_read(int kernel_id, double out[3]);
 void hwang_prof_reset(void);
 
+/* -- Replay: the GPU with the host out of the way ------------------------------
+ * Not in the reference; a measurement hook (bench.py's `replay` block).  The path is bound by the host's entropy
+ * decoders, so the launches it produces say little about what the kernels can do.  hwang_replay_keep makes the
+ * device's executor remember the descriptors of the last `pictures` pictures submitted; after a decode, with every
+ * decoder idle but alive, hwang_replay_run launches the reconstruction kernels for `width` of those pictures per
+ * launch, `launches` times back to back (chain != 0: as one k_chain launch each instead of the wide kernels).  The
+ * pictures are decoded again in place - a measurement, not a decode.  out[0] = distinct pictures available, out[1] =
+ * pictures per launch used, out[2] = launches, out[3] = seconds (HIP events around all of them); the per-kernel
+ * spans come from hwang_prof_*. */
+int hwang_replay_keep(int device, int pictures);
+int hwang_replay_run(int device, int width, int launches, int chain, double out[4], char* error, size_t error_capacity);
+
 /* -- Orderly shutdown ----------------------------------------------------------
  * Stops the per-device executor threads after draining their streams.  The
  * library also does this from atexit; call it earlier (the ctypes package does,

@@ -4,7 +4,7 @@
 lscpu | grep -E "Model name|Socket|Core|Thread|NUMA" 
 for d in /sys/class/drm/card*/device; do echo "$d numa_node=$(cat $d/numa_node 2>/dev/null) local_cpulist=$(cat $d/local_cpulist 2>/dev/null)"; done 2>/dev/null | head -8
 cat /sys/devices/system/cpu/cpu0/topology/thread_siblings_list /sys/devices/system/cpu/cpu1/topology/thread_siblings_list
-B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-host-output"
+B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-hbm-output"
 q() { python -c "
 import json,sys
 d=json.loads(open('$1').read().strip().splitlines()[-1])
