@@ -11,7 +11,7 @@ HIPFLAGS   := --offload-arch=$(ARCH) $(CXXFLAGS)
 CSRC       := hwang_amd/csrc
 BUILD      := build/obj
 
-CPP_SRCS   := $(wildcard $(CSRC)/*.cpp $(CSRC)/h264/*.cpp $(CSRC)/amd/*.cpp)
+CPP_SRCS   := $(wildcard $(CSRC)/*.cpp $(CSRC)/h264/*.cpp $(CSRC)/hevc/*.cpp $(CSRC)/amd/*.cpp)
 HIP_SRCS   := $(wildcard $(CSRC)/amd/*.hip)
 OBJS       := $(patsubst %.cpp,$(BUILD)/%.o,$(CPP_SRCS)) \
               $(patsubst %.hip,$(BUILD)/%.hip.o,$(HIP_SRCS))

@@ -41,6 +41,8 @@ typedef struct {
   int random_intra;    /* intra modes (chroma, 16x16, 4x4, 8x8) and the intra family drawn by hash among the valid ones instead of
                           by best match: every mode of every family with every availability pattern shows up */
   int no_stss;         /* leave the sync sample box out when every sample is one (--gop 1) */
+  int hevc_entry;      /* container tests: 1 = the sample entry is 'hev1' with an hvcC box, 2 = 'hvc1' (the samples stay
+                          what they are: only indexers and format switches look at such a file) */
   int chunk_samples;   /* > 0: chunks of this many samples (every third chunk one more), the sound track's chunks between
                           them: several stsc runs, one chunk offset per chunk with gaps */
   int cover;           /* widens syntax coverage by hash (tests/coverage_model.py): intra macroblocks of every family in P and B slices,
@@ -2234,6 +2236,95 @@ static void bzero_(Buf* b, size_t n) {
   }
 }
 
+/* HEVCDecoderConfigurationRecord (ISO/IEC 14496-15 8.3.3.1) for --hevc-entry: Main profile, level 4, one VPS / SPS / PPS.
+ * The SPS follows ITU-T H.265 7.3.2.2 as far as a parser of the picture geometry reads (profile_tier_level, ids,
+ * chroma format, size, conformance window, bit depths, POC bits, sub-layer ordering, coding / transform block sizes);
+ * VPS and PPS are stubs.  Written from the syntax tables - no HEVC encoder or decoder has seen it. */
+static size_t hevc_nal(const uint8_t* rbsp, size_t n, int type, uint8_t* out) {
+  size_t o = 0;
+  out[o++] = (uint8_t)(type << 1);  /* forbidden_zero_bit, nal_unit_type, top bit of nuh_layer_id */
+  out[o++] = 1;                     /* nuh_layer_id 0, nuh_temporal_id_plus1 1 */
+  int zeros = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (zeros >= 2 && rbsp[i] <= 3) {
+      out[o++] = 3;
+      zeros = 0;
+    }
+    out[o++] = rbsp[i];
+    zeros = rbsp[i] == 0 ? zeros + 1 : 0;
+  }
+  return o;
+}
+static size_t build_hvcc(const Cfg* c, uint8_t* out) {
+  const int cw = (c->width + 7) & ~7, ch = (c->height + 7) & ~7;  /* multiples of the minimum coding block (8) */
+  BitWriter w = {0};
+  bw_put(&w, 0, 4);  /* sps_video_parameter_set_id */
+  bw_put(&w, 0, 3);  /* sps_max_sub_layers_minus1 */
+  bw_put(&w, 1, 1);  /* sps_temporal_id_nesting_flag */
+  bw_put(&w, 0, 2); bw_put(&w, 0, 1); bw_put(&w, 1, 5);        /* general profile space 0, Main tier, profile 1 (Main) */
+  bw_put(&w, 0x60000000u, 32);                                 /* compatibility: Main, Main 10 */
+  bw_put(&w, 1, 1); bw_put(&w, 0, 1); bw_put(&w, 0, 1); bw_put(&w, 1, 1);  /* progressive, !interlaced, !non-packed, frame-only */
+  bw_put(&w, 0, 32); bw_put(&w, 0, 11);                        /* 43 reserved zero bits */
+  bw_put(&w, 0, 1);                                            /* general_inbld_flag / reserved */
+  bw_put(&w, 120, 8);                                          /* general_level_idc: 4.0 */
+  bw_ue(&w, 0);      /* sps_seq_parameter_set_id */
+  bw_ue(&w, 1);      /* chroma_format_idc 4:2:0 */
+  bw_ue(&w, (unsigned)cw);
+  bw_ue(&w, (unsigned)ch);
+  if (cw != c->width || ch != c->height) {
+    bw_put(&w, 1, 1);  /* conformance window, in chroma sample units */
+    bw_ue(&w, 0); bw_ue(&w, (unsigned)(cw - c->width) / 2); bw_ue(&w, 0); bw_ue(&w, (unsigned)(ch - c->height) / 2);
+  } else {
+    bw_put(&w, 0, 1);
+  }
+  bw_ue(&w, 0); bw_ue(&w, 0);  /* bit depths 8 */
+  bw_ue(&w, 4);                /* log2_max_pic_order_cnt_lsb_minus4 */
+  bw_put(&w, 1, 1);            /* sps_sub_layer_ordering_info_present_flag */
+  bw_ue(&w, 4); bw_ue(&w, 2); bw_ue(&w, 0);  /* max_dec_pic_buffering_minus1, num_reorder, max_latency_increase_plus1 */
+  bw_ue(&w, 0);                /* log2_min_luma_coding_block_size_minus3: 8 */
+  bw_ue(&w, 3);                /* log2_diff_max_min: CTB 64 */
+  bw_ue(&w, 0);                /* log2_min_luma_transform_block_size_minus2: 4 */
+  bw_ue(&w, 3);                /* log2_diff_max_min transform: 32 */
+  bw_ue(&w, 1); bw_ue(&w, 1);  /* max_transform_hierarchy_depth inter / intra */
+  bw_put(&w, 0, 1); bw_put(&w, 0, 1); bw_put(&w, 1, 1); bw_put(&w, 0, 1);  /* scaling lists, amp, sao, pcm */
+  bw_ue(&w, 0);                /* num_short_term_ref_pic_sets */
+  bw_put(&w, 0, 1); bw_put(&w, 1, 1); bw_put(&w, 0, 1); bw_put(&w, 0, 1); bw_put(&w, 0, 1);  /* long-term, tmvp, strong intra, vui, ext */
+  bw_put(&w, 1, 1);
+  while (w.pos & 7) bw_put(&w, 0, 1);
+  uint8_t sps[256], vps[16], pps[16];
+  const size_t sps_len = hevc_nal(w.buf, w.pos / 8, 33, sps);
+  free(w.buf);
+  static const uint8_t vps_rbsp[] = {0x0c, 0x01, 0xff, 0xff, 0x01, 0x60, 0x00, 0x00, 0x00, 0x90};
+  static const uint8_t pps_rbsp[] = {0xc1, 0x72, 0xb4, 0x62, 0x40};
+  const size_t vps_len = hevc_nal(vps_rbsp, sizeof(vps_rbsp), 32, vps);
+  const size_t pps_len = hevc_nal(pps_rbsp, sizeof(pps_rbsp), 34, pps);
+  size_t o = 0;
+  out[o++] = 1;                 /* configurationVersion */
+  out[o++] = 1;                 /* profile space 0, Main tier, profile_idc 1 */
+  out[o++] = 0x60; out[o++] = 0; out[o++] = 0; out[o++] = 0;  /* general_profile_compatibility_flags */
+  out[o++] = 0x90; out[o++] = 0; out[o++] = 0; out[o++] = 0; out[o++] = 0; out[o++] = 0;  /* constraint indicator flags */
+  out[o++] = 120;               /* general_level_idc */
+  out[o++] = 0xf0; out[o++] = 0;  /* reserved 1111, min_spatial_segmentation_idc 0 */
+  out[o++] = 0xfc;              /* reserved 111111, parallelismType 0 */
+  out[o++] = 0xfc | 1;          /* reserved, chromaFormat 1 */
+  out[o++] = 0xf8;              /* reserved, bitDepthLumaMinus8 0 */
+  out[o++] = 0xf8;              /* reserved, bitDepthChromaMinus8 0 */
+  out[o++] = 0; out[o++] = 0;   /* avgFrameRate */
+  out[o++] = (uint8_t)(0 << 6 | 1 << 3 | 1 << 2 | (c->nal_length_size - 1));  /* constantFrameRate, numTemporalLayers 1, nested, length size */
+  out[o++] = 3;                 /* numOfArrays */
+  const uint8_t* nals[3] = {vps, sps, pps};
+  const size_t lens[3] = {vps_len, sps_len, pps_len};
+  for (int a = 0; a < 3; ++a) {
+    out[o++] = (uint8_t)(0x80 | (32 + a));  /* array_completeness, NAL_unit_type */
+    out[o++] = 0; out[o++] = 1;             /* numNalus */
+    out[o++] = (uint8_t)(lens[a] >> 8); out[o++] = (uint8_t)lens[a];
+    memcpy(out + o, nals[a], lens[a]);
+    o += lens[a];
+  }
+  return o;
+}
+
+
 /* samples in chunk k of the video track (--chunk-samples; 0 = everything in one chunk) */
 static size_t chunk_len(const Cfg* c, size_t k, size_t first, size_t n) {
   if (c->chunk_samples <= 0) return n;
@@ -2377,12 +2468,17 @@ static void build_moov(Buf* m, const Cfg* c, const uint8_t* avcc, size_t avcc_le
   {
     size_t a = box_begin(m, "stsd");
     b32(m, 0); b32(m, 1);
-    size_t v = box_begin(m, "avc1");
+    size_t v = box_begin(m, c->hevc_entry == 1 ? "hev1" : c->hevc_entry == 2 ? "hvc1" : "avc1");
     bzero_(m, 6); b16(m, 1); bzero_(m, 16);
     b16(m, (uint32_t)c->width); b16(m, (uint32_t)c->height);
     b32(m, 0x00480000); b32(m, 0x00480000); b32(m, 0); b16(m, 1); bzero_(m, 32); b16(m, 0x18); b16(m, 0xffff);
-    size_t cc = box_begin(m, "avcC");
-    bput(m, avcc, avcc_len);
+    size_t cc = box_begin(m, c->hevc_entry ? "hvcC" : "avcC");
+    if (c->hevc_entry) {
+      uint8_t hvcc[512];
+      bput(m, hvcc, build_hvcc(c, hvcc));
+    } else {
+      bput(m, avcc, avcc_len);
+    }
     box_end(m, cc);
     box_end(m, v);
     box_end(m, a);
@@ -2649,6 +2745,7 @@ int main(int argc, char** argv) {
   c.random_intra = arg_int(argc, argv, "--random-intra", 0);
   c.cover = arg_int(argc, argv, "--cover", 0);
   c.no_stss = arg_int(argc, argv, "--no-stss", 0);
+  c.hevc_entry = arg_int(argc, argv, "--hevc-entry", 0);
   c.chunk_samples = arg_int(argc, argv, "--chunk-samples", 0);
   c.wild_mv = arg_int(argc, argv, "--wild-mv", 0);
   c.global_mv = arg_int(argc, argv, "--global-mv", 0);

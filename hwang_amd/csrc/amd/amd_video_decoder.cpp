@@ -20,6 +20,7 @@
 #include "amd_video_decoder.h"
 
 #include "../h264/h264_parser.h"
+#include "../hevc/hvcc.h"
 #include "../sparse_hints.h"
 #include "../util/cpus.h"
 #include "../util/numa.h"
@@ -127,9 +128,20 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   Result configure(const FrameInfo& metadata, const std::vector<uint8_t>& extradata) override {
     trace::event("configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
+    // The format switch of the reference's software backend (software_video_decoder.cpp:124-135): h264 / avc1, the
+    // HEVC names, anything else.  HEVC is recognised and refused by name, with what the track's hvcC says it is.
+    if (hevc::is_hevc_format(metadata.format)) {
+      hevc::Config hc;
+      std::string why;
+      if (!hevc::parse_hvcc(extradata.data(), extradata.size(), &hc, &why))
+        return Result(false, "AMDVideoDecoder: HEVC ('" + metadata.format + "') is not supported by this backend (H.264 only), and the "
+                             "track's hvcC cannot be read: " + why);
+      return Result(false, "AMDVideoDecoder: HEVC ('" + metadata.format + "') is not supported by this backend (H.264 only); the track is " +
+                               hevc::describe(hc));
+    }
     if (metadata.format != "h264" && metadata.format != "avc1") {
-      return Result(false, "AMDVideoDecoder: unsupported format '" + metadata.format +
-                               "' (H.264 in avc1/h264 sample entries only)");
+      return Result(false, "Unsupported video codec: " + metadata.format + ". Supported codecs are: h264 (avc1); hevc/h265 is "
+                           "recognised but not decoded");
     }
     if (parser_) {
       folded_decoded_ += parser_->pictures_decoded();

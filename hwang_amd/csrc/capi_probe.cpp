@@ -7,6 +7,7 @@
 #include "../../include/hwang_amd.h"
 
 #include "h264/h264_parser.h"
+#include "hevc/hvcc.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -198,4 +199,19 @@ extern "C" int hwang_h264_probe_workers(const uint8_t* avcc, size_t avcc_size, c
                                         char* error, size_t error_capacity) {
   return run_probe(avcc, avcc_size, data, sample_offsets, sample_sizes, num_samples, wanted, num_wanted, keyframes,
                    num_keyframes, workers, out, 9, error, error_capacity);
+}
+
+// Host only: what an hvcC box payload (the metadata MP4IndexCreator returns for an hev1 / hvc1 track) says about its
+// track; 0 and the description, or 1 and what is wrong with the record.
+extern "C" int hwang_hevc_describe_config(const uint8_t* hvcc, size_t size, char* out, size_t capacity) {
+  hevc::Config c;
+  std::string text;
+  const bool ok = hevc::parse_hvcc(hvcc, size, &c, &text);
+  if (ok) text = hevc::describe(c);
+  if (out && capacity) {
+    const size_t n = std::min(text.size(), capacity - 1);
+    memcpy(out, text.data(), n);
+    out[n] = 0;
+  }
+  return ok ? 0 : 1;
 }

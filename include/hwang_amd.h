@@ -313,6 +313,13 @@ int hwang_h264_probe_workers(const uint8_t* avcc, size_t avcc_size, const uint8_
                              const uint64_t* keyframes, size_t num_keyframes,
                              int workers, int64_t out[9], char* error, size_t error_capacity);
 
+/* Host only: what the hvcC payload of an hev1 / hvc1 track (MP4IndexCreator's metadata for it,
+ * mp4_index_creator.cpp:454-469) says about the track - profile, tier, level, picture size, chroma format, bit depth,
+ * CTB size, parameter set counts.  The AMD backend's configure() answers an HEVC format name
+ * (software_video_decoder.cpp:128-132) with this text inside its "not supported" Result.  Returns 0, or 1 with what
+ * is wrong with the record in `out`. */
+int hwang_hevc_describe_config(const uint8_t* hvcc, size_t size, char* out, size_t capacity);
+
 /* -- Profiling hooks ---------------------------------------------------------
  * When enabled, every kernel launch of the backend is bracketed with HIP
  * events on its own stream; hwang_prof_read drains the accumulated

@@ -1,0 +1,90 @@
+"""HEVC behind the boundary, as far as it can be checked on this pool: the indexer
+names an hev1 / hvc1 track and hands out its hvcC payload exactly as the reference's indexer does (compiled in place:
+oracle/_ref/ref_mp4_index, mp4_index_creator.cpp:454-469); the backend's format switch recognises the HEVC names of the
+reference's software backend (software_video_decoder.cpp:128-132), reads the record and refuses the track by name.  There
+is no HEVC decoder: no HEVC stream and no HEVC decoder exist on the build image or the GPU boxes to check one against."""
+import ctypes as C
+import os
+
+import pytest
+
+from tests.corpus_util import make_clip
+from tests.util import ROOT
+
+
+def describe(lib, payload):
+    out = C.create_string_buffer(512)
+    rc = lib.hwang_hevc_describe_config(payload, len(payload), out, 512)
+    return rc, out.value.decode()
+
+
+@pytest.mark.parametrize("entry,fourcc", [(1, "hev1"), (2, "hvc1")])
+def test_hevc_track_is_indexed_and_described(hw, tmp_path, entry, fourcc):
+    from hwang_amd._capi import lib
+    path = str(tmp_path / (fourcc + ".mp4"))
+    make_clip(path, width=320, height=180, yuv=False, frames=12, gop=6, bframes=1, hevc_entry=entry)
+    idx = hw.index_video(path)
+    assert idx.format() == fourcc and idx.frames() == 12 and idx.keyframe_indices() == [0, 6]
+    payload = bytes(idx.metadata_bytes())
+    assert payload[0] == 1 and len(payload) > 23
+    rc, text = describe(lib, payload)
+    assert rc == 0
+    # 320x180 is coded as 320x184 (a multiple of the 8-sample minimum coding block) with a conformance window
+    assert text == ("HEVC Main profile, Main tier, level 4.0; 320x180 (coded 320x184), 4:2:0 8-bit, CTB 64; "
+                    "1 VPS / 1 SPS / 1 PPS, 4-byte NAL lengths"), text
+
+
+def test_hev1_index_equals_the_reference_indexers(hw, tmp_path):
+    """The reference's indexer knows 'hev1' (not 'hvc1': mp4_index_creator.cpp:454): same tables, same extradata."""
+    import json
+    import subprocess
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_mp4_index")   # the reference indexer compiled in place
+    if not os.path.exists(ref_bin):
+        pytest.skip("reference indexer not built here")
+    path = str(tmp_path / "hev1.mp4")
+    make_clip(path, width=640, height=368, yuv=False, frames=20, gop=10, bframes=2, hevc_entry=1)
+    ref = json.loads(subprocess.check_output([ref_bin, path]))
+    idx = hw.index_video(path)
+    assert not ref["error"] and ref["format"] == "hev1" == idx.format()
+    assert ref["metadata"] == bytes(idx.metadata_bytes()).hex() and len(ref["metadata"]) > 46
+    assert ref["sample_offsets"] == idx.sample_offsets() and ref["sample_sizes"] == idx.sample_sizes()
+    assert ref["keyframes"] == idx.keyframe_indices()
+    assert (ref["width"], ref["height"]) == (idx.frame_width(), idx.frame_height())
+
+
+def test_damaged_records_are_named(hw):
+    from hwang_amd._capi import lib
+    assert describe(lib, b"\x01" * 10) == (1, "the hvcC payload is shorter than the 23 bytes of its fixed part")
+    rc, text = describe(lib, b"\x02" + b"\x00" * 30)
+    assert rc == 1 and "configurationVersion 2" in text
+    good = bytes([1, 1, 0x60, 0, 0, 0, 0x90, 0, 0, 0, 0, 0, 93, 0xf0, 0, 0xfc, 0xfd, 0xfa, 0xfa, 0, 0, 0x0f, 1, 0xa1, 0, 1, 0, 40])
+    rc, text = describe(lib, good)   # an SPS array that claims 40 bytes and has none
+    assert rc == 1 and "runs past the end" in text
+    rc, text = describe(lib, good[:23][:22] + b"\x00")   # no arrays at all: described from the record's header alone
+    assert rc == 0 and text.startswith("HEVC Main profile, Main tier, level 3.1; 4:2:0 10-bit (no SPS in the record)"), text
+
+
+@pytest.mark.gpu
+def test_backend_refuses_hevc_by_name(hw, tmp_path):
+    import torch
+    assert torch.cuda.is_available()
+    from hwang_amd._capi import lib
+    path = str(tmp_path / "hev1.mp4")
+    make_clip(path, width=320, height=240, yuv=False, frames=6, gop=6, bframes=0, hevc_entry=1)
+    idx = hw.index_video(path)
+    dec = lib.hwang_decoder_create(1, 0, 1, 3)
+    assert dec
+    extradata = bytes(idx.metadata_bytes())
+    try:
+        for name in ("hev1", "hevc", "h265", "hvc1"):
+            assert lib.hwang_decoder_configure(dec, 320, 240, name.encode(), extradata, len(extradata)) != 0
+            msg = lib.hwang_decoder_last_error(dec).decode()
+            assert "HEVC ('%s') is not supported by this backend (H.264 only)" % name in msg and "Main profile" in msg and "320x240" in msg, msg
+        assert lib.hwang_decoder_configure(dec, 320, 240, b"vp09", extradata, len(extradata)) != 0
+        assert "Unsupported video codec: vp09" in lib.hwang_decoder_last_error(dec).decode()
+    finally:
+        lib.hwang_decoder_destroy(dec)
+    # ... and through the reference's Python surface: a RuntimeError that names the codec
+    import hwang
+    with pytest.raises(RuntimeError, match="HEVC"):
+        hwang.Decoder(path, device_type=hwang.DeviceType.GPU).retrieve([0])
