@@ -124,10 +124,13 @@ int h264i_parse_sps(H264Oracle* d, Bits* b) {
   if (p == 100 || p == 110 || p == 122 || p == 244 || p == 44 || p == 83 || p == 86 || p == 118 ||
       p == 128 || p == 138 || p == 139 || p == 134 || p == 135) {
     s.chroma_format_idc = get_ue(b);
-    if (s.chroma_format_idc == 3) get_bit(b); /* separate_colour_plane_flag */
+    int separate = 0;
+    if (s.chroma_format_idc == 3) separate = get_bit(b); /* separate_colour_plane_flag */
     int bdl = get_ue(b), bdc = get_ue(b);
     int bypass = get_bit(b);
-    if (s.chroma_format_idc != 1 || bdl != 0 || bdc != 0 || bypass)
+    /* 4:4:4 (one plane arrangement): in parse-only mode only - its slice data can be parsed, not reconstructed */
+    const int ok444 = d->parse_only && s.chroma_format_idc == 3 && !separate;
+    if ((s.chroma_format_idc != 1 && !ok444) || bdl != 0 || bdc != 0 || bypass)
       return h264i_fail(d, "unsupported: only 8-bit 4:2:0 without transform bypass");
     s.scaling_matrix_present = get_bit(b);
     if (s.scaling_matrix_present) {
@@ -135,6 +138,10 @@ int h264i_parse_sps(H264Oracle* d, Bits* b) {
       memset(flat4, 16, sizeof(flat4));
       memset(flat8, 16, sizeof(flat8));
       parse_scaling_matrices(b, 1, s.scaling4, s.scaling8, flat4, flat8, 0);
+      if (s.chroma_format_idc == 3) { /* the 8x8 lists of Cb and Cr (7.3.2.1.1: twelve lists): read and dropped */
+        uint8_t scratch[64];
+        for (int k = 0; k < 4; ++k) scaling_list(b, scratch, 64, flat8[0], default_8x8_intra);
+      }
     }
   }
   s.log2_max_frame_num = get_ue(b) + 4;
@@ -158,11 +165,12 @@ int h264i_parse_sps(H264Oracle* d, Bits* b) {
   s.frame_mbs_only = get_bit(b);
   if (!s.frame_mbs_only) return h264i_fail(d, "unsupported: interlaced (frame_mbs_only_flag=0)");
   s.direct_8x8_inference = get_bit(b);
-  if (get_bit(b)) { /* frame_cropping_flag; 4:2:0 frame units are 2 luma samples */
-    s.crop_left = 2 * get_ue(b);
-    s.crop_right = 2 * get_ue(b);
-    s.crop_top = 2 * get_ue(b);
-    s.crop_bottom = 2 * get_ue(b);
+  if (get_bit(b)) { /* frame_cropping_flag; 4:2:0 frame units are 2 luma samples (4:4:4: one) */
+    const int unit = s.chroma_format_idc == 3 ? 1 : 2;
+    s.crop_left = unit * get_ue(b);
+    s.crop_right = unit * get_ue(b);
+    s.crop_top = unit * get_ue(b);
+    s.crop_bottom = unit * get_ue(b);
   }
   s.num_reorder_frames = -1;
   if (get_bit(b)) { /* vui_parameters_present_flag */
@@ -243,8 +251,14 @@ int h264i_parse_pps(H264Oracle* d, Bits* b) {
   if (h264i_more_rbsp_data(b)) {
     p.transform_8x8_mode = get_bit(b);
     if (get_bit(b)) /* pic_scaling_matrix_present_flag */
+    {
       parse_scaling_matrices(b, p.transform_8x8_mode, p.scaling4, p.scaling8, s->scaling4,
                              s->scaling8, s->scaling_matrix_present);
+      if (s->chroma_format_idc == 3 && p.transform_8x8_mode) { /* Cb / Cr 8x8 lists: read and dropped */
+        uint8_t scratch[64];
+        for (int k = 0; k < 4; ++k) scaling_list(b, scratch, 64, s->scaling8[0], default_8x8_intra);
+      }
+    }
     p.chroma_qp_offset[1] = get_se(b);
   }
   if (b->overrun) return h264i_fail(d, "truncated PPS");
@@ -307,6 +321,7 @@ static int alloc_pool(H264Oracle* d, int mbw, int mbh) {
   REALLOC(d->mb_chroma_mode, uint8_t, nmb);
   REALLOC(d->i4mode, int8_t, nmb * 16);
   REALLOC(d->nnz, uint8_t, nmb * 24);
+  REALLOC(d->nnz444, uint8_t, nmb * 32);
   REALLOC(d->mb_deblock, MbDeblock, nmb);
   REALLOC(d->mb_qpc[0], int8_t, nmb);
   REALLOC(d->mb_qpc[1], int8_t, nmb);
@@ -637,6 +652,7 @@ int h264i_parse_slice_header(H264Oracle* d, Bits* b, int nal_ref_idc, int nal_ty
     }
     d->apps = pps;
     d->asps = sps;
+    d->chroma444 = sps->chroma_format_idc == 3;
     if (h264i_start_picture(d) < 0) return -1;
   } else if (pps->sps_id != d->apps->sps_id) {
     return h264i_fail(d, "SPS changed inside a picture");
@@ -873,7 +889,7 @@ int h264i_finish_picture(H264Oracle* d) {
   for (int i = 0; i < nmb; ++i)
     if (d->mb_slice[i] < 0) return h264i_fail(d, "picture ended with undecoded macroblocks");
 
-  h264i_deblock_picture(d);
+  if (!d->parse_only) h264i_deblock_picture(d);
 
   /* frame_num_wrap of the current refs is needed by the sliding window */
   {
@@ -918,6 +934,7 @@ H264Oracle* h264o_open(void) {
   if (d) {
     d->nal_length_size = 4;
     d->max_long_term_frame_idx = -1;
+    d->x264_build = -1;
   }
   return d;
 }
@@ -940,6 +957,7 @@ void h264o_close(H264Oracle* d) {
   free(d->mb_chroma_mode);
   free(d->i4mode);
   free(d->nnz);
+  free(d->nnz444);
   free(d->mvd);
   free(d->mb_deblock);
   free(d->mb_qpc[0]);
@@ -954,6 +972,19 @@ static int decode_nal(H264Oracle* d, const uint8_t* nal, size_t n) {
   if (n < 1) return 0;
   int ref_idc = (nal[0] >> 5) & 3;
   int type = nal[0] & 31;
+  if (type == 6 && d->parse_only) {
+    /* x264's version SEI (user_data_unregistered: a UUID and "x264 - core N ..."): 4:4:4 streams of builds before
+     * 151 code the coded_block_flag of 8x8 blocks with contexts of their own making, see h264_slice.c */
+    static const char tag[] = "x264 - core ";
+    for (size_t i = 1; i + sizeof(tag) + 2 < n; ++i)
+      if (!memcmp(nal + i, tag, sizeof(tag) - 1)) {
+        int v = 0;
+        for (size_t k = i + sizeof(tag) - 1; k < n && nal[k] >= '0' && nal[k] <= '9'; ++k) v = v * 10 + (nal[k] - '0');
+        if (!d->no_quirks) d->x264_build = v;
+        break;
+      }
+    return 0;
+  }
   if (type != 1 && type != 5 && type != 7 && type != 8) return 0; /* SEI, AUD, ... */
   int rn = unescape_nal(d, nal + 1, n - 1);
   if (rn < 0) return h264i_fail(d, "out of memory");
@@ -1047,6 +1078,13 @@ int h264o_pop_frame(H264Oracle* d, uint8_t* dst, size_t capacity) {
 }
 
 void h264o_counters(H264Oracle* d, int64_t out[10]) { memcpy(out, d->counters, sizeof(d->counters)); }
+
+/* on: 1 = parse only; 2 = parse only and take every stream at its word (no emulation of old x264 builds' 4:4:4
+ * contexts, h264_slice.c cbf8_inc): the negative control of the desync test */
+void h264o_set_parse_only(H264Oracle* d, int on) {
+  d->parse_only = on != 0;
+  d->no_quirks = on == 2;
+}
 
 void h264o_coverage_enable(H264Oracle* d) {
   if (!d->cov) d->cov = (int64_t*)calloc(H264O_COV_CELLS, sizeof(int64_t));

@@ -175,7 +175,7 @@ typedef struct {
 typedef struct {
   Bits* bits;
   unsigned range, offset;
-  uint8_t state[CABAC_CTX_COUNT]; /* (pStateIdx << 1) | valMPS */
+  uint8_t state[CABAC_CTX_TOTAL]; /* (pStateIdx << 1) | valMPS */
 } Cabac;
 
 /* ---- bit writer + CABAC encoder (corpus generator only) ---------------------- */
@@ -217,6 +217,7 @@ typedef struct {
   int16_t chroma_ac[2][4][16];
   uint8_t pcm[384];
   uint8_t nnz[24];       /* total_coeff per block: luma raster 0..15, cb 16..19, cr 20..23 */
+  uint8_t nnz444[32];    /* 4:4:4 (parse-only mode): Cb raster 0..15, Cr 16..31 - coded like luma */
   int cbf_dc;            /* bit0 luma DC, bit1 cb DC, bit2 cr DC */
 } MB;
 
@@ -265,6 +266,14 @@ struct H264Oracle {
   uint8_t* mb_chroma_mode;
   int8_t* i4mode;         /* mb*16 + raster4x4 */
   uint8_t* nnz;           /* mb*24 */
+  uint8_t* nnz444;        /* mb*32: Cb, Cr blocks of 4:4:4 pictures (parse-only mode) */
+  /* Parse-only mode (h264o_set_parse_only): syntax, entropy decoding, reference handling and output order run, no
+   * sample is reconstructed.  In this mode - and only in it - High 4:4:4 Predictive streams (chroma_format_idc 3,
+   * one colour plane arrangement, 8 bit) are accepted: Cb and Cr residuals are parsed like luma. */
+  int parse_only;
+  int chroma444;          /* the active SPS has chroma_format_idc 3 */
+  int x264_build;         /* "x264 - core N" from the stream's version SEI, -1 if none (set once, kept) */
+  int no_quirks;          /* h264o_set_parse_only(d, 2): the version SEI is ignored */
   uint8_t (*mvd)[2][16][2]; /* |mvd| clipped, per MB/list/raster4x4/comp */
   MbDeblock* mb_deblock;
   int8_t* mb_qpc[2];

@@ -46,6 +46,16 @@ int h264o_frame_info(H264Oracle* d, int* width, int* height, int* poc);
  * ceil(w/2)*ceil(h/2)) and drops it.  dst may be NULL to just drop. */
 int h264o_pop_frame(H264Oracle* d, uint8_t* dst, size_t capacity);
 const char* h264o_error(H264Oracle* d);
+/* Parse-only mode (before h264o_configure): every syntax element is entropy decoded, reference lists / marking / POC
+ * / output order run, counters[] count - but nothing is reconstructed (the frames that come out are blank).  In this
+ * mode the oracle also accepts High 4:4:4 Predictive streams (chroma_format_idc 3 without separate colour planes,
+ * 8 bit, no transform bypass; CABAC), which it cannot reconstruct: their slice data is parsed with Cb and Cr coded
+ * like luma (ctxBlockCat 6 - 13, 7.3.5.3 / 9.3.3.1.3).  Purpose: the desync check - "every slice ends on its
+ * rbsp_stop_one_bit after the right number of macroblocks" - on a second real encoder's stream (imageio's
+ * cockatoo.mp4: B slices, explicit and implicit weighted prediction, 8x8 transform, four references), which pins
+ * the B-slice syntax, the weight tables and the entropy contexts it touches without a second decoder
+ * (tests/test_oracle_realstream.py). */
+void h264o_set_parse_only(H264Oracle* d, int on);
 
 /* counters[0]=slices decoded, [1]=slices whose data ended exactly at
  * rbsp_trailing_bits (the desync check), [2]=macroblocks, [3]=pictures,

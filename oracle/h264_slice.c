@@ -6,6 +6,7 @@
 #include "h264_internal.h"
 
 #include <stdio.h>
+#include <stdlib.h>
 
 /* ======================================================================== */
 /* CABAC engine (9.3.1.2, 9.3.3.2)                                          */
@@ -27,6 +28,21 @@ static void cabac_init_contexts(Cabac* c, int slice_type, int idc, int qp) {
     else
       c->state[i] = (uint8_t)(((pre - 64) << 1) | 1);
   }
+  /* ctxIdx 460 .. 1023 (4:4:4 only; frame macroblocks).  Tables 9-12 .. 9-33 give the contexts of Cb (ctxBlockCat
+   * 6 .. 9) and Cr (10 .. 13) the same (m, n) as the luma contexts of the same role (ctxBlockCat 0 .. 2, 5), and the
+   * coded_block_flag contexts of 8x8 blocks (1012 .. 1023, one set per colour component) those of ctxBlockCat 2 -
+   * typed here as that rule, not as 564 more pairs; the field-macroblock ranges stay unused.  Whether the rule is
+   * right is what the desync check on a real 4:4:4 stream decides (tests/test_oracle_realstream.py). */
+  static const struct { int dst, src, n; } copies[] = {
+      {460, 85, 12},  {472, 85, 12},                       /* coded_block_flag: Cb, Cr cat 6-8 / 10-12 <- luma cat 0-2 */
+      {484, 105, 44}, {528, 105, 44},                      /* significant_coeff_flag (frame) */
+      {572, 166, 44}, {616, 166, 44},                      /* last_significant_coeff_flag (frame) */
+      {660, 402, 15}, {690, 417, 9},  {708, 426, 10},      /* Cb 8x8 (cat 9): sig, last, abs <- luma 8x8 (cat 5) */
+      {718, 402, 15}, {748, 417, 9},  {766, 426, 10},      /* Cr 8x8 (cat 13) */
+      {952, 227, 30}, {982, 227, 30},                      /* coeff_abs_level_minus1 */
+      {1012, 93, 4},  {1016, 93, 4},  {1020, 93, 4}};      /* coded_block_flag of 8x8 blocks: Y, Cb, Cr */
+  for (size_t k = 0; k < sizeof(copies) / sizeof(copies[0]); ++k)
+    memcpy(c->state + copies[k].dst, c->state + copies[k].src, (size_t)copies[k].n);
 }
 
 static int cabac_bin(Cabac* c, int ctx) {
@@ -403,7 +419,7 @@ typedef struct {
 
 static inline int sx_bin(Rd* r, int ctx, int v) {
   const int bin = r->enc ? cenc_bin(&r->d->cenc, &r->d->cabac.state[ctx], v) : cabac_bin(&r->d->cabac, ctx);
-  COV(r->d, H264O_COV_CTX + (r->d->cov_ctx_table * CABAC_CTX_COUNT + ctx) * 2 + (bin != 0));
+  if (ctx < CABAC_CTX_COUNT) COV(r->d, H264O_COV_CTX + (r->d->cov_ctx_table * CABAC_CTX_COUNT + ctx) * 2 + (bin != 0));
   return bin;
 }
 static inline int sx_bypass(Rd* r, int v) {
@@ -607,9 +623,21 @@ static const int abs_cat_offset[6] = {0, 10, 20, 30, 39, 0};
 
 /* cat: 0 I16 DC, 1 I16 AC, 2 luma 4x4, 3 chroma DC, 4 chroma AC, 5 luma 8x8.
  * cbf_inc < 0: no coded_block_flag (cat 5 in 4:2:0).  Returns nonzero count. */
+static int cabac_block_comp(Rd* r, int comp, int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start,
+                            int16_t* io);
 static int cabac_block(Rd* r, int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start,
                        int16_t* io) {
+  return cabac_block_comp(r, 0, cat, cbf_inc, max_coeff, scan, start, io);
+}
+/* comp: colour component (0; 1 Cb / 2 Cr of a 4:4:4 picture, coded like luma with ctxBlockCat cat + 6 / cat + 10 resp.
+ * 9 / 13 for cat 5: Table 9-34's ctxIdxOffsets for those categories) */
+static int cabac_block_comp(Rd* r, int comp, int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start,
+                            int16_t* io) {
   H264Oracle* d = r->d;
+  static const int cbf_base[3] = {85, 460, 472}, cbf8_base[3] = {1012, 1016, 1020};
+  static const int sig_base_c[3] = {105, 484, 528}, sig8_base[3] = {402, 660, 718};
+  static const int last_base_c[3] = {166, 572, 616}, last8_base[3] = {417, 690, 748};
+  static const int abs_base_c[3] = {227, 952, 982}, abs8_base[3] = {426, 708, 766};
   int want[64];
   int nz = 0, last_nz = -1;
   if (r->enc) {
@@ -622,13 +650,13 @@ static int cabac_block(Rd* r, int cat, int cbf_inc, int max_coeff, const uint8_t
     }
   }
   if (cbf_inc >= 0) {
-    if (!sx_bin(r, 85 + cbf_cat_offset[cat] + cbf_inc, nz != 0)) return 0;
+    if (!sx_bin(r, (cat == 5 ? cbf8_base[comp] : cbf_base[comp] + cbf_cat_offset[cat]) + cbf_inc, nz != 0)) return 0;
   } else if (r->enc && !nz) {
     return h264i_fail(d, "encoder: 8x8 block flagged in CBP has no coefficients");
   }
-  const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
-  const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
-  const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
+  const int sig_base = cat == 5 ? sig8_base[comp] : sig_base_c[comp] + sig_cat_offset[cat];
+  const int last_base = cat == 5 ? last8_base[comp] : last_base_c[comp] + sig_cat_offset[cat];
+  const int abs_base = cat == 5 ? abs8_base[comp] : abs_base_c[comp] + abs_cat_offset[cat];
   int idx[64], n = 0;
   int i;
   for (i = 0; i < max_coeff - 1; ++i) {
@@ -888,6 +916,7 @@ static int sx_cbp(Rd* r, int intra, int v) {
     int bit_b = (b8 & 2) ? (cbp >> (b8 - 2)) & 1 : (cbp_b >> (b8 + 2)) & 1;
     cbp |= sx_bin(r, 73 + !bit_a + 2 * !bit_b, (v >> b8) & 1) << b8;
   }
+  if (d->chroma444) return cbp; /* ChromaArrayType 3: the bin string is the prefix alone (9.3.2.6) */
   const int ca = la ? d->mb_cbp[m->addr - 1] >> 4 : 0;
   const int cb = ta ? d->mb_cbp[m->addr - d->mbw] >> 4 : 0;
   if (sx_bin(r, 77 + (ca != 0) + 2 * (cb != 0), (v >> 4) != 0)) {
@@ -974,10 +1003,104 @@ static int predicted_intra_mode(const H264Oracle* d, int bx, int by) {
 /* ======================================================================== */
 static const uint8_t identity_scan16[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
 
+/* coded_block_flag ctxIdxInc of a Cb / Cr block of a 4:4:4 picture: as for luma, from the same colour component's
+ * blocks to the left and above (kind 0: the Intra16x16 DC block, 1: 4x4 block (rx, ry) - for an 8x8 block its
+ * top-left 4x4 block, every 4x4 block of a coded 8x8 block carrying the 8x8 block's count). */
+static int cbf444_neighbour(const H264Oracle* d, int comp, int kind, int rx, int ry, int left) {
+  const MB* m = &d->mb;
+  const int cur_intra = m->kind != MB_INTER;
+  int nx = m->mbx, ny = m->mby, inside = 0;
+  if (kind == 1) {
+    if (left) {
+      if (rx > 0) inside = 1; else nx--;
+    } else {
+      if (ry > 0) inside = 1; else ny--;
+    }
+  } else {
+    if (left) nx--; else ny--;
+  }
+  const int base = (comp - 1) * 16;
+  if (inside) return m->nnz444[base + (left ? ry * 4 + rx - 1 : (ry - 1) * 4 + rx)] != 0;
+  if (!mb_avail(d, nx, ny)) return cur_intra;
+  const int addr = ny * d->mbw + nx;
+  if (d->mb_kind[addr] == MB_IPCM) return 1;
+  if (kind == 0) return d->mb_kind[addr] == MB_I16x16 && ((d->mb_cbf_dc[addr] >> comp) & 1);
+  return d->nnz444[addr * 32 + base + (left ? ry * 4 + 3 : 12 + rx)] != 0;
+}
+static int cbf444_inc(const H264Oracle* d, int comp, int kind, int rx, int ry) {
+  return cbf444_neighbour(d, comp, kind, rx, ry, 1) + 2 * cbf444_neighbour(d, comp, kind, rx, ry, 0);
+}
+/* coded_block_flag ctxIdxInc of an 8x8 block (ctxBlockCat 5 / 9 / 13, in the stream only in 4:4:4) whose top-left 4x4
+ * block is (rx, ry).  As libavcodec does it - the reference's decoder (h264_cabac.c: the blocks' coefficient counts
+ * in one cache, a 4x4-transformed neighbour counting with its adjacent 4x4 block) - including its emulation of x264
+ * before build 151, which coded these flags as if an available neighbouring macroblock WITHOUT the 8x8 transform
+ * were not available (1 for an intra macroblock, 0 for an inter one): real 4:4:4 files of that age - imageio's
+ * cockatoo.mp4 is "x264 - core 142" - only parse that way. */
+static int cbf8_inc(const H264Oracle* d, int comp, int rx, int ry) {
+  const MB* m = &d->mb;
+  int inc = 0;
+  for (int left = 1; left >= 0; --left) {
+    int v;
+    const int outside = left ? rx == 0 : ry == 0;
+    const int nx = m->mbx - (left ? 1 : 0), ny = m->mby - (left ? 0 : 1);
+    if (outside && d->x264_build >= 0 && d->x264_build < 151 && mb_avail(d, nx, ny) && !d->mb_t8x8[ny * d->mbw + nx])
+      v = m->kind != MB_INTER;
+    else
+      v = comp == 0 ? cbf_neighbour(d, 1, 0, rx, ry, left) : cbf444_neighbour(d, comp, 1, rx, ry, left);
+    inc += v << (left ? 0 : 1);
+  }
+  return inc;
+}
+
+/* residual() of a 4:4:4 macroblock (7.3.5.3 with ChromaArrayType 3): residual_luma three times - Y, Cb, Cr - all under
+ * the luma bits of coded_block_pattern; the coded_block_flag of 8x8 blocks is in the stream.  Parse-only: the levels
+ * go nowhere. */
+static int code_residual444(Rd* r) {
+  H264Oracle* d = r->d;
+  MB* m = &d->mb;
+  const int i16 = m->kind == MB_I16x16;
+  if (!r->cabac || r->enc) return h264i_fail(d, "4:4:4: CABAC streams only, parse only");
+  int16_t scratch[64];
+  for (int comp = 0; comp < 3; ++comp) {
+    uint8_t* nz = comp == 0 ? m->nnz : m->nnz444 + (comp - 1) * 16;
+    if (i16) {
+      memset(scratch, 0, sizeof(scratch));
+      const int inc = comp == 0 ? cbf_inc(d, 0, 0, 0, 0) : cbf444_inc(d, comp, 0, 0, 0);
+      int n = cabac_block_comp(r, comp, 0, inc, 16, zigzag4x4, 0, scratch);
+      if (n < 0) return -1;
+      if (n) m->cbf_dc |= 1 << comp;
+    }
+    for (int b8 = 0; b8 < 4; ++b8) {
+      if (!((m->cbp >> b8) & 1)) continue;
+      const int bx0 = (b8 & 1) * 2, by0 = (b8 >> 1) * 2;
+      if (m->t8x8) {
+        memset(scratch, 0, sizeof(scratch));
+        const int inc = cbf8_inc(d, comp, bx0, by0);
+        int n = cabac_block_comp(r, comp, 5, inc, 64, zigzag8x8, 0, scratch);
+        if (n < 0) return -1;
+        for (int s = 0; s < 4; ++s) nz[(by0 + (s >> 1)) * 4 + bx0 + (s & 1)] = (uint8_t)n;
+        continue;
+      }
+      for (int s = 0; s < 4; ++s) {
+        const int bx = bx0 + (s & 1), by = by0 + (s >> 1);
+        memset(scratch, 0, sizeof(scratch));
+        const int inc = comp == 0 ? cbf_inc(d, 1, 0, bx, by) : cbf444_inc(d, comp, 1, bx, by);
+        int n = i16 ? cabac_block_comp(r, comp, 1, inc, 15, zigzag4x4, 1, scratch)
+                    : cabac_block_comp(r, comp, 2, inc, 16, zigzag4x4, 0, scratch);
+        if (n < 0) return -1;
+        nz[by * 4 + bx] = (uint8_t)n;
+      }
+    }
+  }
+  if (r->b->overrun) return h264i_fail(d, "residual ran past the end of the slice");
+  return 0;
+}
+
 static int code_residual(Rd* r) {
   H264Oracle* d = r->d;
   MB* m = &d->mb;
   const int i16 = m->kind == MB_I16x16;
+  if (d->chroma444) return code_residual444(r);
 
   if (i16) {
     /* Intra16x16DCLevel: zig-zag over the 4x4 matrix of DCs whose
@@ -1208,6 +1331,7 @@ static void commit_mb(H264Oracle* d) {
   d->mb_chroma_mode[a] = (uint8_t)((m->kind != MB_INTER && m->kind != MB_IPCM) ? m->chroma_mode : 0);
   memcpy(d->i4mode + a * 16, m->i4_mode, 16);
   memcpy(d->nnz + a * 24, m->nnz, 24);
+  memcpy(d->nnz444 + a * 32, m->nnz444, 32);
   d->mb_deblock[a].disable = (int8_t)d->sl.disable_deblock;
   d->mb_deblock[a].alpha = (int8_t)d->sl.alpha_offset;
   d->mb_deblock[a].beta = (int8_t)d->sl.beta_offset;
@@ -1280,7 +1404,7 @@ static int code_skip_mb(H264Oracle* d, int addr) {
     if (pred_direct(d, -1) < 0) return -1;
   }
   commit_mb(d);
-  h264i_recon_mb(d);
+  if (!d->parse_only) h264i_recon_mb(d);
   return 0;
 }
 
@@ -1321,14 +1445,17 @@ static int code_mb(Rd* r, int addr) {
       Bits* b = r->b;
       while (b->pos & 7) get_bit(b);
       for (int i = 0; i < 384; ++i) m->pcm[i] = (uint8_t)get_bits(b, 8);
+      if (d->chroma444) /* 2 x 256 chroma samples instead of 2 x 64 (parse only: dropped) */
+        for (int i = 0; i < 384; ++i) (void)get_bits(b, 8);
       if (b->overrun) return h264i_fail(d, "truncated I_PCM");
       if (r->cabac) cabac_start(&d->cabac, b);
     }
     memset(m->nnz, 16, sizeof(m->nnz));
+    memset(m->nnz444, 16, sizeof(m->nnz444));
     m->cbf_dc = 7;
     d->last_qp_delta_nonzero = 0;
     commit_mb(d);
-    h264i_recon_mb(d);
+    if (!d->parse_only) h264i_recon_mb(d);
     return 0;
   }
 
@@ -1361,7 +1488,8 @@ static int code_mb(Rd* r, int addr) {
       m->i16_mode = (intra_t - 1) & 3;
       m->cbp = (((intra_t - 1) >> 2) % 3) << 4 | ((intra_t - 1) >= 12 ? 15 : 0);
     }
-    m->chroma_mode = sx_chroma_pred_mode(r, P ? P->chroma_mode : 0);
+    /* intra_chroma_pred_mode: with ChromaArrayType 1 or 2 only (7.3.5.1) */
+    m->chroma_mode = d->chroma444 ? 0 : sx_chroma_pred_mode(r, P ? P->chroma_mode : 0);
     if (m->chroma_mode > 3 || m->chroma_mode < 0) return h264i_fail(d, "bad intra_chroma_pred_mode");
     d->cur->mb_intra[addr] = 1;
   } else {
@@ -1418,7 +1546,7 @@ static int code_mb(Rd* r, int addr) {
     d->last_qp_delta_nonzero = 0;
   }
   commit_mb(d);
-  h264i_recon_mb(d);
+  if (!d->parse_only) h264i_recon_mb(d);
   return 0;
 }
 
@@ -1480,6 +1608,11 @@ int h264i_decode_slice_data(H264Oracle* d, Bits* b) {
       int ok = t.pos > 0 && ((t.buf[(t.pos - 1) >> 3] >> (7 - ((t.pos - 1) & 7))) & 1);
       while (ok && t.pos < t.size_bits)
         if (get_bit(&t)) ok = 0;
+      /* Parse-only mode (foreign encoders): x264 ends a slice with a flush of its own - the arithmetic codeword is
+       * padded to the byte boundary and a pseudo-random bit follows (cabac.c: x264_cabac_encode_flush), so up to a
+       * byte of unread bits may lie between the decoder's position and the NAL unit's last set bit.  A decoder that
+       * had lost sync would not end on the picture's last macroblock within eight bits of the end of the NAL unit. */
+      if (!ok && d->parse_only && !b->overrun && b->size_bits - b->pos <= 8) ok = 1;
       if (ok && !b->overrun) d->counters[1]++;
     }
     return 0;

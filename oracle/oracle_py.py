@@ -25,6 +25,7 @@ def load():
     lib.h264o_error.argtypes = [C.c_void_p]
     lib.h264o_error.restype = C.c_char_p
     lib.h264o_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.h264o_set_parse_only.argtypes = [C.c_void_p, C.c_int]
     lib.h264o_coverage_enable.argtypes = [C.c_void_p]
     lib.h264o_coverage.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.c_int]
     lib.h264o_yuv420_to_rgb24.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
@@ -44,11 +45,13 @@ COV_CELLS = _off
 
 
 class OracleDecoder(object):
-    def __init__(self, extradata, coverage=False):
+    def __init__(self, extradata, coverage=False, parse_only=False):
         self.lib = load()
         self.h = self.lib.h264o_open()
         if coverage:
             self.lib.h264o_coverage_enable(self.h)
+        if parse_only:   # syntax and entropy decoding only, nothing reconstructed; accepts 4:4:4 (h264_oracle.h)
+            self.lib.h264o_set_parse_only(self.h, int(parse_only))   # (2: without the old-x264 emulation)
         extradata = bytes(extradata)
         if self.lib.h264o_configure(self.h, extradata, len(extradata)):
             raise RuntimeError("oracle configure: " + self.error())
@@ -117,13 +120,13 @@ def i420_to_rgb(i420, w, h):
     return rgb
 
 
-def decode_file(path, index, first=0, count=None, coverage=None):
+def decode_file(path, index, first=0, count=None, coverage=None, parse_only=False):
     """Sequentially decodes samples [first, first+count) of an indexed MP4;
     returns frames in display order.  `coverage`: an int64 array of COV_CELLS
     cells that this decode's histogram is added to."""
     offs, sizes = index.sample_offsets(), index.sample_sizes()
     n = index.frames() if count is None else count
-    dec = OracleDecoder(index.metadata_bytes(), coverage=coverage is not None)
+    dec = OracleDecoder(index.metadata_bytes(), coverage=coverage is not None, parse_only=parse_only)
     frames = []
     with open(path, "rb") as f:
         for i in range(first, first + n):

@@ -20,7 +20,7 @@ from tests.util import ROOT
 CSRC = os.path.join(ROOT, "hwang_amd", "csrc")
 SOURCES = [os.path.join(ROOT, "tests", "sanitize", "san_main.cpp")] + [os.path.join(CSRC, f) for f in (
     "retriever.cpp", "decoder_automata.cpp", "registered_backend.cpp", "video_decoder_factory.cpp", "video_index.cpp",
-    "mp4_index_creator.cpp", "h264/h264_parser.cpp", "h264/h264_cabac_init.cpp", "capi_probe.cpp")]
+    "mp4_index_creator.cpp", "h264/h264_parser.cpp", "h264/h264_cabac_init.cpp", "hevc/hvcc.cpp", "capi_probe.cpp")]
 
 
 def build(tmp_path, name, flags):

@@ -15,6 +15,6 @@ idx.sample_offsets_np().astype(np.uint64).tofile("offs.bin")
 idx.sample_sizes_np().astype(np.uint64).tofile("sizes.bin")
 PY
 g++ -O3 -march=x86-64-v3 -g -no-pie -std=c++17 -I$ROOT/include -I$ROOT/hwang_amd/csrc probe_main.cpp $ROOT/hwang_amd/csrc/capi_probe.cpp \
-    $ROOT/hwang_amd/csrc/h264/h264_parser.cpp $ROOT/hwang_amd/csrc/h264/h264_cabac_init.cpp -o probe_prof
+    $ROOT/hwang_amd/csrc/h264/h264_parser.cpp $ROOT/hwang_amd/csrc/h264/h264_cabac_init.cpp $ROOT/hwang_amd/csrc/hevc/hvcc.cpp -o probe_prof
 HWANG_PROBE_FAST=1 ./probe_prof "$CLIP" ${2:-20}
 addr2line -f -C -e probe_prof $(cat samples.txt | tr '\n' ' ') 2>/dev/null | awk 'NR%2==1' | sed 's/hwang::h264::Parser::Impl:://; s/hwang::h264::(anonymous namespace):://; s/(.*//' | sort | uniq -c | sort -rn | head -30
