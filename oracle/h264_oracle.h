@@ -15,8 +15,12 @@
  * reconstruction arithmetic (interpolation, weighted prediction, in-loop
  * filter, transforms, intra and motion-vector prediction) is also checked
  * against numpy / Python restatements written from the clauses
- * (tests/test_*_independent.py) - not the entropy tables, which nothing here
- * can check.
+ * (tests/test_*_independent.py).  The entropy tables and the slice-data syntax
+ * are checked by two foreign encoders' streams ending every slice where they
+ * must: realshort.mp4 (decoded) and, since round 4, cockatoo.mp4 - B slices,
+ * weighted prediction, 8x8 transform - in the parse-only mode below
+ * (tests/test_oracle_realstream.py).  No decoded SAMPLE has ever been compared
+ * with FFmpeg's: that is what "unpinned" means here.
  */
 #ifndef ORACLE_H264_ORACLE_H_
 #define ORACLE_H264_ORACLE_H_
