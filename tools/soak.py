@@ -63,17 +63,19 @@ if int(os.environ.get("WORKERS", 1)):
     import hwang
     ridx = hwang.VideoIndex.deserialize(idx.serialize())
     ref_host = out.cpu().numpy()   # the last round above was identical to the reference, or counted as bad
-    for workers in (16, 4):
+    # (1, 0): the reference's unmodified caller - one interval per initialize, the backend's own workers, the pictures
+    # of a GOP as chain launches (k_chain); the others: the grouped caller through the wide kernels
+    for workers, group in ((1, 0), (16, int(os.environ.get("GROUP_MB", 16)) << 20), (4, int(os.environ.get("GROUP_MB", 16)) << 20)):
         rdec = hwang.Decoder(path, video_index=ridx, device_type=hwang.DeviceType.GPU, num_devices=workers,
-                             interval_group_bytes=int(os.environ.get("GROUP_MB", 16)) << 20)
+                             interval_group_bytes=group)
         for r in range(ROUNDS):
             frames = rdec.retrieve(rows)
             wrong = [i for i, f in enumerate(frames) if not np.array_equal(f, ref_host[i])]
             if wrong:
                 bad += 1
-                print("MISMATCH workers %d round %d: frames %s" % (workers, r, wrong[:10]))
+                print("MISMATCH workers %d group %d round %d: frames %s" % (workers, group, r, wrong[:10]))
             del frames
-        print("workers %d: %d rounds done" % (workers, ROUNDS))
+        print("workers %d, interval groups of %d bytes: %d rounds done" % (workers, group, ROUNDS))
         del rdec
 print("soak: %s" % ("OK, every round identical" if bad == 0 else "%d rounds differ" % bad))
 sys.exit(1 if bad else 0)
