@@ -479,8 +479,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.desc.do_intra = d.has_intra;
     sub.desc.do_deblock = d.any_deblock;
     sub.desc.do_mv = d.mv_deferred;
-    static const bool inject = getenv("HWANG_INJECT_FAULT") != nullptr;  // tests/test_gpu_decode.py: the fault path
-    sub.desc.inject_fault = inject ? 1 : 0;
+    // tests/test_gpu_decode.py, test_gpu_chain.py: the fault paths (1: k_deblock withholds a band hand-off word; 2: a
+    // chain launch's inter waves withhold one run's bit)
+    static const int inject = getenv("HWANG_INJECT_FAULT") ? std::max(1, atoi(getenv("HWANG_INJECT_FAULT"))) : 0;
+    sub.desc.inject_fault = static_cast<uint32_t>(inject);
     sub.num_mbs = static_cast<int>(nmb);
     sub.heavy = (d.has_intra && !d.has_inter) ? 1 : 0;
     sub.num_intra_mbs = d.num_intra_mbs;

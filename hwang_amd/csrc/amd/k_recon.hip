@@ -2306,7 +2306,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
   if (wave == 0 && band == 0 && lane == 0) G.progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
   int seen = 0;  // importing: macroblocks of the row above known to be final
   // test hook: a band whose progress words carry a wrong tag looks exactly like a band that never reports
-  const uint64_t epoch_out = job.inject_fault ? epoch ^ (1ull << 63) : epoch;
+  const uint64_t epoch_out = job.inject_fault == 1 ? epoch ^ (1ull << 63) : epoch;
   auto import_wait = [&](int need) {
     for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
       const uint64_t v = agent_ld64(&ctl->db_prog[band - 1]);
@@ -2857,7 +2857,8 @@ __global__ __launch_bounds__((kBandWaves + kChainInterWaves) * 64) void k_chain(
       }
       // the run's samples have landed (they were stored write-through): say so
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0)
+      // (test hook, HWANG_INJECT_FAULT=2: one run of the picture never reports - what a lost hand-off would look like)
+      if (lane == 0 && !(job.inject_fault == 2 && row == ip.mb_height / 2 && j == 0))
         __hip_atomic_fetch_or((HW_AS1 uint64_t*)&static_cast<BandCtl*>(job.band_ctl)->inter_mask[row], 1ull << j, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_AGENT);
     }

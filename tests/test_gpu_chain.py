@@ -96,3 +96,23 @@ def test_serial_decoder_chains(tmp_path):
     assert "chain launches" in log
     want, _ = run_worker(tmp_path, [{"path": path, "width": 640, "height": 368, "rows": rows, "lanes": 2, "rgb": True}], {"HWANG_CHAIN": "0"})
     assert got == want
+
+
+def test_lost_chain_hand_off_fails_the_request_quickly(tmp_path):
+    """A chain launch in which one run of inter macroblocks never reports (test hook HWANG_INJECT_FAULT=2): the stages
+    that wait for it give up after their bounded polls - the first expiry makes the others give up at their next look -
+    the batch's fault word says which hand-off was lost, the request fails with that message and returns within
+    seconds (not after every waiting wave has sat out its own bound)."""
+    import time
+    path = str(tmp_path / "fault.mp4")
+    make_clip(path, width=640, height=368, yuv=False, frames=12, gop=12, bframes=0, refs=2)
+    spec = str(tmp_path / "spec.json")
+    with open(spec, "w") as f:
+        json.dump({"clips": [{"path": path, "width": 640, "height": 368, "rows": None, "lanes": 1}]}, f)
+    env = dict(os.environ, HWANG_CHAIN="1", HWANG_INJECT_FAULT="2")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_chain_worker.py"), spec], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "RESULT" not in r.stdout
+    assert "k_chain: inter macroblocks that a row waits for never landed" in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 120
