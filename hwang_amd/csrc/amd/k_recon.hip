@@ -571,6 +571,16 @@ __device__ __forceinline__ void chain_dbg(uint32_t code, int a, int b) {
     __hip_atomic_store((HW_AS1 uint32_t*)&g_chain_dbg[blockIdx.x * 8 + (threadIdx.x >> 6)], code << 24 | (static_cast<uint32_t>(a) & 0xfff) << 12 | (static_cast<uint32_t>(b) & 0xfff),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+#ifdef EXP_STAMPS
+// Experiment (tools/experiments/exp_stamps.py): where one wave's time goes inside a row kernel - s_memtime at up to 8
+// points per macroblock of ONE row of the first picture of the launch.
+__device__ uint64_t g_stamps[256 * 8];
+#define STAMP(on, mb, slot) do { if ((on) && (threadIdx.x & 63) == 0 && (mb) < 256) g_stamps[(mb) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP_VALUE(on, mb, v) do { if ((on) && (threadIdx.x & 63) == 0 && (mb) < 256) g_stamps[(mb) * 8 + 7] = (v); } while (0)
+#else
+#define STAMP(on, mb, slot) do { } while (0)
+#define STAMP_VALUE(on, mb, v) do { } while (0)
+#endif
 __device__ __forceinline__ bool fault_seen() {
   return __hip_atomic_load((const HW_AS1 uint32_t*)&g_fault_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
 }
@@ -1135,28 +1145,27 @@ struct IntraWaveLds {
 // raster-order chain as intra prediction: a wave per macroblock row, four
 // rows per workgroup, neighbours handed on through LDS (the previous
 // macroblock's right column, a line buffer with every macroblock's bottom
-// row) and, between workgroups, through tagged words in global memory.  The chain itself is scalar work: lane 0 walks the partitions,
-// the other lanes move data.  Pictures wider than kLineMbs macroblocks are
+// row) and, between workgroups, through tagged words in global memory.
+// Pictures wider than kLineMbs macroblocks are
 // derived on the host instead (h264_parser: PicBuffers::device_mv).
 // ===========================================================================
 namespace {
-struct MvEdge {        // what a neighbour below / to the right needs of a macroblock
-  uint32_t mv[4];      // packed (x, y) of four 4x4 blocks
-  int8_t ref[2];       // reference index of the two 8x8 quadrants they lie in (-1: intra / unused)
-  int8_t pad[2];
+struct MvEdge {        // what a neighbour below / to the right needs of a macroblock: five dwords
+  uint32_t mv[4];      // packed (x, y) of four 4x4 blocks; 0 where the block has no reference (intra)
+  uint32_t refs;       // reference index of the two 8x8 quadrants they lie in, one byte each (-1: intra / unused)
 };
-struct MvNb {
-  int ref;             // -2 not available, -1 intra or list unused, >= 0 reference index
-  int x, y;
+struct MvCell {        // one 4x4 block as a neighbour
+  uint32_t mv;         // packed (x, y); 0 unless ref >= 0
+  int ref;             // -2 not available (outside the slice / picture, or later in decoding order), -1 intra or list unused, >= 0
 };
 constexpr int kMvChunk = 4;  // macroblocks whose records travel together (prefetch distance)
 // A picture's rows are spread over workgroups ("bands") of kMvWaves rows, one
 // wave per row.  Inside a band rows hand on through LDS; the last row of a
-// band exports its line to MvCtl in global memory and the first row of the
-// next band imports it.  Measured on the skeleton
+// band exports its line to MvCtl in global memory and the band below imports it.
+// Measured on the skeleton
 // (tools/experiments/rowpipe_bands.hip): a picture takes ~mb_width + 2 *
 // mb_height steps instead of ~mb_width * mb_height / 16, and a step is as fast
-// as a lone wave's because at most one wave sits on each SIMD.
+// as a lone wave's because at most one row wave sits on each SIMD.
 //
 // Hand-off words carry their own validity: every 32-bit datum travels as a
 // 64-bit store {datum, JobDesc::mv_epoch}, which is single-copy atomic, so the
@@ -1164,24 +1173,55 @@ constexpr int kMvChunk = 4;  // macroblocks whose records travel together (prefe
 // consumer needs one round trip, not two (the scheme of low-latency collective
 // protocols).  Nothing is cleared between pictures: a slot left over from an
 // earlier picture carries an earlier epoch.
+//
+// What a step costs (round 4, s_memtime stamps inside the kernel: tools/experiments/exp_stamps.py): a lone wave issues
+// an instruction every four to five clocks WHATEVER unit executes it, so the step is the number of instructions on
+// the macroblock's path and nothing else - moving the prediction to the scalar unit (round 2) had bought nothing,
+// its branches cost.  The path is therefore written without branches on values: neighbours as {vector, reference}
+// cells with the availability folded into the reference (-2), vectors packed (x, y) and compared / selected /
+// medianed as such (v_pk_min_i16 / v_pk_max_i16), every lane computing the same prediction; partitioned macroblocks
+// gather their surroundings into a 6 x 5 grid of cells in LDS once and index it.  No store follows a load in the
+// row waves' queue conditionally, so the wait for the prefetched records is a count, not a drain.
 constexpr int kMvWaves = kBandWaves;
+constexpr int kMvGridW = 6;  // cells of rows -1 .. 3, columns -1 .. 4 around / inside the macroblock
 struct MvWaveLds {
-  uint32_t mv[kMvChunk][16];  // the vectors of a partitioned macroblock while they are derived
-  uint32_t x[64];             // the chunk's window of the extra-difference stream
-  uint32_t ref[kMvChunk];     // ref_idx[0][0..3]
-  uint32_t info[kMvChunk];    // nz_mask | mv_flags << 16 | mv_shape << 24
-  uint32_t kind[kMvChunk];    // kind | flags << 8 | ...
-  uint32_t sub[kMvChunk];
-  MvEdge left;                // right column (blocks 3, 7, 11, 15; quadrants 1, 3) of the previous macroblock
+  uint32_t x[64];                  // the chunk's window of the extra-difference stream
+  alignas(8) MvCell grid[32];      // [(y + 1) * kMvGridW + x + 1]
+  uint32_t left[8];                // MvEdge of the previous macroblock's right column (blocks 3, 7, 11, 15; quadrants 1, 3)
 };
-// decode-order index of the 4x4 block at raster position (x, y) of a macroblock
-__device__ __forceinline__ int zz_of(int x, int y) { return ((y >> 1) << 3) | ((x >> 1) << 2) | ((y & 1) << 1) | (x & 1); }
-__device__ __forceinline__ int med3(int a, int b, int c) {
-  return a > b ? (b > c ? b : (a > c ? c : a)) : (a > c ? a : (b > c ? c : b));
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ uint32_t pk_add_u16(uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// 8.4.1.3: the prediction for a partition with reference `ref` from its neighbours A (left), B (top), C (top-right, or
+// top-left where that one is not available); dir: 0 median, 1 16x8 top, 2 16x8 bottom, 3 8x16 left, 4 8x16 right.
+__device__ __forceinline__ uint32_t mv_predict(const MvCell A, const MvCell B, const MvCell C, int ref, int dir) {
+  const bool ea = A.ref == ref, eb = B.ref == ref, ec = C.ref == ref;
+  const int matches = static_cast<int>(ea) + static_cast<int>(eb) + static_cast<int>(ec);
+  const uint32_t lo = pk_min_i16(A.mv, B.mv), hi = pk_max_i16(A.mv, B.mv);
+  const uint32_t median = pk_max_i16(lo, pk_min_i16(hi, C.mv));
+  const uint32_t the_one = ea ? A.mv : (eb ? B.mv : C.mv);
+  const bool only_a = matches == 0 && B.ref == -2 && C.ref == -2 && A.ref != -2;
+  uint32_t p = matches == 1 ? the_one : (only_a ? A.mv : median);
+  p = (dir == 1 && eb) ? B.mv : p;
+  p = ((dir == 2 || dir == 3) && ea) ? A.mv : p;
+  p = (dir == 4 && ec) ? C.mv : p;
+  return p;
 }
 }  // namespace
 
-__global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs, int njobs) {
+__global__ __launch_bounds__((kMvWaves + 1) * 64) void k_mv(JobDesc* __restrict__ jobs, int njobs) {
   // Bands are handed out by ticket, band-major: whoever holds band b of a
   // picture started after the holder of band b - 1, so a poll below never waits
   // for a workgroup that is not running yet - whatever order the dispatcher
@@ -1193,62 +1233,85 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
   if (threadIdx.x == 0) s_ticket = atomicAdd(&jobs[0].ticket_mv, 1u);
   if (threadIdx.x <= kMvWaves) s_progress[threadIdx.x] = 0;
   __syncthreads();
-  const int band = static_cast<int>(s_ticket) / njobs;
-  const JobDesc& job = jobs[static_cast<int>(s_ticket) % njobs];
+  const int ticket = __builtin_amdgcn_readfirstlane(static_cast<int>(s_ticket));
+  const int band = ticket / njobs;
+  const JobDesc& job = jobs[ticket % njobs];
   if (!job.do_mv) return;
   const PictureParams& pp = job.pp;
   const MbInfo* __restrict__ mbs = job.mbs;
   MbMotion* __restrict__ motions = const_cast<MbMotion*>(job.motions);
   const PMotion* __restrict__ pmos = job.pmo;
   const uint32_t* __restrict__ pmx = job.pmx;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int mby = band * kMvWaves + wave;
-  if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
-  lds_counter* progress = (lds_counter*)s_progress;
-  MvWaveLds& L = s_lds[wave];
-  const MvEdge* line_up = wave == 0 ? s_line[kMvWaves] : s_line[wave - 1];
-  MvEdge* line_me = s_line[wave];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int W = pp.mb_width;
   BandCtl* ctl = static_cast<BandCtl*>(job.band_ctl);
   const uint32_t epoch = job.epoch;
-  const bool importing = wave == 0 && band > 0;
-  const bool exporting = wave == kMvWaves - 1 && mby + 1 < pp.mb_height;
-  int seen = 0;  // macroblocks of the row above whose edges are in s_line[kMvWaves]
-  // First row of a band: fetch the next eight entries of the band above (lane ->
-  // entry lane >> 3, word lane & 7), keep the complete ones in front of the first
-  // missing word - in LDS, where the code below finds them like any other row's
-  // - and repeat until `need` macroblocks are there.  Whatever else has arrived
-  // comes along, so a consumer that has fallen behind catches up in one round
-  // trip.  A poll that never succeeds (cannot happen by construction) ends in
-  // wrong vectors, not in a hung GPU.
-  auto import_until = [&](int need) {
-    if (seen >= need) return;
+  lds_counter* progress = (lds_counter*)s_progress;
+  if (wave == kMvWaves) {
+    // The band's IMPORTER.  The line of the band above comes from global memory, a round trip of a microsecond or more
+    // per look; this wave does nothing but look: the next eight entries of the band above (lane -> entry lane >> 3,
+    // word lane & 7), the complete ones in front of the first missing word go to LDS - where the band's first row
+    // finds them like any other row finds the row above - and the counter that row waits on follows.  Whatever else
+    // has arrived comes along.  A poll that never succeeds (cannot happen by construction) is reported and the
+    // counter released: wrong vectors and a failed request, not a hung GPU.
+    if (band == 0 || band * kMvWaves >= pp.mb_height) return;
     const uint64_t* src = ctl->lines + static_cast<size_t>(band - 1) * kLineMbs * kMvLineWords;
-    for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
+    int seen = 0;  // macroblocks of the row above whose edges are in s_line[kMvWaves]
+    for (int tries = 0; tries < (1 << 21) && seen < W; ++tries) {
       const int e = seen + (lane >> 3), d = lane & 7;
       const bool act = d < 5 && e < W;
       uint64_t v = 0;
       if (act) v = agent_ld64(src + e * 5 + d);
       const uint64_t missing = __ballot(act && static_cast<uint32_t>(v >> 32) != epoch);
       const int nvalid = min(missing ? __builtin_ctzll(missing) >> 3 : 8, W - seen);
-      if (act && (lane >> 3) < nvalid) reinterpret_cast<uint32_t*>(&s_line[kMvWaves][e])[d] = static_cast<uint32_t>(v);
-      seen += nvalid;
-      if (seen < need) __builtin_amdgcn_s_sleep(1);
+      if (nvalid) {
+        if (act && (lane >> 3) < nvalid) reinterpret_cast<uint32_t*>(&s_line[kMvWaves][e])[d] = static_cast<uint32_t>(v);
+        seen += nvalid;
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        progress[0] = seen;
+      } else {
+        __builtin_amdgcn_s_sleep(1);
+      }
     }
-    if (seen < need) {
+    if (seen < W) {
       report_fault(job, FAULT_MV_IMPORT);
-      seen = need;
+      progress[0] = 1 << 30;
     }
-    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    wave_sync();
-  };
+    return;
+  }
+  const int mby = band * kMvWaves + wave;
+  if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
+  MvWaveLds& L = s_lds[wave];
+  const uint32_t* up = reinterpret_cast<const uint32_t*>(wave == 0 ? s_line[kMvWaves] : s_line[wave - 1]);  // 5 dwords a macroblock
+  uint32_t* line_me = reinterpret_cast<uint32_t*>(s_line[wave]);
+  const bool exporting = wave == kMvWaves - 1 && mby + 1 < pp.mb_height;
+  const int export_lanes = exporting ? 5 : 0;
   if (wave == 0 && band == 0 && lane == 0) s_progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
+
+  // ---- what a lane is in the 6 x 5 grid of a partitioned macroblock's surroundings (lanes 0 .. 29), fixed for the row:
+  // which neighbour supplies the cell, where in the line above / the left column its vector and reference byte are
+  const int g_row = lane / kMvGridW, g_col = lane % kMvGridW;
+  int g_flag = 0;        // the MVF_AVAIL_* bit that makes the cell available (0: never - inside / right of the macroblock)
+  int g_up = 0;          // row 0: dword of `up` relative to 5 * mbx that holds the vector
+  int g_up_refs = 4;     //        ... and the one with the reference bytes
+  int g_shift = 0;       // which byte of it
+  if (lane < 30) {
+    if (g_row == 0) {
+      if (g_col == 0) { g_flag = MVF_AVAIL_D; g_up = -5 + 3; g_up_refs = -5 + 4; g_shift = 8; }
+      else if (g_col == 5) { g_flag = MVF_AVAIL_C; g_up = 5; g_up_refs = 5 + 4; g_shift = 0; }
+      else { g_flag = MVF_AVAIL_B; g_up = g_col - 1; g_up_refs = 4; g_shift = 8 * ((g_col - 1) >> 1); }
+    } else if (g_col == 0) {
+      g_flag = MVF_AVAIL_A;
+      g_shift = 8 * ((g_row - 1) >> 1);
+    }
+  }
+  // lanes 0 .. 35 of the MbMotion record (36 dwords: vectors of list 0, list 1 unused, surfaces, indices)
+  const bool rec_vec = lane < 16, rec_slot = lane == 32, rec_ref = lane == 34, rec_ones = lane == 33 || lane == 35;
 
   {
     // Records travel kMvChunk macroblocks at a time, one chunk ahead: a single
     // macroblock of lead is less than the memory latency once the per-macroblock
-    // work is down to a fraction of a microsecond.  lane -> (macroblock lane >> 4,
-    // block lane & 15) for the vectors, lanes 0..3 one macroblock each for the rest.
+    // work is down to a fraction of a microsecond.  Lanes 0..3 hold one macroblock each.
     // The macroblocks' motion arrives as PMotion (12 B: reference indices, their surfaces, the first
     // difference) plus, for partitioned macroblocks, further differences in the row's extra stream; a
     // 64-word window of that stream travels with every chunk.
@@ -1283,22 +1346,17 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
     };
     prefetch(0, xptr);
     asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_slot), "+v"(n_info), "+v"(n_kind), "+v"(n_sub), "+v"(n_x));
-    int left_ref0 = -1;         // left neighbour's top-right quadrant: reference index ...
-    uint32_t left_mv0 = 0;      // ... and the vector of its block 3 (registers; L.left is the LDS copy for the general path)
+    int left_ref = -1;        // left neighbour's top-right quadrant: reference index ...
+    uint32_t left_mv = 0;     // ... and the vector of its block 3 (registers; L.left is the LDS copy for partitioned macroblocks)
+    uint32_t* out = reinterpret_cast<uint32_t*>(motions + mby * W) + lane;  // this lane's dword of the row's first record
     for (int mbx0 = 0; mbx0 < W; mbx0 += kMvChunk) {
       L.x[lane] = n_x;
-      if (lane < kMvChunk) {
-        L.ref[lane] = n_ref;
-        L.info[lane] = n_info;
-        L.kind[lane] = n_kind;
-        L.sub[lane] = n_sub;
-      }
       // the chunk's records stay in these registers (lane k holds macroblock k's
-      // words): readlane hands them to the scalar unit without an LDS round trip
+      // words): readlane hands them on without an LDS round trip
       const uint32_t c_info = n_info, c_kind = n_kind, c_sub = n_sub, c_ref = n_ref, c_slot = n_slot, c_mv = n_mv;
-      // where the next chunk's extras start: behind this chunk's
       uint32_t xo = 0;  // extras of this chunk consumed so far (index into L.x)
       {
+        // where the next chunk's extras start: behind this chunk's
         const uint32_t e = (lane < kMvChunk && mbx0 + lane < W) ? extras_of(c_info, c_sub) : 0;
         const uint32_t total = __builtin_amdgcn_readlane(e, 0) + __builtin_amdgcn_readlane(e, 1) + __builtin_amdgcn_readlane(e, 2) +
                                __builtin_amdgcn_readlane(e, 3);
@@ -1308,143 +1366,64 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
       wave_sync();
       for (int k = 0; k < kMvChunk && mbx0 + k < W; ++k) {
         const int mbx = mbx0 + k;
-        const int mbi = mby * W + mbx;
-        // Everything below is wave-uniform arithmetic: what is read from LDS goes
-        // through readfirstlane, so the compiler keeps it in SGPRs and the scalar
-        // unit does the work (one cycle an instruction instead of four, with 16
-        // waves sharing the CU's SIMDs).
+#ifdef EXP_STAMPS
+        const bool st_on = EXP_STAMPS == 1 && ticket % njobs == 0 && mby == EXP_STAMP_ROW;
+#endif
+        STAMP(st_on, mbx, 0);
         const uint32_t info = __builtin_amdgcn_readlane(c_info, k);
         const int flags = (info >> 16) & 0xff, shape = (info >> 24) & 3, sub = __builtin_amdgcn_readlane(c_sub, k);
         const bool intra = (__builtin_amdgcn_readlane(c_kind, k) >> 8) & MBF_INTRA;  // MbInfo::flags is byte 1
         const bool deferred = flags & MVF_DEFERRED;
-        uint32_t* cmv = L.mv[k];
         const uint32_t refw = intra ? 0xffffffffu : __builtin_amdgcn_readlane(c_ref, k);
+        const uint32_t slotw = intra ? 0xffffffffu : __builtin_amdgcn_readlane(c_slot, k);
+        const uint32_t mvd0 = __builtin_amdgcn_readlane(c_mv, k);  // PMotion::mvd0
         auto cref = [&](int b8) { return (int)(int8_t)((refw >> (8 * b8)) & 0xff); };
-        if (deferred && (flags & (MVF_AVAIL_B | MVF_AVAIL_C | MVF_AVAIL_D))) {
-          if (importing) import_until(min(mbx + 2, W));
-          else row_wait(progress, wave, min(mbx + 2, W));
-        }
-        auto unpack_x = [](uint32_t v) { return (int)(int16_t)(v & 0xffff); };
-        auto unpack_y = [](uint32_t v) { return (int)(int16_t)(v >> 16); };
+        if (deferred && (flags & (MVF_AVAIL_B | MVF_AVAIL_C | MVF_AVAIL_D))) row_wait(progress, wave, min(mbx + 2, W));
+        STAMP(st_on, mbx, 1);
         const bool whole = deferred && ((flags & MVF_PSKIP) || shape == 0);
-        uint32_t whole_mv = 0;  // the macroblock's single vector when `whole`
+        // what leaves the macroblock: lanes 0..15 their block's vector, lanes 0..3 the right column's / the bottom
+        // row's; block 3's for the next macroblock's prediction (0 where there is no reference: intra, not derived here)
+        uint32_t blk = 0, right = 0, bottom = 0, block3 = 0;
         if (whole) {
-          // One prediction for the macroblock, from neighbours that all lie outside
-          // it.  The six LDS reads go out together and unconditionally (a value
-          // behind a cleared availability bit is simply not used); the rest is
-          // scalar arithmetic, and the result never passes through LDS.
-          const MvEdge& eb = line_up[mbx];
-          const MvEdge& ec = line_up[min(mbx + 1, W - 1)];
-          const MvEdge& ed = line_up[max(mbx - 1, 0)];
-          const uint32_t vb = eb.mv[0], vc = ec.mv[0], vd = ed.mv[3];
-          const uint32_t wb = *reinterpret_cast<const uint32_t*>(eb.ref), wc = *reinterpret_cast<const uint32_t*>(ec.ref),
-                         wd = *reinterpret_cast<const uint32_t*>(ed.ref);
-          const uint32_t svb = __builtin_amdgcn_readfirstlane(vb), svc = __builtin_amdgcn_readfirstlane(vc),
-                         svd = __builtin_amdgcn_readfirstlane(vd);
-          const int qb = (int)(int8_t)(__builtin_amdgcn_readfirstlane(wb) & 0xff), qc = (int)(int8_t)(__builtin_amdgcn_readfirstlane(wc) & 0xff),
-                    qd = (int)(int8_t)((__builtin_amdgcn_readfirstlane(wd) >> 8) & 0xff);
-          int ra = -2, ax = 0, ay = 0, rb = -2, bx = 0, by = 0, rc = -2, cx = 0, cy = 0;
-          if (flags & MVF_AVAIL_A) {
-            ra = left_ref0 < 0 ? -1 : left_ref0;
-            if (left_ref0 >= 0) { ax = unpack_x(left_mv0); ay = unpack_y(left_mv0); }
-          }
-          if (flags & MVF_AVAIL_B) {
-            rb = qb < 0 ? -1 : qb;
-            if (qb >= 0) { bx = unpack_x(svb); by = unpack_y(svb); }
-          }
-          if (flags & MVF_AVAIL_C) {
-            rc = qc < 0 ? -1 : qc;
-            if (qc >= 0) { cx = unpack_x(svc); cy = unpack_y(svc); }
-          } else if (flags & MVF_AVAIL_D) {
-            rc = qd < 0 ? -1 : qd;
-            if (qd >= 0) { cx = unpack_x(svd); cy = unpack_y(svd); }
-          }
+          // One prediction for the macroblock, from neighbours that all lie outside it.  The LDS reads go out together
+          // and unconditionally (a value behind a cleared availability bit is simply not used).
+          const int xc = min(mbx + 1, W - 1), xd = max(mbx - 1, 0);
+          const uint32_t b_mv = up[5 * mbx], b_refs = up[5 * mbx + 4];
+          const uint32_t c_mvw = up[5 * xc], c_refs = up[5 * xc + 4];
+          const uint32_t d_mvw = up[5 * xd + 3], d_refs = up[5 * xd + 4];
+          const bool av_a = flags & MVF_AVAIL_A, av_b = flags & MVF_AVAIL_B, av_c = flags & MVF_AVAIL_C, av_d = flags & MVF_AVAIL_D;
+          MvCell A, B, C;
+          A.ref = av_a ? max(left_ref, -1) : -2;
+          A.mv = av_a ? left_mv : 0u;
+          B.ref = av_b ? max((int)(int8_t)(b_refs & 0xff), -1) : -2;
+          B.mv = av_b ? b_mv : 0u;
+          const int c_ref_ = max((int)(int8_t)(c_refs & 0xff), -1), d_ref_ = max((int)(int8_t)((d_refs >> 8) & 0xff), -1);
+          C.ref = av_c ? c_ref_ : (av_d ? d_ref_ : -2);
+          C.mv = av_c ? c_mvw : (av_d ? d_mvw : 0u);
           const bool skip = flags & MVF_PSKIP;
-          const int ref = skip ? 0 : cref(0);
-          int mx, my;
-          const int match = (ra == ref) + (rb == ref) + (rc == ref);
-          if (match == 1) {
-            mx = ra == ref ? ax : (rb == ref ? bx : cx);
-            my = ra == ref ? ay : (rb == ref ? by : cy);
-          } else if (match == 0 && rb == -2 && rc == -2 && ra != -2) {
-            mx = ax;
-            my = ay;
-          } else {
-            mx = med3(ax, bx, cx);
-            my = med3(ay, by, cy);
-          }
-          if (skip) {
-            if (ra == -2 || rb == -2 || (ra == 0 && ax == 0 && ay == 0) || (rb == 0 && bx == 0 && by == 0)) mx = my = 0;
-          } else {
-            const uint32_t d = __builtin_amdgcn_readlane(c_mv, k);  // PMotion::mvd0
-            mx += unpack_x(d);
-            my += unpack_y(d);
-          }
-          whole_mv = (uint32_t)(uint16_t)mx | ((uint32_t)(uint16_t)my << 16);
+          const uint32_t pred = mv_predict(A, B, C, skip ? 0 : cref(0), 0);
+          const bool zero = A.ref == -2 || B.ref == -2 || (A.ref == 0 && A.mv == 0) || (B.ref == 0 && B.mv == 0);
+          const uint32_t whole_mv = skip ? (zero ? 0u : pred) : pk_add_u16(pred, mvd0);
+          blk = right = bottom = block3 = whole_mv;
         } else if (deferred) {
-          auto sref = [](const int8_t& r) { return (int)(int8_t)__builtin_amdgcn_readfirstlane((uint32_t)(uint8_t)r); };
-          auto fetch = [&](int rx, int ry, int cur_zz) -> MvNb {
-            MvNb nb = {-2, 0, 0};
-            if (rx > 3 && ry >= 0) return nb;
-            int ref;
-            uint32_t v;
-            if (rx >= 0 && rx <= 3 && ry >= 0) {
-              if (zz_of(rx, ry) >= cur_zz) return nb;
-              ref = cref((ry >> 1) * 2 + (rx >> 1));
-              v = __builtin_amdgcn_readfirstlane(cmv[ry * 4 + rx]);
-            } else if (ry >= 0) {  // left neighbour
-              if (!(flags & MVF_AVAIL_A)) return nb;
-              ref = sref(L.left.ref[ry >> 1]);
-              v = __builtin_amdgcn_readfirstlane(L.left.mv[ry]);
-            } else if (rx < 0) {   // top-left
-              if (!(flags & MVF_AVAIL_D)) return nb;
-              ref = sref(line_up[mbx - 1].ref[1]);
-              v = __builtin_amdgcn_readfirstlane(line_up[mbx - 1].mv[3]);
-            } else if (rx <= 3) {  // top
-              if (!(flags & MVF_AVAIL_B)) return nb;
-              ref = sref(line_up[mbx].ref[rx >> 1]);
-              v = __builtin_amdgcn_readfirstlane(line_up[mbx].mv[rx]);
-            } else {               // top-right
-              if (!(flags & MVF_AVAIL_C)) return nb;
-              ref = sref(line_up[mbx + 1].ref[0]);
-              v = __builtin_amdgcn_readfirstlane(line_up[mbx + 1].mv[0]);
-            }
-            nb.ref = -1;
-            if (ref < 0) return nb;
-            nb.ref = ref;
-            nb.x = unpack_x(v);
-            nb.y = unpack_y(v);
-            return nb;
-          };
-          // dir: 0 median, 1 16x8 top, 2 16x8 bottom, 3 8x16 left, 4 8x16 right
-          auto predict = [&](int bx, int by, int bw, int ref, int dir, int& ox, int& oy) {
-            const int zz = zz_of(bx, by);
-            const MvNb A = fetch(bx - 1, by, zz);
-            const MvNb B = fetch(bx, by - 1, zz);
-            MvNb C = fetch(bx + bw, by - 1, zz);
-            if (C.ref == -2) C = fetch(bx - 1, by - 1, zz);
-            int pick = -1;  // 0 A, 1 B, 2 C
-            if (dir == 1 && B.ref == ref) pick = 1;
-            if (dir == 2 && A.ref == ref) pick = 0;
-            if (dir == 3 && A.ref == ref) pick = 0;
-            if (dir == 4 && C.ref == ref) pick = 2;
-            if (pick < 0) {
-              const int match = (A.ref == ref) + (B.ref == ref) + (C.ref == ref);
-              if (match == 1) pick = A.ref == ref ? 0 : (B.ref == ref ? 1 : 2);
-              else if (match == 0 && B.ref == -2 && C.ref == -2 && A.ref != -2) pick = 0;
-            }
-            if (pick == 0) { ox = A.x; oy = A.y; }
-            else if (pick == 1) { ox = B.x; oy = B.y; }
-            else if (pick == 2) { ox = C.x; oy = C.y; }
-            else { ox = med3(A.x, B.x, C.x); oy = med3(A.y, B.y, C.y); }
-          };
-          auto fill = [&](int bx, int by, int bw, int bh, int mvx, int mvy) {
-            const uint32_t packed = (uint32_t)(uint16_t)mvx | ((uint32_t)(uint16_t)mvy << 16);
-            for (int yy = by; yy < by + bh; ++yy)
-              for (int xx = bx; xx < bx + bw; ++xx) cmv[yy * 4 + xx] = packed;
-          };
+          // ---- the surroundings, one cell a lane
+          if (lane < 30) {
+            // (the cells of neighbours that do not exist - left of the first, right of the last macroblock - read some
+            // word of the line: their availability bit is clear)
+            const int last = 5 * W - 1;
+            const uint32_t t_mv = up[min(max(5 * mbx + g_up, 0), last)], t_refs = up[min(max(5 * mbx + g_up_refs, 0), last)];
+            const uint32_t l_mv = L.left[(g_row - 1) & 3], l_refs = L.left[4];
+            const bool top = g_row == 0;
+            const bool avail = (flags & g_flag) != 0;
+            const int r = max((int)(int8_t)(((top ? t_refs : l_refs) >> g_shift) & 0xff), -1);
+            MvCell c;
+            c.ref = avail ? r : -2;
+            c.mv = avail ? (top ? t_mv : l_mv) : 0u;
+            L.grid[lane] = c;
+          }
+          wave_sync();
+          int part = 0;  // partitions in decode order: the first difference is mvd0, the others follow in the stream
           const int nparts = shape == 3 ? 4 : 2;  // 16x16 took the path above
-          int part = 0;                           // partitions in decode order: the first difference is mvd0, the others follow in the stream
           for (int i = 0; i < nparts; ++i) {
             int px, py, pw, ph;
             if (shape == 1) { px = 0; py = i * 2; pw = 4; ph = 2; }
@@ -1457,58 +1436,65 @@ __global__ __launch_bounds__(kMvWaves * 64) void k_mv(JobDesc* __restrict__ jobs
               if (ss == 1 || ss == 3) sh = 1;
             }
             const int ref = cref((py >> 1) * 2 + (px >> 1));
+            const int dir = shape == 1 ? (i == 0 ? 1 : 2) : (shape == 2 ? (i == 0 ? 3 : 4) : 0);
             for (int sy = 0; sy < ph; sy += sh)
               for (int sx = 0; sx < pw; sx += sw) {
                 const int bx = px + sx, by = py + sy;
-                int dir = 0;
-                if (shape == 1) dir = i == 0 ? 1 : 2;
-                if (shape == 2) dir = i == 0 ? 3 : 4;
-                int mx, my;
-                predict(bx, by, sw, ref, dir, mx, my);
-                const uint32_t d = part == 0 ? __builtin_amdgcn_readlane(c_mv, k) : __builtin_amdgcn_readfirstlane(L.x[(xo + part - 1) & 63]);
+                // cells: A (bx - 1, by), B (bx, by - 1), C (bx + sw, by - 1), D (bx - 1, by - 1)
+                const int at = (by + 1) * kMvGridW + bx;
+                const MvCell A = L.grid[at], B = L.grid[at - kMvGridW + 1], Cr = L.grid[at - kMvGridW + 1 + sw], D = L.grid[at - kMvGridW];
+                const uint32_t d = part == 0 ? mvd0 : L.x[(xo + part - 1) & 63];
                 ++part;
-                fill(bx, by, sw, sh, mx + unpack_x(d), my + unpack_y(d));
+                MvCell C;
+                C.ref = Cr.ref == -2 ? D.ref : Cr.ref;
+                C.mv = Cr.ref == -2 ? D.mv : Cr.mv;
+                MvCell f;
+                f.mv = pk_add_u16(mv_predict(A, B, C, ref, dir), d);
+                f.ref = ref;
+                const int x = lane & 3, y = (lane >> 2) & 3;
+                if (lane < 16 && x >= bx && x < bx + sw && y >= by && y < by + sh) L.grid[(y + 1) * kMvGridW + x + 1] = f;
+                wave_sync();
               }
           }
           xo += part - 1;
+          blk = L.grid[(((lane >> 2) & 3) + 1) * kMvGridW + (lane & 3) + 1].mv;
+          right = L.grid[((lane & 3) + 1) * kMvGridW + 4].mv;
+          bottom = L.grid[4 * kMvGridW + (lane & 3) + 1].mv;
+          block3 = L.grid[kMvGridW + 4].mv;
         }
         wave_sync();
+        STAMP(st_on, mbx, 2);
         // The prefetched registers have arrived by now; saying so before the store
         // below is issued keeps the next chunk from waiting on that store (in-order
         // vmcnt, see k_deblock).
         if (k == kMvChunk - 1 || mbx == W - 1)
           asm volatile("" : "+v"(n_mv), "+v"(n_ref), "+v"(n_slot), "+v"(n_info), "+v"(n_kind), "+v"(n_sub), "+v"(n_x));
-        // The macroblock's full MbMotion (36 dwords: vectors of list 0, list 1 unused, surfaces, indices) for
-        // k_inter and k_bs - written here for every compact macroblock, intra ones included (no reference).
-        if ((flags & MVF_COMPACT) && lane < 36) {
-          uint32_t v = 0;
-          if (lane < 16) v = deferred ? (whole ? whole_mv : cmv[lane]) : 0;
-          else if (lane == 32) v = intra ? 0xffffffffu : __builtin_amdgcn_readlane(c_slot, k);
-          else if (lane == 34) v = refw;
-          else if (lane == 33 || lane == 35) v = 0xffffffffu;
-          gst32(reinterpret_cast<uint32_t*>(&motions[mbi]) + lane, v);
+        // The macroblock's full MbMotion for k_inter and k_bs - written here for every compact macroblock, intra ones
+        // included (no reference).  (Whether it is written is a matter of the lane mask, not of a branch: see above.)
+        {
+          uint32_t v = rec_vec ? blk : 0u;
+          v = rec_slot ? slotw : v;
+          v = rec_ref ? refw : v;
+          v = rec_ones ? 0xffffffffu : v;
+          if (lane < ((flags & MVF_COMPACT) ? 36 : 0)) gst32(out + mbx * 36, v);
         }
-        if (lane < 4) {
-          line_me[mbx].mv[lane] = whole ? whole_mv : cmv[12 + lane];
-          L.left.mv[lane] = whole ? whole_mv : cmv[lane * 4 + 3];
-        } else if (lane == 4) {
-          line_me[mbx].ref[0] = (int8_t)cref(2);
-          line_me[mbx].ref[1] = (int8_t)cref(3);
-          L.left.ref[0] = (int8_t)cref(1);
-          L.left.ref[1] = (int8_t)cref(3);
+        STAMP(st_on, mbx, 3);
+        const uint32_t refs_bottom = static_cast<uint32_t>(static_cast<uint8_t>(cref(2))) | (static_cast<uint32_t>(static_cast<uint8_t>(cref(3))) << 8);
+        const uint32_t refs_right = static_cast<uint32_t>(static_cast<uint8_t>(cref(1))) | (static_cast<uint32_t>(static_cast<uint8_t>(cref(3))) << 8);
+        if (lane < 5) {
+          line_me[5 * mbx + lane] = lane < 4 ? bottom : refs_bottom;
+          L.left[lane] = lane < 4 ? right : refs_right;
         }
-        left_ref0 = cref(1);
-        left_mv0 = whole ? whole_mv : __builtin_amdgcn_readfirstlane(cmv[3]);
-        if (exporting) {
-          // the band below reads this row's edges from global memory
-          uint64_t* dst = ctl->lines + (static_cast<size_t>(band) * kLineMbs + mbx) * kMvLineWords;
-          const uint32_t refs = static_cast<uint32_t>(static_cast<uint8_t>(cref(2))) | (static_cast<uint32_t>(static_cast<uint8_t>(cref(3))) << 8);
-          if (lane < 5) agent_st64(dst + lane, (static_cast<uint64_t>(epoch) << 32) | (lane < 4 ? (whole ? whole_mv : cmv[12 + (lane & 3)]) : refs));
-          __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        } else {
-          __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          progress[wave + 1] = mbx + 1;
-        }
+        left_ref = cref(1);
+        left_mv = block3;
+        // the band below reads this row's edges from global memory
+        if (lane < export_lanes)
+          agent_st64(ctl->lines + (static_cast<size_t>(band) * kLineMbs + mbx) * kMvLineWords + lane,
+                     (static_cast<uint64_t>(epoch) << 32) | (lane < 4 ? bottom : refs_bottom));
+        __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        progress[wave + 1] = mbx + 1;
+        STAMP(st_on, mbx, 4);
+        STAMP_VALUE(st_on, mbx, (whole ? 1 : 0) | (deferred ? 2 : 0) | (shape << 4));
       }
       wave_sync();  // the chunk buffer is rewritten at the top of the next round
     }
@@ -2440,6 +2426,10 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
       while (todo) {
         const int mbx = mbx0 + __builtin_ctzll(todo);
         todo &= todo - 1;
+#ifdef EXP_STAMPS
+        const bool sd_on = EXP_STAMPS == 2 && !CHAIN && mby == EXP_STAMP_ROW;
+#endif
+        STAMP(sd_on, mbx, 0);
         uint8_t* gy = rowy + mbx * 16;
         uint8_t* gu = rowu + mbx * 8;
         uint8_t* gv = rowv + mbx * 8;
@@ -2494,6 +2484,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
         if (lane < 24) reinterpret_cast<uint32_t*>(&L.db)[lane] = n_db;
         if (todo) prefetch(mbx0 + __builtin_ctzll(todo), mbx0 + __builtin_ctzll(todo) == mbx + 1);
         wave_sync();
+        STAMP(sd_on, mbx, 1);
         // ---- this lane's parameters for all eight edge steps, in registers
         const int emask = L.db.emask;
         const bool top_edge = mby > 0 && (emask & 0x10);
@@ -2525,6 +2516,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
             if (lane < 24) top_word = sld32<CHAIN>(src);
           }
         }
+        STAMP(sd_on, mbx, 2);
         // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each.
         // Edges 0 and 2 touch disjoint samples (x <= 3 and x >= 4), so when the odd edges are not filtered
         // - every macroblock with the 8x8 transform, and many without - both run in ONE step, the second on
@@ -2558,6 +2550,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
           }
           wave_sync();
         }
+        STAMP(sd_on, mbx, 3);
         // ---- the left neighbour's last four columns are final now (only this macroblock's left edge touches them
         // from this row): store them at once, so that by the time this macroblock's progress is published - after
         // its horizontal edges, below - the left neighbour is final IN MEMORY and the row below may filter under it.
@@ -2593,6 +2586,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
           }
           wave_sync();
         }
+        STAMP(sd_on, mbx, 4);
         // ---- horizontal edges: lanes 0..15 one luma column each, 16..31 chroma columns; edges 0 and 2 paired
         // like the vertical ones when edges 1 and 3 are not filtered
         const int hm = ((emask >> 4) & 0xf) & (top_edge ? 0xf : 0xe);
@@ -2626,7 +2620,10 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
         // ---- the previous filtered macroblock's stores have had this whole
         // iteration to land: make sure, then everything before this macroblock
         // is final (skipped ones included)
+        STAMP(sd_on, mbx, 5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(sd_on, mbx, 6);
+        STAMP_VALUE(sd_on, mbx, emask | (top_edge ? 0x100 : 0));
         if (exporting) { if (lane == 0) agent_st64(&ctl->db_prog[band], epoch_out | static_cast<uint32_t>(mbx)); }
         else progress[wave + 1] = mbx;
         publish_fin(mbx);
@@ -2904,6 +2901,11 @@ __global__ __launch_bounds__((kBandWaves + kChainInterWaves) * 64) void k_chain(
 
 }  // namespace amd
 }  // namespace hwang
+#ifdef EXP_STAMPS
+extern "C" int hwang_debug_stamps(uint64_t* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(hwang::amd::g_stamps), sizeof(uint64_t) * 256 * 8, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" int hwang_debug_chain_state(uint32_t* out, int n) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(hwang::amd::g_chain_dbg), sizeof(uint32_t) * (n < 2048 ? n : 2048), 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
 }
@@ -2928,7 +2930,7 @@ hipError_t launch_batch(const JobDesc* jobs, int njobs, int max_mbs, int max_row
   prof::Span span;
   if (any_mv) {
     if (profiled) span = prof::begin(stream);
-    hipLaunchKernelGGL(k_mv, dim3(njobs * ((max_rows + kMvWaves - 1) / kMvWaves)), dim3(kMvWaves * 64), 0, stream,
+    hipLaunchKernelGGL(k_mv, dim3(njobs * ((max_rows + kMvWaves - 1) / kMvWaves)), dim3((kMvWaves + 1) * 64), 0, stream,
                        const_cast<JobDesc*>(jobs), njobs);
     if (profiled) prof::end(span, stream, prof::K_MV, bytes[3]);
   }
@@ -2969,7 +2971,7 @@ hipError_t launch_pre(const JobDesc* jobs, int njobs, int max_mbs, int max_rows,
   prof::Span span;
   if (any_mv) {
     if (profiled) span = prof::begin(stream);
-    hipLaunchKernelGGL(k_mv, dim3(njobs * ((max_rows + kMvWaves - 1) / kMvWaves)), dim3(kMvWaves * 64), 0, stream,
+    hipLaunchKernelGGL(k_mv, dim3(njobs * ((max_rows + kMvWaves - 1) / kMvWaves)), dim3((kMvWaves + 1) * 64), 0, stream,
                        const_cast<JobDesc*>(jobs), njobs);
     if (profiled) prof::end(span, stream, prof::K_MV, bytes[0]);
   }
