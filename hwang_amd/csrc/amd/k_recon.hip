@@ -2032,85 +2032,61 @@ __global__ __launch_bounds__(kBandWaves * 64) void k_intra(JobDesc* __restrict__
 // ===========================================================================
 namespace {
 
-// One edge position.  v[0..7] = p3 p2 p1 p0 q0 q1 q2 q3 (chroma uses p1..q1
-// only); filtered in place.  Returns false when nothing changed.
-__device__ __forceinline__ bool filter_line(int* v, int bs, int alpha, int beta, int tc0, bool chroma) {
-  const int p0 = v[3], p1 = v[2], q0 = v[4], q1 = v[5];
-  if (iabs(p0 - q0) >= alpha || iabs(p1 - p0) >= beta || iabs(q1 - q0) >= beta) return false;
-  if (bs < 4) {
-    int tc;
-    if (chroma) {
-      tc = tc0 + 1;
-    } else {
-      const int p2 = v[1], q2 = v[6];
-      const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
-      tc = tc0 + (ap < beta) + (aq < beta);
-      if (ap < beta) v[2] = p1 + iclip(-tc0, tc0, (p2 + ((p0 + q0 + 1) >> 1) - (p1 << 1)) >> 1);
-      if (aq < beta) v[5] = q1 + iclip(-tc0, tc0, (q2 + ((p0 + q0 + 1) >> 1) - (q1 << 1)) >> 1);
-    }
-    const int delta = iclip(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
-    v[3] = clip8(p0 + delta);
-    v[4] = clip8(q0 - delta);
-    return true;
+// One line across an edge: p3 p2 p1 p0 | q0 q1 q2 q3 (chroma uses p1 .. q1 only), filtered in place (8.7.2.3 / 8.7.2.4).
+// Written without a branch on a value: a lone wave issues an instruction every four to five clocks whatever it is, a
+// row's step is the number of instructions on its path (see k_mv), and the lanes of one edge differ in everything -
+// strength, plane, whether the thresholds let the filter act at all.  Every lane computes the bS < 4 filter; the
+// bS = 4 formulas are computed where SOME lane of the wave needs them (`some_strong`, uniform).
+struct EdgeLine {
+  int p3, p2, p1, p0, q0, q1, q2, q3;
+};
+__device__ __forceinline__ void filter_line(EdgeLine& v, int bs, int alpha, int beta, int tc0, bool chroma, bool some_strong) {
+  const int p0 = v.p0, p1 = v.p1, p2 = v.p2, q0 = v.q0, q1 = v.q1, q2 = v.q2;
+  const bool on = bs != 0 && iabs(p0 - q0) < alpha && iabs(p1 - p0) < beta && iabs(q1 - q0) < beta;
+  const bool ap = !chroma && iabs(p2 - p0) < beta, aq = !chroma && iabs(q2 - q0) < beta;
+  const int tc = tc0 + (chroma ? 1 : static_cast<int>(ap) + static_cast<int>(aq));
+  const int delta = iclip(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
+  const int avg = (p0 + q0 + 1) >> 1;
+  int np0 = clip8(p0 + delta), nq0 = clip8(q0 - delta);
+  int np1 = ap ? p1 + iclip(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
+  int nq1 = aq ? q1 + iclip(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
+  int np2 = p2, nq2 = q2;
+  if (some_strong) {
+    const bool strong = bs == 4;
+    const bool close = iabs(p0 - q0) < ((alpha >> 2) + 2);
+    const bool sp = ap && close, sq = aq && close;
+    const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
+    const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
+    const int s_p1 = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1, s_q1 = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
+    const int s_p2 = sp ? (2 * v.p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2, s_q2 = sq ? (2 * v.q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
+    np0 = strong ? s_p0 : np0;
+    nq0 = strong ? s_q0 : nq0;
+    np1 = strong ? s_p1 : np1;
+    nq1 = strong ? s_q1 : nq1;
+    np2 = strong ? s_p2 : np2;
+    nq2 = strong ? s_q2 : nq2;
   }
-  if (chroma) {
-    v[3] = (2 * p1 + p0 + q1 + 2) >> 2;
-    v[4] = (2 * q1 + q0 + p1 + 2) >> 2;
-    return true;
-  }
-  const int p2 = v[1], q2 = v[6], p3 = v[0], q3 = v[7];
-  const int ap = iabs(p2 - p0), aq = iabs(q2 - q0);
-  const bool strong = iabs(p0 - q0) < ((alpha >> 2) + 2);
-  if (ap < beta && strong) {
-    v[3] = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3;
-    v[2] = (p2 + p1 + p0 + q0 + 2) >> 2;
-    v[1] = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
-  } else {
-    v[3] = (2 * p1 + p0 + q1 + 2) >> 2;
-  }
-  if (aq < beta && strong) {
-    v[4] = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3;
-    v[5] = (p0 + q0 + q1 + q2 + 2) >> 2;
-    v[6] = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
-  } else {
-    v[4] = (2 * q1 + q0 + p1 + 2) >> 2;
-  }
-  return true;
+  v.p0 = on ? np0 : p0;
+  v.q0 = on ? nq0 : q0;
+  v.p1 = on ? np1 : p1;
+  v.q1 = on ? nq1 : q1;
+  v.p2 = on ? np2 : p2;
+  v.q2 = on ? nq2 : q2;
 }
-
-// Filters the edge whose first q sample is at `q` in an LDS tile; `step` is
-// the distance between samples across the edge (1: vertical edge, row stride:
-// horizontal edge).  Vertical edges move the 8 samples as two dwords.
-// `paired`: another lane filters the edge eight luma (four chroma) samples further on in the same step.  Luma
-// words are disjoint then; the two chroma edges share the word between them, so chroma stores only the two
-// samples it may change.
-__device__ __forceinline__ void filter_edge(uint8_t* q, int step, int bs, int alpha, int beta, int tc0, bool chroma,
-                                            bool paired = false) {
-  int v[8];
-  if (step == 1) {
-    const uint32_t lo = *reinterpret_cast<const uint32_t*>(q - 4), hi = *reinterpret_cast<const uint32_t*>(q);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i] = (lo >> (8 * i)) & 0xff;
-      v[4 + i] = (hi >> (8 * i)) & 0xff;
-    }
-    if (!filter_line(v, bs, alpha, beta, tc0, chroma)) return;
-    if (paired && chroma) {
-      q[-1] = (uint8_t)v[3];
-      q[0] = (uint8_t)v[4];
-      return;
-    }
-    *reinterpret_cast<uint32_t*>(q - 4) = v[0] | (v[1] << 8) | (v[2] << 16) | ((uint32_t)v[3] << 24);
-    *reinterpret_cast<uint32_t*>(q) = v[4] | (v[5] << 8) | (v[6] << 16) | ((uint32_t)v[7] << 24);
-  } else {
-    const int lo = chroma ? 2 : 0, hi = chroma ? 6 : 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (i >= lo && i < hi) ? q[(i - 4) * step] : 0;
-    if (!filter_line(v, bs, alpha, beta, tc0, chroma)) return;
-#pragma unroll
-    for (int i = 1; i < 7; ++i)
-      if (i >= lo && i < hi) q[(i - 4) * step] = (uint8_t)v[i];
-  }
+// The same across a VERTICAL edge, on the two dwords of a row that meet there (lo = p3 p2 p1 p0, hi = q0 q1 q2 q3).
+__device__ __forceinline__ void filter_dwords(uint32_t& lo, uint32_t& hi, int bs, int alpha, int beta, int tc0, bool chroma, bool some_strong) {
+  EdgeLine v;
+  v.p3 = lo & 0xff;
+  v.p2 = (lo >> 8) & 0xff;
+  v.p1 = (lo >> 16) & 0xff;
+  v.p0 = lo >> 24;
+  v.q0 = hi & 0xff;
+  v.q1 = (hi >> 8) & 0xff;
+  v.q2 = (hi >> 16) & 0xff;
+  v.q3 = hi >> 24;
+  filter_line(v, bs, alpha, beta, tc0, chroma, some_strong);
+  lo = static_cast<uint32_t>(v.p3) | (static_cast<uint32_t>(v.p2) << 8) | (static_cast<uint32_t>(v.p1) << 16) | (static_cast<uint32_t>(v.p0) << 24);
+  hi = static_cast<uint32_t>(v.q0) | (static_cast<uint32_t>(v.q1) << 8) | (static_cast<uint32_t>(v.q2) << 16) | (static_cast<uint32_t>(v.q3) << 24);
 }
 
 __device__ int boundary_strength(const MbInfo& pm, const MbInfo& qm, const MbMotion* pmo, const MbMotion* qmo,
@@ -2161,19 +2137,16 @@ struct DbInfo {
 };
 static_assert(sizeof(DbInfo) == 96, "DbInfo must stay 96 bytes");
 
-// luma tile: picture rows -4..15, cols -4..15 -> 20 x 20 bytes, stride 24;
-// chroma tiles: rows -2..7, cols -4..7 -> 10 x 12 bytes, stride 12.  Column 4
-// of either tile is the macroblock's first column, so every row is a whole
-// number of aligned dwords in LDS and in the picture.
-constexpr int LS = 24, CS = 12;
+// A macroblock's samples while it is filtered: three tiles (Y, Cb, Cr) of 20 rows x 24 bytes, twice (the tile of the
+// macroblock before stays readable: its last columns are this one's left neighbours).
+//   luma   row y (-4 .. 15) -> tile row y + 4;  column x (0 .. 15) -> byte 4 + x
+//   chroma row j (-2 .. 7)  -> tile row j + 4 for j < 2, j + 8 from 2 on;  column x -> byte 4 + x for x < 4, 8 + x from 4 on
+// so that the horizontal edges of all three planes are the same code: edge e of a column reads tile rows 4e .. 4e + 7
+// (p3 .. q3; chroma edge 1 of the standard is e = 2 and uses p1 .. q1 = rows 4e + 2 .. 4e + 5: chroma rows 2 .. 5), and
+// a row's two dwords that meet at a vertical edge are dwords e, e + 1 of the tile row (chroma: 1 | 3 for its second edge).
+constexpr int TR = 24, kTileBytes = 20 * TR;
 struct DeblockWaveLds {
-  uint8_t lt[20 * LS];
-  uint8_t ct[2][10 * CS];
-  // The same tiles as they are in memory (every load and every slide is mirrored here): a dword the filters left as it
-  // was is not stored again.  A P picture's filtered macroblocks change a fraction of their samples; writing all of
-  // them back cost 4.5 MB of HBM writes per 3.1 MB picture (and fetches of the partly written lines).
-  uint8_t lt0[20 * LS];
-  uint8_t ct0[2][10 * CS];
+  alignas(16) uint8_t tile[2][3 * kTileBytes];
   DbInfo db;
 };
 
@@ -2281,7 +2254,6 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
   if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
   lds_counter* progress = (lds_counter*)G.progress;
   DeblockWaveLds& L = G.w[wave];
-  uint8_t* lt = L.lt;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const int W = pp.mb_width;
@@ -2342,7 +2314,22 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
     uint8_t* rowu = cur.u + (size_t)(mby * 8) * cp;
     uint8_t* rowv = cur.v + (size_t)(mby * 8) * cp;
     const DbInfo* rowdb = dbs + mby * W;
-    int tile_mbx = -2;  // macroblock whose samples the tile holds (its last four columns slide left)
+    int tile_mbx = -2;  // macroblock whose samples the tile before the current one holds (its last four columns are the left neighbours)
+    int ts = 0;         // which of the two tiles the current macroblock uses
+    // ---- what a lane is, fixed for the row.  As a ROW of the macroblock (vertical edges, stores): lanes 0..15 luma
+    // rows, 16..31 chroma rows of both planes; as a COLUMN (horizontal edges): lanes 0..15 luma columns, 16..31
+    // chroma columns, lanes 32..63 the same again (they take the second edge of a pair).
+    const int l32 = lane & 31;
+    const bool v_chroma = l32 >= 16, h_chroma = l32 >= 16;
+    const int c_plane = (l32 - 16) >> 3, c_idx = (l32 - 16) & 7;   // chroma lanes: plane, row or column
+    const int v_off = v_chroma ? (1 + c_plane) * kTileBytes + (c_idx < 2 ? c_idx + 4 : c_idx + 8) * TR : (4 + l32) * TR;
+    const int h_off = h_chroma ? (1 + c_plane) * kTileBytes + (c_idx < 4 ? 4 + c_idx : 8 + c_idx) : 4 + l32;
+    uint8_t* const v_grow = v_chroma ? (c_plane ? rowv : rowu) + c_idx * cp : rowy + l32 * yp;  // the row's first sample in the picture
+    const int v_xs = v_chroma ? 3 : 4;                                 // log2 of a macroblock's width in that plane
+    const bool v_low = v_chroma ? c_idx >= 6 : l32 >= 12;              // rows the band below filters under
+    // the four strengths of a lane's edge segment are one dword of the record; the plane's thresholds another
+    const int kk = l32 < 16 ? (l32 >> 2) : (((l32 - 16) & 7) >> 1);
+    const int pl = l32 < 16 ? 0 : 1 + ((l32 - 16) >> 3);
 
     for (int mbx0 = 0; mbx0 < W; mbx0 += 64) {
       // Macroblocks without a single edge to filter are skipped outright: they
@@ -2433,29 +2420,10 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
         uint8_t* gy = rowy + mbx * 16;
         uint8_t* gu = rowu + mbx * 8;
         uint8_t* gv = rowv + mbx * 8;
-        // ---- left columns: slide from the tile, or take the prefetched ones
-        if (tile_mbx == mbx - 1) {
-          uint32_t keep = 0;
-          if (lane < 20) keep = *reinterpret_cast<const uint32_t*>(&L.lt[lane * LS + 16]);
-          else if (lane < 40) keep = *reinterpret_cast<const uint32_t*>(&L.ct[(lane - 20) / 10][((lane - 20) % 10) * CS + 8]);
-          wave_sync();
-          if (lane < 20) {
-            *reinterpret_cast<uint32_t*>(&L.lt[lane * LS]) = keep;
-            *reinterpret_cast<uint32_t*>(&L.lt0[lane * LS]) = keep;  // (the previous macroblock stored them, or they never changed)
-          } else if (lane < 40) {
-            *reinterpret_cast<uint32_t*>(&L.ct[(lane - 20) / 10][((lane - 20) % 10) * CS]) = keep;
-            *reinterpret_cast<uint32_t*>(&L.ct0[(lane - 20) / 10][((lane - 20) % 10) * CS]) = keep;
-          }
-        } else if (mbx > 0) {
-          if (lane < 16) {
-            *reinterpret_cast<uint32_t*>(&L.lt[(4 + lane) * LS]) = n_left;
-            *reinterpret_cast<uint32_t*>(&L.lt0[(4 + lane) * LS]) = n_left;
-          } else if (lane < 32) {
-            *reinterpret_cast<uint32_t*>(&L.ct[(lane - 16) >> 3][(2 + ((lane - 16) & 7)) * CS]) = n_left;
-            *reinterpret_cast<uint32_t*>(&L.ct0[(lane - 16) >> 3][(2 + ((lane - 16) & 7)) * CS]) = n_left;
-          }
-        }
         // ---- land the prefetched interior + record, start the next prefetches
+        uint8_t* T = L.tile[ts];
+        const uint8_t* Tprev = L.tile[ts ^ 1];
+        const bool left_in_tile = tile_mbx == mbx - 1;
         if ((mbx >> 2) != gcur) {  // a new group: what was in flight becomes current, the group after it is requested
           g_luma = n_gluma;
           g_chroma = n_gchroma;
@@ -2464,34 +2432,24 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
           if (g >= 0) prefetch_group(g);
         }
         if ((lane & 3) == (mbx & 3)) {  // the lanes that hold this macroblock's part of the group
-          uint32_t* lrow = reinterpret_cast<uint32_t*>(&L.lt[(4 + (lane >> 2)) * LS + 4]);
+          uint32_t* lrow = reinterpret_cast<uint32_t*>(T + (4 + (lane >> 2)) * TR + 4);
           lrow[0] = g_luma.x;
           lrow[1] = g_luma.y;
           lrow[2] = g_luma.z;
           lrow[3] = g_luma.w;
-          uint32_t* lrow0 = reinterpret_cast<uint32_t*>(&L.lt0[(4 + (lane >> 2)) * LS + 4]);
-          lrow0[0] = g_luma.x;
-          lrow0[1] = g_luma.y;
-          lrow0[2] = g_luma.z;
-          lrow0[3] = g_luma.w;
-          uint32_t* crow = reinterpret_cast<uint32_t*>(&L.ct[lane >> 5][(2 + ((lane >> 2) & 7)) * CS + 4]);
+          const int j = (lane >> 2) & 7;
+          uint32_t* crow = reinterpret_cast<uint32_t*>(T + (1 + (lane >> 5)) * kTileBytes + (j < 2 ? j + 4 : j + 8) * TR + 4);
           crow[0] = g_chroma.x;
-          crow[1] = g_chroma.y;
-          uint32_t* crow0 = reinterpret_cast<uint32_t*>(&L.ct0[lane >> 5][(2 + ((lane >> 2) & 7)) * CS + 4]);
-          crow0[0] = g_chroma.x;
-          crow0[1] = g_chroma.y;
+          crow[2] = g_chroma.y;
         }
         if (lane < 24) reinterpret_cast<uint32_t*>(&L.db)[lane] = n_db;
+        const uint32_t left_far = n_left;  // (the left neighbour's columns from memory, when it was skipped)
         if (todo) prefetch(mbx0 + __builtin_ctzll(todo), mbx0 + __builtin_ctzll(todo) == mbx + 1);
         wave_sync();
         STAMP(sd_on, mbx, 1);
         // ---- this lane's parameters for all eight edge steps, in registers
         const int emask = L.db.emask;
         const bool top_edge = mby > 0 && (emask & 0x10);
-        // lanes 32..63 mirror lanes 0..31 (they take the second edge of a pair, below)
-        const int l32 = lane & 31;
-        const int kk = l32 < 16 ? (l32 >> 2) : (((l32 - 16) & 7) >> 1);
-        const int pl = l32 < 16 ? 0 : 1 + ((l32 - 16) >> 3);
         const uint32_t vbs = *reinterpret_cast<const uint32_t*>(L.db.bs[0][kk]);
         const uint32_t hbs = *reinterpret_cast<const uint32_t*>(L.db.bs[1][kk]);
         const uint32_t a3 = L.db.alpha[pl][0] | (L.db.alpha[pl][1] << 8) | (L.db.alpha[pl][2] << 16);
@@ -2499,6 +2457,8 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
         uint32_t tcw[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) tcw[c] = L.db.tc0[pl][c][0] | (L.db.tc0[pl][c][1] << 8) | (L.db.tc0[pl][c][2] << 16);
+        // (bS = 4 exists on macroblock edges of intra macroblocks only: the formulas for it are skipped where no lane has it)
+        const bool some_strong = __ballot(((vbs | hbs) & 0x04040404u) != 0) != 0;
         // ---- rows above: wait for the row above to be two macroblocks ahead
         uint32_t top_word = 0;
         if (top_edge) {
@@ -2517,106 +2477,132 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
           }
         }
         STAMP(sd_on, mbx, 2);
-        // ---- vertical edges: lanes 0..15 one luma row each, 16..31 one chroma row each.
-        // Edges 0 and 2 touch disjoint samples (x <= 3 and x >= 4), so when the odd edges are not filtered
-        // - every macroblock with the 8x8 transform, and many without - both run in ONE step, the second on
-        // lanes 32..63: half the dependent edge steps of the pass.
-        if (!(emask & 0xa) && (emask & 0x5)) {
-          const int e = (lane >> 5) * 2;
-          const int bs = (vbs >> (8 * e)) & 0xff;
-          const int cls = e == 0 ? 0 : 2;
-          const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
-          const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
-          if (((emask >> e) & 1) && bs) {
-            const int p = (l32 - 16) >> 3, i = (l32 - 16) & 7;
-            uint8_t* q = l32 < 16 ? lt + (4 + l32) * LS + 4 + e * 4 : L.ct[p] + (2 + i) * CS + 4 + e * 2;
-            filter_edge(q, 1, bs, alpha, beta, tc0, l32 >= 16, true);
-          }
-          wave_sync();
-        } else
+        // ---- vertical edges, in registers: lanes 0..15 one luma row each, 16..31 one chroma row each.  The row's dwords
+        // R0 (the left neighbour's last four columns) R1 .. R4 (chroma: R1 and R3); edge e lies between R[e] and R[e + 1],
+        // the chroma edges between R0 | R1 and R1 | R3.
+        uint32_t R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0;
+        if (lane < 32) {
+          const uint32_t* row = reinterpret_cast<const uint32_t*>(T + v_off);
+          R1 = row[1];
+          R2 = row[2];
+          R3 = row[3];
+          R4 = row[4];
+          if (left_in_tile) R0 = *reinterpret_cast<const uint32_t*>(Tprev + v_off + (v_chroma ? 12 : 16));
+          else R0 = left_far;
+        }
+        const uint32_t O0 = R0, O1 = R1, O2 = R2, O3 = R3, O4 = R4;  // as they are in memory
+        if (emask & 0xf) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (!((emask >> e) & 1)) continue;  // wave uniform: nothing on this edge
-          const int bs = (vbs >> (8 * e)) & 0xff;
-          const int cls = e == 0 ? 0 : 2;
-          const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
-          const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
-          // luma rows (lanes 0..15) and chroma rows (16..31, even edges only) share
-          // one instruction stream: the sample pointer and the plane are lane data
-          if (lane < 32 && bs && (lane < 16 || !(e & 1))) {
-            const int p = (lane - 16) >> 3, i = (lane - 16) & 7;
-            uint8_t* q = lane < 16 ? lt + (4 + lane) * LS + 4 + e * 4 : L.ct[p] + (2 + i) * CS + 4 + e * 2;
-            filter_edge(q, 1, bs, alpha, beta, tc0, lane >= 16);
+          for (int e = 0; e < 4; ++e) {
+            if (!((emask >> e) & 1)) continue;  // wave uniform: nothing on this edge
+            const int cls = e == 0 ? 0 : 2;
+            int bs = (vbs >> (8 * e)) & 0xff;
+            if (lane >= 32 || (v_chroma && (e & 1))) bs = 0;
+            const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
+            const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
+            if (e == 0) filter_dwords(R0, R1, bs, alpha, beta, tc0, v_chroma, some_strong);
+            else if (e == 1) filter_dwords(R1, R2, bs, alpha, beta, tc0, v_chroma, some_strong);
+            else if (e == 2) {
+              uint32_t lo = v_chroma ? R1 : R2;
+              filter_dwords(lo, R3, bs, alpha, beta, tc0, v_chroma, some_strong);
+              R1 = v_chroma ? lo : R1;
+              R2 = v_chroma ? R2 : lo;
+            } else filter_dwords(R3, R4, bs, alpha, beta, tc0, v_chroma, some_strong);
           }
-          wave_sync();
+          if (lane < 32) {
+            uint32_t* row = reinterpret_cast<uint32_t*>(T + v_off);
+            row[1] = R1;
+            row[2] = R2;
+            row[3] = R3;
+            row[4] = R4;
+          }
+          // ---- the left neighbour's last four columns are final now (only this macroblock's left edge touches them
+          // from this row): store them at once, so that by the time this macroblock's progress is published - after
+          // its horizontal edges, below - the left neighbour is final IN MEMORY and the row below may filter under it.
+          if ((emask & 1) && mbx > 0 && lane < 32 && R0 != O0) {
+            uint8_t* g = v_grow + (mbx << v_xs) - 4;
+            if (CHAIN || (exporting && v_low)) agent_st32(g, R0);
+            else gst32(g, R0);
+          }
         }
         STAMP(sd_on, mbx, 3);
-        // ---- the left neighbour's last four columns are final now (only this macroblock's left edge touches them
-        // from this row): store them at once, so that by the time this macroblock's progress is published - after
-        // its horizontal edges, below - the left neighbour is final IN MEMORY and the row below may filter under it.
-        // (They used to go out with the whole tile at the end of the iteration and count one macroblock later: a
-        // row ran three macroblocks behind the row above instead of two.)
-        if ((emask & 1) && mbx > 0 && lane < 32) {
-          if (lane < 16) {
-            const int r = 4 + lane;
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.lt[r * LS]);
-            if (v != *reinterpret_cast<const uint32_t*>(&L.lt0[r * LS])) {
-              if (CHAIN || (exporting && r >= 16)) agent_st32(gy + (r - 4) * yp - 4, v);
-              else gst32(gy + (r - 4) * yp - 4, v);
-            }
-          } else {
-            const int p = (lane - 16) >> 3, r = 2 + ((lane - 16) & 7);
-            uint8_t* g = p ? gv : gu;
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS]);
-            if (v != *reinterpret_cast<const uint32_t*>(&L.ct0[p][r * CS])) {
-              if (CHAIN || (exporting && r >= 8)) agent_st32(g + (r - 2) * cp - 4, v);
-              else gst32(g + (r - 2) * cp - 4, v);
-            }
-          }
-        }
         // ---- the rows above arrive now (their latency hid behind the vertical edges)
         if (top_edge) {
           if (lane < 16) {
-            *reinterpret_cast<uint32_t*>(&L.lt[(lane >> 2) * LS + 4 + (lane & 3) * 4]) = top_word;
-            *reinterpret_cast<uint32_t*>(&L.lt0[(lane >> 2) * LS + 4 + (lane & 3) * 4]) = top_word;
+            *reinterpret_cast<uint32_t*>(T + (lane >> 2) * TR + 4 + (lane & 3) * 4) = top_word;
           } else if (lane < 24) {
             const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
-            *reinterpret_cast<uint32_t*>(&L.ct[p][cr * CS + 4 + cc * 4]) = top_word;
-            *reinterpret_cast<uint32_t*>(&L.ct0[p][cr * CS + 4 + cc * 4]) = top_word;
+            *reinterpret_cast<uint32_t*>(T + (1 + p) * kTileBytes + (2 + cr) * TR + (cc ? 12 : 4)) = top_word;
           }
-          wave_sync();
         }
+        wave_sync();
         STAMP(sd_on, mbx, 4);
-        // ---- horizontal edges: lanes 0..15 one luma column each, 16..31 chroma columns; edges 0 and 2 paired
-        // like the vertical ones when edges 1 and 3 are not filtered
+        // ---- horizontal edges, in registers: lanes 0..15 one luma column each, 16..31 chroma columns.  Edges 0 and 2
+        // touch disjoint rows, so when the odd edges are not filtered - every macroblock with the 8x8 transform, and
+        // many without - both run in ONE step, the second on lanes 32..63.
         const int hm = ((emask >> 4) & 0xf) & (top_edge ? 0xf : 0xe);
         if (!(hm & 0xa) && (hm & 0x5)) {
           const int e = (lane >> 5) * 2;
-          const int bs = (hbs >> (8 * e)) & 0xff;
           const int cls = e == 0 ? 1 : 2;
+          int bs = (hbs >> (8 * e)) & 0xff;
+          if (!((hm >> e) & 1)) bs = 0;
           const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
           const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
-          if (((hm >> e) & 1) && bs) {
-            const int p = (l32 - 16) >> 3, i = (l32 - 16) & 7;
-            uint8_t* q = l32 < 16 ? lt + (4 + e * 4) * LS + 4 + l32 : L.ct[p] + (2 + e * 2) * CS + 4 + i;
-            filter_edge(q, l32 < 16 ? LS : CS, bs, alpha, beta, tc0, l32 >= 16);
+          uint8_t* col = T + h_off + (lane >> 5) * 8 * TR;
+          EdgeLine v;
+          v.p3 = col[0];
+          v.p2 = col[TR];
+          v.p1 = col[2 * TR];
+          v.p0 = col[3 * TR];
+          v.q0 = col[4 * TR];
+          v.q1 = col[5 * TR];
+          v.q2 = col[6 * TR];
+          v.q3 = col[7 * TR];
+          filter_line(v, bs, alpha, beta, tc0, h_chroma, some_strong);
+          if (bs) {
+            col[TR] = static_cast<uint8_t>(v.p2);
+            col[2 * TR] = static_cast<uint8_t>(v.p1);
+            col[3 * TR] = static_cast<uint8_t>(v.p0);
+            col[4 * TR] = static_cast<uint8_t>(v.q0);
+            col[5 * TR] = static_cast<uint8_t>(v.q1);
+            col[6 * TR] = static_cast<uint8_t>(v.q2);
           }
-          wave_sync();
-        } else
+        } else if (hm) {
+          uint8_t* col = T + h_off;
+          int v[20];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          if (!((emask >> (4 + e)) & 1) || (e == 0 && !top_edge)) continue;
-          const int bs = (hbs >> (8 * e)) & 0xff;
-          const int cls = e == 0 ? 1 : 2;
-          const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
-          const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
-          if (lane < 32 && bs && (lane < 16 || !(e & 1))) {
-            const int p = (lane - 16) >> 3, i = (lane - 16) & 7;
-            uint8_t* q = lane < 16 ? lt + (4 + e * 4) * LS + 4 + lane : L.ct[p] + (2 + e * 2) * CS + 4 + i;
-            filter_edge(q, lane < 16 ? LS : CS, bs, alpha, beta, tc0, lane >= 16);
+          for (int i = 0; i < 20; ++i) v[i] = col[i * TR];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (!((hm >> e) & 1)) continue;
+            const int cls = e == 0 ? 1 : 2;
+            int bs = (hbs >> (8 * e)) & 0xff;
+            if (lane >= 32 || (h_chroma && (e & 1))) bs = 0;
+            const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
+            const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
+            EdgeLine l;
+            l.p3 = v[4 * e];
+            l.p2 = v[4 * e + 1];
+            l.p1 = v[4 * e + 2];
+            l.p0 = v[4 * e + 3];
+            l.q0 = v[4 * e + 4];
+            l.q1 = v[4 * e + 5];
+            l.q2 = v[4 * e + 6];
+            l.q3 = v[4 * e + 7];
+            filter_line(l, bs, alpha, beta, tc0, h_chroma, some_strong);
+            v[4 * e + 1] = l.p2;
+            v[4 * e + 2] = l.p1;
+            v[4 * e + 3] = l.p0;
+            v[4 * e + 4] = l.q0;
+            v[4 * e + 5] = l.q1;
+            v[4 * e + 6] = l.q2;
           }
-          wave_sync();
+          if (lane < 32) {
+#pragma unroll
+            for (int i = 1; i < 19; ++i) col[i * TR] = static_cast<uint8_t>(v[i]);
+          }
         }
+        wave_sync();
         // ---- the previous filtered macroblock's stores have had this whole
         // iteration to land: make sure, then everything before this macroblock
         // is final (skipped ones included)
@@ -2631,32 +2617,40 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
         // compiler from waiting for them at the top of the next iteration, where
         // its in-order counter would also cover the stores issued just below.
         asm volatile("" : "+v"(n_gluma), "+v"(n_gchroma), "+v"(n_db), "+v"(n_left));
-        // ---- store what else the filters may have touched: rows 0..15 x cols 0..15
-        // and, with a top edge, rows -4..-1 x cols 0..15 (chroma: rows 0..7 x
-        // cols 0..7 and rows -2..-1 x cols 0..7).  The corner above-left belongs
-        // to other macroblocks' edges and is never written from here.
-        for (int t = lane; t < 100; t += 64) {
-          const int r = t / 5, c4 = t % 5;
-          if (c4 >= 1 && (r >= 4 || top_edge)) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.lt[r * LS + c4 * 4]);
-            if (v != *reinterpret_cast<const uint32_t*>(&L.lt0[r * LS + c4 * 4])) {
-              if (CHAIN || (exporting && r >= 16)) agent_st32(gy + (r - 4) * yp + (c4 - 1) * 4, v);  // the band below reads these rows
-              else gst32(gy + (r - 4) * yp + (c4 - 1) * 4, v);
-            }
+        // ---- store what the filters changed: the row lanes compare their row with what it was in memory (a P
+        // picture's filtered macroblocks change a fraction of their samples; writing all of them back cost 4.5 MB of
+        // HBM writes per 3.1 MB picture, and fetches of the partly written lines), and the lanes that fetched the rows
+        // above theirs.  The corner above-left belongs to other macroblocks' edges and is never written from here.
+        if (lane < 32) {
+          const uint32_t* row = reinterpret_cast<const uint32_t*>(T + v_off);
+          const uint32_t F1 = row[1], F2 = row[2], F3 = row[3], F4 = row[4];
+          uint8_t* g = v_grow + (mbx << v_xs);
+          const bool far = CHAIN || (exporting && v_low);  // the band below reads these rows
+          if (F1 != O1) { if (far) agent_st32(g, F1); else gst32(g, F1); }
+          if (F3 != O3) { if (far) agent_st32(g + (v_chroma ? 4 : 8), F3); else gst32(g + (v_chroma ? 4 : 8), F3); }
+          if (!v_chroma) {
+            if (F2 != O2) { if (far) agent_st32(g + 4, F2); else gst32(g + 4, F2); }
+            if (F4 != O4) { if (far) agent_st32(g + 12, F4); else gst32(g + 12, F4); }
           }
         }
-        if (lane < 60) {
-          const int p = lane / 30, t = lane % 30, r = t / 3, c4 = t % 3;
-          uint8_t* g = p ? gv : gu;
-          if (c4 >= 1 && (r >= 2 || top_edge)) {
-            const uint32_t v = *reinterpret_cast<const uint32_t*>(&L.ct[p][r * CS + c4 * 4]);
-            if (v != *reinterpret_cast<const uint32_t*>(&L.ct0[p][r * CS + c4 * 4])) {
-              if (CHAIN || (exporting && r >= 8)) agent_st32(g + (r - 2) * cp + (c4 - 1) * 4, v);
-              else gst32(g + (r - 2) * cp + (c4 - 1) * 4, v);
-            }
+        if (top_edge && lane < 24) {
+          uint32_t f;
+          uint8_t* g;
+          if (lane < 16) {
+            f = *reinterpret_cast<const uint32_t*>(T + (lane >> 2) * TR + 4 + (lane & 3) * 4);
+            g = gy + ((lane >> 2) - 4) * yp + (lane & 3) * 4;
+          } else {
+            const int t = lane - 16, p = t >> 2, cr = (t >> 1) & 1, cc = t & 1;
+            f = *reinterpret_cast<const uint32_t*>(T + (1 + p) * kTileBytes + (2 + cr) * TR + (cc ? 12 : 4));
+            g = (p ? gv : gu) + (cr - 2) * cp + cc * 4;
+          }
+          if (f != top_word) {
+            if (CHAIN) agent_st32(g, f);
+            else gst32(g, f);
           }
         }
         tile_mbx = mbx;
+        ts ^= 1;
         {
           // a gap behind this macroblock: let its stores land now and raise the counter over the gap
           const int next = todo ? mbx0 + __builtin_ctzll(todo) : (mbx0 + 64 < W ? mbx0 + 64 : W + 1);
