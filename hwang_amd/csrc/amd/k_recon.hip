@@ -2127,13 +2127,13 @@ __device__ int boundary_strength(const MbInfo& pm, const MbInfo& qm, const MbMot
 struct DbInfo {
   uint8_t bs[2][4][4];   // [0 vertical / 1 horizontal edges][position along the edge / 4][edge 0..3]:
                          // the four strengths one filter lane needs are one dword
-  uint8_t alpha[3][3];   // [plane][0 left, 1 top, 2 internal]
-  uint8_t beta[3][3];
-  uint8_t tc0[3][3][3];  // [plane][class][bS - 1]
+  uint8_t alpha[3][4];   // [plane][0 left, 1 top, 2 internal, -]: a plane's thresholds are one dword for the lane
+  uint8_t beta[3][4];
+  uint8_t tc0[3][3][4];  // [plane][class][bS - 1, -]
   uint8_t t8x8;
   uint8_t any;           // some bs != 0
   uint8_t emask;         // bit e: vertical edge e has a non-zero bS, bit 4 + e: horizontal edge e
-  uint8_t pad[16];
+  uint8_t pad[1];
 };
 static_assert(sizeof(DbInfo) == 96, "DbInfo must stay 96 bytes");
 
@@ -2326,7 +2326,9 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
     const int h_off = h_chroma ? (1 + c_plane) * kTileBytes + (c_idx < 4 ? 4 + c_idx : 8 + c_idx) : 4 + l32;
     uint8_t* const v_grow = v_chroma ? (c_plane ? rowv : rowu) + c_idx * cp : rowy + l32 * yp;  // the row's first sample in the picture
     const int v_xs = v_chroma ? 3 : 4;                                 // log2 of a macroblock's width in that plane
-    const bool v_low = v_chroma ? c_idx >= 6 : l32 >= 12;              // rows the band below filters under
+    // the band below reads the last rows of this one through agent-scope loads: a band's last row stores everything
+    // that way (which rows they are is lane data; one kind of store per wave keeps the store phase half as long)
+    const bool far = CHAIN || exporting;
     // the four strengths of a lane's edge segment are one dword of the record; the plane's thresholds another
     const int kk = l32 < 16 ? (l32 >> 2) : (((l32 - 16) & 7) >> 1);
     const int pl = l32 < 16 ? 0 : 1 + ((l32 - 16) >> 3);
@@ -2452,11 +2454,11 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
         const bool top_edge = mby > 0 && (emask & 0x10);
         const uint32_t vbs = *reinterpret_cast<const uint32_t*>(L.db.bs[0][kk]);
         const uint32_t hbs = *reinterpret_cast<const uint32_t*>(L.db.bs[1][kk]);
-        const uint32_t a3 = L.db.alpha[pl][0] | (L.db.alpha[pl][1] << 8) | (L.db.alpha[pl][2] << 16);
-        const uint32_t b3 = L.db.beta[pl][0] | (L.db.beta[pl][1] << 8) | (L.db.beta[pl][2] << 16);
+        const uint32_t a3 = *reinterpret_cast<const uint32_t*>(L.db.alpha[pl]);
+        const uint32_t b3 = *reinterpret_cast<const uint32_t*>(L.db.beta[pl]);
         uint32_t tcw[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tcw[c] = L.db.tc0[pl][c][0] | (L.db.tc0[pl][c][1] << 8) | (L.db.tc0[pl][c][2] << 16);
+        for (int c = 0; c < 3; ++c) tcw[c] = *reinterpret_cast<const uint32_t*>(L.db.tc0[pl][c]);
         // (bS = 4 exists on macroblock edges of intra macroblocks only: the formulas for it are skipped where no lane has it)
         const bool some_strong = __ballot(((vbs | hbs) & 0x04040404u) != 0) != 0;
         // ---- rows above: wait for the row above to be two macroblocks ahead
@@ -2480,18 +2482,49 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
         // ---- vertical edges, in registers: lanes 0..15 one luma row each, 16..31 one chroma row each.  The row's dwords
         // R0 (the left neighbour's last four columns) R1 .. R4 (chroma: R1 and R3); edge e lies between R[e] and R[e + 1],
         // the chroma edges between R0 | R1 and R1 | R3.
-        uint32_t R0 = 0, R1 = 0, R2 = 0, R3 = 0, R4 = 0;
-        if (lane < 32) {
+        // (lanes 32..63 hold the same rows as 0..31: they take the second edge of a pair, below)
+        uint32_t R0, R1, R2, R3, R4;
+        {
           const uint32_t* row = reinterpret_cast<const uint32_t*>(T + v_off);
           R1 = row[1];
           R2 = row[2];
           R3 = row[3];
           R4 = row[4];
           if (left_in_tile) R0 = *reinterpret_cast<const uint32_t*>(Tprev + v_off + (v_chroma ? 12 : 16));
-          else R0 = left_far;
+          else R0 = left_far;  // (lanes 0..31; the twins never use it)
         }
         const uint32_t O0 = R0, O1 = R1, O2 = R2, O3 = R3, O4 = R4;  // as they are in memory
-        if (emask & 0xf) {
+        if (!(emask & 0xa) && (emask & 0x5)) {
+          // Edges 0 and 2 touch disjoint samples, so when the odd edges are not filtered - every macroblock with the
+          // 8x8 transform, and many without - both run in ONE step, the second on lanes 32..63, whose results come
+          // back over v_permlane32_swap.  (Chroma: the two edges share the dword between them; edge 0 changes its first
+          // sample, edge 2 its last.)
+          const bool second = lane >= 32;
+          const int e = second ? 2 : 0, cls = second ? 2 : 0;
+          int bs = (vbs >> (8 * e)) & 0xff;
+          if (!((emask >> e) & 1)) bs = 0;
+          const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
+          const int tc0 = bs && bs < 4 ? ((second ? tcw[2] : tcw[0]) >> (8 * (bs - 1))) & 0xff : 0;
+          uint32_t lo = second ? (v_chroma ? R1 : R2) : R0, hi = second ? R3 : R1;
+          filter_dwords(lo, hi, bs, alpha, beta, tc0, v_chroma, some_strong);
+          const uint32_t lo2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false)[1];  // every lane: the value of its twin in lanes 32..63
+          const uint32_t hi2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false)[1];
+          if (!second) {
+            R0 = lo;
+            R1 = v_chroma ? (hi & 0x0000ffffu) | (lo2 & 0xffff0000u) : hi;
+            R2 = v_chroma ? R2 : lo2;
+            R3 = hi2;
+            uint32_t* row = reinterpret_cast<uint32_t*>(T + v_off);
+            row[1] = R1;
+            row[2] = R2;
+            row[3] = R3;
+            if ((emask & 1) && mbx > 0 && R0 != O0) {
+              uint8_t* g = v_grow + (mbx << v_xs) - 4;
+              if (far) agent_st32(g, R0);
+              else gst32(g, R0);
+            }
+          }
+        } else if (emask & 0xf) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             if (!((emask >> e) & 1)) continue;  // wave uniform: nothing on this edge
@@ -2521,7 +2554,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
           // its horizontal edges, below - the left neighbour is final IN MEMORY and the row below may filter under it.
           if ((emask & 1) && mbx > 0 && lane < 32 && R0 != O0) {
             uint8_t* g = v_grow + (mbx << v_xs) - 4;
-            if (CHAIN || (exporting && v_low)) agent_st32(g, R0);
+            if (far) agent_st32(g, R0);
             else gst32(g, R0);
           }
         }
@@ -2625,7 +2658,6 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
           const uint32_t* row = reinterpret_cast<const uint32_t*>(T + v_off);
           const uint32_t F1 = row[1], F2 = row[2], F3 = row[3], F4 = row[4];
           uint8_t* g = v_grow + (mbx << v_xs);
-          const bool far = CHAIN || (exporting && v_low);  // the band below reads these rows
           if (F1 != O1) { if (far) agent_st32(g, F1); else gst32(g, F1); }
           if (F3 != O3) { if (far) agent_st32(g + (v_chroma ? 4 : 8), F3); else gst32(g + (v_chroma ? 4 : 8), F3); }
           if (!v_chroma) {
