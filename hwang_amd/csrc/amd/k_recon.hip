@@ -1685,6 +1685,10 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
         const int mbx = mbx0 + __builtin_ctzll(todo);
         todo &= todo - 1;
         const MbInfo mb = next_mb;
+#ifdef EXP_STAMPS
+        const bool si_on = EXP_STAMPS == 3 && !CHAIN && mby == EXP_STAMP_ROW;
+#endif
+        STAMP(si_on, mbx, 0);
         // land this macroblock's residual in LDS, start the next one's loads
         reinterpret_cast<uint32_t*>(L.res_y)[lane] = r0;
         reinterpret_cast<uint32_t*>(L.res_y)[64 + lane] = r1;
@@ -1720,6 +1724,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
           else if (lds_nb) import_line(need);
           else import_wait(need);
         }
+        STAMP(si_on, mbx, 1);
         // ---- neighbours into the tiles
         if (lds_nb) {
           // left column: the previous macroblock of this row is still in the tile
@@ -1763,6 +1768,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
           }
         }
         wave_sync();
+        STAMP(si_on, mbx, 2);
 
         if (pcm) {
           const uint8_t* src = reinterpret_cast<const uint8_t*>(coefs + mb.coef_offset);
@@ -1908,6 +1914,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
           }
         }
 
+        STAMP(si_on, mbx, 3);
         // chroma 8x8, both planes: two samples per lane
         if (!pcm) {
           int outc[2];
@@ -1957,6 +1964,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
             if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(mbx));
           }
         }
+        STAMP(si_on, mbx, 4);
         // ---- tiles -> surface: one dword per lane (luma), 32 lanes x dword (chroma)
         {
           const int r = lane >> 2, c4 = (lane & 3) * 4;
@@ -1993,6 +2001,8 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
           publish(todo ? mbx0 + __builtin_ctzll(todo) : min(mbx0 + 64, pp.mb_width));  // up to the next intra macroblock
         }
         prev_mbx = mbx;
+        STAMP(si_on, mbx, 5);
+        STAMP_VALUE(si_on, mbx, mb.kind);
       }
     }
     // inter macroblocks at the end of the row need no work: the row is done
@@ -2048,17 +2058,34 @@ __device__ __forceinline__ void filter_line(EdgeLine& v, int bs, int alpha, int 
   const int delta = iclip(-tc, tc, (((q0 - p0) << 2) + (p1 - q1) + 4) >> 3);
   const int avg = (p0 + q0 + 1) >> 1;
   int np0 = clip8(p0 + delta), nq0 = clip8(q0 - delta);
-  int np1 = ap ? p1 + iclip(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1) : p1;
-  int nq1 = aq ? q1 + iclip(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1) : q1;
+  // (KEEP: the value exists before the select that may discard it - otherwise the compiler sinks its computation into
+  // an exec-mask region of its own, and a region costs more issue slots than the three or four instructions it guards)
+#define KEEP(x) asm volatile("" : "+v"(x))
+  int mp1 = p1 + iclip(-tc0, tc0, (p2 + avg - (p1 << 1)) >> 1), mq1 = q1 + iclip(-tc0, tc0, (q2 + avg - (q1 << 1)) >> 1);
+  KEEP(mp1);
+  KEEP(mq1);
+  int np1 = ap ? mp1 : p1;
+  int nq1 = aq ? mq1 : q1;
   int np2 = p2, nq2 = q2;
   if (some_strong) {
     const bool strong = bs == 4;
     const bool close = iabs(p0 - q0) < ((alpha >> 2) + 2);
     const bool sp = ap && close, sq = aq && close;
-    const int s_p0 = sp ? (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3 : (2 * p1 + p0 + q1 + 2) >> 2;
-    const int s_q0 = sq ? (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3 : (2 * q1 + q0 + p1 + 2) >> 2;
-    const int s_p1 = sp ? (p2 + p1 + p0 + q0 + 2) >> 2 : p1, s_q1 = sq ? (p0 + q0 + q1 + q2 + 2) >> 2 : q1;
-    const int s_p2 = sp ? (2 * v.p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3 : p2, s_q2 = sq ? (2 * v.q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3 : q2;
+    int a0 = (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3, b0 = (2 * p1 + p0 + q1 + 2) >> 2;
+    int c0 = (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3, d0 = (2 * q1 + q0 + p1 + 2) >> 2;
+    int a1 = (p2 + p1 + p0 + q0 + 2) >> 2, c1 = (p0 + q0 + q1 + q2 + 2) >> 2;
+    int a2 = (2 * v.p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3, c2 = (2 * v.q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+    KEEP(a0);
+    KEEP(b0);
+    KEEP(c0);
+    KEEP(d0);
+    KEEP(a1);
+    KEEP(c1);
+    KEEP(a2);
+    KEEP(c2);
+    const int s_p0 = sp ? a0 : b0, s_q0 = sq ? c0 : d0;
+    const int s_p1 = sp ? a1 : p1, s_q1 = sq ? c1 : q1;
+    const int s_p2 = sp ? a2 : p2, s_q2 = sq ? c2 : q2;
     np0 = strong ? s_p0 : np0;
     nq0 = strong ? s_q0 : nq0;
     np1 = strong ? s_p1 : np1;
@@ -2072,6 +2099,7 @@ __device__ __forceinline__ void filter_line(EdgeLine& v, int bs, int alpha, int 
   v.q1 = on ? nq1 : q1;
   v.p2 = on ? np2 : p2;
   v.q2 = on ? nq2 : q2;
+#undef KEEP
 }
 // The same across a VERTICAL edge, on the two dwords of a row that meet there (lo = p3 p2 p1 p0, hi = q0 q1 q2 q3).
 __device__ __forceinline__ void filter_dwords(uint32_t& lo, uint32_t& hi, int bs, int alpha, int beta, int tc0, bool chroma, bool some_strong) {

@@ -22,7 +22,7 @@ if not os.path.exists(path):
                            "--gop", "60", "--bframes", "2", "--threads", "16", "--qp", "26", "--fps", "30", "--out", path], stdout=subprocess.DEVNULL)
 idx = hw.index_video(path)
 import torch  # noqa: E402
-rows = [57]   # the P picture three before the second keyframe: a long chain of P pictures, the last launch is one of them
+rows = [int(os.environ.get("ROW", 57))]   # 57: the P picture three before the second keyframe (a long chain of P pictures, the last launch is one of them); 60: a keyframe
 dec = hw.Decoder(path, video_index=idx, num_lanes=1)
 lib.hwang_prof_reset()
 lib.hwang_prof_enable(1)
