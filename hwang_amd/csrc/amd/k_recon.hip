@@ -2488,7 +2488,11 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
 #pragma unroll
         for (int c = 0; c < 3; ++c) tcw[c] = *reinterpret_cast<const uint32_t*>(L.db.tc0[pl][c]);
         // (bS = 4 exists on macroblock edges of intra macroblocks only: the formulas for it are skipped where no lane has it)
-        const bool some_strong = __ballot(((vbs | hbs) & 0x04040404u) != 0) != 0;
+        // (and per edge: the macroblock edge - byte 0 of the strengths - is where an intra macroblock has it, its
+        // inner edges have bS 3: three of an intra macroblock's four steps per direction skip the formulas)
+        const bool strong_outer = __ballot(((vbs | hbs) & 0x00000004u) != 0) != 0;
+        const bool strong_inner = __ballot(((vbs | hbs) & 0x04040400u) != 0) != 0;
+        const bool some_strong = strong_outer || strong_inner;
         // ---- rows above: wait for the row above to be two macroblocks ahead
         uint32_t top_word = 0;
         if (top_edge) {
@@ -2561,14 +2565,14 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
             if (lane >= 32 || (v_chroma && (e & 1))) bs = 0;
             const int alpha = (a3 >> (8 * cls)) & 0xff, beta = (b3 >> (8 * cls)) & 0xff;
             const int tc0 = bs && bs < 4 ? (tcw[cls] >> (8 * (bs - 1))) & 0xff : 0;
-            if (e == 0) filter_dwords(R0, R1, bs, alpha, beta, tc0, v_chroma, some_strong);
-            else if (e == 1) filter_dwords(R1, R2, bs, alpha, beta, tc0, v_chroma, some_strong);
+            if (e == 0) filter_dwords(R0, R1, bs, alpha, beta, tc0, v_chroma, strong_outer);
+            else if (e == 1) filter_dwords(R1, R2, bs, alpha, beta, tc0, v_chroma, strong_inner);
             else if (e == 2) {
               uint32_t lo = v_chroma ? R1 : R2;
-              filter_dwords(lo, R3, bs, alpha, beta, tc0, v_chroma, some_strong);
+              filter_dwords(lo, R3, bs, alpha, beta, tc0, v_chroma, strong_inner);
               R1 = v_chroma ? lo : R1;
               R2 = v_chroma ? R2 : lo;
-            } else filter_dwords(R3, R4, bs, alpha, beta, tc0, v_chroma, some_strong);
+            } else filter_dwords(R3, R4, bs, alpha, beta, tc0, v_chroma, strong_inner);
           }
           if (lane < 32) {
             uint32_t* row = reinterpret_cast<uint32_t*>(T + v_off);
@@ -2650,7 +2654,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
             l.q1 = v[4 * e + 5];
             l.q2 = v[4 * e + 6];
             l.q3 = v[4 * e + 7];
-            filter_line(l, bs, alpha, beta, tc0, h_chroma, some_strong);
+            filter_line(l, bs, alpha, beta, tc0, h_chroma, e == 0 ? strong_outer : strong_inner);
             v[4 * e + 1] = l.p2;
             v[4 * e + 2] = l.p1;
             v[4 * e + 3] = l.p0;

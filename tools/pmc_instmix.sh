@@ -5,14 +5,14 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out
 FR=${FRAMES:-10800}
-python3 bench.py --frames $FR --steps 1 --warmup 1 --no-cpu-baseline --no-hbm-output > /dev/null 2>&1
+python3 bench.py --frames $FR --steps 1 --warmup 1 --no-cpu-baseline --no-hbm-output --no-reference-api > /dev/null 2>&1
 (cd /tmp && rocprofv3 --list-avail 2>/dev/null | grep -o -E "SQ_(WAVES|INSTS_VALU|INSTS_SALU|INSTS_LDS|INSTS_VMEM_RD|INSTS_VMEM_WR|INSTS_VMEM|INSTS_SMEM|WAVE_CYCLES|BUSY_CYCLES|WAIT_INST_ANY|ACTIVE_INST_VALU|INST_CYCLES_VMEM|WAIT_ANY|LDS_BANK_CONFLICT|INSTS_VALU_MFMA_I8)\b" | sort -u | tr '\n' ' ') > gpurun_out/pmc_avail.txt
 cat gpurun_out/pmc_avail.txt; echo
 i=0
 SETS=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT")
 for set in "${SETS[@]:0:${NSETS:-3}}"; do
   i=$((i+1)); rm -rf /tmp/pmc_mix$i
-  (cd /tmp && rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_mix$i -o pmc --output-format csv -- python3 "$GRAFT_REPO_ROOT/bench.py" --frames $FR --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-output > /dev/null 2> "$GRAFT_REPO_ROOT/gpurun_out/pmc_mix$i.err")
+  (cd /tmp && rocprofv3 --pmc $set --kernel-trace -d /tmp/pmc_mix$i -o pmc --output-format csv -- python3 "$GRAFT_REPO_ROOT/bench.py" --frames $FR --steps 1 --warmup 0 --no-cpu-baseline --no-hbm-output --no-reference-api > /dev/null 2> "$GRAFT_REPO_ROOT/gpurun_out/pmc_mix$i.err")
   tail -1 gpurun_out/pmc_mix$i.err
 done
 python3 - <<'PY' > gpurun_out/pmc_instmix.json
