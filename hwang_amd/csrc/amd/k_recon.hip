@@ -1578,23 +1578,27 @@ template <bool CHAIN>
 __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, const int wave, const int lane, IntraGroupLds& G,
                                            const IntraTables& T) {
   const PictureParams& pp = job.pp;
+  // (copies: a field read through `pp` is a load from global memory wherever it is used - the compiler cannot know that
+  // the stores below leave the descriptor alone - and a load in the macroblock loop is a round trip, and a drain of
+  // everything in flight, on the chain)
+  const int W = pp.mb_width, H = pp.mb_height;
   const MbInfo* __restrict__ mbs = job.mbs;
   const uint32_t* __restrict__ coefs = job.coefs;
   const int mby = band * kBandWaves + wave;
-  if (mby >= pp.mb_height) return;  // no workgroup barrier below this point
+  if (mby >= H) return;  // no workgroup barrier below this point
   lds_counter* progress = (lds_counter*)G.progress;
   IntraWaveLds& L = G.w[wave];
   uint8_t* tile = L.tile;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
-  const bool lds_nb = !job.do_inter && pp.mb_width <= kLineMbs;  // wave uniform
+  const bool lds_nb = !job.do_inter && W <= kLineMbs;  // wave uniform
   uint8_t (*line_up)[32] = wave == 0 ? G.line[kBandWaves] : G.line[wave - 1];
   uint8_t (*line_me)[32] = G.line[wave];
   BandCtl* ctl = static_cast<BandCtl*>(job.band_ctl);
   const uint32_t epoch = job.epoch;
   const bool importing = wave == 0 && band > 0;
-  const bool exporting = wave == kBandWaves - 1 && mby + 1 < pp.mb_height;
-  uint64_t* const xline = ctl->lines + static_cast<size_t>(bands_of(pp.mb_height)) * kLineMbs * kMvLineWords;
+  const bool exporting = wave == kBandWaves - 1 && mby + 1 < H;
+  uint64_t* const xline = ctl->lines + static_cast<size_t>(bands_of(H)) * kLineMbs * kMvLineWords;
   if (wave == 0 && band == 0 && lane == 0) G.progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
   int seen = 0;  // importing: macroblocks of the row above that are known final (and, with lds_nb, sit in s_line[kBandWaves])
   // lds_nb pictures: fetch the next eight entries of the band above, keep the
@@ -1604,11 +1608,11 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
     const uint64_t* src = xline + static_cast<size_t>(band - 1) * kLineMbs * kIntraLineWords;
     for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
       const int e = seen + (lane >> 3), d = lane & 7;
-      const bool act = e < pp.mb_width;
+      const bool act = e < W;
       uint64_t v = 0;
       if (act) v = agent_ld64(src + e * kIntraLineWords + d);
       const uint64_t missing = __ballot(act && static_cast<uint32_t>(v >> 32) != epoch);
-      const int nvalid = min(missing ? __builtin_ctzll(missing) >> 3 : 8, pp.mb_width - seen);
+      const int nvalid = min(missing ? __builtin_ctzll(missing) >> 3 : 8, W - seen);
       if (act && (lane >> 3) < nvalid) reinterpret_cast<uint32_t*>(G.line[kBandWaves][e])[d] = static_cast<uint32_t>(v);
       seen += nvalid;
       if (seen < need) __builtin_amdgcn_s_sleep(1);
@@ -1658,23 +1662,23 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
   const uint32_t* __restrict__ resid = reinterpret_cast<const uint32_t*>(job.resid);
   {
     int prev_mbx = -2;  // macroblock whose samples the tile still holds
-    for (int mbx0 = 0; mbx0 < pp.mb_width; mbx0 += 64) {
+    for (int mbx0 = 0; mbx0 < W; mbx0 += 64) {
       // which of the next 64 macroblocks of this row are intra?
       const int probe = mbx0 + lane;
-      const bool is_intra = probe < pp.mb_width && (gld8(&mbs[mby * pp.mb_width + probe].flags) & MBF_INTRA);
+      const bool is_intra = probe < W && (gld8(&mbs[mby * W + probe].flags) & MBF_INTRA);
       unsigned long long todo = __ballot(is_intra);
       // Surface path (pictures with inter macroblocks): those are final since k_inter, so the row is complete up to its
       // next intra macroblock the moment the previous one's samples have landed - say so at once, not only "up to the
       // one just finished".  A row below then waits only where an intra macroblock really sits above an intra
       // macroblock (in a P picture they are few and scattered: the wavefront used to crawl through every row at the
       // pace of the rows above whether or not anything there concerned it).
-      if (!lds_nb) publish(todo ? mbx0 + __builtin_ctzll(todo) : min(mbx0 + 64, pp.mb_width));
+      if (!lds_nb) publish(todo ? mbx0 + __builtin_ctzll(todo) : min(mbx0 + 64, W));
       // residual of the first macroblock of the run; inside the loop the next one's is fetched a macroblock ahead
       // (and its record: a load at the top of the macroblock would sit on the chain)
       uint32_t r0 = 0, r1 = 0, r2 = 0;
       MbInfo next_mb = {};
       if (todo) {
-        const int first = mby * pp.mb_width + mbx0 + __builtin_ctzll(todo);
+        const int first = mby * W + mbx0 + __builtin_ctzll(todo);
         const uint32_t* rp = resid + (size_t)first * 192;
         r0 = gld32(rp + lane);
         r1 = gld32(rp + 64 + lane);
@@ -1694,7 +1698,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
         reinterpret_cast<uint32_t*>(L.res_y)[64 + lane] = r1;
         reinterpret_cast<uint32_t*>(L.res_c)[lane] = r2;
         if (todo) {
-          const int nxt = mby * pp.mb_width + mbx0 + __builtin_ctzll(todo);
+          const int nxt = mby * W + mbx0 + __builtin_ctzll(todo);
           const uint32_t* rp = resid + (size_t)nxt * 192;
           r0 = gld32(rp + lane);
           r1 = gld32(rp + 64 + lane);
@@ -1712,14 +1716,14 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
           // top-right neighbour's, and of this row up to the left neighbour's, have to have landed
           if (job.do_inter) {
             bool ok = true;
-            if ((hB || hC || hD) && mby > 0) ok = chain_need_inter(ctl, mby - 1, min(mbx + 1, pp.mb_width - 1), seen_inter_up);
+            if ((hB || hC || hD) && mby > 0) ok = chain_need_inter(ctl, mby - 1, min(mbx + 1, W - 1), seen_inter_up);
             if (ok && hA && mbx > 0) ok = chain_need_inter(ctl, mby, mbx - 1, seen_inter_me);
             if (!ok) report_fault(job, FAULT_CHAIN_INTER);
           }
         }
         // the row above must be complete up to the top-right neighbour
         if (hB || hC || hD) {
-          const int need = min(mbx + 2, pp.mb_width);
+          const int need = min(mbx + 2, W);
           if (!importing) row_wait(progress, wave, need);
           else if (lds_nb) import_line(need);
           else import_wait(need);
@@ -1998,7 +2002,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
             progress[wave + 1] = mbx + 1;
           }
         } else {
-          publish(todo ? mbx0 + __builtin_ctzll(todo) : min(mbx0 + 64, pp.mb_width));  // up to the next intra macroblock
+          publish(todo ? mbx0 + __builtin_ctzll(todo) : min(mbx0 + 64, W));  // up to the next intra macroblock
         }
         prev_mbx = mbx;
         STAMP(si_on, mbx, 5);
@@ -2008,14 +2012,14 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
     // inter macroblocks at the end of the row need no work: the row is done
     if (lds_nb) {
       __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (!exporting) progress[wave + 1] = pp.mb_width;  // (every macroblock of an lds_nb picture exported its own entry)
+      if (!exporting) progress[wave + 1] = W;  // (every macroblock of an lds_nb picture exported its own entry)
     } else {
-      publish(pp.mb_width);
+      publish(W);
     }
     if constexpr (CHAIN) {
       // the row is through: its samples have landed
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(pp.mb_width));
+      if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(W));
     }
   }
 }
