@@ -9,6 +9,7 @@ bash tools/bench_profile.sh > gpurun_out/bench_profile.log 2>&1; head -c 600 gpu
 bash tools/pmc_profile.sh > gpurun_out/pmc_profile.log 2>&1; tail -5 gpurun_out/pmc_profile.log
 timeout 600 python3 tools/replay_probe.py frames=10800 widths=8,48,111 launches=40 out=gpurun_out/replay.json > /dev/null 2> gpurun_out/replay.err; tail -2 gpurun_out/replay.err
 timeout 600 python3 tools/replay_probe.py frames=10800 lanes=128 widths=48,128,185 launches=30 out=gpurun_out/replay_128lanes.json > /dev/null 2> gpurun_out/replay128.err; tail -2 gpurun_out/replay128.err
+NSETS=2 bash tools/pmc_instmix.sh > gpurun_out/pmc_instmix.log 2>&1; tail -3 gpurun_out/pmc_instmix.log
 for c in C2 C4; do
   python3 bench.py --config $c --no-reference-api > gpurun_out/bench_$c.json 2> gpurun_out/bench_$c.err
   head -c 400 gpurun_out/bench_$c.json; echo
