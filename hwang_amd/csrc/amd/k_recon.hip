@@ -1591,7 +1591,8 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
   uint8_t* tile = L.tile;
   const Surface cur = pp.surfaces[pp.cur_slot];
   const int yp = pp.y_pitch, cp = pp.c_pitch;
-  const bool lds_nb = !job.do_inter && W <= kLineMbs;  // wave uniform
+  const bool do_inter = job.do_inter;
+  const bool lds_nb = !do_inter && W <= kLineMbs;  // wave uniform
   uint8_t (*line_up)[32] = wave == 0 ? G.line[kBandWaves] : G.line[wave - 1];
   uint8_t (*line_me)[32] = G.line[wave];
   BandCtl* ctl = static_cast<BandCtl*>(job.band_ctl);
@@ -1714,7 +1715,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
         if constexpr (CHAIN) {
           // the neighbours among the INTER macroblocks come from this same launch: the runs of the row above up to the
           // top-right neighbour's, and of this row up to the left neighbour's, have to have landed
-          if (job.do_inter) {
+          if (do_inter) {
             bool ok = true;
             if ((hB || hC || hD) && mby > 0) ok = chain_need_inter(ctl, mby - 1, min(mbx + 1, W - 1), seen_inter_up);
             if (ok && hA && mbx > 0) ok = chain_need_inter(ctl, mby, mbx - 1, seen_inter_me);
@@ -2290,9 +2291,11 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
   const int yp = pp.y_pitch, cp = pp.c_pitch;
   const int W = pp.mb_width;
   BandCtl* ctl = static_cast<BandCtl*>(job.band_ctl);
-  const uint64_t epoch = static_cast<uint64_t>(job.epoch) << 32;
+  const uint32_t epoch32 = job.epoch;  // (locals: see the lesson about descriptor fields in loops)
+  const uint64_t epoch = static_cast<uint64_t>(epoch32) << 32;
+  const bool has_row_below = mby + 1 < pp.mb_height;
   const bool importing = wave == 0 && band > 0;
-  const bool exporting = wave == kBandWaves - 1 && mby + 1 < pp.mb_height;
+  const bool exporting = wave == kBandWaves - 1 && has_row_below;
   if (wave == 0 && band == 0 && lane == 0) G.progress[0] = 1 << 30;  // the row above the picture: only this wave reads it
   int seen = 0;  // importing: macroblocks of the row above known to be final
   // test hook: a band whose progress words carry a wrong tag looks exactly like a band that never reports
@@ -2328,8 +2331,8 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
       if (chain_intra) {
         // (m + 2 in both rows: the intra macroblock to the right of m predicts from m's column too - top-left in the
         // row below, and in THIS row from the row above, whose last lines this row's top edges change)
-        ok = chain_need_intra(ctl, job.epoch, mby, static_cast<uint32_t>(min(m + 2, W)), seen_intra_me);
-        if (ok && mby + 1 < pp.mb_height) ok = chain_need_intra(ctl, job.epoch, mby + 1, static_cast<uint32_t>(min(m + 2, W)), seen_intra_below);
+        ok = chain_need_intra(ctl, epoch32, mby, static_cast<uint32_t>(min(m + 2, W)), seen_intra_me);
+        if (ok && has_row_below) ok = chain_need_intra(ctl, epoch32, mby + 1, static_cast<uint32_t>(min(m + 2, W)), seen_intra_below);
         if (!ok) report_fault(job, FAULT_CHAIN_INTRA);
       }
     }
