@@ -6,14 +6,22 @@
 //               8x8 inverse transforms, quarter-sample luma and eighth-sample
 //               chroma motion compensation from unaligned dword fetches
 //               (default, explicit and implicit weighting), + residual
-//   k_mv        motion vectors of P macroblocks from the parsed differences
+//   k_mv        motion vectors of P macroblocks from the parsed differences (a row pipeline like k_intra's; the
+//               prediction branch-free on packed vectors, a fifth wave per workgroup imports the band above's line)
 //   k_residual  dequant + inverse transforms of the intra macroblocks -> int16
 //   k_intra     intra prediction in dependency order: a wave per macroblock
 //               row, four rows (one workgroup) per band, progress handed down
 //               through LDS inside a band and through agent-scope words in
 //               global memory between bands
 //   k_bs        boundary strengths, alpha / beta / tc0, edge masks per macroblock
-//   k_deblock   in-loop deblocking filter, same banded row pipeline
+//   k_deblock   in-loop deblocking filter, same banded row pipeline; a row's vertical edges on its dwords and a
+//               column's horizontal edges on its bytes, in registers
+//   k_chain     k_inter + k_intra + k_deblock of a lane's dependent pictures as ONE launch of overlapping stages
+//
+// What the row pipelines cost: a lone wave issues an instruction every four to five clocks whatever unit executes it,
+// so a macroblock's step is the number of instructions on its path ("What a step costs"): their
+// hot paths are written without branches on values, and nothing that is a load from global memory sits in a
+// macroblock loop unless it is a prefetch.
 //
 // These replace what the reference gets from libavcodec's hl_decode_mb /
 // loop_filter behind avcodec_send_packet
