@@ -26,7 +26,10 @@ process instead (shared work queue, lanes bound round-robin to the devices).
 
 Prints ONE JSON line on rank 0.  `roofline` is measured live with HIP events
 on the executor's streams (hwang_prof_*) in an extra pass after the timed
-region (`end_to_end_frac`: SURVEY 8(d)'s whole-pipeline accounting);
+region (`end_to_end_frac`: SURVEY 8(d)'s whole-pipeline accounting; `frac_replayed_wide`:
+the same kernel in the widest run of `replay` - the step's last pictures relaunched
+straight from HBM, the host out of the way - beside `frac`, which stays the timed
+configuration's);
 `value_reference_api*` are the same request through the reference's Python API
 (one DecoderAutomata): with the reference's own unmodified caller loop
 (num_devices = 1, one interval per initialize: python/hwang/decoder.py:28,60-67)
