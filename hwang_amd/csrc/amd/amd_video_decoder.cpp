@@ -68,6 +68,16 @@ constexpr int kBounce = 4;      // pinned output bounce buffers (serial entropy 
 constexpr int kPipeBounce = 24; // ... with entropy workers: frames are fetched before their pictures reach the GPU
 constexpr int kCopiers = 4;     // ... and this many threads copy them out of the bounce buffers (copier_loop)
 
+// The entropy workers of every decoder that was created with num_devices = 1 ("the backend decides"): ONE pool for
+// the process.  The reference's callers make one such decoder per thread or per pipeline instance
+// (python/hwang/decoder.py:28; Scanner: one DecoderAutomata per pipeline instance); with a pool each, N of them would
+// run 16 N threads on the same CPUs.  Sized by the first decoder that asks; never destroyed (its threads sleep on a
+// condition variable and touch nothing but the jobs they are handed; parsers drain their own pictures before they go).
+h264::WorkerPool* shared_entropy_pool(int threads) {
+  static h264::WorkerPool* pool = new h264::WorkerPool(threads);
+  return pool;
+}
+
 class AMDVideoDecoder : public VideoDecoderInterface,
                         public SparseDecodeHints,
                         public PlanarOutput,
@@ -107,7 +117,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       // (a decoder that chose its workers itself - num_devices = 1, the reference's own caller - serves one interval
       // at a time: a window of two pictures per worker is all it can fill, and it should not pin 1.6 GB for it)
       max_in_flight_ = auto_workers_ ? 2 * num_workers_ : std::min(std::max(4 * num_workers_, 64), 128);
-      pool_.reset(new h264::WorkerPool(num_workers_));
+      if (auto_workers_) {
+        shared_pool_ = shared_entropy_pool(num_workers_);
+      } else {
+        pool_.reset(new h264::WorkerPool(num_workers_));
+      }
     }
     // A staging set is tied up from begin_picture until the GPU is through with the picture.  The GPU needs ~2 ms per
     // dependent picture and interval, the workers deliver a picture every ~0.15 ms: only with the pictures of many
@@ -150,7 +164,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     }
     HWANG_RETURN_ON_ERROR(drain_and_reset());
     info_ = metadata;
-    parser_.reset(new h264::Parser(this, pool_.get(), max_in_flight_));
+    parser_.reset(new h264::Parser(this, shared_pool_ ? shared_pool_ : pool_.get(), max_in_flight_));
     if (!parser_->configure(extradata.data(), extradata.size()))
       return Result(false, "AMDVideoDecoder::configure: " + parser_->error());
     if (parser_->width() != static_cast<int>(metadata.width) ||
@@ -200,6 +214,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     int slot;
     if (!outq_.try_pop(slot)) return Result();
     buffered_.fetch_sub(1, std::memory_order_acq_rel);
+    if (slot >= 0) note_undelivered(-1);
     std::lock_guard<std::mutex> lk(out_mu_);
     if (slot >= 0) unref_surface_locked(slot, kHeldByOutput);
     return Result();
@@ -377,13 +392,23 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     int ji = -1;
     {
       int oldest = -1;
-      const int nj = static_cast<int>(jobs_.size());
+      const int nj = jobs_ready_;
       for (int k = 0; k < nj && ji < 0; ++k) {
         const int i = (job_cursor_ + k) % nj;
         const Job& cand = jobs_[i];
         if (cand.in_use.load(std::memory_order_acquire)) continue;
         if (!cand.stamp.seq || done[cand.stamp.lane] >= cand.stamp.seq) ji = i;
         else if (oldest < 0 || cand.order < jobs_[oldest].order) oldest = i;
+      }
+      // (a decoder that sized its own window - num_devices = 1 - makes its staging sets as the intervals turn out to
+      // need them: one more rather than a wait)
+      if (ji < 0 && jobs_ready_ < static_cast<int>(jobs_.size())) {
+        std::string alloc_error;
+        if (alloc_job(jobs_[jobs_ready_], &alloc_error)) ji = jobs_ready_++;
+        else if (oldest < 0) {
+          *error = alloc_error;
+          return false;
+        }
       }
       if (ji < 0) ji = oldest;
     }
@@ -400,7 +425,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       j.stamp = Stamp();
     }
     j.in_use.store(true, std::memory_order_release);
-    job_cursor_ = (ji + 1) % static_cast<int>(jobs_.size());
+    job_cursor_ = (ji + 1) % std::max(1, jobs_ready_);
     j.lane = cur_lane_;
     out->cookie = ji;
     out->mb = j.mb_host;
@@ -602,6 +627,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       return;
     }
     buffered_.fetch_add(1, std::memory_order_acq_rel);
+    if (slot >= 0) note_undelivered(1);
   }
 
   void release_surface(int slot) override {
@@ -806,6 +832,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     copy_error_.clear();
     outq_.clear();
     buffered_.store(0);
+    note_undelivered(-undelivered_.load(std::memory_order_acquire));
     for (SurfaceSlot& s : surf_) s.held = 0;
     return Result();
   }
@@ -876,31 +903,43 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       jobs_.clear();
       jobs_.resize(std::max(max_in_flight_ + 8, std::min(max_in_flight_ + pipe_depth_, affordable)));
     }
-    for (Job& j : jobs_) {
-      if (hipHostMalloc(reinterpret_cast<void**>(&j.mb_host), nmb * sizeof(MbInfo), hipHostMallocDefault) != hipSuccess ||
-          hipHostMalloc(reinterpret_cast<void**>(&j.coef_host), coef_capacity_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-          hipHostMalloc(reinterpret_cast<void**>(&j.slice_host), kMaxSlices * sizeof(SliceParams), hipHostMallocDefault) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.mb_dev), nmb * sizeof(MbInfo)) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.motion_dev), nmb * sizeof(MbMotion)) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.pmo_dev), nmb * sizeof(PMotion)) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.pmx_dev), (pmx_words_ + 64) * sizeof(uint32_t)) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.coef_dev), coef_capacity_ * sizeof(uint32_t)) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.slice_dev), kMaxSlices * sizeof(SliceParams)) != hipSuccess ||
-          hipMalloc(&j.db_dev, amd::deblock_scratch_bytes(static_cast<int>(nmb))) != hipSuccess ||
-          hipMalloc(reinterpret_cast<void**>(&j.resid_dev), nmb * 384 * sizeof(int16_t)) != hipSuccess ||
-          hipMalloc(&j.band_ctl_dev, amd::band_ctl_bytes(mbh_)) != hipSuccess ||
-          hipMemset(j.band_ctl_dev, 0, amd::band_ctl_bytes(mbh_)) != hipSuccess) {
-        *error = "AMDVideoDecoder: out of memory for staging buffers";
-        return false;
-      }
-      if (!gpu_visible(j.mb_host) || !gpu_visible(j.coef_host) || !gpu_visible(j.slice_host)) {
-        *error = "AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device";
-        return false;
-      }
-      j.stamp = Stamp();
+    // (with workers chosen by the backend itself only a floor of sets is made here, the rest on demand: begin_picture)
+    const int eager = auto_workers_ ? std::min<int>(static_cast<int>(jobs_.size()), 8) : static_cast<int>(jobs_.size());
+    jobs_ready_ = 0;
+    for (int i = 0; i < eager; ++i) {
+      if (!alloc_job(jobs_[i], error)) return false;
+      jobs_ready_ = i + 1;
     }
     job_cursor_ = 0;
     rollback.armed = false;
+    return true;
+  }
+
+  // One staging set: pinned host buffers for the records of a picture, their device copies and the per-picture scratch.
+  bool alloc_job(Job& j, std::string* error) {
+    const size_t nmb = static_cast<size_t>(mbw_) * mbh_;
+    if (hipHostMalloc(reinterpret_cast<void**>(&j.mb_host), nmb * sizeof(MbInfo), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&j.coef_host), coef_capacity_ * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&j.slice_host), kMaxSlices * sizeof(SliceParams), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&j.mb_dev), nmb * sizeof(MbInfo)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&j.motion_dev), nmb * sizeof(MbMotion)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&j.pmo_dev), nmb * sizeof(PMotion)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&j.pmx_dev), (pmx_words_ + 64) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&j.coef_dev), coef_capacity_ * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&j.slice_dev), kMaxSlices * sizeof(SliceParams)) != hipSuccess ||
+        hipMalloc(&j.db_dev, amd::deblock_scratch_bytes(static_cast<int>(nmb))) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&j.resid_dev), nmb * 384 * sizeof(int16_t)) != hipSuccess ||
+        hipMalloc(&j.band_ctl_dev, amd::band_ctl_bytes(mbh_)) != hipSuccess ||
+        hipMemset(j.band_ctl_dev, 0, amd::band_ctl_bytes(mbh_)) != hipSuccess) {
+      (void)hipGetLastError();
+      *error = "AMDVideoDecoder: out of memory for staging buffers";
+      return false;
+    }
+    if (!gpu_visible(j.mb_host) || !gpu_visible(j.coef_host) || !gpu_visible(j.slice_host)) {
+      *error = "AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device";
+      return false;
+    }
+    j.stamp = Stamp();
     return true;
   }
 
@@ -979,6 +1018,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   void teardown() {
+    note_undelivered(-undelivered_.load(std::memory_order_acquire));  // (frames nobody will fetch any more)
     if (getenv("HWANG_EXEC_DEBUG"))
       fprintf(stderr, "[decoder lane %d] samples fed %lld in %.3f s of feed() (%.3f s of it stalled on the GPU: motion waits %lld, "
                       "job-ring waits %lld, surface waits %lld), workers %d\n", lanes_.empty() ? -1 : lanes_[0],
@@ -1063,6 +1103,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
                     "(set_wanted) and was not decoded");
     outq_.try_pop(slot);
     buffered_.fetch_sub(1, std::memory_order_acq_rel);
+    note_undelivered(-1);
     trace::event("get_frame", slot);
     const SurfaceSlot& s = surf_[slot];
     amd::ConvSubmit sub;
@@ -1172,7 +1213,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   const bool rotate_always_ = getenv("HWANG_TEST_ROTATE_LANES") != nullptr;
   const bool host_mv_ = getenv("HWANG_HOST_MV") != nullptr;  // experiment: P vectors derived on the host
   int pipe_depth_ = 0;          // ... and how many more may be queued towards the GPU (fewer when the staging budget says so)
-  std::unique_ptr<h264::WorkerPool> pool_;
+  std::unique_ptr<h264::WorkerPool> pool_;       // num_devices > 1: this decoder's own threads
+  h264::WorkerPool* shared_pool_ = nullptr;      // num_devices = 1: the process-wide pool (shared_entropy_pool)
   std::vector<std::thread> copiers_;
   bool copiers_stop_ = false;   // (out_mu_)
   std::string copy_error_;      // (out_mu_) a conversion that failed under a copier; reported by the next get_frame
@@ -1206,6 +1248,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   SurfaceSlot surf_[amd::kMaxSurfaces];
   std::vector<Job> jobs_;
   int job_cursor_ = 0;
+  int jobs_ready_ = 0;  // jobs_[0 .. jobs_ready_) have their buffers (the rest are made on demand, alloc_job)
   std::vector<Bounce> bounce_;
   int bounce_cursor_ = 0;
 
@@ -1213,6 +1256,13 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   std::condition_variable out_cv_;  // a deferred conversion was submitted or cancelled
   Queue<int> outq_{4096};  // surface slot per frame in display order, -1 = skipped (hwang/util/queue.h's role)
   std::atomic<int> buffered_{0};
+  // real frames among them (skipped output positions hold no surface): what GpuExecutor::replay must not run over
+  std::atomic<int> undelivered_{0};
+  void note_undelivered(int delta) {
+    if (!delta) return;
+    undelivered_.fetch_add(delta, std::memory_order_acq_rel);
+    if (exec_) exec_->note_undelivered(delta);
+  }
 
   BackendCounters counters_;
   int64_t decoded_base_ = 0, skipped_base_ = 0, folded_decoded_ = 0, folded_skipped_ = 0;

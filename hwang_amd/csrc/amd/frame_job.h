@@ -203,7 +203,9 @@ struct alignas(16) JobDesc {
   // = row_start[mb_height] followed by the difference words
   const PMotion* pmo;
   const uint32_t* pmx;
-  uint64_t reserved;
+  // Chain launches: the launch's control words (ChainArgs::tickets; k_recon.hip: kChainFaultWord, kChainBeatWord);
+  // nullptr in every other launch
+  const uint32_t* chain_ctl;
   UploadDesc uploads[kJobUploads];
   // Chain launches (k_chain): the job - index into the launch's table - that reconstructs surface s in this same
   // launch, -1 if the surface was final before the launch.  A picture that predicts from such a surface follows the
@@ -230,7 +232,7 @@ struct ChainArgs {
   const JobDesc* jobs;
   const uint32_t* row_units;    // job << 8 | stage << 7 | band     (stage 0 intra, 1 deblock)
   const uint32_t* inter_units;  // job << 20 | run                  (run = row * ceil(mb_width / kChainRun) + j: macroblocks 8 j .. of the row)
-  uint32_t* tickets;            // [0] rows, [1] inter; zeroed with the table
+  uint32_t* tickets;            // [0] rows, [1] inter, [2] the launch's first fault, [3] its heartbeat; zeroed with the table
   uint32_t num_row_units, num_inter_units;
   uint64_t bytes;               // algorithmic, for the span
 };

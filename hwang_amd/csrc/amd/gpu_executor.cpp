@@ -122,6 +122,7 @@ bool GpuExecutor::start(std::string* error) {
   }
   // experiment knobs: how many of the heavy engines take work, how many batches each keeps in flight
   if (const char* e = getenv("HWANG_HEAVY_ENGINES")) heavy_engines_ = std::max(1, std::min(kHeavyEngines, atoi(e)));
+  if (const char* e = getenv("HWANG_NO_HEAVY")) no_heavy_ = atoi(e) != 0;  // experiment: intra-only pictures travel in the light batches
   if (const char* e = getenv("HWANG_HEAVY_INFLIGHT")) heavy_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
   if (const char* e = getenv("HWANG_LIGHT_INFLIGHT")) light_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
   if (const char* e = getenv("HWANG_LIGHT_ENGINES")) light_engines_ = std::max(1, std::min(1 + kExtraLightEngines, atoi(e)));
@@ -245,7 +246,7 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
       for (const Lane& l : lanes_) busy += l.active && (!l.fifo.empty() || l.launched != l.completed);
       with_its_chain = busy <= chain_max_lanes_;
     }
-    it.engine = (job.heavy && !with_its_chain) ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
+    it.engine = (job.heavy && !with_its_chain && !no_heavy_) ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
     it.pre = prestage_ ? 0 : 2;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
@@ -335,7 +336,39 @@ bool GpuExecutor::replay(int width, int launches, bool chain, ReplayResult* out,
     *error = "GpuExecutor::replay: no pictures kept (keep_recent before the decode)";
     return false;
   }
+  if (undelivered_.load(std::memory_order_acquire) > 0) {
+    // the pictures are decoded in place again: a frame somebody has yet to fetch from one of these surfaces may come
+    // out of a picture whose references have been reused since
+    *error = "GpuExecutor::replay: a decoder of this device still holds decoded frames that were not fetched or discarded";
+    return false;
+  }
   width = std::max(1, std::min<int>({width, static_cast<int>(pics.size()), kMaxJobs}));
+  if (chain) {
+    // a chain launch's unit table holds kUnitWords words: fewer pictures per launch rather than a truncated list
+    size_t words = 4;
+    int fit = 0;
+    for (; fit < width; ++fit) {
+      const PicSubmit& p = pics[fit % pics.size()];
+      const size_t bands = static_cast<size_t>((p.desc.pp.mb_height + 3) / 4);
+      const size_t runs = static_cast<size_t>(p.desc.pp.mb_height) * ((p.desc.pp.mb_width + kChainRun - 1) / kChainRun);
+      const size_t units = (p.desc.do_inter ? runs : 0) + (p.desc.do_intra ? bands : 0) + (p.desc.do_deblock ? bands : 0);
+      if (words + units > kUnitWords) break;
+      words += units;
+    }
+    // (the launches rotate through the kept pictures: size for the largest of them)
+    size_t worst = 0;
+    for (const PicSubmit& p : pics) {
+      const size_t bands = static_cast<size_t>((p.desc.pp.mb_height + 3) / 4);
+      const size_t runs = static_cast<size_t>(p.desc.pp.mb_height) * ((p.desc.pp.mb_width + kChainRun - 1) / kChainRun);
+      worst = std::max(worst, runs + 2 * bands);
+    }
+    fit = std::min<int>(fit, static_cast<int>((kUnitWords - 4) / std::max<size_t>(worst, 1)));
+    if (fit < 1) {
+      *error = "GpuExecutor::replay: one picture's units do not fit a chain launch's unit table";
+      return false;
+    }
+    width = fit;
+  }
   if (hipSetDevice(device_) != hipSuccess) {
     *error = "GpuExecutor::replay: cannot select the device";
     return false;
@@ -347,6 +380,7 @@ bool GpuExecutor::replay(int width, int launches, bool chain, ReplayResult* out,
     return false;
   }
   static uint32_t replay_epoch = 0x40000000u;
+  __atomic_store_n(fault_flags_, 0u, __ATOMIC_RELEASE);
   hipError_t e = hipEventRecord(e0, en.stream);
   for (int it = 0; it < launches && e == hipSuccess; ++it) {
     int max_mbs = 0, max_rows = 0;
@@ -358,7 +392,8 @@ bool GpuExecutor::replay(int width, int launches, bool chain, ReplayResult* out,
       jd = p.desc;
       jd.num_uploads = 0;  // the records are where the decode left them
       jd.ticket_mv = jd.ticket_db = jd.ticket_in = 0;
-      jd.fault = nullptr;
+      jd.fault = fault_flags_;  // (engine 0's first word: the executor is idle, nobody else writes it)
+      jd.chain_ctl = chain ? en.unit_table_dev[0] : nullptr;
       jd.epoch = ++replay_epoch ? replay_epoch : ++replay_epoch;
       for (int k = 0; k < 256; ++k) jd.slot_job[k] = -1;
       max_mbs = std::max(max_mbs, p.num_mbs);
@@ -396,7 +431,8 @@ bool GpuExecutor::replay(int width, int launches, bool chain, ReplayResult* out,
       for (int i = 0; i < width; ++i) {
         const JobDesc& jd = en.job_table_host[0][i];
         const int runs = jd.pp.mb_height * ((jd.pp.mb_width + kChainRun - 1) / kChainRun);
-        for (int r = 0; r < runs && 4 + nrows + ninter < kUnitWords; ++r) inter[ninter++] = static_cast<uint32_t>(i) << 20 | static_cast<uint32_t>(r);
+        if (!jd.do_inter) continue;
+        for (int r = 0; r < runs; ++r) inter[ninter++] = static_cast<uint32_t>(i) << 20 | static_cast<uint32_t>(r);  // (width was sized for it)
       }
       ChainArgs args;
       args.jobs = en.job_table_dev[0];
@@ -424,6 +460,10 @@ bool GpuExecutor::replay(int width, int launches, bool chain, ReplayResult* out,
   (void)hipEventDestroy(e1);
   if (e != hipSuccess) {
     *error = std::string("GpuExecutor::replay: ") + hipGetErrorString(e);
+    return false;
+  }
+  if (const uint32_t code = __atomic_load_n(fault_flags_, __ATOMIC_ACQUIRE)) {
+    *error = std::string("GpuExecutor::replay: a hand-off timed out (") + fault_name(code) + "); the timing is void";
     return false;
   }
   out->width = width;
@@ -465,6 +505,21 @@ void GpuExecutor::complete(Batch* b, hipError_t status) {
   // launch failure: every lane's wait() fails from here on.
   if (b->fault) {
     const uint32_t code = __atomic_load_n(const_cast<uint32_t*>(b->fault), __ATOMIC_ACQUIRE);
+    const bool chain_fault = code == FAULT_CHAIN_REFERENCE || code == FAULT_CHAIN_INTER || code == FAULT_CHAIN_INTRA;
+    if (chain_fault && b->chain && !b->retried && status == hipSuccess && error_.empty() && !stop_) {
+      // A chain launch gave up: nothing in it moved for its polls' bound.  The pictures' records are intact and the
+      // wide kernels order pictures by kernel boundaries, not by hand-offs: the engine thread runs the batch again
+      // through them (rerun_wide); the batch stays in flight under a new ticket until that run is through.
+      fprintf(stderr, "hwang_amd: a chain launch timed out (%s); running its %zu picture(s) again through the wide kernels\n",
+              fault_name(code), b->retry_mbs.size());
+      b->retried = true;
+      b->retry_pending = true;
+      b->ticket = ++next_ticket_;
+      __atomic_store_n(const_cast<uint32_t*>(b->fault), 0u, __ATOMIC_RELEASE);
+      ++stats_.chain_retries;
+      cv_work_[b->engine].notify_one();
+      return;
+    }
     if (code && error_.empty())
       error_ = std::string("GpuExecutor: row-pipeline hand-off timed out (") + fault_name(code) +
                "); the batch's pictures are invalid";
@@ -620,6 +675,61 @@ void GpuExecutor::run_pre() {
   (void)hipStreamSynchronize(en.stream);
 }
 
+// The second run of a chain batch whose polls expired (complete()): every picture of the table through the wide
+// kernels, one launch_main per picture in table order - a lane's pictures stand in the table in decoding order and
+// pictures of different lanes do not refer to each other, so stream order is all the ordering there is - then the
+// batch's conversions and its completion mark again.  The records-only stage's results (vectors, boundary strengths,
+// intra residuals) and the records are where they were; every sample of every picture is written again before it is
+// filtered, so what the abandoned launch left in the surfaces does not matter.  Fresh epochs: the abandoned launch
+// may have left hand-off words of these pictures behind.
+void GpuExecutor::rerun_wide(Engine& en, Batch& batch) {
+  const int slot = batch.slot;
+  const int n = static_cast<int>(batch.retry_mbs.size());
+  trace::event("chain batch rerun", n);
+  for (int i = 0; i < n; ++i) {
+    JobDesc& jd = en.job_table_host[slot][i];
+    jd.chain_ctl = nullptr;
+    jd.num_uploads = 0;
+    jd.ticket_mv = jd.ticket_db = jd.ticket_in = 0;
+    jd.epoch ^= 0x80000000u;  // (a decoder counts its epochs up from 1: the upper half is free)
+    if (jd.epoch == 0) jd.epoch = 0x80000000u;
+    if (jd.inject_fault == 2) jd.inject_fault = 0;  // (the test hook of the chain's hand-off)
+    for (int k = 0; k < 256; ++k) jd.slot_job[k] = -1;
+  }
+  hipError_t e = launch_table_copy(en.job_table_dev[slot], en.job_table_host[slot], sizeof(JobDesc) * n, en.stream);
+  const uint64_t no_bytes[3] = {0, 0, 0};  // (the spans of the first attempt carry the batch's bytes)
+  for (int i = 0; i < n && e == hipSuccess; ++i) {
+    const JobDesc& jd = en.job_table_host[slot][i];
+    e = launch_main(en.job_table_dev[slot] + i, 1, batch.retry_mbs[i], jd.pp.mb_height, jd.do_inter != 0, jd.do_intra != 0,
+                    jd.do_deblock != 0, no_bytes, en.stream);
+  }
+  const std::vector<ConvSubmit>& convs = batch.retry_convs;
+  if (!convs.empty() && e == hipSuccess) {
+    int mw = 0, mh = 0;
+    for (const ConvSubmit& c : convs) {
+      mw = std::max(mw, c.desc.width);
+      mh = std::max(mh, c.desc.height);
+    }
+    // (the conversion table of the first attempt is still on the device)
+    e = launch_convert_batch(en.conv_table_dev[slot], static_cast<int>(convs.size()), mw, mh, 0, en.stream);
+    for (size_t i = 0; i < convs.size() && e == hipSuccess; ++i)
+      if (convs[i].d2h_dst)
+        e = hipMemcpyAsync(convs[i].d2h_dst, convs[i].desc.dst, convs[i].d2h_bytes, hipMemcpyDeviceToHost, en.stream);
+  }
+  if (e == hipSuccess) {
+    if (use_hostfunc_) {
+      e = hipLaunchHostFunc(en.stream, &GpuExecutor::on_batch_done, &batch);
+    } else {
+      e = launch_done(const_cast<uint32_t*>(batch.flag), batch.ticket, en.stream);
+      cv_poll_.notify_one();
+    }
+  }
+  if (e != hipSuccess) {
+    (void)hipStreamSynchronize(en.stream);
+    complete(&batch, e);
+  }
+}
+
 void GpuExecutor::run(int engine) {
   if (engine == kPreEngine) return run_pre();
   {
@@ -663,7 +773,20 @@ void GpuExecutor::run(int engine) {
           if (eligible(l, engine)) return true;
         return false;
       };
-      cv_work_[engine].wait(lk, [&] { return stop_ || (en.inflight < max_inflight && have_work()); });
+      Batch* again = nullptr;
+      auto retry_wanted = [&] {
+        for (Batch& b : en.batches)
+          if (b.in_flight && b.retry_pending) again = &b;
+        return again != nullptr;
+      };
+      cv_work_[engine].wait(lk, [&] { return stop_ || retry_wanted() || (en.inflight < max_inflight && have_work()); });
+      if (!again) retry_wanted();  // (stop_ may have ended the wait before the predicate looked)
+      if (again) {  // (also while stopping: the batch is in flight until its second run has completed)
+        again->retry_pending = false;
+        lk.unlock();
+        rerun_wide(en, *again);
+        continue;
+      }
       if (stop_) break;
       for (int i = 0; i < kInflight; ++i)
         if (!en.batches[i].in_flight) slot = i;
@@ -735,6 +858,15 @@ void GpuExecutor::run(int engine) {
         if (taken) batch.lane_counts.emplace_back(static_cast<int>(li), taken);
       }
       batch.in_flight = true;
+      batch.chain = any_chain;
+      batch.retried = batch.retry_pending = false;
+      batch.slot = slot;
+      batch.retry_mbs.clear();
+      batch.retry_convs.clear();
+      if (any_chain) {
+        for (const PicSubmit& p : pics) batch.retry_mbs.push_back(p.num_mbs);
+        batch.retry_convs = convs;
+      }
       batch.owner = this;
       batch.engine = engine;
       batch.ticket = ++next_ticket_;
@@ -769,6 +901,7 @@ void GpuExecutor::run(int engine) {
         jd.num_uploads = prestage_ ? 0 : p.ncopies;
         jd.ticket_mv = jd.ticket_db = jd.ticket_in = 0;
         jd.fault = const_cast<uint32_t*>(batch.fault);
+        jd.chain_ctl = any_chain ? en.unit_table_dev[slot] : nullptr;
         for (int c = 0; c < p.ncopies; ++c) {
           jd.uploads[c].dst = p.copies[c].dst;
           jd.uploads[c].src = p.copies[c].src;

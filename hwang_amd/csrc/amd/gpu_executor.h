@@ -47,6 +47,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -109,6 +110,7 @@ class GpuExecutor {
 
   struct Stats {
     uint64_t batches = 0, pictures = 0, conversions = 0;
+    uint64_t chain_retries = 0;  // chain launches that timed out and were run again through the wide kernels
   };
   Stats stats();
 
@@ -122,6 +124,9 @@ class GpuExecutor {
   // not a decode - call it when nothing else is submitted and before the decoders are used again for real only after
   // they have been re-configured (a new interval starts from a keyframe anyway).
   void keep_recent(int pictures);
+  // Decoders report frames that are decoded (or on their way) and not yet fetched or discarded: replay() decodes in
+  // place over the decoders' surfaces and refuses to while anybody still has a frame to collect from them.
+  void note_undelivered(int delta) { undelivered_.fetch_add(delta, std::memory_order_acq_rel); }
   struct ReplayResult {
     int pictures_available = 0;  // distinct pictures the executor still holds descriptors for (P / B pictures)
     int width = 0;               // pictures per launch actually used
@@ -169,6 +174,16 @@ class GpuExecutor {
     volatile uint32_t* fault = nullptr; // pinned host memory: FAULT_* code stored by a row kernel whose poll expired
     std::vector<Item*> pre_items;       // a batch of the records-only stage: the items it covers (they stay in their
                                         // lanes' queues - a deque keeps references valid - until the sample stage took them)
+    // A chain launch whose polls expired (FAULT_CHAIN_*: nothing in the launch moved for the polls' bound - a device
+    // shared with something that starves it, or a lost hand-off) is not the end of the executor: its pictures'
+    // records are intact and the wide kernels need no hand-off between pictures, so the engine runs the batch once
+    // more through them, picture by picture (complete() arms it, run() does it; a fault in THAT run is final).
+    bool chain = false;                 // launched as a chain
+    bool retried = false;               // ... and already run a second time
+    bool retry_pending = false;         // (mu_) complete() asks the engine thread for the second run
+    int slot = 0;                       // the engine's table set the batch was built in
+    std::vector<int> retry_mbs;         // per picture of the table: macroblocks
+    std::vector<ConvSubmit> retry_convs;  // the conversions that followed the pictures
   };
 
   // End of a batch: credits the lanes and wakes waiters.  Detected by the
@@ -214,6 +229,7 @@ class GpuExecutor {
     uint32_t* unit_table_dev[kInflight] = {nullptr, nullptr, nullptr};
   };
   static constexpr size_t kUnitWords = size_t(1) << 18;  // per table: 1 MB, ~250 1080p pictures' worth of units
+  void rerun_wide(Engine& en, Batch& batch);
 
   // May engine `e` take the head of this lane's queue?  (mu_ held)
   bool eligible(const Lane& l, int e) const {
@@ -245,6 +261,7 @@ class GpuExecutor {
   //    +4 % (heavy) and +3 % (light) returned frames/s at lower CPU time; the
   //    4K configurations do not change.
   // HWANG_HEAVY_ENGINES / HWANG_HEAVY_INFLIGHT / HWANG_LIGHT_INFLIGHT override.
+  bool no_heavy_ = false;
   int heavy_engines_ = 1;
   int heavy_inflight_ = 1;
   int light_inflight_ = 1;
@@ -253,6 +270,7 @@ class GpuExecutor {
   int total_inflight_ = 0;
   bool use_hostfunc_ = false;
   bool prestage_ = true;
+  std::atomic<int64_t> undelivered_{0};
   int keep_recent_ = 0;                 // (mu_)
   std::deque<PicSubmit> recent_;        // (mu_) the last keep_recent_ pictures submitted
   int chain_max_lanes_ = 2;  // chain launches only while at most this many lanes of the executor have work (HWANG_CHAIN_MAX_LANES)

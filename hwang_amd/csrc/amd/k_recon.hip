@@ -563,13 +563,23 @@ __device__ __forceinline__ int bands_of(int mb_height) { return (mb_height + kBa
 // A bounded poll of another band expired.  The polls are bounded so that a
 // protocol error can never hang the GPU; this makes the same error loud on the
 // host (GpuExecutor::complete fails the batch) instead of silent wrong samples.
-// (A fault is sticky on the host - the executor fails every request from then on - so it may be sticky here as well:
-// once one poll of a chain launch has expired, the others give up at their next look instead of each sitting out its
-// own bound; a launch with a broken hand-off then ends in a fraction of a second, not in minutes.)
-__device__ uint32_t g_fault_seen = 0;
+// Chain launches carry four control words (ChainArgs::tickets = JobDesc::chain_ctl, zeroed by the host with every
+// launch's unit table): [0] / [1] the tickets, [2] the first fault of THIS launch - once one poll has expired the
+// others give up at their next look instead of each sitting out its own bound, so a launch with a broken hand-off
+// ends in a fraction of a second; nothing outlives the launch - and [3] a heartbeat that every stage raises with
+// each piece of progress it publishes.  A poll only counts tries during which the heartbeat stood still: its bound
+// is "nothing in the whole launch has moved for that long", not "my producer took that long" - a row unit may sit
+// behind a chain of pictures, on a device it shares with other engines' launches and other processes.
+constexpr int kChainFaultWord = 2, kChainBeatWord = 3;
+constexpr int kChainTries = 1 << 17;  // ~0.1 - 0.2 s of polling with the whole launch standing still
+static_assert(kChainRun == 8, "chain_need_inter: one bit of BandCtl::inter_mask per run of 8 macroblocks (upto_mb >> 3)");
 __device__ __forceinline__ void report_fault(const JobDesc& job, uint32_t code) {
   if (job.fault) __hip_atomic_store((HW_AS1 uint32_t*)job.fault, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __hip_atomic_store((HW_AS1 uint32_t*)&g_fault_seen, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (job.chain_ctl) __hip_atomic_store((HW_AS1 uint32_t*)(job.chain_ctl + kChainFaultWord), code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (one lane calls this)
+__device__ __forceinline__ void chain_beat(const uint32_t* chain_ctl) {
+  (void)__hip_atomic_fetch_add((HW_AS1 uint32_t*)(chain_ctl + kChainBeatWord), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Development aid: what every wave of a chain launch is doing (hwang_debug_chain_state reads it while the launch is
 // still running): code << 24 | a << 12 | b per workgroup and wave.
@@ -589,9 +599,26 @@ __device__ uint64_t g_stamps[256 * 8];
 #define STAMP(on, mb, slot) do { } while (0)
 #define STAMP_VALUE(on, mb, v) do { } while (0)
 #endif
-__device__ __forceinline__ bool fault_seen() {
-  return __hip_atomic_load((const HW_AS1 uint32_t*)&g_fault_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
-}
+// Every 256th try of a chain poll: has another poll of this launch given up (then so does this one), has anything in
+// the launch moved since this poll last looked (then its count starts again)?
+struct ChainPoll {
+  const uint32_t* ctl;
+  uint32_t beat = 0;
+  int tries = 0;
+  bool armed = false;  // (the heartbeat is first read at the 256th try: a wait that is over at once costs nothing extra)
+  __device__ __forceinline__ explicit ChainPoll(const uint32_t* chain_ctl) : ctl(chain_ctl) {}
+  // false: give up
+  __device__ __forceinline__ bool again() {
+    if ((++tries & 255) == 0) {
+      if (__hip_atomic_load((const HW_AS1 uint32_t*)(ctl + kChainFaultWord), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+      const uint32_t b = __hip_atomic_load((const HW_AS1 uint32_t*)(ctl + kChainBeatWord), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (armed && b != beat) tries = 0;
+      beat = b;
+      armed = true;
+    }
+    return tries < kChainTries;
+  }
+};
 
 constexpr int kInterWaves = 4;
 // Reference window of one macroblock and one list, staged in LDS with the
@@ -671,14 +698,12 @@ HW_FN void chain_wait_reference(const JobDesc& ref, const JobDesc& job, int top,
   for (int row = last; row >= first; --row) {  // (bottom-up: the lowest row is normally the last to get there)
     bool ok = false;
     chain_dbg(3, row, need);
-    for (int tries = 0; tries < (1 << 17) && !ok; ++tries) {
+    ChainPoll poll(job.chain_ctl);
+    do {
       const uint64_t v = agent_ld64(words + row);
       ok = static_cast<uint32_t>(v >> 32) == epoch && static_cast<uint32_t>(v) >= need;
-      if (!ok) {
-        if ((tries & 255) == 255 && fault_seen()) break;
-        __builtin_amdgcn_s_sleep(2);
-      }
-    }
+      if (!ok) __builtin_amdgcn_s_sleep(2);
+    } while (!ok && poll.again());
     if (!ok) {
       report_fault(job, FAULT_CHAIN_REFERENCE);
       return;
@@ -687,29 +712,28 @@ HW_FN void chain_wait_reference(const JobDesc& ref, const JobDesc& job, int top,
 }
 // A stage's bounded poll of another stage's per-row word; what was seen last is kept, so a stage that trails the
 // other closely asks once per stretch the other has advanced, not once per macroblock.
-constexpr int kChainTries = 1 << 17;  // ~0.1 - 0.2 s of polling: far beyond any wait that can succeed
-HW_FN bool chain_need_inter(const BandCtl* ctl, int row, int upto_mb, uint64_t& seen) {
+HW_FN bool chain_need_inter(const uint32_t* chain_ctl, const BandCtl* ctl, int row, int upto_mb, uint64_t& seen) {
   const uint64_t want = (2ull << (upto_mb >> 3)) - 1;  // every run up to the one that holds macroblock upto_mb (run 63: all ones)
   if ((seen & want) == want) return true;
   chain_dbg(1, row, upto_mb);
-  for (int tries = 0; tries < kChainTries; ++tries) {
+  ChainPoll poll(chain_ctl);
+  do {
     seen = agent_ld64(&ctl->inter_mask[row]);
     if ((seen & want) == want) return true;
-    if ((tries & 255) == 255 && fault_seen()) return false;
     __builtin_amdgcn_s_sleep(1);
-  }
+  } while (poll.again());
   return false;
 }
-HW_FN bool chain_need_intra(const BandCtl* ctl, uint32_t epoch, int row, uint32_t count, uint32_t& seen) {
+HW_FN bool chain_need_intra(const uint32_t* chain_ctl, const BandCtl* ctl, uint32_t epoch, int row, uint32_t count, uint32_t& seen) {
   if (seen >= count) return true;
   chain_dbg(2, row, count);
-  for (int tries = 0; tries < kChainTries; ++tries) {
+  ChainPoll poll(chain_ctl);
+  do {
     const uint64_t v = agent_ld64(&ctl->intra_prog[row]);
     if (static_cast<uint32_t>(v >> 32) == epoch) seen = static_cast<uint32_t>(v);
     if (seen >= count) return true;
-    if ((tries & 255) == 255 && fault_seen()) return false;
     __builtin_amdgcn_s_sleep(1);
-  }
+  } while (poll.again());
   return false;
 }
 }  // namespace
@@ -1663,7 +1687,10 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
     }
     // (chain: the deblocking of this launch follows this row's and the next row's intra stage macroblock by macroblock)
     if constexpr (CHAIN) {
-      if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(done));
+      if (lane == 0) {
+        agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(done));
+        chain_beat(job.chain_ctl);
+      }
     }
   };
 
@@ -1725,8 +1752,8 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
           // top-right neighbour's, and of this row up to the left neighbour's, have to have landed
           if (do_inter) {
             bool ok = true;
-            if ((hB || hC || hD) && mby > 0) ok = chain_need_inter(ctl, mby - 1, min(mbx + 1, W - 1), seen_inter_up);
-            if (ok && hA && mbx > 0) ok = chain_need_inter(ctl, mby, mbx - 1, seen_inter_me);
+            if ((hB || hC || hD) && mby > 0) ok = chain_need_inter(job.chain_ctl, ctl, mby - 1, min(mbx + 1, W - 1), seen_inter_up);
+            if (ok && hA && mbx > 0) ok = chain_need_inter(job.chain_ctl, ctl, mby, mbx - 1, seen_inter_me);
             if (!ok) report_fault(job, FAULT_CHAIN_INTER);
           }
         }
@@ -1974,7 +2001,10 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
             // (the LDS hand-over to the row below needs no stores to have landed; the deblocking of this launch does:
             // what is in flight here is the PREVIOUS macroblock's samples - say that everything before this one is there)
             __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(mbx));
+            if (lane == 0) {
+              agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(mbx));
+              chain_beat(job.chain_ctl);
+            }
           }
         }
         STAMP(si_on, mbx, 4);
@@ -2028,7 +2058,10 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
     if constexpr (CHAIN) {
       // the row is through: its samples have landed
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(W));
+      if (lane == 0) {
+        agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(W));
+        chain_beat(job.chain_ctl);
+      }
     }
   }
 }
@@ -2334,13 +2367,13 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
       if (m < 0) return;
       m = min(m, W - 1);
       bool ok = true;
-      if (chain_inter) ok = chain_need_inter(ctl, mby, m, seen_inter);
+      if (chain_inter) ok = chain_need_inter(job.chain_ctl, ctl, mby, m, seen_inter);
       if (!ok) report_fault(job, FAULT_CHAIN_INTER);
       if (chain_intra) {
         // (m + 2 in both rows: the intra macroblock to the right of m predicts from m's column too - top-left in the
         // row below, and in THIS row from the row above, whose last lines this row's top edges change)
-        ok = chain_need_intra(ctl, epoch32, mby, static_cast<uint32_t>(min(m + 2, W)), seen_intra_me);
-        if (ok && has_row_below) ok = chain_need_intra(ctl, epoch32, mby + 1, static_cast<uint32_t>(min(m + 2, W)), seen_intra_below);
+        ok = chain_need_intra(job.chain_ctl, ctl, epoch32, mby, static_cast<uint32_t>(min(m + 2, W)), seen_intra_me);
+        if (ok && has_row_below) ok = chain_need_intra(job.chain_ctl, ctl, epoch32, mby + 1, static_cast<uint32_t>(min(m + 2, W)), seen_intra_below);
         if (!ok) report_fault(job, FAULT_CHAIN_INTRA);
       }
     }
@@ -2349,7 +2382,10 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
   // this one follow)
   auto publish_fin = [&](int v) {
     if constexpr (CHAIN) {
-      if (lane == 0) agent_st64(&ctl->fin[mby], epoch | static_cast<uint32_t>(v));
+      if (lane == 0) {
+        agent_st64(&ctl->fin[mby], epoch | static_cast<uint32_t>(v));
+        chain_beat(job.chain_ctl);
+      }
     }
   };
   {
@@ -2931,6 +2967,7 @@ __global__ __launch_bounds__((kBandWaves + kChainInterWaves) * 64) void k_chain(
       if (lane == 0 && !(job.inject_fault == 2 && row == ip.mb_height / 2 && j == 0))
         __hip_atomic_fetch_or((HW_AS1 uint64_t*)&static_cast<BandCtl*>(job.band_ctl)->inter_mask[row], 1ull << j, __ATOMIC_RELAXED,
                               __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) chain_beat(job.chain_ctl);
     }
     return;
   }

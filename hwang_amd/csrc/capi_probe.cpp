@@ -9,6 +9,8 @@
 #include "h264/h264_parser.h"
 #include "hevc/hvcc.h"
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -45,6 +47,10 @@ struct ProbeSink : public h264::PictureSink {
   uint64_t digest_noslot = 1469598103934665603ull;  // the same records with MbMotion::ref_slot blanked
   std::vector<int> outputs;  // slot per output (-1 skipped)
   int64_t coef_total = 0, inter_pics = 0;
+  // HWANG_PROBE_TIMES=1 (serial decoding only): wall time between begin_picture and end_picture per picture kind
+  bool times = getenv("HWANG_PROBE_TIMES") != nullptr;
+  std::chrono::steady_clock::time_point t_begin;
+  int64_t ns_kind[2] = {0, 0}, n_kind[2] = {0, 0}, coef_kind[2] = {0, 0};
 
   bool fast = getenv("HWANG_PROBE_FAST") != nullptr;  // timing runs: no digest, no clearing
   void mix(const void* p, size_t n, bool both = true) {
@@ -96,6 +102,7 @@ struct ProbeSink : public h264::PictureSink {
     out->slices = st.slices.data();
     out->max_slices = static_cast<int>(st.slices.size());
     out->slot = slot;
+    if (times) t_begin = std::chrono::steady_clock::now();
     out->device_mv = fast;  // timing runs measure what the GPU path runs (P vectors left to k_mv); digests keep the host derivation
     if (fast) {
       if (slots[slot].pmo.size() != static_cast<size_t>(nmb)) {
@@ -109,6 +116,12 @@ struct ProbeSink : public h264::PictureSink {
     return true;
   }
   bool end_picture(const h264::PicDone& d, std::string*) override {
+    if (times) {
+      const int k = d.has_inter ? 1 : 0;
+      ns_kind[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+      ++n_kind[k];
+      coef_kind[k] += static_cast<int64_t>(d.coef_count);
+    }
     Staging& st = staging[d.cookie];
     if (!fast)
       for (amd::MbInfo m : st.mb) {  // the derivation hints are not part of what the golden digests froze
@@ -170,6 +183,11 @@ static int run_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
     std::string worker_error;  // entropy workers: flush() does not wait for them
     if (!parser.wait_idle(&worker_error)) return report(worker_error);
   }
+  if (sink.times)
+    for (int k = 0; k < 2; ++k)
+      if (sink.n_kind[k])
+        fprintf(stderr, "probe: %lld %s pictures, %.3f ms and %.0f coefficient words each\n", (long long)sink.n_kind[k],
+                k ? "inter" : "intra-only", 1e-6 * sink.ns_kind[k] / sink.n_kind[k], 1.0 * sink.coef_kind[k] / sink.n_kind[k]);
   int64_t skipped_out = 0;
   for (int s : sink.outputs) skipped_out += s < 0;
   out[0] = parser.slices();

@@ -13,6 +13,10 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#ifdef HWANG_CABAC_TRACE
+#include <stdio.h>
+#include <vector>
+#endif
 #include <emmintrin.h>
 #include <immintrin.h>
 
@@ -152,6 +156,41 @@ __attribute__((noinline)) static uint64_t cabac_refill_slow(uint64_t value, int*
   return value;
 }
 
+#ifdef HWANG_CABAC_TRACE
+// Development aid (tools/hostprof/engine_bench.cpp): the context index of every bin of ONE slice (HWANG_CABAC_TRACE_SLICE
+// = its number in the run, default 0), with the contexts and the bytes the slice started from - so that formulations of
+// the arithmetic decoder can be timed on a real bin sequence with no syntax around it.  0xffff = bypass, 0xfffe = terminate.
+struct CabacTrace {
+  std::vector<uint16_t> ctx;
+  int slice = -1, want = getenv("HWANG_CABAC_TRACE_SLICE") ? atoi(getenv("HWANG_CABAC_TRACE_SLICE")) : 0;
+  bool on = false;
+  void begin(const uint16_t* state, int nstate, const uint8_t* data, const uint8_t* end) {
+    flush();
+    on = ++slice == want;
+    if (!on) return;
+    FILE* f = fopen("cabac_trace_init.bin", "wb");
+    const uint32_t n = static_cast<uint32_t>(end - data), ns = static_cast<uint32_t>(nstate);
+    fwrite(&ns, 4, 1, f);
+    fwrite(state, 2, ns, f);
+    fwrite(&n, 4, 1, f);
+    fwrite(data, 1, n, f);
+    fclose(f);
+  }
+  void flush() {
+    if (!on) return;
+    FILE* f = fopen("cabac_trace_ctx.bin", "wb");
+    fwrite(ctx.data(), 2, ctx.size(), f);
+    fclose(f);
+    on = false;
+  }
+  ~CabacTrace() { flush(); }
+};
+static CabacTrace g_cabac_trace;
+#define CABAC_TRACE(c) do { if (g_cabac_trace.on) g_cabac_trace.ctx.push_back(static_cast<uint16_t>(c)); } while (0)
+#else
+#define CABAC_TRACE(c) do { } while (0)
+#endif
+
 struct Cabac {
   const uint8_t* p = nullptr;
   const uint8_t* end = nullptr;
@@ -191,6 +230,9 @@ struct Cabac {
     overrun = false;
     range = 510;
     refill();
+#ifdef HWANG_CABAC_TRACE
+    g_cabac_trace.begin(state, CABAC_CTX_COUNT, data, data_end);
+#endif
   }
   // bits of the stream consumed so far
   int bits_consumed() const { return static_cast<int>(p - start) * 8 - extra; }
@@ -206,6 +248,7 @@ struct Cabac {
     }
   }
   __attribute__((always_inline)) inline int bin(int ctx) {
+    CABAC_TRACE(ctx);
     const uint32_t st = state[ctx];
     const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
     uint32_t r = range - lps;
@@ -223,6 +266,7 @@ struct Cabac {
     return static_cast<int>((st & 1) ^ l);
   }
   __attribute__((always_inline)) inline int bypass() {
+    CABAC_TRACE(0xffff);
     extra -= 1;
     if (__builtin_expect(extra < 8, 0)) refill();
     const uint64_t scaled = static_cast<uint64_t>(range) << extra;
@@ -231,6 +275,7 @@ struct Cabac {
     return static_cast<int>(mask & 1);
   }
   inline int terminate() {
+    CABAC_TRACE(0xfffe);
     range -= 2;
     const uint64_t scaled = static_cast<uint64_t>(range) << extra;
     if (value >= scaled) return 1;
@@ -278,6 +323,7 @@ struct CabacLocal {
     overrun |= ov;
   }
   __attribute__((always_inline)) int bin(int ctx) {
+    CABAC_TRACE(ctx);
     const uint32_t st = state[ctx];
     const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
     uint32_t r = range - lps;
@@ -294,6 +340,7 @@ struct CabacLocal {
     return static_cast<int>((st & 1) ^ l);
   }
   __attribute__((always_inline)) int bypass() {
+    CABAC_TRACE(0xffff);
     extra -= 1;
     if (__builtin_expect(extra < 8, 0)) refill();
     const uint64_t scaled = static_cast<uint64_t>(range) << extra;
@@ -302,6 +349,7 @@ struct CabacLocal {
     return static_cast<int>(mask & 1);
   }
   __attribute__((always_inline)) int terminate() {
+    CABAC_TRACE(0xfffe);
     range -= 2;
     const uint64_t scaled = static_cast<uint64_t>(range) << extra;
     if (value >= scaled) return 1;
@@ -1130,6 +1178,7 @@ struct SliceData {
       overrun |= ov;
     };
     auto bin = [&](int ctx) __attribute__((always_inline)) -> int {
+      CABAC_TRACE(ctx);
       const uint32_t st = state[ctx];
       const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
       uint32_t r = range - lps;
@@ -1146,6 +1195,7 @@ struct SliceData {
       return static_cast<int>((st & 1) ^ l);
     };
     auto bypass = [&]() __attribute__((always_inline)) -> int {
+      CABAC_TRACE(0xffff);
       extra -= 1;
       if (__builtin_expect(extra < 8, 0)) refill();
       const uint64_t scaled = static_cast<uint64_t>(range) << extra;

@@ -87,10 +87,14 @@ bool parse_sps(const uint8_t* nal, size_t size, Config* c) {
   c->height = static_cast<int>(b.ue());
   if (b.u(1)) {  // conformance_window_flag; offsets in chroma units
     const int sub_w = (c->sps_chroma_format == 1 || c->sps_chroma_format == 2) ? 2 : 1, sub_h = c->sps_chroma_format == 1 ? 2 : 1;
-    c->crop_left = sub_w * static_cast<int>(b.ue());
-    c->crop_right = sub_w * static_cast<int>(b.ue());
-    c->crop_top = sub_h * static_cast<int>(b.ue());
-    c->crop_bottom = sub_h * static_cast<int>(b.ue());
+    // (a hostile record: the offsets are kept unsigned until they have been held against the picture size)
+    const uint64_t l = static_cast<uint64_t>(b.ue()) * sub_w, r = static_cast<uint64_t>(b.ue()) * sub_w;
+    const uint64_t t = static_cast<uint64_t>(b.ue()) * sub_h, bo = static_cast<uint64_t>(b.ue()) * sub_h;
+    if (c->width <= 0 || c->height <= 0 || l + r >= static_cast<uint64_t>(c->width) || t + bo >= static_cast<uint64_t>(c->height)) return false;
+    c->crop_left = static_cast<int>(l);
+    c->crop_right = static_cast<int>(r);
+    c->crop_top = static_cast<int>(t);
+    c->crop_bottom = static_cast<int>(bo);
   }
   c->sps_bit_depth_luma = 8 + static_cast<int>(b.ue());
   c->sps_bit_depth_chroma = 8 + static_cast<int>(b.ue());

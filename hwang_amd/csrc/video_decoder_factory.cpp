@@ -27,7 +27,9 @@ VideoDecoderInterface* VideoDecoderFactory::make_from_config(
       if (device_handle.type != DeviceType::GPU) return nullptr;
       return make_amd_video_decoder(device_handle.id, num_devices);
     default:
-      return make_registered(device_handle, num_devices, type);
+      // (0 is this library's own "the caller is the parallelism" - ParallelRetriever's lanes; the reference's callers
+      // always pass >= 1, video_decoder_factory.cpp:90-91, and a registered backend is written against those)
+      return make_registered(device_handle, num_devices ? num_devices : 1, type);
   }
 }
 

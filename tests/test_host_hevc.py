@@ -64,6 +64,59 @@ def test_damaged_records_are_named(hw):
     assert rc == 0 and text.startswith("HEVC Main profile, Main tier, level 3.1; 4:2:0 10-bit (no SPS in the record)"), text
 
 
+class _Bits:
+    def __init__(self):
+        self.bits = []
+
+    def u(self, n, v):
+        self.bits += [(v >> (n - 1 - i)) & 1 for i in range(n)]
+
+    def ue(self, v):
+        n = (v + 1).bit_length()
+        self.u(n - 1, 0)
+        self.u(n, v + 1)
+
+    def nal(self, header):
+        bits = self.bits + [1]
+        bits += [0] * (-len(bits) % 8)
+        raw = bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+        out, zeros = bytearray(header), 0
+        for b in raw:   # emulation prevention (7.4.2)
+            if zeros >= 2 and b <= 3:
+                out.append(3)
+                zeros = 0
+            out.append(b)
+            zeros = zeros + 1 if b == 0 else 0
+        return bytes(out)
+
+
+def _hvcc_with_sps(width, height, crop):
+    b = _Bits()
+    b.u(4, 0); b.u(3, 0); b.u(1, 1)                 # VPS id, max_sub_layers_minus1, temporal id nesting
+    b.u(2, 0); b.u(1, 0); b.u(5, 1); b.u(32, 0x60000000); b.u(4, 9); b.u(43, 0); b.u(1, 0); b.u(8, 93)   # profile_tier_level
+    b.ue(0); b.ue(1); b.ue(width); b.ue(height)     # SPS id, 4:2:0, size
+    b.u(1, 1)
+    for v in crop:
+        b.ue(v)
+    b.ue(0); b.ue(0); b.ue(4); b.u(1, 1); b.ue(1); b.ue(0); b.ue(0)   # bit depths, POC bits, one ordering entry
+    b.ue(0); b.ue(3); b.ue(0); b.ue(3)              # coding block 8 .. 64, transform block 4 .. 32
+    sps = b.nal(bytes([0x42, 0x01]))
+    head = bytes([1, 1, 0x60, 0, 0, 0, 0x90, 0, 0, 0, 0, 0, 93, 0xf0, 0, 0xfc, 0xfd, 0xf8, 0xf8, 0, 0, 0x0f])
+    return head + bytes([1, 0xa1, 0, 1]) + len(sps).to_bytes(2, "big") + sps
+
+
+def test_hostile_conformance_windows_are_not_believed(hw):
+    """crop offsets are Exp-Golomb values an attacker picks - up to 2^32 - 2 each, times the chroma
+    sub-sampling factor: no signed overflow (this file is in the sanitizer build), no negative size in the text."""
+    from hwang_amd._capi import lib
+    rc, text = describe(lib, _hvcc_with_sps(640, 368, (0, 0, 0, 4)))
+    assert rc == 0 and "; 640x360 (coded 640x368), 4:2:0 8-bit, CTB 64;" in text, text
+    for crop in [(0x7fffffff, 0, 0, 0), (0xfffffffe, 0xfffffffe, 0xfffffffe, 0xfffffffe), (160, 160, 0, 0), (0, 0, 92, 92),
+                 (0x40000000, 0x40000000, 0, 0)]:
+        rc, text = describe(lib, _hvcc_with_sps(640, 368, crop))
+        assert rc == 0 and "(its SPS could not be read)" in text and "-" not in text.replace("-bit", "").replace("-byte", ""), (crop, text)
+
+
 @pytest.mark.gpu
 def test_backend_refuses_hevc_by_name(hw, tmp_path):
     import torch

@@ -11,7 +11,8 @@ int main(int argc,char**argv){
   size_t n=offs.size()/8; int64_t out[8]; char err[256];
   int reps = argc>2?atoi(argv[2]):1; int gop = argc>3?atoi(argv[3]):60;
   // sparse: want the frame just before each keyframe-aligned GOP end -> B pictures are skipped
-  std::vector<uint64_t> wanted; for(size_t g=gop-3; g<n; g+=gop) wanted.push_back(g);
+  size_t first = argc>4?atoi(argv[4]):gop-3;
+  std::vector<uint64_t> wanted; for(size_t g=first; g<n; g+=gop) wanted.push_back(g);
   sampler_start();
   double best=1e9;
   for(int r=0;r<reps;r++){
