@@ -11,6 +11,10 @@
 
 #include <chrono>
 #include <cstdio>
+#include <linux/perf_event.h>
+#include <sys/ioctl.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -51,6 +55,33 @@ struct ProbeSink : public h264::PictureSink {
   bool times = getenv("HWANG_PROBE_TIMES") != nullptr;
   std::chrono::steady_clock::time_point t_begin;
   int64_t ns_kind[2] = {0, 0}, n_kind[2] = {0, 0}, coef_kind[2] = {0, 0};
+  // ... and, where the kernel lets a process count its own events (the GPU boxes do, the build container's VM has no
+  // PMU), user-mode instructions / cycles / branch misses per picture kind
+  int pfd[3] = {-1, -1, -1};
+  uint64_t pstart[3] = {0, 0, 0}, pkind[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  void perf_open() {
+    const uint64_t cfg[3] = {PERF_COUNT_HW_INSTRUCTIONS, PERF_COUNT_HW_CPU_CYCLES, PERF_COUNT_HW_BRANCH_MISSES};
+    for (int i = 0; i < 3; ++i) {
+      perf_event_attr a;
+      std::memset(&a, 0, sizeof(a));
+      a.size = sizeof(a);
+      a.type = PERF_TYPE_HARDWARE;
+      a.config = cfg[i];
+      a.exclude_kernel = 1;
+      a.exclude_hv = 1;
+      pfd[i] = static_cast<int>(syscall(SYS_perf_event_open, &a, 0, -1, -1, 0));
+    }
+  }
+  void perf_read(uint64_t out[3]) {
+    for (int i = 0; i < 3; ++i) {
+      out[i] = 0;
+      if (pfd[i] >= 0 && read(pfd[i], &out[i], 8) != 8) out[i] = 0;
+    }
+  }
+  ~ProbeSink() override {
+    for (int fd : pfd)
+      if (fd >= 0) close(fd);
+  }
 
   bool fast = getenv("HWANG_PROBE_FAST") != nullptr;  // timing runs: no digest, no clearing
   void mix(const void* p, size_t n, bool both = true) {
@@ -102,7 +133,14 @@ struct ProbeSink : public h264::PictureSink {
     out->slices = st.slices.data();
     out->max_slices = static_cast<int>(st.slices.size());
     out->slot = slot;
-    if (times) t_begin = std::chrono::steady_clock::now();
+    if (times) {
+      if (pfd[0] == -1) {
+        perf_open();
+        if (pfd[0] < 0) pfd[0] = -2;
+      }
+      perf_read(pstart);
+      t_begin = std::chrono::steady_clock::now();
+    }
     out->device_mv = fast;  // timing runs measure what the GPU path runs (P vectors left to k_mv); digests keep the host derivation
     if (fast) {
       if (slots[slot].pmo.size() != static_cast<size_t>(nmb)) {
@@ -121,6 +159,9 @@ struct ProbeSink : public h264::PictureSink {
       ns_kind[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
       ++n_kind[k];
       coef_kind[k] += static_cast<int64_t>(d.coef_count);
+      uint64_t now[3];
+      perf_read(now);
+      for (int i = 0; i < 3; ++i) pkind[k][i] += now[i] - pstart[i];
     }
     Staging& st = staging[d.cookie];
     if (!fast)
@@ -186,8 +227,10 @@ static int run_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
   if (sink.times)
     for (int k = 0; k < 2; ++k)
       if (sink.n_kind[k])
-        fprintf(stderr, "probe: %lld %s pictures, %.3f ms and %.0f coefficient words each\n", (long long)sink.n_kind[k],
-                k ? "inter" : "intra-only", 1e-6 * sink.ns_kind[k] / sink.n_kind[k], 1.0 * sink.coef_kind[k] / sink.n_kind[k]);
+        fprintf(stderr, "probe: %lld %s pictures, %.3f ms and %.0f coefficient words each; %.0f instructions, %.0f cycles, %.0f branch misses each\n",
+                (long long)sink.n_kind[k], k ? "inter" : "intra-only", 1e-6 * sink.ns_kind[k] / sink.n_kind[k],
+                1.0 * sink.coef_kind[k] / sink.n_kind[k], 1.0 * sink.pkind[k][0] / sink.n_kind[k], 1.0 * sink.pkind[k][1] / sink.n_kind[k],
+                1.0 * sink.pkind[k][2] / sink.n_kind[k]);
   int64_t skipped_out = 0;
   for (int s : sink.outputs) skipped_out += s < 0;
   out[0] = parser.slices();

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Development aid: the host parser of one or more parser libraries (build_variant.sh, or the product library) on a
+C1-shaped clip, one thread: wall time per picture and - where the kernel lets a process count its own events -
+instructions / cycles / branch misses per picture kind (HWANG_PROBE_TIMES, capi_probe.cpp).
+usage: lib_counters.py clip.mp4 lib_a.so [lib_b.so ...]"""
+import ctypes as C
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ["HWANG_PROBE_FAST"] = "1"
+os.environ["HWANG_PROBE_TIMES"] = "1"
+import hwang_amd as hw  # noqa: E402
+
+path = sys.argv[1]
+idx = hw.index_video(path)
+data = np.fromfile(path, dtype=np.uint8)
+offs = idx.sample_offsets_np().astype(np.uint64)
+sizes = idx.sample_sizes_np().astype(np.uint64)
+avcc = bytes(idx.metadata_bytes())
+gop = 60
+wanted = np.arange(gop - 3, idx.frames(), gop, dtype=np.uint64)
+for libpath in sys.argv[2:]:
+    lib = C.CDLL(os.path.abspath(libpath))
+    lib.hwang_h264_probe.restype = C.c_int
+    lib.hwang_h264_probe.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                     C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
+    print("==", libpath, flush=True)
+    best = 1e9
+    for rep in range(3):
+        out = (C.c_int64 * 8)()
+        err = C.create_string_buffer(256)
+        t = time.time()
+        rc = lib.hwang_h264_probe(avcc, len(avcc), data.ctypes.data, offs.ctypes.data, sizes.ctypes.data, len(offs), wanted.ctypes.data, len(wanted),
+                                  out, err, 256)
+        dt = time.time() - t
+        if rc:
+            raise SystemExit(err.value)
+        best = min(best, dt)
+    print("   %d pictures decoded: best %.3f ms per picture (digest %x)" % (out[2], 1e3 * best / out[2], out[7]), flush=True)
