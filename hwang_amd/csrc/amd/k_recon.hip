@@ -566,10 +566,12 @@ __device__ __forceinline__ int bands_of(int mb_height) { return (mb_height + kBa
 // Chain launches carry four control words (ChainArgs::tickets = JobDesc::chain_ctl, zeroed by the host with every
 // launch's unit table): [0] / [1] the tickets, [2] the first fault of THIS launch - once one poll has expired the
 // others give up at their next look instead of each sitting out its own bound, so a launch with a broken hand-off
-// ends in a fraction of a second; nothing outlives the launch - and [3] a heartbeat that every stage raises with
-// each piece of progress it publishes.  A poll only counts tries during which the heartbeat stood still: its bound
-// is "nothing in the whole launch has moved for that long", not "my producer took that long" - a row unit may sit
-// behind a chain of pictures, on a device it shares with other engines' launches and other processes.
+// ends in a fraction of a second; nothing outlives the launch - and [3] a heartbeat that is raised whenever a row of a
+// unit or a run of inter macroblocks is through (a same-address atomic per published macroblock was measured: it
+// serialises in the L2 and cost the reference's caller a quarter of its rate).  A poll only counts tries during which
+// neither the word it watches nor the heartbeat moved: its bound is "neither my producer nor anything else in the
+// launch has got anywhere for that long", not "my producer took that long" - a row unit may sit behind a chain of
+// pictures, on a device it shares with other engines' launches and other processes.
 constexpr int kChainFaultWord = 2, kChainBeatWord = 3;
 constexpr int kChainTries = 1 << 17;  // ~0.1 - 0.2 s of polling with the whole launch standing still
 static_assert(kChainRun == 8, "chain_need_inter: one bit of BandCtl::inter_mask per run of 8 macroblocks (upto_mb >> 3)");
@@ -604,11 +606,16 @@ __device__ uint64_t g_stamps[256 * 8];
 struct ChainPoll {
   const uint32_t* ctl;
   uint32_t beat = 0;
+  uint64_t watched = 0;
   int tries = 0;
   bool armed = false;  // (the heartbeat is first read at the 256th try: a wait that is over at once costs nothing extra)
   __device__ __forceinline__ explicit ChainPoll(const uint32_t* chain_ctl) : ctl(chain_ctl) {}
-  // false: give up
-  __device__ __forceinline__ bool again() {
+  // `seen`: the word this poll watches, as just read.  false: give up
+  __device__ __forceinline__ bool again(uint64_t seen) {
+    if (seen != watched) {  // my producer moved (not far enough yet)
+      watched = seen;
+      tries = 0;
+    }
     if ((++tries & 255) == 0) {
       if (__hip_atomic_load((const HW_AS1 uint32_t*)(ctl + kChainFaultWord), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
       const uint32_t b = __hip_atomic_load((const HW_AS1 uint32_t*)(ctl + kChainBeatWord), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -699,11 +706,12 @@ HW_FN void chain_wait_reference(const JobDesc& ref, const JobDesc& job, int top,
     bool ok = false;
     chain_dbg(3, row, need);
     ChainPoll poll(job.chain_ctl);
+    uint64_t v;
     do {
-      const uint64_t v = agent_ld64(words + row);
+      v = agent_ld64(words + row);
       ok = static_cast<uint32_t>(v >> 32) == epoch && static_cast<uint32_t>(v) >= need;
       if (!ok) __builtin_amdgcn_s_sleep(2);
-    } while (!ok && poll.again());
+    } while (!ok && poll.again(v));
     if (!ok) {
       report_fault(job, FAULT_CHAIN_REFERENCE);
       return;
@@ -721,19 +729,20 @@ HW_FN bool chain_need_inter(const uint32_t* chain_ctl, const BandCtl* ctl, int r
     seen = agent_ld64(&ctl->inter_mask[row]);
     if ((seen & want) == want) return true;
     __builtin_amdgcn_s_sleep(1);
-  } while (poll.again());
+  } while (poll.again(seen));
   return false;
 }
 HW_FN bool chain_need_intra(const uint32_t* chain_ctl, const BandCtl* ctl, uint32_t epoch, int row, uint32_t count, uint32_t& seen) {
   if (seen >= count) return true;
   chain_dbg(2, row, count);
   ChainPoll poll(chain_ctl);
+  uint64_t v;
   do {
-    const uint64_t v = agent_ld64(&ctl->intra_prog[row]);
+    v = agent_ld64(&ctl->intra_prog[row]);
     if (static_cast<uint32_t>(v >> 32) == epoch) seen = static_cast<uint32_t>(v);
     if (seen >= count) return true;
     __builtin_amdgcn_s_sleep(1);
-  } while (poll.again());
+  } while (poll.again(v));
   return false;
 }
 }  // namespace
@@ -1687,10 +1696,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
     }
     // (chain: the deblocking of this launch follows this row's and the next row's intra stage macroblock by macroblock)
     if constexpr (CHAIN) {
-      if (lane == 0) {
-        agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(done));
-        chain_beat(job.chain_ctl);
-      }
+      if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(done));
     }
   };
 
@@ -2001,10 +2007,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
             // (the LDS hand-over to the row below needs no stores to have landed; the deblocking of this launch does:
             // what is in flight here is the PREVIOUS macroblock's samples - say that everything before this one is there)
             __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-              agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(mbx));
-              chain_beat(job.chain_ctl);
-            }
+            if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(mbx));
           }
         }
         STAMP(si_on, mbx, 4);
@@ -2058,10 +2061,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
     if constexpr (CHAIN) {
       // the row is through: its samples have landed
       __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) {
-        agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(W));
-        chain_beat(job.chain_ctl);
-      }
+      if (lane == 0) agent_st64(&ctl->intra_prog[mby], (static_cast<uint64_t>(epoch) << 32) | static_cast<uint32_t>(W));
     }
   }
 }
@@ -2382,10 +2382,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
   // this one follow)
   auto publish_fin = [&](int v) {
     if constexpr (CHAIN) {
-      if (lane == 0) {
-        agent_st64(&ctl->fin[mby], epoch | static_cast<uint32_t>(v));
-        chain_beat(job.chain_ctl);
-      }
+      if (lane == 0) agent_st64(&ctl->fin[mby], epoch | static_cast<uint32_t>(v));
     }
   };
   {
@@ -3004,7 +3001,10 @@ __global__ __launch_bounds__((kBandWaves + kChainInterWaves) * 64) void k_chain(
     // through with this unit's LDS
     __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     chain_dbg(7, u >> 8, u & 0xff);
-    if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)&S.arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) {
+      chain_beat(job.chain_ctl);  // (a row of the unit is through)
+      __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)&S.arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
   chain_dbg(9, 0, 0);
 }

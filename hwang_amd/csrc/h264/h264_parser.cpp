@@ -13,7 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
-#ifdef HWANG_CABAC_TRACE
+#if defined(HWANG_CABAC_TRACE) || defined(HWANG_REGION_COUNTERS)
 #include <stdio.h>
 #include <vector>
 #endif
@@ -155,6 +155,55 @@ __attribute__((noinline)) static uint64_t cabac_refill_slow(uint64_t value, int*
   *p_io = p;
   return value;
 }
+
+#ifdef HWANG_REGION_COUNTERS
+// Development aid (tools/hostprof/build_variant.sh NAME -DHWANG_REGION_COUNTERS): user-mode instructions retired per
+// REGION of the macroblock layer, exact - the counter is read (a system call whose kernel side is not counted) whenever
+// the parser passes from one region to the next; every switch costs the region it leaves ~25-30 instructions.
+#include <linux/perf_event.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+enum { R_OTHER, R_MBHEAD, R_PSKIP, R_BEGIN, R_MBTYPE, R_INTER_REFS, R_INTER_MVD, R_INTRAMODES, R_CBP, R_T8X8, R_QPD, R_RES_FILL, R_RESIDUAL, R_RES_BLOCK, R_COMMIT, R_COUNT };
+struct RegionCounters {
+  int fd = -1;
+  uint64_t instr[R_COUNT] = {0}, enters[R_COUNT] = {0}, last = 0;
+  int cur = R_OTHER;
+  RegionCounters() {
+    perf_event_attr a;
+    memset(&a, 0, sizeof(a));
+    a.size = sizeof(a);
+    a.type = PERF_TYPE_HARDWARE;
+    a.config = PERF_COUNT_HW_INSTRUCTIONS;
+    a.exclude_kernel = 1;
+    a.exclude_hv = 1;
+    fd = static_cast<int>(syscall(SYS_perf_event_open, &a, 0, -1, -1, 0));
+  }
+  void enter(int r) {
+    uint64_t now = 0;
+    if (fd < 0 || read(fd, &now, 8) != 8) return;
+    instr[cur] += now - last;
+    last = now;
+    cur = r;
+    ++enters[r];
+  }
+  ~RegionCounters() {
+    static const char* const names[R_COUNT] = {"outside the macroblock layer", "position + skip flag + end_of_slice", "P_Skip", "begin_mb", "mb_type",
+                                               "inter: shapes + references", "inter: differences", "intra prediction modes", "coded_block_pattern",
+                                               "transform_size_8x8_flag", "mb_qp_delta", "residual: fill_nz_cache", "residual: around the blocks",
+                                               "residual: cabac_block", "commit_mb"};
+    enter(R_OTHER);
+    uint64_t total = 0;
+    for (uint64_t v : instr) total += v;
+    for (int i = 0; i < R_COUNT; ++i)
+      fprintf(stderr, "region %-36s %14llu instructions %5.1f %%  %10llu entries  %8.1f per entry\n", names[i], (unsigned long long)instr[i],
+              total ? 100.0 * instr[i] / total : 0.0, (unsigned long long)enters[i], enters[i] ? 1.0 * instr[i] / enters[i] : 0.0);
+  }
+};
+static RegionCounters g_regions;
+#define REGION(r) g_regions.enter(r)
+#else
+#define REGION(r) do { } while (0)
+#endif
 
 #ifdef HWANG_CABAC_TRACE
 // Development aid (tools/hostprof/engine_bench.cpp): the context index of every bin of ONE slice (HWANG_CABAC_TRACE_SLICE
@@ -576,6 +625,8 @@ struct SliceData {
   // what begin_mb + decode_skip_mb + commit_mb would have produced field by field.
   MbMotion pskip_motion;
   int32_t pskip_ref_uid = -1;
+  MbInfo pskip_info;
+  int pskip_info_qp = -1;
   // compact motion hand-over of the picture in progress (bufs.pmo / bufs.pmx)
   bool compact = false;        // macroblocks of P / I slices are written as PMotion
   bool any_compact = false, any_full_motion = false;
@@ -588,6 +639,7 @@ struct SliceData {
     // offset: av[(oy + 1) * 3 + ox + 1] for ox in -1..1, oy in -1..0
     bool av[6];
     bool avA, avB;
+    uint8_t av_bits;  // A | B << 1 | C << 2 | D << 3: the order of MBF_AVAIL_A .. D (<< 2) and MVF_AVAIL_A .. D (<< 4)
     int mv_shape, mv_sub, mv_pskip, mv_defer;  // deferred motion-vector derivation (P macroblocks)
     int pm_parts;  // compact hand-over: partitions whose difference has been written so far
     // motion record of each available, non-intra neighbour (same index as
@@ -597,6 +649,7 @@ struct SliceData {
     int8_t i4_mode[16];
     uint8_t nnz[24];
     uint8_t nz_left[8], nz_top[8];  // fill_nz_cache(): 4 luma + 2 Cb + 2 Cr flags per edge
+    uint8_t dc_left, dc_top;        // ... and the DC blocks' flags of the two neighbour macroblocks
     int cbf_dc;
     uint32_t coded_mask;
     // the macroblock's non-zero levels as they will be handed over (MbInfo::ncoef): (group * 16 + position) << 16 | level
@@ -679,6 +732,8 @@ struct SliceData {
   }
 
   // =================================================================== MBs
+  static_assert(amd::MBF_AVAIL_A == 4 && amd::MBF_AVAIL_B == 8 && amd::MBF_AVAIL_C == 16 && amd::MBF_AVAIL_D == 32, "Mb::av_bits << 2");
+  static_assert(amd::MVF_AVAIL_A == 16 && amd::MVF_AVAIL_B == 32 && amd::MVF_AVAIL_C == 64 && amd::MVF_AVAIL_D == 128, "Mb::av_bits << 4");
   // Sets the current macroblock's position and which neighbours are available
   // (6.4.9: inside the picture and in the same slice).  Everything else asks
   // mb.av[] instead of re-deriving it per syntax element.
@@ -696,15 +751,18 @@ struct SliceData {
     mb.addr = addr;
     if (bufs.pmx && mb.mbx == 0) bufs.pmx[mb.mby] = static_cast<uint32_t>(pmx_used);  // this row's extras start here
     const bool left = mb.mbx > 0, top = mb.mby > 0, right = mb.mbx + 1 < mbw;
-    const int16_t si = static_cast<int16_t>(slice_index);
-    mb.av[0] = left && top && mb_slice[addr - mbw - 1] == si;   // D
-    mb.av[1] = top && mb_slice[addr - mbw] == si;               // B
-    mb.av[2] = right && top && mb_slice[addr - mbw + 1] == si;  // C
-    mb.av[3] = left && mb_slice[addr - 1] == si;                // A
-    mb.av[4] = true;                                            // the macroblock itself
-    mb.av[5] = false;                                           // right neighbour: never decoded yet
+    // (a slice is a run of macroblocks in raster order - FMO / ASO are refused - and starts where the one before ended:
+    // a macroblock in front of this one belongs to this slice exactly if it is not in front of the slice's first)
+    const int first = sl.first_mb;
+    mb.av[0] = left && top && addr - mbw - 1 >= first;   // D
+    mb.av[1] = top && addr - mbw >= first;               // B
+    mb.av[2] = right && top && addr - mbw + 1 >= first;  // C
+    mb.av[3] = left && addr - 1 >= first;                // A
+    mb.av[4] = true;                                     // the macroblock itself
+    mb.av[5] = false;                                    // right neighbour: never decoded yet
     mb.avA = mb.av[3];
     mb.avB = mb.av[1];
+    mb.av_bits = static_cast<uint8_t>((mb.av[3] ? 1 : 0) | (mb.av[1] ? 2 : 0) | (mb.av[2] ? 4 : 0) | (mb.av[0] ? 8 : 0));
   }
   inline bool nb_avail(int ox, int oy) const { return mb.av[(oy + 1) * 3 + ox + 1]; }
   inline bool mb_avail(int mbx, int mby) const {
@@ -1148,14 +1206,42 @@ struct SliceData {
     return total;
   }
 
-  // Residual block (9.3.2.x via 7.3.5.3.3).  Most of a picture's bins are
-  // decoded here, so the arithmetic decoder's registers (offset, range, bit
-  // budget, read pointer) live in locals for the duration of the block: the
-  // context bytes are stored through a uint8_t pointer, which may alias any
-  // member of the Cabac object and would otherwise force a store and reload of
-  // the engine state around every single bin.
+  // The residual of one macroblock (7.3.5.3 with 9.3.2.x / 7.3.5.3.3), CABAC.  Most of a picture's bins are decoded
+  // here, so the arithmetic decoder's registers (offset, range, bit budget, read pointer) live in locals for ALL the
+  // blocks of the macroblock: the blocks - up to 27 of them, many with a single coded_block_flag bin and nothing
+  // behind it - are one loop over a list around ONE inlined copy of the block reader, not a call per block that loads
+  // the engine from the Cabac object and stores it back (round 5, counted on the GPU box: ~95 instructions between two
+  // blocks, 600 per macroblock of a P picture and 1 300 of an I picture, beside the bins' own).  The context words are
+  // 16-bit on purpose (see Cabac::state).
   // Non-zero levels are appended to mb.ent with flat index `gbase` + raster position (gbase = group * 16).
-  int cabac_block(int cat, int cbf_inc, int max_coeff, const uint8_t* scan, int start, int gbase) {
+  enum : uint8_t { RB_I16DC = 0, RB_LUMA4 = 1, RB_LUMA8 = 2, RB_CHROMA_DC = 3, RB_CHROMA_AC = 4 };
+  bool cabac_residual() {
+    REGION(R_RES_FILL);
+    fill_nz_cache();
+    REGION(R_RESIDUAL);
+    const bool i16 = mb.kind == MB_I16x16;
+    // the macroblock's blocks in decoding order: kind << 5 | index (luma: raster 4x4 index / 8x8 index; chroma: p << 2 | s)
+    uint8_t list[32];
+    int nlist = 0;
+    if (i16) list[nlist++] = RB_I16DC << 5;
+    for (int b8 = 0; b8 < 4; ++b8) {
+      if (!((mb.cbp >> b8) & 1)) continue;
+      if (mb.t8x8) {
+        list[nlist++] = static_cast<uint8_t>(RB_LUMA8 << 5 | b8);
+      } else {
+        for (int s = 0; s < 4; ++s)
+          list[nlist++] = static_cast<uint8_t>(RB_LUMA4 << 5 | (((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)));
+      }
+    }
+    const int cc = mb.cbp >> 4;
+    if (cc) {
+      list[nlist++] = RB_CHROMA_DC << 5 | 0;
+      list[nlist++] = RB_CHROMA_DC << 5 | 4;
+    }
+    if (cc == 2)
+      for (int k = 0; k < 8; ++k) list[nlist++] = static_cast<uint8_t>(RB_CHROMA_AC << 5 | k);
+    if (!nlist) return true;
+
     Cabac& c = cabac;
     uint64_t value = c.value;
     uint32_t range = c.range;
@@ -1211,70 +1297,117 @@ struct SliceData {
       if (overrun) c.overrun = true;
     };
 
-    if (cbf_inc >= 0 && !bin(85 + cbf_cat_offset[cat] + cbf_inc)) {
-      leave();
-      return 0;
-    }
-    const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
-    const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
-    const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
-    uint8_t idx[64];
-    int n = 0, i;
-    const int lastpos = max_coeff - 1;
-    if (cat == 5) {
-      for (i = 0; i < lastpos; ++i)
-        if (bin(sig_base + sig_coeff_offset_8x8[i])) {
-          idx[n++] = static_cast<uint8_t>(i);
-          if (bin(last_base + last_coeff_offset_8x8[i])) break;
-        }
-    } else if (cat == 3) {
-      for (i = 0; i < lastpos; ++i) {
-        const int inc = imin(i, 2);
-        if (bin(sig_base + inc)) {
-          idx[n++] = static_cast<uint8_t>(i);
-          if (bin(last_base + inc)) break;
-        }
+    for (int li = 0; li < nlist; ++li) {
+      const int kind = list[li] >> 5, which = list[li] & 31;
+      int cat, inc, max_coeff, start = 0, gbase;
+      const uint8_t* scan = zigzag4x4;
+      switch (kind) {
+        case RB_I16DC:
+          cat = 0; inc = cbf_inc(0, 0, 0, 0); max_coeff = 16; gbase = 16 * amd::kMaskLumaDc;
+          break;
+        case RB_LUMA4:
+          cat = i16 ? 1 : 2; inc = cbf_inc(1, 0, which & 3, which >> 2); max_coeff = i16 ? 15 : 16; start = i16 ? 1 : 0; gbase = 16 * which;
+          break;
+        case RB_LUMA8:
+          cat = 5; inc = -1; max_coeff = 64; scan = zigzag8x8; gbase = 64 * which;
+          break;
+        case RB_CHROMA_DC:
+          cat = 3; inc = cbf_inc(2, which >> 2, 0, 0); max_coeff = 4; scan = dc_scan4; gbase = 16 * amd::kMaskChromaDc + which;
+          break;
+        default:
+          cat = 4; inc = cbf_inc(3, which >> 2, which & 1, (which >> 1) & 1); max_coeff = 15; start = 1; gbase = 16 * (amd::kMaskChromaAc + which);
+          break;
       }
-    } else {
-      for (i = 0; i < lastpos; ++i)
-        if (bin(sig_base + i)) {
-          idx[n++] = static_cast<uint8_t>(i);
-          if (bin(last_base + i)) break;
-        }
-    }
-    if (i == lastpos) idx[n++] = static_cast<uint8_t>(lastpos);
-    int gt1 = 0, eq1 = 0;
-    const int gt_cap = 4 - (cat == 3 ? 1 : 0);
-    uint32_t* const ent = mb.ent + mb.nent;  // n <= 64 entries; a macroblock never has more than 26 * 16
-    for (int k = n - 1; k >= 0; --k) {
-      const int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
-      int val;
-      if (!bin(abs_base + inc0)) {
-        val = 1;
-        ++eq1;
-      } else {
-        const int inc = 5 + imin(gt_cap, gt1);
-        val = 2;
-        while (val < 15 && bin(abs_base + inc)) ++val;
-        if (val == 15) {
-          int k0 = 0;
-          while (bypass()) {
-            val += 1 << k0;
-            if (++k0 > 24) {
-              leave();
-              return fail("CABAC: coeff_abs_level overflow") ? 0 : -1;
+      int n = 0;
+      if (inc < 0 || bin(85 + cbf_cat_offset[cat] + inc)) {
+        const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
+        const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
+        const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
+        uint8_t idx[64];
+        int i;
+        const int lastpos = max_coeff - 1;
+        if (cat == 5) {
+          for (i = 0; i < lastpos; ++i)
+            if (bin(sig_base + sig_coeff_offset_8x8[i])) {
+              idx[n++] = static_cast<uint8_t>(i);
+              if (bin(last_base + last_coeff_offset_8x8[i])) break;
+            }
+        } else if (cat == 3) {
+          for (i = 0; i < lastpos; ++i) {
+            const int ci = imin(i, 2);
+            if (bin(sig_base + ci)) {
+              idx[n++] = static_cast<uint8_t>(i);
+              if (bin(last_base + ci)) break;
             }
           }
-          while (k0--) val += bypass() << k0;
+        } else {
+          for (i = 0; i < lastpos; ++i)
+            if (bin(sig_base + i)) {
+              idx[n++] = static_cast<uint8_t>(i);
+              if (bin(last_base + i)) break;
+            }
         }
-        ++gt1;
+        if (i == lastpos) idx[n++] = static_cast<uint8_t>(lastpos);
+        int gt1 = 0, eq1 = 0;
+        const int gt_cap = 4 - (cat == 3 ? 1 : 0);
+        uint32_t* const ent = mb.ent + mb.nent;  // n <= 64 entries; a macroblock never has more than 26 * 16
+        for (int k = n - 1; k >= 0; --k) {
+          const int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
+          int val;
+          if (!bin(abs_base + inc0)) {
+            val = 1;
+            ++eq1;
+          } else {
+            const int ainc = 5 + imin(gt_cap, gt1);
+            val = 2;
+            while (val < 15 && bin(abs_base + ainc)) ++val;
+            if (val == 15) {
+              int k0 = 0;
+              while (bypass()) {
+                val += 1 << k0;
+                if (++k0 > 24) {
+                  leave();
+                  return fail("CABAC: coeff_abs_level overflow");
+                }
+              }
+              while (k0--) val += bypass() << k0;
+            }
+            ++gt1;
+          }
+          if (bypass()) val = -val;
+          ent[k] = (static_cast<uint32_t>(gbase + scan[start + idx[k]]) << 16) | static_cast<uint16_t>(val);
+        }
+        mb.nent += n;
       }
-      if (bypass()) val = -val;
-      ent[k] = (static_cast<uint32_t>(gbase + scan[start + idx[k]]) << 16) | static_cast<uint16_t>(val);
+      switch (kind) {
+        case RB_I16DC:
+          if (n) {
+            mb.coded_mask |= 1u << amd::kMaskLumaDc;
+            mb.cbf_dc |= 1;
+          }
+          break;
+        case RB_LUMA4:
+          if (n) mb.coded_mask |= 1u << which;
+          mb.nnz[which] = static_cast<uint8_t>(n);
+          break;
+        case RB_LUMA8:
+          for (int s = 0; s < 4; ++s) mb.nnz[((which >> 1) * 2 + (s >> 1)) * 4 + (which & 1) * 2 + (s & 1)] = static_cast<uint8_t>(n);
+          if (n) mb.coded_mask |= 0xfu << (4 * which);
+          break;
+        case RB_CHROMA_DC:
+          if (n) {
+            mb.coded_mask |= 1u << amd::kMaskChromaDc;
+            mb.cbf_dc |= 2 << (which >> 2);
+          }
+          break;
+        default:
+          if (n) mb.coded_mask |= 1u << (amd::kMaskChromaAc + which);
+          mb.nnz[16 + which] = static_cast<uint8_t>(n);
+          break;
+      }
     }
-    mb.nent += n;
     leave();
-    return n;
+    return true;
   }
 
   int cbf_neighbour(int kind, int p, int rx, int ry, bool left) const {
@@ -1315,7 +1448,9 @@ struct SliceData {
       const int b = ry > 0 ? mb.nnz[16 + 4 * p + rx] != 0 : mb.nz_top[4 + 2 * p + rx];
       return a + 2 * b;
     }
-    return cbf_neighbour(kind, p, rx, ry, true) + 2 * cbf_neighbour(kind, p, rx, ry, false);
+    // the DC blocks: the neighbour macroblocks' flags, gathered by fill_nz_cache (bit 0 Intra16x16 DC, bits 1 / 2 Cb / Cr DC)
+    const int bit = kind == 0 ? 0 : 1 + p;
+    return ((mb.dc_left >> bit) & 1) + 2 * ((mb.dc_top >> bit) & 1);
   }
   // coded_block_flag context inputs of the blocks along the left and top edge of the current
   // macroblock (9.3.3.1.1.9): "unavailable" counts as coded for intra macroblocks, I_PCM
@@ -1323,6 +1458,17 @@ struct SliceData {
   void fill_nz_cache() {
     const uint8_t unavailable = mb.kind != MB_INTER;
     const int a = mb.addr;
+    // DC blocks (cbf_neighbour's rules for kinds 0 and 2): unavailable counts as coded for intra macroblocks, I_PCM as
+    // coded; the Intra16x16 DC flag of a neighbour that is not Intra16x16 is 0
+    auto dc_flags = [&](bool avail, int na) -> uint8_t {
+      if (!avail) return unavailable ? 7 : 0;
+      const int k = mb_kind[na];
+      if (k == MB_IPCM) return 7;
+      const int f = mb_cbf_dc[na];
+      return static_cast<uint8_t>((f & 6) | (k == MB_I16x16 ? (f & 1) : 0));
+    };
+    mb.dc_left = dc_flags(mb.av[3], a - 1);
+    mb.dc_top = dc_flags(mb.av[1], a - mbw);
     if (mb.av[3]) {
       const uint8_t* n = &nnz[(a - 1) * 24];
       const bool pcm = mb_kind[a - 1] == MB_IPCM;
@@ -1375,9 +1521,12 @@ struct SliceData {
     Cabac& c = cabac;
     if (st == 2) return rd_intra_mb_type(3, 1);
     if (st == 0) {
-      if (!c.bin(14)) {
-        if (!c.bin(15)) return 3 * c.bin(16);
-        return 2 - c.bin(17);
+      {
+        CabacLocal l(cabac);  // (up to three bins: the engine in registers)
+        if (!l.bin(14)) {
+          if (!l.bin(15)) return 3 * l.bin(16);
+          return 2 - l.bin(17);
+        }
       }
       return 5 + rd_intra_mb_type(17, 0);
     }
@@ -1585,47 +1734,31 @@ struct SliceData {
   }
 
   bool parse_residual() {
+    if (use_cabac) return cabac_residual();
     const bool i16 = mb.kind == MB_I16x16;
-    if (use_cabac) fill_nz_cache();
     if (i16) {
-      int n;
-      if (use_cabac) {
-        n = cabac_block(0, cbf_inc(0, 0, 0, 0), 16, zigzag4x4, 0, 16 * amd::kMaskLumaDc);
-        if (n > 0) mb.coded_mask |= 1u << amd::kMaskLumaDc;
-      } else {
-        int16_t tmp[16] = {0};
-        n = cavlc_block(cavlc_nc(0, 0, 0), 16, zigzag4x4, 0, tmp);
-        if (n > 0) emit_levels(amd::kMaskLumaDc, 0, tmp, 16);
-      }
+      int16_t tmp[16] = {0};
+      const int n = cavlc_block(cavlc_nc(0, 0, 0), 16, zigzag4x4, 0, tmp);
       if (n < 0) return false;
+      if (n > 0) emit_levels(amd::kMaskLumaDc, 0, tmp, 16);
       if (n) mb.cbf_dc |= 1;
     }
     for (int b8 = 0; b8 < 4; ++b8) {
       if (!((mb.cbp >> b8) & 1)) continue;
       if (mb.t8x8) {
         // 64 coefficients in raster 8x8 order spread over groups 4*b8..4*b8+3
-        if (use_cabac) {
-          // groups 4*b8 .. 4*b8+3 are adjacent in the scratch area: the 64 levels land in place
-          int n = cabac_block(5, -1, 64, zigzag8x8, 0, 16 * 4 * b8);
-          if (n < 0) return false;
-          for (int s = 0; s < 4; ++s) mb.nnz[((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)] = static_cast<uint8_t>(n);
-          if (n) mb.coded_mask |= 0xfu << (4 * b8);
-          continue;
-        }
         int16_t blk[64];
         memset(blk, 0, sizeof(blk));
         int total = 0;
-        {
-          for (int s = 0; s < 4; ++s) {
-            const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
-            int16_t tmp[16] = {0};
-            int n = cavlc_block(cavlc_nc(0, bx, by), 16, identity_scan16, 0, tmp);
-            if (n < 0) return false;
-            for (int k = 0; k < 16; ++k)
-              if (tmp[k]) blk[zigzag8x8[4 * k + s]] = tmp[k];
-            mb.nnz[by * 4 + bx] = static_cast<uint8_t>(n);
-            total += n;
-          }
+        for (int s = 0; s < 4; ++s) {
+          const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
+          int16_t tmp[16] = {0};
+          int n = cavlc_block(cavlc_nc(0, bx, by), 16, identity_scan16, 0, tmp);
+          if (n < 0) return false;
+          for (int k = 0; k < 16; ++k)
+            if (tmp[k]) blk[zigzag8x8[4 * k + s]] = tmp[k];
+          mb.nnz[by * 4 + bx] = static_cast<uint8_t>(n);
+          total += n;
         }
         if (total) {
           for (int g = 0; g < 4; ++g) emit_levels(4 * b8 + g, 0, blk + 16 * g, 16, true);
@@ -1635,33 +1768,20 @@ struct SliceData {
       for (int s = 0; s < 4; ++s) {
         const int bx = (b8 & 1) * 2 + (s & 1), by = (b8 >> 1) * 2 + (s >> 1);
         const int ri = by * 4 + bx;
-        int n;
-        if (use_cabac) {
-          n = i16 ? cabac_block(1, cbf_inc(1, 0, bx, by), 15, zigzag4x4, 1, 16 * ri)
-                  : cabac_block(2, cbf_inc(1, 0, bx, by), 16, zigzag4x4, 0, 16 * ri);
-          if (n > 0) mb.coded_mask |= 1u << ri;
-        } else {
-          int16_t tmp[16] = {0};
-          n = i16 ? cavlc_block(cavlc_nc(0, bx, by), 15, zigzag4x4, 1, tmp) : cavlc_block(cavlc_nc(0, bx, by), 16, zigzag4x4, 0, tmp);
-          if (n > 0) emit_levels(ri, 0, tmp, 16);
-        }
+        int16_t tmp[16] = {0};
+        const int n = i16 ? cavlc_block(cavlc_nc(0, bx, by), 15, zigzag4x4, 1, tmp) : cavlc_block(cavlc_nc(0, bx, by), 16, zigzag4x4, 0, tmp);
         if (n < 0) return false;
+        if (n > 0) emit_levels(ri, 0, tmp, 16);
         mb.nnz[ri] = static_cast<uint8_t>(n);
       }
     }
     const int cc = mb.cbp >> 4;
     if (cc) {
       for (int p = 0; p < 2; ++p) {
-        int n;
-        if (use_cabac) {
-          n = cabac_block(3, cbf_inc(2, p, 0, 0), 4, dc_scan4, 0, 16 * amd::kMaskChromaDc + 4 * p);
-          if (n > 0) mb.coded_mask |= 1u << amd::kMaskChromaDc;
-        } else {
-          int16_t tmp[4] = {0, 0, 0, 0};
-          n = cavlc_block(-1, 4, dc_scan4, 0, tmp);
-          if (n > 0) emit_levels(amd::kMaskChromaDc, 4 * p, tmp, 4);
-        }
+        int16_t tmp[4] = {0, 0, 0, 0};
+        const int n = cavlc_block(-1, 4, dc_scan4, 0, tmp);
         if (n < 0) return false;
+        if (n > 0) emit_levels(amd::kMaskChromaDc, 4 * p, tmp, 4);
         if (n) mb.cbf_dc |= 2 << p;
       }
     }
@@ -1670,20 +1790,14 @@ struct SliceData {
         for (int s = 0; s < 4; ++s) {
           const int bx = s & 1, by = s >> 1;
           const int g = amd::kMaskChromaAc + 4 * p + s;
-          int n;
-          if (use_cabac) {
-            n = cabac_block(4, cbf_inc(3, p, bx, by), 15, zigzag4x4, 1, 16 * g);
-            if (n > 0) mb.coded_mask |= 1u << g;
-          } else {
-            int16_t tmp[16] = {0};
-            n = cavlc_block(cavlc_nc(1 + p, bx, by), 15, zigzag4x4, 1, tmp);
-            if (n > 0) emit_levels(g, 0, tmp, 16);
-          }
+          int16_t tmp[16] = {0};
+          const int n = cavlc_block(cavlc_nc(1 + p, bx, by), 15, zigzag4x4, 1, tmp);
           if (n < 0) return false;
+          if (n > 0) emit_levels(g, 0, tmp, 16);
           mb.nnz[16 + 4 * p + s] = static_cast<uint8_t>(n);
         }
     }
-    if (!use_cabac && bits.overrun) return fail("residual ran past the end of the slice");
+    if (bits.overrun) return fail("residual ran past the end of the slice");
     return true;
   }
 
@@ -1795,9 +1909,182 @@ struct SliceData {
     return true;
   }
 
+  // The motion syntax of a macroblock of a P slice (7.3.5.1 / 7.3.5.2, mb_type 0 .. 4 of Table 7-13): exactly what
+  // parse_inter does for it - the same reads in the same order, the same stores - with the shapes spelled out.  Through
+  // parse_inter's loops over lists, partitions and sub-partitions a P macroblock took ~1 400 instructions here, of which
+  // ~350 belonged to its ten bins (round 5, counted per region on the GPU box's EPYC: tools/hostprof, -DHWANG_REGION_COUNTERS);
+  // in a P picture that was a quarter of the parser's instructions.
+  bool parse_inter_p(int mb_type) {
+    const int a = mb.addr;
+    MbMotion& mo = cur->motion[a];
+    int32_t* const uid = &cur->ref_uid[0][static_cast<size_t>(a) * 4];
+    const int nref = sl.num_ref_idx[0];
+    // the reference of the 8x8 quadrants in `mask`: index into the list, its surface, its picture (set_ref8)
+    auto set_refs = [&](int mask, int ref) __attribute__((always_inline)) {
+      int slot = -1, u = -1;
+      if (sl.ref[0][ref].d) {
+        slot = sl.ref[0][ref].slot;
+        u = sl.ref[0][ref].uid;
+      }
+      for (int q = 0; q < 4; ++q)
+        if ((mask >> q) & 1) {
+          mo.ref_idx[0][q] = static_cast<int8_t>(ref);
+          mo.ref_slot[0][q] = static_cast<int8_t>(slot);
+          uid[q] = u;
+        }
+    };
+    // ref_idx_l0 of the partition that starts at quadrant b8 (absent - inferred 0 - with one reference and in P_8x8ref0)
+    // (the contexts of 9.3.3.1.1.6 for list 0 of a P slice: "the neighbouring partition's reference index is above 0" of
+    // the 8x8 to the left and above - in this macroblock, or the adjoining quadrant of the macroblock next door; an intra,
+    // skipped or not yet decoded quadrant holds -1 / 0 there and an unavailable macroblock does not count)
+    auto read_ref = [&](int b8, int* ref) __attribute__((always_inline)) -> bool {
+      if (mb_type == 4 || nref <= 1) {
+        *ref = 0;
+        return nref >= 1;
+      }
+      if (!use_cabac) {
+        *ref = rd_ref_idx(0, b8);
+        return *ref >= 0 && *ref < nref;
+      }
+      bool ca, cb;
+      switch (b8) {
+        case 0:
+          ca = mb.avA && cur->motion[a - 1].ref_idx[0][1] > 0;
+          cb = mb.avB && cur->motion[a - mbw].ref_idx[0][2] > 0;
+          break;
+        case 1:
+          ca = mo.ref_idx[0][0] > 0;
+          cb = mb.avB && cur->motion[a - mbw].ref_idx[0][3] > 0;
+          break;
+        case 2:
+          ca = mb.avA && cur->motion[a - 1].ref_idx[0][3] > 0;
+          cb = mo.ref_idx[0][0] > 0;
+          break;
+        default:
+          ca = mo.ref_idx[0][2] > 0;
+          cb = mo.ref_idx[0][1] > 0;
+          break;
+      }
+      int inc = (ca ? 1 : 0) + (cb ? 2 : 0), v = 0;
+      CabacLocal c(cabac);
+      while (c.bin(54 + inc)) {
+        ++v;
+        inc = (inc >> 2) + 4;
+        if (v >= 32) return false;
+      }
+      *ref = v;
+      return v < nref;
+    };
+    const int shape = mb_type >= 3 ? 3 : mb_type;
+    int sub = 0;
+    if (shape == 3)
+      for (int i = 0; i < 4; ++i) {
+        const int t = rd_sub_mb_type();
+        if (t < 0 || t > 3) return fail("bad sub_mb_type");
+        mb.sub_type[i] = t;
+        sub |= t << (2 * i);
+      }
+    int r;
+    switch (shape) {
+      case 0:
+        if (!read_ref(0, &r)) return fail("ref_idx out of range");
+        set_refs(15, r);
+        break;
+      case 1:
+        if (!read_ref(0, &r)) return fail("ref_idx out of range");
+        set_refs(3, r);
+        if (!read_ref(2, &r)) return fail("ref_idx out of range");
+        set_refs(12, r);
+        break;
+      case 2:
+        if (!read_ref(0, &r)) return fail("ref_idx out of range");
+        set_refs(5, r);
+        if (!read_ref(1, &r)) return fail("ref_idx out of range");
+        set_refs(10, r);
+        break;
+      default:
+        for (int i = 0; i < 4; ++i) {
+          if (!read_ref(i, &r)) return fail("ref_idx out of range");
+          set_refs(1 << i, r);
+        }
+        break;
+    }
+    REGION(R_INTER_MVD);
+    mb.mv_defer = 1;  // the differences are recorded, the vectors derived per picture later (k_mv / derive_deferred)
+    mb.mv_shape = shape;
+    mb.mv_sub = sub;
+    uint8_t* const mvd0 = mvd_at(a, 0, 0);
+    bool ok = true;
+    // mvd_l0 of the (sub-)partition whose top-left 4x4 block is (bx, by), bw x bh blocks: read, kept as |mvd| for the
+    // contexts of what follows (set_mvd_block), handed over
+    auto one = [&](int bx, int by, int bw, int bh) __attribute__((always_inline)) {
+      int dx, dy;
+      rd_mvd_pair(0, bx, by, &dx, &dy);
+      const uint16_t pat = static_cast<uint16_t>(imin(iabs(dx), 255) | (imin(iabs(dy), 255) << 8));
+      if (bw == 4) {  // whole rows of the macroblock's sixteen {|mvd_x|, |mvd_y|} pairs: 8 bytes each
+        const __m128i v = _mm_set1_epi16(static_cast<int16_t>(pat));
+        for (int y = by; y < by + bh; y += 2) _mm_storeu_si128(reinterpret_cast<__m128i*>(mvd0 + y * 8), v);
+      } else {
+        for (int y = by; y < by + bh; ++y)
+          for (int x = bx; x < bx + bw; ++x) memcpy(mvd0 + (y * 4 + x) * 2, &pat, 2);
+      }
+      if (compact) {
+        // decode order = the order k_mv walks the partitions in
+        if (mb.pm_parts++ == 0) {
+          bufs.pmo[a].mvd0[0] = static_cast<int16_t>(dx);
+          bufs.pmo[a].mvd0[1] = static_cast<int16_t>(dy);
+        } else if (pmx_used >= bufs.pmx_capacity) {
+          ok = false;
+        } else {
+          bufs.pmx[pmx_used++] = static_cast<uint16_t>(dx) | (static_cast<uint32_t>(static_cast<uint16_t>(dy)) << 16);
+        }
+      } else {
+        set_mv_block(0, bx, by, bw, bh, dx, dy);
+      }
+    };
+    switch (shape) {
+      case 0:
+        one(0, 0, 4, 4);
+        break;
+      case 1:
+        one(0, 0, 4, 2);
+        one(0, 2, 4, 2);
+        break;
+      case 2:
+        one(0, 0, 2, 4);
+        one(2, 0, 2, 4);
+        break;
+      default:
+        for (int i = 0; i < 4 && ok; ++i) {
+          const int px = (i & 1) * 2, py = (i >> 1) * 2;
+          switch ((sub >> (2 * i)) & 3) {
+            case 0:
+              one(px, py, 2, 2);
+              break;
+            case 1:
+              one(px, py, 2, 1);
+              one(px, py + 1, 2, 1);
+              break;
+            case 2:
+              one(px, py, 1, 2);
+              one(px + 1, py, 1, 2);
+              break;
+            default:
+              one(px, py, 1, 1);
+              one(px + 1, py, 1, 1);
+              one(px, py + 1, 1, 1);
+              one(px + 1, py + 1, 1, 1);
+              break;
+          }
+        }
+        break;
+    }
+    return ok || fail("motion extras overflow");
+  }
+
   // (the caller has called set_position(addr))
   void begin_mb(int addr) {
-    {
+    if (sl.type == 1 || !compact) {  // (what reads them - pred_mv, pred_direct - runs for B slices and for sinks that leave the vectors to the host)
       static const int off_x[4] = {-1, 0, 1, -1}, off_y[4] = {-1, -1, -1, 0};
       for (int k = 0; k < 4; ++k) {
         const int na = addr + off_y[k] * mbw + off_x[k];
@@ -1854,10 +2141,14 @@ struct SliceData {
     uint8_t f = 0;
     if (mb.t8x8) f |= amd::MBF_T8X8;
     if (intra) f |= amd::MBF_INTRA;
-    if (intra_mb_ok(mb.mbx - 1, mb.mby)) f |= amd::MBF_AVAIL_A;
-    if (intra_mb_ok(mb.mbx, mb.mby - 1)) f |= amd::MBF_AVAIL_B;
-    if (intra_mb_ok(mb.mbx + 1, mb.mby - 1)) f |= amd::MBF_AVAIL_C;
-    if (intra_mb_ok(mb.mbx - 1, mb.mby - 1)) f |= amd::MBF_AVAIL_D;
+    if (!p.constrained_intra_pred) {  // (intra_mb_ok is the neighbour's availability then)
+      f |= static_cast<uint8_t>(mb.av_bits << 2);
+    } else {
+      if (intra_mb_ok(mb.mbx - 1, mb.mby)) f |= amd::MBF_AVAIL_A;
+      if (intra_mb_ok(mb.mbx, mb.mby - 1)) f |= amd::MBF_AVAIL_B;
+      if (intra_mb_ok(mb.mbx + 1, mb.mby - 1)) f |= amd::MBF_AVAIL_C;
+      if (intra_mb_ok(mb.mbx - 1, mb.mby - 1)) f |= amd::MBF_AVAIL_D;
+    }
     if (sl.disable_deblock != 1) {
       if (mb.mbx > 0 && !(sl.disable_deblock == 2 && mb_slice[a - 1] != mb_slice[a])) f |= amd::MBF_DB_LEFT;
       if (mb.mby > 0 && !(sl.disable_deblock == 2 && mb_slice[a - mbw] != mb_slice[a])) f |= amd::MBF_DB_TOP;
@@ -1886,10 +2177,7 @@ struct SliceData {
       }
       if (mb.mv_defer) mf |= amd::MVF_DEFERRED;
       if (mb.mv_pskip) mf |= amd::MVF_PSKIP;
-      if (mb.av[3]) mf |= amd::MVF_AVAIL_A;
-      if (mb.av[1]) mf |= amd::MVF_AVAIL_B;
-      if (mb.av[2]) mf |= amd::MVF_AVAIL_C;
-      if (mb.av[0]) mf |= amd::MVF_AVAIL_D;
+      mf |= static_cast<uint8_t>(mb.av_bits << 4);
       o.mv_flags = mf;
       o.mv_shape = static_cast<uint8_t>(mb.mv_shape);
       o.mv_sub = static_cast<uint8_t>(mb.mv_sub);
@@ -1899,10 +2187,15 @@ struct SliceData {
       rec[2] = o.mv_sub;
       if (mb.mv_defer) cur->mv_deferred = true;
     }
-    for (int k = 0; k < 8; ++k) o.i4_modes[k] = static_cast<uint8_t>((mb.i4_mode[2 * k] & 15) | (mb.i4_mode[2 * k + 1] << 4));
+    if (intra) {
+      for (int k = 0; k < 8; ++k) o.i4_modes[k] = static_cast<uint8_t>((mb.i4_mode[2 * k] & 15) | (mb.i4_mode[2 * k + 1] << 4));
+    } else {
+      memset(o.i4_modes, 0x22, sizeof(o.i4_modes));  // (begin_mb's value - DC - in every nibble: an inter macroblock has no modes)
+    }
     uint16_t nz = static_cast<uint16_t>(~_mm_movemask_epi8(
         _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(mb.nnz)), _mm_setzero_si128())));
-    if (mb.t8x8)  // the transform block is the 8x8: any coefficient marks all four
+    if (mb.t8x8 && !use_cabac)  // the transform block is the 8x8: any coefficient marks all four (CABAC: parse_residual has
+                                // given the four blocks of an 8x8 the same count already)
       for (int b8 = 0; b8 < 4; ++b8) {
         const int o4 = (b8 >> 1) * 8 + (b8 & 1) * 2;
         const uint16_t m = (1u << o4) | (1u << (o4 + 1)) | (1u << (o4 + 4)) | (1u << (o4 + 5));
@@ -1946,6 +2239,7 @@ struct SliceData {
     memset(pskip_motion.ref_slot, -1, sizeof(pskip_motion.ref_slot));
     memset(pskip_motion.ref_idx, -1, sizeof(pskip_motion.ref_idx));
     pskip_ref_uid = -1;
+    pskip_info_qp = -1;  // (the record template: made for the first P_Skip macroblock, and again when QP_Y has moved)
     if (sl.num_ref_idx[0] > 0 && sl.ref[0][0].d) {
       const RefSnap& r = sl.ref[0][0];
       for (int q = 0; q < 4; ++q) {
@@ -1959,6 +2253,7 @@ struct SliceData {
   // P_Skip in one pass: exactly the stores begin_mb + decode_skip_mb + commit_mb make for it
   // (tests/golden/parser_digest.json pins the records byte for byte).
   bool decode_pskip(int addr) {
+    REGION(R_PSKIP);
     const Pps& p = *apps;
     last_qp_delta_nonzero = 0;
     // host-side context state the neighbours will ask for
@@ -1993,14 +2288,22 @@ struct SliceData {
     }
     has_inter = true;
     ++mbs_decoded;
-    // the record
-    MbInfo o;
-    memset(&o, 0, sizeof(o));
-    o.kind = amd::MBK_INTER;
+    // the record: what does not change from one P_Skip macroblock of the slice to the next comes from a template
+    if (pskip_info_qp != qp) {
+      memset(&pskip_info, 0, sizeof(pskip_info));
+      pskip_info.kind = amd::MBK_INTER;
+      pskip_info.deblock_internal = sl.disable_deblock != 1;
+      pskip_info.qp = static_cast<uint8_t>(qp);
+      pskip_info.qpc[0] = chroma_qp_table[iclip(0, 51, qp + p.chroma_qp_offset[0])];
+      pskip_info.qpc[1] = chroma_qp_table[iclip(0, 51, qp + p.chroma_qp_offset[1])];
+      pskip_info.slice = static_cast<uint8_t>(slice_index - 1);
+      memset(pskip_info.i4_modes, 0x22, sizeof(pskip_info.i4_modes));
+      pskip_info_qp = qp;
+    }
+    MbInfo o = pskip_info;
     uint8_t f = 0;
     if (!p.constrained_intra_pred) {
-      f |= (mb.av[3] ? amd::MBF_AVAIL_A : 0) | (mb.av[1] ? amd::MBF_AVAIL_B : 0) | (mb.av[2] ? amd::MBF_AVAIL_C : 0) |
-           (mb.av[0] ? amd::MBF_AVAIL_D : 0);
+      f |= static_cast<uint8_t>(mb.av_bits << 2);
     } else {
       if (intra_mb_ok(mb.mbx - 1, mb.mby)) f |= amd::MBF_AVAIL_A;
       if (intra_mb_ok(mb.mbx, mb.mby - 1)) f |= amd::MBF_AVAIL_B;
@@ -2010,24 +2313,17 @@ struct SliceData {
     if (sl.disable_deblock != 1) {
       if (mb.mbx > 0 && !(sl.disable_deblock == 2 && mb_slice[addr - 1] != mb_slice[addr])) f |= amd::MBF_DB_LEFT;
       if (mb.mby > 0 && !(sl.disable_deblock == 2 && mb_slice[addr - mbw] != mb_slice[addr])) f |= amd::MBF_DB_TOP;
-      o.deblock_internal = 1;
     }
     o.flags = f;
-    o.qp = static_cast<uint8_t>(qp);
-    o.qpc[0] = chroma_qp_table[iclip(0, 51, qp + p.chroma_qp_offset[0])];
-    o.qpc[1] = chroma_qp_table[iclip(0, 51, qp + p.chroma_qp_offset[1])];
-    o.slice = static_cast<uint8_t>(slice_index - 1);
-    const uint8_t mf = static_cast<uint8_t>(amd::MVF_DEFERRED | amd::MVF_PSKIP | (compact ? amd::MVF_COMPACT : 0) | (mb.av[3] ? amd::MVF_AVAIL_A : 0) |
-                                            (mb.av[1] ? amd::MVF_AVAIL_B : 0) | (mb.av[2] ? amd::MVF_AVAIL_C : 0) |
-                                            (mb.av[0] ? amd::MVF_AVAIL_D : 0));
+    const uint8_t mf = static_cast<uint8_t>(amd::MVF_DEFERRED | amd::MVF_PSKIP | (compact ? amd::MVF_COMPACT : 0) | (mb.av_bits << 4));
     o.mv_flags = mf;
     uint8_t* rec = &cur->mvrec[static_cast<size_t>(addr) * 3];
     rec[0] = mf;
     rec[1] = rec[2] = 0;
     cur->mv_deferred = true;
-    memset(o.i4_modes, 0x22, sizeof(o.i4_modes));
     o.coef_offset = static_cast<uint32_t>(coef_used);
     bufs.mb[addr] = o;
+    REGION(R_MBHEAD);
     return true;
   }
 
@@ -2051,8 +2347,10 @@ struct SliceData {
 
   bool decode_mb(int addr) {
     const Pps& p = *apps;
+    REGION(R_BEGIN);
     begin_mb(addr);
     const int st = sl.type;
+    REGION(R_MBTYPE);
     const int t = rd_mb_type();
     int intra_t = -1;
     if (st == 2) {
@@ -2092,6 +2390,7 @@ struct SliceData {
     }
 
     if (intra_t >= 0) {
+      REGION(R_INTRAMODES);
       if (intra_t == 0) {
         mb.kind = MB_I4x4;
         if (p.transform_8x8_mode && rd_t8x8_flag()) {
@@ -2099,6 +2398,48 @@ struct SliceData {
           mb.t8x8 = 1;
         }
         const int nblk = mb.kind == MB_I4x4 ? 16 : 4;
+        if (use_cabac) {
+          // The modes of the sixteen blocks (or four) in one pass: the arithmetic decoder in registers throughout, and
+          // the neighbours' modes (8.3.1.1 / 8.3.2.1) in a 5 x 5 grid whose row -1 / column -1 are the macroblocks
+          // above / to the left: -1 = not available for intra prediction (then the prediction is DC whatever the
+          // other neighbour says), 2 = a neighbour that is not Intra4x4 / Intra8x8.  (predicted_intra_mode +
+          // rd_intra_pred_mode per block were 1 100 of an Intra4x4 macroblock's instructions outside its bins.)
+          int8_t grid[25];
+          {
+            const int a = mb.addr;
+            auto edge = [&](bool avail, int na, int8_t* dst, int stride, int first, int step) {
+              int8_t fill = 2;
+              const int kind = avail ? mb_kind[na] : MB_NONE;
+              if (!avail || (kind == MB_INTER && p.constrained_intra_pred)) fill = -1;
+              const bool modes = avail && (kind == MB_I4x4 || kind == MB_I8x8);
+              for (int i = 0; i < 4; ++i) dst[i * stride] = modes ? static_cast<int8_t>(i4mode[na * 16 + first + i * step]) : fill;
+            };
+            edge(mb.av[1], a - mbw, grid + 1, 1, 12, 1);   // above: its bottom row
+            edge(mb.av[3], a - 1, grid + 5, 5, 3, 4);      // left: its right column
+          }
+          CabacLocal c(cabac);
+          for (int k = 0; k < nblk; ++k) {
+            const int bx = nblk == 16 ? blk4_x[k] : (k & 1) * 2, by = nblk == 16 ? blk4_y[k] : (k >> 1) * 2;
+            const int m = imin(grid[(by + 1) * 5 + bx], grid[by * 5 + bx + 1]);
+            const int pm = m < 0 ? 2 : m;
+            int mode = pm;
+            if (!c.bin(68)) {
+              int rem = c.bin(69);
+              rem |= c.bin(69) << 1;
+              rem |= c.bin(69) << 2;
+              mode = rem < pm ? rem : rem + 1;
+            }
+            if (nblk == 16) {
+              mb.i4_mode[by * 4 + bx] = static_cast<int8_t>(mode);
+              grid[(by + 1) * 5 + bx + 1] = static_cast<int8_t>(mode);
+            } else {
+              for (int s = 0; s < 4; ++s) {
+                mb.i4_mode[(by + (s >> 1)) * 4 + bx + (s & 1)] = static_cast<int8_t>(mode);
+                grid[(by + (s >> 1) + 1) * 5 + bx + (s & 1) + 1] = static_cast<int8_t>(mode);
+              }
+            }
+          }
+        } else
         for (int k = 0; k < nblk; ++k) {
           const int bx = nblk == 16 ? blk4_x[k] : (k & 1) * 2, by = nblk == 16 ? blk4_y[k] : (k >> 1) * 2;
           const int pm = predicted_intra_mode(bx, by);
@@ -2117,16 +2458,18 @@ struct SliceData {
       if (mb.chroma_mode > 3 || mb.chroma_mode < 0) return fail("bad intra_chroma_pred_mode");
       cur->mb_intra[addr] = 1;
     } else {
+      REGION(R_INTER_REFS);
       mb.kind = MB_INTER;
       if (st == 1 && t == 0) {
         mb.direct16 = 1;
         memset(&direct8[addr * 4], 1, 4);
         if (!pred_direct(-1)) return false;
-      } else if (!parse_inter(t)) {
+      } else if (!(st == 0 ? parse_inter_p(t) : parse_inter(t))) {
         return false;
       }
     }
 
+    REGION(R_CBP);
     if (mb.kind != MB_I16x16) {
       int cbp = rd_cbp(mb.kind != MB_INTER);
       if (cbp < 0) return fail("bad coded_block_pattern");
@@ -2143,20 +2486,26 @@ struct SliceData {
             }
           }
         }
+        REGION(R_T8X8);
         if (ok) mb.t8x8 = rd_t8x8_flag();
       }
     }
+    REGION(R_QPD);
     if (mb.cbp || mb.kind == MB_I16x16) {
       const int dq = rd_qp_delta();
       if (dq < -26 || dq > 25) return fail("mb_qp_delta out of range");
       last_qp_delta_nonzero = dq != 0;
       qp = (qp + dq + 52) % 52;
       mb.qp = qp;
+      REGION(R_RESIDUAL);
       if (!parse_residual()) return false;
     } else {
       last_qp_delta_nonzero = 0;
     }
-    return commit_mb(nullptr);
+    REGION(R_COMMIT);
+    const bool ok = commit_mb(nullptr);
+    REGION(R_MBHEAD);
+    return ok;
   }
 
   bool decode_slice_data(Bits& b) {
@@ -2180,6 +2529,7 @@ struct SliceData {
         if (!b.bit()) return fail("cabac_alignment_one_bit is zero");
       cabac.init_contexts(sl.type, sl.cabac_init_idc, sl.qp);
       cabac.begin(b.buf + (b.pos >> 3), b.buf + ((b.size_bits + 7) >> 3));
+      REGION(R_MBHEAD);
       for (;;) {
         if (addr >= nmb) return fail("slice runs past the end of the picture");
         bool skipped = false;
@@ -2195,6 +2545,7 @@ struct SliceData {
         ++addr;
         if (cabac.terminate()) break;
       }
+      REGION(R_OTHER);
       {  // desync check: last consumed bit is the stop bit, only zeros follow
         const int pos = (b.pos & ~7) + cabac.bits_consumed();
         bool ok = pos > 0 && pos <= b.size_bits && ((b.buf[(pos - 1) >> 3] >> (7 - ((pos - 1) & 7))) & 1);
