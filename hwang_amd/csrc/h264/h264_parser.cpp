@@ -173,7 +173,11 @@ struct RegionCounters {
     memset(&a, 0, sizeof(a));
     a.size = sizeof(a);
     a.type = PERF_TYPE_HARDWARE;
+#ifdef HWANG_REGION_CYCLES  // (cycles instead: the reads disturb the pipeline, the shares still say where the time is)
+    a.config = PERF_COUNT_HW_CPU_CYCLES;
+#else
     a.config = PERF_COUNT_HW_INSTRUCTIONS;
+#endif
     a.exclude_kernel = 1;
     a.exclude_hv = 1;
     fd = static_cast<int>(syscall(SYS_perf_event_open, &a, 0, -1, -1, 0));
