@@ -50,6 +50,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HWANG_HOST_COUNTERS", "1")  # the lane threads count their own instructions / cycles (bench line: host_lane_threads)
 
 WIDTH, HEIGHT = 1920, 1080
 UNIQUE_FRAMES = 1200          # encoded once ...
@@ -404,6 +405,19 @@ def main():
     host_cpus_busy = ((c1.user - c0.user) + (c1.system - c0.system)) / elapsed
     stats = br.stats()
     dev_stats = br.device_stats()
+    # what the lane threads - the entropy decoders - executed in the last step, from the CPU's own counters (rank 0's)
+    hc = br.host_counters()
+    host_lane_threads = None
+    if hc["cpu_ns"] and stats["pictures_reconstructed"]:
+        n = stats["pictures_reconstructed"]
+        host_lane_threads = {"cpu_ms_per_picture": round(hc["cpu_ns"] / 1e6 / n, 3)}
+        if hc["cycles"]:
+            host_lane_threads.update({"instructions_per_picture": int(hc["instructions"] / n), "cycles_per_picture": int(hc["cycles"] / n),
+                                      "branch_misses_per_picture": int(hc["branch_misses"] / n),
+                                      "ipc": round(hc["instructions"] / hc["cycles"], 2),
+                                      "ghz_while_running": round(hc["cycles"] / hc["cpu_ns"], 2),
+                                      "what": "user-mode counters of the retriever's lane threads over the last timed step (perf_event_open, "
+                                              "per thread); the single-thread figures of the parser alone are in profiles/r05_host_perf_counters.txt"})
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -645,6 +659,7 @@ def main():
             "value_reference_api": reference_api,
             "parity_check": parity,
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
+            "host_lane_threads": host_lane_threads,
             "samples_fed_per_s_rank0": round(stats["samples_fed"] / (elapsed / args.steps), 1),
             "host_cpus_busy_rank0": round(host_cpus_busy, 2),
             "host_cpus_total": host_cpus_total,

@@ -123,6 +123,7 @@ PROTOTYPES = {
     "hwang_retriever_retrieve": (C.c_int, [vp, vp, vp, C.c_size_t, u64p, C.c_size_t, vp, C.c_size_t, C.c_int]),
     "hwang_retriever_last_error": (C.c_char_p, [vp]),
     "hwang_retriever_stats": (None, [vp, i64p]),
+    "hwang_retriever_host_counters": (None, [vp, i64p]),
     # kernels
     "hwang_k_yuv420_to_rgb24": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "hwang_h264_probe": (C.c_int, [vp, C.c_size_t, vp, u64p, u64p, C.c_size_t, u64p, C.c_size_t,

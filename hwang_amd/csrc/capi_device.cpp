@@ -217,5 +217,12 @@ void hwang_retriever_stats(hwang_retriever* r, int64_t stats[10]) {
   stats[8] = s.stall_ns;
   stats[9] = 0;
 }
+void hwang_retriever_host_counters(hwang_retriever* r, int64_t out[4]) {
+  ParallelRetriever::Stats s = r->r->stats();
+  out[0] = s.lane_instructions;
+  out[1] = s.lane_cycles;
+  out[2] = s.lane_branch_misses;
+  out[3] = s.lane_cpu_ns;
+}
 
 }  // extern "C"

@@ -1,5 +1,10 @@
 #include "retriever.h"
 
+#include <linux/perf_event.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
+
 #include "util/avc_sample.h"
 #include "util/cpus.h"
 #include "util/numa.h"
@@ -147,6 +152,47 @@ size_t frame_bytes_of(const VideoIndex& index, bool yuv) {
   const size_t w = index.frame_width(), h = index.frame_height();
   return yuv ? w * h + 2 * ((w + 1) / 2) * ((h + 1) / 2) : w * h * 3;
 }
+// A thread's own CPU time and - on request, where the kernel lets a process count its events - the user-mode
+// instructions, cycles and mispredicted branches it retired (bench.py: host_lane_threads).
+struct ThreadCounters {
+  int fd[3] = {-1, -1, -1};
+  int64_t cpu0 = 0;
+  static int64_t thread_cpu_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    return static_cast<int64_t>(ts.tv_sec) * 1000000000 + ts.tv_nsec;
+  }
+  explicit ThreadCounters(bool hardware) {
+    cpu0 = thread_cpu_ns();
+    if (!hardware) return;
+    const uint64_t cfg[3] = {PERF_COUNT_HW_INSTRUCTIONS, PERF_COUNT_HW_CPU_CYCLES, PERF_COUNT_HW_BRANCH_MISSES};
+    for (int i = 0; i < 3; ++i) {
+      perf_event_attr a;
+      std::memset(&a, 0, sizeof(a));
+      a.size = sizeof(a);
+      a.type = PERF_TYPE_HARDWARE;
+      a.config = cfg[i];
+      a.exclude_kernel = 1;
+      a.exclude_hv = 1;
+      fd[i] = static_cast<int>(syscall(SYS_perf_event_open, &a, 0, -1, -1, 0));
+    }
+  }
+  void stop(int64_t* cpu_ns, int64_t* instructions, int64_t* cycles, int64_t* branch_misses) {
+    *cpu_ns = thread_cpu_ns() - cpu0;
+    int64_t* out[3] = {instructions, cycles, branch_misses};
+    for (int i = 0; i < 3; ++i) {
+      uint64_t v = 0;
+      if (fd[i] >= 0 && read(fd[i], &v, 8) == 8) *out[i] = static_cast<int64_t>(v);
+      if (fd[i] >= 0) close(fd[i]);
+      fd[i] = -1;
+    }
+  }
+  ~ThreadCounters() {
+    for (int f : fd)
+      if (f >= 0) close(f);
+  }
+};
+
 // (width, height, format, avcC) as one comparable blob
 std::vector<uint8_t> config_key_of(const VideoIndex& index) {
   std::vector<uint8_t> k;
@@ -273,6 +319,7 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
   }
 
   std::atomic<bool> abort{false};
+  const bool host_counters = getenv("HWANG_HOST_COUNTERS") != nullptr;
   size_t nl = std::min(lanes_.size(), order.size());
   // A lane's working set grows with the picture (records of a 4K picture:
   // ~13 MB); beyond two lanes per CPU the parsers evict each other (measured
@@ -292,6 +339,7 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
     lane.samples_fed = 0;
     lane.frames_returned = 0;
     lane.items = 0;
+    lane.cpu_ns = lane.instructions = lane.cycles = lane.branch_misses = 0;
     threads.emplace_back([&, li]() {
       Lane& lane = lanes_[li];
       pthread_setname_np(pthread_self(), "hw-lane");
@@ -299,6 +347,7 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
       // staging buffers it is the first to ask for - stay on the socket its GPU hangs off (HWANG_NUMA_AFFINITY=0/1)
       if (numa::enabled(devices_.size() > 1 || shard_world_ > 1))
         numa::bind_current_thread_to_node(VideoDecoderFactory::device_numa_node(devices_[lane.device_slot]));
+      ThreadCounters counters(host_counters);
       Result r;
       for (auto& b : lane.backend)
         if (auto* c = dynamic_cast<CountedBackend*>(b.get())) c->reset_counters();
@@ -331,6 +380,7 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
         if (r.ok) r = b->wait_until_frames_copied();
       if (!r.ok) abort.store(true);
       lane.result = r;
+      counters.stop(&lane.cpu_ns, &lane.instructions, &lane.cycles, &lane.branch_misses);
     });
   }
   for (auto& t : threads) t.join();
@@ -341,6 +391,10 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
     if (!lane.result.ok && result.ok) result = lane.result;
     stats_.samples_fed += lane.samples_fed;
     stats_.frames_returned += lane.frames_returned;
+    stats_.lane_cpu_ns += lane.cpu_ns;
+    stats_.lane_instructions += lane.instructions;
+    stats_.lane_cycles += lane.cycles;
+    stats_.lane_branch_misses += lane.branch_misses;
     DeviceStats& ds = device_stats_[lane.device_slot];
     ds.items += lane.items;
     ds.frames_returned += lane.frames_returned;

@@ -52,6 +52,8 @@ class ParallelRetriever {
     int64_t entropy_ns = 0;
     int64_t stall_ns = 0;
     int64_t wall_ns = 0;
+    // the lane threads' own CPU time, and (HWANG_HOST_COUNTERS=1, where perf_event_open is allowed) what they executed
+    int64_t lane_cpu_ns = 0, lane_instructions = 0, lane_cycles = 0, lane_branch_misses = 0;
   };
 
   // What each device of the retriever did in the last call.
@@ -122,6 +124,7 @@ class ParallelRetriever {
     int64_t samples_fed = 0;
     int64_t frames_returned = 0;
     int64_t items = 0;
+    int64_t cpu_ns = 0, instructions = 0, cycles = 0, branch_misses = 0;  // of the lane's thread in the last call
   };
 
   ParallelRetriever() {}

@@ -99,6 +99,13 @@ class BatchRetriever(object):
         self.retrieve_into(full)
         return [[b[i] for i in range(b.shape[0])] for b in bufs]
 
+    def host_counters(self):
+        """What the lane threads of the last call executed (hwang_retriever_host_counters: all zeros but cpu_ns unless
+        HWANG_HOST_COUNTERS=1 was set and the kernel lets the process count its own events)."""
+        s = (C.c_int64 * 4)()
+        lib.hwang_retriever_host_counters(self._h, s)
+        return dict(zip(("instructions", "cycles", "branch_misses", "cpu_ns"), list(s)))
+
     def stats(self):
         s = (C.c_int64 * 10)()
         lib.hwang_retriever_stats(self._h, s)

@@ -277,6 +277,11 @@ const char* hwang_retriever_last_error(hwang_retriever* r);
  *  [7] wall nanoseconds, [8] nanoseconds lanes were blocked on the GPU (staging
  *  ring full), summed over lanes, [9] reserved (0) */
 void hwang_retriever_stats(hwang_retriever* r, int64_t stats[10]);
+/* Measurement aid (bench.py's `host_lane_threads` block): what the lane threads of the last retrieve() executed, from
+ * the CPU's own counters where the kernel lets a process count its events (HWANG_HOST_COUNTERS=1 in the environment
+ * when the call starts; all zeros otherwise): [0] user-mode instructions, [1] cycles, [2] mispredicted branches,
+ * [3] CPU nanoseconds of those threads (CLOCK_THREAD_CPUTIME_ID, always filled). */
+void hwang_retriever_host_counters(hwang_retriever* r, int64_t out[4]);
 
 /* -- Kernel-level entry points (parity tests + per-kernel roofline) ---------
  * Each runs one HIP kernel of the reconstruct pipeline on device buffers the
