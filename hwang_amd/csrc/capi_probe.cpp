@@ -54,11 +54,11 @@ struct ProbeSink : public h264::PictureSink {
   // HWANG_PROBE_TIMES=1 (serial decoding only): wall time between begin_picture and end_picture per picture kind
   bool times = getenv("HWANG_PROBE_TIMES") != nullptr;
   std::chrono::steady_clock::time_point t_begin;
-  int64_t ns_kind[2] = {0, 0}, n_kind[2] = {0, 0}, coef_kind[2] = {0, 0};
+  int64_t ns_kind[3] = {0, 0, 0}, n_kind[3] = {0, 0, 0}, coef_kind[3] = {0, 0, 0};  // intra-only, P, with B slices
   // ... and, where the kernel lets a process count its own events (the GPU boxes do, the build container's VM has no
   // PMU), user-mode instructions / cycles / branch misses per picture kind
   int pfd[3] = {-1, -1, -1};
-  uint64_t pstart[3] = {0, 0, 0}, pkind[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  uint64_t pstart[3] = {0, 0, 0}, pkind[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
   void perf_open() {
     const uint64_t cfg[3] = {PERF_COUNT_HW_INSTRUCTIONS, PERF_COUNT_HW_CPU_CYCLES, PERF_COUNT_HW_BRANCH_MISSES};
     for (int i = 0; i < 3; ++i) {
@@ -155,7 +155,7 @@ struct ProbeSink : public h264::PictureSink {
   }
   bool end_picture(const h264::PicDone& d, std::string*) override {
     if (times) {
-      const int k = d.has_inter ? 1 : 0;
+      const int k = (d.slice_type_mask & 2) ? 2 : (d.has_inter ? 1 : 0);
       ns_kind[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
       ++n_kind[k];
       coef_kind[k] += static_cast<int64_t>(d.coef_count);
@@ -225,10 +225,10 @@ static int run_probe(const uint8_t* avcc, size_t avcc_size, const uint8_t* data,
     if (!parser.wait_idle(&worker_error)) return report(worker_error);
   }
   if (sink.times)
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 3; ++k)
       if (sink.n_kind[k])
         fprintf(stderr, "probe: %lld %s pictures, %.3f ms and %.0f coefficient words each; %.0f instructions, %.0f cycles, %.0f branch misses each\n",
-                (long long)sink.n_kind[k], k ? "inter" : "intra-only", 1e-6 * sink.ns_kind[k] / sink.n_kind[k],
+                (long long)sink.n_kind[k], k == 2 ? "B" : (k ? "inter" : "intra-only"), 1e-6 * sink.ns_kind[k] / sink.n_kind[k],
                 1.0 * sink.coef_kind[k] / sink.n_kind[k], 1.0 * sink.pkind[k][0] / sink.n_kind[k], 1.0 * sink.pkind[k][1] / sink.n_kind[k],
                 1.0 * sink.pkind[k][2] / sink.n_kind[k]);
   int64_t skipped_out = 0;

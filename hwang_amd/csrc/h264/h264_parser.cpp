@@ -2534,20 +2534,31 @@ struct SliceData {
       cabac.init_contexts(sl.type, sl.cabac_init_idc, sl.qp);
       cabac.begin(b.buf + (b.pos >> 3), b.buf + ((b.size_bits + 7) >> 3));
       REGION(R_MBHEAD);
+      // mb_skip_flag of the macroblock at `addr` (the caller has called set_position): 9.3.3.1.1.1
+      const int skip_base = sl.type == 0 ? 11 : 24;
+      auto skip_ctx = [&]() __attribute__((always_inline)) {
+        return skip_base + ((mb.avA && !mb_skip[addr - 1]) ? 1 : 0) + ((mb.avB && !mb_skip[addr - mbw]) ? 1 : 0);
+      };
+      bool skipped = false;
+      set_position(addr);
+      if (sl.type != 2) skipped = cabac.bin(skip_ctx());
       for (;;) {
-        if (addr >= nmb) return fail("slice runs past the end of the picture");
-        bool skipped = false;
-        set_position(addr);
-        if (sl.type != 2) {
-          int inc = 0;
-          if (mb.avA && !mb_skip[addr - 1]) inc++;
-          if (mb.avB && !mb_skip[addr - mbw]) inc++;
-          skipped = cabac.bin((sl.type == 0 ? 11 : 24) + inc);
-        }
         if (!(skipped ? decode_skip_mb(addr) : decode_mb(addr))) return false;
         if (cabac.overrun) return fail("slice data ran past the end of the NAL unit");
         ++addr;
-        if (cabac.terminate()) break;
+        // end_of_slice_flag and the next macroblock's skip flag in one go: the engine in registers for the pair
+        bool past_end = false;
+        {
+          CabacLocal c(cabac);
+          if (c.terminate()) break;
+          if (addr >= nmb) {
+            past_end = true;
+          } else {
+            set_position(addr);
+            if (sl.type != 2) skipped = c.bin(skip_ctx());
+          }
+        }
+        if (past_end) return fail("slice runs past the end of the picture");
       }
       REGION(R_OTHER);
       {  // desync check: last consumed bit is the stop bit, only zeros follow

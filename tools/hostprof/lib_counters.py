@@ -23,7 +23,8 @@ offs = idx.sample_offsets_np().astype(np.uint64)
 sizes = idx.sample_sizes_np().astype(np.uint64)
 avcc = bytes(idx.metadata_bytes())
 gop = 60
-wanted = np.arange(gop - 3, idx.frames(), gop, dtype=np.uint64)
+# every GOP up to its last P picture, B pictures skipped (what C1 mostly decodes) - or, ALL=1, every picture
+wanted = np.arange(gop - 3, idx.frames(), gop, dtype=np.uint64) if not os.environ.get("ALL") else np.arange(idx.frames(), dtype=np.uint64)
 for libpath in sys.argv[2:]:
     lib = C.CDLL(os.path.abspath(libpath))
     lib.hwang_h264_probe.restype = C.c_int
