@@ -80,6 +80,7 @@ h264::WorkerPool* shared_entropy_pool(int threads) {
 
 class AMDVideoDecoder : public VideoDecoderInterface,
                         public SparseDecodeHints,
+                        public BatchingHints,
                         public PlanarOutput,
                         public CountedBackend,
                         public h264::PictureSink {
@@ -260,6 +261,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   // ------------------------------------------------------------ extensions
+  void set_long_queue(bool long_queue) override {
+    if (exec_)
+      for (int lane : lanes_) exec_->set_lane_patient(lane, long_queue);
+  }
   void set_wanted_frames(const std::vector<uint64_t>& ordinals) override {
     pending_wanted_ = ordinals;
     if (parser_) parser_->set_wanted(ordinals);

@@ -122,6 +122,13 @@ bool GpuExecutor::start(std::string* error) {
   }
   // experiment knobs: how many of the heavy engines take work, how many batches each keeps in flight
   if (const char* e = getenv("HWANG_HEAVY_ENGINES")) heavy_engines_ = std::max(1, std::min(kHeavyEngines, atoi(e)));
+  if (const char* e = getenv("HWANG_LINGER_US")) linger_us_ = std::max(0, std::min(atoi(e), 50000));
+  if (const char* e = getenv("HWANG_LINGER_IDLE_US")) linger_idle_us_ = std::max(50, std::min(atoi(e), 50000));
+  if (const char* e = getenv("HWANG_LINGER_FILL")) linger_fill_ = std::max(1, std::min(atoi(e), 100));
+  if (const char* e = getenv("HWANG_HEAVY_LINGER_US")) heavy_linger_us_ = std::max(0, std::min(atoi(e), 50000));
+  if (const char* e = getenv("HWANG_HEAVY_LINGER_PICTURES")) heavy_linger_pictures_ = std::max(1, atoi(e));
+  if (const char* e = getenv("HWANG_PRE_LINGER_US")) pre_linger_us_ = std::max(0, std::min(atoi(e), 50000));
+  if (const char* e = getenv("HWANG_PRE_LINGER_PICTURES")) pre_linger_pictures_ = std::max(1, atoi(e));
   if (const char* e = getenv("HWANG_NO_HEAVY")) no_heavy_ = atoi(e) != 0;  // experiment: intra-only pictures travel in the light batches
   if (const char* e = getenv("HWANG_HEAVY_INFLIGHT")) heavy_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
   if (const char* e = getenv("HWANG_LIGHT_INFLIGHT")) light_inflight_ = std::max(1, std::min(kInflight, atoi(e)));
@@ -210,6 +217,7 @@ int GpuExecutor::register_lane(int light_group, bool chain) {
       l.last_engine = light_engine;
       l.light_engine = light_engine;
       l.chain = chain;
+      l.patient = false;
       l.waiters = 0;
       l.active = true;
       return static_cast<int>(i);
@@ -225,6 +233,11 @@ void GpuExecutor::unregister_lane(int lane) {
   std::unique_lock<std::mutex> lk(mu_);
   lanes_[lane].cv.wait(lk, [&] { return lanes_[lane].completed == lanes_[lane].submitted || !error_.empty() || stop_; });
   lanes_[lane].active = false;
+}
+
+void GpuExecutor::set_lane_patient(int lane, bool patient) {
+  std::lock_guard<std::mutex> lk(mu_);
+  lanes_[lane].patient = patient;
 }
 
 uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
@@ -248,6 +261,7 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     }
     it.engine = (job.heavy && !with_its_chain && !no_heavy_) ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
     it.pre = prestage_ ? 0 : 2;
+    it.t_submit = std::chrono::steady_clock::now();
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
     target = prestage_ ? kPreEngine : it.engine;
@@ -593,7 +607,41 @@ void GpuExecutor::run_pre() {
             if (it.is_picture && it.pre == 0) return true;
         return false;
       };
-      cv_work_[kPreEngine].wait(lk, [&] { return stop_ || (en.inflight < 1 && have_work()); });
+      int seen_waiting = 0;
+      auto last_growth = std::chrono::steady_clock::now();
+      for (;;) {
+        cv_work_[kPreEngine].wait(lk, [&] { return stop_ || (en.inflight < 1 && have_work()); });
+        if (stop_ || !pre_linger_us_) break;
+        // Linger (see run()): k_mv is a row pipeline of ~0.3 ms whatever the width; launched for whatever has
+        // arrived since the last launch it ran two thousand times a step for four pictures each.  Keyframes do not
+        // wait (their stage is an upload and k_residual, and their whole GOP waits for them), nor does anything
+        // while few lanes are busy.
+        int busy = 0, waiting = 0;
+        bool keyframe = false, latency_lanes = false;
+        const auto now = std::chrono::steady_clock::now();
+        auto oldest = now;
+        for (const Lane& l : lanes_) {
+          if (!l.active) continue;
+          const bool b = !l.fifo.empty() || l.launched != l.completed;
+          busy += b;
+          latency_lanes |= b && (l.chain || !l.patient);
+          for (const Item& it : l.fifo)
+            if (it.is_picture && it.pre == 0) {
+              ++waiting;
+              keyframe |= it.pic.heavy != 0;
+              if (it.t_submit < oldest) oldest = it.t_submit;
+            }
+        }
+        if (busy <= chain_max_lanes_ || latency_lanes || (keyframe && !last_was_keyframes_only) || waiting >= pre_linger_pictures_) break;
+        if (waiting > seen_waiting) {
+          seen_waiting = waiting;
+          last_growth = now;
+        }
+        const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - oldest).count();
+        const auto idle = std::chrono::duration_cast<std::chrono::microseconds>(now - last_growth).count();
+        if (waited >= pre_linger_us_ || idle >= linger_idle_us_) break;
+        cv_work_[kPreEngine].wait_for(lk, std::chrono::microseconds(std::max<long>(std::min<long>(pre_linger_us_ - waited, linger_idle_us_ - idle), 50)));
+      }
       if (stop_) break;
       for (int i = 0; i < kInflight; ++i)
         if (!en.batches[i].in_flight) slot = i;
@@ -779,7 +827,52 @@ void GpuExecutor::run(int engine) {
           if (b.in_flight && b.retry_pending) again = &b;
         return again != nullptr;
       };
-      cv_work_[engine].wait(lk, [&] { return stop_ || retry_wanted() || (en.inflight < max_inflight && have_work()); });
+      int seen_ready = 0;
+      auto last_growth = std::chrono::steady_clock::now();
+      for (;;) {
+        cv_work_[engine].wait(lk, [&] { return stop_ || retry_wanted() || (en.inflight < max_inflight && have_work()); });
+        const int linger_us = is_light(engine) ? linger_us_ : heavy_linger_us_;
+        if (stop_ || again || !linger_us) break;
+        // Linger: a batch holds at most one picture per lane and lasts as long as its slowest row pipeline whatever its
+        // width.  With a thread per CPU the lanes deliver a steady stream (no bursts between quota freezes), and a
+        // batch formed the moment the last one ended would carry a third of the lanes: wait until most of this
+        // engine's active lanes have a picture ready, or the oldest one has waited its share.  Not with few lanes busy
+        // (the reference's caller: latency is all it has).
+        int busy = 0, mine = 0, ready = 0, coming = 0;
+        bool latency_lanes = false;  // a decoder with entropy workers (one automata, intervals in turn) is served at once
+        const auto now = std::chrono::steady_clock::now();
+        auto oldest = now;
+        for (const Lane& l : lanes_) {
+          if (!l.active) continue;
+          const bool b = !l.fifo.empty() || l.launched != l.completed;
+          busy += b;
+          latency_lanes |= b && (l.chain || !l.patient);
+          if (is_light(engine) && l.light_engine != engine) continue;
+          ++mine;  // (every active lane of the engine: one whose thread is parsing for it right now will have a picture soon)
+          if (eligible(l, engine)) {
+            ++ready;
+            const Item& it = l.fifo.front();
+            if (it.is_picture && it.t_submit < oldest) oldest = it.t_submit;
+          } else if (!l.fifo.empty() && l.fifo.front().is_picture && l.fifo.front().engine == engine && l.fifo.front().pre != 2) {
+            ++coming;  // in (or waiting for) the records-only stage: eligible within a launch of that
+          }
+        }
+        // (a heavy engine cannot know how many keyframes are on their way: a count, not a share of the lanes)
+        const bool full = is_light(engine) ? ready * 100 >= mine * linger_fill_ : ready >= heavy_linger_pictures_;
+        if (busy <= chain_max_lanes_ || latency_lanes || full) break;
+        // ... and only while pictures keep arriving: at the tail of a request, or in a small one, a batch that nothing
+        // has joined for `linger_idle_us_` goes as it is
+        if (ready + coming > seen_ready) {
+          seen_ready = ready + coming;
+          last_growth = now;
+        }
+        const auto waited = std::chrono::duration_cast<std::chrono::microseconds>(now - oldest).count();
+        const auto idle = std::chrono::duration_cast<std::chrono::microseconds>(now - last_growth).count();
+        if (waited >= linger_us || (coming == 0 && idle >= linger_idle_us_)) break;
+        long remaining = linger_us - waited;
+        if (coming == 0) remaining = std::min<long>(remaining, linger_idle_us_ - idle);
+        cv_work_[engine].wait_for(lk, std::chrono::microseconds(std::max<long>(remaining, 50)));
+      }
       if (!again) retry_wanted();  // (stop_ may have ended the wait before the predicate looked)
       if (again) {  // (also while stopping: the batch is in flight until its second run has completed)
         again->retry_pending = false;

@@ -48,6 +48,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <deque>
@@ -96,6 +97,9 @@ class GpuExecutor {
   // in launches as wide as the lanes make them.
   int register_lane(int light_group = 0, bool chain = false);
   void unregister_lane(int lane);
+  // The lane's owner will keep it fed from a long queue (BatchingHints): the engines may linger for wider launches
+  // while every busy lane is such a lane.
+  void set_lane_patient(int lane, bool patient);
   // Both return the lane-local sequence number of the submission (1, 2, ...).
   uint64_t submit_picture(int lane, const PicSubmit& job);
   uint64_t submit_convert(int lane, const ConvSubmit& job);
@@ -148,6 +152,7 @@ class GpuExecutor {
     bool is_picture;
     int engine = 0;  // pictures: the engine that must run it
     int pre = 2;     // pictures: the records-only stage: 0 waiting, 1 in flight, 2 done (or not used)
+    std::chrono::steady_clock::time_point t_submit;  // pictures: when the lane handed it over (batch formation: linger)
     PicSubmit pic;
     ConvSubmit conv;
   };
@@ -158,6 +163,7 @@ class GpuExecutor {
     int last_engine = 0;
     int light_engine = 0;  // engine of the lane's P / B pictures
     bool chain = false;    // see register_lane
+    bool patient = false;  // see set_lane_patient
     int waiters = 0;  // threads blocked in wait()
     // A completed batch wakes exactly the lanes it contained (one shared
     // condition variable woke every blocked lane thread for every batch: 10 %
@@ -262,6 +268,15 @@ class GpuExecutor {
   //    4K configurations do not change.
   // HWANG_HEAVY_ENGINES / HWANG_HEAVY_INFLIGHT / HWANG_LIGHT_INFLIGHT override.
   bool no_heavy_ = false;
+  // A light engine that serves many lanes forms its next batch when `linger_fill_` per cent of its active lanes have a
+  // picture ready - or the oldest of them has waited `linger_us_` (0: as soon as the previous batch is through).
+  int linger_us_ = 6000, linger_fill_ = 85;
+  int linger_idle_us_ = 700;  // ... and no engine lingers once nothing has joined its batch for this long
+  // ... a heavy engine when `heavy_linger_pictures_` keyframes are ready or the oldest has waited `heavy_linger_us_`, the
+  // records-only stage when `pre_linger_pictures_` pictures wait or the oldest has waited `pre_linger_us_` (keyframes
+  // never wait there)
+  int heavy_linger_us_ = 6000, heavy_linger_pictures_ = 8;
+  int pre_linger_us_ = 2500, pre_linger_pictures_ = 32;
   int heavy_engines_ = 1;
   int heavy_inflight_ = 1;
   int light_inflight_ = 1;

@@ -62,35 +62,54 @@ Result ParallelRetriever::set_shard(int32_t rank, int32_t world) {
 
 ParallelRetriever::~ParallelRetriever() {}
 
-Result ParallelRetriever::run_item(Lane& lane, VideoDecoderInterface* dec, const WorkItem& item,
-                                   const VideoIndex& index, const uint8_t* file,
-                                   size_t file_size, uint8_t* out,
-                                   size_t frame_bytes, bool yuv) {
-  auto* hints = dynamic_cast<SparseDecodeHints*>(dec);
-  auto* planar = dynamic_cast<PlanarOutput*>(dec);
-  if (yuv && !planar) {
-    return Result(false, "retrieve: backend has no planar (I420) output");
-  }
-  const std::vector<uint64_t>& valid = *item.valid;
-  if (hints) {
-    std::vector<uint64_t> ordinals(valid.size());
-    for (size_t i = 0; i < valid.size(); ++i) ordinals[i] = valid[i] - item.start;
-    hints->set_wanted_frames(ordinals);
-  }
-  const auto& offs = index.sample_offsets();
-  const auto& sizes = index.sample_sizes();
-  const auto& kfs = index.keyframe_indices();
-  size_t kf_cursor =
-      std::lower_bound(kfs.begin(), kfs.end(), item.start) - kfs.begin();
+// One work item on its way through a backend, a sample at a time (ItemRun::step), so that a thread can drive several
+// items - on different backends - in turn: while one decoder's pictures are on the GPU the thread parses for another.
+// The protocol is the reference automata's (decoder_automata.cpp:287-404): feed every sample up to the last wanted
+// frame, fetch wanted frames and discard the others as they appear, (nullptr, 0) + flush at the end.
+struct ParallelRetriever::ItemRun {
+  const WorkItem* item = nullptr;
+  VideoDecoderInterface* dec = nullptr;
+  PlanarOutput* planar = nullptr;
+  const VideoIndex* index = nullptr;
+  const uint8_t* file = nullptr;
+  size_t file_size = 0;
+  uint8_t* out = nullptr;
+  size_t frame_bytes = 0;
+  bool yuv = false;
+  uint64_t s = 0, next_out = 0;  // next sample to feed; display ordinal of the next output frame
+  size_t got = 0, kf_cursor = 0;
 
-  uint64_t next_out = item.start;  // display ordinal of the next output frame
-  size_t got = 0;
-  auto consume = [&]() -> Result {
+  Result start(VideoDecoderInterface* d, const WorkItem& it, const VideoIndex& idx, const uint8_t* f, size_t fsize, uint8_t* o,
+               size_t fbytes, bool want_yuv) {
+    item = &it;
+    dec = d;
+    index = &idx;
+    file = f;
+    file_size = fsize;
+    out = o;
+    frame_bytes = fbytes;
+    yuv = want_yuv;
+    auto* hints = dynamic_cast<SparseDecodeHints*>(dec);
+    planar = dynamic_cast<PlanarOutput*>(dec);
+    if (yuv && !planar) return Result(false, "retrieve: backend has no planar (I420) output");
+    const std::vector<uint64_t>& valid = *it.valid;
+    if (hints) {
+      std::vector<uint64_t> ordinals(valid.size());
+      for (size_t i = 0; i < valid.size(); ++i) ordinals[i] = valid[i] - it.start;
+      hints->set_wanted_frames(ordinals);
+    }
+    const auto& kfs = idx.keyframe_indices();
+    kf_cursor = std::lower_bound(kfs.begin(), kfs.end(), it.start) - kfs.begin();
+    s = next_out = it.start;
+    got = 0;
+    return Result();
+  }
+  Result consume(Lane& lane) {
+    const std::vector<uint64_t>& valid = *item->valid;
     while (got < valid.size() && dec->decoded_frames_buffered() > 0) {
       if (next_out == valid[got]) {
-        uint8_t* dst = out + (item.out_slot + got) * frame_bytes;
-        HWANG_RETURN_ON_ERROR(yuv ? planar->get_frame_yuv(dst, frame_bytes)
-                                  : dec->get_frame(dst, frame_bytes));
+        uint8_t* dst = out + (item->out_slot + got) * frame_bytes;
+        HWANG_RETURN_ON_ERROR(yuv ? planar->get_frame_yuv(dst, frame_bytes) : dec->get_frame(dst, frame_bytes));
         ++got;
         ++lane.frames_returned;
       } else {
@@ -99,38 +118,40 @@ Result ParallelRetriever::run_item(Lane& lane, VideoDecoderInterface* dec, const
       ++next_out;
     }
     return Result();
-  };
-
-  for (uint64_t s = item.start; s < item.end && got < valid.size(); ++s) {
-    if (offs[s] > file_size || sizes[s] > file_size - offs[s]) {
-      return Result(false, "retrieve: sample " + std::to_string(s) +
-                               " lies outside the file");
+  }
+  // Feeds one sample, or - when there is none left to feed - ends the interval (*done).
+  Result step(Lane& lane, bool* done) {
+    const std::vector<uint64_t>& valid = *item->valid;
+    *done = false;
+    if (s < item->end && got < valid.size()) {
+      const auto& offs = index->sample_offsets();
+      const auto& sizes = index->sample_sizes();
+      const auto& kfs = index->keyframe_indices();
+      if (offs[s] > file_size || sizes[s] > file_size - offs[s])
+        return Result(false, "retrieve: sample " + std::to_string(s) + " lies outside the file");
+      bool keyframe = false;
+      if (kf_cursor < kfs.size() && kfs[kf_cursor] == s) {
+        keyframe = true;
+        ++kf_cursor;
+      }
+      HWANG_RETURN_ON_ERROR(dec->feed(file + offs[s], sizes[s], keyframe));
+      ++lane.samples_fed;
+      ++s;
+      return consume(lane);
     }
-    bool keyframe = false;
-    if (kf_cursor < kfs.size() && kfs[kf_cursor] == s) {
-      keyframe = true;
-      ++kf_cursor;
-    }
-    HWANG_RETURN_ON_ERROR(dec->feed(file + offs[s], sizes[s], keyframe));
-    ++lane.samples_fed;
-    HWANG_RETURN_ON_ERROR(consume());
+    // End of interval: empty packet + flush pushes out whatever the reorder
+    // buffer still holds (decoder_automata.cpp:383-389 protocol).
+    *done = true;
+    HWANG_RETURN_ON_ERROR(dec->feed(nullptr, 0, false));
+    HWANG_RETURN_ON_ERROR(dec->flush());
+    HWANG_RETURN_ON_ERROR(consume(lane));
+    while (dec->decoded_frames_buffered() > 0) HWANG_RETURN_ON_ERROR(dec->discard_frame());
+    if (got != valid.size())
+      return Result(false, "retrieve: interval [" + std::to_string(item->start) + "," + std::to_string(item->end) + ") produced " +
+                               std::to_string(got) + " of " + std::to_string(valid.size()) + " wanted frames");
+    return Result();
   }
-  // End of interval: empty packet + flush pushes out whatever the reorder
-  // buffer still holds (decoder_automata.cpp:383-389 protocol).
-  HWANG_RETURN_ON_ERROR(dec->feed(nullptr, 0, false));
-  HWANG_RETURN_ON_ERROR(dec->flush());
-  HWANG_RETURN_ON_ERROR(consume());
-  while (dec->decoded_frames_buffered() > 0) {
-    HWANG_RETURN_ON_ERROR(dec->discard_frame());
-  }
-  if (got != valid.size()) {
-    return Result(false, "retrieve: interval [" + std::to_string(item.start) +
-                             "," + std::to_string(item.end) + ") produced " +
-                             std::to_string(got) + " of " +
-                             std::to_string(valid.size()) + " wanted frames");
-  }
-  return Result();
-}
+};
 
 Result ParallelRetriever::retrieve(const VideoIndex& index, const uint8_t* file,
                                    size_t file_size,
@@ -340,47 +361,119 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
     lane.frames_returned = 0;
     lane.items = 0;
     lane.cpu_ns = lane.instructions = lane.cycles = lane.branch_misses = 0;
-    threads.emplace_back([&, li]() {
-      Lane& lane = lanes_[li];
+  }
+  // A thread drives several lanes in turn, a sample of each at a time (HWANG_LANES_PER_THREAD overrides how many): the lanes -
+  // the decode streams in flight, hence the width of the GPU's launches - stay what they were with half the threads.
+  // A lane's thread waits for the GPU about as long as it parses; with a thread per lane that took three threads per
+  // CPU to keep the CPUs busy, and the parser pays for being descheduled (counted on the box, tools/hostprof/
+  // lib_counters_mt.py: 6.09 M cycles per P picture with a thread per CPU, 6.33 M with three).
+  // Default: a thread per usable CPU (48 lanes on 16 CPUs: three lanes a thread) - when the queue is long.  A thread
+  // that drives several items at once cannot give one away, so with few items per lane the end of the call is a few
+  // threads finishing their two or three long items while the other CPUs idle (measured: one 4K60 stream of 20 GOPs,
+  // 497 -> 315 frames/s; 4K every 10th frame, 60 items on 32 lanes, 638 -> 572): then a thread per lane, as in rounds
+  // 1-4, and the operating system does the balancing.  The same threshold tells the backends whether they may trade a
+  // picture's latency for wider launches (BatchingHints).
+  const bool long_queue = order.size() >= 8 * nl;
+  for (size_t li = 0; li < nl; ++li)
+    for (auto& b : lanes_[li].backend)
+      if (auto* h = dynamic_cast<BatchingHints*>(b.get())) h->set_long_queue(long_queue);
+  size_t nthreads = long_queue ? std::min<size_t>(nl, static_cast<size_t>(std::max(1, effective_cpus()))) : nl;
+  if (const char* e = getenv("HWANG_LANES_PER_THREAD")) {
+    const size_t share = static_cast<size_t>(std::max(1, std::min(atoi(e), 8)));
+    nthreads = (nl + share - 1) / share;
+  }
+  // (lanes t, t + T, t + 2 T, ... of a thread: with several devices they are all lanes of ONE device when T is a
+  // multiple of the device count, which the rounding below sees to)
+  if (devices_.size() > 1) nthreads = std::min(nl, (nthreads + devices_.size() - 1) / devices_.size() * devices_.size());
+  for (size_t ti = 0; ti < nthreads; ++ti) {
+    threads.emplace_back([&, ti]() {
       pthread_setname_np(pthread_self(), "hw-lane");
+      std::vector<size_t> mine;
+      for (size_t li = ti; li < nl; li += nthreads) mine.push_back(li);
       // several GPUs on one host (one process driving them, or one rank per GPU): a lane's thread - and the pinned
       // staging buffers it is the first to ask for - stay on the socket its GPU hangs off (HWANG_NUMA_AFFINITY=0/1)
       if (numa::enabled(devices_.size() > 1 || shard_world_ > 1))
-        numa::bind_current_thread_to_node(VideoDecoderFactory::device_numa_node(devices_[lane.device_slot]));
+        numa::bind_current_thread_to_node(VideoDecoderFactory::device_numa_node(devices_[lanes_[mine[0]].device_slot]));
       ThreadCounters counters(host_counters);
-      Result r;
-      for (auto& b : lane.backend)
-        if (auto* c = dynamic_cast<CountedBackend*>(b.get())) c->reset_counters();
-      // configure() once per call and clip, not once per interval (the reference re-opens its codec
-      // for every interval, decoder.py:65): a backend is re-configured only when the clip changes
-      for (auto& key : lane.config_key) key.clear();
-      int turn = 0;
-      bool first = true;
-      while (r.ok && !abort.load()) {
-        size_t k = first ? li : cursor.fetch_add(1);
-        first = false;
-        if (k >= order.size()) break;
-        const WorkItem& item = items[order[k]];
-        const Request& rq = requests[item.request];
-        if (lane.config_key[turn] != keys[item.request]) {
-          VideoDecoderInterface::FrameInfo info;
-          info.width = rq.index->frame_width();
-          info.height = rq.index->frame_height();
-          info.format = rq.index->format();
-          r = lane.backend[turn]->configure(info, rq.index->metadata_bytes());
-          if (!r.ok) break;
-          lane.config_key[turn] = keys[item.request];
-        }
-        r = run_item(lane, lane.backend[turn].get(), item, *rq.index, rq.file, rq.file_size, rq.out,
-                     frame_bytes[item.request], yuv);
-        ++lane.items;
-        turn = (turn + 1) % kBackendsPerLane;
+      struct Slot {
+        size_t li;
+        ItemRun run;
+        bool active = false, first = true, finished = false;
+        int turn = 0;
+        Result r;
+      };
+      std::vector<Slot> slots(mine.size());
+      for (size_t k = 0; k < mine.size(); ++k) {
+        slots[k].li = mine[k];
+        Lane& lane = lanes_[mine[k]];
+        for (auto& b : lane.backend)
+          if (auto* c = dynamic_cast<CountedBackend*>(b.get())) c->reset_counters();
+        // configure() once per call and clip, not once per interval (the reference re-opens its codec
+        // for every interval, decoder.py:65): a backend is re-configured only when the clip changes
+        for (auto& key : lane.config_key) key.clear();
       }
-      for (auto& b : lane.backend)
-        if (r.ok) r = b->wait_until_frames_copied();
-      if (!r.ok) abort.store(true);
-      lane.result = r;
-      counters.stop(&lane.cpu_ns, &lane.instructions, &lane.cycles, &lane.branch_misses);
+      bool failed = false;
+      size_t live = slots.size();
+      while (live > 0 && !failed && !abort.load()) {
+        for (Slot& sl : slots) {
+          if (sl.finished) continue;
+          Lane& lane = lanes_[sl.li];
+          if (!sl.active) {
+            // the lane's next item: lane li starts with item li (so every lane, hence every device, has work from the
+            // first moment whatever order the threads come up in), everything after that comes from the shared queue
+            const size_t k = sl.first ? sl.li : cursor.fetch_add(1);
+            sl.first = false;
+            if (k >= order.size()) {
+              sl.finished = true;
+              --live;
+              continue;
+            }
+            const WorkItem& item = items[order[k]];
+            const Request& rq = requests[item.request];
+            if (lane.config_key[sl.turn] != keys[item.request]) {
+              VideoDecoderInterface::FrameInfo info;
+              info.width = rq.index->frame_width();
+              info.height = rq.index->frame_height();
+              info.format = rq.index->format();
+              sl.r = lane.backend[sl.turn]->configure(info, rq.index->metadata_bytes());
+              if (sl.r.ok) lane.config_key[sl.turn] = keys[item.request];
+            }
+            if (sl.r.ok)
+              sl.r = sl.run.start(lane.backend[sl.turn].get(), item, *rq.index, rq.file, rq.file_size, rq.out, frame_bytes[item.request], yuv);
+            sl.active = sl.r.ok;
+          }
+          if (sl.active) {
+            bool done = false;
+            sl.r = sl.run.step(lane, &done);
+            if (done || !sl.r.ok) {
+              sl.active = false;
+              ++lane.items;
+              // (each lane alternates between its two backends from item to item: the next item's keyframe is on its
+              // way while the previous one's last pictures finish on the other backend's executor lane)
+              sl.turn = (sl.turn + 1) % kBackendsPerLane;
+            }
+          }
+          if (!sl.r.ok) {
+            failed = true;
+            break;
+          }
+        }
+      }
+      int64_t cpu_ns = 0, instructions = 0, cycles = 0, branch_misses = 0;
+      for (Slot& sl : slots) {
+        Lane& lane = lanes_[sl.li];
+        Result r = sl.r;
+        for (auto& b : lane.backend)
+          if (r.ok && !failed) r = b->wait_until_frames_copied();
+        if (!r.ok) abort.store(true);
+        lane.result = r;
+      }
+      counters.stop(&cpu_ns, &instructions, &cycles, &branch_misses);
+      Lane& first_lane = lanes_[mine[0]];  // (the thread's counters are booked on its first lane)
+      first_lane.cpu_ns = cpu_ns;
+      first_lane.instructions = instructions;
+      first_lane.cycles = cycles;
+      first_lane.branch_misses = branch_misses;
     });
   }
   for (auto& t : threads) t.join();

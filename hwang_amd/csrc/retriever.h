@@ -128,9 +128,7 @@ class ParallelRetriever {
   };
 
   ParallelRetriever() {}
-  Result run_item(Lane& lane, VideoDecoderInterface* dec, const WorkItem& item, const VideoIndex& index,
-                  const uint8_t* file, size_t file_size, uint8_t* out,
-                  size_t frame_bytes, bool yuv);
+  struct ItemRun;  // a work item on its way through a backend, a sample at a time (retriever.cpp)
 
   std::vector<DeviceHandle> devices_;
   std::vector<DeviceStats> device_stats_;

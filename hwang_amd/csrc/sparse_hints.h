@@ -31,6 +31,16 @@ class SparseDecodeHints {
 
 namespace hwang {
 
+// Optional: the caller says whether this decoder is one of many that it will keep fed from a long queue of work
+// items (ParallelRetriever with many items per lane).  A backend may then trade a picture's latency for wider GPU
+// launches (GpuExecutor: engines that linger); without it - the reference's callers never say it - every picture goes
+// the shortest way.
+class BatchingHints {
+ public:
+  virtual ~BatchingHints() {}
+  virtual void set_long_queue(bool long_queue) = 0;
+};
+
 // Optional: planar output of the normative decoder result (cropped I420:
 // Y w*h, U then V ceil(w/2)*ceil(h/2)), consumed like get_frame().  The
 // bit-exact parity tests compare this against the oracle; RGB is derived

@@ -56,6 +56,25 @@ def test_automatic_lane_count(hw):
             assert struct.unpack("<I", f.tobytes()[:4])[0] == r
 
 
+def test_lanes_shared_by_threads(hw, monkeypatch):
+    """A retriever thread drives several lanes in turn, a sample of each at a time (HWANG_LANES_PER_THREAD, default 2):
+    whatever the split - a thread per lane as in rounds 1-4, two, three, more lanes than there are - every row comes
+    back, in request order, with the sample it names."""
+    import struct
+    rows = sorted(set(list(range(0, 600, 7)) + [1, 2, 3, 299, 300, 301, 599]))
+    for share in ("1", "2", "3", "8"):
+        monkeypatch.setenv("HWANG_LANES_PER_THREAD", share)
+        for lanes in (1, 2, 5, 12):
+            dec = _stamp_decoder(hw, 600, 20, 4, 2, lanes)
+            frames = dec.retrieve(rows)
+            assert len(frames) == len(rows)
+            for r, f in zip(rows, frames):
+                assert struct.unpack("<I", f.tobytes()[:4])[0] == r, (share, lanes, r)
+            st = dec.stats()
+            assert st["frames_returned"] == len(rows)
+            del dec
+
+
 def _stamp_clip(hw, n, gop, w, h, tag=0):
     import struct
 
