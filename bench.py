@@ -652,6 +652,10 @@ def main():
                                   "%d ranks sharing %d GPU(s) (development run: gloo, not a scaling number)"
                                   % (world, torch.cuda.device_count())),
                        "lanes_per_gpu": lanes // len(devices), "host_cpus": effective_cpus(),
+                       # (retriever.cpp: a thread per usable CPU drives the lanes in turn when there are eight work items
+                       # per lane or more, else a thread per lane; HWANG_LANES_PER_THREAD overrides)
+                       "lane_threads": (min(lanes, effective_cpus()) if stats["intervals"] >= 8 * lanes else lanes)
+                       if not os.environ.get("HWANG_LANES_PER_THREAD") else -(-lanes // max(1, int(os.environ["HWANG_LANES_PER_THREAD"]))),
                        "sharding": "GOP work items, longest-first split, no collective on the data path"},
             "value_host_output": round(value, 2) if not args.hbm_output else value_other,
             "value_hbm_resident": value_other if not args.hbm_output else round(value, 2),

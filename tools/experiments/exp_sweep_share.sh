@@ -1,10 +1,9 @@
-# Development aid: lanes per thread x linger settings, alternating on one box (bench line of each).
+# Development aid: linger settings, alternating on one box (bench line of each).
 run() {  # tag "ENV=.. ENV=.." lanes
   env $2 timeout 900 python3 bench.py --lanes $3 --steps 6 --warmup 2 --no-cpu-baseline --no-hbm-output --no-reference-api 2>/dev/null | tail -1 > gpurun_out/r05_sweep_$1.json
   python3 - gpurun_out/r05_sweep_$1.json "$2 lanes=$3" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-h = d.get("host_lane_threads") or {}
 r = d.get("roofline") or {}
 k = d.get("kernels") or {}
 def g(n, f): return (k.get(n) or {}).get(f)
@@ -14,10 +13,8 @@ print(sys.argv[2].replace("HWANG_", ""), "| value", d.get("value"), "cpu ms/pic"
 PY
 }
 for i in 1 2; do
-  run a$i "HWANG_LANES_PER_THREAD=1" 48
-  run c$i "HWANG_LANES_PER_THREAD=3 HWANG_LINGER_US=4000 HWANG_HEAVY_LINGER_US=5000 HWANG_PRE_LINGER_US=2000" 48
-  run d$i "HWANG_LANES_PER_THREAD=3 HWANG_LINGER_US=5000 HWANG_HEAVY_LINGER_US=6000 HWANG_PRE_LINGER_US=2500" 48
-  run e$i "HWANG_LANES_PER_THREAD=2 HWANG_LINGER_US=4000 HWANG_HEAVY_LINGER_US=5000 HWANG_PRE_LINGER_US=2000" 48
-  run f$i "HWANG_LANES_PER_THREAD=4 HWANG_LINGER_US=5000 HWANG_HEAVY_LINGER_US=6000 HWANG_PRE_LINGER_US=2500" 64
-  run g$i "HWANG_LANES_PER_THREAD=3 HWANG_LINGER_US=6000 HWANG_LINGER_FILL=90 HWANG_HEAVY_LINGER_US=6000 HWANG_PRE_LINGER_US=2500" 48
+  run a$i "HWANG_LINGER_US=6000" 48
+  run b$i "HWANG_LINGER_US=9000" 48
+  run c$i "HWANG_LINGER_US=12000 HWANG_HEAVY_LINGER_US=9000" 48
+  run d$i "HWANG_LINGER_US=9000 HWANG_HEAVY_LINGER_US=10000 HWANG_PRE_LINGER_US=3500" 48
 done
