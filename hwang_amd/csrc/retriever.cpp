@@ -373,7 +373,9 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
   // 497 -> 315 frames/s; 4K every 10th frame, 60 items on 32 lanes, 638 -> 572): then a thread per lane, as in rounds
   // 1-4, and the operating system does the balancing.  The same threshold tells the backends whether they may trade a
   // picture's latency for wider launches (BatchingHints).
-  const bool long_queue = order.size() >= 8 * nl;
+  size_t long_from = 8;  // work items per lane (HWANG_LONG_QUEUE_FROM: the tests set 1 to run small clips this way)
+  if (const char* e = getenv("HWANG_LONG_QUEUE_FROM")) long_from = static_cast<size_t>(std::max(1, atoi(e)));
+  const bool long_queue = order.size() >= long_from * nl;
   for (size_t li = 0; li < nl; ++li)
     for (auto& b : lanes_[li].backend)
       if (auto* h = dynamic_cast<BatchingHints*>(b.get())) h->set_long_queue(long_queue);

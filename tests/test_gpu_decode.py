@@ -275,6 +275,27 @@ def test_wide_batches_are_deterministic(hw, gpu, tmp_path):
             bad = np.nonzero((got[0] != ref[0]) | (got[1] != ref[1]))[0]
             assert bad.size == 0, "lanes %d round %d: frames %s differ from the single-lane decode" % (lanes, rnd, bad[:8].tolist())
         del dec
+    # ... and the way long queues are served (round 5: a thread per CPU driving several lanes in turn, engines that
+    # linger for company, keyframes predicted on the heavy engine and deblocked in the light batches): the retriever
+    # takes it from eight work items per lane up - here from one (HWANG_LONG_QUEUE_FROM), and with two or five lanes
+    # per thread
+    for lanes, share in ((48, None), (24, "2"), (40, "5")):
+        os.environ["HWANG_LONG_QUEUE_FROM"] = "1"
+        if share:
+            os.environ["HWANG_LANES_PER_THREAD"] = share
+        try:
+            dec = hw.Decoder(path, video_index=idx, num_lanes=lanes)
+            for rnd in range(3):
+                out.zero_()
+                dec.retrieve_into(rows, out.data_ptr(), out.numel())
+                got = sums()
+                bad = np.nonzero((got[0] != ref[0]) | (got[1] != ref[1]))[0]
+                assert bad.size == 0, "long queue, lanes %d share %s round %d: frames %s differ from the single-lane decode" % (
+                    lanes, share, rnd, bad[:8].tolist())
+            del dec
+        finally:
+            os.environ.pop("HWANG_LONG_QUEUE_FROM", None)
+            os.environ.pop("HWANG_LANES_PER_THREAD", None)
 
 
 def test_4k_wide_pictures(hw, oracle, gpu, tmp_path):
