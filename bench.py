@@ -357,6 +357,8 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+    # (round 5: the retriever drives these lanes with ONE thread per usable CPU when the queue is long - see
+    # config.lane_threads - the lane count below is how many decode streams are in flight, i.e. the launch width)
     # 3 lanes per usable CPU (a lane waits for the GPU about as long as it parses;
     # the CPUs are the bottleneck: measured 32 / 40 / 48 / 64 lanes on 16 CPUs ->
     # 660 / 676 / 698 / 651 frames/s); with several ranks on one host the CPUs are shared
