@@ -367,6 +367,10 @@ def main():
     per_cpu = 3 if WIDTH * HEIGHT <= 2 * 1920 * 1088 else 2
     lanes = args.lanes or max(2, min(128, per_cpu * effective_cpus() // world))
     devices = (forced_ids or list(range(in_process_devices))) if in_process_devices > 1 else [device_index]
+    if world > 1 and "HWANG_RETRIEVER_THREADS" not in os.environ:
+        # a rank per GPU on one host: the ranks share the host's CPUs, each drives its lanes with its share of them
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        os.environ["HWANG_RETRIEVER_THREADS"] = str(max(1, effective_cpus() // max(1, local_world)))
     br = BatchRetriever(device_ids=devices, num_lanes=lanes, shard=(rank, world) if world > 1 else None)
     # request k's frames land in HOST memory (D2H is part of the job; N ranks: each rank writes the rows
     # of its share into its own copy of the batch's output - pageable memory, so only the pages of its share ever
@@ -656,7 +660,8 @@ def main():
                        "lanes_per_gpu": lanes // len(devices), "host_cpus": effective_cpus(),
                        # (retriever.cpp: a thread per usable CPU drives the lanes in turn when there are eight work items
                        # per lane or more, else a thread per lane; HWANG_LANES_PER_THREAD overrides)
-                       "lane_threads": (min(lanes, effective_cpus()) if stats["intervals"] >= 8 * lanes else lanes)
+                       "lane_threads": (min(lanes, int(os.environ.get("HWANG_RETRIEVER_THREADS", effective_cpus())))
+                                        if stats["intervals"] >= 8 * lanes else lanes)
                        if not os.environ.get("HWANG_LANES_PER_THREAD") else -(-lanes // max(1, int(os.environ["HWANG_LANES_PER_THREAD"]))),
                        "sharding": "GOP work items, longest-first split, no collective on the data path"},
             "value_host_output": round(value, 2) if not args.hbm_output else value_other,

@@ -380,6 +380,10 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
     for (auto& b : lanes_[li].backend)
       if (auto* h = dynamic_cast<BatchingHints*>(b.get())) h->set_long_queue(long_queue);
   size_t nthreads = long_queue ? std::min<size_t>(nl, static_cast<size_t>(std::max(1, effective_cpus()))) : nl;
+  // (several processes sharing one host's CPUs - a rank per GPU - say how many threads are theirs: bench.py divides the
+  // usable CPUs by the local world size)
+  if (const char* e = getenv("HWANG_RETRIEVER_THREADS"))
+    if (long_queue) nthreads = std::min<size_t>(nl, static_cast<size_t>(std::max(1, atoi(e))));
   if (const char* e = getenv("HWANG_LANES_PER_THREAD")) {
     const size_t share = static_cast<size_t>(std::max(1, std::min(atoi(e), 8)));
     nthreads = (nl + share - 1) / share;
