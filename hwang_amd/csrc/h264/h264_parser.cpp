@@ -114,20 +114,43 @@ struct Bits {
 // bits.  Decisions are branch-free (the LPS/MPS outcome is data, not control
 // flow - about half of all bins sit in contexts near p = 0.5 and mispredict).
 struct CabacTables {
-  uint8_t next[128][2];   // [state = pStateIdx << 1 | valMPS][0 MPS taken, 1 LPS taken]
-  uint32_t lps4[128];     // [state]: rangeTabLPS for qCodIRangeIdx 0..3, one byte each - the load depends on the
-                          // context only, so it is off the range -> range chain that paces consecutive bins
+  uint32_t lps4[128];     // [state = pStateIdx << 1 | valMPS]: rangeTabLPS for qCodIRangeIdx 0..3, one byte each - the load
+                          // depends on the context only, so it is off the range -> range chain that paces consecutive bins
+  uint8_t mlps[256];      // the next state: [128 + state] after the MPS, [128 + ~state] = [127 - state] after the LPS
   CabacTables() {
     for (int st = 0; st < 128; ++st) {
       const int ps = st >> 1, mps = st & 1;
-      next[st][0] = static_cast<uint8_t>(((ps < 62 ? ps + 1 : ps) << 1) | mps);
-      next[st][1] = static_cast<uint8_t>((cabac_trans_lps[ps] << 1) | (ps == 0 ? !mps : mps));
+      mlps[128 + st] = static_cast<uint8_t>(((ps < 62 ? ps + 1 : ps) << 1) | mps);
+      mlps[127 - st] = static_cast<uint8_t>((cabac_trans_lps[ps] << 1) | (ps == 0 ? !mps : mps));
       lps4[st] = 0;
       for (int q = 0; q < 4; ++q) lps4[st] |= static_cast<uint32_t>(cabac_range_lps[ps][q]) << (8 * q);
     }
   }
 };
 static const CabacTables g_cabac_tables;
+
+// One decision of the arithmetic decoder (9.3.3.2.1) without the refill: the engine's registers by reference, so that
+// every caller keeps them where it has them (members, or locals for a run of bins).  The outcome is a sign: state ^
+// ~sign indexes ONE table for the next state on either side and its low bit is the decoded bin - 8-10 % fewer
+// instructions per picture than a mask, a two-column table and an exclusive-or with the MPS, and the rangeTabLPS load
+// stays off the range -> range chain (counted on the GPU box, profiles/r05_host_perf_counters.txt: -3.5 % cycles of an
+// intra picture, -2.5 % of a P picture; the same with the load ON the chain - one table indexed by range and state -
+// has as few instructions and gains less).
+static inline __attribute__((always_inline)) int cabac_step(uint16_t* state, int ctx, uint64_t& value, uint32_t& range, int& extra) {
+  const int32_t s = state[ctx];
+  const uint32_t lps = (g_cabac_tables.lps4[s] >> ((range >> 3) & 24)) & 0xff;
+  uint32_t r = range - lps;
+  const uint64_t scaled = static_cast<uint64_t>(r) << extra;
+  const int64_t d = static_cast<int64_t>(value - scaled);  // >= 0: the LPS
+  value = d >= 0 ? static_cast<uint64_t>(d) : value;
+  r = d >= 0 ? lps : r;
+  const int32_t sx = s ^ static_cast<int32_t>(~(d >> 63));
+  state[ctx] = g_cabac_tables.mlps[128 + sx];
+  const int shift = __builtin_clz(r) - 23;  // 0 when r >= 256
+  range = r << shift;
+  extra -= shift;
+  return sx & 1;
+}
 
 // cold path of the arithmetic decoder: called with extra < 8 (or -9 at the
 // start of a slice), returns with extra >= 24
@@ -163,7 +186,7 @@ __attribute__((noinline)) static uint64_t cabac_refill_slow(uint64_t value, int*
 #include <linux/perf_event.h>
 #include <sys/syscall.h>
 #include <unistd.h>
-enum { R_OTHER, R_MBHEAD, R_PSKIP, R_BEGIN, R_MBTYPE, R_INTER_REFS, R_INTER_MVD, R_INTRAMODES, R_CBP, R_T8X8, R_QPD, R_RES_FILL, R_RESIDUAL, R_RES_BLOCK, R_COMMIT, R_COUNT };
+enum { R_OTHER, R_MBHEAD, R_PSKIP, R_BEGIN, R_MBTYPE, R_INTER_REFS, R_INTER_MVD, R_INTRAMODES, R_CBP, R_T8X8, R_QPD, R_RES_FILL, R_RESIDUAL, R_RES_BLOCK, R_COMMIT, R_RES_HEAD, R_RES_SIG, R_RES_LEVEL, R_RES_TAIL, R_COUNT };
 struct RegionCounters {
   int fd = -1;
   uint64_t instr[R_COUNT] = {0}, enters[R_COUNT] = {0}, last = 0;
@@ -194,7 +217,8 @@ struct RegionCounters {
     static const char* const names[R_COUNT] = {"outside the macroblock layer", "position + skip flag + end_of_slice", "P_Skip", "begin_mb", "mb_type",
                                                "inter: shapes + references", "inter: differences", "intra prediction modes", "coded_block_pattern",
                                                "transform_size_8x8_flag", "mb_qp_delta", "residual: fill_nz_cache", "residual: around the blocks",
-                                               "residual: cabac_block", "commit_mb"};
+                                               "residual: cabac_block", "commit_mb", "residual (fine): block head + coded_block_flag", "residual (fine): significance map",
+                                               "residual (fine): levels", "residual (fine): block tail"};
     enter(R_OTHER);
     uint64_t total = 0;
     for (uint64_t v : instr) total += v;
@@ -207,6 +231,11 @@ static RegionCounters g_regions;
 #define REGION(r) g_regions.enter(r)
 #else
 #define REGION(r) do { } while (0)
+#endif
+#if defined(HWANG_REGION_COUNTERS) && defined(HWANG_REGION_FINE)  // (inside the residual's block loop: ~28 instructions a switch, five a block)
+#define REGIONF(r) g_regions.enter(r)
+#else
+#define REGIONF(r) do { } while (0)
 #endif
 
 #ifdef HWANG_CABAC_TRACE
@@ -302,21 +331,9 @@ struct Cabac {
   }
   __attribute__((always_inline)) inline int bin(int ctx) {
     CABAC_TRACE(ctx);
-    const uint32_t st = state[ctx];
-    const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
-    uint32_t r = range - lps;
-    const uint64_t scaled = static_cast<uint64_t>(r) << extra;
-    // all ones when the LPS is decoded (value >= scaled)
-    const uint64_t lmask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
-    value -= scaled & lmask;
-    r += (lps - r) & static_cast<uint32_t>(lmask);
-    const uint32_t l = static_cast<uint32_t>(lmask) & 1;
-    state[ctx] = g_cabac_tables.next[st][l];
-    const int shift = __builtin_clz(r) - 23;  // 0 when r >= 256
-    range = r << shift;
-    extra -= shift;
+    const int b = cabac_step(state, ctx, value, range, extra);
     if (__builtin_expect(extra < 8, 0)) refill();
-    return static_cast<int>((st & 1) ^ l);
+    return b;
   }
   __attribute__((always_inline)) inline int bypass() {
     CABAC_TRACE(0xffff);
@@ -377,20 +394,9 @@ struct CabacLocal {
   }
   __attribute__((always_inline)) int bin(int ctx) {
     CABAC_TRACE(ctx);
-    const uint32_t st = state[ctx];
-    const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
-    uint32_t r = range - lps;
-    const uint64_t scaled = static_cast<uint64_t>(r) << extra;
-    const uint64_t lmask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
-    value -= scaled & lmask;
-    r += (lps - r) & static_cast<uint32_t>(lmask);
-    const uint32_t l = static_cast<uint32_t>(lmask) & 1;
-    state[ctx] = g_cabac_tables.next[st][l];
-    const int shift = __builtin_clz(r) - 23;
-    range = r << shift;
-    extra -= shift;
+    const int b = cabac_step(state, ctx, value, range, extra);
     if (__builtin_expect(extra < 8, 0)) refill();
-    return static_cast<int>((st & 1) ^ l);
+    return b;
   }
   __attribute__((always_inline)) int bypass() {
     CABAC_TRACE(0xffff);
@@ -1269,20 +1275,9 @@ struct SliceData {
     };
     auto bin = [&](int ctx) __attribute__((always_inline)) -> int {
       CABAC_TRACE(ctx);
-      const uint32_t st = state[ctx];
-      const uint32_t lps = (g_cabac_tables.lps4[st] >> ((range >> 3) & 24)) & 0xff;
-      uint32_t r = range - lps;
-      const uint64_t scaled = static_cast<uint64_t>(r) << extra;
-      const uint64_t lmask = ~static_cast<uint64_t>(static_cast<int64_t>(value - scaled) >> 63);
-      value -= scaled & lmask;
-      r += (lps - r) & static_cast<uint32_t>(lmask);
-      const uint32_t l = static_cast<uint32_t>(lmask) & 1;
-      state[ctx] = g_cabac_tables.next[st][l];
-      const int shift = __builtin_clz(r) - 23;
-      range = r << shift;
-      extra -= shift;
+      const int b = cabac_step(state, ctx, value, range, extra);
       if (__builtin_expect(extra < 8, 0)) refill();
-      return static_cast<int>((st & 1) ^ l);
+      return b;
     };
     auto bypass = [&]() __attribute__((always_inline)) -> int {
       CABAC_TRACE(0xffff);
@@ -1302,6 +1297,7 @@ struct SliceData {
     };
 
     for (int li = 0; li < nlist; ++li) {
+      REGIONF(R_RES_HEAD);
       const int kind = list[li] >> 5, which = list[li] & 31;
       int cat, inc, max_coeff, start = 0, gbase;
       const uint8_t* scan = zigzag4x4;
@@ -1324,6 +1320,7 @@ struct SliceData {
       }
       int n = 0;
       if (inc < 0 || bin(85 + cbf_cat_offset[cat] + inc)) {
+        REGIONF(R_RES_SIG);
         const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
         const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
         const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
@@ -1352,6 +1349,7 @@ struct SliceData {
             }
         }
         if (i == lastpos) idx[n++] = static_cast<uint8_t>(lastpos);
+        REGIONF(R_RES_LEVEL);
         int gt1 = 0, eq1 = 0;
         const int gt_cap = 4 - (cat == 3 ? 1 : 0);
         uint32_t* const ent = mb.ent + mb.nent;  // n <= 64 entries; a macroblock never has more than 26 * 16
@@ -1383,6 +1381,7 @@ struct SliceData {
         }
         mb.nent += n;
       }
+      REGIONF(R_RES_TAIL);
       switch (kind) {
         case RB_I16DC:
           if (n) {
@@ -1410,6 +1409,7 @@ struct SliceData {
           break;
       }
     }
+    REGIONF(R_RESIDUAL);
     leave();
     return true;
   }

@@ -25,19 +25,25 @@ avcc = bytes(idx.metadata_bytes())
 gop = 60
 # every GOP up to its last P picture, B pictures skipped (what C1 mostly decodes) - or, ALL=1, every picture
 wanted = np.arange(gop - 3, idx.frames(), gop, dtype=np.uint64) if not os.environ.get("ALL") else np.arange(idx.frames(), dtype=np.uint64)
+if os.environ.get("WANTED") == "keys":  # the keyframes alone (what follows each in its GOP serves nobody and is not parsed)
+    wanted = np.arange(0, idx.frames(), gop, dtype=np.uint64)
+if os.environ.get("WANTED") == "b":  # one B picture per GOP, the last: every P picture before it and that one B picture
+    wanted = np.arange(gop - 2, idx.frames(), gop, dtype=np.uint64)
+keys = np.arange(0, idx.frames(), gop, dtype=np.uint64)  # (the clip's closed GOPs; only used with WANTED set)
 for libpath in sys.argv[2:]:
     lib = C.CDLL(os.path.abspath(libpath))
-    lib.hwang_h264_probe.restype = C.c_int
-    lib.hwang_h264_probe.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                     C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
+    lib.hwang_h264_probe_workers.restype = C.c_int
+    lib.hwang_h264_probe_workers.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                             C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_int64), C.c_char_p, C.c_size_t]
     print("==", libpath, flush=True)
     best = 1e9
-    for rep in range(3):
-        out = (C.c_int64 * 8)()
+    for rep in range(int(os.environ.get("REPS", "3"))):
+        out = (C.c_int64 * 9)()
         err = C.create_string_buffer(256)
         t = time.time()
-        rc = lib.hwang_h264_probe(avcc, len(avcc), data.ctypes.data, offs.ctypes.data, sizes.ctypes.data, len(offs), wanted.ctypes.data, len(wanted),
-                                  out, err, 256)
+        nk = len(keys) if os.environ.get("WANTED") else 0
+        rc = lib.hwang_h264_probe_workers(avcc, len(avcc), data.ctypes.data, offs.ctypes.data, sizes.ctypes.data, len(offs), wanted.ctypes.data,
+                                          len(wanted), keys.ctypes.data if nk else None, nk, 0, out, err, 256)
         dt = time.time() - t
         if rc:
             raise SystemExit(err.value)
