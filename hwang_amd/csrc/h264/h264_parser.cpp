@@ -186,7 +186,7 @@ __attribute__((noinline)) static uint64_t cabac_refill_slow(uint64_t value, int*
 #include <linux/perf_event.h>
 #include <sys/syscall.h>
 #include <unistd.h>
-enum { R_OTHER, R_MBHEAD, R_PSKIP, R_BEGIN, R_MBTYPE, R_INTER_REFS, R_INTER_MVD, R_INTRAMODES, R_CBP, R_T8X8, R_QPD, R_RES_FILL, R_RESIDUAL, R_RES_BLOCK, R_COMMIT, R_RES_HEAD, R_RES_SIG, R_RES_LEVEL, R_RES_TAIL, R_COUNT };
+enum { R_OTHER, R_MBHEAD, R_PSKIP, R_BEGIN, R_MBTYPE, R_INTER_REFS, R_INTER_MVD, R_INTRAMODES, R_CBP, R_T8X8, R_QPD, R_RES_FILL, R_RESIDUAL, R_RES_BLOCK, R_COMMIT, R_COUNT };
 struct RegionCounters {
   int fd = -1;
   uint64_t instr[R_COUNT] = {0}, enters[R_COUNT] = {0}, last = 0;
@@ -217,8 +217,7 @@ struct RegionCounters {
     static const char* const names[R_COUNT] = {"outside the macroblock layer", "position + skip flag + end_of_slice", "P_Skip", "begin_mb", "mb_type",
                                                "inter: shapes + references", "inter: differences", "intra prediction modes", "coded_block_pattern",
                                                "transform_size_8x8_flag", "mb_qp_delta", "residual: fill_nz_cache", "residual: around the blocks",
-                                               "residual: cabac_block", "commit_mb", "residual (fine): block head + coded_block_flag", "residual (fine): significance map",
-                                               "residual (fine): levels", "residual (fine): block tail"};
+                                               "residual: cabac_block", "commit_mb"};
     enter(R_OTHER);
     uint64_t total = 0;
     for (uint64_t v : instr) total += v;
@@ -231,11 +230,6 @@ static RegionCounters g_regions;
 #define REGION(r) g_regions.enter(r)
 #else
 #define REGION(r) do { } while (0)
-#endif
-#if defined(HWANG_REGION_COUNTERS) && defined(HWANG_REGION_FINE)  // (inside the residual's block loop: ~28 instructions a switch, five a block)
-#define REGIONF(r) g_regions.enter(r)
-#else
-#define REGIONF(r) do { } while (0)
 #endif
 
 #ifdef HWANG_CABAC_TRACE
@@ -545,9 +539,6 @@ const uint8_t b_sub_info[13][2] = {{0, 3}, {0, 0}, {0, 1}, {0, 2}, {1, 0}, {2, 0
                                    {2, 1}, {1, 2}, {2, 2}, {3, 0}, {3, 1}, {3, 2}};
 inline bool uses_list(int pred, int list) { return pred == 2 || pred == list; }
 
-const int cbf_cat_offset[6] = {0, 4, 8, 12, 16, 0};
-const int sig_cat_offset[6] = {0, 15, 29, 44, 47, 0};
-const int abs_cat_offset[6] = {0, 10, 20, 30, 39, 0};
 const uint8_t identity_scan16[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
 const uint8_t dc_scan4[4] = {0, 1, 2, 3};
 
@@ -658,7 +649,7 @@ struct SliceData {
     int sub_type[4];
     int8_t i4_mode[16];
     uint8_t nnz[24];
-    uint8_t nz_left[8], nz_top[8];  // fill_nz_cache(): 4 luma + 2 Cb + 2 Cr flags per edge
+    uint8_t nzc[48];                // fill_nz_cache(): coded flags of this macroblock's blocks and of those along its edges
     uint8_t dc_left, dc_top;        // ... and the DC blocks' flags of the two neighbour macroblocks
     int cbf_dc;
     uint32_t coded_mask;
@@ -1218,39 +1209,22 @@ struct SliceData {
 
   // The residual of one macroblock (7.3.5.3 with 9.3.2.x / 7.3.5.3.3), CABAC.  Most of a picture's bins are decoded
   // here, so the arithmetic decoder's registers (offset, range, bit budget, read pointer) live in locals for ALL the
-  // blocks of the macroblock: the blocks - up to 27 of them, many with a single coded_block_flag bin and nothing
-  // behind it - are one loop over a list around ONE inlined copy of the block reader, not a call per block that loads
-  // the engine from the Cabac object and stores it back (round 5, counted on the GPU box: ~95 instructions between two
-  // blocks, 600 per macroblock of a P picture and 1 300 of an I picture, beside the bins' own).  The context words are
-  // 16-bit on purpose (see Cabac::state).
+  // blocks of the macroblock - up to 27 of them, many with a single coded_block_flag bin and nothing behind it.  The
+  // block reader is instantiated per ctxBlockCat (its bounds, scan and context bases are constants then) and the callers
+  // are plain loops per kind of block: a block's coded_block_flag context is two loads from the flag cache
+  // (fill_nz_cache) and what it leaves behind two stores and an OR into a register.  (Round 5, counted on the GPU
+  // box: a list of blocks around ONE copy of the reader, with a switch before and after every block, spent ~170
+  // instructions per block outside the reader - a quarter of an intra picture's instructions.)  The context words
+  // are 16-bit on purpose (see Cabac::state).
   // Non-zero levels are appended to mb.ent with flat index `gbase` + raster position (gbase = group * 16).
-  enum : uint8_t { RB_I16DC = 0, RB_LUMA4 = 1, RB_LUMA8 = 2, RB_CHROMA_DC = 3, RB_CHROMA_AC = 4 };
+  template <int N> struct Cat { static constexpr int value = N; };
+  static constexpr int nzc_luma(int which) { return 9 + (which >> 2) * 8 + (which & 3); }
+  static constexpr int nzc_chroma(int p, int s) { return (1 + 3 * p + (s >> 1)) * 8 + 6 + (s & 1); }
   bool cabac_residual() {
     REGION(R_RES_FILL);
     fill_nz_cache();
     REGION(R_RESIDUAL);
     const bool i16 = mb.kind == MB_I16x16;
-    // the macroblock's blocks in decoding order: kind << 5 | index (luma: raster 4x4 index / 8x8 index; chroma: p << 2 | s)
-    uint8_t list[32];
-    int nlist = 0;
-    if (i16) list[nlist++] = RB_I16DC << 5;
-    for (int b8 = 0; b8 < 4; ++b8) {
-      if (!((mb.cbp >> b8) & 1)) continue;
-      if (mb.t8x8) {
-        list[nlist++] = static_cast<uint8_t>(RB_LUMA8 << 5 | b8);
-      } else {
-        for (int s = 0; s < 4; ++s)
-          list[nlist++] = static_cast<uint8_t>(RB_LUMA4 << 5 | (((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1)));
-      }
-    }
-    const int cc = mb.cbp >> 4;
-    if (cc) {
-      list[nlist++] = RB_CHROMA_DC << 5 | 0;
-      list[nlist++] = RB_CHROMA_DC << 5 | 4;
-    }
-    if (cc == 2)
-      for (int k = 0; k < 8; ++k) list[nlist++] = static_cast<uint8_t>(RB_CHROMA_AC << 5 | k);
-    if (!nlist) return true;
 
     Cabac& c = cabac;
     uint64_t value = c.value;
@@ -1288,182 +1262,167 @@ struct SliceData {
       value -= scaled & mask;
       return static_cast<int>(mask & 1);
     };
+    int nent = mb.nent;
+    uint32_t coded = mb.coded_mask;
     auto leave = [&]() {
       c.value = value;
       c.range = range;
       c.extra = extra;
       c.p = p;
       if (overrun) c.overrun = true;
+      mb.nent = nent;
+      mb.coded_mask = coded;
     };
 
-    for (int li = 0; li < nlist; ++li) {
-      REGIONF(R_RES_HEAD);
-      const int kind = list[li] >> 5, which = list[li] & 31;
-      int cat, inc, max_coeff, start = 0, gbase;
-      const uint8_t* scan = zigzag4x4;
-      switch (kind) {
-        case RB_I16DC:
-          cat = 0; inc = cbf_inc(0, 0, 0, 0); max_coeff = 16; gbase = 16 * amd::kMaskLumaDc;
-          break;
-        case RB_LUMA4:
-          cat = i16 ? 1 : 2; inc = cbf_inc(1, 0, which & 3, which >> 2); max_coeff = i16 ? 15 : 16; start = i16 ? 1 : 0; gbase = 16 * which;
-          break;
-        case RB_LUMA8:
-          cat = 5; inc = -1; max_coeff = 64; scan = zigzag8x8; gbase = 64 * which;
-          break;
-        case RB_CHROMA_DC:
-          cat = 3; inc = cbf_inc(2, which >> 2, 0, 0); max_coeff = 4; scan = dc_scan4; gbase = 16 * amd::kMaskChromaDc + which;
-          break;
-        default:
-          cat = 4; inc = cbf_inc(3, which >> 2, which & 1, (which >> 1) & 1); max_coeff = 15; start = 1; gbase = 16 * (amd::kMaskChromaAc + which);
-          break;
-      }
-      int n = 0;
-      if (inc < 0 || bin(85 + cbf_cat_offset[cat] + inc)) {
-        REGIONF(R_RES_SIG);
-        const int sig_base = cat == 5 ? 402 : 105 + sig_cat_offset[cat];
-        const int last_base = cat == 5 ? 417 : 166 + sig_cat_offset[cat];
-        const int abs_base = cat == 5 ? 426 : 227 + abs_cat_offset[cat];
-        uint8_t idx[64];
-        int i;
-        const int lastpos = max_coeff - 1;
-        if (cat == 5) {
-          for (i = 0; i < lastpos; ++i)
-            if (bin(sig_base + sig_coeff_offset_8x8[i])) {
-              idx[n++] = static_cast<uint8_t>(i);
-              if (bin(last_base + last_coeff_offset_8x8[i])) break;
-            }
-        } else if (cat == 3) {
-          for (i = 0; i < lastpos; ++i) {
-            const int ci = imin(i, 2);
-            if (bin(sig_base + ci)) {
-              idx[n++] = static_cast<uint8_t>(i);
-              if (bin(last_base + ci)) break;
-            }
+    // One block of category `cat` whose coded_block_flag context increment is `inc`: the number of its non-zero
+    // levels, -1 for a level that does not end.
+    auto block = [&](auto cat_c, int inc, int gbase) __attribute__((always_inline)) -> int {
+      constexpr int cat = decltype(cat_c)::value;
+      constexpr int max_coeff = cat == 5 ? 64 : cat == 3 ? 4 : (cat == 1 || cat == 4) ? 15 : 16;
+      constexpr int start = (cat == 1 || cat == 4) ? 1 : 0;
+      constexpr int cbf_ctx = 85 + (cat == 1 ? 4 : cat == 2 ? 8 : cat == 3 ? 12 : cat == 4 ? 16 : 0);
+      constexpr int sig_off = cat == 1 ? 15 : cat == 2 ? 29 : cat == 3 ? 44 : cat == 4 ? 47 : 0;
+      constexpr int abs_off = cat == 1 ? 10 : cat == 2 ? 20 : cat == 3 ? 30 : cat == 4 ? 39 : 0;
+      static_assert(cat >= 0 && cat <= 5, "ctxBlockCat");
+      if (cat != 5 && !bin(cbf_ctx + inc)) return 0;  // (an 8x8 block has no flag of its own outside 4:4:4)
+      constexpr int sig_base = cat == 5 ? 402 : 105 + sig_off;
+      constexpr int last_base = cat == 5 ? 417 : 166 + sig_off;
+      constexpr int abs_base = cat == 5 ? 426 : 227 + abs_off;
+      const uint8_t* const scan = cat == 5 ? zigzag8x8 : cat == 3 ? dc_scan4 : zigzag4x4;
+      uint8_t idx[64];
+      int n = 0, i;
+      constexpr int lastpos = max_coeff - 1;
+      if (cat == 5) {
+        for (i = 0; i < lastpos; ++i)
+          if (bin(sig_base + sig_coeff_offset_8x8[i])) {
+            idx[n++] = static_cast<uint8_t>(i);
+            if (bin(last_base + last_coeff_offset_8x8[i])) break;
           }
+      } else if (cat == 3) {
+        for (i = 0; i < lastpos; ++i) {
+          const int ci = imin(i, 2);
+          if (bin(sig_base + ci)) {
+            idx[n++] = static_cast<uint8_t>(i);
+            if (bin(last_base + ci)) break;
+          }
+        }
+      } else {
+        for (i = 0; i < lastpos; ++i)
+          if (bin(sig_base + i)) {
+            idx[n++] = static_cast<uint8_t>(i);
+            if (bin(last_base + i)) break;
+          }
+      }
+      if (i == lastpos) idx[n++] = static_cast<uint8_t>(lastpos);
+      int gt1 = 0, eq1 = 0;
+      constexpr int gt_cap = 4 - (cat == 3 ? 1 : 0);
+      uint32_t* const ent = mb.ent + nent;  // n <= 64 entries; a macroblock never has more than 26 * 16
+      for (int k = n - 1; k >= 0; --k) {
+        const int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
+        int val;
+        if (!bin(abs_base + inc0)) {
+          val = 1;
+          ++eq1;
         } else {
-          for (i = 0; i < lastpos; ++i)
-            if (bin(sig_base + i)) {
-              idx[n++] = static_cast<uint8_t>(i);
-              if (bin(last_base + i)) break;
+          const int ainc = 5 + imin(gt_cap, gt1);
+          val = 2;
+          while (val < 15 && bin(abs_base + ainc)) ++val;
+          if (val == 15) {
+            int k0 = 0;
+            while (bypass()) {
+              val += 1 << k0;
+              if (++k0 > 24) return -1;
             }
-        }
-        if (i == lastpos) idx[n++] = static_cast<uint8_t>(lastpos);
-        REGIONF(R_RES_LEVEL);
-        int gt1 = 0, eq1 = 0;
-        const int gt_cap = 4 - (cat == 3 ? 1 : 0);
-        uint32_t* const ent = mb.ent + mb.nent;  // n <= 64 entries; a macroblock never has more than 26 * 16
-        for (int k = n - 1; k >= 0; --k) {
-          const int inc0 = gt1 ? 0 : imin(4, 1 + eq1);
-          int val;
-          if (!bin(abs_base + inc0)) {
-            val = 1;
-            ++eq1;
-          } else {
-            const int ainc = 5 + imin(gt_cap, gt1);
-            val = 2;
-            while (val < 15 && bin(abs_base + ainc)) ++val;
-            if (val == 15) {
-              int k0 = 0;
-              while (bypass()) {
-                val += 1 << k0;
-                if (++k0 > 24) {
-                  leave();
-                  return fail("CABAC: coeff_abs_level overflow");
-                }
-              }
-              while (k0--) val += bypass() << k0;
-            }
-            ++gt1;
+            while (k0--) val += bypass() << k0;
           }
-          if (bypass()) val = -val;
-          ent[k] = (static_cast<uint32_t>(gbase + scan[start + idx[k]]) << 16) | static_cast<uint16_t>(val);
+          ++gt1;
         }
-        mb.nent += n;
+        if (bypass()) val = -val;
+        ent[k] = (static_cast<uint32_t>(gbase + scan[start + idx[k]]) << 16) | static_cast<uint16_t>(val);
       }
-      REGIONF(R_RES_TAIL);
-      switch (kind) {
-        case RB_I16DC:
-          if (n) {
-            mb.coded_mask |= 1u << amd::kMaskLumaDc;
-            mb.cbf_dc |= 1;
-          }
-          break;
-        case RB_LUMA4:
-          if (n) mb.coded_mask |= 1u << which;
-          mb.nnz[which] = static_cast<uint8_t>(n);
-          break;
-        case RB_LUMA8:
-          for (int s = 0; s < 4; ++s) mb.nnz[((which >> 1) * 2 + (s >> 1)) * 4 + (which & 1) * 2 + (s & 1)] = static_cast<uint8_t>(n);
-          if (n) mb.coded_mask |= 0xfu << (4 * which);
-          break;
-        case RB_CHROMA_DC:
-          if (n) {
-            mb.coded_mask |= 1u << amd::kMaskChromaDc;
-            mb.cbf_dc |= 2 << (which >> 2);
-          }
-          break;
-        default:
-          if (n) mb.coded_mask |= 1u << (amd::kMaskChromaAc + which);
-          mb.nnz[16 + which] = static_cast<uint8_t>(n);
-          break;
+      nent += n;
+      return n;
+    };
+    auto overflow = [&]() {
+      leave();
+      return fail("CABAC: coeff_abs_level overflow");
+    };
+    // the DC blocks' increments: the neighbour macroblocks' flags (bit 0 Intra16x16 DC, bits 1 / 2 Cb / Cr DC)
+    auto dc_inc = [&](int bit) { return ((mb.dc_left >> bit) & 1) + 2 * ((mb.dc_top >> bit) & 1); };
+    uint8_t* const nzc = mb.nzc;
+
+    if (i16) {
+      const int n = block(Cat<0>(), dc_inc(0), 16 * amd::kMaskLumaDc);
+      if (__builtin_expect(n < 0, 0)) return overflow();
+      if (n) {
+        coded |= 1u << amd::kMaskLumaDc;
+        mb.cbf_dc |= 1;
       }
     }
-    REGIONF(R_RESIDUAL);
+    if (mb.cbp & 15) {
+      if (mb.t8x8) {
+        for (int b8 = 0; b8 < 4; ++b8) {
+          if (!((mb.cbp >> b8) & 1)) continue;
+          const int n = block(Cat<5>(), 0, 64 * b8);
+          if (__builtin_expect(n < 0, 0)) return overflow();
+          const int w0 = (b8 >> 1) * 8 + (b8 & 1) * 2, pos = nzc_luma(w0);
+          const uint8_t cnt = static_cast<uint8_t>(n), f = n != 0;
+          mb.nnz[w0] = mb.nnz[w0 + 1] = mb.nnz[w0 + 4] = mb.nnz[w0 + 5] = cnt;
+          nzc[pos] = nzc[pos + 1] = nzc[pos + 8] = nzc[pos + 9] = f;
+          if (n) coded |= 0xfu << (4 * b8);
+        }
+      } else {
+        auto luma4 = [&](auto cat_c) __attribute__((always_inline)) -> bool {
+          for (int b8 = 0; b8 < 4; ++b8) {
+            if (!((mb.cbp >> b8) & 1)) continue;
+            for (int s = 0; s < 4; ++s) {
+              const int which = ((b8 >> 1) * 2 + (s >> 1)) * 4 + (b8 & 1) * 2 + (s & 1), pos = nzc_luma(which);
+              const int n = block(cat_c, nzc[pos - 1] + 2 * nzc[pos - 8], 16 * which);
+              if (__builtin_expect(n < 0, 0)) return false;
+              mb.nnz[which] = static_cast<uint8_t>(n);
+              nzc[pos] = n != 0;
+              coded |= static_cast<uint32_t>(n != 0) << which;
+            }
+          }
+          return true;
+        };
+        if (!(i16 ? luma4(Cat<1>()) : luma4(Cat<2>()))) return overflow();
+      }
+    }
+    const int cc = mb.cbp >> 4;
+    if (cc) {
+      for (int pl = 0; pl < 2; ++pl) {
+        const int n = block(Cat<3>(), dc_inc(1 + pl), 16 * amd::kMaskChromaDc + 4 * pl);
+        if (__builtin_expect(n < 0, 0)) return overflow();
+        if (n) {
+          coded |= 1u << amd::kMaskChromaDc;
+          mb.cbf_dc |= 2 << pl;
+        }
+      }
+      if (cc == 2)
+        for (int k = 0; k < 8; ++k) {
+          const int pos = nzc_chroma(k >> 2, k & 3);
+          const int n = block(Cat<4>(), nzc[pos - 1] + 2 * nzc[pos - 8], 16 * (amd::kMaskChromaAc + k));
+          if (__builtin_expect(n < 0, 0)) return overflow();
+          mb.nnz[16 + k] = static_cast<uint8_t>(n);
+          nzc[pos] = n != 0;
+          coded |= static_cast<uint32_t>(n != 0) << (amd::kMaskChromaAc + k);
+        }
+    }
     leave();
     return true;
   }
 
-  int cbf_neighbour(int kind, int p, int rx, int ry, bool left) const {
-    const bool cur_intra = mb.kind != MB_INTER;
-    int nx = mb.mbx, ny = mb.mby;
-    bool inside = false;
-    if (kind == 1 || kind == 3) {
-      if (left) {
-        if (rx > 0) inside = true; else nx--;
-      } else {
-        if (ry > 0) inside = true; else ny--;
-      }
-    } else {
-      if (left) nx--; else ny--;
-    }
-    if (inside) {
-      if (kind == 1) return mb.nnz[left ? ry * 4 + rx - 1 : (ry - 1) * 4 + rx] != 0;
-      return mb.nnz[16 + 4 * p + (left ? ry * 2 + rx - 1 : (ry - 1) * 2 + rx)] != 0;
-    }
-    if (!nb_avail(nx - mb.mbx, ny - mb.mby)) return cur_intra;
-    const int addr = ny * mbw + nx;
-    if (mb_kind[addr] == MB_IPCM) return 1;
-    switch (kind) {
-      case 0: return mb_kind[addr] == MB_I16x16 && (mb_cbf_dc[addr] & 1);
-      case 1: return nnz[addr * 24 + (left ? ry * 4 + 3 : 12 + rx)] != 0;
-      case 2: return (mb_cbf_dc[addr] >> (1 + p)) & 1;
-      default: return nnz[addr * 24 + 16 + 4 * p + (left ? ry * 2 + 1 : 2 + rx)] != 0;
-    }
-  }
-  int cbf_inc(int kind, int p, int rx, int ry) const {
-    if (kind == 1) {  // luma 4x4 / Intra16x16 AC: left and top flags from the cache, the rest from mb.nnz
-      const int a = rx > 0 ? mb.nnz[ry * 4 + rx - 1] != 0 : mb.nz_left[ry];
-      const int b = ry > 0 ? mb.nnz[(ry - 1) * 4 + rx] != 0 : mb.nz_top[rx];
-      return a + 2 * b;
-    }
-    if (kind == 3) {  // chroma AC
-      const int a = rx > 0 ? mb.nnz[16 + 4 * p + ry * 2] != 0 : mb.nz_left[4 + 2 * p + ry];
-      const int b = ry > 0 ? mb.nnz[16 + 4 * p + rx] != 0 : mb.nz_top[4 + 2 * p + rx];
-      return a + 2 * b;
-    }
-    // the DC blocks: the neighbour macroblocks' flags, gathered by fill_nz_cache (bit 0 Intra16x16 DC, bits 1 / 2 Cb / Cr DC)
-    const int bit = kind == 0 ? 0 : 1 + p;
-    return ((mb.dc_left >> bit) & 1) + 2 * ((mb.dc_top >> bit) & 1);
-  }
-  // coded_block_flag context inputs of the blocks along the left and top edge of the current
-  // macroblock (9.3.3.1.1.9): "unavailable" counts as coded for intra macroblocks, I_PCM
-  // neighbours as coded.  Filled once per macroblock that has a residual.
+  // coded_block_flag context inputs (9.3.3.1.1.9) of the macroblock's blocks, one byte each, 0 / 1: a block's
+  // increment is the flag to its left + twice the flag above it, both found by position - luma block (x, y) at 9 + 8 y +
+  // x, its left neighbour one before it and the one above it eight before it; the Cb blocks in columns 6-7 of rows 1-2
+  // and the Cr blocks of rows 4-5 likewise (nzc_luma / nzc_chroma).  Filled here, once per macroblock that has a
+  // residual: the macroblock's own positions 0, and along the edges the flags of the neighbour macroblocks' blocks -
+  // "unavailable" counts as coded for intra macroblocks, I_PCM neighbours as coded - then kept by the block loops.
   void fill_nz_cache() {
     const uint8_t unavailable = mb.kind != MB_INTER;
     const int a = mb.addr;
-    // DC blocks (cbf_neighbour's rules for kinds 0 and 2): unavailable counts as coded for intra macroblocks, I_PCM as
-    // coded; the Intra16x16 DC flag of a neighbour that is not Intra16x16 is 0
+    // DC blocks: the same rules; the Intra16x16 DC flag of a neighbour that is not Intra16x16 is 0
     auto dc_flags = [&](bool avail, int na) -> uint8_t {
       if (!avail) return unavailable ? 7 : 0;
       const int k = mb_kind[na];
@@ -1473,23 +1432,29 @@ struct SliceData {
     };
     mb.dc_left = dc_flags(mb.av[3], a - 1);
     mb.dc_top = dc_flags(mb.av[1], a - mbw);
+    uint8_t* const z = mb.nzc;
+    memset(z, 0, sizeof(mb.nzc));
     if (mb.av[3]) {
       const uint8_t* n = &nnz[(a - 1) * 24];
       const bool pcm = mb_kind[a - 1] == MB_IPCM;
-      for (int y = 0; y < 4; ++y) mb.nz_left[y] = pcm || n[y * 4 + 3] != 0;
+      for (int y = 0; y < 4; ++y) z[8 * (y + 1)] = pcm || n[y * 4 + 3] != 0;
       for (int pl = 0; pl < 2; ++pl)
-        for (int y = 0; y < 2; ++y) mb.nz_left[4 + 2 * pl + y] = pcm || n[16 + 4 * pl + y * 2 + 1] != 0;
+        for (int y = 0; y < 2; ++y) z[nzc_chroma(pl, 2 * y) - 1] = pcm || n[16 + 4 * pl + y * 2 + 1] != 0;
     } else {
-      memset(mb.nz_left, unavailable, sizeof(mb.nz_left));
+      for (int y = 0; y < 4; ++y) z[8 * (y + 1)] = unavailable;
+      for (int pl = 0; pl < 2; ++pl)
+        for (int y = 0; y < 2; ++y) z[nzc_chroma(pl, 2 * y) - 1] = unavailable;
     }
     if (mb.av[1]) {
       const uint8_t* n = &nnz[(a - mbw) * 24];
       const bool pcm = mb_kind[a - mbw] == MB_IPCM;
-      for (int x = 0; x < 4; ++x) mb.nz_top[x] = pcm || n[12 + x] != 0;
+      for (int x = 0; x < 4; ++x) z[1 + x] = pcm || n[12 + x] != 0;
       for (int pl = 0; pl < 2; ++pl)
-        for (int x = 0; x < 2; ++x) mb.nz_top[4 + 2 * pl + x] = pcm || n[16 + 4 * pl + 2 + x] != 0;
+        for (int x = 0; x < 2; ++x) z[nzc_chroma(pl, x) - 8] = pcm || n[16 + 4 * pl + 2 + x] != 0;
     } else {
-      memset(mb.nz_top, unavailable, sizeof(mb.nz_top));
+      for (int x = 0; x < 4; ++x) z[1 + x] = unavailable;
+      for (int pl = 0; pl < 2; ++pl)
+        for (int x = 0; x < 2; ++x) z[nzc_chroma(pl, x) - 8] = unavailable;
     }
   }
 
