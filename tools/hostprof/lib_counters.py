@@ -27,6 +27,8 @@ gop = 60
 wanted = np.arange(gop - 3, idx.frames(), gop, dtype=np.uint64) if not os.environ.get("ALL") else np.arange(idx.frames(), dtype=np.uint64)
 if os.environ.get("WANTED") == "keys":  # the keyframes alone (what follows each in its GOP serves nobody and is not parsed)
     wanted = np.arange(0, idx.frames(), gop, dtype=np.uint64)
+if os.environ.get("WANTED") == "p":  # the last P picture of every GOP: no B picture at all
+    wanted = np.arange(gop - 3, idx.frames(), gop, dtype=np.uint64)
 if os.environ.get("WANTED") == "b":  # one B picture per GOP, the last: every P picture before it and that one B picture
     wanted = np.arange(gop - 2, idx.frames(), gop, dtype=np.uint64)
 keys = np.arange(0, idx.frames(), gop, dtype=np.uint64)  # (the clip's closed GOPs; only used with WANTED set)

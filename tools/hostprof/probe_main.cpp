@@ -110,7 +110,7 @@ int main(int argc,char**argv){
   int reps = argc>2?atoi(argv[2]):1; int gop = argc>3?atoi(argv[3]):60;
   // sparse: want the frame just before each keyframe-aligned GOP end -> B pictures are skipped
   size_t first = argc>4?atoi(argv[4]):gop-3;
-  std::vector<uint64_t> wanted; for(size_t g=first; g<n; g+=gop) wanted.push_back(g);
+  std::vector<uint64_t> wanted; for(size_t g=first; g<n; g+=(getenv("ALL")?1:gop)) wanted.push_back(g);   // ALL=1: every picture from `first` on
   const bool perf_on = getenv("HWANG_PROBE_PERF") != nullptr;
   Perf* perf = perf_on ? new Perf() : nullptr;
   const long iperiod = getenv("HWANG_PROBE_ISAMPLE") ? atol(getenv("HWANG_PROBE_ISAMPLE")) : 0;
