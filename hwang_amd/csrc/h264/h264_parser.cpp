@@ -649,7 +649,9 @@ struct SliceData {
     const MbMotion* nbmo[6];
     int sub_type[4];
     int8_t i4_mode[16];
-    uint8_t nnz[24];
+    uint8_t* nnz;       // this macroblock's 24 counts IN the picture's array (begin_mb): written in place - a copy at the end would
+                        // load 16 bytes that byte stores still in the store queue had just written, and wait for them to drain
+    uint16_t nz_mask;   // CABAC: the 4x4 luma blocks (raster) with levels, as the residual reader saw them
     uint8_t nzc[48];                // fill_nz_cache(): coded flags of this macroblock's blocks and of those along its edges
     uint8_t dc_left, dc_top;        // ... and the DC blocks' flags of the two neighbour macroblocks
     int cbf_dc;
@@ -1310,7 +1312,7 @@ struct SliceData {
       return static_cast<int>(mask & 1);
     };
     int nent = mb.nent;
-    uint32_t coded = mb.coded_mask;
+    uint32_t coded = mb.coded_mask, nzm = 0;
     auto leave = [&]() {
       c.value = value;
       c.range = range;
@@ -1319,6 +1321,7 @@ struct SliceData {
       if (overrun) c.overrun = true;
       mb.nent = nent;
       mb.coded_mask = coded;
+      mb.nz_mask = static_cast<uint16_t>(nzm);
     };
 
     // One block of category `cat` whose coded_block_flag context increment is `inc`: the number of its non-zero
@@ -1416,7 +1419,10 @@ struct SliceData {
           const uint8_t cnt = static_cast<uint8_t>(n), f = n != 0;
           mb.nnz[w0] = mb.nnz[w0 + 1] = mb.nnz[w0 + 4] = mb.nnz[w0 + 5] = cnt;
           nzc[pos] = nzc[pos + 1] = nzc[pos + 8] = nzc[pos + 9] = f;
-          if (n) coded |= 0xfu << (4 * b8);
+          if (n) {
+            coded |= 0xfu << (4 * b8);
+            nzm |= 0x33u << w0;
+          }
         }
       } else {
         auto luma4 = [&](auto cat_c) __attribute__((always_inline)) -> bool {
@@ -1429,6 +1435,7 @@ struct SliceData {
               mb.nnz[which] = static_cast<uint8_t>(n);
               nzc[pos] = n != 0;
               coded |= static_cast<uint32_t>(n != 0) << which;
+              nzm |= static_cast<uint32_t>(n != 0) << which;
             }
           }
           return true;
@@ -2118,7 +2125,9 @@ struct SliceData {
     mb.nent = 0;
     memset(mb.sub_type, 0, sizeof(mb.sub_type));
     memset(mb.i4_mode, 2, sizeof(mb.i4_mode));
-    memset(mb.nnz, 0, sizeof(mb.nnz));
+    mb.nnz = &nnz[static_cast<size_t>(addr) * 24];
+    memset(mb.nnz, 0, 24);
+    mb.nz_mask = 0;
     MbMotion& mo = cur->motion[addr];
     if (!compact) memset(mo.mv, 0, sizeof(mo.mv));  // compact slices never read or upload these vectors
     memset(mo.ref_slot, -1, sizeof(mo.ref_slot));
@@ -2147,7 +2156,6 @@ struct SliceData {
     mb_cbf_dc[a] = static_cast<uint8_t>(mb.cbf_dc);
     mb_chroma_mode[a] = static_cast<uint8_t>((mb.kind != MB_INTER && mb.kind != MB_IPCM) ? mb.chroma_mode : 0);
     memcpy(&i4mode[a * 16], mb.i4_mode, 16);
-    memcpy(&nnz[a * 24], mb.nnz, 24);
     const bool intra = mb.kind != MB_INTER;
     cur->mb_intra[a] = intra;
     if (intra) { has_intra = true; ++intra_mbs; } else has_inter = true;
@@ -2208,15 +2216,17 @@ struct SliceData {
     } else {
       memset(o.i4_modes, 0x22, sizeof(o.i4_modes));  // (begin_mb's value - DC - in every nibble: an inter macroblock has no modes)
     }
-    uint16_t nz = static_cast<uint16_t>(~_mm_movemask_epi8(
-        _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(mb.nnz)), _mm_setzero_si128())));
-    if (mb.t8x8 && !use_cabac)  // the transform block is the 8x8: any coefficient marks all four (CABAC: parse_residual has
-                                // given the four blocks of an 8x8 the same count already)
-      for (int b8 = 0; b8 < 4; ++b8) {
-        const int o4 = (b8 >> 1) * 8 + (b8 & 1) * 2;
-        const uint16_t m = (1u << o4) | (1u << (o4 + 1)) | (1u << (o4 + 4)) | (1u << (o4 + 5));
-        if (nz & m) nz |= m;
-      }
+    uint16_t nz = mb.nz_mask;  // (CABAC: the residual reader's; an 8x8 block marks its four 4x4 blocks)
+    if (!use_cabac) {
+      nz = static_cast<uint16_t>(~_mm_movemask_epi8(
+          _mm_cmpeq_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(mb.nnz)), _mm_setzero_si128())));
+      if (mb.t8x8)  // the transform block is the 8x8: any coefficient marks all four
+        for (int b8 = 0; b8 < 4; ++b8) {
+          const int o4 = (b8 >> 1) * 8 + (b8 & 1) * 2;
+          const uint16_t m = (1u << o4) | (1u << (o4 + 1)) | (1u << (o4 + 4)) | (1u << (o4 + 5));
+          if (nz & m) nz |= m;
+        }
+    }
     if (mb.kind == MB_IPCM) nz = 0xffff;
     o.nz_mask = nz;
 
@@ -2399,7 +2409,7 @@ struct SliceData {
         for (int i = 0; i < 384; ++i) pcm[i] = static_cast<uint8_t>(bits.get(8));
         if (bits.overrun) return fail("truncated I_PCM");
       }
-      memset(mb.nnz, 16, sizeof(mb.nnz));
+      memset(mb.nnz, 16, 24);
       mb.cbf_dc = 7;
       last_qp_delta_nonzero = 0;
       return commit_mb(pcm);

@@ -56,12 +56,12 @@ struct ISampler {
   int fd = -1;
   void* ring = nullptr;
   size_t pages = 1024;
-  bool start(long period) {
+  bool start(long period, bool cycles = false) {
     perf_event_attr a;
     memset(&a, 0, sizeof(a));
     a.size = sizeof(a);
     a.type = PERF_TYPE_HARDWARE;
-    a.config = PERF_COUNT_HW_INSTRUCTIONS;
+    a.config = cycles ? PERF_COUNT_HW_CPU_CYCLES : PERF_COUNT_HW_INSTRUCTIONS;  // HWANG_PROBE_CSAMPLE=period: by cycles instead
     a.sample_period = (uint64_t)period;
     a.sample_type = PERF_SAMPLE_IP;
     a.disabled = 1;
@@ -113,10 +113,11 @@ int main(int argc,char**argv){
   std::vector<uint64_t> wanted; for(size_t g=first; g<n; g+=(getenv("ALL")?1:gop)) wanted.push_back(g);   // ALL=1: every picture from `first` on
   const bool perf_on = getenv("HWANG_PROBE_PERF") != nullptr;
   Perf* perf = perf_on ? new Perf() : nullptr;
-  const long iperiod = getenv("HWANG_PROBE_ISAMPLE") ? atol(getenv("HWANG_PROBE_ISAMPLE")) : 0;
+  const bool by_cycles = getenv("HWANG_PROBE_CSAMPLE") != nullptr;
+  const long iperiod = by_cycles ? atol(getenv("HWANG_PROBE_CSAMPLE")) : getenv("HWANG_PROBE_ISAMPLE") ? atol(getenv("HWANG_PROBE_ISAMPLE")) : 0;
   ISampler isampler;
   if (!perf_on && !iperiod) sampler_start();
-  if (iperiod) isampler.start(iperiod);
+  if (iperiod) isampler.start(iperiod, by_cycles);
   if (perf) perf->start();
   double best=1e9;
   for(int r=0;r<reps;r++){
