@@ -715,6 +715,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     uint8_t* dev = nullptr;
     size_t capacity = 0;
     uint8_t* dst = nullptr;  // pending copy-out target
+    bool direct = false;     // ... is page-locked: the D2H copy writes it, nothing is left to copy when it has landed
     size_t size = 0;
     Stamp stamp;             // the conversion that fills it
     bool queued = false;     // ... has been submitted (entropy workers: it may wait for its picture)
@@ -776,11 +777,12 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     const Stamp st = b.stamp;
     uint8_t* const dst = b.dst;
     const size_t size = b.size;
+    const bool direct = b.direct;
     lk.unlock();
     std::string error;
     const bool ok = wait_stamp(st, &error);
     trace::event("copy-out starts", static_cast<long>(size));
-    if (ok) std::memcpy(dst, b.host, size);
+    if (ok && !direct) std::memcpy(dst, b.host, size);
     trace::event("copy-out done");
     lk.lock();
     if (!ok && copy_error_.empty()) copy_error_ = error;
@@ -1072,12 +1074,16 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   // devices: a request's output lives on one of them), the conversion kernel
   // writes it over xGMI - point-to-point stores, no copy, no collective - for
   // which peer access is switched on the first time the pair is seen.
-  bool is_device_pointer(const void* p, Result* peer_error) {
+  // ... or page-locked host memory (hipHostMalloc / hipHostRegister: `*pinned_host`)?  Then the copy engine can write
+  // the frame where the caller wants it and the bounce buffer's host half - and a 6 MB memcpy on a CPU - is not needed.
+  bool is_device_pointer(const void* p, Result* peer_error, bool* pinned_host) {
+    *pinned_host = false;
     hipPointerAttribute_t attr;
     if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
       (void)hipGetLastError();  // unregistered host memory reports an error
       return false;
     }
+    if (attr.type == hipMemoryTypeHost) *pinned_host = true;
     if (attr.type != hipMemoryTypeDevice) return false;
     if (attr.device != device_ && attr.device != peer_enabled_) {
       const hipError_t e = hipDeviceEnablePeerAccess(attr.device, 0);
@@ -1124,7 +1130,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     sub.bytes = need + (yuv ? need : w * h + 2 * cw * ch);
     Result r;
     int bounce = -1;
-    if (is_device_pointer(dst, &r)) {
+    bool pinned_host = false;
+    if (is_device_pointer(dst, &r, &pinned_host)) {
       if (!r.ok) return finish_take(slot, r);
       sub.desc.dst = dst;  // the kernel writes caller memory in HBM directly
     } else {
@@ -1132,10 +1139,11 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       if (!r.ok) return finish_take(slot, r);
       Bounce& b = bounce_[bounce];
       sub.desc.dst = b.dev;
-      sub.d2h_dst = b.host;
+      sub.d2h_dst = pinned_host ? dst : b.host;  // (page-locked caller memory: the D2H copy lands in it)
       sub.d2h_bytes = need;
       std::lock_guard<std::mutex> lk(out_mu_);
       b.dst = dst;
+      b.direct = pinned_host;
       b.size = need;
       b.queued = false;
       b.stamp = Stamp();

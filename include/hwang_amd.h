@@ -155,7 +155,10 @@ int hwang_decoder_feed(hwang_decoder* dec, const uint8_t* encoded,
                        size_t encoded_size, int keyframe);
 int hwang_decoder_flush(hwang_decoder* dec);
 int hwang_decoder_discard_frame(hwang_decoder* dec);
-/* `decoded` may be host or device (HBM) memory; RGB24, stride width*3. */
+/* `decoded` may be host or device (HBM) memory; RGB24, stride width*3.  Device memory is written by the conversion
+ * kernel itself, page-locked host memory (hipHostMalloc / hipHostRegister) by the D2H copy, pageable host memory through
+ * a pinned bounce buffer and a memcpy - as the NVIDIA backend's cudaMemcpyDefault serves all three
+ * (nvidia_video_decoder.cpp:445-446). */
 int hwang_decoder_get_frame(hwang_decoder* dec, uint8_t* decoded,
                             size_t decoded_size);
 int hwang_decoder_decoded_frames_buffered(hwang_decoder* dec);

@@ -147,6 +147,33 @@ def test_device_resident_output(hw, oracle, gpu, tmp_path):
         assert np.array_equal(host[k], oracle.i420_to_rgb(gold[r], 320, 240))
 
 
+def test_page_locked_host_output(hw, oracle, gpu, tmp_path):
+    """A caller's buffer in page-locked host memory receives the D2H copy itself (no bounce buffer's host half, no
+    memcpy): the same bytes as a pageable buffer gets - through one decoder and through the lanes of a batched call,
+    and at an offset into the allocation (the pointer handed over is not the allocation's base)."""
+    torch = gpu
+    path = str(tmp_path / "pin.mp4")
+    gold = make_clip(path, frames=24, gop=12, bframes=2)
+    idx = hw.index_video(path)
+    rows = [1, 2, 5, 11, 12, 17, 23]
+    frame = 240 * 320 * 3
+    pinned = torch.zeros((len(rows) + 1) * frame, dtype=torch.uint8, pin_memory=True)
+    assert pinned.is_pinned()
+    dec = hw.Decoder(path, video_index=idx, num_lanes=2)
+    dec.retrieve_into(rows, pinned.data_ptr() + frame, len(rows) * frame)
+    got = pinned.numpy()[frame:].reshape(len(rows), 240, 320, 3)
+    assert not pinned.numpy()[:frame].any()
+    for k, r in enumerate(rows):
+        assert np.array_equal(got[k], oracle.i420_to_rgb(gold[r], 320, 240)), "row %d" % r
+    pageable = np.zeros((len(rows), 240, 320, 3), dtype=np.uint8)
+    br = hw.BatchRetriever(device_ids=[0], num_lanes=4)
+    p2 = torch.zeros(len(rows) * frame, dtype=torch.uint8, pin_memory=True)
+    with open(path, "rb") as f:
+        br.retrieve_into([(idx, f, rows, pageable.ctypes.data, pageable.nbytes), (idx, f, rows, p2.data_ptr(), p2.numel())])
+    assert np.array_equal(pageable, got)
+    assert np.array_equal(p2.numpy().reshape(pageable.shape), got)
+
+
 def test_1080p_cropping(hw, oracle, gpu, tmp_path):
     path = str(tmp_path / "hd.mp4")
     gold = make_clip(path, width=1920, height=1080, frames=5, gop=5, bframes=2, threads=4)
