@@ -40,8 +40,12 @@ $(BUILD)/%.hip.o: %.hip $(HDRS)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# -Bsymbolic: the library's own references to its C++ classes bind inside it.  Those classes carry the reference's
+# names (hwang::DecoderAutomata, hwang::VideoDecoderFactory, ...); a host program that contains hwang's own classes -
+# which is what INTEGRATION.md describes - would otherwise interpose them (found by tests/test_integration_shim.py:
+# hwang_decoder_create() landed in the HOST's make_from_config and recursed).
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -pthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -Wl,-Bsymbolic -o $@ $(OBJS) -pthread
 
 oracle:
 	$(MAKE) -C oracle

@@ -415,11 +415,11 @@ def main():
     hc = br.host_counters()
     host_lane_threads = None
     if hc["cpu_ns"] and stats["pictures_reconstructed"]:
-        n = stats["pictures_reconstructed"]
-        host_lane_threads = {"cpu_ms_per_picture": round(hc["cpu_ns"] / 1e6 / n, 3)}
+        npics = stats["pictures_reconstructed"]   # (not `n`: that is the clip's frame count, printed in config.workload)
+        host_lane_threads = {"cpu_ms_per_picture": round(hc["cpu_ns"] / 1e6 / npics, 3)}
         if hc["cycles"]:
-            host_lane_threads.update({"instructions_per_picture": int(hc["instructions"] / n), "cycles_per_picture": int(hc["cycles"] / n),
-                                      "branch_misses_per_picture": int(hc["branch_misses"] / n),
+            host_lane_threads.update({"instructions_per_picture": int(hc["instructions"] / npics), "cycles_per_picture": int(hc["cycles"] / npics),
+                                      "branch_misses_per_picture": int(hc["branch_misses"] / npics),
                                       "ipc": round(hc["instructions"] / hc["cycles"], 2),
                                       "ghz_while_running": round(hc["cycles"] / hc["cpu_ns"], 2),
                                       "what": "user-mode counters of the retriever's lane threads over the last timed step (perf_event_open, "
@@ -518,6 +518,9 @@ def main():
             roofline = {"bound": "hbm", "kernel": best[0], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                         "traffic": pmc_traffic_per_launch(best[0], best[2] / best[3]),
+                        "traffic_source": "profiles/pmc_summary.json (separate rocprofv3 --pmc passes of this bench command on the "
+                                          "tree that last committed that file): HBM bytes per picture of the kernel, scaled to this "
+                                          "run's pictures per launch - a ratio carried over, not counters of this run",
                         "algorithmic_bytes_per_launch": round(best[2] / best[3]),
                         "launches": int(best[3]), "avg_launch_us": round(best[1] / best[3], 1),
                         "end_to_end_frac": round(e2e_bytes / (prof_stats["wall_ns"] * 1e-9) / (HBM_PEAK_GBS * 1e9), 5),
@@ -637,6 +640,10 @@ def main():
                 return {"value": round(got / t_api, 2), "unit": "frames/s", "num_devices": num_devices,
                         "host_cpus_busy": round(cpu_api / t_api, 2), "calls": len(parts), "api": what}
             reference_api_unmodified = {
+                # what differs from the reference's caller although its loop is kept line for line
+                "deviations": ["hwang/decoder.py passes consume=True to initialize() (the bytes are moved, not copied)",
+                               "num_devices=1 selects the backend's shared pool of entropy workers (up to 16 threads) where the "
+                               "reference's software backend takes it as libavcodec's thread_count = 1"],
                 "num_devices_1": run_api(1, 0, "hwang.Decoder(path, device_type=GPU).retrieve(rows) exactly as python/hwang/"
                                                "decoder.py:28,60-67 drive it: DecoderAutomata(handle, 1, AMD), one initialize + "
                                                "get_frames per planner interval (the backend picks its entropy workers itself)"),
@@ -652,6 +659,7 @@ def main():
     if rank == 0:
         value = total_rows * args.steps / elapsed
         unique = min(UNIQUE_FRAMES, n)
+        assert n == index.frames() == args.frames, "config.workload must name the clip that was decoded"
         print(json.dumps({
             "metric": "decoded frames/sec, 1080p H.264 1%-sparse sample, 1/2/4/8 MI355X vs FFmpeg CPU",
             "value": round(value, 2),
@@ -672,6 +680,7 @@ def main():
                                       BFRAMES, QP, nreq, len(row_sets[0]),
                                       ", seeds %d..%d" % (SEED, SEED + nreq - 1) if CONFIGS[CONFIG]["rows"] == "1pct" else "",
                                       args.gpus, "HBM (--hbm-output)" if args.hbm_output else "host memory (D2H inside the timed region)"),
+                       "frames": n, "unique_frames": unique, "repeats": max(1, n // unique), "rows_per_request": len(row_sets[0]),
                        "launch": ("one process, %d devices" % len(devices) if in_process_devices > 1 else
                                   "%d rank(s), one GPU each" % world if not oversubscribed else
                                   "%d ranks sharing %d GPU(s) (development run: gloo, not a scaling number)"

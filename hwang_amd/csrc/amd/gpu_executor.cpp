@@ -262,6 +262,7 @@ uint64_t GpuExecutor::submit_picture(int lane, const PicSubmit& job) {
     it.engine = (job.heavy && !with_its_chain && !no_heavy_) ? 1 + lane % heavy_engines_ : lanes_[lane].light_engine;
     it.pre = prestage_ ? 0 : 2;
     it.t_submit = std::chrono::steady_clock::now();
+    lanes_[lane].t_last_submit = it.t_submit;
     lanes_[lane].fifo.push_back(it);
     seq = ++lanes_[lane].submitted;
     target = prestage_ ? kPreEngine : it.engine;
@@ -520,7 +521,11 @@ void GpuExecutor::complete(Batch* b, hipError_t status) {
   if (b->fault) {
     const uint32_t code = __atomic_load_n(const_cast<uint32_t*>(b->fault), __ATOMIC_ACQUIRE);
     const bool chain_fault = code == FAULT_CHAIN_REFERENCE || code == FAULT_CHAIN_INTER || code == FAULT_CHAIN_INTRA;
-    if (chain_fault && b->chain && !b->retried && status == hipSuccess && error_.empty() && !stop_) {
+    // (only with this batch alone on its engine: a later batch already queued on the stream behind the faulted launch
+    // predicts from and converts the surfaces the chain left unfinished, and its completion would credit the lanes
+    // past this batch's sequence numbers - with HWANG_*_INFLIGHT > 1 the fault stays what it was, a sticky error)
+    if (chain_fault && b->chain && !b->retried && status == hipSuccess && error_.empty() && !stop_ &&
+        engines_[b->engine].inflight == 1) {
       // A chain launch gave up: nothing in it moved for its polls' bound.  The pictures' records are intact and the
       // wide kernels order pictures by kernel boundaries, not by hand-offs: the engine thread runs the batch again
       // through them (rerun_wide); the batch stays in flight under a new ticket until that run is through.
@@ -848,7 +853,14 @@ void GpuExecutor::run(int engine) {
           busy += b;
           latency_lanes |= b && (l.chain || !l.patient);
           if (is_light(engine) && l.light_engine != engine) continue;
-          ++mine;  // (every active lane of the engine: one whose thread is parsing for it right now will have a picture soon)
+          // A lane counts towards the engine's share while it is at work: something queued or in flight, or a picture
+          // submitted within the last linger period (its thread is parsing the next one).  Not every REGISTERED lane:
+          // the retriever registers two backends per lane and decodes with one at a time, and another decoder's idle
+          // lanes on the device are registered too - with those in `mine` the fill test could never be met and every
+          // batch waited for the age limit instead.
+          const bool at_work = b || std::chrono::duration_cast<std::chrono::microseconds>(now - l.t_last_submit).count() < linger_us;
+          if (!at_work) continue;
+          ++mine;
           if (eligible(l, engine)) {
             ++ready;
             const Item& it = l.fifo.front();

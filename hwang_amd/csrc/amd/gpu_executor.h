@@ -160,6 +160,7 @@ class GpuExecutor {
     bool active = false;
     std::deque<Item> fifo;
     uint64_t submitted = 0, launched = 0, completed = 0;
+    std::chrono::steady_clock::time_point t_last_submit{};  // the lane's latest picture (run(): which lanes are at work)
     int last_engine = 0;
     int light_engine = 0;  // engine of the lane's P / B pictures
     bool chain = false;    // see register_lane

@@ -63,3 +63,83 @@ int main() {
     run = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "configure ok=0" in run.stdout and "message=" in run.stdout and len(run.stdout.split("message=")[1].strip()) > 5
+
+
+# ---- the reference's own DecoderAutomata above the seam (VERDICT r5 "what's missing" 3) ------------------------------
+# /root/reference/hwang/decoder_automata.cpp, compiled where it lies (logging stub for glog), linked with the adapter
+# above and a test-local VideoDecoderFactory::make_from_config (tests/fixtures/ref_automata_driver.cpp): hwang's
+# feeder/retriever state machine calling hwang_decoder_* through INTEGRATION.md's shim.  Here over the STAMP protocol
+# fixture (no GPU); tests/test_gpu_ref_automata.py runs the same binary over the MI355X backend.
+import random
+import struct
+
+from tests import ref_driver
+
+needs_ref_driver = pytest.mark.skipif(
+    not os.path.exists(os.path.join(REF, "hwang", "decoder_automata.cpp")) and not os.path.exists(ref_driver.DRIVER),
+    reason="reference tree not present and the driver was not prebuilt")
+
+
+def stamp_clip(hw, n, gop, gap=0):
+    samples = [struct.pack("<I", i) + b"x" * (6 + i % 5) for i in range(n)]
+    offs, sizes, blob, o = [], [], bytearray(), 0
+    for i, s in enumerate(samples):
+        if gap and i % gop == 0 and i:
+            blob += b"\0" * gap
+            o += gap
+        offs.append(o)
+        sizes.append(len(s))
+        blob += s
+        o += len(s)
+    idx = hw.VideoIndex(timescale=1000, duration=n * 1000, width=4, height=2, format="avc1", sample_offsets=offs,
+                        sample_sizes=sizes, keyframe_indices=list(range(0, n, gop)), metadata=b"")
+    return idx, bytes(blob)
+
+
+def run_stamp(hw, tmp_path, idx, blob, rows, chunks):
+    assert ref_driver.build_driver()
+    plan = hw.slice_into_video_intervals(idx, rows)
+    ref_driver.write_plan(str(tmp_path / "plan.txt"), idx, plan, chunks)
+    (tmp_path / "blob.bin").write_bytes(blob)
+    r = ref_driver.run_driver(str(tmp_path / "plan.txt"), str(tmp_path / "blob.bin"), str(tmp_path / "out.bin"),
+                              hw.STAMP, 0, stamp=True)
+    assert r.returncode == 0, r.stdout + r.stderr[-2000:]
+    out = (tmp_path / "out.bin").read_bytes()
+    fs = idx.frame_width() * idx.frame_height() * 3
+    got = [int.from_bytes(out[i * fs:i * fs + 4], "little") for i in range(len(out) // fs)]
+    trace = [int(x) for x in r.stdout.split("trace=")[1].split()]
+    keys = ("configures", "feeds", "keyframe_feeds", "empty_feeds", "flushes", "gets", "discards", "hints")
+    return got, dict(zip(keys, trace))
+
+
+@needs_ref_driver
+def test_reference_automata_drives_the_c_abi_call_trace(hw, tmp_path):
+    """SURVEY 3.2's probe, now through the shim: 4 touched GOPs of 10 samples, wanted {3,4,27,55,58,99} ->
+    configure x1, feed x40 (4 keyframes), empty feed x3, flush x3, get_frame x6, discard x34."""
+    idx, blob = stamp_clip(hw, 100, 10)
+    rows = [3, 4, 27, 55, 58, 99]
+    got, t = run_stamp(hw, tmp_path, idx, blob, rows, [4, 2])
+    assert got == rows
+    assert t == dict(configures=1, feeds=40, keyframe_feeds=4, empty_feeds=3, flushes=3, gets=6, discards=34, hints=0)
+
+
+@needs_ref_driver
+@pytest.mark.parametrize("seed", range(4))
+def test_reference_automata_sparse_equals_sequential(hw, tmp_path, seed):
+    """GatherFramesComparison's invariant (decoder_automata_test.cpp:262-342): what the sparse request returns is what
+    a sequential decode holds at those positions - the reference's automata, this library's C ABI, random plans and
+    random get_frames chunking."""
+    rnd = random.Random(100 + seed)
+    n, gop = rnd.randint(20, 150), rnd.randint(1, 17)
+    idx, blob = stamp_clip(hw, n, gop, gap=rnd.choice([0, 5]))
+    rows = sorted(rnd.sample(range(n), rnd.randint(1, min(n, 25))))
+    chunks, left = [], len(rows)
+    while left:
+        k = rnd.randint(1, left)
+        chunks.append(k)
+        left -= k
+    got, t = run_stamp(hw, tmp_path, idx, blob, rows, chunks)
+    assert got == rows
+    seq, _ = run_stamp(hw, tmp_path, idx, blob, list(range(n)), [n])
+    assert [seq[r] for r in rows] == got
+    assert t["gets"] == len(rows) and t["configures"] == 1
