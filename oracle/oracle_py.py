@@ -136,3 +136,99 @@ def decode_file(path, index, first=0, count=None, coverage=None, parse_only=Fals
     if coverage is not None:
         coverage += dec.coverage()
     return frames, dec.counters()
+
+
+# ---------------------------------------------------------------------------------------------------------- HEVC
+_HEVC_LIB = os.path.join(_HERE, "_build", "liboracle_hevc.so")
+
+
+def load_hevc():
+    if not os.path.exists(_HEVC_LIB):
+        raise ImportError("HEVC oracle not built: run `make -C oracle`")
+    lib = C.CDLL(_HEVC_LIB)
+    lib.hevco_open.restype = C.c_void_p
+    lib.hevco_close.argtypes = [C.c_void_p]
+    lib.hevco_configure.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.hevco_decode.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.hevco_flush.argtypes = [C.c_void_p]
+    lib.hevco_frames_ready.argtypes = [C.c_void_p]
+    lib.hevco_frame_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.hevco_pop_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.hevco_error.argtypes = [C.c_void_p]
+    lib.hevco_error.restype = C.c_char_p
+    lib.hevco_counters.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    lib.hevco_set_parse_only.argtypes = [C.c_void_p, C.c_int]
+    lib.hevco_residual_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.hevco_intra_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    lib.hevco_inter_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p]
+    return lib
+
+
+class HevcOracleDecoder(object):
+    """The H.264 wrapper's interface over oracle/hevc_*.c (hvcC extradata, length-prefixed samples)."""
+
+    def __init__(self, extradata, parse_only=False):
+        self.lib = load_hevc()
+        self.h = self.lib.hevco_open()
+        if parse_only:
+            self.lib.hevco_set_parse_only(self.h, 1)
+        extradata = bytes(extradata)
+        if self.lib.hevco_configure(self.h, extradata, len(extradata)):
+            raise RuntimeError("HEVC oracle configure: " + self.error())
+
+    def error(self):
+        return self.lib.hevco_error(self.h).decode()
+
+    def close(self):
+        if self.h:
+            self.lib.hevco_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _drain(self, out):
+        w, h, poc = C.c_int(), C.c_int(), C.c_int()
+        while self.lib.hevco_frames_ready(self.h) > 0:
+            self.lib.hevco_frame_info(self.h, C.byref(w), C.byref(h), C.byref(poc))
+            n = w.value * h.value + 2 * ((w.value + 1) // 2) * ((h.value + 1) // 2)
+            buf = np.empty(n, dtype=np.uint8)
+            self.lib.hevco_pop_frame(self.h, buf.ctypes.data, n)
+            out.append((buf, w.value, h.value, poc.value))
+
+    def decode(self, sample):
+        sample = bytes(sample)
+        if self.lib.hevco_decode(self.h, sample, len(sample)):
+            raise RuntimeError("HEVC oracle decode: " + self.error())
+        out = []
+        self._drain(out)
+        return out
+
+    def flush(self):
+        if self.lib.hevco_flush(self.h):
+            raise RuntimeError("HEVC oracle flush: " + self.error())
+        out = []
+        self._drain(out)
+        return out
+
+    def counters(self):
+        c = (C.c_int64 * 12)()
+        self.lib.hevco_counters(self.h, c)
+        keys = ("slices", "slices_clean_end", "coding_units", "pictures", "i_slices", "p_slices", "b_slices", "intra_cus",
+                "skip_cus", "md5_checked", "md5_mismatch", "transform_units")
+        return dict(zip(keys, list(c)))
+
+
+def decode_file_hevc(path, index, first=0, count=None, parse_only=False):
+    """Sequentially decodes samples [first, first+count) of an indexed MP4 with an HEVC track; frames in display order."""
+    offs, sizes = index.sample_offsets(), index.sample_sizes()
+    n = index.frames() if count is None else count
+    dec = HevcOracleDecoder(index.metadata_bytes(), parse_only=parse_only)
+    frames = []
+    with open(path, "rb") as f:
+        for i in range(first, first + n):
+            f.seek(offs[i])
+            frames += dec.decode(f.read(sizes[i]))
+    frames += dec.flush()
+    return frames, dec.counters()
