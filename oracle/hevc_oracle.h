@@ -62,6 +62,15 @@ void hevco_intra_block(const uint8_t* corner_and_left, const uint8_t* top, int l
 void hevco_inter_block(const uint8_t* ref, int ref_w, int ref_h, int c_idx, int x, int y, int w, int h, int mvx, int mvy,
                        uint8_t* pred);
 
+/* in-loop filter arithmetic on explicit samples: a 4-line luma edge segment (8 samples across per line), one chroma
+ * edge row (p1 p0 q0 q1, strength 2), SAO of a block treated as a whole picture */
+void hevco_deblock_luma(uint8_t* blk, int bs, int qp_p, int qp_q, int beta_offset_div2, int tc_offset_div2, int no_p, int no_q);
+void hevco_deblock_chroma(uint8_t* row, int qp_p, int qp_q, int c_qp_pic_offset, int tc_offset_div2);
+void hevco_sao_block(const uint8_t* in, int w, int h, int type, int band_pos, int eo_class, const int8_t* offsets, uint8_t* out);
+/* a constant table of hevc_tables.h by name ("trans_matrix", "cabac_init", "scan20" ...): pointer and size in bytes */
+const void* hevco_table(const char* name, int* bytes);
+void hevco_set_parse_only(HevcOracle* d, int on);
+
 #ifdef __cplusplus
 }
 #endif

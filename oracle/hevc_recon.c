@@ -552,3 +552,59 @@ void hv_sao_picture(HevcOracle* d) {
       }
     }
 }
+
+/* ---------------------------------------------------------------------- hooks for tests/test_hevc_independent.py */
+/* one 4-line luma edge segment: blk[line * 8 + k], k = 0..7 across the edge (p3 p2 p1 p0 | q0 q1 q2 q3) */
+void hevco_deblock_luma(uint8_t* blk, int bs, int qp_p, int qp_q, int beta_offset_div2, int tc_offset_div2, int no_p, int no_q) {
+  const int qpl = (qp_p + qp_q + 1) >> 1;
+  const int beta = hevc_beta_table[hv_clip3(0, 51, qpl + (beta_offset_div2 << 1))];
+  const int tc = hevc_tc_table[hv_clip3(0, 53, qpl + 2 * (bs - 1) + (tc_offset_div2 << 1))];
+  filter_luma_segment(blk + 4, 1, 8, beta, tc, no_p, no_q);
+}
+/* one chroma edge sample row: p1 p0 | q0 q1, bS = 2 */
+void hevco_deblock_chroma(uint8_t* row, int qp_p, int qp_q, int c_qp_pic_offset, int tc_offset_div2) {
+  const int qpi = ((qp_p + qp_q + 1) >> 1) + c_qp_pic_offset;
+  const int qpc = qpi < 30 ? qpi : qpi >= 43 ? qpi - 6 : hevc_qpc_table[qpi - 30];
+  const int tc = hevc_tc_table[hv_clip3(0, 53, qpc + 2 + (tc_offset_div2 << 1))];
+  const int p1 = row[0], p0 = row[1], q0 = row[2], q1 = row[3];
+  const int delta = hv_clip3(-tc, tc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+  row[1] = (uint8_t)hv_clip8(p0 + delta);
+  row[2] = (uint8_t)hv_clip8(q0 - delta);
+}
+/* SAO of a w x h block that is a whole picture (samples whose neighbour lies outside stay as they are) */
+void hevco_sao_block(const uint8_t* in, int w, int h, int type, int band_pos, int eo_class, const int8_t* offsets, uint8_t* out) {
+  static const int8_t hpos[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}}, vpos[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+  int band[32];
+  memset(band, 0, sizeof(band));
+  for (int k = 0; k < 4; ++k) band[(k + band_pos) & 31] = k + 1;
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) {
+      const int v = in[y * w + x];
+      int idx = 0;
+      if (type == 1) {
+        idx = band[v >> 3];
+      } else if (type == 2) {
+        const int xa = x + hpos[eo_class][0], ya = y + vpos[eo_class][0], xb = x + hpos[eo_class][1], yb = y + vpos[eo_class][1];
+        if (xa >= 0 && ya >= 0 && xb >= 0 && yb >= 0 && xa < w && xb < w && ya < h && yb < h) {
+          const int sum = 2 + hv_sign(v - in[ya * w + xa]) + hv_sign(v - in[yb * w + xb]);
+          idx = sum == 2 ? 0 : sum < 2 ? sum + 1 : sum;
+        }
+      }
+      out[y * w + x] = (uint8_t)(idx ? hv_clip8(v + offsets[idx - 1]) : v);
+    }
+}
+/* the constant tables, by name (tests/test_hevc_tables.py) */
+const void* hevco_table(const char* name, int* bytes) {
+#define T(n, t) if (!strcmp(name, n)) { *bytes = (int)sizeof(t); return t; }
+  T("cabac_init", hevc_cabac_init) T("range_lps", hevc_range_lps) T("trans_lps", hevc_trans_lps) T("trans_matrix", hevc_trans_matrix)
+  T("dst4", hevc_dst4) T("luma_filter", hevc_luma_filter) T("chroma_filter", hevc_chroma_filter) T("intra_angle", hevc_intra_angle)
+  T("inv_angle", hevc_inv_angle) T("beta", hevc_beta_table) T("tc", hevc_tc_table) T("qpc", hevc_qpc_table)
+  T("scaling_intra8", hevc_default_scaling_intra8) T("scaling_inter8", hevc_default_scaling_inter8) T("ctx_idx_map4", hevc_ctx_idx_map4)
+#undef T
+  if (!strncmp(name, "scan", 4) && strlen(name) == 6) { /* "scanLS": log2 size L, scan index S */
+    *bytes = 1 << (2 * (name[4] - '0'));
+    return hv_scan(name[4] - '0', name[5] - '0');
+  }
+  *bytes = 0;
+  return NULL;
+}

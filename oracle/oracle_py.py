@@ -162,6 +162,9 @@ def load_hevc():
     lib.hevco_intra_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.hevco_inter_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p]
+    lib.hevco_deblock_luma.argtypes = [C.c_void_p] + [C.c_int] * 7
+    lib.hevco_deblock_chroma.argtypes = [C.c_void_p] + [C.c_int] * 4
+    lib.hevco_sao_block.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     return lib
 
 

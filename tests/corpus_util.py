@@ -216,3 +216,55 @@ def golden_md5(name):
         with open(os.path.join(ROOT, "tests", "golden", "corpus_md5.json")) as f:
             _GOLDEN_MD5 = json.load(f)
     return _GOLDEN_MD5["cases"][name]
+
+
+# ---------------------------------------------------------------------------------------------------------- HEVC
+HEVC_ENCODER = os.path.join(ROOT, "corpus", "_build", "hevc_encoder")
+
+
+def make_hevc_clip(path, width=128, height=96, yuv=True, **kw):
+    """corpus/hevc_encoder.c: a seeded HEVC Main clip in MP4; returns the encoder's own reconstruction (display order,
+    cropped I420, one row per frame) when yuv=True."""
+    if not os.path.exists(HEVC_ENCODER):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "corpus")])
+    args = [HEVC_ENCODER, "--width", str(width), "--height", str(height), "--out", path]
+    ypath = path + ".yuv"
+    if yuv:
+        args += ["--yuv-out", ypath]
+    for k, v in kw.items():
+        args += ["--" + k.replace("_", "-"), str(v)]
+    r = subprocess.run(args, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("HEVC corpus encoder failed: " + r.stderr[-400:])
+    if not yuv:
+        return None
+    fs = width * height + 2 * ((width + 1) // 2) * ((height + 1) // 2)
+    gold = np.fromfile(ypath, dtype=np.uint8).reshape(-1, fs)
+    os.unlink(ypath)
+    return gold
+
+
+# (name, kwargs): small clips that together touch every tool the HEVC generator can emit
+HEVC_MATRIX = [
+    ("i_ctb16", dict(frames=3, intra_only=1, ctb=16)),
+    ("i_ctb32_sao_pcm", dict(frames=2, intra_only=1, ctb=32, sao=3, pcm=1)),
+    ("i_ctb64_qp22", dict(frames=2, intra_only=1, ctb=64, qp=22)),
+    ("i_pcm2_tskip_bypass", dict(frames=2, intra_only=1, pcm=2, tskip=1, bypass=1)),
+    ("i_sdh_qp20", dict(frames=2, intra_only=1, sdh=1, qp=20)),
+    ("i_qpswing", dict(frames=2, intra_only=1, qp_swing=2, ctb=32, cb_off=3, cr_off=-4)),
+    ("i_scaling_random_modes", dict(frames=2, intra_only=1, scaling=3, random_intra=1)),
+    ("i_slices_cip_nolf", dict(frames=2, intra_only=1, slices=3, cip=1, lf_across=0, sao=1)),
+    ("i_wpp", dict(frames=2, intra_only=1, wpp=1, ctb=16, qp_swing=1)),
+    ("i_deep_tree_cover", dict(frames=2, intra_only=1, cover=1, th_intra=3, max_tb=16, strong=0)),
+    ("i_odd_size", dict(width=134, height=90, frames=2, intra_only=1, ctb=32, sao=1)),
+    ("p_refs2", dict(frames=6, gop=6, refs=2)),
+    ("ibp", dict(frames=9, gop=9, bframes=2, refs=2)),
+    ("ibp_amp_wp_ctb32", dict(frames=9, gop=9, bframes=2, refs=3, amp=1, ctb=32, wp=1)),
+    ("pyramid_sao_sdh_cover", dict(frames=13, gop=13, bframes=3, bpyramid=1, refs=4, sao=1, sdh=1, cover=1)),
+    ("merge2_pml3_notmvp", dict(frames=12, gop=6, bframes=1, refs=2, merge_cand=2, pml=3, tmvp=0, mvd_l1_zero=1)),
+    ("rps_sps_pocwrap_ctb64", dict(frames=20, gop=20, bframes=2, rps_sps=1, poc_bits=4, cabac_init=2, qp_swing=2, ctb=64)),
+    ("everything", dict(frames=8, gop=8, bframes=1, slices=2, wpp=1, ctb=16, cip=1, pcm=1, tskip=1, bypass=1, scaling=1, sao=1,
+                        amp=1, sdh=1, deblock_off=2, beta=2, tc=-1, slice_cb_off=2, extra_nals=1, nal_length_size=2, hvc1=1)),
+    ("deblock_off_th0", dict(frames=5, gop=5, bframes=1, deblock_off=1, th_inter=0, th_intra=0, max_tb=16)),
+    ("merge1_p", dict(frames=5, gop=5, refs=1, merge_cand=1, qp=36)),
+]
