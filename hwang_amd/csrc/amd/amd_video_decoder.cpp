@@ -19,6 +19,8 @@
 // to be reused, and wait_until_frames_copied().
 #include "amd_video_decoder.h"
 
+#include "hevc_video_decoder.h"
+
 #include "../h264/h264_parser.h"
 #include "../hevc/hvcc.h"
 #include "../sparse_hints.h"
@@ -144,19 +146,17 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     trace::event("configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
     // The format switch of the reference's software backend (software_video_decoder.cpp:124-135): h264 / avc1, the
-    // HEVC names, anything else.  HEVC is recognised and refused by name, with what the track's hvcC says it is.
+    // HEVC names, anything else.  An HEVC track goes to the HEVC half of this backend (hevc_video_decoder.cpp: host
+    // parser + k_hevc.hip); every later call is forwarded to it until a configure() names H.264 again.
     if (hevc::is_hevc_format(metadata.format)) {
-      hevc::Config hc;
-      std::string why;
-      if (!hevc::parse_hvcc(extradata.data(), extradata.size(), &hc, &why))
-        return Result(false, "AMDVideoDecoder: HEVC ('" + metadata.format + "') is not supported by this backend (H.264 only), and the "
-                             "track's hvcC cannot be read: " + why);
-      return Result(false, "AMDVideoDecoder: HEVC ('" + metadata.format + "') is not supported by this backend (H.264 only); the track is " +
-                               hevc::describe(hc));
+      if (!hevc_) hevc_.reset(make_hevc_delegate(device_));
+      hevc_active_ = true;
+      if (!pending_wanted_.empty()) hevc_->set_wanted_frames(pending_wanted_);
+      return hevc_->configure(metadata, extradata);
     }
+    hevc_active_ = false;
     if (metadata.format != "h264" && metadata.format != "avc1") {
-      return Result(false, "Unsupported video codec: " + metadata.format + ". Supported codecs are: h264 (avc1); hevc/h265 is "
-                           "recognised but not decoded");
+      return Result(false, "Unsupported video codec: " + metadata.format + ". Supported codecs are: h264 (avc1) and hevc (h265, hev1, hvc1)");
     }
     if (parser_) {
       folded_decoded_ += parser_->pictures_decoded();
@@ -182,6 +182,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   Result feed(const uint8_t* encoded_buffer, size_t encoded_size, bool keyframe) override {
+    if (hevc_active_) return hevc_->feed(encoded_buffer, encoded_size, keyframe);
     if (encoded_size == 0) return Result();  // end-of-interval marker; flush() follows
     if (!parser_) return Result(false, "AMDVideoDecoder::feed before configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
@@ -202,6 +203,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   Result flush() override {
+    if (hevc_active_) {
+      pending_wanted_.clear();
+      return hevc_->flush();
+    }
     if (!parser_) return Result();
     HWANG_HIP_RETURN(hipSetDevice(device_));
     if (!parser_->flush()) return Result(false, "AMDVideoDecoder::flush: " + parser_->error());
@@ -212,6 +217,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   Result discard_frame() override {
+    if (hevc_active_) return hevc_->discard_frame();
     int slot;
     if (!outq_.try_pop(slot)) return Result();
     buffered_.fetch_sub(1, std::memory_order_acq_rel);
@@ -222,15 +228,21 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
   Result get_frame(uint8_t* decoded_buffer, size_t decoded_size) override {
+    if (hevc_active_) return hevc_->get_frame(decoded_buffer, decoded_size);
     return take_frame(decoded_buffer, decoded_size, false);
   }
   Result get_frame_yuv(uint8_t* decoded_buffer, size_t decoded_size) override {
+    if (hevc_active_) return hevc_->get_frame_yuv(decoded_buffer, decoded_size);
     return take_frame(decoded_buffer, decoded_size, true);
   }
 
-  int decoded_frames_buffered() override { return buffered_.load(std::memory_order_acquire); }
+  int decoded_frames_buffered() override {
+    if (hevc_active_) return hevc_->decoded_frames_buffered();
+    return buffered_.load(std::memory_order_acquire);
+  }
 
   Result wait_until_frames_copied() override {
+    if (hevc_active_) return hevc_->wait_until_frames_copied();
     trace::event("wait_until_frames_copied");
     struct Done {
       ~Done() { trace::event("frames copied"); }
@@ -267,6 +279,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
   void set_wanted_frames(const std::vector<uint64_t>& ordinals) override {
     pending_wanted_ = ordinals;
+    if (hevc_active_) {
+      hevc_->set_wanted_frames(ordinals);
+      return;
+    }
     if (parser_) parser_->set_wanted(ordinals);
   }
   void set_interval_keyframes(const std::vector<uint64_t>& ordinals) override {
@@ -274,6 +290,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (parser_) parser_->set_keyframes(ordinals);
   }
   BackendCounters counters() override {
+    if (hevc_active_) return hevc_->counters();
     BackendCounters c = counters_;
     c.bytes_uploaded = bytes_uploaded_.load();
     c.pictures_reconstructed = folded_decoded_ + (parser_ ? parser_->pictures_decoded() : 0) - decoded_base_;
@@ -281,6 +298,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     return c;
   }
   void reset_counters() override {
+    if (hevc_) hevc_->reset_counters();
     counters_ = BackendCounters();
     bytes_uploaded_.store(0);
     decoded_base_ = folded_decoded_ + (parser_ ? parser_->pictures_decoded() : 0);
@@ -641,6 +659,8 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
 
  private:
+  std::unique_ptr<HevcDelegate> hevc_;  // the HEVC half (hevc_video_decoder.cpp), made at the first HEVC configure()
+  bool hevc_active_ = false;            // ... and in charge since the last configure()
   enum { kHeldByParser = 1, kHeldByOutput = 2 };
   // beyond this many surfaces, wait for an upload rather than grow (with entropy workers: the pictures in flight and
   // the intervals still on the GPU hold surfaces too)

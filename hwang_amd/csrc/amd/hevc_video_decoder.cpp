@@ -1,0 +1,489 @@
+// The HEVC half of the MI355X backend behind VideoDecoderInterface (the reference's
+// software backend takes HEVC tracks too, impls/software/software_video_decoder.cpp:128-132).  AMDVideoDecoder
+// (amd_video_decoder.cpp) hands every call over to an object of this class once configure() has seen an HEVC format
+// name.  One HIP stream per decoder orders everything: a picture's records (host parser, hevc/hevc_parser.cpp) are
+// copied from pinned staging memory, its kernels (k_hevc.hip) run in decoding order, the colour conversion of a
+// fetched frame and its copy-out queue up behind the picture they show.  Latency-oriented and simple - the batching
+// executor of the H.264 path is not used here (DESIGN.md section 5a says what that costs).
+#include "hevc_video_decoder.h"
+
+#include "../hevc/hevc_parser.h"
+#include "../sparse_hints.h"
+#include "hevc_frame_job.h"
+#include "hip_check.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <vector>
+
+namespace hwang {
+
+hipError_t launch_yuv420_to_rgb24(const uint8_t* y, const uint8_t* u, const uint8_t* v, int y_stride, int c_stride, int width, int height,
+                                  uint8_t* rgb, hipStream_t stream);
+namespace amd {
+namespace hevc {
+hipError_t launch_picture(const PicParams& pp, const PicParams* pp_dev, hipStream_t stream);
+}
+}  // namespace amd
+
+namespace {
+
+namespace gh = amd::hevc;
+constexpr int kSets = 3;
+
+class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
+ public:
+  explicit HEVCVideoDecoder(int device) : device_(device) {}
+  ~HEVCVideoDecoder() override {
+    (void)hipSetDevice(device_);
+    parser_.reset();
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    free_all();
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+
+  Result configure(const VideoDecoderInterface::FrameInfo& info, const std::vector<uint8_t>& extradata) override {
+    HWANG_HIP_RETURN(hipSetDevice(device_));
+    if (!stream_) HWANG_HIP_RETURN(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+    if (parser_) {
+      folded_decoded_ += parser_->pictures_decoded();
+      folded_skipped_ += parser_->pictures_skipped();
+    }
+    parser_.reset();  // (releases its surfaces)
+    HWANG_HIP_RETURN(hipStreamSynchronize(stream_));
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (int slot : outq_)
+        if (slot >= 0) surf_[slot].held &= ~kOutput;
+      outq_.clear();
+      buffered_.store(0);
+    }
+    parser_.reset(new hevc::Parser(this));
+    if (!parser_->configure(extradata.data(), extradata.size())) return Result(false, "AMDVideoDecoder::configure (HEVC): " + parser_->error());
+    if (parser_->width() != static_cast<int>(info.width) || parser_->height() != static_cast<int>(info.height))
+      return Result(false, "AMDVideoDecoder::configure (HEVC): stream is " + std::to_string(parser_->width()) + "x" + std::to_string(parser_->height()) +
+                               " but the container says " + std::to_string(info.width) + "x" + std::to_string(info.height));
+    info_ = info;
+    if (!pending_wanted_.empty()) parser_->set_wanted(pending_wanted_);
+    return Result();
+  }
+
+  Result feed(const uint8_t* data, size_t size, bool /*keyframe*/) override {
+    if (!size) return Result();
+    if (!parser_) return Result(false, "AMDVideoDecoder::feed before configure");
+    HWANG_HIP_RETURN(hipSetDevice(device_));
+    ++counters_.samples_fed;
+    if (!parser_->decode(data, size)) {
+      const std::string why = parser_->error();
+      return Result(false, "AMDVideoDecoder::feed (HEVC): " + why);
+    }
+    return take_error();
+  }
+
+  Result flush() override {
+    if (!parser_) return Result();
+    HWANG_HIP_RETURN(hipSetDevice(device_));
+    parser_->flush();
+    pending_wanted_.clear();
+    return take_error();
+  }
+
+  Result discard_frame() override {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (outq_.empty()) return Result();
+    const int slot = outq_.front();
+    outq_.pop_front();
+    buffered_.fetch_sub(1, std::memory_order_acq_rel);
+    if (slot >= 0) surf_[slot].held &= ~kOutput;
+    return Result();
+  }
+
+  Result get_frame(uint8_t* dst, size_t size) override { return take(dst, size, false); }
+  Result get_frame_yuv(uint8_t* dst, size_t size) override { return take(dst, size, true); }
+  int decoded_frames_buffered() override { return buffered_.load(std::memory_order_acquire); }
+
+  Result wait_until_frames_copied() override {
+    HWANG_HIP_RETURN(hipSetDevice(device_));
+    if (stream_) HWANG_HIP_RETURN(hipStreamSynchronize(stream_));
+    if (fault_host_ && *fault_host_) {
+      *fault_host_ = 0;
+      return Result(false, "AMDVideoDecoder (HEVC): the intra wavefront timed out waiting for the row above; the picture is invalid");
+    }
+    return take_error();
+  }
+
+  void set_wanted_frames(const std::vector<uint64_t>& ordinals) override {
+    pending_wanted_ = ordinals;
+    if (parser_) parser_->set_wanted(ordinals);
+  }
+  BackendCounters counters() override {
+    BackendCounters c = counters_;
+    c.bytes_uploaded = bytes_uploaded_;
+    c.pictures_reconstructed = folded_decoded_ + (parser_ ? parser_->pictures_decoded() : 0) - decoded_base_;
+    c.pictures_skipped = folded_skipped_ + (parser_ ? parser_->pictures_skipped() : 0) - skipped_base_;
+    return c;
+  }
+  void reset_counters() override {
+    counters_ = BackendCounters();
+    bytes_uploaded_ = 0;
+    decoded_base_ = folded_decoded_ + (parser_ ? parser_->pictures_decoded() : 0);
+    skipped_base_ = folded_skipped_ + (parser_ ? parser_->pictures_skipped() : 0);
+  }
+
+  // ----------------------------------------------------------------------------------------- PictureSink
+  bool begin_picture(const hevc::PicSetup& s, hevc::PicBuffers* out, std::string* error) override {
+    if (!ensure_geometry(s, error)) return false;
+    Set& set = sets_[next_set_];
+    if (set.busy) {
+      if (hipEventSynchronize(set.done) != hipSuccess) {
+        *error = "hipEventSynchronize failed";
+        return false;
+      }
+      set.busy = false;
+    }
+    int slot = -1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (size_t i = 0; i < surf_.size() && slot < 0; ++i)
+        if (!surf_[i].held) slot = static_cast<int>(i);
+      if (slot < 0 && surf_.size() < static_cast<size_t>(gh::kMaxSurfaces)) {
+        surf_.push_back(SurfaceSlot());
+        slot = static_cast<int>(surf_.size()) - 1;
+      }
+      if (slot >= 0) surf_[slot].held = kParser;
+    }
+    if (slot < 0) {
+      *error = "no free surface: decoded frames are not being fetched or discarded";
+      return false;
+    }
+    if (!surf_[slot].dev && hipMalloc(reinterpret_cast<void**>(&surf_[slot].dev), surface_bytes_) != hipSuccess) {
+      *error = "out of HBM for an HEVC surface";
+      std::lock_guard<std::mutex> lk(mu_);
+      surf_[slot].held = 0;
+      return false;
+    }
+    uint8_t* h = set.host;
+    out->slot = slot;
+    out->cookie = &set;
+    out->res = reinterpret_cast<gh::ResTu*>(h + off_.res);
+    out->cap_res = cap_.res;
+    out->coefs = reinterpret_cast<uint32_t*>(h + off_.coefs);
+    out->cap_coefs = cap_.coefs;
+    out->pus = reinterpret_cast<gh::InterPu*>(h + off_.pus);
+    out->cap_pus = cap_.pus;
+    out->weights = reinterpret_cast<gh::WeightEntry*>(h + off_.weights);
+    out->cap_weights = cap_.weights;
+    for (int c = 0; c < 3; ++c) {
+      out->intra[c] = reinterpret_cast<gh::IntraTu*>(h + off_.intra[c]);
+      out->cap_intra[c] = cap_.intra[c];
+      out->intra_ctb_first[c] = reinterpret_cast<uint32_t*>(h + off_.first[c]);
+    }
+    out->edges = reinterpret_cast<gh::EdgeInfo*>(h + off_.edges);
+    out->sao = reinterpret_cast<gh::SaoCtb*>(h + off_.sao);
+    out->slices = reinterpret_cast<gh::SliceLoop*>(h + off_.slices);
+    out->scaling = h + off_.scaling;
+    return true;
+  }
+
+  bool end_picture(const hevc::PicDone& d, std::string* error) override {
+    Set& set = *static_cast<Set*>(d.cookie);
+    gh::PicParams pp;
+    std::memset(&pp, 0, sizeof(pp));
+    pp.width = cw_;
+    pp.height = ch_;
+    pp.y_pitch = y_pitch_;
+    pp.c_pitch = y_pitch_ / 2;
+    pp.log2_ctb = log2_ctb_;
+    pp.width_ctb = wctb_;
+    pp.height_ctb = hctb_;
+    pp.cb_qp_offset = d.cb_qp_offset;
+    pp.cr_qp_offset = d.cr_qp_offset;
+    pp.pcm_bits_luma = d.pcm_bits_luma;
+    pp.pcm_bits_chroma = d.pcm_bits_chroma;
+    pp.num_res = static_cast<int32_t>(d.num_res);
+    pp.num_pu = static_cast<int32_t>(d.num_pus);
+    for (int c = 0; c < 3; ++c) pp.num_intra[c] = static_cast<int32_t>(d.num_intra[c]);
+    pp.sao_enabled = d.sao;
+    pp.deblock_enabled = d.deblock;
+    pp.dst = surface_of(surf_[d.slot].dev);
+    pp.recon = d.sao ? surface_of(work_) : pp.dst;
+    for (int i = 0; i < d.num_ref_slots; ++i) pp.refs[d.ref_slots[i]] = surface_of(surf_[d.ref_slots[i]].dev);
+    uint8_t* dv = set.dev;
+    pp.res = reinterpret_cast<const gh::ResTu*>(dv + off_.res);
+    pp.coefs = reinterpret_cast<const uint32_t*>(dv + off_.coefs);
+    pp.pus = reinterpret_cast<const gh::InterPu*>(dv + off_.pus);
+    pp.weights = reinterpret_cast<const gh::WeightEntry*>(dv + off_.weights);
+    for (int c = 0; c < 3; ++c) {
+      pp.intra[c] = reinterpret_cast<const gh::IntraTu*>(dv + off_.intra[c]);
+      pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dv + off_.first[c]);
+    }
+    pp.edges = reinterpret_cast<const gh::EdgeInfo*>(dv + off_.edges);
+    pp.sao = reinterpret_cast<const gh::SaoCtb*>(dv + off_.sao);
+    pp.slices = reinterpret_cast<const gh::SliceLoop*>(dv + off_.slices);
+    pp.scaling = d.scaling ? dv + off_.scaling : nullptr;
+    pp.resid[0] = resid_;
+    pp.resid[1] = resid_ + static_cast<size_t>(y_pitch_) * ch_;
+    pp.resid[2] = pp.resid[1] + static_cast<size_t>(y_pitch_ / 2) * (ch_ / 2);
+    pp.progress = progress_;
+    pp.fault = fault_dev_;
+    std::memcpy(set.host + off_.params, &pp, sizeof(pp));
+    auto up = [&](size_t off, size_t bytes) {
+      if (!bytes) return hipSuccess;
+      bytes_uploaded_ += static_cast<int64_t>(bytes);
+      return hipMemcpyAsync(dv + off, set.host + off, bytes, hipMemcpyHostToDevice, stream_);
+    };
+    const size_t ctbs = static_cast<size_t>(wctb_) * hctb_;
+    hipError_t e = up(off_.params, sizeof(pp));
+    if (e == hipSuccess) e = up(off_.res, d.num_res * sizeof(gh::ResTu));
+    if (e == hipSuccess) e = up(off_.coefs, d.num_coefs * sizeof(uint32_t));
+    if (e == hipSuccess) e = up(off_.pus, d.num_pus * sizeof(gh::InterPu));
+    if (e == hipSuccess) e = up(off_.weights, d.num_weights * sizeof(gh::WeightEntry));
+    for (int c = 0; c < 3 && e == hipSuccess; ++c) {
+      e = up(off_.intra[c], d.num_intra[c] * sizeof(gh::IntraTu));
+      if (e == hipSuccess && (d.num_intra[0] || d.num_intra[1] || d.num_intra[2])) e = up(off_.first[c], (ctbs + 1) * sizeof(uint32_t));
+    }
+    if (e == hipSuccess && (d.deblock || d.sao)) e = up(off_.edges, static_cast<size_t>(cw_ / 4) * (ch_ / 4) * sizeof(gh::EdgeInfo));
+    if (e == hipSuccess && d.sao) e = up(off_.sao, ctbs * sizeof(gh::SaoCtb));
+    if (e == hipSuccess && (d.deblock || d.sao)) e = up(off_.slices, static_cast<size_t>(std::max(d.num_slices, 1)) * sizeof(gh::SliceLoop));
+    if (e == hipSuccess && d.scaling) e = up(off_.scaling, 4064);
+    if (e == hipSuccess) e = hipMemsetAsync(resid_, 0, resid_bytes_, stream_);
+    if (e == hipSuccess) e = hipMemsetAsync(progress_, 0, sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_), stream_);
+    if (e == hipSuccess) e = gh::launch_picture(pp, reinterpret_cast<const gh::PicParams*>(dv + off_.params), stream_);
+    if (e == hipSuccess) e = hipEventRecord(set.done, stream_);
+    if (e != hipSuccess) {
+      *error = std::string("HEVC picture submission failed: ") + hipGetErrorString(e);
+      return false;
+    }
+    set.busy = true;
+    next_set_ = (next_set_ + 1) % kSets;
+    return true;
+  }
+
+  void abandon_picture(const hevc::PicDone& /*d*/) override {}
+
+  void output_picture(int slot) override {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (outq_.size() >= 1024) {
+      sink_error_ = "too many undelivered pictures (decoded frames are not being fetched or discarded)";
+      return;
+    }
+    if (slot >= 0) surf_[slot].held |= kOutput;
+    outq_.push_back(slot);
+    buffered_.fetch_add(1, std::memory_order_acq_rel);
+  }
+
+  void release_surface(int slot) override {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (slot >= 0 && slot < static_cast<int>(surf_.size())) surf_[slot].held &= ~kParser;
+  }
+
+ private:
+  enum { kParser = 1, kOutput = 2 };
+  struct SurfaceSlot {
+    uint8_t* dev = nullptr;
+    int held = 0;
+  };
+  struct Set {
+    uint8_t* host = nullptr;
+    uint8_t* dev = nullptr;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+  };
+  struct Offsets {
+    size_t params, res, coefs, pus, weights, intra[3], first[3], edges, sao, slices, scaling, total;
+  };
+  struct Caps {
+    size_t res, coefs, pus, weights, intra[3];
+  };
+
+  gh::Surface surface_of(uint8_t* base) const {
+    gh::Surface s;
+    s.y = base;
+    s.u = base + static_cast<size_t>(y_pitch_) * ch_;
+    s.v = s.u + static_cast<size_t>(y_pitch_ / 2) * (ch_ / 2);
+    return s;
+  }
+
+  Result take_error() {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (sink_error_.empty()) return Result();
+    Result r(false, "AMDVideoDecoder (HEVC): " + sink_error_);
+    sink_error_.clear();
+    return r;
+  }
+
+  void free_all() {
+    for (SurfaceSlot& s : surf_)
+      if (s.dev) (void)hipFree(s.dev);
+    surf_.clear();
+    for (Set& s : sets_) {
+      if (s.host) (void)hipHostFree(s.host);
+      if (s.dev) (void)hipFree(s.dev);
+      if (s.done) (void)hipEventDestroy(s.done);
+      s = Set();
+    }
+    if (work_) (void)hipFree(work_);
+    if (resid_) (void)hipFree(resid_);
+    if (progress_) (void)hipFree(progress_);
+    if (rgb_dev_) (void)hipFree(rgb_dev_);
+    if (fault_host_) (void)hipHostFree(fault_host_);
+    work_ = nullptr;
+    resid_ = nullptr;
+    progress_ = nullptr;
+    rgb_dev_ = nullptr;
+    fault_host_ = nullptr;
+    fault_dev_ = nullptr;
+    cw_ = ch_ = 0;
+  }
+
+  bool ensure_geometry(const hevc::PicSetup& s, std::string* error) {
+    if (s.width == cw_ && s.height == ch_ && s.log2_ctb == log2_ctb_) {
+      crop_l_ = s.crop_left;
+      crop_t_ = s.crop_top;
+      return true;
+    }
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (const SurfaceSlot& sl : surf_)
+        if (sl.held) {
+          *error = "the picture size changed while frames of the old size are still held";
+          return false;
+        }
+    }
+    free_all();
+    cw_ = s.width;
+    ch_ = s.height;
+    log2_ctb_ = s.log2_ctb;
+    crop_l_ = s.crop_left;
+    crop_t_ = s.crop_top;
+    wctb_ = (cw_ + (1 << log2_ctb_) - 1) >> log2_ctb_;
+    hctb_ = (ch_ + (1 << log2_ctb_) - 1) >> log2_ctb_;
+    y_pitch_ = (cw_ + 255) & ~255;
+    surface_bytes_ = static_cast<size_t>(y_pitch_) * ch_ * 3 / 2;
+    const size_t w4h4 = static_cast<size_t>(cw_ / 4) * (ch_ / 4), ctbs = static_cast<size_t>(wctb_) * hctb_;
+    cap_.res = w4h4 * 3 / 2 + 64;
+    cap_.coefs = static_cast<size_t>(cw_) * ch_ * 3 / 2 + 64;
+    cap_.pus = w4h4 / 2 + 64;
+    cap_.weights = 2 * 16 * static_cast<size_t>(gh::kMaxSlices);
+    cap_.intra[0] = w4h4 + 64;
+    cap_.intra[1] = cap_.intra[2] = w4h4 / 4 + 64;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+      const size_t at = o;
+      o = (o + bytes + 255) & ~static_cast<size_t>(255);
+      return at;
+    };
+    off_.params = take(sizeof(gh::PicParams));
+    off_.res = take(cap_.res * sizeof(gh::ResTu));
+    off_.coefs = take(cap_.coefs * sizeof(uint32_t));
+    off_.pus = take(cap_.pus * sizeof(gh::InterPu));
+    off_.weights = take(cap_.weights * sizeof(gh::WeightEntry));
+    for (int c = 0; c < 3; ++c) off_.intra[c] = take(cap_.intra[c] * sizeof(gh::IntraTu));
+    for (int c = 0; c < 3; ++c) off_.first[c] = take((ctbs + 1) * sizeof(uint32_t));
+    off_.edges = take(w4h4 * sizeof(gh::EdgeInfo));
+    off_.sao = take(ctbs * sizeof(gh::SaoCtb));
+    off_.slices = take(gh::kMaxSlices * sizeof(gh::SliceLoop));
+    off_.scaling = take(4064);
+    off_.total = o;
+    bool ok = true;
+    for (Set& set : sets_) {
+      ok = ok && hipHostMalloc(reinterpret_cast<void**>(&set.host), off_.total, hipHostMallocDefault) == hipSuccess;
+      ok = ok && hipMalloc(reinterpret_cast<void**>(&set.dev), off_.total) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&set.done, hipEventDisableTiming) == hipSuccess;
+    }
+    resid_bytes_ = surface_bytes_ * sizeof(int16_t);
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&work_), surface_bytes_) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&resid_), resid_bytes_) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&progress_), sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_)) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&rgb_dev_), static_cast<size_t>(cw_) * ch_ * 3) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void**>(&fault_host_), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
+    if (ok) {
+      *fault_host_ = 0;
+      ok = hipHostGetDevicePointer(reinterpret_cast<void**>(&fault_dev_), fault_host_, 0) == hipSuccess;
+    }
+    if (!ok) {
+      *error = "out of memory for the HEVC decoder's buffers (" + std::to_string(cw_) + "x" + std::to_string(ch_) + ")";
+      free_all();
+      return false;
+    }
+    next_set_ = 0;
+    return true;
+  }
+
+  Result take(uint8_t* dst, size_t dst_size, bool yuv) {
+    HWANG_HIP_RETURN(hipSetDevice(device_));
+    const size_t w = info_.width, h = info_.height, cw = (w + 1) / 2, chh = (h + 1) / 2;
+    const size_t need = yuv ? w * h + 2 * cw * chh : w * h * 3;
+    int slot;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (outq_.empty()) return Result();
+      if (dst_size < need) return Result(false, "AMDVideoDecoder::get_frame: buffer too small");
+      slot = outq_.front();
+      if (slot < 0)
+        return Result(false, "AMDVideoDecoder::get_frame: this output position was excluded by the sparse hint (set_wanted) or could not be decoded");
+      outq_.pop_front();
+      buffered_.fetch_sub(1, std::memory_order_acq_rel);
+    }
+    const gh::Surface s = surface_of(surf_[slot].dev);
+    const uint8_t* y = s.y + static_cast<size_t>(crop_t_) * y_pitch_ + crop_l_;
+    const uint8_t* u = s.u + static_cast<size_t>(crop_t_ / 2) * (y_pitch_ / 2) + crop_l_ / 2;
+    const uint8_t* v = s.v + static_cast<size_t>(crop_t_ / 2) * (y_pitch_ / 2) + crop_l_ / 2;
+    hipPointerAttribute_t attr;
+    const bool device_dst = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    if (!device_dst) (void)hipGetLastError();
+    hipError_t e = hipSuccess;
+    if (yuv) {
+      const hipMemcpyKind kind = device_dst ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+      e = hipMemcpy2DAsync(dst, w, y, static_cast<size_t>(y_pitch_), w, h, kind, stream_);
+      if (e == hipSuccess) e = hipMemcpy2DAsync(dst + w * h, cw, u, static_cast<size_t>(y_pitch_ / 2), cw, chh, kind, stream_);
+      if (e == hipSuccess) e = hipMemcpy2DAsync(dst + w * h + cw * chh, cw, v, static_cast<size_t>(y_pitch_ / 2), cw, chh, kind, stream_);
+    } else {
+      uint8_t* rgb = device_dst ? dst : rgb_dev_;
+      e = launch_yuv420_to_rgb24(y, u, v, y_pitch_, y_pitch_ / 2, static_cast<int>(w), static_cast<int>(h), rgb, stream_);
+      if (e == hipSuccess && !device_dst) e = hipMemcpyAsync(dst, rgb_dev_, need, hipMemcpyDeviceToHost, stream_);
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      surf_[slot].held &= ~kOutput;  // (whatever takes the surface next queues up behind this on the stream)
+    }
+    if (e != hipSuccess) return Result(false, std::string("AMDVideoDecoder::get_frame (HEVC): ") + hipGetErrorString(e));
+    return Result();
+  }
+
+  const int device_;
+  hipStream_t stream_ = nullptr;
+  std::unique_ptr<hevc::Parser> parser_;
+  VideoDecoderInterface::FrameInfo info_;
+  std::vector<uint64_t> pending_wanted_;
+  std::mutex mu_;
+  std::vector<SurfaceSlot> surf_;
+  std::deque<int> outq_;
+  std::atomic<int> buffered_{0};
+  std::string sink_error_;
+  Set sets_[kSets];
+  int next_set_ = 0;
+  Offsets off_ = {};
+  Caps cap_ = {};
+  int cw_ = 0, ch_ = 0, log2_ctb_ = 0, wctb_ = 0, hctb_ = 0, y_pitch_ = 0, crop_l_ = 0, crop_t_ = 0;
+  size_t surface_bytes_ = 0, resid_bytes_ = 0;
+  uint8_t* work_ = nullptr;
+  int16_t* resid_ = nullptr;
+  uint32_t* progress_ = nullptr;
+  uint8_t* rgb_dev_ = nullptr;
+  uint32_t* fault_host_ = nullptr;
+  uint32_t* fault_dev_ = nullptr;
+  BackendCounters counters_;
+  int64_t bytes_uploaded_ = 0, folded_decoded_ = 0, folded_skipped_ = 0, decoded_base_ = 0, skipped_base_ = 0;
+};
+
+}  // namespace
+
+HevcDelegate* make_hevc_delegate(int device_id) { return new HEVCVideoDecoder(device_id); }
+
+}  // namespace hwang

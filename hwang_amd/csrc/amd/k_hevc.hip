@@ -1,0 +1,515 @@
+// HIP kernels of the HEVC path for gfx950 (wave64): one picture's records (hevc_frame_job.h) -> samples.
+//
+//   k_hevc_residual   8.6.3 scaling + 8.6.4 inverse transforms (DCT 4..32, DST 4x4, transform skip, bypass): one
+//                     wavefront per transform block, coefficients scattered into LDS, both matrix passes out of LDS,
+//                     the residual written to the int16 residual planes (zeroed per picture).
+//   k_hevc_inter      8.5.3.3 fractional sample interpolation (8-tap luma, 4-tap chroma, references clamped to the
+//                     picture), default and explicit weighting, + residual: one workgroup per prediction block.
+//   k_hevc_intra      8.4.4.2 intra prediction (substitution, [1 2 1] / strong smoothing, planar, DC, 33 angles, edge
+//                     filters, I_PCM) + residual: a wavefront of coding tree block rows per colour plane - row r of
+//                     plane c follows the progress word of row r - 1 two blocks behind (the above-right block is a
+//                     neighbour); the three planes are independent chains and run side by side.
+//   k_hevc_deblock    8.7.2.5: one thread per 4-sample edge segment, all vertical edges of the picture, then (a second
+//                     launch) all horizontal ones - HEVC's filter is defined that way, nothing is serial in it.
+//   k_hevc_sao        8.7.3: band / edge offsets from the deblocked picture into the DPB surface.
+// These are byte stencils bound by HBM and, for k_hevc_intra, by the dependent chain along a block row; no MFMA.
+// What they compute is checked bit for bit against the CPU oracle and against the numpy statements of
+// tests/hevc_numpy.py (tests/test_gpu_hevc.py).  HEVC parity with FFmpeg is unpinned.
+#include <hip/hip_runtime.h>
+
+#include "hevc_frame_job.h"
+#include "hip_check.h"
+
+namespace {
+
+using namespace hwang::amd::hevc;
+
+// --- tables (ITU-T H.265 8.6.4.2, Tables 8-4 / 8-5 / 8-11 / 8-12; tests/test_tables_match.py: same constants as hevc/hevc_tables.h)
+__constant__ int8_t kTrans[32][32] = {
+    {64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64},
+    {90, 90, 88, 85, 82, 78, 73, 67, 61, 54, 46, 38, 31, 22, 13, 4, -4, -13, -22, -31, -38, -46, -54, -61, -67, -73, -78, -82, -85, -88, -90, -90},
+    {90, 87, 80, 70, 57, 43, 25, 9, -9, -25, -43, -57, -70, -80, -87, -90, -90, -87, -80, -70, -57, -43, -25, -9, 9, 25, 43, 57, 70, 80, 87, 90},
+    {90, 82, 67, 46, 22, -4, -31, -54, -73, -85, -90, -88, -78, -61, -38, -13, 13, 38, 61, 78, 88, 90, 85, 73, 54, 31, 4, -22, -46, -67, -82, -90},
+    {89, 75, 50, 18, -18, -50, -75, -89, -89, -75, -50, -18, 18, 50, 75, 89, 89, 75, 50, 18, -18, -50, -75, -89, -89, -75, -50, -18, 18, 50, 75, 89},
+    {88, 67, 31, -13, -54, -82, -90, -78, -46, -4, 38, 73, 90, 85, 61, 22, -22, -61, -85, -90, -73, -38, 4, 46, 78, 90, 82, 54, 13, -31, -67, -88},
+    {87, 57, 9, -43, -80, -90, -70, -25, 25, 70, 90, 80, 43, -9, -57, -87, -87, -57, -9, 43, 80, 90, 70, 25, -25, -70, -90, -80, -43, 9, 57, 87},
+    {85, 46, -13, -67, -90, -73, -22, 38, 82, 88, 54, -4, -61, -90, -78, -31, 31, 78, 90, 61, 4, -54, -88, -82, -38, 22, 73, 90, 67, 13, -46, -85},
+    {83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83, 83, 36, -36, -83, -83, -36, 36, 83},
+    {82, 22, -54, -90, -61, 13, 78, 85, 31, -46, -90, -67, 4, 73, 88, 38, -38, -88, -73, -4, 67, 90, 46, -31, -85, -78, -13, 61, 90, 54, -22, -82},
+    {80, 9, -70, -87, -25, 57, 90, 43, -43, -90, -57, 25, 87, 70, -9, -80, -80, -9, 70, 87, 25, -57, -90, -43, 43, 90, 57, -25, -87, -70, 9, 80},
+    {78, -4, -82, -73, 13, 85, 67, -22, -88, -61, 31, 90, 54, -38, -90, -46, 46, 90, 38, -54, -90, -31, 61, 88, 22, -67, -85, -13, 73, 82, 4, -78},
+    {75, -18, -89, -50, 50, 89, 18, -75, -75, 18, 89, 50, -50, -89, -18, 75, 75, -18, -89, -50, 50, 89, 18, -75, -75, 18, 89, 50, -50, -89, -18, 75},
+    {73, -31, -90, -22, 78, 67, -38, -90, -13, 82, 61, -46, -88, -4, 85, 54, -54, -85, 4, 88, 46, -61, -82, 13, 90, 38, -67, -78, 22, 90, 31, -73},
+    {70, -43, -87, 9, 90, 25, -80, -57, 57, 80, -25, -90, -9, 87, 43, -70, -70, 43, 87, -9, -90, -25, 80, 57, -57, -80, 25, 90, 9, -87, -43, 70},
+    {67, -54, -78, 38, 85, -22, -90, 4, 90, 13, -88, -31, 82, 46, -73, -61, 61, 73, -46, -82, 31, 88, -13, -90, -4, 90, 22, -85, -38, 78, 54, -67},
+    {64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64, 64, -64, -64, 64},
+    {61, -73, -46, 82, 31, -88, -13, 90, -4, -90, 22, 85, -38, -78, 54, 67, -67, -54, 78, 38, -85, -22, 90, 4, -90, 13, 88, -31, -82, 46, 73, -61},
+    {57, -80, -25, 90, -9, -87, 43, 70, -70, -43, 87, 9, -90, 25, 80, -57, -57, 80, 25, -90, 9, 87, -43, -70, 70, 43, -87, -9, 90, -25, -80, 57},
+    {54, -85, -4, 88, -46, -61, 82, 13, -90, 38, 67, -78, -22, 90, -31, -73, 73, 31, -90, 22, 78, -67, -38, 90, -13, -82, 61, 46, -88, 4, 85, -54},
+    {50, -89, 18, 75, -75, -18, 89, -50, -50, 89, -18, -75, 75, 18, -89, 50, 50, -89, 18, 75, -75, -18, 89, -50, -50, 89, -18, -75, 75, 18, -89, 50},
+    {46, -90, 38, 54, -90, 31, 61, -88, 22, 67, -85, 13, 73, -82, 4, 78, -78, -4, 82, -73, -13, 85, -67, -22, 88, -61, -31, 90, -54, -38, 90, -46},
+    {43, -90, 57, 25, -87, 70, 9, -80, 80, -9, -70, 87, -25, -57, 90, -43, -43, 90, -57, -25, 87, -70, -9, 80, -80, 9, 70, -87, 25, 57, -90, 43},
+    {38, -88, 73, -4, -67, 90, -46, -31, 85, -78, 13, 61, -90, 54, 22, -82, 82, -22, -54, 90, -61, -13, 78, -85, 31, 46, -90, 67, 4, -73, 88, -38},
+    {36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36, 36, -83, 83, -36, -36, 83, -83, 36},
+    {31, -78, 90, -61, 4, 54, -88, 82, -38, -22, 73, -90, 67, -13, -46, 85, -85, 46, 13, -67, 90, -73, 22, 38, -82, 88, -54, -4, 61, -90, 78, -31},
+    {25, -70, 90, -80, 43, 9, -57, 87, -87, 57, -9, -43, 80, -90, 70, -25, -25, 70, -90, 80, -43, -9, 57, -87, 87, -57, 9, 43, -80, 90, -70, 25},
+    {22, -61, 85, -90, 73, -38, -4, 46, -78, 90, -82, 54, -13, -31, 67, -88, 88, -67, 31, 13, -54, 82, -90, 78, -46, 4, 38, -73, 90, -85, 61, -22},
+    {18, -50, 75, -89, 89, -75, 50, -18, -18, 50, -75, 89, -89, 75, -50, 18, 18, -50, 75, -89, 89, -75, 50, -18, -18, 50, -75, 89, -89, 75, -50, 18},
+    {13, -38, 61, -78, 88, -90, 85, -73, 54, -31, 4, 22, -46, 67, -82, 90, -90, 82, -67, 46, -22, -4, 31, -54, 73, -85, 90, -88, 78, -61, 38, -13},
+    {9, -25, 43, -57, 70, -80, 87, -90, 90, -87, 80, -70, 57, -43, 25, -9, -9, 25, -43, 57, -70, 80, -87, 90, -90, 87, -80, 70, -57, 43, -25, 9},
+    {4, -13, 22, -31, 38, -46, 54, -61, 67, -73, 78, -82, 85, -88, 90, -90, 90, -90, 88, -85, 82, -78, 73, -67, 61, -54, 46, -38, 31, -22, 13, -4}};
+__constant__ int8_t kDst[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+__constant__ int8_t kLumaTaps[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+__constant__ int8_t kChromaTaps[8][4] = {{0, 64, 0, 0},   {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4},
+                                         {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+__constant__ int8_t kAngle[35] = {0,   0,   32,  26,  21,  17,  13,  9,  5,  2,  0,  -2, -5, -9, -13, -17, -21, -26,
+                                  -32, -26, -21, -17, -13, -9,  -5,  -2, 0,  2,  5,  9,  13, 17, 21,  26,  32};
+__constant__ int16_t kInvAngle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+__constant__ uint8_t kBeta[52] = {0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  0,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,
+                                  16, 17, 18, 20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+__constant__ uint8_t kTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1,  1,  1,  1,  1,  1,
+                                2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+__constant__ uint8_t kQpc[13] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37};
+__constant__ int kLevelScale[6] = {40, 45, 51, 57, 64, 72};
+
+__device__ inline int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+__device__ inline int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
+__device__ inline int iabs(int v) { return v < 0 ? -v : v; }
+__device__ inline uint8_t* plane_of(const Surface& s, int c) { return c == 0 ? s.y : c == 1 ? s.u : s.v; }
+
+// ---------------------------------------------------------------------------------------------------- residual
+constexpr int kResWaves = 4;
+
+__global__ __launch_bounds__(64 * kResWaves) void k_hevc_residual(const PicParams* __restrict__ ppp) {
+  const PicParams& pp = *ppp;
+  __shared__ int d[kResWaves][1024];
+  __shared__ int g[kResWaves][1024];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int t = blockIdx.x * kResWaves + wave;
+  const bool active = t < pp.num_res;
+  ResTu tu;
+  if (active) tu = pp.res[t];
+  const int log2 = active ? tu.log2 : 2, n = 1 << log2, nn = n * n;
+  int* dd = d[wave];
+  int* gg = g[wave];
+  for (int i = lane; i < nn; i += 64) dd[i] = 0;
+  __syncthreads();
+  const bool bypass = active && (tu.flags & RES_BYPASS), tskip = active && (tu.flags & RES_TSKIP), dst = active && (tu.flags & RES_DST);
+  if (active) {
+    const uint8_t* m = nullptr;
+    if (tu.matrix != 0xff && pp.scaling) {
+      const int off = log2 == 2 ? 0 : log2 == 3 ? 96 : log2 == 4 ? 480 : 2016;
+      m = pp.scaling + off + tu.matrix * nn;
+    }
+    const int bd_shift = log2 + 3, qp = tu.qp;
+    for (uint32_t k = lane; k < tu.ncoef; k += 64) {
+      const uint32_t e = pp.coefs[tu.coef_offset + k];
+      const int pos = e >> 16, lev = static_cast<int16_t>(e & 0xffff);
+      int v = lev;
+      if (!bypass) {
+        const long long s = ((static_cast<long long>(lev) * (m ? m[pos] : 16) * kLevelScale[qp % 6]) << (qp / 6)) + (1ll << (bd_shift - 1));
+        const long long q = s >> bd_shift;
+        v = static_cast<int>(q < -32768 ? -32768 : q > 32767 ? 32767 : q);
+      }
+      dd[pos] = v;
+    }
+  }
+  __syncthreads();
+  const int step = 32 >> log2;
+  if (active && !bypass && !tskip) {  // columns
+    for (int o = lane; o < nn; o += 64) {
+      const int i = o / n, x = o % n;  // output row i of column x
+      int e = 0;
+      for (int j = 0; j < n; ++j) e += (dst ? kDst[j][i] : kTrans[j * step][i]) * dd[j * n + x];
+      gg[o] = clip3(-32768, 32767, (e + 64) >> 7);
+    }
+  }
+  __syncthreads();
+  if (active) {
+    const int pitch = tu.c_idx ? pp.c_pitch : pp.y_pitch;
+    int16_t* out = pp.resid[tu.c_idx] + static_cast<size_t>(tu.y) * pitch + tu.x;
+    for (int o = lane; o < nn; o += 64) {
+      const int y = o / n, i = o % n;
+      int r;
+      if (bypass) {
+        r = dd[o];
+      } else if (tskip) {
+        r = ((dd[o] << 7) + 2048) >> 12;
+      } else {
+        int e = 0;
+        for (int j = 0; j < n; ++j) e += (dst ? kDst[j][i] : kTrans[j * step][i]) * gg[y * n + j];
+        r = (e + 2048) >> 12;
+      }
+      out[static_cast<size_t>(y) * pitch + i] = static_cast<int16_t>(r);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------- inter
+__device__ inline int ref_at(const uint8_t* p, int pitch, int w, int h, int x, int y) {
+  return p[static_cast<size_t>(clip3(0, h - 1, y)) * pitch + clip3(0, w - 1, x)];
+}
+// predSamplesLX (14 bit) of one sample
+__device__ inline int interp(const uint8_t* ref, int pitch, int w, int h, bool chroma, int xi, int yi, int xf, int yf) {
+  const int taps = chroma ? 4 : 8, before = chroma ? 1 : 3;
+  if (!xf && !yf) return ref_at(ref, pitch, w, h, xi, yi) << 6;
+  if (!yf) {
+    int v = 0;
+    for (int t = 0; t < taps; ++t) v += (chroma ? kChromaTaps[xf][t] : kLumaTaps[xf][t]) * ref_at(ref, pitch, w, h, xi + t - before, yi);
+    return v;
+  }
+  if (!xf) {
+    int v = 0;
+    for (int t = 0; t < taps; ++t) v += (chroma ? kChromaTaps[yf][t] : kLumaTaps[yf][t]) * ref_at(ref, pitch, w, h, xi, yi + t - before);
+    return v;
+  }
+  int v = 0;
+  for (int u = 0; u < taps; ++u) {
+    int r = 0;
+    for (int t = 0; t < taps; ++t) r += (chroma ? kChromaTaps[xf][t] : kLumaTaps[xf][t]) * ref_at(ref, pitch, w, h, xi + t - before, yi + u - before);
+    v += (chroma ? kChromaTaps[yf][u] : kLumaTaps[yf][u]) * r;
+  }
+  return v >> 6;
+}
+
+__global__ __launch_bounds__(256) void k_hevc_inter(const PicParams* __restrict__ ppp) {
+  const PicParams& pp = *ppp;
+  const InterPu pu = pp.pus[blockIdx.x];
+  for (int c = 0; c < 3; ++c) {
+    const int sub = c ? 1 : 0;
+    const int x0 = pu.x >> sub, y0 = pu.y >> sub, w = pu.w >> sub, h = pu.h >> sub;
+    const int pw = pp.width >> sub, ph = pp.height >> sub, pitch = c ? pp.c_pitch : pp.y_pitch;
+    const int fb = c ? 3 : 2, fm = (1 << fb) - 1;
+    uint8_t* dst = plane_of(pp.recon, c);
+    const int16_t* res = pp.resid[c];
+    const uint8_t* r0 = (pu.pred_flag & 1) ? plane_of(pp.refs[pu.ref_slot[0]], c) : nullptr;
+    const uint8_t* r1 = (pu.pred_flag & 2) ? plane_of(pp.refs[pu.ref_slot[1]], c) : nullptr;
+    WeightEntry w0 = {}, w1 = {};
+    if (pu.weighted) {
+      if (r0) w0 = pp.weights[pu.wp[0]];
+      if (r1) w1 = pp.weights[pu.wp[1]];
+    }
+    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
+      const int x = x0 + i % w, y = y0 + i / w;
+      int p0 = 0, p1 = 0;
+      if (r0) p0 = interp(r0, pitch, pw, ph, c != 0, x + (pu.mv[0][0] >> fb), y + (pu.mv[0][1] >> fb), pu.mv[0][0] & fm, pu.mv[0][1] & fm);
+      if (r1) p1 = interp(r1, pitch, pw, ph, c != 0, x + (pu.mv[1][0] >> fb), y + (pu.mv[1][1] >> fb), pu.mv[1][0] & fm, pu.mv[1][1] & fm);
+      int v;
+      if (!pu.weighted) {
+        v = (r0 && r1) ? (p0 + p1 + 64) >> 7 : ((r0 ? p0 : p1) + 32) >> 6;
+      } else {
+        const int lwd = (c ? (r0 ? w0 : w1).log2wd[1] : (r0 ? w0 : w1).log2wd[0]) + 6;
+        if (r0 && r1)
+          v = (p0 * w0.w[c] + p1 * w1.w[c] + ((w0.o[c] + w1.o[c] + 1) << lwd)) >> (lwd + 1);
+        else if (r0)
+          v = ((p0 * w0.w[c] + (1 << (lwd - 1))) >> lwd) + w0.o[c];
+        else
+          v = ((p1 * w1.w[c] + (1 << (lwd - 1))) >> lwd) + w1.o[c];
+      }
+      const size_t at = static_cast<size_t>(y) * pitch + x;
+      dst[at] = static_cast<uint8_t>(clip8(clip8(v) + res[at]));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------- intra
+constexpr uint32_t kIntraSpins = 1u << 22;  // bounded wait for the row above (then: fault, the host fails the picture)
+
+// one colour plane's row of coding tree blocks per workgroup of ONE wavefront (__syncthreads is a wave barrier here)
+__global__ __launch_bounds__(64) void k_hevc_intra(const PicParams* __restrict__ ppp) {
+  const PicParams& pp = *ppp;
+  const int c = blockIdx.y, row = blockIdx.x, lane = threadIdx.x;
+  const int pitch = c ? pp.c_pitch : pp.y_pitch, unit = c ? 2 : 4;
+  uint8_t* plane = plane_of(pp.recon, c);
+  const int16_t* res = pp.resid[c];
+  const IntraTu* tus = pp.intra[c];
+  const uint32_t* first = pp.intra_ctb_first[c];
+  uint32_t* progress = pp.progress + c * pp.height_ctb;
+  __shared__ int left[132], top[132], fl[132], ft[132], refbuf[3 * 32 + 8];
+  __shared__ int s_any;
+  for (int col = 0; col < pp.width_ctb; ++col) {
+    const int ctb = row * pp.width_ctb + col;
+    const uint32_t t0 = first[ctb], t1 = first[ctb + 1];
+    if (t1 > t0 && row > 0) {
+      const uint32_t need = static_cast<uint32_t>(col + 2 < pp.width_ctb ? col + 2 : pp.width_ctb);
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&progress[row - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > kIntraSpins) {
+          if (lane == 0) atomicExch(pp.fault, 1u);
+          return;
+        }
+      }
+    }
+    for (uint32_t ti = t0; ti < t1; ++ti) {
+      const IntraTu tu = tus[ti];
+      const int log2 = tu.log2, n = 1 << log2, x0 = tu.x, y0 = tu.y;
+      uint8_t* dst = plane + static_cast<size_t>(y0) * pitch + x0;
+      const int16_t* rs = res + static_cast<size_t>(y0) * pitch + x0;
+      if (tu.mode == kIntraPcm) {
+        for (int i = lane; i < n * n; i += 64) dst[static_cast<size_t>(i / n) * pitch + i % n] = static_cast<uint8_t>(clip8(rs[static_cast<size_t>(i / n) * pitch + i % n]));
+        continue;
+      }
+      const int mode = tu.mode;
+      // neighbours: -1 marks a sample that does not exist
+      for (int k = lane; k < 2 * n; k += 64) {
+        left[1 + k] = ((tu.avail_left >> (k / unit)) & 1) ? plane[static_cast<size_t>(y0 + k) * pitch + x0 - 1] : -1;
+        top[1 + k] = ((tu.avail_top >> (k / unit)) & 1) ? plane[static_cast<size_t>(y0 - 1) * pitch + x0 + k] : -1;
+      }
+      if (lane == 0) left[0] = (tu.flags & INTRA_CORNER) ? plane[static_cast<size_t>(y0 - 1) * pitch + x0 - 1] : -1;
+      __syncthreads();
+      if (lane == 0) {  // 8.4.4.2.2: substitution, serial by definition (each missing sample copies its predecessor)
+        int any = left[0] >= 0;
+        for (int k = 1; k <= 2 * n && !any; ++k) any = left[k] >= 0 || top[k] >= 0;
+        if (!any) {
+          for (int k = 0; k <= 2 * n; ++k) left[k] = top[k] = 128;
+        } else {
+          if (left[2 * n] < 0) {
+            int v = -1;
+            for (int k = 2 * n - 1; k >= 0 && v < 0; --k) v = left[k];
+            for (int k = 1; k <= 2 * n && v < 0; ++k) v = top[k];
+            left[2 * n] = v;
+          }
+          for (int k = 2 * n - 1; k >= 0; --k)
+            if (left[k] < 0) left[k] = left[k + 1];
+          top[0] = left[0];
+          for (int k = 1; k <= 2 * n; ++k)
+            if (top[k] < 0) top[k] = top[k - 1];
+        }
+        top[0] = left[0];
+        // 8.4.4.2.3: which smoothing, if any
+        int filt = 0;
+        if (c == 0 && mode != 1 && n != 4) {
+          const int a = iabs(mode - 26), b = iabs(mode - 10);
+          const int dist = a < b ? a : b, thres = n == 8 ? 7 : n == 16 ? 1 : 0;
+          if (dist > thres) {
+            filt = 1;
+            if ((tu.flags & INTRA_STRONG) && n == 32 && iabs(left[0] + top[64] - 2 * top[32]) < 8 && iabs(left[0] + left[64] - 2 * left[32]) < 8) filt = 2;
+          }
+        }
+        s_any = filt;
+      }
+      __syncthreads();
+      const int filt = s_any;
+      const int* L = left;
+      const int* T = top;
+      if (filt) {
+        for (int k = lane; k <= 2 * n; k += 64) {
+          if (filt == 2) {
+            fl[k] = (k == 0 || k == 64) ? left[k] : ((64 - k) * left[0] + k * left[64] + 32) >> 6;
+            ft[k] = (k == 0 || k == 64) ? top[k] : ((64 - k) * top[0] + k * top[64] + 32) >> 6;
+          } else if (k == 0) {
+            fl[0] = ft[0] = (left[1] + 2 * left[0] + top[1] + 2) >> 2;
+          } else if (k == 2 * n) {
+            fl[k] = left[k];
+            ft[k] = top[k];
+          } else {
+            fl[k] = (left[k + 1] + 2 * left[k] + left[k - 1] + 2) >> 2;
+            ft[k] = (top[k + 1] + 2 * top[k] + top[k - 1] + 2) >> 2;
+          }
+        }
+        __syncthreads();
+        L = fl;
+        T = ft;
+      }
+      // angular modes: the extended main reference, ref[-n .. 2n] at refbuf[32 + 1 + k]
+      int* ref = refbuf + 33;
+      const int angle = mode >= 2 ? kAngle[mode] : 0;
+      const bool vertical = mode >= 18;
+      if (mode >= 2) {
+        const int* mainr = vertical ? T : L;
+        const int* side = vertical ? L : T;
+        const int last = (n * angle) >> 5;
+        for (int k = lane - 32; k <= 2 * n; k += 64) {
+          if (k >= 0) {
+            if (k <= n || angle >= 0) ref[k] = mainr[k];
+          } else if (angle < 0 && last < -1 && k >= last) {
+            ref[k] = side[(k * kInvAngle[mode - 11] + 128) >> 8];
+          }
+        }
+        __syncthreads();
+      }
+      for (int i = lane; i < n * n; i += 64) {
+        const int x = i % n, y = i / n;
+        int v;
+        if (mode == 0) {
+          v = ((n - 1 - x) * L[1 + y] + (x + 1) * T[1 + n] + (n - 1 - y) * T[1 + x] + (y + 1) * L[1 + n] + n) >> (log2 + 1);
+        } else if (mode == 1) {
+          int sum = n;
+          for (int k = 0; k < n; ++k) sum += L[1 + k] + T[1 + k];
+          const int dc = sum >> (log2 + 1);
+          v = dc;
+          if (c == 0 && n < 32) {
+            if (x == 0 && y == 0) v = (L[1] + 2 * dc + T[1] + 2) >> 2;
+            else if (y == 0) v = (T[1 + x] + 3 * dc + 2) >> 2;
+            else if (x == 0) v = (L[1 + y] + 3 * dc + 2) >> 2;
+          }
+        } else {
+          const int j = vertical ? y : x, ii = vertical ? x : y;  // j: distance from the main reference
+          const int idx = ((j + 1) * angle) >> 5, fact = ((j + 1) * angle) & 31;
+          v = fact ? ((32 - fact) * ref[ii + idx + 1] + fact * ref[ii + idx + 2] + 16) >> 5 : ref[ii + idx + 1];
+          if (c == 0 && n < 32) {
+            if (mode == 26 && x == 0) v = clip8(T[1] + ((L[1 + y] - L[0]) >> 1));
+            if (mode == 10 && y == 0) v = clip8(L[1] + ((T[1 + x] - T[0]) >> 1));
+          }
+        }
+        dst[static_cast<size_t>(y) * pitch + x] = static_cast<uint8_t>(clip8(v + rs[static_cast<size_t>(y) * pitch + x]));
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+    // this block of the row is final as far as later rows are concerned
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&progress[row], static_cast<uint32_t>(col + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// -------------------------------------------------------------------------------------------------- deblocking
+__device__ void luma_segment(uint8_t* q0, int across, int along, int beta, int tc, bool no_p, bool no_q) {
+#define P(k, l) q0[-((k) + 1) * across + (l) * along]
+#define Q(k, l) q0[(k) * across + (l) * along]
+  const int dp0 = iabs(P(2, 0) - 2 * P(1, 0) + P(0, 0)), dp3 = iabs(P(2, 3) - 2 * P(1, 3) + P(0, 3));
+  const int dq0 = iabs(Q(2, 0) - 2 * Q(1, 0) + Q(0, 0)), dq3 = iabs(Q(2, 3) - 2 * Q(1, 3) + Q(0, 3));
+  if (dp0 + dq0 + dp3 + dq3 >= beta) return;
+  const bool s0 = 2 * (dp0 + dq0) < (beta >> 2) && iabs(P(3, 0) - P(0, 0)) + iabs(Q(0, 0) - Q(3, 0)) < (beta >> 3) && iabs(P(0, 0) - Q(0, 0)) < ((5 * tc + 1) >> 1);
+  const bool s3 = 2 * (dp3 + dq3) < (beta >> 2) && iabs(P(3, 3) - P(0, 3)) + iabs(Q(0, 3) - Q(3, 3)) < (beta >> 3) && iabs(P(0, 3) - Q(0, 3)) < ((5 * tc + 1) >> 1);
+  const bool strong = s0 && s3;
+  const int side = (beta + (beta >> 1)) >> 3;
+  const bool dep = dp0 + dp3 < side, deq = dq0 + dq3 < side;
+  for (int l = 0; l < 4; ++l) {
+    const int p0 = P(0, l), p1 = P(1, l), p2 = P(2, l), p3 = P(3, l), q0v = Q(0, l), q1 = Q(1, l), q2 = Q(2, l), q3 = Q(3, l);
+    if (strong) {
+      if (!no_p) {
+        P(0, l) = static_cast<uint8_t>(clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0v + q1 + 4) >> 3));
+        P(1, l) = static_cast<uint8_t>(clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0v + 2) >> 2));
+        P(2, l) = static_cast<uint8_t>(clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0v + 4) >> 3));
+      }
+      if (!no_q) {
+        Q(0, l) = static_cast<uint8_t>(clip3(q0v - 2 * tc, q0v + 2 * tc, (p1 + 2 * p0 + 2 * q0v + 2 * q1 + q2 + 4) >> 3));
+        Q(1, l) = static_cast<uint8_t>(clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0v + q1 + q2 + 2) >> 2));
+        Q(2, l) = static_cast<uint8_t>(clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0v + q1 + 3 * q2 + 2 * q3 + 4) >> 3));
+      }
+    } else {
+      int delta = (9 * (q0v - p0) - 3 * (q1 - p1) + 8) >> 4;
+      if (iabs(delta) >= tc * 10) continue;
+      delta = clip3(-tc, tc, delta);
+      if (!no_p) {
+        P(0, l) = static_cast<uint8_t>(clip8(p0 + delta));
+        if (dep) P(1, l) = static_cast<uint8_t>(clip8(p1 + clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1)));
+      }
+      if (!no_q) {
+        Q(0, l) = static_cast<uint8_t>(clip8(q0v - delta));
+        if (deq) Q(1, l) = static_cast<uint8_t>(clip8(q1 + clip3(-(tc >> 1), tc >> 1, (((q2 + q0v + 1) >> 1) - q1 - delta) >> 1)));
+      }
+    }
+  }
+#undef P
+#undef Q
+}
+
+__global__ __launch_bounds__(256) void k_hevc_deblock(const PicParams* __restrict__ ppp, int dir) {
+  const PicParams& pp = *ppp;
+  const int w4 = pp.width >> 2, h4 = pp.height >> 2;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= w4 * h4) return;
+  const int x = i % w4, y = i / w4;
+  const EdgeInfo e = pp.edges[i];
+  const int bs = dir ? (e.bs >> 2) & 3 : e.bs & 3;
+  if (!bs) return;
+  const EdgeInfo p = pp.edges[dir ? i - w4 : i - 1];
+  const SliceLoop sl = pp.slices[e.slice];
+  const int qpl = (e.qp + p.qp + 1) >> 1;
+  const bool no_p = p.flags & 1, no_q = e.flags & 1;
+  {
+    const int beta = kBeta[clip3(0, 51, qpl + sl.beta_offset)];
+    const int tc = kTc[clip3(0, 53, qpl + 2 * (bs - 1) + sl.tc_offset)];
+    uint8_t* q0 = pp.recon.y + static_cast<size_t>(y * 4) * pp.y_pitch + x * 4;
+    luma_segment(q0, dir ? pp.y_pitch : 1, dir ? 1 : pp.y_pitch, beta, tc, no_p, no_q);
+  }
+  if (bs == 2 && !((dir ? y : x) & 3)) {
+    for (int c = 1; c < 3; ++c) {
+      const int qpi = qpl + (c == 1 ? pp.cb_qp_offset : pp.cr_qp_offset);
+      const int qpc = qpi < 30 ? qpi : qpi >= 43 ? qpi - 6 : kQpc[qpi - 30];
+      const int tc = kTc[clip3(0, 53, qpc + 2 + sl.tc_offset)];
+      uint8_t* q0 = plane_of(pp.recon, c) + static_cast<size_t>(y * 2) * pp.c_pitch + x * 2;
+      const int across = dir ? pp.c_pitch : 1, along = dir ? 1 : pp.c_pitch;
+      for (int l = 0; l < 2; ++l) {
+        uint8_t* q = q0 + l * along;
+        const int p0 = q[-across], p1 = q[-2 * across], q0v = q[0], q1 = q[across];
+        const int delta = clip3(-tc, tc, (((q0v - p0) << 2) + p1 - q1 + 4) >> 3);
+        if (!no_p) q[-across] = static_cast<uint8_t>(clip8(p0 + delta));
+        if (!no_q) q[0] = static_cast<uint8_t>(clip8(q0v - delta));
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------------- SAO
+__global__ __launch_bounds__(256) void k_hevc_sao(const PicParams* __restrict__ ppp) {
+  const PicParams& pp = *ppp;
+  const int c = blockIdx.z, sub = c ? 1 : 0;
+  const int pw = pp.width >> sub, ph = pp.height >> sub, pitch = c ? pp.c_pitch : pp.y_pitch;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= pw || y >= ph) return;
+  const uint8_t* src = plane_of(pp.recon, c);
+  uint8_t* dst = plane_of(pp.dst, c);
+  const int w4 = pp.width >> 2;
+  const int xl = x << sub, yl = y << sub;
+  const int ctb = (yl >> pp.log2_ctb) * pp.width_ctb + (xl >> pp.log2_ctb);
+  const SaoCtb p = pp.sao[ctb];
+  const EdgeInfo e = pp.edges[(yl >> 2) * w4 + (xl >> 2)];
+  const SliceLoop sl = pp.slices[e.slice];
+  const int v = src[static_cast<size_t>(y) * pitch + x];
+  int out = v;
+  const int type = (c ? sl.sao_chroma : sl.sao_luma) ? p.type[c] : 0;
+  if (type && !(e.flags & 1)) {
+    int idx = 0;
+    if (type == 1) {
+      const int k = ((v >> 3) - p.band_pos[c]) & 31;
+      idx = k < 4 ? k + 1 : 0;
+    } else {
+      const int cl = p.eo_class[c];
+      const int dx = cl == 1 ? 0 : cl == 3 ? -1 : 1, dy = cl == 0 ? 0 : 1;  // the second neighbour; the first is its mirror image
+      const int xa = x - dx, ya = y - dy, xb = x + dx, yb = y + dy;
+      bool ok = xa >= 0 && xb >= 0 && xa < pw && xb < pw && ya >= 0 && yb < ph;
+      if (ok) {
+        const EdgeInfo ea = pp.edges[((ya << sub) >> 2) * w4 + ((xa << sub) >> 2)], eb = pp.edges[((yb << sub) >> 2) * w4 + ((xb << sub) >> 2)];
+        // across a slice boundary the later slice's flag decides
+        if (ea.slice != e.slice) ok = ok && (pp.slices[ea.slice].first_ctb > sl.first_ctb ? pp.slices[ea.slice].across : sl.across);
+        if (eb.slice != e.slice) ok = ok && (pp.slices[eb.slice].first_ctb > sl.first_ctb ? pp.slices[eb.slice].across : sl.across);
+      }
+      if (ok) {
+        const int a = src[static_cast<size_t>(ya) * pitch + xa], b = src[static_cast<size_t>(yb) * pitch + xb];
+        const int s = (v > a) - (v < a) + (v > b) - (v < b);
+        idx = s == -2 ? 1 : s == -1 ? 2 : s == 1 ? 3 : s == 2 ? 4 : 0;
+      }
+    }
+    if (idx) out = clip8(v + p.offset[c][idx - 1]);
+  }
+  dst[static_cast<size_t>(y) * pitch + x] = static_cast<uint8_t>(out);
+}
+
+}  // namespace
+
+namespace hwang {
+namespace amd {
+namespace hevc {
+
+// One picture's kernels on `stream`, in order.  `pp_dev` is the device copy of `pp` (already in the stream's past).
+hipError_t launch_picture(const PicParams& pp, const PicParams* pp_dev, hipStream_t stream) {
+  if (pp.num_res) hipLaunchKernelGGL(k_hevc_residual, dim3((pp.num_res + kResWaves - 1) / kResWaves), dim3(64 * kResWaves), 0, stream, pp_dev);
+  if (pp.num_pu) hipLaunchKernelGGL(k_hevc_inter, dim3(pp.num_pu), dim3(256), 0, stream, pp_dev);
+  if (pp.num_intra[0] || pp.num_intra[1] || pp.num_intra[2]) hipLaunchKernelGGL(k_hevc_intra, dim3(pp.height_ctb, 3), dim3(64), 0, stream, pp_dev);
+  if (pp.deblock_enabled) {
+    const int units = (pp.width >> 2) * (pp.height >> 2);
+    hipLaunchKernelGGL(k_hevc_deblock, dim3((units + 255) / 256), dim3(256), 0, stream, pp_dev, 0);
+    hipLaunchKernelGGL(k_hevc_deblock, dim3((units + 255) / 256), dim3(256), 0, stream, pp_dev, 1);
+  }
+  if (pp.sao_enabled) hipLaunchKernelGGL(k_hevc_sao, dim3((pp.width + 255) / 256, pp.height, 3), dim3(256), 0, stream, pp_dev);
+  return hipGetLastError();
+}
+
+}  // namespace hevc
+}  // namespace amd
+}  // namespace hwang

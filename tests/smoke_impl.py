@@ -47,3 +47,21 @@ def run():
         assert st["pictures_reconstructed"] > 0
     print("smoke: sparse decode of %d rows bit-exact vs oracle (%d pictures reconstructed on the GPU)"
           % (len(rows), st["pictures_reconstructed"]))
+
+    # HEVC: a small I / P / B clip with SAO through the same entry points, against the HEVC oracle
+    from tests.corpus_util import make_hevc_clip
+    with tempfile.TemporaryDirectory() as tmp:
+        path = tmp + "/smoke_hevc.mp4"
+        make_hevc_clip(path, width=176, height=144, yuv=False, frames=9, gop=9, bframes=2, refs=2, sao=1, ctb=32)
+        index = hwang_amd.index_video(path)
+        frames, ctr = oracle_py.decode_file_hevc(path, index)
+        assert ctr["md5_mismatch"] == 0 and ctr["md5_checked"] == 9
+        rows = [0, 2, 3, 8]
+        dec = hwang_amd.Decoder(path, video_index=index, num_lanes=2)
+        yuv = dec.retrieve_yuv(rows)
+        rgb = dec.retrieve(rows)
+        for k, r in enumerate(rows):
+            buf, w, h, _ = frames[r]
+            assert np.array_equal(yuv[k], buf), "HEVC frame %d: I420 != oracle" % r
+            assert np.array_equal(rgb[k], oracle_py.i420_to_rgb(buf, w, h)), "HEVC frame %d: RGB != oracle" % r
+    print("smoke: HEVC sparse decode of %d rows bit-exact vs the HEVC oracle" % len(rows))

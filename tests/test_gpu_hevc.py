@@ -1,0 +1,83 @@
+"""-m gpu: HEVC through the C ABI - host parser + k_hevc.hip - against the corpus encoder's
+reconstruction, which the CPU oracle reproduces (tests/test_hevc_corpus.py).  The bar is bit-exact I420 and bit-exact
+RGB against the oracle's statement of the colour conversion.  HEVC parity with FFmpeg is unpinned (no HEVC decoder or
+foreign stream exists on either machine): what these tests pin is the HIP path against the oracle."""
+import numpy as np
+import pytest
+
+from tests.corpus_util import HEVC_MATRIX, make_hevc_clip
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no fallback"
+    return torch
+
+
+@pytest.mark.parametrize("name,kw", HEVC_MATRIX, ids=[m[0] for m in HEVC_MATRIX])
+def test_all_frames_bit_exact(hw, oracle, gpu, tmp_path, name, kw):
+    kw = dict(kw)
+    w, h = kw.pop("width", 128), kw.pop("height", 96)
+    path = str(tmp_path / (name + ".mp4"))
+    gold = make_hevc_clip(path, width=w, height=h, **kw)
+    idx = hw.index_video(path)
+    assert idx.format() in ("hev1", "hvc1")
+    dec = hw.Decoder(path, video_index=idx, num_lanes=2)
+    got = dec.retrieve_yuv(list(range(idx.frames())))
+    assert len(got) == len(gold)
+    for i in range(len(gold)):
+        assert np.array_equal(got[i], gold[i]), "%s: frame %d differs from the oracle / encoder reconstruction" % (name, i)
+
+
+def test_sparse_rows_rgb_and_the_reference_api(hw, oracle, gpu, tmp_path):
+    """Decoder.retrieve(rows): k-th array == frame rows[k] of a sequential decode (GatherFramesComparison's invariant,
+    decoder_automata_test.cpp:262-342 - the reference's only enabled test runs it on an HEVC clip, :160-161), RGB;
+    unwanted non-reference pictures are not reconstructed; the same through one DecoderAutomata (retrieve_serial) and
+    through the pybind11 module's hwang.Decoder."""
+    path = str(tmp_path / "sparse.mp4")
+    gold = make_hevc_clip(path, width=176, height=144, frames=48, gop=12, bframes=2, refs=2, sao=1, ctb=32)
+    idx = hw.index_video(path)
+    rows = [0, 1, 5, 11, 12, 13, 30, 35, 47]
+    dec = hw.Decoder(path, video_index=idx, num_lanes=3)
+    got = dec.retrieve(rows)
+    st = dec.stats()
+    assert st["frames_returned"] == len(rows) and st["pictures_skipped"] > 0
+    for k, r in enumerate(rows):
+        assert got[k].shape == (144, 176, 3)
+        assert np.array_equal(got[k], oracle.i420_to_rgb(gold[r], 176, 144)), "row %d" % r
+    serial = dec.retrieve_serial(rows)
+    for k in range(len(rows)):
+        assert np.array_equal(serial[k], got[k]), "automata path, row %d" % rows[k]
+    import hwang
+    ref = hwang.Decoder(path, device_type=hwang.DeviceType.GPU).retrieve(rows)
+    for k in range(len(rows)):
+        assert np.array_equal(ref[k], got[k]), "hwang.Decoder, row %d" % rows[k]
+
+
+def test_1080p_and_cropping(hw, oracle, gpu, tmp_path):
+    """1920x1080 (coded 1920x1080: a multiple of 8, the last row of 64x64 blocks is cut at 56 rows), CTB 64, B pictures."""
+    path = str(tmp_path / "hd.mp4")
+    gold = make_hevc_clip(path, width=1920, height=1080, frames=4, gop=4, bframes=1, refs=2, ctb=64, sao=1, sdh=1, amp=1, qp=32)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+    got = dec.retrieve_yuv([0, 1, 2, 3])
+    for i in range(4):
+        assert np.array_equal(got[i], gold[i]), "frame %d" % i
+
+
+def test_h264_after_hevc_on_one_decoder_object(hw, oracle, gpu, tmp_path):
+    """configure() switches halves: the same automata decodes an HEVC clip, then an H.264 clip, then HEVC again."""
+    from tests.corpus_util import make_clip
+    p5 = str(tmp_path / "a.mp4")
+    p4 = str(tmp_path / "b.mp4")
+    g5 = make_hevc_clip(p5, frames=6, gop=6, bframes=1)
+    g4 = make_clip(p4, width=128, height=96, frames=6, gop=6, bframes=1)
+    for path, gold in ((p5, g5), (p4, g4), (p5, g5)):
+        idx = hw.index_video(path)
+        dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+        got = dec.retrieve_yuv([0, 2, 5])
+        for k, r in enumerate([0, 2, 5]):
+            assert np.array_equal(got[k], gold[r])

@@ -1,0 +1,68 @@
+"""The product's HOST half of the HEVC path (hwang_amd/csrc/hevc/hevc_parser.cpp: CABAC, candidate derivation, DPB,
+output order, the records of amd/hevc_frame_job.h) without a GPU: tests/fixtures/hevc_records_cpu.cpp links the parser
+with a sink that interprets its records with scalar loops (a test fixture; nothing of it is in libhwang_amd.so) and
+the result must be the corpus encoder's reconstruction, frame for frame.  What k_hevc.hip makes of the same records
+is tests/test_gpu_hevc.py's business."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.corpus_util import HEVC_MATRIX, make_hevc_clip
+from tests.util import ROOT
+
+EXE = os.path.join(ROOT, "tests", "_build", "hevc_records_cpu")
+
+
+@pytest.fixture(scope="module")
+def records_cpu(built):
+    src = [os.path.join(ROOT, "tests", "fixtures", "hevc_records_cpu.cpp"), os.path.join(ROOT, "hwang_amd", "csrc", "hevc", "hevc_parser.cpp")]
+    deps = src + [os.path.join(ROOT, "hwang_amd", "csrc", "hevc", "hevc_parser.h"), os.path.join(ROOT, "hwang_amd", "csrc", "amd", "hevc_frame_job.h"),
+                  os.path.join(ROOT, "hwang_amd", "csrc", "hevc", "hevc_tables.h")]
+    if not os.path.exists(EXE) or any(os.path.getmtime(EXE) < os.path.getmtime(d) for d in deps):
+        os.makedirs(os.path.dirname(EXE), exist_ok=True)
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-o", EXE] + src)
+    return EXE
+
+
+def run_host(exe, hw, path, tmp_path, wanted=()):
+    idx = hw.index_video(path)
+    offs, sizes = idx.sample_offsets(), idx.sample_sizes()
+    data = open(path, "rb").read()
+    (tmp_path / "hvcc").write_bytes(bytes(idx.metadata_bytes()))
+    (tmp_path / "blob").write_bytes(b"".join(data[o:o + s] for o, s in zip(offs, sizes)))
+    (tmp_path / "sizes").write_text("\n".join(str(s) for s in sizes))
+    r = subprocess.run([exe, str(tmp_path / "hvcc"), str(tmp_path / "blob"), str(tmp_path / "sizes"), str(tmp_path / "out.yuv")] +
+                       [str(w) for w in wanted], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr[-1000:]
+    info = dict(kv.split("=") for kv in r.stdout.split())
+    return np.fromfile(str(tmp_path / "out.yuv"), dtype=np.uint8), {k: int(v) for k, v in info.items()}
+
+
+@pytest.mark.parametrize("name,kw", HEVC_MATRIX, ids=[m[0] for m in HEVC_MATRIX])
+def test_host_parser_records_reproduce_the_clip(records_cpu, hw, tmp_path, name, kw):
+    kw = dict(kw)
+    w, h = kw.pop("width", 128), kw.pop("height", 96)
+    path = str(tmp_path / (name + ".mp4"))
+    gold = make_hevc_clip(path, width=w, height=h, **kw)
+    got, info = run_host(records_cpu, hw, path, tmp_path)
+    got = got.reshape(-1, gold.shape[1])
+    assert len(got) == len(gold) == info["frames"] and info["skipped_positions"] == 0
+    for i in range(len(gold)):
+        assert np.array_equal(got[i], gold[i]), "%s: frame %d" % (name, i)
+
+
+def test_sparse_hint_skips_only_pictures_nothing_refers_to(records_cpu, hw, tmp_path):
+    path = str(tmp_path / "c.mp4")
+    gold = make_hevc_clip(path, frames=13, gop=13, bframes=3, bpyramid=1, refs=4)
+    wanted = [0, 2, 6, 9, 12]      # 2 is a reference B picture (the middle of 1..3), 6 and 9 are not
+    got, info = run_host(records_cpu, hw, path, tmp_path, wanted=wanted)
+    got = got.reshape(-1, gold.shape[1])
+    assert len(got) == 13 and info["skipped"] > 0 and info["skipped"] == info["skipped_positions"]
+    assert info["decoded"] + info["skipped"] == 13
+    for r in wanted:
+        assert np.array_equal(got[r], gold[r]), "wanted row %d" % r
+    # whatever was decoded although unwanted is right too; the skipped positions are the zero frames
+    for r in range(13):
+        assert np.array_equal(got[r], gold[r]) or not got[r].any()
