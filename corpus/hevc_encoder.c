@@ -769,6 +769,20 @@ static void analyse_intra(Enc* e, HvCu* cu) {
 /* ---- inter unit ---- */
 static int pu_luma_sad(Enc* e, const HvPu* pu, const HvMv* mv) {
   HevcOracle* d = e->d;
+  if (mv->pred_flag != 3) { /* one list, whole-sample vector: no interpolation to do */
+    const int l = (mv->pred_flag & 1) ? 0 : 1;
+    if (!((mv->mv[l][0] | mv->mv[l][1]) & 3)) {
+      const uint8_t* ref = d->ref_list[l][mv->ref_idx[l]]->plane[0];
+      const uint8_t* src = e->scene.plane[0];
+      const int dx = mv->mv[l][0] >> 2, dy = mv->mv[l][1] >> 2;
+      int sad = 0;
+      for (int y = pu->y; y < pu->y + pu->h; ++y) {
+        const uint8_t* row = ref + hv_clip3(0, e->ch - 1, y + dy) * e->cw;
+        for (int x = pu->x; x < pu->x + pu->w; ++x) sad += hv_abs(src[y * e->cw + x] - row[hv_clip3(0, e->cw - 1, x + dx)]);
+      }
+      return sad;
+    }
+  }
   static int16_t t[2][64 * 64];
   const int n = pu->w * pu->h;
   for (int l = 0; l < 2; ++l)

@@ -131,6 +131,7 @@ PROTOTYPES = {
     "hwang_h264_probe_workers": (C.c_int, [vp, C.c_size_t, vp, u64p, u64p, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, C.c_int,
                                            i64p, C.c_char_p, C.c_size_t]),
     "hwang_hevc_describe_config": (C.c_int, [vp, C.c_size_t, C.c_char_p, C.c_size_t]),
+    "hwang_hevc_run_test_picture": (C.c_int, [vp, C.c_char_p, C.c_size_t]),
     # profiling
     "hwang_prof_enable": (None, [C.c_int]),
     "hwang_prof_num_kernels": (C.c_int, []),

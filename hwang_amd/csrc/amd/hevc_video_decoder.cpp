@@ -9,12 +9,16 @@
 
 #include "../hevc/hevc_parser.h"
 #include "../sparse_hints.h"
+#include "../../../include/hwang_amd.h"
 #include "hevc_frame_job.h"
 #include "hip_check.h"
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -77,7 +81,13 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (!parser_) return Result(false, "AMDVideoDecoder::feed before configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
     ++counters_.samples_fed;
-    if (!parser_->decode(data, size)) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int64_t stall0 = counters_.stall_ns, submit0 = submit_ns_;
+    const bool ok = parser_->decode(data, size);
+    // (entropy_ns: the host parser alone - waits for a staging set and the submission of the picture taken out)
+    counters_.entropy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() -
+                            (counters_.stall_ns - stall0) - (submit_ns_ - submit0);
+    if (!ok) {
       const std::string why = parser_->error();
       return Result(false, "AMDVideoDecoder::feed (HEVC): " + why);
     }
@@ -139,10 +149,12 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (!ensure_geometry(s, error)) return false;
     Set& set = sets_[next_set_];
     if (set.busy) {
+      const auto t0 = std::chrono::steady_clock::now();
       if (hipEventSynchronize(set.done) != hipSuccess) {
         *error = "hipEventSynchronize failed";
         return false;
       }
+      counters_.stall_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
       set.busy = false;
     }
     int slot = -1;
@@ -190,6 +202,11 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   }
 
   bool end_picture(const hevc::PicDone& d, std::string* error) override {
+    struct Timer {
+      int64_t* acc;
+      std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      ~Timer() { *acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+    } timer{&submit_ns_};
     Set& set = *static_cast<Set*>(d.cookie);
     gh::PicParams pp;
     std::memset(&pp, 0, sizeof(pp));
@@ -479,11 +496,124 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   uint32_t* fault_host_ = nullptr;
   uint32_t* fault_dev_ = nullptr;
   BackendCounters counters_;
+  int64_t submit_ns_ = 0;
   int64_t bytes_uploaded_ = 0, folded_decoded_ = 0, folded_skipped_ = 0, decoded_base_ = 0, skipped_base_ = 0;
 };
 
 }  // namespace
 
 HevcDelegate* make_hevc_delegate(int device_id) { return new HEVCVideoDecoder(device_id); }
+
+}  // namespace hwang
+
+// C ABI test hook (include/hwang_amd.h: hwang_hevc_test_picture): one picture's worth of hand-made records through
+// k_hevc.hip, so that the kernels can be compared with the numpy statements of tests/hevc_numpy.py block by block
+// (tests/test_gpu_hevc_kernels.py) - without a stream, a parser or the oracle in between.
+extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, char* error, size_t error_capacity) {
+  using namespace hwang;
+  namespace gh = amd::hevc;
+  auto fail = [&](const char* what) {
+    if (error && error_capacity) snprintf(error, error_capacity, "%s", what);
+    return 1;
+  };
+  if (!t || t->width <= 0 || t->height <= 0 || (t->width & 7) || (t->height & 7) || t->num_refs < 0 || t->num_refs >= gh::kMaxSurfaces - 2) return fail("bad geometry");
+  const int W = t->width, H = t->height, pitch = (W + 255) & ~255;
+  const size_t surf_bytes = static_cast<size_t>(pitch) * H * 3 / 2;
+  const int wctb = (W + (1 << t->log2_ctb) - 1) >> t->log2_ctb, hctb = (H + (1 << t->log2_ctb) - 1) >> t->log2_ctb;
+  const size_t ctbs = static_cast<size_t>(wctb) * hctb, w4h4 = static_cast<size_t>(W / 4) * (H / 4);
+  std::vector<void*> owned;
+  auto dev = [&](size_t bytes, const void* src) -> uint8_t* {
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    owned.push_back(p);
+    if (src && bytes && hipMemcpy(p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (!src && hipMemset(p, 0, bytes ? bytes : 16) != hipSuccess) return nullptr;
+    return static_cast<uint8_t*>(p);
+  };
+  auto cleanup = [&] {
+    for (void* p : owned) (void)hipFree(p);
+  };
+  auto upload_surface = [&](const uint8_t* i420) -> uint8_t* {
+    uint8_t* d = dev(surf_bytes, nullptr);
+    if (!d || !i420) return d;
+    bool ok = hipMemcpy2D(d, static_cast<size_t>(pitch), i420, static_cast<size_t>(W), static_cast<size_t>(W), static_cast<size_t>(H), hipMemcpyHostToDevice) == hipSuccess;
+    const uint8_t* u = i420 + static_cast<size_t>(W) * H;
+    uint8_t* du = d + static_cast<size_t>(pitch) * H;
+    ok = ok && hipMemcpy2D(du, static_cast<size_t>(pitch / 2), u, static_cast<size_t>(W / 2), static_cast<size_t>(W / 2), static_cast<size_t>(H / 2), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy2D(du + static_cast<size_t>(pitch / 2) * (H / 2), static_cast<size_t>(pitch / 2), u + static_cast<size_t>(W / 2) * (H / 2), static_cast<size_t>(W / 2),
+                           static_cast<size_t>(W / 2), static_cast<size_t>(H / 2), hipMemcpyHostToDevice) == hipSuccess;
+    return ok ? d : nullptr;
+  };
+  auto surface_of = [&](uint8_t* base) {
+    gh::Surface s;
+    s.y = base;
+    s.u = base + static_cast<size_t>(pitch) * H;
+    s.v = s.u + static_cast<size_t>(pitch / 2) * (H / 2);
+    return s;
+  };
+  gh::PicParams pp;
+  std::memset(&pp, 0, sizeof(pp));
+  pp.width = W; pp.height = H; pp.y_pitch = pitch; pp.c_pitch = pitch / 2;
+  pp.log2_ctb = t->log2_ctb; pp.width_ctb = wctb; pp.height_ctb = hctb;
+  pp.cb_qp_offset = t->cb_qp_offset; pp.cr_qp_offset = t->cr_qp_offset;
+  pp.pcm_bits_luma = pp.pcm_bits_chroma = 8;
+  pp.num_res = t->num_res; pp.num_pu = t->num_pus;
+  for (int c = 0; c < 3; ++c) pp.num_intra[c] = t->num_intra[c];
+  pp.sao_enabled = t->sao_enabled; pp.deblock_enabled = t->deblock_enabled;
+  uint8_t* recon = upload_surface(t->recon_in);
+  uint8_t* dst = t->sao_enabled ? dev(surf_bytes, nullptr) : recon;
+  bool ok = recon && dst;
+  pp.recon = surface_of(recon);
+  pp.dst = surface_of(dst);
+  for (int r = 0; r < t->num_refs && ok; ++r) {
+    uint8_t* s = upload_surface(t->refs + static_cast<size_t>(r) * W * H * 3 / 2);
+    ok = s != nullptr;
+    pp.refs[r] = surface_of(s);
+  }
+  pp.res = reinterpret_cast<const gh::ResTu*>(dev(sizeof(gh::ResTu) * static_cast<size_t>(t->num_res), t->res));
+  pp.coefs = reinterpret_cast<const uint32_t*>(dev(sizeof(uint32_t) * static_cast<size_t>(t->num_coefs), t->coefs));
+  pp.pus = reinterpret_cast<const gh::InterPu*>(dev(sizeof(gh::InterPu) * static_cast<size_t>(t->num_pus), t->pus));
+  pp.weights = reinterpret_cast<const gh::WeightEntry*>(dev(sizeof(gh::WeightEntry) * static_cast<size_t>(t->num_weights), t->weights));
+  for (int c = 0; c < 3; ++c) {
+    pp.intra[c] = reinterpret_cast<const gh::IntraTu*>(dev(sizeof(gh::IntraTu) * static_cast<size_t>(t->num_intra[c]), t->intra[c]));
+    pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dev(sizeof(uint32_t) * (ctbs + 1), t->intra_first[c]));
+  }
+  pp.edges = reinterpret_cast<const gh::EdgeInfo*>(dev(sizeof(gh::EdgeInfo) * w4h4, t->edges));
+  pp.sao = reinterpret_cast<const gh::SaoCtb*>(dev(sizeof(gh::SaoCtb) * ctbs, t->sao));
+  pp.slices = reinterpret_cast<const gh::SliceLoop*>(dev(sizeof(gh::SliceLoop) * static_cast<size_t>(std::max(t->num_slices, 1)), t->slices));
+  pp.scaling = t->scaling ? dev(4064, t->scaling) : nullptr;
+  int16_t* resid = reinterpret_cast<int16_t*>(dev(surf_bytes * 2, nullptr));
+  pp.resid[0] = resid;
+  pp.resid[1] = resid + static_cast<size_t>(pitch) * H;
+  pp.resid[2] = pp.resid[1] + static_cast<size_t>(pitch / 2) * (H / 2);
+  pp.progress = reinterpret_cast<uint32_t*>(dev(sizeof(uint32_t) * 3 * static_cast<size_t>(hctb), nullptr));
+  pp.fault = reinterpret_cast<uint32_t*>(dev(sizeof(uint32_t), nullptr));
+  const gh::PicParams* pp_dev = reinterpret_cast<const gh::PicParams*>(dev(sizeof(pp), &pp));
+  ok = ok && pp.res && pp.coefs && pp.pus && pp.weights && pp.edges && pp.sao && pp.slices && resid && pp.progress && pp.fault && pp_dev;
+  if (ok) ok = gh::launch_picture(pp, pp_dev, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  uint32_t fault = 0;
+  if (ok) ok = hipMemcpy(&fault, pp.fault, sizeof(fault), hipMemcpyDeviceToHost) == hipSuccess;
+  if (ok && t->out) {
+    const gh::Surface s = pp.dst;
+    ok = hipMemcpy2D(t->out, static_cast<size_t>(W), s.y, static_cast<size_t>(pitch), static_cast<size_t>(W), static_cast<size_t>(H), hipMemcpyDeviceToHost) == hipSuccess;
+    uint8_t* ou = t->out + static_cast<size_t>(W) * H;
+    ok = ok && hipMemcpy2D(ou, static_cast<size_t>(W / 2), s.u, static_cast<size_t>(pitch / 2), static_cast<size_t>(W / 2), static_cast<size_t>(H / 2), hipMemcpyDeviceToHost) == hipSuccess;
+    ok = ok && hipMemcpy2D(ou + static_cast<size_t>(W / 2) * (H / 2), static_cast<size_t>(W / 2), s.v, static_cast<size_t>(pitch / 2), static_cast<size_t>(W / 2), static_cast<size_t>(H / 2),
+                           hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  if (ok && t->resid_out) {  // the three residual planes, w x h and (w/2) x (h/2) x 2, int16
+    int16_t* o = t->resid_out;
+    ok = hipMemcpy2D(o, static_cast<size_t>(W) * 2, pp.resid[0], static_cast<size_t>(pitch) * 2, static_cast<size_t>(W) * 2, static_cast<size_t>(H), hipMemcpyDeviceToHost) == hipSuccess;
+    o += static_cast<size_t>(W) * H;
+    for (int c = 1; c < 3 && ok; ++c, o += static_cast<size_t>(W / 2) * (H / 2))
+      ok = hipMemcpy2D(o, static_cast<size_t>(W / 2) * 2, pp.resid[c], static_cast<size_t>(pitch / 2) * 2, static_cast<size_t>(W / 2) * 2, static_cast<size_t>(H / 2), hipMemcpyDeviceToHost) == hipSuccess;
+  }
+  cleanup();
+  if (!ok) return fail("a HIP call failed (out of memory, or no GPU)");
+  if (fault) return fail("the intra wavefront timed out");
+  return 0;
+}
+
+namespace hwang {
 
 }  // namespace hwang

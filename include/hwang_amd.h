@@ -328,6 +328,35 @@ int hwang_h264_probe_workers(const uint8_t* avcc, size_t avcc_size, const uint8_
  * is wrong with the record in `out`. */
 int hwang_hevc_describe_config(const uint8_t* hvcc, size_t size, char* out, size_t capacity);
 
+/* -- HEVC kernel test hook -----------------------------------------------------
+ * One picture's worth of hand-made records (hwang_amd/csrc/amd/hevc_frame_job.h: the seam between the host parser and
+ * k_hevc.hip) through the HEVC kernels on the current device: residual -> inter -> intra -> deblocking -> SAO, as the
+ * backend launches them for a decoded picture.  The test suite drives it with records built in numpy and compares
+ * the result with numpy statements of H.265 8.4 - 8.7 (tests/test_gpu_hevc_kernels.py): the HEVC counterpart of the
+ * reference having no kernel of its own to test (its HEVC arithmetic is libavcodec's,
+ * impls/software/software_video_decoder.cpp:128-132).  Record arrays are in the layouts of hevc_frame_job.h. */
+typedef struct hwang_hevc_test_picture {
+  int32_t width, height, log2_ctb;  /* coded size, multiples of 8 */
+  int32_t cb_qp_offset, cr_qp_offset, sao_enabled, deblock_enabled;
+  const uint8_t* recon_in;          /* I420 (w*h*3/2): what the reconstruction surface holds before the kernels run */
+  const uint8_t* refs;              /* num_refs I420 pictures back to back: reference surfaces 0 .. num_refs - 1 */
+  int32_t num_refs;
+  int32_t num_res, num_coefs, num_pus, num_weights, num_intra[3], num_slices;
+  const void* res;                  /* ResTu[num_res] */
+  const uint32_t* coefs;            /* level stream */
+  const void* pus;                  /* InterPu[num_pus] */
+  const void* weights;              /* WeightEntry[num_weights] */
+  const void* intra[3];             /* IntraTu[num_intra[c]] per plane */
+  const uint32_t* intra_first[3];   /* per plane: coding tree blocks + 1 offsets */
+  const void* edges;                /* EdgeInfo[(w/4)*(h/4)] */
+  const void* sao;                  /* SaoCtb[coding tree blocks] */
+  const void* slices;               /* SliceLoop[num_slices] */
+  const uint8_t* scaling;           /* 4064 bytes or NULL */
+  uint8_t* out;                     /* I420 result */
+  int16_t* resid_out;               /* optional: the residual planes (w*h + 2*(w/2)*(h/2) int16) */
+} hwang_hevc_test_picture;
+int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, char* error, size_t error_capacity);
+
 /* -- Profiling hooks ---------------------------------------------------------
  * When enabled, every kernel launch of the backend is bracketed with HIP
  * events on its own stream; hwang_prof_read drains the accumulated

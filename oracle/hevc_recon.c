@@ -154,32 +154,40 @@ void hevco_intra_block(const uint8_t* corner_and_left, const uint8_t* top_in, in
 /* ------------------------------------------------------------------------------------------------ inter, 8.5.3.3 */
 static inline int ref_sample(const uint8_t* ref, int w, int h, int x, int y) { return ref[hv_clip3(0, h - 1, y) * w + hv_clip3(0, w - 1, x)]; }
 
-/* one block of prediction samples at 14-bit precision (predSamplesLX) */
+/* one block of prediction samples at 14-bit precision (predSamplesLX, 8.5.3.3.3): rows of the reference are fetched
+ * once, clamped to the picture (the padding of 8.5.3.3.3.1), filtered horizontally at full precision (shift1 = 0 at
+ * 8 bits), then vertically */
 void hv_interp_block(const uint8_t* ref, int rw, int rh, int chroma, int x, int y, int w, int h, int mvx, int mvy, int16_t* out) {
   const int fbits = chroma ? 3 : 2, taps = chroma ? 4 : 8, before = chroma ? 1 : 3;
   const int xf = mvx & ((1 << fbits) - 1), yf = mvy & ((1 << fbits) - 1);
   const int xi = x + (mvx >> fbits), yi = y + (mvy >> fbits);
   const int8_t* fx = chroma ? hevc_chroma_filter[xf] : hevc_luma_filter[xf];
   const int8_t* fy = chroma ? hevc_chroma_filter[yf] : hevc_luma_filter[yf];
+  static int hor[(64 + 7) * 64];
+  int row[64 + 8];
+  const int rows = yf ? h + taps - 1 : h, y0 = yf ? yi - before : yi;
+  for (int j = 0; j < rows; ++j) {
+    const uint8_t* src = ref + (size_t)hv_clip3(0, rh - 1, y0 + j) * rw;
+    if (xf) {
+      for (int i = 0; i < w + taps - 1; ++i) row[i] = src[hv_clip3(0, rw - 1, xi - before + i)];
+      for (int i = 0; i < w; ++i) {
+        int v = 0;
+        for (int t = 0; t < taps; ++t) v += fx[t] * row[i + t];
+        hor[j * w + i] = v;
+      }
+    } else {
+      for (int i = 0; i < w; ++i) hor[j * w + i] = src[hv_clip3(0, rw - 1, xi + i)] << (yf ? 0 : 6);
+    }
+  }
   for (int j = 0; j < h; ++j)
     for (int i = 0; i < w; ++i) {
       int v;
-      if (!xf && !yf) {
-        v = ref_sample(ref, rw, rh, xi + i, yi + j) << 6;
-      } else if (!yf) {
-        v = 0;
-        for (int t = 0; t < taps; ++t) v += fx[t] * ref_sample(ref, rw, rh, xi + i + t - before, yi + j);
-      } else if (!xf) {
-        v = 0;
-        for (int t = 0; t < taps; ++t) v += fy[t] * ref_sample(ref, rw, rh, xi + i, yi + j + t - before);
+      if (!yf) {
+        v = hor[j * w + i];
       } else {
         v = 0;
-        for (int u = 0; u < taps; ++u) {
-          int r = 0;
-          for (int t = 0; t < taps; ++t) r += fx[t] * ref_sample(ref, rw, rh, xi + i + t - before, yi + j + u - before);
-          v += fy[u] * r; /* (shift1 = 0 at 8 bits) */
-        }
-        v >>= 6;
+        for (int t = 0; t < taps; ++t) v += fy[t] * hor[(j + t) * w + i];
+        if (xf) v >>= 6; /* shift2 */
       }
       out[j * w + i] = (int16_t)v;
     }

@@ -39,7 +39,7 @@ def test_product_does_not_reference_oracle():
                     if f.endswith(".py"):
                         hit = re.search(r'^\s*(from|import)\s+oracle\b|liboracle|oracle_py', t, flags=re.M)
                     else:
-                        hit = re.search(r'#include\s+"[^"]*oracle|liboracle|h264o_|h264i_', t)
+                        hit = re.search(r'#include\s+"[^"]*oracle|liboracle|h264o_|h264i_|hevco_', t)
                     if hit:
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad

@@ -1,0 +1,323 @@
+"""-m gpu: the HEVC kernels (hwang_amd/csrc/amd/k_hevc.hip) against the numpy statements of tests/hevc_numpy.py, fed
+with records built here - no stream, no parser and no oracle in between (hwang_hevc_run_test_picture, include/
+hwang_amd.h).  Residual blocks of every size / QP / transform, all 35 intra modes with every availability pattern the
+substitution process distinguishes, every fractional position of both interpolation filters with vectors far outside
+the picture, default / explicit weights, the luma and chroma deblocking filters over random edge maps, SAO band and
+all four edge classes."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import hevc_numpy as hn
+
+pytestmark = pytest.mark.gpu
+
+RES = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2", "u1"), ("c_idx", "u1"), ("qp", "u1"), ("flags", "u1"), ("matrix", "u1"), ("pad", "u1", 3),
+                ("coef_offset", "<u4"), ("ncoef", "<u4")])
+PU = np.dtype([("x", "<u2"), ("y", "<u2"), ("w", "u1"), ("h", "u1"), ("pred_flag", "u1"), ("weighted", "u1"), ("ref_slot", "u1", 2),
+               ("mv", "<i2", (2, 2)), ("wp", "<u2", 2), ("pad", "<u2")])
+WT = np.dtype([("w", "<i2", 3), ("o", "<i2", 3), ("log2wd", "u1", 2), ("pad", "u1", 2)])
+ITU = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2", "u1"), ("mode", "u1"), ("flags", "u1"), ("pad", "u1"), ("avail_left", "<u4"), ("avail_top", "<u4")])
+SAO = np.dtype([("type", "u1", 3), ("band_pos", "u1", 3), ("eo_class", "u1", 3), ("offset", "i1", (3, 4)), ("pad", "u1", 3)])
+SLICE = np.dtype([("beta", "i1"), ("tc", "i1"), ("across", "u1"), ("sao_luma", "u1"), ("sao_chroma", "u1"), ("pad", "u1", 3), ("first_ctb", "<u4")])
+EDGE = np.dtype([("bs", "u1"), ("qp", "i1"), ("flags", "u1"), ("slice", "u1")])
+assert (RES.itemsize, PU.itemsize, WT.itemsize, ITU.itemsize, SAO.itemsize, SLICE.itemsize, EDGE.itemsize) == (20, 24, 16, 16, 24, 12, 4)
+
+
+class PictureArgs(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("log2_ctb", C.c_int32), ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32),
+                ("sao_enabled", C.c_int32), ("deblock_enabled", C.c_int32), ("recon_in", C.c_void_p), ("refs", C.c_void_p), ("num_refs", C.c_int32),
+                ("num_res", C.c_int32), ("num_coefs", C.c_int32), ("num_pus", C.c_int32), ("num_weights", C.c_int32), ("num_intra", C.c_int32 * 3),
+                ("num_slices", C.c_int32), ("res", C.c_void_p), ("coefs", C.c_void_p), ("pus", C.c_void_p), ("weights", C.c_void_p),
+                ("intra", C.c_void_p * 3), ("intra_first", C.c_void_p * 3), ("edges", C.c_void_p), ("sao", C.c_void_p), ("slices", C.c_void_p),
+                ("scaling", C.c_void_p), ("out", C.c_void_p), ("resid_out", C.c_void_p)]
+
+
+def run_picture(hw, w, h, log2_ctb=4, recon=None, refs=(), res=None, coefs=None, pus=None, weights=None, intra=(None, None, None),
+                edges=None, sao=None, slices=None, cb_off=0, cr_off=0, deblock=False, want_resid=False):
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU; there is no fallback"
+    from hwang_amd._capi import lib
+    ctbs = ((w + (1 << log2_ctb) - 1) >> log2_ctb) * ((h + (1 << log2_ctb) - 1) >> log2_ctb)
+    wctb = (w + (1 << log2_ctb) - 1) >> log2_ctb
+    keep = []
+
+    def arr(a, dtype, n=0):
+        a = np.zeros(max(n, 1), dtype=dtype) if a is None else np.ascontiguousarray(a, dtype=dtype)
+        keep.append(a)
+        return a
+    t = PictureArgs()
+    t.width, t.height, t.log2_ctb, t.cb_qp_offset, t.cr_qp_offset = w, h, log2_ctb, cb_off, cr_off
+    t.sao_enabled, t.deblock_enabled = int(sao is not None), int(deblock)
+    fs = w * h * 3 // 2
+    rin = arr(recon if recon is not None else np.full(fs, 128), np.uint8)
+    t.recon_in = rin.ctypes.data
+    rf = arr(np.concatenate([np.asarray(r, dtype=np.uint8).ravel() for r in refs]) if refs else None, np.uint8)
+    t.refs, t.num_refs = rf.ctypes.data, len(refs)
+    r_, c_, p_, w_ = arr(res, RES), arr(coefs, np.uint32), arr(pus, PU), arr(weights, WT)
+    t.res, t.num_res = r_.ctypes.data, 0 if res is None else len(r_)
+    t.coefs, t.num_coefs = c_.ctypes.data, 0 if coefs is None else len(c_)
+    t.pus, t.num_pus = p_.ctypes.data, 0 if pus is None else len(p_)
+    t.weights, t.num_weights = w_.ctypes.data, 0 if weights is None else len(w_)
+    for c in range(3):
+        it = arr(intra[c], ITU)
+        n = 0 if intra[c] is None else len(it)
+        # every block of the list is filed under the coding tree block it lies in; lists arrive sorted that way
+        first = np.zeros(ctbs + 1, dtype=np.uint32)
+        if n:
+            sub = 1 if c else 0
+            ctb_of = ((it["y"].astype(int) << sub) >> log2_ctb) * wctb + ((it["x"].astype(int) << sub) >> log2_ctb)
+            order = np.argsort(ctb_of, kind="stable")     # the lists are grouped by coding tree block, in raster order
+            it = arr(it[order], ITU)
+            first[1:] = np.cumsum(np.bincount(ctb_of, minlength=ctbs))
+        keep.append(first)
+        t.intra[c], t.intra_first[c], t.num_intra[c] = it.ctypes.data, first.ctypes.data, n
+    e_ = arr(edges, EDGE, (w // 4) * (h // 4))
+    s_ = arr(sao, SAO, ctbs)
+    sl = arr(slices if slices is not None else np.array([(0, 0, 1, 1, 1, [0, 0, 0], 0)], dtype=SLICE), SLICE)
+    t.edges, t.sao, t.slices, t.num_slices = e_.ctypes.data, s_.ctypes.data, sl.ctypes.data, len(sl)
+    out = np.zeros(fs, dtype=np.uint8)
+    resid = np.zeros(fs, dtype=np.int16)
+    t.out = out.ctypes.data
+    t.resid_out = resid.ctypes.data if want_resid else None
+    err = C.create_string_buffer(256)
+    rc = lib.hwang_hevc_run_test_picture(C.byref(t), err, 256)
+    assert rc == 0, err.value.decode()
+    planes = (out[:w * h].reshape(h, w), out[w * h:w * h + w * h // 4].reshape(h // 2, w // 2), out[w * h + w * h // 4:].reshape(h // 2, w // 2))
+    rplanes = (resid[:w * h].reshape(h, w), resid[w * h:w * h + w * h // 4].reshape(h // 2, w // 2), resid[w * h + w * h // 4:].reshape(h // 2, w // 2))
+    return planes, rplanes
+
+
+def test_residual_kernel(hw):
+    rnd = np.random.default_rng(21)
+    W, H = 128, 64
+    for rep in range(6):
+        res, coefs, want = [], [], [np.zeros((H, W), dtype=np.int64), np.zeros((H // 2, W // 2), dtype=np.int64), np.zeros((H // 2, W // 2), dtype=np.int64)]
+        # a grid of 32x32 cells, one block of some size and plane in each
+        for cy in range(0, H, 32):
+            for cx in range(0, W, 32):
+                log2 = int(rnd.integers(2, 6))
+                c_idx = int(rnd.integers(0, 3))
+                if c_idx and log2 == 5:
+                    log2 = 4
+                n = 1 << log2
+                x, y = (cx >> (1 if c_idx else 0)), (cy >> (1 if c_idx else 0))
+                qp, intra = int(rnd.integers(0, 52)), int(rnd.integers(0, 2))
+                tskip = bool(log2 == 2 and rnd.integers(0, 3) == 0)
+                bypass = bool(rnd.integers(0, 7) == 0)
+                lev = np.zeros((n, n), dtype=np.int64)
+                k = int(rnd.integers(1, min(n * n, 40) + 1))
+                lev[rnd.integers(0, n, k), rnd.integers(0, n, k)] = rnd.integers(-32768 if rep == 0 else -60, 32768 if rep == 0 else 61, k)
+                pos = np.flatnonzero(lev)
+                flags = (1 if (intra and c_idx == 0 and log2 == 2) else 0) | (2 if tskip else 0) | (4 if bypass else 0)
+                res.append((x, y, log2, c_idx, qp, flags, 0xff, [0, 0, 0], len(coefs), len(pos)))
+                coefs += [int(p) << 16 | (int(lev.ravel()[p]) & 0xffff) for p in pos]
+                r = lev if bypass else hn.residual(lev, qp, intra, c_idx, transform_skip=tskip)
+                want[c_idx][y:y + n, x:x + n] = np.asarray(r).astype(np.int16)
+        _, got = run_picture(hw, W, H, res=np.array(res, dtype=RES), coefs=np.array(coefs, dtype=np.uint32), want_resid=True)
+        for c in range(3):
+            assert np.array_equal(got[c].astype(np.int64), want[c]), (rep, c)
+
+
+def substitute(avail, vals, n):
+    """8.4.4.2.2 on one line of 4n + 1 samples: bottom-left ... corner ... top-right."""
+    if not avail.any():
+        return np.full(4 * n + 1, 128, dtype=np.int64)
+    v = vals.astype(np.int64).copy()
+    a = avail.copy()
+    if not a[0]:
+        v[0] = v[np.flatnonzero(a)[0]]
+        a[0] = True
+    for i in range(1, 4 * n + 1):
+        if not a[i]:
+            v[i] = v[i - 1]
+    return v
+
+
+@pytest.mark.parametrize("log2", [2, 3, 4, 5])
+def test_intra_kernel(hw, log2):
+    rnd = np.random.default_rng(40 + log2)
+    n = 1 << log2
+    cell = 8 * n            # every block sits inside a cell of its own (chroma: half of it), its neighbours are what recon_in holds
+    cols, rows = 6, 6
+    W, H = cols * cell, rows * cell
+    for c_idx in (0, 1):
+        sub = 1 if c_idx else 0
+        pw, ph = W >> sub, H >> sub
+        smooth = rnd.integers(0, 2)
+        planes = [rnd.integers(0, 256, (H, W)), rnd.integers(0, 256, (H // 2, W // 2)), rnd.integers(0, 256, (H // 2, W // 2))]
+        if smooth:
+            planes[c_idx] = np.clip(90 + (np.add.outer(np.arange(ph), np.arange(pw)) // 6) + rnd.integers(0, 2, (ph, pw)), 0, 255)
+        recon = np.concatenate([p.astype(np.uint8).ravel() for p in planes])
+        recs, expect = [], []
+        unit = 2 if c_idx else 4
+        mode = 0
+        for ry in range(rows):
+            for rx in range(cols):
+                x, y = (rx * cell >> sub) + n, (ry * cell >> sub) + n
+                pat = int(rnd.integers(0, 6))
+                nu = 2 * n // unit
+                al = int(rnd.integers(0, 1 << nu)) if pat > 1 else ((1 << nu) - 1 if pat == 0 else 0)
+                at = int(rnd.integers(0, 1 << nu)) if pat > 1 else ((1 << nu) - 1 if pat == 0 else 0)
+                corner = int(rnd.integers(0, 2)) if pat > 1 else (1 if pat == 0 else 0)
+                strong = int(rnd.integers(0, 2))
+                recs.append((x, y, log2, mode, corner | strong << 1, 0, al, at))
+                p = planes[c_idx]
+                left_vals = np.array([p[y + k, x - 1] for k in range(2 * n)])
+                top_vals = np.array([p[y - 1, x + k] for k in range(2 * n)])
+                la = np.array([(al >> (k // unit)) & 1 for k in range(2 * n)], dtype=bool)
+                ta = np.array([(at >> (k // unit)) & 1 for k in range(2 * n)], dtype=bool)
+                line_v = np.concatenate([left_vals[::-1], [p[y - 1, x - 1]], top_vals])
+                line_a = np.concatenate([la[::-1], [bool(corner)], ta])
+                line = substitute(line_a, line_v, n)
+                left = np.concatenate([[line[2 * n]], line[:2 * n][::-1]])
+                top = line[2 * n:]
+                expect.append((x, y, hn.intra_predict(left, top, n, c_idx, mode, bool(strong))))
+                mode = (mode + 1) % 35
+        intra = [None, None, None]
+        intra[c_idx] = np.array(recs, dtype=ITU)
+        got, _ = run_picture(hw, W, H, log2_ctb=6, recon=recon, intra=tuple(intra))
+        for (x, y, want) in expect:
+            assert np.array_equal(got[c_idx][y:y + n, x:x + n].astype(np.int64), want), (c_idx, x, y)
+
+
+def test_inter_kernel(hw):
+    rnd = np.random.default_rng(50)
+    W, H = 256, 192
+    refs = [np.concatenate([rnd.integers(0, 256, W * H), rnd.integers(0, 256, W * H // 2)]).astype(np.uint8) for _ in range(2)]
+    refs[0][:W * 3] = 255
+    refs[1][-W // 2 * 4:] = 0
+    rp = [(r[:W * H].reshape(H, W), r[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), r[W * H + W * H // 4:].reshape(H // 2, W // 2)) for r in refs]
+    weights = np.array([([64, 70, 60], [3, -2, 1], [6, 6], [0, 0]), ([61, 64, 66], [-4, 2, 0], [6, 6], [0, 0]),
+                        ([1, 1, 1], [0, 5, -5], [0, 0], [0, 0]), ([130, 100, 90], [10, -10, 7], [7, 5], [0, 0])], dtype=WT)
+    pus, expect = [], []
+    sizes = [(8, 8), (16, 8), (8, 16), (16, 16), (8, 4), (4, 8), (32, 32), (16, 4), (12, 16), (64, 32)]
+    k = 0
+    for y in range(0, H, 32):
+        for x in range(0, W, 64):
+            w, h = sizes[k % len(sizes)]
+            pf = [1, 2, 3][k % 3] if w + h != 12 else [1, 2][k % 2]
+            mv = [[int(rnd.integers(-40, 41)), int(rnd.integers(-40, 41))], [int(rnd.integers(-700, 700)), int(rnd.integers(-500, 500))]]
+            if k % 4 == 0:
+                mv[0] = [(k // 4 % 4) + 4 * int(rnd.integers(-3, 4)), (k // 16 % 4) + 4 * int(rnd.integers(-3, 4))]
+            weighted = int(k % 5 in (1, 3))
+            wp = [int(rnd.integers(0, 4)), int(rnd.integers(0, 4))]     # (the denominators are those of the first list in use, as in the kernel)
+            pus.append((x, y, w, h, pf, weighted, [0, 1], mv, wp, 0))
+            for c in range(3):
+                sub = 1 if c else 0
+                p = [hn.pred_samples(rp[l][c], x >> sub, y >> sub, w >> sub, h >> sub, mv[l][0], mv[l][1], chroma=bool(c)) if (pf >> l) & 1 else None for l in range(2)]
+                if not weighted:
+                    v = hn.inter_bi(p[0], p[1]) if pf == 3 else np.clip(((p[0] if pf == 1 else p[1]) + 32) >> 6, 0, 255)
+                else:
+                    w0, w1 = weights[wp[0]], weights[wp[1]]
+                    ld = int((w0 if pf & 1 else w1)["log2wd"][1 if c else 0])
+                    if pf == 3:
+                        v = hn.inter_weighted_bi(p[0], p[1], int(w0["w"][c]), int(w1["w"][c]), int(w0["o"][c]), int(w1["o"][c]), ld)
+                    elif pf == 1:
+                        v = hn.inter_weighted_uni(p[0], int(w0["w"][c]), int(w0["o"][c]), ld)
+                    else:
+                        v = hn.inter_weighted_uni(p[1], int(w1["w"][c]), int(w1["o"][c]), ld)
+                expect.append((c, x >> sub, y >> sub, v))
+            k += 1
+    got, _ = run_picture(hw, W, H, refs=refs, pus=np.array(pus, dtype=PU), weights=weights)
+    for (c, x, y, v) in expect:
+        assert np.array_equal(got[c][y:y + v.shape[0], x:x + v.shape[1]].astype(np.int64), v), (c, x, y)
+
+
+def test_all_fractional_positions(hw):
+    rnd = np.random.default_rng(51)
+    W, H = 256, 128
+    ref = np.concatenate([rnd.integers(0, 256, W * H), rnd.integers(0, 256, W * H // 2)]).astype(np.uint8)
+    planes = (ref[:W * H].reshape(H, W), ref[W * H:W * H + W * H // 4].reshape(H // 2, W // 2), ref[W * H + W * H // 4:].reshape(H // 2, W // 2))
+    pus, expect = [], []
+    for yf in range(8):
+        for xf in range(8):
+            x, y = xf * 32, yf * 16
+            mv = [xf + 8 * int(rnd.integers(-4, 5)), yf + 8 * int(rnd.integers(-4, 5))]    # luma fractions (mv & 3), chroma fractions (mv & 7): all 64
+            pus.append((x, y, 16, 16, 1, 0, [0, 0], [mv, [0, 0]], [0, 0], 0))
+            for c in range(3):
+                sub = 1 if c else 0
+                expect.append((c, x >> sub, y >> sub, hn.inter_default(planes[c], x >> sub, y >> sub, 16 >> sub, 16 >> sub, mv[0], mv[1], chroma=bool(c))))
+    got, _ = run_picture(hw, W, H, refs=[ref], pus=np.array(pus, dtype=PU))
+    for (c, x, y, v) in expect:
+        assert np.array_equal(got[c][y:y + v.shape[0], x:x + v.shape[1]].astype(np.int64), v), (c, x, y)
+
+
+def test_deblocking_kernel(hw):
+    rnd = np.random.default_rng(60)
+    W, H = 128, 64
+    w4, h4 = W // 4, H // 4
+    for rep in range(4):
+        base = rnd.integers(40, 200, (H // 8, W // 8))
+        y = np.clip(np.kron(base, np.ones((8, 8), dtype=int)) + rnd.integers(-3, 4, (H, W)), 0, 255)      # 8x8 blocks of different levels: edges to smooth
+        u = np.clip(np.kron(rnd.integers(60, 190, (H // 16, W // 16)), np.ones((8, 8), dtype=int)) + rnd.integers(-2, 3, (H // 2, W // 2)), 0, 255)
+        v = np.clip(np.kron(rnd.integers(60, 190, (H // 16, W // 16)), np.ones((8, 8), dtype=int)) + rnd.integers(-2, 3, (H // 2, W // 2)), 0, 255)
+        edges = np.zeros((h4, w4), dtype=EDGE)
+        edges["qp"] = np.kron(rnd.integers(15, 50, (h4 // 2, w4 // 2)), np.ones((2, 2), dtype=int))
+        edges["flags"] = (rnd.integers(0, 12, (h4, w4)) == 0)
+        bsv = rnd.integers(0, 3, (h4, w4)) * (np.arange(w4)[None, :] % 2 == 0) * (np.arange(w4)[None, :] > 0)
+        bsh = rnd.integers(0, 3, (h4, w4)) * (np.arange(h4)[:, None] % 2 == 0) * (np.arange(h4)[:, None] > 0)
+        edges["bs"] = bsv | bsh << 2
+        slices = np.array([(2 * int(rnd.integers(-3, 4)), 2 * int(rnd.integers(-3, 4)), 1, 1, 1, [0, 0, 0], 0)], dtype=SLICE)
+        cb_off, cr_off = int(rnd.integers(-6, 7)), int(rnd.integers(-6, 7))
+        # numpy: all vertical edges, then all horizontal ones (8.7.2)
+        wy, wu, wv = y.copy(), u.copy(), v.copy()
+        for d in range(2):
+            for by in range(h4):
+                for bx in range(w4):
+                    bs = int((bsh if d else bsv)[by, bx])
+                    if not bs:
+                        continue
+                    p = edges[by - 1, bx] if d else edges[by, bx - 1]
+                    q = edges[by, bx]
+                    if d:
+                        blk = wy[by * 4 - 4:by * 4 + 4, bx * 4:bx * 4 + 4].T
+                    else:
+                        blk = wy[by * 4:by * 4 + 4, bx * 4 - 4:bx * 4 + 4]
+                    out = hn.deblock_luma(blk, bs, int(p["qp"]), int(q["qp"]), int(slices[0]["beta"]) // 2, int(slices[0]["tc"]) // 2, bool(p["flags"]), bool(q["flags"]))
+                    if d:
+                        wy[by * 4 - 4:by * 4 + 4, bx * 4:bx * 4 + 4] = out.T
+                    else:
+                        wy[by * 4:by * 4 + 4, bx * 4 - 4:bx * 4 + 4] = out
+                    if bs == 2 and (by if d else bx) % 4 == 0:
+                        for plane, off in ((wu, cb_off), (wv, cr_off)):
+                            for l in range(2):
+                                if d:
+                                    row = plane[by * 2 - 2:by * 2 + 2, bx * 2 + l]
+                                else:
+                                    row = plane[by * 2 + l, bx * 2 - 2:bx * 2 + 2]
+                                r = hn.deblock_chroma(row, int(p["qp"]), int(q["qp"]), off, int(slices[0]["tc"]) // 2)
+                                if p["flags"]:
+                                    r[1] = int(row[1])
+                                if q["flags"]:
+                                    r[2] = int(row[2])
+                                if d:
+                                    plane[by * 2 - 2:by * 2 + 2, bx * 2 + l] = r
+                                else:
+                                    plane[by * 2 + l, bx * 2 - 2:bx * 2 + 2] = r
+        recon = np.concatenate([y.ravel(), u.ravel(), v.ravel()]).astype(np.uint8)
+        got, _ = run_picture(hw, W, H, recon=recon, edges=edges.ravel(), slices=slices, cb_off=cb_off, cr_off=cr_off, deblock=True)
+        assert np.array_equal(got[0].astype(np.int64), wy), rep
+        assert np.array_equal(got[1].astype(np.int64), wu) and np.array_equal(got[2].astype(np.int64), wv), rep
+        assert (wy != y).any() and (wu != u).any()
+
+
+def test_sao_kernel(hw):
+    rnd = np.random.default_rng(70)
+    W, H = 64, 48
+    for typ in (1, 2):
+        for cls in range(4 if typ == 2 else 1):
+            y = rnd.integers(0, 256, (H, W))
+            u = np.clip(128 + rnd.integers(-4, 5, (H // 2, W // 2)), 0, 255)
+            v = rnd.integers(0, 256, (H // 2, W // 2))
+            sao = np.zeros(1, dtype=SAO)      # one 64x64 coding tree block covers the picture
+            sao["type"] = typ
+            sao["eo_class"] = cls
+            sao["band_pos"] = [int(rnd.integers(0, 32)) for _ in range(3)]
+            sao["offset"] = rnd.integers(-7, 8, (3, 4))
+            recon = np.concatenate([y.ravel(), u.ravel(), v.ravel()]).astype(np.uint8)
+            got, _ = run_picture(hw, W, H, log2_ctb=6, recon=recon, sao=sao)
+            for c, plane in enumerate((y, u, v)):
+                want = hn.sao(plane, typ, int(sao["band_pos"][0][c]), cls, sao["offset"][0][c])
+                assert np.array_equal(got[c].astype(np.int64), want), (typ, cls, c)

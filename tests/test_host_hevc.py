@@ -118,26 +118,33 @@ def test_hostile_conformance_windows_are_not_believed(hw):
 
 
 @pytest.mark.gpu
-def test_backend_refuses_hevc_by_name(hw, tmp_path):
+def test_backend_takes_hevc_by_every_name_the_reference_reads(hw, tmp_path):
+    """The format switch of software_video_decoder.cpp:124-135: "h265" / "hev1" / "hevc" (and the other sample entry
+    type, "hvc1") select the HEVC half of the backend; an unknown name is refused with the list of what is supported;
+    an hev1 track whose samples are not HEVC (the container fixtures of the H.264 corpus generator) fails as a Result,
+    not as a crash."""
     import torch
     assert torch.cuda.is_available()
     from hwang_amd._capi import lib
-    path = str(tmp_path / "hev1.mp4")
-    make_clip(path, width=320, height=240, yuv=False, frames=6, gop=6, bframes=0, hevc_entry=1)
+    from tests.corpus_util import make_hevc_clip
+    path = str(tmp_path / "real.mp4")
+    make_hevc_clip(path, width=320, height=240, yuv=False, frames=3, gop=3)
     idx = hw.index_video(path)
     dec = lib.hwang_decoder_create(1, 0, 1, 3)
     assert dec
     extradata = bytes(idx.metadata_bytes())
     try:
         for name in ("hev1", "hevc", "h265", "hvc1"):
-            assert lib.hwang_decoder_configure(dec, 320, 240, name.encode(), extradata, len(extradata)) != 0
-            msg = lib.hwang_decoder_last_error(dec).decode()
-            assert "HEVC ('%s') is not supported by this backend (H.264 only)" % name in msg and "Main profile" in msg and "320x240" in msg, msg
+            assert lib.hwang_decoder_configure(dec, 320, 240, name.encode(), extradata, len(extradata)) == 0, lib.hwang_decoder_last_error(dec).decode()
+        assert lib.hwang_decoder_configure(dec, 322, 240, b"hev1", extradata, len(extradata)) != 0
+        assert "but the container says 322x240" in lib.hwang_decoder_last_error(dec).decode()
         assert lib.hwang_decoder_configure(dec, 320, 240, b"vp09", extradata, len(extradata)) != 0
-        assert "Unsupported video codec: vp09" in lib.hwang_decoder_last_error(dec).decode()
+        msg = lib.hwang_decoder_last_error(dec).decode()
+        assert "Unsupported video codec: vp09" in msg and "hevc" in msg and "h264" in msg
     finally:
         lib.hwang_decoder_destroy(dec)
-    # ... and through the reference's Python surface: a RuntimeError that names the codec
+    fake = str(tmp_path / "fake.mp4")
+    make_clip(fake, width=320, height=240, yuv=False, frames=6, gop=6, bframes=0, hevc_entry=1)
     import hwang
-    with pytest.raises(RuntimeError, match="HEVC"):
-        hwang.Decoder(path, device_type=hwang.DeviceType.GPU).retrieve([0])
+    with pytest.raises(RuntimeError):
+        hwang.Decoder(fake, device_type=hwang.DeviceType.GPU).retrieve([0])
