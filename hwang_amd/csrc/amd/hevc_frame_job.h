@@ -5,8 +5,8 @@
 // kernels are launched over:
 //   ResTu      one transform block with levels: k_hevc_residual (scaling 8.6.3, transforms 8.6.4) -> residual planes
 //   InterPu    one prediction block: k_hevc_inter (8.5.3.3 interpolation + weighting, + residual) -> reconstruction
-//   IntraTu    one intra-predicted transform block per colour plane, in decoding order per coding tree block:
-//              k_hevc_intra (8.4.4.2; a wavefront of coding tree block rows per plane)
+//   IntraTu    one intra-predicted transform block per colour plane, in decoding order: k_hevc_intra (8.4.4.2) takes
+//              them by ticket and lets each wait for exactly the neighbouring blocks it reads (a dataflow wavefront)
 //   edge maps  per 4x4 luma block: boundary strengths of its left / top edge, QpY, "leave alone" flag:
 //              k_hevc_deblock (8.7.2), k_hevc_sao (8.7.3, with SaoCtb per coding tree block)
 // Surfaces are planar I420 of the coded size; luma pitch a multiple of 256 bytes, chroma pitch half of it.
@@ -61,9 +61,11 @@ struct IntraTu {
   uint8_t pad;
   uint32_t avail_left;  // bit k: unit k of the left column exists (units of 4 luma samples, from the top, 2n samples)
   uint32_t avail_top;   // bit k: unit k of the row above (from the left, 2n samples)
+  uint32_t wait_left;   // ... and is written by an intra block of this picture (an earlier record of the same list):
+  uint32_t wait_top;    //     k_hevc_intra waits for its "done" mark; everything else is final before the kernel starts
 };
-static_assert(sizeof(IntraTu) == 16, "IntraTu");
-enum : uint8_t { INTRA_CORNER = 1, INTRA_STRONG = 2 /* strong_intra_smoothing_enabled_flag */ };
+static_assert(sizeof(IntraTu) == 24, "IntraTu");
+enum : uint8_t { INTRA_CORNER = 1, INTRA_STRONG = 2 /* strong_intra_smoothing_enabled_flag */, INTRA_WAIT_CORNER = 4 };
 constexpr uint8_t kIntraPcm = 0xff;
 
 struct SaoCtb {
@@ -111,14 +113,14 @@ struct PicParams {
   const uint32_t* coefs;
   const InterPu* pus;
   const WeightEntry* weights;
-  const IntraTu* intra[3];
-  const uint32_t* intra_ctb_first[3];  // per plane: width_ctb * height_ctb + 1 offsets into intra[c]
+  const IntraTu* intra[3];             // per plane, decoding order
   const EdgeInfo* edges;
   const SaoCtb* sao;
   const SliceLoop* slices;
   const uint8_t* scaling;      // ScalingFactor tables: f4[6][16] f8[6][64] f16[6][256] f32[2][1024], or null
   int16_t* resid[3];           // residual planes, pitches as the surfaces'
-  uint32_t* progress;          // intra wavefront: [plane][ctb row] -> coding tree blocks completed (zeroed per picture)
+  uint32_t* intra_ticket;      // [3]: next record of each plane's list (zeroed per picture)
+  uint8_t* intra_done[3];      // per plane, per 4x4 luma block: an intra block covering it is final (zeroed per picture)
   uint32_t* fault;             // set by a kernel whose bounded wait expired
 };
 

@@ -192,7 +192,6 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     for (int c = 0; c < 3; ++c) {
       out->intra[c] = reinterpret_cast<gh::IntraTu*>(h + off_.intra[c]);
       out->cap_intra[c] = cap_.intra[c];
-      out->intra_ctb_first[c] = reinterpret_cast<uint32_t*>(h + off_.first[c]);
     }
     out->edges = reinterpret_cast<gh::EdgeInfo*>(h + off_.edges);
     out->sao = reinterpret_cast<gh::SaoCtb*>(h + off_.sao);
@@ -236,7 +235,6 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     pp.weights = reinterpret_cast<const gh::WeightEntry*>(dv + off_.weights);
     for (int c = 0; c < 3; ++c) {
       pp.intra[c] = reinterpret_cast<const gh::IntraTu*>(dv + off_.intra[c]);
-      pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dv + off_.first[c]);
     }
     pp.edges = reinterpret_cast<const gh::EdgeInfo*>(dv + off_.edges);
     pp.sao = reinterpret_cast<const gh::SaoCtb*>(dv + off_.sao);
@@ -245,7 +243,8 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     pp.resid[0] = resid_;
     pp.resid[1] = resid_ + static_cast<size_t>(y_pitch_) * ch_;
     pp.resid[2] = pp.resid[1] + static_cast<size_t>(y_pitch_ / 2) * (ch_ / 2);
-    pp.progress = progress_;
+    pp.intra_ticket = progress_;
+    for (int c = 0; c < 3; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(progress_ + 4) + static_cast<size_t>(c) * (cw_ / 4) * (ch_ / 4);
     pp.fault = fault_dev_;
     std::memcpy(set.host + off_.params, &pp, sizeof(pp));
     auto up = [&](size_t off, size_t bytes) {
@@ -261,14 +260,13 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (e == hipSuccess) e = up(off_.weights, d.num_weights * sizeof(gh::WeightEntry));
     for (int c = 0; c < 3 && e == hipSuccess; ++c) {
       e = up(off_.intra[c], d.num_intra[c] * sizeof(gh::IntraTu));
-      if (e == hipSuccess && (d.num_intra[0] || d.num_intra[1] || d.num_intra[2])) e = up(off_.first[c], (ctbs + 1) * sizeof(uint32_t));
     }
     if (e == hipSuccess && (d.deblock || d.sao)) e = up(off_.edges, static_cast<size_t>(cw_ / 4) * (ch_ / 4) * sizeof(gh::EdgeInfo));
     if (e == hipSuccess && d.sao) e = up(off_.sao, ctbs * sizeof(gh::SaoCtb));
     if (e == hipSuccess && (d.deblock || d.sao)) e = up(off_.slices, static_cast<size_t>(std::max(d.num_slices, 1)) * sizeof(gh::SliceLoop));
     if (e == hipSuccess && d.scaling) e = up(off_.scaling, 4064);
     if (e == hipSuccess) e = hipMemsetAsync(resid_, 0, resid_bytes_, stream_);
-    if (e == hipSuccess) e = hipMemsetAsync(progress_, 0, sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_), stream_);
+    if (e == hipSuccess && (d.num_intra[0] || d.num_intra[1] || d.num_intra[2])) e = hipMemsetAsync(progress_, 0, progress_bytes_, stream_);
     if (e == hipSuccess) e = gh::launch_picture(pp, reinterpret_cast<const gh::PicParams*>(dv + off_.params), stream_);
     if (e == hipSuccess) e = hipEventRecord(set.done, stream_);
     if (e != hipSuccess) {
@@ -311,7 +309,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     bool busy = false;
   };
   struct Offsets {
-    size_t params, res, coefs, pus, weights, intra[3], first[3], edges, sao, slices, scaling, total;
+    size_t params, res, coefs, pus, weights, intra[3], edges, sao, slices, scaling, total;
   };
   struct Caps {
     size_t res, coefs, pus, weights, intra[3];
@@ -401,7 +399,6 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     off_.pus = take(cap_.pus * sizeof(gh::InterPu));
     off_.weights = take(cap_.weights * sizeof(gh::WeightEntry));
     for (int c = 0; c < 3; ++c) off_.intra[c] = take(cap_.intra[c] * sizeof(gh::IntraTu));
-    for (int c = 0; c < 3; ++c) off_.first[c] = take((ctbs + 1) * sizeof(uint32_t));
     off_.edges = take(w4h4 * sizeof(gh::EdgeInfo));
     off_.sao = take(ctbs * sizeof(gh::SaoCtb));
     off_.slices = take(gh::kMaxSlices * sizeof(gh::SliceLoop));
@@ -416,7 +413,8 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     resid_bytes_ = surface_bytes_ * sizeof(int16_t);
     ok = ok && hipMalloc(reinterpret_cast<void**>(&work_), surface_bytes_) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&resid_), resid_bytes_) == hipSuccess;
-    ok = ok && hipMalloc(reinterpret_cast<void**>(&progress_), sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_)) == hipSuccess;
+    progress_bytes_ = 16 + 3 * w4h4;  // the three tickets, then a done map per plane
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&progress_), progress_bytes_) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&rgb_dev_), static_cast<size_t>(cw_) * ch_ * 3) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&fault_host_), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
     if (ok) {
@@ -488,7 +486,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   Offsets off_ = {};
   Caps cap_ = {};
   int cw_ = 0, ch_ = 0, log2_ctb_ = 0, wctb_ = 0, hctb_ = 0, y_pitch_ = 0, crop_l_ = 0, crop_t_ = 0;
-  size_t surface_bytes_ = 0, resid_bytes_ = 0;
+  size_t surface_bytes_ = 0, resid_bytes_ = 0, progress_bytes_ = 0;
   uint8_t* work_ = nullptr;
   int16_t* resid_ = nullptr;
   uint32_t* progress_ = nullptr;
@@ -576,7 +574,6 @@ extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, cha
   pp.weights = reinterpret_cast<const gh::WeightEntry*>(dev(sizeof(gh::WeightEntry) * static_cast<size_t>(t->num_weights), t->weights));
   for (int c = 0; c < 3; ++c) {
     pp.intra[c] = reinterpret_cast<const gh::IntraTu*>(dev(sizeof(gh::IntraTu) * static_cast<size_t>(t->num_intra[c]), t->intra[c]));
-    pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dev(sizeof(uint32_t) * (ctbs + 1), t->intra_first[c]));
   }
   pp.edges = reinterpret_cast<const gh::EdgeInfo*>(dev(sizeof(gh::EdgeInfo) * w4h4, t->edges));
   pp.sao = reinterpret_cast<const gh::SaoCtb*>(dev(sizeof(gh::SaoCtb) * ctbs, t->sao));
@@ -586,10 +583,11 @@ extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, cha
   pp.resid[0] = resid;
   pp.resid[1] = resid + static_cast<size_t>(pitch) * H;
   pp.resid[2] = pp.resid[1] + static_cast<size_t>(pitch / 2) * (H / 2);
-  pp.progress = reinterpret_cast<uint32_t*>(dev(sizeof(uint32_t) * 3 * static_cast<size_t>(hctb), nullptr));
+  pp.intra_ticket = reinterpret_cast<uint32_t*>(dev(16 + 3 * w4h4, nullptr));
+  for (int c = 0; c < 3 && pp.intra_ticket; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(pp.intra_ticket + 4) + static_cast<size_t>(c) * w4h4;
   pp.fault = reinterpret_cast<uint32_t*>(dev(sizeof(uint32_t), nullptr));
   const gh::PicParams* pp_dev = reinterpret_cast<const gh::PicParams*>(dev(sizeof(pp), &pp));
-  ok = ok && pp.res && pp.coefs && pp.pus && pp.weights && pp.edges && pp.sao && pp.slices && resid && pp.progress && pp.fault && pp_dev;
+  ok = ok && pp.res && pp.coefs && pp.pus && pp.weights && pp.edges && pp.sao && pp.slices && resid && pp.intra_ticket && pp.fault && pp_dev;
   if (ok) ok = gh::launch_picture(pp, pp_dev, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
   uint32_t fault = 0;
   if (ok) ok = hipMemcpy(&fault, pp.fault, sizeof(fault), hipMemcpyDeviceToHost) == hipSuccess;

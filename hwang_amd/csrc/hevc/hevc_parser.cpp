@@ -357,10 +357,15 @@ class Cabac {
     }
     return 0;
   }
+  // n bypass bins at once (n <= 16): the offset divided by the range is the n bins read as a number
   unsigned bypass_bits(int n) {
-    unsigned v = 0;
-    while (n--) v = v << 1 | static_cast<unsigned>(bypass());
-    return v;
+    if (n <= 1) return n ? static_cast<unsigned>(bypass()) : 0u;
+    if (bits_ < n) refill();
+    bits_ -= n;
+    const uint64_t scaled = static_cast<uint64_t>(range_) << bits_;
+    const uint64_t q = value_ / scaled;
+    value_ -= q * scaled;
+    return static_cast<unsigned>(q);
   }
   int terminate() {
     range_ -= 2;
@@ -828,12 +833,15 @@ struct Parser::Impl {
       }
     return nullptr;
   }
+  // Motion fields are 24 bytes per 4x4 block (3 MB at 1080p): the buffers circulate between the pictures of the DPB
+  // instead of being allocated - and paged in - per picture.
+  std::vector<std::vector<Motion>> motion_pool;
   void drop(Pic* p) {
     if (p->slot >= 0) sink->release_surface(p->slot);
     p->in_use = false;
     p->slot = -1;
-    p->motion.clear();
-    p->motion.shrink_to_fit();
+    if (p->motion.capacity()) motion_pool.push_back(std::move(p->motion));
+    p->motion = std::vector<Motion>();
   }
   void release_unused() {
     for (Pic& p : dpb)
@@ -994,12 +1002,20 @@ struct Parser::Impl {
     w4 = S->width / 4;
     h4 = S->height / 4;
     const size_t n = static_cast<size_t>(w4) * h4;
-    m_pred.assign(n, 0); m_skip.assign(n, 0); m_depth.assign(n, 0); m_mode.assign(n, 1); m_flags.assign(n, 0);
-    m_nz.assign(n, 0); m_edge.assign(n, 0); m_qp.assign(n, 0);
+    // Only what is OR-ed into starts from zero; every other map is read only where this picture has already written
+    // it (availability goes by z-order and slice, 6.4.1, not by what a map holds).
+    if (m_pred.size() != n) {
+      m_pred.assign(n, 0); m_skip.assign(n, 0); m_depth.assign(n, 0); m_mode.assign(n, 1); m_flags.assign(n, 0); m_qp.assign(n, 0);
+    }
+    m_nz.assign(n, 0); m_edge.assign(n, 0);
     ctb_slice.assign(static_cast<size_t>(S->wctb) * S->hctb, 0xffff);
     slice_addr.clear();
     num_slices = 0;
-    cur->motion.assign(n, Motion());
+    if (!motion_pool.empty()) {
+      cur->motion = std::move(motion_pool.back());
+      motion_pool.pop_back();
+    }
+    if (cur->motion.size() != n) cur->motion.assign(n, Motion());  // (a recycled field holds its last picture: every unit overwrites its part)
     PicSetup setup;
     setup.width = S->width;
     setup.height = S->height;
@@ -1016,7 +1032,6 @@ struct Parser::Impl {
     done.pcm_bits_luma = S->pcm_bits_y;
     done.pcm_bits_chroma = S->pcm_bits_c;
     const int ctbs = S->wctb * S->hctb;
-    for (int c = 0; c < 3; ++c) std::fill(buf.intra_ctb_first[c], buf.intra_ctb_first[c] + ctbs + 1, 0u);
     std::memset(buf.sao, 0, sizeof(SaoCtb) * static_cast<size_t>(ctbs));
     pic_open = true;
     return true;
@@ -1052,40 +1067,29 @@ struct Parser::Impl {
   }
 
   bool close_picture() {
-    // edge records
+    // the strengths of the edges that may be filtered (QpY / flags / slice of every block were written with its unit)
     bool any_bs = false;
-    for (int y = 0; y < h4; ++y)
+    for (int y = 0; y < h4; ++y) {
+      EdgeInfo* erow = &buf.edges[static_cast<size_t>(y) * w4];
+      const uint8_t* edge = &m_edge[static_cast<size_t>(y) * w4];
       for (int x = 0; x < w4; ++x) {
+        const uint8_t eg = edge[x];
+        if (!(eg & 48)) continue;
         const int i = y * w4 + x;
-        EdgeInfo e;
-        e.qp = m_qp[i];
-        e.flags = (m_flags[i] & 4) ? 1 : 0;
-        const uint16_t sl = ctb_slice[((y * 4) >> S->log2_ctb) * S->wctb + ((x * 4) >> S->log2_ctb)];
-        e.slice = static_cast<uint8_t>(sl == 0xffff ? 0 : sl);
         int bs[2] = {0, 0};
         for (int dir = 0; dir < 2; ++dir) {
-          if (((dir ? y : x) & 1) || !(m_edge[i] & (dir ? 32 : 16))) continue;
+          if (((dir ? y : x) & 1) || !(eg & (dir ? 32 : 16))) continue;
           const int j = dir ? i - w4 : i - 1;
           if (m_pred[i] == 2 || m_pred[j] == 2) bs[dir] = 2;
-          else if ((m_edge[i] & (dir ? 4 : 1)) && (m_nz[i] || m_nz[j])) bs[dir] = 1;
+          else if ((eg & (dir ? 4 : 1)) && (m_nz[i] || m_nz[j])) bs[dir] = 1;
           else bs[dir] = motion_bs(cur->motion[j], cur->motion[i]);
         }
-        e.bs = static_cast<uint8_t>(bs[0] | bs[1] << 2);
-        any_bs |= e.bs != 0;
-        buf.edges[i] = e;
-      }
-    done.deblock = any_bs;
-    done.num_slices = num_slices;
-    // the per-plane intra lists are complete: turn the per-block counts into offsets
-    const int ctbs = S->wctb * S->hctb;
-    for (int c = 0; c < 3; ++c) {
-      uint32_t at = 0;
-      for (int k = 0; k <= ctbs; ++k) {
-        const uint32_t n = buf.intra_ctb_first[c][k];
-        buf.intra_ctb_first[c][k] = at;
-        at += n;
+        erow[x].bs = static_cast<uint8_t>(bs[0] | bs[1] << 2);
+        any_bs |= erow[x].bs != 0;
       }
     }
+    done.deblock = any_bs;
+    done.num_slices = num_slices;
     if (S->scaling_enabled) {
       done.scaling = true;
       std::memcpy(buf.scaling, P->scaling_present ? &P->scaling : &S->scaling, sizeof(Scaling));
@@ -1371,7 +1375,10 @@ struct Parser::Impl {
         m_depth[i] = static_cast<uint8_t>(cu.depth);
         m_flags[i] = fl;
         m_qp[i] = static_cast<int8_t>(cu.qp);
-        if (cu.intra) m_mode[i] = 1;
+        if (cu.intra) {
+          m_mode[i] = 1;
+          cur->motion[i].flags = 0;  // "intra" as far as later pictures' temporal candidates and this picture's strengths go
+        }
       }
   }
 
@@ -1397,17 +1404,15 @@ struct Parser::Impl {
 
   // one intra-predicted block of one plane: the record k_hevc_intra works from
   bool emit_intra(int c, int x, int y, int log2, int mode) {
-    const int ctb = ((y << (c ? 1 : 0)) >> S->log2_ctb) * S->wctb + ((x << (c ? 1 : 0)) >> S->log2_ctb);
     if (done.num_intra[c] >= buf.cap_intra[c]) return fail("intra block list overflow");
     IntraTu& t = buf.intra[c][done.num_intra[c]++];
-    ++buf.intra_ctb_first[c][ctb];  // (a count until close_picture turns the table into offsets)
     t.x = static_cast<uint16_t>(x);
     t.y = static_cast<uint16_t>(y);
     t.log2 = static_cast<uint8_t>(log2);
     t.mode = static_cast<uint8_t>(mode);
     t.flags = S->strong ? amd::hevc::INTRA_STRONG : 0;
     t.pad = 0;
-    t.avail_left = t.avail_top = 0;
+    t.avail_left = t.avail_top = t.wait_left = t.wait_top = 0;
     if (mode == amd::hevc::kIntraPcm) return true;
     const int sub = c ? 1 : 0, unit = c ? 2 : 4, n = 1 << log2;
     const int xl = x << sub, yl = y << sub;
@@ -1415,10 +1420,18 @@ struct Parser::Impl {
       if (!zavail(xl, yl, xn << sub, yn << sub)) return false;
       return !P->cip || m_pred[((yn << sub) >> 2) * w4 + ((xn << sub) >> 2)] == 2;
     };
-    if (ok(x - 1, y - 1)) t.flags |= amd::hevc::INTRA_CORNER;
+    // a neighbour that an intra block of this picture writes is waited for; what inter prediction wrote is final
+    auto intra_written = [&](int xn, int yn) { return m_pred[((yn << sub) >> 2) * w4 + ((xn << sub) >> 2)] == 2; };
+    if (ok(x - 1, y - 1)) t.flags |= amd::hevc::INTRA_CORNER | (intra_written(x - 1, y - 1) ? amd::hevc::INTRA_WAIT_CORNER : 0);
     for (int k = 0; k < 2 * n / unit; ++k) {
-      if (ok(x - 1, y + k * unit)) t.avail_left |= 1u << k;
-      if (ok(x + k * unit, y - 1)) t.avail_top |= 1u << k;
+      if (ok(x - 1, y + k * unit)) {
+        t.avail_left |= 1u << k;
+        if (intra_written(x - 1, y + k * unit)) t.wait_left |= 1u << k;
+      }
+      if (ok(x + k * unit, y - 1)) {
+        t.avail_top |= 1u << k;
+        if (intra_written(x + k * unit, y - 1)) t.wait_top |= 1u << k;
+      }
     }
     return true;
   }
@@ -1433,8 +1446,9 @@ struct Parser::Impl {
       if (mode >= 6 && mode <= 14) scan = 2;
       if (mode >= 22 && mode <= 30) scan = 1;
     }
-    const uint8_t* sbs = scans().t[log2 - 2][scan];
-    const uint8_t* pss = scans().t[2][scan];
+    static const Scans& sc_tab = scans();
+    const uint8_t* sbs = sc_tab.t[log2 - 2][scan];
+    const uint8_t* pss = sc_tab.t[2][scan];
     // last significant position
     int off, shift;
     if (c == 0) { off = 3 * (log2 - 2) + ((log2 - 1) >> 2); shift = (log2 + 1) >> 2; }
@@ -1541,8 +1555,17 @@ struct Parser::Impl {
       const bool hidden = !cu.bypass && P->sign_hiding && last_sig - first_sig > 3;
       if (g1pos >= 0 && bin(HC_GREATER2 + ctx_set + (c ? 4 : 0))) g2 |= 1u << g1pos;
       uint16_t neg = 0;
-      for (int k = 15; k >= 0; --k)
-        if (((sig >> k) & 1) && (!hidden || k != first_sig) && cabac.bypass()) neg |= 1u << k;
+      {  // coeff_sign_flag of every level whose sign is coded, highest scan position first: one read
+        uint16_t coded = sig;
+        if (hidden) coded &= static_cast<uint16_t>(~(1u << first_sig));
+        const int ns = __builtin_popcount(coded);
+        unsigned bits = cabac.bypass_bits(ns);
+        for (int k = 15, left = ns; left > 0; --k)
+          if ((coded >> k) & 1) {
+            --left;
+            if ((bits >> left) & 1) neg |= 1u << k;
+          }
+      }
       int nsig = 0, sum = 0, rice = 0;
       for (int k = 15; k >= 0; --k) {
         if (!((sig >> k) & 1)) continue;
@@ -1881,8 +1904,19 @@ struct Parser::Impl {
         }
       }
     }
-    for (int y = y0; y < y0 + n; y += 4)
-      for (int x = x0; x < x0 + n; x += 4) m_qp[(y >> 2) * w4 + (x >> 2)] = static_cast<int8_t>(cu.qp);
+    {
+      EdgeInfo e;
+      e.bs = 0;
+      e.qp = static_cast<int8_t>(cu.qp);
+      e.flags = (cu.bypass || (cu.pcm && S->pcm_lf_off)) ? 1 : 0;
+      e.slice = static_cast<uint8_t>(slice_idx);
+      for (int y = y0; y < y0 + n; y += 4)
+        for (int x = x0; x < x0 + n; x += 4) {
+          const int i = (y >> 2) * w4 + (x >> 2);
+          m_qp[i] = static_cast<int8_t>(cu.qp);
+          buf.edges[i] = e;
+        }
+    }
     last_qp = cu.qp;
     return !cabac.overrun();
   }

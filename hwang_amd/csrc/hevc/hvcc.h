@@ -1,11 +1,9 @@
-// HEVC behind the same boundary - as far as this backend goes: it reads what the container says about an HEVC track and
-// says no with a name.  The reference's software backend takes "h265" / "hev1" / "hevc" and hands the stream to
-// libavcodec's HEVC decoder (impls/software/software_video_decoder.cpp:128-132); its indexer returns the hvcC box
-// payload as the track's metadata (mp4_index_creator.cpp:454-469).  Here configure() parses that payload - the
-// HEVCDecoderConfigurationRecord of ISO/IEC 14496-15 8.3.3.1 and the first sequence parameter set in it (ITU-T H.265
-// 7.3.2.2, as far as the picture size and the coding block sizes) - and refuses the track with a message that says what
-// it is.  No HEVC stream exists on the build image or on the GPU boxes to check a decoder against, which is why there
-// is none.  Host only.
+// What the container says about an HEVC track: the HEVCDecoderConfigurationRecord of ISO/IEC 14496-15 8.3.3.1 (the hvcC
+// box payload the reference's indexer returns as the track's metadata, mp4_index_creator.cpp:454-469) and the first
+// sequence parameter set in it (ITU-T H.265 7.3.2.2, as far as the picture size and the coding block sizes), as text
+// for messages and for `hwang_hevc_describe_config`; and the format names that select the HEVC half of the backend
+// (the reference's software backend: impls/software/software_video_decoder.cpp:128-132).  Decoding itself is
+// hevc_parser.cpp + ../amd/k_hevc.hip.  Host only.
 #pragma once
 
 #include <cstddef>

@@ -346,8 +346,7 @@ typedef struct hwang_hevc_test_picture {
   const uint32_t* coefs;            /* level stream */
   const void* pus;                  /* InterPu[num_pus] */
   const void* weights;              /* WeightEntry[num_weights] */
-  const void* intra[3];             /* IntraTu[num_intra[c]] per plane */
-  const uint32_t* intra_first[3];   /* per plane: coding tree blocks + 1 offsets */
+  const void* intra[3];             /* IntraTu[num_intra[c]] per plane, in decoding order */
   const void* edges;                /* EdgeInfo[(w/4)*(h/4)] */
   const void* sao;                  /* SaoCtb[coding tree blocks] */
   const void* slices;               /* SliceLoop[num_slices] */

@@ -15,6 +15,22 @@
  *     (8x8 transform), the CAVLC tables beyond the prefix-code property.
  * Field/MBAFF contexts (277-398, 436-459) are not carried: interlaced coding
  * is outside the supported feature set.
+ *
+ * CAVLC checklist (no CAVLC stream from another encoder exists here, so no stream can do this):
+ *   table                               structural check                         read against the clause table
+ *   coeff_token, 0 <= nC < 2  (9-5)     complete prefix code, 62 codes          entry by entry by the round-5 reviewer, from memory: no error found
+ *   coeff_token, 2 <= nC < 4            complete prefix code                     not re-read by anyone but the author
+ *   coeff_token, 4 <= nC < 8            complete prefix code                     not re-read
+ *   coeff_token, 8 <= nC (6-bit FLC)    by construction (4 * (tc - 1) + t1, 3 = none)  -
+ *   coeff_token, chroma DC (nC = -1)    complete prefix code                     entry by entry by the round-5 reviewer: no error found
+ *   total_zeros 4x4, tzVlcIndex 1       complete prefix code                     row 1 by the round-5 reviewer: no error found
+ *   total_zeros 4x4, tzVlcIndex 2..15   complete prefix codes                    not re-read
+ *   total_zeros chroma DC (9-9)         complete prefix codes                    not re-read
+ *   run_before (9-10)                   complete prefix codes                    all seven rows by the round-5 reviewer: no error found
+ *   level_prefix / suffixLength rules   (no table: 9.2.2.1 as arithmetic)        exercised incl. level_prefix 14, 15, >= 16 (corpus --cover)
+ *   coded_block_pattern me(v) maps      permutations of 0..47                    both maps by the round-5 reviewer: no error found
+ * A wrong entry in a "not re-read" row would still be a complete prefix code only if it swapped two codewords of equal
+ * length or re-shaped the tree consistently: the check narrows the room for a typo, it does not close it.
  */
 #ifndef ORACLE_H264_TABLES_H_
 #define ORACLE_H264_TABLES_H_
