@@ -5,8 +5,9 @@
 // kernels are launched over:
 //   ResTu      one transform block with levels: k_hevc_residual (scaling 8.6.3, transforms 8.6.4) -> residual planes
 //   InterPu    one prediction block: k_hevc_inter (8.5.3.3 interpolation + weighting, + residual) -> reconstruction
-//   IntraTu    one intra-predicted transform block per colour plane, in decoding order: k_hevc_intra (8.4.4.2) takes
-//              them by ticket and lets each wait for exactly the neighbouring blocks it reads (a dataflow wavefront)
+//   IntraTu    one intra-predicted transform block per colour plane, in decoding order (8.4.4.2): k_hevc_intra_rows
+//              walks them as a wavefront of coding tree block rows (intra pictures), k_hevc_intra_flow takes them by
+//              ticket and lets each wait for exactly the neighbouring blocks it reads (scattered intra blocks)
 //   edge maps  per 4x4 luma block: boundary strengths of its left / top edge, QpY, "leave alone" flag:
 //              k_hevc_deblock (8.7.2), k_hevc_sao (8.7.3, with SaoCtb per coding tree block)
 // Surfaces are planar I420 of the coded size; luma pitch a multiple of 256 bytes, chroma pitch half of it.
@@ -114,12 +115,16 @@ struct PicParams {
   const InterPu* pus;
   const WeightEntry* weights;
   const IntraTu* intra[3];             // per plane, decoding order
+  const uint32_t* intra_ctb_first[3];  // per plane: width_ctb * height_ctb + 1 offsets into intra[c] (k_hevc_intra_rows)
+  int32_t intra_rows;                  // 1: the picture is mostly intra, k_hevc_intra_rows; 0: k_hevc_intra_flow
+  int32_t pad0;
   const EdgeInfo* edges;
   const SaoCtb* sao;
   const SliceLoop* slices;
   const uint8_t* scaling;      // ScalingFactor tables: f4[6][16] f8[6][64] f16[6][256] f32[2][1024], or null
   int16_t* resid[3];           // residual planes, pitches as the surfaces'
-  uint32_t* intra_ticket;      // [3]: next record of each plane's list (zeroed per picture)
+  uint32_t* progress;          // k_hevc_intra_rows: [plane][block row] -> blocks completed (zeroed per picture)
+  uint32_t* intra_ticket;      // k_hevc_intra_flow: [3] next record of each plane's list (zeroed per picture)
   uint8_t* intra_done[3];      // per plane, per 4x4 luma block: an intra block covering it is final (zeroed per picture)
   uint32_t* fault;             // set by a kernel whose bounded wait expired
 };

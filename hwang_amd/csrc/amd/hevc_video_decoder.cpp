@@ -192,6 +192,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     for (int c = 0; c < 3; ++c) {
       out->intra[c] = reinterpret_cast<gh::IntraTu*>(h + off_.intra[c]);
       out->cap_intra[c] = cap_.intra[c];
+      out->intra_ctb_first[c] = reinterpret_cast<uint32_t*>(h + off_.first[c]);
     }
     out->edges = reinterpret_cast<gh::EdgeInfo*>(h + off_.edges);
     out->sao = reinterpret_cast<gh::SaoCtb*>(h + off_.sao);
@@ -235,7 +236,10 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     pp.weights = reinterpret_cast<const gh::WeightEntry*>(dv + off_.weights);
     for (int c = 0; c < 3; ++c) {
       pp.intra[c] = reinterpret_cast<const gh::IntraTu*>(dv + off_.intra[c]);
+      pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dv + off_.first[c]);
     }
+    // mostly intra (an I picture, a scene cut): the row wavefront; scattered intra blocks: the dataflow kernel
+    pp.intra_rows = d.num_intra[0] * 64 > static_cast<size_t>(cw_ / 4) * (ch_ / 4) * 3 ? 1 : 0;
     pp.edges = reinterpret_cast<const gh::EdgeInfo*>(dv + off_.edges);
     pp.sao = reinterpret_cast<const gh::SaoCtb*>(dv + off_.sao);
     pp.slices = reinterpret_cast<const gh::SliceLoop*>(dv + off_.slices);
@@ -244,7 +248,8 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     pp.resid[1] = resid_ + static_cast<size_t>(y_pitch_) * ch_;
     pp.resid[2] = pp.resid[1] + static_cast<size_t>(y_pitch_ / 2) * (ch_ / 2);
     pp.intra_ticket = progress_;
-    for (int c = 0; c < 3; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(progress_ + 4) + static_cast<size_t>(c) * (cw_ / 4) * (ch_ / 4);
+    pp.progress = progress_ + 4;
+    for (int c = 0; c < 3; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(progress_ + 4 + 3 * hctb_) + static_cast<size_t>(c) * (cw_ / 4) * (ch_ / 4);
     pp.fault = fault_dev_;
     std::memcpy(set.host + off_.params, &pp, sizeof(pp));
     auto up = [&](size_t off, size_t bytes) {
@@ -260,13 +265,15 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (e == hipSuccess) e = up(off_.weights, d.num_weights * sizeof(gh::WeightEntry));
     for (int c = 0; c < 3 && e == hipSuccess; ++c) {
       e = up(off_.intra[c], d.num_intra[c] * sizeof(gh::IntraTu));
+      if (e == hipSuccess && pp.intra_rows) e = up(off_.first[c], (ctbs + 1) * sizeof(uint32_t));
     }
     if (e == hipSuccess && (d.deblock || d.sao)) e = up(off_.edges, static_cast<size_t>(cw_ / 4) * (ch_ / 4) * sizeof(gh::EdgeInfo));
     if (e == hipSuccess && d.sao) e = up(off_.sao, ctbs * sizeof(gh::SaoCtb));
     if (e == hipSuccess && (d.deblock || d.sao)) e = up(off_.slices, static_cast<size_t>(std::max(d.num_slices, 1)) * sizeof(gh::SliceLoop));
     if (e == hipSuccess && d.scaling) e = up(off_.scaling, 4064);
     if (e == hipSuccess) e = hipMemsetAsync(resid_, 0, resid_bytes_, stream_);
-    if (e == hipSuccess && (d.num_intra[0] || d.num_intra[1] || d.num_intra[2])) e = hipMemsetAsync(progress_, 0, progress_bytes_, stream_);
+    if (e == hipSuccess && (d.num_intra[0] || d.num_intra[1] || d.num_intra[2]))
+      e = hipMemsetAsync(progress_, 0, pp.intra_rows ? 16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) : progress_bytes_, stream_);
     if (e == hipSuccess) e = gh::launch_picture(pp, reinterpret_cast<const gh::PicParams*>(dv + off_.params), stream_);
     if (e == hipSuccess) e = hipEventRecord(set.done, stream_);
     if (e != hipSuccess) {
@@ -309,7 +316,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     bool busy = false;
   };
   struct Offsets {
-    size_t params, res, coefs, pus, weights, intra[3], edges, sao, slices, scaling, total;
+    size_t params, res, coefs, pus, weights, intra[3], first[3], edges, sao, slices, scaling, total;
   };
   struct Caps {
     size_t res, coefs, pus, weights, intra[3];
@@ -399,6 +406,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     off_.pus = take(cap_.pus * sizeof(gh::InterPu));
     off_.weights = take(cap_.weights * sizeof(gh::WeightEntry));
     for (int c = 0; c < 3; ++c) off_.intra[c] = take(cap_.intra[c] * sizeof(gh::IntraTu));
+    for (int c = 0; c < 3; ++c) off_.first[c] = take((ctbs + 1) * sizeof(uint32_t));
     off_.edges = take(w4h4 * sizeof(gh::EdgeInfo));
     off_.sao = take(ctbs * sizeof(gh::SaoCtb));
     off_.slices = take(gh::kMaxSlices * sizeof(gh::SliceLoop));
@@ -413,7 +421,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     resid_bytes_ = surface_bytes_ * sizeof(int16_t);
     ok = ok && hipMalloc(reinterpret_cast<void**>(&work_), surface_bytes_) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&resid_), resid_bytes_) == hipSuccess;
-    progress_bytes_ = 16 + 3 * w4h4;  // the three tickets, then a done map per plane
+    progress_bytes_ = 16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) + 3 * w4h4;  // tickets, row progress words, a done map per plane
     ok = ok && hipMalloc(reinterpret_cast<void**>(&progress_), progress_bytes_) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&rgb_dev_), static_cast<size_t>(cw_) * ch_ * 3) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&fault_host_), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
@@ -583,8 +591,29 @@ extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, cha
   pp.resid[0] = resid;
   pp.resid[1] = resid + static_cast<size_t>(pitch) * H;
   pp.resid[2] = pp.resid[1] + static_cast<size_t>(pitch / 2) * (H / 2);
-  pp.intra_ticket = reinterpret_cast<uint32_t*>(dev(16 + 3 * w4h4, nullptr));
-  for (int c = 0; c < 3 && pp.intra_ticket; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(pp.intra_ticket + 4) + static_cast<size_t>(c) * w4h4;
+  pp.intra_ticket = reinterpret_cast<uint32_t*>(dev(16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb) + 3 * w4h4, nullptr));
+  pp.progress = pp.intra_ticket ? pp.intra_ticket + 4 : nullptr;
+  for (int c = 0; c < 3 && pp.intra_ticket; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(pp.intra_ticket + 4 + 3 * hctb) + static_cast<size_t>(c) * w4h4;
+  pp.intra_rows = t->intra_rows;
+  if (t->intra_rows) {  // the row kernel's table: the lists must be grouped by coding tree block, in raster order
+    for (int c = 0; c < 3 && ok; ++c) {
+      std::vector<uint32_t> first(ctbs + 1, 0);
+      const gh::IntraTu* it = static_cast<const gh::IntraTu*>(t->intra[c]);
+      long prev = -1;
+      for (int k = 0; k < t->num_intra[c]; ++k) {
+        const long ctb = static_cast<long>(((it[k].y << (c ? 1 : 0)) >> t->log2_ctb) * wctb + ((it[k].x << (c ? 1 : 0)) >> t->log2_ctb));
+        if (ctb < prev) {
+          cleanup();
+          return fail("intra_rows: the records are not grouped by coding tree block");
+        }
+        prev = ctb;
+        ++first[static_cast<size_t>(ctb) + 1];
+      }
+      for (size_t k = 1; k <= ctbs; ++k) first[k] += first[k - 1];
+      pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dev(sizeof(uint32_t) * (ctbs + 1), first.data()));
+      ok = pp.intra_ctb_first[c] != nullptr;
+    }
+  }
   pp.fault = reinterpret_cast<uint32_t*>(dev(sizeof(uint32_t), nullptr));
   const gh::PicParams* pp_dev = reinterpret_cast<const gh::PicParams*>(dev(sizeof(pp), &pp));
   ok = ok && pp.res && pp.coefs && pp.pus && pp.weights && pp.edges && pp.sao && pp.slices && resid && pp.intra_ticket && pp.fault && pp_dev;

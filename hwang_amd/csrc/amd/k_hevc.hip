@@ -5,14 +5,14 @@
 //                     the residual written to the int16 residual planes (zeroed per picture).
 //   k_hevc_inter      8.5.3.3 fractional sample interpolation (8-tap luma, 4-tap chroma, references clamped to the
 //                     picture), default and explicit weighting, + residual: one workgroup per prediction block.
-//   k_hevc_intra      8.4.4.2 intra prediction (substitution, [1 2 1] / strong smoothing, planar, DC, 33 angles, edge
-//                     filters, I_PCM) + residual: a wavefront of coding tree block rows per colour plane - row r of
-//                     plane c follows the progress word of row r - 1 two blocks behind (the above-right block is a
-//                     neighbour); the three planes are independent chains and run side by side.
+//   k_hevc_intra_*    8.4.4.2 intra prediction (substitution, [1 2 1] / strong smoothing, planar, DC, 33 angles, edge
+//                     filters, I_PCM) + residual, one wavefront per block at a time.  _rows: a wavefront of coding tree
+//                     block rows per colour plane (intra pictures); _flow: blocks taken by ticket, each waiting for
+//                     exactly the neighbouring units it reads (the scattered intra blocks of P / B pictures).
 //   k_hevc_deblock    8.7.2.5: one thread per 4-sample edge segment, all vertical edges of the picture, then (a second
 //                     launch) all horizontal ones - HEVC's filter is defined that way, nothing is serial in it.
 //   k_hevc_sao        8.7.3: band / edge offsets from the deblocked picture into the DPB surface.
-// These are byte stencils bound by HBM and, for k_hevc_intra, by the dependent chain along a block row; no MFMA.
+// These are byte stencils bound by HBM and, for k_hevc_intra_rows, by the dependent chain along a block row; no MFMA.
 // What they compute is checked bit for bit against the CPU oracle and against the numpy statements of
 // tests/hevc_numpy.py (tests/test_gpu_hevc.py).  HEVC parity with FFmpeg is unpinned.
 #include <hip/hip_runtime.h>
@@ -213,31 +213,147 @@ __global__ __launch_bounds__(256) void k_hevc_inter(const PicParams* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------- intra
-constexpr uint32_t kIntraSpins = 1u << 22;  // bounded wait for the row above (then: fault, the host fails the picture)
+// One intra-predicted transform block (8.4.4.2), by ONE wavefront (the workgroup: __syncthreads is a wave barrier).
+// The 4n + 1 neighbours are fetched straight from where the substitution process of 8.4.4.2.2 would copy them from -
+// which sample that is follows from the availability bits alone (the nearest existing sample below / before, else the
+// first existing one), so no lane waits for another; smoothing, the extended reference of the angular modes and the
+// prediction itself are lane-parallel over LDS.  line[i]: i < 2n left (bottom-up), 2n the corner, > 2n top.
+__device__ void intra_block(const IntraTu& tu, int c, uint8_t* plane, const int16_t* res, int pitch, int* line, int* filt_line, int* refbuf, int lane) {
+  const int ushift = c ? 1 : 2;  // availability comes in units of 4 luma / 2 chroma samples
+  const int log2 = tu.log2, n = 1 << log2, x0 = tu.x, y0 = tu.y, nu = (2 * n) >> ushift;
+  uint8_t* dst = plane + static_cast<size_t>(y0) * pitch + x0;
+  const int16_t* rs = res + static_cast<size_t>(y0) * pitch + x0;
+  if (tu.mode == kIntraPcm) {
+    for (int i = lane; i < n * n; i += 64) dst[static_cast<size_t>(i / n) * pitch + i % n] = static_cast<uint8_t>(clip8(rs[static_cast<size_t>(i / n) * pitch + i % n]));
+  } else {
+  const int mode = tu.mode;
+  // availability in line order, one bit per unit: left units bottom-up, the corner, top units left to right
+  uint64_t mask = 0;
+  for (int k = 0; k < nu; ++k) mask |= static_cast<uint64_t>((tu.avail_left >> (nu - 1 - k)) & 1) << k;
+  mask |= static_cast<uint64_t>(tu.flags & INTRA_CORNER ? 1 : 0) << nu;
+  mask |= static_cast<uint64_t>(tu.avail_top & ((1u << nu) - 1)) << (nu + 1);
+  for (int i = lane; i <= 4 * n; i += 64) {
+    int v = 128;
+    if (mask) {
+      // the unit of sample i, and the unit its value comes from
+      int u = i < 2 * n ? i >> ushift : i == 2 * n ? nu : nu + 1 + ((i - 2 * n - 1) >> ushift);
+      int src = i;
+      if (!((mask >> u) & 1)) {
+        const uint64_t below = mask & ((1ull << u) - 1);
+        if (below) {
+          const int su = 63 - __builtin_clzll(below);  // nearest existing unit before: its LAST sample
+          src = su < nu ? (su << ushift) + (1 << ushift) - 1 : su == nu ? 2 * n : 2 * n + 1 + ((su - nu - 1) << ushift) + (1 << ushift) - 1;
+        } else {
+          const int su = __builtin_ctzll(mask);        // nothing before: the FIRST existing sample of the line
+          src = su < nu ? (su << ushift) : su == nu ? 2 * n : 2 * n + 1 + ((su - nu - 1) << ushift);
+        }
+      }
+      if (src < 2 * n) v = plane[static_cast<size_t>(y0 + 2 * n - 1 - src) * pitch + x0 - 1];
+      else if (src == 2 * n) v = plane[static_cast<size_t>(y0 - 1) * pitch + x0 - 1];
+      else v = plane[static_cast<size_t>(y0 - 1) * pitch + x0 + src - 2 * n - 1];
+    }
+    line[i] = v;
+  }
+  __syncthreads();
+  // 8.4.4.2.3: which smoothing, if any (every lane decides the same)
+  int filt = 0;
+  if (c == 0 && mode != 1 && n != 4) {
+    const int a = iabs(mode - 26), b = iabs(mode - 10);
+    const int dist = a < b ? a : b, thres = n == 8 ? 7 : n == 16 ? 1 : 0;
+    if (dist > thres) {
+      filt = 1;
+      // corner = line[2n], p[-1][2n-1] = line[0], p[2n-1][-1] = line[4n], the middles line[n] (left) and line[3n] (top)
+      if ((tu.flags & INTRA_STRONG) && n == 32 && iabs(line[64] + line[128] - 2 * line[96]) < 8 && iabs(line[64] + line[0] - 2 * line[32]) < 8) filt = 2;
+    }
+  }
+  const int* ln = line;
+  if (filt) {
+    for (int i = lane; i <= 4 * n; i += 64) {
+      int v;
+      if (i == 0 || i == 4 * n) v = line[i];
+      else if (filt == 2) {
+        if (i == 64) v = line[64];
+        else if (i < 64) v = (i * line[64] + (64 - i) * line[0] + 32) >> 6;        // left: distance from the corner is 64 - i
+        else v = ((128 - i) * line[64] + (i - 64) * line[128] + 32) >> 6;
+      } else {
+        v = (line[i - 1] + 2 * line[i] + line[i + 1] + 2) >> 2;
+      }
+      filt_line[i] = v;
+    }
+    __syncthreads();
+    ln = filt_line;
+  }
+#define LEFT(k) ln[2 * n - (k)]       /* k = 0: corner, k = 1 + j: p[-1][j] */
+#define TOP(k) ln[2 * n + (k)]        /* k = 0: corner, k = 1 + j: p[j][-1] */
+  int* ref = refbuf + 33;
+  const int angle = mode >= 2 ? kAngle[mode] : 0;
+  const bool vertical = mode >= 18;
+  if (mode >= 2) {
+    const int last = (n * angle) >> 5;
+    for (int k = lane - 32; k <= 2 * n; k += 64) {
+      if (k >= 0) {
+        if (k <= n || angle >= 0) ref[k] = vertical ? TOP(k) : LEFT(k);
+      } else if (angle < 0 && last < -1 && k >= last) {
+        const int t = (k * kInvAngle[mode - 11] + 128) >> 8;
+        ref[k] = vertical ? LEFT(t) : TOP(t);
+      }
+    }
+    __syncthreads();
+  }
+  int dc = 0;
+  if (mode == 1) {
+    int sum = n;
+    for (int k = 1; k <= n; ++k) sum += LEFT(k) + TOP(k);
+    dc = sum >> (log2 + 1);
+  }
+  for (int i = lane; i < n * n; i += 64) {
+    const int x = i & (n - 1), y = i >> log2;
+    int v;
+    if (mode == 0) {
+      v = ((n - 1 - x) * LEFT(1 + y) + (x + 1) * TOP(1 + n) + (n - 1 - y) * TOP(1 + x) + (y + 1) * LEFT(1 + n) + n) >> (log2 + 1);
+    } else if (mode == 1) {
+      v = dc;
+      if (c == 0 && n < 32) {
+        if (x == 0 && y == 0) v = (LEFT(1) + 2 * dc + TOP(1) + 2) >> 2;
+        else if (y == 0) v = (TOP(1 + x) + 3 * dc + 2) >> 2;
+        else if (x == 0) v = (LEFT(1 + y) + 3 * dc + 2) >> 2;
+      }
+    } else {
+      const int j = vertical ? y : x, ii = vertical ? x : y;  // j: distance from the main reference
+      const int idx = ((j + 1) * angle) >> 5, fact = ((j + 1) * angle) & 31;
+      v = fact ? ((32 - fact) * ref[ii + idx + 1] + fact * ref[ii + idx + 2] + 16) >> 5 : ref[ii + idx + 1];
+      if (c == 0 && n < 32) {
+        if (mode == 26 && x == 0) v = clip8(TOP(1) + ((LEFT(1 + y) - LEFT(0)) >> 1));
+        if (mode == 10 && y == 0) v = clip8(LEFT(1) + ((TOP(1 + x) - TOP(0)) >> 1));
+      }
+    }
+    dst[static_cast<size_t>(y) * pitch + x] = static_cast<uint8_t>(clip8(v + rs[static_cast<size_t>(y) * pitch + x]));
+  }
+#undef LEFT
+#undef TOP
+  }
+}
 
-// Intra prediction as a dataflow wavefront.  Workgroups of ONE wavefront (__syncthreads is a wave barrier here) take
-// the records of a colour plane's list by ticket, in decoding order; a block waits for exactly the neighbouring 4x4
-// units it reads that an earlier record of this picture writes (IntraTu::wait_*: the host knows which neighbours are
-// intra) - each has a "done" byte - and marks its own units when its samples are out.  A ticket holder only ever waits
-// for lower tickets, which are held by running wavefronts: no deadlock whatever the grid.  H.265's z-order leaves a
-// row pipeline 17 rows of parallelism at 1080p; this follows the real dependences: the diagonal of an I picture,
-// and next to nothing in the scattered intra blocks of P and B pictures.
-// Per block: the 4n + 1 neighbours are fetched straight from where the substitution process of 8.4.4.2.2 would copy
-// them from - which sample that is follows from the availability bits alone (the nearest existing sample below /
-// before, else the first existing one), so no lane waits for another; smoothing, the extended reference of the
-// angular modes and the prediction itself are lane-parallel over LDS.
-__global__ __launch_bounds__(64) void k_hevc_intra(const PicParams* __restrict__ ppp) {
+constexpr uint32_t kIntraSpins = 1u << 22;  // bounded wait for a neighbour (then: fault, the host fails the picture)
+
+// Intra prediction, variant 1: a dataflow wavefront for pictures whose intra blocks are scattered (P and B pictures).
+// Workgroups of one wavefront take the records of a colour plane's list by ticket, in decoding order; a block waits
+// for exactly the neighbouring 4x4 units it reads that an earlier record of this picture writes (IntraTu::wait_*: the
+// host knows which neighbours are intra) - each has a "done" byte - and marks its own units when its samples are out.
+// A ticket holder only ever waits for lower tickets, which are held by running wavefronts: no deadlock whatever the
+// grid.  NOT for intra pictures: there nearly every block waits for its predecessor, and a thousand wavefronts
+// spinning on their neighbours starve the few that can run (measured: 415 ms per picture,
+// profiles/r06_hevc_dataflow_everywhere_kernel_stats.csv); those take variant 2.
+__global__ __launch_bounds__(64) void k_hevc_intra_flow(const PicParams* __restrict__ ppp) {
   const PicParams& pp = *ppp;
   const int c = blockIdx.y, lane = threadIdx.x;
-  const int pitch = c ? pp.c_pitch : pp.y_pitch, ushift = c ? 1 : 2;  // a unit: 4 luma / 2 chroma samples = one 4x4 luma block
-  const int sub = c ? 1 : 0, w4 = pp.width >> 2;
+  const int pitch = c ? pp.c_pitch : pp.y_pitch, ushift = c ? 1 : 2, sub = c ? 1 : 0, w4 = pp.width >> 2;
   uint8_t* plane = plane_of(pp.recon, c);
-  const int16_t* res = pp.resid[c];
   const IntraTu* tus = pp.intra[c];
   const uint32_t count = static_cast<uint32_t>(pp.num_intra[c]);
   uint32_t* ticket = pp.intra_ticket + c;
   uint8_t* done = pp.intra_done[c];
-  __shared__ int line[132], filt_line[132], refbuf[3 * 32 + 8];  // line[i]: i < 2n left (bottom-up), 2n corner, > 2n top
+  __shared__ int line[132], filt_line[132], refbuf[3 * 32 + 8];
   __shared__ uint32_t s_ticket;
   for (;;) {
     if (lane == 0) s_ticket = atomicAdd(ticket, 1u);
@@ -245,149 +361,86 @@ __global__ __launch_bounds__(64) void k_hevc_intra(const PicParams* __restrict__
     const uint32_t ti = s_ticket;
     __syncthreads();
     if (ti >= count) return;
-    {
-      const IntraTu tu = tus[ti];
-      const int log2 = tu.log2, n = 1 << log2, x0 = tu.x, y0 = tu.y;
-      const int ux = (x0 << sub) >> 2, uy = (y0 << sub) >> 2, nu = (2 * n) >> ushift;
-      if (tu.mode != kIntraPcm && (tu.wait_left | tu.wait_top | (tu.flags & INTRA_WAIT_CORNER))) {
-        // lane k < nu: left unit k (from the top); nu <= k < 2 nu: top unit k - nu; k = 2 nu: the corner
-        const uint8_t* flag = nullptr;
-        if (lane < nu) {
-          if ((tu.wait_left >> lane) & 1) flag = done + (uy + lane) * w4 + ux - 1;
-        } else if (lane < 2 * nu) {
-          if ((tu.wait_top >> (lane - nu)) & 1) flag = done + (uy - 1) * w4 + ux + lane - nu;
-        } else if (lane == 2 * nu && (tu.flags & INTRA_WAIT_CORNER)) {
-          flag = done + (uy - 1) * w4 + ux - 1;
-        }
-        uint32_t spins = 0;
-        for (;;) {
-          const bool ok = !flag || __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0;
-          if (__all(ok)) break;
-          __builtin_amdgcn_s_sleep(1);
-          if (++spins > kIntraSpins) {
-            if (lane == 0) atomicExch(pp.fault, 1u);
-            return;
-          }
+    const IntraTu tu = tus[ti];
+    const int n = 1 << tu.log2, ux = (tu.x << sub) >> 2, uy = (tu.y << sub) >> 2, nu = (2 * n) >> ushift;
+    if (tu.mode != kIntraPcm && (tu.wait_left | tu.wait_top | (tu.flags & INTRA_WAIT_CORNER))) {
+      // lane k < nu: left unit k (from the top); nu <= k < 2 nu: top unit k - nu; k = 2 nu: the corner
+      const uint8_t* flag = nullptr;
+      if (lane < nu) {
+        if ((tu.wait_left >> lane) & 1) flag = done + (uy + lane) * w4 + ux - 1;
+      } else if (lane < 2 * nu) {
+        if ((tu.wait_top >> (lane - nu)) & 1) flag = done + (uy - 1) * w4 + ux + lane - nu;
+      } else if (lane == 2 * nu && (tu.flags & INTRA_WAIT_CORNER)) {
+        flag = done + (uy - 1) * w4 + ux - 1;
+      }
+      uint32_t spins = 0;
+      for (;;) {
+        const bool ok = !flag || __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (__all(ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kIntraSpins) {
+          if (lane == 0) atomicExch(pp.fault, 1u);
+          return;
         }
       }
-      uint8_t* dst = plane + static_cast<size_t>(y0) * pitch + x0;
-      const int16_t* rs = res + static_cast<size_t>(y0) * pitch + x0;
-      if (tu.mode == kIntraPcm) {
-        for (int i = lane; i < n * n; i += 64) dst[static_cast<size_t>(i / n) * pitch + i % n] = static_cast<uint8_t>(clip8(rs[static_cast<size_t>(i / n) * pitch + i % n]));
-      } else {
-      const int mode = tu.mode;
-      // availability in line order, one bit per unit: left units bottom-up, the corner, top units left to right
-      uint64_t mask = 0;
-      for (int k = 0; k < nu; ++k) mask |= static_cast<uint64_t>((tu.avail_left >> (nu - 1 - k)) & 1) << k;
-      mask |= static_cast<uint64_t>(tu.flags & INTRA_CORNER ? 1 : 0) << nu;
-      mask |= static_cast<uint64_t>(tu.avail_top & ((1u << nu) - 1)) << (nu + 1);
-      for (int i = lane; i <= 4 * n; i += 64) {
-        int v = 128;
-        if (mask) {
-          // the unit of sample i, and the unit its value comes from
-          int u = i < 2 * n ? i >> ushift : i == 2 * n ? nu : nu + 1 + ((i - 2 * n - 1) >> ushift);
-          int src = i;
-          if (!((mask >> u) & 1)) {
-            const uint64_t below = mask & ((1ull << u) - 1);
-            if (below) {
-              const int su = 63 - __builtin_clzll(below);  // nearest existing unit before: its LAST sample
-              src = su < nu ? (su << ushift) + (1 << ushift) - 1 : su == nu ? 2 * n : 2 * n + 1 + ((su - nu - 1) << ushift) + (1 << ushift) - 1;
-            } else {
-              const int su = __builtin_ctzll(mask);        // nothing before: the FIRST existing sample of the line
-              src = su < nu ? (su << ushift) : su == nu ? 2 * n : 2 * n + 1 + ((su - nu - 1) << ushift);
-            }
-          }
-          if (src < 2 * n) v = plane[static_cast<size_t>(y0 + 2 * n - 1 - src) * pitch + x0 - 1];
-          else if (src == 2 * n) v = plane[static_cast<size_t>(y0 - 1) * pitch + x0 - 1];
-          else v = plane[static_cast<size_t>(y0 - 1) * pitch + x0 + src - 2 * n - 1];
-        }
-        line[i] = v;
-      }
-      __syncthreads();
-      // 8.4.4.2.3: which smoothing, if any (every lane decides the same)
-      int filt = 0;
-      if (c == 0 && mode != 1 && n != 4) {
-        const int a = iabs(mode - 26), b = iabs(mode - 10);
-        const int dist = a < b ? a : b, thres = n == 8 ? 7 : n == 16 ? 1 : 0;
-        if (dist > thres) {
-          filt = 1;
-          // corner = line[2n], p[-1][2n-1] = line[0], p[2n-1][-1] = line[4n], the middles line[n] (left) and line[3n] (top)
-          if ((tu.flags & INTRA_STRONG) && n == 32 && iabs(line[64] + line[128] - 2 * line[96]) < 8 && iabs(line[64] + line[0] - 2 * line[32]) < 8) filt = 2;
-        }
-      }
-      const int* ln = line;
-      if (filt) {
-        for (int i = lane; i <= 4 * n; i += 64) {
-          int v;
-          if (i == 0 || i == 4 * n) v = line[i];
-          else if (filt == 2) {
-            if (i == 64) v = line[64];
-            else if (i < 64) v = (i * line[64] + (64 - i) * line[0] + 32) >> 6;        // left: distance from the corner is 64 - i
-            else v = ((128 - i) * line[64] + (i - 64) * line[128] + 32) >> 6;
-          } else {
-            v = (line[i - 1] + 2 * line[i] + line[i + 1] + 2) >> 2;
-          }
-          filt_line[i] = v;
-        }
-        __syncthreads();
-        ln = filt_line;
-      }
-#define LEFT(k) ln[2 * n - (k)]       /* k = 0: corner, k = 1 + j: p[-1][j] */
-#define TOP(k) ln[2 * n + (k)]        /* k = 0: corner, k = 1 + j: p[j][-1] */
-      int* ref = refbuf + 33;
-      const int angle = mode >= 2 ? kAngle[mode] : 0;
-      const bool vertical = mode >= 18;
-      if (mode >= 2) {
-        const int last = (n * angle) >> 5;
-        for (int k = lane - 32; k <= 2 * n; k += 64) {
-          if (k >= 0) {
-            if (k <= n || angle >= 0) ref[k] = vertical ? TOP(k) : LEFT(k);
-          } else if (angle < 0 && last < -1 && k >= last) {
-            const int t = (k * kInvAngle[mode - 11] + 128) >> 8;
-            ref[k] = vertical ? LEFT(t) : TOP(t);
-          }
-        }
-        __syncthreads();
-      }
-      int dc = 0;
-      if (mode == 1) {
-        int sum = n;
-        for (int k = 1; k <= n; ++k) sum += LEFT(k) + TOP(k);
-        dc = sum >> (log2 + 1);
-      }
-      for (int i = lane; i < n * n; i += 64) {
-        const int x = i & (n - 1), y = i >> log2;
-        int v;
-        if (mode == 0) {
-          v = ((n - 1 - x) * LEFT(1 + y) + (x + 1) * TOP(1 + n) + (n - 1 - y) * TOP(1 + x) + (y + 1) * LEFT(1 + n) + n) >> (log2 + 1);
-        } else if (mode == 1) {
-          v = dc;
-          if (c == 0 && n < 32) {
-            if (x == 0 && y == 0) v = (LEFT(1) + 2 * dc + TOP(1) + 2) >> 2;
-            else if (y == 0) v = (TOP(1 + x) + 3 * dc + 2) >> 2;
-            else if (x == 0) v = (LEFT(1 + y) + 3 * dc + 2) >> 2;
-          }
-        } else {
-          const int j = vertical ? y : x, ii = vertical ? x : y;  // j: distance from the main reference
-          const int idx = ((j + 1) * angle) >> 5, fact = ((j + 1) * angle) & 31;
-          v = fact ? ((32 - fact) * ref[ii + idx + 1] + fact * ref[ii + idx + 2] + 16) >> 5 : ref[ii + idx + 1];
-          if (c == 0 && n < 32) {
-            if (mode == 26 && x == 0) v = clip8(TOP(1) + ((LEFT(1 + y) - LEFT(0)) >> 1));
-            if (mode == 10 && y == 0) v = clip8(LEFT(1) + ((TOP(1 + x) - TOP(0)) >> 1));
-          }
-        }
-        dst[static_cast<size_t>(y) * pitch + x] = static_cast<uint8_t>(clip8(v + rs[static_cast<size_t>(y) * pitch + x]));
-      }
-#undef LEFT
-#undef TOP
-      }
-      // the block's samples are out: mark the units it covers (a release after the fence; waiters acquire)
-      __threadfence();
-      __syncthreads();
-      const int cnt = n >> ushift;
-      if (lane < cnt * cnt) __hip_atomic_store(done + (uy + lane / cnt) * w4 + ux + lane % cnt, static_cast<uint8_t>(1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
+    intra_block(tu, c, plane, pp.resid[c], pitch, line, filt_line, refbuf, lane);
+    // the block's samples are out: mark the units it covers (a release after the fence; waiters acquire)
+    __threadfence();
+    __syncthreads();
+    const int cnt = n >> ushift;
+    if (lane < cnt * cnt) __hip_atomic_store(done + (uy + lane / cnt) * w4 + ux + lane % cnt, static_cast<uint8_t>(1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
+}
+
+// Intra prediction, variant 2: a wavefront of coding tree block rows, for pictures that are mostly intra.  One
+// wavefront per (row, colour plane); row r follows the progress word of row r - 1 two blocks behind (the above-right
+// block is a neighbour); within a block the transform blocks are a dependent chain anyway (z-order: each quadrant leans
+// on the ones before it).  17 rows at 1080p with 64x64 blocks is all the parallelism that leaves - but nobody spins
+// except one wavefront per row.
+__global__ __launch_bounds__(64) void k_hevc_intra_rows(const PicParams* __restrict__ ppp) {
+  const PicParams& pp = *ppp;
+  const int c = blockIdx.y, row = blockIdx.x, lane = threadIdx.x;
+  const int pitch = c ? pp.c_pitch : pp.y_pitch;
+  uint8_t* plane = plane_of(pp.recon, c);
+  const IntraTu* tus = pp.intra[c];
+  const uint32_t* first = pp.intra_ctb_first[c] + row * pp.width_ctb;
+  uint32_t* progress = pp.progress + c * pp.height_ctb;
+  __shared__ int line[132], filt_line[132], refbuf[3 * 32 + 8];
+  uint32_t t_next = first[0];
+  int published = 0;
+  for (int col = 0; col < pp.width_ctb; ++col) {
+    const uint32_t t0 = t_next, t1 = first[col + 1];
+    t_next = t1;
+    if (t1 == t0) continue;  // nothing intra in this block
+    // the blocks passed without work are final too: say so before waiting, or the row below waits for this row's wait
+    if (published < col) {
+      if (lane == 0) __hip_atomic_store(&progress[row], static_cast<uint32_t>(col), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      published = col;
+    }
+    if (row > 0) {
+      const uint32_t need = static_cast<uint32_t>(col + 2 < pp.width_ctb ? col + 2 : pp.width_ctb);
+      uint32_t spins = 0;
+      while (__hip_atomic_load(&progress[row - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > kIntraSpins) {
+          if (lane == 0) atomicExch(pp.fault, 1u);
+          return;
+        }
+      }
+    }
+    for (uint32_t ti = t0; ti < t1; ++ti) {
+      intra_block(tus[ti], c, plane, pp.resid[c], pitch, line, filt_line, refbuf, lane);
+      __threadfence_block();
+      __syncthreads();
+    }
+    // everything up to this block of the row is final as far as later rows are concerned
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&progress[row], static_cast<uint32_t>(col + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    published = col + 1;
+  }
+  if (published < pp.width_ctb && lane == 0) __hip_atomic_store(&progress[row], static_cast<uint32_t>(pp.width_ctb), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // -------------------------------------------------------------------------------------------------- deblocking
@@ -526,9 +579,13 @@ hipError_t launch_picture(const PicParams& pp, const PicParams* pp_dev, hipStrea
   if (pp.num_res) hipLaunchKernelGGL(k_hevc_residual, dim3((pp.num_res + kResWaves - 1) / kResWaves), dim3(64 * kResWaves), 0, stream, pp_dev);
   if (pp.num_pu) hipLaunchKernelGGL(k_hevc_inter, dim3(pp.num_pu), dim3(256), 0, stream, pp_dev);
   if (pp.num_intra[0] || pp.num_intra[1] || pp.num_intra[2]) {
-    // persistent wavefronts: enough to cover a diagonal of the picture, no more than there are records
-    const int most = pp.num_intra[0] > pp.num_intra[1] ? pp.num_intra[0] : pp.num_intra[1];
-    hipLaunchKernelGGL(k_hevc_intra, dim3(most < 1024 ? most : 1024, 3), dim3(64), 0, stream, pp_dev);
+    if (pp.intra_rows) {
+      hipLaunchKernelGGL(k_hevc_intra_rows, dim3(pp.height_ctb, 3), dim3(64), 0, stream, pp_dev);
+    } else {
+      // as many wavefronts as a sparse picture has independent blocks in flight; each takes records until none are left
+      const int most = pp.num_intra[0] > pp.num_intra[1] ? pp.num_intra[0] : pp.num_intra[1];
+      hipLaunchKernelGGL(k_hevc_intra_flow, dim3(most < 256 ? most : 256, 3), dim3(64), 0, stream, pp_dev);
+    }
   }
   if (pp.deblock_enabled) {
     const int units = (pp.width >> 2) * (pp.height >> 2);

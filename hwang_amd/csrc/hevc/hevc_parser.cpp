@@ -1032,6 +1032,7 @@ struct Parser::Impl {
     done.pcm_bits_luma = S->pcm_bits_y;
     done.pcm_bits_chroma = S->pcm_bits_c;
     const int ctbs = S->wctb * S->hctb;
+    for (int c = 0; c < 3; ++c) std::fill(buf.intra_ctb_first[c], buf.intra_ctb_first[c] + ctbs + 1, 0u);
     std::memset(buf.sao, 0, sizeof(SaoCtb) * static_cast<size_t>(ctbs));
     pic_open = true;
     return true;
@@ -1090,6 +1091,18 @@ struct Parser::Impl {
     }
     done.deblock = any_bs;
     done.num_slices = num_slices;
+    // the per-plane intra lists are complete: the per-block counts become offsets
+    {
+      const int ctbs = S->wctb * S->hctb;
+      for (int c = 0; c < 3; ++c) {
+        uint32_t at = 0;
+        for (int k = 0; k <= ctbs; ++k) {
+          const uint32_t nk = buf.intra_ctb_first[c][k];
+          buf.intra_ctb_first[c][k] = at;
+          at += nk;
+        }
+      }
+    }
     if (S->scaling_enabled) {
       done.scaling = true;
       std::memcpy(buf.scaling, P->scaling_present ? &P->scaling : &S->scaling, sizeof(Scaling));
@@ -1406,6 +1419,7 @@ struct Parser::Impl {
   bool emit_intra(int c, int x, int y, int log2, int mode) {
     if (done.num_intra[c] >= buf.cap_intra[c]) return fail("intra block list overflow");
     IntraTu& t = buf.intra[c][done.num_intra[c]++];
+    ++buf.intra_ctb_first[c][((y << (c ? 1 : 0)) >> S->log2_ctb) * S->wctb + ((x << (c ? 1 : 0)) >> S->log2_ctb)];  // (a count until close_picture)
     t.x = static_cast<uint16_t>(x);
     t.y = static_cast<uint16_t>(y);
     t.log2 = static_cast<uint8_t>(log2);

@@ -338,6 +338,8 @@ int hwang_hevc_describe_config(const uint8_t* hvcc, size_t size, char* out, size
 typedef struct hwang_hevc_test_picture {
   int32_t width, height, log2_ctb;  /* coded size, multiples of 8 */
   int32_t cb_qp_offset, cr_qp_offset, sao_enabled, deblock_enabled;
+  int32_t intra_rows;               /* 1: k_hevc_intra_rows (records grouped by coding tree block), 0: k_hevc_intra_flow */
+  int32_t reserved;
   const uint8_t* recon_in;          /* I420 (w*h*3/2): what the reconstruction surface holds before the kernels run */
   const uint8_t* refs;              /* num_refs I420 pictures back to back: reference surfaces 0 .. num_refs - 1 */
   int32_t num_refs;

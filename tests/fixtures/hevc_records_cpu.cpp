@@ -38,6 +38,7 @@ struct CpuSink : public hevc::PictureSink {
   std::vector<gh::InterPu> pus;
   std::vector<gh::WeightEntry> weights;
   std::vector<gh::IntraTu> intra[3];
+  std::vector<uint32_t> first[3];
   std::vector<gh::EdgeInfo> edges;
   std::vector<gh::SaoCtb> sao;
   std::vector<gh::SliceLoop> slices = std::vector<gh::SliceLoop>(gh::kMaxSlices);
@@ -56,6 +57,7 @@ struct CpuSink : public hevc::PictureSink {
     weights.assign(2 * 16 * gh::kMaxSlices, gh::WeightEntry());
     for (int c = 0; c < 3; ++c) {
       intra[c].assign((c ? w4h4 / 4 : w4h4) + 64, gh::IntraTu());
+      first[c].assign(ctbs + 1, 0);
     }
     edges.assign(w4h4, gh::EdgeInfo());
     sao.assign(ctbs, gh::SaoCtb());
@@ -78,6 +80,7 @@ struct CpuSink : public hevc::PictureSink {
     for (int c = 0; c < 3; ++c) {
       out->intra[c] = intra[c].data();
       out->cap_intra[c] = intra[c].size();
+      out->intra_ctb_first[c] = first[c].data();
     }
     out->edges = edges.data();
     out->sao = sao.data();

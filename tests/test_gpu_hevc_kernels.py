@@ -28,7 +28,7 @@ assert (RES.itemsize, PU.itemsize, WT.itemsize, ITU.itemsize, SAO.itemsize, SLIC
 
 class PictureArgs(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("log2_ctb", C.c_int32), ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32),
-                ("sao_enabled", C.c_int32), ("deblock_enabled", C.c_int32), ("recon_in", C.c_void_p), ("refs", C.c_void_p), ("num_refs", C.c_int32),
+                ("sao_enabled", C.c_int32), ("deblock_enabled", C.c_int32), ("intra_rows", C.c_int32), ("reserved", C.c_int32), ("recon_in", C.c_void_p), ("refs", C.c_void_p), ("num_refs", C.c_int32),
                 ("num_res", C.c_int32), ("num_coefs", C.c_int32), ("num_pus", C.c_int32), ("num_weights", C.c_int32), ("num_intra", C.c_int32 * 3),
                 ("num_slices", C.c_int32), ("res", C.c_void_p), ("coefs", C.c_void_p), ("pus", C.c_void_p), ("weights", C.c_void_p),
                 ("intra", C.c_void_p * 3), ("edges", C.c_void_p), ("sao", C.c_void_p), ("slices", C.c_void_p),
@@ -36,7 +36,7 @@ class PictureArgs(C.Structure):
 
 
 def run_picture(hw, w, h, log2_ctb=4, recon=None, refs=(), res=None, coefs=None, pus=None, weights=None, intra=(None, None, None),
-                edges=None, sao=None, slices=None, cb_off=0, cr_off=0, deblock=False, want_resid=False):
+                edges=None, sao=None, slices=None, cb_off=0, cr_off=0, deblock=False, want_resid=False, intra_rows=False):
     import torch
     assert torch.cuda.is_available(), "GPU tests need a GPU; there is no fallback"
     from hwang_amd._capi import lib
@@ -50,7 +50,7 @@ def run_picture(hw, w, h, log2_ctb=4, recon=None, refs=(), res=None, coefs=None,
         return a
     t = PictureArgs()
     t.width, t.height, t.log2_ctb, t.cb_qp_offset, t.cr_qp_offset = w, h, log2_ctb, cb_off, cr_off
-    t.sao_enabled, t.deblock_enabled = int(sao is not None), int(deblock)
+    t.sao_enabled, t.deblock_enabled, t.intra_rows = int(sao is not None), int(deblock), int(intra_rows)
     fs = w * h * 3 // 2
     rin = arr(recon if recon is not None else np.full(fs, 128), np.uint8)
     t.recon_in = rin.ctypes.data
@@ -64,6 +64,10 @@ def run_picture(hw, w, h, log2_ctb=4, recon=None, refs=(), res=None, coefs=None,
     for c in range(3):
         it = arr(intra[c], ITU)
         n = 0 if intra[c] is None else len(it)
+        if n and intra_rows:       # the row kernel wants the list grouped by coding tree block, in raster order
+            sub = 1 if c else 0
+            ctb_of = ((it["y"].astype(int) << sub) >> log2_ctb) * wctb + ((it["x"].astype(int) << sub) >> log2_ctb)
+            it = arr(it[np.argsort(ctb_of, kind="stable")], ITU)
         t.intra[c], t.num_intra[c] = it.ctypes.data, n
     e_ = arr(edges, EDGE, (w // 4) * (h // 4))
     s_ = arr(sao, SAO, ctbs)
@@ -169,9 +173,10 @@ def test_intra_kernel(hw, log2):
                 mode = (mode + 1) % 35
         intra = [None, None, None]
         intra[c_idx] = np.array(recs, dtype=ITU)
-        got, _ = run_picture(hw, W, H, log2_ctb=6, recon=recon, intra=tuple(intra))
-        for (x, y, want) in expect:
-            assert np.array_equal(got[c_idx][y:y + n, x:x + n].astype(np.int64), want), (c_idx, x, y)
+        for rows_kernel in (False, True):
+            got, _ = run_picture(hw, W, H, log2_ctb=6, recon=recon, intra=tuple(intra), intra_rows=rows_kernel)
+            for (x, y, want) in expect:
+                assert np.array_equal(got[c_idx][y:y + n, x:x + n].astype(np.int64), want), (c_idx, x, y, rows_kernel)
 
 
 def test_inter_kernel(hw):
@@ -353,5 +358,7 @@ def test_intra_dataflow_waits_for_its_neighbours(hw):
             plane[y:y + n, x:x + n] = np.clip(pred + r, 0, 255)
             mode = 2 + (mode - 1) % 33 if (bx + by) % 3 else (bx % 2)     # angular modes mostly, planar / DC now and then
     intra = (np.array(recs, dtype=ITU), None, None)
-    got, _ = run_picture(hw, W, H, log2_ctb=6, intra=intra, res=np.array(res, dtype=RES), coefs=np.array(coefs, dtype=np.uint32))
-    assert np.array_equal(got[0].astype(np.int64), plane)
+    for rows_kernel in (False, True):   # (for the row kernel every 8x8 block is a "coding tree block" of its own: raster order is its order)
+        got, _ = run_picture(hw, W, H, log2_ctb=3 if rows_kernel else 6, intra=intra, res=np.array(res, dtype=RES), coefs=np.array(coefs, dtype=np.uint32),
+                             intra_rows=rows_kernel)
+        assert np.array_equal(got[0].astype(np.int64), plane), rows_kernel
