@@ -121,6 +121,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (stream_) HWANG_HIP_RETURN(hipStreamSynchronize(stream_));
     if (fault_host_ && *fault_host_) {
       *fault_host_ = 0;
+      resid_dirty_ = true;
       return Result(false, "AMDVideoDecoder (HEVC): the intra wavefront timed out waiting for the row above; the picture is invalid");
     }
     return take_error();
@@ -230,20 +231,27 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     pp.recon = d.sao ? surface_of(work_) : pp.dst;
     for (int i = 0; i < d.num_ref_slots; ++i) pp.refs[d.ref_slots[i]] = surface_of(surf_[d.ref_slots[i]].dev);
     uint8_t* dv = set.dev;
-    pp.res = reinterpret_cast<const gh::ResTu*>(dv + off_.res);
-    pp.coefs = reinterpret_cast<const uint32_t*>(dv + off_.coefs);
-    pp.pus = reinterpret_cast<const gh::InterPu*>(dv + off_.pus);
-    pp.weights = reinterpret_cast<const gh::WeightEntry*>(dv + off_.weights);
-    for (int c = 0; c < 3; ++c) {
-      pp.intra[c] = reinterpret_cast<const gh::IntraTu*>(dv + off_.intra[c]);
-      pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dv + off_.first[c]);
-    }
+    const size_t ctbs = static_cast<size_t>(wctb_) * hctb_;
     // mostly intra (an I picture, a scene cut): the row wavefront; scattered intra blocks: the dataflow kernel
     pp.intra_rows = d.num_intra[0] * 64 > static_cast<size_t>(cw_ / 4) * (ch_ / 4) * 3 ? 1 : 0;
+    // part B packed downwards in place (every list moves to where the one before it ends): one copy instead of ten
+    size_t packed = off_.part_b;
+    auto pack = [&](size_t from, size_t bytes) {
+      const size_t at = packed;
+      if (bytes && from != at) std::memmove(set.host + at, set.host + from, bytes);
+      packed = (at + bytes + 15) & ~static_cast<size_t>(15);
+      return at;
+    };
+    pp.res = reinterpret_cast<const gh::ResTu*>(dv + pack(off_.res, d.num_res * sizeof(gh::ResTu)));
+    pp.coefs = reinterpret_cast<const uint32_t*>(dv + pack(off_.coefs, d.num_coefs * sizeof(uint32_t)));
+    pp.pus = reinterpret_cast<const gh::InterPu*>(dv + pack(off_.pus, d.num_pus * sizeof(gh::InterPu)));
+    pp.weights = reinterpret_cast<const gh::WeightEntry*>(dv + pack(off_.weights, d.num_weights * sizeof(gh::WeightEntry)));
+    for (int c = 0; c < 3; ++c) pp.intra[c] = reinterpret_cast<const gh::IntraTu*>(dv + pack(off_.intra[c], d.num_intra[c] * sizeof(gh::IntraTu)));
+    for (int c = 0; c < 3; ++c) pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dv + pack(off_.first[c], pp.intra_rows ? (ctbs + 1) * sizeof(uint32_t) : 0));
+    pp.scaling = d.scaling ? dv + pack(off_.scaling, 4064) : nullptr;
     pp.edges = reinterpret_cast<const gh::EdgeInfo*>(dv + off_.edges);
     pp.sao = reinterpret_cast<const gh::SaoCtb*>(dv + off_.sao);
     pp.slices = reinterpret_cast<const gh::SliceLoop*>(dv + off_.slices);
-    pp.scaling = d.scaling ? dv + off_.scaling : nullptr;
     pp.resid[0] = resid_;
     pp.resid[1] = resid_ + static_cast<size_t>(y_pitch_) * ch_;
     pp.resid[2] = pp.resid[1] + static_cast<size_t>(y_pitch_ / 2) * (ch_ / 2);
@@ -257,21 +265,14 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       bytes_uploaded_ += static_cast<int64_t>(bytes);
       return hipMemcpyAsync(dv + off, set.host + off, bytes, hipMemcpyHostToDevice, stream_);
     };
-    const size_t ctbs = static_cast<size_t>(wctb_) * hctb_;
-    hipError_t e = up(off_.params, sizeof(pp));
-    if (e == hipSuccess) e = up(off_.res, d.num_res * sizeof(gh::ResTu));
-    if (e == hipSuccess) e = up(off_.coefs, d.num_coefs * sizeof(uint32_t));
-    if (e == hipSuccess) e = up(off_.pus, d.num_pus * sizeof(gh::InterPu));
-    if (e == hipSuccess) e = up(off_.weights, d.num_weights * sizeof(gh::WeightEntry));
-    for (int c = 0; c < 3 && e == hipSuccess; ++c) {
-      e = up(off_.intra[c], d.num_intra[c] * sizeof(gh::IntraTu));
-      if (e == hipSuccess && pp.intra_rows) e = up(off_.first[c], (ctbs + 1) * sizeof(uint32_t));
+    hipError_t e = up(off_.params, off_.part_b);            // part A
+    if (e == hipSuccess) e = up(off_.part_b, packed - off_.part_b);  // part B
+    // the residual planes are zero between pictures (the kernels that read a residual clear it); only a picture that
+    // did not run to its end leaves them in doubt
+    if (e == hipSuccess && resid_dirty_) {
+      e = hipMemsetAsync(resid_, 0, resid_bytes_, stream_);
+      resid_dirty_ = false;
     }
-    if (e == hipSuccess && (d.deblock || d.sao)) e = up(off_.edges, static_cast<size_t>(cw_ / 4) * (ch_ / 4) * sizeof(gh::EdgeInfo));
-    if (e == hipSuccess && d.sao) e = up(off_.sao, ctbs * sizeof(gh::SaoCtb));
-    if (e == hipSuccess && (d.deblock || d.sao)) e = up(off_.slices, static_cast<size_t>(std::max(d.num_slices, 1)) * sizeof(gh::SliceLoop));
-    if (e == hipSuccess && d.scaling) e = up(off_.scaling, 4064);
-    if (e == hipSuccess) e = hipMemsetAsync(resid_, 0, resid_bytes_, stream_);
     if (e == hipSuccess && (d.num_intra[0] || d.num_intra[1] || d.num_intra[2]))
       e = hipMemsetAsync(progress_, 0, pp.intra_rows ? 16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) : progress_bytes_, stream_);
     if (e == hipSuccess) e = gh::launch_picture(pp, reinterpret_cast<const gh::PicParams*>(dv + off_.params), stream_);
@@ -316,7 +317,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     bool busy = false;
   };
   struct Offsets {
-    size_t params, res, coefs, pus, weights, intra[3], first[3], edges, sao, slices, scaling, total;
+    size_t params, res, coefs, pus, weights, intra[3], first[3], edges, sao, slices, scaling, part_b, total;
   };
   struct Caps {
     size_t res, coefs, pus, weights, intra[3];
@@ -400,16 +401,19 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       o = (o + bytes + 255) & ~static_cast<size_t>(255);
       return at;
     };
+    // part A, copied as one piece with every picture: parameters, slices, SAO parameters, the per-4x4 edge records
     off_.params = take(sizeof(gh::PicParams));
+    off_.slices = take(gh::kMaxSlices * sizeof(gh::SliceLoop));
+    off_.sao = take(ctbs * sizeof(gh::SaoCtb));
+    off_.edges = take(w4h4 * sizeof(gh::EdgeInfo));
+    off_.part_b = o;
+    // part B: the lists, written by the parser at these worst-case offsets, packed downwards before their one copy
     off_.res = take(cap_.res * sizeof(gh::ResTu));
     off_.coefs = take(cap_.coefs * sizeof(uint32_t));
     off_.pus = take(cap_.pus * sizeof(gh::InterPu));
     off_.weights = take(cap_.weights * sizeof(gh::WeightEntry));
     for (int c = 0; c < 3; ++c) off_.intra[c] = take(cap_.intra[c] * sizeof(gh::IntraTu));
     for (int c = 0; c < 3; ++c) off_.first[c] = take((ctbs + 1) * sizeof(uint32_t));
-    off_.edges = take(w4h4 * sizeof(gh::EdgeInfo));
-    off_.sao = take(ctbs * sizeof(gh::SaoCtb));
-    off_.slices = take(gh::kMaxSlices * sizeof(gh::SliceLoop));
     off_.scaling = take(4064);
     off_.total = o;
     bool ok = true;
@@ -435,6 +439,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       return false;
     }
     next_set_ = 0;
+    resid_dirty_ = true;
     return true;
   }
 
@@ -495,6 +500,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   Caps cap_ = {};
   int cw_ = 0, ch_ = 0, log2_ctb_ = 0, wctb_ = 0, hctb_ = 0, y_pitch_ = 0, crop_l_ = 0, crop_t_ = 0;
   size_t surface_bytes_ = 0, resid_bytes_ = 0, progress_bytes_ = 0;
+  bool resid_dirty_ = true;  // (freshly allocated, or a picture faulted)
   uint8_t* work_ = nullptr;
   int16_t* resid_ = nullptr;
   uint32_t* progress_ = nullptr;

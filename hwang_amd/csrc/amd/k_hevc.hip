@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256) void k_hevc_inter(const PicParams* __restrict_
     const int pw = pp.width >> sub, ph = pp.height >> sub, pitch = c ? pp.c_pitch : pp.y_pitch;
     const int fb = c ? 3 : 2, fm = (1 << fb) - 1;
     uint8_t* dst = plane_of(pp.recon, c);
-    const int16_t* res = pp.resid[c];
+    int16_t* res = pp.resid[c];
     const uint8_t* r0 = (pu.pred_flag & 1) ? plane_of(pp.refs[pu.ref_slot[0]], c) : nullptr;
     const uint8_t* r1 = (pu.pred_flag & 2) ? plane_of(pp.refs[pu.ref_slot[1]], c) : nullptr;
     WeightEntry w0 = {}, w1 = {};
@@ -207,24 +207,43 @@ __global__ __launch_bounds__(256) void k_hevc_inter(const PicParams* __restrict_
           v = ((p1 * w1.w[c] + (1 << (lwd - 1))) >> lwd) + w1.o[c];
       }
       const size_t at = static_cast<size_t>(y) * pitch + x;
-      dst[at] = static_cast<uint8_t>(clip8(clip8(v) + res[at]));
+      const int r = res[at];
+      if (r) res[at] = 0;  // every sample's residual is read exactly once (by this kernel or by the intra one): the planes are zero again after the picture
+      dst[at] = static_cast<uint8_t>(clip8(clip8(v) + r));
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------------------- intra
+// intraPredAngle and invAngle (tables 8-4, 8-5) in LDS: a table in memory is a cache round trip in every block of the chain
+__device__ inline void load_angles(int* angtab, int lane) {
+  if (lane < 35) angtab[lane] = kAngle[lane];
+  if (lane < 15) angtab[35 + lane] = kInvAngle[lane];
+  __syncthreads();
+}
+
 // One intra-predicted transform block (8.4.4.2), by ONE wavefront (the workgroup: __syncthreads is a wave barrier).
 // The 4n + 1 neighbours are fetched straight from where the substitution process of 8.4.4.2.2 would copy them from -
 // which sample that is follows from the availability bits alone (the nearest existing sample below / before, else the
 // first existing one), so no lane waits for another; smoothing, the extended reference of the angular modes and the
 // prediction itself are lane-parallel over LDS.  line[i]: i < 2n left (bottom-up), 2n the corner, > 2n top.
-__device__ void intra_block(const IntraTu& tu, int c, uint8_t* plane, const int16_t* res, int pitch, int* line, int* filt_line, int* refbuf, int lane) {
+// `out` is where neighbours are read from and the block goes, (x0, y0) the block's position there: the surface, or (row
+// kernel, kTile) an LDS tile of the coding tree block with its rim; `res` likewise the residual plane or an LDS copy of
+// the coding tree block's part of it (already cleared in HBM by whoever copied it).
+template <bool kTile>
+__device__ void intra_block(const IntraTu& tu, int x0, int y0, int c, uint8_t* out, int pitch, int16_t* res, int res_pitch, int* line, int* filt_line, int* refbuf, const int* angtab, int lane) {
   const int ushift = c ? 1 : 2;  // availability comes in units of 4 luma / 2 chroma samples
-  const int log2 = tu.log2, n = 1 << log2, x0 = tu.x, y0 = tu.y, nu = (2 * n) >> ushift;
-  uint8_t* dst = plane + static_cast<size_t>(y0) * pitch + x0;
-  const int16_t* rs = res + static_cast<size_t>(y0) * pitch + x0;
+  const int log2 = tu.log2, n = 1 << log2, nu = (2 * n) >> ushift;
+  uint8_t* nb = out;
+  const int nb_pitch = pitch;
+  uint8_t* dst = out + y0 * pitch + x0;
+  int16_t* rs = res + y0 * res_pitch + x0;
   if (tu.mode == kIntraPcm) {
-    for (int i = lane; i < n * n; i += 64) dst[static_cast<size_t>(i / n) * pitch + i % n] = static_cast<uint8_t>(clip8(rs[static_cast<size_t>(i / n) * pitch + i % n]));
+    for (int i = lane; i < n * n; i += 64) {
+      const int r = rs[(i / n) * res_pitch + i % n];
+      if (!kTile && r) rs[(i / n) * res_pitch + i % n] = 0;
+      dst[(i / n) * pitch + i % n] = static_cast<uint8_t>(clip8(r));
+    }
   } else {
   const int mode = tu.mode;
   // availability in line order, one bit per unit: left units bottom-up, the corner, top units left to right
@@ -248,9 +267,9 @@ __device__ void intra_block(const IntraTu& tu, int c, uint8_t* plane, const int1
           src = su < nu ? (su << ushift) : su == nu ? 2 * n : 2 * n + 1 + ((su - nu - 1) << ushift);
         }
       }
-      if (src < 2 * n) v = plane[static_cast<size_t>(y0 + 2 * n - 1 - src) * pitch + x0 - 1];
-      else if (src == 2 * n) v = plane[static_cast<size_t>(y0 - 1) * pitch + x0 - 1];
-      else v = plane[static_cast<size_t>(y0 - 1) * pitch + x0 + src - 2 * n - 1];
+      if (src < 2 * n) v = nb[(y0 + 2 * n - 1 - src) * nb_pitch + x0 - 1];
+      else if (src == 2 * n) v = nb[(y0 - 1) * nb_pitch + x0 - 1];
+      else v = nb[(y0 - 1) * nb_pitch + x0 + src - 2 * n - 1];
     }
     line[i] = v;
   }
@@ -286,7 +305,7 @@ __device__ void intra_block(const IntraTu& tu, int c, uint8_t* plane, const int1
 #define LEFT(k) ln[2 * n - (k)]       /* k = 0: corner, k = 1 + j: p[-1][j] */
 #define TOP(k) ln[2 * n + (k)]        /* k = 0: corner, k = 1 + j: p[j][-1] */
   int* ref = refbuf + 33;
-  const int angle = mode >= 2 ? kAngle[mode] : 0;
+  const int angle = mode >= 2 ? angtab[mode] : 0;
   const bool vertical = mode >= 18;
   if (mode >= 2) {
     const int last = (n * angle) >> 5;
@@ -294,7 +313,7 @@ __device__ void intra_block(const IntraTu& tu, int c, uint8_t* plane, const int1
       if (k >= 0) {
         if (k <= n || angle >= 0) ref[k] = vertical ? TOP(k) : LEFT(k);
       } else if (angle < 0 && last < -1 && k >= last) {
-        const int t = (k * kInvAngle[mode - 11] + 128) >> 8;
+        const int t = (k * angtab[35 + mode - 11] + 128) >> 8;
         ref[k] = vertical ? LEFT(t) : TOP(t);
       }
     }
@@ -327,7 +346,11 @@ __device__ void intra_block(const IntraTu& tu, int c, uint8_t* plane, const int1
         if (mode == 10 && y == 0) v = clip8(LEFT(1) + ((TOP(1 + x) - TOP(0)) >> 1));
       }
     }
-    dst[static_cast<size_t>(y) * pitch + x] = static_cast<uint8_t>(clip8(v + rs[static_cast<size_t>(y) * pitch + x]));
+    {
+      const int r = rs[y * res_pitch + x];
+      if (!kTile && r) rs[y * res_pitch + x] = 0;
+      dst[y * pitch + x] = static_cast<uint8_t>(clip8(v + r));
+    }
   }
 #undef LEFT
 #undef TOP
@@ -353,8 +376,9 @@ __global__ __launch_bounds__(64) void k_hevc_intra_flow(const PicParams* __restr
   const uint32_t count = static_cast<uint32_t>(pp.num_intra[c]);
   uint32_t* ticket = pp.intra_ticket + c;
   uint8_t* done = pp.intra_done[c];
-  __shared__ int line[132], filt_line[132], refbuf[3 * 32 + 8];
+  __shared__ int line[132], filt_line[132], refbuf[3 * 32 + 8], angtab[50];
   __shared__ uint32_t s_ticket;
+  load_angles(angtab, lane);
   for (;;) {
     if (lane == 0) s_ticket = atomicAdd(ticket, 1u);
     __syncthreads();
@@ -384,7 +408,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_flow(const PicParams* __restr
         }
       }
     }
-    intra_block(tu, c, plane, pp.resid[c], pitch, line, filt_line, refbuf, lane);
+    intra_block<false>(tu, tu.x, tu.y, c, plane, pitch, pp.resid[c], pitch, line, filt_line, refbuf, angtab, lane);
     // the block's samples are out: mark the units it covers (a release after the fence; waiters acquire)
     __threadfence();
     __syncthreads();
@@ -396,19 +420,34 @@ __global__ __launch_bounds__(64) void k_hevc_intra_flow(const PicParams* __restr
 // Intra prediction, variant 2: a wavefront of coding tree block rows, for pictures that are mostly intra.  One
 // wavefront per (row, colour plane); row r follows the progress word of row r - 1 two blocks behind (the above-right
 // block is a neighbour); within a block the transform blocks are a dependent chain anyway (z-order: each quadrant leans
-// on the ones before it).  17 rows at 1080p with 64x64 blocks is all the parallelism that leaves - but nobody spins
-// except one wavefront per row.
+// on the ones before it).  17 rows at 1080p with 64x64 blocks is all the parallelism that leaves, so what counts is the
+// time per transform block, and two dependent HBM round trips per block (its record, then its residual) were most of it:
+// the coding tree block with its rim (the row above up to the above-right block, the column to the left), its part of
+// the residual plane and its records are copied into LDS first, the chain runs out of LDS, the block goes back in rows.
+constexpr int kTilePitch = 144;  // 16 bytes (the left column is the last of them) + 2 x 64 samples
+constexpr int kTileRecs = 256;   // the records of a 64x64 block of 4x4s
+
 __global__ __launch_bounds__(64) void k_hevc_intra_rows(const PicParams* __restrict__ ppp) {
   const PicParams& pp = *ppp;
   const int c = blockIdx.y, row = blockIdx.x, lane = threadIdx.x;
-  const int pitch = c ? pp.c_pitch : pp.y_pitch;
+  const int sub = c ? 1 : 0, pitch = c ? pp.c_pitch : pp.y_pitch, pw = pp.width >> sub, ph = pp.height >> sub;
+  const int S = (1 << pp.log2_ctb) >> sub;  // the coding tree block in samples of this plane
   uint8_t* plane = plane_of(pp.recon, c);
+  int16_t* resid = pp.resid[c];
   const IntraTu* tus = pp.intra[c];
   const uint32_t* first = pp.intra_ctb_first[c] + row * pp.width_ctb;
   uint32_t* progress = pp.progress + c * pp.height_ctb;
-  __shared__ int line[132], filt_line[132], refbuf[3 * 32 + 8];
+  __shared__ int line[132], filt_line[132], refbuf[3 * 32 + 8], angtab[50];
+  load_angles(angtab, lane);
+  __shared__ __attribute__((aligned(16))) uint8_t tile[(64 + 1) * kTilePitch];
+  __shared__ __attribute__((aligned(16))) int16_t rtile[64 * 64];
+  __shared__ uint32_t recs[kTileRecs * 6];
+  static_assert(sizeof(IntraTu) == 24, "records are copied as six words");
+  uint8_t* const origin = tile + kTilePitch + 16;  // the block's sample (0, 0); the rim is at -1
   uint32_t t_next = first[0];
   int published = 0;
+  const int cy = row * S, wpr = S >> 2;
+  const int lcpr = pp.log2_ctb - sub - 4, lrpr = pp.log2_ctb - sub - 3;  // log2 of the 16-byte pieces per row of the block / of its residual
   for (int col = 0; col < pp.width_ctb; ++col) {
     const uint32_t t0 = t_next, t1 = first[col + 1];
     t_next = t1;
@@ -418,6 +457,43 @@ __global__ __launch_bounds__(64) void k_hevc_intra_rows(const PicParams* __restr
       if (lane == 0) __hip_atomic_store(&progress[row], static_cast<uint32_t>(col), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
       published = col;
     }
+    const int cx = col * S;
+    // what does not depend on the row above: the block itself (what inter prediction left there), its residual - cleared
+    // behind the copy: every sample's residual is read once - and the column left of it (this wavefront's own work)
+    // (16 bytes a lane and all of a copy's loads in flight at once: what is past the picture's width is pitch padding)
+    if (lcpr >= 0) {
+      uint4 blk[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, r = i >> lcpr, x = cx + 16 * (i & ((1 << lcpr) - 1));
+        blk[k] = (r < S && cy + r < ph && x < pw) ? *reinterpret_cast<const uint4*>(plane + static_cast<size_t>(cy + r) * pitch + x) : uint4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, r = i >> lcpr;
+        if (r < S) *reinterpret_cast<uint4*>(origin + r * kTilePitch + 16 * (i & ((1 << lcpr) - 1))) = blk[k];
+      }
+    } else {
+      for (int i = lane; i < S * wpr; i += 64) {
+        const int r = i / wpr, x = cx + 4 * (i % wpr), y = cy + r;
+        if (y < ph && x < pw) *reinterpret_cast<uint32_t*>(origin + r * kTilePitch + 4 * (i % wpr)) = *reinterpret_cast<const uint32_t*>(plane + static_cast<size_t>(y) * pitch + x);
+      }
+    }
+    {
+      uint4 blk[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = lane + 64 * k, r = i >> lrpr, x = cx + 8 * (i & ((1 << lrpr) - 1));
+        blk[k] = (r < S && cy + r < ph && x < pw) ? *reinterpret_cast<const uint4*>(resid + static_cast<size_t>(cy + r) * pitch + x) : uint4{0, 0, 0, 0};
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = lane + 64 * k, r = i >> lrpr, x = cx + 8 * (i & ((1 << lrpr) - 1));
+        if (blk[k].x | blk[k].y | blk[k].z | blk[k].w) *reinterpret_cast<uint4*>(resid + static_cast<size_t>(cy + r) * pitch + x) = uint4{0, 0, 0, 0};
+        if (r < S) reinterpret_cast<uint4*>(rtile)[i] = blk[k];
+      }
+    }
+    for (int r = lane; r < S; r += 64) origin[r * kTilePitch - 1] = (cx > 0 && cy + r < ph) ? plane[static_cast<size_t>(cy + r) * pitch + cx - 1] : 0;
     if (row > 0) {
       const uint32_t need = static_cast<uint32_t>(col + 2 < pp.width_ctb ? col + 2 : pp.width_ctb);
       uint32_t spins = 0;
@@ -429,10 +505,33 @@ __global__ __launch_bounds__(64) void k_hevc_intra_rows(const PicParams* __restr
         }
       }
     }
-    for (uint32_t ti = t0; ti < t1; ++ti) {
-      intra_block(tus[ti], c, plane, pp.resid[c], pitch, line, filt_line, refbuf, lane);
-      __threadfence_block();
+    // the row above, from the sample left of the block to the end of the above-right block
+    for (int i = lane; i < 2 * S + 1; i += 64) {
+      const int x = cx - 1 + i;
+      origin[-kTilePitch - 1 + i] = (cy > 0 && x >= 0 && x < pw) ? plane[static_cast<size_t>(cy - 1) * pitch + x] : 0;
+    }
+    for (uint32_t base = t0; base < t1; base += kTileRecs) {
+      const int m = static_cast<int>(t1 - base < static_cast<uint32_t>(kTileRecs) ? t1 - base : kTileRecs);
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(tus + base);
+      for (int i = lane; i < m * 6; i += 64) recs[i] = src[i];
       __syncthreads();
+      for (int k = 0; k < m; ++k) {
+        const IntraTu& tu = reinterpret_cast<const IntraTu*>(recs)[k];
+        intra_block<true>(tu, tu.x - cx, tu.y - cy, c, origin, kTilePitch, rtile, S, line, filt_line, refbuf, angtab, lane);
+        __syncthreads();
+      }
+    }
+    if (lcpr >= 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = lane + 64 * k, r = i >> lcpr, x = cx + 16 * (i & ((1 << lcpr) - 1));
+        if (r < S && cy + r < ph && x < pw) *reinterpret_cast<uint4*>(plane + static_cast<size_t>(cy + r) * pitch + x) = *reinterpret_cast<const uint4*>(origin + r * kTilePitch + 16 * (i & ((1 << lcpr) - 1)));
+      }
+    } else {
+      for (int i = lane; i < S * wpr; i += 64) {
+        const int r = i / wpr, x = cx + 4 * (i % wpr), y = cy + r;
+        if (y < ph && x < pw) *reinterpret_cast<uint32_t*>(plane + static_cast<size_t>(y) * pitch + x) = *reinterpret_cast<const uint32_t*>(origin + r * kTilePitch + 4 * (i % wpr));
+      }
     }
     // everything up to this block of the row is final as far as later rows are concerned
     __threadfence();

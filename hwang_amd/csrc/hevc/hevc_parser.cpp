@@ -397,13 +397,15 @@ class Cabac {
 };
 
 // ------------------------------------------------------------------------------------------------- pictures
-struct Motion {  // per 4x4 luma block
+struct Motion {  // per 4x4 luma block, 16 bytes
   int16_t mv[2][2];
   int8_t ref[2];
   uint8_t flags;   // bit 0 / 1: list used
-  uint8_t lt[2];
-  int32_t ref_poc[2];
+  uint8_t rid[2];  // which picture each list refers to: its DPB entry while the picture that holds this field was
+                   // decoded (Pic::ref_poc_tab / ref_lt_tab say what that entry was: later pictures' temporal candidates)
+  uint8_t pad[3];
 };
+static_assert(sizeof(Motion) == 16, "Motion");
 
 struct Pic {
   bool in_use = false;
@@ -411,11 +413,14 @@ struct Pic {
   int poc = 0, ref = 0 /* 0 none, 1 short, 2 long */, latency = 0;
   bool waiting = false;  // for output
   bool placeholder = false;  // skipped on purpose / made up for a missing reference
+  int32_t ref_poc_tab[amd::hevc::kMaxSurfaces] = {0};  // POC / long-term state of DPB entry i when this picture referred to it
+  uint8_t ref_lt_tab[amd::hevc::kMaxSurfaces] = {0};
   std::vector<Motion> motion;
 };
 
 struct Scans {
   uint8_t t[4][3][64];
+  uint8_t inv[4][3][64];  // position (x | y << log2) -> index in the scan
   Scans() {
     for (int l = 0; l < 4; ++l) {
       const int n = 1 << l;
@@ -436,6 +441,8 @@ struct Scans {
       i = 0;
       for (x = 0; x < n; ++x)
         for (y = 0; y < n; ++y) t[l][2][i++] = static_cast<uint8_t>(x | y << 4);
+      for (int sc = 0; sc < 3; ++sc)
+        for (int k = 0; k < n * n; ++k) inv[l][sc][(t[l][sc][k] & 15) | (t[l][sc][k] >> 4) << l] = static_cast<uint8_t>(k);
     }
   }
 };
@@ -483,6 +490,8 @@ struct Parser::Impl {
   std::vector<uint16_t> ctb_slice;   // slice index per coding tree block, 0xffff = not decoded
   std::vector<uint32_t> slice_addr;  // SliceAddrRs per slice
   uint32_t zmap[256];                // Morton order of a 16 x 16 grid of 4x4 blocks
+  std::vector<uint32_t> zorder;      // per 4x4 block of the picture: its address in decoding (z-scan) order
+  int zorder_w4 = 0, zorder_h4 = 0, zorder_lc = 0;
   int num_slices = 0;
 
   // current slice
@@ -891,7 +900,7 @@ struct Parser::Impl {
     p->poc = poc_value;
     p->ref = state;
     p->placeholder = true;
-    p->motion.assign(static_cast<size_t>(w4) * h4, Motion());
+    p->motion.assign(S ? static_cast<size_t>(S->wctb) * S->hctb << (2 * (S->log2_ctb - 2)) : 0, Motion());
     return p;
   }
 
@@ -1002,6 +1011,7 @@ struct Parser::Impl {
     w4 = S->width / 4;
     h4 = S->height / 4;
     const size_t n = static_cast<size_t>(w4) * h4;
+    build_zorder();
     // Only what is OR-ed into starts from zero; every other map is read only where this picture has already written
     // it (availability goes by z-order and slice, 6.4.1, not by what a map holds).
     if (m_pred.size() != n) {
@@ -1015,7 +1025,9 @@ struct Parser::Impl {
       cur->motion = std::move(motion_pool.back());
       motion_pool.pop_back();
     }
-    if (cur->motion.size() != n) cur->motion.assign(n, Motion());  // (a recycled field holds its last picture: every unit overwrites its part)
+    // (z-order addresses run over whole coding tree blocks, also where the picture ends inside one)
+    const size_t msize = static_cast<size_t>(S->wctb) * S->hctb << (2 * (S->log2_ctb - 2));
+    if (cur->motion.size() != msize) cur->motion.assign(msize, Motion());  // (a recycled field holds its last picture: every unit overwrites its part)
     PicSetup setup;
     setup.width = S->width;
     setup.height = S->height;
@@ -1051,14 +1063,14 @@ struct Parser::Impl {
     auto far = [](const int16_t* a, const int16_t* b) { return iabs(a[0] - b[0]) >= 4 || iabs(a[1] - b[1]) >= 4; };
     if (np == 1) {
       const int lp = (p.flags & 1) ? 0 : 1, lq = (q.flags & 1) ? 0 : 1;
-      if (p.ref_poc[lp] != q.ref_poc[lq]) return 1;
+      if (p.rid[lp] != q.rid[lq]) return 1;
       return far(p.mv[lp], q.mv[lq]);
     }
     if (np == 2) {
-      const bool straight = p.ref_poc[0] == q.ref_poc[0] && p.ref_poc[1] == q.ref_poc[1];
-      const bool crossed = p.ref_poc[0] == q.ref_poc[1] && p.ref_poc[1] == q.ref_poc[0];
+      const bool straight = p.rid[0] == q.rid[0] && p.rid[1] == q.rid[1];
+      const bool crossed = p.rid[0] == q.rid[1] && p.rid[1] == q.rid[0];
       if (!straight && !crossed) return 1;
-      if (p.ref_poc[0] != p.ref_poc[1]) {
+      if (p.rid[0] != p.rid[1]) {
         if (straight) return far(p.mv[0], q.mv[0]) || far(p.mv[1], q.mv[1]);
         return far(p.mv[0], q.mv[1]) || far(p.mv[1], q.mv[0]);
       }
@@ -1083,7 +1095,7 @@ struct Parser::Impl {
           const int j = dir ? i - w4 : i - 1;
           if (m_pred[i] == 2 || m_pred[j] == 2) bs[dir] = 2;
           else if ((eg & (dir ? 4 : 1)) && (m_nz[i] || m_nz[j])) bs[dir] = 1;
-          else bs[dir] = motion_bs(cur->motion[j], cur->motion[i]);
+          else bs[dir] = motion_bs(cur->motion[zorder[j]], cur->motion[zorder[i]]);
         }
         erow[x].bs = static_cast<uint8_t>(bs[0] | bs[1] << 2);
         any_bs |= erow[x].bs != 0;
@@ -1115,11 +1127,17 @@ struct Parser::Impl {
   }
 
   // ------------------------------------------------------------------------------- availability, 6.4.1 / 6.4.2
-  uint32_t zaddr(int x, int y) const {
-    const int lc = S->log2_ctb;
-    const uint32_t ctb = static_cast<uint32_t>((y >> lc) * S->wctb + (x >> lc));
-    const int mask = (1 << (lc - 2)) - 1;
-    return ctb << (2 * (lc - 2)) | zmap[((x >> 2) & mask) | ((y >> 2) & mask) << 4];
+  uint32_t zaddr(int x, int y) const { return zorder[(y >> 2) * w4 + (x >> 2)]; }
+  void build_zorder() {
+    if (zorder_w4 == w4 && zorder_h4 == h4 && zorder_lc == S->log2_ctb) return;
+    zorder_w4 = w4; zorder_h4 = h4; zorder_lc = S->log2_ctb;
+    zorder.resize(static_cast<size_t>(w4) * h4);
+    const int lc = S->log2_ctb, mask = (1 << (lc - 2)) - 1;
+    for (int y4 = 0; y4 < h4; ++y4)
+      for (int x4 = 0; x4 < w4; ++x4) {
+        const uint32_t ctb = static_cast<uint32_t>(((y4 * 4) >> lc) * S->wctb + ((x4 * 4) >> lc));
+        zorder[static_cast<size_t>(y4) * w4 + x4] = ctb << (2 * (lc - 2)) | zmap[(x4 & mask) | (y4 & mask) << 4];
+      }
   }
   bool zavail(int xc, int yc, int xn, int yn) const {
     if (xn < 0 || yn < 0 || xn >= S->width || yn >= S->height) return false;
@@ -1149,7 +1167,8 @@ struct Parser::Impl {
       ok = zavail(xp, yp, xn, yn);
     return ok && m_pred[(yn >> 2) * w4 + (xn >> 2)] == 1;
   }
-  const Motion& mot(int x, int y) const { return cur->motion[(y >> 2) * w4 + (x >> 2)]; }
+  // (motion fields are laid out in decoding order - zorder[] - so that a unit's blocks are neighbours in memory)
+  const Motion& mot(int x, int y) const { return cur->motion[zorder[(y >> 2) * w4 + (x >> 2)]]; }
 
   static void scale_mv(int16_t* mv, int td, int tb) {
     td = clip3(-128, 127, td);
@@ -1180,7 +1199,7 @@ struct Parser::Impl {
         xc = xp + (w >> 1);
         yc = yp + (h >> 1);
       }
-      const Motion& c = col->motion[(((yc >> 4) << 4) >> 2) * w4 + (((xc >> 4) << 4) >> 2)];
+      const Motion& c = col->motion[zorder[(((yc >> 4) << 4) >> 2) * w4 + (((xc >> 4) << 4) >> 2)]];
       if (!c.flags) continue;
       int lc;
       if (!(c.flags & 1)) lc = 1;
@@ -1191,10 +1210,10 @@ struct Parser::Impl {
           for (int i = 0; i < sh.nref[l]; ++i) no_backward &= list[l][i]->poc <= cur->poc;
         lc = no_backward ? X : (sh.col_from_l0 ? 1 : 0);
       }
-      if (cur_long != (c.lt[lc] != 0)) continue;
+      if (cur_long != (col->ref_lt_tab[c.rid[lc]] != 0)) continue;
       out[0] = c.mv[lc][0];
       out[1] = c.mv[lc][1];
-      const int cd = col->poc - c.ref_poc[lc], td = cur->poc - target->poc;
+      const int cd = col->poc - col->ref_poc_tab[c.rid[lc]], td = cur->poc - target->poc;
       if (!cur_long && cd != td) scale_mv(out, cd, td);
       return true;
     }
@@ -1390,7 +1409,7 @@ struct Parser::Impl {
         m_qp[i] = static_cast<int8_t>(cu.qp);
         if (cu.intra) {
           m_mode[i] = 1;
-          cur->motion[i].flags = 0;  // "intra" as far as later pictures' temporal candidates and this picture's strengths go
+          cur->motion[zorder[i]].flags = 0;  // "intra" as far as later pictures' temporal candidates and this picture's strengths go
         }
       }
   }
@@ -1476,15 +1495,9 @@ struct Parser::Impl {
     if (py > 3) { const int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + static_cast<int>(cabac.bypass_bits(nb)); }
     if (scan == 2) std::swap(lx, ly);
     if (lx >= n || ly >= n) return fail("last significant coefficient outside its block");
-    int last_sb = (1 << (2 * (log2 - 2))) - 1, last_pos = 16;
-    for (;;) {
-      if (!last_pos) {
-        last_pos = 16;
-        if (--last_sb < 0) return fail("last significant coefficient not in the scan");
-      }
-      --last_pos;
-      if (((sbs[last_sb] & 15) << 2) + (pss[last_pos] & 15) == lx && ((sbs[last_sb] >> 4) << 2) + (pss[last_pos] >> 4) == ly) break;
-    }
+    // where the last significant position sits in the scan: sub-block, then position within it
+    const int last_sb = sc_tab.inv[log2 - 2][scan][(lx >> 2) | (ly >> 2) << (log2 - 2)];
+    const int last_pos = sc_tab.inv[2][scan][(lx & 3) | (ly & 3) << 2];
     if (done.num_res >= buf.cap_res) return fail("transform block list overflow");
     ResTu& r = buf.res[done.num_res];
     r.x = static_cast<uint16_t>(x);
@@ -1794,8 +1807,9 @@ struct Parser::Impl {
       if ((m.flags >> l) & 1) {
         if (m.ref[l] < 0 || m.ref[l] >= sh.nref[l]) return fail("reference index %d of %d", m.ref[l], sh.nref[l]);
         const Pic* r = list[l][m.ref[l]];
-        m.ref_poc[l] = r->poc;
-        m.lt[l] = r->ref == 2;
+        m.rid[l] = static_cast<uint8_t>(r - dpb);
+        cur->ref_poc_tab[m.rid[l]] = r->poc;
+        cur->ref_lt_tab[m.rid[l]] = r->ref == 2;
         if (r->slot < 0) return fail("prediction from a picture that was not decoded (POC %d)", r->poc);
         p.ref_slot[l] = static_cast<uint8_t>(r->slot);
         note_ref_slot(r->slot);
@@ -1804,11 +1818,19 @@ struct Parser::Impl {
         p.wp[l] = static_cast<uint16_t>(weights_base[l] + m.ref[l]);
       } else {
         m.ref[l] = -1;
+        m.rid[l] = 0;
         m.mv[l][0] = m.mv[l][1] = 0;
       }
     }
-    for (int yy = y; yy < y + h; yy += 4)
-      for (int xx = x; xx < x + w; xx += 4) cur->motion[(yy >> 2) * w4 + (xx >> 2)] = m;
+    {
+      // in aligned squares: each is one run of the z-ordered field
+      const int sq = (x | y | w | h) & -(x | y | w | h), per = (sq >> 2) * (sq >> 2);
+      for (int yy = y; yy < y + h; yy += sq)
+        for (int xx = x; xx < x + w; xx += sq) {
+          Motion* run = &cur->motion[zorder[(yy >> 2) * w4 + (xx >> 2)]];
+          for (int k = 0; k < per; ++k) run[k] = m;
+        }
+    }
     // a prediction block edge inside the unit
     if (x > cu.x)
       for (int k = 0; k < h; k += 4) m_edge[((y + k) >> 2) * w4 + (x >> 2)] |= 2 | edge_on_v;

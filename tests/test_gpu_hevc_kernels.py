@@ -146,34 +146,44 @@ def test_intra_kernel(hw, log2):
         if smooth:
             planes[c_idx] = np.clip(90 + (np.add.outer(np.arange(ph), np.arange(pw)) // 6) + rnd.integers(0, 2, (ph, pw)), 0, 255)
         recon = np.concatenate([p.astype(np.uint8).ravel() for p in planes])
-        recs, expect = [], []
         unit = 2 if c_idx else 4
-        mode = 0
-        for ry in range(rows):
-            for rx in range(cols):
-                x, y = (rx * cell >> sub) + n, (ry * cell >> sub) + n
-                pat = int(rnd.integers(0, 6))
-                nu = 2 * n // unit
-                al = int(rnd.integers(0, 1 << nu)) if pat > 1 else ((1 << nu) - 1 if pat == 0 else 0)
-                at = int(rnd.integers(0, 1 << nu)) if pat > 1 else ((1 << nu) - 1 if pat == 0 else 0)
-                corner = int(rnd.integers(0, 2)) if pat > 1 else (1 if pat == 0 else 0)
-                strong = int(rnd.integers(0, 2))
-                recs.append((x, y, log2, mode, corner | strong << 1, 0, al, at, 0, 0))     # nothing to wait for: the neighbours are recon_in's
-                p = planes[c_idx]
-                left_vals = np.array([p[y + k, x - 1] for k in range(2 * n)])
-                top_vals = np.array([p[y - 1, x + k] for k in range(2 * n)])
-                la = np.array([(al >> (k // unit)) & 1 for k in range(2 * n)], dtype=bool)
-                ta = np.array([(at >> (k // unit)) & 1 for k in range(2 * n)], dtype=bool)
-                line_v = np.concatenate([left_vals[::-1], [p[y - 1, x - 1]], top_vals])
-                line_a = np.concatenate([la[::-1], [bool(corner)], ta])
-                line = substitute(line_a, line_v, n)
-                left = np.concatenate([[line[2 * n]], line[:2 * n][::-1]])
-                top = line[2 * n:]
-                expect.append((x, y, hn.intra_predict(left, top, n, c_idx, mode, bool(strong))))
-                mode = (mode + 1) % 35
-        intra = [None, None, None]
-        intra[c_idx] = np.array(recs, dtype=ITU)
+        S = 64 >> sub
         for rows_kernel in (False, True):
+            recs, expect = [], []
+            mode = 0
+            for ry in range(rows):
+                for rx in range(cols):
+                    x, y = (rx * cell >> sub) + n, (ry * cell >> sub) + n
+                    pat = int(rnd.integers(0, 6))
+                    nu = 2 * n // unit
+                    al = int(rnd.integers(0, 1 << nu)) if pat > 1 else ((1 << nu) - 1 if pat == 0 else 0)
+                    at = int(rnd.integers(0, 1 << nu)) if pat > 1 else ((1 << nu) - 1 if pat == 0 else 0)
+                    corner = int(rnd.integers(0, 2)) if pat > 1 else (1 if pat == 0 else 0)
+                    if rows_kernel:
+                        # k_hevc_intra_rows keeps one coding tree block and its rim in LDS: what a stream can mark available
+                        # (6.4.1: nothing below the block's row, nothing right of it except in the row above) is all it holds
+                        cx, cy = x // S * S, y // S * S
+                        for k in range(nu):
+                            if y + k * unit >= cy + S:
+                                al &= ~(1 << k)
+                            if x + k * unit >= cx + (S if y > cy else 2 * S):
+                                at &= ~(1 << k)
+                    strong = int(rnd.integers(0, 2))
+                    recs.append((x, y, log2, mode, corner | strong << 1, 0, al, at, 0, 0))     # nothing to wait for: the neighbours are recon_in's
+                    p = planes[c_idx]
+                    left_vals = np.array([p[y + k, x - 1] for k in range(2 * n)])
+                    top_vals = np.array([p[y - 1, x + k] for k in range(2 * n)])
+                    la = np.array([(al >> (k // unit)) & 1 for k in range(2 * n)], dtype=bool)
+                    ta = np.array([(at >> (k // unit)) & 1 for k in range(2 * n)], dtype=bool)
+                    line_v = np.concatenate([left_vals[::-1], [p[y - 1, x - 1]], top_vals])
+                    line_a = np.concatenate([la[::-1], [bool(corner)], ta])
+                    line = substitute(line_a, line_v, n)
+                    left = np.concatenate([[line[2 * n]], line[:2 * n][::-1]])
+                    top = line[2 * n:]
+                    expect.append((x, y, hn.intra_predict(left, top, n, c_idx, mode, bool(strong))))
+                    mode = (mode + 1) % 35
+            intra = [None, None, None]
+            intra[c_idx] = np.array(recs, dtype=ITU)
             got, _ = run_picture(hw, W, H, log2_ctb=6, recon=recon, intra=tuple(intra), intra_rows=rows_kernel)
             for (x, y, want) in expect:
                 assert np.array_equal(got[c_idx][y:y + n, x:x + n].astype(np.int64), want), (c_idx, x, y, rows_kernel)
