@@ -1,0 +1,279 @@
+#include "hevc_engine.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+
+namespace hwang {
+
+hipError_t launch_yuv420_to_rgb24(const uint8_t* y, const uint8_t* u, const uint8_t* v, int y_stride, int c_stride, int width, int height,
+                                  uint8_t* rgb, hipStream_t stream);
+
+namespace amd {
+namespace hevc {
+
+hipError_t launch_batch(const PicParams* const* pp, const Batch& batch, int n, hipStream_t stream);
+
+namespace {
+constexpr size_t kBatchesInFlight = 2;  // per stream: one running, one queued behind it; the third is being collected
+std::mutex g_engines_mu;
+std::map<int, std::weak_ptr<Engine>> g_engines;
+}  // namespace
+
+std::shared_ptr<Engine> Engine::for_device(int device) {
+  std::lock_guard<std::mutex> lk(g_engines_mu);
+  std::shared_ptr<Engine> e = g_engines[device].lock();
+  if (!e) {
+    e.reset(new Engine(device));
+    g_engines[device] = e;
+  }
+  return e;
+}
+
+Engine::Engine(int device) : device_(device) { thread_ = std::thread([this] { run(); }); }
+
+Engine::~Engine() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+  }
+  cv_work_.notify_all();
+  if (thread_.joinable()) thread_.join();
+}
+
+int Engine::add_client() {
+  std::lock_guard<std::mutex> lk(mu_);
+  for (size_t i = 0; i < clients_.size(); ++i)
+    if (!clients_[i].used) {
+      clients_[i] = Client();
+      clients_[i].used = true;
+      return static_cast<int>(i);
+    }
+  clients_.emplace_back();
+  clients_.back().used = true;
+  return static_cast<int>(clients_.size()) - 1;
+}
+
+void Engine::remove_client(int client) {
+  std::lock_guard<std::mutex> lk(mu_);
+  if (client >= 0 && client < static_cast<int>(clients_.size())) clients_[client].used = false;
+}
+
+void Engine::submit(int client, EngineJob* job) {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    job->launched.store(0, std::memory_order_relaxed);
+    job->failed = false;
+    clients_[client].queue.push_back(job);
+  }
+  cv_work_.notify_one();
+}
+
+bool Engine::wait_launched(EngineJob* job) {
+  if (!job->launched.load(std::memory_order_acquire)) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_done_.wait(lk, [&] { return job->launched.load(std::memory_order_acquire) != 0; });
+  }
+  return !job->failed;
+}
+
+bool Engine::drain(int client) {
+  std::unique_lock<std::mutex> lk(mu_);
+  cv_done_.wait(lk, [&] { return clients_[client].queue.empty() && !clients_[client].taking; });
+  return error_.empty();
+}
+
+void Engine::settled(int client) {
+  std::lock_guard<std::mutex> lk(mu_);
+  clients_[client].last_stream = -1;
+  clients_[client].last_event = nullptr;
+}
+
+std::string Engine::error() {
+  std::lock_guard<std::mutex> lk(mu_);
+  return error_;
+}
+
+void Engine::run() {
+  (void)hipSetDevice(device_);
+  bool ok = hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking) == hipSuccess;
+  for (hipStream_t& s : stream_) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+  auto new_event = [&]() {
+    hipEvent_t e = nullptr;
+    if (!event_pool_.empty()) {
+      e = event_pool_.back();
+      event_pool_.pop_back();
+    } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      e = nullptr;
+    }
+    return e;
+  };
+  std::vector<EngineJob*> pictures[2], outputs;
+  std::vector<int> touched;
+  uint64_t round = 0;
+  // HWANG_HEVC_ENGINE_STATS=1: what the batches looked like, on stderr when the engine goes
+  const bool stats = std::getenv("HWANG_HEVC_ENGINE_STATS") != nullptr;
+  int64_t n_batches[2] = {0, 0}, n_pictures[2] = {0, 0}, n_outputs = 0, issue_ns = 0, copy_ns = 0, issue_max_ns = 0, idle_rounds = 0;
+  auto now_ns = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  std::unique_lock<std::mutex> lk(mu_);
+  if (!ok) error_ = "the HEVC engine could not create its streams";
+  for (;;) {
+    for (auto* fl : {&inflight_[0], &inflight_[1], &copy_inflight_})
+      while (!fl->empty() && hipEventQuery(fl->front()) != hipErrorNotReady) {
+        event_pool_.push_back(fl->front());
+        fl->pop_front();
+      }
+    // ---- collect what may go now
+    ++round;
+    pictures[0].clear();
+    pictures[1].clear();
+    outputs.clear();
+    touched.clear();
+    bool waiting = false, queued = false;
+    for (size_t ci = 0; ci < clients_.size(); ++ci) {
+      Client& c = clients_[ci];
+      bool took_picture = false, took_output = false, took = false;
+      while (!c.queue.empty()) {
+        queued = true;
+        EngineJob* j = c.queue.front();
+        const int s = j->kind == EngineJob::kPicture && j->pp.intra_rows ? kHeavy : kLight;
+        if (!error_.empty()) {  // nothing runs any more: fail what is queued
+          j->failed = true;
+          j->launched.store(1, std::memory_order_release);
+          c.queue.pop_front();
+          continue;
+        }
+        if (inflight_[s].size() >= kBatchesInFlight) break;
+        // one picture of a decoder per batch, and none behind a fetched frame of it (a batch's pictures run before its
+        // conversions, and the picture may be going into the very surface the frame is read from)
+        if (j->kind == EngineJob::kPicture && (took_picture || took_output || pictures[s].size() >= static_cast<size_t>(kMaxBatch))) break;
+        if (c.last_stream >= 0 && c.last_stream != s) {
+          // its predecessor went to the other stream: not before that has finished (and never in the same round)
+          if (c.last_round == round || hipEventQuery(c.last_event) == hipErrorNotReady) {
+            waiting = true;
+            break;
+          }
+        }
+        c.queue.pop_front();
+        (j->kind == EngineJob::kPicture ? pictures[s] : outputs).push_back(j);
+        took_picture = took_picture || j->kind == EngineJob::kPicture;
+        took_output = took_output || j->kind != EngineJob::kPicture;
+        took = true;
+        c.last_stream = s;
+        c.last_event = j->done;
+        c.last_round = round;
+      }
+      if (took) {
+        c.taking = true;  // (drain: popped, not yet in a stream)
+        touched.push_back(static_cast<int>(ci));
+      }
+    }
+    if (!error_.empty()) cv_done_.notify_all();
+    if (pictures[0].empty() && pictures[1].empty() && outputs.empty()) {
+      if (stop_ && !queued) break;
+      ++idle_rounds;
+      if (waiting || queued || !inflight_[0].empty() || !inflight_[1].empty())
+        cv_work_.wait_for(lk, std::chrono::microseconds(50));
+      else
+        cv_work_.wait(lk);
+      continue;
+    }
+    lk.unlock();
+    // ---- into the streams
+    const int64_t t_issue = stats ? now_ns() : 0;
+    hipError_t e = hipSuccess;
+    bool copied = false;
+    for (auto& list : pictures)
+      for (EngineJob* j : list)
+        for (const EngineJob::Copy& cp : j->copy)
+          if (cp.bytes && e == hipSuccess) {
+            e = hipMemcpyAsync(cp.dst, cp.src, cp.bytes, hipMemcpyHostToDevice, copy_stream_);
+            copied = true;
+          }
+    if (stats) copy_ns += now_ns() - t_issue;
+    hipEvent_t copies_done = nullptr;
+    if (copied && e == hipSuccess) {
+      copies_done = new_event();
+      e = copies_done ? hipEventRecord(copies_done, copy_stream_) : hipErrorOutOfMemory;
+    }
+    hipEvent_t batch_event[2] = {nullptr, nullptr};
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+      if (pictures[s].empty() && !(s == kLight && !outputs.empty())) continue;
+      if (!pictures[s].empty()) {
+        if (copies_done) e = hipStreamWaitEvent(stream_[s], copies_done, 0);
+        Batch batch;
+        const PicParams* pps[kMaxBatch];
+        int n = 0;
+        for (EngineJob* j : pictures[s]) {
+          if (j->clear_resid && e == hipSuccess) e = hipMemsetAsync(j->clear_resid, 0, j->clear_resid_bytes, stream_[s]);
+          pps[n] = &j->pp;
+          batch.pic[n++] = j->pp_dev;
+        }
+        if (e == hipSuccess) e = launch_batch(pps, batch, n, stream_[s]);
+        for (EngineJob* j : pictures[s])
+          if (e == hipSuccess) e = hipEventRecord(j->done, stream_[s]);
+      }
+      if (s == kLight)
+        for (EngineJob* j : outputs) {
+          if (e != hipSuccess) break;
+          const size_t w = j->width, h = j->height, cw = (w + 1) / 2, ch = (h + 1) / 2;
+          if (j->kind == EngineJob::kRgb) {
+            uint8_t* rgb = j->out_on_device ? j->out : j->rgb_dev;
+            e = launch_yuv420_to_rgb24(j->y, j->u, j->v, j->y_pitch, j->y_pitch / 2, j->width, j->height, rgb, stream_[s]);
+            if (e == hipSuccess && !j->out_on_device) e = hipMemcpyAsync(j->out, rgb, w * h * 3, hipMemcpyDeviceToHost, stream_[s]);
+          } else {
+            const hipMemcpyKind kind = j->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+            e = hipMemcpy2DAsync(j->out, w, j->y, static_cast<size_t>(j->y_pitch), w, h, kind, stream_[s]);
+            if (e == hipSuccess) e = hipMemcpy2DAsync(j->out + w * h, cw, j->u, static_cast<size_t>(j->y_pitch / 2), cw, ch, kind, stream_[s]);
+            if (e == hipSuccess) e = hipMemcpy2DAsync(j->out + w * h + cw * ch, cw, j->v, static_cast<size_t>(j->y_pitch / 2), cw, ch, kind, stream_[s]);
+          }
+          if (e == hipSuccess) e = hipEventRecord(j->done, stream_[s]);
+        }
+      if (e == hipSuccess) {
+        batch_event[s] = new_event();
+        e = batch_event[s] ? hipEventRecord(batch_event[s], stream_[s]) : hipErrorOutOfMemory;
+      }
+    }
+    if (stats) {
+      const int64_t d = now_ns() - t_issue;
+      issue_ns += d;
+      issue_max_ns = d > issue_max_ns ? d : issue_max_ns;
+      for (int s = 0; s < 2; ++s)
+        if (!pictures[s].empty()) {
+          ++n_batches[s];
+          n_pictures[s] += static_cast<int64_t>(pictures[s].size());
+        }
+      n_outputs += static_cast<int64_t>(outputs.size());
+    }
+    lk.lock();
+    if (copies_done) copy_inflight_.push_back(copies_done);
+    for (int s = 0; s < 2; ++s)
+      if (batch_event[s]) inflight_[s].push_back(batch_event[s]);
+    if (e != hipSuccess && error_.empty()) error_ = std::string("the HEVC engine failed to launch a batch: ") + hipGetErrorString(e);
+    for (auto* list : {&pictures[0], &pictures[1], &outputs})
+      for (EngineJob* j : *list) {
+        j->failed = e != hipSuccess;
+        j->launched.store(1, std::memory_order_release);
+      }
+    for (int ci : touched) clients_[ci].taking = false;
+    cv_done_.notify_all();
+  }
+  lk.unlock();
+  if (stats)
+    std::fprintf(stderr, "[hevc engine %d] light: %lld pictures in %lld batches; heavy: %lld in %lld; %lld fetched frames; issuing took %.1f ms (copies %.1f ms), "
+                 "longest round %.2f ms; %lld empty rounds\n", device_, (long long)n_pictures[0], (long long)n_batches[0], (long long)n_pictures[1], (long long)n_batches[1],
+                 (long long)n_outputs, issue_ns / 1e6, copy_ns / 1e6, issue_max_ns / 1e6, (long long)idle_rounds);
+  for (hipStream_t s : {copy_stream_, stream_[0], stream_[1]})
+    if (s) {
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+    }
+  for (auto* fl : {&inflight_[0], &inflight_[1], &copy_inflight_})
+    for (hipEvent_t e : *fl) (void)hipEventDestroy(e);
+  for (hipEvent_t e : event_pool_) (void)hipEventDestroy(e);
+}
+
+}  // namespace hevc
+}  // namespace amd
+}  // namespace hwang

@@ -117,7 +117,7 @@ struct PicParams {
   const IntraTu* intra[3];             // per plane, decoding order
   const uint32_t* intra_ctb_first[3];  // per plane: width_ctb * height_ctb + 1 offsets into intra[c] (k_hevc_intra_rows)
   int32_t intra_rows;                  // 1: the picture is mostly intra, k_hevc_intra_rows; 0: k_hevc_intra_flow
-  int32_t pad0;
+  int32_t clear_words;                 // 32-bit words from `intra_ticket` on that the picture's intra kernel expects zeroed (k_hevc_clear)
   const EdgeInfo* edges;
   const SaoCtb* sao;
   const SliceLoop* slices;
@@ -127,6 +127,15 @@ struct PicParams {
   uint32_t* intra_ticket;      // k_hevc_intra_flow: [3] next record of each plane's list (zeroed per picture)
   uint8_t* intra_done[3];      // per plane, per 4x4 luma block: an intra block covering it is final (zeroed per picture)
   uint32_t* fault;             // set by a kernel whose bounded wait expired
+};
+
+// What one launch works on: pictures of different decoders (nothing in common but the GPU), each with its own grid
+// coordinate; kernels whose grid is sized by the largest picture let the blocks past a smaller one's end return.
+constexpr int kMaxBatch = 32;
+struct Batch {
+  const PicParams* pic[kMaxBatch];  // device pointers
+  int32_t spin_sleep = 1;           // how long a wavefront that waits for a neighbour sleeps between two looks (x 64 clocks x 8)
+  int32_t pad = 0;
 };
 
 }  // namespace hevc

@@ -1,15 +1,16 @@
 // The HEVC half of the MI355X backend behind VideoDecoderInterface (the reference's
 // software backend takes HEVC tracks too, impls/software/software_video_decoder.cpp:128-132).  AMDVideoDecoder
 // (amd_video_decoder.cpp) hands every call over to an object of this class once configure() has seen an HEVC format
-// name.  One HIP stream per decoder orders everything: a picture's records (host parser, hevc/hevc_parser.cpp) are
-// copied from pinned staging memory, its kernels (k_hevc.hip) run in decoding order, the colour conversion of a
-// fetched frame and its copy-out queue up behind the picture they show.  Latency-oriented and simple - the batching
-// executor of the H.264 path is not used here (DESIGN.md section 5a says what that costs).
+// name.  A decoder owns its surfaces, its staging sets (pinned host memory + device copies of a picture's records,
+// written by the host parser hevc/hevc_parser.cpp) and its scratch planes; what it does NOT own is a stream: every picture
+// and every fetched frame is a job handed to the GPU's submission engine (hevc_engine.h), which batches the jobs of all
+// decoders into a few streams.
 #include "hevc_video_decoder.h"
 
 #include "../hevc/hevc_parser.h"
 #include "../sparse_hints.h"
 #include "../../../include/hwang_amd.h"
+#include "hevc_engine.h"
 #include "hevc_frame_job.h"
 #include "hip_check.h"
 
@@ -26,11 +27,9 @@
 
 namespace hwang {
 
-hipError_t launch_yuv420_to_rgb24(const uint8_t* y, const uint8_t* u, const uint8_t* v, int y_stride, int c_stride, int width, int height,
-                                  uint8_t* rgb, hipStream_t stream);
 namespace amd {
 namespace hevc {
-hipError_t launch_picture(const PicParams& pp, const PicParams* pp_dev, hipStream_t stream);
+hipError_t launch_batch(const PicParams* const* pp, const Batch& batch, int n, hipStream_t stream);
 }
 }  // namespace amd
 
@@ -38,27 +37,31 @@ namespace {
 
 namespace gh = amd::hevc;
 constexpr int kSets = 3;
+constexpr int kOutputs = 6;  // fetched frames on their way (take): conversion, copy-out, for pageable caller memory a bounce buffer
 
 class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
  public:
-  explicit HEVCVideoDecoder(int device) : device_(device) {}
+  explicit HEVCVideoDecoder(int device) : device_(device), engine_(gh::Engine::for_device(device)), client_(engine_->add_client()) {}
   ~HEVCVideoDecoder() override {
     (void)hipSetDevice(device_);
     parser_.reset();
-    if (stream_) (void)hipStreamSynchronize(stream_);
+    (void)quiesce();
     free_all();
-    if (stream_) (void)hipStreamDestroy(stream_);
+    for (Output& o : outputs_) {
+      if (o.host) (void)hipHostFree(o.host);
+      if (o.job.done) (void)hipEventDestroy(o.job.done);
+    }
+    engine_->remove_client(client_);
   }
 
   Result configure(const VideoDecoderInterface::FrameInfo& info, const std::vector<uint8_t>& extradata) override {
     HWANG_HIP_RETURN(hipSetDevice(device_));
-    if (!stream_) HWANG_HIP_RETURN(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
     if (parser_) {
       folded_decoded_ += parser_->pictures_decoded();
       folded_skipped_ += parser_->pictures_skipped();
     }
     parser_.reset();  // (releases its surfaces)
-    HWANG_HIP_RETURN(hipStreamSynchronize(stream_));
+    HWANG_RETURN_ON_ERROR(quiesce());
     {
       std::lock_guard<std::mutex> lk(mu_);
       for (int slot : outq_)
@@ -80,6 +83,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (!size) return Result();
     if (!parser_) return Result(false, "AMDVideoDecoder::feed before configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
+    HWANG_RETURN_ON_ERROR(deliver_outputs(false));
     ++counters_.samples_fed;
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t stall0 = counters_.stall_ns, submit0 = submit_ns_;
@@ -118,7 +122,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
 
   Result wait_until_frames_copied() override {
     HWANG_HIP_RETURN(hipSetDevice(device_));
-    if (stream_) HWANG_HIP_RETURN(hipStreamSynchronize(stream_));
+    HWANG_RETURN_ON_ERROR(quiesce());
     if (fault_host_ && *fault_host_) {
       *fault_host_ = 0;
       resid_dirty_ = true;
@@ -151,6 +155,10 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     Set& set = sets_[next_set_];
     if (set.busy) {
       const auto t0 = std::chrono::steady_clock::now();
+      if (!engine_->wait_launched(&set.job)) {
+        *error = engine_->error();
+        return false;
+      }
       if (hipEventSynchronize(set.done) != hipSuccess) {
         *error = "hipEventSynchronize failed";
         return false;
@@ -209,7 +217,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       ~Timer() { *acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
     } timer{&submit_ns_};
     Set& set = *static_cast<Set*>(d.cookie);
-    gh::PicParams pp;
+    gh::PicParams& pp = set.job.pp;
     std::memset(&pp, 0, sizeof(pp));
     pp.width = cw_;
     pp.height = ch_;
@@ -259,28 +267,23 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     pp.progress = progress_ + 4;
     for (int c = 0; c < 3; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(progress_ + 4 + 3 * hctb_) + static_cast<size_t>(c) * (cw_ / 4) * (ch_ / 4);
     pp.fault = fault_dev_;
+    // what the picture's intra kernel counts in, zeroed by the batch's first kernel: the rows' progress words or everything
+    pp.clear_words = static_cast<int32_t>((pp.intra_rows ? 16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) : progress_bytes_) / 4);
     std::memcpy(set.host + off_.params, &pp, sizeof(pp));
-    auto up = [&](size_t off, size_t bytes) {
-      if (!bytes) return hipSuccess;
-      bytes_uploaded_ += static_cast<int64_t>(bytes);
-      return hipMemcpyAsync(dv + off, set.host + off, bytes, hipMemcpyHostToDevice, stream_);
-    };
-    hipError_t e = up(off_.params, off_.part_b);            // part A
-    if (e == hipSuccess) e = up(off_.part_b, packed - off_.part_b);  // part B
+    gh::EngineJob& job = set.job;
+    job.kind = gh::EngineJob::kPicture;
+    job.pp_dev = reinterpret_cast<const gh::PicParams*>(dv + off_.params);
+    job.copy[0] = {dv, set.host, packed};  // part A and the packed part B are one piece
+    job.copy[1] = {nullptr, nullptr, 0};
+    bytes_uploaded_ += static_cast<int64_t>(packed);
     // the residual planes are zero between pictures (the kernels that read a residual clear it); only a picture that
     // did not run to its end leaves them in doubt
-    if (e == hipSuccess && resid_dirty_) {
-      e = hipMemsetAsync(resid_, 0, resid_bytes_, stream_);
-      resid_dirty_ = false;
-    }
-    if (e == hipSuccess && (d.num_intra[0] || d.num_intra[1] || d.num_intra[2]))
-      e = hipMemsetAsync(progress_, 0, pp.intra_rows ? 16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) : progress_bytes_, stream_);
-    if (e == hipSuccess) e = gh::launch_picture(pp, reinterpret_cast<const gh::PicParams*>(dv + off_.params), stream_);
-    if (e == hipSuccess) e = hipEventRecord(set.done, stream_);
-    if (e != hipSuccess) {
-      *error = std::string("HEVC picture submission failed: ") + hipGetErrorString(e);
-      return false;
-    }
+    job.clear_resid = resid_dirty_ ? resid_ : nullptr;
+    job.clear_resid_bytes = resid_bytes_;
+    resid_dirty_ = false;
+    job.done = set.done;
+    engine_->submit(client_, &job);
+    (void)error;
     set.busy = true;
     next_set_ = (next_set_ + 1) % kSets;
     return true;
@@ -315,6 +318,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     uint8_t* dev = nullptr;
     hipEvent_t done = nullptr;
     bool busy = false;
+    gh::EngineJob job;
   };
   struct Offsets {
     size_t params, res, coefs, pus, weights, intra[3], first[3], edges, sao, slices, scaling, part_b, total;
@@ -347,7 +351,9 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       if (s.host) (void)hipHostFree(s.host);
       if (s.dev) (void)hipFree(s.dev);
       if (s.done) (void)hipEventDestroy(s.done);
-      s = Set();
+      s.host = s.dev = nullptr;
+      s.done = nullptr;
+      s.busy = false;
     }
     if (work_) (void)hipFree(work_);
     if (resid_) (void)hipFree(resid_);
@@ -369,7 +375,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       crop_t_ = s.crop_top;
       return true;
     }
-    if (stream_) (void)hipStreamSynchronize(stream_);
+    (void)quiesce();
     {
       std::lock_guard<std::mutex> lk(mu_);
       for (const SurfaceSlot& sl : surf_)
@@ -420,12 +426,12 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     for (Set& set : sets_) {
       ok = ok && hipHostMalloc(reinterpret_cast<void**>(&set.host), off_.total, hipHostMallocDefault) == hipSuccess;
       ok = ok && hipMalloc(reinterpret_cast<void**>(&set.dev), off_.total) == hipSuccess;
-      ok = ok && hipEventCreateWithFlags(&set.done, hipEventDisableTiming) == hipSuccess;
+      ok = ok && hipEventCreateWithFlags(&set.done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
     }
     resid_bytes_ = surface_bytes_ * sizeof(int16_t);
     ok = ok && hipMalloc(reinterpret_cast<void**>(&work_), surface_bytes_) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&resid_), resid_bytes_) == hipSuccess;
-    progress_bytes_ = 16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) + 3 * w4h4;  // tickets, row progress words, a done map per plane
+    progress_bytes_ = (16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) + 3 * w4h4 + 3) & ~static_cast<size_t>(3);  // tickets, row progress words, a done map per plane
     ok = ok && hipMalloc(reinterpret_cast<void**>(&progress_), progress_bytes_) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&rgb_dev_), static_cast<size_t>(cw_) * ch_ * 3) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&fault_host_), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
@@ -462,30 +468,103 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     const uint8_t* y = s.y + static_cast<size_t>(crop_t_) * y_pitch_ + crop_l_;
     const uint8_t* u = s.u + static_cast<size_t>(crop_t_ / 2) * (y_pitch_ / 2) + crop_l_ / 2;
     const uint8_t* v = s.v + static_cast<size_t>(crop_t_ / 2) * (y_pitch_ / 2) + crop_l_ / 2;
+    // Where the frame goes: HBM (the conversion writes it), page-locked host memory (the D2H copy writes it), or pageable
+    // host memory - a copy into that would block its caller until every picture in flight is done; it lands in a
+    // page-locked bounce buffer instead and is copied out when a later call finds it there (wait_until_frames_copied at
+    // the latest: the interface's own contract for when fetched frames are valid).
     hipPointerAttribute_t attr;
-    const bool device_dst = hipPointerGetAttributes(&attr, dst) == hipSuccess && attr.type == hipMemoryTypeDevice;
-    if (!device_dst) (void)hipGetLastError();
-    hipError_t e = hipSuccess;
-    if (yuv) {
-      const hipMemcpyKind kind = device_dst ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-      e = hipMemcpy2DAsync(dst, w, y, static_cast<size_t>(y_pitch_), w, h, kind, stream_);
-      if (e == hipSuccess) e = hipMemcpy2DAsync(dst + w * h, cw, u, static_cast<size_t>(y_pitch_ / 2), cw, chh, kind, stream_);
-      if (e == hipSuccess) e = hipMemcpy2DAsync(dst + w * h + cw * chh, cw, v, static_cast<size_t>(y_pitch_ / 2), cw, chh, kind, stream_);
-    } else {
-      uint8_t* rgb = device_dst ? dst : rgb_dev_;
-      e = launch_yuv420_to_rgb24(y, u, v, y_pitch_, y_pitch_ / 2, static_cast<int>(w), static_cast<int>(h), rgb, stream_);
-      if (e == hipSuccess && !device_dst) e = hipMemcpyAsync(dst, rgb_dev_, need, hipMemcpyDeviceToHost, stream_);
+    const bool known = hipPointerGetAttributes(&attr, dst) == hipSuccess;
+    if (!known) (void)hipGetLastError();
+    const bool device_dst = known && attr.type == hipMemoryTypeDevice;
+    const bool direct = device_dst || (known && attr.type == hipMemoryTypeHost);
+    Output& o = outputs_[output_next_];
+    output_next_ = (output_next_ + 1) % kOutputs;
+    HWANG_RETURN_ON_ERROR(deliver(o, true));
+    if (!o.job.done && hipEventCreateWithFlags(&o.job.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess)
+      return Result(false, "AMDVideoDecoder::get_frame (HEVC): hipEventCreate failed");
+    if (!direct && o.cap < need) {
+      if (o.host) (void)hipHostFree(o.host);
+      o.host = nullptr;
+      o.cap = 0;
+      if (hipHostMalloc(reinterpret_cast<void**>(&o.host), need, hipHostMallocDefault) != hipSuccess)
+        return Result(false, "AMDVideoDecoder::get_frame (HEVC): no page-locked memory for the output bounce buffer");
+      o.cap = need;
     }
+    gh::EngineJob& job = o.job;
+    job.kind = yuv ? gh::EngineJob::kYuv : gh::EngineJob::kRgb;
+    job.y = y;
+    job.u = u;
+    job.v = v;
+    job.y_pitch = y_pitch_;
+    job.width = static_cast<int>(w);
+    job.height = static_cast<int>(h);
+    job.rgb_dev = rgb_dev_;
+    job.out = direct ? dst : o.host;
+    job.out_on_device = device_dst;
+    o.dst = direct ? nullptr : dst;
+    o.bytes = need;
+    o.active = true;
+    engine_->submit(client_, &job);
     {
       std::lock_guard<std::mutex> lk(mu_);
-      surf_[slot].held &= ~kOutput;  // (whatever takes the surface next queues up behind this on the stream)
+      surf_[slot].held &= ~kOutput;  // (whatever takes the surface next is a later job of this decoder: behind this one)
     }
-    if (e != hipSuccess) return Result(false, std::string("AMDVideoDecoder::get_frame (HEVC): ") + hipGetErrorString(e));
     return Result();
   }
 
+  struct Output {
+    gh::EngineJob job;
+    uint8_t* host = nullptr;  // bounce buffer
+    size_t cap = 0;
+    uint8_t* dst = nullptr;   // pageable caller memory the frame is owed to (null: the job writes the destination itself)
+    size_t bytes = 0;
+    bool active = false;
+  };
+  // Finishes a fetched frame: its job is through (and, from a bounce buffer, copied out).  `wait`: waits for that, else
+  // leaves it if it is not there yet.
+  Result deliver(Output& o, bool wait) {
+    if (!o.active) return Result();
+    if (!wait && !o.job.launched.load(std::memory_order_acquire)) return Result();
+    if (!engine_->wait_launched(&o.job)) {
+      o.active = false;
+      return Result(false, "AMDVideoDecoder::get_frame (HEVC): " + engine_->error());
+    }
+    if (wait) {
+      HWANG_HIP_RETURN(hipEventSynchronize(o.job.done));
+    } else {
+      const hipError_t q = hipEventQuery(o.job.done);
+      if (q == hipErrorNotReady) return Result();
+      HWANG_HIP_RETURN(q);
+    }
+    if (o.dst) std::memcpy(o.dst, o.host, o.bytes);
+    o.dst = nullptr;
+    o.active = false;
+    return Result();
+  }
+  Result deliver_outputs(bool wait) {
+    for (int k = 0; k < kOutputs; ++k) HWANG_RETURN_ON_ERROR(deliver(outputs_[(output_next_ + k) % kOutputs], wait));  // oldest first
+    return Result();
+  }
+  // Everything this decoder has submitted is done: its pictures, its fetched frames (delivered).
+  Result quiesce() {
+    const bool ok = engine_->drain(client_);
+    for (Set& set : sets_)
+      if (set.busy) {
+        (void)engine_->wait_launched(&set.job);
+        if (set.done) (void)hipEventSynchronize(set.done);
+        set.busy = false;
+      }
+    Result r = deliver_outputs(true);
+    engine_->settled(client_);
+    if (!ok && r.ok) r = Result(false, "AMDVideoDecoder (HEVC): " + engine_->error());
+    return r;
+  }
+
   const int device_;
-  hipStream_t stream_ = nullptr;
+  std::shared_ptr<gh::Engine> engine_;
+  const int client_;
+  Output outputs_[kOutputs];
+  int output_next_ = 0;
   std::unique_ptr<hevc::Parser> parser_;
   VideoDecoderInterface::FrameInfo info_;
   std::vector<uint64_t> pending_wanted_;
@@ -597,7 +676,11 @@ extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, cha
   pp.resid[0] = resid;
   pp.resid[1] = resid + static_cast<size_t>(pitch) * H;
   pp.resid[2] = pp.resid[1] + static_cast<size_t>(pitch / 2) * (H / 2);
-  pp.intra_ticket = reinterpret_cast<uint32_t*>(dev(16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb) + 3 * w4h4, nullptr));
+  // (handed over full of ones: k_hevc_clear, the batch's first kernel, is what zeroes it)
+  const size_t progress_bytes = (16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb) + 3 * w4h4 + 3) & ~static_cast<size_t>(3);
+  const std::vector<uint8_t> ones(progress_bytes, 0xff);
+  pp.intra_ticket = reinterpret_cast<uint32_t*>(dev(progress_bytes, ones.data()));
+  pp.clear_words = static_cast<int32_t>(progress_bytes / 4);
   pp.progress = pp.intra_ticket ? pp.intra_ticket + 4 : nullptr;
   for (int c = 0; c < 3 && pp.intra_ticket; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(pp.intra_ticket + 4 + 3 * hctb) + static_cast<size_t>(c) * w4h4;
   pp.intra_rows = t->intra_rows;
@@ -623,7 +706,12 @@ extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, cha
   pp.fault = reinterpret_cast<uint32_t*>(dev(sizeof(uint32_t), nullptr));
   const gh::PicParams* pp_dev = reinterpret_cast<const gh::PicParams*>(dev(sizeof(pp), &pp));
   ok = ok && pp.res && pp.coefs && pp.pus && pp.weights && pp.edges && pp.sao && pp.slices && resid && pp.intra_ticket && pp.fault && pp_dev;
-  if (ok) ok = gh::launch_picture(pp, pp_dev, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  if (ok) {
+    gh::Batch batch;
+    batch.pic[0] = pp_dev;
+    const gh::PicParams* pps[1] = {&pp};
+    ok = gh::launch_batch(pps, batch, 1, nullptr) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+  }
   uint32_t fault = 0;
   if (ok) ok = hipMemcpy(&fault, pp.fault, sizeof(fault), hipMemcpyDeviceToHost) == hipSuccess;
   if (ok && t->out) {

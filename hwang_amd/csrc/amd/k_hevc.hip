@@ -17,6 +17,8 @@
 // tests/hevc_numpy.py (tests/test_gpu_hevc.py).  HEVC parity with FFmpeg is unpinned.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "hevc_frame_job.h"
 #include "hip_check.h"
 
@@ -77,11 +79,21 @@ __device__ inline int clip8(int v) { return v < 0 ? 0 : v > 255 ? 255 : v; }
 __device__ inline int iabs(int v) { return v < 0 ? -v : v; }
 __device__ inline uint8_t* plane_of(const Surface& s, int c) { return c == 0 ? s.y : c == 1 ? s.u : s.v; }
 
+// The words an intra kernel counts in - tickets, the rows' progress, the "done" bytes - start every picture at zero.
+__global__ __launch_bounds__(256) void k_hevc_clear(const Batch batch) {
+  const PicParams& pp = *batch.pic[blockIdx.y];
+  if (!(pp.num_intra[0] | pp.num_intra[1] | pp.num_intra[2])) return;
+  const int first = blockIdx.x * 1024 + threadIdx.x * 4;
+  for (int k = 0; k < 4; ++k)
+    if (first + k < pp.clear_words) pp.intra_ticket[first + k] = 0;
+}
+
 // ---------------------------------------------------------------------------------------------------- residual
 constexpr int kResWaves = 4;
 
-__global__ __launch_bounds__(64 * kResWaves) void k_hevc_residual(const PicParams* __restrict__ ppp) {
-  const PicParams& pp = *ppp;
+__global__ __launch_bounds__(64 * kResWaves) void k_hevc_residual(const Batch batch) {
+  const PicParams& pp = *batch.pic[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) * kResWaves >= pp.num_res) return;
   __shared__ int d[kResWaves][1024];
   __shared__ int g[kResWaves][1024];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -172,8 +184,9 @@ __device__ inline int interp(const uint8_t* ref, int pitch, int w, int h, bool c
   return v >> 6;
 }
 
-__global__ __launch_bounds__(256) void k_hevc_inter(const PicParams* __restrict__ ppp) {
-  const PicParams& pp = *ppp;
+__global__ __launch_bounds__(256) void k_hevc_inter(const Batch batch) {
+  const PicParams& pp = *batch.pic[blockIdx.y];
+  if (static_cast<int>(blockIdx.x) >= pp.num_pu) return;
   const InterPu pu = pp.pus[blockIdx.x];
   for (int c = 0; c < 3; ++c) {
     const int sub = c ? 1 : 0;
@@ -367,8 +380,8 @@ constexpr uint32_t kIntraSpins = 1u << 22;  // bounded wait for a neighbour (the
 // grid.  NOT for intra pictures: there nearly every block waits for its predecessor, and a thousand wavefronts
 // spinning on their neighbours starve the few that can run (measured: 415 ms per picture,
 // profiles/r06_hevc_dataflow_everywhere_kernel_stats.csv); those take variant 2.
-__global__ __launch_bounds__(64) void k_hevc_intra_flow(const PicParams* __restrict__ ppp) {
-  const PicParams& pp = *ppp;
+__global__ __launch_bounds__(64) void k_hevc_intra_flow(const Batch batch) {
+  const PicParams& pp = *batch.pic[blockIdx.z];
   const int c = blockIdx.y, lane = threadIdx.x;
   const int pitch = c ? pp.c_pitch : pp.y_pitch, ushift = c ? 1 : 2, sub = c ? 1 : 0, w4 = pp.width >> 2;
   uint8_t* plane = plane_of(pp.recon, c);
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_flow(const PicParams* __restr
       for (;;) {
         const bool ok = !flag || __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0;
         if (__all(ok)) break;
-        __builtin_amdgcn_s_sleep(1);
+        for (int k = 0; k < batch.spin_sleep; ++k) __builtin_amdgcn_s_sleep(8);
         if (++spins > kIntraSpins) {
           if (lane == 0) atomicExch(pp.fault, 1u);
           return;
@@ -427,9 +440,10 @@ __global__ __launch_bounds__(64) void k_hevc_intra_flow(const PicParams* __restr
 constexpr int kTilePitch = 144;  // 16 bytes (the left column is the last of them) + 2 x 64 samples
 constexpr int kTileRecs = 256;   // the records of a 64x64 block of 4x4s
 
-__global__ __launch_bounds__(64) void k_hevc_intra_rows(const PicParams* __restrict__ ppp) {
-  const PicParams& pp = *ppp;
+__global__ __launch_bounds__(64) void k_hevc_intra_rows(const Batch batch) {
+  const PicParams& pp = *batch.pic[blockIdx.z];
   const int c = blockIdx.y, row = blockIdx.x, lane = threadIdx.x;
+  if (row >= pp.height_ctb) return;
   const int sub = c ? 1 : 0, pitch = c ? pp.c_pitch : pp.y_pitch, pw = pp.width >> sub, ph = pp.height >> sub;
   const int S = (1 << pp.log2_ctb) >> sub;  // the coding tree block in samples of this plane
   uint8_t* plane = plane_of(pp.recon, c);
@@ -498,7 +512,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_rows(const PicParams* __restr
       const uint32_t need = static_cast<uint32_t>(col + 2 < pp.width_ctb ? col + 2 : pp.width_ctb);
       uint32_t spins = 0;
       while (__hip_atomic_load(&progress[row - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        __builtin_amdgcn_s_sleep(1);
+        for (int k = 0; k < batch.spin_sleep; ++k) __builtin_amdgcn_s_sleep(8);
         if (++spins > kIntraSpins) {
           if (lane == 0) atomicExch(pp.fault, 1u);
           return;
@@ -585,8 +599,9 @@ __device__ void luma_segment(uint8_t* q0, int across, int along, int beta, int t
 #undef Q
 }
 
-__global__ __launch_bounds__(256) void k_hevc_deblock(const PicParams* __restrict__ ppp, int dir) {
-  const PicParams& pp = *ppp;
+__global__ __launch_bounds__(256) void k_hevc_deblock(const Batch batch, int dir) {
+  const PicParams& pp = *batch.pic[blockIdx.y];
+  if (!pp.deblock_enabled) return;
   const int w4 = pp.width >> 2, h4 = pp.height >> 2;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= w4 * h4) return;
@@ -623,9 +638,10 @@ __global__ __launch_bounds__(256) void k_hevc_deblock(const PicParams* __restric
 }
 
 // --------------------------------------------------------------------------------------------------------- SAO
-__global__ __launch_bounds__(256) void k_hevc_sao(const PicParams* __restrict__ ppp) {
-  const PicParams& pp = *ppp;
-  const int c = blockIdx.z, sub = c ? 1 : 0;
+__global__ __launch_bounds__(256) void k_hevc_sao(const Batch batch) {
+  const PicParams& pp = *batch.pic[blockIdx.z / 3];
+  if (!pp.sao_enabled) return;
+  const int c = blockIdx.z % 3, sub = c ? 1 : 0;
   const int pw = pp.width >> sub, ph = pp.height >> sub, pitch = c ? pp.c_pitch : pp.y_pitch;
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
   if (x >= pw || y >= ph) return;
@@ -673,25 +689,58 @@ namespace hwang {
 namespace amd {
 namespace hevc {
 
-// One picture's kernels on `stream`, in order.  `pp_dev` is the device copy of `pp` (already in the stream's past).
-hipError_t launch_picture(const PicParams& pp, const PicParams* pp_dev, hipStream_t stream) {
-  if (pp.num_res) hipLaunchKernelGGL(k_hevc_residual, dim3((pp.num_res + kResWaves - 1) / kResWaves), dim3(64 * kResWaves), 0, stream, pp_dev);
-  if (pp.num_pu) hipLaunchKernelGGL(k_hevc_inter, dim3(pp.num_pu), dim3(256), 0, stream, pp_dev);
-  if (pp.num_intra[0] || pp.num_intra[1] || pp.num_intra[2]) {
-    if (pp.intra_rows) {
-      hipLaunchKernelGGL(k_hevc_intra_rows, dim3(pp.height_ctb, 3), dim3(64), 0, stream, pp_dev);
-    } else {
-      // as many wavefronts as a sparse picture has independent blocks in flight; each takes records until none are left
-      const int most = pp.num_intra[0] > pp.num_intra[1] ? pp.num_intra[0] : pp.num_intra[1];
-      hipLaunchKernelGGL(k_hevc_intra_flow, dim3(most < 256 ? most : 256, 3), dim3(64), 0, stream, pp_dev);
+// The kernels of `n` pictures of different decoders on `stream`, stage by stage: one launch per stage whatever `n` is.
+// `pp[i]` is the host copy of picture i's parameters (for the grids), `batch.pic[i]` its device copy (already in the
+// stream's past).  Pictures that take the row wavefront and pictures that take the dataflow kernel get a launch each.
+hipError_t launch_batch(const PicParams* const* pp, const Batch& batch, int n, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  if (n > kMaxBatch) return hipErrorInvalidValue;
+  int res = 0, pus = 0, units = 0, width = 0, height = 0, clear = 0;
+  bool deblock = false, sao = false;
+  static const int flow_cap = std::getenv("HWANG_HEVC_FLOW_WORKERS") ? std::atoi(std::getenv("HWANG_HEVC_FLOW_WORKERS")) : 12;
+  static const int spin = std::getenv("HWANG_HEVC_SPIN_SLEEP") ? std::atoi(std::getenv("HWANG_HEVC_SPIN_SLEEP")) : 32;
+  Batch rows, flow;
+  static const int rows_spin = std::getenv("HWANG_HEVC_ROWS_SLEEP") ? std::atoi(std::getenv("HWANG_HEVC_ROWS_SLEEP")) : 16;
+  flow.spin_sleep = spin;
+  rows.spin_sleep = rows_spin;
+  int n_rows = 0, n_flow = 0, rows_ctb = 0, flow_most = 0;
+  for (int i = 0; i < n; ++i) {
+    const PicParams& p = *pp[i];
+    res = p.num_res > res ? p.num_res : res;
+    pus = p.num_pu > pus ? p.num_pu : pus;
+    if (p.deblock_enabled) {
+      deblock = true;
+      const int u = (p.width >> 2) * (p.height >> 2);
+      units = u > units ? u : units;
+    }
+    if (p.sao_enabled) {
+      sao = true;
+      width = p.width > width ? p.width : width;
+      height = p.height > height ? p.height : height;
+    }
+    if (p.num_intra[0] || p.num_intra[1] || p.num_intra[2]) {
+      clear = p.clear_words > clear ? p.clear_words : clear;
+      if (p.intra_rows) {
+        rows.pic[n_rows++] = batch.pic[i];
+        rows_ctb = p.height_ctb > rows_ctb ? p.height_ctb : rows_ctb;
+      } else {
+        // as many wavefronts as a sparse picture has independent blocks in flight; each takes records until none are left
+        const int most = p.num_intra[0] > p.num_intra[1] ? p.num_intra[0] : p.num_intra[1];
+        flow.pic[n_flow++] = batch.pic[i];
+        flow_most = most > flow_most ? most : flow_most;
+      }
     }
   }
-  if (pp.deblock_enabled) {
-    const int units = (pp.width >> 2) * (pp.height >> 2);
-    hipLaunchKernelGGL(k_hevc_deblock, dim3((units + 255) / 256), dim3(256), 0, stream, pp_dev, 0);
-    hipLaunchKernelGGL(k_hevc_deblock, dim3((units + 255) / 256), dim3(256), 0, stream, pp_dev, 1);
+  if (clear) hipLaunchKernelGGL(k_hevc_clear, dim3((clear + 1023) / 1024, n), dim3(256), 0, stream, batch);
+  if (res) hipLaunchKernelGGL(k_hevc_residual, dim3((res + kResWaves - 1) / kResWaves, n), dim3(64 * kResWaves), 0, stream, batch);
+  if (pus) hipLaunchKernelGGL(k_hevc_inter, dim3(pus, n), dim3(256), 0, stream, batch);
+  if (n_rows) hipLaunchKernelGGL(k_hevc_intra_rows, dim3(rows_ctb, 3, n_rows), dim3(64), 0, stream, rows);
+  if (n_flow) hipLaunchKernelGGL(k_hevc_intra_flow, dim3(flow_most < flow_cap ? flow_most : flow_cap, 3, n_flow), dim3(64), 0, stream, flow);
+  if (deblock) {
+    hipLaunchKernelGGL(k_hevc_deblock, dim3((units + 255) / 256, n), dim3(256), 0, stream, batch, 0);
+    hipLaunchKernelGGL(k_hevc_deblock, dim3((units + 255) / 256, n), dim3(256), 0, stream, batch, 1);
   }
-  if (pp.sao_enabled) hipLaunchKernelGGL(k_hevc_sao, dim3((pp.width + 255) / 256, pp.height, 3), dim3(256), 0, stream, pp_dev);
+  if (sao) hipLaunchKernelGGL(k_hevc_sao, dim3((width + 255) / 256, height, 3 * n), dim3(256), 0, stream, batch);
   return hipGetLastError();
 }
 

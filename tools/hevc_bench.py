@@ -62,8 +62,10 @@ def build_clip(workdir, width, height, gops, gop, frames, qp, bframes=2):
 
 
 def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, steps=3, fraction=0.01, workdir="/tmp/hwang_hevc_bench"):
+    import ctypes as C
     import numpy as np
     import hwang_amd as hw
+    import hwang_amd._capi
     t0 = time.perf_counter()
     blob, idx = build_clip(workdir, width, height, gops, gop, frames, qp)
     t_build = time.perf_counter() - t0
@@ -78,6 +80,8 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
         times.append(time.perf_counter() - t)
         assert len(out) == len(rows) and out[0].shape == (height, width, 3)
         st = dec.stats()
+        hc = (C.c_int64 * 4)()
+        hw._capi.lib.hwang_retriever_host_counters(dec._get_retriever(), hc)
         del out
     best = min(times)
     return {"what": "HEVC Main %dx%d, %d frames (%d unique GOPs of %d, CTB 64, 2 B pictures, SAO, AMP, sign hiding, QP %d), %.0f %% uniform-random "
@@ -86,6 +90,8 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
             "pictures_reconstructed": st["pictures_reconstructed"], "pictures_skipped": st["pictures_skipped"],
             "pictures_reconstructed_per_s": round(st["pictures_reconstructed"] / best, 1),
             "host_parse_ms_per_picture": round(st["entropy_ns"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
+            "lane_cpu_ms_per_picture": round(hc[3] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
+            "lane_wall_ms_per_picture": round(lanes * times[-1] * 1e3 / max(1, st["pictures_reconstructed"]), 3),
             "staging_stall_ms_per_picture": round(st["stall_ns"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
             "upload_MB_per_picture": round(st["bytes_uploaded"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
             "bytes_per_sample": round(sum(idx.sample_sizes()) / n), "clip_build_s": round(t_build, 1),
