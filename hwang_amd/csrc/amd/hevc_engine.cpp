@@ -114,6 +114,7 @@ void Engine::run() {
   uint64_t round = 0;
   // HWANG_HEVC_ENGINE_STATS=1: what the batches looked like, on stderr when the engine goes
   const bool stats = std::getenv("HWANG_HEVC_ENGINE_STATS") != nullptr;
+  const bool copy_on_own_stream = !std::getenv("HWANG_HEVC_COPY_STREAM") || std::atoi(std::getenv("HWANG_HEVC_COPY_STREAM")) != 0;
   int64_t n_batches[2] = {0, 0}, n_pictures[2] = {0, 0}, n_outputs = 0, issue_ns = 0, copy_ns = 0, issue_max_ns = 0, idle_rounds = 0;
   auto now_ns = [] { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   std::unique_lock<std::mutex> lk(mu_);
@@ -184,12 +185,12 @@ void Engine::run() {
     const int64_t t_issue = stats ? now_ns() : 0;
     hipError_t e = hipSuccess;
     bool copied = false;
-    for (auto& list : pictures)
-      for (EngineJob* j : list)
+    for (int s = 0; s < 2; ++s)
+      for (EngineJob* j : pictures[s])
         for (const EngineJob::Copy& cp : j->copy)
           if (cp.bytes && e == hipSuccess) {
-            e = hipMemcpyAsync(cp.dst, cp.src, cp.bytes, hipMemcpyHostToDevice, copy_stream_);
-            copied = true;
+            e = hipMemcpyAsync(cp.dst, cp.src, cp.bytes, hipMemcpyHostToDevice, copy_on_own_stream ? copy_stream_ : stream_[s]);
+            copied = copy_on_own_stream;
           }
     if (stats) copy_ns += now_ns() - t_issue;
     hipEvent_t copies_done = nullptr;
