@@ -50,7 +50,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("HWANG_HOST_COUNTERS", "1")  # the lane threads count their own instructions / cycles (bench line: host_lane_threads)
 
 WIDTH, HEIGHT = 1920, 1080
 UNIQUE_FRAMES = 1200          # encoded once ...
@@ -291,9 +290,15 @@ def main():
                     help="skip the extra pass through hwang.Decoder(...).retrieve(rows), the reference's own API (N = 1)")
     ap.add_argument("--reference-api-threads", type=int, default=int(os.environ.get("HWANG_BENCH_REF_THREADS", 0)),
                     help="num_devices handed to the reference API's DecoderAutomata (default: the usable CPUs)")
+    ap.add_argument("--host-counters", action="store_true",
+                    help="HWANG_HOST_COUNTERS=1: the lane threads count their instructions / cycles / mispredicted branches "
+                         "(perf_event_open per thread and call; off by default - the line is measured as a user runs the library)")
+    ap.add_argument("--no-hevc", action="store_true", help="skip the HEVC leg (tools/hevc_bench.py: SURVEY section 8 row f4, N = 1)")
     ap.add_argument("--unique", type=int, default=0,
                     help="unique frames encoded before the clip repeats (default: the configuration's; C1: 1200 x 90)")
     args = ap.parse_args()
+    if args.host_counters:
+        os.environ["HWANG_HOST_COUNTERS"] = "1"
     args.frames = select_config(args.config, args.frames)
     if args.unique:
         global UNIQUE_FRAMES
@@ -652,6 +657,16 @@ def main():
                                     "hwang.Decoder(path, device_type=GPU, num_devices=%d).retrieve(rows): pybind11 "
                                     "hwang._python.DecoderAutomata -> VideoDecoderFactory -> AMD backend; intervals in 128 MB "
                                     "groups per initialize(); numpy frames in host memory" % t_ref)
+    # SURVEY section 8 row f4 beside the north-star path: the same retrieve call on an HEVC Main clip of the same shape
+    # (tools/hevc_bench.py; its own corpus encoder's output - HEVC parity is unpinned).  Not `value`.
+    hevc = None
+    if rank == 0 and args.gpus == 1 and not args.no_hevc and args.config == "C1":
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import hevc_bench
+            hevc = hevc_bench.run(frames=36000, lanes=24, steps=2)
+        except Exception as e:  # the leg is an extra: the contract's line does not depend on it
+            hevc = {"error": "%s: %s" % (type(e).__name__, e)}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -687,16 +702,16 @@ def main():
                                   % (world, torch.cuda.device_count())),
                        "lanes_per_gpu": lanes // len(devices), "host_cpus": effective_cpus(),
                        # (retriever.cpp: a thread per usable CPU drives the lanes in turn when there are eight work items
-                       # per lane or more, else a thread per lane; HWANG_LANES_PER_THREAD overrides)
-                       "lane_threads": (min(lanes, int(os.environ.get("HWANG_RETRIEVER_THREADS", effective_cpus())))
-                                        if stats["intervals"] >= 8 * lanes else lanes)
-                       if not os.environ.get("HWANG_LANES_PER_THREAD") else -(-lanes // max(1, int(os.environ["HWANG_LANES_PER_THREAD"]))),
+                       # per lane or more, else a thread per lane; HWANG_LANES_PER_THREAD overrides - the number is the
+                       # library's own, hwang_retriever_stats[9])
+                       "lane_threads": stats["lane_threads"],
                        "sharding": "GOP work items, longest-first split, no collective on the data path"},
             "value_host_output": round(value, 2) if not args.hbm_output else value_other,
             "value_hbm_resident": value_other if not args.hbm_output else round(value, 2),
             "value_host_output_page_locked": value_pinned,
             "value_reference_api_unmodified": reference_api_unmodified,
             "value_reference_api": reference_api,
+            "hevc_main_1080p": hevc,
             "parity_check": parity,
             "pictures_reconstructed_per_s": round(total_pics * 1.0 / (elapsed / args.steps), 1),
             "host_lane_threads": host_lane_threads,

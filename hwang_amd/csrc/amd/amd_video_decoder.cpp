@@ -425,12 +425,17 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       }
       // (a decoder that sized its own window - num_devices = 1 - makes its staging sets as the intervals turn out to
       // need them: one more rather than a wait)
-      if (ji < 0 && jobs_ready_ < static_cast<int>(jobs_.size())) {
+      if (ji < 0 && jobs_ready_ < static_cast<int>(jobs_.size()) && !jobs_alloc_failed_) {
         std::string alloc_error;
         if (alloc_job(jobs_[jobs_ready_], &alloc_error)) ji = jobs_ready_++;
-        else if (oldest < 0) {
-          *error = alloc_error;
-          return false;
+        else {
+          // memory is short: no further attempts (each costs a ms-scale hipHostMalloc on the feed thread), the decoder
+          // waits for its oldest set from here on
+          jobs_alloc_failed_ = true;
+          if (oldest < 0) {
+            *error = alloc_error;
+            return false;
+          }
         }
       }
       if (ji < 0) ji = oldest;
@@ -933,6 +938,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     // (with workers chosen by the backend itself only a floor of sets is made here, the rest on demand: begin_picture)
     const int eager = auto_workers_ ? std::min<int>(static_cast<int>(jobs_.size()), 8) : static_cast<int>(jobs_.size());
     jobs_ready_ = 0;
+    jobs_alloc_failed_ = false;
     for (int i = 0; i < eager; ++i) {
       if (!alloc_job(jobs_[i], error)) return false;
       jobs_ready_ = i + 1;
@@ -959,10 +965,12 @@ class AMDVideoDecoder : public VideoDecoderInterface,
         hipMalloc(&j.band_ctl_dev, amd::band_ctl_bytes(mbh_)) != hipSuccess ||
         hipMemset(j.band_ctl_dev, 0, amd::band_ctl_bytes(mbh_)) != hipSuccess) {
       (void)hipGetLastError();
+      free_job(j);  // (what was allocated before the call that failed)
       *error = "AMDVideoDecoder: out of memory for staging buffers";
       return false;
     }
     if (!gpu_visible(j.mb_host) || !gpu_visible(j.coef_host) || !gpu_visible(j.slice_host)) {
+      free_job(j);
       *error = "AMDVideoDecoder: pinned staging memory is not mapped at its host address on this device";
       return false;
     }
@@ -1011,22 +1019,24 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     return hipHostGetDevicePointer(&dev, host, 0) == hipSuccess && dev == host;
   }
 
+  static void free_job(Job& j) {
+    if (j.mb_host) (void)hipHostFree(j.mb_host);
+    if (j.coef_host) (void)hipHostFree(j.coef_host);
+    if (j.slice_host) (void)hipHostFree(j.slice_host);
+    if (j.mb_dev) (void)hipFree(j.mb_dev);
+    if (j.motion_dev) (void)hipFree(j.motion_dev);
+    if (j.pmo_dev) (void)hipFree(j.pmo_dev);
+    if (j.pmx_dev) (void)hipFree(j.pmx_dev);
+    if (j.coef_dev) (void)hipFree(j.coef_dev);
+    if (j.slice_dev) (void)hipFree(j.slice_dev);
+    if (j.db_dev) (void)hipFree(j.db_dev);
+    if (j.resid_dev) (void)hipFree(j.resid_dev);
+    if (j.band_ctl_dev) (void)hipFree(j.band_ctl_dev);
+    j = Job();
+  }
+
   void free_buffers() {
-    for (Job& j : jobs_) {
-      if (j.mb_host) (void)hipHostFree(j.mb_host);
-      if (j.coef_host) (void)hipHostFree(j.coef_host);
-      if (j.slice_host) (void)hipHostFree(j.slice_host);
-      if (j.mb_dev) (void)hipFree(j.mb_dev);
-      if (j.motion_dev) (void)hipFree(j.motion_dev);
-      if (j.pmo_dev) (void)hipFree(j.pmo_dev);
-      if (j.pmx_dev) (void)hipFree(j.pmx_dev);
-      if (j.coef_dev) (void)hipFree(j.coef_dev);
-      if (j.slice_dev) (void)hipFree(j.slice_dev);
-      if (j.db_dev) (void)hipFree(j.db_dev);
-      if (j.resid_dev) (void)hipFree(j.resid_dev);
-      if (j.band_ctl_dev) (void)hipFree(j.band_ctl_dev);
-      j = Job();
-    }
+    for (Job& j : jobs_) free_job(j);
     for (SurfaceSlot& s : surf_) {
       if (s.dev) (void)hipFree(s.dev);
       for (int k = 0; k < 2; ++k) {
@@ -1282,6 +1292,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   std::vector<Job> jobs_;
   int job_cursor_ = 0;
   int jobs_ready_ = 0;  // jobs_[0 .. jobs_ready_) have their buffers (the rest are made on demand, alloc_job)
+  bool jobs_alloc_failed_ = false;  // an on-demand set could not be allocated: stop trying until the buffers are rebuilt
   std::vector<Bounce> bounce_;
   int bounce_cursor_ = 0;
 

@@ -37,6 +37,12 @@
 #include "frame_job.h"
 #include "prof.h"
 
+// How long a wavefront that waits for another unit's progress word sleeps between two looks, in units of the original
+// 64 / 128 clocks (an experiment knob: the HEVC kernels gained from looking less often).
+#ifndef HW_POLL_SCALE
+#define HW_POLL_SCALE 1
+#endif
+
 #include <hip/hip_runtime.h>
 
 namespace hwang {
@@ -710,7 +716,7 @@ HW_FN void chain_wait_reference(const JobDesc& ref, const JobDesc& job, int top,
     do {
       v = agent_ld64(words + row);
       ok = static_cast<uint32_t>(v >> 32) == epoch && static_cast<uint32_t>(v) >= need;
-      if (!ok) __builtin_amdgcn_s_sleep(2);
+      if (!ok) __builtin_amdgcn_s_sleep(2 * HW_POLL_SCALE);
     } while (!ok && poll.again(v));
     if (!ok) {
       report_fault(job, FAULT_CHAIN_REFERENCE);
@@ -728,7 +734,7 @@ HW_FN bool chain_need_inter(const uint32_t* chain_ctl, const BandCtl* ctl, int r
   do {
     seen = agent_ld64(&ctl->inter_mask[row]);
     if ((seen & want) == want) return true;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(1 * HW_POLL_SCALE);
   } while (poll.again(seen));
   return false;
 }
@@ -741,7 +747,7 @@ HW_FN bool chain_need_intra(const uint32_t* chain_ctl, const BandCtl* ctl, uint3
     v = agent_ld64(&ctl->intra_prog[row]);
     if (static_cast<uint32_t>(v >> 32) == epoch) seen = static_cast<uint32_t>(v);
     if (seen >= count) return true;
-    __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_s_sleep(1 * HW_POLL_SCALE);
   } while (poll.again(v));
   return false;
 }
@@ -1657,7 +1663,10 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
       const int nvalid = min(missing ? __builtin_ctzll(missing) >> 3 : 8, W - seen);
       if (act && (lane >> 3) < nvalid) reinterpret_cast<uint32_t*>(G.line[kBandWaves][e])[d] = static_cast<uint32_t>(v);
       seen += nvalid;
-      if (seen < need) __builtin_amdgcn_s_sleep(1);
+      if (seen < need) {
+        if (nvalid) __builtin_amdgcn_s_sleep(1);
+        else __builtin_amdgcn_s_sleep(1 * HW_POLL_SCALE);
+      }
     }
     if (seen < need) {  // impossible by construction; reported, not hung
       report_fault(job, FAULT_INTRA_LINE);
@@ -1671,7 +1680,7 @@ __device__ __forceinline__ void intra_band(const JobDesc& job, const int band, c
     for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
       const uint64_t v = agent_ld64(&ctl->in_prog[band - 1]);
       if (static_cast<uint32_t>(v >> 32) == epoch) seen = static_cast<int>(static_cast<uint32_t>(v));
-      if (seen < need) __builtin_amdgcn_s_sleep(2);
+      if (seen < need) __builtin_amdgcn_s_sleep(2 * HW_POLL_SCALE);
     }
     if (seen < need) {
       report_fault(job, FAULT_INTRA_PROGRESS);
@@ -2345,7 +2354,7 @@ __device__ __forceinline__ void deblock_band(const JobDesc& job, const int band,
     for (int tries = 0; tries < (1 << 21) && seen < need; ++tries) {
       const uint64_t v = agent_ld64(&ctl->db_prog[band - 1]);
       if ((v & 0xffffffff00000000ull) == epoch) seen = static_cast<int>(static_cast<uint32_t>(v));
-      if (seen < need) __builtin_amdgcn_s_sleep(2);
+      if (seen < need) __builtin_amdgcn_s_sleep(2 * HW_POLL_SCALE);
     }
     if (seen < need) {  // a poll that never succeeds (impossible by construction) is reported to the host, and does not hang
       report_fault(job, FAULT_DEBLOCK_PROGRESS);

@@ -215,7 +215,7 @@ void hwang_retriever_stats(hwang_retriever* r, int64_t stats[10]) {
   stats[6] = s.entropy_ns;
   stats[7] = s.wall_ns;
   stats[8] = s.stall_ns;
-  stats[9] = 0;
+  stats[9] = s.lane_threads;
 }
 void hwang_retriever_host_counters(hwang_retriever* r, int64_t out[4]) {
   ParallelRetriever::Stats s = r->r->stats();

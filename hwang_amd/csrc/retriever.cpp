@@ -391,6 +391,7 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
   // (lanes t, t + T, t + 2 T, ... of a thread: with several devices they are all lanes of ONE device when T is a
   // multiple of the device count, which the rounding below sees to)
   if (devices_.size() > 1) nthreads = std::min(nl, (nthreads + devices_.size() - 1) / devices_.size() * devices_.size());
+  stats_.lane_threads = static_cast<int64_t>(nthreads);
   for (size_t ti = 0; ti < nthreads; ++ti) {
     threads.emplace_back([&, ti]() {
       pthread_setname_np(pthread_self(), "hw-lane");
@@ -469,8 +470,13 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
       for (Slot& sl : slots) {
         Lane& lane = lanes_[sl.li];
         Result r = sl.r;
-        for (auto& b : lane.backend)
-          if (r.ok && !failed) r = b->wait_until_frames_copied();
+        // Every backend of every lane of this thread is drained whatever happened - after an error too (the failing
+        // lane's or another thread's): conversions and copies into the caller's output may still be in flight, and the
+        // caller is free to let go of that memory the moment retrieve() returns.  Only the first error is reported.
+        for (auto& b : lane.backend) {
+          const Result w = b->wait_until_frames_copied();
+          if (r.ok && !failed && !w.ok) r = w;
+        }
         if (!r.ok) abort.store(true);
         lane.result = r;
       }

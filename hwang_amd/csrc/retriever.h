@@ -52,6 +52,7 @@ class ParallelRetriever {
     int64_t entropy_ns = 0;
     int64_t stall_ns = 0;
     int64_t wall_ns = 0;
+    int64_t lane_threads = 0;  // threads that drove the lanes of the last call
     // the lane threads' own CPU time, and (HWANG_HOST_COUNTERS=1, where perf_event_open is allowed) what they executed
     int64_t lane_cpu_ns = 0, lane_instructions = 0, lane_cycles = 0, lane_branch_misses = 0;
   };

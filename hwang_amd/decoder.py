@@ -110,7 +110,7 @@ class BatchRetriever(object):
         s = (C.c_int64 * 10)()
         lib.hwang_retriever_stats(self._h, s)
         keys = ("intervals", "samples_fed", "pictures_reconstructed", "pictures_skipped", "frames_returned",
-                "bytes_uploaded", "entropy_ns", "wall_ns", "stall_ns", "reserved")
+                "bytes_uploaded", "entropy_ns", "wall_ns", "stall_ns", "lane_threads")
         return dict(zip(keys, list(s)))
 
     def device_stats(self):
@@ -286,7 +286,7 @@ class Decoder(object):
         lib.hwang_retriever_stats(self._get_retriever(), s)
         keys = ("intervals", "samples_fed", "pictures_reconstructed",
                 "pictures_skipped", "frames_returned", "bytes_uploaded",
-                "entropy_ns", "wall_ns", "stall_ns", "reserved")
+                "entropy_ns", "wall_ns", "stall_ns", "lane_threads")
         return dict(zip(keys, list(s)))
 
     def device_stats(self):

@@ -278,7 +278,7 @@ const char* hwang_retriever_last_error(hwang_retriever* r);
  *  [5] bytes uploaded (macroblock records + coefficients),
  *  [6] host entropy-decode nanoseconds summed over lanes (GPU stalls excluded),
  *  [7] wall nanoseconds, [8] nanoseconds lanes were blocked on the GPU (staging
- *  ring full), summed over lanes, [9] reserved (0) */
+ *  ring full), summed over lanes, [9] the threads that drove the lanes of the last call */
 void hwang_retriever_stats(hwang_retriever* r, int64_t stats[10]);
 /* Measurement aid (bench.py's `host_lane_threads` block): what the lane threads of the last retrieve() executed, from
  * the CPU's own counters where the kernel lets a process count its events (HWANG_HOST_COUNTERS=1 in the environment

@@ -57,7 +57,7 @@ def test_automatic_lane_count(hw):
 
 
 def test_lanes_shared_by_threads(hw, monkeypatch):
-    """A retriever thread drives several lanes in turn, a sample of each at a time (HWANG_LANES_PER_THREAD, default 2):
+    """A retriever thread drives several lanes in turn, a sample of each at a time (HWANG_LANES_PER_THREAD; default: a thread per usable CPU when there are eight work items per lane or more, else a thread per lane):
     whatever the split - a thread per lane as in rounds 1-4, two, three, more lanes than there are - every row comes
     back, in request order, with the sample it names."""
     import struct
