@@ -271,8 +271,12 @@ class GpuExecutor {
   bool no_heavy_ = false;
   // A light engine that serves many lanes forms its next batch when `linger_fill_` per cent of its active lanes have a
   // picture ready - or the oldest of them has waited `linger_us_` (0: as soon as the previous batch is through).
-  int linger_us_ = 6000, linger_fill_ = 85;
-  int linger_idle_us_ = 700;  // ... and no engine lingers once nothing has joined its batch for this long
+  // (round 6, after the share was taken of the lanes at work instead of all registered ones - the test could not be met
+  // before: `value` is flat from 0 to 12 ms of age limit, 984 - 1 000 frames/s, because the 16 CPUs' parsers bound it;
+  // what changes is the width of the launches: 587 launches of 777 us -> 440 of 813 us per step, the deblocking kernel's
+  // achieved bandwidth 0.019 -> 0.024 of peak.  24 ms costs 20 % of `value` with 48 lanes.  profiles/r06_linger_sweep*.txt)
+  int linger_us_ = 12000, linger_fill_ = 100;
+  int linger_idle_us_ = 1500;  // ... and no engine lingers once nothing has joined its batch for this long
   // ... a heavy engine when `heavy_linger_pictures_` keyframes are ready or the oldest has waited `heavy_linger_us_`, the
   // records-only stage when `pre_linger_pictures_` pictures wait or the oldest has waited `pre_linger_us_` (keyframes
   // never wait there)

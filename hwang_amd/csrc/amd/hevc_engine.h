@@ -1,13 +1,15 @@
 // The submission engine of the HEVC path: ONE thread per GPU puts the work of every HEVC decoder on that GPU into a few
 // HIP streams, a batch of pictures per launch (k_hevc.hip: launch_batch).
 //
-// Why not a stream per decoder (the first version, profiles/r06_hevc_*): a process gets GPU_MAX_HW_QUEUES = 4 hardware
-// queues; HIP folds all its streams onto them, and a queue is served in order - a picture of decoder A waits behind the
-// copies and the 5 ms intra wavefront of decoder B that happens to share its queue.  Measured with 32 decoders: the GPU
-// ran 1.8 kernels at a time on average, was idle 29 % of the time, and a picture took ~50 ms from submission to its end
-// for 1.5 - 6.5 ms of kernels (profiles/r06_hevc_kernel_trace_analysis.txt, tools/experiments/stream_concurrency).  The
-// engine uses three queues on purpose: copies, "light" batches (pictures with scattered intra blocks; fetched frames'
-// conversion and copy-out), "heavy" batches (intra pictures: a long, thin wavefront that should not hold anything up).
+// Why not a stream per decoder (the first version, profiles/r06_hevc_*): HIP folds a process's streams onto
+// GPU_MAX_HW_QUEUES hardware queues - 4 by default, 16 with this library loaded first (gpu_executor.cpp asks for them) -
+// and a queue is served in order: a picture of decoder A waits behind the copies and the 5 ms intra wavefront of the
+// decoder B that happens to share its queue.  Measured with 32 decoders on 16 queues: the GPU ran 1.8 kernels at a time on
+// average, was idle 29 % of the time, every kernel's longest run was an intra picture's 11 - 12 ms
+// (profiles/r06_hevc_kernel_trace_analysis.txt; tools/experiments/src/stream_concurrency.hip: 4 / 8 / 16 queues run 4 / 8 /
+// 15 spinning kernels at once, 32 queues 5.6).  The engine uses three queues on purpose: copies, "light" batches (pictures
+// with scattered intra blocks; fetched frames' conversion and copy-out), "heavy" batches (intra pictures: a long, thin
+// wavefront that should not hold anything up).
 //
 // Order: a decoder's jobs are launched in the order it submitted them.  Inside a stream that is stream order; when a
 // job's predecessor went to the other stream the job waits (in the engine's list, not in the stream: nothing queues up
