@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <map>
 
+#include <pthread.h>
+
 namespace hwang {
 
 hipError_t launch_yuv420_to_rgb24(const uint8_t* y, const uint8_t* u, const uint8_t* v, int y_stride, int c_stride, int width, int height,
@@ -96,6 +98,7 @@ std::string Engine::error() {
 }
 
 void Engine::run() {
+  pthread_setname_np(pthread_self(), "hw-hevc-engine");
   (void)hipSetDevice(device_);
   bool ok = hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking) == hipSuccess;
   for (hipStream_t& s : stream_) ok = ok && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;

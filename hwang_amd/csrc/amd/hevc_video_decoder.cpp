@@ -36,7 +36,12 @@ hipError_t launch_batch(const PicParams* const* pp, const Batch& batch, int n, h
 namespace {
 
 namespace gh = amd::hevc;
-constexpr int kSets = 3;
+// Staging sets per decoder: how many pictures the host parser may be ahead of the GPU.  An intra picture takes the GPU
+// 5 - 10 ms from submission to its end and the next pictures parse in ~3 ms each: with three sets the thread stalled on
+// the intra picture's set once per interval (1080p bench: 440 -> 460 frames/s with five).  A set is sized for the worst
+// picture (1080p: 20 MB pinned + 20 MB of HBM), so large pictures keep three.
+constexpr int kSets = 5;
+constexpr size_t kSmallSetBytes = size_t(32) << 20;
 constexpr int kOutputs = 6;  // fetched frames on their way (take): conversion, copy-out, for pageable caller memory a bounce buffer
 
 class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
@@ -285,7 +290,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     engine_->submit(client_, &job);
     (void)error;
     set.busy = true;
-    next_set_ = (next_set_ + 1) % kSets;
+    next_set_ = (next_set_ + 1) % num_sets_;
     return true;
   }
 
@@ -423,7 +428,9 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     off_.scaling = take(4064);
     off_.total = o;
     bool ok = true;
-    for (Set& set : sets_) {
+    num_sets_ = off_.total <= kSmallSetBytes ? kSets : 3;
+    for (int k = 0; k < num_sets_; ++k) {
+      Set& set = sets_[k];
       ok = ok && hipHostMalloc(reinterpret_cast<void**>(&set.host), off_.total, hipHostMallocDefault) == hipSuccess;
       ok = ok && hipMalloc(reinterpret_cast<void**>(&set.dev), off_.total) == hipSuccess;
       ok = ok && hipEventCreateWithFlags(&set.done, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
@@ -574,6 +581,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   std::atomic<int> buffered_{0};
   std::string sink_error_;
   Set sets_[kSets];
+  int num_sets_ = kSets;  // (of sets_: the ones with buffers)
   int next_set_ = 0;
   Offsets off_ = {};
   Caps cap_ = {};

@@ -397,7 +397,7 @@ class Cabac {
 };
 
 // ------------------------------------------------------------------------------------------------- pictures
-struct Motion {  // per 4x4 luma block, 16 bytes
+struct Motion {  // per prediction block, 16 bytes
   int16_t mv[2][2];
   int8_t ref[2];
   uint8_t flags;   // bit 0 / 1: list used
@@ -415,9 +415,19 @@ struct Pic {
   bool placeholder = false;  // skipped on purpose / made up for a missing reference
   int32_t ref_poc_tab[amd::hevc::kMaxSurfaces] = {0};  // POC / long-term state of DPB entry i when this picture referred to it
   uint8_t ref_lt_tab[amd::hevc::kMaxSurfaces] = {0};
-  std::vector<Motion> motion;
+  // Motion: one entry per prediction block ([0]: none - intra, or a placeholder picture), and per 4x4 luma block, in
+  // z-order, which entry covers it.  (A field of 16-byte motions per 4x4 block was 2 MB written per 1080p picture, 13 %
+  // of a P picture's parse; the index is a quarter of it, and two blocks of one prediction block compare equal by index.)
+  std::vector<Motion> pu_motion;
+  std::vector<uint32_t> pu_of;
 };
 
+// sig_coeff_flag's context (9.3.4.2.5) by scan position: the pattern of a 4x4 sub-block given which of its right / lower
+// neighbours are coded (sigCtx 0..2 before the per-size offsets), and Table 9-41's map for 4x4 blocks - per scan type.
+struct SigTables {
+  uint8_t pat[3][4][16];
+  uint8_t map4[3][16];
+};
 struct Scans {
   uint8_t t[4][3][64];
   uint8_t inv[4][3][64];  // position (x | y << log2) -> index in the scan
@@ -449,6 +459,23 @@ struct Scans {
 const Scans& scans() {
   static const Scans s;
   return s;
+}
+const SigTables& sig_tables() {
+  static const SigTables t = [] {
+    SigTables r;
+    const Scans& sc = scans();
+    for (int scan = 0; scan < 3; ++scan)
+      for (int k = 0; k < 16; ++k) {
+        const int xp = sc.t[2][scan][k] & 15, yp = sc.t[2][scan][k] >> 4;
+        r.pat[scan][0][k] = static_cast<uint8_t>(xp + yp == 0 ? 2 : xp + yp < 3 ? 1 : 0);
+        r.pat[scan][1][k] = static_cast<uint8_t>(yp == 0 ? 2 : yp == 1 ? 1 : 0);
+        r.pat[scan][2][k] = static_cast<uint8_t>(xp == 0 ? 2 : xp == 1 ? 1 : 0);
+        r.pat[scan][3][k] = 2;
+        r.map4[scan][k] = hevc_ctx_idx_map4[(yp << 2) + xp];
+      }
+    return r;
+  }();
+  return t;
 }
 
 enum { PART_2Nx2N = 0, PART_2NxN, PART_Nx2N, PART_NxN, PART_2NxnU, PART_2NxnD, PART_nLx2N, PART_nRx2N };
@@ -485,6 +512,7 @@ struct Parser::Impl {
   PicBuffers buf;
   PicDone done;
   int w4 = 0, h4 = 0;
+  int pic_w = 0, pic_h = 0, pic_lc = 0, pic_wctb = 0, pic_zmask = 0;  // the active SPS's, where every neighbour test wants them
   std::vector<uint8_t> m_pred, m_skip, m_depth, m_mode, m_flags, m_nz, m_edge;
   std::vector<int8_t> m_qp;
   std::vector<uint16_t> ctb_slice;   // slice index per coding tree block, 0xffff = not decoded
@@ -842,15 +870,18 @@ struct Parser::Impl {
       }
     return nullptr;
   }
-  // Motion fields are 24 bytes per 4x4 block (3 MB at 1080p): the buffers circulate between the pictures of the DPB
-  // instead of being allocated - and paged in - per picture.
-  std::vector<std::vector<Motion>> motion_pool;
+  // The motion index maps (0.5 MB at 1080p) and the motion lists circulate between the pictures of the DPB instead of
+  // being allocated - and paged in - per picture.
+  std::vector<std::vector<uint32_t>> motion_pool;
+  std::vector<std::vector<Motion>> pu_pool;
   void drop(Pic* p) {
     if (p->slot >= 0) sink->release_surface(p->slot);
     p->in_use = false;
     p->slot = -1;
-    if (p->motion.capacity()) motion_pool.push_back(std::move(p->motion));
-    p->motion = std::vector<Motion>();
+    if (p->pu_of.capacity()) motion_pool.push_back(std::move(p->pu_of));
+    if (p->pu_motion.capacity()) pu_pool.push_back(std::move(p->pu_motion));
+    p->pu_of = std::vector<uint32_t>();
+    p->pu_motion = std::vector<Motion>();
   }
   void release_unused() {
     for (Pic& p : dpb)
@@ -900,7 +931,8 @@ struct Parser::Impl {
     p->poc = poc_value;
     p->ref = state;
     p->placeholder = true;
-    p->motion.assign(S ? static_cast<size_t>(S->wctb) * S->hctb << (2 * (S->log2_ctb - 2)) : 0, Motion());
+    p->pu_of.assign(S ? static_cast<size_t>(S->wctb) * S->hctb << (2 * (S->log2_ctb - 2)) : 0, 0u);
+    p->pu_motion.assign(1, Motion());
     return p;
   }
 
@@ -1009,6 +1041,7 @@ struct Parser::Impl {
   // ----------------------------------------------------------------------------------- picture-level state
   bool open_picture() {
     w4 = S->width / 4;
+    pic_w = S->width; pic_h = S->height; pic_lc = S->log2_ctb; pic_wctb = S->wctb; pic_zmask = (1 << (S->log2_ctb - 2)) - 1;
     h4 = S->height / 4;
     const size_t n = static_cast<size_t>(w4) * h4;
     build_zorder();
@@ -1022,12 +1055,17 @@ struct Parser::Impl {
     slice_addr.clear();
     num_slices = 0;
     if (!motion_pool.empty()) {
-      cur->motion = std::move(motion_pool.back());
+      cur->pu_of = std::move(motion_pool.back());
       motion_pool.pop_back();
     }
+    if (!pu_pool.empty()) {
+      cur->pu_motion = std::move(pu_pool.back());
+      pu_pool.pop_back();
+    }
+    cur->pu_motion.assign(1, Motion());
     // (z-order addresses run over whole coding tree blocks, also where the picture ends inside one)
     const size_t msize = static_cast<size_t>(S->wctb) * S->hctb << (2 * (S->log2_ctb - 2));
-    if (cur->motion.size() != msize) cur->motion.assign(msize, Motion());  // (a recycled field holds its last picture: every unit overwrites its part)
+    if (cur->pu_of.size() != msize) cur->pu_of.assign(msize, 0u);  // (a recycled map holds its last picture: every unit overwrites its part)
     PicSetup setup;
     setup.width = S->width;
     setup.height = S->height;
@@ -1086,6 +1124,14 @@ struct Parser::Impl {
       EdgeInfo* erow = &buf.edges[static_cast<size_t>(y) * w4];
       const uint8_t* edge = &m_edge[static_cast<size_t>(y) * w4];
       for (int x = 0; x < w4; ++x) {
+        if (!(x & 7) && x + 8 <= w4) {  // eight blocks without an edge that may be filtered: most of a picture of large units
+          uint64_t eight;
+          std::memcpy(&eight, edge + x, 8);
+          if (!(eight & 0x3030303030303030ull)) {
+            x += 7;
+            continue;
+          }
+        }
         const uint8_t eg = edge[x];
         if (!(eg & 48)) continue;
         const int i = y * w4 + x;
@@ -1095,7 +1141,10 @@ struct Parser::Impl {
           const int j = dir ? i - w4 : i - 1;
           if (m_pred[i] == 2 || m_pred[j] == 2) bs[dir] = 2;
           else if ((eg & (dir ? 4 : 1)) && (m_nz[i] || m_nz[j])) bs[dir] = 1;
-          else bs[dir] = motion_bs(cur->motion[zorder[j]], cur->motion[zorder[i]]);
+          else {
+            const uint32_t pj = cur->pu_of[zorder[j]], pi = cur->pu_of[zorder[i]];
+            bs[dir] = pj == pi ? 0 : motion_bs(cur->pu_motion[pj], cur->pu_motion[pi]);
+          }
         }
         erow[x].bs = static_cast<uint8_t>(bs[0] | bs[1] << 2);
         any_bs |= erow[x].bs != 0;
@@ -1140,10 +1189,14 @@ struct Parser::Impl {
       }
   }
   bool zavail(int xc, int yc, int xn, int yn) const {
-    if (xn < 0 || yn < 0 || xn >= S->width || yn >= S->height) return false;
-    if (zaddr(xn, yn) > zaddr(xc, yc)) return false;
-    const uint16_t sn = ctb_slice[(yn >> S->log2_ctb) * S->wctb + (xn >> S->log2_ctb)];
-    const uint16_t sc = ctb_slice[(yc >> S->log2_ctb) * S->wctb + (xc >> S->log2_ctb)];
+    if (static_cast<unsigned>(xn) >= static_cast<unsigned>(pic_w) || static_cast<unsigned>(yn) >= static_cast<unsigned>(pic_h)) return false;
+    // by coding tree block first (raster order, and the only place a slice can begin), inside one by the small z-map
+    const int lc = pic_lc;
+    const int cn = (yn >> lc) * pic_wctb + (xn >> lc), cc = (yc >> lc) * pic_wctb + (xc >> lc);
+    if (cn == cc) return zmap[((xn >> 2) & pic_zmask) | ((yn >> 2) & pic_zmask) << 4] <= zmap[((xc >> 2) & pic_zmask) | ((yc >> 2) & pic_zmask) << 4];
+    if (cn > cc) return false;
+    const uint16_t sn = ctb_slice[cn], sc = ctb_slice[cc];
+    if (sn == sc) return sn != 0xffff;
     return sn != 0xffff && sc != 0xffff && slice_addr[sn] == slice_addr[sc];
   }
 
@@ -1168,7 +1221,7 @@ struct Parser::Impl {
     return ok && m_pred[(yn >> 2) * w4 + (xn >> 2)] == 1;
   }
   // (motion fields are laid out in decoding order - zorder[] - so that a unit's blocks are neighbours in memory)
-  const Motion& mot(int x, int y) const { return cur->motion[zorder[(y >> 2) * w4 + (x >> 2)]]; }
+  const Motion& mot(int x, int y) const { return cur->pu_motion[cur->pu_of[zorder[(y >> 2) * w4 + (x >> 2)]]]; }
 
   static void scale_mv(int16_t* mv, int td, int tb) {
     td = clip3(-128, 127, td);
@@ -1186,7 +1239,7 @@ struct Parser::Impl {
   bool temporal(int xp, int yp, int w, int h, int ref_idx, int X, int16_t* out) {
     if (!sh.tmvp) return false;
     const Pic* col = list[(sh.type == SL_B && !sh.col_from_l0) ? 1 : 0][sh.col_ref];
-    if (!col || col->motion.empty()) return false;
+    if (!col || col->pu_of.empty()) return false;
     const Pic* target = list[X][ref_idx];
     const bool cur_long = target->ref == 2;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -1199,7 +1252,7 @@ struct Parser::Impl {
         xc = xp + (w >> 1);
         yc = yp + (h >> 1);
       }
-      const Motion& c = col->motion[zorder[(((yc >> 4) << 4) >> 2) * w4 + (((xc >> 4) << 4) >> 2)]];
+      const Motion& c = col->pu_motion[col->pu_of[zorder[(((yc >> 4) << 4) >> 2) * w4 + (((xc >> 4) << 4) >> 2)]]];
       if (!c.flags) continue;
       int lc;
       if (!(c.flags & 1)) lc = 1;
@@ -1396,22 +1449,31 @@ struct Parser::Impl {
     return q < 30 ? q : q >= 43 ? q - 6 : hevc_qpc_table[q - 30];
   }
 
+  // n4 bytes of a row of a coding unit: 2, 4, 8 or 16 (a fixed size is a store or two, not a call)
+  static void fill_run(uint8_t* p, uint8_t v, int n4) {
+    switch (n4) {
+      case 2: std::memset(p, v, 2); break;
+      case 4: std::memset(p, v, 4); break;
+      case 8: std::memset(p, v, 8); break;
+      case 16: std::memset(p, v, 16); break;
+      default: std::memset(p, v, static_cast<size_t>(n4)); break;
+    }
+  }
   void mark_cu(const Cu& cu) {
     const int n = 1 << cu.log2;
     const uint8_t fl = static_cast<uint8_t>((cu.pcm ? 1 : 0) | (cu.bypass ? 2 : 0) | ((cu.bypass || (cu.pcm && S->pcm_lf_off)) ? 4 : 0));
-    for (int y = cu.y; y < cu.y + n; y += 4)
-      for (int x = cu.x; x < cu.x + n; x += 4) {
-        const int i = (y >> 2) * w4 + (x >> 2);
-        m_pred[i] = cu.intra ? 2 : 1;
-        m_skip[i] = cu.skip;
-        m_depth[i] = static_cast<uint8_t>(cu.depth);
-        m_flags[i] = fl;
-        m_qp[i] = static_cast<int8_t>(cu.qp);
-        if (cu.intra) {
-          m_mode[i] = 1;
-          cur->motion[zorder[i]].flags = 0;  // "intra" as far as later pictures' temporal candidates and this picture's strengths go
-        }
-      }
+    const int n4 = n >> 2;
+    for (int y = cu.y; y < cu.y + n; y += 4) {
+      const size_t i = static_cast<size_t>(y >> 2) * w4 + (cu.x >> 2);
+      fill_run(&m_pred[i], cu.intra ? 2 : 1, n4);
+      fill_run(&m_skip[i], cu.skip, n4);
+      fill_run(&m_depth[i], static_cast<uint8_t>(cu.depth), n4);
+      fill_run(&m_flags[i], fl, n4);
+      fill_run(reinterpret_cast<uint8_t*>(&m_qp[i]), static_cast<uint8_t>(static_cast<int8_t>(cu.qp)), n4);
+      if (cu.intra) fill_run(&m_mode[i], 1, n4);
+    }
+    // "intra" as far as later pictures' temporal candidates and this picture's strengths go (an aligned square: one run)
+    if (cu.intra) std::memset(&cur->pu_of[zorder[static_cast<size_t>(cu.y >> 2) * w4 + (cu.x >> 2)]], 0, sizeof(uint32_t) * n4 * n4);
   }
 
   void mpm(int x, int y, int cand[3]) const {  // 8.4.2
@@ -1480,6 +1542,7 @@ struct Parser::Impl {
       if (mode >= 22 && mode <= 30) scan = 1;
     }
     static const Scans& sc_tab = scans();
+    static const SigTables& sg_tab = sig_tables();
     const uint8_t* sbs = sc_tab.t[log2 - 2][scan];
     const uint8_t* pss = sc_tab.t[2][scan];
     // last significant position
@@ -1529,32 +1592,25 @@ struct Parser::Impl {
       uint16_t sig = 0;
       if (i == last_sb) sig |= 1u << last_pos;
       if (coded) {
-        const int prev = right | below << 1;
-        for (int k = (i == last_sb ? last_pos - 1 : 15); k >= 0; --k) {
-          if (k > 0 || !infer_dc) {
-            const int xp = pss[k] & 15, yp = pss[k] >> 4, xc = (xs << 2) + xp, yc = (ys << 2) + yp;
-            int sc;
-            if (log2 == 2) sc = hevc_ctx_idx_map4[(yc << 2) + xc];
-            else if (xc + yc == 0) sc = 0;
-            else {
-              if (prev == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
-              else if (prev == 1) sc = yp == 0 ? 2 : yp == 1 ? 1 : 0;
-              else if (prev == 2) sc = xp == 0 ? 2 : xp == 1 ? 1 : 0;
-              else sc = 2;
-              if (c == 0) {
-                if (xs || ys) sc += 3;
-                sc += log2 == 3 ? (scan == 0 ? 9 : 15) : 21;
-              } else {
-                sc += log2 == 3 ? 9 : 12;
-              }
-            }
-            if (bin(HC_SIG_COEFF + (c ? 27 + sc : sc))) {
-              sig |= 1u << k;
-              infer_dc = false;
-            }
-          } else {
-            sig |= 1;
+        const uint8_t* pat;
+        int base;
+        if (log2 == 2) {
+          pat = sg_tab.map4[scan];
+          base = HC_SIG_COEFF + (c ? 27 : 0);
+        } else {
+          pat = sg_tab.pat[scan][right | below << 1];
+          base = HC_SIG_COEFF + (c ? 27 + (log2 == 3 ? 9 : 12) : ((xs || ys) ? 3 : 0) + (log2 == 3 ? (scan == 0 ? 9 : 15) : 21));
+        }
+        const bool dc_block = log2 != 2 && !xs && !ys;  // the block's DC coefficient has a context of its own
+        int k = i == last_sb ? last_pos - 1 : 15;
+        for (; k > 0; --k)
+          if (bin(base + pat[k])) {
+            sig |= 1u << k;
+            infer_dc = false;
           }
+        if (k == 0) {
+          if (infer_dc) sig |= 1;
+          else if (bin(dc_block ? HC_SIG_COEFF + (c ? 27 : 0) : base + pat[0])) sig |= 1;
         }
       }
       if (!sig) continue;
@@ -1563,11 +1619,13 @@ struct Parser::Impl {
       first_sb = false;
       c1 = 1;
       uint16_t g1 = 0, g2 = 0;
-      int first_sig = 16, last_sig = -1, ng1 = 0, g1pos = -1;
-      for (int k = 15; k >= 0; --k) {
-        if (!((sig >> k) & 1)) continue;
-        if (ng1 < 8) {
-          ++ng1;
+      const int first_sig = __builtin_ctz(sig), last_sig = 31 - __builtin_clz(static_cast<uint32_t>(sig));
+      int g1pos = -1;
+      {
+        uint32_t m = sig;
+        for (int ng1 = 0; m && ng1 < 8; ++ng1) {  // (the first eight levels of a sub-block only)
+          const int k = 31 - __builtin_clz(m);
+          m &= ~(1u << k);
           if (bin(HC_GREATER1 + ctx_set * 4 + c1 + (c ? 16 : 0))) {
             g1 |= 1u << k;
             c1 = 0;
@@ -1576,8 +1634,6 @@ struct Parser::Impl {
             ++c1;
           }
         }
-        if (last_sig < 0) last_sig = k;
-        first_sig = k;
       }
       const bool hidden = !cu.bypass && P->sign_hiding && last_sig - first_sig > 3;
       if (g1pos >= 0 && bin(HC_GREATER2 + ctx_set + (c ? 4 : 0))) g2 |= 1u << g1pos;
@@ -1587,15 +1643,18 @@ struct Parser::Impl {
         if (hidden) coded &= static_cast<uint16_t>(~(1u << first_sig));
         const int ns = __builtin_popcount(coded);
         unsigned bits = cabac.bypass_bits(ns);
-        for (int k = 15, left = ns; left > 0; --k)
-          if ((coded >> k) & 1) {
-            --left;
-            if ((bits >> left) & 1) neg |= 1u << k;
-          }
+        int left = ns;
+        for (uint32_t m = coded; m;) {
+          const int k = 31 - __builtin_clz(m);
+          m &= ~(1u << k);
+          --left;
+          if ((bits >> left) & 1) neg |= 1u << k;
+        }
       }
       int nsig = 0, sum = 0, rice = 0;
-      for (int k = 15; k >= 0; --k) {
-        if (!((sig >> k) & 1)) continue;
+      for (uint32_t m = sig; m;) {
+        const int k = 31 - __builtin_clz(m);
+        m &= ~(1u << k);
         const int base = 1 + ((g1 >> k) & 1) + ((g2 >> k) & 1);
         int a = base;
         if (base == (nsig < 8 ? (k == g1pos ? 3 : 2) : 1)) {
@@ -1823,12 +1882,14 @@ struct Parser::Impl {
       }
     }
     {
-      // in aligned squares: each is one run of the z-ordered field
+      const uint32_t pu_index = static_cast<uint32_t>(cur->pu_motion.size());
+      cur->pu_motion.push_back(m);
+      // in aligned squares: each is one run of the z-ordered map
       const int sq = (x | y | w | h) & -(x | y | w | h), per = (sq >> 2) * (sq >> 2);
       for (int yy = y; yy < y + h; yy += sq)
         for (int xx = x; xx < x + w; xx += sq) {
-          Motion* run = &cur->motion[zorder[(yy >> 2) * w4 + (xx >> 2)]];
-          for (int k = 0; k < per; ++k) run[k] = m;
+          uint32_t* run = &cur->pu_of[zorder[(yy >> 2) * w4 + (xx >> 2)]];
+          for (int k = 0; k < per; ++k) run[k] = pu_index;
         }
     }
     // a prediction block edge inside the unit

@@ -81,3 +81,43 @@ def test_h264_after_hevc_on_one_decoder_object(hw, oracle, gpu, tmp_path):
         got = dec.retrieve_yuv([0, 2, 5])
         for k, r in enumerate([0, 2, 5]):
             assert np.array_equal(got[k], gold[r])
+
+
+def test_engine_batches_pictures_of_many_decoders_and_sizes(hw, oracle, gpu, tmp_path):
+    """The submission engine (hevc_engine.cpp) puts pictures of every HEVC decoder on the GPU into the same launches:
+    two clips of different sizes and coding tree block sizes, short GOPs (an intra picture every few frames: heavy and
+    light batches alternate for every decoder), 6 lanes each = 24 decoders, driven from two threads at once, three
+    rounds - every frame of every round bit-exact, I420 (copied out plane by plane) and RGB (converted, through the
+    page-locked bounce buffers into pageable arrays)."""
+    import threading
+    clips = []
+    for name, kw in (("a", dict(width=176, height=144, frames=60, gop=6, bframes=2, refs=2, ctb=16, sao=1)),
+                     ("b", dict(width=320, height=192, frames=48, gop=8, bframes=1, refs=2, ctb=64, sao=1, amp=1, sdh=1))):
+        path = str(tmp_path / (name + ".mp4"))
+        w, h = kw.pop("width"), kw.pop("height")
+        gold = make_hevc_clip(path, width=w, height=h, **kw)
+        idx = hw.index_video(path)
+        clips.append((path, idx, gold, w, h, hw.Decoder(path, video_index=idx, num_lanes=6)))
+    errors = []
+
+    def work(path, idx, gold, w, h, dec):
+        try:
+            for rnd in range(3):
+                got = dec.retrieve_yuv(list(range(idx.frames())))
+                for i in range(len(gold)):
+                    if not np.array_equal(got[i], gold[i]):
+                        raise AssertionError("%s round %d: I420 frame %d differs" % (path, rnd, i))
+                rows = list(range(rnd, idx.frames(), 5))
+                rgb = dec.retrieve(rows)
+                for k, r in enumerate(rows):
+                    if not np.array_equal(rgb[k], oracle.i420_to_rgb(gold[r], w, h)):
+                        raise AssertionError("%s round %d: RGB row %d differs" % (path, rnd, r))
+        except Exception as e:  # noqa: BLE001 - reported by the test's own thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=c) for c in clips]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]

@@ -22,7 +22,10 @@ def records_cpu(built):
                   os.path.join(ROOT, "hwang_amd", "csrc", "hevc", "hevc_tables.h")]
     if not os.path.exists(EXE) or any(os.path.getmtime(EXE) < os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(EXE), exist_ok=True)
-        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-o", EXE] + src)
+        # (pytest-xdist: several workers may find the binary stale at once - each builds its own and renames it into place)
+        tmp = "%s.%d" % (EXE, os.getpid())
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wno-sign-compare", "-o", tmp] + src)
+        os.replace(tmp, EXE)
     return EXE
 
 

@@ -1,0 +1,10 @@
+timeout 900 python -m pytest tests/test_gpu_hevc_kernels.py tests/test_gpu_hevc.py tests/test_gpu_ref_automata.py -x -q -m gpu > gpurun_out/r06_g33_hevc.txt 2>&1
+tail -3 gpurun_out/r06_g33_hevc.txt
+for l in 16 24 24; do
+timeout 600 python tools/hevc_bench.py --frames 36000 --steps 3 --lanes $l 2> gpurun_out/r06_hevc_j.err > gpurun_out/r06_hevc_j_$l.json
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r06_hevc_j_$l.json"))
+print("lanes $l:", d["value"], d["pictures_reconstructed_per_s"], d["host_parse_ms_per_picture"], d["lane_cpu_ms_per_picture"], d["staging_stall_ms_per_picture"], d["lane_wall_ms_per_picture"])
+PY
+done

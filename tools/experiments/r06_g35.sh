@@ -1,0 +1,8 @@
+for l in 16 24 24 32; do
+timeout 600 python tools/hevc_bench.py --frames 36000 --steps 3 --lanes $l 2> gpurun_out/r06_hevc_j.err > gpurun_out/r06_hevc_k_$l.json
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r06_hevc_k_$l.json"))
+print("lanes $l:", d["value"], d["seconds_per_call"], d["pictures_reconstructed_per_s"], d["host_parse_ms_per_picture"], d["lane_cpu_ms_per_picture"], d["staging_stall_ms_per_picture"], d["lane_wall_ms_per_picture"])
+PY
+done

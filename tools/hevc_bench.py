@@ -84,6 +84,20 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
         hw._capi.lib.hwang_retriever_host_counters(dec._get_retriever(), hc)
         del out
     best = min(times)
+    if os.environ.get("HEVC_BENCH_THREADS"):   # where the process's CPU time went, thread by thread (lane threads end with their call)
+        rows_ = []
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                comm = open("/proc/self/task/%s/comm" % tid).read().strip()
+                f = open("/proc/self/task/%s/stat" % tid).read().rsplit(")", 1)[1].split()
+                rows_.append((int(f[11]) + int(f[12]), comm, tid))
+            except OSError:
+                pass
+        tick = os.sysconf("SC_CLK_TCK")
+        for t, comm, tid in sorted(rows_, reverse=True)[:12]:
+            print("thread %-16s %7.2f s" % (comm, t / tick), file=sys.stderr)
+        ru = os.times()
+        print("process user %.2f s system %.2f s; calls took %s" % (ru.user, ru.system, times), file=sys.stderr)
     return {"what": "HEVC Main %dx%d, %d frames (%d unique GOPs of %d, CTB 64, 2 B pictures, SAO, AMP, sign hiding, QP %d), %.0f %% uniform-random "
                     "sample, one batched call, %d lanes of one GPU, RGB24 into host memory" % (width, height, n, gops, gop, qp, 100 * fraction, lanes),
             "rows": len(rows), "value": round(len(rows) / best, 2), "unit": "frames/s", "seconds_per_call": [round(t, 3) for t in times],
