@@ -89,7 +89,6 @@ bool Engine::drain(int client) {
 void Engine::settled(int client) {
   std::lock_guard<std::mutex> lk(mu_);
   clients_[client].last_stream = -1;
-  clients_[client].last_event = nullptr;
 }
 
 std::string Engine::error() {
@@ -114,7 +113,6 @@ void Engine::run() {
   };
   std::vector<EngineJob*> pictures[2], outputs;
   std::vector<int> touched;
-  uint64_t round = 0;
   // HWANG_HEVC_ENGINE_STATS=1: what the batches looked like, on stderr when the engine goes
   const bool stats = std::getenv("HWANG_HEVC_ENGINE_STATS") != nullptr;
   const bool copy_on_own_stream = !std::getenv("HWANG_HEVC_COPY_STREAM") || std::atoi(std::getenv("HWANG_HEVC_COPY_STREAM")) != 0;
@@ -123,13 +121,21 @@ void Engine::run() {
   std::unique_lock<std::mutex> lk(mu_);
   if (!ok) error_ = "the HEVC engine could not create its streams";
   for (;;) {
-    for (auto* fl : {&inflight_[0], &inflight_[1], &copy_inflight_})
-      while (!fl->empty() && hipEventQuery(fl->front()) != hipErrorNotReady) {
-        event_pool_.push_back(fl->front());
-        fl->pop_front();
+    // which batches are through (the engine's own lists: no lock - a lane that hands over a job must not wait for a
+    // HIP call; with the queries under the lock the lanes spent 0.5 ms per picture in submit())
+    lk.unlock();
+    for (int s = 0; s < 2; ++s)
+      while (!inflight_[s].empty() && hipEventQuery(inflight_[s].front()) != hipErrorNotReady) {
+        event_pool_.push_back(inflight_[s].front());
+        inflight_[s].pop_front();
+        ++completed_seq_[s];
       }
+    while (!copy_inflight_.empty() && hipEventQuery(copy_inflight_.front()) != hipErrorNotReady) {
+      event_pool_.push_back(copy_inflight_.front());
+      copy_inflight_.pop_front();
+    }
+    lk.lock();
     // ---- collect what may go now
-    ++round;
     pictures[0].clear();
     pictures[1].clear();
     outputs.clear();
@@ -152,12 +158,10 @@ void Engine::run() {
         // one picture of a decoder per batch, and none behind a fetched frame of it (a batch's pictures run before its
         // conversions, and the picture may be going into the very surface the frame is read from)
         if (j->kind == EngineJob::kPicture && (took_picture || took_output || pictures[s].size() >= static_cast<size_t>(kMaxBatch))) break;
-        if (c.last_stream >= 0 && c.last_stream != s) {
-          // its predecessor went to the other stream: not before that has finished (and never in the same round)
-          if (c.last_round == round || hipEventQuery(c.last_event) == hipErrorNotReady) {
-            waiting = true;
-            break;
-          }
+        if (c.last_stream >= 0 && c.last_stream != s && completed_seq_[c.last_stream] < c.last_seq) {
+          // its predecessor went to the other stream: not before that one's batch has finished
+          waiting = true;
+          break;
         }
         c.queue.pop_front();
         (j->kind == EngineJob::kPicture ? pictures[s] : outputs).push_back(j);
@@ -165,8 +169,7 @@ void Engine::run() {
         took_output = took_output || j->kind != EngineJob::kPicture;
         took = true;
         c.last_stream = s;
-        c.last_event = j->done;
-        c.last_round = round;
+        c.last_seq = launched_seq_[s] + 1;  // (the batch this round makes for the stream)
       }
       if (took) {
         c.taking = true;  // (drain: popped, not yet in a stream)
@@ -252,8 +255,13 @@ void Engine::run() {
     }
     lk.lock();
     if (copies_done) copy_inflight_.push_back(copies_done);
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < 2; ++s) {
+      const bool took = !pictures[s].empty() || (s == kLight && !outputs.empty());
+      if (!took) continue;
+      ++launched_seq_[s];
       if (batch_event[s]) inflight_[s].push_back(batch_event[s]);
+      else ++completed_seq_[s];  // (the launch failed: nothing will ever fire; error_ ends the engine's work)
+    }
     if (e != hipSuccess && error_.empty()) error_ = std::string("the HEVC engine failed to launch a batch: ") + hipGetErrorString(e);
     for (auto* list : {&pictures[0], &pictures[1], &outputs})
       for (EngineJob* j : *list) {

@@ -13,7 +13,7 @@
 //
 // Order: a decoder's jobs are launched in the order it submitted them.  Inside a stream that is stream order; when a
 // job's predecessor went to the other stream the job waits (in the engine's list, not in the stream: nothing queues up
-// behind it) until the predecessor's event has fired.  Batches are formed from whatever is eligible whenever a stream has
+// behind it) until the predecessor's batch is through.  Batches are formed from whatever is eligible whenever a stream has
 // fewer than two batches in flight - while they run, the next one fills up.
 #pragma once
 
@@ -45,7 +45,7 @@ struct EngineJob {
     void* dst;
     const void* src;
     size_t bytes;
-  } copy[2] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}};  // host -> device, before the kernels
+  } copy[3] = {{nullptr, nullptr, 0}, {nullptr, nullptr, 0}, {nullptr, nullptr, 0}};  // host -> device, before the kernels
   int16_t* clear_resid = nullptr;     // residual planes to zero first (after a faulted picture)
   size_t clear_resid_bytes = 0;
   // kRgb / kYuv: a fetched frame.  y/u/v: the cropped picture in its surface; `out`: device, page-locked or bounce memory
@@ -85,8 +85,7 @@ class Engine {
     bool used = false;
     std::deque<EngineJob*> queue;
     int last_stream = -1;                 // where its most recent job went
-    hipEvent_t last_event = nullptr;      // ... and that job's event
-    uint64_t last_round = 0;              // ... and the round of collecting it was taken in
+    uint64_t last_seq = 0;                // ... and which batch of that stream it was in
     bool taking = false;                  // jobs of it are between the list and a stream
   };
   enum { kLight = 0, kHeavy = 1 };
@@ -98,7 +97,8 @@ class Engine {
   std::string error_;
   hipStream_t copy_stream_ = nullptr, stream_[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> event_pool_;
-  std::deque<hipEvent_t> inflight_[2];    // a batch event each
+  std::deque<hipEvent_t> inflight_[2];    // a batch event each (the engine thread's own)
+  uint64_t launched_seq_[2] = {0, 0}, completed_seq_[2] = {0, 0};  // batches put into / through each stream
   std::deque<hipEvent_t> copy_inflight_;  // the copy stream's events, kept until they have fired
   std::thread thread_;
 };

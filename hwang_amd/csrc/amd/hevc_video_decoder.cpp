@@ -20,9 +20,11 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 namespace hwang {
@@ -44,11 +46,26 @@ constexpr int kSets = 5;
 constexpr size_t kSmallSetBytes = size_t(32) << 20;
 constexpr int kOutputs = 6;  // fetched frames on their way (take): conversion, copy-out, for pageable caller memory a bounce buffer
 
+// Waits for an event without holding a CPU: hipEventSynchronize spins for the whole wait (measured: the lanes' CPU time
+// per picture was parse + stall to the millisecond, with hipEventBlockingSync or without), and the GPU box gives the
+// process 16 CPUs that the parsers need.  A look every 100 us costs a picture's set at most that much latency.
+hipError_t sleepy_event_wait(hipEvent_t e) {
+  for (;;) {
+    const hipError_t q = hipEventQuery(e);
+    if (q != hipErrorNotReady) return q;
+    std::this_thread::sleep_for(std::chrono::microseconds(100));
+  }
+}
+
 class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
  public:
   explicit HEVCVideoDecoder(int device) : device_(device), engine_(gh::Engine::for_device(device)), client_(engine_->add_client()) {}
   ~HEVCVideoDecoder() override {
     (void)hipSetDevice(device_);
+    if (std::getenv("HWANG_HEVC_ENGINE_STATS") && parser_)
+      std::fprintf(stderr, "[hevc decoder %p] pictures %lld: parse %.1f ms, waiting for a set %.1f ms, submitting %.1f ms (%.1f ms of it handing the job to the engine), copying frames out of bounce buffers %.1f ms\n",
+                   static_cast<void*>(this), (long long)(folded_decoded_ + parser_->pictures_decoded()), counters_.entropy_ns / 1e6, counters_.stall_ns / 1e6,
+                   submit_ns_ / 1e6, engine_submit_ns_ / 1e6, copy_out_ns_ / 1e6);
     parser_.reset();
     (void)quiesce();
     free_all();
@@ -164,8 +181,8 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
         *error = engine_->error();
         return false;
       }
-      if (hipEventSynchronize(set.done) != hipSuccess) {
-        *error = "hipEventSynchronize failed";
+      if (sleepy_event_wait(set.done) != hipSuccess) {
+        *error = "waiting for a staging set's event failed";
         return false;
       }
       counters_.stall_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -247,20 +264,22 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     const size_t ctbs = static_cast<size_t>(wctb_) * hctb_;
     // mostly intra (an I picture, a scene cut): the row wavefront; scattered intra blocks: the dataflow kernel
     pp.intra_rows = d.num_intra[0] * 64 > static_cast<size_t>(cw_ / 4) * (ch_ / 4) * 3 ? 1 : 0;
-    // part B packed downwards in place (every list moves to where the one before it ends): one copy instead of ten
-    size_t packed = off_.part_b;
+    // Three copies: part A with the transform block list behind it (where the parser wrote them), the level stream
+    // (where it is), and the small lists - prediction blocks in place, the ones after them moved down to follow.  (One
+    // copy of everything packed downwards moved a megabyte a picture in host memory: 0.46 ms of the lane's CPU.)
+    pp.res = reinterpret_cast<const gh::ResTu*>(dv + off_.res);
+    pp.coefs = reinterpret_cast<const uint32_t*>(dv + off_.coefs);
+    size_t packed = off_.pus;
     auto pack = [&](size_t from, size_t bytes) {
       const size_t at = packed;
       if (bytes && from != at) std::memmove(set.host + at, set.host + from, bytes);
       packed = (at + bytes + 15) & ~static_cast<size_t>(15);
       return at;
     };
-    pp.res = reinterpret_cast<const gh::ResTu*>(dv + pack(off_.res, d.num_res * sizeof(gh::ResTu)));
-    pp.coefs = reinterpret_cast<const uint32_t*>(dv + pack(off_.coefs, d.num_coefs * sizeof(uint32_t)));
     pp.pus = reinterpret_cast<const gh::InterPu*>(dv + pack(off_.pus, d.num_pus * sizeof(gh::InterPu)));
     pp.weights = reinterpret_cast<const gh::WeightEntry*>(dv + pack(off_.weights, d.num_weights * sizeof(gh::WeightEntry)));
     for (int c = 0; c < 3; ++c) pp.intra[c] = reinterpret_cast<const gh::IntraTu*>(dv + pack(off_.intra[c], d.num_intra[c] * sizeof(gh::IntraTu)));
-    for (int c = 0; c < 3; ++c) pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dv + pack(off_.first[c], pp.intra_rows ? (ctbs + 1) * sizeof(uint32_t) : 0));
+    for (int c = 0; c < 3; ++c) pp.intra_ctb_first[c] = reinterpret_cast<const uint32_t*>(dv + pack(off_.first[c], d.num_intra[c] ? (ctbs + 1) * sizeof(uint32_t) : 0));
     pp.scaling = d.scaling ? dv + pack(off_.scaling, 4064) : nullptr;
     pp.edges = reinterpret_cast<const gh::EdgeInfo*>(dv + off_.edges);
     pp.sao = reinterpret_cast<const gh::SaoCtb*>(dv + off_.sao);
@@ -278,16 +297,21 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     gh::EngineJob& job = set.job;
     job.kind = gh::EngineJob::kPicture;
     job.pp_dev = reinterpret_cast<const gh::PicParams*>(dv + off_.params);
-    job.copy[0] = {dv, set.host, packed};  // part A and the packed part B are one piece
-    job.copy[1] = {nullptr, nullptr, 0};
-    bytes_uploaded_ += static_cast<int64_t>(packed);
+    job.copy[0] = {dv, set.host, off_.res + d.num_res * sizeof(gh::ResTu)};
+    job.copy[1] = {dv + off_.coefs, set.host + off_.coefs, d.num_coefs * sizeof(uint32_t)};
+    job.copy[2] = {dv + off_.pus, set.host + off_.pus, packed - off_.pus};
+    bytes_uploaded_ += static_cast<int64_t>(job.copy[0].bytes + job.copy[1].bytes + job.copy[2].bytes);
     // the residual planes are zero between pictures (the kernels that read a residual clear it); only a picture that
     // did not run to its end leaves them in doubt
     job.clear_resid = resid_dirty_ ? resid_ : nullptr;
     job.clear_resid_bytes = resid_bytes_;
     resid_dirty_ = false;
     job.done = set.done;
-    engine_->submit(client_, &job);
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      engine_->submit(client_, &job);
+      engine_submit_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
     (void)error;
     set.busy = true;
     next_set_ = (next_set_ + 1) % num_sets_;
@@ -537,13 +561,17 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       return Result(false, "AMDVideoDecoder::get_frame (HEVC): " + engine_->error());
     }
     if (wait) {
-      HWANG_HIP_RETURN(hipEventSynchronize(o.job.done));
+      HWANG_HIP_RETURN(sleepy_event_wait(o.job.done));
     } else {
       const hipError_t q = hipEventQuery(o.job.done);
       if (q == hipErrorNotReady) return Result();
       HWANG_HIP_RETURN(q);
     }
-    if (o.dst) std::memcpy(o.dst, o.host, o.bytes);
+    if (o.dst) {
+      const auto t0 = std::chrono::steady_clock::now();
+      std::memcpy(o.dst, o.host, o.bytes);
+      copy_out_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
     o.dst = nullptr;
     o.active = false;
     return Result();
@@ -558,7 +586,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     for (Set& set : sets_)
       if (set.busy) {
         (void)engine_->wait_launched(&set.job);
-        if (set.done) (void)hipEventSynchronize(set.done);
+        if (set.done) (void)sleepy_event_wait(set.done);
         set.busy = false;
       }
     Result r = deliver_outputs(true);
@@ -595,7 +623,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   uint32_t* fault_host_ = nullptr;
   uint32_t* fault_dev_ = nullptr;
   BackendCounters counters_;
-  int64_t submit_ns_ = 0;
+  int64_t submit_ns_ = 0, copy_out_ns_ = 0, engine_submit_ns_ = 0;
   int64_t bytes_uploaded_ = 0, folded_decoded_ = 0, folded_skipped_ = 0, decoded_base_ = 0, skipped_base_ = 0;
 };
 
@@ -692,7 +720,7 @@ extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, cha
   pp.progress = pp.intra_ticket ? pp.intra_ticket + 4 : nullptr;
   for (int c = 0; c < 3 && pp.intra_ticket; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(pp.intra_ticket + 4 + 3 * hctb) + static_cast<size_t>(c) * w4h4;
   pp.intra_rows = t->intra_rows;
-  if (t->intra_rows) {  // the row kernel's table: the lists must be grouped by coding tree block, in raster order
+  {  // the intra kernels' table: the lists must be grouped by coding tree block, in raster order
     for (int c = 0; c < 3 && ok; ++c) {
       std::vector<uint32_t> first(ctbs + 1, 0);
       const gh::IntraTu* it = static_cast<const gh::IntraTu*>(t->intra[c]);
@@ -701,7 +729,7 @@ extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, cha
         const long ctb = static_cast<long>(((it[k].y << (c ? 1 : 0)) >> t->log2_ctb) * wctb + ((it[k].x << (c ? 1 : 0)) >> t->log2_ctb));
         if (ctb < prev) {
           cleanup();
-          return fail("intra_rows: the records are not grouped by coding tree block");
+          return fail("the intra records are not grouped by coding tree block");
         }
         prev = ctb;
         ++first[static_cast<size_t>(ctb) + 1];

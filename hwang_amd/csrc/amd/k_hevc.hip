@@ -373,12 +373,14 @@ __device__ void intra_block(const IntraTu& tu, int x0, int y0, int c, uint8_t* o
 constexpr uint32_t kIntraSpins = 1u << 22;  // bounded wait for a neighbour (then: fault, the host fails the picture)
 
 // Intra prediction, variant 1: a dataflow wavefront for pictures whose intra blocks are scattered (P and B pictures).
-// Workgroups of one wavefront take the records of a colour plane's list by ticket, in decoding order; a block waits
-// for exactly the neighbouring 4x4 units it reads that an earlier record of this picture writes (IntraTu::wait_*: the
-// host knows which neighbours are intra) - each has a "done" byte - and marks its own units when its samples are out.
-// A ticket holder only ever waits for lower tickets, which are held by running wavefronts: no deadlock whatever the
-// grid.  NOT for intra pictures: there nearly every block waits for its predecessor, and a thousand wavefronts
-// spinning on their neighbours starve the few that can run (measured: 415 ms per picture,
+// Workgroups of one wavefront take the coding tree blocks of a colour plane by ticket, in raster order, and work through a
+// block's records in decoding order; a transform block waits for exactly the neighbouring 4x4 units it reads that an
+// earlier record of this picture writes in ANOTHER coding tree block (IntraTu::wait_*: the host knows which neighbours
+// are intra) - each has a "done" byte - and marks its own units when its samples are out.  A ticket holder only ever
+// waits for lower tickets (left, above, above-right in raster order), which are held by running wavefronts: no deadlock
+// whatever the grid.  (A ticket per RECORD, the first version, handed every dependent pair of neighbours from one
+// wavefront to another through a flag: most of the kernel's time was that.)  NOT for intra pictures: there the
+// wavefronts would spin on their neighbours (415 ms per picture with a ticket per record,
 // profiles/r06_hevc_dataflow_everywhere_kernel_stats.csv); those take variant 2.
 __global__ __launch_bounds__(64) void k_hevc_intra_flow(const Batch batch) {
   const PicParams& pp = *batch.pic[blockIdx.z];
@@ -386,47 +388,60 @@ __global__ __launch_bounds__(64) void k_hevc_intra_flow(const Batch batch) {
   const int pitch = c ? pp.c_pitch : pp.y_pitch, ushift = c ? 1 : 2, sub = c ? 1 : 0, w4 = pp.width >> 2;
   uint8_t* plane = plane_of(pp.recon, c);
   const IntraTu* tus = pp.intra[c];
-  const uint32_t count = static_cast<uint32_t>(pp.num_intra[c]);
+  const uint32_t* first = pp.intra_ctb_first[c];
+  const uint32_t ctbs = static_cast<uint32_t>(pp.width_ctb * pp.height_ctb);
   uint32_t* ticket = pp.intra_ticket + c;
   uint8_t* done = pp.intra_done[c];
+  const int n4 = 1 << (pp.log2_ctb - 2);  // a coding tree block in 4x4 luma units
   __shared__ int line[132], filt_line[132], refbuf[3 * 32 + 8], angtab[50];
   __shared__ uint32_t s_ticket;
   load_angles(angtab, lane);
   for (;;) {
     if (lane == 0) s_ticket = atomicAdd(ticket, 1u);
     __syncthreads();
-    const uint32_t ti = s_ticket;
+    const uint32_t ctb = s_ticket;
     __syncthreads();
-    if (ti >= count) return;
-    const IntraTu tu = tus[ti];
-    const int n = 1 << tu.log2, ux = (tu.x << sub) >> 2, uy = (tu.y << sub) >> 2, nu = (2 * n) >> ushift;
-    if (tu.mode != kIntraPcm && (tu.wait_left | tu.wait_top | (tu.flags & INTRA_WAIT_CORNER))) {
-      // lane k < nu: left unit k (from the top); nu <= k < 2 nu: top unit k - nu; k = 2 nu: the corner
-      const uint8_t* flag = nullptr;
-      if (lane < nu) {
-        if ((tu.wait_left >> lane) & 1) flag = done + (uy + lane) * w4 + ux - 1;
-      } else if (lane < 2 * nu) {
-        if ((tu.wait_top >> (lane - nu)) & 1) flag = done + (uy - 1) * w4 + ux + lane - nu;
-      } else if (lane == 2 * nu && (tu.flags & INTRA_WAIT_CORNER)) {
-        flag = done + (uy - 1) * w4 + ux - 1;
-      }
-      uint32_t spins = 0;
-      for (;;) {
-        const bool ok = !flag || __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0;
-        if (__all(ok)) break;
-        for (int k = 0; k < batch.spin_sleep; ++k) __builtin_amdgcn_s_sleep(8);
-        if (++spins > kIntraSpins) {
-          if (lane == 0) atomicExch(pp.fault, 1u);
-          return;
+    if (ctb >= ctbs) return;
+    const uint32_t t0 = first[ctb], t1 = first[ctb + 1];
+    if (t0 == t1) continue;
+    const int bx = static_cast<int>(ctb % static_cast<uint32_t>(pp.width_ctb)) * n4, by = static_cast<int>(ctb / static_cast<uint32_t>(pp.width_ctb)) * n4;
+    for (uint32_t ti = t0; ti < t1; ++ti) {
+      const IntraTu tu = tus[ti];
+      const int n = 1 << tu.log2, ux = (tu.x << sub) >> 2, uy = (tu.y << sub) >> 2, nu = (2 * n) >> ushift;
+      if (tu.mode != kIntraPcm && (tu.wait_left | tu.wait_top | (tu.flags & INTRA_WAIT_CORNER))) {
+        // lane k < nu: left unit k (from the top); nu <= k < 2 nu: top unit k - nu; k = 2 nu: the corner - unless the
+        // unit lies in this coding tree block: then this wavefront wrote it, some blocks ago
+        const uint8_t* flag = nullptr;
+        int fx = -1, fy = -1;
+        if (lane < nu) {
+          if ((tu.wait_left >> lane) & 1) { fx = ux - 1; fy = uy + lane; }
+        } else if (lane < 2 * nu) {
+          if ((tu.wait_top >> (lane - nu)) & 1) { fx = ux + lane - nu; fy = uy - 1; }
+        } else if (lane == 2 * nu && (tu.flags & INTRA_WAIT_CORNER)) {
+          fx = ux - 1;
+          fy = uy - 1;
+        }
+        if (fx >= 0 && !(fx >= bx && fx < bx + n4 && fy >= by && fy < by + n4)) flag = done + fy * w4 + fx;
+        if (__any(flag != nullptr)) {
+          uint32_t spins = 0;
+          for (;;) {
+            const bool ok = !flag || __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            if (__all(ok)) break;
+            for (int k = 0; k < batch.spin_sleep; ++k) __builtin_amdgcn_s_sleep(8);
+            if (++spins > kIntraSpins) {
+              if (lane == 0) atomicExch(pp.fault, 1u);
+              return;
+            }
+          }
         }
       }
+      intra_block<false>(tu, tu.x, tu.y, c, plane, pitch, pp.resid[c], pitch, line, filt_line, refbuf, angtab, lane);
+      // the block's samples are out: mark the units it covers (a release after the fence; waiters acquire)
+      __threadfence();
+      __syncthreads();
+      const int cnt = n >> ushift;
+      if (lane < cnt * cnt) __hip_atomic_store(done + (uy + lane / cnt) * w4 + ux + lane % cnt, static_cast<uint8_t>(1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    intra_block<false>(tu, tu.x, tu.y, c, plane, pitch, pp.resid[c], pitch, line, filt_line, refbuf, angtab, lane);
-    // the block's samples are out: mark the units it covers (a release after the fence; waiters acquire)
-    __threadfence();
-    __syncthreads();
-    const int cnt = n >> ushift;
-    if (lane < cnt * cnt) __hip_atomic_store(done + (uy + lane / cnt) * w4 + ux + lane % cnt, static_cast<uint8_t>(1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -697,8 +712,8 @@ hipError_t launch_batch(const PicParams* const* pp, const Batch& batch, int n, h
   if (n > kMaxBatch) return hipErrorInvalidValue;
   int res = 0, pus = 0, units = 0, width = 0, height = 0, clear = 0;
   bool deblock = false, sao = false;
-  static const int flow_cap = std::getenv("HWANG_HEVC_FLOW_WORKERS") ? std::atoi(std::getenv("HWANG_HEVC_FLOW_WORKERS")) : 12;
-  static const int spin = std::getenv("HWANG_HEVC_SPIN_SLEEP") ? std::atoi(std::getenv("HWANG_HEVC_SPIN_SLEEP")) : 32;
+  static const int flow_cap = std::getenv("HWANG_HEVC_FLOW_WORKERS") ? std::atoi(std::getenv("HWANG_HEVC_FLOW_WORKERS")) : 32;
+  static const int spin = std::getenv("HWANG_HEVC_SPIN_SLEEP") ? std::atoi(std::getenv("HWANG_HEVC_SPIN_SLEEP")) : 4;
   Batch rows, flow;
   static const int rows_spin = std::getenv("HWANG_HEVC_ROWS_SLEEP") ? std::atoi(std::getenv("HWANG_HEVC_ROWS_SLEEP")) : 16;
   flow.spin_sleep = spin;
@@ -724,8 +739,8 @@ hipError_t launch_batch(const PicParams* const* pp, const Batch& batch, int n, h
         rows.pic[n_rows++] = batch.pic[i];
         rows_ctb = p.height_ctb > rows_ctb ? p.height_ctb : rows_ctb;
       } else {
-        // as many wavefronts as a sparse picture has independent blocks in flight; each takes records until none are left
-        const int most = p.num_intra[0] > p.num_intra[1] ? p.num_intra[0] : p.num_intra[1];
+        // as many wavefronts as a sparse picture has independent coding tree blocks in flight; each takes blocks until none are left
+        const int most = p.width_ctb * p.height_ctb;
         flow.pic[n_flow++] = batch.pic[i];
         flow_most = most > flow_most ? most : flow_most;
       }

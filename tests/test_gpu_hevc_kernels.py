@@ -64,7 +64,7 @@ def run_picture(hw, w, h, log2_ctb=4, recon=None, refs=(), res=None, coefs=None,
     for c in range(3):
         it = arr(intra[c], ITU)
         n = 0 if intra[c] is None else len(it)
-        if n and intra_rows:       # the row kernel wants the list grouped by coding tree block, in raster order
+        if n:       # both intra kernels want the list grouped by coding tree block, in raster order
             sub = 1 if c else 0
             ctb_of = ((it["y"].astype(int) << sub) >> log2_ctb) * wctb + ((it["x"].astype(int) << sub) >> log2_ctb)
             it = arr(it[np.argsort(ctb_of, kind="stable")], ITU)

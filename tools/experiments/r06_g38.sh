@@ -1,0 +1,10 @@
+timeout 900 python -m pytest tests/test_gpu_hevc.py tests/test_gpu_hevc_kernels.py -x -q -m gpu 2>&1 | tail -3
+for cfg in "12 32" "32 32" "64 8" "64 1" "128 4" "256 1" "32 4"; do
+set -- $cfg
+HWANG_HEVC_FLOW_WORKERS=$1 HWANG_HEVC_SPIN_SLEEP=$2 timeout 600 python tools/hevc_bench.py --frames 36000 --steps 3 --lanes 24 2> gpurun_out/r06_hevc_i.err > gpurun_out/r06_hevc_i.json
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r06_hevc_i.json"))
+print("workers $1 sleep $2:", d["value"], d["pictures_reconstructed_per_s"], d["host_parse_ms_per_picture"], d["lane_cpu_ms_per_picture"], d["staging_stall_ms_per_picture"])
+PY
+done
