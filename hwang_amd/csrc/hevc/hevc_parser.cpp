@@ -48,6 +48,10 @@ class Bits {
   unsigned ue() {
     int z = 0;
     while (z < 32 && !u(1) && !bad_) ++z;
+    if (z >= 32) {  // (no syntax element is that long: 9.2 allows 32 bits in all)
+      bad_ = true;
+      return 0;
+    }
     return z ? ((1u << z) - 1 + u(z)) : 0;
   }
   int se() {
@@ -307,6 +311,7 @@ class Cabac {
   void start(const uint8_t* p, size_t n, size_t at) {
     p_ = p;
     n_ = n;
+    broken_ = false;
     restart(at);
   }
   void restart(size_t at) {
@@ -315,13 +320,21 @@ class Cabac {
     bits_ = -9;
     range_ = 510;
     refill();
+    // 9.3.2.5: ivlOffset is never 510 or 511 in a conforming stream; in a damaged one it may be, and every step of the
+    // engine relies on offset < range (a bypass read would return more than its n bits).  Forced inside; the slice ends
+    // in an error through its end-of-slice checks.
+    const uint64_t limit = static_cast<uint64_t>(range_) << bits_;
+    if (value_ >= limit) {
+      value_ = limit - 1;
+      broken_ = true;
+    }
   }
   // bytes consumed once the engine has terminated: the stop bit is the last bit the nine-bit window took
   size_t aligned_end() const {
     const size_t consumed = pos_ * 8 - static_cast<size_t>(bits_);
     return (consumed + 7) >> 3;
   }
-  bool overrun() const { return pos_ > n_ + 8; }
+  bool overrun() const { return broken_ || pos_ > n_ + 8; }
 
   int decision(uint8_t* ctx) {
     int state = *ctx >> 1, mps = *ctx & 1;
@@ -394,6 +407,7 @@ class Cabac {
   uint64_t value_ = 0;
   int bits_ = 0;
   uint32_t range_ = 510;
+  bool broken_ = false;  // the engine was started on bits that are not an arithmetic codeword
 };
 
 // ------------------------------------------------------------------------------------------------- pictures
@@ -512,6 +526,7 @@ struct Parser::Impl {
   PicBuffers buf;
   PicDone done;
   int w4 = 0, h4 = 0;
+  int next_ctb = 0;  // the picture's coding tree blocks before this address are decoded
   int pic_w = 0, pic_h = 0, pic_lc = 0, pic_wctb = 0, pic_zmask = 0;  // the active SPS's, where every neighbour test wants them
   std::vector<uint8_t> m_pred, m_skip, m_depth, m_mode, m_flags, m_nz, m_edge;
   std::vector<int8_t> m_qp;
@@ -1054,6 +1069,7 @@ struct Parser::Impl {
     ctb_slice.assign(static_cast<size_t>(S->wctb) * S->hctb, 0xffff);
     slice_addr.clear();
     num_slices = 0;
+    next_ctb = 0;
     if (!motion_pool.empty()) {
       cur->pu_of = std::move(motion_pool.back());
       motion_pool.pop_back();
@@ -1512,7 +1528,7 @@ struct Parser::Impl {
     const int sub = c ? 1 : 0, unit = c ? 2 : 4, n = 1 << log2;
     const int xl = x << sub, yl = y << sub;
     auto ok = [&](int xn, int yn) {
-      if (!zavail(xl, yl, xn << sub, yn << sub)) return false;
+      if (!zavail(xl, yl, xn * (1 << sub), yn * (1 << sub))) return false;  // (xn, yn may be -1)
       return !P->cip || m_pred[((yn << sub) >> 2) * w4 + ((xn << sub) >> 2)] == 2;
     };
     // a neighbour that an intra block of this picture writes is waited for; what inter prediction wrote is final
@@ -2141,6 +2157,7 @@ struct Parser::Impl {
         last_qp = sh.qp;
       }
       ctb_slice[addr] = static_cast<uint16_t>(slice_idx);
+      next_ctb = addr + 1;
       if (sh.sao_y || sh.sao_c) sao_syntax(rx, ry);
       if (!coding_quadtree(rx << S->log2_ctb, ry << S->log2_ctb, S->log2_ctb, 0)) return false;
       if (P->wpp && rx == (S->wctb > 1 ? 1 : 0)) std::memcpy(ctx_saved, ctx, sizeof(ctx));
@@ -2208,6 +2225,9 @@ struct Parser::Impl {
     }
     if (!build_lists()) return false;
     if (num_slices >= amd::hevc::kMaxSlices) return fail("more than %d slices in a picture", amd::hevc::kMaxSlices);
+    // 7.4.7.1: slice segment addresses increase within a picture.  The kernels depend on it too: the intra records are
+    // listed by coding tree block in the order the blocks were decoded, which must be raster order.
+    if (sh.address < next_ctb) return fail("slice segment address %d, but the picture's blocks up to %d are decoded already", sh.address, next_ctb);
     slice_idx = num_slices++;
     slice_addr.push_back(static_cast<uint32_t>(sh.address));
     SliceLoop& sl = buf.slices[slice_idx];
@@ -2305,6 +2325,8 @@ bool Parser::decode(const uint8_t* sample, size_t size) {
     }
   }
   d.skipping = false;
+  // (the slice data readers report running past the end of their NAL unit by returning false, nothing else)
+  if (!ok && d.error.empty()) d.fail("the slice data is damaged: the arithmetic decoder ran past the end of its NAL unit");
   return ok;
 }
 

@@ -2,6 +2,8 @@
 reconstruction, which the CPU oracle reproduces (tests/test_hevc_corpus.py).  The bar is bit-exact I420 and bit-exact
 RGB against the oracle's statement of the colour conversion.  HEVC parity with FFmpeg is unpinned (no HEVC decoder or
 foreign stream exists on either machine): what these tests pin is the HIP path against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -121,3 +123,43 @@ def test_engine_batches_pictures_of_many_decoders_and_sizes(hw, oracle, gpu, tmp
     for t in threads:
         t.join()
     assert not errors, errors[0]
+
+
+@pytest.mark.parametrize("name", ["ibp_amp_wp_ctb32", "everything", "i_slices_cip_nolf"])
+def test_corrupt_streams_never_hang_the_gpu(hw, oracle, gpu, tmp_path, name):
+    """Bit flips in HEVC samples reach the kernels as absurd vectors, levels and modes (or are refused by the parser -
+    tests/test_hevc_fuzz.py checks on the CPU that no record points outside the picture).  Either is fine; a hung or
+    faulted GPU is not: every request returns, and the engine is still healthy afterwards - the pristine clip decodes
+    bit-exactly through the same process."""
+    kw = dict(dict(HEVC_MATRIX)[name])
+    w, h = kw.pop("width", 128), kw.pop("height", 96)
+    path = str(tmp_path / "fz.mp4")
+    gold = make_hevc_clip(path, width=w, height=h, **kw)
+    idx = hw.index_video(path)
+    nf = idx.frames()
+    data0 = np.fromfile(path, dtype=np.uint8)
+    offs, sizes = idx.sample_offsets(), idx.sample_sizes()
+    rng = np.random.default_rng(23)
+    errors = decoded = 0
+    trials = 60
+    for trial in range(trials):
+        data = data0.copy()
+        for _ in range(1 + trial % 5):
+            s = int(rng.integers(0, len(offs)))
+            pos = offs[s] + int(rng.integers(6, sizes[s]))
+            data[pos] ^= 1 << int(rng.integers(0, 8))
+        bad = str(tmp_path / ("fz_%d.mp4" % trial))
+        data.tofile(bad)
+        dec = hw.Decoder(bad, video_index=idx, num_lanes=2)
+        try:
+            out = dec.retrieve_yuv(list(range(nf)))
+            assert len(out) == nf
+            decoded += 1
+        except RuntimeError:
+            errors += 1
+        del dec
+        os.unlink(bad)
+    assert errors + decoded == trials and errors > 0
+    got = hw.Decoder(path, video_index=idx, num_lanes=2).retrieve_yuv(list(range(nf)))
+    for i in range(nf):
+        assert np.array_equal(got[i], gold[i])
