@@ -655,7 +655,16 @@ struct Parser::Impl {
       return fail("SPS: block sizes out of range (CTB %d, CB %d, TB %d..%d)", s.log2_ctb, s.log2_min_cb, s.log2_min_tb, s.log2_max_tb);
     const int mcb = 1 << s.log2_min_cb;
     if (s.width <= 0 || s.height <= 0 || s.width > 8192 || s.height > 8192 || s.width % mcb || s.height % mcb) return fail("SPS: picture size %dx%d", s.width, s.height);
-    if (s.pcm && (s.log2_max_pcm > 5 || s.log2_max_pcm > s.log2_ctb || s.pcm_bits_y > 8 || s.pcm_bits_c > 8)) return fail("SPS: pcm parameters out of range");
+    if (s.pcm && (s.log2_max_pcm > 5 || s.log2_max_pcm > s.log2_ctb || s.log2_min_pcm < s.log2_min_cb || s.pcm_bits_y > 8 || s.pcm_bits_c > 8))
+      return fail("SPS: pcm parameters out of range");
+    // (every one of these is a shift count, a loop bound or a table index further down)
+    if (s.log2_max_poc_lsb > 16) return fail("SPS: log2_max_pic_order_cnt_lsb %d", s.log2_max_poc_lsb);
+    if (s.max_dec_pic_buffering < 1 || s.max_dec_pic_buffering > 16 || s.max_num_reorder < 0 || s.max_num_reorder >= s.max_dec_pic_buffering + (s.max_dec_pic_buffering == 1))
+      return fail("SPS: decoded picture buffer of %d pictures, %d reordered", s.max_dec_pic_buffering, s.max_num_reorder);
+    if (s.th_inter < 0 || s.th_intra < 0 || s.th_inter > s.log2_ctb - s.log2_min_tb || s.th_intra > s.log2_ctb - s.log2_min_tb)
+      return fail("SPS: max_transform_hierarchy_depth %d / %d", s.th_inter, s.th_intra);
+    if (s.crop_l < 0 || s.crop_r < 0 || s.crop_t < 0 || s.crop_b < 0 || s.crop_l + s.crop_r >= s.width || s.crop_t + s.crop_b >= s.height)
+      return fail("SPS: conformance window %d %d %d %d of %dx%d", s.crop_l, s.crop_r, s.crop_t, s.crop_b, s.width, s.height);
     s.wctb = (s.width + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
     s.hctb = (s.height + (1 << s.log2_ctb) - 1) >> s.log2_ctb;
     s.valid = true;
@@ -705,6 +714,10 @@ struct Parser::Impl {
     p.pml = 2 + static_cast<int>(b.ue());
     p.sh_ext = b.u(1) != 0;
     if (b.bad()) return fail("PPS: ran out of data");
+    if (p.nref_default[0] > 15 || p.nref_default[1] > 15 || p.init_qp < 0 || p.init_qp > 51 || p.qp_delta_depth < 0 || p.qp_delta_depth > 3 || p.cb_off < -12 ||
+        p.cb_off > 12 || p.cr_off < -12 || p.cr_off > 12 || p.beta_off < -6 || p.beta_off > 6 || p.tc_off < -6 || p.tc_off > 6 || p.pml < 2 || p.pml > 6)
+      return fail("PPS: a parameter is out of its range (init_qp %d, offsets %d %d %d %d, depth %d, merge level %d)", p.init_qp, p.cb_off, p.cr_off, p.beta_off,
+                  p.tc_off, p.qp_delta_depth, p.pml);
     p.valid = true;
     pps[id] = p;
     return true;
@@ -719,6 +732,8 @@ struct Parser::Impl {
     P = &pps[pid];
     if (!sps[P->sps_id].valid) return fail("slice refers to sequence parameter set %d, which was never sent", P->sps_id);
     S = &sps[P->sps_id];
+    if (P->pml > S->log2_ctb || P->qp_delta_depth > S->log2_ctb - S->log2_min_cb)
+      return fail("picture parameter set %u does not fit its sequence parameter set (merge level %d, quantisation group depth %d)", pid, P->pml, P->qp_delta_depth);
     h->pps_id = static_cast<int>(pid);
     const int ctbs = S->wctb * S->hctb;
     if (!h->first) {
@@ -871,6 +886,9 @@ struct Parser::Impl {
       if (b.u(1)) return fail("slice header alignment bits are not zero");
     if (b.bad()) return fail("slice header: ran out of data");
     if (h->qp < 0 || h->qp > 51) return fail("SliceQpY %d", h->qp);
+    if (h->beta_off < -6 || h->beta_off > 6 || h->tc_off < -6 || h->tc_off > 6 || P->cb_off + h->cb_off < -12 || P->cb_off + h->cb_off > 12 ||
+        P->cr_off + h->cr_off < -12 || P->cr_off + h->cr_off > 12)
+      return fail("slice header: deblocking / chroma offsets out of range (%d %d %d %d)", h->beta_off, h->tc_off, h->cb_off, h->cr_off);
     h->data_offset = b.pos() >> 3;
     return true;
   }

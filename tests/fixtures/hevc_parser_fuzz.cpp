@@ -5,7 +5,7 @@
 //   * every record it hands to the GPU kernels (amd/hevc_frame_job.h) stays inside the picture, its lists and its
 //     surfaces - k_hevc.hip trusts the records, so a damaged stream must never produce one that points outside.
 //
-//   hevc_parser_fuzz <hvcc file> <samples blob> <sizes file> <seed> <iterations>
+//   hevc_parser_fuzz <hvcc file> <samples blob> <sizes file> <seed> <iterations> [damage kind 0..7, default: all in turn]
 // Prints "ok: <iterations> damaged streams, <n> pictures checked, <m> ended in an error"; exit code 1 on a bad record.
 #include "../../hwang_amd/csrc/hevc/hevc_parser.h"
 
@@ -197,6 +197,7 @@ int main(int argc, char** argv) {
   }
   rng_state = std::strtoull(argv[4], nullptr, 10) * 2654435761u + 1;
   const int iterations = std::atoi(argv[5]);
+  const int only_kind = argc > 6 ? std::atoi(argv[6]) : -1;
   long long pictures = 0, errors = 0;
   for (int it = 0; it < iterations; ++it) {
     std::vector<std::vector<uint8_t>> samples;
@@ -206,7 +207,7 @@ int main(int argc, char** argv) {
       at += s;
     }
     std::vector<uint8_t> hvcc = hvcc0;
-    const int kind = static_cast<int>(rnd() % 8);
+    const int kind = only_kind >= 0 ? only_kind : static_cast<int>(rnd() % 8);
     const int hits = 1 + static_cast<int>(rnd() % 6);
     for (int h = 0; h < hits; ++h) {
       std::vector<uint8_t>& s = samples[rnd() % samples.size()];
