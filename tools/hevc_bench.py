@@ -61,7 +61,75 @@ def build_clip(workdir, width, height, gops, gop, frames, qp, bframes=2):
     return blob_path, idx
 
 
-def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, steps=3, fraction=0.01, workdir="/tmp/hwang_hevc_bench"):
+def cpu_worker(spec_path):
+    """Child process (`hevc_bench.py --cpu-worker spec.json`): the CPU oracle (oracle/hevc_*.c - test infrastructure, used
+    here as bench.py's cpu_baseline leg uses the H.264 one) under the reference's semantics: every sample of the GOP is
+    fed (software_video_decoder.cpp driven by DecoderAutomata), unwanted frames are discarded, wanted ones become RGB24."""
+    import hashlib
+    from oracle import oracle_py
+    spec = json.load(open(spec_path))
+    extradata = bytes.fromhex(spec["extradata"])
+    returned = fed = 0
+    md5s = {}
+    t0 = time.time()
+    with open(spec["blob"], "rb") as f:
+        for gop in spec["gops"]:
+            dec = oracle_py.HevcOracleDecoder(extradata)
+            frames = []
+            for off, size in gop["samples"]:
+                f.seek(off)
+                frames += dec.decode(f.read(size))
+                fed += 1
+            frames += dec.flush()
+            for k, row in zip(gop["wanted"], gop["rows"]):
+                buf, w, h, _ = frames[k]
+                md5s[str(row)] = hashlib.md5(oracle_py.i420_to_rgb(buf, w, h).tobytes()).hexdigest()
+                returned += 1
+            dec.close()
+    print(json.dumps({"returned": returned, "fed": fed, "seconds": time.time() - t0, "md5": md5s}))
+
+
+def cpu_baseline(blob, idx, rows, workers=16, max_gops=32):
+    """The oracle on the first `max_gops` touched GOPs of the request, `workers` single-threaded decoders; also the
+    MD5 of every frame it returned (the parity check of the GPU leg)."""
+    import tempfile
+    offs, sizes = idx.sample_offsets(), idx.sample_sizes()
+    kfs = list(idx.keyframe_indices()) + [idx.frames()]
+    gops, ki = [], 0
+    for r in rows:
+        while kfs[ki + 1] <= r:
+            ki += 1
+        if gops and gops[-1]["gop"] == ki:
+            gops[-1]["wanted"].append(r - kfs[ki])
+            gops[-1]["rows"].append(r)
+        elif len(gops) < max_gops:
+            gops.append({"gop": ki, "samples": [(offs[k], sizes[k]) for k in range(kfs[ki], kfs[ki + 1])], "wanted": [r - kfs[ki]], "rows": [r]})
+        else:
+            break
+    workers = max(1, min(workers, len(gops)))
+    with tempfile.TemporaryDirectory() as tmp:
+        procs = []
+        for i in range(workers):
+            spec = os.path.join(tmp, "w%d.json" % i)
+            json.dump({"blob": blob, "extradata": bytes(idx.metadata_bytes()).hex(), "gops": gops[i::workers]}, open(spec, "w"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", spec], stdout=subprocess.PIPE))
+        res = []
+        for p in procs:
+            out, _ = p.communicate()
+            if p.returncode:
+                raise RuntimeError("hevc_bench: a cpu_baseline worker failed")
+            res.append(json.loads(out.decode().strip().splitlines()[-1]))
+    busy = max(r["seconds"] for r in res)
+    md5 = {}
+    for r in res:
+        md5.update(r["md5"])
+    return {"value": round(sum(r["returned"] for r in res) / busy, 3), "unit": "frames/s", "cores": workers, "kind": "port",
+            "fed_samples_per_s": round(sum(r["fed"] for r in res) / busy, 1),
+            "sample": "%d touched GOPs of the same request (%d samples fed, %d wanted frames returned as RGB24), %d single-threaded oracle "
+                      "decoders, reference semantics (whole GOP decoded), %.1f s" % (len(gops), sum(r["fed"] for r in res), sum(r["returned"] for r in res), workers, busy)}, md5
+
+
+def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, steps=3, fraction=0.01, workdir="/tmp/hwang_hevc_bench", cpu=False):
     import ctypes as C
     import numpy as np
     import hwang_amd as hw
@@ -82,6 +150,15 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
         st = dec.stats()
         hc = (C.c_int64 * 4)()
         hw._capi.lib.hwang_retriever_host_counters(dec._get_retriever(), hc)
+        if cpu and cpu is not True:
+            pass
+        elif cpu:   # (once, outside the timed calls' clock: the oracle on a sample of the request, and its frames against these)
+            import hashlib
+            cpu, md5 = cpu_baseline(blob, idx, rows)
+            checked = [r for r in rows if str(r) in md5]
+            same = sum(hashlib.md5(out[rows.index(r)].tobytes()).hexdigest() == md5[str(r)] for r in checked)
+            cpu["parity_check"] = {"rows_compared": len(checked), "rows_equal": same,
+                                   "what": "MD5 of the RGB24 frame returned by the GPU path against the oracle's for the same row"}
         del out
     best = min(times)
     if os.environ.get("HEVC_BENCH_THREADS"):   # where the process's CPU time went, thread by thread (lane threads end with their call)
@@ -109,11 +186,16 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
             "staging_stall_ms_per_picture": round(st["stall_ns"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
             "upload_MB_per_picture": round(st["bytes_uploaded"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
             "bytes_per_sample": round(sum(idx.sample_sizes()) / n), "clip_build_s": round(t_build, 1),
+            "cpu_baseline": cpu if cpu else None,
             "parity": "unpinned: no HEVC decoder or foreign stream exists on either machine (DESIGN.md section 5a)"}
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(sys.argv[2])
+        sys.exit(0)
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle on a sample of the request and compare its frames")
     ap.add_argument("--frames", type=int, default=7200)
     ap.add_argument("--gops", type=int, default=8)
     ap.add_argument("--gop", type=int, default=24)
@@ -123,4 +205,4 @@ if __name__ == "__main__":
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     a = ap.parse_args()
-    print(json.dumps(run(width=a.width, height=a.height, gops=a.gops, gop=a.gop, frames=a.frames, lanes=a.lanes, steps=a.steps, fraction=a.fraction)))
+    print(json.dumps(run(width=a.width, height=a.height, gops=a.gops, gop=a.gop, frames=a.frames, lanes=a.lanes, steps=a.steps, fraction=a.fraction, cpu=a.cpu_baseline)))
