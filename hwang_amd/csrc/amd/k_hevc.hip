@@ -161,29 +161,12 @@ __global__ __launch_bounds__(64 * kResWaves) void k_hevc_residual(const Batch ba
 __device__ inline int ref_at(const uint8_t* p, int pitch, int w, int h, int x, int y) {
   return p[static_cast<size_t>(clip3(0, h - 1, y)) * pitch + clip3(0, w - 1, x)];
 }
-// predSamplesLX (14 bit) of one sample
-__device__ inline int interp(const uint8_t* ref, int pitch, int w, int h, bool chroma, int xi, int yi, int xf, int yf) {
-  const int taps = chroma ? 4 : 8, before = chroma ? 1 : 3;
-  if (!xf && !yf) return ref_at(ref, pitch, w, h, xi, yi) << 6;
-  if (!yf) {
-    int v = 0;
-    for (int t = 0; t < taps; ++t) v += (chroma ? kChromaTaps[xf][t] : kLumaTaps[xf][t]) * ref_at(ref, pitch, w, h, xi + t - before, yi);
-    return v;
-  }
-  if (!xf) {
-    int v = 0;
-    for (int t = 0; t < taps; ++t) v += (chroma ? kChromaTaps[yf][t] : kLumaTaps[yf][t]) * ref_at(ref, pitch, w, h, xi, yi + t - before);
-    return v;
-  }
-  int v = 0;
-  for (int u = 0; u < taps; ++u) {
-    int r = 0;
-    for (int t = 0; t < taps; ++t) r += (chroma ? kChromaTaps[xf][t] : kLumaTaps[xf][t]) * ref_at(ref, pitch, w, h, xi + t - before, yi + u - before);
-    v += (chroma ? kChromaTaps[yf][u] : kLumaTaps[yf][u]) * r;
-  }
-  return v >> 6;
-}
 
+// One workgroup per prediction block.  Per colour plane and list: the reference window - the block plus the filter's
+// 7 (3) extra rows and columns, clamped at the picture's edges as 8.5.3.3.3 says - is copied into LDS once (a sample of
+// a 64x64 block was fetched 64 times when every output sample interpolated for itself), the horizontal pass writes
+// 16-bit intermediates into LDS, the vertical pass reads them; list 0's 14-bit prediction waits in LDS for list 1's.
+constexpr int kRefPitch = 72;  // 64 + 7 samples of a window row (+ 1)
 __global__ __launch_bounds__(256) void k_hevc_inter(const Batch batch) {
   const PicParams& pp = *batch.pic[blockIdx.y];
   // Workgroups go to the eight XCDs in turn (the grid's x is a multiple of 8), and each XCD has an L2 of its own: XCD k
@@ -194,41 +177,82 @@ __global__ __launch_bounds__(256) void k_hevc_inter(const Batch batch) {
   const int pi = static_cast<int>(blockIdx.x & 7) * chunk + k;
   if (k >= chunk || pi >= pp.num_pu) return;
   const InterPu pu = pp.pus[pi];
+  __shared__ uint8_t s_ref[71 * kRefPitch];
+  __shared__ int16_t s_tmp[71 * 64];
+  __shared__ int16_t s_p0[64 * 64];
+  const int tid = threadIdx.x;
   for (int c = 0; c < 3; ++c) {
     const int sub = c ? 1 : 0;
     const int x0 = pu.x >> sub, y0 = pu.y >> sub, w = pu.w >> sub, h = pu.h >> sub;
     const int pw = pp.width >> sub, ph = pp.height >> sub, pitch = c ? pp.c_pitch : pp.y_pitch;
-    const int fb = c ? 3 : 2, fm = (1 << fb) - 1;
+    const int fb = c ? 3 : 2, fm = (1 << fb) - 1, taps = c ? 4 : 8, before = c ? 1 : 3;
     uint8_t* dst = plane_of(pp.recon, c);
     int16_t* res = pp.resid[c];
-    const uint8_t* r0 = (pu.pred_flag & 1) ? plane_of(pp.refs[pu.ref_slot[0]], c) : nullptr;
-    const uint8_t* r1 = (pu.pred_flag & 2) ? plane_of(pp.refs[pu.ref_slot[1]], c) : nullptr;
+    const bool use0 = pu.pred_flag & 1, use1 = pu.pred_flag & 2;
     WeightEntry w0 = {}, w1 = {};
     if (pu.weighted) {
-      if (r0) w0 = pp.weights[pu.wp[0]];
-      if (r1) w1 = pp.weights[pu.wp[1]];
+      if (use0) w0 = pp.weights[pu.wp[0]];
+      if (use1) w1 = pp.weights[pu.wp[1]];
     }
-    for (int i = threadIdx.x; i < w * h; i += blockDim.x) {
-      const int x = x0 + i % w, y = y0 + i / w;
-      int p0 = 0, p1 = 0;
-      if (r0) p0 = interp(r0, pitch, pw, ph, c != 0, x + (pu.mv[0][0] >> fb), y + (pu.mv[0][1] >> fb), pu.mv[0][0] & fm, pu.mv[0][1] & fm);
-      if (r1) p1 = interp(r1, pitch, pw, ph, c != 0, x + (pu.mv[1][0] >> fb), y + (pu.mv[1][1] >> fb), pu.mv[1][0] & fm, pu.mv[1][1] & fm);
-      int v;
-      if (!pu.weighted) {
-        v = (r0 && r1) ? (p0 + p1 + 64) >> 7 : ((r0 ? p0 : p1) + 32) >> 6;
-      } else {
-        const int lwd = (c ? (r0 ? w0 : w1).log2wd[1] : (r0 ? w0 : w1).log2wd[0]) + 6;
-        if (r0 && r1)
-          v = (p0 * w0.w[c] + p1 * w1.w[c] + ((w0.o[c] + w1.o[c] + 1) << lwd)) >> (lwd + 1);
-        else if (r0)
-          v = ((p0 * w0.w[c] + (1 << (lwd - 1))) >> lwd) + w0.o[c];
-        else
-          v = ((p1 * w1.w[c] + (1 << (lwd - 1))) >> lwd) + w1.o[c];
+    for (int l = 0; l < 2; ++l) {
+      if (!((pu.pred_flag >> l) & 1)) continue;
+      const uint8_t* ref = plane_of(pp.refs[pu.ref_slot[l]], c);
+      const int xf = pu.mv[l][0] & fm, yf = pu.mv[l][1] & fm;
+      const int xi = x0 + (pu.mv[l][0] >> fb) - (xf ? before : 0), yi = y0 + (pu.mv[l][1] >> fb) - (yf ? before : 0);
+      const int rw = w + (xf ? taps - 1 : 0), rh = h + (yf ? taps - 1 : 0);
+      __syncthreads();  // (the passes of the previous list / plane are through with the buffers)
+      for (int i = tid; i < rw * rh; i += 256) {
+        const int ry = i / rw, rx = i - ry * rw;
+        s_ref[ry * kRefPitch + rx] = static_cast<uint8_t>(ref_at(ref, pitch, pw, ph, xi + rx, yi + ry));
       }
-      const size_t at = static_cast<size_t>(y) * pitch + x;
-      const int r = res[at];
-      if (r) res[at] = 0;  // every sample's residual is read exactly once (by this kernel or by the intra one): the planes are zero again after the picture
-      dst[at] = static_cast<uint8_t>(clip8(clip8(v) + r));
+      __syncthreads();
+      const int8_t* tx = c ? kChromaTaps[xf] : kLumaTaps[xf];
+      const int8_t* ty = c ? kChromaTaps[yf] : kLumaTaps[yf];
+      for (int i = tid; i < w * rh; i += 256) {  // horizontal pass (or a copy): rh rows of w intermediates
+        const int ry = i / w, x = i - ry * w;
+        int v;
+        if (xf) {
+          v = 0;
+          for (int t = 0; t < taps; ++t) v += tx[t] * s_ref[ry * kRefPitch + x + t];
+        } else {
+          v = s_ref[ry * kRefPitch + x];
+        }
+        s_tmp[ry * 64 + x] = static_cast<int16_t>(v);
+      }
+      __syncthreads();
+      const bool last = l == 1 || !use1;
+      for (int i = tid; i < w * h; i += 256) {
+        const int yy = i / w, xx = i - yy * w;
+        int p;  // predSamplesLX, 14 bit
+        if (yf) {
+          p = 0;
+          for (int t = 0; t < taps; ++t) p += ty[t] * s_tmp[(yy + t) * 64 + xx];
+          if (xf) p >>= 6;
+        } else {
+          p = xf ? s_tmp[yy * 64 + xx] : s_tmp[yy * 64 + xx] << 6;
+        }
+        if (!last) {
+          s_p0[i] = static_cast<int16_t>(p);  // (read back by this very thread)
+          continue;
+        }
+        const int p0 = use0 ? (l == 0 ? p : s_p0[i]) : 0, p1 = use1 ? p : 0;
+        int v;
+        if (!pu.weighted) {
+          v = (use0 && use1) ? (p0 + p1 + 64) >> 7 : ((use0 ? p0 : p1) + 32) >> 6;
+        } else {
+          const int lwd = (c ? (use0 ? w0 : w1).log2wd[1] : (use0 ? w0 : w1).log2wd[0]) + 6;
+          if (use0 && use1)
+            v = (p0 * w0.w[c] + p1 * w1.w[c] + ((w0.o[c] + w1.o[c] + 1) << lwd)) >> (lwd + 1);
+          else if (use0)
+            v = ((p0 * w0.w[c] + (1 << (lwd - 1))) >> lwd) + w0.o[c];
+          else
+            v = ((p1 * w1.w[c] + (1 << (lwd - 1))) >> lwd) + w1.o[c];
+        }
+        const size_t at = static_cast<size_t>(y0 + yy) * pitch + x0 + xx;
+        const int r = res[at];
+        if (r) res[at] = 0;  // every sample's residual is read exactly once (by this kernel or by the intra one): the planes are zero again after the picture
+        dst[at] = static_cast<uint8_t>(clip8(clip8(v) + r));
+      }
     }
   }
 }
