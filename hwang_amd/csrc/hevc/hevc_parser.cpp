@@ -430,7 +430,7 @@ struct Pic {
   int32_t ref_poc_tab[amd::hevc::kMaxSurfaces] = {0};  // POC / long-term state of DPB entry i when this picture referred to it
   uint8_t ref_lt_tab[amd::hevc::kMaxSurfaces] = {0};
   // Motion: one entry per prediction block ([0]: none - intra, or a placeholder picture), and per 4x4 luma block, in
-  // z-order, which entry covers it.  (A field of 16-byte motions per 4x4 block was 2 MB written per 1080p picture, 13 %
+  // raster order, which entry covers it.  (A field of 16-byte motions per 4x4 block was 2 MB written per 1080p picture, 13 %
   // of a P picture's parse; the index is a quarter of it, and two blocks of one prediction block compare equal by index.)
   std::vector<Motion> pu_motion;
   std::vector<uint32_t> pu_of;
@@ -533,8 +533,6 @@ struct Parser::Impl {
   std::vector<uint16_t> ctb_slice;   // slice index per coding tree block, 0xffff = not decoded
   std::vector<uint32_t> slice_addr;  // SliceAddrRs per slice
   uint32_t zmap[256];                // Morton order of a 16 x 16 grid of 4x4 blocks
-  std::vector<uint32_t> zorder;      // per 4x4 block of the picture: its address in decoding (z-scan) order
-  int zorder_w4 = 0, zorder_h4 = 0, zorder_lc = 0;
   int num_slices = 0;
 
   // current slice
@@ -964,7 +962,7 @@ struct Parser::Impl {
     p->poc = poc_value;
     p->ref = state;
     p->placeholder = true;
-    p->pu_of.assign(S ? static_cast<size_t>(S->wctb) * S->hctb << (2 * (S->log2_ctb - 2)) : 0, 0u);
+    p->pu_of.assign(S ? static_cast<size_t>(S->width / 4) * (S->height / 4) : 0, 0u);
     p->pu_motion.assign(1, Motion());
     return p;
   }
@@ -1077,7 +1075,6 @@ struct Parser::Impl {
     pic_w = S->width; pic_h = S->height; pic_lc = S->log2_ctb; pic_wctb = S->wctb; pic_zmask = (1 << (S->log2_ctb - 2)) - 1;
     h4 = S->height / 4;
     const size_t n = static_cast<size_t>(w4) * h4;
-    build_zorder();
     // Only what is OR-ed into starts from zero; every other map is read only where this picture has already written
     // it (availability goes by z-order and slice, 6.4.1, not by what a map holds).
     if (m_pred.size() != n) {
@@ -1097,8 +1094,7 @@ struct Parser::Impl {
       pu_pool.pop_back();
     }
     cur->pu_motion.assign(1, Motion());
-    // (z-order addresses run over whole coding tree blocks, also where the picture ends inside one)
-    const size_t msize = static_cast<size_t>(S->wctb) * S->hctb << (2 * (S->log2_ctb - 2));
+    const size_t msize = n;
     if (cur->pu_of.size() != msize) cur->pu_of.assign(msize, 0u);  // (a recycled map holds its last picture: every unit overwrites its part)
     PicSetup setup;
     setup.width = S->width;
@@ -1176,7 +1172,7 @@ struct Parser::Impl {
           if (m_pred[i] == 2 || m_pred[j] == 2) bs[dir] = 2;
           else if ((eg & (dir ? 4 : 1)) && (m_nz[i] || m_nz[j])) bs[dir] = 1;
           else {
-            const uint32_t pj = cur->pu_of[zorder[j]], pi = cur->pu_of[zorder[i]];
+            const uint32_t pj = cur->pu_of[j], pi = cur->pu_of[i];
             bs[dir] = pj == pi ? 0 : motion_bs(cur->pu_motion[pj], cur->pu_motion[pi]);
           }
         }
@@ -1210,19 +1206,7 @@ struct Parser::Impl {
   }
 
   // ------------------------------------------------------------------------------- availability, 6.4.1 / 6.4.2
-  uint32_t zaddr(int x, int y) const { return zorder[(y >> 2) * w4 + (x >> 2)]; }
-  void build_zorder() {
-    if (zorder_w4 == w4 && zorder_h4 == h4 && zorder_lc == S->log2_ctb) return;
-    zorder_w4 = w4; zorder_h4 = h4; zorder_lc = S->log2_ctb;
-    zorder.resize(static_cast<size_t>(w4) * h4);
-    const int lc = S->log2_ctb, mask = (1 << (lc - 2)) - 1;
-    for (int y4 = 0; y4 < h4; ++y4)
-      for (int x4 = 0; x4 < w4; ++x4) {
-        const uint32_t ctb = static_cast<uint32_t>(((y4 * 4) >> lc) * S->wctb + ((x4 * 4) >> lc));
-        zorder[static_cast<size_t>(y4) * w4 + x4] = ctb << (2 * (lc - 2)) | zmap[(x4 & mask) | (y4 & mask) << 4];
-      }
-  }
-  bool zavail(int xc, int yc, int xn, int yn) const {
+  __attribute__((always_inline)) bool zavail(int xc, int yc, int xn, int yn) const {
     if (static_cast<unsigned>(xn) >= static_cast<unsigned>(pic_w) || static_cast<unsigned>(yn) >= static_cast<unsigned>(pic_h)) return false;
     // by coding tree block first (raster order, and the only place a slice can begin), inside one by the small z-map
     const int lc = pic_lc;
@@ -1254,8 +1238,7 @@ struct Parser::Impl {
       ok = zavail(xp, yp, xn, yn);
     return ok && m_pred[(yn >> 2) * w4 + (xn >> 2)] == 1;
   }
-  // (motion fields are laid out in decoding order - zorder[] - so that a unit's blocks are neighbours in memory)
-  const Motion& mot(int x, int y) const { return cur->pu_motion[cur->pu_of[zorder[(y >> 2) * w4 + (x >> 2)]]]; }
+  const Motion& mot(int x, int y) const { return cur->pu_motion[cur->pu_of[(y >> 2) * w4 + (x >> 2)]]; }
 
   static void scale_mv(int16_t* mv, int td, int tb) {
     td = clip3(-128, 127, td);
@@ -1286,7 +1269,7 @@ struct Parser::Impl {
         xc = xp + (w >> 1);
         yc = yp + (h >> 1);
       }
-      const Motion& c = col->pu_motion[col->pu_of[zorder[(((yc >> 4) << 4) >> 2) * w4 + (((xc >> 4) << 4) >> 2)]]];
+      const Motion& c = col->pu_motion[col->pu_of[(((yc >> 4) << 4) >> 2) * w4 + (((xc >> 4) << 4) >> 2)]];
       if (!c.flags) continue;
       int lc;
       if (!(c.flags & 1)) lc = 1;
@@ -1506,8 +1489,9 @@ struct Parser::Impl {
       fill_run(reinterpret_cast<uint8_t*>(&m_qp[i]), static_cast<uint8_t>(static_cast<int8_t>(cu.qp)), n4);
       if (cu.intra) fill_run(&m_mode[i], 1, n4);
     }
-    // "intra" as far as later pictures' temporal candidates and this picture's strengths go (an aligned square: one run)
-    if (cu.intra) std::memset(&cur->pu_of[zorder[static_cast<size_t>(cu.y >> 2) * w4 + (cu.x >> 2)]], 0, sizeof(uint32_t) * n4 * n4);
+    // "intra" as far as later pictures' temporal candidates and this picture's strengths go
+    if (cu.intra)
+      for (int y = cu.y; y < cu.y + n; y += 4) std::memset(&cur->pu_of[static_cast<size_t>(y >> 2) * w4 + (cu.x >> 2)], 0, sizeof(uint32_t) * n4);
   }
 
   void mpm(int x, int y, int cand[3]) const {  // 8.4.2
@@ -1918,13 +1902,10 @@ struct Parser::Impl {
     {
       const uint32_t pu_index = static_cast<uint32_t>(cur->pu_motion.size());
       cur->pu_motion.push_back(m);
-      // in aligned squares: each is one run of the z-ordered map
-      const int sq = (x | y | w | h) & -(x | y | w | h), per = (sq >> 2) * (sq >> 2);
-      for (int yy = y; yy < y + h; yy += sq)
-        for (int xx = x; xx < x + w; xx += sq) {
-          uint32_t* run = &cur->pu_of[zorder[(yy >> 2) * w4 + (xx >> 2)]];
-          for (int k = 0; k < per; ++k) run[k] = pu_index;
-        }
+      for (int yy = y; yy < y + h; yy += 4) {
+        uint32_t* run = &cur->pu_of[static_cast<size_t>(yy >> 2) * w4 + (x >> 2)];
+        for (int k = 0; k < (w >> 2); ++k) run[k] = pu_index;
+      }
     }
     // a prediction block edge inside the unit
     if (x > cu.x)
