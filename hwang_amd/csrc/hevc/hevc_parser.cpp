@@ -306,6 +306,18 @@ bool parse_rps(Bits& b, Rps* out, int idx, int num_sets, const Rps* sets) {
 // ------------------------------------------------------------------------------------------------------- CABAC
 // 9.3.4.3 with the offset kept scaled: `value` holds ivlOffset in its top bits and `bits` not yet consumed bits
 // below it, so a renormalisation is a subtraction from `bits` and a refill happens once per 32 bits.
+struct NextCtx {
+  uint8_t t[2][128];  // [outcome is the less probable symbol][state << 1 | MPS] -> the context's next byte
+  NextCtx() {
+    for (int st = 0; st < 64; ++st)
+      for (int mps = 0; mps < 2; ++mps) {
+        t[0][st << 1 | mps] = static_cast<uint8_t>((st < 62 ? st + 1 : st) << 1 | mps);
+        t[1][st << 1 | mps] = static_cast<uint8_t>(hevc_trans_lps[st] << 1 | (st == 0 ? !mps : mps));
+      }
+  }
+};
+static const NextCtx kNextCtx;
+
 class Cabac {
  public:
   void start(const uint8_t* p, size_t n, size_t at) {
@@ -336,23 +348,19 @@ class Cabac {
   }
   bool overrun() const { return broken_ || pos_ > n_ + 8; }
 
+  // 9.3.4.3.2.  The context byte is state << 1 | MPS; what follows an outcome is one table lookup (the next byte for either
+  // outcome, the MPS flip at state 0 folded in), and the outcome selects - offset, range, next byte, bin - without a
+  // branch: which way a bin goes is the least predictable branch of the parser.
   int decision(uint8_t* ctx) {
-    int state = *ctx >> 1, mps = *ctx & 1;
-    const uint32_t lps = hevc_range_lps[state][(range_ >> 6) & 3];
-    range_ -= lps;
-    const uint64_t scaled = static_cast<uint64_t>(range_) << bits_;
-    int bin;
-    if (value_ >= scaled) {
-      value_ -= scaled;
-      range_ = lps;
-      bin = !mps;
-      if (state == 0) mps = !mps;
-      state = hevc_trans_lps[state];
-    } else {
-      bin = mps;
-      if (state < 62) ++state;
-    }
-    *ctx = static_cast<uint8_t>(state << 1 | mps);
+    const uint32_t s = *ctx;
+    const uint32_t lps = hevc_range_lps[s >> 1][(range_ >> 6) & 3];
+    const uint32_t rmps = range_ - lps;
+    const uint64_t scaled = static_cast<uint64_t>(rmps) << bits_;
+    const bool is_lps = value_ >= scaled;
+    value_ -= is_lps ? scaled : 0;
+    range_ = is_lps ? lps : rmps;
+    *ctx = kNextCtx.t[is_lps][s];
+    const int bin = static_cast<int>((s & 1) ^ static_cast<uint32_t>(is_lps));
     if (range_ < 256) {
       const int n = __builtin_clz(range_) - 23;
       range_ <<= n;
