@@ -8,7 +8,7 @@
 //   IntraTu    one intra-predicted transform block per colour plane, in decoding order (8.4.4.2): k_hevc_intra_rows
 //              walks them as a wavefront of coding tree block rows (intra pictures), k_hevc_intra_flow takes them by
 //              ticket and lets each wait for exactly the neighbouring blocks it reads (scattered intra blocks)
-//   edge maps  per 4x4 luma block: boundary strengths of its left / top edge, QpY, "leave alone" flag:
+//   edge maps  per 4x4 luma block: boundary strengths of its left / top edge (or "compare the motion"), QpY, "leave alone" flag:
 //              k_hevc_deblock (8.7.2), k_hevc_sao (8.7.3, with SaoCtb per coding tree block)
 // Surfaces are planar I420 of the coded size; luma pitch a multiple of 256 bytes, chroma pitch half of it.
 #pragma once
@@ -86,7 +86,8 @@ struct SliceLoop {       // per slice: what the in-loop filters need
 
 // per 4x4 luma block (EdgeInfo[w4 * h4])
 struct EdgeInfo {
-  uint8_t bs;      // bits 0-1: strength of the left edge, bits 2-3: of the top edge
+  uint8_t bs;      // bits 0-1: strength of the left edge, bits 2-3: of the top edge; 3: an edge between two prediction blocks
+                   // with nothing else to decide it - k_hevc_deblock compares their motion (8.7.2.4, the last rule) itself
   int8_t qp;       // QpY
   uint8_t flags;   // bit 0: pcm with the loop filter off / transquant bypass: the in-loop filters leave the samples alone
   uint8_t slice;   // index into SliceLoop
@@ -126,6 +127,7 @@ struct PicParams {
   uint32_t* progress;          // k_hevc_intra_rows: [plane][block row] -> blocks completed (zeroed per picture)
   uint32_t* intra_ticket;      // k_hevc_intra_flow: [3] next record of each plane's list (zeroed per picture)
   uint8_t* intra_done[3];      // per plane, per 4x4 luma block: an intra block covering it is final (zeroed per picture)
+  uint32_t* pu_map;            // per 4x4 luma block: which InterPu covers it (written by k_hevc_inter, read by k_hevc_deblock)
   uint32_t* fault;             // set by a kernel whose bounded wait expired
 };
 

@@ -291,6 +291,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     pp.progress = progress_ + 4;
     for (int c = 0; c < 3; ++c) pp.intra_done[c] = reinterpret_cast<uint8_t*>(progress_ + 4 + 3 * hctb_) + static_cast<size_t>(c) * (cw_ / 4) * (ch_ / 4);
     pp.fault = fault_dev_;
+    pp.pu_map = pu_map_;
     // what the picture's intra kernel counts in, zeroed by the batch's first kernel: the rows' progress words or everything
     pp.clear_words = static_cast<int32_t>((pp.intra_rows ? 16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) : progress_bytes_) / 4);
     std::memcpy(set.host + off_.params, &pp, sizeof(pp));
@@ -387,6 +388,8 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (work_) (void)hipFree(work_);
     if (resid_) (void)hipFree(resid_);
     if (progress_) (void)hipFree(progress_);
+    if (pu_map_) (void)hipFree(pu_map_);
+    pu_map_ = nullptr;
     if (rgb_dev_) (void)hipFree(rgb_dev_);
     if (fault_host_) (void)hipHostFree(fault_host_);
     work_ = nullptr;
@@ -464,6 +467,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     ok = ok && hipMalloc(reinterpret_cast<void**>(&resid_), resid_bytes_) == hipSuccess;
     progress_bytes_ = (16 + sizeof(uint32_t) * 3 * static_cast<size_t>(hctb_) + 3 * w4h4 + 3) & ~static_cast<size_t>(3);  // tickets, row progress words, a done map per plane
     ok = ok && hipMalloc(reinterpret_cast<void**>(&progress_), progress_bytes_) == hipSuccess;
+    ok = ok && hipMalloc(reinterpret_cast<void**>(&pu_map_), sizeof(uint32_t) * w4h4) == hipSuccess;
     ok = ok && hipMalloc(reinterpret_cast<void**>(&rgb_dev_), static_cast<size_t>(cw_) * ch_ * 3) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void**>(&fault_host_), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess;
     if (ok) {
@@ -619,6 +623,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   uint8_t* work_ = nullptr;
   int16_t* resid_ = nullptr;
   uint32_t* progress_ = nullptr;
+  uint32_t* pu_map_ = nullptr;  // per 4x4 luma block: its prediction block (k_hevc_inter -> k_hevc_deblock)
   uint8_t* rgb_dev_ = nullptr;
   uint32_t* fault_host_ = nullptr;
   uint32_t* fault_dev_ = nullptr;
@@ -740,8 +745,9 @@ extern "C" int hwang_hevc_run_test_picture(const hwang_hevc_test_picture* t, cha
     }
   }
   pp.fault = reinterpret_cast<uint32_t*>(dev(sizeof(uint32_t), nullptr));
+  pp.pu_map = reinterpret_cast<uint32_t*>(dev(sizeof(uint32_t) * w4h4, nullptr));
   const gh::PicParams* pp_dev = reinterpret_cast<const gh::PicParams*>(dev(sizeof(pp), &pp));
-  ok = ok && pp.res && pp.coefs && pp.pus && pp.weights && pp.edges && pp.sao && pp.slices && resid && pp.intra_ticket && pp.fault && pp_dev;
+  ok = ok && pp.res && pp.coefs && pp.pus && pp.weights && pp.edges && pp.sao && pp.slices && resid && pp.intra_ticket && pp.fault && pp.pu_map && pp_dev;
   if (ok) {
     gh::Batch batch;
     batch.pic[0] = pp_dev;

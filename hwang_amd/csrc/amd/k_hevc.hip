@@ -181,6 +181,10 @@ __global__ __launch_bounds__(256) void k_hevc_inter(const Batch batch) {
   __shared__ int16_t s_tmp[71 * 64];
   __shared__ int16_t s_p0[64 * 64];
   const int tid = threadIdx.x;
+  {  // which prediction block covers a 4x4 block: the deblocking kernel compares the motion across block edges (bS 3)
+    const int bw = pu.w >> 2, bh = pu.h >> 2, w4 = pp.width >> 2;
+    for (int i = tid; i < bw * bh; i += 256) pp.pu_map[((pu.y >> 2) + i / bw) * w4 + (pu.x >> 2) + i % bw] = static_cast<uint32_t>(pi);
+  }
   for (int c = 0; c < 3; ++c) {
     const int sub = c ? 1 : 0;
     const int x0 = pu.x >> sub, y0 = pu.y >> sub, w = pu.w >> sub, h = pu.h >> sub;
@@ -644,6 +648,27 @@ __device__ void luma_segment(uint8_t* q0, int across, int along, int beta, int t
 #undef Q
 }
 
+// 8.7.2.4, the last rule: two prediction blocks differ enough for a filtered edge if they use different reference pictures
+// or numbers of vectors, or a vector component differs by a whole sample or more (4 quarter samples).  "The same
+// picture" is "the same surface" here; for two vectors each either pairing of the lists may match.
+__device__ inline int motion_bs(const InterPu& p, const InterPu& q) {
+  const int np = (p.pred_flag & 1) + (p.pred_flag >> 1), nq = (q.pred_flag & 1) + (q.pred_flag >> 1);
+  if (np != nq) return 1;
+  auto far = [](const int16_t* a, const int16_t* b) { return iabs(a[0] - b[0]) >= 4 || iabs(a[1] - b[1]) >= 4; };
+  if (np == 1) {
+    const int lp = (p.pred_flag & 1) ? 0 : 1, lq = (q.pred_flag & 1) ? 0 : 1;
+    return p.ref_slot[lp] != q.ref_slot[lq] || far(p.mv[lp], q.mv[lq]);
+  }
+  const bool straight = p.ref_slot[0] == q.ref_slot[0] && p.ref_slot[1] == q.ref_slot[1];
+  const bool crossed = p.ref_slot[0] == q.ref_slot[1] && p.ref_slot[1] == q.ref_slot[0];
+  if (!straight && !crossed) return 1;
+  if (p.ref_slot[0] != p.ref_slot[1]) {
+    if (straight) return far(p.mv[0], q.mv[0]) || far(p.mv[1], q.mv[1]);
+    return far(p.mv[0], q.mv[1]) || far(p.mv[1], q.mv[0]);
+  }
+  return (far(p.mv[0], q.mv[0]) || far(p.mv[1], q.mv[1])) && (far(p.mv[0], q.mv[1]) || far(p.mv[1], q.mv[0]));
+}
+
 __global__ __launch_bounds__(256) void k_hevc_deblock(const Batch batch, int dir) {
   const PicParams& pp = *batch.pic[blockIdx.y];
   if (!pp.deblock_enabled) return;
@@ -652,8 +677,14 @@ __global__ __launch_bounds__(256) void k_hevc_deblock(const Batch batch, int dir
   if (i >= w4 * h4) return;
   const int x = i % w4, y = i / w4;
   const EdgeInfo e = pp.edges[i];
-  const int bs = dir ? (e.bs >> 2) & 3 : e.bs & 3;
+  int bs = dir ? (e.bs >> 2) & 3 : e.bs & 3;
   if (!bs) return;
+  if (bs == 3) {
+    const uint32_t pj = pp.pu_map[dir ? i - w4 : i - 1], pq = pp.pu_map[i];
+    if (pj == pq) return;
+    bs = motion_bs(pp.pus[pj], pp.pus[pq]);
+    if (!bs) return;
+  }
   const EdgeInfo p = pp.edges[dir ? i - w4 : i - 1];
   const SliceLoop sl = pp.slices[e.slice];
   const int qpl = (e.qp + p.qp + 1) >> 1;

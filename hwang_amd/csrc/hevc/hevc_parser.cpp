@@ -1132,29 +1132,9 @@ struct Parser::Impl {
     if (done.num_ref_slots < amd::hevc::kMaxSurfaces) done.ref_slots[done.num_ref_slots++] = slot;
   }
 
-  // 8.7.2.4: boundary strengths of every 8x8-grid edge that is a transform or prediction block edge and may be filtered
-  static int motion_bs(const Motion& p, const Motion& q) {
-    const int np = (p.flags & 1) + (p.flags >> 1), nq = (q.flags & 1) + (q.flags >> 1);
-    if (np != nq) return 1;
-    auto far = [](const int16_t* a, const int16_t* b) { return iabs(a[0] - b[0]) >= 4 || iabs(a[1] - b[1]) >= 4; };
-    if (np == 1) {
-      const int lp = (p.flags & 1) ? 0 : 1, lq = (q.flags & 1) ? 0 : 1;
-      if (p.rid[lp] != q.rid[lq]) return 1;
-      return far(p.mv[lp], q.mv[lq]);
-    }
-    if (np == 2) {
-      const bool straight = p.rid[0] == q.rid[0] && p.rid[1] == q.rid[1];
-      const bool crossed = p.rid[0] == q.rid[1] && p.rid[1] == q.rid[0];
-      if (!straight && !crossed) return 1;
-      if (p.rid[0] != p.rid[1]) {
-        if (straight) return far(p.mv[0], q.mv[0]) || far(p.mv[1], q.mv[1]);
-        return far(p.mv[0], q.mv[1]) || far(p.mv[1], q.mv[0]);
-      }
-      return (far(p.mv[0], q.mv[0]) || far(p.mv[1], q.mv[1])) && (far(p.mv[0], q.mv[1]) || far(p.mv[1], q.mv[0]));
-    }
-    return 0;
-  }
-
+  // 8.7.2.4: boundary strengths of every 8x8-grid edge that is a transform or prediction block edge and may be filtered:
+  // 2 beside an intra block, 1 at a transform block edge with levels on either side, else - between two different
+  // prediction blocks - 3: the deblocking kernel compares their motion (it has the prediction block records)
   bool close_picture() {
     // the strengths of the edges that may be filtered (QpY / flags / slice of every block were written with its unit)
     bool any_bs = false;
@@ -1181,7 +1161,7 @@ struct Parser::Impl {
           else if ((eg & (dir ? 4 : 1)) && (m_nz[i] || m_nz[j])) bs[dir] = 1;
           else {
             const uint32_t pj = cur->pu_of[j], pi = cur->pu_of[i];
-            bs[dir] = pj == pi ? 0 : motion_bs(cur->pu_motion[pj], cur->pu_motion[pi]);
+            bs[dir] = pj == pi ? 0 : 3;
           }
         }
         erow[x].bs = static_cast<uint8_t>(bs[0] | bs[1] << 2);

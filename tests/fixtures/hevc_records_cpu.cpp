@@ -14,6 +14,7 @@
 #include <cstring>
 #include <fstream>
 #include <iterator>
+#include <utility>
 #include <vector>
 
 using namespace hwang;
@@ -310,13 +311,40 @@ struct CpuSink : public hevc::PictureSink {
     }
     // deblocking: all vertical edges, then all horizontal ones
     const int w4 = W / 4, h4 = H / 4;
+    // an edge marked 3 lies between two prediction blocks and nothing but their motion decides it (8.7.2.4's last rule:
+    // another reference picture or number of vectors, or a component a whole sample apart)
+    std::vector<uint32_t> pu_of(static_cast<size_t>(w4) * h4, 0);
+    for (size_t t = 0; t < d.num_pus; ++t)
+      for (int yy = 0; yy < pus[t].h; yy += 4)
+        for (int xx = 0; xx < pus[t].w; xx += 4) pu_of[static_cast<size_t>((pus[t].y + yy) / 4) * w4 + (pus[t].x + xx) / 4] = static_cast<uint32_t>(t);
+    auto motion_differs = [&](const gh::InterPu& a, const gh::InterPu& b) {
+      std::vector<std::pair<int, std::pair<int, int>>> va, vb;  // (surface, vector) of every list in use
+      for (int l = 0; l < 2; ++l) {
+        if ((a.pred_flag >> l) & 1) va.push_back({a.ref_slot[l], {a.mv[l][0], a.mv[l][1]}});
+        if ((b.pred_flag >> l) & 1) vb.push_back({b.ref_slot[l], {b.mv[l][0], b.mv[l][1]}});
+      }
+      if (va.size() != vb.size()) return true;
+      auto apart = [](const std::pair<int, int>& u, const std::pair<int, int>& v) { return iabs(u.first - v.first) >= 4 || iabs(u.second - v.second) >= 4; };
+      if (va.size() == 1) return va[0].first != vb[0].first || apart(va[0].second, vb[0].second);
+      const bool same_set = (va[0].first == vb[0].first && va[1].first == vb[1].first) || (va[0].first == vb[1].first && va[1].first == vb[0].first);
+      if (!same_set) return true;
+      const bool straight = apart(va[0].second, vb[0].second) || apart(va[1].second, vb[1].second);
+      const bool crossed = apart(va[0].second, vb[1].second) || apart(va[1].second, vb[0].second);
+      if (va[0].first == va[1].first) return straight && crossed;          // both vectors into one picture: either pairing may match
+      return va[0].first == vb[0].first ? straight : crossed;
+    };
     if (d.deblock)
       for (int dir = 0; dir < 2; ++dir)
         for (int y = 0; y < h4; ++y)
           for (int x = 0; x < w4; ++x) {
             const gh::EdgeInfo& e = edges[static_cast<size_t>(y) * w4 + x];
-            const int bs = dir ? (e.bs >> 2) & 3 : e.bs & 3;
+            int bs = dir ? (e.bs >> 2) & 3 : e.bs & 3;
             if (!bs) continue;
+            if (bs == 3) {
+              const uint32_t pq = pu_of[static_cast<size_t>(y) * w4 + x], pp_ = pu_of[static_cast<size_t>(dir ? (y - 1) * w4 + x : y * w4 + x - 1)];
+              if (pq == pp_ || !motion_differs(pus[pp_], pus[pq])) continue;
+              bs = 1;
+            }
             const gh::EdgeInfo& p = edges[static_cast<size_t>(dir ? (y - 1) * w4 + x : y * w4 + x - 1)];
             const gh::SliceLoop& sl = slices[e.slice];
             const int qpl = (e.qp + p.qp + 1) >> 1;
