@@ -310,6 +310,83 @@ def test_deblocking_kernel(hw):
         assert (wy != y).any() and (wu != u).any()
 
 
+def test_deblocking_motion_rule(hw):
+    """Edges marked 3: k_hevc_deblock decides them from the two prediction blocks' motion (8.7.2.4's last rule).  A
+    picture of 8x8 prediction blocks over two flat reference pictures (a block's prediction is a constant whatever its
+    vector: 100, 140 or their mean 120), vectors / references / lists drawn from a few values so that every case of the
+    rule occurs; the expected picture is numpy's filter over the strengths this test derives from the rule's text."""
+    rnd = np.random.default_rng(61)
+    W, H = 128, 64
+    w4, h4 = W // 4, H // 4
+    flat = [np.concatenate([np.full(W * H, 100), np.full(W * H // 2, 90)]).astype(np.uint8),
+            np.concatenate([np.full(W * H, 140), np.full(W * H // 2, 160)]).astype(np.uint8)]
+    level = {(0,): 100, (1,): 140, (0, 0): 100, (1, 1): 140, (0, 1): 120, (1, 0): 120}
+
+    def strength(a, b):
+        """a, b: lists of (reference picture, vector) of the lists in use.  1 unless the same pictures are referred to by
+        the same number of vectors and every vector has a partner within a sample (either pairing when both refer to
+        one picture)."""
+        if len(a) != len(b) or sorted(r for r, _ in a) != sorted(r for r, _ in b):
+            return 1
+        near = lambda u, v: abs(u[0] - v[0]) < 4 and abs(u[1] - v[1]) < 4
+        if len(a) == 1:
+            return 0 if near(a[0][1], b[0][1]) else 1
+        pairings = []
+        if a[0][0] == b[0][0] and a[1][0] == b[1][0]:
+            pairings.append(near(a[0][1], b[0][1]) and near(a[1][1], b[1][1]))
+        if a[0][0] == b[1][0] and a[1][0] == b[0][0]:
+            pairings.append(near(a[0][1], b[1][1]) and near(a[1][1], b[0][1]))
+        return 0 if any(pairings) else 1
+
+    for rep in range(3):
+        pus, motion = [], {}
+        for by in range(H // 8):
+            for bx in range(W // 8):
+                kind = int(rnd.integers(0, 4))        # list 0, list 1, both, both into one picture
+                refs = [(int(rnd.integers(0, 2)),), (int(rnd.integers(0, 2)),), (0, 1) if rnd.integers(0, 2) else (1, 0), (int(rnd.integers(0, 2)),) * 2][kind]
+                mvs = [(int(rnd.choice([0, 2, 4, 9])), int(rnd.choice([0, 3, -5]))) for _ in refs]
+                pred_flag = [1, 2, 3, 3][kind]
+                rs, mv = [0, 0], [[0, 0], [0, 0]]
+                lists = [0] if kind == 0 else [1] if kind == 1 else [0, 1]
+                for l, r, m in zip(lists, refs, mvs):
+                    rs[l], mv[l] = r, list(m)
+                pus.append((bx * 8, by * 8, 8, 8, pred_flag, 0, rs, mv, [0, 0], 0))
+                motion[(bx, by)] = (list(zip(refs, mvs)), level[refs])
+        y = np.zeros((H, W), dtype=np.int64)
+        for (bx, by), (_, lv) in motion.items():
+            y[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = lv
+        edges = np.zeros((h4, w4), dtype=EDGE)
+        edges["qp"] = 38
+        bsv = np.where((np.arange(w4)[None, :] % 2 == 0) & (np.arange(w4)[None, :] > 0), 3, 0) * np.ones((h4, 1), dtype=int)
+        bsh = np.where((np.arange(h4)[:, None] % 2 == 0) & (np.arange(h4)[:, None] > 0), 3, 0) * np.ones((1, w4), dtype=int)
+        edges["bs"] = bsv | bsh << 2
+        slices = np.array([(0, 0, 1, 1, 1, [0, 0, 0], 0)], dtype=SLICE)
+        want = y.copy()
+        filtered = 0
+        for d in range(2):
+            for by in range(h4):
+                for bx in range(w4):
+                    if not int((bsh if d else bsv)[by, bx]):
+                        continue
+                    q = motion[(bx // 2, by // 2)][0]
+                    p = motion[(bx // 2, (by - 1) // 2)][0] if d else motion[((bx - 1) // 2, by // 2)][0]
+                    if not strength(p, q):
+                        continue
+                    filtered += 1
+                    if d:
+                        blk = want[by * 4 - 4:by * 4 + 4, bx * 4:bx * 4 + 4].T
+                    else:
+                        blk = want[by * 4:by * 4 + 4, bx * 4 - 4:bx * 4 + 4]
+                    out = hn.deblock_luma(blk, 1, 38, 38, 0, 0, False, False)
+                    if d:
+                        want[by * 4 - 4:by * 4 + 4, bx * 4:bx * 4 + 4] = out.T
+                    else:
+                        want[by * 4:by * 4 + 4, bx * 4 - 4:bx * 4 + 4] = out
+        got, _ = run_picture(hw, W, H, refs=flat, pus=np.array(pus, dtype=PU), edges=edges.ravel(), slices=slices, deblock=True)
+        assert np.array_equal(got[0].astype(np.int64), want), rep
+        assert filtered > 50 and (want != y).any()
+
+
 def test_sao_kernel(hw):
     rnd = np.random.default_rng(70)
     W, H = 64, 48
