@@ -28,6 +28,8 @@ typedef struct {
   int ctb, min_tb, max_tb, th_intra, th_inter;
   int amp, sao, pcm, tskip, bypass, sdh, qp_swing, scaling, wp, tmvp, strong, merge_cand, pml, slices, wpp;
   int deblock_off, beta, tc, cip, rps_sps, poc_bits, random_intra, cabac_init, cb_off, cr_off, nal_length_size, extra_nals;
+  int long_term;   /* the GOP's first picture stays as a long-term reference once the short-term set has let go of it:
+                      1 - listed in every slice header (poc_lsb_lt), 2 - as the SPS's one long-term candidate (lt_idx_sps) */
   int bpyramid, lf_across, mvd_l1_zero, hvc1, intra_only, cover, slice_cb_off;
   const char* out;
   const char* yuv_out;
@@ -273,7 +275,11 @@ static void write_parameter_sets(Enc* e) {
   }
   bw_ue(&w, (uint32_t)e->num_sps_sets);
   for (int i = 0; i < e->num_sps_sets; ++i) put_st_rps(&w, &e->sps_sets[i], i);
-  bw_put(&w, 0, 1);                       /* long_term_ref_pics_present_flag */
+  bw_put(&w, c->long_term ? 1 : 0, 1);    /* long_term_ref_pics_present_flag */
+  if (c->long_term) {
+    bw_ue(&w, c->long_term == 2 ? 1 : 0);               /* num_long_term_ref_pics_sps */
+    if (c->long_term == 2) { bw_put(&w, 0, (int)c->poc_bits); bw_put(&w, 1, 1); } /* lt_ref_pic_poc_lsb_sps = 0, used_by_curr_pic_lt_sps_flag */
+  }
   bw_put(&w, (uint32_t)c->tmvp, 1); bw_put(&w, (uint32_t)c->strong, 1);
   bw_put(&w, 0, 1); bw_put(&w, 0, 1);     /* vui, extension */
   bw_trailing(&w);
@@ -393,6 +399,13 @@ static void refset_add(Enc* e, int poc) {
   }
 }
 
+static int lt_wanted(const Enc* e, const PicPlan* pp) {
+  if (!e->c.long_term || pp->idr) return 0;
+  for (int i = 0; i < e->n_refset; ++i)
+    if (e->refset[i] == 0) return 0;
+  return 1;
+}
+
 /* ---- slice header (7.3.6.1), mirrored by hv_parse_slice_header ---- */
 static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb, const HvRps* rps, int nl0, int nl1) {
   const Cfg* c = &e->c;
@@ -414,6 +427,17 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
     } else {
       bw_put(w, 0, 1);
       put_st_rps(w, rps, e->num_sps_sets);
+    }
+    if (c->long_term) { /* the GOP's first picture (POC 0), as soon as it is in no short-term set any more */
+      const int use_lt = lt_wanted(e, pp);
+      if (c->long_term == 2) bw_ue(w, (uint32_t)use_lt);             /* num_long_term_sps (its one candidate: no lt_idx_sps) */
+      bw_ue(w, (uint32_t)(c->long_term == 1 ? use_lt : 0));           /* num_long_term_pics */
+      if (use_lt) {
+        if (c->long_term == 1) { bw_put(w, 0, c->poc_bits); bw_put(w, 1, 1); } /* poc_lsb_lt, used_by_curr_pic_lt_flag */
+        const int cycle = pp->disp >> c->poc_bits, present = cycle > 0 || ((h >> 21) & 1);
+        bw_put(w, (uint32_t)present, 1);                               /* delta_poc_msb_present_flag */
+        if (present) bw_ue(w, (uint32_t)cycle);                        /* delta_poc_msb_cycle_lt */
+      }
     }
     if (c->tmvp) bw_put(w, pp->type != HV_SLICE_I, 1); /* slice_temporal_mvp_enabled_flag */
   }
@@ -854,10 +878,13 @@ static void analyse_pu(Enc* e, HvCu* cu, int pi) {
   int best_sad[2] = {1 << 30, 1 << 30}, best_ref[2] = {0, 0};
   int16_t best_mv[2][2] = {{0, 0}, {0, 0}};
   for (int l = 0; l < (sh->slice_type == HV_SLICE_B ? 2 : 1); ++l)
-    for (int r = 0; r < hv_min(sh->num_ref_idx[l], 2 + c->cover); ++r) {
+    for (int r = 0; r < hv_min(sh->num_ref_idx[l], (c->long_term ? 16 : 2) + c->cover); ++r) {
       int16_t cand[2][2], mv[2];
       hv_amvp_candidates(d, cu, pu->x, pu->y, pu->w, pu->h, pi, l, r, cand);
-      const int sad = search_list(e, pu, l, r, cand, mv) + 4 * r;
+      int sad = search_list(e, pu, l, r, cand, mv) + 4 * r;
+      /* --long-term: a share of the blocks is pushed to the list's last entry - the long-term picture when one is listed -
+         whatever it costs, so that unscaled predictors and the long / short-term candidate rules are exercised */
+      if (c->long_term && r == sh->num_ref_idx[l] - 1 && (hash3(h, 0x4c54, (uint32_t)l) % 3) == 0) sad -= 1 << 20;
       if (sad < best_sad[l]) { best_sad[l] = sad; best_ref[l] = r; best_mv[l][0] = mv[0]; best_mv[l][1] = mv[1]; }
     }
   int idc = 0, inter_sad = best_sad[0];
@@ -1115,8 +1142,8 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
   rps_for(e, pp->disp, &rps);
   int nl0 = 0, nl1 = 0;
   if (pp->type != HV_SLICE_I) {
-    const int total = rps.num_negative + rps.num_positive;
-    nl0 = hv_min(hv_max(total, 1), hv_min(c->refs, 15));
+    const int total = rps.num_negative + rps.num_positive + lt_wanted(e, pp);
+    nl0 = hv_min(hv_max(total, 1), hv_min(c->refs + (c->long_term ? 1 : 0), 15));
     nl1 = nl0;
     if (c->cover && total > 1 && (e->h & 3) == 0) nl0 = nl1 = hv_min(total + 1, 15); /* lists longer than the set: entries repeat */
   }
@@ -1361,7 +1388,7 @@ static void usage(void) {
           "  [--qp 30] [--seed 1] [--fps 30] [--ctb 16|32|64] [--min-tb 4] [--max-tb 32] [--th-intra 1] [--th-inter 1]\n"
           "  [--amp 0] [--sao 0|1|3 (+4: luma off, +8: chroma off)] [--pcm 0|1|2] [--tskip 0] [--bypass 0] [--sdh 0]\n"
           "  [--qp-swing 0|depth+1] [--scaling 0..3] [--wp 0] [--tmvp 1] [--strong 1] [--merge-cand 5] [--pml 2]\n"
-          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8]\n"
+          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2]\n"
           "  [--random-intra 0] [--cabac-init 0|1|2] [--cb-off 0] [--cr-off 0] [--slice-cb-off 0] [--nal-length-size 4]\n"
           "  [--extra-nals 0] [--bpyramid 0] [--lf-across 1] [--mvd-l1-zero 0] [--hvc1 0] [--intra-only 0] [--cover 0]\n");
 }
@@ -1378,7 +1405,7 @@ int main(int argc, char** argv) {
   A(pml, "--pml", 2); A(slices, "--slices", 1); A(wpp, "--wpp", 0); A(deblock_off, "--deblock-off", 0); A(beta, "--beta", 0);
   A(tc, "--tc", 0); A(cip, "--cip", 0); A(rps_sps, "--rps-sps", 0); A(poc_bits, "--poc-bits", 8); A(random_intra, "--random-intra", 0);
   A(cabac_init, "--cabac-init", 0); A(cb_off, "--cb-off", 0); A(cr_off, "--cr-off", 0); A(slice_cb_off, "--slice-cb-off", 0);
-  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0);
+  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0);
   A(lf_across, "--lf-across", 1); A(mvd_l1_zero, "--mvd-l1-zero", 0); A(hvc1, "--hvc1", 0); A(intra_only, "--intra-only", 0);
   A(cover, "--cover", 0);
 #undef A

@@ -267,4 +267,10 @@ HEVC_MATRIX = [
                         amp=1, sdh=1, deblock_off=2, beta=2, tc=-1, slice_cb_off=2, extra_nals=1, nal_length_size=2, hvc1=1)),
     ("deblock_off_th0", dict(frames=5, gop=5, bframes=1, deblock_off=1, th_inter=0, th_intra=0, max_tb=16)),
     ("merge1_p", dict(frames=5, gop=5, refs=1, merge_cand=1, qp=36)),
+    # long-term reference pictures (8.3.2): the GOP's first picture stays in the DPB after the short-term sets have let go
+    # of it - listed in the slice headers (1) or as the SPS's candidate (2); vectors into it are never scaled, a temporal
+    # candidate across the long-term / short-term divide is no candidate (8.5.3.2.7-8), POC most significant bits signalled
+    ("lt_p", dict(frames=10, gop=10, refs=2, long_term=1)),
+    ("lt_sps_b_tmvp", dict(frames=13, gop=13, bframes=2, refs=2, long_term=2, tmvp=1, ctb=32)),
+    ("lt_pyramid_pocwrap", dict(frames=40, gop=40, bframes=3, bpyramid=1, refs=3, long_term=1, poc_bits=4, sao=1)),
 ]

@@ -119,7 +119,17 @@ struct CpuSink : public hevc::PictureSink {
     n_coef += static_cast<int64_t>(d.num_coefs);
     n_pu += static_cast<int64_t>(d.num_pus);
     n_intra += static_cast<int64_t>(d.num_intra[0] + d.num_intra[1] + d.num_intra[2]);
-    if (std::getenv("HEVC_RECORDS_VERBOSE")) std::printf("picture: res=%zu levels=%zu pus=%zu intra=%zu/%zu/%zu\n", d.num_res, d.num_coefs, d.num_pus, d.num_intra[0], d.num_intra[1], d.num_intra[2]);
+    if (std::getenv("HEVC_RECORDS_VERBOSE")) {
+      std::printf("picture (surface %d): res=%zu levels=%zu pus=%zu intra=%zu/%zu/%zu; prediction blocks per reference surface:", d.slot, d.num_res, d.num_coefs, d.num_pus,
+                  d.num_intra[0], d.num_intra[1], d.num_intra[2]);
+      int per_slot[gh::kMaxSurfaces] = {0};
+      for (size_t t = 0; t < d.num_pus; ++t)
+        for (int l = 0; l < 2; ++l)
+          if ((pus[t].pred_flag >> l) & 1) ++per_slot[pus[t].ref_slot[l]];
+      for (int k = 0; k < gh::kMaxSurfaces; ++k)
+        if (per_slot[k]) std::printf(" %d:%d", k, per_slot[k]);
+      std::printf("\n");
+    }
     Plane3& cur = surf[d.slot];
     std::vector<int16_t> resid[3];
     for (int c = 0; c < 3; ++c) resid[c].assign(cur.p[c].size(), 0);
