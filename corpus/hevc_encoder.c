@@ -28,6 +28,9 @@ typedef struct {
   int ctb, min_tb, max_tb, th_intra, th_inter;
   int amp, sao, pcm, tskip, bypass, sdh, qp_swing, scaling, wp, tmvp, strong, merge_cand, pml, slices, wpp;
   int deblock_off, beta, tc, cip, rps_sps, poc_bits, random_intra, cabac_init, cb_off, cr_off, nal_length_size, extra_nals;
+  int inter_rps;   /* reference picture sets are coded by prediction from an earlier one wherever a deltaRps exists (7.3.7);
+                      needs --rps-sps: a slice header's own set is predicted from one of the SPS's */
+  int rplm;        /* ref_pic_lists_modification() in the slice headers: list entries drawn from the whole set */
   int long_term;   /* the GOP's first picture stays as a long-term reference once the short-term set has let go of it:
                       1 - listed in every slice header (poc_lsb_lt), 2 - as the SPS's one long-term candidate (lt_idx_sps) */
   int bpyramid, lf_across, mvd_l1_zero, hvc1, intra_only, cover, slice_cb_off;
@@ -234,6 +237,43 @@ static void put_st_rps(BitW* w, const HvRps* r, int idx) {
   }
 }
 
+/* `r` coded by prediction from `ref` = sets[idx - delta_idx] (inter_ref_pic_set_prediction_flag = 1): possible when one
+   deltaRps maps entries of ref (or zero: the picture ref belonged to) onto every entry of r; returns 0 if there is none */
+static int put_st_rps_inter(BitW* w, const HvRps* r, const HvRps* ref, int idx, int num_sets, int delta_idx) {
+  int tgt[32], nt = 0, src[33], ns = 0;
+  for (int i = 0; i < r->num_negative; ++i) tgt[nt++] = r->delta_poc_s0[i];
+  for (int i = 0; i < r->num_positive; ++i) tgt[nt++] = r->delta_poc_s1[i];
+  for (int i = 0; i < ref->num_negative; ++i) src[ns++] = ref->delta_poc_s0[i];
+  for (int i = 0; i < ref->num_positive; ++i) src[ns++] = ref->delta_poc_s1[i];
+  src[ns] = 0; /* index NumDeltaPocs: deltaRps itself */
+  for (int i = 0; i < r->num_negative; ++i) if (!r->used_s0[i]) return 0;
+  for (int i = 0; i < r->num_positive; ++i) if (!r->used_s1[i]) return 0;
+  for (int d = -20; d <= 20; ++d) {
+    if (!d) continue;
+    int covered = 0, clash = 0;
+    for (int t = 0; t < nt; ++t) {
+      int hit = 0;
+      for (int j = 0; j <= ns; ++j) hit += src[j] + d == tgt[t];
+      covered += hit > 0;
+    }
+    for (int j = 0; j <= ns; ++j) clash |= src[j] + d == 0; /* an entry that lands on the picture itself must be switched off: it is (its flags are 0) */
+    (void)clash;
+    if (covered != nt) continue;
+    bw_put(w, 1, 1);
+    if (idx == num_sets) bw_ue(w, (uint32_t)delta_idx - 1);
+    bw_put(w, d < 0, 1);
+    bw_ue(w, (uint32_t)(d < 0 ? -d : d) - 1);
+    for (int j = 0; j <= ns; ++j) {
+      int member = 0;
+      for (int t = 0; t < nt; ++t) member |= src[j] + d == tgt[t];
+      bw_put(w, (uint32_t)member, 1);        /* used_by_curr_pic_flag */
+      if (!member) bw_put(w, 0, 1);          /* use_delta_flag */
+    }
+    return 1;
+  }
+  return 0;
+}
+
 static int log2i(int v) { int n = 0; while ((1 << n) < v) ++n; return n; }
 
 static void write_parameter_sets(Enc* e) {
@@ -274,7 +314,8 @@ static void write_parameter_sets(Enc* e) {
     bw_put(&w, c->pcm == 2 ? 1 : 0, 1);                                        /* pcm_loop_filter_disabled_flag */
   }
   bw_ue(&w, (uint32_t)e->num_sps_sets);
-  for (int i = 0; i < e->num_sps_sets; ++i) put_st_rps(&w, &e->sps_sets[i], i);
+  for (int i = 0; i < e->num_sps_sets; ++i)
+    if (!(c->inter_rps && i > 0 && put_st_rps_inter(&w, &e->sps_sets[i], &e->sps_sets[i - 1], i, e->num_sps_sets, 1))) put_st_rps(&w, &e->sps_sets[i], i);
   bw_put(&w, c->long_term ? 1 : 0, 1);    /* long_term_ref_pics_present_flag */
   if (c->long_term) {
     bw_ue(&w, c->long_term == 2 ? 1 : 0);               /* num_long_term_ref_pics_sps */
@@ -306,7 +347,7 @@ static void write_parameter_sets(Enc* e) {
   bw_se(&w, 0); bw_se(&w, 0);
   bw_put(&w, (c->scaling & 2) ? 1 : 0, 1);
   if (c->scaling & 2) put_scaling_lists(&w, (uint32_t)c->seed * 17 + 3);
-  bw_put(&w, 0, 1);                       /* lists_modification_present_flag */
+  bw_put(&w, c->rplm ? 1 : 0, 1);         /* lists_modification_present_flag */
   bw_ue(&w, (uint32_t)c->pml - 2);
   bw_put(&w, 0, 1); bw_put(&w, 0, 1);
   bw_trailing(&w);
@@ -426,7 +467,10 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
       if (e->num_sps_sets > 1) bw_put(w, (uint32_t)idx, hv_ceil_log2((unsigned)e->num_sps_sets));
     } else {
       bw_put(w, 0, 1);
-      put_st_rps(w, rps, e->num_sps_sets);
+      int predicted = 0;
+      if (c->inter_rps)
+        for (int k = 1; k <= e->num_sps_sets && !predicted; ++k) predicted = put_st_rps_inter(w, rps, &e->sps_sets[e->num_sps_sets - k], e->num_sps_sets, e->num_sps_sets, k);
+      if (!predicted) put_st_rps(w, rps, e->num_sps_sets);
     }
     if (c->long_term) { /* the GOP's first picture (POC 0), as soon as it is in no short-term set any more */
       const int use_lt = lt_wanted(e, pp);
@@ -449,6 +493,16 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
     if (ovr) {
       bw_ue(w, (uint32_t)nl0 - 1);
       if (pp->type == HV_SLICE_B) bw_ue(w, (uint32_t)nl1 - 1);
+    }
+    const int total_curr = rps->num_negative + rps->num_positive + lt_wanted(e, pp);   /* NumPicTotalCurr: every entry is "used" */
+    if (c->rplm && total_curr > 1) { /* ref_pic_lists_modification() */
+      const int bits = hv_ceil_log2((unsigned)total_curr);
+      for (int l = 0; l < (pp->type == HV_SLICE_B ? 2 : 1); ++l) {
+        const int on = (int)(hash3(h, 0x726c, (uint32_t)l) % 3) != 0;
+        bw_put(w, (uint32_t)on, 1);
+        if (on)
+          for (int i = 0; i < (l ? nl1 : nl0); ++i) bw_put(w, hash3(h, 0x726d + (uint32_t)l, (uint32_t)i) % (unsigned)total_curr, bits);
+      }
     }
     if (pp->type == HV_SLICE_B) bw_put(w, (uint32_t)c->mvd_l1_zero, 1);
     if (c->cabac_init) bw_put(w, c->cabac_init == 2 ? (h >> 3) & 1 : 1, 1);
@@ -1388,7 +1442,7 @@ static void usage(void) {
           "  [--qp 30] [--seed 1] [--fps 30] [--ctb 16|32|64] [--min-tb 4] [--max-tb 32] [--th-intra 1] [--th-inter 1]\n"
           "  [--amp 0] [--sao 0|1|3 (+4: luma off, +8: chroma off)] [--pcm 0|1|2] [--tskip 0] [--bypass 0] [--sdh 0]\n"
           "  [--qp-swing 0|depth+1] [--scaling 0..3] [--wp 0] [--tmvp 1] [--strong 1] [--merge-cand 5] [--pml 2]\n"
-          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2]\n"
+          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2] [--inter-rps 0] [--rplm 0]\n"
           "  [--random-intra 0] [--cabac-init 0|1|2] [--cb-off 0] [--cr-off 0] [--slice-cb-off 0] [--nal-length-size 4]\n"
           "  [--extra-nals 0] [--bpyramid 0] [--lf-across 1] [--mvd-l1-zero 0] [--hvc1 0] [--intra-only 0] [--cover 0]\n");
 }
@@ -1405,7 +1459,7 @@ int main(int argc, char** argv) {
   A(pml, "--pml", 2); A(slices, "--slices", 1); A(wpp, "--wpp", 0); A(deblock_off, "--deblock-off", 0); A(beta, "--beta", 0);
   A(tc, "--tc", 0); A(cip, "--cip", 0); A(rps_sps, "--rps-sps", 0); A(poc_bits, "--poc-bits", 8); A(random_intra, "--random-intra", 0);
   A(cabac_init, "--cabac-init", 0); A(cb_off, "--cb-off", 0); A(cr_off, "--cr-off", 0); A(slice_cb_off, "--slice-cb-off", 0);
-  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0);
+  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0); A(inter_rps, "--inter-rps", 0); A(rplm, "--rplm", 0);
   A(lf_across, "--lf-across", 1); A(mvd_l1_zero, "--mvd-l1-zero", 0); A(hvc1, "--hvc1", 0); A(intra_only, "--intra-only", 0);
   A(cover, "--cover", 0);
 #undef A
@@ -1435,7 +1489,7 @@ int main(int argc, char** argv) {
       rps_for(e, plan[i].disp, &r);
       int known = 0;
       for (int k = 0; k < e->num_sps_sets; ++k) known |= rps_equal(&e->sps_sets[k], &r);
-      if (!known) e->sps_sets[e->num_sps_sets++] = r;
+      if (!known && !(c->rps_sps == 2 && (i & 1))) e->sps_sets[e->num_sps_sets++] = r;   /* (2: every other picture's set only - the rest is the slice headers' business) */
       if (plan[i].is_ref) refset_add(e, plan[i].disp);
     }
     e->n_refset = 0;

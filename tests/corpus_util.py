@@ -273,4 +273,10 @@ HEVC_MATRIX = [
     ("lt_p", dict(frames=10, gop=10, refs=2, long_term=1)),
     ("lt_sps_b_tmvp", dict(frames=13, gop=13, bframes=2, refs=2, long_term=2, tmvp=1, ctb=32)),
     ("lt_pyramid_pocwrap", dict(frames=40, gop=40, bframes=3, bpyramid=1, refs=3, long_term=1, poc_bits=4, sao=1)),
+    # reference picture sets coded by prediction from an earlier one (7.3.7 / 7.4.8: what real encoders do) - in the SPS,
+    # and a slice header's own set from one of the SPS's; ref_pic_lists_modification(): list entries from anywhere in the set
+    ("inter_rps_sps", dict(frames=20, gop=20, bframes=2, refs=3, rps_sps=1, inter_rps=1)),
+    ("inter_rps_slices_pyramid", dict(frames=20, gop=20, bframes=3, bpyramid=1, refs=4, rps_sps=2, inter_rps=1, ctb=32)),
+    ("rplm_b", dict(frames=12, gop=12, bframes=2, refs=3, rplm=1)),
+    ("rplm_lt_inter_rps_tmvp", dict(frames=16, gop=16, bframes=1, refs=4, rplm=1, long_term=1, rps_sps=2, inter_rps=1, tmvp=1)),
 ]
