@@ -30,6 +30,10 @@ typedef struct {
   int deblock_off, beta, tc, cip, rps_sps, poc_bits, random_intra, cabac_init, cb_off, cr_off, nal_length_size, extra_nals;
   int inter_rps;   /* reference picture sets are coded by prediction from an earlier one wherever a deltaRps exists (7.3.7);
                       needs --rps-sps: a slice header's own set is predicted from one of the SPS's */
+  int sub_layers;  /* 2: the sequence says it has two temporal sub-layers (profile_tier_level with a sub-layer level, ordering
+                      info per sub-layer) and pictures nothing refers to are in the upper one (nuh_temporal_id_plus1 = 2, TSA_N) */
+  int keep_unused; /* every other picture keeps the farthest picture of its set without using it (used_by_curr_pic_flag = 0:
+                      RefPicSetStFoll - in the DPB, in no list, not counted in NumPicTotalCurr) */
   int rplm;        /* ref_pic_lists_modification() in the slice headers: list entries drawn from the whole set */
   int long_term;   /* the GOP's first picture stays as a long-term reference once the short-term set has let go of it:
                       1 - listed in every slice header (poc_lsb_lt), 2 - as the SPS's one long-term candidate (lt_idx_sps) */
@@ -142,9 +146,10 @@ static void box_end(Buf* b, size_t at) {
 }
 
 /* NAL unit: two-byte header + RBSP with emulation prevention (7.4.2) */
+static int g_nal_tid_plus1 = 1; /* nuh_temporal_id_plus1 of the NAL units written next */
 static void nal_append(Buf* out, int type, const uint8_t* rbsp, size_t n) {
   b8(out, (uint32_t)type << 1);
-  b8(out, 1);
+  b8(out, (uint32_t)g_nal_tid_plus1);
   int zeros = 0;
   for (size_t i = 0; i < n; ++i) {
     if (zeros >= 2 && rbsp[i] <= 3) { b8(out, 3); zeros = 0; }
@@ -181,12 +186,18 @@ typedef struct {
   uint32_t h; /* hash base of the current picture */
 } Enc;
 
-static void put_profile_tier_level(BitW* w) {
+static void put_profile_tier_level_sub(BitW* w, int max_sub_layers_minus1);
+static void put_profile_tier_level(BitW* w) { put_profile_tier_level_sub(w, 0); }
+static void put_profile_tier_level_sub(BitW* w, int msl) {
   bw_put(w, 0, 2); bw_put(w, 0, 1); bw_put(w, 1, 5);   /* profile space 0, Main tier, Main profile */
   bw_put(w, 0x60000000u, 32);                           /* compatible with Main and Main 10 */
   bw_put(w, 1, 1); bw_put(w, 0, 1); bw_put(w, 0, 1); bw_put(w, 1, 1);
   bw_put(w, 0, 32); bw_put(w, 0, 11); bw_put(w, 0, 1);  /* 43 reserved zero bits, general_inbld_flag */
   bw_put(w, 120, 8);                                    /* level 4 */
+  for (int i = 0; i < msl; ++i) { bw_put(w, 0, 1); bw_put(w, 1, 1); }   /* sub_layer_profile_present_flag 0, sub_layer_level_present_flag 1 */
+  if (msl > 0)
+    for (int i = msl; i < 8; ++i) bw_put(w, 0, 2);      /* reserved_zero_2bits */
+  for (int i = 0; i < msl; ++i) bw_put(w, 93, 8);        /* sub_layer_level_idc: 3.1 */
 }
 
 static void put_scaling_lists(BitW* w, uint32_t seed) {
@@ -282,8 +293,9 @@ static void write_parameter_sets(Enc* e) {
   e->vps.n = 0;
   nal_append(&e->vps, 32, vps_rbsp, sizeof(vps_rbsp));
   BitW w = {0};
-  bw_put(&w, 0, 4); bw_put(&w, 0, 3); bw_put(&w, 1, 1);
-  put_profile_tier_level(&w);
+  const int msl = c->sub_layers == 2 ? 1 : 0;
+  bw_put(&w, 0, 4); bw_put(&w, (uint32_t)msl, 3); bw_put(&w, 1, 1);
+  put_profile_tier_level_sub(&w, msl);
   bw_ue(&w, 0); bw_ue(&w, 1);
   bw_ue(&w, (uint32_t)e->cw); bw_ue(&w, (uint32_t)e->ch);
   if (e->cw != c->width || e->ch != c->height) {
@@ -293,10 +305,12 @@ static void write_parameter_sets(Enc* e) {
   }
   bw_ue(&w, 0); bw_ue(&w, 0);
   bw_ue(&w, (uint32_t)c->poc_bits - 4);
-  bw_put(&w, 1, 1);
-  bw_ue(&w, (uint32_t)c->refs + 1); /* sps_max_dec_pic_buffering_minus1: the references and the current picture, one to spare */
-  bw_ue(&w, c->bframes ? (c->bpyramid ? 2u : 1u) : 0u);
-  bw_ue(&w, 0);
+  bw_put(&w, 1, 1);                 /* sps_sub_layer_ordering_info_present_flag: one triple per sub-layer */
+  for (int i = 0; i <= msl; ++i) {
+    bw_ue(&w, (uint32_t)c->refs + 1); /* sps_max_dec_pic_buffering_minus1: the references and the current picture, one to spare */
+    bw_ue(&w, c->bframes ? (c->bpyramid ? 2u : 1u) : 0u);
+    bw_ue(&w, 0);
+  }
   bw_ue(&w, 0);                                   /* minimum coding block 8 */
   bw_ue(&w, (uint32_t)log2i(c->ctb) - 3);
   bw_ue(&w, (uint32_t)log2i(c->min_tb) - 2);
@@ -421,6 +435,16 @@ static void rps_for(const Enc* e, int poc, HvRps* r) {
   r->num_positive = np;
   for (int i = 0; i < nn; ++i) { r->delta_poc_s0[i] = neg[i] - poc; r->used_s0[i] = 1; }
   for (int i = 0; i < np; ++i) { r->delta_poc_s1[i] = pos[i] - poc; r->used_s1[i] = 1; }
+  if (e->c.keep_unused && nn + np > 1 && (hash3((uint32_t)e->c.seed, 0x6b75, (uint32_t)poc) & 1)) {
+    if (nn > 1) r->used_s0[nn - 1] = 0;
+    else if (np > 1) r->used_s1[np - 1] = 0;
+  }
+}
+static int rps_used(const HvRps* r) {
+  int n = 0;
+  for (int i = 0; i < r->num_negative; ++i) n += r->used_s0[i];
+  for (int i = 0; i < r->num_positive; ++i) n += r->used_s1[i];
+  return n;
 }
 static int rps_equal(const HvRps* a, const HvRps* b) {
   if (a->num_negative != b->num_negative || a->num_positive != b->num_positive) return 0;
@@ -494,7 +518,7 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
       bw_ue(w, (uint32_t)nl0 - 1);
       if (pp->type == HV_SLICE_B) bw_ue(w, (uint32_t)nl1 - 1);
     }
-    const int total_curr = rps->num_negative + rps->num_positive + lt_wanted(e, pp);   /* NumPicTotalCurr: every entry is "used" */
+    const int total_curr = rps_used(rps) + lt_wanted(e, pp);   /* NumPicTotalCurr */
     if (c->rplm && total_curr > 1) { /* ref_pic_lists_modification() */
       const int bits = hv_ceil_log2((unsigned)total_curr);
       for (int l = 0; l < (pp->type == HV_SLICE_B ? 2 : 1); ++l) {
@@ -1196,7 +1220,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
   rps_for(e, pp->disp, &rps);
   int nl0 = 0, nl1 = 0;
   if (pp->type != HV_SLICE_I) {
-    const int total = rps.num_negative + rps.num_positive + lt_wanted(e, pp);
+    const int total = rps_used(&rps) + lt_wanted(e, pp);
     nl0 = hv_min(hv_max(total, 1), hv_min(c->refs + (c->long_term ? 1 : 0), 15));
     nl1 = nl0;
     if (c->cover && total > 1 && (e->h & 3) == 0) nl0 = nl1 = hv_min(total + 1, 15); /* lists longer than the set: entries repeat */
@@ -1281,7 +1305,9 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
     Buf rbsp = {0}, nal = {0};
     bput(&rbsp, hdr_rbsp[k].b, hdr_rbsp[k].n);
     bput(&rbsp, d->ce.buf, d->ce.nbits / 8);
-    nal_append(&nal, nal_type, rbsp.b, rbsp.n);
+    g_nal_tid_plus1 = (c->sub_layers == 2 && !pp->is_ref && !pp->idr) ? 2 : 1;
+    nal_append(&nal, (c->sub_layers == 2 && !pp->is_ref && !pp->idr) ? 2 /* TSA_N */ : nal_type, rbsp.b, rbsp.n);
+    g_nal_tid_plus1 = 1;
     sample_add_nal(sample, c->nal_length_size, &nal);
     free(rbsp.b);
     free(nal.b);
@@ -1442,7 +1468,7 @@ static void usage(void) {
           "  [--qp 30] [--seed 1] [--fps 30] [--ctb 16|32|64] [--min-tb 4] [--max-tb 32] [--th-intra 1] [--th-inter 1]\n"
           "  [--amp 0] [--sao 0|1|3 (+4: luma off, +8: chroma off)] [--pcm 0|1|2] [--tskip 0] [--bypass 0] [--sdh 0]\n"
           "  [--qp-swing 0|depth+1] [--scaling 0..3] [--wp 0] [--tmvp 1] [--strong 1] [--merge-cand 5] [--pml 2]\n"
-          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2] [--inter-rps 0] [--rplm 0]\n"
+          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2] [--inter-rps 0] [--rplm 0] [--keep-unused 0] [--sub-layers 1|2]\n"
           "  [--random-intra 0] [--cabac-init 0|1|2] [--cb-off 0] [--cr-off 0] [--slice-cb-off 0] [--nal-length-size 4]\n"
           "  [--extra-nals 0] [--bpyramid 0] [--lf-across 1] [--mvd-l1-zero 0] [--hvc1 0] [--intra-only 0] [--cover 0]\n");
 }
@@ -1459,7 +1485,7 @@ int main(int argc, char** argv) {
   A(pml, "--pml", 2); A(slices, "--slices", 1); A(wpp, "--wpp", 0); A(deblock_off, "--deblock-off", 0); A(beta, "--beta", 0);
   A(tc, "--tc", 0); A(cip, "--cip", 0); A(rps_sps, "--rps-sps", 0); A(poc_bits, "--poc-bits", 8); A(random_intra, "--random-intra", 0);
   A(cabac_init, "--cabac-init", 0); A(cb_off, "--cb-off", 0); A(cr_off, "--cr-off", 0); A(slice_cb_off, "--slice-cb-off", 0);
-  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0); A(inter_rps, "--inter-rps", 0); A(rplm, "--rplm", 0);
+  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0); A(inter_rps, "--inter-rps", 0); A(rplm, "--rplm", 0); A(keep_unused, "--keep-unused", 0); A(sub_layers, "--sub-layers", 1);
   A(lf_across, "--lf-across", 1); A(mvd_l1_zero, "--mvd-l1-zero", 0); A(hvc1, "--hvc1", 0); A(intra_only, "--intra-only", 0);
   A(cover, "--cover", 0);
 #undef A

@@ -279,4 +279,11 @@ HEVC_MATRIX = [
     ("inter_rps_slices_pyramid", dict(frames=20, gop=20, bframes=3, bpyramid=1, refs=4, rps_sps=2, inter_rps=1, ctb=32)),
     ("rplm_b", dict(frames=12, gop=12, bframes=2, refs=3, rplm=1)),
     ("rplm_lt_inter_rps_tmvp", dict(frames=16, gop=16, bframes=1, refs=4, rplm=1, long_term=1, rps_sps=2, inter_rps=1, tmvp=1)),
+    # pictures kept in the DPB without being used by the current one (used_by_curr_pic_flag = 0: RefPicSetStFoll)
+    ("keep_unused_p", dict(frames=16, gop=16, refs=3, keep_unused=1)),
+    ("keep_unused_b_rplm", dict(frames=20, gop=20, bframes=2, refs=4, keep_unused=1, rplm=1, tmvp=1)),
+    ("keep_unused_pyramid_lt", dict(frames=20, gop=20, bframes=3, bpyramid=1, refs=4, keep_unused=1, rps_sps=2, inter_rps=1, long_term=2)),
+    # two temporal sub-layers: profile_tier_level with a sub-layer level, ordering info per sub-layer, TSA_N pictures with
+    # nuh_temporal_id_plus1 = 2
+    ("sub_layers_b", dict(frames=13, gop=13, bframes=2, refs=2, sub_layers=2, tmvp=1)),
 ]

@@ -56,9 +56,12 @@ def test_host_parser_records_reproduce_the_clip(records_cpu, hw, tmp_path, name,
         assert np.array_equal(got[i], gold[i]), "%s: frame %d" % (name, i)
 
 
-def test_sparse_hint_skips_only_pictures_nothing_refers_to(records_cpu, hw, tmp_path):
+@pytest.mark.parametrize("sub_layers", [1, 2])
+def test_sparse_hint_skips_only_pictures_nothing_refers_to(records_cpu, hw, tmp_path, sub_layers):
+    """(sub_layers = 2: the pictures nothing refers to are TSA_N pictures of the upper temporal sub-layer - still the
+    highest layer's sub-layer non-reference pictures, still the only ones a sparse request may leave out.)"""
     path = str(tmp_path / "c.mp4")
-    gold = make_hevc_clip(path, frames=13, gop=13, bframes=3, bpyramid=1, refs=4)
+    gold = make_hevc_clip(path, frames=13, gop=13, bframes=3, bpyramid=1, refs=4, sub_layers=sub_layers)
     wanted = [0, 2, 6, 9, 12]      # 2 is a reference B picture (the middle of 1..3), 6 and 9 are not
     got, info = run_host(records_cpu, hw, path, tmp_path, wanted=wanted)
     got = got.reshape(-1, gold.shape[1])
