@@ -30,6 +30,8 @@ typedef struct {
   int deblock_off, beta, tc, cip, rps_sps, poc_bits, random_intra, cabac_init, cb_off, cr_off, nal_length_size, extra_nals;
   int inter_rps;   /* reference picture sets are coded by prediction from an earlier one wherever a deltaRps exists (7.3.7);
                       needs --rps-sps: a slice header's own set is predicted from one of the SPS's */
+  int sh_extras;   /* the optional bits of the slice segment header: output_flag_present_flag (pic_output_flag = 1),
+                      num_extra_slice_header_bits = 2, slice_segment_header_extension of a few bytes */
   int sub_layers;  /* 2: the sequence says it has two temporal sub-layers (profile_tier_level with a sub-layer level, ordering
                       info per sub-layer) and pictures nothing refers to are in the upper one (nuh_temporal_id_plus1 = 2, TSA_N) */
   int keep_unused; /* every other picture keeps the farthest picture of its set without using it (used_by_curr_pic_flag = 0:
@@ -332,8 +334,9 @@ static void write_parameter_sets(Enc* e) {
     if (!(c->inter_rps && i > 0 && put_st_rps_inter(&w, &e->sps_sets[i], &e->sps_sets[i - 1], i, e->num_sps_sets, 1))) put_st_rps(&w, &e->sps_sets[i], i);
   bw_put(&w, c->long_term ? 1 : 0, 1);    /* long_term_ref_pics_present_flag */
   if (c->long_term) {
-    bw_ue(&w, c->long_term == 2 ? 1 : 0);               /* num_long_term_ref_pics_sps */
-    if (c->long_term == 2) { bw_put(&w, 0, (int)c->poc_bits); bw_put(&w, 1, 1); } /* lt_ref_pic_poc_lsb_sps = 0, used_by_curr_pic_lt_sps_flag */
+    bw_ue(&w, c->long_term == 2 ? 1 : c->long_term == 3 ? 2 : 0);    /* num_long_term_ref_pics_sps */
+    if (c->long_term == 3) { bw_put(&w, 5, (int)c->poc_bits); bw_put(&w, 0, 1); }  /* (3) a candidate nobody picks in front of the one that is */
+    if (c->long_term >= 2) { bw_put(&w, 0, (int)c->poc_bits); bw_put(&w, 1, 1); }  /* lt_ref_pic_poc_lsb_sps = 0, used_by_curr_pic_lt_sps_flag */
   }
   bw_put(&w, (uint32_t)c->tmvp, 1); bw_put(&w, (uint32_t)c->strong, 1);
   bw_put(&w, 0, 1); bw_put(&w, 0, 1);     /* vui, extension */
@@ -343,7 +346,7 @@ static void write_parameter_sets(Enc* e) {
   free(w.b);
   memset(&w, 0, sizeof(w));
   bw_ue(&w, 0); bw_ue(&w, 0);
-  bw_put(&w, 0, 1); bw_put(&w, 0, 1); bw_put(&w, 0, 3);
+  bw_put(&w, 0, 1); bw_put(&w, c->sh_extras ? 1 : 0, 1); bw_put(&w, c->sh_extras ? 2 : 0, 3); /* dependent slices off, output_flag_present_flag, num_extra_slice_header_bits */
   bw_put(&w, (uint32_t)c->sdh, 1); bw_put(&w, c->cabac_init ? 1 : 0, 1);
   bw_ue(&w, (uint32_t)hv_min(c->refs, 15) - 1); bw_ue(&w, (uint32_t)hv_min(c->refs, 15) - 1);
   bw_se(&w, 0);                           /* init_qp_minus26: slices carry the difference */
@@ -363,7 +366,7 @@ static void write_parameter_sets(Enc* e) {
   if (c->scaling & 2) put_scaling_lists(&w, (uint32_t)c->seed * 17 + 3);
   bw_put(&w, c->rplm ? 1 : 0, 1);         /* lists_modification_present_flag */
   bw_ue(&w, (uint32_t)c->pml - 2);
-  bw_put(&w, 0, 1); bw_put(&w, 0, 1);
+  bw_put(&w, c->sh_extras ? 1 : 0, 1); bw_put(&w, 0, 1);   /* slice_segment_header_extension_present_flag, pps_extension */
   bw_trailing(&w);
   e->pps.n = 0;
   nal_append(&e->pps, 34, w.b, w.bits / 8);
@@ -480,7 +483,9 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
   if (pp->idr) bw_put(w, 0, 1);
   bw_ue(w, 0);
   if (first_ctb) bw_put(w, (uint32_t)first_ctb, hv_ceil_log2((unsigned)(sps->width_ctb * sps->height_ctb)));
+  if (c->sh_extras) bw_put(w, (h >> 24) & 3, 2);  /* slice_reserved_flag[0..1]: whatever */
   bw_ue(w, (uint32_t)pp->type);
+  if (c->sh_extras) bw_put(w, 1, 1);              /* pic_output_flag */
   if (!pp->idr) {
     bw_put(w, (uint32_t)pp->disp & ((1u << c->poc_bits) - 1), c->poc_bits);
     int idx = -1;
@@ -498,9 +503,10 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
     }
     if (c->long_term) { /* the GOP's first picture (POC 0), as soon as it is in no short-term set any more */
       const int use_lt = lt_wanted(e, pp);
-      if (c->long_term == 2) bw_ue(w, (uint32_t)use_lt);             /* num_long_term_sps (its one candidate: no lt_idx_sps) */
+      if (c->long_term >= 2) bw_ue(w, (uint32_t)use_lt);             /* num_long_term_sps */
       bw_ue(w, (uint32_t)(c->long_term == 1 ? use_lt : 0));           /* num_long_term_pics */
       if (use_lt) {
+        if (c->long_term == 3) bw_put(w, 1, 1);                        /* lt_idx_sps: the second of two candidates (one bit) */
         if (c->long_term == 1) { bw_put(w, 0, c->poc_bits); bw_put(w, 1, 1); } /* poc_lsb_lt, used_by_curr_pic_lt_flag */
         const int cycle = pp->disp >> c->poc_bits, present = cycle > 0 || ((h >> 21) & 1);
         bw_put(w, (uint32_t)present, 1);                               /* delta_poc_msb_present_flag */
@@ -579,6 +585,11 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
      * stream may say "none listed" only if the slice is one row long - this encoder lists none and relies on
      * decoders that walk (the oracle and the product do); offset_len / entry_point_offset are therefore absent */
     bw_ue(w, 0);
+  }
+  if (c->sh_extras) { /* slice_segment_header_extension: length, then bytes nobody interprets */
+    const int n = (int)((h >> 26) % 4);
+    bw_ue(w, (uint32_t)n);
+    for (int i = 0; i < n; ++i) bw_put(w, hash3(h, 0x7368, (uint32_t)i) & 0xff, 8);
   }
   bw_trailing(w);
 }
@@ -1468,7 +1479,7 @@ static void usage(void) {
           "  [--qp 30] [--seed 1] [--fps 30] [--ctb 16|32|64] [--min-tb 4] [--max-tb 32] [--th-intra 1] [--th-inter 1]\n"
           "  [--amp 0] [--sao 0|1|3 (+4: luma off, +8: chroma off)] [--pcm 0|1|2] [--tskip 0] [--bypass 0] [--sdh 0]\n"
           "  [--qp-swing 0|depth+1] [--scaling 0..3] [--wp 0] [--tmvp 1] [--strong 1] [--merge-cand 5] [--pml 2]\n"
-          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2] [--inter-rps 0] [--rplm 0] [--keep-unused 0] [--sub-layers 1|2]\n"
+          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2|3] [--inter-rps 0] [--rplm 0] [--keep-unused 0] [--sub-layers 1|2] [--sh-extras 0]\n"
           "  [--random-intra 0] [--cabac-init 0|1|2] [--cb-off 0] [--cr-off 0] [--slice-cb-off 0] [--nal-length-size 4]\n"
           "  [--extra-nals 0] [--bpyramid 0] [--lf-across 1] [--mvd-l1-zero 0] [--hvc1 0] [--intra-only 0] [--cover 0]\n");
 }
@@ -1485,7 +1496,7 @@ int main(int argc, char** argv) {
   A(pml, "--pml", 2); A(slices, "--slices", 1); A(wpp, "--wpp", 0); A(deblock_off, "--deblock-off", 0); A(beta, "--beta", 0);
   A(tc, "--tc", 0); A(cip, "--cip", 0); A(rps_sps, "--rps-sps", 0); A(poc_bits, "--poc-bits", 8); A(random_intra, "--random-intra", 0);
   A(cabac_init, "--cabac-init", 0); A(cb_off, "--cb-off", 0); A(cr_off, "--cr-off", 0); A(slice_cb_off, "--slice-cb-off", 0);
-  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0); A(inter_rps, "--inter-rps", 0); A(rplm, "--rplm", 0); A(keep_unused, "--keep-unused", 0); A(sub_layers, "--sub-layers", 1);
+  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0); A(inter_rps, "--inter-rps", 0); A(rplm, "--rplm", 0); A(keep_unused, "--keep-unused", 0); A(sub_layers, "--sub-layers", 1); A(sh_extras, "--sh-extras", 0);
   A(lf_across, "--lf-across", 1); A(mvd_l1_zero, "--mvd-l1-zero", 0); A(hvc1, "--hvc1", 0); A(intra_only, "--intra-only", 0);
   A(cover, "--cover", 0);
 #undef A

@@ -286,4 +286,8 @@ HEVC_MATRIX = [
     # two temporal sub-layers: profile_tier_level with a sub-layer level, ordering info per sub-layer, TSA_N pictures with
     # nuh_temporal_id_plus1 = 2
     ("sub_layers_b", dict(frames=13, gop=13, bframes=2, refs=2, sub_layers=2, tmvp=1)),
+    # the optional bits of a slice segment header (pic_output_flag, extra header bits, the header extension) in front of
+    # several slices and wavefront rows; the SPS's long-term candidates chosen by lt_idx_sps
+    ("sh_extras_slices_wpp", dict(frames=12, gop=6, bframes=2, refs=2, sh_extras=1, slices=3, wpp=1, ctb=16)),
+    ("lt_idx_sps_sh_extras", dict(frames=14, gop=14, bframes=1, refs=2, long_term=3, sh_extras=1)),
 ]
