@@ -30,6 +30,8 @@ typedef struct {
   int deblock_off, beta, tc, cip, rps_sps, poc_bits, random_intra, cabac_init, cb_off, cr_off, nal_length_size, extra_nals;
   int inter_rps;   /* reference picture sets are coded by prediction from an earlier one wherever a deltaRps exists (7.3.7);
                       needs --rps-sps: a slice header's own set is predicted from one of the SPS's */
+  int multi_pps;   /* two picture parameter sets, taken in turn by the pictures: the second has another init_qp_minus26 and
+                      num_ref_idx_default_active of 1 / 1 (the slice headers make up for both) */
   int sh_extras;   /* the optional bits of the slice segment header: output_flag_present_flag (pic_output_flag = 1),
                       num_extra_slice_header_bits = 2, slice_segment_header_extension of a few bytes */
   int sub_layers;  /* 2: the sequence says it has two temporal sub-layers (profile_tier_level with a sub-layer level, ordering
@@ -176,7 +178,7 @@ typedef struct {
   HevcOracle* d; /* the reconstruction context: DPB, maps, pools, syntax walk */
   Scene scene;
   int cw, ch;    /* coded size */
-  Buf vps, sps, pps;
+  Buf vps, sps, pps, pps1;   /* (pps1: the second picture parameter set of --multi-pps) */
   HvRps sps_sets[16];
   int num_sps_sets;
   int refset[HV_MAX_REFS], n_refset; /* POCs of the reference pictures kept */
@@ -344,12 +346,15 @@ static void write_parameter_sets(Enc* e) {
   e->sps.n = 0;
   nal_append(&e->sps, 33, w.b, w.bits / 8);
   free(w.b);
+  e->pps.n = 0;
+  e->pps1.n = 0;
+  for (int pps_id = 0; pps_id < (c->multi_pps ? 2 : 1); ++pps_id) {
   memset(&w, 0, sizeof(w));
-  bw_ue(&w, 0); bw_ue(&w, 0);
+  bw_ue(&w, (uint32_t)pps_id); bw_ue(&w, 0);
   bw_put(&w, 0, 1); bw_put(&w, c->sh_extras ? 1 : 0, 1); bw_put(&w, c->sh_extras ? 2 : 0, 3); /* dependent slices off, output_flag_present_flag, num_extra_slice_header_bits */
   bw_put(&w, (uint32_t)c->sdh, 1); bw_put(&w, c->cabac_init ? 1 : 0, 1);
-  bw_ue(&w, (uint32_t)hv_min(c->refs, 15) - 1); bw_ue(&w, (uint32_t)hv_min(c->refs, 15) - 1);
-  bw_se(&w, 0);                           /* init_qp_minus26: slices carry the difference */
+  bw_ue(&w, pps_id ? 0u : (uint32_t)hv_min(c->refs, 15) - 1); bw_ue(&w, pps_id ? 0u : (uint32_t)hv_min(c->refs, 15) - 1);
+  bw_se(&w, pps_id ? 3 : 0);              /* init_qp_minus26: slices carry the difference */
   bw_put(&w, (uint32_t)c->cip, 1); bw_put(&w, (uint32_t)c->tskip, 1);
   bw_put(&w, c->qp_swing ? 1 : 0, 1);
   if (c->qp_swing) bw_ue(&w, (uint32_t)hv_min(c->qp_swing - 1, log2i(c->ctb) - 3)); /* diff_cu_qp_delta_depth */
@@ -368,9 +373,10 @@ static void write_parameter_sets(Enc* e) {
   bw_ue(&w, (uint32_t)c->pml - 2);
   bw_put(&w, c->sh_extras ? 1 : 0, 1); bw_put(&w, 0, 1);   /* slice_segment_header_extension_present_flag, pps_extension */
   bw_trailing(&w);
-  e->pps.n = 0;
-  nal_append(&e->pps, 34, w.b, w.bits / 8);
+  nal_append(pps_id ? &e->pps1 : &e->pps, 34, w.b, w.bits / 8);
   free(w.b);
+  }
+
 }
 
 static size_t build_hvcc(const Enc* e, uint8_t* out) {
@@ -383,13 +389,16 @@ static size_t build_hvcc(const Enc* e, uint8_t* out) {
   out[o++] = 0; out[o++] = 0;
   out[o++] = (uint8_t)(1 << 3 | 1 << 2 | (e->c.nal_length_size - 1));
   out[o++] = 3;
-  const Buf* nals[3] = {&e->vps, &e->sps, &e->pps};
+  const Buf* nals[4] = {&e->vps, &e->sps, &e->pps, &e->pps1};
   for (int a = 0; a < 3; ++a) {
+    const int count = a == 2 && e->pps1.n ? 2 : 1;   /* the array of picture parameter sets may hold two */
     out[o++] = (uint8_t)(0x80 | (32 + a));
-    out[o++] = 0; out[o++] = 1;
-    out[o++] = (uint8_t)(nals[a]->n >> 8); out[o++] = (uint8_t)nals[a]->n;
-    memcpy(out + o, nals[a]->b, nals[a]->n);
-    o += nals[a]->n;
+    out[o++] = 0; out[o++] = (uint8_t)count;
+    for (int k = 0; k < count; ++k) {
+      out[o++] = (uint8_t)(nals[a + k]->n >> 8); out[o++] = (uint8_t)nals[a + k]->n;
+      memcpy(out + o, nals[a + k]->b, nals[a + k]->n);
+      o += nals[a + k]->n;
+    }
   }
   return o;
 }
@@ -481,7 +490,8 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
   const uint32_t h = hash3(e->h, 0x51, (uint32_t)first_ctb);
   bw_put(w, first_ctb == 0, 1);
   if (pp->idr) bw_put(w, 0, 1);
-  bw_ue(w, 0);
+  const int pps_id = c->multi_pps ? (int)(e->pic_counter & 1) : 0;
+  bw_ue(w, (uint32_t)pps_id);
   if (first_ctb) bw_put(w, (uint32_t)first_ctb, hv_ceil_log2((unsigned)(sps->width_ctb * sps->height_ctb)));
   if (c->sh_extras) bw_put(w, (h >> 24) & 3, 2);  /* slice_reserved_flag[0..1]: whatever */
   bw_ue(w, (uint32_t)pp->type);
@@ -517,7 +527,7 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
   }
   if (c->sao) { bw_put(w, (c->sao & 4) ? 0 : 1, 1); bw_put(w, (c->sao & 8) ? 0 : 1, 1); }
   if (pp->type != HV_SLICE_I) {
-    const int def = hv_min(c->refs, 15);
+    const int def = pps_id ? 1 : hv_min(c->refs, 15);
     const int ovr = nl0 != def || (pp->type == HV_SLICE_B && nl1 != def);
     bw_put(w, (uint32_t)ovr, 1);
     if (ovr) {
@@ -568,7 +578,7 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
     }
     bw_ue(w, (uint32_t)(5 - c->merge_cand));
   }
-  bw_se(w, hv_clip3(0, 51, c->qp + ((pp->type == HV_SLICE_B && !pp->is_ref) ? 2 : 0) - (pp->type == HV_SLICE_I ? 2 : 0)) - 26);
+  bw_se(w, hv_clip3(0, 51, c->qp + ((pp->type == HV_SLICE_B && !pp->is_ref) ? 2 : 0) - (pp->type == HV_SLICE_I ? 2 : 0)) - 26 - (pps_id ? 3 : 0));
   if (c->slice_cb_off) { bw_se(w, c->slice_cb_off); bw_se(w, -c->slice_cb_off); }
   const int override = c->deblock_off || c->beta || c->tc;
   bw_put(w, (uint32_t)override, 1);
@@ -1298,6 +1308,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
       sample_add_nal(sample, c->nal_length_size, &e->vps);
       sample_add_nal(sample, c->nal_length_size, &e->sps);
       sample_add_nal(sample, c->nal_length_size, &e->pps);
+      if (e->pps1.n) sample_add_nal(sample, c->nal_length_size, &e->pps1);
     }
     free(nal.b);
   }
@@ -1479,7 +1490,7 @@ static void usage(void) {
           "  [--qp 30] [--seed 1] [--fps 30] [--ctb 16|32|64] [--min-tb 4] [--max-tb 32] [--th-intra 1] [--th-inter 1]\n"
           "  [--amp 0] [--sao 0|1|3 (+4: luma off, +8: chroma off)] [--pcm 0|1|2] [--tskip 0] [--bypass 0] [--sdh 0]\n"
           "  [--qp-swing 0|depth+1] [--scaling 0..3] [--wp 0] [--tmvp 1] [--strong 1] [--merge-cand 5] [--pml 2]\n"
-          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2|3] [--inter-rps 0] [--rplm 0] [--keep-unused 0] [--sub-layers 1|2] [--sh-extras 0]\n"
+          "  [--slices 1] [--wpp 0] [--deblock-off 0|1|2] [--beta 0] [--tc 0] [--cip 0] [--rps-sps 0] [--poc-bits 8] [--long-term 0|1|2|3] [--inter-rps 0] [--rplm 0] [--keep-unused 0] [--sub-layers 1|2] [--sh-extras 0] [--multi-pps 0]\n"
           "  [--random-intra 0] [--cabac-init 0|1|2] [--cb-off 0] [--cr-off 0] [--slice-cb-off 0] [--nal-length-size 4]\n"
           "  [--extra-nals 0] [--bpyramid 0] [--lf-across 1] [--mvd-l1-zero 0] [--hvc1 0] [--intra-only 0] [--cover 0]\n");
 }
@@ -1496,7 +1507,7 @@ int main(int argc, char** argv) {
   A(pml, "--pml", 2); A(slices, "--slices", 1); A(wpp, "--wpp", 0); A(deblock_off, "--deblock-off", 0); A(beta, "--beta", 0);
   A(tc, "--tc", 0); A(cip, "--cip", 0); A(rps_sps, "--rps-sps", 0); A(poc_bits, "--poc-bits", 8); A(random_intra, "--random-intra", 0);
   A(cabac_init, "--cabac-init", 0); A(cb_off, "--cb-off", 0); A(cr_off, "--cr-off", 0); A(slice_cb_off, "--slice-cb-off", 0);
-  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0); A(inter_rps, "--inter-rps", 0); A(rplm, "--rplm", 0); A(keep_unused, "--keep-unused", 0); A(sub_layers, "--sub-layers", 1); A(sh_extras, "--sh-extras", 0);
+  A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0); A(inter_rps, "--inter-rps", 0); A(rplm, "--rplm", 0); A(keep_unused, "--keep-unused", 0); A(sub_layers, "--sub-layers", 1); A(sh_extras, "--sh-extras", 0); A(multi_pps, "--multi-pps", 0);
   A(lf_across, "--lf-across", 1); A(mvd_l1_zero, "--mvd-l1-zero", 0); A(hvc1, "--hvc1", 0); A(intra_only, "--intra-only", 0);
   A(cover, "--cover", 0);
 #undef A

@@ -290,4 +290,7 @@ HEVC_MATRIX = [
     # several slices and wavefront rows; the SPS's long-term candidates chosen by lt_idx_sps
     ("sh_extras_slices_wpp", dict(frames=12, gop=6, bframes=2, refs=2, sh_extras=1, slices=3, wpp=1, ctb=16)),
     ("lt_idx_sps_sh_extras", dict(frames=14, gop=14, bframes=1, refs=2, long_term=3, sh_extras=1)),
+    # two picture parameter sets taken in turn (another init_qp, other default list lengths), both in hvcC and repeated in band
+    ("multi_pps", dict(frames=12, gop=6, bframes=2, refs=3, multi_pps=1, extra_nals=1)),
+    ("multi_pps_qpswing", dict(frames=10, gop=10, refs=2, multi_pps=1, qp_swing=2, cabac_init=2)),
 ]
