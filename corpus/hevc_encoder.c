@@ -484,7 +484,7 @@ static int lt_wanted(const Enc* e, const PicPlan* pp) {
 }
 
 /* ---- slice header (7.3.6.1), mirrored by hv_parse_slice_header ---- */
-static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb, const HvRps* rps, int nl0, int nl1) {
+static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb, const HvRps* rps, int nl0, int nl1, int n_entry, const uint32_t* entry) {
   const Cfg* c = &e->c;
   const HvSps* sps = &e->d->sps[0];
   const uint32_t h = hash3(e->h, 0x51, (uint32_t)first_ctb);
@@ -591,10 +591,14 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
     bw_put(w, (uint32_t)c->lf_across, 1);
   }
   if (c->wpp) {
-    /* entry points: the offsets are not known before the slice data is written; rows are found by walking, so a
-     * stream may say "none listed" only if the slice is one row long - this encoder lists none and relies on
-     * decoders that walk (the oracle and the product do); offset_len / entry_point_offset are therefore absent */
-    bw_ue(w, 0);
+    /* entry points (7.3.6.1): the bytes of every wavefront row's substream but the last, emulation prevention bytes
+     * counted, 32 bits each.  They are known once the slice data is written: the header is written twice - without
+     * them for the analysis (which needs a header to parse, not its length), with them for the stream. */
+    bw_ue(w, (uint32_t)n_entry);
+    if (n_entry) {
+      bw_ue(w, 31);
+      for (int i = 0; i < n_entry; ++i) bw_put(w, entry[i] - 1, 32);
+    }
   }
   if (c->sh_extras) { /* slice_segment_header_extension: length, then bytes nobody interprets */
     const int n = (int)((h >> 26) % 4);
@@ -1257,7 +1261,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
   /* analysis, slice by slice */
   for (int k = 0; k < e->n_slices; ++k) {
     BitW w = {0};
-    write_slice_header(e, &w, pp, e->slice_start[k], &rps, nl0, nl1);
+    write_slice_header(e, &w, pp, e->slice_start[k], &rps, nl0, nl1, 0, NULL);
     bput(&hdr_rbsp[k], w.b, w.bits / 8);
     HvBits b = {w.b, w.bits / 8, 0, 0};
     HvSliceHeader sh;
@@ -1319,12 +1323,35 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
     d->slice_idx = k;
     d->enc = 1;
     d->enc_end_ctb = e->slice_start[k + 1];
+    d->enc_nsub = 0;
     hv_cabac_enc_start(&d->ce);
     const int rc = hv_slice_data(d);
     d->enc = 0;
     if (rc) return fprintf(stderr, "slice data walk failed: %s\n", d->error), -1;
     hv_cabac_enc_finish_slice(&d->ce);
     Buf rbsp = {0}, nal = {0};
+    if (c->wpp && d->enc_nsub > 0) {
+      /* the header once more, now with the entry points: a substream's size in the NAL unit, i.e. with the emulation
+         prevention bytes that fall into it (the header ends on its alignment one bit: the count of zeros starts afresh) */
+      uint32_t entry[256];
+      const size_t nbytes = d->ce.nbits / 8;
+      size_t start = 0;
+      int zeros = 0, sub = 0;
+      uint32_t size = 0;
+      for (size_t i = 0; i <= nbytes; ++i) {
+        if (sub < d->enc_nsub && i == d->enc_sub_start[sub]) { entry[sub++] = size; size = 0; start = i; }
+        if (i == nbytes) break;
+        if (zeros >= 2 && d->ce.buf[i] <= 3) { ++size; zeros = 0; }
+        ++size;
+        zeros = d->ce.buf[i] == 0 ? zeros + 1 : 0;
+      }
+      (void)start;
+      BitW w2 = {0};
+      write_slice_header(e, &w2, pp, e->slice_start[k], &rps, nl0, nl1, d->enc_nsub, entry);
+      hdr_rbsp[k].n = 0;
+      bput(&hdr_rbsp[k], w2.b, w2.bits / 8);
+      free(w2.b);
+    }
     bput(&rbsp, hdr_rbsp[k].b, hdr_rbsp[k].n);
     bput(&rbsp, d->ce.buf, d->ce.nbits / 8);
     g_nal_tid_plus1 = (c->sub_layers == 2 && !pp->is_ref && !pp->idr) ? 2 : 1;

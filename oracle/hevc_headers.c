@@ -582,7 +582,10 @@ int hv_parse_slice_header(HevcOracle* d, HvBits* b, int nal_type, HvSliceHeader*
     if (sh->num_entry_points > 0) {
       const int len = 1 + (int)hvb_ue(b);
       if (len > 32) return hv_fail(d, "offset_len_minus1 %d", len - 1), -1;
-      for (int i = 0; i < sh->num_entry_points; ++i) hvb_u(b, len); /* (the walk finds the rows by itself) */
+      for (int i = 0; i < sh->num_entry_points; ++i) {
+        const uint32_t v = hvb_u(b, len) + 1;
+        if (i < 256) sh->entry_point[i] = v;   /* (the walk finds the rows by itself, and compares: hv_slice_data) */
+      }
     }
   }
   if (pps->slice_header_extension_present) {

@@ -129,6 +129,7 @@ typedef struct {
   int qp_delta, cb_qp_offset, cr_qp_offset;
   int deblocking_disabled, beta_offset_div2, tc_offset_div2, loop_filter_across_slices;
   int num_entry_points;
+  uint32_t entry_point[256]; /* entry_point_offset_minus1 + 1 of the first 256: checked against the rows the walk finds */
   /* derived */
   int slice_qp, slice_addr_rs; /* SliceAddrRs: address of the first CTB of the (independent) slice */
   size_t data_byte_offset;     /* of slice_segment_data() within the RBSP */
@@ -296,6 +297,8 @@ struct HevcOracle {
   int recon_next;  /* units [recon_next, num_cu) have been parsed but not reconstructed (a slice at a time) */
   int walk_cu;     /* enc: next unit of the plan (d->cus) the walk writes */
   int enc_end_ctb; /* enc: address of the coding tree block behind the slice's last one */
+  int enc_nsub;    /* enc, wavefront rows: the substreams begun after the slice's first ... */
+  size_t enc_sub_start[256]; /* ... and the byte of the slice data each begins at (the encoder's entry points) */
   int greater1_state; /* c1 of 9.3.4.2.6 carried across sub-blocks */
   /* expected picture hash (SEI), -1 = none */
   int have_md5;

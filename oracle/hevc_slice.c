@@ -1444,6 +1444,8 @@ int hv_slice_data(HevcOracle* d) {
   d->is_cu_qp_delta_coded = 0;
   d->cu_qp_delta_val = 0;
   int addr = sh->segment_address;
+  size_t wpp_sub_start = d->enc ? 0 : d->sh.data_byte_offset;  /* dec: where the current wavefront substream began */
+  int wpp_zeros = 0, wpp_sub = 0;
   for (;;) {
     const int rx = addr % s->width_ctb, ry = addr / s->width_ctb;
     d->ctb_addr_rs = addr;
@@ -1471,10 +1473,28 @@ int hv_slice_data(HevcOracle* d) {
       if (!cterm(d, 1)) return hv_fail(d, "end_of_subset_one_bit is not set at the end of row %d", ry), -1;
       if (d->enc) {
         while (d->ce.nbits & 7) ce_write(&d->ce, 0);
+        if (d->enc_nsub < 256) d->enc_sub_start[d->enc_nsub++] = d->ce.nbits / 8;
         ce_init_engine(&d->ce);
       } else {
         while (d->cd.pos & 7)
           if (cd_bit(&d->cd)) return hv_fail(d, "wavefront substream does not end on zero alignment bits"), -1;
+        /* a slice header that lists entry points must list THIS one: the substream just ended is entry_point_offset
+           bytes long in the NAL unit - the bytes here plus the emulation prevention bytes that were taken out of it
+           (7.4.7.1; the zero count starts afresh behind the header's alignment bit, and runs on across substreams) */
+        if (d->sh.num_entry_points > 0) {
+          const size_t end = d->cd.pos >> 3;
+          uint32_t size = 0;
+          for (size_t i = wpp_sub_start; i < end; ++i) {
+            if (wpp_zeros >= 2 && d->cd.p[i] <= 3) { ++size; wpp_zeros = 0; }
+            ++size;
+            wpp_zeros = d->cd.p[i] == 0 ? wpp_zeros + 1 : 0;
+          }
+          if (wpp_sub >= d->sh.num_entry_points) return hv_fail(d, "more wavefront rows than the slice header's %d entry points", d->sh.num_entry_points), -1;
+          if (wpp_sub < 256 && d->sh.entry_point[wpp_sub] != size)
+            return hv_fail(d, "entry point %d says %u bytes, the substream is %u", wpp_sub, d->sh.entry_point[wpp_sub], size), -1;
+          ++wpp_sub;
+          wpp_sub_start = end;
+        }
         cd_init_engine(&d->cd);
       }
     }
