@@ -163,3 +163,37 @@ def test_corrupt_streams_never_hang_the_gpu(hw, oracle, gpu, tmp_path, name):
     got = hw.Decoder(path, video_index=idx, num_lanes=2).retrieve_yuv(list(range(nf)))
     for i in range(nf):
         assert np.array_equal(got[i], gold[i])
+
+
+def test_frames_into_hbm_and_into_page_locked_memory(hw, oracle, gpu, tmp_path):
+    """The three kinds of destination get_frame may be handed (hevc_video_decoder.cpp: take): HBM - the conversion kernel
+    writes it -, page-locked host memory - the D2H copy writes it, also at an offset into the allocation -, pageable
+    memory - through a bounce buffer.  The same bytes in all three, RGB and I420."""
+    torch = gpu
+    path = str(tmp_path / "dst.mp4")
+    w, h = 176, 144
+    gold = make_hevc_clip(path, width=w, height=h, frames=24, gop=12, bframes=2, refs=2, sao=1, ctb=32)
+    idx = hw.index_video(path)
+    rows = [1, 2, 5, 11, 12, 17, 23]
+    frame = w * h * 3
+    dec = hw.Decoder(path, video_index=idx, num_lanes=2)
+    want = np.stack([oracle.i420_to_rgb(gold[r], w, h) for r in rows])
+    dev = torch.zeros((len(rows), h, w, 3), dtype=torch.uint8, device="cuda")
+    dec.retrieve_into(rows, dev.data_ptr(), dev.numel())
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), want)
+    pinned = torch.zeros((len(rows) + 1) * frame, dtype=torch.uint8, pin_memory=True)
+    dec.retrieve_into(rows, pinned.data_ptr() + frame, len(rows) * frame)
+    assert not pinned.numpy()[:frame].any()
+    assert np.array_equal(pinned.numpy()[frame:].reshape(want.shape), want)
+    assert np.array_equal(np.stack(dec.retrieve(rows)), want)
+    # I420 into HBM (three strided device-to-device copies) and into page-locked memory
+    yframe = w * h * 3 // 2
+    dev_yuv = torch.zeros(len(rows) * yframe, dtype=torch.uint8, device="cuda")
+    dec.retrieve_into(rows, dev_yuv.data_ptr(), dev_yuv.numel(), yuv=True)
+    torch.cuda.synchronize()
+    pin_yuv = torch.zeros(len(rows) * yframe, dtype=torch.uint8, pin_memory=True)
+    dec.retrieve_into(rows, pin_yuv.data_ptr(), pin_yuv.numel(), yuv=True)
+    for k, r in enumerate(rows):
+        assert np.array_equal(dev_yuv.cpu().numpy()[k * yframe:(k + 1) * yframe], gold[r]), "I420 in HBM, row %d" % r
+        assert np.array_equal(pin_yuv.numpy()[k * yframe:(k + 1) * yframe], gold[r]), "I420 page-locked, row %d" % r
