@@ -70,6 +70,19 @@ def test_1080p_and_cropping(hw, oracle, gpu, tmp_path):
         assert np.array_equal(got[i], gold[i]), "frame %d" % i
 
 
+def test_2160p(hw, oracle, gpu, tmp_path):
+    """3840x2160 (coded 3840x2160; the last row of 64x64 blocks is cut at 48 rows): 4 096-byte surface pitch, 2 040 coding
+    tree blocks, staging sets above the size that gets five of them (three then), the kernels' grids at four times the
+    bench clip's area."""
+    path = str(tmp_path / "uhd.mp4")
+    gold = make_hevc_clip(path, width=3840, height=2160, frames=3, gop=3, bframes=1, refs=2, ctb=64, sao=1, amp=1, qp=36)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=1)
+    got = dec.retrieve_yuv([0, 1, 2])
+    for i in range(3):
+        assert np.array_equal(got[i], gold[i]), "frame %d" % i
+
+
 def test_h264_after_hevc_on_one_decoder_object(hw, oracle, gpu, tmp_path):
     """configure() switches halves: the same automata decodes an HEVC clip, then an H.264 clip, then HEVC again."""
     from tests.corpus_util import make_clip
