@@ -293,4 +293,8 @@ HEVC_MATRIX = [
     # two picture parameter sets taken in turn (another init_qp, other default list lengths), both in hvcC and repeated in band
     ("multi_pps", dict(frames=12, gop=6, bframes=2, refs=3, multi_pps=1, extra_nals=1)),
     ("multi_pps_qpswing", dict(frames=10, gop=10, refs=2, multi_pps=1, qp_swing=2, cabac_init=2)),
+    # the smallest pictures: one coding tree block that the picture does not fill, a single row / column of blocks
+    ("tiny_8x8", dict(width=8, height=8, frames=5, gop=5, bframes=1, refs=2, ctb=16, sao=1)),
+    ("tiny_row_264x8", dict(width=264, height=8, frames=5, gop=5, bframes=1, refs=2, ctb=64, sao=1, amp=1)),
+    ("tiny_column_16x136", dict(width=16, height=136, frames=5, gop=5, bframes=1, refs=2, ctb=16, sao=1, wpp=1)),
 ]
