@@ -8,7 +8,7 @@
 //   IntraTu    one intra-predicted transform block per colour plane, in decoding order (8.4.4.2): k_hevc_intra_rows
 //              walks them as a wavefront of coding tree block rows (intra pictures), k_hevc_intra_flow takes them by
 //              ticket and lets each wait for exactly the neighbouring blocks it reads (scattered intra blocks)
-//   edge maps  per 4x4 luma block: boundary strengths of its left / top edge (or "compare the motion"), QpY, "leave alone" flag:
+//   edge maps  per 4x4 luma block: which of its sides are block edges that may be filtered, levels / intra, QpY, "leave alone" flag:
 //              k_hevc_deblock (8.7.2), k_hevc_sao (8.7.3, with SaoCtb per coding tree block)
 // Surfaces are planar I420 of the coded size; luma pitch a multiple of 256 bytes, chroma pitch half of it.
 #pragma once
@@ -84,13 +84,21 @@ struct SliceLoop {       // per slice: what the in-loop filters need
   uint32_t first_ctb;             // SliceAddrRs
 };
 
-// per 4x4 luma block (EdgeInfo[w4 * h4])
+// per 4x4 luma block (EdgeInfo[w4 * h4]): what the in-loop filters need to know about the block.  The boundary
+// strengths (8.7.2.4) are derived by k_hevc_deblock from the two blocks either side of an 8x8-grid edge: 2 if either is
+// intra, 1 at a transform block edge with levels on either side, else by the motion of the two prediction blocks.
 struct EdgeInfo {
-  uint8_t bs;      // bits 0-1: strength of the left edge, bits 2-3: of the top edge; 3: an edge between two prediction blocks
-                   // with nothing else to decide it - k_hevc_deblock compares their motion (8.7.2.4, the last rule) itself
+  uint8_t edge;    // EDGE_*
   int8_t qp;       // QpY
   uint8_t flags;   // bit 0: pcm with the loop filter off / transquant bypass: the in-loop filters leave the samples alone
   uint8_t slice;   // index into SliceLoop
+};
+enum : uint8_t {
+  EDGE_TU_LEFT = 1, EDGE_PU_LEFT = 2,   // the block's left side is a transform / prediction block edge
+  EDGE_TU_TOP = 4, EDGE_PU_TOP = 8,
+  EDGE_ON_LEFT = 16, EDGE_ON_TOP = 32,  // ... and may be filtered (deblocking on in the slice; not a picture edge, not a slice edge the flags exclude)
+  EDGE_LEVELS = 64,                     // the block's transform block has levels
+  EDGE_INTRA = 128
 };
 
 struct Surface {

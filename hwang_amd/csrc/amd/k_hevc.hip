@@ -677,15 +677,19 @@ __global__ __launch_bounds__(256) void k_hevc_deblock(const Batch batch, int dir
   if (i >= w4 * h4) return;
   const int x = i % w4, y = i / w4;
   const EdgeInfo e = pp.edges[i];
-  int bs = dir ? (e.bs >> 2) & 3 : e.bs & 3;
-  if (!bs) return;
-  if (bs == 3) {
-    const uint32_t pj = pp.pu_map[dir ? i - w4 : i - 1], pq = pp.pu_map[i];
-    if (pj == pq) return;
-    bs = motion_bs(pp.pus[pj], pp.pus[pq]);
-    if (!bs) return;
-  }
+  // an edge of the 8x8 grid that is a transform or prediction block edge and may be filtered
+  if (((dir ? y : x) & 1) || !(e.edge & (dir ? EDGE_ON_TOP : EDGE_ON_LEFT))) return;
   const EdgeInfo p = pp.edges[dir ? i - w4 : i - 1];
+  int bs;  // 8.7.2.4
+  if ((e.edge | p.edge) & EDGE_INTRA) {
+    bs = 2;
+  } else if ((e.edge & (dir ? EDGE_TU_TOP : EDGE_TU_LEFT)) && ((e.edge | p.edge) & EDGE_LEVELS)) {
+    bs = 1;
+  } else {
+    const uint32_t pj = pp.pu_map[dir ? i - w4 : i - 1], pq = pp.pu_map[i];
+    if (pj == pq || !motion_bs(pp.pus[pj], pp.pus[pq])) return;
+    bs = 1;
+  }
   const SliceLoop sl = pp.slices[e.slice];
   const int qpl = (e.qp + p.qp + 1) >> 1;
   const bool no_p = p.flags & 1, no_q = e.flags & 1;

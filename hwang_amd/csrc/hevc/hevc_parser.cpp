@@ -535,6 +535,7 @@ struct Parser::Impl {
   PicDone done;
   int w4 = 0, h4 = 0;
   int next_ctb = 0;  // the picture's coding tree blocks before this address are decoded
+  bool pic_deblock = false;  // a coding unit of the picture lies in a slice with the deblocking filter on
   int pic_w = 0, pic_h = 0, pic_lc = 0, pic_wctb = 0, pic_zmask = 0;  // the active SPS's, where every neighbour test wants them
   std::vector<uint8_t> m_pred, m_skip, m_depth, m_mode, m_flags, m_nz, m_edge;
   std::vector<int8_t> m_qp;
@@ -1093,6 +1094,7 @@ struct Parser::Impl {
     slice_addr.clear();
     num_slices = 0;
     next_ctb = 0;
+    pic_deblock = false;
     if (!motion_pool.empty()) {
       cur->pu_of = std::move(motion_pool.back());
       motion_pool.pop_back();
@@ -1132,43 +1134,8 @@ struct Parser::Impl {
     if (done.num_ref_slots < amd::hevc::kMaxSurfaces) done.ref_slots[done.num_ref_slots++] = slot;
   }
 
-  // 8.7.2.4: boundary strengths of every 8x8-grid edge that is a transform or prediction block edge and may be filtered:
-  // 2 beside an intra block, 1 at a transform block edge with levels on either side, else - between two different
-  // prediction blocks - 3: the deblocking kernel compares their motion (it has the prediction block records)
   bool close_picture() {
-    // the strengths of the edges that may be filtered (QpY / flags / slice of every block were written with its unit)
-    bool any_bs = false;
-    for (int y = 0; y < h4; ++y) {
-      EdgeInfo* erow = &buf.edges[static_cast<size_t>(y) * w4];
-      const uint8_t* edge = &m_edge[static_cast<size_t>(y) * w4];
-      for (int x = 0; x < w4; ++x) {
-        if (!(x & 7) && x + 8 <= w4) {  // eight blocks without an edge that may be filtered: most of a picture of large units
-          uint64_t eight;
-          std::memcpy(&eight, edge + x, 8);
-          if (!(eight & 0x3030303030303030ull)) {
-            x += 7;
-            continue;
-          }
-        }
-        const uint8_t eg = edge[x];
-        if (!(eg & 48)) continue;
-        const int i = y * w4 + x;
-        int bs[2] = {0, 0};
-        for (int dir = 0; dir < 2; ++dir) {
-          if (((dir ? y : x) & 1) || !(eg & (dir ? 32 : 16))) continue;
-          const int j = dir ? i - w4 : i - 1;
-          if (m_pred[i] == 2 || m_pred[j] == 2) bs[dir] = 2;
-          else if ((eg & (dir ? 4 : 1)) && (m_nz[i] || m_nz[j])) bs[dir] = 1;
-          else {
-            const uint32_t pj = cur->pu_of[j], pi = cur->pu_of[i];
-            bs[dir] = pj == pi ? 0 : 3;
-          }
-        }
-        erow[x].bs = static_cast<uint8_t>(bs[0] | bs[1] << 2);
-        any_bs |= erow[x].bs != 0;
-      }
-    }
-    done.deblock = any_bs;
+    done.deblock = pic_deblock;  // (some slice has the deblocking filter on; which edges, how strongly: k_hevc_deblock)
     done.num_slices = num_slices;
     // the per-plane intra lists are complete: the per-block counts become offsets
     {
@@ -1932,6 +1899,7 @@ struct Parser::Impl {
       if (left && !sl.across && !zavail(x0, y0, x0 - 1, y0)) left = false;
       if (top && !sl.across && !zavail(x0, y0, x0, y0 - 1)) top = false;
       const bool on = !sh.db_off;
+      pic_deblock = pic_deblock || on;
       edge_on_v = on ? 16 : 0;
       edge_on_h = on ? 32 : 0;
       for (int k = 0; k < n; k += 4) {
@@ -2015,15 +1983,19 @@ struct Parser::Impl {
       }
     }
     {
+      // the unit is complete: what the in-loop filters need to know about each of its 4x4 blocks - which sides are block
+      // edges that may be filtered (m_edge, collected while the unit was parsed), levels, intra, QpY.  The boundary
+      // strengths themselves are the deblocking kernel's business (8.7.2.4 needs nothing but these and the motion).
       EdgeInfo e;
-      e.bs = 0;
       e.qp = static_cast<int8_t>(cu.qp);
       e.flags = (cu.bypass || (cu.pcm && S->pcm_lf_off)) ? 1 : 0;
       e.slice = static_cast<uint8_t>(slice_idx);
+      const uint8_t intra_bit = cu.intra ? amd::hevc::EDGE_INTRA : 0;
       for (int y = y0; y < y0 + n; y += 4)
         for (int x = x0; x < x0 + n; x += 4) {
           const int i = (y >> 2) * w4 + (x >> 2);
           m_qp[i] = static_cast<int8_t>(cu.qp);
+          e.edge = static_cast<uint8_t>(m_edge[i] | (m_nz[i] ? amd::hevc::EDGE_LEVELS : 0) | intra_bit);
           buf.edges[i] = e;
         }
     }

@@ -321,8 +321,8 @@ struct CpuSink : public hevc::PictureSink {
     }
     // deblocking: all vertical edges, then all horizontal ones
     const int w4 = W / 4, h4 = H / 4;
-    // an edge marked 3 lies between two prediction blocks and nothing but their motion decides it (8.7.2.4's last rule:
-    // another reference picture or number of vectors, or a component a whole sample apart)
+    // which prediction block covers a 4x4 block (8.7.2.4's last rule compares the motion of the two sides of an edge: another
+    // reference picture or number of vectors, or a component a whole sample apart)
     std::vector<uint32_t> pu_of(static_cast<size_t>(w4) * h4, 0);
     for (size_t t = 0; t < d.num_pus; ++t)
       for (int yy = 0; yy < pus[t].h; yy += 4)
@@ -348,13 +348,19 @@ struct CpuSink : public hevc::PictureSink {
         for (int y = 0; y < h4; ++y)
           for (int x = 0; x < w4; ++x) {
             const gh::EdgeInfo& e = edges[static_cast<size_t>(y) * w4 + x];
-            int bs = dir ? (e.bs >> 2) & 3 : e.bs & 3;
-            if (!bs) continue;
-            if (bs == 3) {
+            // 8.7.2.4 from what the records say about the two blocks either side: only edges of the 8x8 grid that are block
+            // edges and may be filtered; intra on either side: 2; a transform block edge with levels on either side: 1;
+            // else the motion of the two prediction blocks decides
+            if (((dir ? y : x) & 1) || !(e.edge & (dir ? gh::EDGE_ON_TOP : gh::EDGE_ON_LEFT))) continue;
+            const gh::EdgeInfo& nb = edges[static_cast<size_t>(dir ? (y - 1) * w4 + x : y * w4 + x - 1)];
+            int bs = 0;
+            if ((e.edge & gh::EDGE_INTRA) || (nb.edge & gh::EDGE_INTRA)) bs = 2;
+            else if ((e.edge & (dir ? gh::EDGE_TU_TOP : gh::EDGE_TU_LEFT)) && ((e.edge & gh::EDGE_LEVELS) || (nb.edge & gh::EDGE_LEVELS))) bs = 1;
+            else {
               const uint32_t pq = pu_of[static_cast<size_t>(y) * w4 + x], pp_ = pu_of[static_cast<size_t>(dir ? (y - 1) * w4 + x : y * w4 + x - 1)];
-              if (pq == pp_ || !motion_differs(pus[pp_], pus[pq])) continue;
-              bs = 1;
+              if (pq != pp_ && motion_differs(pus[pp_], pus[pq])) bs = 1;
             }
+            if (!bs) continue;
             const gh::EdgeInfo& p = edges[static_cast<size_t>(dir ? (y - 1) * w4 + x : y * w4 + x - 1)];
             const gh::SliceLoop& sl = slices[e.slice];
             const int qpl = (e.qp + p.qp + 1) >> 1;

@@ -22,7 +22,8 @@ ITU = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2", "u1"), ("mode", "u1"), ("fl
                 ("wait_left", "<u4"), ("wait_top", "<u4")])
 SAO = np.dtype([("type", "u1", 3), ("band_pos", "u1", 3), ("eo_class", "u1", 3), ("offset", "i1", (3, 4)), ("pad", "u1", 3)])
 SLICE = np.dtype([("beta", "i1"), ("tc", "i1"), ("across", "u1"), ("sao_luma", "u1"), ("sao_chroma", "u1"), ("pad", "u1", 3), ("first_ctb", "<u4")])
-EDGE = np.dtype([("bs", "u1"), ("qp", "i1"), ("flags", "u1"), ("slice", "u1")])
+EDGE = np.dtype([("edge", "u1"), ("qp", "i1"), ("flags", "u1"), ("slice", "u1")])
+E_TU_LEFT, E_PU_LEFT, E_TU_TOP, E_PU_TOP, E_ON_LEFT, E_ON_TOP, E_LEVELS, E_INTRA = 1, 2, 4, 8, 16, 32, 64, 128   # hevc_frame_job.h: EDGE_*
 assert (RES.itemsize, PU.itemsize, WT.itemsize, ITU.itemsize, SAO.itemsize, SLICE.itemsize, EDGE.itemsize) == (20, 24, 16, 24, 24, 12, 4)
 
 
@@ -263,9 +264,25 @@ def test_deblocking_kernel(hw):
         edges = np.zeros((h4, w4), dtype=EDGE)
         edges["qp"] = np.kron(rnd.integers(15, 50, (h4 // 2, w4 // 2)), np.ones((2, 2), dtype=int))
         edges["flags"] = (rnd.integers(0, 12, (h4, w4)) == 0)
-        bsv = rnd.integers(0, 3, (h4, w4)) * (np.arange(w4)[None, :] % 2 == 0) * (np.arange(w4)[None, :] > 0)
-        bsh = rnd.integers(0, 3, (h4, w4)) * (np.arange(h4)[:, None] % 2 == 0) * (np.arange(h4)[:, None] > 0)
-        edges["bs"] = bsv | bsh << 2
+        # what the host says about each 4x4 block (per 8x8 block: intra or not, levels or not; per side: a transform block
+        # edge or only a prediction block edge, filtered or not) - the kernel derives the strengths (8.7.2.4), and so
+        # does this test: 2 beside an intra block, 1 at a transform block edge with levels on either side, else 0 (no
+        # prediction block records here: both sides are "the same block")
+        intra = np.kron(rnd.integers(0, 10, (h4 // 2, w4 // 2)) < 3, np.ones((2, 2), dtype=int)).astype(bool)
+        levels = np.kron(rnd.integers(0, 2, (h4 // 2, w4 // 2)), np.ones((2, 2), dtype=int)).astype(bool)
+        on_l = (rnd.integers(0, 10, (h4, w4)) < 8) & (np.arange(w4)[None, :] > 0)
+        on_t = (rnd.integers(0, 10, (h4, w4)) < 8) & (np.arange(h4)[:, None] > 0)
+        tu_l, tu_t = rnd.integers(0, 10, (h4, w4)) < 7, rnd.integers(0, 10, (h4, w4)) < 7
+        edges["edge"] = (on_l * E_ON_LEFT | on_t * E_ON_TOP | tu_l * E_TU_LEFT | ~tu_l * E_PU_LEFT | tu_t * E_TU_TOP | ~tu_t * E_PU_TOP |
+                         levels * E_LEVELS | intra * E_INTRA).astype(np.uint8)
+        bsv, bsh = np.zeros((h4, w4), dtype=int), np.zeros((h4, w4), dtype=int)
+        for by in range(h4):
+            for bx in range(w4):
+                if on_l[by, bx] and bx % 2 == 0:
+                    bsv[by, bx] = 2 if intra[by, bx] or intra[by, bx - 1] else 1 if tu_l[by, bx] and (levels[by, bx] or levels[by, bx - 1]) else 0
+                if on_t[by, bx] and by % 2 == 0:
+                    bsh[by, bx] = 2 if intra[by, bx] or intra[by - 1, bx] else 1 if tu_t[by, bx] and (levels[by, bx] or levels[by - 1, bx]) else 0
+        assert (bsv == 1).any() and (bsv == 2).any() and (bsh == 1).any() and (bsh == 2).any()
         slices = np.array([(2 * int(rnd.integers(-3, 4)), 2 * int(rnd.integers(-3, 4)), 1, 1, 1, [0, 0, 0], 0)], dtype=SLICE)
         cb_off, cr_off = int(rnd.integers(-6, 7)), int(rnd.integers(-6, 7))
         # numpy: all vertical edges, then all horizontal ones (8.7.2)
@@ -311,7 +328,8 @@ def test_deblocking_kernel(hw):
 
 
 def test_deblocking_motion_rule(hw):
-    """Edges marked 3: k_hevc_deblock decides them from the two prediction blocks' motion (8.7.2.4's last rule).  A
+    """Prediction block edges with no levels and nothing intra beside them: k_hevc_deblock decides them from the two
+    prediction blocks' motion (8.7.2.4's last rule).  A
     picture of 8x8 prediction blocks over two flat reference pictures (a block's prediction is a constant whatever its
     vector: 100, 140 or their mean 120), vectors / references / lists drawn from a few values so that every case of the
     rule occurs; the expected picture is numpy's filter over the strengths this test derives from the rule's text."""
@@ -357,9 +375,9 @@ def test_deblocking_motion_rule(hw):
             y[by * 8:by * 8 + 8, bx * 8:bx * 8 + 8] = lv
         edges = np.zeros((h4, w4), dtype=EDGE)
         edges["qp"] = 38
-        bsv = np.where((np.arange(w4)[None, :] % 2 == 0) & (np.arange(w4)[None, :] > 0), 3, 0) * np.ones((h4, 1), dtype=int)
-        bsh = np.where((np.arange(h4)[:, None] % 2 == 0) & (np.arange(h4)[:, None] > 0), 3, 0) * np.ones((1, w4), dtype=int)
-        edges["bs"] = bsv | bsh << 2
+        bsv = np.where((np.arange(w4)[None, :] % 2 == 0) & (np.arange(w4)[None, :] > 0), 1, 0) * np.ones((h4, 1), dtype=int)   # prediction block edges
+        bsh = np.where((np.arange(h4)[:, None] % 2 == 0) & (np.arange(h4)[:, None] > 0), 1, 0) * np.ones((1, w4), dtype=int)
+        edges["edge"] = (bsv * (E_PU_LEFT | E_ON_LEFT) | bsh * (E_PU_TOP | E_ON_TOP)).astype(np.uint8)   # no levels, nothing intra: the motion decides
         slices = np.array([(0, 0, 1, 1, 1, [0, 0, 0], 0)], dtype=SLICE)
         want = y.copy()
         filtered = 0
