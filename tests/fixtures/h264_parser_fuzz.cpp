@@ -124,6 +124,20 @@ struct CheckingSink : public h264::PictureSink {
       if (m.kind == amd::MBK_I4x4 || m.kind == amd::MBK_I8x8)
         for (int k = 0; k < 16; ++k) check(((m.i4_modes[k >> 1] >> (4 * (k & 1))) & 15) <= 8, "Intra4x4 / 8x8 mode", k);
       check(m.mv_shape <= 3, "partition shape", m.mv_shape);
+      {  // neighbours the kernels read on the strength of these flags must exist
+        const int mbx = static_cast<int>(i % static_cast<size_t>(mbw)), mby = static_cast<int>(i / static_cast<size_t>(mbw));
+        const bool a = mbx > 0, b = mby > 0, c = mby > 0 && mbx < mbw - 1, dd = mbx > 0 && mby > 0;
+        check(!(m.flags & amd::MBF_AVAIL_A) || a, "left neighbour outside the picture", mbx, mby);
+        check(!(m.flags & amd::MBF_AVAIL_B) || b, "top neighbour outside the picture", mbx, mby);
+        check(!(m.flags & amd::MBF_AVAIL_C) || c, "top-right neighbour outside the picture", mbx, mby);
+        check(!(m.flags & amd::MBF_AVAIL_D) || dd, "top-left neighbour outside the picture", mbx, mby);
+        check(!(m.flags & amd::MBF_DB_LEFT) || a, "left edge filtered at the picture's edge", mbx, mby);
+        check(!(m.flags & amd::MBF_DB_TOP) || b, "top edge filtered at the picture's edge", mbx, mby);
+        check(!(m.mv_flags & amd::MVF_AVAIL_A) || a, "left vector neighbour outside the picture", mbx, mby);
+        check(!(m.mv_flags & amd::MVF_AVAIL_B) || b, "top vector neighbour outside the picture", mbx, mby);
+        check(!(m.mv_flags & amd::MVF_AVAIL_C) || c, "top-right vector neighbour outside the picture", mbx, mby);
+        check(!(m.mv_flags & amd::MVF_AVAIL_D) || dd, "top-left vector neighbour outside the picture", mbx, mby);
+      }
       // motion
       if (compact && (i % static_cast<size_t>(mbw)) == 0 && d.compact_motion) {
         px = pmx[d.slot][i / static_cast<size_t>(mbw)];
