@@ -1,20 +1,27 @@
-// HIP kernels of the HEVC path for gfx950 (wave64): one picture's records (hevc_frame_job.h) -> samples.
+// HIP kernels of the HEVC path for gfx950 (wave64): the records of a BATCH of pictures (hevc_frame_job.h: up to 32 pictures
+// of different decoders per launch, hevc_engine.cpp) -> samples.
 //
+//   k_hevc_clear      the words the intra kernels count in, zeroed.
 //   k_hevc_residual   8.6.3 scaling + 8.6.4 inverse transforms (DCT 4..32, DST 4x4, transform skip, bypass): one
 //                     wavefront per transform block, coefficients scattered into LDS, both matrix passes out of LDS,
-//                     the residual written to the int16 residual planes (zeroed per picture).
+//                     the residual written to the int16 residual planes (zero between pictures: readers clear them).
 //   k_hevc_inter      8.5.3.3 fractional sample interpolation (8-tap luma, 4-tap chroma, references clamped to the
-//                     picture), default and explicit weighting, + residual: one workgroup per prediction block.
+//                     picture), default and explicit weighting, + residual: one workgroup per prediction block, the
+//                     reference window staged in LDS, separable passes; an eighth of a picture's blocks per XCD.
 //   k_hevc_intra_*    8.4.4.2 intra prediction (substitution, [1 2 1] / strong smoothing, planar, DC, 33 angles, edge
 //                     filters, I_PCM) + residual, one wavefront per block at a time.  _rows: a wavefront of coding tree
-//                     block rows per colour plane (intra pictures); _flow: blocks taken by ticket, each waiting for
-//                     exactly the neighbouring units it reads (the scattered intra blocks of P / B pictures).
-//   k_hevc_deblock    8.7.2.5: one thread per 4-sample edge segment, all vertical edges of the picture, then (a second
-//                     launch) all horizontal ones - HEVC's filter is defined that way, nothing is serial in it.
-//   k_hevc_sao        8.7.3: band / edge offsets from the deblocked picture into the DPB surface.
-// These are byte stencils bound by HBM and, for k_hevc_intra_rows, by the dependent chain along a block row; no MFMA.
+//                     block rows per colour plane, working out of an LDS tile (intra pictures); _flow: coding tree blocks
+//                     taken by ticket, a block waiting for exactly the neighbouring units in OTHER coding tree blocks
+//                     that it reads (the scattered intra blocks of P / B pictures).
+//   k_hevc_deblock    8.7.2: boundary strengths from the blocks' properties and the prediction block records, then one
+//                     thread per 4-sample edge segment, all vertical edges of the picture, then (a second launch) all
+//                     horizontal ones - HEVC's filter is defined that way, nothing is serial in it.
+//   k_hevc_sao        8.7.3: band / edge offsets from the deblocked picture into the DPB surface, four samples a thread,
+//                     a band of rows per XCD.
+// These are byte stencils bound by HBM and, for the intra kernels, by the dependent chain of blocks; no MFMA.
 // What they compute is checked bit for bit against the CPU oracle and against the numpy statements of
-// tests/hevc_numpy.py (tests/test_gpu_hevc.py).  HEVC parity with FFmpeg is unpinned.
+// tests/hevc_numpy.py (tests/test_gpu_hevc.py, tests/test_gpu_hevc_kernels.py).  HEVC parity with FFmpeg is unpinned
+// (DESIGN.md section 5a).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
