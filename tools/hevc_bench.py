@@ -129,7 +129,7 @@ def cpu_baseline(blob, idx, rows, workers=16, max_gops=32):
                       "decoders, reference semantics (whole GOP decoded), %.1f s" % (len(gops), sum(r["fed"] for r in res), sum(r["returned"] for r in res), workers, busy)}, md5
 
 
-def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, steps=3, fraction=0.01, workdir="/tmp/hwang_hevc_bench", cpu=False):
+def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, steps=3, fraction=0.01, workdir="/tmp/hwang_hevc_bench", cpu=False, soak=None):
     import ctypes as C
     import numpy as np
     import hwang_amd as hw
@@ -148,6 +148,12 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
         times.append(time.perf_counter() - t)
         assert len(out) == len(rows) and out[0].shape == (height, width, 3)
         st = dec.stats()
+        if soak is not None:   # (every call must return the very same frames: the engine's batches differ from call to call)
+            import hashlib
+            h = hashlib.md5()
+            for f in out:
+                h.update(f.tobytes())
+            soak.append(h.hexdigest())
         hc = (C.c_int64 * 4)()
         hw._capi.lib.hwang_retriever_host_counters(dec._get_retriever(), hc)
         if cpu and cpu is not True:
@@ -195,6 +201,7 @@ if __name__ == "__main__":
         cpu_worker(sys.argv[2])
         sys.exit(0)
     ap = argparse.ArgumentParser()
+    ap.add_argument("--soak", action="store_true", help="hash the frames of every call: all calls must return the same")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time the CPU oracle on a sample of the request and compare its frames")
     ap.add_argument("--frames", type=int, default=7200)
     ap.add_argument("--gops", type=int, default=8)
@@ -205,4 +212,10 @@ if __name__ == "__main__":
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     a = ap.parse_args()
-    print(json.dumps(run(width=a.width, height=a.height, gops=a.gops, gop=a.gop, frames=a.frames, lanes=a.lanes, steps=a.steps, fraction=a.fraction, cpu=a.cpu_baseline)))
+    digests = [] if a.soak else None
+    res = run(width=a.width, height=a.height, gops=a.gops, gop=a.gop, frames=a.frames, lanes=a.lanes, steps=a.steps, fraction=a.fraction, cpu=a.cpu_baseline,
+              soak=digests)
+    if a.soak:
+        res["soak"] = {"calls": len(digests), "distinct_digests": len(set(digests)), "digest": digests[0]}
+        assert len(set(digests)) == 1, "calls returned different frames: %s" % digests
+    print(json.dumps(res))
