@@ -18,7 +18,8 @@ namespace hevc {
 hipError_t launch_batch(const PicParams* const* pp, const Batch& batch, int n, hipStream_t stream);
 
 namespace {
-constexpr size_t kBatchesInFlight = 2;  // per stream: one running, one queued behind it; the third is being collected
+// batches in flight per stream: one running, one queued behind it; the third is being collected
+constexpr size_t kBatchesInFlightDefault = 2;
 std::mutex g_engines_mu;
 std::map<int, std::weak_ptr<Engine>> g_engines;
 }  // namespace
@@ -111,7 +112,16 @@ void Engine::run() {
     }
     return e;
   };
-  std::vector<EngineJob*> pictures[2], outputs;
+  // (experiment knobs: how many of the light / heavy streams are used, how many batches each keeps in flight)
+  auto knob = [](const char* name, int dflt, int lo, int hi) {
+    const char* e = std::getenv(name);
+    const int v = e ? std::atoi(e) : dflt;
+    return v < lo ? lo : v > hi ? hi : v;
+  };
+  const int light_streams = knob("HWANG_HEVC_LIGHT_STREAMS", 2, 1, kLightStreams), heavy_streams = knob("HWANG_HEVC_HEAVY_STREAMS", 2, 1, kHeavyStreams);
+  const size_t light_room = static_cast<size_t>(knob("HWANG_HEVC_LIGHT_INFLIGHT", static_cast<int>(kBatchesInFlightDefault), 1, 4));
+  const size_t heavy_room = static_cast<size_t>(knob("HWANG_HEVC_HEAVY_INFLIGHT", static_cast<int>(kBatchesInFlightDefault), 1, 4));
+  std::vector<EngineJob*> pictures[kStreams], outputs[kStreams];
   std::vector<int> touched;
   // HWANG_HEVC_ENGINE_STATS=1: what the batches looked like, on stderr when the engine goes
   const bool stats = std::getenv("HWANG_HEVC_ENGINE_STATS") != nullptr;
@@ -124,7 +134,7 @@ void Engine::run() {
     // which batches are through (the engine's own lists: no lock - a lane that hands over a job must not wait for a
     // HIP call; with the queries under the lock the lanes spent 0.5 ms per picture in submit())
     lk.unlock();
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < kStreams; ++s)
       while (!inflight_[s].empty() && hipEventQuery(inflight_[s].front()) != hipErrorNotReady) {
         event_pool_.push_back(inflight_[s].front());
         inflight_[s].pop_front();
@@ -136,38 +146,49 @@ void Engine::run() {
     }
     lk.lock();
     // ---- collect what may go now
-    pictures[0].clear();
-    pictures[1].clear();
-    outputs.clear();
+    for (int s = 0; s < kStreams; ++s) {
+      pictures[s].clear();
+      outputs[s].clear();
+    }
     touched.clear();
-    bool waiting = false, queued = false;
+    bool waiting = false, queued = false, any = false;
     for (size_t ci = 0; ci < clients_.size(); ++ci) {
       Client& c = clients_[ci];
       bool took_picture = false, took_output = false, took = false;
       while (!c.queue.empty()) {
         queued = true;
         EngineJob* j = c.queue.front();
-        const int s = j->kind == EngineJob::kPicture && j->pp.intra_rows ? kHeavy : kLight;
         if (!error_.empty()) {  // nothing runs any more: fail what is queued
           j->failed = true;
           j->launched.store(1, std::memory_order_release);
           c.queue.pop_front();
           continue;
         }
-        if (inflight_[s].size() >= kBatchesInFlight) break;
-        // one picture of a decoder per batch, and none behind a fetched frame of it (a batch's pictures run before its
+        const bool heavy = j->kind == EngineJob::kPicture && j->pp.intra_rows;
+        const int first = heavy ? kLightStreams : 0, last = heavy ? kLightStreams + heavy_streams : light_streams;
+        // Which stream of its kind: the one the decoder's last job went to if it is of that kind and has room (stream
+        // order then, no waiting) - else the emptiest with room, which the job may enter once its predecessor's batch in
+        // the other stream is through.
+        int s = -1;
+        const size_t room = heavy ? heavy_room : light_room;
+        if (c.last_stream >= first && c.last_stream < last && inflight_[c.last_stream].size() < room) s = c.last_stream;
+        if (s < 0)
+          for (int k = first; k < last; ++k)
+            if (inflight_[k].size() < room && (s < 0 || inflight_[k].size() + pictures[k].size() < inflight_[s].size() + pictures[s].size())) s = k;
+        if (s < 0) break;  // every stream of the kind is full
+        // one picture of a decoder per round, and none behind a fetched frame of it (a batch's pictures run before its
         // conversions, and the picture may be going into the very surface the frame is read from)
         if (j->kind == EngineJob::kPicture && (took_picture || took_output || pictures[s].size() >= static_cast<size_t>(kMaxBatch))) break;
         if (c.last_stream >= 0 && c.last_stream != s && completed_seq_[c.last_stream] < c.last_seq) {
-          // its predecessor went to the other stream: not before that one's batch has finished
+          // its predecessor went to another stream: not before that one's batch has finished
           waiting = true;
           break;
         }
         c.queue.pop_front();
-        (j->kind == EngineJob::kPicture ? pictures[s] : outputs).push_back(j);
+        (j->kind == EngineJob::kPicture ? pictures[s] : outputs[s]).push_back(j);
         took_picture = took_picture || j->kind == EngineJob::kPicture;
         took_output = took_output || j->kind != EngineJob::kPicture;
-        took = true;
+        took = any = true;
         c.last_stream = s;
         c.last_seq = launched_seq_[s] + 1;  // (the batch this round makes for the stream)
       }
@@ -177,10 +198,12 @@ void Engine::run() {
       }
     }
     if (!error_.empty()) cv_done_.notify_all();
-    if (pictures[0].empty() && pictures[1].empty() && outputs.empty()) {
+    if (!any) {
       if (stop_ && !queued) break;
       ++idle_rounds;
-      if (waiting || queued || !inflight_[0].empty() || !inflight_[1].empty())
+      bool busy = false;
+      for (int s = 0; s < kStreams; ++s) busy = busy || !inflight_[s].empty();
+      if (waiting || queued || busy)
         cv_work_.wait_for(lk, std::chrono::microseconds(50));
       else
         cv_work_.wait(lk);
@@ -191,7 +214,7 @@ void Engine::run() {
     const int64_t t_issue = stats ? now_ns() : 0;
     hipError_t e = hipSuccess;
     bool copied = false;
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < kStreams; ++s)
       for (EngineJob* j : pictures[s])
         for (const EngineJob::Copy& cp : j->copy)
           if (cp.bytes && e == hipSuccess) {
@@ -204,9 +227,9 @@ void Engine::run() {
       copies_done = new_event();
       e = copies_done ? hipEventRecord(copies_done, copy_stream_) : hipErrorOutOfMemory;
     }
-    hipEvent_t batch_event[2] = {nullptr, nullptr};
-    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
-      if (pictures[s].empty() && !(s == kLight && !outputs.empty())) continue;
+    hipEvent_t batch_event[kStreams] = {};
+    for (int s = 0; s < kStreams && e == hipSuccess; ++s) {
+      if (pictures[s].empty() && outputs[s].empty()) continue;
       if (!pictures[s].empty()) {
         if (copies_done) e = hipStreamWaitEvent(stream_[s], copies_done, 0);
         Batch batch;
@@ -221,22 +244,21 @@ void Engine::run() {
         for (EngineJob* j : pictures[s])
           if (e == hipSuccess) e = hipEventRecord(j->done, stream_[s]);
       }
-      if (s == kLight)
-        for (EngineJob* j : outputs) {
-          if (e != hipSuccess) break;
-          const size_t w = j->width, h = j->height, cw = (w + 1) / 2, ch = (h + 1) / 2;
-          if (j->kind == EngineJob::kRgb) {
-            uint8_t* rgb = j->out_on_device ? j->out : j->rgb_dev;
-            e = launch_yuv420_to_rgb24(j->y, j->u, j->v, j->y_pitch, j->y_pitch / 2, j->width, j->height, rgb, stream_[s]);
-            if (e == hipSuccess && !j->out_on_device) e = hipMemcpyAsync(j->out, rgb, w * h * 3, hipMemcpyDeviceToHost, stream_[s]);
-          } else {
-            const hipMemcpyKind kind = j->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-            e = hipMemcpy2DAsync(j->out, w, j->y, static_cast<size_t>(j->y_pitch), w, h, kind, stream_[s]);
-            if (e == hipSuccess) e = hipMemcpy2DAsync(j->out + w * h, cw, j->u, static_cast<size_t>(j->y_pitch / 2), cw, ch, kind, stream_[s]);
-            if (e == hipSuccess) e = hipMemcpy2DAsync(j->out + w * h + cw * ch, cw, j->v, static_cast<size_t>(j->y_pitch / 2), cw, ch, kind, stream_[s]);
-          }
-          if (e == hipSuccess) e = hipEventRecord(j->done, stream_[s]);
+      for (EngineJob* j : outputs[s]) {
+        if (e != hipSuccess) break;
+        const size_t w = j->width, h = j->height, cw = (w + 1) / 2, ch = (h + 1) / 2;
+        if (j->kind == EngineJob::kRgb) {
+          uint8_t* rgb = j->out_on_device ? j->out : j->rgb_dev;
+          e = launch_yuv420_to_rgb24(j->y, j->u, j->v, j->y_pitch, j->y_pitch / 2, j->width, j->height, rgb, stream_[s]);
+          if (e == hipSuccess && !j->out_on_device) e = hipMemcpyAsync(j->out, rgb, w * h * 3, hipMemcpyDeviceToHost, stream_[s]);
+        } else {
+          const hipMemcpyKind kind = j->out_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+          e = hipMemcpy2DAsync(j->out, w, j->y, static_cast<size_t>(j->y_pitch), w, h, kind, stream_[s]);
+          if (e == hipSuccess) e = hipMemcpy2DAsync(j->out + w * h, cw, j->u, static_cast<size_t>(j->y_pitch / 2), cw, ch, kind, stream_[s]);
+          if (e == hipSuccess) e = hipMemcpy2DAsync(j->out + w * h + cw * ch, cw, j->v, static_cast<size_t>(j->y_pitch / 2), cw, ch, kind, stream_[s]);
         }
+        if (e == hipSuccess) e = hipEventRecord(j->done, stream_[s]);
+      }
       if (e == hipSuccess) {
         batch_event[s] = new_event();
         e = batch_event[s] ? hipEventRecord(batch_event[s], stream_[s]) : hipErrorOutOfMemory;
@@ -246,28 +268,29 @@ void Engine::run() {
       const int64_t d = now_ns() - t_issue;
       issue_ns += d;
       issue_max_ns = d > issue_max_ns ? d : issue_max_ns;
-      for (int s = 0; s < 2; ++s)
+      for (int s = 0; s < kStreams; ++s) {
         if (!pictures[s].empty()) {
-          ++n_batches[s];
-          n_pictures[s] += static_cast<int64_t>(pictures[s].size());
+          ++n_batches[s >= kLightStreams];
+          n_pictures[s >= kLightStreams] += static_cast<int64_t>(pictures[s].size());
         }
-      n_outputs += static_cast<int64_t>(outputs.size());
+        n_outputs += static_cast<int64_t>(outputs[s].size());
+      }
     }
     lk.lock();
     if (copies_done) copy_inflight_.push_back(copies_done);
-    for (int s = 0; s < 2; ++s) {
-      const bool took = !pictures[s].empty() || (s == kLight && !outputs.empty());
-      if (!took) continue;
+    for (int s = 0; s < kStreams; ++s) {
+      if (pictures[s].empty() && outputs[s].empty()) continue;
       ++launched_seq_[s];
       if (batch_event[s]) inflight_[s].push_back(batch_event[s]);
       else ++completed_seq_[s];  // (the launch failed: nothing will ever fire; error_ ends the engine's work)
     }
     if (e != hipSuccess && error_.empty()) error_ = std::string("the HEVC engine failed to launch a batch: ") + hipGetErrorString(e);
-    for (auto* list : {&pictures[0], &pictures[1], &outputs})
-      for (EngineJob* j : *list) {
-        j->failed = e != hipSuccess;
-        j->launched.store(1, std::memory_order_release);
-      }
+    for (int s = 0; s < kStreams; ++s)
+      for (auto* list : {&pictures[s], &outputs[s]})
+        for (EngineJob* j : *list) {
+          j->failed = e != hipSuccess;
+          j->launched.store(1, std::memory_order_release);
+        }
     for (int ci : touched) clients_[ci].taking = false;
     cv_done_.notify_all();
   }
@@ -276,13 +299,16 @@ void Engine::run() {
     std::fprintf(stderr, "[hevc engine %d] light: %lld pictures in %lld batches; heavy: %lld in %lld; %lld fetched frames; issuing took %.1f ms (copies %.1f ms), "
                  "longest round %.2f ms; %lld empty rounds\n", device_, (long long)n_pictures[0], (long long)n_batches[0], (long long)n_pictures[1], (long long)n_batches[1],
                  (long long)n_outputs, issue_ns / 1e6, copy_ns / 1e6, issue_max_ns / 1e6, (long long)idle_rounds);
-  for (hipStream_t s : {copy_stream_, stream_[0], stream_[1]})
+  for (int k = -1; k < kStreams; ++k) {
+    hipStream_t s = k < 0 ? copy_stream_ : stream_[k];
     if (s) {
       (void)hipStreamSynchronize(s);
       (void)hipStreamDestroy(s);
     }
-  for (auto* fl : {&inflight_[0], &inflight_[1], &copy_inflight_})
-    for (hipEvent_t e : *fl) (void)hipEventDestroy(e);
+  }
+  for (auto& fl : inflight_)
+    for (hipEvent_t e : fl) (void)hipEventDestroy(e);
+  for (hipEvent_t e : copy_inflight_) (void)hipEventDestroy(e);
   for (hipEvent_t e : event_pool_) (void)hipEventDestroy(e);
 }
 

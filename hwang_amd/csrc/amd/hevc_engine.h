@@ -7,12 +7,13 @@
 // decoder B that happens to share its queue.  Measured with 32 decoders on 16 queues: the GPU ran 1.8 kernels at a time on
 // average, was idle 29 % of the time, every kernel's longest run was an intra picture's 11 - 12 ms
 // (profiles/r06_hevc_kernel_trace_analysis.txt; tools/experiments/src/stream_concurrency.hip: 4 / 8 / 16 queues run 4 / 8 /
-// 15 spinning kernels at once, 32 queues 5.6).  The engine uses three queues on purpose: copies, "light" batches (pictures
-// with scattered intra blocks; fetched frames' conversion and copy-out), "heavy" batches (intra pictures: a long, thin
-// wavefront that should not hold anything up).
+// 15 spinning kernels at once, 32 queues 5.6).  The engine uses five queues on purpose: copies, two for "light" batches
+// (pictures with scattered intra blocks; fetched frames' conversion and copy-out), two for "heavy" batches (intra pictures:
+// a long, thin wavefront that should not hold anything up - with one heavy stream it was the busiest thing on the GPU;
+// with three or four the batches get so small that the rate drops again: profiles/r06_hevc_engine_streams_sweep.txt).
 //
 // Order: a decoder's jobs are launched in the order it submitted them.  Inside a stream that is stream order; when a
-// job's predecessor went to the other stream the job waits (in the engine's list, not in the stream: nothing queues up
+// job's predecessor went to another stream the job waits (in the engine's list, not in the stream: nothing queues up
 // behind it) until the predecessor's batch is through.  Batches are formed from whatever is eligible whenever a stream has
 // fewer than two batches in flight - while they run, the next one fills up.
 #pragma once
@@ -88,17 +89,18 @@ class Engine {
     uint64_t last_seq = 0;                // ... and which batch of that stream it was in
     bool taking = false;                  // jobs of it are between the list and a stream
   };
-  enum { kLight = 0, kHeavy = 1 };
+  // streams 0 .. kLightStreams - 1 take light batches, the rest heavy ones
+  static constexpr int kLightStreams = 2, kHeavyStreams = 4, kStreams = kLightStreams + kHeavyStreams;  // (at most; two heavy ones are used)
   const int device_;
   std::mutex mu_;
   std::condition_variable cv_work_, cv_done_;
   std::vector<Client> clients_;
   bool stop_ = false;
   std::string error_;
-  hipStream_t copy_stream_ = nullptr, stream_[2] = {nullptr, nullptr};
+  hipStream_t copy_stream_ = nullptr, stream_[kStreams] = {};
   std::vector<hipEvent_t> event_pool_;
-  std::deque<hipEvent_t> inflight_[2];    // a batch event each (the engine thread's own)
-  uint64_t launched_seq_[2] = {0, 0}, completed_seq_[2] = {0, 0};  // batches put into / through each stream
+  std::deque<hipEvent_t> inflight_[kStreams];    // a batch event each (the engine thread's own)
+  uint64_t launched_seq_[kStreams] = {}, completed_seq_[kStreams] = {};  // batches put into / through each stream
   std::deque<hipEvent_t> copy_inflight_;  // the copy stream's events, kept until they have fired
   std::thread thread_;
 };
