@@ -277,6 +277,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
     if (exec_)
       for (int lane : lanes_) exec_->set_lane_patient(lane, long_queue);
   }
+  bool feed_would_wait() override { return hevc_active_ && hevc_->feed_would_wait(); }
   void set_wanted_frames(const std::vector<uint64_t>& ordinals) override {
     pending_wanted_ = ordinals;
     if (hevc_active_) {

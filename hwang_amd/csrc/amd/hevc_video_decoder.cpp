@@ -49,10 +49,13 @@ constexpr int kOutputs = 6;  // fetched frames on their way (take): conversion, 
 // Waits for an event without holding a CPU: hipEventSynchronize spins for the whole wait (measured: the lanes' CPU time
 // per picture was parse + stall to the millisecond, with hipEventBlockingSync or without), and the GPU box gives the
 // process 16 CPUs that the parsers need.  A look every 100 us costs a picture's set at most that much latency.
+std::atomic<long long> g_event_waits{0}, g_event_sleeps{0};  // (HWANG_HEVC_ENGINE_STATS: how often a wait found its event unfinished)
 hipError_t sleepy_event_wait(hipEvent_t e) {
+  g_event_waits.fetch_add(1, std::memory_order_relaxed);
   for (;;) {
     const hipError_t q = hipEventQuery(e);
     if (q != hipErrorNotReady) return q;
+    g_event_sleeps.fetch_add(1, std::memory_order_relaxed);
     std::this_thread::sleep_for(std::chrono::microseconds(100));
   }
 }
@@ -62,9 +65,15 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   explicit HEVCVideoDecoder(int device) : device_(device), engine_(gh::Engine::for_device(device)), client_(engine_->add_client()) {}
   ~HEVCVideoDecoder() override {
     (void)hipSetDevice(device_);
+    if (std::getenv("HWANG_HEVC_ENGINE_STATS") && parser_ && g_event_waits.exchange(0))
+      std::fprintf(stderr, "[hevc decoders] event waits (all decoders, since the last line): %lld sleeps of 100 us\n", g_event_sleeps.exchange(0));
+    if (std::getenv("HWANG_HEVC_ENGINE_STATS") && parser_ && (dbg_stalls_[0] || dbg_stalls_[1]))
+      std::fprintf(stderr, "[hevc decoder %p] waited for a set %lld times behind an inter picture (submitted %.2f ms before, on average), %lld times behind an intra picture (%.2f ms)\n",
+                   static_cast<void*>(this), (long long)dbg_stalls_[0], dbg_stalls_[0] ? dbg_age_ns_[0] / 1e6 / dbg_stalls_[0] : 0.0, (long long)dbg_stalls_[1],
+                   dbg_stalls_[1] ? dbg_age_ns_[1] / 1e6 / dbg_stalls_[1] : 0.0);
     if (std::getenv("HWANG_HEVC_ENGINE_STATS") && parser_)
-      std::fprintf(stderr, "[hevc decoder %p] pictures %lld: parse %.1f ms, waiting for a set %.1f ms, submitting %.1f ms (%.1f ms of it handing the job to the engine), copying frames out of bounce buffers %.1f ms\n",
-                   static_cast<void*>(this), (long long)(folded_decoded_ + parser_->pictures_decoded()), counters_.entropy_ns / 1e6, counters_.stall_ns / 1e6,
+      std::fprintf(stderr, "[hevc decoder %p] pictures %lld: parse %.1f ms, waiting for a set %.1f ms (%.1f ms of it until the engine had launched the set's picture), submitting %.1f ms (%.1f ms of it handing the job to the engine), copying frames out of bounce buffers %.1f ms\n",
+                   static_cast<void*>(this), (long long)(folded_decoded_ + parser_->pictures_decoded()), counters_.entropy_ns / 1e6, counters_.stall_ns / 1e6, launch_wait_ns_ / 1e6,
                    submit_ns_ / 1e6, engine_submit_ns_ / 1e6, copy_out_ns_ / 1e6);
     parser_.reset();
     (void)quiesce();
@@ -157,6 +166,13 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     pending_wanted_ = ordinals;
     if (parser_) parser_->set_wanted(ordinals);
   }
+  bool feed_would_wait() override {
+    if (!engine_) return false;
+    Set& set = sets_[next_set_];
+    if (!set.busy) return false;
+    if (!set.job.launched.load(std::memory_order_acquire)) return true;
+    return !set.job.failed && hipEventQuery(set.done) == hipErrorNotReady;
+  }
   BackendCounters counters() override {
     BackendCounters c = counters_;
     c.bytes_uploaded = bytes_uploaded_;
@@ -180,6 +196,12 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       if (!engine_->wait_launched(&set.job)) {
         *error = engine_->error();
         return false;
+      }
+      launch_wait_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      if (hipEventQuery(set.done) == hipErrorNotReady) {  // (debug statistics: which pictures are waited for, how old they are)
+        const int k = set.job.pp.intra_rows ? 1 : 0;
+        ++dbg_stalls_[k];
+        dbg_age_ns_[k] += std::chrono::duration_cast<std::chrono::nanoseconds>(t0 - set.submitted).count();
       }
       if (sleepy_event_wait(set.done) != hipSuccess) {
         *error = "waiting for a staging set's event failed";
@@ -312,6 +334,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
       const auto t0 = std::chrono::steady_clock::now();
       engine_->submit(client_, &job);
       engine_submit_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+      set.submitted = t0;
     }
     (void)error;
     set.busy = true;
@@ -349,6 +372,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     hipEvent_t done = nullptr;
     bool busy = false;
     gh::EngineJob job;
+    std::chrono::steady_clock::time_point submitted;
   };
   struct Offsets {
     size_t params, res, coefs, pus, weights, intra[3], first[3], edges, sao, slices, scaling, part_b, total;
@@ -628,7 +652,8 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   uint32_t* fault_host_ = nullptr;
   uint32_t* fault_dev_ = nullptr;
   BackendCounters counters_;
-  int64_t submit_ns_ = 0, copy_out_ns_ = 0, engine_submit_ns_ = 0;
+  int64_t submit_ns_ = 0, copy_out_ns_ = 0, engine_submit_ns_ = 0, launch_wait_ns_ = 0;
+  int64_t dbg_stalls_[2] = {0, 0}, dbg_age_ns_[2] = {0, 0};
   int64_t bytes_uploaded_ = 0, folded_decoded_ = 0, folded_skipped_ = 0, decoded_base_ = 0, skipped_base_ = 0;
 };
 

@@ -25,6 +25,7 @@ class HevcDelegate {
   virtual void set_wanted_frames(const std::vector<uint64_t>& ordinals) = 0;
   virtual BackendCounters counters() = 0;
   virtual void reset_counters() = 0;
+  virtual bool feed_would_wait() = 0;   // BatchingHints
 };
 
 // Never null; the device is opened at the first configure().

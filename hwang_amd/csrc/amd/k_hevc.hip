@@ -269,6 +269,20 @@ __global__ __launch_bounds__(256) void k_hevc_inter(const Batch batch) {
 }
 
 // ------------------------------------------------------------------------------------------------------- intra
+// Hand-offs between workgroups of ONE launch (the two intra kernels) use agent-scope accesses for the flags AND for the
+// samples that cross (sc1 on gfx950: they go past the per-XCD L2), not acquire / release fences: at agent scope those are
+// buffer_inv sc1 / buffer_wbl2 sc1 - the whole L2 of the XCD invalidated in every poll, written back behind every
+// transform block - and every kernel running beside this one pays for them (measured: each kernel of a batch took as
+// much longer as the batch had pictures, more streams bought nothing; profiles/r06_hevc_fence_free_*).  The producer's
+// stores are through (s_waitcnt vmcnt(0): the workgroup is one wavefront) before it raises the flag; the consumer
+// issues its loads behind the poll.
+#define HW_AS1 __attribute__((address_space(1)))
+__device__ __forceinline__ uint32_t agent_ld32(const void* p) { return __hip_atomic_load((const HW_AS1 uint32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int agent_ld8(const void* p) { return __hip_atomic_load((const HW_AS1 uint8_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_st32(void* p, uint32_t v) { __hip_atomic_store((HW_AS1 uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void agent_st8(void* p, uint8_t v) { __hip_atomic_store((HW_AS1 uint8_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stores_through() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // intraPredAngle and invAngle (tables 8-4, 8-5) in LDS: a table in memory is a cache round trip in every block of the chain
 __device__ inline void load_angles(int* angtab, int lane) {
   if (lane < 35) angtab[lane] = kAngle[lane];
@@ -296,7 +310,8 @@ __device__ void intra_block(const IntraTu& tu, int x0, int y0, int c, uint8_t* o
     for (int i = lane; i < n * n; i += 64) {
       const int r = rs[(i / n) * res_pitch + i % n];
       if (!kTile && r) rs[(i / n) * res_pitch + i % n] = 0;
-      dst[(i / n) * pitch + i % n] = static_cast<uint8_t>(clip8(r));
+      if (kTile) dst[(i / n) * pitch + i % n] = static_cast<uint8_t>(clip8(r));
+      else agent_st8(dst + (i / n) * pitch + i % n, static_cast<uint8_t>(clip8(r)));
     }
   } else {
   const int mode = tu.mode;
@@ -321,9 +336,9 @@ __device__ void intra_block(const IntraTu& tu, int x0, int y0, int c, uint8_t* o
           src = su < nu ? (su << ushift) : su == nu ? 2 * n : 2 * n + 1 + ((su - nu - 1) << ushift);
         }
       }
-      if (src < 2 * n) v = nb[(y0 + 2 * n - 1 - src) * nb_pitch + x0 - 1];
-      else if (src == 2 * n) v = nb[(y0 - 1) * nb_pitch + x0 - 1];
-      else v = nb[(y0 - 1) * nb_pitch + x0 + src - 2 * n - 1];
+      // (surface variant: a neighbour may be another wavefront's work of this launch)
+      const uint8_t* from = src < 2 * n ? nb + (y0 + 2 * n - 1 - src) * nb_pitch + x0 - 1 : src == 2 * n ? nb + (y0 - 1) * nb_pitch + x0 - 1 : nb + (y0 - 1) * nb_pitch + x0 + src - 2 * n - 1;
+      v = kTile ? *from : agent_ld8(from);
     }
     line[i] = v;
   }
@@ -403,7 +418,8 @@ __device__ void intra_block(const IntraTu& tu, int x0, int y0, int c, uint8_t* o
     {
       const int r = rs[y * res_pitch + x];
       if (!kTile && r) rs[y * res_pitch + x] = 0;
-      dst[y * pitch + x] = static_cast<uint8_t>(clip8(v + r));
+      if (kTile) dst[y * pitch + x] = static_cast<uint8_t>(clip8(v + r));
+      else agent_st8(dst + y * pitch + x, static_cast<uint8_t>(clip8(v + r)));
     }
   }
 #undef LEFT
@@ -466,7 +482,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_flow(const Batch batch) {
         if (__any(flag != nullptr)) {
           uint32_t spins = 0;
           for (;;) {
-            const bool ok = !flag || __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            const bool ok = !flag || agent_ld8(flag) != 0;
             if (__all(ok)) break;
             for (int k = 0; k < batch.spin_sleep; ++k) __builtin_amdgcn_s_sleep(8);
             if (++spins > kIntraSpins) {
@@ -477,11 +493,11 @@ __global__ __launch_bounds__(64) void k_hevc_intra_flow(const Batch batch) {
         }
       }
       intra_block<false>(tu, tu.x, tu.y, c, plane, pitch, pp.resid[c], pitch, line, filt_line, refbuf, angtab, lane);
-      // the block's samples are out: mark the units it covers (a release after the fence; waiters acquire)
-      __threadfence();
+      // the block's samples are out (agent-scope stores, all through): mark the units it covers
+      stores_through();
       __syncthreads();
       const int cnt = n >> ushift;
-      if (lane < cnt * cnt) __hip_atomic_store(done + (uy + lane / cnt) * w4 + ux + lane % cnt, static_cast<uint8_t>(1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane < cnt * cnt) agent_st8(done + (uy + lane / cnt) * w4 + ux + lane % cnt, 1);
     }
   }
 }
@@ -515,7 +531,7 @@ __global__ __launch_bounds__(64) void k_hevc_intra_rows(const Batch batch) {
   static_assert(sizeof(IntraTu) == 24, "records are copied as six words");
   uint8_t* const origin = tile + kTilePitch + 16;  // the block's sample (0, 0); the rim is at -1
   uint32_t t_next = first[0];
-  int published = 0;
+  int published = 0, tile_col = -2;  // tile_col: the block the tile holds
   const int cy = row * S, wpr = S >> 2;
   const int lcpr = pp.log2_ctb - sub - 4, lrpr = pp.log2_ctb - sub - 3;  // log2 of the 16-byte pieces per row of the block / of its residual
   for (int col = 0; col < pp.width_ctb; ++col) {
@@ -524,10 +540,15 @@ __global__ __launch_bounds__(64) void k_hevc_intra_rows(const Batch batch) {
     if (t1 == t0) continue;  // nothing intra in this block
     // the blocks passed without work are final too: say so before waiting, or the row below waits for this row's wait
     if (published < col) {
-      if (lane == 0) __hip_atomic_store(&progress[row], static_cast<uint32_t>(col), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane == 0) agent_st32(&progress[row], static_cast<uint32_t>(col));
       published = col;
     }
     const int cx = col * S;
+    // the column left of the block: the last column of the tile when the block to the left was this wavefront's previous
+    // one (taken before the tile is overwritten), else what the inter kernel left in the surface
+    int left_sample = 0;
+    if (lane < S && cx > 0 && cy + lane < ph) left_sample = tile_col == col - 1 ? origin[lane * kTilePitch + S - 1] : plane[static_cast<size_t>(cy + lane) * pitch + cx - 1];
+    tile_col = col;
     // what does not depend on the row above: the block itself (what inter prediction left there), its residual - cleared
     // behind the copy: every sample's residual is read once - and the column left of it (this wavefront's own work)
     // (16 bytes a lane and all of a copy's loads in flight at once: what is past the picture's width is pitch padding)
@@ -563,11 +584,11 @@ __global__ __launch_bounds__(64) void k_hevc_intra_rows(const Batch batch) {
         if (r < S) reinterpret_cast<uint4*>(rtile)[i] = blk[k];
       }
     }
-    for (int r = lane; r < S; r += 64) origin[r * kTilePitch - 1] = (cx > 0 && cy + r < ph) ? plane[static_cast<size_t>(cy + r) * pitch + cx - 1] : 0;
+    if (lane < S) origin[lane * kTilePitch - 1] = static_cast<uint8_t>(left_sample);
     if (row > 0) {
       const uint32_t need = static_cast<uint32_t>(col + 2 < pp.width_ctb ? col + 2 : pp.width_ctb);
       uint32_t spins = 0;
-      while (__hip_atomic_load(&progress[row - 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+      while (agent_ld32(&progress[row - 1]) < need) {
         for (int k = 0; k < batch.spin_sleep; ++k) __builtin_amdgcn_s_sleep(8);
         if (++spins > kIntraSpins) {
           if (lane == 0) atomicExch(pp.fault, 1u);
@@ -575,10 +596,13 @@ __global__ __launch_bounds__(64) void k_hevc_intra_rows(const Batch batch) {
         }
       }
     }
-    // the row above, from the sample left of the block to the end of the above-right block
-    for (int i = lane; i < 2 * S + 1; i += 64) {
-      const int x = cx - 1 + i;
-      origin[-kTilePitch - 1 + i] = (cy > 0 && x >= 0 && x < pw) ? plane[static_cast<size_t>(cy - 1) * pitch + x] : 0;
+    __asm__ volatile("" ::: "memory");
+    // the row above, from the sample left of the block to the end of the above-right block: the last row of another
+    // wavefront's blocks (agent-scope stores there, agent-scope loads here), a word a lane - the first one for its last byte
+    if (lane < 2 * (S >> 2) + 1) {
+      const int x = cx - 4 + 4 * lane;
+      const uint32_t w = (cy > 0 && x >= 0 && x < pw) ? agent_ld32(plane + static_cast<size_t>(cy - 1) * pitch + x) : 0u;
+      *reinterpret_cast<uint32_t*>(origin - kTilePitch - 4 + 4 * lane) = w;
     }
     for (uint32_t base = t0; base < t1; base += kTileRecs) {
       const int m = static_cast<int>(t1 - base < static_cast<uint32_t>(kTileRecs) ? t1 - base : kTileRecs);
@@ -595,21 +619,23 @@ __global__ __launch_bounds__(64) void k_hevc_intra_rows(const Batch batch) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int i = lane + 64 * k, r = i >> lcpr, x = cx + 16 * (i & ((1 << lcpr) - 1));
-        if (r < S && cy + r < ph && x < pw) *reinterpret_cast<uint4*>(plane + static_cast<size_t>(cy + r) * pitch + x) = *reinterpret_cast<const uint4*>(origin + r * kTilePitch + 16 * (i & ((1 << lcpr) - 1)));
+        if (r < S - 1 && cy + r < ph && x < pw) *reinterpret_cast<uint4*>(plane + static_cast<size_t>(cy + r) * pitch + x) = *reinterpret_cast<const uint4*>(origin + r * kTilePitch + 16 * (i & ((1 << lcpr) - 1)));
       }
     } else {
-      for (int i = lane; i < S * wpr; i += 64) {
+      for (int i = lane; i < (S - 1) * wpr; i += 64) {
         const int r = i / wpr, x = cx + 4 * (i % wpr), y = cy + r;
         if (y < ph && x < pw) *reinterpret_cast<uint32_t*>(plane + static_cast<size_t>(y) * pitch + x) = *reinterpret_cast<const uint32_t*>(origin + r * kTilePitch + 4 * (i % wpr));
       }
     }
+    // the block's last row is what the row below reads while this launch runs: agent-scope stores
+    if (lane < wpr && cy + S - 1 < ph && cx + 4 * lane < pw)
+      agent_st32(plane + static_cast<size_t>(cy + S - 1) * pitch + cx + 4 * lane, *reinterpret_cast<const uint32_t*>(origin + (S - 1) * kTilePitch + 4 * lane));
     // everything up to this block of the row is final as far as later rows are concerned
-    __threadfence();
-    __syncthreads();
-    if (lane == 0) __hip_atomic_store(&progress[row], static_cast<uint32_t>(col + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    stores_through();
+    if (lane == 0) agent_st32(&progress[row], static_cast<uint32_t>(col + 1));
     published = col + 1;
   }
-  if (published < pp.width_ctb && lane == 0) __hip_atomic_store(&progress[row], static_cast<uint32_t>(pp.width_ctb), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (published < pp.width_ctb && lane == 0) agent_st32(&progress[row], static_cast<uint32_t>(pp.width_ctb));
 }
 
 // -------------------------------------------------------------------------------------------------- deblocking

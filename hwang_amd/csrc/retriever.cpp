@@ -407,6 +407,7 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
         ItemRun run;
         bool active = false, first = true, finished = false;
         int turn = 0;
+        BatchingHints* hints = nullptr;  // of the backend the item in hand runs on
         Result r;
       };
       std::vector<Slot> slots(mine.size());
@@ -421,10 +422,17 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
       }
       bool failed = false;
       size_t live = slots.size();
+      size_t passed_over = 0;  // items in a row whose decoder would have started by waiting for the GPU
       while (live > 0 && !failed && !abort.load()) {
         for (Slot& sl : slots) {
           if (sl.finished) continue;
           Lane& lane = lanes_[sl.li];
+          if (sl.active && live > 1 && passed_over + 1 < live && sl.hints && sl.hints->feed_would_wait()) {
+            // another item of this thread first; when all of them would wait, the next one simply does
+            ++passed_over;
+            continue;
+          }
+          passed_over = 0;
           if (!sl.active) {
             // the lane's next item: lane li starts with item li (so every lane, hence every device, has work from the
             // first moment whatever order the threads come up in), everything after that comes from the shared queue
@@ -448,6 +456,7 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
             if (sl.r.ok)
               sl.r = sl.run.start(lane.backend[sl.turn].get(), item, *rq.index, rq.file, rq.file_size, rq.out, frame_bytes[item.request], yuv);
             sl.active = sl.r.ok;
+            sl.hints = dynamic_cast<BatchingHints*>(lane.backend[sl.turn].get());
           }
           if (sl.active) {
             bool done = false;

@@ -39,6 +39,10 @@ class BatchingHints {
  public:
   virtual ~BatchingHints() {}
   virtual void set_long_queue(bool long_queue) = 0;
+  // True while the next feed() would start by waiting for the GPU (the staging memory its next picture needs is still
+  // being read by an earlier picture's kernels).  A thread that drives several decoders in turn feeds another one first.
+  // Only a hint: feed() is correct whatever this says.
+  virtual bool feed_would_wait() { return false; }
 };
 
 // Optional: planar output of the normative decoder result (cropped I420:

@@ -142,10 +142,25 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
     dec = hw.Decoder(blob, video_index=idx, num_lanes=lanes)
     dec.retrieve(rows[:8])     # first-use costs outside
     times = []
+    cpus_used = []
+
+    def throttled_ms():   # the cgroup's own count of the time its threads were frozen for having used up the quota
+        try:
+            for line in open("/sys/fs/cgroup/cpu.stat"):
+                if line.startswith("throttled_usec"):
+                    return int(line.split()[1]) / 1e3
+        except OSError:
+            pass
+        return None
+    frozen = []
     for _ in range(steps):
+        c0, z0 = os.times(), throttled_ms()
         t = time.perf_counter()
         out = dec.retrieve(rows)
         times.append(time.perf_counter() - t)
+        c1, z1 = os.times(), throttled_ms()
+        cpus_used.append(round((c1.user - c0.user + c1.system - c0.system) / times[-1], 2))
+        frozen.append(None if z0 is None or z1 is None else round(z1 - z0, 1))
         assert len(out) == len(rows) and out[0].shape == (height, width, 3)
         st = dec.stats()
         if soak is not None:   # (every call must return the very same frames: the engine's batches differ from call to call)
@@ -188,6 +203,8 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
             "pictures_reconstructed_per_s": round(st["pictures_reconstructed"] / best, 1),
             "host_parse_ms_per_picture": round(st["entropy_ns"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
             "lane_cpu_ms_per_picture": round(hc[3] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
+            "lane_threads": st["lane_threads"], "work_items": st["intervals"],
+            "process_cpus_used_per_call": cpus_used, "cgroup_throttled_ms_per_call": frozen,
             "lane_wall_ms_per_picture": round(lanes * times[-1] * 1e3 / max(1, st["pictures_reconstructed"]), 3),
             "staging_stall_ms_per_picture": round(st["stall_ns"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
             "upload_MB_per_picture": round(st["bytes_uploaded"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
