@@ -9,8 +9,9 @@
 // (profiles/r06_hevc_kernel_trace_analysis.txt; tools/experiments/src/stream_concurrency.hip: 4 / 8 / 16 queues run 4 / 8 /
 // 15 spinning kernels at once, 32 queues 5.6).  The engine uses five queues on purpose: copies, two for "light" batches
 // (pictures with scattered intra blocks; fetched frames' conversion and copy-out), two for "heavy" batches (intra pictures:
-// a long, thin wavefront that should not hold anything up - with one heavy stream it was the busiest thing on the GPU;
-// with three or four the batches get so small that the rate drops again: profiles/r06_hevc_engine_streams_sweep.txt).
+// a long, thin wavefront that should not hold anything up).  How many of each no longer matters: while the intra kernels
+// handed over with agent-scope fences (whole-L2 write-backs and invalidations) more streams only made every kernel slower;
+// since they do not, one to four heavy streams measure the same (profiles/r06_hevc_fence_free_sweeps.txt).
 //
 // Order: a decoder's jobs are launched in the order it submitted them.  Inside a stream that is stream order; when a
 // job's predecessor went to another stream the job waits (in the engine's list, not in the stream: nothing queues up

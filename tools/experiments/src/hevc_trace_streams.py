@@ -54,3 +54,17 @@ for stream, ks in sorted(per.items(), key=lambda kv: -len(kv[1])):
         print("   %d batches, %.2f pictures each (max %d); duration median %.2f ms, 90 %% %.2f ms; idle before the next: median %.2f ms, 90 %% %.2f ms, total %.3f of the span"
               % (len(batches), sum(pics) / len(pics), max(pics), dur[len(dur) // 2] / 1e6, dur[int(0.9 * len(dur))] / 1e6, idle[len(idle) // 2] / 1e6,
                  idle[int(0.9 * len(idle))] / 1e6, sum(idle) / span))
+
+# how a kernel's duration depends on the pictures in its launch
+by = defaultdict(list)
+for r in rows:
+    if int(r["Start_Timestamp"]) < t_from or "k_hevc" not in r["Kernel_Name"] or "deblock" in r["Kernel_Name"]:
+        continue   # (k_hevc_deblock's name has a comma: the trace was cut by columns)
+    s = r["Kernel_Name"].split("::", 1)[1].split("(")[0]
+    gy = int(r["Grid_Size_Y"]) // int(r["Workgroup_Size_Y"])
+    gz = int(r["Grid_Size_Z"]) // int(r["Workgroup_Size_Z"])
+    k = gz if s in ("k_hevc_intra_flow", "k_hevc_intra_rows") else gy // 3 if s == "k_hevc_sao" else gy
+    by[(s, k)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+for s in ["k_hevc_intra_rows", "k_hevc_intra_flow", "k_hevc_residual", "k_hevc_inter", "k_hevc_sao"]:
+    print(s + ": pictures in the launch -> launches, median us")
+    print("   " + "; ".join("%d -> %d, %.0f" % (k, len(v), sorted(v)[len(v) // 2]) for (n, k), v in sorted(by.items()) if n == s and len(v) >= 5))
