@@ -138,6 +138,35 @@ def test_engine_batches_pictures_of_many_decoders_and_sizes(hw, oracle, gpu, tmp
     assert not errors, errors[0]
 
 
+def test_a_thread_drives_several_hevc_decoders(hw, oracle, gpu, tmp_path):
+    """Long queues are served by a thread per CPU that feeds several lanes in turn, a sample of each at a time, and
+    passes over a decoder whose next picture would start by waiting for the GPU (BatchingHints::feed_would_wait:
+    the staging set it needs is still being read).  Three and six lanes per thread, every frame of a clip of short
+    GOPs (40 work items), three rounds each: bit-exact, and the same through the sparse path."""
+    import os
+    path = str(tmp_path / "t.mp4")
+    gold = make_hevc_clip(path, width=320, height=192, frames=120, gop=3, bframes=0, refs=2, ctb=32, sao=1)
+    idx = hw.index_video(path)
+    for lanes, share in ((6, "3"), (12, "6"), (8, "1")):
+        os.environ["HWANG_LONG_QUEUE_FROM"] = "1"
+        os.environ["HWANG_LANES_PER_THREAD"] = share
+        try:
+            dec = hw.Decoder(path, video_index=idx, num_lanes=lanes)
+            for rnd in range(3):
+                got = dec.retrieve_yuv(list(range(idx.frames())))
+                for i in range(len(gold)):
+                    assert np.array_equal(got[i], gold[i]), "lanes %d, %s a thread, round %d: frame %d differs" % (lanes, share, rnd, i)
+                rows = list(range(rnd, idx.frames(), 7))
+                rgb = dec.retrieve(rows)
+                for k, r in enumerate(rows):
+                    assert np.array_equal(rgb[k], oracle.i420_to_rgb(gold[r], 320, 192)), "lanes %d round %d: RGB row %d differs" % (lanes, rnd, r)
+            assert dec.stats()["lane_threads"] == (lanes + int(share) - 1) // int(share)
+            del dec
+        finally:
+            os.environ.pop("HWANG_LONG_QUEUE_FROM", None)
+            os.environ.pop("HWANG_LANES_PER_THREAD", None)
+
+
 @pytest.mark.parametrize("name", ["ibp_amp_wp_ctb32", "everything", "i_slices_cip_nolf"])
 def test_corrupt_streams_never_hang_the_gpu(hw, oracle, gpu, tmp_path, name):
     """Bit flips in HEVC samples reach the kernels as absurd vectors, levels and modes (or are refused by the parser -
