@@ -40,7 +40,9 @@ def load_stamp_backend():
     src = os.path.join(ROOT, "tests", "fixtures", "stamp_backend.c")
     if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-pthread", src, "-o", out])
+        tmp = "%s.%d.tmp" % (out, os.getpid())   # (pytest-xdist: several workers may get here at once)
+        subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-pthread", src, "-o", tmp])
+        os.replace(tmp, out)
     fixture = ctypes.CDLL(out)
     vtable = ctypes.c_void_p.in_dll(fixture, "hwang_stamp_vtable")
     assert lib.hwang_register_decoder_backend(STAMP, ctypes.addressof(vtable)) == 0
