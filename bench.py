@@ -664,7 +664,7 @@ def main():
         try:
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import hevc_bench
-            hevc = hevc_bench.run(frames=36000, lanes=32, steps=2, cpu=not args.no_cpu_baseline)
+            hevc = hevc_bench.run(frames=36000, lanes=32, steps=3, cpu=not args.no_cpu_baseline, thread_per_lane=True)
         except Exception as e:  # the leg is an extra: the contract's line does not depend on it
             hevc = {"error": "%s: %s" % (type(e).__name__, e)}
     if world > 1:

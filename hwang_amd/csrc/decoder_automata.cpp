@@ -1,6 +1,7 @@
 #include "decoder_automata.h"
 
 #include "sparse_hints.h"
+#include "hevc/hvcc.h"
 #include "util/avc_sample.h"
 #include "util/trace.h"
 
@@ -122,7 +123,7 @@ Result DecoderAutomata::initialize(std::vector<EncodedData>&& encoded_data,
   failed_ = false;
   failure_ = Result();
 
-  nal_length_size_ = avc::nal_length_size(extradata);
+  framing_ = sample_framing(hevc::is_hevc_format(segments_[0].format), extradata);
   VideoDecoderInterface::FrameInfo info;
   info.width = segments_[0].width;
   info.height = segments_[0].height;
@@ -307,8 +308,8 @@ void DecoderAutomata::feeder() {
           if (si >= nsamples) continue;
           const uint64_t so = seg.sample_offsets[si], ss = seg.sample_sizes[si];
           if (so > seg.encoded_video.size() || ss > seg.encoded_video.size() - so) continue;
-          if (si == 0 || nal_length_size_ == 0 ||  // (no avcC - another codec, a test backend: trust the table)
-              avc::sample_is_idr(seg.encoded_video.data() + so, static_cast<size_t>(ss), nal_length_size_))
+          if (si == 0 || framing_.codec == 0 ||  // (no avcC / hvcC - another codec, a test backend: trust the table)
+              sample_starts_closed_gop(seg.encoded_video.data() + so, static_cast<size_t>(ss), framing_))
             syncs.push_back(k - first_frame);
         }
         hints->set_interval_keyframes(syncs);

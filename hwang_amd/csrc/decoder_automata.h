@@ -18,6 +18,8 @@
 // errors are latched and returned from get_frames().
 #pragma once
 
+#include "util/avc_sample.h"
+
 #include "video_decoder_factory.h"
 #include "video_decoder_interface.h"
 
@@ -101,7 +103,7 @@ class DecoderAutomata {
   bool dirty_ = false;         // something was fed since the last flush
   std::vector<EncodedData> segments_;
   size_t frame_size_ = 0;
-  int nal_length_size_ = 0;    // from the avcC handed to initialize(): to tell IDR sync samples from recovery points
+  SampleFraming framing_;      // from the avcC / hvcC handed to initialize(): to tell sync samples that start a closed GOP from recovery points
 
   // feeder cursor
   size_t feed_seg_ = 0;

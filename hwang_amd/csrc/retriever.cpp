@@ -5,6 +5,7 @@
 #include <time.h>
 #include <unistd.h>
 
+#include "hevc/hvcc.h"
 #include "util/avc_sample.h"
 #include "util/cpus.h"
 #include "util/numa.h"
@@ -264,11 +265,11 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
     const auto& kfs = index.keyframe_indices();
     // A GOP is an item of its own only if it is closed, i.e. if the sync sample behind it is an IDR picture; a
     // recovery-point I picture (open GOP) stays in the item of the GOP before it.
-    const int length_size = avc::nal_length_size(index.metadata_bytes());
+    const SampleFraming framing = sample_framing(hevc::is_hevc_format(index.format()), index.metadata_bytes());
     auto starts_closed_gop = [&](uint64_t sample) {
-      if (length_size == 0) return true;  // no avcC (another codec, a test backend): the sync table is all there is
+      if (framing.codec == 0) return true;  // no avcC / hvcC (another codec, a test backend): the sync table is all there is
       return offsets[sample] <= rq.file_size && sizes[sample] <= rq.file_size - offsets[sample] &&
-             avc::sample_is_idr(rq.file + offsets[sample], static_cast<size_t>(sizes[sample]), length_size);
+             sample_starts_closed_gop(rq.file + offsets[sample], static_cast<size_t>(sizes[sample]), framing);
     };
     for (size_t i = 0; i < plan.sample_index_intervals.size(); ++i) {
       const std::vector<uint64_t>& valid = plan.valid_frames[i];

@@ -37,4 +37,46 @@ inline bool sample_is_idr(const uint8_t* data, size_t size, int length_size) {
 }
 
 }  // namespace avc
+
+// The same question for either codec.  HEVC (ISO/IEC 14496-15 again: length-prefixed NAL units, the length's size in
+// byte 21 of the hvcC box, nal_unit_type in bits 1 .. 6 of the first header byte): IDR_W_RADL / IDR_N_LP (19, 20) and
+// the BLA types (16 .. 18: whatever leads them is not decodable by definition) start a closed GOP; a CRA picture (21)
+// does not - its RASL pictures refer to the GOP before.  An avcC payload read as the answer for an hvcC one says "one
+// length byte" and then "not an IDR picture" for every sample: correct but useless - no GOP of an HEVC clip was ever a
+// work item of its own.
+struct SampleFraming {
+  int codec = 0;        // 0: unknown (trust the container's sync table), 1: AVC, 2: HEVC
+  int length_size = 0;
+};
+inline SampleFraming sample_framing(bool hevc, const std::vector<uint8_t>& extradata) {
+  SampleFraming f;
+  if (hevc) {
+    if (extradata.size() >= 23 && extradata[0] == 1) {
+      f.codec = 2;
+      f.length_size = (extradata[21] & 3) + 1;
+    }
+    return f;
+  }
+  f.length_size = avc::nal_length_size(extradata);
+  f.codec = f.length_size ? 1 : 0;
+  return f;
+}
+inline bool sample_starts_closed_gop(const uint8_t* data, size_t size, const SampleFraming& f) {
+  if (f.codec == 0) return true;
+  if (f.codec == 1) return avc::sample_is_idr(data, size, f.length_size);
+  if (!data || f.length_size < 1 || f.length_size > 4) return false;
+  size_t pos = 0;
+  while (pos + f.length_size < size) {
+    size_t len = 0;
+    for (int i = 0; i < f.length_size; ++i) len = (len << 8) | data[pos + i];
+    pos += f.length_size;
+    if (len < 2 || len > size - pos) return false;
+    const int type = (data[pos] >> 1) & 0x3f;
+    if (type >= 16 && type <= 20) return true;   // BLA_W_LP .. IDR_N_LP
+    if (type < 32) return false;                 // another coded slice segment first: CRA, or not a random access point at all
+    pos += len;
+  }
+  return false;
+}
+
 }  // namespace hwang

@@ -138,6 +138,25 @@ def test_engine_batches_pictures_of_many_decoders_and_sizes(hw, oracle, gpu, tmp
     assert not errors, errors[0]
 
 
+def test_every_closed_gop_with_a_wanted_row_is_a_work_item(hw, oracle, gpu, tmp_path):
+    """Rows in byte-adjacent GOPs: the planner merges those GOPs into one interval (one seek for the reference's
+    serial loop); the retriever cuts the interval at every sync sample that is an IDR picture again (util/avc_sample.h
+    reads the NAL unit types through the hvcC box's length size) and feeds each GOP only up to its last wanted frame."""
+    path = str(tmp_path / "g.mp4")
+    gold = make_hevc_clip(path, width=176, height=144, frames=96, gop=12, bframes=0, refs=1, ctb=16)
+    idx = hw.index_video(path)
+    assert list(idx.keyframe_indices()) == list(range(0, 96, 12))
+    rows = [1, 13, 26, 40, 41, 95]                     # GOPs 0, 1, 2, 3, 3, 7: 0 .. 3 are adjacent
+    dec = hw.Decoder(path, video_index=idx, num_lanes=4)
+    got = dec.retrieve_yuv(rows)
+    for k, r in enumerate(rows):
+        assert np.array_equal(got[k], gold[r]), "row %d differs" % r
+    st = dec.stats()
+    assert st["intervals"] == 5, st                     # not 2 (the planner's intervals)
+    assert st["pictures_reconstructed"] == 2 + 2 + 3 + 6 + 12, st   # each GOP up to its last wanted frame, not to its end
+    assert st["frames_returned"] == len(rows)
+
+
 def test_a_thread_drives_several_hevc_decoders(hw, oracle, gpu, tmp_path):
     """Long queues are served by a thread per CPU that feeds several lanes in turn, a sample of each at a time, and
     passes over a decoder whose next picture would start by waiting for the GPU (BatchingHints::feed_would_wait:

@@ -129,7 +129,8 @@ def cpu_baseline(blob, idx, rows, workers=16, max_gops=32):
                       "decoders, reference semantics (whole GOP decoded), %.1f s" % (len(gops), sum(r["fed"] for r in res), sum(r["returned"] for r in res), workers, busy)}, md5
 
 
-def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, steps=3, fraction=0.01, workdir="/tmp/hwang_hevc_bench", cpu=False, soak=None):
+def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, steps=3, fraction=0.01, workdir="/tmp/hwang_hevc_bench", cpu=False, soak=None,
+        thread_per_lane=False):
     import ctypes as C
     import numpy as np
     import hwang_amd as hw
@@ -140,7 +141,9 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
     n = idx.frames()
     rows = sorted(np.random.default_rng(20240601).choice(n, max(1, round(fraction * n)), replace=False).tolist())
     dec = hw.Decoder(blob, video_index=idx, num_lanes=lanes)
-    dec.retrieve(rows[:8])     # first-use costs outside
+    dec.retrieve(rows[:8])     # first-use costs outside ...
+    del_me = dec.retrieve(rows)  # ... and every lane's staging sets and surfaces (one untimed call of the whole request)
+    del del_me
     times = []
     cpus_used = []
 
@@ -155,8 +158,20 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
     frozen = []
     for _ in range(steps):
         c0, z0 = os.times(), throttled_ms()
+        # (thread_per_lane: the retriever drives several lanes from a thread per CPU when a call has eight work items a
+        # lane or more - tuned on the H.264 path; this path measures higher with a thread per lane)
+        keep = os.environ.get("HWANG_LONG_QUEUE_FROM")
+        if thread_per_lane:
+            os.environ["HWANG_LONG_QUEUE_FROM"] = "1000000"
         t = time.perf_counter()
-        out = dec.retrieve(rows)
+        try:
+            out = dec.retrieve(rows)
+        finally:
+            if thread_per_lane:
+                if keep is None:
+                    os.environ.pop("HWANG_LONG_QUEUE_FROM", None)
+                else:
+                    os.environ["HWANG_LONG_QUEUE_FROM"] = keep
         times.append(time.perf_counter() - t)
         c1, z1 = os.times(), throttled_ms()
         cpus_used.append(round((c1.user - c0.user + c1.system - c0.system) / times[-1], 2))
@@ -181,7 +196,7 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
             cpu["parity_check"] = {"rows_compared": len(checked), "rows_equal": same,
                                    "what": "MD5 of the RGB24 frame returned by the GPU path against the oracle's for the same row"}
         del out
-    best = min(times)
+    best = sum(times) / len(times)   # (the mean of the timed calls - not the best one: a call that catches a burst of CPU beyond the quota is 10 % faster)
     if os.environ.get("HEVC_BENCH_THREADS"):   # where the process's CPU time went, thread by thread (lane threads end with their call)
         rows_ = []
         for tid in os.listdir("/proc/self/task"):
@@ -198,7 +213,8 @@ def run(width=1920, height=1080, gops=8, gop=24, frames=7200, qp=30, lanes=16, s
         print("process user %.2f s system %.2f s; calls took %s" % (ru.user, ru.system, times), file=sys.stderr)
     return {"what": "HEVC Main %dx%d, %d frames (%d unique GOPs of %d, CTB 64, 2 B pictures, SAO, AMP, sign hiding, QP %d), %.0f %% uniform-random "
                     "sample, one batched call, %d lanes of one GPU, RGB24 into host memory" % (width, height, n, gops, gop, qp, 100 * fraction, lanes),
-            "rows": len(rows), "value": round(len(rows) / best, 2), "unit": "frames/s", "seconds_per_call": [round(t, 3) for t in times],
+            "rows": len(rows), "value": round(len(rows) / best, 2), "unit": "frames/s", "value_is": "rows x timed calls / their total time (one untimed call of the same request first)",
+            "seconds_per_call": [round(t, 3) for t in times],
             "pictures_reconstructed": st["pictures_reconstructed"], "pictures_skipped": st["pictures_skipped"],
             "pictures_reconstructed_per_s": round(st["pictures_reconstructed"] / best, 1),
             "host_parse_ms_per_picture": round(st["entropy_ns"] / 1e6 / max(1, st["pictures_reconstructed"]), 3),
@@ -224,6 +240,7 @@ if __name__ == "__main__":
     ap.add_argument("--gops", type=int, default=8)
     ap.add_argument("--gop", type=int, default=24)
     ap.add_argument("--lanes", type=int, default=16)
+    ap.add_argument("--thread-per-lane", action="store_true", help="a lane thread per lane whatever the queue length")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--fraction", type=float, default=0.01)
     ap.add_argument("--width", type=int, default=1920)
@@ -231,7 +248,7 @@ if __name__ == "__main__":
     a = ap.parse_args()
     digests = [] if a.soak else None
     res = run(width=a.width, height=a.height, gops=a.gops, gop=a.gop, frames=a.frames, lanes=a.lanes, steps=a.steps, fraction=a.fraction, cpu=a.cpu_baseline,
-              soak=digests)
+              soak=digests, thread_per_lane=a.thread_per_lane)
     if a.soak:
         res["soak"] = {"calls": len(digests), "distinct_digests": len(set(digests)), "digest": digests[0]}
         assert len(set(digests)) == 1, "calls returned different frames: %s" % digests
