@@ -152,6 +152,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
       if (!hevc_) hevc_.reset(make_hevc_delegate(device_));
       hevc_active_ = true;
       if (!pending_wanted_.empty()) hevc_->set_wanted_frames(pending_wanted_);
+      if (!pending_keyframes_.empty()) hevc_->set_interval_keyframes(pending_keyframes_);
       return hevc_->configure(metadata, extradata);
     }
     hevc_active_ = false;
@@ -205,6 +206,7 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   Result flush() override {
     if (hevc_active_) {
       pending_wanted_.clear();
+      pending_keyframes_.clear();
       return hevc_->flush();
     }
     if (!parser_) return Result();
@@ -288,6 +290,10 @@ class AMDVideoDecoder : public VideoDecoderInterface,
   }
   void set_interval_keyframes(const std::vector<uint64_t>& ordinals) override {
     pending_keyframes_ = ordinals;
+    if (hevc_active_) {
+      hevc_->set_interval_keyframes(ordinals);
+      return;
+    }
     if (parser_) parser_->set_keyframes(ordinals);
   }
   BackendCounters counters() override {

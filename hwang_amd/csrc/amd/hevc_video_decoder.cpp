@@ -107,6 +107,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
                                " but the container says " + std::to_string(info.width) + "x" + std::to_string(info.height));
     info_ = info;
     if (!pending_wanted_.empty()) parser_->set_wanted(pending_wanted_);
+    if (!pending_keyframes_.empty()) parser_->set_keyframes(pending_keyframes_);
     return Result();
   }
 
@@ -134,6 +135,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     HWANG_HIP_RETURN(hipSetDevice(device_));
     parser_->flush();
     pending_wanted_.clear();
+    pending_keyframes_.clear();
     return take_error();
   }
 
@@ -165,6 +167,10 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   void set_wanted_frames(const std::vector<uint64_t>& ordinals) override {
     pending_wanted_ = ordinals;
     if (parser_) parser_->set_wanted(ordinals);
+  }
+  void set_interval_keyframes(const std::vector<uint64_t>& ordinals) override {
+    pending_keyframes_ = ordinals;
+    if (parser_) parser_->set_keyframes(ordinals);
   }
   bool feed_would_wait() override {
     if (!engine_) return false;
@@ -630,7 +636,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   int output_next_ = 0;
   std::unique_ptr<hevc::Parser> parser_;
   VideoDecoderInterface::FrameInfo info_;
-  std::vector<uint64_t> pending_wanted_;
+  std::vector<uint64_t> pending_wanted_, pending_keyframes_;
   std::mutex mu_;
   std::vector<SurfaceSlot> surf_;
   std::deque<int> outq_;

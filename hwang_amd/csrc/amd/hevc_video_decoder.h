@@ -23,6 +23,7 @@ class HevcDelegate {
   virtual int decoded_frames_buffered() = 0;
   virtual Result wait_until_frames_copied() = 0;
   virtual void set_wanted_frames(const std::vector<uint64_t>& ordinals) = 0;
+  virtual void set_interval_keyframes(const std::vector<uint64_t>& ordinals) = 0;
   virtual BackendCounters counters() = 0;
   virtual void reset_counters() = 0;
   virtual bool feed_would_wait() = 0;   // BatchingHints

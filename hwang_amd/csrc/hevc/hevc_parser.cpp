@@ -515,6 +515,8 @@ struct Parser::Impl {
   const Pps* P = nullptr;
   int64_t decoded = 0, skipped = 0;
   std::vector<uint64_t> wanted;
+  std::vector<uint64_t> keyframes;   // decoding-order ordinals of the interval's closed-GOP sync samples (optional)
+  uint64_t pictures_started = 0;     // pictures (= samples) since the interval began
   uint64_t outputs_emitted = 0;
 
   // DPB
@@ -2176,6 +2178,48 @@ struct Parser::Impl {
       if (pic_open && !close_picture()) return false;
       sh = h;
       skipping = false;
+      // Sparse decode, the tail of a GOP or of the interval: a picture at decoding position d is output at position
+      // d - sps_max_num_reorder_pics or later, so once d exceeds the last wanted position of its GOP by more than
+      // that, neither it nor anything that follows up to the next closed GOP can be wanted or be referred to by a
+      // wanted picture.  Whatever the DPB holds goes out first (every wanted position is among it or out already),
+      // then each such sample is one void output position and no work.  (h264_parser.cpp: start_picture does the same.)
+      {
+        const uint64_t ordinal = pictures_started++;
+        if (!wanted.empty()) {
+          uint64_t g0 = 0, g1 = UINT64_MAX;
+          if (!keyframes.empty()) {
+            auto it = std::upper_bound(keyframes.begin(), keyframes.end(), ordinal);
+            if (it != keyframes.end()) g1 = *it;
+            if (it != keyframes.begin()) g0 = *(it - 1);
+          }
+          auto hi = std::lower_bound(wanted.begin(), wanted.end(), g1);
+          const bool any = hi != wanted.begin() && *(hi - 1) >= g0;
+          if (!any || ordinal > *(hi - 1) + static_cast<uint64_t>(S ? S->max_num_reorder : 0)) {
+            cur = nullptr;
+            // (what is still waiting beyond the last wanted position would come out in the wrong places - the samples
+            // skipped from here on have positions among them: void positions, like theirs)
+            const uint64_t keep_to = any ? *(hi - 1) : 0;
+            for (Pic& p : dpb)
+              if (p.in_use && p.waiting && !any) p.placeholder = true;
+            for (;;) {
+              if (any && outputs_emitted > keep_to)
+                for (Pic& p : dpb)
+                  if (p.in_use && p.waiting) p.placeholder = true;
+              if (!bump()) break;
+            }
+            for (Pic& p : dpb)
+              if (p.in_use) {
+                p.ref = 0;
+                drop(&p);
+              }
+            sink->output_picture(-1);
+            ++outputs_emitted;
+            skipping = true;
+            ++skipped;
+            return true;
+          }
+        }
+      }
       if (!start_picture(type, tid)) return false;
       // sparse decode: a picture nothing refers to, at an output position nobody asked for
       const bool sub_layer_non_ref = type <= 14 && !(type & 1);
@@ -2325,7 +2369,9 @@ bool Parser::flush() {
   d.first_picture = true;
   d.prev_tid0_poc = 0;
   d.outputs_emitted = 0;
+  d.pictures_started = 0;
   d.wanted.clear();
+  d.keyframes.clear();
   d.error.clear();
   return true;
 }
@@ -2333,6 +2379,10 @@ bool Parser::flush() {
 void Parser::set_wanted(const std::vector<uint64_t>& ordinals) {
   impl_->wanted = ordinals;
   std::sort(impl_->wanted.begin(), impl_->wanted.end());
+}
+void Parser::set_keyframes(const std::vector<uint64_t>& ordinals) {
+  impl_->keyframes = ordinals;
+  std::sort(impl_->keyframes.begin(), impl_->keyframes.end());
 }
 int Parser::width() const { return impl_->S ? impl_->S->width - impl_->S->crop_l - impl_->S->crop_r : 0; }
 int Parser::height() const { return impl_->S ? impl_->S->height - impl_->S->crop_t - impl_->S->crop_b : 0; }

@@ -81,6 +81,10 @@ class Parser {
   // display-order positions (from the start of the interval) that will be fetched: unwanted pictures that nothing
   // refers to (sub-layer non-reference pictures of the highest temporal layer) are not decoded
   void set_wanted(const std::vector<uint64_t>& ordinals);
+  // ... and, optionally, which samples of the interval (decoding order, same origin) start a closed GOP: what lies
+  // between a GOP's last wanted position (+ the reorder depth) and the next of these is not decoded at all, and neither
+  // is anything behind the interval's last wanted position.  Every such sample is still one (void) output position.
+  void set_keyframes(const std::vector<uint64_t>& ordinals);
   int width() const;   // cropped
   int height() const;
   const std::string& error() const;

@@ -4,7 +4,7 @@
 // check parser + seam against the oracle's pictures (tests/test_hevc_host.py).  What k_hevc.hip does with the same
 // records is checked on the GPU (tests/test_gpu_hevc.py); this file shares no code with it.
 //
-//   hevc_records_cpu <hvcc file> <samples blob> <sizes file (one decimal per line)> <out.yuv> [wanted ordinals...]
+//   hevc_records_cpu <hvcc file> <samples blob> <sizes file (one decimal per line)> <out.yuv> [wanted ordinals...] [kf keyframe ordinals...]
 // Output: cropped I420 frames in display order; a skipped output position is written as a frame of zeros.
 #include "../../hwang_amd/csrc/hevc/hevc_parser.h"
 #include "../../hwang_amd/csrc/hevc/hevc_tables.h"
@@ -503,9 +503,14 @@ int main(int argc, char** argv) {
     std::printf("configure: %s\n", parser.error().c_str());
     return 1;
   }
-  std::vector<uint64_t> wanted;
-  for (int i = 5; i < argc; ++i) wanted.push_back(std::strtoull(argv[i], nullptr, 10));
+  std::vector<uint64_t> wanted, keyframes;   // [wanted ordinals ...] ["kf" closed-GOP sync sample ordinals ...]
+  bool kf = false;
+  for (int i = 5; i < argc; ++i) {
+    if (std::string(argv[i]) == "kf") kf = true;
+    else (kf ? keyframes : wanted).push_back(std::strtoull(argv[i], nullptr, 10));
+  }
   if (!wanted.empty()) parser.set_wanted(wanted);
+  if (!keyframes.empty()) parser.set_keyframes(keyframes);
   size_t at = 0;
   for (size_t i = 0; i < sizes.size(); ++i) {
     if (!parser.decode(blob.data() + at, sizes[i])) {

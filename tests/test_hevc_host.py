@@ -29,7 +29,7 @@ def records_cpu(built):
     return EXE
 
 
-def run_host(exe, hw, path, tmp_path, wanted=()):
+def run_host(exe, hw, path, tmp_path, wanted=(), keyframes=()):
     idx = hw.index_video(path)
     offs, sizes = idx.sample_offsets(), idx.sample_sizes()
     data = open(path, "rb").read()
@@ -37,7 +37,7 @@ def run_host(exe, hw, path, tmp_path, wanted=()):
     (tmp_path / "blob").write_bytes(b"".join(data[o:o + s] for o, s in zip(offs, sizes)))
     (tmp_path / "sizes").write_text("\n".join(str(s) for s in sizes))
     r = subprocess.run([exe, str(tmp_path / "hvcc"), str(tmp_path / "blob"), str(tmp_path / "sizes"), str(tmp_path / "out.yuv")] +
-                       [str(w) for w in wanted], capture_output=True, text=True, timeout=300)
+                       [str(w) for w in wanted] + (["kf"] + [str(k) for k in keyframes] if keyframes else []), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr[-1000:]
     info = dict(kv.split("=") for kv in r.stdout.split())
     return np.fromfile(str(tmp_path / "out.yuv"), dtype=np.uint8), {k: int(v) for k, v in info.items()}
@@ -72,3 +72,29 @@ def test_sparse_hint_skips_only_pictures_nothing_refers_to(records_cpu, hw, tmp_
     # whatever was decoded although unwanted is right too; the skipped positions are the zero frames
     for r in range(13):
         assert np.array_equal(got[r], gold[r]) or not got[r].any()
+
+
+@pytest.mark.parametrize("bframes", [0, 2])
+def test_gop_tails_and_the_interval_tail_are_not_decoded(records_cpu, hw, tmp_path, bframes):
+    """An interval of four closed GOPs with wanted rows in the first, second and fourth: told where the GOPs begin
+    (Parser::set_keyframes, what DecoderAutomata passes through SparseDecodeHints::set_interval_keyframes), the parser
+    decodes each GOP up to its last wanted position plus the reorder depth and nothing of the third; every sample is
+    still one output position, and the wanted ones hold the right frames."""
+    path = str(tmp_path / "k.mp4")
+    gold = make_hevc_clip(path, width=64, height=64, frames=48, gop=12, bframes=bframes, refs=2)
+    wanted = [1, 13, 17, 38]
+    full, info_full = run_host(records_cpu, hw, path, tmp_path, wanted=wanted)
+    got, info = run_host(records_cpu, hw, path, tmp_path, wanted=wanted, keyframes=[0, 12, 24, 36])
+    got = got.reshape(-1, gold.shape[1])
+    assert len(got) == 48 and info["frames"] == 48 and info["decoded"] + info["skipped"] == 48
+    for r in wanted:
+        assert np.array_equal(got[r], gold[r]), "wanted row %d" % r
+    for r in range(48):
+        assert np.array_equal(got[r], gold[r]) or not got[r].any()
+    assert not got[24:36].any(), "nothing of the GOP without a wanted row is decoded"
+    assert info["decoded"] < info_full["decoded"], (info, info_full)
+    if bframes == 0:
+        assert info["decoded"] == 2 + 6 + 0 + 3 and info_full["decoded"] == 39, (info, info_full)
+    # without the GOP boundaries: everything up to the last wanted position (+ reorder depth), nothing behind it
+    full = full.reshape(-1, gold.shape[1])
+    assert not full[38 + 6:].any() and info_full["decoded"] <= 38 + 6
