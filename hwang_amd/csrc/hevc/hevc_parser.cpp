@@ -307,12 +307,17 @@ bool parse_rps(Bits& b, Rps* out, int idx, int num_sets, const Rps* sets) {
 // 9.3.4.3 with the offset kept scaled: `value` holds ivlOffset in its top bits and `bits` not yet consumed bits
 // below it, so a renormalisation is a subtraction from `bits` and a refill happens once per 32 bits.
 struct NextCtx {
-  uint8_t t[2][128];  // [outcome is the less probable symbol][state << 1 | MPS] -> the context's next byte
+  uint8_t mlps[256];   // the next context byte: [128 + state] after the more probable symbol, [127 - state] after the other
+  uint32_t lps4[128];  // [state = pStateIdx << 1 | valMps]: rangeTabLps for qRangeIdx 0 .. 3, a byte each - the load depends
+                       // on the context only, so it is off the range -> range chain that paces consecutive bins
   NextCtx() {
     for (int st = 0; st < 64; ++st)
       for (int mps = 0; mps < 2; ++mps) {
-        t[0][st << 1 | mps] = static_cast<uint8_t>((st < 62 ? st + 1 : st) << 1 | mps);
-        t[1][st << 1 | mps] = static_cast<uint8_t>(hevc_trans_lps[st] << 1 | (st == 0 ? !mps : mps));
+        const int s = st << 1 | mps;
+        mlps[128 + s] = static_cast<uint8_t>((st < 62 ? st + 1 : st) << 1 | mps);
+        mlps[127 - s] = static_cast<uint8_t>(hevc_trans_lps[st] << 1 | (st == 0 ? !mps : mps));
+        lps4[s] = 0;
+        for (int q = 0; q < 4; ++q) lps4[s] |= static_cast<uint32_t>(hevc_range_lps[st][q]) << (8 * q);
       }
   }
 };
@@ -348,35 +353,33 @@ class Cabac {
   }
   bool overrun() const { return broken_ || pos_ > n_ + 8; }
 
-  // 9.3.4.3.2.  The context byte is state << 1 | MPS; what follows an outcome is one table lookup (the next byte for either
-  // outcome, the MPS flip at state 0 folded in), and the outcome selects - offset, range, next byte, bin - without a
-  // branch: which way a bin goes is the least predictable branch of the parser.
-  int decision(uint8_t* ctx) {
-    const uint32_t s = *ctx;
-    const uint32_t lps = hevc_range_lps[s >> 1][(range_ >> 6) & 3];
-    const uint32_t rmps = range_ - lps;
-    const uint64_t scaled = static_cast<uint64_t>(rmps) << bits_;
-    const bool is_lps = value_ >= scaled;
-    value_ -= is_lps ? scaled : 0;
-    range_ = is_lps ? lps : rmps;
-    *ctx = kNextCtx.t[is_lps][s];
-    const int bin = static_cast<int>((s & 1) ^ static_cast<uint32_t>(is_lps));
-    if (range_ < 256) {
-      const int n = __builtin_clz(range_) - 23;
-      range_ <<= n;
-      bits_ -= n;
-      if (bits_ < 0) refill();
-    }
-    return bin;
+  // 9.3.4.3.2, as h264_parser.cpp's cabac_step has it (counted there on the box's CPU: profiles/r05_host_perf_counters.txt).
+  // The context is state << 1 | MPS in a 16-bit word - a byte store may alias anything, which would force the engine's
+  // own members through memory around every bin.  The outcome is a sign: state ^ ~sign indexes ONE table for the next
+  // state on either side and its low bit is the bin; offset, range and next state are selected without a branch (which
+  // way a bin goes is the least predictable branch of the parser).
+  int decision(uint16_t* ctx) {
+    const int32_t s = *ctx;
+    const uint32_t lps = (kNextCtx.lps4[s] >> ((range_ >> 3) & 24)) & 0xff;
+    uint32_t r = range_ - lps;
+    const uint64_t scaled = static_cast<uint64_t>(r) << bits_;
+    const int64_t d = static_cast<int64_t>(value_ - scaled);  // >= 0: the less probable symbol
+    value_ = d >= 0 ? static_cast<uint64_t>(d) : value_;
+    r = d >= 0 ? lps : r;
+    const int32_t sx = s ^ static_cast<int32_t>(~(d >> 63));
+    *ctx = kNextCtx.mlps[128 + sx];
+    const int n = __builtin_clz(r) - 23;  // 0 when r >= 256
+    range_ = r << n;
+    bits_ -= n;
+    if (bits_ < 0) refill();
+    return sx & 1;
   }
   int bypass() {
     if (--bits_ < 0) refill();
     const uint64_t scaled = static_cast<uint64_t>(range_) << bits_;
-    if (value_ >= scaled) {
-      value_ -= scaled;
-      return 1;
-    }
-    return 0;
+    const int64_t d = static_cast<int64_t>(value_ - scaled);  // (offset < 2^62: the sign of the difference is the bin)
+    value_ = d >= 0 ? static_cast<uint64_t>(d) : value_;
+    return static_cast<int>(~d >> 63) & 1;
   }
   // n bypass bins at once (n <= 16): the offset divided by the range is the n bins read as a number
   unsigned bypass_bits(int n) {
@@ -550,7 +553,7 @@ struct Parser::Impl {
   SliceHdr sh;
   int slice_idx = 0;
   Cabac cabac;
-  uint8_t ctx[HC_CTX_COUNT], ctx_saved[HC_CTX_COUNT];
+  uint16_t ctx[HC_CTX_COUNT], ctx_saved[HC_CTX_COUNT];  // (16-bit on purpose: Cabac::decision)
   bool qp_delta_coded = false;
   int qp_delta_val = 0, qp_prev = 0, last_qp = 0, qg_x = 0, qg_y = 0;
   int weights_base[2] = {0, 0};
@@ -1419,7 +1422,7 @@ struct Parser::Impl {
       const int v = hevc_cabac_init[t][i];
       const int pre = clip3(1, 126, ((((v >> 4) * 5 - 45) * qp) >> 4) + ((v & 15) << 3) - 16);
       const int mps = pre > 63;
-      ctx[i] = static_cast<uint8_t>((mps ? pre - 64 : 63 - pre) << 1 | mps);
+      ctx[i] = static_cast<uint16_t>((mps ? pre - 64 : 63 - pre) << 1 | mps);
     }
   }
   int bin(int c) { return cabac.decision(&ctx[c]); }
