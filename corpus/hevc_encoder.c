@@ -27,7 +27,7 @@ typedef struct {
   int width, height, frames, gop, bframes, refs, qp, seed, fps;
   int ctb, min_tb, max_tb, th_intra, th_inter;
   int amp, sao, pcm, tskip, bypass, sdh, qp_swing, scaling, wp, tmvp, strong, merge_cand, pml, slices, wpp;
-  int deblock_off, beta, tc, cip, rps_sps, poc_bits, random_intra, cabac_init, cb_off, cr_off, nal_length_size, extra_nals;
+  int deblock_off, beta, tc, cip, rps_sps, poc_bits, random_intra, cabac_init, cb_off, cr_off, nal_length_size, extra_nals, open_gop;
   int inter_rps;   /* reference picture sets are coded by prediction from an earlier one wherever a deltaRps exists (7.3.7);
                       needs --rps-sps: a slice header's own set is predicted from one of the SPS's */
   int multi_pps;   /* two picture parameter sets, taken in turn by the pictures: the second has another init_qp_minus26 and
@@ -171,6 +171,7 @@ typedef struct {
   int disp;       /* display index within the GOP = POC */
   int type;       /* HV_SLICE_I / P / B */
   int is_ref, idr;
+  int cra, rasl;  /* --open-gop: a CRA picture at the head of a GOP, the leading pictures (RASL_N) behind it in decoding order */
 } PicPlan;
 
 typedef struct {
@@ -182,6 +183,7 @@ typedef struct {
   HvRps sps_sets[16];
   int num_sps_sets;
   int refset[HV_MAX_REFS], n_refset; /* POCs of the reference pictures kept */
+  int purge_below;                   /* --open-gop: the CRA picture's POC while what precedes it is still kept for its leading pictures, else -1 */
   uint32_t pic_counter;
   /* per picture */
   HvSliceHeader slice_sh[64];
@@ -429,6 +431,25 @@ static int plan_gop(const Cfg* c, int n, PicPlan* out) {
   return k;
 }
 
+/* --open-gop, every GOP but the first: a CRA picture (21) in place of the IDR picture, displayed behind `bframes` leading
+ * pictures that are decoded after it and predict from it AND from the last picture of the GOP before (RASL_N, 8): what
+ * x265 writes by default.  Decoding that starts at the CRA picture cannot decode them (8.3.3: their references are made
+ * up); everything behind the CRA picture in output order refers to nothing in front of it. */
+static int plan_open_gop(const Cfg* c, int n, PicPlan* out) {
+  int k = 0;
+  const int lead = hv_min(c->bframes, n - 1);
+  out[k++] = (PicPlan){lead, HV_SLICE_I, 1, 0, 1, 0};
+  for (int i = 0; i < lead; ++i) out[k++] = (PicPlan){i, HV_SLICE_B, 0, 0, 0, 1};
+  int prev = lead;
+  while (prev < n - 1) {
+    int next = hv_min(prev + c->bframes + 1, n - 1);
+    out[k++] = (PicPlan){next, HV_SLICE_P, 1, 0, 0, 0};
+    for (int i = prev + 1; i < next; ++i) out[k++] = (PicPlan){i, HV_SLICE_B, 0, 0, 0, 0};
+    prev = next;
+  }
+  return k;
+}
+
 /* the reference picture set of a picture at `poc`: everything in refset, nearest first on either side */
 static void rps_for(const Enc* e, int poc, HvRps* r) {
   memset(r, 0, sizeof(*r));
@@ -489,7 +510,7 @@ static void write_slice_header(Enc* e, BitW* w, const PicPlan* pp, int first_ctb
   const HvSps* sps = &e->d->sps[0];
   const uint32_t h = hash3(e->h, 0x51, (uint32_t)first_ctb);
   bw_put(w, first_ctb == 0, 1);
-  if (pp->idr) bw_put(w, 0, 1);
+  if (pp->idr || pp->cra) bw_put(w, 0, 1);   /* no_output_of_prior_pics_flag: every IRAP picture has it */
   const int pps_id = c->multi_pps ? (int)(e->pic_counter & 1) : 0;
   bw_ue(w, (uint32_t)pps_id);
   if (first_ctb) bw_put(w, (uint32_t)first_ctb, hv_ceil_log2((unsigned)(sps->width_ctb * sps->height_ctb)));
@@ -1241,6 +1262,14 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
   HevcOracle* d = e->d;
   e->h = hash3((uint32_t)c->seed, e->pic_counter++, 0xabc);
   if (pp->idr) e->n_refset = 0;
+  if (pp->cra) e->purge_below = pp->disp;
+  else if (!pp->rasl && e->purge_below >= 0) { /* the first trailing picture: nothing in front of the CRA picture is kept any longer */
+    int m = 0;
+    for (int i = 0; i < e->n_refset; ++i)
+      if (e->refset[i] >= e->purge_below) e->refset[m++] = e->refset[i];
+    e->n_refset = m;
+    e->purge_below = -1;
+  }
   HvRps rps;
   rps_for(e, pp->disp, &rps);
   int nl0 = 0, nl1 = 0;
@@ -1251,7 +1280,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
     if (c->cover && total > 1 && (e->h & 3) == 0) nl0 = nl1 = hv_min(total + 1, 15); /* lists longer than the set: entries repeat */
   }
   scene_render(&e->scene, (int)(e->pic_counter - 1) + 0);
-  const int nal_type = pp->idr ? 19 : pp->is_ref ? 1 : 0;
+  const int nal_type = pp->idr ? 19 : pp->cra ? 21 : pp->rasl ? 8 : pp->is_ref ? 1 : 0;
   const HvSps* sps = &d->sps[0];
   const int total_ctb = sps->width_ctb * sps->height_ctb;
   e->n_slices = hv_min(hv_max(c->slices, 1), total_ctb);
@@ -1354,8 +1383,8 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
     }
     bput(&rbsp, hdr_rbsp[k].b, hdr_rbsp[k].n);
     bput(&rbsp, d->ce.buf, d->ce.nbits / 8);
-    g_nal_tid_plus1 = (c->sub_layers == 2 && !pp->is_ref && !pp->idr) ? 2 : 1;
-    nal_append(&nal, (c->sub_layers == 2 && !pp->is_ref && !pp->idr) ? 2 /* TSA_N */ : nal_type, rbsp.b, rbsp.n);
+    g_nal_tid_plus1 = (c->sub_layers == 2 && !pp->is_ref && !pp->idr && !pp->rasl) ? 2 : 1;
+    nal_append(&nal, (c->sub_layers == 2 && !pp->is_ref && !pp->idr && !pp->rasl) ? 2 /* TSA_N */ : nal_type, rbsp.b, rbsp.n);
     g_nal_tid_plus1 = 1;
     sample_add_nal(sample, c->nal_length_size, &nal);
     free(rbsp.b);
@@ -1524,6 +1553,7 @@ static void usage(void) {
 
 int main(int argc, char** argv) {
   Enc* e = (Enc*)calloc(1, sizeof(Enc));
+  e->purge_below = -1;
   Cfg* c = &e->c;
 #define A(name, flag, def) c->name = arg_int(argc, argv, flag, def)
   A(width, "--width", 0); A(height, "--height", 0); A(frames, "--frames", 0); A(gop, "--gop", 30); A(bframes, "--bframes", 0);
@@ -1532,7 +1562,7 @@ int main(int argc, char** argv) {
   A(pcm, "--pcm", 0); A(tskip, "--tskip", 0); A(bypass, "--bypass", 0); A(sdh, "--sdh", 0); A(qp_swing, "--qp-swing", 0);
   A(scaling, "--scaling", 0); A(wp, "--wp", 0); A(tmvp, "--tmvp", 1); A(strong, "--strong", 1); A(merge_cand, "--merge-cand", 5);
   A(pml, "--pml", 2); A(slices, "--slices", 1); A(wpp, "--wpp", 0); A(deblock_off, "--deblock-off", 0); A(beta, "--beta", 0);
-  A(tc, "--tc", 0); A(cip, "--cip", 0); A(rps_sps, "--rps-sps", 0); A(poc_bits, "--poc-bits", 8); A(random_intra, "--random-intra", 0);
+  A(tc, "--tc", 0); A(cip, "--cip", 0); A(rps_sps, "--rps-sps", 0); A(poc_bits, "--poc-bits", 8); A(random_intra, "--random-intra", 0); A(open_gop, "--open-gop", 0);
   A(cabac_init, "--cabac-init", 0); A(cb_off, "--cb-off", 0); A(cr_off, "--cr-off", 0); A(slice_cb_off, "--slice-cb-off", 0);
   A(nal_length_size, "--nal-length-size", 4); A(extra_nals, "--extra-nals", 0); A(bpyramid, "--bpyramid", 0); A(long_term, "--long-term", 0); A(inter_rps, "--inter-rps", 0); A(rplm, "--rplm", 0); A(keep_unused, "--keep-unused", 0); A(sub_layers, "--sub-layers", 1); A(sh_extras, "--sh-extras", 0); A(multi_pps, "--multi-pps", 0);
   A(lf_across, "--lf-across", 1); A(mvd_l1_zero, "--mvd-l1-zero", 0); A(hvc1, "--hvc1", 0); A(intra_only, "--intra-only", 0);
@@ -1584,15 +1614,21 @@ int main(int argc, char** argv) {
   size_t k = 0;
   for (int g0 = 0; g0 < c->frames; g0 += c->gop) {
     PicPlan plan[600];
-    const int n = plan_gop(c, hv_min(c->gop, c->frames - g0), plan);
+    const int open = c->open_gop && g0 > 0 && c->bframes > 0 && !c->intra_only;
+    const int n = open ? plan_open_gop(c, hv_min(c->gop, c->frames - g0), plan) : plan_gop(c, hv_min(c->gop, c->frames - g0), plan);
+    /* (--open-gop: one IDR picture at the start, the picture order count runs on through the GOPs) */
+    const int poc_base = c->open_gop ? g0 : 0;
     for (int i = 0; i < n; ++i, ++k) {
       /* the scene is rendered at the DISPLAY position */
       const uint32_t keep = e->pic_counter;
       e->pic_counter = (uint32_t)(g0 + plan[i].disp);
+      plan[i].disp += poc_base;
+      if (c->open_gop && g0 > 0) plan[i].idr = 0, plan[i].cra = plan[i].cra || (i == 0);
       const int rc = encode_picture(e, &plan[i], &samples[k]);
+      plan[i].disp -= poc_base;
       e->pic_counter = keep + 1;
       if (rc) return 1;
-      keys[k] = (uint8_t)plan[i].idr;
+      keys[k] = (uint8_t)(plan[i].idr || plan[i].cra);
       cts[k] = g0 + plan[i].disp - (int)k + (c->bframes ? (c->bpyramid ? 2 : 1) : 0);
       while (hevco_frames_ready(e->d)) {
         int w, h, poc;

@@ -78,6 +78,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     parser_.reset();
     (void)quiesce();
     free_all();
+    if (fill_stream_) (void)hipStreamDestroy(fill_stream_);
     for (Output& o : outputs_) {
       if (o.host) (void)hipHostFree(o.host);
       if (o.job.done) (void)hipEventDestroy(o.job.done);
@@ -366,6 +367,51 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (slot >= 0 && slot < static_cast<int>(surf_.size())) surf_[slot].held &= ~kParser;
   }
 
+  // A reference picture that was never in the stream (decoding entered at a CRA picture; hevc_parser.h): a surface of
+  // 128s.  Rare - once or twice per such entry - and outside the engine's order, so it waits: a free surface may still be
+  // read by pictures of this decoder that are on the GPU (a surface is free from the moment the PARSER lets go of it;
+  // a picture that takes it over queues up behind those, this fill does not).
+  int missing_surface(std::string* error) override {
+    for (int i = 0; i < num_sets_; ++i) {
+      Set& set = sets_[i];
+      if (!set.busy) continue;
+      if (!engine_->wait_launched(&set.job)) {
+        *error = engine_->error();
+        return -1;
+      }
+      if (sleepy_event_wait(set.done) != hipSuccess) {
+        *error = "waiting for a staging set's event failed";
+        return -1;
+      }
+      set.busy = false;
+    }
+    int slot = -1;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      for (size_t i = 0; i < surf_.size() && slot < 0; ++i)
+        if (!surf_[i].held) slot = static_cast<int>(i);
+      if (slot < 0 && surf_.size() < static_cast<size_t>(gh::kMaxSurfaces)) {
+        surf_.push_back(SurfaceSlot());
+        slot = static_cast<int>(surf_.size()) - 1;
+      }
+      if (slot >= 0) surf_[slot].held = kParser;
+    }
+    if (slot < 0) {
+      *error = "no free surface: decoded frames are not being fetched or discarded";
+      return -1;
+    }
+    bool ok = surf_[slot].dev || hipMalloc(reinterpret_cast<void**>(&surf_[slot].dev), surface_bytes_) == hipSuccess;
+    if (ok && !fill_stream_) ok = hipStreamCreateWithFlags(&fill_stream_, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMemsetAsync(surf_[slot].dev, 128, surface_bytes_, fill_stream_) == hipSuccess && hipStreamSynchronize(fill_stream_) == hipSuccess;
+    if (!ok) {
+      *error = "could not make a grey surface for a reference picture that is not in the stream";
+      std::lock_guard<std::mutex> lk(mu_);
+      surf_[slot].held = 0;
+      return -1;
+    }
+    return slot;
+  }
+
  private:
   enum { kParser = 1, kOutput = 2 };
   struct SurfaceSlot {
@@ -630,6 +676,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   }
 
   const int device_;
+  hipStream_t fill_stream_ = nullptr;   // missing_surface()
   std::shared_ptr<gh::Engine> engine_;
   const int client_;
   Output outputs_[kOutputs];

@@ -438,6 +438,7 @@ struct Pic {
   int poc = 0, ref = 0 /* 0 none, 1 short, 2 long */, latency = 0;
   bool waiting = false;  // for output
   bool placeholder = false;  // skipped on purpose / made up for a missing reference
+  bool made_up = false;      // ... the latter: gets a surface of 128s when something predicts from it
   int32_t ref_poc_tab[amd::hevc::kMaxSurfaces] = {0};  // POC / long-term state of DPB entry i when this picture referred to it
   uint8_t ref_lt_tab[amd::hevc::kMaxSurfaces] = {0};
   // Motion: one entry per prediction block ([0]: none - intra, or a placeholder picture), and per 4x4 luma block, in
@@ -967,15 +968,16 @@ struct Parser::Impl {
     }
     return nullptr;
   }
-  // 8.3.3: a reference that was never decoded (a stream entered at a CRA picture): a stand-in without motion whose
-  // samples are whatever its surface holds - it is never wanted itself, and what predicts from it is not decodable
-  // in the first place
+  // 8.3.3: a reference that was never decoded (a stream entered at a CRA picture): a stand-in without motion; it gets
+  // a surface of 128s (8.3.3.2) when a prediction block first refers to it - the CRA picture's leading pictures do,
+  // and they are output like every other picture (one frame per sample: the callers count)
   Pic* make_missing(int poc_value, int state) {
     Pic* p = grab_pic();
     if (!p) return nullptr;
     p->poc = poc_value;
     p->ref = state;
     p->placeholder = true;
+    p->made_up = true;
     p->pu_of.assign(S ? static_cast<size_t>(S->width / 4) * (S->height / 4) : 0, 0u);
     p->pu_motion.assign(1, Motion());
     return p;
@@ -1869,7 +1871,13 @@ struct Parser::Impl {
         m.rid[l] = static_cast<uint8_t>(r - dpb);
         cur->ref_poc_tab[m.rid[l]] = r->poc;
         cur->ref_lt_tab[m.rid[l]] = r->ref == 2;
-        if (r->slot < 0) return fail("prediction from a picture that was not decoded (POC %d)", r->poc);
+        if (r->slot < 0) {
+          if (!r->made_up) return fail("prediction from a picture that was not decoded (POC %d)", r->poc);
+          std::string why;
+          const int made = sink->missing_surface(&why);
+          if (made < 0) return fail("prediction from a picture that was never in the stream (POC %d): %s", r->poc, why.c_str());
+          dpb[m.rid[l]].slot = made;
+        }
         p.ref_slot[l] = static_cast<uint8_t>(r->slot);
         note_ref_slot(r->slot);
         p.mv[l][0] = m.mv[l][0];

@@ -68,6 +68,13 @@ class PictureSink {
   // display order; slot < 0: an output position whose picture was skipped on purpose (sparse hint)
   virtual void output_picture(int slot) = 0;
   virtual void release_surface(int slot) = 0;
+  // 8.3.3.2: a surface of the current picture's size whose samples are all 128, for a reference picture that was never
+  // decoded (a stream entered at a CRA picture: its leading pictures predict from the GOP before).  Asked for when a
+  // prediction block first refers to such a picture, released through release_surface like any other.  < 0: none.
+  virtual int missing_surface(std::string* error) {
+    *error = "this sink has no surfaces for made-up reference pictures";
+    return -1;
+  }
   virtual void abandon_picture(const PicDone& /*done*/) {}
 };
 

@@ -297,4 +297,8 @@ HEVC_MATRIX = [
     ("tiny_8x8", dict(width=8, height=8, frames=5, gop=5, bframes=1, refs=2, ctb=16, sao=1)),
     ("tiny_row_264x8", dict(width=264, height=8, frames=5, gop=5, bframes=1, refs=2, ctb=64, sao=1, amp=1)),
     ("tiny_column_16x136", dict(width=16, height=136, frames=5, gop=5, bframes=1, refs=2, ctb=16, sao=1, wpp=1)),
+    # open GOPs, x265's default: every GOP but the first starts with a CRA picture (21) whose leading pictures (RASL_N)
+    # predict across it from the GOP before; one IDR picture, the picture order count runs through (and wraps)
+    ("open_gop_bb", dict(frames=36, gop=12, bframes=2, refs=2, open_gop=1, poc_bits=5)),
+    ("open_gop_tools", dict(frames=27, gop=9, bframes=2, refs=3, open_gop=1, tmvp=1, sao=1, amp=1, ctb=32, wp=1, slices=2, extra_nals=1)),
 ]

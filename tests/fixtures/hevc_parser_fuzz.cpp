@@ -178,6 +178,15 @@ struct CheckingSink : public hevc::PictureSink {
   void release_surface(int slot) override {
     if (slot >= 0 && slot < gh::kMaxSurfaces) held[slot] = 0;
   }
+  int missing_surface(std::string* error) override {
+    for (int i = 0; i < gh::kMaxSurfaces; ++i)
+      if (!held[i]) {
+        held[i] = 1;
+        return i;
+      }
+    *error = "no free surface";
+    return -1;
+  }
 };
 
 static uint64_t rng_state;

@@ -481,6 +481,20 @@ struct CpuSink : public hevc::PictureSink {
   void release_surface(int slot) override {
     if (slot >= 0) held[slot] = 0;
   }
+  int missing_surface(std::string* error) override {
+    int slot = -1;
+    for (int i = 0; i < gh::kMaxSurfaces && slot < 0; ++i)
+      if (!held[i]) slot = i;
+    if (slot < 0) {
+      *error = "no free surface";
+      return -1;
+    }
+    held[slot] = 1;
+    surf[slot].p[0].assign(static_cast<size_t>(W) * H, 128);
+    surf[slot].p[1].assign(static_cast<size_t>(W) * H / 4, 128);
+    surf[slot].p[2].assign(static_cast<size_t>(W) * H / 4, 128);
+    return slot;
+  }
 };
 
 static std::vector<uint8_t> slurp(const char* path) {

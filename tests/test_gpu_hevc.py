@@ -157,6 +157,42 @@ def test_every_closed_gop_with_a_wanted_row_is_a_work_item(hw, oracle, gpu, tmp_
     assert st["frames_returned"] == len(rows)
 
 
+@pytest.mark.parametrize("name", ["open_gop_bb", "open_gop_tools"])
+def test_open_gops_and_decoding_that_enters_at_a_cra_picture(hw, oracle, gpu, tmp_path, name):
+    """x265's default GOP structure: CRA pictures with leading pictures that predict across them.  Sequentially every
+    frame is the encoder's reconstruction.  A sparse request whose interval starts at a CRA sync sample enters the
+    stream there: the leading pictures' references were never decoded, 8.3.3 makes them up as surfaces of 128s
+    (HEVCVideoDecoder::missing_surface), and what comes out is what the oracle gives from the same entry point - the
+    leading pictures included; a CRA picture inside an interval is not a place to cut it (util/avc_sample.h), so its
+    leading pictures are the sequential decode's there."""
+    kw = dict(dict(HEVC_MATRIX)[name])
+    path = str(tmp_path / "o.mp4")
+    gold = make_hevc_clip(path, **kw)
+    idx = hw.index_video(path)
+    n, gop = kw["frames"], kw["gop"]
+    dec = hw.Decoder(path, video_index=idx, num_lanes=3)
+    got = dec.retrieve_yuv(list(range(n)))
+    for i in range(n):
+        assert np.array_equal(got[i], gold[i]), "sequential, frame %d" % i
+    # (the reference's planner - pinned by its golden values - starts the request's FIRST interval at the file's first
+    # sync sample when the GOPs in between are byte-adjacent: rows of the second GOP are decoded from the IDR picture,
+    # rows of the third enter at its CRA picture)
+    enters = 2 * gop
+    assert [iv[0] for iv in hw.slice_into_video_intervals(idx, [enters, enters + 1])] == [(enters, n)]
+    want, _ = oracle.decode_file_hevc(path, idx, first=enters, count=n - enters)
+    for rows in ([enters, enters + 1, enters + 2, enters + 7], [enters + 1], [enters + 3, n - 1], [gop, gop + 1, enters, enters + 1]):
+        got = dec.retrieve_yuv(rows)
+        for k, r in enumerate(rows):
+            if rows[0] < enters:        # decoded from the IDR picture on: the leading pictures have their references
+                assert np.array_equal(got[k], gold[r]), "rows %s: row %d" % (rows, r)
+            else:
+                assert np.array_equal(got[k], want[r - enters][0]), "rows %s: row %d against the oracle entering at sample %d" % (rows, r, enters)
+                assert np.array_equal(got[k], gold[r]) == (r >= enters + kw["bframes"])
+        serial = dec.retrieve_serial(rows)
+        for k in range(len(rows)):
+            assert np.array_equal(serial[k], oracle.i420_to_rgb(got[k], 128, 96)), "automata path, rows %s: row %d" % (rows, rows[k])
+
+
 def test_a_thread_drives_several_hevc_decoders(hw, oracle, gpu, tmp_path):
     """Long queues are served by a thread per CPU that feeds several lanes in turn, a sample of each at a time, and
     passes over a decoder whose next picture would start by waiting for the GPU (BatchingHints::feed_would_wait:

@@ -29,11 +29,12 @@ def records_cpu(built):
     return EXE
 
 
-def run_host(exe, hw, path, tmp_path, wanted=(), keyframes=()):
+def run_host(exe, hw, path, tmp_path, wanted=(), keyframes=(), first=0):
     idx = hw.index_video(path)
     offs, sizes = idx.sample_offsets(), idx.sample_sizes()
     data = open(path, "rb").read()
     (tmp_path / "hvcc").write_bytes(bytes(idx.metadata_bytes()))
+    offs, sizes = offs[first:], sizes[first:]
     (tmp_path / "blob").write_bytes(b"".join(data[o:o + s] for o, s in zip(offs, sizes)))
     (tmp_path / "sizes").write_text("\n".join(str(s) for s in sizes))
     r = subprocess.run([exe, str(tmp_path / "hvcc"), str(tmp_path / "blob"), str(tmp_path / "sizes"), str(tmp_path / "out.yuv")] +
@@ -98,3 +99,28 @@ def test_gop_tails_and_the_interval_tail_are_not_decoded(records_cpu, hw, tmp_pa
     # without the GOP boundaries: everything up to the last wanted position (+ reorder depth), nothing behind it
     full = full.reshape(-1, gold.shape[1])
     assert not full[38 + 6:].any() and info_full["decoded"] <= 38 + 6
+
+
+@pytest.mark.parametrize("name", ["open_gop_bb", "open_gop_tools"])
+def test_decoding_from_a_cra_picture(records_cpu, hw, oracle, tmp_path, name):
+    """Random access into an open GOP (what a seek into an x265 stream is): decoding starts at the CRA picture, its
+    leading pictures refer to pictures that were never decoded - 8.3.3 makes them up - and are output all the same
+    (one frame per sample: the automata counts).  Everything behind the CRA picture in output order is the sequential
+    decode's; the leading pictures are whatever the made-up references give, the same in the oracle and here."""
+    kw = dict(dict(HEVC_MATRIX)[name])
+    path = str(tmp_path / "o.mp4")
+    gold = make_hevc_clip(path, **kw)
+    idx = hw.index_video(path)
+    gop, lead = kw["gop"], kw["bframes"]
+    assert list(idx.keyframe_indices()) == list(range(0, kw["frames"], gop))     # the CRA pictures are sync samples
+    for first in range(gop, kw["frames"], gop):
+        got, info = run_host(records_cpu, hw, path, tmp_path, first=first)
+        got = got.reshape(-1, gold.shape[1])
+        want, ctr = oracle.decode_file_hevc(path, idx, first=first, count=idx.frames() - first)
+        assert len(got) == len(want) == idx.frames() - first
+        assert ctr["md5_mismatch"] == lead                      # the oracle's own check: only the leading pictures are off
+        for i in range(len(got)):
+            assert np.array_equal(got[i], want[i][0]), "from sample %d: output %d" % (first, i)
+            if i >= lead:
+                assert np.array_equal(got[i], gold[first + i]), "from sample %d: output %d against the sequential decode" % (first, i)
+        assert any(not np.array_equal(got[i], gold[first + i]) for i in range(lead))
