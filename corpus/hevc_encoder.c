@@ -171,7 +171,8 @@ typedef struct {
   int disp;       /* display index within the GOP = POC */
   int type;       /* HV_SLICE_I / P / B */
   int is_ref, idr;
-  int cra, rasl;  /* --open-gop: a CRA picture at the head of a GOP, the leading pictures (RASL_N) behind it in decoding order */
+  int cra, rasl;  /* --open-gop 1: a CRA picture at the head of a GOP, the leading pictures (RASL_N) behind it in decoding order */
+  int radl;       /* --open-gop 2: an IDR_W_RADL picture there instead, its leading pictures (RADL_N) predict from it alone */
 } PicPlan;
 
 typedef struct {
@@ -1280,7 +1281,7 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
     if (c->cover && total > 1 && (e->h & 3) == 0) nl0 = nl1 = hv_min(total + 1, 15); /* lists longer than the set: entries repeat */
   }
   scene_render(&e->scene, (int)(e->pic_counter - 1) + 0);
-  const int nal_type = pp->idr ? 19 : pp->cra ? 21 : pp->rasl ? 8 : pp->is_ref ? 1 : 0;
+  const int nal_type = pp->idr ? 19 : pp->cra ? 21 : pp->rasl ? 8 : pp->radl ? 6 : pp->is_ref ? 1 : 0;
   const HvSps* sps = &d->sps[0];
   const int total_ctb = sps->width_ctb * sps->height_ctb;
   e->n_slices = hv_min(hv_max(c->slices, 1), total_ctb);
@@ -1383,8 +1384,8 @@ static int encode_picture(Enc* e, const PicPlan* pp, Buf* sample) {
     }
     bput(&rbsp, hdr_rbsp[k].b, hdr_rbsp[k].n);
     bput(&rbsp, d->ce.buf, d->ce.nbits / 8);
-    g_nal_tid_plus1 = (c->sub_layers == 2 && !pp->is_ref && !pp->idr && !pp->rasl) ? 2 : 1;
-    nal_append(&nal, (c->sub_layers == 2 && !pp->is_ref && !pp->idr && !pp->rasl) ? 2 /* TSA_N */ : nal_type, rbsp.b, rbsp.n);
+    g_nal_tid_plus1 = (c->sub_layers == 2 && !pp->is_ref && !pp->idr && !pp->rasl && !pp->radl) ? 2 : 1;
+    nal_append(&nal, (c->sub_layers == 2 && !pp->is_ref && !pp->idr && !pp->rasl && !pp->radl) ? 2 /* TSA_N */ : nal_type, rbsp.b, rbsp.n);
     g_nal_tid_plus1 = 1;
     sample_add_nal(sample, c->nal_length_size, &nal);
     free(rbsp.b);
@@ -1617,13 +1618,19 @@ int main(int argc, char** argv) {
     const int open = c->open_gop && g0 > 0 && c->bframes > 0 && !c->intra_only;
     const int n = open ? plan_open_gop(c, hv_min(c->gop, c->frames - g0), plan) : plan_gop(c, hv_min(c->gop, c->frames - g0), plan);
     /* (--open-gop: one IDR picture at the start, the picture order count runs on through the GOPs) */
-    const int poc_base = c->open_gop ? g0 : 0;
+    const int poc_base = c->open_gop == 1 ? g0 : (c->open_gop == 2 && open) ? -hv_min(c->bframes, n - 1) : 0;
     for (int i = 0; i < n; ++i, ++k) {
       /* the scene is rendered at the DISPLAY position */
       const uint32_t keep = e->pic_counter;
       e->pic_counter = (uint32_t)(g0 + plan[i].disp);
       plan[i].disp += poc_base;
-      if (c->open_gop && g0 > 0) plan[i].idr = 0, plan[i].cra = plan[i].cra || (i == 0);
+      if (c->open_gop == 1 && g0 > 0) plan[i].idr = 0, plan[i].cra = plan[i].cra || (i == 0);
+      if (c->open_gop == 2 && open) { /* closed after all: the head is an IDR picture (POC 0), the leading pictures have negative POCs */
+        plan[i].idr = plan[i].cra;
+        plan[i].cra = 0;
+        plan[i].radl = plan[i].rasl;
+        plan[i].rasl = 0;
+      }
       const int rc = encode_picture(e, &plan[i], &samples[k]);
       plan[i].disp -= poc_base;
       e->pic_counter = keep + 1;

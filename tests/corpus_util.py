@@ -301,4 +301,7 @@ HEVC_MATRIX = [
     # predict across it from the GOP before; one IDR picture, the picture order count runs through (and wraps)
     ("open_gop_bb", dict(frames=36, gop=12, bframes=2, refs=2, open_gop=1, poc_bits=5)),
     ("open_gop_tools", dict(frames=27, gop=9, bframes=2, refs=3, open_gop=1, tmvp=1, sao=1, amp=1, ctb=32, wp=1, slices=2, extra_nals=1)),
+    # closed GOPs with leading pictures: IDR_W_RADL pictures whose RADL_N pictures are displayed in front of them and
+    # predict from them alone - negative picture order counts, and a work item whose first outputs are not its first sample
+    ("radl_bb_tmvp", dict(frames=36, gop=12, bframes=2, refs=2, open_gop=2, tmvp=1, sao=1)),
 ]

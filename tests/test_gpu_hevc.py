@@ -193,6 +193,28 @@ def test_open_gops_and_decoding_that_enters_at_a_cra_picture(hw, oracle, gpu, tm
             assert np.array_equal(serial[k], oracle.i420_to_rgb(got[k], 128, 96)), "automata path, rows %s: row %d" % (rows, rows[k])
 
 
+def test_leading_pictures_of_a_closed_gop(hw, oracle, gpu, tmp_path):
+    """IDR_W_RADL pictures with RADL pictures: a work item that starts at such a sync sample outputs the leading
+    pictures first (negative picture order counts), so its first wanted rows are not its first sample's picture."""
+    kw = dict(dict(HEVC_MATRIX)["radl_bb_tmvp"])
+    path = str(tmp_path / "r.mp4")
+    gold = make_hevc_clip(path, **kw)
+    idx = hw.index_video(path)
+    n, gop = kw["frames"], kw["gop"]
+    dec = hw.Decoder(path, video_index=idx, num_lanes=3)
+    got = dec.retrieve_yuv(list(range(n)))
+    for i in range(n):
+        assert np.array_equal(got[i], gold[i]), "sequential, frame %d" % i
+    assert dec.stats()["intervals"] == n // gop                       # every GOP is closed: three work items
+    for rows in ([gop, gop + 1, gop + 2], [gop + 1, 2 * gop, 2 * gop + 1, n - 1], [2 * gop + 1]):
+        got = dec.retrieve_yuv(rows)
+        for k, r in enumerate(rows):
+            assert np.array_equal(got[k], gold[r]), "rows %s: row %d" % (rows, r)
+        serial = dec.retrieve_serial(rows)
+        for k in range(len(rows)):
+            assert np.array_equal(serial[k], oracle.i420_to_rgb(got[k], 128, 96)), "automata path, rows %s: row %d" % (rows, rows[k])
+
+
 def test_a_thread_drives_several_hevc_decoders(hw, oracle, gpu, tmp_path):
     """Long queues are served by a thread per CPU that feeds several lanes in turn, a sample of each at a time, and
     passes over a decoder whose next picture would start by waiting for the GPU (BatchingHints::feed_would_wait:

@@ -15,7 +15,7 @@ from tests.corpus_util import HEVC_MATRIX, make_hevc_clip
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "_build", "hevc_parser_fuzz")
 CASES = ["i_ctb32_sao_pcm", "i_pcm2_tskip_bypass", "i_scaling_random_modes", "i_slices_cip_nolf", "i_wpp", "ibp_amp_wp_ctb32",
-         "pyramid_sao_sdh_cover", "rps_sps_pocwrap_ctb64", "everything", "lt_sps_b_tmvp", "lt_pyramid_pocwrap", "inter_rps_slices_pyramid", "rplm_lt_inter_rps_tmvp", "keep_unused_b_rplm", "sub_layers_b", "sh_extras_slices_wpp", "multi_pps", "open_gop_bb", "open_gop_tools"]
+         "pyramid_sao_sdh_cover", "rps_sps_pocwrap_ctb64", "everything", "lt_sps_b_tmvp", "lt_pyramid_pocwrap", "inter_rps_slices_pyramid", "rplm_lt_inter_rps_tmvp", "keep_unused_b_rplm", "sub_layers_b", "sh_extras_slices_wpp", "multi_pps", "open_gop_bb", "open_gop_tools", "radl_bb_tmvp"]
 
 
 @pytest.fixture(scope="module")
