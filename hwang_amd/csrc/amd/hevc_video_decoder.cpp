@@ -116,7 +116,12 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (!size) return Result();
     if (!parser_) return Result(false, "AMDVideoDecoder::feed before configure");
     HWANG_HIP_RETURN(hipSetDevice(device_));
-    HWANG_RETURN_ON_ERROR(deliver_outputs(false));
+    {
+      // (frames fetched earlier whose copies have landed go out of their bounce buffers now - unless the fetching thread
+      // is at the ring this very moment: DecoderAutomata feeds and fetches from two threads)
+      std::unique_lock<std::mutex> ol(out_mu_, std::try_to_lock);
+      if (ol.owns_lock()) HWANG_RETURN_ON_ERROR(deliver_outputs(false));
+    }
     ++counters_.samples_fed;
     const auto t0 = std::chrono::steady_clock::now();
     const int64_t stall0 = counters_.stall_ns, submit0 = submit_ns_;
@@ -588,6 +593,12 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     if (!known) (void)hipGetLastError();
     const bool device_dst = known && attr.type == hipMemoryTypeDevice;
     const bool direct = device_dst || (known && attr.type == hipMemoryTypeHost);
+    // The ring of fetched frames belongs to one thread at a time: feed() - another thread under DecoderAutomata - delivers
+    // from it too, and an entry that is armed here (active, destination set) before its job has been handed to the engine
+    // looked to that thread like the entry's PREVIOUS frame, landed: it copied the old bounce buffer into the new
+    // destination and closed the entry (a fetched frame that was an earlier one of the same request, 1 - 3 % of the
+    // requests through the reference's API: tools/experiments/src/hevc_serial_race.py).
+    std::lock_guard<std::mutex> ol(out_mu_);
     Output& o = outputs_[output_next_];
     output_next_ = (output_next_ + 1) % kOutputs;
     HWANG_RETURN_ON_ERROR(deliver(o, true));
@@ -669,7 +680,11 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
         if (set.done) (void)sleepy_event_wait(set.done);
         set.busy = false;
       }
-    Result r = deliver_outputs(true);
+    Result r;
+    {
+      std::lock_guard<std::mutex> ol(out_mu_);
+      r = deliver_outputs(true);
+    }
     engine_->settled(client_);
     if (!ok && r.ok) r = Result(false, "AMDVideoDecoder (HEVC): " + engine_->error());
     return r;
@@ -679,6 +694,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   hipStream_t fill_stream_ = nullptr;   // missing_surface()
   std::shared_ptr<gh::Engine> engine_;
   const int client_;
+  std::mutex out_mu_;   // outputs_, output_next_
   Output outputs_[kOutputs];
   int output_next_ = 0;
   std::unique_ptr<hevc::Parser> parser_;

@@ -215,6 +215,24 @@ def test_leading_pictures_of_a_closed_gop(hw, oracle, gpu, tmp_path):
             assert np.array_equal(serial[k], oracle.i420_to_rgb(got[k], 128, 96)), "automata path, rows %s: row %d" % (rows, rows[k])
 
 
+def test_fetching_and_feeding_from_two_threads_many_times(hw, oracle, gpu, tmp_path):
+    """DecoderAutomata feeds on one thread and fetches on another; frames fetched into pageable memory wait in a ring of
+    page-locked bounce buffers that BOTH threads deliver from.  An entry armed by the fetching thread before its job had
+    reached the engine looked "landed" to the feeding thread, which copied the entry's previous frame into the new
+    destination: 1 - 3 % of such requests returned an earlier frame of the same request in a later row.  300 requests
+    through the reference's API, every frame against the retriever's."""
+    path = str(tmp_path / "t.mp4")
+    make_hevc_clip(path, frames=36, gop=12, bframes=2, refs=2, open_gop=1, yuv=False)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=2)
+    for rows in ([3, 11, 12, 30], [24, 25, 26, 31], [0, 1, 2, 3, 4, 5, 6, 7, 8, 9]):
+        want = dec.retrieve(rows)
+        for it in range(100):
+            got = dec.retrieve_serial(rows)
+            for k, r in enumerate(rows):
+                assert np.array_equal(got[k], want[k]), "request %d, rows %s: row %d is not the retriever's frame" % (it, rows, r)
+
+
 def test_a_thread_drives_several_hevc_decoders(hw, oracle, gpu, tmp_path):
     """Long queues are served by a thread per CPU that feeds several lanes in turn, a sample of each at a time, and
     passes over a decoder whose next picture would start by waiting for the GPU (BatchingHints::feed_would_wait:
