@@ -62,7 +62,9 @@ hipError_t sleepy_event_wait(hipEvent_t e) {
 
 class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
  public:
-  explicit HEVCVideoDecoder(int device) : device_(device), engine_(gh::Engine::for_device(device)), client_(engine_->add_client()) {}
+  explicit HEVCVideoDecoder(int device) : device_(device), engine_(gh::Engine::for_device(device)), client_(engine_->add_client()) {
+    surf_.reserve(gh::kMaxSurfaces);  // (grows under mu_ on the feeding thread; never moves under the fetching one)
+  }
   ~HEVCVideoDecoder() override {
     (void)hipSetDevice(device_);
     if (std::getenv("HWANG_HEVC_ENGINE_STATS") && parser_ && g_event_waits.exchange(0))
@@ -457,7 +459,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
   void free_all() {
     for (SurfaceSlot& s : surf_)
       if (s.dev) (void)hipFree(s.dev);
-    surf_.clear();
+    surf_.clear();  // (keeps its capacity)
     for (Set& s : sets_) {
       if (s.host) (void)hipHostFree(s.host);
       if (s.dev) (void)hipFree(s.dev);
@@ -570,6 +572,7 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
     const size_t w = info_.width, h = info_.height, cw = (w + 1) / 2, chh = (h + 1) / 2;
     const size_t need = yuv ? w * h + 2 * cw * chh : w * h * 3;
     int slot;
+    uint8_t* surface_dev = nullptr;
     {
       std::lock_guard<std::mutex> lk(mu_);
       if (outq_.empty()) return Result();
@@ -579,8 +582,9 @@ class HEVCVideoDecoder : public HevcDelegate, public hevc::PictureSink {
         return Result(false, "AMDVideoDecoder::get_frame: this output position was excluded by the sparse hint (set_wanted) or could not be decoded");
       outq_.pop_front();
       buffered_.fetch_sub(1, std::memory_order_acq_rel);
+      surface_dev = surf_[slot].dev;
     }
-    const gh::Surface s = surface_of(surf_[slot].dev);
+    const gh::Surface s = surface_of(surface_dev);
     const uint8_t* y = s.y + static_cast<size_t>(crop_t_) * y_pitch_ + crop_l_;
     const uint8_t* u = s.u + static_cast<size_t>(crop_t_ / 2) * (y_pitch_ / 2) + crop_l_ / 2;
     const uint8_t* v = s.v + static_cast<size_t>(crop_t_ / 2) * (y_pitch_ / 2) + crop_l_ / 2;
