@@ -271,16 +271,33 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
       return offsets[sample] <= rq.file_size && sizes[sample] <= rq.file_size - offsets[sample] &&
              sample_starts_closed_gop(rq.file + offsets[sample], static_cast<size_t>(sizes[sample]), framing);
     };
+    auto hevc_kind = [&](uint64_t sample) {
+      return sample < offsets.size() && offsets[sample] <= rq.file_size && sizes[sample] <= rq.file_size - offsets[sample]
+                 ? hevc_sample_kind(rq.file + offsets[sample], static_cast<size_t>(sizes[sample]), framing)
+                 : 0;
+    };
     for (size_t i = 0; i < plan.sample_index_intervals.size(); ++i) {
       const std::vector<uint64_t>& valid = plan.valid_frames[i];
       if (valid.empty()) continue;
       const uint64_t istart = std::get<0>(plan.sample_index_intervals[i]);
       const uint64_t iend = std::get<1>(plan.sample_index_intervals[i]);
+      // ... and an HEVC GOP that starts with a CRA picture (x265's default) when none of the CRA picture's LEADING pictures
+      // is wanted: they are the samples right behind it, displayed in front of it at the positions sample .. sample +
+      // L - 1, and the only pictures of the GOP that refer to anything before it.  (Entered at the CRA picture they would
+      // be decoded from made-up references, hevc_parser.h: missing_surface - a wanted one keeps its GOP in the item before.)
+      auto may_start_item = [&](uint64_t sample) {
+        if (starts_closed_gop(sample)) return true;
+        if (framing.codec != 2 || hevc_kind(sample) != 2) return false;
+        uint64_t leading = 0;
+        while (sample + 1 + leading < iend && hevc_kind(sample + 1 + leading) == 3) ++leading;
+        const auto lo = std::lower_bound(valid.begin(), valid.end(), sample);
+        return lo == valid.end() || *lo >= sample + leading;
+      };
       size_t k = std::upper_bound(kfs.begin(), kfs.end(), istart) - kfs.begin();  // first keyframe after istart
       uint64_t gop_start = istart;
       size_t v = 0;
       while (v < valid.size()) {
-        while (k < kfs.size() && kfs[k] < iend && !starts_closed_gop(kfs[k])) ++k;
+        while (k < kfs.size() && kfs[k] < iend && !may_start_item(kfs[k])) ++k;
         const uint64_t gop_end = (k < kfs.size() && kfs[k] < iend) ? kfs[k] : iend;
         size_t v2 = v;
         while (v2 < valid.size() && valid[v2] < gop_end) ++v2;

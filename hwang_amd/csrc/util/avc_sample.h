@@ -79,4 +79,24 @@ inline bool sample_starts_closed_gop(const uint8_t* data, size_t size, const Sam
   return false;
 }
 
+// HEVC only: what the sample's first coded slice segment is - 1: an IDR or BLA picture (a closed GOP starts here), 2: a CRA
+// picture, 3: a leading picture (RADL / RASL: nal_unit_type 6 .. 9), 0: anything else or malformed framing.
+inline int hevc_sample_kind(const uint8_t* data, size_t size, const SampleFraming& f) {
+  if (f.codec != 2 || !data || f.length_size < 1 || f.length_size > 4) return 0;
+  size_t pos = 0;
+  while (pos + f.length_size < size) {
+    size_t len = 0;
+    for (int i = 0; i < f.length_size; ++i) len = (len << 8) | data[pos + i];
+    pos += f.length_size;
+    if (len < 2 || len > size - pos) return 0;
+    const int type = (data[pos] >> 1) & 0x3f;
+    if (type >= 16 && type <= 20) return 1;
+    if (type == 21) return 2;
+    if (type >= 6 && type <= 9) return 3;
+    if (type < 32) return 0;
+    pos += len;
+  }
+  return 0;
+}
+
 }  // namespace hwang

@@ -43,6 +43,12 @@ int main() {
     cut.resize(cut.size() - 2);              // a length that runs past the sample
     CHECK(!sample_starts_closed_gop(cut.data(), cut.size(), f));
     CHECK(!sample_starts_closed_gop(nullptr, 0, f));
+    // what kind of sample: 1 closed GOP, 2 CRA, 3 leading, 0 other
+    for (int type : {16, 19, 20}) { auto s = cat({aud, sei, hevc_nal(ls, type)}); CHECK(hevc_sample_kind(s.data(), s.size(), f) == 1); }
+    { auto s = cat({aud, vps, sps, pps, hevc_nal(ls, 21)}); CHECK(hevc_sample_kind(s.data(), s.size(), f) == 2); }
+    for (int type : {6, 7, 8, 9}) { auto s = cat({aud, hevc_nal(ls, type)}); CHECK(hevc_sample_kind(s.data(), s.size(), f) == 3); }
+    for (int type : {0, 1, 2, 5}) { auto s = cat({hevc_nal(ls, type)}); CHECK(hevc_sample_kind(s.data(), s.size(), f) == 0); }
+    CHECK(hevc_sample_kind(only_sets.data(), only_sets.size(), f) == 0 && hevc_sample_kind(cut.data(), cut.size(), f) == 0);
   }
   {  // an hvcC too short to say: the container's sync table is all there is
     const SampleFraming f = sample_framing(true, std::vector<uint8_t>{1, 1, 0x60});

@@ -215,6 +215,28 @@ def test_leading_pictures_of_a_closed_gop(hw, oracle, gpu, tmp_path):
             assert np.array_equal(serial[k], oracle.i420_to_rgb(got[k], 128, 96)), "automata path, rows %s: row %d" % (rows, rows[k])
 
 
+def test_a_cra_gop_is_a_work_item_unless_one_of_its_leading_pictures_is_wanted(hw, oracle, gpu, tmp_path):
+    """Open GOPs (x265's default): a GOP that starts with a CRA picture is a work item of its own - decoding enters at
+    the CRA picture - when no wanted row is one of the CRA picture's leading pictures; a wanted leading picture keeps its
+    GOP in the item of the GOP before, where it has its references.  Every frame is the sequential decode's either way.
+    (Where the PLANNER starts an interval at a CRA picture - rows [5, 25]: the GOP between holds nothing - decoding enters
+    there as the reference's would, leading picture or not: test_open_gops_and_decoding_that_enters_at_a_cra_picture.)"""
+    kw = dict(dict(HEVC_MATRIX)["open_gop_bb"])
+    path = str(tmp_path / "o.mp4")
+    gold = make_hevc_clip(path, **kw)
+    idx = hw.index_video(path)
+    dec = hw.Decoder(path, video_index=idx, num_lanes=3)
+    for rows, items in (([5, 27, 35], 2),        # [0, 12) and [24, 36): the second GOP holds nothing wanted
+                        ([5, 14, 25], 2),        # 25 leads the CRA picture of sample 24: [0, 12) and [12, 36), entered at the CRA picture of sample 12
+                        ([13, 26], 2),           # 13 leads the CRA picture of sample 12: [0, 24) and [24, 36)
+                        ([5, 14, 26, 35], 3),    # nothing leading: three items
+                        ([12, 13, 24, 25], 1)):  # leading pictures everywhere: one item
+        got = dec.retrieve_yuv(rows)
+        for k, r in enumerate(rows):
+            assert np.array_equal(got[k], gold[r]), "rows %s: row %d" % (rows, r)
+        assert dec.stats()["intervals"] == items, (rows, dec.stats())
+
+
 def test_fetching_and_feeding_from_two_threads_many_times(hw, oracle, gpu, tmp_path):
     """DecoderAutomata feeds on one thread and fetches on another; frames fetched into pageable memory wait in a ring of
     page-locked bounce buffers that BOTH threads deliver from.  An entry armed by the fetching thread before its job had
