@@ -295,6 +295,12 @@ Result ParallelRetriever::retrieve_batch(const std::vector<Request>& requests, b
       };
       size_t k = std::upper_bound(kfs.begin(), kfs.end(), istart) - kfs.begin();  // first keyframe after istart
       uint64_t gop_start = istart;
+      // The planner may start an interval AT a CRA picture (the GOP before it holds nothing wanted).  If one of that
+      // picture's leading pictures is wanted, decoding starts a sync sample earlier: the leading picture has its
+      // references then and is the sequential decode's frame - entered at the CRA picture it would be predicted from
+      // made-up references (which is what DecoderAutomata's callers get there, as the reference's do worse: libavcodec
+      // drops those frames).  The extra GOP is decoded without a wanted row in it, i.e. reference pictures only.
+      if (framing.codec == 2 && k >= 2 && kfs[k - 1] == istart && !may_start_item(istart)) gop_start = kfs[k - 2];
       size_t v = 0;
       while (v < valid.size()) {
         while (k < kfs.size() && kfs[k] < iend && !may_start_item(kfs[k])) ++k;
